@@ -1,0 +1,111 @@
+"""Deterministic synthetic FASTA/FASTQ generators (SURVEY.md section 8(d) workloads).
+
+CPU generators use numpy (tests, fixtures); `fasta_acgt_device` builds the multi-GB bench inputs
+directly in HBM with torch so bench.py never round-trips 10 GB through the host.
+"""
+import numpy as np
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def wrap_lines(seq: np.ndarray, width: int) -> bytes:
+    """seq bytes -> text with '\n' after every `width` bases and at the end (none if empty)."""
+    n = len(seq)
+    if n == 0:
+        return b""
+    if width <= 0:
+        return seq.tobytes() + b"\n"
+    full, rem = divmod(n, width)
+    out = np.empty(n + full + (1 if rem else 0), dtype=np.uint8)
+    if full:
+        body = out[: full * (width + 1)].reshape(full, width + 1)
+        body[:, :width] = seq[: full * width].reshape(full, width)
+        body[:, width] = 10
+    if rem:
+        out[full * (width + 1): full * (width + 1) + rem] = seq[full * width:]
+        out[-1] = 10
+    return out.tobytes()
+
+
+def fasta_acgt(n_bases: int, n_records: int = 1, width: int = 80, seed: int = 12345,
+               name=lambda k: b">seq%d synthetic random ACGT" % (k + 1)) -> bytes:
+    """cfg1-style: uniform ACGT, `n_records` records of (almost) equal length, `width`-column lines."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    parts = []
+    per = n_bases // n_records
+    for k in range(n_records):
+        n = per if k + 1 < n_records else n_bases - per * (n_records - 1)
+        seq = _ACGT[rng.integers(0, 4, n, dtype=np.uint8)]
+        parts.append(name(k) + b"\n" + wrap_lines(seq, width))
+    return b"".join(parts)
+
+
+def fasta_mixed(n_records: int = 20, mean_len: int = 3000, width: int = 60, seed: int = 1,
+                p_lower: float = 0.3, iupac: bool = True, empty_every: int = 7) -> bytes:
+    """Soft-masked runs, N runs, IUPAC codes, empty records -- exercises mask RLE and emit edge cases."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    alpha = np.frombuffer(b"ACGT" * 8 + (b"RYSWKMBDHVN-" if iupac else b""), dtype=np.uint8)
+    parts = []
+    for k in range(n_records):
+        if empty_every and k % empty_every == empty_every - 1:
+            n = 0
+        else:
+            n = int(rng.integers(1, 2 * mean_len))
+        seq = alpha[rng.integers(0, len(alpha), n)]
+        pos = 0
+        while pos < n:                                   # alternate upper / lower runs
+            run = int(rng.geometric(1.0 / 300))
+            if rng.random() < p_lower:
+                seg = seq[pos:pos + run]
+                letters = seg != ord("-")
+                seg[letters] |= 0x20
+            pos += run
+        if n > 600 and rng.random() < 0.5:
+            a = int(rng.integers(0, n - 520))
+            seq[a:a + 510] = ord("N")
+        hdr = b">rec%d" % k + (b" some comment %d" % (k * 7) if k % 3 else b"")
+        parts.append(hdr + b"\n" + wrap_lines(seq, width))
+    return b"".join(parts)
+
+
+def fastq_reads(n_reads: int, read_len: int = 150, seed: int = 7, var_len: bool = False) -> bytes:
+    """cfg5-style: ACGT 0.22 each, acgt 0.025 each, N 0.02; quality uniform Phred 0-40."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    alpha = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)
+    p = np.array([0.22] * 4 + [0.025] * 4 + [0.02])
+    parts = []
+    for k in range(n_reads):
+        n = int(rng.integers(1, read_len + 1)) if var_len else read_len
+        seq = alpha[rng.choice(9, n, p=p)]
+        qual = rng.integers(33, 74, n, dtype=np.uint8)
+        parts.append(b"@read%d len=%d\n" % (k + 1, n) + seq.tobytes() + b"\n+\n" + qual.tobytes() + b"\n")
+    return b"".join(parts)
+
+
+def fasta_acgt_device(total_bytes: int, n_records: int = 100, width: int = 80, seed: int = 2024, device="cuda"):
+    """cfg2/cfg3-style FASTA of ~total_bytes built in device memory; returns a uint8 torch tensor.
+
+    Every record is `>chrK synthetic random ACGT record K\n` + bases wrapped at `width`.  Record
+    lengths are multiples of `width` (so the text is exactly header + rows of width+1 bytes).
+    """
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    hdrs = [b">chr%d synthetic random ACGT record %d\n" % (k + 1, k + 1) for k in range(n_records)]
+    hdr_total = sum(len(h) for h in hdrs)
+    rows_total = max(n_records, (total_bytes - hdr_total) // (width + 1))
+    rows_per = rows_total // n_records
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    total = hdr_total + rows_per * n_records * (width + 1)
+    out = torch.empty(total, dtype=torch.uint8, device=device)
+    pos = 0
+    for k in range(n_records):
+        h = torch.tensor(list(hdrs[k]), dtype=torch.uint8, device=device)
+        out[pos:pos + len(h)] = h
+        pos += len(h)
+        body = out[pos:pos + rows_per * (width + 1)].view(rows_per, width + 1)
+        idx = torch.randint(0, 4, (rows_per, width), dtype=torch.int64, device=device, generator=g)
+        body[:, :width] = lut[idx]
+        body[:, width] = 10
+        pos += rows_per * (width + 1)
+    return out
