@@ -1,0 +1,217 @@
+"""ctypes binding of the libnaf_gpu.so C-ABI (include/naf_gpu.h).
+
+Used by the tests and bench.py; the shipped hosts are the C programs in naf_amd/host/.  Device
+buffers are torch uint8 CUDA(HIP) tensors -- torch is plumbing for HBM allocations and streams only.
+There is no CPU fallback: loading fails loudly if the shared library is missing, and `Context()`
+raises if no gfx950 device is usable.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnaf_gpu.so")
+
+OUT_DEFAULT, OUT_FASTA, OUT_FASTQ, OUT_SEQ, OUT_SEQUENCES, OUT_4BIT = -1, 0, 1, 2, 3, 4
+SEQ_DNA, SEQ_RNA, SEQ_PROTEIN, SEQ_TEXT = 0, 1, 2, 3
+FMT_AUTO, FMT_FASTA, FMT_FASTQ = 0, 1, 2
+E_CAP = -6
+
+EXPORTS = [
+    "naf_gpu_init", "naf_gpu_shutdown", "naf_gpu_strerror", "naf_gpu_last_error", "naf_gpu_set_stream",
+    "naf_gpu_synchronize", "naf_gpu_reserve", "naf_gpu_malloc", "naf_gpu_free", "naf_gpu_host_alloc",
+    "naf_gpu_host_free", "naf_gpu_upload", "naf_gpu_download", "naf_gpu_zstd_decompress",
+    "naf_gpu_zstd_compress", "naf_gpu_zstd_compress_bound", "naf_gpu_parse_header", "naf_gpu_parse_header_host",
+    "naf_gpu_unnaf_size", "naf_gpu_unnaf", "naf_gpu_unnaf_range", "naf_gpu_ennaf_bound", "naf_gpu_ennaf",
+    "naf_gpu_set_timing", "naf_gpu_get_timing",
+]
+
+
+class UnnafOpts(C.Structure):
+    _fields_ = [("out_type", C.c_int), ("use_mask", C.c_int), ("line_length", C.c_int64)]
+
+
+class Header(C.Structure):
+    _fields_ = [("version", C.c_int), ("seq_type", C.c_int), ("flags", C.c_int), ("separator", C.c_uint8),
+                ("line_length", C.c_uint64), ("n_sequences", C.c_uint64), ("title_off", C.c_uint64), ("title_len", C.c_uint64),
+                ("orig_size", C.c_uint64 * 6), ("comp_size", C.c_uint64 * 6), ("payload_off", C.c_uint64 * 6)]
+
+
+class EnnafOpts(C.Structure):
+    _fields_ = [("format", C.c_int), ("seq_type", C.c_int), ("no_mask", C.c_int), ("strict", C.c_int), ("level", C.c_int),
+                ("line_length", C.c_int64), ("title", C.c_char_p)]
+
+
+class EnnafReport(C.Structure):
+    _fields_ = [("format", C.c_int), ("n_sequences", C.c_uint64), ("n_bases", C.c_uint64), ("longest_line", C.c_uint64),
+                ("unexpected_id", C.c_uint64 * 257), ("unexpected_comment", C.c_uint64 * 257),
+                ("unexpected_seq", C.c_uint64 * 257), ("unexpected_qual", C.c_uint64 * 257),
+                ("section_orig", C.c_uint64 * 6), ("section_comp", C.c_uint64 * 6)]
+
+
+class NafGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("naf_gpu error %d: %s" % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+_lib = None
+
+
+def load():
+    """dlopen libnaf_gpu.so (no HIP call is made here, so this works on a machine without a GPU)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libnaf_gpu.so is not built (run `make` or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+        L.naf_gpu_init.argtypes = [i, C.POINTER(vp)]
+        L.naf_gpu_shutdown.argtypes = [vp]
+        L.naf_gpu_shutdown.restype = None
+        L.naf_gpu_strerror.restype = C.c_char_p
+        L.naf_gpu_last_error.restype = C.c_char_p
+        L.naf_gpu_last_error.argtypes = [vp]
+        L.naf_gpu_set_stream.argtypes = [vp, vp]
+        L.naf_gpu_synchronize.argtypes = [vp]
+        L.naf_gpu_reserve.argtypes = [vp, sz]
+        L.naf_gpu_zstd_decompress.argtypes = [vp, vp, sz, i, vp, sz, C.POINTER(sz)]
+        L.naf_gpu_parse_header.argtypes = [vp, vp, sz, C.POINTER(Header)]
+        L.naf_gpu_parse_header_host.argtypes = [C.c_char_p, sz, C.POINTER(Header), C.c_char_p]
+        L.naf_gpu_unnaf_size.argtypes = [vp, vp, sz, C.POINTER(UnnafOpts), C.POINTER(sz)]
+        L.naf_gpu_unnaf.argtypes = [vp, vp, sz, C.POINTER(UnnafOpts), vp, sz, C.POINTER(sz)]
+        L.naf_gpu_unnaf_range.argtypes = [vp, vp, sz, C.POINTER(UnnafOpts), C.c_uint64, C.c_uint64, vp, sz, C.POINTER(sz)]
+        L.naf_gpu_set_timing.argtypes = [vp, i]
+        L.naf_gpu_get_timing.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(i), i]
+        for opt in ("naf_gpu_zstd_compress", "naf_gpu_ennaf"):
+            if hasattr(L, opt):
+                pass
+        if hasattr(L, "naf_gpu_zstd_compress"):
+            L.naf_gpu_zstd_compress.argtypes = [vp, vp, sz, i, vp, sz, C.POINTER(sz)]
+            L.naf_gpu_zstd_compress_bound.argtypes = [sz]
+            L.naf_gpu_zstd_compress_bound.restype = sz
+        if hasattr(L, "naf_gpu_ennaf"):
+            L.naf_gpu_ennaf.argtypes = [vp, vp, sz, C.POINTER(EnnafOpts), vp, sz, C.POINTER(sz), C.POINTER(EnnafReport)]
+            L.naf_gpu_ennaf_bound.argtypes = [sz]
+            L.naf_gpu_ennaf_bound.restype = sz
+        _lib = L
+    return _lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One per device / per process rank.  Work is enqueued on torch's current stream for the device."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        import torch
+        self.L = load()
+        self.h = C.c_void_p()
+        rc = self.L.naf_gpu_init(device, C.byref(self.h))
+        if rc:
+            raise NafGpuError(rc, self.L.naf_gpu_strerror(rc).decode())
+        self.device = torch.device("cuda", device)
+        if use_torch_stream:
+            s = torch.cuda.current_stream(self.device)
+            self._check(self.L.naf_gpu_set_stream(self.h, C.c_void_p(s.cuda_stream)))
+
+    def close(self):
+        if self.h:
+            self.L.naf_gpu_shutdown(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise NafGpuError(rc, self.L.naf_gpu_last_error(self.h).decode("latin1"))
+
+    def to_device(self, data: bytes):
+        import torch
+        import numpy as np
+        if len(data) == 0:
+            return torch.empty(0, dtype=torch.uint8, device=self.device)
+        return torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(self.device)
+
+    def reserve(self, nbytes):
+        self._check(self.L.naf_gpu_reserve(self.h, nbytes))
+
+    # ---- zstd ----
+    def zstd_decompress(self, d_frame, out_cap, has_magic=True):
+        import torch
+        out = torch.empty(max(out_cap, 1), dtype=torch.uint8, device=self.device)
+        n = C.c_size_t()
+        self._check(self.L.naf_gpu_zstd_decompress(self.h, _ptr(d_frame), d_frame.numel(), int(has_magic), _ptr(out), out_cap, C.byref(n)))
+        return out[:n.value]
+
+    def zstd_compress(self, d_src, level=1):
+        import torch
+        cap = self.L.naf_gpu_zstd_compress_bound(d_src.numel())
+        out = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        n = C.c_size_t()
+        self._check(self.L.naf_gpu_zstd_compress(self.h, _ptr(d_src), d_src.numel(), level, _ptr(out), cap, C.byref(n)))
+        return out[:n.value]
+
+    # ---- unnaf ----
+    def parse_header(self, d_naf):
+        h = Header()
+        self._check(self.L.naf_gpu_parse_header(self.h, _ptr(d_naf), d_naf.numel(), C.byref(h)))
+        return h
+
+    def unnaf_size(self, d_naf, out_type=OUT_DEFAULT, use_mask=True, line_length=-1):
+        o = UnnafOpts(out_type, int(use_mask), line_length)
+        n = C.c_size_t()
+        self._check(self.L.naf_gpu_unnaf_size(self.h, _ptr(d_naf), d_naf.numel(), C.byref(o), C.byref(n)))
+        return n.value
+
+    def unnaf(self, d_naf, out_type=OUT_DEFAULT, use_mask=True, line_length=-1, out=None):
+        import torch
+        o = UnnafOpts(out_type, int(use_mask), line_length)
+        if out is None:
+            size = self.unnaf_size(d_naf, out_type, use_mask, line_length)
+            out = torch.empty(max(size, 1), dtype=torch.uint8, device=self.device)
+        n = C.c_size_t()
+        self._check(self.L.naf_gpu_unnaf(self.h, _ptr(d_naf), d_naf.numel(), C.byref(o), _ptr(out), out.numel(), C.byref(n)))
+        return out[:n.value]
+
+    def unnaf_range(self, d_naf, begin, end, out_type=OUT_DEFAULT, use_mask=True, line_length=-1, out=None):
+        import torch
+        o = UnnafOpts(out_type, int(use_mask), line_length)
+        if out is None:
+            out = torch.empty(max(end - begin, 1), dtype=torch.uint8, device=self.device)
+        n = C.c_size_t()
+        self._check(self.L.naf_gpu_unnaf_range(self.h, _ptr(d_naf), d_naf.numel(), C.byref(o), begin, end, _ptr(out), out.numel(), C.byref(n)))
+        return out[:n.value]
+
+    # ---- ennaf ----
+    def ennaf(self, d_text, seq_type=SEQ_DNA, fmt=FMT_AUTO, no_mask=False, level=1, line_length=-1, title=None, out=None):
+        import torch
+        o = EnnafOpts(fmt, seq_type, int(no_mask), 0, level, line_length, title)
+        if out is None:
+            cap = self.L.naf_gpu_ennaf_bound(d_text.numel())
+            out = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        n = C.c_size_t()
+        rep = EnnafReport()
+        self._check(self.L.naf_gpu_ennaf(self.h, _ptr(d_text), d_text.numel(), C.byref(o), _ptr(out), out.numel(), C.byref(n), C.byref(rep)))
+        return out[:n.value], rep
+
+    # ---- timing ----
+    def set_timing(self, on):
+        self._check(self.L.naf_gpu_set_timing(self.h, int(on)))
+
+    def get_timing(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        cnt = (C.c_int * cap)()
+        n = self.L.naf_gpu_get_timing(self.h, names, ms, cnt, cap)
+        return [(names[i].decode(), ms[i], cnt[i]) for i in range(n)]
+
+    def synchronize(self):
+        self._check(self.L.naf_gpu_synchronize(self.h))

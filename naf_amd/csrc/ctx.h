@@ -1,0 +1,64 @@
+// ctx.h -- internal context of libnaf_gpu: stream, scratch arena, error text, per-kernel timing.
+#pragma once
+#include "common.h"
+#include "../../include/naf_gpu.h"
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <vector>
+#include <string>
+
+struct ArenaChunk { u8 *base; size_t cap, used; };
+
+struct KTime { const char *name; hipEvent_t a, b; };
+
+struct naf_gpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<ArenaChunk> chunks;       // scratch arena; consolidated into one chunk at reset
+    size_t high_water = 0;
+    u8 *h_stage = nullptr;                // pinned host staging for small readbacks
+    size_t h_stage_cap = 0;
+    void *d_predef = nullptr;             // predefined LL/OF/ML FSE tables (RFC 8878 3.1.1.3.2.2)
+    char err[512] = {0};
+    bool timing = false;
+    std::vector<KTime> ktimes;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    // result of the last get_timing aggregation
+    std::vector<std::string> agg_names; std::vector<float> agg_ms; std::vector<int> agg_n;
+};
+
+int  ctx_fail(naf_gpu_ctx *c, int code, const char *fmt, ...);
+#define HIP_TRY(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return ctx_fail((c), NAF_GPU_EHIP, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+// Scratch arena: pointers stay valid until arena_reset.  Returns nullptr on allocation failure.
+void  arena_reset(naf_gpu_ctx *c);
+void *arena_alloc(naf_gpu_ctx *c, size_t bytes);
+template <typename T> T *arena_new(naf_gpu_ctx *c, size_t n) { return (T *)arena_alloc(c, n * sizeof(T)); }
+
+// Small device->host readback through pinned staging (synchronises the stream).
+int ctx_readback(naf_gpu_ctx *c, void *h_dst, const void *d_src, size_t bytes);
+
+void ktime_begin(naf_gpu_ctx *c, const char *name);
+void ktime_end(naf_gpu_ctx *c);
+
+// Launch wrapper: records event pairs when timing is on.
+#define LAUNCH(c, name, kern, grid, block, shmem, ...) do { \
+    ktime_begin((c), name); \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (shmem), (c)->stream, __VA_ARGS__); \
+    ktime_end((c)); } while (0)
+
+static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+// ---- scan utilities (scan.hip) ---------------------------------------------------------------------
+// Exclusive prefix sum of n u64 values in place -> also returns the total through d_total (device u64).
+int scan_exclusive_u64(naf_gpu_ctx *c, u64 *d_vals, size_t n, u64 *d_total);
+// Inclusive running maximum of i32 values in place (table-ownership propagation).
+int scan_inclusive_max_i32(naf_gpu_ctx *c, i32 *d_vals, size_t n);
+
+// ---- zstd (zstd_dec.hip) -----------------------------------------------------------------------------
+// Decode frames at d_src (device).  If only_size, stops after sizes are known.
+int zstd_decode(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len);
+int zstd_init_tables(naf_gpu_ctx *c);

@@ -1,0 +1,639 @@
+// emit.hip -- unnaf on gfx950: small-section decode, offset scans and the text re-emit kernels.
+//
+// Replaces (reference, unnaf/src): load_ids/load_names/load_lengths/load_mask input.c:145-246,
+// write_4bit_as_fasta output.c:445-454 (+ codes_to_nucs utils.c:74-83), mask_dna_buffer output.c:295-322,
+// print_dna_split_into_lines output.c:339-360, print_dna_buffer_as_fasta output.c:369-430,
+// print_fasta output.c:608-674, print_fastq output-fastq.c:100-149, print_dna output.c:457-512,
+// print_sequences output-sequences.c:60-116, print_4bit output.c:266-292.
+//
+// The reference streams 256 KiB buffers through a state machine; here every output byte is a pure
+// function of prefix sums (record text offsets, record base offsets, mask toggle positions), so any
+// 16-byte output chunk is produced independently by one lane:
+//   rec_out[r]  = text offset of record r            (scan of header + body sizes)
+//   rec_base[r] = index of record r's first base      (scan of lengths)
+//   toggles[k]  = base index where the soft-mask state flips (scan of mask units, units != 255 toggle)
+#include "ctx.h"
+#include "wgscan.h"
+
+enum { EM_FASTA = 0, EM_FASTQ = 1, EM_SEQ = 2, EM_SEQUENCES = 3 };
+
+struct EmitP {
+    // text geometry
+    const u64 *rec_out, *rec_base;     // N+1 entries each
+    const u64 *rec_len;                // N
+    const u32 *hdr_len;                // N   (0 for EM_SEQUENCES / EM_SEQ)
+    const u64 *idz, *nmz;              // positions of the '\0' terminators in ids / names (N each)
+    const u8 *ids, *names;
+    const u8 *seq;                     // packed 4-bit codes, or text bytes
+    const u8 *qual;
+    const u64 *toggles; u64 n_toggles;
+    u64 N, T, L;
+    u64 out_begin, out_end;            // byte range of the full text to produce; out[0] = byte out_begin
+    u32 lut[4];                        // 16-entry code -> ASCII table as four dwords
+    u32 Ldiv_magic;                    // unused when L+1 >= 2^32
+    int mode, has_ids, has_names, masking, upper;
+    u8 sep, hdr_char;
+    int force_slow;
+};
+
+// ---- prep kernels --------------------------------------------------------------------------------------------
+__global__ void k_len_flags(const u32 *units, u64 n, u64 *flag)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = units[i] != 0xFFFFFFFFu;
+}
+__global__ void k_len_acc(const u32 *units, u64 n, const u64 *ridx, u64 *rec_len, u64 N)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && ridx[i] < N) atomicAdd((unsigned long long *)&rec_len[ridx[i]], (unsigned long long)units[i]);
+}
+
+// positions of zero bytes: tile = 256 threads x 16 bytes
+#define ZT_BYTES 16
+#define ZT_TILE (256 * ZT_BYTES)
+__device__ __forceinline__ u32 zero_byte_mask16(const u8 *p, u64 base, u64 n)
+{
+    u32 m = 0;
+    if (base + ZT_BYTES <= n) {
+        u64 a = ld64(p + base), b = ld64(p + base + 8);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { if (((a >> (8 * i)) & 0xFF) == 0) m |= 1u << i; if (((b >> (8 * i)) & 0xFF) == 0) m |= 1u << (8 + i); }
+    } else {
+        for (int i = 0; i < ZT_BYTES; i++) if (base + i < n && p[base + i] == 0) m |= 1u << i;
+    }
+    return m;
+}
+__global__ __launch_bounds__(256) void k_zero_count(const u8 *p, u64 n, u64 *tile_cnt)
+{
+    __shared__ u64 lds[4];
+    u64 base = (u64)blockIdx.x * ZT_TILE + (u64)threadIdx.x * ZT_BYTES;
+    u64 c = base < n ? __popc(zero_byte_mask16(p, base, n)) : 0, tot;
+    wg_scan_inclusive<u64, OpAdd>(c, &tot, lds);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_zero_scatter(const u8 *p, u64 n, const u64 *tile_pre, u64 *pos_out, u64 cap)
+{
+    __shared__ u64 lds[4];
+    u64 base = (u64)blockIdx.x * ZT_TILE + (u64)threadIdx.x * ZT_BYTES;
+    u32 m = base < n ? zero_byte_mask16(p, base, n) : 0;
+    u64 c = __popc(m), tot;
+    u64 incl = wg_scan_inclusive<u64, OpAdd>(c, &tot, lds);
+    u64 k = tile_pre[blockIdx.x] + incl - c;
+    while (m) { int b = __ffs(m) - 1; m &= m - 1; if (k < cap) pos_out[k] = base + b; k++; }
+}
+
+// mask units: running base position (u64 sum of units) + compaction of toggle positions (units != 255)
+#define MT_TILE (256 * 16)
+__global__ __launch_bounds__(256) void k_mask_count(const u8 *units, u64 n, u64 *tile_sum, u64 *tile_cnt)
+{
+    __shared__ u64 lds[4];
+    u64 base = (u64)blockIdx.x * MT_TILE + (u64)threadIdx.x * 16;
+    u64 s = 0, c = 0;
+    for (int i = 0; i < 16; i++) if (base + i < n) { u32 u = units[base + i]; s += u; c += u != 255; }
+    u64 t1, t2;
+    wg_scan_inclusive<u64, OpAdd>(s, &t1, lds);
+    wg_scan_inclusive<u64, OpAdd>(c, &t2, lds);
+    if (threadIdx.x == 0) { tile_sum[blockIdx.x] = t1; tile_cnt[blockIdx.x] = t2; }
+}
+__global__ __launch_bounds__(256) void k_mask_scatter(const u8 *units, u64 n, const u64 *tile_sum_pre, const u64 *tile_cnt_pre, u64 *toggles)
+{
+    __shared__ u64 lds[4];
+    u64 base = (u64)blockIdx.x * MT_TILE + (u64)threadIdx.x * 16;
+    u64 s = 0, c = 0;
+    for (int i = 0; i < 16; i++) if (base + i < n) { u32 u = units[base + i]; s += u; c += u != 255; }
+    u64 t;
+    u64 si = wg_scan_inclusive<u64, OpAdd>(s, &t, lds);
+    u64 ci = wg_scan_inclusive<u64, OpAdd>(c, &t, lds);
+    u64 pos = tile_sum_pre[blockIdx.x] + si - s, k = tile_cnt_pre[blockIdx.x] + ci - c;
+    for (int i = 0; i < 16; i++) if (base + i < n) { u32 u = units[base + i]; pos += u; if (u != 255) toggles[k++] = pos; }
+}
+
+// per-record header length and text size
+__global__ void k_rec_sizes(u64 N, const u64 *rec_len, const u64 *idz, const u64 *nmz, int has_ids, int has_names,
+                            int mode, u64 L, u32 *hdr_len, u64 *out_size, u64 *base_size)
+{
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    u64 len = rec_len[r];
+    u64 h = 0;
+    if (mode == EM_FASTA || mode == EM_FASTQ) {
+        u64 idl = 0, nml = 0;
+        if (has_ids) idl = idz[r] - (r ? idz[r - 1] + 1 : 0);
+        if (has_names) nml = nmz[r] - (r ? nmz[r - 1] + 1 : 0);
+        u64 name = has_ids ? idl + ((has_names && nml) ? 1 + nml : 0) : nml;     // output.c:105-124
+        h = 1 + name + 1;
+    }
+    hdr_len[r] = (u32)h;
+    u64 body;
+    if (mode == EM_FASTQ) body = 2 * len + 4;                                       // SEQ \n + \n QUAL \n
+    else if (mode == EM_SEQUENCES) body = len + 1;
+    else body = len ? len + (L ? (len + L - 1) / L : 1) : 0;                        // ceil(len/L) newlines, none if empty
+    out_size[r] = h + body;
+    base_size[r] = len;
+}
+
+// ---- emit ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 upper_bound_u64(const u64 *a, u64 lo, u64 hi, u64 v)   // first index in [lo,hi) with a[i] > v
+{
+    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__device__ __forceinline__ u32 lut_char(const EmitP &P, u32 code)
+{
+    return (P.lut[code >> 2] >> (8 * (code & 3))) & 0xFF;
+}
+
+template <bool FOURBIT>
+__device__ __forceinline__ u32 base_char(const EmitP &P, u64 g)
+{
+    if (FOURBIT) { u32 b = P.seq[g >> 1]; return lut_char(P, (g & 1) ? (b >> 4) : (b & 15)); }
+    u32 ch = P.seq[g];
+    if (P.upper && ch >= 'a' && ch <= 'z') ch -= 32;                               // output.c:363-366 toupper
+    return ch;
+}
+
+__device__ __forceinline__ bool base_masked(const EmitP &P, u64 g, u64 klo, u64 khi)
+{
+    return (upper_bound_u64(P.toggles, klo, khi, g) & 1) != 0;                      // output.c:295-322 as parity of toggles <= g
+}
+
+__device__ __forceinline__ u32 header_char(const EmitP &P, u64 r, u64 k, u32 hl)
+{
+    if (k == 0) return P.hdr_char;
+    if (k == hl - 1) return '\n';
+    k -= 1;
+    u64 ids0 = 0, idl = 0, nm0 = 0;
+    if (P.has_ids) { ids0 = r ? P.idz[r - 1] + 1 : 0; idl = P.idz[r] - ids0; }
+    if (P.has_names) nm0 = r ? P.nmz[r - 1] + 1 : 0;
+    if (P.has_ids) {
+        if (k < idl) return P.ids[ids0 + k];
+        if (k == idl) return P.sep;
+        return P.names[nm0 + (k - idl - 1)];
+    }
+    return P.names[nm0 + k];
+}
+
+// One output byte (slow path; every edge case goes through here).
+template <bool FOURBIT>
+__device__ u32 emit_byte(const EmitP &P, u64 p, u64 rlo, u64 rhi, u64 klo, u64 khi)
+{
+    if (P.mode == EM_SEQ) {
+        u32 ch = base_char<FOURBIT>(P, p);
+        if (P.masking && base_masked(P, p, klo, khi)) ch += 32;
+        return ch;
+    }
+    u64 r = upper_bound_u64(P.rec_out, rlo, rhi + 1, p) - 1;
+    u64 off = p - P.rec_out[r];
+    u32 hl = P.hdr_len[r];
+    if (off < hl) return header_char(P, r, off, hl);
+    u64 q = off - hl, len = P.rec_len[r], j;
+    if (P.mode == EM_FASTQ) {
+        if (q < len) return base_char<FOURBIT>(P, P.rec_base[r] + q);              // unnaf.c:442: never masked
+        q -= len;
+        if (q == 0) return '\n';
+        if (q == 1) return '+';
+        if (q == 2) return '\n';
+        q -= 3;
+        if (q < len) return P.qual[P.rec_base[r] + q];
+        return '\n';
+    }
+    if (P.mode == EM_SEQUENCES || P.L == 0) { if (q >= len) return '\n'; j = q; }
+    else {
+        u64 line = q / (P.L + 1), col = q - line * (P.L + 1);
+        if (col == P.L) return '\n';
+        j = line * P.L + col;
+        if (j >= len) return '\n';
+    }
+    u64 g = P.rec_base[r] + j;
+    u32 ch = base_char<FOURBIT>(P, g);
+    if (P.masking && base_masked(P, g, klo, khi)) ch += 32;
+    return ch;
+}
+
+// 16 consecutive bases starting at base index g as ASCII in two u64 (little endian: base 0 in byte 0).
+template <bool FOURBIT>
+__device__ __forceinline__ void bases16(const EmitP &P, u64 g, u64 &lo, u64 &hi)
+{
+    if (!FOURBIT) {
+        lo = ld64(P.seq + g); hi = ld64(P.seq + g + 8);
+        if (P.upper) {
+            // toupper on ASCII letters only, 8 bytes at a time
+            auto up = [](u64 v) { u64 r = 0; for (int i = 0; i < 8; i++) { u32 c = (v >> (8 * i)) & 0xFF; if (c >= 'a' && c <= 'z') c -= 32; r |= (u64)c << (8 * i); } return r; };
+            lo = up(lo); hi = up(hi);
+        }
+        return;
+    }
+    const u8 *a = P.seq + (g >> 1);
+    u64 nib = ld64(a);
+    if (g & 1) nib = (nib >> 4) | ((u64)a[8] << 60);
+    u32 out[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        u32 t = (u32)(nib >> (16 * w)) & 0xFFFF;                // 4 nibbles n3n2n1n0
+        u32 y = (t | (t << 8)) & 0x00FF00FF;
+        u32 z = (y | (y << 4)) & 0x0F0F0F0F;                    // one nibble per byte
+        u32 sel = z & 0x07070707;
+        u32 l = __builtin_amdgcn_perm(P.lut[1], P.lut[0], sel); // codes 0..7
+        u32 h = __builtin_amdgcn_perm(P.lut[3], P.lut[2], sel); // codes 8..15
+        u32 m = ((z >> 3) & 0x01010101) * 0xFF;
+        out[w] = (l & ~m) | (h & m);
+    }
+    lo = (u64)out[0] | ((u64)out[1] << 32); hi = (u64)out[2] | ((u64)out[3] << 32);
+}
+
+__device__ __forceinline__ u64 spread_bits8(u32 b)            // bit i of b -> 0x20 in byte i
+{
+    u64 r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r |= (u64)((b >> i) & 1) << (8 * i + 5);
+    return r;
+}
+
+__device__ __forceinline__ u64 low_bytes_mask(int n)           // n in [0,8] -> lowest n bytes set
+{
+    return n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1);
+}
+
+template <bool FOURBIT>
+__global__ __launch_bounds__(256) void k_emit(EmitP P, u8 *out)
+{
+    __shared__ u64 sh[4];                                       // rlo, rhi, klo, khi for this workgroup
+    u64 wg_first = P.out_begin + (u64)blockIdx.x * 4096, wg_last = wg_first + 4095;
+    if (wg_last >= P.out_end) wg_last = P.out_end - 1;
+    if (threadIdx.x < 2 && P.mode != EM_SEQ) {
+        u64 p = threadIdx.x == 0 ? wg_first : wg_last;
+        sh[threadIdx.x] = upper_bound_u64(P.rec_out, 0, P.N + 1, p) - 1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        // toggle window: all toggles that can affect bases of records rlo..rhi inside this workgroup
+        u64 g;
+        if (P.mode == EM_SEQ) g = threadIdx.x == 0 ? wg_first : wg_last + 1;
+        else g = threadIdx.x == 0 ? P.rec_base[sh[0]] : P.rec_base[sh[1] + 1];
+        if (P.mode != EM_SEQ && threadIdx.x == 0) {
+            // tighten the lower bound: first base this workgroup can touch inside record rlo
+            u64 r = sh[0], off = wg_first - P.rec_out[r], hl = P.hdr_len[r];
+            if (off > hl) { u64 q = off - hl; u64 j = (P.mode == EM_FASTA && P.L) ? (q / (P.L + 1)) * P.L : (P.mode == EM_FASTQ ? 0 : q); if (j > P.rec_len[r]) j = P.rec_len[r]; g += j; }
+        }
+        u64 k = P.masking ? upper_bound_u64(P.toggles, 0, P.n_toggles, g) : 0;
+        // lower bound keeps parity information: klo must be even-aligned count of toggles <= g (we keep absolute indices)
+        sh[2 + threadIdx.x] = k;
+    }
+    __syncthreads();
+    u64 rlo = sh[0], rhi = sh[1], klo = sh[2], khi = sh[3];
+    // absolute-index searches inside [klo, khi] preserve parity because upper_bound returns absolute counts
+    u64 p0 = wg_first + (u64)threadIdx.x * 16;
+    if (p0 >= P.out_end) return;
+    u8 *o = out + (p0 - P.out_begin);
+    u32 nbytes = P.out_end - p0 < 16 ? (u32)(P.out_end - p0) : 16;
+
+    bool fast = false; u64 g0 = 0, len = 0, j0 = 0; int nl_b = 64; bool qual_copy = false; u64 qoff = 0;
+    if (nbytes == 16 && !P.force_slow) {
+        if (P.mode == EM_SEQ) { fast = true; g0 = p0; len = ~0ull; j0 = 0; }
+        else {
+            u64 r = upper_bound_u64(P.rec_out, rlo, rhi + 1, p0) - 1;
+            u64 body = P.rec_out[r] + P.hdr_len[r], next = P.rec_out[r + 1];
+            if (p0 >= body && p0 + 16 <= next) {
+                u64 q0 = p0 - body; len = P.rec_len[r];
+                if (P.mode == EM_FASTQ) {
+                    if (q0 + 16 <= len) { fast = true; j0 = q0; g0 = P.rec_base[r] + j0; len = ~0ull; }
+                    else if (q0 >= len + 3 && q0 + 16 <= 2 * len + 3) { qual_copy = true; qoff = P.rec_base[r] + (q0 - len - 3); }
+                } else if (P.mode == EM_SEQUENCES || P.L == 0) { fast = true; j0 = q0; g0 = P.rec_base[r] + j0; }
+                else if (P.L >= 16) {
+                    u64 line = q0 / (P.L + 1), col = q0 - line * (P.L + 1);
+                    j0 = line * P.L + col; g0 = P.rec_base[r] + j0;
+                    u64 d = P.L - col;                         // byte index of the line-end newline
+                    nl_b = d < 16 ? (int)d : 64;
+                    fast = true;
+                }
+            }
+        }
+    }
+    if (qual_copy) { st64(o, ld64(P.qual + qoff)); st64(o + 8, ld64(P.qual + qoff + 8)); return; }
+    if (fast) {
+        u64 lo, hi;
+        bases16<FOURBIT>(P, g0, lo, hi);
+        if (P.masking) {
+            u64 k = upper_bound_u64(P.toggles, klo, khi, g0);  // toggles <= g0
+            u32 state = (u32)(k & 1), m16 = 0; u64 pos = g0;
+            // walk the toggles that fall inside (g0, g0+16)
+            for (;;) {
+                u64 nxt = k < khi ? P.toggles[k] : ~0ull;
+                u64 end = nxt < g0 + 16 ? nxt : g0 + 16;
+                if (state && end > pos) m16 |= (u32)(((1u << (end - pos)) - 1) << (pos - g0));
+                if (nxt >= g0 + 16) break;
+                pos = nxt; state ^= 1; k++;
+            }
+            lo += spread_bits8(m16 & 0xFF); hi += spread_bits8(m16 >> 8);
+        }
+        if (nl_b < 16) {
+            // bytes < nl_b keep, byte nl_b = '\n', bytes > nl_b take the previous base
+            u64 slo = lo << 8, shi = (hi << 8) | (lo >> 56);
+            u64 mlo = low_bytes_mask(nl_b), mhi = nl_b > 8 ? low_bytes_mask(nl_b - 8) : 0;
+            u64 m1lo = low_bytes_mask(nl_b + 1), m1hi = nl_b + 1 > 8 ? low_bytes_mask(nl_b + 1 - 8) : 0;
+            lo = (lo & mlo) | (slo & ~m1lo); hi = (hi & mhi) | (shi & ~m1hi);
+            if (nl_b < 8) lo |= (u64)'\n' << (8 * nl_b); else hi |= (u64)'\n' << (8 * (nl_b - 8));
+        }
+        u64 j15 = j0 + 15 - (15 > nl_b ? 1 : 0);
+        if (j15 >= len) hi = (hi & 0x00FFFFFFFFFFFFFFull) | ((u64)'\n' << 56);     // record-end newline
+        st64(o, lo); st64(o + 8, hi);
+        return;
+    }
+    for (u32 b = 0; b < nbytes; b++) o[b] = (u8)emit_byte<FOURBIT>(P, p0 + b, rlo, rhi, klo, khi);
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+static int zero_positions(naf_gpu_ctx *c, const u8 *d_buf, u64 n, u64 N, u64 **out)
+{
+    u64 *pos = arena_new<u64>(c, N + 1);
+    if (!pos) return NAF_GPU_ENOMEM;
+    u64 tiles = (n + ZT_TILE - 1) / ZT_TILE;
+    u64 *cnt = arena_new<u64>(c, tiles + 2);
+    if (!cnt) return NAF_GPU_ENOMEM;
+    u64 *d_total = cnt + tiles + 1;
+    if (tiles) LAUNCH(c, "unnaf_zero_count", k_zero_count, tiles, 256, 0, d_buf, n, cnt);
+    int rc = scan_exclusive_u64(c, cnt, tiles, d_total); if (rc) return rc;
+    u64 total = 0;
+    rc = ctx_readback(c, &total, d_total, 8); if (rc) return rc;
+    if (total < N) return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted ids - can't read id %llu\n", (unsigned long long)total);   // input.c:167,195
+    if (tiles) LAUNCH(c, "unnaf_zero_scatter", k_zero_scatter, tiles, 256, 0, d_buf, n, (const u64 *)cnt, pos, N);
+    *out = pos;
+    return 0;
+}
+
+extern "C" int naf_gpu_parse_header_host(const void *h_naf, size_t len, naf_gpu_header *h, char errbuf[128])
+{
+    // unnaf/src/input.c:31-77 read_header, utils.c:117-141 read_number, unnaf.c:402-404
+    const u8 *p = (const u8 *)h_naf; size_t pos = 0;
+    memset(h, 0, sizeof *h);
+#define HF(msg) do { if (errbuf) snprintf(errbuf, 128, "%s", msg); return NAF_GPU_EFORMAT; } while (0)
+    if (len == 0) HF("empty input");
+    if (len < 3) HF("incomplete or truncated input\n");
+    if (p[0] != 0x01 || p[1] != 0xF9 || p[2] != 0xEC) HF("not a NAF format\n");
+    pos = 3;
+    if (pos >= len) HF("incomplete or truncated input\n");
+    h->version = p[pos++];
+    if (h->version < 1 || h->version > 2) { if (errbuf) snprintf(errbuf, 128, "unknown version (%d) of NAF format\n", h->version); return NAF_GPU_EFORMAT; }
+    h->seq_type = NAF_SEQ_DNA;
+    if (h->version > 1) {
+        if (pos >= len) HF("incomplete or truncated input\n");
+        int t = p[pos++];
+        if (t < 1 || t > 3) { if (errbuf) snprintf(errbuf, 128, "unknown sequence type (%d) found in NAF file\n", t); return NAF_GPU_EFORMAT; }
+        h->seq_type = t;
+    }
+    if (pos + 2 > len) HF("incomplete or truncated input\n");
+    h->flags = p[pos++]; h->separator = p[pos++];
+    if (h->separator < 0x20 || h->separator > 0x7E) HF("unsupported name separator character\n");
+    auto rd = [&](u64 *v) -> int {
+        u64 a = 0; if (pos >= len) return 1;
+        u8 ch = p[pos++];
+        if (ch == 128) return 2;
+        while (ch & 128) { if (a & (127ull << 57)) return 3; a = (a << 7) | (ch & 127); if (pos >= len) return 1; ch = p[pos++]; }
+        if (a & (127ull << 57)) return 3;
+        *v = (a << 7) | ch; return 0;
+    };
+#define RD(dst) do { int e_ = rd(&(dst)); if (e_ == 1) HF("incomplete or truncated input\n"); \
+        if (e_ == 2) HF("invalid input: error parsing variable length encoded number\n"); \
+        if (e_ == 3) HF("invalid input: overflow reading a variable length encoded number\n"); } while (0)
+    RD(h->line_length); RD(h->n_sequences);
+    if (h->flags & 0x40) { RD(h->title_len); h->title_off = pos; if (pos + h->title_len > len) HF("incomplete or truncated input\n"); pos += h->title_len; }
+    static const int bit[6] = { 0x20, 0x10, 0x08, 0x04, 0x02, 0x01 };
+    for (int i = 0; i < 6; i++) {
+        if (!(h->flags & bit[i])) continue;
+        RD(h->orig_size[i]); RD(h->comp_size[i]);
+        if (pos + h->comp_size[i] > len) HF("incomplete or truncated input\n");
+        h->payload_off[i] = pos; pos += h->comp_size[i];
+    }
+    return 0;
+}
+
+extern "C" int naf_gpu_parse_header(naf_gpu_ctx *c, const void *d_naf, size_t len, naf_gpu_header *h)
+{
+    // The framing is a few dozen bytes at <= 8 places; pull 64-byte windows to the host as needed.
+    if (!c || !h) return NAF_GPU_EARG;
+    const u8 *d = (const u8 *)d_naf;
+    std::vector<u8> shadow(len < 64 ? len : 64);
+    // Strategy: keep a sparse host shadow: parse with a reader that fetches windows on demand.
+    memset(h, 0, sizeof *h);
+    struct Win { size_t off, n; u8 b[96]; } w = { 0, 0, {0} };
+    auto need = [&](size_t pos, size_t n) -> const u8 * {
+        if (pos + n > len) return nullptr;
+        if (pos < w.off || pos + n > w.off + w.n) {
+            w.off = pos; w.n = len - pos < sizeof w.b ? len - pos : sizeof w.b;
+            if (ctx_readback(c, w.b, d + pos, w.n)) return nullptr;
+        }
+        return w.b + (pos - w.off);
+    };
+#define DF(msg) return ctx_fail(c, NAF_GPU_EFORMAT, "%s", msg)
+    if (len == 0) DF("empty input");
+    const u8 *p = need(0, len < 8 ? len : 8);
+    if (!p || len < 3) DF("incomplete or truncated input\n");
+    if (p[0] != 0x01 || p[1] != 0xF9 || p[2] != 0xEC) DF("not a NAF format\n");
+    size_t pos = 3;
+    auto byte = [&](u8 *v) -> bool { const u8 *q = need(pos, 1); if (!q) return false; *v = *q; pos++; return true; };
+    u8 t;
+    if (!byte(&t)) DF("incomplete or truncated input\n");
+    h->version = t;
+    if (h->version < 1 || h->version > 2) return ctx_fail(c, NAF_GPU_EFORMAT, "unknown version (%d) of NAF format\n", h->version);
+    if (h->version > 1) { if (!byte(&t)) DF("incomplete or truncated input\n"); if (t < 1 || t > 3) return ctx_fail(c, NAF_GPU_EFORMAT, "unknown sequence type (%d) found in NAF file\n", t); h->seq_type = t; }
+    if (!byte(&t)) DF("incomplete or truncated input\n"); h->flags = t;
+    if (!byte(&t)) DF("incomplete or truncated input\n"); h->separator = t;
+    if (h->separator < 0x20 || h->separator > 0x7E) DF("unsupported name separator character\n");
+    auto rd = [&](u64 *v) -> int {
+        u64 a = 0; u8 ch;
+        if (!byte(&ch)) return 1;
+        if (ch == 128) return 2;
+        while (ch & 128) { if (a & (127ull << 57)) return 3; a = (a << 7) | (ch & 127); if (!byte(&ch)) return 1; }
+        if (a & (127ull << 57)) return 3;
+        *v = (a << 7) | ch; return 0;
+    };
+#define RDD(dst) do { int e_ = rd(&(dst)); if (e_ == 1) DF("incomplete or truncated input\n"); \
+        if (e_ == 2) DF("invalid input: error parsing variable length encoded number\n"); \
+        if (e_ == 3) DF("invalid input: overflow reading a variable length encoded number\n"); } while (0)
+    RDD(h->line_length); RDD(h->n_sequences);
+    if (h->flags & 0x40) { RDD(h->title_len); h->title_off = pos; if (pos + h->title_len > len) DF("incomplete or truncated input\n"); pos += h->title_len; }
+    static const int bit[6] = { 0x20, 0x10, 0x08, 0x04, 0x02, 0x01 };
+    for (int i = 0; i < 6; i++) {
+        if (!(h->flags & bit[i])) continue;
+        RDD(h->orig_size[i]); RDD(h->comp_size[i]);
+        if (pos + h->comp_size[i] > len) DF("incomplete or truncated input\n");
+        h->payload_off[i] = pos; pos += h->comp_size[i];
+    }
+    return 0;
+}
+
+enum { S_IDS = 0, S_NAMES, S_LEN, S_MASK, S_SEQ, S_QUAL };
+
+struct UnnafPlan {
+    naf_gpu_header h; EmitP P; u64 total; bool fourbit; bool empty;
+    u64 seq_bytes; bool need_qual;
+};
+
+static int load_section(naf_gpu_ctx *c, const u8 *d_naf, const naf_gpu_header &h, int i, u64 expect, const char *what, u8 **out)
+{
+    u8 *buf = (u8 *)arena_alloc(c, expect + 32);
+    if (!buf) return NAF_GPU_ENOMEM;
+    size_t n = 0;
+    int rc = zstd_decode(c, d_naf + h.payload_off[i], h.comp_size[i], 0, buf, expect, &n);
+    if (rc == NAF_GPU_ECAP || (rc == 0 && n != expect)) return ctx_fail(c, NAF_GPU_EFORMAT, "can't decompress %s\n", what);   // input.c:156,184,213,231
+    if (rc) return rc;
+    *out = buf;
+    return 0;
+}
+
+// Everything except the sequence / quality payload decode and the emit itself.
+static int unnaf_prepare(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_gpu_unnaf_opts *o, UnnafPlan &pl)
+{
+    int rc = naf_gpu_parse_header(c, d_naf, naf_len, &pl.h); if (rc) return rc;
+    const naf_gpu_header &h = pl.h;
+    EmitP &P = pl.P; memset(&P, 0, sizeof P);
+    int has_ids = (h.flags >> 5) & 1, has_names = (h.flags >> 4) & 1, has_len = (h.flags >> 3) & 1,
+        has_mask = (h.flags >> 2) & 1, has_data = (h.flags >> 1) & 1, has_qual = h.flags & 1;
+    int mode = o->out_type == NAF_OUT_DEFAULT ? (has_qual ? NAF_OUT_FASTQ : NAF_OUT_FASTA) : o->out_type;   // unnaf.c:372-375
+    pl.empty = false; pl.total = 0; pl.need_qual = false;
+    pl.fourbit = h.seq_type <= NAF_SEQ_RNA;
+    u64 N = h.n_sequences, T = h.orig_size[S_SEQ];
+    pl.seq_bytes = pl.fourbit ? (T + 1) / 2 : T;
+    if (N == 0 || !has_data) { pl.empty = true; return 0; }                         // unnaf.c:409, output.c:610
+    if (mode == NAF_OUT_FASTQ && !has_qual) return ctx_fail(c, NAF_GPU_EFORMAT, "FASTQ output requested, but input has no qualities\n");
+    if (mode == NAF_OUT_4BIT) {
+        if (!pl.fourbit) return ctx_fail(c, NAF_GPU_EFORMAT, "input has no 4-bit encoded data, but %s sequences\n", h.seq_type == NAF_SEQ_PROTEIN ? "protein" : "text");
+        P.mode = -1; pl.total = pl.seq_bytes; return 0;
+    }
+    P.mode = mode == NAF_OUT_FASTA ? EM_FASTA : mode == NAF_OUT_FASTQ ? EM_FASTQ : mode == NAF_OUT_SEQ ? EM_SEQ : EM_SEQUENCES;
+    P.N = N; P.T = T;
+    P.L = o->line_length >= 0 ? (u64)o->line_length : h.line_length;
+    P.sep = h.separator; P.hdr_char = P.mode == EM_FASTQ ? '@' : '>';
+    P.masking = o->use_mask && has_mask && P.mode != EM_FASTQ && pl.fourbit;         // unnaf.c:442; mask only exists for DNA/RNA
+    P.upper = !pl.fourbit && !o->use_mask;
+    const char *tab = h.seq_type == NAF_SEQ_RNA ? "-UGKCYSBAWRDMHVN" : "-TGKCYSBAWRDMHVN";   // unnaf.c:13,369
+    memcpy(P.lut, tab, 16);
+    const char *fs = getenv("NAF_GPU_FORCE_SLOW"); P.force_slow = fs && fs[0] == '1';
+    pl.need_qual = P.mode == EM_FASTQ;
+
+    if (P.mode == EM_SEQ) {
+        pl.total = T;
+    } else {
+        if (!has_len) return ctx_fail(c, NAF_GPU_EFORMAT, "archive has no lengths");
+        u8 *lens = nullptr;
+        if ((rc = load_section(c, d_naf, h, S_LEN, h.orig_size[S_LEN], "lengths", &lens))) return rc;
+        u64 n_len = h.orig_size[S_LEN] / 4;
+        u64 *flag = arena_new<u64>(c, n_len + 2), *rec_len = arena_new<u64>(c, N + 1);
+        if (!flag || !rec_len) return NAF_GPU_ENOMEM;
+        HIP_TRY(c, hipMemsetAsync(rec_len, 0, (N + 1) * 8, c->stream));
+        if (n_len) LAUNCH(c, "unnaf_len_flags", k_len_flags, cdiv(n_len, 256), 256, 0, (const u32 *)lens, n_len, flag);
+        if ((rc = scan_exclusive_u64(c, flag, n_len, flag + n_len + 1))) return rc;
+        if (n_len) LAUNCH(c, "unnaf_len_acc", k_len_acc, cdiv(n_len, 256), 256, 0, (const u32 *)lens, n_len, (const u64 *)flag, rec_len, N);
+        u64 nrec = 0;
+        if ((rc = ctx_readback(c, &nrec, flag + n_len + 1, 8))) return rc;
+        if (nrec < N) return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted lengths: %llu records described, %llu expected", (unsigned long long)nrec, (unsigned long long)N);
+        P.rec_len = rec_len;
+        P.has_ids = 0; P.has_names = 0;
+        if (P.mode == EM_FASTA || P.mode == EM_FASTQ) {
+            P.has_ids = has_ids; P.has_names = has_names;
+            if (has_ids) {
+                u8 *b = nullptr; u64 *z = nullptr;
+                if (h.orig_size[S_IDS] == 0) return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted ids - not 0-terminated\n");
+                if ((rc = load_section(c, d_naf, h, S_IDS, h.orig_size[S_IDS], "ids", &b))) return rc;
+                if ((rc = zero_positions(c, b, h.orig_size[S_IDS], N, &z))) return rc;
+                P.ids = b; P.idz = z;
+            }
+            if (has_names) {
+                u8 *b = nullptr; u64 *z = nullptr;
+                if (h.orig_size[S_NAMES] == 0) return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted names - not 0-terminated\n");
+                if ((rc = load_section(c, d_naf, h, S_NAMES, h.orig_size[S_NAMES], "names", &b))) return rc;
+                if ((rc = zero_positions(c, b, h.orig_size[S_NAMES], N, &z))) return rc;
+                P.names = b; P.nmz = z;
+            }
+        }
+        u32 *hdr_len = arena_new<u32>(c, N + 1);
+        u64 *rec_out = arena_new<u64>(c, N + 2), *rec_base = arena_new<u64>(c, N + 2);
+        if (!hdr_len || !rec_out || !rec_base) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "unnaf_rec_sizes", k_rec_sizes, cdiv(N, 256), 256, 0, N, (const u64 *)rec_len, P.idz, P.nmz, P.has_ids, P.has_names, P.mode, P.L, hdr_len, rec_out, rec_base);
+        // exclusive scans; element N receives the total (scan over N+1 entries with a zero tail)
+        HIP_TRY(c, hipMemsetAsync(rec_out + N, 0, 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(rec_base + N, 0, 8, c->stream));
+        if ((rc = scan_exclusive_u64(c, rec_out, N + 1, (u64 *)nullptr))) return rc;
+        if ((rc = scan_exclusive_u64(c, rec_base, N + 1, (u64 *)nullptr))) return rc;
+        u64 tot[2];
+        if ((rc = ctx_readback(c, &tot[0], rec_out + N, 8))) return rc;
+        if ((rc = ctx_readback(c, &tot[1], rec_base + N, 8))) return rc;
+        if (tot[1] != T) return ctx_fail(c, NAF_GPU_EFORMAT, "sum of lengths (%llu) differs from the stored sequence length (%llu)", (unsigned long long)tot[1], (unsigned long long)T);
+        if (P.mode == EM_SEQUENCES && T == 0) tot[0] = 0;                            // output-sequences.c:81: nothing printed
+        P.hdr_len = hdr_len; P.rec_out = rec_out; P.rec_base = rec_base;
+        pl.total = tot[0];
+    }
+    if (P.masking) {
+        u8 *mu = nullptr; u64 n_mask = h.orig_size[S_MASK];
+        if ((rc = load_section(c, d_naf, h, S_MASK, n_mask, "mask", &mu))) return rc;
+        u64 tiles = (n_mask + MT_TILE - 1) / MT_TILE;
+        u64 *ts = arena_new<u64>(c, tiles + 2), *tc = arena_new<u64>(c, tiles + 2);
+        if (!ts || !tc) return NAF_GPU_ENOMEM;
+        if (tiles) LAUNCH(c, "unnaf_mask_count", k_mask_count, tiles, 256, 0, (const u8 *)mu, n_mask, ts, tc);
+        if ((rc = scan_exclusive_u64(c, ts, tiles, (u64 *)nullptr))) return rc;
+        if ((rc = scan_exclusive_u64(c, tc, tiles, tc + tiles + 1))) return rc;
+        u64 ntog = 0;
+        if ((rc = ctx_readback(c, &ntog, tc + tiles + 1, 8))) return rc;
+        u64 *tg = arena_new<u64>(c, ntog + 1);
+        if (!tg) return NAF_GPU_ENOMEM;
+        if (tiles) LAUNCH(c, "unnaf_mask_scatter", k_mask_scatter, tiles, 256, 0, (const u8 *)mu, n_mask, (const u64 *)ts, (const u64 *)tc, tg);
+        P.toggles = tg; P.n_toggles = ntog;
+    }
+    return 0;
+}
+
+static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_gpu_unnaf_opts *o,
+                     u64 out_begin, u64 out_end, bool whole, u8 *d_out, size_t out_cap, size_t *out_len, bool size_only)
+{
+    if (!c || !d_naf || !o || !out_len) return NAF_GPU_EARG;
+    arena_reset(c);
+    UnnafPlan pl;
+    int rc = unnaf_prepare(c, d_naf, naf_len, o, pl); if (rc) return rc;
+    if (pl.empty) { *out_len = 0; return 0; }
+    if (whole) { out_begin = 0; out_end = pl.total; }
+    if (out_end > pl.total) out_end = pl.total;
+    if (out_begin > out_end) out_begin = out_end;
+    *out_len = out_end - out_begin;
+    if (size_only) { *out_len = pl.total; return 0; }
+    if (*out_len > out_cap) return ctx_fail(c, NAF_GPU_ECAP, "unnaf output needs %llu bytes, capacity %zu", (unsigned long long)*out_len, out_cap);
+    if (*out_len == 0) return 0;
+    const naf_gpu_header &h = pl.h;
+    // sequence payload (the dominant zstd stream)
+    u8 *seq = (u8 *)arena_alloc(c, pl.seq_bytes + 64);
+    if (!seq) return NAF_GPU_ENOMEM;
+    size_t n = 0;
+    rc = zstd_decode(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, seq, pl.seq_bytes, &n);
+    if (rc == NAF_GPU_ECAP || (rc == 0 && n != pl.seq_bytes)) return ctx_fail(c, NAF_GPU_EFORMAT, "can't decompress sequence\n");
+    if (rc) return rc;
+    if (pl.P.mode == -1) {                                                             // --4bit: the stream itself
+        HIP_TRY(c, hipMemcpyAsync(d_out, seq + out_begin, out_end - out_begin, hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    }
+    pl.P.seq = seq;
+    if (pl.need_qual) {
+        u8 *q = nullptr;
+        if ((rc = load_section(c, d_naf, h, S_QUAL, h.orig_size[S_QUAL], "quality", &q))) return rc;
+        pl.P.qual = q;
+    }
+    pl.P.out_begin = out_begin; pl.P.out_end = out_end;
+    u32 grid = cdiv(out_end - out_begin, 4096);
+    if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit<true>, grid, 256, 0, pl.P, d_out);
+    else LAUNCH(c, "unnaf_emit", k_emit<false>, grid, 256, 0, pl.P, d_out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int naf_gpu_unnaf_size(naf_gpu_ctx *c, const void *d_naf, size_t naf_len, const naf_gpu_unnaf_opts *o, size_t *out_len)
+{
+    return unnaf_run(c, (const u8 *)d_naf, naf_len, o, 0, 0, true, nullptr, 0, out_len, true);
+}
+extern "C" int naf_gpu_unnaf(naf_gpu_ctx *c, const void *d_naf, size_t naf_len, const naf_gpu_unnaf_opts *o, void *d_out, size_t out_cap, size_t *out_len)
+{
+    return unnaf_run(c, (const u8 *)d_naf, naf_len, o, 0, 0, true, (u8 *)d_out, out_cap, out_len, false);
+}
+extern "C" int naf_gpu_unnaf_range(naf_gpu_ctx *c, const void *d_naf, size_t naf_len, const naf_gpu_unnaf_opts *o,
+                                   uint64_t out_begin, uint64_t out_end, void *d_out, size_t out_cap, size_t *out_len)
+{
+    return unnaf_run(c, (const u8 *)d_naf, naf_len, o, out_begin, out_end, false, (u8 *)d_out, out_cap, out_len, false);
+}

@@ -1,0 +1,200 @@
+// naf_gpu.hip -- context, scratch arena, error reporting, timing, memory helpers of libnaf_gpu.
+#include "ctx.h"
+#include <string.h>
+#include <map>
+
+int ctx_fail(naf_gpu_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        va_list ap; va_start(ap, fmt);
+        vsnprintf(c->err, sizeof c->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+extern "C" const char *naf_gpu_strerror(int code)
+{
+    switch (code) {
+    case NAF_GPU_OK: return "ok";
+    case NAF_GPU_ENODEV: return "no usable gfx950 device";
+    case NAF_GPU_EHIP: return "HIP runtime error";
+    case NAF_GPU_ENOMEM: return "out of device memory";
+    case NAF_GPU_EFORMAT: return "malformed NAF container";
+    case NAF_GPU_EZSTD: return "corrupt or unsupported zstd frame";
+    case NAF_GPU_ECAP: return "output buffer too small";
+    case NAF_GPU_EINPUT: return "invalid input text";
+    case NAF_GPU_EARG: return "invalid argument";
+    default: return "unknown error";
+    }
+}
+
+extern "C" const char *naf_gpu_last_error(const naf_gpu_ctx *c) { return c ? c->err : "no context"; }
+
+extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
+{
+    if (!out) return NAF_GPU_EARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return NAF_GPU_ENODEV;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return NAF_GPU_ENODEV;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return NAF_GPU_ENODEV;     // kernels are built for gfx950 only
+    if (hipSetDevice(device) != hipSuccess) return NAF_GPU_ENODEV;
+    naf_gpu_ctx *c = new naf_gpu_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return NAF_GPU_EHIP; }
+    c->own_stream = true;
+    c->h_stage_cap = 1 << 16;
+    if (hipHostMalloc((void **)&c->h_stage, c->h_stage_cap, hipHostMallocDefault) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return NAF_GPU_ENOMEM; }
+    int rc = zstd_init_tables(c);
+    if (rc) { naf_gpu_shutdown(c); return rc; }
+    *out = c;
+    return NAF_GPU_OK;
+}
+
+extern "C" void naf_gpu_shutdown(naf_gpu_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto &ch : c->chunks) hipFree(ch.base);
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    if (c->d_predef) hipFree(c->d_predef);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int naf_gpu_set_stream(naf_gpu_ctx *c, void *s)
+{
+    // s is a hipStream_t; NULL is HIP's default (null) stream, exactly as in the HIP API.
+    if (!c) return NAF_GPU_EARG;
+    hipStreamSynchronize(c->stream);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)s; c->own_stream = false;
+    return 0;
+}
+
+extern "C" int naf_gpu_synchronize(naf_gpu_ctx *c) { if (!c) return NAF_GPU_EARG; HIP_TRY(c, hipStreamSynchronize(c->stream)); return 0; }
+
+// ---- arena -----------------------------------------------------------------------------------------------
+static const size_t ARENA_ALIGN = 256;
+static const size_t ARENA_MIN_CHUNK = (size_t)64 << 20;
+
+void arena_reset(naf_gpu_ctx *c)
+{
+    size_t total = 0;
+    for (auto &ch : c->chunks) { total += ch.cap; ch.used = 0; }
+    if (c->chunks.size() > 1) {                      // consolidate so steady state is one chunk, no hipMalloc
+        hipStreamSynchronize(c->stream);
+        for (auto &ch : c->chunks) hipFree(ch.base);
+        c->chunks.clear();
+        u8 *p = nullptr;
+        if (hipMalloc((void **)&p, total) == hipSuccess) c->chunks.push_back({ p, total, 0 });
+    }
+}
+
+void *arena_alloc(naf_gpu_ctx *c, size_t bytes)
+{
+    bytes = (bytes + ARENA_ALIGN - 1) & ~(ARENA_ALIGN - 1);
+    if (bytes == 0) bytes = ARENA_ALIGN;
+    for (auto &ch : c->chunks)
+        if (ch.cap - ch.used >= bytes) { void *p = ch.base + ch.used; ch.used += bytes; return p; }
+    size_t cap = bytes > ARENA_MIN_CHUNK ? bytes : ARENA_MIN_CHUNK;
+    u8 *p = nullptr;
+    if (hipMalloc((void **)&p, cap) != hipSuccess) { ctx_fail(c, NAF_GPU_ENOMEM, "hipMalloc(%zu) failed", cap); return nullptr; }
+    c->chunks.push_back({ p, cap, bytes });
+    return p;
+}
+
+extern "C" int naf_gpu_reserve(naf_gpu_ctx *c, size_t bytes)
+{
+    if (!c) return NAF_GPU_EARG;
+    size_t total = 0;
+    for (auto &ch : c->chunks) total += ch.cap;
+    if (total >= bytes && c->chunks.size() <= 1) return 0;
+    hipStreamSynchronize(c->stream);
+    for (auto &ch : c->chunks) hipFree(ch.base);
+    c->chunks.clear();
+    u8 *p = nullptr;
+    if (bytes < total) bytes = total;
+    HIP_TRY(c, hipMalloc((void **)&p, bytes));
+    c->chunks.push_back({ p, bytes, 0 });
+    return 0;
+}
+
+int ctx_readback(naf_gpu_ctx *c, void *h_dst, const void *d_src, size_t bytes)
+{
+    if (bytes > c->h_stage_cap) {
+        HIP_TRY(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_stage, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(h_dst, c->h_stage, bytes);
+    return 0;
+}
+
+// ---- memory helpers for hosts that do not link HIP ----------------------------------------------------------
+extern "C" int naf_gpu_malloc(naf_gpu_ctx *c, size_t bytes, void **p) { if (!c || !p) return NAF_GPU_EARG; HIP_TRY(c, hipMalloc(p, bytes ? bytes : 1)); return 0; }
+extern "C" int naf_gpu_free(naf_gpu_ctx *c, void *p) { if (!c) return NAF_GPU_EARG; HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(p)); return 0; }
+extern "C" int naf_gpu_host_alloc(naf_gpu_ctx *c, size_t bytes, void **p) { if (!c || !p) return NAF_GPU_EARG; HIP_TRY(c, hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault)); return 0; }
+extern "C" int naf_gpu_host_free(naf_gpu_ctx *c, void *p) { if (!c) return NAF_GPU_EARG; HIP_TRY(c, hipHostFree(p)); return 0; }
+extern "C" int naf_gpu_upload(naf_gpu_ctx *c, void *d, const void *h, size_t n) { if (!c) return NAF_GPU_EARG; if (n) HIP_TRY(c, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream)); return 0; }
+extern "C" int naf_gpu_download(naf_gpu_ctx *c, void *h, const void *d, size_t n)
+{
+    if (!c) return NAF_GPU_EARG;
+    if (n) HIP_TRY(c, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- timing -------------------------------------------------------------------------------------------------
+extern "C" int naf_gpu_set_timing(naf_gpu_ctx *c, int enable)
+{
+    if (!c) return NAF_GPU_EARG;
+    c->timing = enable != 0; c->ktimes.clear(); c->ev_used = 0;
+    return 0;
+}
+
+static hipEvent_t ev_get(naf_gpu_ctx *c)
+{
+    if (c->ev_used == c->ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); c->ev_pool.push_back(e); }
+    return c->ev_pool[c->ev_used++];
+}
+
+void ktime_begin(naf_gpu_ctx *c, const char *name)
+{
+    if (!c->timing) return;
+    KTime k; k.name = name; k.a = ev_get(c); k.b = ev_get(c);
+    hipEventRecord(k.a, c->stream);
+    c->ktimes.push_back(k);
+}
+
+void ktime_end(naf_gpu_ctx *c)
+{
+    if (!c->timing) return;
+    hipEventRecord(c->ktimes.back().b, c->stream);
+}
+
+extern "C" int naf_gpu_get_timing(naf_gpu_ctx *c, const char **names, float *ms, int *launches, int cap)
+{
+    if (!c) return NAF_GPU_EARG;
+    hipStreamSynchronize(c->stream);
+    std::map<std::string, std::pair<float, int>> agg;
+    std::vector<std::string> order;
+    for (auto &k : c->ktimes) {
+        float t = 0; hipEventElapsedTime(&t, k.a, k.b);
+        auto it = agg.find(k.name);
+        if (it == agg.end()) { agg[k.name] = { t, 1 }; order.push_back(k.name); }
+        else { it->second.first += t; it->second.second++; }
+    }
+    c->agg_names = order; c->agg_ms.clear(); c->agg_n.clear();
+    for (auto &n : order) { c->agg_ms.push_back(agg[n].first); c->agg_n.push_back(agg[n].second); }
+    int n = (int)order.size() < cap ? (int)order.size() : cap;
+    for (int i = 0; i < n; i++) { names[i] = c->agg_names[i].c_str(); ms[i] = c->agg_ms[i]; launches[i] = c->agg_n[i]; }
+    c->ktimes.clear(); c->ev_used = 0;
+    return n;
+}

@@ -1,0 +1,490 @@
+// zstd_dec.hip -- zstd frame decoder for gfx950 (RFC 8878; replaces libzstd behind
+// unnaf/src/input.c:155,183,212,230 one-shot sections and input.c:262-434 streamed sequence/quality).
+//
+// Pipeline per frame (all data stays in HBM):
+//   k_scan_blocks    one lane walks the 3-byte block headers -> ZBlock[]           (serial by format)
+//   k_parse_blocks   one lane per block: literals / sequences section headers
+//   max-scans        which earlier block owns the Huffman / LL / OF / ML table in force (treeless, repeat)
+//   k_build_huf/fse  one lane per defining block builds decoding tables into a pool
+//   k_decode_seq     one lane per block with sequences: FSE decode -> (ll, ml, offset) arrays,
+//                    repeat offsets kept symbolic against the block-entry state
+//   k_rep_chain      one wave composes the repeat-offset state across blocks
+//   scan             regenerated sizes -> output offsets
+//   k_huf_literals   ONE LANE PER HUFFMAN STREAM (4 per block, 16 blocks per wave), tables in LDS
+//   k_copy_fill      raw / RLE blocks and raw / RLE literals, one workgroup per block
+//   k_exec_seq       one wave per block with sequences, ticket-ordered, waits on per-block done flags
+#include "ctx.h"
+#include "zstd_dec_core.h"
+
+struct ZStat {                 // device-side counters read back by the host
+    u32 nblk; u32 err; u64 end_off;
+    u32 n_huf_def, n_seq_blk, max_huf_log, pad;
+    u32 huf_pool_used, fse_pool_used;
+    u64 total_seq, total_out;
+    u32 ticket, pad2;
+};
+
+static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
+
+__global__ void k_scan_blocks(const u8 *src, u64 len, u64 first_off, ZBlock *blk, u32 cap, ZStat *st)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u64 pos = first_off; u32 n = 0, err = 0;
+    for (;;) {
+        if (pos + 3 > len) { err = ZE_TRUNC; break; }
+        u32 h = ld24(src + pos);
+        u32 last = h & 1, type = (h >> 1) & 3, size = h >> 3;
+        if (type == 3 || size > ZBLOCK_MAX) { err = ZE_CORRUPT; break; }
+        u32 csize = type == BT_RLE ? 1 : size;
+        if (pos + 3 + csize > len) { err = ZE_TRUNC; break; }
+        if (n < cap) { ZBlock &b = blk[n]; b.src_off = pos + 3; b.bsize = size; b.btype = (u8)type; b.last = (u8)last; }
+        n++; pos += 3 + csize;
+        if (last) break;
+    }
+    st->nblk = n; st->end_off = pos; st->err = err;
+}
+
+__global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_huf, i32 *own_ll, i32 *own_of, i32 *own_ml,
+                               u64 *seq_cnt, ZStat *st)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblk) return;
+    ZBlock b = blk[i];
+    zstd_parse_block(src + b.src_off, b);
+    blk[i] = b;
+    set_err(st, b.err);
+    bool comp = b.btype == BT_COMP && !b.err;
+    own_huf[i] = (comp && b.lit_type == LIT_HUF) ? (i32)i : -1;
+    bool sq = comp && b.nseq > 0;
+    own_ll[i] = (sq && b.modes[0] != SM_REPEAT) ? (i32)i : -1;
+    own_of[i] = (sq && b.modes[1] != SM_REPEAT) ? (i32)i : -1;
+    own_ml[i] = (sq && b.modes[2] != SM_REPEAT) ? (i32)i : -1;
+    seq_cnt[i] = sq ? b.nseq : 0;
+    if (comp && b.lit_type == LIT_HUF) atomicAdd(&st->n_huf_def, 1u);
+    if (sq) atomicAdd(&st->n_seq_blk, 1u);
+}
+
+__global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblk) return;
+    if (blk[i].btype != BT_COMP || blk[i].lit_type != LIT_HUF || blk[i].err) return;
+    const u8 *c = src + blk[i].src_off;
+    u8 w[256]; u32 nw = 0, used = 0;
+    u32 log = huf_read_weights(c + blk[i].lit_off, blk[i].lit_csize, w, &nw, &used);
+    if (!log) { set_err(st, ZE_CORRUPT); blk[i].err = ZE_CORRUPT; return; }
+    u32 bytes = 2u << log; if (bytes < 16) bytes = 16;
+    u32 off = atomicAdd(&st->huf_pool_used, bytes);
+    if (off + bytes > pool_cap) { set_err(st, ZE_POOL); return; }
+    huf_build_table((u16 *)(pool + off), w, nw, log);
+    blk[i].huf_tab = off; blk[i].huf_log = (u8)log;
+    atomicMax(&st->max_huf_log, log);
+}
+
+__global__ void k_build_fse(const u8 *src, ZBlock *blk, u32 nblk, FseE *pool, u32 pool_cap, ZStat *st)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblk) return;
+    if (blk[i].btype != BT_COMP || blk[i].nseq == 0 || blk[i].err) return;
+    const u8 *c = src + blk[i].src_off;
+    u32 pos = blk[i].seq_off, len = blk[i].bsize;
+    const u32 max_log[3] = { 9, 8, 9 }, max_sym[3] = { 35, 31, 52 };
+    for (int k = 0; k < 3; k++) {
+        u32 m = blk[i].modes[k];
+        if (m == SM_RLE) pos++;
+        else if (m == SM_FSE) {
+            i16 norm[64]; u16 next[64]; u32 nsym, log;
+            u32 d = fse_read_ncount(c + pos, len - pos, max_log[k], max_sym[k], norm, &nsym, &log);
+            if (!d) { set_err(st, ZE_CORRUPT); return; }
+            pos += d;
+            u32 off = atomicAdd(&st->fse_pool_used, 1u << log);
+            if (off + (1u << log) > pool_cap) { set_err(st, ZE_POOL); return; }
+            if (!fse_build_table(pool + off, norm, nsym, log, next)) { set_err(st, ZE_CORRUPT); return; }
+            blk[i].fse_tab[k] = off;
+        }
+    }
+}
+
+__global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
+                             const u64 *seq_base, const FseE *pool, const FseE *predef,
+                             u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblk) return;
+    ZBlock &b = blk[i];
+    sizes[i] = b.regen;
+    if (b.btype != BT_COMP || b.nseq == 0 || b.err) return;
+    const i32 *own[3] = { own_ll, own_of, own_ml };
+    const u32 predef_off[3] = { 0, 64, 96 }, predef_log[3] = { 6, 5, 6 };
+    SeqTab tab[3];
+    for (int k = 0; k < 3; k++) {
+        i32 ob = own[k][i];
+        if (ob < 0) { set_err(st, ZE_CORRUPT); b.err = ZE_CORRUPT; return; }      // repeat mode without a table
+        b.fse_owner[k] = ob;
+        u32 m = blk[ob].modes[k];
+        tab[k].rle = m == SM_RLE; tab[k].rle_sym = blk[ob].fse_tab[k];
+        if (m == SM_PREDEF) { tab[k].t = predef + predef_off[k]; tab[k].log = predef_log[k]; }
+        else if (m == SM_FSE) { tab[k].t = pool + blk[ob].fse_tab[k]; tab[k].log = blk[ob].fse_log[k]; }
+        else { tab[k].t = predef; tab[k].log = 0; }
+    }
+    u64 base = seq_base[i], sll = 0, sml = 0;
+    b.seq_base = base;
+    u32 rep_out[3];
+    u8 e = zstd_decode_sequences(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tab,
+                                 o_ll + base, o_ml + base, o_of + base, rep_out, &sll, &sml);
+    if (e) { set_err(st, e); b.err = e; return; }
+    if (sll > b.lit_regen || b.lit_regen + sml > ZBLOCK_MAX) { set_err(st, ZE_CORRUPT); b.err = ZE_CORRUPT; return; }
+    b.rep_out[0] = rep_out[0]; b.rep_out[1] = rep_out[1]; b.rep_out[2] = rep_out[2];
+    b.regen = (u32)(b.lit_regen + sml);
+    sizes[i] = b.regen;
+}
+
+// One wave: 64 blocks per step are loaded coalesced, then composed lane by lane through shuffles.
+__global__ void k_rep_chain(ZBlock *blk, u32 nblk)
+{
+    int lane = threadIdx.x;
+    u32 r0 = 1, r1 = 4, r2 = 8;                              // RFC 8878 3.1.1.5 initial repeat offsets
+    for (u32 base = 0; base < nblk; base += 64) {
+        u32 i = base + lane;
+        u32 has = 0, o0 = 0, o1 = 0, o2 = 0;
+        if (i < nblk && blk[i].btype == BT_COMP && blk[i].nseq > 0 && !blk[i].err) { has = 1; o0 = blk[i].rep_out[0]; o1 = blk[i].rep_out[1]; o2 = blk[i].rep_out[2]; }
+        u32 in0 = 0, in1 = 0, in2 = 0;
+        for (int j = 0; j < 64; j++) {
+            u32 hj = __shfl(has, j, 64);
+            if (!hj) continue;                               // wave-uniform
+            u32 a = __shfl(o0, j, 64), b = __shfl(o1, j, 64), c = __shfl(o2, j, 64);
+            if (lane == j) { in0 = r0; in1 = r1; in2 = r2; }
+            u32 rin[3] = { r0, r1, r2 };
+            u32 n0 = sym_resolve(a, rin), n1 = sym_resolve(b, rin), n2 = sym_resolve(c, rin);
+            r0 = n0; r1 = n1; r2 = n2;
+        }
+        if (has) { blk[i].rep_in[0] = in0; blk[i].rep_in[1] = in1; blk[i].rep_in[2] = in2; }
+    }
+}
+
+__global__ void k_set_offsets(ZBlock *blk, u32 nblk, const u64 *offs, u32 *done, u32 *seq_list, u32 *seq_list_n)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblk) return;
+    blk[i].out_off = offs[i];
+    bool sq = blk[i].btype == BT_COMP && blk[i].nseq > 0;
+    if (done) done[i] = sq ? 0u : 1u;
+    (void)seq_list; (void)seq_list_n;
+}
+
+// Compact list of blocks with sequences, in block order (rank = exclusive count of seq blocks before i).
+__global__ void k_seq_list(const ZBlock *blk, u32 nblk, const u64 *rank, u32 *list)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblk) return;
+    if (blk[i].btype == BT_COMP && blk[i].nseq > 0) list[rank[i]] = i;
+}
+__global__ void k_seq_flag(const ZBlock *blk, u32 nblk, u64 *flag)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nblk) flag[i] = (blk[i].btype == BT_COMP && blk[i].nseq > 0) ? 1 : 0;
+}
+
+// ---- Huffman literals: one lane per stream, 16 blocks per 64-lane workgroup, tables staged in LDS ----------
+#define HUF_BLOCKS_PER_WG 16
+__global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf,
+                                                      const u8 *pool, u32 slot_bytes, u8 *dst, u8 *lit_scratch, ZStat *st)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 lds[];
+    int lane = threadIdx.x;
+    u32 b0 = blockIdx.x * HUF_BLOCKS_PER_WG;
+    // stage the table in force for each of the 16 blocks (16-byte pieces, all 64 lanes cooperate)
+    for (u32 j = 0; j < HUF_BLOCKS_PER_WG; j++) {
+        u32 bi = b0 + j;
+        if (bi >= nblk) break;
+        const ZBlock &b = blk[bi];
+        if (b.btype != BT_COMP || b.lit_type < LIT_HUF || b.err) continue;
+        i32 ob = own_huf[bi];
+        if (ob < 0) continue;
+        u32 bytes = 2u << blk[ob].huf_log; if (bytes < 16) bytes = 16;
+        const uint4 *g = (const uint4 *)(pool + blk[ob].huf_tab);
+        uint4 *l = (uint4 *)(lds + j * slot_bytes);
+        for (u32 k = lane; k < bytes / 16; k += 64) l[k] = g[k];
+    }
+    __syncthreads();
+    u32 j = lane >> 2, s = lane & 3, bi = b0 + j;
+    if (bi >= nblk) return;
+    const ZBlock &b = blk[bi];
+    if (b.btype != BT_COMP || b.lit_type < LIT_HUF || b.err) return;
+    i32 ob = own_huf[bi];
+    if (ob < 0) { if (s == 0) set_err(st, ZE_CORRUPT); return; }     // treeless without a previous table
+    u32 log = blk[ob].huf_log;
+    const u16 *tab = (const u16 *)(lds + j * slot_bytes);
+    const u8 *c = src + b.src_off + b.huf_streams_off;
+    u8 *out = (b.nseq == 0 ? dst : lit_scratch) + b.out_off;
+    u32 regen = b.lit_regen;
+    u8 e;
+    if (b.nstreams == 1) {
+        if (s != 0) return;
+        e = huf_decode_stream(c, b.huf_streams_size, tab, log, out, regen);
+    } else {
+        u32 s1 = ld16(c), s2 = ld16(c + 2), s3 = ld16(c + 4), tot = b.huf_streams_size - 6;
+        if (s1 + s2 + s3 >= tot || !s1 || !s2 || !s3) { if (s == 0) set_err(st, ZE_CORRUPT); return; }
+        u32 per = (regen + 3) / 4;
+        if (per * 3 > regen) { if (s == 0) set_err(st, ZE_CORRUPT); return; }
+        u32 off = s == 0 ? 0 : (s == 1 ? s1 : (s == 2 ? s1 + s2 : s1 + s2 + s3));
+        u32 sz = s == 0 ? s1 : (s == 1 ? s2 : (s == 2 ? s3 : tot - s1 - s2 - s3));
+        u32 n = s < 3 ? per : regen - 3 * per;
+        e = huf_decode_stream(c + 6 + off, sz, tab, log, out + s * per, n);
+    }
+    if (e) set_err(st, e);
+}
+
+// ---- raw / RLE blocks and raw / RLE literal sections: one workgroup per block ------------------------------
+__global__ __launch_bounds__(256) void k_copy_fill(const u8 *src, const ZBlock *blk, u32 nblk, u8 *dst, u8 *lit_scratch)
+{
+    u32 i = blockIdx.x;
+    const ZBlock &b = blk[i];
+    const u8 *from; u8 *to; u32 n; bool fill;
+    if (b.btype == BT_RAW) { from = src + b.src_off; to = dst + b.out_off; n = b.bsize; fill = false; }
+    else if (b.btype == BT_RLE) { from = src + b.src_off; to = dst + b.out_off; n = b.bsize; fill = true; }
+    else if (!b.err && b.lit_type <= LIT_RLE) {
+        from = src + b.src_off + b.lit_off; to = (b.nseq == 0 ? dst : lit_scratch) + b.out_off; n = b.lit_regen; fill = b.lit_type == LIT_RLE;
+    } else return;
+    u32 t = threadIdx.x;
+    if (fill) {
+        u64 v = 0x0101010101010101ull * from[0];
+        for (u32 k = t * 8; k + 8 <= n; k += 256 * 8) st64(to + k, v);
+        for (u32 k = (n & ~7u) + t; k < n; k += 256) to[k] = (u8)v;
+    } else {
+        for (u32 k = t * 8; k + 8 <= n; k += 256 * 8) st64(to + k, ld64(from + k));
+        for (u32 k = (n & ~7u) + t; k < n; k += 256) to[k] = from[k];
+    }
+}
+
+// ---- sequence execution (3.1.1.4): one wave per block with sequences ----------------------------------------
+__device__ __forceinline__ void wait_block_done(volatile u32 *done, u32 j)
+{
+    // lane 0 polls (relaxed, agent scope); one acquire afterwards drops stale L1 lines (guide G16)
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(&done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void k_exec_seq(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *offs, u32 nblk,
+                                                  const u32 *o_ll, const u32 *o_ml, const u32 *o_of,
+                                                  const u8 *lit_scratch, u8 *dst, u32 *done, ZStat *st)
+{
+    __shared__ u32 sh_ticket;
+    int lane = threadIdx.x;
+    if (lane == 0) sh_ticket = atomicAdd(&st->ticket, 1u);
+    __syncthreads();
+    u32 t = sh_ticket;
+    if (t >= n_seq_blk) return;
+    u32 bi = seq_list[t];
+    const ZBlock &b = blk[bi];
+    u64 out_off = b.out_off;
+    u8 *out = dst + out_off;
+    const u8 *lits = lit_scratch + out_off;
+    u32 rep_in[3] = { b.rep_in[0], b.rep_in[1], b.rep_in[2] };
+    u64 sbase = b.seq_base;
+    u32 op = 0, lp = 0, nseq = b.err ? 0 : b.nseq;
+    u32 lo_idx = bi;                       // blocks [lo_idx, bi) are known complete
+    u32 fenced = 0;                        // bytes of this block's output known visible to the whole wave
+    bool bad = false;
+    for (u32 s = 0; s < nseq; s++) {
+        u32 ll = o_ll[sbase + s], ml = o_ml[sbase + s];
+        u32 off = sym_resolve(o_of[sbase + s], rep_in);
+        for (u32 k = lane; k < ll; k += 64) out[op + k] = lits[lp + k];
+        op += ll; lp += ll;
+        u64 pos_abs = out_off + op;
+        if (off > pos_abs) { bad = true; break; }                     // reaches before the frame start
+        u64 src_abs = pos_abs - off;
+        if (src_abs < out_off) {
+            // source (partly) in earlier blocks: confirm every block from the one holding src_abs up to lo_idx
+            u32 lo = 0, hi = lo_idx;                                 // largest j with offs[j] <= src_abs
+            while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (offs[mid] <= src_abs) lo = mid; else hi = mid; }
+            for (u32 j = lo_idx; j-- > lo;) wait_block_done(done, j);
+            if (lo < lo_idx) lo_idx = lo;
+        }
+        u64 src_end = src_abs + (off < ml ? off : ml);
+        if (src_end > out_off + fenced && src_end > out_off) {      // depends on bytes this wave wrote since the last fence
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __syncthreads();
+            fenced = op;
+        }
+        const u8 *from = dst + src_abs;
+        if (off >= ml) { for (u32 k = lane; k < ml; k += 64) out[op + k] = from[k]; }
+        else           { for (u32 k = lane; k < ml; k += 64) out[op + k] = from[k % off]; }
+        op += ml;
+    }
+    if (!bad && !b.err) {
+        u32 rest = b.lit_regen - lp;
+        for (u32 k = lane; k < rest; k += 64) out[op + k] = lits[lp + k];
+        op += rest;
+        if (op != b.regen) bad = true;
+    }
+    if (bad && lane == 0) set_err(st, ZE_CORRUPT);
+    // publish: every lane's stores drained, then agent-scope release, then the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&done[bi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- host orchestration ------------------------------------------------------------------------------------------
+int zstd_init_tables(naf_gpu_ctx *c)
+{
+    static const i16 LL[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1 };
+    static const i16 OF[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
+    static const i16 ML[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 };
+    FseE tabs[64 + 32 + 64]; u16 next[64];
+    if (!fse_build_table(tabs, LL, 36, 6, next) || !fse_build_table(tabs + 64, OF, 29, 5, next) || !fse_build_table(tabs + 96, ML, 53, 6, next))
+        return ctx_fail(c, NAF_GPU_EZSTD, "predefined FSE tables");
+    HIP_TRY(c, hipMalloc(&c->d_predef, sizeof tabs));
+    HIP_TRY(c, hipMemcpy(c->d_predef, tabs, sizeof tabs, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int zerr(naf_gpu_ctx *c, u32 e, const char *where)
+{
+    const char *m = e == ZE_TRUNC ? "truncated" : e == ZE_CORRUPT ? "corrupt" : e == ZE_UNSUP ? "unsupported feature" : "table pool";
+    return ctx_fail(c, NAF_GPU_EZSTD, "zstd frame %s (%s)", m, where);
+}
+
+// Decode ONE frame whose header (after the magic) starts at d_src[0].  *consumed = bytes of the frame.
+static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *d_dst, size_t dst_cap,
+                           size_t *out_len, size_t *consumed)
+{
+    u8 hb[18]; size_t hl = src_len < 18 ? src_len : 18;
+    int rc = ctx_readback(c, hb, d_src, hl); if (rc) return rc;
+    ZFrameHdr fh = zstd_parse_frame_header(hb, hl);
+    if (fh.err) return zerr(c, (u32)fh.err, "frame header");
+
+    ZStat *st = arena_new<ZStat>(c, 1);
+    if (!st) return NAF_GPU_ENOMEM;
+    HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(ZStat), c->stream));
+    // ---- block index
+    u32 cap = (u32)(src_len / 2048 + 1024);
+    ZBlock *blk = nullptr; ZStat hs;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        blk = arena_new<ZBlock>(c, cap);
+        if (!blk) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zstd_scan_blocks", k_scan_blocks, 1, 64, 0, d_src, (u64)src_len, (u64)fh.hdr_size, blk, cap, st);
+        rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+        if (hs.err) return zerr(c, hs.err, "block headers");
+        if (hs.nblk <= cap) break;
+        cap = hs.nblk;
+    }
+    u32 nblk = hs.nblk;
+    size_t frame_end = hs.end_off + (fh.checksum ? 4 : 0);
+    if (frame_end > src_len) return zerr(c, ZE_TRUNC, "checksum");
+    *consumed = frame_end;
+
+    // ---- parse + ownership
+    i32 *own = arena_new<i32>(c, (size_t)nblk * 4);
+    u64 *seq_cnt = arena_new<u64>(c, (size_t)nblk + 1), *sizes = arena_new<u64>(c, (size_t)nblk + 1);
+    if (!own || !seq_cnt || !sizes) return NAF_GPU_ENOMEM;
+    i32 *own_huf = own, *own_ll = own + nblk, *own_of = own + 2 * (size_t)nblk, *own_ml = own + 3 * (size_t)nblk;
+    u32 g = cdiv(nblk, 64);
+    LAUNCH(c, "zstd_parse_blocks", k_parse_blocks, g, 64, 0, d_src, blk, nblk, own_huf, own_ll, own_of, own_ml, seq_cnt, st);
+    rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+    if (hs.err) return zerr(c, hs.err, "block parse");
+    u32 n_seq_blk = hs.n_seq_blk, n_huf_def = hs.n_huf_def;
+    if ((rc = scan_inclusive_max_i32(c, own_huf, nblk))) return rc;
+    u64 *d_total_seq = (u64 *)((u8 *)st + offsetof(ZStat, total_seq));
+    u64 *d_total_out = (u64 *)((u8 *)st + offsetof(ZStat, total_out));
+    u8 *huf_pool = nullptr; FseE *fse_pool = nullptr; u32 *o_ll = nullptr, *o_ml = nullptr, *o_of = nullptr;
+    if (n_huf_def) {
+        u32 pool_cap = n_huf_def * 4096u;                            // 2^11 entries * 2 B worst case per table
+        huf_pool = (u8 *)arena_alloc(c, pool_cap);
+        if (!huf_pool) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st);
+    }
+    if (n_seq_blk) {
+        if ((rc = scan_inclusive_max_i32(c, own_ll, nblk))) return rc;
+        if ((rc = scan_inclusive_max_i32(c, own_of, nblk))) return rc;
+        if ((rc = scan_inclusive_max_i32(c, own_ml, nblk))) return rc;
+        if ((rc = scan_exclusive_u64(c, seq_cnt, nblk, d_total_seq))) return rc;
+        u32 fse_cap = n_seq_blk * (512 + 256 + 512);
+        fse_pool = arena_new<FseE>(c, fse_cap);
+        if (!fse_pool) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zstd_build_fse", k_build_fse, g, 64, 0, d_src, blk, nblk, fse_pool, fse_cap, st);
+        rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+        if (hs.err) return zerr(c, hs.err, "table build");
+        size_t ns = hs.total_seq ? hs.total_seq : 1;
+        o_ll = arena_new<u32>(c, ns); o_ml = arena_new<u32>(c, ns); o_of = arena_new<u32>(c, ns);
+        if (!o_ll || !o_ml || !o_of) return NAF_GPU_ENOMEM;
+    }
+    LAUNCH(c, "zstd_decode_seq", k_decode_seq, g, 64, 0, d_src, blk, nblk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
+           (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st);
+    if (n_seq_blk) LAUNCH(c, "zstd_rep_chain", k_rep_chain, 1, 64, 0, blk, nblk);
+    if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
+    rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+    if (hs.err) return zerr(c, hs.err, "sequences");
+    *out_len = hs.total_out;
+    if (fh.has_fcs && fh.content_size != hs.total_out) return zerr(c, ZE_CORRUPT, "content size mismatch");
+    if (hs.total_out > dst_cap) return ctx_fail(c, NAF_GPU_ECAP, "zstd output needs %llu bytes, capacity %zu", (unsigned long long)hs.total_out, dst_cap);
+
+    u32 *done = nullptr, *seq_list = nullptr; u8 *lit_scratch = nullptr;
+    if (n_seq_blk) {
+        done = arena_new<u32>(c, nblk); seq_list = arena_new<u32>(c, n_seq_blk);
+        lit_scratch = (u8 *)arena_alloc(c, hs.total_out + 16);
+        u64 *flag = arena_new<u64>(c, (size_t)nblk + 1);
+        if (!done || !seq_list || !lit_scratch || !flag) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zstd_seq_flag", k_seq_flag, g, 64, 0, (const ZBlock *)blk, nblk, flag);
+        if ((rc = scan_exclusive_u64(c, flag, nblk, (u64 *)nullptr))) return rc;
+        LAUNCH(c, "zstd_seq_list", k_seq_list, g, 64, 0, (const ZBlock *)blk, nblk, (const u64 *)flag, seq_list);
+    }
+    LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, done, (u32 *)nullptr, (u32 *)nullptr);
+    if (n_huf_def) {
+        u32 slot = 2u << hs.max_huf_log; if (slot < 16) slot = 16;
+        LAUNCH(c, "zstd_huf_literals", k_huf_literals, cdiv(nblk, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG,
+               d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st);
+    }
+    LAUNCH(c, "zstd_copy_fill", k_copy_fill, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, d_dst, lit_scratch);
+    if (n_seq_blk)
+        LAUNCH(c, "zstd_exec_seq", k_exec_seq, n_seq_blk, 64, 0, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
+               (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st);
+    rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+    if (hs.err) return zerr(c, hs.err, "block decode");
+    return 0;
+}
+
+int zstd_decode(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len)
+{
+    size_t pos = 0, out = 0; bool first = true;
+    *out_len = 0;
+    while (pos < src_len || first) {
+        if (!(first && !has_magic)) {
+            u8 m[8]; size_t ml = src_len - pos < 8 ? src_len - pos : 8;
+            if (ml < 4) return zerr(c, ZE_TRUNC, "magic");
+            int rc = ctx_readback(c, m, d_src + pos, ml); if (rc) return rc;
+            u32 magic = ld32(m);
+            if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {              // skippable frame (3.1.2)
+                if (ml < 8) return zerr(c, ZE_TRUNC, "skippable frame");
+                size_t sz = ld32(m + 4);
+                if (pos + 8 + sz > src_len) return zerr(c, ZE_TRUNC, "skippable frame");
+                pos += 8 + sz; first = false; continue;
+            }
+            if (magic != 0xFD2FB528u) return zerr(c, ZE_CORRUPT, "bad magic");
+            pos += 4;
+        }
+        first = false;
+        size_t n = 0, used = 0;
+        int rc = zstd_decode_one(c, d_src + pos, src_len - pos, d_dst + out, dst_cap > out ? dst_cap - out : 0, &n, &used);
+        if (rc == NAF_GPU_ECAP) { *out_len = out + n; return rc; }
+        if (rc) return rc;
+        out += n; pos += used;
+    }
+    *out_len = out;
+    return 0;
+}
+
+extern "C" int naf_gpu_zstd_decompress(naf_gpu_ctx *c, const void *d_src, size_t src_len, int has_magic,
+                                       void *d_dst, size_t dst_cap, size_t *out_len)
+{
+    if (!c || !d_src || !out_len) return NAF_GPU_EARG;
+    arena_reset(c);
+    return zstd_decode(c, (const u8 *)d_src, src_len, has_magic, (u8 *)d_dst, dst_cap, out_len);
+}

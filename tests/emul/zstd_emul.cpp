@@ -1,0 +1,147 @@
+// zstd_emul.cpp -- DEVELOPMENT/TEST HARNESS, not product code.
+// Compiles the per-lane kernel logic of naf_amd/csrc/zstd_dec_core.h for the host and single-steps it
+// in the same phase order as the HIP kernels (scan -> parse -> ownership -> tables -> sequences ->
+// rep chain -> offsets -> literals -> execute), so kernel logic can be checked on a machine without a
+// GPU.  Nothing in libnaf_gpu.so links this file; the GPU tests exercise the real kernels.
+#include "../../naf_amd/csrc/zstd_dec_core.h"
+#include <vector>
+#include <stdlib.h>
+
+extern "C" long long emul_zstd_decompress_frame(const u8 *src, size_t len, u8 *dst, size_t cap)
+{
+    if (len < 5 || ld32(src) != 0xFD2FB528u) return -1;
+    src += 4; len -= 4;
+    ZFrameHdr fh = zstd_parse_frame_header(src, len);
+    if (fh.err) return -10 - fh.err;
+    // k_scan_blocks
+    std::vector<ZBlock> blk;
+    u64 pos = fh.hdr_size;
+    for (;;) {
+        if (pos + 3 > len) return -2;
+        u32 h = ld24(src + pos), last = h & 1, type = (h >> 1) & 3, size = h >> 3;
+        if (type == 3 || size > ZBLOCK_MAX) return -3;
+        u32 csize = type == BT_RLE ? 1 : size;
+        if (pos + 3 + csize > len) return -2;
+        ZBlock b; memset(&b, 0, sizeof b);
+        b.src_off = pos + 3; b.bsize = size; b.btype = (u8)type; b.last = (u8)last;
+        blk.push_back(b); pos += 3 + csize;
+        if (last) break;
+    }
+    u32 n = (u32)blk.size();
+    // k_parse_blocks + ownership (inclusive max-scan)
+    std::vector<i32> own[4];
+    for (auto &o : own) o.assign(n, -1);
+    for (u32 i = 0; i < n; i++) {
+        zstd_parse_block(src + blk[i].src_off, blk[i]);
+        if (blk[i].err) return -100 - blk[i].err;
+        bool comp = blk[i].btype == BT_COMP, sq = comp && blk[i].nseq > 0;
+        own[0][i] = comp && blk[i].lit_type == LIT_HUF ? (i32)i : -1;
+        for (int k = 0; k < 3; k++) own[1 + k][i] = sq && blk[i].modes[k] != SM_REPEAT ? (i32)i : -1;
+    }
+    for (auto &o : own) for (u32 i = 1; i < n; i++) if (o[i - 1] > o[i]) o[i] = o[i - 1];
+    // k_build_huf / k_build_fse
+    std::vector<std::vector<u16>> huf(n);
+    std::vector<std::vector<FseE>> fse[3]; for (auto &f : fse) f.resize(n);
+    FseE predef[160]; u16 nx[64];
+    static const i16 LL[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1 };
+    static const i16 OF[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
+    static const i16 ML[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 };
+    fse_build_table(predef, LL, 36, 6, nx); fse_build_table(predef + 64, OF, 29, 5, nx); fse_build_table(predef + 96, ML, 53, 6, nx);
+    const u32 max_log[3] = { 9, 8, 9 }, max_sym[3] = { 35, 31, 52 };
+    for (u32 i = 0; i < n; i++) {
+        ZBlock &b = blk[i]; const u8 *c = src + b.src_off;
+        if (b.btype != BT_COMP) continue;
+        if (b.lit_type == LIT_HUF) {
+            u8 w[256]; u32 nw = 0, used = 0;
+            u32 log = huf_read_weights(c + b.lit_off, b.lit_csize, w, &nw, &used);
+            if (!log) return -4;
+            huf[i].resize(1u << log); huf_build_table(huf[i].data(), w, nw, log); b.huf_log = (u8)log;
+            if (used != b.huf_streams_off - b.lit_off) return -5;
+        }
+        if (b.nseq) {
+            u32 p = b.seq_off;
+            for (int k = 0; k < 3; k++) {
+                if (b.modes[k] == SM_RLE) p++;
+                else if (b.modes[k] == SM_FSE) {
+                    i16 norm[64]; u32 nsym, log;
+                    u32 d = fse_read_ncount(c + p, b.bsize - p, max_log[k], max_sym[k], norm, &nsym, &log);
+                    if (!d || log != b.fse_log[k]) return -6;
+                    p += d; fse[k][i].resize(1u << log);
+                    if (!fse_build_table(fse[k][i].data(), norm, nsym, log, nx)) return -7;
+                }
+            }
+            if (p != b.seq_bits_off) return -8;
+        }
+    }
+    // k_decode_seq
+    std::vector<std::vector<u32>> sll(n), sml(n), sof(n);
+    for (u32 i = 0; i < n; i++) {
+        ZBlock &b = blk[i];
+        if (b.btype != BT_COMP || !b.nseq) continue;
+        SeqTab tab[3]; const u32 po[3] = { 0, 64, 96 }, pl[3] = { 6, 5, 6 };
+        for (int k = 0; k < 3; k++) {
+            i32 ob = own[1 + k][i]; if (ob < 0) return -9;
+            u32 m = blk[ob].modes[k];
+            tab[k].rle = m == SM_RLE; tab[k].rle_sym = blk[ob].fse_tab[k];
+            if (m == SM_PREDEF) { tab[k].t = predef + po[k]; tab[k].log = pl[k]; }
+            else if (m == SM_FSE) { tab[k].t = fse[k][ob].data(); tab[k].log = blk[ob].fse_log[k]; }
+            else { tab[k].t = predef; tab[k].log = 0; }
+        }
+        sll[i].resize(b.nseq); sml[i].resize(b.nseq); sof[i].resize(b.nseq);
+        u64 tl = 0, tm = 0; u32 ro[3];
+        u8 e = zstd_decode_sequences(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tab, sll[i].data(), sml[i].data(), sof[i].data(), ro, &tl, &tm);
+        if (e) return -200 - e;
+        if (tl > b.lit_regen) return -11;
+        b.rep_out[0] = ro[0]; b.rep_out[1] = ro[1]; b.rep_out[2] = ro[2];
+        b.regen = (u32)(b.lit_regen + tm);
+    }
+    // k_rep_chain + offsets
+    u32 rep[3] = { 1, 4, 8 }; u64 off = 0;
+    for (u32 i = 0; i < n; i++) {
+        ZBlock &b = blk[i];
+        b.out_off = off; off += b.regen;
+        if (b.btype == BT_COMP && b.nseq) {
+            b.rep_in[0] = rep[0]; b.rep_in[1] = rep[1]; b.rep_in[2] = rep[2];
+            u32 r0 = sym_resolve(b.rep_out[0], rep), r1 = sym_resolve(b.rep_out[1], rep), r2 = sym_resolve(b.rep_out[2], rep);
+            rep[0] = r0; rep[1] = r1; rep[2] = r2;
+        }
+    }
+    if (off > cap) return -12;
+    if (fh.has_fcs && fh.content_size != off) return -13;
+    // literals + execution
+    std::vector<u8> lit(ZBLOCK_MAX + 64);
+    for (u32 i = 0; i < n; i++) {
+        ZBlock &b = blk[i]; const u8 *c = src + b.src_off; u8 *out = dst + b.out_off;
+        if (b.btype == BT_RAW) { memcpy(out, c, b.bsize); continue; }
+        if (b.btype == BT_RLE) { memset(out, c[0], b.bsize); continue; }
+        u8 *lp = b.nseq ? lit.data() : out;
+        if (b.lit_type == LIT_RAW) memcpy(lp, c + b.lit_off, b.lit_regen);
+        else if (b.lit_type == LIT_RLE) memset(lp, c[b.lit_off], b.lit_regen);
+        else {
+            i32 ob = own[0][i]; if (ob < 0) return -14;
+            const u16 *tab = huf[ob].data(); u32 log = blk[ob].huf_log;
+            const u8 *s = c + b.huf_streams_off;
+            if (b.nstreams == 1) { if (huf_decode_stream(s, b.huf_streams_size, tab, log, lp, b.lit_regen)) return -15; }
+            else {
+                u32 s1 = ld16(s), s2 = ld16(s + 2), s3 = ld16(s + 4), tot = b.huf_streams_size - 6, per = (b.lit_regen + 3) / 4;
+                if (s1 + s2 + s3 >= tot) return -16;
+                u32 offs[4] = { 0, s1, s1 + s2, s1 + s2 + s3 }, szs[4] = { s1, s2, s3, tot - s1 - s2 - s3 };
+                for (u32 k = 0; k < 4; k++)
+                    if (huf_decode_stream(s + 6 + offs[k], szs[k], tab, log, lp + k * per, k < 3 ? per : b.lit_regen - 3 * per)) return -17;
+            }
+        }
+        if (!b.nseq) continue;
+        u32 op = 0, l = 0;
+        for (u32 q = 0; q < b.nseq; q++) {
+            u32 ll = sll[i][q], ml = sml[i][q], of = sym_resolve(sof[i][q], b.rep_in);
+            memcpy(out + op, lit.data() + l, ll); op += ll; l += ll;
+            if (of > b.out_off + op) return -18;
+            const u8 *from = out + op - of;
+            for (u32 k = 0; k < ml; k++) out[op + k] = from[of >= ml ? k : k % of];
+            op += ml;
+        }
+        memcpy(out + op, lit.data() + l, b.lit_regen - l); op += b.lit_regen - l;
+        if (op != b.regen) return -19;
+    }
+    return (long long)off;
+}

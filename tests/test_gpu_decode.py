@@ -1,0 +1,130 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against
+the oracle and the golden vectors made by the real reference.  Nothing here reads /root/reference."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_bytes, naf_cases, zstd_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from naf_amd import capi
+    ctx = capi.Context(0)
+    yield ctx
+    ctx.close()
+
+
+def host(t):
+    return t.cpu().numpy().tobytes()
+
+
+@pytest.mark.parametrize("case", zstd_cases(), ids=lambda c: c["name"])
+def test_zstd_decode_golden_frames(gpu, case):
+    frame = golden_bytes("zstd", case["name"] + ".zst")
+    out = gpu.zstd_decompress(gpu.to_device(frame), case["len"] + 64)
+    got = host(out)
+    assert len(got) == case["len"] and sha(got) == case["sha256"]
+
+
+def test_zstd_decode_matches_oracle_on_naf_sections(gpu, oracle):
+    for case in naf_cases():
+        naf = golden_bytes("naf", case["name"] + ".naf")
+        h = oracle.parse_naf(naf)
+        for i in range(6):
+            if h.payload_off[i] is None:
+                continue
+            ref = oracle.zstd_decompress(h.frame(naf, i))
+            sec = naf[h.payload_off[i]: h.payload_off[i] + h.comp[i]]
+            out = gpu.zstd_decompress(gpu.to_device(sec), len(ref) + 64, has_magic=False)
+            assert host(out) == ref, (case["name"], i)
+
+
+def test_zstd_rejects_corrupt_frames(gpu):
+    from naf_amd.capi import NafGpuError
+    frame = bytearray(golden_bytes("zstd", "ids_l3.zst"))
+    with pytest.raises(NafGpuError):
+        gpu.zstd_decompress(gpu.to_device(bytes(frame[: len(frame) // 2])), 1 << 20)
+    frame[3] ^= 0xFF
+    with pytest.raises(NafGpuError):
+        gpu.zstd_decompress(gpu.to_device(bytes(frame)), 1 << 20)
+
+
+MODES = {"fasta": (0, True, -1), "seq": (2, True, -1), "sequences": (3, True, -1), "4bit": (4, True, -1),
+         "fasta_nomask": (0, False, -1), "fasta_ll13": (0, True, 13), "fasta_ll0": (0, True, 0), "fastq": (1, True, -1)}
+
+
+@pytest.mark.parametrize("force_slow", ["0", "1"])
+@pytest.mark.parametrize("case", naf_cases(), ids=lambda c: c["name"])
+def test_unnaf_matches_reference_outputs(gpu, case, force_slow, monkeypatch):
+    """Bit-exact against the outputs of the real reference unnaf on reference-made archives."""
+    monkeypatch.setenv("NAF_GPU_FORCE_SLOW", force_slow)
+    naf = golden_bytes("naf", case["name"] + ".naf")
+    d = gpu.to_device(naf)
+    for m, (mode, use_mask, ll) in MODES.items():
+        if m not in case["outputs"]:
+            continue
+        exp = case["outputs"][m]
+        assert gpu.unnaf_size(d, mode, use_mask, ll) == exp["len"], m
+        got = host(gpu.unnaf(d, mode, use_mask, ll))
+        assert len(got) == exp["len"], m
+        assert sha(got) == exp["sha256"], m
+
+
+def test_unnaf_reference_suite(gpu, oracle):
+    """The reference's own tests: oracle-made archive -> GPU unnaf == *.out-ref."""
+    from conftest import ref_cases
+    for case in ref_cases():
+        ea, ua = case["ennaf_args"], case["unnaf_args"]
+        if "--charcount" in ua:
+            continue
+        st = oracle.RNA if "--rna" in ea else oracle.PROTEIN if "--protein" in ea else oracle.TEXT if "--text" in ea else oracle.DNA
+        text = golden_bytes("ref_tests", case["set"], case["input"])
+        naf = oracle.ennaf(text, st, "--no-mask" in ea)
+        mode = 2 if "--seq" in ua else 3 if "--sequences" in ua else -1
+        exp = golden_bytes("ref_tests", case["set"], case["name"] + ".out-ref")
+        got = host(gpu.unnaf(gpu.to_device(naf), mode, "--no-mask" not in ua)) if len(naf) else b""
+        assert got == exp, case["name"]
+
+
+def test_unnaf_range_sharding_is_consistent(gpu):
+    """Per-GPU byte ranges (multi-GPU sharding) concatenate to the whole text."""
+    naf = golden_bytes("naf", "mixed_60.naf")
+    d = gpu.to_device(naf)
+    whole = host(gpu.unnaf(d, 0))
+    n = len(whole)
+    cuts = [0, 1, 17, n // 3, n // 3 + 5, 2 * n // 3, n - 1, n]
+    parts = [host(gpu.unnaf_range(d, a, b, 0)) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert b"".join(parts) == whole
+
+
+def test_unnaf_random_archives_against_oracle(gpu, oracle):
+    """Seeded random FASTA/FASTQ -> oracle archive (raw zstd blocks) -> GPU == oracle, all modes."""
+    from naf_amd import synth
+    rng = np.random.default_rng(123)
+    for i in range(12):
+        if i % 3 == 2:
+            text = synth.fastq_reads(int(rng.integers(1, 400)), int(rng.integers(1, 200)), seed=i, var_len=True)
+        else:
+            text = synth.fasta_mixed(int(rng.integers(1, 30)), int(rng.integers(1, 2000)), int(rng.choice([0, 1, 5, 16, 17, 60, 80])), seed=i,
+                                     empty_every=int(rng.integers(2, 6)))
+        naf = oracle.ennaf(text)
+        d = gpu.to_device(naf)
+        for mode in (-1, 0, 2, 3, 4):
+            for use_mask in (True, False):
+                for ll in (-1, 0, 1, 15, 16, 33):
+                    if ll != -1 and mode not in (0,):
+                        continue
+                    exp = oracle.unnaf(naf, mode, use_mask=use_mask, line_length=ll)
+                    got = host(gpu.unnaf(d, mode, use_mask, ll))
+                    assert got == exp, (i, mode, use_mask, ll)
