@@ -57,8 +57,11 @@ static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 int scan_exclusive_u64(naf_gpu_ctx *c, u64 *d_vals, size_t n, u64 *d_total);
 // Inclusive running maximum of i32 values in place (table-ownership propagation).
 int scan_inclusive_max_i32(naf_gpu_ctx *c, i32 *d_vals, size_t n);
+int scan_inclusive_max_i64(naf_gpu_ctx *c, i64 *d_vals, size_t n);
 
 // ---- zstd (zstd_dec.hip) -----------------------------------------------------------------------------
 // Decode frames at d_src (device).  If only_size, stops after sizes are known.
 int zstd_decode(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len);
 int zstd_init_tables(naf_gpu_ctx *c);
+// One frame of independently coded blocks; with_magic=0 omits the 4 magic bytes (as stored in a .naf section).
+int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic);

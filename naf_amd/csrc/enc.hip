@@ -1,0 +1,541 @@
+// enc.hip -- ennaf on gfx950: FASTA stream split, soft-mask run-length scan, 4-bit packing and the
+// container writer.  Replaces (reference, ennaf/src): confirm_input_format process.c:547-583,
+// process_non_well_formed_fasta process.c:358-427 (+ in_get_until :258, str_append_char :301),
+// name/comm/seq writers process.c:12-57, add_length encoders.c:72-95, extract_mask/add_mask
+// encoders.c:98-146, encode_dna encoders.c:30-69 (+ nuc_code tables.c:189-197), header/section writer
+// ennaf.c:538-589, write_variable_length_encoded_number encoders.c:175-190.
+//
+// The reference is a byte-at-a-time state machine.  Here the state of any byte is recovered from two
+// running maxima -- position of the last EOL-class byte and of the last space-class byte before it --
+// because a FASTA line is a header iff it starts with '>' and the ID/comment split is the first
+// space-class byte of the header line.  Tiles of 4 KiB (256 lanes x 16 B) are classified independently
+// once those maxima are scanned across tiles; stream offsets come from prefix sums of per-tile counts.
+#include "ctx.h"
+#include "wgscan.h"
+
+#define ET_BYTES 16
+#define ET_TILE (256 * ET_BYTES)
+
+struct OpMaxI64 { template <typename T> __device__ static T id() { return (T)(-1); } template <typename T> __device__ static T f(T a, T b) { return (i64)a > (i64)b ? a : b; } };
+struct OpMaxU64 { template <typename T> __device__ static T id() { return (T)0; } template <typename T> __device__ static T f(T a, T b) { return a > b ? a : b; } };
+
+struct EncP {
+    const u8 *text; u64 n, p0;
+    u32 expected[8];             // bitmap of bytes accepted in sequence lines (tables.c:72-123)
+    u8 replacement;              // 'N' / 'X' / '?'  (ennaf.c:447-470)
+    u8 id_gt_unexpected;         // text+FASTA: '>' also ends ID scanning (ennaf.c:478 flips the shared table)
+    u8 strict, pad;
+};
+
+__device__ __forceinline__ bool c_eol(u32 c) { return c >= 0x0A && c <= 0x0D; }
+__device__ __forceinline__ bool c_space(u32 c) { return (c >= 0x09 && c <= 0x0D) || c == 0x20; }
+__device__ __forceinline__ bool c_unexp_text(u32 c) { return c <= 0x20 || c == 0x7F || c == 0xFF; }
+__device__ __forceinline__ bool c_unexp_comment(u32 c) { return c < 0x20 || c == 0x7F || c == 0xFF; }
+__device__ __forceinline__ bool c_expected(const EncP &P, u32 c) { return (P.expected[c >> 5] >> (c & 31)) & 1; }
+
+// ---- K1: per-tile last EOL / last space position -------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_enc_last(EncP P, i64 *tile_eol, i64 *tile_sp)
+{
+    __shared__ u64 lds[4];
+    u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
+    i64 le = -1, ls = -1;
+    if (base < P.n) {
+        u32 cnt = P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES;
+        for (u32 i = 0; i < cnt; i++) { u32 c = P.text[base + i]; if (c_space(c)) { ls = (i64)(base + i); if (c_eol(c)) le = ls; } }
+    }
+    u64 t;
+    wg_scan_inclusive<u64, OpMaxI64>((u64)le, &t, lds); i64 te = (i64)t;
+    wg_scan_inclusive<u64, OpMaxI64>((u64)ls, &t, lds); i64 ts = (i64)t;
+    if (threadIdx.x == 0) { tile_eol[blockIdx.x] = te; tile_sp[blockIdx.x] = ts; }
+}
+
+// ---- classification of 16 bytes given the running maxima at the first byte ---------------------------------------
+enum { EV_SEQ = 0, EV_IDS = 1, EV_CMT = 2 };
+struct TileCtx { i64 last_eol, last_sp; bool hdr; };
+
+// Sink interface: emit(stream, ch); header_start(pos); header_end(pos); line_end(pos) for sequence lines;
+// unexpected(kind, ch) with kind 0 id, 1 comment, 2 sequence.
+template <typename Sink>
+__device__ __forceinline__ void classify_range(const EncP &P, u64 pos, u32 cnt, bool with_eof, TileCtx ctx, Sink &S)
+{
+    i64 le = ctx.last_eol, ls = ctx.last_sp; bool hdr = ctx.hdr;
+    for (u32 k = 0; k < cnt + (with_eof ? 1u : 0u); k++) {
+        u64 i = pos + k;
+        bool eof = k >= cnt;
+        u32 c = eof ? 0x0A : P.text[i];                       // end of input acts as one final line end
+        if (i >= P.p0) {                                       // leading space-class bytes are skipped (process.c:551-553)
+            i64 line_start = le + 1;
+            if (hdr) {
+                if ((i64)i == line_start) { S.header_start(i); }
+                else if (ls < line_start) {                    // still inside the ID (process.c:363-368)
+                    if (c_space(c)) { S.emit(EV_IDS, 0); if (c_eol(c)) { S.emit(EV_CMT, 0); S.header_end(i); } }
+                    else if (c_unexp_text(c) || (P.id_gt_unexpected && c == '>')) { S.unexpected(0, c); S.emit(EV_SEQ, '?'); }
+                    else S.emit(EV_IDS, c);
+                } else {                                       // comment (process.c:370-377)
+                    if (c_eol(c)) { S.emit(EV_CMT, 0); S.header_end(i); }
+                    else if (c_unexp_comment(c)) { S.unexpected(1, c); S.emit(EV_CMT, '?'); }
+                    else S.emit(EV_CMT, c);
+                }
+            } else {                                           // sequence line (process.c:387-412)
+                if (c_eol(c)) S.line_end(i);
+                else if (c_space(c)) {}
+                else if (c_expected(P, c)) S.emit(EV_SEQ, c);
+                else { S.unexpected(2, c); S.emit(EV_SEQ, P.replacement); }
+            }
+        }
+        if (eof) break;
+        if (c_space(c)) {
+            ls = (i64)i;
+            if (c_eol(c)) { le = (i64)i; hdr = (i + 1 < P.n) && P.text[i + 1] == '>'; }
+        }
+    }
+}
+
+// Running maxima and header flag at the first byte of this thread's 16-byte piece.
+__device__ __forceinline__ TileCtx thread_ctx(const EncP &P, const i64 *tile_eol, const i64 *tile_sp, u64 base, u64 *lds)
+{
+    i64 le = -1, ls = -1;
+    if (base < P.n) {
+        u32 cnt = P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES;
+        for (u32 i = 0; i < cnt; i++) { u32 c = P.text[base + i]; if (c_space(c)) { ls = (i64)(base + i); if (c_eol(c)) le = ls; } }
+    }
+    u64 t;
+    i64 ie = (i64)wg_scan_inclusive<u64, OpMaxI64>((u64)le, &t, lds);
+    i64 is = (i64)wg_scan_inclusive<u64, OpMaxI64>((u64)ls, &t, lds);
+    // exclusive = inclusive of the previous thread
+    i64 pe = (i64)shfl_up_t((u64)ie, 1), ps = (i64)shfl_up_t((u64)is, 1);
+    __shared__ u64 wl[8];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) { wl[wave] = (u64)ie; wl[4 + wave] = (u64)is; }
+    __syncthreads();
+    if (lane == 0) { pe = wave ? (i64)wl[wave - 1] : -1; ps = wave ? (i64)wl[4 + wave - 1] : -1; }
+    __syncthreads();
+    i64 ce = blockIdx.x ? tile_eol[blockIdx.x - 1] : -1, cs = blockIdx.x ? tile_sp[blockIdx.x - 1] : -1;
+    TileCtx c;
+    c.last_eol = pe > ce ? pe : ce; c.last_sp = ps > cs ? ps : cs;
+    i64 ls0 = c.last_eol + 1;
+    c.hdr = (u64)ls0 < P.n && P.text[ls0] == '>';
+    return c;
+}
+
+struct CountSink {
+    u32 nseq = 0, nids = 0, ncmt = 0, nrec = 0, tail = 0;      // tail = sequence bytes since the last EOL seen
+    bool saw_eol = false;
+    __device__ void emit(int s, u32) { if (s == EV_SEQ) { nseq++; tail++; } else if (s == EV_IDS) nids++; else ncmt++; }
+    __device__ void header_start(u64) { nrec++; }
+    __device__ void header_end(u64) { tail = 0; saw_eol = true; }
+    __device__ void line_end(u64) { tail = 0; saw_eol = true; }
+    __device__ void unexpected(int, u32) {}
+};
+
+// ---- K2: per-tile stream byte counts -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, const i64 *tile_sp,
+                                                    u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail)
+{
+    __shared__ u64 lds[4];
+    u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds);
+    CountSink S;
+    if (base <= P.n) {
+        // the virtual end-of-input byte belongs to the thread whose piece contains position n
+        u32 cnt = base < P.n ? (P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES) : 0;
+        bool eof_here = (base + cnt == P.n) && cnt < ET_BYTES;
+        classify_range(P, base, cnt, eof_here, ctx, S);
+    }
+    u64 tot;
+    wg_scan_inclusive<u64, OpAdd>((u64)S.nseq, &tot, lds); if (threadIdx.x == 0) t_seq[blockIdx.x] = tot;
+    wg_scan_inclusive<u64, OpAdd>((u64)S.nids, &tot, lds); if (threadIdx.x == 0) t_ids[blockIdx.x] = tot;
+    wg_scan_inclusive<u64, OpAdd>((u64)S.ncmt, &tot, lds); if (threadIdx.x == 0) t_cmt[blockIdx.x] = tot;
+    wg_scan_inclusive<u64, OpAdd>((u64)S.nrec, &tot, lds); if (threadIdx.x == 0) t_rec[blockIdx.x] = tot;
+    // tail of the tile: sequence bytes after the last EOL inside the tile (whole tile if it has none)
+    // encoded per thread as (has_eol, tail); combine right-to-left: first thread from the end that saw an EOL stops the sum
+    u64 key = ((u64)(S.saw_eol ? threadIdx.x + 1 : 0) << 32);
+    u64 lastw; wg_scan_inclusive<u64, OpMaxU64>(key, &lastw, lds);
+    u32 last_thread_with_eol = (u32)(lastw >> 32);             // 0 = none, else index+1
+    u64 contrib = (threadIdx.x + 1 > last_thread_with_eol) ? S.nseq : (threadIdx.x + 1 == last_thread_with_eol ? S.tail : 0);
+    wg_scan_inclusive<u64, OpAdd>(contrib, &tot, lds);
+    if (threadIdx.x == 0) t_tail[blockIdx.x] = (u32)tot | (last_thread_with_eol ? 0x80000000u : 0);
+}
+
+// ---- K3: scatter --------------------------------------------------------------------------------------------------------
+struct EncOut {
+    u8 *seq, *ids, *cmt;          // seq = one byte per base (post-replacement), ids/comments final streams
+    u64 *rec_begin, *rec_end;     // base index where record r's bases start / end
+    u64 *unexpected;              // [3][257]
+    u64 *longest;                 // max line length
+    const u64 *t_seq, *t_ids, *t_cmt, *t_rec; const u32 *t_tail; const i64 *tile_eol;
+};
+
+struct WriteSink {
+    const EncOut &O; u64 bseq, bids, bcmt, rec; u64 line_b; u64 best; bool line_valid;
+    __device__ WriteSink(const EncOut &o) : O(o) {}
+    __device__ void emit(int s, u32 ch) { if (s == EV_SEQ) O.seq[bseq++] = (u8)ch; else if (s == EV_IDS) O.ids[bids++] = (u8)ch; else O.cmt[bcmt++] = (u8)ch; }
+    __device__ void header_start(u64) { if (rec > 0) O.rec_end[rec - 1] = bseq; rec++; }
+    __device__ void header_end(u64) { O.rec_begin[rec - 1] = bseq; line_b = bseq; }
+    __device__ void line_end(u64) { u64 len = bseq - line_b; if (len > best) best = len; line_b = bseq; }
+    __device__ void unexpected(int kind, u32 ch) { atomicAdd((unsigned long long *)&O.unexpected[kind * 257 + ch], 1ull); }
+};
+
+__global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, EncOut O)
+{
+    __shared__ u64 lds[4];
+    u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds);
+    u32 cnt = 0; bool eof_here = false, active = base <= P.n;
+    if (active) {
+        cnt = base < P.n ? (P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES) : 0;
+        eof_here = (base + cnt == P.n) && cnt < ET_BYTES;
+    }
+    CountSink C;
+    if (active) classify_range(P, base, cnt, eof_here, ctx, C);
+    u64 tot;
+    u64 iseq = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq, &tot, lds);
+    u64 iids = wg_scan_inclusive<u64, OpAdd>((u64)C.nids, &tot, lds);
+    u64 icmt = wg_scan_inclusive<u64, OpAdd>((u64)C.ncmt, &tot, lds);
+    u64 irec = wg_scan_inclusive<u64, OpAdd>((u64)C.nrec, &tot, lds);
+    WriteSink W(O);
+    W.bseq = O.t_seq[blockIdx.x] + iseq - C.nseq; W.bids = O.t_ids[blockIdx.x] + iids - C.nids;
+    W.bcmt = O.t_cmt[blockIdx.x] + icmt - C.ncmt; W.rec = O.t_rec[blockIdx.x] + irec - C.nrec;
+    // base count at the start of the line this thread begins in: B at the most recent EOL before `base`.
+    // Within the tile: B at an EOL is non-decreasing with position, so a running max over earlier threads works.
+    u64 my_last_eol_b = C.saw_eol ? (W.bseq + C.nseq - C.tail) : 0;
+    u64 incl = wg_scan_inclusive<u64, OpMaxU64>(C.saw_eol ? my_last_eol_b + 1 : 0, &tot, lds);   // +1 so that 0 means "none"
+    u64 prev = shfl_up_t(incl, 1);
+    __shared__ u64 wl[4];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) wl[wave] = incl;
+    __syncthreads();
+    if (lane == 0) prev = wave ? wl[wave - 1] : 0;
+    if (prev) W.line_b = prev - 1;
+    else {
+        // the line began in an earlier tile t' (the tile holding the last EOL): B = t_seq[t'+1] - tail(t')
+        i64 le = blockIdx.x ? tile_eol[blockIdx.x - 1] : -1;
+        if (le < 0 || (u64)(le + 1) <= P.p0) W.line_b = 0;
+        else { u64 tp = (u64)le / ET_TILE; W.line_b = O.t_seq[tp + 1] - (O.t_tail[tp] & 0x7FFFFFFFu); }
+    }
+    W.best = 0;
+    if (active) classify_range(P, base, cnt, eof_here, ctx, W);
+    u64 best; wg_scan_inclusive<u64, OpMaxU64>(W.best, &best, lds);
+    if (threadIdx.x == 0 && best) atomicMax((unsigned long long *)O.longest, (unsigned long long)best);
+}
+
+// ---- lengths: u32 units with 0xFFFFFFFF continuation (encoders.c:72-95) ----------------------------------------------------
+__global__ void k_len_unit_count(const u64 *rec_begin, const u64 *rec_end, u64 N, u64 total_bases, u64 *units)
+{
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    u64 end = r + 1 < N ? rec_end[r] : total_bases;
+    u64 len = end - rec_begin[r];
+    units[r] = len / 0xFFFFFFFFull + 1;
+}
+__global__ void k_len_unit_write(const u64 *rec_begin, const u64 *rec_end, u64 N, u64 total_bases, const u64 *unit_off, u32 *out)
+{
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    u64 end = r + 1 < N ? rec_end[r] : total_bases;
+    u64 len = end - rec_begin[r], o = unit_off[r];
+    while (len >= 0xFFFFFFFFull) { out[o++] = 0xFFFFFFFFu; len -= 0xFFFFFFFFull; }
+    out[o] = (u32)len;
+}
+
+// ---- soft mask: boundaries of (byte >= 96) runs -> u8 units with 255 continuation (encoders.c:98-146) -----------------------
+#define MB_TILE (256 * 16)
+__device__ __forceinline__ u32 mask_boundary_bits(const u8 *seq, u64 base, u64 T)
+{
+    // bit i set when base+i starts a new run, i.e. its case differs from the previous base (the virtual
+    // base -1 is "unmasked": a masked first base opens a zero-length unmasked run, encoders.c:132)
+    u32 m = 0;
+    bool prev = base ? seq[base - 1] >= 96 : false;
+    for (u32 i = 0; i < 16 && base + i < T; i++) { bool cur = seq[base + i] >= 96; if (cur != prev) m |= 1u << i; prev = cur; }
+    return m;
+}
+__global__ __launch_bounds__(256) void k_mask_bcount(const u8 *seq, u64 T, u64 *tile_cnt)
+{
+    __shared__ u64 lds[4];
+    u64 base = (u64)blockIdx.x * MB_TILE + (u64)threadIdx.x * 16;
+    u64 c = base < T ? __popc(mask_boundary_bits(seq, base, T)) : 0, tot;
+    wg_scan_inclusive<u64, OpAdd>(c, &tot, lds);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_mask_bscatter(const u8 *seq, u64 T, const u64 *tile_pre, u64 *bnd)
+{
+    __shared__ u64 lds[4];
+    u64 base = (u64)blockIdx.x * MB_TILE + (u64)threadIdx.x * 16;
+    u32 m = base < T ? mask_boundary_bits(seq, base, T) : 0;
+    u64 c = __popc(m), tot;
+    u64 incl = wg_scan_inclusive<u64, OpAdd>(c, &tot, lds);
+    u64 k = tile_pre[blockIdx.x] + incl - c;
+    while (m) { int b = __ffs(m) - 1; m &= m - 1; bnd[k++] = base + b; }
+}
+// run r (0-based) spans [start_r, start_{r+1}) with start_0 = 0, start_{r} = bnd[r-1], end of last = T
+__global__ void k_mask_run_units(const u64 *bnd, u64 nb, u64 T, u64 *units)
+{
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nb) return;
+    u64 s = r ? bnd[r - 1] : 0, e = r < nb ? bnd[r] : T;
+    units[r] = (e - s) / 255 + 1;
+}
+__global__ void k_mask_units_write(const u64 *bnd, u64 nb, u64 T, const u64 *unit_off, u64 total_units, u8 *out)
+{
+    u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= total_units) return;
+    // run = last r with unit_off[r] <= u
+    u64 lo = 0, hi = nb + 1;
+    while (lo + 1 < hi) { u64 mid = (lo + hi) >> 1; if (unit_off[mid] <= u) lo = mid; else hi = mid; }
+    u64 r = lo, s = r ? bnd[r - 1] : 0, e = r < nb ? bnd[r] : T, len = e - s;
+    u64 k = u - unit_off[r], full = len / 255;
+    out[u] = k < full ? 255 : (u8)(len % 255);
+}
+
+// ---- 4-bit pack (encoders.c:30-69, tables.c:189-197) ---------------------------------------------------------------------------
+__device__ __forceinline__ u32 nuc4(u32 c)
+{
+    // "-TGKCYSBAWRDMHVN" inverse; U == T; everything else 15
+    switch (c & ~0x20u) {
+    case 'A': return 8; case 'C': return 4; case 'G': return 2; case 'T': case 'U': return 1;
+    case 'N': return 15; case 'R': return 10; case 'Y': return 5; case 'S': return 6; case 'W': return 9;
+    case 'K': return 3; case 'M': return 12; case 'B': return 7; case 'D': return 11; case 'H': return 13; case 'V': return 14;
+    default: break;
+    }
+    if (c == '-') return 0;
+    return 15;
+}
+__global__ __launch_bounds__(256) void k_pack4(const u8 *seq, u64 T, u8 *packed)
+{
+    __shared__ u8 lut[256];
+    { u32 c = threadIdx.x; u32 v = nuc4(c); if (!((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '-')) v = 15; lut[c] = (u8)v; }
+    __syncthreads();
+    u64 i = ((u64)blockIdx.x * 256 + threadIdx.x) * 16;      // 16 bases -> 8 bytes
+    if (i >= T) return;
+    u64 out = 0;
+    if (i + 16 <= T) {
+        u64 a = ld64(seq + i), b = ld64(seq + i + 8);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 lo0 = lut[(a >> (16 * k)) & 0xFF], hi0 = lut[(a >> (16 * k + 8)) & 0xFF];
+            u32 lo1 = lut[(b >> (16 * k)) & 0xFF], hi1 = lut[(b >> (16 * k + 8)) & 0xFF];
+            out |= (u64)(lo0 | (hi0 << 4)) << (8 * k);
+            out |= (u64)(lo1 | (hi1 << 4)) << (8 * (k + 4));
+        }
+        st64(packed + i / 2, out);
+    } else {
+        for (u64 k = i; k < T; k += 2) {
+            u32 lo = lut[seq[k]], hi = k + 1 < T ? lut[seq[k + 1]] : 0;
+            packed[k / 2] = (u8)(lo | (hi << 4));
+        }
+    }
+}
+__global__ void k_toupper(u8 *p, u64 n)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { u32 c = p[i]; if (c >= 'a' && c <= 'z') p[i] = (u8)(c - 32); }
+}
+
+// ---- format sniffing (process.c:547-583) -----------------------------------------------------------------------------------------
+__global__ void k_sniff(const u8 *text, u64 n, u64 *out /* p0, first char, prev char */)
+{
+    int lane = threadIdx.x;
+    for (u64 base = 0; base < n; base += 64) {
+        u64 i = base + lane;
+        u32 c = i < n ? text[i] : 0x100;
+        bool nonspace = i < n && !c_space(c);
+        u64 m = __ballot(nonspace);
+        if (m) {
+            int first = __ffsll((long long)m) - 1;
+            if (lane == first) { out[0] = i; out[1] = c; out[2] = i ? text[i - 1] : '\n'; }
+            return;
+        }
+    }
+    if (lane == 0) { out[0] = n; out[1] = 0x100; out[2] = '\n'; }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------------------------
+static size_t vle(u64 v, u8 *out)                                 // encoders.c:175-190
+{
+    u8 tmp[10]; int n = 0;
+    tmp[n++] = (u8)(v & 127); v >>= 7;
+    while (v) { tmp[n++] = (u8)(128 | (v & 127)); v >>= 7; }
+    for (int i = 0; i < n; i++) out[i] = tmp[n - 1 - i];
+    return (size_t)n;
+}
+
+extern "C" size_t naf_gpu_ennaf_bound(size_t n) { return n + n / 1024 + (1 << 16); }
+
+static void set_expected(EncP &P, int seq_type, bool fasta)
+{
+    memset(P.expected, 0, sizeof P.expected);
+    auto set = [&](u32 c) { P.expected[c >> 5] |= 1u << (c & 31); };
+    if (seq_type == NAF_SEQ_DNA || seq_type == NAF_SEQ_RNA) {
+        const char *a = seq_type == NAF_SEQ_DNA ? "ABCDGHKMNRSTVWY" : "ABCDGHKMNRSUVWY";       // tables.c:72-90
+        for (const char *p = a; *p; p++) { set((u32)*p); set((u32)*p | 0x20); }
+        set('-'); P.replacement = 'N';
+    } else if (seq_type == NAF_SEQ_PROTEIN) {                                                     // tables.c:104-112
+        for (u32 c = 'A'; c <= 'Z'; c++) { set(c); set(c | 0x20); }
+        set('*'); set('-'); P.replacement = 'X';
+    } else {                                                                                      // tables.c:115-123
+        for (u32 c = 0x21; c <= 0xFE; c++) if (c != 0x7F) set(c);
+        P.replacement = '?';
+        P.id_gt_unexpected = fasta;
+        // mid-line '>' is kept as data in text mode (process.c:410); a '>' right after an EOL starts a record
+    }
+}
+
+struct SecOut { u64 orig, comp; };
+
+static int put_section(naf_gpu_ctx *c, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so)
+{
+    size_t bound = naf_gpu_zstd_compress_bound(stream_len);
+    u8 *tmp = (u8 *)arena_alloc(c, bound);
+    if (!tmp) return NAF_GPU_ENOMEM;
+    size_t clen = 0;
+    int rc = zstd_encode(c, d_stream, stream_len, level, tmp, bound, &clen, 0); if (rc) return rc;
+    u8 hdr[20]; size_t hl = vle(orig, hdr); hl += vle(clen, hdr + hl);
+    if (pos + hl + clen > cap) return ctx_fail(c, NAF_GPU_ECAP, "ennaf output capacity %zu too small", cap);
+    HIP_TRY(c, hipMemcpyAsync(d_naf + pos, hdr, hl, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));                 // hdr is a stack buffer
+    pos += hl;
+    HIP_TRY(c, hipMemcpyAsync(d_naf + pos, tmp, clen, hipMemcpyDeviceToDevice, c->stream));
+    pos += clen;
+    so.orig = orig; so.comp = clen;
+    return 0;
+}
+
+extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_gpu_ennaf_opts *o,
+                             void *d_naf_, size_t cap, size_t *naf_len, naf_gpu_ennaf_report *rep)
+{
+    if (!c || !o || !d_naf_ || !naf_len || (!d_text_ && n)) return NAF_GPU_EARG;
+    arena_reset(c);
+    const u8 *d_text = (const u8 *)d_text_; u8 *d_naf = (u8 *)d_naf_;
+    naf_gpu_ennaf_report R; memset(&R, 0, sizeof R);
+    int seq_type = o->seq_type;
+    if (seq_type < 0 || seq_type > 3) return ctx_fail(c, NAF_GPU_EARG, "bad seq_type");
+    bool fourbit = seq_type <= NAF_SEQ_RNA;
+    bool store_mask = !(o->no_mask || !fourbit);                                                  // ennaf.c:445
+
+    // confirm_input_format
+    u64 *d_sn = arena_new<u64>(c, 4); if (!d_sn) return NAF_GPU_ENOMEM;
+    u64 sn[3] = { 0, 0x100, '\n' };
+    if (n) { LAUNCH(c, "ennaf_sniff", k_sniff, 1, 64, 0, d_text, (u64)n, d_sn); int rc = ctx_readback(c, sn, d_sn, 24); if (rc) return rc; }
+    int format = 0;
+    if (sn[1] != 0x100) {
+        bool at_line_start = sn[2] >= 0x0A && sn[2] <= 0x0D;
+        if (sn[1] == '>' && at_line_start) format = NAF_FMT_FASTA;
+        else if (sn[1] == '@' && at_line_start) format = NAF_FMT_FASTQ;
+        else if (sn[1] == '>' || sn[1] == '@') return ctx_fail(c, NAF_GPU_EINPUT, "invalid input - first '%c' is not at the beginning of the line\n", (int)sn[1]);
+        else return ctx_fail(c, NAF_GPU_EINPUT, "input data is in unknown format - first non-space character is neither '>' nor '@'\n");
+        if (o->format != NAF_FMT_AUTO && o->format != format) return ctx_fail(c, NAF_GPU_EINPUT, "input format is different from format specified in the command line\n");
+    }
+    if (format == NAF_FMT_FASTQ) return ctx_fail(c, NAF_GPU_EINPUT, "FASTQ input is not yet handled by the gfx950 encoder (FASTA only in this release)\n");
+    R.format = format;
+
+    u8 *s_ids = nullptr, *s_cmt = nullptr, *s_seq = nullptr, *s_mask = nullptr; u32 *s_len = nullptr;
+    u64 n_ids = 0, n_cmt = 0, n_lenb = 0, n_mask = 0, n_seqb = 0, T = 0, N = 0, longest = 0;
+    int rc;
+    if (format == NAF_FMT_FASTA) {
+        EncP P; memset(&P, 0, sizeof P);
+        P.text = d_text; P.n = n; P.p0 = sn[0];
+        set_expected(P, seq_type, true);
+        u64 tiles = n / ET_TILE + 1;                                                              // +1: the virtual end-of-input byte
+        i64 *t_eol = arena_new<i64>(c, tiles + 1), *t_sp = arena_new<i64>(c, tiles + 1);
+        u64 *t_seq = arena_new<u64>(c, tiles + 2), *t_ids = arena_new<u64>(c, tiles + 2), *t_cmt = arena_new<u64>(c, tiles + 2), *t_rec = arena_new<u64>(c, tiles + 2);
+        u32 *t_tail = arena_new<u32>(c, tiles + 1);
+        u64 *tot = arena_new<u64>(c, 8);
+        if (!t_eol || !t_sp || !t_seq || !t_ids || !t_cmt || !t_rec || !t_tail || !tot) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "ennaf_last", k_enc_last, tiles, 256, 0, P, t_eol, t_sp);
+        // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
+        if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
+        if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
+        LAUNCH(c, "ennaf_count", k_enc_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail);
+        if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_ids, tiles, tot + 1))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_rec, tiles, tot + 3))) return rc;
+        // t_seq[tiles] must hold the grand total for the "line began in an earlier tile" lookup
+        HIP_TRY(c, hipMemcpyAsync(t_seq + tiles, tot + 0, 8, hipMemcpyDeviceToDevice, c->stream));
+        u64 h[4];
+        if ((rc = ctx_readback(c, h, tot, 32))) return rc;
+        T = h[0]; n_ids = h[1]; n_cmt = h[2]; N = h[3];
+        u8 *bases = (u8 *)arena_alloc(c, T + 64);
+        s_ids = (u8 *)arena_alloc(c, n_ids + 16); s_cmt = (u8 *)arena_alloc(c, n_cmt + 16);
+        u64 *rec_begin = arena_new<u64>(c, N + 1), *rec_end = arena_new<u64>(c, N + 1);
+        u64 *d_unexp = arena_new<u64>(c, 3 * 257 + 1);
+        if (!bases || !s_ids || !s_cmt || !rec_begin || !rec_end || !d_unexp) return NAF_GPU_ENOMEM;
+        HIP_TRY(c, hipMemsetAsync(d_unexp, 0, (3 * 257 + 1) * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(rec_begin, 0, (N + 1) * 8, c->stream));
+        EncOut O; O.seq = bases; O.ids = s_ids; O.cmt = s_cmt; O.rec_begin = rec_begin; O.rec_end = rec_end;
+        O.unexpected = d_unexp; O.longest = d_unexp + 3 * 257;
+        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_rec = t_rec; O.t_tail = t_tail; O.tile_eol = t_eol;
+        LAUNCH(c, "ennaf_scatter", k_enc_scatter, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+        std::vector<u64> hu(3 * 257 + 1);
+        if ((rc = ctx_readback(c, hu.data(), d_unexp, hu.size() * 8))) return rc;
+        for (int i = 0; i < 257; i++) { R.unexpected_id[i] = hu[i]; R.unexpected_comment[i] = hu[257 + i]; R.unexpected_seq[i] = hu[514 + i]; }
+        longest = hu[3 * 257];
+        if (o->strict) {
+            for (int k = 0; k < 3; k++) for (int i = 0; i < 257; i++) if (hu[k * 257 + i])
+                return ctx_fail(c, NAF_GPU_EINPUT, k == 0 ? "unexpected character '%c' in ID\n" : k == 1 ? "unexpected character '%c' in comment\n" : "unexpected sequence code '%c'\n", i);
+        }
+        // lengths
+        if (N) {
+            u64 *lu = arena_new<u64>(c, N + 2); if (!lu) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "ennaf_len_count", k_len_unit_count, cdiv(N, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, N, T, lu);
+            if ((rc = scan_exclusive_u64(c, lu, N, lu + N + 1))) return rc;
+            u64 nu = 0; if ((rc = ctx_readback(c, &nu, lu + N + 1, 8))) return rc;
+            s_len = arena_new<u32>(c, nu + 1); if (!s_len) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "ennaf_len_write", k_len_unit_write, cdiv(N, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, N, T, (const u64 *)lu, s_len);
+            n_lenb = nu * 4;
+        }
+        // mask
+        if (store_mask && T) {
+            u64 mt = (T + MB_TILE - 1) / MB_TILE;
+            u64 *tc = arena_new<u64>(c, mt + 2); if (!tc) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "ennaf_mask_bcount", k_mask_bcount, mt, 256, 0, (const u8 *)bases, T, tc);
+            if ((rc = scan_exclusive_u64(c, tc, mt, tc + mt + 1))) return rc;
+            u64 nb = 0; if ((rc = ctx_readback(c, &nb, tc + mt + 1, 8))) return rc;
+            u64 *bnd = arena_new<u64>(c, nb + 1), *ru = arena_new<u64>(c, nb + 3);
+            if (!bnd || !ru) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "ennaf_mask_bscatter", k_mask_bscatter, mt, 256, 0, (const u8 *)bases, T, (const u64 *)tc, bnd);
+            LAUNCH(c, "ennaf_mask_runs", k_mask_run_units, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, ru);
+            if ((rc = scan_exclusive_u64(c, ru, nb + 1, ru + nb + 2))) return rc;
+            u64 nu = 0; if ((rc = ctx_readback(c, &nu, ru + nb + 2, 8))) return rc;
+            s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "ennaf_mask_units", k_mask_units_write, cdiv(nu, 256), 256, 0, (const u64 *)bnd, nb, T, (const u64 *)ru, nu, s_mask);
+            n_mask = nu;
+        }
+        // sequence stream
+        if (fourbit) {
+            n_seqb = (T + 1) / 2;
+            s_seq = (u8 *)arena_alloc(c, n_seqb + 16); if (!s_seq) return NAF_GPU_ENOMEM;
+            if (T) LAUNCH(c, "ennaf_pack4", k_pack4, cdiv(T, 256 * 16), 256, 0, (const u8 *)bases, T, s_seq);
+        } else {
+            if (o->no_mask && T) LAUNCH(c, "ennaf_toupper", k_toupper, cdiv(T, 256), 256, 0, bases, T);   // process.c:46-51
+            s_seq = bases; n_seqb = T;
+        }
+    }
+    R.n_sequences = N; R.n_bases = T; R.longest_line = longest;
+
+    // container (ennaf.c:538-589)
+    u8 hd[64 + 32]; size_t hl = 0;
+    hd[hl++] = 0x01; hd[hl++] = 0xF9; hd[hl++] = 0xEC;
+    if (seq_type == NAF_SEQ_DNA) hd[hl++] = 1; else { hd[hl++] = 2; hd[hl++] = (u8)seq_type; }
+    size_t tl = o->title ? strlen(o->title) : 0;
+    hd[hl++] = (u8)(((o->title ? 1 : 0) << 6) | (1 << 5) | (1 << 4) | (1 << 3) | ((store_mask ? 1 : 0) << 2) | (1 << 1) | 0);
+    hd[hl++] = ' ';
+    hl += vle(o->line_length >= 0 ? (u64)o->line_length : longest, hd + hl);
+    hl += vle(N, hd + hl);
+    if (o->title) hl += vle(tl, hd + hl);
+    size_t pos = 0;
+    if (hl + tl > cap) return ctx_fail(c, NAF_GPU_ECAP, "ennaf output capacity %zu too small", cap);
+    HIP_TRY(c, hipMemcpyAsync(d_naf, hd, hl, hipMemcpyHostToDevice, c->stream)); pos += hl;
+    if (tl) { HIP_TRY(c, hipMemcpyAsync(d_naf + pos, o->title, tl, hipMemcpyHostToDevice, c->stream)); pos += tl; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    SecOut so[6]; memset(so, 0, sizeof so);
+    if ((rc = put_section(c, s_ids, n_ids, n_ids, o->level, d_naf, cap, pos, so[0]))) return rc;
+    if ((rc = put_section(c, s_cmt, n_cmt, n_cmt, o->level, d_naf, cap, pos, so[1]))) return rc;
+    if ((rc = put_section(c, (const u8 *)s_len, n_lenb, n_lenb, o->level, d_naf, cap, pos, so[2]))) return rc;
+    if (store_mask) { if ((rc = put_section(c, s_mask, n_mask, n_mask, o->level, d_naf, cap, pos, so[3]))) return rc; }
+    if ((rc = put_section(c, s_seq, n_seqb, T, o->level, d_naf, cap, pos, so[4]))) return rc;      // ennaf.c:582: number of bases
+    for (int i = 0; i < 6; i++) { R.section_orig[i] = so[i].orig; R.section_comp[i] = so[i].comp; }
+    *naf_len = pos;
+    if (rep) *rep = R;
+    return 0;
+}

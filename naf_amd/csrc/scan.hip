@@ -81,3 +81,8 @@ int scan_inclusive_max_i32(naf_gpu_ctx *c, i32 *d_vals, size_t n)
     // tile aggregates of a max-scan combine with max as well: reuse the recursion with OpMax/exclusive
     return scan_rec<i32, OpMax, false>(c, d_vals, n, (i32 *)nullptr);
 }
+
+int scan_inclusive_max_i64(naf_gpu_ctx *c, i64 *d_vals, size_t n)
+{
+    return scan_rec<i64, OpMax, false>(c, d_vals, n, (i64 *)nullptr);
+}

@@ -1,0 +1,317 @@
+// zstd_enc_core.h -- per-lane logic of the zstd block encoder (RFC 8878 compliant output; replaces
+// libzstd behind ennaf/src/compressor.c:119-147 compress() / :64-96 compressor_end_stream()).
+//
+// Blocks are coded independently (no repeat offsets, no treeless literals, no cross-block matches)
+// so any block range can be produced by any GPU and still concatenates into ONE valid frame
+// (reference unnaf accepts exactly one frame for sequence and quality).
+// Level-1 style coding: literals-only Compressed blocks with a 4-stream Huffman literals section and
+// zero sequences; RLE blocks for constant data; Raw blocks when entropy coding does not pay.
+#pragma once
+#include "common.h"
+
+#define ZENC_HUF_MAXBITS 11
+
+// ---- length-limited Huffman code lengths from a histogram -------------------------------------------------
+// cnt[256] -> len[256] (0 for absent symbols).  Returns the maximum length (tableLog), or 0 when fewer
+// than two distinct symbols are present.  Scratch: order[256], node arrays of 512 entries.
+NAF_HD u32 huf_build_lengths(const u32 *cnt, u8 *len)
+{
+    u16 order[256]; u32 n = 0;
+    for (u32 s = 0; s < 256; s++) { len[s] = 0; if (cnt[s]) order[n++] = (u16)s; }
+    if (n < 2) return 0;
+    // sort present symbols by count ascending (insertion sort; n <= 256, one lane per block)
+    for (u32 i = 1; i < n; i++) {
+        u16 v = order[i]; u32 c = cnt[v]; u32 j = i;
+        while (j > 0 && cnt[order[j - 1]] > c) { order[j] = order[j - 1]; j--; }
+        order[j] = v;
+    }
+    // two-queue Huffman construction; parent links give depths
+    u32 w[512]; u16 parent[512];
+    for (u32 i = 0; i < n; i++) w[i] = cnt[order[i]];
+    u32 leaf = 0, inode = n, next = n;              // queue 1: leaves [leaf,n) ; queue 2: internal [inode,next)
+    while ((n - leaf) + (next - inode) > 1) {
+        u32 a, b;
+        if (leaf < n && (inode >= next || w[leaf] <= w[inode])) a = leaf++; else a = inode++;
+        if (leaf < n && (inode >= next || w[leaf] <= w[inode])) b = leaf++; else b = inode++;
+        w[next] = w[a] + w[b]; parent[a] = (u16)next; parent[b] = (u16)next; next++;
+    }
+    u32 root = next - 1; u8 depth[512];
+    depth[root] = 0;
+    for (u32 i = root; i-- > 0;) depth[i] = (u8)(depth[parent[i]] + 1);
+    u32 maxlen = 0;
+    for (u32 i = 0; i < n; i++) { u32 d = depth[i]; if (d > maxlen) maxlen = d; len[order[i]] = (u8)d; }
+    if (maxlen <= ZENC_HUF_MAXBITS) return maxlen;
+    // length limiting: clamp, then repair the Kraft sum (units of 2^-MAXBITS) to exactly 1
+    i32 K = 0;
+    for (u32 i = 0; i < n; i++) { u8 &l = len[order[i]]; if (l > ZENC_HUF_MAXBITS) l = ZENC_HUF_MAXBITS; K += 1 << (ZENC_HUF_MAXBITS - l); }
+    const i32 full = 1 << ZENC_HUF_MAXBITS;
+    while (K > full) {                              // lengthen the rarest symbol that can still grow
+        for (u32 i = 0; i < n && K > full; i++) {
+            u8 &l = len[order[i]];
+            if (l < ZENC_HUF_MAXBITS) { K -= 1 << (ZENC_HUF_MAXBITS - l - 1); l++; }
+        }
+    }
+    while (K < full) {                              // shorten the most frequent symbols that fit
+        bool any = false;
+        for (u32 i = n; i-- > 0 && K < full;) {
+            u8 &l = len[order[i]];
+            if (l > 1 && K + (1 << (ZENC_HUF_MAXBITS - l)) <= full) { K += 1 << (ZENC_HUF_MAXBITS - l); l--; any = true; }
+        }
+        if (!any) break;
+    }
+    if (K != full) return 0;
+    maxlen = 0;
+    for (u32 i = 0; i < n; i++) if (len[order[i]] > maxlen) maxlen = len[order[i]];
+    return maxlen;
+}
+
+// Canonical code values in the order the zstd decoder expects (4.2.1): within the decoding table,
+// symbols are laid out by increasing weight (= decreasing length), ties by symbol value; the code of a
+// symbol is the index of its first table cell >> (log - len).
+NAF_HD void huf_assign_codes(const u8 *len, u32 log, u16 *code)
+{
+    u32 cnt[ZENC_HUF_MAXBITS + 2], start[ZENC_HUF_MAXBITS + 2];
+    for (u32 r = 0; r <= ZENC_HUF_MAXBITS + 1; r++) cnt[r] = 0;
+    for (u32 s = 0; s < 256; s++) if (len[s]) cnt[log + 1 - len[s]]++;            // index by weight
+    u32 pos = 0;
+    for (u32 wgt = 1; wgt <= log; wgt++) { start[wgt] = pos; pos += cnt[wgt] << (wgt - 1); }
+    for (u32 s = 0; s < 256; s++) {
+        if (!len[s]) { code[s] = 0; continue; }
+        u32 wgt = log + 1 - len[s];
+        code[s] = (u16)(start[wgt] >> (wgt - 1));                                // = cell index >> (log - len)
+        start[wgt] += 1u << (wgt - 1);
+    }
+}
+
+// ---- forward bit writer (all zstd bit-streams are written forward, little-endian, read backward) -------------
+struct BitW { u8 *p; u64 acc; u32 n; };
+NAF_HD void bitw_init(BitW &b, u8 *p) { b.p = p; b.acc = 0; b.n = 0; }
+NAF_HD void bitw_add(BitW &b, u32 v, u32 nbits) { b.acc |= (u64)(v & ((nbits >= 32) ? 0xFFFFFFFFu : ((1u << nbits) - 1))) << b.n; b.n += nbits; }
+NAF_HD void bitw_flush(BitW &b) { while (b.n >= 8) { *b.p++ = (u8)b.acc; b.acc >>= 8; b.n -= 8; } }
+// final marker bit + padding; returns end pointer
+NAF_HD u8 *bitw_close(BitW &b) { bitw_add(b, 1, 1); bitw_flush(b); if (b.n) { *b.p++ = (u8)b.acc; b.n = 0; } return b.p; }
+
+// ---- FSE encoder for Huffman weights (4.2.1.2) --------------------------------------------------------------------
+struct FseCSym { i32 deltaNbBits; i32 deltaFindState; };
+
+// Normalize counts of symbols 0..maxsym to sum 2^log, every present symbol >= 1.  Returns false if impossible.
+NAF_HD bool fse_normalize(const u32 *cnt, u32 maxsym, u32 total, u32 log, i16 *norm)
+{
+    u32 size = 1u << log, present = 0;
+    for (u32 s = 0; s <= maxsym; s++) present += cnt[s] != 0;
+    if (present > size || present < 2) return false;
+    u32 sum = 0, big = 0;
+    for (u32 s = 0; s <= maxsym; s++) {
+        if (!cnt[s]) { norm[s] = 0; continue; }
+        u32 v = (u32)(((u64)cnt[s] * size) / total);
+        if (v == 0) v = 1;
+        norm[s] = (i16)v; sum += v;
+        if (cnt[s] > cnt[big] || !cnt[big]) big = s;
+    }
+    // repair the sum: first on the most frequent symbol, then round-robin
+    while (sum != size) {
+        if (sum < size) { norm[big] += (i16)(size - sum); sum = size; }
+        else {
+            u32 over = sum - size;
+            if ((u32)norm[big] > over + 0) { norm[big] -= (i16)over; sum = size; if (norm[big] < 1) return false; }
+            else {
+                bool any = false;
+                for (u32 s = 0; s <= maxsym && sum > size; s++) if (norm[s] > 1) { norm[s]--; sum--; any = true; }
+                if (!any) return false;
+            }
+        }
+    }
+    return true;
+}
+
+// Table description (4.1.1), mirror of fse_read_ncount.  Returns bytes written.
+NAF_HD u32 fse_write_ncount(u8 *out, const i16 *norm, u32 maxsym, u32 log)
+{
+    BitW b; bitw_init(b, out);
+    bitw_add(b, log - 5, 4);
+    i32 remaining = (1 << log) + 1, threshold = 1 << log; u32 nbits = log + 1, s = 0;
+    while (remaining > 1 && s <= maxsym) {
+        i32 count = norm[s++];
+        i32 max = (2 * threshold - 1) - remaining;
+        remaining -= count < 0 ? -count : count;
+        count++;
+        if (count >= threshold) count += max;
+        bitw_add(b, (u32)count, nbits - (count < max ? 1 : 0));
+        bitw_flush(b);
+        if (count == 1) {                                      // probability 0: repeat flags
+            u32 start = s;
+            while (s <= maxsym && norm[s] == 0) s++;
+            u32 run = s - start;
+            while (run >= 3) { bitw_add(b, 3, 2); run -= 3; bitw_flush(b); }
+            bitw_add(b, run, 2); bitw_flush(b);
+        }
+        while (remaining < threshold && threshold > 1) { nbits--; threshold >>= 1; }
+    }
+    bitw_flush(b);
+    if (b.n) { *b.p++ = (u8)b.acc; }
+    return (u32)(b.p - out);
+}
+
+// Encoding tables (state table + per-symbol transforms).  tableU16 needs 2^log entries.
+NAF_HD void fse_build_ctable(const i16 *norm, u32 maxsym, u32 log, u16 *tableU16, FseCSym *tt)
+{
+    u32 size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    u8 tsym[64]; u32 cumul[18]; u32 high = size - 1;
+    cumul[0] = 0;
+    for (u32 u = 1; u <= maxsym + 1; u++) {
+        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tsym[high--] = (u8)(u - 1); }
+        else cumul[u] = cumul[u - 1] + (u32)norm[u - 1];
+    }
+    u32 pos = 0;
+    for (u32 s = 0; s <= maxsym; s++)
+        for (i32 i = 0; i < norm[s]; i++) { tsym[pos] = (u8)s; do { pos = (pos + step) & mask; } while (pos > high); }
+    for (u32 u = 0; u < size; u++) { u32 s = tsym[u]; tableU16[cumul[s]++] = (u16)(size + u); }
+    i32 total = 0;
+    for (u32 s = 0; s <= maxsym; s++) {
+        i32 nc = norm[s];
+        if (nc == 0) { tt[s].deltaNbBits = (i32)(((log + 1) << 16) - (1u << log)); tt[s].deltaFindState = 0; }
+        else if (nc == -1 || nc == 1) { tt[s].deltaNbBits = (i32)((log << 16) - (1u << log)); tt[s].deltaFindState = total - 1; total++; }
+        else {
+            u32 maxBitsOut = log - (u32)hibit32((u32)nc - 1);
+            u32 minStatePlus = (u32)nc << maxBitsOut;
+            tt[s].deltaNbBits = (i32)((maxBitsOut << 16) - minStatePlus);
+            tt[s].deltaFindState = total - nc;
+            total += nc;
+        }
+    }
+}
+
+// FSE-compress `n` weights (values 0..maxsym) with two interleaved states.  Returns bytes written, 0 on failure.
+NAF_HD u32 fse_compress_weights(u8 *out, u32 cap, const u8 *w, u32 n)
+{
+    if (n < 2) return 0;
+    u32 cnt[16]; for (u32 i = 0; i < 16; i++) cnt[i] = 0;
+    u32 maxsym = 0, maxcnt = 0;
+    for (u32 i = 0; i < n; i++) { cnt[w[i]]++; if (w[i] > maxsym) maxsym = w[i]; }
+    for (u32 s = 0; s <= maxsym; s++) if (cnt[s] > maxcnt) maxcnt = cnt[s];
+    if (maxcnt == n || maxcnt == 1) return 0;                  // single symbol / nothing to gain
+    u32 log = n > 24 ? 6 : 5;
+    i16 norm[16];
+    if (!fse_normalize(cnt, maxsym, n, log, norm)) return 0;
+    if (cap < 64) return 0;
+    u32 hdr = fse_write_ncount(out, norm, maxsym, log);
+    u16 tableU16[64]; FseCSym tt[16];
+    fse_build_ctable(norm, maxsym, log, tableU16, tt);
+    BitW b; bitw_init(b, out + hdr);
+    u32 st1, st2;
+    auto init_state = [&](u32 sym) -> u32 {
+        u32 nbBitsOut = (u32)((tt[sym].deltaNbBits + (1 << 15)) >> 16);
+        i32 v = (i32)(nbBitsOut << 16) - tt[sym].deltaNbBits;
+        return tableU16[(v >> nbBitsOut) + tt[sym].deltaFindState];
+    };
+    auto encode = [&](u32 &st, u32 sym) {
+        u32 nbBitsOut = (u32)(((i32)st + tt[sym].deltaNbBits) >> 16);
+        bitw_add(b, st, nbBitsOut); bitw_flush(b);
+        st = tableU16[((i32)st >> nbBitsOut) + tt[sym].deltaFindState];
+    };
+    const u8 *ip = w + n;
+    if (n & 1) { st1 = init_state(*--ip); st2 = init_state(*--ip); encode(st1, *--ip); }
+    else { st2 = init_state(*--ip); st1 = init_state(*--ip); }
+    while (ip > w) { encode(st2, *--ip); if (ip > w) encode(st1, *--ip); }
+    bitw_add(b, st2, log); bitw_flush(b);
+    bitw_add(b, st1, log); bitw_flush(b);
+    u8 *end = bitw_close(b);
+    u32 total = (u32)(end - out);
+    if (total > cap) return 0;
+    return total;
+}
+
+// Huffman tree description (4.2.1): FSE-compressed weights when smaller (mandatory above 128 weights),
+// else direct 4-bit weights.  len[] = code lengths, log = max length.  Returns bytes, 0 = not representable.
+NAF_HD u32 huf_write_tree(u8 *out, const u8 *len, u32 log)
+{
+    u8 w[256]; u32 last = 0;
+    for (u32 s = 0; s < 256; s++) { w[s] = len[s] ? (u8)(log + 1 - len[s]) : 0; if (len[s]) last = s; }
+    u32 n = last;                                              // weights for symbols 0..last-1; the last is implied
+    if (n == 0) return 0;
+    u8 tmp[160];
+    u32 fs = fse_compress_weights(tmp, sizeof tmp, w, n);
+    if (fs > 1 && fs < 128 && fs < (n + 1) / 2 + 0u + 1) { out[0] = (u8)fs; for (u32 i = 0; i < fs; i++) out[1 + i] = tmp[i]; return 1 + fs; }
+    if (n > 128) return 0;
+    out[0] = (u8)(127 + n);
+    for (u32 i = 0; i < n; i += 2) out[1 + i / 2] = (u8)((w[i] << 4) | (i + 1 < n ? w[i + 1] : 0));
+    return 1 + (n + 1) / 2;
+}
+
+// Size in bytes of one Huffman stream holding the given per-symbol counts.
+NAF_HD u32 huf_stream_bytes(const u32 *cnt, const u8 *len)
+{
+    u64 bits = 0;
+    for (u32 s = 0; s < 256; s++) bits += (u64)cnt[s] * len[s];
+    return (u32)((bits + 1 + 7) / 8);                          // + final marker bit
+}
+
+// Encode src[0..n) into one Huffman stream (4.2.2: written forward, so that the LAST symbol is read first).
+// codes: code | len << 16 per symbol.  Returns bytes written.
+template <typename TabPtr>
+NAF_HD u32 huf_encode_stream(u8 *out, const u8 *src, u32 n, TabPtr codes)
+{
+    BitW b; bitw_init(b, out);
+    for (u32 i = n; i-- > 0;) {                                // decoder emits the first symbol from the top of the stream
+        u32 e = codes[src[i]];
+        bitw_add(b, e & 0xFFFF, e >> 16);
+        if (b.n >= 32) bitw_flush(b);
+    }
+    bitw_flush(b);
+    return (u32)(bitw_close(b) - out);
+}
+
+// ---- block planning ------------------------------------------------------------------------------------------------
+enum { ZK_RAW = 0, ZK_RLE = 1, ZK_HUF = 2 };
+struct ZEncPlan {
+    u32 n;              // regenerated size of the block
+    u32 csize;          // bytes of the block INCLUDING its 3-byte header
+    u32 ssz[4];         // Huffman stream sizes
+    u16 tree_bytes;     // Huffman tree description size
+    u8  kind, log, lhdr;// ZK_*, table log, literals-section header size (3/4/5)
+    u8  pad;
+};
+
+// hist[4][256] = byte counts of the four stream quarters of the block.  Fills plan, len[256], tree[<=160].
+NAF_HD void zenc_plan_block(const u32 *hist, u32 n, ZEncPlan &p, u8 *len, u8 *tree)
+{
+    p.n = n; p.kind = ZK_RAW; p.csize = 3 + n; p.log = 0; p.tree_bytes = 0; p.lhdr = 0;
+    if (n == 0) return;
+    u32 tot[256]; u32 distinct = 0, only = 0;
+    for (u32 s = 0; s < 256; s++) { tot[s] = hist[s] + hist[256 + s] + hist[512 + s] + hist[768 + s]; if (tot[s]) { distinct++; only = s; } }
+    if (distinct == 1) { p.kind = ZK_RLE; p.csize = 4; (void)only; return; }
+    if (n < 64) return;
+    u32 log = huf_build_lengths(tot, len);
+    if (!log) return;
+    u32 tb = huf_write_tree(tree, len, log);
+    if (!tb) return;
+    u32 body = tb + 6;
+    for (u32 k = 0; k < 4; k++) { p.ssz[k] = huf_stream_bytes(hist + 256 * k, len); body += p.ssz[k]; if (p.ssz[k] > 0xFFFF) return; }
+    u32 lhdr = (n < 1024 && body < 1024) ? 3 : ((n < 16384 && body < 16384) ? 4 : 5);
+    if (body >= (1u << 18)) return;
+    u32 csize = 3 + lhdr + body + 1;                           // + sequences header (0 sequences)
+    if (csize >= 3 + n) return;                                // entropy coding does not pay: Raw block
+    p.kind = ZK_HUF; p.csize = csize; p.log = (u8)log; p.tree_bytes = (u16)tb; p.lhdr = (u8)lhdr;
+}
+
+// Block header + literals header + tree + jump table.  Returns the offset of the first Huffman stream.
+NAF_HD u32 zenc_write_block_prefix(u8 *out, const ZEncPlan &p, const u8 *tree, bool last, u8 rle_byte)
+{
+    u32 type = p.kind == ZK_HUF ? 2 : p.kind;
+    u32 bsize = p.kind == ZK_HUF ? p.csize - 3 : p.n;
+    u32 bh = (last ? 1u : 0u) | (type << 1) | (bsize << 3);
+    out[0] = (u8)bh; out[1] = (u8)(bh >> 8); out[2] = (u8)(bh >> 16);
+    if (p.kind == ZK_RLE) { out[3] = rle_byte; return 4; }
+    if (p.kind == ZK_RAW) return 3;
+    u32 body = p.csize - 3 - p.lhdr - 1, pos = 3;
+    if (p.lhdr == 3) { u32 h = 2u | (1u << 2) | (p.n << 4) | (body << 14); out[pos] = (u8)h; out[pos + 1] = (u8)(h >> 8); out[pos + 2] = (u8)(h >> 16); }
+    else if (p.lhdr == 4) { u32 h = 2u | (2u << 2) | (p.n << 4) | (body << 18); st32(out + pos, h); }
+    else { u64 h = 2u | (3u << 2) | ((u64)p.n << 4) | ((u64)body << 22); st32(out + pos, (u32)h); out[pos + 4] = (u8)(h >> 32); }
+    pos += p.lhdr;
+    for (u32 i = 0; i < p.tree_bytes; i++) out[pos + i] = tree[i];
+    pos += p.tree_bytes;
+    out[pos] = (u8)p.ssz[0]; out[pos + 1] = (u8)(p.ssz[0] >> 8);
+    out[pos + 2] = (u8)p.ssz[1]; out[pos + 3] = (u8)(p.ssz[1] >> 8);
+    out[pos + 4] = (u8)p.ssz[2]; out[pos + 5] = (u8)(p.ssz[2] >> 8);
+    return pos + 6;
+}
