@@ -25,6 +25,7 @@ struct ZStat {                 // device-side counters read back by the host
 };
 
 static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
+static __device__ __forceinline__ u64 shfl_u64(u64 v, int l) { u32 lo = __shfl((u32)v, l, 64), hi = __shfl((u32)(v >> 32), l, 64); return ((u64)hi << 32) | lo; }
 
 __global__ void k_scan_blocks(const u8 *src, u64 len, u64 first_off, ZBlock *blk, u32 cap, ZStat *st)
 {
@@ -42,6 +43,147 @@ __global__ void k_scan_blocks(const u8 *src, u64 len, u64 first_off, ZBlock *blk
         if (last) break;
     }
     st->nblk = n; st->end_off = pos; st->err = err;
+}
+
+// ---- speculative parallel block index -----------------------------------------------------------------------
+// The 3-byte block headers form a linked list that has to be walked serially by the format.  To index a
+// multi-GB frame without a multi-ms serial walk:
+//   1. k_spec_find   cut the frame into 1 MiB chunks; in the first 128 KiB + 3 of each chunk (a block start
+//                    must lie there) test every byte as a candidate start and keep the smallest one whose
+//                    chain survives SPEC_HOPS header validations (type 3 / size > 128 KiB kill ~95 % of
+//                    random positions per hop; survivors are on, or quickly merge into, the true chain)
+//   2. k_spec_land   walk each chunk's candidate chain to the first block start in the NEXT chunk
+//                    ("landing"), once from the candidate and once from the previous chunk's landing
+//   3. k_spec_resolve one wave runs over the chunks in order: the true start of chunk c+1 is F_c(true start
+//                    of chunk c); when the speculated start of chunk c equals the true one, the precomputed
+//                    landing is reused, otherwise the chunk is re-walked on the spot.  Starts are therefore
+//                    EXACT by construction -- speculation only decides how much is reused.
+//   4. k_spec_walk   count, then write, the ZBlock records of every chunk in parallel.
+#define SPEC_CHUNK   (1024u * 1024u)
+#define SPEC_WINDOW  (ZBLOCK_MAX + 4u)
+#define SPEC_HOPS    10
+#define SPEC_NONE    0xFFFFFFFFFFFFFFFFull
+#define SPEC_END     0xFFFFFFFFFFFFFFFEull       // chain reached the last block of the frame
+
+__device__ __forceinline__ bool spec_hdr_ok(u32 h, u64 pos, u64 len, u32 &adv)
+{
+    u32 type = (h >> 1) & 3, size = h >> 3;
+    if (type == 3 || size > ZBLOCK_MAX) return false;
+    adv = 3 + (type == BT_RLE ? 1 : size);
+    return pos + adv <= len;
+}
+__device__ __forceinline__ bool spec_hop(const u8 *src, u64 len, u64 &pos, bool &last)
+{
+    if (pos + 3 > len) return false;
+    u32 h = ld24(src + pos), adv;
+    if (!spec_hdr_ok(h, pos, len, adv)) return false;
+    last = h & 1; pos += adv;
+    return true;
+}
+// Walk from `pos` to the first block start >= stop.  Returns SPEC_END after the last block, SPEC_NONE on an invalid header.
+__device__ __forceinline__ u64 spec_land(const u8 *src, u64 len, u64 pos, u64 stop, u64 *end_off)
+{
+    bool last = false;
+    while (pos < stop) {
+        if (!spec_hop(src, len, pos, last)) return SPEC_NONE;
+        if (last) { if (end_off) *end_off = pos; return SPEC_END; }
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(256) void k_spec_find(const u8 *src, u64 len, u32 nchunks, u64 *first)
+{
+    const u32 tiles = (SPEC_WINDOW + 4095) / 4096;
+    u32 c = blockIdx.x / tiles + 1;                          // chunk 0 starts at the known first block
+    if (c >= nchunks) return;
+    u64 base = (u64)c * SPEC_CHUNK;
+    u32 k0 = ((blockIdx.x % tiles) * 256 + threadIdx.x) * 16;
+    if (k0 >= SPEC_WINDOW || base + k0 + 24 > len) {
+        if (k0 >= SPEC_WINDOW || base + k0 + 3 > len) return;
+    }
+    // 16 candidate positions from 18 bytes held in registers
+    u64 w0 = 0, w1 = 0, w2 = 0;
+    if (base + k0 + 24 <= len) { w0 = ld64(src + base + k0); w1 = ld64(src + base + k0 + 8); w2 = ld64(src + base + k0 + 16); }
+    else { u8 t[24]; for (int i = 0; i < 24; i++) t[i] = base + k0 + i < len ? src[base + k0 + i] : 0xFF; w0 = ld64(t); w1 = ld64(t + 8); w2 = ld64(t + 16); }
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) {
+        if (k0 + k >= SPEC_WINDOW) break;
+        u32 sh = 8 * (k & 7);
+        u64 lo = k < 8 ? w0 : w1, hi = k < 8 ? w1 : w2;
+        u32 h = (u32)((sh ? (lo >> sh) | (hi << (64 - sh)) : lo) & 0xFFFFFF), adv;
+        u64 pos = base + k0 + k;
+        if (!spec_hdr_ok(h, pos, len, adv)) continue;
+        bool last = h & 1, ok = true;
+        u64 p = pos + adv;
+        if (last) ok = p + 4 >= len;
+        for (int hop = 1; ok && !last && hop < SPEC_HOPS; hop++) {
+            if (!spec_hop(src, len, p, last)) ok = false;
+            else if (last) ok = p + 4 >= len;                // a chain may only end at the end of the frame (+checksum)
+        }
+        if (ok) { atomicMin((unsigned long long *)&first[c], (unsigned long long)pos); break; }
+    }
+}
+
+// land[c+1] = F_c(first[c]) ; first[0] is the known true start.
+__global__ void k_spec_land(const u8 *src, u64 len, const u64 *first, u32 nchunks, u64 *land)
+{
+    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    u64 s = first[c];
+    land[c + 1] = s == SPEC_NONE ? SPEC_NONE : spec_land(src, len, s, (u64)(c + 1) * SPEC_CHUNK, nullptr);
+    if (c == 0) land[0] = s;
+}
+// G[c] = F_c(land[c]) (reuses land[c+1] when the candidate already was the landing)
+__global__ void k_spec_land2(const u8 *src, u64 len, const u64 *first, const u64 *land, u32 nchunks, u64 *G)
+{
+    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    u64 l = land[c];
+    if (l == first[c]) G[c] = land[c + 1];
+    else if (l >= SPEC_END) G[c] = SPEC_NONE;
+    else G[c] = spec_land(src, len, l, (u64)(c + 1) * SPEC_CHUNK, nullptr);
+}
+// One wave: exact chunk starts.  start[c] for c in [0, nchunks], start[nchunks] = SPEC_END when the frame is well formed.
+__global__ void k_spec_resolve(const u8 *src, u64 len, const u64 *land, const u64 *G, u32 nchunks, u64 *start, ZStat *st)
+{
+    int lane = threadIdx.x;
+    u64 t = land[0];                                           // true start of chunk 0
+    if (lane == 0) start[0] = t;
+    for (u32 base = 0; base < nchunks; base += 64) {
+        u32 c = base + lane;
+        u64 lc = c < nchunks ? land[c] : SPEC_NONE, gc = c < nchunks ? G[c] : SPEC_NONE;
+        for (int j = 0; j < 64 && base + j < nchunks; j++) {
+            u64 lj = shfl_u64(lc, j), gj = shfl_u64(gc, j);
+            u64 nxt;
+            if (t >= SPEC_END) nxt = t;                        // past the end of the frame (or broken): propagate
+            else if (lj == t) nxt = gj;
+            else { u64 e = 0; nxt = spec_land(src, len, t, (u64)(base + j + 1) * SPEC_CHUNK, &e); }   // speculation missed: re-walk (uniform)
+            t = nxt;
+            if (lane == 0) start[base + j + 1] = t;
+        }
+    }
+    if (lane == 0 && t != SPEC_END) atomicMax(&st->err, (u32)ZE_CORRUPT);
+}
+
+// WRITE=false: count blocks per chunk; WRITE=true: emit ZBlock records at count[c] (exclusive-scanned).
+template <bool WRITE>
+__global__ void k_spec_walk(const u8 *src, u64 len, const u64 *start, u32 nchunks, u64 *count, ZBlock *blk, ZStat *st)
+{
+    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    u64 pos = start[c], lim = start[c + 1];
+    u64 n = 0, o = WRITE ? count[c] : 0;
+    if (pos < SPEC_END) {
+        bool last = false;
+        while (pos < lim) {
+            u64 p0 = pos; u32 h = ld24(src + pos);
+            if (!spec_hop(src, len, pos, last)) { atomicMax(&st->err, (u32)ZE_CORRUPT); break; }
+            if (WRITE) { ZBlock &b = blk[o + n]; b.src_off = p0 + 3; b.bsize = h >> 3; b.btype = (u8)((h >> 1) & 3); b.last = (u8)(h & 1); }
+            n++;
+            if (last) { if (!WRITE) st->end_off = pos; break; }
+        }
+    }
+    if (!WRITE) count[c] = n;
 }
 
 __global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_huf, i32 *own_ll, i32 *own_of, i32 *own_ml,
@@ -365,16 +507,47 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     if (!st) return NAF_GPU_ENOMEM;
     HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(ZStat), c->stream));
     // ---- block index
-    u32 cap = (u32)(src_len / 2048 + 1024);
-    ZBlock *blk = nullptr; ZStat hs;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        blk = arena_new<ZBlock>(c, cap);
-        if (!blk) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "zstd_scan_blocks", k_scan_blocks, 1, 64, 0, d_src, (u64)src_len, (u64)fh.hdr_size, blk, cap, st);
+    ZBlock *blk = nullptr; ZStat hs; bool indexed = false;
+    const char *nospec = getenv("NAF_GPU_SERIAL_INDEX");
+    if (src_len > 4ull * SPEC_CHUNK && !(nospec && nospec[0] == '1')) {
+        u32 nchunks = (u32)((src_len + SPEC_CHUNK - 1) / SPEC_CHUNK);
+        u64 *first = arena_new<u64>(c, nchunks + 1), *land = arena_new<u64>(c, nchunks + 2), *G = arena_new<u64>(c, nchunks + 1);
+        u64 *start = arena_new<u64>(c, nchunks + 2), *cnt = arena_new<u64>(c, (size_t)nchunks + 2);
+        if (!first || !land || !G || !start || !cnt) return NAF_GPU_ENOMEM;
+        HIP_TRY(c, hipMemsetAsync(first, 0xFF, (size_t)nchunks * 8, c->stream));
+        u64 *h0 = (u64 *)c->h_stage; *h0 = fh.hdr_size;
+        HIP_TRY(c, hipMemcpyAsync(first, h0, 8, hipMemcpyHostToDevice, c->stream));
+        u32 grid = cdiv(SPEC_WINDOW, 256 * 16) * (nchunks - 1), gl = cdiv(nchunks, 64);
+        LAUNCH(c, "zstd_index_find", k_spec_find, grid, 256, 0, d_src, (u64)src_len, nchunks, first);
+        LAUNCH(c, "zstd_index_land", k_spec_land, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, nchunks, land);
+        LAUNCH(c, "zstd_index_land2", k_spec_land2, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, (const u64 *)land, nchunks, G);
+        LAUNCH(c, "zstd_index_resolve", k_spec_resolve, 1, 64, 0, d_src, (u64)src_len, (const u64 *)land, (const u64 *)G, nchunks, start, st);
+        LAUNCH(c, "zstd_index_count", (k_spec_walk<false>), gl, 64, 0, d_src, (u64)src_len, (const u64 *)start, nchunks, cnt, (ZBlock *)nullptr, st);
+        u64 *d_tot = cnt + nchunks + 1;
+        if ((rc = scan_exclusive_u64(c, cnt, nchunks, d_tot))) return rc;
+        u64 tot = 0;
         rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
-        if (hs.err) return zerr(c, hs.err, "block headers");
-        if (hs.nblk <= cap) break;
-        cap = hs.nblk;
+        rc = ctx_readback(c, &tot, d_tot, 8); if (rc) return rc;
+        if (!hs.err && tot > 0 && tot < 0x7FFFFFFFull) {
+            blk = arena_new<ZBlock>(c, tot);
+            if (!blk) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "zstd_index_write", (k_spec_walk<true>), gl, 64, 0, d_src, (u64)src_len, (const u64 *)start, nchunks, cnt, blk, st);
+            hs.nblk = (u32)tot; indexed = true;
+        } else {
+            HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(ZStat), c->stream));     // not one well-formed frame for the parallel walk: serial walk decides
+        }
+    }
+    if (!indexed) {
+        u32 cap = (u32)(src_len / 2048 + 1024);
+        for (int attempt = 0; attempt < 2; attempt++) {
+            blk = arena_new<ZBlock>(c, cap);
+            if (!blk) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "zstd_scan_blocks", k_scan_blocks, 1, 64, 0, d_src, (u64)src_len, (u64)fh.hdr_size, blk, cap, st);
+            rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+            if (hs.err) return zerr(c, hs.err, "block headers");
+            if (hs.nblk <= cap) break;
+            cap = hs.nblk;
+        }
     }
     u32 nblk = hs.nblk;
     size_t frame_end = hs.end_off + (fh.checksum ? 4 : 0);
