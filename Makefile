@@ -6,7 +6,7 @@ CSRC     = naf_amd/csrc
 OBJS     = $(CSRC)/naf_gpu.o $(CSRC)/scan.o $(CSRC)/zstd_dec.o $(CSRC)/emit.o $(CSRC)/zstd_enc.o $(CSRC)/enc.o
 HDRS     = $(wildcard $(CSRC)/*.h) include/naf_gpu.h
 
-all: naf_amd/libnaf_gpu.so oracle
+all: naf_amd/libnaf_gpu.so hosts oracle emul
 
 naf_amd/libnaf_gpu.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS)
@@ -14,13 +14,18 @@ naf_amd/libnaf_gpu.so: $(OBJS)
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+hosts: naf_amd/bin/ennaf naf_amd/bin/unnaf
+naf_amd/bin/%: naf_amd/host/%.c naf_amd/host/host_common.h include/naf_gpu.h naf_amd/libnaf_gpu.so
+	@mkdir -p naf_amd/bin
+	gcc -O2 -std=gnu99 -Wall -o $@ $< -Lnaf_amd -lnaf_gpu -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
+
 oracle:
 	$(MAKE) -s -C oracle all
 
 emul: tests/emul/libzstd_emul.so
-tests/emul/libzstd_emul.so: tests/emul/zstd_emul.cpp $(CSRC)/zstd_dec_core.h $(CSRC)/common.h
-	g++ -O2 -std=c++17 -fPIC -shared -o $@ tests/emul/zstd_emul.cpp
+tests/emul/libzstd_emul.so: tests/emul/zstd_emul.cpp tests/emul/zstd_enc_emul.cpp $(CSRC)/zstd_dec_core.h $(CSRC)/zstd_enc_core.h $(CSRC)/common.h
+	g++ -O2 -std=c++17 -fPIC -shared -o $@ tests/emul/zstd_emul.cpp tests/emul/zstd_enc_emul.cpp
 
 clean:
-	rm -f $(CSRC)/*.o naf_amd/libnaf_gpu.so tests/emul/*.so
-.PHONY: all oracle emul clean
+	rm -rf $(CSRC)/*.o naf_amd/libnaf_gpu.so tests/emul/*.so naf_amd/bin
+.PHONY: all oracle emul hosts clean

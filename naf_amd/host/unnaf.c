@@ -1,0 +1,222 @@
+/* unnaf -- NAF decompressor front end for the MI355X path.
+ * Command line, outputs and messages follow unnaf/src/unnaf.c:197-456 and unnaf/src/output.c of the
+ * reference; every decompression and the text re-emit run on the GPU through libnaf_gpu.so. */
+#include "host_common.h"
+
+typedef enum { UNDECIDED, FORMAT_NAME, PART_LIST, PART_SIZES, NUMBER_OF_SEQUENCES, TITLE, IDS, NAMES, LENGTHS, TOTAL_LENGTH,
+               MASK, TOTAL_MASK_LENGTH, FOUR_BIT, DNA, MASKED_DNA, UNMASKED_DNA, SEQ, SEQUENCES, CHARCOUNT,
+               FASTA, MASKED_FASTA, UNMASKED_FASTA, FASTQ } OUTPUT_TYPE;
+static OUTPUT_TYPE out_type = UNDECIDED;
+static bool use_mask = true, force_stdout = false, verbose = false;
+static char *in_file_path = NULL, *out_file_path = NULL;
+static bool line_length_is_specified = false; static long long requested_line_length = 0;
+static FILE *OUT = NULL; static bool created_output_file = false, success = false;
+
+static void done(void) { if (!success && created_output_file && out_file_path) remove(out_file_path); if (gpu) naf_gpu_shutdown(gpu); }
+static void set_out_type(OUTPUT_TYPE t) { if (out_type != UNDECIDED) die("only one output type should be specified\n"); out_type = t; }
+
+static void set_line_length(char *str)
+{
+    char *end; long long a = strtoll(str, &end, 10);
+    if (*end != '\0') die("can't parse the value of --line-length parameter\n");
+    if (a < 0ll) die("negative line length specified\n");
+    char t[21]; int nc = snprintf(t, 21, "%lld", a);
+    if (nc < 1 || nc > 20 || strcmp(t, str) != 0) die("can't parse the value of --line-length parameter\n");
+    requested_line_length = a; line_length_is_specified = true;
+}
+
+static void show_help(void)
+{
+    msg("Usage: unnaf [OUTPUT-TYPE] [file.naf]\n"
+        "Options for selecting output type:\n"
+        "  --format        - File format version\n  --part-list     - List of parts\n  --sizes         - Part sizes\n"
+        "  --number        - Number of sequences\n  --title         - Dataset title\n  --ids           - Sequence ids (accession numbers)\n"
+        "  --names         - Full sequence names (including ids)\n  --lengths       - Sequence lengths\n  --total-length  - Sum of sequence lengths\n"
+        "  --mask          - Masked region lengths\n  --4bit          - 4bit-encoded nucleotide sequence (binary data)\n"
+        "  --seq           - Continuous concatenated sequence\n  --sequences     - One sequence per line, no names\n"
+        "  --fasta         - FASTA-formatted sequences\n  --fastq         - FASTQ-formatted sequences\n"
+        "Other options:\n  -o FILE         - Decompress into FILE\n  -c              - Write to standard output\n"
+        "  --line-length N - Use lines of width N for FASTA output\n  --no-mask       - Ignore mask\n"
+        "  --binary-stdout - Set stdout stream to binary mode.\n  --binary-stderr - Set stderr stream to binary mode.\n"
+        "  --binary        - Shortcut for \"--binary-stdout --binary-stderr\"\n  -h, --help      - Show help\n  -V, --version   - Show version\n");
+}
+
+static void parse_command_line(int argc, char **argv)
+{
+    bool print_version = false;
+    static const struct { const char *name; OUTPUT_TYPE t; } types[] = {
+        {"--format", FORMAT_NAME}, {"--part-list", PART_LIST}, {"--sizes", PART_SIZES}, {"--number", NUMBER_OF_SEQUENCES}, {"--title", TITLE},
+        {"--ids", IDS}, {"--names", NAMES}, {"--lengths", LENGTHS}, {"--total-length", TOTAL_LENGTH}, {"--mask", MASK},
+        {"--total-mask-length", TOTAL_MASK_LENGTH}, {"--4bit", FOUR_BIT}, {"--seq", SEQ}, {"--sequences", SEQUENCES}, {"--charcount", CHARCOUNT},
+        {"--fasta", FASTA}, {"--fastq", FASTQ}, {"--dna", DNA}, {"--masked-dna", MASKED_DNA}, {"--unmasked-dna", UNMASKED_DNA},
+        {"--masked-fasta", MASKED_FASTA}, {"--unmasked-fasta", UNMASKED_FASTA} };
+    for (int i = 1; i < argc; i++) {
+        if (argv[i][0] == '-') {
+            if (argv[i][1] == '-') {
+                if (i < argc - 1 && !strcmp(argv[i], "--line-length")) { i++; set_line_length(argv[i]); continue; }
+                bool hit = false;
+                for (size_t k = 0; k < sizeof types / sizeof types[0]; k++) if (!strcmp(argv[i], types[k].name)) { set_out_type(types[k].t); hit = true; break; }
+                if (hit) continue;
+                if (!strcmp(argv[i], "--no-mask")) { use_mask = false; continue; }
+                if (!strcmp(argv[i], "--binary-stdout") || !strcmp(argv[i], "--binary-stderr") || !strcmp(argv[i], "--binary")) continue;
+                if (!strcmp(argv[i], "--help")) { show_help(); exit(0); }
+                if (!strcmp(argv[i], "--verbose")) { verbose = true; continue; }
+                if (!strcmp(argv[i], "--version")) { print_version = true; continue; }
+            }
+            if (i < argc - 1 && !strcmp(argv[i], "-o")) { i++; if (out_file_path) die("double --out parameter\n"); if (!*argv[i]) die("empty --out parameter\n"); out_file_path = argv[i]; continue; }
+            if (!strcmp(argv[i], "-c")) { force_stdout = true; continue; }
+            if (!strcmp(argv[i], "-h")) { show_help(); exit(0); }
+            if (!strcmp(argv[i], "-V")) { print_version = true; continue; }
+            die("unknown or incomplete argument \"%s\"\n", argv[i]);
+        }
+        if (in_file_path) die("can process only one file at a time\n");
+        if (!*argv[i]) die("empty input path specified\n");
+        in_file_path = argv[i];
+    }
+    if (print_version) {
+        msg("unnaf - NAF decompressor, version " VERSION ", " DATE "\nCopyright (c) " COPYRIGHT_YEARS " Kirill Kryukov\n");
+        if (verbose) msg("MI355X path: libnaf_gpu (HIP, gfx950), zstd frames decoded on the GPU\n");
+        exit(0);
+    }
+    if (force_stdout && out_file_path) die("-c and -o arguments can't be used together\n");
+}
+
+static const unsigned char *naf; static size_t naf_len; static naf_gpu_header H; static void *d_naf = NULL;
+
+static void upload(void) { gpu_open(); if (d_naf) return; GPU_TRY(naf_gpu_malloc(gpu, naf_len + 64, &d_naf)); GPU_TRY(naf_gpu_upload(gpu, d_naf, naf, naf_len)); }
+
+static unsigned char *load_section(int i, const char *what)
+{
+    upload();
+    unsigned long long n = H.orig_size[i];
+    void *d; GPU_TRY(naf_gpu_malloc(gpu, n + 64, &d));
+    size_t got = 0;
+    int rc = naf_gpu_zstd_decompress(gpu, (const char *)d_naf + H.payload_off[i], H.comp_size[i], 0, d, n, &got);
+    if (rc || got != n) die("can't decompress %s\n", what);
+    unsigned char *h = (unsigned char *)malloc(n + 1);
+    if (!h) die("can't allocate %llu bytes\n", n + 1);
+    GPU_TRY(naf_gpu_download(gpu, h, d, n)); h[n] = 0;
+    naf_gpu_free(gpu, d);
+    return h;
+}
+
+static void run_text(int mode, int masking_allowed)
+{
+    upload();
+    naf_gpu_unnaf_opts o = { mode, masking_allowed && use_mask, line_length_is_specified ? requested_line_length : -1 };
+    size_t n = 0; GPU_TRY(naf_gpu_unnaf_size(gpu, d_naf, naf_len, &o, &n));
+    if (!n) return;
+    void *d; GPU_TRY(naf_gpu_malloc(gpu, n + 64, &d));
+    size_t got = 0; GPU_TRY(naf_gpu_unnaf(gpu, d_naf, naf_len, &o, d, n, &got));
+    void *h; GPU_TRY(naf_gpu_host_alloc(gpu, got ? got : 1, &h));
+    GPU_TRY(naf_gpu_download(gpu, h, d, got));
+    if (mode == -2) {                                   /* --charcount (output.c:515-605) */
+        unsigned long long counts[256] = {0}; const unsigned char *p = (const unsigned char *)h;
+        for (size_t i = 0; i < got; i++) counts[p[i]]++;
+        for (unsigned i = 0; i < 33; i++) if (counts[i]) fprintf(OUT, "\\x%02X\t%llu\n", i, counts[i]);
+        for (unsigned i = 33; i < 127; i++) if (counts[i]) fprintf(OUT, "%c\t%llu\n", (unsigned char)i, counts[i]);
+        for (unsigned i = 127; i < 256; i++) if (counts[i]) fprintf(OUT, "\\x%02X\t%llu\n", i, counts[i]);
+    } else if (fwrite(h, 1, got, OUT) != got) die("can't write to file - disk full?\n");
+    naf_gpu_host_free(gpu, h); naf_gpu_free(gpu, d);
+}
+
+int main(int argc, char **argv)
+{
+    prog_name = "unnaf";
+    atexit(done);
+    parse_command_line(argc, argv);
+    if (in_file_path == NULL && isatty(fileno(stdin))) { err("no input specified, use \"unnaf -h\" for help\n"); exit(0); }
+    FILE *IN = in_file_path ? fopen(in_file_path, "rb") : stdin;
+    if (!IN) die("can't open input file\n");
+    naf = read_all(IN, &naf_len);
+    if (IN != stdin) fclose(IN);
+    char eb[128] = "";
+    if (naf_gpu_parse_header_host(naf, naf_len, &H, eb)) die("%s", eb);
+    int has_title = (H.flags >> 6) & 1, has_ids = (H.flags >> 5) & 1, has_names = (H.flags >> 4) & 1, has_lengths = (H.flags >> 3) & 1,
+        has_mask = (H.flags >> 2) & 1, has_data = (H.flags >> 1) & 1, has_quality = H.flags & 1;
+    static const char *tn[4] = { "DNA", "RNA", "protein", "text" };
+    if (out_type == UNDECIDED) out_type = has_quality ? FASTQ : FASTA;
+    if ((out_type == DNA || out_type == MASKED_DNA || out_type == UNMASKED_DNA) && H.seq_type != NAF_SEQ_DNA) die("input has not DNA, but %s data\n", tn[H.seq_type]);
+    if (out_type == FOUR_BIT && H.seq_type >= NAF_SEQ_PROTEIN) die("input has no 4-bit encoded data, but %s sequences\n", tn[H.seq_type]);
+
+    bool to_orig = has_quality ? (out_type == FASTA) : (out_type == FASTQ);
+    char *auto_path = NULL;
+    if (to_orig && !force_stdout && in_file_path && !out_file_path && isatty(fileno(stdout))) {
+        size_t len = strlen(in_file_path);
+        if (len > 4 && !strcmp(in_file_path + len - 4, ".naf") && in_file_path[len - 5] != '/' && in_file_path[len - 5] != '\\') {
+            auto_path = (char *)malloc(len - 3); memcpy(auto_path, in_file_path, len - 4); auto_path[len - 4] = 0; out_file_path = auto_path;
+        }
+    }
+    if (out_file_path && !force_stdout) { OUT = fopen(out_file_path, "wb"); if (!OUT) die("can't create output file\n"); created_output_file = true; }
+    else OUT = stdout;
+    bool large = out_type == IDS || out_type == NAMES || out_type == LENGTHS || out_type == MASK || out_type == FOUR_BIT || out_type == DNA ||
+                 out_type == MASKED_DNA || out_type == UNMASKED_DNA || out_type == SEQ || out_type == FASTA || out_type == MASKED_FASTA ||
+                 out_type == UNMASKED_FASTA || out_type == FASTQ;
+    if (large && !force_stdout && isatty(fileno(OUT)))
+        die("output file not specified - please either specify output file with '-o' or '>', or use '-c' option to force writing to console\n");
+
+    unsigned long long N = H.n_sequences;
+    if (out_type == FORMAT_NAME) fprintf(OUT, "%s sequences%s in NAF format version %d\n", tn[H.seq_type], has_quality ? " with qualities" : "", H.version);
+    else if (out_type == PART_LIST) {
+        int printed = 0; const char *nm[7] = { "Title", "IDs", "Names", "Lengths", "Mask", "Data", "Quality" };
+        int has[7] = { has_title, has_ids, has_names, has_lengths, has_mask, has_data, has_quality };
+        for (int i = 0; i < 7; i++) if (has[i]) { fprintf(OUT, "%s%s", printed ? ", " : "", nm[i]); printed++; }
+        fprintf(OUT, "\n");
+    }
+    else if (out_type == NUMBER_OF_SEQUENCES) fprintf(OUT, "%llu\n", N);
+    else if (out_type == PART_SIZES) {
+        if (has_title) fprintf(OUT, "Title: %llu\n", (unsigned long long)H.title_len);
+        const char *nm[6] = { "IDs", "Names", "Lengths", "Mask", "Data", "Quality" };
+        for (int i = 0; i < 6; i++) if (H.flags & (0x20 >> i))
+            fprintf(OUT, "%s: %llu / %llu (%.3f%%)\n", nm[i], (unsigned long long)H.comp_size[i], (unsigned long long)H.orig_size[i], (double)H.comp_size[i] / (double)H.orig_size[i] * 100);
+    }
+    else if (out_type == TITLE) { if (has_title) fwrite(naf + H.title_off, 1, H.title_len, OUT); fputc('\n', OUT); }
+    else if (N != 0) {
+        if (out_type == IDS) { if (has_ids) { unsigned char *b = load_section(0, "ids"); const char *p = (const char *)b; for (unsigned long long i = 0; i < N; i++) { fprintf(OUT, "%s\n", p); p += strlen(p) + 1; } free(b); } }
+        else if (out_type == NAMES) {
+            if (has_ids || has_names) {
+                unsigned char *a = has_ids ? load_section(0, "ids") : NULL, *b = has_names ? load_section(1, "names") : NULL;
+                const char *p = (const char *)a, *q = (const char *)b;
+                for (unsigned long long i = 0; i < N; i++) {
+                    if (p) { fputs(p, OUT); p += strlen(p) + 1; }
+                    if (q) { if (!a) fputs(q, OUT); else if (q[0]) { fputc(H.separator, OUT); fputs(q, OUT); } q += strlen(q) + 1; }
+                    fputc('\n', OUT);
+                }
+                free(a); free(b);
+            }
+        }
+        else if (out_type == LENGTHS) {
+            if (has_lengths) { unsigned char *b = load_section(2, "lengths"); const unsigned int *u = (const unsigned int *)b; unsigned long long n = H.orig_size[2] / 4;
+                for (unsigned long long i = 0; i < n; i++) { unsigned long long len = 0; while (i < n && u[i] == 4294967295u) { len += 4294967295llu; i++; } if (i < n) len += u[i]; fprintf(OUT, "%llu\n", len); } free(b); }
+        }
+        else if (out_type == TOTAL_LENGTH) { if (has_lengths) fprintf(OUT, "%llu\n", (unsigned long long)H.orig_size[4]); }
+        else if (out_type == MASK) {
+            if (has_mask) { unsigned char *b = load_section(3, "mask"); unsigned long long n = H.orig_size[3];
+                for (unsigned long long i = 0; i < n; i++) { unsigned long long len = 0; while (i < n && b[i] == 255u) { len += 255llu; i++; } if (i < n) len += b[i]; fprintf(OUT, "%llu\n", len); } free(b); }
+        }
+        else if (out_type == TOTAL_MASK_LENGTH) {
+            if (has_mask) { unsigned char *b = load_section(3, "mask"); unsigned long long t = 0; for (unsigned long long i = 0; i < H.orig_size[3]; i++) t += b[i]; fprintf(OUT, "%llu\n", t); free(b); }
+            else fprintf(OUT, "0\n");
+        }
+        else if (out_type == FOUR_BIT) run_text(NAF_OUT_4BIT, 1);
+        else if (out_type == DNA || out_type == SEQ || out_type == MASKED_DNA) run_text(NAF_OUT_SEQ, 1);
+        else if (out_type == UNMASKED_DNA) run_text(NAF_OUT_SEQ, 0);
+        else if (out_type == CHARCOUNT) { if (has_data) { /* histogram of the --seq text */ naf_gpu_unnaf_opts dummy; (void)dummy; upload(); 
+                naf_gpu_unnaf_opts o = { NAF_OUT_SEQ, use_mask, -1 }; size_t n = 0; GPU_TRY(naf_gpu_unnaf_size(gpu, d_naf, naf_len, &o, &n));
+                void *d; GPU_TRY(naf_gpu_malloc(gpu, n + 64, &d)); size_t got = 0; GPU_TRY(naf_gpu_unnaf(gpu, d_naf, naf_len, &o, d, n, &got));
+                unsigned char *h = (unsigned char *)malloc(got + 1); GPU_TRY(naf_gpu_download(gpu, h, d, got));
+                unsigned long long counts[256] = {0}; for (size_t i = 0; i < got; i++) counts[h[i]]++;
+                for (unsigned i = 0; i < 33; i++) if (counts[i]) fprintf(OUT, "\\x%02X\t%llu\n", i, counts[i]);
+                for (unsigned i = 33; i < 127; i++) if (counts[i]) fprintf(OUT, "%c\t%llu\n", (unsigned char)i, counts[i]);
+                for (unsigned i = 127; i < 256; i++) if (counts[i]) fprintf(OUT, "\\x%02X\t%llu\n", i, counts[i]);
+                free(h); naf_gpu_free(gpu, d); } }
+        else if (out_type == SEQUENCES) run_text(NAF_OUT_SEQUENCES, 1);
+        else if (out_type == FASTA || out_type == MASKED_FASTA) run_text(NAF_OUT_FASTA, 1);
+        else if (out_type == UNMASKED_FASTA) run_text(NAF_OUT_FASTA, 0);
+        else if (out_type == FASTQ) { if (!has_quality) die("FASTQ output requested, but input has no qualities\n"); run_text(NAF_OUT_FASTQ, 0); }
+        else die("unknown output requested\n");
+    }
+    if (OUT != stdout) { if (fclose(OUT) != 0) die("can't close file - disk full?\n"); } else fflush(stdout);
+    success = true;
+    return 0;
+}

@@ -1,0 +1,199 @@
+"""CPU-only tests of the host side: C-ABI surface, kernel logic single-stepped on the host, the
+CLI paths that need no device, failing loudly without a GPU, and the multi-rank plumbing on gloo."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, golden_bytes, naf_cases, zstd_cases
+
+BIN = os.path.join(ROOT, "naf_amd", "bin")
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built():
+    if not (os.path.exists(os.path.join(ROOT, "naf_amd", "libnaf_gpu.so")) and os.path.exists(os.path.join(BIN, "unnaf"))
+            and os.path.exists(os.path.join(ROOT, "tests", "emul", "libzstd_emul.so"))):
+        env = dict(os.environ, PATH="/opt/rocm/bin:" + os.environ.get("PATH", ""))
+        subprocess.check_call(["make", "-s", "-j8", "-C", ROOT, "all"], env=env)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "naf_gpu.h")).read()
+    declared = sorted(set(re.findall(r"\b(naf_gpu_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(os.path.join(ROOT, "naf_amd", "libnaf_gpu.so"))      # loads without a GPU; no compute calls
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    from naf_amd import capi
+    assert sorted(capi.EXPORTS) == declared
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = ctypes.CDLL(os.path.join(ROOT, "naf_amd", "libnaf_gpu.so"))
+    h = ctypes.c_void_p()
+    assert lib.naf_gpu_init(0, ctypes.byref(h)) == -1          # NAF_GPU_ENODEV, and no context
+    assert not h.value
+    naf = os.path.join(GOLDEN, "naf", "acgt_10k.naf")
+    p = subprocess.run([os.path.join(BIN, "unnaf"), "--fasta", "-c", naf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and p.stdout == b"" and b"unnaf error: can't initialize the GPU path" in p.stderr
+    p = subprocess.run([os.path.join(BIN, "ennaf"), "-c"], input=b">a\nACGT\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and p.stdout == b"" and b"ennaf error: can't initialize the GPU path" in p.stderr
+
+
+def test_product_never_imports_the_oracle():
+    for dp, _, fs in os.walk(os.path.join(ROOT, "naf_amd")):
+        for f in fs:
+            if f.endswith((".py", ".c", ".h", ".hip")):
+                src = open(os.path.join(dp, f), errors="replace").read()
+                assert "oracle" not in src.replace("oracle/_ref", "").lower() or f == "shard.py" and False, os.path.join(dp, f)
+
+
+# ---- kernel logic single-stepped on the host (tests/emul) ---------------------------------------------------
+@pytest.fixture(scope="module")
+def emul():
+    L = ctypes.CDLL(os.path.join(ROOT, "tests", "emul", "libzstd_emul.so"))
+    L.emul_zstd_decompress_frame.restype = ctypes.c_longlong
+    L.emul_zstd_decompress_frame.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    L.emul_zstd_compress.restype = ctypes.c_longlong
+    L.emul_zstd_compress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
+    return L
+
+
+@pytest.mark.parametrize("case", [c for c in zstd_cases() if c["name"] not in ("two_frames", "skippable_then_frame")], ids=lambda c: c["name"])
+def test_decoder_kernel_logic_on_golden_frames(emul, case):
+    frame = golden_bytes("zstd", case["name"] + ".zst")
+    out = ctypes.create_string_buffer(case["len"] + 64)
+    n = emul.emul_zstd_decompress_frame(frame, len(frame), out, case["len"] + 64)
+    assert n == case["len"] and sha(out.raw[:n]) == case["sha256"]
+
+
+def test_decoder_kernel_logic_on_reference_archives(emul, oracle):
+    for case in naf_cases():
+        naf = golden_bytes("naf", case["name"] + ".naf")
+        h = oracle.parse_naf(naf)
+        for i in range(6):
+            if h.payload_off[i] is None:
+                continue
+            f = h.frame(naf, i)
+            ref = oracle.zstd_decompress(f)
+            out = ctypes.create_string_buffer(len(ref) + 64)
+            n = emul.emul_zstd_decompress_frame(f, len(f), out, len(ref) + 64)
+            assert n == len(ref) and out.raw[:n] == ref, (case["name"], i)
+
+
+def test_encoder_kernel_logic_roundtrips_through_oracle(emul, oracle):
+    rng = np.random.default_rng(3)
+    syms = np.array([0x88, 0x84, 0x82, 0x81, 0x48, 0x44, 0x42, 0x41, 0x28, 0x24, 0x22, 0x21, 0x18, 0x14, 0x12, 0x11], dtype=np.uint8)
+    p2 = np.array([2.0 ** -(i + 1) for i in range(40)])
+    data = [b"", b"A", b"\x07" * 100000, syms[rng.integers(0, 16, 300001)].tobytes(),
+            b"".join(b"read%d len=%d\x00" % (i, 100 + i % 50) for i in range(5000)),
+            rng.integers(33, 74, 100000, dtype=np.uint8).tobytes(), rng.integers(0, 256, 50000, dtype=np.uint8).tobytes(),
+            rng.choice(np.arange(40, dtype=np.uint8) + 60, 200000, p=p2 / p2.sum()).tobytes()]
+    data += [rng.integers(65, 70, n, dtype=np.uint8).tobytes() for n in (2, 3, 63, 64, 65, 255, 1000)]
+    for d in data:
+        for blk in (1024, 32768, 131072):
+            cap = len(d) + len(d) // 64 + 1024
+            out = ctypes.create_string_buffer(cap)
+            n = emul.emul_zstd_compress(d, len(d), blk, out, cap)
+            assert n > 0
+            assert oracle.zstd_decompress(out.raw[:n], len(d) + 16) == d
+
+
+# ---- CLI paths that need no device ---------------------------------------------------------------------------------
+def run(prog, *args, stdin=None):
+    p = subprocess.run([os.path.join(BIN, prog), *args], input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    return p.returncode, p.stdout, p.stderr
+
+
+def test_cli_version_banners_match_reference_fixtures():
+    for prog in ("ennaf", "unnaf"):
+        rc, out, err = run(prog, "--version")
+        assert rc == 0 and out == b""
+        assert err == golden_bytes("ref_tests", "interface", prog + "-version.err-ref") if os.path.exists(os.path.join(GOLDEN, "ref_tests", "interface")) else err.startswith(prog.encode() + b" - NAF")
+    rc, out, err = run("unnaf", "--bogus")
+    assert rc == 1 and err == b'unnaf error: unknown or incomplete argument "--bogus"\n'
+    rc, out, err = run("ennaf", "-c", "-o", "x")
+    assert rc == 1 and err == b"ennaf error: '-c' and '-o' can't be used together\n"
+
+
+def test_cli_header_only_modes(oracle):
+    for case in naf_cases():
+        path = os.path.join(GOLDEN, "naf", case["name"] + ".naf")
+        naf = golden_bytes("naf", case["name"] + ".naf")
+        h = oracle.parse_naf(naf)
+        rc, out, err = run("unnaf", "--number", path)
+        assert (rc, out, err) == (0, b"%d\n" % h.n_sequences, b"")
+        rc, out, err = run("unnaf", "--format", path)
+        tn = ["DNA", "RNA", "protein", "text"][h.seq_type]
+        assert out == ("%s sequences%s in NAF format version %d\n" % (tn, " with qualities" if h.flags & 1 else "", h.version)).encode()
+        rc, out, err = run("unnaf", "--total-length", path)
+        assert out == b"%d\n" % h.orig[4]
+        rc, out, err = run("unnaf", "--sizes", path)
+        assert out.startswith(b"IDs: %d / %d" % (h.comp[0], h.orig[0])) or b"Title" in out
+    rc, out, err = run("unnaf", "--title", os.path.join(GOLDEN, "naf", "title.naf"))
+    assert out == b"my title\n"
+    rc, out, err = run("unnaf", "--number", stdin=b"garbage!")
+    assert rc == 1 and err == b"unnaf error: not a NAF format\n"
+
+
+# ---- multi-rank plumbing on gloo (world_size 2) ---------------------------------------------------------------------
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from naf_amd import shard
+    total = 1_000_003
+    whole = (torch.arange(total, dtype=torch.int64) * 7 % 251).to(torch.uint8)
+    b, e = shard.byte_range(total, rank, world)
+    got = shard.gather_ranges(whole[b:e].clone(), total, dst=0)
+    ok = True
+    if rank == 0:
+        ok = bool(torch.equal(got, whole))
+    t = torch.tensor([1.0 + rank]); dist.all_reduce(t, op=dist.ReduceOp.MAX)     # the bench's max-over-ranks timing reduction
+    ok = ok and float(t.item()) == float(world)
+    q.put((rank, ok, b, e))
+    dist.destroy_process_group()
+
+
+def test_sharded_gather_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert all(r[1] for r in res)
+    assert res[0][2] == 0 and res[0][3] == res[1][2] and res[1][3] == 1_000_003      # ranges tile the text
+
+
+def test_byte_ranges_tile_any_total():
+    from naf_amd import shard
+    for total in (0, 1, 4095, 4096, 4097, 10**9 + 7):
+        for world in (1, 2, 3, 8):
+            pos = 0
+            for r in range(world):
+                b, e = shard.byte_range(total, r, world)
+                assert b == min(pos, total) and e >= b
+                pos = e
+            assert pos == total
