@@ -255,92 +255,107 @@ __device__ __forceinline__ u64 low_bytes_mask(int n)           // n in [0,8] -> 
     return n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1);
 }
 
+// One workgroup produces EMIT_SPAN consecutive output bytes as EMIT_SPAN/4096 tiles of 256 lanes x 16 B.
+// The record window [rlo, rhi] and the toggle window [klo, khi] are found once per span (they need dependent
+// binary-search loads); inside the span a lane keeps its current record's geometry in registers and only
+// searches again when a chunk leaves that record.
+#define EMIT_SPAN (64u * 1024u)
 template <bool FOURBIT>
 __global__ __launch_bounds__(256) void k_emit(EmitP P, u8 *out)
 {
-    __shared__ u64 sh[4];                                       // rlo, rhi, klo, khi for this workgroup
-    u64 wg_first = P.out_begin + (u64)blockIdx.x * 4096, wg_last = wg_first + 4095;
-    if (wg_last >= P.out_end) wg_last = P.out_end - 1;
+    __shared__ u64 sh[4];                                       // rlo, rhi, klo, khi for this span
+    u64 span_first = P.out_begin + (u64)blockIdx.x * EMIT_SPAN, span_last = span_first + EMIT_SPAN - 1;
+    if (span_last >= P.out_end) span_last = P.out_end - 1;
     if (threadIdx.x < 2 && P.mode != EM_SEQ) {
-        u64 p = threadIdx.x == 0 ? wg_first : wg_last;
+        u64 p = threadIdx.x == 0 ? span_first : span_last;
         sh[threadIdx.x] = upper_bound_u64(P.rec_out, 0, P.N + 1, p) - 1;
     }
     __syncthreads();
     if (threadIdx.x < 2) {
-        // toggle window: all toggles that can affect bases of records rlo..rhi inside this workgroup
-        u64 g;
-        if (P.mode == EM_SEQ) g = threadIdx.x == 0 ? wg_first : wg_last + 1;
-        else g = threadIdx.x == 0 ? P.rec_base[sh[0]] : P.rec_base[sh[1] + 1];
-        if (P.mode != EM_SEQ && threadIdx.x == 0) {
-            // tighten the lower bound: first base this workgroup can touch inside record rlo
-            u64 r = sh[0], off = wg_first - P.rec_out[r], hl = P.hdr_len[r];
-            if (off > hl) { u64 q = off - hl; u64 j = (P.mode == EM_FASTA && P.L) ? (q / (P.L + 1)) * P.L : (P.mode == EM_FASTQ ? 0 : q); if (j > P.rec_len[r]) j = P.rec_len[r]; g += j; }
+        u64 k = 0;
+        if (P.masking) {
+            // toggle window: every toggle that can affect a base this span touches
+            u64 g;
+            if (P.mode == EM_SEQ) g = threadIdx.x == 0 ? span_first : span_last + 1;
+            else g = threadIdx.x == 0 ? P.rec_base[sh[0]] : P.rec_base[sh[1] + 1];
+            if (P.mode != EM_SEQ && threadIdx.x == 0) {
+                // tighten the lower bound: first base the span can touch inside record rlo
+                u64 r = sh[0], off = span_first - P.rec_out[r], hl = P.hdr_len[r];
+                if (off > hl) { u64 q = off - hl; u64 j = (P.mode == EM_FASTA && P.L) ? (q / (P.L + 1)) * P.L : (P.mode == EM_FASTQ ? 0 : q); if (j > P.rec_len[r]) j = P.rec_len[r]; g += j; }
+            }
+            k = upper_bound_u64(P.toggles, 0, P.n_toggles, g);
         }
-        u64 k = P.masking ? upper_bound_u64(P.toggles, 0, P.n_toggles, g) : 0;
-        // lower bound keeps parity information: klo must be even-aligned count of toggles <= g (we keep absolute indices)
         sh[2 + threadIdx.x] = k;
     }
     __syncthreads();
-    u64 rlo = sh[0], rhi = sh[1], klo = sh[2], khi = sh[3];
-    // absolute-index searches inside [klo, khi] preserve parity because upper_bound returns absolute counts
-    u64 p0 = wg_first + (u64)threadIdx.x * 16;
-    if (p0 >= P.out_end) return;
-    u8 *o = out + (p0 - P.out_begin);
-    u32 nbytes = P.out_end - p0 < 16 ? (u32)(P.out_end - p0) : 16;
+    const u64 rlo = sh[0], rhi = sh[1], klo = sh[2], khi = sh[3];
+    const bool any_toggle = P.masking && klo < khi;
+    // cached geometry of the lane's current record
+    u64 c_ro = 1, c_rn = 0, c_body = 0, c_len = 0, c_base = 0;
 
-    bool fast = false; u64 g0 = 0, len = 0, j0 = 0; int nl_b = 64; bool qual_copy = false; u64 qoff = 0;
-    if (nbytes == 16 && !P.force_slow) {
-        if (P.mode == EM_SEQ) { fast = true; g0 = p0; len = ~0ull; j0 = 0; }
-        else {
-            u64 r = upper_bound_u64(P.rec_out, rlo, rhi + 1, p0) - 1;
-            u64 body = P.rec_out[r] + P.hdr_len[r], next = P.rec_out[r + 1];
-            if (p0 >= body && p0 + 16 <= next) {
-                u64 q0 = p0 - body; len = P.rec_len[r];
-                if (P.mode == EM_FASTQ) {
-                    if (q0 + 16 <= len) { fast = true; j0 = q0; g0 = P.rec_base[r] + j0; len = ~0ull; }
-                    else if (q0 >= len + 3 && q0 + 16 <= 2 * len + 3) { qual_copy = true; qoff = P.rec_base[r] + (q0 - len - 3); }
-                } else if (P.mode == EM_SEQUENCES || P.L == 0) { fast = true; j0 = q0; g0 = P.rec_base[r] + j0; }
-                else if (P.L >= 16) {
-                    u64 line = q0 / (P.L + 1), col = q0 - line * (P.L + 1);
-                    j0 = line * P.L + col; g0 = P.rec_base[r] + j0;
-                    u64 d = P.L - col;                         // byte index of the line-end newline
-                    nl_b = d < 16 ? (int)d : 64;
-                    fast = true;
+    for (u64 tile = span_first; tile <= span_last; tile += 4096) {
+        u64 p0 = tile + (u64)threadIdx.x * 16;
+        if (p0 >= P.out_end) break;
+        u8 *o = out + (p0 - P.out_begin);
+        u32 nbytes = P.out_end - p0 < 16 ? (u32)(P.out_end - p0) : 16;
+        bool fast = false, qual_copy = false; u64 g0 = 0, len = 0, j0 = 0, qoff = 0; int nl_b = 64;
+        if (nbytes == 16 && !P.force_slow) {
+            if (P.mode == EM_SEQ) { fast = true; g0 = p0; len = ~0ull; }
+            else {
+                if (!(p0 >= c_ro && p0 < c_rn)) {
+                    u64 r = upper_bound_u64(P.rec_out, rlo, rhi + 1, p0) - 1;
+                    c_ro = P.rec_out[r]; c_rn = P.rec_out[r + 1]; c_body = c_ro + P.hdr_len[r]; c_len = P.rec_len[r]; c_base = P.rec_base[r];
+                }
+                if (p0 >= c_body && p0 + 16 <= c_rn) {
+                    u64 q0 = p0 - c_body; len = c_len;
+                    if (P.mode == EM_FASTQ) {
+                        if (q0 + 16 <= len) { fast = true; j0 = q0; g0 = c_base + j0; len = ~0ull; }
+                        else if (q0 >= len + 3 && q0 + 16 <= 2 * len + 3) { qual_copy = true; qoff = c_base + (q0 - len - 3); }
+                    } else if (P.mode == EM_SEQUENCES || P.L == 0) { fast = true; j0 = q0; g0 = c_base + j0; }
+                    else if (P.L >= 16) {
+                        u64 line, col;
+                        if ((q0 >> 32) == 0 && (P.L >> 31) == 0) { u32 d = (u32)P.L + 1, l32 = (u32)q0 / d; line = l32; col = (u32)q0 - l32 * d; }
+                        else { line = q0 / (P.L + 1); col = q0 - line * (P.L + 1); }
+                        j0 = line * P.L + col; g0 = c_base + j0;
+                        u64 d = P.L - col;                      // byte index of the line-end newline
+                        nl_b = d < 16 ? (int)d : 64;
+                        fast = true;
+                    }
                 }
             }
         }
-    }
-    if (qual_copy) { st64(o, ld64(P.qual + qoff)); st64(o + 8, ld64(P.qual + qoff + 8)); return; }
-    if (fast) {
-        u64 lo, hi;
-        bases16<FOURBIT>(P, g0, lo, hi);
-        if (P.masking) {
-            u64 k = upper_bound_u64(P.toggles, klo, khi, g0);  // toggles <= g0
-            u32 state = (u32)(k & 1), m16 = 0; u64 pos = g0;
-            // walk the toggles that fall inside (g0, g0+16)
-            for (;;) {
-                u64 nxt = k < khi ? P.toggles[k] : ~0ull;
-                u64 end = nxt < g0 + 16 ? nxt : g0 + 16;
-                if (state && end > pos) m16 |= (u32)(((1u << (end - pos)) - 1) << (pos - g0));
-                if (nxt >= g0 + 16) break;
-                pos = nxt; state ^= 1; k++;
+        if (qual_copy) { uint4 v; memcpy(&v, P.qual + qoff, 16); memcpy(o, &v, 16); continue; }
+        if (fast) {
+            u64 lo, hi;
+            bases16<FOURBIT>(P, g0, lo, hi);
+            if (any_toggle) {
+                u64 k = upper_bound_u64(P.toggles, klo, khi, g0);  // toggles <= g0
+                u32 state = (u32)(k & 1), m16 = 0; u64 pos = g0;
+                for (;;) {                                      // walk the toggles that fall inside (g0, g0+16)
+                    u64 nxt = k < khi ? P.toggles[k] : ~0ull;
+                    u64 end = nxt < g0 + 16 ? nxt : g0 + 16;
+                    if (state && end > pos) m16 |= (u32)(((1u << (end - pos)) - 1) << (pos - g0));
+                    if (nxt >= g0 + 16) break;
+                    pos = nxt; state ^= 1; k++;
+                }
+                lo += spread_bits8(m16 & 0xFF); hi += spread_bits8(m16 >> 8);
+            } else if (P.masking && (klo & 1)) { lo += 0x2020202020202020ull; hi += 0x2020202020202020ull; }   // whole span inside one masked run
+            if (nl_b < 16) {
+                // bytes < nl_b keep, byte nl_b = '\n', bytes > nl_b take the previous base
+                u64 slo = lo << 8, shi = (hi << 8) | (lo >> 56);
+                u64 mlo = low_bytes_mask(nl_b), mhi = nl_b > 8 ? low_bytes_mask(nl_b - 8) : 0;
+                u64 m1lo = low_bytes_mask(nl_b + 1), m1hi = nl_b + 1 > 8 ? low_bytes_mask(nl_b + 1 - 8) : 0;
+                lo = (lo & mlo) | (slo & ~m1lo); hi = (hi & mhi) | (shi & ~m1hi);
+                if (nl_b < 8) lo |= (u64)'\n' << (8 * nl_b); else hi |= (u64)'\n' << (8 * (nl_b - 8));
             }
-            lo += spread_bits8(m16 & 0xFF); hi += spread_bits8(m16 >> 8);
+            u64 j15 = j0 + 15 - (15 > nl_b ? 1 : 0);
+            if (j15 >= len) hi = (hi & 0x00FFFFFFFFFFFFFFull) | ((u64)'\n' << 56);     // record-end newline
+            uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
+            memcpy(o, &v, 16);
+            continue;
         }
-        if (nl_b < 16) {
-            // bytes < nl_b keep, byte nl_b = '\n', bytes > nl_b take the previous base
-            u64 slo = lo << 8, shi = (hi << 8) | (lo >> 56);
-            u64 mlo = low_bytes_mask(nl_b), mhi = nl_b > 8 ? low_bytes_mask(nl_b - 8) : 0;
-            u64 m1lo = low_bytes_mask(nl_b + 1), m1hi = nl_b + 1 > 8 ? low_bytes_mask(nl_b + 1 - 8) : 0;
-            lo = (lo & mlo) | (slo & ~m1lo); hi = (hi & mhi) | (shi & ~m1hi);
-            if (nl_b < 8) lo |= (u64)'\n' << (8 * nl_b); else hi |= (u64)'\n' << (8 * (nl_b - 8));
-        }
-        u64 j15 = j0 + 15 - (15 > nl_b ? 1 : 0);
-        if (j15 >= len) hi = (hi & 0x00FFFFFFFFFFFFFFull) | ((u64)'\n' << 56);     // record-end newline
-        st64(o, lo); st64(o + 8, hi);
-        return;
+        for (u32 b = 0; b < nbytes; b++) o[b] = (u8)emit_byte<FOURBIT>(P, p0 + b, rlo, rhi, klo, khi);
     }
-    for (u32 b = 0; b < nbytes; b++) o[b] = (u8)emit_byte<FOURBIT>(P, p0 + b, rlo, rhi, klo, khi);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -617,7 +632,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         pl.P.qual = q;
     }
     pl.P.out_begin = out_begin; pl.P.out_end = out_end;
-    u32 grid = cdiv(out_end - out_begin, 4096);
+    u32 grid = cdiv(out_end - out_begin, EMIT_SPAN);
     if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit<true>, grid, 256, 0, pl.P, d_out);
     else LAUNCH(c, "unnaf_emit", k_emit<false>, grid, 256, 0, pl.P, d_out);
     HIP_TRY(c, hipGetLastError());

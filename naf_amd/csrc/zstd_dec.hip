@@ -328,15 +328,28 @@ __global__ void k_seq_flag(const ZBlock *blk, u32 nblk, u64 *flag)
 }
 
 // ---- Huffman literals: one lane per stream, 16 blocks per 64-lane workgroup, tables staged in LDS ----------
+// Both sides of every stream go through LDS so that each lane's ~4.5 B/symbol-group trickle becomes whole
+// 64-byte sectors on the memory side (64 lanes walk 64 streams that are KiB apart: per-lane 8-byte global
+// accesses re-fetch every sector ~8 times once 2048 streams per CU overflow the 32 KiB L1):
+//   input : per-lane circular window of two 64-byte sectors in LDS; the next lower sector is loaded into
+//           registers one round (32 symbols) before it is committed to LDS, so its latency is hidden
+//   output: per-lane 32-byte LDS row per round, written out by lane pairs with 16-byte stores
+// Tables with codes longer than 7 bits (a round could cross more than one sector) use the register-prefetch
+// reader instead.
 #define HUF_BLOCKS_PER_WG 16
+#define HUF_ROUND 32                       // symbols per lane per round
+#define HUF_OROW 40                        // output row pitch (32 + 8)
+#define HUF_IROW 136                       // input window pitch (128 + 8)
 __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf,
                                                       const u8 *pool, u32 slot_bytes, u8 *dst, u8 *lit_scratch, ZStat *st)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
+    u8 *orows = lds + HUF_BLOCKS_PER_WG * slot_bytes;                // 64 x 40 B
+    u64 *row_out = (u64 *)(orows + 64 * HUF_OROW);                   // per-row global destination (0 = idle lane)
+    u8 *irows = (u8 *)(row_out + 64);                                 // 64 x 136 B
     int lane = threadIdx.x;
     u32 b0 = blockIdx.x * HUF_BLOCKS_PER_WG;
-    // stage the table in force for each of the 16 blocks (16-byte pieces, all 64 lanes cooperate)
-    for (u32 j = 0; j < HUF_BLOCKS_PER_WG; j++) {
+    for (u32 j = 0; j < HUF_BLOCKS_PER_WG; j++) {                     // stage the table in force for each block
         u32 bi = b0 + j;
         if (bi >= nblk) break;
         const ZBlock &b = blk[bi];
@@ -348,33 +361,145 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
         uint4 *l = (uint4 *)(lds + j * slot_bytes);
         for (u32 k = lane; k < bytes / 16; k += 64) l[k] = g[k];
     }
-    __syncthreads();
+    // per-lane stream set-up
     u32 j = lane >> 2, s = lane & 3, bi = b0 + j;
-    if (bi >= nblk) return;
-    const ZBlock &b = blk[bi];
-    if (b.btype != BT_COMP || b.lit_type < LIT_HUF || b.err) return;
-    i32 ob = own_huf[bi];
-    if (ob < 0) { if (s == 0) set_err(st, ZE_CORRUPT); return; }     // treeless without a previous table
-    u32 log = blk[ob].huf_log;
-    const u16 *tab = (const u16 *)(lds + j * slot_bytes);
-    const u8 *c = src + b.src_off + b.huf_streams_off;
-    u8 *out = (b.nseq == 0 ? dst : lit_scratch) + b.out_off;
-    u32 regen = b.lit_regen;
-    u8 e;
-    if (b.nstreams == 1) {
-        if (s != 0) return;
-        e = huf_decode_stream(c, b.huf_streams_size, tab, log, out, regen);
-    } else {
-        u32 s1 = ld16(c), s2 = ld16(c + 2), s3 = ld16(c + 4), tot = b.huf_streams_size - 6;
-        if (s1 + s2 + s3 >= tot || !s1 || !s2 || !s3) { if (s == 0) set_err(st, ZE_CORRUPT); return; }
-        u32 per = (regen + 3) / 4;
-        if (per * 3 > regen) { if (s == 0) set_err(st, ZE_CORRUPT); return; }
-        u32 off = s == 0 ? 0 : (s == 1 ? s1 : (s == 2 ? s1 + s2 : s1 + s2 + s3));
-        u32 sz = s == 0 ? s1 : (s == 1 ? s2 : (s == 2 ? s3 : tot - s1 - s2 - s3));
-        u32 n = s < 3 ? per : regen - 3 * per;
-        e = huf_decode_stream(c + 6 + off, sz, tab, log, out + s * per, n);
+    bool valid = false; u32 log = 1, n = 0; u8 *out = nullptr; const u16 *tab = (const u16 *)lds;
+    BitR br; br.consumed = 64; br.c = 0; br.ptr = br.start = src; br.bad = false;
+    u8 err = 0;
+    if (bi < nblk) {
+        const ZBlock &b = blk[bi];
+        if (b.btype == BT_COMP && b.lit_type >= LIT_HUF && !b.err) {
+            i32 ob = own_huf[bi];
+            if (ob < 0) { if (s == 0) err = ZE_CORRUPT; }                // treeless without a previous table
+            else {
+                log = blk[ob].huf_log; tab = (const u16 *)(lds + j * slot_bytes);
+                const u8 *c = src + b.src_off + b.huf_streams_off;
+                u8 *o = (b.nseq == 0 ? dst : lit_scratch) + b.out_off;
+                u32 regen = b.lit_regen;
+                if (b.nstreams == 1) {
+                    if (s == 0) { valid = true; n = regen; out = o; bitr_init(br, c, b.huf_streams_size); }
+                } else {
+                    u32 s1 = ld16(c), s2 = ld16(c + 2), s3 = ld16(c + 4), tot = b.huf_streams_size - 6, per = (regen + 3) / 4;
+                    if (s1 + s2 + s3 >= tot || !s1 || !s2 || !s3 || per * 3 > regen) { if (s == 0) err = ZE_CORRUPT; }
+                    else {
+                        u32 off = s == 0 ? 0 : (s == 1 ? s1 : (s == 2 ? s1 + s2 : s1 + s2 + s3));
+                        u32 sz = s == 0 ? s1 : (s == 1 ? s2 : (s == 2 ? s3 : tot - s1 - s2 - s3));
+                        valid = true; n = s < 3 ? per : regen - 3 * per; out = o + s * per;
+                        bitr_init(br, c + 6 + off, sz);
+                    }
+                }
+                if (valid && br.bad) { valid = false; err = ZE_CORRUPT; }
+            }
+        }
     }
-    if (e) set_err(st, e);
+    row_out[lane] = valid ? (u64)out : 0;
+    u32 my_rounds = valid ? n / HUF_ROUND : 0xFFFFFFFFu;                 // wave-uniform round count
+    for (int d = 32; d; d >>= 1) { u32 o = (u32)__shfl_xor((int)my_rounds, d, 64); my_rounds = o < my_rounds ? o : my_rounds; }
+    u32 rounds = my_rounds == 0xFFFFFFFFu ? 0 : my_rounds;
+    bool wide = __all(!valid || log <= 7);
+    __syncthreads();
+    u8 *orow = orows + lane * HUF_OROW;
+    u32 R = 0;
+    if (wide) {
+        // ---- sector-window reader -------------------------------------------------------------------------
+        u8 *irow = irows + lane * HUF_IROW;
+        const u32 rbytes = 28;                                            // 32 symbols x 7 bits
+        bool live = valid && (u64)(br.ptr - br.start) >= 192;
+        u64 gp = (u64)br.ptr, lo = 0;
+        uint4 st0, st1, st2, st3; bool pending = false;
+        st0 = st1 = st2 = st3 = make_uint4(0, 0, 0, 0);
+        if (live) {
+            u64 top = (gp + 7) & ~63ull;                                  // sector holding the last container byte
+            lo = top - 64;
+            const uint4 *g0 = (const uint4 *)lo;
+#pragma unroll
+            for (int q = 0; q < 8; q++) { uint4 v = g0[q]; u32 o = (u32)((lo + 16 * q) & 127); *(u64 *)(irow + o) = (u64)v.x | ((u64)v.y << 32); *(u64 *)(irow + o + 8) = (u64)v.z | ((u64)v.w << 32); }
+        }
+        for (; R < rounds; R++) {
+            if (!__all(!valid || (live && gp - (u64)br.start >= 160))) break;   // near a stream start: generic reader finishes
+            if (valid) {
+                if (pending) {                                            // commit the sector fetched during the previous round
+                    lo -= 64; u32 o = (u32)(lo & 127);
+                    *(u64 *)(irow + o) = (u64)st0.x | ((u64)st0.y << 32); *(u64 *)(irow + o + 8) = (u64)st0.z | ((u64)st0.w << 32);
+                    *(u64 *)(irow + o + 16) = (u64)st1.x | ((u64)st1.y << 32); *(u64 *)(irow + o + 24) = (u64)st1.z | ((u64)st1.w << 32);
+                    *(u64 *)(irow + o + 32) = (u64)st2.x | ((u64)st2.y << 32); *(u64 *)(irow + o + 40) = (u64)st2.z | ((u64)st2.w << 32);
+                    *(u64 *)(irow + o + 48) = (u64)st3.x | ((u64)st3.y << 32); *(u64 *)(irow + o + 56) = (u64)st3.z | ((u64)st3.w << 32);
+                    pending = false;
+                }
+                if (lo + 2 * rbytes > gp) {                               // the round after this one may read below `lo`
+                    const uint4 *g0 = (const uint4 *)(lo - 64);
+                    st0 = g0[0]; st1 = g0[1]; st2 = g0[2]; st3 = g0[3]; pending = true;
+                }
+#pragma unroll
+                for (u32 g = 0; g < HUF_ROUND / 8; g++) {
+                    u32 k = br.consumed >> 3;
+                    if (k) {                                              // refill the container from the LDS window
+                        gp -= k; br.consumed &= 7;
+                        u32 o = (u32)(gp & 127), sh = (o & 7) * 8;
+                        u64 q0 = *(const u64 *)(irow + (o & ~7u)), q1 = *(const u64 *)(irow + (((o & ~7u) + 8) & 127));
+                        br.c = sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0;
+                    }
+                    *(u64 *)(orow + g * 8) = huf_decode8(br, tab, log);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (u32 jj = 0; jj < 2; jj++) {
+                u32 row = jj * 32 + (lane >> 1), piece = lane & 1;
+                u64 o = row_out[row];
+                if (o) {
+                    const u8 *r = orows + row * HUF_OROW + piece * 16;
+                    uint4 v; u64 a = *(const u64 *)r, bb = *(const u64 *)(r + 8);
+                    v.x = (u32)a; v.y = (u32)(a >> 32); v.z = (u32)bb; v.w = (u32)(bb >> 32);
+                    memcpy((u8 *)o + (u64)R * HUF_ROUND + piece * 16, &v, 16);
+                }
+            }
+            __syncthreads();
+        }
+        br.ptr = (const u8 *)gp;
+    } else {
+        // ---- register double buffer: W1 holds the 8 bytes below the container, loaded one refill ahead -------
+        u64 W1 = 0;
+        const u32 need = 96 + 16;
+        bool fast_ok = valid && (u64)(br.ptr - br.start) >= need + 8;
+        if (fast_ok) { bitr_reload(br); W1 = ld64(br.ptr - 8); }
+        for (; R < rounds; R++) {
+            if (!__all(!valid || (fast_ok && (u64)(br.ptr - br.start) >= need))) break;
+            if (valid) {
+                for (u32 g = 0; g < HUF_ROUND / 8; g++) {
+                    u64 acc = 0;
+#pragma unroll
+                    for (u32 h = 0; h < 2; h++) {
+                        u32 k = br.consumed >> 3;
+                        if (k) { br.c = (br.c << (8 * k)) | (W1 >> (64 - 8 * k)); br.ptr -= k; br.consumed &= 7; W1 = ld64(br.ptr - 8); }
+#pragma unroll
+                        for (u32 q = 0; q < 4; q++) { u32 e = tab[bitr_peek(br, log)]; br.consumed += e >> 8; acc |= (u64)(e & 0xFF) << (8 * (4 * h + q)); }
+                    }
+                    *(u64 *)(orow + g * 8) = acc;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (u32 jj = 0; jj < 2; jj++) {
+                u32 row = jj * 32 + (lane >> 1), piece = lane & 1;
+                u64 o = row_out[row];
+                if (o) {
+                    const u8 *r = orows + row * HUF_OROW + piece * 16;
+                    uint4 v; u64 a = *(const u64 *)r, bb = *(const u64 *)(r + 8);
+                    v.x = (u32)a; v.y = (u32)(a >> 32); v.z = (u32)bb; v.w = (u32)(bb >> 32);
+                    memcpy((u8 *)o + (u64)R * HUF_ROUND + piece * 16, &v, 16);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (valid) {
+        u32 done = R * HUF_ROUND;
+        u8 e = huf_decode_n(br, tab, log, out + done, n - done);
+        if (!e) { bitr_reload(br); if (!bitr_finished(br)) e = ZE_CORRUPT; }
+        if (e) err = e;
+    }
+    if (err) set_err(st, err);
 }
 
 // ---- raw / RLE blocks and raw / RLE literal sections: one workgroup per block ------------------------------
@@ -612,7 +737,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, done, (u32 *)nullptr, (u32 *)nullptr);
     if (n_huf_def) {
         u32 slot = 2u << hs.max_huf_log; if (slot < 16) slot = 16;
-        LAUNCH(c, "zstd_huf_literals", k_huf_literals, cdiv(nblk, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG,
+        LAUNCH(c, "zstd_huf_literals", k_huf_literals, cdiv(nblk, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * HUF_OROW + 64 * 8 + 64 * HUF_IROW,
                d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st);
     }
     LAUNCH(c, "zstd_copy_fill", k_copy_fill, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, d_dst, lit_scratch);
