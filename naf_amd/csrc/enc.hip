@@ -34,24 +34,34 @@ __device__ __forceinline__ bool c_unexp_comment(u32 c) { return c < 0x20 || c ==
 __device__ __forceinline__ bool c_expected(const EncP &P, u32 c) { return (P.expected[c >> 5] >> (c & 31)) & 1; }
 
 // ---- K1: per-tile last EOL / last space position -------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_enc_last(EncP P, i64 *tile_eol, i64 *tile_sp)
+// Line starts: a non-EOL byte at i >= p0 whose predecessor is an EOL byte (or i == p0).
+__device__ __forceinline__ u32 count_line_starts(const EncP &P, u64 base, u32 cnt)
+{
+    u32 n = 0; bool prev_eol = base == 0 ? true : c_eol(P.text[base - 1]);
+    for (u32 i = 0; i < cnt; i++) { u32 c = P.text[base + i]; bool e = c_eol(c); if (!e && base + i >= P.p0 && (prev_eol || base + i == P.p0)) n++; prev_eol = e; }
+    return n;
+}
+
+__global__ __launch_bounds__(256) void k_enc_last(EncP P, i64 *tile_eol, i64 *tile_sp, u64 *tile_ls)
 {
     __shared__ u64 lds[4];
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
-    i64 le = -1, ls = -1;
+    i64 le = -1, ls = -1; u32 nls = 0;
     if (base < P.n) {
         u32 cnt = P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES;
         for (u32 i = 0; i < cnt; i++) { u32 c = P.text[base + i]; if (c_space(c)) { ls = (i64)(base + i); if (c_eol(c)) le = ls; } }
+        if (tile_ls) nls = count_line_starts(P, base, cnt);
     }
     u64 t;
     wg_scan_inclusive<u64, OpMaxI64>((u64)le, &t, lds); i64 te = (i64)t;
     wg_scan_inclusive<u64, OpMaxI64>((u64)ls, &t, lds); i64 ts = (i64)t;
     if (threadIdx.x == 0) { tile_eol[blockIdx.x] = te; tile_sp[blockIdx.x] = ts; }
+    if (tile_ls) { wg_scan_inclusive<u64, OpAdd>((u64)nls, &t, lds); if (threadIdx.x == 0) tile_ls[blockIdx.x] = t; }
 }
 
 // ---- classification of 16 bytes given the running maxima at the first byte ---------------------------------------
 enum { EV_SEQ = 0, EV_IDS = 1, EV_CMT = 2 };
-struct TileCtx { i64 last_eol, last_sp; bool hdr; };
+struct TileCtx { i64 last_eol, last_sp; bool hdr; i64 ord; };
 
 // Sink interface: emit(stream, ch); header_start(pos); header_end(pos); line_end(pos) for sequence lines;
 // unexpected(kind, ch) with kind 0 id, 1 comment, 2 sequence.
@@ -219,20 +229,165 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
     if (threadIdx.x == 0 && best) atomicMax((unsigned long long *)O.longest, (unsigned long long)best);
 }
 
-// ---- lengths: u32 units with 0xFFFFFFFF continuation (encoders.c:72-95) ----------------------------------------------------
-__global__ void k_len_unit_count(const u64 *rec_begin, const u64 *rec_end, u64 N, u64 total_bases, u64 *units)
+
+// ======================= FASTQ (process.c:477-544) =================================================================
+// Non-empty lines cycle header / sequence / plus / quality; blank EOL runs between them are skipped, so the
+// type of a byte is (ordinal of its line) mod 4 and the ordinal is a prefix count of line starts.
+enum { EV_QUAL = 3 };
+enum { FQ_E_AT = 0, FQ_E_PLUS = 1, FQ_E_QLEN = 2 };
+struct FqOut {
+    u8 *seq, *ids, *cmt, *qual;
+    u64 *rec_begin, *rec_end, *q_begin, *q_end;
+    u64 *unexpected;              // [4][257]: id, comment, sequence, quality
+    u64 *first_error;             // min over (record * 4 + kind)
+    const u64 *t_seq, *t_ids, *t_cmt, *t_qual, *t_ls;
+};
+
+template <typename Sink>
+__device__ __forceinline__ void classify_range_fastq(const EncP &P, u64 pos, u32 cnt, bool with_eof, TileCtx ctx, Sink &S)
+{
+    i64 le = ctx.last_eol, ls = ctx.last_sp, ord = ctx.ord;
+    for (u32 k = 0; k < cnt + (with_eof ? 1u : 0u); k++) {
+        u64 i = pos + k;
+        bool eof = k >= cnt;
+        u32 c = eof ? 0x0A : P.text[i];
+        if (i >= P.p0) {
+            bool prev_eol = i == P.p0 || le == (i64)i - 1;
+            if (!c_eol(c)) {
+                if (prev_eol) ord++;                                   // a new line starts here
+                i64 line_start = le + 1; if ((u64)line_start < P.p0) line_start = (i64)P.p0;
+                u64 rec = (u64)ord >> 2; u32 type = (u32)ord & 3; bool first = (i64)i == line_start;
+                if (type == 0) {
+                    if (first) { if (c != '@') S.error(rec, FQ_E_AT); S.header_start(rec); }
+                    else if (ls < line_start) {
+                        if (c_space(c)) S.emit(EV_IDS, 0);
+                        else if (c_unexp_text(c)) { S.unexpected(0, c); S.emit(EV_SEQ, '?'); }
+                        else S.emit(EV_IDS, c);
+                    } else {
+                        if (c_unexp_comment(c)) { S.unexpected(1, c); S.emit(EV_CMT, '?'); }
+                        else S.emit(EV_CMT, c);
+                    }
+                } else if (type == 1) {
+                    if (c_space(c)) {}
+                    else if (c_expected(P, c)) S.emit(EV_SEQ, c);
+                    else { S.unexpected(2, c); S.emit(EV_SEQ, P.replacement); }
+                } else if (type == 2) {
+                    if (first && c != '+') S.error(rec, FQ_E_PLUS);
+                } else {
+                    if (first) { S.qual_begin(rec); S.emit(EV_QUAL, c); }   // process.c:522: appended unconditionally
+                    else if (c >= 0x21 && c <= 0x7E) S.emit(EV_QUAL, c);
+                    else if (c_space(c)) {}
+                    else { S.unexpected(3, c); S.emit(EV_QUAL, '!'); }
+                }
+            } else if (!prev_eol) {                                    // this EOL closes a line
+                i64 line_start = le + 1; if ((u64)line_start < P.p0) line_start = (i64)P.p0;
+                u64 rec = (u64)ord >> 2; u32 type = (u32)ord & 3;
+                if (type == 0) { if (ls < line_start) S.emit(EV_IDS, 0); S.emit(EV_CMT, 0); S.header_end(rec); }
+                else if (type == 1) S.seq_end(rec);
+                else if (type == 3) S.qual_end(rec);
+            } else if (ord >= 0 && (ord & 3) == 0 && !eof) {
+                // blank line right after a header: the reference reads an empty read and then needs '+'
+                S.error((u64)ord >> 2, FQ_E_PLUS);
+            }
+        }
+        if (eof) break;
+        if (c_space(c)) { ls = (i64)i; if (c_eol(c)) le = (i64)i; }
+    }
+}
+
+struct FqCount {
+    u32 nseq = 0, nids = 0, ncmt = 0, nqual = 0;
+    __device__ void emit(int s, u32) { if (s == EV_SEQ) nseq++; else if (s == EV_IDS) nids++; else if (s == EV_CMT) ncmt++; else nqual++; }
+    __device__ void header_start(u64) {} __device__ void header_end(u64) {} __device__ void seq_end(u64) {}
+    __device__ void qual_begin(u64) {} __device__ void qual_end(u64) {}
+    __device__ void unexpected(int, u32) {} __device__ void error(u64, int) {}
+};
+struct FqWrite {
+    const FqOut &O; u64 bseq, bids, bcmt, bqual;
+    __device__ FqWrite(const FqOut &o) : O(o) {}
+    __device__ void emit(int s, u32 ch) { if (s == EV_SEQ) O.seq[bseq++] = (u8)ch; else if (s == EV_IDS) O.ids[bids++] = (u8)ch; else if (s == EV_CMT) O.cmt[bcmt++] = (u8)ch; else O.qual[bqual++] = (u8)ch; }
+    __device__ void header_start(u64) {}
+    __device__ void header_end(u64 r) { O.rec_begin[r] = bseq; }
+    __device__ void seq_end(u64 r) { O.rec_end[r] = bseq; }
+    __device__ void qual_begin(u64 r) { O.q_begin[r] = bqual; }
+    __device__ void qual_end(u64 r) { O.q_end[r] = bqual; }
+    __device__ void unexpected(int kind, u32 ch) { atomicAdd((unsigned long long *)&O.unexpected[kind * 257 + ch], 1ull); }
+    __device__ void error(u64 r, int kind) { atomicMin((unsigned long long *)O.first_error, (unsigned long long)(r * 4 + kind)); }
+};
+
+// ordinal of the line in progress at `base`: (#line starts before base) - 1
+__device__ __forceinline__ i64 thread_ord(const EncP &P, const u64 *t_ls, u64 base, u64 *lds)
+{
+    u32 nls = 0;
+    if (base < P.n) { u32 cnt = P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES; nls = count_line_starts(P, base, cnt); }
+    u64 t; u64 incl = wg_scan_inclusive<u64, OpAdd>((u64)nls, &t, lds);
+    return (i64)(t_ls[blockIdx.x] + incl - nls) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol, const i64 *tile_sp, const u64 *t_ls,
+                                                     u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_qual)
+{
+    __shared__ u64 lds[4];
+    u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds);
+    ctx.ord = thread_ord(P, t_ls, base, lds);
+    FqCount S;
+    if (base <= P.n) {
+        u32 cnt = base < P.n ? (P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES) : 0;
+        classify_range_fastq(P, base, cnt, (base + cnt == P.n) && cnt < ET_BYTES, ctx, S);
+    }
+    u64 tot;
+    wg_scan_inclusive<u64, OpAdd>((u64)S.nseq, &tot, lds); if (threadIdx.x == 0) t_seq[blockIdx.x] = tot;
+    wg_scan_inclusive<u64, OpAdd>((u64)S.nids, &tot, lds); if (threadIdx.x == 0) t_ids[blockIdx.x] = tot;
+    wg_scan_inclusive<u64, OpAdd>((u64)S.ncmt, &tot, lds); if (threadIdx.x == 0) t_cmt[blockIdx.x] = tot;
+    wg_scan_inclusive<u64, OpAdd>((u64)S.nqual, &tot, lds); if (threadIdx.x == 0) t_qual[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, FqOut O)
+{
+    __shared__ u64 lds[4];
+    u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds);
+    ctx.ord = thread_ord(P, O.t_ls, base, lds);
+    u32 cnt = 0; bool eof_here = false, active = base <= P.n;
+    if (active) { cnt = base < P.n ? (P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES) : 0; eof_here = (base + cnt == P.n) && cnt < ET_BYTES; }
+    FqCount C;
+    if (active) classify_range_fastq(P, base, cnt, eof_here, ctx, C);
+    u64 tot;
+    u64 iseq = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq, &tot, lds);
+    u64 iids = wg_scan_inclusive<u64, OpAdd>((u64)C.nids, &tot, lds);
+    u64 icmt = wg_scan_inclusive<u64, OpAdd>((u64)C.ncmt, &tot, lds);
+    u64 iq = wg_scan_inclusive<u64, OpAdd>((u64)C.nqual, &tot, lds);
+    FqWrite W(O);
+    W.bseq = O.t_seq[blockIdx.x] + iseq - C.nseq; W.bids = O.t_ids[blockIdx.x] + iids - C.nids;
+    W.bcmt = O.t_cmt[blockIdx.x] + icmt - C.ncmt; W.bqual = O.t_qual[blockIdx.x] + iq - C.nqual;
+    if (active) classify_range_fastq(P, base, cnt, eof_here, ctx, W);
+}
+
+// read lengths, quality-length check (process.c:531-535) and the longest read
+__global__ void k_fq_check(const u64 *rec_begin, const u64 *rec_end, const u64 *q_begin, const u64 *q_end, u64 N, u64 *first_error, u64 *longest)
 {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= N) return;
-    u64 end = r + 1 < N ? rec_end[r] : total_bases;
+    u64 len = rec_end[r] - rec_begin[r], ql = q_end[r] - q_begin[r];
+    if (len != ql) atomicMin((unsigned long long *)first_error, (unsigned long long)(r * 4 + FQ_E_QLEN));
+    atomicMax((unsigned long long *)longest, (unsigned long long)len);
+}
+
+// ---- lengths: u32 units with 0xFFFFFFFF continuation (encoders.c:72-95) ----------------------------------------------------
+__global__ void k_len_unit_count(const u64 *rec_begin, const u64 *rec_end, u64 N, u64 total_bases, u64 *units, int all_ends)
+{
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    u64 end = (all_ends || r + 1 < N) ? rec_end[r] : total_bases;
     u64 len = end - rec_begin[r];
     units[r] = len / 0xFFFFFFFFull + 1;
 }
-__global__ void k_len_unit_write(const u64 *rec_begin, const u64 *rec_end, u64 N, u64 total_bases, const u64 *unit_off, u32 *out)
+__global__ void k_len_unit_write(const u64 *rec_begin, const u64 *rec_end, u64 N, u64 total_bases, const u64 *unit_off, u32 *out, int all_ends)
 {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= N) return;
-    u64 end = r + 1 < N ? rec_end[r] : total_bases;
+    u64 end = (all_ends || r + 1 < N) ? rec_end[r] : total_bases;
     u64 len = end - rec_begin[r], o = unit_off[r];
     while (len >= 0xFFFFFFFFull) { out[o++] = 0xFFFFFFFFu; len -= 0xFFFFFFFFull; }
     out[o] = (u32)len;
@@ -425,12 +580,72 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
         else return ctx_fail(c, NAF_GPU_EINPUT, "input data is in unknown format - first non-space character is neither '>' nor '@'\n");
         if (o->format != NAF_FMT_AUTO && o->format != format) return ctx_fail(c, NAF_GPU_EINPUT, "input format is different from format specified in the command line\n");
     }
-    if (format == NAF_FMT_FASTQ) return ctx_fail(c, NAF_GPU_EINPUT, "FASTQ input is not yet handled by the gfx950 encoder (FASTA only in this release)\n");
     R.format = format;
+    bool store_qual = format == NAF_FMT_FASTQ;                                                    // ennaf.c:477
 
-    u8 *s_ids = nullptr, *s_cmt = nullptr, *s_seq = nullptr, *s_mask = nullptr; u32 *s_len = nullptr;
-    u64 n_ids = 0, n_cmt = 0, n_lenb = 0, n_mask = 0, n_seqb = 0, T = 0, N = 0, longest = 0;
+    u8 *s_ids = nullptr, *s_cmt = nullptr, *s_seq = nullptr, *s_mask = nullptr, *s_qual = nullptr, *bases = nullptr; u32 *s_len = nullptr;
+    u64 n_ids = 0, n_cmt = 0, n_lenb = 0, n_mask = 0, n_seqb = 0, n_qual = 0, T = 0, N = 0, longest = 0;
+    u64 *rec_begin = nullptr, *rec_end = nullptr; int all_ends = 0;
     int rc;
+    if (format == NAF_FMT_FASTQ) {
+        EncP P; memset(&P, 0, sizeof P);
+        P.text = d_text; P.n = n; P.p0 = sn[0];
+        set_expected(P, seq_type, false);
+        u64 tiles = n / ET_TILE + 1;
+        i64 *t_eol = arena_new<i64>(c, tiles + 1), *t_sp = arena_new<i64>(c, tiles + 1);
+        u64 *t_ls = arena_new<u64>(c, tiles + 2), *t_seq = arena_new<u64>(c, tiles + 2), *t_ids = arena_new<u64>(c, tiles + 2),
+            *t_cmt = arena_new<u64>(c, tiles + 2), *t_qual = arena_new<u64>(c, tiles + 2);
+        u64 *tot = arena_new<u64>(c, 8);
+        if (!t_eol || !t_sp || !t_ls || !t_seq || !t_ids || !t_cmt || !t_qual || !tot) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "ennaf_last", k_enc_last, tiles, 256, 0, P, t_eol, t_sp, t_ls);
+        if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
+        if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_ls, tiles, tot + 4))) return rc;
+        LAUNCH(c, "ennaf_fq_count", k_encq_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual);
+        if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_ids, tiles, tot + 1))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_qual, tiles, tot + 3))) return rc;
+        u64 h[5]; u8 lastb = 0;
+        if ((rc = ctx_readback(c, h, tot, 40))) return rc;
+        if ((rc = ctx_readback(c, &lastb, d_text + n - 1, 1))) return rc;
+        T = h[0]; n_ids = h[1]; n_cmt = h[2]; n_qual = h[3];
+        u64 nlines = h[4]; N = (nlines + 3) / 4;
+        // truncated input (process.c:499,510,513,517,520)
+        if (nlines % 4 == 1 && !(lastb >= 0x0A && lastb <= 0x0D)) return ctx_fail(c, NAF_GPU_EINPUT, "truncated FASTQ input: last sequence has no sequence data\n");
+        bases = (u8 *)arena_alloc(c, T + 64);
+        s_ids = (u8 *)arena_alloc(c, n_ids + 16); s_cmt = (u8 *)arena_alloc(c, n_cmt + 16); s_qual = (u8 *)arena_alloc(c, n_qual + 16);
+        rec_begin = arena_new<u64>(c, N + 1); rec_end = arena_new<u64>(c, N + 1);
+        u64 *q_begin = arena_new<u64>(c, N + 1), *q_end = arena_new<u64>(c, N + 1);
+        u64 *d_unexp = arena_new<u64>(c, 4 * 257 + 2);
+        if (!bases || !s_ids || !s_cmt || !s_qual || !rec_begin || !rec_end || !q_begin || !q_end || !d_unexp) return NAF_GPU_ENOMEM;
+        HIP_TRY(c, hipMemsetAsync(d_unexp, 0, (4 * 257 + 2) * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(d_unexp + 4 * 257, 0xFF, 8, c->stream));                        // first_error = none
+        HIP_TRY(c, hipMemsetAsync(rec_begin, 0, (N + 1) * 8, c->stream)); HIP_TRY(c, hipMemsetAsync(rec_end, 0, (N + 1) * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(q_begin, 0, (N + 1) * 8, c->stream)); HIP_TRY(c, hipMemsetAsync(q_end, 0, (N + 1) * 8, c->stream));
+        FqOut O; O.seq = bases; O.ids = s_ids; O.cmt = s_cmt; O.qual = s_qual; O.rec_begin = rec_begin; O.rec_end = rec_end; O.q_begin = q_begin; O.q_end = q_end;
+        O.unexpected = d_unexp; O.first_error = d_unexp + 4 * 257;
+        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_qual = t_qual; O.t_ls = t_ls;
+        LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+        if (nlines / 4) LAUNCH(c, "ennaf_fq_check", k_fq_check, cdiv(nlines / 4, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, (const u64 *)q_begin, (const u64 *)q_end, nlines / 4, O.first_error, d_unexp + 4 * 257 + 1);
+        std::vector<u64> hu(4 * 257 + 2);
+        if ((rc = ctx_readback(c, hu.data(), d_unexp, hu.size() * 8))) return rc;
+        u64 fe = hu[4 * 257];
+        u64 trunc_rec = nlines % 4 ? nlines / 4 : ~0ull;                                             // the incomplete record
+        if (fe != ~0ull && (fe >> 2) <= trunc_rec) {
+            u64 r = fe >> 2; int kind = (int)(fe & 3);
+            if (kind == FQ_E_AT) return ctx_fail(c, NAF_GPU_EINPUT, "invalid FASTQ input: Can't find '@' after sequence %llu\n", (unsigned long long)r);
+            if (kind == FQ_E_PLUS) return ctx_fail(c, NAF_GPU_EINPUT, "invalid FASTQ input: can't find '+' line of sequence %llu\n", (unsigned long long)r + 1);
+            u64 v[4];
+            if ((rc = ctx_readback(c, &v[0], rec_begin + r, 8)) || (rc = ctx_readback(c, &v[1], rec_end + r, 8)) || (rc = ctx_readback(c, &v[2], q_begin + r, 8)) || (rc = ctx_readback(c, &v[3], q_end + r, 8))) return rc;
+            return ctx_fail(c, NAF_GPU_EINPUT, "quality length of sequence %llu (%llu) doesn't match sequence length (%llu)\n",
+                            (unsigned long long)r + 1, (unsigned long long)(v[3] - v[2]), (unsigned long long)(v[1] - v[0]));
+        }
+        if (nlines % 4) return ctx_fail(c, NAF_GPU_EINPUT, "truncated FASTQ input: last sequence has no quality\n");
+        for (int i = 0; i < 257; i++) { R.unexpected_id[i] = hu[i]; R.unexpected_comment[i] = hu[257 + i]; R.unexpected_seq[i] = hu[514 + i]; R.unexpected_qual[i] = hu[771 + i]; }
+        longest = hu[4 * 257 + 1];
+        all_ends = 1;
+    }
     if (format == NAF_FMT_FASTA) {
         EncP P; memset(&P, 0, sizeof P);
         P.text = d_text; P.n = n; P.p0 = sn[0];
@@ -441,7 +656,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
         u32 *t_tail = arena_new<u32>(c, tiles + 1);
         u64 *tot = arena_new<u64>(c, 8);
         if (!t_eol || !t_sp || !t_seq || !t_ids || !t_cmt || !t_rec || !t_tail || !tot) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "ennaf_last", k_enc_last, tiles, 256, 0, P, t_eol, t_sp);
+        LAUNCH(c, "ennaf_last", k_enc_last, tiles, 256, 0, P, t_eol, t_sp, (u64 *)nullptr);
         // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
         if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
         if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
@@ -455,9 +670,9 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
         u64 h[4];
         if ((rc = ctx_readback(c, h, tot, 32))) return rc;
         T = h[0]; n_ids = h[1]; n_cmt = h[2]; N = h[3];
-        u8 *bases = (u8 *)arena_alloc(c, T + 64);
+        bases = (u8 *)arena_alloc(c, T + 64);
         s_ids = (u8 *)arena_alloc(c, n_ids + 16); s_cmt = (u8 *)arena_alloc(c, n_cmt + 16);
-        u64 *rec_begin = arena_new<u64>(c, N + 1), *rec_end = arena_new<u64>(c, N + 1);
+        rec_begin = arena_new<u64>(c, N + 1); rec_end = arena_new<u64>(c, N + 1);
         u64 *d_unexp = arena_new<u64>(c, 3 * 257 + 1);
         if (!bases || !s_ids || !s_cmt || !rec_begin || !rec_end || !d_unexp) return NAF_GPU_ENOMEM;
         HIP_TRY(c, hipMemsetAsync(d_unexp, 0, (3 * 257 + 1) * 8, c->stream));
@@ -474,14 +689,16 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
             for (int k = 0; k < 3; k++) for (int i = 0; i < 257; i++) if (hu[k * 257 + i])
                 return ctx_fail(c, NAF_GPU_EINPUT, k == 0 ? "unexpected character '%c' in ID\n" : k == 1 ? "unexpected character '%c' in comment\n" : "unexpected sequence code '%c'\n", i);
         }
+    }
+    if (format != 0) {
         // lengths
         if (N) {
             u64 *lu = arena_new<u64>(c, N + 2); if (!lu) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "ennaf_len_count", k_len_unit_count, cdiv(N, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, N, T, lu);
+            LAUNCH(c, "ennaf_len_count", k_len_unit_count, cdiv(N, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, N, T, lu, all_ends);
             if ((rc = scan_exclusive_u64(c, lu, N, lu + N + 1))) return rc;
             u64 nu = 0; if ((rc = ctx_readback(c, &nu, lu + N + 1, 8))) return rc;
             s_len = arena_new<u32>(c, nu + 1); if (!s_len) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "ennaf_len_write", k_len_unit_write, cdiv(N, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, N, T, (const u64 *)lu, s_len);
+            LAUNCH(c, "ennaf_len_write", k_len_unit_write, cdiv(N, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, N, T, (const u64 *)lu, s_len, all_ends);
             n_lenb = nu * 4;
         }
         // mask
@@ -518,7 +735,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     hd[hl++] = 0x01; hd[hl++] = 0xF9; hd[hl++] = 0xEC;
     if (seq_type == NAF_SEQ_DNA) hd[hl++] = 1; else { hd[hl++] = 2; hd[hl++] = (u8)seq_type; }
     size_t tl = o->title ? strlen(o->title) : 0;
-    hd[hl++] = (u8)(((o->title ? 1 : 0) << 6) | (1 << 5) | (1 << 4) | (1 << 3) | ((store_mask ? 1 : 0) << 2) | (1 << 1) | 0);
+    hd[hl++] = (u8)(((o->title ? 1 : 0) << 6) | (1 << 5) | (1 << 4) | (1 << 3) | ((store_mask ? 1 : 0) << 2) | (1 << 1) | (store_qual ? 1 : 0));
     hd[hl++] = ' ';
     hl += vle(o->line_length >= 0 ? (u64)o->line_length : longest, hd + hl);
     hl += vle(N, hd + hl);
@@ -534,6 +751,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     if ((rc = put_section(c, (const u8 *)s_len, n_lenb, n_lenb, o->level, d_naf, cap, pos, so[2]))) return rc;
     if (store_mask) { if ((rc = put_section(c, s_mask, n_mask, n_mask, o->level, d_naf, cap, pos, so[3]))) return rc; }
     if ((rc = put_section(c, s_seq, n_seqb, T, o->level, d_naf, cap, pos, so[4]))) return rc;      // ennaf.c:582: number of bases
+    if (store_qual) { if ((rc = put_section(c, s_qual, n_qual, n_qual, o->level, d_naf, cap, pos, so[5]))) return rc; }
     for (int i = 0; i < 6; i++) { R.section_orig[i] = so[i].orig; R.section_comp[i] = so[i].comp; }
     *naf_len = pos;
     if (rep) *rep = R;

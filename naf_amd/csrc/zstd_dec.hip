@@ -333,7 +333,7 @@ __global__ void k_seq_flag(const ZBlock *blk, u32 nblk, u64 *flag)
 // accesses re-fetch every sector ~8 times once 2048 streams per CU overflow the 32 KiB L1):
 //   input : per-lane circular window of two 64-byte sectors in LDS; the next lower sector is loaded into
 //           registers one round (32 symbols) before it is committed to LDS, so its latency is hidden
-//   output: per-lane 32-byte LDS row per round, written out by lane pairs with 16-byte stores
+//   output: 16 symbols are gathered in registers and leave as one 16-byte store per lane
 // Tables with codes longer than 7 bits (a round could cross more than one sector) use the register-prefetch
 // reader instead.
 #define HUF_BLOCKS_PER_WG 16
@@ -344,9 +344,7 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
                                                       const u8 *pool, u32 slot_bytes, u8 *dst, u8 *lit_scratch, ZStat *st)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
-    u8 *orows = lds + HUF_BLOCKS_PER_WG * slot_bytes;                // 64 x 40 B
-    u64 *row_out = (u64 *)(orows + 64 * HUF_OROW);                   // per-row global destination (0 = idle lane)
-    u8 *irows = (u8 *)(row_out + 64);                                 // 64 x 136 B
+    u8 *irows = lds + HUF_BLOCKS_PER_WG * slot_bytes;                // 64 x 136 B
     int lane = threadIdx.x;
     u32 b0 = blockIdx.x * HUF_BLOCKS_PER_WG;
     for (u32 j = 0; j < HUF_BLOCKS_PER_WG; j++) {                     // stage the table in force for each block
@@ -392,13 +390,11 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
             }
         }
     }
-    row_out[lane] = valid ? (u64)out : 0;
     u32 my_rounds = valid ? n / HUF_ROUND : 0xFFFFFFFFu;                 // wave-uniform round count
     for (int d = 32; d; d >>= 1) { u32 o = (u32)__shfl_xor((int)my_rounds, d, 64); my_rounds = o < my_rounds ? o : my_rounds; }
     u32 rounds = my_rounds == 0xFFFFFFFFu ? 0 : my_rounds;
     bool wide = __all(!valid || log <= 7);
     __syncthreads();
-    u8 *orow = orows + lane * HUF_OROW;
     u32 R = 0;
     if (wide) {
         // ---- sector-window reader -------------------------------------------------------------------------
@@ -415,6 +411,7 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
 #pragma unroll
             for (int q = 0; q < 8; q++) { uint4 v = g0[q]; u32 o = (u32)((lo + 16 * q) & 127); *(u64 *)(irow + o) = (u64)v.x | ((u64)v.y << 32); *(u64 *)(irow + o + 8) = (u64)v.z | ((u64)v.w << 32); }
         }
+        u32 bits = br.consumed;                                            // bits consumed since the container at gp
         for (; R < rounds; R++) {
             if (!__all(!valid || (live && gp - (u64)br.start >= 160))) break;   // near a stream start: generic reader finishes
             if (valid) {
@@ -430,32 +427,33 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
                     const uint4 *g0 = (const uint4 *)(lo - 64);
                     st0 = g0[0]; st1 = g0[1]; st2 = g0[2]; st3 = g0[3]; pending = true;
                 }
+                u64 accs[HUF_ROUND / 8];
 #pragma unroll
                 for (u32 g = 0; g < HUF_ROUND / 8; g++) {
-                    u32 k = br.consumed >> 3;
-                    if (k) {                                              // refill the container from the LDS window
-                        gp -= k; br.consumed &= 7;
-                        u32 o = (u32)(gp & 127), sh = (o & 7) * 8;
-                        u64 q0 = *(const u64 *)(irow + (o & ~7u)), q1 = *(const u64 *)(irow + (((o & ~7u) + 8) & 127));
-                        br.c = sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0;
-                    }
-                    *(u64 *)(orow + g * 8) = huf_decode8(br, tab, log);
-                }
-            }
-            __syncthreads();
+                    // refill: move the container down by the whole bytes consumed, keep the window top-aligned
+                    gp -= bits >> 3; bits &= 7;
+                    u32 o = (u32)(gp & 127), sh = (o & 7) * 8;
+                    u64 q0 = *(const u64 *)(irow + (o & ~7u)), q1 = *(const u64 *)(irow + (((o & ~7u) + 8) & 127));
+                    u64 w = (sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0) << bits;
+                    u64 acc = 0;
 #pragma unroll
-            for (u32 jj = 0; jj < 2; jj++) {
-                u32 row = jj * 32 + (lane >> 1), piece = lane & 1;
-                u64 o = row_out[row];
-                if (o) {
-                    const u8 *r = orows + row * HUF_OROW + piece * 16;
-                    uint4 v; u64 a = *(const u64 *)r, bb = *(const u64 *)(r + 8);
-                    v.x = (u32)a; v.y = (u32)(a >> 32); v.z = (u32)bb; v.w = (u32)(bb >> 32);
-                    memcpy((u8 *)o + (u64)R * HUF_ROUND + piece * 16, &v, 16);
+                    for (u32 q = 0; q < 8; q++) {
+                        u32 e = tab[(u32)(w >> 32) >> (32 - log)];
+                        u32 nb = e >> 8;
+                        w <<= nb; bits += nb;
+                        acc |= (u64)(e & 0xFF) << (8 * q);
+                    }
+                    accs[g] = acc;
+                }
+                u8 *gout = out + (u64)R * HUF_ROUND;
+#pragma unroll
+                for (u32 g = 0; g < HUF_ROUND / 16; g++) {
+                    uint4 v; v.x = (u32)accs[2 * g]; v.y = (u32)(accs[2 * g] >> 32); v.z = (u32)accs[2 * g + 1]; v.w = (u32)(accs[2 * g + 1] >> 32);
+                    memcpy(gout + 16 * g, &v, 16);
                 }
             }
-            __syncthreads();
         }
+        if (valid && live) { gp -= bits >> 3; bits &= 7; br.c = ld64((const u8 *)gp); br.consumed = bits; }
         br.ptr = (const u8 *)gp;
     } else {
         // ---- register double buffer: W1 holds the 8 bytes below the container, loaded one refill ahead -------
@@ -475,22 +473,9 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
 #pragma unroll
                         for (u32 q = 0; q < 4; q++) { u32 e = tab[bitr_peek(br, log)]; br.consumed += e >> 8; acc |= (u64)(e & 0xFF) << (8 * (4 * h + q)); }
                     }
-                    *(u64 *)(orow + g * 8) = acc;
+                    st64(out + (u64)R * HUF_ROUND + g * 8, acc);
                 }
             }
-            __syncthreads();
-#pragma unroll
-            for (u32 jj = 0; jj < 2; jj++) {
-                u32 row = jj * 32 + (lane >> 1), piece = lane & 1;
-                u64 o = row_out[row];
-                if (o) {
-                    const u8 *r = orows + row * HUF_OROW + piece * 16;
-                    uint4 v; u64 a = *(const u64 *)r, bb = *(const u64 *)(r + 8);
-                    v.x = (u32)a; v.y = (u32)(a >> 32); v.z = (u32)bb; v.w = (u32)(bb >> 32);
-                    memcpy((u8 *)o + (u64)R * HUF_ROUND + piece * 16, &v, 16);
-                }
-            }
-            __syncthreads();
         }
     }
     if (valid) {
@@ -737,7 +722,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, done, (u32 *)nullptr, (u32 *)nullptr);
     if (n_huf_def) {
         u32 slot = 2u << hs.max_huf_log; if (slot < 16) slot = 16;
-        LAUNCH(c, "zstd_huf_literals", k_huf_literals, cdiv(nblk, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * HUF_OROW + 64 * 8 + 64 * HUF_IROW,
+        LAUNCH(c, "zstd_huf_literals", k_huf_literals, cdiv(nblk, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * HUF_IROW,
                d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st);
     }
     LAUNCH(c, "zstd_copy_fill", k_copy_fill, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, d_dst, lit_scratch);

@@ -66,18 +66,18 @@ def check_ennaf(gpu, O, text, seq_type=0, no_mask=False, line_length=-1, title=N
     d_naf, rep = gpu.ennaf(gpu.to_device(text), seq_type=seq_type, no_mask=no_mask, line_length=line_length, title=title)
     mine = host(d_naf)
     h = O.parse_naf(mine)
-    streams = [sp.ids, sp.comments, sp.lengths, sp.mask, sp.seq]
-    names = ["ids", "comments", "lengths", "mask", "seq"]
+    streams = [sp.ids, sp.comments, sp.lengths, sp.mask, sp.seq, sp.qual]
+    names = ["ids", "comments", "lengths", "mask", "seq", "qual"]
     store_mask = not (no_mask or seq_type >= 2)
-    for i in range(5):
-        if i == 3 and not store_mask:
+    for i in range(6):
+        if (i == 3 and not store_mask) or (i == 5 and sp.format != O.FMT_FASTQ):
             assert h.payload_off[i] is None
             continue
         assert O.zstd_decompress(h.frame(mine, i), len(streams[i]) + 16) == streams[i], names[i]
     assert h.n_sequences == sp.n_sequences and h.orig[O.SEQ] == sp.n_bases
     assert h.line_length == (sp.longest_line if line_length < 0 else line_length)
     assert rep.n_sequences == sp.n_sequences and rep.n_bases == sp.n_bases and rep.longest_line == sp.longest_line
-    for key, arr in (("id", rep.unexpected_id), ("comment", rep.unexpected_comment), ("seq", rep.unexpected_seq)):
+    for key, arr in (("id", rep.unexpected_id), ("comment", rep.unexpected_comment), ("seq", rep.unexpected_seq), ("qual", rep.unexpected_qual)):
         assert list(arr) == sp.unexpected[key], key
     ref = O.ennaf(text, seq_type, no_mask, line_length, title)
     assert mine[: h.header_bytes] == ref[: O.parse_naf(ref).header_bytes]    # container framing identical
@@ -105,18 +105,19 @@ def test_ennaf_golden_fasta_cases(gpu, oracle):
     for case in naf_cases():
         naf = golden_bytes("naf", case["name"] + ".naf")
         h = oracle.parse_naf(naf)
-        if h.flags & 1:
-            continue                                                          # FASTQ input: not yet on the GPU encoder
         try:
             text = golden_bytes("naf", case["name"] + ".in")
         except FileNotFoundError:
-            text = oracle.unnaf(naf, 0)
+            text = oracle.unnaf(naf, -1)
         args = case["ennaf_args"]
         ll = int(args[args.index("--line-length") + 1]) if "--line-length" in args else -1
         title = args[args.index("--title") + 1].encode() if "--title" in args else None
         mine = check_ennaf(gpu, oracle, text, _seq_type(args, oracle), "--no-mask" in args, ll, title)
         if oracle.have_ref():                                                 # the real reference decodes our archive bit-exactly
-            assert oracle.ref_unnaf(mine, ("--fasta",)) == oracle.ref_unnaf(naf, ("--fasta",)), case["name"]
+            if h.flags & 1:       # FASTQ text came back upper-case (unnaf.c:442), so only the FASTQ view is comparable
+                assert oracle.ref_unnaf(mine) == oracle.ref_unnaf(naf), case["name"]
+            else:
+                assert oracle.ref_unnaf(mine, ("--fasta",)) == oracle.ref_unnaf(naf, ("--fasta",)), case["name"]
 
 
 def test_ennaf_fuzz_against_oracle(gpu, oracle):
@@ -153,3 +154,72 @@ def test_ennaf_unnaf_roundtrip_large(gpu):
     assert d_naf.numel() < 0.26 * text.numel()
     back = gpu.unnaf(d_naf, 0)
     assert torch.equal(back, text)
+
+
+def test_ennaf_fastq_against_oracle(gpu, oracle):
+    from naf_amd import synth
+    from naf_amd.capi import NafGpuError
+    rng = np.random.default_rng(23)
+    for i in range(10):
+        text = synth.fastq_reads(int(rng.integers(1, 600)), int(rng.integers(1, 300)), seed=100 + i, var_len=bool(i % 2))
+        check_ennaf(gpu, oracle, text)
+    # tolerant grammar: blank lines between records/lines, spaces, bad quality bytes, comments, control bytes in ids
+    weird = (b"@r1 c\nAC GT\n+\n!!\x01!\n\n@r2\x02x\tcomment\there\nACNNxz\n\n+r2 again\n\nII II\x7f\x80\n@r3\nA\n+\n~")
+    check_ennaf(gpu, oracle, weird)
+    check_ennaf(gpu, oracle, b"\n\n" + weird + b"\n\n\n")
+    # every way the reference dies, with its message
+    bad = {b"@r1\nACGT\n+\n!!!\n": "quality length of sequence 1 (3) doesn't match sequence length (4)",
+           b"@r1\nACGT\n": "truncated FASTQ input: last sequence has no quality",
+           b"@r1\nACGT\n+\n": "truncated FASTQ input: last sequence has no quality",
+           b"@r1": "truncated FASTQ input: last sequence has no sequence data",
+           b"@r1\nACGT\nIIII\n": "can't find '+' line of sequence 1",
+           b"@r1\nAC\n+\nII\nr2\nAC\n+\nII\n": "Can't find '@' after sequence 1",
+           b"@r1\r\nAC\r\n+\r\nII\r\n": "can't find '+' line of sequence 1"}
+    for t, msg in bad.items():
+        with pytest.raises(ValueError):
+            oracle.split_text(t)
+        try:
+            oracle.split_text(t)
+        except ValueError as e:
+            assert msg in str(e), (t, str(e))
+        with pytest.raises(NafGpuError) as ei:
+            gpu.ennaf(gpu.to_device(t))
+        assert msg in str(ei.value), (t, str(ei.value))
+
+
+def test_ennaf_fastq_fuzz(gpu, oracle):
+    """Structured fuzz: mostly valid records with random damage; both sides must agree on die-or-encode."""
+    from naf_amd.capi import NafGpuError
+    rng = np.random.default_rng(29)
+    seq_al = np.frombuffer(b"ACGTNacgtn-RYxz \t", dtype=np.uint8)
+    q_al = np.frombuffer(b"!#5AIZ~ \t\x01\x80", dtype=np.uint8)
+    eols = [b"\n", b"\n", b"\n", b"\n\n", b"\n\r\n", b"\x0b"]
+    agree = died = 0
+    for i in range(250):
+        recs = []
+        for r in range(int(rng.integers(1, 6))):
+            n = int(rng.integers(1, 40))
+            seq = seq_al[rng.integers(0, len(seq_al), n)].tobytes()
+            nb = len(seq.replace(b" ", b"").replace(b"\t", b""))
+            qual = q_al[rng.integers(0, len(q_al) - 4, nb)].tobytes() if nb else b""
+            if rng.random() < 0.2 and nb:                       # sprinkle droppable / replaceable bytes into the quality
+                k = int(rng.integers(0, nb)); qual = qual[:k] + bytes([int(q_al[rng.integers(len(q_al) - 4, len(q_al))])]) + qual[k:]
+            hdr = b"@r%d" % r + (b" c%d\tx" % r if rng.random() < 0.5 else b"") + (b"\x02" if rng.random() < 0.1 else b"")
+            e = [eols[int(rng.integers(0, len(eols)))] for _ in range(4)]
+            e[0] = b"\n"                                        # the reference needs a single EOL after the header
+            recs.append(hdr + e[0] + seq + e[1] + b"+" + (b"anything" if rng.random() < 0.3 else b"") + e[2] + qual + e[3])
+        t = b"".join(recs)
+        if rng.random() < 0.15:
+            t = t[: int(rng.integers(1, len(t)))]                # truncation
+        try:
+            oracle.split_text(t)
+        except ValueError as err:
+            with pytest.raises(NafGpuError) as ei:
+                gpu.ennaf(gpu.to_device(t))
+            if "quality length" in str(err) or "truncated" in str(err):
+                assert str(err).strip() in str(ei.value), (t, str(err), str(ei.value))
+            died += 1
+            continue
+        check_ennaf(gpu, oracle, t)
+        agree += 1
+    assert agree > 40 and died > 20, (agree, died)
