@@ -358,6 +358,35 @@ __global__ __launch_bounds__(256) void k_emit(EmitP P, u8 *out)
     }
 }
 
+// Base-index range [g_lo, g_hi) that output bytes [out_begin, out_end) can touch (conservative on both sides).
+__global__ void k_range_bases(EmitP P, u64 *out2)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    if (P.mode == EM_SEQ) { out2[0] = P.out_begin; out2[1] = P.out_end; return; }
+    u64 pb = P.out_begin, pe = P.out_end - 1;
+    u64 r0 = upper_bound_u64(P.rec_out, 0, P.N + 1, pb) - 1, r1 = upper_bound_u64(P.rec_out, 0, P.N + 1, pe) - 1;
+    auto lower = [&](u64 r, u64 p) -> u64 {                      // bases of record r before text byte p
+        u64 off = p - P.rec_out[r], hl = P.hdr_len[r], len = P.rec_len[r];
+        if (off <= hl) return 0;
+        u64 q = off - hl, j;
+        if (P.mode == EM_FASTQ) j = 0;
+        else if (P.mode == EM_FASTA && P.L) j = (q / (P.L + 1)) * P.L;
+        else j = q;
+        return j > len ? len : j;
+    };
+    auto upper = [&](u64 r, u64 p) -> u64 {                      // one past the last base of record r at or before byte p
+        u64 off = p - P.rec_out[r], hl = P.hdr_len[r], len = P.rec_len[r];
+        if (off < hl) return 0;
+        u64 q = off - hl, j;
+        if (P.mode == EM_FASTQ) j = len;
+        else if (P.mode == EM_FASTA && P.L) j = (q / (P.L + 1) + 1) * P.L;
+        else j = q + 1;
+        return j > len ? len : j;
+    };
+    out2[0] = P.rec_base[r0] + lower(r0, pb);
+    out2[1] = P.rec_base[r1] + upper(r1, pe);
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 static int zero_positions(naf_gpu_ctx *c, const u8 *d_buf, u64 n, u64 N, u64 **out)
 {
@@ -614,22 +643,50 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     if (*out_len > out_cap) return ctx_fail(c, NAF_GPU_ECAP, "unnaf output needs %llu bytes, capacity %zu", (unsigned long long)*out_len, out_cap);
     if (*out_len == 0) return 0;
     const naf_gpu_header &h = pl.h;
+    pl.P.out_begin = out_begin; pl.P.out_end = out_end;
+    // Byte-range call (multi-GPU shard): find the bases this range touches and decode only the zstd blocks behind them.
+    ZRange rgs, rgq; ZRange *prs = nullptr, *prq = nullptr;
+    if (!whole && pl.P.mode != -1) {
+        u64 *d_g = arena_new<u64>(c, 2); if (!d_g) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "unnaf_range_bases", k_range_bases, 1, 64, 0, pl.P, d_g);
+        u64 g[2]; if ((rc = ctx_readback(c, g, d_g, 16))) return rc;
+        if (g[1] < g[0]) g[1] = g[0];
+        rgs.want_lo = pl.fourbit ? g[0] / 2 : g[0]; rgs.want_hi = pl.fourbit ? (g[1] + 1) / 2 : g[1];
+        rgq.want_lo = g[0]; rgq.want_hi = g[1];
+        prs = &rgs; prq = &rgq;
+    }
     // sequence payload (the dominant zstd stream)
-    u8 *seq = (u8 *)arena_alloc(c, pl.seq_bytes + 64);
+    u64 seq_need = prs ? (rgs.want_hi - rgs.want_lo) + 2 * 131072 + 64 : pl.seq_bytes + 64;
+    if (seq_need > pl.seq_bytes + 64) seq_need = pl.seq_bytes + 64;
+    u8 *seq = (u8 *)arena_alloc(c, seq_need);
     if (!seq) return NAF_GPU_ENOMEM;
     size_t n = 0;
-    rc = zstd_decode(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, seq, pl.seq_bytes, &n);
+    rc = zstd_decode_range(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, seq, prs ? seq_need : pl.seq_bytes, &n, prs);
+    if (rc == NAF_GPU_ECAP && prs) {                                                 // dependent blocks: needs the whole stream
+        seq = (u8 *)arena_alloc(c, pl.seq_bytes + 64); if (!seq) return NAF_GPU_ENOMEM;
+        rc = zstd_decode(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, seq, pl.seq_bytes, &n); prs = nullptr;
+    }
     if (rc == NAF_GPU_ECAP || (rc == 0 && n != pl.seq_bytes)) return ctx_fail(c, NAF_GPU_EFORMAT, "can't decompress sequence\n");
     if (rc) return rc;
     if (pl.P.mode == -1) {                                                             // --4bit: the stream itself
         HIP_TRY(c, hipMemcpyAsync(d_out, seq + out_begin, out_end - out_begin, hipMemcpyDeviceToDevice, c->stream));
         return 0;
     }
-    pl.P.seq = seq;
+    pl.P.seq = (prs && prs->ranged) ? seq - prs->got_lo : seq;
     if (pl.need_qual) {
-        u8 *q = nullptr;
-        if ((rc = load_section(c, d_naf, h, S_QUAL, h.orig_size[S_QUAL], "quality", &q))) return rc;
-        pl.P.qual = q;
+        u64 qn = h.orig_size[S_QUAL];
+        u64 q_need = prq ? (rgq.want_hi - rgq.want_lo) + 2 * 131072 + 64 : qn + 64;
+        if (q_need > qn + 64) q_need = qn + 64;
+        u8 *q = (u8 *)arena_alloc(c, q_need); if (!q) return NAF_GPU_ENOMEM;
+        size_t qgot = 0;
+        rc = zstd_decode_range(c, d_naf + h.payload_off[S_QUAL], h.comp_size[S_QUAL], 0, q, prq ? q_need : qn, &qgot, prq);
+        if (rc == NAF_GPU_ECAP && prq) {
+            q = (u8 *)arena_alloc(c, qn + 64); if (!q) return NAF_GPU_ENOMEM;
+            rc = zstd_decode(c, d_naf + h.payload_off[S_QUAL], h.comp_size[S_QUAL], 0, q, qn, &qgot); prq = nullptr;
+        }
+        if (rc == NAF_GPU_ECAP || (rc == 0 && qgot != qn)) return ctx_fail(c, NAF_GPU_EFORMAT, "can't decompress quality\n");
+        if (rc) return rc;
+        pl.P.qual = (prq && prq->ranged) ? q - prq->got_lo : q;
     }
     pl.P.out_begin = out_begin; pl.P.out_end = out_end;
     u32 grid = cdiv(out_end - out_begin, EMIT_SPAN);

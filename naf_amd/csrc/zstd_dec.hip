@@ -206,9 +206,9 @@ __global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_hu
     if (sq) atomicAdd(&st->n_seq_blk, 1u);
 }
 
-__global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st)
+__global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first)
 {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 i = first + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblk) return;
     if (blk[i].btype != BT_COMP || blk[i].lit_type != LIT_HUF || blk[i].err) return;
     const u8 *c = src + blk[i].src_off;
@@ -341,12 +341,12 @@ __global__ void k_seq_flag(const ZBlock *blk, u32 nblk, u64 *flag)
 #define HUF_OROW 40                        // output row pitch (32 + 8)
 #define HUF_IROW 136                       // input window pitch (128 + 8)
 __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf,
-                                                      const u8 *pool, u32 slot_bytes, u8 *dst, u8 *lit_scratch, ZStat *st)
+                                                      const u8 *pool, u32 slot_bytes, u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     u8 *irows = lds + HUF_BLOCKS_PER_WG * slot_bytes;                // 64 x 136 B
     int lane = threadIdx.x;
-    u32 b0 = blockIdx.x * HUF_BLOCKS_PER_WG;
+    u32 b0 = b_first + blockIdx.x * HUF_BLOCKS_PER_WG;
     for (u32 j = 0; j < HUF_BLOCKS_PER_WG; j++) {                     // stage the table in force for each block
         u32 bi = b0 + j;
         if (bi >= nblk) break;
@@ -488,9 +488,10 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
 }
 
 // ---- raw / RLE blocks and raw / RLE literal sections: one workgroup per block ------------------------------
-__global__ __launch_bounds__(256) void k_copy_fill(const u8 *src, const ZBlock *blk, u32 nblk, u8 *dst, u8 *lit_scratch)
+__global__ __launch_bounds__(256) void k_copy_fill(const u8 *src, const ZBlock *blk, u32 nblk, u8 *dst, u8 *lit_scratch, u32 b_first)
 {
-    u32 i = blockIdx.x;
+    u32 i = b_first + blockIdx.x;
+    if (i >= nblk) return;
     const ZBlock &b = blk[i];
     const u8 *from; u8 *to; u32 n; bool fill;
     if (b.btype == BT_RAW) { from = src + b.src_off; to = dst + b.out_off; n = b.bsize; fill = false; }
@@ -584,6 +585,20 @@ __global__ __launch_bounds__(64) void k_exec_seq(const ZBlock *blk, const u32 *s
     }
 }
 
+// Blocks whose regenerated bytes intersect [want_lo, want_hi): first block index, one-past-last, and their byte span.
+__global__ void k_find_range(const u64 *offs, u32 nblk, u64 total, u64 want_lo, u64 want_hi, const i32 *own_huf, u64 *out4)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    u32 lo = 0, hi = nblk;                                   // last block with offs <= want_lo
+    while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (offs[mid] <= want_lo) lo = mid; else hi = mid; }
+    u32 b_lo = lo;
+    lo = b_lo; hi = nblk;                                    // first block with offs >= want_hi
+    while (lo < hi) { u32 mid = (lo + hi) >> 1; if (offs[mid] < want_hi) lo = mid + 1; else hi = mid; }
+    u32 b_hi = lo;
+    out4[0] = b_lo; out4[1] = b_hi; out4[2] = offs[b_lo]; out4[3] = b_hi < nblk ? offs[b_hi] : total;
+    i32 ob = own_huf[b_lo]; out4[4] = ob < 0 ? b_lo : (u64)ob;      // first block whose Huffman table can be in force in the range
+}
+
 // ---- host orchestration ------------------------------------------------------------------------------------------
 int zstd_init_tables(naf_gpu_ctx *c)
 {
@@ -606,7 +621,7 @@ static int zerr(naf_gpu_ctx *c, u32 e, const char *where)
 
 // Decode ONE frame whose header (after the magic) starts at d_src[0].  *consumed = bytes of the frame.
 static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *d_dst, size_t dst_cap,
-                           size_t *out_len, size_t *consumed)
+                           size_t *out_len, size_t *consumed, ZRange *rg)
 {
     u8 hb[18]; size_t hl = src_len < 18 ? src_len : 18;
     int rc = ctx_readback(c, hb, d_src, hl); if (rc) return rc;
@@ -678,12 +693,6 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     u64 *d_total_seq = (u64 *)((u8 *)st + offsetof(ZStat, total_seq));
     u64 *d_total_out = (u64 *)((u8 *)st + offsetof(ZStat, total_out));
     u8 *huf_pool = nullptr; FseE *fse_pool = nullptr; u32 *o_ll = nullptr, *o_ml = nullptr, *o_of = nullptr;
-    if (n_huf_def) {
-        u32 pool_cap = n_huf_def * 4096u;                            // 2^11 entries * 2 B worst case per table
-        huf_pool = (u8 *)arena_alloc(c, pool_cap);
-        if (!huf_pool) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st);
-    }
     if (n_seq_blk) {
         if ((rc = scan_inclusive_max_i32(c, own_ll, nblk))) return rc;
         if ((rc = scan_inclusive_max_i32(c, own_of, nblk))) return rc;
@@ -707,7 +716,21 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     if (hs.err) return zerr(c, hs.err, "sequences");
     *out_len = hs.total_out;
     if (fh.has_fcs && fh.content_size != hs.total_out) return zerr(c, ZE_CORRUPT, "content size mismatch");
-    if (hs.total_out > dst_cap) return ctx_fail(c, NAF_GPU_ECAP, "zstd output needs %llu bytes, capacity %zu", (unsigned long long)hs.total_out, dst_cap);
+    // Range request (multi-GPU sharding): decode only the blocks that feed [want_lo, want_hi).  Needs blocks that
+    // do not reference earlier output, i.e. a frame without sequences (this build's own frames; reference-made
+    // random-ACGT frames); otherwise the whole frame is decoded.
+    u32 b_first = 0, b_count = nblk, huf_first = 0; u64 bias = 0;
+    if (rg) { rg->got_lo = 0; rg->got_hi = hs.total_out; rg->ranged = false; }
+    if (rg && n_seq_blk == 0 && nblk > 0 && rg->want_hi > rg->want_lo) {
+        u64 *r4 = arena_new<u64>(c, 5); if (!r4) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zstd_find_range", k_find_range, 1, 64, 0, (const u64 *)sizes, nblk, (u64)hs.total_out, rg->want_lo, rg->want_hi, (const i32 *)own_huf, r4);
+        u64 h4[5]; rc = ctx_readback(c, h4, r4, 40); if (rc) return rc;
+        huf_first = (u32)h4[4];
+        b_first = (u32)h4[0]; b_count = (u32)(h4[1] - h4[0]); bias = h4[2];
+        rg->got_lo = h4[2]; rg->got_hi = h4[3]; rg->ranged = true;
+        if (h4[3] - h4[2] > dst_cap) return ctx_fail(c, NAF_GPU_ECAP, "zstd range output needs %llu bytes, capacity %zu", (unsigned long long)(h4[3] - h4[2]), dst_cap);
+        d_dst -= bias;                                       // block b lands at d_dst_orig + (out_off[b] - got_lo)
+    } else if (hs.total_out > dst_cap) return ctx_fail(c, NAF_GPU_ECAP, "zstd output needs %llu bytes, capacity %zu", (unsigned long long)hs.total_out, dst_cap);
 
     u32 *done = nullptr, *seq_list = nullptr; u8 *lit_scratch = nullptr;
     if (n_seq_blk) {
@@ -721,11 +744,20 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     }
     LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, done, (u32 *)nullptr, (u32 *)nullptr);
     if (n_huf_def) {
+        // tables of the blocks that will be decoded (and of the earlier blocks that own a table in force there)
+        u32 hb_end = b_first + b_count, hb_n = hb_end - huf_first;
+        u32 pool_cap = (hb_n < n_huf_def ? hb_n : n_huf_def) * 4096u + 4096u;   // 2^11 entries * 2 B worst case per table
+        huf_pool = (u8 *)arena_alloc(c, pool_cap);
+        if (!huf_pool) return NAF_GPU_ENOMEM;
+        if (hb_n) LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(hb_n, 64), 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first);
+        rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+        if (hs.err) return zerr(c, hs.err, "Huffman tables");
         u32 slot = 2u << hs.max_huf_log; if (slot < 16) slot = 16;
-        LAUNCH(c, "zstd_huf_literals", k_huf_literals, cdiv(nblk, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * HUF_IROW,
-               d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st);
+        u32 b_end = b_first + b_count;
+        if (b_count) LAUNCH(c, "zstd_huf_literals", k_huf_literals, cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * HUF_IROW,
+               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first);
     }
-    LAUNCH(c, "zstd_copy_fill", k_copy_fill, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, d_dst, lit_scratch);
+    if (b_count) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
     if (n_seq_blk)
         LAUNCH(c, "zstd_exec_seq", k_exec_seq, n_seq_blk, 64, 0, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
                (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st);
@@ -734,7 +766,14 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     return 0;
 }
 
+int zstd_decode_range(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len, ZRange *rg);
 int zstd_decode(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len)
+{
+    return zstd_decode_range(c, d_src, src_len, has_magic, d_dst, dst_cap, out_len, nullptr);
+}
+
+// rg != nullptr: first frame only is range-decoded (sections written by ennaf are exactly one frame)
+int zstd_decode_range(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len, ZRange *rg)
 {
     size_t pos = 0, out = 0; bool first = true;
     *out_len = 0;
@@ -755,7 +794,8 @@ int zstd_decode(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, 
         }
         first = false;
         size_t n = 0, used = 0;
-        int rc = zstd_decode_one(c, d_src + pos, src_len - pos, d_dst + out, dst_cap > out ? dst_cap - out : 0, &n, &used);
+        int rc = zstd_decode_one(c, d_src + pos, src_len - pos, d_dst + out, dst_cap > out ? dst_cap - out : 0, &n, &used, out == 0 ? rg : nullptr);
+        if (rg && rg->ranged && pos + used < src_len) return ctx_fail(c, NAF_GPU_EZSTD, "range decode needs a single-frame stream");
         if (rc == NAF_GPU_ECAP) { *out_len = out + n; return rc; }
         if (rc) return rc;
         out += n; pos += used;

@@ -108,6 +108,24 @@ def test_unnaf_range_sharding_is_consistent(gpu):
     assert b"".join(parts) == whole
 
 
+def test_unnaf_range_on_own_archives_decodes_only_needed_blocks(gpu, oracle):
+    """Own archives (independent blocks) take the block-range path: every cut of FASTA / FASTQ / --seq /
+    --sequences text equals the slice of the whole text."""
+    from naf_amd import synth
+    rng = np.random.default_rng(4)
+    texts = [synth.fasta_acgt(700000, 5, 80, seed=21), synth.fasta_mixed(25, 30000, 60, seed=22), synth.fastq_reads(3000, 150, seed=23)]
+    for text in texts:
+        d_naf, rep = gpu.ennaf(gpu.to_device(text))
+        for mode in (-1, 0, 2, 3):
+            if mode == 0 and text[:1] == b"@":
+                pass
+            whole = host(gpu.unnaf(d_naf, mode))
+            n = len(whole)
+            cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, 6)]))
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                assert host(gpu.unnaf_range(d_naf, a, b, mode)) == whole[a:b], (mode, a, b)
+
+
 def test_unnaf_random_archives_against_oracle(gpu, oracle):
     """Seeded random FASTA/FASTQ -> oracle archive (raw zstd blocks) -> GPU == oracle, all modes."""
     from naf_amd import synth
