@@ -14,27 +14,7 @@
 //   toggles[k]  = base index where the soft-mask state flips (scan of mask units, units != 255 toggle)
 #include "ctx.h"
 #include "wgscan.h"
-
-enum { EM_FASTA = 0, EM_FASTQ = 1, EM_SEQ = 2, EM_SEQUENCES = 3 };
-
-struct EmitP {
-    // text geometry
-    const u64 *rec_out, *rec_base;     // N+1 entries each
-    const u64 *rec_len;                // N
-    const u32 *hdr_len;                // N   (0 for EM_SEQUENCES / EM_SEQ)
-    const u64 *idz, *nmz;              // positions of the '\0' terminators in ids / names (N each)
-    const u8 *ids, *names;
-    const u8 *seq;                     // packed 4-bit codes, or text bytes
-    const u8 *qual;
-    const u64 *toggles; u64 n_toggles;
-    u64 N, T, L;
-    u64 out_begin, out_end;            // byte range of the full text to produce; out[0] = byte out_begin
-    u32 lut[4];                        // 16-entry code -> ASCII table as four dwords
-    u32 Ldiv_magic;                    // unused when L+1 >= 2^32
-    int mode, has_ids, has_names, masking, upper;
-    u8 sep, hdr_char;
-    int force_slow;
-};
+#include "emit_core.h"
 
 // ---- prep kernels --------------------------------------------------------------------------------------------
 __global__ void k_len_flags(const u32 *units, u64 n, u64 *flag)
@@ -133,12 +113,6 @@ __global__ void k_rec_sizes(u64 N, const u64 *rec_len, const u64 *idz, const u64
 }
 
 // ---- emit ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 upper_bound_u64(const u64 *a, u64 lo, u64 hi, u64 v)   // first index in [lo,hi) with a[i] > v
-{
-    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-
 __device__ __forceinline__ u32 lut_char(const EmitP &P, u32 code)
 {
     return (P.lut[code >> 2] >> (8 * (code & 3))) & 0xFF;
@@ -227,32 +201,7 @@ __device__ __forceinline__ void bases16(const EmitP &P, u64 g, u64 &lo, u64 &hi)
     const u8 *a = P.seq + (g >> 1);
     u64 nib = ld64(a);
     if (g & 1) nib = (nib >> 4) | ((u64)a[8] << 60);
-    u32 out[4];
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        u32 t = (u32)(nib >> (16 * w)) & 0xFFFF;                // 4 nibbles n3n2n1n0
-        u32 y = (t | (t << 8)) & 0x00FF00FF;
-        u32 z = (y | (y << 4)) & 0x0F0F0F0F;                    // one nibble per byte
-        u32 sel = z & 0x07070707;
-        u32 l = __builtin_amdgcn_perm(P.lut[1], P.lut[0], sel); // codes 0..7
-        u32 h = __builtin_amdgcn_perm(P.lut[3], P.lut[2], sel); // codes 8..15
-        u32 m = ((z >> 3) & 0x01010101) * 0xFF;
-        out[w] = (l & ~m) | (h & m);
-    }
-    lo = (u64)out[0] | ((u64)out[1] << 32); hi = (u64)out[2] | ((u64)out[3] << 32);
-}
-
-__device__ __forceinline__ u64 spread_bits8(u32 b)            // bit i of b -> 0x20 in byte i
-{
-    u64 r = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r |= (u64)((b >> i) & 1) << (8 * i + 5);
-    return r;
-}
-
-__device__ __forceinline__ u64 low_bytes_mask(int n)           // n in [0,8] -> lowest n bytes set
-{
-    return n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1);
+    expand16(P.lut, nib, lo, hi);
 }
 
 // One workgroup produces EMIT_SPAN consecutive output bytes as EMIT_SPAN/4096 tiles of 256 lanes x 16 B.
@@ -290,71 +239,106 @@ __global__ __launch_bounds__(256) void k_emit(EmitP P, u8 *out)
     __syncthreads();
     const u64 rlo = sh[0], rhi = sh[1], klo = sh[2], khi = sh[3];
     const bool any_toggle = P.masking && klo < khi;
-    // cached geometry of the lane's current record
+    // cached geometry of the lane's current record, and the lane's (line, col) inside it: consecutive tiles of a lane
+    // are 4096 bytes apart, so (line, col) advances by a constant instead of a division per chunk
     u64 c_ro = 1, c_rn = 0, c_body = 0, c_len = 0, c_base = 0;
+    u64 w_line = 0, w_q0 = 0; u32 w_col = 0; bool w_ok = false;
+    const u32 Lp1 = (P.L >> 31) ? 0 : (u32)P.L + 1;
+    const u32 dq = Lp1 ? 4096u / Lp1 : 0, dr = Lp1 ? 4096u % Lp1 : 0;
 
-    for (u64 tile = span_first; tile <= span_last; tile += 4096) {
-        u64 p0 = tile + (u64)threadIdx.x * 16;
-        if (p0 >= P.out_end) break;
-        u8 *o = out + (p0 - P.out_begin);
-        u32 nbytes = P.out_end - p0 < 16 ? (u32)(P.out_end - p0) : 16;
-        bool fast = false, qual_copy = false; u64 g0 = 0, len = 0, j0 = 0, qoff = 0; int nl_b = 64;
-        if (nbytes == 16 && !P.force_slow) {
-            if (P.mode == EM_SEQ) { fast = true; g0 = p0; len = ~0ull; }
+    struct Chunk { u64 p0, g0, len, j0, qoff; int nl_b; u32 nbytes; bool fast, qual_copy, live; };
+    // geometry of one 16-byte chunk (no payload access)
+    auto prep = [&](u64 tile) -> Chunk {
+        Chunk k; k.p0 = tile + (u64)threadIdx.x * 16; k.g0 = 0; k.len = 0; k.j0 = 0; k.qoff = 0; k.nl_b = 64; k.fast = false; k.qual_copy = false;
+        k.live = tile <= span_last && k.p0 < P.out_end; k.nbytes = 0;
+        if (!k.live) return k;
+        u64 p0 = k.p0;
+        k.nbytes = P.out_end - p0 < 16 ? (u32)(P.out_end - p0) : 16;
+        if (k.nbytes == 16 && !P.force_slow) {
+            if (P.mode == EM_SEQ) { k.fast = true; k.g0 = p0; k.len = ~0ull; }
             else {
                 if (!(p0 >= c_ro && p0 < c_rn)) {
                     u64 r = upper_bound_u64(P.rec_out, rlo, rhi + 1, p0) - 1;
                     c_ro = P.rec_out[r]; c_rn = P.rec_out[r + 1]; c_body = c_ro + P.hdr_len[r]; c_len = P.rec_len[r]; c_base = P.rec_base[r];
+                    w_ok = false;
                 }
                 if (p0 >= c_body && p0 + 16 <= c_rn) {
-                    u64 q0 = p0 - c_body; len = c_len;
+                    u64 q0 = p0 - c_body; k.len = c_len;
                     if (P.mode == EM_FASTQ) {
-                        if (q0 + 16 <= len) { fast = true; j0 = q0; g0 = c_base + j0; len = ~0ull; }
-                        else if (q0 >= len + 3 && q0 + 16 <= 2 * len + 3) { qual_copy = true; qoff = c_base + (q0 - len - 3); }
-                    } else if (P.mode == EM_SEQUENCES || P.L == 0) { fast = true; j0 = q0; g0 = c_base + j0; }
+                        if (q0 + 16 <= c_len) { k.fast = true; k.j0 = q0; k.g0 = c_base + q0; k.len = ~0ull; }
+                        else if (q0 >= c_len + 3 && q0 + 16 <= 2 * c_len + 3) { k.qual_copy = true; k.qoff = c_base + (q0 - c_len - 3); }
+                    } else if (P.mode == EM_SEQUENCES || P.L == 0) { k.fast = true; k.j0 = q0; k.g0 = c_base + q0; }
                     else if (P.L >= 16) {
                         u64 line, col;
-                        if ((q0 >> 32) == 0 && (P.L >> 31) == 0) { u32 d = (u32)P.L + 1, l32 = (u32)q0 / d; line = l32; col = (u32)q0 - l32 * d; }
+                        if (Lp1 && w_ok && q0 == w_q0 + 4096) {      // same record as this lane's previous tile
+                            u32 c2 = w_col + dr; line = w_line + dq;
+                            if (c2 >= Lp1) { c2 -= Lp1; line++; }
+                            col = c2;
+                        }
+                        else if ((q0 >> 32) == 0 && Lp1) { u32 l32 = (u32)q0 / Lp1; line = l32; col = (u32)q0 - l32 * Lp1; }
                         else { line = q0 / (P.L + 1); col = q0 - line * (P.L + 1); }
-                        j0 = line * P.L + col; g0 = c_base + j0;
+                        w_q0 = q0; w_line = line; w_col = (u32)col; w_ok = true;
+                        k.j0 = line * P.L + col; k.g0 = c_base + k.j0;
                         u64 d = P.L - col;                      // byte index of the line-end newline
-                        nl_b = d < 16 ? (int)d : 64;
-                        fast = true;
+                        k.nl_b = d < 16 ? (int)d : 64;
+                        k.fast = true;
                     }
                 }
             }
         }
-        if (qual_copy) { uint4 v; memcpy(&v, P.qual + qoff, 16); memcpy(o, &v, 16); continue; }
-        if (fast) {
-            u64 lo, hi;
-            bases16<FOURBIT>(P, g0, lo, hi);
+        return k;
+    };
+    // payload fetch: 16 nibbles (or 16 text bytes) starting at base g0
+    auto fetch = [&](const Chunk &k, u64 &a, u64 &b) {
+        a = b = 0;
+        if (!k.live) return;
+        if (k.qual_copy) { a = ld64(P.qual + k.qoff); b = ld64(P.qual + k.qoff + 8); }
+        else if (k.fast) {
+            if (FOURBIT) { const u8 *s = P.seq + (k.g0 >> 1); a = ld64(s); b = s[8]; }
+            else { a = ld64(P.seq + k.g0); b = ld64(P.seq + k.g0 + 8); }
+        }
+    };
+    auto finish = [&](const Chunk &k, u64 a, u64 b) {
+        if (!k.live) return;
+        u8 *o = out + (k.p0 - P.out_begin);
+        if (k.qual_copy) { uint4 v; v.x = (u32)a; v.y = (u32)(a >> 32); v.z = (u32)b; v.w = (u32)(b >> 32); memcpy(o, &v, 16); return; }
+        if (k.fast) {
+            u64 lo, hi, g0 = k.g0;
+            if (FOURBIT) { u64 nib = a; if (g0 & 1) nib = (nib >> 4) | (b << 60); expand16(P.lut, nib, lo, hi); }
+            else {
+                lo = a; hi = b;
+                if (P.upper) {
+                    auto up = [](u64 v) { u64 r = 0; for (int i = 0; i < 8; i++) { u32 c = (v >> (8 * i)) & 0xFF; if (c >= 'a' && c <= 'z') c -= 32; r |= (u64)c << (8 * i); } return r; };
+                    lo = up(lo); hi = up(hi);
+                }
+            }
             if (any_toggle) {
-                u64 k = upper_bound_u64(P.toggles, klo, khi, g0);  // toggles <= g0
-                u32 state = (u32)(k & 1), m16 = 0; u64 pos = g0;
+                u64 kk = upper_bound_u64(P.toggles, klo, khi, g0);  // toggles <= g0
+                u32 state = (u32)(kk & 1), m16 = 0; u64 pos = g0;
                 for (;;) {                                      // walk the toggles that fall inside (g0, g0+16)
-                    u64 nxt = k < khi ? P.toggles[k] : ~0ull;
+                    u64 nxt = kk < khi ? P.toggles[kk] : ~0ull;
                     u64 end = nxt < g0 + 16 ? nxt : g0 + 16;
                     if (state && end > pos) m16 |= (u32)(((1u << (end - pos)) - 1) << (pos - g0));
                     if (nxt >= g0 + 16) break;
-                    pos = nxt; state ^= 1; k++;
+                    pos = nxt; state ^= 1; kk++;
                 }
                 lo += spread_bits8(m16 & 0xFF); hi += spread_bits8(m16 >> 8);
             } else if (P.masking && (klo & 1)) { lo += 0x2020202020202020ull; hi += 0x2020202020202020ull; }   // whole span inside one masked run
-            if (nl_b < 16) {
-                // bytes < nl_b keep, byte nl_b = '\n', bytes > nl_b take the previous base
-                u64 slo = lo << 8, shi = (hi << 8) | (lo >> 56);
-                u64 mlo = low_bytes_mask(nl_b), mhi = nl_b > 8 ? low_bytes_mask(nl_b - 8) : 0;
-                u64 m1lo = low_bytes_mask(nl_b + 1), m1hi = nl_b + 1 > 8 ? low_bytes_mask(nl_b + 1 - 8) : 0;
-                lo = (lo & mlo) | (slo & ~m1lo); hi = (hi & mhi) | (shi & ~m1hi);
-                if (nl_b < 8) lo |= (u64)'\n' << (8 * nl_b); else hi |= (u64)'\n' << (8 * (nl_b - 8));
-            }
-            u64 j15 = j0 + 15 - (15 > nl_b ? 1 : 0);
-            if (j15 >= len) hi = (hi & 0x00FFFFFFFFFFFFFFull) | ((u64)'\n' << 56);     // record-end newline
+            if (k.nl_b < 16) splice_newline(lo, hi, k.nl_b);
+            u64 j15 = k.j0 + 15 - (15 > k.nl_b ? 1 : 0);
+            if (j15 >= k.len) hi = (hi & 0x00FFFFFFFFFFFFFFull) | ((u64)'\n' << 56);     // record-end newline
             uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
             memcpy(o, &v, 16);
-            continue;
+            return;
         }
-        for (u32 b = 0; b < nbytes; b++) o[b] = (u8)emit_byte<FOURBIT>(P, p0 + b, rlo, rhi, klo, khi);
+        for (u32 bb = 0; bb < k.nbytes; bb++) o[bb] = (u8)emit_byte<FOURBIT>(P, k.p0 + bb, rlo, rhi, klo, khi);
+    };
+    // two tiles per iteration: both payload loads are in flight before either chunk is expanded and stored
+    for (u64 tile = span_first; tile <= span_last; tile += 8192) {
+        Chunk ka = prep(tile), kb = prep(tile + 4096);
+        u64 a0, a1, b0, b1;
+        fetch(ka, a0, a1); fetch(kb, b0, b1);
+        finish(ka, a0, a1); finish(kb, b0, b1);
     }
 }
 
@@ -654,6 +638,19 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         rgs.want_lo = pl.fourbit ? g[0] / 2 : g[0]; rgs.want_hi = pl.fourbit ? (g[1] + 1) / 2 : g[1];
         rgq.want_lo = g[0]; rgq.want_hi = g[1];
         prs = &rgs; prq = &rgq;
+    }
+    // Whole FASTA text of a 4-bit archive: decode and emit in one kernel when the frame is literal-only.
+    // (Measured slower than decode + emit on MI355X for now: its per-lane 16-byte text stores are partial-line
+    // writes from 600 k streams; kept behind NAF_GPU_FUSE=1 and under test until the text is staged through LDS.)
+    const char *fuse = getenv("NAF_GPU_FUSE");
+    if (whole && pl.P.mode == EM_FASTA && pl.fourbit && (pl.P.L == 0 || pl.P.L >= 16) && !pl.P.force_slow && fuse && fuse[0] == '1') {
+        size_t n2 = 0;
+        rc = zstd_decode_fused_fasta(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, &n2, &pl.P, d_out);
+        if (rc == 0) {
+            if (n2 != pl.seq_bytes) return ctx_fail(c, NAF_GPU_EFORMAT, "can't decompress sequence\n");
+            return 0;
+        }
+        if (rc != -100) return rc;
     }
     // sequence payload (the dominant zstd stream)
     u64 seq_need = prs ? (rgs.want_hi - rgs.want_lo) + 2 * 131072 + 64 : pl.seq_bytes + 64;

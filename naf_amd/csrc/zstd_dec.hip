@@ -15,13 +15,14 @@
 //   k_exec_seq       one wave per block with sequences, ticket-ordered, waits on per-block done flags
 #include "ctx.h"
 #include "zstd_dec_core.h"
+#include "emit_core.h"
 
 struct ZStat {                 // device-side counters read back by the host
     u32 nblk; u32 err; u64 end_off;
     u32 n_huf_def, n_seq_blk, max_huf_log, pad;
     u32 huf_pool_used, fse_pool_used;
     u64 total_seq, total_out;
-    u32 ticket, pad2;
+    u32 ticket, n_plain_huf;     // n_plain_huf: compressed blocks with Huffman literals and no sequences
 };
 
 static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
@@ -203,6 +204,7 @@ __global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_hu
     own_ml[i] = (sq && b.modes[2] != SM_REPEAT) ? (i32)i : -1;
     seq_cnt[i] = sq ? b.nseq : 0;
     if (comp && b.lit_type == LIT_HUF) atomicAdd(&st->n_huf_def, 1u);
+    if (comp && b.lit_type >= LIT_HUF && b.nseq == 0) atomicAdd(&st->n_plain_huf, 1u);
     if (sq) atomicAdd(&st->n_seq_blk, 1u);
 }
 
@@ -327,6 +329,132 @@ __global__ void k_seq_flag(const ZBlock *blk, u32 nblk, u64 *flag)
     if (i < nblk) flag[i] = (blk[i].btype == BT_COMP && blk[i].nseq > 0) ? 1 : 0;
 }
 
+
+// ---- fused decode + FASTA emit -----------------------------------------------------------------------------------
+// For frames made only of literal blocks (this build's own archives, reference archives of random DNA) the decoded
+// 4-bit stream never has to exist in HBM: the lane that decodes a Huffman stream knows the base index of every
+// symbol it produces, so it can write the FASTA text itself -- 16 bases per 8 decoded bytes, with the line-end and
+// record-end newlines that follow its bases.  Headers are written by k_emit_headers.  This removes the 2 x 4.94 GB
+// (10 GB config) round trip of the packed stream and the separate emit pass.
+struct LaneEmit { u64 g, rec_end_g, tp, r, tk; u32 col, mstate; };
+
+__device__ __forceinline__ void le_next_record(const EmitP &P, LaneEmit &e)
+{
+    u64 r = e.r + 1;
+    while (r < P.N && P.rec_base[r + 1] == P.rec_base[r]) r++;            // records without bases have no body
+    e.r = r;
+    if (r < P.N) { e.tp = P.rec_out[r] + P.hdr_len[r]; e.rec_end_g = P.rec_base[r + 1]; }
+    else e.rec_end_g = ~0ull;
+    e.col = 0;
+}
+__device__ __forceinline__ void le_init(const EmitP &P, LaneEmit &e, u64 g)
+{
+    e.g = g; e.col = 0; e.tk = 0; e.mstate = 0; e.r = 0; e.tp = 0; e.rec_end_g = ~0ull;
+    if (g >= P.T) return;
+    u64 r = upper_bound_u64(P.rec_base, 0, P.N + 1, g) - 1;
+    u64 j = g - P.rec_base[r];
+    e.r = r; e.rec_end_g = P.rec_base[r + 1];
+    e.tp = P.rec_out[r] + P.hdr_len[r] + j + (P.L ? j / P.L : 0);
+    e.col = P.L ? (u32)(j % P.L) : 0;
+    if (P.masking) {                                                      // tk = number of toggles < g
+        u64 lo = 0, hi = P.n_toggles;
+        while (lo < hi) { u64 mid = (lo + hi) >> 1; if (P.toggles[mid] < g) lo = mid + 1; else hi = mid; }
+        e.tk = lo; e.mstate = (u32)(lo & 1);
+    }
+}
+__device__ __forceinline__ void le_one_base(const EmitP &P, LaneEmit &e, u8 *text, u32 code)
+{
+    if (P.masking) while (e.tk < P.n_toggles && P.toggles[e.tk] <= e.g) { e.mstate ^= 1; e.tk++; }
+    u32 ch = (P.lut[code >> 2] >> (8 * (code & 3))) & 0xFF;
+    if (e.mstate) ch += 32;
+    text[e.tp++] = (u8)ch;
+    e.g++; e.col++;
+    bool rec_done = e.g == e.rec_end_g;
+    if ((P.L && e.col == P.L) || rec_done) { text[e.tp++] = '\n'; e.col = 0; }
+    if (rec_done) le_next_record(P, e);
+}
+// nb bases (<= 16) held as nibbles of `nib`.  lut2 (LDS): packed byte -> two ASCII bytes.  own_ahead: this lane
+// will itself write at least the next 32 bases after this group, so a 16-byte store may run past the group's end.
+__device__ __forceinline__ void le_group(const EmitP &P, LaneEmit &e, u8 *text, u64 nib, u32 nb, const u16 *lut2, bool own_ahead)
+{
+    if (e.g >= P.T) return;
+    if (P.T - e.g < nb) nb = (u32)(P.T - e.g);                              // odd total: the final high nibble is padding
+    if (nb == 16 && e.g + 16 <= e.rec_end_g && (P.L == 0 || P.L >= 16)) {
+        u32 lo32 = (u32)nib, hi32 = (u32)(nib >> 32);
+        u32 d0 = (u32)lut2[lo32 & 0xFF] | ((u32)lut2[(lo32 >> 8) & 0xFF] << 16);
+        u32 d1 = (u32)lut2[(lo32 >> 16) & 0xFF] | ((u32)lut2[lo32 >> 24] << 16);
+        u32 d2 = (u32)lut2[hi32 & 0xFF] | ((u32)lut2[(hi32 >> 8) & 0xFF] << 16);
+        u32 d3 = (u32)lut2[(hi32 >> 16) & 0xFF] | ((u32)lut2[hi32 >> 24] << 16);
+        if (P.masking && (e.mstate || (e.tk < P.n_toggles && P.toggles[e.tk] < e.g + 16))) {
+            u32 m16 = 0; u64 pos = e.g;
+            for (;;) {
+                u64 nxt = e.tk < P.n_toggles ? P.toggles[e.tk] : ~0ull;
+                u64 end = nxt < e.g + 16 ? nxt : e.g + 16;
+                if (e.mstate && end > pos) m16 |= (u32)(((1u << (end - pos)) - 1) << (pos - e.g));
+                if (nxt >= e.g + 16) break;
+                pos = nxt > pos ? nxt : pos; e.mstate ^= 1; e.tk++;
+            }
+            auto sp = [](u32 x) { return ((x & 1) | ((x & 2) << 7) | ((x & 4) << 14) | ((x & 8) << 21)) * 0x20u; };
+            d0 += sp(m16 & 15); d1 += sp((m16 >> 4) & 15); d2 += sp((m16 >> 8) & 15); d3 += sp(m16 >> 12);
+        }
+        u8 *o = text + e.tp;
+        uint4 v; v.x = d0; v.y = d1; v.z = d2; v.w = d3;
+        if (P.L && e.col + 16 >= P.L) {
+            u32 nl = (u32)P.L - e.col;
+            if (nl == 16) { memcpy(o, &v, 16); o[16] = '\n'; }
+            else if (own_ahead) {
+                // bytes [0,nl) | '\n' | bytes [nl,16): store the 16 bytes, then the tail again one byte later, then the
+                // newline.  The second store runs past byte 16; this lane overwrites that region with its next groups.
+                u32 w = nl >> 2, bsh = nl & 3;
+                u32 c0 = w == 0 ? d0 : (w == 1 ? d1 : (w == 2 ? d2 : d3));
+                u32 c1 = w == 0 ? d1 : (w == 1 ? d2 : (w == 2 ? d3 : 0));
+                u32 c2 = w == 0 ? d2 : (w == 1 ? d3 : 0);
+                u32 c3 = w == 0 ? d3 : 0;
+                uint4 t;
+                t.x = __builtin_amdgcn_alignbyte(c1, c0, bsh); t.y = __builtin_amdgcn_alignbyte(c2, c1, bsh);
+                t.z = __builtin_amdgcn_alignbyte(c3, c2, bsh); t.w = __builtin_amdgcn_alignbyte(0u, c3, bsh);
+                memcpy(o, &v, 16);
+                memcpy(o + nl + 1, &t, 16);
+                o[nl] = '\n';
+            } else {
+                u64 lo = (u64)d0 | ((u64)d1 << 32), hi = (u64)d2 | ((u64)d3 << 32);
+                u32 extra = splice_newline(lo, hi, (int)nl);
+                v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
+                memcpy(o, &v, 16); o[16] = (u8)extra;
+            }
+            e.tp += 17; e.col = e.col + 16 - (u32)P.L;
+        } else {
+            memcpy(o, &v, 16);
+            e.tp += 16; e.col += 16;
+        }
+        e.g += 16;
+        if (e.g == e.rec_end_g) {
+            if (!(P.L && e.col == 0)) text[e.tp++] = '\n';                   // unless the line-end newline was the record end
+            le_next_record(P, e);
+        }
+        return;
+    }
+    for (u32 i = 0; i < nb; i++) le_one_base(P, e, text, (u32)(nib >> (4 * i)) & 15);
+}
+
+__global__ void k_emit_headers(EmitP P, u8 *text)
+{
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.N) return;
+    u32 hl = P.hdr_len[r]; u64 at = P.rec_out[r];
+    u64 ids0 = 0, idl = 0, nm0 = 0;
+    if (P.has_ids) { ids0 = r ? P.idz[r - 1] + 1 : 0; idl = P.idz[r] - ids0; }
+    if (P.has_names) nm0 = r ? P.nmz[r - 1] + 1 : 0;
+    for (u32 k = 0; k < hl; k++) {
+        u32 ch;
+        if (k == 0) ch = P.hdr_char;
+        else if (k == hl - 1) ch = '\n';
+        else if (P.has_ids) { u64 q = k - 1; ch = q < idl ? P.ids[ids0 + q] : (q == idl ? P.sep : P.names[nm0 + (q - idl - 1)]); }
+        else ch = P.names[nm0 + k - 1];
+        text[at + k] = (u8)ch;
+    }
+}
+
 // ---- Huffman literals: one lane per stream, 16 blocks per 64-lane workgroup, tables staged in LDS ----------
 // Both sides of every stream go through LDS so that each lane's ~4.5 B/symbol-group trickle becomes whole
 // 64-byte sectors on the memory side (64 lanes walk 64 streams that are KiB apart: per-lane 8-byte global
@@ -338,13 +466,22 @@ __global__ void k_seq_flag(const ZBlock *blk, u32 nblk, u64 *flag)
 // reader instead.
 #define HUF_BLOCKS_PER_WG 16
 #define HUF_ROUND 32                       // symbols per lane per round
-#define HUF_OROW 40                        // output row pitch (32 + 8)
+#define HUF_OROW 72                        // output row pitch (64 + 8)
 #define HUF_IROW 136                       // input window pitch (128 + 8)
+template <bool FUSE>
 __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf,
-                                                      const u8 *pool, u32 slot_bytes, u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first)
+                                                      const u8 *pool, u32 slot_bytes, u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first,
+                                                      EmitP EP, u8 *text)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     u8 *irows = lds + HUF_BLOCKS_PER_WG * slot_bytes;                // 64 x 136 B
+    u16 *lut2 = (u16 *)(irows + 64 * HUF_IROW);                       // FUSE: packed byte -> two ASCII bytes
+    u8 *orows = (u8 *)lut2;                                           // !FUSE: 64 output rows of 72 B + 64 row pointers
+    u64 *row_out = (u64 *)(orows + 64 * HUF_OROW);
+    if (FUSE) for (u32 v = threadIdx.x; v < 256; v += 64) {
+        u32 a = v & 15, b = v >> 4;
+        lut2[v] = (u16)(((EP.lut[a >> 2] >> (8 * (a & 3))) & 0xFF) | (((EP.lut[b >> 2] >> (8 * (b & 3))) & 0xFF) << 8));
+    }
     int lane = threadIdx.x;
     u32 b0 = b_first + blockIdx.x * HUF_BLOCKS_PER_WG;
     for (u32 j = 0; j < HUF_BLOCKS_PER_WG; j++) {                     // stage the table in force for each block
@@ -390,6 +527,9 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
             }
         }
     }
+    if (!FUSE) row_out[lane] = valid ? (u64)out : 0;
+    LaneEmit le; le.g = 0; le.rec_end_g = 0; le.tp = 0; le.r = 0; le.tk = 0; le.col = 0; le.mstate = 0;
+    if (FUSE && valid) le_init(EP, le, 2 * (u64)out);                       // dst is null: `out` is the byte offset in the packed stream
     u32 my_rounds = valid ? n / HUF_ROUND : 0xFFFFFFFFu;                 // wave-uniform round count
     for (int d = 32; d; d >>= 1) { u32 o = (u32)__shfl_xor((int)my_rounds, d, 64); my_rounds = o < my_rounds ? o : my_rounds; }
     u32 rounds = my_rounds == 0xFFFFFFFFu ? 0 : my_rounds;
@@ -445,17 +585,38 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
                     }
                     accs[g] = acc;
                 }
-                u8 *gout = out + (u64)R * HUF_ROUND;
+                if (FUSE) {
 #pragma unroll
-                for (u32 g = 0; g < HUF_ROUND / 16; g++) {
-                    uint4 v; v.x = (u32)accs[2 * g]; v.y = (u32)(accs[2 * g] >> 32); v.z = (u32)accs[2 * g + 1]; v.w = (u32)(accs[2 * g + 1] >> 32);
-                    memcpy(gout + 16 * g, &v, 16);
+                    for (u32 g = 0; g < HUF_ROUND / 8; g++) le_group(EP, le, text, accs[g], 16, lut2, true);   // >= 160 more input bytes follow: this lane owns far more than the next 32 bases
+                } else {
+                    u8 *orow = orows + lane * HUF_OROW + (R & 1) * 32;
+#pragma unroll
+                    for (u32 g = 0; g < HUF_ROUND / 8; g++) *(u64 *)(orow + 8 * g) = accs[g];
                 }
             }
+            if (!FUSE && (R & 1)) {                                      // two rounds = 64 bytes per lane: write rows out, 4 lanes per row
+                __syncthreads();
+#pragma unroll
+                for (u32 jj = 0; jj < 4; jj++) {
+                    u32 row = jj * 16 + (lane >> 2), piece = lane & 3;
+                    u64 o = row_out[row];
+                    if (o) {
+                        const u8 *r = orows + row * HUF_OROW + piece * 16;
+                        uint4 v; u64 a = *(const u64 *)r, bb = *(const u64 *)(r + 8);
+                        v.x = (u32)a; v.y = (u32)(a >> 32); v.z = (u32)bb; v.w = (u32)(bb >> 32);
+                        memcpy((u8 *)o + (u64)(R - 1) * HUF_ROUND + piece * 16, &v, 16);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (!FUSE && (R & 1) && valid) {                                  // an odd number of rounds ran: flush the pending half row
+            const u8 *r = orows + lane * HUF_OROW;
+            for (u32 q = 0; q < 32; q += 8) st64(out + (u64)(R - 1) * HUF_ROUND + q, *(const u64 *)(r + q));
         }
         if (valid && live) { gp -= bits >> 3; bits &= 7; br.c = ld64((const u8 *)gp); br.consumed = bits; }
         br.ptr = (const u8 *)gp;
-    } else {
+    } else if (!FUSE) {
         // ---- register double buffer: W1 holds the 8 bytes below the container, loaded one refill ahead -------
         u64 W1 = 0;
         const u32 need = 96 + 16;
@@ -480,7 +641,17 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
     }
     if (valid) {
         u32 done = R * HUF_ROUND;
-        u8 e = huf_decode_n(br, tab, log, out + done, n - done);
+        u8 e = 0;
+        if (FUSE) {
+            u32 rem = n - done;
+            while (rem && !e) {                                               // 8 symbols (16 bases) at a time through the generic reader
+                u32 k = rem < 8 ? rem : 8; u8 tmp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+                e = huf_decode_n(br, tab, log, tmp, k);
+                u64 nib; memcpy(&nib, tmp, 8);
+                le_group(EP, le, text, nib, 2 * k, lut2, false);
+                rem -= k;
+            }
+        } else e = huf_decode_n(br, tab, log, out + done, n - done);
         if (!e) { bitr_reload(br); if (!bitr_finished(br)) e = ZE_CORRUPT; }
         if (e) err = e;
     }
@@ -613,6 +784,7 @@ int zstd_init_tables(naf_gpu_ctx *c)
     return 0;
 }
 
+#define ZSTD_NEED_TWO_PASS (-100)
 static int zerr(naf_gpu_ctx *c, u32 e, const char *where)
 {
     const char *m = e == ZE_TRUNC ? "truncated" : e == ZE_CORRUPT ? "corrupt" : e == ZE_UNSUP ? "unsupported feature" : "table pool";
@@ -621,7 +793,7 @@ static int zerr(naf_gpu_ctx *c, u32 e, const char *where)
 
 // Decode ONE frame whose header (after the magic) starts at d_src[0].  *consumed = bytes of the frame.
 static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *d_dst, size_t dst_cap,
-                           size_t *out_len, size_t *consumed, ZRange *rg)
+                           size_t *out_len, size_t *consumed, ZRange *rg, const EmitP *fuse, u8 *text)
 {
     u8 hb[18]; size_t hl = src_len < 18 ? src_len : 18;
     int rc = ctx_readback(c, hb, d_src, hl); if (rc) return rc;
@@ -689,6 +861,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
     if (hs.err) return zerr(c, hs.err, "block parse");
     u32 n_seq_blk = hs.n_seq_blk, n_huf_def = hs.n_huf_def;
+    // fused decode+emit needs every block to be a literal-only Huffman block
+    if (fuse && !(n_seq_blk == 0 && hs.n_plain_huf == nblk && nblk > 0)) return ZSTD_NEED_TWO_PASS;
     if ((rc = scan_inclusive_max_i32(c, own_huf, nblk))) return rc;
     u64 *d_total_seq = (u64 *)((u8 *)st + offsetof(ZStat, total_seq));
     u64 *d_total_out = (u64 *)((u8 *)st + offsetof(ZStat, total_out));
@@ -720,6 +894,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     // do not reference earlier output, i.e. a frame without sequences (this build's own frames; reference-made
     // random-ACGT frames); otherwise the whole frame is decoded.
     u32 b_first = 0, b_count = nblk, huf_first = 0; u64 bias = 0;
+    if (fuse) { d_dst = nullptr; dst_cap = ~(size_t)0; }
     if (rg) { rg->got_lo = 0; rg->got_hi = hs.total_out; rg->ranged = false; }
     if (rg && n_seq_blk == 0 && nblk > 0 && rg->want_hi > rg->want_lo) {
         u64 *r4 = arena_new<u64>(c, 5); if (!r4) return NAF_GPU_ENOMEM;
@@ -754,10 +929,14 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         if (hs.err) return zerr(c, hs.err, "Huffman tables");
         u32 slot = 2u << hs.max_huf_log; if (slot < 16) slot = 16;
         u32 b_end = b_first + b_count;
-        if (b_count) LAUNCH(c, "zstd_huf_literals", k_huf_literals, cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * HUF_IROW,
-               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first);
+        if (fuse && hs.max_huf_log > 7) return ZSTD_NEED_TWO_PASS;
+        EmitP ep; memset(&ep, 0, sizeof ep); if (fuse) ep = *fuse;
+        if (b_count && fuse) LAUNCH(c, "zstd_huf_fused_emit", (k_huf_literals<true>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * HUF_IROW + 512,
+               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text);
+        else if (b_count) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * HUF_IROW + 64 * HUF_OROW + 512,
+               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text);
     }
-    if (b_count) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
+    if (b_count && !fuse) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
     if (n_seq_blk)
         LAUNCH(c, "zstd_exec_seq", k_exec_seq, n_seq_blk, 64, 0, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
                (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st);
@@ -766,10 +945,22 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     return 0;
 }
 
-int zstd_decode_range(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len, ZRange *rg);
 int zstd_decode(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len)
 {
     return zstd_decode_range(c, d_src, src_len, has_magic, d_dst, dst_cap, out_len, nullptr);
+}
+
+int zstd_decode_fused_fasta(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, size_t *out_len, const EmitP *P, u8 *text)
+{
+    // single frame only; returns ZSTD_NEED_TWO_PASS when the frame has blocks the fused kernel does not cover
+    size_t used = 0; u8 m[4];
+    size_t pos = 0;
+    if (has_magic) { if (src_len < 4) return zerr(c, ZE_TRUNC, "magic"); int rc = ctx_readback(c, m, d_src, 4); if (rc) return rc; if (ld32(m) != 0xFD2FB528u) return ZSTD_NEED_TWO_PASS; pos = 4; }
+    int rc = zstd_decode_one(c, d_src + pos, src_len - pos, nullptr, 0, out_len, &used, nullptr, P, text);
+    if (rc) return rc;
+    if (pos + used != src_len) return ZSTD_NEED_TWO_PASS;
+    LAUNCH(c, "unnaf_emit_headers", k_emit_headers, cdiv(P->N, 256), 256, 0, *P, text);
+    return 0;
 }
 
 // rg != nullptr: first frame only is range-decoded (sections written by ennaf are exactly one frame)
@@ -794,7 +985,7 @@ int zstd_decode_range(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_m
         }
         first = false;
         size_t n = 0, used = 0;
-        int rc = zstd_decode_one(c, d_src + pos, src_len - pos, d_dst + out, dst_cap > out ? dst_cap - out : 0, &n, &used, out == 0 ? rg : nullptr);
+        int rc = zstd_decode_one(c, d_src + pos, src_len - pos, d_dst + out, dst_cap > out ? dst_cap - out : 0, &n, &used, out == 0 ? rg : nullptr, nullptr, nullptr);
         if (rg && rg->ranged && pos + used < src_len) return ctx_fail(c, NAF_GPU_EZSTD, "range decode needs a single-frame stream");
         if (rc == NAF_GPU_ECAP) { *out_len = out + n; return rc; }
         if (rc) return rc;

@@ -64,11 +64,13 @@ MODES = {"fasta": (0, True, -1), "seq": (2, True, -1), "sequences": (3, True, -1
          "fasta_nomask": (0, False, -1), "fasta_ll13": (0, True, 13), "fasta_ll0": (0, True, 0), "fastq": (1, True, -1)}
 
 
-@pytest.mark.parametrize("force_slow", ["0", "1"])
+@pytest.mark.parametrize("path", ["fused", "twopass", "slow"])
 @pytest.mark.parametrize("case", naf_cases(), ids=lambda c: c["name"])
-def test_unnaf_matches_reference_outputs(gpu, case, force_slow, monkeypatch):
-    """Bit-exact against the outputs of the real reference unnaf on reference-made archives."""
-    monkeypatch.setenv("NAF_GPU_FORCE_SLOW", force_slow)
+def test_unnaf_matches_reference_outputs(gpu, case, path, monkeypatch):
+    """Bit-exact against the outputs of the real reference unnaf on reference-made archives, through each of the
+    three emit paths: fused decode+emit (literal-only frames), decode then 16-byte-chunk emit, per-byte emit."""
+    monkeypatch.setenv("NAF_GPU_FORCE_SLOW", "1" if path == "slow" else "0")
+    monkeypatch.setenv("NAF_GPU_FUSE", "1" if path == "fused" else "0")
     naf = golden_bytes("naf", case["name"] + ".naf")
     d = gpu.to_device(naf)
     for m, (mode, use_mask, ll) in MODES.items():
@@ -124,6 +126,27 @@ def test_unnaf_range_on_own_archives_decodes_only_needed_blocks(gpu, oracle):
             cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, 6)]))
             for a, b in zip(cuts[:-1], cuts[1:]):
                 assert host(gpu.unnaf_range(d_naf, a, b, mode)) == whole[a:b], (mode, a, b)
+
+
+def test_fused_path_on_own_archives(gpu, oracle, monkeypatch):
+    """Own archives are literal-only, so whole-FASTA calls take the fused kernel: compare with the two-pass path
+    and the oracle over record shapes that stress it (empty records, tiny records, masks, odd totals, line widths)."""
+    from naf_amd import synth
+    rng = np.random.default_rng(77)
+    texts = [synth.fasta_acgt(1000001, 3, 80, seed=31), synth.fasta_acgt(300000, 2, 0, seed=32), synth.fasta_acgt(99999, 7, 16, seed=33),
+             synth.fasta_mixed(60, 9000, 60, seed=34, empty_every=4), synth.fasta_mixed(400, 40, 17, seed=35, empty_every=3),
+             synth.fasta_mixed(30, 70000, 1000, seed=36), b">only\n" + b"acgtn" * 20001 + b"\n>e1\n>e2\n>last\nA\n"]
+    for text in texts:
+        d_naf, rep = gpu.ennaf(gpu.to_device(text))
+        exp = oracle.unnaf(host(d_naf), 0)
+        for ll in (-1, 0, 16, 61, 100000):
+            for um in (True, False):
+                e = exp if (ll == -1 and um) else oracle.unnaf(host(d_naf), 0, use_mask=um, line_length=ll)
+                monkeypatch.setenv("NAF_GPU_FUSE", "1")
+                a = host(gpu.unnaf(d_naf, 0, um, ll))
+                monkeypatch.setenv("NAF_GPU_FUSE", "0")
+                b = host(gpu.unnaf(d_naf, 0, um, ll))
+                assert a == e and b == e, (len(text), ll, um)
 
 
 def test_unnaf_random_archives_against_oracle(gpu, oracle):
