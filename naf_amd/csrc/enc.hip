@@ -34,12 +34,42 @@ __device__ __forceinline__ bool c_unexp_comment(u32 c) { return c < 0x20 || c ==
 __device__ __forceinline__ bool c_expected(const EncP &P, u32 c) { return (P.expected[c >> 5] >> (c & 31)) & 1; }
 
 // ---- K1: per-tile last EOL / last space position -------------------------------------------------------------
+// A thread's 16 input bytes, held in registers (two 8-byte loads instead of 16 byte loads).
+struct Piece { u64 w0, w1; u32 cnt; };
+__device__ __forceinline__ Piece load_piece(const EncP &P, u64 base)
+{
+    Piece pc; pc.w0 = pc.w1 = 0; pc.cnt = 0;
+    if (base >= P.n) return pc;
+    if (base + ET_BYTES <= P.n) { pc.w0 = ld64(P.text + base); pc.w1 = ld64(P.text + base + 8); pc.cnt = ET_BYTES; return pc; }
+    pc.cnt = (u32)(P.n - base);
+    for (u32 i = 0; i < pc.cnt; i++) { u64 c = P.text[base + i]; if (i < 8) pc.w0 |= c << (8 * i); else pc.w1 |= c << (8 * (i - 8)); }
+    return pc;
+}
+__device__ __forceinline__ u32 piece_byte(const Piece &pc, u32 k) { return (u32)((k < 8 ? pc.w0 >> (8 * k) : pc.w1 >> (8 * (k - 8))) & 0xFF); }
+
+// Byte classes in LDS: one lookup per byte instead of range compares and a bitmap fetched from kernel arguments.
+enum { CL_EOL = 1, CL_SPACE = 2, CL_EXPECTED = 4, CL_UNEXP_TEXT = 8, CL_UNEXP_COMMENT = 16 };
+__device__ __forceinline__ void fill_classes(const EncP &P, u8 *cls)      // blockDim.x == 256
+{
+    u32 c = threadIdx.x;
+    cls[c] = (u8)((c_eol(c) ? CL_EOL : 0) | (c_space(c) ? CL_SPACE : 0) | (c_expected(P, c) ? CL_EXPECTED : 0) |
+                  (c_unexp_text(c) ? CL_UNEXP_TEXT : 0) | (c_unexp_comment(c) ? CL_UNEXP_COMMENT : 0));
+    __syncthreads();
+}
+
 // Line starts: a non-EOL byte at i >= p0 whose predecessor is an EOL byte (or i == p0).
-__device__ __forceinline__ u32 count_line_starts(const EncP &P, u64 base, u32 cnt)
+__device__ __forceinline__ u32 count_line_starts(const EncP &P, u64 base, const Piece &pc)
 {
     u32 n = 0; bool prev_eol = base == 0 ? true : c_eol(P.text[base - 1]);
-    for (u32 i = 0; i < cnt; i++) { u32 c = P.text[base + i]; bool e = c_eol(c); if (!e && base + i >= P.p0 && (prev_eol || base + i == P.p0)) n++; prev_eol = e; }
+#pragma unroll
+    for (u32 i = 0; i < ET_BYTES; i++) if (i < pc.cnt) { u32 c = piece_byte(pc, i); bool e = c_eol(c); if (!e && base + i >= P.p0 && (prev_eol || base + i == P.p0)) n++; prev_eol = e; }
     return n;
+}
+__device__ __forceinline__ void last_eol_space(const Piece &pc, u64 base, i64 &le, i64 &ls)
+{
+    le = -1; ls = -1;
+#pragma unroll
+    for (u32 i = 0; i < ET_BYTES; i++) if (i < pc.cnt) { u32 c = piece_byte(pc, i); if (c_space(c)) { ls = (i64)(base + i); if (c_eol(c)) le = ls; } }
 }
 
 __global__ __launch_bounds__(256) void k_enc_last(EncP P, i64 *tile_eol, i64 *tile_sp, u64 *tile_ls)
@@ -47,11 +77,9 @@ __global__ __launch_bounds__(256) void k_enc_last(EncP P, i64 *tile_eol, i64 *ti
     __shared__ u64 lds[4];
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     i64 le = -1, ls = -1; u32 nls = 0;
-    if (base < P.n) {
-        u32 cnt = P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES;
-        for (u32 i = 0; i < cnt; i++) { u32 c = P.text[base + i]; if (c_space(c)) { ls = (i64)(base + i); if (c_eol(c)) le = ls; } }
-        if (tile_ls) nls = count_line_starts(P, base, cnt);
-    }
+    Piece pc = load_piece(P, base);
+    last_eol_space(pc, base, le, ls);
+    if (tile_ls && pc.cnt) nls = count_line_starts(P, base, pc);
     u64 t;
     wg_scan_inclusive<u64, OpMaxI64>((u64)le, &t, lds); i64 te = (i64)t;
     wg_scan_inclusive<u64, OpMaxI64>((u64)ls, &t, lds); i64 ts = (i64)t;
@@ -66,49 +94,48 @@ struct TileCtx { i64 last_eol, last_sp; bool hdr; i64 ord; };
 // Sink interface: emit(stream, ch); header_start(pos); header_end(pos); line_end(pos) for sequence lines;
 // unexpected(kind, ch) with kind 0 id, 1 comment, 2 sequence.
 template <typename Sink>
-__device__ __forceinline__ void classify_range(const EncP &P, u64 pos, u32 cnt, bool with_eof, TileCtx ctx, Sink &S)
+__device__ __forceinline__ void classify_range(const EncP &P, u64 pos, const Piece &pc, bool with_eof, TileCtx ctx, Sink &S, const u8 *cls)
 {
     i64 le = ctx.last_eol, ls = ctx.last_sp; bool hdr = ctx.hdr;
+    const u32 cnt = pc.cnt;
     for (u32 k = 0; k < cnt + (with_eof ? 1u : 0u); k++) {
         u64 i = pos + k;
         bool eof = k >= cnt;
-        u32 c = eof ? 0x0A : P.text[i];                       // end of input acts as one final line end
+        u32 c = eof ? 0x0A : piece_byte(pc, k);               // end of input acts as one final line end
+        u32 cl = cls[c];
         if (i >= P.p0) {                                       // leading space-class bytes are skipped (process.c:551-553)
             i64 line_start = le + 1;
             if (hdr) {
                 if ((i64)i == line_start) { S.header_start(i); }
                 else if (ls < line_start) {                    // still inside the ID (process.c:363-368)
-                    if (c_space(c)) { S.emit(EV_IDS, 0); if (c_eol(c)) { S.emit(EV_CMT, 0); S.header_end(i); } }
-                    else if (c_unexp_text(c) || (P.id_gt_unexpected && c == '>')) { S.unexpected(0, c); S.emit(EV_SEQ, '?'); }
+                    if (cl & CL_SPACE) { S.emit(EV_IDS, 0); if (cl & CL_EOL) { S.emit(EV_CMT, 0); S.header_end(i); } }
+                    else if ((cl & CL_UNEXP_TEXT) || (P.id_gt_unexpected && c == '>')) { S.unexpected(0, c); S.emit(EV_SEQ, '?'); }
                     else S.emit(EV_IDS, c);
                 } else {                                       // comment (process.c:370-377)
-                    if (c_eol(c)) { S.emit(EV_CMT, 0); S.header_end(i); }
-                    else if (c_unexp_comment(c)) { S.unexpected(1, c); S.emit(EV_CMT, '?'); }
+                    if (cl & CL_EOL) { S.emit(EV_CMT, 0); S.header_end(i); }
+                    else if (cl & CL_UNEXP_COMMENT) { S.unexpected(1, c); S.emit(EV_CMT, '?'); }
                     else S.emit(EV_CMT, c);
                 }
             } else {                                           // sequence line (process.c:387-412)
-                if (c_eol(c)) S.line_end(i);
-                else if (c_space(c)) {}
-                else if (c_expected(P, c)) S.emit(EV_SEQ, c);
+                if (cl & CL_EOL) S.line_end(i);
+                else if (cl & CL_SPACE) {}
+                else if (cl & CL_EXPECTED) S.emit(EV_SEQ, c);
                 else { S.unexpected(2, c); S.emit(EV_SEQ, P.replacement); }
             }
         }
         if (eof) break;
-        if (c_space(c)) {
+        if (cl & CL_SPACE) {
             ls = (i64)i;
-            if (c_eol(c)) { le = (i64)i; hdr = (i + 1 < P.n) && P.text[i + 1] == '>'; }
+            if (cl & CL_EOL) { le = (i64)i; u32 nx = k + 1 < cnt ? piece_byte(pc, k + 1) : (i + 1 < P.n ? P.text[i + 1] : 0u); hdr = nx == '>'; }
         }
     }
 }
 
 // Running maxima and header flag at the first byte of this thread's 16-byte piece.
-__device__ __forceinline__ TileCtx thread_ctx(const EncP &P, const i64 *tile_eol, const i64 *tile_sp, u64 base, u64 *lds)
+__device__ __forceinline__ TileCtx thread_ctx(const EncP &P, const i64 *tile_eol, const i64 *tile_sp, u64 base, u64 *lds, const Piece &pc)
 {
     i64 le = -1, ls = -1;
-    if (base < P.n) {
-        u32 cnt = P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES;
-        for (u32 i = 0; i < cnt; i++) { u32 c = P.text[base + i]; if (c_space(c)) { ls = (i64)(base + i); if (c_eol(c)) le = ls; } }
-    }
+    last_eol_space(pc, base, le, ls);
     u64 t;
     i64 ie = (i64)wg_scan_inclusive<u64, OpMaxI64>((u64)le, &t, lds);
     i64 is = (i64)wg_scan_inclusive<u64, OpMaxI64>((u64)ls, &t, lds);
@@ -143,14 +170,16 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
                                                     u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail)
 {
     __shared__ u64 lds[4];
+    __shared__ u8 cls[256];
+    fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
-    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds);
+    Piece pc = load_piece(P, base);
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pc);
     CountSink S;
     if (base <= P.n) {
         // the virtual end-of-input byte belongs to the thread whose piece contains position n
-        u32 cnt = base < P.n ? (P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES) : 0;
-        bool eof_here = (base + cnt == P.n) && cnt < ET_BYTES;
-        classify_range(P, base, cnt, eof_here, ctx, S);
+        bool eof_here = (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
+        classify_range(P, base, pc, eof_here, ctx, S, cls);
     }
     u64 tot;
     wg_scan_inclusive<u64, OpAdd>((u64)S.nseq, &tot, lds); if (threadIdx.x == 0) t_seq[blockIdx.x] = tot;
@@ -176,10 +205,27 @@ struct EncOut {
     const u64 *t_seq, *t_ids, *t_cmt, *t_rec; const u32 *t_tail; const i64 *tile_eol;
 };
 
+// The tile's sequence bytes are staged in LDS and leave as aligned 8-byte stores: one-byte scattered stores
+// cost a partial-line HBM write each.
+__device__ __forceinline__ void flush_tile(u8 *dst, const u8 *stage, u32 n)
+{
+    u32 head = (u32)((8 - ((uintptr_t)dst & 7)) & 7); if (head > n) head = n;
+    if (threadIdx.x < head) dst[threadIdx.x] = stage[threadIdx.x];
+    u32 words = (n - head) >> 3;
+    const u64 *s64 = (const u64 *)stage;
+    for (u32 w = threadIdx.x; w < words; w += blockDim.x) {
+        u32 off = head + 8 * w, sh = (off & 7) * 8;
+        u64 a = s64[off >> 3], b = s64[(off >> 3) + 1];
+        *(u64 *)(dst + off) = sh ? (a >> sh) | (b << (64 - sh)) : a;
+    }
+    u32 done = head + 8 * words;
+    if (threadIdx.x < n - done) dst[done + threadIdx.x] = stage[done + threadIdx.x];
+}
+
 struct WriteSink {
-    const EncOut &O; u64 bseq, bids, bcmt, rec; u64 line_b; u64 best; bool line_valid;
+    const EncOut &O; u64 bseq, bids, bcmt, rec; u64 line_b; u64 best; bool line_valid; u8 *stage; u64 tbase;
     __device__ WriteSink(const EncOut &o) : O(o) {}
-    __device__ void emit(int s, u32 ch) { if (s == EV_SEQ) O.seq[bseq++] = (u8)ch; else if (s == EV_IDS) O.ids[bids++] = (u8)ch; else O.cmt[bcmt++] = (u8)ch; }
+    __device__ void emit(int s, u32 ch) { if (s == EV_SEQ) stage[bseq++ - tbase] = (u8)ch; else if (s == EV_IDS) O.ids[bids++] = (u8)ch; else O.cmt[bcmt++] = (u8)ch; }
     __device__ void header_start(u64) { if (rec > 0) O.rec_end[rec - 1] = bseq; rec++; }
     __device__ void header_end(u64) { O.rec_begin[rec - 1] = bseq; line_b = bseq; }
     __device__ void line_end(u64) { u64 len = bseq - line_b; if (len > best) best = len; line_b = bseq; }
@@ -189,21 +235,23 @@ struct WriteSink {
 __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, EncOut O)
 {
     __shared__ u64 lds[4];
+    __shared__ u8 cls[256];
+    fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
-    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds);
-    u32 cnt = 0; bool eof_here = false, active = base <= P.n;
-    if (active) {
-        cnt = base < P.n ? (P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES) : 0;
-        eof_here = (base + cnt == P.n) && cnt < ET_BYTES;
-    }
+    Piece pc = load_piece(P, base);
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pc);
+    bool active = base <= P.n;
+    bool eof_here = active && (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
     CountSink C;
-    if (active) classify_range(P, base, cnt, eof_here, ctx, C);
-    u64 tot;
-    u64 iseq = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq, &tot, lds);
+    if (active) classify_range(P, base, pc, eof_here, ctx, C, cls);
+    u64 tot, tot0;
+    u64 iseq = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq, &tot0, lds);
     u64 iids = wg_scan_inclusive<u64, OpAdd>((u64)C.nids, &tot, lds);
     u64 icmt = wg_scan_inclusive<u64, OpAdd>((u64)C.ncmt, &tot, lds);
     u64 irec = wg_scan_inclusive<u64, OpAdd>((u64)C.nrec, &tot, lds);
-    WriteSink W(O);
+    __shared__ __attribute__((aligned(8))) u8 stage[ET_TILE + 16];
+    u32 tile_seq = (u32)tot0;
+    WriteSink W(O); W.stage = stage; W.tbase = O.t_seq[blockIdx.x];
     W.bseq = O.t_seq[blockIdx.x] + iseq - C.nseq; W.bids = O.t_ids[blockIdx.x] + iids - C.nids;
     W.bcmt = O.t_cmt[blockIdx.x] + icmt - C.ncmt; W.rec = O.t_rec[blockIdx.x] + irec - C.nrec;
     // base count at the start of the line this thread begins in: B at the most recent EOL before `base`.
@@ -224,7 +272,9 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
         else { u64 tp = (u64)le / ET_TILE; W.line_b = O.t_seq[tp + 1] - (O.t_tail[tp] & 0x7FFFFFFFu); }
     }
     W.best = 0;
-    if (active) classify_range(P, base, cnt, eof_here, ctx, W);
+    if (active) classify_range(P, base, pc, eof_here, ctx, W, cls);
+    __syncthreads();
+    flush_tile(O.seq + W.tbase, stage, tile_seq);
     u64 best; wg_scan_inclusive<u64, OpMaxU64>(W.best, &best, lds);
     if (threadIdx.x == 0 && best) atomicMax((unsigned long long *)O.longest, (unsigned long long)best);
 }
@@ -244,39 +294,41 @@ struct FqOut {
 };
 
 template <typename Sink>
-__device__ __forceinline__ void classify_range_fastq(const EncP &P, u64 pos, u32 cnt, bool with_eof, TileCtx ctx, Sink &S)
+__device__ __forceinline__ void classify_range_fastq(const EncP &P, u64 pos, const Piece &pc, bool with_eof, TileCtx ctx, Sink &S, const u8 *cls)
 {
     i64 le = ctx.last_eol, ls = ctx.last_sp, ord = ctx.ord;
+    const u32 cnt = pc.cnt;
     for (u32 k = 0; k < cnt + (with_eof ? 1u : 0u); k++) {
         u64 i = pos + k;
         bool eof = k >= cnt;
-        u32 c = eof ? 0x0A : P.text[i];
+        u32 c = eof ? 0x0A : piece_byte(pc, k);
+        u32 cl = cls[c];
         if (i >= P.p0) {
             bool prev_eol = i == P.p0 || le == (i64)i - 1;
-            if (!c_eol(c)) {
+            if (!(cl & CL_EOL)) {
                 if (prev_eol) ord++;                                   // a new line starts here
                 i64 line_start = le + 1; if ((u64)line_start < P.p0) line_start = (i64)P.p0;
                 u64 rec = (u64)ord >> 2; u32 type = (u32)ord & 3; bool first = (i64)i == line_start;
                 if (type == 0) {
                     if (first) { if (c != '@') S.error(rec, FQ_E_AT); S.header_start(rec); }
                     else if (ls < line_start) {
-                        if (c_space(c)) S.emit(EV_IDS, 0);
-                        else if (c_unexp_text(c)) { S.unexpected(0, c); S.emit(EV_SEQ, '?'); }
+                        if (cl & CL_SPACE) S.emit(EV_IDS, 0);
+                        else if (cl & CL_UNEXP_TEXT) { S.unexpected(0, c); S.emit(EV_SEQ, '?'); }
                         else S.emit(EV_IDS, c);
                     } else {
-                        if (c_unexp_comment(c)) { S.unexpected(1, c); S.emit(EV_CMT, '?'); }
+                        if (cl & CL_UNEXP_COMMENT) { S.unexpected(1, c); S.emit(EV_CMT, '?'); }
                         else S.emit(EV_CMT, c);
                     }
                 } else if (type == 1) {
-                    if (c_space(c)) {}
-                    else if (c_expected(P, c)) S.emit(EV_SEQ, c);
+                    if (cl & CL_SPACE) {}
+                    else if (cl & CL_EXPECTED) S.emit(EV_SEQ, c);
                     else { S.unexpected(2, c); S.emit(EV_SEQ, P.replacement); }
                 } else if (type == 2) {
                     if (first && c != '+') S.error(rec, FQ_E_PLUS);
                 } else {
                     if (first) { S.qual_begin(rec); S.emit(EV_QUAL, c); }   // process.c:522: appended unconditionally
                     else if (c >= 0x21 && c <= 0x7E) S.emit(EV_QUAL, c);
-                    else if (c_space(c)) {}
+                    else if (cl & CL_SPACE) {}
                     else { S.unexpected(3, c); S.emit(EV_QUAL, '!'); }
                 }
             } else if (!prev_eol) {                                    // this EOL closes a line
@@ -291,7 +343,7 @@ __device__ __forceinline__ void classify_range_fastq(const EncP &P, u64 pos, u32
             }
         }
         if (eof) break;
-        if (c_space(c)) { ls = (i64)i; if (c_eol(c)) le = (i64)i; }
+        if (cl & CL_SPACE) { ls = (i64)i; if (cl & CL_EOL) le = (i64)i; }
     }
 }
 
@@ -303,9 +355,9 @@ struct FqCount {
     __device__ void unexpected(int, u32) {} __device__ void error(u64, int) {}
 };
 struct FqWrite {
-    const FqOut &O; u64 bseq, bids, bcmt, bqual;
+    const FqOut &O; u64 bseq, bids, bcmt, bqual; u8 *sstage, *qstage; u64 sbase, qbase;
     __device__ FqWrite(const FqOut &o) : O(o) {}
-    __device__ void emit(int s, u32 ch) { if (s == EV_SEQ) O.seq[bseq++] = (u8)ch; else if (s == EV_IDS) O.ids[bids++] = (u8)ch; else if (s == EV_CMT) O.cmt[bcmt++] = (u8)ch; else O.qual[bqual++] = (u8)ch; }
+    __device__ void emit(int s, u32 ch) { if (s == EV_SEQ) sstage[bseq++ - sbase] = (u8)ch; else if (s == EV_IDS) O.ids[bids++] = (u8)ch; else if (s == EV_CMT) O.cmt[bcmt++] = (u8)ch; else qstage[bqual++ - qbase] = (u8)ch; }
     __device__ void header_start(u64) {}
     __device__ void header_end(u64 r) { O.rec_begin[r] = bseq; }
     __device__ void seq_end(u64 r) { O.rec_end[r] = bseq; }
@@ -316,10 +368,9 @@ struct FqWrite {
 };
 
 // ordinal of the line in progress at `base`: (#line starts before base) - 1
-__device__ __forceinline__ i64 thread_ord(const EncP &P, const u64 *t_ls, u64 base, u64 *lds)
+__device__ __forceinline__ i64 thread_ord(const EncP &P, const u64 *t_ls, u64 base, u64 *lds, const Piece &pc)
 {
-    u32 nls = 0;
-    if (base < P.n) { u32 cnt = P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES; nls = count_line_starts(P, base, cnt); }
+    u32 nls = pc.cnt ? count_line_starts(P, base, pc) : 0;
     u64 t; u64 incl = wg_scan_inclusive<u64, OpAdd>((u64)nls, &t, lds);
     return (i64)(t_ls[blockIdx.x] + incl - nls) - 1;
 }
@@ -328,14 +379,14 @@ __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol,
                                                      u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_qual)
 {
     __shared__ u64 lds[4];
+    __shared__ u8 cls[256];
+    fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
-    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds);
-    ctx.ord = thread_ord(P, t_ls, base, lds);
+    Piece pc = load_piece(P, base);
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pc);
+    ctx.ord = thread_ord(P, t_ls, base, lds, pc);
     FqCount S;
-    if (base <= P.n) {
-        u32 cnt = base < P.n ? (P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES) : 0;
-        classify_range_fastq(P, base, cnt, (base + cnt == P.n) && cnt < ET_BYTES, ctx, S);
-    }
+    if (base <= P.n) classify_range_fastq(P, base, pc, (base + pc.cnt == P.n) && pc.cnt < ET_BYTES, ctx, S, cls);
     u64 tot;
     wg_scan_inclusive<u64, OpAdd>((u64)S.nseq, &tot, lds); if (threadIdx.x == 0) t_seq[blockIdx.x] = tot;
     wg_scan_inclusive<u64, OpAdd>((u64)S.nids, &tot, lds); if (threadIdx.x == 0) t_ids[blockIdx.x] = tot;
@@ -346,22 +397,29 @@ __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol,
 __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, FqOut O)
 {
     __shared__ u64 lds[4];
+    __shared__ u8 cls[256];
+    fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
-    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds);
-    ctx.ord = thread_ord(P, O.t_ls, base, lds);
-    u32 cnt = 0; bool eof_here = false, active = base <= P.n;
-    if (active) { cnt = base < P.n ? (P.n - base < ET_BYTES ? (u32)(P.n - base) : ET_BYTES) : 0; eof_here = (base + cnt == P.n) && cnt < ET_BYTES; }
+    Piece pc = load_piece(P, base);
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pc);
+    ctx.ord = thread_ord(P, O.t_ls, base, lds, pc);
+    bool active = base <= P.n;
+    bool eof_here = active && (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
     FqCount C;
-    if (active) classify_range_fastq(P, base, cnt, eof_here, ctx, C);
-    u64 tot;
-    u64 iseq = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq, &tot, lds);
+    if (active) classify_range_fastq(P, base, pc, eof_here, ctx, C, cls);
+    u64 tot, tots, totq;
+    u64 iseq = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq, &tots, lds);
     u64 iids = wg_scan_inclusive<u64, OpAdd>((u64)C.nids, &tot, lds);
     u64 icmt = wg_scan_inclusive<u64, OpAdd>((u64)C.ncmt, &tot, lds);
-    u64 iq = wg_scan_inclusive<u64, OpAdd>((u64)C.nqual, &tot, lds);
-    FqWrite W(O);
+    u64 iq = wg_scan_inclusive<u64, OpAdd>((u64)C.nqual, &totq, lds);
+    __shared__ __attribute__((aligned(8))) u8 sstage[ET_TILE + 16], qstage[ET_TILE + 16];
+    FqWrite W(O); W.sstage = sstage; W.qstage = qstage; W.sbase = O.t_seq[blockIdx.x]; W.qbase = O.t_qual[blockIdx.x];
     W.bseq = O.t_seq[blockIdx.x] + iseq - C.nseq; W.bids = O.t_ids[blockIdx.x] + iids - C.nids;
     W.bcmt = O.t_cmt[blockIdx.x] + icmt - C.ncmt; W.bqual = O.t_qual[blockIdx.x] + iq - C.nqual;
-    if (active) classify_range_fastq(P, base, cnt, eof_here, ctx, W);
+    if (active) classify_range_fastq(P, base, pc, eof_here, ctx, W, cls);
+    __syncthreads();
+    flush_tile(O.seq + W.sbase, sstage, (u32)tots);
+    flush_tile(O.qual + W.qbase, qstage, (u32)totq);
 }
 
 // read lengths, quality-length check (process.c:531-535) and the longest read
@@ -399,8 +457,17 @@ __device__ __forceinline__ u32 mask_boundary_bits(const u8 *seq, u64 base, u64 T
 {
     // bit i set when base+i starts a new run, i.e. its case differs from the previous base (the virtual
     // base -1 is "unmasked": a masked first base opens a zero-length unmasked run, encoders.c:132)
-    u32 m = 0;
     bool prev = base ? seq[base - 1] >= 96 : false;
+    if (base + 16 <= T) {
+        // byte >= 96 as the top bit of each byte, gathered to one bit per byte (base is 16-aligned, so is seq)
+        const u64 L7 = 0x7f7f7f7f7f7f7f7full, H = 0x8080808080808080ull, MM = 0x0102040810204080ull;
+        u64 w0 = *(const u64 *)(seq + base), w1 = *(const u64 *)(seq + base + 8);
+        u64 t0 = (((w0 & L7) + 0x2020202020202020ull) | w0) & H;
+        u64 t1 = (((w1 & L7) + 0x2020202020202020ull) | w1) & H;
+        u32 c = (u32)((t0 >> 7) * MM >> 56) | ((u32)((t1 >> 7) * MM >> 56) << 8);
+        return (c ^ ((c << 1) | (prev ? 1u : 0u))) & 0xFFFFu;
+    }
+    u32 m = 0;
     for (u32 i = 0; i < 16 && base + i < T; i++) { bool cur = seq[base + i] >= 96; if (cur != prev) m |= 1u << i; prev = cur; }
     return m;
 }

@@ -11,34 +11,82 @@
 #include "zstd_enc_core.h"
 
 #define ZENC_TREE_SLOT 192
+#include "wgscan.h"
+struct OpMaxU64 { template <typename T> __device__ static T id() { return (T)0; } template <typename T> __device__ static T f(T a, T b) { return a > b ? a : b; } };
+#define ZENC_HCOPIES 4
+struct ZPlanWS {
+    u32 tot[256]; u32 w[512]; u16 order[256]; u16 parent[512]; u8 depth[512];
+    u8 len[256], wt[256], tree[ZENC_TREE_SLOT], tmp[160];
+    FseWS fse; u32 log, tb;
+};
 
 // even split of n bytes into nblk blocks: block b starts at b*(n/nblk) + min(b, n%nblk)
 __host__ __device__ static inline u64 zenc_block_lo(u64 n, u32 nblk, u32 b) { u64 q = n / nblk, r = n % nblk; return (u64)b * q + (b < r ? b : r); }
 
 __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u8 *lens, u8 *trees, u64 *csize)
 {
-    __shared__ u32 hist[1024];
+    // ZENC_HCOPIES copies of the 4 quarter histograms (copy = lane % copies): few distinct symbols (packed ACGT has 16) would
+    // otherwise serialise every LDS atomic of a wave on the same handful of addresses
+    __shared__ u32 hist[ZENC_HCOPIES * 1024];
     u32 b = blockIdx.x;
     u64 lo = zenc_block_lo(n, nblk, b), hi = zenc_block_lo(n, nblk, b + 1);
     u32 bn = (u32)(hi - lo);
-    for (u32 i = threadIdx.x; i < 1024; i += 256) hist[i] = 0;
+    for (u32 i = threadIdx.x; i < ZENC_HCOPIES * 1024; i += 256) hist[i] = 0;
     __syncthreads();
     u32 per = (bn + 3) / 4; if (!per) per = 1;
     const u8 *s = src + lo;
-    for (u32 i = threadIdx.x * 4; i < bn; i += 1024) {
-        // 4 consecutive bytes per thread; quarter index per byte
+    u32 *my = hist + (threadIdx.x & (ZENC_HCOPIES - 1)) * 1024;
+    for (u32 i = threadIdx.x * 8; i < bn; i += 2048) {
+        if (i + 8 <= bn) {
+            u64 w = ld64(s + i);
 #pragma unroll
-        for (u32 k = 0; k < 4; k++) if (i + k < bn) { u32 q = (i + k) / per; if (q > 3) q = 3; atomicAdd(&hist[q * 256 + s[i + k]], 1u); }
+            for (u32 k = 0; k < 8; k++) { u32 pos = i + k, q = (pos >= per) + (pos >= 2 * per) + (pos >= 3 * per); atomicAdd(&my[q * 256 + (u32)((w >> (8 * k)) & 0xFF)], 1u); }
+        } else {
+            for (u32 k = 0; i + k < bn; k++) { u32 pos = i + k, q = (pos >= per) + (pos >= 2 * per) + (pos >= 3 * per); atomicAdd(&my[q * 256 + s[pos]], 1u); }
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        ZEncPlan p; u8 len[256]; u8 tree[ZENC_TREE_SLOT];
-        zenc_plan_block(hist, bn, p, len, tree);
-        plan[b] = p; csize[b] = p.csize;
-        if (p.kind == ZK_HUF) {
-            for (u32 i = 0; i < 256; i++) lens[(u64)b * 256 + i] = len[i];
-            for (u32 i = 0; i < p.tree_bytes; i++) trees[(u64)b * ZENC_TREE_SLOT + i] = tree[i];
+    for (u32 i = threadIdx.x; i < 1024; i += 256) { u32 v = 0; for (u32 k = 0; k < ZENC_HCOPIES; k++) v += hist[k * 1024 + i]; hist[i] = v; }
+    __syncthreads();
+    // ---- plan: same decisions as zenc_plan_block, with the per-symbol loops spread over the 256 threads and every
+    // table of the serial steps in LDS (one lane walking private arrays in scratch memory cost 0.3 ms per block)
+    __shared__ ZPlanWS ws;
+    __shared__ u64 red[4];
+    const u32 sym = threadIdx.x;
+    u32 mine = hist[sym] + hist[256 + sym] + hist[512 + sym] + hist[768 + sym];
+    ws.tot[sym] = mine; ws.len[sym] = 0;
+    u32 distinct = (u32)__syncthreads_count(mine != 0);
+    ZEncPlan p; p.n = bn; p.kind = ZK_RAW; p.csize = 3 + bn; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0;
+    p.ssz[0] = p.ssz[1] = p.ssz[2] = p.ssz[3] = 0;
+    bool huf = false;
+    if (bn && distinct == 1) { p.kind = ZK_RLE; p.csize = 4; }
+    else if (bn >= 64 && distinct >= 2) {
+        // rank sort by (count, symbol): the order a stable insertion sort over ascending symbols gives
+        if (mine) {
+            u32 r = 0;
+            for (u32 t = 0; t < 256; t++) { u32 c = ws.tot[t]; r += (c != 0) && (c < mine || (c == mine && t < sym)); }
+            ws.order[r] = (u16)sym;
         }
+        __syncthreads();
+        if (threadIdx.x == 0) ws.log = huf_lengths_sorted(ws.tot, ws.order, distinct, ws.len, ws.w, ws.parent, ws.depth);
+        __syncthreads();
+        u32 log = ws.log;
+        if (log) {
+            u32 l = ws.len[sym];
+            ws.wt[sym] = l ? (u8)(log + 1 - l) : 0;
+            u64 lastw; wg_scan_inclusive<u64, OpMaxU64>(l ? (u64)sym : 0, &lastw, red);
+            if (threadIdx.x == 0) ws.tb = huf_write_tree_w(ws.tree, ws.wt, (u32)lastw, ws.tmp, ws.fse);
+            u64 bits;
+            for (u32 k = 0; k < 4; k++) { wg_scan_inclusive<u64, OpAdd>((u64)hist[256 * k + sym] * l, &bits, red); p.ssz[k] = (u32)((bits + 1 + 7) / 8); }
+            __syncthreads();
+            u32 tb = ws.tb;
+            if (tb) { zenc_plan_finish(p, bn, log, tb); huf = p.kind == ZK_HUF; }
+        }
+    }
+    if (threadIdx.x == 0) { plan[b] = p; csize[b] = p.csize; }
+    if (huf) {
+        lens[(u64)b * 256 + sym] = ws.len[sym];
+        if (sym < p.tree_bytes) trees[(u64)b * ZENC_TREE_SLOT + sym] = ws.tree[sym];
     }
 }
 

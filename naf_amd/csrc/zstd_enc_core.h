@@ -14,19 +14,11 @@
 // ---- length-limited Huffman code lengths from a histogram -------------------------------------------------
 // cnt[256] -> len[256] (0 for absent symbols).  Returns the maximum length (tableLog), or 0 when fewer
 // than two distinct symbols are present.  Scratch: order[256], node arrays of 512 entries.
-NAF_HD u32 huf_build_lengths(const u32 *cnt, u8 *len)
+// Code lengths from symbols already sorted by (count, symbol) ascending: order[0..n), n >= 2.  len[] must be
+// zero for absent symbols.  w/parent/depth: 512-entry workspaces (LDS on the GPU).
+NAF_HD u32 huf_lengths_sorted(const u32 *cnt, const u16 *order, u32 n, u8 *len, u32 *w, u16 *parent, u8 *depth)
 {
-    u16 order[256]; u32 n = 0;
-    for (u32 s = 0; s < 256; s++) { len[s] = 0; if (cnt[s]) order[n++] = (u16)s; }
-    if (n < 2) return 0;
-    // sort present symbols by count ascending (insertion sort; n <= 256, one lane per block)
-    for (u32 i = 1; i < n; i++) {
-        u16 v = order[i]; u32 c = cnt[v]; u32 j = i;
-        while (j > 0 && cnt[order[j - 1]] > c) { order[j] = order[j - 1]; j--; }
-        order[j] = v;
-    }
     // two-queue Huffman construction; parent links give depths
-    u32 w[512]; u16 parent[512];
     for (u32 i = 0; i < n; i++) w[i] = cnt[order[i]];
     u32 leaf = 0, inode = n, next = n;              // queue 1: leaves [leaf,n) ; queue 2: internal [inode,next)
     while ((n - leaf) + (next - inode) > 1) {
@@ -35,7 +27,7 @@ NAF_HD u32 huf_build_lengths(const u32 *cnt, u8 *len)
         if (leaf < n && (inode >= next || w[leaf] <= w[inode])) b = leaf++; else b = inode++;
         w[next] = w[a] + w[b]; parent[a] = (u16)next; parent[b] = (u16)next; next++;
     }
-    u32 root = next - 1; u8 depth[512];
+    u32 root = next - 1;
     depth[root] = 0;
     for (u32 i = root; i-- > 0;) depth[i] = (u8)(depth[parent[i]] + 1);
     u32 maxlen = 0;
@@ -63,6 +55,21 @@ NAF_HD u32 huf_build_lengths(const u32 *cnt, u8 *len)
     maxlen = 0;
     for (u32 i = 0; i < n; i++) if (len[order[i]] > maxlen) maxlen = len[order[i]];
     return maxlen;
+}
+
+NAF_HD u32 huf_build_lengths(const u32 *cnt, u8 *len)
+{
+    u16 order[256]; u32 n = 0;
+    for (u32 s = 0; s < 256; s++) { len[s] = 0; if (cnt[s]) order[n++] = (u16)s; }
+    if (n < 2) return 0;
+    // sort present symbols by count ascending, ties by symbol (stable insertion sort)
+    for (u32 i = 1; i < n; i++) {
+        u16 v = order[i]; u32 c = cnt[v]; u32 j = i;
+        while (j > 0 && cnt[order[j - 1]] > c) { order[j] = order[j - 1]; j--; }
+        order[j] = v;
+    }
+    u32 w[512]; u16 parent[512]; u8 depth[512];
+    return huf_lengths_sorted(cnt, order, n, len, w, parent, depth);
 }
 
 // Canonical code values in the order the zstd decoder expects (4.2.1): within the decoding table,
@@ -152,11 +159,14 @@ NAF_HD u32 fse_write_ncount(u8 *out, const i16 *norm, u32 maxsym, u32 log)
     return (u32)(b.p - out);
 }
 
+// Workspace of the weight encoder (LDS on the GPU: dynamically indexed private arrays would live in scratch memory)
+struct FseWS { u32 cnt[16]; i16 norm[16]; u16 tableU16[64]; FseCSym tt[16]; u8 tsym[64]; u32 cumul[18]; };
+
 // Encoding tables (state table + per-symbol transforms).  tableU16 needs 2^log entries.
-NAF_HD void fse_build_ctable(const i16 *norm, u32 maxsym, u32 log, u16 *tableU16, FseCSym *tt)
+NAF_HD void fse_build_ctable(const i16 *norm, u32 maxsym, u32 log, u16 *tableU16, FseCSym *tt, u8 *tsym, u32 *cumul)
 {
     u32 size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
-    u8 tsym[64]; u32 cumul[18]; u32 high = size - 1;
+    u32 high = size - 1;
     cumul[0] = 0;
     for (u32 u = 1; u <= maxsym + 1; u++) {
         if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tsym[high--] = (u8)(u - 1); }
@@ -182,21 +192,20 @@ NAF_HD void fse_build_ctable(const i16 *norm, u32 maxsym, u32 log, u16 *tableU16
 }
 
 // FSE-compress `n` weights (values 0..maxsym) with two interleaved states.  Returns bytes written, 0 on failure.
-NAF_HD u32 fse_compress_weights(u8 *out, u32 cap, const u8 *w, u32 n)
+NAF_HD u32 fse_compress_weights(u8 *out, u32 cap, const u8 *w, u32 n, FseWS &ws)
 {
     if (n < 2) return 0;
-    u32 cnt[16]; for (u32 i = 0; i < 16; i++) cnt[i] = 0;
+    u32 *cnt = ws.cnt; i16 *norm = ws.norm; u16 *tableU16 = ws.tableU16; FseCSym *tt = ws.tt;
+    for (u32 i = 0; i < 16; i++) cnt[i] = 0;
     u32 maxsym = 0, maxcnt = 0;
     for (u32 i = 0; i < n; i++) { cnt[w[i]]++; if (w[i] > maxsym) maxsym = w[i]; }
     for (u32 s = 0; s <= maxsym; s++) if (cnt[s] > maxcnt) maxcnt = cnt[s];
     if (maxcnt == n || maxcnt == 1) return 0;                  // single symbol / nothing to gain
     u32 log = n > 24 ? 6 : 5;
-    i16 norm[16];
     if (!fse_normalize(cnt, maxsym, n, log, norm)) return 0;
     if (cap < 64) return 0;
     u32 hdr = fse_write_ncount(out, norm, maxsym, log);
-    u16 tableU16[64]; FseCSym tt[16];
-    fse_build_ctable(norm, maxsym, log, tableU16, tt);
+    fse_build_ctable(norm, maxsym, log, tableU16, tt, ws.tsym, ws.cumul);
     BitW b; bitw_init(b, out + hdr);
     u32 st1, st2;
     auto init_state = [&](u32 sym) -> u32 {
@@ -223,19 +232,23 @@ NAF_HD u32 fse_compress_weights(u8 *out, u32 cap, const u8 *w, u32 n)
 
 // Huffman tree description (4.2.1): FSE-compressed weights when smaller (mandatory above 128 weights),
 // else direct 4-bit weights.  len[] = code lengths, log = max length.  Returns bytes, 0 = not representable.
-NAF_HD u32 huf_write_tree(u8 *out, const u8 *len, u32 log)
+// w[0..n) = weights of symbols 0..n-1 (n = index of the last present symbol, whose weight is implied).
+NAF_HD u32 huf_write_tree_w(u8 *out, const u8 *w, u32 n, u8 *tmp /*160*/, FseWS &ws)
 {
-    u8 w[256]; u32 last = 0;
-    for (u32 s = 0; s < 256; s++) { w[s] = len[s] ? (u8)(log + 1 - len[s]) : 0; if (len[s]) last = s; }
-    u32 n = last;                                              // weights for symbols 0..last-1; the last is implied
     if (n == 0) return 0;
-    u8 tmp[160];
-    u32 fs = fse_compress_weights(tmp, sizeof tmp, w, n);
+    u32 fs = fse_compress_weights(tmp, 160, w, n, ws);
     if (fs > 1 && fs < 128 && fs < (n + 1) / 2 + 0u + 1) { out[0] = (u8)fs; for (u32 i = 0; i < fs; i++) out[1 + i] = tmp[i]; return 1 + fs; }
     if (n > 128) return 0;
     out[0] = (u8)(127 + n);
     for (u32 i = 0; i < n; i += 2) out[1 + i / 2] = (u8)((w[i] << 4) | (i + 1 < n ? w[i + 1] : 0));
     return 1 + (n + 1) / 2;
+}
+NAF_HD u32 huf_write_tree(u8 *out, const u8 *len, u32 log)
+{
+    u8 w[256]; u32 last = 0;
+    for (u32 s = 0; s < 256; s++) { w[s] = len[s] ? (u8)(log + 1 - len[s]) : 0; if (len[s]) last = s; }
+    u8 tmp[160]; FseWS ws;
+    return huf_write_tree_w(out, w, last, tmp, ws);            // weights for symbols 0..last-1; the last is implied
 }
 
 // Size in bytes of one Huffman stream holding the given per-symbol counts.
@@ -247,18 +260,35 @@ NAF_HD u32 huf_stream_bytes(const u32 *cnt, const u8 *len)
 }
 
 // Encode src[0..n) into one Huffman stream (4.2.2: written forward, so that the LAST symbol is read first).
-// codes: code | len << 16 per symbol.  Returns bytes written.
+// codes: code | len << 16 per symbol.  Input is consumed 8 bytes per load (walking down), output leaves as 8-byte
+// words -- byte-granular stores from 600 k lanes cost 12x the algorithmic HBM write traffic.  Returns bytes written.
 template <typename TabPtr>
 NAF_HD u32 huf_encode_stream(u8 *out, const u8 *src, u32 n, TabPtr codes)
 {
-    BitW b; bitw_init(b, out);
-    for (u32 i = n; i-- > 0;) {                                // decoder emits the first symbol from the top of the stream
-        u32 e = codes[src[i]];
-        bitw_add(b, e & 0xFFFF, e >> 16);
-        if (b.n >= 32) bitw_flush(b);
+    u64 acc = 0; u32 nb = 0; u8 *p = out;
+    u32 i = n;
+    while (i >= 8) {                                           // symbols i-1 .. i-8, highest index first
+        i -= 8;
+        u64 w = ld64(src + i);
+#pragma unroll
+        for (int k = 7; k >= 0; k--) {
+            u32 e = codes[(u32)(w >> (8 * k)) & 0xFF];
+            u32 len = e >> 16; u64 v = (u64)(e & 0xFFFF);
+            acc |= v << nb;                                    // nb < 64 here; bits that do not fit are re-added after the flush
+            if (nb + len >= 64) { st64(p, acc); p += 8; acc = nb ? (v >> (64 - nb)) : 0; nb = nb + len - 64; }
+            else nb += len;
+        }
     }
-    bitw_flush(b);
-    return (u32)(bitw_close(b) - out);
+    while (i-- > 0) {
+        u32 e = codes[src[i]];
+        u32 len = e >> 16; u64 v = (u64)(e & 0xFFFF);
+        acc |= v << nb;
+        if (nb + len >= 64) { st64(p, acc); p += 8; acc = nb ? (v >> (64 - nb)) : 0; nb = nb + len - 64; }
+        else nb += len;
+    }
+    acc |= 1ull << nb; nb++;                                   // final marker bit (nb <= 63 before, so it fits)
+    while (nb > 0) { *p++ = (u8)acc; acc >>= 8; nb = nb > 8 ? nb - 8 : 0; }
+    return (u32)(p - out);
 }
 
 // ---- block planning ------------------------------------------------------------------------------------------------
@@ -272,6 +302,7 @@ struct ZEncPlan {
     u8  pad;
 };
 
+NAF_HD void zenc_plan_finish(ZEncPlan &p, u32 n, u32 log, u32 tb);
 // hist[4][256] = byte counts of the four stream quarters of the block.  Fills plan, len[256], tree[<=160].
 NAF_HD void zenc_plan_block(const u32 *hist, u32 n, ZEncPlan &p, u8 *len, u8 *tree)
 {
@@ -285,8 +316,14 @@ NAF_HD void zenc_plan_block(const u32 *hist, u32 n, ZEncPlan &p, u8 *len, u8 *tr
     if (!log) return;
     u32 tb = huf_write_tree(tree, len, log);
     if (!tb) return;
+    for (u32 k = 0; k < 4; k++) p.ssz[k] = huf_stream_bytes(hist + 256 * k, len);
+    zenc_plan_finish(p, n, log, tb);
+}
+// last step of the plan: p.ssz[] hold the four stream sizes; decides Huffman vs Raw
+NAF_HD void zenc_plan_finish(ZEncPlan &p, u32 n, u32 log, u32 tb)
+{
     u32 body = tb + 6;
-    for (u32 k = 0; k < 4; k++) { p.ssz[k] = huf_stream_bytes(hist + 256 * k, len); body += p.ssz[k]; if (p.ssz[k] > 0xFFFF) return; }
+    for (u32 k = 0; k < 4; k++) { body += p.ssz[k]; if (p.ssz[k] > 0xFFFF) return; }
     u32 lhdr = (n < 1024 && body < 1024) ? 3 : ((n < 16384 && body < 16384) ? 4 : 5);
     if (body >= (1u << 18)) return;
     u32 csize = 3 + lhdr + body + 1;                           // + sequences header (0 sequences)
