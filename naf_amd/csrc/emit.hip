@@ -342,13 +342,303 @@ __global__ __launch_bounds__(256) void k_emit(EmitP P, u8 *out)
     }
 }
 
+// ---- short-record emit ----------------------------------------------------------------------------------------
+// FASTQ reads and short FASTA records put a record boundary into (almost) every 16-byte chunk, so the long-record
+// kernel above would take its byte-at-a-time path everywhere.  Here a workgroup stages the geometry of every record
+// its span touches in LDS (binary search and geometry loads stop being dependent global loads), and a lane
+// composes its 16 output bytes from SEGMENTS -- header bytes, up to 16 bases, the "\n+\n" joint, up to 16 quality
+// bytes, a newline -- each placed with one 128-bit shift.
+#define ES_SPAN (32u * 1024u)
+#define ES_CAP 1024
+
+// keep the first n bytes of {slo,shi}, shift them to byte offset pos of {lo,hi}
+__device__ __forceinline__ void place16(u64 &lo, u64 &hi, u64 slo, u64 shi, u32 pos, u32 n)
+{
+    if (n <= 8) { shi = 0; slo &= low_bytes_mask((int)n); } else if (n < 16) shi &= low_bytes_mask((int)n - 8);
+    if (pos == 0) { lo |= slo; hi |= shi; }
+    else if (pos < 8) { lo |= slo << (8 * pos); hi |= (shi << (8 * pos)) | (slo >> (64 - 8 * pos)); }
+    else if (pos == 8) hi |= slo;
+    else hi |= slo << (8 * (pos - 8));
+}
+
+// +32 on the bases of {lo,hi} (16 bases from base index g0) that lie in masked runs (output.c:295-322)
+__device__ __forceinline__ void mask16(const EmitP &P, u64 klo, u64 khi, bool any_toggle, u64 g0, u64 &lo, u64 &hi)
+{
+    if (any_toggle) {
+        u64 kk = upper_bound_u64(P.toggles, klo, khi, g0);      // toggles <= g0
+        u32 state = (u32)(kk & 1), m16 = 0; u64 pos = g0;
+        for (;;) {
+            u64 nxt = kk < khi ? P.toggles[kk] : ~0ull;
+            u64 end = nxt < g0 + 16 ? nxt : g0 + 16;
+            if (state && end > pos) m16 |= (u32)(((1u << (end - pos)) - 1) << (pos - g0));
+            if (nxt >= g0 + 16) break;
+            pos = nxt; state ^= 1; kk++;
+        }
+        lo += spread_bits8(m16 & 0xFF); hi += spread_bits8(m16 >> 8);
+    } else if (P.masking && (klo & 1)) { lo += 0x2020202020202020ull; hi += 0x2020202020202020ull; }
+}
+
+// record window [rlo, rhi] and toggle window [klo, khi] of one span -> sh[0..3]; needs blockDim.x >= 2
+__device__ __forceinline__ void span_windows(const EmitP &P, u64 span_first, u64 span_last, u64 *sh)
+{
+    if (threadIdx.x < 2 && P.mode != EM_SEQ) {
+        u64 p = threadIdx.x == 0 ? span_first : span_last;
+        sh[threadIdx.x] = upper_bound_u64(P.rec_out, 0, P.N + 1, p) - 1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        u64 k = 0;
+        if (P.masking) {
+            u64 g;
+            if (P.mode == EM_SEQ) g = threadIdx.x == 0 ? span_first : span_last + 1;
+            else g = threadIdx.x == 0 ? P.rec_base[sh[0]] : P.rec_base[sh[1] + 1];
+            if (P.mode != EM_SEQ && threadIdx.x == 0) {
+                u64 r = sh[0], off = span_first - P.rec_out[r], hl = P.hdr_len[r];
+                if (off > hl) { u64 q = off - hl; u64 j = (P.mode == EM_FASTA && P.L) ? (q / (P.L + 1)) * P.L : (P.mode == EM_FASTQ ? 0 : q); if (j > P.rec_len[r]) j = P.rec_len[r]; g += j; }
+            }
+            k = upper_bound_u64(P.toggles, 0, P.n_toggles, g);
+        }
+        sh[2 + threadIdx.x] = k;
+    }
+    __syncthreads();
+}
+
+// Header lines of records [r0, r0+n) as one contiguous byte stream ('>'|'@' name '\n', output.c:105-132), so that
+// the emit kernel copies header bytes like any other byte source.  One lane per record.
+__global__ void k_hdr_len64(const u32 *hdr_len, u64 r0, u64 n, u64 *out)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = hdr_len[r0 + i];
+}
+__global__ void k_hdr_build(EmitP P, u64 r0, u64 n, const u64 *hdr_off, u8 *text)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 r = r0 + i; u32 hl = P.hdr_len[r];
+    u8 *o = text + hdr_off[i];
+    u64 ids0 = 0, idl = 0, nm0 = 0;
+    if (P.has_ids) { ids0 = r ? P.idz[r - 1] + 1 : 0; idl = P.idz[r] - ids0; }
+    if (P.has_names) nm0 = r ? P.nmz[r - 1] + 1 : 0;
+    o[0] = P.hdr_char; o[hl - 1] = '\n';
+    for (u32 k = 0; k + 2 < hl; k++) {
+        u32 ch;
+        if (P.has_ids) ch = k < idl ? P.ids[ids0 + k] : (k == idl ? P.sep : P.names[nm0 + (k - idl - 1)]); else ch = P.names[nm0 + k];
+        o[1 + k] = (u8)ch;
+    }
+}
+
+// One 16-byte chunk composed from segments.  One iteration = one SEGMENT: n_main bytes copied from a byte source or
+// expanded from bases, followed by up to 3 constant bytes (the newline that ends a line / read / quality string, or the
+// "\n+\n" joint).  `geo(r, ...)` supplies a record's geometry (LDS or global).
+template <bool FOURBIT, typename Geo>
+__device__ __forceinline__ void compose_chunk(const EmitP &P, Geo &geo, u64 p0, u32 nbytes, u64 r, u64 klo, u64 khi, bool any_toggle, u32 Lp1_32, u8 *o)
+{
+    const bool hdrs = P.hdr_text != nullptr;
+    u64 ro, rn, len, base, ho; u32 hl;
+    geo(r, ro, rn, len, base, ho, hl);
+    u64 lo = 0, hi = 0; u32 pos = 0;
+    while (pos < nbytes) {
+        u64 p = p0 + pos;
+        while (p >= rn) { r++; geo(r, ro, rn, len, base, ho, hl); }   // every record prints at least one byte
+        u64 off = p - ro;
+        const u8 *src = nullptr; u64 g = 0; bool is_bases = false;
+        u64 n_main = 0; u32 tc = 0, n_tc = 0;
+        if (off < hl) { src = P.hdr_text + ho + off; n_main = hl - off; }
+        else {
+            u64 q = off - hl;
+            if (P.mode == EM_FASTQ) {                            // SEQ \n + \n QUAL \n (output-fastq.c:100-149); never masked
+                if (q < len + 3) {
+                    u64 skip = 0;
+                    if (q < len) { is_bases = true; g = base + q; n_main = len - q; } else skip = q - len;
+                    tc = 0x0A2B0Au >> (8 * (u32)skip); n_tc = 3 - (u32)skip;
+                } else { src = P.qual + base + (q - len - 3); n_main = 2 * len + 3 - q; tc = '\n'; n_tc = 1; }
+            } else {
+                tc = '\n'; n_tc = 1;
+                if (P.mode == EM_SEQUENCES || P.L == 0) { if (q < len) { is_bases = true; g = base + q; n_main = len - q; } }
+                else {
+                    u64 line, col;
+                    if (Lp1_32 && (q >> 32) == 0) { u32 l32 = (u32)q / Lp1_32; line = l32; col = (u32)q - l32 * Lp1_32; }
+                    else { line = q / (P.L + 1); col = q - line * (P.L + 1); }
+                    u64 j = line * P.L + col;
+                    if (col != P.L && j < len) { is_bases = true; g = base + j; n_main = len - j < P.L - col ? len - j : P.L - col; }
+                }
+            }
+        }
+        u32 rem = nbytes - pos;
+        u32 n1 = n_main < rem ? (u32)n_main : rem;
+        if (n1) {
+            u64 slo, shi;
+            if (is_bases) { bases16<FOURBIT>(P, g, slo, shi); if (P.mode != EM_FASTQ) mask16(P, klo, khi, any_toggle, g, slo, shi); }
+            else if (!hdrs && off < hl) {                          // no header stream: byte-wise
+                slo = shi = 0;
+                for (u32 b = 0; b < n1; b++) { u64 ch = header_char(P, r, off + b, hl); if (b < 8) slo |= ch << (8 * b); else shi |= ch << (8 * (b - 8)); }
+            }
+            else { slo = ld64(src); shi = n1 > 8 ? ld64(src + 8) : 0; }
+            place16(lo, hi, slo, shi, pos, n1);
+            pos += n1; rem -= n1;
+        }
+        if (n1 == n_main && rem && n_tc) { u32 n2 = n_tc < rem ? n_tc : rem; place16(lo, hi, tc, 0, pos, n2); pos += n2; }
+    }
+    if (nbytes == 16) { uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32); memcpy(o, &v, 16); }
+    else for (u32 b = 0; b < nbytes; b++) o[b] = (u8)((b < 8 ? lo >> (8 * b) : hi >> (8 * (b - 8))) & 0xFF);
+}
+
+struct GeoGlobal {
+    const EmitP &P;
+    __device__ GeoGlobal(const EmitP &p) : P(p) {}
+    __device__ __forceinline__ void operator()(u64 r, u64 &ro, u64 &rn, u64 &len, u64 &base, u64 &ho, u32 &hl) const
+    { ro = P.rec_out[r]; rn = P.rec_out[r + 1]; len = P.rec_len[r]; base = P.rec_base[r]; hl = P.hdr_len[r]; ho = P.hdr_text ? P.hdr_off[r - P.hdr_r0] : 0; }
+};
+
+template <bool FOURBIT>
+__global__ __launch_bounds__(256) void k_emit_short(EmitP P, u8 *out)
+{
+    __shared__ u64 sh[4];
+    __shared__ u64 s_ro[ES_CAP + 1], s_len[ES_CAP], s_base[ES_CAP], s_ho[ES_CAP];
+    __shared__ u32 s_hl[ES_CAP];
+    u64 span_first = P.out_begin + (u64)blockIdx.x * ES_SPAN, span_last = span_first + ES_SPAN - 1;
+    if (span_last >= P.out_end) span_last = P.out_end - 1;
+    span_windows(P, span_first, span_last, sh);
+    const u64 rlo = sh[0], rhi = sh[1], klo = sh[2], khi = sh[3];
+    const bool any_toggle = P.masking && klo < khi;
+    const u64 nrec = rhi - rlo + 1;
+    const bool in_lds = nrec <= ES_CAP;
+    const bool hdrs = P.hdr_text != nullptr;
+    if (in_lds) {
+        for (u32 i = threadIdx.x; i < (u32)nrec; i += 256) {
+            u64 r = rlo + i; s_ro[i] = P.rec_out[r]; s_len[i] = P.rec_len[r]; s_base[i] = P.rec_base[r]; s_hl[i] = P.hdr_len[r];
+            s_ho[i] = hdrs ? P.hdr_off[r - P.hdr_r0] : 0;
+        }
+        if (threadIdx.x == 0) s_ro[nrec] = P.rec_out[rhi + 1];
+        __syncthreads();
+    }
+    const u32 Lp1_32 = (P.L + 1) >> 32 ? 0 : (u32)(P.L + 1);
+    auto geo_lds = [&](u64 r, u64 &ro, u64 &rn, u64 &len, u64 &base, u64 &ho, u32 &hl) {
+        u32 i = (u32)(r - rlo); ro = s_ro[i]; rn = s_ro[i + 1]; len = s_len[i]; base = s_base[i]; hl = s_hl[i]; ho = s_ho[i];
+    };
+    GeoGlobal geo_g(P);
+    for (u64 tile = span_first; tile <= span_last; tile += 4096) {
+        u64 p0 = tile + (u64)threadIdx.x * 16;
+        if (p0 > span_last) continue;
+        u32 nbytes = P.out_end - p0 < 16 ? (u32)(P.out_end - p0) : 16;
+        u8 *o = out + (p0 - P.out_begin);
+        if (in_lds) {
+            u32 lo_ = 0, hi_ = (u32)nrec; while (lo_ < hi_) { u32 mid = (lo_ + hi_) >> 1; if (s_ro[mid] <= p0) lo_ = mid + 1; else hi_ = mid; }
+            compose_chunk<FOURBIT>(P, geo_lds, p0, nbytes, rlo + lo_ - 1, klo, khi, any_toggle, Lp1_32, o);
+        } else {
+            u64 r = upper_bound_u64(P.rec_out, rlo, rhi + 1, p0) - 1;
+            compose_chunk<FOURBIT>(P, geo_g, p0, nbytes, r, klo, khi, any_toggle, Lp1_32, o);
+        }
+    }
+}
+
+// ---- long-record emit: one 4 KiB tile per workgroup, one 16-byte chunk per lane ---------------------------------------
+// A plain "read 8 B, write 16 B" kernel of this shape moves 15 GB in 2.4 ms on MI355X, and leaves about 110 vector
+// instructions per wavefront before the ALUs become the limit; so everything that is the same for the whole tile
+// (record, its geometry, the line/column of the tile's first byte, the mask toggles that can fall inside) is looked
+// up once per tile by k_tile_index and read here through scalar loads.
+struct TileIdx { u64 gline, k, khi; u32 col, fast; };   // gline: base index of the first base of the tile's first line (wrap) / first byte
+#define TI_HDR 0xFFFFFFFFu
+__global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr)            // ntiles + 1 entries each
+{
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > ntiles) return;
+    u64 p = P.out_begin + t * 4096;
+    TileIdx x; x.fast = 0; x.gline = 0; x.khi = 0;
+    if (p >= P.out_end) { tr[t] = ~0ull; x.k = P.n_toggles; x.col = TI_HDR; ti[t] = x; return; }
+    u64 g;
+    if (P.mode == EM_SEQ) { tr[t] = 0; x.col = 0; g = p; x.gline = p; }
+    else {
+        u64 r = upper_bound_u64(P.rec_out, 0, P.N + 1, p) - 1;
+        u64 off = p - P.rec_out[r], hl = P.hdr_len[r], len = P.rec_len[r], j = 0;
+        tr[t] = r; x.col = TI_HDR;
+        if (off >= hl) {
+            u64 q = off - hl;
+            if (P.mode == EM_FASTA && P.L) {
+                u64 line = q / (P.L + 1), col = q - line * (P.L + 1);
+                j = line * P.L + (col < P.L ? col : P.L);
+                if (P.L < 0xFFFFFFF0ull) { x.gline = P.rec_base[r] + line * P.L; x.col = (u32)col; }
+            } else if (P.mode != EM_FASTQ) { j = q; x.col = 0; x.gline = P.rec_base[r] + q; }
+            if (j > len) j = len;
+        }
+        g = P.rec_base[r] + j;
+    }
+    x.k = P.masking ? upper_bound_u64(P.toggles, 0, P.n_toggles, g) : 0;
+    ti[t] = x;
+}
+// fast = the whole tile lies in the body of one record (and the next tile starts in the same record, so that the
+// record's final newline is not in it); every other tile goes on the list of the segment-composing kernel
+__global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr, u32 *list, u32 *count)
+{
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    const bool wrap = P.mode == EM_FASTA && P.L != 0;
+    bool fast = ti[t].col != TI_HDR && tr[t] == tr[t + 1] && P.out_begin + (t + 1) * 4096 <= P.out_end && !P.force_slow && (!wrap || P.L >= 16);
+    ti[t].khi = ti[t + 1].k;
+    ti[t].fast = fast ? 1u : 0u;
+    if (!fast) list[atomicAdd(count, 1u)] = (u32)t;
+}
+
+template <bool FOURBIT>
+__global__ __launch_bounds__(256) void k_emit_tile(EmitP P, const TileIdx *ti, u8 *out)
+{
+    const TileIdx a = ti[blockIdx.x];
+    if (!a.fast) return;
+    const u32 lane16 = threadIdx.x * 16;
+    u64 g0; u32 nl_b = 64;
+    if (P.mode == EM_FASTA && P.L != 0) {
+        const u32 Lp1 = (u32)P.L + 1;
+        u32 c = a.col + lane16, dl;
+        if (Lp1 < 32768) dl = __umulhi(c, P.Ldiv_magic); else dl = c >= Lp1 ? 1u : 0u;   // c < Lp1 + 4096: exact (see unnaf_run)
+        u32 col = c - dl * Lp1;
+        g0 = a.gline + (u64)dl * (u32)P.L + col;
+        u32 d = (u32)P.L - col;                                  // byte index of the line-end newline
+        nl_b = d < 16 ? d : 64;
+    } else g0 = a.gline + lane16;
+    u64 lo, hi;
+    if (FOURBIT) {
+        // 16 nibbles from base g0: one 16-byte load from the 8-aligned address below, then a funnel shift
+        u64 addr = (u64)P.seq + (g0 >> 1);
+        const uint4 q = *(const uint4 *)(addr & ~7ull);
+        u64 q0 = (u64)q.x | ((u64)q.y << 32), q1 = (u64)q.z | ((u64)q.w << 32);
+        u32 sh = (u32)(addr & 7) * 8 + (u32)(g0 & 1) * 4;
+        expand16(P.lut, sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0, lo, hi);
+    } else bases16<false>(P, g0, lo, hi);
+    mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
+    if (nl_b < 16) splice_newline(lo, hi, (int)nl_b);
+    uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
+    *(uint4 *)(out + (u64)blockIdx.x * 4096 + lane16) = v;
+}
+
+template <bool FOURBIT>
+__global__ __launch_bounds__(256) void k_emit_rest(EmitP P, const TileIdx *ti, const u64 *tr, const u32 *list, const u32 *count, u8 *out)
+{
+    if (blockIdx.x >= *count) return;
+    const u64 t = list[blockIdx.x];
+    const TileIdx a = ti[t];
+    u64 p0 = P.out_begin + t * 4096 + threadIdx.x * 16;
+    if (p0 >= P.out_end) return;
+    u32 nbytes = P.out_end - p0 < 16 ? (u32)(P.out_end - p0) : 16;
+    const u32 Lp1_32 = (P.L + 1) >> 32 ? 0 : (u32)(P.L + 1);
+    u8 *o = out + (p0 - P.out_begin);
+    if (P.mode == EM_SEQ) {                                      // tail of a --seq range: byte-wise
+        for (u32 bb = 0; bb < nbytes; bb++) o[bb] = (u8)emit_byte<FOURBIT>(P, p0 + bb, 0, 0, a.k, a.khi);
+        return;
+    }
+    u64 rlo = tr[t], rhi = tr[t + 1] == ~0ull ? P.N - 1 : tr[t + 1];
+    u64 r = upper_bound_u64(P.rec_out, rlo, rhi + 1, p0) - 1;
+    GeoGlobal geo_g(P);
+    compose_chunk<FOURBIT>(P, geo_g, p0, nbytes, r, a.k, a.khi, P.masking && a.k < a.khi, Lp1_32, o);
+}
+
 // Base-index range [g_lo, g_hi) that output bytes [out_begin, out_end) can touch (conservative on both sides).
 __global__ void k_range_bases(EmitP P, u64 *out2)
 {
     if (threadIdx.x || blockIdx.x) return;
-    if (P.mode == EM_SEQ) { out2[0] = P.out_begin; out2[1] = P.out_end; return; }
+    if (P.mode == EM_SEQ) { out2[0] = P.out_begin; out2[1] = P.out_end; out2[2] = out2[3] = 0; return; }
     u64 pb = P.out_begin, pe = P.out_end - 1;
     u64 r0 = upper_bound_u64(P.rec_out, 0, P.N + 1, pb) - 1, r1 = upper_bound_u64(P.rec_out, 0, P.N + 1, pe) - 1;
+    out2[2] = r0; out2[3] = r1;
     auto lower = [&](u64 r, u64 p) -> u64 {                      // bases of record r before text byte p
         u64 off = p - P.rec_out[r], hl = P.hdr_len[r], len = P.rec_len[r];
         if (off <= hl) return 0;
@@ -630,10 +920,12 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     pl.P.out_begin = out_begin; pl.P.out_end = out_end;
     // Byte-range call (multi-GPU shard): find the bases this range touches and decode only the zstd blocks behind them.
     ZRange rgs, rgq; ZRange *prs = nullptr, *prq = nullptr;
+    u64 rec0 = 0, rec1 = pl.P.N ? pl.P.N - 1 : 0;                                        // records the byte range touches
     if (!whole && pl.P.mode != -1) {
-        u64 *d_g = arena_new<u64>(c, 2); if (!d_g) return NAF_GPU_ENOMEM;
+        u64 *d_g = arena_new<u64>(c, 4); if (!d_g) return NAF_GPU_ENOMEM;
         LAUNCH(c, "unnaf_range_bases", k_range_bases, 1, 64, 0, pl.P, d_g);
-        u64 g[2]; if ((rc = ctx_readback(c, g, d_g, 16))) return rc;
+        u64 g[4]; if ((rc = ctx_readback(c, g, d_g, 32))) return rc;
+        rec0 = g[2]; rec1 = g[3];
         if (g[1] < g[0]) g[1] = g[0];
         rgs.want_lo = pl.fourbit ? g[0] / 2 : g[0]; rgs.want_hi = pl.fourbit ? (g[1] + 1) / 2 : g[1];
         rgq.want_lo = g[0]; rgq.want_hi = g[1];
@@ -686,9 +978,49 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         pl.P.qual = (prq && prq->ranged) ? q - prq->got_lo : q;
     }
     pl.P.out_begin = out_begin; pl.P.out_end = out_end;
-    u32 grid = cdiv(out_end - out_begin, EMIT_SPAN);
-    if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit<true>, grid, 256, 0, pl.P, d_out);
-    else LAUNCH(c, "unnaf_emit", k_emit<false>, grid, 256, 0, pl.P, d_out);
+    // short records (FASTQ reads, contigs, proteins): segment-composing kernel; long records: streaming kernel
+    const char *ek = getenv("NAF_GPU_EMIT");
+    bool short_rec = pl.P.mode != EM_SEQ && pl.total / pl.P.N < 16384;
+    if (ek && !strcmp(ek, "short")) short_rec = pl.P.mode != EM_SEQ;
+    if (ek && !strcmp(ek, "long")) short_rec = false;
+    if (pl.P.force_slow) { short_rec = false; ek = "span"; }
+    if (short_rec) {
+        if (pl.P.mode == EM_FASTA || pl.P.mode == EM_FASTQ) {
+            u64 nr = rec1 - rec0 + 1, htot = 0;
+            u64 *ho = arena_new<u64>(c, nr + 2); if (!ho) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "unnaf_hdr_len64", k_hdr_len64, cdiv(nr, 256), 256, 0, pl.P.hdr_len, rec0, nr, ho);
+            if ((rc = scan_exclusive_u64(c, ho, nr, ho + nr + 1))) return rc;
+            if ((rc = ctx_readback(c, &htot, ho + nr + 1, 8))) return rc;
+            u8 *ht = (u8 *)arena_alloc(c, htot + 32); if (!ht) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "unnaf_hdr_build", k_hdr_build, cdiv(nr, 256), 256, 0, pl.P, rec0, nr, (const u64 *)ho, ht);
+            pl.P.hdr_off = ho; pl.P.hdr_text = ht; pl.P.hdr_r0 = rec0;
+        }
+        u32 grid = cdiv(out_end - out_begin, ES_SPAN);
+        if (pl.fourbit) LAUNCH(c, "unnaf_emit_short", k_emit_short<true>, grid, 256, 0, pl.P, d_out);
+        else LAUNCH(c, "unnaf_emit_short", k_emit_short<false>, grid, 256, 0, pl.P, d_out);
+    } else if (ek && !strcmp(ek, "span")) {                                              // previous long-record kernel (kept as a cross-check)
+        u32 grid = cdiv(out_end - out_begin, EMIT_SPAN);
+        if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit<true>, grid, 256, 0, pl.P, d_out);
+        else LAUNCH(c, "unnaf_emit", k_emit<false>, grid, 256, 0, pl.P, d_out);
+    } else {
+        u64 ntiles = cdiv(out_end - out_begin, 4096);
+        TileIdx *ti = arena_new<TileIdx>(c, ntiles + 2); u64 *tr = arena_new<u64>(c, ntiles + 2);
+        u32 *list = arena_new<u32>(c, ntiles + 1), *cnt = arena_new<u32>(c, 2);
+        if (!ti || !tr || !list || !cnt) return NAF_GPU_ENOMEM;
+        HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, c->stream));
+        // exact c / (L+1) for c < L + 1 + 4096 as mulhi(c, M), M = floor(2^32 / (L+1)) + 1, valid while c * (L+1) < 2^32
+        u64 Lp1 = pl.P.L + 1;
+        pl.P.Ldiv_magic = (Lp1 >= 2 && Lp1 < 32768) ? (u32)((1ull << 32) / Lp1 + 1) : 0;
+        LAUNCH(c, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr);
+        LAUNCH(c, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt);
+        u32 nrest = 0;                                                                   // tiles holding a header or a record boundary
+        if ((rc = ctx_readback(c, &nrest, cnt, 4))) return rc;
+        if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit_tile<true>, (u32)ntiles, 256, 0, pl.P, (const TileIdx *)ti, d_out);
+        else LAUNCH(c, "unnaf_emit", k_emit_tile<false>, (u32)ntiles, 256, 0, pl.P, (const TileIdx *)ti, d_out);
+        if (!nrest) {}
+        else if (pl.fourbit) LAUNCH(c, "unnaf_emit_rest", k_emit_rest<true>, (u32)nrest, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
+        else LAUNCH(c, "unnaf_emit_rest", k_emit_rest<false>, nrest, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
+    }
     HIP_TRY(c, hipGetLastError());
     return 0;
 }

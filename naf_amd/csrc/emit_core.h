@@ -14,6 +14,7 @@ struct EmitP {
     const u8 *ids, *names;
     const u8 *seq;                     // packed 4-bit codes, or text bytes
     const u8 *qual;
+    const u64 *hdr_off; const u8 *hdr_text; u64 hdr_r0;   // short-record path: header lines of records >= hdr_r0 as one stream
     const u64 *toggles; u64 n_toggles;
     u64 N, T, L;
     u64 out_begin, out_end;            // byte range of the full text to produce; out[0] = byte out_begin

@@ -217,10 +217,10 @@ __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 
     u8 w[256]; u32 nw = 0, used = 0;
     u32 log = huf_read_weights(c + blk[i].lit_off, blk[i].lit_csize, w, &nw, &used);
     if (!log) { set_err(st, ZE_CORRUPT); blk[i].err = ZE_CORRUPT; return; }
-    u32 bytes = 2u << log; if (bytes < 16) bytes = 16;
+    u32 bytes = huf_tab_bytes(log);
     u32 off = atomicAdd(&st->huf_pool_used, bytes);
     if (off + bytes > pool_cap) { set_err(st, ZE_POOL); return; }
-    huf_build_table((u16 *)(pool + off), w, nw, log);
+    huf_build_any((u16 *)(pool + off), w, nw, log);
     blk[i].huf_tab = off; blk[i].huf_log = (u8)log;
     atomicMax(&st->max_huf_log, log);
 }
@@ -468,14 +468,15 @@ __global__ void k_emit_headers(EmitP P, u8 *text)
 #define HUF_ROUND 32                       // symbols per lane per round
 #define HUF_OROW 72                        // output row pitch (64 + 8)
 #define HUF_IROW 136                       // input window pitch (128 + 8)
+#define HUF_IROW_BIG 264                   // four-sector window for tables of more than 7 bits
 template <bool FUSE>
 __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf,
                                                       const u8 *pool, u32 slot_bytes, u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first,
-                                                      EmitP EP, u8 *text)
+                                                      EmitP EP, u8 *text, u32 ipitch)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
-    u8 *irows = lds + HUF_BLOCKS_PER_WG * slot_bytes;                // 64 x 136 B
-    u16 *lut2 = (u16 *)(irows + 64 * HUF_IROW);                       // FUSE: packed byte -> two ASCII bytes
+    u8 *irows = lds + HUF_BLOCKS_PER_WG * slot_bytes;                // 64 input rings of ipitch bytes (136: 2 sectors, 264: 4 sectors)
+    u16 *lut2 = (u16 *)(irows + 64 * ipitch);                         // FUSE: packed byte -> two ASCII bytes
     u8 *orows = (u8 *)lut2;                                           // !FUSE: 64 output rows of 72 B + 64 row pointers
     u64 *row_out = (u64 *)(orows + 64 * HUF_OROW);
     if (FUSE) for (u32 v = threadIdx.x; v < 256; v += 64) {
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
         if (b.btype != BT_COMP || b.lit_type < LIT_HUF || b.err) continue;
         i32 ob = own_huf[bi];
         if (ob < 0) continue;
-        u32 bytes = 2u << blk[ob].huf_log; if (bytes < 16) bytes = 16;
+        u32 bytes = huf_tab_bytes(blk[ob].huf_log);
         const uint4 *g = (const uint4 *)(pool + blk[ob].huf_tab);
         uint4 *l = (uint4 *)(lds + j * slot_bytes);
         for (u32 k = lane; k < bytes / 16; k += 64) l[k] = g[k];
@@ -533,14 +534,15 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
     u32 my_rounds = valid ? n / HUF_ROUND : 0xFFFFFFFFu;                 // wave-uniform round count
     for (int d = 32; d; d >>= 1) { u32 o = (u32)__shfl_xor((int)my_rounds, d, 64); my_rounds = o < my_rounds ? o : my_rounds; }
     u32 rounds = my_rounds == 0xFFFFFFFFu ? 0 : my_rounds;
-    bool wide = __all(!valid || log <= 7);
+    // tables of more than 7 bits: 32 symbols can take 44 bytes, so the input ring is 4 sectors and a refill feeds 4 symbols
+    const bool big = ipitch > HUF_IROW;
+    const u32 rmask = big ? 255u : 127u, rbytes = big ? 44u : 28u, guard = big ? 192u : 160u;
     __syncthreads();
     u32 R = 0;
-    if (wide) {
+    {
         // ---- sector-window reader -------------------------------------------------------------------------
-        u8 *irow = irows + lane * HUF_IROW;
-        const u32 rbytes = 28;                                            // 32 symbols x 7 bits
-        bool live = valid && (u64)(br.ptr - br.start) >= 192;
+        u8 *irow = irows + lane * ipitch;
+        bool live = valid && (u64)(br.ptr - br.start) >= guard + 32;
         u64 gp = (u64)br.ptr, lo = 0;
         uint4 st0, st1, st2, st3; bool pending = false;
         st0 = st1 = st2 = st3 = make_uint4(0, 0, 0, 0);
@@ -549,41 +551,63 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
             lo = top - 64;
             const uint4 *g0 = (const uint4 *)lo;
 #pragma unroll
-            for (int q = 0; q < 8; q++) { uint4 v = g0[q]; u32 o = (u32)((lo + 16 * q) & 127); *(u64 *)(irow + o) = (u64)v.x | ((u64)v.y << 32); *(u64 *)(irow + o + 8) = (u64)v.z | ((u64)v.w << 32); }
+            for (int q = 0; q < 8; q++) { uint4 v = g0[q]; u32 o = (u32)((lo + 16 * q) & rmask); *(u64 *)(irow + o) = (u64)v.x | ((u64)v.y << 32); *(u64 *)(irow + o + 8) = (u64)v.z | ((u64)v.w << 32); }
         }
         u32 bits = br.consumed;                                            // bits consumed since the container at gp
         for (; R < rounds; R++) {
-            if (!__all(!valid || (live && gp - (u64)br.start >= 160))) break;   // near a stream start: generic reader finishes
+            if (!__all(!valid || (live && gp - (u64)br.start >= guard))) break;   // near a stream start: generic reader finishes
             if (valid) {
                 if (pending) {                                            // commit the sector fetched during the previous round
-                    lo -= 64; u32 o = (u32)(lo & 127);
+                    lo -= 64; u32 o = (u32)(lo & rmask);
                     *(u64 *)(irow + o) = (u64)st0.x | ((u64)st0.y << 32); *(u64 *)(irow + o + 8) = (u64)st0.z | ((u64)st0.w << 32);
                     *(u64 *)(irow + o + 16) = (u64)st1.x | ((u64)st1.y << 32); *(u64 *)(irow + o + 24) = (u64)st1.z | ((u64)st1.w << 32);
                     *(u64 *)(irow + o + 32) = (u64)st2.x | ((u64)st2.y << 32); *(u64 *)(irow + o + 40) = (u64)st2.z | ((u64)st2.w << 32);
                     *(u64 *)(irow + o + 48) = (u64)st3.x | ((u64)st3.y << 32); *(u64 *)(irow + o + 56) = (u64)st3.z | ((u64)st3.w << 32);
                     pending = false;
                 }
-                if (lo + 2 * rbytes > gp) {                               // the round after this one may read below `lo`
+                if (lo + 2 * rbytes + 8 > gp) {                           // the round after this one may read below `lo`
                     const uint4 *g0 = (const uint4 *)(lo - 64);
                     st0 = g0[0]; st1 = g0[1]; st2 = g0[2]; st3 = g0[3]; pending = true;
                 }
                 u64 accs[HUF_ROUND / 8];
+                if (!big) {
 #pragma unroll
-                for (u32 g = 0; g < HUF_ROUND / 8; g++) {
-                    // refill: move the container down by the whole bytes consumed, keep the window top-aligned
-                    gp -= bits >> 3; bits &= 7;
-                    u32 o = (u32)(gp & 127), sh = (o & 7) * 8;
-                    u64 q0 = *(const u64 *)(irow + (o & ~7u)), q1 = *(const u64 *)(irow + (((o & ~7u) + 8) & 127));
-                    u64 w = (sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0) << bits;
-                    u64 acc = 0;
+                    for (u32 g = 0; g < HUF_ROUND / 8; g++) {
+                        // refill: move the container down by the whole bytes consumed, keep the window top-aligned
+                        gp -= bits >> 3; bits &= 7;
+                        u32 o = (u32)(gp & 127), sh = (o & 7) * 8;
+                        u64 q0 = *(const u64 *)(irow + (o & ~7u)), q1 = *(const u64 *)(irow + (((o & ~7u) + 8) & 127));
+                        u64 w = (sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0) << bits;
+                        u64 acc = 0;
 #pragma unroll
-                    for (u32 q = 0; q < 8; q++) {
-                        u32 e = tab[(u32)(w >> 32) >> (32 - log)];
-                        u32 nb = e >> 8;
-                        w <<= nb; bits += nb;
-                        acc |= (u64)(e & 0xFF) << (8 * q);
+                        for (u32 q = 0; q < 8; q++) {
+                            u32 e = tab[(u32)(w >> 32) >> (32 - log)];
+                            u32 nb = e >> 8;
+                            w <<= nb; bits += nb;
+                            acc |= (u64)(e & 0xFF) << (8 * q);
+                        }
+                        accs[g] = acc;
                     }
-                    accs[g] = acc;
+                } else {
+#pragma unroll
+                    for (u32 g = 0; g < HUF_ROUND / 8; g++) {
+                        u64 acc = 0;
+#pragma unroll
+                        for (u32 h = 0; h < 2; h++) {
+                            gp -= bits >> 3; bits &= 7;
+                            u32 o = (u32)(gp & 255), sh = (o & 7) * 8;
+                            u64 q0 = *(const u64 *)(irow + (o & ~7u)), q1 = *(const u64 *)(irow + (((o & ~7u) + 8) & 255));
+                            u64 w = (sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0) << bits;
+#pragma unroll
+                            for (u32 q = 0; q < 4; q++) {
+                                u32 e = huf_look(tab, (u32)(w >> 32) >> (32 - log), log);
+                                u32 nb = e >> 8;
+                                w <<= nb; bits += nb;
+                                acc |= (u64)(e & 0xFF) << (8 * (4 * h + q));
+                            }
+                        }
+                        accs[g] = acc;
+                    }
                 }
                 if (FUSE) {
 #pragma unroll
@@ -616,28 +640,6 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
         }
         if (valid && live) { gp -= bits >> 3; bits &= 7; br.c = ld64((const u8 *)gp); br.consumed = bits; }
         br.ptr = (const u8 *)gp;
-    } else if (!FUSE) {
-        // ---- register double buffer: W1 holds the 8 bytes below the container, loaded one refill ahead -------
-        u64 W1 = 0;
-        const u32 need = 96 + 16;
-        bool fast_ok = valid && (u64)(br.ptr - br.start) >= need + 8;
-        if (fast_ok) { bitr_reload(br); W1 = ld64(br.ptr - 8); }
-        for (; R < rounds; R++) {
-            if (!__all(!valid || (fast_ok && (u64)(br.ptr - br.start) >= need))) break;
-            if (valid) {
-                for (u32 g = 0; g < HUF_ROUND / 8; g++) {
-                    u64 acc = 0;
-#pragma unroll
-                    for (u32 h = 0; h < 2; h++) {
-                        u32 k = br.consumed >> 3;
-                        if (k) { br.c = (br.c << (8 * k)) | (W1 >> (64 - 8 * k)); br.ptr -= k; br.consumed &= 7; W1 = ld64(br.ptr - 8); }
-#pragma unroll
-                        for (u32 q = 0; q < 4; q++) { u32 e = tab[bitr_peek(br, log)]; br.consumed += e >> 8; acc |= (u64)(e & 0xFF) << (8 * (4 * h + q)); }
-                    }
-                    st64(out + (u64)R * HUF_ROUND + g * 8, acc);
-                }
-            }
-        }
     }
     if (valid) {
         u32 done = R * HUF_ROUND;
@@ -921,20 +923,21 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     if (n_huf_def) {
         // tables of the blocks that will be decoded (and of the earlier blocks that own a table in force there)
         u32 hb_end = b_first + b_count, hb_n = hb_end - huf_first;
-        u32 pool_cap = (hb_n < n_huf_def ? hb_n : n_huf_def) * 4096u + 4096u;   // 2^11 entries * 2 B worst case per table
+        u32 pool_cap = (hb_n < n_huf_def ? hb_n : n_huf_def) * (u32)HUFC_BYTES + 4096u;   // largest table form (log > 8: compact)
         huf_pool = (u8 *)arena_alloc(c, pool_cap);
         if (!huf_pool) return NAF_GPU_ENOMEM;
         if (hb_n) LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(hb_n, 64), 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first);
         rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
         if (hs.err) return zerr(c, hs.err, "Huffman tables");
-        u32 slot = 2u << hs.max_huf_log; if (slot < 16) slot = 16;
+        u32 slot = huf_tab_bytes(hs.max_huf_log);
         u32 b_end = b_first + b_count;
         if (fuse && hs.max_huf_log > 7) return ZSTD_NEED_TWO_PASS;
         EmitP ep; memset(&ep, 0, sizeof ep); if (fuse) ep = *fuse;
-        if (b_count && fuse) LAUNCH(c, "zstd_huf_fused_emit", (k_huf_literals<true>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * HUF_IROW + 512,
-               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text);
-        else if (b_count) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * HUF_IROW + 64 * HUF_OROW + 512,
-               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text);
+        u32 ipitch = hs.max_huf_log > 7 ? HUF_IROW_BIG : HUF_IROW;
+        if (b_count && fuse) LAUNCH(c, "zstd_huf_fused_emit", (k_huf_literals<true>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 512,
+               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch);
+        else if (b_count) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512,
+               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch);
     }
     if (b_count && !fuse) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
     if (n_seq_blk)

@@ -109,3 +109,41 @@ def fasta_acgt_device(total_bytes: int, n_records: int = 100, width: int = 80, s
         body[:, width] = 10
         pos += rows_per * (width + 1)
     return out
+
+
+def fastq_reads_device(total_bytes: int, read_len: int = 150, seed: int = 7, device="cuda", chunk_reads: int = 1 << 22):
+    """cfg5-style FASTQ of ~total_bytes built in device memory (uint8 torch tensor).
+
+    Reads `@readN len=L`, bases ACGT 0.22 each / acgt 0.025 each / N 0.02, quality uniform Phred 0-40.
+    Reads are generated in groups that share the number of digits of N, so that every group is a
+    fixed-width 2-D byte matrix.
+    """
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    base_lut = torch.tensor(list(b"A" * 220 + b"C" * 220 + b"G" * 220 + b"T" * 220 + b"a" * 25 + b"c" * 25 + b"g" * 25 + b"t" * 25 + b"N" * 20),
+                            dtype=torch.uint8, device=device)
+    tail = b" len=%d\n" % read_len
+    parts, made, n = [], 0, 1
+    while made < total_bytes:
+        digits = len(str(n))
+        width = 5 + digits + len(tail) + read_len + 3 + read_len + 1
+        cnt = min(10 ** digits - n, chunk_reads, max(1, (total_bytes - made + width - 1) // width))
+        m = torch.empty((cnt, width), dtype=torch.uint8, device=device)
+        m[:, 0:5] = torch.tensor(list(b"@read"), dtype=torch.uint8, device=device)
+        ids = torch.arange(n, n + cnt, dtype=torch.int64, device=device)
+        for d in range(digits):
+            m[:, 5 + d] = ((ids // (10 ** (digits - 1 - d))) % 10 + 48).to(torch.uint8)
+        p = 5 + digits
+        m[:, p:p + len(tail)] = torch.tensor(list(tail), dtype=torch.uint8, device=device)
+        p += len(tail)
+        m[:, p:p + read_len] = base_lut[torch.randint(0, 1000, (cnt, read_len), dtype=torch.int64, device=device, generator=g)]
+        p += read_len
+        m[:, p:p + 3] = torch.tensor(list(b"\n+\n"), dtype=torch.uint8, device=device)
+        p += 3
+        m[:, p:p + read_len] = torch.randint(33, 74, (cnt, read_len), dtype=torch.int64, device=device, generator=g).to(torch.uint8)
+        m[:, p + read_len] = 10
+        parts.append(m.reshape(-1))
+        made += cnt * width
+        n += cnt
+    return torch.cat(parts)

@@ -7,6 +7,8 @@
 #include <vector>
 #include <stdlib.h>
 
+static unsigned g_max_huf_log = 0;
+extern "C" unsigned emul_max_huf_log(void) { unsigned v = g_max_huf_log; g_max_huf_log = 0; return v; }
 extern "C" long long emul_zstd_decompress_frame(const u8 *src, size_t len, u8 *dst, size_t cap)
 {
     if (len < 5 || ld32(src) != 0xFD2FB528u) return -1;
@@ -55,7 +57,7 @@ extern "C" long long emul_zstd_decompress_frame(const u8 *src, size_t len, u8 *d
             u8 w[256]; u32 nw = 0, used = 0;
             u32 log = huf_read_weights(c + b.lit_off, b.lit_csize, w, &nw, &used);
             if (!log) return -4;
-            huf[i].resize(1u << log); huf_build_table(huf[i].data(), w, nw, log); b.huf_log = (u8)log;
+            huf[i].resize(huf_tab_bytes(log) / 2); huf_build_any(huf[i].data(), w, nw, log); b.huf_log = (u8)log; if (log > g_max_huf_log) g_max_huf_log = log;
             if (used != b.huf_streams_off - b.lit_off) return -5;
         }
         if (b.nseq) {

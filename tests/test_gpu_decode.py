@@ -64,12 +64,14 @@ MODES = {"fasta": (0, True, -1), "seq": (2, True, -1), "sequences": (3, True, -1
          "fasta_nomask": (0, False, -1), "fasta_ll13": (0, True, 13), "fasta_ll0": (0, True, 0), "fastq": (1, True, -1)}
 
 
-@pytest.mark.parametrize("path", ["fused", "twopass", "slow"])
+@pytest.mark.parametrize("path", ["fused", "long", "span", "short", "slow"])
 @pytest.mark.parametrize("case", naf_cases(), ids=lambda c: c["name"])
 def test_unnaf_matches_reference_outputs(gpu, case, path, monkeypatch):
     """Bit-exact against the outputs of the real reference unnaf on reference-made archives, through each of the
-    three emit paths: fused decode+emit (literal-only frames), decode then 16-byte-chunk emit, per-byte emit."""
+    emit paths: fused decode+emit (literal-only frames), decode then the tile-indexed long-record kernel, the older
+    span kernel, the short-record segment-composing kernel, per-byte emit."""
     monkeypatch.setenv("NAF_GPU_FORCE_SLOW", "1" if path == "slow" else "0")
+    monkeypatch.setenv("NAF_GPU_EMIT", path if path in ("long", "span", "short") else "")
     monkeypatch.setenv("NAF_GPU_FUSE", "1" if path == "fused" else "0")
     naf = golden_bytes("naf", case["name"] + ".naf")
     d = gpu.to_device(naf)
@@ -110,10 +112,12 @@ def test_unnaf_range_sharding_is_consistent(gpu):
     assert b"".join(parts) == whole
 
 
-def test_unnaf_range_on_own_archives_decodes_only_needed_blocks(gpu, oracle):
+@pytest.mark.parametrize("emit", ["long", "span", "short"])
+def test_unnaf_range_on_own_archives_decodes_only_needed_blocks(gpu, oracle, emit, monkeypatch):
     """Own archives (independent blocks) take the block-range path: every cut of FASTA / FASTQ / --seq /
     --sequences text equals the slice of the whole text."""
     from naf_amd import synth
+    monkeypatch.setenv("NAF_GPU_EMIT", emit)
     rng = np.random.default_rng(4)
     texts = [synth.fasta_acgt(700000, 5, 80, seed=21), synth.fasta_mixed(25, 30000, 60, seed=22), synth.fastq_reads(3000, 150, seed=23)]
     for text in texts:
@@ -145,13 +149,21 @@ def test_fused_path_on_own_archives(gpu, oracle, monkeypatch):
                 monkeypatch.setenv("NAF_GPU_FUSE", "1")
                 a = host(gpu.unnaf(d_naf, 0, um, ll))
                 monkeypatch.setenv("NAF_GPU_FUSE", "0")
+                monkeypatch.setenv("NAF_GPU_EMIT", "long")
                 b = host(gpu.unnaf(d_naf, 0, um, ll))
-                assert a == e and b == e, (len(text), ll, um)
+                monkeypatch.setenv("NAF_GPU_EMIT", "short")
+                b2 = host(gpu.unnaf(d_naf, 0, um, ll))
+                monkeypatch.setenv("NAF_GPU_EMIT", "span")
+                b3 = host(gpu.unnaf(d_naf, 0, um, ll))
+                monkeypatch.setenv("NAF_GPU_EMIT", "")
+                assert a == e and b == e and b2 == e and b3 == e, (len(text), ll, um)
 
 
-def test_unnaf_random_archives_against_oracle(gpu, oracle):
+@pytest.mark.parametrize("emit", ["long", "span", "short"])
+def test_unnaf_random_archives_against_oracle(gpu, oracle, emit, monkeypatch):
     """Seeded random FASTA/FASTQ -> oracle archive (raw zstd blocks) -> GPU == oracle, all modes."""
     from naf_amd import synth
+    monkeypatch.setenv("NAF_GPU_EMIT", emit)
     rng = np.random.default_rng(123)
     for i in range(12):
         if i % 3 == 2:
