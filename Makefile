@@ -6,7 +6,11 @@ CSRC     = naf_amd/csrc
 OBJS     = $(CSRC)/naf_gpu.o $(CSRC)/scan.o $(CSRC)/zstd_dec.o $(CSRC)/emit.o $(CSRC)/zstd_enc.o $(CSRC)/enc.o
 HDRS     = $(wildcard $(CSRC)/*.h) include/naf_gpu.h
 
-all: naf_amd/libnaf_gpu.so hosts oracle emul
+all: naf_amd/libnaf_gpu.so hosts oracle emul tools/bw_calibrate
+
+# known-byte-count kernels used to calibrate the PMC counters (tools/profile_bench.sh)
+tools/bw_calibrate: tools/bw_calibrate.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -w -o $@ $<
 
 naf_amd/libnaf_gpu.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS)

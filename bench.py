@@ -97,10 +97,12 @@ def main():
     def step():
         return ctx.unnaf(d_naf, capi.OUT_FASTA, out=out)
 
-    for _ in range(args.warmup):
-        r = step()
+    r = step()                                # untimed: bit-exact round trip at full size (size-independent property)
     torch.cuda.synchronize()
-    ok = bool(torch.equal(r, text))           # bit-exact round trip at full size (size-independent property)
+    ok = bool(torch.equal(r, text))
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+    torch.cuda.synchronize()
 
     if world > 1:
         dist.barrier()
@@ -138,8 +140,17 @@ def main():
     # so bytes/time over the step equals the launch-weighted average
     dom_ms = kt[dom][0]
     achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
+    # HBM traffic of that kernel per step, from the committed PMC passes of this same workload (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in separate runs, tools/profile_bench.sh; FETCH doubled as the gfx950 guide prescribes)
+    traffic, traffic_src = None, None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if abs(pm["text_bytes"] - n_text) < 0.01 * n_text and dom in pm["kernels"]:
+            traffic = int(pm["kernels"][dom]["fetch_bytes"] + pm["kernels"][dom]["write_bytes"]); traffic_src = pm["source"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": None,
+                "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(alg[dom]), "kernel_ms_per_step": round(dom_ms, 4), "launches_per_step": kt[dom][1],
                 "path_bytes_per_step": int(n_naf + n_text),
                 "path_frac": round((n_naf + n_text) / (ms_per_step * 1e-3) / HBM_PEAK, 4),

@@ -1,0 +1,65 @@
+#!/bin/bash
+# Produces the files under profiles/ for one round:  tools/profile_bench.sh r01   (run on the GPU box, from the repo root)
+#   <tag>_bench_line.json                     the JSON line of a plain `python bench.py`
+#   <tag>_bench_rocprofv3_kernel_stats.csv    rocprofv3 --kernel-trace --stats of `python bench.py --steps 3 --no-cpu`
+#   <tag>_pmc_fetch.csv / _pmc_write.csv      per-kernel FETCH_SIZE / WRITE_SIZE sums (separate --pmc passes, no tracing
+#                                             domains besides the kernel dispatch records), incl. the calibration kernel
+# Everything is written under gpurun_out/<tag>/ ; copy what should be judged into profiles/.
+set -u
+tag=${1:-r01}
+out=gpurun_out/$tag; mkdir -p $out
+export TMPDIR=/tmp
+python bench.py > $out/${tag}_bench_line.json 2> $out/bench.err
+tail -c 400 $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 3 --no-cpu > $out/stats.log 2>&1
+cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/${tag}_bench_rocprofv3_kernel_stats.csv
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  printf 'pmc: %s\n' $ctr > $out/pmc_$ctr.txt
+  rocprofv3 -i $out/pmc_$ctr.txt --output-format csv -d $out/pmc_$ctr -- python bench.py --steps 1 --warmup 0 --no-cpu > $out/pmc_$ctr.log 2>&1
+  rocprofv3 -i $out/pmc_$ctr.txt --output-format csv -d $out/cal_$ctr -- tools/bw_calibrate > $out/cal_$ctr.log 2>&1
+done
+python - "$out" "$tag" <<'PY'
+import csv, glob, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+for ctr, name in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    rows = []
+    for d, label in ((f"{out}/pmc_{ctr}", "bench"), (f"{out}/cal_{ctr}", "calibration")):
+        fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+        if not fs: continue
+        agg = collections.OrderedDict()
+        for r in csv.DictReader(open(fs[0])):
+            if r["Counter_Name"] != ctr: continue
+            k = r["Kernel_Name"].split("(")[0]
+            a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
+        for k, (n, v) in agg.items():
+            rows.append((label, k, n, v))
+    with open(f"{out}/{tag}_pmc_{name}.csv", "w") as f:
+        f.write(f"run,kernel,dispatch_rows,{ctr}_sum\n")
+        for r in rows: f.write("%s,%s,%d,%.0f\n" % r)
+PY
+python - "$out" "$tag" <<'PY'
+import csv, json, sys
+out, tag = sys.argv[1], sys.argv[2]
+line = json.loads(open(f"{out}/{tag}_bench_line.json").read().strip().splitlines()[-1])
+text_bytes = int(line["config"]["workload"].split("FASTA ")[-1].split(" B")[0])
+# kernel function -> the name bench.py times it under; the PMC passes ran ONE step plus one verification step and one
+# instrumented step = 3 unnaf calls, and 2 ennaf calls
+names = {"k_huf_literals": "zstd_huf_literals", "k_emit_tile": "unnaf_emit", "k_emit_rest": "unnaf_emit_rest", "k_build_huf": "zstd_build_huf",
+         "k_spec_find": "zstd_index_find", "k_spec_resolve": "zstd_index_resolve", "k_copy_fill": "zstd_copy_fill"}
+calls = 3
+k = {}
+# counter unit = KiB.  FETCH_SIZE tallies a wide coalesced read at 1/2 (guide; k_expand / k_read calibration: x2), the
+# Huffman kernel's one-64-byte-sector-per-lane reads at 1/1.742 (k_sector_read calibration); WRITE_SIZE is exact (k_expand / k_write)
+fetch_factor = {"k_huf_literals": 1.742}
+for ctr, name in (("fetch", "fetch_bytes"), ("write", "write_bytes")):
+    for r in csv.DictReader(open(f"{out}/{tag}_pmc_{ctr}.csv")):
+        if r["run"] != "bench": continue
+        fn = r["kernel"].replace("void ", "").split("<")[0]
+        if fn in names:
+            scale = 1024 * (fetch_factor.get(fn, 2.0) if ctr == "fetch" else 1.0)
+            k.setdefault(names[fn], {"fetch_bytes": 0, "write_bytes": 0})[name] += float(r[list(r.keys())[-1]]) * scale / calls
+json.dump({"source": f"profiles/{tag}_pmc_fetch.csv + {tag}_pmc_write.csv (rocprofv3 --pmc, separate passes; counter unit KiB; FETCH_SIZE x2 for coalesced reads, x1.742 for the per-lane 64-byte sector reads of zstd_huf_literals, WRITE_SIZE x1; factors calibrated with tools/bw_calibrate.hip)",
+           "text_bytes": text_bytes, "unnaf_calls_in_pass": calls, "kernels": k}, open(f"{out}/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(k, indent=1))
+PY
+ls -la $out/*.csv $out/*.json
