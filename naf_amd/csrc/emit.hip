@@ -15,6 +15,7 @@
 #include "ctx.h"
 #include "wgscan.h"
 #include "emit_core.h"
+#include <thread>
 
 // ---- prep kernels --------------------------------------------------------------------------------------------
 __global__ void k_len_flags(const u32 *units, u64 n, u64 *flag)
@@ -830,6 +831,18 @@ static int unnaf_prepare(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const 
     const char *fs = getenv("NAF_GPU_FORCE_SLOW"); P.force_slow = fs && fs[0] == '1';
     pl.need_qual = P.mode == EM_FASTQ;
 
+    return 0;
+}
+
+// The side streams (lengths, ids, names, mask) and the prefix tables built from them.  Runs on whichever context it is given:
+// the archive's own for byte-range calls, the side context (second host thread, second stream) for whole-text calls.
+static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl)
+{
+    const naf_gpu_header &h = pl.h;
+    EmitP &P = pl.P;
+    int has_ids = (h.flags >> 5) & 1, has_names = (h.flags >> 4) & 1, has_len = (h.flags >> 3) & 1;
+    u64 N = h.n_sequences, T = h.orig_size[S_SEQ];
+    int rc;
     if (P.mode == EM_SEQ) {
         pl.total = T;
     } else {
@@ -909,6 +922,64 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     UnnafPlan pl;
     int rc = unnaf_prepare(c, d_naf, naf_len, o, pl); if (rc) return rc;
     if (pl.empty) { *out_len = 0; return 0; }
+    const naf_gpu_header &h = pl.h;
+    ZRange rgs, rgq; ZRange *prs = nullptr, *prq = nullptr;
+    u8 *seq = nullptr;
+    // sequence (and quality) payload: the dominant zstd streams
+    auto payload = [&]() -> int {
+        int r;
+        u64 seq_need = prs ? (rgs.want_hi - rgs.want_lo) + 2 * 131072 + 64 : pl.seq_bytes + 64;
+        if (seq_need > pl.seq_bytes + 64) seq_need = pl.seq_bytes + 64;
+        seq = (u8 *)arena_alloc(c, seq_need);
+        if (!seq) return NAF_GPU_ENOMEM;
+        size_t n = 0;
+        r = zstd_decode_range(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, seq, prs ? seq_need : pl.seq_bytes, &n, prs);
+        if (r == NAF_GPU_ECAP && prs) {                                              // dependent blocks: needs the whole stream
+            seq = (u8 *)arena_alloc(c, pl.seq_bytes + 64); if (!seq) return NAF_GPU_ENOMEM;
+            r = zstd_decode(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, seq, pl.seq_bytes, &n); prs = nullptr;
+        }
+        if (r == NAF_GPU_ECAP || (r == 0 && n != pl.seq_bytes)) return ctx_fail(c, NAF_GPU_EFORMAT, "can't decompress sequence\n");
+        if (r) return r;
+        pl.P.seq = (prs && prs->ranged) ? seq - prs->got_lo : seq;
+        if (pl.need_qual) {
+            u64 qn = h.orig_size[S_QUAL];
+            u64 q_need = prq ? (rgq.want_hi - rgq.want_lo) + 2 * 131072 + 64 : qn + 64;
+            if (q_need > qn + 64) q_need = qn + 64;
+            u8 *q = (u8 *)arena_alloc(c, q_need); if (!q) return NAF_GPU_ENOMEM;
+            size_t qgot = 0;
+            r = zstd_decode_range(c, d_naf + h.payload_off[S_QUAL], h.comp_size[S_QUAL], 0, q, prq ? q_need : qn, &qgot, prq);
+            if (r == NAF_GPU_ECAP && prq) {
+                q = (u8 *)arena_alloc(c, qn + 64); if (!q) return NAF_GPU_ENOMEM;
+                r = zstd_decode(c, d_naf + h.payload_off[S_QUAL], h.comp_size[S_QUAL], 0, q, qn, &qgot); prq = nullptr;
+            }
+            if (r == NAF_GPU_ECAP || (r == 0 && qgot != qn)) return ctx_fail(c, NAF_GPU_EFORMAT, "can't decompress quality\n");
+            if (r) return r;
+            pl.P.qual = (prq && prq->ranged) ? q - prq->got_lo : q;
+        }
+        return 0;
+    };
+    const char *fuse = getenv("NAF_GPU_FUSE");
+    const bool fuse_on = fuse && fuse[0] == '1';
+    const char *ser = getenv("NAF_GPU_SERIAL_SECTIONS");
+    // Whole-text call: the side streams (a chain of small launches and read-backs, mostly latency) are prepared by a second
+    // host thread on the side context's stream while this thread decodes the payload; they meet before the emit.
+    const bool par = whole && !size_only && pl.P.mode != -1 && c->side && !fuse_on && !(ser && ser[0] == '1');
+    bool payload_done = false;
+    if (par) {
+        arena_reset(c->side);
+        HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->side->stream, c->fork_ev, 0));
+        int rc_side = 0;
+        std::thread th([&] { hipSetDevice(c->device); rc_side = unnaf_sections(c->side, d_naf, pl); });
+        rc = payload();
+        th.join();
+        if (rc_side) { memcpy(c->err, c->side->err, sizeof c->err); return rc_side; }   // the order a sequential run reports errors in
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->side->stream));
+        payload_done = true;
+    } else if (pl.P.mode != -1) {
+        if ((rc = unnaf_sections(c, d_naf, pl))) return rc;
+    }
     if (whole) { out_begin = 0; out_end = pl.total; }
     if (out_end > pl.total) out_end = pl.total;
     if (out_begin > out_end) out_begin = out_end;
@@ -916,10 +987,8 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     if (size_only) { *out_len = pl.total; return 0; }
     if (*out_len > out_cap) return ctx_fail(c, NAF_GPU_ECAP, "unnaf output needs %llu bytes, capacity %zu", (unsigned long long)*out_len, out_cap);
     if (*out_len == 0) return 0;
-    const naf_gpu_header &h = pl.h;
     pl.P.out_begin = out_begin; pl.P.out_end = out_end;
     // Byte-range call (multi-GPU shard): find the bases this range touches and decode only the zstd blocks behind them.
-    ZRange rgs, rgq; ZRange *prs = nullptr, *prq = nullptr;
     u64 rec0 = 0, rec1 = pl.P.N ? pl.P.N - 1 : 0;                                        // records the byte range touches
     if (!whole && pl.P.mode != -1) {
         u64 *d_g = arena_new<u64>(c, 4); if (!d_g) return NAF_GPU_ENOMEM;
@@ -934,8 +1003,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     // Whole FASTA text of a 4-bit archive: decode and emit in one kernel when the frame is literal-only.
     // (Measured slower than decode + emit on MI355X for now: its per-lane 16-byte text stores are partial-line
     // writes from 600 k streams; kept behind NAF_GPU_FUSE=1 and under test until the text is staged through LDS.)
-    const char *fuse = getenv("NAF_GPU_FUSE");
-    if (whole && pl.P.mode == EM_FASTA && pl.fourbit && (pl.P.L == 0 || pl.P.L >= 16) && !pl.P.force_slow && fuse && fuse[0] == '1') {
+    if (whole && pl.P.mode == EM_FASTA && pl.fourbit && (pl.P.L == 0 || pl.P.L >= 16) && !pl.P.force_slow && fuse_on) {
         size_t n2 = 0;
         rc = zstd_decode_fused_fasta(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, &n2, &pl.P, d_out);
         if (rc == 0) {
@@ -944,38 +1012,10 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         }
         if (rc != -100) return rc;
     }
-    // sequence payload (the dominant zstd stream)
-    u64 seq_need = prs ? (rgs.want_hi - rgs.want_lo) + 2 * 131072 + 64 : pl.seq_bytes + 64;
-    if (seq_need > pl.seq_bytes + 64) seq_need = pl.seq_bytes + 64;
-    u8 *seq = (u8 *)arena_alloc(c, seq_need);
-    if (!seq) return NAF_GPU_ENOMEM;
-    size_t n = 0;
-    rc = zstd_decode_range(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, seq, prs ? seq_need : pl.seq_bytes, &n, prs);
-    if (rc == NAF_GPU_ECAP && prs) {                                                 // dependent blocks: needs the whole stream
-        seq = (u8 *)arena_alloc(c, pl.seq_bytes + 64); if (!seq) return NAF_GPU_ENOMEM;
-        rc = zstd_decode(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, seq, pl.seq_bytes, &n); prs = nullptr;
-    }
-    if (rc == NAF_GPU_ECAP || (rc == 0 && n != pl.seq_bytes)) return ctx_fail(c, NAF_GPU_EFORMAT, "can't decompress sequence\n");
-    if (rc) return rc;
+    if (!payload_done && (rc = payload())) return rc;
     if (pl.P.mode == -1) {                                                             // --4bit: the stream itself
         HIP_TRY(c, hipMemcpyAsync(d_out, seq + out_begin, out_end - out_begin, hipMemcpyDeviceToDevice, c->stream));
         return 0;
-    }
-    pl.P.seq = (prs && prs->ranged) ? seq - prs->got_lo : seq;
-    if (pl.need_qual) {
-        u64 qn = h.orig_size[S_QUAL];
-        u64 q_need = prq ? (rgq.want_hi - rgq.want_lo) + 2 * 131072 + 64 : qn + 64;
-        if (q_need > qn + 64) q_need = qn + 64;
-        u8 *q = (u8 *)arena_alloc(c, q_need); if (!q) return NAF_GPU_ENOMEM;
-        size_t qgot = 0;
-        rc = zstd_decode_range(c, d_naf + h.payload_off[S_QUAL], h.comp_size[S_QUAL], 0, q, prq ? q_need : qn, &qgot, prq);
-        if (rc == NAF_GPU_ECAP && prq) {
-            q = (u8 *)arena_alloc(c, qn + 64); if (!q) return NAF_GPU_ENOMEM;
-            rc = zstd_decode(c, d_naf + h.payload_off[S_QUAL], h.comp_size[S_QUAL], 0, q, qn, &qgot); prq = nullptr;
-        }
-        if (rc == NAF_GPU_ECAP || (rc == 0 && qgot != qn)) return ctx_fail(c, NAF_GPU_EFORMAT, "can't decompress quality\n");
-        if (rc) return rc;
-        pl.P.qual = (prq && prq->ranged) ? q - prq->got_lo : q;
     }
     pl.P.out_begin = out_begin; pl.P.out_end = out_end;
     // short records (FASTQ reads, contigs, proteins): segment-composing kernel; long records: streaming kernel

@@ -49,6 +49,13 @@ extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
     if (hipHostMalloc((void **)&c->h_stage, c->h_stage_cap, hipHostMallocDefault) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return NAF_GPU_ENOMEM; }
     int rc = zstd_init_tables(c);
     if (rc) { naf_gpu_shutdown(c); return rc; }
+    // side context: shares the device and the constant tables
+    naf_gpu_ctx *sc = new naf_gpu_ctx();
+    sc->device = device; sc->d_predef = c->d_predef; sc->h_stage_cap = 1 << 16;
+    if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess || hipHostMalloc((void **)&sc->h_stage, sc->h_stage_cap, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess) { delete sc; naf_gpu_shutdown(c); return NAF_GPU_EHIP; }
+    sc->own_stream = true;
+    c->side = sc;
     *out = c;
     return NAF_GPU_OK;
 }
@@ -58,6 +65,16 @@ extern "C" void naf_gpu_shutdown(naf_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    if (c->side) {
+        naf_gpu_ctx *sc = c->side;
+        hipStreamSynchronize(sc->stream);
+        for (auto &ch : sc->chunks) hipFree(ch.base);
+        for (auto e : sc->ev_pool) hipEventDestroy(e);
+        if (sc->h_stage) hipHostFree(sc->h_stage);
+        if (sc->own_stream) hipStreamDestroy(sc->stream);
+        delete sc;
+    }
+    if (c->fork_ev) hipEventDestroy(c->fork_ev);
     for (auto &ch : c->chunks) hipFree(ch.base);
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->d_predef) hipFree(c->d_predef);
@@ -156,6 +173,7 @@ extern "C" int naf_gpu_set_timing(naf_gpu_ctx *c, int enable)
 {
     if (!c) return NAF_GPU_EARG;
     c->timing = enable != 0; c->ktimes.clear(); c->ev_used = 0;
+    if (c->side) { c->side->timing = c->timing; c->side->ktimes.clear(); c->side->ev_used = 0; }
     return 0;
 }
 
@@ -183,13 +201,18 @@ extern "C" int naf_gpu_get_timing(naf_gpu_ctx *c, const char **names, float *ms,
 {
     if (!c) return NAF_GPU_EARG;
     hipStreamSynchronize(c->stream);
+    if (c->side) hipStreamSynchronize(c->side->stream);
     std::map<std::string, std::pair<float, int>> agg;
     std::vector<std::string> order;
-    for (auto &k : c->ktimes) {
-        float t = 0; hipEventElapsedTime(&t, k.a, k.b);
-        auto it = agg.find(k.name);
-        if (it == agg.end()) { agg[k.name] = { t, 1 }; order.push_back(k.name); }
-        else { it->second.first += t; it->second.second++; }
+    for (naf_gpu_ctx *x : { c, c->side }) {
+        if (!x) continue;
+        for (auto &k : x->ktimes) {
+            float t = 0; hipEventElapsedTime(&t, k.a, k.b);
+            auto it = agg.find(k.name);
+            if (it == agg.end()) { agg[k.name] = { t, 1 }; order.push_back(k.name); }
+            else { it->second.first += t; it->second.second++; }
+        }
+        x->ktimes.clear(); x->ev_used = 0;
     }
     c->agg_names = order; c->agg_ms.clear(); c->agg_n.clear();
     for (auto &n : order) { c->agg_ms.push_back(agg[n].first); c->agg_n.push_back(agg[n].second); }

@@ -28,13 +28,24 @@ struct ZStat {                 // device-side counters read back by the host
 static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
 static __device__ __forceinline__ u64 shfl_u64(u64 v, int l) { u32 lo = __shfl((u32)v, l, 64), hi = __shfl((u32)(v >> 32), l, 64); return ((u64)hi << 32) | lo; }
 
-__global__ void k_scan_blocks(const u8 *src, u64 len, u64 first_off, ZBlock *blk, u32 cap, ZStat *st)
+#define SCAN_LDS_MAX (60u * 1024u)
+__global__ __launch_bounds__(64) void k_scan_blocks(const u8 *src, u64 len, u64 first_off, ZBlock *blk, u32 cap, ZStat *st)
 {
+    // small frames (side streams: many tiny blocks) are walked out of LDS: the header chain is one dependent load per block
+    __shared__ __attribute__((aligned(16))) u8 buf[SCAN_LDS_MAX + 16];
+    const bool in_lds = len <= SCAN_LDS_MAX;
+    if (in_lds) {
+        for (u32 i = threadIdx.x * 16; i < (u32)len; i += 64 * 16) {
+            if (i + 16 <= len) { uint4 v; memcpy(&v, src + i, 16); *(uint4 *)(buf + i) = v; }
+            else for (u32 k = i; k < (u32)len; k++) buf[k] = src[k];
+        }
+    }
+    __syncthreads();
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     u64 pos = first_off; u32 n = 0, err = 0;
     for (;;) {
         if (pos + 3 > len) { err = ZE_TRUNC; break; }
-        u32 h = ld24(src + pos);
+        u32 h = in_lds ? ((u32)buf[pos] | ((u32)buf[pos + 1] << 8) | ((u32)buf[pos + 2] << 16)) : ld24(src + pos);
         u32 last = h & 1, type = (h >> 1) & 3, size = h >> 3;
         if (type == 3 || size > ZBLOCK_MAX) { err = ZE_CORRUPT; break; }
         u32 csize = type == BT_RLE ? 1 : size;
@@ -92,15 +103,20 @@ __device__ __forceinline__ u64 spec_land(const u8 *src, u64 len, u64 pos, u64 st
     return pos;
 }
 
-__global__ __launch_bounds__(256) void k_spec_find(const u8 *src, u64 len, u32 nchunks, u64 *first)
+// Candidates are searched in window bytes [w_lo, w_hi) of every chunk.  Two passes: the first 40 KiB (where the
+// first block start of a chunk lies whenever blocks compress to under 40 KiB -- this build's 32 KiB blocks, and
+// 128 KiB blocks at ratios above 3.2), then the rest of the 128 KiB window for the chunks still without a candidate.
+#define SPEC_WINDOW1 (40u * 1024u)
+__global__ __launch_bounds__(256) void k_spec_find(const u8 *src, u64 len, u32 nchunks, u64 *first, u32 w_lo, u32 w_hi)
 {
-    const u32 tiles = (SPEC_WINDOW + 4095) / 4096;
+    const u32 tiles = (w_hi - w_lo + 4095) / 4096;
     u32 c = blockIdx.x / tiles + 1;                          // chunk 0 starts at the known first block
     if (c >= nchunks) return;
+    if (w_lo && first[c] != SPEC_NONE) return;               // second pass: only chunks the first pass left empty
     u64 base = (u64)c * SPEC_CHUNK;
-    u32 k0 = ((blockIdx.x % tiles) * 256 + threadIdx.x) * 16;
-    if (k0 >= SPEC_WINDOW || base + k0 + 24 > len) {
-        if (k0 >= SPEC_WINDOW || base + k0 + 3 > len) return;
+    u32 k0 = w_lo + ((blockIdx.x % tiles) * 256 + threadIdx.x) * 16;
+    if (k0 >= w_hi || base + k0 + 24 > len) {
+        if (k0 >= w_hi || base + k0 + 3 > len) return;
     }
     // 16 candidate positions from 18 bytes held in registers
     u64 w0 = 0, w1 = 0, w2 = 0;
@@ -108,7 +124,7 @@ __global__ __launch_bounds__(256) void k_spec_find(const u8 *src, u64 len, u32 n
     else { u8 t[24]; for (int i = 0; i < 24; i++) t[i] = base + k0 + i < len ? src[base + k0 + i] : 0xFF; w0 = ld64(t); w1 = ld64(t + 8); w2 = ld64(t + 16); }
 #pragma unroll
     for (u32 k = 0; k < 16; k++) {
-        if (k0 + k >= SPEC_WINDOW) break;
+        if (k0 + k >= w_hi) break;
         u32 sh = 8 * (k & 7);
         u64 lo = k < 8 ? w0 : w1, hi = k < 8 ? w1 : w2;
         u32 h = (u32)((sh ? (lo >> sh) | (hi << (64 - sh)) : lo) & 0xFFFFFF), adv;
@@ -153,6 +169,17 @@ __global__ void k_spec_resolve(const u8 *src, u64 len, const u64 *land, const u6
     for (u32 base = 0; base < nchunks; base += 64) {
         u32 c = base + lane;
         u64 lc = c < nchunks ? land[c] : SPEC_NONE, gc = c < nchunks ? G[c] : SPEC_NONE;
+        // whole batch at once when the speculation holds: t is the speculated start of the batch's first chunk and every
+        // chunk's landing is the speculated start of the next one -- then (induction) all of them are the true starts
+        if (base + 64 < nchunks) {
+            u64 ln = land[c + 1];
+            bool ok = lc < SPEC_END && gc < SPEC_END && gc == ln;
+            if (shfl_u64(lc, 0) == t && __all(ok)) {
+                start[c + 1] = gc;
+                t = shfl_u64(gc, 63);
+                continue;
+            }
+        }
         for (int j = 0; j < 64 && base + j < nchunks; j++) {
             u64 lj = shfl_u64(lc, j), gj = shfl_u64(gc, j);
             u64 nxt;
@@ -816,8 +843,9 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         HIP_TRY(c, hipMemsetAsync(first, 0xFF, (size_t)nchunks * 8, c->stream));
         u64 *h0 = (u64 *)c->h_stage; *h0 = fh.hdr_size;
         HIP_TRY(c, hipMemcpyAsync(first, h0, 8, hipMemcpyHostToDevice, c->stream));
-        u32 grid = cdiv(SPEC_WINDOW, 256 * 16) * (nchunks - 1), gl = cdiv(nchunks, 64);
-        LAUNCH(c, "zstd_index_find", k_spec_find, grid, 256, 0, d_src, (u64)src_len, nchunks, first);
+        u32 gl = cdiv(nchunks, 64);
+        LAUNCH(c, "zstd_index_find", k_spec_find, cdiv(SPEC_WINDOW1, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, 0u, SPEC_WINDOW1);
+        LAUNCH(c, "zstd_index_find2", k_spec_find, cdiv(SPEC_WINDOW - SPEC_WINDOW1, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, SPEC_WINDOW1, SPEC_WINDOW);
         LAUNCH(c, "zstd_index_land", k_spec_land, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, nchunks, land);
         LAUNCH(c, "zstd_index_land2", k_spec_land2, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, (const u64 *)land, nchunks, G);
         LAUNCH(c, "zstd_index_resolve", k_spec_resolve, 1, 64, 0, d_src, (u64)src_len, (const u64 *)land, (const u64 *)G, nchunks, start, st);
@@ -837,7 +865,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         }
     }
     if (!indexed) {
-        u32 cap = (u32)(src_len / 2048 + 1024);
+        u32 cap = (u32)(src_len / 16 + 1024);                         // one pass for anything but pathological runs of empty blocks
         for (int attempt = 0; attempt < 2; attempt++) {
             blk = arena_new<ZBlock>(c, cap);
             if (!blk) return NAF_GPU_ENOMEM;
