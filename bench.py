@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(text_dev, size_bytes):
+def cpu_baseline(text_dev, size_bytes, ctx=None):
     """Reference unnaf/ennaf (oracle/_ref, built from the reference sources) on this box's host cores,
     one thread (the reference is single-threaded), on a bounded sample of the same workload."""
     import numpy as np
@@ -48,9 +48,25 @@ def cpu_baseline(text_dev, size_bytes):
         subprocess.check_call([ref_u, os.path.join(shm, "s.naf"), "-o", os.path.join(shm, "s.out")])
         t_u = time.perf_counter() - t0
         same = subprocess.call(["cmp", "-s", os.path.join(shm, "s.fa"), os.path.join(shm, "s.out")]) == 0
-        return {"value": round(cut / t_u / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "reference",
-                "sample": "reference unnaf (oracle/_ref, libzstd 1.4.9) on the first %.2f GB of the same FASTA, tmpfs, 1 thread" % (cut / 1e9),
-                "ennaf_value": round(cut / t_e / 1e9, 4), "roundtrip_ok": bool(same)}
+        out = {"value": round(cut / t_u / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "reference",
+               "sample": "reference unnaf (oracle/_ref, libzstd 1.4.9) on the first %.2f GB of the same FASTA, tmpfs, 1 thread" % (cut / 1e9),
+               "ennaf_value": round(cut / t_e / 1e9, 4), "roundtrip_ok": bool(same)}
+        if ctx is not None:
+            # the GPU decoder on the archive the REFERENCE ennaf made of that sample (128 KiB dependent blocks)
+            import torch
+            from naf_amd import capi
+            ref_naf = torch.from_numpy(np.fromfile(os.path.join(shm, "s.naf"), dtype=np.uint8)).to(text_dev.device)
+            buf = torch.empty(cut + 64, dtype=torch.uint8, device=text_dev.device)
+            r = ctx.unnaf(ref_naf, capi.OUT_FASTA, out=buf)
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(r, sample[:cut]))
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ctx.unnaf(ref_naf, capi.OUT_FASTA, out=buf)
+            torch.cuda.synchronize()
+            out["gpu_unnaf_of_reference_archive"] = {"value": round(cut * 3 / (time.perf_counter() - t0) / 1e9, 2), "unit": "GB/s",
+                                                      "archive_bytes": int(ref_naf.numel()), "text_bytes": int(cut), "bit_exact": ok}
+        return out
     finally:
         subprocess.call(["rm", "-rf", shm])
 
@@ -158,7 +174,7 @@ def main():
 
     cb = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cb = cpu_baseline(text, int(min(args.cpu_sample, n_text)))
+        cb = cpu_baseline(text, int(min(args.cpu_sample, n_text)), ctx)
     if rank == 0:
         line = {
             "metric": "unnaf GB/s (uncompressed bases out) on synthetic FASTA", "value": round(value, 3), "unit": "GB/s",

@@ -72,6 +72,7 @@ int  naf_gpu_host_alloc(naf_gpu_ctx *ctx, size_t bytes, void **h_pinned);
 int  naf_gpu_host_free(naf_gpu_ctx *ctx, void *h_pinned);
 int  naf_gpu_upload(naf_gpu_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);     /* async on the stream */
 int  naf_gpu_download(naf_gpu_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* returns after completion */
+int  naf_gpu_download_async(naf_gpu_ctx *ctx, void *h_pinned_dst, const void *d_src, size_t bytes);   /* async on the stream; pair with naf_gpu_synchronize */
 
 /* ---- zstd ----------------------------------------------------------------------------------------- */
 /* Decode one or more concatenated zstd frames (RFC 8878, no dictionaries) resident in HBM.

@@ -168,6 +168,13 @@ extern "C" int naf_gpu_download(naf_gpu_ctx *c, void *h, const void *d, size_t n
     return 0;
 }
 
+extern "C" int naf_gpu_download_async(naf_gpu_ctx *c, void *h, const void *d, size_t n)
+{
+    if (!c) return NAF_GPU_EARG;
+    if (n) HIP_TRY(c, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
 // ---- timing -------------------------------------------------------------------------------------------------
 extern "C" int naf_gpu_set_timing(naf_gpu_ctx *c, int enable)
 {

@@ -128,8 +128,12 @@ int main(int argc, char **argv)
     }
     FILE *IN = in_file_path ? fopen(in_file_path, "rb") : stdin;
     if (!IN) die("can't open input file\n");
-    size_t n = 0; unsigned char *text = read_all(IN, &n);
+    phase("start");
+    size_t n = 0; unsigned char *text = NULL;
+    void *d_text = read_to_device(IN, &n);                 /* regular file: straight to HBM through the pinned ring */
+    if (!d_text) text = read_all(IN, &n);
     if (IN != stdin) fclose(IN);
+    phase("read + upload");
 
     char *auto_path = NULL;
     if (!force_stdout && !out_file_path && isatty(fileno(stdout))) {
@@ -137,20 +141,21 @@ int main(int argc, char **argv)
         size_t len = strlen(in_file_path) + 5; auto_path = (char *)malloc(len); snprintf(auto_path, len, "%s.naf", in_file_path); out_file_path = auto_path;
     }
     gpu_open();
-    void *d_text, *d_naf; size_t cap = naf_gpu_ennaf_bound(n), naf_len = 0;
-    GPU_TRY(naf_gpu_malloc(gpu, n + 64, &d_text)); GPU_TRY(naf_gpu_malloc(gpu, cap, &d_naf));
-    GPU_TRY(naf_gpu_upload(gpu, d_text, text, n));
+    void *d_naf; size_t cap = naf_gpu_ennaf_bound(n), naf_len = 0;
+    if (!d_text) { GPU_TRY(naf_gpu_malloc(gpu, n + 64, &d_text)); GPU_TRY(naf_gpu_upload(gpu, d_text, text, n)); }
+    GPU_TRY(naf_gpu_malloc(gpu, cap, &d_naf));
     naf_gpu_ennaf_opts o = { fmt_cmd, seq_type, no_mask, strict, level, line_length_is_specified ? requested_line_length : -1, title };
     static naf_gpu_ennaf_report R;
+    phase("allocation");
     GPU_TRY(naf_gpu_ennaf(gpu, d_text, n, &o, d_naf, cap, &naf_len, &R));
+    phase("ennaf on the GPU");
     if (R.format && fmt_ext != NAF_FMT_AUTO && fmt_ext != R.format) warn("input file extension does not match its actual format\n");
     if (fmt_ext != NAF_FMT_AUTO && fmt_cmd != NAF_FMT_AUTO && fmt_ext != fmt_cmd) warn("input file extension does not match format specified in the command line\n");
-    unsigned char *out = (unsigned char *)malloc(naf_len ? naf_len : 1);
-    GPU_TRY(naf_gpu_download(gpu, out, d_naf, naf_len));
     FILE *OUT = stdout;
     if (out_file_path && !force_stdout) { OUT = fopen(out_file_path, "wb"); if (!OUT) die("can't create output file\n"); created_output_file = true; }
     if (verbose) msg("Output line length: %llu\n", line_length_is_specified ? (unsigned long long)requested_line_length : (unsigned long long)R.longest_line);
-    if (fwrite(out, 1, naf_len, OUT) != naf_len) die("can't write to file - disk full?\n");
+    write_from_device(OUT, d_naf, naf_len);
+    phase("download + write");
     if (OUT != stdout) { if (fclose(OUT) != 0) die("can't close file - disk full?\n"); } else fflush(stdout);
     if (!well_formed) {
         static const char *tn[4] = { "DNA", "RNA", "protein", "text" };

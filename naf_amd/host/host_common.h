@@ -29,18 +29,78 @@ __attribute__((noreturn)) static void die(const char *format, ...)
     exit(1);
 }
 
+/* NAF_GPU_CLI_TIMING=1: wall-clock of the host phases on stderr (development aid; off by default so stderr matches the reference) */
+#include <time.h>
+static void phase(const char *what)
+{
+    static int on = -1; static double t_last = 0;
+    if (on < 0) { const char *e = getenv("NAF_GPU_CLI_TIMING"); on = e && e[0] == '1'; }
+    if (!on) return;
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    double t = ts.tv_sec + ts.tv_nsec * 1e-9;
+    if (t_last != 0) fprintf(stderr, "[timing] %-28s %8.1f ms\n", what, (t - t_last) * 1e3);
+    t_last = t;
+}
+
 static naf_gpu_ctx *gpu = NULL;
 static void gpu_open(void)
 {
     if (gpu) return;
+    phase("before GPU init");
     const char *dev = getenv("NAF_GPU_DEVICE");
     int rc = naf_gpu_init(dev ? atoi(dev) : 0, &gpu);
     if (rc) die("can't initialize the GPU path: %s\n", naf_gpu_strerror(rc));
+    phase("GPU init");
 }
 #define GPU_TRY(call) do { int rc_ = (call); if (rc_) { const char *m_ = naf_gpu_last_error(gpu); size_t l_ = strlen(m_); \
     die("%s%s", m_, (l_ && m_[l_ - 1] == '\n') ? "" : "\n"); } } while (0)
 
-/* Whole input into pinned host memory (file or stdin). */
+/* ---- file <-> device through two pinned chunks: the PCIe copy of one chunk overlaps the file I/O of the next ---- */
+#define IO_CHUNK ((size_t)64 << 20)
+static void *io_pin[2] = { NULL, NULL };
+static void io_open(void)
+{
+    gpu_open();
+    if (!io_pin[0]) { GPU_TRY(naf_gpu_host_alloc(gpu, IO_CHUNK, &io_pin[0])); GPU_TRY(naf_gpu_host_alloc(gpu, IO_CHUNK, &io_pin[1])); }
+}
+static void write_from_device(FILE *f, const void *d, size_t n)
+{
+    if (!n) return;
+    io_open();
+    size_t off = 0; int cur = 0;
+    GPU_TRY(naf_gpu_download_async(gpu, io_pin[0], d, n < IO_CHUNK ? n : IO_CHUNK));
+    while (off < n) {
+        size_t len = n - off < IO_CHUNK ? n - off : IO_CHUNK, nxt = off + len, nlen = n - nxt < IO_CHUNK ? n - nxt : IO_CHUNK;
+        GPU_TRY(naf_gpu_synchronize(gpu));                                   /* chunk `cur` has arrived */
+        if (nlen) GPU_TRY(naf_gpu_download_async(gpu, io_pin[cur ^ 1], (const char *)d + nxt, nlen));
+        if (fwrite(io_pin[cur], 1, len, f) != len) die("can't write to file - disk full?\n");
+        off = nxt; cur ^= 1;
+    }
+}
+/* Regular file of known size straight into device memory; returns NULL when the size is not known up front (pipes). */
+static void *read_to_device(FILE *f, size_t *len)
+{
+    if (f == stdin || fseek(f, 0, SEEK_END) != 0) return NULL;
+    long sz = ftell(f); rewind(f);
+    if (sz <= 0) return NULL;
+    io_open();
+    void *d; GPU_TRY(naf_gpu_malloc(gpu, (size_t)sz + 64, &d));
+    size_t n = 0; int cur = 0;
+    for (;;) {
+        size_t want = (size_t)sz - n < IO_CHUNK ? (size_t)sz - n : IO_CHUNK;
+        if (!want) break;
+        GPU_TRY(naf_gpu_synchronize(gpu));                                   /* the upload that last used this chunk is done */
+        size_t r = fread(io_pin[cur], 1, want, f);
+        if (!r) break;
+        GPU_TRY(naf_gpu_upload(gpu, (char *)d + n, io_pin[cur], r));
+        n += r; cur ^= 1;
+    }
+    GPU_TRY(naf_gpu_synchronize(gpu));
+    *len = n;
+    return d;
+}
+
+/* Whole input into host memory (file or stdin). */
 static unsigned char *read_all(FILE *f, size_t *len)
 {
     size_t cap = 1 << 20, n = 0;

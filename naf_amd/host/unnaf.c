@@ -83,7 +83,7 @@ static void parse_command_line(int argc, char **argv)
 
 static const unsigned char *naf; static size_t naf_len; static naf_gpu_header H; static void *d_naf = NULL;
 
-static void upload(void) { gpu_open(); if (d_naf) return; GPU_TRY(naf_gpu_malloc(gpu, naf_len + 64, &d_naf)); GPU_TRY(naf_gpu_upload(gpu, d_naf, naf, naf_len)); }
+static void upload(void) { gpu_open(); if (d_naf) return; GPU_TRY(naf_gpu_malloc(gpu, naf_len + 64, &d_naf)); GPU_TRY(naf_gpu_upload(gpu, d_naf, naf, naf_len)); GPU_TRY(naf_gpu_synchronize(gpu)); phase("archive upload"); }
 
 static unsigned char *load_section(int i, const char *what)
 {
@@ -107,7 +107,10 @@ static void run_text(int mode, int masking_allowed)
     size_t n = 0; GPU_TRY(naf_gpu_unnaf_size(gpu, d_naf, naf_len, &o, &n));
     if (!n) return;
     void *d; GPU_TRY(naf_gpu_malloc(gpu, n + 64, &d));
+    phase("size + output allocation");
     size_t got = 0; GPU_TRY(naf_gpu_unnaf(gpu, d_naf, naf_len, &o, d, n, &got));
+    GPU_TRY(naf_gpu_synchronize(gpu)); phase("unnaf on the GPU");
+    if (mode != -2) { write_from_device(OUT, d, got); phase("download + write"); naf_gpu_free(gpu, d); return; }
     void *h; GPU_TRY(naf_gpu_host_alloc(gpu, got ? got : 1, &h));
     GPU_TRY(naf_gpu_download(gpu, h, d, got));
     if (mode == -2) {                                   /* --charcount (output.c:515-605) */
@@ -128,7 +131,9 @@ int main(int argc, char **argv)
     if (in_file_path == NULL && isatty(fileno(stdin))) { err("no input specified, use \"unnaf -h\" for help\n"); exit(0); }
     FILE *IN = in_file_path ? fopen(in_file_path, "rb") : stdin;
     if (!IN) die("can't open input file\n");
+    phase("start");
     naf = read_all(IN, &naf_len);
+    phase("read archive");
     if (IN != stdin) fclose(IN);
     char eb[128] = "";
     if (naf_gpu_parse_header_host(naf, naf_len, &H, eb)) die("%s", eb);
