@@ -150,10 +150,10 @@ def main():
     kt = {n: (ms, k) for n, ms, k in timing}
     packed = (rep.n_bases + 1) // 2
     # algorithmic bytes per launch of each candidate dominant kernel
-    alg = {"zstd_huf_literals": rep.section_comp[4] + packed, "unnaf_emit": packed + n_text}
+    alg = {"zstd_huf_literals": rep.section_comp[4] + packed, "unnaf_emit": packed + n_text}          # DESIGN.md section 3
     dom = max(alg, key=lambda k: kt.get(k, (0, 1))[0])
-    # the same kernel is also launched for the few-KB side streams; their bytes and time are inside the sums,
-    # so bytes/time over the step equals the launch-weighted average
+    # launches for the side streams run on the side context's stream, concurrently, and are reported as "side:<name>";
+    # the names used here are the payload launches only (one k_huf_literals launch over the sequence stream per step)
     dom_ms = kt[dom][0]
     achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
     # HBM traffic of that kernel per step, from the committed PMC passes of this same workload (rocprofv3 --pmc

@@ -215,8 +215,10 @@ extern "C" int naf_gpu_get_timing(naf_gpu_ctx *c, const char **names, float *ms,
         if (!x) continue;
         for (auto &k : x->ktimes) {
             float t = 0; hipEventElapsedTime(&t, k.a, k.b);
-            auto it = agg.find(k.name);
-            if (it == agg.end()) { agg[k.name] = { t, 1 }; order.push_back(k.name); }
+            // launches of the side context run concurrently with the payload decode: listed under their own names
+            std::string nm = x == c ? std::string(k.name) : std::string("side:") + k.name;
+            auto it = agg.find(nm);
+            if (it == agg.end()) { agg[nm] = { t, 1 }; order.push_back(nm); }
             else { it->second.first += t; it->second.second++; }
         }
         x->ktimes.clear(); x->ev_used = 0;
