@@ -48,15 +48,35 @@ __device__ __forceinline__ Piece load_piece(const EncP &P, u64 base)
 __device__ __forceinline__ u32 piece_byte(const Piece &pc, u32 k) { return (u32)((k < 8 ? pc.w0 >> (8 * k) : pc.w1 >> (8 * (k - 8))) & 0xFF); }
 
 // Byte classes in LDS: one lookup per byte instead of range compares and a bitmap fetched from kernel arguments.
-enum { CL_EOL = 1, CL_SPACE = 2, CL_EXPECTED = 4, CL_UNEXP_TEXT = 8, CL_UNEXP_COMMENT = 16 };
+enum { CL_EOL = 1, CL_SPACE = 2, CL_EXPECTED = 4, CL_GT = 8, CL_UNEXP_TEXT = 16, CL_UNEXP_COMMENT = 32 };
 __device__ __forceinline__ void fill_classes(const EncP &P, u8 *cls)      // blockDim.x == 256
 {
     u32 c = threadIdx.x;
-    cls[c] = (u8)((c_eol(c) ? CL_EOL : 0) | (c_space(c) ? CL_SPACE : 0) | (c_expected(P, c) ? CL_EXPECTED : 0) |
+    cls[c] = (u8)((c_eol(c) ? CL_EOL : 0) | (c_space(c) ? CL_SPACE : 0) | (c_expected(P, c) ? CL_EXPECTED : 0) | (c == '>' ? CL_GT : 0) |
                   (c_unexp_text(c) ? CL_UNEXP_TEXT : 0) | (c_unexp_comment(c) ? CL_UNEXP_COMMENT : 0));
     __syncthreads();
 }
 
+// One bit per byte of the piece for each class (bit k = byte k).  With these a piece that lies inside sequence lines needs no
+// per-byte state machine: counts are popcounts, the last EOL / space a count-leading-zeros.
+struct PMask { u32 eol, sp, exp, gt; };
+template <bool NEED_EXP>
+__device__ __forceinline__ PMask piece_masks(const Piece &pc, const u8 *cls)
+{
+    PMask m; m.eol = m.sp = m.exp = m.gt = 0;
+#pragma unroll
+    for (u32 k = 0; k < ET_BYTES; k++) if (k < pc.cnt) {
+        u32 cl = cls[piece_byte(pc, k)];
+        m.eol |= (cl & 1u) << k; m.sp |= ((cl >> 1) & 1u) << k; m.gt |= ((cl >> 3) & 1u) << k;
+        if (NEED_EXP) m.exp |= ((cl >> 2) & 1u) << k;
+    }
+    return m;
+}
+__device__ __forceinline__ void last_eol_space_m(const PMask &m, u64 base, i64 &le, i64 &ls)
+{
+    le = m.eol ? (i64)(base + (31 - __clz((int)m.eol))) : -1;
+    ls = m.sp ? (i64)(base + (31 - __clz((int)m.sp))) : -1;
+}
 // Line starts: a non-EOL byte at i >= p0 whose predecessor is an EOL byte (or i == p0).
 __device__ __forceinline__ u32 count_line_starts(const EncP &P, u64 base, const Piece &pc)
 {
@@ -65,6 +85,16 @@ __device__ __forceinline__ u32 count_line_starts(const EncP &P, u64 base, const 
     for (u32 i = 0; i < ET_BYTES; i++) if (i < pc.cnt) { u32 c = piece_byte(pc, i); bool e = c_eol(c); if (!e && base + i >= P.p0 && (prev_eol || base + i == P.p0)) n++; prev_eol = e; }
     return n;
 }
+__device__ __forceinline__ u32 count_line_starts_m(const EncP &P, u64 base, const Piece &pc, const PMask &m)
+{
+    if (base + ET_BYTES <= P.p0) return 0;
+    if (base < P.p0) return count_line_starts(P, base, pc);               // the piece holding the first marker: byte-wise
+    u32 valid = pc.cnt >= 32 ? ~0u : ((1u << pc.cnt) - 1);
+    u32 prev = base == 0 ? 1u : (c_eol(P.text[base - 1]) ? 1u : 0u);
+    if (base == P.p0) prev = 1;
+    return __popc(~m.eol & ((m.eol << 1) | prev) & valid);
+}
+
 __device__ __forceinline__ void last_eol_space(const Piece &pc, u64 base, i64 &le, i64 &ls)
 {
     le = -1; ls = -1;
@@ -75,11 +105,14 @@ __device__ __forceinline__ void last_eol_space(const Piece &pc, u64 base, i64 &l
 __global__ __launch_bounds__(256) void k_enc_last(EncP P, i64 *tile_eol, i64 *tile_sp, u64 *tile_ls)
 {
     __shared__ u64 lds[4];
+    __shared__ u8 cls[256];
+    fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     i64 le = -1, ls = -1; u32 nls = 0;
     Piece pc = load_piece(P, base);
-    last_eol_space(pc, base, le, ls);
-    if (tile_ls && pc.cnt) nls = count_line_starts(P, base, pc);
+    PMask pm = piece_masks<false>(pc, cls);
+    last_eol_space_m(pm, base, le, ls);
+    if (tile_ls && pc.cnt) nls = count_line_starts_m(P, base, pc, pm);
     u64 t;
     wg_scan_inclusive<u64, OpMaxI64>((u64)le, &t, lds); i64 te = (i64)t;
     wg_scan_inclusive<u64, OpMaxI64>((u64)ls, &t, lds); i64 ts = (i64)t;
@@ -132,10 +165,10 @@ __device__ __forceinline__ void classify_range(const EncP &P, u64 pos, const Pie
 }
 
 // Running maxima and header flag at the first byte of this thread's 16-byte piece.
-__device__ __forceinline__ TileCtx thread_ctx(const EncP &P, const i64 *tile_eol, const i64 *tile_sp, u64 base, u64 *lds, const Piece &pc)
+__device__ __forceinline__ TileCtx thread_ctx(const EncP &P, const i64 *tile_eol, const i64 *tile_sp, u64 base, u64 *lds, const PMask &pm)
 {
     i64 le = -1, ls = -1;
-    last_eol_space(pc, base, le, ls);
+    last_eol_space_m(pm, base, le, ls);
     u64 t;
     i64 ie = (i64)wg_scan_inclusive<u64, OpMaxI64>((u64)le, &t, lds);
     i64 is = (i64)wg_scan_inclusive<u64, OpMaxI64>((u64)ls, &t, lds);
@@ -165,6 +198,12 @@ struct CountSink {
     __device__ void unexpected(int, u32) {}
 };
 
+// A full 16-byte piece that lies inside sequence lines: not in a header at its first byte, no header starting inside it.
+__device__ __forceinline__ bool seq_piece(const EncP &P, u64 base, const Piece &pc, const PMask &pm, const TileCtx &ctx)
+{
+    return pc.cnt == ET_BYTES && base >= P.p0 && !ctx.hdr && ((pm.eol << 1) & pm.gt & 0xFFFFu) == 0;
+}
+
 // ---- K2: per-tile stream byte counts -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, const i64 *tile_sp,
                                                     u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail)
@@ -174,18 +213,22 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
     fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
-    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pc);
+    PMask pm = piece_masks<false>(pc, cls);
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pm);
     CountSink S;
-    if (base <= P.n) {
+    if (seq_piece(P, base, pc, pm, ctx)) {
+        // a full piece inside sequence lines: every non-space byte is a base (process.c:387-412)
+        S.nseq = 16 - __popc(pm.sp); S.saw_eol = pm.eol != 0;
+        S.tail = pm.eol ? __popc(~pm.sp & 0xFFFFu & ~((2u << (31 - __clz((int)pm.eol))) - 1)) : S.nseq;
+    } else if (base <= P.n) {
         // the virtual end-of-input byte belongs to the thread whose piece contains position n
         bool eof_here = (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
         classify_range(P, base, pc, eof_here, ctx, S, cls);
     }
+    // four counts in one scan: 16-bit fields (a tile holds 4096 bytes, a byte adds at most 2 to a field)
     u64 tot;
-    wg_scan_inclusive<u64, OpAdd>((u64)S.nseq, &tot, lds); if (threadIdx.x == 0) t_seq[blockIdx.x] = tot;
-    wg_scan_inclusive<u64, OpAdd>((u64)S.nids, &tot, lds); if (threadIdx.x == 0) t_ids[blockIdx.x] = tot;
-    wg_scan_inclusive<u64, OpAdd>((u64)S.ncmt, &tot, lds); if (threadIdx.x == 0) t_cmt[blockIdx.x] = tot;
-    wg_scan_inclusive<u64, OpAdd>((u64)S.nrec, &tot, lds); if (threadIdx.x == 0) t_rec[blockIdx.x] = tot;
+    wg_scan_inclusive<u64, OpAdd>((u64)S.nseq | ((u64)S.nids << 16) | ((u64)S.ncmt << 32) | ((u64)S.nrec << 48), &tot, lds);
+    if (threadIdx.x == 0) { t_seq[blockIdx.x] = tot & 0xFFFF; t_ids[blockIdx.x] = (tot >> 16) & 0xFFFF; t_cmt[blockIdx.x] = (tot >> 32) & 0xFFFF; t_rec[blockIdx.x] = tot >> 48; }
     // tail of the tile: sequence bytes after the last EOL inside the tile (whole tile if it has none)
     // encoded per thread as (has_eol, tail); combine right-to-left: first thread from the end that saw an EOL stops the sum
     u64 key = ((u64)(S.saw_eol ? threadIdx.x + 1 : 0) << 32);
@@ -222,6 +265,17 @@ __device__ __forceinline__ void flush_tile(u8 *dst, const u8 *stage, u32 n)
     if (threadIdx.x < n - done) dst[done + threadIdx.x] = stage[done + threadIdx.x];
 }
 
+__device__ __forceinline__ u64 low_bytes(u32 n) { return n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1); }   // lowest n bytes set
+// first n (<= 16) bytes of {lo, hi} to LDS at any alignment (gfx950 handles unaligned ds accesses)
+__device__ __forceinline__ void lds_store_n(u8 *p, u64 lo, u64 hi, u32 n)
+{
+    if (n >= 16) { __builtin_memcpy(p, &lo, 8); __builtin_memcpy(p + 8, &hi, 8); return; }
+    if (n & 8) { __builtin_memcpy(p, &lo, 8); p += 8; lo = hi; }
+    if (n & 4) { u32 v = (u32)lo; __builtin_memcpy(p, &v, 4); p += 4; lo >>= 32; }
+    if (n & 2) { u16 v = (u16)lo; __builtin_memcpy(p, &v, 2); p += 2; lo >>= 16; }
+    if (n & 1) *p = (u8)lo;
+}
+
 struct WriteSink {
     const EncOut &O; u64 bseq, bids, bcmt, rec; u64 line_b; u64 best; bool line_valid; u8 *stage; u64 tbase;
     __device__ WriteSink(const EncOut &o) : O(o) {}
@@ -239,16 +293,20 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
     fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
-    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pc);
+    PMask pm = piece_masks<true>(pc, cls);
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pm);
     bool active = base <= P.n;
     bool eof_here = active && (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
+    // fast: inside sequence lines and nothing to replace (every non-space byte is an expected one)
+    const bool fast = seq_piece(P, base, pc, pm, ctx) && (~pm.sp & ~pm.exp & 0xFFFFu) == 0;
     CountSink C;
-    if (active) classify_range(P, base, pc, eof_here, ctx, C, cls);
-    u64 tot, tot0;
-    u64 iseq = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq, &tot0, lds);
-    u64 iids = wg_scan_inclusive<u64, OpAdd>((u64)C.nids, &tot, lds);
-    u64 icmt = wg_scan_inclusive<u64, OpAdd>((u64)C.ncmt, &tot, lds);
-    u64 irec = wg_scan_inclusive<u64, OpAdd>((u64)C.nrec, &tot, lds);
+    if (fast) {
+        C.nseq = 16 - __popc(pm.sp); C.saw_eol = pm.eol != 0;
+        C.tail = pm.eol ? __popc(~pm.sp & 0xFFFFu & ~((2u << (31 - __clz((int)pm.eol))) - 1)) : C.nseq;
+    } else if (active) classify_range(P, base, pc, eof_here, ctx, C, cls);
+    u64 tot, totp;
+    u64 ip = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq | ((u64)C.nids << 16) | ((u64)C.ncmt << 32) | ((u64)C.nrec << 48), &totp, lds);
+    u64 iseq = ip & 0xFFFF, iids = (ip >> 16) & 0xFFFF, icmt = (ip >> 32) & 0xFFFF, irec = ip >> 48, tot0 = totp & 0xFFFF;
     __shared__ __attribute__((aligned(8))) u8 stage[ET_TILE + 16];
     u32 tile_seq = (u32)tot0;
     WriteSink W(O); W.stage = stage; W.tbase = O.t_seq[blockIdx.x];
@@ -272,11 +330,29 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
         else { u64 tp = (u64)le / ET_TILE; W.line_b = O.t_seq[tp + 1] - (O.t_tail[tp] & 0x7FFFFFFFu); }
     }
     W.best = 0;
-    if (active) classify_range(P, base, pc, eof_here, ctx, W, cls);
+    if (fast) {
+        u32 e = pm.eol;
+        while (e) {                                               // line ends inside the piece (usually one or none)
+            u32 k = (u32)__ffs((int)e) - 1; e &= e - 1;
+            u64 b_here = W.bseq + __popc(~pm.sp & ((1u << k) - 1));
+            u64 len = b_here - W.line_b; if (len > W.best) W.best = len; W.line_b = b_here;
+        }
+        // drop the space-class bytes (highest first, so lower positions stay put), then store the bases with a few wide,
+        // possibly unaligned LDS stores: 16 one-byte stores at a 16-byte lane stride are an 8-way bank conflict each
+        u64 lo = pc.w0, hi = pc.w1; u32 d = pm.sp;
+        while (d) {
+            u32 k = 31 - __clz((int)d); d &= ~(1u << k);
+            u64 slo = (lo >> 8) | (hi << 56), shi = hi >> 8;
+            if (k < 8) { u64 m = low_bytes(k); lo = (lo & m) | (slo & ~m); hi = shi; }
+            else { u64 m = low_bytes(k - 8); hi = (hi & m) | (shi & ~m); }
+        }
+        lds_store_n(stage + (W.bseq - W.tbase), lo, hi, C.nseq);
+    } else if (active) classify_range(P, base, pc, eof_here, ctx, W, cls);
     __syncthreads();
     flush_tile(O.seq + W.tbase, stage, tile_seq);
     u64 best; wg_scan_inclusive<u64, OpMaxU64>(W.best, &best, lds);
-    if (threadIdx.x == 0 && best) atomicMax((unsigned long long *)O.longest, (unsigned long long)best);
+    // millions of workgroups, one address: look before touching it atomically
+    if (threadIdx.x == 0 && best > __atomic_load_n(O.longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)O.longest, (unsigned long long)best);
 }
 
 
@@ -368,9 +444,9 @@ struct FqWrite {
 };
 
 // ordinal of the line in progress at `base`: (#line starts before base) - 1
-__device__ __forceinline__ i64 thread_ord(const EncP &P, const u64 *t_ls, u64 base, u64 *lds, const Piece &pc)
+__device__ __forceinline__ i64 thread_ord(const EncP &P, const u64 *t_ls, u64 base, u64 *lds, const Piece &pc, const PMask &pm)
 {
-    u32 nls = pc.cnt ? count_line_starts(P, base, pc) : 0;
+    u32 nls = pc.cnt ? count_line_starts_m(P, base, pc, pm) : 0;
     u64 t; u64 incl = wg_scan_inclusive<u64, OpAdd>((u64)nls, &t, lds);
     return (i64)(t_ls[blockIdx.x] + incl - nls) - 1;
 }
@@ -383,8 +459,9 @@ __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol,
     fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
-    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pc);
-    ctx.ord = thread_ord(P, t_ls, base, lds, pc);
+    PMask pm = piece_masks<false>(pc, cls);
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pm);
+    ctx.ord = thread_ord(P, t_ls, base, lds, pc, pm);
     FqCount S;
     if (base <= P.n) classify_range_fastq(P, base, pc, (base + pc.cnt == P.n) && pc.cnt < ET_BYTES, ctx, S, cls);
     u64 tot;
@@ -401,8 +478,9 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
     fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
-    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pc);
-    ctx.ord = thread_ord(P, O.t_ls, base, lds, pc);
+    PMask pm = piece_masks<false>(pc, cls);
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pm);
+    ctx.ord = thread_ord(P, O.t_ls, base, lds, pc, pm);
     bool active = base <= P.n;
     bool eof_here = active && (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
     FqCount C;
@@ -429,7 +507,7 @@ __global__ void k_fq_check(const u64 *rec_begin, const u64 *rec_end, const u64 *
     if (r >= N) return;
     u64 len = rec_end[r] - rec_begin[r], ql = q_end[r] - q_begin[r];
     if (len != ql) atomicMin((unsigned long long *)first_error, (unsigned long long)(r * 4 + FQ_E_QLEN));
-    atomicMax((unsigned long long *)longest, (unsigned long long)len);
+    if (len > __atomic_load_n(longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)longest, (unsigned long long)len);
 }
 
 // ---- lengths: u32 units with 0xFFFFFFFF continuation (encoders.c:72-95) ----------------------------------------------------
