@@ -48,27 +48,28 @@ __device__ __forceinline__ Piece load_piece(const EncP &P, u64 base)
 __device__ __forceinline__ u32 piece_byte(const Piece &pc, u32 k) { return (u32)((k < 8 ? pc.w0 >> (8 * k) : pc.w1 >> (8 * (k - 8))) & 0xFF); }
 
 // Byte classes in LDS: one lookup per byte instead of range compares and a bitmap fetched from kernel arguments.
-enum { CL_EOL = 1, CL_SPACE = 2, CL_EXPECTED = 4, CL_GT = 8, CL_UNEXP_TEXT = 16, CL_UNEXP_COMMENT = 32 };
+enum { CL_EOL = 1, CL_SPACE = 2, CL_EXPECTED = 4, CL_GT = 8, CL_UNEXP_TEXT = 16, CL_UNEXP_COMMENT = 32, CL_QUAL = 64 };
 __device__ __forceinline__ void fill_classes(const EncP &P, u8 *cls)      // blockDim.x == 256
 {
     u32 c = threadIdx.x;
     cls[c] = (u8)((c_eol(c) ? CL_EOL : 0) | (c_space(c) ? CL_SPACE : 0) | (c_expected(P, c) ? CL_EXPECTED : 0) | (c == '>' ? CL_GT : 0) |
-                  (c_unexp_text(c) ? CL_UNEXP_TEXT : 0) | (c_unexp_comment(c) ? CL_UNEXP_COMMENT : 0));
+                  (c_unexp_text(c) ? CL_UNEXP_TEXT : 0) | (c_unexp_comment(c) ? CL_UNEXP_COMMENT : 0) | ((c >= 0x21 && c <= 0x7E) ? CL_QUAL : 0));
     __syncthreads();
 }
 
 // One bit per byte of the piece for each class (bit k = byte k).  With these a piece that lies inside sequence lines needs no
 // per-byte state machine: counts are popcounts, the last EOL / space a count-leading-zeros.
-struct PMask { u32 eol, sp, exp, gt; };
-template <bool NEED_EXP>
+struct PMask { u32 eol, sp, exp, gt, q; };
+template <bool NEED_EXP, bool NEED_Q = false>
 __device__ __forceinline__ PMask piece_masks(const Piece &pc, const u8 *cls)
 {
-    PMask m; m.eol = m.sp = m.exp = m.gt = 0;
+    PMask m; m.eol = m.sp = m.exp = m.gt = m.q = 0;
 #pragma unroll
     for (u32 k = 0; k < ET_BYTES; k++) if (k < pc.cnt) {
         u32 cl = cls[piece_byte(pc, k)];
         m.eol |= (cl & 1u) << k; m.sp |= ((cl >> 1) & 1u) << k; m.gt |= ((cl >> 3) & 1u) << k;
         if (NEED_EXP) m.exp |= ((cl >> 2) & 1u) << k;
+        if (NEED_Q) m.q |= ((cl >> 6) & 1u) << k;
     }
     return m;
 }
@@ -451,6 +452,18 @@ __device__ __forceinline__ i64 thread_ord(const EncP &P, const u64 *t_ls, u64 ba
     return (i64)(t_ls[blockIdx.x] + incl - nls) - 1;
 }
 
+// A full piece in the middle of a read's sequence line (returns 1) or quality line (3) with nothing to drop or replace; else 0.
+__device__ __forceinline__ int fq_piece(const EncP &P, u64 base, const Piece &pc, const PMask &pm, const TileCtx &ctx)
+{
+    if (pc.cnt != ET_BYTES || pm.eol || ctx.ord < 0) return 0;
+    i64 line_start = ctx.last_eol + 1; if ((u64)line_start < P.p0) line_start = (i64)P.p0;
+    if (line_start >= (i64)base) return 0;                     // the line's first byte has its own rules (process.c:522)
+    u32 type = (u32)ctx.ord & 3;
+    if (type == 1 && pm.sp == 0 && pm.exp == 0xFFFFu) return 1;
+    if (type == 3 && pm.q == 0xFFFFu) return 3;
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol, const i64 *tile_sp, const u64 *t_ls,
                                                      u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_qual)
 {
@@ -459,16 +472,16 @@ __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol,
     fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
-    PMask pm = piece_masks<false>(pc, cls);
+    PMask pm = piece_masks<true, true>(pc, cls);
     TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pm);
     ctx.ord = thread_ord(P, t_ls, base, lds, pc, pm);
     FqCount S;
-    if (base <= P.n) classify_range_fastq(P, base, pc, (base + pc.cnt == P.n) && pc.cnt < ET_BYTES, ctx, S, cls);
+    int fast = fq_piece(P, base, pc, pm, ctx);
+    if (fast == 1) S.nseq = 16; else if (fast == 3) S.nqual = 16;
+    else if (base <= P.n) classify_range_fastq(P, base, pc, (base + pc.cnt == P.n) && pc.cnt < ET_BYTES, ctx, S, cls);
     u64 tot;
-    wg_scan_inclusive<u64, OpAdd>((u64)S.nseq, &tot, lds); if (threadIdx.x == 0) t_seq[blockIdx.x] = tot;
-    wg_scan_inclusive<u64, OpAdd>((u64)S.nids, &tot, lds); if (threadIdx.x == 0) t_ids[blockIdx.x] = tot;
-    wg_scan_inclusive<u64, OpAdd>((u64)S.ncmt, &tot, lds); if (threadIdx.x == 0) t_cmt[blockIdx.x] = tot;
-    wg_scan_inclusive<u64, OpAdd>((u64)S.nqual, &tot, lds); if (threadIdx.x == 0) t_qual[blockIdx.x] = tot;
+    wg_scan_inclusive<u64, OpAdd>((u64)S.nseq | ((u64)S.nids << 16) | ((u64)S.ncmt << 32) | ((u64)S.nqual << 48), &tot, lds);
+    if (threadIdx.x == 0) { t_seq[blockIdx.x] = tot & 0xFFFF; t_ids[blockIdx.x] = (tot >> 16) & 0xFFFF; t_cmt[blockIdx.x] = (tot >> 32) & 0xFFFF; t_qual[blockIdx.x] = tot >> 48; }
 }
 
 __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, FqOut O)
@@ -478,23 +491,25 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
     fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
-    PMask pm = piece_masks<false>(pc, cls);
+    PMask pm = piece_masks<true, true>(pc, cls);
     TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pm);
     ctx.ord = thread_ord(P, O.t_ls, base, lds, pc, pm);
     bool active = base <= P.n;
     bool eof_here = active && (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
     FqCount C;
-    if (active) classify_range_fastq(P, base, pc, eof_here, ctx, C, cls);
-    u64 tot, tots, totq;
-    u64 iseq = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq, &tots, lds);
-    u64 iids = wg_scan_inclusive<u64, OpAdd>((u64)C.nids, &tot, lds);
-    u64 icmt = wg_scan_inclusive<u64, OpAdd>((u64)C.ncmt, &tot, lds);
-    u64 iq = wg_scan_inclusive<u64, OpAdd>((u64)C.nqual, &totq, lds);
+    const int fast = fq_piece(P, base, pc, pm, ctx);
+    if (fast == 1) C.nseq = 16; else if (fast == 3) C.nqual = 16;
+    else if (active) classify_range_fastq(P, base, pc, eof_here, ctx, C, cls);
+    u64 totp;
+    u64 ip = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq | ((u64)C.nids << 16) | ((u64)C.ncmt << 32) | ((u64)C.nqual << 48), &totp, lds);
+    u64 iseq = ip & 0xFFFF, iids = (ip >> 16) & 0xFFFF, icmt = (ip >> 32) & 0xFFFF, iq = ip >> 48, tots = totp & 0xFFFF, totq = totp >> 48;
     __shared__ __attribute__((aligned(8))) u8 sstage[ET_TILE + 16], qstage[ET_TILE + 16];
     FqWrite W(O); W.sstage = sstage; W.qstage = qstage; W.sbase = O.t_seq[blockIdx.x]; W.qbase = O.t_qual[blockIdx.x];
     W.bseq = O.t_seq[blockIdx.x] + iseq - C.nseq; W.bids = O.t_ids[blockIdx.x] + iids - C.nids;
     W.bcmt = O.t_cmt[blockIdx.x] + icmt - C.ncmt; W.bqual = O.t_qual[blockIdx.x] + iq - C.nqual;
-    if (active) classify_range_fastq(P, base, pc, eof_here, ctx, W, cls);
+    if (fast == 1) lds_store_n(sstage + (W.bseq - W.sbase), pc.w0, pc.w1, 16);
+    else if (fast == 3) lds_store_n(qstage + (W.bqual - W.qbase), pc.w0, pc.w1, 16);
+    else if (active) classify_range_fastq(P, base, pc, eof_here, ctx, W, cls);
     __syncthreads();
     flush_tile(O.seq + W.sbase, sstage, (u32)tots);
     flush_tile(O.qual + W.qbase, qstage, (u32)totq);
@@ -575,16 +590,13 @@ __global__ void k_mask_run_units(const u64 *bnd, u64 nb, u64 T, u64 *units)
     u64 s = r ? bnd[r - 1] : 0, e = r < nb ? bnd[r] : T;
     units[r] = (e - s) / 255 + 1;
 }
-__global__ void k_mask_units_write(const u64 *bnd, u64 nb, u64 T, const u64 *unit_off, u64 total_units, u8 *out)
+// every unit that is not the last of its run is 255: the array is pre-filled with 255 and one lane per run writes the remainder
+__global__ void k_mask_units_write(const u64 *bnd, u64 nb, u64 T, const u64 *unit_off, u8 *out)
 {
-    u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= total_units) return;
-    // run = last r with unit_off[r] <= u
-    u64 lo = 0, hi = nb + 1;
-    while (lo + 1 < hi) { u64 mid = (lo + hi) >> 1; if (unit_off[mid] <= u) lo = mid; else hi = mid; }
-    u64 r = lo, s = r ? bnd[r - 1] : 0, e = r < nb ? bnd[r] : T, len = e - s;
-    u64 k = u - unit_off[r], full = len / 255;
-    out[u] = k < full ? 255 : (u8)(len % 255);
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nb) return;
+    u64 s = r ? bnd[r - 1] : 0, e = r < nb ? bnd[r] : T, len = e - s;
+    out[unit_off[r] + len / 255] = (u8)(len % 255);
 }
 
 // ---- 4-bit pack (encoders.c:30-69, tables.c:189-197) ---------------------------------------------------------------------------
@@ -860,7 +872,8 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
             if ((rc = scan_exclusive_u64(c, ru, nb + 1, ru + nb + 2))) return rc;
             u64 nu = 0; if ((rc = ctx_readback(c, &nu, ru + nb + 2, 8))) return rc;
             s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "ennaf_mask_units", k_mask_units_write, cdiv(nu, 256), 256, 0, (const u64 *)bnd, nb, T, (const u64 *)ru, nu, s_mask);
+            HIP_TRY(c, hipMemsetAsync(s_mask, 0xFF, nu, c->stream));
+            LAUNCH(c, "ennaf_mask_units", k_mask_units_write, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, (const u64 *)ru, s_mask);
             n_mask = nu;
         }
         // sequence stream
