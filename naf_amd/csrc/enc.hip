@@ -694,13 +694,13 @@ static void set_expected(EncP &P, int seq_type, bool fasta)
 
 struct SecOut { u64 orig, comp; };
 
-static int put_section(naf_gpu_ctx *c, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so)
+static int put_section(naf_gpu_ctx *c, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz = 0)
 {
     size_t bound = naf_gpu_zstd_compress_bound(stream_len);
     u8 *tmp = (u8 *)arena_alloc(c, bound);
     if (!tmp) return NAF_GPU_ENOMEM;
     size_t clen = 0;
-    int rc = zstd_encode(c, d_stream, stream_len, level, tmp, bound, &clen, 0); if (rc) return rc;
+    int rc = zstd_encode(c, d_stream, stream_len, level, tmp, bound, &clen, 0, lz); if (rc) return rc;
     u8 hdr[20]; size_t hl = vle(orig, hdr); hl += vle(clen, hdr + hl);
     if (pos + hl + clen > cap) return ctx_fail(c, NAF_GPU_ECAP, "ennaf output capacity %zu too small", cap);
     HIP_TRY(c, hipMemcpyAsync(d_naf + pos, hdr, hl, hipMemcpyHostToDevice, c->stream));
@@ -904,9 +904,11 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     if (tl) { HIP_TRY(c, hipMemcpyAsync(d_naf + pos, o->title, tl, hipMemcpyHostToDevice, c->stream)); pos += tl; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     SecOut so[6]; memset(so, 0, sizeof so);
-    if ((rc = put_section(c, s_ids, n_ids, n_ids, o->level, d_naf, cap, pos, so[0]))) return rc;
-    if ((rc = put_section(c, s_cmt, n_cmt, n_cmt, o->level, d_naf, cap, pos, so[1]))) return rc;
-    if ((rc = put_section(c, (const u8 *)s_len, n_lenb, n_lenb, o->level, d_naf, cap, pos, so[2]))) return rc;
+    // ids, names and lengths are text-like / repetitive and small: always through the LZ stage (as reference level 1 does);
+    // mask, sequence and quality get it from level 2 up
+    if ((rc = put_section(c, s_ids, n_ids, n_ids, o->level, d_naf, cap, pos, so[0], 1))) return rc;
+    if ((rc = put_section(c, s_cmt, n_cmt, n_cmt, o->level, d_naf, cap, pos, so[1], 1))) return rc;
+    if ((rc = put_section(c, (const u8 *)s_len, n_lenb, n_lenb, o->level, d_naf, cap, pos, so[2], 1))) return rc;
     if (store_mask) { if ((rc = put_section(c, s_mask, n_mask, n_mask, o->level, d_naf, cap, pos, so[3]))) return rc; }
     if ((rc = put_section(c, s_seq, n_seqb, T, o->level, d_naf, cap, pos, so[4]))) return rc;      // ennaf.c:582: number of bases
     if (store_qual) { if ((rc = put_section(c, s_qual, n_qual, n_qual, o->level, d_naf, cap, pos, so[5]))) return rc; }

@@ -78,6 +78,7 @@ extern "C" void naf_gpu_shutdown(naf_gpu_ctx *c)
     for (auto &ch : c->chunks) hipFree(ch.base);
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->d_predef) hipFree(c->d_predef);
+    if (c->d_seqctab) hipFree(c->d_seqctab);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;

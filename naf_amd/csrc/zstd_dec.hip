@@ -561,9 +561,10 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
     u32 my_rounds = valid ? n / HUF_ROUND : 0xFFFFFFFFu;                 // wave-uniform round count
     for (int d = 32; d; d >>= 1) { u32 o = (u32)__shfl_xor((int)my_rounds, d, 64); my_rounds = o < my_rounds ? o : my_rounds; }
     u32 rounds = my_rounds == 0xFFFFFFFFu ? 0 : my_rounds;
+    if (ipitch & 0x8000u) { rounds = 0; ipitch &= 0x7FFFu; }     // NAF_GPU_HUF_GENERIC=1: every symbol through the generic reader (cross-check)
     // tables of more than 7 bits: 32 symbols can take 44 bytes, so the input ring is 4 sectors and a refill feeds 4 symbols
     const bool big = ipitch > HUF_IROW;
-    const u32 rmask = big ? 255u : 127u, rbytes = big ? 44u : 28u, guard = big ? 192u : 160u;
+    const u32 rmask = big ? 255u : 127u, guard = big ? 192u : 160u;
     __syncthreads();
     u32 R = 0;
     {
@@ -592,7 +593,10 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
                     *(u64 *)(irow + o + 48) = (u64)st3.x | ((u64)st3.y << 32); *(u64 *)(irow + o + 56) = (u64)st3.z | ((u64)st3.w << 32);
                     pending = false;
                 }
-                if (lo + 2 * rbytes + 8 > gp) {                           // the round after this one may read below `lo`
+                // request the sector below when the round after this one may read below `lo`.  The sector is committed at the next
+                // round start over the ring's top sector, which must be dead by then: gp < lo + 56 in the two-sector ring
+                // (reads reach (gp & ~7) + 15), whatever the stream's rate -- a 1-bit code moves gp by only 4 bytes a round
+                if (lo + (big ? 96u : 56u) > gp) {
                     const uint4 *g0 = (const uint4 *)(lo - 64);
                     st0 = g0[0]; st1 = g0[1]; st2 = g0[2]; st3 = g0[3]; pending = true;
                 }
@@ -962,10 +966,11 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         if (fuse && hs.max_huf_log > 7) return ZSTD_NEED_TWO_PASS;
         EmitP ep; memset(&ep, 0, sizeof ep); if (fuse) ep = *fuse;
         u32 ipitch = hs.max_huf_log > 7 ? HUF_IROW_BIG : HUF_IROW;
+        u32 ipitch_arg = ipitch | ((getenv("NAF_GPU_HUF_GENERIC") && getenv("NAF_GPU_HUF_GENERIC")[0] == '1') ? 0x8000u : 0u);
         if (b_count && fuse) LAUNCH(c, "zstd_huf_fused_emit", (k_huf_literals<true>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 512,
-               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch);
+               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg);
         else if (b_count) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512 + (getenv("NAF_GPU_PADLDS") ? atoi(getenv("NAF_GPU_PADLDS")) : 0),
-               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch);
+               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg);
     }
     if (b_count && !fuse) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
     if (n_seq_blk)

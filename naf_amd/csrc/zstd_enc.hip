@@ -23,13 +23,16 @@ struct ZPlanWS {
 // even split of n bytes into nblk blocks: block b starts at b*(n/nblk) + min(b, n%nblk)
 __host__ __device__ static inline u64 zenc_block_lo(u64 n, u32 nblk, u32 b) { u64 q = n / nblk, r = n % nblk; return (u64)b * q + (b < r ? b : r); }
 
-__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u32 *codes, u8 *trees, u64 *csize)
+// blk_len == nullptr: block b is the b-th piece of the even split of src[0..n).  Otherwise block b is src[b*slot .. b*slot + blk_len[b])
+// (the literals the LZ stage left of block b).
+__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u32 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot)
 {
     // ZENC_HCOPIES copies of the 4 quarter histograms (copy = lane % copies): few distinct symbols (packed ACGT has 16) would
     // otherwise serialise every LDS atomic of a wave on the same handful of addresses
     __shared__ u32 hist[ZENC_HCOPIES * 1024];
     u32 b = blockIdx.x;
     u64 lo = zenc_block_lo(n, nblk, b), hi = zenc_block_lo(n, nblk, b + 1);
+    if (blk_len) { lo = (u64)b * slot; hi = lo + blk_len[b]; }
     u32 bn = (u32)(hi - lo);
     for (u32 i = threadIdx.x; i < ZENC_HCOPIES * 1024; i += 256) hist[i] = 0;
     __syncthreads();
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
             if (tb) { zenc_plan_finish(p, bn, log, tb); huf = p.kind == ZK_HUF; }
         }
     }
-    if (threadIdx.x == 0) { plan[b] = p; csize[b] = p.csize; }
+    if (threadIdx.x == 0) { plan[b] = p; if (csize) csize[b] = p.csize; }
     if (huf) {
         // canonical codes (huf_assign_codes): symbols of one weight take consecutive cells in symbol order, so the code of a
         // symbol is its weight group's first cell >> (weight - 1) plus its rank inside the group
@@ -115,6 +118,108 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
         codes[(u64)b * 256 + sym] = l ? (((wstart[wgt] >> (wgt - 1)) + rank) | (l << 16)) : 0;
         if (sym < p.tree_bytes) trees[(u64)b * ZENC_TREE_SLOT + sym] = ws.tree[sym];
     }
+}
+
+// ======================= LZ stage (level >= 2; always for the id / name streams of an archive) ==============================
+// Matches are searched inside a block only and every offset is coded as a new offset, so blocks stay independent (any
+// block range can still be produced by any GPU).  One wavefront per block: 64 consecutive positions are tested per round
+// against a hash table of earlier positions (block and table in LDS), the first lane with a match of >= LZ_MINMATCH wins,
+// the literals before it and the (ll, ml, distance) triple are emitted, and the round restarts behind the match.
+#define LZ_MINMATCH 5
+#define LZ_HASH_LOG 12
+#define LZ_BLOCK_MAX 32768
+struct LzBufs {
+    u8 *lits; u64 slot;                 // literals of block b at lits + b*slot
+    u16 *ll, *ml, *of; u64 seq_slot;    // sequences of block b at [b*seq_slot ..)
+    u32 *nseq, *nlit;
+    u8 *seqbuf; u32 *seq_bytes;         // encoded Sequences_Section of block b at seqbuf + b*slot
+};
+__global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk, LzBufs B)
+{
+    __shared__ __attribute__((aligned(16))) u8 buf[LZ_BLOCK_MAX + 64];
+    __shared__ u16 tab[1 << LZ_HASH_LOG];
+    const u32 b = blockIdx.x, lane = threadIdx.x;
+    const u64 lo = zenc_block_lo(n, nblk, b);
+    const u32 bn = (u32)(zenc_block_lo(n, nblk, b + 1) - lo);
+    for (u32 i = lane * 16; i < bn; i += 64 * 16) {
+        if (i + 16 <= bn) { uint4 v; __builtin_memcpy(&v, src + lo + i, 16); *(uint4 *)(buf + i) = v; }
+        else for (u32 k = i; k < bn; k++) buf[k] = src[lo + k];
+    }
+    for (u32 i = lane; i < (1u << LZ_HASH_LOG); i += 64) tab[i] = 0;     // 0 = empty, else position + 1
+    for (u32 i = bn + lane; i < bn + 64 && i < LZ_BLOCK_MAX + 64; i += 64) buf[i] = 0;
+    __syncthreads();
+    u8 *lits = B.lits + (u64)b * B.slot;
+    u16 *sll = B.ll + (u64)b * B.seq_slot, *sml = B.ml + (u64)b * B.seq_slot, *sof = B.of + (u64)b * B.seq_slot;
+    u32 cur = 0, anchor = 0, ns = 0, nl = 0;
+    while (cur + LZ_MINMATCH <= bn) {
+        u32 p = cur + lane; bool valid = p + LZ_MINMATCH <= bn;
+        u32 v = 0, h = 0, c = 0, m = 0;
+        if (valid) {
+            __builtin_memcpy(&v, buf + p, 4);
+            h = (v * 2654435761u) >> (32 - LZ_HASH_LOG);
+            c = tab[h];                                              // positions of earlier rounds only (< cur)
+            if (c) {
+                u32 q = c - 1, cv; __builtin_memcpy(&cv, buf + q, 4);
+                if (cv == v) {
+                    m = 4;
+                    for (;;) {                                       // 4 bytes per step; buf is zero-padded behind bn
+                        u32 x, y; __builtin_memcpy(&x, buf + q + m, 4); __builtin_memcpy(&y, buf + p + m, 4);
+                        u32 d = x ^ y;
+                        if (d) { m += (u32)(__ffs((int)d) - 1) >> 3; break; }
+                        m += 4;
+                        if (p + m >= bn) break;
+                    }
+                    if (p + m > bn) m = bn - p;
+                }
+            }
+        }
+        u64 win = __ballot(m >= LZ_MINMATCH);
+        if (!win) { if (valid) tab[h] = (u16)(p + 1); cur += 64; continue; }
+        u32 f = (u32)__ffsll((long long)win) - 1;
+        u32 pf = cur + f, mf = (u32)__shfl((int)m, (int)f, 64), cf = (u32)__shfl((int)c, (int)f, 64) - 1;
+        u32 ll = pf - anchor;
+        for (u32 k = lane; k < ll; k += 64) lits[nl + k] = buf[anchor + k];
+        if (lane == 0) { sll[ns] = (u16)ll; sml[ns] = (u16)mf; sof[ns] = (u16)(pf - cf); }
+        nl += ll; ns++;
+        if (valid && lane <= f) tab[h] = (u16)(p + 1);
+        cur = anchor = pf + mf;
+    }
+    for (u32 k = lane; k < bn - anchor; k += 64) lits[nl + k] = buf[anchor + k];
+    nl += bn - anchor;
+    if (lane == 0) { B.nseq[b] = ns; B.nlit[b] = nl; }
+}
+
+// Sequences_Section of every block (one lane per block; predefined FSE encoding tables staged in LDS)
+__global__ __launch_bounds__(64) void k_lz_seqenc(u32 nblk, LzBufs B, const SeqCTabs *tabs)
+{
+    __shared__ SeqCTabs T;
+    for (u32 i = threadIdx.x; i < sizeof(SeqCTabs) / 4; i += 64) ((u32 *)&T)[i] = ((const u32 *)tabs)[i];
+    __syncthreads();
+    u32 b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= nblk) return;
+    SeqCTab ct[3]; zenc_seq_ctabs(T, ct);
+    u32 ns = B.nseq[b], bytes = 1;
+    u8 *out = B.seqbuf + (u64)b * B.slot;
+    if (ns == 0) out[0] = 0;
+    else bytes = zenc_write_sequences(out, (u32)B.slot, B.ll + (u64)b * B.seq_slot, B.ml + (u64)b * B.seq_slot, B.of + (u64)b * B.seq_slot, ns, ct);
+    B.seq_bytes[b] = bytes;                                              // 0: does not fit its slot, the block stays literal-only
+}
+
+// literals section size of an LZ block from the plan of its literals
+__host__ __device__ static inline u32 lz_lit_section_bytes(const ZEncPlan &p)
+{
+    if (p.kind == ZK_HUF) return p.csize - 3 - 1;
+    u32 hdr = p.n < 32 ? 1 : (p.n < 4096 ? 2 : 3);
+    return p.kind == ZK_RLE ? hdr + 1 : hdr + p.n;
+}
+// per block: the smaller of the literal-only coding (plan0) and the LZ coding (plan1 + sequences)
+__global__ void k_lz_choose(u32 nblk, const ZEncPlan *plan0, const ZEncPlan *plan1, const u32 *nseq, const u32 *seq_bytes, u8 *mode, u64 *csize)
+{
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    u32 s0 = plan0[b].csize, s1 = 3 + lz_lit_section_bytes(plan1[b]) + seq_bytes[b];
+    bool lz = nseq[b] > 0 && seq_bytes[b] > 0 && s1 < s0;
+    mode[b] = lz ? 1 : 0; csize[b] = lz ? s1 : s0;
 }
 
 #define ZENC_BLOCKS_PER_WG 16
@@ -169,8 +274,11 @@ __device__ __forceinline__ void huf_encode_stream_staged(u8 *out, const u8 *src,
     while (nb > 0) { *p++ = (u8)acc; acc >>= 8; nb = nb > 8 ? nb - 8 : 0; }
 }
 
+// LZ-coded blocks (mode[b] != 0) take their literals from L.lits with the plan / codes / tree of those literals (plan1 ...)
+// and append the Sequences_Section made by k_lz_seqenc; all other blocks are coded from src as literal-only blocks.
+struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u32 *codes1; const u8 *trees1; LzBufs B; };
 __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nblk, const ZEncPlan *plan, const u32 *codes_g, const u8 *trees,
-                                                    const u64 *offs, u8 *dst, u64 frame_hdr)
+                                                    const u64 *offs, u8 *dst, u64 frame_hdr, ZWriteLz L)
 {
     __shared__ __attribute__((aligned(16))) u32 codes[ZENC_BLOCKS_PER_WG][256];
     __shared__ __attribute__((aligned(16))) u8 orows[64 * ZENC_OROW];
@@ -179,31 +287,54 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
     for (u32 jj = 0; jj < ZENC_BLOCKS_PER_WG; jj++) {               // code tables made by k_zenc_plan: 1 KiB per block, coalesced
         u32 bb = b0 + jj;
         if (bb >= nblk) break;
-        if (plan[bb].kind != ZK_HUF) continue;
-        const uint4 *g = (const uint4 *)(codes_g + (u64)bb * 256);
+        const bool lzb = L.mode && L.mode[bb];
+        if ((lzb ? L.plan1[bb].kind : plan[bb].kind) != ZK_HUF) continue;
+        const uint4 *g = (const uint4 *)((lzb ? L.codes1 : codes_g) + (u64)bb * 256);
         ((uint4 *)codes[jj])[lane] = g[lane];
     }
     __syncthreads();
     u32 j = lane >> 2, k = lane & 3, b = b0 + j;
     if (b < nblk) {
-        const ZEncPlan p = plan[b];
-        u64 lo = zenc_block_lo(n, nblk, b);
+        const bool lzb = L.mode && L.mode[b];
         u8 *out = dst + frame_hdr + offs[b];
-        if (k == 0) zenc_write_block_prefix(out, p, trees + (u64)b * ZENC_TREE_SLOT, b + 1 == nblk, p.n ? src[lo] : 0);
-        if (p.kind == ZK_HUF) {
-            u32 per = (p.n + 3) / 4;
-            u32 cnt = k < 3 ? per : p.n - 3 * per;
-            u32 o = 3 + p.lhdr + p.tree_bytes + 6;
-            for (u32 q = 0; q < k; q++) o += p.ssz[q];
-            huf_encode_stream_staged(out + o, src + lo + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
-            if (k == 3) out[p.csize - 1] = 0;                       // Number_of_Sequences = 0
+        if (!lzb) {
+            const ZEncPlan p = plan[b];
+            u64 lo = zenc_block_lo(n, nblk, b);
+            if (k == 0) zenc_write_block_prefix(out, p, trees + (u64)b * ZENC_TREE_SLOT, b + 1 == nblk, p.n ? src[lo] : 0);
+            if (p.kind == ZK_HUF) {
+                u32 per = (p.n + 3) / 4;
+                u32 cnt = k < 3 ? per : p.n - 3 * per;
+                u32 o = 3 + p.lhdr + p.tree_bytes + 6;
+                for (u32 q = 0; q < k; q++) o += p.ssz[q];
+                huf_encode_stream_staged(out + o, src + lo + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
+                if (k == 3) out[p.csize - 1] = 0;                   // Number_of_Sequences = 0
+            }
+        } else {
+            const ZEncPlan p = L.plan1[b];                          // plan of the block's literals (p.n = their number)
+            const u8 *lits = L.B.lits + (u64)b * L.B.slot;
+            const u32 lsec = lz_lit_section_bytes(p), sbytes = L.B.seq_bytes[b];
+            if (k == 0) zenc_write_block_header(out, 2, lsec + sbytes, b + 1 == nblk);
+            if (p.kind == ZK_HUF) {
+                if (k == 0) zenc_write_huf_lit_prefix(out + 3, p, L.trees1 + (u64)b * ZENC_TREE_SLOT);
+                u32 per = (p.n + 3) / 4;
+                u32 cnt = k < 3 ? per : p.n - 3 * per;
+                u32 o = 3 + p.lhdr + p.tree_bytes + 6;
+                for (u32 q = 0; q < k; q++) o += p.ssz[q];
+                huf_encode_stream_staged(out + o, lits + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
+            } else if (k == 0) {
+                u32 h = zenc_lit_header_raw(out + 3, p.kind == ZK_RLE ? 1u : 0u, p.n);
+                if (p.kind == ZK_RLE) out[3 + h] = lits[0];
+                else for (u32 i = 0; i < p.n; i++) out[3 + h + i] = lits[i];      // fewer than 64 literals, or incompressible ones
+            }
+            const u8 *sq = L.B.seqbuf + (u64)b * L.B.slot;
+            for (u32 i = k; i < sbytes; i += 4) out[3 + lsec + i] = sq[i];
         }
     }
     // raw blocks: whole-wave copy
     for (u32 jj = 0; jj < ZENC_BLOCKS_PER_WG; jj++) {
         u32 bb = b0 + jj;
         if (bb >= nblk) break;
-        if (plan[bb].kind != ZK_RAW) continue;
+        if ((L.mode && L.mode[bb]) || plan[bb].kind != ZK_RAW) continue;
         u64 lo = zenc_block_lo(n, nblk, bb);
         u32 bn = plan[bb].n;
         const u8 *s = src + lo; u8 *o = dst + frame_hdr + offs[bb] + 3;
@@ -227,12 +358,16 @@ extern "C" size_t naf_gpu_zstd_compress_bound(size_t n)
 }
 
 // block_log: log2 of the target block size (clamped to 17 = the format maximum of 128 KiB)
-int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic)
+int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz)
 {
     u32 block_log = 15;                                          // 32 KiB: 4 streams of 8 KiB; more streams = more decode parallelism
     const char *e = getenv("NAF_GPU_BLOCK_LOG");
     if (e) { int v = atoi(e); if (v >= 10 && v <= 17) block_log = (u32)v; }
-    (void)level;
+    const char *el = getenv("NAF_GPU_LZ");                       // "0": never, "all": every stream (tests)
+    bool use_lz = lz || level >= 2;
+    if (el && !strcmp(el, "0")) use_lz = false;
+    if (el && !strcmp(el, "all")) use_lz = true;
+    if (use_lz && block_log > 15) block_log = 15;                // LZ lengths and distances are kept in 16 bits
     u64 bs = 1ull << block_log;
     u64 nblk64 = n ? (n + bs - 1) / bs : 1;
     if (nblk64 > 0x7FFFFFFFull) return ctx_fail(c, NAF_GPU_EARG, "stream too large");
@@ -243,11 +378,32 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
     u32 *codes = arena_new<u32>(c, (size_t)nblk * 256); u8 *trees = (u8 *)arena_alloc(c, (size_t)nblk * ZENC_TREE_SLOT);
     u64 *offs = arena_new<u64>(c, (size_t)nblk + 2);
     if (!plan || !codes || !trees || !offs) return NAF_GPU_ENOMEM;
-    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs);
+    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0);
+    ZWriteLz L; memset(&L, 0, sizeof L);
+    if (use_lz && n >= 64) {
+        if (!c->d_seqctab) {
+            SeqCTabs T; zenc_build_predefined(T);
+            HIP_TRY(c, hipMalloc(&c->d_seqctab, sizeof T));
+            HIP_TRY(c, hipMemcpy(c->d_seqctab, &T, sizeof T, hipMemcpyHostToDevice));
+        }
+        LzBufs B; B.slot = bs; B.seq_slot = bs / 4 + 2;
+        B.lits = (u8 *)arena_alloc(c, (size_t)nblk * B.slot + 64); B.seqbuf = (u8 *)arena_alloc(c, (size_t)nblk * B.slot + 64);
+        B.ll = arena_new<u16>(c, (size_t)nblk * B.seq_slot); B.ml = arena_new<u16>(c, (size_t)nblk * B.seq_slot); B.of = arena_new<u16>(c, (size_t)nblk * B.seq_slot);
+        B.nseq = arena_new<u32>(c, nblk); B.nlit = arena_new<u32>(c, nblk); B.seq_bytes = arena_new<u32>(c, nblk);
+        ZEncPlan *plan1 = arena_new<ZEncPlan>(c, nblk);
+        u32 *codes1 = arena_new<u32>(c, (size_t)nblk * 256); u8 *trees1 = (u8 *)arena_alloc(c, (size_t)nblk * ZENC_TREE_SLOT);
+        u8 *mode = (u8 *)arena_alloc(c, nblk);
+        if (!B.lits || !B.seqbuf || !B.ll || !B.ml || !B.of || !B.nseq || !B.nlit || !B.seq_bytes || !plan1 || !codes1 || !trees1 || !mode) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, 0, d_src, (u64)n, nblk, B);
+        LAUNCH(c, "zenc_lz_seqenc", k_lz_seqenc, cdiv(nblk, 64), 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
+        LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot);
+        LAUNCH(c, "zenc_lz_choose", k_lz_choose, cdiv(nblk, 256), 256, 0, nblk, (const ZEncPlan *)plan, (const ZEncPlan *)plan1, (const u32 *)B.nseq, (const u32 *)B.seq_bytes, mode, offs);
+        L.mode = mode; L.plan1 = plan1; L.codes1 = codes1; L.trees1 = trees1; L.B = B;
+    }
     int rc = scan_exclusive_u64(c, offs, nblk, offs + nblk + 1); if (rc) return rc;
     LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, with_magic);
     LAUNCH(c, "zenc_write", k_zenc_write, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, d_src, (u64)n, nblk, (const ZEncPlan *)plan, (const u32 *)codes, (const u8 *)trees,
-           (const u64 *)offs, d_dst, hdr);
+           (const u64 *)offs, d_dst, hdr, L);
     u64 total = 0;
     rc = ctx_readback(c, &total, offs + nblk + 1, 8); if (rc) return rc;
     *out_len = hdr + total;

@@ -8,6 +8,7 @@
 // zero sequences; RLE blocks for constant data; Raw blocks when entropy coding does not pay.
 #pragma once
 #include "common.h"
+#include "zstd_dec_core.h"                                     // ll_base / ll_bits / ml_base / ml_bits for the sequences encoder
 
 #define ZENC_HUF_MAXBITS 11
 
@@ -191,6 +192,20 @@ NAF_HD void fse_build_ctable(const i16 *norm, u32 maxsym, u32 log, u16 *tableU16
     }
 }
 
+// FSE encoder state steps (the encoder mirror of the decoder's base/nbits cells)
+NAF_HD u32 fse_cinit(const u16 *tableU16, const FseCSym *tt, u32 sym)
+{
+    u32 nbBitsOut = (u32)((tt[sym].deltaNbBits + (1 << 15)) >> 16);
+    i32 v = (i32)(nbBitsOut << 16) - tt[sym].deltaNbBits;
+    return tableU16[(v >> nbBitsOut) + tt[sym].deltaFindState];
+}
+NAF_HD void fse_cencode(BitW &b, u32 &st, const u16 *tableU16, const FseCSym *tt, u32 sym)
+{
+    u32 nbBitsOut = (u32)(((i32)st + tt[sym].deltaNbBits) >> 16);
+    bitw_add(b, st, nbBitsOut); bitw_flush(b);
+    st = tableU16[((i32)st >> nbBitsOut) + tt[sym].deltaFindState];
+}
+
 // FSE-compress `n` weights (values 0..maxsym) with two interleaved states.  Returns bytes written, 0 on failure.
 NAF_HD u32 fse_compress_weights(u8 *out, u32 cap, const u8 *w, u32 n, FseWS &ws)
 {
@@ -331,16 +346,11 @@ NAF_HD void zenc_plan_finish(ZEncPlan &p, u32 n, u32 log, u32 tb)
     p.kind = ZK_HUF; p.csize = csize; p.log = (u8)log; p.tree_bytes = (u16)tb; p.lhdr = (u8)lhdr;
 }
 
-// Block header + literals header + tree + jump table.  Returns the offset of the first Huffman stream.
-NAF_HD u32 zenc_write_block_prefix(u8 *out, const ZEncPlan &p, const u8 *tree, bool last, u8 rle_byte)
+// Huffman literals section header + tree + jump table at out[0..); returns the offset of the first stream.
+// body = tree + 6 + streams (Compressed_Size), p.n = Regenerated_Size.
+NAF_HD u32 zenc_write_huf_lit_prefix(u8 *out, const ZEncPlan &p, const u8 *tree)
 {
-    u32 type = p.kind == ZK_HUF ? 2 : p.kind;
-    u32 bsize = p.kind == ZK_HUF ? p.csize - 3 : p.n;
-    u32 bh = (last ? 1u : 0u) | (type << 1) | (bsize << 3);
-    out[0] = (u8)bh; out[1] = (u8)(bh >> 8); out[2] = (u8)(bh >> 16);
-    if (p.kind == ZK_RLE) { out[3] = rle_byte; return 4; }
-    if (p.kind == ZK_RAW) return 3;
-    u32 body = p.csize - 3 - p.lhdr - 1, pos = 3;
+    u32 body = p.csize - 3 - p.lhdr - 1, pos = 0;
     if (p.lhdr == 3) { u32 h = 2u | (1u << 2) | (p.n << 4) | (body << 14); out[pos] = (u8)h; out[pos + 1] = (u8)(h >> 8); out[pos + 2] = (u8)(h >> 16); }
     else if (p.lhdr == 4) { u32 h = 2u | (2u << 2) | (p.n << 4) | (body << 18); st32(out + pos, h); }
     else { u64 h = 2u | (3u << 2) | ((u64)p.n << 4) | ((u64)body << 22); st32(out + pos, (u32)h); out[pos + 4] = (u8)(h >> 32); }
@@ -351,4 +361,87 @@ NAF_HD u32 zenc_write_block_prefix(u8 *out, const ZEncPlan &p, const u8 *tree, b
     out[pos + 2] = (u8)p.ssz[1]; out[pos + 3] = (u8)(p.ssz[1] >> 8);
     out[pos + 4] = (u8)p.ssz[2]; out[pos + 5] = (u8)(p.ssz[2] >> 8);
     return pos + 6;
+}
+NAF_HD void zenc_write_block_header(u8 *out, u32 type, u32 bsize, bool last)
+{
+    u32 bh = (last ? 1u : 0u) | (type << 1) | (bsize << 3);
+    out[0] = (u8)bh; out[1] = (u8)(bh >> 8); out[2] = (u8)(bh >> 16);
+}
+// Block header + literals header + tree + jump table.  Returns the offset of the first Huffman stream.
+NAF_HD u32 zenc_write_block_prefix(u8 *out, const ZEncPlan &p, const u8 *tree, bool last, u8 rle_byte)
+{
+    u32 type = p.kind == ZK_HUF ? 2 : p.kind;
+    zenc_write_block_header(out, type, p.kind == ZK_HUF ? p.csize - 3 : p.n, last);
+    if (p.kind == ZK_RLE) { out[3] = rle_byte; return 4; }
+    if (p.kind == ZK_RAW) return 3;
+    return 3 + zenc_write_huf_lit_prefix(out + 3, p, tree);
+}
+
+// ---- sequences section (3.1.1.3.2), predefined distributions only -------------------------------------------------------------
+// The LZ stage of this encoder finds matches inside a block only and codes every offset as a new offset (value = offset + 3),
+// so blocks stay independent of each other.  LL / OF / ML codes use the predefined FSE distributions (mode byte 0): no table
+// descriptions to build or transmit.
+struct SeqCTab { const u16 *tableU16; const FseCSym *tt; u32 log; };
+NAF_HD u32 zenc_ll_code(u32 ll) { if (ll < 16) return ll; u32 c = 16; while (c < 35 && ll_base(c + 1) <= ll) c++; return c; }
+NAF_HD u32 zenc_ml_code(u32 ml) { if (ml < 35) return ml - 3; u32 c = 32; while (c < 52 && ml_base(c + 1) <= ml) c++; return c; }
+
+// Encoding tables of the three predefined distributions: tableU16[64 + 32 + 64], tt[36 + 29 + 53].
+struct SeqCTabs { u16 tableU16[160]; FseCSym tt[118]; };
+NAF_HD void zenc_build_predefined(SeqCTabs &T)
+{
+    const i16 LL[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1 };
+    const i16 OF[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
+    const i16 ML[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 };
+    u8 tsym[64]; u32 cumul[56];
+    fse_build_ctable(LL, 35, 6, T.tableU16, T.tt, tsym, cumul);
+    fse_build_ctable(OF, 28, 5, T.tableU16 + 64, T.tt + 36, tsym, cumul);
+    fse_build_ctable(ML, 52, 6, T.tableU16 + 96, T.tt + 65, tsym, cumul);
+}
+NAF_HD void zenc_seq_ctabs(const SeqCTabs &T, SeqCTab ct[3])
+{
+    ct[0].tableU16 = T.tableU16; ct[0].tt = T.tt; ct[0].log = 6;
+    ct[1].tableU16 = T.tableU16 + 64; ct[1].tt = T.tt + 36; ct[1].log = 5;
+    ct[2].tableU16 = T.tableU16 + 96; ct[2].tt = T.tt + 65; ct[2].log = 6;
+}
+
+// Sequences_Section for nseq >= 1 sequences (ll = literals before the match, ml = match length >= 3, of = distance >= 1).
+// Written forward; the decoder reads it from the end, so the LAST sequence is coded first.  Returns bytes, 0 if cap is short.
+NAF_HD u32 zenc_write_sequences(u8 *out, u32 cap, const u16 *ll, const u16 *ml, const u16 *of, u32 nseq, const SeqCTab ct[3])
+{
+    if (cap < 64) return 0;
+    u32 pos = 0;
+    if (nseq < 128) out[pos++] = (u8)nseq;
+    else if (nseq < 0x7F00) { out[pos++] = (u8)((nseq >> 8) + 128); out[pos++] = (u8)nseq; }
+    else { out[pos++] = 255; out[pos++] = (u8)(nseq - 0x7F00); out[pos++] = (u8)((nseq - 0x7F00) >> 8); }
+    out[pos++] = 0;                                            // Symbol_Compression_Modes: predefined x3
+    BitW b; bitw_init(b, out + pos);
+    u32 i = nseq - 1;
+    u32 llc = zenc_ll_code(ll[i]), mlc = zenc_ml_code(ml[i]), ofv = (u32)of[i] + 3, ofc = (u32)hibit32(ofv);
+    u32 sML = fse_cinit(ct[2].tableU16, ct[2].tt, mlc), sOF = fse_cinit(ct[1].tableU16, ct[1].tt, ofc), sLL = fse_cinit(ct[0].tableU16, ct[0].tt, llc);
+    bitw_add(b, ll[i] - ll_base(llc), ll_bits(llc)); bitw_flush(b);
+    bitw_add(b, ml[i] - ml_base(mlc), ml_bits(mlc)); bitw_flush(b);
+    bitw_add(b, ofv - (1u << ofc), ofc); bitw_flush(b);
+    while (i-- > 0) {
+        if ((u32)(b.p - out) + 32 > cap) return 0;                // a sequence adds at most 62 bits
+        llc = zenc_ll_code(ll[i]); mlc = zenc_ml_code(ml[i]); ofv = (u32)of[i] + 3; ofc = (u32)hibit32(ofv);
+        fse_cencode(b, sOF, ct[1].tableU16, ct[1].tt, ofc);
+        fse_cencode(b, sML, ct[2].tableU16, ct[2].tt, mlc);
+        fse_cencode(b, sLL, ct[0].tableU16, ct[0].tt, llc);
+        bitw_add(b, ll[i] - ll_base(llc), ll_bits(llc)); bitw_flush(b);
+        bitw_add(b, ml[i] - ml_base(mlc), ml_bits(mlc)); bitw_flush(b);
+        bitw_add(b, ofv - (1u << ofc), ofc); bitw_flush(b);
+    }
+    bitw_add(b, sML, ct[2].log); bitw_flush(b);
+    bitw_add(b, sOF, ct[1].log); bitw_flush(b);
+    bitw_add(b, sLL, ct[0].log); bitw_flush(b);
+    u8 *end = bitw_close(b);
+    return (u32)(end - out);
+}
+
+// Raw / RLE literals section header (3.1.1.3.1.1): returns header bytes.
+NAF_HD u32 zenc_lit_header_raw(u8 *out, u32 type, u32 regen)
+{
+    if (regen < 32) { out[0] = (u8)(type | (regen << 3)); return 1; }
+    if (regen < 4096) { u32 h = type | (1u << 2) | (regen << 4); out[0] = (u8)h; out[1] = (u8)(h >> 8); return 2; }
+    u32 h = type | (3u << 2) | (regen << 4); out[0] = (u8)h; out[1] = (u8)(h >> 8); out[2] = (u8)(h >> 16); return 3;
 }

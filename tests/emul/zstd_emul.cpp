@@ -147,3 +147,50 @@ extern "C" long long emul_zstd_decompress_frame(const u8 *src, size_t len, u8 *d
     }
     return (long long)off;
 }
+
+// ---- the sector-window reader of k_huf_literals, single-stepped for one stream --------------------------------------------
+// Same statements as the kernel's per-lane loop (ring of two 64-byte sectors in "LDS", register-staged prefetch), so the
+// window arithmetic can be checked on the host against the plain reader for any stream shape.  Returns 0 when both agree.
+extern "C" int emul_window_reader(const u8 *stream, u32 size, const u8 *weights, u32 nw, u32 log, u32 n, u64 align_off, int big)
+{
+    std::vector<u8> hay(size + 1024 + 256);
+    u8 *base = hay.data() + 256; base += (64 - ((uintptr_t)base & 63)) & 63; base += align_off;
+    memset(hay.data(), 0xAA, hay.size());
+    memcpy(base, stream, size);
+    std::vector<u16> tabv(huf_tab_bytes(log) / 2); huf_build_any(tabv.data(), weights, nw, log); const u16 *tab = tabv.data();
+    std::vector<u8> ref(n + 64), out(n + 64);
+    if (huf_decode_stream(base, size, tab, log, ref.data(), n)) return -1;
+    BitR br; bitr_init(br, base, size); if (br.bad) return -2;
+    if (!big && log > 7) return -5;
+    const u32 HUF_ROUND = 32, rmask = big ? 255u : 127u, guard = big ? 192u : 160u;
+    u8 irow[264];
+    u32 rounds = n / HUF_ROUND, R = 0;
+    bool live = (u64)(br.ptr - br.start) >= guard + 32;
+    u64 gp = (u64)br.ptr, lo = 0; u8 st[64]; bool pending = false;
+    if (live) { u64 top = (gp + 7) & ~63ull; lo = top - 64; for (int q = 0; q < 8; q++) memcpy(irow + ((lo + 16 * q) & rmask), (const u8 *)(lo + 16 * q), 16); }
+    u32 bits = br.consumed;
+    for (; R < rounds; R++) {
+        if (!(live && gp - (u64)br.start >= guard)) break;
+        if (pending) { lo -= 64; memcpy(irow + (lo & rmask), st, 64); pending = false; }
+        if (lo + (big ? 96u : 56u) > gp) { memcpy(st, (const u8 *)(lo - 64), 64); pending = true; }
+        for (u32 g = 0; g < HUF_ROUND / 8; g++) {
+            for (u32 h = 0; h < (big ? 2u : 1u); h++) {
+                gp -= bits >> 3; bits &= 7;
+                u32 o = (u32)(gp & rmask), sh = (o & 7) * 8;
+                u64 q0, q1; memcpy(&q0, irow + (o & ~7u), 8); memcpy(&q1, irow + (((o & ~7u) + 8) & rmask), 8);
+                u64 w = (sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0) << bits;
+                for (u32 q = 0; q < (big ? 4u : 8u); q++) {
+                    u32 e = huf_look(tab, (u32)(w >> 32) >> (32 - log), log); u32 nb = e >> 8; w <<= nb; bits += nb;
+                    out[R * HUF_ROUND + g * 8 + (big ? 4 * h : 0) + q] = (u8)e;
+                }
+            }
+        }
+    }
+    if (live) { gp -= bits >> 3; bits &= 7; br.c = ld64((const u8 *)gp); br.consumed = bits; }
+    br.ptr = (const u8 *)gp;
+    u32 done = R * HUF_ROUND;
+    if (huf_decode_n(br, tab, log, out.data() + done, n - done)) return -3;
+    bitr_reload(br); if (!bitr_finished(br)) return -4;
+    for (u32 i = 0; i < n; i++) if (out[i] != ref[i]) return (int)i + 1;
+    return 0;
+}

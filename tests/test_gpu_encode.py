@@ -57,6 +57,57 @@ def test_zstd_compress_roundtrip(gpu, oracle, block_log, monkeypatch):
             assert fi.lit_huf > 0 and fi.lit_treeless == 0 and fi.n_sequences == 0   # independent blocks
 
 
+def lz_datasets():
+    rng = np.random.default_rng(9)
+    for name, d in datasets():
+        yield name, d
+    yield "srr_ids", b"".join(b"SRR%07d.%d length=%d\x00" % (1234567, i, 150) for i in range(1, 30000))
+    yield "lengths", np.full(50000, 150, dtype="<u4").tobytes()
+    yield "lengths_var", rng.integers(100, 160, 50000).astype("<u4").tobytes()
+    rep = (b"abcdefghij" * 1000 + rng.integers(0, 256, 5000, dtype=np.uint8).tobytes()) * 5
+    yield "repeats", rep
+    yield "long_run", b"A" * 40000 + b"CGT" * 20000 + b"N" * 12345
+    for i in range(8):
+        n = int(rng.integers(1, 90000)); a = int(rng.choice([2, 4, 16, 256]))
+        d = rng.integers(0, a, n, dtype=np.uint8).tobytes()
+        yield "fuzz%d" % i, (d[: n // 3] * 3 if i % 2 else d)
+
+
+@pytest.mark.parametrize("block_log", ["12", "15"])
+def test_zstd_compress_lz_roundtrip(gpu, oracle, block_log, monkeypatch):
+    """LZ stage (matches inside a block, predefined FSE sequence tables): frames decode under the from-spec oracle, the
+    HIP decoder and -- when this machine has it -- libzstd itself; never larger than the literal-only coding."""
+    import ctypes
+    zlib = None
+    for cand in ("/opt/conda/lib/libzstd.so", "libzstd.so.1"):
+        try:
+            zlib = ctypes.CDLL(cand); break
+        except OSError:
+            pass
+    if zlib is not None:
+        zlib.ZSTD_decompress.restype = ctypes.c_size_t
+        zlib.ZSTD_decompress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    monkeypatch.setenv("NAF_GPU_BLOCK_LOG", block_log)
+    for name, d in lz_datasets():
+        monkeypatch.setenv("NAF_GPU_LZ", "0")
+        plain = host(gpu.zstd_compress(gpu.to_device(d)))
+        monkeypatch.setenv("NAF_GPU_LZ", "all")
+        frame = gpu.zstd_compress(gpu.to_device(d))
+        fb = host(frame)
+        assert len(fb) <= len(plain), name
+        assert oracle.zstd_decompress(fb, len(d) + 16) == d, name
+        assert host(gpu.zstd_decompress(frame, len(d) + 64)) == d, name
+        if zlib is not None:
+            out = ctypes.create_string_buffer(len(d) + 64)
+            r = zlib.ZSTD_decompress(out, len(d) + 64, fb, len(fb))
+            assert r == len(d) and out.raw[:r] == d, name
+        if name == "srr_ids":
+            assert len(fb) < 0.2 * len(d) and len(plain) > 0.4 * len(d)      # what the stage is for
+            assert oracle.zstd_frame_info(fb).n_sequences > 0
+        if name == "lengths":
+            assert len(fb) < 0.01 * len(d)
+
+
 def _seq_type(args, O):
     return O.RNA if "--rna" in args else O.PROTEIN if "--protein" in args else O.TEXT if "--text" in args else O.DNA
 

@@ -113,6 +113,28 @@ def test_encoder_kernel_logic_roundtrips_through_oracle(emul, oracle):
             assert oracle.zstd_decompress(out.raw[:n], len(d) + 16) == d
 
 
+def test_decoder_window_reader_at_every_rate_and_alignment(emul):
+    """k_huf_literals' sector-window reader (two-sector LDS ring, register-staged prefetch; four sectors above 7-bit codes),
+    single-stepped on the host: streams from 1 bit to 11 bits per symbol, every start alignment class, against the plain reader.
+    (A 1-bit code moves the read position by 4 bytes a round -- the case that once let the ring overwrite live bytes.)"""
+    emul.emul_window_roundtrip.restype = ctypes.c_int
+    emul.emul_window_roundtrip.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int]
+    rng = np.random.default_rng(11)
+    streams = []
+    for alpha in (2, 3, 4, 16, 41, 100, 256):
+        streams.append(rng.integers(0, alpha, 9000, dtype=np.uint8).tobytes())
+    p2 = np.array([2.0 ** -(i + 1) for i in range(30)])
+    streams.append(rng.choice(np.arange(30, dtype=np.uint8), 9000, p=p2 / p2.sum()).tobytes())       # codes up to 11 bits
+    streams.append((b"\x00" * 50 + b"\x01") * 170)                                                    # 1-bit code, long runs
+    for d in streams:
+        for n in (len(d), 6009, 999, 257):
+            for align in (0, 1, 7, 8, 22, 37, 55, 56, 57, 63):
+                r_big = emul.emul_window_roundtrip(d[:n], n, align, 1)
+                assert r_big == 0, (len(set(d)), n, align, "big", r_big)
+                r = emul.emul_window_roundtrip(d[:n], n, align, 0)
+                assert r in (0, -5), (len(set(d)), n, align, "small", r)                           # -5: table wider than 7 bits
+
+
 # ---- CLI paths that need no device ---------------------------------------------------------------------------------
 def run(prog, *args, stdin=None):
     p = subprocess.run([os.path.join(BIN, prog), *args], input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
