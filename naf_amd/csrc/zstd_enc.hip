@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
 #define LZ_MINMATCH 5
 #define LZ_HASH_LOG 12
 #define LZ_BLOCK_MAX 32768
+#define LZ_LANE_EXT 32                    // bytes a lane extends its own match by before the wave takes over
 struct LzBufs {
     u8 *lits; u64 slot;                 // literals of block b at lits + b*slot
     u16 *ll, *ml, *of; u64 seq_slot;    // sequences of block b at [b*seq_slot ..)
@@ -136,7 +137,7 @@ struct LzBufs {
 };
 __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk, LzBufs B)
 {
-    __shared__ __attribute__((aligned(16))) u8 buf[LZ_BLOCK_MAX + 64];
+    __shared__ __attribute__((aligned(16))) u8 buf[LZ_BLOCK_MAX + 320];
     __shared__ u16 tab[1 << LZ_HASH_LOG];
     const u32 b = blockIdx.x, lane = threadIdx.x;
     const u64 lo = zenc_block_lo(n, nblk, b);
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk,
         else for (u32 k = i; k < bn; k++) buf[k] = src[lo + k];
     }
     for (u32 i = lane; i < (1u << LZ_HASH_LOG); i += 64) tab[i] = 0;     // 0 = empty, else position + 1
-    for (u32 i = bn + lane; i < bn + 64 && i < LZ_BLOCK_MAX + 64; i += 64) buf[i] = 0;
+    for (u32 i = bn + lane; i < bn + 320 && i < LZ_BLOCK_MAX + 320; i += 64) buf[i] = 0;
     __syncthreads();
     u8 *lits = B.lits + (u64)b * B.slot;
     u16 *sll = B.ll + (u64)b * B.seq_slot, *sml = B.ml + (u64)b * B.seq_slot, *sof = B.of + (u64)b * B.seq_slot;
@@ -167,22 +168,40 @@ __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk,
                         u32 d = x ^ y;
                         if (d) { m += (u32)(__ffs((int)d) - 1) >> 3; break; }
                         m += 4;
-                        if (p + m >= bn) break;
+                        if (p + m >= bn || m >= LZ_LANE_EXT) break;   // long matches are finished by the whole wave (below)
                     }
                     if (p + m > bn) m = bn - p;
                 }
             }
         }
         u64 win = __ballot(m >= LZ_MINMATCH);
-        if (!win) { if (valid) tab[h] = (u16)(p + 1); cur += 64; continue; }
-        u32 f = (u32)__ffsll((long long)win) - 1;
-        u32 pf = cur + f, mf = (u32)__shfl((int)m, (int)f, 64), cf = (u32)__shfl((int)c, (int)f, 64) - 1;
-        u32 ll = pf - anchor;
-        for (u32 k = lane; k < ll; k += 64) lits[nl + k] = buf[anchor + k];
-        if (lane == 0) { sll[ns] = (u16)ll; sml[ns] = (u16)mf; sof[ns] = (u16)(pf - cf); }
-        nl += ll; ns++;
-        if (valid && lane <= f) tab[h] = (u16)(p + 1);
-        cur = anchor = pf + mf;
+        if (valid) tab[h] = (u16)(p + 1);                            // later lanes win ties; any earlier position is a fine candidate
+        // greedy left to right over this round's 64 positions: take the first match at or after `anchor`, jump behind it, repeat
+        u32 next = cur < anchor ? anchor : cur;
+        while (next < cur + 64) {
+            u64 w2 = win & ~((1ull << (next - cur)) - 1);
+            if (!w2) break;
+            u32 f = (u32)__ffsll((long long)w2) - 1;
+            u32 pf = cur + f, mf = (u32)__shfl((int)m, (int)f, 64), cf = (u32)__shfl((int)c, (int)f, 64) - 1;
+            while (mf >= LZ_LANE_EXT && pf + mf < bn) {              // 256 bytes per step: lane k compares bytes [4k, 4k+4) behind the match so far
+                u32 x, y; __builtin_memcpy(&x, buf + cf + mf + 4 * lane, 4); __builtin_memcpy(&y, buf + pf + mf + 4 * lane, 4);
+                u32 d = x ^ y;                                        // reads stay inside the zero padding behind bn (bn + 256 + 4)
+                u64 ne = __ballot(d != 0);
+                if (!ne) { mf += 256; continue; }
+                u32 l0 = (u32)__ffsll((long long)ne) - 1;
+                u32 d0 = (u32)__shfl((int)d, (int)l0, 64);
+                mf += 4 * l0 + (((u32)__ffs((int)d0) - 1) >> 3);
+                break;
+            }
+            if (pf + mf > bn) mf = bn - pf;
+            u32 ll = pf - anchor;
+            for (u32 k = lane; k < ll; k += 64) lits[nl + k] = buf[anchor + k];
+            if (lane == 0) { sll[ns] = (u16)ll; sml[ns] = (u16)mf; sof[ns] = (u16)(pf - cf); }
+            nl += ll; ns++;
+            anchor = next = pf + mf;
+        }
+        cur += 64;
+        if (cur < anchor) cur = anchor;                             // a match ran past the round: resume behind it
     }
     for (u32 k = lane; k < bn - anchor; k += 64) lits[nl + k] = buf[anchor + k];
     nl += bn - anchor;
