@@ -83,7 +83,8 @@ int  naf_gpu_zstd_decompress(naf_gpu_ctx *ctx, const void *d_src, size_t src_len
                              void *d_dst, size_t dst_cap, size_t *out_len);
 
 /* Compress d_src into ONE zstd frame made of independently coded blocks (single frame: SURVEY.md R1).
- * level follows ennaf's --level semantics loosely: <=1 entropy-only blocks. */
+ * level <= 1: entropy-only blocks (Huffman literals, RLE, raw); level >= 2 adds the LZ stage (matches inside a block, coded
+ * with the predefined FSE sequence tables).  Blocks never depend on each other at any level. */
 int  naf_gpu_zstd_compress(naf_gpu_ctx *ctx, const void *d_src, size_t src_len, int level,
                            void *d_dst, size_t dst_cap, size_t *out_len);
 size_t naf_gpu_zstd_compress_bound(size_t src_len);
@@ -125,7 +126,7 @@ typedef struct {
     int      seq_type;          /* NAF_SEQ_* */
     int      no_mask;           /* --no-mask */
     int      strict;            /* --strict */
-    int      level;             /* --level */
+    int      level;             /* --level: ids / names / lengths always take the LZ stage; >= 2 extends it to mask, sequence, quality */
     int64_t  line_length;       /* <0: store the longest line; >=0: --line-length N */
     const char *title;          /* --title or NULL */
 } naf_gpu_ennaf_opts;
