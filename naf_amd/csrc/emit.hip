@@ -836,7 +836,7 @@ static int unnaf_prepare(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const 
 
 // The side streams (lengths, ids, names, mask) and the prefix tables built from them.  Runs on whichever context it is given:
 // the archive's own for byte-range calls, the side context (second host thread, second stream) for whole-text calls.
-static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl)
+static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gpu_ctx *aux = nullptr)
 {
     const naf_gpu_header &h = pl.h;
     EmitP &P = pl.P;
@@ -847,37 +847,56 @@ static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl)
         pl.total = T;
     } else {
         if (!has_len) return ctx_fail(c, NAF_GPU_EFORMAT, "archive has no lengths");
-        u8 *lens = nullptr;
-        if ((rc = load_section(c, d_naf, h, S_LEN, h.orig_size[S_LEN], "lengths", &lens))) return rc;
-        u64 n_len = h.orig_size[S_LEN] / 4;
-        u64 *flag = arena_new<u64>(c, n_len + 2), *rec_len = arena_new<u64>(c, N + 1);
-        if (!flag || !rec_len) return NAF_GPU_ENOMEM;
-        HIP_TRY(c, hipMemsetAsync(rec_len, 0, (N + 1) * 8, c->stream));
-        if (n_len) LAUNCH(c, "unnaf_len_flags", k_len_flags, cdiv(n_len, 256), 256, 0, (const u32 *)lens, n_len, flag);
-        if ((rc = scan_exclusive_u64(c, flag, n_len, flag + n_len + 1))) return rc;
-        if (n_len) LAUNCH(c, "unnaf_len_acc", k_len_acc, cdiv(n_len, 256), 256, 0, (const u32 *)lens, n_len, (const u64 *)flag, rec_len, N);
-        u64 nrec = 0;
-        if ((rc = ctx_readback(c, &nrec, flag + n_len + 1, 8))) return rc;
-        if (nrec < N) return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted lengths: %llu records described, %llu expected", (unsigned long long)nrec, (unsigned long long)N);
-        P.rec_len = rec_len;
+        // ids and names: on `aux` (its own host thread and stream) beside the lengths when there is one, else after them
         P.has_ids = 0; P.has_names = 0;
-        if (P.mode == EM_FASTA || P.mode == EM_FASTQ) {
-            P.has_ids = has_ids; P.has_names = has_names;
-            if (has_ids) {
+        const bool want_names = P.mode == EM_FASTA || P.mode == EM_FASTQ;
+        if (want_names) { P.has_ids = has_ids; P.has_names = has_names; }
+        auto ids_names = [&](naf_gpu_ctx *x) -> int {
+            int r;
+            if (want_names && has_ids) {
                 u8 *b = nullptr; u64 *z = nullptr;
-                if (h.orig_size[S_IDS] == 0) return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted ids - not 0-terminated\n");
-                if ((rc = load_section(c, d_naf, h, S_IDS, h.orig_size[S_IDS], "ids", &b))) return rc;
-                if ((rc = zero_positions(c, b, h.orig_size[S_IDS], N, &z))) return rc;
+                if (h.orig_size[S_IDS] == 0) return ctx_fail(x, NAF_GPU_EFORMAT, "corrupted ids - not 0-terminated\n");
+                if ((r = load_section(x, d_naf, h, S_IDS, h.orig_size[S_IDS], "ids", &b))) return r;
+                if ((r = zero_positions(x, b, h.orig_size[S_IDS], N, &z))) return r;
                 P.ids = b; P.idz = z;
             }
-            if (has_names) {
+            if (want_names && has_names) {
                 u8 *b = nullptr; u64 *z = nullptr;
-                if (h.orig_size[S_NAMES] == 0) return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted names - not 0-terminated\n");
-                if ((rc = load_section(c, d_naf, h, S_NAMES, h.orig_size[S_NAMES], "names", &b))) return rc;
-                if ((rc = zero_positions(c, b, h.orig_size[S_NAMES], N, &z))) return rc;
+                if (h.orig_size[S_NAMES] == 0) return ctx_fail(x, NAF_GPU_EFORMAT, "corrupted names - not 0-terminated\n");
+                if ((r = load_section(x, d_naf, h, S_NAMES, h.orig_size[S_NAMES], "names", &b))) return r;
+                if ((r = zero_positions(x, b, h.orig_size[S_NAMES], N, &z))) return r;
                 P.names = b; P.nmz = z;
             }
-        }
+            return 0;
+        };
+        u64 *rec_len = nullptr;
+        auto lengths = [&]() -> int {
+            int r;
+            u8 *lens = nullptr;
+            if ((r = load_section(c, d_naf, h, S_LEN, h.orig_size[S_LEN], "lengths", &lens))) return r;
+            u64 n_len = h.orig_size[S_LEN] / 4;
+            u64 *flag = arena_new<u64>(c, n_len + 2); rec_len = arena_new<u64>(c, N + 1);
+            if (!flag || !rec_len) return NAF_GPU_ENOMEM;
+            HIP_TRY(c, hipMemsetAsync(rec_len, 0, (N + 1) * 8, c->stream));
+            if (n_len) LAUNCH(c, "unnaf_len_flags", k_len_flags, cdiv(n_len, 256), 256, 0, (const u32 *)lens, n_len, flag);
+            if ((r = scan_exclusive_u64(c, flag, n_len, flag + n_len + 1))) return r;
+            if (n_len) LAUNCH(c, "unnaf_len_acc", k_len_acc, cdiv(n_len, 256), 256, 0, (const u32 *)lens, n_len, (const u64 *)flag, rec_len, N);
+            u64 nrec = 0;
+            if ((r = ctx_readback(c, &nrec, flag + n_len + 1, 8))) return r;
+            if (nrec < N) return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted lengths: %llu records described, %llu expected", (unsigned long long)nrec, (unsigned long long)N);
+            return 0;
+        };
+        const bool aux_run = aux && want_names && (has_ids || has_names);
+        int rc_aux = 0;
+        std::thread th;
+        if (aux_run) th = std::thread([&] { hipSetDevice(c->device); rc_aux = ids_names(aux); });     // no return until it is joined
+        rc = lengths();
+        if (aux_run) { th.join(); hipStreamSynchronize(aux->stream); }
+        if (rc) return rc;                                                                               // the order a sequential run reports in
+        if (!aux_run) rc_aux = ids_names(c);
+        else if (rc_aux) memcpy(c->err, aux->err, sizeof c->err);
+        if (rc_aux) return rc_aux;
+        P.rec_len = rec_len;
         u32 *hdr_len = arena_new<u32>(c, N + 1);
         u64 *rec_out = arena_new<u64>(c, N + 2), *rec_base = arena_new<u64>(c, N + 2);
         if (!hdr_len || !rec_out || !rec_base) return NAF_GPU_ENOMEM;
@@ -926,7 +945,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     ZRange rgs, rgq; ZRange *prs = nullptr, *prq = nullptr;
     u8 *seq = nullptr;
     // sequence (and quality) payload: the dominant zstd streams
-    auto payload = [&]() -> int {
+    auto payload_seq = [&]() -> int {
         int r;
         u64 seq_need = prs ? (rgs.want_hi - rgs.want_lo) + 2 * 131072 + 64 : pl.seq_bytes + 64;
         if (seq_need > pl.seq_bytes + 64) seq_need = pl.seq_bytes + 64;
@@ -941,23 +960,27 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         if (r == NAF_GPU_ECAP || (r == 0 && n != pl.seq_bytes)) return ctx_fail(c, NAF_GPU_EFORMAT, "can't decompress sequence\n");
         if (r) return r;
         pl.P.seq = (prs && prs->ranged) ? seq - prs->got_lo : seq;
-        if (pl.need_qual) {
-            u64 qn = h.orig_size[S_QUAL];
-            u64 q_need = prq ? (rgq.want_hi - rgq.want_lo) + 2 * 131072 + 64 : qn + 64;
-            if (q_need > qn + 64) q_need = qn + 64;
-            u8 *q = (u8 *)arena_alloc(c, q_need); if (!q) return NAF_GPU_ENOMEM;
-            size_t qgot = 0;
-            r = zstd_decode_range(c, d_naf + h.payload_off[S_QUAL], h.comp_size[S_QUAL], 0, q, prq ? q_need : qn, &qgot, prq);
-            if (r == NAF_GPU_ECAP && prq) {
-                q = (u8 *)arena_alloc(c, qn + 64); if (!q) return NAF_GPU_ENOMEM;
-                r = zstd_decode(c, d_naf + h.payload_off[S_QUAL], h.comp_size[S_QUAL], 0, q, qn, &qgot); prq = nullptr;
-            }
-            if (r == NAF_GPU_ECAP || (r == 0 && qgot != qn)) return ctx_fail(c, NAF_GPU_EFORMAT, "can't decompress quality\n");
-            if (r) return r;
-            pl.P.qual = (prq && prq->ranged) ? q - prq->got_lo : q;
-        }
         return 0;
     };
+    // qc: the context the quality stream is decoded on (the archive's own, or the second side context beside the sequence stream)
+    auto payload_qual = [&](naf_gpu_ctx *qc) -> int {
+        int r;
+        u64 qn = h.orig_size[S_QUAL];
+        u64 q_need = prq ? (rgq.want_hi - rgq.want_lo) + 2 * 131072 + 64 : qn + 64;
+        if (q_need > qn + 64) q_need = qn + 64;
+        u8 *q = (u8 *)arena_alloc(qc, q_need); if (!q) return NAF_GPU_ENOMEM;
+        size_t qgot = 0;
+        r = zstd_decode_range(qc, d_naf + h.payload_off[S_QUAL], h.comp_size[S_QUAL], 0, q, prq ? q_need : qn, &qgot, prq);
+        if (r == NAF_GPU_ECAP && prq) {
+            q = (u8 *)arena_alloc(qc, qn + 64); if (!q) return NAF_GPU_ENOMEM;
+            r = zstd_decode(qc, d_naf + h.payload_off[S_QUAL], h.comp_size[S_QUAL], 0, q, qn, &qgot); prq = nullptr;
+        }
+        if (r == NAF_GPU_ECAP || (r == 0 && qgot != qn)) return ctx_fail(qc, NAF_GPU_EFORMAT, "can't decompress quality\n");
+        if (r) return r;
+        pl.P.qual = (prq && prq->ranged) ? q - prq->got_lo : q;
+        return 0;
+    };
+    auto payload = [&]() -> int { int r = payload_seq(); if (r) return r; return pl.need_qual ? payload_qual(c) : 0; };
     const char *fuse = getenv("NAF_GPU_FUSE");
     const bool fuse_on = fuse && fuse[0] == '1';
     const char *ser = getenv("NAF_GPU_SERIAL_SECTIONS");
@@ -969,13 +992,23 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         arena_reset(c->side);
         HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->side->stream, c->fork_ev, 0));
-        int rc_side = 0;
-        std::thread th([&] { hipSetDevice(c->device); rc_side = unnaf_sections(c->side, d_naf, pl); });
-        rc = payload();
+        int rc_side = 0, rc_q = 0;
+        const bool qpar = pl.need_qual && c->side2;
+        if (qpar) { arena_reset(c->side2); HIP_TRY(c, hipStreamWaitEvent(c->side2->stream, c->fork_ev, 0)); }
+        if (c->side3) { arena_reset(c->side3); HIP_TRY(c, hipStreamWaitEvent(c->side3->stream, c->fork_ev, 0)); }
+        // no early return between here and the joins
+        std::thread th([&] { hipSetDevice(c->device); rc_side = unnaf_sections(c->side, d_naf, pl, c->side3); });
+        std::thread thq;
+        if (qpar) thq = std::thread([&] { hipSetDevice(c->device); rc_q = payload_qual(c->side2); });
+        rc = payload_seq();
+        if (!rc && pl.need_qual && !qpar) rc = payload_qual(c);
         th.join();
+        if (qpar) thq.join();
         if (rc_side) { memcpy(c->err, c->side->err, sizeof c->err); return rc_side; }   // the order a sequential run reports errors in
         if (rc) return rc;
+        if (rc_q) { memcpy(c->err, c->side2->err, sizeof c->err); return rc_q; }
         HIP_TRY(c, hipStreamSynchronize(c->side->stream));
+        if (qpar) HIP_TRY(c, hipStreamSynchronize(c->side2->stream));
         payload_done = true;
     } else if (pl.P.mode != -1) {
         if ((rc = unnaf_sections(c, d_naf, pl))) return rc;

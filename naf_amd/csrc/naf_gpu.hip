@@ -49,13 +49,17 @@ extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
     if (hipHostMalloc((void **)&c->h_stage, c->h_stage_cap, hipHostMallocDefault) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return NAF_GPU_ENOMEM; }
     int rc = zstd_init_tables(c);
     if (rc) { naf_gpu_shutdown(c); return rc; }
-    // side context: shares the device and the constant tables
-    naf_gpu_ctx *sc = new naf_gpu_ctx();
-    sc->device = device; sc->d_predef = c->d_predef; sc->h_stage_cap = 1 << 16;
-    if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess || hipHostMalloc((void **)&sc->h_stage, sc->h_stage_cap, hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess) { delete sc; naf_gpu_shutdown(c); return NAF_GPU_EHIP; }
-    sc->own_stream = true;
-    c->side = sc;
+    // side contexts: share the device and the constant tables
+    if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess) { naf_gpu_shutdown(c); return NAF_GPU_EHIP; }
+    for (int k = 0; k < 3; k++) {
+        naf_gpu_ctx *sc = new naf_gpu_ctx();
+        sc->device = device; sc->d_predef = c->d_predef; sc->h_stage_cap = 1 << 16;
+        if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess || hipHostMalloc((void **)&sc->h_stage, sc->h_stage_cap, hipHostMallocDefault) != hipSuccess) {
+            delete sc; naf_gpu_shutdown(c); return NAF_GPU_EHIP;
+        }
+        sc->own_stream = true;
+        (k == 0 ? c->side : k == 1 ? c->side2 : c->side3) = sc;
+    }
     *out = c;
     return NAF_GPU_OK;
 }
@@ -65,8 +69,8 @@ extern "C" void naf_gpu_shutdown(naf_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    if (c->side) {
-        naf_gpu_ctx *sc = c->side;
+    for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3 }) {
+        if (!sc) continue;
         hipStreamSynchronize(sc->stream);
         for (auto &ch : sc->chunks) hipFree(ch.base);
         for (auto e : sc->ev_pool) hipEventDestroy(e);
@@ -181,7 +185,7 @@ extern "C" int naf_gpu_set_timing(naf_gpu_ctx *c, int enable)
 {
     if (!c) return NAF_GPU_EARG;
     c->timing = enable != 0; c->ktimes.clear(); c->ev_used = 0;
-    if (c->side) { c->side->timing = c->timing; c->side->ktimes.clear(); c->side->ev_used = 0; }
+    for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3 }) if (sc) { sc->timing = c->timing; sc->ktimes.clear(); sc->ev_used = 0; }
     return 0;
 }
 
@@ -209,10 +213,10 @@ extern "C" int naf_gpu_get_timing(naf_gpu_ctx *c, const char **names, float *ms,
 {
     if (!c) return NAF_GPU_EARG;
     hipStreamSynchronize(c->stream);
-    if (c->side) hipStreamSynchronize(c->side->stream);
+    for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3 }) if (sc) hipStreamSynchronize(sc->stream);
     std::map<std::string, std::pair<float, int>> agg;
     std::vector<std::string> order;
-    for (naf_gpu_ctx *x : { c, c->side }) {
+    for (naf_gpu_ctx *x : { c, c->side, c->side2, c->side3 }) {
         if (!x) continue;
         for (auto &k : x->ktimes) {
             float t = 0; hipEventElapsedTime(&t, k.a, k.b);

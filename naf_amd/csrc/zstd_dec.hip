@@ -19,7 +19,7 @@
 
 struct ZStat {                 // device-side counters read back by the host
     u32 nblk; u32 err; u64 end_off;
-    u32 n_huf_def, n_seq_blk, max_huf_log, pad;
+    u32 n_huf_def, n_seq_blk, max_huf_log, rep_slow;   // rep_slow bit 0: some block's exit repeat offsets depend on its entry state; bit 1: some sequence uses a repeat code
     u32 huf_pool_used, fse_pool_used;
     u64 total_seq, total_out;
     u32 ticket, n_plain_huf;     // n_plain_huf: compressed blocks with Huffman literals and no sequences
@@ -28,33 +28,44 @@ struct ZStat {                 // device-side counters read back by the host
 static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
 static __device__ __forceinline__ u64 shfl_u64(u64 v, int l) { u32 lo = __shfl((u32)v, l, 64), hi = __shfl((u32)(v >> 32), l, 64); return ((u64)hi << 32) | lo; }
 
-#define SCAN_LDS_MAX (60u * 1024u)
+#define SCAN_WIN (48u * 1024u)
+// Serial walk of the block headers (frames too small for the parallel index, or not one well-formed chain).  The header chain
+// is one dependent load per block, so the frame is pulled through LDS a 48 KiB window at a time (coalesced) and walked there.
 __global__ __launch_bounds__(64) void k_scan_blocks(const u8 *src, u64 len, u64 first_off, ZBlock *blk, u32 cap, ZStat *st)
 {
-    // small frames (side streams: many tiny blocks) are walked out of LDS: the header chain is one dependent load per block
-    __shared__ __attribute__((aligned(16))) u8 buf[SCAN_LDS_MAX + 16];
-    const bool in_lds = len <= SCAN_LDS_MAX;
-    if (in_lds) {
-        for (u32 i = threadIdx.x * 16; i < (u32)len; i += 64 * 16) {
-            if (i + 16 <= len) { uint4 v; memcpy(&v, src + i, 16); *(uint4 *)(buf + i) = v; }
-            else for (u32 k = i; k < (u32)len; k++) buf[k] = src[k];
-        }
-    }
+    __shared__ __attribute__((aligned(16))) u8 buf[SCAN_WIN + 16];
+    __shared__ u64 s_pos; __shared__ u32 s_n, s_err, s_done;
+    if (threadIdx.x == 0) { s_pos = first_off; s_n = 0; s_err = 0; s_done = 0; }
     __syncthreads();
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    u64 pos = first_off; u32 n = 0, err = 0;
     for (;;) {
-        if (pos + 3 > len) { err = ZE_TRUNC; break; }
-        u32 h = in_lds ? ((u32)buf[pos] | ((u32)buf[pos + 1] << 8) | ((u32)buf[pos + 2] << 16)) : ld24(src + pos);
-        u32 last = h & 1, type = (h >> 1) & 3, size = h >> 3;
-        if (type == 3 || size > ZBLOCK_MAX) { err = ZE_CORRUPT; break; }
-        u32 csize = type == BT_RLE ? 1 : size;
-        if (pos + 3 + csize > len) { err = ZE_TRUNC; break; }
-        if (n < cap) { ZBlock &b = blk[n]; b.src_off = pos + 3; b.bsize = size; b.btype = (u8)type; b.last = (u8)last; }
-        n++; pos += 3 + csize;
-        if (last) break;
+        const u64 wlo = s_pos;
+        const u32 wn = len - wlo < SCAN_WIN ? (u32)(len > wlo ? len - wlo : 0) : SCAN_WIN;
+        for (u32 i = threadIdx.x * 16; i < wn; i += 64 * 16) {
+            if (i + 16 <= wn) { uint4 v; memcpy(&v, src + wlo + i, 16); *(uint4 *)(buf + i) = v; }
+            else for (u32 k = i; k < wn; k++) buf[k] = src[wlo + k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 pos = wlo; u32 n = s_n, err = 0; bool done = false;
+            for (;;) {
+                if (pos + 3 > len) { err = ZE_TRUNC; done = true; break; }
+                if (pos + 3 > wlo + wn) break;                          // header outside the window: slide
+                u32 o = (u32)(pos - wlo);
+                u32 h = (u32)buf[o] | ((u32)buf[o + 1] << 8) | ((u32)buf[o + 2] << 16);
+                u32 last = h & 1, type = (h >> 1) & 3, size = h >> 3;
+                if (type == 3 || size > ZBLOCK_MAX) { err = ZE_CORRUPT; done = true; break; }
+                u32 csize = type == BT_RLE ? 1 : size;
+                if (pos + 3 + csize > len) { err = ZE_TRUNC; done = true; break; }
+                if (n < cap) { ZBlock &b = blk[n]; b.src_off = pos + 3; b.bsize = size; b.btype = (u8)type; b.last = (u8)last; }
+                n++; pos += 3 + csize;
+                if (last) { done = true; break; }
+            }
+            s_pos = pos; s_n = n; s_err = err; s_done = done ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_done) break;
     }
-    st->nblk = n; st->end_off = pos; st->err = err;
+    if (threadIdx.x == 0) { st->nblk = s_n; st->end_off = s_pos; st->err = s_err; }
 }
 
 // ---- speculative parallel block index -----------------------------------------------------------------------
@@ -280,6 +291,11 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
                              const u64 *seq_base, const FseE *pool, const FseE *predef,
                              u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st)
 {
+    // the predefined tables (what this build's own LZ blocks use) in LDS: the lane's whole job is a chain of dependent table reads
+    __shared__ FseE s_pre[160];
+    for (u32 k = threadIdx.x; k < 160; k += blockDim.x) s_pre[k] = predef[k];
+    __syncthreads();
+    predef = s_pre;
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblk) return;
     ZBlock &b = blk[i];
@@ -301,13 +317,30 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
     u64 base = seq_base[i], sll = 0, sml = 0;
     b.seq_base = base;
     u32 rep_out[3];
+    bool uses_rep = false;
     u8 e = zstd_decode_sequences(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tab,
-                                 o_ll + base, o_ml + base, o_of + base, rep_out, &sll, &sml);
+                                 o_ll + base, o_ml + base, o_of + base, rep_out, &sll, &sml, &uses_rep);
     if (e) { set_err(st, e); b.err = e; return; }
+    if (uses_rep) atomicOr(&st->rep_slow, 2u);
     if (sll > b.lit_regen || b.lit_regen + sml > ZBLOCK_MAX) { set_err(st, ZE_CORRUPT); b.err = ZE_CORRUPT; return; }
     b.rep_out[0] = rep_out[0]; b.rep_out[1] = rep_out[1]; b.rep_out[2] = rep_out[2];
     b.regen = (u32)(b.lit_regen + sml);
     sizes[i] = b.regen;
+}
+
+// Entry repeat offsets of every block with sequences, in parallel: a block that introduces three new offsets leaves a state that
+// does not depend on what it entered with, so its successor just takes it.  Only when some exit state is still symbolic
+// (few sequences in a block) does the serial composition below have to run.
+__global__ void k_rep_fast(ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, ZStat *st)
+{
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seq_blk) return;
+    ZBlock &b = blk[seq_list[t]];
+    if (t == 0) { b.rep_in[0] = 1; b.rep_in[1] = 4; b.rep_in[2] = 8; return; }      // RFC 8878 3.1.1.5
+    const ZBlock &p = blk[seq_list[t - 1]];
+    u32 a = p.rep_out[0], bb = p.rep_out[1], c = p.rep_out[2];
+    if (p.err || sym_is(a) || sym_is(bb) || sym_is(c)) { atomicOr(&st->rep_slow, 1u); return; }
+    b.rep_in[0] = a; b.rep_in[1] = bb; b.rep_in[2] = c;
 }
 
 // One wave: 64 blocks per step are loaded coalesced, then composed lane by lane through shuffles.
@@ -916,12 +949,23 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         o_ll = arena_new<u32>(c, ns); o_ml = arena_new<u32>(c, ns); o_of = arena_new<u32>(c, ns);
         if (!o_ll || !o_ml || !o_of) return NAF_GPU_ENOMEM;
     }
+    u32 *seq_list = nullptr;                                 // indices of the blocks that have sequences, in order
+    if (n_seq_blk) {
+        seq_list = arena_new<u32>(c, n_seq_blk);
+        u64 *flag = arena_new<u64>(c, (size_t)nblk + 1);
+        if (!seq_list || !flag) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zstd_seq_flag", k_seq_flag, g, 64, 0, (const ZBlock *)blk, nblk, flag);
+        if ((rc = scan_exclusive_u64(c, flag, nblk, (u64 *)nullptr))) return rc;
+        LAUNCH(c, "zstd_seq_list", k_seq_list, g, 64, 0, (const ZBlock *)blk, nblk, (const u64 *)flag, seq_list);
+    }
     LAUNCH(c, "zstd_decode_seq", k_decode_seq, g, 64, 0, d_src, blk, nblk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
            (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st);
-    if (n_seq_blk) LAUNCH(c, "zstd_rep_chain", k_rep_chain, 1, 64, 0, blk, nblk);
+    if (n_seq_blk) LAUNCH(c, "zstd_rep_fast", k_rep_fast, cdiv(n_seq_blk, 256), 256, 0, blk, (const u32 *)seq_list, n_seq_blk, st);
     if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
     rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
     if (hs.err) return zerr(c, hs.err, "sequences");
+    // entry states matter only when some sequence of the frame uses a repeat code (this build's own LZ blocks never do)
+    if (n_seq_blk && hs.rep_slow == 3) LAUNCH(c, "zstd_rep_chain", k_rep_chain, 1, 64, 0, blk, nblk);
     *out_len = hs.total_out;
     if (fh.has_fcs && fh.content_size != hs.total_out) return zerr(c, ZE_CORRUPT, "content size mismatch");
     // Range request (multi-GPU sharding): decode only the blocks that feed [want_lo, want_hi).  Needs blocks that
@@ -941,15 +985,11 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         d_dst -= bias;                                       // block b lands at d_dst_orig + (out_off[b] - got_lo)
     } else if (hs.total_out > dst_cap) return ctx_fail(c, NAF_GPU_ECAP, "zstd output needs %llu bytes, capacity %zu", (unsigned long long)hs.total_out, dst_cap);
 
-    u32 *done = nullptr, *seq_list = nullptr; u8 *lit_scratch = nullptr;
+    u32 *done = nullptr; u8 *lit_scratch = nullptr;
     if (n_seq_blk) {
-        done = arena_new<u32>(c, nblk); seq_list = arena_new<u32>(c, n_seq_blk);
+        done = arena_new<u32>(c, nblk);
         lit_scratch = (u8 *)arena_alloc(c, hs.total_out + 16);
-        u64 *flag = arena_new<u64>(c, (size_t)nblk + 1);
-        if (!done || !seq_list || !lit_scratch || !flag) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "zstd_seq_flag", k_seq_flag, g, 64, 0, (const ZBlock *)blk, nblk, flag);
-        if ((rc = scan_exclusive_u64(c, flag, nblk, (u64 *)nullptr))) return rc;
-        LAUNCH(c, "zstd_seq_list", k_seq_list, g, 64, 0, (const ZBlock *)blk, nblk, (const u64 *)flag, seq_list);
+        if (!done || !lit_scratch) return NAF_GPU_ENOMEM;
     }
     LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, done, (u32 *)nullptr, (u32 *)nullptr);
     if (n_huf_def) {
