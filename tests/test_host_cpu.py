@@ -113,6 +113,44 @@ def test_encoder_kernel_logic_roundtrips_through_oracle(emul, oracle):
             assert oracle.zstd_decompress(out.raw[:n], len(d) + 16) == d
 
 
+def test_lz_block_format_against_three_decoders(emul, oracle):
+    """The LZ-coded block layout of the GPU encoder (sequences with predefined FSE tables, new-offset codes only, literals
+    Huffman / raw / RLE), produced here by a serial reference of the same layout: decodable by the from-spec oracle, by the
+    decoder kernels' logic (emul) and -- when this machine has it -- by libzstd itself."""
+    emul.emul_zstd_compress_lz.restype = ctypes.c_longlong
+    emul.emul_zstd_compress_lz.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
+    zlib = None
+    for cand in ("/opt/conda/lib/libzstd.so", "libzstd.so.1"):
+        try:
+            zlib = ctypes.CDLL(cand); break
+        except OSError:
+            pass
+    if zlib is not None:
+        zlib.ZSTD_decompress.restype = ctypes.c_size_t
+        zlib.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    rng = np.random.default_rng(21)
+    data = [b"", b"A", b"abcabcabcabcabc", b"".join(b"SRR%07d.%d length=%d\x00" % (1234567, i, 150) for i in range(1, 6000)),
+            np.full(20000, 150, dtype="<u4").tobytes(), (b"abcdefghij" * 700 + rng.integers(0, 256, 3000, dtype=np.uint8).tobytes()) * 4,
+            b"A" * 40000 + b"CGT" * 9000, rng.integers(0, 4, 50000, dtype=np.uint8).tobytes()]
+    for i in range(40):
+        n = int(rng.integers(1, 30000)); a = int(rng.choice([2, 4, 16, 256]))
+        d = rng.integers(0, a, n, dtype=np.uint8).tobytes()
+        data.append(d[: n // 3] * 3 if i % 2 else d)
+    for d in data:
+        for blk in (256, 4096, 32768):
+            cap = 2 * len(d) + 1024
+            out = ctypes.create_string_buffer(cap)
+            n = emul.emul_zstd_compress_lz(d, len(d), blk, out, cap)
+            assert n > 0, (len(d), blk, n)
+            frame = out.raw[:n]
+            assert oracle.zstd_decompress(frame, len(d) + 16) == d
+            back = ctypes.create_string_buffer(len(d) + 64)
+            assert emul.emul_zstd_decompress_frame(frame, n, back, len(d) + 64) == len(d) and back.raw[:len(d)] == d
+            if zlib is not None:
+                r = zlib.ZSTD_decompress(back, len(d) + 64, frame, n)
+                assert r == len(d) and back.raw[:r] == d
+
+
 def test_decoder_window_reader_at_every_rate_and_alignment(emul):
     """k_huf_literals' sector-window reader (two-sector LDS ring, register-staged prefetch; four sectors above 7-bit codes),
     single-stepped on the host: streams from 1 bit to 11 bits per symbol, every start alignment class, against the plain reader.
