@@ -807,8 +807,7 @@ static int unnaf_prepare(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const 
     int rc = naf_gpu_parse_header(c, d_naf, naf_len, &pl.h); if (rc) return rc;
     const naf_gpu_header &h = pl.h;
     EmitP &P = pl.P; memset(&P, 0, sizeof P);
-    int has_ids = (h.flags >> 5) & 1, has_names = (h.flags >> 4) & 1, has_len = (h.flags >> 3) & 1,
-        has_mask = (h.flags >> 2) & 1, has_data = (h.flags >> 1) & 1, has_qual = h.flags & 1;
+    int has_mask = (h.flags >> 2) & 1, has_data = (h.flags >> 1) & 1, has_qual = h.flags & 1;
     int mode = o->out_type == NAF_OUT_DEFAULT ? (has_qual ? NAF_OUT_FASTQ : NAF_OUT_FASTA) : o->out_type;   // unnaf.c:372-375
     pl.empty = false; pl.total = 0; pl.need_qual = false;
     pl.fourbit = h.seq_type <= NAF_SEQ_RNA;

@@ -133,7 +133,6 @@ __global__ __launch_bounds__(256) void k_spec_find(const u8 *src, u64 len, u32 n
     u64 w0 = 0, w1 = 0, w2 = 0;
     if (base + k0 + 24 <= len) { w0 = ld64(src + base + k0); w1 = ld64(src + base + k0 + 8); w2 = ld64(src + base + k0 + 16); }
     else { u8 t[24]; for (int i = 0; i < 24; i++) t[i] = base + k0 + i < len ? src[base + k0 + i] : 0xFF; w0 = ld64(t); w1 = ld64(t + 8); w2 = ld64(t + 16); }
-#pragma unroll
     for (u32 k = 0; k < 16; k++) {
         if (k0 + k >= w_hi) break;
         u32 sh = 8 * (k & 7);

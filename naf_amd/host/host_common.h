@@ -21,7 +21,7 @@ static const char *prog_name = "naf";
 
 static void msg(const char *format, ...) { va_list a; va_start(a, format); vfprintf(stderr, format, a); va_end(a); }
 static void err(const char *format, ...) { fprintf(stderr, "%s error: ", prog_name); va_list a; va_start(a, format); vfprintf(stderr, format, a); va_end(a); }
-static void warn(const char *format, ...) { fprintf(stderr, "%s warning: ", prog_name); va_list a; va_start(a, format); vfprintf(stderr, format, a); va_end(a); }
+__attribute__((unused)) static void warn(const char *format, ...) { fprintf(stderr, "%s warning: ", prog_name); va_list a; va_start(a, format); vfprintf(stderr, format, a); va_end(a); }
 __attribute__((noreturn)) static void die(const char *format, ...)
 {
     fprintf(stderr, "%s error: ", prog_name);
@@ -78,7 +78,7 @@ static void write_from_device(FILE *f, const void *d, size_t n)
     }
 }
 /* Regular file of known size straight into device memory; returns NULL when the size is not known up front (pipes). */
-static void *read_to_device(FILE *f, size_t *len)
+__attribute__((unused)) static void *read_to_device(FILE *f, size_t *len)
 {
     if (f == stdin || fseek(f, 0, SEEK_END) != 0) return NULL;
     long sz = ftell(f); rewind(f);
