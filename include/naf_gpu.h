@@ -74,6 +74,9 @@ int  naf_gpu_upload(naf_gpu_ctx *ctx, void *d_dst, const void *h_src, size_t byt
 int  naf_gpu_download(naf_gpu_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* returns after completion */
 int  naf_gpu_download_async(naf_gpu_ctx *ctx, void *h_pinned_dst, const void *d_src, size_t bytes);   /* async on the stream; pair with naf_gpu_synchronize */
 
+/* Byte histogram of a device buffer (unnaf --charcount over the --seq text, output.c:515-605). */
+int  naf_gpu_histogram(naf_gpu_ctx *ctx, const void *d_buf, size_t n, uint64_t counts[256]);
+
 /* ---- zstd ----------------------------------------------------------------------------------------- */
 /* Decode one or more concatenated zstd frames (RFC 8878, no dictionaries) resident in HBM.
  * has_magic = 0: the first frame lacks its 4-byte magic, exactly as stored inside a .naf section

@@ -1110,3 +1110,30 @@ extern "C" int naf_gpu_unnaf_range(naf_gpu_ctx *c, const void *d_naf, size_t naf
 {
     return unnaf_run(c, (const u8 *)d_naf, naf_len, o, out_begin, out_end, false, (u8 *)d_out, out_cap, out_len, false);
 }
+
+// ---- byte histogram (unnaf --charcount, output.c:515-605) ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_histogram(const u8 *p, u64 n, unsigned long long *counts)
+{
+    __shared__ u32 h[4][256];                                     // one copy per wavefront: fewer same-address LDS atomics
+    for (u32 i = threadIdx.x; i < 1024; i += 256) ((u32 *)h)[i] = 0;
+    __syncthreads();
+    u32 *my = h[threadIdx.x >> 6];
+    const u64 per = 65536;                                       // bytes per workgroup
+    u64 lo = (u64)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (u64 i = lo + (u64)threadIdx.x * 8; i < hi; i += 256 * 8) {
+        if (i + 8 <= hi) { u64 w = ld64(p + i); for (int k = 0; k < 8; k++) atomicAdd(&my[(w >> (8 * k)) & 0xFF], 1u); }
+        else for (u64 k = i; k < hi; k++) atomicAdd(&my[p[k]], 1u);
+    }
+    __syncthreads();
+    u32 v = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+    if (v) atomicAdd(&counts[threadIdx.x], (unsigned long long)v);
+}
+extern "C" int naf_gpu_histogram(naf_gpu_ctx *c, const void *d_buf, size_t n, uint64_t counts[256])
+{
+    if (!c || !counts || (!d_buf && n)) return NAF_GPU_EARG;
+    arena_reset(c);
+    unsigned long long *d = arena_new<unsigned long long>(c, 256); if (!d) return NAF_GPU_ENOMEM;
+    HIP_TRY(c, hipMemsetAsync(d, 0, 256 * 8, c->stream));
+    if (n) LAUNCH(c, "histogram", k_histogram, cdiv(n, 65536), 256, 0, (const u8 *)d_buf, (u64)n, d);
+    return ctx_readback(c, counts, d, 256 * 8);
+}

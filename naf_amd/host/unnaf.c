@@ -110,17 +110,7 @@ static void run_text(int mode, int masking_allowed)
     phase("size + output allocation");
     size_t got = 0; GPU_TRY(naf_gpu_unnaf(gpu, d_naf, naf_len, &o, d, n, &got));
     GPU_TRY(naf_gpu_synchronize(gpu)); phase("unnaf on the GPU");
-    if (mode != -2) { write_from_device(OUT, d, got); phase("download + write"); naf_gpu_free(gpu, d); return; }
-    void *h; GPU_TRY(naf_gpu_host_alloc(gpu, got ? got : 1, &h));
-    GPU_TRY(naf_gpu_download(gpu, h, d, got));
-    if (mode == -2) {                                   /* --charcount (output.c:515-605) */
-        unsigned long long counts[256] = {0}; const unsigned char *p = (const unsigned char *)h;
-        for (size_t i = 0; i < got; i++) counts[p[i]]++;
-        for (unsigned i = 0; i < 33; i++) if (counts[i]) fprintf(OUT, "\\x%02X\t%llu\n", i, counts[i]);
-        for (unsigned i = 33; i < 127; i++) if (counts[i]) fprintf(OUT, "%c\t%llu\n", (unsigned char)i, counts[i]);
-        for (unsigned i = 127; i < 256; i++) if (counts[i]) fprintf(OUT, "\\x%02X\t%llu\n", i, counts[i]);
-    } else if (fwrite(h, 1, got, OUT) != got) die("can't write to file - disk full?\n");
-    naf_gpu_host_free(gpu, h); naf_gpu_free(gpu, d);
+    write_from_device(OUT, d, got); phase("download + write"); naf_gpu_free(gpu, d);
 }
 
 int main(int argc, char **argv)
@@ -209,12 +199,12 @@ int main(int argc, char **argv)
         else if (out_type == CHARCOUNT) { if (has_data) { /* histogram of the --seq text */ naf_gpu_unnaf_opts dummy; (void)dummy; upload(); 
                 naf_gpu_unnaf_opts o = { NAF_OUT_SEQ, use_mask, -1 }; size_t n = 0; GPU_TRY(naf_gpu_unnaf_size(gpu, d_naf, naf_len, &o, &n));
                 void *d; GPU_TRY(naf_gpu_malloc(gpu, n + 64, &d)); size_t got = 0; GPU_TRY(naf_gpu_unnaf(gpu, d_naf, naf_len, &o, d, n, &got));
-                unsigned char *h = (unsigned char *)malloc(got + 1); GPU_TRY(naf_gpu_download(gpu, h, d, got));
-                unsigned long long counts[256] = {0}; for (size_t i = 0; i < got; i++) counts[h[i]]++;
+                uint64_t cnt64[256]; GPU_TRY(naf_gpu_histogram(gpu, d, got, cnt64));
+                unsigned long long counts[256]; for (unsigned i = 0; i < 256; i++) counts[i] = cnt64[i];
                 for (unsigned i = 0; i < 33; i++) if (counts[i]) fprintf(OUT, "\\x%02X\t%llu\n", i, counts[i]);
                 for (unsigned i = 33; i < 127; i++) if (counts[i]) fprintf(OUT, "%c\t%llu\n", (unsigned char)i, counts[i]);
                 for (unsigned i = 127; i < 256; i++) if (counts[i]) fprintf(OUT, "\\x%02X\t%llu\n", i, counts[i]);
-                free(h); naf_gpu_free(gpu, d); } }
+                naf_gpu_free(gpu, d); } }
         else if (out_type == SEQUENCES) run_text(NAF_OUT_SEQUENCES, 1);
         else if (out_type == FASTA || out_type == MASKED_FASTA) run_text(NAF_OUT_FASTA, 1);
         else if (out_type == UNMASKED_FASTA) run_text(NAF_OUT_FASTA, 0);
