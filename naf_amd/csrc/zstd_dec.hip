@@ -23,6 +23,7 @@ struct ZStat {                 // device-side counters read back by the host
     u32 huf_pool_used, fse_pool_used;
     u64 total_seq, total_out;
     u32 ticket, n_plain_huf;     // n_plain_huf: compressed blocks with Huffman literals and no sequences
+    u32 max_seq_regen, pad2;      // largest regenerated size among the blocks that have sequences
 };
 
 static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
@@ -325,6 +326,7 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
     b.rep_out[0] = rep_out[0]; b.rep_out[1] = rep_out[1]; b.rep_out[2] = rep_out[2];
     b.regen = (u32)(b.lit_regen + sml);
     sizes[i] = b.regen;
+    atomicMax(&st->max_seq_regen, b.regen);
 }
 
 // Entry repeat offsets of every block with sequences, in parallel: a block that introduces three new offsets leaves a state that
@@ -821,6 +823,103 @@ __global__ __launch_bounds__(64) void k_exec_seq(const ZBlock *blk, const u32 *s
     }
 }
 
+// Same job for frames whose blocks regenerate at most EXEC_LDS bytes each (this build's LZ-coded streams: 16 KiB blocks): the
+// block is assembled in LDS, where a match that reads what the previous sequence wrote costs a barrier instead of a
+// round trip through L2, and leaves as one coalesced copy.  Sequences are taken 64 at a time: every lane places the literals
+// of one sequence (their positions are a prefix sum), then the matches run in order.
+#define EXEC_LDS 16384u
+__device__ __forceinline__ u32 wave_excl_sum(u32 v, u32 *total)
+{
+    u32 x = v;
+    for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)x, d, 64); if ((int)(threadIdx.x & 63) >= d) x += y; }
+    *total = (u32)__shfl((int)x, 63, 64);
+    return x - v;
+}
+__global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *offs, u32 nblk,
+                                                      const u32 *o_ll, const u32 *o_ml, const u32 *o_of,
+                                                      const u8 *lit_scratch, u8 *dst, u32 *done, ZStat *st)
+{
+    __shared__ __attribute__((aligned(16))) u8 obuf[EXEC_LDS + 64];
+    __shared__ u32 sh_ticket;
+    const u32 lane = threadIdx.x;
+    if (lane == 0) sh_ticket = atomicAdd(&st->ticket, 1u);
+    __syncthreads();
+    u32 t = sh_ticket;
+    if (t >= n_seq_blk) return;
+    u32 bi = seq_list[t];
+    const ZBlock &b = blk[bi];
+    const u64 out_off = b.out_off;
+    const u8 *lits = lit_scratch + out_off;
+    u32 rep_in[3] = { b.rep_in[0], b.rep_in[1], b.rep_in[2] };
+    const u64 sbase = b.seq_base;
+    u32 op = 0, lp = 0, nseq = b.err ? 0 : b.nseq, lo_idx = bi;
+    bool bad = b.regen > EXEC_LDS;
+    for (u32 s0 = 0; s0 < nseq && !bad; s0 += 64) {
+        u32 n = nseq - s0 < 64 ? nseq - s0 : 64;
+        u32 ll = 0, ml = 0, of = 0;
+        if (lane < n) { ll = o_ll[sbase + s0 + lane]; ml = o_ml[sbase + s0 + lane]; of = sym_resolve(o_of[sbase + s0 + lane], rep_in); }
+        u32 tot_all, tot_ll;
+        u32 my_op = op + wave_excl_sum(ll + ml, &tot_all), my_lp = lp + wave_excl_sum(ll, &tot_ll);
+        if (op + tot_all > b.regen || lp + tot_ll > b.lit_regen) { bad = true; break; }
+        // literals: short runs by their own lane, long ones by the whole wave
+        if (ll <= 32) for (u32 k = 0; k < ll; k++) obuf[my_op + k] = lits[my_lp + k];
+        u64 big = __ballot(ll > 32);
+        while (big) {
+            int j = __ffsll((long long)big) - 1; big &= big - 1;
+            u32 l = (u32)__shfl((int)ll, j, 64), o = (u32)__shfl((int)my_op, j, 64), p = (u32)__shfl((int)my_lp, j, 64);
+            for (u32 k = lane; k < l; k += 64) obuf[o + k] = lits[p + k];
+        }
+        __syncthreads();
+        for (u32 j = 0; j < n; j++) {
+            u32 mlj = (u32)__shfl((int)ml, (int)j, 64), ofj = (u32)__shfl((int)of, (int)j, 64);
+            u32 d = (u32)__shfl((int)(my_op + ll), (int)j, 64);
+            u64 pos_abs = out_off + d;
+            if (ofj == 0 || ofj > pos_abs) { bad = true; break; }                     // reaches before the frame start
+            if (ofj <= d) {                                                            // source inside this block: LDS to LDS
+                const u8 *from = obuf + d - ofj;
+                if (ofj >= mlj) { for (u32 k = lane; k < mlj; k += 64) obuf[d + k] = from[k]; }
+                else            { for (u32 k = lane; k < mlj; k += 64) obuf[d + k] = from[k % ofj]; }
+            } else {
+                // source (partly) in earlier blocks: confirm every block from the one holding it up to this one, then read HBM
+                u64 src_abs = pos_abs - ofj;
+                u32 lo = 0, hi = lo_idx;
+                while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (offs[mid] <= src_abs) lo = mid; else hi = mid; }
+                for (u32 q = lo_idx; q-- > lo;) wait_block_done(done, q);
+                if (lo < lo_idx) lo_idx = lo;
+                u32 outside = (u32)(out_off - src_abs);                                // bytes of the pattern that lie before this block
+                for (u32 k = lane; k < mlj; k += 64) {
+                    u32 r = ofj >= mlj ? k : k % ofj;
+                    obuf[d + k] = r < outside ? dst[src_abs + r] : obuf[r - outside];
+                }
+            }
+            __syncthreads();
+        }
+        op += tot_all; lp += tot_ll;
+    }
+    if (!bad && !b.err) {
+        u32 rest = b.lit_regen - lp;
+        if (op + rest != b.regen) bad = true;
+        else for (u32 k = lane; k < rest; k += 64) obuf[op + k] = lits[lp + k];
+    }
+    __syncthreads();
+    if (!bad && !b.err) {
+        u8 *out = dst + out_off; u32 nb = b.regen;
+        u32 head = (u32)((16 - ((uintptr_t)out & 15)) & 15); if (head > nb) head = nb;
+        if (lane < head) out[lane] = obuf[lane];
+        u32 words = (nb - head) >> 4;
+        for (u32 w = lane; w < words; w += 64) { uint4 v; memcpy(&v, obuf + head + 16 * w, 16); *(uint4 *)(out + head + 16 * w) = v; }
+        for (u32 k = head + 16 * words + lane; k < nb; k += 64) out[k] = obuf[k];
+    }
+    if (bad && lane == 0) set_err(st, ZE_CORRUPT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&done[bi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // Blocks whose regenerated bytes intersect [want_lo, want_hi): first block index, one-past-last, and their byte span.
 __global__ void k_find_range(const u64 *offs, u32 nblk, u64 total, u64 want_lo, u64 want_hi, const i32 *own_huf, u64 *out4)
 {
@@ -963,6 +1062,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
     rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
     if (hs.err) return zerr(c, hs.err, "sequences");
+    const u32 max_seq_regen = hs.max_seq_regen;
     // entry states matter only when some sequence of the frame uses a repeat code (this build's own LZ blocks never do)
     if (n_seq_blk && hs.rep_slow == 3) LAUNCH(c, "zstd_rep_chain", k_rep_chain, 1, 64, 0, blk, nblk);
     *out_len = hs.total_out;
@@ -1012,9 +1112,15 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg);
     }
     if (b_count && !fuse) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
-    if (n_seq_blk)
-        LAUNCH(c, "zstd_exec_seq", k_exec_seq, n_seq_blk, 64, 0, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
-               (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st);
+    if (n_seq_blk) {
+        const char *el = getenv("NAF_GPU_EXEC_LDS");                      // "0": always the HBM executor (cross-check)
+        if (max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
+            LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, n_seq_blk, 64, 0, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
+                   (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st);
+        else
+            LAUNCH(c, "zstd_exec_seq", k_exec_seq, n_seq_blk, 64, 0, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
+                   (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st);
+    }
     rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
     if (hs.err) return zerr(c, hs.err, "block decode");
     return 0;

@@ -29,8 +29,12 @@ def host(t):
     return t.cpu().numpy().tobytes()
 
 
+@pytest.mark.parametrize("executor", ["auto", "hbm"])
 @pytest.mark.parametrize("case", zstd_cases(), ids=lambda c: c["name"])
-def test_zstd_decode_golden_frames(gpu, case):
+def test_zstd_decode_golden_frames(gpu, case, executor, monkeypatch):
+    """libzstd-made frames (every level, long windows, multi-threaded, streaming): frames whose blocks regenerate at most 16 KiB
+    run their sequences in the LDS executor, the others in the HBM executor; "hbm" forces the latter for every frame."""
+    monkeypatch.setenv("NAF_GPU_EXEC_LDS", "0" if executor == "hbm" else "1")
     frame = golden_bytes("zstd", case["name"] + ".zst")
     out = gpu.zstd_decompress(gpu.to_device(frame), case["len"] + 64)
     got = host(out)

@@ -96,7 +96,10 @@ def test_zstd_compress_lz_roundtrip(gpu, oracle, block_log, monkeypatch):
         fb = host(frame)
         assert len(fb) <= len(plain), name
         assert oracle.zstd_decompress(fb, len(d) + 16) == d, name
-        assert host(gpu.zstd_decompress(frame, len(d) + 64)) == d, name
+        assert host(gpu.zstd_decompress(frame, len(d) + 64)) == d, name     # LDS sequence executor (blocks <= 16 KiB)
+        monkeypatch.setenv("NAF_GPU_EXEC_LDS", "0")
+        assert host(gpu.zstd_decompress(frame, len(d) + 64)) == d, name     # HBM sequence executor
+        monkeypatch.setenv("NAF_GPU_EXEC_LDS", "1")
         if zlib is not None:
             out = ctypes.create_string_buffer(len(d) + 64)
             r = zlib.ZSTD_decompress(out, len(d) + 64, fb, len(fb))
