@@ -330,18 +330,29 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
 }
 
 // Entry repeat offsets of every block with sequences, in parallel: a block that introduces three new offsets leaves a state that
-// does not depend on what it entered with, so its successor just takes it.  Only when some exit state is still symbolic
-// (few sequences in a block) does the serial composition below have to run.
+// does not depend on what it entered with, so its successor just takes it; a symbolic exit state (few sequences in a block) is
+// resolved by substituting the predecessors' exit states one after the other.  The serial composition below remains as the
+// fallback for frames with errors in them.
 __global__ void k_rep_fast(ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, ZStat *st)
 {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_seq_blk) return;
     ZBlock &b = blk[seq_list[t]];
-    if (t == 0) { b.rep_in[0] = 1; b.rep_in[1] = 4; b.rep_in[2] = 8; return; }      // RFC 8878 3.1.1.5
-    const ZBlock &p = blk[seq_list[t - 1]];
-    u32 a = p.rep_out[0], bb = p.rep_out[1], c = p.rep_out[2];
-    if (p.err || sym_is(a) || sym_is(bb) || sym_is(c)) { atomicOr(&st->rep_slow, 1u); return; }
-    b.rep_in[0] = a; b.rep_in[1] = bb; b.rep_in[2] = c;
+    // walk back over the predecessors, substituting their exit states into what is still symbolic: stops at the first block
+    // that leaves a fully concrete state (almost always the immediate predecessor) or at the start of the frame (1, 4, 8)
+    u32 cur[3] = { sym_make(0, 0), sym_make(1, 0), sym_make(2, 0) };
+    for (u32 p = t; sym_is(cur[0]) || sym_is(cur[1]) || sym_is(cur[2]);) {
+        u32 prev[3];
+        if (p == 0) { prev[0] = 1; prev[1] = 4; prev[2] = 8; }                     // RFC 8878 3.1.1.5: everything resolves here
+        else { const ZBlock &q = blk[seq_list[--p]]; if (q.err) { atomicOr(&st->rep_slow, 1u); return; } prev[0] = q.rep_out[0]; prev[1] = q.rep_out[1]; prev[2] = q.rep_out[2]; }
+        for (int k = 0; k < 3; k++) {
+            if (!sym_is(cur[k])) continue;
+            u32 slot = (cur[k] >> 29) & 3, delta = cur[k] & 0x1FFFFFFFu, v = prev[slot];
+            if (sym_is(v)) cur[k] = v + delta;                                      // still symbolic: deltas add up
+            else { u32 r = v - delta; cur[k] = r ? r : 1; }
+        }
+    }
+    b.rep_in[0] = cur[0]; b.rep_in[1] = cur[1]; b.rep_in[2] = cur[2];
 }
 
 // One wave: 64 blocks per step are loaded coalesced, then composed lane by lane through shuffles.
@@ -1064,7 +1075,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     if (hs.err) return zerr(c, hs.err, "sequences");
     const u32 max_seq_regen = hs.max_seq_regen;
     // entry states matter only when some sequence of the frame uses a repeat code (this build's own LZ blocks never do)
-    if (n_seq_blk && hs.rep_slow == 3) LAUNCH(c, "zstd_rep_chain", k_rep_chain, 1, 64, 0, blk, nblk);
+    if (n_seq_blk && (hs.rep_slow & 1)) LAUNCH(c, "zstd_rep_chain", k_rep_chain, 1, 64, 0, blk, nblk);
     *out_len = hs.total_out;
     if (fh.has_fcs && fh.content_size != hs.total_out) return zerr(c, ZE_CORRUPT, "content size mismatch");
     // Range request (multi-GPU sharding): decode only the blocks that feed [want_lo, want_hi).  Needs blocks that
