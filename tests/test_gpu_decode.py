@@ -89,6 +89,30 @@ def test_unnaf_matches_reference_outputs(gpu, case, path, monkeypatch):
         assert sha(got) == exp["sha256"], m
 
 
+def test_unnaf_survives_corrupt_sections(gpu, oracle):
+    """A damaged section must come back as an error (or, when the damage happens to decode, as some text) -- never a crash or a
+    hang; the side streams are decoded by helper host threads, so this also walks their error paths."""
+    from naf_amd.capi import NafGpuError
+    rng = np.random.default_rng(8)
+    for name in ("mixed_60", "fastq_4k"):
+        naf = bytearray(golden_bytes("naf", name + ".naf"))
+        h = oracle.parse_naf(bytes(naf))
+        for i in range(6):
+            if h.payload_off[i] is None or h.comp[i] < 8:
+                continue
+            for trial in range(6):
+                bad = bytearray(naf)
+                pos = h.payload_off[i] + int(rng.integers(0, h.comp[i]))
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+                if trial == 5:
+                    bad = bad[: h.payload_off[i] + h.comp[i] // 2]                # truncated inside the section
+                for mode in (-1, 2):
+                    try:
+                        gpu.unnaf(gpu.to_device(bytes(bad)), mode)
+                    except NafGpuError:
+                        pass
+
+
 def test_unnaf_reference_suite(gpu, oracle):
     """The reference's own tests: oracle-made archive -> GPU unnaf == *.out-ref."""
     from conftest import ref_cases
