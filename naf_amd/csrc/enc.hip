@@ -452,6 +452,22 @@ __device__ __forceinline__ i64 thread_ord(const EncP &P, const u64 *t_ls, u64 ba
     return (i64)(t_ls[blockIdx.x] + incl - nls) - 1;
 }
 
+struct SlowCtx { i64 le, ls, ord; };
+// slow lanes -> dense list (ballot compaction per wave, wave offsets through LDS); also parks each slow lane's context in LDS
+__device__ __forceinline__ void slow_gather(bool slow, const TileCtx &ctx, SlowCtx *s_ctx, u16 *s_list, u32 *s_n)
+{
+    __shared__ u32 wn[4];
+    u64 bal = __ballot(slow);
+    u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 idx = (u32)__popcll(bal & ((1ull << lane) - 1));
+    if (lane == 0) wn[wave] = (u32)__popcll(bal);
+    __syncthreads();
+    for (u32 w = 0; w < wave; w++) idx += wn[w];
+    if (slow) { s_list[idx] = (u16)threadIdx.x; s_ctx[threadIdx.x].le = ctx.last_eol; s_ctx[threadIdx.x].ls = ctx.last_sp; s_ctx[threadIdx.x].ord = ctx.ord; }
+    if (threadIdx.x == 0) *s_n = wn[0] + wn[1] + wn[2] + wn[3];
+    __syncthreads();
+}
+
 // A full piece in the middle of a read's sequence line (returns 1) or quality line (3) with nothing to drop or replace; else 0.
 __device__ __forceinline__ int fq_piece(const EncP &P, u64 base, const Piece &pc, const PMask &pm, const TileCtx &ctx)
 {
@@ -478,7 +494,22 @@ __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol,
     FqCount S;
     int fast = fq_piece(P, base, pc, pm, ctx);
     if (fast == 1) S.nseq = 16; else if (fast == 3) S.nqual = 16;
-    else if (base <= P.n) classify_range_fastq(P, base, pc, (base + pc.cnt == P.n) && pc.cnt < ET_BYTES, ctx, S, cls);
+    // The other pieces (headers, line ends: about a quarter of them in 150-bp reads) need the per-byte state machine.  They
+    // are gathered and handled by the first lanes of the workgroup, so that one wavefront walks the slow path instead of all four.
+    __shared__ SlowCtx s_ctx[256]; __shared__ u16 s_list[256]; __shared__ u32 s_nslow; __shared__ u64 s_cnt[256];
+    const bool slow = !fast && base <= P.n;
+    slow_gather(slow, ctx, s_ctx, s_list, &s_nslow);
+    if (threadIdx.x < s_nslow) {
+        u32 who = s_list[threadIdx.x];
+        u64 b2 = (u64)blockIdx.x * ET_TILE + (u64)who * ET_BYTES;
+        Piece p2 = load_piece(P, b2);
+        TileCtx c2; c2.last_eol = s_ctx[who].le; c2.last_sp = s_ctx[who].ls; c2.hdr = false; c2.ord = s_ctx[who].ord;
+        FqCount S2;
+        classify_range_fastq(P, b2, p2, (b2 + p2.cnt == P.n) && p2.cnt < ET_BYTES, c2, S2, cls);
+        s_cnt[who] = (u64)S2.nseq | ((u64)S2.nids << 16) | ((u64)S2.ncmt << 32) | ((u64)S2.nqual << 48);
+    }
+    __syncthreads();
+    if (slow) { u64 v = s_cnt[threadIdx.x]; S.nseq = v & 0xFFFF; S.nids = (v >> 16) & 0xFFFF; S.ncmt = (v >> 32) & 0xFFFF; S.nqual = (u32)(v >> 48); }
     u64 tot;
     wg_scan_inclusive<u64, OpAdd>((u64)S.nseq | ((u64)S.nids << 16) | ((u64)S.ncmt << 32) | ((u64)S.nqual << 48), &tot, lds);
     if (threadIdx.x == 0) { t_seq[blockIdx.x] = tot & 0xFFFF; t_ids[blockIdx.x] = (tot >> 16) & 0xFFFF; t_cmt[blockIdx.x] = (tot >> 32) & 0xFFFF; t_qual[blockIdx.x] = tot >> 48; }
@@ -499,7 +530,21 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
     FqCount C;
     const int fast = fq_piece(P, base, pc, pm, ctx);
     if (fast == 1) C.nseq = 16; else if (fast == 3) C.nqual = 16;
-    else if (active) classify_range_fastq(P, base, pc, eof_here, ctx, C, cls);
+    __shared__ SlowCtx s_ctx[256]; __shared__ u16 s_list[256]; __shared__ u32 s_nslow; __shared__ u64 s_cnt[256];
+    __shared__ u64 s_w[256][4];                                   // stream positions of the slow pieces for the write pass
+    const bool slow = !fast && active;
+    slow_gather(slow, ctx, s_ctx, s_list, &s_nslow);
+    if (threadIdx.x < s_nslow) {
+        u32 who = s_list[threadIdx.x];
+        u64 b2 = (u64)blockIdx.x * ET_TILE + (u64)who * ET_BYTES;
+        Piece p2 = load_piece(P, b2);
+        TileCtx c2; c2.last_eol = s_ctx[who].le; c2.last_sp = s_ctx[who].ls; c2.hdr = false; c2.ord = s_ctx[who].ord;
+        FqCount S2;
+        classify_range_fastq(P, b2, p2, (b2 + p2.cnt == P.n) && p2.cnt < ET_BYTES, c2, S2, cls);
+        s_cnt[who] = (u64)S2.nseq | ((u64)S2.nids << 16) | ((u64)S2.ncmt << 32) | ((u64)S2.nqual << 48);
+    }
+    __syncthreads();
+    if (slow) { u64 v = s_cnt[threadIdx.x]; C.nseq = v & 0xFFFF; C.nids = (v >> 16) & 0xFFFF; C.ncmt = (v >> 32) & 0xFFFF; C.nqual = (u32)(v >> 48); }
     u64 totp;
     u64 ip = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq | ((u64)C.nids << 16) | ((u64)C.ncmt << 32) | ((u64)C.nqual << 48), &totp, lds);
     u64 iseq = ip & 0xFFFF, iids = (ip >> 16) & 0xFFFF, icmt = (ip >> 32) & 0xFFFF, iq = ip >> 48, tots = totp & 0xFFFF, totq = totp >> 48;
@@ -509,7 +554,17 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
     W.bcmt = O.t_cmt[blockIdx.x] + icmt - C.ncmt; W.bqual = O.t_qual[blockIdx.x] + iq - C.nqual;
     if (fast == 1) lds_store_n(sstage + (W.bseq - W.sbase), pc.w0, pc.w1, 16);
     else if (fast == 3) lds_store_n(qstage + (W.bqual - W.qbase), pc.w0, pc.w1, 16);
-    else if (active) classify_range_fastq(P, base, pc, eof_here, ctx, W, cls);
+    else if (slow) { s_w[threadIdx.x][0] = W.bseq; s_w[threadIdx.x][1] = W.bids; s_w[threadIdx.x][2] = W.bcmt; s_w[threadIdx.x][3] = W.bqual; }
+    __syncthreads();
+    if (threadIdx.x < s_nslow) {                                  // write pass of the slow pieces, again by the first lanes
+        u32 who = s_list[threadIdx.x];
+        u64 b2 = (u64)blockIdx.x * ET_TILE + (u64)who * ET_BYTES;
+        Piece p2 = load_piece(P, b2);
+        TileCtx c2; c2.last_eol = s_ctx[who].le; c2.last_sp = s_ctx[who].ls; c2.hdr = false; c2.ord = s_ctx[who].ord;
+        FqWrite W2(O); W2.sstage = sstage; W2.qstage = qstage; W2.sbase = W.sbase; W2.qbase = W.qbase;
+        W2.bseq = s_w[who][0]; W2.bids = s_w[who][1]; W2.bcmt = s_w[who][2]; W2.bqual = s_w[who][3];
+        classify_range_fastq(P, b2, p2, (b2 + p2.cnt == P.n) && p2.cnt < ET_BYTES, c2, W2, cls);
+    }
     __syncthreads();
     flush_tile(O.seq + W.sbase, sstage, (u32)tots);
     flush_tile(O.qual + W.qbase, qstage, (u32)totq);
