@@ -54,7 +54,10 @@ extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
     for (int k = 0; k < 3; k++) {
         naf_gpu_ctx *sc = new naf_gpu_ctx();
         sc->device = device; sc->d_predef = c->d_predef; sc->h_stage_cap = 1 << 16;
-        if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess || hipHostMalloc((void **)&sc->h_stage, sc->h_stage_cap, hipHostMallocDefault) != hipSuccess) {
+        // highest priority: the side chains are many tiny kernels; behind the payload's bulk kernels they would only be scheduled
+        // once those drain, and the call would end up waiting for them
+        int prio_lo = 0, prio_hi = 0; hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (hipStreamCreateWithPriority(&sc->stream, hipStreamNonBlocking, prio_hi) != hipSuccess || hipHostMalloc((void **)&sc->h_stage, sc->h_stage_cap, hipHostMallocDefault) != hipSuccess) {
             delete sc; naf_gpu_shutdown(c); return NAF_GPU_EHIP;
         }
         sc->own_stream = true;
