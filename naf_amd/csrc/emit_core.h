@@ -46,7 +46,7 @@ __device__ __forceinline__ void expand16(const u32 lut[4], u64 nib, u64 &lo, u64
         u32 sel = z & 0x07070707;
         u32 l = __builtin_amdgcn_perm(lut[1], lut[0], sel);     // codes 0..7
         u32 h = __builtin_amdgcn_perm(lut[3], lut[2], sel);     // codes 8..15
-        u32 m = ((z >> 3) & 0x01010101) * 0xFF;
+        u32 b3 = (z >> 3) & 0x01010101, m = (b3 << 8) - b3;          // 0xFF in the bytes whose code is >= 8 (a multiply by 0xFF is quarter rate)
         out[w] = (l & ~m) | (h & m);
     }
     lo = (u64)out[0] | ((u64)out[1] << 32); hi = (u64)out[2] | ((u64)out[3] << 32);
