@@ -658,9 +658,8 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
 #pragma unroll
                         for (u32 q = 0; q < 8; q++) {
                             u32 e = tab[(u32)(w >> 32) >> (32 - log)];
-                            u32 nb = e >> 8;
-                            w <<= nb; bits += nb;
-                            acc |= (u64)(e & 0xFF) << (8 * q);
+                            w <<= (e & 63); bits += hufe_nb(e);           // nbits <= 11: the shift reads it straight from the entry
+                            acc |= (u64)hufe_sym(e) << (8 * q);
                         }
                         accs[g] = acc;
                     }
@@ -677,9 +676,8 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
 #pragma unroll
                             for (u32 q = 0; q < 4; q++) {
                                 u32 e = huf_look(tab, (u32)(w >> 32) >> (32 - log), log);
-                                u32 nb = e >> 8;
-                                w <<= nb; bits += nb;
-                                acc |= (u64)(e & 0xFF) << (8 * (4 * h + q));
+                                w <<= (e & 63); bits += hufe_nb(e);
+                                acc |= (u64)hufe_sym(e) << (8 * (4 * h + q));
                             }
                         }
                         accs[g] = acc;

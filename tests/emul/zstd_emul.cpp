@@ -180,8 +180,8 @@ extern "C" int emul_window_reader(const u8 *stream, u32 size, const u8 *weights,
                 u64 q0, q1; memcpy(&q0, irow + (o & ~7u), 8); memcpy(&q1, irow + (((o & ~7u) + 8) & rmask), 8);
                 u64 w = (sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0) << bits;
                 for (u32 q = 0; q < (big ? 4u : 8u); q++) {
-                    u32 e = huf_look(tab, (u32)(w >> 32) >> (32 - log), log); u32 nb = e >> 8; w <<= nb; bits += nb;
-                    out[R * HUF_ROUND + g * 8 + (big ? 4 * h : 0) + q] = (u8)e;
+                    u32 e = huf_look(tab, (u32)(w >> 32) >> (32 - log), log); u32 nb = hufe_nb(e); w <<= nb; bits += nb;
+                    out[R * HUF_ROUND + g * 8 + (big ? 4 * h : 0) + q] = (u8)hufe_sym(e);
                 }
             }
         }
