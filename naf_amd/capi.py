@@ -75,6 +75,7 @@ def load():
         L.naf_gpu_set_stream.argtypes = [vp, vp]
         L.naf_gpu_synchronize.argtypes = [vp]
         L.naf_gpu_reserve.argtypes = [vp, sz]
+        L.naf_gpu_histogram.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64)]
         L.naf_gpu_zstd_decompress.argtypes = [vp, vp, sz, i, vp, sz, C.POINTER(sz)]
         L.naf_gpu_parse_header.argtypes = [vp, vp, sz, C.POINTER(Header)]
         L.naf_gpu_parse_header_host.argtypes = [C.c_char_p, sz, C.POINTER(Header), C.c_char_p]
@@ -188,6 +189,12 @@ class Context:
         n = C.c_size_t()
         self._check(self.L.naf_gpu_unnaf_range(self.h, _ptr(d_naf), d_naf.numel(), C.byref(o), begin, end, _ptr(out), out.numel(), C.byref(n)))
         return out[:n.value]
+
+    def histogram(self, d_buf):
+        """Byte counts of a device buffer (unnaf --charcount)."""
+        cnt = (C.c_uint64 * 256)()
+        self._check(self.L.naf_gpu_histogram(self.h, _ptr(d_buf), d_buf.numel(), cnt))
+        return list(cnt)
 
     # ---- ennaf ----
     def ennaf(self, d_text, seq_type=SEQ_DNA, fmt=FMT_AUTO, no_mask=False, level=1, line_length=-1, title=None, out=None):

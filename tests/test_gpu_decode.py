@@ -89,6 +89,15 @@ def test_unnaf_matches_reference_outputs(gpu, case, path, monkeypatch):
         assert sha(got) == exp["sha256"], m
 
 
+def test_histogram_matches_numpy(gpu):
+    rng = np.random.default_rng(2)
+    for n in (0, 1, 7, 65536, 65537, 1000003):
+        d = rng.integers(0, 256, n, dtype=np.uint8)
+        d[: n // 3] = 65
+        got = gpu.histogram(gpu.to_device(d.tobytes())) if n else [0] * 256
+        assert got == np.bincount(d, minlength=256).tolist(), n
+
+
 def test_unnaf_survives_corrupt_sections(gpu, oracle):
     """A damaged section must come back as an error (or, when the damage happens to decode, as some text) -- never a crash or a
     hang; the side streams are decoded by helper host threads, so this also walks their error paths."""

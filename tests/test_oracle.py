@@ -91,10 +91,18 @@ def test_reference_suite_through_oracle(oracle, case):
     text = golden_bytes("ref_tests", case["set"], case["input"])
     ea, ua = case["ennaf_args"], case["unnaf_args"]
     st = _seq_type(ea, O)
-    if "--charcount" in ua:
-        pytest.skip("--charcount is an out-of-scope extraction mode (SURVEY.md 8(f).2)")
     sp = O.split_text(text, st, "--no-mask" in ea)
     naf = O.ennaf(text, st, "--no-mask" in ea)
+    if "--charcount" in ua:                                   # output.c:515-605: byte counts of the --seq text
+        seq = O.unnaf(naf, O.MODE_SEQ, use_mask="--no-mask" not in ua)
+        cnt = [0] * 256
+        for b in seq:
+            cnt[b] += 1
+        lines = ["\\x%02X\t%d\n" % (i, cnt[i]) for i in range(33) if cnt[i]]
+        lines += ["%c\t%d\n" % (i, cnt[i]) for i in range(33, 127) if cnt[i]]
+        lines += ["\\x%02X\t%d\n" % (i, cnt[i]) for i in range(127, 256) if cnt[i]]
+        assert "".join(lines).encode("latin1") == golden_bytes("ref_tests", case["set"], case["name"] + ".out-ref")
+        return
     mode = O.MODE_SEQ if "--seq" in ua else O.MODE_SEQUENCES if "--sequences" in ua else -1
     out = O.unnaf(naf, mode, use_mask="--no-mask" not in ua)
     pre = [case["set"], case["name"]]
