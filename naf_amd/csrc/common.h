@@ -9,9 +9,11 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define NAF_HD __host__ __device__ __forceinline__
+#define NAF_HDM __host__ __device__ __forceinline__      /* member functions */
 #define NAF_D __device__ __forceinline__
 #else
 #define NAF_HD static inline
+#define NAF_HDM inline
 #endif
 
 typedef uint8_t u8;

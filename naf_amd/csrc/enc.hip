@@ -526,7 +526,6 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
     TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pm);
     ctx.ord = thread_ord(P, O.t_ls, base, lds, pc, pm);
     bool active = base <= P.n;
-    bool eof_here = active && (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
     FqCount C;
     const int fast = fq_piece(P, base, pc, pm, ctx);
     if (fast == 1) C.nseq = 16; else if (fast == 3) C.nqual = 16;

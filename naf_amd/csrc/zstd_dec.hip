@@ -544,7 +544,7 @@ __global__ void k_emit_headers(EmitP P, u8 *text)
 template <bool FUSE>
 __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf,
                                                       const u8 *pool, u32 slot_bytes, u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first,
-                                                      EmitP EP, u8 *text, u32 ipitch)
+                                                      EmitP EP, u8 *text, u32 ipitch, u64 src_len)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     u8 *irows = lds + HUF_BLOCKS_PER_WG * slot_bytes;                // 64 input rings of ipitch bytes (136: 2 sectors, 264: 4 sectors)
@@ -615,7 +615,9 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
     {
         // ---- sector-window reader -------------------------------------------------------------------------
         u8 *irow = irows + lane * ipitch;
-        bool live = valid && (u64)(br.ptr - br.start) >= guard + 32;
+        // the window's first fill reads whole sectors around the stream's end: never past the end of the source buffer (the
+        // last stream of the last block of a buffer then simply takes the plain reader)
+        bool live = valid && (u64)(br.ptr - br.start) >= guard + 32 && (((u64)br.ptr + 7) & ~63ull) + 64 <= (u64)src + src_len;
         u64 gp = (u64)br.ptr, lo = 0;
         uint4 st0, st1, st2, st3; bool pending = false;
         st0 = st1 = st2 = st3 = make_uint4(0, 0, 0, 0);
@@ -1116,9 +1118,9 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         u32 ipitch = hs.max_huf_log > 7 ? HUF_IROW_BIG : HUF_IROW;
         u32 ipitch_arg = ipitch | ((getenv("NAF_GPU_HUF_GENERIC") && getenv("NAF_GPU_HUF_GENERIC")[0] == '1') ? 0x8000u : 0u);
         if (b_count && fuse) LAUNCH(c, "zstd_huf_fused_emit", (k_huf_literals<true>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 512,
-               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg);
+               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len);
         else if (b_count) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512 + (getenv("NAF_GPU_PADLDS") ? atoi(getenv("NAF_GPU_PADLDS")) : 0),
-               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg);
+               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len);
     }
     if (b_count && !fuse) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
     if (n_seq_blk) {
