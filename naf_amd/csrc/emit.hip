@@ -363,19 +363,37 @@ __device__ __forceinline__ void place16(u64 &lo, u64 &hi, u64 slo, u64 shi, u32 
 }
 
 // +32 on the bases of {lo,hi} (16 bases from base index g0) that lie in masked runs (output.c:295-322)
+// tog[0..n) are toggles number klo .. klo+n-1 (global memory, or the tile's window staged in LDS)
+__device__ __forceinline__ void mask16_from(const u64 *tog, u32 n, u64 klo, u64 g0, u64 &lo, u64 &hi)
+{
+    u32 a = 0, b = n;                                           // toggles <= g0
+    while (a < b) { u32 mid = (a + b) >> 1; if (tog[mid] <= g0) a = mid + 1; else b = mid; }
+    u32 kk = a, state = (u32)((klo + kk) & 1), m16 = 0; u64 pos = g0;
+    for (;;) {
+        u64 nxt = kk < n ? tog[kk] : ~0ull;
+        u64 end = nxt < g0 + 16 ? nxt : g0 + 16;
+        if (state && end > pos) m16 |= (u32)(((1u << (end - pos)) - 1) << (pos - g0));
+        if (nxt >= g0 + 16) break;
+        pos = nxt; state ^= 1; kk++;
+    }
+    lo += spread_bits8(m16 & 0xFF); hi += spread_bits8(m16 >> 8);
+}
 __device__ __forceinline__ void mask16(const EmitP &P, u64 klo, u64 khi, bool any_toggle, u64 g0, u64 &lo, u64 &hi)
 {
     if (any_toggle) {
-        u64 kk = upper_bound_u64(P.toggles, klo, khi, g0);      // toggles <= g0
-        u32 state = (u32)(kk & 1), m16 = 0; u64 pos = g0;
-        for (;;) {
-            u64 nxt = kk < khi ? P.toggles[kk] : ~0ull;
-            u64 end = nxt < g0 + 16 ? nxt : g0 + 16;
-            if (state && end > pos) m16 |= (u32)(((1u << (end - pos)) - 1) << (pos - g0));
-            if (nxt >= g0 + 16) break;
-            pos = nxt; state ^= 1; kk++;
+        if (khi - klo <= 0x7FFFFFFFull) mask16_from(P.toggles + klo, (u32)(khi - klo), klo, g0, lo, hi);
+        else {
+            u64 kk = upper_bound_u64(P.toggles, klo, khi, g0);      // toggles <= g0
+            u32 state = (u32)(kk & 1), m16 = 0; u64 pos = g0;
+            for (;;) {
+                u64 nxt = kk < khi ? P.toggles[kk] : ~0ull;
+                u64 end = nxt < g0 + 16 ? nxt : g0 + 16;
+                if (state && end > pos) m16 |= (u32)(((1u << (end - pos)) - 1) << (pos - g0));
+                if (nxt >= g0 + 16) break;
+                pos = nxt; state ^= 1; kk++;
+            }
+            lo += spread_bits8(m16 & 0xFF); hi += spread_bits8(m16 >> 8);
         }
-        lo += spread_bits8(m16 & 0xFF); hi += spread_bits8(m16 >> 8);
     } else if (P.masking && (klo & 1)) { lo += 0x2020202020202020ull; hi += 0x2020202020202020ull; }
 }
 
@@ -606,6 +624,7 @@ __global__ __launch_bounds__(256) void k_emit_fastq_records(EmitP P, u8 *out)
 // instructions per wavefront before the ALUs become the limit; so everything that is the same for the whole tile
 // (record, its geometry, the line/column of the tile's first byte, the mask toggles that can fall inside) is looked
 // up once per tile by k_tile_index and read here through scalar loads.
+#define EMIT_TOG_LDS 256u
 struct TileIdx { u64 gline, k, khi; u32 col, fast; };   // gline: base index of the first base of the tile's first line (wrap) / first byte
 #define TI_HDR 0xFFFFFFFFu
 __global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr)            // ntiles + 1 entries each
@@ -653,6 +672,12 @@ __global__ __launch_bounds__(256) void k_emit_tile(EmitP P, const TileIdx *ti, u
 {
     const TileIdx a = ti[blockIdx.x];
     if (!a.fast) return;
+    // soft-masked genomes put a dozen toggles into every tile: the tile's window goes to LDS once instead of every lane
+    // walking it in global memory
+    __shared__ u64 s_tog[EMIT_TOG_LDS];
+    const u32 ntog = (u32)(a.khi - a.k < EMIT_TOG_LDS ? a.khi - a.k : EMIT_TOG_LDS);
+    const bool use_tog = P.masking && a.k < a.khi && a.khi - a.k <= EMIT_TOG_LDS;
+    if (use_tog) { for (u32 i = threadIdx.x; i < ntog; i += 256) s_tog[i] = P.toggles[a.k + i]; __syncthreads(); }
     const u32 lane16 = threadIdx.x * 16;
     u64 g0; u32 nl_b = 64;
     if (P.mode == EM_FASTA && P.L != 0) {
@@ -673,7 +698,8 @@ __global__ __launch_bounds__(256) void k_emit_tile(EmitP P, const TileIdx *ti, u
         u32 sh = (u32)(addr & 7) * 8 + (u32)(g0 & 1) * 4;
         expand16(P.lut, sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0, lo, hi);
     } else bases16<false>(P, g0, lo, hi);
-    mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
+    if (use_tog) mask16_from(s_tog, ntog, a.k, g0, lo, hi);
+    else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
     if (nl_b < 16) splice_newline(lo, hi, (int)nl_b);
     uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
     *(uint4 *)(out + (u64)blockIdx.x * 4096 + lane16) = v;
