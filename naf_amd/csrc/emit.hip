@@ -927,9 +927,9 @@ static int unnaf_prepare(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const 
     return 0;
 }
 
-// The side streams (lengths, ids, names, mask) and the prefix tables built from them.  Runs on whichever context it is given:
-// the archive's own for byte-range calls, the side context (second host thread, second stream) for whole-text calls.
-static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gpu_ctx *aux = nullptr)
+// Lengths, ids, names and the prefix tables built from them (text offset / first base of every record).  `aux`: a context of its
+// own for ids + names (second host thread and stream); nullptr = everything on c, in order.
+static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gpu_ctx *aux)
 {
     const naf_gpu_header &h = pl.h;
     EmitP &P = pl.P;
@@ -1007,22 +1007,44 @@ static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gp
         P.hdr_len = hdr_len; P.rec_out = rec_out; P.rec_base = rec_base;
         pl.total = tot[0];
     }
-    if (P.masking) {
+    return 0;
+}
+
+// The side streams (lengths, ids, names, mask) and the tables built from them.  Runs on whichever context it is given: the
+// archive's own for byte-range calls (aux = aux_mask = nullptr: sequential), the side context for whole-text calls, which also
+// hands over contexts for ids + names and for the mask.
+static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gpu_ctx *aux = nullptr, naf_gpu_ctx *aux_mask = nullptr)
+{
+    const naf_gpu_header &h = pl.h;
+    EmitP &P = pl.P;
+    // mask stream -> toggle table.  A handful of long Huffman streams: its decode is pure latency, so with `aux_mask` it runs on a
+    // context of its own from the start of the call
+    auto mask_part = [&](naf_gpu_ctx *x) -> int {
+        int r;
         u8 *mu = nullptr; u64 n_mask = h.orig_size[S_MASK];
-        if ((rc = load_section(c, d_naf, h, S_MASK, n_mask, "mask", &mu))) return rc;
+        if ((r = load_section(x, d_naf, h, S_MASK, n_mask, "mask", &mu))) return r;
         u64 tiles = (n_mask + MT_TILE - 1) / MT_TILE;
-        u64 *ts = arena_new<u64>(c, tiles + 2), *tc = arena_new<u64>(c, tiles + 2);
+        u64 *ts = arena_new<u64>(x, tiles + 2), *tc = arena_new<u64>(x, tiles + 2);
         if (!ts || !tc) return NAF_GPU_ENOMEM;
-        if (tiles) LAUNCH(c, "unnaf_mask_count", k_mask_count, tiles, 256, 0, (const u8 *)mu, n_mask, ts, tc);
-        if ((rc = scan_exclusive_u64(c, ts, tiles, (u64 *)nullptr))) return rc;
-        if ((rc = scan_exclusive_u64(c, tc, tiles, tc + tiles + 1))) return rc;
+        if (tiles) LAUNCH(x, "unnaf_mask_count", k_mask_count, tiles, 256, 0, (const u8 *)mu, n_mask, ts, tc);
+        if ((r = scan_exclusive_u64(x, ts, tiles, (u64 *)nullptr))) return r;
+        if ((r = scan_exclusive_u64(x, tc, tiles, tc + tiles + 1))) return r;
         u64 ntog = 0;
-        if ((rc = ctx_readback(c, &ntog, tc + tiles + 1, 8))) return rc;
-        u64 *tg = arena_new<u64>(c, ntog + 1);
+        if ((r = ctx_readback(x, &ntog, tc + tiles + 1, 8))) return r;
+        u64 *tg = arena_new<u64>(x, ntog + 1);
         if (!tg) return NAF_GPU_ENOMEM;
-        if (tiles) LAUNCH(c, "unnaf_mask_scatter", k_mask_scatter, tiles, 256, 0, (const u8 *)mu, n_mask, (const u64 *)ts, (const u64 *)tc, tg);
+        if (tiles) LAUNCH(x, "unnaf_mask_scatter", k_mask_scatter, tiles, 256, 0, (const u8 *)mu, n_mask, (const u64 *)ts, (const u64 *)tc, tg);
         P.toggles = tg; P.n_toggles = ntog;
-    }
+        return 0;
+    };
+    int rc_mask = 0; std::thread thm;
+    const bool mask_started = P.masking && aux_mask;
+    if (mask_started) thm = std::thread([&] { hipSetDevice(c->device); rc_mask = mask_part(aux_mask); });      // joined below: no return before
+    int rc = unnaf_sections_main(c, d_naf, pl, aux);
+    if (mask_started) { thm.join(); hipStreamSynchronize(aux_mask->stream); }
+    if (rc) return rc;                                                                                     // the order a sequential run reports in
+    if (mask_started && rc_mask) { memcpy(c->err, aux_mask->err, sizeof c->err); return rc_mask; }
+    if (P.masking && !mask_started && (rc = mask_part(c))) return rc;
     return 0;
 }
 
@@ -1089,8 +1111,9 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         const bool qpar = pl.need_qual && c->side2;
         if (qpar) { arena_reset(c->side2); HIP_TRY(c, hipStreamWaitEvent(c->side2->stream, c->fork_ev, 0)); }
         if (c->side3) { arena_reset(c->side3); HIP_TRY(c, hipStreamWaitEvent(c->side3->stream, c->fork_ev, 0)); }
+        if (c->side4) { arena_reset(c->side4); HIP_TRY(c, hipStreamWaitEvent(c->side4->stream, c->fork_ev, 0)); }
         // no early return between here and the joins
-        std::thread th([&] { hipSetDevice(c->device); rc_side = unnaf_sections(c->side, d_naf, pl, c->side3); });
+        std::thread th([&] { hipSetDevice(c->device); rc_side = unnaf_sections(c->side, d_naf, pl, c->side3, nullptr); });   // the mask stays on this context: a fifth thread measured slower
         std::thread thq;
         if (qpar) thq = std::thread([&] { hipSetDevice(c->device); rc_q = payload_qual(c->side2); });
         rc = payload_seq();

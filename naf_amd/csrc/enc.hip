@@ -748,13 +748,13 @@ static void set_expected(EncP &P, int seq_type, bool fasta)
 
 struct SecOut { u64 orig, comp; };
 
-static int put_section(naf_gpu_ctx *c, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz = 0)
+static int put_section(naf_gpu_ctx *c, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz = 0, int block_log = 0)
 {
     size_t bound = naf_gpu_zstd_compress_bound(stream_len);
     u8 *tmp = (u8 *)arena_alloc(c, bound);
     if (!tmp) return NAF_GPU_ENOMEM;
     size_t clen = 0;
-    int rc = zstd_encode(c, d_stream, stream_len, level, tmp, bound, &clen, 0, lz); if (rc) return rc;
+    int rc = zstd_encode(c, d_stream, stream_len, level, tmp, bound, &clen, 0, lz, block_log); if (rc) return rc;
     u8 hdr[20]; size_t hl = vle(orig, hdr); hl += vle(clen, hdr + hl);
     if (pos + hl + clen > cap) return ctx_fail(c, NAF_GPU_ECAP, "ennaf output capacity %zu too small", cap);
     HIP_TRY(c, hipMemcpyAsync(d_naf + pos, hdr, hl, hipMemcpyHostToDevice, c->stream));
@@ -795,6 +795,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     bool store_qual = format == NAF_FMT_FASTQ;                                                    // ennaf.c:477
 
     u8 *s_ids = nullptr, *s_cmt = nullptr, *s_seq = nullptr, *s_mask = nullptr, *s_qual = nullptr, *bases = nullptr; u32 *s_len = nullptr;
+    int mask_block_log = 15;
     u64 n_ids = 0, n_cmt = 0, n_lenb = 0, n_mask = 0, n_seqb = 0, n_qual = 0, T = 0, N = 0, longest = 0;
     u64 *rec_begin = nullptr, *rec_end = nullptr; int all_ends = 0;
     int rc;
@@ -928,6 +929,10 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
             s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
             HIP_TRY(c, hipMemsetAsync(s_mask, 0xFF, nu, c->stream));
             LAUNCH(c, "ennaf_mask_units", k_mask_units_write, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, (const u64 *)ru, s_mask);
+            // Block size of the mask stream.  Real soft-masking (runs of a few hundred bases) gives a few MB of high-entropy units, i.e. a
+            // few hundred blocks whose Huffman streams the decoder walks serially: 8 KiB blocks (2 KiB streams) cut that latency to a
+            // quarter.  Very long runs give strings of 255s (constant blocks, nothing to walk): 32 KiB blocks keep the block count down.
+            mask_block_log = nu / (nb + 1) > 1000 ? 15 : 13;
             n_mask = nu;
         }
         // sequence stream
@@ -963,7 +968,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     if ((rc = put_section(c, s_ids, n_ids, n_ids, o->level, d_naf, cap, pos, so[0], 1))) return rc;
     if ((rc = put_section(c, s_cmt, n_cmt, n_cmt, o->level, d_naf, cap, pos, so[1], 1))) return rc;
     if ((rc = put_section(c, (const u8 *)s_len, n_lenb, n_lenb, o->level, d_naf, cap, pos, so[2], 1))) return rc;
-    if (store_mask) { if ((rc = put_section(c, s_mask, n_mask, n_mask, o->level, d_naf, cap, pos, so[3]))) return rc; }
+    if (store_mask) { if ((rc = put_section(c, s_mask, n_mask, n_mask, o->level, d_naf, cap, pos, so[3], 0, mask_block_log))) return rc; }
     if ((rc = put_section(c, s_seq, n_seqb, T, o->level, d_naf, cap, pos, so[4]))) return rc;      // ennaf.c:582: number of bases
     if (store_qual) { if ((rc = put_section(c, s_qual, n_qual, n_qual, o->level, d_naf, cap, pos, so[5]))) return rc; }
     for (int i = 0; i < 6; i++) { R.section_orig[i] = so[i].orig; R.section_comp[i] = so[i].comp; }

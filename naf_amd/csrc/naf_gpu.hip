@@ -72,7 +72,7 @@ extern "C" void naf_gpu_shutdown(naf_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3 }) {
+    for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3, c->side4 }) {
         if (!sc) continue;
         hipStreamSynchronize(sc->stream);
         for (auto &ch : sc->chunks) hipFree(ch.base);
@@ -188,7 +188,7 @@ extern "C" int naf_gpu_set_timing(naf_gpu_ctx *c, int enable)
 {
     if (!c) return NAF_GPU_EARG;
     c->timing = enable != 0; c->ktimes.clear(); c->ev_used = 0;
-    for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3 }) if (sc) { sc->timing = c->timing; sc->ktimes.clear(); sc->ev_used = 0; }
+    for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3, c->side4 }) if (sc) { sc->timing = c->timing; sc->ktimes.clear(); sc->ev_used = 0; }
     return 0;
 }
 
@@ -216,10 +216,10 @@ extern "C" int naf_gpu_get_timing(naf_gpu_ctx *c, const char **names, float *ms,
 {
     if (!c) return NAF_GPU_EARG;
     hipStreamSynchronize(c->stream);
-    for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3 }) if (sc) hipStreamSynchronize(sc->stream);
+    for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3, c->side4 }) if (sc) hipStreamSynchronize(sc->stream);
     std::map<std::string, std::pair<float, int>> agg;
     std::vector<std::string> order;
-    for (naf_gpu_ctx *x : { c, c->side, c->side2, c->side3 }) {
+    for (naf_gpu_ctx *x : { c, c->side, c->side2, c->side3, c->side4 }) {
         if (!x) continue;
         for (auto &k : x->ktimes) {
             float t = 0; hipEventElapsedTime(&t, k.a, k.b);

@@ -377,9 +377,10 @@ extern "C" size_t naf_gpu_zstd_compress_bound(size_t n)
 }
 
 // block_log: log2 of the target block size (clamped to 17 = the format maximum of 128 KiB)
-int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz)
+int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz, int block_log_hint)
 {
     u32 block_log = 15;                                          // 32 KiB: 4 streams of 8 KiB; more streams = more decode parallelism
+    if (block_log_hint >= 10 && block_log_hint <= 17) block_log = (u32)block_log_hint;
     const char *e = getenv("NAF_GPU_BLOCK_LOG");
     if (e) { int v = atoi(e); if (v >= 10 && v <= 17) block_log = (u32)v; }
     const char *el = getenv("NAF_GPU_LZ");                       // "0": never, "all": every stream (tests)
