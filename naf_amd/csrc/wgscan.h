@@ -24,14 +24,36 @@ template <typename T> __device__ __forceinline__ T shfl_idx_t(T v, int l)
     } else return (T)__shfl((int)v, l, 64);
 }
 
+// One DPP hop of the wave scan: lanes without a source keep `idv` (the operator's identity).
+template <int CTRL, int ROW_MASK, typename T> __device__ __forceinline__ T dpp_hop(T idv, T v)
+{
+    if constexpr (sizeof(T) == 8) {
+        u32 lo = (u32)__builtin_amdgcn_update_dpp((int)(u32)(u64)idv, (int)(u32)(u64)v, CTRL, ROW_MASK, 0xf, false);
+        u32 hi = (u32)__builtin_amdgcn_update_dpp((int)(u32)((u64)idv >> 32), (int)(u32)((u64)v >> 32), CTRL, ROW_MASK, 0xf, false);
+        return (T)(((u64)hi << 32) | lo);
+    } else return (T)__builtin_amdgcn_update_dpp((int)idv, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+// Inclusive scan across the 64 lanes of a wavefront on the DPP path (no LDS crossbar): shifts of 1, 2, 4, 8 inside each
+// row of 16 lanes, then lane 15 of rows 0 / 2 broadcast into rows 1 / 3, then lane 31 into the upper half.
+template <typename T, typename Op> __device__ __forceinline__ T wave_scan_inclusive(T v)
+{
+    const T idv = Op::template id<T>();
+    v = Op::template f<T>(dpp_hop<0x111, 0xf>(idv, v), v);
+    v = Op::template f<T>(dpp_hop<0x112, 0xf>(idv, v), v);
+    v = Op::template f<T>(dpp_hop<0x114, 0xf>(idv, v), v);
+    v = Op::template f<T>(dpp_hop<0x118, 0xf>(idv, v), v);
+    v = Op::template f<T>(dpp_hop<0x142, 0xa>(idv, v), v);
+    v = Op::template f<T>(dpp_hop<0x143, 0xc>(idv, v), v);
+    return v;
+}
+
 // Inclusive scan of one value per thread across the 256-thread workgroup; returns inclusive result,
 // *total = workgroup aggregate.
 template <typename T, typename Op>
 __device__ __forceinline__ T wg_scan_inclusive(T v, T *total, T *lds /* 4 entries */)
 {
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { T o = shfl_up_t(v, d); if (lane >= d) v = Op::template f<T>(o, v); }
+    v = wave_scan_inclusive<T, Op>(v);
     if (lane == 63) lds[wave] = v;
     __syncthreads();
     T pre = Op::template id<T>(), tot = Op::template id<T>();
@@ -41,4 +63,3 @@ __device__ __forceinline__ T wg_scan_inclusive(T v, T *total, T *lds /* 4 entrie
     *total = tot;
     return Op::template f<T>(pre, v);
 }
-
