@@ -27,7 +27,7 @@ oracle:
 	$(MAKE) -s -C oracle all
 
 emul: tests/emul/libzstd_emul.so
-tests/emul/libzstd_emul.so: tests/emul/zstd_emul.cpp tests/emul/zstd_enc_emul.cpp $(CSRC)/zstd_dec_core.h $(CSRC)/zstd_enc_core.h $(CSRC)/common.h
+tests/emul/libzstd_emul.so: tests/emul/zstd_emul.cpp tests/emul/zstd_enc_emul.cpp $(CSRC)/zstd_dec_core.h $(CSRC)/zstd_enc_core.h $(CSRC)/enc_swar.h $(CSRC)/common.h
 	g++ -O2 -std=c++17 -fPIC -shared -o $@ tests/emul/zstd_emul.cpp tests/emul/zstd_enc_emul.cpp
 
 clean:

@@ -12,11 +12,13 @@
 // once those maxima are scanned across tiles; stream offsets come from prefix sums of per-tile counts.
 #include "ctx.h"
 #include "wgscan.h"
+#include "enc_swar.h"
 
 #define ET_BYTES 16
 #define ET_TILE (256 * ET_BYTES)
 
 struct OpMaxI64 { template <typename T> __device__ static T id() { return (T)(-1); } template <typename T> __device__ static T f(T a, T b) { return (i64)a > (i64)b ? a : b; } };
+struct OpMaxU32 { template <typename T> __device__ static T id() { return (T)0; } template <typename T> __device__ static T f(T a, T b) { return a > b ? a : b; } };
 struct OpMaxU64 { template <typename T> __device__ static T id() { return (T)0; } template <typename T> __device__ static T f(T a, T b) { return a > b ? a : b; } };
 
 struct EncP {
@@ -25,6 +27,7 @@ struct EncP {
     u8 replacement;              // 'N' / 'X' / '?'  (ennaf.c:447-470)
     u8 id_gt_unexpected;         // text+FASTA: '>' also ends ID scanning (ennaf.c:478 flips the shared table)
     u8 strict, pad;
+    u32 qlo, qhi;                // quick table of accepted letters (enc_swar.h), built in set_expected
 };
 
 __device__ __forceinline__ bool c_eol(u32 c) { return c >= 0x0A && c <= 0x0D; }
@@ -58,25 +61,45 @@ __device__ __forceinline__ void fill_classes(const EncP &P, u8 *cls)      // blo
 }
 
 // One bit per byte of the piece for each class (bit k = byte k).  With these a piece that lies inside sequence lines needs no
-// per-byte state machine: counts are popcounts, the last EOL / space a count-leading-zeros.
-struct PMask { u32 eol, sp, exp, gt, q; };
-template <bool NEED_EXP, bool NEED_Q = false>
-__device__ __forceinline__ PMask piece_masks(const Piece &pc, const u8 *cls)
+// per-byte state machine: counts are popcounts, the last EOL / space a count-leading-zeros.  EOL / space / '>' come from four-
+// bytes-at-a-time arithmetic (enc_swar.h); a zero-padded partial piece sets none of them.
+struct PMask { u32 eol, sp, gt; };
+__device__ __forceinline__ PMask piece_masks(const Piece &pc)
 {
-    PMask m; m.eol = m.sp = m.exp = m.gt = m.q = 0;
-#pragma unroll
-    for (u32 k = 0; k < ET_BYTES; k++) if (k < pc.cnt) {
-        u32 cl = cls[piece_byte(pc, k)];
-        m.eol |= (cl & 1u) << k; m.sp |= ((cl >> 1) & 1u) << k; m.gt |= ((cl >> 3) & 1u) << k;
-        if (NEED_EXP) m.exp |= ((cl >> 2) & 1u) << k;
-        if (NEED_Q) m.q |= ((cl >> 6) & 1u) << k;
-    }
+    u32 w[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) };
+    PieceFlags f = piece_flags(w);
+    PMask m; m.eol = f.eol; m.sp = f.sp; m.gt = f.gt;
     return m;
+}
+// Every byte of a full piece is space-class (when `allow_space`) or an accepted sequence letter: the quick table answers for
+// A C G T N in either case, the bytes it does not know are looked up in the class table one by one.
+__device__ __forceinline__ bool piece_all_expected(const EncP &P, const Piece &pc, const PMask &pm, const u8 *cls, bool allow_space)
+{
+    u32 w[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) };
+    u32 cand = piece_not_quick(w, P.qlo, P.qhi);
+    if (allow_space) cand &= ~pm.sp;
+    while (cand) {
+        u32 k = (u32)__ffs((int)cand) - 1; cand &= cand - 1;
+        if (!(cls[piece_byte(pc, k)] & CL_EXPECTED)) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ bool piece_all_qual(const Piece &pc)
+{
+    u32 w[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) };
+    return piece_all_quality(w);
 }
 __device__ __forceinline__ void last_eol_space_m(const PMask &m, u64 base, i64 &le, i64 &ls)
 {
     le = m.eol ? (i64)(base + (31 - __clz((int)m.eol))) : -1;
     ls = m.sp ? (i64)(base + (31 - __clz((int)m.sp))) : -1;
+}
+// (position in the tile + 1) of the piece's last EOL-class byte in the low half and of its last space-class byte in the high
+// half, 0 = none: both running maxima of a tile travel through one scan of packed 16-bit values.
+__device__ __forceinline__ u32 tile_pos_pair(const PMask &m)
+{
+    u32 t16 = threadIdx.x * ET_BYTES + 1;
+    return (m.eol ? t16 + (31 - __clz((int)m.eol)) : 0u) | ((m.sp ? t16 + (31 - __clz((int)m.sp)) : 0u) << 16);
 }
 // Line starts: a non-EOL byte at i >= p0 whose predecessor is an EOL byte (or i == p0).
 __device__ __forceinline__ u32 count_line_starts(const EncP &P, u64 base, const Piece &pc)
@@ -105,20 +128,47 @@ __device__ __forceinline__ void last_eol_space(const Piece &pc, u64 base, i64 &l
 
 __global__ __launch_bounds__(256) void k_enc_last(EncP P, i64 *tile_eol, i64 *tile_sp, u64 *tile_ls)
 {
-    __shared__ u64 lds[4];
-    __shared__ u8 cls[256];
-    fill_classes(P, cls);
+    __shared__ u32 s_pos[4], s_nls[4];
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
-    i64 le = -1, ls = -1; u32 nls = 0;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     Piece pc = load_piece(P, base);
-    PMask pm = piece_masks<false>(pc, cls);
-    last_eol_space_m(pm, base, le, ls);
-    if (tile_ls && pc.cnt) nls = count_line_starts_m(P, base, pc, pm);
-    u64 t;
-    wg_scan_inclusive<u64, OpMaxI64>((u64)le, &t, lds); i64 te = (i64)t;
-    wg_scan_inclusive<u64, OpMaxI64>((u64)ls, &t, lds); i64 ts = (i64)t;
-    if (threadIdx.x == 0) { tile_eol[blockIdx.x] = te; tile_sp[blockIdx.x] = ts; }
-    if (tile_ls) { wg_scan_inclusive<u64, OpAdd>((u64)nls, &t, lds); if (threadIdx.x == 0) tile_ls[blockIdx.x] = t; }
+    PMask pm = piece_masks(pc);
+    u32 v = wave_scan_inclusive<u32, OpPkMaxU16>(tile_pos_pair(pm));
+    u32 nls = (tile_ls && pc.cnt) ? count_line_starts_m(P, base, pc, pm) : 0;
+    if (tile_ls) nls = wave_scan_inclusive<u32, OpAdd>(nls);
+    if (lane == 63) { s_pos[wave] = v; s_nls[wave] = nls; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 m = OpPkMaxU16::f<u32>(OpPkMaxU16::f<u32>(s_pos[0], s_pos[1]), OpPkMaxU16::f<u32>(s_pos[2], s_pos[3]));
+        u64 tb = (u64)blockIdx.x * ET_TILE;
+        tile_eol[blockIdx.x] = (m & 0xFFFF) ? (i64)(tb + (m & 0xFFFF) - 1) : -1;
+        tile_sp[blockIdx.x] = (m >> 16) ? (i64)(tb + (m >> 16) - 1) : -1;
+        if (tile_ls) tile_ls[blockIdx.x] = (u64)s_nls[0] + s_nls[1] + s_nls[2] + s_nls[3];
+    }
+}
+
+// FASTA wants only the LAST EOL / space of each tile.  In line-wrapped text both sit in the tile's last kilobyte: one wavefront
+// per tile looks there first and walks back through the other three quarters only while something is still missing.
+__global__ __launch_bounds__(256) void k_enc_last_fa(EncP P, i64 *tile_eol, i64 *tile_sp, u64 tiles)
+{
+    u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u64 t = (u64)blockIdx.x * 4 + wave;
+    if (t >= tiles) return;
+    u64 tb = t * ET_TILE; u32 found = 0;
+    for (int q = 3; q >= 0; q--) {
+        Piece pc = load_piece(P, tb + (u32)q * 1024 + lane * ET_BYTES);
+        PMask pm = piece_masks(pc);
+        u32 t16 = (u32)q * 1024 + lane * ET_BYTES + 1;
+        u32 v = (pm.eol ? t16 + (31 - __clz((int)pm.eol)) : 0u) | ((pm.sp ? t16 + (31 - __clz((int)pm.sp)) : 0u) << 16);
+        v = (u32)__builtin_amdgcn_readlane((int)wave_scan_inclusive<u32, OpPkMaxU16>(v), 63);
+        if (!(found & 0xFFFF)) found |= v & 0xFFFF;
+        if (!(found >> 16)) found |= v & 0xFFFF0000u;
+        if ((found & 0xFFFF) && (found >> 16)) break;
+    }
+    if (lane == 0) {
+        tile_eol[t] = (found & 0xFFFF) ? (i64)(tb + (found & 0xFFFF) - 1) : -1;
+        tile_sp[t] = (found >> 16) ? (i64)(tb + (found >> 16) - 1) : -1;
+    }
 }
 
 // ---- classification of 16 bytes given the running maxima at the first byte ---------------------------------------
@@ -166,24 +216,21 @@ __device__ __forceinline__ void classify_range(const EncP &P, u64 pos, const Pie
 }
 
 // Running maxima and header flag at the first byte of this thread's 16-byte piece.
-__device__ __forceinline__ TileCtx thread_ctx(const EncP &P, const i64 *tile_eol, const i64 *tile_sp, u64 base, u64 *lds, const PMask &pm)
+__device__ __forceinline__ TileCtx thread_ctx(const EncP &P, const i64 *tile_eol, const i64 *tile_sp, u64 base, const PMask &pm)
 {
-    i64 le = -1, ls = -1;
-    last_eol_space_m(pm, base, le, ls);
-    u64 t;
-    i64 ie = (i64)wg_scan_inclusive<u64, OpMaxI64>((u64)le, &t, lds);
-    i64 is = (i64)wg_scan_inclusive<u64, OpMaxI64>((u64)ls, &t, lds);
-    // exclusive = inclusive of the previous thread
-    i64 pe = (i64)shfl_up_t((u64)ie, 1), ps = (i64)shfl_up_t((u64)is, 1);
-    __shared__ u64 wl[8];
+    __shared__ u32 wl[4];
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 63) { wl[wave] = (u64)ie; wl[4 + wave] = (u64)is; }
+    u32 inc = wave_scan_inclusive<u32, OpPkMaxU16>(tile_pos_pair(pm));
+    if (lane == 63) wl[wave] = inc;
+    u32 ex = wave_shift_up1<u32, OpPkMaxU16>(inc);              // exclusive: what the earlier lanes saw
     __syncthreads();
-    if (lane == 0) { pe = wave ? (i64)wl[wave - 1] : -1; ps = wave ? (i64)wl[4 + wave - 1] : -1; }
-    __syncthreads();
-    i64 ce = blockIdx.x ? tile_eol[blockIdx.x - 1] : -1, cs = blockIdx.x ? tile_sp[blockIdx.x - 1] : -1;
+#pragma unroll
+    for (int w = 0; w < 3; w++) if (w < wave) ex = OpPkMaxU16::f<u32>(ex, wl[w]);
+    u64 tb = (u64)blockIdx.x * ET_TILE;
     TileCtx c;
-    c.last_eol = pe > ce ? pe : ce; c.last_sp = ps > cs ? ps : cs;
+    // a hit inside the tile is later than anything carried in from the tiles before it
+    c.last_eol = (ex & 0xFFFF) ? (i64)(tb + (ex & 0xFFFF) - 1) : (blockIdx.x ? tile_eol[blockIdx.x - 1] : -1);
+    c.last_sp = (ex >> 16) ? (i64)(tb + (ex >> 16) - 1) : (blockIdx.x ? tile_sp[blockIdx.x - 1] : -1);
     i64 ls0 = c.last_eol + 1;
     c.hdr = (u64)ls0 < P.n && P.text[ls0] == '>';
     return c;
@@ -209,13 +256,12 @@ __device__ __forceinline__ bool seq_piece(const EncP &P, u64 base, const Piece &
 __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, const i64 *tile_sp,
                                                     u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail)
 {
-    __shared__ u64 lds[4];
     __shared__ u8 cls[256];
     fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
-    PMask pm = piece_masks<false>(pc, cls);
-    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pm);
+    PMask pm = piece_masks(pc);
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, pm);
     CountSink S;
     if (seq_piece(P, base, pc, pm, ctx)) {
         // a full piece inside sequence lines: every non-space byte is a base (process.c:387-412)
@@ -226,18 +272,24 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
         bool eof_here = (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
         classify_range(P, base, pc, eof_here, ctx, S, cls);
     }
-    // four counts in one scan: 16-bit fields (a tile holds 4096 bytes, a byte adds at most 2 to a field)
-    u64 tot;
-    wg_scan_inclusive<u64, OpAdd>((u64)S.nseq | ((u64)S.nids << 16) | ((u64)S.ncmt << 32) | ((u64)S.nrec << 48), &tot, lds);
-    if (threadIdx.x == 0) { t_seq[blockIdx.x] = tot & 0xFFFF; t_ids[blockIdx.x] = (tot >> 16) & 0xFFFF; t_cmt[blockIdx.x] = (tot >> 32) & 0xFFFF; t_rec[blockIdx.x] = tot >> 48; }
-    // tail of the tile: sequence bytes after the last EOL inside the tile (whole tile if it has none)
-    // encoded per thread as (has_eol, tail); combine right-to-left: first thread from the end that saw an EOL stops the sum
-    u64 key = ((u64)(S.saw_eol ? threadIdx.x + 1 : 0) << 32);
-    u64 lastw; wg_scan_inclusive<u64, OpMaxU64>(key, &lastw, lds);
-    u32 last_thread_with_eol = (u32)(lastw >> 32);             // 0 = none, else index+1
-    u64 contrib = (threadIdx.x + 1 > last_thread_with_eol) ? S.nseq : (threadIdx.x + 1 == last_thread_with_eol ? S.tail : 0);
-    wg_scan_inclusive<u64, OpAdd>(contrib, &tot, lds);
-    if (threadIdx.x == 0) t_tail[blockIdx.x] = (u32)tot | (last_thread_with_eol ? 0x80000000u : 0);
+    // four counts in two scans of packed 16-bit fields (a tile holds 4096 bytes, a byte adds at most 2 to a field); the tail of
+    // the tile -- sequence bytes after its last EOL, the whole tile if it has none -- falls out of the same scan: the last
+    // thread that saw an EOL knows how many bases follow it.
+    __shared__ u32 s_a[4], s_b[4], s_last[4];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 wa = wave_scan_inclusive<u32, OpAdd>(S.nseq | (S.nids << 16)), wb = wave_scan_inclusive<u32, OpAdd>(S.ncmt | (S.nrec << 16));
+    u64 bal = __ballot(S.saw_eol);
+    if (lane == 63) { s_a[wave] = wa; s_b[wave] = wb; }
+    if (lane == 0) s_last[wave] = bal ? (u32)(wave * 64 + (63 - __clzll((long long)bal)) + 1) : 0u;
+    __syncthreads();
+    u32 pre = 0, tota = 0, totb = 0, last = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { if (w < wave) pre += s_a[w]; tota += s_a[w]; totb += s_b[w]; last = s_last[w] > last ? s_last[w] : last; }
+    if (threadIdx.x == 0) {
+        t_seq[blockIdx.x] = tota & 0xFFFF; t_ids[blockIdx.x] = tota >> 16; t_cmt[blockIdx.x] = totb & 0xFFFF; t_rec[blockIdx.x] = totb >> 16;
+        if (!last) t_tail[blockIdx.x] = tota & 0xFFFF;
+    }
+    if (threadIdx.x + 1 == last) t_tail[blockIdx.x] = ((tota & 0xFFFF) - ((pre + wa) & 0xFFFF) + S.tail) | 0x80000000u;
 }
 
 // ---- K3: scatter --------------------------------------------------------------------------------------------------------
@@ -289,41 +341,45 @@ struct WriteSink {
 
 __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, EncOut O)
 {
-    __shared__ u64 lds[4];
     __shared__ u8 cls[256];
     fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
-    PMask pm = piece_masks<true>(pc, cls);
-    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pm);
+    PMask pm = piece_masks(pc);
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, pm);
     bool active = base <= P.n;
     bool eof_here = active && (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
     // fast: inside sequence lines and nothing to replace (every non-space byte is an expected one)
-    const bool fast = seq_piece(P, base, pc, pm, ctx) && (~pm.sp & ~pm.exp & 0xFFFFu) == 0;
+    const bool fast = seq_piece(P, base, pc, pm, ctx) && piece_all_expected(P, pc, pm, cls, true);
     CountSink C;
     if (fast) {
         C.nseq = 16 - __popc(pm.sp); C.saw_eol = pm.eol != 0;
         C.tail = pm.eol ? __popc(~pm.sp & 0xFFFFu & ~((2u << (31 - __clz((int)pm.eol))) - 1)) : C.nseq;
     } else if (active) classify_range(P, base, pc, eof_here, ctx, C, cls);
-    u64 tot, totp;
-    u64 ip = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq | ((u64)C.nids << 16) | ((u64)C.ncmt << 32) | ((u64)C.nrec << 48), &totp, lds);
-    u64 iseq = ip & 0xFFFF, iids = (ip >> 16) & 0xFFFF, icmt = (ip >> 32) & 0xFFFF, irec = ip >> 48, tot0 = totp & 0xFFFF;
-    __shared__ __attribute__((aligned(8))) u8 stage[ET_TILE + 16];
-    u32 tile_seq = (u32)tot0;
-    WriteSink W(O); W.stage = stage; W.tbase = O.t_seq[blockIdx.x];
-    W.bseq = O.t_seq[blockIdx.x] + iseq - C.nseq; W.bids = O.t_ids[blockIdx.x] + iids - C.nids;
-    W.bcmt = O.t_cmt[blockIdx.x] + icmt - C.ncmt; W.rec = O.t_rec[blockIdx.x] + irec - C.nrec;
-    // base count at the start of the line this thread begins in: B at the most recent EOL before `base`.
-    // Within the tile: B at an EOL is non-decreasing with position, so a running max over earlier threads works.
-    u64 my_last_eol_b = C.saw_eol ? (W.bseq + C.nseq - C.tail) : 0;
-    u64 incl = wg_scan_inclusive<u64, OpMaxU64>(C.saw_eol ? my_last_eol_b + 1 : 0, &tot, lds);   // +1 so that 0 means "none"
-    u64 prev = shfl_up_t(incl, 1);
-    __shared__ u64 wl[4];
+    __shared__ u32 s_a[4], s_b[4], s_l[4];
+    u32 prea, preb, tota;
+    u32 ia = wg_scan1<u32, OpAdd>(C.nseq | (C.nids << 16), &prea, &tota, s_a);
+    u32 ib = wave_scan_inclusive<u32, OpAdd>(C.ncmt | (C.nrec << 16));
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 63) wl[wave] = incl;
+    preb = 0;                                                     // the second pair shares the barrier of the line-start scan below
+    ia += prea;
+    u32 iseq = ia & 0xFFFF, iids = ia >> 16, tile_seq = tota & 0xFFFF;
+    __shared__ __attribute__((aligned(8))) u8 stage[ET_TILE + 16];
+    WriteSink W(O); W.stage = stage; W.tbase = O.t_seq[blockIdx.x];
+    W.bseq = W.tbase + iseq - C.nseq; W.bids = O.t_ids[blockIdx.x] + iids - C.nids;
+    // base count at the start of the line this thread begins in: B at the most recent EOL before `base`.
+    // Within the tile: B at an EOL is non-decreasing with position, so a running max over earlier threads works
+    // (tile-relative and +1, so that 0 means "none").
+    u32 rel = C.saw_eol ? (u32)(iseq - C.tail) + 1 : 0;
+    u32 inc = wave_scan_inclusive<u32, OpMaxU32>(rel);
+    if (lane == 63) { s_b[wave] = ib; s_l[wave] = inc; }
+    u32 prev = wave_shift_up1<u32, OpMaxU32>(inc);
     __syncthreads();
-    if (lane == 0) prev = wave ? wl[wave - 1] : 0;
-    if (prev) W.line_b = prev - 1;
+#pragma unroll
+    for (int w = 0; w < 3; w++) if (w < wave) { preb += s_b[w]; prev = s_l[w] > prev ? s_l[w] : prev; }
+    ib += preb;
+    W.bcmt = O.t_cmt[blockIdx.x] + (ib & 0xFFFF) - C.ncmt; W.rec = O.t_rec[blockIdx.x] + (ib >> 16) - C.nrec;
+    if (prev) W.line_b = W.tbase + prev - 1;
     else {
         // the line began in an earlier tile t' (the tile holding the last EOL): B = t_seq[t'+1] - tail(t')
         i64 le = blockIdx.x ? tile_eol[blockIdx.x - 1] : -1;
@@ -351,7 +407,8 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
     } else if (active) classify_range(P, base, pc, eof_here, ctx, W, cls);
     __syncthreads();
     flush_tile(O.seq + W.tbase, stage, tile_seq);
-    u64 best; wg_scan_inclusive<u64, OpMaxU64>(W.best, &best, lds);
+    __shared__ u64 s_best[4];
+    u64 best = wg_reduce1<u64, OpMaxU64>(W.best, s_best);
     // millions of workgroups, one address: look before touching it atomically
     if (threadIdx.x == 0 && best > __atomic_load_n(O.longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)O.longest, (unsigned long long)best);
 }
@@ -469,14 +526,14 @@ __device__ __forceinline__ void slow_gather(bool slow, const TileCtx &ctx, SlowC
 }
 
 // A full piece in the middle of a read's sequence line (returns 1) or quality line (3) with nothing to drop or replace; else 0.
-__device__ __forceinline__ int fq_piece(const EncP &P, u64 base, const Piece &pc, const PMask &pm, const TileCtx &ctx)
+__device__ __forceinline__ int fq_piece(const EncP &P, u64 base, const Piece &pc, const PMask &pm, const TileCtx &ctx, const u8 *cls)
 {
     if (pc.cnt != ET_BYTES || pm.eol || ctx.ord < 0) return 0;
     i64 line_start = ctx.last_eol + 1; if ((u64)line_start < P.p0) line_start = (i64)P.p0;
     if (line_start >= (i64)base) return 0;                     // the line's first byte has its own rules (process.c:522)
     u32 type = (u32)ctx.ord & 3;
-    if (type == 1 && pm.sp == 0 && pm.exp == 0xFFFFu) return 1;
-    if (type == 3 && pm.q == 0xFFFFu) return 3;
+    if (type == 1 && pm.sp == 0 && piece_all_expected(P, pc, pm, cls, false)) return 1;
+    if (type == 3 && piece_all_qual(pc)) return 3;
     return 0;
 }
 
@@ -488,11 +545,11 @@ __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol,
     fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
-    PMask pm = piece_masks<true, true>(pc, cls);
-    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pm);
+    PMask pm = piece_masks(pc);
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, pm);
     ctx.ord = thread_ord(P, t_ls, base, lds, pc, pm);
     FqCount S;
-    int fast = fq_piece(P, base, pc, pm, ctx);
+    int fast = fq_piece(P, base, pc, pm, ctx, cls);
     if (fast == 1) S.nseq = 16; else if (fast == 3) S.nqual = 16;
     // The other pieces (headers, line ends: about a quarter of them in 150-bp reads) need the per-byte state machine.  They
     // are gathered and handled by the first lanes of the workgroup, so that one wavefront walks the slow path instead of all four.
@@ -522,12 +579,12 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
     fill_classes(P, cls);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
-    PMask pm = piece_masks<true, true>(pc, cls);
-    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, lds, pm);
+    PMask pm = piece_masks(pc);
+    TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, pm);
     ctx.ord = thread_ord(P, O.t_ls, base, lds, pc, pm);
     bool active = base <= P.n;
     FqCount C;
-    const int fast = fq_piece(P, base, pc, pm, ctx);
+    const int fast = fq_piece(P, base, pc, pm, ctx, cls);
     if (fast == 1) C.nseq = 16; else if (fast == 3) C.nqual = 16;
     __shared__ SlowCtx s_ctx[256]; __shared__ u16 s_list[256]; __shared__ u32 s_nslow; __shared__ u64 s_cnt[256];
     __shared__ u64 s_w[256][4];                                   // stream positions of the slow pieces for the write pass
@@ -618,17 +675,11 @@ __device__ __forceinline__ u32 mask_boundary_bits(const u8 *seq, u64 base, u64 T
     for (u32 i = 0; i < 16 && base + i < T; i++) { bool cur = seq[base + i] >= 96; if (cur != prev) m |= 1u << i; prev = cur; }
     return m;
 }
-__global__ __launch_bounds__(256) void k_mask_bcount(const u8 *seq, u64 T, u64 *tile_cnt)
+__global__ __launch_bounds__(256) void k_mask_bscatter(const u8 *seq, u64 T, const u64 *tile_pre, u64 nb, u64 *bnd)
 {
     __shared__ u64 lds[4];
-    u64 base = (u64)blockIdx.x * MB_TILE + (u64)threadIdx.x * 16;
-    u64 c = base < T ? __popc(mask_boundary_bits(seq, base, T)) : 0, tot;
-    wg_scan_inclusive<u64, OpAdd>(c, &tot, lds);
-    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
-}
-__global__ __launch_bounds__(256) void k_mask_bscatter(const u8 *seq, u64 T, const u64 *tile_pre, u64 *bnd)
-{
-    __shared__ u64 lds[4];
+    // most tiles of most inputs hold no case change: those are not read a second time
+    if ((blockIdx.x + 1 < gridDim.x ? tile_pre[blockIdx.x + 1] : nb) == tile_pre[blockIdx.x]) return;
     u64 base = (u64)blockIdx.x * MB_TILE + (u64)threadIdx.x * 16;
     u32 m = base < T ? mask_boundary_bits(seq, base, T) : 0;
     u64 c = __popc(m), tot;
@@ -666,9 +717,16 @@ __device__ __forceinline__ u32 nuc4(u32 c)
     if (c == '-') return 0;
     return 15;
 }
-__global__ __launch_bounds__(256) void k_pack4(const u8 *seq, u64 T, u8 *packed)
+// With tile_cnt the kernel also counts the soft-mask run boundaries of its 4096 bases (k_mask_bcount's job): both walk the same bytes.
+__global__ __launch_bounds__(256) void k_pack4(const u8 *seq, u64 T, u8 *packed, u64 *tile_cnt)
 {
     __shared__ u8 lut[256];
+    if (tile_cnt) {
+        __shared__ u32 s_c[4];
+        u64 base = (u64)blockIdx.x * MB_TILE + (u64)threadIdx.x * 16;
+        u32 tot = wg_reduce1<u32, OpAdd>(base < T ? (u32)__popc(mask_boundary_bits(seq, base, T)) : 0u, s_c);
+        if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+    }
     { u32 c = threadIdx.x; u32 v = nuc4(c); if (!((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '-')) v = 15; lut[c] = (u8)v; }
     __syncthreads();
     u64 i = ((u64)blockIdx.x * 256 + threadIdx.x) * 16;      // 16 bases -> 8 bytes
@@ -744,6 +802,11 @@ static void set_expected(EncP &P, int seq_type, bool fasta)
         P.id_gt_unexpected = fasta;
         // mid-line '>' is kept as data in text mode (process.c:410); a '>' right after an EOL starts a record
     }
+    // quick table (enc_swar.h): slot (c >> 1) & 7 holds the accepted upper-case letter out of A C G T U N, 0xFF elsewhere
+    u8 q[8]; memset(q, 0xFF, 8);
+    auto has = [&](u32 c) { return (P.expected[c >> 5] >> (c & 31)) & 1u; };
+    for (const char *p = "ACGTUN"; *p; p++) { u32 ch = (u32)*p; if (has(ch) && has(ch | 0x20) && q[(ch >> 1) & 7] == 0xFF) q[(ch >> 1) & 7] = (u8)ch; }
+    memcpy(&P.qlo, q, 4); memcpy(&P.qhi, q + 4, 4);
 }
 
 struct SecOut { u64 orig, comp; };
@@ -868,7 +931,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
         u32 *t_tail = arena_new<u32>(c, tiles + 1);
         u64 *tot = arena_new<u64>(c, 8);
         if (!t_eol || !t_sp || !t_seq || !t_ids || !t_cmt || !t_rec || !t_tail || !tot) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "ennaf_last", k_enc_last, tiles, 256, 0, P, t_eol, t_sp, (u64 *)nullptr);
+        LAUNCH(c, "ennaf_last", k_enc_last_fa, cdiv(tiles, 4), 256, 0, P, t_eol, t_sp, tiles);
         // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
         if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
         if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
@@ -913,16 +976,25 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
             LAUNCH(c, "ennaf_len_write", k_len_unit_write, cdiv(N, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, N, T, (const u64 *)lu, s_len, all_ends);
             n_lenb = nu * 4;
         }
-        // mask
+        // sequence stream; the 4-bit pack also counts the soft-mask run boundaries per tile of 4096 bases
+        u64 mt = (T + MB_TILE - 1) / MB_TILE;
+        u64 *tc = nullptr;
+        if (store_mask && T) { tc = arena_new<u64>(c, mt + 2); if (!tc) return NAF_GPU_ENOMEM; }
+        if (fourbit) {
+            n_seqb = (T + 1) / 2;
+            s_seq = (u8 *)arena_alloc(c, n_seqb + 16); if (!s_seq) return NAF_GPU_ENOMEM;
+            if (T) LAUNCH(c, "ennaf_pack4", k_pack4, cdiv(T, 256 * 16), 256, 0, (const u8 *)bases, T, s_seq, tc);
+        } else {
+            if (o->no_mask && T) LAUNCH(c, "ennaf_toupper", k_toupper, cdiv(T, 256), 256, 0, bases, T);   // process.c:46-51
+            s_seq = bases; n_seqb = T;
+        }
+        // mask (only ever stored next to a 4-bit sequence stream, ennaf.c:445)
         if (store_mask && T) {
-            u64 mt = (T + MB_TILE - 1) / MB_TILE;
-            u64 *tc = arena_new<u64>(c, mt + 2); if (!tc) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "ennaf_mask_bcount", k_mask_bcount, mt, 256, 0, (const u8 *)bases, T, tc);
             if ((rc = scan_exclusive_u64(c, tc, mt, tc + mt + 1))) return rc;
             u64 nb = 0; if ((rc = ctx_readback(c, &nb, tc + mt + 1, 8))) return rc;
             u64 *bnd = arena_new<u64>(c, nb + 1), *ru = arena_new<u64>(c, nb + 3);
             if (!bnd || !ru) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "ennaf_mask_bscatter", k_mask_bscatter, mt, 256, 0, (const u8 *)bases, T, (const u64 *)tc, bnd);
+            if (nb) LAUNCH(c, "ennaf_mask_bscatter", k_mask_bscatter, mt, 256, 0, (const u8 *)bases, T, (const u64 *)tc, nb, bnd);
             LAUNCH(c, "ennaf_mask_runs", k_mask_run_units, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, ru);
             if ((rc = scan_exclusive_u64(c, ru, nb + 1, ru + nb + 2))) return rc;
             u64 nu = 0; if ((rc = ctx_readback(c, &nu, ru + nb + 2, 8))) return rc;
@@ -934,15 +1006,6 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
             // quarter.  Very long runs give strings of 255s (constant blocks, nothing to walk): 32 KiB blocks keep the block count down.
             mask_block_log = nu / (nb + 1) > 1000 ? 15 : 13;
             n_mask = nu;
-        }
-        // sequence stream
-        if (fourbit) {
-            n_seqb = (T + 1) / 2;
-            s_seq = (u8 *)arena_alloc(c, n_seqb + 16); if (!s_seq) return NAF_GPU_ENOMEM;
-            if (T) LAUNCH(c, "ennaf_pack4", k_pack4, cdiv(T, 256 * 16), 256, 0, (const u8 *)bases, T, s_seq);
-        } else {
-            if (o->no_mask && T) LAUNCH(c, "ennaf_toupper", k_toupper, cdiv(T, 256), 256, 0, bases, T);   // process.c:46-51
-            s_seq = bases; n_seqb = T;
         }
     }
     R.n_sequences = N; R.n_bases = T; R.longest_line = longest;

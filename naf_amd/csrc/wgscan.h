@@ -47,6 +47,32 @@ template <typename T, typename Op> __device__ __forceinline__ T wave_scan_inclus
     return v;
 }
 
+// Two 16-bit maxima in one 32-bit value (v_pk_max_u16).
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+struct OpPkMaxU16 {
+    template <typename T> __device__ static T id() { return (T)0; }
+    template <typename T> __device__ static T f(T a, T b) { return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, (u32)a), __builtin_bit_cast(u16x2_t, (u32)b))); }
+};
+// lane i <- lane i-1 of the wavefront; lane 0 gets the identity
+template <typename T, typename Op> __device__ __forceinline__ T wave_shift_up1(T v) { return dpp_hop<0x138, 0xf>(Op::template id<T>(), v); }
+
+// Workgroup scan with ONE barrier: returns the wave-inclusive value, *pre = aggregate of the earlier waves (inclusive result =
+// f(*pre, return)), *total = workgroup aggregate.  `slots` (4 entries) must not be written again before another barrier.
+template <typename T, typename Op>
+__device__ __forceinline__ T wg_scan1(T v, T *pre_out, T *total, T *slots)
+{
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_scan_inclusive<T, Op>(v);
+    if (lane == 63) slots[wave] = v;
+    __syncthreads();
+    T pre = Op::template id<T>(), tot = Op::template id<T>();
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; w++) { T x = slots[w]; if (w < wave) pre = Op::template f<T>(pre, x); tot = Op::template f<T>(tot, x); }
+    *pre_out = pre; *total = tot;
+    return v;
+}
+template <typename T, typename Op> __device__ __forceinline__ T wg_reduce1(T v, T *slots) { T pre, tot; wg_scan1<T, Op>(v, &pre, &tot, slots); return tot; }
+
 // Inclusive scan of one value per thread across the 256-thread workgroup; returns inclusive result,
 // *total = workgroup aggregate.
 template <typename T, typename Op>

@@ -257,3 +257,41 @@ def test_byte_ranges_tile_any_total():
                 assert b == min(pos, total) and e >= b
                 pos = e
             assert pos == total
+
+
+# ---- encoder front end: the four-bytes-per-instruction byte classes against the plain predicates -------------------------------
+def _quick_table(expected):
+    """host side of enc.hip:set_expected -- slot (c >> 1) & 7 holds the accepted upper-case letter, 0xFF elsewhere"""
+    t = [0xFF] * 8
+    for ch in b"ACGTUN":
+        if ch in expected and (ch | 0x20) in expected and t[(ch >> 1) & 7] == 0xFF:
+            t[(ch >> 1) & 7] = ch
+    return int.from_bytes(bytes(t[:4]), "little"), int.from_bytes(bytes(t[4:]), "little"), {c for c in t if c != 0xFF}
+
+
+@pytest.mark.parametrize("alphabet", [b"ABCDGHKMNRSTVWY", b"ABCDGHKMNRSUVWY", bytes(range(0x41, 0x5B))])
+def test_swar_piece_flags_every_byte_every_position(alphabet):
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "emul", "libzstd_emul.so"))
+    expected = set(alphabet) | {c | 0x20 for c in alphabet} | {ord("-")}
+    qlo, qhi, quick = _quick_table(expected)
+    assert quick                                                # the table is not empty for any of the reference's alphabets
+    rng = np.random.default_rng(5)
+    out = (ctypes.c_uint32 * 6)()
+    fills = [bytes([65] * 16), bytes([10] * 16), bytes([0x20] * 16), bytes([0x7E] * 16), bytes(rng.integers(0, 256, 16, dtype=np.uint8)),
+             bytes(rng.choice(np.frombuffer(b"ACGTNacgtn\n", dtype=np.uint8), 16))]
+    is_eol = lambda c: 0x0A <= c <= 0x0D
+    is_sp = lambda c: 0x09 <= c <= 0x0D or c == 0x20
+    is_quick = lambda c: (c & 0xDF) in quick and c in expected
+    for fill in fills:
+        for pos in range(16):
+            for b in range(256):
+                p = bytearray(fill); p[pos] = b
+                lib.emul_piece_flags(bytes(p), qlo, qhi, out)
+                assert out[0] == sum(1 << i for i, c in enumerate(p) if is_eol(c)), (fill, pos, b)
+                assert out[1] == sum(1 << i for i, c in enumerate(p) if is_sp(c)), (fill, pos, b)
+                assert out[2] == sum(1 << i for i, c in enumerate(p) if c == 0x3E), (fill, pos, b)
+                assert out[3] == int(all(is_sp(c) or is_quick(c) for c in p)), (fill, pos, b)
+                assert out[4] == int(all(is_quick(c) for c in p)), (fill, pos, b)
+                assert out[5] == int(all(0x21 <= c <= 0x7E for c in p)), (fill, pos, b)
+                # the quick test is only ever a sufficient one
+                if out[3]: assert all(is_sp(c) or c in expected for c in p)
