@@ -14,6 +14,11 @@
 #include "wgscan.h"
 struct OpMaxU64 { template <typename T> __device__ static T id() { return (T)0; } template <typename T> __device__ static T f(T a, T b) { return a > b ? a : b; } };
 #define ZENC_HCOPIES 4
+// Huffman tree descriptions of a sample of the blocks, looked up by weight table (one per zstd_encode call, zeroed by the host).
+#define ZENC_CACHE_ENTRIES 256
+struct ZTreeEntry { u64 key; u32 tb, pad; u8 wt[256]; u8 tree[ZENC_TREE_SLOT]; };   // key 0: empty
+struct ZTreeCache { ZTreeEntry e[ZENC_CACHE_ENTRIES]; };
+static_assert(ZENC_CACHE_ENTRIES == 256, "one entry per thread of the plan kernel");
 struct ZPlanWS {
     u32 tot[256]; u32 w[512]; u16 order[256]; u16 parent[512]; u8 depth[512];
     u8 len[256], wt[256], tree[ZENC_TREE_SLOT], tmp[160];
@@ -25,12 +30,12 @@ __host__ __device__ static inline u64 zenc_block_lo(u64 n, u32 nblk, u32 b) { u6
 
 // blk_len == nullptr: block b is the b-th piece of the even split of src[0..n).  Otherwise block b is src[b*slot .. b*slot + blk_len[b])
 // (the literals the LZ stage left of block b).
-__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u32 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot)
+__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u32 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse)
 {
     // ZENC_HCOPIES copies of the 4 quarter histograms (copy = lane % copies): few distinct symbols (packed ACGT has 16) would
     // otherwise serialise every LDS atomic of a wave on the same handful of addresses
     __shared__ u32 hist[ZENC_HCOPIES * 1024];
-    u32 b = blockIdx.x;
+    u32 b = sample_stride ? blockIdx.x * sample_stride : blockIdx.x;
     u64 lo = zenc_block_lo(n, nblk, b), hi = zenc_block_lo(n, nblk, b + 1);
     if (blk_len) { lo = (u64)b * slot; hi = lo + blk_len[b]; }
     u32 bn = (u32)(hi - lo);
@@ -95,7 +100,33 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
             u32 l = ws.len[sym];
             ws.wt[sym] = l ? (u8)(log + 1 - l) : 0;
             u64 lastw; wg_scan_inclusive<u64, OpMaxU64>(l ? (u64)sym : 0, &lastw, red);
-            if (threadIdx.x == 0) ws.tb = huf_write_tree_w(ws.tree, ws.wt, (u32)lastw, ws.tmp, ws.fse);
+            // The tree description depends on the weights only, and blocks of one stream keep producing the same few weight
+            // tables (packed random ACGT: one).  A first launch (sample_stride != 0) plans a sample of the blocks and leaves
+            // their descriptions in `cache`; the launch over all blocks looks its weights up there and codes them itself
+            // only on a miss -- the serial FSE coding of the weights by one lane was half of this kernel's time.
+            u64 hk; wg_scan_inclusive<u64, OpAdd>(l ? (u64)(sym * 16 + (log + 1 - l) + 1) * 0x9E3779B97F4A7C15ull ^ ((u64)sym << 40) : 0, &hk, red);
+            hk |= 1;                                                            // 0 marks an empty entry
+            bool hit = false;
+            if (cache && !sample_stride) {
+                __shared__ u32 s_slot;
+                if (threadIdx.x == 0) s_slot = ~0u;
+                __syncthreads();
+                if (cache->e[sym].key == hk) atomicMin(&s_slot, sym);
+                __syncthreads();
+                u32 slot_i = s_slot;
+                if (slot_i != ~0u) {
+                    const ZTreeEntry *ce = &cache->e[slot_i];
+                    hit = __syncthreads_and(ce->wt[sym] == ws.wt[sym]) != 0;   // exact comparison: the hash only picks the entry
+                    if (hit) { if (sym < ZENC_TREE_SLOT) ws.tree[sym] = ce->tree[sym]; if (sym == 0) ws.tb = ce->tb; }
+                }
+            }
+            if (!hit && threadIdx.x == 0) ws.tb = huf_write_tree_w(ws.tree, ws.wt, (u32)lastw, ws.tmp, ws.fse, try_fse != 0);
+            if (cache && sample_stride) {
+                __syncthreads();
+                ZTreeEntry *ce = &cache->e[blockIdx.x];
+                ce->wt[sym] = ws.wt[sym]; if (sym < ZENC_TREE_SLOT) ce->tree[sym] = ws.tree[sym];
+                if (sym == 0) { ce->tb = ws.tb; ce->key = ws.tb ? hk : 0; }
+            }
             u64 bits;
             for (u32 k = 0; k < 4; k++) { wg_scan_inclusive<u64, OpAdd>((u64)hist[256 * k + sym] * l, &bits, red); p.ssz[k] = (u32)((bits + 1 + 7) / 8); }
             __syncthreads();
@@ -400,8 +431,16 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
     ZEncPlan *plan = arena_new<ZEncPlan>(c, nblk);
     u32 *codes = arena_new<u32>(c, (size_t)nblk * 256); u8 *trees = (u8 *)arena_alloc(c, (size_t)nblk * ZENC_TREE_SLOT);
     u64 *offs = arena_new<u64>(c, (size_t)nblk + 2);
-    if (!plan || !codes || !trees || !offs) return NAF_GPU_ENOMEM;
-    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0);
+    // level 1 writes Huffman weights directly where the format allows it (up to 128 of them): FSE-coding them saves about a
+    // dozen bytes per block and costs one lane a serial pass per block
+    const u32 try_fse = level >= 2;
+    // tree descriptions of ZENC_CACHE_ENTRIES evenly spaced blocks first (worth a launch from a few thousand blocks up)
+    const u32 sample_stride = nblk >= 16 * ZENC_CACHE_ENTRIES ? nblk / ZENC_CACHE_ENTRIES : 0;
+    ZTreeCache *cache = sample_stride ? arena_new<ZTreeCache>(c, 1) : nullptr;
+    if (!plan || !codes || !trees || !offs || (sample_stride && !cache)) return NAF_GPU_ENOMEM;
+    if (cache) HIP_TRY(c, hipMemsetAsync(cache, 0, sizeof(ZTreeCache), c->stream));
+    if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse);
+    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse);
     ZWriteLz L; memset(&L, 0, sizeof L);
     if (use_lz && n >= 64) {
         if (!c->d_seqctab) {
@@ -419,7 +458,7 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
         if (!B.lits || !B.seqbuf || !B.ll || !B.ml || !B.of || !B.nseq || !B.nlit || !B.seq_bytes || !plan1 || !codes1 || !trees1 || !mode) return NAF_GPU_ENOMEM;
         LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, 0, d_src, (u64)n, nblk, B);
         LAUNCH(c, "zenc_lz_seqenc", k_lz_seqenc, cdiv(nblk, 64), 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
-        LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot);
+        LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse);
         LAUNCH(c, "zenc_lz_choose", k_lz_choose, cdiv(nblk, 256), 256, 0, nblk, (const ZEncPlan *)plan, (const ZEncPlan *)plan1, (const u32 *)B.nseq, (const u32 *)B.seq_bytes, mode, offs);
         L.mode = mode; L.plan1 = plan1; L.codes1 = codes1; L.trees1 = trees1; L.B = B;
     }

@@ -248,10 +248,12 @@ NAF_HD u32 fse_compress_weights(u8 *out, u32 cap, const u8 *w, u32 n, FseWS &ws)
 // Huffman tree description (4.2.1): FSE-compressed weights when smaller (mandatory above 128 weights),
 // else direct 4-bit weights.  len[] = code lengths, log = max length.  Returns bytes, 0 = not representable.
 // w[0..n) = weights of symbols 0..n-1 (n = index of the last present symbol, whose weight is implied).
-NAF_HD u32 huf_write_tree_w(u8 *out, const u8 *w, u32 n, u8 *tmp /*160*/, FseWS &ws)
+// try_fse = false: direct weights whenever they are representable (n <= 128) -- a dozen bytes per block more, none of the
+// serial FSE coding.
+NAF_HD u32 huf_write_tree_w(u8 *out, const u8 *w, u32 n, u8 *tmp /*160*/, FseWS &ws, bool try_fse = true)
 {
     if (n == 0) return 0;
-    u32 fs = fse_compress_weights(tmp, 160, w, n, ws);
+    u32 fs = (try_fse || n > 128) ? fse_compress_weights(tmp, 160, w, n, ws) : 0;
     if (fs > 1 && fs < 128 && fs < (n + 1) / 2 + 0u + 1) { out[0] = (u8)fs; for (u32 i = 0; i < fs; i++) out[1 + i] = tmp[i]; return 1 + fs; }
     if (n > 128) return 0;
     out[0] = (u8)(127 + n);
