@@ -425,6 +425,7 @@ struct FqOut {
     u64 *unexpected;              // [4][257]: id, comment, sequence, quality
     u64 *first_error;             // min over (record * 4 + kind)
     const u64 *t_seq, *t_ids, *t_cmt, *t_qual, *t_ls;
+    const u32 *piece_cnt;         // per 16-byte piece: the four stream counts found by k_encq_count, 8 bits each
 };
 
 template <typename Sink>
@@ -538,7 +539,7 @@ __device__ __forceinline__ int fq_piece(const EncP &P, u64 base, const Piece &pc
 }
 
 __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol, const i64 *tile_sp, const u64 *t_ls,
-                                                     u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_qual)
+                                                     u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_qual, u32 *piece_cnt)
 {
     __shared__ u64 lds[4];
     __shared__ u8 cls[256];
@@ -567,6 +568,8 @@ __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol,
     }
     __syncthreads();
     if (slow) { u64 v = s_cnt[threadIdx.x]; S.nseq = v & 0xFFFF; S.nids = (v >> 16) & 0xFFFF; S.ncmt = (v >> 32) & 0xFFFF; S.nqual = (u32)(v >> 48); }
+    // the four counts of every piece (each at most 17) are kept for the scatter pass, which then walks the slow pieces once, not twice
+    piece_cnt[(u64)blockIdx.x * 256 + threadIdx.x] = S.nseq | (S.nids << 8) | (S.ncmt << 16) | (S.nqual << 24);
     u64 tot;
     wg_scan_inclusive<u64, OpAdd>((u64)S.nseq | ((u64)S.nids << 16) | ((u64)S.ncmt << 32) | ((u64)S.nqual << 48), &tot, lds);
     if (threadIdx.x == 0) { t_seq[blockIdx.x] = tot & 0xFFFF; t_ids[blockIdx.x] = (tot >> 16) & 0xFFFF; t_cmt[blockIdx.x] = (tot >> 32) & 0xFFFF; t_qual[blockIdx.x] = tot >> 48; }
@@ -585,22 +588,11 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
     bool active = base <= P.n;
     FqCount C;
     const int fast = fq_piece(P, base, pc, pm, ctx, cls);
-    if (fast == 1) C.nseq = 16; else if (fast == 3) C.nqual = 16;
-    __shared__ SlowCtx s_ctx[256]; __shared__ u16 s_list[256]; __shared__ u32 s_nslow; __shared__ u64 s_cnt[256];
+    { u32 v = O.piece_cnt[(u64)blockIdx.x * 256 + threadIdx.x]; C.nseq = v & 0xFF; C.nids = (v >> 8) & 0xFF; C.ncmt = (v >> 16) & 0xFF; C.nqual = v >> 24; }
+    __shared__ SlowCtx s_ctx[256]; __shared__ u16 s_list[256]; __shared__ u32 s_nslow;
     __shared__ u64 s_w[256][4];                                   // stream positions of the slow pieces for the write pass
     const bool slow = !fast && active;
     slow_gather(slow, ctx, s_ctx, s_list, &s_nslow);
-    if (threadIdx.x < s_nslow) {
-        u32 who = s_list[threadIdx.x];
-        u64 b2 = (u64)blockIdx.x * ET_TILE + (u64)who * ET_BYTES;
-        Piece p2 = load_piece(P, b2);
-        TileCtx c2; c2.last_eol = s_ctx[who].le; c2.last_sp = s_ctx[who].ls; c2.hdr = false; c2.ord = s_ctx[who].ord;
-        FqCount S2;
-        classify_range_fastq(P, b2, p2, (b2 + p2.cnt == P.n) && p2.cnt < ET_BYTES, c2, S2, cls);
-        s_cnt[who] = (u64)S2.nseq | ((u64)S2.nids << 16) | ((u64)S2.ncmt << 32) | ((u64)S2.nqual << 48);
-    }
-    __syncthreads();
-    if (slow) { u64 v = s_cnt[threadIdx.x]; C.nseq = v & 0xFFFF; C.nids = (v >> 16) & 0xFFFF; C.ncmt = (v >> 32) & 0xFFFF; C.nqual = (u32)(v >> 48); }
     u64 totp;
     u64 ip = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq | ((u64)C.nids << 16) | ((u64)C.ncmt << 32) | ((u64)C.nqual << 48), &totp, lds);
     u64 iseq = ip & 0xFFFF, iids = (ip >> 16) & 0xFFFF, icmt = (ip >> 32) & 0xFFFF, iq = ip >> 48, tots = totp & 0xFFFF, totq = totp >> 48;
@@ -871,12 +863,13 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
         u64 *t_ls = arena_new<u64>(c, tiles + 2), *t_seq = arena_new<u64>(c, tiles + 2), *t_ids = arena_new<u64>(c, tiles + 2),
             *t_cmt = arena_new<u64>(c, tiles + 2), *t_qual = arena_new<u64>(c, tiles + 2);
         u64 *tot = arena_new<u64>(c, 8);
-        if (!t_eol || !t_sp || !t_ls || !t_seq || !t_ids || !t_cmt || !t_qual || !tot) return NAF_GPU_ENOMEM;
+        u32 *piece_cnt = arena_new<u32>(c, tiles * 256);
+        if (!t_eol || !t_sp || !t_ls || !t_seq || !t_ids || !t_cmt || !t_qual || !tot || !piece_cnt) return NAF_GPU_ENOMEM;
         LAUNCH(c, "ennaf_last", k_enc_last, tiles, 256, 0, P, t_eol, t_sp, t_ls);
         if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
         if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
         if ((rc = scan_exclusive_u64(c, t_ls, tiles, tot + 4))) return rc;
-        LAUNCH(c, "ennaf_fq_count", k_encq_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual);
+        LAUNCH(c, "ennaf_fq_count", k_encq_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, piece_cnt);
         if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
         if ((rc = scan_exclusive_u64(c, t_ids, tiles, tot + 1))) return rc;
         if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;
@@ -900,7 +893,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
         HIP_TRY(c, hipMemsetAsync(q_begin, 0, (N + 1) * 8, c->stream)); HIP_TRY(c, hipMemsetAsync(q_end, 0, (N + 1) * 8, c->stream));
         FqOut O; O.seq = bases; O.ids = s_ids; O.cmt = s_cmt; O.qual = s_qual; O.rec_begin = rec_begin; O.rec_end = rec_end; O.q_begin = q_begin; O.q_end = q_end;
         O.unexpected = d_unexp; O.first_error = d_unexp + 4 * 257;
-        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_qual = t_qual; O.t_ls = t_ls;
+        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_qual = t_qual; O.t_ls = t_ls; O.piece_cnt = piece_cnt;
         LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
         if (nlines / 4) LAUNCH(c, "ennaf_fq_check", k_fq_check, cdiv(nlines / 4, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, (const u64 *)q_begin, (const u64 *)q_end, nlines / 4, O.first_error, d_unexp + 4 * 257 + 1);
         std::vector<u64> hu(4 * 257 + 2);

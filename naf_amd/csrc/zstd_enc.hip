@@ -30,7 +30,7 @@ __host__ __device__ static inline u64 zenc_block_lo(u64 n, u32 nblk, u32 b) { u6
 
 // blk_len == nullptr: block b is the b-th piece of the even split of src[0..n).  Otherwise block b is src[b*slot .. b*slot + blk_len[b])
 // (the literals the LZ stage left of block b).
-__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u32 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse)
+__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse)
 {
     // ZENC_HCOPIES copies of the 4 quarter histograms (copy = lane % copies): few distinct symbols (packed ACGT has 16) would
     // otherwise serialise every LDS atomic of a wave on the same handful of addresses
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
         __syncthreads();
         if (sym == 0) { u32 pos = 0; for (u32 w = 1; w <= p.log; w++) { wstart[w] = pos; pos += wcnt[w] << (w - 1); } }
         __syncthreads();
-        codes[(u64)b * 256 + sym] = l ? (((wstart[wgt] >> (wgt - 1)) + rank) | (l << 16)) : 0;
+        codes[(u64)b * 256 + sym] = l ? (u16)(((wstart[wgt] >> (wgt - 1)) + rank) | (l << 12)) : (u16)0;   // code (<= 11 bits) | length << 12
         if (sym < p.tree_bytes) trees[(u64)b * ZENC_TREE_SLOT + sym] = ws.tree[sym];
     }
 }
@@ -166,10 +166,13 @@ struct LzBufs {
     u32 *nseq, *nlit;
     u8 *seqbuf; u32 *seq_bytes;         // encoded Sequences_Section of block b at seqbuf + b*slot
 };
-__global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk, LzBufs B)
+// Dynamic LDS: the block (block size + 320 bytes of zero padding) followed by the hash table; sized by the host for the
+// block size in use, since LDS per wavefront is what bounds the blocks in flight (16 KiB blocks: 6 per CU, 32 KiB: 3).
+__global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk, LzBufs B, u32 buf_bytes)
 {
-    __shared__ __attribute__((aligned(16))) u8 buf[LZ_BLOCK_MAX + 320];
-    __shared__ u16 tab[1 << LZ_HASH_LOG];
+    extern __shared__ __attribute__((aligned(16))) u8 lz_lds[];
+    u8 *buf = lz_lds;
+    u16 *tab = (u16 *)(lz_lds + buf_bytes);
     const u32 b = blockIdx.x, lane = threadIdx.x;
     const u64 lo = zenc_block_lo(n, nblk, b);
     const u32 bn = (u32)(zenc_block_lo(n, nblk, b + 1) - lo);
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk,
         else for (u32 k = i; k < bn; k++) buf[k] = src[lo + k];
     }
     for (u32 i = lane; i < (1u << LZ_HASH_LOG); i += 64) tab[i] = 0;     // 0 = empty, else position + 1
-    for (u32 i = bn + lane; i < bn + 320 && i < LZ_BLOCK_MAX + 320; i += 64) buf[i] = 0;
+    for (u32 i = bn + lane; i < bn + 320 && i < buf_bytes; i += 64) buf[i] = 0;
     __syncthreads();
     u8 *lits = B.lits + (u64)b * B.slot;
     u16 *sll = B.ll + (u64)b * B.seq_slot, *sml = B.ml + (u64)b * B.seq_slot, *sof = B.of + (u64)b * B.seq_slot;
@@ -277,7 +280,7 @@ __global__ void k_lz_choose(u32 nblk, const ZEncPlan *plan0, const ZEncPlan *pla
 // One Huffman stream (4.2.2: written forward so that the LAST symbol is read first) by one lane.  Input is pulled 64 bytes
 // at a time into registers (walking down), output is collected in the lane's LDS row and leaves as aligned 64-byte
 // segments: per-lane 8-byte loads re-fetch every line 4x and per-lane 8-byte stores cost 6x the bytes at the HBM.
-__device__ __forceinline__ void huf_encode_stream_staged(u8 *out, const u8 *src, u32 n, const u32 *codes, u8 *orow)
+__device__ __forceinline__ void huf_encode_stream_staged(u8 *out, const u8 *src, u32 n, const u16 *codes, u8 *orow)
 {
     u64 acc = 0; u32 nb = 0; u8 *p = out;
     u32 fill = 0; bool staged = false;                            // staged: p is 64-byte aligned and row[0..fill) holds the bytes at p
@@ -300,7 +303,7 @@ __device__ __forceinline__ void huf_encode_stream_staged(u8 *out, const u8 *src,
         }
     };
     auto put = [&](u32 sym) {
-        u32 e = codes[sym]; u32 len = e >> 16; u64 v = (u64)(e & 0xFFFF);
+        u32 e = codes[sym]; u32 len = e >> 12; u64 v = (u64)(e & 0xFFF);
         acc |= v << nb;                                            // nb < 64 here; bits that do not fit are re-added after the word leaves
         if (nb + len >= 64) { emit_word(acc); acc = nb ? (v >> (64 - nb)) : 0; nb = nb + len - 64; }
         else nb += len;
@@ -326,21 +329,22 @@ __device__ __forceinline__ void huf_encode_stream_staged(u8 *out, const u8 *src,
 
 // LZ-coded blocks (mode[b] != 0) take their literals from L.lits with the plan / codes / tree of those literals (plan1 ...)
 // and append the Sequences_Section made by k_lz_seqenc; all other blocks are coded from src as literal-only blocks.
-struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u32 *codes1; const u8 *trees1; LzBufs B; };
-__global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nblk, const ZEncPlan *plan, const u32 *codes_g, const u8 *trees,
+struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u16 *codes1; const u8 *trees1; LzBufs B; };
+__global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nblk, const ZEncPlan *plan, const u16 *codes_g, const u8 *trees,
                                                     const u64 *offs, u8 *dst, u64 frame_hdr, ZWriteLz L)
 {
-    __shared__ __attribute__((aligned(16))) u32 codes[ZENC_BLOCKS_PER_WG][256];
+    // 16-bit entries: 8 KiB of tables per workgroup instead of 16 -- LDS is what bounds the waves resident per CU here
+    __shared__ __attribute__((aligned(16))) u16 codes[ZENC_BLOCKS_PER_WG][256];
     __shared__ __attribute__((aligned(16))) u8 orows[64 * ZENC_OROW];
     int lane = threadIdx.x;
     u32 b0 = blockIdx.x * ZENC_BLOCKS_PER_WG;
-    for (u32 jj = 0; jj < ZENC_BLOCKS_PER_WG; jj++) {               // code tables made by k_zenc_plan: 1 KiB per block, coalesced
+    for (u32 jj = 0; jj < ZENC_BLOCKS_PER_WG; jj++) {               // code tables made by k_zenc_plan: 512 B per block, coalesced
         u32 bb = b0 + jj;
         if (bb >= nblk) break;
         const bool lzb = L.mode && L.mode[bb];
         if ((lzb ? L.plan1[bb].kind : plan[bb].kind) != ZK_HUF) continue;
         const uint4 *g = (const uint4 *)((lzb ? L.codes1 : codes_g) + (u64)bb * 256);
-        ((uint4 *)codes[jj])[lane] = g[lane];
+        if (lane < 32) ((uint4 *)codes[jj])[lane] = g[lane];
     }
     __syncthreads();
     u32 j = lane >> 2, k = lane & 3, b = b0 + j;
@@ -429,7 +433,7 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
     u64 hdr = with_magic ? 6 : 2;
     if (cap < hdr + n + 3ull * nblk) return ctx_fail(c, NAF_GPU_ECAP, "zstd_compress capacity %zu too small (bound %llu)", cap, (unsigned long long)(hdr + n + 3ull * nblk));
     ZEncPlan *plan = arena_new<ZEncPlan>(c, nblk);
-    u32 *codes = arena_new<u32>(c, (size_t)nblk * 256); u8 *trees = (u8 *)arena_alloc(c, (size_t)nblk * ZENC_TREE_SLOT);
+    u16 *codes = arena_new<u16>(c, (size_t)nblk * 256); u8 *trees = (u8 *)arena_alloc(c, (size_t)nblk * ZENC_TREE_SLOT);
     u64 *offs = arena_new<u64>(c, (size_t)nblk + 2);
     // level 1 writes Huffman weights directly where the format allows it (up to 128 of them): FSE-coding them saves about a
     // dozen bytes per block and costs one lane a serial pass per block
@@ -453,10 +457,11 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
         B.ll = arena_new<u16>(c, (size_t)nblk * B.seq_slot); B.ml = arena_new<u16>(c, (size_t)nblk * B.seq_slot); B.of = arena_new<u16>(c, (size_t)nblk * B.seq_slot);
         B.nseq = arena_new<u32>(c, nblk); B.nlit = arena_new<u32>(c, nblk); B.seq_bytes = arena_new<u32>(c, nblk);
         ZEncPlan *plan1 = arena_new<ZEncPlan>(c, nblk);
-        u32 *codes1 = arena_new<u32>(c, (size_t)nblk * 256); u8 *trees1 = (u8 *)arena_alloc(c, (size_t)nblk * ZENC_TREE_SLOT);
+        u16 *codes1 = arena_new<u16>(c, (size_t)nblk * 256); u8 *trees1 = (u8 *)arena_alloc(c, (size_t)nblk * ZENC_TREE_SLOT);
         u8 *mode = (u8 *)arena_alloc(c, nblk);
         if (!B.lits || !B.seqbuf || !B.ll || !B.ml || !B.of || !B.nseq || !B.nlit || !B.seq_bytes || !plan1 || !codes1 || !trees1 || !mode) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, 0, d_src, (u64)n, nblk, B);
+        const u32 lz_buf = (u32)((bs + 1 + 320 + 15) & ~15ull);           // a block of the even split holds at most bs bytes
+        LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << LZ_HASH_LOG), d_src, (u64)n, nblk, B, lz_buf);
         LAUNCH(c, "zenc_lz_seqenc", k_lz_seqenc, cdiv(nblk, 64), 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
         LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse);
         LAUNCH(c, "zenc_lz_choose", k_lz_choose, cdiv(nblk, 256), 256, 0, nblk, (const ZEncPlan *)plan, (const ZEncPlan *)plan1, (const u32 *)B.nseq, (const u32 *)B.seq_bytes, mode, offs);
@@ -464,7 +469,7 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
     }
     int rc = scan_exclusive_u64(c, offs, nblk, offs + nblk + 1); if (rc) return rc;
     LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, with_magic);
-    LAUNCH(c, "zenc_write", k_zenc_write, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, d_src, (u64)n, nblk, (const ZEncPlan *)plan, (const u32 *)codes, (const u8 *)trees,
+    LAUNCH(c, "zenc_write", k_zenc_write, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, d_src, (u64)n, nblk, (const ZEncPlan *)plan, (const u16 *)codes, (const u8 *)trees,
            (const u64 *)offs, d_dst, hdr, L);
     u64 total = 0;
     rc = ctx_readback(c, &total, offs + nblk + 1, 8); if (rc) return rc;
