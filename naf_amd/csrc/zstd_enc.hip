@@ -454,7 +454,7 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
         }
         LzBufs B; B.slot = bs; B.seq_slot = bs / 4 + 2;
         B.lits = (u8 *)arena_alloc(c, (size_t)nblk * B.slot + 64); B.seqbuf = (u8 *)arena_alloc(c, (size_t)nblk * B.slot + 64);
-        B.ll = arena_new<u16>(c, (size_t)nblk * B.seq_slot); B.ml = arena_new<u16>(c, (size_t)nblk * B.seq_slot); B.of = arena_new<u16>(c, (size_t)nblk * B.seq_slot);
+        B.ll = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8); B.ml = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8); B.of = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8);   // + 8: read in groups of eight
         B.nseq = arena_new<u32>(c, nblk); B.nlit = arena_new<u32>(c, nblk); B.seq_bytes = arena_new<u32>(c, nblk);
         ZEncPlan *plan1 = arena_new<ZEncPlan>(c, nblk);
         u16 *codes1 = arena_new<u16>(c, (size_t)nblk * 256); u8 *trees1 = (u8 *)arena_alloc(c, (size_t)nblk * ZENC_TREE_SLOT);

@@ -96,6 +96,8 @@ struct BitW { u8 *p; u64 acc; u32 n; };
 NAF_HD void bitw_init(BitW &b, u8 *p) { b.p = p; b.acc = 0; b.n = 0; }
 NAF_HD void bitw_add(BitW &b, u32 v, u32 nbits) { b.acc |= (u64)(v & ((nbits >= 32) ? 0xFFFFFFFFu : ((1u << nbits) - 1))) << b.n; b.n += nbits; }
 NAF_HD void bitw_flush(BitW &b) { while (b.n >= 8) { *b.p++ = (u8)b.acc; b.acc >>= 8; b.n -= 8; } }
+// four bytes at once when there are that many: leaves fewer than 32 bits, so another 32 can be added before the next flush
+NAF_HD void bitw_flush32(BitW &b) { if (b.n >= 32) { st32(b.p, (u32)b.acc); b.p += 4; b.acc >>= 32; b.n -= 32; } }
 // final marker bit + padding; returns end pointer
 NAF_HD u8 *bitw_close(BitW &b) { bitw_add(b, 1, 1); bitw_flush(b); if (b.n) { *b.p++ = (u8)b.acc; b.n = 0; } return b.p; }
 
@@ -203,6 +205,13 @@ NAF_HD void fse_cencode(BitW &b, u32 &st, const u16 *tableU16, const FseCSym *tt
 {
     u32 nbBitsOut = (u32)(((i32)st + tt[sym].deltaNbBits) >> 16);
     bitw_add(b, st, nbBitsOut); bitw_flush(b);
+    st = tableU16[((i32)st >> nbBitsOut) + tt[sym].deltaFindState];
+}
+// the same without the flush (the caller flushes 32 bits at a time)
+NAF_HD void fse_cencode_nf(BitW &b, u32 &st, const u16 *tableU16, const FseCSym *tt, u32 sym)
+{
+    u32 nbBitsOut = (u32)(((i32)st + tt[sym].deltaNbBits) >> 16);
+    bitw_add(b, st, nbBitsOut);
     st = tableU16[((i32)st >> nbBitsOut) + tt[sym].deltaFindState];
 }
 
@@ -417,22 +426,30 @@ NAF_HD u32 zenc_write_sequences(u8 *out, u32 cap, const u16 *ll, const u16 *ml, 
     else { out[pos++] = 255; out[pos++] = (u8)(nseq - 0x7F00); out[pos++] = (u8)((nseq - 0x7F00) >> 8); }
     out[pos++] = 0;                                            // Symbol_Compression_Modes: predefined x3
     BitW b; bitw_init(b, out + pos);
+    // The three arrays are read eight entries (16 bytes) at a time, walking down: one lane per block reads them from HBM, and an
+    // access per sequence and array was a memory latency each.  The arrays must be readable up to the next multiple of 8 entries.
+    u16 cl[8], cm[8], co[8];
     u32 i = nseq - 1;
-    u32 llc = zenc_ll_code(ll[i]), mlc = zenc_ml_code(ml[i]), ofv = (u32)of[i] + 3, ofc = (u32)hibit32(ofv);
+    memcpy(cl, ll + (i & ~7u), 16); memcpy(cm, ml + (i & ~7u), 16); memcpy(co, of + (i & ~7u), 16);
+    u32 vl = cl[i & 7], vm = cm[i & 7];
+    u32 llc = zenc_ll_code(vl), mlc = zenc_ml_code(vm), ofv = (u32)co[i & 7] + 3, ofc = (u32)hibit32(ofv);
     u32 sML = fse_cinit(ct[2].tableU16, ct[2].tt, mlc), sOF = fse_cinit(ct[1].tableU16, ct[1].tt, ofc), sLL = fse_cinit(ct[0].tableU16, ct[0].tt, llc);
-    bitw_add(b, ll[i] - ll_base(llc), ll_bits(llc)); bitw_flush(b);
-    bitw_add(b, ml[i] - ml_base(mlc), ml_bits(mlc)); bitw_flush(b);
-    bitw_add(b, ofv - (1u << ofc), ofc); bitw_flush(b);
+    bitw_add(b, vl - ll_base(llc), ll_bits(llc)); bitw_add(b, vm - ml_base(mlc), ml_bits(mlc)); bitw_flush32(b);
+    bitw_add(b, ofv - (1u << ofc), ofc); bitw_flush32(b);
     while (i-- > 0) {
-        if ((u32)(b.p - out) + 32 > cap) return 0;                // a sequence adds at most 62 bits
-        llc = zenc_ll_code(ll[i]); mlc = zenc_ml_code(ml[i]); ofv = (u32)of[i] + 3; ofc = (u32)hibit32(ofv);
-        fse_cencode(b, sOF, ct[1].tableU16, ct[1].tt, ofc);
-        fse_cencode(b, sML, ct[2].tableU16, ct[2].tt, mlc);
-        fse_cencode(b, sLL, ct[0].tableU16, ct[0].tt, llc);
-        bitw_add(b, ll[i] - ll_base(llc), ll_bits(llc)); bitw_flush(b);
-        bitw_add(b, ml[i] - ml_base(mlc), ml_bits(mlc)); bitw_flush(b);
-        bitw_add(b, ofv - (1u << ofc), ofc); bitw_flush(b);
+        if ((u32)(b.p - out) + 32 > cap) return 0;                // a sequence adds at most 74 bits
+        if ((i & 7) == 7) { memcpy(cl, ll + i - 7, 16); memcpy(cm, ml + i - 7, 16); memcpy(co, of + i - 7, 16); }
+        vl = cl[i & 7]; vm = cm[i & 7];
+        llc = zenc_ll_code(vl); mlc = zenc_ml_code(vm); ofv = (u32)co[i & 7] + 3; ofc = (u32)hibit32(ofv);
+        // fewer than 32 bits are pending at each step: + 26 (states) / + 32 (ll, ml extra bits) / + 16 (offset extra bits)
+        fse_cencode_nf(b, sOF, ct[1].tableU16, ct[1].tt, ofc);
+        fse_cencode_nf(b, sML, ct[2].tableU16, ct[2].tt, mlc);
+        fse_cencode_nf(b, sLL, ct[0].tableU16, ct[0].tt, llc);
+        bitw_flush32(b);
+        bitw_add(b, vl - ll_base(llc), ll_bits(llc)); bitw_add(b, vm - ml_base(mlc), ml_bits(mlc)); bitw_flush32(b);
+        bitw_add(b, ofv - (1u << ofc), ofc); bitw_flush32(b);
     }
+    bitw_flush(b);
     bitw_add(b, sML, ct[2].log); bitw_flush(b);
     bitw_add(b, sOF, ct[1].log); bitw_flush(b);
     bitw_add(b, sLL, ct[0].log); bitw_flush(b);

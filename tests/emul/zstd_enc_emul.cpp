@@ -50,7 +50,7 @@ extern "C" long long emul_zstd_compress_lz(const u8 *src, size_t n, u32 block, u
     SeqCTabs T; zenc_build_predefined(T); SeqCTab ct[3]; zenc_seq_ctabs(T, ct);
     size_t nblk = n ? (n + block - 1) / block : 1;
     std::vector<u8> lits(block + 16), seqb(block * 4 + 64);
-    std::vector<u16> ll(block / 4 + 2), ml(block / 4 + 2), of(block / 4 + 2);
+    std::vector<u16> ll(block / 4 + 2 + 8), ml(block / 4 + 2 + 8), of(block / 4 + 2 + 8);   // + 8: read in groups of eight
     for (size_t b = 0; b < nblk; b++) {
         const u8 *s = src + b * block; u32 bn = (u32)(n - b * block < block ? n - b * block : block);
         bool last = b + 1 == nblk;
