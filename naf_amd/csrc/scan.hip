@@ -6,15 +6,17 @@
 #define SCAN_ITEMS   8
 #define SCAN_TILE    (SCAN_THREADS * SCAN_ITEMS)
 
+// Items are taken striped (item i of a thread is i * 256 + thread): every load and store of a wavefront is one contiguous
+// 512-byte run.  (Eight consecutive items per thread made each access touch 64 lines.)
 template <typename T, typename Op>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_reduce(const T *vals, size_t n, T *sums)
 {
     __shared__ T lds[4];
-    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + threadIdx.x;
     T acc = Op::template id<T>();
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) acc = Op::template f<T>(acc, vals[base + i]);
-    T tot; wg_scan_inclusive<T, Op>(acc, &tot, lds);
+    for (int i = 0; i < SCAN_ITEMS; i++) { size_t k = base + (size_t)i * SCAN_THREADS; if (k < n) acc = Op::template f<T>(acc, vals[k]); }
+    T tot = wg_reduce1<T, Op>(acc, lds);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
@@ -22,24 +24,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_reduce(const T *vals
 template <typename T, typename Op, bool EXCL>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_apply(T *vals, size_t n, const T *tile_pre)
 {
-    __shared__ T lds[4];
-    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-    T v[SCAN_ITEMS]; T acc = Op::template id<T>();
+    __shared__ T lds[2][4];
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + threadIdx.x;
+    T v[SCAN_ITEMS];
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = base + i < n ? vals[base + i] : Op::template id<T>(); acc = Op::template f<T>(acc, v[i]); }
-    T tot; T incl = wg_scan_inclusive<T, Op>(acc, &tot, lds);
-    // exclusive prefix of this thread = inclusive of previous thread
-    T prev = shfl_up_t(incl, 1);
-    __shared__ T wave_last[4];
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 63) wave_last[wave] = incl;
-    __syncthreads();
-    if (lane == 0) prev = wave == 0 ? Op::template id<T>() : wave_last[wave - 1];
-    T run = tile_pre ? Op::template f<T>(tile_pre[blockIdx.x], prev) : prev;
+    for (int i = 0; i < SCAN_ITEMS; i++) { size_t k = base + (size_t)i * SCAN_THREADS; v[i] = k < n ? vals[k] : Op::template id<T>(); }
+    T run = tile_pre ? tile_pre[blockIdx.x] : Op::template id<T>();
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        if (EXCL) { if (base + i < n) vals[base + i] = run; run = Op::template f<T>(run, v[i]); }
-        else { run = Op::template f<T>(run, v[i]); if (base + i < n) vals[base + i] = run; }
+    for (int i = 0; i < SCAN_ITEMS; i++) {                     // one 256-wide scan per stripe; the slot pairs alternate, so one barrier each
+        T pre, tot;
+        T wi = wg_scan1<T, Op>(v[i], &pre, &tot, lds[i & 1]);
+        T r = Op::template f<T>(run, Op::template f<T>(pre, EXCL ? wave_shift_up1<T, Op>(wi) : wi));
+        size_t k = base + (size_t)i * SCAN_THREADS;
+        if (k < n) vals[k] = r;
+        run = Op::template f<T>(run, tot);
     }
 }
 
