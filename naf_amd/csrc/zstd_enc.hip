@@ -276,38 +276,30 @@ __global__ void k_lz_choose(u32 nblk, const ZEncPlan *plan0, const ZEncPlan *pla
 }
 
 #define ZENC_BLOCKS_PER_WG 16
-#define ZENC_OROW 80                      // LDS output row per lane: one 64-byte segment + the word that spills over it + pad
+#define ZENC_OROW 80                      // LDS output row per lane: one 64-byte segment + the 8-byte store that may start at its byte 63, 16-byte aligned
 // One Huffman stream (4.2.2: written forward so that the LAST symbol is read first) by one lane.  Input is pulled 64 bytes
 // at a time into registers (walking down), output is collected in the lane's LDS row and leaves as aligned 64-byte
 // segments: per-lane 8-byte loads re-fetch every line 4x and per-lane 8-byte stores cost 6x the bytes at the HBM.
+// Codes are appended to a 64-bit accumulator in groups that cannot overflow it (8 symbols when codes are at most 7 bits long,
+// else 4: fewer than 8 bits are pending between groups), and whole bytes move to the row once per group -- no test per symbol.
+template <int GROUP>
 __device__ __forceinline__ void huf_encode_stream_staged(u8 *out, const u8 *src, u32 n, const u16 *codes, u8 *orow)
 {
-    u64 acc = 0; u32 nb = 0; u8 *p = out;
-    u32 fill = 0; bool staged = false;                            // staged: p is 64-byte aligned and row[0..fill) holds the bytes at p
-    auto emit_word = [&](u64 w) {
-        if (!staged) {
-            st64(p, w); p += 8;
-            u32 mis = (u32)((uintptr_t)p & 63);
-            if (mis < 8) {                                        // crossed into a new segment: its first `mis` bytes go to the row
-                p -= mis; staged = true; fill = mis;
-                if (mis) { u64 t = w >> (8 * (8 - mis)); __builtin_memcpy(orow, &t, 8); }
-            }
-            return;
-        }
-        __builtin_memcpy(orow + fill, &w, 8); fill += 8;
+    u64 acc = 0; u32 nb = 0;
+    u32 lo = (u32)((uintptr_t)out & 63), fill = lo;               // row[lo..fill) = bytes of the 64-byte segment at seg not yet written
+    u8 *seg = out - lo;
+    auto flush_group = [&]() {
+        __builtin_memcpy(orow + fill, &acc, 8);                    // unaligned LDS store; only the whole bytes are kept
+        fill += nb >> 3; acc >>= (nb & ~7u); nb &= 7;
         if (fill >= 64) {
-            const uint4 *r = (const uint4 *)orow; uint4 *g = (uint4 *)p;
-            g[0] = r[0]; g[1] = r[1]; g[2] = r[2]; g[3] = r[3];
-            u64 t; __builtin_memcpy(&t, orow + 64, 8); __builtin_memcpy(orow, &t, 8);
-            p += 64; fill -= 64;
+            if (lo == 0) { const uint4 *r = (const uint4 *)orow; uint4 *g = (uint4 *)seg; g[0] = r[0]; g[1] = r[1]; g[2] = r[2]; g[3] = r[3]; }
+            else { for (u32 k = lo; k < 64; k++) seg[k] = orow[k]; lo = 0; }       // the stream's first, partial segment
+            u64 t0, t1; __builtin_memcpy(&t0, orow + 64, 8); __builtin_memcpy(&t1, orow + 72, 8);
+            __builtin_memcpy(orow, &t0, 8); __builtin_memcpy(orow + 8, &t1, 8);
+            seg += 64; fill -= 64;
         }
     };
-    auto put = [&](u32 sym) {
-        u32 e = codes[sym]; u32 len = e >> 12; u64 v = (u64)(e & 0xFFF);
-        acc |= v << nb;                                            // nb < 64 here; bits that do not fit are re-added after the word leaves
-        if (nb + len >= 64) { emit_word(acc); acc = nb ? (v >> (64 - nb)) : 0; nb = nb + len - 64; }
-        else nb += len;
-    };
+    auto put_e = [&](u32 e) { acc |= (u64)(e & 0xFFF) << nb; nb += e >> 12; };
     u32 i = n;
     while (i >= 64) {                                             // symbols i-1 .. i-64, highest index first
         i -= 64;
@@ -316,15 +308,29 @@ __device__ __forceinline__ void huf_encode_stream_staged(u8 *out, const u8 *src,
         for (int wdx = 7; wdx >= 0; wdx--) {
             const uint4 &qq = q[wdx >> 1];
             u64 w = (wdx & 1) ? ((u64)qq.z | ((u64)qq.w << 32)) : ((u64)qq.x | ((u64)qq.y << 32));
+            // the eight table entries first, then the appends: inside the append chain every symbol would wait for its own LDS
+            // round trip (the row stores in between keep the compiler from hoisting the lookups)
+            u32 e[8];
 #pragma unroll
-            for (int k = 7; k >= 0; k--) put((u32)(w >> (8 * k)) & 0xFF);
+            for (int k = 0; k < 8; k++) e[k] = codes[(u32)(w >> (8 * k)) & 0xFF];
+            if (GROUP == 8) {
+#pragma unroll
+                for (int k = 7; k >= 0; k--) put_e(e[k]);
+                flush_group();
+            } else {
+                put_e(e[7]); put_e(e[6]); put_e(e[5]); put_e(e[4]); flush_group();
+                put_e(e[3]); put_e(e[2]); put_e(e[1]); put_e(e[0]); flush_group();
+            }
         }
     }
-    while (i-- > 0) put(src[i]);
-    acc |= 1ull << nb; nb++;                                      // final marker bit (nb <= 63 before, so it fits)
-    // tail: what is in the row, then the last bits, byte-wise
-    if (staged) { for (u32 k = 0; k < fill; k++) p[k] = orow[k]; p += fill; }
-    while (nb > 0) { *p++ = (u8)acc; acc >>= 8; nb = nb > 8 ? nb - 8 : 0; }
+    while (i > 0) {                                               // the ragged start of the stream, four symbols per group
+        u32 g = i < 4 ? i : 4;
+        for (u32 k = 0; k < g; k++) put_e(codes[src[--i]]);
+        flush_group();
+    }
+    acc |= 1ull << nb; nb++;                                      // final marker bit (nb < 8 before)
+    __builtin_memcpy(orow + fill, &acc, 8); fill += (nb + 7) >> 3;
+    for (u32 k = lo; k < fill; k++) seg[k] = orow[k];
 }
 
 // LZ-coded blocks (mode[b] != 0) take their literals from L.lits with the plan / codes / tree of those literals (plan1 ...)
@@ -360,7 +366,8 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
                 u32 cnt = k < 3 ? per : p.n - 3 * per;
                 u32 o = 3 + p.lhdr + p.tree_bytes + 6;
                 for (u32 q = 0; q < k; q++) o += p.ssz[q];
-                huf_encode_stream_staged(out + o, src + lo + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
+                if (p.log <= 7) huf_encode_stream_staged<8>(out + o, src + lo + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
+                else huf_encode_stream_staged<4>(out + o, src + lo + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
                 if (k == 3) out[p.csize - 1] = 0;                   // Number_of_Sequences = 0
             }
         } else {
@@ -374,7 +381,8 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
                 u32 cnt = k < 3 ? per : p.n - 3 * per;
                 u32 o = 3 + p.lhdr + p.tree_bytes + 6;
                 for (u32 q = 0; q < k; q++) o += p.ssz[q];
-                huf_encode_stream_staged(out + o, lits + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
+                if (p.log <= 7) huf_encode_stream_staged<8>(out + o, lits + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
+                else huf_encode_stream_staged<4>(out + o, lits + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
             } else if (k == 0) {
                 u32 h = zenc_lit_header_raw(out + 3, p.kind == ZK_RLE ? 1u : 0u, p.n);
                 if (p.kind == ZK_RLE) out[3 + h] = lits[0];
