@@ -655,12 +655,11 @@ __device__ __forceinline__ u32 mask_boundary_bits(const u8 *seq, u64 base, u64 T
     // base -1 is "unmasked": a masked first base opens a zero-length unmasked run, encoders.c:132)
     bool prev = base ? seq[base - 1] >= 96 : false;
     if (base + 16 <= T) {
-        // byte >= 96 as the top bit of each byte, gathered to one bit per byte (base is 16-aligned, so is seq)
-        const u64 L7 = 0x7f7f7f7f7f7f7f7full, H = 0x8080808080808080ull, MM = 0x0102040810204080ull;
-        u64 w0 = *(const u64 *)(seq + base), w1 = *(const u64 *)(seq + base + 8);
-        u64 t0 = (((w0 & L7) + 0x2020202020202020ull) | w0) & H;
-        u64 t1 = (((w1 & L7) + 0x2020202020202020ull) | w1) & H;
-        u32 c = (u32)((t0 >> 7) * MM >> 56) | ((u32)((t1 >> 7) * MM >> 56) << 8);
+        // byte >= 96 <=> bit 7 or (bit 6 and bit 5): the top bit of each byte, gathered to one bit per byte (base is 16-aligned, so is seq)
+        uint4 v = *(const uint4 *)(seq + base);
+        const u32 H = 0x80808080u;
+        u32 c = swar_movemask16((v.x | ((v.x << 1) & (v.x << 2))) & H, (v.y | ((v.y << 1) & (v.y << 2))) & H,
+                                (v.z | ((v.z << 1) & (v.z << 2))) & H, (v.w | ((v.w << 1) & (v.w << 2))) & H);
         return (c ^ ((c << 1) | (prev ? 1u : 0u))) & 0xFFFFu;
     }
     u32 m = 0;
