@@ -51,6 +51,18 @@ def cpu_baseline(text_dev, size_bytes, ctx=None):
         out = {"value": round(cut / t_u / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "reference",
                "sample": "reference unnaf (oracle/_ref, libzstd 1.4.9) on the first %.2f GB of the same FASTA, tmpfs, 1 thread" % (cut / 1e9),
                "ennaf_value": round(cut / t_e / 1e9, 4), "roundtrip_ok": bool(same)}
+        # the "whole box" figure -- the reference is single-threaded, so one instance per host core (capped), all
+        # decoding the same archive concurrently to /dev/null; aggregate = instances x sample bytes / wall time of the slowest
+        ncpu = min(os.cpu_count() or 1, 64)
+        if ncpu > 1:
+            t0 = time.perf_counter()
+            with open(os.devnull, "wb") as dn:
+                ps = [subprocess.Popen([ref_u, os.path.join(shm, "s.naf")], stdout=dn) for _ in range(ncpu)]
+                rcs = [q.wait() for q in ps]
+            t_all = time.perf_counter() - t0
+            if all(rc == 0 for rc in rcs):
+                out["all_cores"] = {"value": round(ncpu * cut / t_all / 1e9, 3), "unit": "GB/s", "cores": ncpu,
+                                    "sample": "%d concurrent reference unnaf instances, each decoding the same %.2f GB sample archive to /dev/null" % (ncpu, cut / 1e9)}
         if ctx is not None:
             # the GPU decoder on the archive the REFERENCE ennaf made of that sample (128 KiB dependent blocks)
             import torch
