@@ -429,21 +429,39 @@ __global__ void k_hdr_len64(const u32 *hdr_len, u64 r0, u64 n, u64 *out)
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = hdr_len[r0 + i];
 }
-__global__ void k_hdr_build(EmitP P, u64 r0, u64 n, const u64 *hdr_off, u8 *text)
+__device__ __forceinline__ void store_upto16(u8 *p, u64 lo, u64 hi, u32 n)
 {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= 16) { uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32); memcpy(p, &v, 16); return; }
+    if (n & 8) { st64(p, lo); p += 8; lo = hi; }
+    if (n & 4) { st32(p, (u32)lo); p += 4; lo >>= 32; }
+    if (n & 2) { p[0] = (u8)lo; p[1] = (u8)(lo >> 8); p += 2; lo >>= 16; }
+    if (n & 1) p[0] = (u8)lo;
+}
+template <u32 LANES = 16>
+__device__ __forceinline__ void group_copy(u8 *dst, const u8 *src, u64 n, u32 g)      // LANES lanes, sources padded by >= 16 bytes
+{
+    for (u64 i = (u64)g * 16; i < n; i += LANES * 16) {
+        u64 lo = ld64(src + i), hi = ld64(src + i + 8);
+        store_upto16(dst + i, lo, hi, n - i < 16 ? (u32)(n - i) : 16u);
+    }
+}
+
+// eight lanes per header, 16 bytes per lane and step (one lane per header walking it byte by byte ran at 90 GB/s)
+__global__ __launch_bounds__(256) void k_hdr_build(EmitP P, u64 r0, u64 n, const u64 *hdr_off, u8 *text)
+{
+    u64 i = (u64)blockIdx.x * 32 + (threadIdx.x >> 3);
+    u32 g = threadIdx.x & 7;
     if (i >= n) return;
     u64 r = r0 + i; u32 hl = P.hdr_len[r];
     u8 *o = text + hdr_off[i];
-    u64 ids0 = 0, idl = 0, nm0 = 0;
+    u64 ids0 = 0, idl = 0, nm0 = 0, nml = 0;
     if (P.has_ids) { ids0 = r ? P.idz[r - 1] + 1 : 0; idl = P.idz[r] - ids0; }
-    if (P.has_names) nm0 = r ? P.nmz[r - 1] + 1 : 0;
-    o[0] = P.hdr_char; o[hl - 1] = '\n';
-    for (u32 k = 0; k + 2 < hl; k++) {
-        u32 ch;
-        if (P.has_ids) ch = k < idl ? P.ids[ids0 + k] : (k == idl ? P.sep : P.names[nm0 + (k - idl - 1)]); else ch = P.names[nm0 + k];
-        o[1 + k] = (u8)ch;
-    }
+    if (P.has_names) { nm0 = r ? P.nmz[r - 1] + 1 : 0; nml = P.nmz[r] - nm0; }
+    if (g == 0) { o[0] = P.hdr_char; o[hl - 1] = '\n'; }
+    if (P.has_ids) {
+        group_copy<8>(o + 1, P.ids + ids0, idl, g);
+        if (P.has_names && nml) { if (g == 0) o[1 + idl] = P.sep; group_copy<8>(o + 2 + idl, P.names + nm0, nml, g); }
+    } else group_copy<8>(o + 1, P.names + nm0, nml, g);
 }
 
 // One 16-byte chunk composed from segments.  One iteration = one SEGMENT: n_main bytes copied from a byte source or
@@ -556,21 +574,6 @@ __global__ __launch_bounds__(256) void k_emit_short(EmitP P, u8 *out)
 // when the whole text is wanted there is nothing to search: 16 lanes take one read and copy / expand its pieces 16 bytes per
 // lane per step.  About 0.1 instructions per output byte against 37 for the chunk-composing kernel above, which stays for
 // byte-range calls and FASTA.
-__device__ __forceinline__ void store_upto16(u8 *p, u64 lo, u64 hi, u32 n)
-{
-    if (n >= 16) { uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32); memcpy(p, &v, 16); return; }
-    if (n & 8) { st64(p, lo); p += 8; lo = hi; }
-    if (n & 4) { st32(p, (u32)lo); p += 4; lo >>= 32; }
-    if (n & 2) { p[0] = (u8)lo; p[1] = (u8)(lo >> 8); p += 2; lo >>= 16; }
-    if (n & 1) p[0] = (u8)lo;
-}
-__device__ __forceinline__ void group_copy(u8 *dst, const u8 *src, u64 n, u32 g)      // 16 lanes, sources padded by >= 16 bytes
-{
-    for (u64 i = (u64)g * 16; i < n; i += 256) {
-        u64 lo = ld64(src + i), hi = ld64(src + i + 8);
-        store_upto16(dst + i, lo, hi, n - i < 16 ? (u32)(n - i) : 16u);
-    }
-}
 #define ER_STAGE 16384u
 template <bool FOURBIT>
 __global__ __launch_bounds__(256) void k_emit_fastq_records(EmitP P, u8 *out)
@@ -1184,7 +1187,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             if ((rc = scan_exclusive_u64(c, ho, nr, ho + nr + 1))) return rc;
             if ((rc = ctx_readback(c, &htot, ho + nr + 1, 8))) return rc;
             u8 *ht = (u8 *)arena_alloc(c, htot + 32); if (!ht) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "unnaf_hdr_build", k_hdr_build, cdiv(nr, 256), 256, 0, pl.P, rec0, nr, (const u64 *)ho, ht);
+            LAUNCH(c, "unnaf_hdr_build", k_hdr_build, cdiv(nr, 32), 256, 0, pl.P, rec0, nr, (const u64 *)ho, ht);
             pl.P.hdr_off = ho; pl.P.hdr_text = ht; pl.P.hdr_r0 = rec0;
         }
         u32 grid = cdiv(out_end - out_begin, ES_SPAN);

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(64) void k_scan_blocks(const u8 *src, u64 len, u64 
 //                    EXACT by construction -- speculation only decides how much is reused.
 //   4. k_spec_walk   count, then write, the ZBlock records of every chunk in parallel.
 #define SPEC_CHUNK   (1024u * 1024u)
+#define SPEC_CHUNK_SMALL (16u * 1024u)    // frames of 64 KiB .. 4 MiB: every byte is a candidate
 #define SPEC_WINDOW  (ZBLOCK_MAX + 4u)
 #define SPEC_HOPS    10
 #define SPEC_NONE    0xFFFFFFFFFFFFFFFFull
@@ -119,13 +120,13 @@ __device__ __forceinline__ u64 spec_land(const u8 *src, u64 len, u64 pos, u64 st
 // first block start of a chunk lies whenever blocks compress to under 40 KiB -- this build's 32 KiB blocks, and
 // 128 KiB blocks at ratios above 3.2), then the rest of the 128 KiB window for the chunks still without a candidate.
 #define SPEC_WINDOW1 (40u * 1024u)
-__global__ __launch_bounds__(256) void k_spec_find(const u8 *src, u64 len, u32 nchunks, u64 *first, u32 w_lo, u32 w_hi)
+__global__ __launch_bounds__(256) void k_spec_find(const u8 *src, u64 len, u32 nchunks, u64 *first, u32 w_lo, u32 w_hi, u32 chunk)
 {
     const u32 tiles = (w_hi - w_lo + 4095) / 4096;
     u32 c = blockIdx.x / tiles + 1;                          // chunk 0 starts at the known first block
     if (c >= nchunks) return;
     if (w_lo && first[c] != SPEC_NONE) return;               // second pass: only chunks the first pass left empty
-    u64 base = (u64)c * SPEC_CHUNK;
+    u64 base = (u64)c * chunk;
     u32 k0 = w_lo + ((blockIdx.x % tiles) * 256 + threadIdx.x) * 16;
     if (k0 >= w_hi || base + k0 + 24 > len) {
         if (k0 >= w_hi || base + k0 + 3 > len) return;
@@ -141,10 +142,15 @@ __global__ __launch_bounds__(256) void k_spec_find(const u8 *src, u64 len, u32 n
         u32 h = (u32)((sh ? (lo >> sh) | (hi << (64 - sh)) : lo) & 0xFFFFFF), adv;
         u64 pos = base + k0 + k;
         if (!spec_hdr_ok(h, pos, len, adv)) continue;
+        // An empty Raw block that is not the last one is legal but nobody writes it, while runs of zero bytes (a direct Huffman
+        // weight table whose first symbols do not occur) read as chains of exactly that: not taken as candidates.  (If a frame
+        // really holds one, the chunks in front of it get no candidate and are re-walked by the resolve pass: still exact.)
+        if ((h >> 1) == 0 && !(h & 1)) continue;
         bool last = h & 1, ok = true;
         u64 p = pos + adv;
         if (last) ok = p + 4 >= len;
         for (int hop = 1; ok && !last && hop < SPEC_HOPS; hop++) {
+            if (p + 3 <= len && (ld24(src + p) >> 1) == 0 && !(ld24(src + p) & 1)) { ok = false; break; }
             if (!spec_hop(src, len, p, last)) ok = false;
             else if (last) ok = p + 4 >= len;                // a chain may only end at the end of the frame (+checksum)
         }
@@ -153,26 +159,26 @@ __global__ __launch_bounds__(256) void k_spec_find(const u8 *src, u64 len, u32 n
 }
 
 // land[c+1] = F_c(first[c]) ; first[0] is the known true start.
-__global__ void k_spec_land(const u8 *src, u64 len, const u64 *first, u32 nchunks, u64 *land)
+__global__ void k_spec_land(const u8 *src, u64 len, const u64 *first, u32 nchunks, u64 *land, u32 chunk)
 {
     u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     u64 s = first[c];
-    land[c + 1] = s == SPEC_NONE ? SPEC_NONE : spec_land(src, len, s, (u64)(c + 1) * SPEC_CHUNK, nullptr);
+    land[c + 1] = s == SPEC_NONE ? SPEC_NONE : spec_land(src, len, s, (u64)(c + 1) * chunk, nullptr);
     if (c == 0) land[0] = s;
 }
 // G[c] = F_c(land[c]) (reuses land[c+1] when the candidate already was the landing)
-__global__ void k_spec_land2(const u8 *src, u64 len, const u64 *first, const u64 *land, u32 nchunks, u64 *G)
+__global__ void k_spec_land2(const u8 *src, u64 len, const u64 *first, const u64 *land, u32 nchunks, u64 *G, u32 chunk)
 {
     u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     u64 l = land[c];
     if (l == first[c]) G[c] = land[c + 1];
     else if (l >= SPEC_END) G[c] = SPEC_NONE;
-    else G[c] = spec_land(src, len, l, (u64)(c + 1) * SPEC_CHUNK, nullptr);
+    else G[c] = spec_land(src, len, l, (u64)(c + 1) * chunk, nullptr);
 }
 // One wave: exact chunk starts.  start[c] for c in [0, nchunks], start[nchunks] = SPEC_END when the frame is well formed.
-__global__ void k_spec_resolve(const u8 *src, u64 len, const u64 *land, const u64 *G, u32 nchunks, u64 *start, ZStat *st)
+__global__ void k_spec_resolve(const u8 *src, u64 len, const u64 *land, const u64 *G, u32 nchunks, u64 *start, ZStat *st, u32 chunk)
 {
     int lane = threadIdx.x;
     u64 t = land[0];                                           // true start of chunk 0
@@ -196,7 +202,7 @@ __global__ void k_spec_resolve(const u8 *src, u64 len, const u64 *land, const u6
             u64 nxt;
             if (t >= SPEC_END) nxt = t;                        // past the end of the frame (or broken): propagate
             else if (lj == t) nxt = gj;
-            else { u64 e = 0; nxt = spec_land(src, len, t, (u64)(base + j + 1) * SPEC_CHUNK, &e); }   // speculation missed: re-walk (uniform)
+            else { u64 e = 0; nxt = spec_land(src, len, t, (u64)(base + j + 1) * chunk, &e); }   // speculation missed: re-walk (uniform)
             t = nxt;
             if (lane == 0) start[base + j + 1] = t;
         }
@@ -981,8 +987,14 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     // ---- block index
     ZBlock *blk = nullptr; ZStat hs; bool indexed = false;
     const char *nospec = getenv("NAF_GPU_SERIAL_INDEX");
-    if (src_len > 4ull * SPEC_CHUNK && !(nospec && nospec[0] == '1')) {
-        u32 nchunks = (u32)((src_len + SPEC_CHUNK - 1) / SPEC_CHUNK);
+    // Frames of more than 4 MiB: 1 MiB chunks, candidates in the first 40 KiB / 128 KiB of each.  Smaller frames can still hold
+    // tens of thousands of tiny blocks (ids / names / lengths that compress 100:1 in 16 KiB blocks -- a serial walk of those
+    // costs milliseconds): 16 KiB chunks with every byte tested as a candidate.  The chunk size changes nothing but how much of
+    // the speculation is reused: the resolve pass re-walks from the true start wherever a chunk's candidate was wrong or missing.
+    const u32 chunk = src_len > 4ull * SPEC_CHUNK ? SPEC_CHUNK : SPEC_CHUNK_SMALL;
+    const u32 win1 = chunk == SPEC_CHUNK ? SPEC_WINDOW1 : SPEC_CHUNK_SMALL, win2 = chunk == SPEC_CHUNK ? SPEC_WINDOW : SPEC_CHUNK_SMALL;
+    if (src_len > 4ull * SPEC_CHUNK_SMALL && !(nospec && nospec[0] == '1')) {
+        u32 nchunks = (u32)((src_len + chunk - 1) / chunk);
         u64 *first = arena_new<u64>(c, nchunks + 1), *land = arena_new<u64>(c, nchunks + 2), *G = arena_new<u64>(c, nchunks + 1);
         u64 *start = arena_new<u64>(c, nchunks + 2), *cnt = arena_new<u64>(c, (size_t)nchunks + 2);
         if (!first || !land || !G || !start || !cnt) return NAF_GPU_ENOMEM;
@@ -990,11 +1002,11 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         u64 *h0 = (u64 *)c->h_stage; *h0 = fh.hdr_size;
         HIP_TRY(c, hipMemcpyAsync(first, h0, 8, hipMemcpyHostToDevice, c->stream));
         u32 gl = cdiv(nchunks, 64);
-        LAUNCH(c, "zstd_index_find", k_spec_find, cdiv(SPEC_WINDOW1, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, 0u, SPEC_WINDOW1);
-        LAUNCH(c, "zstd_index_find2", k_spec_find, cdiv(SPEC_WINDOW - SPEC_WINDOW1, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, SPEC_WINDOW1, SPEC_WINDOW);
-        LAUNCH(c, "zstd_index_land", k_spec_land, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, nchunks, land);
-        LAUNCH(c, "zstd_index_land2", k_spec_land2, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, (const u64 *)land, nchunks, G);
-        LAUNCH(c, "zstd_index_resolve", k_spec_resolve, 1, 64, 0, d_src, (u64)src_len, (const u64 *)land, (const u64 *)G, nchunks, start, st);
+        LAUNCH(c, "zstd_index_find", k_spec_find, cdiv(win1, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, 0u, win1, chunk);
+        if (win2 > win1) LAUNCH(c, "zstd_index_find2", k_spec_find, cdiv(win2 - win1, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, win1, win2, chunk);
+        LAUNCH(c, "zstd_index_land", k_spec_land, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, nchunks, land, chunk);
+        LAUNCH(c, "zstd_index_land2", k_spec_land2, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, (const u64 *)land, nchunks, G, chunk);
+        LAUNCH(c, "zstd_index_resolve", k_spec_resolve, 1, 64, 0, d_src, (u64)src_len, (const u64 *)land, (const u64 *)G, nchunks, start, st, chunk);
         LAUNCH(c, "zstd_index_count", (k_spec_walk<false>), gl, 64, 0, d_src, (u64)src_len, (const u64 *)start, nchunks, cnt, (ZBlock *)nullptr, st);
         u64 *d_tot = cnt + nchunks + 1;
         if ((rc = scan_exclusive_u64(c, cnt, nchunks, d_tot))) return rc;

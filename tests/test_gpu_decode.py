@@ -54,6 +54,44 @@ def test_zstd_decode_matches_oracle_on_naf_sections(gpu, oracle):
             assert host(out) == ref, (case["name"], i)
 
 
+def _hand_frame(blocks):
+    """zstd frame (magic, single-segment off, window 2^23, no checksum) from (type, payload, regen) blocks: type 0 raw, 1 RLE"""
+    out = bytearray(b"\x28\xb5\x2f\xfd\x00\x68")
+    for i, (t, payload, regen) in enumerate(blocks):
+        h = (1 if i + 1 == len(blocks) else 0) | (t << 1) | (regen << 3)
+        out += bytes([h & 0xFF, (h >> 8) & 0xFF, (h >> 16) & 0xFF]) + payload
+    return bytes(out)
+
+
+@pytest.mark.parametrize("total", [300 << 10, 9 << 20])
+def test_zstd_block_index_survives_lookalike_headers(gpu, total):
+    """The parallel block index tests bytes as candidate block headers (16 KiB chunks with every byte tested for frames of up to
+    4 MiB, 1 MiB chunks above).  Payloads full of bytes that READ as valid header chains -- runs of zeros (empty raw blocks), of
+    0x02 (RLE blocks, a hop of 4), tiny raw blocks -- and real empty raw blocks in the middle of the frame must not change
+    the result: candidates only decide how much of the speculation is reused."""
+    rng = np.random.default_rng(total)
+    blocks, expect = [], bytearray()
+    while len(expect) < total:
+        kind = int(rng.integers(0, 6))
+        if kind == 0:                                             # raw block of zeros: 3-byte groups read as empty raw blocks
+            n = int(rng.integers(30, 5000)); blocks.append((0, bytes(n), n)); expect += bytes(n)
+        elif kind == 1:                                           # raw block of 02 00 00 xx: each group reads as an RLE block
+            n = int(rng.integers(8, 3000)) * 4; pl = bytes([2, 0, 0, 7] * (n // 4)); blocks.append((0, pl, n)); expect += pl
+        elif kind == 2:                                           # a real empty raw block in the middle of the frame
+            blocks.append((0, b"", 0))
+        elif kind == 3:                                           # RLE block
+            n = int(rng.integers(1, 100000)); b = int(rng.integers(0, 256)); blocks.append((1, bytes([b]), n)); expect += bytes([b]) * n
+        elif kind == 4:                                           # a burst of tiny raw blocks
+            for _ in range(int(rng.integers(1, 400))):
+                n = int(rng.integers(1, 6)); pl = rng.integers(0, 256, n, dtype=np.uint8).tobytes(); blocks.append((0, pl, n)); expect += pl
+        else:                                                     # random raw data up to the block size limit
+            n = int(rng.integers(1, 131072)); pl = rng.integers(0, 256, n, dtype=np.uint8).tobytes(); blocks.append((0, pl, n)); expect += pl
+    frame = _hand_frame(blocks)
+    out = gpu.zstd_decompress(gpu.to_device(frame), len(expect) + 64)
+    got = host(out)
+    assert len(got) == len(expect) and sha(got) == sha(bytes(expect))
+
+
 def test_zstd_rejects_corrupt_frames(gpu):
     from naf_amd.capi import NafGpuError
     frame = bytearray(golden_bytes("zstd", "ids_l3.zst"))
