@@ -236,6 +236,74 @@ __device__ __forceinline__ TileCtx thread_ctx(const EncP &P, const i64 *tile_eol
     return c;
 }
 
+// ---- segment-wise classification of a piece that holds header bytes ---------------------------------------------------------
+// The same state machine as classify_range, advanced one LINE SEGMENT at a time: the EOL bits of the piece cut it into at most a few
+// runs, each of which is header text (ID up to the first space-class byte, comment after it) or sequence, and moves to its stream
+// in bulk.  Valid only for a full piece behind p0 whose bytes need no replacement in the roles they fall into; the caller finds
+// that out with a dry run into a RoleSink (one bit per byte and role) before anything is emitted, and falls back to the per-byte
+// walk otherwise.  Sink interface: ids_range / cmt_range / seq_range(piece, first, end[, space bits]), term(stream) for the
+// \0 terminators, header_start / header_end / line_end as in classify_range.
+__device__ __forceinline__ u32 range_mask(u32 a, u32 b) { return ((1u << b) - 1) & ~((1u << a) - 1); }       // bits [a, b), b <= 16
+template <typename Sink>
+__device__ __forceinline__ void classify_segments(const EncP &P, u64 base, const Piece &pc, const PMask &pm, const TileCtx &ctx, Sink &S)
+{
+    i64 le = ctx.last_eol, ls = ctx.last_sp; bool hdr = ctx.hdr;
+    u32 k = 0;
+    while (k < ET_BYTES) {
+        const u32 em = pm.eol >> k;
+        const u32 e = em ? k + (u32)__ffs((int)em) - 1 : ET_BYTES;         // the EOL that ends this run, or the end of the piece
+        if (hdr) {
+            const i64 line_start = le + 1;
+            u32 a = k;
+            if ((i64)(base + a) == line_start) { S.header_start(base + a); a++; }     // the '>' itself
+            if (a < e) {
+                const u32 spm = pm.sp & range_mask(a, e);
+                if (ls < line_start) {                                      // no space-class byte in this line so far: the ID
+                    const u32 f = spm ? (u32)__ffs((int)spm) - 1 : e;
+                    if (f > a) S.ids_range(pc, a, f);
+                    if (f < e) { S.term(EV_IDS); if (f + 1 < e) S.cmt_range(pc, f + 1, e); }
+                } else S.cmt_range(pc, a, e);
+                if (spm) ls = (i64)(base + (31 - __clz((int)spm)));
+            }
+            if (e < ET_BYTES) { if (ls < line_start) S.term(EV_IDS); S.term(EV_CMT); S.header_end(base + e); }
+        } else {
+            if (k < e) { S.seq_range(pc, k, e, pm.sp); const u32 spm = pm.sp & range_mask(k, e); if (spm) ls = (i64)(base + (31 - __clz((int)spm))); }
+            if (e < ET_BYTES) S.line_end(base + e);
+        }
+        if (e >= ET_BYTES) break;
+        le = ls = (i64)(base + e);
+        const u32 nx = e + 1 < ET_BYTES ? piece_byte(pc, e + 1) : (base + ET_BYTES < P.n ? (u32)P.text[base + ET_BYTES] : 0u);
+        hdr = nx == '>';
+        k = e + 1;
+    }
+}
+struct RoleSink {
+    u32 idm = 0, cmm = 0, sqm = 0;
+    __device__ void ids_range(const Piece &, u32 a, u32 b) { idm |= range_mask(a, b); }
+    __device__ void cmt_range(const Piece &, u32 a, u32 b) { cmm |= range_mask(a, b); }
+    __device__ void seq_range(const Piece &, u32 a, u32 b, u32 sp) { sqm |= range_mask(a, b) & ~sp; }
+    __device__ void term(int) {} __device__ void header_start(u64) {} __device__ void header_end(u64) {} __device__ void line_end(u64) {}
+};
+// Can this piece take the segment-wise path?  (Full piece behind p0, and no byte that its role would replace.)
+__device__ __forceinline__ bool segments_ok(const EncP &P, u64 base, const Piece &pc, const PMask &pm, const TileCtx &ctx, const u8 *cls)
+{
+    if (pc.cnt != ET_BYTES || base <= P.p0) return false;
+    RoleSink R; classify_segments(P, base, pc, pm, ctx, R);
+    u32 w[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) };
+    if ((R.idm | R.cmm) && ((R.idm | R.cmm) & piece_ctl_mask(w))) return false;
+    if (P.id_gt_unexpected && (R.idm & pm.gt)) return false;
+    u32 cand = R.sqm ? (piece_not_quick(w, P.qlo, P.qhi) & R.sqm) : 0u;
+    while (cand) { u32 k = (u32)__ffs((int)cand) - 1; cand &= cand - 1; if (!(cls[piece_byte(pc, k)] & CL_EXPECTED)) return false; }
+    return true;
+}
+// bytes [a, 16) of the piece moved down to byte 0
+__device__ __forceinline__ void piece_from(const Piece &pc, u32 a, u64 &lo, u64 &hi)
+{
+    if (a == 0) { lo = pc.w0; hi = pc.w1; }
+    else if (a < 8) { lo = (pc.w0 >> (8 * a)) | (pc.w1 << (64 - 8 * a)); hi = pc.w1 >> (8 * a); }
+    else { lo = pc.w1 >> (8 * (a - 8)); hi = 0; }
+}
+
 struct CountSink {
     u32 nseq = 0, nids = 0, ncmt = 0, nrec = 0, tail = 0;      // tail = sequence bytes since the last EOL seen
     bool saw_eol = false;
@@ -244,6 +312,10 @@ struct CountSink {
     __device__ void header_end(u64) { tail = 0; saw_eol = true; }
     __device__ void line_end(u64) { tail = 0; saw_eol = true; }
     __device__ void unexpected(int, u32) {}
+    __device__ void ids_range(const Piece &, u32 a, u32 b) { nids += b - a; }
+    __device__ void cmt_range(const Piece &, u32 a, u32 b) { ncmt += b - a; }
+    __device__ void seq_range(const Piece &, u32 a, u32 b, u32 sp) { u32 c = (u32)__popc(range_mask(a, b) & ~sp); nseq += c; tail += c; }
+    __device__ void term(int st) { if (st == EV_IDS) nids++; else ncmt++; }
 };
 
 // A full 16-byte piece that lies inside sequence lines: not in a header at its first byte, no header starting inside it.
@@ -270,7 +342,8 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
     } else if (base <= P.n) {
         // the virtual end-of-input byte belongs to the thread whose piece contains position n
         bool eof_here = (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
-        classify_range(P, base, pc, eof_here, ctx, S, cls);
+        if (segments_ok(P, base, pc, pm, ctx, cls)) classify_segments(P, base, pc, pm, ctx, S);
+        else classify_range(P, base, pc, eof_here, ctx, S, cls);
     }
     // four counts in two scans of packed 16-bit fields (a tile holds 4096 bytes, a byte adds at most 2 to a field); the tail of
     // the tile -- sequence bytes after its last EOL, the whole tile if it has none -- falls out of the same scan: the last
@@ -329,6 +402,16 @@ __device__ __forceinline__ void lds_store_n(u8 *p, u64 lo, u64 hi, u32 n)
     if (n & 1) *p = (u8)lo;
 }
 
+// first n (<= 16) bytes of {lo, hi} to global memory at any alignment
+__device__ __forceinline__ void global_store_n(u8 *p, u64 lo, u64 hi, u32 n)
+{
+    if (n >= 16) { st64(p, lo); st64(p + 8, hi); return; }
+    if (n & 8) { st64(p, lo); p += 8; lo = hi; }
+    if (n & 4) { st32(p, (u32)lo); p += 4; lo >>= 32; }
+    if (n & 2) { p[0] = (u8)lo; p[1] = (u8)(lo >> 8); p += 2; lo >>= 16; }
+    if (n & 1) p[0] = (u8)lo;
+}
+
 struct WriteSink {
     const EncOut &O; u64 bseq, bids, bcmt, rec; u64 line_b; u64 best; bool line_valid; u8 *stage; u64 tbase;
     __device__ WriteSink(const EncOut &o) : O(o) {}
@@ -337,6 +420,22 @@ struct WriteSink {
     __device__ void header_end(u64) { O.rec_begin[rec - 1] = bseq; line_b = bseq; }
     __device__ void line_end(u64) { u64 len = bseq - line_b; if (len > best) best = len; line_b = bseq; }
     __device__ void unexpected(int kind, u32 ch) { atomicAdd((unsigned long long *)&O.unexpected[kind * 257 + ch], 1ull); }
+    __device__ void ids_range(const Piece &pc, u32 a, u32 b) { u64 lo, hi; piece_from(pc, a, lo, hi); global_store_n(O.ids + bids, lo, hi, b - a); bids += b - a; }
+    __device__ void cmt_range(const Piece &pc, u32 a, u32 b) { u64 lo, hi; piece_from(pc, a, lo, hi); global_store_n(O.cmt + bcmt, lo, hi, b - a); bcmt += b - a; }
+    __device__ void seq_range(const Piece &pc, u32 a, u32 b, u32 sp)
+    {
+        u64 lo, hi; piece_from(pc, a, lo, hi);
+        u32 d = (sp >> a) & ((1u << (b - a)) - 1);                 // space-class bytes inside the run: dropped, highest first
+        const u32 n = (b - a) - (u32)__popc(d);
+        while (d) {
+            u32 k = 31 - __clz((int)d); d &= ~(1u << k);
+            u64 slo = (lo >> 8) | (hi << 56), shi = hi >> 8;
+            if (k < 8) { u64 m = low_bytes(k); lo = (lo & m) | (slo & ~m); hi = shi; }
+            else { u64 m = low_bytes(k - 8); hi = (hi & m) | (shi & ~m); }
+        }
+        lds_store_n(stage + (bseq - tbase), lo, hi, n); bseq += n;
+    }
+    __device__ void term(int st) { emit(st, 0); }
 };
 
 __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, EncOut O)
@@ -351,11 +450,11 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
     bool eof_here = active && (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
     // fast: inside sequence lines and nothing to replace (every non-space byte is an expected one)
     const bool fast = seq_piece(P, base, pc, pm, ctx) && piece_all_expected(P, pc, pm, cls, true);
-    CountSink C;
+    CountSink C; bool seg = false;
     if (fast) {
         C.nseq = 16 - __popc(pm.sp); C.saw_eol = pm.eol != 0;
         C.tail = pm.eol ? __popc(~pm.sp & 0xFFFFu & ~((2u << (31 - __clz((int)pm.eol))) - 1)) : C.nseq;
-    } else if (active) classify_range(P, base, pc, eof_here, ctx, C, cls);
+    } else if (active) { seg = segments_ok(P, base, pc, pm, ctx, cls); if (seg) classify_segments(P, base, pc, pm, ctx, C); else classify_range(P, base, pc, eof_here, ctx, C, cls); }
     __shared__ u32 s_a[4], s_b[4], s_l[4];
     u32 prea, preb, tota;
     u32 ia = wg_scan1<u32, OpAdd>(C.nseq | (C.nids << 16), &prea, &tota, s_a);
@@ -404,7 +503,7 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
             else { u64 m = low_bytes(k - 8); hi = (hi & m) | (shi & ~m); }
         }
         lds_store_n(stage + (W.bseq - W.tbase), lo, hi, C.nseq);
-    } else if (active) classify_range(P, base, pc, eof_here, ctx, W, cls);
+    } else if (active) { if (seg) classify_segments(P, base, pc, pm, ctx, W); else classify_range(P, base, pc, eof_here, ctx, W, cls); }
     __syncthreads();
     flush_tile(O.seq + W.tbase, stage, tile_seq);
     __shared__ u64 s_best[4];

@@ -69,3 +69,18 @@ NAF_HD bool piece_all_quality(const u32 w[4])
     for (int i = 0; i < 4; i++) { u32 x = w[i], l = x & L; ok &= (l + 0x5F5F5F5Fu) & ~(l + 0x01010101u) & ~x; }
     return (ok & H) == H;
 }
+
+// one bit per byte that is a control character for header text: < 0x20, 0x7F or 0xFF (tables.c: the bytes replaced by '?' in
+// comments; in IDs the space 0x20 joins them, but a space ends the ID before it could be part of it)
+NAF_HD u32 piece_ctl_mask(const u32 w[4])
+{
+    const u32 H = 0x80808080u, L = 0x7F7F7F7Fu;
+    u32 f[4];
+    for (int i = 0; i < 4; i++) {
+        u32 x = w[i], l = x & L;
+        u32 lt20 = ~x & ~(l + 0x60606060u) & H;                  // < 128 and low seven bits < 0x20
+        u32 y = x ^ 0x7F7F7F7Fu, z = ~x;                          // zero bytes where x is 0x7F / 0xFF
+        f[i] = lt20 | (~(((y & L) + L) | y) & H) | (~(((z & L) + L) | z) & H);
+    }
+    return swar_movemask16(f[0], f[1], f[2], f[3]);
+}

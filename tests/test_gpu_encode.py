@@ -188,6 +188,48 @@ def test_ennaf_fuzz_against_oracle(gpu, oracle):
             check_ennaf(gpu, oracle, t, oracle.PROTEIN, no_mask=True)
 
 
+def test_ennaf_fuzz_realistic_records(gpu, oracle):
+    """Record-shaped inputs: printable headers with IDs and comments of every length (the pieces that take the segment-wise
+    header path of the split kernels), ragged line widths, LF / CRLF / blank lines, the odd tab, '>' or control byte inside a
+    header and unexpected letter inside a sequence (pieces that must fall back to the per-byte walk)."""
+    rng = np.random.default_rng(2024)
+    printable = np.frombuffer(bytes(range(0x21, 0x7F)), dtype=np.uint8)
+    bases = np.frombuffer(b"ACGTACGTACGTNacgtnRYKM-", dtype=np.uint8)
+
+    def rand(alpha, n):
+        return alpha[rng.integers(0, len(alpha), n)].tobytes()
+
+    for i in range(120):
+        eol = b"\r\n" if i % 4 == 1 else b"\n"
+        out = bytearray()
+        for r in range(int(rng.integers(1, 40))):
+            hdr = b">" + rand(printable, int(rng.integers(0, 45)))
+            if rng.random() < 0.8:
+                words = [rand(printable, int(rng.integers(1, 14))) for _ in range(int(rng.integers(0, 9)))]
+                hdr += b" " + b" ".join(words)
+            if rng.random() < 0.05:
+                hdr += b"\tafter a tab"
+            if rng.random() < 0.03:
+                hdr = hdr[:3] + b"\x01" + hdr[3:]
+            out += hdr + eol
+            width = int(rng.integers(1, 120))
+            total = int(rng.integers(0, 700)) if rng.random() < 0.9 else 0
+            seq = bytearray(rand(bases, total))
+            if total and rng.random() < 0.1:
+                seq[int(rng.integers(0, total))] = ord("!")
+            for a in range(0, total, width):
+                out += seq[a:a + width] + eol
+                if rng.random() < 0.02:
+                    out += eol
+        t = bytes(out)
+        if i % 6 == 0 and t.endswith(eol):
+            t = t[: -len(eol)]                                            # no line end after the last line
+        check_ennaf(gpu, oracle, t)
+        if i % 5 == 0:
+            check_ennaf(gpu, oracle, t, oracle.PROTEIN)
+            check_ennaf(gpu, oracle, t, oracle.TEXT, no_mask=True)
+
+
 def test_ennaf_edge_inputs(gpu, oracle):
     from naf_amd.capi import NafGpuError
     for t in (b"", b"\n\n", b">", b">a", b">a b", b">a\n", b">a\nACGT", b">a\n\n\n>b\n", b">a\r\nAC\r\n", b">x\n" + b"A" * 4096 + b"\n", b">x\n" + b"ac" * 5000):
