@@ -402,6 +402,20 @@ __device__ __forceinline__ void lds_store_n(u8 *p, u64 lo, u64 hi, u32 n)
     if (n & 1) *p = (u8)lo;
 }
 
+// bytes [a, b) of the piece without their space-class bytes, moved down to byte 0; returns how many are left
+__device__ __forceinline__ u32 piece_run_compact(const Piece &pc, u32 a, u32 b, u32 sp, u64 &lo, u64 &hi)
+{
+    piece_from(pc, a, lo, hi);
+    u32 d = (sp >> a) & ((1u << (b - a)) - 1);
+    const u32 n = (b - a) - (u32)__popc(d);
+    while (d) {                                                   // highest first, so the lower positions stay put
+        u32 k = 31 - __clz((int)d); d &= ~(1u << k);
+        u64 slo = (lo >> 8) | (hi << 56), shi = hi >> 8;
+        if (k < 8) { u64 m = low_bytes(k); lo = (lo & m) | (slo & ~m); hi = shi; }
+        else { u64 m = low_bytes(k - 8); hi = (hi & m) | (shi & ~m); }
+    }
+    return n;
+}
 // first n (<= 16) bytes of {lo, hi} to global memory at any alignment
 __device__ __forceinline__ void global_store_n(u8 *p, u64 lo, u64 hi, u32 n)
 {
@@ -422,19 +436,7 @@ struct WriteSink {
     __device__ void unexpected(int kind, u32 ch) { atomicAdd((unsigned long long *)&O.unexpected[kind * 257 + ch], 1ull); }
     __device__ void ids_range(const Piece &pc, u32 a, u32 b) { u64 lo, hi; piece_from(pc, a, lo, hi); global_store_n(O.ids + bids, lo, hi, b - a); bids += b - a; }
     __device__ void cmt_range(const Piece &pc, u32 a, u32 b) { u64 lo, hi; piece_from(pc, a, lo, hi); global_store_n(O.cmt + bcmt, lo, hi, b - a); bcmt += b - a; }
-    __device__ void seq_range(const Piece &pc, u32 a, u32 b, u32 sp)
-    {
-        u64 lo, hi; piece_from(pc, a, lo, hi);
-        u32 d = (sp >> a) & ((1u << (b - a)) - 1);                 // space-class bytes inside the run: dropped, highest first
-        const u32 n = (b - a) - (u32)__popc(d);
-        while (d) {
-            u32 k = 31 - __clz((int)d); d &= ~(1u << k);
-            u64 slo = (lo >> 8) | (hi << 56), shi = hi >> 8;
-            if (k < 8) { u64 m = low_bytes(k); lo = (lo & m) | (slo & ~m); hi = shi; }
-            else { u64 m = low_bytes(k - 8); hi = (hi & m) | (shi & ~m); }
-        }
-        lds_store_n(stage + (bseq - tbase), lo, hi, n); bseq += n;
-    }
+    __device__ void seq_range(const Piece &pc, u32 a, u32 b, u32 sp) { u64 lo, hi; u32 n = piece_run_compact(pc, a, b, sp, lo, hi); lds_store_n(stage + (bseq - tbase), lo, hi, n); bseq += n; }
     __device__ void term(int st) { emit(st, 0); }
 };
 
@@ -587,6 +589,12 @@ struct FqCount {
     __device__ void header_start(u64) {} __device__ void header_end(u64) {} __device__ void seq_end(u64) {}
     __device__ void qual_begin(u64) {} __device__ void qual_end(u64) {}
     __device__ void unexpected(int, u32) {} __device__ void error(u64, int) {}
+    __device__ void ids_range(const Piece &, u32 a, u32 b) { nids += b - a; }
+    __device__ void cmt_range(const Piece &, u32 a, u32 b) { ncmt += b - a; }
+    __device__ void seq_range(const Piece &, u32 a, u32 b, u32 sp) { nseq += (u32)__popc(range_mask(a, b) & ~sp); }
+    __device__ void qual_range(const Piece &, u32 a, u32 b, u32 sp) { nqual += (u32)__popc(range_mask(a, b) & ~sp); }
+    __device__ void qual_first(u32) { nqual++; }
+    __device__ void term(int st) { if (st == EV_IDS) nids++; else ncmt++; }
 };
 struct FqWrite {
     const FqOut &O; u64 bseq, bids, bcmt, bqual; u8 *sstage, *qstage; u64 sbase, qbase;
@@ -599,7 +607,82 @@ struct FqWrite {
     __device__ void qual_end(u64 r) { O.q_end[r] = bqual; }
     __device__ void unexpected(int kind, u32 ch) { atomicAdd((unsigned long long *)&O.unexpected[kind * 257 + ch], 1ull); }
     __device__ void error(u64 r, int kind) { atomicMin((unsigned long long *)O.first_error, (unsigned long long)(r * 4 + kind)); }
+    __device__ void ids_range(const Piece &pc, u32 a, u32 b) { u64 lo, hi; piece_from(pc, a, lo, hi); global_store_n(O.ids + bids, lo, hi, b - a); bids += b - a; }
+    __device__ void cmt_range(const Piece &pc, u32 a, u32 b) { u64 lo, hi; piece_from(pc, a, lo, hi); global_store_n(O.cmt + bcmt, lo, hi, b - a); bcmt += b - a; }
+    __device__ void seq_range(const Piece &pc, u32 a, u32 b, u32 sp) { u64 lo, hi; u32 n = piece_run_compact(pc, a, b, sp, lo, hi); lds_store_n(sstage + (bseq - sbase), lo, hi, n); bseq += n; }
+    __device__ void qual_range(const Piece &pc, u32 a, u32 b, u32 sp) { u64 lo, hi; u32 n = piece_run_compact(pc, a, b, sp, lo, hi); lds_store_n(qstage + (bqual - qbase), lo, hi, n); bqual += n; }
+    __device__ void qual_first(u32 ch) { emit(EV_QUAL, ch); }
+    __device__ void term(int st) { emit(st, 0); }
 };
+
+// ---- FASTQ pieces segment-wise (see classify_segments): the runs between EOL bytes are whole lines or parts of lines whose type is
+// the line ordinal mod 4.  Same conditions: full piece behind p0, no byte that its role would replace (dry run into FqRoleSink).
+template <typename Sink>
+__device__ __forceinline__ void classify_segments_fastq(const EncP &P, u64 base, const Piece &pc, const PMask &pm, const TileCtx &ctx, Sink &S)
+{
+    i64 le = ctx.last_eol, ls = ctx.last_sp, ord = ctx.ord;
+    u32 k = 0;
+    while (k < ET_BYTES) {
+        const u64 i = base + k;
+        const bool prev_eol = le == (i64)i - 1;
+        i64 line_start = le + 1; if ((u64)line_start < P.p0) line_start = (i64)P.p0;
+        if ((pm.eol >> k) & 1) {                                          // one EOL byte
+            if (!prev_eol) {                                              // it closes a line
+                const u64 rec = (u64)ord >> 2; const u32 type = (u32)ord & 3;
+                if (type == 0) { if (ls < line_start) S.term(EV_IDS); S.term(EV_CMT); S.header_end(rec); }
+                else if (type == 1) S.seq_end(rec);
+                else if (type == 3) S.qual_end(rec);
+            } else if (ord >= 0 && (ord & 3) == 0) S.error((u64)ord >> 2, FQ_E_PLUS);   // blank line right after a header
+            le = ls = (i64)i; k++;
+            continue;
+        }
+        const u32 em = pm.eol >> k;
+        const u32 e = em ? k + (u32)__ffs((int)em) - 1 : ET_BYTES;       // run of non-EOL bytes [k, e)
+        if (prev_eol) { ord++; line_start = (i64)i; }                     // a new line starts here
+        const u64 rec = (u64)ord >> 2; const u32 type = (u32)ord & 3; const bool first = (i64)i == line_start;
+        const u32 spm = pm.sp & range_mask(k, e);
+        u32 a = k;
+        if (type == 0) {
+            if (first) { if (piece_byte(pc, k) != '@') S.error(rec, FQ_E_AT); S.header_start(rec); a++; }
+            if (a < e) {
+                const u32 sp2 = pm.sp & range_mask(a, e);
+                if (ls < line_start) {
+                    const u32 f = sp2 ? (u32)__ffs((int)sp2) - 1 : e;
+                    if (f > a) S.ids_range(pc, a, f);
+                    if (f < e) { S.term(EV_IDS); if (f + 1 < e) S.cmt_range(pc, f + 1, e); }
+                } else S.cmt_range(pc, a, e);
+            }
+        } else if (type == 1) S.seq_range(pc, k, e, pm.sp);
+        else if (type == 2) { if (first && piece_byte(pc, k) != '+') S.error(rec, FQ_E_PLUS); }
+        else {
+            if (first) { S.qual_begin(rec); S.qual_first(piece_byte(pc, k)); a++; }     // process.c:522: the first byte goes in whatever it is
+            if (a < e) S.qual_range(pc, a, e, pm.sp);
+        }
+        if (spm) ls = (i64)(base + (31 - __clz((int)spm)));
+        k = e;
+    }
+}
+struct FqRoleSink {
+    u32 idm = 0, cmm = 0, sqm = 0, qlm = 0;
+    __device__ void ids_range(const Piece &, u32 a, u32 b) { idm |= range_mask(a, b); }
+    __device__ void cmt_range(const Piece &, u32 a, u32 b) { cmm |= range_mask(a, b); }
+    __device__ void seq_range(const Piece &, u32 a, u32 b, u32 sp) { sqm |= range_mask(a, b) & ~sp; }
+    __device__ void qual_range(const Piece &, u32 a, u32 b, u32 sp) { qlm |= range_mask(a, b) & ~sp; }
+    __device__ void qual_first(u32) {}
+    __device__ void term(int) {} __device__ void header_start(u64) {} __device__ void header_end(u64) {} __device__ void seq_end(u64) {}
+    __device__ void qual_begin(u64) {} __device__ void qual_end(u64) {} __device__ void error(u64, int) {}
+};
+__device__ __forceinline__ bool segments_ok_fastq(const EncP &P, u64 base, const Piece &pc, const PMask &pm, const TileCtx &ctx, const u8 *cls)
+{
+    if (pc.cnt != ET_BYTES || base <= P.p0 || ctx.ord < 0) return false;
+    FqRoleSink R; classify_segments_fastq(P, base, pc, pm, ctx, R);
+    u32 w[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) };
+    if ((R.idm | R.cmm) && ((R.idm | R.cmm) & piece_ctl_mask(w))) return false;
+    if (R.qlm && (R.qlm & piece_not_quality_mask(w))) return false;
+    u32 cand = R.sqm ? (piece_not_quick(w, P.qlo, P.qhi) & R.sqm) : 0u;
+    while (cand) { u32 k = (u32)__ffs((int)cand) - 1; cand &= cand - 1; if (!(cls[piece_byte(pc, k)] & CL_EXPECTED)) return false; }
+    return true;
+}
 
 // ordinal of the line in progress at `base`: (#line starts before base) - 1
 __device__ __forceinline__ i64 thread_ord(const EncP &P, const u64 *t_ls, u64 base, u64 *lds, const Piece &pc, const PMask &pm)
@@ -662,7 +745,8 @@ __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol,
         Piece p2 = load_piece(P, b2);
         TileCtx c2; c2.last_eol = s_ctx[who].le; c2.last_sp = s_ctx[who].ls; c2.hdr = false; c2.ord = s_ctx[who].ord;
         FqCount S2;
-        classify_range_fastq(P, b2, p2, (b2 + p2.cnt == P.n) && p2.cnt < ET_BYTES, c2, S2, cls);
+        if (segments_ok_fastq(P, b2, p2, piece_masks(p2), c2, cls)) classify_segments_fastq(P, b2, p2, piece_masks(p2), c2, S2);
+        else classify_range_fastq(P, b2, p2, (b2 + p2.cnt == P.n) && p2.cnt < ET_BYTES, c2, S2, cls);
         s_cnt[who] = (u64)S2.nseq | ((u64)S2.nids << 16) | ((u64)S2.ncmt << 32) | ((u64)S2.nqual << 48);
     }
     __syncthreads();
@@ -710,7 +794,8 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
         TileCtx c2; c2.last_eol = s_ctx[who].le; c2.last_sp = s_ctx[who].ls; c2.hdr = false; c2.ord = s_ctx[who].ord;
         FqWrite W2(O); W2.sstage = sstage; W2.qstage = qstage; W2.sbase = W.sbase; W2.qbase = W.qbase;
         W2.bseq = s_w[who][0]; W2.bids = s_w[who][1]; W2.bcmt = s_w[who][2]; W2.bqual = s_w[who][3];
-        classify_range_fastq(P, b2, p2, (b2 + p2.cnt == P.n) && p2.cnt < ET_BYTES, c2, W2, cls);
+        if (segments_ok_fastq(P, b2, p2, piece_masks(p2), c2, cls)) classify_segments_fastq(P, b2, p2, piece_masks(p2), c2, W2);
+        else classify_range_fastq(P, b2, p2, (b2 + p2.cnt == P.n) && p2.cnt < ET_BYTES, c2, W2, cls);
     }
     __syncthreads();
     flush_tile(O.seq + W.sbase, sstage, (u32)tots);

@@ -84,3 +84,12 @@ NAF_HD u32 piece_ctl_mask(const u32 w[4])
     }
     return swar_movemask16(f[0], f[1], f[2], f[3]);
 }
+
+// one bit per byte outside 0x21..0x7E
+NAF_HD u32 piece_not_quality_mask(const u32 w[4])
+{
+    const u32 H = 0x80808080u, L = 0x7F7F7F7Fu;
+    u32 f[4];
+    for (int i = 0; i < 4; i++) { u32 x = w[i], l = x & L; f[i] = ~((l + 0x5F5F5F5Fu) & ~(l + 0x01010101u) & ~x) & H; }
+    return swar_movemask16(f[0], f[1], f[2], f[3]);
+}

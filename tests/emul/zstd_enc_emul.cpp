@@ -123,10 +123,10 @@ extern "C" int emul_window_roundtrip(const u8 *syms, u32 n, u64 align_off, int b
 
 // ---- encoder front end: SWAR byte classes (enc_swar.h) ----------------------------------------------------------------------
 #include "../../naf_amd/csrc/enc_swar.h"
-extern "C" void emul_piece_flags(const uint8_t *piece16, uint32_t qlo, uint32_t qhi, uint32_t out[7])
+extern "C" void emul_piece_flags(const uint8_t *piece16, uint32_t qlo, uint32_t qhi, uint32_t out[8])
 {
     u32 w[4]; memcpy(w, piece16, 16);
     PieceFlags f = piece_flags(w);
     u32 nq = piece_not_quick(w, qlo, qhi);
-    out[0] = f.eol; out[1] = f.sp; out[2] = f.gt; out[3] = (nq & ~f.sp) == 0; out[4] = nq == 0; out[5] = piece_all_quality(w); out[6] = piece_ctl_mask(w);
+    out[0] = f.eol; out[1] = f.sp; out[2] = f.gt; out[3] = (nq & ~f.sp) == 0; out[4] = nq == 0; out[5] = piece_all_quality(w); out[6] = piece_ctl_mask(w); out[7] = piece_not_quality_mask(w);
 }

@@ -341,3 +341,33 @@ def test_ennaf_fastq_fuzz(gpu, oracle):
         check_ennaf(gpu, oracle, t)
         agree += 1
     assert agree > 40 and died > 20, (agree, died)
+
+
+def test_ennaf_fastq_fuzz_realistic_records(gpu, oracle):
+    """Instrument-style reads: long headers with comments (the segment-wise path of the FASTQ split kernels), read lengths
+    from 1 to 400 with N and lower case, the full quality range, '+' lines that repeat the header, blank lines between
+    records; a few pieces with a control byte or a stray space so that the per-byte walk is taken beside it."""
+    rng = np.random.default_rng(77)
+    bases = np.frombuffer(b"ACGTACGTACGTNacgtn", dtype=np.uint8)
+    quals = np.frombuffer(bytes(range(0x21, 0x7F)), dtype=np.uint8)
+    for i in range(60):
+        out = bytearray()
+        for r in range(int(rng.integers(1, 60))):
+            hdr = b"@M%05d:%d:000000000-A%dXY:1:%d:%d:%d" % (int(rng.integers(0, 99999)), i, r, int(rng.integers(1101, 2119)), int(rng.integers(1000, 30000)), int(rng.integers(1000, 30000)))
+            if rng.random() < 0.8:
+                hdr += b" %d:N:0:%s" % (1 + (r & 1), bases[rng.integers(0, 4, int(rng.integers(0, 17)))].tobytes())
+            if rng.random() < 0.04:
+                hdr += b"\x01"
+            n = int(rng.integers(1, 400))
+            seq = bytearray(bases[rng.integers(0, len(bases), n)].tobytes())
+            qual = bytearray(quals[rng.integers(0, len(quals), n)].tobytes())
+            if rng.random() < 0.05:
+                k = int(rng.integers(0, n)); seq = seq[:k] + b" " + seq[k:]
+            if rng.random() < 0.05 and n > 1:
+                k = int(rng.integers(1, n)); qual = qual[:k] + b" " + qual[k:]
+            plus = b"+" + (hdr[1:] if rng.random() < 0.3 else b"")
+            out += hdr + b"\n" + seq + b"\n" + plus + b"\n" + qual + b"\n" + (b"\n" if rng.random() < 0.05 else b"")
+        t = bytes(out)
+        if i % 7 == 0:
+            t = t.rstrip(b"\n")
+        check_ennaf(gpu, oracle, t)

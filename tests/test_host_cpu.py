@@ -276,7 +276,7 @@ def test_swar_piece_flags_every_byte_every_position(alphabet):
     qlo, qhi, quick = _quick_table(expected)
     assert quick                                                # the table is not empty for any of the reference's alphabets
     rng = np.random.default_rng(5)
-    out = (ctypes.c_uint32 * 7)()
+    out = (ctypes.c_uint32 * 8)()
     fills = [bytes([65] * 16), bytes([10] * 16), bytes([0x20] * 16), bytes([0x7E] * 16), bytes(rng.integers(0, 256, 16, dtype=np.uint8)),
              bytes(rng.choice(np.frombuffer(b"ACGTNacgtn\n", dtype=np.uint8), 16))]
     is_eol = lambda c: 0x0A <= c <= 0x0D
@@ -294,5 +294,6 @@ def test_swar_piece_flags_every_byte_every_position(alphabet):
                 assert out[4] == int(all(is_quick(c) for c in p)), (fill, pos, b)
                 assert out[5] == int(all(0x21 <= c <= 0x7E for c in p)), (fill, pos, b)
                 assert out[6] == sum(1 << i for i, c in enumerate(p) if c < 0x20 or c in (0x7F, 0xFF)), (fill, pos, b)
+                assert out[7] == sum(1 << i for i, c in enumerate(p) if not 0x21 <= c <= 0x7E), (fill, pos, b)
                 # the quick test is only ever a sufficient one
                 if out[3]: assert all(is_sp(c) or c in expected for c in p)
