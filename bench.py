@@ -174,10 +174,18 @@ def main():
     packed = (rep.n_bases + 1) // 2
     # algorithmic bytes per launch of each candidate dominant kernel
     alg = {"zstd_huf_literals": rep.section_comp[4] + packed, "unnaf_emit": packed + n_text}
-    dom = max(alg, key=lambda k: kt.get(k, (0, 1))[0])
-    # launches for the side streams run on the side context's stream, concurrently, and are reported as "side:<name>";
-    # the names used here are the payload launches only (one k_huf_literals launch over the sequence stream per step)
-    dom_ms = kt[dom][0]
+    # Launches on the side contexts' streams are reported as "side:<name>".  The sequence stream's Huffman literals are decoded in a
+    # few launches over consecutive block ranges and the text behind a finished range is emitted on a second stream beside the
+    # decode of the next one: a kernel's time per step is the sum over its launches of the step -- for the emit,
+    # the ones on this context plus "side:unnaf_emit"; "side:zstd_huf_literals" are the side streams' own and not counted.  The
+    # launches overlap each other, so each carries the other's contention: the per-kernel fractions are lower bounds.
+    def kernel_ms(name):
+        ms, k = kt.get(name, (0.0, 0))
+        if name == "unnaf_emit":
+            ms2, k2 = kt.get("side:unnaf_emit", (0.0, 0)); ms += ms2; k += k2
+        return ms, max(k, 1)
+    dom = max(alg, key=lambda k: kernel_ms(k)[0])
+    dom_ms, dom_launches = kernel_ms(dom)
     achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
     # HBM traffic of that kernel per step, from the committed PMC passes of this same workload (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in separate runs, tools/profile_bench.sh; FETCH doubled as the gfx950 guide prescribes)
@@ -190,7 +198,8 @@ def main():
         pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": int(alg[dom]), "kernel_ms_per_step": round(dom_ms, 4), "launches_per_step": kt[dom][1],
+                "algorithmic_bytes_per_launch": int(alg[dom] // dom_launches), "avg_launch_ms": round(dom_ms / dom_launches, 4),
+                "kernel_ms_per_step": round(dom_ms, 4), "launches_per_step": dom_launches,
                 "path_bytes_per_step": int(n_naf + n_text),
                 "path_frac": round((n_naf + n_text) / (ms_per_step * 1e-3) / HBM_PEAK, 4),
                 "kernels_ms": {n: round(ms, 3) for n, (ms, k) in sorted(kt.items(), key=lambda x: -x[1][0])[:8]}}

@@ -932,7 +932,8 @@ static int unnaf_prepare(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const 
 
 // Lengths, ids, names and the prefix tables built from them (text offset / first base of every record).  `aux`: a context of its
 // own for ids + names (second host thread and stream); nullptr = everything on c, in order.
-static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gpu_ctx *aux)
+template <typename Hook>
+static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gpu_ctx *aux, Hook early, bool early_has_work)
 {
     const naf_gpu_header &h = pl.h;
     EmitP &P = pl.P;
@@ -966,29 +967,33 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
             return 0;
         };
         u64 *rec_len = nullptr;
-        auto lengths = [&]() -> int {
+        auto lengths = [&](naf_gpu_ctx *x) -> int {
             int r;
             u8 *lens = nullptr;
-            if ((r = load_section(c, d_naf, h, S_LEN, h.orig_size[S_LEN], "lengths", &lens))) return r;
+            if ((r = load_section(x, d_naf, h, S_LEN, h.orig_size[S_LEN], "lengths", &lens))) return r;
             u64 n_len = h.orig_size[S_LEN] / 4;
-            u64 *flag = arena_new<u64>(c, n_len + 2); rec_len = arena_new<u64>(c, N + 1);
+            u64 *flag = arena_new<u64>(x, n_len + 2); rec_len = arena_new<u64>(x, N + 1);
             if (!flag || !rec_len) return NAF_GPU_ENOMEM;
-            HIP_TRY(c, hipMemsetAsync(rec_len, 0, (N + 1) * 8, c->stream));
-            if (n_len) LAUNCH(c, "unnaf_len_flags", k_len_flags, cdiv(n_len, 256), 256, 0, (const u32 *)lens, n_len, flag);
-            if ((r = scan_exclusive_u64(c, flag, n_len, flag + n_len + 1))) return r;
-            if (n_len) LAUNCH(c, "unnaf_len_acc", k_len_acc, cdiv(n_len, 256), 256, 0, (const u32 *)lens, n_len, (const u64 *)flag, rec_len, N);
+            HIP_TRY(x, hipMemsetAsync(rec_len, 0, (N + 1) * 8, x->stream));
+            if (n_len) LAUNCH(x, "unnaf_len_flags", k_len_flags, cdiv(n_len, 256), 256, 0, (const u32 *)lens, n_len, flag);
+            if ((r = scan_exclusive_u64(x, flag, n_len, flag + n_len + 1))) return r;
+            if (n_len) LAUNCH(x, "unnaf_len_acc", k_len_acc, cdiv(n_len, 256), 256, 0, (const u32 *)lens, n_len, (const u64 *)flag, rec_len, N);
             u64 nrec = 0;
-            if ((r = ctx_readback(c, &nrec, flag + n_len + 1, 8))) return r;
-            if (nrec < N) return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted lengths: %llu records described, %llu expected", (unsigned long long)nrec, (unsigned long long)N);
+            if ((r = ctx_readback(x, &nrec, flag + n_len + 1, 8))) return r;
+            if (nrec < N) return ctx_fail(x, NAF_GPU_EFORMAT, "corrupted lengths: %llu records described, %llu expected", (unsigned long long)nrec, (unsigned long long)N);
             return 0;
         };
+        // With a second context: ids and names go there.  When this context also has the mask stream to decode (`early`), the
+        // lengths follow the names over there, so that the two chains (mask | ids, names, lengths) are about as long as each other.
         const bool aux_run = aux && want_names && (has_ids || has_names);
-        int rc_aux = 0;
+        int rc_aux = 0, rc_len = 0;
         std::thread th;
-        if (aux_run) th = std::thread([&] { hipSetDevice(c->device); rc_aux = ids_names(aux); });     // no return until it is joined
-        rc = lengths();
+        const bool len_on_aux = aux_run && early_has_work;
+        if (aux_run) th = std::thread([&] { hipSetDevice(c->device); rc_aux = ids_names(aux); if (len_on_aux) rc_len = lengths(aux); });     // no return until it is joined
+        early();                                                                                         // work that needs none of this (the mask stream)
+        if (!len_on_aux) rc_len = lengths(c);
         if (aux_run) { th.join(); hipStreamSynchronize(aux->stream); }
-        if (rc) return rc;                                                                               // the order a sequential run reports in
+        if (rc_len) { if (len_on_aux) memcpy(c->err, aux->err, sizeof c->err); return rc_len; }           // the order a sequential run reports in: lengths, ids, names
         if (!aux_run) rc_aux = ids_names(c);
         else if (rc_aux) memcpy(c->err, aux->err, sizeof c->err);
         if (rc_aux) return rc_aux;
@@ -1043,11 +1048,19 @@ static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gp
     int rc_mask = 0; std::thread thm;
     const bool mask_started = P.masking && aux_mask;
     if (mask_started) thm = std::thread([&] { hipSetDevice(c->device); rc_mask = mask_part(aux_mask); });      // joined below: no return before
-    int rc = unnaf_sections_main(c, d_naf, pl, aux);
+    // Without a context of its own the mask goes FIRST on this one, right after the ids / names thread has been started: this
+    // context would otherwise idle while it waits for that thread, and the mask decode (a few long Huffman streams) is pure latency.
+    // Errors keep the order of a sequential run: lengths, ids, names, then mask.
+    bool mask_early = false; char mask_err[sizeof c->err];
+    auto early = [&]() {
+        if (P.masking && !mask_started && P.mode != EM_SEQ && aux) { mask_early = true; rc_mask = mask_part(c); if (rc_mask) memcpy(mask_err, c->err, sizeof c->err); }
+    };
+    int rc = unnaf_sections_main(c, d_naf, pl, aux, early, P.masking && !mask_started && P.mode != EM_SEQ && aux != nullptr);
     if (mask_started) { thm.join(); hipStreamSynchronize(aux_mask->stream); }
     if (rc) return rc;                                                                                     // the order a sequential run reports in
     if (mask_started && rc_mask) { memcpy(c->err, aux_mask->err, sizeof c->err); return rc_mask; }
-    if (P.masking && !mask_started && (rc = mask_part(c))) return rc;
+    if (mask_early) { if (rc_mask) { memcpy(c->err, mask_err, sizeof c->err); return rc_mask; } }
+    else if (P.masking && !mask_started && (rc = mask_part(c))) return rc;
     return 0;
 }
 
@@ -1106,6 +1119,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     // host thread on the side context's stream while this thread decodes the payload; they meet before the emit.
     const bool par = whole && !size_only && pl.P.mode != -1 && c->side && !fuse_on && !(ser && ser[0] == '1');
     bool payload_done = false;
+    ZSplit split; split.parts = 0; split.done = 0; split.status = nullptr;
     if (par) {
         arena_reset(c->side);
         HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
@@ -1116,10 +1130,19 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         if (c->side3) { arena_reset(c->side3); HIP_TRY(c, hipStreamWaitEvent(c->side3->stream, c->fork_ev, 0)); }
         if (c->side4) { arena_reset(c->side4); HIP_TRY(c, hipStreamWaitEvent(c->side4->stream, c->fork_ev, 0)); }
         // no early return between here and the joins
-        std::thread th([&] { hipSetDevice(c->device); rc_side = unnaf_sections(c->side, d_naf, pl, c->side3, nullptr); });   // the mask stays on this context: a fifth thread measured slower
+        std::thread th([&] { hipSetDevice(c->device); rc_side = unnaf_sections(c->side, d_naf, pl, c->side3, nullptr); });   // the mask stays on this context: a thread of its own measured slower, with and without the split decode
         std::thread thq;
         if (qpar) thq = std::thread([&] { hipSetDevice(c->device); rc_q = payload_qual(c->side2); });
+        // decode -> emit pipeline (ZSplit): the quality context is free when there is no quality stream
+        const char *nsp = getenv("NAF_GPU_SPLIT");
+        const int nparts = nsp ? atoi(nsp) : 4;
+        if (!pl.need_qual && c->side2 && nparts >= 2 && nparts <= ZSPLIT_MAX && pl.P.mode != -1) {
+            split.parts = nparts; split.done = 0;
+            for (int k = 0; k < nparts; k++) split.ev[k] = c->split_ev[k];
+            c->zsplit = &split;
+        }
         rc = payload_seq();
+        c->zsplit = nullptr;
         if (!rc && pl.need_qual && !qpar) rc = payload_qual(c);
         th.join();
         if (qpar) thq.join();
@@ -1202,21 +1225,46 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         TileIdx *ti = arena_new<TileIdx>(c, ntiles + 2); u64 *tr = arena_new<u64>(c, ntiles + 2);
         u32 *list = arena_new<u32>(c, ntiles + 1), *cnt = arena_new<u32>(c, 2);
         if (!ti || !tr || !list || !cnt) return NAF_GPU_ENOMEM;
-        HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, c->stream));
+        if (!split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, c->stream));
         // exact c / (L+1) for c < L + 1 + 4096 as mulhi(c, M), M = floor(2^32 / (L+1)) + 1, valid while c * (L+1) < 2^32
         u64 Lp1 = pl.P.L + 1;
         pl.P.Ldiv_magic = (Lp1 >= 2 && Lp1 < 32768) ? (u32)((1ull << 32) / Lp1 + 1) : 0;
-        LAUNCH(c, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr);
-        LAUNCH(c, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt);
+        // With a split decode (ZSplit) the index and the tiles behind the finished parts run on the second stream beside the
+        // decode of the next part; this stream takes the tiles behind the last part, the boundary tiles, and waits for the other.
+        naf_gpu_ctx *ic = split.done ? c->side2 : c;                                     // context the tile index is built on
+        if (split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, ic->stream));
+        LAUNCH(ic, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr);
+        LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt);
         u32 nrest = 0;                                                                   // tiles holding a header or a record boundary
-        if ((rc = ctx_readback(c, &nrest, cnt, 4))) return rc;
-        if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit_tile<true>, (u32)ntiles, 256, 0, pl.P, (const TileIdx *)ti, d_out);
-        else LAUNCH(c, "unnaf_emit", k_emit_tile<false>, (u32)ntiles, 256, 0, pl.P, (const TileIdx *)ti, d_out);
+        if ((rc = ctx_readback(ic, &nrest, cnt, 4))) { if (ic != c) memcpy(c->err, ic->err, sizeof c->err); return rc; }
+        u64 t_done = 0;
+        if (split.done) {
+            HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX], ic->stream));
+            for (int k = 0; k + 1 < split.parts; k++) {
+                // a tile's bases all lie below its last text position, and a lane reads at most 32 packed bytes past its own
+                u64 bases_ready = split.out_end[k] * (pl.fourbit ? 2u : 1u);
+                u64 t_hi = bases_ready / 4096; t_hi = t_hi > 1 ? t_hi - 1 : 0;
+                if (t_hi > ntiles) t_hi = ntiles;
+                if (t_hi <= t_done) continue;
+                HIP_TRY(c, hipStreamWaitEvent(ic->stream, split.ev[k], 0));
+                if (pl.fourbit) LAUNCH(ic, "unnaf_emit", k_emit_tile<true>, (u32)(t_hi - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
+                else LAUNCH(ic, "unnaf_emit", k_emit_tile<false>, (u32)(t_hi - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
+                t_done = t_hi;
+            }
+            HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX + 1], ic->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX], 0));         // the index
+        }
+        if (t_done < ntiles) {
+            if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit_tile<true>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
+            else LAUNCH(c, "unnaf_emit", k_emit_tile<false>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
+        }
         if (!nrest) {}
         else if (pl.fourbit) LAUNCH(c, "unnaf_emit_rest", k_emit_rest<true>, (u32)nrest, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
         else LAUNCH(c, "unnaf_emit_rest", k_emit_rest<false>, nrest, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
+        if (split.done) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX + 1], 0));
     }
     HIP_TRY(c, hipGetLastError());
+    if ((rc = zstd_split_status(c, &split))) return rc;           // a split decode left its status for after the emit was queued
     return 0;
 }
 

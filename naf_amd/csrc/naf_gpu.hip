@@ -51,6 +51,7 @@ extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
     if (rc) { naf_gpu_shutdown(c); return rc; }
     // side contexts: share the device and the constant tables
     if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess) { naf_gpu_shutdown(c); return NAF_GPU_EHIP; }
+    for (int k = 0; k < ZSPLIT_MAX + 2; k++) if (hipEventCreateWithFlags(&c->split_ev[k], hipEventDisableTiming) != hipSuccess) { naf_gpu_shutdown(c); return NAF_GPU_EHIP; }
     for (int k = 0; k < 3; k++) {
         naf_gpu_ctx *sc = new naf_gpu_ctx();
         sc->device = device; sc->d_predef = c->d_predef; sc->h_stage_cap = 1 << 16;
@@ -82,6 +83,7 @@ extern "C" void naf_gpu_shutdown(naf_gpu_ctx *c)
         delete sc;
     }
     if (c->fork_ev) hipEventDestroy(c->fork_ev);
+    for (int k = 0; k < ZSPLIT_MAX + 2; k++) if (c->split_ev[k]) hipEventDestroy(c->split_ev[k]);
     for (auto &ch : c->chunks) hipFree(ch.base);
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->d_predef) hipFree(c->d_predef);

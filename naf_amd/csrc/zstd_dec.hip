@@ -32,15 +32,17 @@ static __device__ __forceinline__ u64 shfl_u64(u64 v, int l) { u32 lo = __shfl((
 #define SCAN_WIN (48u * 1024u)
 // Serial walk of the block headers (frames too small for the parallel index, or not one well-formed chain).  The header chain
 // is one dependent load per block, so the frame is pulled through LDS a 48 KiB window at a time (coalesced) and walked there.
-__global__ __launch_bounds__(64) void k_scan_blocks(const u8 *src, u64 len, u64 first_off, ZBlock *blk, u32 cap, ZStat *st)
+// The window (dynamic LDS, `win` + 16 bytes) is sized to the frame: a 48 KiB allocation waits for a CU to drain when a big
+// kernel of another stream fills the device, and the frames that come here are mostly a few hundred bytes.
+__global__ __launch_bounds__(64) void k_scan_blocks(const u8 *src, u64 len, u64 first_off, ZBlock *blk, u32 cap, ZStat *st, u32 win)
 {
-    __shared__ __attribute__((aligned(16))) u8 buf[SCAN_WIN + 16];
+    extern __shared__ __attribute__((aligned(16))) u8 buf[];
     __shared__ u64 s_pos; __shared__ u32 s_n, s_err, s_done;
     if (threadIdx.x == 0) { s_pos = first_off; s_n = 0; s_err = 0; s_done = 0; }
     __syncthreads();
     for (;;) {
         const u64 wlo = s_pos;
-        const u32 wn = len - wlo < SCAN_WIN ? (u32)(len > wlo ? len - wlo : 0) : SCAN_WIN;
+        const u32 wn = len - wlo < win ? (u32)(len > wlo ? len - wlo : 0) : win;
         for (u32 i = threadIdx.x * 16; i < wn; i += 64 * 16) {
             if (i + 16 <= wn) { uint4 v; memcpy(&v, src + wlo + i, 16); *(uint4 *)(buf + i) = v; }
             else for (u32 k = i; k < wn; k++) buf[k] = src[wlo + k];
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64) void k_scan_blocks(const u8 *src, u64 len, u64 
 //                    EXACT by construction -- speculation only decides how much is reused.
 //   4. k_spec_walk   count, then write, the ZBlock records of every chunk in parallel.
 #define SPEC_CHUNK   (1024u * 1024u)
-#define SPEC_CHUNK_SMALL (16u * 1024u)    // frames of 64 KiB .. 4 MiB: every byte is a candidate
+#define SPEC_CHUNK_SMALL (16u * 1024u)    // frames of up to 4 MiB: chunks of 256 B .. 16 KiB, every byte is a candidate
 #define SPEC_WINDOW  (ZBLOCK_MAX + 4u)
 #define SPEC_HOPS    10
 #define SPEC_NONE    0xFFFFFFFFFFFFFFFFull
@@ -267,6 +269,41 @@ __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 
     huf_build_any((u16 *)(pool + off), w, nw, log);
     blk[i].huf_tab = off; blk[i].huf_log = (u8)log;
     atomicMax(&st->max_huf_log, log);
+}
+
+// The same for streams of a few blocks (ids, names, lengths, the last block of a mask stream): one block per workgroup, the tree
+// description, the weights, the builder's workspace and the table in LDS, so that the lone working lane waits for LDS, not for
+// scratch memory (0.3 - 1 ms per launch otherwise, on the critical path of every small stream).
+__global__ __launch_bounds__(64) void k_build_huf_lds(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first)
+{
+    __shared__ HufBuildWS ws;
+    __shared__ __attribute__((aligned(16))) u8 in[192], w[256];
+    __shared__ __attribute__((aligned(16))) u16 tab[HUFC_BYTES / 2 > 256 ? HUFC_BYTES / 2 : 256];
+    __shared__ u32 s_log, s_off;
+    u32 i = first + blockIdx.x;
+    if (i >= nblk) return;
+    if (blk[i].btype != BT_COMP || blk[i].lit_type != LIT_HUF || blk[i].err) return;
+    const u8 *c = src + blk[i].src_off + blk[i].lit_off;
+    const u32 len = blk[i].lit_csize, n_in = len < 192 ? len : 192;          // a tree description takes at most 129 bytes
+    for (u32 k = threadIdx.x; k < n_in; k += 64) in[k] = c[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 nw = 0, used = 0;
+        u32 log = huf_read_weights_ws(in, n_in, w, &nw, &used, ws);
+        u32 off = 0;
+        if (!log) { set_err(st, ZE_CORRUPT); blk[i].err = ZE_CORRUPT; }
+        else {
+            u32 bytes = huf_tab_bytes(log);
+            off = atomicAdd(&st->huf_pool_used, bytes);
+            if (off + bytes > pool_cap) { set_err(st, ZE_POOL); log = 0; }
+            else { huf_build_any_ws(tab, w, nw, log, ws); blk[i].huf_tab = off; blk[i].huf_log = (u8)log; atomicMax(&st->max_huf_log, log); }
+        }
+        s_log = log; s_off = off;
+    }
+    __syncthreads();
+    if (!s_log) return;
+    const u32 bytes = huf_tab_bytes(s_log);
+    for (u32 k = threadIdx.x; k < bytes / 16; k += 64) ((uint4 *)(pool + s_off))[k] = ((const uint4 *)tab)[k];
 }
 
 __global__ void k_build_fse(const u8 *src, ZBlock *blk, u32 nblk, FseE *pool, u32 pool_cap, ZStat *st)
@@ -988,12 +1025,15 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     ZBlock *blk = nullptr; ZStat hs; bool indexed = false;
     const char *nospec = getenv("NAF_GPU_SERIAL_INDEX");
     // Frames of more than 4 MiB: 1 MiB chunks, candidates in the first 40 KiB / 128 KiB of each.  Smaller frames can still hold
-    // tens of thousands of tiny blocks (ids / names / lengths that compress 100:1 in 16 KiB blocks -- a serial walk of those
-    // costs milliseconds): 16 KiB chunks with every byte tested as a candidate.  The chunk size changes nothing but how much of
+    // thousands of tiny blocks (ids / names / lengths that compress 100:1 in 16 KiB blocks, a mask stream that is 1200 RLE blocks
+    // of 4 bytes -- a serial walk of those costs milliseconds): small chunks with every byte tested as a candidate.  The chunk size changes nothing but how much of
     // the speculation is reused: the resolve pass re-walks from the true start wherever a chunk's candidate was wrong or missing.
-    const u32 chunk = src_len > 4ull * SPEC_CHUNK ? SPEC_CHUNK : SPEC_CHUNK_SMALL;
-    const u32 win1 = chunk == SPEC_CHUNK ? SPEC_WINDOW1 : SPEC_CHUNK_SMALL, win2 = chunk == SPEC_CHUNK ? SPEC_WINDOW : SPEC_CHUNK_SMALL;
-    if (src_len > 4ull * SPEC_CHUNK_SMALL && !(nospec && nospec[0] == '1')) {
+    u32 chunk = SPEC_CHUNK, win1 = SPEC_WINDOW1, win2 = SPEC_WINDOW;
+    if (src_len <= 4ull * SPEC_CHUNK) {                          // about 128 chunks of 256 B .. 16 KiB, every byte a candidate
+        chunk = 256; while (chunk < SPEC_CHUNK_SMALL && (u64)chunk * 128 < src_len) chunk *= 2;
+        win1 = win2 = chunk;
+    }
+    if (src_len >= 2048 && !(nospec && nospec[0] == '1')) {
         u32 nchunks = (u32)((src_len + chunk - 1) / chunk);
         u64 *first = arena_new<u64>(c, nchunks + 1), *land = arena_new<u64>(c, nchunks + 2), *G = arena_new<u64>(c, nchunks + 1);
         u64 *start = arena_new<u64>(c, nchunks + 2), *cnt = arena_new<u64>(c, (size_t)nchunks + 2);
@@ -1027,7 +1067,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         for (int attempt = 0; attempt < 2; attempt++) {
             blk = arena_new<ZBlock>(c, cap);
             if (!blk) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "zstd_scan_blocks", k_scan_blocks, 1, 64, 0, d_src, (u64)src_len, (u64)fh.hdr_size, blk, cap, st);
+            const u32 win = src_len < SCAN_WIN ? (u32)((src_len + 15) & ~15ull) + 16 : SCAN_WIN;
+            LAUNCH(c, "zstd_scan_blocks", k_scan_blocks, 1, 64, win + 16, d_src, (u64)src_len, (u64)fh.hdr_size, blk, cap, st, win);
             rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
             if (hs.err) return zerr(c, hs.err, "block headers");
             if (hs.nblk <= cap) break;
@@ -1114,13 +1155,15 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         if (!done || !lit_scratch) return NAF_GPU_ENOMEM;
     }
     LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, done, (u32 *)nullptr, (u32 *)nullptr);
+    bool copy_fill_done = false;
     if (n_huf_def) {
         // tables of the blocks that will be decoded (and of the earlier blocks that own a table in force there)
         u32 hb_end = b_first + b_count, hb_n = hb_end - huf_first;
         u32 pool_cap = (hb_n < n_huf_def ? hb_n : n_huf_def) * (u32)HUFC_BYTES + 4096u;   // largest table form (log > 8: compact)
         huf_pool = (u8 *)arena_alloc(c, pool_cap);
         if (!huf_pool) return NAF_GPU_ENOMEM;
-        if (hb_n) LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(hb_n, 64), 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first);
+        if (hb_n && hb_n <= 512) LAUNCH(c, "zstd_build_huf", k_build_huf_lds, hb_n, 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first);
+        else if (hb_n) LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(hb_n, 64), 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first);
         rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
         if (hs.err) return zerr(c, hs.err, "Huffman tables");
         u32 slot = huf_tab_bytes(hs.max_huf_log);
@@ -1131,10 +1174,35 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         u32 ipitch_arg = ipitch | ((getenv("NAF_GPU_HUF_GENERIC") && getenv("NAF_GPU_HUF_GENERIC")[0] == '1') ? 0x8000u : 0u);
         if (b_count && fuse) LAUNCH(c, "zstd_huf_fused_emit", (k_huf_literals<true>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 512,
                d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len);
-        else if (b_count) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512 + (getenv("NAF_GPU_PADLDS") ? atoi(getenv("NAF_GPU_PADLDS")) : 0),
+        else if (b_count) {
+            const u32 huf_lds = slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512 + (getenv("NAF_GPU_PADLDS") ? atoi(getenv("NAF_GPU_PADLDS")) : 0);
+            ZSplit *sp = c->zsplit;
+            if (sp && !rg && n_seq_blk == 0 && b_first == 0 && b_count == nblk && b_count >= 4096u * (u32)sp->parts) {
+                // literal-only frame of a whole-text call: block ranges in order, an event behind each (see ZSplit); the raw / RLE
+                // blocks first, so that a finished part is complete
+                LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
+                copy_fill_done = true;
+                u32 lo_b = 0;
+                for (int k = 0; k < sp->parts; k++) {
+                    u32 hi_b = k + 1 == sp->parts ? b_count : (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
+                    if (k + 1 < sp->parts) { rc = ctx_readback(c, &sp->out_end[k], sizes + hi_b, 8); if (rc) return rc; }     // before the launches: a read-back waits for the stream
+                    else sp->out_end[k] = hs.total_out;
+                    lo_b = hi_b;
+                }
+                lo_b = 0;
+                for (int k = 0; k < sp->parts; k++) {
+                    u32 hi_b = k + 1 == sp->parts ? b_count : (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
+                    if (hi_b > lo_b) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds,
+                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len);
+                    HIP_TRY(c, hipEventRecord(sp->ev[k], c->stream));
+                    lo_b = hi_b;
+                }
+                sp->done = 1;
+            } else LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, huf_lds,
                d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len);
+        }
     }
-    if (b_count && !fuse) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
+    if (b_count && !fuse && !copy_fill_done) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
     if (n_seq_blk) {
         const char *el = getenv("NAF_GPU_EXEC_LDS");                      // "0": always the HBM executor (cross-check)
         if (max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
@@ -1144,7 +1212,17 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             LAUNCH(c, "zstd_exec_seq", k_exec_seq, n_seq_blk, 64, 0, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
                    (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st);
     }
+    if (c->zsplit && c->zsplit->done) { c->zsplit->status = st; return 0; }      // the caller checks the status once the emit is queued (zstd_split_status)
     rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+    if (hs.err) return zerr(c, hs.err, "block decode");
+    return 0;
+}
+
+// status of a split decode whose final read-back was left to the caller
+int zstd_split_status(naf_gpu_ctx *c, const ZSplit *sp)
+{
+    if (!sp || !sp->done || !sp->status) return 0;
+    ZStat hs; int rc = ctx_readback(c, &hs, sp->status, sizeof hs); if (rc) return rc;
     if (hs.err) return zerr(c, hs.err, "block decode");
     return 0;
 }

@@ -63,7 +63,7 @@ def _hand_frame(blocks):
     return bytes(out)
 
 
-@pytest.mark.parametrize("total", [300 << 10, 9 << 20])
+@pytest.mark.parametrize("total", [6 << 10, 60 << 10, 300 << 10, 9 << 20])
 def test_zstd_block_index_survives_lookalike_headers(gpu, total):
     """The parallel block index tests bytes as candidate block headers (16 KiB chunks with every byte tested for frames of up to
     4 MiB, 1 MiB chunks above).  Payloads full of bytes that READ as valid header chains -- runs of zeros (empty raw blocks), of
