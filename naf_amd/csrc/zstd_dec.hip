@@ -1177,19 +1177,22 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         else if (b_count) {
             const u32 huf_lds = slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512 + (getenv("NAF_GPU_PADLDS") ? atoi(getenv("NAF_GPU_PADLDS")) : 0);
             ZSplit *sp = c->zsplit;
-            if (sp && !rg && n_seq_blk == 0 && b_first == 0 && b_count == nblk && b_count >= 4096u * (u32)sp->parts) {
+            const char *smin = getenv("NAF_GPU_SPLIT_MIN");                      // blocks per part below which a split is not worth its launches (tests lower it)
+            const u32 split_min = smin ? (u32)atoi(smin) : 4096u;
+            if (sp && !rg && n_seq_blk == 0 && b_first == 0 && b_count == nblk && b_count >= split_min * (u32)sp->parts && b_count >= 16u * HUF_BLOCKS_PER_WG * (u32)sp->parts) {
                 // literal-only frame of a whole-text call: block ranges in order, an event behind each (see ZSplit); the raw / RLE
                 // blocks first, so that a finished part is complete
                 LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
                 copy_fill_done = true;
-                u32 lo_b = 0;
-                for (int k = 0; k < sp->parts; k++) {
-                    u32 hi_b = k + 1 == sp->parts ? b_count : (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
-                    if (k + 1 < sp->parts) { rc = ctx_readback(c, &sp->out_end[k], sizes + hi_b, 8); if (rc) return rc; }     // before the launches: a read-back waits for the stream
-                    else sp->out_end[k] = hs.total_out;
-                    lo_b = hi_b;
+                // output offsets of the range ends: gathered on the device, one read-back (before the launches: it waits for the stream)
+                u64 *ends = arena_new<u64>(c, ZSPLIT_MAX); if (!ends) return NAF_GPU_ENOMEM;
+                for (int k = 0; k + 1 < sp->parts; k++) {
+                    u32 hi_b = (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
+                    HIP_TRY(c, hipMemcpyAsync(ends + k, sizes + hi_b, 8, hipMemcpyDeviceToDevice, c->stream));
                 }
-                lo_b = 0;
+                rc = ctx_readback(c, sp->out_end, ends, 8 * (size_t)(sp->parts - 1)); if (rc) return rc;
+                sp->out_end[sp->parts - 1] = hs.total_out;
+                u32 lo_b = 0;
                 for (int k = 0; k < sp->parts; k++) {
                     u32 hi_b = k + 1 == sp->parts ? b_count : (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
                     if (hi_b > lo_b) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds,

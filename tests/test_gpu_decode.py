@@ -256,3 +256,27 @@ def test_unnaf_random_archives_against_oracle(gpu, oracle, emit, monkeypatch):
                     exp = oracle.unnaf(naf, mode, use_mask=use_mask, line_length=ll)
                     got = host(gpu.unnaf(d, mode, use_mask, ll))
                     assert got == exp, (i, mode, use_mask, ll)
+
+
+@pytest.mark.parametrize("parts", ["2", "3", "4", "8"])
+def test_unnaf_decode_emit_pipeline_matches_single_launch(gpu, parts, monkeypatch):
+    """Whole-text calls on literal-only sequence streams decode the literals in block ranges and emit finished ranges on a second
+    stream; by default only from 16 k blocks up.  With the threshold lowered a 170 MB text (2600 blocks) takes that path:
+    same bytes as the single-launch order, for FASTA (tile kernels, soft mask on) and for --seq."""
+    import torch
+    from naf_amd import capi, synth
+    text = synth.fasta_acgt_device(170_000_000, n_records=7, width=60, seed=31)
+    low = torch.rand(text.numel(), device=text.device) < 0.3                      # soft-mask a third of the letters
+    letters = (text >= 65) & (text <= 90)
+    hdr = torch.zeros_like(low); pos = (text == 62).nonzero().flatten().tolist(); eol = (text == 10).nonzero().flatten()
+    for p in pos:                                                                 # keep the header lines as they are
+        e = int(eol[torch.searchsorted(eol, p)].item()); hdr[p:e + 1] = True
+    text = torch.where(low & letters & ~hdr, text + 32, text)
+    d_naf, _ = gpu.ennaf(text)
+    monkeypatch.setenv("NAF_GPU_SPLIT", "1")
+    ref_fa = gpu.unnaf(d_naf, capi.OUT_FASTA).clone(); ref_seq = gpu.unnaf(d_naf, capi.OUT_SEQ).clone()
+    assert torch.equal(ref_fa, text)
+    monkeypatch.setenv("NAF_GPU_SPLIT", parts); monkeypatch.setenv("NAF_GPU_SPLIT_MIN", "32")
+    for _ in range(3):                                                            # the streams race differently every time
+        assert torch.equal(gpu.unnaf(d_naf, capi.OUT_FASTA), ref_fa)
+        assert torch.equal(gpu.unnaf(d_naf, capi.OUT_SEQ), ref_seq)
