@@ -432,7 +432,7 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
     if (el && !strcmp(el, "all")) use_lz = true;
     // LZ-coded streams: 16 KiB blocks.  The decoder decodes and executes the sequences of a block serially, so a stream's latency is
     // that of its longest block; matches in ids / names / lengths are a few dozen bytes back anyway.
-    if (use_lz && !e) block_log = 14;
+    if (use_lz && !e) { block_log = 14; const char *lb = getenv("NAF_GPU_LZ_BLOCK_LOG"); if (lb && atoi(lb) >= 10 && atoi(lb) <= 15) block_log = (u32)atoi(lb); }
     if (use_lz && block_log > 15) block_log = 15;                // LZ lengths and distances are kept in 16 bits
     u64 bs = 1ull << block_log;
     u64 nblk64 = n ? (n + bs - 1) / bs : 1;
