@@ -280,3 +280,24 @@ def test_unnaf_decode_emit_pipeline_matches_single_launch(gpu, parts, monkeypatc
     for _ in range(3):                                                            # the streams race differently every time
         assert torch.equal(gpu.unnaf(d_naf, capi.OUT_FASTA), ref_fa)
         assert torch.equal(gpu.unnaf(d_naf, capi.OUT_SEQ), ref_seq)
+
+
+def test_unnaf_decode_emit_pipeline_reports_corrupt_stream(gpu, oracle, monkeypatch):
+    """In the pipelined order the decoder's status is read after the emit has been queued: a damaged sequence stream must still end
+    in an error (never in text), and the context must stay usable."""
+    import torch
+    from naf_amd import capi, synth
+    from naf_amd.capi import NafGpuError
+    text = synth.fasta_acgt_device(170_000_000, n_records=3, width=80, seed=32)
+    d_naf, _ = gpu.ennaf(text)
+    h = oracle.parse_naf(host(d_naf[:4096]) + bytes(64))                         # header + section table live in the first bytes
+    monkeypatch.setenv("NAF_GPU_SPLIT", "4"); monkeypatch.setenv("NAF_GPU_SPLIT_MIN", "32")
+    assert torch.equal(gpu.unnaf(d_naf, capi.OUT_FASTA), text)
+    bad = d_naf.clone()
+    seq_off, seq_len = h.payload_off[4], h.comp[4]
+    for frac in (0.1, 0.5, 0.9):                                                  # a Huffman stream's final byte must not be zero: kill a few of them
+        p = seq_off + int(seq_len * frac)
+        bad[p:p + 40000] = 0
+    with pytest.raises(NafGpuError):
+        gpu.unnaf(bad, capi.OUT_FASTA)
+    assert torch.equal(gpu.unnaf(d_naf, capi.OUT_FASTA), text)
