@@ -86,8 +86,9 @@ int  naf_gpu_zstd_decompress(naf_gpu_ctx *ctx, const void *d_src, size_t src_len
                              void *d_dst, size_t dst_cap, size_t *out_len);
 
 /* Compress d_src into ONE zstd frame made of independently coded blocks (single frame: SURVEY.md R1).
- * level <= 1: entropy-only blocks (Huffman literals, RLE, raw); level >= 2 adds the LZ stage (matches inside a block, coded
- * with the predefined FSE sequence tables).  Blocks never depend on each other at any level. */
+ * level <= 1: entropy-only blocks (Huffman literals, RLE, raw), Huffman weights written directly wherever the format allows
+ * (up to 128 weights); level >= 2 adds the LZ stage (matches inside a block, coded with the predefined FSE sequence tables)
+ * and FSE-codes the Huffman weights when that is smaller.  Blocks never depend on each other at any level. */
 int  naf_gpu_zstd_compress(naf_gpu_ctx *ctx, const void *d_src, size_t src_len, int level,
                            void *d_dst, size_t dst_cap, size_t *out_len);
 size_t naf_gpu_zstd_compress_bound(size_t src_len);
