@@ -164,6 +164,18 @@ int ctx_readback(naf_gpu_ctx *c, void *h_dst, const void *d_src, size_t bytes)
     return 0;
 }
 
+// two small read-backs with one wait for the stream
+int ctx_readback2(naf_gpu_ctx *c, void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2)
+{
+    if (n1 + n2 + 16 > c->h_stage_cap) { int rc = ctx_readback(c, h1, d1, n1); return rc ? rc : ctx_readback(c, h2, d2, n2); }
+    u8 *st = (u8 *)c->h_stage; size_t o2 = (n1 + 15) & ~(size_t)15;
+    HIP_TRY(c, hipMemcpyAsync(st, d1, n1, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(st + o2, d2, n2, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(h1, st, n1); memcpy(h2, st + o2, n2);
+    return 0;
+}
+
 // ---- memory helpers for hosts that do not link HIP ----------------------------------------------------------
 extern "C" int naf_gpu_malloc(naf_gpu_ctx *c, size_t bytes, void **p) { if (!c || !p) return NAF_GPU_EARG; HIP_TRY(c, hipMalloc(p, bytes ? bytes : 1)); return 0; }
 extern "C" int naf_gpu_free(naf_gpu_ctx *c, void *p) { if (!c) return NAF_GPU_EARG; HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(p)); return 0; }

@@ -121,6 +121,7 @@ __device__ __forceinline__ u64 spec_land(const u8 *src, u64 len, u64 pos, u64 st
 // Candidates are searched in window bytes [w_lo, w_hi) of every chunk.  Two passes: the first 40 KiB (where the
 // first block start of a chunk lies whenever blocks compress to under 40 KiB -- this build's 32 KiB blocks, and
 // 128 KiB blocks at ratios above 3.2), then the rest of the 128 KiB window for the chunks still without a candidate.
+#define SPEC_WINDOW0 (20u * 1024u)
 #define SPEC_WINDOW1 (40u * 1024u)
 __global__ __launch_bounds__(256) void k_spec_find(const u8 *src, u64 len, u32 nchunks, u64 *first, u32 w_lo, u32 w_hi, u32 chunk)
 {
@@ -1042,7 +1043,11 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         u64 *h0 = (u64 *)c->h_stage; *h0 = fh.hdr_size;
         HIP_TRY(c, hipMemcpyAsync(first, h0, 8, hipMemcpyHostToDevice, c->stream));
         u32 gl = cdiv(nchunks, 64);
-        LAUNCH(c, "zstd_index_find", k_spec_find, cdiv(win1, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, 0u, win1, chunk);
+        // the first block start of a chunk lies in its first 20 KiB whenever blocks compress to less than that (this build's 32 KiB
+        // blocks of packed bases: 16 KiB); the passes behind it only run for the chunks still without a candidate
+        const u32 win0 = chunk == SPEC_CHUNK ? SPEC_WINDOW0 : win1;
+        LAUNCH(c, "zstd_index_find", k_spec_find, cdiv(win0, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, 0u, win0, chunk);
+        if (win1 > win0) LAUNCH(c, "zstd_index_find2", k_spec_find, cdiv(win1 - win0, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, win0, win1, chunk);
         if (win2 > win1) LAUNCH(c, "zstd_index_find2", k_spec_find, cdiv(win2 - win1, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, win1, win2, chunk);
         LAUNCH(c, "zstd_index_land", k_spec_land, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, nchunks, land, chunk);
         LAUNCH(c, "zstd_index_land2", k_spec_land2, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, (const u64 *)land, nchunks, G, chunk);
@@ -1051,8 +1056,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         u64 *d_tot = cnt + nchunks + 1;
         if ((rc = scan_exclusive_u64(c, cnt, nchunks, d_tot))) return rc;
         u64 tot = 0;
-        rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
-        rc = ctx_readback(c, &tot, d_tot, 8); if (rc) return rc;
+        rc = ctx_readback2(c, &hs, st, sizeof hs, &tot, d_tot, 8); if (rc) return rc;
         if (!hs.err && tot > 0 && tot < 0x7FFFFFFFull) {
             blk = arena_new<ZBlock>(c, tot);
             if (!blk) return NAF_GPU_ENOMEM;
