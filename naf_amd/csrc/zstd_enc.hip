@@ -93,7 +93,42 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
             ws.order[r] = (u16)sym;
         }
         __syncthreads();
-        if (threadIdx.x == 0) ws.log = huf_lengths_sorted(ws.tot, ws.order, distinct, ws.len, ws.w, ws.parent, ws.depth);
+        // Code lengths.  Up to 64 symbols (packed bases: 16, qualities: ~40): the two-queue construction of huf_lengths_sorted by
+        // the first wavefront with the node weights, parents and depths in registers (lane = node index, read and written with
+        // v_readlane / compare-and-select under uniform control flow) -- the same picks in the same order, without an LDS round
+        // trip per step.  More symbols, or a depth above the limit: the serial routine (its length limiting is rarely needed).
+        if (distinct <= 64) {
+            if (threadIdx.x < 64) {
+                const u32 lane = threadIdx.x, n = distinct;
+                u32 wl = lane < n ? ws.tot[ws.order[lane]] : 0xFFFFFFFFu;      // leaf weights, ascending
+                u32 wi = 0xFFFFFFFFu, pl = 0, pi = 0;                          // internal node weights / parents (index of an internal node)
+                u32 leaf = 0, inode = 0, next = 0;                              // uniform: heads of the two queues, internal nodes made so far
+                for (u32 step = 0; step + 1 < n; step++) {
+                    u32 sum = 0;
+#pragma unroll
+                    for (int pick = 0; pick < 2; pick++) {
+                        const u32 lw = leaf < n ? (u32)__builtin_amdgcn_readlane((int)wl, (int)__builtin_amdgcn_readfirstlane((int)(leaf < 64 ? leaf : 63))) : 0xFFFFFFFFu;
+                        const u32 iw = inode < next ? (u32)__builtin_amdgcn_readlane((int)wi, (int)__builtin_amdgcn_readfirstlane((int)inode)) : 0xFFFFFFFFu;
+                        if (leaf < n && (inode >= next || lw <= iw)) { sum += lw; if (lane == leaf) pl = next; leaf++; }
+                        else { sum += iw; if (lane == inode) pi = next; inode++; }
+                    }
+                    if (lane == next) wi = sum;
+                    next++;
+                }
+                // depths: the root is internal node n-2; walk the internal nodes down, then every leaf takes its parent's + 1
+                u32 di = 0;
+                for (u32 k = n - 2; k-- > 0;) {
+                    const u32 par = (u32)__builtin_amdgcn_readlane((int)pi, (int)__builtin_amdgcn_readfirstlane((int)k));
+                    const u32 dpar = (u32)__builtin_amdgcn_readlane((int)di, (int)__builtin_amdgcn_readfirstlane((int)par));
+                    if (lane == k) di = dpar + 1;
+                }
+                const u32 dl = (u32)__shfl((int)di, (int)(pl & 63), 64) + 1;
+                u32 mx = lane < n ? dl : 0;
+                for (int d = 32; d; d >>= 1) { u32 o = (u32)__shfl_xor((int)mx, d, 64); mx = o > mx ? o : mx; }
+                if (mx <= ZENC_HUF_MAXBITS) { if (lane < n) ws.len[ws.order[lane]] = (u8)dl; if (lane == 0) ws.log = mx; }
+                else if (lane == 0) ws.log = huf_lengths_sorted(ws.tot, ws.order, distinct, ws.len, ws.w, ws.parent, ws.depth);
+            }
+        } else if (threadIdx.x == 0) ws.log = huf_lengths_sorted(ws.tot, ws.order, distinct, ws.len, ws.w, ws.parent, ws.depth);
         __syncthreads();
         u32 log = ws.log;
         if (log) {
