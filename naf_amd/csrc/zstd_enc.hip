@@ -46,11 +46,22 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
     // copy c keeps symbol s in slot (s + 8c) & 255: the four copies of a symbol sit in four different LDS banks
     const u32 cpy = threadIdx.x & (ZENC_HCOPIES - 1), rot = 8 * cpy;
     u32 *my = hist + cpy * 1024;
+    const u64 rot8 = 0x0101010101010101ull * rot;                 // rot < 128: added to every byte at once, carries cut at the byte tops
     for (u32 i = threadIdx.x * 8; i < bn; i += 2048) {
         if (i + 8 <= bn) {
             u64 w = ld64(s + i);
+            const u32 q0 = (i >= per) + (i >= 2 * per) + (i >= 3 * per), q7 = (i + 7 >= per) + (i + 7 >= 2 * per) + (i + 7 >= 3 * per);
+            if (q0 == q7) {                                       // the word lies in one quarter (all but three words of a block)
+                const u64 H = 0x8080808080808080ull;
+                const u64 wr = ((w & ~H) + rot8) ^ (w & H);      // (byte + rot) & 0xFF for all eight bytes
+                u32 *hq = my + q0 * 256;
+                const u32 lo = (u32)wr, hi = (u32)(wr >> 32);
 #pragma unroll
-            for (u32 k = 0; k < 8; k++) { u32 pos = i + k, q = (pos >= per) + (pos >= 2 * per) + (pos >= 3 * per); atomicAdd(&my[q * 256 + (((u32)(w >> (8 * k)) + rot) & 0xFF)], 1u); }
+                for (u32 k = 0; k < 4; k++) { atomicAdd(&hq[(lo >> (8 * k)) & 0xFF], 1u); atomicAdd(&hq[(hi >> (8 * k)) & 0xFF], 1u); }
+            } else {
+#pragma unroll
+                for (u32 k = 0; k < 8; k++) { u32 pos = i + k, q = (pos >= per) + (pos >= 2 * per) + (pos >= 3 * per); atomicAdd(&my[q * 256 + (((u32)(w >> (8 * k)) + rot) & 0xFF)], 1u); }
+            }
         } else {
             for (u32 k = 0; i + k < bn; k++) { u32 pos = i + k, q = (pos >= per) + (pos >= 2 * per) + (pos >= 3 * per); atomicAdd(&my[q * 256 + ((s[pos] + rot) & 0xFF)], 1u); }
         }
