@@ -35,19 +35,25 @@ __device__ __forceinline__ u64 upper_bound_u64(const u64 *a, u64 lo, u64 hi, u64
 
 // 16 four-bit codes (nibble i = base i) -> 16 ASCII bytes in two u64, through the 16-entry table P.lut
 // (unnaf.c:13 "-TGKCYSBAWRDMHVN", 'U' for RNA) held in four SGPR dwords and v_perm_b32.
+// Eight codes at a time: the even and the odd nibbles of a 32-bit word are each four bytes already (x & 0x0F0F0F0F,
+// (x >> 4) & 0x0F0F0F0F); both go through the table and a last v_perm_b32 interleaves the two results.
+__device__ __forceinline__ u32 expand_codes4(const u32 lut[4], u32 v)      // four codes, one per byte -> four ASCII bytes
+{
+    const u32 sel = v & 0x07070707u;
+    const u32 l = __builtin_amdgcn_perm(lut[1], lut[0], sel);              // codes 0..7
+    const u32 h = __builtin_amdgcn_perm(lut[3], lut[2], sel);              // codes 8..15
+    const u32 m = __builtin_amdgcn_perm(0u, 0x0000FF00u, (v >> 3) & 0x01010101u);   // 0xFF in the bytes whose code is >= 8
+    return (l & ~m) | (h & m);
+}
 __device__ __forceinline__ void expand16(const u32 lut[4], u64 nib, u64 &lo, u64 &hi)
 {
     u32 out[4];
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
-        u32 t = (u32)(nib >> (16 * w)) & 0xFFFF;                // 4 nibbles n3n2n1n0
-        u32 y = (t | (t << 8)) & 0x00FF00FF;
-        u32 z = (y | (y << 4)) & 0x0F0F0F0F;                    // one nibble per byte
-        u32 sel = z & 0x07070707;
-        u32 l = __builtin_amdgcn_perm(lut[1], lut[0], sel);     // codes 0..7
-        u32 h = __builtin_amdgcn_perm(lut[3], lut[2], sel);     // codes 8..15
-        u32 b3 = (z >> 3) & 0x01010101, m = (b3 << 8) - b3;          // 0xFF in the bytes whose code is >= 8 (a multiply by 0xFF is quarter rate)
-        out[w] = (l & ~m) | (h & m);
+    for (int w = 0; w < 2; w++) {
+        const u32 x = (u32)(nib >> (32 * w));
+        const u32 E = expand_codes4(lut, x & 0x0F0F0F0Fu), O = expand_codes4(lut, (x >> 4) & 0x0F0F0F0Fu);   // bases 0,2,4,6 / 1,3,5,7 of the word
+        out[2 * w] = __builtin_amdgcn_perm(O, E, 0x05010400u);             // E0 O0 E1 O1
+        out[2 * w + 1] = __builtin_amdgcn_perm(O, E, 0x07030602u);         // E2 O2 E3 O3
     }
     lo = (u64)out[0] | ((u64)out[1] << 32); hi = (u64)out[2] | ((u64)out[3] << 32);
 }
