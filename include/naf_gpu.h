@@ -147,6 +147,92 @@ size_t naf_gpu_ennaf_bound(size_t text_len);
 int  naf_gpu_ennaf(naf_gpu_ctx *ctx, const void *d_text, size_t text_len, const naf_gpu_ennaf_opts *opts,
                    void *d_naf, size_t naf_cap, size_t *naf_len, naf_gpu_ennaf_report *report);
 
+/* ---- ennaf of ONE input on several GPUs (BASELINE configs[4]) ------------------------------------------------
+ * The text is cut into consecutive slices, one per GPU ("shard"); every shard runs the same kernels as naf_gpu_ennaf on its
+ * slice and the parts are joined into ONE archive with ONE zstd frame per stream, as reference unnaf requires.
+ * What the reference carries from chunk to chunk in its static state travels between shards in a small fixed-size record:
+ *   - the half-filled byte of the 4-bit packer   `parity` + pending nibble, ennaf/src/encoders.c:30-69, flushed ennaf.c:525-529
+ *   - the open soft-mask run                      `mask_on` / `mask_len`,    encoders.c:126-146, flushed ennaf.c:511
+ *   - the record a cut falls into                 add_length(),              process.c:424 (FASTA slices may start inside a record)
+ *   - n_sequences, seq_size_original, longest_line_length, the unexpected-character tallies (process.c:389-393,424-425)
+ * Protocol (the same calls whether the shards are threads of one process or ranks of torch.distributed / MPI):
+ *   0. naf_gpu_ennaf_sniff on the start of the text -> format and p0; slices start at p0.
+ *      Cuts: FASTA behind any EOL-class byte (naf_gpu_ennaf_find_cut); FASTQ at a line start whose ordinal is a multiple of 4
+ *      (naf_gpu_ennaf_count_lines of every nominal slice, prefix sum, naf_gpu_ennaf_find_cut with the lines to skip).
+ *   1. every shard: naf_gpu_ennaf_shard_begin(slice) -> naf_gpu_shard_info.            [all-gather the infos]
+ *   2. every shard: naf_gpu_ennaf_shard_finish(all infos) -> its parts of the six frames in a device buffer + their sizes.
+ *                                                                                      [gather the naf_gpu_shard_pieces]
+ *   3. anyone: naf_gpu_ennaf_stitch_plan -> where every part and the framing bytes go; move the bytes (naf_gpu_ennaf_stitch for
+ *      buffers one process can address, RCCL send/recv or per-GPU D2H + pwrite otherwise).
+ * An error of any shard (strict mode, malformed FASTQ) is reported by every shard's finish with the reference's message and
+ * the record numbered across shards. */
+enum { NAF_GPU_MAX_SHARDS = 64 };
+typedef struct {
+    uint32_t shard, n_shards;
+    int32_t  format, seq_type;
+    uint64_t text_len;
+    uint64_t n_sequences, n_bases, longest_line;
+    uint64_t lead_bases;                    /* FASTA: bases in front of the slice's first header (they end an earlier shard's record) */
+    uint64_t n_ids, n_comments, n_quality;  /* bytes of the slice's ids / comments / quality streams */
+    uint64_t mask_changes;                  /* case changes at base positions >= 1 of the slice, the first and the last of them */
+    uint64_t mask_first_change, mask_last_change;
+    uint8_t  first_base, last_base;         /* post-replacement; valid when n_bases > 0 */
+    uint8_t  store_mask, store_quality, pad_[4];
+    int32_t  err_kind; uint32_t err_char;   /* 0 = none; see naf_gpu_ennaf_shard_finish */
+    uint64_t err_record, err_a, err_b;
+    uint64_t unexpected[4][257];            /* id, comment, sequence, quality (process.c:75-96) */
+} naf_gpu_shard_info;
+
+typedef struct {
+    uint64_t off[6], len[6];                /* this shard's part of each stream's frame inside its piece buffer (ids, comments, lengths, mask, sequence, quality) */
+    uint64_t raw[6];                        /* uncompressed bytes behind each part (sequence: bases) */
+    uint64_t total;                         /* bytes used in the piece buffer */
+} naf_gpu_shard_pieces;
+
+typedef struct {
+    uint64_t dst_off, len, src_off;         /* archive offset; source offset inside the shard's piece buffer, or inside `lit` */
+    int32_t  shard, stream;                 /* shard < 0: framing bytes from `lit` */
+} naf_gpu_stitch_seg;
+
+/* process.c:547-583: format of the text and the offset of its first record.  *format = 0 for an empty / all-space text. */
+int  naf_gpu_ennaf_sniff(naf_gpu_ctx *ctx, const void *d_text, size_t text_len, int want_format, int *format, uint64_t *p0);
+/* FASTQ: line starts (non-EOL byte behind an EOL-class byte) inside a slice; prev_is_eol: the byte in front of the slice is
+ * EOL-class, or the slice starts at p0. */
+int  naf_gpu_ennaf_count_lines(naf_gpu_ctx *ctx, const void *d_slice, size_t len, int prev_is_eol, uint64_t *n_line_starts);
+/* Where a shard may begin inside a slice: FASTA -- the first byte behind an EOL-class byte; FASTQ -- line start number
+ * skip_lines (0-based) of the slice.  *offset = len when the slice holds no such place. */
+int  naf_gpu_ennaf_find_cut(naf_gpu_ctx *ctx, const void *d_slice, size_t len, int format, int prev_is_eol, uint64_t skip_lines,
+                            uint64_t *offset);
+/* Step 1.  format: NAF_FMT_FASTA or NAF_FMT_FASTQ (from the sniff).  The slice must stay in place until the finish. */
+int  naf_gpu_ennaf_shard_begin(naf_gpu_ctx *ctx, const void *d_slice, size_t len, const naf_gpu_ennaf_opts *opts, int format,
+                               uint32_t shard, uint32_t n_shards, naf_gpu_shard_info *info);
+size_t naf_gpu_ennaf_shard_bound(size_t slice_len);
+/* Step 2.  infos[n_shards] in shard order (this context's own among them).  NAF_GPU_EINPUT + last_error when any shard failed. */
+int  naf_gpu_ennaf_shard_finish(naf_gpu_ctx *ctx, const naf_gpu_ennaf_opts *opts, const naf_gpu_shard_info *infos,
+                                void *d_pieces, size_t cap, naf_gpu_shard_pieces *pieces);
+/* What the finish of shard `shard` applies on behalf of its neighbours, derived from the infos alone (host only, no device needed;
+ * exported so that hosts can log it and tests can check it against the reference's chunk-to-chunk state). */
+typedef struct {
+    uint64_t first_record;      /* records in the shards in front (numbers the reference's messages) */
+    uint64_t tail_extra;        /* bases of later shards that belong to this shard's last record */
+    uint64_t run_ext;           /* bases of later shards that continue this shard's last soft-mask run */
+    uint32_t skip_first;        /* 1: the shard's first base is the high nibble of an earlier shard's last packed byte */
+    uint32_t tail_hi;           /* 4-bit code completing the shard's last packed byte when its pack window is odd */
+    int32_t  prev_masked;       /* case in front of the shard's first base */
+    int32_t  skip_run0;         /* 1: the bases in front of the shard's first case change are emitted by an earlier shard's run */
+    uint8_t  first[6], last[6]; /* per stream: this part opens the frame (2-byte header) / closes it (last-block flag) */
+    uint8_t  pad_[4];
+} naf_gpu_shard_carry;
+int  naf_gpu_ennaf_shard_carry(const naf_gpu_shard_info *infos, uint32_t n_shards, uint32_t shard, naf_gpu_shard_carry *out);
+/* Step 3 (host only, no device needed).  segs: at least 7 + 6 * n_shards entries; lit: at least 256 + strlen(title) bytes.
+ * report (optional) receives the totals of the whole input. */
+int  naf_gpu_ennaf_stitch_plan(const naf_gpu_ennaf_opts *opts, const naf_gpu_shard_info *infos, const naf_gpu_shard_pieces *pieces,
+                               uint32_t n_shards, naf_gpu_stitch_seg *segs, size_t seg_cap, size_t *n_segs,
+                               uint8_t *lit, size_t lit_cap, size_t *lit_len, uint64_t *naf_len, naf_gpu_ennaf_report *report);
+/* Execute a plan when this process can address every piece buffer (one device, or peers with access enabled). */
+int  naf_gpu_ennaf_stitch(naf_gpu_ctx *ctx, const naf_gpu_stitch_seg *segs, size_t n_segs, const uint8_t *lit,
+                          const void *const *d_piece_bufs, void *d_naf, size_t naf_cap);
+
 /* ---- instrumentation ---------------------------------------------------------------------------------- */
 /* Per-kernel device time (hipEvent pairs on the ctx stream) of the last call, for bench.py's roofline
  * object.  names[i] points to static strings.  Returns the number of entries written (<= cap). */

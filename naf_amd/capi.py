@@ -23,7 +23,10 @@ EXPORTS = [
     "naf_gpu_zstd_compress", "naf_gpu_zstd_compress_bound", "naf_gpu_parse_header", "naf_gpu_parse_header_host",
     "naf_gpu_unnaf_size", "naf_gpu_unnaf", "naf_gpu_unnaf_range", "naf_gpu_ennaf_bound", "naf_gpu_ennaf",
     "naf_gpu_set_timing", "naf_gpu_get_timing",
+    "naf_gpu_ennaf_sniff", "naf_gpu_ennaf_count_lines", "naf_gpu_ennaf_find_cut", "naf_gpu_ennaf_shard_begin", "naf_gpu_ennaf_shard_bound",
+    "naf_gpu_ennaf_shard_finish", "naf_gpu_ennaf_shard_carry", "naf_gpu_ennaf_stitch_plan", "naf_gpu_ennaf_stitch",
 ]
+MAX_SHARDS = 64
 
 
 class UnnafOpts(C.Structure):
@@ -46,6 +49,30 @@ class EnnafReport(C.Structure):
                 ("unexpected_id", C.c_uint64 * 257), ("unexpected_comment", C.c_uint64 * 257),
                 ("unexpected_seq", C.c_uint64 * 257), ("unexpected_qual", C.c_uint64 * 257),
                 ("section_orig", C.c_uint64 * 6), ("section_comp", C.c_uint64 * 6)]
+
+
+class ShardInfo(C.Structure):
+    """naf_gpu_shard_info: what one shard of a multi-GPU ennaf tells the others (exchanged verbatim as bytes)."""
+    _fields_ = [("shard", C.c_uint32), ("n_shards", C.c_uint32), ("format", C.c_int32), ("seq_type", C.c_int32), ("text_len", C.c_uint64),
+                ("n_sequences", C.c_uint64), ("n_bases", C.c_uint64), ("longest_line", C.c_uint64), ("lead_bases", C.c_uint64),
+                ("n_ids", C.c_uint64), ("n_comments", C.c_uint64), ("n_quality", C.c_uint64),
+                ("mask_changes", C.c_uint64), ("mask_first_change", C.c_uint64), ("mask_last_change", C.c_uint64),
+                ("first_base", C.c_uint8), ("last_base", C.c_uint8), ("store_mask", C.c_uint8), ("store_quality", C.c_uint8), ("pad_", C.c_uint8 * 4),
+                ("err_kind", C.c_int32), ("err_char", C.c_uint32), ("err_record", C.c_uint64), ("err_a", C.c_uint64), ("err_b", C.c_uint64),
+                ("unexpected", (C.c_uint64 * 257) * 4)]
+
+
+class ShardPieces(C.Structure):
+    _fields_ = [("off", C.c_uint64 * 6), ("len", C.c_uint64 * 6), ("raw", C.c_uint64 * 6), ("total", C.c_uint64)]
+
+
+class ShardCarry(C.Structure):
+    _fields_ = [("first_record", C.c_uint64), ("tail_extra", C.c_uint64), ("run_ext", C.c_uint64), ("skip_first", C.c_uint32), ("tail_hi", C.c_uint32),
+                ("prev_masked", C.c_int32), ("skip_run0", C.c_int32), ("first", C.c_uint8 * 6), ("last", C.c_uint8 * 6), ("pad_", C.c_uint8 * 4)]
+
+
+class StitchSeg(C.Structure):
+    _fields_ = [("dst_off", C.c_uint64), ("len", C.c_uint64), ("src_off", C.c_uint64), ("shard", C.c_int32), ("stream", C.c_int32)]
 
 
 class NafGpuError(RuntimeError):
@@ -95,8 +122,48 @@ def load():
             L.naf_gpu_ennaf.argtypes = [vp, vp, sz, C.POINTER(EnnafOpts), vp, sz, C.POINTER(sz), C.POINTER(EnnafReport)]
             L.naf_gpu_ennaf_bound.argtypes = [sz]
             L.naf_gpu_ennaf_bound.restype = sz
+        u64p = C.POINTER(C.c_uint64)
+        L.naf_gpu_ennaf_sniff.argtypes = [vp, vp, sz, i, C.POINTER(i), u64p]
+        L.naf_gpu_ennaf_count_lines.argtypes = [vp, vp, sz, i, u64p]
+        L.naf_gpu_ennaf_find_cut.argtypes = [vp, vp, sz, i, i, C.c_uint64, u64p]
+        L.naf_gpu_ennaf_shard_begin.argtypes = [vp, vp, sz, C.POINTER(EnnafOpts), i, C.c_uint32, C.c_uint32, C.POINTER(ShardInfo)]
+        L.naf_gpu_ennaf_shard_bound.argtypes = [sz]
+        L.naf_gpu_ennaf_shard_bound.restype = sz
+        L.naf_gpu_ennaf_shard_finish.argtypes = [vp, C.POINTER(EnnafOpts), C.POINTER(ShardInfo), vp, sz, C.POINTER(ShardPieces)]
+        L.naf_gpu_ennaf_shard_carry.argtypes = [C.POINTER(ShardInfo), C.c_uint32, C.c_uint32, C.POINTER(ShardCarry)]
+        L.naf_gpu_ennaf_stitch_plan.argtypes = [C.POINTER(EnnafOpts), C.POINTER(ShardInfo), C.POINTER(ShardPieces), C.c_uint32, C.POINTER(StitchSeg), sz,
+                                                C.POINTER(sz), C.c_char_p, sz, C.POINTER(sz), u64p, C.POINTER(EnnafReport)]
+        L.naf_gpu_ennaf_stitch.argtypes = [vp, C.POINTER(StitchSeg), sz, C.c_char_p, C.POINTER(vp), vp, sz]
         _lib = L
     return _lib
+
+
+def shard_carry(infos, k):
+    """Host-only: what shard k's finish applies on behalf of its neighbours (naf_gpu_ennaf_shard_carry)."""
+    L = load()
+    arr = (ShardInfo * len(infos))(*infos)
+    out = ShardCarry()
+    rc = L.naf_gpu_ennaf_shard_carry(arr, len(infos), k, C.byref(out))
+    if rc:
+        raise NafGpuError(rc, L.naf_gpu_strerror(rc).decode())
+    return out
+
+
+def stitch_plan(opts, infos, pieces):
+    """Host-only: (segments, literal bytes, archive length, report) of the joined archive (naf_gpu_ennaf_stitch_plan)."""
+    L = load()
+    n = len(infos)
+    ia = (ShardInfo * n)(*infos)
+    pa = (ShardPieces * n)(*pieces)
+    segs = (StitchSeg * (7 + 6 * n))()
+    title = opts.title or b""
+    lit = C.create_string_buffer(256 + len(title))
+    ns, ll, nl = C.c_size_t(), C.c_size_t(), C.c_uint64()
+    rep = EnnafReport()
+    rc = L.naf_gpu_ennaf_stitch_plan(C.byref(opts), ia, pa, n, segs, len(segs), C.byref(ns), lit, len(lit), C.byref(ll), C.byref(nl), C.byref(rep))
+    if rc:
+        raise NafGpuError(rc, L.naf_gpu_strerror(rc).decode())
+    return [segs[k] for k in range(ns.value)], lit.raw[:ll.value], nl.value, rep
 
 
 def _ptr(t):
@@ -197,9 +264,9 @@ class Context:
         return list(cnt)
 
     # ---- ennaf ----
-    def ennaf(self, d_text, seq_type=SEQ_DNA, fmt=FMT_AUTO, no_mask=False, level=1, line_length=-1, title=None, out=None):
+    def ennaf(self, d_text, seq_type=SEQ_DNA, fmt=FMT_AUTO, no_mask=False, level=1, line_length=-1, title=None, out=None, strict=False):
         import torch
-        o = EnnafOpts(fmt, seq_type, int(no_mask), 0, level, line_length, title)
+        o = EnnafOpts(fmt, seq_type, int(no_mask), int(strict), level, line_length, title)
         if out is None:
             cap = self.L.naf_gpu_ennaf_bound(d_text.numel())
             out = torch.empty(cap, dtype=torch.uint8, device=self.device)
@@ -207,6 +274,41 @@ class Context:
         rep = EnnafReport()
         self._check(self.L.naf_gpu_ennaf(self.h, _ptr(d_text), d_text.numel(), C.byref(o), _ptr(out), out.numel(), C.byref(n), C.byref(rep)))
         return out[:n.value], rep
+
+    # ---- ennaf of one input on several GPUs: the per-shard calls (orchestration in naf_amd/shard.py) ----
+    def ennaf_sniff(self, d_text, fmt=FMT_AUTO):
+        f, p0 = C.c_int(), C.c_uint64()
+        self._check(self.L.naf_gpu_ennaf_sniff(self.h, _ptr(d_text), d_text.numel(), fmt, C.byref(f), C.byref(p0)))
+        return f.value, p0.value
+
+    def ennaf_count_lines(self, d_slice, prev_is_eol):
+        n = C.c_uint64()
+        self._check(self.L.naf_gpu_ennaf_count_lines(self.h, _ptr(d_slice), d_slice.numel(), int(prev_is_eol), C.byref(n)))
+        return n.value
+
+    def ennaf_find_cut(self, d_slice, fmt, prev_is_eol, skip_lines=0):
+        off = C.c_uint64()
+        self._check(self.L.naf_gpu_ennaf_find_cut(self.h, _ptr(d_slice), d_slice.numel(), fmt, int(prev_is_eol), skip_lines, C.byref(off)))
+        return off.value
+
+    def ennaf_shard_begin(self, d_slice, opts, fmt, shard, n_shards):
+        info = ShardInfo()
+        self._check(self.L.naf_gpu_ennaf_shard_begin(self.h, _ptr(d_slice), d_slice.numel(), C.byref(opts), fmt, shard, n_shards, C.byref(info)))
+        return info
+
+    def ennaf_shard_finish(self, opts, infos, text_len):
+        import torch
+        cap = self.L.naf_gpu_ennaf_shard_bound(text_len)
+        buf = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        arr = (ShardInfo * len(infos))(*infos)
+        pc = ShardPieces()
+        self._check(self.L.naf_gpu_ennaf_shard_finish(self.h, C.byref(opts), arr, _ptr(buf), cap, C.byref(pc)))
+        return buf, pc
+
+    def ennaf_stitch(self, segs, lit, bufs, out):
+        sa = (StitchSeg * len(segs))(*segs)
+        pa = (C.c_void_p * len(bufs))(*[b.data_ptr() for b in bufs])
+        self._check(self.L.naf_gpu_ennaf_stitch(self.h, sa, len(segs), lit, pa, _ptr(out), out.numel()))
 
     # ---- timing ----
     def set_timing(self, on):

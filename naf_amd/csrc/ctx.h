@@ -43,6 +43,7 @@ struct naf_gpu_ctx {
     hipEvent_t fork_ev = nullptr;
     struct ZSplit *zsplit = nullptr;        // set by unnaf for the sequence stream of a whole-text call: Huffman literals in parts (below)
     hipEvent_t split_ev[ZSPLIT_MAX + 2] = {};
+    void *shard_state = nullptr;            // enc.hip: what naf_gpu_ennaf_shard_begin leaves for naf_gpu_ennaf_shard_finish
 };
 
 int  ctx_fail(naf_gpu_ctx *c, int code, const char *fmt, ...);
@@ -79,6 +80,7 @@ int scan_inclusive_max_i64(naf_gpu_ctx *c, i64 *d_vals, size_t n);
 // Decode frames at d_src (device).  If only_size, stops after sizes are known.
 int zstd_decode(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len);
 int zstd_init_tables(naf_gpu_ctx *c);
+void ennaf_shard_state_free(naf_gpu_ctx *c);    // enc.hip
 // Range decode: only the blocks whose output intersects [want_lo, want_hi) are decoded; d_dst[0] then holds
 // regenerated byte got_lo.  ranged=false means the whole stream was decoded (d_dst[0] = byte 0).
 struct EmitP;
@@ -90,4 +92,5 @@ int zstd_decode_range(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_m
 int zstd_split_status(naf_gpu_ctx *c, const ZSplit *sp);
 // One frame of independently coded blocks; with_magic=0 omits the 4 magic bytes (as stored in a .naf section).
 // level >= 2 (or lz != 0) adds the LZ stage (matches inside a block).
+enum { ZENC_PART = 16, ZENC_PART_FIRST = 32, ZENC_PART_LAST = 64 };     // with_magic flags: a shard's part of a frame (zstd_enc.hip)
 int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz = 0, int block_log_hint = 0);

@@ -760,7 +760,7 @@ __global__ void k_range_bases(EmitP P, u64 *out2)
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
-static int zero_positions(naf_gpu_ctx *c, const u8 *d_buf, u64 n, u64 N, u64 **out)
+static int zero_positions(naf_gpu_ctx *c, const u8 *d_buf, u64 n, u64 N, u64 **out, bool names)
 {
     u64 *pos = arena_new<u64>(c, N + 1);
     if (!pos) return NAF_GPU_ENOMEM;
@@ -772,10 +772,28 @@ static int zero_positions(naf_gpu_ctx *c, const u8 *d_buf, u64 n, u64 N, u64 **o
     int rc = scan_exclusive_u64(c, cnt, tiles, d_total); if (rc) return rc;
     u64 total = 0;
     rc = ctx_readback(c, &total, d_total, 8); if (rc) return rc;
-    if (total < N) return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted ids - can't read id %llu\n", (unsigned long long)total);   // input.c:167,195
+    if (total < N) return ctx_fail(c, NAF_GPU_EFORMAT, names ? "corrupted names - can't read name %llu\n" : "currupted ids - can't read id %llu\n", (unsigned long long)total);   // input.c:167,195 ("currupted" is the reference's spelling)
     if (tiles) LAUNCH(c, "unnaf_zero_scatter", k_zero_scatter, tiles, 256, 0, d_buf, n, (const u64 *)cnt, pos, N);
     *out = pos;
     return 0;
+}
+
+// Size fields a well-formed archive cannot hold.  A zstd block regenerates at most 128 KiB from no less than 3 bytes, so a
+// section of c compressed bytes decodes to fewer than (c + 4) * 2^16 bytes (twice that many bases for the 4-bit sequence
+// stream); every record costs at least one byte of archive in the streams that describe it.  Fields beyond these bounds are a
+// corrupted header, reported the way the reference reports a section it cannot decode (input.c:156,184,213,231) -- before any
+// buffer is sized from them.
+static const char *header_sanity(const naf_gpu_header *h, size_t len)
+{
+    static const char *what[6] = { "can't decompress ids\n", "can't decompress names\n", "can't decompress lengths\n", "can't decompress mask\n",
+                                   "can't decompress sequence\n", "can't decompress quality\n" };
+    for (int i = 0; i < 6; i++) {
+        const u64 cs = h->comp_size[i] + 4;                                   // comp_size <= len < 2^63 here
+        const u64 lim = cs > (1ull << 46) ? ~0ull : cs << (i == 4 ? 17 : 16);
+        if (h->orig_size[i] > lim) return what[i];
+    }
+    if (h->n_sequences > ((u64)len << 16)) return "corrupted header: more sequences than the archive can describe\n";
+    return nullptr;
 }
 
 extern "C" int naf_gpu_parse_header_host(const void *h_naf, size_t len, naf_gpu_header *h, char errbuf[128])
@@ -813,14 +831,17 @@ extern "C" int naf_gpu_parse_header_host(const void *h_naf, size_t len, naf_gpu_
         if (e_ == 2) HF("invalid input: error parsing variable length encoded number\n"); \
         if (e_ == 3) HF("invalid input: overflow reading a variable length encoded number\n"); } while (0)
     RD(h->line_length); RD(h->n_sequences);
-    if (h->flags & 0x40) { RD(h->title_len); h->title_off = pos; if (pos + h->title_len > len) HF("incomplete or truncated input\n"); pos += h->title_len; }
+    // sizes are compared in subtraction form: a field near 2^64 must not wrap the sum
+    if (h->flags & 0x40) { RD(h->title_len); h->title_off = pos; if (h->title_len > len - pos) HF("incomplete or truncated input\n"); pos += h->title_len; }
     static const int bit[6] = { 0x20, 0x10, 0x08, 0x04, 0x02, 0x01 };
     for (int i = 0; i < 6; i++) {
         if (!(h->flags & bit[i])) continue;
         RD(h->orig_size[i]); RD(h->comp_size[i]);
-        if (pos + h->comp_size[i] > len) HF("incomplete or truncated input\n");
+        if (h->comp_size[i] > len - pos) HF("incomplete or truncated input\n");
         h->payload_off[i] = pos; pos += h->comp_size[i];
     }
+    const char *bad = header_sanity(h, len);
+    if (bad) HF(bad);
     return 0;
 }
 
@@ -868,14 +889,16 @@ extern "C" int naf_gpu_parse_header(naf_gpu_ctx *c, const void *d_naf, size_t le
         if (e_ == 2) DF("invalid input: error parsing variable length encoded number\n"); \
         if (e_ == 3) DF("invalid input: overflow reading a variable length encoded number\n"); } while (0)
     RDD(h->line_length); RDD(h->n_sequences);
-    if (h->flags & 0x40) { RDD(h->title_len); h->title_off = pos; if (pos + h->title_len > len) DF("incomplete or truncated input\n"); pos += h->title_len; }
+    if (h->flags & 0x40) { RDD(h->title_len); h->title_off = pos; if (h->title_len > len - pos) DF("incomplete or truncated input\n"); pos += h->title_len; }
     static const int bit[6] = { 0x20, 0x10, 0x08, 0x04, 0x02, 0x01 };
     for (int i = 0; i < 6; i++) {
         if (!(h->flags & bit[i])) continue;
         RDD(h->orig_size[i]); RDD(h->comp_size[i]);
-        if (pos + h->comp_size[i] > len) DF("incomplete or truncated input\n");
+        if (h->comp_size[i] > len - pos) DF("incomplete or truncated input\n");
         h->payload_off[i] = pos; pos += h->comp_size[i];
     }
+    const char *bad = header_sanity(h, len);
+    if (bad) DF(bad);
     return 0;
 }
 
@@ -912,6 +935,10 @@ static int unnaf_prepare(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const 
     pl.seq_bytes = pl.fourbit ? (T + 1) / 2 : T;
     if (N == 0 || !has_data) { pl.empty = true; return 0; }                         // unnaf.c:409, output.c:610
     if (mode == NAF_OUT_FASTQ && !has_qual) return ctx_fail(c, NAF_GPU_EFORMAT, "FASTQ output requested, but input has no qualities\n");
+    // every base needs its quality byte: a shorter quality stream would be read past its end by the emit kernels (the reference
+    // has no message for this -- print_quality_from_file, output-fastq.c:69-85, never returns on such an archive)
+    if (mode == NAF_OUT_FASTQ && h.orig_size[S_QUAL] < T)
+        return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted quality: %llu quality codes stored for %llu bases\n", (unsigned long long)h.orig_size[S_QUAL], (unsigned long long)T);
     if (mode == NAF_OUT_4BIT) {
         if (!pl.fourbit) return ctx_fail(c, NAF_GPU_EFORMAT, "input has no 4-bit encoded data, but %s sequences\n", h.seq_type == NAF_SEQ_PROTEIN ? "protein" : "text");
         P.mode = -1; pl.total = pl.seq_bytes; return 0;
@@ -954,14 +981,14 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
                 u8 *b = nullptr; u64 *z = nullptr;
                 if (h.orig_size[S_IDS] == 0) return ctx_fail(x, NAF_GPU_EFORMAT, "corrupted ids - not 0-terminated\n");
                 if ((r = load_section(x, d_naf, h, S_IDS, h.orig_size[S_IDS], "ids", &b))) return r;
-                if ((r = zero_positions(x, b, h.orig_size[S_IDS], N, &z))) return r;
+                if ((r = zero_positions(x, b, h.orig_size[S_IDS], N, &z, false))) return r;
                 P.ids = b; P.idz = z;
             }
             if (want_names && has_names) {
                 u8 *b = nullptr; u64 *z = nullptr;
                 if (h.orig_size[S_NAMES] == 0) return ctx_fail(x, NAF_GPU_EFORMAT, "corrupted names - not 0-terminated\n");
                 if ((r = load_section(x, d_naf, h, S_NAMES, h.orig_size[S_NAMES], "names", &b))) return r;
-                if ((r = zero_positions(x, b, h.orig_size[S_NAMES], N, &z))) return r;
+                if ((r = zero_positions(x, b, h.orig_size[S_NAMES], N, &z, true))) return r;
                 P.names = b; P.nmz = z;
             }
             return 0;

@@ -193,18 +193,18 @@ __device__ __forceinline__ void classify_range(const EncP &P, u64 pos, const Pie
                 if ((i64)i == line_start) { S.header_start(i); }
                 else if (ls < line_start) {                    // still inside the ID (process.c:363-368)
                     if (cl & CL_SPACE) { S.emit(EV_IDS, 0); if (cl & CL_EOL) { S.emit(EV_CMT, 0); S.header_end(i); } }
-                    else if ((cl & CL_UNEXP_TEXT) || (P.id_gt_unexpected && c == '>')) { S.unexpected(0, c); S.emit(EV_SEQ, '?'); }
+                    else if ((cl & CL_UNEXP_TEXT) || (P.id_gt_unexpected && c == '>')) { S.unexpected(0, c, i); S.emit(EV_SEQ, '?'); }
                     else S.emit(EV_IDS, c);
                 } else {                                       // comment (process.c:370-377)
                     if (cl & CL_EOL) { S.emit(EV_CMT, 0); S.header_end(i); }
-                    else if (cl & CL_UNEXP_COMMENT) { S.unexpected(1, c); S.emit(EV_CMT, '?'); }
+                    else if (cl & CL_UNEXP_COMMENT) { S.unexpected(1, c, i); S.emit(EV_CMT, '?'); }
                     else S.emit(EV_CMT, c);
                 }
             } else {                                           // sequence line (process.c:387-412)
                 if (cl & CL_EOL) S.line_end(i);
                 else if (cl & CL_SPACE) {}
                 else if (cl & CL_EXPECTED) S.emit(EV_SEQ, c);
-                else { S.unexpected(2, c); S.emit(EV_SEQ, P.replacement); }
+                else { S.unexpected(2, c, i); S.emit(EV_SEQ, P.replacement); }
             }
         }
         if (eof) break;
@@ -311,7 +311,7 @@ struct CountSink {
     __device__ void header_start(u64) { nrec++; }
     __device__ void header_end(u64) { tail = 0; saw_eol = true; }
     __device__ void line_end(u64) { tail = 0; saw_eol = true; }
-    __device__ void unexpected(int, u32) {}
+    __device__ void unexpected(int, u32, u64) {}
     __device__ void ids_range(const Piece &, u32 a, u32 b) { nids += b - a; }
     __device__ void cmt_range(const Piece &, u32 a, u32 b) { ncmt += b - a; }
     __device__ void seq_range(const Piece &, u32 a, u32 b, u32 sp) { u32 c = (u32)__popc(range_mask(a, b) & ~sp); nseq += c; tail += c; }
@@ -365,12 +365,32 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
     if (threadIdx.x + 1 == last) t_tail[blockIdx.x] = ((tota & 0xFFFF) - ((pre + wa) & 0xFFFF) + S.tail) | 0x80000000u;
 }
 
+// --strict (process.c:98-140): the reference dies at the FIRST unexpected byte of the input.  Every unexpected byte reports
+// (position, stream kind, byte) as one 64-bit key and the smallest key wins; the record number of the message is then counted
+// from the text in front of that position (k_count_starts), on the error path only.
+__device__ __forceinline__ unsigned long long strict_key(u64 pos, int kind, u32 ch) { return ((unsigned long long)pos << 11) | ((unsigned long long)kind << 9) | (ch & 0x1FFu); }
+// FASTA (fastq == 0): headers that start at or before `pos` ('>' first on its line); FASTQ: line starts at or before `pos`.
+__global__ __launch_bounds__(256) void k_count_starts(const u8 *text, u64 p0, u64 pos, int fastq, unsigned long long *out)
+{
+    __shared__ u64 lds[4];
+    u64 n = 0;
+    for (u64 q = p0 + (u64)blockIdx.x * 256 + threadIdx.x; q <= pos; q += (u64)gridDim.x * 256) {
+        const u32 c = text[q];
+        const bool first = q == p0 || c_eol(text[q - 1]);
+        if (first && (fastq ? !c_eol(c) : c == '>')) n++;
+    }
+    n = wg_reduce1<u64, OpAdd>(n, lds);
+    if (threadIdx.x == 0 && n) atomicAdd(out, (unsigned long long)n);
+}
+
 // ---- K3: scatter --------------------------------------------------------------------------------------------------------
 struct EncOut {
     u8 *seq, *ids, *cmt;          // seq = one byte per base (post-replacement), ids/comments final streams
     u64 *rec_begin, *rec_end;     // base index where record r's bases start / end
     u64 *unexpected;              // [3][257]
     u64 *longest;                 // max line length
+    u64 *lead;                    // bases in front of the first header (a shard that starts inside a record; 0 for a whole input)
+    u64 *strict_first;            // --strict: min over strict_key of the unexpected bytes (nullptr otherwise)
     const u64 *t_seq, *t_ids, *t_cmt, *t_rec; const u32 *t_tail; const i64 *tile_eol;
 };
 
@@ -430,10 +450,10 @@ struct WriteSink {
     const EncOut &O; u64 bseq, bids, bcmt, rec; u64 line_b; u64 best; bool line_valid; u8 *stage; u64 tbase;
     __device__ WriteSink(const EncOut &o) : O(o) {}
     __device__ void emit(int s, u32 ch) { if (s == EV_SEQ) stage[bseq++ - tbase] = (u8)ch; else if (s == EV_IDS) O.ids[bids++] = (u8)ch; else O.cmt[bcmt++] = (u8)ch; }
-    __device__ void header_start(u64) { if (rec > 0) O.rec_end[rec - 1] = bseq; rec++; }
+    __device__ void header_start(u64) { if (rec > 0) O.rec_end[rec - 1] = bseq; else *O.lead = bseq; rec++; }
     __device__ void header_end(u64) { O.rec_begin[rec - 1] = bseq; line_b = bseq; }
     __device__ void line_end(u64) { u64 len = bseq - line_b; if (len > best) best = len; line_b = bseq; }
-    __device__ void unexpected(int kind, u32 ch) { atomicAdd((unsigned long long *)&O.unexpected[kind * 257 + ch], 1ull); }
+    __device__ void unexpected(int kind, u32 ch, u64 pos) { atomicAdd((unsigned long long *)&O.unexpected[kind * 257 + ch], 1ull); if (O.strict_first) atomicMin((unsigned long long *)O.strict_first, strict_key(pos, kind, ch)); }
     __device__ void ids_range(const Piece &pc, u32 a, u32 b) { u64 lo, hi; piece_from(pc, a, lo, hi); global_store_n(O.ids + bids, lo, hi, b - a); bids += b - a; }
     __device__ void cmt_range(const Piece &pc, u32 a, u32 b) { u64 lo, hi; piece_from(pc, a, lo, hi); global_store_n(O.cmt + bcmt, lo, hi, b - a); bcmt += b - a; }
     __device__ void seq_range(const Piece &pc, u32 a, u32 b, u32 sp) { u64 lo, hi; u32 n = piece_run_compact(pc, a, b, sp, lo, hi); lds_store_n(stage + (bseq - tbase), lo, hi, n); bseq += n; }
@@ -525,6 +545,7 @@ struct FqOut {
     u64 *rec_begin, *rec_end, *q_begin, *q_end;
     u64 *unexpected;              // [4][257]: id, comment, sequence, quality
     u64 *first_error;             // min over (record * 4 + kind)
+    u64 *strict_first;            // --strict: min over strict_key of the unexpected bytes (nullptr otherwise)
     const u64 *t_seq, *t_ids, *t_cmt, *t_qual, *t_ls;
     const u32 *piece_cnt;         // per 16-byte piece: the four stream counts found by k_encq_count, 8 bits each
 };
@@ -549,23 +570,23 @@ __device__ __forceinline__ void classify_range_fastq(const EncP &P, u64 pos, con
                     if (first) { if (c != '@') S.error(rec, FQ_E_AT); S.header_start(rec); }
                     else if (ls < line_start) {
                         if (cl & CL_SPACE) S.emit(EV_IDS, 0);
-                        else if (cl & CL_UNEXP_TEXT) { S.unexpected(0, c); S.emit(EV_SEQ, '?'); }
+                        else if (cl & CL_UNEXP_TEXT) { S.unexpected(0, c, i); S.emit(EV_SEQ, '?'); }
                         else S.emit(EV_IDS, c);
                     } else {
-                        if (cl & CL_UNEXP_COMMENT) { S.unexpected(1, c); S.emit(EV_CMT, '?'); }
+                        if (cl & CL_UNEXP_COMMENT) { S.unexpected(1, c, i); S.emit(EV_CMT, '?'); }
                         else S.emit(EV_CMT, c);
                     }
                 } else if (type == 1) {
                     if (cl & CL_SPACE) {}
                     else if (cl & CL_EXPECTED) S.emit(EV_SEQ, c);
-                    else { S.unexpected(2, c); S.emit(EV_SEQ, P.replacement); }
+                    else { S.unexpected(2, c, i); S.emit(EV_SEQ, P.replacement); }
                 } else if (type == 2) {
                     if (first && c != '+') S.error(rec, FQ_E_PLUS);
                 } else {
                     if (first) { S.qual_begin(rec); S.emit(EV_QUAL, c); }   // process.c:522: appended unconditionally
                     else if (c >= 0x21 && c <= 0x7E) S.emit(EV_QUAL, c);
                     else if (cl & CL_SPACE) {}
-                    else { S.unexpected(3, c); S.emit(EV_QUAL, '!'); }
+                    else { S.unexpected(3, c, i); S.emit(EV_QUAL, '!'); }
                 }
             } else if (!prev_eol) {                                    // this EOL closes a line
                 i64 line_start = le + 1; if ((u64)line_start < P.p0) line_start = (i64)P.p0;
@@ -588,7 +609,7 @@ struct FqCount {
     __device__ void emit(int s, u32) { if (s == EV_SEQ) nseq++; else if (s == EV_IDS) nids++; else if (s == EV_CMT) ncmt++; else nqual++; }
     __device__ void header_start(u64) {} __device__ void header_end(u64) {} __device__ void seq_end(u64) {}
     __device__ void qual_begin(u64) {} __device__ void qual_end(u64) {}
-    __device__ void unexpected(int, u32) {} __device__ void error(u64, int) {}
+    __device__ void unexpected(int, u32, u64) {} __device__ void error(u64, int) {}
     __device__ void ids_range(const Piece &, u32 a, u32 b) { nids += b - a; }
     __device__ void cmt_range(const Piece &, u32 a, u32 b) { ncmt += b - a; }
     __device__ void seq_range(const Piece &, u32 a, u32 b, u32 sp) { nseq += (u32)__popc(range_mask(a, b) & ~sp); }
@@ -605,7 +626,7 @@ struct FqWrite {
     __device__ void seq_end(u64 r) { O.rec_end[r] = bseq; }
     __device__ void qual_begin(u64 r) { O.q_begin[r] = bqual; }
     __device__ void qual_end(u64 r) { O.q_end[r] = bqual; }
-    __device__ void unexpected(int kind, u32 ch) { atomicAdd((unsigned long long *)&O.unexpected[kind * 257 + ch], 1ull); }
+    __device__ void unexpected(int kind, u32 ch, u64 pos) { atomicAdd((unsigned long long *)&O.unexpected[kind * 257 + ch], 1ull); if (O.strict_first) atomicMin((unsigned long long *)O.strict_first, strict_key(pos, kind, ch)); }
     __device__ void error(u64 r, int kind) { atomicMin((unsigned long long *)O.first_error, (unsigned long long)(r * 4 + kind)); }
     __device__ void ids_range(const Piece &pc, u32 a, u32 b) { u64 lo, hi; piece_from(pc, a, lo, hi); global_store_n(O.ids + bids, lo, hi, b - a); bids += b - a; }
     __device__ void cmt_range(const Piece &pc, u32 a, u32 b) { u64 lo, hi; piece_from(pc, a, lo, hi); global_store_n(O.cmt + bcmt, lo, hi, b - a); bcmt += b - a; }
@@ -833,11 +854,12 @@ __global__ void k_len_unit_write(const u64 *rec_begin, const u64 *rec_end, u64 N
 
 // ---- soft mask: boundaries of (byte >= 96) runs -> u8 units with 255 continuation (encoders.c:98-146) -----------------------
 #define MB_TILE (256 * 16)
-__device__ __forceinline__ u32 mask_boundary_bits(const u8 *seq, u64 base, u64 T)
+__device__ __forceinline__ u32 mask_boundary_bits(const u8 *seq, u64 base, u64 T, bool prev0)
 {
-    // bit i set when base+i starts a new run, i.e. its case differs from the previous base (the virtual
-    // base -1 is "unmasked": a masked first base opens a zero-length unmasked run, encoders.c:132)
-    bool prev = base ? seq[base - 1] >= 96 : false;
+    // bit i set when base+i starts a new run, i.e. its case differs from the previous base.  prev0 = case in front of base 0:
+    // "unmasked" for a whole input (a masked first base opens a zero-length unmasked run, encoders.c:132), the case of the
+    // last base of the shards in front for a shard of one.
+    bool prev = base ? seq[base - 1] >= 96 : prev0;
     if (base + 16 <= T) {
         // byte >= 96 <=> bit 7 or (bit 6 and bit 5): the top bit of each byte, gathered to one bit per byte (base is 16-aligned, so is seq)
         uint4 v = *(const uint4 *)(seq + base);
@@ -850,32 +872,48 @@ __device__ __forceinline__ u32 mask_boundary_bits(const u8 *seq, u64 base, u64 T
     for (u32 i = 0; i < 16 && base + i < T; i++) { bool cur = seq[base + i] >= 96; if (cur != prev) m |= 1u << i; prev = cur; }
     return m;
 }
-__global__ __launch_bounds__(256) void k_mask_bscatter(const u8 *seq, u64 T, const u64 *tile_pre, u64 nb, u64 *bnd)
+__global__ __launch_bounds__(256) void k_mask_bscatter(const u8 *seq, u64 T, const u64 *tile_pre, u64 nb, u64 *bnd, int prev0)
 {
     __shared__ u64 lds[4];
     // most tiles of most inputs hold no case change: those are not read a second time
     if ((blockIdx.x + 1 < gridDim.x ? tile_pre[blockIdx.x + 1] : nb) == tile_pre[blockIdx.x]) return;
     u64 base = (u64)blockIdx.x * MB_TILE + (u64)threadIdx.x * 16;
-    u32 m = base < T ? mask_boundary_bits(seq, base, T) : 0;
+    u32 m = base < T ? mask_boundary_bits(seq, base, T, prev0 != 0) : 0;
     u64 c = __popc(m), tot;
     u64 incl = wg_scan_inclusive<u64, OpAdd>(c, &tot, lds);
     u64 k = tile_pre[blockIdx.x] + incl - c;
     while (m) { int b = __ffs(m) - 1; m &= m - 1; bnd[k++] = base + b; }
 }
-// run r (0-based) spans [start_r, start_{r+1}) with start_0 = 0, start_{r} = bnd[r-1], end of last = T
-__global__ void k_mask_run_units(const u64 *bnd, u64 nb, u64 T, u64 *units)
+// Shards of one input (naf_gpu_ennaf_shard_*): case changes INSIDE the shard (positions >= 1) per tile, their first and last
+// position, and the first / last base -- what the neighbours need to continue a run across the cut.
+// out: [0] first internal boundary (~0: none), [1] last internal boundary (0: none), [2] first base | last base << 8
+__global__ __launch_bounds__(256) void k_mask_census(const u8 *seq, u64 T, u64 *tile_cnt, unsigned long long *out)
+{
+    __shared__ u32 s_c[4];
+    u64 base = (u64)blockIdx.x * MB_TILE + (u64)threadIdx.x * 16;
+    u32 m = base < T ? mask_boundary_bits(seq, base, T, seq[0] >= 96) : 0;       // prev0 = the first base's own case: position 0 never counts
+    u32 tot = wg_reduce1<u32, OpAdd>((u32)__popc(m), s_c);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+    if (m) { atomicMin(&out[0], (unsigned long long)(base + (u32)__ffs((int)m) - 1)); atomicMax(&out[1], (unsigned long long)(base + 31 - __clz((int)m))); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[2] = (unsigned long long)seq[0] | ((unsigned long long)seq[T - 1] << 8);
+}
+__global__ void k_add_u64(u64 *p, u64 v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += v; }
+// run r (0-based) spans [start_r, start_{r+1}) with start_0 = 0, start_{r} = bnd[r-1]; the last one ends at T + ext, ext = the
+// bases of the following shards that continue it (0 for a whole input).  skip0: run 0 -- the bases in front of this shard's first
+// case change -- continues a run of an earlier shard, which emits its units.
+__global__ void k_mask_run_units(const u64 *bnd, u64 nb, u64 T, u64 *units, u64 ext, int skip0)
 {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > nb) return;
-    u64 s = r ? bnd[r - 1] : 0, e = r < nb ? bnd[r] : T;
-    units[r] = (e - s) / 255 + 1;
+    u64 s = r ? bnd[r - 1] : 0, e = r < nb ? bnd[r] : T + ext;
+    units[r] = (skip0 && r == 0) ? 0 : (e - s) / 255 + 1;
 }
 // every unit that is not the last of its run is 255: the array is pre-filled with 255 and one lane per run writes the remainder
-__global__ void k_mask_units_write(const u64 *bnd, u64 nb, u64 T, const u64 *unit_off, u8 *out)
+__global__ void k_mask_units_write(const u64 *bnd, u64 nb, u64 T, const u64 *unit_off, u8 *out, u64 ext, int skip0)
 {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > nb) return;
-    u64 s = r ? bnd[r - 1] : 0, e = r < nb ? bnd[r] : T, len = e - s;
+    if (r > nb || (skip0 && r == 0)) return;
+    u64 s = r ? bnd[r - 1] : 0, e = r < nb ? bnd[r] : T + ext, len = e - s;
     out[unit_off[r] + len / 255] = (u8)(len % 255);
 }
 
@@ -893,17 +931,22 @@ __device__ __forceinline__ u32 nuc4(u32 c)
     return 15;
 }
 // With tile_cnt the kernel also counts the soft-mask run boundaries of its 4096 bases (k_mask_bcount's job): both walk the same bytes.
-__global__ __launch_bounds__(256) void k_pack4(const u8 *seq, u64 T, u8 *packed, u64 *tile_cnt)
+// The pack window starts `skip` (0 or 1) bases into the stream: the first base of a shard whose global base index is odd is the
+// high nibble of the previous shard's last byte (encoders.c:30-69 keeps that half byte in `parity` between chunks); `tail_hi` is
+// the code that completes this shard's own last byte when its window is odd (the next shard's first base; 0 at the end of the data,
+// ennaf.c:525-529).
+__global__ __launch_bounds__(256) void k_pack4(const u8 *seq, u64 T, u8 *packed, u64 *tile_cnt, u32 skip, u32 tail_hi)
 {
     __shared__ u8 lut[256];
     if (tile_cnt) {
         __shared__ u32 s_c[4];
         u64 base = (u64)blockIdx.x * MB_TILE + (u64)threadIdx.x * 16;
-        u32 tot = wg_reduce1<u32, OpAdd>(base < T ? (u32)__popc(mask_boundary_bits(seq, base, T)) : 0u, s_c);
+        u32 tot = wg_reduce1<u32, OpAdd>(base < T ? (u32)__popc(mask_boundary_bits(seq, base, T, false)) : 0u, s_c);
         if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
     }
     { u32 c = threadIdx.x; u32 v = nuc4(c); if (!((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '-')) v = 15; lut[c] = (u8)v; }
     __syncthreads();
+    seq += skip; T -= skip;                                      // (T >= skip: the host launches nothing for an empty window)
     u64 i = ((u64)blockIdx.x * 256 + threadIdx.x) * 16;      // 16 bases -> 8 bytes
     if (i >= T) return;
     u64 out = 0;
@@ -919,7 +962,7 @@ __global__ __launch_bounds__(256) void k_pack4(const u8 *seq, u64 T, u8 *packed,
         st64(packed + i / 2, out);
     } else {
         for (u64 k = i; k < T; k += 2) {
-            u32 lo = lut[seq[k]], hi = k + 1 < T ? lut[seq[k + 1]] : 0;
+            u32 lo = lut[seq[k]], hi = k + 1 < T ? lut[seq[k + 1]] : tail_hi;
             packed[k / 2] = (u8)(lo | (hi << 4));
         }
     }
@@ -946,6 +989,52 @@ __global__ void k_sniff(const u8 *text, u64 n, u64 *out /* p0, first char, prev 
         }
     }
     if (lane == 0) { out[0] = n; out[1] = 0x100; out[2] = '\n'; }
+}
+
+// ---- shard cuts ------------------------------------------------------------------------------------------------------------------------
+// FASTQ records are four non-empty lines (process.c:477-544), so a slice of the text can only be cut where the ordinal of a line
+// start is a multiple of four; the ordinals come from a census of every slice.  A line start is a non-EOL byte behind an EOL-class
+// byte -- the rule of count_line_starts above, for a slice whose first byte may sit in the middle of a line.
+#define LC_TILE 4096
+__device__ __forceinline__ u32 slice_line_starts16(const u8 *t, u64 base, u64 n, int prev_is_eol)
+{
+    u32 m = 0; bool prev = base ? c_eol(t[base - 1]) : prev_is_eol != 0;
+    for (u32 i = 0; i < 16 && base + i < n; i++) { const bool e = c_eol(t[base + i]); if (!e && prev) m |= 1u << i; prev = e; }
+    return m;
+}
+__global__ __launch_bounds__(256) void k_line_count(const u8 *t, u64 n, int prev_is_eol, u64 *tile_cnt)
+{
+    __shared__ u32 s_c[4];
+    const u64 base = (u64)blockIdx.x * LC_TILE + (u64)threadIdx.x * 16;
+    const u32 tot = wg_reduce1<u32, OpAdd>(base < n ? (u32)__popc(slice_line_starts16(t, base, n, prev_is_eol)) : 0u, s_c);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+}
+// position of line start number `want` (0-based) of the slice; n when it has fewer.  One workgroup: the tile is found by bisection
+// over the scanned tile counts, the byte inside it by a scan of the 256 pieces.
+__global__ __launch_bounds__(256) void k_line_find(const u8 *t, u64 n, int prev_is_eol, const u64 *tile_pre, u64 tiles, u64 total, u64 want, u64 *out)
+{
+    __shared__ u64 lds[4];
+    if (want >= total) { if (threadIdx.x == 0) *out = n; return; }
+    u64 lo = 0, hi = tiles;                                       // last tile with tile_pre <= want
+    while (hi - lo > 1) { const u64 mid = (lo + hi) / 2; if (tile_pre[mid] <= want) lo = mid; else hi = mid; }
+    const u64 base = lo * LC_TILE + (u64)threadIdx.x * 16;
+    const u32 m = base < n ? slice_line_starts16(t, base, n, prev_is_eol) : 0u;
+    u64 tot; const u64 incl = wg_scan_inclusive<u64, OpAdd>((u64)__popc(m), &tot, lds);
+    const u64 first = tile_pre[lo] + incl - __popc(m);            // ordinal of this piece's first line start
+    if (m && want >= first && want < first + __popc(m)) {
+        u32 mm = m; for (u64 k = first; k < want; k++) mm &= mm - 1;
+        *out = base + (u32)__ffs((int)mm) - 1;
+    }
+}
+// FASTA can be cut behind any EOL-class byte (the split kernels recover a byte's state from the last EOL in front of it, and the
+// start of a slice acts as one): first such position, n when the slice has none.
+__global__ __launch_bounds__(256) void k_eol_find(const u8 *t, u64 n, int prev_is_eol, unsigned long long *out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0 && prev_is_eol) atomicMin(out, 0ull);
+    for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q + 1 < n; q += (u64)gridDim.x * 256) {
+        if (q + 1 >= __atomic_load_n(out, __ATOMIC_RELAXED)) return;       // something earlier is known already
+        if (c_eol(t[q])) { atomicMin(out, (unsigned long long)(q + 1)); return; }
+    }
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------------------
@@ -984,6 +1073,313 @@ static void set_expected(EncP &P, int seq_type, bool fasta)
     memcpy(&P.qlo, q, 4); memcpy(&P.qhi, q + 4, 4);
 }
 
+// host-side copy of nuc4 (the high nibble a shard borrows from its neighbour's first base)
+static u32 nuc4_host(u32 c)
+{
+    static const char tab[] = "-TGKCYSBAWRDMHVN";
+    if (c == '-') return 0;
+    u32 u = c & ~0x20u;
+    if (u == 'U') return 1;
+    if (u >= 'A' && u <= 'Z') for (u32 k = 1; k < 16; k++) if ((u32)tab[k] == u) return k;
+    return 15;
+}
+
+// confirm_input_format (process.c:547-583): first non-space byte, the byte in front of it
+static int ennaf_sniff(naf_gpu_ctx *c, const u8 *d_text, u64 n, int want_format, int *format, u64 *p0)
+{
+    u64 *d_sn = arena_new<u64>(c, 4); if (!d_sn) return NAF_GPU_ENOMEM;
+    u64 sn[3] = { 0, 0x100, '\n' };
+    if (n) { LAUNCH(c, "ennaf_sniff", k_sniff, 1, 64, 0, d_text, n, d_sn); int rc = ctx_readback(c, sn, d_sn, 24); if (rc) return rc; }
+    *format = 0; *p0 = sn[0];
+    if (sn[1] != 0x100) {
+        bool at_line_start = sn[2] >= 0x0A && sn[2] <= 0x0D;
+        if (sn[1] == '>' && at_line_start) *format = NAF_FMT_FASTA;
+        else if (sn[1] == '@' && at_line_start) *format = NAF_FMT_FASTQ;
+        else if (sn[1] == '>' || sn[1] == '@') return ctx_fail(c, NAF_GPU_EINPUT, "invalid input - first '%c' is not at the beginning of the line\n", (int)sn[1]);
+        else return ctx_fail(c, NAF_GPU_EINPUT, "input data is in unknown format - first non-space character is neither '>' nor '@'\n");
+        if (want_format != NAF_FMT_AUTO && want_format != *format) return ctx_fail(c, NAF_GPU_EINPUT, "input format is different from format specified in the command line\n");
+    }
+    return 0;
+}
+
+// What the text-split pass of one input -- or of one shard of it -- leaves in the arena, and the first reason the reference would
+// have died for (record numbers local to the shard; the caller adds the records of the shards in front).
+enum { SE_NONE = 0, SE_AT, SE_PLUS, SE_QLEN, SE_NOSEQ, SE_NOQUAL, SE_STRICT };
+struct EnnafSplit {
+    int format, seq_type; bool fourbit, store_mask, store_qual, no_mask;
+    u8 *bases, *s_ids, *s_cmt, *s_qual;
+    u64 n_ids, n_cmt, n_qual, T, N, longest, lead;
+    u64 *rec_begin, *rec_end; int all_ends;
+    u64 unexpected[4][257];
+    int err_kind; u32 err_char; u64 err_rec, err_a, err_b;
+    // soft-mask census of a shard (positions >= 1); tc = per-tile counts kept for the finish
+    bool census; u64 *tc; u64 mask_changes, mask_first, mask_last; u8 first_base, last_base;
+};
+
+static int split_error_text(naf_gpu_ctx *c, int seq_type, int kind, u32 ch, u64 rec, u64 a, u64 b, u64 rec0)
+{
+    static const char *tn[4] = { "DNA", "RNA", "protein", "text" };
+    const unsigned long long r = (unsigned long long)(rec0 + rec);
+    switch (kind) {
+    case SE_AT: return ctx_fail(c, NAF_GPU_EINPUT, "invalid FASTQ input: Can't find '@' after sequence %llu\n", r);
+    case SE_PLUS: return ctx_fail(c, NAF_GPU_EINPUT, "invalid FASTQ input: can't find '+' line of sequence %llu\n", r + 1);
+    case SE_QLEN: return ctx_fail(c, NAF_GPU_EINPUT, "quality length of sequence %llu (%llu) doesn't match sequence length (%llu)\n", r + 1, (unsigned long long)a, (unsigned long long)b);
+    case SE_NOSEQ: return ctx_fail(c, NAF_GPU_EINPUT, "truncated FASTQ input: last sequence has no sequence data\n");
+    case SE_NOQUAL: return ctx_fail(c, NAF_GPU_EINPUT, "truncated FASTQ input: last sequence has no quality\n");
+    case SE_STRICT:                                                                                // process.c:98-140; rec is 1-based here
+        if (a == 0) return ctx_fail(c, NAF_GPU_EINPUT, "unexpected character '%c' in ID of sequence %llu\n", (int)(unsigned char)ch, r);
+        if (a == 1) return ctx_fail(c, NAF_GPU_EINPUT, "unexpected character '%c' in comment of sequence %llu\n", (int)(unsigned char)ch, r);
+        if (a == 2) return ctx_fail(c, NAF_GPU_EINPUT, "unexpected %s code '%c' in sequence %llu\n", tn[seq_type & 3], (int)(unsigned char)ch, r);
+        return ctx_fail(c, NAF_GPU_EINPUT, "unexpected quality code '%c' in sequence %llu\n", (int)(unsigned char)ch, r);
+    default: return 0;
+    }
+}
+
+// The split pass (E1-E4): text -> ids, comments, bases (1 B/base, post-replacement), quality, record table.  p0 = first byte of
+// the first record; last_part: the text ends where the input ends (the truncation rules of process.c:499-520 apply).
+static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_ennaf_opts *o, int format, u64 p0, bool last_part, EnnafSplit &S)
+{
+    memset(&S, 0, sizeof S);
+    int seq_type = o->seq_type, rc;
+    S.format = format; S.seq_type = seq_type;
+    S.fourbit = seq_type <= NAF_SEQ_RNA;
+    S.store_mask = !(o->no_mask || !S.fourbit);                                                   // ennaf.c:445
+    S.store_qual = format == NAF_FMT_FASTQ;                                                       // ennaf.c:477
+    S.no_mask = o->no_mask != 0; (void)last_part;
+    u8 *&bases = S.bases; u8 *&s_ids = S.s_ids, *&s_cmt = S.s_cmt, *&s_qual = S.s_qual;
+    u64 &n_ids = S.n_ids, &n_cmt = S.n_cmt, &n_qual = S.n_qual, &T = S.T, &N = S.N, &longest = S.longest;
+    u64 *&rec_begin = S.rec_begin, *&rec_end = S.rec_end;
+    if (format == NAF_FMT_FASTQ) {
+        EncP P; memset(&P, 0, sizeof P);
+        P.text = d_text; P.n = n; P.p0 = p0;
+        set_expected(P, seq_type, false);
+        u64 tiles = n / ET_TILE + 1;
+        i64 *t_eol = arena_new<i64>(c, tiles + 1), *t_sp = arena_new<i64>(c, tiles + 1);
+        u64 *t_ls = arena_new<u64>(c, tiles + 2), *t_seq = arena_new<u64>(c, tiles + 2), *t_ids = arena_new<u64>(c, tiles + 2),
+            *t_cmt = arena_new<u64>(c, tiles + 2), *t_qual = arena_new<u64>(c, tiles + 2);
+        u64 *tot = arena_new<u64>(c, 8);
+        u32 *piece_cnt = arena_new<u32>(c, tiles * 256);
+        if (!t_eol || !t_sp || !t_ls || !t_seq || !t_ids || !t_cmt || !t_qual || !tot || !piece_cnt) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "ennaf_last", k_enc_last, tiles, 256, 0, P, t_eol, t_sp, t_ls);
+        if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
+        if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_ls, tiles, tot + 4))) return rc;
+        LAUNCH(c, "ennaf_fq_count", k_encq_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, piece_cnt);
+        if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_ids, tiles, tot + 1))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_qual, tiles, tot + 3))) return rc;
+        u64 h[5]; u8 lastb = 0x0A;
+        if (n) { if ((rc = ctx_readback2(c, h, tot, 40, &lastb, d_text + n - 1, 1))) return rc; }
+        else if ((rc = ctx_readback(c, h, tot, 40))) return rc;
+        T = h[0]; n_ids = h[1]; n_cmt = h[2]; n_qual = h[3];
+        u64 nlines = h[4]; N = (nlines + 3) / 4;
+        // truncated input (process.c:499,510,513,517,520)
+        if (nlines % 4 == 1 && !(lastb >= 0x0A && lastb <= 0x0D)) { S.err_kind = SE_NOSEQ; return 0; }
+        bases = (u8 *)arena_alloc(c, T + 64);
+        s_ids = (u8 *)arena_alloc(c, n_ids + 16); s_cmt = (u8 *)arena_alloc(c, n_cmt + 16); s_qual = (u8 *)arena_alloc(c, n_qual + 16);
+        rec_begin = arena_new<u64>(c, N + 1); rec_end = arena_new<u64>(c, N + 1);
+        u64 *q_begin = arena_new<u64>(c, N + 1), *q_end = arena_new<u64>(c, N + 1);
+        const size_t NU = 4 * 257 + 3;                                                             // histograms, first_error, longest, strict key
+        u64 *d_unexp = arena_new<u64>(c, NU);
+        if (!bases || !s_ids || !s_cmt || !s_qual || !rec_begin || !rec_end || !q_begin || !q_end || !d_unexp) return NAF_GPU_ENOMEM;
+        HIP_TRY(c, hipMemsetAsync(d_unexp, 0, NU * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(d_unexp + 4 * 257, 0xFF, 8, c->stream));                        // first_error = none
+        HIP_TRY(c, hipMemsetAsync(d_unexp + 4 * 257 + 2, 0xFF, 8, c->stream));                    // strict key = none
+        HIP_TRY(c, hipMemsetAsync(rec_begin, 0, (N + 1) * 8, c->stream)); HIP_TRY(c, hipMemsetAsync(rec_end, 0, (N + 1) * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(q_begin, 0, (N + 1) * 8, c->stream)); HIP_TRY(c, hipMemsetAsync(q_end, 0, (N + 1) * 8, c->stream));
+        FqOut O; O.seq = bases; O.ids = s_ids; O.cmt = s_cmt; O.qual = s_qual; O.rec_begin = rec_begin; O.rec_end = rec_end; O.q_begin = q_begin; O.q_end = q_end;
+        O.unexpected = d_unexp; O.first_error = d_unexp + 4 * 257; O.strict_first = o->strict ? d_unexp + 4 * 257 + 2 : nullptr;
+        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_qual = t_qual; O.t_ls = t_ls; O.piece_cnt = piece_cnt;
+        LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+        if (nlines / 4) LAUNCH(c, "ennaf_fq_check", k_fq_check, cdiv(nlines / 4, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, (const u64 *)q_begin, (const u64 *)q_end, nlines / 4, O.first_error, d_unexp + 4 * 257 + 1);
+        std::vector<u64> hu(NU);
+        if ((rc = ctx_readback(c, hu.data(), d_unexp, NU * 8))) return rc;
+        // The reference stops at the first problem in input order.  Structural ones come as (record, kind); an unexpected byte under
+        // --strict as a text position, turned into (record, line of the record) by counting the line starts in front of it.  Inside
+        // a record the order of detection is: '@' (first byte of line 0), id / comment bytes, bases, '+' (line 2), quality bytes,
+        // quality length (end of line 3).
+        u64 fe = hu[4 * 257];
+        u64 trunc_rec = nlines % 4 ? nlines / 4 : ~0ull;                                           // the incomplete record
+        u64 best_rec = ~0ull; int best_stage = 99, best_kind = SE_NONE;
+        if (fe != ~0ull && (fe >> 2) <= trunc_rec) {
+            int kind = (int)(fe & 3);
+            best_rec = fe >> 2; best_stage = kind == FQ_E_AT ? 0 : kind == FQ_E_PLUS ? 3 : 5;
+            best_kind = kind == FQ_E_AT ? SE_AT : kind == FQ_E_PLUS ? SE_PLUS : SE_QLEN;
+        }
+        const u64 sk = hu[4 * 257 + 2];
+        if (o->strict && sk != ~0ull) {
+            const u64 pos = sk >> 11; const int skind = (int)((sk >> 9) & 3);
+            unsigned long long *d_cnt = arena_new<unsigned long long>(c, 1); if (!d_cnt) return NAF_GPU_ENOMEM;
+            HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 8, c->stream));
+            LAUNCH(c, "ennaf_count_starts", k_count_starts, (u32)((pos - p0) / 65536 + 1 < 1024 ? (pos - p0) / 65536 + 1 : 1024), 256, 0, d_text, p0, pos, 1, d_cnt);
+            u64 cnt = 0; if ((rc = ctx_readback(c, &cnt, d_cnt, 8))) return rc;
+            const u64 ord = cnt ? cnt - 1 : 0, srec = ord >> 2; const int sstage = skind <= 1 ? 1 : skind == 2 ? 2 : 4;
+            if (srec <= trunc_rec && (srec < best_rec || (srec == best_rec && sstage < best_stage))) {
+                S.err_kind = SE_STRICT; S.err_char = (u32)(sk & 0x1FF); S.err_rec = srec + 1; S.err_a = (u64)skind;
+                return 0;
+            }
+        }
+        if (best_kind != SE_NONE) {
+            S.err_kind = best_kind; S.err_rec = best_rec;
+            if (best_kind == SE_QLEN) {
+                u64 v[4]; const u64 r = best_rec;
+                if ((rc = ctx_readback2(c, &v[0], rec_begin + r, 8, &v[1], rec_end + r, 8)) || (rc = ctx_readback2(c, &v[2], q_begin + r, 8, &v[3], q_end + r, 8))) return rc;
+                S.err_a = v[3] - v[2]; S.err_b = v[1] - v[0];
+            }
+            return 0;
+        }
+        if (nlines % 4) { S.err_kind = SE_NOQUAL; return 0; }
+        for (int k = 0; k < 4; k++) for (int i = 0; i < 257; i++) S.unexpected[k][i] = hu[k * 257 + i];
+        longest = hu[4 * 257 + 1];
+        S.all_ends = 1;
+    }
+    if (format == NAF_FMT_FASTA) {
+        EncP P; memset(&P, 0, sizeof P);
+        P.text = d_text; P.n = n; P.p0 = p0;
+        set_expected(P, seq_type, true);
+        u64 tiles = n / ET_TILE + 1;                                                              // +1: the virtual end-of-input byte
+        i64 *t_eol = arena_new<i64>(c, tiles + 1), *t_sp = arena_new<i64>(c, tiles + 1);
+        u64 *t_seq = arena_new<u64>(c, tiles + 2), *t_ids = arena_new<u64>(c, tiles + 2), *t_cmt = arena_new<u64>(c, tiles + 2), *t_rec = arena_new<u64>(c, tiles + 2);
+        u32 *t_tail = arena_new<u32>(c, tiles + 1);
+        u64 *tot = arena_new<u64>(c, 8);
+        if (!t_eol || !t_sp || !t_seq || !t_ids || !t_cmt || !t_rec || !t_tail || !tot) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "ennaf_last", k_enc_last_fa, cdiv(tiles, 4), 256, 0, P, t_eol, t_sp, tiles);
+        // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
+        if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
+        if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
+        LAUNCH(c, "ennaf_count", k_enc_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail);
+        if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_ids, tiles, tot + 1))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_rec, tiles, tot + 3))) return rc;
+        // t_seq[tiles] must hold the grand total for the "line began in an earlier tile" lookup
+        HIP_TRY(c, hipMemcpyAsync(t_seq + tiles, tot + 0, 8, hipMemcpyDeviceToDevice, c->stream));
+        u64 h[4];
+        if ((rc = ctx_readback(c, h, tot, 32))) return rc;
+        T = h[0]; n_ids = h[1]; n_cmt = h[2]; N = h[3];
+        bases = (u8 *)arena_alloc(c, T + 64);
+        s_ids = (u8 *)arena_alloc(c, n_ids + 16); s_cmt = (u8 *)arena_alloc(c, n_cmt + 16);
+        rec_begin = arena_new<u64>(c, N + 1); rec_end = arena_new<u64>(c, N + 1);
+        const size_t NU = 3 * 257 + 3;                                                             // histograms, longest, strict key, lead
+        u64 *d_unexp = arena_new<u64>(c, NU);
+        if (!bases || !s_ids || !s_cmt || !rec_begin || !rec_end || !d_unexp) return NAF_GPU_ENOMEM;
+        HIP_TRY(c, hipMemsetAsync(d_unexp, 0, NU * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(d_unexp + 3 * 257 + 1, 0xFF, 8, c->stream));                    // strict key = none
+        HIP_TRY(c, hipMemsetAsync(rec_begin, 0, (N + 1) * 8, c->stream));
+        EncOut O; O.seq = bases; O.ids = s_ids; O.cmt = s_cmt; O.rec_begin = rec_begin; O.rec_end = rec_end;
+        O.unexpected = d_unexp; O.longest = d_unexp + 3 * 257; O.strict_first = o->strict ? d_unexp + 3 * 257 + 1 : nullptr; O.lead = d_unexp + 3 * 257 + 2;
+        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_rec = t_rec; O.t_tail = t_tail; O.tile_eol = t_eol;
+        LAUNCH(c, "ennaf_scatter", k_enc_scatter, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+        std::vector<u64> hu(NU);
+        if ((rc = ctx_readback(c, hu.data(), d_unexp, NU * 8))) return rc;
+        const u64 sk = hu[3 * 257 + 1];
+        if (o->strict && sk != ~0ull) {                                                            // process.c:98-140: n_sequences + 1 = headers read so far
+            const u64 pos = sk >> 11;
+            unsigned long long *d_cnt = arena_new<unsigned long long>(c, 1); if (!d_cnt) return NAF_GPU_ENOMEM;
+            HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 8, c->stream));
+            LAUNCH(c, "ennaf_count_starts", k_count_starts, (u32)((pos - p0) / 65536 + 1 < 1024 ? (pos - p0) / 65536 + 1 : 1024), 256, 0, d_text, p0, pos, 0, d_cnt);
+            u64 cnt = 0; if ((rc = ctx_readback(c, &cnt, d_cnt, 8))) return rc;
+            S.err_kind = SE_STRICT; S.err_char = (u32)(sk & 0x1FF); S.err_rec = cnt; S.err_a = (sk >> 9) & 3;
+            return 0;
+        }
+        for (int k = 0; k < 3; k++) for (int i = 0; i < 257; i++) S.unexpected[k][i] = hu[k * 257 + i];
+        longest = hu[3 * 257];
+        S.lead = N ? hu[3 * 257 + 2] : T;
+    }
+    return 0;
+}
+
+// What the neighbours of a shard contribute to its streams (all zero for a whole input).
+struct EnnafCarry {
+    u64 tail_extra;        // bases of the following shards that still belong to this shard's last record (FASTA cut inside a record)
+    u32 skip_first;        // 1: this shard's first base is the high nibble of the previous shard's last packed byte
+    u32 tail_hi;           // code that completes this shard's last packed byte when its pack window is odd (0 at the end of the data)
+    int prev_masked;       // case of the last base in front of the shard ("unmasked" in front of base 0, encoders.c:132)
+    int skip_run0;         // 1: the bases in front of the shard's first case change continue a run that an earlier shard emits
+    u64 run_ext;           // bases of the following shards that continue this shard's last mask run
+};
+struct EnnafStreams { const u8 *ptr[6]; u64 len[6], orig[6]; int lz[6], block_log[6]; bool present[6]; };
+
+// E5-E7: lengths, 4-bit pack, mask units -> the six uncompressed streams.
+static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, EnnafStreams &X)
+{
+    memset(&X, 0, sizeof X);
+    int rc; const u64 T = S.T, N = S.N;
+    u32 *s_len = nullptr; u8 *s_seq = nullptr, *s_mask = nullptr;
+    u64 n_lenb = 0, n_seqb = 0, n_mask = 0; int mask_block_log = 15;
+    if (S.format != 0) {
+        if (N) {
+            u64 *lu = arena_new<u64>(c, N + 2); if (!lu) return NAF_GPU_ENOMEM;
+            const u64 total = T + K.tail_extra;                                                    // where the last record of a FASTA part ends
+            LAUNCH(c, "ennaf_len_count", k_len_unit_count, cdiv(N, 256), 256, 0, (const u64 *)S.rec_begin, (const u64 *)S.rec_end, N, total, lu, S.all_ends);
+            if ((rc = scan_exclusive_u64(c, lu, N, lu + N + 1))) return rc;
+            u64 nu = 0; if ((rc = ctx_readback(c, &nu, lu + N + 1, 8))) return rc;
+            s_len = arena_new<u32>(c, nu + 1); if (!s_len) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "ennaf_len_write", k_len_unit_write, cdiv(N, 256), 256, 0, (const u64 *)S.rec_begin, (const u64 *)S.rec_end, N, total, (const u64 *)lu, s_len, S.all_ends);
+            n_lenb = nu * 4;
+        }
+        // sequence stream; for a whole input the 4-bit pack also counts the soft-mask run boundaries per tile of 4096 bases (a shard
+        // has counted them in its census already)
+        u64 mt = (T + MB_TILE - 1) / MB_TILE;
+        u64 *tc = S.tc;
+        if (S.store_mask && T && !S.census) { tc = arena_new<u64>(c, mt + 2); if (!tc) return NAF_GPU_ENOMEM; }
+        if (S.fourbit) {
+            const u64 Tp = T > K.skip_first ? T - K.skip_first : 0;                                // bases of the pack window
+            n_seqb = (Tp + 1) / 2;
+            s_seq = (u8 *)arena_alloc(c, n_seqb + 16); if (!s_seq) return NAF_GPU_ENOMEM;
+            if (T) LAUNCH(c, "ennaf_pack4", k_pack4, cdiv(T, 256 * 16), 256, 0, (const u8 *)S.bases, T, s_seq, S.census ? (u64 *)nullptr : tc, K.skip_first, K.tail_hi);
+        } else {
+            if (S.no_mask && T) LAUNCH(c, "ennaf_toupper", k_toupper, cdiv(T, 256), 256, 0, S.bases, T);   // process.c:46-51
+            s_seq = S.bases; n_seqb = T;
+        }
+        // mask (only ever stored next to a 4-bit sequence stream, ennaf.c:445)
+        if (S.store_mask && T) {
+            const int b0 = S.census ? ((S.first_base >= 96) != (K.prev_masked != 0)) : 0;          // a shard's case change at its first base
+            if (b0) LAUNCH(c, "ennaf_mask_b0", k_add_u64, 1, 64, 0, tc, (u64)1);
+            if ((rc = scan_exclusive_u64(c, tc, mt, tc + mt + 1))) return rc;
+            u64 nb = 0; if ((rc = ctx_readback(c, &nb, tc + mt + 1, 8))) return rc;
+            u64 *bnd = arena_new<u64>(c, nb + 1), *ru = arena_new<u64>(c, nb + 3);
+            if (!bnd || !ru) return NAF_GPU_ENOMEM;
+            if (nb) LAUNCH(c, "ennaf_mask_bscatter", k_mask_bscatter, mt, 256, 0, (const u8 *)S.bases, T, (const u64 *)tc, nb, bnd, K.prev_masked);
+            LAUNCH(c, "ennaf_mask_runs", k_mask_run_units, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, ru, K.run_ext, K.skip_run0);
+            if ((rc = scan_exclusive_u64(c, ru, nb + 1, ru + nb + 2))) return rc;
+            u64 nu = 0; if ((rc = ctx_readback(c, &nu, ru + nb + 2, 8))) return rc;
+            s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
+            if (nu) HIP_TRY(c, hipMemsetAsync(s_mask, 0xFF, nu, c->stream));
+            LAUNCH(c, "ennaf_mask_units", k_mask_units_write, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, (const u64 *)ru, s_mask, K.run_ext, K.skip_run0);
+            // Block size of the mask stream.  Real soft-masking (runs of a few hundred bases) gives a few MB of high-entropy units, i.e. a
+            // few hundred blocks whose Huffman streams the decoder walks serially: 8 KiB blocks (2 KiB streams) cut that latency to a
+            // quarter.  Very long runs give strings of 255s (constant blocks, nothing to walk): 32 KiB blocks keep the block count down.
+            mask_block_log = nu / (nb + 1) > 1000 ? 15 : 13;
+            n_mask = nu;
+        }
+    }
+    // ids, names and lengths are text-like / repetitive and small: always through the LZ stage (as reference level 1 does);
+    // mask, sequence and quality get it from level 2 up
+    X.ptr[0] = S.s_ids; X.len[0] = X.orig[0] = S.n_ids; X.lz[0] = 1; X.present[0] = true;
+    X.ptr[1] = S.s_cmt; X.len[1] = X.orig[1] = S.n_cmt; X.lz[1] = 1; X.present[1] = true;
+    X.ptr[2] = (const u8 *)s_len; X.len[2] = X.orig[2] = n_lenb; X.lz[2] = 1; X.present[2] = true;
+    X.ptr[3] = s_mask; X.len[3] = X.orig[3] = n_mask; X.block_log[3] = mask_block_log; X.present[3] = S.store_mask;
+    X.ptr[4] = s_seq; X.len[4] = n_seqb; X.orig[4] = T; X.present[4] = true;                      // ennaf.c:582: number of bases
+    X.ptr[5] = S.s_qual; X.len[5] = X.orig[5] = S.n_qual; X.present[5] = S.store_qual;
+    return 0;
+}
+
+// container header (ennaf.c:538-556): magic, version, flags, separator, line length, N, title
+static size_t naf_header_bytes(const naf_gpu_ennaf_opts *o, bool store_mask, bool store_qual, u64 longest, u64 N, u8 *hd /* >= 40 */)
+{
+    size_t hl = 0;
+    hd[hl++] = 0x01; hd[hl++] = 0xF9; hd[hl++] = 0xEC;
+    if (o->seq_type == NAF_SEQ_DNA) hd[hl++] = 1; else { hd[hl++] = 2; hd[hl++] = (u8)o->seq_type; }
+    hd[hl++] = (u8)(((o->title ? 1 : 0) << 6) | (1 << 5) | (1 << 4) | (1 << 3) | ((store_mask ? 1 : 0) << 2) | (1 << 1) | (store_qual ? 1 : 0));
+    hd[hl++] = ' ';
+    hl += vle(o->line_length >= 0 ? (u64)o->line_length : longest, hd + hl);
+    hl += vle(N, hd + hl);
+    if (o->title) hl += vle(strlen(o->title), hd + hl);
+    return hl;
+}
+
 struct SecOut { u64 orig, comp; };
 
 static int put_section(naf_gpu_ctx *c, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz = 0, int block_log = 0)
@@ -1011,207 +1407,302 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     arena_reset(c);
     const u8 *d_text = (const u8 *)d_text_; u8 *d_naf = (u8 *)d_naf_;
     naf_gpu_ennaf_report R; memset(&R, 0, sizeof R);
-    int seq_type = o->seq_type;
-    if (seq_type < 0 || seq_type > 3) return ctx_fail(c, NAF_GPU_EARG, "bad seq_type");
-    bool fourbit = seq_type <= NAF_SEQ_RNA;
-    bool store_mask = !(o->no_mask || !fourbit);                                                  // ennaf.c:445
-
-    // confirm_input_format
-    u64 *d_sn = arena_new<u64>(c, 4); if (!d_sn) return NAF_GPU_ENOMEM;
-    u64 sn[3] = { 0, 0x100, '\n' };
-    if (n) { LAUNCH(c, "ennaf_sniff", k_sniff, 1, 64, 0, d_text, (u64)n, d_sn); int rc = ctx_readback(c, sn, d_sn, 24); if (rc) return rc; }
-    int format = 0;
-    if (sn[1] != 0x100) {
-        bool at_line_start = sn[2] >= 0x0A && sn[2] <= 0x0D;
-        if (sn[1] == '>' && at_line_start) format = NAF_FMT_FASTA;
-        else if (sn[1] == '@' && at_line_start) format = NAF_FMT_FASTQ;
-        else if (sn[1] == '>' || sn[1] == '@') return ctx_fail(c, NAF_GPU_EINPUT, "invalid input - first '%c' is not at the beginning of the line\n", (int)sn[1]);
-        else return ctx_fail(c, NAF_GPU_EINPUT, "input data is in unknown format - first non-space character is neither '>' nor '@'\n");
-        if (o->format != NAF_FMT_AUTO && o->format != format) return ctx_fail(c, NAF_GPU_EINPUT, "input format is different from format specified in the command line\n");
-    }
+    if (o->seq_type < 0 || o->seq_type > 3) return ctx_fail(c, NAF_GPU_EARG, "bad seq_type");
+    int format = 0, rc; u64 p0 = 0;
+    if ((rc = ennaf_sniff(c, d_text, n, o->format, &format, &p0))) return rc;
     R.format = format;
-    bool store_qual = format == NAF_FMT_FASTQ;                                                    // ennaf.c:477
-
-    u8 *s_ids = nullptr, *s_cmt = nullptr, *s_seq = nullptr, *s_mask = nullptr, *s_qual = nullptr, *bases = nullptr; u32 *s_len = nullptr;
-    int mask_block_log = 15;
-    u64 n_ids = 0, n_cmt = 0, n_lenb = 0, n_mask = 0, n_seqb = 0, n_qual = 0, T = 0, N = 0, longest = 0;
-    u64 *rec_begin = nullptr, *rec_end = nullptr; int all_ends = 0;
-    int rc;
-    if (format == NAF_FMT_FASTQ) {
-        EncP P; memset(&P, 0, sizeof P);
-        P.text = d_text; P.n = n; P.p0 = sn[0];
-        set_expected(P, seq_type, false);
-        u64 tiles = n / ET_TILE + 1;
-        i64 *t_eol = arena_new<i64>(c, tiles + 1), *t_sp = arena_new<i64>(c, tiles + 1);
-        u64 *t_ls = arena_new<u64>(c, tiles + 2), *t_seq = arena_new<u64>(c, tiles + 2), *t_ids = arena_new<u64>(c, tiles + 2),
-            *t_cmt = arena_new<u64>(c, tiles + 2), *t_qual = arena_new<u64>(c, tiles + 2);
-        u64 *tot = arena_new<u64>(c, 8);
-        u32 *piece_cnt = arena_new<u32>(c, tiles * 256);
-        if (!t_eol || !t_sp || !t_ls || !t_seq || !t_ids || !t_cmt || !t_qual || !tot || !piece_cnt) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "ennaf_last", k_enc_last, tiles, 256, 0, P, t_eol, t_sp, t_ls);
-        if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
-        if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_ls, tiles, tot + 4))) return rc;
-        LAUNCH(c, "ennaf_fq_count", k_encq_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, piece_cnt);
-        if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_ids, tiles, tot + 1))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_qual, tiles, tot + 3))) return rc;
-        u64 h[5]; u8 lastb = 0;
-        if ((rc = ctx_readback(c, h, tot, 40))) return rc;
-        if ((rc = ctx_readback(c, &lastb, d_text + n - 1, 1))) return rc;
-        T = h[0]; n_ids = h[1]; n_cmt = h[2]; n_qual = h[3];
-        u64 nlines = h[4]; N = (nlines + 3) / 4;
-        // truncated input (process.c:499,510,513,517,520)
-        if (nlines % 4 == 1 && !(lastb >= 0x0A && lastb <= 0x0D)) return ctx_fail(c, NAF_GPU_EINPUT, "truncated FASTQ input: last sequence has no sequence data\n");
-        bases = (u8 *)arena_alloc(c, T + 64);
-        s_ids = (u8 *)arena_alloc(c, n_ids + 16); s_cmt = (u8 *)arena_alloc(c, n_cmt + 16); s_qual = (u8 *)arena_alloc(c, n_qual + 16);
-        rec_begin = arena_new<u64>(c, N + 1); rec_end = arena_new<u64>(c, N + 1);
-        u64 *q_begin = arena_new<u64>(c, N + 1), *q_end = arena_new<u64>(c, N + 1);
-        u64 *d_unexp = arena_new<u64>(c, 4 * 257 + 2);
-        if (!bases || !s_ids || !s_cmt || !s_qual || !rec_begin || !rec_end || !q_begin || !q_end || !d_unexp) return NAF_GPU_ENOMEM;
-        HIP_TRY(c, hipMemsetAsync(d_unexp, 0, (4 * 257 + 2) * 8, c->stream));
-        HIP_TRY(c, hipMemsetAsync(d_unexp + 4 * 257, 0xFF, 8, c->stream));                        // first_error = none
-        HIP_TRY(c, hipMemsetAsync(rec_begin, 0, (N + 1) * 8, c->stream)); HIP_TRY(c, hipMemsetAsync(rec_end, 0, (N + 1) * 8, c->stream));
-        HIP_TRY(c, hipMemsetAsync(q_begin, 0, (N + 1) * 8, c->stream)); HIP_TRY(c, hipMemsetAsync(q_end, 0, (N + 1) * 8, c->stream));
-        FqOut O; O.seq = bases; O.ids = s_ids; O.cmt = s_cmt; O.qual = s_qual; O.rec_begin = rec_begin; O.rec_end = rec_end; O.q_begin = q_begin; O.q_end = q_end;
-        O.unexpected = d_unexp; O.first_error = d_unexp + 4 * 257;
-        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_qual = t_qual; O.t_ls = t_ls; O.piece_cnt = piece_cnt;
-        LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
-        if (nlines / 4) LAUNCH(c, "ennaf_fq_check", k_fq_check, cdiv(nlines / 4, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, (const u64 *)q_begin, (const u64 *)q_end, nlines / 4, O.first_error, d_unexp + 4 * 257 + 1);
-        std::vector<u64> hu(4 * 257 + 2);
-        if ((rc = ctx_readback(c, hu.data(), d_unexp, hu.size() * 8))) return rc;
-        u64 fe = hu[4 * 257];
-        u64 trunc_rec = nlines % 4 ? nlines / 4 : ~0ull;                                             // the incomplete record
-        if (fe != ~0ull && (fe >> 2) <= trunc_rec) {
-            u64 r = fe >> 2; int kind = (int)(fe & 3);
-            if (kind == FQ_E_AT) return ctx_fail(c, NAF_GPU_EINPUT, "invalid FASTQ input: Can't find '@' after sequence %llu\n", (unsigned long long)r);
-            if (kind == FQ_E_PLUS) return ctx_fail(c, NAF_GPU_EINPUT, "invalid FASTQ input: can't find '+' line of sequence %llu\n", (unsigned long long)r + 1);
-            u64 v[4];
-            if ((rc = ctx_readback(c, &v[0], rec_begin + r, 8)) || (rc = ctx_readback(c, &v[1], rec_end + r, 8)) || (rc = ctx_readback(c, &v[2], q_begin + r, 8)) || (rc = ctx_readback(c, &v[3], q_end + r, 8))) return rc;
-            return ctx_fail(c, NAF_GPU_EINPUT, "quality length of sequence %llu (%llu) doesn't match sequence length (%llu)\n",
-                            (unsigned long long)r + 1, (unsigned long long)(v[3] - v[2]), (unsigned long long)(v[1] - v[0]));
-        }
-        if (nlines % 4) return ctx_fail(c, NAF_GPU_EINPUT, "truncated FASTQ input: last sequence has no quality\n");
-        for (int i = 0; i < 257; i++) { R.unexpected_id[i] = hu[i]; R.unexpected_comment[i] = hu[257 + i]; R.unexpected_seq[i] = hu[514 + i]; R.unexpected_qual[i] = hu[771 + i]; }
-        longest = hu[4 * 257 + 1];
-        all_ends = 1;
-    }
-    if (format == NAF_FMT_FASTA) {
-        EncP P; memset(&P, 0, sizeof P);
-        P.text = d_text; P.n = n; P.p0 = sn[0];
-        set_expected(P, seq_type, true);
-        u64 tiles = n / ET_TILE + 1;                                                              // +1: the virtual end-of-input byte
-        i64 *t_eol = arena_new<i64>(c, tiles + 1), *t_sp = arena_new<i64>(c, tiles + 1);
-        u64 *t_seq = arena_new<u64>(c, tiles + 2), *t_ids = arena_new<u64>(c, tiles + 2), *t_cmt = arena_new<u64>(c, tiles + 2), *t_rec = arena_new<u64>(c, tiles + 2);
-        u32 *t_tail = arena_new<u32>(c, tiles + 1);
-        u64 *tot = arena_new<u64>(c, 8);
-        if (!t_eol || !t_sp || !t_seq || !t_ids || !t_cmt || !t_rec || !t_tail || !tot) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "ennaf_last", k_enc_last_fa, cdiv(tiles, 4), 256, 0, P, t_eol, t_sp, tiles);
-        // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
-        if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
-        if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
-        LAUNCH(c, "ennaf_count", k_enc_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail);
-        if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_ids, tiles, tot + 1))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_rec, tiles, tot + 3))) return rc;
-        // t_seq[tiles] must hold the grand total for the "line began in an earlier tile" lookup
-        HIP_TRY(c, hipMemcpyAsync(t_seq + tiles, tot + 0, 8, hipMemcpyDeviceToDevice, c->stream));
-        u64 h[4];
-        if ((rc = ctx_readback(c, h, tot, 32))) return rc;
-        T = h[0]; n_ids = h[1]; n_cmt = h[2]; N = h[3];
-        bases = (u8 *)arena_alloc(c, T + 64);
-        s_ids = (u8 *)arena_alloc(c, n_ids + 16); s_cmt = (u8 *)arena_alloc(c, n_cmt + 16);
-        rec_begin = arena_new<u64>(c, N + 1); rec_end = arena_new<u64>(c, N + 1);
-        u64 *d_unexp = arena_new<u64>(c, 3 * 257 + 1);
-        if (!bases || !s_ids || !s_cmt || !rec_begin || !rec_end || !d_unexp) return NAF_GPU_ENOMEM;
-        HIP_TRY(c, hipMemsetAsync(d_unexp, 0, (3 * 257 + 1) * 8, c->stream));
-        HIP_TRY(c, hipMemsetAsync(rec_begin, 0, (N + 1) * 8, c->stream));
-        EncOut O; O.seq = bases; O.ids = s_ids; O.cmt = s_cmt; O.rec_begin = rec_begin; O.rec_end = rec_end;
-        O.unexpected = d_unexp; O.longest = d_unexp + 3 * 257;
-        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_rec = t_rec; O.t_tail = t_tail; O.tile_eol = t_eol;
-        LAUNCH(c, "ennaf_scatter", k_enc_scatter, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
-        std::vector<u64> hu(3 * 257 + 1);
-        if ((rc = ctx_readback(c, hu.data(), d_unexp, hu.size() * 8))) return rc;
-        for (int i = 0; i < 257; i++) { R.unexpected_id[i] = hu[i]; R.unexpected_comment[i] = hu[257 + i]; R.unexpected_seq[i] = hu[514 + i]; }
-        longest = hu[3 * 257];
-        if (o->strict) {
-            for (int k = 0; k < 3; k++) for (int i = 0; i < 257; i++) if (hu[k * 257 + i])
-                return ctx_fail(c, NAF_GPU_EINPUT, k == 0 ? "unexpected character '%c' in ID\n" : k == 1 ? "unexpected character '%c' in comment\n" : "unexpected sequence code '%c'\n", i);
-        }
-    }
-    if (format != 0) {
-        // lengths
-        if (N) {
-            u64 *lu = arena_new<u64>(c, N + 2); if (!lu) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "ennaf_len_count", k_len_unit_count, cdiv(N, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, N, T, lu, all_ends);
-            if ((rc = scan_exclusive_u64(c, lu, N, lu + N + 1))) return rc;
-            u64 nu = 0; if ((rc = ctx_readback(c, &nu, lu + N + 1, 8))) return rc;
-            s_len = arena_new<u32>(c, nu + 1); if (!s_len) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "ennaf_len_write", k_len_unit_write, cdiv(N, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, N, T, (const u64 *)lu, s_len, all_ends);
-            n_lenb = nu * 4;
-        }
-        // sequence stream; the 4-bit pack also counts the soft-mask run boundaries per tile of 4096 bases
-        u64 mt = (T + MB_TILE - 1) / MB_TILE;
-        u64 *tc = nullptr;
-        if (store_mask && T) { tc = arena_new<u64>(c, mt + 2); if (!tc) return NAF_GPU_ENOMEM; }
-        if (fourbit) {
-            n_seqb = (T + 1) / 2;
-            s_seq = (u8 *)arena_alloc(c, n_seqb + 16); if (!s_seq) return NAF_GPU_ENOMEM;
-            if (T) LAUNCH(c, "ennaf_pack4", k_pack4, cdiv(T, 256 * 16), 256, 0, (const u8 *)bases, T, s_seq, tc);
-        } else {
-            if (o->no_mask && T) LAUNCH(c, "ennaf_toupper", k_toupper, cdiv(T, 256), 256, 0, bases, T);   // process.c:46-51
-            s_seq = bases; n_seqb = T;
-        }
-        // mask (only ever stored next to a 4-bit sequence stream, ennaf.c:445)
-        if (store_mask && T) {
-            if ((rc = scan_exclusive_u64(c, tc, mt, tc + mt + 1))) return rc;
-            u64 nb = 0; if ((rc = ctx_readback(c, &nb, tc + mt + 1, 8))) return rc;
-            u64 *bnd = arena_new<u64>(c, nb + 1), *ru = arena_new<u64>(c, nb + 3);
-            if (!bnd || !ru) return NAF_GPU_ENOMEM;
-            if (nb) LAUNCH(c, "ennaf_mask_bscatter", k_mask_bscatter, mt, 256, 0, (const u8 *)bases, T, (const u64 *)tc, nb, bnd);
-            LAUNCH(c, "ennaf_mask_runs", k_mask_run_units, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, ru);
-            if ((rc = scan_exclusive_u64(c, ru, nb + 1, ru + nb + 2))) return rc;
-            u64 nu = 0; if ((rc = ctx_readback(c, &nu, ru + nb + 2, 8))) return rc;
-            s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
-            HIP_TRY(c, hipMemsetAsync(s_mask, 0xFF, nu, c->stream));
-            LAUNCH(c, "ennaf_mask_units", k_mask_units_write, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, (const u64 *)ru, s_mask);
-            // Block size of the mask stream.  Real soft-masking (runs of a few hundred bases) gives a few MB of high-entropy units, i.e. a
-            // few hundred blocks whose Huffman streams the decoder walks serially: 8 KiB blocks (2 KiB streams) cut that latency to a
-            // quarter.  Very long runs give strings of 255s (constant blocks, nothing to walk): 32 KiB blocks keep the block count down.
-            mask_block_log = nu / (nb + 1) > 1000 ? 15 : 13;
-            n_mask = nu;
-        }
-    }
-    R.n_sequences = N; R.n_bases = T; R.longest_line = longest;
+    EnnafSplit S;
+    if ((rc = ennaf_split(c, d_text, n, o, format, p0, true, S))) return rc;
+    if (S.err_kind) return split_error_text(c, o->seq_type, S.err_kind, S.err_char, S.err_rec, S.err_a, S.err_b, 0);
+    EnnafCarry K; memset(&K, 0, sizeof K);
+    EnnafStreams X;
+    if ((rc = ennaf_streams(c, S, K, X))) return rc;
+    for (int i = 0; i < 257; i++) { R.unexpected_id[i] = S.unexpected[0][i]; R.unexpected_comment[i] = S.unexpected[1][i]; R.unexpected_seq[i] = S.unexpected[2][i]; R.unexpected_qual[i] = S.unexpected[3][i]; }
+    R.n_sequences = S.N; R.n_bases = S.T; R.longest_line = S.longest;
 
     // container (ennaf.c:538-589)
-    u8 hd[64 + 32]; size_t hl = 0;
-    hd[hl++] = 0x01; hd[hl++] = 0xF9; hd[hl++] = 0xEC;
-    if (seq_type == NAF_SEQ_DNA) hd[hl++] = 1; else { hd[hl++] = 2; hd[hl++] = (u8)seq_type; }
+    u8 hd[64]; size_t hl = naf_header_bytes(o, S.store_mask, S.store_qual, S.longest, S.N, hd);
     size_t tl = o->title ? strlen(o->title) : 0;
-    hd[hl++] = (u8)(((o->title ? 1 : 0) << 6) | (1 << 5) | (1 << 4) | (1 << 3) | ((store_mask ? 1 : 0) << 2) | (1 << 1) | (store_qual ? 1 : 0));
-    hd[hl++] = ' ';
-    hl += vle(o->line_length >= 0 ? (u64)o->line_length : longest, hd + hl);
-    hl += vle(N, hd + hl);
-    if (o->title) hl += vle(tl, hd + hl);
     size_t pos = 0;
     if (hl + tl > cap) return ctx_fail(c, NAF_GPU_ECAP, "ennaf output capacity %zu too small", cap);
     HIP_TRY(c, hipMemcpyAsync(d_naf, hd, hl, hipMemcpyHostToDevice, c->stream)); pos += hl;
     if (tl) { HIP_TRY(c, hipMemcpyAsync(d_naf + pos, o->title, tl, hipMemcpyHostToDevice, c->stream)); pos += tl; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     SecOut so[6]; memset(so, 0, sizeof so);
-    // ids, names and lengths are text-like / repetitive and small: always through the LZ stage (as reference level 1 does);
-    // mask, sequence and quality get it from level 2 up
-    if ((rc = put_section(c, s_ids, n_ids, n_ids, o->level, d_naf, cap, pos, so[0], 1))) return rc;
-    if ((rc = put_section(c, s_cmt, n_cmt, n_cmt, o->level, d_naf, cap, pos, so[1], 1))) return rc;
-    if ((rc = put_section(c, (const u8 *)s_len, n_lenb, n_lenb, o->level, d_naf, cap, pos, so[2], 1))) return rc;
-    if (store_mask) { if ((rc = put_section(c, s_mask, n_mask, n_mask, o->level, d_naf, cap, pos, so[3], 0, mask_block_log))) return rc; }
-    if ((rc = put_section(c, s_seq, n_seqb, T, o->level, d_naf, cap, pos, so[4]))) return rc;      // ennaf.c:582: number of bases
-    if (store_qual) { if ((rc = put_section(c, s_qual, n_qual, n_qual, o->level, d_naf, cap, pos, so[5]))) return rc; }
+    for (int i = 0; i < 6; i++)
+        if (X.present[i] && (rc = put_section(c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i]))) return rc;
     for (int i = 0; i < 6; i++) { R.section_orig[i] = so[i].orig; R.section_comp[i] = so[i].comp; }
     *naf_len = pos;
     if (rep) *rep = R;
+    return 0;
+}
+
+// ======================= one input on several GPUs (include/naf_gpu.h: "ennaf of ONE input on several GPUs") =========================
+struct EnnafShardState { EnnafSplit S; const u8 *text; u64 n; u32 shard, n_shards; bool begun; };
+
+extern "C" int naf_gpu_ennaf_sniff(naf_gpu_ctx *c, const void *d_text, size_t n, int want_format, int *format, uint64_t *p0)
+{
+    if (!c || !format || !p0 || (!d_text && n)) return NAF_GPU_EARG;
+    arena_reset(c);
+    u64 p = 0; int rc = ennaf_sniff(c, (const u8 *)d_text, n, want_format, format, &p);
+    *p0 = p;
+    return rc;
+}
+
+static int line_census(naf_gpu_ctx *c, const u8 *t, u64 n, int prev_is_eol, u64 **tile_pre, u64 *tiles_out, u64 *total)
+{
+    const u64 tiles = (n + LC_TILE - 1) / LC_TILE;
+    u64 *cnt = arena_new<u64>(c, tiles + 2); if (!cnt) return NAF_GPU_ENOMEM;
+    if (tiles) LAUNCH(c, "ennaf_line_count", k_line_count, tiles, 256, 0, t, n, prev_is_eol, cnt);
+    int rc = scan_exclusive_u64(c, cnt, tiles, cnt + tiles + 1); if (rc) return rc;
+    if ((rc = ctx_readback(c, total, cnt + tiles + 1, 8))) return rc;
+    *tile_pre = cnt; *tiles_out = tiles;
+    return 0;
+}
+
+extern "C" int naf_gpu_ennaf_count_lines(naf_gpu_ctx *c, const void *d_slice, size_t len, int prev_is_eol, uint64_t *n_line_starts)
+{
+    if (!c || !n_line_starts || (!d_slice && len)) return NAF_GPU_EARG;
+    arena_reset(c);
+    u64 *pre, tiles, total = 0;
+    int rc = line_census(c, (const u8 *)d_slice, len, prev_is_eol, &pre, &tiles, &total);
+    *n_line_starts = total;
+    return rc;
+}
+
+extern "C" int naf_gpu_ennaf_find_cut(naf_gpu_ctx *c, const void *d_slice, size_t len, int format, int prev_is_eol, uint64_t skip_lines, uint64_t *offset)
+{
+    if (!c || !offset || (!d_slice && len) || (format != NAF_FMT_FASTA && format != NAF_FMT_FASTQ)) return NAF_GPU_EARG;
+    arena_reset(c);
+    const u8 *t = (const u8 *)d_slice; int rc;
+    u64 *d_out = arena_new<u64>(c, 1); if (!d_out) return NAF_GPU_ENOMEM;
+    u64 v = len;
+    HIP_TRY(c, hipMemcpyAsync(d_out, &v, 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));                                                   // v is a stack variable
+    if (format == NAF_FMT_FASTA) {
+        // the answer is normally within the first line: look at the first 64 KiB, then at everything
+        const u64 first = len < 65536 ? len : 65536;
+        LAUNCH(c, "ennaf_eol_find", k_eol_find, 1, 256, 0, t, first, prev_is_eol, (unsigned long long *)d_out);
+        if ((rc = ctx_readback(c, &v, d_out, 8))) return rc;
+        if (v >= first && first < len) {
+            v = len;
+            HIP_TRY(c, hipMemcpyAsync(d_out, &v, 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            LAUNCH(c, "ennaf_eol_find", k_eol_find, 1024, 256, 0, t, (u64)len, prev_is_eol, (unsigned long long *)d_out);
+            if ((rc = ctx_readback(c, &v, d_out, 8))) return rc;
+        }
+        *offset = v > len ? len : v;
+        return 0;
+    }
+    u64 *pre, tiles, total = 0;
+    if ((rc = line_census(c, t, len, prev_is_eol, &pre, &tiles, &total))) return rc;
+    if (skip_lines < total) LAUNCH(c, "ennaf_line_find", k_line_find, 1, 256, 0, t, (u64)len, prev_is_eol, (const u64 *)pre, tiles, total, (u64)skip_lines, d_out);
+    if ((rc = ctx_readback(c, &v, d_out, 8))) return rc;
+    *offset = v;
+    return 0;
+}
+
+extern "C" size_t naf_gpu_ennaf_shard_bound(size_t n) { return n + n / 512 + (1 << 16); }
+
+extern "C" int naf_gpu_ennaf_shard_begin(naf_gpu_ctx *c, const void *d_slice, size_t n, const naf_gpu_ennaf_opts *o, int format,
+                                         uint32_t shard, uint32_t n_shards, naf_gpu_shard_info *info)
+{
+    if (!c || !o || !info || (!d_slice && n) || n_shards == 0 || n_shards > NAF_GPU_MAX_SHARDS || shard >= n_shards) return NAF_GPU_EARG;
+    if (format != NAF_FMT_FASTA && format != NAF_FMT_FASTQ) return ctx_fail(c, NAF_GPU_EARG, "shard_begin needs the sniffed format");
+    if (o->seq_type < 0 || o->seq_type > 3) return ctx_fail(c, NAF_GPU_EARG, "bad seq_type");
+    arena_reset(c);
+    if (!c->shard_state) c->shard_state = new EnnafShardState();
+    EnnafShardState *st = (EnnafShardState *)c->shard_state;
+    st->begun = false; st->text = (const u8 *)d_slice; st->n = n; st->shard = shard; st->n_shards = n_shards;
+    EnnafSplit &S = st->S;
+    int rc = ennaf_split(c, st->text, n, o, format, 0, shard + 1 == n_shards, S); if (rc) return rc;
+    memset(info, 0, sizeof *info);
+    info->shard = shard; info->n_shards = n_shards; info->format = format; info->seq_type = o->seq_type; info->text_len = n;
+    info->store_mask = S.store_mask; info->store_quality = S.store_qual;
+    info->err_kind = S.err_kind; info->err_char = S.err_char; info->err_record = S.err_rec; info->err_a = S.err_a; info->err_b = S.err_b;
+    st->begun = true;
+    if (S.err_kind) return 0;                                                                      // reported by every shard's finish
+    info->n_sequences = S.N; info->n_bases = S.T; info->longest_line = S.longest; info->lead_bases = S.lead;
+    info->n_ids = S.n_ids; info->n_comments = S.n_cmt; info->n_quality = S.n_qual;
+    memcpy(info->unexpected, S.unexpected, sizeof S.unexpected);
+    S.census = true; S.mask_first = ~0ull;
+    if (S.T) {
+        if (S.store_mask) {
+            const u64 mt = (S.T + MB_TILE - 1) / MB_TILE;
+            S.tc = arena_new<u64>(c, mt + 2); unsigned long long *d_o = arena_new<unsigned long long>(c, 3);
+            if (!S.tc || !d_o) return NAF_GPU_ENOMEM;
+            u64 init[3] = { ~0ull, 0, 0 };
+            HIP_TRY(c, hipMemcpyAsync(d_o, init, 24, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            LAUNCH(c, "ennaf_mask_census", k_mask_census, mt, 256, 0, (const u8 *)S.bases, S.T, S.tc, d_o);
+            u64 *d_tot = arena_new<u64>(c, 1); if (!d_tot) return NAF_GPU_ENOMEM;
+            u64 got[3]; if ((rc = ctx_readback(c, got, d_o, 24))) return rc;
+            S.mask_first = got[0]; S.mask_last = got[1]; S.first_base = (u8)got[2]; S.last_base = (u8)(got[2] >> 8);
+            // number of changes: the per-tile counts are summed by the scan of the finish; here a reduction of the same array
+            u64 *tmp = arena_new<u64>(c, mt + 2); if (!tmp) return NAF_GPU_ENOMEM;
+            HIP_TRY(c, hipMemcpyAsync(tmp, S.tc, mt * 8, hipMemcpyDeviceToDevice, c->stream));
+            if ((rc = scan_exclusive_u64(c, tmp, mt, d_tot))) return rc;
+            if ((rc = ctx_readback(c, &S.mask_changes, d_tot, 8))) return rc;
+        } else {
+            if ((rc = ctx_readback2(c, &S.first_base, S.bases, 1, &S.last_base, S.bases + S.T - 1, 1))) return rc;
+        }
+    }
+    info->mask_changes = S.mask_changes; info->mask_first_change = S.mask_first; info->mask_last_change = S.mask_last;
+    info->first_base = S.first_base; info->last_base = S.last_base;
+    return 0;
+}
+
+// What shard k inherits from and owes to its neighbours, from everybody's info.
+struct ShardView { EnnafCarry K; u64 rec0; bool first[6], last[6]; };
+static bool shard_mask_b0(const naf_gpu_shard_info *in, uint32_t j)                               // case change at the first base of shard j
+{
+    bool prev = false;                                                                             // "unmasked" in front of base 0
+    for (uint32_t i = 0; i < j; i++) if (in[i].n_bases) prev = in[i].last_base >= 96;
+    return in[j].n_bases && ((in[j].first_base >= 96) != prev);
+}
+static void shard_view(const naf_gpu_shard_info *in, uint32_t n, uint32_t k, ShardView &V)
+{
+    memset(&V, 0, sizeof V);
+    const bool fourbit = in[k].seq_type <= NAF_SEQ_RNA;
+    u64 S_k = 0; bool any_before = false, prev_masked = false;
+    for (uint32_t j = 0; j < k; j++) { S_k += in[j].n_bases; V.rec0 += in[j].n_sequences; if (in[j].n_bases) { any_before = true; prev_masked = in[j].last_base >= 96; } }
+    EnnafCarry &K = V.K;
+    // 4-bit parity (encoders.c:30-69)
+    auto skip_of = [&](uint32_t j, u64 Sj) -> u32 { return (fourbit && (Sj & 1) && in[j].n_bases) ? 1u : 0u; };
+    K.skip_first = skip_of(k, S_k);
+    if (fourbit && in[k].n_bases && ((in[k].n_bases - K.skip_first) & 1))
+        for (uint32_t j = k + 1; j < n; j++) if (in[j].n_bases) { K.tail_hi = nuc4_host(in[j].first_base); break; }
+    // the record a FASTA cut falls into (process.c:424)
+    if (in[k].n_sequences)
+        for (uint32_t j = k + 1; j < n; j++) { if (in[j].n_sequences) { K.tail_extra += in[j].lead_bases; break; } K.tail_extra += in[j].n_bases; }
+    // soft-mask runs (encoders.c:126-146)
+    K.prev_masked = prev_masked; K.skip_run0 = any_before;
+    if (in[k].n_bases)
+        for (uint32_t j = k + 1; j < n; j++) {
+            if (!in[j].n_bases) continue;
+            if (shard_mask_b0(in, j)) break;
+            if (in[j].mask_changes) { K.run_ext += in[j].mask_first_change; break; }
+            K.run_ext += in[j].n_bases;
+        }
+    // which parts exist: the frame header goes in front of shard 0's part, the last block flag on the last part that has bytes
+    auto has = [&](uint32_t j, int s) -> bool {
+        switch (s) {
+        case 0: return in[j].n_ids != 0;
+        case 1: return in[j].n_comments != 0;
+        case 2: return in[j].n_sequences != 0;
+        case 3: { if (!in[j].store_mask || !in[j].n_bases) return false;
+                  bool before = false; for (uint32_t i = 0; i < j; i++) if (in[i].n_bases) before = true;
+                  return !before || shard_mask_b0(in, j) || in[j].mask_changes != 0; }
+        case 4: { u64 Sj = 0; for (uint32_t i = 0; i < j; i++) Sj += in[i].n_bases; return in[j].n_bases > skip_of(j, Sj); }
+        default: return in[j].n_quality != 0;
+        }
+    };
+    for (int s = 0; s < 6; s++) {
+        int lastj = -1;
+        for (uint32_t j = 0; j < n; j++) if (has(j, s)) lastj = (int)j;
+        V.first[s] = k == 0;
+        V.last[s] = lastj < 0 ? (k + 1 == n) : ((int)k == lastj);
+    }
+}
+
+static int shards_error(naf_gpu_ctx *c, const naf_gpu_shard_info *in, uint32_t n)
+{
+    u64 rec0 = 0;
+    for (uint32_t j = 0; j < n; j++) {
+        if (in[j].err_kind) return split_error_text(c, in[j].seq_type, in[j].err_kind, in[j].err_char, in[j].err_record, in[j].err_a, in[j].err_b, rec0);
+        rec0 += in[j].n_sequences;
+    }
+    return 0;
+}
+
+extern "C" int naf_gpu_ennaf_shard_finish(naf_gpu_ctx *c, const naf_gpu_ennaf_opts *o, const naf_gpu_shard_info *infos, void *d_pieces_, size_t cap, naf_gpu_shard_pieces *pieces)
+{
+    if (!c || !o || !infos || !pieces || !d_pieces_) return NAF_GPU_EARG;
+    EnnafShardState *st = (EnnafShardState *)c->shard_state;
+    if (!st || !st->begun) return ctx_fail(c, NAF_GPU_EARG, "shard_finish without shard_begin");
+    st->begun = false;
+    const uint32_t n = st->n_shards, k = st->shard;
+    for (uint32_t j = 0; j < n; j++) if (infos[j].shard != j || infos[j].n_shards != n) return ctx_fail(c, NAF_GPU_EARG, "shard infos out of order");
+    int rc = shards_error(c, infos, n); if (rc) return rc;
+    ShardView V; shard_view(infos, n, k, V);
+    EnnafStreams X;
+    if ((rc = ennaf_streams(c, st->S, V.K, X))) return rc;
+    memset(pieces, 0, sizeof *pieces);
+    u8 *dst = (u8 *)d_pieces_; size_t pos = 0;
+    for (int i = 0; i < 6; i++) {
+        if (!X.present[i]) continue;
+        const size_t need = naf_gpu_zstd_compress_bound(X.len[i]);
+        if (pos + need > cap) return ctx_fail(c, NAF_GPU_ECAP, "shard piece buffer of %zu bytes is too small", cap);
+        size_t clen = 0;
+        const int flags = ZENC_PART | (V.first[i] ? ZENC_PART_FIRST : 0) | (V.last[i] ? ZENC_PART_LAST : 0);
+        if ((rc = zstd_encode(c, X.ptr[i], X.len[i], o->level, dst + pos, cap - pos, &clen, flags, X.lz[i], X.block_log[i]))) return rc;
+        pieces->off[i] = pos; pieces->len[i] = clen; pieces->raw[i] = X.orig[i];
+        pos += (clen + 15) & ~(size_t)15;
+    }
+    pieces->total = pos;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int naf_gpu_ennaf_stitch_plan(const naf_gpu_ennaf_opts *o, const naf_gpu_shard_info *in, const naf_gpu_shard_pieces *pc, uint32_t n,
+                                         naf_gpu_stitch_seg *segs, size_t seg_cap, size_t *n_segs, uint8_t *lit, size_t lit_cap, size_t *lit_len,
+                                         uint64_t *naf_len, naf_gpu_ennaf_report *rep)
+{
+    if (!o || !in || !pc || !segs || !n_segs || !lit || !lit_len || !naf_len || n == 0 || n > NAF_GPU_MAX_SHARDS) return NAF_GPU_EARG;
+    const size_t tl = o->title ? strlen(o->title) : 0;
+    if (seg_cap < 7 + 6 * (size_t)n || lit_cap < 256 + tl) return NAF_GPU_ECAP;
+    naf_gpu_ennaf_report R; memset(&R, 0, sizeof R);
+    R.format = in[0].format;
+    for (uint32_t j = 0; j < n; j++) {
+        if (in[j].err_kind) return NAF_GPU_EINPUT;
+        R.n_sequences += in[j].n_sequences; R.n_bases += in[j].n_bases;
+        if (in[j].longest_line > R.longest_line) R.longest_line = in[j].longest_line;
+        for (int i = 0; i < 257; i++) { R.unexpected_id[i] += in[j].unexpected[0][i]; R.unexpected_comment[i] += in[j].unexpected[1][i];
+                                        R.unexpected_seq[i] += in[j].unexpected[2][i]; R.unexpected_qual[i] += in[j].unexpected[3][i]; }
+    }
+    const bool present[6] = { true, true, true, in[0].store_mask != 0, true, in[0].store_quality != 0 };
+    size_t ns = 0, ll = 0; u64 pos = 0;
+    size_t hl = naf_header_bytes(o, present[3], present[5], R.longest_line, R.n_sequences, lit);
+    if (tl) memcpy(lit + hl, o->title, tl);
+    segs[ns++] = { 0, hl + tl, 0, -1, -1 }; ll = hl + tl; pos = hl + tl;
+    for (int s = 0; s < 6; s++) {
+        if (!present[s]) continue;
+        u64 orig = 0, comp = 0;
+        for (uint32_t j = 0; j < n; j++) { orig += pc[j].raw[s]; comp += pc[j].len[s]; }
+        if (s == 4) orig = R.n_bases;                                                              // ennaf.c:582: number of bases
+        size_t h0 = ll; ll += vle(orig, lit + ll); ll += vle(comp, lit + ll);
+        segs[ns++] = { pos, ll - h0, h0, -1, s }; pos += ll - h0;
+        for (uint32_t j = 0; j < n; j++) if (pc[j].len[s]) { segs[ns++] = { pos, pc[j].len[s], pc[j].off[s], (int32_t)j, s }; pos += pc[j].len[s]; }
+        R.section_orig[s] = orig; R.section_comp[s] = comp;
+    }
+    *n_segs = ns; *lit_len = ll; *naf_len = pos;
+    if (rep) *rep = R;
+    return 0;
+}
+
+extern "C" int naf_gpu_ennaf_stitch(naf_gpu_ctx *c, const naf_gpu_stitch_seg *segs, size_t n_segs, const uint8_t *lit, const void *const *bufs, void *d_naf, size_t cap)
+{
+    if (!c || !segs || !lit || !bufs || !d_naf) return NAF_GPU_EARG;
+    for (size_t i = 0; i < n_segs; i++) {
+        const naf_gpu_stitch_seg &g = segs[i];
+        if (g.dst_off + g.len > cap) return ctx_fail(c, NAF_GPU_ECAP, "ennaf output capacity %zu too small", cap);
+        if (!g.len) continue;
+        if (g.shard < 0) HIP_TRY(c, hipMemcpyAsync((u8 *)d_naf + g.dst_off, lit + g.src_off, g.len, hipMemcpyHostToDevice, c->stream));
+        else HIP_TRY(c, hipMemcpyAsync((u8 *)d_naf + g.dst_off, (const u8 *)bufs[g.shard] + g.src_off, g.len, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));                                                   // lit is the caller's
+    return 0;
+}
+
+void ennaf_shard_state_free(naf_gpu_ctx *c) { delete (EnnafShardState *)c->shard_state; c->shard_state = nullptr; }
+
+extern "C" int naf_gpu_ennaf_shard_carry(const naf_gpu_shard_info *infos, uint32_t n, uint32_t k, naf_gpu_shard_carry *out)
+{
+    if (!infos || !out || n == 0 || n > NAF_GPU_MAX_SHARDS || k >= n) return NAF_GPU_EARG;
+    ShardView V; shard_view(infos, n, k, V);
+    memset(out, 0, sizeof *out);
+    out->first_record = V.rec0; out->tail_extra = V.K.tail_extra; out->run_ext = V.K.run_ext;
+    out->skip_first = V.K.skip_first; out->tail_hi = V.K.tail_hi; out->prev_masked = V.K.prev_masked; out->skip_run0 = V.K.skip_run0;
+    for (int s = 0; s < 6; s++) { out->first[s] = V.first[s]; out->last[s] = V.last[s]; }
     return 0;
 }

@@ -381,7 +381,7 @@ __device__ __forceinline__ void huf_encode_stream_staged(u8 *out, const u8 *src,
 
 // LZ-coded blocks (mode[b] != 0) take their literals from L.lits with the plan / codes / tree of those literals (plan1 ...)
 // and append the Sequences_Section made by k_lz_seqenc; all other blocks are coded from src as literal-only blocks.
-struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u16 *codes1; const u8 *trees1; LzBufs B; };
+struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u16 *codes1; const u8 *trees1; LzBufs B; u32 not_last; };   // not_last: the frame continues behind these blocks (a shard's part of a frame)
 __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nblk, const ZEncPlan *plan, const u16 *codes_g, const u8 *trees,
                                                     const u64 *offs, u8 *dst, u64 frame_hdr, ZWriteLz L)
 {
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
         if (!lzb) {
             const ZEncPlan p = plan[b];
             u64 lo = zenc_block_lo(n, nblk, b);
-            if (k == 0) zenc_write_block_prefix(out, p, trees + (u64)b * ZENC_TREE_SLOT, b + 1 == nblk, p.n ? src[lo] : 0);
+            if (k == 0) zenc_write_block_prefix(out, p, trees + (u64)b * ZENC_TREE_SLOT, b + 1 == nblk && !L.not_last, p.n ? src[lo] : 0);
             if (p.kind == ZK_HUF) {
                 u32 per = (p.n + 3) / 4;
                 u32 cnt = k < 3 ? per : p.n - 3 * per;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
             const ZEncPlan p = L.plan1[b];                          // plan of the block's literals (p.n = their number)
             const u8 *lits = L.B.lits + (u64)b * L.B.slot;
             const u32 lsec = lz_lit_section_bytes(p), sbytes = L.B.seq_bytes[b];
-            if (k == 0) zenc_write_block_header(out, 2, lsec + sbytes, b + 1 == nblk);
+            if (k == 0) zenc_write_block_header(out, 2, lsec + sbytes, b + 1 == nblk && !L.not_last);
             if (p.kind == ZK_HUF) {
                 if (k == 0) zenc_write_huf_lit_prefix(out + 3, p, L.trees1 + (u64)b * ZENC_TREE_SLOT);
                 u32 per = (p.n + 3) / 4;
@@ -466,8 +466,18 @@ extern "C" size_t naf_gpu_zstd_compress_bound(size_t n)
 }
 
 // block_log: log2 of the target block size (clamped to 17 = the format maximum of 128 KiB)
+// with_magic: 1 = whole frame with its magic number, 0 = whole frame without it (as stored in a .naf section),
+//   ZENC_PART | ZENC_PART_FIRST | ZENC_PART_LAST = a shard's part of a frame: blocks only, behind the 2-byte frame header when
+//   FIRST, ending the frame when LAST (an empty part that is not LAST is zero bytes; an empty LAST part is one empty Raw block).
 int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz, int block_log_hint)
 {
+    const bool part = (with_magic & ZENC_PART) != 0, part_first = (with_magic & ZENC_PART_FIRST) != 0, part_last = (with_magic & ZENC_PART_LAST) != 0;
+    if (part) with_magic = 0;
+    if (part && n == 0 && !part_last) {
+        if (part_first) { if (cap < 2) return ctx_fail(c, NAF_GPU_ECAP, "zstd_compress capacity %zu too small", cap); LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, 0); }
+        *out_len = part_first ? 2 : 0;
+        return 0;
+    }
     u32 block_log = 15;                                          // 32 KiB: 4 streams of 8 KiB; more streams = more decode parallelism
     if (block_log_hint >= 10 && block_log_hint <= 17) block_log = (u32)block_log_hint;
     const char *e = getenv("NAF_GPU_BLOCK_LOG");
@@ -484,7 +494,7 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
     u64 nblk64 = n ? (n + bs - 1) / bs : 1;
     if (nblk64 > 0x7FFFFFFFull) return ctx_fail(c, NAF_GPU_EARG, "stream too large");
     u32 nblk = (u32)nblk64;
-    u64 hdr = with_magic ? 6 : 2;
+    u64 hdr = with_magic ? 6 : (part && !part_first) ? 0 : 2;
     if (cap < hdr + n + 3ull * nblk) return ctx_fail(c, NAF_GPU_ECAP, "zstd_compress capacity %zu too small (bound %llu)", cap, (unsigned long long)(hdr + n + 3ull * nblk));
     ZEncPlan *plan = arena_new<ZEncPlan>(c, nblk);
     u16 *codes = arena_new<u16>(c, (size_t)nblk * 256); u8 *trees = (u8 *)arena_alloc(c, (size_t)nblk * ZENC_TREE_SLOT);
@@ -500,6 +510,7 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
     if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse);
     LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse);
     ZWriteLz L; memset(&L, 0, sizeof L);
+    L.not_last = part && !part_last;
     if (use_lz && n >= 64) {
         if (!c->d_seqctab) {
             SeqCTabs T; zenc_build_predefined(T);
@@ -522,7 +533,7 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
         L.mode = mode; L.plan1 = plan1; L.codes1 = codes1; L.trees1 = trees1; L.B = B;
     }
     int rc = scan_exclusive_u64(c, offs, nblk, offs + nblk + 1); if (rc) return rc;
-    LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, with_magic);
+    if (hdr) LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, with_magic);
     LAUNCH(c, "zenc_write", k_zenc_write, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, d_src, (u64)n, nblk, (const ZEncPlan *)plan, (const u16 *)codes, (const u8 *)trees,
            (const u64 *)offs, d_dst, hdr, L);
     u64 total = 0;

@@ -27,14 +27,6 @@ static void set_format(const char *s)
     if (fmt_cmd == NAF_FMT_AUTO) die("unknown input format specified: \"%s\"\n", s);
 }
 static void set_level(char *str) { char *end; long a = strtol(str, &end, 10); if (a < -131072 || a > 22 || *end) die("invalid value of --level, should be from %ld to %ld\n", -131072l, 22l); level = (int)a; }
-static long long parse_ll(char *str, const char *what)
-{
-    char *end; long long a = strtoll(str, &end, 10);
-    if (*end != '\0') die("can't parse the value of %s\n", what);
-    char t[21]; int nc = snprintf(t, 21, "%lld", a);
-    if (nc < 1 || nc > 20 || strcmp(t, str) != 0) die("can't parse the value of %s\n", what);
-    return a;
-}
 static void show_help(void)
 {
     msg("Usage: ennaf [OPTIONS] [infile]\nOptions:\n"
@@ -58,8 +50,8 @@ static void parse_command_line(int argc, char **argv)
                     if (!strcmp(argv[i], "--name")) { i++; if (!*argv[i]) die("empty --name parameter\n"); continue; }
                     if (!strcmp(argv[i], "--title")) { i++; if (title) die("double --title parameter\n"); if (!*argv[i]) die("empty --title parameter\n"); title = argv[i]; continue; }
                     if (!strcmp(argv[i], "--level")) { i++; set_level(argv[i]); continue; }
-                    if (!strcmp(argv[i], "--line-length")) { i++; long long a = parse_ll(argv[i], "--line-length parameter"); if (a < 0) die("negative line length specified\n"); requested_line_length = a; line_length_is_specified = true; continue; }
-                    if (!strcmp(argv[i], "--long")) { i++; long long a = parse_ll(argv[i], "--long argument");
+                    if (!strcmp(argv[i], "--line-length")) { i++; long long a; int how = decimal_arg(argv[i], &a); if (how == 0) die("can't parse the value of --line-length parameter\n"); if (a < 0) die("negative line length specified\n"); if (how != 2) die("can't parse the value of --line-length parameter\n"); requested_line_length = a; line_length_is_specified = true; continue; }
+                    if (!strcmp(argv[i], "--long")) { i++; long long a; if (decimal_arg(argv[i], &a) != 2) die("can't parse the value of --long argument\n");
                         if (a < 10) warn("--long value of is %lld is smaller than the lowest supported value %d, using %d instead\n", a, 10, 10);
                         else if (a > 31) warn("--long value of is %lld is larger than the largest supported value %d, using %d instead\n", a, 31, 31);
                         continue; }

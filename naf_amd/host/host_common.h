@@ -42,6 +42,32 @@ static void phase(const char *what)
     t_last = t;
 }
 
+/* A decimal command-line argument, judged the way the reference judges one: strtoll must consume the whole argument, and the
+ * value printed back with %lld must reproduce the argument byte for byte (unnaf/src/unnaf.c:224-239, ennaf/src/ennaf.c:230-273).
+ * Returns 0 when strtoll would stop early or convert nothing (trailing garbage), 1 when it converts but the argument is not
+ * the canonical spelling of the value (white space, '+', leading zeros, "-0", out of range), 2 when it is.  *v as strtoll
+ * would return it (saturated), for results 1 and 2. */
+__attribute__((unused)) static int decimal_arg(const char *s, long long *v)
+{
+    const char *p = s;
+    while (*p == ' ' || (*p >= '\t' && *p <= '\r')) p++;
+    bool neg = false;
+    if (*p == '+' || *p == '-') { neg = *p == '-'; p++; }
+    const char *digits = p;
+    const unsigned long long lim = neg ? 9223372036854775808ull : 9223372036854775807ull;
+    unsigned long long mag = 0; bool saturated = false;
+    for (; *p >= '0' && *p <= '9'; p++) {
+        unsigned dg = (unsigned)(*p - '0');
+        if (saturated || mag > (lim - dg) / 10) { saturated = true; mag = lim; } else mag = mag * 10 + dg;
+    }
+    *v = 0;
+    if (p == digits) return s[0] ? 0 : 1;              /* nothing converted: only the empty argument gets past the end test */
+    if (*p) return 0;
+    *v = neg ? (long long)(0ull - mag) : (long long)mag;
+    bool canonical = !saturated && digits == s + (neg ? 1 : 0) && !(digits[0] == '0' && digits[1]) && !(neg && mag == 0);
+    return canonical ? 2 : 1;
+}
+
 static naf_gpu_ctx *gpu = NULL;
 static void gpu_open(void)
 {

@@ -17,11 +17,10 @@ static void set_out_type(OUTPUT_TYPE t) { if (out_type != UNDECIDED) die("only o
 
 static void set_line_length(char *str)
 {
-    char *end; long long a = strtoll(str, &end, 10);
-    if (*end != '\0') die("can't parse the value of --line-length parameter\n");
-    if (a < 0ll) die("negative line length specified\n");
-    char t[21]; int nc = snprintf(t, 21, "%lld", a);
-    if (nc < 1 || nc > 20 || strcmp(t, str) != 0) die("can't parse the value of --line-length parameter\n");
+    long long a; int how = decimal_arg(str, &a);
+    if (how == 0) die("can't parse the value of --line-length parameter\n");
+    if (a < 0) die("negative line length specified\n");
+    if (how != 2) die("can't parse the value of --line-length parameter\n");
     requested_line_length = a; line_length_is_specified = true;
 }
 
@@ -100,6 +99,20 @@ static unsigned char *load_section(int i, const char *what)
     return h;
 }
 
+/* ids / names: N strings, each with its terminator inside the section (input.c:145-200: "not 0-terminated", then the walk that
+ * stops at "can't read id %llu" when the section holds fewer than N of them -- "currupted" is the reference's spelling for ids) */
+static unsigned char *load_strings(int i, const char *what, unsigned long long n_strings)
+{
+    unsigned long long n = H.orig_size[i];
+    if (n == 0) die("corrupted %s - not 0-terminated\n", what);
+    unsigned char *b = load_section(i, what);
+    if (b[n - 1] != 0) die("corrupted %s - not 0-terminated\n", what);
+    unsigned long long have = 0;
+    for (const unsigned char *p = b, *e = b + n; p < e && have < n_strings; have++) p = (const unsigned char *)memchr(p, 0, (size_t)(e - p)) + 1;
+    if (have < n_strings) { if (i == 0) die("currupted ids - can't read id %llu\n", have); else die("corrupted names - can't read name %llu\n", have); }
+    return b;
+}
+
 static void run_text(int mode, int masking_allowed)
 {
     upload();
@@ -167,10 +180,10 @@ int main(int argc, char **argv)
     }
     else if (out_type == TITLE) { if (has_title) fwrite(naf + H.title_off, 1, H.title_len, OUT); fputc('\n', OUT); }
     else if (N != 0) {
-        if (out_type == IDS) { if (has_ids) { unsigned char *b = load_section(0, "ids"); const char *p = (const char *)b; for (unsigned long long i = 0; i < N; i++) { fprintf(OUT, "%s\n", p); p += strlen(p) + 1; } free(b); } }
+        if (out_type == IDS) { if (has_ids) { unsigned char *b = load_strings(0, "ids", N); const char *p = (const char *)b; for (unsigned long long i = 0; i < N; i++) { fprintf(OUT, "%s\n", p); p += strlen(p) + 1; } free(b); } }
         else if (out_type == NAMES) {
             if (has_ids || has_names) {
-                unsigned char *a = has_ids ? load_section(0, "ids") : NULL, *b = has_names ? load_section(1, "names") : NULL;
+                unsigned char *a = has_ids ? load_strings(0, "ids", N) : NULL, *b = has_names ? load_strings(1, "names", N) : NULL;
                 const char *p = (const char *)a, *q = (const char *)b;
                 for (unsigned long long i = 0; i < N; i++) {
                     if (p) { fputs(p, OUT); p += strlen(p) + 1; }

@@ -1,11 +1,27 @@
-"""Multi-GPU sharding of one archive: every rank produces a contiguous byte range of
-the output text with naf_gpu_unnaf_range; the ranges are gathered to one rank with a single collective
-(RCCL all_gather over xGMI on GPUs; the same code runs on gloo for the CPU tests).  No other exchange
-is needed: record / line / mask context is recomputed per rank from the (small) side streams."""
+"""One archive on several GPUs (BASELINE configs[3] and [4]).
+
+Decode: every rank produces a contiguous byte range of the output text with naf_gpu_unnaf_range (record / line / mask context is
+recomputed per rank from the small side streams) and the ranges are gathered to one rank: the root posts one receive per peer
+straight into that peer's place in the output buffer, the peers send -- a gather-to-root of unequal segments as one group of
+point-to-point transfers (ncclGroupStart / ncclSend / ncclRecv on RCCL: xGMI is point-to-point, each peer's segment travels over
+its own link into the root).  No padding, no copy of the whole text on every rank.
+
+Encode: the text is cut into one slice per rank, every rank runs naf_gpu_ennaf_shard_begin / _finish on its slice, the fixed-size
+shard records are all-gathered in between, and the compressed parts are gathered into ONE archive with one zstd frame per stream
+(include/naf_gpu.h, "ennaf of ONE input on several GPUs").
+
+The same functions run on gloo with CPU tensors (tests/test_host_cpu.py drives them with a stand-in context)."""
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
+from . import capi
 
+EOL = (0x0A, 0x0B, 0x0C, 0x0D)
+
+
+# ---------------------------------------------------------------------------------------------------------------- decode
 def byte_range(total: int, rank: int, world: int, align: int = 4096):
     """Contiguous [begin, end) of rank's share; boundaries aligned so each rank writes whole 4 KiB tiles."""
     per = (total + world - 1) // world
@@ -15,32 +31,232 @@ def byte_range(total: int, rank: int, world: int, align: int = 4096):
     return b, e
 
 
-def gather_ranges(local: torch.Tensor, total: int, dst: int = 0, group=None):
-    """Concatenate every rank's range on `dst` (None elsewhere).  One all_gather on equal-size padded
-    segments: xGMI is point-to-point, so one large collective beats many small sends."""
+def _p2p(ops):
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def gather_ranges(local: torch.Tensor, total: int, dst: int = 0, group=None, out: torch.Tensor = None):
+    """Gather-to-root of every rank's byte range: returns the whole text on `dst` (None elsewhere).  `out`: where the root
+    wants it (at least `total` bytes); the root's own range is copied in place, the others are received in place."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    per = max(byte_range(total, r, world)[1] - byte_range(total, r, world)[0] for r in range(world))
-    seg = torch.zeros(per, dtype=torch.uint8, device=local.device)
-    seg[: local.numel()] = local
-    out = [torch.empty(per, dtype=torch.uint8, device=local.device) for _ in range(world)]
-    dist.all_gather(out, seg, group=group)
     if rank != dst:
+        if local.numel():
+            _p2p([dist.P2POp(dist.isend, local, dst, group)])
         return None
-    parts = []
+    if out is None:
+        out = torch.empty(max(total, 1), dtype=torch.uint8, device=local.device)
+    ops = []
     for r in range(world):
         b, e = byte_range(total, r, world)
-        parts.append(out[r][: e - b])
-    return torch.cat(parts)
+        if e == b:
+            continue
+        if r == rank:
+            out[b:e].copy_(local[: e - b])
+        else:
+            ops.append(dist.P2POp(dist.irecv, out[b:e], r, group))
+    _p2p(ops)
+    return out[:total]
 
 
-def unnaf_sharded(ctx, d_naf, out_type=0, use_mask=True, line_length=-1, dst=0, group=None):
-    """Each rank holds the archive (it is ~25 % of the text); returns the whole text on `dst`."""
-    total = ctx.unnaf_size(d_naf, out_type, use_mask, line_length)
+def unnaf_sharded(ctx, d_naf, out_type=0, use_mask=True, line_length=-1, dst=0, group=None, out=None, total=None, scratch=None):
+    """Each rank holds the archive (it is ~25 % of the text) and decodes its byte range of the text; the root decodes its own
+    range straight into its place of `out` and receives the others in place.  Returns the whole text on `dst`, None elsewhere.
+    `scratch`: buffer for a non-root rank's range (allocated when missing)."""
+    if total is None:
+        total = ctx.unnaf_size(d_naf, out_type, use_mask, line_length)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     b, e = byte_range(total, rank, world)
-    local = ctx.unnaf_range(d_naf, b, e, out_type, use_mask, line_length)
     if world == 1:
-        return local
-    return gather_ranges(local, total, dst, group)
+        return ctx.unnaf_range(d_naf, b, e, out_type, use_mask, line_length, out=out)
+    if rank != dst:
+        if e > b:
+            local = ctx.unnaf_range(d_naf, b, e, out_type, use_mask, line_length, out=scratch)
+            _p2p([dist.P2POp(dist.isend, local, dst, group)])
+        return None
+    if out is None:
+        out = torch.empty(max(total, 1), dtype=torch.uint8, device=d_naf.device)
+    if e > b:
+        ctx.unnaf_range(d_naf, b, e, out_type, use_mask, line_length, out=out[b:e])
+    ops = []
+    for r in range(world):
+        rb, re_ = byte_range(total, r, world)
+        if r != rank and re_ > rb:
+            ops.append(dist.P2POp(dist.irecv, out[rb:re_], r, group))
+    _p2p(ops)
+    return out[:total]
+
+
+# ---------------------------------------------------------------------------------------------------------------- encode
+def make_opts(fmt=capi.FMT_AUTO, seq_type=capi.SEQ_DNA, no_mask=False, strict=False, level=1, line_length=-1, title=None):
+    return capi.EnnafOpts(fmt, seq_type, int(no_mask), int(strict), level, line_length, title)
+
+
+def _is_eol(b):
+    return int(b) in EOL
+
+
+def cuts_local(ctx, d_text, fmt, p0, n_shards):
+    """Start offset of every shard (n_shards + 1 entries, the last one = len) of a text one context can address: nominal equal
+    slices moved forward to the next place a shard may begin (FASTA: behind an EOL; FASTQ: a line start whose ordinal is 0 mod 4)."""
+    n = d_text.numel()
+    cuts = [p0]
+    for k in range(1, n_shards):
+        a = p0 + (n - p0) * k // n_shards
+        a = max(a, cuts[-1])
+        if a >= n or a == 0:
+            cuts.append(min(a, n) if a else cuts[-1])
+            continue
+        # the slice handed to the library starts one byte early with prev_is_eol = 0: that byte decides about position a itself
+        if fmt == capi.FMT_FASTA:
+            off = ctx.ennaf_find_cut(d_text[a - 1:], fmt, False)
+        else:
+            lines = ctx.ennaf_count_lines(d_text[p0:a], True) if a > p0 else 0
+            off = ctx.ennaf_find_cut(d_text[a - 1:], fmt, False, (-lines) % 4)
+        cuts.append(min(n, a - 1 + off))
+    cuts.append(n)
+    return cuts
+
+
+def ennaf_sharded_local(ctxs, d_text, opts=None, out=None):
+    """N contexts of one process (one per device, or several on one device): returns (archive, report).  Each context sees a
+    view of the same text; with one device per context the caller places the slices (see naf_amd/host/ennaf.c)."""
+    opts = opts or make_opts()
+    c0 = ctxs[0]
+    fmt, p0 = c0.ennaf_sniff(d_text, opts.format)
+    if fmt == 0 or len(ctxs) == 1:
+        return c0.ennaf(d_text, seq_type=opts.seq_type, fmt=opts.format, no_mask=bool(opts.no_mask), level=opts.level,
+                        line_length=opts.line_length, title=opts.title, out=out, strict=bool(opts.strict))
+    n = len(ctxs)
+    cuts = cuts_local(c0, d_text, fmt, p0, n)
+    slices = [d_text[cuts[k]:cuts[k + 1]] for k in range(n)]
+    infos = [ctxs[k].ennaf_shard_begin(slices[k], opts, fmt, k, n) for k in range(n)]
+    bufs, pieces = [], []
+    for k in range(n):
+        b, pc = ctxs[k].ennaf_shard_finish(opts, infos, slices[k].numel())
+        bufs.append(b)
+        pieces.append(pc)
+    segs, lit, naf_len, rep = capi.stitch_plan(opts, infos, pieces)
+    if out is None:
+        out = torch.empty(max(naf_len, 1), dtype=torch.uint8, device=d_text.device)
+    c0.ennaf_stitch(segs, lit, bufs, out)
+    return out[:naf_len], rep
+
+
+def _all_gather_bytes(raw: bytes, device, group):
+    """all_gather of one fixed-size record per rank."""
+    world = dist.get_world_size(group)
+    t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t, group=group)
+    return [bytes(o.cpu().numpy().tobytes()) for o in outs]
+
+
+def _all_gather_ints(vals, device, group):
+    world = dist.get_world_size(group)
+    t = torch.tensor(list(vals), dtype=torch.int64, device=device)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t, group=group)
+    return [[int(x) for x in o.cpu().tolist()] for o in outs]
+
+
+def ennaf_sharded(ctx, d_buf, n, opts=None, dst=0, group=None, everywhere=False):
+    """Ranks of a process group; rank r holds bytes [a_r, a_{r+1}) of the text in d_buf[:n] (consecutive slices in rank order;
+    d_buf may be longer than n: spare room behind the slice takes the few bytes a shard borrows from the next slice).
+    Returns (archive, report, info) on `dst` -- on every rank with everywhere=True -- and (None, report, info) elsewhere;
+    info = {"cut": bytes of this slice that went to the previous shard, "halo": bytes borrowed from the following slices}."""
+    opts = opts or make_opts()
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = d_buf.device
+    # format and first record: rank 0 looks at its slice, everybody hears
+    meta = [0, 0]
+    if rank == 0:
+        meta = list(ctx.ennaf_sniff(d_buf[:n], opts.format))
+    meta = _all_gather_ints(meta, dev, group)[0]
+    fmt, p0 = meta
+    if fmt == 0:
+        raise ValueError("empty input: nothing to shard")
+    lo = p0 if rank == 0 else 0
+    # byte in front of every slice: an EOL makes position 0 of the slice a place where a line starts
+    last = int(d_buf[n - 1].item()) if n > lo else -1
+    tails = _all_gather_ints([last], dev, group)
+    prev = 0x0A                                   # the byte "in front of" p0 counts as a line end
+    for r in range(rank):
+        if tails[r][0] >= 0:
+            prev = tails[r][0]
+    prev_is_eol = rank == 0 or _is_eol(prev)
+    mine = d_buf[lo:n]
+    # where my shard begins inside my slice
+    skip = 0
+    if fmt == capi.FMT_FASTQ:
+        cnt = ctx.ennaf_count_lines(mine, prev_is_eol) if mine.numel() else 0
+        cnts = _all_gather_ints([cnt], dev, group)
+        skip = (-sum(c[0] for c in cnts[:rank])) % 4
+    if rank == 0:
+        cut = 0
+    else:
+        cut = ctx.ennaf_find_cut(mine, fmt, prev_is_eol, skip) if mine.numel() else 0
+    # heads: the bytes in front of each rank's cut belong to the shard before it; a slice without a cut is all head
+    lens = _all_gather_ints([cut, mine.numel()], dev, group)
+    maxc = max(c for c, _ in lens)
+    heads = None
+    if maxc:
+        h = torch.zeros(maxc, dtype=torch.uint8, device=dev)
+        h[:cut] = mine[:cut]
+        heads = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(heads, h, group=group)
+    borrow = []
+    for r in range(rank + 1, world):
+        c, ln = lens[r]
+        if c:
+            borrow.append(heads[r][:c])
+        if c < ln:
+            break
+    halo = sum(int(b.numel()) for b in borrow)
+    own = mine.numel() - cut
+    if own == 0 and lens[rank][1] > 0 and rank > 0:
+        borrow, halo = [], 0                                      # my whole slice went to an earlier shard: nothing starts here
+    if halo and d_buf.numel() >= n + halo:
+        pos = n
+        for b in borrow:
+            d_buf[pos:pos + b.numel()] = b
+            pos += b.numel()
+        text = d_buf[lo + cut:n + halo]
+    elif halo:
+        text = torch.cat([mine[cut:]] + borrow)
+    else:
+        text = mine[cut:]
+    info = ctx.ennaf_shard_begin(text, opts, fmt, rank, world)
+    infos = [capi.ShardInfo.from_buffer_copy(b) for b in _all_gather_bytes(bytes(info), dev, group)]
+    buf, pc = ctx.ennaf_shard_finish(opts, infos, text.numel())
+    pieces = [capi.ShardPieces.from_buffer_copy(b) for b in _all_gather_bytes(bytes(pc), dev, group)]
+    segs, lit, naf_len, rep = capi.stitch_plan(opts, infos, pieces)
+    extra = {"cut": cut, "halo": halo, "format": fmt, "text_len": int(text.numel())}
+    out = None
+    ops = []
+    if rank == dst:
+        out = torch.empty(max(naf_len, 1), dtype=torch.uint8, device=dev)
+        lit_t = torch.frombuffer(bytearray(lit), dtype=torch.uint8).to(dev)
+        for g in segs:
+            if g.len == 0:
+                continue
+            if g.shard < 0:
+                out[g.dst_off:g.dst_off + g.len] = lit_t[g.src_off:g.src_off + g.len]
+            elif g.shard == rank:
+                out[g.dst_off:g.dst_off + g.len] = buf[g.src_off:g.src_off + g.len]
+            else:
+                ops.append(dist.P2POp(dist.irecv, out[g.dst_off:g.dst_off + g.len], g.shard, group))
+    else:
+        for g in segs:
+            if g.shard == rank and g.len:
+                ops.append(dist.P2POp(dist.isend, buf[g.src_off:g.src_off + g.len], dst, group))
+    _p2p(ops)
+    if everywhere:
+        if rank != dst:
+            out = torch.empty(max(naf_len, 1), dtype=torch.uint8, device=dev)
+        dist.broadcast(out, dst, group=group)
+    return (out[:naf_len] if out is not None else None), rep, extra

@@ -1,0 +1,217 @@
+"""GPU parity tests of ennaf on several GPUs (include/naf_gpu.h, "ennaf of ONE input on several GPUs"), run as N contexts on the
+one device of the test box: the joined archive must hold exactly the six streams the oracle makes of the WHOLE text, its
+container framing must equal the reference's, and the real reference unnaf (oracle/_ref) must decode it to the text.  Also the
+per-shard records the device reports against the CPU stand-in of tests/shard_standin.py, the reference's die() messages with the
+record numbered across shards, and --strict (process.c:98-140) against the real reference's stderr."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "naf_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    import torch
+    assert torch.cuda.is_available()
+    from naf_amd import capi
+    cs = [capi.Context(0) for _ in range(8)]
+    yield cs
+    for c in cs:
+        c.close()
+
+
+def host(t):
+    return t.cpu().numpy().tobytes()
+
+
+def join(ctxs, text, n, opts=None):
+    from naf_amd import shard
+    d = ctxs[0].to_device(text)
+    naf, rep = shard.ennaf_sharded_local(ctxs[:n], d, opts or shard.make_opts())
+    return host(naf), rep
+
+
+def check(O, ctxs, text, n, seq_type=0, no_mask=False, ref=True):
+    from naf_amd import shard
+    from test_shard_cpu import check_against_whole
+    naf, rep = join(ctxs, text, n, shard.make_opts(seq_type=seq_type, no_mask=no_mask))
+    check_against_whole(O, text, naf, rep, seq_type, no_mask)
+    sp = O.split_text(text, seq_type, no_mask)
+    consistent = int(np.frombuffer(sp.lengths, dtype="<u4").astype(np.uint64).sum()) == sp.n_bases        # not an R7 input
+    if sp.n_sequences and consistent:
+        assert host(ctxs[0].unnaf(ctxs[0].to_device(naf), -1)) == O.unnaf(O.ennaf(text, seq_type, no_mask), -1)   # and the HIP decoder reads it
+        if ref and O.have_ref():
+            fq = sp.format == O.FMT_FASTQ
+            args = ("--rna",) if seq_type == 1 else ("--protein",) if seq_type == 2 else ("--text",) if seq_type == 3 else ()
+            want = O.ref_unnaf(O.ref_ennaf(text, args + (("--no-mask",) if no_mask else ())))
+            assert O.ref_unnaf(naf) == want
+    return naf
+
+
+def test_sharded_fasta_fuzz(ctxs, oracle):
+    from test_shard_cpu import fasta_fuzz
+    rng = np.random.default_rng(41)
+    for i in range(40):
+        text = fasta_fuzz(rng, int(rng.integers(1, 8)), int(rng.integers(1, 6000)))
+        for n in (2, 3, 8):
+            check(oracle, ctxs, text, n, ref=(i % 4 == 0))
+
+
+def test_sharded_one_record_mask_run_across_three_shards(ctxs, oracle):
+    seq = b"ACG" + b"acgtn" * 161 + b"TTGCA" * 50 + b"a"
+    text = b">chr1 one record\n" + b"".join(seq[a:a + 7] + b"\n" for a in range(0, len(seq), 7))
+    for n in (2, 3, 5, 8):
+        check(oracle, ctxs, text, n)
+    for body in (b"acgt" * 300, b"ACGT" * 300, b"aCgT" * 300, b"a", b"A"):
+        text = b">x\n" + b"".join(body[a:a + 11] + b"\n" for a in range(0, len(body), 11))
+        for n in (2, 3, 8):
+            check(oracle, ctxs, text, n)
+
+
+def test_sharded_odd_base_counts_at_every_cut(ctxs, oracle):
+    """Lines of 7 bases and cuts behind any of them: every shard starts at an odd or even base index as it falls; the packed
+    stream must be the one of the whole text, nibble for nibble."""
+    rng = np.random.default_rng(8)
+    bases = np.frombuffer(b"ACGTNacgtRY", dtype=np.uint8)
+    for L in (1, 7, 9, 61):
+        body = bases[rng.integers(0, len(bases), 4001)].tobytes()
+        text = b">r1 d\n" + b"".join(body[a:a + L] + b"\n" for a in range(0, 1501, L)) + b">r2\n" + b"".join(body[a:a + L] + b"\n" for a in range(1501, 4001, L))
+        for n in (2, 3, 8):
+            check(oracle, ctxs, text, n, ref=(L == 7))
+
+
+def test_sharded_tiny_and_edge_inputs(ctxs, oracle):
+    for text in (b">a\nACGT\n", b">a\n", b">a", b">a b\nAC\n>c\n\n>d\nacgtn", b">x\n" + b"A" * 300, b"\n\n >x\nAC\n".replace(b" ", b""),
+                 b">a\r\nAC\r\nGT\r\n>b\r\n\r\nTT", b">x\x01y\nAC\n>z\n"):
+        for n in (2, 3, 8):
+            check(oracle, ctxs, text, n)
+
+
+def test_sharded_other_sequence_types(ctxs, oracle):
+    from test_shard_cpu import fasta_fuzz
+    rng = np.random.default_rng(3)
+    text = fasta_fuzz(rng, 5, 2500)
+    for st, nm in ((oracle.PROTEIN, False), (oracle.TEXT, False), (oracle.DNA, True), (oracle.RNA, False), (oracle.TEXT, True)):
+        for n in (2, 3):
+            check(oracle, ctxs, text, n, st, nm)
+
+
+def test_sharded_fastq_mixed_case(ctxs, oracle):
+    from naf_amd import synth
+    rng = np.random.default_rng(11)
+    for i in range(10):
+        text = synth.fastq_reads(int(rng.integers(1, 400)), int(rng.integers(1, 200)), seed=200 + i, var_len=bool(i % 2))
+        for n in (2, 3, 8):
+            check(oracle, ctxs, text, n, ref=(i % 3 == 0))
+    weird = b"\n\n@r1 c\nAC GT\n+\n!!!!\n\n@r2\tcomment\nACNNxz\n\n+r2 again\n\nIIIIII\n@r3\nA\n+\n~"
+    for n in (2, 3):
+        check(oracle, ctxs, weird, n)
+
+
+def test_sharded_large_roundtrip(ctxs, oracle):
+    """200 MB over 8 shards: size-independent property (decode of the joined archive == input) and the same archive sections as
+    the one-GPU encoder's (their decoded streams are compared on the device)."""
+    import torch
+    from naf_amd import synth, shard
+    text = synth.fasta_acgt_device(200_000_000, n_records=7, width=80, seed=3)
+    naf, rep = shard.ennaf_sharded_local(ctxs, text)
+    assert rep.n_sequences == 7 and rep.longest_line == 80
+    back = ctxs[0].unnaf(naf, 0)
+    assert torch.equal(back, text)
+    one, rep1 = ctxs[0].ennaf(text)
+    h8, h1 = ctxs[0].parse_header(naf), ctxs[0].parse_header(one)
+    assert list(h8.orig_size) == list(h1.orig_size) and h8.n_sequences == h1.n_sequences
+    if oracle.have_ref():                                       # the reference reads the first 4 MB of it the same way
+        sample = host(ctxs[0].unnaf(naf, 0)[:4_000_000])
+        assert oracle.ref_unnaf(host(naf))[:4_000_000] == sample
+
+
+def test_shard_records_match_the_stand_in(ctxs, oracle):
+    """naf_gpu_ennaf_shard_begin on the device reports what the CPU stand-in derives from the oracle's view of the same slice."""
+    from naf_amd import shard, synth
+    from shard_standin import StandInCtx
+    from test_shard_cpu import fasta_fuzz
+    rng = np.random.default_rng(77)
+    texts = [fasta_fuzz(rng, 4, 3000) for _ in range(6)] + [synth.fastq_reads(90, 60, seed=9, var_len=True)]
+    fields = ("n_sequences", "n_bases", "longest_line", "lead_bases", "n_ids", "n_comments", "n_quality", "mask_changes", "store_mask", "store_quality")
+    for text in texts:
+        d = ctxs[0].to_device(text)
+        opts = shard.make_opts()
+        fmt, p0 = ctxs[0].ennaf_sniff(d)
+        sfmt, sp0 = StandInCtx(oracle).ennaf_sniff(text)
+        assert (fmt, p0) == (sfmt, sp0)
+        for n in (2, 3, 8):
+            cuts = shard.cuts_local(ctxs[0], d, fmt, p0, n)
+            import torch
+            scuts = shard.cuts_local(StandInCtx(oracle), torch.frombuffer(bytearray(text), dtype=torch.uint8), fmt, p0, n)
+            assert cuts == scuts
+            for k in range(n):
+                a = ctxs[k].ennaf_shard_begin(d[cuts[k]:cuts[k + 1]], opts, fmt, k, n)
+                b = StandInCtx(oracle).ennaf_shard_begin(text[cuts[k]:cuts[k + 1]], opts, fmt, k, n)
+                for f in fields:
+                    assert getattr(a, f) == getattr(b, f), (f, k, n)
+                if a.n_bases:
+                    assert (a.first_base, a.last_base) == (b.first_base, b.last_base)
+                    if a.mask_changes:
+                        assert (a.mask_first_change, a.mask_last_change) == (b.mask_first_change, b.mask_last_change)
+
+
+def test_sharded_errors_number_records_across_shards(ctxs, oracle):
+    from naf_amd import shard, synth
+    from naf_amd.capi import NafGpuError
+    good = synth.fastq_reads(40, 50, seed=1)
+    recs = good.split(b"\n@")
+    recs = [recs[0]] + [b"@" + r for r in recs[1:]]
+    recs = [r if r.endswith(b"\n") else r + b"\n" for r in recs]
+    bad_q = list(recs); bad_q[33] = bad_q[33].rstrip(b"\n")[:-1] + b"\n"              # record 34 loses one quality byte
+    bad_plus = list(recs); l = bad_plus[20].split(b"\n"); l[2] = b"x"; bad_plus[20] = b"\n".join(l)
+    for broken in (b"".join(bad_q), b"".join(bad_plus), good + b"@last\nACGT\n"):
+        with pytest.raises(ValueError) as e0:
+            oracle.split_text(broken)
+        for n in (2, 3, 8):
+            with pytest.raises(NafGpuError) as e1:
+                join(ctxs, broken, n)
+            assert str(e0.value).strip() in str(e1.value), (n, str(e0.value), str(e1.value))
+
+
+def _ref_strict(oracle, text, args=()):
+    rc, out, err = oracle.ref_ennaf_full(text, ("--strict",) + tuple(args))
+    return rc, err.decode("latin1")
+
+
+def test_strict_matches_the_reference(ctxs, oracle):
+    """--strict through the C-ABI (one GPU and sharded) and through the CLI: the reference's message, character and record."""
+    from naf_amd import shard
+    from naf_amd.capi import NafGpuError
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built")
+    fa = b">r1 ok\nACGT\nAC!T\n>r2\x01x c\nAC\n>r3 co\x02mment\nACZT\n"
+    cases = [(fa, ()), (b">r1\nACGT\n>r2 c\x7fc\nAC\n", ()), (b">a\nACGT\n>b\nACGT\n>c\nAC.GT\n", ()), (fa, ("--protein",)), (b">a\nAC\x01GT\n", ("--text",)),
+             (b">a\nACGU\n", ("--rna",)), (b">a\nACGU\n", ()),
+             (b"@r1\nACGT\n+\nIIII\n@r2\nAC.T\n+\nIIII\n", ()), (b"@r1\nACGT\n+\nII\x01I\n@r2\nAC.T\n+\nIIII\n", ()),
+             (b"@r1 c\x01\nACGT\n+\nIIII\n", ()), (b"@r1\nACGT\n+\nIIII\n@r\x022\nACGT\n+\nIIII\n", ()),
+             (b"@r1\nACGT\n+\nIII\n@r2\nAC.T\n+\nIIII\n", ()),           # the quality length of record 1 comes first
+             (b"@r1\nAC.T\n+\nIII\n", ()),                               # the base comes before its record's quality length
+             (b">ok\nACGT\n", ()), (b"@ok\nACGT\n+\nIIII\n", ())]
+    st = {"--protein": 2, "--text": 3, "--rna": 1}
+    for text, args in cases:
+        rc, err = _ref_strict(oracle, text, args)
+        seq_type = st.get(args[0], 0) if args else 0
+        for n in (1, 2, 3):
+            opts = shard.make_opts(seq_type=seq_type, strict=True)
+            if rc == 0:
+                join(ctxs, text, n, opts)
+                continue
+            with pytest.raises(NafGpuError) as e:
+                join(ctxs, text, n, opts)
+            assert err.startswith("ennaf error: ") and err[len("ennaf error: "):].strip() in str(e.value), (text, n, err, str(e.value))
+        p = subprocess.run([os.path.join(BIN, "ennaf"), "--strict", *args, "-c"], input=text, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert (p.returncode, p.stderr.decode("latin1")) == (rc, err), (text, args)
+    p = subprocess.run([os.path.join(BIN, "ennaf"), "--strict", "--well-formed", "-c"], input=b">a\nAC\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 1 and p.stderr == b"ennaf error: '--well-formed' and '--strict' can't be used together\n"
