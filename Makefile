@@ -3,7 +3,7 @@ HIPCC   ?= hipcc
 ARCH    ?= gfx950
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value
 CSRC     = naf_amd/csrc
-OBJS     = $(CSRC)/naf_gpu.o $(CSRC)/scan.o $(CSRC)/zstd_dec.o $(CSRC)/emit.o $(CSRC)/zstd_enc.o $(CSRC)/enc.o
+OBJS     = $(CSRC)/naf_gpu.o $(CSRC)/scan.o $(CSRC)/zstd_dec.o $(CSRC)/emit.o $(CSRC)/zstd_enc.o $(CSRC)/enc.o $(CSRC)/io.o
 HDRS     = $(wildcard $(CSRC)/*.h) include/naf_gpu.h
 
 all: naf_amd/libnaf_gpu.so hosts oracle emul tools/bw_calibrate

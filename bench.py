@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the NAF hot path on MI355X.
 
-Workload (BASELINE.json configs[1], the config the metric is quoted on for one GPU):
+N = 1 (BASELINE.json configs[1], the config the metric is quoted on for one GPU):
     unnaf decode of a 10 GB synthetic-ACGT .naf, archive resident in HBM, FASTA text produced in HBM.
-One "step" = one complete naf_gpu_unnaf pass over the archive (small sections + offset scans + zstd
-decode of the sequence stream + 4-bit unpack / mask / line-wrap emit).  The archive is made in-run by
-the GPU encoder (naf_gpu_ennaf); its encode throughput is reported as an extra field.
+    One "step" = one complete naf_gpu_unnaf pass over the archive (small sections + offset scans + zstd decode of the sequence
+    stream + 4-bit unpack / mask / line-wrap emit).  The archive is made in-run by the GPU encoder (naf_gpu_ennaf); its throughput
+    and roofline ride along (configs[2]), as do the decode of the REFERENCE-made archive of the same text and the file -> file
+    times of both CLIs next to the reference's.
 
-N GPUs (weak scaling): every rank decodes its own 10 GB archive; no data-path collective (the path
-shards by independent archives / block ranges); barrier + max-over-ranks timing as the contract asks.
+N > 1 (configs[3] shape, weak scaling: 10 GB of text per GPU):
+    ONE archive of N x 10 GB of text -- made in-run by the sharded encoder (naf_gpu_ennaf_shard_*: every rank encodes its slice,
+    the parts are joined into one frame per stream; configs[4] shape) -- is decoded by all ranks: rank r produces bytes
+    [r, r+1) x total/N of the text with naf_gpu_unnaf_range and the ranges are gathered to rank 0 over RCCL (one group of
+    point-to-point transfers into place).  One step = range decode on every rank + the gather.  `--replicas` runs the round-1
+    shape instead (one archive per GPU, no data-path collective).
 
 Emits ONE JSON line on rank 0.
 """
@@ -23,31 +28,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md
+REF_E = os.path.join(ROOT, "oracle", "_ref", "ennaf")
+REF_U = os.path.join(ROOT, "oracle", "_ref", "unnaf")
+BIN = os.path.join(ROOT, "naf_amd", "bin")
 
 
-def cpu_baseline(text_dev, size_bytes, ctx=None):
-    """Reference unnaf/ennaf (oracle/_ref, built from the reference sources) on this box's host cores,
-    one thread (the reference is single-threaded), on a bounded sample of the same workload."""
+def have_ref():
+    return os.access(REF_E, os.X_OK) and os.access(REF_U, os.X_OK)
+
+
+def cpu_baseline(text_dev, size_bytes, ctx=None, full_ref_archive=True, e2e_bytes=0):
+    """Reference unnaf/ennaf (oracle/_ref, built from the reference sources) on this box's host cores, one thread (the reference
+    is single-threaded), on a bounded sample of the same workload; the GPU decoder on the archive the reference makes of the
+    WHOLE text; and file -> file wall time of both CLIs beside the reference's."""
     import numpy as np
-    ref_e = os.path.join(ROOT, "oracle", "_ref", "ennaf")
-    ref_u = os.path.join(ROOT, "oracle", "_ref", "unnaf")
-    if not (os.access(ref_e, os.X_OK) and os.access(ref_u, os.X_OK)):
+    if not have_ref():
         return None
     shm = "/dev/shm/naf_bench_%d" % os.getpid()
     os.makedirs(shm, exist_ok=True)
+    P = lambda name: os.path.join(shm, name)
     try:
         sample = text_dev[:size_bytes]
         # cut at a line end so the sample is a well-formed FASTA prefix
         cut = int((sample == 10).nonzero()[-1].item()) + 1
-        sample[:cut].cpu().numpy().tofile(os.path.join(shm, "s.fa"))
+        sample[:cut].cpu().numpy().tofile(P("s.fa"))
         env = dict(os.environ, TMPDIR=shm)
         t0 = time.perf_counter()
-        subprocess.check_call([ref_e, os.path.join(shm, "s.fa"), "-o", os.path.join(shm, "s.naf")], env=env)
+        subprocess.check_call([REF_E, P("s.fa"), "-o", P("s.naf")], env=env)
         t_e = time.perf_counter() - t0
         t0 = time.perf_counter()
-        subprocess.check_call([ref_u, os.path.join(shm, "s.naf"), "-o", os.path.join(shm, "s.out")])
+        subprocess.check_call([REF_U, P("s.naf"), "-o", P("s.out")])
         t_u = time.perf_counter() - t0
-        same = subprocess.call(["cmp", "-s", os.path.join(shm, "s.fa"), os.path.join(shm, "s.out")]) == 0
+        same = subprocess.call(["cmp", "-s", P("s.fa"), P("s.out")]) == 0
         out = {"value": round(cut / t_u / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "reference",
                "sample": "reference unnaf (oracle/_ref, libzstd 1.4.9) on the first %.2f GB of the same FASTA, tmpfs, 1 thread" % (cut / 1e9),
                "ennaf_value": round(cut / t_e / 1e9, 4), "roundtrip_ok": bool(same)}
@@ -57,30 +69,114 @@ def cpu_baseline(text_dev, size_bytes, ctx=None):
         if ncpu > 1:
             t0 = time.perf_counter()
             with open(os.devnull, "wb") as dn:
-                ps = [subprocess.Popen([ref_u, os.path.join(shm, "s.naf")], stdout=dn) for _ in range(ncpu)]
+                ps = [subprocess.Popen([REF_U, P("s.naf")], stdout=dn) for _ in range(ncpu)]
                 rcs = [q.wait() for q in ps]
             t_all = time.perf_counter() - t0
             if all(rc == 0 for rc in rcs):
                 out["all_cores"] = {"value": round(ncpu * cut / t_all / 1e9, 3), "unit": "GB/s", "cores": ncpu,
                                     "sample": "%d concurrent reference unnaf instances, each decoding the same %.2f GB sample archive to /dev/null" % (ncpu, cut / 1e9)}
         if ctx is not None:
-            # the GPU decoder on the archive the REFERENCE ennaf made of that sample (128 KiB dependent blocks)
+            # the GPU decoder on the archive the REFERENCE ennaf makes (128 KiB dependent blocks) -- of the whole text
             import torch
             from naf_amd import capi
-            ref_naf = torch.from_numpy(np.fromfile(os.path.join(shm, "s.naf"), dtype=np.uint8)).to(text_dev.device)
-            buf = torch.empty(cut + 64, dtype=torch.uint8, device=text_dev.device)
+            src, n_src, naf_path = P("s.fa"), cut, P("s.naf")
+            if full_ref_archive and text_dev.numel() > cut:
+                try:
+                    text_dev.cpu().numpy().tofile(P("full.fa"))
+                    t0 = time.perf_counter()
+                    subprocess.check_call([REF_E, P("full.fa"), "-o", P("full.naf")], env=env)
+                    n_src, naf_path = int(text_dev.numel()), P("full.naf")
+                    out["ennaf_full"] = {"value": round(n_src / (time.perf_counter() - t0) / 1e9, 4), "unit": "GB/s", "text_bytes": n_src}
+                except (OSError, subprocess.CalledProcessError) as ex:             # tmpfs too small for the whole text: the sample's archive
+                    out["full_archive_skipped"] = repr(ex)[:120]
+                if os.path.exists(P("full.fa")):
+                    os.remove(P("full.fa"))
+            ref_naf = torch.from_numpy(np.fromfile(naf_path, dtype=np.uint8)).to(text_dev.device)
+            buf = torch.empty(n_src + 64, dtype=torch.uint8, device=text_dev.device)
             r = ctx.unnaf(ref_naf, capi.OUT_FASTA, out=buf)
             torch.cuda.synchronize()
-            ok = bool(torch.equal(r, sample[:cut]))
+            ok = bool(torch.equal(r, text_dev[:n_src]))
             t0 = time.perf_counter()
             for _ in range(3):
                 ctx.unnaf(ref_naf, capi.OUT_FASTA, out=buf)
             torch.cuda.synchronize()
-            out["gpu_unnaf_of_reference_archive"] = {"value": round(cut * 3 / (time.perf_counter() - t0) / 1e9, 2), "unit": "GB/s",
-                                                      "archive_bytes": int(ref_naf.numel()), "text_bytes": int(cut), "bit_exact": ok}
+            dt = (time.perf_counter() - t0) / 3
+            ctx.set_timing(True)
+            ctx.unnaf(ref_naf, capi.OUT_FASTA, out=buf)
+            kt = sorted(ctx.get_timing(), key=lambda x: -x[1])[:6]
+            ctx.set_timing(False)
+            out["gpu_unnaf_of_reference_archive"] = {"value": round(n_src / dt / 1e9, 2), "unit": "GB/s", "ms": round(dt * 1e3, 3),
+                                                      "archive_bytes": int(ref_naf.numel()), "text_bytes": int(n_src), "bit_exact": ok,
+                                                      "kernels_ms": {n: round(ms, 3) for n, ms, k in kt}}
+            del ref_naf, buf
+        if e2e_bytes and os.access(os.path.join(BIN, "ennaf"), os.X_OK):
+            # drop-in reality check: file -> file through the CLIs (tmpfs; PCIe, file I/O and process start included) -- never the `value`
+            e2e = text_dev[:e2e_bytes]
+            cut2 = int((e2e == 10).nonzero()[-1].item()) + 1
+            e2e[:cut2].cpu().numpy().tofile(P("e.fa"))
+            def timed(cmd):
+                t0 = time.perf_counter()
+                rc = subprocess.call(cmd, env=env, stderr=subprocess.DEVNULL)
+                return round(time.perf_counter() - t0, 3) if rc == 0 else None
+            res = {"text_bytes": cut2, "unit": "s, file -> file on tmpfs"}
+            res["ennaf"] = timed([os.path.join(BIN, "ennaf"), P("e.fa"), "-o", P("e.naf")])
+            res["unnaf"] = timed([os.path.join(BIN, "unnaf"), P("e.naf"), "-o", P("e.out")])
+            res["roundtrip_ok"] = subprocess.call(["cmp", "-s", P("e.fa"), P("e.out")]) == 0
+            res["reference_ennaf"] = timed([REF_E, P("e.fa"), "-o", P("e.ref.naf")])
+            res["reference_unnaf"] = timed([REF_U, P("e.ref.naf"), "-o", P("e.out")])
+            res["unnaf_of_reference_archive"] = timed([os.path.join(BIN, "unnaf"), P("e.ref.naf"), "-o", P("e.out")])
+            out["end_to_end"] = res
         return out
     finally:
         subprocess.call(["rm", "-rf", shm])
+
+
+def load_traffic(kernel, n_text, fname="pmc_traffic.json"):
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        if abs(pm["text_bytes"] - n_text) < 0.01 * n_text and kernel in pm["kernels"]:
+            return int(pm["kernels"][kernel]["fetch_bytes"] + pm["kernels"][kernel]["write_bytes"]), pm["source"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
+def roofline_of(kt, alg, n_text, path_bytes, ms_per_step, fname="pmc_traffic.json", merge_side=()):
+    """Roofline object of the dominant kernel among `alg` (name -> algorithmic bytes per step).  Launches on the side contexts'
+    streams are reported as "side:<name>"; a kernel in `merge_side` counts its side launches too (the emit of a split decode)."""
+    def kernel_ms(name):
+        ms, k = kt.get(name, (0.0, 0))
+        if name in merge_side:
+            ms2, k2 = kt.get("side:" + name, (0.0, 0)); ms += ms2; k += k2
+        return ms, max(k, 1)
+    dom = max(alg, key=lambda k: kernel_ms(k)[0])
+    dom_ms, dom_launches = kernel_ms(dom)
+    if dom_ms <= 0:
+        return None
+    achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
+    traffic, traffic_src = load_traffic(dom, n_text, fname)
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": int(alg[dom] // dom_launches), "avg_launch_ms": round(dom_ms / dom_launches, 4),
+            "kernel_ms_per_step": round(dom_ms, 4), "launches_per_step": dom_launches,
+            "path_bytes_per_step": int(path_bytes),
+            "path_frac": round(path_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 4),
+            "kernels_ms": {n: round(ms, 3) for n, (ms, k) in sorted(kt.items(), key=lambda x: -x[1][0])[:8]}}
+
+
+def weighted_sum(t, offset):
+    """Position-weighted byte sum (fits int64 up to 100 GB): additive over consecutive ranges, so the sum over the ranks' ranges
+    of the decoded text must equal the sum over the ranks' slices of the input -- a checksum of checksums at full size."""
+    import torch
+    if t.numel() == 0:
+        return 0
+    tot = 0
+    step = 1 << 28
+    for a in range(0, t.numel(), step):
+        seg = t[a:a + step].to(torch.int64)
+        idx = (torch.arange(a, a + seg.numel(), device=t.device, dtype=torch.int64) + offset) % 65521 + 1
+        tot += int((seg * idx).sum().item())
+    return tot
 
 
 def main():
@@ -91,11 +187,12 @@ def main():
     ap.add_argument("--size", type=float, default=10e9, help="FASTA bytes per GPU (default: the 10 GB config)")
     ap.add_argument("--records", type=int, default=100)
     ap.add_argument("--cpu-sample", type=float, default=2e9, help="bytes of FASTA timed on the CPU reference")
+    ap.add_argument("--e2e-size", type=float, default=4e9, help="bytes of FASTA run file -> file through the CLIs (0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--shard", action="store_true",
-                    help="strong scaling instead of the default weak scaling: ONE archive (same on every rank), every rank decodes its 1/N byte "
-                         "range of the text (only the zstd blocks behind it) and the ranges are gathered with one RCCL all_gather "
-                         "(BASELINE configs[3] shape); not the default, the driver's contract line is the weak-scaling one")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1: one archive per GPU, no data-path collective (the round-1 shape) instead of one sharded archive + gather")
+    ap.add_argument("--force-sharded", action="store_true", help="run the N > 1 code path with whatever world size there is (1 on the test box)")
+    ap.add_argument("--fastq-size", type=float, default=4e9, help="N > 1: FASTQ bytes per GPU for the sharded FASTQ encode (configs[4]; 0: skip)")
     args = ap.parse_args()
 
     import torch
@@ -104,125 +201,200 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    multi = world > 1 or args.force_sharded
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29555")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    dev = "cuda:%d" % local
+    sharded = multi and not args.replicas
 
-    from naf_amd import capi, synth
+    from naf_amd import capi, synth, shard
     ctx = capi.Context(local)
     size = int(args.size)
-    text = synth.fasta_acgt_device(size, n_records=args.records, width=80, seed=2024 + (0 if args.shard else rank), device="cuda:%d" % local)
+    spare = 1 << 20                                                    # room behind a slice for what a shard borrows from the next one
+    text_buf = None
+    text = synth.fasta_acgt_device(size, n_records=args.records, width=80, seed=2024 + rank, device=dev)
     n_text = text.numel()
+    if sharded:
+        # rank r's records are numbered from r * records on: the concatenation of the slices is one FASTA
+        text_buf = torch.empty(n_text + spare, dtype=torch.uint8, device=dev)
+        text_buf[:n_text] = text
+        text = text_buf[:n_text]
     ctx.reserve(int(n_text * 1.7) + (2 << 30))     # scratch arena sized up front: growth (hipMalloc) and the consolidation after it are not part of a step
 
-    # ---- archive made by the GPU encoder (timed separately; reported as ennaf_value)
-    naf_buf = torch.empty(int(n_text * 0.27) + (1 << 20), dtype=torch.uint8, device=text.device)
-    torch.cuda.synchronize()
-    enc_times = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        d_naf, rep = ctx.ennaf(text, out=naf_buf)
+    extra = {}
+    if not sharded:
+        # ---- archive made by the GPU encoder (timed separately; reported as ennaf_value)
+        naf_buf = torch.empty(int(n_text * 0.27) + (1 << 20), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
-        enc_times.append(time.perf_counter() - t0)
-    n_naf = d_naf.numel()
-    out = torch.empty(n_text + 64, dtype=torch.uint8, device=text.device)
-
-    if args.shard:
-        from naf_amd import shard
-        if world == 1:
-            step = lambda: ctx.unnaf_range(d_naf, 0, n_text, capi.OUT_FASTA)
-        else:
-            step = lambda: shard.unnaf_sharded(ctx, d_naf, capi.OUT_FASTA)
+        enc_times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            d_naf, rep = ctx.ennaf(text, out=naf_buf)
+            torch.cuda.synchronize()
+            enc_times.append(time.perf_counter() - t0)
+        ctx.set_timing(True)
+        ctx.ennaf(text, out=naf_buf)
+        enc_kt = {n: (ms, k) for n, ms, k in ctx.get_timing()}
+        ctx.set_timing(False)
+        n_naf = d_naf.numel()
+        total_text = n_text
+        out = torch.empty(n_text + 64, dtype=torch.uint8, device=dev)
+        step = lambda: ctx.unnaf(d_naf, capi.OUT_FASTA, out=out)
+        r = step()                                # untimed: bit-exact round trip at full size (size-independent property)
+        torch.cuda.synchronize()
+        ok = bool(torch.equal(r, text))
     else:
-        def step():
-            return ctx.unnaf(d_naf, capi.OUT_FASTA, out=out)
-
-    r = step()                                # untimed: bit-exact round trip at full size (size-independent property)
-    torch.cuda.synchronize()
-    ok = bool(torch.equal(r, text)) if r is not None else True          # --shard: the gathered text lives on rank 0
+        # ---- ONE archive of the whole job's text, made by the sharded encoder; every rank keeps a copy (2.5 GB per 10 GB of text)
+        opts = shard.make_opts()
+        d_naf, rep, sinfo = shard.ennaf_sharded(ctx, text_buf, n_text, opts, dst=0, everywhere=True)
+        torch.cuda.synchronize(); dist.barrier()
+        enc_times = []
+        for _ in range(2):
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            shard.ennaf_sharded(ctx, text_buf, n_text, opts, dst=0, everywhere=False)
+            torch.cuda.synchronize(); dist.barrier()
+            enc_times.append(time.perf_counter() - t0)
+        n_naf = d_naf.numel()
+        total_text = ctx.unnaf_size(d_naf, capi.OUT_FASTA)
+        b, e = shard.byte_range(total_text, rank, world)
+        out = torch.empty(total_text + 64, dtype=torch.uint8, device=dev) if rank == 0 else None
+        scratch = torch.empty(e - b + 64, dtype=torch.uint8, device=dev) if rank != 0 else None
+        step = lambda: shard.unnaf_sharded(ctx, d_naf, capi.OUT_FASTA, dst=0, out=out, total=total_text, scratch=scratch)
+        r = step()
+        torch.cuda.synchronize()
+        # full-size check: sum over ranks of the weighted sum of every slice == weighted sum of the gathered text on rank 0, and
+        # every rank's own decoded range against the same positions of the text it holds (where they overlap)
+        off = sum(x for x in [n_text] * rank)                    # slices are equal-sized by construction
+        mine = torch.tensor([weighted_sum(text, off), n_text], dtype=torch.int64, device=dev)
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        ok = True
+        if rank == 0:
+            ok = int(mine[1].item()) == total_text and int(mine[0].item()) == weighted_sum(r, 0) and bool(torch.equal(r[:n_text], text))
+        extra["sharded_ennaf"] = {"value": round(total_text / min(enc_times) / 1e9, 3), "unit": "GB/s FASTA in, whole job: split + streams + zstd on every rank, parts gathered to rank 0 (BASELINE configs[4] shape on FASTA)",
+                                  "borrowed_bytes": sinfo["halo"], "given_bytes": sinfo["cut"]}
     for _ in range(max(0, args.warmup - 1)):
         step()
     torch.cuda.synchronize()
 
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=text.device)
+    if multi:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([float(n_text)], dtype=torch.float64, device=text.device)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_text = float(n_text) if args.shard else float(tot.item())
-    else:
-        total_text = float(n_text)
+        if not sharded:
+            tot = torch.tensor([float(n_text)], dtype=torch.float64, device=dev)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            total_text = float(tot.item())
     ms_per_step = dt / args.steps * 1e3
-    value = total_text * args.steps / dt / 1e9
+    value = float(total_text) * args.steps / dt / 1e9
+
+    if sharded:
+        # the two halves of a step on their own: range decode (max over ranks), then the gather of already decoded ranges
+        b, e = shard.byte_range(total_text, rank, world)
+        buf = out[b:e] if rank == 0 else scratch
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.unnaf_range(d_naf, b, e, capi.OUT_FASTA, out=buf)
+        torch.cuda.synchronize()
+        td = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            shard.gather_ranges(buf[: e - b], total_text, dst=0, out=out)
+        torch.cuda.synchronize(); dist.barrier()
+        tg = time.perf_counter() - t0
+        extra["range_decode_ms"] = round(float(td.item()) / args.steps * 1e3, 3)
+        extra["gather_ms"] = round(tg / args.steps * 1e3, 3)
+        extra["decode_only_value"] = round(float(total_text) * args.steps / float(td.item()) / 1e9, 3)
+        if args.fastq_size > 0:
+            # configs[4] proper: FASTQ (mixed case, N, full quality range) sharded over the ranks
+            fq = synth.fastq_reads_device(int(args.fastq_size), seed=7 + rank, device=dev)
+            fq_buf = torch.empty(fq.numel() + spare, dtype=torch.uint8, device=dev)
+            fq_buf[: fq.numel()] = fq
+            nfq = fq.numel(); del fq
+            shard.ennaf_sharded(ctx, fq_buf, nfq, shard.make_opts(), dst=0)
+            ts = []
+            for _ in range(2):
+                torch.cuda.synchronize(); dist.barrier()
+                t0 = time.perf_counter()
+                fq_naf, fq_rep, _ = shard.ennaf_sharded(ctx, fq_buf, nfq, shard.make_opts(), dst=0)
+                torch.cuda.synchronize(); dist.barrier()
+                ts.append(time.perf_counter() - t0)
+            tot = torch.tensor([float(nfq)], dtype=torch.float64, device=dev)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            fq_ok = None
+            if rank == 0:
+                back = ctx.unnaf(fq_naf, capi.OUT_FASTQ)
+                # FASTQ comes back with upper-case bases (unnaf.c:442, R3): rank 0's own slice, case-folded, and the total size
+                fq_ok = int(back.numel()) == int(tot.item()) and bool(torch.equal((back[:nfq] & 0xDF), (fq_buf[:nfq] & 0xDF)))
+                extra["sharded_ennaf_fastq"] = {"value": round(float(tot.item()) / min(ts) / 1e9, 3), "unit": "GB/s FASTQ in (BASELINE configs[4] shape)",
+                                                "text_bytes": int(tot.item()), "naf_ratio": round(fq_naf.numel() / float(tot.item()), 4), "roundtrip_ok_case_folded": fq_ok}
+            del fq_buf
 
     # ---- per-kernel device time (HIP events on the stream the kernels run on), one extra instrumented step
     ctx.set_timing(True)
-    ctx.unnaf(d_naf, capi.OUT_FASTA, out=out)
-    timing = ctx.get_timing()
+    if sharded:
+        b, e = shard.byte_range(total_text, rank, world)
+        ctx.unnaf_range(d_naf, b, e, capi.OUT_FASTA, out=(out[b:e] if rank == 0 else scratch))
+        my_text = e - b
+    else:
+        ctx.unnaf(d_naf, capi.OUT_FASTA, out=out)
+        my_text = n_text
+    kt = {n: (ms, k) for n, ms, k in ctx.get_timing()}
     ctx.set_timing(False)
-    kt = {n: (ms, k) for n, ms, k in timing}
+    frac_mine = my_text / float(total_text) if sharded else 1.0
     packed = (rep.n_bases + 1) // 2
-    # algorithmic bytes per launch of each candidate dominant kernel
-    alg = {"zstd_huf_literals": rep.section_comp[4] + packed, "unnaf_emit": packed + n_text}
-    # Launches on the side contexts' streams are reported as "side:<name>".  The sequence stream's Huffman literals are decoded in a
-    # few launches over consecutive block ranges and the text behind a finished range is emitted on a second stream beside the
-    # decode of the next one: a kernel's time per step is the sum over its launches of the step -- for the emit,
-    # the ones on this context plus "side:unnaf_emit"; "side:zstd_huf_literals" are the side streams' own and not counted.  The
-    # launches overlap each other, so each carries the other's contention: the per-kernel fractions are lower bounds.
-    def kernel_ms(name):
-        ms, k = kt.get(name, (0.0, 0))
-        if name == "unnaf_emit":
-            ms2, k2 = kt.get("side:unnaf_emit", (0.0, 0)); ms += ms2; k += k2
-        return ms, max(k, 1)
-    dom = max(alg, key=lambda k: kernel_ms(k)[0])
-    dom_ms, dom_launches = kernel_ms(dom)
-    achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
-    # HBM traffic of that kernel per step, from the committed PMC passes of this same workload (rocprofv3 --pmc
-    # FETCH_SIZE / WRITE_SIZE in separate runs, tools/profile_bench.sh; FETCH doubled as the gfx950 guide prescribes)
-    traffic, traffic_src = None, None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if abs(pm["text_bytes"] - n_text) < 0.01 * n_text and dom in pm["kernels"]:
-            traffic = int(pm["kernels"][dom]["fetch_bytes"] + pm["kernels"][dom]["write_bytes"]); traffic_src = pm["source"]
-    except (OSError, KeyError, ValueError):
-        pass
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": int(alg[dom] // dom_launches), "avg_launch_ms": round(dom_ms / dom_launches, 4),
-                "kernel_ms_per_step": round(dom_ms, 4), "launches_per_step": dom_launches,
-                "path_bytes_per_step": int(n_naf + n_text),
-                "path_frac": round((n_naf + n_text) / (ms_per_step * 1e-3) / HBM_PEAK, 4),
-                "kernels_ms": {n: round(ms, 3) for n, (ms, k) in sorted(kt.items(), key=lambda x: -x[1][0])[:8]}}
+    # algorithmic bytes per step of each candidate dominant kernel; a rank of a sharded job moves its share
+    alg = {"zstd_huf_literals": (rep.section_comp[4] + packed) * frac_mine, "unnaf_emit": packed * frac_mine + my_text}
+    roofline = roofline_of(kt, alg, n_text, (n_naf * frac_mine + my_text), ms_per_step if not sharded else extra["range_decode_ms"], merge_side=("unnaf_emit",))
+    ennaf_roofline = None
+    if not sharded:
+        T = rep.n_bases
+        comp = rep.section_comp[4]
+        ealg = {"ennaf_scatter": n_text + T, "ennaf_count": n_text, "ennaf_last": n_text // 4, "ennaf_pack4": T + packed, "zenc_plan": packed, "zenc_write": packed + comp}
+        ennaf_roofline = roofline_of(enc_kt, ealg, n_text, n_text + n_naf, min(enc_times) * 1e3, fname="pmc_traffic_ennaf.json")
 
     cb = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cb = cpu_baseline(text, int(min(args.cpu_sample, n_text)), ctx)
+        del out
+        cb = cpu_baseline(text, int(min(args.cpu_sample, n_text)), ctx, e2e_bytes=int(min(args.e2e_size, n_text)))
     if rank == 0:
+        if sharded:
+            workload = ("unnaf decode of ONE archive of %.1f GB of synthetic-ACGT FASTA (%.1f GB per GPU, BASELINE configs[3] shape), %d records per GPU, 80-col lines; "
+                        "archive made in-run by the sharded GPU ennaf; .naf %d B -> FASTA %d B; every rank holds the archive, rank r emits 1/N of the text, RCCL gather to rank 0"
+                        % (total_text / 1e9, n_text / 1e9, args.records, n_naf, total_text))
+            par = "one archive, 1/N of the text per GPU by byte range (only the zstd blocks behind it are decoded), gather-to-root as one group of RCCL send/recv"
+        else:
+            workload = ("unnaf decode of a %.1f GB synthetic-ACGT FASTA archive per GPU (BASELINE configs[1]), %d records, 80-col lines; archive made in-run by the GPU ennaf; .naf %d B -> FASTA %d B, resident in HBM"
+                        % (n_text / 1e9, args.records, n_naf, n_text))
+            par = "one archive per GPU, no data-path collective"
         line = {
             "metric": "unnaf GB/s (uncompressed bases out) on synthetic FASTA", "value": round(value, 3), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong" if args.shard else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "unnaf decode of a %.1f GB synthetic-ACGT FASTA archive per GPU (BASELINE configs[1]), %d records, 80-col lines; archive made in-run by the GPU ennaf; .naf %d B -> FASTA %d B, resident in HBM"
-                                   % (n_text / 1e9, args.records, n_naf, n_text),
-                       "parallelism": ("one archive, 1/N of the text per GPU by byte range, one RCCL all_gather" if args.shard
-                                       else "one archive per GPU, no data-path collective")},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": workload, "parallelism": par},
             "roundtrip_bit_exact": ok,
-            "ennaf_value": round(n_text / min(enc_times) / 1e9, 3), "ennaf_unit": "GB/s FASTA in (device-resident, same data)",
-            "naf_ratio": round(n_naf / n_text, 4),
-            "roofline": roofline, "cpu_baseline": cb,
+            "ennaf_value": round(float(total_text) / min(enc_times) / 1e9, 3),
+            "ennaf_unit": "GB/s FASTA in (device-resident, same data%s)" % (", sharded over the ranks, parts gathered to rank 0" if sharded else ""),
+            "naf_ratio": round(n_naf / float(total_text), 4),
+            "roofline": roofline, "ennaf_roofline": ennaf_roofline, "cpu_baseline": cb,
         }
+        line.update(extra)
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
     ctx.close()
 

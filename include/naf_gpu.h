@@ -74,6 +74,12 @@ int  naf_gpu_upload(naf_gpu_ctx *ctx, void *d_dst, const void *h_src, size_t byt
 int  naf_gpu_download(naf_gpu_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* returns after completion */
 int  naf_gpu_download_async(naf_gpu_ctx *ctx, void *h_pinned_dst, const void *d_src, size_t bytes);   /* async on the stream; pair with naf_gpu_synchronize */
 
+/* File <-> HBM through pinned staging on several host threads (io.hip; NAF_GPU_IO_THREADS, default 8): what the reference does with
+ * fread / fwrite of 16 KiB (ennaf/src/process.c:143-150, unnaf/src/files.c).  fd must support pread / pwrite (a regular file); the
+ * calls return when the transfer is complete.  naf_gpu_write_file first waits for the work queued on the ctx stream. */
+int  naf_gpu_read_file(naf_gpu_ctx *ctx, int fd, uint64_t file_off, size_t len, void *d_dst);
+int  naf_gpu_write_file(naf_gpu_ctx *ctx, int fd, uint64_t file_off, const void *d_src, size_t len);
+
 /* Byte histogram of a device buffer (unnaf --charcount over the --seq text, output.c:515-605). */
 int  naf_gpu_histogram(naf_gpu_ctx *ctx, const void *d_buf, size_t n, uint64_t counts[256]);
 

@@ -43,6 +43,7 @@ struct naf_gpu_ctx {
     hipEvent_t fork_ev = nullptr;
     struct ZSplit *zsplit = nullptr;        // set by unnaf for the sequence stream of a whole-text call: Huffman literals in parts (below)
     hipEvent_t split_ev[ZSPLIT_MAX + 2] = {};
+    void *io_pool = nullptr;                // io.hip: pinned staging lanes of naf_gpu_read_file / naf_gpu_write_file
     void *shard_state = nullptr;            // enc.hip: what naf_gpu_ennaf_shard_begin leaves for naf_gpu_ennaf_shard_finish
 };
 
@@ -81,6 +82,7 @@ int scan_inclusive_max_i64(naf_gpu_ctx *c, i64 *d_vals, size_t n);
 int zstd_decode(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len);
 int zstd_init_tables(naf_gpu_ctx *c);
 void ennaf_shard_state_free(naf_gpu_ctx *c);    // enc.hip
+void io_pool_free(naf_gpu_ctx *c);               // io.hip
 // Range decode: only the blocks whose output intersects [want_lo, want_hi) are decoded; d_dst[0] then holds
 // regenerated byte got_lo.  ranged=false means the whole stream was decoded (d_dst[0] = byte 0).
 struct EmitP;

@@ -1,0 +1,121 @@
+// io.hip -- file <-> HBM ("host I/O path").  The reference moves every byte through one thread and 16 KiB
+// fread / fwrite calls (ennaf/src/process.c:143-150, unnaf/src/output.c:640-651, files.c); a device-resident codec that finishes
+// 10 GB in milliseconds is then only as fast as its file I/O.  Here a transfer is cut into 16 MiB chunks dealt round-robin to a
+// few host threads, each with two pinned staging buffers and a HIP stream of its own: while one chunk of a lane is on the PCIe
+// link (hipMemcpyAsync), the lane's thread is in pread / pwrite for its other chunk, and the lanes run beside each other -- page
+// cache copies, PCIe and (for tmpfs / NVMe) the file system all see several requests in flight.
+#include "ctx.h"
+#include <thread>
+#include <atomic>
+#include <unistd.h>
+#include <errno.h>
+
+static const size_t IO_CHUNK = (size_t)16 << 20;
+struct IoLane { hipStream_t s = nullptr; void *pin[2] = { nullptr, nullptr }; hipEvent_t ev[2] = { nullptr, nullptr }; };
+struct IoPool { int lanes = 0; IoLane lane[16]; };
+
+static IoPool *io_pool(naf_gpu_ctx *c)
+{
+    if (c->io_pool) return (IoPool *)c->io_pool;
+    IoPool *p = new IoPool();
+    const char *e = getenv("NAF_GPU_IO_THREADS");
+    int n = e ? atoi(e) : 8; if (n < 1) n = 1; if (n > 16) n = 16;
+    for (int i = 0; i < n; i++) {
+        IoLane &L = p->lane[i];
+        bool ok = hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < 2 && ok; k++) ok = hipHostMalloc(&L.pin[k], IO_CHUNK, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) break;
+        p->lanes++;
+    }
+    c->io_pool = p;
+    return p;
+}
+
+void io_pool_free(naf_gpu_ctx *c)
+{
+    IoPool *p = (IoPool *)c->io_pool; if (!p) return;
+    for (int i = 0; i < 16; i++) {
+        IoLane &L = p->lane[i];
+        for (int k = 0; k < 2; k++) { if (L.pin[k]) hipHostFree(L.pin[k]); if (L.ev[k]) hipEventDestroy(L.ev[k]); }
+        if (L.s) hipStreamDestroy(L.s);
+    }
+    delete p; c->io_pool = nullptr;
+}
+
+static bool pread_full(int fd, void *buf, size_t n, u64 off)
+{
+    u8 *p = (u8 *)buf;
+    while (n) { ssize_t r = pread(fd, p, n, (off_t)off); if (r < 0 && errno == EINTR) continue; if (r <= 0) return false; p += r; n -= (size_t)r; off += (u64)r; }
+    return true;
+}
+static bool pwrite_full(int fd, const void *buf, size_t n, u64 off)
+{
+    const u8 *p = (const u8 *)buf;
+    while (n) { ssize_t r = pwrite(fd, p, n, (off_t)off); if (r < 0 && errno == EINTR) continue; if (r <= 0) return false; p += r; n -= (size_t)r; off += (u64)r; }
+    return true;
+}
+
+extern "C" int naf_gpu_read_file(naf_gpu_ctx *c, int fd, uint64_t file_off, size_t len, void *d_dst)
+{
+    if (!c || (!d_dst && len)) return NAF_GPU_EARG;
+    if (!len) return 0;
+    IoPool *P = io_pool(c);
+    if (P->lanes == 0) return ctx_fail(c, NAF_GPU_ENOMEM, "can't allocate pinned staging buffers");
+    const u64 nchunks = (len + IO_CHUNK - 1) / IO_CHUNK;
+    const int T = (int)(nchunks < (u64)P->lanes ? nchunks : (u64)P->lanes);
+    std::atomic<int> bad(0);
+    auto work = [&](int t) {
+        hipSetDevice(c->device);
+        IoLane &L = P->lane[t]; bool used[2] = { false, false };
+        for (u64 i = (u64)t, k = 0; i < nchunks && !bad.load(); i += (u64)T, k++) {
+            const int slot = (int)(k & 1); const u64 off = i * IO_CHUNK; const size_t n = len - off < IO_CHUNK ? (size_t)(len - off) : IO_CHUNK;
+            if (used[slot] && hipEventSynchronize(L.ev[slot]) != hipSuccess) { bad = 2; break; }          // the upload that last read this buffer
+            if (!pread_full(fd, L.pin[slot], n, file_off + off)) { bad = 1; break; }
+            if (hipMemcpyAsync((u8 *)d_dst + off, L.pin[slot], n, hipMemcpyHostToDevice, L.s) != hipSuccess || hipEventRecord(L.ev[slot], L.s) != hipSuccess) { bad = 2; break; }
+            used[slot] = true;
+        }
+        if (hipStreamSynchronize(L.s) != hipSuccess) bad = 2;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    if (bad == 1) return ctx_fail(c, NAF_GPU_EARG, "can't read the input (short read or not a seekable file)");
+    if (bad) return ctx_fail(c, NAF_GPU_EHIP, "host -> device copy failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+extern "C" int naf_gpu_write_file(naf_gpu_ctx *c, int fd, uint64_t file_off, const void *d_src, size_t len)
+{
+    if (!c || (!d_src && len)) return NAF_GPU_EARG;
+    if (!len) return 0;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));                      // whatever produced d_src
+    IoPool *P = io_pool(c);
+    if (P->lanes == 0) return ctx_fail(c, NAF_GPU_ENOMEM, "can't allocate pinned staging buffers");
+    const u64 nchunks = (len + IO_CHUNK - 1) / IO_CHUNK;
+    const int T = (int)(nchunks < (u64)P->lanes ? nchunks : (u64)P->lanes);
+    std::atomic<int> bad(0);
+    auto work = [&](int t) {
+        hipSetDevice(c->device);
+        IoLane &L = P->lane[t];
+        auto issue = [&](u64 i, int slot) -> bool {
+            const u64 off = i * IO_CHUNK; const size_t n = len - off < IO_CHUNK ? (size_t)(len - off) : IO_CHUNK;
+            return hipMemcpyAsync(L.pin[slot], (const u8 *)d_src + off, n, hipMemcpyDeviceToHost, L.s) == hipSuccess && hipEventRecord(L.ev[slot], L.s) == hipSuccess;
+        };
+        if ((u64)t < nchunks && !issue((u64)t, 0)) { bad = 2; return; }
+        for (u64 i = (u64)t, k = 0; i < nchunks && !bad.load(); i += (u64)T, k++) {
+            const int slot = (int)(k & 1); const u64 off = i * IO_CHUNK; const size_t n = len - off < IO_CHUNK ? (size_t)(len - off) : IO_CHUNK;
+            if (i + (u64)T < nchunks && !issue(i + (u64)T, slot ^ 1)) { bad = 2; break; }                   // next chunk on the link while this one is written
+            if (hipEventSynchronize(L.ev[slot]) != hipSuccess) { bad = 2; break; }
+            if (!pwrite_full(fd, L.pin[slot], n, file_off + off)) { bad = 1; break; }
+        }
+        hipStreamSynchronize(L.s);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    if (bad == 1) return ctx_fail(c, NAF_GPU_EARG, "can't write to file - disk full?");
+    if (bad) return ctx_fail(c, NAF_GPU_EHIP, "device -> host copy failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}

@@ -83,6 +83,7 @@ extern "C" void naf_gpu_shutdown(naf_gpu_ctx *c)
         delete sc;
     }
     ennaf_shard_state_free(c);
+    io_pool_free(c);
     if (c->fork_ev) hipEventDestroy(c->fork_ev);
     for (int k = 0; k < ZSPLIT_MAX + 2; k++) if (c->split_ev[k]) hipEventDestroy(c->split_ev[k]);
     for (auto &ch : c->chunks) hipFree(ch.base);

@@ -106,6 +106,83 @@ static void report(const unsigned long long *n, const char *name)      /* proces
     if (n[256]) msg("    EOF: %llu\n", n[256]);
 }
 
+/* ---- one input on several GPUs (NAF_GPUS=a,b,...; include/naf_gpu.h "ennaf of ONE input on several GPUs") ----------------------
+ * One host thread per device.  Every thread reads its nominal slice of the file straight into its device, the cuts are moved to
+ * where a shard may begin (FASTA: behind a line end; FASTQ: a line whose ordinal is a multiple of four, from a census of every
+ * slice), each thread fetches the few bytes its shard borrows from the next slice, and the shards run naf_gpu_ennaf_shard_begin /
+ * _finish with the fixed-size shard records exchanged through memory in between.  The parts are written into their places of
+ * the output file by the threads that made them (per-GPU D2H + pwrite), or in order by the main thread when the output is a pipe. */
+#define SHARD_SPARE ((size_t)16 << 20)
+typedef struct {
+    int k, n, device, fd, prev_is_eol;
+    naf_gpu_ctx *c;
+    size_t a, b;                    /* nominal slice [a, b) of the file */
+    void *d_buf; uint64_t lines, cut;
+    size_t lo, len;                 /* the shard's text inside d_buf */
+    void *d_pieces; naf_gpu_shard_pieces pc;
+    int rc; char msg[512];
+} enc_job;
+static enc_job ejobs[MAX_DEVS];
+static naf_gpu_shard_info sh_infos[MAX_DEVS];
+static pthread_barrier_t sh_bar;
+static int sh_fmt = 0, sh_fallback = 0, sh_out_fd = -1; static uint64_t sh_p0 = 0; static off_t sh_out_at = 0;
+static naf_gpu_ennaf_opts sh_opts;
+static naf_gpu_stitch_seg sh_segs[7 + 6 * MAX_DEVS]; static size_t sh_nsegs = 0;
+
+static void job_fail(enc_job *j, int rc) { j->rc = rc; snprintf(j->msg, sizeof j->msg, "%s", naf_gpu_last_error(j->c)); }
+#define JOB_TRY(j, call) do { int rc__ = (call); if (rc__ && !(j)->rc) job_fail((j), rc__); } while (0)
+static void jobs_check(int n)            /* after a barrier: the first failed shard's message, as the reference would print it */
+{
+    for (int k = 0; k < n; k++) if (ejobs[k].rc) { size_t l = strlen(ejobs[k].msg); die("%s%s", ejobs[k].msg, (l && ejobs[k].msg[l - 1] == '\n') ? "" : "\n"); }
+}
+
+static void *enc_worker(void *arg)
+{
+    enc_job *j = (enc_job *)arg; const int k = j->k, n = j->n;
+    if (!j->c) j->c = ctx_open(j->device);
+    naf_gpu_ctx *c = j->c;
+    const size_t nom = j->b - j->a;
+    JOB_TRY(j, naf_gpu_malloc(c, nom + SHARD_SPARE + 64, &j->d_buf));
+    if (!j->rc) JOB_TRY(j, naf_gpu_read_file(c, j->fd, j->a, nom, j->d_buf));
+    if (k == 0 && !j->rc) {
+        JOB_TRY(j, naf_gpu_ennaf_sniff(c, j->d_buf, nom, sh_opts.format, &sh_fmt, &sh_p0));
+        if (!j->rc && (sh_fmt == 0 || sh_p0 >= nom)) sh_fallback = 1;            /* nothing but white space in the first slice: one device does it */
+    }
+    pthread_barrier_wait(&sh_bar);                                               /* 1: format known */
+    if (k == 0) jobs_check(n);
+    if (sh_fallback || ejobs[0].rc) return NULL;
+    const size_t lo = k == 0 ? (size_t)sh_p0 : 0;
+    if (sh_fmt == NAF_FMT_FASTQ) JOB_TRY(j, naf_gpu_ennaf_count_lines(c, (char *)j->d_buf + lo, nom - lo, j->prev_is_eol, &j->lines));
+    pthread_barrier_wait(&sh_bar);                                               /* 2: census */
+    uint64_t before = 0; for (int i = 0; i < k; i++) before += ejobs[i].lines;
+    j->cut = 0;
+    if (k > 0 && !j->rc) JOB_TRY(j, naf_gpu_ennaf_find_cut(c, j->d_buf, nom, sh_fmt, j->prev_is_eol, (4 - before % 4) % 4, &j->cut));
+    pthread_barrier_wait(&sh_bar);                                               /* 3: cuts */
+    if (k == 0) {
+        jobs_check(n);
+        for (int i = 1; i < n; i++) if (ejobs[i].cut > SHARD_SPARE || ejobs[i].cut >= ejobs[i].b - ejobs[i].a) sh_fallback = 2;    /* a line longer than the spare room, or a slice without a cut */
+    }
+    pthread_barrier_wait(&sh_bar);                                               /* 4: verdict on the cuts */
+    if (sh_fallback) return NULL;
+    const size_t borrow = k + 1 < n ? (size_t)ejobs[k + 1].cut : 0;
+    if (borrow) JOB_TRY(j, naf_gpu_read_file(c, j->fd, j->b, borrow, (char *)j->d_buf + nom));
+    j->lo = lo + (size_t)j->cut; j->len = nom - j->lo + borrow;
+    if (!j->rc) JOB_TRY(j, naf_gpu_ennaf_shard_begin(c, (char *)j->d_buf + j->lo, j->len, &sh_opts, sh_fmt, (uint32_t)k, (uint32_t)n, &sh_infos[k]));
+    pthread_barrier_wait(&sh_bar);                                               /* 5: shard records */
+    if (k == 0) jobs_check(n);
+    const size_t pcap = naf_gpu_ennaf_shard_bound(j->len);
+    JOB_TRY(j, naf_gpu_malloc(c, pcap, &j->d_pieces));
+    if (!j->rc) JOB_TRY(j, naf_gpu_ennaf_shard_finish(c, &sh_opts, sh_infos, j->d_pieces, pcap, &j->pc));
+    pthread_barrier_wait(&sh_bar);                                               /* 6: parts */
+    if (k == 0) return NULL;                                                     /* the main thread plans and opens the output, then calls enc_write */
+    pthread_barrier_wait(&sh_bar);                                               /* 7: plan + output file */
+    if (sh_out_fd >= 0)
+        for (size_t i = 0; i < sh_nsegs; i++) if (sh_segs[i].shard == k && sh_segs[i].len)
+            JOB_TRY(j, naf_gpu_write_file(c, sh_out_fd, (uint64_t)sh_out_at + sh_segs[i].dst_off, (char *)j->d_pieces + sh_segs[i].src_off, sh_segs[i].len));
+    pthread_barrier_wait(&sh_bar);                                               /* 8: written */
+    return NULL;
+}
+
 int main(int argc, char **argv)
 {
     prog_name = "ennaf";
@@ -121,32 +198,97 @@ int main(int argc, char **argv)
     FILE *IN = in_file_path ? fopen(in_file_path, "rb") : stdin;
     if (!IN) die("can't open input file\n");
     phase("start");
-    size_t n = 0; unsigned char *text = NULL;
-    void *d_text = read_to_device(IN, &n);                 /* regular file: straight to HBM through the pinned ring */
-    if (!d_text) text = read_all(IN, &n);
-    if (IN != stdin) fclose(IN);
-    phase("read + upload");
-
     char *auto_path = NULL;
     if (!force_stdout && !out_file_path && isatty(fileno(stdout))) {
         if (!in_file_path) die("output file is not specified\n");
         size_t len = strlen(in_file_path) + 5; auto_path = (char *)malloc(len); snprintf(auto_path, len, "%s.naf", in_file_path); out_file_path = auto_path;
     }
-    gpu_open();
-    void *d_naf; size_t cap = naf_gpu_ennaf_bound(n), naf_len = 0;
-    if (!d_text) { GPU_TRY(naf_gpu_malloc(gpu, n + 64, &d_text)); GPU_TRY(naf_gpu_upload(gpu, d_text, text, n)); }
-    GPU_TRY(naf_gpu_malloc(gpu, cap, &d_naf));
     naf_gpu_ennaf_opts o = { fmt_cmd, seq_type, no_mask, strict, level, line_length_is_specified ? requested_line_length : -1, title };
     static naf_gpu_ennaf_report R;
-    phase("allocation");
-    GPU_TRY(naf_gpu_ennaf(gpu, d_text, n, &o, d_naf, cap, &naf_len, &R));
-    phase("ennaf on the GPU");
+    FILE *OUT = stdout;
+    void *d_naf = NULL; size_t naf_len = 0;
+    bool sharded = false; static unsigned char sh_lit[4096 + 256]; size_t nthreads = 0; pthread_t th[MAX_DEVS];
+
+    /* ---- several devices: a regular file of known size, cut into one slice per context */
+    devices_parse();
+    struct stat st;
+    if (n_devs > 1 && fd_is_regular(fileno(IN)) && fstat(fileno(IN), &st) == 0 && (size_t)st.st_size >= (size_t)n_devs * 65536 && (!title || strlen(title) < 4096)) {
+        const size_t fn = (size_t)st.st_size; const int n = n_devs;
+        gpu_open();
+        sh_opts = o;
+        pthread_barrier_init(&sh_bar, NULL, (unsigned)n);
+        for (int k = 0; k < n; k++) {
+            enc_job *j = &ejobs[k]; memset(j, 0, sizeof *j);
+            j->k = k; j->n = n; j->device = dev_ids[k]; j->fd = fileno(IN); j->c = k == 0 ? gpu : NULL;
+            j->a = fn / (size_t)n * (size_t)k; j->b = k + 1 < n ? fn / (size_t)n * (size_t)(k + 1) : fn;
+            j->prev_is_eol = 1;
+            if (k > 0) { unsigned char pb = 0; if (pread(j->fd, &pb, 1, (off_t)j->a - 1) != 1) die("can't read the input\n"); j->prev_is_eol = pb >= 0x0A && pb <= 0x0D; }
+        }
+        for (int k = 1; k < n; k++) { if (pthread_create(&th[k], NULL, enc_worker, &ejobs[k]) != 0) die("can't start a device thread\n"); nthreads++; }
+        enc_worker(&ejobs[0]);
+        if (sh_fallback) {
+            for (int k = 1; k < n; k++) pthread_join(th[k], NULL);
+            for (int k = 1; k < n; k++) if (ejobs[k].c) { naf_gpu_free(ejobs[k].c, ejobs[k].d_buf); naf_gpu_shutdown(ejobs[k].c); }
+            naf_gpu_free(gpu, ejobs[0].d_buf);
+            if (sh_fallback == 2) warn("a shard boundary falls into a line longer than %zu bytes; encoding on one device\n", SHARD_SPARE);
+        } else {
+            jobs_check(n);
+            naf_gpu_shard_pieces pcs[MAX_DEVS]; for (int k = 0; k < n; k++) pcs[k] = ejobs[k].pc;
+            size_t ll = 0; uint64_t nl = 0;
+            int rc = naf_gpu_ennaf_stitch_plan(&o, sh_infos, pcs, (uint32_t)n, sh_segs, sizeof sh_segs / sizeof sh_segs[0], &sh_nsegs, sh_lit, sizeof sh_lit, &ll, &nl, &R);
+            if (rc) die("can't join the parts of the archive: %s\n", naf_gpu_strerror(rc));
+            naf_len = (size_t)nl; sharded = true;
+            phase("ennaf on the GPUs");
+        }
+    }
+    if (!sharded) {
+        size_t n = 0; unsigned char *text = NULL;
+        void *d_text = read_to_device(IN, &n);                 /* regular file: straight to HBM through the pinned lanes */
+        if (!d_text) text = read_all(IN, &n);
+        phase("read + upload");
+        gpu_open();
+        size_t cap = naf_gpu_ennaf_bound(n);
+        if (!d_text) { GPU_TRY(naf_gpu_malloc(gpu, n + 64, &d_text)); GPU_TRY(naf_gpu_upload(gpu, d_text, text, n)); }
+        GPU_TRY(naf_gpu_malloc(gpu, cap, &d_naf));
+        phase("allocation");
+        GPU_TRY(naf_gpu_ennaf(gpu, d_text, n, &o, d_naf, cap, &naf_len, &R));
+        phase("ennaf on the GPU");
+    }
+    if (IN != stdin) fclose(IN);
     if (R.format && fmt_ext != NAF_FMT_AUTO && fmt_ext != R.format) warn("input file extension does not match its actual format\n");
     if (fmt_ext != NAF_FMT_AUTO && fmt_cmd != NAF_FMT_AUTO && fmt_ext != fmt_cmd) warn("input file extension does not match format specified in the command line\n");
-    FILE *OUT = stdout;
     if (out_file_path && !force_stdout) { OUT = fopen(out_file_path, "wb"); if (!OUT) die("can't create output file\n"); created_output_file = true; }
     if (verbose) msg("Output line length: %llu\n", line_length_is_specified ? (unsigned long long)requested_line_length : (unsigned long long)R.longest_line);
-    write_from_device(OUT, d_naf, naf_len);
+    if (!sharded) write_from_device(OUT, d_naf, naf_len);
+    else {
+        const int n = n_devs;
+        fflush(OUT);
+        off_t at = fd_is_regular(fileno(OUT)) ? lseek(fileno(OUT), 0, SEEK_CUR) : (off_t)-1;
+        sh_out_fd = at >= 0 ? fileno(OUT) : -1; sh_out_at = at >= 0 ? at : 0;
+        pthread_barrier_wait(&sh_bar);                                           /* 7: the workers write their parts */
+        for (size_t i = 0; i < sh_nsegs; i++) {
+            const naf_gpu_stitch_seg *g = &sh_segs[i];
+            if (!g->len) continue;
+            if (at >= 0) {
+                if (g->shard < 0) { if (pwrite(fileno(OUT), sh_lit + g->src_off, g->len, at + (off_t)g->dst_off) != (ssize_t)g->len) die("can't write to file - disk full?\n"); }
+                else if (g->shard == 0) JOB_TRY(&ejobs[0], naf_gpu_write_file(gpu, fileno(OUT), (uint64_t)at + g->dst_off, (char *)ejobs[0].d_pieces + g->src_off, g->len));
+            }
+        }
+        pthread_barrier_wait(&sh_bar);                                           /* 8 */
+        for (int k = 1; k < n; k++) pthread_join(th[k], NULL);
+        jobs_check(n);
+        if (at >= 0) { if (lseek(fileno(OUT), at + (off_t)naf_len, SEEK_SET) < 0) die("can't write to file - disk full?\n"); }
+        else for (size_t i = 0; i < sh_nsegs; i++) {                             /* a pipe: the parts in order, through the main thread */
+            const naf_gpu_stitch_seg *g = &sh_segs[i];
+            if (!g->len) continue;
+            if (g->shard < 0) { if (fwrite(sh_lit + g->src_off, 1, g->len, OUT) != g->len) die("can't write to file - disk full?\n"); continue; }
+            unsigned char *h = (unsigned char *)malloc(g->len); if (!h) die("can't allocate %llu bytes\n", (unsigned long long)g->len);
+            CTX_TRY(ejobs[g->shard].c, naf_gpu_download(ejobs[g->shard].c, h, (char *)ejobs[g->shard].d_pieces + g->src_off, g->len));
+            if (fwrite(h, 1, g->len, OUT) != g->len) die("can't write to file - disk full?\n");
+            free(h);
+        }
+        for (int k = 1; k < n; k++) naf_gpu_shutdown(ejobs[k].c);
+    }
     phase("download + write");
     if (OUT != stdout) { if (fclose(OUT) != 0) die("can't close file - disk full?\n"); } else fflush(stdout);
     if (!well_formed) {

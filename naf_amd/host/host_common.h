@@ -69,19 +69,57 @@ __attribute__((unused)) static int decimal_arg(const char *s, long long *v)
 }
 
 static naf_gpu_ctx *gpu = NULL;
+static void devices_parse(void);
+static int first_device(void);
 static void gpu_open(void)
 {
     if (gpu) return;
     phase("before GPU init");
-    const char *dev = getenv("NAF_GPU_DEVICE");
-    int rc = naf_gpu_init(dev ? atoi(dev) : 0, &gpu);
+    int rc = naf_gpu_init(first_device(), &gpu);
     if (rc) die("can't initialize the GPU path: %s\n", naf_gpu_strerror(rc));
     phase("GPU init");
 }
 #define GPU_TRY(call) do { int rc_ = (call); if (rc_) { const char *m_ = naf_gpu_last_error(gpu); size_t l_ = strlen(m_); \
     die("%s%s", m_, (l_ && m_[l_ - 1] == '\n') ? "" : "\n"); } } while (0)
 
-/* ---- file <-> device through two pinned chunks: the PCIe copy of one chunk overlaps the file I/O of the next ---- */
+/* ---- devices ----------------------------------------------------------------------------------------------------------------
+ * NAF_GPUS=0,1,2,...  one context per entry (an entry may repeat a device: several contexts on one GPU); without it the single
+ * device NAF_GPU_DEVICE (default 0).  The first entry is also the context `gpu` of the single-device paths. */
+#include <pthread.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#define MAX_DEVS 64
+static int dev_ids[MAX_DEVS], n_devs = 0;
+static void devices_parse(void)
+{
+    if (n_devs) return;
+    const char *e = getenv("NAF_GPUS");
+    if (e && *e) {
+        const char *p = e;
+        while (*p && n_devs < MAX_DEVS) {
+            char *end; long v = strtol(p, &end, 10);
+            if (end == p || v < 0) die("can't parse NAF_GPUS=\"%s\"\n", e);
+            dev_ids[n_devs++] = (int)v;
+            p = end; while (*p == ',' || *p == ' ') p++;
+        }
+    }
+    if (!n_devs) { const char *d = getenv("NAF_GPU_DEVICE"); dev_ids[n_devs++] = d ? atoi(d) : 0; }
+}
+static int first_device(void) { devices_parse(); return dev_ids[0]; }
+#define CTX_TRY(ctx, call) do { int rc_ = (call); if (rc_) { const char *m_ = naf_gpu_last_error(ctx); size_t l_ = strlen(m_); \
+    die("%s%s", m_, (l_ && m_[l_ - 1] == '\n') ? "" : "\n"); } } while (0)
+static naf_gpu_ctx *ctx_open(int device)
+{
+    naf_gpu_ctx *c = NULL;
+    int rc = naf_gpu_init(device, &c);
+    if (rc) die("can't initialize the GPU path: %s\n", naf_gpu_strerror(rc));
+    return c;
+}
+static bool fd_is_regular(int fd) { struct stat st; return fstat(fd, &st) == 0 && S_ISREG(st.st_mode); }
+
+/* ---- file <-> device --------------------------------------------------------------------------------------------------------
+ * Regular files go through naf_gpu_read_file / naf_gpu_write_file (several host threads, pinned staging, pread / pwrite at
+ * offsets); pipes through the sequential two-chunk ring below. */
 #define IO_CHUNK ((size_t)64 << 20)
 static void *io_pin[2] = { NULL, NULL };
 static void io_open(void)
@@ -92,6 +130,15 @@ static void io_open(void)
 static void write_from_device(FILE *f, const void *d, size_t n)
 {
     if (!n) return;
+    fflush(f);
+    if (fd_is_regular(fileno(f))) {
+        off_t at = lseek(fileno(f), 0, SEEK_CUR);
+        if (at >= 0) {
+            GPU_TRY(naf_gpu_write_file(gpu, fileno(f), (uint64_t)at, d, n));
+            if (lseek(fileno(f), at + (off_t)n, SEEK_SET) < 0) die("can't write to file - disk full?\n");
+            return;
+        }
+    }
     io_open();
     size_t off = 0; int cur = 0;
     GPU_TRY(naf_gpu_download_async(gpu, io_pin[0], d, n < IO_CHUNK ? n : IO_CHUNK));
@@ -106,22 +153,15 @@ static void write_from_device(FILE *f, const void *d, size_t n)
 /* Regular file of known size straight into device memory; returns NULL when the size is not known up front (pipes). */
 __attribute__((unused)) static void *read_to_device(FILE *f, size_t *len)
 {
-    if (f == stdin || fseek(f, 0, SEEK_END) != 0) return NULL;
-    long sz = ftell(f); rewind(f);
-    if (sz <= 0) return NULL;
-    io_open();
-    void *d; GPU_TRY(naf_gpu_malloc(gpu, (size_t)sz + 64, &d));
-    size_t n = 0; int cur = 0;
-    for (;;) {
-        size_t want = (size_t)sz - n < IO_CHUNK ? (size_t)sz - n : IO_CHUNK;
-        if (!want) break;
-        GPU_TRY(naf_gpu_synchronize(gpu));                                   /* the upload that last used this chunk is done */
-        size_t r = fread(io_pin[cur], 1, want, f);
-        if (!r) break;
-        GPU_TRY(naf_gpu_upload(gpu, (char *)d + n, io_pin[cur], r));
-        n += r; cur ^= 1;
-    }
-    GPU_TRY(naf_gpu_synchronize(gpu));
+    if (f == stdin && !fd_is_regular(fileno(f))) return NULL;
+    if (!fd_is_regular(fileno(f))) return NULL;
+    struct stat st; if (fstat(fileno(f), &st) != 0 || st.st_size <= 0) return NULL;
+    off_t at = lseek(fileno(f), 0, SEEK_CUR); if (at < 0) at = 0;
+    size_t n = (size_t)st.st_size > (size_t)at ? (size_t)st.st_size - (size_t)at : 0;
+    if (!n) return NULL;
+    gpu_open();
+    void *d; GPU_TRY(naf_gpu_malloc(gpu, n + 64, &d));
+    GPU_TRY(naf_gpu_read_file(gpu, fileno(f), (uint64_t)at, n, d));
     *len = n;
     return d;
 }

@@ -113,17 +113,80 @@ static unsigned char *load_strings(int i, const char *what, unsigned long long n
     return b;
 }
 
+/* ---- text output --------------------------------------------------------------------------------------------------------------
+ * The text is produced in byte ranges (naf_gpu_unnaf_range): never more than RANGE bytes of it are resident, so archives whose
+ * text exceeds HBM decode too, and with NAF_GPUS=a,b,... every device takes a contiguous share of the text and writes it into
+ * its place of the output file on its own (per-GPU D2H + pwrite: when the consumer is the host there is nothing to gather over
+ * xGMI first).  A pipe gets the ranges in order from one device. */
+static size_t range_bytes(void)
+{
+    const char *e = getenv("NAF_GPU_RANGE_BYTES");
+    unsigned long long v = e ? strtoull(e, NULL, 10) : 0;
+    if (v < 4096) v = (unsigned long long)16 << 30;
+    return (size_t)(v & ~4095ull);
+}
+typedef struct { int k, n, device; naf_gpu_unnaf_opts o; size_t total, lo, hi; off_t file_at; naf_gpu_ctx *c; } text_job;
+static void *text_worker(void *arg)
+{
+    text_job *j = (text_job *)arg;
+    naf_gpu_ctx *c = j->c;
+    void *d_arc = d_naf;
+    if (!c) {                                                   /* a device of its own: context and a copy of the archive */
+        c = ctx_open(j->device);
+        CTX_TRY(c, naf_gpu_malloc(c, naf_len + 64, &d_arc));
+        CTX_TRY(c, naf_gpu_upload(c, d_arc, naf, naf_len)); CTX_TRY(c, naf_gpu_synchronize(c));
+    }
+    const size_t R = range_bytes(), span = j->hi - j->lo, cap = span < R ? span : R;
+    void *d; CTX_TRY(c, naf_gpu_malloc(c, cap + 64, &d));
+    for (size_t b = j->lo; b < j->hi; b += cap) {
+        size_t e = b + cap < j->hi ? b + cap : j->hi, got = 0;
+        if (j->n == 1 && cap == j->total) CTX_TRY(c, naf_gpu_unnaf(c, d_arc, naf_len, &j->o, d, cap, &got));       /* everything at once: the whole-text call overlaps its side streams */
+        else CTX_TRY(c, naf_gpu_unnaf_range(c, d_arc, naf_len, &j->o, b, e, d, cap, &got));
+        if (got != e - b) die("can't decompress sequence\n");
+        CTX_TRY(c, naf_gpu_write_file(c, fileno(OUT), (uint64_t)j->file_at + b, d, got));
+    }
+    naf_gpu_free(c, d);
+    if (c != gpu) { naf_gpu_free(c, d_arc); naf_gpu_shutdown(c); }
+    return NULL;
+}
+
 static void run_text(int mode, int masking_allowed)
 {
     upload();
     naf_gpu_unnaf_opts o = { mode, masking_allowed && use_mask, line_length_is_specified ? requested_line_length : -1 };
     size_t n = 0; GPU_TRY(naf_gpu_unnaf_size(gpu, d_naf, naf_len, &o, &n));
     if (!n) return;
-    void *d; GPU_TRY(naf_gpu_malloc(gpu, n + 64, &d));
-    phase("size + output allocation");
-    size_t got = 0; GPU_TRY(naf_gpu_unnaf(gpu, d_naf, naf_len, &o, d, n, &got));
-    GPU_TRY(naf_gpu_synchronize(gpu)); phase("unnaf on the GPU");
-    write_from_device(OUT, d, got); phase("download + write"); naf_gpu_free(gpu, d);
+    phase("size");
+    fflush(OUT);
+    off_t at = fd_is_regular(fileno(OUT)) ? lseek(fileno(OUT), 0, SEEK_CUR) : (off_t)-1;
+    if (at >= 0) {
+        devices_parse();
+        int nd = n_devs; if ((size_t)nd > n / 4096 + 1) nd = (int)(n / 4096 + 1);
+        size_t per = ((n + (size_t)nd - 1) / (size_t)nd + 4095) & ~(size_t)4095;
+        text_job jobs[MAX_DEVS]; pthread_t th[MAX_DEVS];
+        for (int k = 0; k < nd; k++) {
+            size_t lo = (size_t)k * per < n ? (size_t)k * per : n, hi = lo + per < n ? lo + per : n;
+            jobs[k] = (text_job){ k, nd, dev_ids[k], o, n, lo, hi, at, k == 0 ? gpu : NULL };
+        }
+        for (int k = 1; k < nd; k++) if (pthread_create(&th[k], NULL, text_worker, &jobs[k]) != 0) die("can't start a device thread\n");
+        text_worker(&jobs[0]);
+        for (int k = 1; k < nd; k++) pthread_join(th[k], NULL);
+        if (lseek(fileno(OUT), at + (off_t)n, SEEK_SET) < 0) die("can't write to file - disk full?\n");
+        phase("unnaf on the GPU + download + write");
+        return;
+    }
+    const size_t R = range_bytes(), cap = n < R ? n : R;
+    void *d; GPU_TRY(naf_gpu_malloc(gpu, cap + 64, &d));
+    if (cap == n) {                                             /* the whole text at once: one pass over the side streams */
+        size_t got = 0; GPU_TRY(naf_gpu_unnaf(gpu, d_naf, naf_len, &o, d, n, &got));
+        GPU_TRY(naf_gpu_synchronize(gpu)); phase("unnaf on the GPU");
+        write_from_device(OUT, d, got);
+    } else for (size_t b = 0; b < n; b += cap) {
+        size_t e = b + cap < n ? b + cap : n, got = 0;
+        GPU_TRY(naf_gpu_unnaf_range(gpu, d_naf, naf_len, &o, b, e, d, cap, &got));
+        write_from_device(OUT, d, got);
+    }
+    phase("download + write"); naf_gpu_free(gpu, d);
 }
 
 int main(int argc, char **argv)

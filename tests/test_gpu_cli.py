@@ -56,3 +56,51 @@ def test_interop_with_the_real_reference(oracle):
                 continue
             a = subprocess.run([os.path.join(BIN, "unnaf"), m, "-c"], input=naf, stdout=subprocess.PIPE, timeout=120).stdout
             assert a == oracle.ref_unnaf(naf, (m,)), (case["name"], m)
+
+
+def test_clis_on_several_contexts_and_in_ranges(oracle, tmp_path):
+    """NAF_GPUS=0,0,0: one host thread and one context per entry (here three on the one device of the test box) -- ennaf cuts the
+    file into slices and joins the parts into one archive, unnaf writes every context's share of the text into its place of the
+    output file.  NAF_GPU_RANGE_BYTES makes the text leave in small byte ranges, the way a text larger than HBM would."""
+    import numpy as np
+    from naf_amd import synth
+    from test_shard_cpu import check_against_whole
+    inputs = {"mixed.fa": synth.fasta_mixed(60, 6000, 60, seed=5), "one.fa": synth.fasta_acgt(700_001, 1, 70, seed=3),
+              "reads.fq": synth.fastq_reads(2500, 100, seed=9, var_len=True)}
+    for name, text in inputs.items():
+        src = tmp_path / name
+        src.write_bytes(text)
+        fq = name.endswith(".fq")
+        for gpus in ("0,0,0", "0,0", "0"):
+            env = dict(os.environ, NAF_GPUS=gpus)
+            arc = tmp_path / (name + "." + gpus.replace(",", "") + ".naf")
+            e = subprocess.run([os.path.join(BIN, "ennaf"), str(src), "-o", str(arc)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+            assert e.returncode == 0 and e.stderr == b"", e.stderr
+            naf = arc.read_bytes()
+            sp = oracle.split_text(text)
+            h = oracle.parse_naf(naf)
+            want = [sp.ids, sp.comments, sp.lengths, sp.mask, sp.seq, sp.qual]
+            for i in range(6):
+                if i == 5 and not fq:
+                    continue
+                assert oracle.zstd_decompress(h.frame(naf, i), len(want[i]) + 16) == want[i], (name, gpus, i)
+            piped = subprocess.run([os.path.join(BIN, "ennaf"), str(src), "-c"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+            assert piped.returncode == 0 and piped.stdout == naf                   # parts in order through a pipe == parts written in place
+            expect = oracle.unnaf(naf, -1)
+            for rng in (None, "65536"):
+                env2 = dict(env)
+                if rng:
+                    env2["NAF_GPU_RANGE_BYTES"] = rng
+                out = tmp_path / "out.txt"
+                u = subprocess.run([os.path.join(BIN, "unnaf"), str(arc), "-o", str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env2)
+                assert u.returncode == 0 and u.stderr == b"", u.stderr
+                assert out.read_bytes() == expect, (name, gpus, rng)
+                u = subprocess.run([os.path.join(BIN, "unnaf"), str(arc), "-c"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env2)
+                assert u.returncode == 0 and u.stdout == expect, (name, gpus, rng)
+    # a malformed record in the last slice: the message numbers it from the start of the file
+    bad = inputs["reads.fq"].rstrip(b"\n")[:-3] + b"\n"
+    (tmp_path / "bad.fq").write_bytes(bad)
+    e = subprocess.run([os.path.join(BIN, "ennaf"), str(tmp_path / "bad.fq"), "-c"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=dict(os.environ, NAF_GPUS="0,0,0"))
+    with pytest.raises(ValueError) as ex:
+        oracle.split_text(bad)
+    assert e.returncode == 1 and e.stdout == b"" and e.stderr.decode() == "ennaf error: " + str(ex.value).strip() + "\n"
