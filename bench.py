@@ -37,6 +37,13 @@ def have_ref():
     return os.access(REF_E, os.X_OK) and os.access(REF_U, os.X_OK)
 
 
+def last_line_end(t):
+    """Length of the longest prefix of t that ends with a line end (looked for in its last 64 KiB)."""
+    w = min(int(t.numel()), 65536)
+    tail = t[t.numel() - w:]
+    return int(t.numel()) - w + int((tail == 10).nonzero()[-1].item()) + 1
+
+
 def cpu_baseline(text_dev, size_bytes, ctx=None, full_ref_archive=True, e2e_bytes=0):
     """Reference unnaf/ennaf (oracle/_ref, built from the reference sources) on this box's host cores, one thread (the reference
     is single-threaded), on a bounded sample of the same workload; the GPU decoder on the archive the reference makes of the
@@ -50,7 +57,7 @@ def cpu_baseline(text_dev, size_bytes, ctx=None, full_ref_archive=True, e2e_byte
     try:
         sample = text_dev[:size_bytes]
         # cut at a line end so the sample is a well-formed FASTA prefix
-        cut = int((sample == 10).nonzero()[-1].item()) + 1
+        cut = last_line_end(sample)
         sample[:cut].cpu().numpy().tofile(P("s.fa"))
         env = dict(os.environ, TMPDIR=shm)
         t0 = time.perf_counter()
@@ -112,7 +119,7 @@ def cpu_baseline(text_dev, size_bytes, ctx=None, full_ref_archive=True, e2e_byte
         if e2e_bytes and os.access(os.path.join(BIN, "ennaf"), os.X_OK):
             # drop-in reality check: file -> file through the CLIs (tmpfs; PCIe, file I/O and process start included) -- never the `value`
             e2e = text_dev[:e2e_bytes]
-            cut2 = int((e2e == 10).nonzero()[-1].item()) + 1
+            cut2 = last_line_end(e2e)
             e2e[:cut2].cpu().numpy().tofile(P("e.fa"))
             def timed(cmd):
                 t0 = time.perf_counter()
@@ -368,7 +375,7 @@ def main():
         ennaf_roofline = roofline_of(enc_kt, ealg, n_text, n_text + n_naf, min(enc_times) * 1e3, fname="pmc_traffic_ennaf.json")
 
     cb = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and not multi and not args.no_cpu:
         del out
         cb = cpu_baseline(text, int(min(args.cpu_sample, n_text)), ctx, e2e_bytes=int(min(args.e2e_size, n_text)))
     if rank == 0:
