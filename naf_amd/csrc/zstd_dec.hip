@@ -24,6 +24,7 @@ struct ZStat {                 // device-side counters read back by the host
     u64 total_seq, total_out;
     u32 ticket, n_plain_huf;     // n_plain_huf: compressed blocks with Huffman literals and no sequences
     u32 max_seq_regen, pad2;      // largest regenerated size among the blocks that have sequences
+    u32 sig_max, sig_nmin;        // largest hash of a block's Huffman weights and the complement of the smallest: equal hashes = one tree for the whole frame
 };
 
 static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
@@ -255,6 +256,17 @@ __global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_hu
     if (sq) atomicAdd(&st->n_seq_blk, 1u);
 }
 
+// Hash of a block's weight table: when every table-defining block of a frame hashes alike (random ACGT: sixteen 4-bit codes in
+// every block) the literals kernel is given room for its multi-symbol table (k_huf_literals).  Equal hashes are only a hint -- the
+// kernel compares the staged tables themselves before it shares one.
+static __device__ __forceinline__ void huf_sig(ZStat *st, const u8 *w, u32 nw)
+{
+    u32 h = 2166136261u ^ nw;
+    for (u32 i = 0; i < nw; i++) h = (h ^ w[i]) * 16777619u;
+    if (h > __atomic_load_n(&st->sig_max, __ATOMIC_RELAXED)) atomicMax(&st->sig_max, h);
+    if (~h > __atomic_load_n(&st->sig_nmin, __ATOMIC_RELAXED)) atomicMax(&st->sig_nmin, ~h);
+}
+
 __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first)
 {
     u32 i = first + blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,6 +282,7 @@ __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 
     huf_build_any((u16 *)(pool + off), w, nw, log);
     blk[i].huf_tab = off; blk[i].huf_log = (u8)log;
     atomicMax(&st->max_huf_log, log);
+    huf_sig(st, w, nw);
 }
 
 // The same for streams of a few blocks (ids, names, lengths, the last block of a mask stream): one block per workgroup, the tree
@@ -297,7 +310,7 @@ __global__ __launch_bounds__(64) void k_build_huf_lds(const u8 *src, ZBlock *blk
             u32 bytes = huf_tab_bytes(log);
             off = atomicAdd(&st->huf_pool_used, bytes);
             if (off + bytes > pool_cap) { set_err(st, ZE_POOL); log = 0; }
-            else { huf_build_any_ws(tab, w, nw, log, ws); blk[i].huf_tab = off; blk[i].huf_log = (u8)log; atomicMax(&st->max_huf_log, log); }
+            else { huf_build_any_ws(tab, w, nw, log, ws); blk[i].huf_tab = off; blk[i].huf_log = (u8)log; atomicMax(&st->max_huf_log, log); huf_sig(st, w, nw); }
         }
         s_log = log; s_off = off;
     }
@@ -588,13 +601,14 @@ __global__ void k_emit_headers(EmitP P, u8 *text)
 template <bool FUSE>
 __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf,
                                                       const u8 *pool, u32 slot_bytes, u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first,
-                                                      EmitP EP, u8 *text, u32 ipitch, u64 src_len)
+                                                      EmitP EP, u8 *text, u32 ipitch, u64 src_len, u32 mk)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     u8 *irows = lds + HUF_BLOCKS_PER_WG * slot_bytes;                // 64 input rings of ipitch bytes (136: 2 sectors, 264: 4 sectors)
     u16 *lut2 = (u16 *)(irows + 64 * ipitch);                         // FUSE: packed byte -> two ASCII bytes
     u8 *orows = (u8 *)lut2;                                           // !FUSE: 64 output rows of 72 B + 64 row pointers
     u64 *row_out = (u64 *)(orows + 64 * HUF_OROW);
+    u32 *mtab = (u32 *)(row_out + 64);                                 // mk != 0: 2^mk entries of the multi-symbol table (below)
     if (FUSE) for (u32 v = threadIdx.x; v < 256; v += 64) {
         u32 a = v & 15, b = v >> 4;
         lut2[v] = (u16)(((EP.lut[a >> 2] >> (8 * (a & 3))) & 0xFF) | (((EP.lut[b >> 2] >> (8 * (b & 3))) & 0xFF) << 8));
@@ -655,6 +669,44 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
     const bool big = ipitch > HUF_IROW;
     const u32 rmask = big ? 255u : 127u, guard = big ? 192u : 160u;
     __syncthreads();
+    // ---- multi-symbol table ------------------------------------------------------------------------------------------------
+    // When the streams of this workgroup all decode with one and the same table of short codes (a frame of random ACGT has the
+    // same sixteen 4-bit codes in every block; blocks that share a tree by construction), one table indexed by the next `mk` bits
+    // returns every whole symbol those bits hold -- up to three, with their total length -- so the dependent chain of shift, LDS
+    // read and shift is walked once per two or three symbols instead of once per symbol.  Entry: symbols in bytes 0..2, total bits
+    // in bits 24..27, symbol count in bits 28..29.  Codes of up to 6 bits only: a round then never takes more than the 28 bytes
+    // the two-sector input ring allows (34 symbols x 6 bits).
+    bool multi = false; u32 decoded = 0;
+    if (!FUSE && mk && !big) {
+        const u64 vm = __ballot(valid);
+        if (vm) {
+            const int l0 = __ffsll((long long)vm) - 1;
+            const u32 log0 = (u32)__shfl((int)log, l0, 64);
+            const u16 *tab0 = (const u16 *)(lds + (u32)(l0 >> 2) * slot_bytes);
+            bool same = log0 <= 6 && log0 <= mk && (!valid || log == log0);
+            if (valid && same && tab != tab0) for (u32 k = 0; k < (1u << log0); k++) same = same && tab[k] == tab0[k];
+            if (__all(same)) {
+                bool bad = false;
+                for (u32 i = (u32)lane; i < (1u << mk); i += 64) {
+                    u32 x = i << (32 - mk), left = mk, e = 0, cnt = 0, tot = 0;
+                    for (u32 q = 0; q < 3; q++) {
+                        const u32 t = tab0[x >> (32 - log0)], nb = t & 0xFF;
+                        if (nb == 0 || nb > left) break;
+                        e |= (t >> 8) << (8 * cnt); cnt++; tot += nb; left -= nb; x <<= nb;
+                    }
+                    if (!cnt) bad = true;
+                    mtab[i] = e | (tot << 24) | (cnt << 28);
+                }
+                multi = !__any(bad);
+                if (multi) {                                             // never run past the stream: a round ends at most 2 symbols over
+                    u32 mr = valid ? (n >= 2 ? (n - 2) / HUF_ROUND : 0) : 0xFFFFFFFFu;
+                    for (int d = 32; d; d >>= 1) { u32 o = (u32)__shfl_xor((int)mr, d, 64); mr = o < mr ? o : mr; }
+                    if (rounds) rounds = mr == 0xFFFFFFFFu ? 0 : mr;
+                }
+            }
+        }
+        __syncthreads();
+    }
     u32 R = 0;
     {
         // ---- sector-window reader -------------------------------------------------------------------------
@@ -673,6 +725,69 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
             for (int q = 0; q < 8; q++) { uint4 v = g0[q]; u32 o = (u32)((lo + 16 * q) & rmask); *(u64 *)(irow + o) = (u64)v.x | ((u64)v.y << 32); *(u64 *)(irow + o + 8) = (u64)v.z | ((u64)v.w << 32); }
         }
         u32 bits = br.consumed;                                            // bits consumed since the container at gp
+        if (multi) {
+            u8 *orow = orows + lane * HUF_OROW;
+            u32 p = 0;                                                    // symbols waiting in this lane's output row
+            for (; R < rounds; R++) {
+                if (!__all(!valid || (live && gp - (u64)br.start >= guard))) break;
+                if (valid) {
+                    if (pending) {
+                        lo -= 64; u32 o = (u32)(lo & rmask);
+                        *(u64 *)(irow + o) = (u64)st0.x | ((u64)st0.y << 32); *(u64 *)(irow + o + 8) = (u64)st0.z | ((u64)st0.w << 32);
+                        *(u64 *)(irow + o + 16) = (u64)st1.x | ((u64)st1.y << 32); *(u64 *)(irow + o + 24) = (u64)st1.z | ((u64)st1.w << 32);
+                        *(u64 *)(irow + o + 32) = (u64)st2.x | ((u64)st2.y << 32); *(u64 *)(irow + o + 40) = (u64)st2.z | ((u64)st2.w << 32);
+                        *(u64 *)(irow + o + 48) = (u64)st3.x | ((u64)st3.y << 32); *(u64 *)(irow + o + 56) = (u64)st3.z | ((u64)st3.w << 32);
+                        pending = false;
+                    }
+                    if (lo + 56u > gp) {
+                        const uint4 *g0 = (const uint4 *)(lo - 64);
+                        st0 = g0[0]; st1 = g0[1]; st2 = g0[2]; st3 = g0[3]; pending = true;
+                    }
+                    // this round fills the row up to 32 (even rounds) or 64 symbols; a look-up adds one to three, so it ends at most
+                    // two symbols over.  Four look-ups (at most 4 x mk <= 40 bits) per refill of the container.
+                    const u32 target = ((R & 1u) + 1u) * HUF_ROUND;
+                    for (u32 g = 0; g < HUF_ROUND / 4 && p < target; g++) {
+                        gp -= bits >> 3; bits &= 7;
+                        u32 o = (u32)(gp & 127), sh = (o & 7) * 8;
+                        u64 q0 = *(const u64 *)(irow + (o & ~7u)), q1 = *(const u64 *)(irow + (((o & ~7u) + 8) & 127));
+                        u64 w = (sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0) << bits;
+#pragma unroll
+                        for (u32 q = 0; q < 4; q++) {
+                            if (p < target) {
+                                const u32 e = mtab[(u32)(w >> 32) >> (32 - mk)];
+                                const u32 nb = (e >> 24) & 15u;
+                                w <<= nb; bits += nb;
+                                __builtin_memcpy(orow + p, &e, 4);            // three symbol bytes and one that the next store overwrites
+                                p += e >> 28;
+                            }
+                        }
+                    }
+                }
+                if (R & 1) {                                              // the rows hold 64 symbols (and up to 2 more): write them out, 4 lanes per row
+                    u32 tail = 0;
+                    if (valid) __builtin_memcpy(&tail, orow + 64, 4);
+                    __syncthreads();
+#pragma unroll
+                    for (u32 jj = 0; jj < 4; jj++) {
+                        u32 row = jj * 16 + (lane >> 2), piece = lane & 3;
+                        u64 o = row_out[row];
+                        if (o) {
+                            const u8 *r = orows + row * HUF_OROW + piece * 16;
+                            uint4 v; u64 a = *(const u64 *)r, bb = *(const u64 *)(r + 8);
+                            v.x = (u32)a; v.y = (u32)(a >> 32); v.z = (u32)bb; v.w = (u32)(bb >> 32);
+                            memcpy((u8 *)o + (u64)(R >> 1) * 64 + piece * 16, &v, 16);
+                        }
+                    }
+                    __syncthreads();
+                    if (valid) { __builtin_memcpy(orow, &tail, 4); p -= 64; }
+                }
+            }
+            if (valid) {                                                  // what is left in the row: at most 34 symbols
+                const u64 at = (u64)(R >> 1) * 64;
+                for (u32 q = 0; q < p; q++) out[at + q] = orow[q];
+                decoded = (u32)at + p;
+            }
+        } else {
         for (; R < rounds; R++) {
             if (!__all(!valid || (live && gp - (u64)br.start >= guard))) break;   // near a stream start: generic reader finishes
             if (valid) {
@@ -758,11 +873,13 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
             const u8 *r = orows + lane * HUF_OROW;
             for (u32 q = 0; q < 32; q += 8) st64(out + (u64)(R - 1) * HUF_ROUND + q, *(const u64 *)(r + q));
         }
+        decoded = R * HUF_ROUND;
+        }
         if (valid && live) { gp -= bits >> 3; bits &= 7; br.c = ld64((const u8 *)gp); br.consumed = bits; }
         br.ptr = (const u8 *)gp;
     }
     if (valid) {
-        u32 done = R * HUF_ROUND;
+        u32 done = decoded;
         u8 e = 0;
         if (FUSE) {
             u32 rem = n - done;
@@ -1177,9 +1294,15 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         u32 ipitch = hs.max_huf_log > 7 ? HUF_IROW_BIG : HUF_IROW;
         u32 ipitch_arg = ipitch | ((getenv("NAF_GPU_HUF_GENERIC") && getenv("NAF_GPU_HUF_GENERIC")[0] == '1') ? 0x8000u : 0u);
         if (b_count && fuse) LAUNCH(c, "zstd_huf_fused_emit", (k_huf_literals<true>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 512,
-               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len);
+               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, 0u);
         else if (b_count) {
-            const u32 huf_lds = slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512 + (getenv("NAF_GPU_PADLDS") ? atoi(getenv("NAF_GPU_PADLDS")) : 0);
+            // room for the multi-symbol table when the frame's blocks carry one and the same tree (hash of the weights, k_build_huf) or
+            // mostly borrow their neighbours' (treeless): 2^8 entries for codes of up to 4 bits, 2^10 up to 6 bits
+            const char *mm = getenv("NAF_GPU_HUF_MULTI");                        // "0": single-symbol look-ups only (cross-check)
+            u32 mk = 0;
+            if (!(mm && mm[0] == '0') && hs.max_huf_log <= 6 && ((hs.sig_max == ~hs.sig_nmin) || (u64)n_huf_def * 4 <= (u64)b_count))
+                mk = hs.max_huf_log <= 4 ? 8u : 10u;
+            const u32 huf_lds = slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512 + (mk ? (4u << mk) : 0u) + (getenv("NAF_GPU_PADLDS") ? atoi(getenv("NAF_GPU_PADLDS")) : 0);
             ZSplit *sp = c->zsplit;
             const char *smin = getenv("NAF_GPU_SPLIT_MIN");                      // blocks per part below which a split is not worth its launches (tests lower it)
             const u32 split_min = smin ? (u32)atoi(smin) : 4096u;
@@ -1200,13 +1323,13 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                 for (int k = 0; k < sp->parts; k++) {
                     u32 hi_b = k + 1 == sp->parts ? b_count : (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
                     if (hi_b > lo_b) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds,
-                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len);
+                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len, mk);
                     HIP_TRY(c, hipEventRecord(sp->ev[k], c->stream));
                     lo_b = hi_b;
                 }
                 sp->done = 1;
             } else LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, huf_lds,
-               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len);
+               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, mk);
         }
     }
     if (b_count && !fuse && !copy_fill_done) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
