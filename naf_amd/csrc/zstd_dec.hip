@@ -23,8 +23,7 @@ struct ZStat {                 // device-side counters read back by the host
     u32 huf_pool_used, fse_pool_used;
     u64 total_seq, total_out;
     u32 ticket, n_plain_huf;     // n_plain_huf: compressed blocks with Huffman literals and no sequences
-    u32 max_seq_regen, pad2;      // largest regenerated size among the blocks that have sequences
-    u32 sig_max, sig_nmin;        // largest hash of a block's Huffman weights and the complement of the smallest: equal hashes = one tree for the whole frame
+    u32 max_seq_regen, n_flat;    // largest regenerated size among the blocks that have sequences; table-defining blocks whose tree is flat
 };
 
 static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
@@ -256,15 +255,14 @@ __global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_hu
     if (sq) atomicAdd(&st->n_seq_blk, 1u);
 }
 
-// Hash of a block's weight table: when every table-defining block of a frame hashes alike (random ACGT: sixteen 4-bit codes in
-// every block) the literals kernel is given room for its multi-symbol table (k_huf_literals).  Equal hashes are only a hint -- the
-// kernel compares the staged tables themselves before it shares one.
-static __device__ __forceinline__ void huf_sig(ZStat *st, const u8 *w, u32 nw)
+// A flat tree: 2^log symbols, every one of weight 1, i.e. every code exactly `log` bits long (packed random ACGT: sixteen 4-bit
+// codes).  Such a stream is a string of fixed-width fields and needs no serial walk (k_flat_literals).
+static __device__ __forceinline__ bool huf_is_flat(const u8 *w, u32 nw, u32 log)
 {
-    u32 h = 2166136261u ^ nw;
-    for (u32 i = 0; i < nw; i++) h = (h ^ w[i]) * 16777619u;
-    if (h > __atomic_load_n(&st->sig_max, __ATOMIC_RELAXED)) atomicMax(&st->sig_max, h);
-    if (~h > __atomic_load_n(&st->sig_nmin, __ATOMIC_RELAXED)) atomicMax(&st->sig_nmin, ~h);
+    if (log > 8) return false;
+    u32 n1 = 0;
+    for (u32 i = 0; i < nw; i++) { if (w[i] > 1) return false; n1 += w[i]; }
+    return n1 == (1u << log);
 }
 
 __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first)
@@ -282,7 +280,8 @@ __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 
     huf_build_any((u16 *)(pool + off), w, nw, log);
     blk[i].huf_tab = off; blk[i].huf_log = (u8)log;
     atomicMax(&st->max_huf_log, log);
-    huf_sig(st, w, nw);
+    const bool flat = huf_is_flat(w, nw, log);
+    blk[i].huf_flat = flat; if (flat) atomicAdd(&st->n_flat, 1u);
 }
 
 // The same for streams of a few blocks (ids, names, lengths, the last block of a mask stream): one block per workgroup, the tree
@@ -310,7 +309,11 @@ __global__ __launch_bounds__(64) void k_build_huf_lds(const u8 *src, ZBlock *blk
             u32 bytes = huf_tab_bytes(log);
             off = atomicAdd(&st->huf_pool_used, bytes);
             if (off + bytes > pool_cap) { set_err(st, ZE_POOL); log = 0; }
-            else { huf_build_any_ws(tab, w, nw, log, ws); blk[i].huf_tab = off; blk[i].huf_log = (u8)log; atomicMax(&st->max_huf_log, log); huf_sig(st, w, nw); }
+            else {
+                huf_build_any_ws(tab, w, nw, log, ws); blk[i].huf_tab = off; blk[i].huf_log = (u8)log; atomicMax(&st->max_huf_log, log);
+                const bool flat = huf_is_flat(w, nw, log);
+                blk[i].huf_flat = flat; if (flat) atomicAdd(&st->n_flat, 1u);
+            }
         }
         s_log = log; s_off = off;
     }
@@ -601,14 +604,13 @@ __global__ void k_emit_headers(EmitP P, u8 *text)
 template <bool FUSE>
 __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf,
                                                       const u8 *pool, u32 slot_bytes, u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first,
-                                                      EmitP EP, u8 *text, u32 ipitch, u64 src_len, u32 mk)
+                                                      EmitP EP, u8 *text, u32 ipitch, u64 src_len, u32 flat_on)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     u8 *irows = lds + HUF_BLOCKS_PER_WG * slot_bytes;                // 64 input rings of ipitch bytes (136: 2 sectors, 264: 4 sectors)
     u16 *lut2 = (u16 *)(irows + 64 * ipitch);                         // FUSE: packed byte -> two ASCII bytes
     u8 *orows = (u8 *)lut2;                                           // !FUSE: 64 output rows of 72 B + 64 row pointers
     u64 *row_out = (u64 *)(orows + 64 * HUF_OROW);
-    u32 *mtab = (u32 *)(row_out + 64);                                 // mk != 0: 2^mk entries of the multi-symbol table (below)
     if (FUSE) for (u32 v = threadIdx.x; v < 256; v += 64) {
         u32 a = v & 15, b = v >> 4;
         lut2[v] = (u16)(((EP.lut[a >> 2] >> (8 * (a & 3))) & 0xFF) | (((EP.lut[b >> 2] >> (8 * (b & 3))) & 0xFF) << 8));
@@ -637,6 +639,7 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
         if (b.btype == BT_COMP && b.lit_type >= LIT_HUF && !b.err) {
             i32 ob = own_huf[bi];
             if (ob < 0) { if (s == 0) err = ZE_CORRUPT; }                // treeless without a previous table
+            else if (!FUSE && flat_on && blk[ob].huf_flat) {}            // fixed-width codes: k_flat_literals has them
             else {
                 log = blk[ob].huf_log; tab = (const u16 *)(lds + j * slot_bytes);
                 const u8 *c = src + b.src_off + b.huf_streams_off;
@@ -669,44 +672,6 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
     const bool big = ipitch > HUF_IROW;
     const u32 rmask = big ? 255u : 127u, guard = big ? 192u : 160u;
     __syncthreads();
-    // ---- multi-symbol table ------------------------------------------------------------------------------------------------
-    // When the streams of this workgroup all decode with one and the same table of short codes (a frame of random ACGT has the
-    // same sixteen 4-bit codes in every block; blocks that share a tree by construction), one table indexed by the next `mk` bits
-    // returns every whole symbol those bits hold -- up to three, with their total length -- so the dependent chain of shift, LDS
-    // read and shift is walked once per two or three symbols instead of once per symbol.  Entry: symbols in bytes 0..2, total bits
-    // in bits 24..27, symbol count in bits 28..29.  Codes of up to 6 bits only: a round then never takes more than the 28 bytes
-    // the two-sector input ring allows (34 symbols x 6 bits).
-    bool multi = false; u32 decoded = 0;
-    if (!FUSE && mk && !big) {
-        const u64 vm = __ballot(valid);
-        if (vm) {
-            const int l0 = __ffsll((long long)vm) - 1;
-            const u32 log0 = (u32)__shfl((int)log, l0, 64);
-            const u16 *tab0 = (const u16 *)(lds + (u32)(l0 >> 2) * slot_bytes);
-            bool same = log0 <= 6 && log0 <= mk && (!valid || log == log0);
-            if (valid && same && tab != tab0) for (u32 k = 0; k < (1u << log0); k++) same = same && tab[k] == tab0[k];
-            if (__all(same)) {
-                bool bad = false;
-                for (u32 i = (u32)lane; i < (1u << mk); i += 64) {
-                    u32 x = i << (32 - mk), left = mk, e = 0, cnt = 0, tot = 0;
-                    for (u32 q = 0; q < 3; q++) {
-                        const u32 t = tab0[x >> (32 - log0)], nb = t & 0xFF;
-                        if (nb == 0 || nb > left) break;
-                        e |= (t >> 8) << (8 * cnt); cnt++; tot += nb; left -= nb; x <<= nb;
-                    }
-                    if (!cnt) bad = true;
-                    mtab[i] = e | (tot << 24) | (cnt << 28);
-                }
-                multi = !__any(bad);
-                if (multi) {                                             // never run past the stream: a round ends at most 2 symbols over
-                    u32 mr = valid ? (n >= 2 ? (n - 2) / HUF_ROUND : 0) : 0xFFFFFFFFu;
-                    for (int d = 32; d; d >>= 1) { u32 o = (u32)__shfl_xor((int)mr, d, 64); mr = o < mr ? o : mr; }
-                    if (rounds) rounds = mr == 0xFFFFFFFFu ? 0 : mr;
-                }
-            }
-        }
-        __syncthreads();
-    }
     u32 R = 0;
     {
         // ---- sector-window reader -------------------------------------------------------------------------
@@ -725,69 +690,6 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
             for (int q = 0; q < 8; q++) { uint4 v = g0[q]; u32 o = (u32)((lo + 16 * q) & rmask); *(u64 *)(irow + o) = (u64)v.x | ((u64)v.y << 32); *(u64 *)(irow + o + 8) = (u64)v.z | ((u64)v.w << 32); }
         }
         u32 bits = br.consumed;                                            // bits consumed since the container at gp
-        if (multi) {
-            u8 *orow = orows + lane * HUF_OROW;
-            u32 p = 0;                                                    // symbols waiting in this lane's output row
-            for (; R < rounds; R++) {
-                if (!__all(!valid || (live && gp - (u64)br.start >= guard))) break;
-                if (valid) {
-                    if (pending) {
-                        lo -= 64; u32 o = (u32)(lo & rmask);
-                        *(u64 *)(irow + o) = (u64)st0.x | ((u64)st0.y << 32); *(u64 *)(irow + o + 8) = (u64)st0.z | ((u64)st0.w << 32);
-                        *(u64 *)(irow + o + 16) = (u64)st1.x | ((u64)st1.y << 32); *(u64 *)(irow + o + 24) = (u64)st1.z | ((u64)st1.w << 32);
-                        *(u64 *)(irow + o + 32) = (u64)st2.x | ((u64)st2.y << 32); *(u64 *)(irow + o + 40) = (u64)st2.z | ((u64)st2.w << 32);
-                        *(u64 *)(irow + o + 48) = (u64)st3.x | ((u64)st3.y << 32); *(u64 *)(irow + o + 56) = (u64)st3.z | ((u64)st3.w << 32);
-                        pending = false;
-                    }
-                    if (lo + 56u > gp) {
-                        const uint4 *g0 = (const uint4 *)(lo - 64);
-                        st0 = g0[0]; st1 = g0[1]; st2 = g0[2]; st3 = g0[3]; pending = true;
-                    }
-                    // this round fills the row up to 32 (even rounds) or 64 symbols; a look-up adds one to three, so it ends at most
-                    // two symbols over.  Four look-ups (at most 4 x mk <= 40 bits) per refill of the container.
-                    const u32 target = ((R & 1u) + 1u) * HUF_ROUND;
-                    for (u32 g = 0; g < HUF_ROUND / 4 && p < target; g++) {
-                        gp -= bits >> 3; bits &= 7;
-                        u32 o = (u32)(gp & 127), sh = (o & 7) * 8;
-                        u64 q0 = *(const u64 *)(irow + (o & ~7u)), q1 = *(const u64 *)(irow + (((o & ~7u) + 8) & 127));
-                        u64 w = (sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0) << bits;
-#pragma unroll
-                        for (u32 q = 0; q < 4; q++) {
-                            if (p < target) {
-                                const u32 e = mtab[(u32)(w >> 32) >> (32 - mk)];
-                                const u32 nb = (e >> 24) & 15u;
-                                w <<= nb; bits += nb;
-                                __builtin_memcpy(orow + p, &e, 4);            // three symbol bytes and one that the next store overwrites
-                                p += e >> 28;
-                            }
-                        }
-                    }
-                }
-                if (R & 1) {                                              // the rows hold 64 symbols (and up to 2 more): write them out, 4 lanes per row
-                    u32 tail = 0;
-                    if (valid) __builtin_memcpy(&tail, orow + 64, 4);
-                    __syncthreads();
-#pragma unroll
-                    for (u32 jj = 0; jj < 4; jj++) {
-                        u32 row = jj * 16 + (lane >> 2), piece = lane & 3;
-                        u64 o = row_out[row];
-                        if (o) {
-                            const u8 *r = orows + row * HUF_OROW + piece * 16;
-                            uint4 v; u64 a = *(const u64 *)r, bb = *(const u64 *)(r + 8);
-                            v.x = (u32)a; v.y = (u32)(a >> 32); v.z = (u32)bb; v.w = (u32)(bb >> 32);
-                            memcpy((u8 *)o + (u64)(R >> 1) * 64 + piece * 16, &v, 16);
-                        }
-                    }
-                    __syncthreads();
-                    if (valid) { __builtin_memcpy(orow, &tail, 4); p -= 64; }
-                }
-            }
-            if (valid) {                                                  // what is left in the row: at most 34 symbols
-                const u64 at = (u64)(R >> 1) * 64;
-                for (u32 q = 0; q < p; q++) out[at + q] = orow[q];
-                decoded = (u32)at + p;
-            }
-        } else {
         for (; R < rounds; R++) {
             if (!__all(!valid || (live && gp - (u64)br.start >= guard))) break;   // near a stream start: generic reader finishes
             if (valid) {
@@ -873,13 +775,11 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
             const u8 *r = orows + lane * HUF_OROW;
             for (u32 q = 0; q < 32; q += 8) st64(out + (u64)(R - 1) * HUF_ROUND + q, *(const u64 *)(r + q));
         }
-        decoded = R * HUF_ROUND;
-        }
         if (valid && live) { gp -= bits >> 3; bits &= 7; br.c = ld64((const u8 *)gp); br.consumed = bits; }
         br.ptr = (const u8 *)gp;
     }
     if (valid) {
-        u32 done = decoded;
+        u32 done = R * HUF_ROUND;
         u8 e = 0;
         if (FUSE) {
             u32 rem = n - done;
@@ -895,6 +795,77 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
         if (e) err = e;
     }
     if (err) set_err(st, err);
+}
+
+// ---- Huffman literals of a flat tree: fixed-width fields, nothing serial -------------------------------------------------------------
+// When every code of a block's table is L bits long, symbol k of a stream sits at bits [E - L(k+1), E - Lk) of the stream (E = the
+// data bits below the end marker; a stream is read from its last byte backwards, RFC 8878 4.2.2), so the 8192 symbols one lane of
+// k_huf_literals walks one after the other can be taken by all lanes at once: one workgroup per block, one wavefront per stream,
+// a lane per group of 16 symbols -- 8 bytes of input at consecutive (descending) addresses across the lanes, 16 bytes of output
+// at consecutive addresses.  L = 4 (sixteen symbols: packed random ACGT) goes through a 256-entry table byte -> two symbols;
+// other widths take the fields out one by one.  Reads stay inside the stream; a stream whose size does not match n x L bits is
+// corrupt (the serial reader's "all bits consumed" test).
+__global__ __launch_bounds__(256) void k_flat_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf, const u8 *pool,
+                                                        u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first)
+{
+    __shared__ u16 pair[256];                                    // L == 4: byte -> symbol of its high nibble | symbol of its low nibble << 8
+    __shared__ u8 sym[256];                                      // code -> symbol
+    const u32 bi = b_first + blockIdx.x;
+    if (bi >= nblk) return;
+    const ZBlock &b = blk[bi];
+    if (b.btype != BT_COMP || b.lit_type < LIT_HUF || b.err) return;
+    const i32 ob = own_huf[bi];
+    if (ob < 0 || !blk[ob].huf_flat) return;
+    const u32 L = blk[ob].huf_log;
+    const u16 *tab = (const u16 *)(pool + blk[ob].huf_tab);
+    if (threadIdx.x < (1u << L)) sym[threadIdx.x] = (u8)(tab[threadIdx.x] >> 8);
+    __syncthreads();
+    if (L == 4) pair[threadIdx.x] = (u16)(sym[threadIdx.x >> 4] | ((u32)sym[threadIdx.x & 15] << 8));
+    __syncthreads();
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u8 *c = src + b.src_off + b.huf_streams_off;
+    u8 *o = (b.nseq == 0 ? dst : lit_scratch) + b.out_off;
+    const u32 regen = b.lit_regen;
+    const u8 *sp; u32 sz, n;
+    if (b.nstreams == 1) { if (wave) return; sp = c; sz = b.huf_streams_size; n = regen; }
+    else {
+        const u32 s1 = ld16(c), s2 = ld16(c + 2), s3 = ld16(c + 4), tot = b.huf_streams_size - 6, per = (regen + 3) / 4;
+        if (s1 + s2 + s3 >= tot || !s1 || !s2 || !s3 || per * 3 > regen) { if (threadIdx.x == 0) set_err(st, ZE_CORRUPT); return; }
+        const u32 off = wave == 0 ? 0 : (wave == 1 ? s1 : (wave == 2 ? s1 + s2 : s1 + s2 + s3));
+        sz = wave == 0 ? s1 : (wave == 1 ? s2 : (wave == 2 ? s3 : tot - s1 - s2 - s3));
+        sp = c + 6 + off; n = wave < 3 ? per : regen - 3 * per; o += wave * per;
+    }
+    const u32 last = sz ? sp[sz - 1] : 0;
+    if (!last) { if (lane == 0) set_err(st, ZE_CORRUPT); return; }
+    const u64 E = 8ull * (sz - 1) + (u32)hibit32(last);        // data bits of the stream
+    if (E != (u64)n * L) { if (lane == 0) set_err(st, ZE_CORRUPT); return; }
+    if (L == 4) {
+        const u32 groups = n >> 4;
+        for (u32 g = lane; g < groups; g += 64) {
+            const u64 B = E - 64ull * (g + 1);                   // first bit of the group's 16 fields (the last of them is lowest)
+            const u64 a = B >> 3; const u32 s = (u32)B & 7;
+            u64 v = ld64(sp + a);
+            if (s) v = (v >> s) | ((u64)sp[a + 8] << (64 - s));
+            const u32 hi = (u32)(v >> 32), lo = (u32)v;
+            uint4 r;
+            r.x = (u32)pair[hi >> 24] | ((u32)pair[(hi >> 16) & 0xFF] << 16);
+            r.y = (u32)pair[(hi >> 8) & 0xFF] | ((u32)pair[hi & 0xFF] << 16);
+            r.z = (u32)pair[lo >> 24] | ((u32)pair[(lo >> 16) & 0xFF] << 16);
+            r.w = (u32)pair[(lo >> 8) & 0xFF] | ((u32)pair[lo & 0xFF] << 16);
+            memcpy(o + 16ull * g, &r, 16);
+        }
+        for (u32 k = (groups << 4) + lane; k < n; k += 64) {     // the last, partial group
+            const u64 B = E - 4ull * (k + 1); const u64 a = B >> 3; const u32 s = (u32)B & 7;
+            u32 v = sp[a]; if (s > 4) v |= (u32)sp[a + 1] << 8;
+            o[k] = sym[(v >> s) & 15];
+        }
+    } else {
+        for (u32 k = lane; k < n; k += 64) {
+            const u64 B = E - (u64)L * (k + 1); const u64 a = B >> 3; const u32 s = (u32)B & 7;
+            u32 v = sp[a]; if (s + L > 8) v |= (u32)sp[a + 1] << 8;
+            o[k] = sym[(v >> s) & ((1u << L) - 1)];
+        }
+    }
 }
 
 // ---- raw / RLE blocks and raw / RLE literal sections: one workgroup per block ------------------------------
@@ -1296,13 +1267,11 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         if (b_count && fuse) LAUNCH(c, "zstd_huf_fused_emit", (k_huf_literals<true>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 512,
                d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, 0u);
         else if (b_count) {
-            // room for the multi-symbol table when the frame's blocks carry one and the same tree (hash of the weights, k_build_huf) or
-            // mostly borrow their neighbours' (treeless): 2^8 entries for codes of up to 4 bits, 2^10 up to 6 bits
-            const char *mm = getenv("NAF_GPU_HUF_MULTI");                        // "0": single-symbol look-ups only (cross-check)
-            u32 mk = 0;
-            if (!(mm && mm[0] == '0') && hs.max_huf_log <= 6 && ((hs.sig_max == ~hs.sig_nmin) || (u64)n_huf_def * 4 <= (u64)b_count))
-                mk = hs.max_huf_log <= 4 ? 8u : 10u;
-            const u32 huf_lds = slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512 + (mk ? (4u << mk) : 0u) + (getenv("NAF_GPU_PADLDS") ? atoi(getenv("NAF_GPU_PADLDS")) : 0);
+            const u32 huf_lds = slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512 + (getenv("NAF_GPU_PADLDS") ? atoi(getenv("NAF_GPU_PADLDS")) : 0);
+            // blocks whose tree is flat go to k_flat_literals; the serial kernel is not launched when that is all of them
+            const char *fl = getenv("NAF_GPU_FLAT");                             // "0": every block through the serial kernel (cross-check)
+            const u32 flat_on = (hs.n_flat && !(fl && fl[0] == '0')) ? 1u : 0u;
+            const bool serial_needed = !flat_on || hs.n_flat < (hb_n < n_huf_def ? hb_n : n_huf_def);
             ZSplit *sp = c->zsplit;
             const char *smin = getenv("NAF_GPU_SPLIT_MIN");                      // blocks per part below which a split is not worth its launches (tests lower it)
             const u32 split_min = smin ? (u32)atoi(smin) : 4096u;
@@ -1322,14 +1291,18 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                 u32 lo_b = 0;
                 for (int k = 0; k < sp->parts; k++) {
                     u32 hi_b = k + 1 == sp->parts ? b_count : (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
-                    if (hi_b > lo_b) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds,
-                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len, mk);
+                    if (hi_b > lo_b && flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, hi_b - lo_b, 256, 0, d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, lo_b);
+                    if (hi_b > lo_b && serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds,
+                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len, flat_on);
                     HIP_TRY(c, hipEventRecord(sp->ev[k], c->stream));
                     lo_b = hi_b;
                 }
                 sp->done = 1;
-            } else LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, huf_lds,
-               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, mk);
+            } else {
+                if (flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, b_count, 256, 0, d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, b_first);
+                if (serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, huf_lds,
+                   d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, flat_on);
+            }
         }
     }
     if (b_count && !fuse && !copy_fill_done) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);

@@ -194,76 +194,3 @@ extern "C" int emul_window_reader(const u8 *stream, u32 size, const u8 *weights,
     for (u32 i = 0; i < n; i++) if (out[i] != ref[i]) return (int)i + 1;
     return 0;
 }
-
-// ---- the multi-symbol variant of the same reader (k_huf_literals, `multi`): one table look-up returns every whole symbol the next
-// mk bits hold; a round fills the output row to 32 / 64 symbols and ends at most two over.  Same statements as the kernel.
-extern "C" int emul_window_reader_multi(const u8 *stream, u32 size, const u8 *weights, u32 nw, u32 log, u32 n, u64 align_off, u32 mk)
-{
-    std::vector<u8> hay(size + 1024 + 256);
-    u8 *base = hay.data() + 256; base += (64 - ((uintptr_t)base & 63)) & 63; base += align_off;
-    memset(hay.data(), 0xAA, hay.size());
-    memcpy(base, stream, size);
-    std::vector<u16> tabv(huf_tab_bytes(log) / 2); huf_build_any(tabv.data(), weights, nw, log); const u16 *tab = tabv.data();
-    std::vector<u8> ref(n + 64), out(n + 64);
-    if (huf_decode_stream(base, size, tab, log, ref.data(), n)) return -1;
-    BitR br; bitr_init(br, base, size); if (br.bad) return -2;
-    if (log > 6 || log > mk) return -5;
-    std::vector<u32> mtab(1u << mk);
-    for (u32 i = 0; i < (1u << mk); i++) {
-        u32 x = i << (32 - mk), left = mk, e = 0, cnt = 0, tot = 0;
-        for (u32 q = 0; q < 3; q++) {
-            const u32 t = tab[x >> (32 - log)], nb = t & 0xFF;
-            if (nb == 0 || nb > left) break;
-            e |= (t >> 8) << (8 * cnt); cnt++; tot += nb; left -= nb; x <<= nb;
-        }
-        if (!cnt) return -6;
-        mtab[i] = e | (tot << 24) | (cnt << 28);
-    }
-    const u32 HUF_ROUND = 32, rmask = 127u, guard = 160u;
-    u8 irow[136], orow[72];
-    u32 rounds = n >= 2 ? (n - 2) / HUF_ROUND : 0, R = 0, p = 0;
-    bool live = (u64)(br.ptr - br.start) >= guard + 32;
-    u64 gp = (u64)br.ptr, lo = 0; u8 st[64]; bool pending = false;
-    if (live) { u64 top = (gp + 7) & ~63ull; lo = top - 64; for (int q = 0; q < 8; q++) memcpy(irow + ((lo + 16 * q) & rmask), (const u8 *)(lo + 16 * q), 16); }
-    u32 bits = br.consumed;
-    for (; R < rounds; R++) {
-        if (!(live && gp - (u64)br.start >= guard)) break;
-        if (pending) { lo -= 64; memcpy(irow + (lo & rmask), st, 64); pending = false; }
-        if (lo + 56u > gp) { memcpy(st, (const u8 *)(lo - 64), 64); pending = true; }
-        const u64 gp_round = gp - (bits >> 3);
-        const u32 target = ((R & 1u) + 1u) * HUF_ROUND;
-        for (u32 g = 0; g < HUF_ROUND / 4 && p < target; g++) {
-            gp -= bits >> 3; bits &= 7;
-            if (gp < lo) return -7;                                          // the ring no longer holds what is read
-            u32 o = (u32)(gp & 127), sh = (o & 7) * 8;
-            u64 q0, q1; memcpy(&q0, irow + (o & ~7u), 8); memcpy(&q1, irow + (((o & ~7u) + 8) & 127), 8);
-            u64 w = (sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0) << bits;
-            for (u32 q = 0; q < 4; q++) {
-                if (p < target) {
-                    const u32 e = mtab[(u32)(w >> 32) >> (32 - mk)];
-                    const u32 nb = (e >> 24) & 15u;
-                    w <<= nb; bits += nb;
-                    memcpy(orow + p, &e, 4);
-                    p += e >> 28;
-                }
-            }
-        }
-        if (gp_round - (gp - (bits >> 3)) > 28) return -8;                   // a round took more input than the two-sector ring allows
-        if (p > target + 2) return -9;
-        if (R & 1) {
-            u32 tail; memcpy(&tail, orow + 64, 4);
-            memcpy(out.data() + (u64)(R >> 1) * 64, orow, 64);
-            memcpy(orow, &tail, 4); p -= 64;
-        }
-    }
-    const u64 at = (u64)(R >> 1) * 64;
-    for (u32 q = 0; q < p; q++) out[at + q] = orow[q];
-    u32 done = (u32)at + p;
-    if (done > n) return -10;
-    if (live) { gp -= bits >> 3; bits &= 7; br.c = ld64((const u8 *)gp); br.consumed = bits; }
-    br.ptr = (const u8 *)gp;
-    if (huf_decode_n(br, tab, log, out.data() + done, n - done)) return -3;
-    bitr_reload(br); if (!bitr_finished(br)) return -4;
-    for (u32 i = 0; i < n; i++) if (out[i] != ref[i]) return (int)i + 1;
-    return 0;
-}

@@ -173,31 +173,6 @@ def test_decoder_window_reader_at_every_rate_and_alignment(emul):
                 assert r in (0, -5), (len(set(d)), n, align, "small", r)                           # -5: table wider than 7 bits
 
 
-def test_decoder_multi_symbol_reader_at_every_rate_and_alignment(emul):
-    """The multi-symbol variant (one look-up returns up to three symbols; codes of up to 6 bits, 8- and 10-bit index): same
-    single-stepping, plus the two bounds its output row and input ring rest on (a round ends at most two symbols over its
-    target and takes at most 28 input bytes)."""
-    emul.emul_window_roundtrip_multi.restype = ctypes.c_int
-    emul.emul_window_roundtrip_multi.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32]
-    rng = np.random.default_rng(12)
-    streams = [rng.integers(0, alpha, 9000, dtype=np.uint8).tobytes() for alpha in (2, 3, 4, 7, 16, 17, 33, 64)]
-    syms = np.array([0x88, 0x84, 0x82, 0x81, 0x48, 0x44, 0x42, 0x41, 0x28, 0x24, 0x22, 0x21, 0x18, 0x14, 0x12, 0x11], dtype=np.uint8)
-    streams.append(syms[rng.integers(0, 16, 9000)].tobytes())                                        # packed random ACGT: sixteen 4-bit codes
-    for skew in (0.5, 0.7):
-        p = np.array([skew ** i for i in range(7)])
-        streams.append(rng.choice(np.arange(7, dtype=np.uint8) + 65, 9000, p=p / p.sum()).tobytes())   # 1- to 6-bit codes mixed
-    streams.append((b"\x00" * 50 + b"\x01") * 170)                                                    # 1-bit code: three symbols per look-up
-    ran = 0
-    for d in streams:
-        for n in (len(d), 6009, 999, 257, 66, 33):
-            for align in (0, 1, 7, 8, 22, 37, 55, 56, 57, 63):
-                for mk in (8, 10):
-                    r = emul.emul_window_roundtrip_multi(d[:n], n, align, mk)
-                    assert r in (0, -5) or (r == -10 and n < 100), (len(set(d)), n, align, mk, r)    # -5: codes longer than 6 bits / than the index; -10: the test's own encoder declines a tiny input
-                    ran += r == 0
-    assert ran > 600
-
-
 # ---- CLI paths that need no device ---------------------------------------------------------------------------------
 def run(prog, *args, stdin=None):
     p = subprocess.run([os.path.join(BIN, prog), *args], input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
