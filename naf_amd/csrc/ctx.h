@@ -79,7 +79,8 @@ int scan_inclusive_max_i64(naf_gpu_ctx *c, i64 *d_vals, size_t n);
 
 // ---- zstd (zstd_dec.hip) -----------------------------------------------------------------------------
 // Decode frames at d_src (device).  If only_size, stops after sizes are known.
-int zstd_decode(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len);
+// head: optional host copy of the first 24 bytes at d_src (fewer when the source is shorter) -- saves the read-back of the frame header
+int zstd_decode(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len, const u8 *head = nullptr);
 int zstd_init_tables(naf_gpu_ctx *c);
 void ennaf_shard_state_free(naf_gpu_ctx *c);    // enc.hip
 void io_pool_free(naf_gpu_ctx *c);               // io.hip
@@ -90,7 +91,7 @@ struct EmitP;
 // the frame needs the two-pass path.
 int zstd_decode_fused_fasta(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, size_t *out_len, const EmitP *P, u8 *text);
 struct ZRange { u64 want_lo, want_hi, got_lo, got_hi; bool ranged; };
-int zstd_decode_range(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len, ZRange *rg);
+int zstd_decode_range(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len, ZRange *rg, const u8 *head = nullptr);
 int zstd_split_status(naf_gpu_ctx *c, const ZSplit *sp);
 // One frame of independently coded blocks; with_magic=0 omits the 4 magic bytes (as stored in a .naf section).
 // level >= 2 (or lz != 0) adds the LZ stage (matches inside a block).

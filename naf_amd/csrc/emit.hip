@@ -65,28 +65,52 @@ __global__ __launch_bounds__(256) void k_zero_scatter(const u8 *p, u64 n, const 
 
 // mask units: running base position (u64 sum of units) + compaction of toggle positions (units != 255)
 #define MT_TILE (256 * 16)
+// 16 units of a lane as four words: their sum (v_sad_u8 against 0) and how many of them are not 255.  Units past n read as 255
+// with sum 0 (the section buffer is padded by 32 bytes, so the loads themselves are safe).
+__device__ __forceinline__ void mask_units16(const u8 *units, u64 base, u64 n, u32 w[4], u32 &sum, u32 &cnt)
+{
+    sum = 0; cnt = 0; w[0] = w[1] = w[2] = w[3] = 0xFFFFFFFFu;
+    if (base >= n) return;
+    const u64 a = ld64(units + base), b = ld64(units + base + 8);
+    w[0] = (u32)a; w[1] = (u32)(a >> 32); w[2] = (u32)b; w[3] = (u32)(b >> 32);
+    const u32 valid = n - base >= 16 ? 16u : (u32)(n - base);
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+        if (valid < 4 * k + 4) { const u32 keep = valid > 4 * k ? valid - 4 * k : 0; w[k] |= keep ? 0xFFFFFFFFu << (8 * keep) : 0xFFFFFFFFu; }
+        const u32 y = ~w[k];                                                     // a byte of y is 0 where the unit is 255
+        const u32 z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);    // 0x80 in exactly those bytes
+        cnt += 4 - (u32)__popc(z);
+        sum += __builtin_amdgcn_sad_u8(w[k], 0u, 0u) - 255u * (u32)__popc(z);
+    }
+    // (the 255s are added back by the caller: sum + 255 * (16 - cnt) would count the padding units too)
+}
 __global__ __launch_bounds__(256) void k_mask_count(const u8 *units, u64 n, u64 *tile_sum, u64 *tile_cnt)
 {
     __shared__ u64 lds[4];
     u64 base = (u64)blockIdx.x * MT_TILE + (u64)threadIdx.x * 16;
-    u64 s = 0, c = 0;
-    for (int i = 0; i < 16; i++) if (base + i < n) { u32 u = units[base + i]; s += u; c += u != 255; }
+    u32 w[4], s32, c32; mask_units16(units, base, n, w, s32, c32);
+    const u32 valid = base >= n ? 0u : (n - base >= 16 ? 16u : (u32)(n - base));
+    u64 s = (u64)s32 + 255ull * (valid - c32), c = c32;
     u64 t1, t2;
     wg_scan_inclusive<u64, OpAdd>(s, &t1, lds);
     wg_scan_inclusive<u64, OpAdd>(c, &t2, lds);
     if (threadIdx.x == 0) { tile_sum[blockIdx.x] = t1; tile_cnt[blockIdx.x] = t2; }
 }
-__global__ __launch_bounds__(256) void k_mask_scatter(const u8 *units, u64 n, const u64 *tile_sum_pre, const u64 *tile_cnt_pre, u64 *toggles)
+__global__ __launch_bounds__(256) void k_mask_scatter(const u8 *units, u64 n, const u64 *tile_sum_pre, const u64 *tile_cnt_pre, u64 *toggles, u64 n_toggles)
 {
     __shared__ u64 lds[4];
+    // a tile of nothing but 255s (the long runs of an unmasked genome) has no toggle to write
+    if ((blockIdx.x + 1 < gridDim.x ? tile_cnt_pre[blockIdx.x + 1] : n_toggles) == tile_cnt_pre[blockIdx.x]) return;
     u64 base = (u64)blockIdx.x * MT_TILE + (u64)threadIdx.x * 16;
-    u64 s = 0, c = 0;
-    for (int i = 0; i < 16; i++) if (base + i < n) { u32 u = units[base + i]; s += u; c += u != 255; }
+    u32 w[4], s32, c32; mask_units16(units, base, n, w, s32, c32);
+    const u32 valid = base >= n ? 0u : (n - base >= 16 ? 16u : (u32)(n - base));
+    u64 s = (u64)s32 + 255ull * (valid - c32), c = c32;
     u64 t;
     u64 si = wg_scan_inclusive<u64, OpAdd>(s, &t, lds);
     u64 ci = wg_scan_inclusive<u64, OpAdd>(c, &t, lds);
+    if (!c32) return;
     u64 pos = tile_sum_pre[blockIdx.x] + si - s, k = tile_cnt_pre[blockIdx.x] + ci - c;
-    for (int i = 0; i < 16; i++) if (base + i < n) { u32 u = units[base + i]; pos += u; if (u != 255) toggles[k++] = pos; }
+    for (u32 i = 0; i < valid; i++) { u32 u = (w[i >> 2] >> (8 * (i & 3))) & 0xFF; pos += u; if (u != 255) toggles[k++] = pos; }
 }
 
 // per-record header length and text size
@@ -778,143 +802,136 @@ static int zero_positions(naf_gpu_ctx *c, const u8 *d_buf, u64 n, u64 N, u64 **o
     return 0;
 }
 
-// Size fields a well-formed archive cannot hold.  A zstd block regenerates at most 128 KiB from no less than 3 bytes, so a
+// ---- container framing (unnaf/src/input.c:31-77 read_header, utils.c:117-141 read_number, unnaf.c:402-404) ---------------------------
+// One routine for both sides: the host calls it on an archive in host memory (the CLI, before the upload), and a one-thread kernel
+// runs it on an archive in HBM -- the section headers form a chain (each one sits behind the previous section's payload), which
+// from the host is one read-back per link; on the device it is one launch and one read-back of the finished structure.
+// Returns 0 or one of the H_* codes below; H_VERSION / H_SEQTYPE leave the offending value in h->version / h->seq_type.
+//
+// Size fields a well-formed archive cannot hold: a zstd block regenerates at most 128 KiB from no less than 3 bytes, so a
 // section of c compressed bytes decodes to fewer than (c + 4) * 2^16 bytes (twice that many bases for the 4-bit sequence
 // stream); every record costs at least one byte of archive in the streams that describe it.  Fields beyond these bounds are a
 // corrupted header, reported the way the reference reports a section it cannot decode (input.c:156,184,213,231) -- before any
-// buffer is sized from them.
-static const char *header_sanity(const naf_gpu_header *h, size_t len)
+// buffer is sized from them.  All sizes are compared in subtraction form: a field near 2^64 must not wrap a sum.
+enum { H_OK = 0, H_EMPTY, H_TRUNC, H_MAGIC, H_VERSION, H_SEQTYPE, H_SEPARATOR, H_VLE_LEAD, H_VLE_OVERFLOW, H_SANE_SECTION /* + section */, H_SANE_COUNT = H_SANE_SECTION + 6 };
+struct ContainerOut { naf_gpu_header h; int code; u8 frame_head[6][24]; };           // frame_head: the first bytes of every section's zstd frame (its header)
+NAF_HD int naf_parse_container(const u8 *p, size_t len, naf_gpu_header *h)
 {
-    static const char *what[6] = { "can't decompress ids\n", "can't decompress names\n", "can't decompress lengths\n", "can't decompress mask\n",
-                                   "can't decompress sequence\n", "can't decompress quality\n" };
+    size_t pos = 0;
+    memset(h, 0, sizeof *h);
+    if (len == 0) return H_EMPTY;
+    if (len < 3) return H_TRUNC;
+    if (p[0] != 0x01 || p[1] != 0xF9 || p[2] != 0xEC) return H_MAGIC;
+    pos = 3;
+    if (pos >= len) return H_TRUNC;
+    h->version = p[pos++];
+    if (h->version < 1 || h->version > 2) return H_VERSION;
+    h->seq_type = NAF_SEQ_DNA;
+    if (h->version > 1) {
+        if (pos >= len) return H_TRUNC;
+        int t = p[pos++];
+        h->seq_type = t;
+        if (t < 1 || t > 3) return H_SEQTYPE;
+    }
+    if (len - pos < 2) return H_TRUNC;
+    h->flags = p[pos++]; h->separator = p[pos++];
+    if (h->separator < 0x20 || h->separator > 0x7E) return H_SEPARATOR;
+    // the numbers in file order: line length, N, [title size], then (original size, compressed size) per present section
+    int e = 0;
+    auto rd = [&](u64 *v) -> int {
+        u64 a = 0; if (pos >= len) return H_TRUNC;
+        u8 ch = p[pos++];
+        if (ch == 128) return H_VLE_LEAD;
+        while (ch & 128) { if (a & (127ull << 57)) return H_VLE_OVERFLOW; a = (a << 7) | (ch & 127); if (pos >= len) return H_TRUNC; ch = p[pos++]; }
+        if (a & (127ull << 57)) return H_VLE_OVERFLOW;
+        *v = (a << 7) | ch; return 0;
+    };
+    if ((e = rd(&h->line_length)) || (e = rd(&h->n_sequences))) return e;
+    if (h->flags & 0x40) { if ((e = rd(&h->title_len))) return e; h->title_off = pos; if (h->title_len > len - pos) return H_TRUNC; pos += h->title_len; }
+    const int bit[6] = { 0x20, 0x10, 0x08, 0x04, 0x02, 0x01 };
+    for (int i = 0; i < 6; i++) {
+        if (!(h->flags & bit[i])) continue;
+        if ((e = rd(&h->orig_size[i])) || (e = rd(&h->comp_size[i]))) return e;
+        if (h->comp_size[i] > len - pos) return H_TRUNC;
+        h->payload_off[i] = pos; pos += h->comp_size[i];
+    }
     for (int i = 0; i < 6; i++) {
         const u64 cs = h->comp_size[i] + 4;                                   // comp_size <= len < 2^63 here
         const u64 lim = cs > (1ull << 46) ? ~0ull : cs << (i == 4 ? 17 : 16);
-        if (h->orig_size[i] > lim) return what[i];
+        if (h->orig_size[i] > lim) return H_SANE_SECTION + i;
     }
-    if (h->n_sequences > ((u64)len << 16)) return "corrupted header: more sequences than the archive can describe\n";
-    return nullptr;
+    if (h->n_sequences > ((u64)len << 16)) return H_SANE_COUNT;
+    return H_OK;
+}
+static void container_error_text(int code, const naf_gpu_header *h, char *buf, size_t cap)
+{
+    static const char *what[6] = { "can't decompress ids\n", "can't decompress names\n", "can't decompress lengths\n", "can't decompress mask\n",
+                                   "can't decompress sequence\n", "can't decompress quality\n" };
+    switch (code) {
+    case H_EMPTY: snprintf(buf, cap, "empty input"); break;
+    case H_TRUNC: snprintf(buf, cap, "incomplete or truncated input\n"); break;
+    case H_MAGIC: snprintf(buf, cap, "not a NAF format\n"); break;
+    case H_VERSION: snprintf(buf, cap, "unknown version (%d) of NAF format\n", h->version); break;
+    case H_SEQTYPE: snprintf(buf, cap, "unknown sequence type (%d) found in NAF file\n", h->seq_type); break;
+    case H_SEPARATOR: snprintf(buf, cap, "unsupported name separator character\n"); break;
+    case H_VLE_LEAD: snprintf(buf, cap, "invalid input: error parsing variable length encoded number\n"); break;
+    case H_VLE_OVERFLOW: snprintf(buf, cap, "invalid input: overflow reading a variable length encoded number\n"); break;
+    case H_SANE_COUNT: snprintf(buf, cap, "corrupted header: more sequences than the archive can describe\n"); break;
+    default: if (code >= H_SANE_SECTION && code < H_SANE_SECTION + 6) snprintf(buf, cap, "%s", what[code - H_SANE_SECTION]); else snprintf(buf, cap, "malformed NAF header\n");
+    }
 }
 
 extern "C" int naf_gpu_parse_header_host(const void *h_naf, size_t len, naf_gpu_header *h, char errbuf[128])
 {
-    // unnaf/src/input.c:31-77 read_header, utils.c:117-141 read_number, unnaf.c:402-404
-    const u8 *p = (const u8 *)h_naf; size_t pos = 0;
-    memset(h, 0, sizeof *h);
-#define HF(msg) do { if (errbuf) snprintf(errbuf, 128, "%s", msg); return NAF_GPU_EFORMAT; } while (0)
-    if (len == 0) HF("empty input");
-    if (len < 3) HF("incomplete or truncated input\n");
-    if (p[0] != 0x01 || p[1] != 0xF9 || p[2] != 0xEC) HF("not a NAF format\n");
-    pos = 3;
-    if (pos >= len) HF("incomplete or truncated input\n");
-    h->version = p[pos++];
-    if (h->version < 1 || h->version > 2) { if (errbuf) snprintf(errbuf, 128, "unknown version (%d) of NAF format\n", h->version); return NAF_GPU_EFORMAT; }
-    h->seq_type = NAF_SEQ_DNA;
-    if (h->version > 1) {
-        if (pos >= len) HF("incomplete or truncated input\n");
-        int t = p[pos++];
-        if (t < 1 || t > 3) { if (errbuf) snprintf(errbuf, 128, "unknown sequence type (%d) found in NAF file\n", t); return NAF_GPU_EFORMAT; }
-        h->seq_type = t;
-    }
-    if (pos + 2 > len) HF("incomplete or truncated input\n");
-    h->flags = p[pos++]; h->separator = p[pos++];
-    if (h->separator < 0x20 || h->separator > 0x7E) HF("unsupported name separator character\n");
-    auto rd = [&](u64 *v) -> int {
-        u64 a = 0; if (pos >= len) return 1;
-        u8 ch = p[pos++];
-        if (ch == 128) return 2;
-        while (ch & 128) { if (a & (127ull << 57)) return 3; a = (a << 7) | (ch & 127); if (pos >= len) return 1; ch = p[pos++]; }
-        if (a & (127ull << 57)) return 3;
-        *v = (a << 7) | ch; return 0;
-    };
-#define RD(dst) do { int e_ = rd(&(dst)); if (e_ == 1) HF("incomplete or truncated input\n"); \
-        if (e_ == 2) HF("invalid input: error parsing variable length encoded number\n"); \
-        if (e_ == 3) HF("invalid input: overflow reading a variable length encoded number\n"); } while (0)
-    RD(h->line_length); RD(h->n_sequences);
-    // sizes are compared in subtraction form: a field near 2^64 must not wrap the sum
-    if (h->flags & 0x40) { RD(h->title_len); h->title_off = pos; if (h->title_len > len - pos) HF("incomplete or truncated input\n"); pos += h->title_len; }
-    static const int bit[6] = { 0x20, 0x10, 0x08, 0x04, 0x02, 0x01 };
+    if (!h) return NAF_GPU_EARG;
+    const int code = naf_parse_container((const u8 *)h_naf, len, h);
+    if (!code) return 0;
+    if (errbuf) container_error_text(code, h, errbuf, 128);
+    return NAF_GPU_EFORMAT;
+}
+
+__global__ void k_parse_container(const u8 *d, u64 len, ContainerOut *out)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    out->code = naf_parse_container(d, (size_t)len, &out->h);
     for (int i = 0; i < 6; i++) {
-        if (!(h->flags & bit[i])) continue;
-        RD(h->orig_size[i]); RD(h->comp_size[i]);
-        if (h->comp_size[i] > len - pos) HF("incomplete or truncated input\n");
-        h->payload_off[i] = pos; pos += h->comp_size[i];
+        const u64 n = out->code ? 0 : (out->h.comp_size[i] < 24 ? out->h.comp_size[i] : 24);
+        for (u64 k = 0; k < 24; k++) out->frame_head[i][k] = k < n ? d[out->h.payload_off[i] + k] : 0;
     }
-    const char *bad = header_sanity(h, len);
-    if (bad) HF(bad);
+}
+
+static int parse_container_device(naf_gpu_ctx *c, const void *d_naf, size_t len, ContainerOut *co)
+{
+    ContainerOut *d_co = arena_new<ContainerOut>(c, 1); if (!d_co) return NAF_GPU_ENOMEM;
+    LAUNCH(c, "unnaf_parse_container", k_parse_container, 1, 64, 0, (const u8 *)d_naf, (u64)len, d_co);
+    int rc = ctx_readback(c, co, d_co, sizeof *co); if (rc) return rc;
+    if (co->code) { char buf[160]; container_error_text(co->code, &co->h, buf, sizeof buf); return ctx_fail(c, NAF_GPU_EFORMAT, "%s", buf); }
     return 0;
 }
 
 extern "C" int naf_gpu_parse_header(naf_gpu_ctx *c, const void *d_naf, size_t len, naf_gpu_header *h)
 {
-    // The framing is a few dozen bytes at <= 8 places; pull 64-byte windows to the host as needed.
     if (!c || !h) return NAF_GPU_EARG;
-    const u8 *d = (const u8 *)d_naf;
-    std::vector<u8> shadow(len < 64 ? len : 64);
-    // Strategy: keep a sparse host shadow: parse with a reader that fetches windows on demand.
-    memset(h, 0, sizeof *h);
-    struct Win { size_t off, n; u8 b[96]; } w = { 0, 0, {0} };
-    auto need = [&](size_t pos, size_t n) -> const u8 * {
-        if (pos + n > len) return nullptr;
-        if (pos < w.off || pos + n > w.off + w.n) {
-            w.off = pos; w.n = len - pos < sizeof w.b ? len - pos : sizeof w.b;
-            if (ctx_readback(c, w.b, d + pos, w.n)) return nullptr;
-        }
-        return w.b + (pos - w.off);
-    };
-#define DF(msg) return ctx_fail(c, NAF_GPU_EFORMAT, "%s", msg)
-    if (len == 0) DF("empty input");
-    const u8 *p = need(0, len < 8 ? len : 8);
-    if (!p || len < 3) DF("incomplete or truncated input\n");
-    if (p[0] != 0x01 || p[1] != 0xF9 || p[2] != 0xEC) DF("not a NAF format\n");
-    size_t pos = 3;
-    auto byte = [&](u8 *v) -> bool { const u8 *q = need(pos, 1); if (!q) return false; *v = *q; pos++; return true; };
-    u8 t;
-    if (!byte(&t)) DF("incomplete or truncated input\n");
-    h->version = t;
-    if (h->version < 1 || h->version > 2) return ctx_fail(c, NAF_GPU_EFORMAT, "unknown version (%d) of NAF format\n", h->version);
-    if (h->version > 1) { if (!byte(&t)) DF("incomplete or truncated input\n"); if (t < 1 || t > 3) return ctx_fail(c, NAF_GPU_EFORMAT, "unknown sequence type (%d) found in NAF file\n", t); h->seq_type = t; }
-    if (!byte(&t)) DF("incomplete or truncated input\n"); h->flags = t;
-    if (!byte(&t)) DF("incomplete or truncated input\n"); h->separator = t;
-    if (h->separator < 0x20 || h->separator > 0x7E) DF("unsupported name separator character\n");
-    auto rd = [&](u64 *v) -> int {
-        u64 a = 0; u8 ch;
-        if (!byte(&ch)) return 1;
-        if (ch == 128) return 2;
-        while (ch & 128) { if (a & (127ull << 57)) return 3; a = (a << 7) | (ch & 127); if (!byte(&ch)) return 1; }
-        if (a & (127ull << 57)) return 3;
-        *v = (a << 7) | ch; return 0;
-    };
-#define RDD(dst) do { int e_ = rd(&(dst)); if (e_ == 1) DF("incomplete or truncated input\n"); \
-        if (e_ == 2) DF("invalid input: error parsing variable length encoded number\n"); \
-        if (e_ == 3) DF("invalid input: overflow reading a variable length encoded number\n"); } while (0)
-    RDD(h->line_length); RDD(h->n_sequences);
-    if (h->flags & 0x40) { RDD(h->title_len); h->title_off = pos; if (h->title_len > len - pos) DF("incomplete or truncated input\n"); pos += h->title_len; }
-    static const int bit[6] = { 0x20, 0x10, 0x08, 0x04, 0x02, 0x01 };
-    for (int i = 0; i < 6; i++) {
-        if (!(h->flags & bit[i])) continue;
-        RDD(h->orig_size[i]); RDD(h->comp_size[i]);
-        if (h->comp_size[i] > len - pos) DF("incomplete or truncated input\n");
-        h->payload_off[i] = pos; pos += h->comp_size[i];
-    }
-    const char *bad = header_sanity(h, len);
-    if (bad) DF(bad);
-    return 0;
+    arena_reset(c);
+    ContainerOut co;
+    int rc = parse_container_device(c, d_naf, len, &co);
+    *h = co.h;
+    return rc;
 }
 
 enum { S_IDS = 0, S_NAMES, S_LEN, S_MASK, S_SEQ, S_QUAL };
 
 struct UnnafPlan {
-    naf_gpu_header h; EmitP P; u64 total; bool fourbit; bool empty;
+    naf_gpu_header h; u8 frame_head[6][24]; EmitP P; u64 total; bool fourbit; bool empty;
     u64 seq_bytes; bool need_qual;
 };
 
-static int load_section(naf_gpu_ctx *c, const u8 *d_naf, const naf_gpu_header &h, int i, u64 expect, const char *what, u8 **out)
+static int load_section(naf_gpu_ctx *c, const u8 *d_naf, const naf_gpu_header &h, int i, u64 expect, const char *what, u8 **out, const u8 *head = nullptr)
 {
     u8 *buf = (u8 *)arena_alloc(c, expect + 32);
     if (!buf) return NAF_GPU_ENOMEM;
     size_t n = 0;
-    int rc = zstd_decode(c, d_naf + h.payload_off[i], h.comp_size[i], 0, buf, expect, &n);
+    int rc = zstd_decode(c, d_naf + h.payload_off[i], h.comp_size[i], 0, buf, expect, &n, head);
     if (rc == NAF_GPU_ECAP || (rc == 0 && n != expect)) return ctx_fail(c, NAF_GPU_EFORMAT, "can't decompress %s\n", what);   // input.c:156,184,213,231
     if (rc) return rc;
     *out = buf;
@@ -924,7 +941,9 @@ static int load_section(naf_gpu_ctx *c, const u8 *d_naf, const naf_gpu_header &h
 // Everything except the sequence / quality payload decode and the emit itself.
 static int unnaf_prepare(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_gpu_unnaf_opts *o, UnnafPlan &pl)
 {
-    int rc = naf_gpu_parse_header(c, d_naf, naf_len, &pl.h); if (rc) return rc;
+    ContainerOut co;
+    int rc = parse_container_device(c, d_naf, naf_len, &co); if (rc) return rc;
+    pl.h = co.h; memcpy(pl.frame_head, co.frame_head, sizeof pl.frame_head);
     const naf_gpu_header &h = pl.h;
     EmitP &P = pl.P; memset(&P, 0, sizeof P);
     int has_mask = (h.flags >> 2) & 1, has_data = (h.flags >> 1) & 1, has_qual = h.flags & 1;
@@ -980,14 +999,14 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
             if (want_names && has_ids) {
                 u8 *b = nullptr; u64 *z = nullptr;
                 if (h.orig_size[S_IDS] == 0) return ctx_fail(x, NAF_GPU_EFORMAT, "corrupted ids - not 0-terminated\n");
-                if ((r = load_section(x, d_naf, h, S_IDS, h.orig_size[S_IDS], "ids", &b))) return r;
+                if ((r = load_section(x, d_naf, h, S_IDS, h.orig_size[S_IDS], "ids", &b, pl.frame_head[S_IDS]))) return r;
                 if ((r = zero_positions(x, b, h.orig_size[S_IDS], N, &z, false))) return r;
                 P.ids = b; P.idz = z;
             }
             if (want_names && has_names) {
                 u8 *b = nullptr; u64 *z = nullptr;
                 if (h.orig_size[S_NAMES] == 0) return ctx_fail(x, NAF_GPU_EFORMAT, "corrupted names - not 0-terminated\n");
-                if ((r = load_section(x, d_naf, h, S_NAMES, h.orig_size[S_NAMES], "names", &b))) return r;
+                if ((r = load_section(x, d_naf, h, S_NAMES, h.orig_size[S_NAMES], "names", &b, pl.frame_head[S_NAMES]))) return r;
                 if ((r = zero_positions(x, b, h.orig_size[S_NAMES], N, &z, true))) return r;
                 P.names = b; P.nmz = z;
             }
@@ -997,7 +1016,7 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
         auto lengths = [&](naf_gpu_ctx *x) -> int {
             int r;
             u8 *lens = nullptr;
-            if ((r = load_section(x, d_naf, h, S_LEN, h.orig_size[S_LEN], "lengths", &lens))) return r;
+            if ((r = load_section(x, d_naf, h, S_LEN, h.orig_size[S_LEN], "lengths", &lens, pl.frame_head[S_LEN]))) return r;
             u64 n_len = h.orig_size[S_LEN] / 4;
             u64 *flag = arena_new<u64>(x, n_len + 2); rec_len = arena_new<u64>(x, N + 1);
             if (!flag || !rec_len) return NAF_GPU_ENOMEM;
@@ -1057,7 +1076,7 @@ static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gp
     auto mask_part = [&](naf_gpu_ctx *x) -> int {
         int r;
         u8 *mu = nullptr; u64 n_mask = h.orig_size[S_MASK];
-        if ((r = load_section(x, d_naf, h, S_MASK, n_mask, "mask", &mu))) return r;
+        if ((r = load_section(x, d_naf, h, S_MASK, n_mask, "mask", &mu, pl.frame_head[S_MASK]))) return r;
         u64 tiles = (n_mask + MT_TILE - 1) / MT_TILE;
         u64 *ts = arena_new<u64>(x, tiles + 2), *tc = arena_new<u64>(x, tiles + 2);
         if (!ts || !tc) return NAF_GPU_ENOMEM;
@@ -1068,7 +1087,7 @@ static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gp
         if ((r = ctx_readback(x, &ntog, tc + tiles + 1, 8))) return r;
         u64 *tg = arena_new<u64>(x, ntog + 1);
         if (!tg) return NAF_GPU_ENOMEM;
-        if (tiles) LAUNCH(x, "unnaf_mask_scatter", k_mask_scatter, tiles, 256, 0, (const u8 *)mu, n_mask, (const u64 *)ts, (const u64 *)tc, tg);
+        if (tiles) LAUNCH(x, "unnaf_mask_scatter", k_mask_scatter, tiles, 256, 0, (const u8 *)mu, n_mask, (const u64 *)ts, (const u64 *)tc, tg, ntog);
         P.toggles = tg; P.n_toggles = ntog;
         return 0;
     };
@@ -1110,7 +1129,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         seq = (u8 *)arena_alloc(c, seq_need);
         if (!seq) return NAF_GPU_ENOMEM;
         size_t n = 0;
-        r = zstd_decode_range(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, seq, prs ? seq_need : pl.seq_bytes, &n, prs);
+        r = zstd_decode_range(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, seq, prs ? seq_need : pl.seq_bytes, &n, prs, pl.frame_head[S_SEQ]);
         if (r == NAF_GPU_ECAP && prs) {                                              // dependent blocks: needs the whole stream
             seq = (u8 *)arena_alloc(c, pl.seq_bytes + 64); if (!seq) return NAF_GPU_ENOMEM;
             r = zstd_decode(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, seq, pl.seq_bytes, &n); prs = nullptr;
@@ -1128,7 +1147,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         if (q_need > qn + 64) q_need = qn + 64;
         u8 *q = (u8 *)arena_alloc(qc, q_need); if (!q) return NAF_GPU_ENOMEM;
         size_t qgot = 0;
-        r = zstd_decode_range(qc, d_naf + h.payload_off[S_QUAL], h.comp_size[S_QUAL], 0, q, prq ? q_need : qn, &qgot, prq);
+        r = zstd_decode_range(qc, d_naf + h.payload_off[S_QUAL], h.comp_size[S_QUAL], 0, q, prq ? q_need : qn, &qgot, prq, pl.frame_head[S_QUAL]);
         if (r == NAF_GPU_ECAP && prq) {
             q = (u8 *)arena_alloc(qc, qn + 64); if (!q) return NAF_GPU_ENOMEM;
             r = zstd_decode(qc, d_naf + h.payload_off[S_QUAL], h.comp_size[S_QUAL], 0, q, qn, &qgot); prq = nullptr;

@@ -1077,6 +1077,121 @@ __global__ void k_find_range(const u64 *offs, u32 nblk, u64 total, u64 want_lo, 
     i32 ob = own_huf[b_lo]; out4[4] = ob < 0 ? b_lo : (u64)ob;      // first block whose Huffman table can be in force in the range
 }
 
+// ---- a small frame in one launch ------------------------------------------------------------------------------------------------
+// The pipeline above costs a frame about 25 launches and half a dozen host read-backs whatever its size -- half a millisecond for
+// the ids, the names and the lengths of an archive of a hundred chromosomes, a few hundred bytes each, and the emit kernels wait
+// for all three.  A frame of up to SMALL_SRC bytes is decoded here by ONE lane, block after block, the way a serial decoder does
+// it (same per-block functions as the kernels above: zstd_dec_core.h), with the Huffman and FSE tables in LDS; one launch, one
+// read-back.  res: [0] error (ZE_*; SMALL_TOO_BIG when the output does not fit `cap` -- the caller then takes the long way, which
+// reports the size needed), [1] bytes produced, [2] bytes of the frame.
+#define SMALL_SRC 16384u
+#define SMALL_OUT 65536u
+#define SMALL_SEQ 131072u
+#define SMALL_TOO_BIG 100u
+__global__ __launch_bounds__(64) void k_small_frame(const u8 *src, u32 len, u8 *dst, u32 cap, u8 *lit, u32 *sq, const FseE *predef, u32 *res)
+{
+    __shared__ HufBuildWS ws;
+    __shared__ __attribute__((aligned(16))) u16 huf[HUFC_BYTES / 2 > 256 ? HUFC_BYTES / 2 : 256];
+    __shared__ FseE fse[512 + 256 + 512];
+    __shared__ u8 w[256];
+    __shared__ i16 norm[64];
+    __shared__ u16 nx[64];
+    if (threadIdx.x) return;
+    u32 err = 0, out = 0, pos = 0;
+    ZFrameHdr fh = zstd_parse_frame_header(src, len);
+    if (fh.err) { res[0] = (u32)fh.err; res[1] = 0; res[2] = 0; return; }
+    pos = fh.hdr_size;
+    u32 huf_log = 0; bool have_huf = false;
+    SeqTab tab[3]; bool have_tab[3] = { false, false, false };
+    const u32 fo[3] = { 0, 512, 768 }, po[3] = { 0, 64, 96 }, pl[3] = { 6, 5, 6 }, max_log[3] = { 9, 8, 9 }, max_sym[3] = { 35, 31, 52 };
+    u32 rep[3] = { 1, 4, 8 };
+    for (;;) {
+        if (pos + 3 > len) { err = ZE_TRUNC; break; }
+        const u32 h = ld24(src + pos), last = h & 1, type = (h >> 1) & 3, size = h >> 3;
+        if (type == 3 || size > ZBLOCK_MAX) { err = ZE_CORRUPT; break; }
+        const u32 csize = type == BT_RLE ? 1 : size;
+        if (pos + 3 + csize > len) { err = ZE_TRUNC; break; }
+        const u8 *c = src + pos + 3;
+        pos += 3 + csize;
+        if (type != BT_COMP) {
+            if ((u64)out + size > cap) { err = SMALL_TOO_BIG; break; }
+            if (type == BT_RAW) for (u32 k = 0; k < size; k++) dst[out + k] = c[k];
+            else { const u8 v = c[0]; for (u32 k = 0; k < size; k++) dst[out + k] = v; }
+            out += size;
+            if (last) break;
+            continue;
+        }
+        ZBlock b; b.src_off = 0; b.bsize = size; b.btype = BT_COMP; b.last = (u8)last;
+        zstd_parse_block(c, b);
+        if (b.err) { err = b.err; break; }
+        // literals: straight into the output when the block has no sequences
+        u8 *lp = b.nseq ? lit : dst + out;
+        if (!b.nseq && (u64)out + b.lit_regen > cap) { err = SMALL_TOO_BIG; break; }
+        if (b.lit_type == LIT_RAW) for (u32 k = 0; k < b.lit_regen; k++) lp[k] = c[b.lit_off + k];
+        else if (b.lit_type == LIT_RLE) { const u8 v = c[b.lit_off]; for (u32 k = 0; k < b.lit_regen; k++) lp[k] = v; }
+        else {
+            if (b.lit_type == LIT_HUF) {
+                u32 nw = 0, used = 0;
+                const u32 lg = huf_read_weights_ws(c + b.lit_off, b.lit_csize, w, &nw, &used, ws);
+                if (!lg || used != b.huf_streams_off - b.lit_off) { err = ZE_CORRUPT; break; }
+                huf_build_any_ws(huf, w, nw, lg, ws); huf_log = lg; have_huf = true;
+            } else if (!have_huf) { err = ZE_CORRUPT; break; }              // treeless without a previous table
+            const u8 *sp = c + b.huf_streams_off;
+            if (b.nstreams == 1) { if (huf_decode_stream(sp, b.huf_streams_size, (const u16 *)huf, huf_log, lp, b.lit_regen)) { err = ZE_CORRUPT; break; } }
+            else {
+                const u32 s1 = ld16(sp), s2 = ld16(sp + 2), s3 = ld16(sp + 4), tot = b.huf_streams_size - 6, per = (b.lit_regen + 3) / 4;
+                if (s1 + s2 + s3 >= tot || !s1 || !s2 || !s3 || per * 3 > b.lit_regen) { err = ZE_CORRUPT; break; }
+                const u32 offs[4] = { 0, s1, s1 + s2, s1 + s2 + s3 }, szs[4] = { s1, s2, s3, tot - s1 - s2 - s3 };
+                bool bad = false;
+                for (u32 k = 0; k < 4 && !bad; k++)
+                    bad = huf_decode_stream(sp + 6 + offs[k], szs[k], (const u16 *)huf, huf_log, lp + k * per, k < 3 ? per : b.lit_regen - 3 * per) != 0;
+                if (bad) { err = ZE_CORRUPT; break; }
+            }
+        }
+        if (!b.nseq) { out += b.lit_regen; if (last) break; continue; }
+        if (b.nseq > SMALL_SEQ) { err = SMALL_TOO_BIG; break; }
+        // sequence tables (3.1.1.3.2.1): predefined, RLE, FSE description, or the table of the previous block
+        u32 p = b.seq_off; bool tbad = false;
+        for (int k = 0; k < 3 && !tbad; k++) {
+            const u32 m = b.modes[k];
+            if (m == SM_PREDEF) { tab[k].t = predef + po[k]; tab[k].log = pl[k]; tab[k].rle = false; tab[k].rle_sym = 0; have_tab[k] = true; }
+            else if (m == SM_RLE) { tab[k].t = predef; tab[k].log = 0; tab[k].rle = true; tab[k].rle_sym = b.fse_tab[k]; have_tab[k] = true; p++; }
+            else if (m == SM_FSE) {
+                u32 nsym, lg;
+                const u32 d = fse_read_ncount(c + p, b.bsize - p, max_log[k], max_sym[k], norm, &nsym, &lg);
+                if (!d || lg != b.fse_log[k] || !fse_build_table(fse + fo[k], norm, nsym, lg, nx)) { tbad = true; break; }
+                p += d; tab[k].t = fse + fo[k]; tab[k].log = lg; tab[k].rle = false; tab[k].rle_sym = 0; have_tab[k] = true;
+            } else if (!have_tab[k]) tbad = true;
+        }
+        if (tbad || p != b.seq_bits_off) { err = ZE_CORRUPT; break; }
+        u32 *sll = sq, *sml = sq + SMALL_SEQ, *sof = sq + 2 * SMALL_SEQ;
+        u64 tl = 0, tm = 0; u32 ro[3];
+        const u8 e = zstd_decode_sequences(c + b.seq_bits_off, b.seq_bits_size, b.nseq, tab, sll, sml, sof, ro, &tl, &tm);
+        if (e) { err = e; break; }
+        if (tl > b.lit_regen) { err = ZE_CORRUPT; break; }
+        const u64 regen = b.lit_regen + tm;
+        if (regen > ZBLOCK_MAX) { err = ZE_CORRUPT; break; }
+        if ((u64)out + regen > cap) { err = SMALL_TOO_BIG; break; }
+        u32 op = out, l = 0; bool xbad = false;
+        for (u32 q = 0; q < b.nseq; q++) {
+            const u32 ll = sll[q], ml = sml[q], of = sym_resolve(sof[q], rep);
+            for (u32 k = 0; k < ll; k++) dst[op + k] = lit[l + k];
+            op += ll; l += ll;
+            if (of == 0 || of > op) { xbad = true; break; }
+            for (u32 k = 0; k < ml; k++) dst[op + k] = dst[op + k - of];
+            op += ml;
+        }
+        if (xbad) { err = ZE_CORRUPT; break; }
+        for (u32 k = l; k < b.lit_regen; k++) dst[op++] = lit[k];
+        { const u32 r0 = sym_resolve(ro[0], rep), r1 = sym_resolve(ro[1], rep), r2 = sym_resolve(ro[2], rep); rep[0] = r0; rep[1] = r1; rep[2] = r2; }
+        out = op;
+        if (last) break;
+    }
+    if (!err && fh.checksum) { if (pos + 4 > len) err = ZE_TRUNC; else pos += 4; }
+    if (!err && fh.has_fcs && fh.content_size != out) err = ZE_CORRUPT;
+    res[0] = err; res[1] = out; res[2] = pos;
+}
+
 // ---- host orchestration ------------------------------------------------------------------------------------------
 int zstd_init_tables(naf_gpu_ctx *c)
 {
@@ -1100,10 +1215,22 @@ static int zerr(naf_gpu_ctx *c, u32 e, const char *where)
 
 // Decode ONE frame whose header (after the magic) starts at d_src[0].  *consumed = bytes of the frame.
 static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *d_dst, size_t dst_cap,
-                           size_t *out_len, size_t *consumed, ZRange *rg, const EmitP *fuse, u8 *text)
+                           size_t *out_len, size_t *consumed, ZRange *rg, const EmitP *fuse, u8 *text, const u8 *head = nullptr)
 {
+    int rc;
+    // small frames (side streams of archives with few records): one launch, one read-back
+    const char *sm = getenv("NAF_GPU_SMALL");                            // "0": never (cross-check)
+    if (!rg && !fuse && src_len && src_len <= SMALL_SRC && dst_cap <= SMALL_OUT && !(sm && sm[0] == '0')) {
+        u8 *lit = (u8 *)arena_alloc(c, ZBLOCK_MAX + 64); u32 *sq = arena_new<u32>(c, 3 * (size_t)SMALL_SEQ); u32 *d_res = arena_new<u32>(c, 4);
+        if (!lit || !sq || !d_res) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zstd_small_frame", k_small_frame, 1, 64, 0, d_src, (u32)src_len, d_dst, (u32)dst_cap, lit, sq, (const FseE *)c->d_predef, d_res);
+        u32 res[3]; if ((rc = ctx_readback(c, res, d_res, 12))) return rc;
+        if (res[0] == 0) { *out_len = res[1]; *consumed = res[2]; return 0; }
+        if (res[0] != SMALL_TOO_BIG) return zerr(c, res[0], "small frame");
+    }
     u8 hb[18]; size_t hl = src_len < 18 ? src_len : 18;
-    int rc = ctx_readback(c, hb, d_src, hl); if (rc) return rc;
+    if (head) memcpy(hb, head, hl);
+    else { rc = ctx_readback(c, hb, d_src, hl); if (rc) return rc; }
     ZFrameHdr fh = zstd_parse_frame_header(hb, hl);
     if (fh.err) return zerr(c, (u32)fh.err, "frame header");
 
@@ -1330,9 +1457,9 @@ int zstd_split_status(naf_gpu_ctx *c, const ZSplit *sp)
     return 0;
 }
 
-int zstd_decode(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len)
+int zstd_decode(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len, const u8 *head)
 {
-    return zstd_decode_range(c, d_src, src_len, has_magic, d_dst, dst_cap, out_len, nullptr);
+    return zstd_decode_range(c, d_src, src_len, has_magic, d_dst, dst_cap, out_len, nullptr, head);
 }
 
 int zstd_decode_fused_fasta(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, size_t *out_len, const EmitP *P, u8 *text)
@@ -1349,7 +1476,7 @@ int zstd_decode_fused_fasta(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int
 }
 
 // rg != nullptr: first frame only is range-decoded (sections written by ennaf are exactly one frame)
-int zstd_decode_range(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len, ZRange *rg)
+int zstd_decode_range(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len, ZRange *rg, const u8 *head)
 {
     size_t pos = 0, out = 0; bool first = true;
     *out_len = 0;
@@ -1370,7 +1497,8 @@ int zstd_decode_range(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_m
         }
         first = false;
         size_t n = 0, used = 0;
-        int rc = zstd_decode_one(c, d_src + pos, src_len - pos, d_dst + out, dst_cap > out ? dst_cap - out : 0, &n, &used, out == 0 ? rg : nullptr, nullptr, nullptr);
+        int rc = zstd_decode_one(c, d_src + pos, src_len - pos, d_dst + out, dst_cap > out ? dst_cap - out : 0, &n, &used, out == 0 ? rg : nullptr, nullptr, nullptr,
+                                 (head && pos == 0 && !has_magic) ? head : nullptr);
         if (rg && rg->ranged && pos + used < src_len) return ctx_fail(c, NAF_GPU_EZSTD, "range decode needs a single-frame stream");
         if (rc == NAF_GPU_ECAP) { *out_len = out + n; return rc; }
         if (rc) return rc;
