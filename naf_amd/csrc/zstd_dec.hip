@@ -235,7 +235,7 @@ __global__ void k_spec_walk(const u8 *src, u64 len, const u64 *start, u32 nchunk
 }
 
 __global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_huf, i32 *own_ll, i32 *own_of, i32 *own_ml,
-                               u64 *seq_cnt, ZStat *st)
+                               u64 *seq_cnt, u64 *sizes, ZStat *st)
 {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblk) return;
@@ -250,6 +250,7 @@ __global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_hu
     own_of[i] = (sq && b.modes[1] != SM_REPEAT) ? (i32)i : -1;
     own_ml[i] = (sq && b.modes[2] != SM_REPEAT) ? (i32)i : -1;
     seq_cnt[i] = sq ? b.nseq : 0;
+    sizes[i] = b.regen;                                          // final unless the block has sequences (k_decode_seq then rewrites it)
     if (comp && b.lit_type == LIT_HUF) atomicAdd(&st->n_huf_def, 1u);
     if (comp && b.lit_type >= LIT_HUF && b.nseq == 0) atomicAdd(&st->n_plain_huf, 1u);
     if (sq) atomicAdd(&st->n_seq_blk, 1u);
@@ -265,12 +266,40 @@ static __device__ __forceinline__ bool huf_is_flat(const u8 *w, u32 nw, u32 log)
     return n1 == (1u << log);
 }
 
-__global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first)
+// Direct (4-bit) weight list of a flat tree, recognised from the description alone: 2^L - 1 listed weights, every one of them 0 or
+// 1, 2^L - 1 ones among them (the last symbol's weight is implied: 1).  No table is built for such a block -- k_flat_literals
+// takes its symbols from the same description.  Returns L, or 0.
+static __device__ __forceinline__ u32 huf_flat_direct(const u8 *d, u32 len)
+{
+    if (len < 1 || d[0] < 128) return 0;
+    const u32 nw = d[0] - 127, bytes = (nw + 1) / 2;
+    if (1 + bytes > len) return 0;
+    u32 ones = 0;
+    for (u32 k = 0; k < bytes; k++) {
+        const u32 v = d[1 + k], hi = v >> 4, lo = (2 * k + 1 < nw) ? (v & 15) : 0;
+        if (hi > 1 || lo > 1) return 0;
+        ones += hi + lo;
+    }
+    const u32 total = ones + 1;                                 // with the implied last symbol
+    if (total < 2 || total > 256 || (total & (total - 1))) return 0;
+    return (u32)hibit32(total);
+}
+
+// range4 (optional, device): [4] = first block whose table may be in force in the wanted byte range, [1] = one past its last block
+// (k_find_range); blocks outside need no table.
+__global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table)
 {
     u32 i = first + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblk) return;
+    if (range4 && (i < (u32)range4[4] || i >= (u32)range4[1])) return;
     if (blk[i].btype != BT_COMP || blk[i].lit_type != LIT_HUF || blk[i].err) return;
     const u8 *c = src + blk[i].src_off;
+    const u32 fl = always_table ? 0u : huf_flat_direct(c + blk[i].lit_off, blk[i].lit_csize);
+    if (fl) {
+        blk[i].huf_tab = 0xFFFFFFFFu; blk[i].huf_log = (u8)fl; blk[i].huf_flat = 1;
+        atomicMax(&st->max_huf_log, fl); atomicAdd(&st->n_flat, 1u);
+        return;
+    }
     u8 w[256]; u32 nw = 0, used = 0;
     u32 log = huf_read_weights(c + blk[i].lit_off, blk[i].lit_csize, w, &nw, &used);
     if (!log) { set_err(st, ZE_CORRUPT); blk[i].err = ZE_CORRUPT; return; }
@@ -817,8 +846,22 @@ __global__ __launch_bounds__(256) void k_flat_literals(const u8 *src, const ZBlo
     const i32 ob = own_huf[bi];
     if (ob < 0 || !blk[ob].huf_flat) return;
     const u32 L = blk[ob].huf_log;
-    const u16 *tab = (const u16 *)(pool + blk[ob].huf_tab);
-    if (threadIdx.x < (1u << L)) sym[threadIdx.x] = (u8)(tab[threadIdx.x] >> 8);
+    if (blk[ob].huf_tab != 0xFFFFFFFFu) {
+        const u16 *tab = (const u16 *)(pool + blk[ob].huf_tab);
+        if (threadIdx.x < (1u << L)) sym[threadIdx.x] = (u8)(tab[threadIdx.x] >> 8);
+    } else {
+        // no table was built (huf_flat_direct): code k is the k-th symbol of weight 1, in symbol order; the last one is implied
+        __shared__ u32 s_wc[4];
+        const u8 *d = src + blk[ob].src_off + blk[ob].lit_off;
+        const u32 nw = (u32)d[0] - 127, t = threadIdx.x;
+        const bool one = t < nw ? (((t & 1) ? d[1 + (t >> 1)] & 15 : d[1 + (t >> 1)] >> 4) == 1) : t == nw;
+        const u64 bal = __ballot(one);
+        if ((t & 63) == 0) s_wc[t >> 6] = (u32)__popcll(bal);
+        __syncthreads();
+        u32 rank = (u32)__popcll(bal & ((1ull << (t & 63)) - 1));
+        for (u32 q = 0; q < (t >> 6); q++) rank += s_wc[q];
+        if (one) sym[rank] = (u8)t;
+    }
     __syncthreads();
     if (L == 4) pair[threadIdx.x] = (u16)(sym[threadIdx.x >> 4] | ((u32)sym[threadIdx.x & 15] << 8));
     __syncthreads();
@@ -1064,7 +1107,7 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
 }
 
 // Blocks whose regenerated bytes intersect [want_lo, want_hi): first block index, one-past-last, and their byte span.
-__global__ void k_find_range(const u64 *offs, u32 nblk, u64 total, u64 want_lo, u64 want_hi, const i32 *own_huf, u64 *out4)
+__global__ void k_find_range(const u64 *offs, u32 nblk, const u64 *total_p, u64 want_lo, u64 want_hi, const i32 *own_huf, u64 *out4)
 {
     if (threadIdx.x || blockIdx.x) return;
     u32 lo = 0, hi = nblk;                                   // last block with offs <= want_lo
@@ -1073,7 +1116,7 @@ __global__ void k_find_range(const u64 *offs, u32 nblk, u64 total, u64 want_lo, 
     lo = b_lo; hi = nblk;                                    // first block with offs >= want_hi
     while (lo < hi) { u32 mid = (lo + hi) >> 1; if (offs[mid] < want_hi) lo = mid + 1; else hi = mid; }
     u32 b_hi = lo;
-    out4[0] = b_lo; out4[1] = b_hi; out4[2] = offs[b_lo]; out4[3] = b_hi < nblk ? offs[b_hi] : total;
+    out4[0] = b_lo; out4[1] = b_hi; out4[2] = offs[b_lo]; out4[3] = b_hi < nblk ? offs[b_hi] : *total_p;
     i32 ob = own_huf[b_lo]; out4[4] = ob < 0 ? b_lo : (u64)ob;      // first block whose Huffman table can be in force in the range
 }
 
@@ -1085,21 +1128,18 @@ __global__ void k_find_range(const u64 *offs, u32 nblk, u64 total, u64 want_lo, 
 // read-back.  res: [0] error (ZE_*; SMALL_TOO_BIG when the output does not fit `cap` -- the caller then takes the long way, which
 // reports the size needed), [1] bytes produced, [2] bytes of the frame.
 #define SMALL_SRC 16384u
-#define SMALL_OUT 65536u
-#define SMALL_SEQ 131072u
+#define SMALL_OUT 32768u
+#define SMALL_SEQ 2048u
 #define SMALL_TOO_BIG 100u
-__global__ __launch_bounds__(64) void k_small_frame(const u8 *src, u32 len, u8 *dst, u32 cap, u8 *lit, u32 *sq, const FseE *predef, u32 *res)
+struct SmallRes { u32 err, out, pos; };
+// The frame's bytes, its output, a block's literals and sequences all sit in LDS while the one lane works (a dependent access costs
+// an LDS round trip, not an HBM one: 180 -> about 15 ns per byte); the other lanes copy the frame in and the output out.
+__device__ void small_frame_decode(const u8 *src, u32 len, u8 *dst, u32 cap, u8 *lit, u32 *sll, u32 *sml, u32 *sof, const FseE *predef,
+                                   HufBuildWS &ws, u16 *huf, FseE *fse, u8 *w, i16 *norm, u16 *nx, SmallRes *res)
 {
-    __shared__ HufBuildWS ws;
-    __shared__ __attribute__((aligned(16))) u16 huf[HUFC_BYTES / 2 > 256 ? HUFC_BYTES / 2 : 256];
-    __shared__ FseE fse[512 + 256 + 512];
-    __shared__ u8 w[256];
-    __shared__ i16 norm[64];
-    __shared__ u16 nx[64];
-    if (threadIdx.x) return;
     u32 err = 0, out = 0, pos = 0;
     ZFrameHdr fh = zstd_parse_frame_header(src, len);
-    if (fh.err) { res[0] = (u32)fh.err; res[1] = 0; res[2] = 0; return; }
+    if (fh.err) { res->err = (u32)fh.err; res->out = 0; res->pos = 0; return; }
     pos = fh.hdr_size;
     u32 huf_log = 0; bool have_huf = false;
     SeqTab tab[3]; bool have_tab[3] = { false, false, false };
@@ -1124,9 +1164,9 @@ __global__ __launch_bounds__(64) void k_small_frame(const u8 *src, u32 len, u8 *
         ZBlock b; b.src_off = 0; b.bsize = size; b.btype = BT_COMP; b.last = (u8)last;
         zstd_parse_block(c, b);
         if (b.err) { err = b.err; break; }
+        if ((u64)out + b.lit_regen > cap) { err = SMALL_TOO_BIG; break; }             // (lit is as large as the output buffer)
         // literals: straight into the output when the block has no sequences
         u8 *lp = b.nseq ? lit : dst + out;
-        if (!b.nseq && (u64)out + b.lit_regen > cap) { err = SMALL_TOO_BIG; break; }
         if (b.lit_type == LIT_RAW) for (u32 k = 0; k < b.lit_regen; k++) lp[k] = c[b.lit_off + k];
         else if (b.lit_type == LIT_RLE) { const u8 v = c[b.lit_off]; for (u32 k = 0; k < b.lit_regen; k++) lp[k] = v; }
         else {
@@ -1164,7 +1204,6 @@ __global__ __launch_bounds__(64) void k_small_frame(const u8 *src, u32 len, u8 *
             } else if (!have_tab[k]) tbad = true;
         }
         if (tbad || p != b.seq_bits_off) { err = ZE_CORRUPT; break; }
-        u32 *sll = sq, *sml = sq + SMALL_SEQ, *sof = sq + 2 * SMALL_SEQ;
         u64 tl = 0, tm = 0; u32 ro[3];
         const u8 e = zstd_decode_sequences(c + b.seq_bits_off, b.seq_bits_size, b.nseq, tab, sll, sml, sof, ro, &tl, &tm);
         if (e) { err = e; break; }
@@ -1189,7 +1228,28 @@ __global__ __launch_bounds__(64) void k_small_frame(const u8 *src, u32 len, u8 *
     }
     if (!err && fh.checksum) { if (pos + 4 > len) err = ZE_TRUNC; else pos += 4; }
     if (!err && fh.has_fcs && fh.content_size != out) err = ZE_CORRUPT;
-    res[0] = err; res[1] = out; res[2] = pos;
+    res->err = err; res->out = out; res->pos = pos;
+}
+__global__ __launch_bounds__(64) void k_small_frame(const u8 *src, u32 len, u8 *dst, u32 cap, const FseE *predef, u32 *res)
+{
+    __shared__ __attribute__((aligned(16))) u8 s_src[SMALL_SRC + 16], s_out[SMALL_OUT + 16], s_lit[SMALL_OUT + 16];
+    __shared__ u32 s_ll[SMALL_SEQ], s_ml[SMALL_SEQ], s_of[SMALL_SEQ];
+    __shared__ HufBuildWS ws;
+    __shared__ __attribute__((aligned(16))) u16 huf[HUFC_BYTES / 2 > 256 ? HUFC_BYTES / 2 : 256];
+    __shared__ FseE fse[512 + 256 + 512];
+    __shared__ FseE s_predef[160];
+    __shared__ u8 w[256];
+    __shared__ i16 norm[64];
+    __shared__ u16 nx[64];
+    __shared__ SmallRes r;
+    for (u32 k = threadIdx.x; k < len; k += 64) s_src[k] = src[k];
+    for (u32 k = threadIdx.x; k < 16; k += 64) s_src[len + k] = 0;
+    for (u32 k = threadIdx.x; k < 160; k += 64) s_predef[k] = predef[k];
+    __syncthreads();
+    if (threadIdx.x == 0) small_frame_decode(s_src, len, s_out, cap < SMALL_OUT ? cap : SMALL_OUT, s_lit, s_ll, s_ml, s_of, s_predef, ws, huf, fse, w, norm, nx, &r);
+    __syncthreads();
+    if (r.err == 0) for (u32 k = threadIdx.x; k < r.out; k += 64) dst[k] = s_out[k];
+    if (threadIdx.x == 0) { res[0] = r.err; res[1] = r.out; res[2] = r.pos; }
 }
 
 // ---- host orchestration ------------------------------------------------------------------------------------------
@@ -1221,9 +1281,9 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     // small frames (side streams of archives with few records): one launch, one read-back
     const char *sm = getenv("NAF_GPU_SMALL");                            // "0": never (cross-check)
     if (!rg && !fuse && src_len && src_len <= SMALL_SRC && dst_cap <= SMALL_OUT && !(sm && sm[0] == '0')) {
-        u8 *lit = (u8 *)arena_alloc(c, ZBLOCK_MAX + 64); u32 *sq = arena_new<u32>(c, 3 * (size_t)SMALL_SEQ); u32 *d_res = arena_new<u32>(c, 4);
-        if (!lit || !sq || !d_res) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "zstd_small_frame", k_small_frame, 1, 64, 0, d_src, (u32)src_len, d_dst, (u32)dst_cap, lit, sq, (const FseE *)c->d_predef, d_res);
+        u32 *d_res = arena_new<u32>(c, 4);
+        if (!d_res) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zstd_small_frame", k_small_frame, 1, 64, 0, d_src, (u32)src_len, d_dst, (u32)dst_cap, (const FseE *)c->d_predef, d_res);
         u32 res[3]; if ((rc = ctx_readback(c, res, d_res, 12))) return rc;
         if (res[0] == 0) { *out_len = res[1]; *consumed = res[2]; return 0; }
         if (res[0] != SMALL_TOO_BIG) return zerr(c, res[0], "small frame");
@@ -1305,16 +1365,60 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     if (!own || !seq_cnt || !sizes) return NAF_GPU_ENOMEM;
     i32 *own_huf = own, *own_ll = own + nblk, *own_of = own + 2 * (size_t)nblk, *own_ml = own + 3 * (size_t)nblk;
     u32 g = cdiv(nblk, 64);
-    LAUNCH(c, "zstd_parse_blocks", k_parse_blocks, g, 64, 0, d_src, blk, nblk, own_huf, own_ll, own_of, own_ml, seq_cnt, st);
-    rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+    LAUNCH(c, "zstd_parse_blocks", k_parse_blocks, g, 64, 0, d_src, blk, nblk, own_huf, own_ll, own_of, own_ml, seq_cnt, sizes, st);
+    if ((rc = scan_inclusive_max_i32(c, own_huf, nblk))) return rc;
+    u64 *d_total_out = (u64 *)((u8 *)st + offsetof(ZStat, total_out));
+    const char *fl_env = getenv("NAF_GPU_FLAT");                                 // "0": every block through the serial kernel (cross-check)
+    const u32 always_table = (fl_env && fl_env[0] == '0') ? 1u : 0u;
+    // Speculative continuation.  Most frames that are long enough to matter are literal-only (this build's own sequence, mask and
+    // quality streams); for those nothing below needs the host: block sizes are final after the parse, so offsets, the block range
+    // of a byte-range request, the Huffman tables and the part boundaries of a split decode are queued right away and the counters
+    // come back in ONE read-back.  A frame that does have sequences then takes the long way from here (its tables are kept).
+    const bool spec = nblk > 512 && !fuse;
+    u64 *r4 = nullptr, *ends = nullptr; u8 *huf_pool = nullptr; u32 pool_cap = 0; bool tables_built = false; bool ranged_build = false;
+    u64 h4[5] = { 0, 0, 0, 0, 0 }, hends[ZSPLIT_MAX] = { 0 };
+    if (spec) {
+        if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
+        u64 *extra = arena_new<u64>(c, 8 + ZSPLIT_MAX); if (!extra) return NAF_GPU_ENOMEM;
+        if (rg && rg->want_hi > rg->want_lo) {
+            r4 = extra;
+            LAUNCH(c, "zstd_find_range", k_find_range, 1, 64, 0, (const u64 *)sizes, nblk, (const u64 *)d_total_out, rg->want_lo, rg->want_hi, (const i32 *)own_huf, r4);
+            ranged_build = true;
+        }
+        const u64 want_pool = (u64)nblk * HUFC_BYTES + 4096;
+        pool_cap = want_pool > 0xFFFFF000ull ? 0xFFFFF000u : (u32)want_pool;
+        huf_pool = (u8 *)arena_alloc(c, pool_cap);
+        if (!huf_pool) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)r4, always_table);
+        ZSplit *sp = c->zsplit;
+        if (sp && !rg && sp->parts >= 2) {
+            ends = extra + 8;
+            for (int k = 0; k + 1 < sp->parts; k++) {
+                u32 hi_b = (u32)((u64)nblk * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
+                HIP_TRY(c, hipMemcpyAsync(ends + k, sizes + hi_b, 8, hipMemcpyDeviceToDevice, c->stream));
+            }
+        }
+        u64 hx[8 + ZSPLIT_MAX];
+        rc = ctx_readback2(c, &hs, st, sizeof hs, hx, extra, sizeof hx); if (rc) return rc;
+        memcpy(h4, hx, sizeof h4); memcpy(hends, hx + 8, sizeof hends);
+        tables_built = true;
+    } else {
+        rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+    }
     if (hs.err) return zerr(c, hs.err, "block parse");
     u32 n_seq_blk = hs.n_seq_blk, n_huf_def = hs.n_huf_def;
     // fused decode+emit needs every block to be a literal-only Huffman block
     if (fuse && !(n_seq_blk == 0 && hs.n_plain_huf == nblk && nblk > 0)) return ZSTD_NEED_TWO_PASS;
-    if ((rc = scan_inclusive_max_i32(c, own_huf, nblk))) return rc;
+    const bool lit_only_spec = spec && n_seq_blk == 0;
+    if (spec && n_seq_blk && ranged_build) {
+        // the block range was worked out from sizes that sequences will change: forget those tables
+        tables_built = false;
+        HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, huf_pool_used), 0, 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, max_huf_log), 0, 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, n_flat), 0, 4, c->stream));
+    }
     u64 *d_total_seq = (u64 *)((u8 *)st + offsetof(ZStat, total_seq));
-    u64 *d_total_out = (u64 *)((u8 *)st + offsetof(ZStat, total_out));
-    u8 *huf_pool = nullptr; FseE *fse_pool = nullptr; u32 *o_ll = nullptr, *o_ml = nullptr, *o_of = nullptr;
+    FseE *fse_pool = nullptr; u32 *o_ll = nullptr, *o_ml = nullptr, *o_of = nullptr;
     if (n_seq_blk) {
         if ((rc = scan_inclusive_max_i32(c, own_ll, nblk))) return rc;
         if ((rc = scan_inclusive_max_i32(c, own_of, nblk))) return rc;
@@ -1339,12 +1443,14 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         if ((rc = scan_exclusive_u64(c, flag, nblk, (u64 *)nullptr))) return rc;
         LAUNCH(c, "zstd_seq_list", k_seq_list, g, 64, 0, (const ZBlock *)blk, nblk, (const u64 *)flag, seq_list);
     }
-    LAUNCH(c, "zstd_decode_seq", k_decode_seq, g, 64, 0, d_src, blk, nblk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
-           (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st);
-    if (n_seq_blk) LAUNCH(c, "zstd_rep_fast", k_rep_fast, cdiv(n_seq_blk, 256), 256, 0, blk, (const u32 *)seq_list, n_seq_blk, st);
-    if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
-    rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
-    if (hs.err) return zerr(c, hs.err, "sequences");
+    if (!lit_only_spec) {
+        LAUNCH(c, "zstd_decode_seq", k_decode_seq, g, 64, 0, d_src, blk, nblk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
+               (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st);
+        if (n_seq_blk) LAUNCH(c, "zstd_rep_fast", k_rep_fast, cdiv(n_seq_blk, 256), 256, 0, blk, (const u32 *)seq_list, n_seq_blk, st);
+        if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
+        rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+        if (hs.err) return zerr(c, hs.err, "sequences");
+    }
     const u32 max_seq_regen = hs.max_seq_regen;
     // entry states matter only when some sequence of the frame uses a repeat code (this build's own LZ blocks never do)
     if (n_seq_blk && (hs.rep_slow & 1)) LAUNCH(c, "zstd_rep_chain", k_rep_chain, 1, 64, 0, blk, nblk);
@@ -1357,9 +1463,11 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     if (fuse) { d_dst = nullptr; dst_cap = ~(size_t)0; }
     if (rg) { rg->got_lo = 0; rg->got_hi = hs.total_out; rg->ranged = false; }
     if (rg && n_seq_blk == 0 && nblk > 0 && rg->want_hi > rg->want_lo) {
-        u64 *r4 = arena_new<u64>(c, 5); if (!r4) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "zstd_find_range", k_find_range, 1, 64, 0, (const u64 *)sizes, nblk, (u64)hs.total_out, rg->want_lo, rg->want_hi, (const i32 *)own_huf, r4);
-        u64 h4[5]; rc = ctx_readback(c, h4, r4, 40); if (rc) return rc;
+        if (!lit_only_spec) {
+            u64 *r4b = arena_new<u64>(c, 5); if (!r4b) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "zstd_find_range", k_find_range, 1, 64, 0, (const u64 *)sizes, nblk, (const u64 *)d_total_out, rg->want_lo, rg->want_hi, (const i32 *)own_huf, r4b);
+            rc = ctx_readback(c, h4, r4b, 40); if (rc) return rc;
+        }
         huf_first = (u32)h4[4];
         b_first = (u32)h4[0]; b_count = (u32)(h4[1] - h4[0]); bias = h4[2];
         rg->got_lo = h4[2]; rg->got_hi = h4[3]; rg->ranged = true;
@@ -1378,13 +1486,15 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     if (n_huf_def) {
         // tables of the blocks that will be decoded (and of the earlier blocks that own a table in force there)
         u32 hb_end = b_first + b_count, hb_n = hb_end - huf_first;
-        u32 pool_cap = (hb_n < n_huf_def ? hb_n : n_huf_def) * (u32)HUFC_BYTES + 4096u;   // largest table form (log > 8: compact)
-        huf_pool = (u8 *)arena_alloc(c, pool_cap);
-        if (!huf_pool) return NAF_GPU_ENOMEM;
-        if (hb_n && hb_n <= 512) LAUNCH(c, "zstd_build_huf", k_build_huf_lds, hb_n, 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first);
-        else if (hb_n) LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(hb_n, 64), 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first);
-        rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
-        if (hs.err) return zerr(c, hs.err, "Huffman tables");
+        if (!tables_built) {
+            pool_cap = (hb_n < n_huf_def ? hb_n : n_huf_def) * (u32)HUFC_BYTES + 4096u;   // largest table form (log > 8: compact)
+            huf_pool = (u8 *)arena_alloc(c, pool_cap);
+            if (!huf_pool) return NAF_GPU_ENOMEM;
+            if (hb_n && hb_n <= 512) LAUNCH(c, "zstd_build_huf", k_build_huf_lds, hb_n, 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first);
+            else if (hb_n) LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(hb_n, 64), 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first, (const u64 *)nullptr, (always_table || fuse) ? 1u : 0u);
+            rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+            if (hs.err) return zerr(c, hs.err, "Huffman tables");
+        }
         u32 slot = huf_tab_bytes(hs.max_huf_log);
         u32 b_end = b_first + b_count;
         if (fuse && hs.max_huf_log > 7) return ZSTD_NEED_TWO_PASS;
@@ -1396,8 +1506,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         else if (b_count) {
             const u32 huf_lds = slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512 + (getenv("NAF_GPU_PADLDS") ? atoi(getenv("NAF_GPU_PADLDS")) : 0);
             // blocks whose tree is flat go to k_flat_literals; the serial kernel is not launched when that is all of them
-            const char *fl = getenv("NAF_GPU_FLAT");                             // "0": every block through the serial kernel (cross-check)
-            const u32 flat_on = (hs.n_flat && !(fl && fl[0] == '0')) ? 1u : 0u;
+            const u32 flat_on = (hs.n_flat && !always_table) ? 1u : 0u;
             const bool serial_needed = !flat_on || hs.n_flat < (hb_n < n_huf_def ? hb_n : n_huf_def);
             ZSplit *sp = c->zsplit;
             const char *smin = getenv("NAF_GPU_SPLIT_MIN");                      // blocks per part below which a split is not worth its launches (tests lower it)
@@ -1407,13 +1516,16 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                 // blocks first, so that a finished part is complete
                 LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
                 copy_fill_done = true;
-                // output offsets of the range ends: gathered on the device, one read-back (before the launches: it waits for the stream)
-                u64 *ends = arena_new<u64>(c, ZSPLIT_MAX); if (!ends) return NAF_GPU_ENOMEM;
-                for (int k = 0; k + 1 < sp->parts; k++) {
-                    u32 hi_b = (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
-                    HIP_TRY(c, hipMemcpyAsync(ends + k, sizes + hi_b, 8, hipMemcpyDeviceToDevice, c->stream));
+                // output offsets of the part ends: they came with the counters when the frame took the speculative route
+                if (ends) for (int k = 0; k + 1 < sp->parts; k++) sp->out_end[k] = hends[k];
+                else {
+                    u64 *e2 = arena_new<u64>(c, ZSPLIT_MAX); if (!e2) return NAF_GPU_ENOMEM;
+                    for (int k = 0; k + 1 < sp->parts; k++) {
+                        u32 hi_b = (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
+                        HIP_TRY(c, hipMemcpyAsync(e2 + k, sizes + hi_b, 8, hipMemcpyDeviceToDevice, c->stream));
+                    }
+                    rc = ctx_readback(c, sp->out_end, e2, 8 * (size_t)(sp->parts - 1)); if (rc) return rc;
                 }
-                rc = ctx_readback(c, sp->out_end, ends, 8 * (size_t)(sp->parts - 1)); if (rc) return rc;
                 sp->out_end[sp->parts - 1] = hs.total_out;
                 u32 lo_b = 0;
                 for (int k = 0; k < sp->parts; k++) {
