@@ -93,6 +93,8 @@ int zstd_decode_fused_fasta(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int
 struct ZRange { u64 want_lo, want_hi, got_lo, got_hi; bool ranged; };
 int zstd_decode_range(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len, ZRange *rg, const u8 *head = nullptr);
 int zstd_split_status(naf_gpu_ctx *c, const ZSplit *sp);
+// up to 4 small frames (no magic) in one launch; ok[k] false = take the ordinary path for frame k
+int zstd_small_batch(naf_gpu_ctx *c, int n, const u8 *const *src, const size_t *len, u8 *const *dst, const size_t *cap, bool *ok);
 // One frame of independently coded blocks; with_magic=0 omits the 4 magic bytes (as stored in a .naf section).
 // level >= 2 (or lz != 0) adds the LZ stage (matches inside a block).
 enum { ZENC_PART = 16, ZENC_PART_FIRST = 32, ZENC_PART_LAST = 64 };     // with_magic flags: a shard's part of a frame (zstd_enc.hip)

@@ -994,19 +994,35 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
         P.has_ids = 0; P.has_names = 0;
         const bool want_names = P.mode == EM_FASTA || P.mode == EM_FASTQ;
         if (want_names) { P.has_ids = has_ids; P.has_names = has_names; }
+        // ids, names and lengths of an archive with few records are a few hundred bytes each: one launch decodes all three (the ones
+        // that are not small, or fail, take the ordinary path below, which also words the error)
+        u8 *pre[3] = { nullptr, nullptr, nullptr };
+        auto small3 = [&](naf_gpu_ctx *x) -> int {
+            const int sec[3] = { S_IDS, S_NAMES, S_LEN }; const bool wanted[3] = { want_names && has_ids != 0, want_names && has_names != 0, true };
+            const u8 *src[3]; size_t len[3], cap[3]; u8 *dst[3]; bool ok[3]; int idx[3], m = 0;
+            for (int k = 0; k < 3; k++) {
+                if (!wanted[k] || h.orig_size[sec[k]] == 0) continue;
+                u8 *b = (u8 *)arena_alloc(x, h.orig_size[sec[k]] + 32); if (!b) return NAF_GPU_ENOMEM;
+                src[m] = d_naf + h.payload_off[sec[k]]; len[m] = h.comp_size[sec[k]]; dst[m] = b; cap[m] = h.orig_size[sec[k]]; idx[m++] = k;
+            }
+            if (!m) return 0;
+            int r = zstd_small_batch(x, m, src, len, dst, cap, ok); if (r) return r;
+            for (int q = 0; q < m; q++) if (ok[q]) pre[idx[q]] = dst[q];
+            return 0;
+        };
         auto ids_names = [&](naf_gpu_ctx *x) -> int {
             int r;
             if (want_names && has_ids) {
-                u8 *b = nullptr; u64 *z = nullptr;
+                u8 *b = pre[0]; u64 *z = nullptr;
                 if (h.orig_size[S_IDS] == 0) return ctx_fail(x, NAF_GPU_EFORMAT, "corrupted ids - not 0-terminated\n");
-                if ((r = load_section(x, d_naf, h, S_IDS, h.orig_size[S_IDS], "ids", &b, pl.frame_head[S_IDS]))) return r;
+                if (!b && (r = load_section(x, d_naf, h, S_IDS, h.orig_size[S_IDS], "ids", &b, pl.frame_head[S_IDS]))) return r;
                 if ((r = zero_positions(x, b, h.orig_size[S_IDS], N, &z, false))) return r;
                 P.ids = b; P.idz = z;
             }
             if (want_names && has_names) {
-                u8 *b = nullptr; u64 *z = nullptr;
+                u8 *b = pre[1]; u64 *z = nullptr;
                 if (h.orig_size[S_NAMES] == 0) return ctx_fail(x, NAF_GPU_EFORMAT, "corrupted names - not 0-terminated\n");
-                if ((r = load_section(x, d_naf, h, S_NAMES, h.orig_size[S_NAMES], "names", &b, pl.frame_head[S_NAMES]))) return r;
+                if (!b && (r = load_section(x, d_naf, h, S_NAMES, h.orig_size[S_NAMES], "names", &b, pl.frame_head[S_NAMES]))) return r;
                 if ((r = zero_positions(x, b, h.orig_size[S_NAMES], N, &z, true))) return r;
                 P.names = b; P.nmz = z;
             }
@@ -1015,8 +1031,8 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
         u64 *rec_len = nullptr;
         auto lengths = [&](naf_gpu_ctx *x) -> int {
             int r;
-            u8 *lens = nullptr;
-            if ((r = load_section(x, d_naf, h, S_LEN, h.orig_size[S_LEN], "lengths", &lens, pl.frame_head[S_LEN]))) return r;
+            u8 *lens = pre[2];
+            if (!lens && (r = load_section(x, d_naf, h, S_LEN, h.orig_size[S_LEN], "lengths", &lens, pl.frame_head[S_LEN]))) return r;
             u64 n_len = h.orig_size[S_LEN] / 4;
             u64 *flag = arena_new<u64>(x, n_len + 2); rec_len = arena_new<u64>(x, N + 1);
             if (!flag || !rec_len) return NAF_GPU_ENOMEM;
@@ -1035,9 +1051,12 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
         int rc_aux = 0, rc_len = 0;
         std::thread th;
         const bool len_on_aux = aux_run && early_has_work;
-        if (aux_run) th = std::thread([&] { hipSetDevice(c->device); rc_aux = ids_names(aux); if (len_on_aux) rc_len = lengths(aux); });     // no return until it is joined
+        int rc_small = 0;
+        if (aux_run && !len_on_aux) rc_small = small3(c);                    // this context has nothing else to do meanwhile
+        if (aux_run) th = std::thread([&] { hipSetDevice(c->device); if (len_on_aux) rc_small = small3(aux); rc_aux = rc_small ? rc_small : ids_names(aux); if (len_on_aux && !rc_small) rc_len = lengths(aux); });     // no return until it is joined
         early();                                                                                         // work that needs none of this (the mask stream)
-        if (!len_on_aux) rc_len = lengths(c);
+        if (!aux_run) rc_small = small3(c);
+        if (!len_on_aux) rc_len = rc_small ? rc_small : lengths(c);
         if (aux_run) { th.join(); hipStreamSynchronize(aux->stream); }
         if (rc_len) { if (len_on_aux) memcpy(c->err, aux->err, sizeof c->err); return rc_len; }           // the order a sequential run reports in: lengths, ids, names
         if (!aux_run) rc_aux = ids_names(c);
@@ -1054,8 +1073,7 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
         if ((rc = scan_exclusive_u64(c, rec_out, N + 1, (u64 *)nullptr))) return rc;
         if ((rc = scan_exclusive_u64(c, rec_base, N + 1, (u64 *)nullptr))) return rc;
         u64 tot[2];
-        if ((rc = ctx_readback(c, &tot[0], rec_out + N, 8))) return rc;
-        if ((rc = ctx_readback(c, &tot[1], rec_base + N, 8))) return rc;
+        if ((rc = ctx_readback2(c, &tot[0], rec_out + N, 8, &tot[1], rec_base + N, 8))) return rc;
         if (tot[1] != T) return ctx_fail(c, NAF_GPU_EFORMAT, "sum of lengths (%llu) differs from the stored sequence length (%llu)", (unsigned long long)tot[1], (unsigned long long)T);
         if (P.mode == EM_SEQUENCES && T == 0) tot[0] = 0;                            // output-sequences.c:81: nothing printed
         P.hdr_len = hdr_len; P.rec_out = rec_out; P.rec_base = rec_base;

@@ -24,6 +24,7 @@ struct ZStat {                 // device-side counters read back by the host
     u64 total_seq, total_out;
     u32 ticket, n_plain_huf;     // n_plain_huf: compressed blocks with Huffman literals and no sequences
     u32 max_seq_regen, n_flat;    // largest regenerated size among the blocks that have sequences; table-defining blocks whose tree is flat
+    u32 n_huf_distinct, n_huf_built;   // tree descriptions that differ from their predecessor's (k_huf_dedup); tables actually built
 };
 
 static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
@@ -256,6 +257,32 @@ __global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_hu
     if (sq) atomicAdd(&st->n_seq_blk, 1u);
 }
 
+// A block whose tree description repeats its predecessor's byte for byte (every block of a frame of random ACGT; long stretches of
+// any frame coded with a cached tree) defines nothing new: it is taken out of the ownership scan, so that it -- and the treeless
+// blocks behind it -- use the earlier block's table, and no table is built for it.
+__global__ void k_huf_dedup(const u8 *src, const ZBlock *blk, u32 nblk, i32 *own_huf, ZStat *st)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    if (i < nblk) {
+        const ZBlock &b = blk[i];
+        const bool def = b.btype == BT_COMP && b.lit_type == LIT_HUF && !b.err;
+        keep = def;
+        if (def && i > 0) {
+            const ZBlock &a = blk[i - 1];
+            const u32 n = b.huf_streams_off - b.lit_off;
+            if (a.btype == BT_COMP && a.lit_type == LIT_HUF && !a.err && a.huf_streams_off - a.lit_off == n) {
+                const u8 *p = src + a.src_off + a.lit_off, *q = src + b.src_off + b.lit_off;
+                bool same = true;
+                for (u32 k = 0; k < n && same; k++) same = p[k] == q[k];
+                if (same) { keep = false; own_huf[i] = -1; }
+            }
+        }
+    }
+    const u64 bal = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&st->n_huf_distinct, (u32)__popcll(bal));
+}
+
 // A flat tree: 2^log symbols, every one of weight 1, i.e. every code exactly `log` bits long (packed random ACGT: sixteen 4-bit
 // codes).  Such a stream is a string of fixed-width fields and needs no serial walk (k_flat_literals).
 static __device__ __forceinline__ bool huf_is_flat(const u8 *w, u32 nw, u32 log)
@@ -287,17 +314,20 @@ static __device__ __forceinline__ u32 huf_flat_direct(const u8 *d, u32 len)
 
 // range4 (optional, device): [4] = first block whose table may be in force in the wanted byte range, [1] = one past its last block
 // (k_find_range); blocks outside need no table.
-__global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table)
+#define HUF_FEW 2048u           // up to this many distinct trees in a frame: k_build_huf_few (LDS) builds them, else k_build_huf
+__global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table, const i32 *own_huf, u32 gate)
 {
     u32 i = first + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblk) return;
+    if (gate && st->n_huf_distinct <= HUF_FEW) return;            // k_build_huf_few has this frame
+    if (own_huf[i] != (i32)i) return;                              // repeats its predecessor's tree (k_huf_dedup)
     if (range4 && (i < (u32)range4[4] || i >= (u32)range4[1])) return;
     if (blk[i].btype != BT_COMP || blk[i].lit_type != LIT_HUF || blk[i].err) return;
     const u8 *c = src + blk[i].src_off;
     const u32 fl = always_table ? 0u : huf_flat_direct(c + blk[i].lit_off, blk[i].lit_csize);
     if (fl) {
         blk[i].huf_tab = 0xFFFFFFFFu; blk[i].huf_log = (u8)fl; blk[i].huf_flat = 1;
-        atomicMax(&st->max_huf_log, fl); atomicAdd(&st->n_flat, 1u);
+        atomicMax(&st->max_huf_log, fl); atomicAdd(&st->n_flat, 1u); atomicAdd(&st->n_huf_built, 1u);
         return;
     }
     u8 w[256]; u32 nw = 0, used = 0;
@@ -311,27 +341,23 @@ __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 
     atomicMax(&st->max_huf_log, log);
     const bool flat = huf_is_flat(w, nw, log);
     blk[i].huf_flat = flat; if (flat) atomicAdd(&st->n_flat, 1u);
+    atomicAdd(&st->n_huf_built, 1u);
 }
 
 // The same for streams of a few blocks (ids, names, lengths, the last block of a mask stream): one block per workgroup, the tree
 // description, the weights, the builder's workspace and the table in LDS, so that the lone working lane waits for LDS, not for
 // scratch memory (0.3 - 1 ms per launch otherwise, on the critical path of every small stream).
-__global__ __launch_bounds__(64) void k_build_huf_lds(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first)
+struct HufLdsWS { HufBuildWS ws; __attribute__((aligned(16))) u8 in[192], w[256]; __attribute__((aligned(16))) u16 tab[HUFC_BYTES / 2 > 256 ? HUFC_BYTES / 2 : 256]; u32 log, off; };
+__device__ void build_huf_one_lds(const u8 *src, ZBlock *blk, u32 i, u8 *pool, u32 pool_cap, ZStat *st, HufLdsWS &S)
 {
-    __shared__ HufBuildWS ws;
-    __shared__ __attribute__((aligned(16))) u8 in[192], w[256];
-    __shared__ __attribute__((aligned(16))) u16 tab[HUFC_BYTES / 2 > 256 ? HUFC_BYTES / 2 : 256];
-    __shared__ u32 s_log, s_off;
-    u32 i = first + blockIdx.x;
-    if (i >= nblk) return;
-    if (blk[i].btype != BT_COMP || blk[i].lit_type != LIT_HUF || blk[i].err) return;
     const u8 *c = src + blk[i].src_off + blk[i].lit_off;
     const u32 len = blk[i].lit_csize, n_in = len < 192 ? len : 192;          // a tree description takes at most 129 bytes
-    for (u32 k = threadIdx.x; k < n_in; k += 64) in[k] = c[k];
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < n_in; k += 64) S.in[k] = c[k];
     __syncthreads();
     if (threadIdx.x == 0) {
         u32 nw = 0, used = 0;
-        u32 log = huf_read_weights_ws(in, n_in, w, &nw, &used, ws);
+        u32 log = huf_read_weights_ws(S.in, n_in, S.w, &nw, &used, S.ws);
         u32 off = 0;
         if (!log) { set_err(st, ZE_CORRUPT); blk[i].err = ZE_CORRUPT; }
         else {
@@ -339,17 +365,46 @@ __global__ __launch_bounds__(64) void k_build_huf_lds(const u8 *src, ZBlock *blk
             off = atomicAdd(&st->huf_pool_used, bytes);
             if (off + bytes > pool_cap) { set_err(st, ZE_POOL); log = 0; }
             else {
-                huf_build_any_ws(tab, w, nw, log, ws); blk[i].huf_tab = off; blk[i].huf_log = (u8)log; atomicMax(&st->max_huf_log, log);
-                const bool flat = huf_is_flat(w, nw, log);
+                huf_build_any_ws(S.tab, S.w, nw, log, S.ws); blk[i].huf_tab = off; blk[i].huf_log = (u8)log; atomicMax(&st->max_huf_log, log);
+                const bool flat = huf_is_flat(S.w, nw, log);
                 blk[i].huf_flat = flat; if (flat) atomicAdd(&st->n_flat, 1u);
+                atomicAdd(&st->n_huf_built, 1u);
             }
         }
-        s_log = log; s_off = off;
+        S.log = log; S.off = off;
     }
     __syncthreads();
-    if (!s_log) return;
-    const u32 bytes = huf_tab_bytes(s_log);
-    for (u32 k = threadIdx.x; k < bytes / 16; k += 64) ((uint4 *)(pool + s_off))[k] = ((const uint4 *)tab)[k];
+    if (!S.log) return;
+    const u32 bytes = huf_tab_bytes(S.log);
+    for (u32 k = threadIdx.x; k < bytes / 16; k += 64) ((uint4 *)(pool + S.off))[k] = ((const uint4 *)S.tab)[k];
+}
+__global__ __launch_bounds__(64) void k_build_huf_lds(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const i32 *own_huf)
+{
+    __shared__ HufLdsWS S;
+    u32 i = first + blockIdx.x;
+    if (i >= nblk) return;
+    if (blk[i].btype != BT_COMP || blk[i].lit_type != LIT_HUF || blk[i].err || own_huf[i] != (i32)i) return;
+    build_huf_one_lds(src, blk, i, pool, pool_cap, st, S);
+}
+// A frame of many blocks and few distinct trees: every workgroup looks through its share of the blocks, 64 at a time, and builds the
+// few owners it finds.  Does nothing when the frame has more than HUF_FEW distinct trees (k_build_huf has it then).
+__global__ __launch_bounds__(64) void k_build_huf_few(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, const u64 *range4, const i32 *own_huf)
+{
+    __shared__ HufLdsWS S;
+    if (st->n_huf_distinct > HUF_FEW) return;
+    u32 lo = 0, hi = nblk;
+    if (range4) { lo = (u32)range4[4]; hi = (u32)range4[1]; if (hi > nblk) hi = nblk; }
+    const u32 per = (hi - lo + gridDim.x - 1) / gridDim.x;
+    const u32 a = lo + blockIdx.x * per, b = a + per < hi ? a + per : hi;
+    for (u32 base = a; base < b; base += 64) {
+        const u32 i = base + threadIdx.x;
+        const bool own = i < b && own_huf[i] == (i32)i && blk[i].btype == BT_COMP && blk[i].lit_type == LIT_HUF && !blk[i].err;
+        u64 m = __ballot(own);
+        while (m) {
+            const u32 k = (u32)__ffsll((long long)m) - 1; m &= m - 1;
+            build_huf_one_lds(src, blk, base + k, pool, pool_cap, st, S);
+        }
+    }
 }
 
 __global__ void k_build_fse(const u8 *src, ZBlock *blk, u32 nblk, FseE *pool, u32 pool_cap, ZStat *st)
@@ -1252,6 +1307,52 @@ __global__ __launch_bounds__(64) void k_small_frame(const u8 *src, u32 len, u8 *
     if (threadIdx.x == 0) { res[0] = r.err; res[1] = r.out; res[2] = r.pos; }
 }
 
+// Several small frames (the ids, names and lengths of an archive with few records) in one launch, one workgroup each.
+struct SmallJobs { const u8 *src[4]; u8 *dst[4]; u32 len[4], cap[4]; };
+__global__ __launch_bounds__(64) void k_small_frames(SmallJobs J, const FseE *predef, u32 *res)
+{
+    __shared__ __attribute__((aligned(16))) u8 s_src[SMALL_SRC + 16], s_out[SMALL_OUT + 16], s_lit[SMALL_OUT + 16];
+    __shared__ u32 s_ll[SMALL_SEQ], s_ml[SMALL_SEQ], s_of[SMALL_SEQ];
+    __shared__ HufBuildWS ws;
+    __shared__ __attribute__((aligned(16))) u16 huf[HUFC_BYTES / 2 > 256 ? HUFC_BYTES / 2 : 256];
+    __shared__ FseE fse[512 + 256 + 512];
+    __shared__ FseE s_predef[160];
+    __shared__ u8 w[256];
+    __shared__ i16 norm[64];
+    __shared__ u16 nx[64];
+    __shared__ SmallRes r;
+    const u32 j = blockIdx.x;
+    const u8 *src = J.src[j]; const u32 len = J.len[j], cap = J.cap[j]; u8 *dst = J.dst[j];
+    for (u32 k = threadIdx.x; k < len; k += 64) s_src[k] = src[k];
+    for (u32 k = threadIdx.x; k < 16; k += 64) s_src[len + k] = 0;
+    for (u32 k = threadIdx.x; k < 160; k += 64) s_predef[k] = predef[k];
+    __syncthreads();
+    if (threadIdx.x == 0) small_frame_decode(s_src, len, s_out, cap < SMALL_OUT ? cap : SMALL_OUT, s_lit, s_ll, s_ml, s_of, s_predef, ws, huf, fse, w, norm, nx, &r);
+    __syncthreads();
+    if (r.err == 0) for (u32 k = threadIdx.x; k < r.out; k += 64) dst[k] = s_out[k];
+    if (threadIdx.x == 0) { res[4 * j] = r.err; res[4 * j + 1] = r.out; res[4 * j + 2] = r.pos; }
+}
+// n <= 4 frames without their magic number (as stored in .naf sections); ok[k] = frame k decoded, consumed all of its source and
+// produced exactly cap[k] bytes.  Frames that are not small, or fail in any way, are left to the caller's ordinary path (which
+// also words the error).
+int zstd_small_batch(naf_gpu_ctx *c, int n, const u8 *const *src, const size_t *len, u8 *const *dst, const size_t *cap, bool *ok)
+{
+    const char *sm = getenv("NAF_GPU_SMALL");
+    SmallJobs J; memset(&J, 0, sizeof J); int m = 0, map[4];
+    for (int k = 0; k < n && k < 4; k++) {
+        ok[k] = false;
+        if (sm && sm[0] == '0') continue;
+        if (len[k] == 0 || len[k] > SMALL_SRC || cap[k] > SMALL_OUT) continue;
+        J.src[m] = src[k]; J.len[m] = (u32)len[k]; J.dst[m] = dst[k]; J.cap[m] = (u32)cap[k]; map[m++] = k;
+    }
+    if (!m) return 0;
+    u32 *d_res = arena_new<u32>(c, 16); if (!d_res) return NAF_GPU_ENOMEM;
+    LAUNCH(c, "zstd_small_frame", k_small_frames, m, 64, 0, J, (const FseE *)c->d_predef, d_res);
+    u32 res[16]; int rc = ctx_readback(c, res, d_res, 16 * (size_t)m); if (rc) return rc;
+    for (int q = 0; q < m; q++) ok[map[q]] = res[4 * q] == 0 && res[4 * q + 1] == J.cap[q] && res[4 * q + 2] == J.len[q];
+    return 0;
+}
+
 // ---- host orchestration ------------------------------------------------------------------------------------------
 int zstd_init_tables(naf_gpu_ctx *c)
 {
@@ -1366,6 +1467,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     i32 *own_huf = own, *own_ll = own + nblk, *own_of = own + 2 * (size_t)nblk, *own_ml = own + 3 * (size_t)nblk;
     u32 g = cdiv(nblk, 64);
     LAUNCH(c, "zstd_parse_blocks", k_parse_blocks, g, 64, 0, d_src, blk, nblk, own_huf, own_ll, own_of, own_ml, seq_cnt, sizes, st);
+    LAUNCH(c, "zstd_huf_dedup", k_huf_dedup, g, 64, 0, d_src, (const ZBlock *)blk, nblk, own_huf, st);
     if ((rc = scan_inclusive_max_i32(c, own_huf, nblk))) return rc;
     u64 *d_total_out = (u64 *)((u8 *)st + offsetof(ZStat, total_out));
     const char *fl_env = getenv("NAF_GPU_FLAT");                                 // "0": every block through the serial kernel (cross-check)
@@ -1389,7 +1491,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         pool_cap = want_pool > 0xFFFFF000ull ? 0xFFFFF000u : (u32)want_pool;
         huf_pool = (u8 *)arena_alloc(c, pool_cap);
         if (!huf_pool) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)r4, always_table);
+        LAUNCH(c, "zstd_build_huf", k_build_huf_few, 1024, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, (const u64 *)r4, (const i32 *)own_huf);
+        LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)r4, always_table, (const i32 *)own_huf, 1u);
         ZSplit *sp = c->zsplit;
         if (sp && !rg && sp->parts >= 2) {
             ends = extra + 8;
@@ -1416,6 +1519,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, huf_pool_used), 0, 4, c->stream));
         HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, max_huf_log), 0, 4, c->stream));
         HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, n_flat), 0, 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, n_huf_built), 0, 4, c->stream));
     }
     u64 *d_total_seq = (u64 *)((u8 *)st + offsetof(ZStat, total_seq));
     FseE *fse_pool = nullptr; u32 *o_ll = nullptr, *o_ml = nullptr, *o_of = nullptr;
@@ -1490,8 +1594,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             pool_cap = (hb_n < n_huf_def ? hb_n : n_huf_def) * (u32)HUFC_BYTES + 4096u;   // largest table form (log > 8: compact)
             huf_pool = (u8 *)arena_alloc(c, pool_cap);
             if (!huf_pool) return NAF_GPU_ENOMEM;
-            if (hb_n && hb_n <= 512) LAUNCH(c, "zstd_build_huf", k_build_huf_lds, hb_n, 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first);
-            else if (hb_n) LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(hb_n, 64), 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first, (const u64 *)nullptr, (always_table || fuse) ? 1u : 0u);
+            if (hb_n && hb_n <= 512) LAUNCH(c, "zstd_build_huf", k_build_huf_lds, hb_n, 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first, (const i32 *)own_huf);
+            else if (hb_n) LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(hb_n, 64), 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first, (const u64 *)nullptr, (always_table || fuse) ? 1u : 0u, (const i32 *)own_huf, 0u);
             rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
             if (hs.err) return zerr(c, hs.err, "Huffman tables");
         }
@@ -1507,14 +1611,14 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             const u32 huf_lds = slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512 + (getenv("NAF_GPU_PADLDS") ? atoi(getenv("NAF_GPU_PADLDS")) : 0);
             // blocks whose tree is flat go to k_flat_literals; the serial kernel is not launched when that is all of them
             const u32 flat_on = (hs.n_flat && !always_table) ? 1u : 0u;
-            const bool serial_needed = !flat_on || hs.n_flat < (hb_n < n_huf_def ? hb_n : n_huf_def);
+            const bool serial_needed = !flat_on || hs.n_flat < hs.n_huf_built;
             ZSplit *sp = c->zsplit;
             const char *smin = getenv("NAF_GPU_SPLIT_MIN");                      // blocks per part below which a split is not worth its launches (tests lower it)
             const u32 split_min = smin ? (u32)atoi(smin) : 4096u;
             if (sp && !rg && n_seq_blk == 0 && b_first == 0 && b_count == nblk && b_count >= split_min * (u32)sp->parts && b_count >= 16u * HUF_BLOCKS_PER_WG * (u32)sp->parts) {
                 // literal-only frame of a whole-text call: block ranges in order, an event behind each (see ZSplit); the raw / RLE
                 // blocks first, so that a finished part is complete
-                LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
+                if (hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
                 copy_fill_done = true;
                 // output offsets of the part ends: they came with the counters when the frame took the speculative route
                 if (ends) for (int k = 0; k + 1 < sp->parts; k++) sp->out_end[k] = hends[k];
@@ -1544,7 +1648,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             }
         }
     }
-    if (b_count && !fuse && !copy_fill_done) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
+    if (b_count && !fuse && !copy_fill_done && hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
     if (n_seq_blk) {
         const char *el = getenv("NAF_GPU_EXEC_LDS");                      // "0": always the HBM executor (cross-check)
         if (max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
