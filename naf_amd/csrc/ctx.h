@@ -17,6 +17,12 @@ struct KTime { const char *name; hipEvent_t a, b; };
 // stream beside the decode of the next part.  out_end[k] = bytes of the decoded stream complete once ev[k] has fired.
 #define ZSPLIT_MAX 8
 struct ZSplit { int parts; hipEvent_t ev[ZSPLIT_MAX]; u64 out_end[ZSPLIT_MAX]; int done; void *status; };   // status: the decoder's device-side ZStat, read by the caller AFTER it has queued the emit (no host wait between decode and emit)
+// A literal-only frame whose blocks all use ONE flat 4-bit tree (packed random ACGT) is not decoded at all: symbol k of a stream
+// sits at a known bit position, so the emit kernel takes its bases straight from the compressed stream (k_emit_tile_flat) and the
+// packed intermediate -- 5 GB written and read back per 10 GB of text -- never exists.  The decoder fills this when asked to and
+// the frame qualifies: per (block, stream) slot the packed offset of its first symbol and the bit address of the end of its data.
+struct FlatStream { u64 q0, A; };
+struct ZFlat { const u8 *src; const FlatStream *si; u64 nslots; const u8 *sym; void *status; bool ready; };
 struct naf_gpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -43,6 +49,7 @@ struct naf_gpu_ctx {
     hipEvent_t fork_ev = nullptr;
     struct ZSplit *zsplit = nullptr;        // set by unnaf for the sequence stream of a whole-text call: Huffman literals in parts (below)
     hipEvent_t split_ev[ZSPLIT_MAX + 2] = {};
+    struct ZFlat *zflat = nullptr;          // set by unnaf when its emit can read a flat frame in place (above)
     void *io_pool = nullptr;                // io.hip: pinned staging lanes of naf_gpu_read_file / naf_gpu_write_file
     void *shard_state = nullptr;            // enc.hip: what naf_gpu_ennaf_shard_begin leaves for naf_gpu_ennaf_shard_finish
 };

@@ -143,9 +143,23 @@ __device__ __forceinline__ u32 lut_char(const EmitP &P, u32 code)
     return (P.lut[code >> 2] >> (8 * (code & 3))) & 0xFF;
 }
 
+// Packed byte q of a flat frame that is read in place (ctx.h: ZFlat): its stream by bisection, then the 4-bit code at its known
+// bit position.  The slow way -- for the few chunks the tile kernel does not take (headers, record ends, stream boundaries).
+__device__ u32 flat_packed_byte(const EmitP &P, u64 q)
+{
+    const FlatStream *si = (const FlatStream *)P.fsi;
+    u64 lo = 0, hi = P.fslots;                                   // last slot with q0 <= q
+    while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (si[mid].q0 <= q) lo = mid; else hi = mid; }
+    if (q >= si[lo + 1].q0) return 0;                            // past the end of the data
+    const u64 B = si[lo].A - 4 * (q - si[lo].q0 + 1), a = B >> 3; const u32 sh = (u32)B & 7;
+    u32 v = P.fsrc[a]; if (sh > 4) v |= (u32)P.fsrc[a + 1] << 8;
+    return P.fsym[(v >> sh) & 15];
+}
+
 template <bool FOURBIT>
 __device__ __forceinline__ u32 base_char(const EmitP &P, u64 g)
 {
+    if (FOURBIT && P.fsrc) { u32 b = flat_packed_byte(P, g >> 1); return lut_char(P, (g & 1) ? (b >> 4) : (b & 15)); }
     if (FOURBIT) { u32 b = P.seq[g >> 1]; return lut_char(P, (g & 1) ? (b >> 4) : (b & 15)); }
     u32 ch = P.seq[g];
     if (P.upper && ch >= 'a' && ch <= 'z') ch -= 32;                               // output.c:363-366 toupper
@@ -221,6 +235,13 @@ __device__ __forceinline__ void bases16(const EmitP &P, u64 g, u64 &lo, u64 &hi)
             auto up = [](u64 v) { u64 r = 0; for (int i = 0; i < 8; i++) { u32 c = (v >> (8 * i)) & 0xFF; if (c >= 'a' && c <= 'z') c -= 32; r |= (u64)c << (8 * i); } return r; };
             lo = up(lo); hi = up(hi);
         }
+        return;
+    }
+    if (P.fsrc) {
+        u64 nib = 0;
+        for (u32 k = 0; k < 8; k++) nib |= (u64)flat_packed_byte(P, (g >> 1) + k) << (8 * k);
+        if (g & 1) nib = (nib >> 4) | ((u64)flat_packed_byte(P, (g >> 1) + 8) << 60);
+        expand16(P.lut, nib, lo, hi);
         return;
     }
     const u8 *a = P.seq + (g >> 1);
@@ -654,7 +675,7 @@ __global__ __launch_bounds__(256) void k_emit_fastq_records(EmitP P, u8 *out)
 #define EMIT_TOG_LDS 256u
 struct TileIdx { u64 gline, k, khi; u32 col, fast; };   // gline: base index of the first base of the tile's first line (wrap) / first byte
 #define TI_HDR 0xFFFFFFFFu
-__global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr)            // ntiles + 1 entries each
+__global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr, u32 *tsig)            // ntiles + 1 entries each; tsig: flat frames only
 {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t > ntiles) return;
@@ -680,6 +701,13 @@ __global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr)         
     }
     x.k = P.masking ? upper_bound_u64(P.toggles, 0, P.n_toggles, g) : 0;
     ti[t] = x;
+    if (tsig) {                                                   // slot of the stream that holds the tile's first packed byte
+        const FlatStream *si = (const FlatStream *)P.fsi;
+        const u64 q = g >> 1;
+        u64 lo = 0, hi = P.fslots;
+        while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (si[mid].q0 <= q) lo = mid; else hi = mid; }
+        tsig[t] = (u32)lo;
+    }
 }
 // fast = the whole tile lies in the body of one record (and the next tile starts in the same record, so that the
 // record's final newline is not in it); every other tile goes on the list of the segment-composing kernel
@@ -725,6 +753,66 @@ __global__ __launch_bounds__(256) void k_emit_tile(EmitP P, const TileIdx *ti, u
         u32 sh = (u32)(addr & 7) * 8 + (u32)(g0 & 1) * 4;
         expand16(P.lut, sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0, lo, hi);
     } else bases16<false>(P, g0, lo, hi);
+    if (use_tog) mask16_from(s_tog, ntog, a.k, g0, lo, hi);
+    else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
+    if (nl_b < 16) splice_newline(lo, hi, (int)nl_b);
+    uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
+    *(uint4 *)(out + (u64)blockIdx.x * 4096 + lane16) = v;
+}
+
+// The same tile kernel for a flat frame read in place: a lane's 16 bases are 8 (9 when its first base is an odd one) consecutive
+// 4-bit codes of one Huffman stream, i.e. 32 (36) bits at a bit position that follows from the stream table -- one unaligned 8-byte
+// load from the COMPRESSED stream, a funnel shift, four look-ups in a 256-entry table "two codes -> four characters" (built per
+// workgroup from the frame's code -> packed byte list and the nucleotide table).  Consecutive lanes read consecutive (descending)
+// words of the stream; a tile touches one stream, or two where one ends.  Chunks that straddle a stream's end, or sit in its
+// last 16 symbols, take the symbols one by one.
+__global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *ti, const u32 *tsig, u8 *out)
+{
+    const TileIdx a = ti[blockIdx.x];
+    if (!a.fast) return;
+    __shared__ u64 s_tog[EMIT_TOG_LDS];
+    __shared__ u32 s_pair[256];
+    {
+        const u32 t = threadIdx.x, p1 = P.fsym[t >> 4], p2 = P.fsym[t & 15];
+        s_pair[t] = lut_char(P, p1 & 15) | (lut_char(P, p1 >> 4) << 8) | (lut_char(P, p2 & 15) << 16) | (lut_char(P, p2 >> 4) << 24);
+    }
+    const u32 ntog = (u32)(a.khi - a.k < EMIT_TOG_LDS ? a.khi - a.k : EMIT_TOG_LDS);
+    const bool use_tog = P.masking && a.k < a.khi && a.khi - a.k <= EMIT_TOG_LDS;
+    if (use_tog) for (u32 i = threadIdx.x; i < ntog; i += 256) s_tog[i] = P.toggles[a.k + i];
+    __syncthreads();
+    const u32 lane16 = threadIdx.x * 16;
+    u64 g0; u32 nl_b = 64;
+    if (P.mode == EM_FASTA && P.L != 0) {
+        const u32 Lp1 = (u32)P.L + 1;
+        u32 c = a.col + lane16, dl;
+        if (Lp1 < 32768) dl = __umulhi(c, P.Ldiv_magic); else dl = c >= Lp1 ? 1u : 0u;
+        u32 col = c - dl * Lp1;
+        g0 = a.gline + (u64)dl * (u32)P.L + col;
+        u32 d = (u32)P.L - col;
+        nl_b = d < 16 ? d : 64;
+    } else g0 = a.gline + lane16;
+    const FlatStream *si = (const FlatStream *)P.fsi;
+    const u64 q = g0 >> 1; const u32 odd = (u32)g0 & 1, need = 8 + odd;
+    u64 sg = tsig[blockIdx.x];
+    FlatStream s0 = si[sg], s1 = si[sg + 1];
+    while (q >= s1.q0 && sg + 1 < P.fslots) { sg++; s0 = s1; s1 = si[sg + 1]; }
+    const u64 k = q - s0.q0, n = s1.q0 - s0.q0, top = s0.A - 4 * k;          // top: the bit above symbol k
+    u64 lo, hi;
+    if (q >= s0.q0 && k + need <= n && top >= 64) {
+        const u64 lb = top - 64, ad = lb >> 3; const u32 sh = (u32)lb & 7;
+        u64 V = ld64(P.fsrc + ad);
+        if (sh) V = (V >> sh) | ((u64)P.fsrc[ad + 8] << (64 - sh));
+        const u32 h = (u32)(V >> 32);
+        const u32 c0 = s_pair[h >> 24], c1 = s_pair[(h >> 16) & 0xFF], c2 = s_pair[(h >> 8) & 0xFF], c3 = s_pair[h & 0xFF];
+        lo = (u64)c0 | ((u64)c1 << 32); hi = (u64)c2 | ((u64)c3 << 32);
+        if (odd) { const u32 c4 = s_pair[(u32)V >> 24]; lo = (lo >> 8) | (hi << 56); hi = (hi >> 8) | ((u64)(c4 & 0xFF) << 56); }
+    } else {
+        lo = hi = 0;
+        for (u32 i = 0; i < 16; i++) {
+            const u64 g = g0 + i; const u32 ch = g < P.T ? base_char<true>(P, g) : 0u;
+            if (i < 8) lo |= (u64)ch << (8 * i); else hi |= (u64)ch << (8 * (i - 8));
+        }
+    }
     if (use_tog) mask16_from(s_tog, ntog, a.k, g0, lo, hi);
     else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
     if (nl_b < 16) splice_newline(lo, hi, (int)nl_b);
@@ -1184,6 +1272,13 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     const bool par = whole && !size_only && pl.P.mode != -1 && c->side && !fuse_on && !(ser && ser[0] == '1');
     bool payload_done = false;
     ZSplit split; split.parts = 0; split.done = 0; split.status = nullptr;
+    // A whole 4-bit text with long records goes through the tile kernels: if its sequence stream turns out to be a flat frame
+    // (ctx.h: ZFlat) those read it in place and nothing is decoded.  NAF_GPU_FLAT_FUSE=0: always decode first (cross-check).
+    ZFlat zflat; memset(&zflat, 0, sizeof zflat);
+    const char *ff = getenv("NAF_GPU_FLAT_FUSE"), *ek0 = getenv("NAF_GPU_EMIT");
+    const bool try_flat = whole && !size_only && pl.fourbit && !fuse_on && !pl.P.force_slow && !(ff && ff[0] == '0') && !(ek0 && ek0[0]) &&
+                          (pl.P.mode == EM_FASTA || pl.P.mode == EM_SEQ || pl.P.mode == EM_SEQUENCES) && pl.P.N && h.orig_size[S_SEQ] / pl.P.N >= 16384 &&
+                          (pl.P.mode != EM_FASTA || pl.P.L == 0 || pl.P.L >= 16);
     if (par) {
         arena_reset(c->side);
         HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
@@ -1205,8 +1300,9 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             for (int k = 0; k < nparts; k++) split.ev[k] = c->split_ev[k];
             c->zsplit = &split;
         }
+        if (try_flat) { zflat.ready = false; c->zflat = &zflat; }
         rc = payload_seq();
-        c->zsplit = nullptr;
+        c->zsplit = nullptr; c->zflat = nullptr;
         if (!rc && pl.need_qual && !qpar) rc = payload_qual(c);
         th.join();
         if (qpar) thq.join();
@@ -1251,7 +1347,13 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         }
         if (rc != -100) return rc;
     }
-    if (!payload_done && (rc = payload())) return rc;
+    if (!payload_done) {
+        if (try_flat) { zflat.ready = false; c->zflat = &zflat; }
+        rc = payload();
+        c->zflat = nullptr;
+        if (rc) return rc;
+    }
+    if (zflat.ready) { pl.P.fsrc = zflat.src; pl.P.fsi = zflat.si; pl.P.fslots = zflat.nslots; pl.P.fsym = zflat.sym; }
     if (pl.P.mode == -1) {                                                             // --4bit: the stream itself
         HIP_TRY(c, hipMemcpyAsync(d_out, seq + out_begin, out_end - out_begin, hipMemcpyDeviceToDevice, c->stream));
         return 0;
@@ -1297,7 +1399,9 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         // decode of the next part; this stream takes the tiles behind the last part, the boundary tiles, and waits for the other.
         naf_gpu_ctx *ic = split.done ? c->side2 : c;                                     // context the tile index is built on
         if (split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, ic->stream));
-        LAUNCH(ic, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr);
+        u32 *tsig = nullptr;
+        if (zflat.ready) { tsig = arena_new<u32>(c, ntiles + 2); if (!tsig) return NAF_GPU_ENOMEM; }
+        LAUNCH(ic, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr, tsig);
         LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt);
         u32 nrest = 0;                                                                   // tiles holding a header or a record boundary
         if ((rc = ctx_readback(ic, &nrest, cnt, 4))) { if (ic != c) memcpy(c->err, ic->err, sizeof c->err); return rc; }
@@ -1318,7 +1422,8 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX + 1], ic->stream));
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX], 0));         // the index
         }
-        if (t_done < ntiles) {
+        if (zflat.ready) LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat, (u32)ntiles, 256, 0, pl.P, (const TileIdx *)ti, (const u32 *)tsig, d_out);
+        else if (t_done < ntiles) {
             if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit_tile<true>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
             else LAUNCH(c, "unnaf_emit", k_emit_tile<false>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
         }
@@ -1329,6 +1434,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     }
     HIP_TRY(c, hipGetLastError());
     if ((rc = zstd_split_status(c, &split))) return rc;           // a split decode left its status for after the emit was queued
+    if (zflat.ready) { ZSplit fs; fs.parts = 0; fs.done = 1; fs.status = zflat.status; if ((rc = zstd_split_status(c, &fs))) return rc; }
     return 0;
 }
 

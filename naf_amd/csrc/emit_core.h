@@ -23,6 +23,8 @@ struct EmitP {
     int mode, has_ids, has_names, masking, upper;
     u8 sep, hdr_char;
     int force_slow;
+    // a flat frame read in place (ctx.h: ZFlat): stream table, source, code -> packed byte; fsrc == nullptr otherwise
+    const u8 *fsrc; const void *fsi; u64 fslots; const u8 *fsym;
 };
 
 

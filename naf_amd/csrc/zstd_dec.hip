@@ -966,6 +966,40 @@ __global__ __launch_bounds__(256) void k_flat_literals(const u8 *src, const ZBlo
     }
 }
 
+// Stream table of a flat frame for the fused emit (ctx.h: ZFlat): four slots per block, the unused ones of a single-stream block
+// empty (they start where the block ends).  Checks what k_flat_literals checks: jump table, end marker, size = n x 4 bits.
+__global__ void k_flat_streams(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf, const u8 *pool, FlatStream *si, u8 *sym, ZStat *st, const u64 *total_out)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) si[4ull * nblk].q0 = *total_out, si[4ull * nblk].A = 0;
+    if (t < 16) {                                                 // code -> symbol, from the one table of the frame
+        u32 b0 = 0; while (b0 < nblk && own_huf[b0] < 0) b0++;
+        if (b0 < nblk) sym[t] = (u8)(((const u16 *)(pool + blk[own_huf[b0]].huf_tab))[t] >> 8);
+    }
+    if (t >= 4ull * nblk) return;
+    const u32 bi = (u32)(t >> 2), s = (u32)t & 3;
+    const ZBlock &b = blk[bi];
+    const u8 *c = src + b.src_off + b.huf_streams_off;
+    const u32 regen = b.lit_regen;
+    FlatStream f; f.q0 = b.out_off + regen; f.A = 0;
+    u32 sz = 0, n = 0; const u8 *sp = c;
+    if (b.nstreams == 1) { if (s == 0) { sz = b.huf_streams_size; n = regen; f.q0 = b.out_off; } }
+    else {
+        const u32 s1 = ld16(c), s2 = ld16(c + 2), s3 = ld16(c + 4), tot = b.huf_streams_size - 6, per = (regen + 3) / 4;
+        if (s1 + s2 + s3 >= tot || !s1 || !s2 || !s3 || per * 3 > regen) { set_err(st, ZE_CORRUPT); si[t] = f; return; }
+        const u32 off = s == 0 ? 0 : (s == 1 ? s1 : (s == 2 ? s1 + s2 : s1 + s2 + s3));
+        sz = s == 0 ? s1 : (s == 1 ? s2 : (s == 2 ? s3 : tot - s1 - s2 - s3));
+        sp = c + 6 + off; n = s < 3 ? per : regen - 3 * per; f.q0 = b.out_off + (u64)s * per;
+    }
+    if (n) {
+        const u32 last = sz ? sp[sz - 1] : 0;
+        const u64 E = last ? 8ull * (sz - 1) + (u32)hibit32(last) : 0;
+        if (!last || E != 4ull * n) set_err(st, ZE_CORRUPT);
+        f.A = 8ull * (u64)(sp - src) + E;
+    }
+    si[t] = f;
+}
+
 // ---- raw / RLE blocks and raw / RLE literal sections: one workgroup per block ------------------------------
 __global__ __launch_bounds__(256) void k_copy_fill(const u8 *src, const ZBlock *blk, u32 nblk, u8 *dst, u8 *lit_scratch, u32 b_first)
 {
@@ -1520,6 +1554,18 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, max_huf_log), 0, 4, c->stream));
         HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, n_flat), 0, 4, c->stream));
         HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, n_huf_built), 0, 4, c->stream));
+    }
+    if (c->zflat && !rg && lit_only_spec && nblk > 0 && hs.n_huf_distinct == 1 && hs.n_huf_built == 1 && hs.n_flat == 1 && hs.max_huf_log == 4 && hs.n_plain_huf == nblk && !always_table) {
+        // every block a plain Huffman block of the same flat 4-bit tree: the caller's emit kernel reads the streams in place
+        ZFlat *zf = c->zflat;
+        FlatStream *si = arena_new<FlatStream>(c, 4 * (size_t)nblk + 1); u8 *d_sym = (u8 *)arena_alloc(c, 16);
+        if (!si || !d_sym) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr);
+        LAUNCH(c, "zstd_flat_streams", k_flat_streams, cdiv(4ull * nblk, 256), 256, 0, d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, si, d_sym, st, (const u64 *)d_total_out);
+        zf->src = d_src; zf->si = si; zf->nslots = 4ull * nblk; zf->sym = d_sym; zf->status = st; zf->ready = true;
+        *out_len = hs.total_out;
+        if (fh.has_fcs && fh.content_size != hs.total_out) return zerr(c, ZE_CORRUPT, "content size mismatch");
+        return 0;
     }
     u64 *d_total_seq = (u64 *)((u8 *)st + offsetof(ZStat, total_seq));
     FseE *fse_pool = nullptr; u32 *o_ll = nullptr, *o_ml = nullptr, *o_of = nullptr;

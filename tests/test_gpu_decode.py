@@ -344,3 +344,55 @@ def test_flat_tree_literals_every_width(gpu, oracle, monkeypatch):
     except NafGpuError:
         pass
     assert made == 49
+
+
+def test_flat_frame_read_in_place_by_the_emit_kernel(gpu, oracle, monkeypatch):
+    """A sequence stream whose blocks all carry one flat 4-bit tree (uniform ACGT) is not decoded: the tile kernel takes the bases
+    from the compressed stream (k_emit_tile_flat).  Against the decode-then-emit path and the oracle: line widths that put every
+    chunk alignment and odd / even first bases into play, several records (header and record-end tiles go the slow way), soft-mask
+    toggles, --seq / --sequences / --line-length, RNA."""
+    import torch
+    from naf_amd import synth
+    rng = np.random.default_rng(101)
+    def uniform_fasta(n_rec, per_rec, width, lower=False, rna=False):
+        out = bytearray()
+        alpha = np.frombuffer(b"ACGU" if rna else b"ACGT", dtype=np.uint8)
+        for r in range(n_rec):
+            seq = alpha[rng.integers(0, 4, per_rec + r)].copy()
+            if lower:                                             # case runs: mask toggles, same 4-bit codes
+                pos = 0
+                while pos < len(seq):
+                    run = int(rng.integers(1, 9000))
+                    if rng.random() < 0.5:
+                        seq[pos:pos + run] |= 0x20
+                    pos += run
+            out += b">rec%d uniform %d\n" % (r, r) + synth.wrap_lines(seq, width)
+        return bytes(out)
+    cases = [(3, 1_500_001, 80, False, False), (2, 2_000_003, 61, True, False), (1, 3_000_000, 0, False, False), (4, 900_017, 16, False, True),
+             (2, 1_200_000, 4096, True, False), (1, 2_500_007, 97, False, False)]
+    for n_rec, per, width, lower, rna in cases:
+        text = uniform_fasta(n_rec, per, width, lower, rna)
+        d_naf, rep = gpu.ennaf(gpu.to_device(text), seq_type=1 if rna else 0)
+        naf = host(d_naf)
+        for mode, ll in ((0, -1), (2, -1), (3, -1), (0, 50), (0, 0)):
+            want = oracle.unnaf(naf, mode, True, ll)
+            monkeypatch.setenv("NAF_GPU_FLAT_FUSE", "1")
+            monkeypatch.setenv("NAF_GPU_DEBUG", "1")
+            got = host(gpu.unnaf(d_naf, mode, line_length=ll))
+            assert got == want, (n_rec, per, width, lower, rna, mode, ll)
+            monkeypatch.setenv("NAF_GPU_FLAT_FUSE", "0")
+            assert host(gpu.unnaf(d_naf, mode, line_length=ll)) == want
+        monkeypatch.setenv("NAF_GPU_FLAT_FUSE", "1")
+        assert host(gpu.unnaf(d_naf, 0, use_mask=False)) == oracle.unnaf(naf, 0, False)
+    # a corrupt stream size is still reported
+    from naf_amd.capi import NafGpuError
+    text = uniform_fasta(1, 2_000_000, 80)
+    d_naf, _ = gpu.ennaf(gpu.to_device(text))
+    bad = bytearray(host(d_naf)); h = oracle.parse_naf(bytes(bad))
+    off = h.payload_off[4] + h.comp[4] // 2
+    bad[off] ^= 0x55; bad[off + 1] ^= 0xAA
+    try:
+        got = host(gpu.unnaf(gpu.to_device(bytes(bad)), 0))
+        assert len(got) == len(text)                               # a flipped payload byte inside a stream only changes bases
+    except NafGpuError:
+        pass
