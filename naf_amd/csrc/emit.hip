@@ -797,21 +797,32 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     FlatStream s0 = si[sg], s1 = si[sg + 1];
     while (q >= s1.q0 && sg + 1 < P.fslots) { sg++; s0 = s1; s1 = si[sg + 1]; }
     const u64 k = q - s0.q0, n = s1.q0 - s0.q0, top = s0.A - 4 * k;          // top: the bit above symbol k
-    u64 lo, hi;
+    u64 lo, hi, V;                                                // V: the codes of symbols k, k+1, ... from the top nibble down
     if (q >= s0.q0 && k + need <= n && top >= 64) {
         const u64 lb = top - 64, ad = lb >> 3; const u32 sh = (u32)lb & 7;
-        u64 V = ld64(P.fsrc + ad);
+        V = ld64(P.fsrc + ad);
         if (sh) V = (V >> sh) | ((u64)P.fsrc[ad + 8] << (64 - sh));
+    } else {
+        // the chunk runs over the end of a stream, or sits in a stream's last 16 symbols: code by code, walking on from this slot
+        V = 0;
+        FlatStream c0 = s0, c1 = s1; u64 cs = sg;
+        for (u32 i = 0; i < need; i++) {
+            const u64 qi = q + i;
+            while (qi >= c1.q0 && cs + 1 < P.fslots) { cs++; c0 = c1; c1 = si[cs + 1]; }
+            u32 code = 0;
+            if (qi >= c0.q0 && qi < c1.q0) {
+                const u64 B = c0.A - 4 * (qi - c0.q0 + 1), ab = B >> 3; const u32 sb = (u32)B & 7;
+                u32 w = P.fsrc[ab]; if (sb > 4) w |= (u32)P.fsrc[ab + 1] << 8;
+                code = (w >> sb) & 15;
+            }
+            V |= (u64)code << (60 - 4 * i);
+        }
+    }
+    {
         const u32 h = (u32)(V >> 32);
         const u32 c0 = s_pair[h >> 24], c1 = s_pair[(h >> 16) & 0xFF], c2 = s_pair[(h >> 8) & 0xFF], c3 = s_pair[h & 0xFF];
         lo = (u64)c0 | ((u64)c1 << 32); hi = (u64)c2 | ((u64)c3 << 32);
         if (odd) { const u32 c4 = s_pair[(u32)V >> 24]; lo = (lo >> 8) | (hi << 56); hi = (hi >> 8) | ((u64)(c4 & 0xFF) << 56); }
-    } else {
-        lo = hi = 0;
-        for (u32 i = 0; i < 16; i++) {
-            const u64 g = g0 + i; const u32 ch = g < P.T ? base_char<true>(P, g) : 0u;
-            if (i < 8) lo |= (u64)ch << (8 * i); else hi |= (u64)ch << (8 * (i - 8));
-        }
     }
     if (use_tog) mask16_from(s_tog, ntog, a.k, g0, lo, hi);
     else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
