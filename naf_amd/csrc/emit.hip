@@ -798,24 +798,38 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     while (q >= s1.q0 && sg + 1 < P.fslots) { sg++; s0 = s1; s1 = si[sg + 1]; }
     const u64 k = q - s0.q0, n = s1.q0 - s0.q0, top = s0.A - 4 * k;          // top: the bit above symbol k
     u64 lo, hi, V;                                                // V: the codes of symbols k, k+1, ... from the top nibble down
-    if (q >= s0.q0 && k + need <= n && top >= 64) {
-        const u64 lb = top - 64, ad = lb >> 3; const u32 sh = (u32)lb & 7;
-        V = ld64(P.fsrc + ad);
-        if (sh) V = (V >> sh) | ((u64)P.fsrc[ad + 8] << (64 - sh));
-    } else {
-        // the chunk runs over the end of a stream, or sits in a stream's last 16 symbols: code by code, walking on from this slot
-        V = 0;
-        FlatStream c0 = s0, c1 = s1; u64 cs = sg;
-        for (u32 i = 0; i < need; i++) {
-            const u64 qi = q + i;
-            while (qi >= c1.q0 && cs + 1 < P.fslots) { cs++; c0 = c1; c1 = si[cs + 1]; }
-            u32 code = 0;
-            if (qi >= c0.q0 && qi < c1.q0) {
-                const u64 B = c0.A - 4 * (qi - c0.q0 + 1), ab = B >> 3; const u32 sb = (u32)B & 7;
-                u32 w = P.fsrc[ab]; if (sb > 4) w |= (u32)P.fsrc[ab + 1] << 8;
-                code = (w >> sb) & 15;
+    // the 64 bits below `top` (a bit address inside the source buffer: what lies below the stream's first symbol is never used)
+    auto window = [&](u64 t) -> u64 {
+        const u64 lb = t - 64, ad = lb >> 3; const u32 sh = (u32)lb & 7;
+        u64 v = ld64(P.fsrc + ad);
+        if (sh) v = (v >> sh) | ((u64)P.fsrc[ad + 8] << (64 - sh));
+        return v;
+    };
+    if (q >= s0.q0 && k + need <= n && top >= 64) V = window(top);
+    else {
+        // the chunk runs over the end of its stream: the rest comes from the top of the next stream that has symbols
+        const u32 have = q >= s0.q0 && k < n ? (u32)(n - k) : 0u;          // symbols of this chunk still in s0 (< need)
+        V = have && top >= 64 ? window(top) & ~(~0ull >> (4 * have)) : 0;
+        FlatStream c0 = s1, c1; u64 cs = sg + 1;
+        bool found = false;
+        for (u32 hop = 0; hop < 8 && cs < P.fslots; hop++) {
+            c1 = si[cs + 1];
+            if (c1.q0 > c0.q0) { found = true; break; }
+            cs++; c0 = c1;
+        }
+        if (found && c1.q0 - c0.q0 >= need - have && c0.A >= 64) V |= window(c0.A) >> (4 * have);
+        else if (found) {                                          // a stream of a handful of symbols (the end of a frame): code by code
+            for (u32 i = have; i < need; i++) {
+                const u64 qi = q + i;
+                while (qi >= c1.q0 && cs + 1 < P.fslots) { cs++; c0 = c1; c1 = si[cs + 1]; }
+                u32 code = 0;
+                if (qi >= c0.q0 && qi < c1.q0) {
+                    const u64 B = c0.A - 4 * (qi - c0.q0 + 1), ab = B >> 3; const u32 sb = (u32)B & 7;
+                    u32 w = P.fsrc[ab]; if (sb > 4) w |= (u32)P.fsrc[ab + 1] << 8;
+                    code = (w >> sb) & 15;
+                }
+                V |= (u64)code << (60 - 4 * i);
             }
-            V |= (u64)code << (60 - 4 * i);
         }
     }
     {
