@@ -675,7 +675,8 @@ __global__ __launch_bounds__(256) void k_emit_fastq_records(EmitP P, u8 *out)
 #define EMIT_TOG_LDS 256u
 struct TileIdx { u64 gline, k, khi; u32 col, fast; };   // gline: base index of the first base of the tile's first line (wrap) / first byte
 #define TI_HDR 0xFFFFFFFFu
-__global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr, u32 *tsig)            // ntiles + 1 entries each; tsig: flat frames only
+struct TileFlat { u64 q0, A, q1, sg; };                  // flat frames: the stream slot that holds the tile's first packed byte (its start, end-of-data bit address, the next slot's start, its index)
+__global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr, TileFlat *tsig)            // ntiles + 1 entries each; tsig: flat frames only
 {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t > ntiles) return;
@@ -706,7 +707,8 @@ __global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr, u32 *tsi
         const u64 q = g >> 1;
         u64 lo = 0, hi = P.fslots;
         while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (si[mid].q0 <= q) lo = mid; else hi = mid; }
-        tsig[t] = (u32)lo;
+        TileFlat f; f.q0 = si[lo].q0; f.A = si[lo].A; f.q1 = si[lo + 1].q0; f.sg = lo;
+        tsig[t] = f;
     }
 }
 // fast = the whole tile lies in the body of one record (and the next tile starts in the same record, so that the
@@ -766,16 +768,18 @@ __global__ __launch_bounds__(256) void k_emit_tile(EmitP P, const TileIdx *ti, u
 // workgroup from the frame's code -> packed byte list and the nucleotide table).  Consecutive lanes read consecutive (descending)
 // words of the stream; a tile touches one stream, or two where one ends.  Chunks that straddle a stream's end, or sit in its
 // last 16 symbols, take the symbols one by one.
-__global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *ti, const u32 *tsig, u8 *out)
+__global__ void k_flat_pair(EmitP P, u32 *pair)
+{
+    const u32 t = threadIdx.x, p1 = P.fsym[t >> 4], p2 = P.fsym[t & 15];
+    pair[t] = lut_char(P, p1 & 15) | (lut_char(P, p1 >> 4) << 8) | (lut_char(P, p2 & 15) << 16) | (lut_char(P, p2 >> 4) << 24);
+}
+__global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *ti, const TileFlat *tsig, u8 *out)
 {
     const TileIdx a = ti[blockIdx.x];
     if (!a.fast) return;
     __shared__ u64 s_tog[EMIT_TOG_LDS];
     __shared__ u32 s_pair[256];
-    {
-        const u32 t = threadIdx.x, p1 = P.fsym[t >> 4], p2 = P.fsym[t & 15];
-        s_pair[t] = lut_char(P, p1 & 15) | (lut_char(P, p1 >> 4) << 8) | (lut_char(P, p2 & 15) << 16) | (lut_char(P, p2 >> 4) << 24);
-    }
+    s_pair[threadIdx.x] = P.fpair[threadIdx.x];
     const u32 ntog = (u32)(a.khi - a.k < EMIT_TOG_LDS ? a.khi - a.k : EMIT_TOG_LDS);
     const bool use_tog = P.masking && a.k < a.khi && a.khi - a.k <= EMIT_TOG_LDS;
     if (use_tog) for (u32 i = threadIdx.x; i < ntog; i += 256) s_tog[i] = P.toggles[a.k + i];
@@ -793,9 +797,13 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     } else g0 = a.gline + lane16;
     const FlatStream *si = (const FlatStream *)P.fsi;
     const u64 q = g0 >> 1; const u32 odd = (u32)g0 & 1, need = 8 + odd;
-    u64 sg = tsig[blockIdx.x];
-    FlatStream s0 = si[sg], s1 = si[sg + 1];
-    while (q >= s1.q0 && sg + 1 < P.fslots) { sg++; s0 = s1; s1 = si[sg + 1]; }
+    const TileFlat tf = tsig[blockIdx.x];
+    u64 sg = tf.sg;
+    FlatStream s0, s1; s0.q0 = tf.q0; s0.A = tf.A; s1.q0 = tf.q1; s1.A = 0;
+    if (q >= s1.q0) {                                             // the tile runs into the next stream(s): this lane's own slot
+        s1 = si[sg + 1];
+        while (q >= s1.q0 && sg + 1 < P.fslots) { sg++; s0 = s1; s1 = si[sg + 1]; }
+    }
     const u64 k = q - s0.q0, n = s1.q0 - s0.q0, top = s0.A - 4 * k;          // top: the bit above symbol k
     u64 lo, hi, V;                                                // V: the codes of symbols k, k+1, ... from the top nibble down
     // the 64 bits below `top` (a bit address inside the source buffer: what lies below the stream's first symbol is never used)
@@ -810,7 +818,7 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         // the chunk runs over the end of its stream: the rest comes from the top of the next stream that has symbols
         const u32 have = q >= s0.q0 && k < n ? (u32)(n - k) : 0u;          // symbols of this chunk still in s0 (< need)
         V = have && top >= 64 ? window(top) & ~(~0ull >> (4 * have)) : 0;
-        FlatStream c0 = s1, c1; u64 cs = sg + 1;
+        FlatStream c0 = si[sg + 1], c1; u64 cs = sg + 1;
         bool found = false;
         for (u32 hop = 0; hop < 8 && cs < P.fslots; hop++) {
             c1 = si[cs + 1];
@@ -1424,8 +1432,12 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         // decode of the next part; this stream takes the tiles behind the last part, the boundary tiles, and waits for the other.
         naf_gpu_ctx *ic = split.done ? c->side2 : c;                                     // context the tile index is built on
         if (split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, ic->stream));
-        u32 *tsig = nullptr;
-        if (zflat.ready) { tsig = arena_new<u32>(c, ntiles + 2); if (!tsig) return NAF_GPU_ENOMEM; }
+        TileFlat *tsig = nullptr;
+        if (zflat.ready) {
+            tsig = arena_new<TileFlat>(c, ntiles + 2); u32 *fpair = arena_new<u32>(c, 256); if (!tsig || !fpair) return NAF_GPU_ENOMEM;
+            LAUNCH(ic, "unnaf_flat_pair", k_flat_pair, 1, 256, 0, pl.P, fpair);
+            pl.P.fpair = fpair;
+        }
         LAUNCH(ic, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr, tsig);
         LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt);
         u32 nrest = 0;                                                                   // tiles holding a header or a record boundary
@@ -1447,7 +1459,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX + 1], ic->stream));
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX], 0));         // the index
         }
-        if (zflat.ready) LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat, (u32)ntiles, 256, 0, pl.P, (const TileIdx *)ti, (const u32 *)tsig, d_out);
+        if (zflat.ready) LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat, (u32)ntiles, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out);
         else if (t_done < ntiles) {
             if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit_tile<true>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
             else LAUNCH(c, "unnaf_emit", k_emit_tile<false>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
