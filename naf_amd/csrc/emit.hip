@@ -768,22 +768,20 @@ __global__ __launch_bounds__(256) void k_emit_tile(EmitP P, const TileIdx *ti, u
 // workgroup from the frame's code -> packed byte list and the nucleotide table).  Consecutive lanes read consecutive (descending)
 // words of the stream; a tile touches one stream, or two where one ends.  Chunks that straddle a stream's end, or sit in its
 // last 16 symbols, take the symbols one by one.
-__global__ void k_flat_pair(EmitP P, u32 *pair)
+__global__ void k_flat_pair(EmitP P, u32 *pair)               // code -> packed byte, sixteen bytes as four dwords
 {
-    const u32 t = threadIdx.x, p1 = P.fsym[t >> 4], p2 = P.fsym[t & 15];
-    pair[t] = lut_char(P, p1 & 15) | (lut_char(P, p1 >> 4) << 8) | (lut_char(P, p2 & 15) << 16) | (lut_char(P, p2 >> 4) << 24);
+    const u32 t = threadIdx.x;
+    if (t < 4) pair[t] = (u32)P.fsym[4 * t] | ((u32)P.fsym[4 * t + 1] << 8) | ((u32)P.fsym[4 * t + 2] << 16) | ((u32)P.fsym[4 * t + 3] << 24);
 }
 __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *ti, const TileFlat *tsig, u8 *out)
 {
     const TileIdx a = ti[blockIdx.x];
     if (!a.fast) return;
     __shared__ u64 s_tog[EMIT_TOG_LDS];
-    __shared__ u32 s_pair[256];
-    s_pair[threadIdx.x] = P.fpair[threadIdx.x];
+    const u32 sl[4] = { P.fpair[0], P.fpair[1], P.fpair[2], P.fpair[3] };     // uniform: scalar loads
     const u32 ntog = (u32)(a.khi - a.k < EMIT_TOG_LDS ? a.khi - a.k : EMIT_TOG_LDS);
     const bool use_tog = P.masking && a.k < a.khi && a.khi - a.k <= EMIT_TOG_LDS;
-    if (use_tog) for (u32 i = threadIdx.x; i < ntog; i += 256) s_tog[i] = P.toggles[a.k + i];
-    __syncthreads();
+    if (use_tog) { for (u32 i = threadIdx.x; i < ntog; i += 256) s_tog[i] = P.toggles[a.k + i]; __syncthreads(); }
     const u32 lane16 = threadIdx.x * 16;
     u64 g0; u32 nl_b = 64;
     if (P.mode == EM_FASTA && P.L != 0) {
@@ -807,11 +805,12 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     const u64 k = q - s0.q0, n = s1.q0 - s0.q0, top = s0.A - 4 * k;          // top: the bit above symbol k
     u64 lo, hi, V;                                                // V: the codes of symbols k, k+1, ... from the top nibble down
     // the 64 bits below `top` (a bit address inside the source buffer: what lies below the stream's first symbol is never used)
-    auto window = [&](u64 t) -> u64 {
-        const u64 lb = t - 64, ad = lb >> 3; const u32 sh = (u32)lb & 7;
-        u64 v = ld64(P.fsrc + ad);
-        if (sh) v = (v >> sh) | ((u64)P.fsrc[ad + 8] << (64 - sh));
-        return v;
+    auto window = [&](u64 t) -> u64 {                             // one 16-byte load from the 8-aligned address below, then a funnel shift
+        const u64 lb = t - 64, addr = (u64)P.fsrc + (lb >> 3);
+        const uint4 w = *(const uint4 *)(addr & ~7ull);
+        const u64 w0 = (u64)w.x | ((u64)w.y << 32), w1 = (u64)w.z | ((u64)w.w << 32);
+        const u32 sh = (u32)(addr & 7) * 8 + ((u32)lb & 7);
+        return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
     };
     if (q >= s0.q0 && k + need <= n && top >= 64) V = window(top);
     else {
@@ -841,10 +840,12 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         }
     }
     {
+        // codes -> packed bytes (the frame's sixteen symbols through v_perm_b32), in stream order: the top nibble of V is symbol k
         const u32 h = (u32)(V >> 32);
-        const u32 c0 = s_pair[h >> 24], c1 = s_pair[(h >> 16) & 0xFF], c2 = s_pair[(h >> 8) & 0xFF], c3 = s_pair[h & 0xFF];
-        lo = (u64)c0 | ((u64)c1 << 32); hi = (u64)c2 | ((u64)c3 << 32);
-        if (odd) { const u32 c4 = s_pair[(u32)V >> 24]; lo = (lo >> 8) | (hi << 56); hi = (hi >> 8) | ((u64)(c4 & 0xFF) << 56); }
+        const u32 E = expand_codes4(sl, h & 0x0F0F0F0Fu), O = expand_codes4(sl, (h >> 4) & 0x0F0F0F0Fu);   // symbols k+7,k+5,k+3,k+1 / k+6,k+4,k+2,k
+        u64 nib = (u64)__builtin_amdgcn_perm(O, E, 0x02060307u) | ((u64)__builtin_amdgcn_perm(O, E, 0x00040105u) << 32);
+        if (odd) { const u32 b8 = expand_codes4(sl, ((u32)V >> 28) & 15u) & 0xFFu; nib = (nib >> 4) | ((u64)b8 << 60); }
+        expand16(P.lut, nib, lo, hi);
     }
     if (use_tog) mask16_from(s_tog, ntog, a.k, g0, lo, hi);
     else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);

@@ -24,7 +24,7 @@ struct EmitP {
     u8 sep, hdr_char;
     int force_slow;
     // a flat frame read in place (ctx.h: ZFlat): stream table, source, code -> packed byte; fsrc == nullptr otherwise
-    const u8 *fsrc; const void *fsi; u64 fslots; const u8 *fsym; const u32 *fpair;    // fpair: two codes -> four characters (256 entries)
+    const u8 *fsrc; const void *fsi; u64 fslots; const u8 *fsym; const u32 *fpair;    // fpair: the 16-entry table code -> packed byte as four dwords (for v_perm_b32)
 };
 
 
