@@ -773,85 +773,110 @@ __global__ void k_flat_pair(EmitP P, u32 *pair)               // code -> packed 
     const u32 t = threadIdx.x;
     if (t < 4) pair[t] = (u32)P.fsym[4 * t] | ((u32)P.fsym[4 * t + 1] << 8) | ((u32)P.fsym[4 * t + 2] << 16) | ((u32)P.fsym[4 * t + 3] << 24);
 }
-__global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *ti, const TileFlat *tsig, u8 *out)
+#define FLAT_TPW 4                                               // tiles per workgroup: a tile alone is three dependent loads and a store, i.e. pure latency
+__global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *ti, const TileFlat *tsig, u8 *out, u64 ntiles)
 {
-    const TileIdx a = ti[blockIdx.x];
-    if (!a.fast) return;
     __shared__ u64 s_tog[EMIT_TOG_LDS];
     const u32 sl[4] = { P.fpair[0], P.fpair[1], P.fpair[2], P.fpair[3] };     // uniform: scalar loads
-    const u32 ntog = (u32)(a.khi - a.k < EMIT_TOG_LDS ? a.khi - a.k : EMIT_TOG_LDS);
-    const bool use_tog = P.masking && a.k < a.khi && a.khi - a.k <= EMIT_TOG_LDS;
-    if (use_tog) { for (u32 i = threadIdx.x; i < ntog; i += 256) s_tog[i] = P.toggles[a.k + i]; __syncthreads(); }
-    const u32 lane16 = threadIdx.x * 16;
-    u64 g0; u32 nl_b = 64;
-    if (P.mode == EM_FASTA && P.L != 0) {
-        const u32 Lp1 = (u32)P.L + 1;
-        u32 c = a.col + lane16, dl;
-        if (Lp1 < 32768) dl = __umulhi(c, P.Ldiv_magic); else dl = c >= Lp1 ? 1u : 0u;
-        u32 col = c - dl * Lp1;
-        g0 = a.gline + (u64)dl * (u32)P.L + col;
-        u32 d = (u32)P.L - col;
-        nl_b = d < 16 ? d : 64;
-    } else g0 = a.gline + lane16;
     const FlatStream *si = (const FlatStream *)P.fsi;
-    const u64 q = g0 >> 1; const u32 odd = (u32)g0 & 1, need = 8 + odd;
-    const TileFlat tf = tsig[blockIdx.x];
-    u64 sg = tf.sg;
-    FlatStream s0, s1; s0.q0 = tf.q0; s0.A = tf.A; s1.q0 = tf.q1; s1.A = 0;
-    if (q >= s1.q0) {                                             // the tile runs into the next stream(s): this lane's own slot
-        s1 = si[sg + 1];
-        while (q >= s1.q0 && sg + 1 < P.fslots) { sg++; s0 = s1; s1 = si[sg + 1]; }
-    }
-    const u64 k = q - s0.q0, n = s1.q0 - s0.q0, top = s0.A - 4 * k;          // top: the bit above symbol k
-    u64 lo, hi, V;                                                // V: the codes of symbols k, k+1, ... from the top nibble down
-    // the 64 bits below `top` (a bit address inside the source buffer: what lies below the stream's first symbol is never used)
-    auto window = [&](u64 t) -> u64 {                             // one 16-byte load from the 8-aligned address below, then a funnel shift
+    const u32 lane16 = threadIdx.x * 16;
+    u64 g0s[FLAT_TPW], Vs[FLAT_TPW]; u32 nls[FLAT_TPW]; bool live[FLAT_TPW];
+    // the 64 bits below `top` (a bit address inside the source buffer: what lies below the stream's first symbol is never used):
+    // one 16-byte load from the 8-aligned address below, then a funnel shift
+    auto window = [&](u64 t) -> u64 {
         const u64 lb = t - 64, addr = (u64)P.fsrc + (lb >> 3);
         const uint4 w = *(const uint4 *)(addr & ~7ull);
         const u64 w0 = (u64)w.x | ((u64)w.y << 32), w1 = (u64)w.z | ((u64)w.w << 32);
         const u32 sh = (u32)(addr & 7) * 8 + ((u32)lb & 7);
         return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
     };
-    if (q >= s0.q0 && k + need <= n && top >= 64) V = window(top);
-    else {
-        // the chunk runs over the end of its stream: the rest comes from the top of the next stream that has symbols
-        const u32 have = q >= s0.q0 && k < n ? (u32)(n - k) : 0u;          // symbols of this chunk still in s0 (< need)
-        V = have && top >= 64 ? window(top) & ~(~0ull >> (4 * have)) : 0;
-        FlatStream c0 = si[sg + 1], c1; u64 cs = sg + 1;
-        bool found = false;
-        for (u32 hop = 0; hop < 8 && cs < P.fslots; hop++) {
-            c1 = si[cs + 1];
-            if (c1.q0 > c0.q0) { found = true; break; }
-            cs++; c0 = c1;
+    // ---- phase 1: where every chunk's codes are, and the loads
+#pragma unroll
+    for (u32 j = 0; j < FLAT_TPW; j++) {
+        const u64 t = (u64)blockIdx.x * FLAT_TPW + j;
+        live[j] = false; g0s[j] = 0; Vs[j] = 0; nls[j] = 64;
+        if (t >= ntiles) continue;
+        const TileIdx a = ti[t];
+        if (!a.fast) continue;
+        live[j] = true;
+        u64 g0; u32 nl_b = 64;
+        if (P.mode == EM_FASTA && P.L != 0) {
+            const u32 Lp1 = (u32)P.L + 1;
+            u32 c = a.col + lane16, dl;
+            if (Lp1 < 32768) dl = __umulhi(c, P.Ldiv_magic); else dl = c >= Lp1 ? 1u : 0u;
+            u32 col = c - dl * Lp1;
+            g0 = a.gline + (u64)dl * (u32)P.L + col;
+            u32 d = (u32)P.L - col;
+            nl_b = d < 16 ? d : 64;
+        } else g0 = a.gline + lane16;
+        g0s[j] = g0; nls[j] = nl_b;
+        const u64 q = g0 >> 1; const u32 need = 8 + ((u32)g0 & 1);
+        const TileFlat tf = tsig[t];
+        u64 sg = tf.sg;
+        FlatStream s0, s1; s0.q0 = tf.q0; s0.A = tf.A; s1.q0 = tf.q1; s1.A = 0;
+        if (q >= s1.q0) {                                             // the tile runs into the next stream(s): this lane's own slot
+            s1 = si[sg + 1];
+            while (q >= s1.q0 && sg + 1 < P.fslots) { sg++; s0 = s1; s1 = si[sg + 1]; }
         }
-        if (found && c1.q0 - c0.q0 >= need - have && c0.A >= 64) V |= window(c0.A) >> (4 * have);
-        else if (found) {                                          // a stream of a handful of symbols (the end of a frame): code by code
-            for (u32 i = have; i < need; i++) {
-                const u64 qi = q + i;
-                while (qi >= c1.q0 && cs + 1 < P.fslots) { cs++; c0 = c1; c1 = si[cs + 1]; }
-                u32 code = 0;
-                if (qi >= c0.q0 && qi < c1.q0) {
-                    const u64 B = c0.A - 4 * (qi - c0.q0 + 1), ab = B >> 3; const u32 sb = (u32)B & 7;
-                    u32 w = P.fsrc[ab]; if (sb > 4) w |= (u32)P.fsrc[ab + 1] << 8;
-                    code = (w >> sb) & 15;
+        const u64 k = q - s0.q0, n = s1.q0 - s0.q0, top = s0.A - 4 * k;          // top: the bit above symbol k
+        u64 V;                                                        // the codes of symbols k, k+1, ... from the top nibble down
+        if (q >= s0.q0 && k + need <= n && top >= 64) V = window(top);
+        else {
+            // the chunk runs over the end of its stream: the rest comes from the top of the next stream that has symbols
+            const u32 have = q >= s0.q0 && k < n ? (u32)(n - k) : 0u;          // symbols of this chunk still in s0 (< need)
+            V = have && top >= 64 ? window(top) & ~(~0ull >> (4 * have)) : 0;
+            FlatStream c0 = si[sg + 1], c1; u64 cs = sg + 1;
+            bool found = false;
+            for (u32 hop = 0; hop < 8 && cs < P.fslots; hop++) {
+                c1 = si[cs + 1];
+                if (c1.q0 > c0.q0) { found = true; break; }
+                cs++; c0 = c1;
+            }
+            if (found && c1.q0 - c0.q0 >= need - have && c0.A >= 64) V |= window(c0.A) >> (4 * have);
+            else if (found) {                                          // a stream of a handful of symbols (the end of a frame): code by code
+                for (u32 i = have; i < need; i++) {
+                    const u64 qi = q + i;
+                    while (qi >= c1.q0 && cs + 1 < P.fslots) { cs++; c0 = c1; c1 = si[cs + 1]; }
+                    u32 code = 0;
+                    if (qi >= c0.q0 && qi < c1.q0) {
+                        const u64 B = c0.A - 4 * (qi - c0.q0 + 1), ab = B >> 3; const u32 sb = (u32)B & 7;
+                        u32 w = P.fsrc[ab]; if (sb > 4) w |= (u32)P.fsrc[ab + 1] << 8;
+                        code = (w >> sb) & 15;
+                    }
+                    V |= (u64)code << (60 - 4 * i);
                 }
-                V |= (u64)code << (60 - 4 * i);
             }
         }
+        Vs[j] = V;
     }
-    {
-        // codes -> packed bytes (the frame's sixteen symbols through v_perm_b32), in stream order: the top nibble of V is symbol k
-        const u32 h = (u32)(V >> 32);
-        const u32 E = expand_codes4(sl, h & 0x0F0F0F0Fu), O = expand_codes4(sl, (h >> 4) & 0x0F0F0F0Fu);   // symbols k+7,k+5,k+3,k+1 / k+6,k+4,k+2,k
-        u64 nib = (u64)__builtin_amdgcn_perm(O, E, 0x02060307u) | ((u64)__builtin_amdgcn_perm(O, E, 0x00040105u) << 32);
-        if (odd) { const u32 b8 = expand_codes4(sl, ((u32)V >> 28) & 15u) & 0xFFu; nib = (nib >> 4) | ((u64)b8 << 60); }
-        expand16(P.lut, nib, lo, hi);
+    // ---- phase 2: codes -> characters, mask, line ends, store
+#pragma unroll
+    for (u32 j = 0; j < FLAT_TPW; j++) {
+        const u64 t = (u64)blockIdx.x * FLAT_TPW + j;
+        if (!live[j]) continue;                                       // (uniform: a tile is live for all its lanes or for none)
+        const TileIdx a = ti[t];
+        const u64 g0 = g0s[j], V = Vs[j];
+        u64 lo, hi;
+        {
+            // codes -> packed bytes (the frame's sixteen symbols through v_perm_b32), in stream order: the top nibble of V is symbol k
+            const u32 h = (u32)(V >> 32);
+            const u32 E = expand_codes4(sl, h & 0x0F0F0F0Fu), O = expand_codes4(sl, (h >> 4) & 0x0F0F0F0Fu);   // symbols k+7,k+5,k+3,k+1 / k+6,k+4,k+2,k
+            u64 nib = (u64)__builtin_amdgcn_perm(O, E, 0x02060307u) | ((u64)__builtin_amdgcn_perm(O, E, 0x00040105u) << 32);
+            if (g0 & 1) { const u32 b8 = expand_codes4(sl, ((u32)V >> 28) & 15u) & 0xFFu; nib = (nib >> 4) | ((u64)b8 << 60); }
+            expand16(P.lut, nib, lo, hi);
+        }
+        const u32 ntog = (u32)(a.khi - a.k < EMIT_TOG_LDS ? a.khi - a.k : EMIT_TOG_LDS);
+        const bool use_tog = P.masking && a.k < a.khi && a.khi - a.k <= EMIT_TOG_LDS;
+        if (use_tog) {
+            __syncthreads();
+            for (u32 i = threadIdx.x; i < ntog; i += 256) s_tog[i] = P.toggles[a.k + i];
+            __syncthreads();
+            mask16_from(s_tog, ntog, a.k, g0, lo, hi);
+        } else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
+        if (nls[j] < 16) splice_newline(lo, hi, (int)nls[j]);
+        uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
+        *(uint4 *)(out + t * 4096 + lane16) = v;
     }
-    if (use_tog) mask16_from(s_tog, ntog, a.k, g0, lo, hi);
-    else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
-    if (nl_b < 16) splice_newline(lo, hi, (int)nl_b);
-    uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
-    *(uint4 *)(out + (u64)blockIdx.x * 4096 + lane16) = v;
 }
 
 template <bool FOURBIT>
@@ -1460,7 +1485,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX + 1], ic->stream));
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX], 0));         // the index
         }
-        if (zflat.ready) LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat, (u32)ntiles, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out);
+        if (zflat.ready) LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat, cdiv(ntiles, FLAT_TPW), 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles);
         else if (t_done < ntiles) {
             if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit_tile<true>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
             else LAUNCH(c, "unnaf_emit", k_emit_tile<false>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
