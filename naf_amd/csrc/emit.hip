@@ -675,7 +675,9 @@ __global__ __launch_bounds__(256) void k_emit_fastq_records(EmitP P, u8 *out)
 #define EMIT_TOG_LDS 256u
 struct TileIdx { u64 gline, k, khi; u32 col, fast; };   // gline: base index of the first base of the tile's first line (wrap) / first byte
 #define TI_HDR 0xFFFFFFFFu
-struct TileFlat { u64 q0, A, q1, sg; };                  // flat frames: the stream slot that holds the tile's first packed byte (its start, end-of-data bit address, the next slot's start, its index)
+// flat frames: the stream that holds the tile's first packed byte qf (first symbol q0, end-of-data bit address A) and the next
+// stream that has symbols (q1, A1; it ends at q2) -- a tile that would reach a third stream goes to the slow list
+struct TileFlat { u64 q0, A, q1, A1, q2, qf; };
 __global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr, TileFlat *tsig)            // ntiles + 1 entries each; tsig: flat frames only
 {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -707,18 +709,25 @@ __global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr, TileFlat
         const u64 q = g >> 1;
         u64 lo = 0, hi = P.fslots;
         while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (si[mid].q0 <= q) lo = mid; else hi = mid; }
-        TileFlat f; f.q0 = si[lo].q0; f.A = si[lo].A; f.q1 = si[lo + 1].q0; f.sg = lo;
+        TileFlat f; f.q0 = si[lo].q0; f.A = si[lo].A; f.qf = q;
+        u64 cs = lo + 1;                                          // next slot that has symbols (single-stream blocks leave three empty)
+        while (cs < P.fslots && si[cs + 1].q0 == si[cs].q0) cs++;
+        f.q1 = si[cs].q0; f.A1 = cs < P.fslots ? si[cs].A : 0;
+        u64 ce = cs < P.fslots ? cs + 1 : cs;
+        while (ce < P.fslots && si[ce + 1].q0 == si[ce].q0) ce++;
+        f.q2 = si[ce].q0;
         tsig[t] = f;
     }
 }
 // fast = the whole tile lies in the body of one record (and the next tile starts in the same record, so that the
 // record's final newline is not in it); every other tile goes on the list of the segment-composing kernel
-__global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr, u32 *list, u32 *count)
+__global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr, u32 *list, u32 *count, const TileFlat *tsig)
 {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     const bool wrap = P.mode == EM_FASTA && P.L != 0;
     bool fast = ti[t].col != TI_HDR && tr[t] == tr[t + 1] && P.out_begin + (t + 1) * 4096 <= P.out_end && !P.force_slow && (!wrap || P.L >= 16);
+    if (fast && tsig) fast = tsig[t].qf + 2048 + 16 < tsig[t].q2 || tsig[t].q2 == tsig[t].q1;   // at most two streams under the tile (q2 == q1: the data end there)
     ti[t].khi = ti[t + 1].k;
     ti[t].fast = fast ? 1u : 0u;
     if (!fast) list[atomicAdd(count, 1u)] = (u32)t;
@@ -778,9 +787,8 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
 {
     __shared__ u64 s_tog[EMIT_TOG_LDS];
     const u32 sl[4] = { P.fpair[0], P.fpair[1], P.fpair[2], P.fpair[3] };     // uniform: scalar loads
-    const FlatStream *si = (const FlatStream *)P.fsi;
     const u32 lane16 = threadIdx.x * 16;
-    u64 g0s[FLAT_TPW], Vs[FLAT_TPW]; u32 nls[FLAT_TPW]; bool live[FLAT_TPW];
+    u64 g0s[FLAT_TPW], V0s[FLAT_TPW], V1s[FLAT_TPW]; u32 nls[FLAT_TPW], haves[FLAT_TPW]; bool live[FLAT_TPW];
     // the 64 bits below `top` (a bit address inside the source buffer: what lies below the stream's first symbol is never used):
     // one 16-byte load from the 8-aligned address below, then a funnel shift
     auto window = [&](u64 t) -> u64 {
@@ -790,11 +798,11 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         const u32 sh = (u32)(addr & 7) * 8 + ((u32)lb & 7);
         return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
     };
-    // ---- phase 1: where every chunk's codes are, and the loads
+    // ---- phase 1: where every chunk's codes are (arithmetic on the tile's two streams, no dependent load), and the loads
 #pragma unroll
     for (u32 j = 0; j < FLAT_TPW; j++) {
         const u64 t = (u64)blockIdx.x * FLAT_TPW + j;
-        live[j] = false; g0s[j] = 0; Vs[j] = 0; nls[j] = 64;
+        live[j] = false; g0s[j] = 0; V0s[j] = 0; V1s[j] = 0; nls[j] = 64; haves[j] = 16;
         if (t >= ntiles) continue;
         const TileIdx a = ti[t];
         if (!a.fast) continue;
@@ -812,42 +820,15 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         g0s[j] = g0; nls[j] = nl_b;
         const u64 q = g0 >> 1; const u32 need = 8 + ((u32)g0 & 1);
         const TileFlat tf = tsig[t];
-        u64 sg = tf.sg;
-        FlatStream s0, s1; s0.q0 = tf.q0; s0.A = tf.A; s1.q0 = tf.q1; s1.A = 0;
-        if (q >= s1.q0) {                                             // the tile runs into the next stream(s): this lane's own slot
-            s1 = si[sg + 1];
-            while (q >= s1.q0 && sg + 1 < P.fslots) { sg++; s0 = s1; s1 = si[sg + 1]; }
+        const bool second = q >= tf.q1;                               // the chunk starts in the tile's second stream
+        const u64 sq0 = second ? tf.q1 : tf.q0, sA = second ? tf.A1 : tf.A, sq1 = second ? tf.q2 : tf.q1;
+        const u64 k = q - sq0, n = sq1 - sq0;
+        u64 top = sA - 4 * k; if (top < 64) top = 64;                 // top: the bit above symbol k
+        V0s[j] = window(top);
+        if (k + need > n) {                                           // it runs over the end of that stream: the rest is the top of the next one
+            haves[j] = (u32)(n - k);
+            V1s[j] = window(tf.A1 < 64 ? 64 : tf.A1);
         }
-        const u64 k = q - s0.q0, n = s1.q0 - s0.q0, top = s0.A - 4 * k;          // top: the bit above symbol k
-        u64 V;                                                        // the codes of symbols k, k+1, ... from the top nibble down
-        if (q >= s0.q0 && k + need <= n && top >= 64) V = window(top);
-        else {
-            // the chunk runs over the end of its stream: the rest comes from the top of the next stream that has symbols
-            const u32 have = q >= s0.q0 && k < n ? (u32)(n - k) : 0u;          // symbols of this chunk still in s0 (< need)
-            V = have && top >= 64 ? window(top) & ~(~0ull >> (4 * have)) : 0;
-            FlatStream c0 = si[sg + 1], c1; u64 cs = sg + 1;
-            bool found = false;
-            for (u32 hop = 0; hop < 8 && cs < P.fslots; hop++) {
-                c1 = si[cs + 1];
-                if (c1.q0 > c0.q0) { found = true; break; }
-                cs++; c0 = c1;
-            }
-            if (found && c1.q0 - c0.q0 >= need - have && c0.A >= 64) V |= window(c0.A) >> (4 * have);
-            else if (found) {                                          // a stream of a handful of symbols (the end of a frame): code by code
-                for (u32 i = have; i < need; i++) {
-                    const u64 qi = q + i;
-                    while (qi >= c1.q0 && cs + 1 < P.fslots) { cs++; c0 = c1; c1 = si[cs + 1]; }
-                    u32 code = 0;
-                    if (qi >= c0.q0 && qi < c1.q0) {
-                        const u64 B = c0.A - 4 * (qi - c0.q0 + 1), ab = B >> 3; const u32 sb = (u32)B & 7;
-                        u32 w = P.fsrc[ab]; if (sb > 4) w |= (u32)P.fsrc[ab + 1] << 8;
-                        code = (w >> sb) & 15;
-                    }
-                    V |= (u64)code << (60 - 4 * i);
-                }
-            }
-        }
-        Vs[j] = V;
     }
     // ---- phase 2: codes -> characters, mask, line ends, store
 #pragma unroll
@@ -855,7 +836,9 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         const u64 t = (u64)blockIdx.x * FLAT_TPW + j;
         if (!live[j]) continue;                                       // (uniform: a tile is live for all its lanes or for none)
         const TileIdx a = ti[t];
-        const u64 g0 = g0s[j], V = Vs[j];
+        const u64 g0 = g0s[j];
+        u64 V = V0s[j];                                               // the codes of symbols k, k+1, ... from the top nibble down
+        if (haves[j] < 16) V = (V & ~(~0ull >> (4 * haves[j]))) | (V1s[j] >> (4 * haves[j]));
         u64 lo, hi;
         {
             // codes -> packed bytes (the frame's sixteen symbols through v_perm_b32), in stream order: the top nibble of V is symbol k
@@ -1465,7 +1448,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             pl.P.fpair = fpair;
         }
         LAUNCH(ic, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr, tsig);
-        LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt);
+        LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt, (const TileFlat *)tsig);
         u32 nrest = 0;                                                                   // tiles holding a header or a record boundary
         if ((rc = ctx_readback(ic, &nrest, cnt, 4))) { if (ic != c) memcpy(c->err, ic->err, sizeof c->err); return rc; }
         u64 t_done = 0;
