@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     __shared__ u64 s_tog[EMIT_TOG_LDS];
     const u32 sl[4] = { P.fpair[0], P.fpair[1], P.fpair[2], P.fpair[3] };     // uniform: scalar loads
     const u32 lane16 = threadIdx.x * 16;
-    u64 g0s[FLAT_TPW], V0s[FLAT_TPW], V1s[FLAT_TPW]; u32 nls[FLAT_TPW], haves[FLAT_TPW]; bool live[FLAT_TPW];
+    u64 V0s[FLAT_TPW], V1s[FLAT_TPW]; u32 grels[FLAT_TPW], nls[FLAT_TPW], haves[FLAT_TPW]; bool live[FLAT_TPW];
     // the 64 bits below `top` (a bit address inside the source buffer: what lies below the stream's first symbol is never used):
     // one 16-byte load from the 8-aligned address below, then a funnel shift
     auto window = [&](u64 t) -> u64 {
@@ -798,35 +798,40 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         const u32 sh = (u32)(addr & 7) * 8 + ((u32)lb & 7);
         return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
     };
-    // ---- phase 1: where every chunk's codes are (arithmetic on the tile's two streams, no dependent load), and the loads
+    // ---- phase 1: where every chunk's codes are, and the loads.  Everything a lane computes is 32-bit and relative to the tile
+    // (its first base line a.gline, its first packed byte tf.qf); the 64-bit parts are the same for the whole tile (scalar).
 #pragma unroll
     for (u32 j = 0; j < FLAT_TPW; j++) {
         const u64 t = (u64)blockIdx.x * FLAT_TPW + j;
-        live[j] = false; g0s[j] = 0; V0s[j] = 0; V1s[j] = 0; nls[j] = 64; haves[j] = 16;
+        live[j] = false; grels[j] = 0; V0s[j] = 0; V1s[j] = 0; nls[j] = 64; haves[j] = 16;
         if (t >= ntiles) continue;
         const TileIdx a = ti[t];
         if (!a.fast) continue;
         live[j] = true;
-        u64 g0; u32 nl_b = 64;
+        u32 grel, nl_b = 64;                                          // grel: the chunk's first base, counted from a.gline
         if (P.mode == EM_FASTA && P.L != 0) {
             const u32 Lp1 = (u32)P.L + 1;
             u32 c = a.col + lane16, dl;
             if (Lp1 < 32768) dl = __umulhi(c, P.Ldiv_magic); else dl = c >= Lp1 ? 1u : 0u;
             u32 col = c - dl * Lp1;
-            g0 = a.gline + (u64)dl * (u32)P.L + col;
+            grel = dl * (u32)P.L + col;
             u32 d = (u32)P.L - col;
             nl_b = d < 16 ? d : 64;
-        } else g0 = a.gline + lane16;
-        g0s[j] = g0; nls[j] = nl_b;
-        const u64 q = g0 >> 1; const u32 need = 8 + ((u32)g0 & 1);
+        } else grel = lane16;
+        grels[j] = grel; nls[j] = nl_b;
         const TileFlat tf = tsig[t];
-        const bool second = q >= tf.q1;                               // the chunk starts in the tile's second stream
-        const u64 sq0 = second ? tf.q1 : tf.q0, sA = second ? tf.A1 : tf.A, sq1 = second ? tf.q2 : tf.q1;
-        const u64 k = q - sq0, n = sq1 - sq0;
-        u64 top = sA - 4 * k; if (top < 64) top = 64;                 // top: the bit above symbol k
+        const u32 par = ((u32)a.gline & 1u) + grel;                   // parity of the chunk's first base in bit 0
+        const u32 need = 8 + (par & 1u);
+        const u32 qrel = (par >> 1) + (u32)((a.gline >> 1) - tf.qf);  // its first packed byte, counted from tf.qf (a.gline <= first base of the tile)
+        const u64 dd1 = tf.q1 - tf.qf, dd2 = tf.q2 - tf.qf;
+        const u32 d1 = dd1 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)dd1, d2 = dd2 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)dd2;
+        const u64 T0 = tf.A - 4 * (tf.qf - tf.q0), T1 = tf.A1 + 4 * (u64)d1;      // bit above the symbol at qrel = 0, in the first / second stream
+        const bool second = qrel >= d1;                               // the chunk starts in the tile's second stream
+        u64 top = (second ? T1 : T0) - 4 * (u64)qrel; if (top < 64) top = 64;
+        const u32 rem = (second ? d2 : d1) - qrel;                    // symbols from the chunk's first one to the end of its stream
         V0s[j] = window(top);
-        if (k + need > n) {                                           // it runs over the end of that stream: the rest is the top of the next one
-            haves[j] = (u32)(n - k);
+        if (need > rem) {                                             // it runs over the end of that stream: the rest is the top of the next one
+            haves[j] = rem;
             V1s[j] = window(tf.A1 < 64 ? 64 : tf.A1);
         }
     }
@@ -836,7 +841,7 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         const u64 t = (u64)blockIdx.x * FLAT_TPW + j;
         if (!live[j]) continue;                                       // (uniform: a tile is live for all its lanes or for none)
         const TileIdx a = ti[t];
-        const u64 g0 = g0s[j];
+        const u64 g0 = a.gline + grels[j];
         u64 V = V0s[j];                                               // the codes of symbols k, k+1, ... from the top nibble down
         if (haves[j] < 16) V = (V & ~(~0ull >> (4 * haves[j]))) | (V1s[j] >> (4 * haves[j]));
         u64 lo, hi;
