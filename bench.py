@@ -366,7 +366,9 @@ def main():
     packed = (rep.n_bases + 1) // 2
     # algorithmic bytes per step of each candidate dominant kernel; a rank of a sharded job moves its share
     alg = {"zstd_huf_literals": (rep.section_comp[4] + packed) * frac_mine, "zstd_flat_literals": (rep.section_comp[4] + packed) * frac_mine,
-           "unnaf_emit": packed * frac_mine + my_text}
+           "unnaf_emit": packed * frac_mine + my_text,
+           # a flat frame is read in place: compressed sequence stream in, text out, no packed intermediate
+           "unnaf_emit_flat": rep.section_comp[4] * frac_mine + my_text}
     roofline = roofline_of(kt, alg, n_text, (n_naf * frac_mine + my_text), ms_per_step if not sharded else extra["range_decode_ms"], merge_side=("unnaf_emit",))
     ennaf_roofline = None
     if not sharded:
