@@ -2,6 +2,7 @@
  * Command line, outputs and messages follow unnaf/src/unnaf.c:197-456 and unnaf/src/output.c of the
  * reference; every decompression and the text re-emit run on the GPU through libnaf_gpu.so. */
 #include "host_common.h"
+#include <sys/mman.h>
 
 typedef enum { UNDECIDED, FORMAT_NAME, PART_LIST, PART_SIZES, NUMBER_OF_SEQUENCES, TITLE, IDS, NAMES, LENGTHS, TOTAL_LENGTH,
                MASK, TOTAL_MASK_LENGTH, FOUR_BIT, DNA, MASKED_DNA, UNMASKED_DNA, SEQ, SEQUENCES, CHARCOUNT,
@@ -82,7 +83,14 @@ static void parse_command_line(int argc, char **argv)
 
 static const unsigned char *naf; static size_t naf_len; static naf_gpu_header H; static void *d_naf = NULL;
 
-static void upload(void) { gpu_open(); if (d_naf) return; GPU_TRY(naf_gpu_malloc(gpu, naf_len + 64, &d_naf)); GPU_TRY(naf_gpu_upload(gpu, d_naf, naf, naf_len)); GPU_TRY(naf_gpu_synchronize(gpu)); phase("archive upload"); }
+static int naf_fd = -1;            /* a regular file: mapped for the header walk and the title, read into HBM by the I/O lanes */
+static void upload_to(naf_gpu_ctx *c, void **d)
+{
+    CTX_TRY(c, naf_gpu_malloc(c, naf_len + 64, d));
+    if (naf_fd >= 0) CTX_TRY(c, naf_gpu_read_file(c, naf_fd, 0, naf_len, *d));
+    else { CTX_TRY(c, naf_gpu_upload(c, *d, naf, naf_len)); CTX_TRY(c, naf_gpu_synchronize(c)); }
+}
+static void upload(void) { gpu_open(); if (d_naf) return; upload_to(gpu, &d_naf); phase("archive upload"); }
 
 static unsigned char *load_section(int i, const char *what)
 {
@@ -133,8 +141,7 @@ static void *text_worker(void *arg)
     void *d_arc = d_naf;
     if (!c) {                                                   /* a device of its own: context and a copy of the archive */
         c = ctx_open(j->device);
-        CTX_TRY(c, naf_gpu_malloc(c, naf_len + 64, &d_arc));
-        CTX_TRY(c, naf_gpu_upload(c, d_arc, naf, naf_len)); CTX_TRY(c, naf_gpu_synchronize(c));
+        upload_to(c, &d_arc);
     }
     const size_t R = range_bytes(), span = j->hi - j->lo, cap = span < R ? span : R;
     void *d; CTX_TRY(c, naf_gpu_malloc(c, cap + 64, &d));
@@ -198,9 +205,13 @@ int main(int argc, char **argv)
     FILE *IN = in_file_path ? fopen(in_file_path, "rb") : stdin;
     if (!IN) die("can't open input file\n");
     phase("start");
-    naf = read_all(IN, &naf_len);
+    struct stat ist;
+    if (fd_is_regular(fileno(IN)) && fstat(fileno(IN), &ist) == 0 && ist.st_size > 0) {
+        void *m = mmap(NULL, (size_t)ist.st_size, PROT_READ, MAP_PRIVATE, fileno(IN), 0);
+        if (m != MAP_FAILED) { naf = (const unsigned char *)m; naf_len = (size_t)ist.st_size; naf_fd = fileno(IN); }
+    }
+    if (naf_fd < 0) { naf = read_all(IN, &naf_len); if (IN != stdin) fclose(IN); }
     phase("read archive");
-    if (IN != stdin) fclose(IN);
     char eb[128] = "";
     if (naf_gpu_parse_header_host(naf, naf_len, &H, eb)) die("%s", eb);
     int has_title = (H.flags >> 6) & 1, has_ids = (H.flags >> 5) & 1, has_names = (H.flags >> 4) & 1, has_lengths = (H.flags >> 3) & 1,
