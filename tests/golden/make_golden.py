@@ -51,6 +51,14 @@ def copy_ref_tests():
                 name = f[:-5]
                 cases.append({"set": tset, "name": name, "input": name.split("-")[0] + ".fa",
                               "ennaf_args": m.group(1).split(), "unnaf_args": m.group(2).split()})
+    # the interface set: expected stdout / stderr of `--version` and of a start without input on a terminal (data only; the tests
+    # build the command lines themselves)
+    src = os.path.join(REF, "tests", "interface")
+    dst = os.path.join(HERE, "ref_tests", "interface")
+    os.makedirs(dst, exist_ok=True)
+    for f in sorted(os.listdir(src)):
+        if f.endswith("-ref"):
+            shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
     json.dump(cases, open(os.path.join(HERE, "ref_cases.json"), "w"), indent=1)
     print("ref cases:", len(cases))
 

@@ -371,3 +371,53 @@ def test_ennaf_fastq_fuzz_realistic_records(gpu, oracle):
         if i % 7 == 0:
             t = t.rstrip(b"\n")
         check_ennaf(gpu, oracle, t)
+
+
+def test_single_record_of_more_than_2_32_bases(gpu, oracle):
+    """One record of 4.4 G bases: its length takes a 0xFFFFFFFF continuation unit (encoders.c:72-95), base indices and text offsets
+    inside the record pass 2^32, and the mask run is 17 million units of 255.  Round trip on the device, the lengths stream
+    spelled out, and the reference-side reading of the length units through --lengths of the CLI."""
+    import torch
+    from naf_amd import synth
+    text = synth.fasta_acgt_device(4_500_000_000, n_records=1, width=80, seed=77)
+    d_naf, rep = gpu.ennaf(text)
+    assert rep.n_sequences == 1 and rep.n_bases > 2 ** 32
+    h = gpu.parse_header(d_naf)
+    assert h.orig_size[2] == 8                                         # two length units
+    lens = gpu.zstd_decompress(d_naf[h.payload_off[2]: h.payload_off[2] + h.comp_size[2]], 8, has_magic=False)
+    u = np.frombuffer(host(lens), dtype="<u4")
+    assert int(u[0]) == 0xFFFFFFFF and int(u[0]) + int(u[1]) == rep.n_bases
+    back = gpu.unnaf(d_naf, 0)
+    assert torch.equal(back, text)
+    del back
+    # byte ranges on both sides of the 2^32-th base and of the 2^32-th text byte
+    for b in (2 ** 32 - 5000, 2 ** 32 + 2 ** 31, text.numel() - 70000):
+        r = gpu.unnaf_range(d_naf, b, b + 65536, 0)
+        assert torch.equal(r, text[b:b + 65536])
+    seq = gpu.unnaf(d_naf, 2)                                            # --seq: the bases alone
+    assert seq.numel() == rep.n_bases
+
+
+def test_ennaf_60mb_mixed_against_the_real_reference(gpu, oracle):
+    """Soft-masked, IUPAC, empty records, CRLF in places, tens of thousands of records: the archive of the GPU encoder decodes under
+    the real reference to what the reference's own archive decodes to, and the GPU decoder reads the reference's archive."""
+    from naf_amd import synth
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built")
+    parts = []
+    for k in range(30):
+        t = synth.fasta_mixed(700, 3000, 60 + k, seed=1000 + k)
+        if k % 5 == 0:
+            t = t.replace(b"\n", b"\r\n")
+        parts.append(t)
+    text = b"".join(parts)
+    assert len(text) > 55_000_000
+    d_naf, rep = gpu.ennaf(gpu.to_device(text))
+    mine = host(d_naf)
+    ref = oracle.ref_ennaf(text)
+    want = oracle.ref_unnaf(ref)
+    assert oracle.ref_unnaf(mine) == want
+    assert host(gpu.unnaf(gpu.to_device(ref), -1)) == want
+    sp_lens = oracle.ref_unnaf(mine, ("--lengths",))
+    assert sp_lens == oracle.ref_unnaf(ref, ("--lengths",))
+    assert oracle.ref_unnaf(mine, ("--mask",)) == oracle.ref_unnaf(ref, ("--mask",))

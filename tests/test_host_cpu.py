@@ -179,11 +179,23 @@ def run(prog, *args, stdin=None):
     return p.returncode, p.stdout, p.stderr
 
 
-def test_cli_version_banners_match_reference_fixtures():
+def test_cli_interface_fixtures_of_the_reference():
+    """The reference's tests/interface set: `--version`, and a start without arguments on a terminal (exit code 0, the hint on
+    stderr, nothing on stdout -- ennaf.c:439-443, unnaf.c:364-368).  The terminal is a pty."""
+    import pty
     for prog in ("ennaf", "unnaf"):
         rc, out, err = run(prog, "--version")
-        assert rc == 0 and out == b""
-        assert err == golden_bytes("ref_tests", "interface", prog + "-version.err-ref") if os.path.exists(os.path.join(GOLDEN, "ref_tests", "interface")) else err.startswith(prog.encode() + b" - NAF")
+        assert rc == 0
+        assert out == golden_bytes("ref_tests", "interface", prog + "-version.out-ref")
+        assert err == golden_bytes("ref_tests", "interface", prog + "-version.err-ref")
+        master, slave = pty.openpty()
+        try:
+            p = subprocess.run([os.path.join(BIN, prog)], stdin=slave, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        finally:
+            os.close(master); os.close(slave)
+        assert p.returncode == 0
+        assert p.stdout == golden_bytes("ref_tests", "interface", prog + "-no-input.out-ref")
+        assert p.stderr == golden_bytes("ref_tests", "interface", prog + "-no-input.err-ref")
     rc, out, err = run("unnaf", "--bogus")
     assert rc == 1 and err == b'unnaf error: unknown or incomplete argument "--bogus"\n'
     rc, out, err = run("ennaf", "-c", "-o", "x")
