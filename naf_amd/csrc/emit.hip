@@ -1323,7 +1323,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     // (ctx.h: ZFlat) those read it in place and nothing is decoded.  NAF_GPU_FLAT_FUSE=0: always decode first (cross-check).
     ZFlat zflat; memset(&zflat, 0, sizeof zflat);
     const char *ff = getenv("NAF_GPU_FLAT_FUSE"), *ek0 = getenv("NAF_GPU_EMIT");
-    const bool try_flat = whole && !size_only && pl.fourbit && !fuse_on && !pl.P.force_slow && !(ff && ff[0] == '0') && !(ek0 && ek0[0]) &&
+    const bool try_flat = !size_only && pl.fourbit && !fuse_on && !pl.P.force_slow && !(ff && ff[0] == '0') && !(ek0 && ek0[0]) &&
                           (pl.P.mode == EM_FASTA || pl.P.mode == EM_SEQ || pl.P.mode == EM_SEQUENCES) && pl.P.N && h.orig_size[S_SEQ] / pl.P.N >= 16384 &&
                           (pl.P.mode != EM_FASTA || pl.P.L == 0 || pl.P.L >= 16);
     if (par) {

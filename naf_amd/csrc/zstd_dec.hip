@@ -1555,7 +1555,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, n_flat), 0, 4, c->stream));
         HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, n_huf_built), 0, 4, c->stream));
     }
-    if (c->zflat && !rg && lit_only_spec && nblk > 0 && hs.n_huf_distinct == 1 && hs.n_huf_built == 1 && hs.n_flat == 1 && hs.max_huf_log == 4 && hs.n_plain_huf == nblk && !always_table) {
+    if (c->zflat && lit_only_spec && nblk > 0 && hs.n_huf_distinct == 1 && hs.n_huf_built == 1 && hs.n_flat == 1 && hs.max_huf_log == 4 && hs.n_plain_huf == nblk && !always_table) {
         // every block a plain Huffman block of the same flat 4-bit tree: the caller's emit kernel reads the streams in place
         ZFlat *zf = c->zflat;
         FlatStream *si = arena_new<FlatStream>(c, 4 * (size_t)nblk + 1); u8 *d_sym = (u8 *)arena_alloc(c, 16);
@@ -1563,6 +1563,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr);
         LAUNCH(c, "zstd_flat_streams", k_flat_streams, cdiv(4ull * nblk, 256), 256, 0, d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, si, d_sym, st, (const u64 *)d_total_out);
         zf->src = d_src; zf->si = si; zf->nslots = 4ull * nblk; zf->sym = d_sym; zf->status = st; zf->ready = true;
+        if (rg) { rg->got_lo = 0; rg->got_hi = hs.total_out; rg->ranged = false; }      // nothing was decoded: the emit kernel finds any byte of the stream itself
         *out_len = hs.total_out;
         if (fh.has_fcs && fh.content_size != hs.total_out) return zerr(c, ZE_CORRUPT, "content size mismatch");
         return 0;
