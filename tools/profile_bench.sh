@@ -1,18 +1,24 @@
 #!/bin/bash
-# Produces the files under profiles/ for one round:  tools/profile_bench.sh r01   (run on the GPU box, from the repo root)
+# Produces the files under profiles/ for one round:  tools/profile_bench.sh r02   (run on the GPU box, from the repo root)
 #   <tag>_bench_line.json                     the JSON line of a plain `python bench.py`
 #   <tag>_bench_rocprofv3_kernel_stats.csv    rocprofv3 --kernel-trace --stats of `python bench.py --steps 3 --no-cpu`
 #   <tag>_pmc_fetch.csv / _pmc_write.csv      per-kernel FETCH_SIZE / WRITE_SIZE sums (separate --pmc passes, no tracing
 #                                             domains besides the kernel dispatch records), incl. the calibration kernel
 # Everything is written under gpurun_out/<tag>/ ; copy what should be judged into profiles/.
 set -u
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 python bench.py > $out/${tag}_bench_line.json 2> $out/bench.err
 tail -c 400 $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 3 --no-cpu > $out/stats.log 2>&1
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/${tag}_bench_rocprofv3_kernel_stats.csv
+# the two-pass decode (what archives that are not one flat tree take), every kernel alone on the device: no fused emit, no split
+NAF_GPU_FLAT_FUSE=0 NAF_GPU_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats2 -- python bench.py --steps 3 --no-cpu > $out/stats2.log 2>&1
+cp $(ls $out/stats2/*/*kernel_stats.csv | head -1) $out/${tag}_twopass_alone_rocprofv3_kernel_stats.csv
+# the serial Huffman kernel on the same data (NAF_GPU_FLAT=0), alone
+NAF_GPU_FLAT=0 NAF_GPU_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats3 -- python bench.py --steps 3 --no-cpu > $out/stats3.log 2>&1
+cp $(ls $out/stats3/*/*kernel_stats.csv | head -1) $out/${tag}_serial_huffman_alone_rocprofv3_kernel_stats.csv
 for ctr in FETCH_SIZE WRITE_SIZE; do
   printf 'pmc: %s\n' $ctr > $out/pmc_$ctr.txt
   rocprofv3 -i $out/pmc_$ctr.txt --output-format csv -d $out/pmc_$ctr -- python bench.py --steps 1 --warmup 0 --no-cpu > $out/pmc_$ctr.log 2>&1
@@ -44,9 +50,13 @@ line = json.loads(open(f"{out}/{tag}_bench_line.json").read().strip().splitlines
 text_bytes = int(line["config"]["workload"].split("FASTA ")[-1].split(" B")[0])
 # kernel function -> the name bench.py times it under; the PMC passes ran ONE step plus one verification step and one
 # instrumented step = 3 unnaf calls, and 2 ennaf calls
-names = {"k_huf_literals": "zstd_huf_literals", "k_emit_tile": "unnaf_emit", "k_emit_rest": "unnaf_emit_rest", "k_build_huf": "zstd_build_huf",
-         "k_spec_find": "zstd_index_find", "k_spec_resolve": "zstd_index_resolve", "k_copy_fill": "zstd_copy_fill"}
+names = {"k_huf_literals": "zstd_huf_literals", "k_flat_literals": "zstd_flat_literals", "k_emit_tile": "unnaf_emit", "k_emit_tile_flat": "unnaf_emit_flat",
+         "k_emit_rest": "unnaf_emit_rest", "k_build_huf": "zstd_build_huf", "k_spec_find": "zstd_index_find", "k_spec_resolve": "zstd_index_resolve",
+         "k_copy_fill": "zstd_copy_fill", "k_flat_streams": "zstd_flat_streams", "k_tile_index": "unnaf_tile_index"}
+enc_names = {"k_enc_scatter": "ennaf_scatter", "k_enc_count": "ennaf_count", "k_enc_last_fa": "ennaf_last", "k_pack4": "ennaf_pack4",
+             "k_zenc_plan": "zenc_plan", "k_zenc_write": "zenc_write", "k_mask_run_units": "ennaf_mask_runs", "k_mask_units_write": "ennaf_mask_units"}
 calls = 3
+enc_calls = 4            # three timed ennaf calls and the instrumented one
 k = {}
 # counter unit = KiB.  FETCH_SIZE tallies a wide coalesced read at 1/2 (guide; k_expand / k_read calibration: x2), the
 # Huffman kernel's one-64-byte-sector-per-lane reads at 1/1.742 (k_sector_read calibration); WRITE_SIZE is exact (k_expand / k_write)
@@ -58,6 +68,16 @@ for ctr, name in (("fetch", "fetch_bytes"), ("write", "write_bytes")):
         if fn in names:
             scale = 1024 * (fetch_factor.get(fn, 2.0) if ctr == "fetch" else 1.0)
             k.setdefault(names[fn], {"fetch_bytes": 0, "write_bytes": 0})[name] += float(r[list(r.keys())[-1]]) * scale / calls
+ke = {}
+for ctr, name in (("fetch", "fetch_bytes"), ("write", "write_bytes")):
+    for r in csv.DictReader(open(f"{out}/{tag}_pmc_{ctr}.csv")):
+        if r["run"] != "bench": continue
+        fn = r["kernel"].replace("void ", "").split("<")[0]
+        if fn in enc_names:
+            scale = 1024 * (2.0 if ctr == "fetch" else 1.0)
+            ke.setdefault(enc_names[fn], {"fetch_bytes": 0, "write_bytes": 0})[name] += float(r[list(r.keys())[-1]]) * scale / enc_calls
+json.dump({"source": f"profiles/{tag}_pmc_fetch.csv + {tag}_pmc_write.csv (rocprofv3 --pmc, separate passes; counter unit KiB; FETCH_SIZE x2, WRITE_SIZE x1; per ennaf call)",
+           "text_bytes": text_bytes, "ennaf_calls_in_pass": enc_calls, "kernels": ke}, open(f"{out}/pmc_traffic_ennaf.json", "w"), indent=1)
 json.dump({"source": f"profiles/{tag}_pmc_fetch.csv + {tag}_pmc_write.csv (rocprofv3 --pmc, separate passes; counter unit KiB; FETCH_SIZE x2 for coalesced reads, x1.742 for the per-lane 64-byte sector reads of zstd_huf_literals, WRITE_SIZE x1; factors calibrated with tools/bw_calibrate.hip)",
            "text_bytes": text_bytes, "unnaf_calls_in_pass": calls, "kernels": k}, open(f"{out}/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(k, indent=1))
