@@ -918,6 +918,29 @@ __global__ void k_range_bases(EmitP P, u64 *out2)
     out2[1] = P.rec_base[r1] + upper(r1, pe);
 }
 
+// ---- bases behind the last record ---------------------------------------------------------------------------------------
+__global__ void k_last_nonempty(const u64 *rec_len, u64 N, unsigned long long *out)          // out[0] = 1 + index of the last record with bases
+{
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < N && rec_len[r]) atomicMax(out, (unsigned long long)(r + 1));
+}
+// Text bytes [lo, hi) of the surplus (counted from its first byte): `cc` bases finish the line in progress, then lines of L, no
+// newline behind the last one (print_dna_split_into_lines, output.c:339-360, carries cur_line_n_bp_remaining over from the last record).
+template <bool FOURBIT>
+__global__ void k_emit_surplus(EmitP P, u64 base0, u64 S, u64 cc, u64 L, int wrap, u64 lo, u64 hi, u8 *out)
+{
+    const u64 j = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= hi) return;
+    u64 g; bool nl = false;
+    if (!wrap || L == 0 || S <= cc) g = base0 + j;
+    else if (j < cc) g = base0 + j;
+    else if (j == cc) { nl = true; g = 0; }
+    else { const u64 j2 = j - cc - 1, line = j2 / (L + 1), col = j2 - line * (L + 1); if (col == L) { nl = true; g = 0; } else g = base0 + cc + line * L + col; }
+    u32 ch = '\n';
+    if (!nl) { ch = base_char<FOURBIT>(P, g); if (P.masking && base_masked(P, g, 0, P.n_toggles)) ch += 32; }
+    out[j - lo] = (u8)ch;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 static int zero_positions(naf_gpu_ctx *c, const u8 *d_buf, u64 n, u64 N, u64 **out, bool names)
 {
@@ -1059,6 +1082,9 @@ enum { S_IDS = 0, S_NAMES, S_LEN, S_MASK, S_SEQ, S_QUAL };
 struct UnnafPlan {
     naf_gpu_header h; u8 frame_head[6][24]; EmitP P; u64 total; bool fourbit; bool empty;
     u64 seq_bytes; bool need_qual;
+    // bases behind the last record (an input with control bytes inside an ID): the reference prints them, wrapped on from
+    // where the last non-empty record's last line stopped, without a final newline (output.c:369-430)
+    u64 main_total, surplus, sur_c, sur_base0;
 };
 
 static int load_section(naf_gpu_ctx *c, const u8 *d_naf, const naf_gpu_header &h, int i, u64 expect, const char *what, u8 **out, const u8 *head = nullptr)
@@ -1083,19 +1109,15 @@ static int unnaf_prepare(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const 
     EmitP &P = pl.P; memset(&P, 0, sizeof P);
     int has_mask = (h.flags >> 2) & 1, has_data = (h.flags >> 1) & 1, has_qual = h.flags & 1;
     int mode = o->out_type == NAF_OUT_DEFAULT ? (has_qual ? NAF_OUT_FASTQ : NAF_OUT_FASTA) : o->out_type;   // unnaf.c:372-375
-    pl.empty = false; pl.total = 0; pl.need_qual = false;
+    pl.empty = false; pl.total = 0; pl.need_qual = false; pl.main_total = pl.surplus = pl.sur_c = pl.sur_base0 = 0;
     pl.fourbit = h.seq_type <= NAF_SEQ_RNA;
     u64 N = h.n_sequences, T = h.orig_size[S_SEQ];
     pl.seq_bytes = pl.fourbit ? (T + 1) / 2 : T;
     if (N == 0 || !has_data) { pl.empty = true; return 0; }                         // unnaf.c:409, output.c:610
     if (mode == NAF_OUT_FASTQ && !has_qual) return ctx_fail(c, NAF_GPU_EFORMAT, "FASTQ output requested, but input has no qualities\n");
-    // every base needs its quality byte: a shorter quality stream would be read past its end by the emit kernels (the reference
-    // has no message for this -- print_quality_from_file, output-fastq.c:69-85, never returns on such an archive)
-    if (mode == NAF_OUT_FASTQ && h.orig_size[S_QUAL] < T)
-        return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted quality: %llu quality codes stored for %llu bases\n", (unsigned long long)h.orig_size[S_QUAL], (unsigned long long)T);
     if (mode == NAF_OUT_4BIT) {
         if (!pl.fourbit) return ctx_fail(c, NAF_GPU_EFORMAT, "input has no 4-bit encoded data, but %s sequences\n", h.seq_type == NAF_SEQ_PROTEIN ? "protein" : "text");
-        P.mode = -1; pl.total = pl.seq_bytes; return 0;
+        P.mode = -1; pl.total = pl.main_total = pl.seq_bytes; return 0;
     }
     P.mode = mode == NAF_OUT_FASTA ? EM_FASTA : mode == NAF_OUT_FASTQ ? EM_FASTQ : mode == NAF_OUT_SEQ ? EM_SEQ : EM_SEQUENCES;
     P.N = N; P.T = T;
@@ -1122,7 +1144,7 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
     u64 N = h.n_sequences, T = h.orig_size[S_SEQ];
     int rc;
     if (P.mode == EM_SEQ) {
-        pl.total = T;
+        pl.total = pl.main_total = T;
     } else {
         if (!has_len) return ctx_fail(c, NAF_GPU_EFORMAT, "archive has no lengths");
         // ids and names: on `aux` (its own host thread and stream) beside the lengths when there is one, else after them
@@ -1209,10 +1231,36 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
         if ((rc = scan_exclusive_u64(c, rec_base, N + 1, (u64 *)nullptr))) return rc;
         u64 tot[2];
         if ((rc = ctx_readback2(c, &tot[0], rec_out + N, 8, &tot[1], rec_base + N, 8))) return rc;
-        if (tot[1] != T) return ctx_fail(c, NAF_GPU_EFORMAT, "sum of lengths (%llu) differs from the stored sequence length (%llu)", (unsigned long long)tot[1], (unsigned long long)T);
+        if (tot[1] > T) return ctx_fail(c, NAF_GPU_EFORMAT, "sum of lengths (%llu) exceeds the stored sequence length (%llu)", (unsigned long long)tot[1], (unsigned long long)T);
+        // every base of a read needs its quality byte: a shorter quality stream would be read past its end by the emit kernels (the
+        // reference has no message for this -- print_quality_from_file, output-fastq.c:69-85, never returns on such an archive)
+        if (P.mode == EM_FASTQ && h.orig_size[S_QUAL] < tot[1])
+            return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted quality: %llu quality codes stored for %llu bases\n", (unsigned long long)h.orig_size[S_QUAL], (unsigned long long)tot[1]);
         if (P.mode == EM_SEQUENCES && T == 0) tot[0] = 0;                            // output-sequences.c:81: nothing printed
         P.hdr_len = hdr_len; P.rec_out = rec_out; P.rec_base = rec_base;
-        pl.total = tot[0];
+        pl.total = pl.main_total = tot[0]; pl.surplus = 0; pl.sur_c = 0;
+        if (tot[1] < T && P.mode != EM_FASTQ) {
+            // more bases than the lengths account for.  FASTQ never prints them (output-fastq.c:100-149 stops after the N-th
+            // read); --sequences appends them raw (output-sequences.c:82-116); FASTA wraps them on from the last non-empty record's line
+            const u64 S = T - tot[1];
+            u64 tail = S;
+            if (P.mode == EM_FASTA) {
+                unsigned long long *d_last = arena_new<unsigned long long>(c, 2); if (!d_last) return NAF_GPU_ENOMEM;
+                HIP_TRY(c, hipMemsetAsync(d_last, 0, 16, c->stream));
+                LAUNCH(c, "unnaf_last_nonempty", k_last_nonempty, cdiv(N, 256), 256, 0, (const u64 *)rec_len, N, d_last);
+                u64 last1 = 0; if ((rc = ctx_readback(c, &last1, d_last, 8))) return rc;
+                if (last1 == 0) tail = 0;                                           // no record ever started a line of bases: nothing is printed
+                else {
+                    u64 len_last = 0; if ((rc = ctx_readback(c, &len_last, rec_len + (last1 - 1), 8))) return rc;
+                    const u64 L = P.L;
+                    const u64 cc = L ? ((len_last % L) ? L - len_last % L : 0) : 0;
+                    pl.sur_c = cc;
+                    if (L && S > cc) { const u64 R = S - cc; tail = cc + 1 + R + (R - 1) / L; }
+                }
+            }
+            pl.surplus = tail ? S : 0; pl.sur_base0 = tot[1];
+            pl.total = pl.main_total + tail;
+        }
     }
     return 0;
 }
@@ -1369,15 +1417,22 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     if (size_only) { *out_len = pl.total; return 0; }
     if (*out_len > out_cap) return ctx_fail(c, NAF_GPU_ECAP, "unnaf output needs %llu bytes, capacity %zu", (unsigned long long)*out_len, out_cap);
     if (*out_len == 0) return 0;
-    pl.P.out_begin = out_begin; pl.P.out_end = out_end;
+    // the records' text is [0, main_total); bases behind the last record follow it and go through k_emit_surplus
+    const u64 m_begin = out_begin < pl.main_total ? out_begin : pl.main_total, m_end = out_end < pl.main_total ? out_end : pl.main_total;
+    const bool has_main = m_end > m_begin, has_tail = out_end > pl.main_total;
+    pl.P.out_begin = m_begin; pl.P.out_end = m_end;
     // Byte-range call (multi-GPU shard): find the bases this range touches and decode only the zstd blocks behind them.
     u64 rec0 = 0, rec1 = pl.P.N ? pl.P.N - 1 : 0;                                        // records the byte range touches
     if (!whole && pl.P.mode != -1) {
-        u64 *d_g = arena_new<u64>(c, 4); if (!d_g) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "unnaf_range_bases", k_range_bases, 1, 64, 0, pl.P, d_g);
-        u64 g[4]; if ((rc = ctx_readback(c, g, d_g, 32))) return rc;
+        u64 g[4] = { pl.sur_base0, pl.sur_base0, rec1, rec1 };
+        if (has_main) {
+            u64 *d_g = arena_new<u64>(c, 4); if (!d_g) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "unnaf_range_bases", k_range_bases, 1, 64, 0, pl.P, d_g);
+            if ((rc = ctx_readback(c, g, d_g, 32))) return rc;
+        }
         rec0 = g[2]; rec1 = g[3];
         if (g[1] < g[0]) g[1] = g[0];
+        if (has_tail) g[1] = pl.P.T;
         rgs.want_lo = pl.fourbit ? g[0] / 2 : g[0]; rgs.want_hi = pl.fourbit ? (g[1] + 1) / 2 : g[1];
         rgq.want_lo = g[0]; rgq.want_hi = g[1];
         prs = &rgs; prq = &rgq;
@@ -1385,7 +1440,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     // Whole FASTA text of a 4-bit archive: decode and emit in one kernel when the frame is literal-only.
     // (Measured slower than decode + emit on MI355X for now: its per-lane 16-byte text stores are partial-line
     // writes from 600 k streams; kept behind NAF_GPU_FUSE=1 and under test until the text is staged through LDS.)
-    if (whole && pl.P.mode == EM_FASTA && pl.fourbit && (pl.P.L == 0 || pl.P.L >= 16) && !pl.P.force_slow && fuse_on) {
+    if (whole && pl.P.mode == EM_FASTA && pl.fourbit && (pl.P.L == 0 || pl.P.L >= 16) && !pl.P.force_slow && fuse_on && !pl.surplus) {
         size_t n2 = 0;
         rc = zstd_decode_fused_fasta(c, d_naf + h.payload_off[S_SEQ], h.comp_size[S_SEQ], 0, &n2, &pl.P, d_out);
         if (rc == 0) {
@@ -1405,83 +1460,91 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         HIP_TRY(c, hipMemcpyAsync(d_out, seq + out_begin, out_end - out_begin, hipMemcpyDeviceToDevice, c->stream));
         return 0;
     }
-    pl.P.out_begin = out_begin; pl.P.out_end = out_end;
-    // short records (FASTQ reads, contigs, proteins): segment-composing kernel; long records: streaming kernel
-    const char *ek = getenv("NAF_GPU_EMIT");
-    bool short_rec = pl.P.mode != EM_SEQ && pl.total / pl.P.N < 16384;
-    if (ek && !strcmp(ek, "short")) short_rec = pl.P.mode != EM_SEQ;
-    if (ek && !strcmp(ek, "long")) short_rec = false;
-    if (pl.P.force_slow) { short_rec = false; ek = "span"; }
-    if (whole && pl.P.mode == EM_FASTQ && !pl.P.force_slow && !(ek && ek[0])) {
-        if (pl.fourbit) LAUNCH(c, "unnaf_emit_records", k_emit_fastq_records<true>, cdiv(pl.P.N, 16), 256, 0, pl.P, d_out);
-        else LAUNCH(c, "unnaf_emit_records", k_emit_fastq_records<false>, cdiv(pl.P.N, 16), 256, 0, pl.P, d_out);
-    } else if (short_rec) {
-        if (pl.P.mode == EM_FASTA || pl.P.mode == EM_FASTQ) {
-            u64 nr = rec1 - rec0 + 1, htot = 0;
-            u64 *ho = arena_new<u64>(c, nr + 2); if (!ho) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "unnaf_hdr_len64", k_hdr_len64, cdiv(nr, 256), 256, 0, pl.P.hdr_len, rec0, nr, ho);
-            if ((rc = scan_exclusive_u64(c, ho, nr, ho + nr + 1))) return rc;
-            if ((rc = ctx_readback(c, &htot, ho + nr + 1, 8))) return rc;
-            u8 *ht = (u8 *)arena_alloc(c, htot + 32); if (!ht) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "unnaf_hdr_build", k_hdr_build, cdiv(nr, 32), 256, 0, pl.P, rec0, nr, (const u64 *)ho, ht);
-            pl.P.hdr_off = ho; pl.P.hdr_text = ht; pl.P.hdr_r0 = rec0;
-        }
-        u32 grid = cdiv(out_end - out_begin, ES_SPAN);
-        if (pl.fourbit) LAUNCH(c, "unnaf_emit_short", k_emit_short<true>, grid, 256, 0, pl.P, d_out);
-        else LAUNCH(c, "unnaf_emit_short", k_emit_short<false>, grid, 256, 0, pl.P, d_out);
-    } else if (ek && !strcmp(ek, "span")) {                                              // previous long-record kernel (kept as a cross-check)
-        u32 grid = cdiv(out_end - out_begin, EMIT_SPAN);
-        if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit<true>, grid, 256, 0, pl.P, d_out);
-        else LAUNCH(c, "unnaf_emit", k_emit<false>, grid, 256, 0, pl.P, d_out);
-    } else {
-        u64 ntiles = cdiv(out_end - out_begin, 4096);
-        TileIdx *ti = arena_new<TileIdx>(c, ntiles + 2); u64 *tr = arena_new<u64>(c, ntiles + 2);
-        u32 *list = arena_new<u32>(c, ntiles + 1), *cnt = arena_new<u32>(c, 2);
-        if (!ti || !tr || !list || !cnt) return NAF_GPU_ENOMEM;
-        if (!split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, c->stream));
-        // exact c / (L+1) for c < L + 1 + 4096 as mulhi(c, M), M = floor(2^32 / (L+1)) + 1, valid while c * (L+1) < 2^32
-        u64 Lp1 = pl.P.L + 1;
-        pl.P.Ldiv_magic = (Lp1 >= 2 && Lp1 < 32768) ? (u32)((1ull << 32) / Lp1 + 1) : 0;
-        // With a split decode (ZSplit) the index and the tiles behind the finished parts run on the second stream beside the
-        // decode of the next part; this stream takes the tiles behind the last part, the boundary tiles, and waits for the other.
-        naf_gpu_ctx *ic = split.done ? c->side2 : c;                                     // context the tile index is built on
-        if (split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, ic->stream));
-        TileFlat *tsig = nullptr;
-        if (zflat.ready) {
-            tsig = arena_new<TileFlat>(c, ntiles + 2); u32 *fpair = arena_new<u32>(c, 256); if (!tsig || !fpair) return NAF_GPU_ENOMEM;
-            LAUNCH(ic, "unnaf_flat_pair", k_flat_pair, 1, 256, 0, pl.P, fpair);
-            pl.P.fpair = fpair;
-        }
-        LAUNCH(ic, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr, tsig);
-        LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt, (const TileFlat *)tsig);
-        u32 nrest = 0;                                                                   // tiles holding a header or a record boundary
-        if ((rc = ctx_readback(ic, &nrest, cnt, 4))) { if (ic != c) memcpy(c->err, ic->err, sizeof c->err); return rc; }
-        u64 t_done = 0;
-        if (split.done) {
-            HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX], ic->stream));
-            for (int k = 0; k + 1 < split.parts; k++) {
-                // a tile's bases all lie below its last text position, and a lane reads at most 32 packed bytes past its own
-                u64 bases_ready = split.out_end[k] * (pl.fourbit ? 2u : 1u);
-                u64 t_hi = bases_ready / 4096; t_hi = t_hi > 1 ? t_hi - 1 : 0;
-                if (t_hi > ntiles) t_hi = ntiles;
-                if (t_hi <= t_done) continue;
-                HIP_TRY(c, hipStreamWaitEvent(ic->stream, split.ev[k], 0));
-                if (pl.fourbit) LAUNCH(ic, "unnaf_emit", k_emit_tile<true>, (u32)(t_hi - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
-                else LAUNCH(ic, "unnaf_emit", k_emit_tile<false>, (u32)(t_hi - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
-                t_done = t_hi;
+    if (has_main) {
+        // short records (FASTQ reads, contigs, proteins): segment-composing kernel; long records: streaming kernel
+        const char *ek = getenv("NAF_GPU_EMIT");
+        bool short_rec = pl.P.mode != EM_SEQ && pl.total / pl.P.N < 16384;
+        if (ek && !strcmp(ek, "short")) short_rec = pl.P.mode != EM_SEQ;
+        if (ek && !strcmp(ek, "long")) short_rec = false;
+        if (pl.P.force_slow) { short_rec = false; ek = "span"; }
+        if (whole && pl.P.mode == EM_FASTQ && !pl.P.force_slow && !(ek && ek[0])) {
+            if (pl.fourbit) LAUNCH(c, "unnaf_emit_records", k_emit_fastq_records<true>, cdiv(pl.P.N, 16), 256, 0, pl.P, d_out);
+            else LAUNCH(c, "unnaf_emit_records", k_emit_fastq_records<false>, cdiv(pl.P.N, 16), 256, 0, pl.P, d_out);
+        } else if (short_rec) {
+            if (pl.P.mode == EM_FASTA || pl.P.mode == EM_FASTQ) {
+                u64 nr = rec1 - rec0 + 1, htot = 0;
+                u64 *ho = arena_new<u64>(c, nr + 2); if (!ho) return NAF_GPU_ENOMEM;
+                LAUNCH(c, "unnaf_hdr_len64", k_hdr_len64, cdiv(nr, 256), 256, 0, pl.P.hdr_len, rec0, nr, ho);
+                if ((rc = scan_exclusive_u64(c, ho, nr, ho + nr + 1))) return rc;
+                if ((rc = ctx_readback(c, &htot, ho + nr + 1, 8))) return rc;
+                u8 *ht = (u8 *)arena_alloc(c, htot + 32); if (!ht) return NAF_GPU_ENOMEM;
+                LAUNCH(c, "unnaf_hdr_build", k_hdr_build, cdiv(nr, 32), 256, 0, pl.P, rec0, nr, (const u64 *)ho, ht);
+                pl.P.hdr_off = ho; pl.P.hdr_text = ht; pl.P.hdr_r0 = rec0;
             }
-            HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX + 1], ic->stream));
-            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX], 0));         // the index
+            u32 grid = cdiv(m_end - m_begin, ES_SPAN);
+            if (pl.fourbit) LAUNCH(c, "unnaf_emit_short", k_emit_short<true>, grid, 256, 0, pl.P, d_out);
+            else LAUNCH(c, "unnaf_emit_short", k_emit_short<false>, grid, 256, 0, pl.P, d_out);
+        } else if (ek && !strcmp(ek, "span")) {                                              // previous long-record kernel (kept as a cross-check)
+            u32 grid = cdiv(m_end - m_begin, EMIT_SPAN);
+            if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit<true>, grid, 256, 0, pl.P, d_out);
+            else LAUNCH(c, "unnaf_emit", k_emit<false>, grid, 256, 0, pl.P, d_out);
+        } else {
+            u64 ntiles = cdiv(m_end - m_begin, 4096);
+            TileIdx *ti = arena_new<TileIdx>(c, ntiles + 2); u64 *tr = arena_new<u64>(c, ntiles + 2);
+            u32 *list = arena_new<u32>(c, ntiles + 1), *cnt = arena_new<u32>(c, 2);
+            if (!ti || !tr || !list || !cnt) return NAF_GPU_ENOMEM;
+            if (!split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, c->stream));
+            // exact c / (L+1) for c < L + 1 + 4096 as mulhi(c, M), M = floor(2^32 / (L+1)) + 1, valid while c * (L+1) < 2^32
+            u64 Lp1 = pl.P.L + 1;
+            pl.P.Ldiv_magic = (Lp1 >= 2 && Lp1 < 32768) ? (u32)((1ull << 32) / Lp1 + 1) : 0;
+            // With a split decode (ZSplit) the index and the tiles behind the finished parts run on the second stream beside the
+            // decode of the next part; this stream takes the tiles behind the last part, the boundary tiles, and waits for the other.
+            naf_gpu_ctx *ic = split.done ? c->side2 : c;                                     // context the tile index is built on
+            if (split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, ic->stream));
+            TileFlat *tsig = nullptr;
+            if (zflat.ready) {
+                tsig = arena_new<TileFlat>(c, ntiles + 2); u32 *fpair = arena_new<u32>(c, 256); if (!tsig || !fpair) return NAF_GPU_ENOMEM;
+                LAUNCH(ic, "unnaf_flat_pair", k_flat_pair, 1, 256, 0, pl.P, fpair);
+                pl.P.fpair = fpair;
+            }
+            LAUNCH(ic, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr, tsig);
+            LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt, (const TileFlat *)tsig);
+            u32 nrest = 0;                                                                   // tiles holding a header or a record boundary
+            if ((rc = ctx_readback(ic, &nrest, cnt, 4))) { if (ic != c) memcpy(c->err, ic->err, sizeof c->err); return rc; }
+            u64 t_done = 0;
+            if (split.done) {
+                HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX], ic->stream));
+                for (int k = 0; k + 1 < split.parts; k++) {
+                    // a tile's bases all lie below its last text position, and a lane reads at most 32 packed bytes past its own
+                    u64 bases_ready = split.out_end[k] * (pl.fourbit ? 2u : 1u);
+                    u64 t_hi = bases_ready / 4096; t_hi = t_hi > 1 ? t_hi - 1 : 0;
+                    if (t_hi > ntiles) t_hi = ntiles;
+                    if (t_hi <= t_done) continue;
+                    HIP_TRY(c, hipStreamWaitEvent(ic->stream, split.ev[k], 0));
+                    if (pl.fourbit) LAUNCH(ic, "unnaf_emit", k_emit_tile<true>, (u32)(t_hi - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
+                    else LAUNCH(ic, "unnaf_emit", k_emit_tile<false>, (u32)(t_hi - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
+                    t_done = t_hi;
+                }
+                HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX + 1], ic->stream));
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX], 0));         // the index
+            }
+            if (zflat.ready) LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat, cdiv(ntiles, FLAT_TPW), 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles);
+            else if (t_done < ntiles) {
+                if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit_tile<true>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
+                else LAUNCH(c, "unnaf_emit", k_emit_tile<false>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
+            }
+            if (!nrest) {}
+            else if (pl.fourbit) LAUNCH(c, "unnaf_emit_rest", k_emit_rest<true>, (u32)nrest, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
+            else LAUNCH(c, "unnaf_emit_rest", k_emit_rest<false>, nrest, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
+            if (split.done) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX + 1], 0));
         }
-        if (zflat.ready) LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat, cdiv(ntiles, FLAT_TPW), 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles);
-        else if (t_done < ntiles) {
-            if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit_tile<true>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
-            else LAUNCH(c, "unnaf_emit", k_emit_tile<false>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
-        }
-        if (!nrest) {}
-        else if (pl.fourbit) LAUNCH(c, "unnaf_emit_rest", k_emit_rest<true>, (u32)nrest, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
-        else LAUNCH(c, "unnaf_emit_rest", k_emit_rest<false>, nrest, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
-        if (split.done) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX + 1], 0));
+    }
+    if (has_tail) {
+        const u64 lo = (out_begin > pl.main_total ? out_begin : pl.main_total) - pl.main_total, hi = out_end - pl.main_total;
+        u8 *dst = d_out + (pl.main_total + lo - out_begin);
+        const int wrap = pl.P.mode == EM_FASTA;
+        if (pl.fourbit) LAUNCH(c, "unnaf_emit_surplus", k_emit_surplus<true>, cdiv(hi - lo, 256), 256, 0, pl.P, pl.sur_base0, pl.surplus, pl.sur_c, pl.P.L, wrap, lo, hi, dst);
+        else LAUNCH(c, "unnaf_emit_surplus", k_emit_surplus<false>, cdiv(hi - lo, 256), 256, 0, pl.P, pl.sur_base0, pl.surplus, pl.sur_c, pl.P.L, wrap, lo, hi, dst);
     }
     HIP_TRY(c, hipGetLastError());
     if ((rc = zstd_split_status(c, &split))) return rc;           // a split decode left its status for after the emit was queued

@@ -137,9 +137,7 @@ def check_ennaf(gpu, O, text, seq_type=0, no_mask=False, line_length=-1, title=N
     assert mine[: h.header_bytes] == ref[: O.parse_naf(ref).header_bytes]    # container framing identical
     if sp.n_sequences:
         assert O.unnaf(mine, -1) == O.unnaf(ref, -1)
-        consistent = int(np.frombuffer(sp.lengths, dtype="<u4").astype(np.uint64).sum()) == sp.n_bases
-        if consistent:      # archives of inputs with control bytes inside an ID carry bases that belong to
-            assert host(gpu.unnaf(d_naf, -1)) == O.unnaf(ref, -1)   # no record; the HIP unnaf refuses those
+        assert host(gpu.unnaf(d_naf, -1)) == O.unnaf(ref, -1)     # R7 inputs too: the bases behind the last record are printed like the reference does
     return mine
 
 
@@ -421,3 +419,44 @@ def test_ennaf_60mb_mixed_against_the_real_reference(gpu, oracle):
     sp_lens = oracle.ref_unnaf(mine, ("--lengths",))
     assert sp_lens == oracle.ref_unnaf(ref, ("--lengths",))
     assert oracle.ref_unnaf(mine, ("--mask",)) == oracle.ref_unnaf(ref, ("--mask",))
+
+
+def test_bases_behind_the_last_record(gpu, oracle):
+    """a control byte inside an ID puts an N into the sequence that no length accounts for; the reference's unnaf prints the
+    surplus behind the last record, wrapped on from the line the last non-empty record stopped in (output.c:369-430), --sequences
+    appends it raw (output-sequences.c:82-116), FASTQ drops it (output-fastq.c:100-149)."""
+    O = oracle
+    rng = np.random.default_rng(77)
+    def dna(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGTacgtNn", dtype=np.uint8), n).tobytes())
+    cases = []
+    for last_len, bad in ((0, 1), (1, 1), (59, 1), (60, 1), (61, 3), (120, 60), (121, 61), (7, 130), (300, 2)):
+        recs = [b">a" + b"\x01" * bad + b"b c\n" + dna(100) + b"\n", b">second\n" + dna(130) + b"\n", b">third\n" + dna(last_len) + b"\n"]
+        cases.append(b"".join(recs))
+        cases.append(b"".join(recs) + b">empty one\n>empty two\n")
+    cases.append(b">x\x02\x03\n>y\x04\n")                                       # every record empty: nothing of the surplus is printed
+    cases.append(b">big\x01\n" + dna(70000) + b"\n>big2\x05\x06\n" + dna(50001) + b"\n")   # long records: the streaming kernels
+    for text in cases:
+        ref = O.ennaf(text)
+        d_naf, _ = gpu.ennaf(gpu.to_device(text))
+        assert host(d_naf)[:20] == ref[:20]
+        for mode in (0, 3, 2):                                                     # --fasta, --sequences, --seq
+            for L in (-1, 0, 1, 7, 60):
+                for use_mask in (True, False):
+                    want = O.unnaf(ref, mode, use_mask=use_mask, line_length=L)
+                    got = host(gpu.unnaf(d_naf, mode, use_mask=use_mask, line_length=L))
+                    assert got == want, (text[:30], mode, L, use_mask)
+                    assert gpu.unnaf_size(d_naf, mode, use_mask, L) == len(want)
+                # byte ranges, as the several-GPU decode asks for them
+                want = O.unnaf(ref, mode, line_length=L)
+                n = len(want)
+                for lo, hi in ((0, n), (n - 1, n), (max(n - 70, 0), n), (n // 2, n), (max(n - 200, 0), max(n - 3, 0)), (n, n)):
+                    if hi > lo:
+                        assert host(gpu.unnaf_range(d_naf, lo, hi, mode, True, L)) == want[lo:hi], (mode, L, lo, hi)
+    if O.have_ref():                                                               # and the real reference, on one of them
+        for text in (cases[4], cases[9], cases[-1]):
+            naf = host(gpu.ennaf(gpu.to_device(text))[0])
+            for args in ((), ("--line-length", "7"), ("--sequences",)):
+                mode = 3 if "--sequences" in args else 0
+                L = 7 if "--line-length" in args else -1
+                assert host(gpu.unnaf(gpu.to_device(naf), mode, line_length=L)) == O.ref_unnaf(naf, args)
