@@ -28,6 +28,7 @@ struct EncP {
     u8 id_gt_unexpected;         // text+FASTA: '>' also ends ID scanning (ennaf.c:478 flips the shared table)
     u8 strict, pad;
     u32 qlo, qhi;                // quick table of accepted letters (enc_swar.h), built in set_expected
+    u32 nuc32[8];                // 4-bit code of the letter whose low five bits are the index (tables.c:189-197), 15 in the other slots
 };
 
 __device__ __forceinline__ bool c_eol(u32 c) { return c >= 0x0A && c <= 0x0D; }
@@ -385,7 +386,8 @@ __global__ __launch_bounds__(256) void k_count_starts(const u8 *text, u64 p0, u6
 
 // ---- K3: scatter --------------------------------------------------------------------------------------------------------
 struct EncOut {
-    u8 *seq, *ids, *cmt;          // seq = one byte per base (post-replacement), ids/comments final streams
+    u8 *seq, *ids, *cmt;          // seq = one byte per base (post-replacement; protein / text), ids/comments final streams
+    u8 *packed; u32 *casebits;    // 4-bit sequence: packed codes and case bits of the shard's base stream (flush_pack); casebits may be null
     u64 *rec_begin, *rec_end;     // base index where record r's bases start / end
     u64 *unexpected;              // [3][257]
     u64 *longest;                 // max line length
@@ -409,6 +411,80 @@ __device__ __forceinline__ void flush_tile(u8 *dst, const u8 *stage, u32 n)
     }
     u32 done = head + 8 * words;
     if (threadIdx.x < n - done) dst[done + threadIdx.x] = stage[done + threadIdx.x];
+}
+
+// ---- 4-bit pack and case bits straight from the staged bases (encoders.c:30-69, tables.c:189-197) ------------------------------------
+// The base stream is cut into GROUPS of 16 bases: 8 packed bytes (base 2i in the low nibble, encoders.c:44-57) and 16 case bits
+// (bit i = base i is >= 96, the test of extract_mask, encoders.c:98-124).  A tile writes the groups that lie wholly inside it with
+// plain stores; the two groups it may share with its neighbours were zeroed by k_pack_edges_zero and take their part with an atomic OR.
+// Bytes in a 4-bit sequence stream are accepted letters, '-', the replacement 'N' and the '?' of a broken ID (process.c:366): the
+// table look-up on the low five bits is exact for those ('-' and '?' have bit 6 clear and differ in bit 4).
+__device__ __forceinline__ u32 nuc4x4(u32 x, const u32 *t)
+{
+    const u32 sel = x & 0x07070707u;
+    const u32 r0 = swar_perm(t[1], t[0], sel), r1 = swar_perm(t[3], t[2], sel), r2 = swar_perm(t[5], t[4], sel), r3 = swar_perm(t[7], t[6], sel);
+    const u32 m3 = ((x >> 3) & 0x01010101u) * 0xFFu, m4 = ((x >> 4) & 0x01010101u) * 0xFFu, m6 = ((x >> 6) & 0x01010101u) * 0xFFu;
+    const u32 lo = (r0 & ~m3) | (r1 & m3), hi = (r2 & ~m3) | (r3 & m3);
+    const u32 tab = (lo & ~m4) | (hi & m4);
+    return (tab & m6) | (m4 & 0x0F0F0F0Fu & ~m6);
+}
+// A C G T/U N in either case: the code sits in the slot (c >> 1) & 7 (A 0, C 1, T/U 2, G 3, N 7)
+__device__ __forceinline__ u32 nuc4x4_quick(u32 x) { return swar_perm(0x0F0F0F0Fu, 0x02010408u, (x >> 1) & 0x07070707u); }
+__device__ __forceinline__ u32 pack_codes8(u32 c0, u32 c1)               // eight codes, one per byte -> four packed bytes
+{
+    const u32 t0 = c0 | (c0 >> 4), t1 = c1 | (c1 >> 4);
+    return swar_perm(t1, t0, 0x06040200u);
+}
+__device__ __forceinline__ bool all_quick16(const u32 w[4], u32 qlo, u32 qhi)
+{
+    const u32 L = 0x7F7F7F7Fu; u32 bad = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { u32 x = w[i], r = swar_perm(qhi, qlo, (x >> 1) & 0x07070707u), d = r ^ (x & 0xDFDFDFDFu); bad |= ((d & L) + L) | d; }
+    return (bad & 0x80808080u) == 0;
+}
+template <bool KNOWN_QUICK>
+__device__ __forceinline__ void flush_pack(const EncP &P, u8 *packed, u32 *casebits, u64 tbase, u32 n, const u8 *stage /* 16-aligned, base tbase at stage[tbase & 15] */)
+{
+    if (!n) return;
+    const u32 o = (u32)(tbase & 15), span = o + n, ng = (span + 15) >> 4;
+    const u64 G0 = tbase >> 4;
+    for (u32 j = threadIdx.x; j < ng; j += blockDim.x) {
+        const uint4 v = *(const uint4 *)(stage + 16 * j);
+        const u32 w[4] = { v.x, v.y, v.z, v.w };
+        u32 cd[4];
+        if (KNOWN_QUICK || all_quick16(w, P.qlo, P.qhi)) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) cd[i] = nuc4x4_quick(w[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) cd[i] = nuc4x4(w[i], P.nuc32);
+        }
+        u64 pk = (u64)pack_codes8(cd[0], cd[1]) | ((u64)pack_codes8(cd[2], cd[3]) << 32);
+        const u32 H = 0x80808080u;
+        u32 cb = swar_movemask16((v.x | ((v.x << 1) & (v.x << 2))) & H, (v.y | ((v.y << 1) & (v.y << 2))) & H,
+                                 (v.z | ((v.z << 1) & (v.z << 2))) & H, (v.w | ((v.w << 1) & (v.w << 2))) & H);
+        const u32 a = j == 0 ? o : 0u, b = span - 16 * j < 16 ? span - 16 * j : 16u;
+        if (a == 0 && b == 16) {
+            *(u64 *)(packed + 8 * (G0 + j)) = pk;
+            if (casebits) ((u16 *)casebits)[G0 + j] = (u16)cb;
+        } else {
+            const u64 nm = (b == 16 ? ~0ull : ((1ull << (4 * b)) - 1)) & ~((1ull << (4 * a)) - 1);
+            cb &= ((1u << b) - 1) & ~((1u << a) - 1);
+            atomicOr((unsigned long long *)(packed + 8 * (G0 + j)), (unsigned long long)(pk & nm));
+            if (casebits) atomicOr(casebits + ((G0 + j) >> 1), cb << (16 * (u32)((G0 + j) & 1)));
+        }
+    }
+}
+// the groups a tile shares with its neighbours (and the last group of the stream, whose padding must read as zero)
+__global__ void k_pack_edges_zero(const u64 *t_seq, u64 tiles, u64 T, u8 *packed, u32 *casebits)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    const u64 b0 = t_seq[t], b1 = t + 1 < tiles ? t_seq[t + 1] : T;
+    if (b1 <= b0) return;
+    const u64 g0 = b0 >> 4, g1 = (b1 - 1) >> 4;
+    *(u64 *)(packed + 8 * g0) = 0; *(u64 *)(packed + 8 * g1) = 0;
+    if (casebits) { ((u16 *)casebits)[g0] = 0; ((u16 *)casebits)[g1] = 0; }
 }
 
 __device__ __forceinline__ u64 low_bytes(u32 n) { return n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1); }   // lowest n bytes set
@@ -460,6 +536,7 @@ struct WriteSink {
     __device__ void term(int st) { emit(st, 0); }
 };
 
+template <bool PACK>
 __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, EncOut O)
 {
     __shared__ u8 cls[256];
@@ -485,8 +562,8 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
     preb = 0;                                                     // the second pair shares the barrier of the line-start scan below
     ia += prea;
     u32 iseq = ia & 0xFFFF, iids = ia >> 16, tile_seq = tota & 0xFFFF;
-    __shared__ __attribute__((aligned(8))) u8 stage[ET_TILE + 16];
-    WriteSink W(O); W.stage = stage; W.tbase = O.t_seq[blockIdx.x];
+    __shared__ __attribute__((aligned(16))) u8 stage[ET_TILE + 48];
+    WriteSink W(O); W.tbase = O.t_seq[blockIdx.x]; W.stage = stage + (PACK ? (u32)(W.tbase & 15) : 0u);   // PACK: groups of 16 bases aligned in LDS
     W.bseq = W.tbase + iseq - C.nseq; W.bids = O.t_ids[blockIdx.x] + iids - C.nids;
     // base count at the start of the line this thread begins in: B at the most recent EOL before `base`.
     // Within the tile: B at an EOL is non-decreasing with position, so a running max over earlier threads works
@@ -524,10 +601,11 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
             if (k < 8) { u64 m = low_bytes(k); lo = (lo & m) | (slo & ~m); hi = shi; }
             else { u64 m = low_bytes(k - 8); hi = (hi & m) | (shi & ~m); }
         }
-        lds_store_n(stage + (W.bseq - W.tbase), lo, hi, C.nseq);
+        lds_store_n(W.stage + (W.bseq - W.tbase), lo, hi, C.nseq);
     } else if (active) { if (seg) classify_segments(P, base, pc, pm, ctx, W); else classify_range(P, base, pc, eof_here, ctx, W, cls); }
     __syncthreads();
-    flush_tile(O.seq + W.tbase, stage, tile_seq);
+    if (PACK) flush_pack<false>(P, O.packed, O.casebits, W.tbase, tile_seq, stage);
+    else flush_tile(O.seq + W.tbase, stage, tile_seq);
     __shared__ u64 s_best[4];
     u64 best = wg_reduce1<u64, OpMaxU64>(W.best, s_best);
     // millions of workgroups, one address: look before touching it atomically
@@ -542,6 +620,7 @@ enum { EV_QUAL = 3 };
 enum { FQ_E_AT = 0, FQ_E_PLUS = 1, FQ_E_QLEN = 2 };
 struct FqOut {
     u8 *seq, *ids, *cmt, *qual;
+    u8 *packed; u32 *casebits;    // as in EncOut
     u64 *rec_begin, *rec_end, *q_begin, *q_end;
     u64 *unexpected;              // [4][257]: id, comment, sequence, quality
     u64 *first_error;             // min over (record * 4 + kind)
@@ -779,6 +858,7 @@ __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol,
     if (threadIdx.x == 0) { t_seq[blockIdx.x] = tot & 0xFFFF; t_ids[blockIdx.x] = (tot >> 16) & 0xFFFF; t_cmt[blockIdx.x] = (tot >> 32) & 0xFFFF; t_qual[blockIdx.x] = tot >> 48; }
 }
 
+template <bool PACK>
 __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, FqOut O)
 {
     __shared__ u64 lds[4];
@@ -800,8 +880,9 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
     u64 totp;
     u64 ip = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq | ((u64)C.nids << 16) | ((u64)C.ncmt << 32) | ((u64)C.nqual << 48), &totp, lds);
     u64 iseq = ip & 0xFFFF, iids = (ip >> 16) & 0xFFFF, icmt = (ip >> 32) & 0xFFFF, iq = ip >> 48, tots = totp & 0xFFFF, totq = totp >> 48;
-    __shared__ __attribute__((aligned(8))) u8 sstage[ET_TILE + 16], qstage[ET_TILE + 16];
-    FqWrite W(O); W.sstage = sstage; W.qstage = qstage; W.sbase = O.t_seq[blockIdx.x]; W.qbase = O.t_qual[blockIdx.x];
+    __shared__ __attribute__((aligned(16))) u8 sstage0[ET_TILE + 48], qstage[ET_TILE + 16];
+    FqWrite W(O); W.qstage = qstage; W.sbase = O.t_seq[blockIdx.x]; W.qbase = O.t_qual[blockIdx.x];
+    u8 *const sstage = sstage0 + (PACK ? (u32)(W.sbase & 15) : 0u); W.sstage = sstage;
     W.bseq = O.t_seq[blockIdx.x] + iseq - C.nseq; W.bids = O.t_ids[blockIdx.x] + iids - C.nids;
     W.bcmt = O.t_cmt[blockIdx.x] + icmt - C.ncmt; W.bqual = O.t_qual[blockIdx.x] + iq - C.nqual;
     if (fast == 1) lds_store_n(sstage + (W.bseq - W.sbase), pc.w0, pc.w1, 16);
@@ -819,7 +900,8 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
         else classify_range_fastq(P, b2, p2, (b2 + p2.cnt == P.n) && p2.cnt < ET_BYTES, c2, W2, cls);
     }
     __syncthreads();
-    flush_tile(O.seq + W.sbase, sstage, (u32)tots);
+    if (PACK) flush_pack<false>(P, O.packed, O.casebits, W.sbase, (u32)tots, sstage0);
+    else flush_tile(O.seq + W.sbase, sstage, (u32)tots);
     flush_tile(O.qual + W.qbase, qstage, (u32)totq);
 }
 
@@ -853,50 +935,6 @@ __global__ void k_len_unit_write(const u64 *rec_begin, const u64 *rec_end, u64 N
 }
 
 // ---- soft mask: boundaries of (byte >= 96) runs -> u8 units with 255 continuation (encoders.c:98-146) -----------------------
-#define MB_TILE (256 * 16)
-__device__ __forceinline__ u32 mask_boundary_bits(const u8 *seq, u64 base, u64 T, bool prev0)
-{
-    // bit i set when base+i starts a new run, i.e. its case differs from the previous base.  prev0 = case in front of base 0:
-    // "unmasked" for a whole input (a masked first base opens a zero-length unmasked run, encoders.c:132), the case of the
-    // last base of the shards in front for a shard of one.
-    bool prev = base ? seq[base - 1] >= 96 : prev0;
-    if (base + 16 <= T) {
-        // byte >= 96 <=> bit 7 or (bit 6 and bit 5): the top bit of each byte, gathered to one bit per byte (base is 16-aligned, so is seq)
-        uint4 v = *(const uint4 *)(seq + base);
-        const u32 H = 0x80808080u;
-        u32 c = swar_movemask16((v.x | ((v.x << 1) & (v.x << 2))) & H, (v.y | ((v.y << 1) & (v.y << 2))) & H,
-                                (v.z | ((v.z << 1) & (v.z << 2))) & H, (v.w | ((v.w << 1) & (v.w << 2))) & H);
-        return (c ^ ((c << 1) | (prev ? 1u : 0u))) & 0xFFFFu;
-    }
-    u32 m = 0;
-    for (u32 i = 0; i < 16 && base + i < T; i++) { bool cur = seq[base + i] >= 96; if (cur != prev) m |= 1u << i; prev = cur; }
-    return m;
-}
-__global__ __launch_bounds__(256) void k_mask_bscatter(const u8 *seq, u64 T, const u64 *tile_pre, u64 nb, u64 *bnd, int prev0)
-{
-    __shared__ u64 lds[4];
-    // most tiles of most inputs hold no case change: those are not read a second time
-    if ((blockIdx.x + 1 < gridDim.x ? tile_pre[blockIdx.x + 1] : nb) == tile_pre[blockIdx.x]) return;
-    u64 base = (u64)blockIdx.x * MB_TILE + (u64)threadIdx.x * 16;
-    u32 m = base < T ? mask_boundary_bits(seq, base, T, prev0 != 0) : 0;
-    u64 c = __popc(m), tot;
-    u64 incl = wg_scan_inclusive<u64, OpAdd>(c, &tot, lds);
-    u64 k = tile_pre[blockIdx.x] + incl - c;
-    while (m) { int b = __ffs(m) - 1; m &= m - 1; bnd[k++] = base + b; }
-}
-// Shards of one input (naf_gpu_ennaf_shard_*): case changes INSIDE the shard (positions >= 1) per tile, their first and last
-// position, and the first / last base -- what the neighbours need to continue a run across the cut.
-// out: [0] first internal boundary (~0: none), [1] last internal boundary (0: none), [2] first base | last base << 8
-__global__ __launch_bounds__(256) void k_mask_census(const u8 *seq, u64 T, u64 *tile_cnt, unsigned long long *out)
-{
-    __shared__ u32 s_c[4];
-    u64 base = (u64)blockIdx.x * MB_TILE + (u64)threadIdx.x * 16;
-    u32 m = base < T ? mask_boundary_bits(seq, base, T, seq[0] >= 96) : 0;       // prev0 = the first base's own case: position 0 never counts
-    u32 tot = wg_reduce1<u32, OpAdd>((u32)__popc(m), s_c);
-    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
-    if (m) { atomicMin(&out[0], (unsigned long long)(base + (u32)__ffs((int)m) - 1)); atomicMax(&out[1], (unsigned long long)(base + 31 - __clz((int)m))); }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[2] = (unsigned long long)seq[0] | ((unsigned long long)seq[T - 1] << 8);
-}
 __global__ void k_add_u64(u64 *p, u64 v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += v; }
 // run r (0-based) spans [start_r, start_{r+1}) with start_0 = 0, start_{r} = bnd[r-1]; the last one ends at T + ext, ext = the
 // bases of the following shards that continue it (0 for a whole input).  skip0: run 0 -- the bases in front of this shard's first
@@ -917,56 +955,65 @@ __global__ void k_mask_units_write(const u64 *bnd, u64 nb, u64 T, const u64 *uni
     out[unit_off[r] + len / 255] = (u8)(len % 255);
 }
 
-// ---- 4-bit pack (encoders.c:30-69, tables.c:189-197) ---------------------------------------------------------------------------
-__device__ __forceinline__ u32 nuc4(u32 c)
+// ---- the same scan over the case BITS that flush_pack leaves for a 4-bit stream: 64 bases per lane, 16384 per tile -------------------
+#define MBB_TILE (256 * 64)
+__device__ __forceinline__ u64 maskb_bits(const u64 *cb, u64 i, u64 T, bool prev0)    // boundaries among bases 64 i .. 64 i + 63
 {
-    // "-TGKCYSBAWRDMHVN" inverse; U == T; everything else 15
-    switch (c & ~0x20u) {
-    case 'A': return 8; case 'C': return 4; case 'G': return 2; case 'T': case 'U': return 1;
-    case 'N': return 15; case 'R': return 10; case 'Y': return 5; case 'S': return 6; case 'W': return 9;
-    case 'K': return 3; case 'M': return 12; case 'B': return 7; case 'D': return 11; case 'H': return 13; case 'V': return 14;
-    default: break;
-    }
-    if (c == '-') return 0;
-    return 15;
+    const u64 w = cb[i];
+    const u64 prev = i ? cb[i - 1] >> 63 : (prev0 ? 1ull : 0ull);
+    u64 m = w ^ ((w << 1) | prev);
+    if (T - 64 * i < 64) m &= (1ull << (T - 64 * i)) - 1;
+    return m;
 }
-// With tile_cnt the kernel also counts the soft-mask run boundaries of its 4096 bases (k_mask_bcount's job): both walk the same bytes.
-// The pack window starts `skip` (0 or 1) bases into the stream: the first base of a shard whose global base index is odd is the
-// high nibble of the previous shard's last byte (encoders.c:30-69 keeps that half byte in `parity` between chunks); `tail_hi` is
-// the code that completes this shard's own last byte when its window is odd (the next shard's first base; 0 at the end of the data,
-// ennaf.c:525-529).
-__global__ __launch_bounds__(256) void k_pack4(const u8 *seq, u64 T, u8 *packed, u64 *tile_cnt, u32 skip, u32 tail_hi)
+__global__ __launch_bounds__(256) void k_maskb_count(const u64 *cb, u64 T, u64 *tile_cnt, int prev0)
 {
-    __shared__ u8 lut[256];
-    if (tile_cnt) {
-        __shared__ u32 s_c[4];
-        u64 base = (u64)blockIdx.x * MB_TILE + (u64)threadIdx.x * 16;
-        u32 tot = wg_reduce1<u32, OpAdd>(base < T ? (u32)__popc(mask_boundary_bits(seq, base, T, false)) : 0u, s_c);
-        if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
-    }
-    { u32 c = threadIdx.x; u32 v = nuc4(c); if (!((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '-')) v = 15; lut[c] = (u8)v; }
-    __syncthreads();
-    seq += skip; T -= skip;                                      // (T >= skip: the host launches nothing for an empty window)
-    u64 i = ((u64)blockIdx.x * 256 + threadIdx.x) * 16;      // 16 bases -> 8 bytes
-    if (i >= T) return;
-    u64 out = 0;
-    if (i + 16 <= T) {
-        u64 a = ld64(seq + i), b = ld64(seq + i + 8);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            u32 lo0 = lut[(a >> (16 * k)) & 0xFF], hi0 = lut[(a >> (16 * k + 8)) & 0xFF];
-            u32 lo1 = lut[(b >> (16 * k)) & 0xFF], hi1 = lut[(b >> (16 * k + 8)) & 0xFF];
-            out |= (u64)(lo0 | (hi0 << 4)) << (8 * k);
-            out |= (u64)(lo1 | (hi1 << 4)) << (8 * (k + 4));
-        }
-        st64(packed + i / 2, out);
-    } else {
-        for (u64 k = i; k < T; k += 2) {
-            u32 lo = lut[seq[k]], hi = k + 1 < T ? lut[seq[k + 1]] : tail_hi;
-            packed[k / 2] = (u8)(lo | (hi << 4));
-        }
-    }
+    __shared__ u32 s_c[4];
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    u32 tot = wg_reduce1<u32, OpAdd>(64 * i < T ? (u32)__popcll(maskb_bits(cb, i, T, prev0 != 0)) : 0u, s_c);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
 }
+__global__ __launch_bounds__(256) void k_maskb_scatter(const u64 *cb, u64 T, const u64 *tile_pre, u64 nb, u64 *bnd, int prev0)
+{
+    __shared__ u64 lds[4];
+    if ((blockIdx.x + 1 < gridDim.x ? tile_pre[blockIdx.x + 1] : nb) == tile_pre[blockIdx.x]) return;
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    u64 m = 64 * i < T ? maskb_bits(cb, i, T, prev0 != 0) : 0;
+    u64 c = (u64)__popcll(m), tot;
+    u64 incl = wg_scan_inclusive<u64, OpAdd>(c, &tot, lds);
+    u64 k = tile_pre[blockIdx.x] + incl - c;
+    while (m) { int b = __ffsll((unsigned long long)m) - 1; m &= m - 1; bnd[k++] = 64 * i + (u32)b; }
+}
+// the census of a shard (see k_mask_census): position 0 never counts
+__global__ __launch_bounds__(256) void k_maskb_census(const u64 *cb, u64 T, u64 *tile_cnt, unsigned long long *out)
+{
+    __shared__ u32 s_c[4];
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    u64 m = 64 * i < T ? maskb_bits(cb, i, T, (cb[0] & 1) != 0) : 0;
+    u32 tot = wg_reduce1<u32, OpAdd>((u32)__popcll(m), s_c);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+    if (m) { atomicMin(&out[0], (unsigned long long)(64 * i + (u32)__ffsll((unsigned long long)m) - 1)); atomicMax(&out[1], (unsigned long long)(64 * i + 63 - (u32)__clzll((long long)m))); }
+}
+// first and last base of a packed stream as letters (upper case from the table of unnaf.c:13, lower when the case bit is set)
+__global__ void k_packed_ends(const u8 *packed, const u64 *cb, u64 T, unsigned long long *out)
+{
+    if (threadIdx.x || blockIdx.x || !T) return;
+    const char *tab = "-TGKCYSBAWRDMHVN";
+    const u32 c0 = packed[0] & 15, c1 = (packed[(T - 1) >> 1] >> (4 * ((T - 1) & 1))) & 15;
+    u32 a = (u32)tab[c0], b = (u32)tab[c1];
+    if (cb) { if (c0 && (cb[0] & 1)) a |= 0x20; if (c1 && ((cb[(T - 1) >> 6] >> ((T - 1) & 63)) & 1)) b |= 0x20; }
+    *out = (unsigned long long)a | ((unsigned long long)b << 8);
+}
+// The pack window of a shard whose first base completes the previous shard's last byte (encoders.c:30-69 keeps that half byte in
+// `parity` between chunks): every code moves down one nibble.  n_in = bytes of the shard's own packed stream.
+__global__ void k_nibble_shift(const u8 *in, u64 n_in, u8 *out, u64 n_out)
+{
+    const u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= n_out) return;
+    if (i + 9 <= n_in && i + 8 <= n_out) { const u64 a = ld64(in + i); st64(out + i, (a >> 4) | ((u64)in[i + 8] << 60)); return; }
+    for (u64 k = i; k < n_out && k < i + 8; k++) { u32 lo = in[k] >> 4, hi = k + 1 < n_in ? in[k + 1] & 15u : 0u; out[k] = (u8)(lo | (hi << 4)); }
+}
+__global__ void k_set_high_nibble(u8 *p, u32 code) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = (u8)((*p & 15u) | (code << 4)); }
+
 __global__ void k_toupper(u8 *p, u64 n)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1049,6 +1096,17 @@ static size_t vle(u64 v, u8 *out)                                 // encoders.c:
 
 extern "C" size_t naf_gpu_ennaf_bound(size_t n) { return n + n / 1024 + (1 << 16); }
 
+// host-side copy of nuc4 (the high nibble a shard borrows from its neighbour's first base)
+static u32 nuc4_host(u32 c)
+{
+    static const char tab[] = "-TGKCYSBAWRDMHVN";
+    if (c == '-') return 0;
+    u32 u = c & ~0x20u;
+    if (u == 'U') return 1;
+    if (u >= 'A' && u <= 'Z') for (u32 k = 1; k < 16; k++) if ((u32)tab[k] == u) return k;
+    return 15;
+}
+
 static void set_expected(EncP &P, int seq_type, bool fasta)
 {
     memset(P.expected, 0, sizeof P.expected);
@@ -1066,22 +1124,12 @@ static void set_expected(EncP &P, int seq_type, bool fasta)
         P.id_gt_unexpected = fasta;
         // mid-line '>' is kept as data in text mode (process.c:410); a '>' right after an EOL starts a record
     }
+    { u8 t[32]; for (u32 i = 0; i < 32; i++) t[i] = (i >= 1 && i <= 26) ? (u8)nuc4_host(0x40u + i) : 15; memcpy(P.nuc32, t, 32); }
     // quick table (enc_swar.h): slot (c >> 1) & 7 holds the accepted upper-case letter out of A C G T U N, 0xFF elsewhere
     u8 q[8]; memset(q, 0xFF, 8);
     auto has = [&](u32 c) { return (P.expected[c >> 5] >> (c & 31)) & 1u; };
     for (const char *p = "ACGTUN"; *p; p++) { u32 ch = (u32)*p; if (has(ch) && has(ch | 0x20) && q[(ch >> 1) & 7] == 0xFF) q[(ch >> 1) & 7] = (u8)ch; }
     memcpy(&P.qlo, q, 4); memcpy(&P.qhi, q + 4, 4);
-}
-
-// host-side copy of nuc4 (the high nibble a shard borrows from its neighbour's first base)
-static u32 nuc4_host(u32 c)
-{
-    static const char tab[] = "-TGKCYSBAWRDMHVN";
-    if (c == '-') return 0;
-    u32 u = c & ~0x20u;
-    if (u == 'U') return 1;
-    if (u >= 'A' && u <= 'Z') for (u32 k = 1; k < 16; k++) if ((u32)tab[k] == u) return k;
-    return 15;
 }
 
 // confirm_input_format (process.c:547-583): first non-space byte, the byte in front of it
@@ -1107,7 +1155,8 @@ static int ennaf_sniff(naf_gpu_ctx *c, const u8 *d_text, u64 n, int want_format,
 enum { SE_NONE = 0, SE_AT, SE_PLUS, SE_QLEN, SE_NOSEQ, SE_NOQUAL, SE_STRICT };
 struct EnnafSplit {
     int format, seq_type; bool fourbit, store_mask, store_qual, no_mask;
-    u8 *bases, *s_ids, *s_cmt, *s_qual;
+    u8 *bases, *s_ids, *s_cmt, *s_qual;                        // bases: one byte per base (protein / text only)
+    u8 *packed; u64 *casebits;                                 // 4-bit: codes of the shard's own base stream (base 0 in the low nibble of byte 0), case bits (store_mask)
     u64 n_ids, n_cmt, n_qual, T, N, longest, lead;
     u64 *rec_begin, *rec_end; int all_ends;
     u64 unexpected[4][257];
@@ -1133,6 +1182,17 @@ static int split_error_text(naf_gpu_ctx *c, int seq_type, int kind, u32 ch, u64 
         return ctx_fail(c, NAF_GPU_EINPUT, "unexpected quality code '%c' in sequence %llu\n", (int)(unsigned char)ch, r);
     default: return 0;
     }
+}
+
+// where the bases go: packed codes (+ case bits when the mask is stored) for a 4-bit stream, one byte per base otherwise
+static int alloc_bases(naf_gpu_ctx *c, EnnafSplit &S)
+{
+    if (S.fourbit) {
+        S.packed = (u8 *)arena_alloc(c, (S.T + 1) / 2 + 64);
+        if (!S.packed) return NAF_GPU_ENOMEM;
+        if (S.store_mask) { S.casebits = (u64 *)arena_alloc(c, (S.T + 63) / 64 * 8 + 64); if (!S.casebits) return NAF_GPU_ENOMEM; }
+    } else { S.bases = (u8 *)arena_alloc(c, S.T + 64); if (!S.bases) return NAF_GPU_ENOMEM; }
+    return 0;
 }
 
 // The split pass (E1-E4): text -> ids, comments, bases (1 B/base, post-replacement), quality, record table.  p0 = first byte of
@@ -1176,22 +1236,25 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         u64 nlines = h[4]; N = (nlines + 3) / 4;
         // truncated input (process.c:499,510,513,517,520)
         if (nlines % 4 == 1 && !(lastb >= 0x0A && lastb <= 0x0D)) { S.err_kind = SE_NOSEQ; return 0; }
-        bases = (u8 *)arena_alloc(c, T + 64);
+        if ((rc = alloc_bases(c, S))) return rc;
         s_ids = (u8 *)arena_alloc(c, n_ids + 16); s_cmt = (u8 *)arena_alloc(c, n_cmt + 16); s_qual = (u8 *)arena_alloc(c, n_qual + 16);
         rec_begin = arena_new<u64>(c, N + 1); rec_end = arena_new<u64>(c, N + 1);
         u64 *q_begin = arena_new<u64>(c, N + 1), *q_end = arena_new<u64>(c, N + 1);
         const size_t NU = 4 * 257 + 3;                                                             // histograms, first_error, longest, strict key
         u64 *d_unexp = arena_new<u64>(c, NU);
-        if (!bases || !s_ids || !s_cmt || !s_qual || !rec_begin || !rec_end || !q_begin || !q_end || !d_unexp) return NAF_GPU_ENOMEM;
+        if (!s_ids || !s_cmt || !s_qual || !rec_begin || !rec_end || !q_begin || !q_end || !d_unexp) return NAF_GPU_ENOMEM;
         HIP_TRY(c, hipMemsetAsync(d_unexp, 0, NU * 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(d_unexp + 4 * 257, 0xFF, 8, c->stream));                        // first_error = none
         HIP_TRY(c, hipMemsetAsync(d_unexp + 4 * 257 + 2, 0xFF, 8, c->stream));                    // strict key = none
         HIP_TRY(c, hipMemsetAsync(rec_begin, 0, (N + 1) * 8, c->stream)); HIP_TRY(c, hipMemsetAsync(rec_end, 0, (N + 1) * 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(q_begin, 0, (N + 1) * 8, c->stream)); HIP_TRY(c, hipMemsetAsync(q_end, 0, (N + 1) * 8, c->stream));
-        FqOut O; O.seq = bases; O.ids = s_ids; O.cmt = s_cmt; O.qual = s_qual; O.rec_begin = rec_begin; O.rec_end = rec_end; O.q_begin = q_begin; O.q_end = q_end;
+        FqOut O; O.seq = bases; O.packed = S.packed; O.casebits = (u32 *)S.casebits; O.ids = s_ids; O.cmt = s_cmt; O.qual = s_qual; O.rec_begin = rec_begin; O.rec_end = rec_end; O.q_begin = q_begin; O.q_end = q_end;
         O.unexpected = d_unexp; O.first_error = d_unexp + 4 * 257; O.strict_first = o->strict ? d_unexp + 4 * 257 + 2 : nullptr;
         O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_qual = t_qual; O.t_ls = t_ls; O.piece_cnt = piece_cnt;
-        LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+        if (S.fourbit) {
+            if (T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(tiles, 256), 256, 0, (const u64 *)t_seq, tiles, T, S.packed, (u32 *)S.casebits);
+            LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter<true>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+        } else LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter<false>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
         if (nlines / 4) LAUNCH(c, "ennaf_fq_check", k_fq_check, cdiv(nlines / 4, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, (const u64 *)q_begin, (const u64 *)q_end, nlines / 4, O.first_error, d_unexp + 4 * 257 + 1);
         std::vector<u64> hu(NU);
         if ((rc = ctx_readback(c, hu.data(), d_unexp, NU * 8))) return rc;
@@ -1258,19 +1321,22 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         u64 h[4];
         if ((rc = ctx_readback(c, h, tot, 32))) return rc;
         T = h[0]; n_ids = h[1]; n_cmt = h[2]; N = h[3];
-        bases = (u8 *)arena_alloc(c, T + 64);
+        if ((rc = alloc_bases(c, S))) return rc;
         s_ids = (u8 *)arena_alloc(c, n_ids + 16); s_cmt = (u8 *)arena_alloc(c, n_cmt + 16);
         rec_begin = arena_new<u64>(c, N + 1); rec_end = arena_new<u64>(c, N + 1);
         const size_t NU = 3 * 257 + 3;                                                             // histograms, longest, strict key, lead
         u64 *d_unexp = arena_new<u64>(c, NU);
-        if (!bases || !s_ids || !s_cmt || !rec_begin || !rec_end || !d_unexp) return NAF_GPU_ENOMEM;
+        if (!s_ids || !s_cmt || !rec_begin || !rec_end || !d_unexp) return NAF_GPU_ENOMEM;
         HIP_TRY(c, hipMemsetAsync(d_unexp, 0, NU * 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(d_unexp + 3 * 257 + 1, 0xFF, 8, c->stream));                    // strict key = none
         HIP_TRY(c, hipMemsetAsync(rec_begin, 0, (N + 1) * 8, c->stream));
-        EncOut O; O.seq = bases; O.ids = s_ids; O.cmt = s_cmt; O.rec_begin = rec_begin; O.rec_end = rec_end;
+        EncOut O; O.seq = bases; O.packed = S.packed; O.casebits = (u32 *)S.casebits; O.ids = s_ids; O.cmt = s_cmt; O.rec_begin = rec_begin; O.rec_end = rec_end;
         O.unexpected = d_unexp; O.longest = d_unexp + 3 * 257; O.strict_first = o->strict ? d_unexp + 3 * 257 + 1 : nullptr; O.lead = d_unexp + 3 * 257 + 2;
         O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_rec = t_rec; O.t_tail = t_tail; O.tile_eol = t_eol;
-        LAUNCH(c, "ennaf_scatter", k_enc_scatter, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+        if (S.fourbit) {
+            if (T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(tiles, 256), 256, 0, (const u64 *)t_seq, tiles, T, S.packed, (u32 *)S.casebits);
+            LAUNCH(c, "ennaf_scatter", k_enc_scatter<true>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+        } else LAUNCH(c, "ennaf_scatter", k_enc_scatter<false>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
         std::vector<u64> hu(NU);
         if ((rc = ctx_readback(c, hu.data(), d_unexp, NU * 8))) return rc;
         const u64 sk = hu[3 * 257 + 1];
@@ -1319,29 +1385,35 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
             LAUNCH(c, "ennaf_len_write", k_len_unit_write, cdiv(N, 256), 256, 0, (const u64 *)S.rec_begin, (const u64 *)S.rec_end, N, total, (const u64 *)lu, s_len, S.all_ends);
             n_lenb = nu * 4;
         }
-        // sequence stream; for a whole input the 4-bit pack also counts the soft-mask run boundaries per tile of 4096 bases (a shard
-        // has counted them in its census already)
-        u64 mt = (T + MB_TILE - 1) / MB_TILE;
+        // sequence stream: flush_pack has left the codes of the shard's own base stream; a shard whose first base belongs to its
+        // neighbour's last byte moves them down a nibble, and an odd window borrows its last high nibble (ennaf.c:525-529: 0 at the end)
+        const u64 mt = (T + MBB_TILE - 1) / MBB_TILE;
         u64 *tc = S.tc;
-        if (S.store_mask && T && !S.census) { tc = arena_new<u64>(c, mt + 2); if (!tc) return NAF_GPU_ENOMEM; }
         if (S.fourbit) {
             const u64 Tp = T > K.skip_first ? T - K.skip_first : 0;                                // bases of the pack window
             n_seqb = (Tp + 1) / 2;
-            s_seq = (u8 *)arena_alloc(c, n_seqb + 16); if (!s_seq) return NAF_GPU_ENOMEM;
-            if (T) LAUNCH(c, "ennaf_pack4", k_pack4, cdiv(T, 256 * 16), 256, 0, (const u8 *)S.bases, T, s_seq, S.census ? (u64 *)nullptr : tc, K.skip_first, K.tail_hi);
+            if (K.skip_first && n_seqb) {
+                s_seq = (u8 *)arena_alloc(c, n_seqb + 16); if (!s_seq) return NAF_GPU_ENOMEM;
+                LAUNCH(c, "ennaf_nibble_shift", k_nibble_shift, cdiv(cdiv(n_seqb, 8), 256), 256, 0, (const u8 *)S.packed, (T + 1) / 2, s_seq, n_seqb);
+            } else s_seq = S.packed;
+            if ((Tp & 1) && K.tail_hi) LAUNCH(c, "ennaf_tail_nibble", k_set_high_nibble, 1, 64, 0, s_seq + n_seqb - 1, K.tail_hi);
         } else {
             if (S.no_mask && T) LAUNCH(c, "ennaf_toupper", k_toupper, cdiv(T, 256), 256, 0, S.bases, T);   // process.c:46-51
             s_seq = S.bases; n_seqb = T;
         }
-        // mask (only ever stored next to a 4-bit sequence stream, ennaf.c:445)
+        // mask (only ever stored next to a 4-bit sequence stream, ennaf.c:445); a shard has counted its boundaries in the census already
         if (S.store_mask && T) {
+            if (!S.census) {
+                tc = arena_new<u64>(c, mt + 2); if (!tc) return NAF_GPU_ENOMEM;
+                LAUNCH(c, "ennaf_mask_count", k_maskb_count, mt, 256, 0, (const u64 *)S.casebits, T, tc, 0);
+            }
             const int b0 = S.census ? ((S.first_base >= 96) != (K.prev_masked != 0)) : 0;          // a shard's case change at its first base
             if (b0) LAUNCH(c, "ennaf_mask_b0", k_add_u64, 1, 64, 0, tc, (u64)1);
             if ((rc = scan_exclusive_u64(c, tc, mt, tc + mt + 1))) return rc;
             u64 nb = 0; if ((rc = ctx_readback(c, &nb, tc + mt + 1, 8))) return rc;
             u64 *bnd = arena_new<u64>(c, nb + 1), *ru = arena_new<u64>(c, nb + 3);
             if (!bnd || !ru) return NAF_GPU_ENOMEM;
-            if (nb) LAUNCH(c, "ennaf_mask_bscatter", k_mask_bscatter, mt, 256, 0, (const u8 *)S.bases, T, (const u64 *)tc, nb, bnd, K.prev_masked);
+            if (nb) LAUNCH(c, "ennaf_mask_bscatter", k_maskb_scatter, mt, 256, 0, (const u64 *)S.casebits, T, (const u64 *)tc, nb, bnd, K.prev_masked);
             LAUNCH(c, "ennaf_mask_runs", k_mask_run_units, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, ru, K.run_ext, K.skip_run0);
             if ((rc = scan_exclusive_u64(c, ru, nb + 1, ru + nb + 2))) return rc;
             u64 nu = 0; if ((rc = ctx_readback(c, &nu, ru + nb + 2, 8))) return rc;
@@ -1528,13 +1600,14 @@ extern "C" int naf_gpu_ennaf_shard_begin(naf_gpu_ctx *c, const void *d_slice, si
     S.census = true; S.mask_first = ~0ull;
     if (S.T) {
         if (S.store_mask) {
-            const u64 mt = (S.T + MB_TILE - 1) / MB_TILE;
+            const u64 mt = (S.T + MBB_TILE - 1) / MBB_TILE;
             S.tc = arena_new<u64>(c, mt + 2); unsigned long long *d_o = arena_new<unsigned long long>(c, 3);
             if (!S.tc || !d_o) return NAF_GPU_ENOMEM;
             u64 init[3] = { ~0ull, 0, 0 };
             HIP_TRY(c, hipMemcpyAsync(d_o, init, 24, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            LAUNCH(c, "ennaf_mask_census", k_mask_census, mt, 256, 0, (const u8 *)S.bases, S.T, S.tc, d_o);
+            LAUNCH(c, "ennaf_mask_census", k_maskb_census, mt, 256, 0, (const u64 *)S.casebits, S.T, S.tc, d_o);
+            LAUNCH(c, "ennaf_ends", k_packed_ends, 1, 64, 0, (const u8 *)S.packed, (const u64 *)S.casebits, S.T, d_o + 2);
             u64 *d_tot = arena_new<u64>(c, 1); if (!d_tot) return NAF_GPU_ENOMEM;
             u64 got[3]; if ((rc = ctx_readback(c, got, d_o, 24))) return rc;
             S.mask_first = got[0]; S.mask_last = got[1]; S.first_base = (u8)got[2]; S.last_base = (u8)(got[2] >> 8);
@@ -1543,6 +1616,11 @@ extern "C" int naf_gpu_ennaf_shard_begin(naf_gpu_ctx *c, const void *d_slice, si
             HIP_TRY(c, hipMemcpyAsync(tmp, S.tc, mt * 8, hipMemcpyDeviceToDevice, c->stream));
             if ((rc = scan_exclusive_u64(c, tmp, mt, d_tot))) return rc;
             if ((rc = ctx_readback(c, &S.mask_changes, d_tot, 8))) return rc;
+        } else if (S.fourbit) {
+            unsigned long long *d_o = arena_new<unsigned long long>(c, 1); if (!d_o) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "ennaf_ends", k_packed_ends, 1, 64, 0, (const u8 *)S.packed, (const u64 *)nullptr, S.T, d_o);
+            u64 got = 0; if ((rc = ctx_readback(c, &got, d_o, 8))) return rc;
+            S.first_base = (u8)got; S.last_base = (u8)(got >> 8);
         } else {
             if ((rc = ctx_readback2(c, &S.first_base, S.bases, 1, &S.last_base, S.bases + S.T - 1, 1))) return rc;
         }
