@@ -326,14 +326,55 @@ __device__ __forceinline__ bool seq_piece(const EncP &P, u64 base, const Piece &
 }
 
 // ---- K2: per-tile stream byte counts -----------------------------------------------------------------------------------
+// A PURE tile -- wholly inside [p0, n), beginning outside a header line and holding no '>' -- is sequence lines and nothing else:
+// every piece takes the popcount path, no lane needs its own running maxima (thread_ctx) and nothing is added to ids, comments or
+// the record table.  Long-record FASTA is pure tiles almost everywhere; the test is workgroup-uniform.
+__device__ __forceinline__ bool tile_may_be_pure(const EncP &P, const i64 *tile_eol)
+{
+    const u64 tb = (u64)blockIdx.x * ET_TILE;
+    if (tb < P.p0 || tb + ET_TILE > P.n) return false;
+    const i64 le0 = blockIdx.x ? tile_eol[blockIdx.x - 1] : -1;                // thread_ctx's c.hdr for a lane with no EOL in front of it in the tile
+    const u64 ls0 = (u64)(le0 + 1);
+    return !(ls0 < P.n && P.text[ls0] == '>');
+}
+// bases of the piece behind its last EOL byte (all of them when it has none)
+__device__ __forceinline__ u32 piece_tail_bases(const PMask &pm)
+{
+    return pm.eol ? (u32)__popc(~pm.sp & 0xFFFFu & ~((2u << (31 - __clz((int)pm.eol))) - 1)) : 16u - (u32)__popc(pm.sp);
+}
+
 __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, const i64 *tile_sp,
                                                     u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail)
 {
     __shared__ u8 cls[256];
-    fill_classes(P, cls);
+    __shared__ u32 s_a[4], s_b[4], s_last[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool maybe = tile_may_be_pure(P, tile_eol);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
     PMask pm = piece_masks(pc);
+    {
+        // per wave: bases, and bases behind the wave's last EOL, in one packed reduction
+        const u32 nseq = 16u - (u32)__popc(pm.sp);
+        const u64 bal = __ballot(pm.eol != 0);
+        const int lastl = bal ? 63 - __clzll((long long)bal) : -1;
+        const u32 after = lane > lastl ? nseq : (lane == lastl ? piece_tail_bases(pm) : 0u);
+        const u32 red = wave_scan_inclusive<u32, OpAdd>(nseq | (after << 16));
+        const bool wave_gt = __ballot(pm.gt != 0) != 0;
+        if (lane == 63) { s_a[wave] = red; s_last[wave] = (bal ? 1u : 0u) | (wave_gt ? 2u : 0u); }
+    }
+    __syncthreads();
+    if (maybe && !((s_last[0] | s_last[1] | s_last[2] | s_last[3]) & 2u)) {
+        if (threadIdx.x == 0) {
+            u32 tot = 0, tail = 0; bool found = false;
+#pragma unroll
+            for (int w = 3; w >= 0; w--) { tot += s_a[w] & 0xFFFF; if (!found) { tail += s_a[w] >> 16; found = (s_last[w] & 1u) != 0; } }
+            t_seq[blockIdx.x] = tot; t_ids[blockIdx.x] = 0; t_cmt[blockIdx.x] = 0; t_rec[blockIdx.x] = 0;
+            t_tail[blockIdx.x] = found ? (tail | 0x80000000u) : tot;
+        }
+        return;
+    }
+    fill_classes(P, cls);                                         // (its barrier also separates the reads of s_a / s_last above from the writes below)
     TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, pm);
     CountSink S;
     if (seq_piece(P, base, pc, pm, ctx)) {
@@ -349,8 +390,6 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
     // four counts in two scans of packed 16-bit fields (a tile holds 4096 bytes, a byte adds at most 2 to a field); the tail of
     // the tile -- sequence bytes after its last EOL, the whole tile if it has none -- falls out of the same scan: the last
     // thread that saw an EOL knows how many bases follow it.
-    __shared__ u32 s_a[4], s_b[4], s_last[4];
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u32 wa = wave_scan_inclusive<u32, OpAdd>(S.nseq | (S.nids << 16)), wb = wave_scan_inclusive<u32, OpAdd>(S.ncmt | (S.nrec << 16));
     u64 bal = __ballot(S.saw_eol);
     if (lane == 63) { s_a[wave] = wa; s_b[wave] = wb; }
@@ -536,14 +575,95 @@ struct WriteSink {
     __device__ void term(int st) { emit(st, 0); }
 };
 
+// base count at the start of the line in progress where the tile begins (the line began in an earlier tile t', the one holding the
+// last EOL in front of this tile: B = t_seq[t'+1] - tail(t'))
+__device__ __forceinline__ u64 tile_line_base(const EncP &P, const EncOut &O, const i64 *tile_eol)
+{
+    const i64 le = blockIdx.x ? tile_eol[blockIdx.x - 1] : -1;
+    if (le < 0 || (u64)(le + 1) <= P.p0) return 0;
+    const u64 tp = (u64)le / ET_TILE;
+    return O.t_seq[tp + 1] - (O.t_tail[tp] & 0x7FFFFFFFu);
+}
+
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, EncOut O)
 {
-    __shared__ u8 cls[256];
-    fill_classes(P, cls);
-    u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
+    __shared__ __attribute__((aligned(16))) u8 stage[ET_TILE + 48];
+    __shared__ u32 s_a[4], s_b[4], s_l[4];
+    __shared__ u64 s_best[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
+    const bool maybe = tile_may_be_pure(P, tile_eol);
+    const u64 tbase = O.t_seq[blockIdx.x];
+    const u64 line_b0 = tile_line_base(P, O, tile_eol);
     Piece pc = load_piece(P, base);
     PMask pm = piece_masks(pc);
+    // ---- a pure tile (see k_enc_count) of A C G T/U N: prefix of the base counts, the line lengths from the lanes that hold an EOL,
+    // bases to LDS, packed codes and case bits out.  No per-lane context, no class table, two barriers.
+    {
+        const u32 w[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) };
+        const bool lane_bad = pm.gt != 0 || (piece_not_quick(w, P.qlo, P.qhi) & ~pm.sp) != 0;
+        const u32 nseq = 16u - (u32)__popc(pm.sp);
+        const u32 incl = wave_scan_inclusive<u32, OpAdd>(nseq);
+        const bool has = pm.eol != 0;
+        const u64 bal = __ballot(has);
+        const int lastl = bal ? 63 - __clzll((long long)bal) : -1;
+        const u32 tail = piece_tail_bases(pm);
+        const u32 ew = incl - tail;                               // wave-relative base count at this lane's last EOL (when it has one)
+        const bool wave_bad = __ballot(lane_bad) != 0;
+        if (lane == 63) { s_a[wave] = incl; s_l[wave] = (bal ? 1u : 0u) | (wave_bad ? 2u : 0u); }
+        if (lane == lastl) s_b[wave] = ew;
+        __syncthreads();
+        if (PACK && maybe && !((s_l[0] | s_l[1] | s_l[2] | s_l[3]) & 2u)) {
+            u32 pre = 0, tile_seq = 0;
+#pragma unroll
+            for (int v = 0; v < 4; v++) { if (v < wave) pre += s_a[v]; tile_seq += s_a[v]; }
+            const u32 ex = pre + incl - nseq;                     // tile-relative index of this lane's first base
+            u32 best = 0;
+            if (has) {
+                // base count at the EOL in front of this lane's first one: an earlier lane of the wave, an earlier wave, or the carry
+                const u64 mlow = bal & ((1ull << lane) - 1);
+                const u32 eprev = (u32)__shfl((int)ew, mlow ? 63 - __clzll((long long)mlow) : lane, 64);
+                bool in_tile = mlow != 0; u32 lb = pre + eprev;
+                if (!in_tile) {
+                    u32 pv = 0;
+#pragma unroll
+                    for (int v = 0; v < 3; v++) { if (v < wave && (s_l[v] & 1u)) { in_tile = true; lb = pv + s_b[v]; } pv += s_a[v]; }
+                }
+                u32 e = pm.eol; bool first = true;
+                while (e) {                                       // line ends inside the piece (usually one)
+                    const u32 k = (u32)__ffs((int)e) - 1; e &= e - 1;
+                    const u32 b_here = ex + (u32)__popc(~pm.sp & ((1u << k) - 1));
+                    if (first && !in_tile) {                      // the line began in front of the tile: 64-bit, once per tile
+                        const u64 len = tbase + b_here - line_b0;
+                        if (len > __atomic_load_n(O.longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)O.longest, (unsigned long long)len);
+                    } else { const u32 len = b_here - lb; best = len > best ? len : best; }
+                    lb = b_here; first = false;
+                }
+            }
+            best = wave_scan_inclusive<u32, OpMaxU32>(best);
+            if (lane == 63) s_best[wave] = best;
+            // drop the space-class bytes (highest first, so lower positions stay put) and park the bases in LDS
+            u64 lo = pc.w0, hi = pc.w1; u32 d = pm.sp;
+            while (d) {
+                const u32 k = 31 - __clz((int)d); d &= ~(1u << k);
+                const u64 slo = (lo >> 8) | (hi << 56), shi = hi >> 8;
+                if (k < 8) { const u64 m = low_bytes(k); lo = (lo & m) | (slo & ~m); hi = shi; }
+                else { const u64 m = low_bytes(k - 8); hi = (hi & m) | (shi & ~m); }
+            }
+            lds_store_n(stage + (u32)(tbase & 15) + ex, lo, hi, nseq);
+            __syncthreads();
+            flush_pack<true>(P, O.packed, O.casebits, tbase, tile_seq, stage);
+            if (threadIdx.x == 0) {
+                u64 b4 = s_best[0] > s_best[1] ? s_best[0] : s_best[1], b5 = s_best[2] > s_best[3] ? s_best[2] : s_best[3];
+                b4 = b4 > b5 ? b4 : b5;
+                if (b4 > __atomic_load_n(O.longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)O.longest, (unsigned long long)b4);
+            }
+            return;
+        }
+    }
+    __shared__ u8 cls[256];
+    fill_classes(P, cls);                                         // (its barrier also separates the reads of s_a / s_l above from the writes below)
     TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, pm);
     bool active = base <= P.n;
     bool eof_here = active && (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
@@ -554,16 +674,13 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
         C.nseq = 16 - __popc(pm.sp); C.saw_eol = pm.eol != 0;
         C.tail = pm.eol ? __popc(~pm.sp & 0xFFFFu & ~((2u << (31 - __clz((int)pm.eol))) - 1)) : C.nseq;
     } else if (active) { seg = segments_ok(P, base, pc, pm, ctx, cls); if (seg) classify_segments(P, base, pc, pm, ctx, C); else classify_range(P, base, pc, eof_here, ctx, C, cls); }
-    __shared__ u32 s_a[4], s_b[4], s_l[4];
     u32 prea, preb, tota;
     u32 ia = wg_scan1<u32, OpAdd>(C.nseq | (C.nids << 16), &prea, &tota, s_a);
     u32 ib = wave_scan_inclusive<u32, OpAdd>(C.ncmt | (C.nrec << 16));
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     preb = 0;                                                     // the second pair shares the barrier of the line-start scan below
     ia += prea;
     u32 iseq = ia & 0xFFFF, iids = ia >> 16, tile_seq = tota & 0xFFFF;
-    __shared__ __attribute__((aligned(16))) u8 stage[ET_TILE + 48];
-    WriteSink W(O); W.tbase = O.t_seq[blockIdx.x]; W.stage = stage + (PACK ? (u32)(W.tbase & 15) : 0u);   // PACK: groups of 16 bases aligned in LDS
+    WriteSink W(O); W.tbase = tbase; W.stage = stage + (PACK ? (u32)(W.tbase & 15) : 0u);   // PACK: groups of 16 bases aligned in LDS
     W.bseq = W.tbase + iseq - C.nseq; W.bids = O.t_ids[blockIdx.x] + iids - C.nids;
     // base count at the start of the line this thread begins in: B at the most recent EOL before `base`.
     // Within the tile: B at an EOL is non-decreasing with position, so a running max over earlier threads works
@@ -578,12 +695,7 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
     ib += preb;
     W.bcmt = O.t_cmt[blockIdx.x] + (ib & 0xFFFF) - C.ncmt; W.rec = O.t_rec[blockIdx.x] + (ib >> 16) - C.nrec;
     if (prev) W.line_b = W.tbase + prev - 1;
-    else {
-        // the line began in an earlier tile t' (the tile holding the last EOL): B = t_seq[t'+1] - tail(t')
-        i64 le = blockIdx.x ? tile_eol[blockIdx.x - 1] : -1;
-        if (le < 0 || (u64)(le + 1) <= P.p0) W.line_b = 0;
-        else { u64 tp = (u64)le / ET_TILE; W.line_b = O.t_seq[tp + 1] - (O.t_tail[tp] & 0x7FFFFFFFu); }
-    }
+    else W.line_b = line_b0;                                      // the line began in an earlier tile
     W.best = 0;
     if (fast) {
         u32 e = pm.eol;
@@ -606,7 +718,6 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
     __syncthreads();
     if (PACK) flush_pack<false>(P, O.packed, O.casebits, W.tbase, tile_seq, stage);
     else flush_tile(O.seq + W.tbase, stage, tile_seq);
-    __shared__ u64 s_best[4];
     u64 best = wg_reduce1<u64, OpMaxU64>(W.best, s_best);
     // millions of workgroups, one address: look before touching it atomically
     if (threadIdx.x == 0 && best > __atomic_load_n(O.longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)O.longest, (unsigned long long)best);
