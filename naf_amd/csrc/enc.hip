@@ -1094,15 +1094,29 @@ __global__ __launch_bounds__(256) void k_maskb_scatter(const u64 *cb, u64 T, con
     u64 k = tile_pre[blockIdx.x] + incl - c;
     while (m) { int b = __ffsll((unsigned long long)m) - 1; m &= m - 1; bnd[k++] = 64 * i + (u32)b; }
 }
-// the census of a shard (see k_mask_census): position 0 never counts
+// The census of a shard: case changes INSIDE the shard (positions >= 1) per tile, and their first and last position -- what the
+// neighbours need to continue a run across the cut.  out: [0] first internal boundary (~0: none), [1] last internal boundary (0: none).
+// One atomic per workgroup at most, and only when it can still improve the value (mixed-case reads change case every few bases).
 __global__ __launch_bounds__(256) void k_maskb_census(const u64 *cb, u64 T, u64 *tile_cnt, unsigned long long *out)
 {
-    __shared__ u32 s_c[4];
+    __shared__ u32 s_c[4]; __shared__ u64 s_lo[4], s_hi[4];
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    u64 m = 64 * i < T ? maskb_bits(cb, i, T, (cb[0] & 1) != 0) : 0;
+    const u64 m = 64 * i < T ? maskb_bits(cb, i, T, (cb[0] & 1) != 0) : 0;      // prev0 = the first base's own case: position 0 never counts
+    const u64 first = m ? 64 * i + (u32)__ffsll((unsigned long long)m) - 1 : ~0ull, last = m ? 64 * i + 63 - (u32)__clzll((long long)m) : 0ull;
+    // positions grow with the lane: the first lane with a change holds the tile's first, the last one its last
+    const u64 bal = __ballot(m != 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (bal && lane == __ffsll((unsigned long long)bal) - 1) s_lo[wave] = first;
+    if (bal && lane == 63 - __clzll((long long)bal)) s_hi[wave] = last;
+    if (!bal && lane == 0) { s_lo[wave] = ~0ull; s_hi[wave] = 0; }
     u32 tot = wg_reduce1<u32, OpAdd>((u32)__popcll(m), s_c);
-    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
-    if (m) { atomicMin(&out[0], (unsigned long long)(64 * i + (u32)__ffsll((unsigned long long)m) - 1)); atomicMax(&out[1], (unsigned long long)(64 * i + 63 - (u32)__clzll((long long)m))); }
+    if (threadIdx.x == 0) {
+        tile_cnt[blockIdx.x] = tot;
+        u64 lo = ~0ull, hi = 0;
+        for (int w = 0; w < 4; w++) { lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; }
+        if (lo < __atomic_load_n(&out[0], __ATOMIC_RELAXED)) atomicMin(&out[0], (unsigned long long)lo);
+        if (hi > __atomic_load_n(&out[1], __ATOMIC_RELAXED)) atomicMax(&out[1], (unsigned long long)hi);
+    }
 }
 // first and last base of a packed stream as letters (upper case from the table of unnaf.c:13, lower when the case bit is set)
 __global__ void k_packed_ends(const u8 *packed, const u64 *cb, u64 T, unsigned long long *out)
@@ -1157,6 +1171,12 @@ __global__ void k_sniff(const u8 *text, u64 n, u64 *out /* p0, first char, prev 
 __device__ __forceinline__ u32 slice_line_starts16(const u8 *t, u64 base, u64 n, int prev_is_eol)
 {
     u32 m = 0; bool prev = base ? c_eol(t[base - 1]) : prev_is_eol != 0;
+    if (base + 16 <= n) {                                         // four bytes per instruction (enc_swar.h); only the EOL bits are kept
+        const u64 a = ld64(t + base), b = ld64(t + base + 8);
+        const u32 w[4] = { (u32)a, (u32)(a >> 32), (u32)b, (u32)(b >> 32) };
+        const u32 eol = piece_flags(w).eol;
+        return ~eol & ((eol << 1) | (prev ? 1u : 0u)) & 0xFFFFu;
+    }
     for (u32 i = 0; i < 16 && base + i < n; i++) { const bool e = c_eol(t[base + i]); if (!e && prev) m |= 1u << i; prev = e; }
     return m;
 }

@@ -146,6 +146,24 @@ def ennaf_sharded_local(ctxs, d_text, opts=None, out=None):
     return out[:naf_len], rep
 
 
+class _Lap:
+    """NAF_SHARD_TIMING=1: wall-clock of the steps of ennaf_sharded on rank 0 (each step ends with a device synchronisation)."""
+    def __init__(self, dev):
+        import os, time
+        self.on = bool(os.environ.get("NAF_SHARD_TIMING")) and dist.get_rank() == 0
+        self.dev, self.time, self.t = dev, time, None
+        if self.on:
+            self.t = time.perf_counter()
+
+    def __call__(self, label):
+        if self.on:
+            if self.dev.type == "cuda":
+                torch.cuda.synchronize(self.dev)
+            now = self.time.perf_counter()
+            print("  shard-timing %-18s %8.3f ms" % (label, (now - self.t) * 1e3), flush=True)
+            self.t = now
+
+
 def _all_gather_bytes(raw: bytes, device, group):
     """all_gather of one fixed-size record per rank."""
     world = dist.get_world_size(group)
@@ -172,6 +190,7 @@ def ennaf_sharded(ctx, d_buf, n, opts=None, dst=0, group=None, everywhere=False)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = d_buf.device
+    lap = _Lap(dev)
     # format and first record: rank 0 looks at its slice, everybody hears
     meta = [0, 0]
     if rank == 0:
@@ -190,6 +209,7 @@ def ennaf_sharded(ctx, d_buf, n, opts=None, dst=0, group=None, everywhere=False)
             prev = tails[r][0]
     prev_is_eol = rank == 0 or _is_eol(prev)
     mine = d_buf[lo:n]
+    lap("sniff+tails")
     # where my shard begins inside my slice
     skip = 0
     if fmt == capi.FMT_FASTQ:
@@ -200,6 +220,7 @@ def ennaf_sharded(ctx, d_buf, n, opts=None, dst=0, group=None, everywhere=False)
         cut = 0
     else:
         cut = ctx.ennaf_find_cut(mine, fmt, prev_is_eol, skip) if mine.numel() else 0
+    lap("lines+cut")
     # heads: the bytes in front of each rank's cut belong to the shard before it; a slice without a cut is all head
     lens = _all_gather_ints([cut, mine.numel()], dev, group)
     maxc = max(c for c, _ in lens)
@@ -230,9 +251,13 @@ def ennaf_sharded(ctx, d_buf, n, opts=None, dst=0, group=None, everywhere=False)
         text = torch.cat([mine[cut:]] + borrow)
     else:
         text = mine[cut:]
+    lap("heads+halo")
     info = ctx.ennaf_shard_begin(text, opts, fmt, rank, world)
+    lap("shard_begin")
     infos = [capi.ShardInfo.from_buffer_copy(b) for b in _all_gather_bytes(bytes(info), dev, group)]
+    lap("gather infos")
     buf, pc = ctx.ennaf_shard_finish(opts, infos, text.numel())
+    lap("shard_finish")
     pieces = [capi.ShardPieces.from_buffer_copy(b) for b in _all_gather_bytes(bytes(pc), dev, group)]
     segs, lit, naf_len, rep = capi.stitch_plan(opts, infos, pieces)
     extra = {"cut": cut, "halo": halo, "format": fmt, "text_len": int(text.numel())}
@@ -255,6 +280,7 @@ def ennaf_sharded(ctx, d_buf, n, opts=None, dst=0, group=None, everywhere=False)
             if g.shard == rank and g.len:
                 ops.append(dist.P2POp(dist.isend, buf[g.src_off:g.src_off + g.len], dst, group))
     _p2p(ops)
+    lap("stitch+gather")
     if everywhere:
         if rank != dst:
             out = torch.empty(max(naf_len, 1), dtype=torch.uint8, device=dev)
