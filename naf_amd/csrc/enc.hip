@@ -28,6 +28,7 @@ struct EncP {
     u8 id_gt_unexpected;         // text+FASTA: '>' also ends ID scanning (ennaf.c:478 flips the shared table)
     u8 strict, pad;
     u32 qlo, qhi;                // quick table of accepted letters (enc_swar.h), built in set_expected
+    u32 plo, phi;                // the same with '\n' and '\r' in slots 5 and 6 (piece_plain)
     u32 nuc32[8];                // 4-bit code of the letter whose low five bits are the index (tables.c:189-197), 15 in the other slots
 };
 
@@ -326,7 +327,8 @@ __device__ __forceinline__ bool seq_piece(const EncP &P, u64 base, const Piece &
 }
 
 // ---- K2: per-tile stream byte counts -----------------------------------------------------------------------------------
-// A PURE tile -- wholly inside [p0, n), beginning outside a header line and holding no '>' -- is sequence lines and nothing else:
+// A PURE tile -- wholly inside [p0, n), beginning outside a header line and made of plain pieces (piece_plain: A C G T/U N in either
+// case, LF, CR; so no '>') -- is sequence lines and nothing else:
 // every piece takes the popcount path, no lane needs its own running maxima (thread_ctx) and nothing is added to ids, comments or
 // the record table.  Long-record FASTA is pure tiles almost everywhere; the test is workgroup-uniform.
 __device__ __forceinline__ bool tile_may_be_pure(const EncP &P, const i64 *tile_eol)
@@ -352,16 +354,19 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
     const bool maybe = tile_may_be_pure(P, tile_eol);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
-    PMask pm = piece_masks(pc);
     {
-        // per wave: bases, and bases behind the wave's last EOL, in one packed reduction
-        const u32 nseq = 16u - (u32)__popc(pm.sp);
-        const u64 bal = __ballot(pm.eol != 0);
+        // per wave: bases, and bases behind the wave's last EOL, in one packed reduction.  Plain pieces only (quick letters, LF, CR):
+        // their line ends are their only space-class bytes
+        const u32 w[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) };
+        PMask pl; pl.gt = 0;
+        const bool plain = piece_plain(w, P.plo, P.phi, &pl.eol); pl.sp = pl.eol;
+        const u32 nseq = 16u - (u32)__popc(pl.sp);
+        const u64 bal = __ballot(pl.eol != 0);
         const int lastl = bal ? 63 - __clzll((long long)bal) : -1;
-        const u32 after = lane > lastl ? nseq : (lane == lastl ? piece_tail_bases(pm) : 0u);
+        const u32 after = lane > lastl ? nseq : (lane == lastl ? piece_tail_bases(pl) : 0u);
         const u32 red = wave_scan_inclusive<u32, OpAdd>(nseq | (after << 16));
-        const bool wave_gt = __ballot(pm.gt != 0) != 0;
-        if (lane == 63) { s_a[wave] = red; s_last[wave] = (bal ? 1u : 0u) | (wave_gt ? 2u : 0u); }
+        const bool wave_bad = __ballot(!plain) != 0;
+        if (lane == 63) { s_a[wave] = red; s_last[wave] = (bal ? 1u : 0u) | (wave_bad ? 2u : 0u); }
     }
     __syncthreads();
     if (maybe && !((s_last[0] | s_last[1] | s_last[2] | s_last[3]) & 2u)) {
@@ -374,6 +379,7 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
         }
         return;
     }
+    PMask pm = piece_masks(pc);
     fill_classes(P, cls);                                         // (its barrier also separates the reads of s_a / s_last above from the writes below)
     TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, pm);
     CountSink S;
@@ -597,12 +603,12 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
     const u64 tbase = O.t_seq[blockIdx.x];
     const u64 line_b0 = tile_line_base(P, O, tile_eol);
     Piece pc = load_piece(P, base);
-    PMask pm = piece_masks(pc);
-    // ---- a pure tile (see k_enc_count) of A C G T/U N: prefix of the base counts, the line lengths from the lanes that hold an EOL,
-    // bases to LDS, packed codes and case bits out.  No per-lane context, no class table, two barriers.
+    // ---- a pure tile (see k_enc_count): prefix of the base counts, the line lengths from the lanes that hold an EOL, bases to LDS,
+    // packed codes and case bits out.  No per-lane context, no class table, two barriers.
     {
         const u32 w[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) };
-        const bool lane_bad = pm.gt != 0 || (piece_not_quick(w, P.qlo, P.qhi) & ~pm.sp) != 0;
+        PMask pm; pm.gt = 0;
+        const bool lane_bad = !piece_plain(w, P.plo, P.phi, &pm.eol); pm.sp = pm.eol;
         const u32 nseq = 16u - (u32)__popc(pm.sp);
         const u32 incl = wave_scan_inclusive<u32, OpAdd>(nseq);
         const bool has = pm.eol != 0;
@@ -664,6 +670,7 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
     }
     __shared__ u8 cls[256];
     fill_classes(P, cls);                                         // (its barrier also separates the reads of s_a / s_l above from the writes below)
+    PMask pm = piece_masks(pc);
     TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, pm);
     bool active = base <= P.n;
     bool eof_here = active && (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
@@ -1261,6 +1268,7 @@ static void set_expected(EncP &P, int seq_type, bool fasta)
     auto has = [&](u32 c) { return (P.expected[c >> 5] >> (c & 31)) & 1u; };
     for (const char *p = "ACGTUN"; *p; p++) { u32 ch = (u32)*p; if (has(ch) && has(ch | 0x20) && q[(ch >> 1) & 7] == 0xFF) q[(ch >> 1) & 7] = (u8)ch; }
     memcpy(&P.qlo, q, 4); memcpy(&P.qhi, q + 4, 4);
+    q[5] = 0x0A; q[6] = 0x0D; memcpy(&P.plo, q, 4); memcpy(&P.phi, q + 4, 4);   // (slots 5 and 6 belong to no letter of A C G T U N)
 }
 
 // confirm_input_format (process.c:547-583): first non-space byte, the byte in front of it

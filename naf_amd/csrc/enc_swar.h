@@ -61,6 +61,23 @@ NAF_HD u32 piece_not_quick(const u32 w[4], u32 qlo, u32 qhi)
     return swar_movemask16(nz[0], nz[1], nz[2], nz[3]);
 }
 
+// Plain sequence text: every byte of the piece is a quick letter (either case) or '\n' / '\r'.  The quick table with '\n' (slot 5:
+// (0x0A >> 1) & 7) and '\r' (slot 6) in two of its free slots answers in one look-up; the case bit is cleared only in bytes that
+// have bit 6, so '*' (0x2A) is not taken for 0x0A.  *eol: one bit per '\n' / '\r' (the passing bytes without bit 6); meaningful
+// only when the function returns true.
+NAF_HD bool piece_plain(const u32 w[4], u32 plo, u32 phi, u32 *eol)
+{
+    const u32 H = 0x80808080u, L = 0x7F7F7F7Fu;
+    u32 bad = 0, e[4];
+    for (int i = 0; i < 4; i++) {
+        const u32 x = w[i], r = swar_perm(phi, plo, (x >> 1) & 0x07070707u), d = r ^ (x & ~((x >> 1) & 0x20202020u));
+        bad |= ((d & L) + L) | d;
+        e[i] = ~(x << 1) & H;
+    }
+    *eol = swar_movemask16(e[0], e[1], e[2], e[3]);
+    return (bad & H) == 0;
+}
+
 // every byte in 0x21..0x7E (the quality characters stored as they are, process.c:522-528)
 NAF_HD bool piece_all_quality(const u32 w[4])
 {

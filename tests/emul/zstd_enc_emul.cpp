@@ -130,3 +130,8 @@ extern "C" void emul_piece_flags(const uint8_t *piece16, uint32_t qlo, uint32_t 
     u32 nq = piece_not_quick(w, qlo, qhi);
     out[0] = f.eol; out[1] = f.sp; out[2] = f.gt; out[3] = (nq & ~f.sp) == 0; out[4] = nq == 0; out[5] = piece_all_quality(w); out[6] = piece_ctl_mask(w); out[7] = piece_not_quality_mask(w);
 }
+extern "C" int emul_piece_plain(const uint8_t *piece16, uint32_t plo, uint32_t phi, uint32_t *eol)
+{
+    u32 w[4]; memcpy(w, piece16, 16);
+    return piece_plain(w, plo, phi, eol) ? 1 : 0;
+}

@@ -281,6 +281,31 @@ def _quick_table(expected):
     return int.from_bytes(bytes(t[:4]), "little"), int.from_bytes(bytes(t[4:]), "little"), {c for c in t if c != 0xFF}
 
 
+@pytest.mark.parametrize("alphabet", [b"ABCDGHKMNRSTVWY", b"ABCDGHKMNRSUVWY"])
+def test_swar_piece_plain_every_byte_every_position(alphabet):
+    """enc_swar.h piece_plain: the test behind the pure-tile paths of k_enc_count / k_enc_scatter -- quick letters, LF and CR only."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "emul", "libzstd_emul.so"))
+    expected = set(alphabet) | {c | 0x20 for c in alphabet} | {ord("-")}
+    qlo, qhi, quick = _quick_table(expected)
+    t = bytearray(qlo.to_bytes(4, "little") + qhi.to_bytes(4, "little"))
+    assert t[5] == 0xFF and t[6] == 0xFF                        # the two slots the line ends go into are free
+    t[5], t[6] = 0x0A, 0x0D
+    plo, phi = int.from_bytes(bytes(t[:4]), "little"), int.from_bytes(bytes(t[4:]), "little")
+    rng = np.random.default_rng(6)
+    eol = ctypes.c_uint32()
+    fills = [bytes([65] * 16), bytes([10] * 16), bytes([13] * 16), bytes(rng.choice(np.frombuffer(b"ACGTNacgtnUu\n\r", dtype=np.uint8), 16)),
+             bytes(rng.choice(np.frombuffer(b"ACGTNacgtn\n", dtype=np.uint8), 16))]
+    ok = lambda c: c in (0x0A, 0x0D) or ((c & 0xDF) in quick and c in expected and c >= 0x40)
+    for fill in fills:
+        for pos in range(16):
+            for b in range(256):
+                p = bytearray(fill); p[pos] = b
+                got = lib.emul_piece_plain(bytes(p), plo, phi, ctypes.byref(eol))
+                assert got == int(all(ok(c) for c in p)), (fill, pos, b)
+                if got:
+                    assert eol.value == sum(1 << i for i, c in enumerate(p) if c in (0x0A, 0x0D)), (fill, pos, b)
+
+
 @pytest.mark.parametrize("alphabet", [b"ABCDGHKMNRSTVWY", b"ABCDGHKMNRSUVWY", bytes(range(0x41, 0x5B))])
 def test_swar_piece_flags_every_byte_every_position(alphabet):
     lib = ctypes.CDLL(os.path.join(ROOT, "tests", "emul", "libzstd_emul.so"))
