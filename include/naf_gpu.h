@@ -136,9 +136,11 @@ typedef struct {
     int      seq_type;          /* NAF_SEQ_* */
     int      no_mask;           /* --no-mask */
     int      strict;            /* --strict */
-    int      level;             /* --level: ids / names / lengths always take the LZ stage; >= 2 extends it to mask, sequence, quality */
+    int      level;             /* --level: 1 = ids / names / lengths matched inside a block, other streams entropy-coded; >= 2 = every stream
+                                 * matched across blocks inside libzstd's window for that level */
     int64_t  line_length;       /* <0: store the longest line; >=0: --line-length N */
     const char *title;          /* --title or NULL */
+    int      long_log;          /* --long N (ennaf.c:247-273): window 2^N for the sequence stream; 0 = not given */
 } naf_gpu_ennaf_opts;
 
 typedef struct {

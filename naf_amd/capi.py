@@ -42,7 +42,7 @@ class Header(C.Structure):
 
 class EnnafOpts(C.Structure):
     _fields_ = [("format", C.c_int), ("seq_type", C.c_int), ("no_mask", C.c_int), ("strict", C.c_int), ("level", C.c_int),
-                ("line_length", C.c_int64), ("title", C.c_char_p)]
+                ("line_length", C.c_int64), ("title", C.c_char_p), ("long_log", C.c_int)]
 
 
 class EnnafReport(C.Structure):
@@ -265,9 +265,9 @@ class Context:
         return list(cnt)
 
     # ---- ennaf ----
-    def ennaf(self, d_text, seq_type=SEQ_DNA, fmt=FMT_AUTO, no_mask=False, level=1, line_length=-1, title=None, out=None, strict=False):
+    def ennaf(self, d_text, seq_type=SEQ_DNA, fmt=FMT_AUTO, no_mask=False, level=1, line_length=-1, title=None, out=None, strict=False, long_log=0):
         import torch
-        o = EnnafOpts(fmt, seq_type, int(no_mask), int(strict), level, line_length, title)
+        o = EnnafOpts(fmt, seq_type, int(no_mask), int(strict), level, line_length, title, long_log)
         if out is None:
             cap = self.L.naf_gpu_ennaf_bound(d_text.numel())
             out = torch.empty(cap, dtype=torch.uint8, device=self.device)

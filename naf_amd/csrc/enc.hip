@@ -1504,7 +1504,7 @@ struct EnnafCarry {
     int skip_run0;         // 1: the bases in front of the shard's first case change continue a run that an earlier shard emits
     u64 run_ext;           // bases of the following shards that continue this shard's last mask run
 };
-struct EnnafStreams { const u8 *ptr[6]; u64 len[6], orig[6]; int lz[6], block_log[6]; bool present[6]; };
+struct EnnafStreams { const u8 *ptr[6]; u64 len[6], orig[6]; int lz[6], block_log[6], window_log[6]; bool present[6]; };
 
 // E5-E7: lengths, 4-bit pack, mask units -> the six uncompressed streams.
 static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, EnnafStreams &X)
@@ -1577,6 +1577,17 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
     return 0;
 }
 
+// Match windows of the six streams.  Level 1 (the default): ids / names / lengths find matches inside a block, the other streams are
+// entropy-coded only.  From level 2 every stream finds matches across blocks inside the window libzstd uses at that level for large
+// inputs (clevels.h); --long N (ennaf.c:247-273, :505) gives the SEQUENCE stream a window of 2^N at any level -- the reference turns
+// on libzstd's long-distance matcher for that stream only (compressor.c:12-16).
+static void ennaf_windows(EnnafStreams &X, const naf_gpu_ennaf_opts *o)
+{
+    const int wl = zenc_level_window(o->level);
+    for (int i = 0; i < 6; i++) X.window_log[i] = wl;
+    if (o->long_log) { X.window_log[4] = o->long_log < 10 ? 10 : o->long_log > 31 ? 31 : o->long_log; X.lz[4] = 1; }
+}
+
 // container header (ennaf.c:538-556): magic, version, flags, separator, line length, N, title
 static size_t naf_header_bytes(const naf_gpu_ennaf_opts *o, bool store_mask, bool store_qual, u64 longest, u64 N, u8 *hd /* >= 40 */)
 {
@@ -1593,13 +1604,13 @@ static size_t naf_header_bytes(const naf_gpu_ennaf_opts *o, bool store_mask, boo
 
 struct SecOut { u64 orig, comp; };
 
-static int put_section(naf_gpu_ctx *c, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz = 0, int block_log = 0)
+static int put_section(naf_gpu_ctx *c, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz = 0, int block_log = 0, int window_log = 0)
 {
     size_t bound = naf_gpu_zstd_compress_bound(stream_len);
     u8 *tmp = (u8 *)arena_alloc(c, bound);
     if (!tmp) return NAF_GPU_ENOMEM;
     size_t clen = 0;
-    int rc = zstd_encode(c, d_stream, stream_len, level, tmp, bound, &clen, 0, lz, block_log); if (rc) return rc;
+    int rc = zstd_encode(c, d_stream, stream_len, level, tmp, bound, &clen, 0, lz, block_log, window_log); if (rc) return rc;
     u8 hdr[20]; size_t hl = vle(orig, hdr); hl += vle(clen, hdr + hl);
     if (pos + hl + clen > cap) return ctx_fail(c, NAF_GPU_ECAP, "ennaf output capacity %zu too small", cap);
     HIP_TRY(c, hipMemcpyAsync(d_naf + pos, hdr, hl, hipMemcpyHostToDevice, c->stream));
@@ -1628,6 +1639,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     EnnafCarry K; memset(&K, 0, sizeof K);
     EnnafStreams X;
     if ((rc = ennaf_streams(c, S, K, X))) return rc;
+    ennaf_windows(X, o);
     for (int i = 0; i < 257; i++) { R.unexpected_id[i] = S.unexpected[0][i]; R.unexpected_comment[i] = S.unexpected[1][i]; R.unexpected_seq[i] = S.unexpected[2][i]; R.unexpected_qual[i] = S.unexpected[3][i]; }
     R.n_sequences = S.N; R.n_bases = S.T; R.longest_line = S.longest;
 
@@ -1641,7 +1653,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     SecOut so[6]; memset(so, 0, sizeof so);
     for (int i = 0; i < 6; i++)
-        if (X.present[i] && (rc = put_section(c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i]))) return rc;
+        if (X.present[i] && (rc = put_section(c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i], X.window_log[i]))) return rc;
     for (int i = 0; i < 6; i++) { R.section_orig[i] = so[i].orig; R.section_comp[i] = so[i].comp; }
     *naf_len = pos;
     if (rep) *rep = R;
@@ -1844,6 +1856,7 @@ extern "C" int naf_gpu_ennaf_shard_finish(naf_gpu_ctx *c, const naf_gpu_ennaf_op
     ShardView V; shard_view(infos, n, k, V);
     EnnafStreams X;
     if ((rc = ennaf_streams(c, st->S, V.K, X))) return rc;
+    ennaf_windows(X, o);
     memset(pieces, 0, sizeof *pieces);
     u8 *dst = (u8 *)d_pieces_; size_t pos = 0;
     for (int i = 0; i < 6; i++) {
@@ -1852,7 +1865,7 @@ extern "C" int naf_gpu_ennaf_shard_finish(naf_gpu_ctx *c, const naf_gpu_ennaf_op
         if (pos + need > cap) return ctx_fail(c, NAF_GPU_ECAP, "shard piece buffer of %zu bytes is too small", cap);
         size_t clen = 0;
         const int flags = ZENC_PART | (V.first[i] ? ZENC_PART_FIRST : 0) | (V.last[i] ? ZENC_PART_LAST : 0);
-        if ((rc = zstd_encode(c, X.ptr[i], X.len[i], o->level, dst + pos, cap - pos, &clen, flags, X.lz[i], X.block_log[i]))) return rc;
+        if ((rc = zstd_encode(c, X.ptr[i], X.len[i], o->level, dst + pos, cap - pos, &clen, flags, X.lz[i], X.block_log[i], X.window_log[i]))) return rc;
         pieces->off[i] = pos; pieces->len[i] = clen; pieces->raw[i] = X.orig[i];
         pos += (clen + 15) & ~(size_t)15;
     }

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
 struct LzBufs {
     u8 *lits; u64 slot;                 // literals of block b at lits + b*slot
     u16 *ll, *ml, *of; u64 seq_slot;    // sequences of block b at [b*seq_slot ..)
+    u32 *ofv;                           // cross-block stage: Offset_Values (repeat codes 1..3, else distance + 3) instead of `of`
     u32 *nseq, *nlit;
     u8 *seqbuf; u32 *seq_bytes;         // encoded Sequences_Section of block b at seqbuf + b*slot
 };
@@ -301,6 +302,216 @@ __global__ __launch_bounds__(64) void k_lz_seqenc(u32 nblk, LzBufs B, const SeqC
     u8 *out = B.seqbuf + (u64)b * B.slot;
     if (ns == 0) out[0] = 0;
     else bytes = zenc_write_sequences(out, (u32)B.slot, B.ll + (u64)b * B.seq_slot, B.ml + (u64)b * B.seq_slot, B.of + (u64)b * B.seq_slot, ns, ct);
+    B.seq_bytes[b] = bytes;                                              // 0: does not fit its slot, the block stays literal-only
+}
+
+// ======================= cross-block matching (level >= 2, --long N) =========================================================================
+// What the reference gets from libzstd's match finders and its long-distance matcher (compressor.c:7-21): matches against anything
+// inside the window, repeat-offset codes, per-block FSE tables.  Built for a GPU as
+//   k_ldm_insert   every ANCHOR position of the stream (content-defined: the hash of its 8 bytes has three zero top bits, so one in
+//                  eight, and the same ones in every copy of a repeat) enters a table keyed by its 16 bytes; the table keeps the
+//                  FIRST occurrence per EPOCH of 2^(wlog-1) bytes (atomicMin), so a position finds a source in its own epoch or
+//                  the one before it -- never further back than the window -- and all positions are inserted at once;
+//   k_lzx_parse    one wavefront per block as in k_lz_parse, with two more sources of matches: the table (source anywhere in the
+//                  window, read from HBM) and, behind every match, the SAME offset again after one to three literals (a
+//                  substituted base costs a repeat code, not a new offset); matches grow backwards into the pending literals;
+//   k_lzx_seqenc   Offset_Values with the block's own repeat-offset history (zstd_enc_core.h: RepState), code tables chosen per
+//                  block between predefined, RLE and FSE_Compressed.
+// Blocks still do not depend on each other's OUTPUT, so a shard of a sharded archive codes its part of the frame alone, matching
+// inside its own part of the stream.
+struct LdmTab { u32 *tab; u32 elog, tlog, wlog, pad; };
+__device__ __forceinline__ u64 ldm_mix(u64 a) { return a * 0x9E3779B185EBCA87ull; }
+__device__ __forceinline__ bool ldm_key(u64 a, u64 b, u32 tlog, u32 &idx)
+{
+    const u64 ha = ldm_mix(a);
+    if (ha >> 61) return false;
+    idx = (u32)((ha ^ (ldm_mix(b ^ 0x5555555555555555ull) >> 7)) >> (64 - tlog));
+    return true;
+}
+__global__ __launch_bounds__(256) void k_ldm_insert(const u8 *src, u64 n, LdmTab L)
+{
+    const u64 p0 = ((u64)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (p0 + 16 > n) return;
+    const u64 w0 = ld64(src + p0), w1 = ld64(src + p0 + 8);
+    u64 w2 = 0;
+    if (p0 + 24 <= n) w2 = ld64(src + p0 + 16); else for (u64 k = p0 + 16; k < n; k++) w2 |= (u64)src[k] << (8 * (k - p0 - 16));
+    const u64 E1 = (1ull << L.elog) - 1;
+#pragma unroll
+    for (u32 k = 0; k < 8; k++) {
+        const u64 pos = p0 + k;
+        if (pos + 16 > n) break;
+        const u64 a = k ? (w0 >> (8 * k)) | (w1 << (64 - 8 * k)) : w0, b = k ? (w1 >> (8 * k)) | (w2 << (64 - 8 * k)) : w1;
+        u32 idx;
+        if (ldm_key(a, b, L.tlog, idx)) atomicMin(&L.tab[((pos >> L.elog) << L.tlog) + idx], (u32)(pos & E1));
+    }
+}
+
+// bytes equal from target position t (block-relative, in LDS) and source position s (block-relative, may be negative: HBM), by the
+// whole wave, 256 bytes per step; stops at the block end.  The LDS copy is zero-padded behind bn, HBM is not read past n.
+__device__ __forceinline__ u32 lzx_wave_match(const u8 *buf, const u8 *gblk /* src + lo */, u64 n_left /* n - lo */, u32 bn, u32 t, i64 s, u32 m0)
+{
+    const u32 lane = threadIdx.x;
+    u32 m = m0;
+    while (t + m < bn) {
+        const i64 sp = s + (i64)m + 4 * (i64)lane;
+        u32 x, y; __builtin_memcpy(&y, buf + t + m + 4 * lane, 4);
+        bool oob = false;
+        if (sp >= 0) __builtin_memcpy(&x, buf + sp, 4);               // (sp < t + m + 4 lane: inside the padded copy)
+        else if (sp + 4 <= (i64)n_left) __builtin_memcpy(&x, gblk + sp, 4);
+        else { x = 0; oob = true; }
+        const u32 d = x ^ y;
+        const u64 ne = __ballot(d != 0 || oob);
+        if (!ne) { m += 256; continue; }
+        const u32 l0 = (u32)__ffsll((long long)ne) - 1;
+        const u32 d0 = (u32)__shfl((int)d, (int)l0, 64);
+        m += 4 * l0 + (d0 ? ((u32)__ffs((int)d0) - 1) >> 3 : 0u);
+        break;
+    }
+    if (t + m > bn) m = bn - t;
+    return m;
+}
+// equal bytes in front of (t, s), at most t - floor of them and never in front of the stream's first byte
+__device__ __forceinline__ u32 lzx_wave_back(const u8 *buf, const u8 *gblk, u64 lo, u32 t, i64 s, u32 floor_)
+{
+    const u32 lane = threadIdx.x;
+    u32 back = 0;
+    for (;;) {
+        const u32 k = back + lane + 1;                               // this lane looks at t - k and s - k
+        bool ok = t >= floor_ + k && (i64)lo + s - (i64)k >= 0;
+        if (ok) { const i64 sp = s - (i64)k; const u32 x = sp >= 0 ? buf[sp] : gblk[sp]; ok = x == buf[t - k]; }
+        const u64 bad = __ballot(!ok);
+        if (!bad) { back += 64; continue; }
+        back += (u32)__ffsll((long long)bad) - 1;
+        break;
+    }
+    return back;
+}
+
+__global__ __launch_bounds__(64) void k_lzx_parse(const u8 *src, u64 n, u32 nblk, LzBufs B, u32 buf_bytes, LdmTab L)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 lz_lds[];
+    u8 *buf = lz_lds;
+    u16 *tab = (u16 *)(lz_lds + buf_bytes);
+    const u32 b = blockIdx.x, lane = threadIdx.x;
+    const u64 lo = zenc_block_lo(n, nblk, b);
+    const u32 bn = (u32)(zenc_block_lo(n, nblk, b + 1) - lo);
+    const u8 *gblk = src + lo;
+    for (u32 i = lane * 16; i < bn; i += 64 * 16) {
+        if (i + 16 <= bn) { uint4 v; __builtin_memcpy(&v, gblk + i, 16); *(uint4 *)(buf + i) = v; }
+        else for (u32 k = i; k < bn; k++) buf[k] = gblk[k];
+    }
+    for (u32 i = lane; i < (1u << LZ_HASH_LOG); i += 64) tab[i] = 0;     // 0 = empty, else position + 1
+    for (u32 i = bn + lane; i < bn + 320 && i < buf_bytes; i += 64) buf[i] = 0;
+    __syncthreads();
+    u8 *lits = B.lits + (u64)b * B.slot;
+    u16 *sll = B.ll + (u64)b * B.seq_slot, *sml = B.ml + (u64)b * B.seq_slot; u32 *sof = B.ofv + (u64)b * B.seq_slot;
+    const u32 max_seq = (u32)B.seq_slot - 2;
+    RepState R; R.r[0] = R.r[1] = R.r[2] = 0;
+    u32 cur = 0, anchor = 0, ns = 0, nl = 0;
+    // literals [anchor, at) and the match (at, ml, distance d) leave the parser; `anchor` moves behind the match
+    auto emit = [&](u32 at, u32 ml, u32 d) {
+        if (ml > 65535u) ml = 65535u;                                // lengths are kept in 16 bits; the rest of the match is found again
+        const u32 ll = at - anchor;
+        for (u32 k = lane; k < ll; k += 64) lits[nl + k] = buf[anchor + k];
+        const u32 v = zenc_offset_value(R, d, ll);
+        if (lane == 0) { sll[ns] = (u16)ll; sml[ns] = (u16)ml; sof[ns] = v; }
+        nl += ll; ns++;
+        anchor = at + ml;
+    };
+    while (cur + LZ_MINMATCH <= bn && ns + 8 < max_seq) {
+        const u32 p = cur + lane; const bool valid = p + LZ_MINMATCH <= bn;
+        u32 v = 0, h = 0, m = 0; i64 c = 0;
+        if (valid) {
+            __builtin_memcpy(&v, buf + p, 4);
+            h = (v * 2654435761u) >> (32 - LZ_HASH_LOG);
+            const u32 ci = tab[h];                                   // positions of earlier rounds only (< cur)
+            if (ci) {
+                const u32 q = ci - 1; u32 cv; __builtin_memcpy(&cv, buf + q, 4);
+                if (cv == v) {
+                    m = 4; c = (i64)q;
+                    for (;;) {
+                        u32 x, y; __builtin_memcpy(&x, buf + q + m, 4); __builtin_memcpy(&y, buf + p + m, 4);
+                        const u32 d = x ^ y;
+                        if (d) { m += (u32)(__ffs((int)d) - 1) >> 3; break; }
+                        m += 4;
+                        if (p + m >= bn || m >= LZ_LANE_EXT) break;
+                    }
+                }
+            }
+            if (p + 16 <= bn) {                                      // an anchor: a source anywhere in the window
+                u64 a8, b8; __builtin_memcpy(&a8, buf + p, 8); __builtin_memcpy(&b8, buf + p + 8, 8);
+                u32 idx;
+                if (ldm_key(a8, b8, L.tlog, idx)) {
+                    const u64 pa = lo + p, e = pa >> L.elog;
+                    u64 q = ~0ull;
+                    const u32 c1 = L.tab[(e << L.tlog) + idx];
+                    if (c1 != 0xFFFFFFFFu && (e << L.elog) + c1 < pa) q = (e << L.elog) + c1;
+                    else if (e > 0) { const u32 c0 = L.tab[((e - 1) << L.tlog) + idx]; if (c0 != 0xFFFFFFFFu) q = ((e - 1) << L.elog) + c0; }
+                    if (q != ~0ull && pa - q < (1ull << L.wlog) && pa - q < 0x7FFFFFF0ull) {
+                        const u8 *g = src + q;
+                        if (ld64(g) == a8 && ld64(g + 8) == b8) {
+                            u32 m2 = 16;
+                            while (p + m2 < bn && m2 < LZ_LANE_EXT && q + m2 + 4 <= n) {
+                                u32 x, y; __builtin_memcpy(&x, g + m2, 4); __builtin_memcpy(&y, buf + p + m2, 4);
+                                const u32 d = x ^ y;
+                                if (d) { m2 += (u32)(__ffs((int)d) - 1) >> 3; break; }
+                                m2 += 4;
+                            }
+                            if (m2 > m) { m = m2; c = (i64)q - (i64)lo; }
+                        }
+                    }
+                }
+            }
+            if (p + m > bn) m = bn - p;
+        }
+        const u64 win = __ballot(m >= LZ_MINMATCH);
+        if (valid) tab[h] = (u16)(p + 1);
+        u32 next = cur < anchor ? anchor : cur;
+        while (next < cur + 64 && ns + 8 < max_seq) {
+            const u64 w2 = win & ~((1ull << (next - cur)) - 1);
+            if (!w2) break;
+            const u32 f = (u32)__ffsll((long long)w2) - 1;
+            u32 pf = cur + f, mf = (u32)__shfl((int)m, (int)f, 64);
+            const u32 clo = (u32)__shfl((int)(u32)(u64)c, (int)f, 64), chi = (u32)__shfl((int)(u32)((u64)c >> 32), (int)f, 64);
+            i64 cf = (i64)(((u64)chi << 32) | clo);
+            if (mf >= LZ_LANE_EXT) mf = lzx_wave_match(buf, gblk, n - lo, bn, pf, cf, mf);
+            const u32 back = lzx_wave_back(buf, gblk, lo, pf, cf, anchor);
+            pf -= back; cf -= back; mf += back;
+            const u32 d = (u32)((i64)pf - cf);
+            emit(pf, mf, d);
+            // the same offset again behind one to three literals: a substitution inside a repeat
+            for (;;) {
+                bool again = false;
+                for (u32 skip = 1; skip <= 3 && !again; skip++) {
+                    const u32 t = anchor + skip;
+                    if (t + 4 > bn) break;
+                    const u32 mr = lzx_wave_match(buf, gblk, n - lo, bn, t, (i64)t - (i64)d, 0);
+                    if (mr >= 4 && ns + 8 < max_seq) { emit(t, mr, d); again = true; }
+                }
+                if (!again) break;
+            }
+            next = anchor;
+        }
+        cur += 64;
+        if (cur < anchor) cur = anchor;
+    }
+    for (u32 k = lane; k < bn - anchor; k += 64) lits[nl + k] = buf[anchor + k];
+    nl += bn - anchor;
+    if (lane == 0) { B.nseq[b] = ns; B.nlit[b] = nl; }
+}
+
+// Sequences_Section of one block per wavefront: the tables live in LDS, lane 0 writes (zenc_write_sequences_x)
+__global__ __launch_bounds__(64) void k_lzx_seqenc(u32 nblk, LzBufs B, const SeqCTabs *tabs)
+{
+    __shared__ SeqCTabs T; __shared__ SeqWS ws;
+    for (u32 i = threadIdx.x; i < sizeof(SeqCTabs) / 4; i += 64) ((u32 *)&T)[i] = ((const u32 *)tabs)[i];
+    __syncthreads();
+    const u32 b = blockIdx.x;
+    if (threadIdx.x) return;
+    const u32 ns = B.nseq[b]; u32 bytes = 1;
+    u8 *out = B.seqbuf + (u64)b * B.slot;
+    if (ns == 0) out[0] = 0;
+    else bytes = zenc_write_sequences_x(out, (u32)B.slot, B.ll + (u64)b * B.seq_slot, B.ml + (u64)b * B.seq_slot, B.ofv + (u64)b * B.seq_slot, ns, T, ws);
     B.seq_bytes[b] = bytes;                                              // 0: does not fit its slot, the block stays literal-only
 }
 
@@ -451,13 +662,22 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
     }
 }
 
-__global__ void k_zenc_frame_header(u8 *dst, int with_magic)
+__global__ void k_zenc_frame_header(u8 *dst, int with_magic, u32 wlog)
 {
     if (threadIdx.x || blockIdx.x) return;
     u32 p = 0;
     if (with_magic) { dst[p++] = 0x28; dst[p++] = 0xB5; dst[p++] = 0x2F; dst[p++] = 0xFD; }
     dst[p++] = 0x00;            // Frame_Header_Descriptor: no FCS, no checksum, no dictionary, windowed (like ennaf -1)
-    dst[p++] = 0x48;            // Window_Descriptor: 2^19 (blocks here never reference earlier data)
+    dst[p++] = (u8)((wlog - 10) << 3);   // Window_Descriptor: 2^19 for blocks that never reference earlier data, else the window the matches were found in
+}
+
+// Window of the match finder at a compression level: none below 2 (matches inside a block only), else windowLog of libzstd's
+// parameter table for inputs above 256 KiB (clevels.h) -- what the reference's streams get from ZSTD_initCStream(level).
+int zenc_level_window(int level)
+{
+    static const unsigned char w[23] = { 0, 0, 20, 21, 21, 21, 21, 21, 21, 21, 22, 22, 22, 22, 22, 22, 22, 23, 23, 23, 25, 26, 27 };
+    if (level < 2) return 0;
+    return w[level > 22 ? 22 : level];
 }
 
 extern "C" size_t naf_gpu_zstd_compress_bound(size_t n)
@@ -469,12 +689,12 @@ extern "C" size_t naf_gpu_zstd_compress_bound(size_t n)
 // with_magic: 1 = whole frame with its magic number, 0 = whole frame without it (as stored in a .naf section),
 //   ZENC_PART | ZENC_PART_FIRST | ZENC_PART_LAST = a shard's part of a frame: blocks only, behind the 2-byte frame header when
 //   FIRST, ending the frame when LAST (an empty part that is not LAST is zero bytes; an empty LAST part is one empty Raw block).
-int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz, int block_log_hint)
+int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz, int block_log_hint, int window_log)
 {
     const bool part = (with_magic & ZENC_PART) != 0, part_first = (with_magic & ZENC_PART_FIRST) != 0, part_last = (with_magic & ZENC_PART_LAST) != 0;
     if (part) with_magic = 0;
     if (part && n == 0 && !part_last) {
-        if (part_first) { if (cap < 2) return ctx_fail(c, NAF_GPU_ECAP, "zstd_compress capacity %zu too small", cap); LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, 0); }
+        if (part_first) { if (cap < 2) return ctx_fail(c, NAF_GPU_ECAP, "zstd_compress capacity %zu too small", cap); LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, 0, (u32)(window_log >= 10 ? window_log : 19)); }
         *out_len = part_first ? 2 : 0;
         return 0;
     }
@@ -490,6 +710,12 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
     // that of its longest block; matches in ids / names / lengths are a few dozen bytes back anyway.
     if (use_lz && !e) { block_log = 14; const char *lb = getenv("NAF_GPU_LZ_BLOCK_LOG"); if (lb && atoi(lb) >= 10 && atoi(lb) <= 15) block_log = (u32)atoi(lb); }
     if (use_lz && block_log > 15) block_log = 15;                // LZ lengths and distances are kept in 16 bits
+    // cross-block matching (window_log >= 10; the host maps level / --long to it): 64 KiB blocks -- fewer block and table headers,
+    // and a repeat is cut less often; lengths still fit 16 bits (k_lzx_parse clamps a match at 65535)
+    const bool lzx = use_lz && window_log >= 10 && n >= 64;
+    if (window_log > 31) window_log = 31;
+    if (lzx) { block_log = 16; const char *lb = getenv("NAF_GPU_LZX_BLOCK_LOG"); if (lb && atoi(lb) >= 12 && atoi(lb) <= 16) block_log = (u32)atoi(lb); }
+    const u32 frame_wlog = lzx ? (u32)window_log : 19u;
     u64 bs = 1ull << block_log;
     u64 nblk64 = n ? (n + bs - 1) / bs : 1;
     if (nblk64 > 0x7FFFFFFFull) return ctx_fail(c, NAF_GPU_EARG, "stream too large");
@@ -517,23 +743,39 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
             HIP_TRY(c, hipMalloc(&c->d_seqctab, sizeof T));
             HIP_TRY(c, hipMemcpy(c->d_seqctab, &T, sizeof T, hipMemcpyHostToDevice));
         }
-        LzBufs B; B.slot = bs; B.seq_slot = bs / 4 + 2;
+        LzBufs B; B.slot = bs; B.seq_slot = bs / 4 + 2; B.of = nullptr; B.ofv = nullptr;
         B.lits = (u8 *)arena_alloc(c, (size_t)nblk * B.slot + 64); B.seqbuf = (u8 *)arena_alloc(c, (size_t)nblk * B.slot + 64);
-        B.ll = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8); B.ml = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8); B.of = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8);   // + 8: read in groups of eight
+        B.ll = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8); B.ml = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8);   // + 8: read in groups of eight
+        if (lzx) B.ofv = arena_new<u32>(c, (size_t)nblk * B.seq_slot + 8); else B.of = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8);
         B.nseq = arena_new<u32>(c, nblk); B.nlit = arena_new<u32>(c, nblk); B.seq_bytes = arena_new<u32>(c, nblk);
         ZEncPlan *plan1 = arena_new<ZEncPlan>(c, nblk);
         u16 *codes1 = arena_new<u16>(c, (size_t)nblk * 256); u8 *trees1 = (u8 *)arena_alloc(c, (size_t)nblk * ZENC_TREE_SLOT);
         u8 *mode = (u8 *)arena_alloc(c, nblk);
-        if (!B.lits || !B.seqbuf || !B.ll || !B.ml || !B.of || !B.nseq || !B.nlit || !B.seq_bytes || !plan1 || !codes1 || !trees1 || !mode) return NAF_GPU_ENOMEM;
+        if (!B.lits || !B.seqbuf || !B.ll || !B.ml || (!B.of && !B.ofv) || !B.nseq || !B.nlit || !B.seq_bytes || !plan1 || !codes1 || !trees1 || !mode) return NAF_GPU_ENOMEM;
         const u32 lz_buf = (u32)((bs + 1 + 320 + 15) & ~15ull);           // a block of the even split holds at most bs bytes
-        LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << LZ_HASH_LOG), d_src, (u64)n, nblk, B, lz_buf);
-        LAUNCH(c, "zenc_lz_seqenc", k_lz_seqenc, cdiv(nblk, 64), 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
+        if (lzx) {
+            // table of first occurrences: one in eight positions is an anchor, epochs of half the window, load factor <= 1/2
+            LdmTab T; T.wlog = (u32)window_log; T.elog = T.wlog - 1; T.pad = 0;
+            const u64 E = 1ull << T.elog, span = n < E ? n : E;
+            u32 tl = 4; while ((1ull << tl) < span / 4 + 16) tl++;
+            T.tlog = tl;
+            const u64 n_ep = (n >> T.elog) + 1, entries = n_ep << T.tlog;
+            T.tab = arena_new<u32>(c, entries); if (!T.tab) return NAF_GPU_ENOMEM;
+            HIP_TRY(c, hipMemsetAsync(T.tab, 0xFF, entries * 4, c->stream));
+            LAUNCH(c, "zenc_ldm_insert", k_ldm_insert, cdiv(cdiv(n, 8), 256), 256, 0, d_src, (u64)n, T);
+            HIP_TRY(c, hipFuncSetAttribute((const void *)k_lzx_parse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lz_buf + (2u << LZ_HASH_LOG))));   // above 64 KiB
+            LAUNCH(c, "zenc_lz_parse", k_lzx_parse, nblk, 64, lz_buf + (2u << LZ_HASH_LOG), d_src, (u64)n, nblk, B, lz_buf, T);
+            LAUNCH(c, "zenc_lz_seqenc", k_lzx_seqenc, nblk, 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
+        } else {
+            LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << LZ_HASH_LOG), d_src, (u64)n, nblk, B, lz_buf);
+            LAUNCH(c, "zenc_lz_seqenc", k_lz_seqenc, cdiv(nblk, 64), 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
+        }
         LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse);
         LAUNCH(c, "zenc_lz_choose", k_lz_choose, cdiv(nblk, 256), 256, 0, nblk, (const ZEncPlan *)plan, (const ZEncPlan *)plan1, (const u32 *)B.nseq, (const u32 *)B.seq_bytes, mode, offs);
         L.mode = mode; L.plan1 = plan1; L.codes1 = codes1; L.trees1 = trees1; L.B = B;
     }
     int rc = scan_exclusive_u64(c, offs, nblk, offs + nblk + 1); if (rc) return rc;
-    if (hdr) LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, with_magic);
+    if (hdr) LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, with_magic, frame_wlog);
     LAUNCH(c, "zenc_write", k_zenc_write, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, d_src, (u64)n, nblk, (const ZEncPlan *)plan, (const u16 *)codes, (const u8 *)trees,
            (const u64 *)offs, d_dst, hdr, L);
     u64 total = 0;
@@ -546,5 +788,5 @@ extern "C" int naf_gpu_zstd_compress(naf_gpu_ctx *c, const void *d_src, size_t n
 {
     if (!c || !d_dst || !out_len || (!d_src && n)) return NAF_GPU_EARG;
     arena_reset(c);
-    return zstd_encode(c, (const u8 *)d_src, n, level, (u8 *)d_dst, cap, out_len, 1);
+    return zstd_encode(c, (const u8 *)d_src, n, level, (u8 *)d_dst, cap, out_len, 1, 0, 0, zenc_level_window(level));
 }

@@ -457,6 +457,137 @@ NAF_HD u32 zenc_write_sequences(u8 *out, u32 cap, const u16 *ll, const u16 *ml, 
     return (u32)(end - out);
 }
 
+// ---- sequences with repeat offsets and per-block FSE tables (levels >= 2, --long) -----------------------------------------------
+// Repeat offsets (3.1.1.5) as far as ONE block can know them: a block is coded without knowing the three offsets the decoder holds
+// when it starts (blocks are produced independently), so a slot is 0 = unknown until a sequence of this block has defined it; an
+// unknown slot is never used as a repeat code.  zenc_offset_value returns the Offset_Value of the sequence (1..3: repeat code,
+// else distance + 3) and applies the decoder's update.
+struct RepState { u32 r[3]; };
+NAF_HD u32 zenc_offset_value(RepState &R, u32 d, u32 ll)
+{
+    u32 v = d + 3;
+    if (ll) { if (d == R.r[0]) v = 1; else if (d == R.r[1]) v = 2; else if (d == R.r[2]) v = 3; }
+    else { if (d == R.r[1]) v = 1; else if (d == R.r[2]) v = 2; else if (R.r[0] > 1 && d == R.r[0] - 1) v = 3; }
+    if (v > 3) { R.r[2] = R.r[1]; R.r[1] = R.r[0]; R.r[0] = d; }
+    else {
+        const u32 idx = v - 1 + (ll ? 0u : 1u);
+        if (idx == 1) { const u32 t = R.r[1]; R.r[1] = R.r[0]; R.r[0] = t; }
+        else if (idx >= 2) { const u32 t = idx == 2 ? R.r[2] : R.r[0] - 1; R.r[2] = R.r[1]; R.r[1] = R.r[0]; R.r[0] = t; }
+    }
+    return v;
+}
+
+// Workspace of the sequences encoder of one block (LDS on the GPU).  Table sizes: LL 2^9, OF 2^8, ML 2^9 at most (3.1.1.3.2.1.1).
+#define ZSEQ_LL_LOG 9
+#define ZSEQ_OF_LOG 8
+#define ZSEQ_ML_LOG 9
+struct SeqWS {
+    u32 cnt[3][64];
+    i16 norm[64];
+    u16 tableU16[(1 << ZSEQ_LL_LOG) + (1 << ZSEQ_OF_LOG) + (1 << ZSEQ_ML_LOG)];
+    FseCSym tt[36 + 32 + 53];
+    u8 tsym[1 << ZSEQ_LL_LOG]; u32 cumul[56];
+};
+// cost in 1/256 bit of coding `cnt` symbols with probabilities norm / 2^log (norm -1 counts as 1); ~0u when a symbol has no code
+NAF_HD u32 zenc_log2_256(u32 v)                                 // 256 * log2(v), v >= 1, piecewise linear between powers of two
+{
+    const u32 h = (u32)hibit32(v);
+    const u32 frac = h >= 8 ? (v >> (h - 8)) - 256 : (v << (8 - h)) - 256;       // 0..255
+    return h * 256 + frac;
+}
+NAF_HD u64 zenc_fse_cost(const u32 *cnt, u32 maxsym, const i16 *norm, u32 log)
+{
+    u64 c = 0;
+    for (u32 s = 0; s <= maxsym; s++) {
+        if (!cnt[s]) continue;
+        const i32 nv = norm[s];
+        if (nv == 0) return ~0ull;
+        c += (u64)cnt[s] * (log * 256 - zenc_log2_256((u32)(nv < 0 ? 1 : nv)));
+    }
+    return c;
+}
+// One of the three code tables of a block: picks predefined / RLE / FSE_Compressed (3.1.1.3.2.1), writes the table description
+// for the last one and builds the encoding table.  Returns the mode (0, 1, 2); *hdr_bytes = bytes appended at `out`.
+NAF_HD u32 zenc_seq_table(u8 *out, u32 *hdr_bytes, const u32 *cnt, u32 alphabet, u32 nseq, u32 max_log, const i16 *pre_norm, u32 pre_n, u32 pre_log,
+                          const SeqCTab &pre, i16 *norm, u16 *tableU16, FseCSym *tt, u8 *tsym, u32 *cumul, SeqCTab &ct)
+{
+    *hdr_bytes = 0;
+    u32 maxsym = 0, present = 0, only = 0;
+    for (u32 s = 0; s < alphabet; s++) if (cnt[s]) { maxsym = s; present++; only = s; }
+    if (present == 1) { out[0] = (u8)only; *hdr_bytes = 1; ct.tableU16 = nullptr; ct.tt = nullptr; ct.log = 0; return 1; }
+    // predefined: usable when every symbol has a code in it
+    u64 cost_pre = ~0ull;
+    if (maxsym < pre_n) cost_pre = zenc_fse_cost(cnt, maxsym, pre_norm, pre_log);
+    // FSE_Compressed: accuracy from the number of sequences (more states than sequences buy nothing)
+    u32 log = (u32)hibit32(nseq) + 1; if (log < 5) log = 5; if (log > max_log) log = max_log;
+    while ((1u << log) < present) log++;
+    u64 cost_fse = ~0ull; u32 nc = 0;
+    if (log <= max_log && fse_normalize(cnt, maxsym, nseq, log, norm)) {
+        nc = fse_write_ncount(out, norm, maxsym, log);
+        cost_fse = zenc_fse_cost(cnt, maxsym, norm, log) + (u64)nc * 8 * 256;
+    }
+    if (cost_fse < cost_pre) {
+        fse_build_ctable(norm, maxsym, log, tableU16, tt, tsym, cumul);
+        *hdr_bytes = nc; ct.tableU16 = tableU16; ct.tt = tt; ct.log = log;
+        return 2;
+    }
+    if (cost_pre == ~0ull) return 3;                            // no way to code this block's sequences: the caller keeps it literal-only
+    ct = pre;
+    return 0;
+}
+
+// Sequences_Section (3.1.1.3.2) for nseq >= 1 sequences with offset VALUES (repeat codes included) and the code tables chosen per
+// block.  ll / ml as in zenc_write_sequences; ofv[i] = Offset_Value >= 1.  Returns bytes written, 0 when cap is short or a table
+// could not be made.
+NAF_HD u32 zenc_write_sequences_x(u8 *out, u32 cap, const u16 *ll, const u16 *ml, const u32 *ofv, u32 nseq, const SeqCTabs &P, SeqWS &ws)
+{
+    if (cap < 256) return 0;
+    const i16 LLn[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1 };
+    const i16 OFn[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
+    const i16 MLn[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 };
+    u32 pos = 0;
+    if (nseq < 128) out[pos++] = (u8)nseq;
+    else if (nseq < 0x7F00) { out[pos++] = (u8)((nseq >> 8) + 128); out[pos++] = (u8)nseq; }
+    else { out[pos++] = 255; out[pos++] = (u8)(nseq - 0x7F00); out[pos++] = (u8)((nseq - 0x7F00) >> 8); }
+    for (u32 t = 0; t < 3; t++) for (u32 s = 0; s < 64; s++) ws.cnt[t][s] = 0;
+    for (u32 i = 0; i < nseq; i++) { ws.cnt[0][zenc_ll_code(ll[i])]++; ws.cnt[1][(u32)hibit32(ofv[i])]++; ws.cnt[2][zenc_ml_code(ml[i])]++; }
+    SeqCTab pre[3]; zenc_seq_ctabs(P, pre);
+    SeqCTab ct[3];
+    const u32 modes_at = pos++;
+    u32 hb, mode[3];
+    mode[0] = zenc_seq_table(out + pos, &hb, ws.cnt[0], 36, nseq, ZSEQ_LL_LOG, LLn, 36, 6, pre[0], ws.norm, ws.tableU16, ws.tt, ws.tsym, ws.cumul, ct[0]); pos += hb;
+    mode[1] = zenc_seq_table(out + pos, &hb, ws.cnt[1], 32, nseq, ZSEQ_OF_LOG, OFn, 29, 5, pre[1], ws.norm, ws.tableU16 + (1 << ZSEQ_LL_LOG), ws.tt + 36, ws.tsym, ws.cumul, ct[1]); pos += hb;
+    mode[2] = zenc_seq_table(out + pos, &hb, ws.cnt[2], 53, nseq, ZSEQ_ML_LOG, MLn, 53, 6, pre[2], ws.norm, ws.tableU16 + (1 << ZSEQ_LL_LOG) + (1 << ZSEQ_OF_LOG), ws.tt + 68, ws.tsym, ws.cumul, ct[2]); pos += hb;
+    if (mode[0] == 3 || mode[1] == 3 || mode[2] == 3) return 0;
+    out[modes_at] = (u8)((mode[0] << 6) | (mode[1] << 4) | (mode[2] << 2));
+    BitW b; bitw_init(b, out + pos);
+    // an RLE table has one state and no bits (Accuracy_Log 0)
+    auto init = [&](const SeqCTab &c, u32 sym) -> u32 { return c.tableU16 ? fse_cinit(c.tableU16, c.tt, sym) : 0u; };
+    auto step = [&](const SeqCTab &c, u32 &st, u32 sym) { if (c.tableU16) fse_cencode_nf(b, st, c.tableU16, c.tt, sym); };
+    u32 i = nseq - 1;
+    u32 vl = ll[i], vm = ml[i], vo = ofv[i];
+    u32 llc = zenc_ll_code(vl), mlc = zenc_ml_code(vm), ofc = (u32)hibit32(vo);
+    u32 sML = init(ct[2], mlc), sOF = init(ct[1], ofc), sLL = init(ct[0], llc);
+    bitw_add(b, vl - ll_base(llc), ll_bits(llc)); bitw_add(b, vm - ml_base(mlc), ml_bits(mlc)); bitw_flush32(b);
+    bitw_add(b, vo - (1u << ofc), ofc); bitw_flush32(b);
+    while (i-- > 0) {
+        if ((u32)(b.p - out) + 40 > cap) return 0;                // a sequence adds at most 26 + 32 + 31 bits
+        vl = ll[i]; vm = ml[i]; vo = ofv[i];
+        llc = zenc_ll_code(vl); mlc = zenc_ml_code(vm); ofc = (u32)hibit32(vo);
+        // fewer than 32 bits are pending at each flush point: + 26 (states) / + 32 (ll, ml extra bits) / + 31 (offset extra bits)
+        step(ct[1], sOF, ofc); step(ct[2], sML, mlc); step(ct[0], sLL, llc);
+        bitw_flush32(b);
+        bitw_add(b, vl - ll_base(llc), ll_bits(llc)); bitw_add(b, vm - ml_base(mlc), ml_bits(mlc)); bitw_flush32(b);
+        bitw_add(b, vo - (1u << ofc), ofc); bitw_flush32(b);
+    }
+    bitw_flush(b);
+    bitw_add(b, sML, ct[2].log); bitw_flush(b);
+    bitw_add(b, sOF, ct[1].log); bitw_flush(b);
+    bitw_add(b, sLL, ct[0].log); bitw_flush(b);
+    u8 *end = bitw_close(b);
+    return (u32)(end - out);
+}
+
 // Raw / RLE literals section header (3.1.1.3.1.1): returns header bytes.
 NAF_HD u32 zenc_lit_header_raw(u8 *out, u32 type, u32 regen)
 {

@@ -8,7 +8,7 @@
 
 static bool verbose = false, no_mask = false, force_stdout = false, strict = false, well_formed = false;
 static char *in_file_path = NULL, *out_file_path = NULL, *title = NULL;
-static int level = 1, fmt_cmd = NAF_FMT_AUTO, seq_type = NAF_SEQ_DNA;
+static int level = 1, fmt_cmd = NAF_FMT_AUTO, seq_type = NAF_SEQ_DNA, long_log = 0;
 static bool line_length_is_specified = false; static long long requested_line_length = 0;
 static bool created_output_file = false, success = false;
 
@@ -52,8 +52,9 @@ static void parse_command_line(int argc, char **argv)
                     if (!strcmp(argv[i], "--level")) { i++; set_level(argv[i]); continue; }
                     if (!strcmp(argv[i], "--line-length")) { i++; long long a; int how = decimal_arg(argv[i], &a); if (how == 0) die("can't parse the value of --line-length parameter\n"); if (a < 0) die("negative line length specified\n"); if (how != 2) die("can't parse the value of --line-length parameter\n"); requested_line_length = a; line_length_is_specified = true; continue; }
                     if (!strcmp(argv[i], "--long")) { i++; long long a; if (decimal_arg(argv[i], &a) != 2) die("can't parse the value of --long argument\n");
-                        if (a < 10) warn("--long value of is %lld is smaller than the lowest supported value %d, using %d instead\n", a, 10, 10);
-                        else if (a > 31) warn("--long value of is %lld is larger than the largest supported value %d, using %d instead\n", a, 31, 31);
+                        if (a < 10) { warn("--long value of is %lld is smaller than the lowest supported value %d, using %d instead\n", a, 10, 10); a = 10; }
+                        else if (a > 31) { warn("--long value of is %lld is larger than the largest supported value %d, using %d instead\n", a, 31, 31); a = 31; }
+                        long_log = (int)a;
                         continue; }
                     if (!strcmp(argv[i], "--out")) { i++; if (out_file_path) die("double --out parameter\n"); if (!*argv[i]) die("empty --out parameter\n"); out_file_path = argv[i]; continue; }
                     if (!strcmp(argv[i], "--in")) { i++; if (in_file_path) die("can compress only one file at a time\n"); if (!*argv[i]) die("empty input file name\n"); in_file_path = argv[i]; continue; }
@@ -203,7 +204,7 @@ int main(int argc, char **argv)
         if (!in_file_path) die("output file is not specified\n");
         size_t len = strlen(in_file_path) + 5; auto_path = (char *)malloc(len); snprintf(auto_path, len, "%s.naf", in_file_path); out_file_path = auto_path;
     }
-    naf_gpu_ennaf_opts o = { fmt_cmd, seq_type, no_mask, strict, level, line_length_is_specified ? requested_line_length : -1, title };
+    naf_gpu_ennaf_opts o = { fmt_cmd, seq_type, no_mask, strict, level, line_length_is_specified ? requested_line_length : -1, title, long_log };
     static naf_gpu_ennaf_report R;
     FILE *OUT = stdout;
     void *d_naf = NULL; size_t naf_len = 0;

@@ -91,8 +91,8 @@ def unnaf_sharded(ctx, d_naf, out_type=0, use_mask=True, line_length=-1, dst=0, 
 
 
 # ---------------------------------------------------------------------------------------------------------------- encode
-def make_opts(fmt=capi.FMT_AUTO, seq_type=capi.SEQ_DNA, no_mask=False, strict=False, level=1, line_length=-1, title=None):
-    return capi.EnnafOpts(fmt, seq_type, int(no_mask), int(strict), level, line_length, title)
+def make_opts(fmt=capi.FMT_AUTO, seq_type=capi.SEQ_DNA, no_mask=False, strict=False, level=1, line_length=-1, title=None, long_log=0):
+    return capi.EnnafOpts(fmt, seq_type, int(no_mask), int(strict), level, line_length, title, long_log)
 
 
 def _is_eol(b):

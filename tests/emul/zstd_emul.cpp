@@ -194,3 +194,32 @@ extern "C" int emul_window_reader(const u8 *stream, u32 size, const u8 *weights,
     for (u32 i = 0; i < n; i++) if (out[i] != ref[i]) return (int)i + 1;
     return 0;
 }
+
+// block statistics of a frame (no magic check on the decoded data): out[0] blocks, [1] compressed blocks, [2] sequences,
+// [3] literal bytes regenerated, [4] bytes of literals sections, [5] bytes of sequences sections
+extern "C" long long emul_zstd_frame_stats(const u8 *src, size_t len, u64 *out)
+{
+    if (len < 5 || ld32(src) != 0xFD2FB528u) return -1;
+    src += 4; len -= 4;
+    ZFrameHdr fh = zstd_parse_frame_header(src, len);
+    if (fh.err) return -10 - fh.err;
+    u64 pos = fh.hdr_size;
+    for (int k = 0; k < 6; k++) out[k] = 0;
+    for (;;) {
+        if (pos + 3 > len) return -2;
+        u32 h = ld24(src + pos), last = h & 1, type = (h >> 1) & 3, size = h >> 3;
+        u32 csize = type == BT_RLE ? 1 : size;
+        if (pos + 3 + csize > len) return -2;
+        ZBlock b; memset(&b, 0, sizeof b);
+        b.src_off = pos + 3; b.bsize = size; b.btype = (u8)type; b.last = (u8)last;
+        out[0]++;
+        if (type == BT_COMP) {
+            zstd_parse_block(src + b.src_off, b);
+            if (b.err) return -100 - b.err;
+            out[1]++; out[2] += b.nseq; out[3] += b.lit_regen; out[4] += b.seq_off ? b.seq_off : size; out[5] += b.seq_off ? size - b.seq_off : 0;
+        } else out[3] += size;
+        pos += 3 + csize;
+        if (last) break;
+    }
+    return (long long)pos;
+}

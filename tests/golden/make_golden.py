@@ -72,25 +72,7 @@ def mask_boundary_fasta():
     return b"".join(parts)
 
 
-def repeat_genome(seed=3, unit=40000, copies=50):
-    rng = np.random.Generator(np.random.PCG64(seed))
-    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    base = acgt[rng.integers(0, 4, unit)]
-    parts = []
-    for i in range(copies):
-        s = base.copy()
-        idx = rng.integers(0, unit, 150)
-        s[idx] = acgt[rng.integers(0, 4, 150)]
-        if i % 3 == 0:
-            s[1000:3000] |= 0x20
-        parts.append(s)
-        parts.append(acgt[rng.integers(0, 4, int(rng.integers(10, 4000)))])
-    seq = np.concatenate(parts)
-    third = len(seq) // 3
-    out = b""
-    for k in range(3):
-        out += b">rep%d repeat-rich synthetic\n" % k + synth.wrap_lines(seq[k * third:(k + 1) * third], 60)
-    return out
+repeat_genome = synth.repeat_genome
 
 
 def naf_cases():

@@ -214,3 +214,18 @@ def test_strict_matches_the_reference(ctxs, oracle):
         assert (p.returncode, p.stderr.decode("latin1")) == (rc, err), (text, args)
     p = subprocess.run([os.path.join(BIN, "ennaf"), "--strict", "--well-formed", "-c"], input=b">a\nAC\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode == 1 and p.stderr == b"ennaf error: '--well-formed' and '--strict' can't be used together\n"
+
+
+def test_sharded_ennaf_at_a_high_level(ctxs, oracle):
+    """Shards of one archive at level 19: every shard matches inside its own part of a stream; the joined frames decode."""
+    from naf_amd import synth, shard
+    text = synth.repeat_genome(seed=5, unit=30000, copies=20)
+    gpu = ctxs[0]
+    naf, rep = shard.ennaf_sharded_local(ctxs[:3], gpu.to_device(text), shard.make_opts(level=19))
+    mine = host(naf)
+    want = oracle.unnaf(oracle.ennaf(text), -1)
+    assert oracle.unnaf(mine, -1) == want
+    assert host(gpu.unnaf(gpu.to_device(mine), -1)) == want
+    if oracle.have_ref():
+        assert oracle.ref_unnaf(mine) == want
+    assert len(mine) < 0.5 * len(host(shard.ennaf_sharded_local(ctxs[:3], gpu.to_device(text), shard.make_opts())[0]))

@@ -151,6 +151,61 @@ def test_lz_block_format_against_three_decoders(emul, oracle):
                 assert r == len(d) and back.raw[:r] == d
 
 
+def test_lzx_block_format_against_the_decoders(emul, oracle):
+    """The cross-block stage of the GPU encoder (zstd_enc.hip: k_ldm_insert / k_lzx_parse / k_lzx_seqenc) as a serial model that shares
+    its sequence writer (zenc_write_sequences_x: repeat-offset codes from a per-block history, predefined / RLE / FSE_Compressed
+    tables chosen per block): frames decode under the from-spec oracle and the decoder kernels' logic, windows 2^10 .. 2^27."""
+    emul.emul_zstd_compress_lzx.restype = ctypes.c_longlong
+    emul.emul_zstd_compress_lzx.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)]
+    rng = np.random.default_rng(23)
+    unit = rng.integers(0, 16, 30000, dtype=np.uint8).tobytes()
+    def mutated(k):
+        a = bytearray(unit)
+        for i in rng.integers(0, len(a), k):
+            a[i] = int(rng.integers(0, 16))
+        return bytes(a)
+    data = [b"", b"A", b"abcabcabcabcabc" * 3, b"".join(b"SRR%07d.%d length=%d\x00" % (1234567, i, 150) for i in range(1, 9000)),
+            np.full(40000, 150, dtype="<u4").tobytes(), b"".join(mutated(40) + rng.integers(0, 16, int(rng.integers(1, 999)), dtype=np.uint8).tobytes() for _ in range(8)),
+            b"A" * 70000 + b"CGT" * 30000 + b"A" * 70000, rng.integers(0, 4, 90000, dtype=np.uint8).tobytes(),
+            unit[:5000] + b"x" + unit[:5000] + b"yz" + unit[:5000] + b"abc" + unit[:5000] + b"defg" + unit[:5000]]
+    for i in range(12):
+        n = int(rng.integers(1, 60000)); a = int(rng.choice([2, 4, 16, 256]))
+        d = rng.integers(0, a, n, dtype=np.uint8).tobytes()
+        data.append(d[: n // 3] * 3 if i % 2 else d)
+    st = (ctypes.c_uint32 * 3)()
+    reps = 0
+    for d in data:
+        for blk, wlog in ((4096, 10), (16384, 17), (32768, 20), (65535, 27)):
+            cap = 2 * len(d) + 4096
+            out = ctypes.create_string_buffer(cap)
+            n = emul.emul_zstd_compress_lzx(d, len(d), blk, wlog, out, cap, st)
+            assert n > 0, (len(d), blk, wlog, n)
+            reps += st[1]
+            frame = out.raw[:n]
+            assert oracle.zstd_decompress(frame, len(d) + 16) == d, (len(d), blk, wlog)
+            back = ctypes.create_string_buffer(len(d) + 64)
+            assert emul.emul_zstd_decompress_frame(frame, n, back, len(d) + 64) == len(d) and back.raw[:len(d)] == d
+    assert reps > 1000                                          # repeat-offset codes are exercised
+
+
+def test_lzx_model_on_the_repeat_genomes_is_close_to_the_reference(emul, oracle):
+    """on the repeat-rich golden inputs the cross-block stage stays within 10 % of the reference's archive made
+    with the same flags (tests/golden/naf/repeat_*.naf, written by the real ennaf -19 / -3 --long 27)."""
+    from naf_amd import synth as mg
+    emul.emul_zstd_compress_lzx.restype = ctypes.c_longlong
+    emul.emul_zstd_compress_lzx.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)]
+    for name, text, wlog in (("repeat_l19", mg.repeat_genome(), 23), ("repeat_long27", mg.repeat_genome(seed=11, unit=300000, copies=8), 27)):
+        ref = open(os.path.join(ROOT, "tests", "golden", "naf", name + ".naf"), "rb").read()
+        seq = oracle.split_text(text, 0, False).seq
+        assert oracle.zstd_decompress(oracle.parse_naf(ref).frame(ref, 4), len(seq) + 16) == seq     # the same stream the reference compressed
+        cap = len(seq) + 4096
+        out = ctypes.create_string_buffer(cap)
+        n = emul.emul_zstd_compress_lzx(seq, len(seq), 65535, wlog, out, cap, None)
+        assert n > 0 and oracle.zstd_decompress(out.raw[:n], len(seq) + 16) == seq
+        ref_frame = oracle.parse_naf(ref).comp[4]
+        assert n <= 1.10 * ref_frame, (name, n, ref_frame)
+
+
 def test_decoder_window_reader_at_every_rate_and_alignment(emul):
     """k_huf_literals' sector-window reader (two-sector LDS ring, register-staged prefetch; four sectors above 7-bit codes),
     single-stepped on the host: streams from 1 bit to 11 bits per symbol, every start alignment class, against the plain reader.
