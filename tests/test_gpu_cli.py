@@ -104,3 +104,24 @@ def test_clis_on_several_contexts_and_in_ranges(oracle, tmp_path):
     with pytest.raises(ValueError) as ex:
         oracle.split_text(bad)
     assert e.returncode == 1 and e.stdout == b"" and e.stderr.decode() == "ennaf error: " + str(ex.value).strip() + "\n"
+
+
+def test_cli_levels_and_long(oracle):
+    """`ennaf -19` and `ennaf -3 --long 27` through the C host: the flags reach the match finder (ennaf.c:247-273, :505), the archives
+    stay within 10 % of the real ennaf's with the same flags and come back through both unnafs; on several contexts too."""
+    from naf_amd import synth
+    for name, text, args in (("repeat_l19", synth.repeat_genome(), ["-19"]),
+                             ("repeat_long27", synth.repeat_genome(seed=11, unit=300000, copies=8), ["-3", "--long", "27"])):
+        ref_len = os.path.getsize(os.path.join(ROOT, "tests", "golden", "naf", name + ".naf"))
+        for env in (dict(os.environ), dict(os.environ, NAF_GPUS="0,0,0")):
+            e = subprocess.run([os.path.join(BIN, "ennaf"), *args, "-c"], input=text, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+            assert e.returncode == 0, e.stderr
+            naf = e.stdout
+            if "NAF_GPUS" not in env:
+                assert len(naf) <= 1.10 * ref_len, (name, len(naf), ref_len)
+            else:
+                assert len(naf) <= 1.35 * ref_len, (name, len(naf), ref_len)      # three shards: each matches inside its own part only
+            u = subprocess.run([os.path.join(BIN, "unnaf"), "-c"], input=naf, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            assert u.returncode == 0 and u.stdout == text
+            if oracle.have_ref():
+                assert oracle.ref_unnaf(naf) == text
