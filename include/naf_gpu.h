@@ -68,6 +68,10 @@ int         naf_gpu_reserve(naf_gpu_ctx *ctx, size_t bytes);
 /* ---- device memory for hosts that do not link HIP themselves (the C CLIs) ---------------------------- */
 int  naf_gpu_malloc(naf_gpu_ctx *ctx, size_t bytes, void **d_ptr);
 int  naf_gpu_free(naf_gpu_ctx *ctx, void *d_ptr);
+/* free / total device memory as the runtime sees it now (the hosts size their chunks of an input larger than HBM with it);
+ * the scratch arena of the context counts as used: naf_gpu_release_scratch gives it back */
+int  naf_gpu_mem_info(naf_gpu_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
+int  naf_gpu_release_scratch(naf_gpu_ctx *ctx);
 int  naf_gpu_host_alloc(naf_gpu_ctx *ctx, size_t bytes, void **h_pinned);
 int  naf_gpu_host_free(naf_gpu_ctx *ctx, void *h_pinned);
 int  naf_gpu_upload(naf_gpu_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);     /* async on the stream */

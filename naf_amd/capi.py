@@ -20,7 +20,7 @@ EXPORTS = [
     "naf_gpu_init", "naf_gpu_shutdown", "naf_gpu_strerror", "naf_gpu_last_error", "naf_gpu_set_stream",
     "naf_gpu_synchronize", "naf_gpu_reserve", "naf_gpu_malloc", "naf_gpu_free", "naf_gpu_host_alloc",
     "naf_gpu_host_free", "naf_gpu_upload", "naf_gpu_download", "naf_gpu_download_async", "naf_gpu_histogram", "naf_gpu_zstd_decompress",
-    "naf_gpu_zstd_compress", "naf_gpu_zstd_compress_bound", "naf_gpu_parse_header", "naf_gpu_parse_header_host",
+    "naf_gpu_mem_info", "naf_gpu_release_scratch", "naf_gpu_zstd_compress", "naf_gpu_zstd_compress_bound", "naf_gpu_parse_header", "naf_gpu_parse_header_host",
     "naf_gpu_unnaf_size", "naf_gpu_unnaf", "naf_gpu_unnaf_range", "naf_gpu_ennaf_bound", "naf_gpu_ennaf",
     "naf_gpu_set_timing", "naf_gpu_get_timing",
     "naf_gpu_ennaf_sniff", "naf_gpu_ennaf_count_lines", "naf_gpu_ennaf_find_cut", "naf_gpu_ennaf_shard_begin", "naf_gpu_ennaf_shard_bound",

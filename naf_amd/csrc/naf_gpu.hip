@@ -137,6 +137,22 @@ void *arena_alloc(naf_gpu_ctx *c, size_t bytes)
     return p;
 }
 
+extern "C" int naf_gpu_mem_info(naf_gpu_ctx *c, size_t *free_bytes, size_t *total_bytes)
+{
+    if (!c || !free_bytes || !total_bytes) return NAF_GPU_EARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemGetInfo(free_bytes, total_bytes));
+    return 0;
+}
+extern "C" int naf_gpu_release_scratch(naf_gpu_ctx *c)
+{
+    if (!c) return NAF_GPU_EARG;
+    hipStreamSynchronize(c->stream);
+    ennaf_shard_state_free(c);                                    // a shard between its begin and its finish lives in the arena
+    for (auto &ch : c->chunks) hipFree(ch.base);
+    c->chunks.clear();
+    return 0;
+}
 extern "C" int naf_gpu_reserve(naf_gpu_ctx *c, size_t bytes)
 {
     if (!c) return NAF_GPU_EARG;

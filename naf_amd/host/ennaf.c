@@ -184,6 +184,129 @@ static void *enc_worker(void *arg)
     return NULL;
 }
 
+/* ---- an input larger than the device memory: the same shard protocol, one shard after the other on ONE device ------------------------
+ * (process.c:143-150 reads 16 KiB at a time and never holds the input; here a CHUNK is what fits the device.)  Pass 1 walks the
+ * file: every chunk ends behind its last complete line (FASTA) or record (FASTQ, from a census of its line starts), runs
+ * naf_gpu_ennaf_shard_begin and keeps only the fixed-size shard record.  Pass 2 reads each chunk again, repeats the begin and -- now
+ * that every record is known -- finishes it; the parts go to a temporary file ($TMPDIR, like the reference's per-stream files,
+ * ennaf.c:478-505) and are joined into the archive by naf_gpu_ennaf_stitch_plan.  NAF_GPU_CHUNK_BYTES sets the chunk size
+ * (default: a fifth of the free device memory); an input that fits one chunk takes the one-call path. */
+#define MAX_CHUNKS NAF_GPU_MAX_SHARDS
+static size_t ch_start[MAX_CHUNKS + 1]; static int ch_n = 0;
+static naf_gpu_shard_info ch_infos[MAX_CHUNKS]; static naf_gpu_shard_pieces ch_pcs[MAX_CHUNKS];
+static size_t ch_tmp_off[MAX_CHUNKS]; static FILE *ch_tmp = NULL;
+static naf_gpu_stitch_seg ch_segs[7 + 6 * MAX_CHUNKS]; static size_t ch_nsegs = 0; static unsigned char ch_lit[4096 + 256];
+
+static size_t chunk_bytes_wanted(size_t file_size)
+{
+    const char *e = getenv("NAF_GPU_CHUNK_BYTES");
+    size_t c = 0;
+    if (e && *e) { char *end; unsigned long long v = strtoull(e, &end, 10); if (*end || v < 4096) die("can't parse NAF_GPU_CHUNK_BYTES=\"%s\"\n", e); c = (size_t)v; }
+    else { size_t fr = 0, tot = 0; GPU_TRY(naf_gpu_mem_info(gpu, &fr, &tot)); c = fr / 5; }
+    if (c < 4096) c = 4096;
+    if ((file_size + c - 1) / c > MAX_CHUNKS - 1) c = (file_size + MAX_CHUNKS - 2) / (MAX_CHUNKS - 1);     /* cuts fall short of the nominal ends: leave one spare */
+    return c;
+}
+/* offset just behind the last EOL-class byte of file range [a, b); a when there is none */
+static size_t last_line_end(int fd, size_t a, size_t b)
+{
+    static unsigned char win[1 << 20];
+    size_t hi = b;
+    while (hi > a) {
+        size_t lo = hi - a > sizeof win ? hi - sizeof win : a, len = hi - lo;
+        if (pread(fd, win, len, (off_t)lo) != (ssize_t)len) die("can't read the input\n");
+        for (size_t i = len; i-- > 0;) if (win[i] >= 0x0A && win[i] <= 0x0D) return lo + i + 1;
+        hi = lo;
+    }
+    return a;
+}
+static bool encode_chunked(FILE *IN, size_t fn, const naf_gpu_ennaf_opts *o, naf_gpu_ennaf_report *R, size_t *naf_len)
+{
+    const int fd = fileno(IN);
+    const size_t C = chunk_bytes_wanted(fn);
+    if (fn <= C) return false;
+    if (title && strlen(title) >= 4096) return false;
+    void *d_buf = NULL; GPU_TRY(naf_gpu_malloc(gpu, C + 64, &d_buf));
+    int fmt = 0; uint64_t p0 = 0;
+    /* pass 1: the cuts and the shard records */
+    size_t pos = 0; int k = 0;
+    while (pos < fn) {
+        if (k >= MAX_CHUNKS) die("input needs more than %d chunks of %zu bytes\n", MAX_CHUNKS, C);
+        size_t end = pos + C < fn ? pos + C : fn;
+        GPU_TRY(naf_gpu_read_file(gpu, fd, pos, end - pos, d_buf));
+        if (k == 0) {
+            GPU_TRY(naf_gpu_ennaf_sniff(gpu, d_buf, end - pos, o->format, &fmt, &p0));
+            if (fmt == 0 || p0 >= end - pos) { naf_gpu_free(gpu, d_buf); return false; }      /* a chunk of white space in front: the one-call path sorts it out */
+            pos = (size_t)p0;
+        }
+        const char *text = (const char *)d_buf + (k == 0 ? (size_t)p0 : 0);
+        if (end < fn) {                                       /* not the last chunk: stop behind the last complete line / record */
+            size_t cut;
+            if (fmt == NAF_FMT_FASTQ) {
+                uint64_t lines = 0, off = 0;
+                GPU_TRY(naf_gpu_ennaf_count_lines(gpu, text, end - pos, 1, &lines));
+                if (lines < 5) die("a FASTQ record does not fit a chunk of %zu bytes (NAF_GPU_CHUNK_BYTES)\n", C);
+                GPU_TRY(naf_gpu_ennaf_find_cut(gpu, text, end - pos, fmt, 1, (lines - 1) / 4 * 4, &off));
+                cut = pos + (size_t)off;
+            } else cut = last_line_end(fd, pos, end);
+            if (cut <= pos) die("a line does not fit a chunk of %zu bytes (NAF_GPU_CHUNK_BYTES)\n", C);
+            end = cut;
+        }
+        ch_start[k] = pos;
+        /* n_shards is not known yet: k + 2 says "not the last one", the records are completed below */
+        GPU_TRY(naf_gpu_ennaf_shard_begin(gpu, text, end - pos, o, fmt, (uint32_t)k, (uint32_t)(end == fn ? k + 1 : k + 2), &ch_infos[k]));
+        pos = end; k++;
+    }
+    ch_n = k; ch_start[k] = fn;
+    for (int i = 0; i < ch_n; i++) ch_infos[i].n_shards = (uint32_t)ch_n;
+    /* pass 2: the parts */
+    { const char *td = getenv("TMPDIR"); char path[4096];
+      snprintf(path, sizeof path, "%s/ennaf-gpu-XXXXXX", (td && *td) ? td : "/tmp");
+      int tfd = mkstemp(path); if (tfd < 0) die("can't create temporary file\n");
+      unlink(path); ch_tmp = fdopen(tfd, "w+b"); if (!ch_tmp) die("can't create temporary file\n"); }
+    size_t tmp_at = 0;
+    for (k = 0; k < ch_n; k++) {
+        const size_t a = ch_start[k], len = ch_start[k + 1] - a;
+        GPU_TRY(naf_gpu_read_file(gpu, fd, a, len, d_buf));
+        naf_gpu_shard_info again;
+        GPU_TRY(naf_gpu_ennaf_shard_begin(gpu, d_buf, len, o, fmt, (uint32_t)k, (uint32_t)ch_n, &again));
+        const size_t pcap = naf_gpu_ennaf_shard_bound(len);
+        void *d_pieces = NULL; GPU_TRY(naf_gpu_malloc(gpu, pcap, &d_pieces));
+        GPU_TRY(naf_gpu_ennaf_shard_finish(gpu, o, ch_infos, d_pieces, pcap, &ch_pcs[k]));
+        ch_tmp_off[k] = tmp_at;
+        if (ch_pcs[k].total) {
+            fflush(ch_tmp);
+            GPU_TRY(naf_gpu_write_file(gpu, fileno(ch_tmp), tmp_at, d_pieces, ch_pcs[k].total));
+            tmp_at += ch_pcs[k].total;
+        }
+        GPU_TRY(naf_gpu_free(gpu, d_pieces));
+    }
+    GPU_TRY(naf_gpu_free(gpu, d_buf));
+    size_t ll = 0; uint64_t nl = 0;
+    int rc = naf_gpu_ennaf_stitch_plan(o, ch_infos, ch_pcs, (uint32_t)ch_n, ch_segs, sizeof ch_segs / sizeof ch_segs[0], &ch_nsegs, ch_lit, sizeof ch_lit, &ll, &nl, R);
+    if (rc) die("can't join the parts of the archive: %s\n", naf_gpu_strerror(rc));
+    *naf_len = (size_t)nl;
+    return true;
+}
+/* the archive of a chunked run: header bytes from the plan, the parts from the temporary file, in archive order */
+static void write_chunked(FILE *OUT)
+{
+    static unsigned char buf[1 << 20];
+    for (size_t i = 0; i < ch_nsegs; i++) {
+        const naf_gpu_stitch_seg *g = &ch_segs[i];
+        if (!g->len) continue;
+        if (g->shard < 0) { if (fwrite(ch_lit + g->src_off, 1, g->len, OUT) != g->len) die("can't write to file - disk full?\n"); continue; }
+        size_t left = g->len; off_t at = (off_t)(ch_tmp_off[g->shard] + g->src_off);
+        while (left) {
+            size_t n = left < sizeof buf ? left : sizeof buf;
+            if (pread(fileno(ch_tmp), buf, n, at) != (ssize_t)n) die("can't read temporary file\n");
+            if (fwrite(buf, 1, n, OUT) != n) die("can't write to file - disk full?\n");
+            left -= n; at += (off_t)n;
+        }
+    }
+    fclose(ch_tmp); ch_tmp = NULL;
+}
+
 int main(int argc, char **argv)
 {
     prog_name = "ennaf";
@@ -242,7 +365,13 @@ int main(int argc, char **argv)
             phase("ennaf on the GPUs");
         }
     }
-    if (!sharded) {
+    bool chunked = false;
+    if (!sharded && fd_is_regular(fileno(IN)) && fstat(fileno(IN), &st) == 0 && st.st_size > 0) {
+        gpu_open();
+        chunked = encode_chunked(IN, (size_t)st.st_size, &o, &R, &naf_len);
+        if (chunked) phase("ennaf in chunks");
+    }
+    if (!sharded && !chunked) {
         size_t n = 0; unsigned char *text = NULL;
         void *d_text = read_to_device(IN, &n);                 /* regular file: straight to HBM through the pinned lanes */
         if (!d_text) text = read_all(IN, &n);
@@ -260,7 +389,8 @@ int main(int argc, char **argv)
     if (fmt_ext != NAF_FMT_AUTO && fmt_cmd != NAF_FMT_AUTO && fmt_ext != fmt_cmd) warn("input file extension does not match format specified in the command line\n");
     if (out_file_path && !force_stdout) { OUT = fopen(out_file_path, "wb"); if (!OUT) die("can't create output file\n"); created_output_file = true; }
     if (verbose) msg("Output line length: %llu\n", line_length_is_specified ? (unsigned long long)requested_line_length : (unsigned long long)R.longest_line);
-    if (!sharded) write_from_device(OUT, d_naf, naf_len);
+    if (chunked) write_chunked(OUT);
+    else if (!sharded) write_from_device(OUT, d_naf, naf_len);
     else {
         const int n = n_devs;
         fflush(OUT);

@@ -3,6 +3,8 @@ test matrix (tests/golden/ref_tests, ref_cases.json) and interoperate with the r
 import os
 import subprocess
 
+import numpy as np
+
 import pytest
 
 from conftest import GOLDEN, ROOT, golden_bytes, naf_cases, ref_cases
@@ -125,3 +127,42 @@ def test_cli_levels_and_long(oracle):
             assert u.returncode == 0 and u.stdout == text
             if oracle.have_ref():
                 assert oracle.ref_unnaf(naf) == text
+
+
+def test_cli_input_in_chunks(oracle, tmp_path):
+    """An input larger than the device memory is encoded one chunk after the other (naf_amd/host/ennaf.c: encode_chunked, the shard
+    protocol on one device, parts through a temporary file).  Forced here with NAF_GPU_CHUNK_BYTES on inputs of a few MB: the
+    archive holds the same six streams as the one-call archive and comes back through both unnafs."""
+    from naf_amd import synth
+    rng = np.random.default_rng(3)
+    fasta = synth.fasta_mixed(40, 60000, 70, 5) + b">last one\n" + bytes(rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), 333333)) + b"\n"
+    fastq = synth.fastq_reads(30000, 150, seed=2) + synth.fastq_reads(3000, 90, seed=4, var_len=True)
+    crlf = fasta[:400000].replace(b"\n", b"\r\n")
+    for name, text, sizes in (("fa", fasta, (400000, 1000003, 2500000)), ("fq", fastq, (200000, 3333333)), ("crlf", crlf, (100000,))):
+        src = tmp_path / (name + ".txt"); src.write_bytes(text)
+        whole = subprocess.run([os.path.join(BIN, "ennaf"), str(src), "-c"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert whole.returncode == 0, whole.stderr
+        hw = oracle.parse_naf(whole.stdout)
+        for cb in sizes:
+            for extra in ([], ["-19"]):
+                e = subprocess.run([os.path.join(BIN, "ennaf"), *extra, str(src), "-c"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120,
+                                   env=dict(os.environ, NAF_GPU_CHUNK_BYTES=str(cb), NAF_GPU_CLI_TIMING="1"))
+                assert e.returncode == 0, e.stderr
+                assert (b"ennaf in chunks" in e.stderr) == (len(text) > cb)      # the chunked path did run
+                naf = e.stdout
+                h = oracle.parse_naf(naf)
+                assert naf[: h.header_bytes] == whole.stdout[: hw.header_bytes]
+                for i in range(6):
+                    if hw.payload_off[i] is None:
+                        assert h.payload_off[i] is None
+                        continue
+                    assert h.orig[i] == hw.orig[i]
+                    assert oracle.zstd_decompress(h.frame(naf, i), hw.orig[i] + 64) == oracle.zstd_decompress(hw.frame(whole.stdout, i), hw.orig[i] + 64), (name, cb, i)
+                u = subprocess.run([os.path.join(BIN, "unnaf"), "-c"], input=naf, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+                assert u.returncode == 0 and u.stdout == oracle.unnaf(whole.stdout, -1)
+                if oracle.have_ref() and len(text) > 3000:
+                    assert oracle.ref_unnaf(naf) == u.stdout
+    # a record that does not fit a chunk
+    e = subprocess.run([os.path.join(BIN, "ennaf"), str(tmp_path / "fa.txt"), "-c"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120,
+                       env=dict(os.environ, NAF_GPU_CHUNK_BYTES="4096"))
+    assert e.returncode != 0 and b"does not fit a chunk" in e.stderr
