@@ -32,6 +32,16 @@ NAF_HD u32 ld16(const u8 *p) { return (u32)p[0] | ((u32)p[1] << 8); }
 NAF_HD void st64(u8 *p, u64 v) { memcpy(p, &v, 8); }
 NAF_HD void st32(u8 *p, u32 v) { memcpy(p, &v, 4); }
 
+// A load from GLOBAL memory at an address held as an integer.  A plain pointer made from an integer is a flat pointer, and flat
+// loads count against lgkmcnt as well as vmcnt: every wait for LDS or scalar data would wait for them too.
+template <typename T> NAF_HD T ldg_at(u64 addr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(1))) T *)addr;
+#else
+    return *(const T *)addr;
+#endif
+}
 NAF_HD int hibit32(u32 v) { return 31 - __builtin_clz(v); }
 
 // ---- backward bit reader (RFC 8878 4.1 "bitstreams are read backward") -----------------------------

@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void k_emit_tile(EmitP P, const TileIdx *ti, u
     if (FOURBIT) {
         // 16 nibbles from base g0: one 16-byte load from the 8-aligned address below, then a funnel shift
         u64 addr = (u64)P.seq + (g0 >> 1);
-        const uint4 q = *(const uint4 *)(addr & ~7ull);
+        const uint4 q = ldg_at<uint4>(addr & ~7ull);
         u64 q0 = (u64)q.x | ((u64)q.y << 32), q1 = (u64)q.z | ((u64)q.w << 32);
         u32 sh = (u32)(addr & 7) * 8 + (u32)(g0 & 1) * 4;
         expand16(P.lut, sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0, lo, hi);
@@ -788,26 +788,25 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     __shared__ u64 s_tog[EMIT_TOG_LDS];
     const u32 sl[4] = { P.fpair[0], P.fpair[1], P.fpair[2], P.fpair[3] };     // uniform: scalar loads
     const u32 lane16 = threadIdx.x * 16;
-    u64 V0s[FLAT_TPW], V1s[FLAT_TPW]; u32 grels[FLAT_TPW], nls[FLAT_TPW], haves[FLAT_TPW]; bool live[FLAT_TPW];
-    // the 64 bits below `top` (a bit address inside the source buffer: what lies below the stream's first symbol is never used):
-    // one 16-byte load from the 8-aligned address below, then a funnel shift
-    auto window = [&](u64 t) -> u64 {
-        const u64 lb = t - 64, addr = (u64)P.fsrc + (lb >> 3);
-        const uint4 w = *(const uint4 *)(addr & ~7ull);
-        const u64 w0 = (u64)w.x | ((u64)w.y << 32), w1 = (u64)w.z | ((u64)w.w << 32);
-        const u32 sh = (u32)(addr & 7) * 8 + ((u32)lb & 7);
-        return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
-    };
-    // ---- phase 1: where every chunk's codes are, and the loads.  Everything a lane computes is 32-bit and relative to the tile
-    // (its first base line a.gline, its first packed byte tf.qf); the 64-bit parts are the same for the whole tile (scalar).
+    // ---- phase 0: the records of the workgroup's tiles (uniform addresses: scalar loads, all of them in flight together -- one
+    // tile after the other, each waiting for its own records and then for its own codes, was four memory latencies in a row)
+    TileIdx A[FLAT_TPW]; TileFlat F[FLAT_TPW]; bool live[FLAT_TPW];
 #pragma unroll
     for (u32 j = 0; j < FLAT_TPW; j++) {
-        const u64 t = (u64)blockIdx.x * FLAT_TPW + j;
-        live[j] = false; grels[j] = 0; V0s[j] = 0; V1s[j] = 0; nls[j] = 64; haves[j] = 16;
-        if (t >= ntiles) continue;
-        const TileIdx a = ti[t];
-        if (!a.fast) continue;
-        live[j] = true;
+        const u64 t = (u64)blockIdx.x * FLAT_TPW + j, tc = t < ntiles ? t : ntiles - 1;
+        A[j] = ti[tc]; F[j] = tsig[tc];
+        live[j] = t < ntiles && A[j].fast != 0;
+    }
+    // ---- phase 1: where every chunk's codes are, and the loads -- the 16 bytes from the 8-aligned address below the 64 bits under
+    // `top` (a bit address inside the source buffer: what lies below the stream's first symbol is never used); the funnel shift
+    // waits until phase 2.  Everything a lane computes is 32-bit and relative to the tile (its first base line a.gline, its first
+    // packed byte tf.qf); the 64-bit parts are the same for the whole tile (scalar).
+    // No branches here: a value that is only loaded on one path needs a copy where the paths join, and that copy waits for the load.
+    // A tile that is not live (it goes to k_emit_rest) loads the first bytes of the source instead.
+    uint4 W0[FLAT_TPW], W1[FLAT_TPW]; u32 sh0[FLAT_TPW], sh1[FLAT_TPW], grels[FLAT_TPW], nls[FLAT_TPW], haves[FLAT_TPW];
+#pragma unroll
+    for (u32 j = 0; j < FLAT_TPW; j++) {
+        const TileIdx &a = A[j]; const TileFlat &tf = F[j];
         u32 grel, nl_b = 64;                                          // grel: the chunk's first base, counted from a.gline
         if (P.mode == EM_FASTA && P.L != 0) {
             const u32 Lp1 = (u32)P.L + 1;
@@ -819,7 +818,6 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
             nl_b = d < 16 ? d : 64;
         } else grel = lane16;
         grels[j] = grel; nls[j] = nl_b;
-        const TileFlat tf = tsig[t];
         const u32 par = ((u32)a.gline & 1u) + grel;                   // parity of the chunk's first base in bit 0
         const u32 need = 8 + (par & 1u);
         const u32 qrel = (par >> 1) + (u32)((a.gline >> 1) - tf.qf);  // its first packed byte, counted from tf.qf (a.gline <= first base of the tile)
@@ -827,23 +825,33 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         const u32 d1 = dd1 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)dd1, d2 = dd2 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)dd2;
         const u64 T0 = tf.A - 4 * (tf.qf - tf.q0), T1 = tf.A1 + 4 * (u64)d1;      // bit above the symbol at qrel = 0, in the first / second stream
         const bool second = qrel >= d1;                               // the chunk starts in the tile's second stream
-        u64 top = (second ? T1 : T0) - 4 * (u64)qrel; if (top < 64) top = 64;
+        u64 top = (second ? T1 : T0) - 4 * (u64)qrel; if (top < 64 || !live[j]) top = 64;
         const u32 rem = (second ? d2 : d1) - qrel;                    // symbols from the chunk's first one to the end of its stream
-        V0s[j] = window(top);
-        if (need > rem) {                                             // it runs over the end of that stream: the rest is the top of the next one
-            haves[j] = rem;
-            V1s[j] = window(tf.A1 < 64 ? 64 : tf.A1);
+        {
+            const u64 lb = top - 64, addr = (u64)P.fsrc + (lb >> 3);
+            W0[j] = ldg_at<uint4>(addr & ~7ull);
+            sh0[j] = (u32)(addr & 7) * 8 + ((u32)lb & 7);
+        }
+        haves[j] = need > rem ? rem : 16u;                            // it runs over the end of that stream: the rest is the top of the next one
+        {
+            const u64 top1 = (tf.A1 < 64 || !live[j]) ? 64 : tf.A1, lb = top1 - 64, addr = (u64)P.fsrc + (lb >> 3);   // the same for every lane of the tile
+            W1[j] = ldg_at<uint4>(addr & ~7ull);
+            sh1[j] = (u32)(addr & 7) * 8 + ((u32)lb & 7);
         }
     }
+    auto funnel = [](const uint4 &w, u32 sh) -> u64 {
+        const u64 w0 = (u64)w.x | ((u64)w.y << 32), w1 = (u64)w.z | ((u64)w.w << 32);
+        return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+    };
     // ---- phase 2: codes -> characters, mask, line ends, store
 #pragma unroll
     for (u32 j = 0; j < FLAT_TPW; j++) {
         const u64 t = (u64)blockIdx.x * FLAT_TPW + j;
-        if (!live[j]) continue;                                       // (uniform: a tile is live for all its lanes or for none)
-        const TileIdx a = ti[t];
+        if (!live[j]) continue;
+        const TileIdx &a = A[j];
         const u64 g0 = a.gline + grels[j];
-        u64 V = V0s[j];                                               // the codes of symbols k, k+1, ... from the top nibble down
-        if (haves[j] < 16) V = (V & ~(~0ull >> (4 * haves[j]))) | (V1s[j] >> (4 * haves[j]));
+        u64 V = funnel(W0[j], sh0[j]);                                // the codes of symbols k, k+1, ... from the top nibble down
+        if (haves[j] < 16) V = (V & ~(~0ull >> (4 * haves[j]))) | (funnel(W1[j], sh1[j]) >> (4 * haves[j]));
         u64 lo, hi;
         {
             // codes -> packed bytes (the frame's sixteen symbols through v_perm_b32), in stream order: the top nibble of V is symbol k

@@ -769,9 +769,8 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
         if (live) {
             u64 top = (gp + 7) & ~63ull;                                  // sector holding the last container byte
             lo = top - 64;
-            const uint4 *g0 = (const uint4 *)lo;
 #pragma unroll
-            for (int q = 0; q < 8; q++) { uint4 v = g0[q]; u32 o = (u32)((lo + 16 * q) & rmask); *(u64 *)(irow + o) = (u64)v.x | ((u64)v.y << 32); *(u64 *)(irow + o + 8) = (u64)v.z | ((u64)v.w << 32); }
+            for (int q = 0; q < 8; q++) { uint4 v = ldg_at<uint4>(lo + 16 * q); u32 o = (u32)((lo + 16 * q) & rmask); *(u64 *)(irow + o) = (u64)v.x | ((u64)v.y << 32); *(u64 *)(irow + o + 8) = (u64)v.z | ((u64)v.w << 32); }
         }
         u32 bits = br.consumed;                                            // bits consumed since the container at gp
         for (; R < rounds; R++) {
@@ -789,8 +788,7 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
                 // round start over the ring's top sector, which must be dead by then: gp < lo + 56 in the two-sector ring
                 // (reads reach (gp & ~7) + 15), whatever the stream's rate -- a 1-bit code moves gp by only 4 bytes a round
                 if (lo + (big ? 96u : 56u) > gp) {
-                    const uint4 *g0 = (const uint4 *)(lo - 64);
-                    st0 = g0[0]; st1 = g0[1]; st2 = g0[2]; st3 = g0[3]; pending = true;
+                    st0 = ldg_at<uint4>(lo - 64); st1 = ldg_at<uint4>(lo - 48); st2 = ldg_at<uint4>(lo - 32); st3 = ldg_at<uint4>(lo - 16); pending = true;
                 }
                 u64 accs[HUF_ROUND / 8];
                 if (!big) {
