@@ -791,11 +791,22 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     // ---- phase 0: the records of the workgroup's tiles (uniform addresses: scalar loads, all of them in flight together -- one
     // tile after the other, each waiting for its own records and then for its own codes, was four memory latencies in a row)
     TileIdx A[FLAT_TPW]; TileFlat F[FLAT_TPW]; bool live[FLAT_TPW];
+    {
+        // (both arrays have FLAT_TPW spare entries behind ntiles; the workgroup's four records are read as whole 16-byte words so
+        // that no field waits for a test on another one)
+        static_assert(sizeof(TileIdx) == 32 && sizeof(TileFlat) == 48, "records are read as 16-byte words");
+        const u64 t0 = (u64)blockIdx.x * FLAT_TPW;
+        const uint4 *pa = (const uint4 *)(ti + t0), *pf = (const uint4 *)(tsig + t0);
+        uint4 ra[2 * FLAT_TPW], rf[3 * FLAT_TPW];
 #pragma unroll
-    for (u32 j = 0; j < FLAT_TPW; j++) {
-        const u64 t = (u64)blockIdx.x * FLAT_TPW + j, tc = t < ntiles ? t : ntiles - 1;
-        A[j] = ti[tc]; F[j] = tsig[tc];
-        live[j] = t < ntiles && A[j].fast != 0;
+        for (u32 i = 0; i < 2 * FLAT_TPW; i++) ra[i] = pa[i];
+#pragma unroll
+        for (u32 i = 0; i < 3 * FLAT_TPW; i++) rf[i] = pf[i];
+#pragma unroll
+        for (u32 j = 0; j < FLAT_TPW; j++) {
+            __builtin_memcpy(&A[j], &ra[2 * j], 32); __builtin_memcpy(&F[j], &rf[3 * j], 48);
+            live[j] = t0 + j < ntiles && A[j].fast != 0;
+        }
     }
     // ---- phase 1: where every chunk's codes are, and the loads -- the 16 bytes from the 8-aligned address below the 64 bits under
     // `top` (a bit address inside the source buffer: what lies below the stream's first symbol is never used); the funnel shift
@@ -1498,7 +1509,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             else LAUNCH(c, "unnaf_emit", k_emit<false>, grid, 256, 0, pl.P, d_out);
         } else {
             u64 ntiles = cdiv(m_end - m_begin, 4096);
-            TileIdx *ti = arena_new<TileIdx>(c, ntiles + 2); u64 *tr = arena_new<u64>(c, ntiles + 2);
+            TileIdx *ti = arena_new<TileIdx>(c, ntiles + 2 + FLAT_TPW); u64 *tr = arena_new<u64>(c, ntiles + 2);
             u32 *list = arena_new<u32>(c, ntiles + 1), *cnt = arena_new<u32>(c, 2);
             if (!ti || !tr || !list || !cnt) return NAF_GPU_ENOMEM;
             if (!split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, c->stream));
@@ -1511,7 +1522,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             if (split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, ic->stream));
             TileFlat *tsig = nullptr;
             if (zflat.ready) {
-                tsig = arena_new<TileFlat>(c, ntiles + 2); u32 *fpair = arena_new<u32>(c, 256); if (!tsig || !fpair) return NAF_GPU_ENOMEM;
+                tsig = arena_new<TileFlat>(c, ntiles + 2 + FLAT_TPW); u32 *fpair = arena_new<u32>(c, 256); if (!tsig || !fpair) return NAF_GPU_ENOMEM;
                 LAUNCH(ic, "unnaf_flat_pair", k_flat_pair, 1, 256, 0, pl.P, fpair);
                 pl.P.fpair = fpair;
             }
