@@ -777,16 +777,37 @@ __global__ __launch_bounds__(256) void k_emit_tile(EmitP P, const TileIdx *ti, u
 // workgroup from the frame's code -> packed byte list and the nucleotide table).  Consecutive lanes read consecutive (descending)
 // words of the stream; a tile touches one stream, or two where one ends.  Chunks that straddle a stream's end, or sit in its
 // last 16 symbols, take the symbols one by one.
-__global__ void k_flat_pair(EmitP P, u32 *pair)               // code -> packed byte, sixteen bytes as four dwords
+__global__ void k_flat_pair(EmitP P, u32 *pair)               // sixteen-entry tables, each as four dwords (for v_perm_b32)
 {
+    // [0..3] code -> packed byte; [4..7] code -> character of the byte's first base (low nibble, encoders.c:44-57); [8..11] -> of its second
     const u32 t = threadIdx.x;
-    if (t < 4) pair[t] = (u32)P.fsym[4 * t] | ((u32)P.fsym[4 * t + 1] << 8) | ((u32)P.fsym[4 * t + 2] << 16) | ((u32)P.fsym[4 * t + 3] << 24);
+    if (t >= 12) return;
+    const u8 *lut = (const u8 *)P.lut;
+    u32 v = 0;
+    for (u32 k = 0; k < 4; k++) {
+        const u32 pk = P.fsym[4 * (t & 3) + k];
+        const u32 b = t < 4 ? pk : (t < 8 ? lut[pk & 15] : lut[pk >> 4]);
+        v |= b << (8 * k);
+    }
+    pair[t] = v;
 }
 #define FLAT_TPW 4                                               // tiles per workgroup: a tile alone is three dependent loads and a store, i.e. pure latency
 __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *ti, const TileFlat *tsig, u8 *out, u64 ntiles)
 {
     __shared__ u64 s_tog[EMIT_TOG_LDS];
-    const u32 sl[4] = { P.fpair[0], P.fpair[1], P.fpair[2], P.fpair[3] };     // uniform: scalar loads
+    // a line end inside a chunk: bytes in front of it stay, the byte at it becomes '\n', bytes behind it take the byte in front of
+    // them -- per position d of the line end, sixteen v_perm_b32 selector bytes (source = this dword and the one below it; 0x0C
+    // selects a zero byte) and the sixteen bytes to OR in
+    __shared__ uint4 s_spl[32];
+    if (threadIdx.x < 16) {
+        const u32 d = threadIdx.x; u32 sel[4], orv[4];
+        for (u32 i = 0; i < 4; i++) {
+            sel[i] = 0; orv[i] = 0;
+            for (u32 j = 0; j < 4; j++) { const u32 p = 4 * i + j; sel[i] |= (p < d ? 4 + j : (p == d ? 0x0Cu : 3 + j)) << (8 * j); if (p == d) orv[i] |= 0x0Au << (8 * j); }
+        }
+        s_spl[2 * d] = make_uint4(sel[0], sel[1], sel[2], sel[3]); s_spl[2 * d + 1] = make_uint4(orv[0], orv[1], orv[2], orv[3]);
+    }
+    const u32 cl[4] = { P.fpair[4], P.fpair[5], P.fpair[6], P.fpair[7] }, ch[4] = { P.fpair[8], P.fpair[9], P.fpair[10], P.fpair[11] };   // uniform: scalar loads
     const u32 lane16 = threadIdx.x * 16;
     // ---- phase 0: the records of the workgroup's tiles (uniform addresses: scalar loads, all of them in flight together -- one
     // tile after the other, each waiting for its own records and then for its own codes, was four memory latencies in a row)
@@ -854,6 +875,7 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         const u64 w0 = (u64)w.x | ((u64)w.y << 32), w1 = (u64)w.z | ((u64)w.w << 32);
         return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
     };
+    __syncthreads();                                              // s_spl (the loads are in flight meanwhile)
     // ---- phase 2: codes -> characters, mask, line ends, store
 #pragma unroll
     for (u32 j = 0; j < FLAT_TPW; j++) {
@@ -865,12 +887,21 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         if (haves[j] < 16) V = (V & ~(~0ull >> (4 * haves[j]))) | (funnel(W1[j], sh1[j]) >> (4 * haves[j]));
         u64 lo, hi;
         {
-            // codes -> packed bytes (the frame's sixteen symbols through v_perm_b32), in stream order: the top nibble of V is symbol k
-            const u32 h = (u32)(V >> 32);
-            const u32 E = expand_codes4(sl, h & 0x0F0F0F0Fu), O = expand_codes4(sl, (h >> 4) & 0x0F0F0F0Fu);   // symbols k+7,k+5,k+3,k+1 / k+6,k+4,k+2,k
-            u64 nib = (u64)__builtin_amdgcn_perm(O, E, 0x02060307u) | ((u64)__builtin_amdgcn_perm(O, E, 0x00040105u) << 32);
-            if (g0 & 1) { const u32 b8 = expand_codes4(sl, ((u32)V >> 28) & 15u) & 0xFFu; nib = (nib >> 4) | ((u64)b8 << 60); }
-            expand16(P.lut, nib, lo, hi);
+            // codes -> characters without the packed byte in between: every code names two characters (its byte's low and high
+            // nibble), looked up in two sixteen-entry tables and woven together in stream order.  The top nibble of V is symbol k:
+            // E holds symbols k+7, k+5, k+3, k+1 (bytes 0..3), O symbols k+6, k+4, k+2, k.
+            const u32 h = (u32)(V >> 32), ce = h & 0x0F0F0F0Fu, co = (h >> 4) & 0x0F0F0F0Fu;
+            const u32 ELo = expand_codes4(cl, ce), EHi = expand_codes4(ch, ce), OLo = expand_codes4(cl, co), OHi = expand_codes4(ch, co);
+            const u32 t1a = __builtin_amdgcn_perm(OHi, OLo, 0x06020703u), t2a = __builtin_amdgcn_perm(EHi, ELo, 0x06020703u);   // k, k+2 / k+1, k+3 as (low, high) pairs
+            const u32 t1b = __builtin_amdgcn_perm(OHi, OLo, 0x04000501u), t2b = __builtin_amdgcn_perm(EHi, ELo, 0x04000501u);   // k+4, k+6 / k+5, k+7
+            u32 w0 = __builtin_amdgcn_perm(t2a, t1a, 0x05040100u), w1 = __builtin_amdgcn_perm(t2a, t1a, 0x07060302u);
+            u32 w2 = __builtin_amdgcn_perm(t2b, t1b, 0x05040100u), w3 = __builtin_amdgcn_perm(t2b, t1b, 0x07060302u);
+            if (g0 & 1) {                                             // the chunk starts at a byte's second base: one character down, the ninth symbol's first on top
+                const u32 c9 = expand_codes4(cl, ((u32)V >> 28) & 15u);
+                w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+                w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 = __builtin_amdgcn_alignbyte(c9, w3, 1);
+            }
+            lo = (u64)w0 | ((u64)w1 << 32); hi = (u64)w2 | ((u64)w3 << 32);
         }
         const u32 ntog = (u32)(a.khi - a.k < EMIT_TOG_LDS ? a.khi - a.k : EMIT_TOG_LDS);
         const bool use_tog = P.masking && a.k < a.khi && a.khi - a.k <= EMIT_TOG_LDS;
@@ -880,8 +911,13 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
             __syncthreads();
             mask16_from(s_tog, ntog, a.k, g0, lo, hi);
         } else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
-        if (nls[j] < 16) splice_newline(lo, hi, (int)nls[j]);
         uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
+        if (nls[j] < 16) {
+            const uint4 sel = s_spl[2 * nls[j]], orv = s_spl[2 * nls[j] + 1];
+            const u32 x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+            v.x = __builtin_amdgcn_perm(x0, 0u, sel.x) | orv.x; v.y = __builtin_amdgcn_perm(x1, x0, sel.y) | orv.y;
+            v.z = __builtin_amdgcn_perm(x2, x1, sel.z) | orv.z; v.w = __builtin_amdgcn_perm(x3, x2, sel.w) | orv.w;
+        }
         *(uint4 *)(out + t * 4096 + lane16) = v;
     }
 }
