@@ -42,6 +42,17 @@ template <typename T> NAF_HD T ldg_at(u64 addr)
     return *(const T *)addr;
 #endif
 }
+// The same for an address of any alignment.  (A naturally-aligned type promises the compiler its alignment: a load whose address
+// is the same in every lane becomes a scalar load, and scalar loads ignore the low two address bits.)
+template <typename T> NAF_HD T ldg_at_unaligned(u64 addr)
+{
+    typedef T __attribute__((aligned(1))) T1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(1))) T1 *)addr;
+#else
+    return *(const T1 *)addr;
+#endif
+}
 NAF_HD int hibit32(u32 v) { return 31 - __builtin_clz(v); }
 
 // ---- backward bit reader (RFC 8878 4.1 "bitstreams are read backward") -----------------------------

@@ -727,7 +727,11 @@ __global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr,
     if (t >= ntiles) return;
     const bool wrap = P.mode == EM_FASTA && P.L != 0;
     bool fast = ti[t].col != TI_HDR && tr[t] == tr[t + 1] && P.out_begin + (t + 1) * 4096 <= P.out_end && !P.force_slow && (!wrap || P.L >= 16);
-    if (fast && tsig) fast = tsig[t].qf + 2048 + 16 < tsig[t].q2 || tsig[t].q2 == tsig[t].q1;   // at most two streams under the tile (q2 == q1: the data end there)
+    if (fast && tsig) {
+        const TileFlat f = tsig[t];
+        fast = f.qf + 2048 + 16 < f.q2 || f.q2 == f.q1;             // at most two streams under the tile (q2 == q1: the data end there)
+        if (f.q2 != f.q1 && (f.A1 > f.A ? f.A1 - f.A : f.A - f.A1) >= (1ull << 29)) fast = false;   // k_emit_tile_flat addresses both streams from one 32-bit base
+    }
     ti[t].khi = ti[t + 1].k;
     ti[t].fast = fast ? 1u : 0u;
     if (!fast) list[atomicAdd(count, 1u)] = (u32)t;
@@ -829,13 +833,15 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
             live[j] = t0 + j < ntiles && A[j].fast != 0;
         }
     }
-    // ---- phase 1: where every chunk's codes are, and the loads -- the 16 bytes from the 8-aligned address below the 64 bits under
-    // `top` (a bit address inside the source buffer: what lies below the stream's first symbol is never used); the funnel shift
-    // waits until phase 2.  Everything a lane computes is 32-bit and relative to the tile (its first base line a.gline, its first
-    // packed byte tf.qf); the 64-bit parts are the same for the whole tile (scalar).
+    // ---- phase 1: where every chunk's codes are, and the loads.  A chunk needs the 36 bits under `top` (nine 4-bit codes; a bit
+    // address inside the source buffer): the eight bytes at (top - 40) >> 3 hold them.  Everything a lane computes is 32-bit: bases
+    // count from the tile's a.gline, packed bytes from tf.qf, bit addresses from a tile-wide base `ub` (a multiple of eight bits,
+    // 4 * QM bits below the lower of the tile's two streams, so that the lane's part K - 4 * qrel never goes negative); the 64-bit
+    // parts are the same for the whole tile and live in scalar registers, the load is scalar base + 32-bit lane offset.
     // No branches here: a value that is only loaded on one path needs a copy where the paths join, and that copy waits for the load.
     // A tile that is not live (it goes to k_emit_rest) loads the first bytes of the source instead.
-    uint4 W0[FLAT_TPW], W1[FLAT_TPW]; u32 sh0[FLAT_TPW], sh1[FLAT_TPW], grels[FLAT_TPW], nls[FLAT_TPW], haves[FLAT_TPW];
+    enum { QM = 4096 };
+    u64 X[FLAT_TPW]; u32 offs[FLAT_TPW], grels[FLAT_TPW], nls[FLAT_TPW], haves[FLAT_TPW];
 #pragma unroll
     for (u32 j = 0; j < FLAT_TPW; j++) {
         const TileIdx &a = A[j]; const TileFlat &tf = F[j];
@@ -856,25 +862,18 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         const u64 dd1 = tf.q1 - tf.qf, dd2 = tf.q2 - tf.qf;
         const u32 d1 = dd1 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)dd1, d2 = dd2 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)dd2;
         const u64 T0 = tf.A - 4 * (tf.qf - tf.q0), T1 = tf.A1 + 4 * (u64)d1;      // bit above the symbol at qrel = 0, in the first / second stream
+        const bool two = tf.q2 != tf.q1;                              // (k_tile_classify: the two streams lie less than 2^30 bits apart)
+        const u64 tmin = two && T1 < T0 ? T1 : T0;
+        const u64 ub = (tmin - 40 - 4 * (u64)QM) & ~7ull;             // may lie below the buffer: only ub + a lane's offset is ever used as an address
+        const u32 K0 = live[j] ? (u32)(T0 - 40 - ub) : 0u, K1 = live[j] && two ? (u32)(T1 - 40 - ub) : K0, qm = live[j] ? ~0u : 0u;
+        const u8 *base = live[j] ? P.fsrc + (i64)ub / 8 : P.fsrc;
         const bool second = qrel >= d1;                               // the chunk starts in the tile's second stream
-        u64 top = (second ? T1 : T0) - 4 * (u64)qrel; if (top < 64 || !live[j]) top = 64;
+        const u32 off = (second ? K1 : K0) - ((4 * qrel) & qm);       // bit offset of (top - 40) from ub
         const u32 rem = (second ? d2 : d1) - qrel;                    // symbols from the chunk's first one to the end of its stream
-        {
-            const u64 lb = top - 64, addr = (u64)P.fsrc + (lb >> 3);
-            W0[j] = ldg_at<uint4>(addr & ~7ull);
-            sh0[j] = (u32)(addr & 7) * 8 + ((u32)lb & 7);
-        }
+        X[j] = ldg_at_unaligned<u64>((u64)base + (off >> 3));
+        offs[j] = off;
         haves[j] = need > rem ? rem : 16u;                            // it runs over the end of that stream: the rest is the top of the next one
-        {
-            const u64 top1 = (tf.A1 < 64 || !live[j]) ? 64 : tf.A1, lb = top1 - 64, addr = (u64)P.fsrc + (lb >> 3);   // the same for every lane of the tile
-            W1[j] = ldg_at<uint4>(addr & ~7ull);
-            sh1[j] = (u32)(addr & 7) * 8 + ((u32)lb & 7);
-        }
     }
-    auto funnel = [](const uint4 &w, u32 sh) -> u64 {
-        const u64 w0 = (u64)w.x | ((u64)w.y << 32), w1 = (u64)w.z | ((u64)w.w << 32);
-        return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
-    };
     __syncthreads();                                              // s_spl (the loads are in flight meanwhile)
     // ---- phase 2: codes -> characters, mask, line ends, store
 #pragma unroll
@@ -883,21 +882,28 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         if (!live[j]) continue;
         const TileIdx &a = A[j];
         const u64 g0 = a.gline + grels[j];
-        u64 V = funnel(W0[j], sh0[j]);                                // the codes of symbols k, k+1, ... from the top nibble down
-        if (haves[j] < 16) V = (V & ~(~0ull >> (4 * haves[j]))) | (funnel(W1[j], sh1[j]) >> (4 * haves[j]));
+        u64 h36 = X[j] >> ((offs[j] & 7) + 4);                        // nine codes: symbol k in bits 35..32, ... symbol k+8 in bits 3..0
+        if (haves[j] < 9) {                                           // the stream ends inside the chunk: the rest is the top of the tile's second stream
+            const TileFlat &tf = F[j];
+            const u64 t1 = tf.A1 - 40, y = ldg_at_unaligned<u64>((u64)P.fsrc + (t1 >> 3));
+            const u64 n36 = (y >> ((u32)(t1 & 7) + 4)) & 0xFFFFFFFFFull;
+            const u32 keep = 4 * haves[j];                             // bits of this stream's symbols
+            h36 = (h36 & ~(0xFFFFFFFFFull >> keep)) | (n36 >> keep);
+        }
+        const u32 h = (u32)(h36 >> 4), n9 = (u32)h36 & 15u;
         u64 lo, hi;
         {
             // codes -> characters without the packed byte in between: every code names two characters (its byte's low and high
-            // nibble), looked up in two sixteen-entry tables and woven together in stream order.  The top nibble of V is symbol k:
+            // nibble), looked up in two sixteen-entry tables and woven together in stream order.  The top nibble of h is symbol k:
             // E holds symbols k+7, k+5, k+3, k+1 (bytes 0..3), O symbols k+6, k+4, k+2, k.
-            const u32 h = (u32)(V >> 32), ce = h & 0x0F0F0F0Fu, co = (h >> 4) & 0x0F0F0F0Fu;
+            const u32 ce = h & 0x0F0F0F0Fu, co = (h >> 4) & 0x0F0F0F0Fu;
             const u32 ELo = expand_codes4(cl, ce), EHi = expand_codes4(ch, ce), OLo = expand_codes4(cl, co), OHi = expand_codes4(ch, co);
             const u32 t1a = __builtin_amdgcn_perm(OHi, OLo, 0x06020703u), t2a = __builtin_amdgcn_perm(EHi, ELo, 0x06020703u);   // k, k+2 / k+1, k+3 as (low, high) pairs
             const u32 t1b = __builtin_amdgcn_perm(OHi, OLo, 0x04000501u), t2b = __builtin_amdgcn_perm(EHi, ELo, 0x04000501u);   // k+4, k+6 / k+5, k+7
             u32 w0 = __builtin_amdgcn_perm(t2a, t1a, 0x05040100u), w1 = __builtin_amdgcn_perm(t2a, t1a, 0x07060302u);
             u32 w2 = __builtin_amdgcn_perm(t2b, t1b, 0x05040100u), w3 = __builtin_amdgcn_perm(t2b, t1b, 0x07060302u);
             if (g0 & 1) {                                             // the chunk starts at a byte's second base: one character down, the ninth symbol's first on top
-                const u32 c9 = expand_codes4(cl, ((u32)V >> 28) & 15u);
+                const u32 c9 = expand_codes4(cl, n9);
                 w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
                 w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 = __builtin_amdgcn_alignbyte(c9, w3, 1);
             }
