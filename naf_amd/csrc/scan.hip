@@ -41,31 +41,48 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_apply(T *vals, size_
     }
 }
 
-template <typename T> __global__ void k_store_total(const T *tile_excl, const T *tile_sum_last, size_t ntiles, T *total)
+// Up to SCAN_SMALL values in ONE launch by one workgroup (a thread takes a contiguous run): the block tables of the small streams,
+// the tile aggregates of the big ones.  A scan used to be five to seven launches whatever its size, and the front of a decode call is
+// a chain of such launches.
+#define SCAN_SMALL 16384
+template <typename T, typename Op, bool EXCL>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_small(T *vals, size_t n, T *total)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *total = tile_excl[ntiles - 1] + *tile_sum_last;
+    __shared__ T lds[4];
+    const size_t per = (n + SCAN_THREADS - 1) / SCAN_THREADS, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    T acc = Op::template id<T>();
+    for (size_t k = lo; k < hi; k++) acc = Op::template f<T>(acc, vals[k]);
+    T tot;
+    const T incl = wg_scan_inclusive<T, Op>(acc, &tot, lds);
+    // exclusive prefix of this thread's run: everything in front of it
+    T run = Op::template id<T>();
+    {
+        __shared__ T s_incl[SCAN_THREADS];
+        s_incl[threadIdx.x] = incl;
+        __syncthreads();
+        if (threadIdx.x) run = s_incl[threadIdx.x - 1];
+    }
+    for (size_t k = lo; k < hi; k++) {
+        const T v = vals[k];
+        if (EXCL) { vals[k] = run; run = Op::template f<T>(run, v); }
+        else { run = Op::template f<T>(run, v); vals[k] = run; }
+    }
+    if (total && threadIdx.x == 0) *total = tot;
 }
 
+// total (optional): the aggregate of all values.  The tile aggregates are scanned by the same routine, and THEIR total is the grand total.
 template <typename T, typename Op, bool EXCL>
 static int scan_rec(naf_gpu_ctx *c, T *vals, size_t n, T *d_total)
 {
     if (n == 0) { if (d_total) HIP_TRY(c, hipMemsetAsync(d_total, 0, sizeof(T), c->stream)); return 0; }
+    if (n <= SCAN_SMALL) { LAUNCH(c, "scan_small", (k_scan_small<T, Op, EXCL>), 1, SCAN_THREADS, 0, vals, n, d_total); return 0; }
     size_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     T *sums = arena_new<T>(c, ntiles + 1);
     if (!sums) return ctx_fail(c, NAF_GPU_ENOMEM, "scan scratch");
     LAUNCH(c, "scan_reduce", (k_scan_tile_reduce<T, Op>), ntiles, SCAN_THREADS, 0, (const T *)vals, n, sums);
-    T *tile_pre = nullptr;
-    if (ntiles > 1 || d_total) {
-        // exclusive scan of tile aggregates (recursive); keep the last aggregate for the total
-        T *last = arena_new<T>(c, 1);
-        if (!last) return ctx_fail(c, NAF_GPU_ENOMEM, "scan scratch");
-        HIP_TRY(c, hipMemcpyAsync(last, sums + ntiles - 1, sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-        int rc = scan_rec<T, Op, true>(c, sums, ntiles, (T *)nullptr);
-        if (rc) return rc;
-        tile_pre = sums;
-        if (d_total) LAUNCH(c, "scan_total", (k_store_total<T>), 1, 64, 0, (const T *)sums, (const T *)last, ntiles, d_total);
-    }
-    LAUNCH(c, "scan_apply", (k_scan_tile_apply<T, Op, EXCL>), ntiles, SCAN_THREADS, 0, vals, n, (const T *)tile_pre);
+    int rc = scan_rec<T, Op, true>(c, sums, ntiles, d_total);      // exclusive scan of the tile aggregates
+    if (rc) return rc;
+    LAUNCH(c, "scan_apply", (k_scan_tile_apply<T, Op, EXCL>), ntiles, SCAN_THREADS, 0, vals, n, (const T *)sums);
     return 0;
 }
 
