@@ -929,10 +929,8 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
 }
 
 template <bool FOURBIT>
-__global__ __launch_bounds__(256) void k_emit_rest(EmitP P, const TileIdx *ti, const u64 *tr, const u32 *list, const u32 *count, u8 *out)
+__device__ __forceinline__ void emit_rest_tile(const EmitP &P, const TileIdx *ti, const u64 *tr, u64 t, u8 *out)
 {
-    if (blockIdx.x >= *count) return;
-    const u64 t = list[blockIdx.x];
     const TileIdx a = ti[t];
     u64 p0 = P.out_begin + t * 4096 + threadIdx.x * 16;
     if (p0 >= P.out_end) return;
@@ -947,6 +945,15 @@ __global__ __launch_bounds__(256) void k_emit_rest(EmitP P, const TileIdx *ti, c
     u64 r = upper_bound_u64(P.rec_out, rlo, rhi + 1, p0) - 1;
     GeoGlobal geo_g(P);
     compose_chunk<FOURBIT>(P, geo_g, p0, nbytes, r, a.k, a.khi, P.masking && a.k < a.khi, Lp1_32, o);
+}
+// The list's length stays on the device: the grid is fixed (EMIT_REST_GRID workgroups stride over the list), so the host queues this
+// kernel without reading the count back -- a synchronisation in front of the main emit launch otherwise.
+#define EMIT_REST_GRID 4096
+template <bool FOURBIT>
+__global__ __launch_bounds__(256) void k_emit_rest(EmitP P, const TileIdx *ti, const u64 *tr, const u32 *list, const u32 *count, u8 *out)
+{
+    const u32 n = *count;
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) emit_rest_tile<FOURBIT>(P, ti, tr, list[i], out);
 }
 
 // Base-index range [g_lo, g_hi) that output bytes [out_begin, out_end) can touch (conservative on both sides).
@@ -1570,8 +1577,6 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             }
             LAUNCH(ic, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr, tsig);
             LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt, (const TileFlat *)tsig);
-            u32 nrest = 0;                                                                   // tiles holding a header or a record boundary
-            if ((rc = ctx_readback(ic, &nrest, cnt, 4))) { if (ic != c) memcpy(c->err, ic->err, sizeof c->err); return rc; }
             u64 t_done = 0;
             if (split.done) {
                 HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX], ic->stream));
@@ -1594,9 +1599,10 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                 if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit_tile<true>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
                 else LAUNCH(c, "unnaf_emit", k_emit_tile<false>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
             }
-            if (!nrest) {}
-            else if (pl.fourbit) LAUNCH(c, "unnaf_emit_rest", k_emit_rest<true>, (u32)nrest, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
-            else LAUNCH(c, "unnaf_emit_rest", k_emit_rest<false>, nrest, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
+            // tiles holding a header or a record boundary (their number stays on the device)
+            const u32 rest_grid = (u32)(ntiles < EMIT_REST_GRID ? ntiles : EMIT_REST_GRID);
+            if (pl.fourbit) LAUNCH(c, "unnaf_emit_rest", k_emit_rest<true>, rest_grid, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
+            else LAUNCH(c, "unnaf_emit_rest", k_emit_rest<false>, rest_grid, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
             if (split.done) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX + 1], 0));
         }
     }

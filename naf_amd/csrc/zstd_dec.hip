@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64) void k_build_huf_lds(const u8 *src, ZBlock *blk
 __global__ __launch_bounds__(64) void k_build_huf_few(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, const u64 *range4, const i32 *own_huf)
 {
     __shared__ HufLdsWS S;
-    if (st->n_huf_distinct > HUF_FEW) return;
+    if (st->n_huf_distinct > HUF_FEW || st->n_huf_distinct == 0) return;     // (a stream of RLE / raw blocks -- an unmasked genome's mask -- has no tree at all)
     u32 lo = 0, hi = nblk;
     if (range4) { lo = (u32)range4[4]; hi = (u32)range4[1]; if (hi > nblk) hi = nblk; }
     const u32 per = (hi - lo + gridDim.x - 1) / gridDim.x;
