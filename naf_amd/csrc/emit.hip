@@ -678,6 +678,18 @@ struct TileIdx { u64 gline, k, khi; u32 col, fast; };   // gline: base index of 
 // flat frames: the stream that holds the tile's first packed byte qf (first symbol q0, end-of-data bit address A) and the next
 // stream that has symbols (q1, A1; it ends at q2) -- a tile that would reach a third stream goes to the slow list
 struct TileFlat { u64 q0, A, q1, A1, q2, qf; };
+// What k_emit_tile_flat needs of a tile, worked out once by k_tile_classify in the place of the TileFlat record (same 48 bytes): the
+// emit kernel ran this 64-bit arithmetic on the scalar unit of every one of its 2.4 M x 4 waves, ran out of scalar registers on it
+// (spills through v_readlane / v_writelane) and paid VALU compares for the 64-bit "less than" the scalar unit lacks.
+//   base     source address of bit `ub`, a multiple of eight bits that lies 4 * QM bits below the lower of the tile's two streams
+//   K0, K1   bit offset from ub of (top - 40) for a chunk whose first packed byte is the tile's first one (qrel = 0), in the first /
+//            second stream; a lane's offset is K - 4 * qrel >= 0
+//   d1, d2   symbols from the tile's first packed byte to the end of the first / second stream
+//   qoff     (a.gline >> 1) - qf, par0 = a.gline & 1
+//   a1_addr, a1_sh   the eight bytes holding the top 36 bits of the second stream, and the shift that brings them down
+struct TileFlatE { u64 base, a1_addr; u32 a1_sh, K0, K1, d1, d2, qoff, par0, pad; };
+static_assert(sizeof(TileFlatE) == sizeof(TileFlat), "the derived record replaces the raw one in place");
+#define FLAT_QM 4096
 __global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr, TileFlat *tsig)            // ntiles + 1 entries each; tsig: flat frames only
 {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -721,16 +733,37 @@ __global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr, TileFlat
 }
 // fast = the whole tile lies in the body of one record (and the next tile starts in the same record, so that the
 // record's final newline is not in it); every other tile goes on the list of the segment-composing kernel
-__global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr, u32 *list, u32 *count, const TileFlat *tsig)
+__global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr, u32 *list, u32 *count, TileFlat *tsig, u32 spare)
 {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntiles) return;
+    TileFlatE e; e.base = (u64)P.fsrc; e.a1_addr = (u64)P.fsrc; e.a1_sh = 4; e.K0 = e.K1 = 0; e.d1 = e.d2 = 0x7FFFFFFFu; e.qoff = 0; e.par0 = 0; e.pad = 0;
+    if (t >= ntiles) {                                            // the spare records a workgroup of the emit kernel may read behind the last tile
+        if (tsig && t < ntiles + spare) { ti[t].fast = 0; *(TileFlatE *)&tsig[t] = e; }
+        return;
+    }
     const bool wrap = P.mode == EM_FASTA && P.L != 0;
     bool fast = ti[t].col != TI_HDR && tr[t] == tr[t + 1] && P.out_begin + (t + 1) * 4096 <= P.out_end && !P.force_slow && (!wrap || P.L >= 16);
-    if (fast && tsig) {
+    if (tsig) {
         const TileFlat f = tsig[t];
-        fast = f.qf + 2048 + 16 < f.q2 || f.q2 == f.q1;             // at most two streams under the tile (q2 == q1: the data end there)
-        if (f.q2 != f.q1 && (f.A1 > f.A ? f.A1 - f.A : f.A - f.A1) >= (1ull << 29)) fast = false;   // k_emit_tile_flat addresses both streams from one 32-bit base
+        if (fast) {
+            fast = f.qf + 2048 + 16 < f.q2 || f.q2 == f.q1;         // at most two streams under the tile (q2 == q1: the data end there)
+            if (f.q2 != f.q1 && (f.A1 > f.A ? f.A1 - f.A : f.A - f.A1) >= (1ull << 29)) fast = false;   // both streams are addressed from one 32-bit base
+        }
+        if (fast) {
+            const u64 gline = ti[t].gline;
+            const u64 dd1 = f.q1 - f.qf, dd2 = f.q2 - f.qf;
+            e.d1 = dd1 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)dd1; e.d2 = dd2 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)dd2;
+            const u64 T0 = f.A - 4 * (f.qf - f.q0), T1 = f.A1 + 4 * (u64)e.d1;      // bit above the symbol at qrel = 0, in the first / second stream
+            const bool two = f.q2 != f.q1;
+            const u64 tmin = two && T1 < T0 ? T1 : T0;
+            const u64 ub = (tmin - 40 - 4 * (u64)FLAT_QM) & ~7ull;   // may lie below the buffer: only ub + a lane's offset is ever used as an address
+            e.base = (u64)P.fsrc + (u64)((i64)ub >> 3);
+            e.K0 = (u32)(T0 - 40 - ub); e.K1 = two ? (u32)(T1 - 40 - ub) : e.K0;
+            e.qoff = (u32)((gline >> 1) - f.qf); e.par0 = (u32)gline & 1u;
+            const u64 t1 = (f.A1 < 40 ? 40 : f.A1) - 40;
+            e.a1_addr = (u64)P.fsrc + (t1 >> 3); e.a1_sh = (u32)(t1 & 7) + 4;
+        }
+        *(TileFlatE *)&tsig[t] = e;
     }
     ti[t].khi = ti[t + 1].k;
     ti[t].fast = fast ? 1u : 0u;
@@ -815,11 +848,11 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     const u32 lane16 = threadIdx.x * 16;
     // ---- phase 0: the records of the workgroup's tiles (uniform addresses: scalar loads, all of them in flight together -- one
     // tile after the other, each waiting for its own records and then for its own codes, was four memory latencies in a row)
-    TileIdx A[FLAT_TPW]; TileFlat F[FLAT_TPW]; bool live[FLAT_TPW];
+    TileIdx A[FLAT_TPW]; TileFlatE F[FLAT_TPW]; bool live[FLAT_TPW];
     {
-        // (both arrays have FLAT_TPW spare entries behind ntiles; the workgroup's four records are read as whole 16-byte words so
-        // that no field waits for a test on another one)
-        static_assert(sizeof(TileIdx) == 32 && sizeof(TileFlat) == 48, "records are read as 16-byte words");
+        // (both arrays have FLAT_TPW spare entries behind ntiles, made harmless by k_tile_classify; the workgroup's four records are
+        // read as whole 16-byte words so that no field waits for a test on another one)
+        static_assert(sizeof(TileIdx) == 32 && sizeof(TileFlatE) == 48, "records are read as 16-byte words");
         const u64 t0 = (u64)blockIdx.x * FLAT_TPW;
         const uint4 *pa = (const uint4 *)(ti + t0), *pf = (const uint4 *)(tsig + t0);
         uint4 ra[2 * FLAT_TPW], rf[3 * FLAT_TPW];
@@ -834,17 +867,15 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         }
     }
     // ---- phase 1: where every chunk's codes are, and the loads.  A chunk needs the 36 bits under `top` (nine 4-bit codes; a bit
-    // address inside the source buffer): the eight bytes at (top - 40) >> 3 hold them.  Everything a lane computes is 32-bit: bases
-    // count from the tile's a.gline, packed bytes from tf.qf, bit addresses from a tile-wide base `ub` (a multiple of eight bits,
-    // 4 * QM bits below the lower of the tile's two streams, so that the lane's part K - 4 * qrel never goes negative); the 64-bit
-    // parts are the same for the whole tile and live in scalar registers, the load is scalar base + 32-bit lane offset.
+    // address inside the source buffer): the eight bytes at (top - 40) >> 3 hold them.  Everything here is 32-bit: bases count from
+    // the tile's a.gline, packed bytes from its first one, bit addresses from a tile-wide base (TileFlatE, worked out by
+    // k_tile_classify); the load is scalar base + 32-bit lane offset.
     // No branches here: a value that is only loaded on one path needs a copy where the paths join, and that copy waits for the load.
-    // A tile that is not live (it goes to k_emit_rest) loads the first bytes of the source instead.
-    enum { QM = 4096 };
+    // A tile that is not live (it goes to k_emit_rest, or lies behind the last one) has a record that points at the source's first bytes.
     u64 X[FLAT_TPW]; u32 offs[FLAT_TPW], grels[FLAT_TPW], nls[FLAT_TPW], haves[FLAT_TPW];
 #pragma unroll
     for (u32 j = 0; j < FLAT_TPW; j++) {
-        const TileIdx &a = A[j]; const TileFlat &tf = F[j];
+        const TileIdx &a = A[j]; const TileFlatE &e = F[j];
         u32 grel, nl_b = 64;                                          // grel: the chunk's first base, counted from a.gline
         if (P.mode == EM_FASTA && P.L != 0) {
             const u32 Lp1 = (u32)P.L + 1;
@@ -856,21 +887,14 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
             nl_b = d < 16 ? d : 64;
         } else grel = lane16;
         grels[j] = grel; nls[j] = nl_b;
-        const u32 par = ((u32)a.gline & 1u) + grel;                   // parity of the chunk's first base in bit 0
+        const u32 par = e.par0 + grel;                                // parity of the chunk's first base in bit 0
         const u32 need = 8 + (par & 1u);
-        const u32 qrel = (par >> 1) + (u32)((a.gline >> 1) - tf.qf);  // its first packed byte, counted from tf.qf (a.gline <= first base of the tile)
-        const u64 dd1 = tf.q1 - tf.qf, dd2 = tf.q2 - tf.qf;
-        const u32 d1 = dd1 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)dd1, d2 = dd2 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)dd2;
-        const u64 T0 = tf.A - 4 * (tf.qf - tf.q0), T1 = tf.A1 + 4 * (u64)d1;      // bit above the symbol at qrel = 0, in the first / second stream
-        const bool two = tf.q2 != tf.q1;                              // (k_tile_classify: the two streams lie less than 2^30 bits apart)
-        const u64 tmin = two && T1 < T0 ? T1 : T0;
-        const u64 ub = (tmin - 40 - 4 * (u64)QM) & ~7ull;             // may lie below the buffer: only ub + a lane's offset is ever used as an address
-        const u32 K0 = live[j] ? (u32)(T0 - 40 - ub) : 0u, K1 = live[j] && two ? (u32)(T1 - 40 - ub) : K0, qm = live[j] ? ~0u : 0u;
-        const u8 *base = live[j] ? P.fsrc + (i64)ub / 8 : P.fsrc;
-        const bool second = qrel >= d1;                               // the chunk starts in the tile's second stream
-        const u32 off = (second ? K1 : K0) - ((4 * qrel) & qm);       // bit offset of (top - 40) from ub
-        const u32 rem = (second ? d2 : d1) - qrel;                    // symbols from the chunk's first one to the end of its stream
-        X[j] = ldg_at_unaligned<u64>((u64)base + (off >> 3));
+        const u32 qrel = (par >> 1) + e.qoff;                         // its first packed byte, counted from the tile's first one
+        const bool second = qrel >= e.d1;                             // the chunk starts in the tile's second stream
+        const u32 qm = live[j] ? ~0u : 0u;                            // (a dead tile's geometry may be anything: its lanes all read offset K = 0)
+        const u32 off = (second ? e.K1 : e.K0) - ((4 * qrel) & qm);   // bit offset of (top - 40) from the tile's base
+        const u32 rem = (second ? e.d2 : e.d1) - qrel;                // symbols from the chunk's first one to the end of its stream
+        X[j] = ldg_at_unaligned<u64>(e.base + (off >> 3));
         offs[j] = off;
         haves[j] = need > rem ? rem : 16u;                            // it runs over the end of that stream: the rest is the top of the next one
     }
@@ -884,9 +908,8 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         const u64 g0 = a.gline + grels[j];
         u64 h36 = X[j] >> ((offs[j] & 7) + 4);                        // nine codes: symbol k in bits 35..32, ... symbol k+8 in bits 3..0
         if (haves[j] < 9) {                                           // the stream ends inside the chunk: the rest is the top of the tile's second stream
-            const TileFlat &tf = F[j];
-            const u64 t1 = tf.A1 - 40, y = ldg_at_unaligned<u64>((u64)P.fsrc + (t1 >> 3));
-            const u64 n36 = (y >> ((u32)(t1 & 7) + 4)) & 0xFFFFFFFFFull;
+            const u64 y = ldg_at_unaligned<u64>(F[j].a1_addr);
+            const u64 n36 = (y >> F[j].a1_sh) & 0xFFFFFFFFFull;
             const u32 keep = 4 * haves[j];                             // bits of this stream's symbols
             h36 = (h36 & ~(0xFFFFFFFFFull >> keep)) | (n36 >> keep);
         }
@@ -1576,7 +1599,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                 pl.P.fpair = fpair;
             }
             LAUNCH(ic, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr, tsig);
-            LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt, (const TileFlat *)tsig);
+            LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles + FLAT_TPW, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt, tsig, (u32)FLAT_TPW);
             u64 t_done = 0;
             if (split.done) {
                 HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX], ic->stream));
