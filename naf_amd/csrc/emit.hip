@@ -844,7 +844,14 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         }
         s_spl[2 * d] = make_uint4(sel[0], sel[1], sel[2], sel[3]); s_spl[2 * d + 1] = make_uint4(orv[0], orv[1], orv[2], orv[3]);
     }
-    const u32 cl[4] = { P.fpair[4], P.fpair[5], P.fpair[6], P.fpair[7] }, ch[4] = { P.fpair[8], P.fpair[9], P.fpair[10], P.fpair[11] };   // uniform: scalar loads
+    // two codes -> their four characters: entry (a << 4 | b) holds first and second base of code a's byte, then of code b's.  The
+    // look-up costs one LDS read per two codes; sixteen-entry tables through v_perm_b32 cost a dozen instructions for the same, and
+    // this kernel is bound by its vector instructions.
+    __shared__ u32 s_pair[256];
+    {
+        const u32 pa = P.fsym[threadIdx.x >> 4], pb = P.fsym[threadIdx.x & 15];
+        s_pair[threadIdx.x] = expand_codes4(P.lut, (pa & 15u) | ((pa >> 4) << 8) | ((pb & 15u) << 16) | ((pb >> 4) << 24));
+    }
     const u32 lane16 = threadIdx.x * 16;
     // ---- phase 0: the records of the workgroup's tiles (uniform addresses: scalar loads, all of them in flight together -- one
     // tile after the other, each waiting for its own records and then for its own codes, was four memory latencies in a row)
@@ -916,17 +923,10 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         const u32 h = (u32)(h36 >> 4), n9 = (u32)h36 & 15u;
         u64 lo, hi;
         {
-            // codes -> characters without the packed byte in between: every code names two characters (its byte's low and high
-            // nibble), looked up in two sixteen-entry tables and woven together in stream order.  The top nibble of h is symbol k:
-            // E holds symbols k+7, k+5, k+3, k+1 (bytes 0..3), O symbols k+6, k+4, k+2, k.
-            const u32 ce = h & 0x0F0F0F0Fu, co = (h >> 4) & 0x0F0F0F0Fu;
-            const u32 ELo = expand_codes4(cl, ce), EHi = expand_codes4(ch, ce), OLo = expand_codes4(cl, co), OHi = expand_codes4(ch, co);
-            const u32 t1a = __builtin_amdgcn_perm(OHi, OLo, 0x06020703u), t2a = __builtin_amdgcn_perm(EHi, ELo, 0x06020703u);   // k, k+2 / k+1, k+3 as (low, high) pairs
-            const u32 t1b = __builtin_amdgcn_perm(OHi, OLo, 0x04000501u), t2b = __builtin_amdgcn_perm(EHi, ELo, 0x04000501u);   // k+4, k+6 / k+5, k+7
-            u32 w0 = __builtin_amdgcn_perm(t2a, t1a, 0x05040100u), w1 = __builtin_amdgcn_perm(t2a, t1a, 0x07060302u);
-            u32 w2 = __builtin_amdgcn_perm(t2b, t1b, 0x05040100u), w3 = __builtin_amdgcn_perm(t2b, t1b, 0x07060302u);
+            // codes -> characters without the packed byte in between: the top byte of h is symbols k and k+1, and so on down
+            u32 w0 = s_pair[h >> 24], w1 = s_pair[(h >> 16) & 0xFFu], w2 = s_pair[(h >> 8) & 0xFFu], w3 = s_pair[h & 0xFFu];
             if (g0 & 1) {                                             // the chunk starts at a byte's second base: one character down, the ninth symbol's first on top
-                const u32 c9 = expand_codes4(cl, n9);
+                const u32 c9 = s_pair[n9 << 4];
                 w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
                 w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 = __builtin_amdgcn_alignbyte(c9, w3, 1);
             }
