@@ -41,10 +41,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_apply(T *vals, size_
     }
 }
 
-// Up to SCAN_SMALL values in ONE launch by one workgroup (a thread takes a contiguous run): the block tables of the small streams,
+// Up to SCAN_SMALL values in ONE launch by one workgroup (a thread takes a contiguous run of at most 16: its loads are dependent ones): the block tables of the small streams,
 // the tile aggregates of the big ones.  A scan used to be five to seven launches whatever its size, and the front of a decode call is
 // a chain of such launches.
-#define SCAN_SMALL 16384
+#define SCAN_SMALL 4096
 template <typename T, typename Op, bool EXCL>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_small(T *vals, size_t n, T *total)
 {
