@@ -1232,7 +1232,7 @@ static size_t vle(u64 v, u8 *out)                                 // encoders.c:
     return (size_t)n;
 }
 
-extern "C" size_t naf_gpu_ennaf_bound(size_t n) { return n + n / 1024 + (1 << 16); }
+extern "C" size_t naf_gpu_ennaf_bound(size_t n) { return n + n / 256 + (1 << 16); }
 
 // host-side copy of nuc4 (the high nibble a shard borrows from its neighbour's first base)
 static u32 nuc4_host(u32 c)
@@ -1725,7 +1725,7 @@ extern "C" int naf_gpu_ennaf_find_cut(naf_gpu_ctx *c, const void *d_slice, size_
     return 0;
 }
 
-extern "C" size_t naf_gpu_ennaf_shard_bound(size_t n) { return n + n / 512 + (1 << 16); }
+extern "C" size_t naf_gpu_ennaf_shard_bound(size_t n) { return n + n / 128 + (1 << 16); }
 
 extern "C" int naf_gpu_ennaf_shard_begin(naf_gpu_ctx *c, const void *d_slice, size_t n, const naf_gpu_ennaf_opts *o, int format,
                                          uint32_t shard, uint32_t n_shards, naf_gpu_shard_info *info)

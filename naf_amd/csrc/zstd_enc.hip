@@ -682,7 +682,7 @@ int zenc_level_window(int level)
 
 extern "C" size_t naf_gpu_zstd_compress_bound(size_t n)
 {
-    return n + 3 * (n / 4096 + 2) + 64;
+    return n + 3 * (n / 1024 + 2) + 64;                            // blocks are never smaller than 1 KiB (a 2^10 window)
 }
 
 // block_log: log2 of the target block size (clamped to 17 = the format maximum of 128 KiB)
@@ -714,7 +714,10 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
     // and a repeat is cut less often; lengths still fit 16 bits (k_lzx_parse clamps a match at 65535)
     const bool lzx = use_lz && window_log >= 10 && n >= 64;
     if (window_log > 31) window_log = 31;
-    if (lzx) { block_log = 16; const char *lb = getenv("NAF_GPU_LZX_BLOCK_LOG"); if (lb && atoi(lb) >= 12 && atoi(lb) <= 16) block_log = (u32)atoi(lb); }
+    if (lzx) {
+        block_log = 16; const char *lb = getenv("NAF_GPU_LZX_BLOCK_LOG"); if (lb && atoi(lb) >= 12 && atoi(lb) <= 16) block_log = (u32)atoi(lb);
+        if (block_log > (u32)window_log) block_log = (u32)window_log;          // Block_Maximum_Size is the smaller of Window_Size and 128 KiB (3.1.1.2.4)
+    }
     const u32 frame_wlog = lzx ? (u32)window_log : 19u;
     u64 bs = 1ull << block_log;
     u64 nblk64 = n ? (n + bs - 1) / bs : 1;

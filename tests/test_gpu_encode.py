@@ -503,3 +503,57 @@ def test_zstd_compress_levels_through_the_c_abi(gpu, oracle):
             assert oracle.zstd_decompress(frame, len(d) + 16) == d, (len(d), level)
         if d is far:
             assert len(frame) < 0.75 * len(d)                                # the second and third copy cost next to nothing
+
+
+def test_small_windows_and_many_epochs(gpu, oracle):
+    """--long 10 ... 16 on inputs of a few hundred kilobytes: the match table runs through hundreds of half-window epochs, and every
+    offset must stay inside the announced window -- the real unnaf decodes with a ring of exactly that size (input.c:271), so an
+    offset beyond it comes back as garbage or an error, not as the text."""
+    from naf_amd import synth
+    O = oracle
+    rng = np.random.default_rng(17)
+    texts = [synth.repeat_genome(seed=21, unit=3000, copies=60), synth.repeat_genome(seed=22, unit=700, copies=300),
+             synth.repeat_genome(seed=23, unit=50000, copies=6),
+             b">one line\n" + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 5000)) * 40 + b"\n"]
+    for text in texts:
+        want = O.unnaf(O.ennaf(text), -1)
+        plain = len(host(gpu.ennaf(gpu.to_device(text))[0]))
+        for level, long_log in ((1, 10), (1, 12), (1, 15), (5, 0), (1, 16), (22, 11)):
+            d_naf, _ = gpu.ennaf(gpu.to_device(text), level=level, long_log=long_log)
+            mine = host(d_naf)
+            h = O.parse_naf(mine)
+            if long_log:
+                assert h.frame(mine, 4)[5] == (long_log - 10) << 3
+            assert O.unnaf(mine, -1) == want
+            assert host(gpu.unnaf(d_naf, -1)) == want
+            if O.have_ref():
+                assert O.ref_unnaf(mine) == want, (len(text), level, long_log)
+            if long_log == 16:
+                assert len(mine) < plain                                       # 64 KiB reach back: the repeats were found
+
+
+def test_zstd_compress_levels_fuzz(gpu, oracle):
+    """naf_gpu_zstd_compress at levels 2 .. 22 on random structured inputs (copies at random distances, alphabets of 2 .. 256, runs,
+    edits inside copies): every frame decodes under the from-spec oracle."""
+    rng = np.random.default_rng(99)
+    for it in range(40):
+        a = int(rng.choice([2, 4, 16, 64, 256]))
+        parts = []
+        pool = [rng.integers(0, a, int(rng.integers(1, 60000)), dtype=np.uint8).tobytes() for _ in range(3)]
+        for _ in range(int(rng.integers(1, 14))):
+            k = int(rng.integers(0, 5))
+            if k == 0:
+                parts.append(rng.integers(0, a, int(rng.integers(0, 30000)), dtype=np.uint8).tobytes())
+            elif k == 1:
+                parts.append(bytes([int(rng.integers(0, a))]) * int(rng.integers(1, 90000)))
+            else:
+                p = bytearray(pool[int(rng.integers(0, 3))])
+                for i in rng.integers(0, len(p), int(rng.integers(0, 20))):
+                    p[i] = int(rng.integers(0, a))
+                lo = int(rng.integers(0, len(p))); hi = int(rng.integers(lo, len(p) + 1))
+                parts.append(bytes(p[lo:hi]))
+        d = b"".join(parts)
+        level = int(rng.choice([2, 3, 9, 17, 20, 22]))
+        frame = host(gpu.zstd_compress(gpu.to_device(d), level=level)) if d else b""
+        if d:
+            assert oracle.zstd_decompress(frame, len(d) + 16) == d, (it, len(d), level)
