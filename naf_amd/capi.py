@@ -92,6 +92,13 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("libnaf_gpu.so is not built (run `make` or __graft_entry__.build()); there is no CPU fallback")
+        # torch first, when it is there: it brings its own libamdhip64, and the library must bind to the HIP runtime the process
+        # already has -- loaded the other way round (library, then torch) the process holds two runtimes and naf_gpu_init finds no
+        # device.  The C hosts link /opt/rocm's runtime and never see torch.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
         L.naf_gpu_init.argtypes = [i, C.POINTER(vp)]
