@@ -557,3 +557,37 @@ def test_zstd_compress_levels_fuzz(gpu, oracle):
         frame = host(gpu.zstd_compress(gpu.to_device(d), level=level)) if d else b""
         if d:
             assert oracle.zstd_decompress(frame, len(d) + 16) == d, (it, len(d), level)
+
+
+def test_pure_tiles_and_their_edges(gpu, oracle):
+    """The pure-tile paths of k_enc_count / k_enc_scatter (4 KiB tiles of plain sequence text: quick letters, LF, CR) next to every
+    way a tile can fail to be pure: line widths around the piece and tile sizes, CRLF, blank lines, leading white space, IUPAC
+    letters, tabs and spaces inside lines, headers at tile borders, a text that ends inside a pure tile."""
+    rng = np.random.default_rng(123)
+    acgt = np.frombuffer(b"ACGTacgtNn", dtype=np.uint8)
+    def seq(n, p=None):
+        return bytes(rng.choice(acgt, n, p=p))
+    def wrap(b, w, eol=b"\n"):
+        return eol.join(b[i:i + w] for i in range(0, len(b), w)) + eol if w else b + eol
+    texts = []
+    for w in (1, 2, 15, 16, 17, 60, 4095, 4096, 4097, 10000, 0):
+        texts.append(b">r1 width %d\n" % w + wrap(seq(int(rng.integers(30000, 70000))), w) + b">r2\n" + wrap(seq(9000), w))
+    texts.append(b">crlf\r\n" + wrap(seq(50000), 70, b"\r\n") + b">b\r\n" + wrap(seq(20000), 61, b"\r\n"))
+    texts.append(b">blank lines\n" + wrap(seq(20000), 50) + b"\n\n\n" + wrap(seq(20000), 50, b"\n\n") + b"\x0b\x0c" + wrap(seq(5000), 33))
+    texts.append(b"  \n\t\n>leading space\n" + wrap(seq(40000), 80))
+    iu = np.frombuffer(b"ACGTRYKMSWBDHVN-acgtn", dtype=np.uint8)
+    texts.append(b">iupac\n" + wrap(bytes(rng.choice(iu, 60000)), 64) + b">plain\n" + wrap(seq(30000), 64))
+    t = bytearray(b">spaces inside\n" + wrap(seq(60000), 75))
+    for i in rng.integers(20, len(t), 40):
+        t[i] = int(rng.choice([0x20, 0x09, ord("x"), ord("*")]))
+    texts.append(bytes(t))
+    for k in range(6):                                                            # headers falling on and around tile borders
+        pad = 4096 * 3 - 20 + k * 7
+        texts.append(b">a\n" + wrap(seq(pad), 0) + b">" + b"h" * (k * 9) + b" c\n" + wrap(seq(12000), 100) + b">z\n" + seq(5) + b"\n")
+    texts.append(b">no final newline\n" + wrap(seq(30000), 80)[:-1])
+    texts.append(b">one\n" + seq(4096 * 5 + 1))
+    texts.append(b">masked runs\n" + wrap(b"a" * 9000 + b"C" * 9001 + b"g" * 8190 + b"T" * 3 + b"n" * 70000, 80))
+    for text in texts:
+        for no_mask in (False, True):
+            check_ennaf(gpu, oracle, text, no_mask=no_mask)
+    check_ennaf(gpu, oracle, texts[3].replace(b"T", b"U").replace(b"t", b"u"), seq_type=1)
