@@ -22,7 +22,8 @@ struct ZSplit { int parts; hipEvent_t ev[ZSPLIT_MAX]; u64 out_end[ZSPLIT_MAX]; i
 // packed intermediate -- 5 GB written and read back per 10 GB of text -- never exists.  The decoder fills this when asked to and
 // the frame qualifies: per (block, stream) slot the packed offset of its first symbol and the bit address of the end of its data.
 struct FlatStream { u64 q0, A; };
-struct ZFlat { const u8 *src; const FlatStream *si; u64 nslots; const u8 *sym; void *status; bool ready; };
+struct ZFlat { const u8 *src; const FlatStream *si; u64 nslots; const u8 *sym; void *status; bool ready;
+               const u8 *tail; u64 tail_q; u32 tail_n; };   // tail: a final Raw block (the byte that holds the padding nibble of an odd stream, zstd_enc) -- its bytes lie in the frame as they are; packed index of its first byte; its length
 struct naf_gpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;

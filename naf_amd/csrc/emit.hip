@@ -147,6 +147,10 @@ __device__ __forceinline__ u32 lut_char(const EmitP &P, u32 code)
 // bit position.  The slow way -- for the few chunks the tile kernel does not take (headers, record ends, stream boundaries).
 __device__ u32 flat_packed_byte(const EmitP &P, u64 q)
 {
+    if (P.ftail && q >= P.ftail_q) {                             // the frame's final Raw or (bit 31 of the length) RLE block
+        const u64 k = q - P.ftail_q;
+        return k < (P.ftail_n & 0x7FFFFFFFu) ? P.ftail[(P.ftail_n >> 31) ? 0 : k] : 0u;
+    }
     const FlatStream *si = (const FlatStream *)P.fsi;
     u64 lo = 0, hi = P.fslots;                                   // last slot with q0 <= q
     while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (si[mid].q0 <= q) lo = mid; else hi = mid; }
@@ -747,6 +751,7 @@ __global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr,
         const TileFlat f = tsig[t];
         if (fast) {
             fast = f.qf + 2048 + 16 < f.q2 || f.q2 == f.q1;         // at most two streams under the tile (q2 == q1: the data end there)
+            if (P.ftail && f.qf + 2048 + 16 >= P.ftail_q) fast = false;   // the bytes of a final Raw block are not in any stream
             if (f.q2 != f.q1 && (f.A1 > f.A ? f.A1 - f.A : f.A - f.A1) >= (1ull << 29)) fast = false;   // both streams are addressed from one 32-bit base
         }
         if (fast) {
@@ -1546,7 +1551,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         c->zflat = nullptr;
         if (rc) return rc;
     }
-    if (zflat.ready) { pl.P.fsrc = zflat.src; pl.P.fsi = zflat.si; pl.P.fslots = zflat.nslots; pl.P.fsym = zflat.sym; }
+    if (zflat.ready) { pl.P.fsrc = zflat.src; pl.P.fsi = zflat.si; pl.P.fslots = zflat.nslots; pl.P.fsym = zflat.sym; pl.P.ftail = zflat.tail; pl.P.ftail_q = zflat.tail_q; pl.P.ftail_n = zflat.tail_n; }
     if (pl.P.mode == -1) {                                                             // --4bit: the stream itself
         HIP_TRY(c, hipMemcpyAsync(d_out, seq + out_begin, out_end - out_begin, hipMemcpyDeviceToDevice, c->stream));
         return 0;

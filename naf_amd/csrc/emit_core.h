@@ -24,6 +24,7 @@ struct EmitP {
     u8 sep, hdr_char;
     int force_slow;
     // a flat frame read in place (ctx.h: ZFlat): stream table, source, code -> packed byte; fsrc == nullptr otherwise
+    const u8 *ftail; u64 ftail_q; u32 ftail_n;   // the frame's final Raw block, if it has one (ZFlat)
     const u8 *fsrc; const void *fsi; u64 fslots; const u8 *fsym; const u32 *fpair;    // fpair: the 16-entry table code -> packed byte as four dwords (for v_perm_b32)
 };
 

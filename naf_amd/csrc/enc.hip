@@ -1504,7 +1504,8 @@ struct EnnafCarry {
     int skip_run0;         // 1: the bases in front of the shard's first case change continue a run that an earlier shard emits
     u64 run_ext;           // bases of the following shards that continue this shard's last mask run
 };
-struct EnnafStreams { const u8 *ptr[6]; u64 len[6], orig[6]; int lz[6], block_log[6], window_log[6]; bool present[6]; };
+struct EnnafStreams { const u8 *ptr[6]; u64 len[6], orig[6]; int lz[6], block_log[6], window_log[6]; bool present[6];
+                      u32 tail[6]; };   // tail: bytes at the end of the stream that go into a Raw block of their own (encode_stream)
 
 // E5-E7: lengths, 4-bit pack, mask units -> the six uncompressed streams.
 static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, EnnafStreams &X)
@@ -1512,7 +1513,7 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
     memset(&X, 0, sizeof X);
     int rc; const u64 T = S.T, N = S.N;
     u32 *s_len = nullptr; u8 *s_seq = nullptr, *s_mask = nullptr;
-    u64 n_lenb = 0, n_seqb = 0, n_mask = 0; int mask_block_log = 15;
+    u64 n_lenb = 0, n_seqb = 0, n_mask = 0; int mask_block_log = 15; u32 seq_tail = 0;
     if (S.format != 0) {
         if (N) {
             u64 *lu = arena_new<u64>(c, N + 2); if (!lu) return NAF_GPU_ENOMEM;
@@ -1536,6 +1537,12 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
                 LAUNCH(c, "ennaf_nibble_shift", k_nibble_shift, cdiv(cdiv(n_seqb, 8), 256), 256, 0, (const u8 *)S.packed, (T + 1) / 2, s_seq, n_seqb);
             } else s_seq = S.packed;
             if ((Tp & 1) && K.tail_hi) LAUNCH(c, "ennaf_tail_nibble", k_set_high_nibble, 1, 64, 0, s_seq + n_seqb - 1, K.tail_hi);
+            // The last byte of an odd stream holds the padding nibble: a byte value the rest of a block of A C G T pairs does not have.
+            // Inside the last Huffman block it would be a seventeenth symbol, that block's tree would differ from every other one, and
+            // the decoder could not read the frame in place (k_emit_tile_flat, zstd_dec.hip: flat_tail): it goes into a Raw block.
+            // (Not for archives with qualities: the reference's FASTQ path holds the sequence frame in memory behind a 4-byte magic number
+            // and stops feeding its decoder 4 bytes early (input.c:254-256, :356-357) -- a last block of 3 + 1 bytes would never arrive.)
+            if ((Tp & 1) && !K.tail_hi && n_seqb >= 2 && !S.store_qual) seq_tail = 1;
         } else {
             if (S.no_mask && T) LAUNCH(c, "ennaf_toupper", k_toupper, cdiv(T, 256), 256, 0, S.bases, T);   // process.c:46-51
             s_seq = S.bases; n_seqb = T;
@@ -1572,7 +1579,7 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
     X.ptr[1] = S.s_cmt; X.len[1] = X.orig[1] = S.n_cmt; X.lz[1] = 1; X.present[1] = true;
     X.ptr[2] = (const u8 *)s_len; X.len[2] = X.orig[2] = n_lenb; X.lz[2] = 1; X.present[2] = true;
     X.ptr[3] = s_mask; X.len[3] = X.orig[3] = n_mask; X.block_log[3] = mask_block_log; X.present[3] = S.store_mask;
-    X.ptr[4] = s_seq; X.len[4] = n_seqb; X.orig[4] = T; X.present[4] = true;                      // ennaf.c:582: number of bases
+    X.ptr[4] = s_seq; X.len[4] = n_seqb; X.orig[4] = T; X.present[4] = true; X.tail[4] = seq_tail;   // ennaf.c:582: number of bases
     X.ptr[5] = S.s_qual; X.len[5] = X.orig[5] = S.n_qual; X.present[5] = S.store_qual;
     return 0;
 }
@@ -1602,15 +1609,30 @@ static size_t naf_header_bytes(const naf_gpu_ennaf_opts *o, bool store_mask, boo
     return hl;
 }
 
+// One stream -> its frame, or its part of a frame (flags: ZENC_PART*; 0 = a whole frame without the magic number).  `tail` bytes at
+// the end are coded as a part of their own, i.e. end up in a Raw block behind the others.
+static int encode_stream(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level, u8 *dst, size_t cap, size_t *clen, int flags, int lz, int block_log, int window_log, u32 tail)
+{
+    if (!tail || len <= tail) return zstd_encode(c, d_stream, len, level, dst, cap, clen, flags, lz, block_log, window_log);
+    const bool part = (flags & ZENC_PART) != 0;
+    const int f1 = ZENC_PART | ((!part || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0);
+    const int f2 = ZENC_PART | ((!part || (flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0);
+    size_t a = 0, b = 0;
+    int rc = zstd_encode(c, d_stream, len - tail, level, dst, cap, &a, f1, lz, block_log, window_log); if (rc) return rc;
+    rc = zstd_encode(c, d_stream + (len - tail), tail, level, dst + a, cap - a, &b, f2, 0, 0, 0); if (rc) return rc;
+    *clen = a + b;
+    return 0;
+}
+
 struct SecOut { u64 orig, comp; };
 
-static int put_section(naf_gpu_ctx *c, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz = 0, int block_log = 0, int window_log = 0)
+static int put_section(naf_gpu_ctx *c, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz = 0, int block_log = 0, int window_log = 0, u32 tail = 0)
 {
     size_t bound = naf_gpu_zstd_compress_bound(stream_len);
     u8 *tmp = (u8 *)arena_alloc(c, bound);
     if (!tmp) return NAF_GPU_ENOMEM;
     size_t clen = 0;
-    int rc = zstd_encode(c, d_stream, stream_len, level, tmp, bound, &clen, 0, lz, block_log, window_log); if (rc) return rc;
+    int rc = encode_stream(c, d_stream, stream_len, level, tmp, bound, &clen, 0, lz, block_log, window_log, tail); if (rc) return rc;
     u8 hdr[20]; size_t hl = vle(orig, hdr); hl += vle(clen, hdr + hl);
     if (pos + hl + clen > cap) return ctx_fail(c, NAF_GPU_ECAP, "ennaf output capacity %zu too small", cap);
     HIP_TRY(c, hipMemcpyAsync(d_naf + pos, hdr, hl, hipMemcpyHostToDevice, c->stream));
@@ -1653,7 +1675,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     SecOut so[6]; memset(so, 0, sizeof so);
     for (int i = 0; i < 6; i++)
-        if (X.present[i] && (rc = put_section(c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i], X.window_log[i]))) return rc;
+        if (X.present[i] && (rc = put_section(c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i]))) return rc;
     for (int i = 0; i < 6; i++) { R.section_orig[i] = so[i].orig; R.section_comp[i] = so[i].comp; }
     *naf_len = pos;
     if (rep) *rep = R;
@@ -1865,7 +1887,7 @@ extern "C" int naf_gpu_ennaf_shard_finish(naf_gpu_ctx *c, const naf_gpu_ennaf_op
         if (pos + need > cap) return ctx_fail(c, NAF_GPU_ECAP, "shard piece buffer of %zu bytes is too small", cap);
         size_t clen = 0;
         const int flags = ZENC_PART | (V.first[i] ? ZENC_PART_FIRST : 0) | (V.last[i] ? ZENC_PART_LAST : 0);
-        if ((rc = zstd_encode(c, X.ptr[i], X.len[i], o->level, dst + pos, cap - pos, &clen, flags, X.lz[i], X.block_log[i], X.window_log[i]))) return rc;
+        if ((rc = encode_stream(c, X.ptr[i], X.len[i], o->level, dst + pos, cap - pos, &clen, flags, X.lz[i], X.block_log[i], X.window_log[i], V.last[i] ? X.tail[i] : 0u))) return rc;
         pieces->off[i] = pos; pieces->len[i] = clen; pieces->raw[i] = X.orig[i];
         pos += (clen + 15) & ~(size_t)15;
     }

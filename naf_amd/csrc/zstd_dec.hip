@@ -25,6 +25,7 @@ struct ZStat {                 // device-side counters read back by the host
     u32 ticket, n_plain_huf;     // n_plain_huf: compressed blocks with Huffman literals and no sequences
     u32 max_seq_regen, n_flat;    // largest regenerated size among the blocks that have sequences; table-defining blocks whose tree is flat
     u32 n_huf_distinct, n_huf_built;   // tree descriptions that differ from their predecessor's (k_huf_dedup); tables actually built
+    u32 last_raw, pad_;                // size of the frame's last block when it is a Raw or (bit 31) RLE one, else 0
 };
 
 static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
@@ -254,6 +255,7 @@ __global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_hu
     sizes[i] = b.regen;                                          // final unless the block has sequences (k_decode_seq then rewrites it)
     if (comp && b.lit_type == LIT_HUF) atomicAdd(&st->n_huf_def, 1u);
     if (comp && b.lit_type >= LIT_HUF && b.nseq == 0) atomicAdd(&st->n_plain_huf, 1u);
+    if (i + 1 == nblk && (b.btype == BT_RAW || b.btype == BT_RLE) && b.bsize) st->last_raw = b.bsize | (b.btype == BT_RLE ? 0x80000000u : 0u);
     if (sq) atomicAdd(&st->n_seq_blk, 1u);
 }
 
@@ -966,10 +968,10 @@ __global__ __launch_bounds__(256) void k_flat_literals(const u8 *src, const ZBlo
 
 // Stream table of a flat frame for the fused emit (ctx.h: ZFlat): four slots per block, the unused ones of a single-stream block
 // empty (they start where the block ends).  Checks what k_flat_literals checks: jump table, end marker, size = n x 4 bits.
-__global__ void k_flat_streams(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf, const u8 *pool, FlatStream *si, u8 *sym, ZStat *st, const u64 *total_out)
+__global__ void k_flat_streams(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf, const u8 *pool, FlatStream *si, u8 *sym, ZStat *st, const u64 *total_out, u64 tail_bytes)
 {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) si[4ull * nblk].q0 = *total_out, si[4ull * nblk].A = 0;
+    if (t == 0) si[4ull * nblk].q0 = *total_out - tail_bytes, si[4ull * nblk].A = 0;      // (nblk: the Huffman blocks; a final Raw block's bytes follow them)
     if (t < 16) {                                                 // code -> symbol, from the one table of the frame
         u32 b0 = 0; while (b0 < nblk && own_huf[b0] < 0) b0++;
         if (b0 < nblk) sym[t] = (u8)(((const u16 *)(pool + blk[own_huf[b0]].huf_tab))[t] >> 8);
@@ -1508,7 +1510,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     // quality streams); for those nothing below needs the host: block sizes are final after the parse, so offsets, the block range
     // of a byte-range request, the Huffman tables and the part boundaries of a split decode are queued right away and the counters
     // come back in ONE read-back.  A frame that does have sequences then takes the long way from here (its tables are kept).
-    const bool spec = nblk > 512 && !fuse;
+    const char *smin = getenv("NAF_GPU_SPEC_MIN");                      // tests: frames of a few dozen blocks through the paths of the big ones
+    const bool spec = nblk > (smin ? (u32)atoi(smin) : 512u) && !fuse;
     u64 *r4 = nullptr, *ends = nullptr; u8 *huf_pool = nullptr; u32 pool_cap = 0; bool tables_built = false; bool ranged_build = false;
     u64 h4[5] = { 0, 0, 0, 0, 0 }, hends[ZSPLIT_MAX] = { 0 };
     if (spec) {
@@ -1553,14 +1556,24 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, n_flat), 0, 4, c->stream));
         HIP_TRY(c, hipMemsetAsync((u8 *)st + offsetof(ZStat, n_huf_built), 0, 4, c->stream));
     }
-    if (c->zflat && lit_only_spec && nblk > 0 && hs.n_huf_distinct == 1 && hs.n_huf_built == 1 && hs.n_flat == 1 && hs.max_huf_log == 4 && hs.n_plain_huf == nblk && !always_table) {
+    // (a final Raw block is allowed: this build's encoder puts the byte with the padding nibble of an odd stream there, so that it does
+    // not bring a seventeenth symbol into the last Huffman block)
+    const bool flat_tail = hs.last_raw != 0 && nblk >= 2 && hs.n_plain_huf == nblk - 1;
+    if (getenv("NAF_GPU_DEBUG_FLAT") && c->zflat) fprintf(stderr, "[flat?] spec %d nblk %u seq_blk %u distinct %u built %u n_flat %u log %u plain %u last_raw %u always %u\n", (int)spec, nblk, n_seq_blk, hs.n_huf_distinct, hs.n_huf_built, hs.n_flat, hs.max_huf_log, hs.n_plain_huf, hs.last_raw, always_table);
+    if (c->zflat && lit_only_spec && nblk > 0 && hs.n_huf_distinct == 1 && hs.n_huf_built == 1 && hs.n_flat == 1 && hs.max_huf_log == 4 && (hs.n_plain_huf == nblk || flat_tail) && !always_table) {
         // every block a plain Huffman block of the same flat 4-bit tree: the caller's emit kernel reads the streams in place
         ZFlat *zf = c->zflat;
-        FlatStream *si = arena_new<FlatStream>(c, 4 * (size_t)nblk + 1); u8 *d_sym = (u8 *)arena_alloc(c, 16);
+        const u32 nhb = flat_tail ? nblk - 1 : nblk;                  // the Huffman blocks
+        FlatStream *si = arena_new<FlatStream>(c, 4 * (size_t)nhb + 1); u8 *d_sym = (u8 *)arena_alloc(c, 16);
         if (!si || !d_sym) return NAF_GPU_ENOMEM;
         LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr);
-        LAUNCH(c, "zstd_flat_streams", k_flat_streams, cdiv(4ull * nblk, 256), 256, 0, d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, si, d_sym, st, (const u64 *)d_total_out);
-        zf->src = d_src; zf->si = si; zf->nslots = 4ull * nblk; zf->sym = d_sym; zf->status = st; zf->ready = true;
+        LAUNCH(c, "zstd_flat_streams", k_flat_streams, cdiv(4ull * nhb, 256), 256, 0, d_src, (const ZBlock *)blk, nhb, (const i32 *)own_huf, (const u8 *)huf_pool, si, d_sym, st, (const u64 *)d_total_out, flat_tail ? (u64)(hs.last_raw & 0x7FFFFFFFu) : 0ull);
+        zf->src = d_src; zf->si = si; zf->nslots = 4ull * nhb; zf->sym = d_sym; zf->status = st; zf->ready = true;
+        {
+            const u32 tn = hs.last_raw & 0x7FFFFFFFu; const bool rle = (hs.last_raw >> 31) != 0;       // an RLE block stores one byte
+            zf->tail = flat_tail ? d_src + (hs.end_off - (rle ? 1u : tn)) : nullptr; zf->tail_q = hs.total_out - (flat_tail ? tn : 0u);
+            zf->tail_n = flat_tail ? (rle ? tn | 0x80000000u : tn) : 0u;
+        }
         if (rg) { rg->got_lo = 0; rg->got_hi = hs.total_out; rg->ranged = false; }      // nothing was decoded: the emit kernel finds any byte of the stream itself
         *out_len = hs.total_out;
         if (fh.has_fcs && fh.content_size != hs.total_out) return zerr(c, ZE_CORRUPT, "content size mismatch");

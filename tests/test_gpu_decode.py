@@ -370,6 +370,8 @@ def test_flat_frame_read_in_place_by_the_emit_kernel(gpu, oracle, monkeypatch):
         return bytes(out)
     cases = [(3, 1_500_001, 80, False, False), (2, 2_000_003, 61, True, False), (1, 3_000_000, 0, False, False), (4, 900_017, 16, False, True),
              (2, 1_200_000, 4096, True, False), (1, 2_500_007, 97, False, False)]
+    monkeypatch.setenv("NAF_GPU_SPEC_MIN", "8")                  # the in-place path is taken from 512 blocks (16 MB of packed bases) up; here from 8
+    cases += [(2, 600_011, w, w % 2 == 1, False) for w in (17, 31, 32, 33, 64, 79, 81, 255, 256, 1000, 5000)]
     for n_rec, per, width, lower, rna in cases:
         text = uniform_fasta(n_rec, per, width, lower, rna)
         d_naf, rep = gpu.ennaf(gpu.to_device(text), seq_type=1 if rna else 0)
@@ -378,8 +380,13 @@ def test_flat_frame_read_in_place_by_the_emit_kernel(gpu, oracle, monkeypatch):
             want = oracle.unnaf(naf, mode, True, ll)
             monkeypatch.setenv("NAF_GPU_FLAT_FUSE", "1")
             monkeypatch.setenv("NAF_GPU_DEBUG", "1")
+            gpu.set_timing(True)
             got = host(gpu.unnaf(d_naf, mode, line_length=ll))
+            ran = {n for n, ms, k in gpu.get_timing()}
+            gpu.set_timing(False)
             assert got == want, (n_rec, per, width, lower, rna, mode, ll)
+            if mode in (0, 3) and (ll < 0 or ll >= 16 or ll == 0) and (width == 0 or width >= 16 or ll >= 16):
+                assert "unnaf_emit_flat" in ran, (width, mode, ll, sorted(ran))   # the kernel under test did run
             monkeypatch.setenv("NAF_GPU_FLAT_FUSE", "0")
             assert host(gpu.unnaf(d_naf, mode, line_length=ll)) == want
         monkeypatch.setenv("NAF_GPU_FLAT_FUSE", "1")
