@@ -890,10 +890,21 @@ struct FqRoleSink {
     __device__ void term(int) {} __device__ void header_start(u64) {} __device__ void header_end(u64) {} __device__ void seq_end(u64) {}
     __device__ void qual_begin(u64) {} __device__ void qual_end(u64) {} __device__ void error(u64, int) {}
 };
-__device__ __forceinline__ bool segments_ok_fastq(const EncP &P, u64 base, const Piece &pc, const PMask &pm, const TileCtx &ctx, const u8 *cls)
+// counts and roles in ONE walk (k_encq_count): the counts are those of the segment-wise classification, valid when the roles pass
+struct FqCountRole {
+    FqCount C; FqRoleSink R;
+    __device__ void ids_range(const Piece &pc, u32 a, u32 b) { C.ids_range(pc, a, b); R.ids_range(pc, a, b); }
+    __device__ void cmt_range(const Piece &pc, u32 a, u32 b) { C.cmt_range(pc, a, b); R.cmt_range(pc, a, b); }
+    __device__ void seq_range(const Piece &pc, u32 a, u32 b, u32 sp) { C.seq_range(pc, a, b, sp); R.seq_range(pc, a, b, sp); }
+    __device__ void qual_range(const Piece &pc, u32 a, u32 b, u32 sp) { C.qual_range(pc, a, b, sp); R.qual_range(pc, a, b, sp); }
+    __device__ void qual_first(u32 ch) { C.qual_first(ch); }
+    __device__ void term(int st) { C.term(st); }
+    __device__ void header_start(u64) {} __device__ void header_end(u64) {} __device__ void seq_end(u64) {}
+    __device__ void qual_begin(u64) {} __device__ void qual_end(u64) {} __device__ void error(u64, int) {}
+};
+// no byte that its role would replace
+__device__ __forceinline__ bool roles_ok_fastq(const EncP &P, const Piece &pc, const FqRoleSink &R, const u8 *cls)
 {
-    if (pc.cnt != ET_BYTES || base <= P.p0 || ctx.ord < 0) return false;
-    FqRoleSink R; classify_segments_fastq(P, base, pc, pm, ctx, R);
     u32 w[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) };
     if ((R.idm | R.cmm) && ((R.idm | R.cmm) & piece_ctl_mask(w))) return false;
     if (R.qlm && (R.qlm & piece_not_quality_mask(w))) return false;
@@ -962,15 +973,21 @@ __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol,
         u64 b2 = (u64)blockIdx.x * ET_TILE + (u64)who * ET_BYTES;
         Piece p2 = load_piece(P, b2);
         TileCtx c2; c2.last_eol = s_ctx[who].le; c2.last_sp = s_ctx[who].ls; c2.hdr = false; c2.ord = s_ctx[who].ord;
-        FqCount S2;
-        if (segments_ok_fastq(P, b2, p2, piece_masks(p2), c2, cls)) classify_segments_fastq(P, b2, p2, piece_masks(p2), c2, S2);
-        else classify_range_fastq(P, b2, p2, (b2 + p2.cnt == P.n) && p2.cnt < ET_BYTES, c2, S2, cls);
-        s_cnt[who] = (u64)S2.nseq | ((u64)S2.nids << 16) | ((u64)S2.ncmt << 32) | ((u64)S2.nqual << 48);
+        FqCount S2; bool segok = false;
+        if (p2.cnt == ET_BYTES && b2 > P.p0 && c2.ord >= 0) {            // a full piece behind p0 in a numbered line
+            FqCountRole CR; classify_segments_fastq(P, b2, p2, piece_masks(p2), c2, CR);
+            if (roles_ok_fastq(P, p2, CR.R, cls)) { S2 = CR.C; segok = true; }
+        }
+        if (!segok) classify_range_fastq(P, b2, p2, (b2 + p2.cnt == P.n) && p2.cnt < ET_BYTES, c2, S2, cls);
+        // bit 63: the piece passed the segment-wise test -- the scatter pass does not walk it a second time to find out
+        s_cnt[who] = (u64)S2.nseq | ((u64)S2.nids << 16) | ((u64)S2.ncmt << 32) | ((u64)S2.nqual << 48) | ((u64)(segok ? 1 : 0) << 63);
     }
     __syncthreads();
-    if (slow) { u64 v = s_cnt[threadIdx.x]; S.nseq = v & 0xFFFF; S.nids = (v >> 16) & 0xFFFF; S.ncmt = (v >> 32) & 0xFFFF; S.nqual = (u32)(v >> 48); }
-    // the four counts of every piece (each at most 17) are kept for the scatter pass, which then walks the slow pieces once, not twice
-    piece_cnt[(u64)blockIdx.x * 256 + threadIdx.x] = S.nseq | (S.nids << 8) | (S.ncmt << 16) | (S.nqual << 24);
+    u32 segok_bit = 0;
+    if (slow) { u64 v = s_cnt[threadIdx.x]; S.nseq = v & 0xFFFF; S.nids = (v >> 16) & 0xFFFF; S.ncmt = (v >> 32) & 0xFFFF; S.nqual = (u32)(v >> 48) & 0x7FFFu; segok_bit = (u32)(v >> 63); }
+    // the four counts of every piece (each at most 17) are kept for the scatter pass, which then walks the slow pieces once, not twice;
+    // bit 31: the verdict of the segment-wise test
+    piece_cnt[(u64)blockIdx.x * 256 + threadIdx.x] = S.nseq | (S.nids << 8) | (S.ncmt << 16) | (S.nqual << 24) | (segok_bit << 31);
     u64 tot;
     wg_scan_inclusive<u64, OpAdd>((u64)S.nseq | ((u64)S.nids << 16) | ((u64)S.ncmt << 32) | ((u64)S.nqual << 48), &tot, lds);
     if (threadIdx.x == 0) { t_seq[blockIdx.x] = tot & 0xFFFF; t_ids[blockIdx.x] = (tot >> 16) & 0xFFFF; t_cmt[blockIdx.x] = (tot >> 32) & 0xFFFF; t_qual[blockIdx.x] = tot >> 48; }
@@ -990,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
     bool active = base <= P.n;
     FqCount C;
     const int fast = fq_piece(P, base, pc, pm, ctx, cls);
-    { u32 v = O.piece_cnt[(u64)blockIdx.x * 256 + threadIdx.x]; C.nseq = v & 0xFF; C.nids = (v >> 8) & 0xFF; C.ncmt = (v >> 16) & 0xFF; C.nqual = v >> 24; }
+    { u32 v = O.piece_cnt[(u64)blockIdx.x * 256 + threadIdx.x]; C.nseq = v & 0xFF; C.nids = (v >> 8) & 0xFF; C.ncmt = (v >> 16) & 0xFF; C.nqual = (v >> 24) & 0x7F; }
     __shared__ SlowCtx s_ctx[256]; __shared__ u16 s_list[256]; __shared__ u32 s_nslow;
     __shared__ u64 s_w[256][4];                                   // stream positions of the slow pieces for the write pass
     const bool slow = !fast && active;
@@ -1014,7 +1031,7 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
         TileCtx c2; c2.last_eol = s_ctx[who].le; c2.last_sp = s_ctx[who].ls; c2.hdr = false; c2.ord = s_ctx[who].ord;
         FqWrite W2(O); W2.sstage = sstage; W2.qstage = qstage; W2.sbase = W.sbase; W2.qbase = W.qbase;
         W2.bseq = s_w[who][0]; W2.bids = s_w[who][1]; W2.bcmt = s_w[who][2]; W2.bqual = s_w[who][3];
-        if (segments_ok_fastq(P, b2, p2, piece_masks(p2), c2, cls)) classify_segments_fastq(P, b2, p2, piece_masks(p2), c2, W2);
+        if (O.piece_cnt[(u64)blockIdx.x * 256 + who] >> 31) classify_segments_fastq(P, b2, p2, piece_masks(p2), c2, W2);   // k_encq_count's verdict
         else classify_range_fastq(P, b2, p2, (b2 + p2.cnt == P.n) && p2.cnt < ET_BYTES, c2, W2, cls);
     }
     __syncthreads();
