@@ -11,6 +11,7 @@
 // space-class byte of the header line.  Tiles of 4 KiB (256 lanes x 16 B) are classified independently
 // once those maxima are scanned across tiles; stream offsets come from prefix sums of per-tile counts.
 #include "ctx.h"
+#include <time.h>
 #include "wgscan.h"
 #include "enc_swar.h"
 
@@ -1605,11 +1606,26 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
 // entropy-coded only.  From level 2 every stream finds matches across blocks inside the window libzstd uses at that level for large
 // inputs (clevels.h); --long N (ennaf.c:247-273, :505) gives the SEQUENCE stream a window of 2^N at any level -- the reference turns
 // on libzstd's long-distance matcher for that stream only (compressor.c:12-16).
-static void ennaf_windows(EnnafStreams &X, const naf_gpu_ennaf_opts *o)
+// Level 1 without --long looks at the sequence stream first (zenc_repeat_probe): when a thirty-second of the probed anchors has an
+// earlier copy nearby, the stream is matched inside the level's own window of 2^19 -- as the reference's level 1 would.
+static int ennaf_windows(naf_gpu_ctx *c, EnnafStreams &X, const naf_gpu_ennaf_opts *o)
 {
     const int wl = zenc_level_window(o->level);
     for (int i = 0; i < 6; i++) X.window_log[i] = wl;
     if (o->long_log) { X.window_log[4] = o->long_log < 10 ? 10 : o->long_log > 31 ? 31 : o->long_log; X.lz[4] = 1; }
+    else if (!wl && X.present[4] && X.len[4]) {
+        const char *pe = getenv("NAF_GPU_PROBE");                 // "0": never look, "1": always match
+        u32 share = 0;
+        if (pe && pe[0] == '1') share = 1024;
+        else if (!(pe && pe[0] == '0')) {
+            struct timespec t0, t1, t2; const bool dbg = getenv("NAF_GPU_DEBUG_PROBE") != nullptr;
+            if (dbg) { clock_gettime(CLOCK_MONOTONIC, &t0); hipStreamSynchronize(c->stream); clock_gettime(CLOCK_MONOTONIC, &t1); }
+            int rc = zenc_repeat_probe(c, X.ptr[4], X.len[4], &share); if (rc) return rc;
+            if (dbg) { clock_gettime(CLOCK_MONOTONIC, &t2); fprintf(stderr, "[probe] drain %.3f ms, probe %.3f ms, share %u/1024\n", (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) * 1e-6, share); }
+        }
+        if (share >= 32) { X.window_log[4] = 19; X.lz[4] = 1; }
+    }
+    return 0;
 }
 
 // container header (ennaf.c:538-556): magic, version, flags, separator, line length, N, title
@@ -1678,7 +1694,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     EnnafCarry K; memset(&K, 0, sizeof K);
     EnnafStreams X;
     if ((rc = ennaf_streams(c, S, K, X))) return rc;
-    ennaf_windows(X, o);
+    if ((rc = ennaf_windows(c, X, o))) return rc;
     for (int i = 0; i < 257; i++) { R.unexpected_id[i] = S.unexpected[0][i]; R.unexpected_comment[i] = S.unexpected[1][i]; R.unexpected_seq[i] = S.unexpected[2][i]; R.unexpected_qual[i] = S.unexpected[3][i]; }
     R.n_sequences = S.N; R.n_bases = S.T; R.longest_line = S.longest;
 
@@ -1895,7 +1911,7 @@ extern "C" int naf_gpu_ennaf_shard_finish(naf_gpu_ctx *c, const naf_gpu_ennaf_op
     ShardView V; shard_view(infos, n, k, V);
     EnnafStreams X;
     if ((rc = ennaf_streams(c, st->S, V.K, X))) return rc;
-    ennaf_windows(X, o);
+    if ((rc = ennaf_windows(c, X, o))) return rc;
     memset(pieces, 0, sizeof *pieces);
     u8 *dst = (u8 *)d_pieces_; size_t pos = 0;
     for (int i = 0; i < 6; i++) {

@@ -8,6 +8,7 @@
 //   k_zenc_write  16 blocks per 64-lane workgroup: code tables in LDS, ONE LANE PER HUFFMAN STREAM
 //                 writes its stream at its final offset; raw/RLE blocks are copied by the whole wave
 #include "ctx.h"
+#include <vector>
 #include "zstd_enc_core.h"
 
 #define ZENC_TREE_SLOT 192
@@ -669,6 +670,65 @@ __global__ void k_zenc_frame_header(u8 *dst, int with_magic, u32 wlog)
     if (with_magic) { dst[p++] = 0x28; dst[p++] = 0xB5; dst[p++] = 0x2F; dst[p++] = 0xFD; }
     dst[p++] = 0x00;            // Frame_Header_Descriptor: no FCS, no checksum, no dictionary, windowed (like ennaf -1)
     dst[p++] = (u8)((wlog - 10) << 3);   // Window_Descriptor: 2^19 for blocks that never reference earlier data, else the window the matches were found in
+}
+
+// ---- is there anything to match?  (level 1) -----------------------------------------------------------------------------------------
+// The reference's level 1 finds the repeats of a repeat-rich genome (its archive is then a fraction of the entropy-coded size); matching
+// a stream costs about ten times the rest of a level-1 encode, and random bases have nothing to match.  So level 1 LOOKS first: one
+// region of 1 MiB in every 64 MiB enters a table of its own (one anchor position in 64: the atomics are what this costs), then every
+// anchor of the same regions asks the table whether an earlier position of its region holds the same 16 bytes.  The share of anchors
+// that do is read back.
+#define PROBE_REGION_LOG 20
+#define PROBE_EVERY 64
+#define PROBE_TLOG 16
+__global__ __launch_bounds__(256) void k_ldm_probe(const u8 *src, u64 n, u32 *tab, u32 *counts /* per workgroup: anchors | hits << 16 */, int pass)
+{
+    // thread: 8 consecutive positions of a sampled region (grid: regions x 512 workgroups)
+    const u64 region = (u64)(blockIdx.x >> 9) * PROBE_EVERY, rbase = region << PROBE_REGION_LOG;
+    const u64 p0 = rbase + ((u64)(blockIdx.x & 511) * 256 + threadIdx.x) * 8;
+    u32 anchors = 0, hits = 0;
+    if (p0 + 24 <= n) {
+        const u64 w0 = ld64(src + p0), w1 = ld64(src + p0 + 8), w2 = ld64(src + p0 + 16);
+        u32 *t = tab + ((u64)(blockIdx.x >> 9) << PROBE_TLOG);
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) {
+            const u64 a = k ? (w0 >> (8 * k)) | (w1 << (64 - 8 * k)) : w0, b = k ? (w1 >> (8 * k)) | (w2 << (64 - 8 * k)) : w1;
+            u32 idx;
+            if (!ldm_key(a, b, PROBE_TLOG, idx) || (ldm_mix(a) >> 58) != 0) continue;     // three more zero bits than k_ldm_insert asks for
+            const u32 rel = (u32)(p0 + k - rbase);
+            if (pass == 0) atomicMin(&t[idx], rel);
+            else {
+                anchors++;
+                const u32 q = t[idx];
+                if (q < rel && rel - q < (1u << 19) && ld64(src + rbase + q) == a && ld64(src + rbase + q + 8) == b) hits++;   // inside level 1's window
+            }
+        }
+    }
+    if (pass) {
+        __shared__ u32 s_c[4];
+        const u32 tot = wg_reduce1<u32, OpAdd>(anchors | (hits << 16), s_c);        // at most 2048 of either per workgroup
+        if (threadIdx.x == 0) counts[blockIdx.x] = tot;                // (one word per workgroup, summed by the host: 40 k atomics on one address took a millisecond)
+    }
+}
+// share of the probed anchors with an earlier copy, in 1/1024
+int zenc_repeat_probe(naf_gpu_ctx *c, const u8 *d_src, size_t n, u32 *share_1024)
+{
+    *share_1024 = 0;
+    if (n < 65536) return 0;                                      // nothing a second block could refer to
+    if (n < (4u << PROBE_REGION_LOG)) { *share_1024 = 1024; return 0; }   // a few megabytes: matching them costs a millisecond or two, just do it
+    const u64 regions = ((n >> PROBE_REGION_LOG) + PROBE_EVERY - 1) / PROBE_EVERY;
+    const u32 nwg = (u32)(regions * 512);
+    u32 *tab = arena_new<u32>(c, regions << PROBE_TLOG), *cnt = arena_new<u32>(c, nwg);
+    if (!tab || !cnt) return NAF_GPU_ENOMEM;
+    HIP_TRY(c, hipMemsetAsync(tab, 0xFF, (regions << PROBE_TLOG) * 4, c->stream));
+    LAUNCH(c, "zenc_probe_insert", k_ldm_probe, nwg, 256, 0, d_src, (u64)n, tab, cnt, 0);
+    LAUNCH(c, "zenc_probe_count", k_ldm_probe, nwg, 256, 0, d_src, (u64)n, tab, cnt, 1);
+    std::vector<u32> hc(nwg);
+    int rc = ctx_readback(c, hc.data(), cnt, (size_t)nwg * 4); if (rc) return rc;
+    u64 h[2] = { 0, 0 };
+    for (u32 v : hc) { h[0] += v & 0xFFFF; h[1] += v >> 16; }
+    if (h[0]) *share_1024 = (u32)(h[1] * 1024 / h[0]);
+    return 0;
 }
 
 // Window of the match finder at a compression level: none below 2 (matches inside a block only), else windowLog of libzstd's

@@ -484,9 +484,18 @@ def test_levels_and_long_match_across_blocks(gpu, oracle):
         assert host(gpu.unnaf(d_naf, -1)) == want
         if O.have_ref():
             assert O.ref_unnaf(mine) == want
-        # level 1 keeps the sequence stream entropy-coded only: the same input is several times larger
+        # level 1 looks at the sequence stream before it decides (zenc_repeat_probe): these repeats it finds, within its window of 2^19
         plain = host(gpu.ennaf(gpu.to_device(text))[0])
-        assert len(plain) > 3 * len(mine)
+        assert O.unnaf(plain, -1) == want
+        if name == "repeat_l19":
+            ref1 = open(os.path.join(ROOT, "tests", "golden", "naf", "repeat_l1.naf"), "rb").read()     # the real ennaf at its default level
+            assert len(plain) <= 1.10 * len(ref1), (len(plain), len(ref1))
+        import os as _os
+        _os.environ["NAF_GPU_PROBE"] = "0"                                      # entropy coding only: several times larger
+        try:
+            assert len(host(gpu.ennaf(gpu.to_device(text))[0])) > 3 * len(mine)
+        finally:
+            del _os.environ["NAF_GPU_PROBE"]
 
 
 def test_zstd_compress_levels_through_the_c_abi(gpu, oracle):
@@ -517,8 +526,12 @@ def test_small_windows_and_many_epochs(gpu, oracle):
              b">one line\n" + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 5000)) * 40 + b"\n"]
     for text in texts:
         want = O.unnaf(O.ennaf(text), -1)
-        plain = len(host(gpu.ennaf(gpu.to_device(text))[0]))
-        for level, long_log in ((1, 10), (1, 12), (1, 15), (5, 0), (1, 16), (22, 11)):
+        os.environ["NAF_GPU_PROBE"] = "0"                                     # level 1 without its look at the stream: entropy coding only
+        try:
+            plain = len(host(gpu.ennaf(gpu.to_device(text))[0]))
+        finally:
+            del os.environ["NAF_GPU_PROBE"]
+        for level, long_log in ((1, 10), (1, 12), (1, 15), (5, 0), (1, 16), (22, 11), (1, 0)):
             d_naf, _ = gpu.ennaf(gpu.to_device(text), level=level, long_log=long_log)
             mine = host(d_naf)
             h = O.parse_naf(mine)
@@ -528,8 +541,8 @@ def test_small_windows_and_many_epochs(gpu, oracle):
             assert host(gpu.unnaf(d_naf, -1)) == want
             if O.have_ref():
                 assert O.ref_unnaf(mine) == want, (len(text), level, long_log)
-            if long_log == 16:
-                assert len(mine) < plain                                       # 64 KiB reach back: the repeats were found
+            if long_log == 16 or (level, long_log) == (1, 0):
+                assert len(mine) < plain                                       # 64 KiB / 512 KiB reach back: the repeats were found
 
 
 def test_zstd_compress_levels_fuzz(gpu, oracle):
