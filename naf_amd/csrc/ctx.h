@@ -108,4 +108,7 @@ int zstd_small_batch(naf_gpu_ctx *c, int n, const u8 *const *src, const size_t *
 enum { ZENC_PART = 16, ZENC_PART_FIRST = 32, ZENC_PART_LAST = 64 };     // with_magic flags: a shard's part of a frame (zstd_enc.hip)
 int zenc_level_window(int level);
 int zenc_repeat_probe(naf_gpu_ctx *c, const u8 *d_src, size_t n, u32 *share_1024);   // level 1: share of sampled anchors that repeat inside their 1 MiB region
-int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz = 0, int block_log_hint = 0, int window_log = 0);   // window_log >= 10: cross-block matching inside that window (zstd_enc.hip)
+// place != nullptr: the frame's size is read back once it is planned and place->fn(place->ud, size) names where it goes (nullptr = give up,
+// the hook has set the context's error); d_dst / cap are not looked at.  Saves the copy of a frame whose position depends on its size.
+struct ZencPlace { u8 *(*fn)(void *ud, size_t frame_len); void *ud; };
+int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz = 0, int block_log_hint = 0, int window_log = 0, const ZencPlace *place = nullptr);   // window_log >= 10: cross-block matching inside that window (zstd_enc.hip)

@@ -1643,15 +1643,29 @@ static size_t naf_header_bytes(const naf_gpu_ennaf_opts *o, bool store_mask, boo
 }
 
 // One stream -> its frame, or its part of a frame (flags: ZENC_PART*; 0 = a whole frame without the magic number).  `tail` bytes at
-// the end are coded as a part of their own, i.e. end up in a Raw block behind the others.
-static int encode_stream(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level, u8 *dst, size_t cap, size_t *clen, int flags, int lz, int block_log, int window_log, u32 tail)
+// the end are coded as a part of their own, i.e. end up in a Raw block behind the others.  With `place` the frame goes where the hook
+// says once its size is known (zstd_encode): the tail part is coded first, into scratch, so that the hook hears the size of the whole.
+struct PlaceTail { const ZencPlace *outer; size_t tail_len; u8 *at; };
+static u8 *place_before_tail(void *ud, size_t len) { PlaceTail *t = (PlaceTail *)ud; return t->at = t->outer->fn(t->outer->ud, len + t->tail_len); }
+static int encode_stream(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level, u8 *dst, size_t cap, size_t *clen, int flags, int lz, int block_log, int window_log, u32 tail, const ZencPlace *place = nullptr)
 {
-    if (!tail || len <= tail) return zstd_encode(c, d_stream, len, level, dst, cap, clen, flags, lz, block_log, window_log);
+    if (!tail || len <= tail) return zstd_encode(c, d_stream, len, level, dst, cap, clen, flags, lz, block_log, window_log, place);
     const bool part = (flags & ZENC_PART) != 0;
     const int f1 = ZENC_PART | ((!part || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0);
     const int f2 = ZENC_PART | ((!part || (flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0);
     size_t a = 0, b = 0;
-    int rc = zstd_encode(c, d_stream, len - tail, level, dst, cap, &a, f1, lz, block_log, window_log); if (rc) return rc;
+    int rc;
+    if (place) {
+        const size_t tb = naf_gpu_zstd_compress_bound(tail);
+        u8 *tmp = (u8 *)arena_alloc(c, tb); if (!tmp) return NAF_GPU_ENOMEM;
+        if ((rc = zstd_encode(c, d_stream + (len - tail), tail, level, tmp, tb, &b, f2, 0, 0, 0))) return rc;
+        PlaceTail T = { place, b, nullptr }; ZencPlace P = { place_before_tail, &T };
+        if ((rc = zstd_encode(c, d_stream, len - tail, level, nullptr, 0, &a, f1, lz, block_log, window_log, &P))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(T.at + a, tmp, b, hipMemcpyDeviceToDevice, c->stream));
+        *clen = a + b;
+        return 0;
+    }
+    rc = zstd_encode(c, d_stream, len - tail, level, dst, cap, &a, f1, lz, block_log, window_log); if (rc) return rc;
     rc = zstd_encode(c, d_stream + (len - tail), tail, level, dst + a, cap - a, &b, f2, 0, 0, 0); if (rc) return rc;
     *clen = a + b;
     return 0;
@@ -1659,20 +1673,29 @@ static int encode_stream(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level,
 
 struct SecOut { u64 orig, comp; };
 
+// a section = VLE(original size) VLE(compressed size) frame (ennaf.c:538-589): the frame is written behind its header at once
+struct SmallBytes { u8 b[24]; u32 n; };
+__global__ void k_put_bytes(u8 *dst, SmallBytes s) { if (threadIdx.x < s.n) dst[threadIdx.x] = s.b[threadIdx.x]; }
+struct SecPlace { naf_gpu_ctx *c; u8 *d_naf; size_t cap, pos; u64 orig; size_t hl; int rc; };
+static u8 *place_section(void *ud, size_t clen)
+{
+    SecPlace *p = (SecPlace *)ud; naf_gpu_ctx *c = p->c;
+    SmallBytes h; memset(&h, 0, sizeof h);
+    size_t hl = vle(p->orig, h.b); hl += vle(clen, h.b + hl); h.n = (u32)hl;
+    if (p->pos + hl + clen > p->cap) { p->rc = ctx_fail(c, NAF_GPU_ECAP, "ennaf output capacity %zu too small", p->cap); return nullptr; }
+    hipLaunchKernelGGL(k_put_bytes, dim3(1), dim3(64), 0, c->stream, p->d_naf + p->pos, h);
+    if (hipGetLastError() != hipSuccess) { p->rc = ctx_fail(c, NAF_GPU_EHIP, "section header launch failed"); return nullptr; }
+    p->hl = hl;
+    return p->d_naf + p->pos + hl;
+}
+
 static int put_section(naf_gpu_ctx *c, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz = 0, int block_log = 0, int window_log = 0, u32 tail = 0)
 {
-    size_t bound = naf_gpu_zstd_compress_bound(stream_len);
-    u8 *tmp = (u8 *)arena_alloc(c, bound);
-    if (!tmp) return NAF_GPU_ENOMEM;
+    SecPlace sp = { c, d_naf, cap, pos, orig, 0, 0 }; ZencPlace P = { place_section, &sp };
     size_t clen = 0;
-    int rc = encode_stream(c, d_stream, stream_len, level, tmp, bound, &clen, 0, lz, block_log, window_log, tail); if (rc) return rc;
-    u8 hdr[20]; size_t hl = vle(orig, hdr); hl += vle(clen, hdr + hl);
-    if (pos + hl + clen > cap) return ctx_fail(c, NAF_GPU_ECAP, "ennaf output capacity %zu too small", cap);
-    HIP_TRY(c, hipMemcpyAsync(d_naf + pos, hdr, hl, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));                 // hdr is a stack buffer
-    pos += hl;
-    HIP_TRY(c, hipMemcpyAsync(d_naf + pos, tmp, clen, hipMemcpyDeviceToDevice, c->stream));
-    pos += clen;
+    int rc = encode_stream(c, d_stream, stream_len, level, nullptr, 0, &clen, 0, lz, block_log, window_log, tail, &P);
+    if (rc) return sp.rc ? sp.rc : rc;
+    pos += sp.hl + clen;
     so.orig = orig; so.comp = clen;
     return 0;
 }

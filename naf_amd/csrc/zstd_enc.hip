@@ -749,12 +749,13 @@ extern "C" size_t naf_gpu_zstd_compress_bound(size_t n)
 // with_magic: 1 = whole frame with its magic number, 0 = whole frame without it (as stored in a .naf section),
 //   ZENC_PART | ZENC_PART_FIRST | ZENC_PART_LAST = a shard's part of a frame: blocks only, behind the 2-byte frame header when
 //   FIRST, ending the frame when LAST (an empty part that is not LAST is zero bytes; an empty LAST part is one empty Raw block).
-int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz, int block_log_hint, int window_log)
+int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz, int block_log_hint, int window_log, const ZencPlace *place)
 {
     const bool part = (with_magic & ZENC_PART) != 0, part_first = (with_magic & ZENC_PART_FIRST) != 0, part_last = (with_magic & ZENC_PART_LAST) != 0;
     if (part) with_magic = 0;
     if (part && n == 0 && !part_last) {
-        if (part_first) { if (cap < 2) return ctx_fail(c, NAF_GPU_ECAP, "zstd_compress capacity %zu too small", cap); LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, 0, (u32)(window_log >= 10 ? window_log : 19)); }
+        if (place && !(d_dst = place->fn(place->ud, part_first ? 2 : 0))) return NAF_GPU_ECAP;
+        if (part_first) { if (!place && cap < 2) return ctx_fail(c, NAF_GPU_ECAP, "zstd_compress capacity %zu too small", cap); LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, 0, (u32)(window_log >= 10 ? window_log : 19)); }
         *out_len = part_first ? 2 : 0;
         return 0;
     }
@@ -784,7 +785,7 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
     if (nblk64 > 0x7FFFFFFFull) return ctx_fail(c, NAF_GPU_EARG, "stream too large");
     u32 nblk = (u32)nblk64;
     u64 hdr = with_magic ? 6 : (part && !part_first) ? 0 : 2;
-    if (cap < hdr + n + 3ull * nblk) return ctx_fail(c, NAF_GPU_ECAP, "zstd_compress capacity %zu too small (bound %llu)", cap, (unsigned long long)(hdr + n + 3ull * nblk));
+    if (!place && cap < hdr + n + 3ull * nblk) return ctx_fail(c, NAF_GPU_ECAP, "zstd_compress capacity %zu too small (bound %llu)", cap, (unsigned long long)(hdr + n + 3ull * nblk));
     ZEncPlan *plan = arena_new<ZEncPlan>(c, nblk);
     u16 *codes = arena_new<u16>(c, (size_t)nblk * 256); u8 *trees = (u8 *)arena_alloc(c, (size_t)nblk * ZENC_TREE_SLOT);
     u64 *offs = arena_new<u64>(c, (size_t)nblk + 2);
@@ -838,11 +839,15 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
         L.mode = mode; L.plan1 = plan1; L.codes1 = codes1; L.trees1 = trees1; L.B = B;
     }
     int rc = scan_exclusive_u64(c, offs, nblk, offs + nblk + 1); if (rc) return rc;
+    u64 total = 0;
+    if (place) {
+        if ((rc = ctx_readback(c, &total, offs + nblk + 1, 8))) return rc;
+        if (!(d_dst = place->fn(place->ud, hdr + total))) return NAF_GPU_ECAP;
+    }
     if (hdr) LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, with_magic, frame_wlog);
     LAUNCH(c, "zenc_write", k_zenc_write, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, d_src, (u64)n, nblk, (const ZEncPlan *)plan, (const u16 *)codes, (const u8 *)trees,
            (const u64 *)offs, d_dst, hdr, L);
-    u64 total = 0;
-    rc = ctx_readback(c, &total, offs + nblk + 1, 8); if (rc) return rc;
+    if (!place && (rc = ctx_readback(c, &total, offs + nblk + 1, 8))) return rc;
     *out_len = hdr + total;
     return 0;
 }
