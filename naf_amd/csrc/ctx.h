@@ -111,4 +111,10 @@ int zenc_repeat_probe(naf_gpu_ctx *c, const u8 *d_src, size_t n, u32 *share_1024
 // place != nullptr: the frame's size is read back once it is planned and place->fn(place->ud, size) names where it goes (nullptr = give up,
 // the hook has set the context's error); d_dst / cap are not looked at.  Saves the copy of a frame whose position depends on its size.
 struct ZencPlace { u8 *(*fn)(void *ud, size_t frame_len); void *ud; };
+// zstd_encode in two halves: begin queues the planning of the blocks and returns without waiting; finish reads the size back, writes the
+// blocks and releases the job (also to be called after a failed begin that left a job).  What a caller queues in between runs beside the planning.
+struct ZencJob;
+int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int with_magic, int lz, int block_log_hint, int window_log, ZencJob **job);
+int zstd_encode_finish(naf_gpu_ctx *c, ZencJob *job, u8 *d_dst, size_t cap, size_t *out_len, const ZencPlace *place);
+void zstd_encode_drop(ZencJob *job);
 int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz = 0, int block_log_hint = 0, int window_log = 0, const ZencPlace *place = nullptr);   // window_log >= 10: cross-block matching inside that window (zstd_enc.hip)

@@ -1647,25 +1647,45 @@ static size_t naf_header_bytes(const naf_gpu_ennaf_opts *o, bool store_mask, boo
 // says once its size is known (zstd_encode): the tail part is coded first, into scratch, so that the hook hears the size of the whole.
 struct PlaceTail { const ZencPlace *outer; size_t tail_len; u8 *at; };
 static u8 *place_before_tail(void *ud, size_t len) { PlaceTail *t = (PlaceTail *)ud; return t->at = t->outer->fn(t->outer->ud, len + t->tail_len); }
+// the two halves of a placed stream (zstd_encode_begin / _finish): what the caller queues between them runs beside the planning
+struct StreamJob { ZencJob *main; const u8 *d_stream; u64 len; int level, flags; u32 tail; };
+static int encode_stream_begin(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level, int flags, int lz, int block_log, int window_log, u32 tail, StreamJob *J)
+{
+    J->main = nullptr; J->d_stream = d_stream; J->len = len; J->level = level; J->flags = flags; J->tail = (tail && len > tail) ? tail : 0;
+    int f1 = flags;
+    if (J->tail) f1 = ZENC_PART | ((!(flags & ZENC_PART) || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0);
+    int rc = zstd_encode_begin(c, d_stream, len - J->tail, level, f1, lz, block_log, window_log, &J->main);
+    if (rc) { zstd_encode_drop(J->main); J->main = nullptr; }
+    return rc;
+}
+static int encode_stream_finish(naf_gpu_ctx *c, StreamJob *J, size_t *clen, const ZencPlace *place)
+{
+    ZencJob *mj = J->main; J->main = nullptr;
+    if (!J->tail) return zstd_encode_finish(c, mj, nullptr, 0, clen, place);
+    const int f2 = ZENC_PART | ((!(J->flags & ZENC_PART) || (J->flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0);
+    size_t a = 0, b = 0;
+    const size_t tb = naf_gpu_zstd_compress_bound(J->tail);
+    u8 *tmp = (u8 *)arena_alloc(c, tb); if (!tmp) { zstd_encode_drop(mj); return NAF_GPU_ENOMEM; }
+    int rc = zstd_encode(c, J->d_stream + (J->len - J->tail), J->tail, J->level, tmp, tb, &b, f2, 0, 0, 0);
+    if (rc) { zstd_encode_drop(mj); return rc; }
+    PlaceTail T = { place, b, nullptr }; ZencPlace P = { place_before_tail, &T };
+    if ((rc = zstd_encode_finish(c, mj, nullptr, 0, &a, &P))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(T.at + a, tmp, b, hipMemcpyDeviceToDevice, c->stream));
+    *clen = a + b;
+    return 0;
+}
 static int encode_stream(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level, u8 *dst, size_t cap, size_t *clen, int flags, int lz, int block_log, int window_log, u32 tail, const ZencPlace *place = nullptr)
 {
-    if (!tail || len <= tail) return zstd_encode(c, d_stream, len, level, dst, cap, clen, flags, lz, block_log, window_log, place);
+    if (place) {
+        StreamJob J; int rc = encode_stream_begin(c, d_stream, len, level, flags, lz, block_log, window_log, tail, &J); if (rc) return rc;
+        return encode_stream_finish(c, &J, clen, place);
+    }
+    if (!tail || len <= tail) return zstd_encode(c, d_stream, len, level, dst, cap, clen, flags, lz, block_log, window_log);
     const bool part = (flags & ZENC_PART) != 0;
     const int f1 = ZENC_PART | ((!part || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0);
     const int f2 = ZENC_PART | ((!part || (flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0);
     size_t a = 0, b = 0;
-    int rc;
-    if (place) {
-        const size_t tb = naf_gpu_zstd_compress_bound(tail);
-        u8 *tmp = (u8 *)arena_alloc(c, tb); if (!tmp) return NAF_GPU_ENOMEM;
-        if ((rc = zstd_encode(c, d_stream + (len - tail), tail, level, tmp, tb, &b, f2, 0, 0, 0))) return rc;
-        PlaceTail T = { place, b, nullptr }; ZencPlace P = { place_before_tail, &T };
-        if ((rc = zstd_encode(c, d_stream, len - tail, level, nullptr, 0, &a, f1, lz, block_log, window_log, &P))) return rc;
-        HIP_TRY(c, hipMemcpyAsync(T.at + a, tmp, b, hipMemcpyDeviceToDevice, c->stream));
-        *clen = a + b;
-        return 0;
-    }
-    rc = zstd_encode(c, d_stream, len - tail, level, dst, cap, &a, f1, lz, block_log, window_log); if (rc) return rc;
+    int rc = zstd_encode(c, d_stream, len - tail, level, dst, cap, &a, f1, lz, block_log, window_log); if (rc) return rc;
     rc = zstd_encode(c, d_stream + (len - tail), tail, level, dst + a, cap - a, &b, f2, 0, 0, 0); if (rc) return rc;
     *clen = a + b;
     return 0;
@@ -1689,12 +1709,17 @@ static u8 *place_section(void *ud, size_t clen)
     return p->d_naf + p->pos + hl;
 }
 
-static int put_section(naf_gpu_ctx *c, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz = 0, int block_log = 0, int window_log = 0, u32 tail = 0)
+// `early`: the stream's planning was queued before (encode_stream_begin); otherwise both halves run here.  The launches go to c's
+// stream (c may be a side context), a failure's text lands in `report`.
+static int put_section(naf_gpu_ctx *c, naf_gpu_ctx *report, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz, int block_log, int window_log, u32 tail, StreamJob *early)
 {
     SecPlace sp = { c, d_naf, cap, pos, orig, 0, 0 }; ZencPlace P = { place_section, &sp };
     size_t clen = 0;
-    int rc = encode_stream(c, d_stream, stream_len, level, nullptr, 0, &clen, 0, lz, block_log, window_log, tail, &P);
-    if (rc) return sp.rc ? sp.rc : rc;
+    StreamJob J;
+    int rc = 0;
+    if (!early) { rc = encode_stream_begin(c, d_stream, stream_len, level, 0, lz, block_log, window_log, tail, &J); early = &J; }
+    if (!rc) rc = encode_stream_finish(c, early, &clen, &P);
+    if (rc) { if (report != c) ctx_fail(report, sp.rc ? sp.rc : rc, "%s", c->err); return sp.rc ? sp.rc : rc; }
     pos += sp.hl + clen;
     so.orig = orig; so.comp = clen;
     return 0;
@@ -1730,8 +1755,39 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     if (tl) { HIP_TRY(c, hipMemcpyAsync(d_naf + pos, o->title, tl, hipMemcpyHostToDevice, c->stream)); pos += tl; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     SecOut so[6]; memset(so, 0, sizeof so);
-    for (int i = 0; i < 6; i++)
-        if (X.present[i] && (rc = put_section(c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i]))) return rc;
+    // The sequence and quality streams are planned on this context's stream while a side context codes ids, names, lengths and mask
+    // (dozens of small launches and a few read-backs each) on its own; the sections still land in file order, each behind the one before.
+    naf_gpu_ctx *sc = c->side;
+    const char *eo = getenv("NAF_GPU_ENC_OVERLAP");
+    const bool overlap = sc && !(eo && !strcmp(eo, "0")) && ((X.present[4] && X.len[4] >= (16u << 20)) || (X.present[5] && X.len[5] >= (16u << 20)));
+    StreamJob big[6]; bool early[6] = { false, false, false, false, false, false };
+    if (overlap) {
+        arena_reset(sc);
+        HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(sc->stream, c->fork_ev, 0));
+        for (int i = 4; i < 6; i++)
+            if (X.present[i]) {
+                if ((rc = encode_stream_begin(c, X.ptr[i], X.len[i], o->level, 0, X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]))) { for (int k = 4; k < i; k++) if (early[k]) zstd_encode_drop(big[k].main); return rc; }
+                early[i] = true;
+            }
+    }
+    bool joined = !overlap;
+    auto join = [&]() -> int {                                     // everything behind this point is on c's stream again
+        if (joined) return 0;
+        joined = true;
+        if (hipEventRecord(c->split_ev[0], sc->stream) != hipSuccess || hipStreamWaitEvent(c->stream, c->split_ev[0], 0) != hipSuccess) return ctx_fail(c, NAF_GPU_EHIP, "ennaf: joining the side stream failed");
+        return 0;
+    };
+    for (int i = 0; i < 6 && !rc; i++) {
+        if (!X.present[i]) continue;
+        if (i >= 4 && (rc = join())) break;
+        naf_gpu_ctx *w = (overlap && i < 4) ? sc : c;
+        rc = put_section(w, c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], early[i] ? &big[i] : nullptr);
+        early[i] = false;
+    }
+    for (int k = 4; k < 6; k++) if (early[k]) zstd_encode_drop(big[k].main);
+    if (!rc) rc = join(); else if (overlap) hipStreamSynchronize(sc->stream);
+    if (rc) return rc;
     for (int i = 0; i < 6; i++) { R.section_orig[i] = so[i].orig; R.section_comp[i] = so[i].comp; }
     *naf_len = pos;
     if (rep) *rep = R;

@@ -78,6 +78,7 @@ extern "C" void naf_gpu_shutdown(naf_gpu_ctx *c)
         hipStreamSynchronize(sc->stream);
         for (auto &ch : sc->chunks) hipFree(ch.base);
         for (auto e : sc->ev_pool) hipEventDestroy(e);
+        if (sc->d_seqctab) hipFree(sc->d_seqctab);
         if (sc->h_stage) hipHostFree(sc->h_stage);
         if (sc->own_stream) hipStreamDestroy(sc->stream);
         delete sc;

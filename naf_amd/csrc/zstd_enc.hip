@@ -594,6 +594,7 @@ __device__ __forceinline__ void huf_encode_stream_staged(u8 *out, const u8 *src,
 // LZ-coded blocks (mode[b] != 0) take their literals from L.lits with the plan / codes / tree of those literals (plan1 ...)
 // and append the Sequences_Section made by k_lz_seqenc; all other blocks are coded from src as literal-only blocks.
 struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u16 *codes1; const u8 *trees1; LzBufs B; u32 not_last; };   // not_last: the frame continues behind these blocks (a shard's part of a frame)
+struct ZencJob { const u8 *src; size_t n; u32 nblk, frame_wlog; ZEncPlan *plan; u16 *codes; u8 *trees; u64 *offs; u64 hdr; int with_magic, empty; ZWriteLz L; };
 __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nblk, const ZEncPlan *plan, const u16 *codes_g, const u8 *trees,
                                                     const u64 *offs, u8 *dst, u64 frame_hdr, ZWriteLz L)
 {
@@ -749,14 +750,15 @@ extern "C" size_t naf_gpu_zstd_compress_bound(size_t n)
 // with_magic: 1 = whole frame with its magic number, 0 = whole frame without it (as stored in a .naf section),
 //   ZENC_PART | ZENC_PART_FIRST | ZENC_PART_LAST = a shard's part of a frame: blocks only, behind the 2-byte frame header when
 //   FIRST, ending the frame when LAST (an empty part that is not LAST is zero bytes; an empty LAST part is one empty Raw block).
-int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz, int block_log_hint, int window_log, const ZencPlace *place)
+int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int with_magic, int lz, int block_log_hint, int window_log, ZencJob **job)
 {
+    ZencJob *J = new ZencJob; *job = J;                          // released by zstd_encode_finish
+    memset(J, 0, sizeof *J);
+    J->src = d_src; J->n = n;
     const bool part = (with_magic & ZENC_PART) != 0, part_first = (with_magic & ZENC_PART_FIRST) != 0, part_last = (with_magic & ZENC_PART_LAST) != 0;
     if (part) with_magic = 0;
     if (part && n == 0 && !part_last) {
-        if (place && !(d_dst = place->fn(place->ud, part_first ? 2 : 0))) return NAF_GPU_ECAP;
-        if (part_first) { if (!place && cap < 2) return ctx_fail(c, NAF_GPU_ECAP, "zstd_compress capacity %zu too small", cap); LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, 0, (u32)(window_log >= 10 ? window_log : 19)); }
-        *out_len = part_first ? 2 : 0;
+        J->empty = 1; J->hdr = part_first ? 2 : 0; J->frame_wlog = (u32)(window_log >= 10 ? window_log : 19);
         return 0;
     }
     u32 block_log = 15;                                          // 32 KiB: 4 streams of 8 KiB; more streams = more decode parallelism
@@ -785,7 +787,6 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
     if (nblk64 > 0x7FFFFFFFull) return ctx_fail(c, NAF_GPU_EARG, "stream too large");
     u32 nblk = (u32)nblk64;
     u64 hdr = with_magic ? 6 : (part && !part_first) ? 0 : 2;
-    if (!place && cap < hdr + n + 3ull * nblk) return ctx_fail(c, NAF_GPU_ECAP, "zstd_compress capacity %zu too small (bound %llu)", cap, (unsigned long long)(hdr + n + 3ull * nblk));
     ZEncPlan *plan = arena_new<ZEncPlan>(c, nblk);
     u16 *codes = arena_new<u16>(c, (size_t)nblk * 256); u8 *trees = (u8 *)arena_alloc(c, (size_t)nblk * ZENC_TREE_SLOT);
     u64 *offs = arena_new<u64>(c, (size_t)nblk + 2);
@@ -799,7 +800,7 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
     if (cache) HIP_TRY(c, hipMemsetAsync(cache, 0, sizeof(ZTreeCache), c->stream));
     if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse);
     LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse);
-    ZWriteLz L; memset(&L, 0, sizeof L);
+    ZWriteLz &L = J->L;
     L.not_last = part && !part_last;
     if (use_lz && n >= 64) {
         if (!c->d_seqctab) {
@@ -839,17 +840,52 @@ int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst,
         L.mode = mode; L.plan1 = plan1; L.codes1 = codes1; L.trees1 = trees1; L.B = B;
     }
     int rc = scan_exclusive_u64(c, offs, nblk, offs + nblk + 1); if (rc) return rc;
+    J->nblk = nblk; J->plan = plan; J->codes = codes; J->trees = trees; J->offs = offs; J->hdr = hdr; J->with_magic = with_magic; J->frame_wlog = frame_wlog;
+    return 0;
+}
+
+// The second half: the frame's size is read back (before the write when a hook places the frame, after it otherwise) and the blocks
+// are written.
+static int zenc_finish(naf_gpu_ctx *c, ZencJob *J, u8 *d_dst, size_t cap, size_t *out_len, const ZencPlace *place);
+void zstd_encode_drop(ZencJob *J) { delete J; }
+int zstd_encode_finish(naf_gpu_ctx *c, ZencJob *J, u8 *d_dst, size_t cap, size_t *out_len, const ZencPlace *place)
+{
+    if (!J) return NAF_GPU_EARG;
+    int rc = zenc_finish(c, J, d_dst, cap, out_len, place);
+    delete J;
+    return rc;
+}
+static int zenc_finish(naf_gpu_ctx *c, ZencJob *J, u8 *d_dst, size_t cap, size_t *out_len, const ZencPlace *place)
+{
+    const u64 hdr = J->hdr; const u32 nblk = J->nblk;
+    if (J->empty) {
+        if (place && !(d_dst = place->fn(place->ud, hdr))) return NAF_GPU_ECAP;
+        if (!place && cap < hdr) return ctx_fail(c, NAF_GPU_ECAP, "zstd_compress capacity %zu too small", cap);
+        if (hdr) LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, 0, J->frame_wlog);
+        *out_len = hdr;
+        return 0;
+    }
+    if (!place && cap < hdr + J->n + 3ull * nblk) return ctx_fail(c, NAF_GPU_ECAP, "zstd_compress capacity %zu too small (bound %llu)", cap, (unsigned long long)(hdr + J->n + 3ull * nblk));
+    int rc;
     u64 total = 0;
     if (place) {
-        if ((rc = ctx_readback(c, &total, offs + nblk + 1, 8))) return rc;
+        if ((rc = ctx_readback(c, &total, J->offs + nblk + 1, 8))) return rc;
         if (!(d_dst = place->fn(place->ud, hdr + total))) return NAF_GPU_ECAP;
     }
-    if (hdr) LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, with_magic, frame_wlog);
-    LAUNCH(c, "zenc_write", k_zenc_write, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, d_src, (u64)n, nblk, (const ZEncPlan *)plan, (const u16 *)codes, (const u8 *)trees,
-           (const u64 *)offs, d_dst, hdr, L);
-    if (!place && (rc = ctx_readback(c, &total, offs + nblk + 1, 8))) return rc;
+    if (hdr) LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, J->with_magic, J->frame_wlog);
+    LAUNCH(c, "zenc_write", k_zenc_write, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, J->src, (u64)J->n, nblk, (const ZEncPlan *)J->plan, (const u16 *)J->codes, (const u8 *)J->trees,
+           (const u64 *)J->offs, d_dst, hdr, J->L);
+    if (!place && (rc = ctx_readback(c, &total, J->offs + nblk + 1, 8))) return rc;
     *out_len = hdr + total;
     return 0;
+}
+
+int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz, int block_log_hint, int window_log, const ZencPlace *place)
+{
+    ZencJob *J = nullptr;
+    int rc = zstd_encode_begin(c, d_src, n, level, with_magic, lz, block_log_hint, window_log, &J);
+    if (rc) { delete J; return rc; }
+    return zstd_encode_finish(c, J, d_dst, cap, out_len, place);
 }
 
 extern "C" int naf_gpu_zstd_compress(naf_gpu_ctx *c, const void *d_src, size_t n, int level, void *d_dst, size_t cap, size_t *out_len)
