@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <vector>
+#include <functional>
 #include <string>
 
 struct ArenaChunk { u8 *base; size_t cap, used; };
@@ -53,7 +54,13 @@ struct naf_gpu_ctx {
     struct ZFlat *zflat = nullptr;          // set by unnaf when its emit can read a flat frame in place (above)
     void *io_pool = nullptr;                // io.hip: pinned staging lanes of naf_gpu_read_file / naf_gpu_write_file
     void *shard_state = nullptr;            // enc.hip: what naf_gpu_ennaf_shard_begin leaves for naf_gpu_ennaf_shard_finish
+    struct HostWorker *worker = nullptr;    // naf_gpu.hip: the host thread that drives this (side) context, kept between calls
 };
+
+// A side context's host thread: started on first use and parked between jobs (creating a thread and its HIP state per call cost
+// more than the chains it ran).  One job at a time; ctx_worker_join returns once the job has.
+void ctx_worker_start(naf_gpu_ctx *x, std::function<void()> job);
+void ctx_worker_join(naf_gpu_ctx *x);
 
 int  ctx_fail(naf_gpu_ctx *c, int code, const char *fmt, ...);
 #define HIP_TRY(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return ctx_fail((c), NAF_GPU_EHIP, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)

@@ -1302,15 +1302,14 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
         // lengths follow the names over there, so that the two chains (mask | ids, names, lengths) are about as long as each other.
         const bool aux_run = aux && want_names && (has_ids || has_names);
         int rc_aux = 0, rc_len = 0;
-        std::thread th;
         const bool len_on_aux = aux_run && early_has_work;
         int rc_small = 0;
         if (aux_run && !len_on_aux) rc_small = small3(c);                    // this context has nothing else to do meanwhile
-        if (aux_run) th = std::thread([&] { hipSetDevice(c->device); if (len_on_aux) rc_small = small3(aux); rc_aux = rc_small ? rc_small : ids_names(aux); if (len_on_aux && !rc_small) rc_len = lengths(aux); });     // no return until it is joined
+        if (aux_run) ctx_worker_start(aux, [&] { if (len_on_aux) rc_small = small3(aux); rc_aux = rc_small ? rc_small : ids_names(aux); if (len_on_aux && !rc_small) rc_len = lengths(aux); });     // no return until it is joined
         early();                                                                                         // work that needs none of this (the mask stream)
         if (!aux_run) rc_small = small3(c);
         if (!len_on_aux) rc_len = rc_small ? rc_small : lengths(c);
-        if (aux_run) { th.join(); hipStreamSynchronize(aux->stream); }
+        if (aux_run) { ctx_worker_join(aux); hipStreamSynchronize(aux->stream); }
         if (rc_len) { if (len_on_aux) memcpy(c->err, aux->err, sizeof c->err); return rc_len; }           // the order a sequential run reports in: lengths, ids, names
         if (!aux_run) rc_aux = ids_names(c);
         else if (rc_aux) memcpy(c->err, aux->err, sizeof c->err);
@@ -1388,9 +1387,9 @@ static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gp
         P.toggles = tg; P.n_toggles = ntog;
         return 0;
     };
-    int rc_mask = 0; std::thread thm;
+    int rc_mask = 0;
     const bool mask_started = P.masking && aux_mask;
-    if (mask_started) thm = std::thread([&] { hipSetDevice(c->device); rc_mask = mask_part(aux_mask); });      // joined below: no return before
+    if (mask_started) ctx_worker_start(aux_mask, [&] { rc_mask = mask_part(aux_mask); });      // joined below: no return before
     // Without a context of its own the mask goes FIRST on this one, right after the ids / names thread has been started: this
     // context would otherwise idle while it waits for that thread, and the mask decode (a few long Huffman streams) is pure latency.
     // Errors keep the order of a sequential run: lengths, ids, names, then mask.
@@ -1399,7 +1398,7 @@ static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gp
         if (P.masking && !mask_started && P.mode != EM_SEQ && aux) { mask_early = true; rc_mask = mask_part(c); if (rc_mask) memcpy(mask_err, c->err, sizeof c->err); }
     };
     int rc = unnaf_sections_main(c, d_naf, pl, aux, early, P.masking && !mask_started && P.mode != EM_SEQ && aux != nullptr);
-    if (mask_started) { thm.join(); hipStreamSynchronize(aux_mask->stream); }
+    if (mask_started) { ctx_worker_join(aux_mask); hipStreamSynchronize(aux_mask->stream); }
     if (rc) return rc;                                                                                     // the order a sequential run reports in
     if (mask_started && rc_mask) { memcpy(c->err, aux_mask->err, sizeof c->err); return rc_mask; }
     if (mask_early) { if (rc_mask) { memcpy(c->err, mask_err, sizeof c->err); return rc_mask; } }
@@ -1480,9 +1479,8 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         if (c->side3) { arena_reset(c->side3); HIP_TRY(c, hipStreamWaitEvent(c->side3->stream, c->fork_ev, 0)); }
         if (c->side4) { arena_reset(c->side4); HIP_TRY(c, hipStreamWaitEvent(c->side4->stream, c->fork_ev, 0)); }
         // no early return between here and the joins
-        std::thread th([&] { hipSetDevice(c->device); rc_side = unnaf_sections(c->side, d_naf, pl, c->side3, nullptr); });   // the mask stays on this context: a thread of its own measured slower, with and without the split decode
-        std::thread thq;
-        if (qpar) thq = std::thread([&] { hipSetDevice(c->device); rc_q = payload_qual(c->side2); });
+        ctx_worker_start(c->side, [&] { rc_side = unnaf_sections(c->side, d_naf, pl, c->side3, nullptr); });   // the mask stays on this context: a thread of its own measured slower, with and without the split decode
+        if (qpar) ctx_worker_start(c->side2, [&] { rc_q = payload_qual(c->side2); });
         // decode -> emit pipeline (ZSplit): the quality context is free when there is no quality stream
         const char *nsp = getenv("NAF_GPU_SPLIT");
         const int nparts = nsp ? atoi(nsp) : 4;
@@ -1495,8 +1493,8 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         rc = payload_seq();
         c->zsplit = nullptr; c->zflat = nullptr;
         if (!rc && pl.need_qual && !qpar) rc = payload_qual(c);
-        th.join();
-        if (qpar) thq.join();
+        ctx_worker_join(c->side);
+        if (qpar) ctx_worker_join(c->side2);
         if (rc_side) { memcpy(c->err, c->side->err, sizeof c->err); return rc_side; }   // the order a sequential run reports errors in
         if (rc) return rc;
         if (rc_q) { memcpy(c->err, c->side2->err, sizeof c->err); return rc_q; }

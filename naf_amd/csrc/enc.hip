@@ -1526,14 +1526,16 @@ struct EnnafStreams { const u8 *ptr[6]; u64 len[6], orig[6]; int lz[6], block_lo
                       u32 tail[6]; };   // tail: bytes at the end of the stream that go into a Raw block of their own (encode_stream)
 
 // E5-E7: lengths, 4-bit pack, mask units -> the six uncompressed streams.
-static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, EnnafStreams &X)
+// part: 1 = ids, names, sequence and quality (nothing to wait for), 2 = lengths and mask (a few read-backs), 3 = all of them.  The two
+// parts may run on different contexts (naf_gpu_ennaf: part 2 on a side stream beside the planning of the sequence frame).
+static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, EnnafStreams &X, int part = 3)
 {
-    memset(&X, 0, sizeof X);
+    if (part & 1) memset(&X, 0, sizeof X);
     int rc; const u64 T = S.T, N = S.N;
     u32 *s_len = nullptr; u8 *s_seq = nullptr, *s_mask = nullptr;
     u64 n_lenb = 0, n_seqb = 0, n_mask = 0; int mask_block_log = 15; u32 seq_tail = 0;
     if (S.format != 0) {
-        if (N) {
+        if (N && (part & 2)) {
             u64 *lu = arena_new<u64>(c, N + 2); if (!lu) return NAF_GPU_ENOMEM;
             const u64 total = T + K.tail_extra;                                                    // where the last record of a FASTA part ends
             LAUNCH(c, "ennaf_len_count", k_len_unit_count, cdiv(N, 256), 256, 0, (const u64 *)S.rec_begin, (const u64 *)S.rec_end, N, total, lu, S.all_ends);
@@ -1547,7 +1549,8 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
         // neighbour's last byte moves them down a nibble, and an odd window borrows its last high nibble (ennaf.c:525-529: 0 at the end)
         const u64 mt = (T + MBB_TILE - 1) / MBB_TILE;
         u64 *tc = S.tc;
-        if (S.fourbit) {
+        if (!(part & 1)) { }
+        else if (S.fourbit) {
             const u64 Tp = T > K.skip_first ? T - K.skip_first : 0;                                // bases of the pack window
             n_seqb = (Tp + 1) / 2;
             if (K.skip_first && n_seqb) {
@@ -1566,7 +1569,7 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
             s_seq = S.bases; n_seqb = T;
         }
         // mask (only ever stored next to a 4-bit sequence stream, ennaf.c:445); a shard has counted its boundaries in the census already
-        if (S.store_mask && T) {
+        if (S.store_mask && T && (part & 2)) {
             if (!S.census) {
                 tc = arena_new<u64>(c, mt + 2); if (!tc) return NAF_GPU_ENOMEM;
                 LAUNCH(c, "ennaf_mask_count", k_maskb_count, mt, 256, 0, (const u64 *)S.casebits, T, tc, 0);
@@ -1586,19 +1589,24 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
             LAUNCH(c, "ennaf_mask_units", k_mask_units_write, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, (const u64 *)ru, s_mask, K.run_ext, K.skip_run0);
             // Block size of the mask stream.  Real soft-masking (runs of a few hundred bases) gives a few MB of high-entropy units, i.e. a
             // few hundred blocks whose Huffman streams the decoder walks serially: 8 KiB blocks (2 KiB streams) cut that latency to a
-            // quarter.  Very long runs give strings of 255s (constant blocks, nothing to walk): 32 KiB blocks keep the block count down.
-            mask_block_log = nu / (nb + 1) > 1000 ? 15 : 13;
+            // quarter.  Very long runs give strings of 255s (constant blocks) and one last block with the remainder in it -- whose four
+            // streams are one lane's work each on either side: small blocks there too.
+            mask_block_log = 13;
             n_mask = nu;
         }
     }
     // ids, names and lengths are text-like / repetitive and small: always through the LZ stage (as reference level 1 does);
     // mask, sequence and quality get it from level 2 up
-    X.ptr[0] = S.s_ids; X.len[0] = X.orig[0] = S.n_ids; X.lz[0] = 1; X.present[0] = true;
-    X.ptr[1] = S.s_cmt; X.len[1] = X.orig[1] = S.n_cmt; X.lz[1] = 1; X.present[1] = true;
-    X.ptr[2] = (const u8 *)s_len; X.len[2] = X.orig[2] = n_lenb; X.lz[2] = 1; X.present[2] = true;
-    X.ptr[3] = s_mask; X.len[3] = X.orig[3] = n_mask; X.block_log[3] = mask_block_log; X.present[3] = S.store_mask;
-    X.ptr[4] = s_seq; X.len[4] = n_seqb; X.orig[4] = T; X.present[4] = true; X.tail[4] = seq_tail;   // ennaf.c:582: number of bases
-    X.ptr[5] = S.s_qual; X.len[5] = X.orig[5] = S.n_qual; X.present[5] = S.store_qual;
+    if (part & 1) {
+        X.ptr[0] = S.s_ids; X.len[0] = X.orig[0] = S.n_ids; X.lz[0] = 1; X.present[0] = true;
+        X.ptr[1] = S.s_cmt; X.len[1] = X.orig[1] = S.n_cmt; X.lz[1] = 1; X.present[1] = true;
+        X.ptr[4] = s_seq; X.len[4] = n_seqb; X.orig[4] = T; X.present[4] = true; X.tail[4] = seq_tail;   // ennaf.c:582: number of bases
+        X.ptr[5] = S.s_qual; X.len[5] = X.orig[5] = S.n_qual; X.present[5] = S.store_qual;
+    }
+    if (part & 2) {
+        X.ptr[2] = (const u8 *)s_len; X.len[2] = X.orig[2] = n_lenb; X.lz[2] = 1; X.present[2] = true;
+        X.ptr[3] = s_mask; X.len[3] = X.orig[3] = n_mask; X.block_log[3] = mask_block_log; X.present[3] = S.store_mask;
+    }
     return 0;
 }
 
@@ -1694,7 +1702,7 @@ static int encode_stream(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level,
 struct SecOut { u64 orig, comp; };
 
 // a section = VLE(original size) VLE(compressed size) frame (ennaf.c:538-589): the frame is written behind its header at once
-struct SmallBytes { u8 b[24]; u32 n; };
+struct SmallBytes { u8 b[60]; u32 n; };
 __global__ void k_put_bytes(u8 *dst, SmallBytes s) { if (threadIdx.x < s.n) dst[threadIdx.x] = s.b[threadIdx.x]; }
 struct SecPlace { naf_gpu_ctx *c; u8 *d_naf; size_t cap, pos; u64 orig; size_t hl; int rc; };
 static u8 *place_section(void *ud, size_t clen)
@@ -1740,26 +1748,22 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     if ((rc = ennaf_split(c, d_text, n, o, format, p0, true, S))) return rc;
     if (S.err_kind) return split_error_text(c, o->seq_type, S.err_kind, S.err_char, S.err_rec, S.err_a, S.err_b, 0);
     EnnafCarry K; memset(&K, 0, sizeof K);
+    // The sequence and quality streams are planned on this context's stream while a side context makes the length and mask units and
+    // codes ids, names, lengths and mask (dozens of small launches and a dozen read-backs) on its own; the sections still land in
+    // file order, each behind the one before.
+    naf_gpu_ctx *sc = c->side;
+    const char *eo = getenv("NAF_GPU_ENC_OVERLAP");
+    const bool overlap = sc && !(eo && !strcmp(eo, "0")) && (S.T >= (32u << 20) || S.n_qual >= (16u << 20));
     EnnafStreams X;
-    if ((rc = ennaf_streams(c, S, K, X))) return rc;
+    if ((rc = ennaf_streams(c, S, K, X, overlap ? 1 : 3))) return rc;
     if ((rc = ennaf_windows(c, X, o))) return rc;
-    for (int i = 0; i < 257; i++) { R.unexpected_id[i] = S.unexpected[0][i]; R.unexpected_comment[i] = S.unexpected[1][i]; R.unexpected_seq[i] = S.unexpected[2][i]; R.unexpected_qual[i] = S.unexpected[3][i]; }
-    R.n_sequences = S.N; R.n_bases = S.T; R.longest_line = S.longest;
-
     // container (ennaf.c:538-589)
     u8 hd[64]; size_t hl = naf_header_bytes(o, S.store_mask, S.store_qual, S.longest, S.N, hd);
     size_t tl = o->title ? strlen(o->title) : 0;
     size_t pos = 0;
     if (hl + tl > cap) return ctx_fail(c, NAF_GPU_ECAP, "ennaf output capacity %zu too small", cap);
-    HIP_TRY(c, hipMemcpyAsync(d_naf, hd, hl, hipMemcpyHostToDevice, c->stream)); pos += hl;
-    if (tl) { HIP_TRY(c, hipMemcpyAsync(d_naf + pos, o->title, tl, hipMemcpyHostToDevice, c->stream)); pos += tl; }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    SecOut so[6]; memset(so, 0, sizeof so);
-    // The sequence and quality streams are planned on this context's stream while a side context codes ids, names, lengths and mask
-    // (dozens of small launches and a few read-backs each) on its own; the sections still land in file order, each behind the one before.
-    naf_gpu_ctx *sc = c->side;
-    const char *eo = getenv("NAF_GPU_ENC_OVERLAP");
-    const bool overlap = sc && !(eo && !strcmp(eo, "0")) && ((X.present[4] && X.len[4] >= (16u << 20)) || (X.present[5] && X.len[5] >= (16u << 20)));
+    { SmallBytes hb; memset(&hb, 0, sizeof hb); memcpy(hb.b, hd, hl); hb.n = (u32)hl; LAUNCH(c, "ennaf_header", k_put_bytes, 1, 64, 0, d_naf, hb); pos += hl; }
+    if (tl) { HIP_TRY(c, hipMemcpyAsync(d_naf + pos, o->title, tl, hipMemcpyHostToDevice, c->stream)); pos += tl; HIP_TRY(c, hipStreamSynchronize(c->stream)); }
     StreamJob big[6]; bool early[6] = { false, false, false, false, false, false };
     if (overlap) {
         arena_reset(sc);
@@ -1770,7 +1774,16 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
                 if ((rc = encode_stream_begin(c, X.ptr[i], X.len[i], o->level, 0, X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]))) { for (int k = 4; k < i; k++) if (early[k]) zstd_encode_drop(big[k].main); return rc; }
                 early[i] = true;
             }
+        if ((rc = ennaf_streams(sc, S, K, X, 2))) {
+            for (int k = 4; k < 6; k++) if (early[k]) zstd_encode_drop(big[k].main);
+            hipStreamSynchronize(sc->stream);
+            return ctx_fail(c, rc, "%s", sc->err);
+        }
     }
+    for (int i = 0; i < 257; i++) { R.unexpected_id[i] = S.unexpected[0][i]; R.unexpected_comment[i] = S.unexpected[1][i]; R.unexpected_seq[i] = S.unexpected[2][i]; R.unexpected_qual[i] = S.unexpected[3][i]; }
+    R.n_sequences = S.N; R.n_bases = S.T; R.longest_line = S.longest;
+
+    SecOut so[6]; memset(so, 0, sizeof so);
     bool joined = !overlap;
     auto join = [&]() -> int {                                     // everything behind this point is on c's stream again
         if (joined) return 0;

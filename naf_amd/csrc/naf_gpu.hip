@@ -1,5 +1,8 @@
 // naf_gpu.hip -- context, scratch arena, error reporting, timing, memory helpers of libnaf_gpu.
 #include "ctx.h"
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <string.h>
 #include <map>
 
@@ -68,6 +71,43 @@ extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
     return NAF_GPU_OK;
 }
 
+struct HostWorker { std::thread th; std::mutex m; std::condition_variable cv; std::function<void()> job; int state = 0; /* 0 idle, 1 posted, 2 running */ bool quit = false; };
+static void worker_main(HostWorker *w, int device)
+{
+    hipSetDevice(device);
+    std::unique_lock<std::mutex> lk(w->m);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->state == 1 || w->quit; });
+        if (w->quit) return;
+        std::function<void()> f = std::move(w->job);
+        w->state = 2;
+        lk.unlock(); f(); lk.lock();
+        w->state = 0;
+        w->cv.notify_all();
+    }
+}
+void ctx_worker_start(naf_gpu_ctx *x, std::function<void()> job)
+{
+    if (!x->worker) { x->worker = new HostWorker; x->worker->th = std::thread(worker_main, x->worker, x->device); }
+    HostWorker *w = x->worker;
+    { std::unique_lock<std::mutex> lk(w->m); w->cv.wait(lk, [&] { return w->state == 0; }); w->job = std::move(job); w->state = 1; }
+    w->cv.notify_all();
+}
+void ctx_worker_join(naf_gpu_ctx *x)
+{
+    HostWorker *w = x->worker; if (!w) return;
+    std::unique_lock<std::mutex> lk(w->m);
+    w->cv.wait(lk, [&] { return w->state == 0; });
+}
+static void ctx_worker_stop(naf_gpu_ctx *x)
+{
+    HostWorker *w = x->worker; if (!w) return;
+    { std::unique_lock<std::mutex> lk(w->m); w->cv.wait(lk, [&] { return w->state == 0; }); w->quit = true; }
+    w->cv.notify_all();
+    w->th.join();
+    delete w; x->worker = nullptr;
+}
+
 extern "C" void naf_gpu_shutdown(naf_gpu_ctx *c)
 {
     if (!c) return;
@@ -75,6 +115,7 @@ extern "C" void naf_gpu_shutdown(naf_gpu_ctx *c)
     hipStreamSynchronize(c->stream);
     for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3, c->side4 }) {
         if (!sc) continue;
+        ctx_worker_stop(sc);
         hipStreamSynchronize(sc->stream);
         for (auto &ch : sc->chunks) hipFree(ch.base);
         for (auto e : sc->ev_pool) hipEventDestroy(e);
@@ -170,8 +211,19 @@ extern "C" int naf_gpu_reserve(naf_gpu_ctx *c, size_t bytes)
     return 0;
 }
 
+// a few bytes straight into the pinned staging buffer (mapped into the device's address space), by a kernel of the stream itself
+__global__ void k_small_to_host(u8 *h, const u8 *d, u32 n) { if (threadIdx.x < n) h[threadIdx.x] = d[threadIdx.x]; __threadfence_system(); }
+
 int ctx_readback(naf_gpu_ctx *c, void *h_dst, const void *d_src, size_t bytes)
 {
+    static const bool by_kernel = getenv("NAF_GPU_READBACK_COPY") == nullptr;
+    if (by_kernel && bytes && bytes <= 256) {
+        hipLaunchKernelGGL(k_small_to_host, dim3(1), dim3(256), 0, c->stream, (u8 *)c->h_stage, (const u8 *)d_src, (u32)bytes);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        memcpy(h_dst, c->h_stage, bytes);
+        return 0;
+    }
     if (bytes > c->h_stage_cap) {
         HIP_TRY(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -48,6 +48,10 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
     const u32 cpy = threadIdx.x & (ZENC_HCOPIES - 1), rot = 8 * cpy;
     u32 *my = hist + cpy * 1024;
     const u64 rot8 = 0x0101010101010101ull * rot;                 // rot < 128: added to every byte at once, carries cut at the byte tops
+#ifdef ZPLAN_NOHIST
+    if (threadIdx.x < 16) for (u32 q = 0; q < 4; q++) hist[q * 256 + threadIdx.x * 17] = bn / 64;
+    if (0)
+#endif
     for (u32 i = threadIdx.x * 8; i < bn; i += 2048) {
         if (i + 8 <= bn) {
             u64 w = ld64(s + i);
