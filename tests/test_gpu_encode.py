@@ -604,3 +604,35 @@ def test_pure_tiles_and_their_edges(gpu, oracle):
         for no_mask in (False, True):
             check_ennaf(gpu, oracle, text, no_mask=no_mask)
     check_ennaf(gpu, oracle, texts[3].replace(b"T", b"U").replace(b"t", b"u"), seq_type=1)
+
+
+def test_sections_coded_beside_each_other_give_the_same_archive(gpu, oracle, monkeypatch):
+    """From 32 M bases (or 16 MiB of qualities) up, ids / names / lengths / mask are coded on a side stream while the sequence and
+    quality frames are planned, and every frame is written at its final place (naf_gpu_ennaf, zstd_encode_begin / _finish).  The
+    archive must be the one the in-order path (NAF_GPU_ENC_OVERLAP=0) writes, byte for byte: FASTA with soft-masked runs and an odd
+    base count (the padding byte's block of its own), FASTQ with mixed case, level 1 and a matching level."""
+    import torch
+    from naf_amd import synth
+    rng = np.random.default_rng(77)
+    fa = synth.fasta_acgt_device(70_000_001, n_records=9, width=61, seed=12)
+    lines = fa.view(-1)
+    m = torch.from_numpy(rng.integers(0, lines.numel() - 5000, 4000)).to(lines.device)
+    for k in range(0, 3000, 7):                                   # lower-case stretches
+        seg = lines[m + k]
+        lines[m + k] = torch.where((seg >= 65) & (seg <= 84), seg + 32, seg)
+    fq = gpu.to_device(synth.fastq_reads(150_000, 150, seed=6) + synth.fastq_reads(20_000, 97, seed=8, var_len=True))
+    for text, levels in ((fa, (1, 3)), (fq, (1,))):
+        for level in levels:
+            monkeypatch.setenv("NAF_GPU_ENC_OVERLAP", "0")
+            a, ra = gpu.ennaf(text, level=level)
+            a = a.clone()
+            monkeypatch.setenv("NAF_GPU_ENC_OVERLAP", "1")
+            b, rb = gpu.ennaf(text, level=level)
+            assert a.numel() == b.numel() and torch.equal(a, b), level
+            assert list(ra.section_comp) == list(rb.section_comp)
+            if text is fa:
+                assert torch.equal(gpu.unnaf(b, 0), text)
+    back = host(gpu.unnaf(b, 1))                                  # reads come back in upper case (SURVEY R3)
+    assert back.upper() == host(fq).upper() and back != host(fq)
+    if oracle.have_ref():
+        assert oracle.ref_unnaf(host(b), ("--fastq",)) == back
