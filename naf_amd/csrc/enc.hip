@@ -1616,7 +1616,9 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
 // on libzstd's long-distance matcher for that stream only (compressor.c:12-16).
 // Level 1 without --long looks at the sequence stream first (zenc_repeat_probe): when a thirty-second of the probed anchors has an
 // earlier copy nearby, the stream is matched inside the level's own window of 2^19 -- as the reference's level 1 would.
-static int ennaf_windows(naf_gpu_ctx *c, EnnafStreams &X, const naf_gpu_ennaf_opts *o)
+// defer != nullptr: a needed look at the sequence stream is left to the caller (*defer = true), who runs ennaf_probe_verdict later
+static void ennaf_probe_verdict(EnnafStreams &X, u32 share) { if (share >= 32) { X.window_log[4] = 19; X.lz[4] = 1; } }
+static int ennaf_windows(naf_gpu_ctx *c, EnnafStreams &X, const naf_gpu_ennaf_opts *o, bool *defer = nullptr)
 {
     const int wl = zenc_level_window(o->level);
     for (int i = 0; i < 6; i++) X.window_log[i] = wl;
@@ -1625,13 +1627,14 @@ static int ennaf_windows(naf_gpu_ctx *c, EnnafStreams &X, const naf_gpu_ennaf_op
         const char *pe = getenv("NAF_GPU_PROBE");                 // "0": never look, "1": always match
         u32 share = 0;
         if (pe && pe[0] == '1') share = 1024;
+        else if (!(pe && pe[0] == '0') && defer) { *defer = true; return 0; }
         else if (!(pe && pe[0] == '0')) {
             struct timespec t0, t1, t2; const bool dbg = getenv("NAF_GPU_DEBUG_PROBE") != nullptr;
             if (dbg) { clock_gettime(CLOCK_MONOTONIC, &t0); hipStreamSynchronize(c->stream); clock_gettime(CLOCK_MONOTONIC, &t1); }
             int rc = zenc_repeat_probe(c, X.ptr[4], X.len[4], &share); if (rc) return rc;
             if (dbg) { clock_gettime(CLOCK_MONOTONIC, &t2); fprintf(stderr, "[probe] drain %.3f ms, probe %.3f ms, share %u/1024\n", (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) * 1e-6, share); }
         }
-        if (share >= 32) { X.window_log[4] = 19; X.lz[4] = 1; }
+        ennaf_probe_verdict(X, share);
     }
     return 0;
 }
@@ -1756,7 +1759,8 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     const bool overlap = sc && !(eo && !strcmp(eo, "0")) && (S.T >= (32u << 20) || S.n_qual >= (16u << 20));
     EnnafStreams X;
     if ((rc = ennaf_streams(c, S, K, X, overlap ? 1 : 3))) return rc;
-    if ((rc = ennaf_windows(c, X, o))) return rc;
+    bool probe_later = false;                                     // level 1: the look at the sequence stream runs beside its planning
+    if ((rc = ennaf_windows(c, X, o, overlap ? &probe_later : nullptr))) return rc;
     // container (ennaf.c:538-589)
     u8 hd[64]; size_t hl = naf_header_bytes(o, S.store_mask, S.store_qual, S.longest, S.N, hd);
     size_t tl = o->title ? strlen(o->title) : 0;
@@ -1774,6 +1778,18 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
                 if ((rc = encode_stream_begin(c, X.ptr[i], X.len[i], o->level, 0, X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]))) { for (int k = 4; k < i; k++) if (early[k]) zstd_encode_drop(big[k].main); return rc; }
                 early[i] = true;
             }
+        if (probe_later) {
+            // the frame is planned as if there were nothing to match (what the look says of nearly every input); a repeat-rich
+            // stream drops that plan and starts over with the match finder
+            u32 share = 0;
+            if ((rc = zenc_repeat_probe(sc, X.ptr[4], X.len[4], &share))) { for (int k = 4; k < 6; k++) if (early[k]) zstd_encode_drop(big[k].main); hipStreamSynchronize(sc->stream); return ctx_fail(c, rc, "%s", sc->err); }
+            ennaf_probe_verdict(X, share);
+            if (X.lz[4]) {
+                zstd_encode_drop(big[4].main); early[4] = false;
+                if ((rc = encode_stream_begin(c, X.ptr[4], X.len[4], o->level, 0, X.lz[4], X.block_log[4], X.window_log[4], X.tail[4], &big[4]))) { if (early[5]) zstd_encode_drop(big[5].main); hipStreamSynchronize(sc->stream); return rc; }
+                early[4] = true;
+            }
+        }
         if ((rc = ennaf_streams(sc, S, K, X, 2))) {
             for (int k = 4; k < 6; k++) if (early[k]) zstd_encode_drop(big[k].main);
             hipStreamSynchronize(sc->stream);
