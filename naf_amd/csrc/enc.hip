@@ -152,25 +152,45 @@ __global__ __launch_bounds__(256) void k_enc_last(EncP P, i64 *tile_eol, i64 *ti
 
 // FASTA wants only the LAST EOL / space of each tile.  In line-wrapped text both sit in the tile's last kilobyte: one wavefront
 // per tile looks there first and walks back through the other three quarters only while something is still missing.
+// Sixteen lanes look at the last 256 bytes of a tile (four tiles per wave): a FASTA line of up to 255 columns ends in there, and a
+// line end is a space-class byte too.  Only a tile whose window holds neither walks its quarters from the back with the whole wave
+// (a long header line, an unwrapped sequence) -- the first look used to be the whole last KiB of every tile, a quarter of the text.
+#define LAST_TPW 4
 __global__ __launch_bounds__(256) void k_enc_last_fa(EncP P, i64 *tile_eol, i64 *tile_sp, u64 tiles)
 {
-    u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    u64 t = (u64)blockIdx.x * 4 + wave;
-    if (t >= tiles) return;
-    u64 tb = t * ET_TILE; u32 found = 0;
-    for (int q = 3; q >= 0; q--) {
-        Piece pc = load_piece(P, tb + (u32)q * 1024 + lane * ET_BYTES);
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, l = lane & 15;
+    const u64 t0 = ((u64)blockIdx.x * 4 + wave) * LAST_TPW;
+    if (t0 >= tiles) return;
+    {
+        const u64 t = t0 + row, tb = t * ET_TILE;
+        Piece pc; pc.w0 = pc.w1 = 0; pc.cnt = 0;
+        if (t < tiles) pc = load_piece(P, tb + (ET_TILE - 256) + l * ET_BYTES);
         PMask pm = piece_masks(pc);
-        u32 t16 = (u32)q * 1024 + lane * ET_BYTES + 1;
+        const u32 t16 = (ET_TILE - 256) + l * ET_BYTES + 1;
         u32 v = (pm.eol ? t16 + (31 - __clz((int)pm.eol)) : 0u) | ((pm.sp ? t16 + (31 - __clz((int)pm.sp)) : 0u) << 16);
-        v = (u32)__builtin_amdgcn_readlane((int)wave_scan_inclusive<u32, OpPkMaxU16>(v), 63);
-        if (!(found & 0xFFFF)) found |= v & 0xFFFF;
-        if (!(found >> 16)) found |= v & 0xFFFF0000u;
-        if ((found & 0xFFFF) && (found >> 16)) break;
-    }
-    if (lane == 0) {
-        tile_eol[t] = (found & 0xFFFF) ? (i64)(tb + (found & 0xFFFF) - 1) : -1;
-        tile_sp[t] = (found >> 16) ? (i64)(tb + (found >> 16) - 1) : -1;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) v = OpPkMaxU16::f<u32>(v, (u32)__shfl_xor((int)v, d, 64));
+        const bool ok = (v & 0xFFFF) && (v >> 16);
+        if (t < tiles && ok && l == 0) { tile_eol[t] = (i64)(tb + (v & 0xFFFF) - 1); tile_sp[t] = (i64)(tb + (v >> 16) - 1); }
+        u64 need = __ballot(t < tiles && !ok && l == 0);
+        while (need) {
+            const u32 jj = (u32)(__ffsll((long long)need) - 1) >> 4; need &= need - 1;
+            const u64 tt = t0 + jj, tbb = tt * ET_TILE; u32 found = 0;
+            for (int q = 3; q >= 0; q--) {
+                Piece p2 = load_piece(P, tbb + (u32)q * 1024 + lane * ET_BYTES);
+                PMask m2 = piece_masks(p2);
+                u32 u16 = (u32)q * 1024 + lane * ET_BYTES + 1;
+                u32 w = (m2.eol ? u16 + (31 - __clz((int)m2.eol)) : 0u) | ((m2.sp ? u16 + (31 - __clz((int)m2.sp)) : 0u) << 16);
+                w = (u32)__builtin_amdgcn_readlane((int)wave_scan_inclusive<u32, OpPkMaxU16>(w), 63);
+                if (!(found & 0xFFFF)) found |= w & 0xFFFF;
+                if (!(found >> 16)) found |= w & 0xFFFF0000u;
+                if ((found & 0xFFFF) && (found >> 16)) break;
+            }
+            if (lane == 0) {
+                tile_eol[tt] = (found & 0xFFFF) ? (i64)(tbb + (found & 0xFFFF) - 1) : -1;
+                tile_sp[tt] = (found >> 16) ? (i64)(tbb + (found >> 16) - 1) : -1;
+            }
+        }
     }
 }
 
@@ -1464,7 +1484,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         u32 *t_tail = arena_new<u32>(c, tiles + 1);
         u64 *tot = arena_new<u64>(c, 8);
         if (!t_eol || !t_sp || !t_seq || !t_ids || !t_cmt || !t_rec || !t_tail || !tot) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "ennaf_last", k_enc_last_fa, cdiv(tiles, 4), 256, 0, P, t_eol, t_sp, tiles);
+        LAUNCH(c, "ennaf_last", k_enc_last_fa, cdiv(tiles, 4 * LAST_TPW), 256, 0, P, t_eol, t_sp, tiles);
         // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
         if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
         if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
