@@ -597,6 +597,7 @@ def test_pure_tiles_and_their_edges(gpu, oracle):
     for k in range(6):                                                            # headers falling on and around tile borders
         pad = 4096 * 3 - 20 + k * 7
         texts.append(b">a\n" + wrap(seq(pad), 0) + b">" + b"h" * (k * 9) + b" c\n" + wrap(seq(12000), 100) + b">z\n" + seq(5) + b"\n")
+    texts.append(b">id " + b"word and " * 1200 + b"\n" + wrap(seq(20000), 80) + b">" + b"i" * 9000 + b"\n" + wrap(seq(700), 80))   # header lines longer than a tile
     texts.append(b">no final newline\n" + wrap(seq(30000), 80)[:-1])
     texts.append(b">one\n" + seq(4096 * 5 + 1))
     texts.append(b">masked runs\n" + wrap(b"a" * 9000 + b"C" * 9001 + b"g" * 8190 + b"T" * 3 + b"n" * 70000, 80))
