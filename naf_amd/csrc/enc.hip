@@ -1789,6 +1789,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     { SmallBytes hb; memset(&hb, 0, sizeof hb); memcpy(hb.b, hd, hl); hb.n = (u32)hl; LAUNCH(c, "ennaf_header", k_put_bytes, 1, 64, 0, d_naf, hb); pos += hl; }
     if (tl) { HIP_TRY(c, hipMemcpyAsync(d_naf + pos, o->title, tl, hipMemcpyHostToDevice, c->stream)); pos += tl; HIP_TRY(c, hipStreamSynchronize(c->stream)); }
     StreamJob big[6]; bool early[6] = { false, false, false, false, false, false };
+    naf_gpu_ctx *sb = nullptr; int rcB = 0;                       // second side context (lengths, mask) and what its thread returns
     if (overlap) {
         arena_reset(sc);
         HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
@@ -1810,7 +1811,18 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
                 early[4] = true;
             }
         }
-        if ((rc = ennaf_streams(sc, S, K, X, 2))) {
+        // lengths and mask: their units and the first half of their frames on a second side context with a host thread of its own,
+        // beside ids and names on the first (many reads make each of the two chains several milliseconds long)
+        sb = S.N >= 65536 ? c->side2 : nullptr;                  // a few records: one chain is short enough, and a thread hand-over is not free
+        if (sb) {
+            arena_reset(sb);
+            HIP_TRY(c, hipStreamWaitEvent(sb->stream, c->fork_ev, 0));
+            ctx_worker_start(sb, [&] {
+                rcB = ennaf_streams(sb, S, K, X, 2);
+                for (int i = 2; i < 4 && !rcB; i++)
+                    if (X.present[i]) { rcB = encode_stream_begin(sb, X.ptr[i], X.len[i], o->level, 0, X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]); early[i] = !rcB; }
+            });
+        } else if ((rc = ennaf_streams(sc, S, K, X, 2))) {
             for (int k = 4; k < 6; k++) if (early[k]) zstd_encode_drop(big[k].main);
             hipStreamSynchronize(sc->stream);
             return ctx_fail(c, rc, "%s", sc->err);
@@ -1820,22 +1832,31 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     R.n_sequences = S.N; R.n_bases = S.T; R.longest_line = S.longest;
 
     SecOut so[6]; memset(so, 0, sizeof so);
-    bool joined = !overlap;
+    bool joined = !overlap, joinedB = sb == nullptr;
     auto join = [&]() -> int {                                     // everything behind this point is on c's stream again
         if (joined) return 0;
         joined = true;
         if (hipEventRecord(c->split_ev[0], sc->stream) != hipSuccess || hipStreamWaitEvent(c->stream, c->split_ev[0], 0) != hipSuccess) return ctx_fail(c, NAF_GPU_EHIP, "ennaf: joining the side stream failed");
+        if (sb && (hipEventRecord(c->split_ev[1], sb->stream) != hipSuccess || hipStreamWaitEvent(c->stream, c->split_ev[1], 0) != hipSuccess)) return ctx_fail(c, NAF_GPU_EHIP, "ennaf: joining the side stream failed");
         return 0;
     };
+    auto joinB = [&]() -> int {                                    // the thread of the second side context has queued its part
+        if (joinedB) return 0;
+        joinedB = true;
+        ctx_worker_join(sb);
+        return rcB ? ctx_fail(c, rcB, "%s", sb->err) : 0;
+    };
     for (int i = 0; i < 6 && !rc; i++) {
+        if (i >= 2 && (rc = joinB())) break;
         if (!X.present[i]) continue;
         if (i >= 4 && (rc = join())) break;
-        naf_gpu_ctx *w = (overlap && i < 4) ? sc : c;
+        naf_gpu_ctx *w = !overlap || i >= 4 ? c : (sb && i >= 2) ? sb : sc;
         rc = put_section(w, c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], early[i] ? &big[i] : nullptr);
         early[i] = false;
     }
-    for (int k = 4; k < 6; k++) if (early[k]) zstd_encode_drop(big[k].main);
-    if (!rc) rc = join(); else if (overlap) hipStreamSynchronize(sc->stream);
+    if (!joinedB) { ctx_worker_join(sb); joinedB = true; }
+    for (int k = 2; k < 6; k++) if (early[k]) zstd_encode_drop(big[k].main);
+    if (!rc) rc = join(); else if (overlap) { hipStreamSynchronize(sc->stream); if (sb) hipStreamSynchronize(sb->stream); }
     if (rc) return rc;
     for (int i = 0; i < 6; i++) { R.section_orig[i] = so[i].orig; R.section_comp[i] = so[i].comp; }
     *naf_len = pos;
