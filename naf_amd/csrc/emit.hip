@@ -834,8 +834,13 @@ __global__ void k_flat_pair(EmitP P, u32 *pair)               // sixteen-entry t
     pair[t] = v;
 }
 #define FLAT_TPW 4                                               // tiles per workgroup: a tile alone is three dependent loads and a store, i.e. pure latency
-__global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *ti, const TileFlat *tsig, u8 *out, u64 ntiles)
+__global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *ti, const TileFlat *tsig, u8 *out, u64 ntiles, u32 xcd_chunk)
 {
+    // Workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md): with xcd_chunk = ceil(grid / 8) every XCD walks one contiguous
+    // eighth of the text instead of every eighth 16 KiB piece of all of it -- no data is shared between workgroups, but an XCD's
+    // address translation then covers an eighth of the pages in flight.  xcd_chunk = 0: workgroups in launch order.
+    u32 wg = blockIdx.x;
+    if (xcd_chunk) { wg = (blockIdx.x & 7u) * xcd_chunk + (blockIdx.x >> 3); if ((u64)wg * FLAT_TPW >= ntiles) return; }
     __shared__ u64 s_tog[EMIT_TOG_LDS];
     // a line end inside a chunk: bytes in front of it stay, the byte at it becomes '\n', bytes behind it take the byte in front of
     // them -- per position d of the line end, sixteen v_perm_b32 selector bytes (source = this dword and the one below it; 0x0C
@@ -865,7 +870,7 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         // (both arrays have FLAT_TPW spare entries behind ntiles, made harmless by k_tile_classify; the workgroup's four records are
         // read as whole 16-byte words so that no field waits for a test on another one)
         static_assert(sizeof(TileIdx) == 32 && sizeof(TileFlatE) == 48, "records are read as 16-byte words");
-        const u64 t0 = (u64)blockIdx.x * FLAT_TPW;
+        const u64 t0 = (u64)wg * FLAT_TPW;
         const uint4 *pa = (const uint4 *)(ti + t0), *pf = (const uint4 *)(tsig + t0);
         uint4 ra[2 * FLAT_TPW], rf[3 * FLAT_TPW];
 #pragma unroll
@@ -914,7 +919,7 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     // ---- phase 2: codes -> characters, mask, line ends, store
 #pragma unroll
     for (u32 j = 0; j < FLAT_TPW; j++) {
-        const u64 t = (u64)blockIdx.x * FLAT_TPW + j;
+        const u64 t = (u64)wg * FLAT_TPW + j;
         if (!live[j]) continue;
         const TileIdx &a = A[j];
         const u64 g0 = a.gline + grels[j];
@@ -1620,7 +1625,11 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                 HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX + 1], ic->stream));
                 HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX], 0));         // the index
             }
-            if (zflat.ready) LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat, cdiv(ntiles, FLAT_TPW), 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles);
+            if (zflat.ready) {
+                const u32 nwg = cdiv(ntiles, FLAT_TPW), chunk = (nwg + 7) / 8;
+                static const bool xcd = !(getenv("NAF_GPU_XCD") && getenv("NAF_GPU_XCD")[0] == '0');
+                LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat, xcd ? chunk * 8 : nwg, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, xcd ? chunk : 0u);
+            }
             else if (t_done < ntiles) {
                 if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit_tile<true>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
                 else LAUNCH(c, "unnaf_emit", k_emit_tile<false>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
