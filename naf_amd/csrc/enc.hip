@@ -1611,7 +1611,7 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
             // few hundred blocks whose Huffman streams the decoder walks serially: 8 KiB blocks (2 KiB streams) cut that latency to a
             // quarter.  Very long runs give strings of 255s (constant blocks) and one last block with the remainder in it -- whose four
             // streams are one lane's work each on either side: small blocks there too.
-            mask_block_log = 13;
+            { const char *mb = getenv("NAF_GPU_MASK_BLOCK_LOG"); mask_block_log = mb && atoi(mb) >= 10 && atoi(mb) <= 15 ? atoi(mb) : 13; }
             n_mask = nu;
         }
     }
