@@ -1543,7 +1543,7 @@ struct EnnafCarry {
     u64 run_ext;           // bases of the following shards that continue this shard's last mask run
 };
 struct EnnafStreams { const u8 *ptr[6]; u64 len[6], orig[6]; int lz[6], block_log[6], window_log[6]; bool present[6];
-                      u32 tail[6]; };   // tail: bytes at the end of the stream that go into a Raw block of their own (encode_stream)
+                      u32 tail[6]; int flags[6]; };   // flags: ZENC_PREFER_RAW for the mask stream   // tail: bytes at the end of the stream that go into a Raw block of their own (encode_stream)
 
 // E5-E7: lengths, 4-bit pack, mask units -> the six uncompressed streams.
 // part: 1 = ids, names, sequence and quality (nothing to wait for), 2 = lengths and mask (a few read-backs), 3 = all of them.  The two
@@ -1625,7 +1625,7 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
     }
     if (part & 2) {
         X.ptr[2] = (const u8 *)s_len; X.len[2] = X.orig[2] = n_lenb; X.lz[2] = 1; X.present[2] = true;
-        X.ptr[3] = s_mask; X.len[3] = X.orig[3] = n_mask; X.block_log[3] = mask_block_log; X.present[3] = S.store_mask;
+        X.ptr[3] = s_mask; X.len[3] = X.orig[3] = n_mask; X.block_log[3] = mask_block_log; X.present[3] = S.store_mask; X.flags[3] = ZENC_PREFER_RAW;
     }
     return 0;
 }
@@ -1742,13 +1742,13 @@ static u8 *place_section(void *ud, size_t clen)
 
 // `early`: the stream's planning was queued before (encode_stream_begin); otherwise both halves run here.  The launches go to c's
 // stream (c may be a side context), a failure's text lands in `report`.
-static int put_section(naf_gpu_ctx *c, naf_gpu_ctx *report, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz, int block_log, int window_log, u32 tail, StreamJob *early)
+static int put_section(naf_gpu_ctx *c, naf_gpu_ctx *report, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz, int block_log, int window_log, u32 tail, StreamJob *early, int flags = 0)
 {
     SecPlace sp = { c, d_naf, cap, pos, orig, 0, 0 }; ZencPlace P = { place_section, &sp };
     size_t clen = 0;
     StreamJob J;
     int rc = 0;
-    if (!early) { rc = encode_stream_begin(c, d_stream, stream_len, level, 0, lz, block_log, window_log, tail, &J); early = &J; }
+    if (!early) { rc = encode_stream_begin(c, d_stream, stream_len, level, flags, lz, block_log, window_log, tail, &J); early = &J; }
     if (!rc) rc = encode_stream_finish(c, early, &clen, &P);
     if (rc) { if (report != c) ctx_fail(report, sp.rc ? sp.rc : rc, "%s", c->err); return sp.rc ? sp.rc : rc; }
     pos += sp.hl + clen;
@@ -1820,7 +1820,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
             ctx_worker_start(sb, [&] {
                 rcB = ennaf_streams(sb, S, K, X, 2);
                 for (int i = 2; i < 4 && !rcB; i++)
-                    if (X.present[i]) { rcB = encode_stream_begin(sb, X.ptr[i], X.len[i], o->level, 0, X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]); early[i] = !rcB; }
+                    if (X.present[i]) { rcB = encode_stream_begin(sb, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]); early[i] = !rcB; }
             });
         } else if ((rc = ennaf_streams(sc, S, K, X, 2))) {
             for (int k = 4; k < 6; k++) if (early[k]) zstd_encode_drop(big[k].main);
@@ -1851,7 +1851,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
         if (!X.present[i]) continue;
         if (i >= 4 && (rc = join())) break;
         naf_gpu_ctx *w = !overlap || i >= 4 ? c : (sb && i >= 2) ? sb : sc;
-        rc = put_section(w, c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], early[i] ? &big[i] : nullptr);
+        rc = put_section(w, c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], early[i] ? &big[i] : nullptr, X.flags[i]);
         early[i] = false;
     }
     if (!joinedB) { ctx_worker_join(sb); joinedB = true; }
@@ -2068,7 +2068,7 @@ extern "C" int naf_gpu_ennaf_shard_finish(naf_gpu_ctx *c, const naf_gpu_ennaf_op
         const size_t need = naf_gpu_zstd_compress_bound(X.len[i]);
         if (pos + need > cap) return ctx_fail(c, NAF_GPU_ECAP, "shard piece buffer of %zu bytes is too small", cap);
         size_t clen = 0;
-        const int flags = ZENC_PART | (V.first[i] ? ZENC_PART_FIRST : 0) | (V.last[i] ? ZENC_PART_LAST : 0);
+        const int flags = ZENC_PART | (V.first[i] ? ZENC_PART_FIRST : 0) | (V.last[i] ? ZENC_PART_LAST : 0) | X.flags[i];
         if ((rc = encode_stream(c, X.ptr[i], X.len[i], o->level, dst + pos, cap - pos, &clen, flags, X.lz[i], X.block_log[i], X.window_log[i], V.last[i] ? X.tail[i] : 0u))) return rc;
         pieces->off[i] = pos; pieces->len[i] = clen; pieces->raw[i] = X.orig[i];
         pos += (clen + 15) & ~(size_t)15;

@@ -328,7 +328,7 @@ struct ZEncPlan {
     u8  pad;
 };
 
-NAF_HD void zenc_plan_finish(ZEncPlan &p, u32 n, u32 log, u32 tb);
+NAF_HD void zenc_plan_finish(ZEncPlan &p, u32 n, u32 log, u32 tb, u32 min_gain = 0);
 // hist[4][256] = byte counts of the four stream quarters of the block.  Fills plan, len[256], tree[<=160].
 NAF_HD void zenc_plan_block(const u32 *hist, u32 n, ZEncPlan &p, u8 *len, u8 *tree)
 {
@@ -346,14 +346,16 @@ NAF_HD void zenc_plan_block(const u32 *hist, u32 n, ZEncPlan &p, u8 *len, u8 *tr
     zenc_plan_finish(p, n, log, tb);
 }
 // last step of the plan: p.ssz[] hold the four stream sizes; decides Huffman vs Raw
-NAF_HD void zenc_plan_finish(ZEncPlan &p, u32 n, u32 log, u32 tb)
+// min_gain: 256ths of the block that entropy coding has to save before it is used (0: any gain; the mask stream asks for an eighth --
+// its units are close to uniform bytes, and a Raw block is a copy for every decoder where a Huffman stream is one lane's serial walk)
+NAF_HD void zenc_plan_finish(ZEncPlan &p, u32 n, u32 log, u32 tb, u32 min_gain)
 {
     u32 body = tb + 6;
     for (u32 k = 0; k < 4; k++) { body += p.ssz[k]; if (p.ssz[k] > 0xFFFF) return; }
     u32 lhdr = (n < 1024 && body < 1024) ? 3 : ((n < 16384 && body < 16384) ? 4 : 5);
     if (body >= (1u << 18)) return;
     u32 csize = 3 + lhdr + body + 1;                           // + sequences header (0 sequences)
-    if (csize >= 3 + n) return;                                // entropy coding does not pay: Raw block
+    if (csize + (u32)(((u64)n * min_gain) >> 8) >= 3 + n) return;   // entropy coding does not pay (enough): Raw block
     p.kind = ZK_HUF; p.csize = csize; p.log = (u8)log; p.tree_bytes = (u16)tb; p.lhdr = (u8)lhdr;
 }
 
