@@ -1776,7 +1776,8 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     // file order, each behind the one before.
     naf_gpu_ctx *sc = c->side;
     const char *eo = getenv("NAF_GPU_ENC_OVERLAP");
-    const bool overlap = sc && !(eo && !strcmp(eo, "0")) && (S.T >= (32u << 20) || S.n_qual >= (16u << 20));
+    const bool force_overlap = eo && !strcmp(eo, "2");             // tests: the concurrent path on inputs of any size
+    const bool overlap = sc && !(eo && !strcmp(eo, "0")) && (force_overlap || S.T >= (32u << 20) || S.n_qual >= (16u << 20));
     EnnafStreams X;
     if ((rc = ennaf_streams(c, S, K, X, overlap ? 1 : 3))) return rc;
     bool probe_later = false;                                     // level 1: the look at the sequence stream runs beside its planning
@@ -1813,7 +1814,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
         }
         // lengths and mask: their units and the first half of their frames on a second side context with a host thread of its own,
         // beside ids and names on the first (many reads make each of the two chains several milliseconds long)
-        sb = S.N >= 65536 ? c->side2 : nullptr;                  // a few records: one chain is short enough, and a thread hand-over is not free
+        sb = (S.N >= 65536 || force_overlap) ? c->side2 : nullptr;                  // a few records: one chain is short enough, and a thread hand-over is not free
         if (sb) {
             arena_reset(sb);
             HIP_TRY(c, hipStreamWaitEvent(sb->stream, c->fork_ev, 0));

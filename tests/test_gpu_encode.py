@@ -643,3 +643,32 @@ def test_sections_coded_beside_each_other_give_the_same_archive(gpu, oracle, mon
     assert back.upper() == host(fq).upper() and back != host(fq)
     if oracle.have_ref():
         assert oracle.ref_unnaf(host(b), ("--fastq",)) == back
+
+
+def test_concurrent_sections_on_small_inputs_and_when_the_archive_does_not_fit(gpu, oracle, monkeypatch):
+    """NAF_GPU_ENC_OVERLAP=2 takes the concurrent back half of naf_gpu_ennaf (side stream, second side thread, the look beside the
+    plan) on inputs of any size: stream parity with the oracle on small FASTA / FASTQ / protein inputs, and an output buffer that
+    is too small at every section must come back as the capacity error (no hang, no write past the buffer, context usable)."""
+    import torch
+    from naf_amd import synth
+    from naf_amd.capi import NafGpuError
+    monkeypatch.setenv("NAF_GPU_ENC_OVERLAP", "2")
+    rng = np.random.default_rng(5)
+    texts = [synth.fasta_mixed(30, 3000, 60, seed=2), synth.fastq_reads(300, 120, seed=3, var_len=True), b">only a header\n", b">e\n\n>f\nACGTN\n",
+             b">p1 protein\n" + bytes(rng.choice(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY*", dtype=np.uint8), 5000)) + b"\n"]
+    for i, text in enumerate(texts):
+        check_ennaf(gpu, oracle, text, seq_type=2 if i == 4 else 0)
+        check_ennaf(gpu, oracle, text, seq_type=2 if i == 4 else 0, title=b"a title")
+    text = gpu.to_device(synth.fasta_mixed(200, 20000, 70, seed=9))
+    whole, _ = gpu.ennaf(text)
+    n = whole.numel(); whole = whole.clone()
+    guard = 4096
+    for cap in (0, 5, 20, 200, 2000, n // 2, n - 1):
+        buf = torch.full((cap + guard,), 0xA5, dtype=torch.uint8, device=text.device)
+        with pytest.raises(NafGpuError):
+            gpu.ennaf(text, out=buf[:cap])
+        torch.cuda.synchronize()
+        assert bool((buf[cap:] == 0xA5).all()), cap                      # nothing written behind the capacity
+    buf = torch.empty(n, dtype=torch.uint8, device=text.device)
+    got, _ = gpu.ennaf(text, out=buf)
+    assert torch.equal(got, whole)
