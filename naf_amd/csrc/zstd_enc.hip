@@ -102,8 +102,39 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
     bool huf = false;
     if (bn && distinct == 1) { p.kind = ZK_RLE; p.csize = 4; }
     else if (bn >= 64 && distinct >= 2) {
+        // 2^k symbols whose two rarest together outweigh the commonest one (packed random bases: sixteen near-equal counts): every
+        // merge of the two-queue construction pairs leaves before it touches a node, level after level -- a balanced tree, every code
+        // k bits, whatever the order of equal counts.  No sort, no construction.
+        __shared__ u32 s_flat_log, s_mm[4][3];
+        {
+            // the two smallest counts (equal ones count twice) and the largest: per wavefront by shuffles, across the four through LDS
+            const u32 v = mine ? mine : 0xFFFFFFFFu;
+            u32 m1 = v, mx = mine;
+            for (int d = 32; d; d >>= 1) { const u32 o = (u32)__shfl_xor((int)m1, d, 64); m1 = o < m1 ? o : m1; const u32 q = (u32)__shfl_xor((int)mx, d, 64); mx = q > mx ? q : mx; }
+            const bool twice = __popcll(__ballot(v == m1)) >= 2;
+            u32 m2 = (v == m1) ? 0xFFFFFFFFu : v;
+            for (int d = 32; d; d >>= 1) { const u32 o = (u32)__shfl_xor((int)m2, d, 64); m2 = o < m2 ? o : m2; }
+            if (twice) m2 = m1;
+            if ((threadIdx.x & 63) == 0) { s_mm[threadIdx.x >> 6][0] = m1; s_mm[threadIdx.x >> 6][1] = m2; s_mm[threadIdx.x >> 6][2] = mx; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                u32 a = 0xFFFFFFFFu, b = 0xFFFFFFFFu, top = 0;                           // a <= b: the two smallest of the eight candidates
+                for (int w = 0; w < 4; w++) {
+                    for (int k = 0; k < 2; k++) { const u32 x = s_mm[w][k]; if (x < a) { b = a; a = x; } else if (x < b) b = x; }
+                    if (s_mm[w][2] > top) top = s_mm[w][2];
+                }
+                const bool pow2 = (distinct & (distinct - 1)) == 0;
+                s_flat_log = (pow2 && distinct >= 2 && b != 0xFFFFFFFFu && (u64)a + b > top) ? (u32)(31 - __clz((int)distinct)) : 0u;
+            }
+            __syncthreads();
+        }
+        const u32 flat_log = s_flat_log;
+        if (flat_log) {
+            if (mine) ws.len[sym] = (u8)flat_log;
+            if (threadIdx.x == 0) ws.log = flat_log;
+        }
         // rank sort by (count, symbol): the order a stable insertion sort over ascending symbols gives
-        if (mine) {
+        else if (mine) {
             u32 r = 0;
             for (u32 j = 0; j < distinct; j++) { u32 t = plist[j], c = ws.tot[t]; r += (c < mine || (c == mine && t < sym)); }
             ws.order[r] = (u16)sym;
@@ -113,7 +144,8 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
         // the first wavefront with the node weights, parents and depths in registers (lane = node index, read and written with
         // v_readlane / compare-and-select under uniform control flow) -- the same picks in the same order, without an LDS round
         // trip per step.  More symbols, or a depth above the limit: the serial routine (its length limiting is rarely needed).
-        if (distinct <= 64) {
+        if (flat_log) { }
+        else if (distinct <= 64) {
             if (threadIdx.x < 64) {
                 const u32 lane = threadIdx.x, n = distinct;
                 u32 wl = lane < n ? ws.tot[ws.order[lane]] : 0xFFFFFFFFu;      // leaf weights, ascending
