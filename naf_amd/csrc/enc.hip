@@ -613,7 +613,7 @@ __device__ __forceinline__ u64 tile_line_base(const EncP &P, const EncOut &O, co
 }
 
 template <bool PACK>
-__global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, EncOut O)
+__global__ __launch_bounds__(256, 8) void k_enc_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, EncOut O)
 {
     __shared__ __attribute__((aligned(16))) u8 stage[ET_TILE + 48];
     __shared__ u32 s_a[4], s_b[4], s_l[4];
@@ -630,6 +630,100 @@ __global__ __launch_bounds__(256) void k_enc_scatter(EncP P, const i64 *tile_eol
         const u32 w[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) };
         PMask pm; pm.gt = 0;
         const bool lane_bad = !piece_plain(w, P.plo, P.phi, &pm.eol); pm.sp = pm.eol;
+        // ---- a REGULAR tile: plain pieces whose line ends sit on a lattice (first one at p1, then every `period` bytes, period >= 33:
+        // lines of one width with one-byte ends -- nearly every tile of a line-wrapped genome).  Then base b of the tile is the text
+        // byte b + (b >= p1 ? 1 + (b - p1) / (period - 1) : 0): every lane fetches the 16 bases of one output group straight from the
+        // text (16 bytes, 17 with the line end taken out) and packs them -- no prefix sum over the lanes, no compaction, no LDS stage.
+        // The test needs text positions only: every line end but the tile's first must lie `period` behind the one before it.
+        if (PACK && maybe) {
+            __shared__ u32 r_cnt[4], r_first[4], r_second[4], r_last[4], r_bad;
+            const bool has = pm.eol != 0;
+            const u32 q = threadIdx.x * ET_BYTES + (has ? (u32)__ffs((int)pm.eol) - 1 : 0u);          // position of the lane's line end in the tile
+            const u64 bal = __ballot(has);
+            const u64 mlow = bal & ((1ull << lane) - 1);
+            const u32 qprev = (u32)__shfl((int)q, mlow ? 63 - __clzll((long long)mlow) : lane, 64);
+            const bool wave_bad = __ballot(lane_bad || (pm.eol & (pm.eol - 1)) != 0) != 0;               // not plain, or two line ends in one piece
+            if (bal) {
+                const u64 bal2 = bal & (bal - 1);
+                if (lane == __ffsll((long long)bal) - 1) r_first[wave] = q;
+                if (bal2 && lane == __ffsll((long long)bal2) - 1) r_second[wave] = q;
+                if (lane == 63 - __clzll((long long)bal)) r_last[wave] = q;
+            }
+            if (lane == 0) r_cnt[wave] = (u32)__popcll(bal) | (wave_bad ? 0x10000u : 0u);
+            if (threadIdx.x == 0) r_bad = 0;
+            *(uint4 *)(stage + ET_BYTES * threadIdx.x) = make_uint4(w[0], w[1], w[2], w[3]);          // the tile as it is, for the gather below
+            __syncthreads();
+            u32 E = 0, p1 = ~0u, p2 = ~0u, prev_last = ~0u; bool anybad = false;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const u32 cv = r_cnt[v], cnt = cv & 0xFFFFu;
+                anybad |= (cv >> 16) != 0;
+                if (cnt) {
+                    if (p1 == ~0u) { p1 = r_first[v]; if (cnt >= 2) p2 = r_second[v]; }
+                    else if (p2 == ~0u) p2 = r_first[v];
+                    if (v < wave) prev_last = r_last[v];
+                }
+                E += cnt;
+            }
+            const u32 period = p2 - p1;
+            const bool tile_ok = !anybad && E >= 2 && period >= 33;
+            bool lane_ok = true;
+            if (has && q != p1) lane_ok = q - (mlow ? qprev : prev_last) == period;
+            if (tile_ok && __ballot(!lane_ok) != 0 && lane == 0) r_bad = 1;
+            __syncthreads();
+            if (tile_ok && !r_bad) {
+                const u32 n = ET_TILE - E, W = period - 1;                    // bases of the tile; bases of a line
+                const u32 o = (u32)(tbase & 15), span = o + n, ng = (span + 15) >> 4;
+                const u64 G0 = tbase >> 4;
+                const float rW = 1.0f / (float)W;
+                for (u32 j = threadIdx.x; j < ng; j += blockDim.x) {
+                    const u32 ga = j == 0 ? o : 0u, gb = span - 16 * j < 16 ? span - 16 * j : 16u;      // bytes [ga, gb) of the group are this tile's
+                    const u32 b_lo = 16 * j + ga - o, nb = gb - ga;
+                    u32 x, e;                                                 // text position of base b_lo; bases from it to the next line end
+                    if (b_lo < p1) { x = b_lo; e = p1 - b_lo; }
+                    else {
+                        const u32 d = b_lo - p1;
+                        u32 k = (u32)((float)d * rW);
+                        if (k * W > d) k--; else if ((k + 1) * W <= d) k++;
+                        x = b_lo + 1 + k; e = W - (d - k * W);
+                    }
+                    // 17 bytes of the tile from x (LDS, any alignment; what lies behind the tile's last base is masked out below)
+                    u64 lo, hi; u8 c16;
+                    __builtin_memcpy(&lo, stage + x, 8); __builtin_memcpy(&hi, stage + x + 8, 8); c16 = stage[x + 16];
+                    if (e < nb) {                                             // the line end at byte e: everything behind it one down, byte 16 comes in
+                        const u64 slo = (lo >> 8) | (hi << 56), shi = (hi >> 8) | ((u64)c16 << 56);
+                        if (e < 8) { const u64 m = low_bytes(e); lo = (lo & m) | (slo & ~m); hi = shi; }
+                        else { const u64 m = low_bytes(e - 8); hi = (hi & m) | (shi & ~m); }
+                    }
+                    if (ga) {                                                 // the group's first bytes belong to the tile in front: up by ga bytes
+                        const u32 sh = 8 * ga;
+                        if (sh < 64) { hi = (hi << sh) | (lo >> (64 - sh)); lo <<= sh; } else { hi = lo << (sh - 64); lo = 0; }
+                    }
+                    const u32 gw[4] = { (u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32) };
+                    u32 cd[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) cd[i] = nuc4x4_quick(gw[i]);
+                    const u64 pk = (u64)pack_codes8(cd[0], cd[1]) | ((u64)pack_codes8(cd[2], cd[3]) << 32);
+                    const u32 H = 0x80808080u;
+                    u32 cb = swar_movemask16((gw[0] | ((gw[0] << 1) & (gw[0] << 2))) & H, (gw[1] | ((gw[1] << 1) & (gw[1] << 2))) & H,
+                                             (gw[2] | ((gw[2] << 1) & (gw[2] << 2))) & H, (gw[3] | ((gw[3] << 1) & (gw[3] << 2))) & H);
+                    if (ga == 0 && gb == 16) {
+                        *(u64 *)(O.packed + 8 * (G0 + j)) = pk;
+                        if (O.casebits) ((u16 *)O.casebits)[G0 + j] = (u16)cb;
+                    } else {
+                        const u64 nm = (gb == 16 ? ~0ull : ((1ull << (4 * gb)) - 1)) & ~((1ull << (4 * ga)) - 1);
+                        cb &= ((1u << gb) - 1) & ~((1u << ga) - 1);
+                        atomicOr((unsigned long long *)(O.packed + 8 * (G0 + j)), (unsigned long long)(pk & nm));
+                        if (O.casebits) atomicOr(O.casebits + ((G0 + j) >> 1), cb << (16 * (u32)((G0 + j) & 1)));
+                    }
+                }
+                if (threadIdx.x == 0) {                                       // line lengths: the one that ends at p1 began in front of the tile, the others hold W bases
+                    u64 len = tbase + p1 - line_b0; if (len < W) len = W;
+                    if (len > __atomic_load_n(O.longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)O.longest, (unsigned long long)len);
+                }
+                return;
+            }
+        }
         const u32 nseq = 16u - (u32)__popc(pm.sp);
         const u32 incl = wave_scan_inclusive<u32, OpAdd>(nseq);
         const bool has = pm.eol != 0;
