@@ -367,10 +367,16 @@ __device__ __forceinline__ u32 piece_tail_bases(const PMask &pm)
 }
 
 __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, const i64 *tile_sp,
-                                                    u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail)
+                                                    u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg)
 {
     __shared__ u8 cls[256];
     __shared__ u32 s_a[4], s_b[4], s_last[4];
+    // REGULAR tiles (t_reg, read by k_enc_scatter<true>): plain pieces whose line ends sit on a lattice -- the first at p1, then one
+    // every `period` bytes, period >= 33: lines of one width with one-byte ends, nearly every tile of a line-wrapped genome.  The
+    // test needs text positions only: every line end but the tile's first lies `period` behind the one before it.
+    // Every wavefront checks its own line ends against its own period (the distance of its first two) and leaves count, first and
+    // last position, period and verdict; the tile's first lane puts the four together -- no barrier beyond the one the counts need.
+    __shared__ u32 r_cnt[4], r_first[4], r_last[4], r_per[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool maybe = tile_may_be_pure(P, tile_eol);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
@@ -388,10 +394,39 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
         const u32 red = wave_scan_inclusive<u32, OpAdd>(nseq | (after << 16));
         const bool wave_bad = __ballot(!plain) != 0;
         if (lane == 63) { s_a[wave] = red; s_last[wave] = (bal ? 1u : 0u) | (wave_bad ? 2u : 0u); }
+        if (maybe) {
+            const bool has = pl.eol != 0;
+            const u32 q = threadIdx.x * ET_BYTES + (has ? (u32)__ffs((int)pl.eol) - 1 : 0u);         // position of the lane's line end in the tile
+            const u64 mlow = bal & ((1ull << lane) - 1);
+            const u32 qprev = (u32)__shfl((int)q, mlow ? 63 - __clzll((long long)mlow) : lane, 64);
+            const u64 bal2 = bal & (bal - 1);
+            const int f1 = bal ? __ffsll((long long)bal) - 1 : 0, f2 = bal2 ? __ffsll((long long)bal2) - 1 : 0;
+            const u32 q1 = (u32)__builtin_amdgcn_readlane((int)q, f1), q2 = (u32)__builtin_amdgcn_readlane((int)q, f2);
+            const u32 ql = (u32)__builtin_amdgcn_readlane((int)q, lastl < 0 ? 0 : lastl);
+            const u32 per = bal2 ? q2 - q1 : 0u;                                                      // 0: fewer than two line ends in this wave
+            const bool lane_bad = (pl.eol & (pl.eol - 1)) != 0 || (has && mlow && q - qprev != per); // two in one piece, or off the wave's lattice
+            const bool wbad = __ballot(lane_bad) != 0;
+            if (lane == 0) { r_cnt[wave] = (u32)__popcll(bal) | (wbad ? 0x10000u : 0u); r_first[wave] = q1; r_last[wave] = ql; r_per[wave] = per; }
+        }
     }
     __syncthreads();
     if (maybe && !((s_last[0] | s_last[1] | s_last[2] | s_last[3]) & 2u)) {
         if (threadIdx.x == 0) {
+            // the four waves' line ends as one lattice: equal periods, and every wave's first line end one period behind the last one before it
+            u32 E = 0, p1 = 0, period = 0, prev_last = 0; bool ok = true, any = false;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const u32 cv = r_cnt[v], cnt = cv & 0xFFFFu;
+                if (cv >> 16) ok = false;
+                if (!cnt) continue;
+                if (any) { const u32 gap = r_first[v] - prev_last; if (!period) period = gap; else if (gap != period) ok = false; }
+                else p1 = r_first[v];
+                if (r_per[v]) { if (!period) period = r_per[v]; else if (r_per[v] != period) ok = false; }
+                any = true; prev_last = r_last[v]; E += cnt;
+            }
+            // (the gather of the scatter pass reads up to 17 bytes from a base's position: not in the text's last tiles)
+            const bool tile_ok = ok && E >= 2 && period >= 33 && ((u64)blockIdx.x + 1) * ET_TILE + 32 <= P.n;
+            t_reg[blockIdx.x] = tile_ok ? (p1 | (period << 12) | (E << 24)) : 0u;
             u32 tot = 0, tail = 0; bool found = false;
 #pragma unroll
             for (int w = 3; w >= 0; w--) { tot += s_a[w] & 0xFFFF; if (!found) { tail += s_a[w] >> 16; found = (s_last[w] & 1u) != 0; } }
@@ -428,6 +463,7 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
     if (threadIdx.x == 0) {
         t_seq[blockIdx.x] = tota & 0xFFFF; t_ids[blockIdx.x] = tota >> 16; t_cmt[blockIdx.x] = totb & 0xFFFF; t_rec[blockIdx.x] = totb >> 16;
         if (!last) t_tail[blockIdx.x] = tota & 0xFFFF;
+        t_reg[blockIdx.x] = 0;
     }
     if (threadIdx.x + 1 == last) t_tail[blockIdx.x] = ((tota & 0xFFFF) - ((pre + wa) & 0xFFFF) + S.tail) | 0x80000000u;
 }
@@ -460,6 +496,7 @@ struct EncOut {
     u64 *lead;                    // bases in front of the first header (a shard that starts inside a record; 0 for a whole input)
     u64 *strict_first;            // --strict: min over strict_key of the unexpected bytes (nullptr otherwise)
     const u64 *t_seq, *t_ids, *t_cmt, *t_rec; const u32 *t_tail; const i64 *tile_eol;
+    const u32 *t_reg;             // k_enc_count's verdict on a tile: p1 | period << 12 | line ends << 24 when it is regular, else 0
 };
 
 // The tile's sequence bytes are staged in LDS and leave as aligned 8-byte stores: one-byte scattered stores
@@ -615,6 +652,68 @@ __device__ __forceinline__ u64 tile_line_base(const EncP &P, const EncOut &O, co
 template <bool PACK>
 __global__ __launch_bounds__(256, 8) void k_enc_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, EncOut O)
 {
+    // ---- a REGULAR tile (k_enc_count's verdict, t_reg): base b of the tile is the text byte b + (b >= p1 ? 1 + (b - p1) / (period - 1) : 0).
+    // Every lane fetches the 16 bases of one output group straight from the text (16 bytes, 17 with the line end taken out) and packs
+    // them: no piece, no classes, no prefix sum over the lanes, no compaction, no LDS, no barrier.
+    if (PACK) {
+        const u32 reg = O.t_reg[blockIdx.x];
+        const u64 tbase = O.t_seq[blockIdx.x];                                // (asked for before the verdict is looked at: both paths need it)
+        if (reg) {
+            const u32 p1 = reg & 0xFFFu, period = (reg >> 12) & 0xFFFu, E = reg >> 24;
+            const u32 n = ET_TILE - E, W = period - 1;                    // bases of the tile; bases of a line
+            const u32 o = (u32)(tbase & 15), span = o + n, ng = (span + 15) >> 4;
+            const u64 G0 = tbase >> 4;
+            const float rW = 1.0f / (float)W;
+            const u8 *tt = P.text + (u64)blockIdx.x * ET_TILE;
+            for (u32 j = threadIdx.x; j < ng; j += blockDim.x) {
+                const u32 ga = j == 0 ? o : 0u, gb = span - 16 * j < 16 ? span - 16 * j : 16u;      // bytes [ga, gb) of the group are this tile's
+                const u32 b_lo = 16 * j + ga - o, nb = gb - ga;
+                u32 x, e;                                                 // text position of base b_lo; bases from it to the next line end
+                if (b_lo < p1) { x = b_lo; e = p1 - b_lo; }
+                else {
+                    const u32 d = b_lo - p1;
+                    u32 k = (u32)((float)d * rW);
+                    if (k * W > d) k--; else if ((k + 1) * W <= d) k++;
+                    x = b_lo + 1 + k; e = W - (d - k * W);
+                }
+                // 17 bytes of the text from x (any alignment; what lies behind the tile's last base is masked out below)
+                u64 lo, hi; u8 c16;
+                lo = ld64(tt + x); hi = ld64(tt + x + 8); c16 = tt[x + 16];
+                if (e < nb) {                                             // the line end at byte e: everything behind it one down, byte 16 comes in
+                    const u64 slo = (lo >> 8) | (hi << 56), shi = (hi >> 8) | ((u64)c16 << 56);
+                    if (e < 8) { const u64 m = low_bytes(e); lo = (lo & m) | (slo & ~m); hi = shi; }
+                    else { const u64 m = low_bytes(e - 8); hi = (hi & m) | (shi & ~m); }
+                }
+                if (ga) {                                                 // the group's first bytes belong to the tile in front: up by ga bytes
+                    const u32 sh = 8 * ga;
+                    if (sh < 64) { hi = (hi << sh) | (lo >> (64 - sh)); lo <<= sh; } else { hi = lo << (sh - 64); lo = 0; }
+                }
+                const u32 gw[4] = { (u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32) };
+                u32 cd[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) cd[i] = nuc4x4_quick(gw[i]);
+                const u64 pk = (u64)pack_codes8(cd[0], cd[1]) | ((u64)pack_codes8(cd[2], cd[3]) << 32);
+                const u32 H = 0x80808080u;
+                u32 cb = swar_movemask16((gw[0] | ((gw[0] << 1) & (gw[0] << 2))) & H, (gw[1] | ((gw[1] << 1) & (gw[1] << 2))) & H,
+                                         (gw[2] | ((gw[2] << 1) & (gw[2] << 2))) & H, (gw[3] | ((gw[3] << 1) & (gw[3] << 2))) & H);
+                if (ga == 0 && gb == 16) {
+                    *(u64 *)(O.packed + 8 * (G0 + j)) = pk;
+                    if (O.casebits) ((u16 *)O.casebits)[G0 + j] = (u16)cb;
+                } else {
+                    const u64 nm = (gb == 16 ? ~0ull : ((1ull << (4 * gb)) - 1)) & ~((1ull << (4 * ga)) - 1);
+                    cb &= ((1u << gb) - 1) & ~((1u << ga) - 1);
+                    atomicOr((unsigned long long *)(O.packed + 8 * (G0 + j)), (unsigned long long)(pk & nm));
+                    if (O.casebits) atomicOr(O.casebits + ((G0 + j) >> 1), cb << (16 * (u32)((G0 + j) & 1)));
+                }
+            }
+            if (threadIdx.x == 0) {                                           // line lengths: the one that ends at p1 began in front of the tile, the others hold W bases
+                const u64 line_b0 = tile_line_base(P, O, tile_eol);
+                u64 len = tbase + p1 - line_b0; if (len < W) len = W;
+                if (len > __atomic_load_n(O.longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)O.longest, (unsigned long long)len);
+            }
+            return;
+        }
+    }
     __shared__ __attribute__((aligned(16))) u8 stage[ET_TILE + 48];
     __shared__ u32 s_a[4], s_b[4], s_l[4];
     __shared__ u64 s_best[4];
@@ -630,100 +729,6 @@ __global__ __launch_bounds__(256, 8) void k_enc_scatter(EncP P, const i64 *tile_
         const u32 w[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) };
         PMask pm; pm.gt = 0;
         const bool lane_bad = !piece_plain(w, P.plo, P.phi, &pm.eol); pm.sp = pm.eol;
-        // ---- a REGULAR tile: plain pieces whose line ends sit on a lattice (first one at p1, then every `period` bytes, period >= 33:
-        // lines of one width with one-byte ends -- nearly every tile of a line-wrapped genome).  Then base b of the tile is the text
-        // byte b + (b >= p1 ? 1 + (b - p1) / (period - 1) : 0): every lane fetches the 16 bases of one output group straight from the
-        // text (16 bytes, 17 with the line end taken out) and packs them -- no prefix sum over the lanes, no compaction, no LDS stage.
-        // The test needs text positions only: every line end but the tile's first must lie `period` behind the one before it.
-        if (PACK && maybe) {
-            __shared__ u32 r_cnt[4], r_first[4], r_second[4], r_last[4], r_bad;
-            const bool has = pm.eol != 0;
-            const u32 q = threadIdx.x * ET_BYTES + (has ? (u32)__ffs((int)pm.eol) - 1 : 0u);          // position of the lane's line end in the tile
-            const u64 bal = __ballot(has);
-            const u64 mlow = bal & ((1ull << lane) - 1);
-            const u32 qprev = (u32)__shfl((int)q, mlow ? 63 - __clzll((long long)mlow) : lane, 64);
-            const bool wave_bad = __ballot(lane_bad || (pm.eol & (pm.eol - 1)) != 0) != 0;               // not plain, or two line ends in one piece
-            if (bal) {
-                const u64 bal2 = bal & (bal - 1);
-                if (lane == __ffsll((long long)bal) - 1) r_first[wave] = q;
-                if (bal2 && lane == __ffsll((long long)bal2) - 1) r_second[wave] = q;
-                if (lane == 63 - __clzll((long long)bal)) r_last[wave] = q;
-            }
-            if (lane == 0) r_cnt[wave] = (u32)__popcll(bal) | (wave_bad ? 0x10000u : 0u);
-            if (threadIdx.x == 0) r_bad = 0;
-            *(uint4 *)(stage + ET_BYTES * threadIdx.x) = make_uint4(w[0], w[1], w[2], w[3]);          // the tile as it is, for the gather below
-            __syncthreads();
-            u32 E = 0, p1 = ~0u, p2 = ~0u, prev_last = ~0u; bool anybad = false;
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const u32 cv = r_cnt[v], cnt = cv & 0xFFFFu;
-                anybad |= (cv >> 16) != 0;
-                if (cnt) {
-                    if (p1 == ~0u) { p1 = r_first[v]; if (cnt >= 2) p2 = r_second[v]; }
-                    else if (p2 == ~0u) p2 = r_first[v];
-                    if (v < wave) prev_last = r_last[v];
-                }
-                E += cnt;
-            }
-            const u32 period = p2 - p1;
-            const bool tile_ok = !anybad && E >= 2 && period >= 33;
-            bool lane_ok = true;
-            if (has && q != p1) lane_ok = q - (mlow ? qprev : prev_last) == period;
-            if (tile_ok && __ballot(!lane_ok) != 0 && lane == 0) r_bad = 1;
-            __syncthreads();
-            if (tile_ok && !r_bad) {
-                const u32 n = ET_TILE - E, W = period - 1;                    // bases of the tile; bases of a line
-                const u32 o = (u32)(tbase & 15), span = o + n, ng = (span + 15) >> 4;
-                const u64 G0 = tbase >> 4;
-                const float rW = 1.0f / (float)W;
-                for (u32 j = threadIdx.x; j < ng; j += blockDim.x) {
-                    const u32 ga = j == 0 ? o : 0u, gb = span - 16 * j < 16 ? span - 16 * j : 16u;      // bytes [ga, gb) of the group are this tile's
-                    const u32 b_lo = 16 * j + ga - o, nb = gb - ga;
-                    u32 x, e;                                                 // text position of base b_lo; bases from it to the next line end
-                    if (b_lo < p1) { x = b_lo; e = p1 - b_lo; }
-                    else {
-                        const u32 d = b_lo - p1;
-                        u32 k = (u32)((float)d * rW);
-                        if (k * W > d) k--; else if ((k + 1) * W <= d) k++;
-                        x = b_lo + 1 + k; e = W - (d - k * W);
-                    }
-                    // 17 bytes of the tile from x (LDS, any alignment; what lies behind the tile's last base is masked out below)
-                    u64 lo, hi; u8 c16;
-                    __builtin_memcpy(&lo, stage + x, 8); __builtin_memcpy(&hi, stage + x + 8, 8); c16 = stage[x + 16];
-                    if (e < nb) {                                             // the line end at byte e: everything behind it one down, byte 16 comes in
-                        const u64 slo = (lo >> 8) | (hi << 56), shi = (hi >> 8) | ((u64)c16 << 56);
-                        if (e < 8) { const u64 m = low_bytes(e); lo = (lo & m) | (slo & ~m); hi = shi; }
-                        else { const u64 m = low_bytes(e - 8); hi = (hi & m) | (shi & ~m); }
-                    }
-                    if (ga) {                                                 // the group's first bytes belong to the tile in front: up by ga bytes
-                        const u32 sh = 8 * ga;
-                        if (sh < 64) { hi = (hi << sh) | (lo >> (64 - sh)); lo <<= sh; } else { hi = lo << (sh - 64); lo = 0; }
-                    }
-                    const u32 gw[4] = { (u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32) };
-                    u32 cd[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) cd[i] = nuc4x4_quick(gw[i]);
-                    const u64 pk = (u64)pack_codes8(cd[0], cd[1]) | ((u64)pack_codes8(cd[2], cd[3]) << 32);
-                    const u32 H = 0x80808080u;
-                    u32 cb = swar_movemask16((gw[0] | ((gw[0] << 1) & (gw[0] << 2))) & H, (gw[1] | ((gw[1] << 1) & (gw[1] << 2))) & H,
-                                             (gw[2] | ((gw[2] << 1) & (gw[2] << 2))) & H, (gw[3] | ((gw[3] << 1) & (gw[3] << 2))) & H);
-                    if (ga == 0 && gb == 16) {
-                        *(u64 *)(O.packed + 8 * (G0 + j)) = pk;
-                        if (O.casebits) ((u16 *)O.casebits)[G0 + j] = (u16)cb;
-                    } else {
-                        const u64 nm = (gb == 16 ? ~0ull : ((1ull << (4 * gb)) - 1)) & ~((1ull << (4 * ga)) - 1);
-                        cb &= ((1u << gb) - 1) & ~((1u << ga) - 1);
-                        atomicOr((unsigned long long *)(O.packed + 8 * (G0 + j)), (unsigned long long)(pk & nm));
-                        if (O.casebits) atomicOr(O.casebits + ((G0 + j) >> 1), cb << (16 * (u32)((G0 + j) & 1)));
-                    }
-                }
-                if (threadIdx.x == 0) {                                       // line lengths: the one that ends at p1 began in front of the tile, the others hold W bases
-                    u64 len = tbase + p1 - line_b0; if (len < W) len = W;
-                    if (len > __atomic_load_n(O.longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)O.longest, (unsigned long long)len);
-                }
-                return;
-            }
-        }
         const u32 nseq = 16u - (u32)__popc(pm.sp);
         const u32 incl = wave_scan_inclusive<u32, OpAdd>(nseq);
         const bool has = pm.eol != 0;
@@ -1575,14 +1580,14 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         u64 tiles = n / ET_TILE + 1;                                                              // +1: the virtual end-of-input byte
         i64 *t_eol = arena_new<i64>(c, tiles + 1), *t_sp = arena_new<i64>(c, tiles + 1);
         u64 *t_seq = arena_new<u64>(c, tiles + 2), *t_ids = arena_new<u64>(c, tiles + 2), *t_cmt = arena_new<u64>(c, tiles + 2), *t_rec = arena_new<u64>(c, tiles + 2);
-        u32 *t_tail = arena_new<u32>(c, tiles + 1);
+        u32 *t_tail = arena_new<u32>(c, tiles + 1), *t_reg = arena_new<u32>(c, tiles + 1);
         u64 *tot = arena_new<u64>(c, 8);
-        if (!t_eol || !t_sp || !t_seq || !t_ids || !t_cmt || !t_rec || !t_tail || !tot) return NAF_GPU_ENOMEM;
+        if (!t_eol || !t_sp || !t_seq || !t_ids || !t_cmt || !t_rec || !t_tail || !t_reg || !tot) return NAF_GPU_ENOMEM;
         LAUNCH(c, "ennaf_last", k_enc_last_fa, cdiv(tiles, 4 * LAST_TPW), 256, 0, P, t_eol, t_sp, tiles);
         // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
         if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
         if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
-        LAUNCH(c, "ennaf_count", k_enc_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail);
+        LAUNCH(c, "ennaf_count", k_enc_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg);
         if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
         if ((rc = scan_exclusive_u64(c, t_ids, tiles, tot + 1))) return rc;
         if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;
@@ -1603,7 +1608,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         HIP_TRY(c, hipMemsetAsync(rec_begin, 0, (N + 1) * 8, c->stream));
         EncOut O; O.seq = bases; O.packed = S.packed; O.casebits = (u32 *)S.casebits; O.ids = s_ids; O.cmt = s_cmt; O.rec_begin = rec_begin; O.rec_end = rec_end;
         O.unexpected = d_unexp; O.longest = d_unexp + 3 * 257; O.strict_first = o->strict ? d_unexp + 3 * 257 + 1 : nullptr; O.lead = d_unexp + 3 * 257 + 2;
-        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_rec = t_rec; O.t_tail = t_tail; O.tile_eol = t_eol;
+        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_rec = t_rec; O.t_tail = t_tail; O.tile_eol = t_eol; O.t_reg = t_reg;
         if (S.fourbit) {
             if (T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(tiles, 256), 256, 0, (const u64 *)t_seq, tiles, T, S.packed, (u32 *)S.casebits);
             LAUNCH(c, "ennaf_scatter", k_enc_scatter<true>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);

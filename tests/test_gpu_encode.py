@@ -585,6 +585,16 @@ def test_pure_tiles_and_their_edges(gpu, oracle):
     texts = []
     for w in (1, 2, 15, 16, 17, 60, 4095, 4096, 4097, 10000, 0):
         texts.append(b">r1 width %d\n" % w + wrap(seq(int(rng.integers(30000, 70000))), w) + b">r2\n" + wrap(seq(9000), w))
+    # regular tiles (k_enc_count's lattice verdict, the arithmetic gather of k_enc_scatter): line widths from the smallest that
+    # qualifies (32) to two lines per tile, every phase of line against tile and of base count against the 16-base groups, a width
+    # that changes inside a tile, one blank line or one longer line inside an otherwise regular tile, the text's last tiles
+    for w in (31, 32, 33, 34, 61, 80, 127, 255, 1000, 2040, 2047, 2048):
+        texts.append(b">w%d\n" % w + wrap(seq(int(rng.integers(90000, 140000))), w))
+    texts.append(b">two widths\n" + wrap(seq(40000), 80) + wrap(seq(40003), 81) + b">r\n" + wrap(seq(30001), 80))
+    t = wrap(seq(80000), 70); k = t.index(b"\n", 30000)
+    texts.append(b">blank inside\n" + t[:k] + b"\n" + t[k:])
+    texts.append(b">long line inside\n" + t[:k] + t[k + 1:])
+    texts.append(b">cr inside\n" + t[:k] + b"\r" + t[k:])
     texts.append(b">crlf\r\n" + wrap(seq(50000), 70, b"\r\n") + b">b\r\n" + wrap(seq(20000), 61, b"\r\n"))
     texts.append(b">blank lines\n" + wrap(seq(20000), 50) + b"\n\n\n" + wrap(seq(20000), 50, b"\n\n") + b"\x0b\x0c" + wrap(seq(5000), 33))
     texts.append(b"  \n\t\n>leading space\n" + wrap(seq(40000), 80))
