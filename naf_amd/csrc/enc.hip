@@ -641,79 +641,156 @@ struct WriteSink {
 
 // base count at the start of the line in progress where the tile begins (the line began in an earlier tile t', the one holding the
 // last EOL in front of this tile: B = t_seq[t'+1] - tail(t'))
-__device__ __forceinline__ u64 tile_line_base(const EncP &P, const EncOut &O, const i64 *tile_eol)
+__device__ __forceinline__ u64 tile_line_base(const EncP &P, const EncOut &O, const i64 *tile_eol, u64 tile)
 {
-    const i64 le = blockIdx.x ? tile_eol[blockIdx.x - 1] : -1;
+    const i64 le = tile ? tile_eol[tile - 1] : -1;
     if (le < 0 || (u64)(le + 1) <= P.p0) return 0;
     const u64 tp = (u64)le / ET_TILE;
     return O.t_seq[tp + 1] - (O.t_tail[tp] & 0x7FFFFFFFu);
 }
 
+// ---- REGULAR tiles (k_enc_count's verdict, t_reg): base b of the tile is the text byte b + (b >= p1 ? 1 + (b - p1) / (period - 1) : 0).
+// The 16 bases of an output group are fetched straight from the text (16 bytes, 17 with the line end taken out) and packed: no piece,
+// no classes, no prefix sum over the lanes, no compaction, no LDS, no barrier.  One wavefront per tile, a lane takes FOUR consecutive
+// groups aligned to four (64 bases): 32 bytes of codes and 8 bytes of case bits leave as two 16-byte stores and one 8-byte store --
+// with a group per lane the 8-byte and 2-byte stores were two thirds of the pass (6.0 ms; 2.1 ms without any store, 4.3 without the
+// 2-byte ones).  Quads that reach over the tile's ends go group by group (atomic OR into the groups shared with the neighbours).
+// Tiles that are not regular are skipped here and done by k_enc_scatter, which skips the regular ones.
+#define REG_TPW 4
+struct RegGroup { u32 ga, gb, e, nb; };
+__device__ __forceinline__ void reg_group_geometry(u32 j, u32 o, u32 span, u32 p1, u32 W, float rW, RegGroup &g, u32 &x)
+{
+    g.ga = j == 0 ? o : 0u; g.gb = span - 16 * j < 16 ? span - 16 * j : 16u;      // bytes [ga, gb) of the group are this tile's
+    const u32 b_lo = 16 * j + g.ga - o; g.nb = g.gb - g.ga;
+    if (b_lo < p1) { x = b_lo; g.e = p1 - b_lo; }                                   // text position of base b_lo; bases from it to the next line end
+    else {
+        const u32 d = b_lo - p1;
+        u32 k = (u32)((float)d * rW);
+        if (k * W > d) k--; else if ((k + 1) * W <= d) k++;
+        x = b_lo + 1 + k; g.e = W - (d - k * W);
+    }
+}
+// the group's 16 bases in place (line end taken out, moved up behind the bytes of the tile in front) -> packed codes and case bits
+__device__ __forceinline__ void reg_group_pack(const RegGroup &g, u64 lo, u64 hi, u32 c16, u64 &pk, u32 &cb)
+{
+    if (g.e < g.nb) {                                                 // the line end at byte e: everything behind it one down, byte 16 comes in
+        const u64 slo = (lo >> 8) | (hi << 56), shi = (hi >> 8) | ((u64)c16 << 56);
+        if (g.e < 8) { const u64 m = low_bytes(g.e); lo = (lo & m) | (slo & ~m); hi = shi; }
+        else { const u64 m = low_bytes(g.e - 8); hi = (hi & m) | (shi & ~m); }
+    }
+    if (g.ga) {                                                       // the group's first bytes belong to the tile in front: up by ga bytes
+        const u32 sh = 8 * g.ga;
+        if (sh < 64) { hi = (hi << sh) | (lo >> (64 - sh)); lo <<= sh; } else { hi = lo << (sh - 64); lo = 0; }
+    }
+    const u32 gw[4] = { (u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32) };
+    u32 cd[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) cd[i] = nuc4x4_quick(gw[i]);
+    pk = (u64)pack_codes8(cd[0], cd[1]) | ((u64)pack_codes8(cd[2], cd[3]) << 32);
+    const u32 H = 0x80808080u;
+    cb = swar_movemask16((gw[0] | ((gw[0] << 1) & (gw[0] << 2))) & H, (gw[1] | ((gw[1] << 1) & (gw[1] << 2))) & H,
+                         (gw[2] | ((gw[2] << 1) & (gw[2] << 2))) & H, (gw[3] | ((gw[3] << 1) & (gw[3] << 2))) & H);
+}
+__device__ __forceinline__ void reg_group_store(const EncOut &O, u64 G, const RegGroup &g, u64 pk, u32 cb)
+{
+    if (g.ga == 0 && g.gb == 16) {
+        *(u64 *)(O.packed + 8 * G) = pk;
+        if (O.casebits) ((u16 *)O.casebits)[G] = (u16)cb;
+    } else {
+        const u64 nm = (g.gb == 16 ? ~0ull : ((1ull << (4 * g.gb)) - 1)) & ~((1ull << (4 * g.ga)) - 1);
+        cb &= ((1u << g.gb) - 1) & ~((1u << g.ga) - 1);
+        atomicOr((unsigned long long *)(O.packed + 8 * G), (unsigned long long)(pk & nm));
+        if (O.casebits) atomicOr(O.casebits + (G >> 1), cb << (16 * (u32)(G & 1)));
+    }
+}
+__global__ __launch_bounds__(256) void k_enc_scatter_regular(EncP P, const i64 *tile_eol, EncOut O, u64 tiles)
+{
+    // per wavefront: the tile's packed groups and case bits on their way from "a group per lane" (loads of neighbouring lanes touch
+    // neighbouring bytes) to "four groups per lane" (wide stores); slot = group index inside the tile + lead
+    __shared__ __attribute__((aligned(16))) u64 s_pk[REG_TPW][264];
+    __shared__ __attribute__((aligned(16))) u16 s_cb[REG_TPW][264];
+    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u64 t = (u64)blockIdx.x * REG_TPW + wv;                      // the wavefront's tile
+    if (t >= tiles) return;
+    const u32 reg = O.t_reg[t];
+    const u64 tb = O.t_seq[t];
+    if (!reg) return;
+    const u32 p1 = reg & 0xFFFu, period = (reg >> 12) & 0xFFFu, E = reg >> 24, W = period - 1, n = ET_TILE - E;
+    const u32 o = (u32)(tb & 15), span = o + n, ng = (span + 15) >> 4;
+    const u64 G0 = tb >> 4;
+    const u32 lead = (u32)(G0 & 3);                                    // groups of the tile's first quad that belong to tiles in front
+    const u32 nq = (lead + ng + 3) >> 2;
+    const float rW = 1.0f / (float)W;
+    const u8 *tt = P.text + t * ET_TILE;
+    u64 *spk = s_pk[wv]; u16 *scb = s_cb[wv];
+    // phase 1: geometry and loads of groups lane, lane + 64, lane + 128, lane + 192 (all in flight together)
+    RegGroup g[4]; u64 lo[4], hi[4]; u32 c16[4]; bool in[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u32 j = 64 * (u32)i + lane;
+        in[i] = j < ng;
+        u32 x = 0;
+        if (in[i]) reg_group_geometry(j, o, span, p1, W, rW, g[i], x); else { g[i].ga = g[i].gb = g[i].e = g[i].nb = 0; }
+        const u8 *at = tt + x;
+        lo[i] = ld64(at); hi[i] = ld64(at + 8); c16[i] = at[16];
+    }
+    // phase 2: pack; whole groups wait in LDS, the two the tile shares with its neighbours go out at once
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (!in[i]) continue;
+        const u32 j = 64 * (u32)i + lane;
+        u64 pk; u32 cb; reg_group_pack(g[i], lo[i], hi[i], c16[i], pk, cb);
+        if (g[i].ga == 0 && g[i].gb == 16) { spk[lead + j] = pk; scb[lead + j] = (u16)cb; }
+        else reg_group_store(O, G0 + j, g[i], pk, cb);
+    }
+    if (ng > 256 && lane == 0) {                                       // a 257th group (few line ends and a tile that starts late in its group)
+        RegGroup g2; u32 x2; reg_group_geometry(256, o, span, p1, W, rW, g2, x2);
+        const u8 *at = tt + x2;
+        u64 pk; u32 cb; reg_group_pack(g2, ld64(at), ld64(at + 8), at[16], pk, cb);
+        if (g2.ga == 0 && g2.gb == 16) { spk[lead + 256] = pk; scb[lead + 256] = (u16)cb; } else reg_group_store(O, G0 + 256, g2, pk, cb);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // phase 3: four groups per lane, aligned to four: 32 bytes of codes and 8 bytes of case bits per lane
+    const u32 j_first_whole = o ? 1u : 0u, j_end_whole = span >> 4;      // groups [j_first_whole, j_end_whole) of the tile are whole
+    const u64 Gq0 = G0 & ~3ull;
+    for (u32 q = lane; q < nq; q += 64) {
+        const u32 s0 = 4 * q;                                           // slot of the quad's first group
+        const bool whole = s0 >= lead + j_first_whole && s0 + 4 <= lead + j_end_whole;
+        if (whole) {
+            const uint4 a = *(const uint4 *)(spk + s0), b2 = *(const uint4 *)(spk + s0 + 2);
+            uint4 *pp = (uint4 *)(O.packed + 8 * (Gq0 + s0));
+            pp[0] = a; pp[1] = b2;
+            if (O.casebits) *(uint2 *)((u16 *)O.casebits + Gq0 + s0) = *(const uint2 *)(scb + s0);
+        } else {
+#pragma unroll
+            for (u32 i = 0; i < 4; i++) {
+                const u32 sl = s0 + i;
+                if (sl >= lead + j_first_whole && sl < lead + j_end_whole) {
+                    *(u64 *)(O.packed + 8 * (Gq0 + sl)) = spk[sl];
+                    if (O.casebits) ((u16 *)O.casebits)[Gq0 + sl] = scb[sl];
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        // line lengths: the lines inside the tile hold W bases.  The one that ends at p1 began in front of the tile: when that tile is
+        // regular with the same period and its last line end lies W bases in front of p1, it holds W too; only otherwise is its
+        // start looked up (three dependent loads)
+        const u32 rp = t ? O.t_reg[t - 1] : 0u;
+        const u32 pl_prev = (rp & 0xFFFu) + ((rp >> 24) - 1) * ((rp >> 12) & 0xFFFu);
+        u64 len = W;
+        if (!(rp && ((rp >> 12) & 0xFFFu) == period && ET_TILE - 1 - pl_prev + p1 == W)) {
+            const u64 first = tb + p1 - tile_line_base(P, O, tile_eol, t);
+            if (first > len) len = first;
+        }
+        if (len > __atomic_load_n(O.longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)O.longest, (unsigned long long)len);
+    }
+}
+
 template <bool PACK>
 __global__ __launch_bounds__(256, 8) void k_enc_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, EncOut O)
 {
-    // ---- a REGULAR tile (k_enc_count's verdict, t_reg): base b of the tile is the text byte b + (b >= p1 ? 1 + (b - p1) / (period - 1) : 0).
-    // Every lane fetches the 16 bases of one output group straight from the text (16 bytes, 17 with the line end taken out) and packs
-    // them: no piece, no classes, no prefix sum over the lanes, no compaction, no LDS, no barrier.
-    if (PACK) {
-        const u32 reg = O.t_reg[blockIdx.x];
-        const u64 tbase = O.t_seq[blockIdx.x];                                // (asked for before the verdict is looked at: both paths need it)
-        if (reg) {
-            const u32 p1 = reg & 0xFFFu, period = (reg >> 12) & 0xFFFu, E = reg >> 24;
-            const u32 n = ET_TILE - E, W = period - 1;                    // bases of the tile; bases of a line
-            const u32 o = (u32)(tbase & 15), span = o + n, ng = (span + 15) >> 4;
-            const u64 G0 = tbase >> 4;
-            const float rW = 1.0f / (float)W;
-            const u8 *tt = P.text + (u64)blockIdx.x * ET_TILE;
-            for (u32 j = threadIdx.x; j < ng; j += blockDim.x) {
-                const u32 ga = j == 0 ? o : 0u, gb = span - 16 * j < 16 ? span - 16 * j : 16u;      // bytes [ga, gb) of the group are this tile's
-                const u32 b_lo = 16 * j + ga - o, nb = gb - ga;
-                u32 x, e;                                                 // text position of base b_lo; bases from it to the next line end
-                if (b_lo < p1) { x = b_lo; e = p1 - b_lo; }
-                else {
-                    const u32 d = b_lo - p1;
-                    u32 k = (u32)((float)d * rW);
-                    if (k * W > d) k--; else if ((k + 1) * W <= d) k++;
-                    x = b_lo + 1 + k; e = W - (d - k * W);
-                }
-                // 17 bytes of the text from x (any alignment; what lies behind the tile's last base is masked out below)
-                u64 lo, hi; u8 c16;
-                lo = ld64(tt + x); hi = ld64(tt + x + 8); c16 = tt[x + 16];
-                if (e < nb) {                                             // the line end at byte e: everything behind it one down, byte 16 comes in
-                    const u64 slo = (lo >> 8) | (hi << 56), shi = (hi >> 8) | ((u64)c16 << 56);
-                    if (e < 8) { const u64 m = low_bytes(e); lo = (lo & m) | (slo & ~m); hi = shi; }
-                    else { const u64 m = low_bytes(e - 8); hi = (hi & m) | (shi & ~m); }
-                }
-                if (ga) {                                                 // the group's first bytes belong to the tile in front: up by ga bytes
-                    const u32 sh = 8 * ga;
-                    if (sh < 64) { hi = (hi << sh) | (lo >> (64 - sh)); lo <<= sh; } else { hi = lo << (sh - 64); lo = 0; }
-                }
-                const u32 gw[4] = { (u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32) };
-                u32 cd[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) cd[i] = nuc4x4_quick(gw[i]);
-                const u64 pk = (u64)pack_codes8(cd[0], cd[1]) | ((u64)pack_codes8(cd[2], cd[3]) << 32);
-                const u32 H = 0x80808080u;
-                u32 cb = swar_movemask16((gw[0] | ((gw[0] << 1) & (gw[0] << 2))) & H, (gw[1] | ((gw[1] << 1) & (gw[1] << 2))) & H,
-                                         (gw[2] | ((gw[2] << 1) & (gw[2] << 2))) & H, (gw[3] | ((gw[3] << 1) & (gw[3] << 2))) & H);
-                if (ga == 0 && gb == 16) {
-                    *(u64 *)(O.packed + 8 * (G0 + j)) = pk;
-                    if (O.casebits) ((u16 *)O.casebits)[G0 + j] = (u16)cb;
-                } else {
-                    const u64 nm = (gb == 16 ? ~0ull : ((1ull << (4 * gb)) - 1)) & ~((1ull << (4 * ga)) - 1);
-                    cb &= ((1u << gb) - 1) & ~((1u << ga) - 1);
-                    atomicOr((unsigned long long *)(O.packed + 8 * (G0 + j)), (unsigned long long)(pk & nm));
-                    if (O.casebits) atomicOr(O.casebits + ((G0 + j) >> 1), cb << (16 * (u32)((G0 + j) & 1)));
-                }
-            }
-            if (threadIdx.x == 0) {                                           // line lengths: the one that ends at p1 began in front of the tile, the others hold W bases
-                const u64 line_b0 = tile_line_base(P, O, tile_eol);
-                u64 len = tbase + p1 - line_b0; if (len < W) len = W;
-                if (len > __atomic_load_n(O.longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)O.longest, (unsigned long long)len);
-            }
-            return;
-        }
-    }
+    if (PACK && O.t_reg[blockIdx.x]) return;                          // a regular tile: k_enc_scatter_regular has it
     __shared__ __attribute__((aligned(16))) u8 stage[ET_TILE + 48];
     __shared__ u32 s_a[4], s_b[4], s_l[4];
     __shared__ u64 s_best[4];
@@ -721,7 +798,7 @@ __global__ __launch_bounds__(256, 8) void k_enc_scatter(EncP P, const i64 *tile_
     const u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     const bool maybe = tile_may_be_pure(P, tile_eol);
     const u64 tbase = O.t_seq[blockIdx.x];
-    const u64 line_b0 = tile_line_base(P, O, tile_eol);
+    const u64 line_b0 = tile_line_base(P, O, tile_eol, blockIdx.x);
     Piece pc = load_piece(P, base);
     // ---- a pure tile (see k_enc_count): prefix of the base counts, the line lengths from the lanes that hold an EOL, bases to LDS,
     // packed codes and case bits out.  No per-lane context, no class table, two barriers.
@@ -1611,6 +1688,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_rec = t_rec; O.t_tail = t_tail; O.tile_eol = t_eol; O.t_reg = t_reg;
         if (S.fourbit) {
             if (T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(tiles, 256), 256, 0, (const u64 *)t_seq, tiles, T, S.packed, (u32 *)S.casebits);
+            if (n >= 2 * ET_TILE) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular, cdiv(tiles, REG_TPW), 256, 0, P, (const i64 *)t_eol, O, tiles);   // (shorter texts have no regular tile)
             LAUNCH(c, "ennaf_scatter", k_enc_scatter<true>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
         } else LAUNCH(c, "ennaf_scatter", k_enc_scatter<false>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
         std::vector<u64> hu(NU);
