@@ -249,11 +249,11 @@ __device__ __forceinline__ TileCtx thread_ctx(const EncP &P, const i64 *tile_eol
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < 3; w++) if (w < wave) ex = OpPkMaxU16::f<u32>(ex, wl[w]);
-    u64 tb = (u64)blockIdx.x * ET_TILE;
+    const u64 tile = base / ET_TILE, tb = tile * ET_TILE;           // (the workgroup's tile: not always blockIdx.x, see EncOut::irr_list)
     TileCtx c;
     // a hit inside the tile is later than anything carried in from the tiles before it
-    c.last_eol = (ex & 0xFFFF) ? (i64)(tb + (ex & 0xFFFF) - 1) : (blockIdx.x ? tile_eol[blockIdx.x - 1] : -1);
-    c.last_sp = (ex >> 16) ? (i64)(tb + (ex >> 16) - 1) : (blockIdx.x ? tile_sp[blockIdx.x - 1] : -1);
+    c.last_eol = (ex & 0xFFFF) ? (i64)(tb + (ex & 0xFFFF) - 1) : (tile ? tile_eol[tile - 1] : -1);
+    c.last_sp = (ex >> 16) ? (i64)(tb + (ex >> 16) - 1) : (tile ? tile_sp[tile - 1] : -1);
     i64 ls0 = c.last_eol + 1;
     c.hdr = (u64)ls0 < P.n && P.text[ls0] == '>';
     return c;
@@ -352,11 +352,11 @@ __device__ __forceinline__ bool seq_piece(const EncP &P, u64 base, const Piece &
 // case, LF, CR; so no '>') -- is sequence lines and nothing else:
 // every piece takes the popcount path, no lane needs its own running maxima (thread_ctx) and nothing is added to ids, comments or
 // the record table.  Long-record FASTA is pure tiles almost everywhere; the test is workgroup-uniform.
-__device__ __forceinline__ bool tile_may_be_pure(const EncP &P, const i64 *tile_eol)
+__device__ __forceinline__ bool tile_may_be_pure(const EncP &P, const i64 *tile_eol, u64 tile)
 {
-    const u64 tb = (u64)blockIdx.x * ET_TILE;
+    const u64 tb = tile * ET_TILE;
     if (tb < P.p0 || tb + ET_TILE > P.n) return false;
-    const i64 le0 = blockIdx.x ? tile_eol[blockIdx.x - 1] : -1;                // thread_ctx's c.hdr for a lane with no EOL in front of it in the tile
+    const i64 le0 = tile ? tile_eol[tile - 1] : -1;                // thread_ctx's c.hdr for a lane with no EOL in front of it in the tile
     const u64 ls0 = (u64)(le0 + 1);
     return !(ls0 < P.n && P.text[ls0] == '>');
 }
@@ -367,7 +367,7 @@ __device__ __forceinline__ u32 piece_tail_bases(const PMask &pm)
 }
 
 __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, const i64 *tile_sp,
-                                                    u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg)
+                                                    u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr)
 {
     __shared__ u8 cls[256];
     __shared__ u32 s_a[4], s_b[4], s_last[4];
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
     // last position, period and verdict; the tile's first lane puts the four together -- no barrier beyond the one the counts need.
     __shared__ u32 r_cnt[4], r_first[4], r_last[4], r_per[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool maybe = tile_may_be_pure(P, tile_eol);
+    const bool maybe = tile_may_be_pure(P, tile_eol, blockIdx.x);
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
     {
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
             }
             // (the gather of the scatter pass reads up to 17 bytes from a base's position: not in the text's last tiles)
             const bool tile_ok = ok && E >= 2 && period >= 33 && ((u64)blockIdx.x + 1) * ET_TILE + 32 <= P.n;
-            t_reg[blockIdx.x] = tile_ok ? (p1 | (period << 12) | (E << 24)) : 0u;
+            t_reg[blockIdx.x] = tile_ok ? (p1 | (period << 12) | (E << 24)) : 0u; t_irr[blockIdx.x] = tile_ok ? 0 : 1;
             u32 tot = 0, tail = 0; bool found = false;
 #pragma unroll
             for (int w = 3; w >= 0; w--) { tot += s_a[w] & 0xFFFF; if (!found) { tail += s_a[w] >> 16; found = (s_last[w] & 1u) != 0; } }
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
     if (threadIdx.x == 0) {
         t_seq[blockIdx.x] = tota & 0xFFFF; t_ids[blockIdx.x] = tota >> 16; t_cmt[blockIdx.x] = totb & 0xFFFF; t_rec[blockIdx.x] = totb >> 16;
         if (!last) t_tail[blockIdx.x] = tota & 0xFFFF;
-        t_reg[blockIdx.x] = 0;
+        t_reg[blockIdx.x] = 0; t_irr[blockIdx.x] = 1;
     }
     if (threadIdx.x + 1 == last) t_tail[blockIdx.x] = ((tota & 0xFFFF) - ((pre + wa) & 0xFFFF) + S.tail) | 0x80000000u;
 }
@@ -496,6 +496,7 @@ struct EncOut {
     u64 *lead;                    // bases in front of the first header (a shard that starts inside a record; 0 for a whole input)
     u64 *strict_first;            // --strict: min over strict_key of the unexpected bytes (nullptr otherwise)
     const u64 *t_seq, *t_ids, *t_cmt, *t_rec; const u32 *t_tail; const i64 *tile_eol;
+    const u32 *irr_list;          // k_enc_scatter<true>: the tiles that are not regular, in order (workgroup b takes irr_list[b]); nullptr: every tile
     const u32 *t_reg;             // k_enc_count's verdict on a tile: p1 | period << 12 | line ends << 24 when it is regular, else 0
 };
 
@@ -577,6 +578,12 @@ __device__ __forceinline__ void flush_pack(const EncP &P, u8 *packed, u32 *caseb
             if (casebits) atomicOr(casebits + ((G0 + j) >> 1), cb << (16 * (u32)((G0 + j) & 1)));
         }
     }
+}
+// the tiles k_enc_count did not find regular, in order (pre = exclusive scan of its 0 / 1 verdicts)
+__global__ void k_irregular_list(const u32 *t_reg, const u64 *pre, u64 tiles, u32 *list)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < tiles && !t_reg[t]) list[pre[t]] = (u32)t;
 }
 // the groups a tile shares with its neighbours (and the last group of the stream, whose padding must read as zero)
 __global__ void k_pack_edges_zero(const u64 *t_seq, u64 tiles, u64 T, u8 *packed, u32 *casebits)
@@ -790,15 +797,15 @@ __global__ __launch_bounds__(256) void k_enc_scatter_regular(EncP P, const i64 *
 template <bool PACK>
 __global__ __launch_bounds__(256, 8) void k_enc_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, EncOut O)
 {
-    if (PACK && O.t_reg[blockIdx.x]) return;                          // a regular tile: k_enc_scatter_regular has it
+    const u64 tile = (PACK && O.irr_list) ? O.irr_list[blockIdx.x] : blockIdx.x;   // regular tiles are k_enc_scatter_regular's
     __shared__ __attribute__((aligned(16))) u8 stage[ET_TILE + 48];
     __shared__ u32 s_a[4], s_b[4], s_l[4];
     __shared__ u64 s_best[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
-    const bool maybe = tile_may_be_pure(P, tile_eol);
-    const u64 tbase = O.t_seq[blockIdx.x];
-    const u64 line_b0 = tile_line_base(P, O, tile_eol, blockIdx.x);
+    const u64 base = (u64)tile * ET_TILE + (u64)threadIdx.x * ET_BYTES;
+    const bool maybe = tile_may_be_pure(P, tile_eol, tile);
+    const u64 tbase = O.t_seq[tile];
+    const u64 line_b0 = tile_line_base(P, O, tile_eol, tile);
     Piece pc = load_piece(P, base);
     // ---- a pure tile (see k_enc_count): prefix of the base counts, the line lengths from the lanes that hold an EOL, bases to LDS,
     // packed codes and case bits out.  No per-lane context, no class table, two barriers.
@@ -885,7 +892,7 @@ __global__ __launch_bounds__(256, 8) void k_enc_scatter(EncP P, const i64 *tile_
     ia += prea;
     u32 iseq = ia & 0xFFFF, iids = ia >> 16, tile_seq = tota & 0xFFFF;
     WriteSink W(O); W.tbase = tbase; W.stage = stage + (PACK ? (u32)(W.tbase & 15) : 0u);   // PACK: groups of 16 bases aligned in LDS
-    W.bseq = W.tbase + iseq - C.nseq; W.bids = O.t_ids[blockIdx.x] + iids - C.nids;
+    W.bseq = W.tbase + iseq - C.nseq; W.bids = O.t_ids[tile] + iids - C.nids;
     // base count at the start of the line this thread begins in: B at the most recent EOL before `base`.
     // Within the tile: B at an EOL is non-decreasing with position, so a running max over earlier threads works
     // (tile-relative and +1, so that 0 means "none").
@@ -897,7 +904,7 @@ __global__ __launch_bounds__(256, 8) void k_enc_scatter(EncP P, const i64 *tile_
 #pragma unroll
     for (int w = 0; w < 3; w++) if (w < wave) { preb += s_b[w]; prev = s_l[w] > prev ? s_l[w] : prev; }
     ib += preb;
-    W.bcmt = O.t_cmt[blockIdx.x] + (ib & 0xFFFF) - C.ncmt; W.rec = O.t_rec[blockIdx.x] + (ib >> 16) - C.nrec;
+    W.bcmt = O.t_cmt[tile] + (ib & 0xFFFF) - C.ncmt; W.rec = O.t_rec[tile] + (ib >> 16) - C.nrec;
     if (prev) W.line_b = W.tbase + prev - 1;
     else W.line_b = line_b0;                                      // the line began in an earlier tile
     W.best = 0;
@@ -1657,23 +1664,27 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         u64 tiles = n / ET_TILE + 1;                                                              // +1: the virtual end-of-input byte
         i64 *t_eol = arena_new<i64>(c, tiles + 1), *t_sp = arena_new<i64>(c, tiles + 1);
         u64 *t_seq = arena_new<u64>(c, tiles + 2), *t_ids = arena_new<u64>(c, tiles + 2), *t_cmt = arena_new<u64>(c, tiles + 2), *t_rec = arena_new<u64>(c, tiles + 2);
-        u32 *t_tail = arena_new<u32>(c, tiles + 1), *t_reg = arena_new<u32>(c, tiles + 1);
+        u32 *t_tail = arena_new<u32>(c, tiles + 1), *t_reg = arena_new<u32>(c, tiles + 1), *irr_list = arena_new<u32>(c, tiles + 1);
+        u64 *t_irr = arena_new<u64>(c, tiles + 2);
         u64 *tot = arena_new<u64>(c, 8);
-        if (!t_eol || !t_sp || !t_seq || !t_ids || !t_cmt || !t_rec || !t_tail || !t_reg || !tot) return NAF_GPU_ENOMEM;
+        if (!t_eol || !t_sp || !t_seq || !t_ids || !t_cmt || !t_rec || !t_tail || !t_reg || !irr_list || !t_irr || !tot) return NAF_GPU_ENOMEM;
         LAUNCH(c, "ennaf_last", k_enc_last_fa, cdiv(tiles, 4 * LAST_TPW), 256, 0, P, t_eol, t_sp, tiles);
         // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
         if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
         if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
-        LAUNCH(c, "ennaf_count", k_enc_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg);
+        LAUNCH(c, "ennaf_count", k_enc_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr);
         if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
         if ((rc = scan_exclusive_u64(c, t_ids, tiles, tot + 1))) return rc;
         if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;
         if ((rc = scan_exclusive_u64(c, t_rec, tiles, tot + 3))) return rc;
+        if ((rc = scan_exclusive_u64(c, t_irr, tiles, tot + 4))) return rc;
+        LAUNCH(c, "ennaf_irregular_list", k_irregular_list, cdiv(tiles, 256), 256, 0, (const u32 *)t_reg, (const u64 *)t_irr, tiles, irr_list);
         // t_seq[tiles] must hold the grand total for the "line began in an earlier tile" lookup
         HIP_TRY(c, hipMemcpyAsync(t_seq + tiles, tot + 0, 8, hipMemcpyDeviceToDevice, c->stream));
-        u64 h[4];
-        if ((rc = ctx_readback(c, h, tot, 32))) return rc;
+        u64 h[5];
+        if ((rc = ctx_readback(c, h, tot, 40))) return rc;
         T = h[0]; n_ids = h[1]; n_cmt = h[2]; N = h[3];
+        const u64 n_irregular = h[4];
         if ((rc = alloc_bases(c, S))) return rc;
         s_ids = (u8 *)arena_alloc(c, n_ids + 16); s_cmt = (u8 *)arena_alloc(c, n_cmt + 16);
         rec_begin = arena_new<u64>(c, N + 1); rec_end = arena_new<u64>(c, N + 1);
@@ -1685,11 +1696,11 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         HIP_TRY(c, hipMemsetAsync(rec_begin, 0, (N + 1) * 8, c->stream));
         EncOut O; O.seq = bases; O.packed = S.packed; O.casebits = (u32 *)S.casebits; O.ids = s_ids; O.cmt = s_cmt; O.rec_begin = rec_begin; O.rec_end = rec_end;
         O.unexpected = d_unexp; O.longest = d_unexp + 3 * 257; O.strict_first = o->strict ? d_unexp + 3 * 257 + 1 : nullptr; O.lead = d_unexp + 3 * 257 + 2;
-        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_rec = t_rec; O.t_tail = t_tail; O.tile_eol = t_eol; O.t_reg = t_reg;
+        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_rec = t_rec; O.t_tail = t_tail; O.tile_eol = t_eol; O.t_reg = t_reg; O.irr_list = S.fourbit ? irr_list : nullptr;
         if (S.fourbit) {
             if (T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(tiles, 256), 256, 0, (const u64 *)t_seq, tiles, T, S.packed, (u32 *)S.casebits);
             if (n >= 2 * ET_TILE) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular, cdiv(tiles, REG_TPW), 256, 0, P, (const i64 *)t_eol, O, tiles);   // (shorter texts have no regular tile)
-            LAUNCH(c, "ennaf_scatter", k_enc_scatter<true>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+            if (n_irregular) LAUNCH(c, "ennaf_scatter", k_enc_scatter<true>, n_irregular, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
         } else LAUNCH(c, "ennaf_scatter", k_enc_scatter<false>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
         std::vector<u64> hu(NU);
         if ((rc = ctx_readback(c, hu.data(), d_unexp, NU * 8))) return rc;
