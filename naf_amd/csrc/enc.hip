@@ -382,18 +382,21 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
     u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
     {
-        // per wave: bases, and bases behind the wave's last EOL, in one packed reduction.  Plain pieces only (quick letters, LF, CR):
-        // their line ends are their only space-class bytes
+        // Plain pieces only (quick letters, LF, CR): their line ends are their only space-class bytes, so a pure tile's base counts
+        // are arithmetic on positions -- 4096 less its line-end bytes, and what follows the last of them -- no prefix sum.  Per wave:
+        // the number of line-end bytes and the position of the last one.
         const u32 w[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) };
         PMask pl; pl.gt = 0;
         const bool plain = piece_plain(w, P.plo, P.phi, &pl.eol); pl.sp = pl.eol;
-        const u32 nseq = 16u - (u32)__popc(pl.sp);
         const u64 bal = __ballot(pl.eol != 0);
         const int lastl = bal ? 63 - __clzll((long long)bal) : -1;
-        const u32 after = lane > lastl ? nseq : (lane == lastl ? piece_tail_bases(pl) : 0u);
-        const u32 red = wave_scan_inclusive<u32, OpAdd>(nseq | (after << 16));
+        const bool two = __ballot((pl.eol & (pl.eol - 1)) != 0) != 0;                                // some piece holds two line-end bytes (CR LF, short lines)
+        u32 nb = (u32)__popcll(bal);
+        if (two) nb = (u32)__builtin_amdgcn_readlane((int)wave_scan_inclusive<u32, OpAdd>((u32)__popc(pl.eol)), 63);
+        const u32 hib = threadIdx.x * ET_BYTES + (pl.eol ? 31u - (u32)__clz((int)pl.eol) : 0u);
+        const u32 lastpos = (u32)__builtin_amdgcn_readlane((int)hib, lastl < 0 ? 0 : lastl);
         const bool wave_bad = __ballot(!plain) != 0;
-        if (lane == 63) { s_a[wave] = red; s_last[wave] = (bal ? 1u : 0u) | (wave_bad ? 2u : 0u); }
+        if (lane == 0) { s_a[wave] = nb | (lastpos << 16); s_last[wave] = (bal ? 1u : 0u) | (wave_bad ? 2u : 0u); }
         if (maybe) {
             const bool has = pl.eol != 0;
             const u32 q = threadIdx.x * ET_BYTES + (has ? (u32)__ffs((int)pl.eol) - 1 : 0u);         // position of the lane's line end in the tile
@@ -404,8 +407,7 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
             const u32 q1 = (u32)__builtin_amdgcn_readlane((int)q, f1), q2 = (u32)__builtin_amdgcn_readlane((int)q, f2);
             const u32 ql = (u32)__builtin_amdgcn_readlane((int)q, lastl < 0 ? 0 : lastl);
             const u32 per = bal2 ? q2 - q1 : 0u;                                                      // 0: fewer than two line ends in this wave
-            const bool lane_bad = (pl.eol & (pl.eol - 1)) != 0 || (has && mlow && q - qprev != per); // two in one piece, or off the wave's lattice
-            const bool wbad = __ballot(lane_bad) != 0;
+            const bool wbad = two || __ballot(has && mlow && q - qprev != per) != 0;                 // two in one piece, or off the wave's lattice
             if (lane == 0) { r_cnt[wave] = (u32)__popcll(bal) | (wbad ? 0x10000u : 0u); r_first[wave] = q1; r_last[wave] = ql; r_per[wave] = per; }
         }
     }
@@ -427,9 +429,9 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
             // (the gather of the scatter pass reads up to 17 bytes from a base's position: not in the text's last tiles)
             const bool tile_ok = ok && E >= 2 && period >= 33 && ((u64)blockIdx.x + 1) * ET_TILE + 32 <= P.n;
             t_reg[blockIdx.x] = tile_ok ? (p1 | (period << 12) | (E << 24)) : 0u; t_irr[blockIdx.x] = tile_ok ? 0 : 1;
-            u32 tot = 0, tail = 0; bool found = false;
+            u32 tot = ET_TILE, tail = 0; bool found = false;
 #pragma unroll
-            for (int w = 3; w >= 0; w--) { tot += s_a[w] & 0xFFFF; if (!found) { tail += s_a[w] >> 16; found = (s_last[w] & 1u) != 0; } }
+            for (int w = 3; w >= 0; w--) { tot -= s_a[w] & 0xFFFF; if (!found && (s_last[w] & 1u)) { tail = ET_TILE - 1 - (s_a[w] >> 16); found = true; } }
             t_seq[blockIdx.x] = tot; t_ids[blockIdx.x] = 0; t_cmt[blockIdx.x] = 0; t_rec[blockIdx.x] = 0;
             t_tail[blockIdx.x] = found ? (tail | 0x80000000u) : tot;
         }
