@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
             for (u32 k = 0; k < 4; k++) { wg_scan_inclusive<u64, OpAdd>((u64)hist[256 * k + sym] * l, &bits, red); p.ssz[k] = (u32)((bits + 1 + 7) / 8); }
             __syncthreads();
             u32 tb = ws.tb;
-            if (tb) { zenc_plan_finish(p, bn, log, tb, min_gain); huf = p.kind == ZK_HUF; }
+            if (tb) { zenc_plan_finish(p, bn, log, tb, min_gain); huf = p.kind == ZK_HUF; if (huf && log == 4 && distinct == 16) p.pad = 1; }   // pad = 1: sixteen 4-bit codes (k_zenc_write packs such a block with all lanes)
         }
     }
     if (threadIdx.x == 0) { plan[b] = p; if (csize) csize[b] = p.csize; }
@@ -627,6 +627,39 @@ __device__ __forceinline__ void huf_encode_stream_staged(u8 *out, const u8 *src,
     for (u32 k = lo; k < fill; k++) seg[k] = orow[k];
 }
 
+// A stream of a block whose sixteen symbols all have 4-bit codes is a string of nibbles: nibble q of the stream is the code of
+// symbol n-1-q (the last symbol is read first, 4.2.2), nibble n the end marker.  Nothing is serial: a lane packs 32 symbols into 16
+// bytes, the wave covers 1024 bytes of the stream per round.  (Packed random bases: every block -- the one-lane-per-stream writer
+// below then has nothing to do.)
+__device__ __forceinline__ void zenc_flat4_stream(u8 *out, const u8 *s, u32 n, const u16 *codes, u32 lane)
+{
+    const u32 B = (4 * n + 8) >> 3;                                   // bytes of the stream
+    for (u32 t0 = lane * 16; t0 < B; t0 += 64 * 16) {
+        const u32 q0 = 2 * t0;
+        if (q0 + 32 <= n) {
+            uint4 v0, v1; __builtin_memcpy(&v0, s + (n - 32 - q0), 16); __builtin_memcpy(&v1, s + (n - 16 - q0), 16);
+            // bytes n-32-q0 .. n-1-q0; nibble q0 + i is the code of byte 31 - i
+            const u32 wd[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+            u64 lo = 0, hi = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const u32 a = (wd[(31 - i) >> 2] >> (8 * ((31 - i) & 3))) & 0xFFu, b2 = (wd[(15 - i) >> 2] >> (8 * ((15 - i) & 3))) & 0xFFu;
+                lo |= (u64)(codes[a] & 0xFu) << (4 * i);
+                hi |= (u64)(codes[b2] & 0xFu) << (4 * i);
+            }
+            const uint4 o4 = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+            __builtin_memcpy(out + t0, &o4, 16);
+        } else {
+            const u32 t1 = t0 + 16 < B ? t0 + 16 : B;
+            for (u32 t = t0; t < t1; t++) {
+                const u32 qa = 2 * t, qb = qa + 1;
+                const u32 na = qa < n ? (codes[s[n - 1 - qa]] & 0xFu) : (qa == n ? 1u : 0u), nbv = qb < n ? (codes[s[n - 1 - qb]] & 0xFu) : (qb == n ? 1u : 0u);
+                out[t] = (u8)(na | (nbv << 4));
+            }
+        }
+    }
+}
+
 // LZ-coded blocks (mode[b] != 0) take their literals from L.lits with the plan / codes / tree of those literals (plan1 ...)
 // and append the Sequences_Section made by k_lz_seqenc; all other blocks are coded from src as literal-only blocks.
 struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u16 *codes1; const u8 *trees1; LzBufs B; u32 not_last; };   // not_last: the frame continues behind these blocks (a shard's part of a frame)
@@ -648,11 +681,26 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
         if (lane < 32) ((uint4 *)codes[jj])[lane] = g[lane];
     }
     __syncthreads();
+    // blocks of sixteen 4-bit codes: the whole wave, a stream after the other
+    for (u32 jj = 0; jj < ZENC_BLOCKS_PER_WG; jj++) {
+        const u32 bb = b0 + jj;
+        if (bb >= nblk) break;
+        if (L.mode && L.mode[bb]) continue;
+        const ZEncPlan p = plan[bb];
+        if (p.kind != ZK_HUF || !p.pad) continue;
+        u8 *out = dst + frame_hdr + offs[bb];
+        const u64 lo = zenc_block_lo(n, nblk, bb);
+        if (lane == 0) { zenc_write_block_prefix(out, p, trees + (u64)bb * ZENC_TREE_SLOT, bb + 1 == nblk && !L.not_last, src[lo]); out[p.csize - 1] = 0; }
+        const u32 per = (p.n + 3) / 4;
+        u32 o = 3 + p.lhdr + p.tree_bytes + 6;
+        for (u32 q = 0; q < 4; q++) { zenc_flat4_stream(out + o, src + lo + (u64)q * per, q < 3 ? per : p.n - 3 * per, codes[jj], (u32)lane); o += p.ssz[q]; }
+    }
     u32 j = lane >> 2, k = lane & 3, b = b0 + j;
     if (b < nblk) {
         const bool lzb = L.mode && L.mode[b];
         u8 *out = dst + frame_hdr + offs[b];
-        if (!lzb) {
+        if (!lzb && plan[b].kind == ZK_HUF && plan[b].pad) { }          // written above
+        else if (!lzb) {
             const ZEncPlan p = plan[b];
             u64 lo = zenc_block_lo(n, nblk, b);
             if (k == 0) zenc_write_block_prefix(out, p, trees + (u64)b * ZENC_TREE_SLOT, b + 1 == nblk && !L.not_last, p.n ? src[lo] : 0);
