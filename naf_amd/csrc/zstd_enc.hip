@@ -211,6 +211,10 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
                 if (sym == 0) { ce->tb = ws.tb; ce->key = ws.tb ? hk : 0; }
             }
             u64 bits;
+            if (flat_log) {                                                      // every code flat_log bits: a quarter's bits are its length times that
+                const u32 perq = (bn + 3) / 4;
+                for (u32 k = 0; k < 4; k++) p.ssz[k] = ((k < 3 ? perq : bn - 3 * perq) * flat_log + 8) >> 3;
+            } else
             for (u32 k = 0; k < 4; k++) { wg_scan_inclusive<u64, OpAdd>((u64)hist[256 * k + sym] * l, &bits, red); p.ssz[k] = (u32)((bits + 1 + 7) / 8); }
             __syncthreads();
             u32 tb = ws.tb;
@@ -218,6 +222,12 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
         }
     }
     if (threadIdx.x == 0) { plan[b] = p; if (csize) csize[b] = p.csize; }
+    if (huf && p.log && ws.len[plist[0]] == p.log && distinct == (1u << p.log)) {
+        // one weight group (2^log symbols of log bits): the code of a symbol is its rank among the symbols that occur
+        const u32 l = ws.len[sym];
+        codes[(u64)b * 256 + sym] = l ? (u16)(myidx | (l << 12)) : (u16)0;
+        if (sym < p.tree_bytes) trees[(u64)b * ZENC_TREE_SLOT + sym] = ws.tree[sym];
+    } else
     if (huf) {
         // canonical codes (huf_assign_codes): symbols of one weight take consecutive cells in symbol order, so the code of a
         // symbol is its weight group's first cell >> (weight - 1) plus its rank inside the group
