@@ -1526,8 +1526,14 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         pool_cap = want_pool > 0xFFFFF000ull ? 0xFFFFF000u : (u32)want_pool;
         huf_pool = (u8 *)arena_alloc(c, pool_cap);
         if (!huf_pool) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "zstd_build_huf", k_build_huf_few, 1024, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, (const u64 *)r4, (const i32 *)own_huf);
-        LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)r4, always_table, (const i32 *)own_huf, 1u);
+        if (nblk <= 16384) {
+            // a stream of a few thousand blocks (a soft-masked genome's mask: a tree per block): a wavefront per block, all at once --
+            // one lane per tree (k_build_huf) is 0.35 ms of serial table building in front of the literals there
+            LAUNCH(c, "zstd_build_huf", k_build_huf_lds, nblk, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const i32 *)own_huf);
+        } else {
+            LAUNCH(c, "zstd_build_huf", k_build_huf_few, 1024, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, (const u64 *)r4, (const i32 *)own_huf);
+            LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)r4, always_table, (const i32 *)own_huf, 1u);
+        }
         ZSplit *sp = c->zsplit;
         if (sp && !rg && sp->parts >= 2) {
             ends = extra + 8;
