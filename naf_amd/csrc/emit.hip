@@ -841,7 +841,7 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     // address translation then covers an eighth of the pages in flight.  xcd_chunk = 0: workgroups in launch order.
     u32 wg = blockIdx.x;
     if (xcd_chunk) { wg = (blockIdx.x & 7u) * xcd_chunk + (blockIdx.x >> 3); if ((u64)wg * FLAT_TPW >= ntiles) return; }
-    __shared__ u64 s_tog[EMIT_TOG_LDS];
+    __shared__ u64 s_tog[FLAT_TPW][EMIT_TOG_LDS];                  // every tile's window of mask toggles (a dozen per tile of a soft-masked genome)
     // a line end inside a chunk: bytes in front of it stay, the byte at it becomes '\n', bytes behind it take the byte in front of
     // them -- per position d of the line end, sixteen v_perm_b32 selector bytes (source = this dword and the one below it; 0x0C
     // selects a zero byte) and the sixteen bytes to OR in
@@ -915,7 +915,19 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         offs[j] = off;
         haves[j] = need > rem ? rem : 16u;                            // it runs over the end of that stream: the rest is the top of the next one
     }
-    __syncthreads();                                              // s_spl (the loads are in flight meanwhile)
+    // the toggles of the four tiles' windows: fetched with the codes (after them: a wait in the middle of phase 2, tile after tile, was
+    // half a millisecond per 4 GB of a soft-masked genome) and parked in LDS before the barrier that s_spl needs anyway
+    if (P.masking) {
+        u64 tg[FLAT_TPW];
+#pragma unroll
+        for (u32 j = 0; j < FLAT_TPW; j++) {
+            const u64 nt = A[j].khi - A[j].k;
+            tg[j] = (live[j] && threadIdx.x < nt && nt <= EMIT_TOG_LDS) ? P.toggles[A[j].k + threadIdx.x] : 0ull;
+        }
+#pragma unroll
+        for (u32 j = 0; j < FLAT_TPW; j++) s_tog[j][threadIdx.x] = tg[j];
+    }
+    __syncthreads();                                              // s_spl, s_tog (the loads are in flight meanwhile)
     // ---- phase 2: codes -> characters, mask, line ends, store
 #pragma unroll
     for (u32 j = 0; j < FLAT_TPW; j++) {
@@ -944,12 +956,8 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
         }
         const u32 ntog = (u32)(a.khi - a.k < EMIT_TOG_LDS ? a.khi - a.k : EMIT_TOG_LDS);
         const bool use_tog = P.masking && a.k < a.khi && a.khi - a.k <= EMIT_TOG_LDS;
-        if (use_tog) {
-            __syncthreads();
-            for (u32 i = threadIdx.x; i < ntog; i += 256) s_tog[i] = P.toggles[a.k + i];
-            __syncthreads();
-            mask16_from(s_tog, ntog, a.k, g0, lo, hi);
-        } else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
+        if (use_tog) mask16_from(s_tog[j], ntog, a.k, g0, lo, hi);
+        else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
         uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
         if (nls[j] < 16) {
             const uint4 sel = s_spl[2 * nls[j]], orv = s_spl[2 * nls[j] + 1];
