@@ -170,3 +170,21 @@ def repeat_genome(seed=3, unit=40000, copies=50):
     for k in range(3):
         out += b">rep%d repeat-rich synthetic\n" % k + wrap_lines(seq[k * third:(k + 1) * third], 60)
     return out
+
+
+def softmask_device(text, seed=3, lo=20, hi=600):
+    """Soft-mask a device FASTA text in place: alternating upper / lower-case runs of lo..hi-1 bases (uniform), the way repeat-masked
+    genome assemblies look (about half of the bases in lower case).  Letters of header lines change case too: harmless for the codec."""
+    import torch
+    n = text.numel()
+    gen = torch.Generator(device=text.device); gen.manual_seed(seed)
+    nruns = n // ((lo + hi) // 2 - 60) + 16
+    bounds = torch.cumsum(torch.randint(lo, hi, (nruns,), device=text.device, generator=gen), 0)
+    CH = 1 << 28
+    for s in range(0, n, CH):
+        e = min(n, s + CH)
+        pos = torch.arange(s, e, device=text.device)
+        par = torch.searchsorted(bounds, pos, right=True) & 1
+        seg = text[s:e]
+        seg[((seg >= 65) & (seg <= 90)) & (par == 1)] += 32
+    return text
