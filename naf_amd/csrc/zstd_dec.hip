@@ -349,7 +349,7 @@ __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 
 // The same for streams of a few blocks (ids, names, lengths, the last block of a mask stream): one block per workgroup, the tree
 // description, the weights, the builder's workspace and the table in LDS, so that the lone working lane waits for LDS, not for
 // scratch memory (0.3 - 1 ms per launch otherwise, on the critical path of every small stream).
-struct HufLdsWS { HufBuildWS ws; __attribute__((aligned(16))) u8 in[192], w[256]; __attribute__((aligned(16))) u16 tab[HUFC_BYTES / 2 > 256 ? HUFC_BYTES / 2 : 256]; u32 log, off; };
+struct HufLdsWS { HufBuildWS ws; __attribute__((aligned(16))) u8 in[192], w[256]; __attribute__((aligned(16))) u16 tab[HUF_TAB_MAX / 2]; u32 log, off; };
 __device__ void build_huf_one_lds(const u8 *src, ZBlock *blk, u32 i, u8 *pool, u32 pool_cap, ZStat *st, HufLdsWS &S)
 {
     const u8 *c = src + blk[i].src_off + blk[i].lit_off;
@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(64) void k_small_frame(const u8 *src, u32 len, u8 *
     __shared__ __attribute__((aligned(16))) u8 s_src[SMALL_SRC + 16], s_out[SMALL_OUT + 16], s_lit[SMALL_OUT + 16];
     __shared__ u32 s_ll[SMALL_SEQ], s_ml[SMALL_SEQ], s_of[SMALL_SEQ];
     __shared__ HufBuildWS ws;
-    __shared__ __attribute__((aligned(16))) u16 huf[HUFC_BYTES / 2 > 256 ? HUFC_BYTES / 2 : 256];
+    __shared__ __attribute__((aligned(16))) u16 huf[HUF_TAB_MAX / 2];
     __shared__ FseE fse[512 + 256 + 512];
     __shared__ FseE s_predef[160];
     __shared__ u8 w[256];
@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(64) void k_small_frames(SmallJobs J, const FseE *pr
     __shared__ __attribute__((aligned(16))) u8 s_src[SMALL_SRC + 16], s_out[SMALL_OUT + 16], s_lit[SMALL_OUT + 16];
     __shared__ u32 s_ll[SMALL_SEQ], s_ml[SMALL_SEQ], s_of[SMALL_SEQ];
     __shared__ HufBuildWS ws;
-    __shared__ __attribute__((aligned(16))) u16 huf[HUFC_BYTES / 2 > 256 ? HUFC_BYTES / 2 : 256];
+    __shared__ __attribute__((aligned(16))) u16 huf[HUF_TAB_MAX / 2];
     __shared__ FseE fse[512 + 256 + 512];
     __shared__ FseE s_predef[160];
     __shared__ u8 w[256];
@@ -1522,7 +1522,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             LAUNCH(c, "zstd_find_range", k_find_range, 1, 64, 0, (const u64 *)sizes, nblk, (const u64 *)d_total_out, rg->want_lo, rg->want_hi, (const i32 *)own_huf, r4);
             ranged_build = true;
         }
-        const u64 want_pool = (u64)nblk * HUFC_BYTES + 4096;
+        const u64 want_pool = (u64)nblk * HUF_TAB_MAX + 4096;
         pool_cap = want_pool > 0xFFFFF000ull ? 0xFFFFF000u : (u32)want_pool;
         huf_pool = (u8 *)arena_alloc(c, pool_cap);
         if (!huf_pool) return NAF_GPU_ENOMEM;
@@ -1655,7 +1655,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         // tables of the blocks that will be decoded (and of the earlier blocks that own a table in force there)
         u32 hb_end = b_first + b_count, hb_n = hb_end - huf_first;
         if (!tables_built) {
-            pool_cap = (hb_n < n_huf_def ? hb_n : n_huf_def) * (u32)HUFC_BYTES + 4096u;   // largest table form (log > 8: compact)
+            pool_cap = (hb_n < n_huf_def ? hb_n : n_huf_def) * (u32)HUF_TAB_MAX + 4096u;   // largest table of either form
             huf_pool = (u8 *)arena_alloc(c, pool_cap);
             if (!huf_pool) return NAF_GPU_ENOMEM;
             if (hb_n && hb_n <= 512) LAUNCH(c, "zstd_build_huf", k_build_huf_lds, hb_n, 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first, (const i32 *)own_huf);
@@ -1663,7 +1663,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
             if (hs.err) return zerr(c, hs.err, "Huffman tables");
         }
-        u32 slot = huf_tab_bytes(hs.max_huf_log);
+        u32 slot = huf_slot_bytes(hs.max_huf_log);
         u32 b_end = b_first + b_count;
         if (fuse && hs.max_huf_log > 7) return ZSTD_NEED_TWO_PASS;
         EmitP ep; memset(&ep, 0, sizeof ep); if (fuse) ep = *fuse;

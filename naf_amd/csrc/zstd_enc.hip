@@ -31,7 +31,7 @@ __host__ __device__ static inline u64 zenc_block_lo(u64 n, u32 nblk, u32 b) { u6
 
 // blk_len == nullptr: block b is the b-th piece of the even split of src[0..n).  Otherwise block b is src[b*slot .. b*slot + blk_len[b])
 // (the literals the LZ stage left of block b).
-__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse, u32 min_gain)
+__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse, u32 min_gain, u32 maxbits)
 {
     // ZENC_HCOPIES copies of the 4 quarter histograms (copy = lane % copies): few distinct symbols (packed ACGT has 16) would
     // otherwise serialise every LDS atomic of a wave on the same handful of addresses
@@ -173,10 +173,10 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
                 const u32 dl = (u32)__shfl((int)di, (int)(pl & 63), 64) + 1;
                 u32 mx = lane < n ? dl : 0;
                 for (int d = 32; d; d >>= 1) { u32 o = (u32)__shfl_xor((int)mx, d, 64); mx = o > mx ? o : mx; }
-                if (mx <= ZENC_HUF_MAXBITS) { if (lane < n) ws.len[ws.order[lane]] = (u8)dl; if (lane == 0) ws.log = mx; }
-                else if (lane == 0) ws.log = huf_lengths_sorted(ws.tot, ws.order, distinct, ws.len, ws.w, ws.parent, ws.depth);
+                if (mx <= maxbits) { if (lane < n) ws.len[ws.order[lane]] = (u8)dl; if (lane == 0) ws.log = mx; }
+                else if (lane == 0) ws.log = huf_lengths_sorted(ws.tot, ws.order, distinct, ws.len, ws.w, ws.parent, ws.depth, maxbits);
             }
-        } else if (threadIdx.x == 0) ws.log = huf_lengths_sorted(ws.tot, ws.order, distinct, ws.len, ws.w, ws.parent, ws.depth);
+        } else if (threadIdx.x == 0) ws.log = huf_lengths_sorted(ws.tot, ws.order, distinct, ws.len, ws.w, ws.parent, ws.depth, maxbits);
         __syncthreads();
         u32 log = ws.log;
         if (log) {
@@ -851,6 +851,8 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     J->src = d_src; J->n = n;
     const bool part = (with_magic & ZENC_PART) != 0, part_first = (with_magic & ZENC_PART_FIRST) != 0, part_last = (with_magic & ZENC_PART_LAST) != 0;
     const u32 min_gain = (with_magic & ZENC_PREFER_RAW) ? 32u : 0u;
+    // (the same streams -- the mask -- keep their codes to 9 bits: this build's decoder then walks them with its single-level table)
+    const u32 maxbits = (with_magic & ZENC_PREFER_RAW) ? 9u : (u32)ZENC_HUF_MAXBITS;
     with_magic &= ~ZENC_PREFER_RAW;
     if (part) with_magic = 0;
     if (part && n == 0 && !part_last) {
@@ -894,8 +896,8 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     ZTreeCache *cache = sample_stride ? arena_new<ZTreeCache>(c, 1) : nullptr;
     if (!plan || !codes || !trees || !offs || (sample_stride && !cache)) return NAF_GPU_ENOMEM;
     if (cache) HIP_TRY(c, hipMemsetAsync(cache, 0, sizeof(ZTreeCache), c->stream));
-    if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse, min_gain);
-    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain);
+    if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse, min_gain, maxbits);
+    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain, maxbits);
     ZWriteLz &L = J->L;
     L.not_last = part && !part_last;
     if (use_lz && n >= 64) {
@@ -931,7 +933,7 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
             LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << LZ_HASH_LOG), d_src, (u64)n, nblk, B, lz_buf);
             LAUNCH(c, "zenc_lz_seqenc", k_lz_seqenc, cdiv(nblk, 64), 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
         }
-        LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse, min_gain);
+        LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse, min_gain, maxbits);
         LAUNCH(c, "zenc_lz_choose", k_lz_choose, cdiv(nblk, 256), 256, 0, nblk, (const ZEncPlan *)plan, (const ZEncPlan *)plan1, (const u32 *)B.nseq, (const u32 *)B.seq_bytes, mode, offs);
         L.mode = mode; L.plan1 = plan1; L.codes1 = codes1; L.trees1 = trees1; L.B = B;
     }

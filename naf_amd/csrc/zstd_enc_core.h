@@ -17,7 +17,7 @@
 // than two distinct symbols are present.  Scratch: order[256], node arrays of 512 entries.
 // Code lengths from symbols already sorted by (count, symbol) ascending: order[0..n), n >= 2.  len[] must be
 // zero for absent symbols.  w/parent/depth: 512-entry workspaces (LDS on the GPU).
-NAF_HD u32 huf_lengths_sorted(const u32 *cnt, const u16 *order, u32 n, u8 *len, u32 *w, u16 *parent, u8 *depth)
+NAF_HD u32 huf_lengths_sorted(const u32 *cnt, const u16 *order, u32 n, u8 *len, u32 *w, u16 *parent, u8 *depth, u32 maxbits = ZENC_HUF_MAXBITS)
 {
     // two-queue Huffman construction; parent links give depths
     for (u32 i = 0; i < n; i++) w[i] = cnt[order[i]];
@@ -33,22 +33,22 @@ NAF_HD u32 huf_lengths_sorted(const u32 *cnt, const u16 *order, u32 n, u8 *len, 
     for (u32 i = root; i-- > 0;) depth[i] = (u8)(depth[parent[i]] + 1);
     u32 maxlen = 0;
     for (u32 i = 0; i < n; i++) { u32 d = depth[i]; if (d > maxlen) maxlen = d; len[order[i]] = (u8)d; }
-    if (maxlen <= ZENC_HUF_MAXBITS) return maxlen;
+    if (maxlen <= maxbits) return maxlen;
     // length limiting: clamp, then repair the Kraft sum (units of 2^-MAXBITS) to exactly 1
     i32 K = 0;
-    for (u32 i = 0; i < n; i++) { u8 &l = len[order[i]]; if (l > ZENC_HUF_MAXBITS) l = ZENC_HUF_MAXBITS; K += 1 << (ZENC_HUF_MAXBITS - l); }
-    const i32 full = 1 << ZENC_HUF_MAXBITS;
+    for (u32 i = 0; i < n; i++) { u8 &l = len[order[i]]; if (l > maxbits) l = maxbits; K += 1 << (maxbits - l); }
+    const i32 full = 1 << maxbits;
     while (K > full) {                              // lengthen the rarest symbol that can still grow
         for (u32 i = 0; i < n && K > full; i++) {
             u8 &l = len[order[i]];
-            if (l < ZENC_HUF_MAXBITS) { K -= 1 << (ZENC_HUF_MAXBITS - l - 1); l++; }
+            if (l < maxbits) { K -= 1 << (maxbits - l - 1); l++; }
         }
     }
     while (K < full) {                              // shorten the most frequent symbols that fit
         bool any = false;
         for (u32 i = n; i-- > 0 && K < full;) {
             u8 &l = len[order[i]];
-            if (l > 1 && K + (1 << (ZENC_HUF_MAXBITS - l)) <= full) { K += 1 << (ZENC_HUF_MAXBITS - l); l--; any = true; }
+            if (l > 1 && K + (1 << (maxbits - l)) <= full) { K += 1 << (maxbits - l); l--; any = true; }
         }
         if (!any) break;
     }
