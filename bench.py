@@ -376,7 +376,7 @@ def main():
         T = rep.n_bases
         comp = rep.section_comp[4]
         # the scatter pass writes the packed codes and the case bits itself (no byte-per-base intermediate)
-        ealg = {"ennaf_scatter_regular": n_text + packed + T // 8, "ennaf_scatter": n_text + packed + T // 8, "ennaf_count": n_text, "ennaf_last": n_text // 16, "zenc_plan": packed, "zenc_write": packed + comp}
+        ealg = {"ennaf_scatter_regular": n_text + packed + T // 8, "ennaf_scatter": n_text + packed + T // 8, "ennaf_count_pure": n_text, "ennaf_count": n_text, "ennaf_last": n_text // 16, "zenc_plan": packed, "zenc_write": packed + comp}
         ennaf_roofline = roofline_of(enc_kt, ealg, n_text, n_text + n_naf, min(enc_times) * 1e3, fname="pmc_traffic_ennaf.json")
 
     if rank == 0 and not multi and args.softmask_size > 0:

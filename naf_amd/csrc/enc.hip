@@ -367,8 +367,10 @@ __device__ __forceinline__ u32 piece_tail_bases(const PMask &pm)
 }
 
 __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, const i64 *tile_sp,
-                                                    u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr)
+                                                    u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr, const u32 *list)
 {
+    const u64 tile = list ? list[blockIdx.x] : blockIdx.x;      // list: the tiles k_enc_count_pure left (4-bit sequence types)
+
     __shared__ u8 cls[256];
     __shared__ u32 s_a[4], s_b[4], s_last[4];
     // REGULAR tiles (t_reg, read by k_enc_scatter<true>): plain pieces whose line ends sit on a lattice -- the first at p1, then one
@@ -378,8 +380,8 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
     // last position, period and verdict; the tile's first lane puts the four together -- no barrier beyond the one the counts need.
     __shared__ u32 r_cnt[4], r_first[4], r_last[4], r_per[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool maybe = tile_may_be_pure(P, tile_eol, blockIdx.x);
-    u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
+    const bool maybe = tile_may_be_pure(P, tile_eol, tile);
+    u64 base = (u64)tile * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
     {
         // Plain pieces only (quick letters, LF, CR): their line ends are their only space-class bytes, so a pure tile's base counts
@@ -427,13 +429,13 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
                 any = true; prev_last = r_last[v]; E += cnt;
             }
             // (the gather of the scatter pass reads up to 17 bytes from a base's position: not in the text's last tiles)
-            const bool tile_ok = ok && E >= 2 && period >= 33 && ((u64)blockIdx.x + 1) * ET_TILE + 32 <= P.n;
-            t_reg[blockIdx.x] = tile_ok ? (p1 | (period << 12) | (E << 24)) : 0u; t_irr[blockIdx.x] = tile_ok ? 0 : 1;
+            const bool tile_ok = ok && E >= 2 && period >= 33 && ((u64)tile + 1) * ET_TILE + 32 <= P.n;
+            t_reg[tile] = tile_ok ? (p1 | (period << 12) | (E << 24)) : 0u; t_irr[tile] = tile_ok ? 0 : 1;
             u32 tot = ET_TILE, tail = 0; bool found = false;
 #pragma unroll
             for (int w = 3; w >= 0; w--) { tot -= s_a[w] & 0xFFFF; if (!found && (s_last[w] & 1u)) { tail = ET_TILE - 1 - (s_a[w] >> 16); found = true; } }
-            t_seq[blockIdx.x] = tot; t_ids[blockIdx.x] = 0; t_cmt[blockIdx.x] = 0; t_rec[blockIdx.x] = 0;
-            t_tail[blockIdx.x] = found ? (tail | 0x80000000u) : tot;
+            t_seq[tile] = tot; t_ids[tile] = 0; t_cmt[tile] = 0; t_rec[tile] = 0;
+            t_tail[tile] = found ? (tail | 0x80000000u) : tot;
         }
         return;
     }
@@ -463,11 +465,70 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
 #pragma unroll
     for (int w = 0; w < 4; w++) { if (w < wave) pre += s_a[w]; tota += s_a[w]; totb += s_b[w]; last = s_last[w] > last ? s_last[w] : last; }
     if (threadIdx.x == 0) {
-        t_seq[blockIdx.x] = tota & 0xFFFF; t_ids[blockIdx.x] = tota >> 16; t_cmt[blockIdx.x] = totb & 0xFFFF; t_rec[blockIdx.x] = totb >> 16;
-        if (!last) t_tail[blockIdx.x] = tota & 0xFFFF;
-        t_reg[blockIdx.x] = 0; t_irr[blockIdx.x] = 1;
+        t_seq[tile] = tota & 0xFFFF; t_ids[tile] = tota >> 16; t_cmt[tile] = totb & 0xFFFF; t_rec[tile] = totb >> 16;
+        if (!last) t_tail[tile] = tota & 0xFFFF;
+        t_reg[tile] = 0; t_irr[tile] = 1;
     }
-    if (threadIdx.x + 1 == last) t_tail[blockIdx.x] = ((tota & 0xFFFF) - ((pre + wa) & 0xFFFF) + S.tail) | 0x80000000u;
+    if (threadIdx.x + 1 == last) t_tail[tile] = ((tota & 0xFFFF) - ((pre + wa) & 0xFFFF) + S.tail) | 0x80000000u;
+}
+
+// ---- the same verdicts for PURE tiles, a wavefront per tile (4-bit sequence types).  A lane holds four pieces of its tile (loads of
+// neighbouring lanes touch neighbouring bytes, all four in flight together); the whole tile is in one wavefront, so counts, the
+// position of the last line end and the lattice test need no LDS and no barrier.  A tile that is not pure (it starts in a header, is
+// not wholly inside the text, or holds anything but plain letters and line ends) is left to k_enc_count (t_needf / t_need).
+__global__ __launch_bounds__(256) void k_enc_count_pure(EncP P, const i64 *tile_eol, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
+                                                         u32 *t_needf, u64 *t_need, u64 tiles)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u64 t = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= tiles) return;
+    if (!tile_may_be_pure(P, tile_eol, t)) { if (lane == 0) { t_needf[t] = 1; t_need[t] = 1; } return; }
+    const u8 *tp = P.text + t * ET_TILE;
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) __builtin_memcpy(&v[k], tp + (64u * (u32)k + lane) * ET_BYTES, 16);
+    u32 eol[4]; bool plain = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const u32 w[4] = { v[k].x, v[k].y, v[k].z, v[k].w }; plain = piece_plain(w, P.plo, P.phi, &eol[k]) && plain; }
+    if (__ballot(!plain) != 0) { if (lane == 0) { t_needf[t] = 1; t_need[t] = 1; } return; }
+    u32 E = 0, nbytes = 0, p1 = 0, period = 0, prev_last = 0, lastpos = 0; bool any = false, two = false, lat_ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool has = eol[k] != 0;
+        const u64 bal = __ballot(has);
+        if (!bal) continue;                                           // (uniform)
+        const bool multi = __ballot((eol[k] & (eol[k] - 1)) != 0) != 0;
+        two = two || multi;
+        const u32 at = (64u * (u32)k + lane) * ET_BYTES;
+        const u32 q = at + (has ? (u32)__ffs((int)eol[k]) - 1 : 0u), hib = at + (has ? 31u - (u32)__clz((int)eol[k]) : 0u);
+        const u32 cnt = (u32)__popcll(bal);
+        nbytes += multi ? (u32)__builtin_amdgcn_readlane((int)wave_scan_inclusive<u32, OpAdd>((u32)__popc(eol[k])), 63) : cnt;
+        const int f1 = __ffsll((long long)bal) - 1, l1 = 63 - __clzll((long long)bal);
+        const u32 qf = (u32)__builtin_amdgcn_readlane((int)q, f1), ql = (u32)__builtin_amdgcn_readlane((int)q, l1);
+        lastpos = (u32)__builtin_amdgcn_readlane((int)hib, l1);
+        const u64 mlow = bal & ((1ull << lane) - 1);
+        const u32 qsh = (u32)__shfl((int)q, mlow ? 63 - __clzll((long long)mlow) : (int)lane, 64);   // (every lane takes part: a lane that sits out cannot be read)
+        const u32 qprev = mlow ? qsh : prev_last;
+        if (!any) { p1 = qf; const u64 bal2 = bal & (bal - 1); if (bal2) period = (u32)__builtin_amdgcn_readlane((int)q, __ffsll((long long)bal2) - 1) - qf; }
+        else if (!period) period = qf - prev_last;
+        // every line end but the tile's first lies one period behind the one before it
+        if (__ballot(has && (any || mlow) && q - qprev != period) != 0) lat_ok = false;
+        any = true; prev_last = ql; E += cnt;
+    }
+    if (lane == 0) {
+        // (the gather of the scatter pass reads up to 17 bytes from a base's position: not in the text's last tiles)
+        const bool tile_ok = lat_ok && !two && E >= 2 && period >= 33 && (t + 1) * ET_TILE + 32 <= P.n;
+        t_reg[t] = tile_ok ? (p1 | (period << 12) | (E << 24)) : 0u; t_irr[t] = tile_ok ? 0 : 1;
+        const u32 tot = ET_TILE - nbytes;
+        t_seq[t] = tot; t_ids[t] = 0; t_cmt[t] = 0; t_rec[t] = 0;
+        t_tail[t] = any ? ((ET_TILE - 1 - lastpos) | 0x80000000u) : tot;
+        t_needf[t] = 0; t_need[t] = 0;
+    }
+}
+__global__ void k_need_list(const u32 *t_needf, const u64 *pre, u64 tiles, u32 *list)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < tiles && t_needf[t]) list[pre[t]] = (u32)t;
 }
 
 // --strict (process.c:98-140): the reference dies at the FIRST unexpected byte of the input.  Every unexpected byte reports
@@ -1674,7 +1735,23 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
         if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
         if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
-        LAUNCH(c, "ennaf_count", k_enc_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr);
+        if (S.fourbit && n >= 16 * ET_TILE) {
+            // pure tiles (nearly all of a genome) a wavefront per tile; the others, from a list, by the general kernel
+            u32 *t_needf = arena_new<u32>(c, tiles + 1), *need_list = arena_new<u32>(c, tiles + 1); u64 *t_need = arena_new<u64>(c, tiles + 2);
+            if (!t_needf || !need_list || !t_need) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "ennaf_count_pure", k_enc_count_pure, cdiv(tiles, 4), 256, 0, P, (const i64 *)t_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, tiles);
+            if ((rc = scan_exclusive_u64(c, t_need, tiles, tot + 5))) return rc;
+            LAUNCH(c, "ennaf_need_list", k_need_list, cdiv(tiles, 256), 256, 0, (const u32 *)t_needf, (const u64 *)t_need, tiles, need_list);
+            u64 n_need = 0;
+            if ((rc = ctx_readback(c, &n_need, tot + 5, 8))) return rc;
+            if (getenv("NAF_GPU_DEBUG_REG")) {
+                std::vector<u32> hr(tiles); hipMemcpy(hr.data(), t_reg, tiles * 4, hipMemcpyDeviceToHost);
+                u64 nz = 0; for (u64 i = 0; i < tiles; i++) nz += hr[i] != 0;
+                fprintf(stderr, "[reg] tiles %llu need %llu regular %llu; reg[1..4] = %08x %08x %08x %08x\n", (unsigned long long)tiles, (unsigned long long)n_need, (unsigned long long)nz, hr[1], hr[2], hr[3], hr[4]);
+            }
+            if (n_need) LAUNCH(c, "ennaf_count", k_enc_count, n_need, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, (const u32 *)need_list);
+        } else
+        LAUNCH(c, "ennaf_count", k_enc_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, (const u32 *)nullptr);
         if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
         if ((rc = scan_exclusive_u64(c, t_ids, tiles, tot + 1))) return rc;
         if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;

@@ -53,7 +53,7 @@ text_bytes = int(line["config"]["workload"].split("FASTA ")[-1].split(" B")[0])
 names = {"k_huf_literals": "zstd_huf_literals", "k_flat_literals": "zstd_flat_literals", "k_emit_tile": "unnaf_emit", "k_emit_tile_flat": "unnaf_emit_flat",
          "k_emit_rest": "unnaf_emit_rest", "k_build_huf": "zstd_build_huf", "k_spec_find": "zstd_index_find", "k_spec_resolve": "zstd_index_resolve",
          "k_copy_fill": "zstd_copy_fill", "k_flat_streams": "zstd_flat_streams", "k_tile_index": "unnaf_tile_index"}
-enc_names = {"k_enc_scatter_regular": "ennaf_scatter_regular", "k_enc_scatter": "ennaf_scatter", "k_enc_count": "ennaf_count", "k_enc_last_fa": "ennaf_last", "k_maskb_count": "ennaf_mask_count", "k_pack_edges_zero": "ennaf_pack_edges",
+enc_names = {"k_enc_scatter_regular": "ennaf_scatter_regular", "k_enc_scatter": "ennaf_scatter", "k_enc_count_pure": "ennaf_count_pure", "k_enc_count": "ennaf_count", "k_enc_last_fa": "ennaf_last", "k_maskb_count": "ennaf_mask_count", "k_pack_edges_zero": "ennaf_pack_edges",
              "k_zenc_plan": "zenc_plan", "k_zenc_write": "zenc_write", "k_mask_run_units": "ennaf_mask_runs", "k_mask_units_write": "ennaf_mask_units"}
 calls = 3
 enc_calls = 4            # three timed ennaf calls and the instrumented one
