@@ -1,7 +1,7 @@
 #!/bin/bash
 # Produces the files under profiles/ for one round:  tools/profile_bench.sh r02   (run on the GPU box, from the repo root)
 #   <tag>_bench_line.json                     the JSON line of a plain `python bench.py`
-#   <tag>_bench_rocprofv3_kernel_stats.csv    rocprofv3 --kernel-trace --stats of `python bench.py --steps 3 --no-cpu`
+#   <tag>_bench_rocprofv3_kernel_stats.csv    rocprofv3 --kernel-trace --stats of `python bench.py --steps 3 --no-cpu --softmask-size 0`
 #   <tag>_pmc_fetch.csv / _pmc_write.csv      per-kernel FETCH_SIZE / WRITE_SIZE sums (separate --pmc passes, no tracing
 #                                             domains besides the kernel dispatch records), incl. the calibration kernel
 # Everything is written under gpurun_out/<tag>/ ; copy what should be judged into profiles/.
@@ -11,17 +11,17 @@ out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 python bench.py > $out/${tag}_bench_line.json 2> $out/bench.err
 tail -c 400 $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 3 --no-cpu > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 3 --no-cpu --softmask-size 0 > $out/stats.log 2>&1
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/${tag}_bench_rocprofv3_kernel_stats.csv
 # the two-pass decode (what archives that are not one flat tree take), every kernel alone on the device: no fused emit, no split
-NAF_GPU_FLAT_FUSE=0 NAF_GPU_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats2 -- python bench.py --steps 3 --no-cpu > $out/stats2.log 2>&1
+NAF_GPU_FLAT_FUSE=0 NAF_GPU_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats2 -- python bench.py --steps 3 --no-cpu --softmask-size 0 > $out/stats2.log 2>&1
 cp $(ls $out/stats2/*/*kernel_stats.csv | head -1) $out/${tag}_twopass_alone_rocprofv3_kernel_stats.csv
 # the serial Huffman kernel on the same data (NAF_GPU_FLAT=0), alone
-NAF_GPU_FLAT=0 NAF_GPU_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats3 -- python bench.py --steps 3 --no-cpu > $out/stats3.log 2>&1
+NAF_GPU_FLAT=0 NAF_GPU_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats3 -- python bench.py --steps 3 --no-cpu --softmask-size 0 > $out/stats3.log 2>&1
 cp $(ls $out/stats3/*/*kernel_stats.csv | head -1) $out/${tag}_serial_huffman_alone_rocprofv3_kernel_stats.csv
 for ctr in FETCH_SIZE WRITE_SIZE; do
   printf 'pmc: %s\n' $ctr > $out/pmc_$ctr.txt
-  rocprofv3 -i $out/pmc_$ctr.txt --output-format csv -d $out/pmc_$ctr -- python bench.py --steps 1 --warmup 0 --no-cpu > $out/pmc_$ctr.log 2>&1
+  rocprofv3 -i $out/pmc_$ctr.txt --output-format csv -d $out/pmc_$ctr -- python bench.py --steps 1 --warmup 0 --no-cpu --softmask-size 0 > $out/pmc_$ctr.log 2>&1
   rocprofv3 -i $out/pmc_$ctr.txt --output-format csv -d $out/cal_$ctr -- tools/bw_calibrate > $out/cal_$ctr.log 2>&1
 done
 python - "$out" "$tag" <<'PY'
