@@ -419,10 +419,15 @@ def main():
             "roofline": roofline, "ennaf_roofline": ennaf_roofline, "cpu_baseline": cb,
         }
         line.update(extra)
-        print(json.dumps(line))
     if multi:
         dist.destroy_process_group()
     ctx.close()
+    if rank == 0:
+        # last thing on stdout (RCCL prints a version banner when the process group goes away)
+        sys.stdout.flush(); sys.stderr.flush()
+        print(json.dumps(line), flush=True)
+        if multi:                                          # ... and another one at exit: nothing of it behind the JSON line
+            os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
 
 
 if __name__ == "__main__":
