@@ -350,35 +350,100 @@ __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 
 // description, the weights, the builder's workspace and the table in LDS, so that the lone working lane waits for LDS, not for
 // scratch memory (0.3 - 1 ms per launch otherwise, on the critical path of every small stream).
 struct HufLdsWS { HufBuildWS ws; __attribute__((aligned(16))) u8 in[192], w[256]; __attribute__((aligned(16))) u16 tab[HUF_TAB_MAX / 2]; u32 log, off; };
+// One tree by one wavefront (blockDim.x == 64), everything in LDS.  What is serial by nature -- FSE-coded weights (4.2.1.2), the
+// compact table of codes longer than HUF_FULL_LOG bits -- is lane 0's; directly stored weights, their check and the single-level
+// table are spread over the lanes (one lane doing all of it from LDS took 70 - 200 us per tree, in front of the literals of a
+// frame with one tree and of a mask stream with thousands).
 __device__ void build_huf_one_lds(const u8 *src, ZBlock *blk, u32 i, u8 *pool, u32 pool_cap, ZStat *st, HufLdsWS &S)
 {
     const u8 *c = src + blk[i].src_off + blk[i].lit_off;
     const u32 len = blk[i].lit_csize, n_in = len < 192 ? len : 192;          // a tree description takes at most 129 bytes
+    const u32 lane = threadIdx.x;
+    __shared__ u32 s_nw;
     __syncthreads();
-    for (u32 k = threadIdx.x; k < n_in; k += 64) S.in[k] = c[k];
+    for (u32 k = lane; k < n_in; k += 64) S.in[k] = c[k];
+    if (lane == 0) { S.log = 0; S.off = 0; s_nw = 0; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    const u32 hb = n_in ? S.in[0] : 0u;
+    if (n_in && hb >= 128) {
+        // direct representation: hb - 127 weights of four bits
+        const u32 n = hb - 127, bytes = (n + 1) / 2;
+        bool bad = 1 + bytes > n_in;
+        u32 sum = 0;
+        if (!bad) for (u32 k = lane; k < n; k += 64) {
+            const u32 w = (k & 1) ? (S.in[1 + k / 2] & 15u) : (S.in[1 + k / 2] >> 4);
+            S.w[k] = (u8)w;
+            if (w > HUF_LOG_MAX) bad = true; else if (w) sum += 1u << (w - 1);
+        }
+        for (int d = 32; d; d >>= 1) sum += (u32)__shfl_xor((int)sum, d, 64);
+        bad = __ballot(bad) != 0;
+        if (lane == 0 && !bad && sum) {
+            const u32 log = (u32)hibit32(sum) + 1, rest = (1u << log) - sum;
+            if (log <= HUF_LOG_MAX && !(rest & (rest - 1))) { S.w[n] = (u8)(hibit32(rest) + 1); s_nw = n + 1; S.log = log; }
+        }
+    } else if (lane == 0 && n_in) {
         u32 nw = 0, used = 0;
-        u32 log = huf_read_weights_ws(S.in, n_in, S.w, &nw, &used, S.ws);
+        const u32 log = huf_read_weights_ws(S.in, n_in, S.w, &nw, &used, S.ws);
+        s_nw = nw; S.log = log;
+    }
+    __syncthreads();
+    u32 log = S.log; const u32 nw = s_nw;
+    if (lane == 0) {
         u32 off = 0;
         if (!log) { set_err(st, ZE_CORRUPT); blk[i].err = ZE_CORRUPT; }
         else {
-            u32 bytes = huf_tab_bytes(log);
+            const u32 bytes = huf_tab_bytes(log);
             off = atomicAdd(&st->huf_pool_used, bytes);
             if (off + bytes > pool_cap) { set_err(st, ZE_POOL); log = 0; }
             else {
-                huf_build_any_ws(S.tab, S.w, nw, log, S.ws); blk[i].huf_tab = off; blk[i].huf_log = (u8)log; atomicMax(&st->max_huf_log, log);
+                blk[i].huf_tab = off; blk[i].huf_log = (u8)log; atomicMax(&st->max_huf_log, log);
                 const bool flat = huf_is_flat(S.w, nw, log);
                 blk[i].huf_flat = flat; if (flat) atomicAdd(&st->n_flat, 1u);
                 atomicAdd(&st->n_huf_built, 1u);
+                if (log > HUF_FULL_LOG) huf_build_compact(S.tab, S.w, nw, log, S.ws);
             }
         }
         S.log = log; S.off = off;
+        for (u32 r = 0; r <= HUF_LOG_MAX + 1; r++) S.ws.cnt[r] = 0;
     }
     __syncthreads();
-    if (!S.log) return;
-    const u32 bytes = huf_tab_bytes(S.log);
-    for (u32 k = threadIdx.x; k < bytes / 16; k += 64) ((uint4 *)(pool + S.off))[k] = ((const uint4 *)S.tab)[k];
+    log = S.log;
+    if (!log) return;
+    if (log <= HUF_FULL_LOG) {
+        // single-level table (huf_build_table): weight groups in ascending order, inside a group the symbols in index order, symbol i
+        // of weight w fills 2^(w-1) cells with  log + 1 - w | i << 8
+        u32 wq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const u32 k = 64u * (u32)q + lane; wq[q] = k < nw ? S.w[k] : 0u; if (wq[q]) atomicAdd(&S.ws.cnt[wq[q]], 1u); }
+        __syncthreads();
+        if (lane == 0) { u32 pos = 0; for (u32 r = 1; r <= log; r++) { S.ws.start[r] = pos; pos += S.ws.cnt[r] << (r - 1); } }
+        __syncthreads();
+        u32 before[HUF_FULL_LOG + 1];                                  // symbols of weight r in the chunks done so far
+#pragma unroll
+        for (u32 r = 0; r <= HUF_FULL_LOG; r++) before[r] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            u32 rank = 0;
+#pragma unroll
+            for (u32 r = 1; r <= HUF_FULL_LOG; r++) {
+                const u64 bal = __ballot(wq[q] == r);
+                if (wq[q] == r) rank = before[r] + (u32)__popcll(bal & ((1ull << lane) - 1));
+                before[r] += (u32)__popcll(bal);
+            }
+            const u32 w = wq[q], cells = w ? 1u << (w - 1) : 0u, at = w ? S.ws.start[w] + rank * cells : 0u;
+            const u16 e = (u16)((log + 1 - w) | ((64u * (u32)q + lane) << 8));
+            if (cells && cells <= 16) for (u32 k = 0; k < cells; k++) S.tab[at + k] = e;
+            u64 big = __ballot(cells > 16);                            // a few symbols with many cells: the whole wave fills them
+            while (big) {
+                const int l = __ffsll((long long)big) - 1; big &= big - 1;
+                const u32 a2 = (u32)__shfl((int)at, l, 64), n2 = (u32)__shfl((int)cells, l, 64), e2 = (u32)__shfl((int)e, l, 64);
+                for (u32 k = lane; k < n2; k += 64) S.tab[a2 + k] = (u16)e2;
+            }
+        }
+        __syncthreads();
+    }
+    const u32 bytes = huf_tab_bytes(log);
+    for (u32 k = lane; k < bytes / 16; k += 64) ((uint4 *)(pool + S.off))[k] = ((const uint4 *)S.tab)[k];
 }
 __global__ __launch_bounds__(64) void k_build_huf_lds(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const i32 *own_huf)
 {
