@@ -1508,6 +1508,14 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     if (src_len <= 4ull * SPEC_CHUNK) {                          // about 128 chunks of 256 B .. 16 KiB, every byte a candidate
         chunk = 256; while (chunk < SPEC_CHUNK_SMALL && (u64)chunk * 128 < src_len) chunk *= 2;
         win1 = win2 = chunk;
+    } else if (src_len <= 256ull * SPEC_CHUNK && fh.hdr_size + 3 <= hl) {
+        // In between (a soft-masked genome's mask: 11 MB of 5 KB blocks): a chunk is walked by one lane, block after block, and 1 MiB
+        // of small blocks is a long walk for eleven lanes.  The frame's first block says what to expect: chunks of about sixteen
+        // such blocks (never wrong, only more or less of the speculation reused).
+        const u32 h0 = (u32)hb[fh.hdr_size] | ((u32)hb[fh.hdr_size + 1] << 8) | ((u32)hb[fh.hdr_size + 2] << 16);
+        const u32 b0 = ((h0 >> 1) & 3) == 1 ? 4u : (h0 >> 3) + 3;     // bytes of the first block (an RLE block stores one byte)
+        u32 want = SPEC_CHUNK_SMALL; while (want < SPEC_CHUNK && want < 16 * b0) want *= 2;
+        if (want < SPEC_CHUNK) { chunk = want; if (win1 > chunk) win1 = chunk; if (win2 > chunk) win2 = chunk; }
     }
     if (src_len >= 2048 && !(nospec && nospec[0] == '1')) {
         u32 nchunks = (u32)((src_len + chunk - 1) / chunk);
