@@ -155,6 +155,9 @@ static const size_t ARENA_MIN_CHUNK = (size_t)64 << 20;
 
 void arena_reset(naf_gpu_ctx *c)
 {
+    // every entry point starts here: the calling thread's current device is made the context's (a host that drives several
+    // contexts from one thread, or has just shut another device's context down, would otherwise allocate and launch on that one)
+    hipSetDevice(c->device);
     size_t total = 0;
     for (auto &ch : c->chunks) { total += ch.cap; ch.used = 0; }
     if (c->chunks.size() > 1) {                      // consolidate so steady state is one chunk, no hipMalloc
@@ -248,9 +251,9 @@ int ctx_readback2(naf_gpu_ctx *c, void *h1, const void *d1, size_t n1, void *h2,
 }
 
 // ---- memory helpers for hosts that do not link HIP ----------------------------------------------------------
-extern "C" int naf_gpu_malloc(naf_gpu_ctx *c, size_t bytes, void **p) { if (!c || !p) return NAF_GPU_EARG; HIP_TRY(c, hipMalloc(p, bytes ? bytes : 1)); return 0; }
+extern "C" int naf_gpu_malloc(naf_gpu_ctx *c, size_t bytes, void **p) { if (!c || !p) return NAF_GPU_EARG; HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipMalloc(p, bytes ? bytes : 1)); return 0; }
 extern "C" int naf_gpu_free(naf_gpu_ctx *c, void *p) { if (!c) return NAF_GPU_EARG; HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(p)); return 0; }
-extern "C" int naf_gpu_host_alloc(naf_gpu_ctx *c, size_t bytes, void **p) { if (!c || !p) return NAF_GPU_EARG; HIP_TRY(c, hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault)); return 0; }
+extern "C" int naf_gpu_host_alloc(naf_gpu_ctx *c, size_t bytes, void **p) { if (!c || !p) return NAF_GPU_EARG; HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault)); return 0; }
 extern "C" int naf_gpu_host_free(naf_gpu_ctx *c, void *p) { if (!c) return NAF_GPU_EARG; HIP_TRY(c, hipHostFree(p)); return 0; }
 extern "C" int naf_gpu_upload(naf_gpu_ctx *c, void *d, const void *h, size_t n) { if (!c) return NAF_GPU_EARG; if (n) HIP_TRY(c, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream)); return 0; }
 extern "C" int naf_gpu_download(naf_gpu_ctx *c, void *h, const void *d, size_t n)

@@ -879,7 +879,10 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
         block_log = 16; const char *lb = getenv("NAF_GPU_LZX_BLOCK_LOG"); if (lb && atoi(lb) >= 12 && atoi(lb) <= 16) block_log = (u32)atoi(lb);
         if (block_log > (u32)window_log) block_log = (u32)window_log;          // Block_Maximum_Size is the smaller of Window_Size and 128 KiB (3.1.1.2.4)
     }
-    const u32 frame_wlog = lzx ? (u32)window_log : 19u;
+    // The window announced in the frame header follows from the OPTIONS alone, not from this part's size: the header is written by the
+    // first part of a sharded / chunked frame, and a first part of a few bytes (the ids of a slice that is one chromosome) says
+    // nothing about the offsets the later parts use -- the reference's streaming decoder sizes its history from this field
+    const u32 frame_wlog = (use_lz && window_log >= 10) ? (u32)window_log : 19u;
     u64 bs = 1ull << block_log;
     u64 nblk64 = n ? (n + bs - 1) / bs : 1;
     if (nblk64 > 0x7FFFFFFFull) return ctx_fail(c, NAF_GPU_EARG, "stream too large");

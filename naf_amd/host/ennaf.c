@@ -200,11 +200,16 @@ static naf_gpu_stitch_seg ch_segs[7 + 6 * MAX_CHUNKS]; static size_t ch_nsegs = 
 static size_t chunk_bytes_wanted(size_t file_size)
 {
     const char *e = getenv("NAF_GPU_CHUNK_BYTES");
-    size_t c = 0;
+    size_t c = 0, fr = 0, tot = 0;
+    GPU_TRY(naf_gpu_mem_info(gpu, &fr, &tot));
     if (e && *e) { char *end; unsigned long long v = strtoull(e, &end, 10); if (*end || v < 4096) die("can't parse NAF_GPU_CHUNK_BYTES=\"%s\"\n", e); c = (size_t)v; }
-    else { size_t fr = 0, tot = 0; GPU_TRY(naf_gpu_mem_info(gpu, &fr, &tot)); c = fr / 5; }
+    else c = fr / 5;
     if (c < 4096) c = 4096;
-    if ((file_size + c - 1) / c > MAX_CHUNKS - 1) c = (file_size + MAX_CHUNKS - 2) / (MAX_CHUNKS - 1);     /* cuts fall short of the nominal ends: leave one spare */
+    if ((file_size + c - 1) / c > MAX_CHUNKS - 1) {
+        c = (file_size + MAX_CHUNKS - 2) / (MAX_CHUNKS - 1);     /* cuts fall short of the nominal ends: leave one spare */
+        /* a chunk needs its text, the streams split from it and their frames at once: about four times its size */
+        if (c > fr / 4) die("input of %zu bytes needs %d chunks of %zu bytes, more than the device can hold at once (%zu bytes free)\n", file_size, MAX_CHUNKS - 1, c, fr);
+    }
     return c;
 }
 /* offset just behind the last EOL-class byte of file range [a, b); a when there is none */
@@ -220,7 +225,8 @@ static size_t last_line_end(int fd, size_t a, size_t b)
     }
     return a;
 }
-static bool encode_chunked(FILE *IN, size_t fn, const naf_gpu_ennaf_opts *o, naf_gpu_ennaf_report *R, size_t *naf_len)
+/* (offsets below count from `base`, the descriptor's position when the program started: `(head -c 100; ennaf) < file` encodes the rest) */
+static bool encode_chunked(FILE *IN, size_t base, size_t fn, const naf_gpu_ennaf_opts *o, naf_gpu_ennaf_report *R, size_t *naf_len)
 {
     const int fd = fileno(IN);
     const size_t C = chunk_bytes_wanted(fn);
@@ -233,7 +239,7 @@ static bool encode_chunked(FILE *IN, size_t fn, const naf_gpu_ennaf_opts *o, naf
     while (pos < fn) {
         if (k >= MAX_CHUNKS) die("input needs more than %d chunks of %zu bytes\n", MAX_CHUNKS, C);
         size_t end = pos + C < fn ? pos + C : fn;
-        GPU_TRY(naf_gpu_read_file(gpu, fd, pos, end - pos, d_buf));
+        GPU_TRY(naf_gpu_read_file(gpu, fd, base + pos, end - pos, d_buf));
         if (k == 0) {
             GPU_TRY(naf_gpu_ennaf_sniff(gpu, d_buf, end - pos, o->format, &fmt, &p0));
             if (fmt == 0 || p0 >= end - pos) { naf_gpu_free(gpu, d_buf); return false; }      /* a chunk of white space in front: the one-call path sorts it out */
@@ -248,13 +254,13 @@ static bool encode_chunked(FILE *IN, size_t fn, const naf_gpu_ennaf_opts *o, naf
                 if (lines < 5) die("a FASTQ record does not fit a chunk of %zu bytes (NAF_GPU_CHUNK_BYTES)\n", C);
                 GPU_TRY(naf_gpu_ennaf_find_cut(gpu, text, end - pos, fmt, 1, (lines - 1) / 4 * 4, &off));
                 cut = pos + (size_t)off;
-            } else cut = last_line_end(fd, pos, end);
+            } else cut = last_line_end(fd, base + pos, base + end) - base;
             if (cut <= pos) die("a line does not fit a chunk of %zu bytes (NAF_GPU_CHUNK_BYTES)\n", C);
             end = cut;
         }
         ch_start[k] = pos;
         /* n_shards is not known yet: k + 2 says "not the last one", the records are completed below */
-        GPU_TRY(naf_gpu_ennaf_shard_begin(gpu, text, end - pos, o, fmt, (uint32_t)k, (uint32_t)(end == fn ? k + 1 : k + 2), &ch_infos[k]));
+        GPU_TRY(naf_gpu_ennaf_shard_begin(gpu, text, end - pos, o, fmt, (uint32_t)k, (uint32_t)(end == fn ? k + 1 : (k + 2 > MAX_CHUNKS ? MAX_CHUNKS : k + 2)), &ch_infos[k]));
         pos = end; k++;
     }
     ch_n = k; ch_start[k] = fn;
@@ -267,7 +273,7 @@ static bool encode_chunked(FILE *IN, size_t fn, const naf_gpu_ennaf_opts *o, naf
     size_t tmp_at = 0;
     for (k = 0; k < ch_n; k++) {
         const size_t a = ch_start[k], len = ch_start[k + 1] - a;
-        GPU_TRY(naf_gpu_read_file(gpu, fd, a, len, d_buf));
+        GPU_TRY(naf_gpu_read_file(gpu, fd, base + a, len, d_buf));
         naf_gpu_shard_info again;
         GPU_TRY(naf_gpu_ennaf_shard_begin(gpu, d_buf, len, o, fmt, (uint32_t)k, (uint32_t)ch_n, &again));
         const size_t pcap = naf_gpu_ennaf_shard_bound(len);
@@ -336,15 +342,19 @@ int main(int argc, char **argv)
     /* ---- several devices: a regular file of known size, cut into one slice per context */
     devices_parse();
     struct stat st;
-    if (n_devs > 1 && fd_is_regular(fileno(IN)) && fstat(fileno(IN), &st) == 0 && (size_t)st.st_size >= (size_t)n_devs * 65536 && (!title || strlen(title) < 4096)) {
-        const size_t fn = (size_t)st.st_size; const int n = n_devs;
+    /* a regular file is read from the descriptor's current position on, whichever path takes it */
+    off_t in_at = fd_is_regular(fileno(IN)) ? lseek(fileno(IN), 0, SEEK_CUR) : (off_t)-1; if (in_at < 0) in_at = 0;
+    size_t in_left = 0;
+    if (fd_is_regular(fileno(IN)) && fstat(fileno(IN), &st) == 0 && (size_t)st.st_size > (size_t)in_at) in_left = (size_t)st.st_size - (size_t)in_at;
+    if (n_devs > 1 && in_left >= (size_t)n_devs * 65536 && (!title || strlen(title) < 4096)) {
+        const size_t fn = in_left; const int n = n_devs;
         gpu_open();
         sh_opts = o;
         pthread_barrier_init(&sh_bar, NULL, (unsigned)n);
         for (int k = 0; k < n; k++) {
             enc_job *j = &ejobs[k]; memset(j, 0, sizeof *j);
             j->k = k; j->n = n; j->device = dev_ids[k]; j->fd = fileno(IN); j->c = k == 0 ? gpu : NULL;
-            j->a = fn / (size_t)n * (size_t)k; j->b = k + 1 < n ? fn / (size_t)n * (size_t)(k + 1) : fn;
+            j->a = (size_t)in_at + fn / (size_t)n * (size_t)k; j->b = (size_t)in_at + (k + 1 < n ? fn / (size_t)n * (size_t)(k + 1) : fn);
             j->prev_is_eol = 1;
             if (k > 0) { unsigned char pb = 0; if (pread(j->fd, &pb, 1, (off_t)j->a - 1) != 1) die("can't read the input\n"); j->prev_is_eol = pb >= 0x0A && pb <= 0x0D; }
         }
@@ -366,9 +376,9 @@ int main(int argc, char **argv)
         }
     }
     bool chunked = false;
-    if (!sharded && fd_is_regular(fileno(IN)) && fstat(fileno(IN), &st) == 0 && st.st_size > 0) {
+    if (!sharded && in_left > 0) {
         gpu_open();
-        chunked = encode_chunked(IN, (size_t)st.st_size, &o, &R, &naf_len);
+        chunked = encode_chunked(IN, (size_t)in_at, in_left, &o, &R, &naf_len);
         if (chunked) phase("ennaf in chunks");
     }
     if (!sharded && !chunked) {
@@ -394,7 +404,7 @@ int main(int argc, char **argv)
     else {
         const int n = n_devs;
         fflush(OUT);
-        off_t at = fd_is_regular(fileno(OUT)) ? lseek(fileno(OUT), 0, SEEK_CUR) : (off_t)-1;
+        off_t at = fd_pwrite_pos(fileno(OUT));                        /* -1: a pipe or `>>`: the parts in order through the main thread */
         sh_out_fd = at >= 0 ? fileno(OUT) : -1; sh_out_at = at >= 0 ? at : 0;
         pthread_barrier_wait(&sh_bar);                                           /* 7: the workers write their parts */
         for (size_t i = 0; i < sh_nsegs; i++) {

@@ -116,6 +116,16 @@ static naf_gpu_ctx *ctx_open(int device)
     return c;
 }
 static bool fd_is_regular(int fd) { struct stat st; return fstat(fd, &st) == 0 && S_ISREG(st.st_mode); }
+/* Position of a descriptor that takes pwrite() at explicit offsets from several threads: a regular file that was not opened for
+ * appending -- on Linux pwrite() to an O_APPEND descriptor ignores its offset and appends, so the chunks of `unnaf x.naf >> all.fa`
+ * would land in arrival order.  -1: write sequentially (pipes, `>>`), the way the reference's fwrite does. */
+static off_t fd_pwrite_pos(int fd)
+{
+    if (!fd_is_regular(fd)) return (off_t)-1;
+    int fl = fcntl(fd, F_GETFL);
+    if (fl < 0 || (fl & O_APPEND)) return (off_t)-1;
+    return lseek(fd, 0, SEEK_CUR);
+}
 
 /* ---- file <-> device --------------------------------------------------------------------------------------------------------
  * Regular files go through naf_gpu_read_file / naf_gpu_write_file (several host threads, pinned staging, pread / pwrite at
@@ -131,13 +141,11 @@ static void write_from_device(FILE *f, const void *d, size_t n)
 {
     if (!n) return;
     fflush(f);
-    if (fd_is_regular(fileno(f))) {
-        off_t at = lseek(fileno(f), 0, SEEK_CUR);
-        if (at >= 0) {
-            GPU_TRY(naf_gpu_write_file(gpu, fileno(f), (uint64_t)at, d, n));
-            if (lseek(fileno(f), at + (off_t)n, SEEK_SET) < 0) die("can't write to file - disk full?\n");
-            return;
-        }
+    off_t at = fd_pwrite_pos(fileno(f));
+    if (at >= 0) {
+        GPU_TRY(naf_gpu_write_file(gpu, fileno(f), (uint64_t)at, d, n));
+        if (lseek(fileno(f), at + (off_t)n, SEEK_SET) < 0) die("can't write to file - disk full?\n");
+        return;
     }
     io_open();
     size_t off = 0; int cur = 0;

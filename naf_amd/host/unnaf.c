@@ -165,7 +165,7 @@ static void run_text(int mode, int masking_allowed)
     if (!n) return;
     phase("size");
     fflush(OUT);
-    off_t at = fd_is_regular(fileno(OUT)) ? lseek(fileno(OUT), 0, SEEK_CUR) : (off_t)-1;
+    off_t at = fd_pwrite_pos(fileno(OUT));                   /* -1: a pipe, or a file opened for appending (`>>`): ranges in order from one device */
     if (at >= 0) {
         devices_parse();
         int nd = n_devs; if ((size_t)nd > n / 4096 + 1) nd = (int)(n / 4096 + 1);
@@ -283,11 +283,19 @@ int main(int argc, char **argv)
         else if (out_type == FOUR_BIT) run_text(NAF_OUT_4BIT, 1);
         else if (out_type == DNA || out_type == SEQ || out_type == MASKED_DNA) run_text(NAF_OUT_SEQ, 1);
         else if (out_type == UNMASKED_DNA) run_text(NAF_OUT_SEQ, 0);
-        else if (out_type == CHARCOUNT) { if (has_data) { /* histogram of the --seq text */ naf_gpu_unnaf_opts dummy; (void)dummy; upload(); 
+        else if (out_type == CHARCOUNT) { if (has_data) {          /* histogram of the --seq text (output.c:515-605), a byte range at a time */
+                upload();
                 naf_gpu_unnaf_opts o = { NAF_OUT_SEQ, use_mask, -1 }; size_t n = 0; GPU_TRY(naf_gpu_unnaf_size(gpu, d_naf, naf_len, &o, &n));
-                void *d; GPU_TRY(naf_gpu_malloc(gpu, n + 64, &d)); size_t got = 0; GPU_TRY(naf_gpu_unnaf(gpu, d_naf, naf_len, &o, d, n, &got));
-                uint64_t cnt64[256]; GPU_TRY(naf_gpu_histogram(gpu, d, got, cnt64));
-                unsigned long long counts[256]; for (unsigned i = 0; i < 256; i++) counts[i] = cnt64[i];
+                const size_t R = range_bytes(), cap = n < R ? n : R;
+                unsigned long long counts[256]; memset(counts, 0, sizeof counts);
+                void *d; GPU_TRY(naf_gpu_malloc(gpu, cap + 64, &d));
+                for (size_t b = 0; b < n; b += cap) {
+                    size_t e = b + cap < n ? b + cap : n, got = 0;
+                    if (cap == n) GPU_TRY(naf_gpu_unnaf(gpu, d_naf, naf_len, &o, d, n, &got));
+                    else GPU_TRY(naf_gpu_unnaf_range(gpu, d_naf, naf_len, &o, b, e, d, cap, &got));
+                    uint64_t cnt64[256]; GPU_TRY(naf_gpu_histogram(gpu, d, got, cnt64));
+                    for (unsigned i = 0; i < 256; i++) counts[i] += cnt64[i];
+                }
                 for (unsigned i = 0; i < 33; i++) if (counts[i]) fprintf(OUT, "\\x%02X\t%llu\n", i, counts[i]);
                 for (unsigned i = 33; i < 127; i++) if (counts[i]) fprintf(OUT, "%c\t%llu\n", (unsigned char)i, counts[i]);
                 for (unsigned i = 127; i < 256; i++) if (counts[i]) fprintf(OUT, "\\x%02X\t%llu\n", i, counts[i]);

@@ -129,7 +129,7 @@ def ennaf_sharded_local(ctxs, d_text, opts=None, out=None):
     fmt, p0 = c0.ennaf_sniff(d_text, opts.format)
     if fmt == 0 or len(ctxs) == 1:
         return c0.ennaf(d_text, seq_type=opts.seq_type, fmt=opts.format, no_mask=bool(opts.no_mask), level=opts.level,
-                        line_length=opts.line_length, title=opts.title, out=out, strict=bool(opts.strict))
+                        line_length=opts.line_length, title=opts.title, out=out, strict=bool(opts.strict), long_log=opts.long_log)
     n = len(ctxs)
     cuts = cuts_local(c0, d_text, fmt, p0, n)
     slices = [d_text[cuts[k]:cuts[k + 1]] for k in range(n)]
@@ -198,7 +198,21 @@ def ennaf_sharded(ctx, d_buf, n, opts=None, dst=0, group=None, everywhere=False)
     meta = _all_gather_ints(meta, dev, group)[0]
     fmt, p0 = meta
     if fmt == 0:
-        raise ValueError("empty input: nothing to shard")
+        # nothing but white space in the first slice.  The C host hands such an input to one device (naf_amd/host/ennaf.c: sh_fallback);
+        # here the slices live on different ranks, so that only works when the other slices are empty too: rank 0 makes the archive
+        # of "no records" with the one-call encoder, as the C host would
+        sizes = _all_gather_ints([n], dev, group)
+        if any(sz[0] for sz in sizes[1:]):
+            raise ValueError("the first rank's slice holds no record start: give rank 0 the beginning of the text")
+        arc, rep = ctx.ennaf(d_buf[:n], seq_type=opts.seq_type, fmt=opts.format, no_mask=bool(opts.no_mask), level=opts.level,
+                             line_length=opts.line_length, title=opts.title, strict=bool(opts.strict), long_log=opts.long_log)
+        info = {"cut": 0, "halo": 0}
+        if everywhere or dst != 0:                               # a few dozen bytes: everybody gets them
+            ln = _all_gather_ints([arc.numel() if rank == 0 else 0], dev, group)[0][0]
+            if rank != 0:
+                arc = torch.empty(ln, dtype=torch.uint8, device=dev)
+            dist.broadcast(arc, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return (arc if (everywhere or rank == dst) else None), rep, info
     lo = p0 if rank == 0 else 0
     # byte in front of every slice: an EOL makes position 0 of the slice a place where a line starts
     last = int(d_buf[n - 1].item()) if n > lo else -1

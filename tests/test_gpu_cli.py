@@ -185,3 +185,31 @@ def test_line_wrapped_text_takes_the_regular_tile_kernels(tmp_path):
     assert need <= 8 and regular >= tiles - 12, (tiles, need, regular)
     u = subprocess.run([os.path.join(BIN, "unnaf"), "-c"], input=e.stdout, stdout=subprocess.PIPE, timeout=120)
     assert u.stdout == text
+
+
+def test_appending_to_a_file_keeps_the_order(tmp_path):
+    """`unnaf x.naf >> all.fa` and `ennaf -c in.fa >> out`: a descriptor opened for appending takes pwrite() at the END whatever the
+    offset says (Linux), so the threaded positional writer must not be used on it -- the reference's sequential fwrite
+    (unnaf/src/output.c:332, ennaf/src/compressor.c:150-173) appends in order.  More than two 16 MiB chunks of text."""
+    from naf_amd import synth
+    rng = np.random.default_rng(5)
+    bases = rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), 40_000_000)
+    text = b">chr1 forty million bases\n" + synth.wrap_lines(bases, 60)
+    src = tmp_path / "a.fa"; src.write_bytes(text)
+    naf = tmp_path / "a.naf"
+    head = b">already here\nACGT\n"
+    for ngpu in ("0", "0,0,0"):
+        env = dict(os.environ, NAF_GPUS=ngpu)
+        out = tmp_path / ("all_%d.fa" % len(ngpu)); out.write_bytes(head)
+        assert subprocess.run([os.path.join(BIN, "ennaf"), str(src), "-o", str(naf)], env=env, timeout=120).returncode == 0
+        with open(out, "ab") as f:
+            assert subprocess.run([os.path.join(BIN, "unnaf"), str(naf)], stdout=f, env=env, timeout=120).returncode == 0
+        assert out.read_bytes() == head + text
+        # the archive appended behind other bytes: cut it off again and decode it
+        arc = tmp_path / ("arc_%d.bin" % len(ngpu)); arc.write_bytes(b"JUNK")
+        with open(arc, "ab") as f:
+            assert subprocess.run([os.path.join(BIN, "ennaf"), "-c", str(src)], stdout=f, env=env, timeout=120).returncode == 0
+        got = arc.read_bytes()
+        assert got[:4] == b"JUNK"
+        u = subprocess.run([os.path.join(BIN, "unnaf"), "-c"], input=got[4:], stdout=subprocess.PIPE, timeout=120)
+        assert u.returncode == 0 and u.stdout == text

@@ -235,3 +235,33 @@ def test_sharded_ennaf_at_a_high_level(ctxs, oracle):
         del os.environ["NAF_GPU_PROBE"]
     lvl1 = host(shard.ennaf_sharded_local(ctxs[:3], gpu.to_device(text), shard.make_opts())[0])      # and with it: the repeats are found
     assert oracle.unnaf(lvl1, -1) == want and len(lvl1) < 1.5 * len(mine)
+
+
+def test_window_descriptor_of_a_sharded_frame_follows_the_options(ctxs, oracle):
+    """The frame header of every stream is written by the FIRST shard; at level >= 2 / --long the later shards match across blocks
+    inside the window of the level, so the header must announce that window even when the first shard's part of a stream is a few
+    bytes (one chromosome: an ids stream of 5 bytes) -- the reference's streaming decoder sizes its history from that field
+    (unnaf/src/input.c:262-285)."""
+    from naf_amd import shard
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    big = acgt[rng.integers(0, 4, 1300000)].tobytes()
+    unit = acgt[rng.integers(0, 4, 3000)].tobytes()
+    text = b">chr1\n" + b"".join(big[a:a + 80] + b"\n" for a in range(0, len(big), 80))
+    for k in range(400):                                             # many records whose ids / names / bases repeat far back
+        text += b">scaffold_%06d some repeated description of a contig\n" % k + unit[(k * 7) % 100:] + b"\n"
+    for level, long_log, want in ((3, 0, 21), (1, 27, None), (19, 0, 23)):
+        opts = shard.make_opts(level=level, long_log=long_log)
+        naf, rep = join(ctxs, text, 3, opts)
+        h = oracle.parse_naf(naf)
+        for i in range(5):
+            fr = h.frame(naf, i)                                     # with the magic number in front
+            assert fr[4] & 0x20 == 0                                 # not single-segment: a Window_Descriptor follows
+            wlog = 10 + (fr[5] >> 3)
+            if want is not None:
+                assert wlog == want, (level, i, wlog)
+            elif i == 4:
+                assert wlog == long_log
+        assert host(ctxs[0].unnaf(ctxs[0].to_device(naf), -1)) == text
+        if oracle.have_ref():
+            assert oracle.ref_unnaf(naf) == text
