@@ -186,6 +186,91 @@ def weighted_sum(t, offset):
     return tot
 
 
+def realistic_vs_reference(ctx, text_dev, size_bytes):
+    """The realistic genome against the real reference on a bounded sample: the reference's archive of the sample decoded by the GPU
+    (bit-exact, timed, per kernel) and by the reference itself (one thread), and the GPU's archive of the sample decoded by the
+    reference (the drop-in direction)."""
+    import numpy as np
+    import torch
+    from naf_amd import capi
+    shm = "/dev/shm/naf_bench_rg_%d" % os.getpid()
+    os.makedirs(shm, exist_ok=True)
+    P = lambda name: os.path.join(shm, name)
+    try:
+        cut = last_line_end(text_dev[:size_bytes])
+        sample = text_dev[:cut]
+        sample.cpu().numpy().tofile(P("r.fa"))
+        env = dict(os.environ, TMPDIR=shm)
+        t0 = time.perf_counter(); subprocess.check_call([REF_E, P("r.fa"), "-o", P("r.naf")], env=env); t_e = time.perf_counter() - t0
+        t0 = time.perf_counter(); subprocess.check_call([REF_U, P("r.naf"), "-o", P("r.out")]); t_u = time.perf_counter() - t0
+        ref_naf = torch.from_numpy(np.fromfile(P("r.naf"), dtype=np.uint8)).to(text_dev.device)
+        buf = torch.empty(cut + 64, dtype=torch.uint8, device=text_dev.device)
+        r = ctx.unnaf(ref_naf, capi.OUT_FASTA, out=buf); torch.cuda.synchronize()
+        ok = bool(torch.equal(r, sample))
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.unnaf(ref_naf, capi.OUT_FASTA, out=buf)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+        ctx.set_timing(True); ctx.unnaf(ref_naf, capi.OUT_FASTA, out=buf); kt = sorted(ctx.get_timing(), key=lambda x: -x[1])[:6]; ctx.set_timing(False)
+        mine, _rep = ctx.ennaf(sample)
+        mine.cpu().numpy().tofile(P("m.naf"))
+        subprocess.check_call([REF_U, P("m.naf"), "-o", P("m.out")])
+        drop_in = subprocess.call(["cmp", "-s", P("r.fa"), P("m.out")]) == 0
+        return {"reference_sample": {"text_bytes": int(cut), "reference_archive_bytes": int(ref_naf.numel()), "gpu_archive_bytes": int(mine.numel()),
+                                     "reference_unnaf_value": round(cut / t_u / 1e9, 3), "reference_ennaf_value": round(cut / t_e / 1e9, 3),
+                                     "gpu_unnaf_of_reference_archive": {"value": round(cut / dt / 1e9, 2), "ms": round(dt * 1e3, 3), "bit_exact": ok,
+                                                                        "kernels_ms": {n: round(ms, 3) for n, ms, k in kt}},
+                                     "reference_unnaf_of_gpu_archive_bit_exact": bool(drop_in), "unit": "GB/s of text"}}
+    finally:
+        subprocess.call(["rm", "-rf", shm])
+
+
+def side_workload(ctx, text, out_mode, what, fold_case=False, reps=3):
+    """One more workload beside the headline config, device-resident both ways: ennaf then unnaf of `text`, each timed as the MEAN of
+    `reps` calls after one untimed call, the round trip checked at full size, per-kernel device time of one instrumented call each
+    way, and the whole call against the HBM roofline on its algorithmic bytes (text + .naf)."""
+    import torch
+    from naf_amd import capi
+    n = int(text.numel())
+    nbuf = torch.empty(int(ctx.L.naf_gpu_ennaf_bound(n)), dtype=torch.uint8, device=text.device)
+    for _ in range(2):                              # untimed: the scratch arenas of the call's side contexts grow, then settle into one allocation each
+        naf, rep = ctx.ennaf(text, out=nbuf)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        naf, rep = ctx.ennaf(text, out=nbuf)
+    torch.cuda.synchronize()
+    t_e = (time.perf_counter() - t0) / reps
+    ctx.set_timing(True); ctx.ennaf(text, out=nbuf); ekt = sorted(ctx.get_timing(), key=lambda x: -x[1])[:5]; ctx.set_timing(False)
+    naf = naf.clone(); del nbuf
+    out = torch.empty(n + 64, dtype=torch.uint8, device=text.device)
+    back = ctx.unnaf(naf, out_mode, out=out)
+    torch.cuda.synchronize()
+    if fold_case:                                   # FASTQ comes back with upper-case bases (unnaf.c:442, SURVEY R3): every byte equal or differing in the case bit only
+        ok = int(back.numel()) == n
+        step = 1 << 28
+        for a in range(0, n, step):
+            x, y = back[a:a + step], text[a:a + step]
+            ok = ok and bool(((x == y) | ((x ^ 32) == y)).all())
+    else:
+        ok = bool(torch.equal(back, text))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.unnaf(naf, out_mode, out=out)
+    torch.cuda.synchronize()
+    t_d = (time.perf_counter() - t0) / reps
+    ctx.set_timing(True); ctx.unnaf(naf, out_mode, out=out); dkt = sorted(ctx.get_timing(), key=lambda x: -x[1])[:6]; ctx.set_timing(False)
+    n_naf = int(naf.numel())
+    res = {"what": what, "text_bytes": n, "naf_bytes": n_naf, "naf_ratio": round(n_naf / n, 4), "unit": "GB/s of text (device-resident, mean of %d calls)" % reps,
+           "unnaf_value": round(n / t_d / 1e9, 3), "unnaf_ms": round(t_d * 1e3, 3), "unnaf_path_frac": round((n + n_naf) / t_d / HBM_PEAK, 4),
+           "unnaf_kernels_ms": {k: round(ms, 3) for k, ms, c in dkt},
+           "ennaf_value": round(n / t_e / 1e9, 3), "ennaf_ms": round(t_e * 1e3, 3), "ennaf_path_frac": round((n + n_naf) / t_e / HBM_PEAK, 4),
+           "ennaf_kernels_ms": {k: round(ms, 3) for k, ms, c in ekt},
+           ("roundtrip_ok_case_folded" if fold_case else "roundtrip_bit_exact"): ok}
+    del out, back
+    return res, naf
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +285,8 @@ def main():
                     help="N > 1: one archive per GPU, no data-path collective (the round-1 shape) instead of one sharded archive + gather")
     ap.add_argument("--force-sharded", action="store_true", help="run the N > 1 code path with whatever world size there is (1 on the test box)")
     ap.add_argument("--softmask-size", type=float, default=4e9, help="N = 1: bytes of a soft-masked FASTA (runs of 20..600 bases) encoded and decoded beside the headline config (0: skip)")
+    ap.add_argument("--realistic-size", type=float, default=4e9, help="N = 1: bytes of a synthetic repeat-masked genome (skewed composition, N runs, IUPAC, soft mask) encoded and decoded beside the headline config (0: skip)")
+    ap.add_argument("--fastq1-size", type=float, default=4e9, help="N = 1: bytes of cfg5 FASTQ encoded and decoded beside the headline config (0: skip)")
     ap.add_argument("--fastq-size", type=float, default=4e9, help="N > 1: FASTQ bytes per GPU for the sharded FASTQ encode (configs[4]; 0: skip)")
     args = ap.parse_args()
 
@@ -234,6 +321,7 @@ def main():
     if not sharded:
         # ---- archive made by the GPU encoder (timed separately; reported as ennaf_value)
         naf_buf = torch.empty(int(n_text * 0.27) + (1 << 20), dtype=torch.uint8, device=dev)
+        ctx.ennaf(text, out=naf_buf)                            # untimed first call (arena growth, lazy initialisation)
         torch.cuda.synchronize()
         enc_times = []
         for _ in range(3):
@@ -280,7 +368,7 @@ def main():
         ok = True
         if rank == 0:
             ok = int(mine[1].item()) == total_text and int(mine[0].item()) == weighted_sum(r, 0) and bool(torch.equal(r[:n_text], text))
-        extra["sharded_ennaf"] = {"value": round(total_text / min(enc_times) / 1e9, 3), "unit": "GB/s FASTA in, whole job: split + streams + zstd on every rank, parts gathered to rank 0 (BASELINE configs[4] shape on FASTA)",
+        extra["sharded_ennaf"] = {"value": round(total_text * len(enc_times) / sum(enc_times) / 1e9, 3), "unit": "GB/s FASTA in, whole job: split + streams + zstd on every rank, parts gathered to rank 0 (BASELINE configs[4] shape on FASTA)",
                                   "borrowed_bytes": sinfo["halo"], "given_bytes": sinfo["cut"]}
     for _ in range(max(0, args.warmup - 1)):
         step()
@@ -348,7 +436,7 @@ def main():
                 back = ctx.unnaf(fq_naf, capi.OUT_FASTQ)
                 # FASTQ comes back with upper-case bases (unnaf.c:442, R3): rank 0's own slice, case-folded, and the total size
                 fq_ok = int(back.numel()) == int(tot.item()) and bool(torch.equal((back[:nfq] & 0xDF), (fq_buf[:nfq] & 0xDF)))
-                extra["sharded_ennaf_fastq"] = {"value": round(float(tot.item()) / min(ts) / 1e9, 3), "unit": "GB/s FASTQ in (BASELINE configs[4] shape)",
+                extra["sharded_ennaf_fastq"] = {"value": round(float(tot.item()) * len(ts) / sum(ts) / 1e9, 3), "unit": "GB/s FASTQ in (BASELINE configs[4] shape)",
                                                 "text_bytes": int(tot.item()), "naf_ratio": round(fq_naf.numel() / float(tot.item()), 4), "roundtrip_ok_case_folded": fq_ok}
             del fq_buf
 
@@ -377,25 +465,31 @@ def main():
         comp = rep.section_comp[4]
         # the scatter pass writes the packed codes and the case bits itself (no byte-per-base intermediate)
         ealg = {"ennaf_scatter_regular": n_text + packed + T // 8, "ennaf_scatter": n_text + packed + T // 8, "ennaf_count_pure": n_text, "ennaf_count": n_text, "ennaf_last": n_text // 16, "zenc_plan": packed, "zenc_write": packed + comp}
-        ennaf_roofline = roofline_of(enc_kt, ealg, n_text, n_text + n_naf, min(enc_times) * 1e3, fname="pmc_traffic_ennaf.json")
+        ennaf_roofline = roofline_of(enc_kt, ealg, n_text, n_text + n_naf, sum(enc_times) / len(enc_times) * 1e3, fname="pmc_traffic_ennaf.json")
 
-    if rank == 0 and not multi and args.softmask_size > 0:
-        # what a repeat-masked assembly looks like: the mask stream and the toggles of every tile are real work here (they are empty
-        # in the headline config); reported beside it, not part of `value`
-        sm = synth.softmask_device(synth.fasta_acgt_device(int(args.softmask_size), n_records=24, width=60, seed=7, device=dev))
-        sm_out = torch.empty(sm.numel() + 64, dtype=torch.uint8, device=dev)
-        te, td = [], []
-        for _ in range(3):
-            torch.cuda.synchronize(); t0 = time.time(); sm_naf, _r = ctx.ennaf(sm); torch.cuda.synchronize(); te.append(time.time() - t0)
-        for _ in range(4):
-            torch.cuda.synchronize(); t0 = time.time(); back = ctx.unnaf(sm_naf, capi.OUT_FASTA, out=sm_out); torch.cuda.synchronize(); td.append(time.time() - t0)
-        extra["softmasked"] = {"text_bytes": int(sm.numel()), "naf_bytes": int(sm_naf.numel()), "unnaf_value": round(sm.numel() / min(td[1:]) / 1e9, 3),
-                               "ennaf_value": round(sm.numel() / min(te[1:]) / 1e9, 3), "unit": "GB/s of text", "roundtrip_bit_exact": bool(torch.equal(back, sm)),
-                               "what": "60-column FASTA, 24 records, alternating upper / lower-case runs of 20..600 bases"}
-        del sm, sm_out, sm_naf, back
+    if rank == 0 and not multi:
+        # ---- the other workloads of north_star, on this GPU, in this line (none of them is `value`)
+        del out
+        if args.softmask_size > 0:
+            # the mask stream and the toggles of every tile are real work here (they are empty in the headline config)
+            sm = synth.softmask_device(synth.fasta_acgt_device(int(args.softmask_size), n_records=24, width=60, seed=7, device=dev))
+            extra["softmasked"], _ = side_workload(ctx, sm, capi.OUT_FASTA, "uniform ACGT, 60-column FASTA, 24 records, alternating upper / lower-case runs of 20..600 bases")
+            del sm, _
+        if args.realistic_size > 0:
+            # what an assembled, repeat-masked genome looks like: skewed pair histogram (GC 41 %, CpG depleted), runs of N, IUPAC codes, soft mask
+            rg = synth.realistic_genome_device(int(args.realistic_size), device=dev)
+            extra["realistic"], rg_naf = side_workload(ctx, rg, capi.OUT_FASTA, "synthetic repeat-masked genome: GC 41 %, CpG at 0.22 of expectation, N runs (telomeres, gaps of 5-100 k), an IUPAC code per Mbase, soft-mask runs of 20..600, 24 records of unequal length, 60-column lines")
+            if have_ref() and not args.no_cpu:
+                extra["realistic"].update(realistic_vs_reference(ctx, rg, int(min(args.cpu_sample / 4, rg.numel()))))
+            del rg, rg_naf
+        if args.fastq1_size > 0:
+            # BASELINE configs[4] on one GPU: FASTQ, 150-base reads, mixed case + N, full quality range (SURVEY 8(d) cfg5 generator)
+            fq = synth.fastq_reads_device(int(args.fastq1_size), seed=7, device=dev)
+            extra["fastq"], _ = side_workload(ctx, fq, capi.OUT_FASTQ, "FASTQ, 150-base reads `@readN len=150`, ACGT 0.22 each / acgt 0.025 each / N 0.02, quality uniform Phred 0-40 (SURVEY 8(d) cfg5 generator)", fold_case=True)
+            del fq, _
+        out = None
     cb = None
     if rank == 0 and not multi and not args.no_cpu:
-        del out
         cb = cpu_baseline(text, int(min(args.cpu_sample, n_text)), ctx, e2e_bytes=int(min(args.e2e_size, n_text)))
     if rank == 0:
         if sharded:
@@ -413,7 +507,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload, "parallelism": par},
             "roundtrip_bit_exact": ok,
-            "ennaf_value": round(float(total_text) / min(enc_times) / 1e9, 3),
+            "ennaf_value": round(float(total_text) * len(enc_times) / sum(enc_times) / 1e9, 3),
             "ennaf_unit": "GB/s FASTA in (device-resident, same data%s)" % (", sharded over the ranks, parts gathered to rank 0" if sharded else ""),
             "naf_ratio": round(n_naf / float(total_text), 4),
             "roofline": roofline, "ennaf_roofline": ennaf_roofline, "cpu_baseline": cb,

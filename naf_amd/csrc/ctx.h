@@ -23,8 +23,15 @@ struct ZSplit { int parts; hipEvent_t ev[ZSPLIT_MAX]; u64 out_end[ZSPLIT_MAX]; i
 // packed intermediate -- 5 GB written and read back per 10 GB of text -- never exists.  The decoder fills this when asked to and
 // the frame qualifies: per (block, stream) slot the packed offset of its first symbol and the bit address of the end of its data.
 struct FlatStream { u64 q0, A; };
+// A frame where most, not all, blocks carry the flat tree (a real genome coded with the encoder's flat preference: runs of N, IUPAC
+// codes, a block with a skewed pair histogram here and there): `cls` holds one byte per block -- bit 0: its streams can be read in
+// place, bit 1: its bytes were decoded into the packed stream -- and the blocks that are not flat, with their two neighbours, ARE
+// decoded (at their natural offsets of the packed stream), so that every 4 KiB tile of text lies either over blocks that can be
+// read in place or over blocks that were decoded.  The slots of a block that cannot be read in place carry A = FLAT_DECODED.
+#define FLAT_DECODED (~0ull)
 struct ZFlat { const u8 *src; const FlatStream *si; u64 nslots; const u8 *sym; void *status; bool ready;
-               const u8 *tail; u64 tail_q; u32 tail_n; };   // tail: a final Raw block (the byte that holds the padding nibble of an odd stream, zstd_enc) -- its bytes lie in the frame as they are; packed index of its first byte; its length
+               const u8 *tail; u64 tail_q; u32 tail_n;
+               const u8 *cls; u32 n_decoded; };   // cls == nullptr: every block is flat (nothing was decoded)   // tail: a final Raw block (the byte that holds the padding nibble of an odd stream, zstd_enc) -- its bytes lie in the frame as they are; packed index of its first byte; its length
 struct naf_gpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -112,7 +119,7 @@ int zstd_split_status(naf_gpu_ctx *c, const ZSplit *sp);
 int zstd_small_batch(naf_gpu_ctx *c, int n, const u8 *const *src, const size_t *len, u8 *const *dst, const size_t *cap, bool *ok);
 // One frame of independently coded blocks; with_magic=0 omits the 4 magic bytes (as stored in a .naf section).
 // level >= 2 (or lz != 0) adds the LZ stage (matches inside a block).
-enum { ZENC_PART = 16, ZENC_PART_FIRST = 32, ZENC_PART_LAST = 64, ZENC_PREFER_RAW = 128 };   // PREFER_RAW: Huffman only where it saves an eighth of the block     // with_magic flags: a shard's part of a frame (zstd_enc.hip)
+enum { ZENC_PART = 16, ZENC_PART_FIRST = 32, ZENC_PART_LAST = 64, ZENC_PREFER_RAW = 128, ZENC_PREFER_FLAT = 256 };   // PREFER_FLAT: k-bit codes for blocks of 2^k symbols unless Huffman coding saves a sixteenth (zstd_enc.hip)   // PREFER_RAW: Huffman only where it saves an eighth of the block     // with_magic flags: a shard's part of a frame (zstd_enc.hip)
 int zenc_level_window(int level);
 int zenc_repeat_probe(naf_gpu_ctx *c, const u8 *d_src, size_t n, u32 *share_1024);   // level 1: share of sampled anchors that repeat inside their 1 MiB region
 // place != nullptr: the frame's size is read back once it is planned and place->fn(place->ud, size) names where it goes (nullptr = give up,

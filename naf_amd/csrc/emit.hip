@@ -155,6 +155,7 @@ __device__ u32 flat_packed_byte(const EmitP &P, u64 q)
     u64 lo = 0, hi = P.fslots;                                   // last slot with q0 <= q
     while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (si[mid].q0 <= q) lo = mid; else hi = mid; }
     if (q >= si[lo + 1].q0) return 0;                            // past the end of the data
+    if (si[lo].A == FLAT_DECODED) return P.seq[q];               // a block that was decoded (ctx.h: ZFlat, `cls`)
     const u64 B = si[lo].A - 4 * (q - si[lo].q0 + 1), a = B >> 3; const u32 sh = (u32)B & 7;
     u32 v = P.fsrc[a]; if (sh > 4) v |= (u32)P.fsrc[a + 1] << 8;
     return P.fsym[(v >> sh) & 15];
@@ -699,7 +700,7 @@ __global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr, TileFlat
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t > ntiles) return;
     u64 p = P.out_begin + t * 4096;
-    TileIdx x; x.fast = 0; x.gline = 0; x.khi = 0;
+    TileIdx x; x.fast = 0; x.gline = 0; x.khi = 0;             // (fast: between index and classify, for flat frames, the class bits of the blocks under the tile)
     if (p >= P.out_end) { tr[t] = ~0ull; x.k = P.n_toggles; x.col = TI_HDR; ti[t] = x; return; }
     u64 g;
     if (P.mode == EM_SEQ) { tr[t] = 0; x.col = 0; g = p; x.gline = p; }
@@ -719,13 +720,21 @@ __global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr, TileFlat
         g = P.rec_base[r] + j;
     }
     x.k = P.masking ? upper_bound_u64(P.toggles, 0, P.n_toggles, g) : 0;
-    ti[t] = x;
-    if (tsig) {                                                   // slot of the stream that holds the tile's first packed byte
+    if (!tsig) { ti[t] = x; return; }
+    {                                                   // slot of the stream that holds the tile's first packed byte
         const FlatStream *si = (const FlatStream *)P.fsi;
         const u64 q = g >> 1;
         u64 lo = 0, hi = P.fslots;
         while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (si[mid].q0 <= q) lo = mid; else hi = mid; }
         TileFlat f; f.q0 = si[lo].q0; f.A = si[lo].A; f.qf = q;
+        if (P.fcls) {
+            // what the blocks under the tile's packed bytes [q, q + 2048 + 16] have in common (bit 0: readable in place, bit 1: decoded);
+            // four slots per block: block b starts at si[4 b].q0
+            u32 c = 3; u64 b = lo >> 2; const u64 nb = P.fslots >> 2, qe = q + 2048 + 16;
+            for (u32 k = 0; k < 6 && b < nb && si[4 * b].q0 <= qe; k++, b++) c &= P.fcls[b];
+            if (b < nb && si[4 * b].q0 <= qe) c = 0;              // more blocks than that (tiny ones): the slow way
+            x.fast = c;
+        } else x.fast = 1;
         u64 cs = lo + 1;                                          // next slot that has symbols (single-stream blocks leave three empty)
         while (cs < P.fslots && si[cs + 1].q0 == si[cs].q0) cs++;
         f.q1 = si[cs].q0; f.A1 = cs < P.fslots ? si[cs].A : 0;
@@ -734,10 +743,13 @@ __global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr, TileFlat
         f.q2 = si[ce].q0;
         tsig[t] = f;
     }
+    ti[t] = x;
 }
 // fast = the whole tile lies in the body of one record (and the next tile starts in the same record, so that the
 // record's final newline is not in it); every other tile goes on the list of the segment-composing kernel
-__global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr, u32 *list, u32 *count, TileFlat *tsig, u32 spare)
+// fast = 1: tile kernel of the launch (k_emit_tile, or k_emit_tile_flat reading the frame in place); 2: a tile of a mostly-flat frame
+// over blocks that were decoded -- k_emit_tile_list takes those from `list2`; 0: k_emit_rest (`list`)
+__global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr, u32 *list, u32 *count, TileFlat *tsig, u32 spare, u32 *list2)
 {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     TileFlatE e; e.base = (u64)P.fsrc; e.a1_addr = (u64)P.fsrc; e.a1_sh = 4; e.K0 = e.K1 = 0; e.d1 = e.d2 = 0x7FFFFFFFu; e.qoff = 0; e.par0 = 0; e.pad = 0;
@@ -747,8 +759,12 @@ __global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr,
     }
     const bool wrap = P.mode == EM_FASTA && P.L != 0;
     bool fast = ti[t].col != TI_HDR && tr[t] == tr[t + 1] && P.out_begin + (t + 1) * 4096 <= P.out_end && !P.force_slow && (!wrap || P.L >= 16);
+    bool packed = false;
     if (tsig) {
         const TileFlat f = tsig[t];
+        const u32 cbits = ti[t].fast;                              // from k_tile_index: 1 unless the frame has decoded blocks
+        packed = fast && (cbits & 2);
+        if (fast && !(cbits & 1)) fast = false;
         if (fast) {
             fast = f.qf + 2048 + 16 < f.q2 || f.q2 == f.q1;         // at most two streams under the tile (q2 == q1: the data end there)
             if (P.ftail && f.qf + 2048 + 16 >= P.ftail_q) fast = false;   // the bytes of a final Raw block are not in any stream
@@ -771,15 +787,13 @@ __global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr,
         *(TileFlatE *)&tsig[t] = e;
     }
     ti[t].khi = ti[t + 1].k;
-    ti[t].fast = fast ? 1u : 0u;
-    if (!fast) list[atomicAdd(count, 1u)] = (u32)t;
+    ti[t].fast = fast ? 1u : (packed ? 2u : 0u);
+    if (!fast) { if (packed) list2[atomicAdd(count + 1, 1u)] = (u32)t; else list[atomicAdd(count, 1u)] = (u32)t; }
 }
 
 template <bool FOURBIT>
-__global__ __launch_bounds__(256) void k_emit_tile(EmitP P, const TileIdx *ti, u8 *out)
+__device__ __forceinline__ void emit_tile_body(const EmitP &P, const TileIdx &a, u8 *out_tile)
 {
-    const TileIdx a = ti[blockIdx.x];
-    if (!a.fast) return;
     // soft-masked genomes put a dozen toggles into every tile: the tile's window goes to LDS once instead of every lane
     // walking it in global memory
     __shared__ u64 s_tog[EMIT_TOG_LDS];
@@ -810,7 +824,26 @@ __global__ __launch_bounds__(256) void k_emit_tile(EmitP P, const TileIdx *ti, u
     else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
     if (nl_b < 16) splice_newline(lo, hi, (int)nl_b);
     uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
-    *(uint4 *)(out + (u64)blockIdx.x * 4096 + lane16) = v;
+    *(uint4 *)(out_tile + lane16) = v;
+}
+template <bool FOURBIT>
+__global__ __launch_bounds__(256) void k_emit_tile(EmitP P, const TileIdx *ti, u8 *out)
+{
+    const TileIdx a = ti[blockIdx.x];
+    if (a.fast != 1) return;
+    emit_tile_body<FOURBIT>(P, a, out + (u64)blockIdx.x * 4096);
+}
+// the tiles of a list (its length stays on the device): the decoded stretches of a mostly-flat frame
+template <bool FOURBIT>
+__global__ __launch_bounds__(256) void k_emit_tile_list(EmitP P, const TileIdx *ti, const u32 *list, const u32 *count, u8 *out)
+{
+    const u32 n = *count;
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        const u32 t = list[i];
+        const TileIdx a = ti[t];
+        emit_tile_body<FOURBIT>(P, a, out + (u64)t * 4096);
+        __syncthreads();                                          // s_tog is reused by the next tile
+    }
 }
 
 // The same tile kernel for a flat frame read in place: a lane's 16 bases are 8 (9 when its first base is an odd one) consecutive
@@ -880,7 +913,7 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
 #pragma unroll
         for (u32 j = 0; j < FLAT_TPW; j++) {
             __builtin_memcpy(&A[j], &ra[2 * j], 32); __builtin_memcpy(&F[j], &rf[3 * j], 48);
-            live[j] = t0 + j < ntiles && A[j].fast != 0;
+            live[j] = t0 + j < ntiles && A[j].fast == 1;
         }
     }
     // ---- phase 1: where every chunk's codes are, and the loads.  A chunk needs the 36 bits under `top` (nine 4-bit codes; a bit
@@ -1562,7 +1595,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         c->zflat = nullptr;
         if (rc) return rc;
     }
-    if (zflat.ready) { pl.P.fsrc = zflat.src; pl.P.fsi = zflat.si; pl.P.fslots = zflat.nslots; pl.P.fsym = zflat.sym; pl.P.ftail = zflat.tail; pl.P.ftail_q = zflat.tail_q; pl.P.ftail_n = zflat.tail_n; }
+    if (zflat.ready) { pl.P.fsrc = zflat.src; pl.P.fsi = zflat.si; pl.P.fslots = zflat.nslots; pl.P.fsym = zflat.sym; pl.P.ftail = zflat.tail; pl.P.ftail_q = zflat.tail_q; pl.P.ftail_n = zflat.tail_n; pl.P.fcls = zflat.cls; }
     if (pl.P.mode == -1) {                                                             // --4bit: the stream itself
         HIP_TRY(c, hipMemcpyAsync(d_out, seq + out_begin, out_end - out_begin, hipMemcpyDeviceToDevice, c->stream));
         return 0;
@@ -1599,15 +1632,16 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             u64 ntiles = cdiv(m_end - m_begin, 4096);
             TileIdx *ti = arena_new<TileIdx>(c, ntiles + 2 + FLAT_TPW); u64 *tr = arena_new<u64>(c, ntiles + 2);
             u32 *list = arena_new<u32>(c, ntiles + 1), *cnt = arena_new<u32>(c, 2);
-            if (!ti || !tr || !list || !cnt) return NAF_GPU_ENOMEM;
-            if (!split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, c->stream));
+            u32 *list2 = (zflat.ready && zflat.cls) ? arena_new<u32>(c, ntiles + 1) : list;      // tiles over decoded blocks of a mostly-flat frame
+            if (!ti || !tr || !list || !cnt || !list2) return NAF_GPU_ENOMEM;
+            if (!split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 8, c->stream));
             // exact c / (L+1) for c < L + 1 + 4096 as mulhi(c, M), M = floor(2^32 / (L+1)) + 1, valid while c * (L+1) < 2^32
             u64 Lp1 = pl.P.L + 1;
             pl.P.Ldiv_magic = (Lp1 >= 2 && Lp1 < 32768) ? (u32)((1ull << 32) / Lp1 + 1) : 0;
             // With a split decode (ZSplit) the index and the tiles behind the finished parts run on the second stream beside the
             // decode of the next part; this stream takes the tiles behind the last part, the boundary tiles, and waits for the other.
             naf_gpu_ctx *ic = split.done ? c->side2 : c;                                     // context the tile index is built on
-            if (split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, ic->stream));
+            if (split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 8, ic->stream));
             TileFlat *tsig = nullptr;
             if (zflat.ready) {
                 tsig = arena_new<TileFlat>(c, ntiles + 2 + FLAT_TPW); u32 *fpair = arena_new<u32>(c, 256); if (!tsig || !fpair) return NAF_GPU_ENOMEM;
@@ -1615,7 +1649,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                 pl.P.fpair = fpair;
             }
             LAUNCH(ic, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr, tsig);
-            LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles + FLAT_TPW, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt, tsig, (u32)FLAT_TPW);
+            LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles + FLAT_TPW, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt, tsig, (u32)FLAT_TPW, list2);
             u64 t_done = 0;
             if (split.done) {
                 HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX], ic->stream));
@@ -1637,6 +1671,12 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                 const u32 nwg = cdiv(ntiles, FLAT_TPW), chunk = (nwg + 7) / 8;
                 static const bool xcd = !(getenv("NAF_GPU_XCD") && getenv("NAF_GPU_XCD")[0] == '0');
                 LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat, xcd ? chunk * 8 : nwg, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, xcd ? chunk : 0u);
+                if (zflat.cls && zflat.n_decoded) {
+                    // a tile costs this kernel about what it costs k_emit_tile: as many workgroups as there can be tiles over decoded blocks, up to a few waves of the device
+                    const u64 est = (u64)zflat.n_decoded * 64 + 64;                           // (blocks of up to 128 KiB: 64 tiles each)
+                    const u32 lgrid = (u32)(est < ntiles ? (est < 16384 ? est : 16384) : (ntiles < 16384 ? ntiles : 16384));
+                    LAUNCH(c, "unnaf_emit", k_emit_tile_list<true>, lgrid, 256, 0, pl.P, (const TileIdx *)ti, (const u32 *)list2, (const u32 *)(cnt + 1), d_out);
+                }
             }
             else if (t_done < ntiles) {
                 if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit_tile<true>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
@@ -1647,6 +1687,10 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             if (pl.fourbit) LAUNCH(c, "unnaf_emit_rest", k_emit_rest<true>, rest_grid, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
             else LAUNCH(c, "unnaf_emit_rest", k_emit_rest<false>, rest_grid, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
             if (split.done) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX + 1], 0));
+            if (zflat.ready && getenv("NAF_GPU_DEBUG_FLAT")) {          // tests: how the tiles were dealt
+                u32 hc[2] = { 0, 0 };
+                if (!ctx_readback(c, hc, cnt, 8)) fprintf(stderr, "[flat tiles] total %llu rest %u decoded %u\n", (unsigned long long)ntiles, hc[0], hc[1]);
+            }
         }
     }
     if (has_tail) {

@@ -25,7 +25,8 @@ struct EmitP {
     int force_slow;
     // a flat frame read in place (ctx.h: ZFlat): stream table, source, code -> packed byte; fsrc == nullptr otherwise
     const u8 *ftail; u64 ftail_q; u32 ftail_n;   // the frame's final Raw block, if it has one (ZFlat)
-    const u8 *fsrc; const void *fsi; u64 fslots; const u8 *fsym; const u32 *fpair;    // fpair: the 16-entry table code -> packed byte as four dwords (for v_perm_b32)
+    const u8 *fsrc; const void *fsi; u64 fslots; const u8 *fsym; const u32 *fpair;
+    const u8 *fcls;                    // per block of a mostly-flat frame: bit 0 = readable in place, bit 1 = decoded into `seq` (ctx.h: ZFlat); nullptr = all flat    // fpair: the 16-entry table code -> packed byte as four dwords (for v_perm_b32)
 };
 
 

@@ -1909,6 +1909,9 @@ static int ennaf_windows(naf_gpu_ctx *c, EnnafStreams &X, const naf_gpu_ennaf_op
 {
     const int wl = zenc_level_window(o->level);
     for (int i = 0; i < 6; i++) X.window_log[i] = wl;
+    // level 1 (the default, "fast"): the sequence stream's blocks of sixteen pair codes stay at four bits per code unless Huffman
+    // coding saves a sixteenth (zstd_enc.hip: ZENC_PREFER_FLAT) -- the decoder then reads them in place
+    if (o->level <= 1) X.flags[4] |= ZENC_PREFER_FLAT;
     if (o->long_log) { X.window_log[4] = o->long_log < 10 ? 10 : o->long_log > 31 ? 31 : o->long_log; X.lz[4] = 1; }
     else if (!wl && X.present[4] && X.len[4]) {
         const char *pe = getenv("NAF_GPU_PROBE");                 // "0": never look, "1": always match
@@ -1951,7 +1954,7 @@ static int encode_stream_begin(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int 
 {
     J->main = nullptr; J->d_stream = d_stream; J->len = len; J->level = level; J->flags = flags; J->tail = (tail && len > tail) ? tail : 0;
     int f1 = flags;
-    if (J->tail) f1 = ZENC_PART | ((!(flags & ZENC_PART) || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0);
+    if (J->tail) f1 = ZENC_PART | ((!(flags & ZENC_PART) || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT));
     int rc = zstd_encode_begin(c, d_stream, len - J->tail, level, f1, lz, block_log, window_log, &J->main);
     if (rc) { zstd_encode_drop(J->main); J->main = nullptr; }
     return rc;
@@ -1980,7 +1983,7 @@ static int encode_stream(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level,
     }
     if (!tail || len <= tail) return zstd_encode(c, d_stream, len, level, dst, cap, clen, flags, lz, block_log, window_log);
     const bool part = (flags & ZENC_PART) != 0;
-    const int f1 = ZENC_PART | ((!part || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0);
+    const int f1 = ZENC_PART | ((!part || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT));
     const int f2 = ZENC_PART | ((!part || (flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0);
     size_t a = 0, b = 0;
     int rc = zstd_encode(c, d_stream, len - tail, level, dst, cap, &a, f1, lz, block_log, window_log); if (rc) return rc;
@@ -2064,7 +2067,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
         HIP_TRY(c, hipStreamWaitEvent(sc->stream, c->fork_ev, 0));
         for (int i = 4; i < 6; i++)
             if (X.present[i]) {
-                if ((rc = encode_stream_begin(c, X.ptr[i], X.len[i], o->level, 0, X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]))) { for (int k = 4; k < i; k++) if (early[k]) zstd_encode_drop(big[k].main); return rc; }
+                if ((rc = encode_stream_begin(c, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]))) { for (int k = 4; k < i; k++) if (early[k]) zstd_encode_drop(big[k].main); return rc; }
                 early[i] = true;
             }
         if (probe_later) {
@@ -2075,7 +2078,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
             ennaf_probe_verdict(X, share);
             if (X.lz[4]) {
                 zstd_encode_drop(big[4].main); early[4] = false;
-                if ((rc = encode_stream_begin(c, X.ptr[4], X.len[4], o->level, 0, X.lz[4], X.block_log[4], X.window_log[4], X.tail[4], &big[4]))) { if (early[5]) zstd_encode_drop(big[5].main); hipStreamSynchronize(sc->stream); return rc; }
+                if ((rc = encode_stream_begin(c, X.ptr[4], X.len[4], o->level, X.flags[4], X.lz[4], X.block_log[4], X.window_log[4], X.tail[4], &big[4]))) { if (early[5]) zstd_encode_drop(big[5].main); hipStreamSynchronize(sc->stream); return rc; }
                 early[4] = true;
             }
         }

@@ -25,7 +25,7 @@ struct ZStat {                 // device-side counters read back by the host
     u32 ticket, n_plain_huf;     // n_plain_huf: compressed blocks with Huffman literals and no sequences
     u32 max_seq_regen, n_flat;    // largest regenerated size among the blocks that have sequences; table-defining blocks whose tree is flat
     u32 n_huf_distinct, n_huf_built;   // tree descriptions that differ from their predecessor's (k_huf_dedup); tables actually built
-    u32 last_raw, pad_;                // size of the frame's last block when it is a Raw or (bit 31) RLE one, else 0
+    u32 last_raw, flat_main_inv;       // size of the frame's last block when it is a Raw or (bit 31) RLE one, else 0; 0xFFFFFFFF - index of the FIRST block that defines a flat 4-bit tree (0: none)
 };
 
 static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
@@ -330,6 +330,7 @@ __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 
     if (fl) {
         blk[i].huf_tab = 0xFFFFFFFFu; blk[i].huf_log = (u8)fl; blk[i].huf_flat = 1;
         atomicMax(&st->max_huf_log, fl); atomicAdd(&st->n_flat, 1u); atomicAdd(&st->n_huf_built, 1u);
+        if (fl == 4) atomicMax(&st->flat_main_inv, 0xFFFFFFFFu - i);
         return;
     }
     u8 w[256]; u32 nw = 0, used = 0;
@@ -343,6 +344,7 @@ __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 
     atomicMax(&st->max_huf_log, log);
     const bool flat = huf_is_flat(w, nw, log);
     blk[i].huf_flat = flat; if (flat) atomicAdd(&st->n_flat, 1u);
+    if (flat && log == 4) atomicMax(&st->flat_main_inv, 0xFFFFFFFFu - i);
     atomicAdd(&st->n_huf_built, 1u);
 }
 
@@ -399,6 +401,7 @@ __device__ void build_huf_one_lds(const u8 *src, ZBlock *blk, u32 i, u8 *pool, u
                 blk[i].huf_tab = off; blk[i].huf_log = (u8)log; atomicMax(&st->max_huf_log, log);
                 const bool flat = huf_is_flat(S.w, nw, log);
                 blk[i].huf_flat = flat; if (flat) atomicAdd(&st->n_flat, 1u);
+                if (flat && log == 4) atomicMax(&st->flat_main_inv, 0xFFFFFFFFu - i);
                 atomicAdd(&st->n_huf_built, 1u);
                 if (log > HUF_FULL_LOG) huf_build_compact(S.tab, S.w, nw, log, S.ws);
             }
@@ -755,7 +758,7 @@ __global__ void k_emit_headers(EmitP P, u8 *text)
 template <bool FUSE>
 __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf,
                                                       const u8 *pool, u32 slot_bytes, u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first,
-                                                      EmitP EP, u8 *text, u32 ipitch, u64 src_len, u32 flat_on)
+                                                      EmitP EP, u8 *text, u32 ipitch, u64 src_len, u32 flat_on, const u8 *sel)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     u8 *irows = lds + HUF_BLOCKS_PER_WG * slot_bytes;                // 64 input rings of ipitch bytes (136: 2 sectors, 264: 4 sectors)
@@ -768,9 +771,23 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
     }
     int lane = threadIdx.x;
     u32 b0 = b_first + blockIdx.x * HUF_BLOCKS_PER_WG;
+    // which of the sixteen blocks have streams for this kernel at all (sel: only the blocks it names; blocks of a flat tree belong to
+    // k_flat_literals): a workgroup without any returns before it stages a table
+    u64 wanted;
+    {
+        const u32 bi = b0 + ((u32)lane >> 2);
+        bool want = false;
+        if (bi < nblk && (!sel || (sel[bi] & 2))) {
+            const ZBlock &b = blk[bi];
+            if (b.btype == BT_COMP && b.lit_type >= LIT_HUF && !b.err) { const i32 ob = own_huf[bi]; want = ob < 0 || FUSE || !(flat_on && blk[ob].huf_flat); }
+        }
+        wanted = __ballot(want);
+        if (!wanted) return;
+    }
     for (u32 j = 0; j < HUF_BLOCKS_PER_WG; j++) {                     // stage the table in force for each block
         u32 bi = b0 + j;
         if (bi >= nblk) break;
+        if (!((wanted >> (4 * j)) & 1)) continue;
         const ZBlock &b = blk[bi];
         if (b.btype != BT_COMP || b.lit_type < LIT_HUF || b.err) continue;
         i32 ob = own_huf[bi];
@@ -785,7 +802,7 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
     bool valid = false; u32 log = 1, n = 0; u8 *out = nullptr; const u16 *tab = (const u16 *)lds;
     BitR br; br.consumed = 64; br.c = 0; br.ptr = br.start = src; br.bad = false;
     u8 err = 0;
-    if (bi < nblk) {
+    if (bi < nblk && ((wanted >> (4 * j)) & 1)) {
         const ZBlock &b = blk[bi];
         if (b.btype == BT_COMP && b.lit_type >= LIT_HUF && !b.err) {
             i32 ob = own_huf[bi];
@@ -955,12 +972,13 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
 // other widths take the fields out one by one.  Reads stay inside the stream; a stream whose size does not match n x L bits is
 // corrupt (the serial reader's "all bits consumed" test).
 __global__ __launch_bounds__(256) void k_flat_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf, const u8 *pool,
-                                                        u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first)
+                                                        u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first, const u8 *sel)
 {
     __shared__ u16 pair[256];                                    // L == 4: byte -> symbol of its high nibble | symbol of its low nibble << 8
     __shared__ u8 sym[256];                                      // code -> symbol
     const u32 bi = b_first + blockIdx.x;
     if (bi >= nblk) return;
+    if (sel && !(sel[bi] & 2)) return;
     const ZBlock &b = blk[bi];
     if (b.btype != BT_COMP || b.lit_type < LIT_HUF || b.err) return;
     const i32 ob = own_huf[bi];
@@ -1065,11 +1083,100 @@ __global__ void k_flat_streams(const u8 *src, const ZBlock *blk, u32 nblk, const
     si[t] = f;
 }
 
+// ---- a frame that is MOSTLY flat (ctx.h: ZFlat, `cls`) --------------------------------------------------------------------------------
+// The flat tree of the frame is the one of its first block that defines a flat 4-bit tree (`main`).  A defining block carries the same
+// tree when its description repeats main's byte for byte (huf_flat = 2).
+__global__ void k_flat_mark_owner(const u8 *src, ZBlock *blk, u32 nblk, const i32 *own_huf, u32 main)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblk || own_huf[i] != (i32)i) return;
+    ZBlock &b = blk[i];
+    if (b.btype != BT_COMP || b.lit_type != LIT_HUF || b.err || !b.huf_flat || b.huf_log != 4) return;
+    const ZBlock &m = blk[main];
+    const u32 n = b.huf_streams_off - b.lit_off;
+    if (m.huf_streams_off - m.lit_off != n) return;
+    const u8 *p = src + m.src_off + m.lit_off, *q = src + b.src_off + b.lit_off;
+    for (u32 k = 0; k < n; k++) if (p[k] != q[k]) return;
+    b.huf_flat = 2;
+}
+// code -> symbol of the main tree: from its table when one was built, else from its directly stored weights (code k is the k-th
+// symbol of weight 1 in symbol order, the last one implied -- as in k_flat_literals).  One workgroup of 256.
+__global__ __launch_bounds__(256) void k_flat_sym(const u8 *src, const ZBlock *blk, u32 main, const u8 *pool, u8 *sym)
+{
+    const ZBlock &m = blk[main];
+    const u32 t = threadIdx.x;
+    if (m.huf_tab != 0xFFFFFFFFu) { if (t < 16) sym[t] = (u8)(((const u16 *)(pool + m.huf_tab))[t] >> 8); return; }
+    __shared__ u32 s_wc[4];
+    const u8 *d = src + m.src_off + m.lit_off;
+    const u32 nw = (u32)d[0] - 127;
+    const bool one = t < nw ? (((t & 1) ? d[1 + (t >> 1)] & 15 : d[1 + (t >> 1)] >> 4) == 1) : t == nw;
+    const u64 bal = __ballot(one);
+    if ((t & 63) == 0) s_wc[t >> 6] = (u32)__popcll(bal);
+    __syncthreads();
+    u32 rank = (u32)__popcll(bal & ((1ull << (t & 63)) - 1));
+    for (u32 q = 0; q < (t >> 6); q++) rank += s_wc[q];
+    if (one && rank < 16) sym[rank] = (u8)t;
+}
+// cls0[i] = 1: block i can be read in place (a plain Huffman block whose tree in force is the main one), else 2
+__global__ void k_flat_class(const ZBlock *blk, u32 nblk, const i32 *own_huf, u8 *cls0)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblk) return;
+    const ZBlock &b = blk[i];
+    bool f = b.btype == BT_COMP && b.lit_type >= LIT_HUF && b.nseq == 0 && !b.err && b.lit_regen > 0;
+    if (f) { const i32 ob = own_huf[i]; f = ob >= 0 && blk[ob].huf_flat == 2; }
+    cls0[i] = f ? 1 : 2;
+}
+// ... and the flat neighbours of a block that is decoded are decoded too (3 = either way): a tile of text that lies across the border
+// then finds all of its packed bytes on one side or the other
+__global__ void k_flat_class2(const u8 *cls0, u32 nblk, u8 *cls, u32 *n_decoded)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 c = 0;
+    if (i < nblk) {
+        c = cls0[i];
+        if (c == 1 && ((i > 0 && cls0[i - 1] == 2) || (i + 1 < nblk && cls0[i + 1] == 2))) c = 3;
+        cls[i] = (u8)c;
+    }
+    const u64 bal = __ballot(c & 2);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_decoded, (u32)__popcll(bal));
+}
+// stream table as k_flat_streams makes it, for every block: a block that cannot be read in place is one slot of FLAT_DECODED
+__global__ void k_flat_streams_mixed(const u8 *src, const ZBlock *blk, u32 nblk, const u8 *cls, FlatStream *si, ZStat *st, const u64 *total_out)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) si[4ull * nblk].q0 = *total_out, si[4ull * nblk].A = 0;
+    if (t >= 4ull * nblk) return;
+    const u32 bi = (u32)(t >> 2), s = (u32)t & 3;
+    const ZBlock &b = blk[bi];
+    FlatStream f; f.q0 = b.out_off + b.regen; f.A = 0;
+    if (!(cls[bi] & 1)) { f.A = FLAT_DECODED; if (s == 0) f.q0 = b.out_off; si[t] = f; return; }
+    const u8 *c = src + b.src_off + b.huf_streams_off;
+    const u32 regen = b.lit_regen;
+    u32 sz = 0, n = 0; const u8 *sp = c;
+    if (b.nstreams == 1) { if (s == 0) { sz = b.huf_streams_size; n = regen; f.q0 = b.out_off; } }
+    else {
+        const u32 s1 = ld16(c), s2 = ld16(c + 2), s3 = ld16(c + 4), tot = b.huf_streams_size - 6, per = (regen + 3) / 4;
+        if (s1 + s2 + s3 >= tot || !s1 || !s2 || !s3 || per * 3 > regen) { set_err(st, ZE_CORRUPT); si[t] = f; return; }
+        const u32 off = s == 0 ? 0 : (s == 1 ? s1 : (s == 2 ? s1 + s2 : s1 + s2 + s3));
+        sz = s == 0 ? s1 : (s == 1 ? s2 : (s == 2 ? s3 : tot - s1 - s2 - s3));
+        sp = c + 6 + off; n = s < 3 ? per : regen - 3 * per; f.q0 = b.out_off + (u64)s * per;
+    }
+    if (n) {
+        const u32 last = sz ? sp[sz - 1] : 0;
+        const u64 E = last ? 8ull * (sz - 1) + (u32)hibit32(last) : 0;
+        if (!last || E != 4ull * n) set_err(st, ZE_CORRUPT);
+        f.A = 8ull * (u64)(sp - src) + E;
+    }
+    si[t] = f;
+}
+
 // ---- raw / RLE blocks and raw / RLE literal sections: one workgroup per block ------------------------------
-__global__ __launch_bounds__(256) void k_copy_fill(const u8 *src, const ZBlock *blk, u32 nblk, u8 *dst, u8 *lit_scratch, u32 b_first)
+__global__ __launch_bounds__(256) void k_copy_fill(const u8 *src, const ZBlock *blk, u32 nblk, u8 *dst, u8 *lit_scratch, u32 b_first, const u8 *sel)
 {
     u32 i = b_first + blockIdx.x;
     if (i >= nblk) return;
+    if (sel && !(sel[i] & 2)) return;
     const ZBlock &b = blk[i];
     const u8 *from; u8 *to; u32 n; bool fill;
     if (b.btype == BT_RAW) { from = src + b.src_off; to = dst + b.out_off; n = b.bsize; fill = false; }
@@ -1658,6 +1765,46 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         if (fh.has_fcs && fh.content_size != hs.total_out) return zerr(c, ZE_CORRUPT, "content size mismatch");
         return 0;
     }
+    // Most blocks flat, some not (ctx.h: ZFlat, `cls`): the blocks that are not, and their neighbours, are decoded into d_dst at their
+    // natural offsets; the caller's emit reads the rest in place.  Whole-stream calls only; a frame whose blocks mostly need
+    // decoding takes the ordinary path below (NAF_GPU_FLAT_MIXED=0: always).
+    {
+        const char *fm = getenv("NAF_GPU_FLAT_MIXED");
+        if (c->zflat && lit_only_spec && nblk > 0 && !always_table && !rg && hs.flat_main_inv && d_dst && hs.total_out <= dst_cap && !(fm && fm[0] == '0')) {
+            const u32 main = 0xFFFFFFFFu - hs.flat_main_inv;
+            ZFlat *zf = c->zflat;
+            FlatStream *si = arena_new<FlatStream>(c, 4 * (size_t)nblk + 1); u8 *d_sym = (u8 *)arena_alloc(c, 16);
+            u8 *cls0 = (u8 *)arena_alloc(c, nblk), *cls = (u8 *)arena_alloc(c, nblk); u32 *d_nx = arena_new<u32>(c, 1);
+            if (!si || !d_sym || !cls0 || !cls || !d_nx) return NAF_GPU_ENOMEM;
+            HIP_TRY(c, hipMemsetAsync(d_nx, 0, 4, c->stream));
+            LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr);
+            LAUNCH(c, "zstd_flat_class", k_flat_mark_owner, g, 64, 0, d_src, blk, nblk, (const i32 *)own_huf, main);
+            LAUNCH(c, "zstd_flat_class", k_flat_sym, 1, 256, 0, d_src, (const ZBlock *)blk, main, (const u8 *)huf_pool, d_sym);
+            LAUNCH(c, "zstd_flat_class", k_flat_class, g, 64, 0, (const ZBlock *)blk, nblk, (const i32 *)own_huf, cls0);
+            LAUNCH(c, "zstd_flat_class", k_flat_class2, g, 64, 0, (const u8 *)cls0, nblk, cls, d_nx);
+            u32 n_dec = 0;
+            if ((rc = ctx_readback(c, &n_dec, d_nx, 4))) return rc;
+            if (getenv("NAF_GPU_DEBUG_FLAT")) fprintf(stderr, "[flat mixed] nblk %u decoded %u main %u\n", nblk, n_dec, main);
+            if ((u64)n_dec * 2 <= nblk) {
+                LAUNCH(c, "zstd_flat_streams", k_flat_streams_mixed, cdiv(4ull * nblk, 256), 256, 0, d_src, (const ZBlock *)blk, nblk, (const u8 *)cls, si, st, (const u64 *)d_total_out);
+                if (n_dec) {
+                    if (hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, d_dst, (u8 *)nullptr, 0u, (const u8 *)cls);
+                    LAUNCH(c, "zstd_flat_literals", k_flat_literals, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, (u8 *)nullptr, st, 0u, (const u8 *)cls);
+                    if (hs.n_flat < hs.n_huf_built) {
+                        const u32 slot = huf_slot_bytes(hs.max_huf_log), ipitch = hs.max_huf_log > 7 ? HUF_IROW_BIG : HUF_IROW;
+                        EmitP ep; memset(&ep, 0, sizeof ep);
+                        LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(nblk, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512,
+                               d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, (u8 *)nullptr, st, 0u, ep, (u8 *)nullptr, ipitch, (u64)src_len, 1u, (const u8 *)cls);
+                    }
+                }
+                zf->src = d_src; zf->si = si; zf->nslots = 4ull * nblk; zf->sym = d_sym; zf->status = st; zf->ready = true;
+                zf->tail = nullptr; zf->tail_q = hs.total_out; zf->tail_n = 0; zf->cls = cls; zf->n_decoded = n_dec;
+                *out_len = hs.total_out;
+                if (fh.has_fcs && fh.content_size != hs.total_out) return zerr(c, ZE_CORRUPT, "content size mismatch");
+                return 0;
+            }
+        }
+    }
     u64 *d_total_seq = (u64 *)((u8 *)st + offsetof(ZStat, total_seq));
     FseE *fse_pool = nullptr; u32 *o_ll = nullptr, *o_ml = nullptr, *o_of = nullptr;
     if (n_seq_blk) {
@@ -1743,7 +1890,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         u32 ipitch = hs.max_huf_log > 7 ? HUF_IROW_BIG : HUF_IROW;
         u32 ipitch_arg = ipitch | ((getenv("NAF_GPU_HUF_GENERIC") && getenv("NAF_GPU_HUF_GENERIC")[0] == '1') ? 0x8000u : 0u);
         if (b_count && fuse) LAUNCH(c, "zstd_huf_fused_emit", (k_huf_literals<true>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 512,
-               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, 0u);
+               d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, 0u, (const u8 *)nullptr);
         else if (b_count) {
             const u32 huf_lds = slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512 + (getenv("NAF_GPU_PADLDS") ? atoi(getenv("NAF_GPU_PADLDS")) : 0);
             // blocks whose tree is flat go to k_flat_literals; the serial kernel is not launched when that is all of them
@@ -1755,7 +1902,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             if (sp && !rg && n_seq_blk == 0 && b_first == 0 && b_count == nblk && b_count >= split_min * (u32)sp->parts && b_count >= 16u * HUF_BLOCKS_PER_WG * (u32)sp->parts) {
                 // literal-only frame of a whole-text call: block ranges in order, an event behind each (see ZSplit); the raw / RLE
                 // blocks first, so that a finished part is complete
-                if (hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
+                if (hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first, (const u8 *)nullptr);
                 copy_fill_done = true;
                 // output offsets of the part ends: they came with the counters when the frame took the speculative route
                 if (ends) for (int k = 0; k + 1 < sp->parts; k++) sp->out_end[k] = hends[k];
@@ -1771,21 +1918,21 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                 u32 lo_b = 0;
                 for (int k = 0; k < sp->parts; k++) {
                     u32 hi_b = k + 1 == sp->parts ? b_count : (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
-                    if (hi_b > lo_b && flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, hi_b - lo_b, 256, 0, d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, lo_b);
+                    if (hi_b > lo_b && flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, hi_b - lo_b, 256, 0, d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, lo_b, (const u8 *)nullptr);
                     if (hi_b > lo_b && serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds,
-                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len, flat_on);
+                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr);
                     HIP_TRY(c, hipEventRecord(sp->ev[k], c->stream));
                     lo_b = hi_b;
                 }
                 sp->done = 1;
             } else {
-                if (flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, b_count, 256, 0, d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, b_first);
+                if (flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, b_count, 256, 0, d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, b_first, (const u8 *)nullptr);
                 if (serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, huf_lds,
-                   d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, flat_on);
+                   d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr);
             }
         }
     }
-    if (b_count && !fuse && !copy_fill_done && hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first);
+    if (b_count && !fuse && !copy_fill_done && hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first, (const u8 *)nullptr);
     if (n_seq_blk) {
         const char *el = getenv("NAF_GPU_EXEC_LDS");                      // "0": always the HBM executor (cross-check)
         if (max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))

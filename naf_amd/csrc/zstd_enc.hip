@@ -31,7 +31,7 @@ __host__ __device__ static inline u64 zenc_block_lo(u64 n, u32 nblk, u32 b) { u6
 
 // blk_len == nullptr: block b is the b-th piece of the even split of src[0..n).  Otherwise block b is src[b*slot .. b*slot + blk_len[b])
 // (the literals the LZ stage left of block b).
-__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse, u32 min_gain, u32 maxbits)
+__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse, u32 min_gain, u32 maxbits, u32 prefer_flat)
 {
     // ZENC_HCOPIES copies of the 4 quarter histograms (copy = lane % copies): few distinct symbols (packed ACGT has 16) would
     // otherwise serialise every LDS atomic of a wave on the same handful of addresses
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
             }
             __syncthreads();
         }
-        const u32 flat_log = s_flat_log;
+        u32 flat_log = s_flat_log;
         if (flat_log) {
             if (mine) ws.len[sym] = (u8)flat_log;
             if (threadIdx.x == 0) ws.log = flat_log;
@@ -179,6 +179,22 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
         } else if (threadIdx.x == 0) ws.log = huf_lengths_sorted(ws.tot, ws.order, distinct, ws.len, ws.w, ws.parent, ws.depth, maxbits);
         __syncthreads();
         u32 log = ws.log;
+        // Flat preference (prefer_flat = d: on when Huffman coding would save less than 1/d of the block).  A block of 2^k distinct
+        // symbols -- the sixteen pairs of A C G T of a real genome's packed stream -- coded with k bits per symbol can be read in place
+        // by this build's decoder (emit.hip: k_emit_tile_flat) and written by all lanes here (zenc_flat4_stream); the few per cent
+        // that its skewed pair histogram would save cost the decoder a pass over the packed stream.
+        if (prefer_flat && log && !flat_log && (distinct & (distinct - 1)) == 0) {
+            const u32 k = (u32)(31 - __clz((int)distinct));
+            u64 hb; wg_scan_inclusive<u64, OpAdd>((u64)mine * ws.len[sym], &hb, red);
+            const u64 fb = (u64)bn * k;
+            if (fb >= hb && (fb - hb) * prefer_flat < fb) {
+                ws.len[sym] = mine ? (u8)k : (u8)0;
+                if (threadIdx.x == 0) ws.log = k;
+                flat_log = k;
+            }
+            __syncthreads();
+            log = ws.log;
+        }
         if (log) {
             u32 l = ws.len[sym];
             ws.wt[sym] = l ? (u8)(log + 1 - l) : 0;
@@ -853,7 +869,11 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     const u32 min_gain = (with_magic & ZENC_PREFER_RAW) ? 32u : 0u;
     // (the same streams -- the mask -- keep their codes to 9 bits: this build's decoder then walks them with its single-level table)
     const u32 maxbits = (with_magic & ZENC_PREFER_RAW) ? 9u : (u32)ZENC_HUF_MAXBITS;
-    with_magic &= ~ZENC_PREFER_RAW;
+    // ZENC_PREFER_FLAT: blocks of 2^k distinct symbols take k-bit codes unless Huffman coding saves a sixteenth of the block
+    // (NAF_GPU_PREFER_FLAT=0: never; =d: the threshold 1/d)
+    u32 prefer_flat = (with_magic & ZENC_PREFER_FLAT) ? 16u : 0u;
+    if (prefer_flat) { const char *pf = getenv("NAF_GPU_PREFER_FLAT"); if (pf && pf[0]) prefer_flat = (u32)atoi(pf); }
+    with_magic &= ~(ZENC_PREFER_RAW | ZENC_PREFER_FLAT);
     if (part) with_magic = 0;
     if (part && n == 0 && !part_last) {
         J->empty = 1; J->hdr = part_first ? 2 : 0; J->frame_wlog = (u32)(window_log >= 10 ? window_log : 19);
@@ -899,8 +919,8 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     ZTreeCache *cache = sample_stride ? arena_new<ZTreeCache>(c, 1) : nullptr;
     if (!plan || !codes || !trees || !offs || (sample_stride && !cache)) return NAF_GPU_ENOMEM;
     if (cache) HIP_TRY(c, hipMemsetAsync(cache, 0, sizeof(ZTreeCache), c->stream));
-    if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse, min_gain, maxbits);
-    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain, maxbits);
+    if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse, min_gain, maxbits, prefer_flat);
+    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain, maxbits, prefer_flat);
     ZWriteLz &L = J->L;
     L.not_last = part && !part_last;
     if (use_lz && n >= 64) {
@@ -936,7 +956,7 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
             LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << LZ_HASH_LOG), d_src, (u64)n, nblk, B, lz_buf);
             LAUNCH(c, "zenc_lz_seqenc", k_lz_seqenc, cdiv(nblk, 64), 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
         }
-        LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse, min_gain, maxbits);
+        LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse, min_gain, maxbits, 0u);
         LAUNCH(c, "zenc_lz_choose", k_lz_choose, cdiv(nblk, 256), 256, 0, nblk, (const ZEncPlan *)plan, (const ZEncPlan *)plan1, (const u32 *)B.nseq, (const u32 *)B.seq_bytes, mode, offs);
         L.mode = mode; L.plan1 = plan1; L.codes1 = codes1; L.trees1 = trees1; L.B = B;
     }

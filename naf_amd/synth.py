@@ -188,3 +188,68 @@ def softmask_device(text, seed=3, lo=20, hi=600):
         seg = text[s:e]
         seg[((seg >= 65) & (seg <= 90)) & (par == 1)] += 32
     return text
+
+
+def realistic_genome_device(total_bytes: int, n_records: int = 24, width: int = 60, seed: int = 11, device="cuda",
+                            gc: float = 0.41, cpg_keep: float = 0.22, n_run_every: int = 40_000_000, iupac_every: int = 1_000_000,
+                            softmask: bool = True):
+    """What an assembled, repeat-masked vertebrate genome looks like to the codec, built in device memory (uint8 torch tensor):
+    GC content `gc`, CpG depleted to `cpg_keep` of its expected frequency (a C followed by G is mostly rewritten to CA -- the pair
+    histogram of the packed stream is visibly skewed), records of unequal length that start and end in a run of N (telomeres) and
+    hold a run of 5 k .. 100 k N every `n_run_every` bases on average (gaps), an IUPAC code every `iupac_every` bases, `width`-column
+    lines, and -- softmask=True -- alternating upper / lower-case runs of 20..600 bases.  Header lines avoid the letters A C G T."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    # record lengths: a geometric-ish spread like chromosomes (largest about five times the smallest)
+    w = torch.linspace(5.0, 1.0, n_records, dtype=torch.float64)
+    hdrs = [b">REF%d L=%d SYN\n" % (k + 1, k) for k in range(n_records)]
+    hdr_total = sum(len(h) for h in hdrs)
+    rows_total = max(n_records, (total_bytes - hdr_total) // (width + 1))
+    rows = [max(1, int(rows_total * float(x) / float(w.sum()))) for x in w]
+    total = hdr_total + sum(rows) * (width + 1)
+    out = torch.empty(total, dtype=torch.uint8, device=device)
+    at, cg = (1.0 - gc) / 2, gc / 2
+    cum = torch.tensor([at, at + cg, at + 2 * cg], dtype=torch.float32, device=device)       # A C G T
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    iupac = torch.tensor(list(b"RYKMSWBDHV"), dtype=torch.uint8, device=device)
+    pos = 0
+    CH = 1 << 22                                                           # rows per step
+    for k in range(n_records):
+        h = torch.tensor(list(hdrs[k]), dtype=torch.uint8, device=device)
+        out[pos:pos + len(h)] = h
+        pos += len(h)
+        nb = rows[k] * (width + 1)
+        body = out[pos:pos + nb].view(rows[k], width + 1)
+        for r0 in range(0, rows[k], CH):
+            r1 = min(rows[k], r0 + CH)
+            u = torch.rand((r1 - r0) * width, dtype=torch.float32, device=device, generator=g)
+            s = lut[torch.bucketize(u, cum)]
+            # CpG depletion: most G that follow a C become A
+            cpg = (s[:-1] == 67) & (s[1:] == 71) & (torch.rand(s.numel() - 1, dtype=torch.float32, device=device, generator=g) >= cpg_keep)
+            s[1:][cpg] = 65
+            body[r0:r1, :width] = s.view(r1 - r0, width)
+            del u, s, cpg
+        body[:, width] = 10
+        seg = out[pos:pos + nb]
+        # telomeres and gaps: runs of N in text coordinates (line ends stay)
+        nbases = rows[k] * width
+        runs = [(0, min(nb, 10_000 + 167 * k)), (max(0, nb - 10_000 - 61 * k), nb)]
+        n_gaps = int(nbases // n_run_every)
+        if n_gaps:
+            starts = torch.randint(0, max(1, nb - 200_000), (n_gaps,), device="cpu", generator=torch.Generator().manual_seed(seed * 1000 + k))
+            lens = torch.randint(5_000, 100_000, (n_gaps,), device="cpu", generator=torch.Generator().manual_seed(seed * 1000 + k + 500))
+            runs += [(int(a), int(a) + int(l)) for a, l in zip(starts.tolist(), lens.tolist())]
+        for a, b in runs:
+            piece = seg[a:b]
+            piece[piece != 10] = 78
+        n_iu = int(nbases // iupac_every)
+        if n_iu:
+            p = torch.randint(0, nb, (n_iu,), device=device, generator=g)
+            cur = seg[p]
+            ok = (cur == 65) | (cur == 67) | (cur == 71) | (cur == 84)
+            seg[p[ok]] = iupac[torch.randint(0, iupac.numel(), (int(ok.sum().item()),), device=device, generator=g)]
+        pos += nb
+    if softmask:
+        softmask_device(out, seed=seed + 1)
+    return out

@@ -403,3 +403,123 @@ def test_flat_frame_read_in_place_by_the_emit_kernel(gpu, oracle, monkeypatch):
         assert len(got) == len(text)                               # a flipped payload byte inside a stream only changes bases
     except NafGpuError:
         pass
+
+
+def _mostly_flat_fasta(rng, n_bases, share, width=80, n_rec=2, lower=True):
+    """Uniform A C G T (flat 4-bit blocks under this build's encoder) in which a `share` of the 32 KiB blocks of the packed stream is
+    made NOT flat, each in one of five ways: a single N (a seventeenth symbol), a stretch of 85 % A (Huffman coding pays), a run of N
+    over whole blocks (RLE blocks), IUPAC codes, a gap character."""
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seq = acgt[rng.integers(0, 4, n_bases)].copy()
+    nblocks = n_bases // 65536 + 1
+    hit = rng.choice(nblocks, max(1, int(nblocks * share)), replace=False)
+    for k, b in enumerate(hit):
+        lo = int(b) * 65536
+        hi = min(n_bases, lo + 65536)
+        if hi - lo < 100:
+            continue
+        kind = k % 5
+        if kind == 0:
+            seq[lo + int(rng.integers(0, hi - lo))] = ord("N")
+        elif kind == 1:
+            m = rng.random(hi - lo) < 0.85
+            seq[lo:hi][m] = ord("A")
+        elif kind == 2:
+            seq[max(0, lo - 70000):hi] = ord("N")                  # more than a whole block of N: at least one RLE block
+        elif kind == 3:
+            p = rng.integers(lo, hi, 40)
+            seq[p] = np.frombuffer(b"RYKMSWBDHV", dtype=np.uint8)[rng.integers(0, 10, 40)]
+        else:
+            seq[lo + 5:lo + 9] = ord("-")
+    if lower:
+        pos = 0
+        while pos < n_bases:
+            run = int(rng.integers(1, 30000))
+            if rng.random() < 0.5:
+                seg = seq[pos:pos + run]
+                seg[seg != ord("-")] |= 0x20
+            pos += run
+    from naf_amd import synth
+    per = n_bases // n_rec
+    out = bytearray()
+    for r in range(n_rec):
+        part = seq[r * per:(r + 1) * per if r + 1 < n_rec else n_bases]
+        out += b">rec%d mostly flat\n" % r + synth.wrap_lines(part, width)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("share", [0.01, 0.1, 0.5])
+def test_mostly_flat_frame_with_blocks_that_are_not(gpu, oracle, monkeypatch, capfd, share):
+    """A real genome under the encoder's flat preference: nearly every block of the sequence stream carries the flat 4-bit tree, a
+    few do not (an N, an IUPAC code, a stretch of skewed composition, a run of N).  Those blocks and their neighbours are decoded,
+    the rest is read in place (zstd_dec.hip "a frame that is MOSTLY flat"; emit.hip: tiles of class 1 / 2).  Against the oracle, the
+    original text and the decode-everything path, at 1, 10 and 50 % of the blocks, through the speculative route of long frames
+    (> 512 blocks) and -- forced -- on short ones, every output mode that takes the tile kernels, with and without the mask."""
+    import re
+    rng = np.random.default_rng(int(share * 1000) + 5)
+    big = _mostly_flat_fasta(rng, 36_000_000, share, width=80, n_rec=2)
+    d_naf, rep = gpu.ennaf(gpu.to_device(big))
+    naf = host(d_naf)
+    info = oracle.zstd_frame_info(oracle.parse_naf(naf).frame(naf, 4))
+    assert info.n_blocks > 512
+    capfd.readouterr()
+    monkeypatch.setenv("NAF_GPU_DEBUG_FLAT", "1")
+    gpu.set_timing(True)
+    got = host(gpu.unnaf(d_naf, 0))
+    ran = {n for n, ms, k in gpu.get_timing()}
+    gpu.set_timing(False)
+    monkeypatch.delenv("NAF_GPU_DEBUG_FLAT")
+    err = capfd.readouterr().err
+    assert got == big
+    assert got == oracle.unnaf(naf, 0)
+    m = re.search(r"\[flat mixed\] nblk (\d+) decoded (\d+)", err)
+    assert m, err
+    nblk, ndec = int(m.group(1)), int(m.group(2))
+    assert 0 < ndec < nblk
+    if share <= 0.1:
+        assert ndec * 2 <= nblk and "unnaf_emit_flat" in ran, (nblk, ndec, sorted(ran))      # the mixed path did run
+        assert ndec <= 3.5 * share * nblk + 8, (nblk, ndec)
+        m2 = re.search(r"\[flat tiles\] total (\d+) rest (\d+) decoded (\d+)", err)
+        assert m2, err
+        tiles, rest, dec = (int(x) for x in m2.groups())
+        assert rest <= 64 and dec <= tiles * (ndec + 1) // nblk + 64, (tiles, rest, dec)       # the slow list holds the header / record-end tiles only
+    monkeypatch.setenv("NAF_GPU_FLAT_MIXED", "0")
+    assert host(gpu.unnaf(d_naf, 0)) == big
+    monkeypatch.delenv("NAF_GPU_FLAT_MIXED")
+    # short frames through the same path, geometry of every kind
+    monkeypatch.setenv("NAF_GPU_SPEC_MIN", "8")
+    for width, n_rec, n in ((61, 3, 2_400_011), (16, 1, 1_700_000), (0, 2, 3_000_001), (97, 2, 2_000_000), (4096, 1, 2_100_000)):
+        text = _mostly_flat_fasta(rng, n, share, width=width, n_rec=n_rec)
+        d2, _ = gpu.ennaf(gpu.to_device(text))
+        n2 = host(d2)
+        for mode, ll, mask in ((0, -1, True), (0, -1, False), (2, -1, True), (3, -1, True), (0, 50, True), (0, 0, True)):
+            want = oracle.unnaf(n2, mode, mask, ll)
+            assert host(gpu.unnaf(d2, mode, line_length=ll, use_mask=mask)) == want, (share, width, n_rec, mode, ll, mask)
+        assert oracle.unnaf(n2, 0) == text
+
+
+def test_realistic_genome_both_ways_against_the_reference(gpu, oracle, monkeypatch):
+    """60 MB of the bench's `realistic` workload (naf_amd/synth.py: skewed composition, CpG depletion, runs of N, IUPAC codes, soft
+    mask, 60-column lines): this build's archive of it -- flat preference on (default) and off -- decodes to the text under this
+    build's unnaf, the oracle and the REAL reference unnaf; the reference's archive of it decodes to the text here."""
+    from naf_amd import synth
+    t = synth.realistic_genome_device(60_000_000, n_records=6, device="cuda", n_run_every=4_000_000, iupac_every=150_000)
+    text = host(t)
+    sizes = {}
+    for pf in ("16", "0"):
+        monkeypatch.setenv("NAF_GPU_PREFER_FLAT", pf)
+        d_naf, rep = gpu.ennaf(t)
+        naf = host(d_naf)
+        sizes[pf] = len(naf)
+        assert host(gpu.unnaf(d_naf, 0)) == text
+        assert oracle.unnaf(naf, 0) == text
+        if oracle.have_ref():
+            assert oracle.ref_unnaf(naf) == text
+        info = oracle.zstd_frame_info(oracle.parse_naf(naf).frame(naf, 4))
+        assert info.seq_blocks == 0
+    monkeypatch.delenv("NAF_GPU_PREFER_FLAT")
+    assert sizes["0"] <= sizes["16"] <= 1.06 * sizes["0"], sizes      # what the flat preference gives up: a few per cent of the archive
+    if oracle.have_ref():
+        ref_naf = oracle.ref_ennaf(text)
+        assert host(gpu.unnaf(gpu.to_device(ref_naf), 0)) == text
+        assert host(gpu.unnaf(gpu.to_device(ref_naf), 0, use_mask=False)) == oracle.ref_unnaf(ref_naf, ("--no-mask",))

@@ -249,7 +249,8 @@ def test_window_descriptor_of_a_sharded_frame_follows_the_options(ctxs, oracle):
     unit = acgt[rng.integers(0, 4, 3000)].tobytes()
     text = b">chr1\n" + b"".join(big[a:a + 80] + b"\n" for a in range(0, len(big), 80))
     for k in range(400):                                             # many records whose ids / names / bases repeat far back
-        text += b">scaffold_%06d some repeated description of a contig\n" % k + unit[(k * 7) % 100:] + b"\n"
+        u = unit[(k * 7) % 100:]
+        text += b">scaffold_%06d some repeated description of a contig\n" % k + b"".join(u[a:a + 80] + b"\n" for a in range(0, len(u), 80))
     for level, long_log, want in ((3, 0, 21), (1, 27, None), (19, 0, 23)):
         opts = shard.make_opts(level=level, long_log=long_log)
         naf, rep = join(ctxs, text, 3, opts)
