@@ -1535,7 +1535,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             for (int k = 0; k < nparts; k++) split.ev[k] = c->split_ev[k];
             c->zsplit = &split;
         }
-        if (try_flat) { zflat.ready = false; c->zflat = &zflat; }
+        if (try_flat) { zflat.ready = false; zflat.aux = c->zsplit ? c->side2 : nullptr; c->zflat = &zflat; }
         rc = payload_seq();
         c->zsplit = nullptr; c->zflat = nullptr;
         if (!rc && pl.need_qual && !qpar) rc = payload_qual(c);
@@ -1671,6 +1671,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                 const u32 nwg = cdiv(ntiles, FLAT_TPW), chunk = (nwg + 7) / 8;
                 static const bool xcd = !(getenv("NAF_GPU_XCD") && getenv("NAF_GPU_XCD")[0] == '0');
                 LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat, xcd ? chunk * 8 : nwg, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, xcd ? chunk : 0u);
+                if (zflat.decoded_ev) HIP_TRY(c, hipStreamWaitEvent(c->stream, zflat.decoded_ev, 0));      // the blocks that were decoded beside it
                 if (zflat.cls && zflat.n_decoded) {
                     // a tile costs this kernel about what it costs k_emit_tile: as many workgroups as there can be tiles over decoded blocks, up to a few waves of the device
                     const u64 est = (u64)zflat.n_decoded * 64 + 64;                           // (blocks of up to 128 KiB: 64 tiles each)

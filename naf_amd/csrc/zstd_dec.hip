@@ -25,6 +25,7 @@ struct ZStat {                 // device-side counters read back by the host
     u32 ticket, n_plain_huf;     // n_plain_huf: compressed blocks with Huffman literals and no sequences
     u32 max_seq_regen, n_flat;    // largest regenerated size among the blocks that have sequences; table-defining blocks whose tree is flat
     u32 n_huf_distinct, n_huf_built;   // tree descriptions that differ from their predecessor's (k_huf_dedup); tables actually built
+    u32 max_lit_regen, pad2_;          // largest literals section of a Huffman-coded block (k_huf_par sizes its parts by it)
     u32 last_raw, flat_main_inv;       // size of the frame's last block when it is a Raw or (bit 31) RLE one, else 0; 0xFFFFFFFF - index of the FIRST block that defines a flat 4-bit tree (0: none)
 };
 
@@ -254,6 +255,7 @@ __global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_hu
     seq_cnt[i] = sq ? b.nseq : 0;
     sizes[i] = b.regen;                                          // final unless the block has sequences (k_decode_seq then rewrites it)
     if (comp && b.lit_type == LIT_HUF) atomicAdd(&st->n_huf_def, 1u);
+    if (comp && b.lit_type >= LIT_HUF) atomicMax(&st->max_lit_regen, b.lit_regen);
     if (comp && b.lit_type >= LIT_HUF && b.nseq == 0) atomicAdd(&st->n_plain_huf, 1u);
     if (i + 1 == nblk && (b.btype == BT_RAW || b.btype == BT_RLE) && b.bsize) st->last_raw = b.bsize | (b.btype == BT_RLE ? 0x80000000u : 0u);
     if (sq) atomicAdd(&st->n_seq_blk, 1u);
@@ -963,6 +965,110 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
     if (err) set_err(st, err);
 }
 
+__device__ __forceinline__ u32 wave_excl_sum(u32 v, u32 *total);
+// ---- Huffman literals in PARTS: P lanes per stream (zstd_dec_core.h "a Huffman stream decoded in parts") ---------------------------------
+// Lane g of the launch: part g % P of stream (g / P) % 4 of block b_first + g / (4 P); P a power of two up to 64, so a wavefront holds
+// whole streams and a lane's predecessor part is the lane below it.  Tables of the workgroup's blocks (one block from P = 16 up) in
+// LDS, input straight from global memory through the register window of the reader (a part is a few hundred consecutive bytes, read
+// downwards a word at a time, two words ahead), output by the lane itself, 8 symbols per store, into its place of the block's
+// literals.  sel / flat_on as in k_huf_literals.
+__global__ __launch_bounds__(64) void k_huf_par(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf, const u8 *pool, u32 slot_bytes,
+                                                 u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first, u32 plog, const u8 *sel, u32 flat_on, u32 margin_env)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 lds[];
+    const u32 lane = threadIdx.x, P = 1u << plog;
+    const u64 g = (u64)blockIdx.x * 64 + lane;
+    const u32 k = (u32)g & (P - 1), s = (u32)(g >> plog) & 3;
+    const u64 bi64 = (u64)b_first + (g >> (plog + 2));
+    const u32 bi = bi64 < nblk ? (u32)bi64 : nblk;
+    const u32 wg_first = b_first + (u32)(((u64)blockIdx.x * 64) >> (plog + 2));
+    const u32 nb_wg = plog >= 4 ? 1u : 16u >> plog, slot_i = plog >= 4 ? 0u : lane >> (plog + 2);
+    bool want = false; i32 ob = -1;
+    if (bi < nblk && (!sel || (sel[bi] & 2))) {
+        const ZBlock &b = blk[bi];
+        if (b.btype == BT_COMP && b.lit_type >= LIT_HUF && !b.err) { ob = own_huf[bi]; want = ob < 0 || !(flat_on && blk[ob].huf_flat); }
+    }
+    const u64 wanted = __ballot(want);
+    if (!wanted) return;
+    for (u32 j = 0; j < nb_wg; j++) {                                  // the tables in force, for the blocks that have streams here
+        const u32 bj = wg_first + j;
+        if (bj >= nblk) break;
+        if (!((wanted >> (j << (plog + 2))) & 1)) continue;            // (first lane of block j)
+        const i32 oj = own_huf[bj];
+        if (oj < 0) continue;
+        const u32 bytes = huf_tab_bytes(blk[oj].huf_log);
+        const uint4 *gt = (const uint4 *)(pool + blk[oj].huf_tab);
+        uint4 *lt = (uint4 *)(lds + j * slot_bytes);
+        for (u32 q = lane; q < bytes / 16; q += 64) lt[q] = gt[q];
+    }
+    __syncthreads();
+    // the lane's stream
+    bool valid = false; u8 err = 0;
+    const u8 *sp = src; u32 sz = 0, n = 0, log = 1; u8 *out = nullptr;
+    const u16 *tab = (const u16 *)(lds + slot_i * slot_bytes);
+    if (want) {
+        const ZBlock &b = blk[bi];
+        if (ob < 0) { if (s == 0 && k == 0) err = ZE_CORRUPT; }        // treeless without a previous table
+        else {
+            log = blk[ob].huf_log;
+            const u8 *c = src + b.src_off + b.huf_streams_off;
+            u8 *o = (b.nseq == 0 ? dst : lit_scratch) + b.out_off;
+            const u32 regen = b.lit_regen;
+            if (b.nstreams == 1) { if (s == 0) { valid = true; sp = c; sz = b.huf_streams_size; n = regen; out = o; } }
+            else {
+                const u32 s1 = ld16(c), s2 = ld16(c + 2), s3 = ld16(c + 4), tot = b.huf_streams_size - 6, per = (regen + 3) / 4;
+                if (s1 + s2 + s3 >= tot || !s1 || !s2 || !s3 || per * 3 > regen) { if (s == 0 && k == 0) err = ZE_CORRUPT; }
+                else {
+                    const u32 off = s == 0 ? 0 : (s == 1 ? s1 : (s == 2 ? s1 + s2 : s1 + s2 + s3));
+                    sz = s == 0 ? s1 : (s == 1 ? s2 : (s == 2 ? s3 : tot - s1 - s2 - s3));
+                    valid = true; sp = c + 6 + off; n = s < 3 ? per : regen - 3 * per; out = o + s * per;
+                }
+            }
+            if (valid && (sz == 0 || sp[sz - 1] == 0)) { valid = false; if (k == 0) err = ZE_CORRUPT; }   // no end marker
+        }
+    }
+    u32 E = 0; i32 Bk = 0, Bk1 = 0;
+    i32 sk = 0, ek = 0; u32 ck = 0;
+    if (valid) {
+        E = 8u * (sz - 1) + (u32)hibit32(sp[sz - 1]);
+        Bk = hufp_cut(E, P, k); Bk1 = hufp_cut(E, P, k + 1);
+        const u32 M = margin_env ? margin_env : hufp_margin(E, n, log);
+        i32 p = (k == 0 || (u64)Bk + M >= E) ? (i32)E : Bk + (i32)M;
+        HufWin r; hufw_init(r, sp, sz, p);
+        if (k) hufw_walk(r, p, Bk, tab, log);
+        sk = p;
+        ck = hufw_walk(r, p, Bk1, tab, log);
+        ek = p;
+    }
+    // every start must be its predecessor's end; the lanes that find otherwise walk again from there, until none does
+    for (u32 round = 0; round <= P; round++) {
+        const i32 prev = __shfl_up(ek, 1, 64);
+        const bool mis = valid && k > 0 && sk != prev;
+        if (!__ballot(mis)) break;
+        if (mis) {
+            i32 p = prev; sk = p;
+            HufWin r; hufw_init(r, sp, sz, p);
+            ck = hufw_walk(r, p, Bk1, tab, log);
+            ek = p;
+        }
+    }
+    // the parts' places: prefix sum of the counts inside the stream; all of it must add up before anything is written
+    u32 tot_wave;
+    const u32 ex = wave_excl_sum(valid ? ck : 0u, &tot_wave);
+    const u32 gbase = (u32)__shfl((int)ex, (int)(lane & ~(P - 1)), 64);
+    const u32 off = ex - gbase;
+    bool bad = valid && k == P - 1 && (off + ck != n || ek != 0);
+    bad = __shfl((int)bad, (int)(lane | (P - 1)), 64) != 0;
+    if (valid && bad) { if (k == 0) err = ZE_CORRUPT; valid = false; }
+    if (valid && ck) {
+        i32 p = sk;
+        HufWin r; hufw_init(r, sp, sz, p);
+        hufw_decode(r, p, tab, log, out + off, ck);
+        if (p != ek) err = ZE_CORRUPT;
+    }
+    if (err) set_err(st, err);
+}
+
 // ---- Huffman literals of a flat tree: fixed-width fields, nothing serial -------------------------------------------------------------
 // When every code of a block's table is L bits long, symbol k of a stream sits at bits [E - L(k+1), E - Lk) of the stream (E = the
 // data bits below the end marker; a stream is read from its last byte backwards, RFC 8878 4.2.2), so the 8192 symbols one lane of
@@ -1118,14 +1224,21 @@ __global__ __launch_bounds__(256) void k_flat_sym(const u8 *src, const ZBlock *b
     if (one && rank < 16) sym[rank] = (u8)t;
 }
 // cls0[i] = 1: block i can be read in place (a plain Huffman block whose tree in force is the main one), else 2
-__global__ void k_flat_class(const ZBlock *blk, u32 nblk, const i32 *own_huf, u8 *cls0)
+__global__ void k_flat_class(const ZBlock *blk, u32 nblk, const i32 *own_huf, u8 *cls0, u32 *n_walk)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nblk) return;
-    const ZBlock &b = blk[i];
-    bool f = b.btype == BT_COMP && b.lit_type >= LIT_HUF && b.nseq == 0 && !b.err && b.lit_regen > 0;
-    if (f) { const i32 ob = own_huf[i]; f = ob >= 0 && blk[ob].huf_flat == 2; }
-    cls0[i] = f ? 1 : 2;
+    bool walk = false;
+    if (i < nblk) {
+        const ZBlock &b = blk[i];
+        const bool huf = b.btype == BT_COMP && b.lit_type >= LIT_HUF && !b.err;
+        bool f = huf && b.nseq == 0 && b.lit_regen > 0;
+        const i32 ob = huf ? own_huf[i] : -1;
+        if (f) f = ob >= 0 && blk[ob].huf_flat == 2;
+        cls0[i] = f ? 1 : 2;
+        walk = huf && !(ob >= 0 && blk[ob].huf_flat);             // its streams need the Huffman walk (k_huf_literals / k_huf_par)
+    }
+    const u64 bal = __ballot(walk);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_walk, (u32)__popcll(bal));
 }
 // ... and the flat neighbours of a block that is decoded are decoded too (3 = either way): a tile of text that lies across the border
 // then finds all of its packed bytes on one side or the other
@@ -1206,6 +1319,16 @@ __device__ __forceinline__ void wait_block_done(volatile u32 *done, u32 j)
     __syncthreads();
 }
 
+// n bytes by the 64 lanes of a wavefront, 16 per lane and step, at any alignment (the regions do not overlap, or the source lies
+// at least n bytes below the destination).  A block of libzstd's with one match in it is 128 KiB of literals around that match:
+// copied a byte per lane and step they were two thousand dependent round trips -- 2 ms for a kernel with almost nothing to do.
+__device__ __forceinline__ void wave_copy(u8 *d, const u8 *s, u32 n, u32 lane)
+{
+#pragma unroll 4
+    for (u32 i = lane * 16; i + 16 <= n; i += 64 * 16) { uint4 v; __builtin_memcpy(&v, s + i, 16); __builtin_memcpy(d + i, &v, 16); }
+    const u32 done = n & ~15u;
+    if (lane < (n & 15u)) d[done + lane] = s[done + lane];
+}
 __global__ __launch_bounds__(64) void k_exec_seq(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *offs, u32 nblk,
                                                   const u32 *o_ll, const u32 *o_ml, const u32 *o_of,
                                                   const u8 *lit_scratch, u8 *dst, u32 *done, ZStat *st)
@@ -1230,7 +1353,7 @@ __global__ __launch_bounds__(64) void k_exec_seq(const ZBlock *blk, const u32 *s
     for (u32 s = 0; s < nseq; s++) {
         u32 ll = o_ll[sbase + s], ml = o_ml[sbase + s];
         u32 off = sym_resolve(o_of[sbase + s], rep_in);
-        for (u32 k = lane; k < ll; k += 64) out[op + k] = lits[lp + k];
+        wave_copy(out + op, lits + lp, ll, (u32)lane);
         op += ll; lp += ll;
         u64 pos_abs = out_off + op;
         if (off > pos_abs) { bad = true; break; }                     // reaches before the frame start
@@ -1249,13 +1372,13 @@ __global__ __launch_bounds__(64) void k_exec_seq(const ZBlock *blk, const u32 *s
             fenced = op;
         }
         const u8 *from = dst + src_abs;
-        if (off >= ml) { for (u32 k = lane; k < ml; k += 64) out[op + k] = from[k]; }
+        if (off >= ml) wave_copy(out + op, from, ml, (u32)lane);
         else           { for (u32 k = lane; k < ml; k += 64) out[op + k] = from[k % off]; }
         op += ml;
     }
     if (!bad && !b.err) {
         u32 rest = b.lit_regen - lp;
-        for (u32 k = lane; k < rest; k += 64) out[op + k] = lits[lp + k];
+        wave_copy(out + op, lits + lp, rest, (u32)lane);
         op += rest;
         if (op != b.regen) bad = true;
     }
@@ -1573,6 +1696,31 @@ int zstd_init_tables(naf_gpu_ctx *c)
     return 0;
 }
 
+
+// Parts per stream for k_huf_par, a power of two up to 64 (returned as its logarithm; 0 = the one-lane-per-stream kernel).
+// Measured (tools/perf_huf.py, profiles/r03_huf_parts.txt): one lane per stream takes 0.95 ms for the 8 K symbols of a stream of this
+// build's 32 KiB blocks and 3.8 ms for the 32 K of libzstd's 128 KiB blocks however few streams there are, and moves 1 GB of symbols
+// per millisecond once the device is full; k_huf_par divides the chain by P but moves only a quarter of that (its lanes read and
+// write 8 bytes at a time, each in a sector of its own).  So parts are taken when the frame is short enough for the chain to be what
+// bounds the serial kernel -- less than 28 KB of literals per symbol of the longest stream -- with as many parts as leave a lane
+// NAF_GPU_HUF_PART symbols (default 128) and the device no more than a million lanes.
+// NAF_GPU_HUF_PAR=0: never, =N: 2^N parts wherever the streams are long enough.
+static u32 huf_par_plog(u32 max_lit_regen, u64 n_blocks)
+{
+    const char *e = getenv("NAF_GPU_HUF_PAR");
+    if (e && e[0] == '0') return 0;
+    const char *t = getenv("NAF_GPU_HUF_PART");
+    u32 target = t ? (u32)atoi(t) : 128u; if (target < 64) target = 64;
+    const u32 nmax = (max_lit_regen + 3) / 4;                     // symbols of the longest stream (blocks of more than 1 KiB have four)
+    u32 plog = 0;
+    while (plog < 6 && (nmax >> (plog + 1)) >= target) plog++;
+    if (e && e[0] >= '1' && e[0] <= '6') { const u32 f = (u32)(e[0] - '0'); return f < plog ? f : plog; }
+    if (n_blocks * (u64)max_lit_regen >= (u64)nmax * 28672) return 0;
+    while (plog && ((n_blocks * 4) << plog) > (1u << 20)) plog--;
+    return plog;
+}
+static u32 huf_par_margin_env() { const char *m = getenv("NAF_GPU_HUF_MARGIN"); return m ? (u32)atoi(m) : 0u; }
+
 #define ZSTD_NEED_TWO_PASS (-100)
 static int zerr(naf_gpu_ctx *c, u32 e, const char *where)
 {
@@ -1774,28 +1922,41 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             const u32 main = 0xFFFFFFFFu - hs.flat_main_inv;
             ZFlat *zf = c->zflat;
             FlatStream *si = arena_new<FlatStream>(c, 4 * (size_t)nblk + 1); u8 *d_sym = (u8 *)arena_alloc(c, 16);
-            u8 *cls0 = (u8 *)arena_alloc(c, nblk), *cls = (u8 *)arena_alloc(c, nblk); u32 *d_nx = arena_new<u32>(c, 1);
+            u8 *cls0 = (u8 *)arena_alloc(c, nblk), *cls = (u8 *)arena_alloc(c, nblk); u32 *d_nx = arena_new<u32>(c, 2);
             if (!si || !d_sym || !cls0 || !cls || !d_nx) return NAF_GPU_ENOMEM;
-            HIP_TRY(c, hipMemsetAsync(d_nx, 0, 4, c->stream));
+            HIP_TRY(c, hipMemsetAsync(d_nx, 0, 8, c->stream));
             LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr);
             LAUNCH(c, "zstd_flat_class", k_flat_mark_owner, g, 64, 0, d_src, blk, nblk, (const i32 *)own_huf, main);
             LAUNCH(c, "zstd_flat_class", k_flat_sym, 1, 256, 0, d_src, (const ZBlock *)blk, main, (const u8 *)huf_pool, d_sym);
-            LAUNCH(c, "zstd_flat_class", k_flat_class, g, 64, 0, (const ZBlock *)blk, nblk, (const i32 *)own_huf, cls0);
+            LAUNCH(c, "zstd_flat_class", k_flat_class, g, 64, 0, (const ZBlock *)blk, nblk, (const i32 *)own_huf, cls0, d_nx + 1);
             LAUNCH(c, "zstd_flat_class", k_flat_class2, g, 64, 0, (const u8 *)cls0, nblk, cls, d_nx);
-            u32 n_dec = 0;
-            if ((rc = ctx_readback(c, &n_dec, d_nx, 4))) return rc;
+            u32 nx2[2] = { 0, 0 };
+            if ((rc = ctx_readback(c, nx2, d_nx, 8))) return rc;
+            const u32 n_dec = nx2[0], n_walk = nx2[1];
             if (getenv("NAF_GPU_DEBUG_FLAT")) fprintf(stderr, "[flat mixed] nblk %u decoded %u main %u\n", nblk, n_dec, main);
             if ((u64)n_dec * 2 <= nblk) {
                 LAUNCH(c, "zstd_flat_streams", k_flat_streams_mixed, cdiv(4ull * nblk, 256), 256, 0, d_src, (const ZBlock *)blk, nblk, (const u8 *)cls, si, st, (const u64 *)d_total_out);
+                zf->decoded_ev = nullptr;
                 if (n_dec) {
+                    // on the caller's spare stream when there is one: the emit of the flat tiles needs none of this
+                    naf_gpu_ctx *mc = c;
+                    if (zf->aux) {
+                        HIP_TRY(c, hipEventRecord(c->split_ev[0], c->stream));
+                        HIP_TRY(c, hipStreamWaitEvent(zf->aux->stream, c->split_ev[0], 0));
+                        c = zf->aux;
+                    }
                     if (hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, d_dst, (u8 *)nullptr, 0u, (const u8 *)cls);
                     LAUNCH(c, "zstd_flat_literals", k_flat_literals, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, (u8 *)nullptr, st, 0u, (const u8 *)cls);
                     if (hs.n_flat < hs.n_huf_built) {
                         const u32 slot = huf_slot_bytes(hs.max_huf_log), ipitch = hs.max_huf_log > 7 ? HUF_IROW_BIG : HUF_IROW;
                         EmitP ep; memset(&ep, 0, sizeof ep);
-                        LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(nblk, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512,
+                        const u32 plog = huf_par_plog(hs.max_lit_regen, n_walk);
+                        if (plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)nblk << (plog + 2), 64), 64, (plog >= 4 ? 1u : 16u >> plog) * slot,
+                               d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, (u8 *)nullptr, st, 0u, plog, (const u8 *)cls, 1u, huf_par_margin_env());
+                        else LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(nblk, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512,
                                d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, (u8 *)nullptr, st, 0u, ep, (u8 *)nullptr, ipitch, (u64)src_len, 1u, (const u8 *)cls);
                     }
+                    if (c != mc) { HIP_TRY(mc, hipEventRecord(mc->split_ev[1], c->stream)); zf->decoded_ev = mc->split_ev[1]; c = mc; }
                 }
                 zf->src = d_src; zf->si = si; zf->nslots = 4ull * nblk; zf->sym = d_sym; zf->status = st; zf->ready = true;
                 zf->tail = nullptr; zf->tail_q = hs.total_out; zf->tail_n = 0; zf->cls = cls; zf->n_decoded = n_dec;
@@ -1896,6 +2057,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             // blocks whose tree is flat go to k_flat_literals; the serial kernel is not launched when that is all of them
             const u32 flat_on = (hs.n_flat && !always_table) ? 1u : 0u;
             const bool serial_needed = !flat_on || hs.n_flat < hs.n_huf_built;
+            const u32 plog = huf_par_plog(hs.max_lit_regen, b_count), par_lds = (plog >= 4 ? 1u : 16u >> plog) * slot;
             ZSplit *sp = c->zsplit;
             const char *smin = getenv("NAF_GPU_SPLIT_MIN");                      // blocks per part below which a split is not worth its launches (tests lower it)
             const u32 split_min = smin ? (u32)atoi(smin) : 4096u;
@@ -1919,7 +2081,9 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                 for (int k = 0; k < sp->parts; k++) {
                     u32 hi_b = k + 1 == sp->parts ? b_count : (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
                     if (hi_b > lo_b && flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, hi_b - lo_b, 256, 0, d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, lo_b, (const u8 *)nullptr);
-                    if (hi_b > lo_b && serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds,
+                    if (hi_b > lo_b && serial_needed && plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)(hi_b - lo_b) << (plog + 2), 64), 64, par_lds,
+                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env());
+                    else if (hi_b > lo_b && serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds,
                            d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr);
                     HIP_TRY(c, hipEventRecord(sp->ev[k], c->stream));
                     lo_b = hi_b;
@@ -1927,7 +2091,9 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                 sp->done = 1;
             } else {
                 if (flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, b_count, 256, 0, d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, b_first, (const u8 *)nullptr);
-                if (serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, huf_lds,
+                if (serial_needed && plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)b_count << (plog + 2), 64), 64, par_lds,
+                   d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env());
+                else if (serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, huf_lds,
                    d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr);
             }
         }

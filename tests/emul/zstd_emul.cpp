@@ -195,6 +195,59 @@ extern "C" int emul_window_reader(const u8 *stream, u32 size, const u8 *weights,
     return 0;
 }
 
+// ---- a stream decoded in parts (k_huf_par), single-stepped: the lanes of one stream one after the other, round after round ----------
+// Same per-lane functions as the kernel (zstd_dec_core.h: hufw_*, hufp_*).  Returns 0 when the parts reproduce the serial decode;
+// *rounds_out = rounds of re-walking it took (0: every part fell into step inside its margin).  margin = 0: the kernel's own choice.
+extern "C" int emul_huf_parts(const u8 *stream, u32 size, const u8 *weights, u32 nw, u32 log, u32 n, u32 P, u32 margin, u64 align_off, u32 *rounds_out)
+{
+    std::vector<u8> hay(size + 1024 + 256);
+    u8 *base = hay.data() + 256 + align_off;
+    memset(hay.data(), 0xAA, hay.size());                          // whatever lies around the stream must not matter
+    memcpy(base, stream, size);
+    std::vector<u16> tabv(huf_tab_bytes(log) / 2); huf_build_any(tabv.data(), weights, nw, log); const u16 *tab = tabv.data();
+    std::vector<u8> ref(n + 64), out(n + 64, 0x55);
+    if (huf_decode_stream(base, size, tab, log, ref.data(), n)) return -1;
+    if (!size || !base[size - 1] || P < 1 || P > 64) return -2;
+    const u32 E = 8 * (size - 1) + (u32)hibit32(base[size - 1]);
+    const u32 M = margin ? margin : hufp_margin(E, n, log);
+    i32 s[64], e[64]; u32 c[64];
+    for (u32 k = 0; k < P; k++) {
+        const i32 Bk = hufp_cut(E, P, k), Bk1 = hufp_cut(E, P, k + 1);
+        i32 p = k == 0 ? (i32)E : ((u64)Bk + M < E ? Bk + (i32)M : (i32)E);
+        HufWin r; hufw_init(r, base, size, p);
+        if (k) hufw_walk(r, p, Bk, tab, log);
+        s[k] = p;
+        c[k] = hufw_walk(r, p, Bk1, tab, log);
+        e[k] = p;
+    }
+    u32 rounds = 0;
+    for (;;) {
+        bool any = false; i32 ns[64]; bool mis[64];
+        for (u32 k = 0; k < P; k++) { mis[k] = k > 0 && s[k] != e[k - 1]; ns[k] = k ? e[k - 1] : s[0]; any |= mis[k]; }   // all lanes look before any lane moves
+        if (!any) break;
+        if (++rounds > 64) return -3;
+        for (u32 k = 0; k < P; k++) if (mis[k]) {
+            i32 p = ns[k]; s[k] = p;
+            HufWin r; hufw_init(r, base, size, p);
+            c[k] = hufw_walk(r, p, hufp_cut(E, P, k + 1), tab, log);
+            e[k] = p;
+        }
+    }
+    if (rounds_out) *rounds_out = rounds;
+    u32 tot = 0; for (u32 k = 0; k < P; k++) tot += c[k];
+    if (tot != n || e[P - 1] != 0) return -4;
+    u32 off = 0;
+    for (u32 k = 0; k < P; k++) {
+        i32 p = s[k]; HufWin r; hufw_init(r, base, size, p);
+        hufw_decode(r, p, tab, log, out.data() + off, c[k]);
+        if (p != e[k]) return -5;
+        off += c[k];
+    }
+    for (u32 i = 0; i < n; i++) if (out[i] != ref[i]) return (int)i + 1;
+    if (out[n] != 0x55) return -6;                                 // nothing written behind the last symbol ... except by the 8-byte group stores inside
+    return 0;
+}
+
 // block statistics of a frame (no magic check on the decoded data): out[0] blocks, [1] compressed blocks, [2] sequences,
 // [3] literal bytes regenerated, [4] bytes of literals sections, [5] bytes of sequences sections
 extern "C" long long emul_zstd_frame_stats(const u8 *src, size_t len, u64 *out)

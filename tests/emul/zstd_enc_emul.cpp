@@ -121,6 +121,24 @@ extern "C" int emul_window_roundtrip(const u8 *syms, u32 n, u64 align_off, int b
     return emul_window_reader(st.data(), sz, w, last + 1, log, n, align_off, big);
 }
 
+// symbols -> one Huffman stream -> the parts algorithm of k_huf_par (zstd_emul.cpp: emul_huf_parts)
+extern "C" int emul_huf_parts(const u8 *stream, u32 size, const u8 *weights, u32 nw, u32 log, u32 n, u32 P, u32 margin, u64 align_off, u32 *rounds_out);
+extern "C" int emul_parts_roundtrip(const u8 *syms, u32 n, u32 P, u32 margin, u64 align_off, u32 *rounds_out)
+{
+    u32 hist[256]; memset(hist, 0, sizeof hist);
+    for (u32 i = 0; i < n; i++) hist[syms[i]]++;
+    u8 len[256]; u32 log = huf_build_lengths(hist, len);
+    if (!log) return -10;
+    u8 w[256]; u32 last = 0;
+    for (u32 s = 0; s < 256; s++) { w[s] = len[s] ? (u8)(log + 1 - len[s]) : 0; if (len[s]) last = s; }
+    u16 code[256]; u32 codes[256];
+    huf_assign_codes(len, log, code);
+    for (u32 k = 0; k < 256; k++) codes[k] = code[k] | ((u32)len[k] << 16);
+    std::vector<u8> st(n * 2 + 64);
+    u32 sz = huf_encode_stream(st.data(), syms, n, codes);
+    return emul_huf_parts(st.data(), sz, w, last + 1, log, n, P, margin, align_off, rounds_out);
+}
+
 // ---- encoder front end: SWAR byte classes (enc_swar.h) ----------------------------------------------------------------------
 #include "../../naf_amd/csrc/enc_swar.h"
 extern "C" void emul_piece_flags(const uint8_t *piece16, uint32_t qlo, uint32_t qhi, uint32_t out[8])

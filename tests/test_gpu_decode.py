@@ -523,3 +523,56 @@ def test_realistic_genome_both_ways_against_the_reference(gpu, oracle, monkeypat
         ref_naf = oracle.ref_ennaf(text)
         assert host(gpu.unnaf(gpu.to_device(ref_naf), 0)) == text
         assert host(gpu.unnaf(gpu.to_device(ref_naf), 0, use_mask=False)) == oracle.ref_unnaf(ref_naf, ("--no-mask",))
+
+
+@pytest.mark.parametrize("part,margin", [("64", "0"), ("64", "8"), ("256", "64"), ("1024", "0"), ("4096", "0")])
+def test_huffman_streams_decoded_in_parts(gpu, oracle, monkeypatch, part, margin):
+    """k_huf_par: P lanes per Huffman stream, every part started inside its predecessor and re-walked until the starts agree
+    (zstd_dec_core.h).  Part sizes from 64 symbols (P = 64 on 16 KiB blocks) to 4096, margins down to 8 bits (nearly every part
+    then needs re-walking), on every libzstd-made golden frame, the sections of the reference-made archives, and this build's own
+    frames of skewed, nearly flat, 1-bit and 11-bit alphabets -- against SHA-256 / the oracle and the one-lane-per-stream kernel."""
+    monkeypatch.setenv("NAF_GPU_HUF_PART", part)
+    if margin != "0":
+        monkeypatch.setenv("NAF_GPU_HUF_MARGIN", margin)
+    for case in zstd_cases():
+        frame = golden_bytes("zstd", case["name"] + ".zst")
+        got = host(gpu.zstd_decompress(gpu.to_device(frame), case["len"] + 64))
+        assert len(got) == case["len"] and sha(got) == case["sha256"], case["name"]
+    for case in naf_cases():
+        naf = golden_bytes("naf", case["name"] + ".naf")
+        d = gpu.to_device(naf)
+        for mode in (0, 2):
+            try:
+                want = oracle.unnaf(naf, mode)
+            except Exception:
+                continue
+            assert host(gpu.unnaf(d, mode)) == want, (case["name"], mode)
+    rng = np.random.default_rng(17)
+    p2 = np.array([2.0 ** -(i + 1) for i in range(30)])
+    pr = np.array([1.0] * 15 + [0.5, 0.5])
+    datas = [rng.choice(np.arange(30, dtype=np.uint8), 700_001, p=p2 / p2.sum()).tobytes(),
+             rng.choice(np.arange(17, dtype=np.uint8), 500_000, p=pr / pr.sum()).tobytes(),
+             rng.integers(33, 74, 400_003, dtype=np.uint8).tobytes(),
+             bytes(rng.choice(np.array([0, 0, 0, 0, 0, 0, 0, 1, 2, 200], dtype=np.uint8), 300_000)),
+             rng.integers(0, 256, 70_000, dtype=np.uint8).tobytes() + bytes(rng.choice(np.arange(100, dtype=np.uint8), 100_000))]
+    for data in datas:
+        for blog in ("13", "15", "17"):
+            monkeypatch.setenv("NAF_GPU_BLOCK_LOG", blog)
+            frame = gpu.zstd_compress(gpu.to_device(data))
+            monkeypatch.delenv("NAF_GPU_BLOCK_LOG")
+            assert oracle.zstd_decompress(host(frame), len(data) + 16) == data
+            assert host(gpu.zstd_decompress(frame, len(data) + 64)) == data, (len(data), blog)
+            monkeypatch.setenv("NAF_GPU_HUF_PAR", "0")
+            assert host(gpu.zstd_decompress(frame, len(data) + 64)) == data
+            monkeypatch.delenv("NAF_GPU_HUF_PAR")
+    # a damaged stream is still refused, or decodes to other bytes -- never past its place
+    data = datas[0]
+    fb = bytearray(host(gpu.zstd_compress(gpu.to_device(data))))
+    from naf_amd.capi import NafGpuError
+    for at in (len(fb) // 3, len(fb) // 2, len(fb) - 9):
+        bad = bytearray(fb); bad[at] ^= 0x5A; bad[at + 1] ^= 0xFF
+        try:
+            got = host(gpu.zstd_decompress(gpu.to_device(bytes(bad)), len(data) + 64))
+            assert len(got) == len(data)
+        except NafGpuError:
+            pass

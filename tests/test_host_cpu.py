@@ -228,6 +228,44 @@ def test_decoder_window_reader_at_every_rate_and_alignment(emul):
                 assert r in (0, -5), (len(set(d)), n, align, "small", r)                           # -5: table wider than 7 bits
 
 
+def test_huffman_stream_decoded_in_parts(emul):
+    """k_huf_par's algorithm single-stepped on the host (zstd_dec_core.h: hufw_*, hufp_*): a stream cut into P parts, every part
+    started inside its predecessor, re-walked until every start equals its predecessor's end, then decoded part by part -- against
+    the serial reader.  Alphabets from 1-bit to 11-bit codes, nearly flat trees (which fall into step slowly: rounds of re-walking
+    must happen and must converge), every P, margins down to none at all, streams shorter than their number of parts."""
+    emul.emul_parts_roundtrip.restype = ctypes.c_int
+    emul.emul_parts_roundtrip.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
+    rng = np.random.default_rng(12)
+    streams = []
+    for alpha in (2, 3, 4, 16, 17, 41, 100, 256):
+        streams.append(rng.integers(0, alpha, 9000, dtype=np.uint8).tobytes())
+    p2 = np.array([2.0 ** -(i + 1) for i in range(30)])
+    streams.append(rng.choice(np.arange(30, dtype=np.uint8), 9000, p=p2 / p2.sum()).tobytes())       # codes up to 11 bits
+    streams.append((b"\x00" * 50 + b"\x01") * 170)                                                    # 1-bit code, long runs
+    pr = np.array([1.0] * 15 + [0.5, 0.5]); streams.append(rng.choice(np.arange(17, dtype=np.uint8), 33000, p=pr / pr.sum()).tobytes())   # fifteen 4-bit and two 5-bit codes
+    pq = np.array([.0826, .0826, .0854, .0574, .0826, .0574, .0126, .0604, .0604, .042, .042, .0574, .0854, .0604, .0604, .0826, 1e-4, 1e-5])
+    streams.append(rng.choice(np.arange(18, dtype=np.uint8), 33000, p=pq / pq.sum()).tobytes())       # pairs of a GC-poor genome and two rare codes
+    rounds = ctypes.c_uint32(0)
+    saw_rounds = 0
+    for d in streams:
+        for n in (len(d), 6009, 999, 257, 40, 3):
+            for P in (1, 2, 4, 16, 64):
+                for margin in (0, 256, 64, 8):
+                    for align in (0, 3):
+                        r = emul.emul_parts_roundtrip(d[:n], n, P, margin, align, ctypes.byref(rounds))
+                        assert r in (0, -10), (len(set(d)), n, P, margin, align, r)             # -10: a single distinct symbol has no Huffman stream
+                        saw_rounds += rounds.value
+    assert saw_rounds > 100                                      # the re-walk rounds did run (tiny margins, nearly flat trees)
+    # with the kernel's own margin the common alphabets fall into step at once nearly always
+    d = streams[-1]
+    tot = 0
+    for P in (16, 64):
+        for k in range(20):
+            assert emul.emul_parts_roundtrip(d[k * 100:], len(d) - k * 100, P, 0, 0, ctypes.byref(rounds)) == 0
+            tot += rounds.value
+    assert tot <= 6                                              # (one stream in forty, measured)
+
+
 # ---- CLI paths that need no device ---------------------------------------------------------------------------------
 def run(prog, *args, stdin=None):
     p = subprocess.run([os.path.join(BIN, prog), *args], input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
