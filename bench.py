@@ -112,9 +112,22 @@ def cpu_baseline(text_dev, size_bytes, ctx=None, full_ref_archive=True, e2e_byte
             ctx.unnaf(ref_naf, capi.OUT_FASTA, out=buf)
             kt = sorted(ctx.get_timing(), key=lambda x: -x[1])[:6]
             ctx.set_timing(False)
+            # one eighth of the text by byte range (what a rank of an 8-GPU job decodes, BASELINE configs[3]): the frame has matches, so
+            # the range's dependency closure is decoded (zstd_dec.hip: k_range_closure), not the whole stream
+            b8 = n_src * 3 // 8; e8 = b8 + n_src // 8
+            rbuf = torch.empty(e8 - b8 + 64, dtype=torch.uint8, device=text_dev.device)
+            r8 = ctx.unnaf_range(ref_naf, b8, e8, capi.OUT_FASTA, out=rbuf); torch.cuda.synchronize()
+            ok8 = bool(torch.equal(r8, text_dev[b8:e8]))
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ctx.unnaf_range(ref_naf, b8, e8, capi.OUT_FASTA, out=rbuf)
+            torch.cuda.synchronize()
+            dt8 = (time.perf_counter() - t0) / 3
             out["gpu_unnaf_of_reference_archive"] = {"value": round(n_src / dt / 1e9, 2), "unit": "GB/s", "ms": round(dt * 1e3, 3),
                                                       "archive_bytes": int(ref_naf.numel()), "text_bytes": int(n_src), "bit_exact": ok,
-                                                      "kernels_ms": {n: round(ms, 3) for n, ms, k in kt}}
+                                                      "kernels_ms": {n: round(ms, 3) for n, ms, k in kt},
+                                                      "range_eighth_ms": round(dt8 * 1e3, 3), "range_eighth_bit_exact": ok8}
+            del rbuf, r8
             del ref_naf, buf
         if e2e_bytes and os.access(os.path.join(BIN, "ennaf"), os.X_OK):
             # drop-in reality check: file -> file through the CLIs (tmpfs; PCIe, file I/O and process start included) -- never the `value`

@@ -113,7 +113,7 @@ struct EmitP;
 // Fused path: decode a literal-only frame straight into FASTA text (no packed stream in HBM).  Returns -100 when
 // the frame needs the two-pass path.
 int zstd_decode_fused_fasta(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, size_t *out_len, const EmitP *P, u8 *text);
-struct ZRange { u64 want_lo, want_hi, got_lo, got_hi; bool ranged; };
+struct ZRange { u64 want_lo, want_hi, got_lo, got_hi; bool ranged; u8 *own_buf; };   // own_buf: set when the decoder had to take a larger buffer than the caller's (the dependency closure of a range in a frame with matches): byte got_lo is own_buf[0]
 int zstd_decode_range(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len, ZRange *rg, const u8 *head = nullptr);
 int zstd_split_status(naf_gpu_ctx *c, const ZSplit *sp);
 // up to 4 small frames (no magic) in one launch; ok[k] false = take the ordinary path for frame k

@@ -1462,6 +1462,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     if (pl.empty) { *out_len = 0; return 0; }
     const naf_gpu_header &h = pl.h;
     ZRange rgs, rgq; ZRange *prs = nullptr, *prq = nullptr;
+    memset(&rgs, 0, sizeof rgs); memset(&rgq, 0, sizeof rgq);
     u8 *seq = nullptr;
     // sequence (and quality) payload: the dominant zstd streams
     auto payload_seq = [&]() -> int {
@@ -1478,7 +1479,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         }
         if (r == NAF_GPU_ECAP || (r == 0 && n != pl.seq_bytes)) return ctx_fail(c, NAF_GPU_EFORMAT, "can't decompress sequence\n");
         if (r) return r;
-        pl.P.seq = (prs && prs->ranged) ? seq - prs->got_lo : seq;
+        pl.P.seq = (prs && prs->ranged) ? (prs->own_buf ? prs->own_buf : seq) - prs->got_lo : seq;
         return 0;
     };
     // qc: the context the quality stream is decoded on (the archive's own, or the second side context beside the sequence stream)
@@ -1496,7 +1497,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         }
         if (r == NAF_GPU_ECAP || (r == 0 && qgot != qn)) return ctx_fail(qc, NAF_GPU_EFORMAT, "can't decompress quality\n");
         if (r) return r;
-        pl.P.qual = (prq && prq->ranged) ? q - prq->got_lo : q;
+        pl.P.qual = (prq && prq->ranged) ? (prq->own_buf ? prq->own_buf : q) - prq->got_lo : q;
         return 0;
     };
     auto payload = [&]() -> int { int r = payload_seq(); if (r) return r; return pl.need_qual ? payload_qual(c) : 0; };

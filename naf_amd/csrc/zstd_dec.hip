@@ -1504,6 +1504,55 @@ __global__ void k_find_range(const u64 *offs, u32 nblk, const u64 *total_p, u64 
     i32 ob = own_huf[b_lo]; out4[4] = ob < 0 ? b_lo : (u64)ob;      // first block whose Huffman table can be in force in the range
 }
 
+// ---- byte-range decode of a frame WITH sequences: the dependency closure of the range (unnaf/src/input.c:271 lets a match reach back
+// 2^31 bytes; what a block range needs in front of it is not a window but everything its matches read, and what THOSE blocks' matches
+// read, and so on) -------------------------------------------------------------------------------------------------------------------
+// f[b] = the block that holds the earliest byte a match of block b reads (b itself when nothing reaches in front of it)
+__global__ void k_seq_reach(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *offs, const u32 *o_ll, const u32 *o_ml, const u32 *o_of, u32 *f)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seq_blk) return;
+    const u32 bi = seq_list[t];
+    const ZBlock &b = blk[bi];
+    if (b.err) return;
+    const u64 start = offs[bi];
+    u64 pos = start, m = start;
+    const u32 rep_in[3] = { b.rep_in[0], b.rep_in[1], b.rep_in[2] };
+    for (u32 q = 0; q < b.nseq; q++) {
+        const u32 ll = o_ll[b.seq_base + q], ml = o_ml[b.seq_base + q], off = sym_resolve(o_of[b.seq_base + q], rep_in);
+        pos += ll;
+        const u64 src = off > pos ? 0 : pos - off;
+        if (src < m) m = src;
+        pos += ml;
+    }
+    if (m >= start) return;                                    // f[bi] stays bi
+    u32 lo = 0, hi = bi;                                       // largest j with offs[j] <= m
+    while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (offs[mid] <= m) lo = mid; else hi = mid; }
+    f[bi] = lo;
+}
+__global__ void k_iota_u32(u32 *f, u32 n) { const u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) f[i] = i; }
+// One wavefront: blocks [b_lo, b_hi) hold the wanted bytes (k_find_range); the closure's first block c is the least fixed point of
+// c = min(c, f[b] for b in [c, b_hi)).  out: [0] c, [1] b_hi, [2] offs[c], [3] offs[b_hi] (or the total), [4] block whose Huffman
+// table is in force at c, [5] / [6] ranks of c / b_hi among the blocks with sequences.
+__global__ __launch_bounds__(64) void k_range_closure(const u32 *f, const u64 *offs, u32 nblk, const u64 *total_p, const u64 *r4, const i32 *own_huf, const u64 *seq_rank, u32 n_seq_blk, u64 *out)
+{
+    const u32 lane = threadIdx.x;
+    const u32 b_lo = (u32)r4[0], b_hi = (u32)r4[1];
+    u32 c = b_lo, lo = b_lo, hi = b_hi;
+    for (;;) {
+        u32 m = c;
+        for (u32 b = lo + lane; b < hi; b += 64) { const u32 v = f[b]; m = v < m ? v : m; }
+        for (int d = 32; d; d >>= 1) { const u32 o = (u32)__shfl_xor((int)m, d, 64); m = o < m ? o : m; }
+        if (m >= c) break;
+        hi = c; lo = m; c = m;                                    // the blocks newly taken in may reach further back
+    }
+    if (lane == 0) {
+        out[0] = c; out[1] = b_hi; out[2] = offs[c]; out[3] = b_hi < nblk ? offs[b_hi] : *total_p;
+        const i32 ob = own_huf[c]; out[4] = ob < 0 ? c : (u64)ob;
+        out[5] = seq_rank[c]; out[6] = b_hi < nblk ? seq_rank[b_hi] : n_seq_blk;
+    }
+}
+
 // ---- a small frame in one launch ------------------------------------------------------------------------------------------------
 // The pipeline above costs a frame about 25 launches and half a dozen host read-backs whatever its size -- half a millisecond for
 // the ids, the names and the lengths of an archive of a hundred chromosomes, a few hundred bytes each, and the emit kernels wait
@@ -1984,9 +2033,10 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         if (!o_ll || !o_ml || !o_of) return NAF_GPU_ENOMEM;
     }
     u32 *seq_list = nullptr;                                 // indices of the blocks that have sequences, in order
+    u64 *seq_rank = nullptr;                                 // blocks with sequences in front of block i
     if (n_seq_blk) {
         seq_list = arena_new<u32>(c, n_seq_blk);
-        u64 *flag = arena_new<u64>(c, (size_t)nblk + 1);
+        u64 *flag = arena_new<u64>(c, (size_t)nblk + 1); seq_rank = flag;
         if (!seq_list || !flag) return NAF_GPU_ENOMEM;
         LAUNCH(c, "zstd_seq_flag", k_seq_flag, g, 64, 0, (const ZBlock *)blk, nblk, flag);
         if ((rc = scan_exclusive_u64(c, flag, nblk, (u64 *)nullptr))) return rc;
@@ -2009,8 +2059,9 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     // do not reference earlier output, i.e. a frame without sequences (this build's own frames; reference-made
     // random-ACGT frames); otherwise the whole frame is decoded.
     u32 b_first = 0, b_count = nblk, huf_first = 0; u64 bias = 0;
+    u32 seq_t0 = 0, seq_t1 = n_seq_blk;                          // the blocks with sequences among the decoded ones: seq_list[seq_t0 .. seq_t1)
     if (fuse) { d_dst = nullptr; dst_cap = ~(size_t)0; }
-    if (rg) { rg->got_lo = 0; rg->got_hi = hs.total_out; rg->ranged = false; }
+    if (rg) { rg->got_lo = 0; rg->got_hi = hs.total_out; rg->ranged = false; rg->own_buf = nullptr; }
     if (rg && n_seq_blk == 0 && nblk > 0 && rg->want_hi > rg->want_lo) {
         if (!lit_only_spec) {
             u64 *r4b = arena_new<u64>(c, 5); if (!r4b) return NAF_GPU_ENOMEM;
@@ -2022,13 +2073,37 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         rg->got_lo = h4[2]; rg->got_hi = h4[3]; rg->ranged = true;
         if (h4[3] - h4[2] > dst_cap) return ctx_fail(c, NAF_GPU_ECAP, "zstd range output needs %llu bytes, capacity %zu", (unsigned long long)(h4[3] - h4[2]), dst_cap);
         d_dst -= bias;                                       // block b lands at d_dst_orig + (out_off[b] - got_lo)
+    } else if (rg && n_seq_blk && nblk > 0 && rg->want_hi > rg->want_lo && !(getenv("NAF_GPU_RANGE_CLOSURE") && getenv("NAF_GPU_RANGE_CLOSURE")[0] == '0')) {
+        // blocks with matches: the range's dependency closure (kernels above).  On archives that are mostly literals -- what the
+        // reference makes of a genome at its default level -- that is the range's own blocks and a few in front of them.
+        u32 *f = arena_new<u32>(c, nblk); u64 *r4b = arena_new<u64>(c, 5 + 8); if (!f || !r4b) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zstd_find_range", k_find_range, 1, 64, 0, (const u64 *)sizes, nblk, (const u64 *)d_total_out, rg->want_lo, rg->want_hi, (const i32 *)own_huf, r4b);
+        LAUNCH(c, "zstd_range_closure", k_iota_u32, g, 64, 0, f, nblk);
+        LAUNCH(c, "zstd_range_closure", k_seq_reach, cdiv(n_seq_blk, 64), 64, 0, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, f);
+        LAUNCH(c, "zstd_range_closure", k_range_closure, 1, 64, 0, (const u32 *)f, (const u64 *)sizes, nblk, (const u64 *)d_total_out, (const u64 *)r4b, (const i32 *)own_huf, (const u64 *)seq_rank, n_seq_blk, r4b + 5);
+        u64 h7[7]; rc = ctx_readback(c, h7, r4b + 5, sizeof h7); if (rc) return rc;
+        const u64 need = h7[3] - h7[2];
+        if (need < hs.total_out) {
+            if (need > dst_cap) {
+                // the caller sized its buffer for the range alone: take the closure's from the arena and say so (ZRange.own_buf)
+                d_dst = (u8 *)arena_alloc(c, need + 64); if (!d_dst) return NAF_GPU_ENOMEM;
+                dst_cap = need; rg->own_buf = d_dst;
+            }
+            huf_first = (u32)h7[4];
+            b_first = (u32)h7[0]; b_count = (u32)(h7[1] - h7[0]); bias = h7[2];
+            seq_t0 = (u32)h7[5]; seq_t1 = (u32)h7[6];
+            rg->got_lo = h7[2]; rg->got_hi = h7[3]; rg->ranged = true;
+            d_dst -= bias;
+        } else if (hs.total_out > dst_cap) return ctx_fail(c, NAF_GPU_ECAP, "zstd output needs %llu bytes, capacity %zu", (unsigned long long)hs.total_out, dst_cap);
     } else if (hs.total_out > dst_cap) return ctx_fail(c, NAF_GPU_ECAP, "zstd output needs %llu bytes, capacity %zu", (unsigned long long)hs.total_out, dst_cap);
 
     u32 *done = nullptr; u8 *lit_scratch = nullptr;
     if (n_seq_blk) {
         done = arena_new<u32>(c, nblk);
-        lit_scratch = (u8 *)arena_alloc(c, hs.total_out + 16);
+        const u64 span = rg && rg->ranged ? rg->got_hi - rg->got_lo : hs.total_out;
+        lit_scratch = (u8 *)arena_alloc(c, span + 16);
         if (!done || !lit_scratch) return NAF_GPU_ENOMEM;
+        lit_scratch -= bias;                                     // indexed by a block's place in the whole output, like d_dst
     }
     LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, done, (u32 *)nullptr, (u32 *)nullptr);
     bool copy_fill_done = false;
@@ -2099,13 +2174,14 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         }
     }
     if (b_count && !fuse && !copy_fill_done && hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first, (const u8 *)nullptr);
-    if (n_seq_blk) {
+    if (seq_t1 > seq_t0) {
         const char *el = getenv("NAF_GPU_EXEC_LDS");                      // "0": always the HBM executor (cross-check)
+        const u32 nx = seq_t1 - seq_t0;
         if (max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
-            LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, n_seq_blk, 64, 0, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
+            LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, nx, 64, 0, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, nblk,
                    (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st);
         else
-            LAUNCH(c, "zstd_exec_seq", k_exec_seq, n_seq_blk, 64, 0, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
+            LAUNCH(c, "zstd_exec_seq", k_exec_seq, nx, 64, 0, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, nblk,
                    (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st);
     }
     if (c->zsplit && c->zsplit->done) { c->zsplit->status = st; return 0; }      // the caller checks the status once the emit is queued (zstd_split_status)

@@ -576,3 +576,52 @@ def test_huffman_streams_decoded_in_parts(gpu, oracle, monkeypatch, part, margin
             assert len(got) == len(data)
         except NafGpuError:
             pass
+
+
+def test_unnaf_range_of_frames_with_matches_decodes_the_dependency_closure(gpu, oracle, monkeypatch, capfd):
+    """A byte range of an archive whose sequence stream holds LZ matches (every reference-made archive; this build's at levels >= 2
+    and on repeat-rich input): the blocks under the range and, transitively, every block their matches read from (zstd_dec.hip
+    k_seq_reach / k_range_closure) -- not the whole stream.  range == slice of the whole text at random cuts, on the reference-made
+    repeat archives (levels 1, 19, --long 27), on reference- and own-made archives of text with far-apart repeats, for the packed
+    4-bit stream, FASTA and FASTQ; the closure is a fraction of the stream where matches are sparse."""
+    from naf_amd import synth
+    rng = np.random.default_rng(9)
+    arcs = [(name, golden_bytes("naf", name + ".naf")) for name in ("repeat_l1", "repeat_l19", "repeat_long27", "fastq_4k", "mixed_60")]
+    # mostly unique sequence with a few far-apart copies: sparse matches, long literal stretches
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    body = acgt[rng.integers(0, 4, 6_000_000)].copy()
+    for k in range(12):
+        a, b = int(rng.integers(0, 5_000_000)), int(rng.integers(0, 5_900_000))
+        body[b:b + 40_000] = body[a:a + 40_000]
+    sparse = b">chrS sparse repeats\n" + synth.wrap_lines(body, 70)
+    if oracle.have_ref():
+        arcs.append(("ref_sparse", oracle.ref_ennaf(sparse)))
+        arcs.append(("ref_sparse_l19", oracle.ref_ennaf(sparse, ("-19",))))
+    own, _ = gpu.ennaf(gpu.to_device(sparse), level=5)
+    arcs.append(("own_sparse_l5", host(own)))
+    for name, naf in arcs:
+        d = gpu.to_device(naf)
+        modes = (1, -1) if name.startswith("fastq") else (0, 2, -1)
+        for mode in modes:
+            monkeypatch.setenv("NAF_GPU_RANGE_CLOSURE", "1")
+            whole = host(gpu.unnaf(d, mode))
+            n = len(whole)
+            cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, 7)]))
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                assert host(gpu.unnaf_range(d, a, b, mode)) == whole[a:b], (name, mode, a, b)
+            monkeypatch.setenv("NAF_GPU_RANGE_CLOSURE", "0")          # the whole-stream fallback stays right too
+            a, b = cuts[len(cuts) // 2 - 1], cuts[len(cuts) // 2]
+            assert host(gpu.unnaf_range(d, a, b, mode)) == whole[a:b]
+    monkeypatch.delenv("NAF_GPU_RANGE_CLOSURE")
+    # the closure of a late eighth of the sparse archive is far smaller than the stream
+    for name, naf in arcs:
+        if "sparse" not in name:
+            continue
+        d = gpu.to_device(naf)
+        n = len(sparse)
+        gpu.set_timing(True)
+        got = host(gpu.unnaf_range(d, n // 2, n // 2 + n // 8, 0))
+        kt = {nm: (ms, k) for nm, ms, k in gpu.get_timing()}
+        gpu.set_timing(False)
+        assert got == sparse[n // 2: n // 2 + n // 8]
+        assert "zstd_range_closure" in kt, (name, sorted(kt))
