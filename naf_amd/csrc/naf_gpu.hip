@@ -288,6 +288,8 @@ static hipEvent_t ev_get(naf_gpu_ctx *c)
 
 void ktime_begin(naf_gpu_ctx *c, const char *name)
 {
+    static const int sync_debug = (getenv("NAF_GPU_SYNC_DEBUG") && getenv("NAF_GPU_SYNC_DEBUG")[0] == '1') ? 1 : 0;
+    if (sync_debug) fprintf(stderr, "[launch] %s\n", name);
     if (!c->timing) return;
     KTime k; k.name = name; k.a = ev_get(c); k.b = ev_get(c);
     hipEventRecord(k.a, c->stream);
@@ -296,6 +298,10 @@ void ktime_begin(naf_gpu_ctx *c, const char *name)
 
 void ktime_end(naf_gpu_ctx *c)
 {
+    // NAF_GPU_SYNC_DEBUG=1 (development): every launch is waited for and named on stderr -- the last name printed before a hang or a
+    // fault is the kernel that did it
+    static const int sync_debug = (getenv("NAF_GPU_SYNC_DEBUG") && getenv("NAF_GPU_SYNC_DEBUG")[0] == '1') ? 1 : 0;
+    if (sync_debug) { fprintf(stderr, "[launch] ...\n"); hipError_t e = hipStreamSynchronize(c->stream); fprintf(stderr, "[launch] done: %s\n", hipGetErrorString(e)); }
     if (!c->timing) return;
     hipEventRecord(c->ktimes.back().b, c->stream);
 }

@@ -563,7 +563,7 @@ __global__ void k_rep_fast(ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, ZSta
         else { const ZBlock &q = blk[seq_list[--p]]; if (q.err) { atomicOr(&st->rep_slow, 1u); return; } prev[0] = q.rep_out[0]; prev[1] = q.rep_out[1]; prev[2] = q.rep_out[2]; }
         for (int k = 0; k < 3; k++) {
             if (!sym_is(cur[k])) continue;
-            u32 slot = (cur[k] >> 29) & 3, delta = cur[k] & 0x1FFFFFFFu, v = prev[slot];
+            u32 slot = sym_slot(cur[k]), delta = sym_delta(cur[k]), v = prev[slot];
             if (sym_is(v)) cur[k] = v + delta;                                      // still symbolic: deltas add up
             else { u32 r = v - delta; cur[k] = r ? r : 1; }
         }
@@ -1313,7 +1313,10 @@ __device__ __forceinline__ void wait_block_done(volatile u32 *done, u32 j)
 {
     // lane 0 polls (relaxed, agent scope); one acquire afterwards drops stale L1 lines (guide G16)
     if (threadIdx.x == 0) {
-        while (__hip_atomic_load(&done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+        // (bounded: a block that never completes -- a bug, or a frame whose sequences lie about their sources -- must end in wrong bytes
+        // and an error, not in a device that has to be reset; about ten seconds)
+        u32 spins = 0;
+        while (__hip_atomic_load(&done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -1358,8 +1361,11 @@ __global__ __launch_bounds__(64) void k_exec_seq(const ZBlock *blk, const u32 *s
         u64 pos_abs = out_off + op;
         if (off > pos_abs) { bad = true; break; }                     // reaches before the frame start
         u64 src_abs = pos_abs - off;
-        if (src_abs < out_off) {
-            // source (partly) in earlier blocks: confirm every block from the one holding src_abs up to lo_idx
+        if (src_abs < offs[lo_idx]) {
+            // source (partly) in blocks not yet known complete: confirm every block from the one holding src_abs up to lo_idx.  (The
+            // test is against the lowest block confirmed so far, not against this block's start: a later match into an already
+            // confirmed block found "the block in front of it" here and waited for that one -- an idle wait in a whole decode, for
+            // ever in a range decode, where blocks in front of the range's closure never run.)
             u32 lo = 0, hi = lo_idx;                                 // largest j with offs[j] <= src_abs
             while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (offs[mid] <= src_abs) lo = mid; else hi = mid; }
             for (u32 j = lo_idx; j-- > lo;) wait_block_done(done, j);
@@ -1450,12 +1456,14 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
                 if (ofj >= mlj) { for (u32 k = lane; k < mlj; k += 64) obuf[d + k] = from[k]; }
                 else            { for (u32 k = lane; k < mlj; k += 64) obuf[d + k] = from[k % ofj]; }
             } else {
-                // source (partly) in earlier blocks: confirm every block from the one holding it up to this one, then read HBM
+                // source (partly) in earlier blocks: confirm every block from the one holding it up to the lowest one confirmed so far, then read HBM
                 u64 src_abs = pos_abs - ofj;
-                u32 lo = 0, hi = lo_idx;
-                while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (offs[mid] <= src_abs) lo = mid; else hi = mid; }
-                for (u32 q = lo_idx; q-- > lo;) wait_block_done(done, q);
-                if (lo < lo_idx) lo_idx = lo;
+                if (src_abs < offs[lo_idx]) {
+                    u32 lo = 0, hi = lo_idx;
+                    while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (offs[mid] <= src_abs) lo = mid; else hi = mid; }
+                    for (u32 q = lo_idx; q-- > lo;) wait_block_done(done, q);
+                    if (lo < lo_idx) lo_idx = lo;
+                }
                 u32 outside = (u32)(out_off - src_abs);                                // bytes of the pattern that lie before this block
                 for (u32 k = lane; k < mlj; k += 64) {
                     u32 r = ofj >= mlj ? k : k % ofj;
@@ -2083,6 +2091,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         LAUNCH(c, "zstd_range_closure", k_range_closure, 1, 64, 0, (const u32 *)f, (const u64 *)sizes, nblk, (const u64 *)d_total_out, (const u64 *)r4b, (const i32 *)own_huf, (const u64 *)seq_rank, n_seq_blk, r4b + 5);
         u64 h7[7]; rc = ctx_readback(c, h7, r4b + 5, sizeof h7); if (rc) return rc;
         const u64 need = h7[3] - h7[2];
+        if (getenv("NAF_GPU_DEBUG_RANGE")) fprintf(stderr, "[range] want %llu..%llu -> blocks %llu..%llu (bytes %llu..%llu of %llu), tables from %llu, seq blocks %llu..%llu of %u\n", (unsigned long long)rg->want_lo, (unsigned long long)rg->want_hi,
+                    (unsigned long long)h7[0], (unsigned long long)h7[1], (unsigned long long)h7[2], (unsigned long long)h7[3], (unsigned long long)hs.total_out, (unsigned long long)h7[4], (unsigned long long)h7[5], (unsigned long long)h7[6], n_seq_blk);
         if (need < hs.total_out) {
             if (need > dst_cap) {
                 // the caller sized its buffer for the range alone: take the closure's from the arena and say so (ZRange.own_buf)

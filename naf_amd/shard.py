@@ -31,10 +31,48 @@ def byte_range(total: int, rank: int, world: int, align: int = 4096):
     return b, e
 
 
+def _staged(t, group):
+    """Device tensors over a backend that only moves host memory (gloo: the two-process tests on a box with one GPU, a job without
+    RCCL): the transfer goes through a host copy.  RCCL moves device memory itself."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def _p2p(ops):
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+    if not ops:
+        return
+    back = []
+    real = []
+    for op in ops:
+        if _staged(op.tensor, op.group):
+            h = op.tensor.cpu() if op.op is dist.isend else torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
+            if op.op is dist.irecv:
+                back.append((op.tensor, h))
+            real.append(dist.P2POp(op.op, h, op.peer, op.group))
+        else:
+            real.append(op)
+    for w in dist.batch_isend_irecv(real):
+        w.wait()
+    for d, h in back:
+        d.copy_(h)
+
+
+def _all_gather(outs, t, group):
+    if _staged(t, group):
+        hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        dist.all_gather(hs, t.cpu(), group=group)
+        for o, h in zip(outs, hs):
+            o.copy_(h)
+    else:
+        dist.all_gather(outs, t, group=group)
+
+
+def _broadcast(t, src, group):
+    if _staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src, group=group)
 
 
 def gather_ranges(local: torch.Tensor, total: int, dst: int = 0, group=None, out: torch.Tensor = None):
@@ -169,7 +207,7 @@ def _all_gather_bytes(raw: bytes, device, group):
     world = dist.get_world_size(group)
     t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
     outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t, group=group)
+    _all_gather(outs, t, group)
     return [bytes(o.cpu().numpy().tobytes()) for o in outs]
 
 
@@ -177,7 +215,7 @@ def _all_gather_ints(vals, device, group):
     world = dist.get_world_size(group)
     t = torch.tensor(list(vals), dtype=torch.int64, device=device)
     outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t, group=group)
+    _all_gather(outs, t, group)
     return [[int(x) for x in o.cpu().tolist()] for o in outs]
 
 
@@ -211,7 +249,7 @@ def ennaf_sharded(ctx, d_buf, n, opts=None, dst=0, group=None, everywhere=False)
             ln = _all_gather_ints([arc.numel() if rank == 0 else 0], dev, group)[0][0]
             if rank != 0:
                 arc = torch.empty(ln, dtype=torch.uint8, device=dev)
-            dist.broadcast(arc, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            _broadcast(arc, dist.get_global_rank(group, 0) if group is not None else 0, group)
         return (arc if (everywhere or rank == dst) else None), rep, info
     lo = p0 if rank == 0 else 0
     # byte in front of every slice: an EOL makes position 0 of the slice a place where a line starts
@@ -243,7 +281,7 @@ def ennaf_sharded(ctx, d_buf, n, opts=None, dst=0, group=None, everywhere=False)
         h = torch.zeros(maxc, dtype=torch.uint8, device=dev)
         h[:cut] = mine[:cut]
         heads = [torch.empty_like(h) for _ in range(world)]
-        dist.all_gather(heads, h, group=group)
+        _all_gather(heads, h, group)
     borrow = []
     for r in range(rank + 1, world):
         c, ln = lens[r]
@@ -298,5 +336,5 @@ def ennaf_sharded(ctx, d_buf, n, opts=None, dst=0, group=None, everywhere=False)
     if everywhere:
         if rank != dst:
             out = torch.empty(max(naf_len, 1), dtype=torch.uint8, device=dev)
-        dist.broadcast(out, dst, group=group)
+        _broadcast(out, dist.get_global_rank(group, dst) if group is not None else dst, group)
     return (out[:naf_len] if out is not None else None), rep, extra

@@ -625,3 +625,28 @@ def test_unnaf_range_of_frames_with_matches_decodes_the_dependency_closure(gpu, 
         gpu.set_timing(False)
         assert got == sparse[n // 2: n // 2 + n // 8]
         assert "zstd_range_closure" in kt, (name, sorted(kt))
+
+
+def test_offset_code_31_a_match_2_gib_back(gpu):
+    """`ennaf --long 31` (ennaf/src/ennaf.c:247-273) lets a match reach back 2^31 bytes and unnaf raises its decoder's window limit
+    to match (unnaf/src/input.c:271); offsets from 2^31 - 3 up take offset code 31.  The frame of tests/golden/make_long31.py (hand
+    assembled from RFC 8878 and checked there against the real libzstd: digests pinned) holds one such match, 2^31 - 2 bytes back
+    across sixteen thousand RLE blocks."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("make_long31", os.path.join(os.path.dirname(__file__), "golden", "make_long31.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    frame = m.frame()
+    assert sha(frame) == m.FRAME_SHA256
+    a, zeros, lits = m.parts()
+    want_sha, n = m.text_digest()
+    assert want_sha == m.TEXT_SHA256
+    out = gpu.zstd_decompress(gpu.to_device(frame), n + 64)
+    assert out.numel() == n
+    assert host(out[:len(a)]) == a
+    z = out[len(a):len(a) + zeros]
+    for i in range(0, zeros, 1 << 28):
+        assert not bool(z[i:i + (1 << 28)].any())
+    assert host(out[len(a) + zeros:]) == lits + a[m.SRC:m.SRC + m.ML]
+    del out, z
+    torch.cuda.empty_cache()

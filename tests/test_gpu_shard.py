@@ -266,3 +266,76 @@ def test_window_descriptor_of_a_sharded_frame_follows_the_options(ctxs, oracle):
         assert host(ctxs[0].unnaf(ctxs[0].to_device(naf), -1)) == text
         if oracle.have_ref():
             assert oracle.ref_unnaf(naf) == text
+
+
+def _two_rank_worker(rank, world, port, q, kind):
+    """One process of a two-rank job on the ONE device of the test box: the real library (capi.Context(0)) on either side of real
+    process boundaries, torch.distributed over gloo (RCCL needs a device per rank; naf_amd/shard.py stages device tensors through
+    the host for gloo) -- sharded encode into one archive on every rank, then the sharded decode of it gathered to rank 0."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")                  # the box's host name may not resolve
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        from naf_amd import capi, shard as sh, synth
+        from oracle import oracle as O
+        import test_shard_cpu as me
+        torch.cuda.set_device(0)
+        ctx = capi.Context(0)
+        rng = np.random.default_rng(123)
+        if kind == "fasta":
+            text = b"\n \n" + me.fasta_fuzz(rng, 4, 40000, width=60) + synth.fasta_acgt(600_001, 2, 80, seed=5)
+        elif kind == "fastq":
+            text = synth.fastq_reads(4000, 120, seed=6, var_len=True)
+        else:                                                          # level 3: matches across blocks inside every shard's part
+            text = synth.repeat_genome(seed=8, unit=30000, copies=12)
+        a = [0, len(text) * 2 // 5, len(text)]                          # uneven nominal slices, cut anywhere
+        mine = text[a[rank]:a[rank + 1]]
+        buf = torch.zeros(len(mine) + (1 << 16), dtype=torch.uint8, device="cuda")
+        buf[: len(mine)] = torch.frombuffer(bytearray(mine), dtype=torch.uint8).cuda()
+        opts = sh.make_opts(level=3 if kind == "repeat" else 1)
+        naf, rep, extra = sh.ennaf_sharded(ctx, buf, len(mine), opts, dst=0, everywhere=True)
+        arc = naf.cpu().numpy().tobytes()
+        ok = True
+        try:
+            if kind != "repeat":
+                me.check_against_whole(O, text, arc, rep)
+            mode = capi.OUT_FASTQ if kind == "fastq" else capi.OUT_FASTA
+            want = O.unnaf(O.ennaf(text), mode)
+            got = sh.unnaf_sharded(ctx, naf, mode, dst=0)
+            if rank == 0:
+                assert got.cpu().numpy().tobytes() == want
+                if O.have_ref() and kind != "fastq":
+                    assert O.ref_unnaf(arc) == want
+            else:
+                assert got is None
+        except AssertionError as e:
+            ok = "rank %d: %r" % (rank, e)
+        ctx.close()
+        q.put((rank, ok, extra))
+    except Exception as e:                                             # noqa: BLE001 -- the parent must hear about it
+        q.put((rank, "rank %d: %r" % (rank, e), {}))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["fasta", "fastq", "repeat"])
+def test_two_processes_one_device_real_library_over_gloo(kind):
+    """the shard protocol and the gather across REAL process boundaries with the HIP library on both sides."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 33500 + os.getpid() % 2000 + {"fasta": 0, "fastq": 11, "repeat": 23}[kind]
+    ps = [mpc.Process(target=_two_rank_worker, args=(r, 2, port, q, kind), daemon=True) for r in range(2)]
+    for p in ps:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=240) for _ in ps)
+    finally:
+        for p in ps:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+    assert all(r[1] is True for r in res), res
+    assert res[1][2]["cut"] > 0 and res[0][2]["halo"] == res[1][2]["cut"]
