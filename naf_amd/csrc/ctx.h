@@ -32,7 +32,7 @@ struct FlatStream { u64 q0, A; };
 struct ZFlat { const u8 *src; const FlatStream *si; u64 nslots; const u8 *sym; void *status; bool ready;
                const u8 *tail; u64 tail_q; u32 tail_n;
                const u8 *cls; u32 n_decoded;       // cls == nullptr: every block is flat (nothing was decoded)
-               struct naf_gpu_ctx *aux; hipEvent_t decoded_ev; };   // aux: a context whose stream is free for the decode of the blocks that are not flat (set by the caller; the emit of the flat tiles runs beside it); decoded_ev: set by the decoder when it used it -- to be waited for before the decoded bytes are read   // tail: a final Raw block (the byte that holds the padding nibble of an odd stream, zstd_enc) -- its bytes lie in the frame as they are; packed index of its first byte; its length
+               struct naf_gpu_ctx *aux; hipEvent_t decoded_ev; void *later; };   // later: the decode of the blocks that are not flat, as a job to be run by the caller once its tile index is queued (zstd_flat_later)   // aux: a context whose stream is free for the decode of the blocks that are not flat (set by the caller; the emit of the flat tiles runs beside it); decoded_ev: set by the decoder when it used it -- to be waited for before the decoded bytes are read   // tail: a final Raw block (the byte that holds the padding nibble of an odd stream, zstd_enc) -- its bytes lie in the frame as they are; packed index of its first byte; its length
 struct naf_gpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -116,6 +116,8 @@ int zstd_decode_fused_fasta(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int
 struct ZRange { u64 want_lo, want_hi, got_lo, got_hi; bool ranged; u8 *own_buf; };   // own_buf: set when the decoder had to take a larger buffer than the caller's (the dependency closure of a range in a frame with matches): byte got_lo is own_buf[0]
 int zstd_decode_range(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, int has_magic, u8 *d_dst, size_t dst_cap, size_t *out_len, ZRange *rg, const u8 *head = nullptr);
 int zstd_split_status(naf_gpu_ctx *c, const ZSplit *sp);
+int zstd_flat_later(naf_gpu_ctx *c, ZFlat *zf);
+void zstd_flat_drop(ZFlat *zf);
 // up to 4 small frames (no magic) in one launch; ok[k] false = take the ordinary path for frame k
 int zstd_small_batch(naf_gpu_ctx *c, int n, const u8 *const *src, const size_t *len, u8 *const *dst, const size_t *cap, bool *ok);
 // One frame of independently coded blocks; with_magic=0 omits the 4 magic bytes (as stored in a .naf section).

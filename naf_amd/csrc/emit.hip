@@ -1512,6 +1512,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     // A whole 4-bit text with long records goes through the tile kernels: if its sequence stream turns out to be a flat frame
     // (ctx.h: ZFlat) those read it in place and nothing is decoded.  NAF_GPU_FLAT_FUSE=0: always decode first (cross-check).
     ZFlat zflat; memset(&zflat, 0, sizeof zflat);
+    struct FlatGuard { ZFlat *z; ~FlatGuard() { zstd_flat_drop(z); } } flat_guard{ &zflat };      // (a job the decoder left and nobody ran: an error on the way)
     const char *ff = getenv("NAF_GPU_FLAT_FUSE"), *ek0 = getenv("NAF_GPU_EMIT");
     const bool try_flat = !size_only && pl.fourbit && !fuse_on && !pl.P.force_slow && !(ff && ff[0] == '0') && !(ek0 && ek0[0]) &&
                           (pl.P.mode == EM_FASTA || pl.P.mode == EM_SEQ || pl.P.mode == EM_SEQUENCES) && pl.P.N && h.orig_size[S_SEQ] / pl.P.N >= 16384 &&
@@ -1651,6 +1652,10 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             }
             LAUNCH(ic, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr, tsig);
             LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles + FLAT_TPW, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt, tsig, (u32)FLAT_TPW, list2);
+            // a mostly-flat frame: the blocks that are not flat are decoded now -- on the spare stream, beside the emit of the flat tiles
+            naf_gpu_ctx *xc = c;                                                              // where the tiles over decoded blocks are emitted
+            const bool flat_job = zflat.ready && zflat.later;
+            if (flat_job) HIP_TRY(c, hipEventRecord(c->split_ev[0], c->stream));              // the job's stream starts behind the tile index
             u64 t_done = 0;
             if (split.done) {
                 HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX], ic->stream));
@@ -1672,12 +1677,15 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                 const u32 nwg = cdiv(ntiles, FLAT_TPW), chunk = (nwg + 7) / 8;
                 static const bool xcd = !(getenv("NAF_GPU_XCD") && getenv("NAF_GPU_XCD")[0] == '0');
                 LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat, xcd ? chunk * 8 : nwg, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, xcd ? chunk : 0u);
-                if (zflat.decoded_ev) HIP_TRY(c, hipStreamWaitEvent(c->stream, zflat.decoded_ev, 0));      // the blocks that were decoded beside it
+                if (flat_job) {                                                               // (queued behind the flat emit: the job waits for its tables on the host)
+                    if ((rc = zstd_flat_later(c, &zflat))) return rc;
+                    if (zflat.aux) xc = zflat.aux;
+                }
                 if (zflat.cls && zflat.n_decoded) {
                     // a tile costs this kernel about what it costs k_emit_tile: as many workgroups as there can be tiles over decoded blocks, up to a few waves of the device
                     const u64 est = (u64)zflat.n_decoded * 64 + 64;                           // (blocks of up to 128 KiB: 64 tiles each)
                     const u32 lgrid = (u32)(est < ntiles ? (est < 16384 ? est : 16384) : (ntiles < 16384 ? ntiles : 16384));
-                    LAUNCH(c, "unnaf_emit", k_emit_tile_list<true>, lgrid, 256, 0, pl.P, (const TileIdx *)ti, (const u32 *)list2, (const u32 *)(cnt + 1), d_out);
+                    LAUNCH(xc, "unnaf_emit", k_emit_tile_list<true>, lgrid, 256, 0, pl.P, (const TileIdx *)ti, (const u32 *)list2, (const u32 *)(cnt + 1), d_out);
                 }
             }
             else if (t_done < ntiles) {
@@ -1686,8 +1694,9 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             }
             // tiles holding a header or a record boundary (their number stays on the device)
             const u32 rest_grid = (u32)(ntiles < EMIT_REST_GRID ? ntiles : EMIT_REST_GRID);
-            if (pl.fourbit) LAUNCH(c, "unnaf_emit_rest", k_emit_rest<true>, rest_grid, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
-            else LAUNCH(c, "unnaf_emit_rest", k_emit_rest<false>, rest_grid, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
+            if (pl.fourbit) LAUNCH(xc, "unnaf_emit_rest", k_emit_rest<true>, rest_grid, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
+            else LAUNCH(xc, "unnaf_emit_rest", k_emit_rest<false>, rest_grid, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
+            if (xc != c) { HIP_TRY(c, hipEventRecord(c->split_ev[1], xc->stream)); HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[1], 0)); }
             if (split.done) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX + 1], 0));
             if (zflat.ready && getenv("NAF_GPU_DEBUG_FLAT")) {          // tests: how the tiles were dealt
                 u32 hc[2] = { 0, 0 };

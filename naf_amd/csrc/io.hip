@@ -20,15 +20,19 @@ static IoPool *io_pool(naf_gpu_ctx *c)
     IoPool *p = new IoPool();
     const char *e = getenv("NAF_GPU_IO_THREADS");
     int n = e ? atoi(e) : 8; if (n < 1) n = 1; if (n > 16) n = 16;
-    for (int i = 0; i < n; i++) {
-        IoLane &L = p->lane[i];
-        bool ok = hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking) == hipSuccess;
-        for (int k = 0; k < 2 && ok; k++) ok = hipHostMalloc(&L.pin[k], IO_CHUNK, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming) == hipSuccess;
-        if (!ok) break;
-        p->lanes++;
-    }
+    p->lanes = n;
     c->io_pool = p;
     return p;
+}
+// A lane's stream and its two pinned buffers are made by the thread that first uses the lane: pinning 256 MiB for eight lanes took the
+// calling thread 0.1 - 0.15 s in front of the first byte moved; the lanes' threads now pin their 32 MiB each beside one another, and a
+// transfer that uses one lane (every write) pins one lane's.
+static bool lane_ready(IoLane &L)
+{
+    if (L.s) return true;
+    bool ok = hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++) ok = hipHostMalloc(&L.pin[k], IO_CHUNK, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming) == hipSuccess;
+    return ok;
 }
 
 void io_pool_free(naf_gpu_ctx *c)
@@ -60,13 +64,13 @@ extern "C" int naf_gpu_read_file(naf_gpu_ctx *c, int fd, uint64_t file_off, size
     if (!c || (!d_dst && len)) return NAF_GPU_EARG;
     if (!len) return 0;
     IoPool *P = io_pool(c);
-    if (P->lanes == 0) return ctx_fail(c, NAF_GPU_ENOMEM, "can't allocate pinned staging buffers");
     const u64 nchunks = (len + IO_CHUNK - 1) / IO_CHUNK;
     const int T = (int)(nchunks < (u64)P->lanes ? nchunks : (u64)P->lanes);
     std::atomic<int> bad(0);
     auto work = [&](int t) {
         hipSetDevice(c->device);
         IoLane &L = P->lane[t]; bool used[2] = { false, false };
+        if (!lane_ready(L)) { bad = 3; return; }
         for (u64 i = (u64)t, k = 0; i < nchunks && !bad.load(); i += (u64)T, k++) {
             const int slot = (int)(k & 1); const u64 off = i * IO_CHUNK; const size_t n = len - off < IO_CHUNK ? (size_t)(len - off) : IO_CHUNK;
             if (used[slot] && hipEventSynchronize(L.ev[slot]) != hipSuccess) { bad = 2; break; }          // the upload that last read this buffer
@@ -80,6 +84,7 @@ extern "C" int naf_gpu_read_file(naf_gpu_ctx *c, int fd, uint64_t file_off, size
     for (int t = 1; t < T; t++) th.emplace_back(work, t);
     work(0);
     for (auto &x : th) x.join();
+    if (bad == 3) return ctx_fail(c, NAF_GPU_ENOMEM, "can't allocate pinned staging buffers");
     if (bad == 1) return ctx_fail(c, NAF_GPU_EARG, "can't read the input (short read or not a seekable file)");
     if (bad) return ctx_fail(c, NAF_GPU_EHIP, "host -> device copy failed: %s", hipGetErrorString(hipGetLastError()));
     return 0;
@@ -91,13 +96,17 @@ extern "C" int naf_gpu_write_file(naf_gpu_ctx *c, int fd, uint64_t file_off, con
     if (!len) return 0;
     HIP_TRY(c, hipStreamSynchronize(c->stream));                      // whatever produced d_src
     IoPool *P = io_pool(c);
-    if (P->lanes == 0) return ctx_fail(c, NAF_GPU_ENOMEM, "can't allocate pinned staging buffers");
     const u64 nchunks = (len + IO_CHUNK - 1) / IO_CHUNK;
-    const int T = (int)(nchunks < (u64)P->lanes ? nchunks : (u64)P->lanes);
+    // ONE writer unless told otherwise (NAF_GPU_IO_WRITE_THREADS): pwrite() into a new tmpfs file runs 7.5 GB/s from one thread and
+    // 4.7 / 3.8 GB/s from two / eight (the file's pages are added under one lock: tools/io_probe, profiles/r03_io_probe.txt), while the
+    // link delivers 50 GB/s to a single stream -- the download of chunk i + 1 runs beside the write of chunk i either way
+    static const int wt = [] { const char *e = getenv("NAF_GPU_IO_WRITE_THREADS"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+    int T = (int)(nchunks < (u64)P->lanes ? nchunks : (u64)P->lanes); if (T > wt) T = wt;
     std::atomic<int> bad(0);
     auto work = [&](int t) {
         hipSetDevice(c->device);
         IoLane &L = P->lane[t];
+        if (!lane_ready(L)) { bad = 3; return; }
         auto issue = [&](u64 i, int slot) -> bool {
             const u64 off = i * IO_CHUNK; const size_t n = len - off < IO_CHUNK ? (size_t)(len - off) : IO_CHUNK;
             return hipMemcpyAsync(L.pin[slot], (const u8 *)d_src + off, n, hipMemcpyDeviceToHost, L.s) == hipSuccess && hipEventRecord(L.ev[slot], L.s) == hipSuccess;
@@ -115,6 +124,7 @@ extern "C" int naf_gpu_write_file(naf_gpu_ctx *c, int fd, uint64_t file_off, con
     for (int t = 1; t < T; t++) th.emplace_back(work, t);
     work(0);
     for (auto &x : th) x.join();
+    if (bad == 3) return ctx_fail(c, NAF_GPU_ENOMEM, "can't allocate pinned staging buffers");
     if (bad == 1) return ctx_fail(c, NAF_GPU_EARG, "can't write to file - disk full?");
     if (bad) return ctx_fail(c, NAF_GPU_EHIP, "device -> host copy failed: %s", hipGetErrorString(hipGetLastError()));
     return 0;

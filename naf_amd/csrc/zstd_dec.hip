@@ -25,7 +25,7 @@ struct ZStat {                 // device-side counters read back by the host
     u32 ticket, n_plain_huf;     // n_plain_huf: compressed blocks with Huffman literals and no sequences
     u32 max_seq_regen, n_flat;    // largest regenerated size among the blocks that have sequences; table-defining blocks whose tree is flat
     u32 n_huf_distinct, n_huf_built;   // tree descriptions that differ from their predecessor's (k_huf_dedup); tables actually built
-    u32 max_lit_regen, pad2_;          // largest literals section of a Huffman-coded block (k_huf_par sizes its parts by it)
+    u32 max_lit_regen, n_huf_pending;  // largest literals section of a Huffman-coded block (k_huf_par sizes its parts by it); trees left without a table by k_build_huf's first phase
     u32 last_raw, flat_main_inv;       // size of the frame's last block when it is a Raw or (bit 31) RLE one, else 0; 0xFFFFFFFF - index of the FIRST block that defines a flat 4-bit tree (0: none)
 };
 
@@ -244,6 +244,7 @@ __global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_hu
     if (i >= nblk) return;
     ZBlock b = blk[i];
     zstd_parse_block(src + b.src_off, b);
+    b.huf_flat = 0; b.huf_tab = 0; b.huf_log = 0;                // (set by the table builders for the blocks that define a tree)
     blk[i] = b;
     set_err(st, b.err);
     bool comp = b.btype == BT_COMP && !b.err;
@@ -319,7 +320,10 @@ static __device__ __forceinline__ u32 huf_flat_direct(const u8 *d, u32 len)
 // range4 (optional, device): [4] = first block whose table may be in force in the wanted byte range, [1] = one past its last block
 // (k_find_range); blocks outside need no table.
 #define HUF_FEW 2048u           // up to this many distinct trees in a frame: k_build_huf_few (LDS) builds them, else k_build_huf
-__global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table, const i32 *own_huf, u32 gate)
+// phase 0: every tree.  Phase 2: every tree not yet marked flat -- a long frame whose caller can read flat blocks in place first gets its
+// flat tree found and its repetitions marked (k_flat_find_main, k_flat_mark_owner: cheap), and the tables of the other trees are built
+// here later, on another stream beside the emit of the flat tiles: this one-lane-per-tree build is 0.45 ms whatever the number of trees.
+__global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table, const i32 *own_huf, u32 gate, u32 phase)
 {
     u32 i = first + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblk) return;
@@ -328,12 +332,15 @@ __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 
     if (range4 && (i < (u32)range4[4] || i >= (u32)range4[1])) return;
     if (blk[i].btype != BT_COMP || blk[i].lit_type != LIT_HUF || blk[i].err) return;
     const u8 *c = src + blk[i].src_off;
-    const u32 fl = always_table ? 0u : huf_flat_direct(c + blk[i].lit_off, blk[i].lit_csize);
-    if (fl) {
-        blk[i].huf_tab = 0xFFFFFFFFu; blk[i].huf_log = (u8)fl; blk[i].huf_flat = 1;
-        atomicMax(&st->max_huf_log, fl); atomicAdd(&st->n_flat, 1u); atomicAdd(&st->n_huf_built, 1u);
-        if (fl == 4) atomicMax(&st->flat_main_inv, 0xFFFFFFFFu - i);
-        return;
+    if (phase == 2 && blk[i].huf_flat) return;                     // the frame's flat tree and its repetitions: k_flat_find_main / k_flat_mark_owner had them
+    {
+        const u32 fl = always_table ? 0u : huf_flat_direct(c + blk[i].lit_off, blk[i].lit_csize);
+        if (fl) {
+            blk[i].huf_tab = 0xFFFFFFFFu; blk[i].huf_log = (u8)fl; blk[i].huf_flat = 1;
+            atomicMax(&st->max_huf_log, fl); atomicAdd(&st->n_flat, 1u); atomicAdd(&st->n_huf_built, 1u);
+            if (fl == 4) atomicMax(&st->flat_main_inv, 0xFFFFFFFFu - i);
+            return;
+        }
     }
     u8 w[256]; u32 nw = 0, used = 0;
     u32 log = huf_read_weights(c + blk[i].lit_off, blk[i].lit_csize, w, &nw, &used);
@@ -358,7 +365,9 @@ struct HufLdsWS { HufBuildWS ws; __attribute__((aligned(16))) u8 in[192], w[256]
 // compact table of codes longer than HUF_FULL_LOG bits -- is lane 0's; directly stored weights, their check and the single-level
 // table are spread over the lanes (one lane doing all of it from LDS took 70 - 200 us per tree, in front of the literals of a
 // frame with one tree and of a mask stream with thousands).
-__device__ void build_huf_one_lds(const u8 *src, ZBlock *blk, u32 i, u8 *pool, u32 pool_cap, ZStat *st, HufLdsWS &S)
+// local_dst != nullptr: the table goes there (LDS of the calling kernel) instead of into the pool, and nothing is recorded in the block --
+// k_huf_par builds the tables of the blocks it decodes this way when nobody has built them (S.log tells it the table's log, 0 = corrupt)
+__device__ void build_huf_one_lds(const u8 *src, ZBlock *blk, u32 i, u8 *pool, u32 pool_cap, ZStat *st, HufLdsWS &S, u8 *local_dst = nullptr)
 {
     const u8 *c = src + blk[i].src_off + blk[i].lit_off;
     const u32 len = blk[i].lit_csize, n_in = len < 192 ? len : 192;          // a tree description takes at most 129 bytes
@@ -394,7 +403,8 @@ __device__ void build_huf_one_lds(const u8 *src, ZBlock *blk, u32 i, u8 *pool, u
     u32 log = S.log; const u32 nw = s_nw;
     if (lane == 0) {
         u32 off = 0;
-        if (!log) { set_err(st, ZE_CORRUPT); blk[i].err = ZE_CORRUPT; }
+        if (!log) { set_err(st, ZE_CORRUPT); if (!local_dst) blk[i].err = ZE_CORRUPT; }
+        else if (local_dst) { if (log > HUF_FULL_LOG) huf_build_compact(S.tab, S.w, nw, log, S.ws); }
         else {
             const u32 bytes = huf_tab_bytes(log);
             off = atomicAdd(&st->huf_pool_used, bytes);
@@ -448,7 +458,8 @@ __device__ void build_huf_one_lds(const u8 *src, ZBlock *blk, u32 i, u8 *pool, u
         __syncthreads();
     }
     const u32 bytes = huf_tab_bytes(log);
-    for (u32 k = lane; k < bytes / 16; k += 64) ((uint4 *)(pool + S.off))[k] = ((const uint4 *)S.tab)[k];
+    uint4 *dst = local_dst ? (uint4 *)local_dst : (uint4 *)(pool + S.off);
+    for (u32 k = lane; k < bytes / 16; k += 64) dst[k] = ((const uint4 *)S.tab)[k];
 }
 __global__ __launch_bounds__(64) void k_build_huf_lds(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const i32 *own_huf)
 {
@@ -457,6 +468,24 @@ __global__ __launch_bounds__(64) void k_build_huf_lds(const u8 *src, ZBlock *blk
     if (i >= nblk) return;
     if (blk[i].btype != BT_COMP || blk[i].lit_type != LIT_HUF || blk[i].err || own_huf[i] != (i32)i) return;
     build_huf_one_lds(src, blk, i, pool, pool_cap, st, S);
+}
+// The frame's flat 4-bit tree, looked for among the first FIND_MAIN_TREES trees the frame defines (a genome's sequence stream carries
+// it from the start or not at all): one wavefront builds them one after the other until one is flat with sixteen 4-bit codes.  (The sixteen pair codes of packed bases reach up to symbol 0x88: more than the 128 weights a direct
+// description holds, so the description is FSE-coded and has to be decoded to be recognised.)  Nothing happens in a frame of at most
+// HUF_FEW distinct trees (k_build_huf_few builds all of those).
+#define FIND_MAIN_TREES 8u
+__global__ __launch_bounds__(64) void k_flat_find_main(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, const i32 *own_huf)
+{
+    __shared__ HufLdsWS S;
+    if (st->n_huf_distinct <= HUF_FEW) return;
+    u32 tried = 0;
+    for (u32 i = 0; i < nblk && tried < FIND_MAIN_TREES; i++) {                 // (uniform: every lane walks the same blocks)
+        if (own_huf[i] != (i32)i || blk[i].btype != BT_COMP || blk[i].lit_type != LIT_HUF || blk[i].err) continue;
+        build_huf_one_lds(src, blk, i, pool, pool_cap, st, S);                   // table, huf_flat, flat_main_inv (a wavefront per tree, in LDS)
+        __syncthreads();
+        tried++;
+        if (blk[i].huf_flat && blk[i].huf_log == 4) return;
+    }
 }
 // A frame of many blocks and few distinct trees: every workgroup looks through its share of the blocks, 64 at a time, and builds the
 // few owners it finds.  Does nothing when the frame has more than HUF_FEW distinct trees (k_build_huf has it then).
@@ -973,9 +1002,13 @@ __device__ __forceinline__ u32 wave_excl_sum(u32 v, u32 *total);
 // downwards a word at a time, two words ahead), output by the lane itself, 8 symbols per store, into its place of the block's
 // literals.  sel / flat_on as in k_huf_literals.
 __global__ __launch_bounds__(64) void k_huf_par(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf, const u8 *pool, u32 slot_bytes,
-                                                 u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first, u32 plog, const u8 *sel, u32 flat_on, u32 margin_env)
+                                                 u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first, u32 plog, const u8 *sel, u32 flat_on, u32 margin_env, u32 build)
 {
+    // build: the trees of the blocks decoded here may have no table yet (huf_log == 0: the caller of a mostly-flat frame left them out,
+    // k_build_huf phase 2) -- the workgroup builds them itself, in LDS, from their descriptions (slot_bytes is HUF_TAB_MAX then)
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
+    __shared__ HufLdsWS S;
+    __shared__ u32 s_log[16];
     const u32 lane = threadIdx.x, P = 1u << plog;
     const u64 g = (u64)blockIdx.x * 64 + lane;
     const u32 k = (u32)g & (P - 1), s = (u32)(g >> plog) & 3;
@@ -996,6 +1029,13 @@ __global__ __launch_bounds__(64) void k_huf_par(const u8 *src, const ZBlock *blk
         if (!((wanted >> (j << (plog + 2))) & 1)) continue;            // (first lane of block j)
         const i32 oj = own_huf[bj];
         if (oj < 0) continue;
+        if (build && blk[oj].huf_log == 0) {                              // (uniform: the whole workgroup builds)
+            build_huf_one_lds(src, (ZBlock *)blk, (u32)oj, nullptr, 0u, st, S, lds + j * slot_bytes);
+            __syncthreads();
+            if (lane == 0) s_log[j] = S.log;
+            continue;
+        }
+        if (lane == 0) s_log[j] = blk[oj].huf_log;
         const u32 bytes = huf_tab_bytes(blk[oj].huf_log);
         const uint4 *gt = (const uint4 *)(pool + blk[oj].huf_tab);
         uint4 *lt = (uint4 *)(lds + j * slot_bytes);
@@ -1009,8 +1049,8 @@ __global__ __launch_bounds__(64) void k_huf_par(const u8 *src, const ZBlock *blk
     if (want) {
         const ZBlock &b = blk[bi];
         if (ob < 0) { if (s == 0 && k == 0) err = ZE_CORRUPT; }        // treeless without a previous table
+        else if ((log = s_log[slot_i]) == 0) { if (s == 0 && k == 0) err = ZE_CORRUPT; }   // its tree description is corrupt
         else {
-            log = blk[ob].huf_log;
             const u8 *c = src + b.src_off + b.huf_streams_off;
             u8 *o = (b.nseq == 0 ? dst : lit_scratch) + b.out_off;
             const u32 regen = b.lit_regen;
@@ -1192,18 +1232,21 @@ __global__ void k_flat_streams(const u8 *src, const ZBlock *blk, u32 nblk, const
 // ---- a frame that is MOSTLY flat (ctx.h: ZFlat, `cls`) --------------------------------------------------------------------------------
 // The flat tree of the frame is the one of its first block that defines a flat 4-bit tree (`main`).  A defining block carries the same
 // tree when its description repeats main's byte for byte (huf_flat = 2).
-__global__ void k_flat_mark_owner(const u8 *src, ZBlock *blk, u32 nblk, const i32 *own_huf, u32 main)
+// by_bytes: the other trees have no tables yet (k_build_huf phase 2 comes later): a repetition of main's description takes main's table
+__global__ void k_flat_mark_owner(const u8 *src, ZBlock *blk, u32 nblk, const i32 *own_huf, u32 main, u32 by_bytes)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblk || own_huf[i] != (i32)i) return;
     ZBlock &b = blk[i];
-    if (b.btype != BT_COMP || b.lit_type != LIT_HUF || b.err || !b.huf_flat || b.huf_log != 4) return;
+    if (b.btype != BT_COMP || b.lit_type != LIT_HUF || b.err) return;
+    if (!by_bytes && (!b.huf_flat || b.huf_log != 4)) return;
     const ZBlock &m = blk[main];
     const u32 n = b.huf_streams_off - b.lit_off;
     if (m.huf_streams_off - m.lit_off != n) return;
     const u8 *p = src + m.src_off + m.lit_off, *q = src + b.src_off + b.lit_off;
     for (u32 k = 0; k < n; k++) if (p[k] != q[k]) return;
     b.huf_flat = 2;
+    if (by_bytes) { b.huf_log = 4; b.huf_tab = m.huf_tab; }
 }
 // code -> symbol of the main tree: from its table when one was built, else from its directly stored weights (code k is the k-th
 // symbol of weight 1 in symbol order, the last one implied -- as in k_flat_literals).  One workgroup of 256.
@@ -1897,7 +1940,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     // come back in ONE read-back.  A frame that does have sequences then takes the long way from here (its tables are kept).
     const char *smin = getenv("NAF_GPU_SPEC_MIN");                      // tests: frames of a few dozen blocks through the paths of the big ones
     const bool spec = nblk > (smin ? (u32)atoi(smin) : 512u) && !fuse;
-    u64 *r4 = nullptr, *ends = nullptr; u8 *huf_pool = nullptr; u32 pool_cap = 0; bool tables_built = false; bool ranged_build = false;
+    u64 *r4 = nullptr, *ends = nullptr; u8 *huf_pool = nullptr; u32 pool_cap = 0; bool tables_built = false; bool ranged_build = false; bool two_phase = false;
     u64 h4[5] = { 0, 0, 0, 0, 0 }, hends[ZSPLIT_MAX] = { 0 };
     if (spec) {
         if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
@@ -1917,7 +1960,10 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             LAUNCH(c, "zstd_build_huf", k_build_huf_lds, nblk, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const i32 *)own_huf);
         } else {
             LAUNCH(c, "zstd_build_huf", k_build_huf_few, 1024, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, (const u64 *)r4, (const i32 *)own_huf);
-            LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)r4, always_table, (const i32 *)own_huf, 1u);
+            // (a caller that can read flat blocks in place gets the flat trees recognised now and the other tables later: see phase 2 below)
+            two_phase = c->zflat && !rg && !always_table;
+            if (two_phase) LAUNCH(c, "zstd_build_huf", k_flat_find_main, 1, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, (const i32 *)own_huf);
+            else LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)r4, always_table, (const i32 *)own_huf, 1u, 0u);
         }
         ZSplit *sp = c->zsplit;
         if (sp && !rg && sp->parts >= 2) {
@@ -1983,7 +2029,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             if (!si || !d_sym || !cls0 || !cls || !d_nx) return NAF_GPU_ENOMEM;
             HIP_TRY(c, hipMemsetAsync(d_nx, 0, 8, c->stream));
             LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr);
-            LAUNCH(c, "zstd_flat_class", k_flat_mark_owner, g, 64, 0, d_src, blk, nblk, (const i32 *)own_huf, main);
+            LAUNCH(c, "zstd_flat_class", k_flat_mark_owner, g, 64, 0, d_src, blk, nblk, (const i32 *)own_huf, main, two_phase ? 1u : 0u);
             LAUNCH(c, "zstd_flat_class", k_flat_sym, 1, 256, 0, d_src, (const ZBlock *)blk, main, (const u8 *)huf_pool, d_sym);
             LAUNCH(c, "zstd_flat_class", k_flat_class, g, 64, 0, (const ZBlock *)blk, nblk, (const i32 *)own_huf, cls0, d_nx + 1);
             LAUNCH(c, "zstd_flat_class", k_flat_class2, g, 64, 0, (const u8 *)cls0, nblk, cls, d_nx);
@@ -1993,27 +2039,42 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             if (getenv("NAF_GPU_DEBUG_FLAT")) fprintf(stderr, "[flat mixed] nblk %u decoded %u main %u\n", nblk, n_dec, main);
             if ((u64)n_dec * 2 <= nblk) {
                 LAUNCH(c, "zstd_flat_streams", k_flat_streams_mixed, cdiv(4ull * nblk, 256), 256, 0, d_src, (const ZBlock *)blk, nblk, (const u8 *)cls, si, st, (const u64 *)d_total_out);
-                zf->decoded_ev = nullptr;
+                zf->decoded_ev = nullptr; zf->later = nullptr;
                 if (n_dec) {
-                    // on the caller's spare stream when there is one: the emit of the flat tiles needs none of this
-                    naf_gpu_ctx *mc = c;
-                    if (zf->aux) {
-                        HIP_TRY(c, hipEventRecord(c->split_ev[0], c->stream));
-                        HIP_TRY(c, hipStreamWaitEvent(zf->aux->stream, c->split_ev[0], 0));
-                        c = zf->aux;
-                    }
-                    if (hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, d_dst, (u8 *)nullptr, 0u, (const u8 *)cls);
-                    LAUNCH(c, "zstd_flat_literals", k_flat_literals, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, (u8 *)nullptr, st, 0u, (const u8 *)cls);
-                    if (hs.n_flat < hs.n_huf_built) {
-                        const u32 slot = huf_slot_bytes(hs.max_huf_log), ipitch = hs.max_huf_log > 7 ? HUF_IROW_BIG : HUF_IROW;
-                        EmitP ep; memset(&ep, 0, sizeof ep);
-                        const u32 plog = huf_par_plog(hs.max_lit_regen, n_walk);
-                        if (plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)nblk << (plog + 2), 64), 64, (plog >= 4 ? 1u : 16u >> plog) * slot,
-                               d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, (u8 *)nullptr, st, 0u, plog, (const u8 *)cls, 1u, huf_par_margin_env());
-                        else LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(nblk, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512,
-                               d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, (u8 *)nullptr, st, 0u, ep, (u8 *)nullptr, ipitch, (u64)src_len, 1u, (const u8 *)cls);
-                    }
-                    if (c != mc) { HIP_TRY(mc, hipEventRecord(mc->split_ev[1], c->stream)); zf->decoded_ev = mc->split_ev[1]; c = mc; }
+                    // The decode of those blocks -- with the tables still to be built for them -- is handed back to the caller as a job: it
+                    // runs once the caller has queued its tile index, on the caller's spare stream when there is one, beside the emit of
+                    // the flat tiles, which needs none of it (zstd_flat_later).
+                    const bool pending = two_phase && hs.n_huf_distinct > HUF_FEW;
+                    const ZStat hs0 = hs; naf_gpu_ctx *mc = c; naf_gpu_ctx *aux = zf->aux;
+                    const u64 src_len64 = (u64)src_len;
+                    zf->later = new std::function<int()>([=]() -> int {
+                        naf_gpu_ctx *c = aux ? aux : mc;
+                        if (c != mc) HIP_TRY(mc, hipStreamWaitEvent(c->stream, mc->split_ev[0], 0));      // recorded by the caller behind its tile index
+                        const u32 plog = n_walk ? huf_par_plog(hs0.max_lit_regen, n_walk) : 0u;
+                        u32 max_log = hs0.max_huf_log;
+                        if (pending && n_walk && !plog) {
+                            // the one-lane-per-stream kernel takes its tables from the pool: the trees left out so far, now
+                            LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)nullptr, 0u, (const i32 *)own_huf, 1u, 2u);
+                            ZStat h2; int r2 = ctx_readback(c, &h2, st, sizeof h2);
+                            if (r2) { if (c != mc) memcpy(mc->err, c->err, sizeof mc->err); return r2; }
+                            if (h2.err) return zerr(mc, h2.err, "Huffman tables");
+                            max_log = h2.max_huf_log;
+                        }
+                        if (hs0.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, d_dst, (u8 *)nullptr, 0u, (const u8 *)cls);
+                        LAUNCH(c, "zstd_flat_literals", k_flat_literals, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, (u8 *)nullptr, st, 0u, (const u8 *)cls);
+                        if (n_walk && plog) {
+                            // (k_huf_par builds the tables it lacks itself, a workgroup at a time, in LDS)
+                            const u32 slot = pending ? (u32)HUF_TAB_MAX : huf_slot_bytes(max_log);
+                            LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)nblk << (plog + 2), 64), 64, (plog >= 4 ? 1u : 16u >> plog) * slot,
+                                   d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, (u8 *)nullptr, st, 0u, plog, (const u8 *)cls, 1u, huf_par_margin_env(), pending ? 1u : 0u);
+                        } else if (n_walk) {
+                            const u32 slot = huf_slot_bytes(max_log), ipitch = max_log > 7 ? HUF_IROW_BIG : HUF_IROW;
+                            EmitP ep; memset(&ep, 0, sizeof ep);
+                            LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(nblk, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512,
+                                   d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, (u8 *)nullptr, st, 0u, ep, (u8 *)nullptr, ipitch, src_len64, 1u, (const u8 *)cls);
+                        }
+                        return 0;
+                    });
                 }
                 zf->src = d_src; zf->si = si; zf->nslots = 4ull * nblk; zf->sym = d_sym; zf->status = st; zf->ready = true;
                 zf->tail = nullptr; zf->tail_q = hs.total_out; zf->tail_n = 0; zf->cls = cls; zf->n_decoded = n_dec;
@@ -2022,6 +2083,12 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                 return 0;
             }
         }
+    }
+    if (two_phase && hs.n_huf_distinct > HUF_FEW) {
+        // not a frame for the in-place emit after all: the tables phase 1 left out, now
+        LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)nullptr, 0u, (const i32 *)own_huf, 1u, 2u);
+        rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+        if (hs.err) return zerr(c, hs.err, "Huffman tables");
     }
     u64 *d_total_seq = (u64 *)((u8 *)st + offsetof(ZStat, total_seq));
     FseE *fse_pool = nullptr; u32 *o_ll = nullptr, *o_ml = nullptr, *o_of = nullptr;
@@ -2125,7 +2192,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             huf_pool = (u8 *)arena_alloc(c, pool_cap);
             if (!huf_pool) return NAF_GPU_ENOMEM;
             if (hb_n && hb_n <= 512) LAUNCH(c, "zstd_build_huf", k_build_huf_lds, hb_n, 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first, (const i32 *)own_huf);
-            else if (hb_n) LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(hb_n, 64), 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first, (const u64 *)nullptr, (always_table || fuse) ? 1u : 0u, (const i32 *)own_huf, 0u);
+            else if (hb_n) LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(hb_n, 64), 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first, (const u64 *)nullptr, (always_table || fuse) ? 1u : 0u, (const i32 *)own_huf, 0u, 0u);
             rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
             if (hs.err) return zerr(c, hs.err, "Huffman tables");
         }
@@ -2167,7 +2234,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     u32 hi_b = k + 1 == sp->parts ? b_count : (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
                     if (hi_b > lo_b && flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, hi_b - lo_b, 256, 0, d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, lo_b, (const u8 *)nullptr);
                     if (hi_b > lo_b && serial_needed && plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)(hi_b - lo_b) << (plog + 2), 64), 64, par_lds,
-                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env());
+                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(), 0u);
                     else if (hi_b > lo_b && serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds,
                            d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr);
                     HIP_TRY(c, hipEventRecord(sp->ev[k], c->stream));
@@ -2177,7 +2244,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             } else {
                 if (flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, b_count, 256, 0, d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, b_first, (const u8 *)nullptr);
                 if (serial_needed && plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)b_count << (plog + 2), 64), 64, par_lds,
-                   d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env());
+                   d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(), 0u);
                 else if (serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, huf_lds,
                    d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr);
             }
@@ -2199,6 +2266,17 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     if (hs.err) return zerr(c, hs.err, "block decode");
     return 0;
 }
+
+// the job a mostly-flat frame's decoder left for after the caller's tile index (ctx.h: ZFlat.later); aux_used: the job went to the spare stream
+int zstd_flat_later(naf_gpu_ctx *c, ZFlat *zf)
+{
+    if (!zf || !zf->later) return 0;
+    std::function<int()> *f = (std::function<int()> *)zf->later; zf->later = nullptr;
+    const int rc = (*f)();
+    delete f;
+    return rc;
+}
+void zstd_flat_drop(ZFlat *zf) { if (zf && zf->later) { delete (std::function<int()> *)zf->later; zf->later = nullptr; } }
 
 // status of a split decode whose final read-back was left to the caller
 int zstd_split_status(naf_gpu_ctx *c, const ZSplit *sp)

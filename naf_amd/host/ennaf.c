@@ -381,9 +381,47 @@ int main(int argc, char **argv)
         chunked = encode_chunked(IN, (size_t)in_at, in_left, &o, &R, &naf_len);
         if (chunked) phase("ennaf in chunks");
     }
+    /* ---- a pipe (process.c:143-150 reads one 16 KiB at a time and never knows how much is coming): chunks of it go through two pinned
+     * buffers straight into a device buffer of PIPE_LIMIT bytes while the next chunk is being read; an input that ends inside it is
+     * encoded from there.  One that does not is spilled -- what has arrived, then the rest -- into a temporary file ($TMPDIR, like
+     * the reference's per-stream temporary files, ennaf.c:478-505), which then takes the path of a regular file of any size. */
+    void *d_piped = NULL; size_t n_piped = 0; FILE *spill = NULL;
+    if (!sharded && !chunked && in_left == 0 && !fd_is_regular(fileno(IN))) {
+        io_open();
+        const char *pe = getenv("NAF_GPU_PIPE_BYTES");
+        size_t limit = pe ? (size_t)strtoull(pe, NULL, 10) : ((size_t)8 << 30);
+        { size_t fr = 0, tot = 0; GPU_TRY(naf_gpu_mem_info(gpu, &fr, &tot)); if (limit > fr / 6) limit = fr / 6; if (limit < 4096) limit = 4096; }
+        GPU_TRY(naf_gpu_malloc(gpu, limit + 64, &d_piped));
+        int cur = 0; bool eof = false, busy[2] = { false, false };
+        while (!eof && n_piped < limit) {
+            size_t want = limit - n_piped < IO_CHUNK ? limit - n_piped : IO_CHUNK, got = 0;
+            if (busy[cur]) { GPU_TRY(naf_gpu_synchronize(gpu)); busy[0] = busy[1] = false; }      /* the upload that last read this buffer */
+            while (got < want) { size_t r = fread((char *)io_pin[cur] + got, 1, want - got, IN); if (!r) { eof = true; break; } got += r; }
+            if (got) { GPU_TRY(naf_gpu_upload(gpu, (char *)d_piped + n_piped, io_pin[cur], got)); busy[cur] = true; n_piped += got; cur ^= 1; }
+        }
+        GPU_TRY(naf_gpu_synchronize(gpu));
+        if (!eof) { int c1 = fgetc(IN); if (c1 == EOF) eof = true; else ungetc(c1, IN); }
+        if (!eof) {
+            const char *td = getenv("TMPDIR"); char path[4096];
+            snprintf(path, sizeof path, "%s/ennaf-gpu-in-XXXXXX", (td && *td) ? td : "/tmp");
+            int tfd = mkstemp(path); if (tfd < 0) die("can't create temporary file\n");
+            unlink(path); spill = fdopen(tfd, "w+b"); if (!spill) die("can't create temporary file\n");
+            write_from_device(spill, d_piped, n_piped);
+            GPU_TRY(naf_gpu_free(gpu, d_piped)); d_piped = NULL;
+            size_t total = n_piped, r;
+            while ((r = fread(io_pin[0], 1, IO_CHUNK, IN)) > 0) { if (fwrite(io_pin[0], 1, r, spill) != r) die("can't write to temporary file - disk full?\n"); total += r; }
+            if (fflush(spill) != 0) die("can't write to temporary file - disk full?\n");
+            rewind(spill);
+            if (IN != stdin) fclose(IN);
+            IN = spill; in_at = 0; in_left = total;
+            phase("pipe spilled to a temporary file");
+            chunked = encode_chunked(IN, 0, in_left, &o, &R, &naf_len);
+            if (chunked) phase("ennaf in chunks");
+        } else phase("pipe read + upload");
+    }
     if (!sharded && !chunked) {
-        size_t n = 0; unsigned char *text = NULL;
-        void *d_text = read_to_device(IN, &n);                 /* regular file: straight to HBM through the pinned lanes */
+        size_t n = n_piped; unsigned char *text = NULL;
+        void *d_text = d_piped ? d_piped : read_to_device(IN, &n);                 /* regular file: straight to HBM through the pinned lanes */
         if (!d_text) text = read_all(IN, &n);
         phase("read + upload");
         gpu_open();
@@ -439,5 +477,8 @@ int main(int argc, char **argv)
     }
     if (verbose) msg("Processed %llu sequences\n", (unsigned long long)R.n_sequences);
     success = true;
+    /* everything is written and closed: the process ends here, without the device-side teardown (freeing gigabytes of device memory,
+     * streams, the runtime's own exit handlers: 0.1 - 0.2 s that nobody waits for; NAF_GPU_SLOW_EXIT=1 runs it) */
+    { const char *se = getenv("NAF_GPU_SLOW_EXIT"); if (!(se && se[0] == '1')) { fflush(NULL); _exit(0); } }
     return 0;
 }

@@ -308,5 +308,8 @@ int main(int argc, char **argv)
     }
     if (OUT != stdout) { if (fclose(OUT) != 0) die("can't close file - disk full?\n"); } else fflush(stdout);
     success = true;
+    /* everything is written and closed: the process ends here, without the device-side teardown (freeing gigabytes of device memory,
+     * streams, the runtime's own exit handlers: 0.1 - 0.2 s that nobody waits for; NAF_GPU_SLOW_EXIT=1 runs it) */
+    { const char *se = getenv("NAF_GPU_SLOW_EXIT"); if (!(se && se[0] == '1')) { fflush(NULL); _exit(0); } }
     return 0;
 }

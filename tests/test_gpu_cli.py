@@ -213,3 +213,38 @@ def test_appending_to_a_file_keeps_the_order(tmp_path):
         assert got[:4] == b"JUNK"
         u = subprocess.run([os.path.join(BIN, "unnaf"), "-c"], input=got[4:], stdout=subprocess.PIPE, timeout=120)
         assert u.returncode == 0 and u.stdout == text
+
+
+def test_ennaf_from_a_pipe_of_any_size(oracle, tmp_path):
+    """process.c:143-150 reads its input 16 KiB at a time and never holds it; here a pipe streams through two pinned buffers into
+    the device, and one that outgrows the device buffer (NAF_GPU_PIPE_BYTES, forced small) is spilled to a temporary file and
+    encoded chunk by chunk (NAF_GPU_CHUNK_BYTES).  Same six streams as the archive of the file, both unnafs decode it."""
+    from naf_amd import synth
+    rng = np.random.default_rng(13)
+    fasta = synth.fasta_mixed(30, 50000, 70, 9) + b">tail\n" + bytes(rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), 200001)) + b"\n"
+    fastq = synth.fastq_reads(20000, 150, seed=3)
+    for name, text in (("fa", fasta), ("fq", fastq)):
+        src = tmp_path / (name + ".txt"); src.write_bytes(text)
+        whole = subprocess.run([os.path.join(BIN, "ennaf"), str(src), "-c"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert whole.returncode == 0, whole.stderr
+        hw = oracle.parse_naf(whole.stdout)
+        want = oracle.unnaf(whole.stdout, -1)
+        for env in ({}, {"NAF_GPU_PIPE_BYTES": "300000"}, {"NAF_GPU_PIPE_BYTES": "1000003", "NAF_GPU_CHUNK_BYTES": "700000"}):
+            with open(src, "rb") as f:
+                cat = subprocess.Popen(["cat"], stdin=f, stdout=subprocess.PIPE)
+                e = subprocess.run([os.path.join(BIN, "ennaf"), "-c"] + (["--fastq"] if name == "fq" else []), stdin=cat.stdout, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120,
+                                   env=dict(os.environ, NAF_GPU_CLI_TIMING="1", **env))
+                cat.wait()
+            assert e.returncode == 0, e.stderr
+            assert (b"pipe spilled" in e.stderr) == bool(env), e.stderr
+            naf = e.stdout
+            h = oracle.parse_naf(naf)
+            for i in range(6):
+                if hw.payload_off[i] is None:
+                    assert h.payload_off[i] is None
+                    continue
+                assert oracle.zstd_decompress(h.frame(naf, i), hw.orig[i] + 64) == oracle.zstd_decompress(hw.frame(whole.stdout, i), hw.orig[i] + 64), (name, env, i)
+            u = subprocess.run([os.path.join(BIN, "unnaf"), "-c"], input=naf, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            assert u.returncode == 0 and u.stdout == want
+            if oracle.have_ref():
+                assert oracle.ref_unnaf(naf) == want

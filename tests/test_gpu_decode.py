@@ -650,3 +650,30 @@ def test_offset_code_31_a_match_2_gib_back(gpu):
     assert host(out[len(a) + zeros:]) == lits + a[m.SRC:m.SRC + m.ML]
     del out, z
     torch.cuda.empty_cache()
+
+
+def test_mostly_flat_frame_at_scale_takes_the_two_phase_tables(gpu, monkeypatch, capfd):
+    """From 16 K blocks and 2 K distinct trees up the decoder finds the frame's flat tree among its first blocks, marks its repetitions
+    by their bytes and leaves the other trees' tables to a job that runs beside the emit of the flat tiles (zstd_dec.hip:
+    k_flat_find_main, k_build_huf phase 2, zstd_flat_later).  1.5 GB of the realistic genome: full-size round trip (the
+    size-independent property), the path taken, and the decode-everything path on the same archive."""
+    import re
+    import torch
+    from naf_amd import synth
+    t = synth.realistic_genome_device(int(1.5e9), device="cuda")
+    d_naf, rep = gpu.ennaf(t)
+    capfd.readouterr()
+    monkeypatch.setenv("NAF_GPU_DEBUG_FLAT", "1")
+    out = gpu.unnaf(d_naf, 0)
+    torch.cuda.synchronize()
+    err = capfd.readouterr().err
+    monkeypatch.delenv("NAF_GPU_DEBUG_FLAT")
+    assert torch.equal(out, t)
+    m = re.search(r"\[flat mixed\] nblk (\d+) decoded (\d+)", err)
+    assert m and int(m.group(1)) > 16384 and 0 < int(m.group(2)) * 2 <= int(m.group(1)), err
+    m2 = re.search(r"\[flat tiles\] total (\d+) rest (\d+) decoded (\d+)", err)
+    assert m2 and int(m2.group(2)) <= 256, err
+    del out
+    monkeypatch.setenv("NAF_GPU_FLAT_MIXED", "0")
+    assert torch.equal(gpu.unnaf(d_naf, 0), t)
+    monkeypatch.delenv("NAF_GPU_FLAT_MIXED")
