@@ -1655,7 +1655,11 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             // a mostly-flat frame: the blocks that are not flat are decoded now -- on the spare stream, beside the emit of the flat tiles
             naf_gpu_ctx *xc = c;                                                              // where the tiles over decoded blocks are emitted
             const bool flat_job = zflat.ready && zflat.later;
-            if (flat_job) HIP_TRY(c, hipEventRecord(c->split_ev[0], c->stream));              // the job's stream starts behind the tile index
+            // the spare stream starts behind the tile index: it takes the job (if any) and the tiles with headers / record ends, beside the bulk emit
+            if (zflat.ready && zflat.aux) {
+                HIP_TRY(c, hipEventRecord(c->split_ev[0], c->stream));
+                if (!flat_job) { HIP_TRY(c, hipStreamWaitEvent(zflat.aux->stream, c->split_ev[0], 0)); xc = zflat.aux; }
+            }
             u64 t_done = 0;
             if (split.done) {
                 HIP_TRY(c, hipEventRecord(c->split_ev[ZSPLIT_MAX], ic->stream));

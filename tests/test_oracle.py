@@ -243,3 +243,23 @@ def test_oracle_against_live_reference_fuzz(oracle):
             assert O.zstd_decompress(h.frame(naf, k)) == s
         if h.n_sequences and h.orig[O.SEQ] == sum(np.frombuffer(sp.lengths, dtype="<u4").astype(int)):
             assert O.ref_unnaf(naf, ("--fasta",)) == O.unnaf(naf, O.MODE_FASTA)
+
+
+def test_cfg1_ten_megabases_cpu_round_trip(oracle):
+    """BASELINE configs[0] / SURVEY 8(d) cfg1: one record `>seq1 synthetic random ACGT`, 10 000 000 uniform bases (PCG64 seed
+    12345), 80-column lines = 10 125 028 bytes; the reference's archive of it was measured at 2 500 852 bytes (2.0007 bit / base).
+    The CPU plumbing both ways: the restatement's archive decodes under the real reference, the reference's under the
+    restatement, and both decode their own."""
+    from naf_amd import synth
+    text = synth.fasta_acgt(10_000_000, 1, 80, seed=12345)
+    assert len(text) == 10_125_028 and text.startswith(b">seq1 synthetic random ACGT\n")
+    mine = oracle.ennaf(text)                                      # (the restatement stores raw blocks: its archive is the 4-bit stream, 5 MB)
+    assert oracle.unnaf(mine, 0) == text
+    h = oracle.parse_naf(mine)
+    assert h.orig[4] == 10_000_000 and h.n_sequences == 1 and h.line_length == 80
+    if oracle.have_ref():
+        ref = oracle.ref_ennaf(text)
+        assert abs(len(ref) - 2_500_852) <= 64, len(ref)           # libzstd's level-1 entropy coding of 16 equally likely pair codes
+        assert oracle.unnaf(ref, 0) == text
+        assert oracle.ref_unnaf(ref) == text
+        assert oracle.ref_unnaf(mine) == text

@@ -1,35 +1,39 @@
 #!/bin/bash
 # Produces the files under profiles/ for one round:  tools/profile_bench.sh r02   (run on the GPU box, from the repo root)
 #   <tag>_bench_line.json                     the JSON line of a plain `python bench.py`
-#   <tag>_bench_rocprofv3_kernel_stats.csv    rocprofv3 --kernel-trace --stats of `python bench.py --steps 3 --no-cpu --softmask-size 0`
+#   <tag>_bench_rocprofv3_kernel_stats.csv    rocprofv3 --kernel-trace --stats of `python bench.py --steps 3 --no-cpu --softmask-size 0 --realistic-size 0 --fastq1-size 0`
+#   <tag>_realistic_rocprofv3_kernel_stats.csv  the same of `tools/perf_side.py realistic` (mostly-flat frame: flat tiles in place, the other blocks decoded beside them)
 #   <tag>_pmc_fetch.csv / _pmc_write.csv      per-kernel FETCH_SIZE / WRITE_SIZE sums (separate --pmc passes, no tracing
 #                                             domains besides the kernel dispatch records), incl. the calibration kernel
 # Everything is written under gpurun_out/<tag>/ ; copy what should be judged into profiles/.
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 python bench.py > $out/${tag}_bench_line.json 2> $out/bench.err
 tail -c 400 $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 3 --no-cpu --softmask-size 0 > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 3 --no-cpu --softmask-size 0 --realistic-size 0 --fastq1-size 0 > $out/stats.log 2>&1
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/${tag}_bench_rocprofv3_kernel_stats.csv
 # the two-pass decode (what archives that are not one flat tree take), every kernel alone on the device: no fused emit, no split
-NAF_GPU_FLAT_FUSE=0 NAF_GPU_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats2 -- python bench.py --steps 3 --no-cpu --softmask-size 0 > $out/stats2.log 2>&1
+NAF_GPU_FLAT_FUSE=0 NAF_GPU_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats2 -- python bench.py --steps 3 --no-cpu --softmask-size 0 --realistic-size 0 --fastq1-size 0 > $out/stats2.log 2>&1
 cp $(ls $out/stats2/*/*kernel_stats.csv | head -1) $out/${tag}_twopass_alone_rocprofv3_kernel_stats.csv
 # the serial Huffman kernel on the same data (NAF_GPU_FLAT=0), alone
-NAF_GPU_FLAT=0 NAF_GPU_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats3 -- python bench.py --steps 3 --no-cpu --softmask-size 0 > $out/stats3.log 2>&1
+NAF_GPU_FLAT=0 NAF_GPU_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats3 -- python bench.py --steps 3 --no-cpu --softmask-size 0 --realistic-size 0 --fastq1-size 0 > $out/stats3.log 2>&1
 cp $(ls $out/stats3/*/*kernel_stats.csv | head -1) $out/${tag}_serial_huffman_alone_rocprofv3_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats4 -- python tools/perf_side.py realistic 4e9 > $out/stats4.log 2>&1
+cp $(ls $out/stats4/*/*kernel_stats.csv | head -1) $out/${tag}_realistic_rocprofv3_kernel_stats.csv
 for ctr in FETCH_SIZE WRITE_SIZE; do
   printf 'pmc: %s\n' $ctr > $out/pmc_$ctr.txt
-  rocprofv3 -i $out/pmc_$ctr.txt --output-format csv -d $out/pmc_$ctr -- python bench.py --steps 1 --warmup 0 --no-cpu --softmask-size 0 > $out/pmc_$ctr.log 2>&1
+  rocprofv3 -i $out/pmc_$ctr.txt --output-format csv -d $out/pmc_$ctr -- python bench.py --steps 1 --warmup 0 --no-cpu --softmask-size 0 --realistic-size 0 --fastq1-size 0 > $out/pmc_$ctr.log 2>&1
   rocprofv3 -i $out/pmc_$ctr.txt --output-format csv -d $out/cal_$ctr -- tools/bw_calibrate > $out/cal_$ctr.log 2>&1
+  NAF_GPU_FLAT=0 NAF_GPU_HUF_PAR=0 rocprofv3 -i $out/pmc_$ctr.txt --output-format csv -d $out/pmcser_$ctr -- python bench.py --steps 1 --warmup 0 --no-cpu --softmask-size 0 --realistic-size 0 --fastq1-size 0 > $out/pmcser_$ctr.log 2>&1
 done
 python - "$out" "$tag" <<'PY'
 import csv, glob, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
 for ctr, name in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     rows = []
-    for d, label in ((f"{out}/pmc_{ctr}", "bench"), (f"{out}/cal_{ctr}", "calibration")):
+    for d, label in ((f"{out}/pmc_{ctr}", "bench"), (f"{out}/cal_{ctr}", "calibration"), (f"{out}/pmcser_{ctr}", "serial_huffman")):
         fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
         if not fs: continue
         agg = collections.OrderedDict()
@@ -63,8 +67,12 @@ k = {}
 fetch_factor = {"k_huf_literals": 1.742}
 for ctr, name in (("fetch", "fetch_bytes"), ("write", "write_bytes")):
     for r in csv.DictReader(open(f"{out}/{tag}_pmc_{ctr}.csv")):
-        if r["run"] != "bench": continue
         fn = r["kernel"].replace("void ", "").split("<")[0]
+        if r["run"] == "serial_huffman" and fn == "k_huf_literals":          # the serial kernel only runs when the flat paths are off: its row comes from that pass
+            scale = 1024 * (fetch_factor.get(fn, 2.0) if ctr == "fetch" else 1.0)
+            k.setdefault(names[fn], {"fetch_bytes": 0, "write_bytes": 0})[name] += float(r[list(r.keys())[-1]]) * scale / calls
+            continue
+        if r["run"] != "bench": continue
         if fn in names:
             scale = 1024 * (fetch_factor.get(fn, 2.0) if ctr == "fetch" else 1.0)
             k.setdefault(names[fn], {"fetch_bytes": 0, "write_bytes": 0})[name] += float(r[list(r.keys())[-1]]) * scale / calls
