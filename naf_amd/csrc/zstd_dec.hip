@@ -1002,7 +1002,7 @@ __device__ __forceinline__ u32 wave_excl_sum(u32 v, u32 *total);
 // downwards a word at a time, two words ahead), output by the lane itself, 8 symbols per store, into its place of the block's
 // literals.  sel / flat_on as in k_huf_literals.
 __global__ __launch_bounds__(64) void k_huf_par(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf, const u8 *pool, u32 slot_bytes,
-                                                 u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first, u32 plog, const u8 *sel, u32 flat_on, u32 margin_env, u32 build)
+                                                 u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first, u32 plog, const u8 *sel, u32 flat_on, u32 margin_env, u32 build, u64 src_len)
 {
     // build: the trees of the blocks decoded here may have no table yet (huf_log == 0: the caller of a mostly-flat frame left them out,
     // k_build_huf phase 2) -- the workgroup builds them itself, in LDS, from their descriptions (slot_bytes is HUF_TAB_MAX then)
@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(64) void k_huf_par(const u8 *src, const ZBlock *blk
         Bk = hufp_cut(E, P, k); Bk1 = hufp_cut(E, P, k + 1);
         const u32 M = margin_env ? margin_env : hufp_margin(E, n, log);
         i32 p = (k == 0 || (u64)Bk + M >= E) ? (i32)E : Bk + (i32)M;
-        HufWin r; hufw_init(r, sp, sz, p);
+        HufWin r; hufw_init(r, sp, sz, p, src, src + src_len);
         if (k) hufw_walk(r, p, Bk, tab, log);
         sk = p;
         ck = hufw_walk(r, p, Bk1, tab, log);
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(64) void k_huf_par(const u8 *src, const ZBlock *blk
         if (!__ballot(mis)) break;
         if (mis) {
             i32 p = prev; sk = p;
-            HufWin r; hufw_init(r, sp, sz, p);
+            HufWin r; hufw_init(r, sp, sz, p, src, src + src_len);
             ck = hufw_walk(r, p, Bk1, tab, log);
             ek = p;
         }
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(64) void k_huf_par(const u8 *src, const ZBlock *blk
     if (valid && bad) { if (k == 0) err = ZE_CORRUPT; valid = false; }
     if (valid && ck) {
         i32 p = sk;
-        HufWin r; hufw_init(r, sp, sz, p);
+        HufWin r; hufw_init(r, sp, sz, p, src, src + src_len);
         hufw_decode(r, p, tab, log, out + off, ck);
         if (p != ek) err = ZE_CORRUPT;
     }
@@ -1799,11 +1799,11 @@ int zstd_init_tables(naf_gpu_ctx *c)
 
 // Parts per stream for k_huf_par, a power of two up to 64 (returned as its logarithm; 0 = the one-lane-per-stream kernel).
 // Measured (tools/perf_huf.py, profiles/r03_huf_parts.txt): one lane per stream takes 0.95 ms for the 8 K symbols of a stream of this
-// build's 32 KiB blocks and 3.8 ms for the 32 K of libzstd's 128 KiB blocks however few streams there are, and moves 1 GB of symbols
-// per millisecond once the device is full; k_huf_par divides the chain by P but moves only a quarter of that (its lanes read and
-// write 8 bytes at a time, each in a sector of its own).  So parts are taken when the frame is short enough for the chain to be what
-// bounds the serial kernel -- less than 28 KB of literals per symbol of the longest stream -- with as many parts as leave a lane
-// NAF_GPU_HUF_PART symbols (default 128) and the device no more than a million lanes.
+// build's 32 KiB blocks and 3.6 - 5 ms for the 32 K of libzstd's 128 KiB blocks however few streams there are, and moves 1 GB of
+// symbols per millisecond once the device is full; k_huf_par divides the chain by P and moves half of that (every part is walked once to
+// be counted, then decoded).  So parts are taken where the chain is what bounds the serial kernel -- less than 84 KiB of literals
+// per symbol of the longest stream: 0.7 GB of this build's blocks, 2.8 GB of libzstd's -- with as many parts as leave a lane
+// NAF_GPU_HUF_PART symbols (default 128) and the device no more than a quarter of a million lanes.
 // NAF_GPU_HUF_PAR=0: never, =N: 2^N parts wherever the streams are long enough.
 static u32 huf_par_plog(u32 max_lit_regen, u64 n_blocks)
 {
@@ -1815,8 +1815,8 @@ static u32 huf_par_plog(u32 max_lit_regen, u64 n_blocks)
     u32 plog = 0;
     while (plog < 6 && (nmax >> (plog + 1)) >= target) plog++;
     if (e && e[0] >= '1' && e[0] <= '6') { const u32 f = (u32)(e[0] - '0'); return f < plog ? f : plog; }
-    if (n_blocks * (u64)max_lit_regen >= (u64)nmax * 28672) return 0;
-    while (plog && ((n_blocks * 4) << plog) > (1u << 20)) plog--;
+    if (n_blocks * (u64)max_lit_regen >= (u64)nmax * 86016) return 0;
+    while (plog && ((n_blocks * 4) << plog) > (1u << 18)) plog--;      // (the device holds 200 k of this kernel's lanes at a time: more parts only add margins)
     return plog;
 }
 static u32 huf_par_margin_env() { const char *m = getenv("NAF_GPU_HUF_MARGIN"); return m ? (u32)atoi(m) : 0u; }
@@ -2066,7 +2066,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                             // (k_huf_par builds the tables it lacks itself, a workgroup at a time, in LDS)
                             const u32 slot = pending ? (u32)HUF_TAB_MAX : huf_slot_bytes(max_log);
                             LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)nblk << (plog + 2), 64), 64, (plog >= 4 ? 1u : 16u >> plog) * slot,
-                                   d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, (u8 *)nullptr, st, 0u, plog, (const u8 *)cls, 1u, huf_par_margin_env(), pending ? 1u : 0u);
+                                   d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, (u8 *)nullptr, st, 0u, plog, (const u8 *)cls, 1u, huf_par_margin_env(), pending ? 1u : 0u, src_len64);
                         } else if (n_walk) {
                             const u32 slot = huf_slot_bytes(max_log), ipitch = max_log > 7 ? HUF_IROW_BIG : HUF_IROW;
                             EmitP ep; memset(&ep, 0, sizeof ep);
@@ -2234,7 +2234,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     u32 hi_b = k + 1 == sp->parts ? b_count : (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
                     if (hi_b > lo_b && flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, hi_b - lo_b, 256, 0, d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, lo_b, (const u8 *)nullptr);
                     if (hi_b > lo_b && serial_needed && plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)(hi_b - lo_b) << (plog + 2), 64), 64, par_lds,
-                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(), 0u);
+                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(), 0u, (u64)src_len);
                     else if (hi_b > lo_b && serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds,
                            d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr);
                     HIP_TRY(c, hipEventRecord(sp->ev[k], c->stream));
@@ -2244,7 +2244,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             } else {
                 if (flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, b_count, 256, 0, d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, b_first, (const u8 *)nullptr);
                 if (serial_needed && plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)b_count << (plog + 2), 64), 64, par_lds,
-                   d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(), 0u);
+                   d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(), 0u, (u64)src_len);
                 else if (serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, huf_lds,
                    d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr);
             }

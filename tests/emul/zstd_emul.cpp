@@ -200,10 +200,12 @@ extern "C" int emul_window_reader(const u8 *stream, u32 size, const u8 *weights,
 // *rounds_out = rounds of re-walking it took (0: every part fell into step inside its margin).  margin = 0: the kernel's own choice.
 extern "C" int emul_huf_parts(const u8 *stream, u32 size, const u8 *weights, u32 nw, u32 log, u32 n, u32 P, u32 margin, u64 align_off, u32 *rounds_out)
 {
+    const bool tight = (align_off >> 32) != 0; align_off &= 0xFFFFFFFFull;   // tight: the stream IS the readable buffer (sector loads at both ends fall back to bytes)
     std::vector<u8> hay(size + 1024 + 256);
     u8 *base = hay.data() + 256 + align_off;
     memset(hay.data(), 0xAA, hay.size());                          // whatever lies around the stream must not matter
     memcpy(base, stream, size);
+    const u8 *lo_ok = tight ? base : hay.data(), *hi_ok = tight ? base + size : hay.data() + hay.size();
     std::vector<u16> tabv(huf_tab_bytes(log) / 2); huf_build_any(tabv.data(), weights, nw, log); const u16 *tab = tabv.data();
     std::vector<u8> ref(n + 64), out(n + 64, 0x55);
     if (huf_decode_stream(base, size, tab, log, ref.data(), n)) return -1;
@@ -214,7 +216,7 @@ extern "C" int emul_huf_parts(const u8 *stream, u32 size, const u8 *weights, u32
     for (u32 k = 0; k < P; k++) {
         const i32 Bk = hufp_cut(E, P, k), Bk1 = hufp_cut(E, P, k + 1);
         i32 p = k == 0 ? (i32)E : ((u64)Bk + M < E ? Bk + (i32)M : (i32)E);
-        HufWin r; hufw_init(r, base, size, p);
+        HufWin r; hufw_init(r, base, size, p, lo_ok, hi_ok);
         if (k) hufw_walk(r, p, Bk, tab, log);
         s[k] = p;
         c[k] = hufw_walk(r, p, Bk1, tab, log);
@@ -228,7 +230,7 @@ extern "C" int emul_huf_parts(const u8 *stream, u32 size, const u8 *weights, u32
         if (++rounds > 64) return -3;
         for (u32 k = 0; k < P; k++) if (mis[k]) {
             i32 p = ns[k]; s[k] = p;
-            HufWin r; hufw_init(r, base, size, p);
+            HufWin r; hufw_init(r, base, size, p, lo_ok, hi_ok);
             c[k] = hufw_walk(r, p, hufp_cut(E, P, k + 1), tab, log);
             e[k] = p;
         }
@@ -238,7 +240,7 @@ extern "C" int emul_huf_parts(const u8 *stream, u32 size, const u8 *weights, u32
     if (tot != n || e[P - 1] != 0) return -4;
     u32 off = 0;
     for (u32 k = 0; k < P; k++) {
-        i32 p = s[k]; HufWin r; hufw_init(r, base, size, p);
+        i32 p = s[k]; HufWin r; hufw_init(r, base, size, p, lo_ok, hi_ok);
         hufw_decode(r, p, tab, log, out.data() + off, c[k]);
         if (p != e[k]) return -5;
         off += c[k];

@@ -251,7 +251,7 @@ def test_huffman_stream_decoded_in_parts(emul):
         for n in (len(d), 6009, 999, 257, 40, 3):
             for P in (1, 2, 4, 16, 64):
                 for margin in (0, 256, 64, 8):
-                    for align in (0, 3):
+                    for align in (0, 3, 61, (1 << 32) | 5):        # (bit 32: the stream is all of the readable buffer)
                         r = emul.emul_parts_roundtrip(d[:n], n, P, margin, align, ctypes.byref(rounds))
                         assert r in (0, -10), (len(set(d)), n, P, margin, align, r)             # -10: a single distinct symbol has no Huffman stream
                         saw_rounds += rounds.value
