@@ -425,6 +425,20 @@ def main():
             shard.gather_ranges(buf[: e - b], total_text, dst=0, out=out)
         torch.cuda.synchronize(); dist.barrier()
         tg = time.perf_counter() - t0
+        # "gather to host" (north_star) without the hop through one GPU: every rank copies its range into its own pinned host buffer
+        # (per-GPU D2H, what the C hosts do with NAF_GPUS); step = range decode + the copy, max over ranks
+        hbuf = torch.empty(e - b, dtype=torch.uint8).pin_memory()
+        hbuf.copy_(buf[: e - b], non_blocking=True); torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.unnaf_range(d_naf, b, e, capi.OUT_FASTA, out=buf)
+            hbuf.copy_(buf[: e - b], non_blocking=True)
+        torch.cuda.synchronize()
+        th = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        extra["to_host_ms"] = round(float(th.item()) / args.steps * 1e3, 3)
+        extra["to_host_value"] = round(float(total_text) * args.steps / float(th.item()) / 1e9, 3)
+        del hbuf
         extra["range_decode_ms"] = round(float(td.item()) / args.steps * 1e3, 3)
         extra["gather_ms"] = round(tg / args.steps * 1e3, 3)
         extra["decode_only_value"] = round(float(total_text) * args.steps / float(td.item()) / 1e9, 3)

@@ -26,17 +26,112 @@ struct ZPlanWS {
     FseWS fse; u32 log, tb;
 };
 
+// Tree description of the flat tree of the sixteen pair codes (weight 1 for each byte whose two nibbles are single bits): the same for
+// every block k_zenc_flat_scan settles, made once on the host with the kernels' own tree writer.
+struct ZFlat16 { u32 tb; u8 tree[ZENC_TREE_SLOT]; };
+static const ZFlat16 &zenc_flat16()
+{
+    static const ZFlat16 T = [] {
+        ZFlat16 t; memset(&t, 0, sizeof t);
+        u8 wt[256]; memset(wt, 0, sizeof wt);
+        for (u32 s = 0; s < 256; s++) if (__builtin_popcount(s & 15u) == 1 && __builtin_popcount(s >> 4) == 1) wt[s] = 1;
+        static FseWS ws; u8 tmp[160];
+        t.tb = huf_write_tree_w(t.tree, wt, 0x88u, tmp, ws, true);       // weights of symbols 0 .. 0x87; that of 0x88, the last, is implied
+        return t;
+    }();
+    return T;
+}
 // even split of n bytes into nblk blocks: block b starts at b*(n/nblk) + min(b, n%nblk)
 __host__ __device__ static inline u64 zenc_block_lo(u64 n, u32 nblk, u32 b) { u64 q = n / nblk, r = n % nblk; return (u64)b * q + (b < r ? b : r); }
 
+// Flat preference, the quick way (ZENC_PREFER_FLAT: the packed 4-bit stream), one WAVE per block and no histogram: when EVERY byte of
+// the block is one of the sixteen pair codes of A C G T (both nibbles a single bit: a nibble-wise population count over eight bytes at
+// a time) and the entropy of an eighth of the block (the first half of every fourth 16-byte piece: 4 K symbols of a 32 KiB block) is
+// above 1 - 1/prefer_flat of four bits per symbol -- Huffman coding cannot save the threshold then -- everything about the block is known
+// without k_zenc_plan: sixteen 4-bit codes in symbol order, four streams of n x 4 bits + the end mark, the tree description f16.  (Codes
+// that happen not to occur still get their place in the tree: every such block of a genome then carries the SAME description, which is
+// what the decoder's in-place reader wants.)  done[b] = 1 for the blocks settled here; k_zenc_plan leaves them alone.
+// A lane's loads are independent and all in flight together; with the test inside k_zenc_plan (a 256-thread block per 32 KiB, its LDS
+// workspace cleared first, a dozen barriers) 152 K blocks took 1.6 - 2.0 ms.
+#define ZENC_FLATSCAN_WAVES 4
+__global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, u8 *done, u32 min_gain, u32 prefer_flat, ZFlat16 f16)
+{
+    __shared__ u32 bins[ZENC_FLATSCAN_WAVES][64];                 // 4 copies x 16 bins per wave: copy = (lane >> 2) & 3
+    const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 b = blockIdx.x * ZENC_FLATSCAN_WAVES + wv;
+    bins[wv][lane] = 0;
+    __syncthreads();
+    bool ok = b < nblk;
+    u32 bn = 0; const u8 *s = src;
+    if (ok) {
+        const u64 lo = zenc_block_lo(n, nblk, b), hi = zenc_block_lo(n, nblk, b + 1);
+        bn = (u32)(hi - lo); s = src + lo;
+        ok = bn >= 2048;
+    }
+    if (ok) {
+        u64 bad = 0;
+        const bool sampler = (lane & 3) == 0;
+        u32 *mybins = &bins[wv][((lane >> 2) & 3) * 16];
+        const u64 M5 = 0x5555555555555555ull, M3 = 0x3333333333333333ull, ONE = 0x1111111111111111ull;
+#pragma unroll 8
+        for (u32 i = lane * 16; i + 16 <= bn; i += 1024) {
+            const u64 w0 = ld64(s + i), w1 = ld64(s + i + 8);
+            u64 c0 = w0 - ((w0 >> 1) & M5), c1 = w1 - ((w1 >> 1) & M5);
+            c0 = (c0 & M3) + ((c0 >> 2) & M3); c1 = (c1 & M3) + ((c1 >> 2) & M3);
+            bad |= (c0 ^ ONE) | (c1 ^ ONE);
+            if (sampler) {
+                // rank of a pair code: 4 log2(high nibble) + log2(low nibble); log2 of a one-hot nibble x is (x >> 1) - (x >> 3)
+                const u64 lg = ((w0 >> 1) & 0x7777777777777777ull) - ((w0 >> 3) & 0x1111111111111111ull);   // per nibble, no borrows for one-hot nibbles
+                const u64 rk = ((lg >> 2) & 0x0C0C0C0C0C0C0C0Cull) | (lg & 0x0303030303030303ull);
+#pragma unroll
+                for (u32 k = 0; k < 8; k++) atomicAdd(&mybins[(u32)(rk >> (8 * k)) & 15u], 1u);
+            }
+        }
+        if (lane == 0) for (u32 k = bn & ~15u; k < bn; k++) { const u32 v = s[k]; if (__popc(v & 15u) != 1 || __popc(v >> 4) != 1) bad = 1; }
+        ok = __ballot(bad != 0) == 0;
+    }
+    __syncthreads();                                             // (every wave gets here: the sample counts are complete)
+    bool fast = false;
+    if (ok) {
+        const u32 c = lane < 16 ? bins[wv][lane] + bins[wv][16 + lane] + bins[wv][32 + lane] + bins[wv][48 + lane] : 0u;
+        u32 ns = c;
+#pragma unroll
+        for (u32 d = 1; d < 16; d <<= 1) ns += __shfl_xor((int)ns, d, 64);
+        float h = c ? (float)c * __log2f((float)ns / (float)c) : 0.0f;        // entropy of the sample, bits
+#pragma unroll
+        for (u32 d = 1; d < 16; d <<= 1) h += __shfl_xor(h, d, 64);
+        ns = (u32)__shfl((int)ns, 0, 64); h = __shfl(h, 0, 64);
+        fast = ns > 0 && h * (float)prefer_flat > 4.0f * (float)ns * (float)(prefer_flat - 1);
+    }
+    if (fast) {
+        const u32 perq = (bn + 3) / 4;
+        ZEncPlan p; p.n = bn; p.kind = ZK_RAW; p.csize = 3 + bn; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0;
+        for (u32 k = 0; k < 4; k++) p.ssz[k] = ((k < 3 ? perq : bn - 3 * perq) * 4 + 8) >> 3;
+        zenc_plan_finish(p, bn, 4, f16.tb, min_gain);
+        fast = p.kind == ZK_HUF;
+        if (fast) {
+            p.pad = 1;                                            // (k_zenc_write packs such a block with all lanes)
+            if (lane == 0) { plan[b] = p; if (csize) csize[b] = p.csize; }
+            for (u32 sym = lane; sym < 256; sym += 64) {
+                const bool is16 = __popc(sym & 15u) == 1 && __popc(sym >> 4) == 1;
+                const u32 hn = sym >> 4, ln = sym & 15u, rank = 4 * ((hn >> 1) - (hn >> 3)) + ((ln >> 1) - (ln >> 3));
+                codes[(u64)b * 256 + sym] = is16 ? (u16)(rank | (4u << 12)) : (u16)0;
+            }
+            for (u32 k = lane; k < p.tree_bytes; k += 64) trees[(u64)b * ZENC_TREE_SLOT + k] = f16.tree[k];
+        }
+    }
+    if (b < nblk && lane == 0) done[b] = fast ? 1 : 0;
+}
+
 // blk_len == nullptr: block b is the b-th piece of the even split of src[0..n).  Otherwise block b is src[b*slot .. b*slot + blk_len[b])
 // (the literals the LZ stage left of block b).
-__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse, u32 min_gain, u32 maxbits, u32 prefer_flat)
+__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse, u32 min_gain, u32 maxbits, u32 prefer_flat, const u8 *done)
 {
     // ZENC_HCOPIES copies of the 4 quarter histograms (copy = lane % copies): few distinct symbols (packed ACGT has 16) would
     // otherwise serialise every LDS atomic of a wave on the same handful of addresses
     __shared__ u32 hist[ZENC_HCOPIES * 1024];
     u32 b = sample_stride ? blockIdx.x * sample_stride : blockIdx.x;
+    if (done && done[b]) return;                                 // settled by k_zenc_flat_scan
     u64 lo = zenc_block_lo(n, nblk, b), hi = zenc_block_lo(n, nblk, b + 1);
     if (blk_len) { lo = (u64)b * slot; hi = lo + blk_len[b]; }
     u32 bn = (u32)(hi - lo);
@@ -919,8 +1014,14 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     ZTreeCache *cache = sample_stride ? arena_new<ZTreeCache>(c, 1) : nullptr;
     if (!plan || !codes || !trees || !offs || (sample_stride && !cache)) return NAF_GPU_ENOMEM;
     if (cache) HIP_TRY(c, hipMemsetAsync(cache, 0, sizeof(ZTreeCache), c->stream));
-    if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse, min_gain, maxbits, prefer_flat);
-    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain, maxbits, prefer_flat);
+    // the packed 4-bit stream: blocks of pure A C G T near four bits of entropy are settled by a wave each, without the planner
+    u8 *done = nullptr;
+    if (prefer_flat >= 2 && n >= 2048 && zenc_flat16().tb) {
+        done = (u8 *)arena_alloc(c, nblk); if (!done) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zenc_flat_scan", k_zenc_flat_scan, cdiv(nblk, ZENC_FLATSCAN_WAVES), 64 * ZENC_FLATSCAN_WAVES, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, done, min_gain, prefer_flat, zenc_flat16());
+    }
+    if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done);
+    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done);
     ZWriteLz &L = J->L;
     L.not_last = part && !part_last;
     if (use_lz && n >= 64) {
@@ -956,7 +1057,7 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
             LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << LZ_HASH_LOG), d_src, (u64)n, nblk, B, lz_buf);
             LAUNCH(c, "zenc_lz_seqenc", k_lz_seqenc, cdiv(nblk, 64), 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
         }
-        LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse, min_gain, maxbits, 0u);
+        LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse, min_gain, maxbits, 0u, (const u8 *)nullptr);
         LAUNCH(c, "zenc_lz_choose", k_lz_choose, cdiv(nblk, 256), 256, 0, nblk, (const ZEncPlan *)plan, (const ZEncPlan *)plan1, (const u32 *)B.nseq, (const u32 *)B.seq_bytes, mode, offs);
         L.mode = mode; L.plan1 = plan1; L.codes1 = codes1; L.trees1 = trees1; L.B = B;
     }
