@@ -131,7 +131,8 @@ struct ZencPlace { u8 *(*fn)(void *ud, size_t frame_len); void *ud; };
 // zstd_encode in two halves: begin queues the planning of the blocks and returns without waiting; finish reads the size back, writes the
 // blocks and releases the job (also to be called after a failed begin that left a job).  What a caller queues in between runs beside the planning.
 struct ZencJob;
-int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int with_magic, int lz, int block_log_hint, int window_log, ZencJob **job);
+// direct / nd: blocks b < nd of exactly 32 KiB whose four streams of 4-bit codes are already in d_src (enc.hip: direct_word); n must be nd x 32 KiB
+int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int with_magic, int lz, int block_log_hint, int window_log, ZencJob **job, const u8 *direct = nullptr, u32 nd = 0);
 int zstd_encode_finish(naf_gpu_ctx *c, ZencJob *job, u8 *d_dst, size_t cap, size_t *out_len, const ZencPlace *place);
 void zstd_encode_drop(ZencJob *job);
 int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz = 0, int block_log_hint = 0, int window_log = 0, const ZencPlace *place = nullptr);   // window_log >= 10: cross-block matching inside that window (zstd_enc.hip)

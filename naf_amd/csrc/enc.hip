@@ -22,6 +22,8 @@ struct OpMaxI64 { template <typename T> __device__ static T id() { return (T)(-1
 struct OpMaxU32 { template <typename T> __device__ static T id() { return (T)0; } template <typename T> __device__ static T f(T a, T b) { return a > b ? a : b; } };
 struct OpMaxU64 { template <typename T> __device__ static T id() { return (T)0; } template <typename T> __device__ static T f(T a, T b) { return a > b ? a : b; } };
 
+#define REG_ACGT 0x80000000u              // t_reg: the regular tile's letters are A C G T / U only
+#define REG_E(reg) (((reg) >> 24) & 0x7Fu)   // t_reg: line ends of the tile
 struct EncP {
     const u8 *text; u64 n, p0;
     u32 expected[8];             // bitmap of bytes accepted in sequence lines (tables.c:72-123)
@@ -487,10 +489,15 @@ __global__ __launch_bounds__(256) void k_enc_count_pure(EncP P, const i64 *tile_
     uint4 v[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) __builtin_memcpy(&v[k], tp + (64u * (u32)k + lane) * ET_BYTES, 16);
-    u32 eol[4]; bool plain = true;
+    u32 eol[4]; bool plain = true; u32 has_n = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const u32 w[4] = { v[k].x, v[k].y, v[k].z, v[k].w }; plain = piece_plain(w, P.plo, P.phi, &eol[k]) && plain; }
+    for (int k = 0; k < 4; k++) {
+        const u32 w[4] = { v[k].x, v[k].y, v[k].z, v[k].w }; plain = piece_plain(w, P.plo, P.phi, &eol[k]) && plain;
+        // among the plain bytes (A C G T U N in either case, LF, CR) only N has both bit 3 and bit 6
+        has_n |= ((w[0] >> 3) & (w[0] >> 6)) | ((w[1] >> 3) & (w[1] >> 6)) | ((w[2] >> 3) & (w[2] >> 6)) | ((w[3] >> 3) & (w[3] >> 6));
+    }
     if (__ballot(!plain) != 0) { if (lane == 0) { t_needf[t] = 1; t_need[t] = 1; } return; }
+    const bool acgt = __ballot((has_n & 0x01010101u) != 0) == 0;
     u32 E = 0, nbytes = 0, p1 = 0, period = 0, prev_last = 0, lastpos = 0; bool any = false, two = false, lat_ok = true;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(256) void k_enc_count_pure(EncP P, const i64 *tile_
     if (lane == 0) {
         // (the gather of the scatter pass reads up to 17 bytes from a base's position: not in the text's last tiles)
         const bool tile_ok = lat_ok && !two && E >= 2 && period >= 33 && (t + 1) * ET_TILE + 32 <= P.n;
-        t_reg[t] = tile_ok ? (p1 | (period << 12) | (E << 24)) : 0u; t_irr[t] = tile_ok ? 0 : 1;
+        t_reg[t] = tile_ok ? (p1 | (period << 12) | (E << 24) | (acgt ? REG_ACGT : 0u)) : 0u; t_irr[t] = tile_ok ? 0 : 1;
         const u32 tot = ET_TILE - nbytes;
         t_seq[t] = tot; t_ids[t] = 0; t_cmt[t] = 0; t_rec[t] = 0;
         t_tail[t] = any ? ((ET_TILE - 1 - lastpos) | 0x80000000u) : tot;
@@ -560,8 +567,12 @@ struct EncOut {
     u64 *strict_first;            // --strict: min over strict_key of the unexpected bytes (nullptr otherwise)
     const u64 *t_seq, *t_ids, *t_cmt, *t_rec; const u32 *t_tail; const i64 *tile_eol;
     const u32 *irr_list;          // k_enc_scatter<true>: the tiles that are not regular, in order (workgroup b takes irr_list[b]); nullptr: every tile
-    const u32 *t_reg;             // k_enc_count's verdict on a tile: p1 | period << 12 | line ends << 24 when it is regular, else 0
+    const u32 *t_reg;             // k_enc_count's verdict on a tile: p1 | period << 12 | line ends << 24 when it is regular, else 0;
+                                  // bit 31 (k_enc_count_pure): and its letters are A C G T / U only
+    const u8 *direct; u32 nd;     // DIRECT blocks (k_direct_blocks; nullptr: none): block b < nd of 32 KiB of the packed stream takes its
+                                  // four Huffman streams of 4-bit codes straight from the scatter pass (direct_word), never its packed bytes
 };
+
 
 // The tile's sequence bytes are staged in LDS and leave as aligned 8-byte stores: one-byte scattered stores
 // cost a partial-line HBM write each.
@@ -642,6 +653,74 @@ __device__ __forceinline__ void flush_pack(const EncP &P, u8 *packed, u32 *caseb
         }
     }
 }
+// Which blocks of 32 KiB of the packed stream are DIRECT (see direct_word), one wavefront per block, before any base is packed:
+//   - every tile that holds one of the block's 65536 bases is regular and made of A C G T / U only (REG_ACGT): the block is pairs of
+//     those four and line ends sit where the scatter pass computes them;
+//   - the entropy of its pair codes, estimated from 64 bytes of every kilobyte of its text (2 K pairs), is above 1 - 1/prefer_flat of
+//     four bits: Huffman coding could not save the encoder's threshold (the same test k_zenc_flat_scan makes on the packed bytes);
+//   - it is not in a region the level-1 look at the stream reads (zenc_repeat_probe: 1 MiB in every 64, as PACKED bytes).
+// t_seq is the exclusive scan of the tiles' base counts with the total behind it.
+#define DIRECT_PROBE_BLOCKS_LOG 5                                 // 32 blocks of 32 KiB per probed MiB, one MiB in 2^6
+__global__ __launch_bounds__(256) void k_direct_blocks(const u8 *text, const u64 *t_seq, const u32 *t_reg, u64 tiles, u32 nd, u32 prefer_flat, int probed, u8 *direct)
+{
+    __shared__ u32 bins[4][64];                                   // 4 copies x 16 bins per wave
+    const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 b = blockIdx.x * 4 + wv;
+    bins[wv][lane] = 0;
+    __syncthreads();
+    bool ok = b < nd;
+    if (ok && probed && (((b >> DIRECT_PROBE_BLOCKS_LOG) & 63u) == 0)) ok = false;
+    u64 t0 = 0, t1 = 0;
+    if (ok) {
+        const u64 B0 = (u64)b << 16, B1 = B0 + 65536;
+        // last tile with t_seq[t] <= B0: 64-ary search
+        u64 lo = 0, hi = tiles;                                   // answer in [lo, hi)
+        while (hi - lo > 1) {
+            const u64 step = (hi - lo + 63) / 64;
+            const u64 p = lo + (u64)lane * step;
+            const bool le = p < hi && t_seq[p] <= B0;
+            const u32 cnt = (u32)__popcll(__ballot(le));          // (t_seq[lo] <= B0 always: cnt >= 1)
+            const u64 nlo = lo + (u64)(cnt - 1) * step, nhi = nlo + step < hi ? nlo + step : hi;
+            lo = nlo; hi = nhi;
+        }
+        t0 = lo;
+        // the tiles behind it that hold bases below B1 (a regular tile holds ~4000: 17 of them at most)
+        const u64 t = t0 + lane;
+        const bool in = t < tiles && t_seq[t] < B1;
+        const u64 bal = __ballot(in);
+        const bool good = !in || ((t_reg[t] & REG_ACGT) != 0);
+        ok = __ballot(!good) == 0 && bal != ~0ull;                // (64 tiles and still not at B1: some hold few bases, leave it)
+        t1 = t0 + (u64)__popcll(bal) - 1;
+    }
+    if (ok) {
+        const u64 x0 = t0 * ET_TILE, span = (t1 + 1 - t0) * ET_TILE;    // (the tiles are regular: wholly inside the text)
+        const u8 *at = text + x0 + (((u64)lane * span) >> 6 & ~63ull);
+        uint4 v[4]; __builtin_memcpy(v, at, 64);
+        const u32 w[16] = { v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w };
+        u32 *mybins = &bins[wv][(lane & 3) * 16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const u32 pr = (w[i] >> (16 * h)) & 0xFFFFu, c0 = pr & 0xFF, c1 = pr >> 8;
+                if ((c0 & 0x40) && (c1 & 0x40)) atomicAdd(&mybins[((c0 >> 1) & 3) | (((c1 >> 1) & 3) << 2)], 1u);   // two letters (a line end has no bit 6); bits 1..2 tell A C G T apart
+            }
+        }
+    }
+    __syncthreads();
+    if (ok) {
+        const u32 c = lane < 16 ? bins[wv][lane] + bins[wv][16 + lane] + bins[wv][32 + lane] + bins[wv][48 + lane] : 0u;
+        u32 ns = c;
+#pragma unroll
+        for (u32 d = 1; d < 16; d <<= 1) ns += __shfl_xor((int)ns, d, 64);
+        float h = c ? (float)c * __log2f((float)ns / (float)c) : 0.0f;
+#pragma unroll
+        for (u32 d = 1; d < 16; d <<= 1) h += __shfl_xor(h, d, 64);
+        ns = (u32)__shfl((int)ns, 0, 64); h = __shfl(h, 0, 64);
+        ok = ns >= 1024 && h * (float)prefer_flat > 4.0f * (float)ns * (float)(prefer_flat - 1);
+    }
+    if (b < nd && lane == 0) direct[b] = ok ? 1 : 0;
+}
 // the tiles k_enc_count did not find regular, in order (pre = exclusive scan of its 0 / 1 verdicts)
 __global__ void k_irregular_list(const u32 *t_reg, const u64 *pre, u64 tiles, u32 *list)
 {
@@ -649,14 +728,17 @@ __global__ void k_irregular_list(const u32 *t_reg, const u64 *pre, u64 tiles, u3
     if (t < tiles && !t_reg[t]) list[pre[t]] = (u32)t;
 }
 // the groups a tile shares with its neighbours (and the last group of the stream, whose padding must read as zero)
-__global__ void k_pack_edges_zero(const u64 *t_seq, u64 tiles, u64 T, u8 *packed, u32 *casebits)
+__global__ void k_pack_edges_zero(const u64 *t_seq, u64 tiles, u64 T, u8 *packed, u32 *casebits, const u8 *direct, u32 nd)
 {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tiles) return;
     const u64 b0 = t_seq[t], b1 = t + 1 < tiles ? t_seq[t + 1] : T;
     if (b1 <= b0) return;
     const u64 g0 = b0 >> 4, g1 = (b1 - 1) >> 4;
-    *(u64 *)(packed + 8 * g0) = 0; *(u64 *)(packed + 8 * g1) = 0;
+    // (a group of a direct block is one word of its stream, see direct_word)
+    const bool d0 = direct && (g0 >> 12) < nd && direct[g0 >> 12], d1 = direct && (g1 >> 12) < nd && direct[g1 >> 12];
+    if (d0) *((u32 *)(packed + ((g0 >> 12) << 15) + (((g0 >> 10) & 3) << 12)) + (1023u - (u32)(g0 & 1023u))) = 0; else *(u64 *)(packed + 8 * g0) = 0;
+    if (d1) *((u32 *)(packed + ((g1 >> 12) << 15) + (((g1 >> 10) & 3) << 12)) + (1023u - (u32)(g1 & 1023u))) = 0; else *(u64 *)(packed + 8 * g1) = 0;
     if (casebits) { ((u16 *)casebits)[g0] = 0; ((u16 *)casebits)[g1] = 0; }
 }
 
@@ -761,8 +843,41 @@ __device__ __forceinline__ void reg_group_pack(const RegGroup &g, u64 lo, u64 hi
     cb = swar_movemask16((gw[0] | ((gw[0] << 1) & (gw[0] << 2))) & H, (gw[1] | ((gw[1] << 1) & (gw[1] << 2))) & H,
                          (gw[2] | ((gw[2] << 1) & (gw[2] << 2))) & H, (gw[3] | ((gw[3] << 1) & (gw[3] << 2))) & H);
 }
+// ---- DIRECT blocks.  A block of 32 KiB of the packed stream that holds nothing but pairs of A C G T and is coded with the flat tree of
+// the sixteen pair codes (zstd_enc.hip: k_zenc_flat_scan) is four Huffman streams of 8192 4-bit codes each: the code of a pair is
+// 4 log2(second base) + log2(first base), i.e. TWO BITS PER BASE, and a stream holds its codes last symbol first (4.2.2).  A group of
+// 16 bases (8 symbols) is then one 32-bit word of its stream -- word 1023 - (group & 1023), symbol s of the group in nibble 7 - s --
+// and the scatter pass writes that word instead of the group's eight packed bytes: the block's streams are ready where its packed bytes
+// would have been (stream k in bytes [4096 k, 4096 k + 4096) of the block's 32 KiB; k_zenc_write copies them out and adds the end marks),
+// 5 GB of 10 GB of bases less to write here and to read twice there.
+__device__ __forceinline__ u32 direct_code32(u64 pk)
+{
+    const u64 lg = ((pk >> 1) & 0x7777777777777777ull) - ((pk >> 3) & 0x1111111111111111ull);      // log2 of a one-hot nibble x: (x >> 1) - (x >> 3)
+    u64 x = lg & 0x3333333333333333ull;                                                            // two bits of every nibble, moved together
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0xFFFFFFFFull;
+    u32 r = __builtin_bswap32((u32)x);                                                             // nibble s -> nibble 7 - s
+    return ((r & 0x0F0F0F0Fu) << 4) | ((r >> 4) & 0x0F0F0F0Fu);
+}
+__device__ __forceinline__ u32 *direct_word(u8 *packed, u64 G)
+{
+    return (u32 *)(packed + ((G >> 12) << 15) + (((G >> 10) & 3) << 12)) + (1023u - (u32)(G & 1023u));
+}
+__device__ __forceinline__ bool direct_group(const EncOut &O, u64 G) { const u64 b = G >> 12; return O.direct && b < O.nd && O.direct[b]; }
 __device__ __forceinline__ void reg_group_store(const EncOut &O, u64 G, const RegGroup &g, u64 pk, u32 cb)
 {
+    if (direct_group(O, G)) {
+        if (g.ga == 0 && g.gb == 16) { *direct_word(O.packed, G) = direct_code32(pk); if (O.casebits) ((u16 *)O.casebits)[G] = (u16)cb; }
+        else {
+            const u64 nm = (g.gb == 16 ? ~0ull : ((1ull << (4 * g.gb)) - 1)) & ~((1ull << (4 * g.ga)) - 1);
+            cb &= ((1u << g.gb) - 1) & ~((1u << g.ga) - 1);
+            atomicOr(direct_word(O.packed, G), direct_code32(pk & nm));          // (an absent base adds no bit: log2 of an empty nibble reads 0)
+            if (O.casebits) atomicOr(O.casebits + (G >> 1), cb << (16 * (u32)(G & 1)));
+        }
+        return;
+    }
     if (g.ga == 0 && g.gb == 16) {
         *(u64 *)(O.packed + 8 * G) = pk;
         if (O.casebits) ((u16 *)O.casebits)[G] = (u16)cb;
@@ -785,7 +900,7 @@ __global__ __launch_bounds__(256) void k_enc_scatter_regular(EncP P, const i64 *
     const u32 reg = O.t_reg[t];
     const u64 tb = O.t_seq[t];
     if (!reg) return;
-    const u32 p1 = reg & 0xFFFu, period = (reg >> 12) & 0xFFFu, E = reg >> 24, W = period - 1, n = ET_TILE - E;
+    const u32 p1 = reg & 0xFFFu, period = (reg >> 12) & 0xFFFu, E = REG_E(reg), W = period - 1, n = ET_TILE - E;
     const u32 o = (u32)(tb & 15), span = o + n, ng = (span + 15) >> 4;
     const u64 G0 = tb >> 4;
     const u32 lead = (u32)(G0 & 3);                                    // groups of the tile's first quad that belong to tiles in front
@@ -826,17 +941,25 @@ __global__ __launch_bounds__(256) void k_enc_scatter_regular(EncP P, const i64 *
     for (u32 q = lane; q < nq; q += 64) {
         const u32 s0 = 4 * q;                                           // slot of the quad's first group
         const bool whole = s0 >= lead + j_first_whole && s0 + 4 <= lead + j_end_whole;
+        const bool dq = direct_group(O, Gq0 + s0);                      // (a quad lies in one stream of one block)
         if (whole) {
             const uint4 a = *(const uint4 *)(spk + s0), b2 = *(const uint4 *)(spk + s0 + 2);
-            uint4 *pp = (uint4 *)(O.packed + 8 * (Gq0 + s0));
-            pp[0] = a; pp[1] = b2;
+            if (dq) {
+                // the quad's four words, the last group first
+                const uint4 cw = make_uint4(direct_code32((u64)b2.z | ((u64)b2.w << 32)), direct_code32((u64)b2.x | ((u64)b2.y << 32)),
+                                            direct_code32((u64)a.z | ((u64)a.w << 32)), direct_code32((u64)a.x | ((u64)a.y << 32)));
+                *(uint4 *)direct_word(O.packed, Gq0 + s0 + 3) = cw;
+            } else {
+                uint4 *pp = (uint4 *)(O.packed + 8 * (Gq0 + s0));
+                pp[0] = a; pp[1] = b2;
+            }
             if (O.casebits) *(uint2 *)((u16 *)O.casebits + Gq0 + s0) = *(const uint2 *)(scb + s0);
         } else {
 #pragma unroll
             for (u32 i = 0; i < 4; i++) {
                 const u32 sl = s0 + i;
                 if (sl >= lead + j_first_whole && sl < lead + j_end_whole) {
-                    *(u64 *)(O.packed + 8 * (Gq0 + sl)) = spk[sl];
+                    if (dq) *direct_word(O.packed, Gq0 + sl) = direct_code32(spk[sl]); else *(u64 *)(O.packed + 8 * (Gq0 + sl)) = spk[sl];
                     if (O.casebits) ((u16 *)O.casebits)[Gq0 + sl] = scb[sl];
                 }
             }
@@ -847,7 +970,7 @@ __global__ __launch_bounds__(256) void k_enc_scatter_regular(EncP P, const i64 *
         // regular with the same period and its last line end lies W bases in front of p1, it holds W too; only otherwise is its
         // start looked up (three dependent loads)
         const u32 rp = t ? O.t_reg[t - 1] : 0u;
-        const u32 pl_prev = (rp & 0xFFFu) + ((rp >> 24) - 1) * ((rp >> 12) & 0xFFFu);
+        const u32 pl_prev = (rp & 0xFFFu) + (REG_E(rp) - 1) * ((rp >> 12) & 0xFFFu);
         u64 len = W;
         if (!(rp && ((rp >> 12) & 0xFFFu) == period && ET_TILE - 1 - pl_prev + p1 == W)) {
             const u64 first = tb + p1 - tile_line_base(P, O, tile_eol, t);
@@ -1586,7 +1709,19 @@ struct EnnafSplit {
     int err_kind; u32 err_char; u64 err_rec, err_a, err_b;
     // soft-mask census of a shard (positions >= 1); tc = per-tile counts kept for the finish
     bool census; u64 *tc; u64 mask_changes, mask_first, mask_last; u8 first_base, last_base;
+    // direct blocks (k_direct_blocks): flags of the first nd blocks of 32 KiB of `packed`; rescatter() packs the bases again without them
+    // (the stream turned out to be worth matching: the match finder wants packed bytes)
+    u8 *direct; u32 nd;
+    struct Scatter4 { EncP P; EncOut O; const i64 *t_eol, *t_sp; const u64 *t_seq; u64 tiles, T, n, n_irregular; } sc4;
 };
+// the scatter pass of a 4-bit FASTA input (O.direct says which blocks are direct)
+static int ennaf_scatter4(naf_gpu_ctx *c, const EnnafSplit::Scatter4 &R, u8 *packed, u64 *casebits)
+{
+    if (R.T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(R.tiles, 256), 256, 0, R.t_seq, R.tiles, R.T, packed, (u32 *)casebits, R.O.direct, R.O.nd);
+    if (R.n >= 2 * ET_TILE) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular, cdiv(R.tiles, REG_TPW), 256, 0, R.P, R.t_eol, R.O, R.tiles);   // (shorter texts have no regular tile)
+    if (R.n_irregular) LAUNCH(c, "ennaf_scatter", k_enc_scatter<true>, R.n_irregular, 256, 0, R.P, R.t_eol, R.t_sp, R.O);
+    return 0;
+}
 
 static int split_error_text(naf_gpu_ctx *c, int seq_type, int kind, u32 ch, u64 rec, u64 a, u64 b, u64 rec0)
 {
@@ -1620,7 +1755,7 @@ static int alloc_bases(naf_gpu_ctx *c, EnnafSplit &S)
 
 // The split pass (E1-E4): text -> ids, comments, bases (1 B/base, post-replacement), quality, record table.  p0 = first byte of
 // the first record; last_part: the text ends where the input ends (the truncation rules of process.c:499-520 apply).
-static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_ennaf_opts *o, int format, u64 p0, bool last_part, EnnafSplit &S)
+static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_ennaf_opts *o, int format, u64 p0, bool last_part, EnnafSplit &S, bool allow_direct = false)
 {
     memset(&S, 0, sizeof S);
     int seq_type = o->seq_type, rc;
@@ -1675,7 +1810,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         O.unexpected = d_unexp; O.first_error = d_unexp + 4 * 257; O.strict_first = o->strict ? d_unexp + 4 * 257 + 2 : nullptr;
         O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_qual = t_qual; O.t_ls = t_ls; O.piece_cnt = piece_cnt;
         if (S.fourbit) {
-            if (T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(tiles, 256), 256, 0, (const u64 *)t_seq, tiles, T, S.packed, (u32 *)S.casebits);
+            if (T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(tiles, 256), 256, 0, (const u64 *)t_seq, tiles, T, S.packed, (u32 *)S.casebits, (const u8 *)nullptr, 0u);
             LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter<true>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
         } else LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter<false>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
         if (nlines / 4) LAUNCH(c, "ennaf_fq_check", k_fq_check, cdiv(nlines / 4, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, (const u64 *)q_begin, (const u64 *)q_end, nlines / 4, O.first_error, d_unexp + 4 * 257 + 1);
@@ -1776,10 +1911,29 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         EncOut O; O.seq = bases; O.packed = S.packed; O.casebits = (u32 *)S.casebits; O.ids = s_ids; O.cmt = s_cmt; O.rec_begin = rec_begin; O.rec_end = rec_end;
         O.unexpected = d_unexp; O.longest = d_unexp + 3 * 257; O.strict_first = o->strict ? d_unexp + 3 * 257 + 1 : nullptr; O.lead = d_unexp + 3 * 257 + 2;
         O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_rec = t_rec; O.t_tail = t_tail; O.tile_eol = t_eol; O.t_reg = t_reg; O.irr_list = S.fourbit ? irr_list : nullptr;
+        O.direct = nullptr; O.nd = 0;
         if (S.fourbit) {
-            if (T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(tiles, 256), 256, 0, (const u64 *)t_seq, tiles, T, S.packed, (u32 *)S.casebits);
-            if (n >= 2 * ET_TILE) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular, cdiv(tiles, REG_TPW), 256, 0, P, (const i64 *)t_eol, O, tiles);   // (shorter texts have no regular tile)
-            if (n_irregular) LAUNCH(c, "ennaf_scatter", k_enc_scatter<true>, n_irregular, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+            // Direct blocks: a whole input at level 1 (no match finder unless the look at the stream says so), blocks of exactly 32 KiB
+            // (the stream's ragged end is coded as a part of its own, ennaf_streams), from 8 MiB of packed bases up
+            const u64 n_seqb = (T + 1) / 2;
+            const char *ed = getenv("NAF_GPU_DIRECT"), *epf = getenv("NAF_GPU_PREFER_FLAT"), *ebl = getenv("NAF_GPU_BLOCK_LOG"), *epr = getenv("NAF_GPU_PROBE"), *elz = getenv("NAF_GPU_LZ");
+            const u32 prefer_flat = epf && epf[0] ? (u32)atoi(epf) : 16u;
+            const u64 nd64 = n_seqb >> 15;
+            if (allow_direct && o->level <= 1 && !o->long_log && !(ed && ed[0] == '0') && prefer_flat >= 2 && !(ebl && atoi(ebl) != 15) && !(epr && epr[0] == '1') && !(elz && !strcmp(elz, "all"))
+                && n >= 16 * ET_TILE && nd64 >= ((ed && ed[0] == '2') ? 2u : 256u) && nd64 < 0x7FFFFFFFull && !((T & 1) && (n_seqb & 32767) == 0)) {
+                S.nd = (u32)nd64; S.direct = (u8 *)arena_alloc(c, S.nd); if (!S.direct) return NAF_GPU_ENOMEM;
+                LAUNCH(c, "ennaf_direct_blocks", k_direct_blocks, cdiv(S.nd, 4), 256, 0, d_text, (const u64 *)t_seq, (const u32 *)t_reg, tiles, S.nd, prefer_flat, (epr && epr[0] == '0') ? 0 : 1, S.direct);
+                O.direct = S.direct; O.nd = S.nd;
+                if (getenv("NAF_GPU_DEBUG_DIRECT")) {
+                    std::vector<u8> hd(S.nd); hipStreamSynchronize(c->stream); hipMemcpy(hd.data(), S.direct, S.nd, hipMemcpyDeviceToHost);
+                    u64 k = 0; for (u8 v : hd) k += v;
+                    fprintf(stderr, "[direct] %llu of %u blocks\n", (unsigned long long)k, S.nd);
+                }
+            }
+            // (S.sc4 stays valid until the call ends -- the tables live in the arena: the same pass can run again without direct blocks
+            // when the stream turns out to be worth matching; what it then adds to the counts of unexpected bytes has been read by then)
+            S.sc4.P = P; S.sc4.O = O; S.sc4.t_eol = t_eol; S.sc4.t_sp = t_sp; S.sc4.t_seq = t_seq; S.sc4.tiles = tiles; S.sc4.T = T; S.sc4.n = n; S.sc4.n_irregular = n_irregular;
+            if ((rc = ennaf_scatter4(c, S.sc4, S.packed, S.casebits))) return rc;
         } else LAUNCH(c, "ennaf_scatter", k_enc_scatter<false>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
         std::vector<u64> hu(NU);
         if ((rc = ctx_readback(c, hu.data(), d_unexp, NU * 8))) return rc;
@@ -1810,7 +1964,8 @@ struct EnnafCarry {
     u64 run_ext;           // bases of the following shards that continue this shard's last mask run
 };
 struct EnnafStreams { const u8 *ptr[6]; u64 len[6], orig[6]; int lz[6], block_log[6], window_log[6]; bool present[6];
-                      u32 tail[6]; int flags[6]; };   // flags: ZENC_PREFER_RAW for the mask stream   // tail: bytes at the end of the stream that go into a Raw block of their own (encode_stream)
+                      u32 tail[6]; int flags[6];
+                      const u8 *direct; u32 nd, tail_packed; };   // direct blocks of the sequence stream (EnnafSplit::direct); tail[4] without them   // flags: ZENC_PREFER_RAW for the mask stream   // tail: bytes at the end of the stream that go into a Raw block of their own (encode_stream)
 
 // E5-E7: lengths, 4-bit pack, mask units -> the six uncompressed streams.
 // part: 1 = ids, names, sequence and quality (nothing to wait for), 2 = lengths and mask (a few read-backs), 3 = all of them.  The two
@@ -1887,6 +2042,9 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
     if (part & 1) {
         X.ptr[0] = S.s_ids; X.len[0] = X.orig[0] = S.n_ids; X.lz[0] = 1; X.present[0] = true;
         X.ptr[1] = S.s_cmt; X.len[1] = X.orig[1] = S.n_cmt; X.lz[1] = 1; X.present[1] = true;
+        // direct blocks are blocks of exactly 32 KiB: the stream's ragged end (with the padding nibble, if any) is a part of its own
+        X.tail_packed = seq_tail; X.direct = nullptr; X.nd = 0;
+        if (S.direct && (part & 1)) { X.direct = S.direct; X.nd = S.nd; seq_tail = (u32)(n_seqb & 32767); }
         X.ptr[4] = s_seq; X.len[4] = n_seqb; X.orig[4] = T; X.present[4] = true; X.tail[4] = seq_tail;   // ennaf.c:582: number of bases
         X.ptr[5] = S.s_qual; X.len[5] = X.orig[5] = S.n_qual; X.present[5] = S.store_qual;
     }
@@ -1950,12 +2108,13 @@ struct PlaceTail { const ZencPlace *outer; size_t tail_len; u8 *at; };
 static u8 *place_before_tail(void *ud, size_t len) { PlaceTail *t = (PlaceTail *)ud; return t->at = t->outer->fn(t->outer->ud, len + t->tail_len); }
 // the two halves of a placed stream (zstd_encode_begin / _finish): what the caller queues between them runs beside the planning
 struct StreamJob { ZencJob *main; const u8 *d_stream; u64 len; int level, flags; u32 tail; };
-static int encode_stream_begin(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level, int flags, int lz, int block_log, int window_log, u32 tail, StreamJob *J)
+static int encode_stream_begin(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level, int flags, int lz, int block_log, int window_log, u32 tail, StreamJob *J, const u8 *direct = nullptr, u32 nd = 0)
 {
     J->main = nullptr; J->d_stream = d_stream; J->len = len; J->level = level; J->flags = flags; J->tail = (tail && len > tail) ? tail : 0;
     int f1 = flags;
     if (J->tail) f1 = ZENC_PART | ((!(flags & ZENC_PART) || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT));
-    int rc = zstd_encode_begin(c, d_stream, len - J->tail, level, f1, lz, block_log, window_log, &J->main);
+    if (direct && (lz || len - J->tail != (u64)nd << 15)) return ctx_fail(c, NAF_GPU_EARG, "direct blocks need a stream of whole blocks and no match finder");
+    int rc = zstd_encode_begin(c, d_stream, len - J->tail, level, f1, lz, block_log, window_log, &J->main, direct, nd);
     if (rc) { zstd_encode_drop(J->main); J->main = nullptr; }
     return rc;
 }
@@ -2012,13 +2171,13 @@ static u8 *place_section(void *ud, size_t clen)
 
 // `early`: the stream's planning was queued before (encode_stream_begin); otherwise both halves run here.  The launches go to c's
 // stream (c may be a side context), a failure's text lands in `report`.
-static int put_section(naf_gpu_ctx *c, naf_gpu_ctx *report, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz, int block_log, int window_log, u32 tail, StreamJob *early, int flags = 0)
+static int put_section(naf_gpu_ctx *c, naf_gpu_ctx *report, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz, int block_log, int window_log, u32 tail, StreamJob *early, int flags = 0, const u8 *direct = nullptr, u32 nd = 0)
 {
     SecPlace sp = { c, d_naf, cap, pos, orig, 0, 0 }; ZencPlace P = { place_section, &sp };
     size_t clen = 0;
     StreamJob J;
     int rc = 0;
-    if (!early) { rc = encode_stream_begin(c, d_stream, stream_len, level, flags, lz, block_log, window_log, tail, &J); early = &J; }
+    if (!early) { rc = encode_stream_begin(c, d_stream, stream_len, level, flags, lz, block_log, window_log, tail, &J, direct, nd); early = &J; }
     if (!rc) rc = encode_stream_finish(c, early, &clen, &P);
     if (rc) { if (report != c) ctx_fail(report, sp.rc ? sp.rc : rc, "%s", c->err); return sp.rc ? sp.rc : rc; }
     pos += sp.hl + clen;
@@ -2038,7 +2197,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     if ((rc = ennaf_sniff(c, d_text, n, o->format, &format, &p0))) return rc;
     R.format = format;
     EnnafSplit S;
-    if ((rc = ennaf_split(c, d_text, n, o, format, p0, true, S))) return rc;
+    if ((rc = ennaf_split(c, d_text, n, o, format, p0, true, S, true))) return rc;
     if (S.err_kind) return split_error_text(c, o->seq_type, S.err_kind, S.err_char, S.err_rec, S.err_a, S.err_b, 0);
     EnnafCarry K; memset(&K, 0, sizeof K);
     // The sequence and quality streams are planned on this context's stream while a side context makes the length and mask units and
@@ -2052,6 +2211,14 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
     if ((rc = ennaf_streams(c, S, K, X, overlap ? 1 : 3))) return rc;
     bool probe_later = false;                                     // level 1: the look at the sequence stream runs beside its planning
     if ((rc = ennaf_windows(c, X, o, overlap ? &probe_later : nullptr))) return rc;
+    // the match finder wants packed bytes in every block: the bases are packed again, without direct blocks
+    auto undirect = [&]() -> int {
+        if (!X.direct) return 0;
+        X.direct = nullptr; X.nd = 0; X.tail[4] = X.tail_packed; S.direct = nullptr; S.nd = 0;
+        S.sc4.O.direct = nullptr; S.sc4.O.nd = 0;
+        return ennaf_scatter4(c, S.sc4, S.packed, S.casebits);
+    };
+    if (X.lz[4] && (rc = undirect())) return rc;
     // container (ennaf.c:538-589)
     u8 hd[64]; size_t hl = naf_header_bytes(o, S.store_mask, S.store_qual, S.longest, S.N, hd);
     size_t tl = o->title ? strlen(o->title) : 0;
@@ -2067,7 +2234,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
         HIP_TRY(c, hipStreamWaitEvent(sc->stream, c->fork_ev, 0));
         for (int i = 4; i < 6; i++)
             if (X.present[i]) {
-                if ((rc = encode_stream_begin(c, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]))) { for (int k = 4; k < i; k++) if (early[k]) zstd_encode_drop(big[k].main); return rc; }
+                if ((rc = encode_stream_begin(c, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i], i == 4 ? X.direct : nullptr, i == 4 ? X.nd : 0u))) { for (int k = 4; k < i; k++) if (early[k]) zstd_encode_drop(big[k].main); return rc; }
                 early[i] = true;
             }
         if (probe_later) {
@@ -2078,6 +2245,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
             ennaf_probe_verdict(X, share);
             if (X.lz[4]) {
                 zstd_encode_drop(big[4].main); early[4] = false;
+                if ((rc = undirect())) { if (early[5]) zstd_encode_drop(big[5].main); hipStreamSynchronize(sc->stream); return rc; }
                 if ((rc = encode_stream_begin(c, X.ptr[4], X.len[4], o->level, X.flags[4], X.lz[4], X.block_log[4], X.window_log[4], X.tail[4], &big[4]))) { if (early[5]) zstd_encode_drop(big[5].main); hipStreamSynchronize(sc->stream); return rc; }
                 early[4] = true;
             }
@@ -2122,7 +2290,7 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
         if (!X.present[i]) continue;
         if (i >= 4 && (rc = join())) break;
         naf_gpu_ctx *w = !overlap || i >= 4 ? c : (sb && i >= 2) ? sb : sc;
-        rc = put_section(w, c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], early[i] ? &big[i] : nullptr, X.flags[i]);
+        rc = put_section(w, c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], early[i] ? &big[i] : nullptr, X.flags[i], i == 4 ? X.direct : nullptr, i == 4 ? X.nd : 0u);
         early[i] = false;
     }
     if (!joinedB) { ctx_worker_join(sb); joinedB = true; }

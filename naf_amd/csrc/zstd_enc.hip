@@ -54,7 +54,8 @@ __host__ __device__ static inline u64 zenc_block_lo(u64 n, u32 nblk, u32 b) { u6
 // A lane's loads are independent and all in flight together; with the test inside k_zenc_plan (a 256-thread block per 32 KiB, its LDS
 // workspace cleared first, a dozen barriers) 152 K blocks took 1.6 - 2.0 ms.
 #define ZENC_FLATSCAN_WAVES 4
-__global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, u8 *done, u32 min_gain, u32 prefer_flat, ZFlat16 f16)
+// direct[b] != 0: the block is known to be such a block and its four streams are already coded (enc.hip: direct_word; plan.pad = 2) -- nothing is read.
+__global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, u8 *done, u32 min_gain, u32 prefer_flat, ZFlat16 f16, const u8 *direct)
 {
     __shared__ u32 bins[ZENC_FLATSCAN_WAVES][64];                 // 4 copies x 16 bins per wave: copy = (lane >> 2) & 3
     const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(con
         bn = (u32)(hi - lo); s = src + lo;
         ok = bn >= 2048;
     }
-    if (ok) {
+    const bool dir = ok && direct && direct[b];
+    if (ok && !dir) {
         u64 bad = 0;
         const bool sampler = (lane & 3) == 0;
         u32 *mybins = &bins[wv][((lane >> 2) & 3) * 16];
@@ -91,8 +93,8 @@ __global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(con
         ok = __ballot(bad != 0) == 0;
     }
     __syncthreads();                                             // (every wave gets here: the sample counts are complete)
-    bool fast = false;
-    if (ok) {
+    bool fast = dir;
+    if (ok && !dir) {
         const u32 c = lane < 16 ? bins[wv][lane] + bins[wv][16 + lane] + bins[wv][32 + lane] + bins[wv][48 + lane] : 0u;
         u32 ns = c;
 #pragma unroll
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(con
         zenc_plan_finish(p, bn, 4, f16.tb, min_gain);
         fast = p.kind == ZK_HUF;
         if (fast) {
-            p.pad = 1;                                            // (k_zenc_write packs such a block with all lanes)
+            p.pad = dir ? 2 : 1;                                  // (k_zenc_write packs such a block with all lanes; 2: copies its ready streams)
             if (lane == 0) { plan[b] = p; if (csize) csize[b] = p.csize; }
             for (u32 sym = lane; sym < 256; sym += 64) {
                 const bool is16 = __popc(sym & 15u) == 1 && __popc(sym >> 4) == 1;
@@ -147,23 +149,33 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
     if (threadIdx.x < 16) for (u32 q = 0; q < 4; q++) hist[q * 256 + threadIdx.x * 17] = bn / 64;
     if (0)
 #endif
-    for (u32 i = threadIdx.x * 8; i < bn; i += 2048) {
-        if (i + 8 <= bn) {
-            u64 w = ld64(s + i);
-            const u32 q0 = (i >= per) + (i >= 2 * per) + (i >= 3 * per), q7 = (i + 7 >= per) + (i + 7 >= 2 * per) + (i + 7 >= 3 * per);
-            if (q0 == q7) {                                       // the word lies in one quarter (all but three words of a block)
-                const u64 H = 0x8080808080808080ull;
-                const u64 wr = ((w & ~H) + rot8) ^ (w & H);      // (byte + rot) & 0xFF for all eight bytes
-                u32 *hq = my + q0 * 256;
-                const u32 lo = (u32)wr, hi = (u32)(wr >> 32);
+    // eight words of a thread in flight together (with one load per trip, a block of 32 KiB was sixteen round trips to memory in a row:
+    // 70 of the planner's 420 us per block of a quality stream)
+    for (u32 i0 = threadIdx.x * 8; i0 < bn; i0 += 8 * 2048) {
+        u64 wv[8];
 #pragma unroll
-                for (u32 k = 0; k < 4; k++) { atomicAdd(&hq[(lo >> (8 * k)) & 0xFF], 1u); atomicAdd(&hq[(hi >> (8 * k)) & 0xFF], 1u); }
+        for (u32 j = 0; j < 8; j++) { const u32 i = i0 + j * 2048; wv[j] = i + 8 <= bn ? ld64(s + i) : 0; }
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) {
+            const u32 i = i0 + j * 2048;
+            if (i >= bn) break;
+            if (i + 8 <= bn) {
+                const u64 w = wv[j];
+                const u32 q0 = (i >= per) + (i >= 2 * per) + (i >= 3 * per), q7 = (i + 7 >= per) + (i + 7 >= 2 * per) + (i + 7 >= 3 * per);
+                if (q0 == q7) {                                       // the word lies in one quarter (all but three words of a block)
+                    const u64 H = 0x8080808080808080ull;
+                    const u64 wr = ((w & ~H) + rot8) ^ (w & H);      // (byte + rot) & 0xFF for all eight bytes
+                    u32 *hq = my + q0 * 256;
+                    const u32 lo = (u32)wr, hi = (u32)(wr >> 32);
+#pragma unroll
+                    for (u32 k = 0; k < 4; k++) { atomicAdd(&hq[(lo >> (8 * k)) & 0xFF], 1u); atomicAdd(&hq[(hi >> (8 * k)) & 0xFF], 1u); }
+                } else {
+#pragma unroll
+                    for (u32 k = 0; k < 8; k++) { u32 pos = i + k, q = (pos >= per) + (pos >= 2 * per) + (pos >= 3 * per); atomicAdd(&my[q * 256 + (((u32)(w >> (8 * k)) + rot) & 0xFF)], 1u); }
+                }
             } else {
-#pragma unroll
-                for (u32 k = 0; k < 8; k++) { u32 pos = i + k, q = (pos >= per) + (pos >= 2 * per) + (pos >= 3 * per); atomicAdd(&my[q * 256 + (((u32)(w >> (8 * k)) + rot) & 0xFF)], 1u); }
+                for (u32 k = 0; i + k < bn; k++) { u32 pos = i + k, q = (pos >= per) + (pos >= 2 * per) + (pos >= 3 * per); atomicAdd(&my[q * 256 + ((s[pos] + rot) & 0xFF)], 1u); }
             }
-        } else {
-            for (u32 k = 0; i + k < bn; k++) { u32 pos = i + k, q = (pos >= per) + (pos >= 2 * per) + (pos >= 3 * per); atomicAdd(&my[q * 256 + ((s[pos] + rot) & 0xFF)], 1u); }
         }
     }
     __syncthreads();
@@ -269,7 +281,35 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
                 u32 mx = lane < n ? dl : 0;
                 for (int d = 32; d; d >>= 1) { u32 o = (u32)__shfl_xor((int)mx, d, 64); mx = o > mx ? o : mx; }
                 if (mx <= maxbits) { if (lane < n) ws.len[ws.order[lane]] = (u8)dl; if (lane == 0) ws.log = mx; }
-                else if (lane == 0) ws.log = huf_lengths_sorted(ws.tot, ws.order, distinct, ws.len, ws.w, ws.parent, ws.depth, maxbits);
+                else {
+                    // Length limiting, huf_lengths_sorted's steps on the lengths in the lanes (lane = rank, rarest first): clamp, then lengthen
+                    // the rarest symbols that can still grow until the Kraft sum (units of 2^-maxbits) is no more than 1, then shorten the
+                    // most frequent ones that fit until it is 1.  The walks are serial in the sum, so they run as uniform loops over the
+                    // ranks with the candidate's length read from its lane (a quality block's 40 symbols: a few hundred scalar steps
+                    // instead of one lane redoing the construction in LDS -- 60 of the planner's 420 us per block).
+                    u32 l = lane < n ? (dl > maxbits ? maxbits : dl) : 0;
+                    i32 K = 0;
+                    { u32 k = lane < n ? 1u << (maxbits - l) : 0u; for (int d = 32; d; d >>= 1) k += (u32)__shfl_xor((int)k, d, 64); K = (i32)k; }
+                    const i32 full = 1 << maxbits;
+                    while (K > full) {
+                        for (u32 i = 0; i < n && K > full; i++) {
+                            const u32 li = (u32)__builtin_amdgcn_readlane((int)l, (int)__builtin_amdgcn_readfirstlane((int)i));
+                            if (li < maxbits) { K -= 1 << (maxbits - li - 1); if (lane == i) l++; }
+                        }
+                    }
+                    while (K < full) {
+                        bool any = false;
+                        for (u32 i = n; i-- > 0 && K < full;) {
+                            const u32 li = (u32)__builtin_amdgcn_readlane((int)l, (int)__builtin_amdgcn_readfirstlane((int)i));
+                            if (li > 1 && K + (1 << (maxbits - li)) <= full) { K += 1 << (maxbits - li); if (lane == i) l--; any = true; }
+                        }
+                        if (!any) break;
+                    }
+                    u32 ml = l;
+                    for (int d = 32; d; d >>= 1) { u32 o = (u32)__shfl_xor((int)ml, d, 64); ml = o > ml ? o : ml; }
+                    if (lane < n) ws.len[ws.order[lane]] = (u8)l;
+                    if (lane == 0) ws.log = K == full ? ml : 0u;
+                }
             }
         } else if (threadIdx.x == 0) ws.log = huf_lengths_sorted(ws.tot, ws.order, distinct, ws.len, ws.w, ws.parent, ws.depth, maxbits);
         __syncthreads();
@@ -314,7 +354,14 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
                     if (hit) { if (sym < ZENC_TREE_SLOT) ws.tree[sym] = ce->tree[sym]; if (sym == 0) ws.tb = ce->tb; }
                 }
             }
-            if (!hit && threadIdx.x == 0) ws.tb = huf_write_tree_w(ws.tree, ws.wt, (u32)lastw, ws.tmp, ws.fse, try_fse != 0);
+            // direct weights (level 1, up to 128 of them): a byte per thread (huf_write_tree_w's layout)
+            const bool direct_w = !try_fse && (u32)lastw >= 1 && (u32)lastw <= 128;
+            if (!hit && direct_w) {
+                const u32 nw = (u32)lastw;
+                if (sym == 0) { ws.tree[0] = (u8)(127 + nw); ws.tb = 1 + (nw + 1) / 2; }
+                if (2 * sym < nw) ws.tree[1 + sym] = (u8)((ws.wt[2 * sym] << 4) | (2 * sym + 1 < nw ? ws.wt[2 * sym + 1] : 0));
+            }
+            else if (!hit && threadIdx.x == 0) ws.tb = huf_write_tree_w(ws.tree, ws.wt, (u32)lastw, ws.tmp, ws.fse, try_fse != 0);
             if (cache && sample_stride) {
                 __syncthreads();
                 ZTreeEntry *ce = &cache->e[blockIdx.x];
@@ -784,7 +831,7 @@ __device__ __forceinline__ void zenc_flat4_stream(u8 *out, const u8 *s, u32 n, c
 // LZ-coded blocks (mode[b] != 0) take their literals from L.lits with the plan / codes / tree of those literals (plan1 ...)
 // and append the Sequences_Section made by k_lz_seqenc; all other blocks are coded from src as literal-only blocks.
 struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u16 *codes1; const u8 *trees1; LzBufs B; u32 not_last; };   // not_last: the frame continues behind these blocks (a shard's part of a frame)
-struct ZencJob { const u8 *src; size_t n; u32 nblk, frame_wlog; ZEncPlan *plan; u16 *codes; u8 *trees; u64 *offs; u64 hdr; int with_magic, empty; ZWriteLz L; };
+struct ZencJob { const u8 *src; size_t n; u32 nblk, frame_wlog; ZEncPlan *plan; u16 *codes; u8 *trees; u64 *offs; u64 hdr; int with_magic, empty; ZWriteLz L; bool direct; };
 __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nblk, const ZEncPlan *plan, const u16 *codes_g, const u8 *trees,
                                                     const u64 *offs, u8 *dst, u64 frame_hdr, ZWriteLz L)
 {
@@ -793,11 +840,16 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
     __shared__ __attribute__((aligned(16))) u8 orows[64 * ZENC_OROW];
     int lane = threadIdx.x;
     u32 b0 = blockIdx.x * ZENC_BLOCKS_PER_WG;
+    {   // nothing but direct blocks (k_zenc_write_direct's): one look at the sixteen plans instead of three walks over them
+        const u32 bb = b0 + (u32)lane;
+        const bool other = lane < ZENC_BLOCKS_PER_WG && bb < nblk && !(plan[bb].kind == ZK_HUF && plan[bb].pad == 2 && !(L.mode && L.mode[bb]));
+        if (__ballot(other) == 0) return;
+    }
     for (u32 jj = 0; jj < ZENC_BLOCKS_PER_WG; jj++) {               // code tables made by k_zenc_plan: 512 B per block, coalesced
         u32 bb = b0 + jj;
         if (bb >= nblk) break;
         const bool lzb = L.mode && L.mode[bb];
-        if ((lzb ? L.plan1[bb].kind : plan[bb].kind) != ZK_HUF) continue;
+        if ((lzb ? L.plan1[bb].kind : plan[bb].kind) != ZK_HUF || (!lzb && plan[bb].pad == 2)) continue;
         const uint4 *g = (const uint4 *)((lzb ? L.codes1 : codes_g) + (u64)bb * 256);
         if (lane < 32) ((uint4 *)codes[jj])[lane] = g[lane];
     }
@@ -809,6 +861,7 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
         if (L.mode && L.mode[bb]) continue;
         const ZEncPlan p = plan[bb];
         if (p.kind != ZK_HUF || !p.pad) continue;
+        if (p.pad == 2) continue;                                     // a direct block: prefix and streams are k_zenc_write_direct's
         u8 *out = dst + frame_hdr + offs[bb];
         const u64 lo = zenc_block_lo(n, nblk, bb);
         if (lane == 0) { zenc_write_block_prefix(out, p, trees + (u64)bb * ZENC_TREE_SLOT, bb + 1 == nblk && !L.not_last, src[lo]); out[p.csize - 1] = 0; }
@@ -867,6 +920,27 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
         for (u32 i = lane * 8; i + 8 <= bn; i += 64 * 8) st64(o + i, ld64(s + i));
         for (u32 i = (bn & ~7u) + lane; i < bn; i += 64) o[i] = s[i];
     }
+}
+
+// Direct blocks (plan.pad == 2; enc.hip: direct_word): stream q of block b is ready in bytes [4096 q, 4096 q + 4096) of the block's 32 KiB
+// of src; it moves to its place behind the block's prefix (written here too) and the end mark follows it.  A workgroup per block, a
+// wavefront per stream, a lane's four 16-byte loads in flight together.
+__global__ __launch_bounds__(256) void k_zenc_write_direct(const u8 *src, u32 nblk, const ZEncPlan *plan, const u8 *trees, const u64 *offs, u8 *dst, u64 frame_hdr, u32 not_last)
+{
+    const u32 b = blockIdx.x, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const ZEncPlan p = plan[b];
+    if (p.kind != ZK_HUF || p.pad != 2) return;
+    u32 o = 3 + p.lhdr + p.tree_bytes + 6;
+    for (u32 k = 0; k < q; k++) o += p.ssz[k];
+    const uint4 *in = (const uint4 *)(src + ((u64)b << 15) + 4096u * q);
+    u8 *out = dst + frame_hdr + offs[b], *so = out + o;
+    if (threadIdx.x == 255) { zenc_write_block_prefix(out, p, trees + (u64)b * ZENC_TREE_SLOT, b + 1 == nblk && !not_last, 0); out[p.csize - 1] = 0; }
+    uint4 v[4];
+#pragma unroll
+    for (u32 r = 0; r < 4; r++) v[r] = in[r * 64 + lane];
+#pragma unroll
+    for (u32 r = 0; r < 4; r++) __builtin_memcpy(so + 16u * (r * 64 + lane), &v[r], 16);
+    if (lane == 0) so[4096] = 1;
 }
 
 __global__ void k_zenc_frame_header(u8 *dst, int with_magic, u32 wlog)
@@ -955,7 +1029,7 @@ extern "C" size_t naf_gpu_zstd_compress_bound(size_t n)
 // with_magic: 1 = whole frame with its magic number, 0 = whole frame without it (as stored in a .naf section),
 //   ZENC_PART | ZENC_PART_FIRST | ZENC_PART_LAST = a shard's part of a frame: blocks only, behind the 2-byte frame header when
 //   FIRST, ending the frame when LAST (an empty part that is not LAST is zero bytes; an empty LAST part is one empty Raw block).
-int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int with_magic, int lz, int block_log_hint, int window_log, ZencJob **job)
+int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int with_magic, int lz, int block_log_hint, int window_log, ZencJob **job, const u8 *direct, u32 nd)
 {
     ZencJob *J = new ZencJob; *job = J;                          // released by zstd_encode_finish
     memset(J, 0, sizeof *J);
@@ -1016,9 +1090,11 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     if (cache) HIP_TRY(c, hipMemsetAsync(cache, 0, sizeof(ZTreeCache), c->stream));
     // the packed 4-bit stream: blocks of pure A C G T near four bits of entropy are settled by a wave each, without the planner
     u8 *done = nullptr;
+    if (direct && (use_lz || block_log != 15 || nblk != nd || n != (size_t)nd << 15 || prefer_flat < 2 || !zenc_flat16().tb))
+        return ctx_fail(c, NAF_GPU_EARG, "direct blocks: the stream must be %u blocks of 32 KiB coded without the match finder", nd);
     if (prefer_flat >= 2 && n >= 2048 && zenc_flat16().tb) {
         done = (u8 *)arena_alloc(c, nblk); if (!done) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "zenc_flat_scan", k_zenc_flat_scan, cdiv(nblk, ZENC_FLATSCAN_WAVES), 64 * ZENC_FLATSCAN_WAVES, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, done, min_gain, prefer_flat, zenc_flat16());
+        LAUNCH(c, "zenc_flat_scan", k_zenc_flat_scan, cdiv(nblk, ZENC_FLATSCAN_WAVES), 64 * ZENC_FLATSCAN_WAVES, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, done, min_gain, prefer_flat, zenc_flat16(), direct);
     }
     if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done);
     LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done);
@@ -1062,6 +1138,7 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
         L.mode = mode; L.plan1 = plan1; L.codes1 = codes1; L.trees1 = trees1; L.B = B;
     }
     int rc = scan_exclusive_u64(c, offs, nblk, offs + nblk + 1); if (rc) return rc;
+    J->direct = direct != nullptr;
     J->nblk = nblk; J->plan = plan; J->codes = codes; J->trees = trees; J->offs = offs; J->hdr = hdr; J->with_magic = with_magic; J->frame_wlog = frame_wlog;
     return 0;
 }
@@ -1097,6 +1174,7 @@ static int zenc_finish(naf_gpu_ctx *c, ZencJob *J, u8 *d_dst, size_t cap, size_t
     if (hdr) LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, J->with_magic, J->frame_wlog);
     LAUNCH(c, "zenc_write", k_zenc_write, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, J->src, (u64)J->n, nblk, (const ZEncPlan *)J->plan, (const u16 *)J->codes, (const u8 *)J->trees,
            (const u64 *)J->offs, d_dst, hdr, J->L);
+    if (J->direct) LAUNCH(c, "zenc_write_direct", k_zenc_write_direct, nblk, 256, 0, J->src, nblk, (const ZEncPlan *)J->plan, (const u8 *)J->trees, (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
     if (!place && (rc = ctx_readback(c, &total, J->offs + nblk + 1, 8))) return rc;
     *out_len = hdr + total;
     return 0;

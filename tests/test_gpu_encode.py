@@ -682,3 +682,69 @@ def test_concurrent_sections_on_small_inputs_and_when_the_archive_does_not_fit(g
     buf = torch.empty(n, dtype=torch.uint8, device=text.device)
     got, _ = gpu.ennaf(text, out=buf)
     assert torch.equal(got, whole)
+
+
+def test_direct_blocks_of_the_sequence_stream(gpu, oracle, monkeypatch, capfd):
+    """Blocks of 32 KiB of the packed stream whose tiles are regular and pure A C G T take their four streams of 4-bit codes straight
+    from the scatter pass (enc.hip: k_direct_blocks, direct_word; zstd_enc.hip: plan.pad == 2).  NAF_GPU_DIRECT=2 lets inputs of two
+    blocks take the path (NAF_GPU_PROBE=0: no block is kept back for the look at the stream): stream parity with the oracle, the
+    decoded text, and the same text as without direct blocks -- around N runs, IUPAC letters, lower case, headers, CRLF, low-entropy
+    stretches (not direct: Huffman coding wins there), odd base counts and every line width's phase against the 16-base groups."""
+    rng = np.random.default_rng(2024)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    def seq(n, p=None):
+        return bytes(rng.choice(acgt, n, p=p))
+    def wrap(b, w, eol=b"\n"):
+        return eol.join(b[i:i + w] for i in range(0, len(b), w)) + eol
+    texts = []
+    texts.append(b">one record\n" + wrap(seq(1_500_001), 80))
+    texts.append(b">w60\n" + wrap(seq(700_000), 60) + b">w61 second record\n" + wrap(seq(650_001), 61) + b">w100\n" + wrap(seq(400_000), 100))
+    lower = seq(300_000).lower()
+    texts.append(b">runs\n" + wrap(seq(500_000) + b"N" * 100_000 + seq(400_000) + lower + seq(300_000) + b"RYKM" * 50 + seq(400_000), 70))
+    texts.append(b">low entropy in the middle\n" + wrap(seq(400_000) + seq(400_000, p=[0.48, 0.02, 0.02, 0.48]) + seq(400_003), 80))
+    texts.append(b">crlf part\r\n" + wrap(seq(300_000), 80, b"\r\n") + b">lf part\n" + wrap(seq(900_000), 80))
+    texts.append(b">exactly whole blocks\n" + wrap(seq(65536 * 6), 80))
+    texts.append(b">odd and whole blocks\n" + wrap(seq(65536 * 6 - 1), 80))
+    monkeypatch.setenv("NAF_GPU_PROBE", "0")
+    monkeypatch.setenv("NAF_GPU_DEBUG_DIRECT", "1")
+    counts = []
+    for text in texts:
+        monkeypatch.setenv("NAF_GPU_DIRECT", "2")
+        capfd.readouterr()
+        a = check_ennaf(gpu, oracle, text)
+        err = capfd.readouterr().err
+        k = [int(l.split()[1]) for l in err.splitlines() if l.startswith("[direct]")]
+        counts.append(k[0] if k else -1)
+        monkeypatch.setenv("NAF_GPU_DIRECT", "0")
+        b = check_ennaf(gpu, oracle, text)
+        assert abs(len(a) - len(b)) < 0.01 * len(b) + 40000
+        assert host(gpu.unnaf(gpu.to_device(a), 0)) == host(gpu.unnaf(gpu.to_device(b), 0))    # (one line width per archive: not the text itself)
+    assert counts[0] >= 9 and counts[1] >= 5 and counts[2] >= 8 and counts[5] >= 4, counts
+    assert counts[6] == -1                                        # an odd count of bases that fills its last block: left to the packed path
+    if oracle.have_ref():
+        monkeypatch.setenv("NAF_GPU_DIRECT", "2")
+        d_naf, _ = gpu.ennaf(gpu.to_device(texts[2]))
+        assert oracle.ref_unnaf(host(d_naf)) == texts[2]
+
+
+def test_direct_blocks_at_scale_and_when_the_stream_is_worth_matching(gpu, monkeypatch, capfd):
+    """The default path (from 8 MiB of packed bases up): most blocks direct, the blocks the look at the stream reads are not; a
+    repeat-rich input packs its bases again for the match finder."""
+    import torch
+    from naf_amd import synth
+    monkeypatch.setenv("NAF_GPU_DEBUG_DIRECT", "1")
+    fa = synth.realistic_genome_device(600_000_000, device="cuda")
+    capfd.readouterr()
+    d_naf, rep = gpu.ennaf(fa)
+    err = capfd.readouterr().err
+    k = [l.split() for l in err.splitlines() if l.startswith("[direct]")]
+    assert k and int(k[0][1]) > 0.5 * int(k[0][3]), err
+    assert torch.equal(gpu.unnaf(d_naf, 0), fa)
+    monkeypatch.setenv("NAF_GPU_DIRECT", "0")
+    d0, _ = gpu.ennaf(fa)
+    assert abs(d0.numel() - d_naf.numel()) < 0.005 * d0.numel()
+    monkeypatch.delenv("NAF_GPU_DIRECT")
+    rp = gpu.to_device(synth.repeat_genome(seed=5, unit=150_000, copies=240))
+    d_rp, _ = gpu.ennaf(rp)
+    assert d_rp.numel() < 0.05 * rp.numel()
+    assert torch.equal(gpu.unnaf(d_rp, 0), rp)
