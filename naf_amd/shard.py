@@ -202,9 +202,14 @@ class _Lap:
             self.t = now
 
 
+HEAD_WINDOW = 8192
+
+
 def _all_gather_bytes(raw: bytes, device, group):
-    """all_gather of one fixed-size record per rank."""
+    """all_gather of one fixed-size record per rank (a single rank: its own record, no device round trip)."""
     world = dist.get_world_size(group)
+    if world == 1:
+        return [bytes(raw)]
     t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
     outs = [torch.empty_like(t) for _ in range(world)]
     _all_gather(outs, t, group)
@@ -213,6 +218,8 @@ def _all_gather_bytes(raw: bytes, device, group):
 
 def _all_gather_ints(vals, device, group):
     world = dist.get_world_size(group)
+    if world == 1:
+        return [[int(x) for x in vals]]
     t = torch.tensor(list(vals), dtype=torch.int64, device=device)
     outs = [torch.empty_like(t) for _ in range(world)]
     _all_gather(outs, t, group)
@@ -229,17 +236,27 @@ def ennaf_sharded(ctx, d_buf, n, opts=None, dst=0, group=None, everywhere=False)
     rank = dist.get_rank(group)
     dev = d_buf.device
     lap = _Lap(dev)
-    # format and first record: rank 0 looks at its slice, everybody hears
+    # ONE exchange in front of the cut: the format and first record (rank 0 looks at its slice), every slice's size and its last byte
+    # (an EOL in front of a slice makes its position 0 a place where a line starts).  The last byte never visits the host on its own:
+    # it rides in the gathered record.
     meta = [0, 0]
     if rank == 0:
         meta = list(ctx.ennaf_sniff(d_buf[:n], opts.format))
-    meta = _all_gather_ints(meta, dev, group)[0]
-    fmt, p0 = meta
+    if world == 1:
+        first = [[meta[0], meta[1], n, -1]]
+    else:
+        rec = torch.tensor([meta[0], meta[1], n, -1], dtype=torch.int64, device=dev)
+        if n > (meta[1] if rank == 0 else 0):
+            rec[3] = d_buf[n - 1]
+        outs = [torch.empty_like(rec) for _ in range(world)]
+        _all_gather(outs, rec, group)
+        first = torch.stack(outs).cpu().tolist()
+    fmt, p0 = int(first[0][0]), int(first[0][1])
     if fmt == 0:
         # nothing but white space in the first slice.  The C host hands such an input to one device (naf_amd/host/ennaf.c: sh_fallback);
         # here the slices live on different ranks, so that only works when the other slices are empty too: rank 0 makes the archive
         # of "no records" with the one-call encoder, as the C host would
-        sizes = _all_gather_ints([n], dev, group)
+        sizes = [[int(f[2])] for f in first]
         if any(sz[0] for sz in sizes[1:]):
             raise ValueError("the first rank's slice holds no record start: give rank 0 the beginning of the text")
         arc, rep = ctx.ennaf(d_buf[:n], seq_type=opts.seq_type, fmt=opts.format, no_mask=bool(opts.no_mask), level=opts.level,
@@ -252,9 +269,7 @@ def ennaf_sharded(ctx, d_buf, n, opts=None, dst=0, group=None, everywhere=False)
             _broadcast(arc, dist.get_global_rank(group, 0) if group is not None else 0, group)
         return (arc if (everywhere or rank == dst) else None), rep, info
     lo = p0 if rank == 0 else 0
-    # byte in front of every slice: an EOL makes position 0 of the slice a place where a line starts
-    last = int(d_buf[n - 1].item()) if n > lo else -1
-    tails = _all_gather_ints([last], dev, group)
+    tails = [[int(f[3]) if int(f[2]) > (p0 if r == 0 else 0) else -1] for r, f in enumerate(first)]
     prev = 0x0A                                   # the byte "in front of" p0 counts as a line end
     for r in range(rank):
         if tails[r][0] >= 0:
@@ -274,14 +289,28 @@ def ennaf_sharded(ctx, d_buf, n, opts=None, dst=0, group=None, everywhere=False)
         cut = ctx.ennaf_find_cut(mine, fmt, prev_is_eol, skip) if mine.numel() else 0
     lap("lines+cut")
     # heads: the bytes in front of each rank's cut belong to the shard before it; a slice without a cut is all head
-    lens = _all_gather_ints([cut, mine.numel()], dev, group)
-    maxc = max(c for c, _ in lens)
+    # one exchange: (cut, slice size) and the first HEAD_WINDOW bytes of the slice (a cut lies a line or a record into the slice: nearly
+    # always inside the window); only a longer head costs a second exchange
     heads = None
-    if maxc:
-        h = torch.zeros(maxc, dtype=torch.uint8, device=dev)
-        h[:cut] = mine[:cut]
-        heads = [torch.empty_like(h) for _ in range(world)]
-        _all_gather(heads, h, group)
+    if world == 1:
+        lens = [[cut, int(mine.numel())]]
+    else:
+        rec = torch.zeros(16 + HEAD_WINDOW, dtype=torch.uint8, device=dev)
+        rec[:16] = torch.tensor([cut, int(mine.numel())], dtype=torch.int64).view(torch.uint8).to(dev)
+        k = min(cut, HEAD_WINDOW)
+        if k:
+            rec[16:16 + k] = mine[:k]
+        outs = [torch.empty_like(rec) for _ in range(world)]
+        _all_gather(outs, rec, group)
+        lens = [[int(x) for x in row] for row in torch.stack([o[:16] for o in outs]).cpu().view(torch.int64).tolist()]
+        maxc = max(c for c, _ in lens)
+        if maxc <= HEAD_WINDOW:
+            heads = [o[16:] for o in outs]
+        else:
+            h = torch.zeros(maxc, dtype=torch.uint8, device=dev)
+            h[:cut] = mine[:cut]
+            heads = [torch.empty_like(h) for _ in range(world)]
+            _all_gather(heads, h, group)
     borrow = []
     for r in range(rank + 1, world):
         c, ln = lens[r]
