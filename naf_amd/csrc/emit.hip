@@ -683,7 +683,7 @@ struct TileIdx { u64 gline, k, khi; u32 col, fast; };   // gline: base index of 
 // flat frames: the stream that holds the tile's first packed byte qf (first symbol q0, end-of-data bit address A) and the next
 // stream that has symbols (q1, A1; it ends at q2) -- a tile that would reach a third stream goes to the slow list
 struct TileFlat { u64 q0, A, q1, A1, q2, qf; };
-// What k_emit_tile_flat needs of a tile, worked out once by k_tile_classify in the place of the TileFlat record (same 48 bytes): the
+// What k_emit_tile_flat needs of a tile, worked out once by k_tile_index and stored as the tile's flat record (48 bytes): the
 // emit kernel ran this 64-bit arithmetic on the scalar unit of every one of its 2.4 M x 4 waves, ran out of scalar registers on it
 // (spills through v_readlane / v_writelane) and paid VALU compares for the 64-bit "less than" the scalar unit lacks.
 //   base     source address of bit `ub`, a multiple of eight bits that lies 4 * QM bits below the lower of the tile's two streams
@@ -695,74 +695,86 @@ struct TileFlat { u64 q0, A, q1, A1, q2, qf; };
 struct TileFlatE { u64 base, a1_addr; u32 a1_sh, K0, K1, d1, d2, qoff, par0, pad; };
 static_assert(sizeof(TileFlatE) == sizeof(TileFlat), "the derived record replaces the raw one in place");
 #define FLAT_QM 4096
-__global__ void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr, TileFlat *tsig)            // ntiles + 1 entries each; tsig: flat frames only
+// One pass makes a tile's record, classifies it and derives what the flat kernel needs (until round 3: k_tile_index wrote raw records,
+// k_tile_classify read them and their neighbours back -- 2.4 M tiles x 80 bytes written, read and written again were most of the two
+// kernels' 164 us in front of a 10 GB emit).  A tile's class needs two values of the tile BEHIND it (its record number and its first
+// toggle): a workgroup does 255 tiles and its last thread the next workgroup's first one once more, handing it over through LDS.
+//   ti[t], tr[t] for t <= ntiles; ti[t].fast = 0 and a harmless flat record for the `spare` entries behind (the flat kernel's workgroups
+//   read whole groups of records).
+// fast = 1: the whole tile lies in the body of one record (and the next tile starts in the same record, so that the record's final
+// newline is not in it) -- tile kernel of the launch (k_emit_tile, or k_emit_tile_flat reading the frame in place); 2: such a tile of a
+// mostly-flat frame over blocks that were decoded -- k_emit_tile_list takes those from `list2`; 0: k_emit_rest (`list`).
+#define TILE_WG 255
+__global__ __launch_bounds__(256) void k_tile_index(EmitP P, u64 ntiles, TileIdx *ti, u64 *tr, u32 *list, u32 *count, TileFlat *tsig, u32 spare, u32 *list2)
 {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > ntiles) return;
-    u64 p = P.out_begin + t * 4096;
-    TileIdx x; x.fast = 0; x.gline = 0; x.khi = 0;             // (fast: between index and classify, for flat frames, the class bits of the blocks under the tile)
-    if (p >= P.out_end) { tr[t] = ~0ull; x.k = P.n_toggles; x.col = TI_HDR; ti[t] = x; return; }
-    u64 g;
-    if (P.mode == EM_SEQ) { tr[t] = 0; x.col = 0; g = p; x.gline = p; }
-    else {
-        u64 r = upper_bound_u64(P.rec_out, 0, P.N + 1, p) - 1;
-        u64 off = p - P.rec_out[r], hl = P.hdr_len[r], len = P.rec_len[r], j = 0;
-        tr[t] = r; x.col = TI_HDR;
-        if (off >= hl) {
-            u64 q = off - hl;
-            if (P.mode == EM_FASTA && P.L) {
-                u64 line = q / (P.L + 1), col = q - line * (P.L + 1);
-                j = line * P.L + (col < P.L ? col : P.L);
-                if (P.L < 0xFFFFFFF0ull) { x.gline = P.rec_base[r] + line * P.L; x.col = (u32)col; }
-            } else if (P.mode != EM_FASTQ) { j = q; x.col = 0; x.gline = P.rec_base[r] + q; }
-            if (j > len) j = len;
+    __shared__ u64 s_k[256], s_r[256];
+    const u64 t = (u64)blockIdx.x * TILE_WG + threadIdx.x;
+    const u64 p = P.out_begin + t * 4096;
+    TileIdx x; x.fast = 0; x.gline = 0; x.khi = 0; x.k = P.n_toggles; x.col = TI_HDR;
+    TileFlat f; f.q0 = f.A = f.q1 = f.A1 = f.q2 = f.qf = 0;
+    u64 r = ~0ull; u32 cbits = 1;
+    const bool inside = t < ntiles && p < P.out_end;              // (t == ntiles and the spare entries: the record of "behind the text")
+    if (inside) {
+        u64 g;
+        if (P.mode == EM_SEQ) { r = 0; x.col = 0; g = p; x.gline = p; }
+        else {
+            r = upper_bound_u64(P.rec_out, 0, P.N + 1, p) - 1;
+            u64 off = p - P.rec_out[r], hl = P.hdr_len[r], len = P.rec_len[r], j = 0;
+            if (off >= hl) {
+                u64 q = off - hl;
+                if (P.mode == EM_FASTA && P.L) {
+                    u64 line = q / (P.L + 1), col = q - line * (P.L + 1);
+                    j = line * P.L + (col < P.L ? col : P.L);
+                    if (P.L < 0xFFFFFFF0ull) { x.gline = P.rec_base[r] + line * P.L; x.col = (u32)col; }
+                } else if (P.mode != EM_FASTQ) { j = q; x.col = 0; x.gline = P.rec_base[r] + q; }
+                if (j > len) j = len;
+            }
+            g = P.rec_base[r] + j;
         }
-        g = P.rec_base[r] + j;
+        x.k = P.masking ? upper_bound_u64(P.toggles, 0, P.n_toggles, g) : 0;
+        if (tsig) {                                              // slot of the stream that holds the tile's first packed byte
+            const FlatStream *si = (const FlatStream *)P.fsi;
+            const u64 q = g >> 1;
+            // streams of this build's frames hold 8192 symbols: slot q >> 13 is the answer or next to it; any other frame costs the
+            // gallop a few steps more than the plain binary search took (20 dependent loads per tile either way before)
+            u64 lo, hi, gs = q >> 13; if (gs >= P.fslots) gs = P.fslots - 1;
+            if (si[gs].q0 <= q) { lo = gs; hi = gs + 1; u64 st = 1; while (hi < P.fslots && si[hi].q0 <= q) { lo = hi; st <<= 1; hi = lo + st; } if (hi > P.fslots) hi = P.fslots; }
+            else { hi = gs; u64 st = 1; lo = gs - 1; while (lo > 0 && si[lo].q0 > q) { hi = lo; st <<= 1; lo = lo > st ? lo - st : 0; } }   // (gs >= 1: si[0].q0 = 0 <= q)
+            while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (si[mid].q0 <= q) lo = mid; else hi = mid; }
+            f.q0 = si[lo].q0; f.A = si[lo].A; f.qf = q;
+            if (P.fcls) {
+                // what the blocks under the tile's packed bytes [q, q + 2048 + 16] have in common (bit 0: readable in place, bit 1: decoded);
+                // four slots per block: block b starts at si[4 b].q0
+                u32 c = 3; u64 b = lo >> 2; const u64 nb = P.fslots >> 2, qe = q + 2048 + 16;
+                for (u32 k = 0; k < 6 && b < nb && si[4 * b].q0 <= qe; k++, b++) c &= P.fcls[b];
+                if (b < nb && si[4 * b].q0 <= qe) c = 0;              // more blocks than that (tiny ones): the slow way
+                cbits = c;
+            }
+            u64 cs = lo + 1;                                          // next slot that has symbols (single-stream blocks leave three empty)
+            while (cs < P.fslots && si[cs + 1].q0 == si[cs].q0) cs++;
+            f.q1 = si[cs].q0; f.A1 = cs < P.fslots ? si[cs].A : 0;
+            u64 ce = cs < P.fslots ? cs + 1 : cs;
+            while (ce < P.fslots && si[ce + 1].q0 == si[ce].q0) ce++;
+            f.q2 = si[ce].q0;
+        }
     }
-    x.k = P.masking ? upper_bound_u64(P.toggles, 0, P.n_toggles, g) : 0;
-    if (!tsig) { ti[t] = x; return; }
-    {                                                   // slot of the stream that holds the tile's first packed byte
-        const FlatStream *si = (const FlatStream *)P.fsi;
-        const u64 q = g >> 1;
-        u64 lo = 0, hi = P.fslots;
-        while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (si[mid].q0 <= q) lo = mid; else hi = mid; }
-        TileFlat f; f.q0 = si[lo].q0; f.A = si[lo].A; f.qf = q;
-        if (P.fcls) {
-            // what the blocks under the tile's packed bytes [q, q + 2048 + 16] have in common (bit 0: readable in place, bit 1: decoded);
-            // four slots per block: block b starts at si[4 b].q0
-            u32 c = 3; u64 b = lo >> 2; const u64 nb = P.fslots >> 2, qe = q + 2048 + 16;
-            for (u32 k = 0; k < 6 && b < nb && si[4 * b].q0 <= qe; k++, b++) c &= P.fcls[b];
-            if (b < nb && si[4 * b].q0 <= qe) c = 0;              // more blocks than that (tiny ones): the slow way
-            x.fast = c;
-        } else x.fast = 1;
-        u64 cs = lo + 1;                                          // next slot that has symbols (single-stream blocks leave three empty)
-        while (cs < P.fslots && si[cs + 1].q0 == si[cs].q0) cs++;
-        f.q1 = si[cs].q0; f.A1 = cs < P.fslots ? si[cs].A : 0;
-        u64 ce = cs < P.fslots ? cs + 1 : cs;
-        while (ce < P.fslots && si[ce + 1].q0 == si[ce].q0) ce++;
-        f.q2 = si[ce].q0;
-        tsig[t] = f;
-    }
-    ti[t] = x;
-}
-// fast = the whole tile lies in the body of one record (and the next tile starts in the same record, so that the
-// record's final newline is not in it); every other tile goes on the list of the segment-composing kernel
-// fast = 1: tile kernel of the launch (k_emit_tile, or k_emit_tile_flat reading the frame in place); 2: a tile of a mostly-flat frame
-// over blocks that were decoded -- k_emit_tile_list takes those from `list2`; 0: k_emit_rest (`list`)
-__global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr, u32 *list, u32 *count, TileFlat *tsig, u32 spare, u32 *list2)
-{
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    s_k[threadIdx.x] = x.k; s_r[threadIdx.x] = r;
+    __syncthreads();
+    if (threadIdx.x == TILE_WG) return;                          // (the next workgroup's first tile: done for its k and r only)
     TileFlatE e; e.base = (u64)P.fsrc; e.a1_addr = (u64)P.fsrc; e.a1_sh = 4; e.K0 = e.K1 = 0; e.d1 = e.d2 = 0x7FFFFFFFu; e.qoff = 0; e.par0 = 0; e.pad = 0;
-    if (t >= ntiles) {                                            // the spare records a workgroup of the emit kernel may read behind the last tile
-        if (tsig && t < ntiles + spare) { ti[t].fast = 0; *(TileFlatE *)&tsig[t] = e; }
+    if (t >= ntiles) {
+        if (t == ntiles) { tr[t] = ~0ull; ti[t] = x; if (tsig && spare) *(TileFlatE *)&tsig[t] = e; }
+        else if (tsig && t < ntiles + spare) { ti[t].fast = 0; *(TileFlatE *)&tsig[t] = e; }
         return;
     }
+    tr[t] = r;
+    if (!inside) { ti[t] = x; if (tsig) *(TileFlatE *)&tsig[t] = e; list[atomicAdd(count, 1u)] = (u32)t; return; }   // (cannot happen: ntiles covers the text)
+    const u64 r_next = s_r[threadIdx.x + 1];
+    x.khi = s_k[threadIdx.x + 1];
     const bool wrap = P.mode == EM_FASTA && P.L != 0;
-    bool fast = ti[t].col != TI_HDR && tr[t] == tr[t + 1] && P.out_begin + (t + 1) * 4096 <= P.out_end && !P.force_slow && (!wrap || P.L >= 16);
+    bool fast = x.col != TI_HDR && r == r_next && P.out_begin + (t + 1) * 4096 <= P.out_end && !P.force_slow && (!wrap || P.L >= 16);
     bool packed = false;
     if (tsig) {
-        const TileFlat f = tsig[t];
-        const u32 cbits = ti[t].fast;                              // from k_tile_index: 1 unless the frame has decoded blocks
         packed = fast && (cbits & 2);
         if (fast && !(cbits & 1)) fast = false;
         if (fast) {
@@ -771,7 +783,7 @@ __global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr,
             if (f.q2 != f.q1 && (f.A1 > f.A ? f.A1 - f.A : f.A - f.A1) >= (1ull << 29)) fast = false;   // both streams are addressed from one 32-bit base
         }
         if (fast) {
-            const u64 gline = ti[t].gline;
+            const u64 gline = x.gline;
             const u64 dd1 = f.q1 - f.qf, dd2 = f.q2 - f.qf;
             e.d1 = dd1 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)dd1; e.d2 = dd2 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)dd2;
             const u64 T0 = f.A - 4 * (f.qf - f.q0), T1 = f.A1 + 4 * (u64)e.d1;      // bit above the symbol at qrel = 0, in the first / second stream
@@ -786,8 +798,8 @@ __global__ void k_tile_classify(EmitP P, u64 ntiles, TileIdx *ti, const u64 *tr,
         }
         *(TileFlatE *)&tsig[t] = e;
     }
-    ti[t].khi = ti[t + 1].k;
-    ti[t].fast = fast ? 1u : (packed ? 2u : 0u);
+    x.fast = fast ? 1u : (packed ? 2u : 0u);
+    ti[t] = x;
     if (!fast) { if (packed) list2[atomicAdd(count + 1, 1u)] = (u32)t; else list[atomicAdd(count, 1u)] = (u32)t; }
 }
 
@@ -900,7 +912,7 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     // tile after the other, each waiting for its own records and then for its own codes, was four memory latencies in a row)
     TileIdx A[FLAT_TPW]; TileFlatE F[FLAT_TPW]; bool live[FLAT_TPW];
     {
-        // (both arrays have FLAT_TPW spare entries behind ntiles, made harmless by k_tile_classify; the workgroup's four records are
+        // (both arrays have FLAT_TPW spare entries behind ntiles, made harmless by k_tile_index; the workgroup's four records are
         // read as whole 16-byte words so that no field waits for a test on another one)
         static_assert(sizeof(TileIdx) == 32 && sizeof(TileFlatE) == 48, "records are read as 16-byte words");
         const u64 t0 = (u64)wg * FLAT_TPW;
@@ -919,7 +931,7 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     // ---- phase 1: where every chunk's codes are, and the loads.  A chunk needs the 36 bits under `top` (nine 4-bit codes; a bit
     // address inside the source buffer): the eight bytes at (top - 40) >> 3 hold them.  Everything here is 32-bit: bases count from
     // the tile's a.gline, packed bytes from its first one, bit addresses from a tile-wide base (TileFlatE, worked out by
-    // k_tile_classify); the load is scalar base + 32-bit lane offset.
+    // k_tile_index); the load is scalar base + 32-bit lane offset.
     // No branches here: a value that is only loaded on one path needs a copy where the paths join, and that copy waits for the load.
     // A tile that is not live (it goes to k_emit_rest, or lies behind the last one) has a record that points at the source's first bytes.
     u64 X[FLAT_TPW]; u32 offs[FLAT_TPW], grels[FLAT_TPW], nls[FLAT_TPW], haves[FLAT_TPW];
@@ -1650,8 +1662,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                 LAUNCH(ic, "unnaf_flat_pair", k_flat_pair, 1, 256, 0, pl.P, fpair);
                 pl.P.fpair = fpair;
             }
-            LAUNCH(ic, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1, 256), 256, 0, pl.P, ntiles, ti, tr, tsig);
-            LAUNCH(ic, "unnaf_tile_classify", k_tile_classify, cdiv(ntiles + FLAT_TPW, 256), 256, 0, pl.P, ntiles, ti, (const u64 *)tr, list, cnt, tsig, (u32)FLAT_TPW, list2);
+            LAUNCH(ic, "unnaf_tile_index", k_tile_index, cdiv(ntiles + 1 + FLAT_TPW, TILE_WG), 256, 0, pl.P, ntiles, ti, tr, list, cnt, tsig, (u32)FLAT_TPW, list2);
             // a mostly-flat frame: the blocks that are not flat are decoded now -- on the spare stream, beside the emit of the flat tiles
             naf_gpu_ctx *xc = c;                                                              // where the tiles over decoded blocks are emitted
             const bool flat_job = zflat.ready && zflat.later;
