@@ -621,19 +621,23 @@ __global__ __launch_bounds__(256) void k_emit_short(EmitP P, u8 *out)
 
 // ---- whole FASTQ text, record-parallel --------------------------------------------------------------------------------------
 // A read is five pieces at known offsets ('@' name '\n' | bases | "\n+\n" | qualities | '\n', output-fastq.c:100-149), so
-// when the whole text is wanted there is nothing to search: 16 lanes take one read and copy / expand its pieces 16 bytes per
+// when the whole text is wanted there is nothing to search: ER_LANES lanes take one read and copy / expand its pieces 16 bytes per
 // lane per step.  About 0.1 instructions per output byte against 37 for the chunk-composing kernel above, which stays for
 // byte-range calls and FASTA.
-#define ER_STAGE 16384u
-template <bool FOURBIT>
+#define ER_STAGE 24576u
+// ER_LANES lanes per read, 256 / ER_LANES reads per workgroup: a workgroup's time is two rounds of dependent loads whatever it moves, so
+// short reads go many to a workgroup (150-base reads, 4 GB of text: 3.8 ms with 16 lanes per read, 2.9 with 8, 2.4 with 4); the host picks
+// the widest grouping whose reads still fit the LDS stage on average.
+template <bool FOURBIT, u32 ER_LANES>
 __global__ __launch_bounds__(256) void k_emit_fastq_records(EmitP P, u8 *out)
 {
-    // the 16 reads of a workgroup are one contiguous piece of text: assembled in LDS (their pieces start at arbitrary byte
+    constexpr u32 ER_READS = 256u / ER_LANES;
+    // the reads of a workgroup are one contiguous piece of text: assembled in LDS (their pieces start at arbitrary byte
     // offsets) and written out as aligned 16-byte stores; only when it does not fit (long reads) the pieces go straight to HBM
     __shared__ __attribute__((aligned(16))) u8 stage[ER_STAGE + 32];
-    const u32 g = threadIdx.x & 15;
-    const u64 r0 = (u64)blockIdx.x * 16, r = r0 + (threadIdx.x >> 4);
-    const u64 rend = r0 + 16 < P.N ? r0 + 16 : P.N;
+    const u32 g = threadIdx.x & (ER_LANES - 1);
+    const u64 r0 = (u64)blockIdx.x * ER_READS, r = r0 + threadIdx.x / ER_LANES;
+    const u64 rend = r0 + ER_READS < P.N ? r0 + ER_READS : P.N;
     const u64 wbase = P.rec_out[r0], wspan = P.rec_out[rend] - wbase;
     const bool in_lds = wspan <= ER_STAGE;
     if (r < P.N) {
@@ -646,17 +650,17 @@ __global__ __launch_bounds__(256) void k_emit_fastq_records(EmitP P, u8 *out)
         if (P.has_names) { nm0 = r ? P.nmz[r - 1] + 1 : 0; nml = P.nmz[r] - nm0; }
         if (g == 0) { o[0] = P.hdr_char; o[hl - 1] = '\n'; }
         if (P.has_ids) {
-            group_copy(o + 1, P.ids + ids0, idl, g);
-            if (P.has_names && nml) { if (g == 0) o[1 + idl] = P.sep; group_copy(o + 2 + idl, P.names + nm0, nml, g); }
-        } else group_copy(o + 1, P.names + nm0, nml, g);
+            group_copy<ER_LANES>(o + 1, P.ids + ids0, idl, g);
+            if (P.has_names && nml) { if (g == 0) o[1 + idl] = P.sep; group_copy<ER_LANES>(o + 2 + idl, P.names + nm0, nml, g); }
+        } else group_copy<ER_LANES>(o + 1, P.names + nm0, nml, g);
         // bases, upper case always (unnaf.c:442: FASTQ output ignores the mask)
         u8 *os = o + hl;
-        for (u64 i = (u64)g * 16; i < len; i += 256) {
+        for (u64 i = (u64)g * 16; i < len; i += 16 * ER_LANES) {
             u64 lo, hi; bases16<FOURBIT>(P, base + i, lo, hi);
             store_upto16(os + i, lo, hi, len - i < 16 ? (u32)(len - i) : 16u);
         }
         if (g == 0) { os[len] = '\n'; os[len + 1] = '+'; os[len + 2] = '\n'; os[2 * len + 3] = '\n'; }
-        group_copy(os + len + 3, P.qual + base, len, g);
+        group_copy<ER_LANES>(os + len + 3, P.qual + base, len, g);
     }
     if (!in_lds) return;
     __syncthreads();
@@ -1622,8 +1626,20 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         if (ek && !strcmp(ek, "long")) short_rec = false;
         if (pl.P.force_slow) { short_rec = false; ek = "span"; }
         if (whole && pl.P.mode == EM_FASTQ && !pl.P.force_slow && !(ek && ek[0])) {
-            if (pl.fourbit) LAUNCH(c, "unnaf_emit_records", k_emit_fastq_records<true>, cdiv(pl.P.N, 16), 256, 0, pl.P, d_out);
-            else LAUNCH(c, "unnaf_emit_records", k_emit_fastq_records<false>, cdiv(pl.P.N, 16), 256, 0, pl.P, d_out);
+            {
+                const u64 avg = pl.P.N ? (pl.P.out_end - pl.P.out_begin) / pl.P.N + 1 : 1;        // bytes of text per read
+                const u32 lanes = avg * 64 <= ER_STAGE * 7 / 8 ? 4u : avg * 32 <= ER_STAGE * 7 / 8 ? 8u : 16u;
+                const u32 grid = (u32)cdiv(pl.P.N, 256u / lanes);
+                if (pl.fourbit) {
+                    if (lanes == 4) LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<true, 4>), grid, 256, 0, pl.P, d_out);
+                    else if (lanes == 8) LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<true, 8>), grid, 256, 0, pl.P, d_out);
+                    else LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<true, 16>), grid, 256, 0, pl.P, d_out);
+                } else {
+                    if (lanes == 4) LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<false, 4>), grid, 256, 0, pl.P, d_out);
+                    else if (lanes == 8) LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<false, 8>), grid, 256, 0, pl.P, d_out);
+                    else LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<false, 16>), grid, 256, 0, pl.P, d_out);
+                }
+            }
         } else if (short_rec) {
             if (pl.P.mode == EM_FASTA || pl.P.mode == EM_FASTQ) {
                 u64 nr = rec1 - rec0 + 1, htot = 0;

@@ -677,3 +677,16 @@ def test_mostly_flat_frame_at_scale_takes_the_two_phase_tables(gpu, monkeypatch,
     monkeypatch.setenv("NAF_GPU_FLAT_MIXED", "0")
     assert torch.equal(gpu.unnaf(d_naf, 0), t)
     monkeypatch.delenv("NAF_GPU_FLAT_MIXED")
+
+
+def test_fastq_record_kernel_groupings(gpu, oracle):
+    """k_emit_fastq_records takes 4, 8 or 16 lanes per read (64, 32 or 16 reads per workgroup, chosen from the mean text per read) and
+    writes a workgroup's reads through LDS when they fit: reads from a few bases to longer than the stage, fixed and variable length,
+    read counts that do not fill the last workgroup -- against the oracle's FASTQ text."""
+    from naf_amd import synth
+    for n, ln, var in ((1, 5, False), (63, 40, True), (65, 150, False), (1000, 150, True), (130, 300, False), (257, 330, True), (33, 700, False),
+                       (40, 1500, True), (17, 3000, False), (5, 9000, False), (9, 30000, True)):
+        text = synth.fastq_reads(n, ln, seed=n + ln, var_len=var)
+        naf = oracle.ennaf(text)
+        exp = oracle.unnaf(naf, 1)
+        assert host(gpu.unnaf(gpu.to_device(naf), 1)) == exp, (n, ln, var)
