@@ -323,16 +323,10 @@ static __device__ __forceinline__ u32 huf_flat_direct(const u8 *d, u32 len)
 // phase 0: every tree.  Phase 2: every tree not yet marked flat -- a long frame whose caller can read flat blocks in place first gets its
 // flat tree found and its repetitions marked (k_flat_find_main, k_flat_mark_owner: cheap), and the tables of the other trees are built
 // here later, on another stream beside the emit of the flat tiles: this one-lane-per-tree build is 0.45 ms whatever the number of trees.
-__global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table, const i32 *own_huf, u32 gate, u32 phase)
+// One tree by one lane, the weights and the builder's workspace in the lane's private arrays (scratch memory).
+static __device__ void build_huf_one_serial(const u8 *src, ZBlock *blk, u32 i, u8 *pool, u32 pool_cap, ZStat *st, u32 always_table)
 {
-    u32 i = first + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nblk) return;
-    if (gate && st->n_huf_distinct <= HUF_FEW) return;            // k_build_huf_few has this frame
-    if (own_huf[i] != (i32)i) return;                              // repeats its predecessor's tree (k_huf_dedup)
-    if (range4 && (i < (u32)range4[4] || i >= (u32)range4[1])) return;
-    if (blk[i].btype != BT_COMP || blk[i].lit_type != LIT_HUF || blk[i].err) return;
     const u8 *c = src + blk[i].src_off;
-    if (phase == 2 && blk[i].huf_flat) return;                     // the frame's flat tree and its repetitions: k_flat_find_main / k_flat_mark_owner had them
     {
         const u32 fl = always_table ? 0u : huf_flat_direct(c + blk[i].lit_off, blk[i].lit_csize);
         if (fl) {
@@ -355,6 +349,138 @@ __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 
     blk[i].huf_flat = flat; if (flat) atomicAdd(&st->n_flat, 1u);
     if (flat && log == 4) atomicMax(&st->flat_main_inv, 0xFFFFFFFFu - i);
     atomicAdd(&st->n_huf_built, 1u);
+}
+static __device__ __forceinline__ bool build_huf_wanted(const ZBlock *blk, u32 i, u32 nblk, const ZStat *st, const u64 *range4, const i32 *own_huf, u32 gate, u32 phase)
+{
+    if (i >= nblk) return false;
+    if (gate && st->n_huf_distinct <= HUF_FEW) return false;       // k_build_huf_few has this frame
+    if (own_huf[i] != (i32)i) return false;                        // repeats its predecessor's tree (k_huf_dedup)
+    if (range4 && (i < (u32)range4[4] || i >= (u32)range4[1])) return false;
+    if (blk[i].btype != BT_COMP || blk[i].lit_type != LIT_HUF || blk[i].err) return false;
+    if (phase == 2 && blk[i].huf_flat) return false;               // the frame's flat tree and its repetitions: k_flat_find_main / k_flat_mark_owner had them
+    return true;
+}
+__global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table, const i32 *own_huf, u32 gate, u32 phase)
+{
+    u32 i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (!build_huf_wanted(blk, i, nblk, st, range4, own_huf, gate, phase)) return;
+    build_huf_one_serial(src, blk, i, pool, pool_cap, st, always_table);
+}
+
+// The same job, sixteen lanes per tree (four trees per wavefront, one wavefront per workgroup): a frame of tens of thousands of distinct
+// trees -- a quality stream, a tree per block -- kept one lane per tree busy with private arrays in scratch memory for 1.8 ms (61 K
+// trees) in front of the first literal.  Directly stored weights (4.2.1.1: up to 128 of four bits) whose longest code fits the
+// single-level table are handled by the group: eight weights per lane in registers, weight groups ranked by shuffles, the table made
+// in LDS and copied out 16 bytes per lane.  FSE-coded weights and codes longer than HUF_FULL_LOG bits: the group's first lane, the old way.
+#define HUFG_TREES 4u
+__global__ __launch_bounds__(64) void k_build_huf16(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table, const i32 *own_huf, u32 gate, u32 phase)
+{
+    __shared__ __attribute__((aligned(16))) u16 s_tab[HUFG_TREES][HUF_TAB_MAX / 2];
+    const u32 lane = threadIdx.x, grp = lane >> 4, sl = lane & 15u;
+    const u32 i = first + blockIdx.x * HUFG_TREES + grp;
+    const bool want = build_huf_wanted(blk, i, nblk, st, range4, own_huf, gate, phase);
+    const u8 *d = src; u32 len = 0, hb = 0;
+    if (want) { d = src + blk[i].src_off + blk[i].lit_off; len = blk[i].lit_csize; hb = len ? d[0] : 0u; }
+    // 0: nothing to do, 1: the group builds, 2: the first lane builds the old way
+    u32 how = !want ? 0u : (hb >= 128 ? 1u : 2u);
+    const u32 n = hb >= 128 ? hb - 127 : 0u, nbytes = (n + 1) / 2;                // n explicit weights, symbols 0 .. n-1; symbol n is implied
+    if (how == 1 && 1 + nbytes > len) how = 2;                                    // (the old way reports it)
+    u32 w8 = 0;                                                                   // weights of symbols 8 sl .. 8 sl + 7, four bits each (symbol 8 sl + j at bits 4j)
+    if (how == 1) {
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) {
+            const u32 bi = 4 * sl + k;
+            if (bi < nbytes) { const u32 v = d[1 + bi]; w8 |= ((v >> 4) | ((2 * bi + 1 < n) ? (v & 15u) << 4 : 0u)) << (8 * k); }
+        }
+    }
+    u32 sum = 0, ones = 0; bool big = false;
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) { const u32 w = (w8 >> (4 * j)) & 15u; if (w > HUF_LOG_MAX) big = true; else if (w) sum += 1u << (w - 1); ones += w == 1; }
+    u32 over1 = 0;                                                                // some weight above 1
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) over1 |= ((w8 >> (4 * j)) & 15u) > 1u;
+    for (u32 dd = 1; dd < 16; dd <<= 1) { sum += (u32)__shfl_xor((int)sum, (int)dd, 64); ones += (u32)__shfl_xor((int)ones, (int)dd, 64); over1 |= (u32)__shfl_xor((int)over1, (int)dd, 64); }
+    const u64 gmask = 0xFFFFull << (16 * grp);
+    if (how == 1 && (__ballot(big) & gmask)) how = 2;
+    u32 log = 0, lastw = 0;
+    if (how == 1) {
+        // a flat tree recognised from its description (huf_flat_direct): no table, k_flat_literals reads the description itself
+        const u32 total = ones + 1;
+        if (!always_table && !over1 && total >= 2 && total <= 256 && !(total & (total - 1))) {
+            if (sl == 0) {
+                const u32 fl = (u32)hibit32(total);
+                blk[i].huf_tab = 0xFFFFFFFFu; blk[i].huf_log = (u8)fl; blk[i].huf_flat = 1;
+                atomicMax(&st->max_huf_log, fl); atomicAdd(&st->n_flat, 1u); atomicAdd(&st->n_huf_built, 1u);
+                if (fl == 4) atomicMax(&st->flat_main_inv, 0xFFFFFFFFu - i);
+            }
+            how = 0;
+        } else if (sum == 0) how = 2;
+        else {
+            log = (u32)hibit32(sum) + 1;
+            const u32 rest = (1u << log) - sum;
+            if (log > HUF_FULL_LOG || (rest & (rest - 1))) how = 2;                // compact tables and corrupt descriptions: the old way
+            else lastw = (u32)hibit32(rest) + 1;
+        }
+    }
+    if (how == 2 && sl == 0) build_huf_one_serial(src, blk, i, pool, pool_cap, st, always_table);
+    u16 *tab = s_tab[grp];
+    u32 pos = 0, n_w1 = 0;
+    if (how == 1) {
+        for (u32 r = 1; r <= log; r++) {                                          // weight groups in ascending order, symbols in index order inside a group
+            u32 m = 0;
+#pragma unroll
+            for (u32 j = 0; j < 8; j++) m |= (((w8 >> (4 * j)) & 15u) == r ? 1u : 0u) << j;
+            const u32 cnt = (u32)__popc(m);
+            u32 incl = cnt;
+            for (u32 dd = 1; dd < 16; dd <<= 1) { const u32 o = (u32)__shfl_up((int)incl, dd, 16); if (sl >= dd) incl += o; }
+            const u32 tot = (u32)__shfl((int)incl, 15, 16);
+            const u32 cells = 1u << (r - 1);
+            u32 rank = incl - cnt;
+            if (r == 1) n_w1 = tot + (lastw == 1);
+            if (cells <= 16) {
+                while (m) {
+                    const u32 j = (u32)__ffs((int)m) - 1; m &= m - 1;
+                    const u16 e = (u16)((log + 1 - r) | ((8 * sl + j) << 8));
+                    const u32 at = pos + rank * cells;
+                    for (u32 k = 0; k < cells; k++) tab[at + k] = e;
+                    rank++;
+                }
+                if (lastw == r && sl == 0) { const u16 e = (u16)((log + 1 - r) | (n << 8)); const u32 at = pos + tot * cells; for (u32 k = 0; k < cells; k++) tab[at + k] = e; }
+            } else {
+                // a few symbols of many cells each: the group fills them together, one symbol after the other
+                for (u32 owner = 0; owner < 16; owner++) {
+                    u32 mo = (u32)__shfl((int)m, (int)owner, 16); u32 rk = (u32)__shfl((int)rank, (int)owner, 16);
+                    while (mo) {
+                        const u32 j = (u32)__ffs((int)mo) - 1; mo &= mo - 1;
+                        const u16 e = (u16)((log + 1 - r) | ((8 * owner + j) << 8));
+                        const u32 at = pos + rk * cells;
+                        for (u32 k = sl; k < cells; k += 16) tab[at + k] = e;
+                        rk++;
+                    }
+                }
+                if (lastw == r) { const u16 e = (u16)((log + 1 - r) | (n << 8)); const u32 at = pos + tot * cells; for (u32 k = sl; k < cells; k += 16) tab[at + k] = e; }
+            }
+            pos += (tot + (lastw == r ? 1u : 0u)) * cells;
+        }
+    }
+    __syncthreads();
+    if (how == 1) {
+        const u32 bytes = huf_tab_bytes(log);
+        u32 off = 0;
+        if (sl == 0) off = atomicAdd(&st->huf_pool_used, bytes);
+        off = (u32)__shfl((int)off, 0, 16);
+        if (off + bytes > pool_cap) { if (sl == 0) set_err(st, ZE_POOL); return; }
+        uint4 *dst = (uint4 *)(pool + off);
+        for (u32 k = sl; k < bytes / 16; k += 16) dst[k] = ((const uint4 *)tab)[k];
+        if (sl == 0) {
+            blk[i].huf_tab = off; blk[i].huf_log = (u8)log;
+            atomicMax(&st->max_huf_log, log);
+            const bool flat = !over1 && lastw == 1 && log <= 8 && n_w1 == (1u << log);      // huf_is_flat
+            blk[i].huf_flat = flat; if (flat) atomicAdd(&st->n_flat, 1u);
+            if (flat && log == 4) atomicMax(&st->flat_main_inv, 0xFFFFFFFFu - i);
+            atomicAdd(&st->n_huf_built, 1u);
+        }
+    }
 }
 
 // The same for streams of a few blocks (ids, names, lengths, the last block of a mask stream): one block per workgroup, the tree
@@ -564,7 +690,7 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
     u32 rep_out[3];
     bool uses_rep = false;
     u8 e = zstd_decode_sequences(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tab,
-                                 o_ll + base, o_ml + base, o_of + base, rep_out, &sll, &sml, &uses_rep);
+                                 o_ll + base, o_ml + base, o_of + base, rep_out, &sll, &sml, &uses_rep, BitReloadWindow());
     if (e) { set_err(st, e); b.err = e; return; }
     if (uses_rep) atomicOr(&st->rep_slow, 2u);
     if (sll > b.lit_regen || b.lit_regen + sml > ZBLOCK_MAX) { set_err(st, ZE_CORRUPT); b.err = ZE_CORRUPT; return; }
@@ -1490,8 +1616,10 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
         }
         __syncthreads();
         for (u32 j = 0; j < n; j++) {
-            u32 mlj = (u32)__shfl((int)ml, (int)j, 64), ofj = (u32)__shfl((int)of, (int)j, 64);
-            u32 d = (u32)__shfl((int)(my_op + ll), (int)j, 64);
+            // (j is uniform: v_readlane, not a trip through the LDS crossbar three times per match)
+            const int ju = __builtin_amdgcn_readfirstlane((int)j);
+            u32 mlj = (u32)__builtin_amdgcn_readlane((int)ml, ju), ofj = (u32)__builtin_amdgcn_readlane((int)of, ju);
+            u32 d = (u32)__builtin_amdgcn_readlane((int)(my_op + ll), ju);
             u64 pos_abs = out_off + d;
             if (ofj == 0 || ofj > pos_abs) { bad = true; break; }                     // reaches before the frame start
             if (ofj <= d) {                                                            // source inside this block: LDS to LDS
@@ -1822,6 +1950,14 @@ static u32 huf_par_plog(u32 max_lit_regen, u64 n_blocks)
 static u32 huf_par_margin_env() { const char *m = getenv("NAF_GPU_HUF_MARGIN"); return m ? (u32)atoi(m) : 0u; }
 
 #define ZSTD_NEED_TWO_PASS (-100)
+// tables of many distinct trees: sixteen lanes per tree (NAF_GPU_HUF_BUILD16=0: one lane per tree, the cross-check)
+static int launch_build_huf(naf_gpu_ctx *c, u32 count, const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table, const i32 *own_huf, u32 gate, u32 phase)
+{
+    const char *e = getenv("NAF_GPU_HUF_BUILD16");
+    if (e && e[0] == '0') LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(count, 64), 64, 0, src, blk, nblk, pool, pool_cap, st, first, range4, always_table, own_huf, gate, phase);
+    else LAUNCH(c, "zstd_build_huf", k_build_huf16, cdiv(count, HUFG_TREES), 64, 0, src, blk, nblk, pool, pool_cap, st, first, range4, always_table, own_huf, gate, phase);
+    return 0;
+}
 static int zerr(naf_gpu_ctx *c, u32 e, const char *where)
 {
     const char *m = e == ZE_TRUNC ? "truncated" : e == ZE_CORRUPT ? "corrupt" : e == ZE_UNSUP ? "unsupported feature" : "table pool";
@@ -1963,7 +2099,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             // (a caller that can read flat blocks in place gets the flat trees recognised now and the other tables later: see phase 2 below)
             two_phase = c->zflat && !rg && !always_table;
             if (two_phase) LAUNCH(c, "zstd_build_huf", k_flat_find_main, 1, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, (const i32 *)own_huf);
-            else LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)r4, always_table, (const i32 *)own_huf, 1u, 0u);
+            else if ((rc = launch_build_huf(c, nblk, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)r4, always_table, (const i32 *)own_huf, 1u, 0u))) return rc;
         }
         ZSplit *sp = c->zsplit;
         if (sp && !rg && sp->parts >= 2) {
@@ -2054,7 +2190,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                         u32 max_log = hs0.max_huf_log;
                         if (pending && n_walk && !plog) {
                             // the one-lane-per-stream kernel takes its tables from the pool: the trees left out so far, now
-                            LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)nullptr, 0u, (const i32 *)own_huf, 1u, 2u);
+                            { int r3 = launch_build_huf(c, nblk, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)nullptr, 0u, (const i32 *)own_huf, 1u, 2u); if (r3) { if (c != mc) memcpy(mc->err, c->err, sizeof mc->err); return r3; } }
                             ZStat h2; int r2 = ctx_readback(c, &h2, st, sizeof h2);
                             if (r2) { if (c != mc) memcpy(mc->err, c->err, sizeof mc->err); return r2; }
                             if (h2.err) return zerr(mc, h2.err, "Huffman tables");
@@ -2086,7 +2222,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     }
     if (two_phase && hs.n_huf_distinct > HUF_FEW) {
         // not a frame for the in-place emit after all: the tables phase 1 left out, now
-        LAUNCH(c, "zstd_build_huf", k_build_huf, g, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)nullptr, 0u, (const i32 *)own_huf, 1u, 2u);
+        if ((rc = launch_build_huf(c, nblk, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)nullptr, 0u, (const i32 *)own_huf, 1u, 2u))) return rc;
         rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
         if (hs.err) return zerr(c, hs.err, "Huffman tables");
     }
@@ -2118,7 +2254,9 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         LAUNCH(c, "zstd_seq_list", k_seq_list, g, 64, 0, (const ZBlock *)blk, nblk, (const u64 *)flag, seq_list);
     }
     if (!lit_only_spec) {
-        LAUNCH(c, "zstd_decode_seq", k_decode_seq, g, 64, 0, d_src, blk, nblk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
+        // (a lane per block, every lane on a chain of its own: a frame of a few thousand blocks spreads over more wavefronts, 16 lanes each)
+        const u32 dsl = nblk < 32768 ? 16u : 64u;
+        LAUNCH(c, "zstd_decode_seq", k_decode_seq, cdiv(nblk, dsl), dsl, 0, d_src, blk, nblk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
                (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st);
         if (n_seq_blk) LAUNCH(c, "zstd_rep_fast", k_rep_fast, cdiv(n_seq_blk, 256), 256, 0, blk, (const u32 *)seq_list, n_seq_blk, st);
         if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
@@ -2192,7 +2330,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             huf_pool = (u8 *)arena_alloc(c, pool_cap);
             if (!huf_pool) return NAF_GPU_ENOMEM;
             if (hb_n && hb_n <= 512) LAUNCH(c, "zstd_build_huf", k_build_huf_lds, hb_n, 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first, (const i32 *)own_huf);
-            else if (hb_n) LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(hb_n, 64), 64, 0, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first, (const u64 *)nullptr, (always_table || fuse) ? 1u : 0u, (const i32 *)own_huf, 0u, 0u);
+            else if (hb_n) { if ((rc = launch_build_huf(c, hb_n, d_src, blk, hb_end, huf_pool, pool_cap, st, huf_first, (const u64 *)nullptr, (always_table || fuse) ? 1u : 0u, (const i32 *)own_huf, 0u, 0u))) return rc; }
             rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
             if (hs.err) return zerr(c, hs.err, "Huffman tables");
         }

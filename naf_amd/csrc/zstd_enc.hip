@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(con
 
 // blk_len == nullptr: block b is the b-th piece of the even split of src[0..n).  Otherwise block b is src[b*slot .. b*slot + blk_len[b])
 // (the literals the LZ stage left of block b).
-__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse, u32 min_gain, u32 maxbits, u32 prefer_flat, const u8 *done)
+__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse, u32 min_gain, u32 maxbits, u32 prefer_flat, const u8 *done, u8 *wt_defer)
 {
     // ZENC_HCOPIES copies of the 4 quarter histograms (copy = lane % copies): few distinct symbols (packed ACGT has 16) would
     // otherwise serialise every LDS atomic of a wave on the same handful of addresses
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
     __syncthreads();
     ZEncPlan p; p.n = bn; p.kind = ZK_RAW; p.csize = 3 + bn; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0;
     p.ssz[0] = p.ssz[1] = p.ssz[2] = p.ssz[3] = 0;
-    bool huf = false;
+    bool huf = false, defer = false;
     if (bn && distinct == 1) { p.kind = ZK_RLE; p.csize = 4; }
     else if (bn >= 64 && distinct >= 2) {
         // 2^k symbols whose two rarest together outweigh the commonest one (packed random bases: sixteen near-equal counts): every
@@ -356,11 +356,16 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
             }
             // direct weights (level 1, up to 128 of them): a byte per thread (huf_write_tree_w's layout)
             const bool direct_w = !try_fse && (u32)lastw >= 1 && (u32)lastw <= 128;
+            defer = wt_defer && !sample_stride && !hit && !direct_w && (u32)lastw >= 1;
             if (!hit && direct_w) {
                 const u32 nw = (u32)lastw;
                 if (sym == 0) { ws.tree[0] = (u8)(127 + nw); ws.tb = 1 + (nw + 1) / 2; }
                 if (2 * sym < nw) ws.tree[1 + sym] = (u8)((ws.wt[2 * sym] << 4) | (2 * sym + 1 < nw ? ws.wt[2 * sym + 1] : 0));
             }
+            // FSE-coded weights (mandatory above 128 of them: packed bases with an N among them reach symbol 0xFF) are a serial job of a
+            // few hundred dependent steps: one lane of this workgroup doing it kept the other 255 waiting -- 6.9 ms for the 30 K blocks of
+            // a FASTQ's sequence stream.  The weights go to k_zenc_tree, which codes the trees of 64 blocks per wavefront, a lane each.
+            else if (!hit && defer) wt_defer[(u64)b * 256 + sym] = ws.wt[sym];
             else if (!hit && threadIdx.x == 0) ws.tb = huf_write_tree_w(ws.tree, ws.wt, (u32)lastw, ws.tmp, ws.fse, try_fse != 0);
             if (cache && sample_stride) {
                 __syncthreads();
@@ -376,6 +381,11 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
             for (u32 k = 0; k < 4; k++) { wg_scan_inclusive<u64, OpAdd>((u64)hist[256 * k + sym] * l, &bits, red); p.ssz[k] = (u32)((bits + 1 + 7) / 8); }
             __syncthreads();
             u32 tb = ws.tb;
+            if (defer) {
+                // pending: k_zenc_tree makes the description and finishes the plan (log and the number of weights parked in the record)
+                huf = true; p.log = (u8)log; p.tree_bytes = (u16)lastw; p.lhdr = (u8)(try_fse != 0);
+                p.pad = (u8)(0x80u | ((log == 4 && distinct == 16) ? 1u : 0u));
+            } else
             if (tb) { zenc_plan_finish(p, bn, log, tb, min_gain); huf = p.kind == ZK_HUF; if (huf && log == 4 && distinct == 16) p.pad = 1; }   // pad = 1: sixteen 4-bit codes (k_zenc_write packs such a block with all lanes)
         }
     }
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
         // one weight group (2^log symbols of log bits): the code of a symbol is its rank among the symbols that occur
         const u32 l = ws.len[sym];
         codes[(u64)b * 256 + sym] = l ? (u16)(myidx | (l << 12)) : (u16)0;
-        if (sym < p.tree_bytes) trees[(u64)b * ZENC_TREE_SLOT + sym] = ws.tree[sym];
+        if (!defer && sym < p.tree_bytes) trees[(u64)b * ZENC_TREE_SLOT + sym] = ws.tree[sym];
     } else
     if (huf) {
         // canonical codes (huf_assign_codes): symbols of one weight take consecutive cells in symbol order, so the code of a
@@ -398,8 +408,31 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
         if (sym == 0) { u32 pos = 0; for (u32 w = 1; w <= p.log; w++) { wstart[w] = pos; pos += wcnt[w] << (w - 1); } }
         __syncthreads();
         codes[(u64)b * 256 + sym] = l ? (u16)(((wstart[wgt] >> (wgt - 1)) + rank) | (l << 12)) : (u16)0;   // code (<= 11 bits) | length << 12
-        if (sym < p.tree_bytes) trees[(u64)b * ZENC_TREE_SLOT + sym] = ws.tree[sym];
+        if (!defer && sym < p.tree_bytes) trees[(u64)b * ZENC_TREE_SLOT + sym] = ws.tree[sym];
     }
+}
+
+// Tree descriptions k_zenc_plan left pending (plan.pad bit 7): one LANE per block, 64 blocks per wavefront, the weight coder's workspace
+// of every lane in LDS at an odd word stride.  Finishes the plan (Huffman or Raw, sizes) exactly as k_zenc_plan would have.
+struct ZTreeLane { FseWS fse; u8 tmp[160]; u8 w[256]; u32 odd; };
+static_assert((sizeof(ZTreeLane) / 4) % 2 == 1, "odd word stride: the lanes' workspaces start in different LDS banks");
+__global__ __launch_bounds__(64) void k_zenc_tree(u32 nblk, ZEncPlan *plan, u8 *trees, u64 *csize, const u8 *wt_defer, u32 min_gain)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 tree_lds[];
+    const u32 b = blockIdx.x * 64 + threadIdx.x;
+    const bool pending = b < nblk && (plan[b].pad & 0x80u);
+    if (!__ballot(pending)) return;
+    if (!pending) return;
+    ZTreeLane &L = ((ZTreeLane *)tree_lds)[threadIdx.x];
+    ZEncPlan p = plan[b];
+    const u32 lastw = p.tree_bytes, log = p.log, try_fse = p.lhdr, flat16 = p.pad & 1u;
+    for (u32 k = 0; k < 256; k += 4) *(u32 *)(L.w + k) = *(const u32 *)(wt_defer + (u64)b * 256 + k);
+    u8 *tree = trees + (u64)b * ZENC_TREE_SLOT;
+    const u32 tb = huf_write_tree_w(tree, L.w, lastw, L.tmp, L.fse, try_fse != 0);
+    p.kind = ZK_RAW; p.csize = 3 + p.n; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0;
+    if (tb) { zenc_plan_finish(p, p.n, log, tb, min_gain); if (p.kind == ZK_HUF && flat16) p.pad = 1; }
+    plan[b] = p;
+    if (csize) csize[b] = p.csize;
 }
 
 // ======================= LZ stage (level >= 2; always for the id / name streams of an archive) ==============================
@@ -1096,8 +1129,12 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
         done = (u8 *)arena_alloc(c, nblk); if (!done) return NAF_GPU_ENOMEM;
         LAUNCH(c, "zenc_flat_scan", k_zenc_flat_scan, cdiv(nblk, ZENC_FLATSCAN_WAVES), 64 * ZENC_FLATSCAN_WAVES, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, done, min_gain, prefer_flat, zenc_flat16(), direct);
     }
-    if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done);
-    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done);
+    if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done, (u8 *)nullptr);
+    // (frames of a few blocks keep the tree with the planner: nothing to gain from a second launch)
+    const char *td = getenv("NAF_GPU_TREE_DEFER");
+    u8 *wt_defer = (nblk >= 256 && !(td && td[0] == '0')) ? (u8 *)arena_alloc(c, (size_t)nblk * 256) : nullptr;
+    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done, wt_defer);
+    if (wt_defer) LAUNCH(c, "zenc_tree", k_zenc_tree, cdiv(nblk, 64), 64, 64 * sizeof(ZTreeLane), nblk, plan, trees, offs, (const u8 *)wt_defer, min_gain);
     ZWriteLz &L = J->L;
     L.not_last = part && !part_last;
     if (use_lz && n >= 64) {
@@ -1133,7 +1170,8 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
             LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << LZ_HASH_LOG), d_src, (u64)n, nblk, B, lz_buf);
             LAUNCH(c, "zenc_lz_seqenc", k_lz_seqenc, cdiv(nblk, 64), 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
         }
-        LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse, min_gain, maxbits, 0u, (const u8 *)nullptr);
+        LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse, min_gain, maxbits, 0u, (const u8 *)nullptr, wt_defer);
+        if (wt_defer) LAUNCH(c, "zenc_tree", k_zenc_tree, cdiv(nblk, 64), 64, 64 * sizeof(ZTreeLane), nblk, plan1, trees1, (u64 *)nullptr, (const u8 *)wt_defer, min_gain);
         LAUNCH(c, "zenc_lz_choose", k_lz_choose, cdiv(nblk, 256), 256, 0, nblk, (const ZEncPlan *)plan, (const ZEncPlan *)plan1, (const u32 *)B.nseq, (const u32 *)B.seq_bytes, mode, offs);
         L.mode = mode; L.plan1 = plan1; L.codes1 = codes1; L.trees1 = trees1; L.B = B;
     }

@@ -690,3 +690,43 @@ def test_fastq_record_kernel_groupings(gpu, oracle):
         naf = oracle.ennaf(text)
         exp = oracle.unnaf(naf, 1)
         assert host(gpu.unnaf(gpu.to_device(naf), 1)) == exp, (n, ln, var)
+
+
+def test_tables_of_many_distinct_trees_sixteen_lanes_per_tree(gpu, oracle, monkeypatch):
+    """k_build_huf16 (zstd_dec.hip): frames of more than 16 K blocks and 2 K distinct trees get their tables from sixteen lanes per tree
+    -- directly stored weights with codes of up to HUF_FULL_LOG bits by the group, FSE-coded weights and longer codes by the group's
+    first lane the old way.  Quality-like, skewed (long codes), wide (symbols up to 255: FSE-coded weights), flat and two-symbol
+    alphabets in 1 KiB blocks, against the data, the one-lane-per-tree kernel and (a cut) the oracle."""
+    rng = np.random.default_rng(23)
+    p2 = np.array([2.0 ** -(i + 1) for i in range(30)])
+    n = 20_000_000
+    datas = [rng.integers(33, 74, n, dtype=np.uint8),
+             rng.choice(np.arange(30, dtype=np.uint8), n, p=p2 / p2.sum()),
+             rng.choice(np.array([0x11, 0x12, 0x21, 0x88, 0xFF, 0xF1, 0x1F, 0x44], dtype=np.uint8), n, p=[.3, .2, .2, .1, .05, .05, .05, .05]),
+             rng.integers(0, 16, n, dtype=np.uint8),
+             rng.choice(np.array([7, 200], dtype=np.uint8), n, p=[.9, .1]),
+             np.concatenate([rng.integers(0, 128, n // 2, dtype=np.uint8), rng.integers(0, 129, n // 2, dtype=np.uint8)])]
+    monkeypatch.setenv("NAF_GPU_LZ", "0")
+    for data in datas:
+        d = gpu.to_device(data.tobytes())
+        monkeypatch.setenv("NAF_GPU_BLOCK_LOG", "10")
+        frame = gpu.zstd_compress(d)
+        monkeypatch.delenv("NAF_GPU_BLOCK_LOG")
+        for flat in (None, "0"):
+            if flat is not None:
+                monkeypatch.setenv("NAF_GPU_FLAT", flat)
+            got = gpu.zstd_decompress(frame, n + 64)
+            assert got.numel() == n and bool((got == d).all())
+            monkeypatch.setenv("NAF_GPU_HUF_BUILD16", "0")
+            got = gpu.zstd_decompress(frame, n + 64)
+            assert got.numel() == n and bool((got == d).all())
+            monkeypatch.delenv("NAF_GPU_HUF_BUILD16")
+            if flat is not None:
+                monkeypatch.delenv("NAF_GPU_FLAT")
+        del got
+    # a cut of the first one under the oracle as well
+    cut = datas[0][:3_000_000].tobytes()
+    monkeypatch.setenv("NAF_GPU_BLOCK_LOG", "10")
+    f2 = host(gpu.zstd_compress(gpu.to_device(cut)))
+    monkeypatch.delenv("NAF_GPU_BLOCK_LOG")
+    assert oracle.zstd_decompress(f2, len(cut) + 16) == cut

@@ -748,3 +748,28 @@ def test_direct_blocks_at_scale_and_when_the_stream_is_worth_matching(gpu, monke
     d_rp, _ = gpu.ennaf(rp)
     assert d_rp.numel() < 0.05 * rp.numel()
     assert torch.equal(gpu.unnaf(d_rp, 0), rp)
+
+
+def test_tree_descriptions_coded_a_lane_per_block_give_the_same_frame(gpu, oracle, monkeypatch):
+    """k_zenc_tree (zstd_enc.hip): FSE-coded Huffman weights (mandatory above 128 of them, and the choice at levels >= 2) are coded
+    64 blocks per wavefront behind the planner instead of by one lane of each planner workgroup.  The frame is byte for byte the one
+    the planner alone makes (NAF_GPU_TREE_DEFER=0) and decodes under the oracle: packed bases with N (symbols up to 0xFF), a wide
+    alphabet, a quality-like one (direct weights at level 1, FSE at level 3) and incompressible bytes."""
+    rng = np.random.default_rng(5)
+    n = 12_000_000
+    pairs = np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88, 0xF1, 0x1F, 0xF8, 0x8F, 0xFF], dtype=np.uint8)
+    pp = np.array([6.0] * 16 + [0.5] * 4 + [0.04]); pp /= pp.sum()
+    datas = [rng.choice(pairs, n, p=pp), rng.integers(0, 200, n, dtype=np.uint8), rng.integers(33, 74, n, dtype=np.uint8), rng.integers(0, 256, 2_000_000, dtype=np.uint8)]
+    for data in datas:
+        d = gpu.to_device(data.tobytes())
+        for level in (1, 3):
+            monkeypatch.setenv("NAF_GPU_LZ", "0")
+            a = host(gpu.zstd_compress(d, level=level))
+            monkeypatch.setenv("NAF_GPU_TREE_DEFER", "0")
+            b = host(gpu.zstd_compress(d, level=level))
+            monkeypatch.delenv("NAF_GPU_TREE_DEFER")
+            monkeypatch.delenv("NAF_GPU_LZ")
+            assert a == b, (len(a), len(b), level)
+            if level == 1:
+                assert oracle.zstd_decompress(a[:], len(data) + 16) == data.tobytes()
+            assert host(gpu.zstd_decompress(gpu.to_device(a), len(data) + 64)) == data.tobytes()
