@@ -323,7 +323,7 @@ class Context:
         self._check(self.L.naf_gpu_set_timing(self.h, int(on)))
 
     def get_timing(self):
-        cap = 64
+        cap = 160
         names = (C.c_char_p * cap)()
         ms = (C.c_float * cap)()
         cnt = (C.c_int * cap)()

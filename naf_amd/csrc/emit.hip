@@ -113,6 +113,70 @@ __global__ __launch_bounds__(256) void k_mask_scatter(const u8 *units, u64 n, co
     for (u32 i = 0; i < valid; i++) { u32 u = (w[i >> 2] >> (8 * (i & 3))) & 0xFF; pos += u; if (u != 255) toggles[k++] = pos; }
 }
 
+// The mask of a text without (or almost without) lower case is a few KB of RLE blocks that regenerate tens of MB of 0xFF units, and the
+// general zstd pipeline -- index, parse, tables, copies, then k_mask_count / scans / k_mask_scatter: some 45 dependent launches and four
+// read-backs -- was what the tile index of a 10 GB decode waited for.  One workgroup takes the whole frame through LDS instead: a run
+// of n units of 255 moves the base position by 255 n, every other unit is a toggle.  Frames with a compressed block, more than `cap`
+// toggles or anything unexpected are left to the general path (res[0] = 0).  res: ok, toggles, units.
+#define MASK_RLE_SRC (48u * 1024u)
+#define MASK_RLE_TOG 8192u
+__global__ __launch_bounds__(256) void k_mask_rle_frame(const u8 *src, u32 len, u32 hdr, u64 expect_units, u64 *toggles, u32 cap, u64 *res)
+{
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
+    extern __shared__ __attribute__((aligned(16))) u8 mbuf[];
+    __shared__ u64 lds[4]; __shared__ u32 s_first;
+    const u32 t = threadIdx.x;
+    for (u32 i = t; i < len; i += 256) mbuf[i] = src[i];
+    if (t == 0) s_first = 0xFFFFFFFFu;
+    __syncthreads();
+    // the leading RLE blocks of 0xFF units, four bytes each: all of them at once
+    const u32 nA = len > hdr ? (len - hdr) / 4 : 0;
+    for (u32 i = t; i < nA; i += 256) {
+        const u32 p = hdr + 4 * i, h = (u32)mbuf[p] | ((u32)mbuf[p + 1] << 8) | ((u32)mbuf[p + 2] << 16);
+        if (!(((h >> 1) & 3) == 1 && !(h & 1) && mbuf[p + 3] == 255)) { atomicMin(&s_first, i); break; }   // (a thread's later blocks lie behind this one)
+    }
+    __syncthreads();
+    const u32 F = s_first < nA ? s_first : nA;
+    u64 mine = 0;
+    for (u32 i = t; i < F; i += 256) { const u32 p = hdr + 4 * i; mine += ((u32)mbuf[p] | ((u32)mbuf[p + 1] << 8) | ((u32)mbuf[p + 2] << 16)) >> 3; }
+    u64 units = 0;
+    wg_scan_inclusive<u64, OpAdd>(mine, &units, lds);
+    u64 base = 255ull * units;
+    // what follows (any RLE block, Raw blocks), block after block, every thread on the same block
+    u32 pos = hdr + 4 * F, nt = 0; bool ok = true, done = false;
+    while (ok && !done) {
+        if (pos + 3 > len) { ok = false; break; }
+        const u32 h = (u32)mbuf[pos] | ((u32)mbuf[pos + 1] << 8) | ((u32)mbuf[pos + 2] << 16);
+        const u32 last = h & 1, type = (h >> 1) & 3, size = h >> 3;
+        if (type == 1) {
+            if (pos + 4 > len) { ok = false; break; }
+            const u32 v = mbuf[pos + 3];
+            if (v != 255) {
+                if ((u64)nt + size > cap) { ok = false; break; }
+                for (u32 k = t; k < size; k += 256) toggles[nt + k] = base + (u64)v * (k + 1);
+                nt += size;
+            }
+            base += (u64)v * size; units += size; pos += 4;
+        } else if (type == 0) {
+            if ((u64)pos + 3 + size > len) { ok = false; break; }
+            const u8 *rb = mbuf + pos + 3;
+            const u32 per = (size + 255) / 256, lo = t * per < size ? t * per : size, hi = lo + per < size ? lo + per : size;
+            u64 sm = 0, cn = 0;
+            for (u32 k = lo; k < hi; k++) { const u32 u = rb[k]; sm += u; cn += u != 255; }
+            u64 tot_s, tot_c;
+            const u64 is = wg_scan_inclusive<u64, OpAdd>(sm, &tot_s, lds);
+            const u64 ic = wg_scan_inclusive<u64, OpAdd>(cn, &tot_c, lds);
+            if (nt + tot_c > cap) { ok = false; break; }
+            u64 at = base + is - sm; u32 idx = nt + (u32)(ic - cn);
+            for (u32 k = lo; k < hi; k++) { const u32 u = rb[k]; at += u; if (u != 255) toggles[idx++] = at; }
+            base += tot_s; nt += (u32)tot_c; units += size; pos += 3 + size;
+        } else ok = false;
+        if (last) done = true;
+    }
+    ok = ok && done && pos == len && units == expect_units;
+    if (t == 0) { res[0] = ok ? 1 : 0; res[1] = nt; res[2] = units; }
+}
+
 // per-record header length and text size
 __global__ void k_rec_sizes(u64 N, const u64 *rec_len, const u64 *idz, const u64 *nmz, int has_ids, int has_names,
                             int mode, u64 L, u32 *hdr_len, u64 *out_size, u64 *base_size)
@@ -1434,6 +1498,27 @@ static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gp
     auto mask_part = [&](naf_gpu_ctx *x) -> int {
         int r;
         u8 *mu = nullptr; u64 n_mask = h.orig_size[S_MASK];
+        {
+            // a frame of a few KB for MBs of units: Raw / RLE blocks, one launch (NAF_GPU_MASK_RLE=0: never)
+            const char *mr = getenv("NAF_GPU_MASK_RLE");
+            const u64 cs = h.comp_size[S_MASK];
+            if (cs >= 4 && cs <= MASK_RLE_SRC && n_mask >= 2 * cs && !(mr && mr[0] == '0')) {
+                // Frame_Header (RFC 8878 3.1.1.1) of a frame without dictionary and checksum: descriptor, window byte, content size
+                const u8 fhd = pl.frame_head[S_MASK][0];
+                const u32 fcs_flag = fhd >> 6, single = (fhd >> 5) & 1;
+                struct { u32 hdr_size; bool ok; } fh;
+                fh.hdr_size = 1 + (single ? 0 : 1) + (fcs_flag == 0 ? single : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8)));
+                fh.ok = !(fhd & 0x0F);                               // no reserved bit, no checksum, no dictionary id
+                if (fh.ok && fh.hdr_size < cs) {
+                    u64 *tg = arena_new<u64>(x, MASK_RLE_TOG + 1), *d_res = arena_new<u64>(x, 4);
+                    if (!tg || !d_res) return NAF_GPU_ENOMEM;
+                    LAUNCH(x, "unnaf_mask_rle", k_mask_rle_frame, 1, 256, (u32)((cs + 15) & ~15ull), d_naf + h.payload_off[S_MASK], (u32)cs, fh.hdr_size, n_mask, tg, MASK_RLE_TOG, d_res);
+                    u64 res[3] = { 0, 0, 0 };
+                    if ((r = ctx_readback(x, res, d_res, 24))) return r;
+                    if (res[0] == 1) { P.toggles = tg; P.n_toggles = res[1]; return 0; }
+                }
+            }
+        }
         if ((r = load_section(x, d_naf, h, S_MASK, n_mask, "mask", &mu, pl.frame_head[S_MASK]))) return r;
         u64 tiles = (n_mask + MT_TILE - 1) / MT_TILE;
         u64 *ts = arena_new<u64>(x, tiles + 2), *tc = arena_new<u64>(x, tiles + 2);

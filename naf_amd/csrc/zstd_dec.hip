@@ -39,6 +39,7 @@ static __device__ __forceinline__ u64 shfl_u64(u64 v, int l) { u32 lo = __shfl((
 // kernel of another stream fills the device, and the frames that come here are mostly a few hundred bytes.
 __global__ __launch_bounds__(64) void k_scan_blocks(const u8 *src, u64 len, u64 first_off, ZBlock *blk, u32 cap, ZStat *st, u32 win)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     extern __shared__ __attribute__((aligned(16))) u8 buf[];
     __shared__ u64 s_pos; __shared__ u32 s_n, s_err, s_done;
     if (threadIdx.x == 0) { s_pos = first_off; s_n = 0; s_err = 0; s_done = 0; }
@@ -126,8 +127,9 @@ __device__ __forceinline__ u64 spec_land(const u8 *src, u64 len, u64 pos, u64 st
 // 128 KiB blocks at ratios above 3.2), then the rest of the 128 KiB window for the chunks still without a candidate.
 #define SPEC_WINDOW0 (20u * 1024u)
 #define SPEC_WINDOW1 (40u * 1024u)
-__global__ __launch_bounds__(256) void k_spec_find(const u8 *src, u64 len, u32 nchunks, u64 *first, u32 w_lo, u32 w_hi, u32 chunk)
+__global__ __launch_bounds__(256) void k_spec_find(const u8 *src, u64 len, u32 nchunks, u64 *first, u32 w_lo, u32 w_hi, u32 chunk, const u32 *skip)
 {
+    if (skip && skip[1] == 1) return;                          // the stride index has the frame (k_stride_tail)
     const u32 tiles = (w_hi - w_lo + 4095) / 4096;
     u32 c = blockIdx.x / tiles + 1;                          // chunk 0 starts at the known first block
     if (c >= nchunks) return;
@@ -165,8 +167,9 @@ __global__ __launch_bounds__(256) void k_spec_find(const u8 *src, u64 len, u32 n
 }
 
 // land[c+1] = F_c(first[c]) ; first[0] is the known true start.
-__global__ void k_spec_land(const u8 *src, u64 len, const u64 *first, u32 nchunks, u64 *land, u32 chunk)
+__global__ void k_spec_land(const u8 *src, u64 len, const u64 *first, u32 nchunks, u64 *land, u32 chunk, const u32 *skip)
 {
+    if (skip && skip[1] == 1) return;
     u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     u64 s = first[c];
@@ -174,8 +177,9 @@ __global__ void k_spec_land(const u8 *src, u64 len, const u64 *first, u32 nchunk
     if (c == 0) land[0] = s;
 }
 // G[c] = F_c(land[c]) (reuses land[c+1] when the candidate already was the landing)
-__global__ void k_spec_land2(const u8 *src, u64 len, const u64 *first, const u64 *land, u32 nchunks, u64 *G, u32 chunk)
+__global__ void k_spec_land2(const u8 *src, u64 len, const u64 *first, const u64 *land, u32 nchunks, u64 *G, u32 chunk, const u32 *skip)
 {
+    if (skip && skip[1] == 1) return;
     u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     u64 l = land[c];
@@ -184,8 +188,10 @@ __global__ void k_spec_land2(const u8 *src, u64 len, const u64 *first, const u64
     else G[c] = spec_land(src, len, l, (u64)(c + 1) * chunk, nullptr);
 }
 // One wave: exact chunk starts.  start[c] for c in [0, nchunks], start[nchunks] = SPEC_END when the frame is well formed.
-__global__ void k_spec_resolve(const u8 *src, u64 len, const u64 *land, const u64 *G, u32 nchunks, u64 *start, ZStat *st, u32 chunk)
+__global__ void k_spec_resolve(const u8 *src, u64 len, const u64 *land, const u64 *G, u32 nchunks, u64 *start, ZStat *st, u32 chunk, const u32 *skip)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
+    if (skip && skip[1] == 1) return;
     int lane = threadIdx.x;
     u64 t = land[0];                                           // true start of chunk 0
     if (lane == 0) start[0] = t;
@@ -218,8 +224,9 @@ __global__ void k_spec_resolve(const u8 *src, u64 len, const u64 *land, const u6
 
 // WRITE=false: count blocks per chunk; WRITE=true: emit ZBlock records at count[c] (exclusive-scanned).
 template <bool WRITE>
-__global__ void k_spec_walk(const u8 *src, u64 len, const u64 *start, u32 nchunks, u64 *count, ZBlock *blk, ZStat *st)
+__global__ void k_spec_walk(const u8 *src, u64 len, const u64 *start, u32 nchunks, u64 *count, ZBlock *blk, ZStat *st, const u32 *skip)
 {
+    if (skip && skip[1] == 1) return;
     u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     u64 pos = start[c], lim = start[c + 1];
@@ -235,6 +242,49 @@ __global__ void k_spec_walk(const u8 *src, u64 len, const u64 *start, u32 nchunk
         }
     }
     if (!WRITE) count[c] = n;
+}
+
+// ---- stride index -------------------------------------------------------------------------------------------------------------
+// A stream of packed bases coded with fixed-width codes (this build's flat blocks, §4.6 of DESIGN.md) is a string of blocks of ONE
+// compressed size: block i starts at off0 + i S when the headers at off0, off0 + S, ... all repeat the first one (induction: a
+// header gives the next start).  k_stride_probe tests every such position at once, k_stride_tail walks what lies behind the first
+// mismatch (the shorter last block, the Raw block of an odd stream's last byte) -- a frame whose tail is longer than STRIDE_TAIL
+// blocks is left to the speculative index, whose kernels return at once when res[1] == 1.  res[0] = blocks of the prefix.
+#define STRIDE_TAIL 64u
+__global__ void k_stride_probe(const u8 *src, u64 len, u64 off0, u32 S, u32 h0, u32 nmax, u32 *res)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nmax) return;
+    const u64 pos = off0 + (u64)i * S;
+    const bool ok = pos + S <= len && ld24(src + pos) == h0;
+    const u64 bad = __ballot(!ok);
+    if (bad && (threadIdx.x & 63) == (u32)(__ffsll((long long)bad) - 1)) atomicMin(&res[0], i);
+}
+__global__ void k_stride_tail(const u8 *src, u64 len, u64 off0, u32 S, u32 nmax, u32 *res, ZBlock *blk, ZStat *st)
+{
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
+    if (threadIdx.x || blockIdx.x) return;
+    const u32 np = res[0] < nmax ? res[0] : nmax;
+    res[0] = np;
+    u64 pos = off0 + (u64)np * S; u32 n = 0; bool done = false;
+    while (n < STRIDE_TAIL) {
+        if (pos + 3 > len) break;
+        const u32 h = ld24(src + pos), last = h & 1, type = (h >> 1) & 3, size = h >> 3;
+        if (type == 3 || size > ZBLOCK_MAX) break;
+        const u32 csize = type == BT_RLE ? 1 : size;
+        if (pos + 3 + csize > len) break;
+        ZBlock &b = blk[np + n]; b.src_off = pos + 3; b.bsize = size; b.btype = (u8)type; b.last = (u8)last;
+        n++; pos += 3 + csize;
+        if (last) { done = true; break; }
+    }
+    res[1] = done ? 1u : 0u;
+    if (done) { st->nblk = np + n; st->end_off = pos; }
+}
+__global__ void k_stride_write(u64 off0, u32 S, u32 h0, const u32 *res, ZBlock *blk)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (res[1] != 1 || i >= res[0]) return;
+    ZBlock &b = blk[i]; b.src_off = off0 + (u64)i * S + 3; b.bsize = h0 >> 3; b.btype = (u8)((h0 >> 1) & 3); b.last = 0;
 }
 
 __global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_huf, i32 *own_ll, i32 *own_of, i32 *own_ml,
@@ -253,7 +303,7 @@ __global__ void k_parse_blocks(const u8 *src, ZBlock *blk, u32 nblk, i32 *own_hu
     own_ll[i] = (sq && b.modes[0] != SM_REPEAT) ? (i32)i : -1;
     own_of[i] = (sq && b.modes[1] != SM_REPEAT) ? (i32)i : -1;
     own_ml[i] = (sq && b.modes[2] != SM_REPEAT) ? (i32)i : -1;
-    seq_cnt[i] = sq ? b.nseq : 0;
+    seq_cnt[i] = sq ? (b.nseq + 3u) & ~3u : 0;                  // a block's sequences start at a multiple of four: k_decode_seq stores them 16 bytes at a time
     sizes[i] = b.regen;                                          // final unless the block has sequences (k_decode_seq then rewrites it)
     if (comp && b.lit_type == LIT_HUF) atomicAdd(&st->n_huf_def, 1u);
     if (comp && b.lit_type >= LIT_HUF) atomicMax(&st->max_lit_regen, b.lit_regen);
@@ -324,7 +374,14 @@ static __device__ __forceinline__ u32 huf_flat_direct(const u8 *d, u32 len)
 // flat tree found and its repetitions marked (k_flat_find_main, k_flat_mark_owner: cheap), and the tables of the other trees are built
 // here later, on another stream beside the emit of the flat tiles: this one-lane-per-tree build is 0.45 ms whatever the number of trees.
 // One tree by one lane, the weights and the builder's workspace in the lane's private arrays (scratch memory).
+struct HufSerialWS { u8 w[256]; HufBuildWS ws; };
+static __device__ void build_huf_one_serial_ws(const u8 *src, ZBlock *blk, u32 i, u8 *pool, u32 pool_cap, ZStat *st, u32 always_table, u8 *w, HufBuildWS &ws);
 static __device__ void build_huf_one_serial(const u8 *src, ZBlock *blk, u32 i, u8 *pool, u32 pool_cap, ZStat *st, u32 always_table)
+{
+    u8 w[256]; HufBuildWS ws;
+    build_huf_one_serial_ws(src, blk, i, pool, pool_cap, st, always_table, w, ws);
+}
+static __device__ void build_huf_one_serial_ws(const u8 *src, ZBlock *blk, u32 i, u8 *pool, u32 pool_cap, ZStat *st, u32 always_table, u8 *w, HufBuildWS &ws)
 {
     const u8 *c = src + blk[i].src_off;
     {
@@ -336,13 +393,13 @@ static __device__ void build_huf_one_serial(const u8 *src, ZBlock *blk, u32 i, u
             return;
         }
     }
-    u8 w[256]; u32 nw = 0, used = 0;
-    u32 log = huf_read_weights(c + blk[i].lit_off, blk[i].lit_csize, w, &nw, &used);
+    u32 nw = 0, used = 0;
+    u32 log = huf_read_weights_ws(c + blk[i].lit_off, blk[i].lit_csize, w, &nw, &used, ws);
     if (!log) { set_err(st, ZE_CORRUPT); blk[i].err = ZE_CORRUPT; return; }
     u32 bytes = huf_tab_bytes(log);
     u32 off = atomicAdd(&st->huf_pool_used, bytes);
     if (off + bytes > pool_cap) { set_err(st, ZE_POOL); return; }
-    huf_build_any((u16 *)(pool + off), w, nw, log);
+    huf_build_any_ws((u16 *)(pool + off), w, nw, log, ws);
     blk[i].huf_tab = off; blk[i].huf_log = (u8)log;
     atomicMax(&st->max_huf_log, log);
     const bool flat = huf_is_flat(w, nw, log);
@@ -372,11 +429,11 @@ __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 
 // trees) in front of the first literal.  Directly stored weights (4.2.1.1: up to 128 of four bits) whose longest code fits the
 // single-level table are handled by the group: eight weights per lane in registers, weight groups ranked by shuffles, the table made
 // in LDS and copied out 16 bytes per lane.  FSE-coded weights and codes longer than HUF_FULL_LOG bits: the group's first lane, the old way.
-#define HUFG_TREES 4u
-__global__ __launch_bounds__(64) void k_build_huf16(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table, const i32 *own_huf, u32 gate, u32 phase)
+#define HUFG_TREES 16u
+__global__ __launch_bounds__(256) void k_build_huf16(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table, const i32 *own_huf, u32 gate, u32 phase)
 {
     __shared__ __attribute__((aligned(16))) u16 s_tab[HUFG_TREES][HUF_TAB_MAX / 2];
-    const u32 lane = threadIdx.x, grp = lane >> 4, sl = lane & 15u;
+    const u32 lane = threadIdx.x & 63u, grp = threadIdx.x >> 4, sl = threadIdx.x & 15u;
     const u32 i = first + blockIdx.x * HUFG_TREES + grp;
     const bool want = build_huf_wanted(blk, i, nblk, st, range4, own_huf, gate, phase);
     const u8 *d = src; u32 len = 0, hb = 0;
@@ -400,19 +457,21 @@ __global__ __launch_bounds__(64) void k_build_huf16(const u8 *src, ZBlock *blk, 
 #pragma unroll
     for (u32 j = 0; j < 8; j++) over1 |= ((w8 >> (4 * j)) & 15u) > 1u;
     for (u32 dd = 1; dd < 16; dd <<= 1) { sum += (u32)__shfl_xor((int)sum, (int)dd, 64); ones += (u32)__shfl_xor((int)ones, (int)dd, 64); over1 |= (u32)__shfl_xor((int)over1, (int)dd, 64); }
-    const u64 gmask = 0xFFFFull << (16 * grp);
+    const u64 gmask = 0xFFFFull << (lane & 48u);
     if (how == 1 && (__ballot(big) & gmask)) how = 2;
     u32 log = 0, lastw = 0;
+    u32 g_log = 0, g_flat = 0, g_built = 0;                                      // what this group adds to the frame's counters (summed per workgroup:
+                                                                                  // tens of thousands of trees each doing four atomics on the same words took 1.5 ms)
     if (how == 1) {
         // a flat tree recognised from its description (huf_flat_direct): no table, k_flat_literals reads the description itself
         const u32 total = ones + 1;
         if (!always_table && !over1 && total >= 2 && total <= 256 && !(total & (total - 1))) {
+            const u32 fl = (u32)hibit32(total);
             if (sl == 0) {
-                const u32 fl = (u32)hibit32(total);
                 blk[i].huf_tab = 0xFFFFFFFFu; blk[i].huf_log = (u8)fl; blk[i].huf_flat = 1;
-                atomicMax(&st->max_huf_log, fl); atomicAdd(&st->n_flat, 1u); atomicAdd(&st->n_huf_built, 1u);
                 if (fl == 4) atomicMax(&st->flat_main_inv, 0xFFFFFFFFu - i);
             }
+            g_log = fl; g_flat = 1; g_built = 1;
             how = 0;
         } else if (sum == 0) how = 2;
         else {
@@ -422,7 +481,10 @@ __global__ __launch_bounds__(64) void k_build_huf16(const u8 *src, ZBlock *blk, 
             else lastw = (u32)hibit32(rest) + 1;
         }
     }
-    if (how == 2 && sl == 0) build_huf_one_serial(src, blk, i, pool, pool_cap, st, always_table);
+    // (the serial lane's weights and workspace in LDS: private arrays are scratch memory, and a kernel whose every wave wants a scratch
+    // allocation took 2.6 ms for 61 K trees and held up every other stream's launches meanwhile)
+    __shared__ HufSerialWS s_ws[HUFG_TREES];
+    if (how == 2 && sl == 0) build_huf_one_serial_ws(src, blk, i, pool, pool_cap, st, always_table, s_ws[grp].w, s_ws[grp].ws);
     u16 *tab = s_tab[grp];
     u32 pos = 0, n_w1 = 0;
     if (how == 1) {
@@ -463,22 +525,31 @@ __global__ __launch_bounds__(64) void k_build_huf16(const u8 *src, ZBlock *blk, 
             pos += (tot + (lastw == r ? 1u : 0u)) * cells;
         }
     }
+    // pool space and counters: one atomic of each kind per workgroup
+    __shared__ u32 s_bytes[HUFG_TREES], s_logs[HUFG_TREES], s_flat[HUFG_TREES], s_built[HUFG_TREES], s_base;
+    const u32 bytes = how == 1 ? huf_tab_bytes(log) : 0u;
+    const bool flat = how == 1 && !over1 && lastw == 1 && log <= 8 && n_w1 == (1u << log);      // huf_is_flat
+    if (how == 1) { g_log = log; g_flat = flat; g_built = 1; }
+    if (sl == 0) { s_bytes[grp] = bytes; s_logs[grp] = g_log; s_flat[grp] = g_flat; s_built[grp] = g_built; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 tb = 0, ml = 0, nf = 0, nb = 0;
+        for (u32 k = 0; k < HUFG_TREES; k++) { const u32 b = s_bytes[k]; s_bytes[k] = tb; tb += b; ml = s_logs[k] > ml ? s_logs[k] : ml; nf += s_flat[k]; nb += s_built[k]; }
+        s_base = tb ? atomicAdd(&st->huf_pool_used, tb) : 0u;
+        if (ml) atomicMax(&st->max_huf_log, ml);
+        if (nf) atomicAdd(&st->n_flat, nf);
+        if (nb) atomicAdd(&st->n_huf_built, nb);
+    }
     __syncthreads();
     if (how == 1) {
-        const u32 bytes = huf_tab_bytes(log);
-        u32 off = 0;
-        if (sl == 0) off = atomicAdd(&st->huf_pool_used, bytes);
-        off = (u32)__shfl((int)off, 0, 16);
+        const u32 off = s_base + s_bytes[grp];
         if (off + bytes > pool_cap) { if (sl == 0) set_err(st, ZE_POOL); return; }
         uint4 *dst = (uint4 *)(pool + off);
         for (u32 k = sl; k < bytes / 16; k += 16) dst[k] = ((const uint4 *)tab)[k];
         if (sl == 0) {
             blk[i].huf_tab = off; blk[i].huf_log = (u8)log;
-            atomicMax(&st->max_huf_log, log);
-            const bool flat = !over1 && lastw == 1 && log <= 8 && n_w1 == (1u << log);      // huf_is_flat
-            blk[i].huf_flat = flat; if (flat) atomicAdd(&st->n_flat, 1u);
+            blk[i].huf_flat = flat;
             if (flat && log == 4) atomicMax(&st->flat_main_inv, 0xFFFFFFFFu - i);
-            atomicAdd(&st->n_huf_built, 1u);
         }
     }
 }
@@ -589,6 +660,7 @@ __device__ void build_huf_one_lds(const u8 *src, ZBlock *blk, u32 i, u8 *pool, u
 }
 __global__ __launch_bounds__(64) void k_build_huf_lds(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const i32 *own_huf)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     __shared__ HufLdsWS S;
     u32 i = first + blockIdx.x;
     if (i >= nblk) return;
@@ -602,6 +674,7 @@ __global__ __launch_bounds__(64) void k_build_huf_lds(const u8 *src, ZBlock *blk
 #define FIND_MAIN_TREES 8u
 __global__ __launch_bounds__(64) void k_flat_find_main(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, const i32 *own_huf)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     __shared__ HufLdsWS S;
     if (st->n_huf_distinct <= HUF_FEW) return;
     u32 tried = 0;
@@ -617,6 +690,7 @@ __global__ __launch_bounds__(64) void k_flat_find_main(const u8 *src, ZBlock *bl
 // few owners it finds.  Does nothing when the frame has more than HUF_FEW distinct trees (k_build_huf has it then).
 __global__ __launch_bounds__(64) void k_build_huf_few(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, const u64 *range4, const i32 *own_huf)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     __shared__ HufLdsWS S;
     if (st->n_huf_distinct > HUF_FEW || st->n_huf_distinct == 0) return;     // (a stream of RLE / raw blocks -- an unmasked genome's mask -- has no tree at all)
     u32 lo = 0, hi = nblk;
@@ -662,6 +736,7 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
                              const u64 *seq_base, const FseE *pool, const FseE *predef,
                              u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     // the predefined tables (what this build's own LZ blocks use) in LDS: the lane's whole job is a chain of dependent table reads
     __shared__ FseE s_pre[160];
     for (u32 k = threadIdx.x; k < 160; k += blockDim.x) s_pre[k] = predef[k];
@@ -689,7 +764,17 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
     b.seq_base = base;
     u32 rep_out[3];
     bool uses_rep = false;
-    u8 e = zstd_decode_sequences(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tab,
+    u8 e;
+    if (blk[own[0][i]].modes[0] == SM_PREDEF && blk[own[1][i]].modes[1] == SM_PREDEF && blk[own[2][i]].modes[2] == SM_PREDEF) {
+        // the predefined tables (this build's LZ blocks at level 1): cells read from LDS as LDS -- through the table pointers of the general
+        // case, which may point into the pool in global memory, every look-up was a flat load
+        SeqTab tp[3];
+        tp[0].t = s_pre; tp[0].log = 6; tp[1].t = s_pre + 64; tp[1].log = 5; tp[2].t = s_pre + 96; tp[2].log = 6;
+        tp[0].rle = tp[1].rle = tp[2].rle = false; tp[0].rle_sym = tp[1].rle_sym = tp[2].rle_sym = 0;
+        e = zstd_decode_sequences<BitReloadWindow, true>(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tp,
+                                 o_ll + base, o_ml + base, o_of + base, rep_out, &sll, &sml, &uses_rep, BitReloadWindow());
+    } else
+    e = zstd_decode_sequences<BitReloadWindow, true>(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tab,
                                  o_ll + base, o_ml + base, o_of + base, rep_out, &sll, &sml, &uses_rep, BitReloadWindow());
     if (e) { set_err(st, e); b.err = e; return; }
     if (uses_rep) atomicOr(&st->rep_slow, 2u);
@@ -729,6 +814,7 @@ __global__ void k_rep_fast(ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, ZSta
 // One wave: 64 blocks per step are loaded coalesced, then composed lane by lane through shuffles.
 __global__ void k_rep_chain(ZBlock *blk, u32 nblk)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     int lane = threadIdx.x;
     u32 r0 = 1, r1 = 4, r2 = 8;                              // RFC 8878 3.1.1.5 initial repeat offsets
     for (u32 base = 0; base < nblk; base += 64) {
@@ -1505,6 +1591,7 @@ __global__ __launch_bounds__(64) void k_exec_seq(const ZBlock *blk, const u32 *s
                                                   const u32 *o_ll, const u32 *o_ml, const u32 *o_of,
                                                   const u8 *lit_scratch, u8 *dst, u32 *done, ZStat *st)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     __shared__ u32 sh_ticket;
     int lane = threadIdx.x;
     if (lane == 0) sh_ticket = atomicAdd(&st->ticket, 1u);
@@ -1584,6 +1671,7 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
                                                       const u32 *o_ll, const u32 *o_ml, const u32 *o_of,
                                                       const u8 *lit_scratch, u8 *dst, u32 *done, ZStat *st)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     __shared__ __attribute__((aligned(16))) u8 obuf[EXEC_LDS + 64];
     __shared__ u32 sh_ticket;
     const u32 lane = threadIdx.x;
@@ -1715,6 +1803,7 @@ __global__ void k_iota_u32(u32 *f, u32 n) { const u32 i = blockIdx.x * blockDim.
 // table is in force at c, [5] / [6] ranks of c / b_hi among the blocks with sequences.
 __global__ __launch_bounds__(64) void k_range_closure(const u32 *f, const u64 *offs, u32 nblk, const u64 *total_p, const u64 *r4, const i32 *own_huf, const u64 *seq_rank, u32 n_seq_blk, u64 *out)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     const u32 lane = threadIdx.x;
     const u32 b_lo = (u32)r4[0], b_hi = (u32)r4[1];
     u32 c = b_lo, lo = b_lo, hi = b_hi;
@@ -1844,6 +1933,7 @@ __device__ void small_frame_decode(const u8 *src, u32 len, u8 *dst, u32 cap, u8 
 }
 __global__ __launch_bounds__(64) void k_small_frame(const u8 *src, u32 len, u8 *dst, u32 cap, const FseE *predef, u32 *res)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     __shared__ __attribute__((aligned(16))) u8 s_src[SMALL_SRC + 16], s_out[SMALL_OUT + 16], s_lit[SMALL_OUT + 16];
     __shared__ u32 s_ll[SMALL_SEQ], s_ml[SMALL_SEQ], s_of[SMALL_SEQ];
     __shared__ HufBuildWS ws;
@@ -1868,6 +1958,7 @@ __global__ __launch_bounds__(64) void k_small_frame(const u8 *src, u32 len, u8 *
 struct SmallJobs { const u8 *src[4]; u8 *dst[4]; u32 len[4], cap[4]; };
 __global__ __launch_bounds__(64) void k_small_frames(SmallJobs J, const FseE *predef, u32 *res)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     __shared__ __attribute__((aligned(16))) u8 s_src[SMALL_SRC + 16], s_out[SMALL_OUT + 16], s_lit[SMALL_OUT + 16];
     __shared__ u32 s_ll[SMALL_SEQ], s_ml[SMALL_SEQ], s_of[SMALL_SEQ];
     __shared__ HufBuildWS ws;
@@ -1955,7 +2046,7 @@ static int launch_build_huf(naf_gpu_ctx *c, u32 count, const u8 *src, ZBlock *bl
 {
     const char *e = getenv("NAF_GPU_HUF_BUILD16");
     if (e && e[0] == '0') LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(count, 64), 64, 0, src, blk, nblk, pool, pool_cap, st, first, range4, always_table, own_huf, gate, phase);
-    else LAUNCH(c, "zstd_build_huf", k_build_huf16, cdiv(count, HUFG_TREES), 64, 0, src, blk, nblk, pool, pool_cap, st, first, range4, always_table, own_huf, gate, phase);
+    else LAUNCH(c, "zstd_build_huf", k_build_huf16, cdiv(count, HUFG_TREES), 256, 0, src, blk, nblk, pool, pool_cap, st, first, range4, always_table, own_huf, gate, phase);
     return 0;
 }
 static int zerr(naf_gpu_ctx *c, u32 e, const char *where)
@@ -2011,22 +2102,46 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     if (src_len >= 2048 && !(nospec && nospec[0] == '1')) {
         u32 nchunks = (u32)((src_len + chunk - 1) / chunk);
         u64 *first = arena_new<u64>(c, nchunks + 1), *land = arena_new<u64>(c, nchunks + 2), *G = arena_new<u64>(c, nchunks + 1);
-        u64 *start = arena_new<u64>(c, nchunks + 2), *cnt = arena_new<u64>(c, (size_t)nchunks + 2);
+        u64 *start = arena_new<u64>(c, nchunks + 2), *cnt = arena_new<u64>(c, (size_t)nchunks + 4);      // (+ the scan's total and the stride index's verdict behind it)
         if (!first || !land || !G || !start || !cnt) return NAF_GPU_ENOMEM;
         HIP_TRY(c, hipMemsetAsync(first, 0xFF, (size_t)nchunks * 8, c->stream));
         u64 *h0 = (u64 *)c->h_stage; *h0 = fh.hdr_size;
         HIP_TRY(c, hipMemcpyAsync(first, h0, 8, hipMemcpyHostToDevice, c->stream));
         u32 gl = cdiv(nchunks, 64);
+        // the stride index first (frames of more than 4 MiB whose first block is a compressed one that is not the last): three launches and
+        // a read-back; a frame it cannot take costs that read-back before the speculative index starts
+        {
+            const char *se = getenv("NAF_GPU_STRIDE_INDEX");
+            if (src_len > 4ull * SPEC_CHUNK && fh.hdr_size + 3 <= hl && !(se && se[0] == '0')) {
+                const u32 h0 = (u32)hb[fh.hdr_size] | ((u32)hb[fh.hdr_size + 1] << 8) | ((u32)hb[fh.hdr_size + 2] << 16);
+                const u32 S = 3 + (h0 >> 3);
+                const u64 nmax64 = (src_len - fh.hdr_size) / S;
+                if (((h0 >> 1) & 3) == BT_COMP && !(h0 & 1) && (h0 >> 3) <= ZBLOCK_MAX && S >= 256 && nmax64 >= 64 && nmax64 < 0x7FFFFF00ull) {
+                    const u32 nmax = (u32)nmax64;
+                    u32 *sres = (u32 *)(cnt + nchunks + 2); ZBlock *sblk = arena_new<ZBlock>(c, (size_t)nmax + STRIDE_TAIL);
+                    if (!sblk) return NAF_GPU_ENOMEM;
+                    HIP_TRY(c, hipMemsetAsync(sres, 0xFF, 8, c->stream));
+                    LAUNCH(c, "zstd_index_stride", k_stride_probe, cdiv(nmax, 256), 256, 0, d_src, (u64)src_len, (u64)fh.hdr_size, S, h0, nmax, sres);
+                    LAUNCH(c, "zstd_index_stride", k_stride_tail, 1, 64, 0, d_src, (u64)src_len, (u64)fh.hdr_size, S, nmax, sres, sblk, st);
+                    LAUNCH(c, "zstd_index_stride", k_stride_write, cdiv(nmax, 256), 256, 0, (u64)fh.hdr_size, S, h0, (const u32 *)sres, sblk);
+                    u32 res2[2] = { 0, 0 };
+                    rc = ctx_readback2(c, &hs, st, sizeof hs, res2, sres, 8); if (rc) return rc;
+                    if (res2[1] == 1u && !hs.err && hs.nblk) { blk = sblk; indexed = true; }
+                }
+            }
+        }
+        const u32 *skip = nullptr;
+        if (!indexed) {
         // the first block start of a chunk lies in its first 20 KiB whenever blocks compress to less than that (this build's 32 KiB
         // blocks of packed bases: 16 KiB); the passes behind it only run for the chunks still without a candidate
         const u32 win0 = chunk == SPEC_CHUNK ? SPEC_WINDOW0 : win1;
-        LAUNCH(c, "zstd_index_find", k_spec_find, cdiv(win0, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, 0u, win0, chunk);
-        if (win1 > win0) LAUNCH(c, "zstd_index_find2", k_spec_find, cdiv(win1 - win0, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, win0, win1, chunk);
-        if (win2 > win1) LAUNCH(c, "zstd_index_find2", k_spec_find, cdiv(win2 - win1, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, win1, win2, chunk);
-        LAUNCH(c, "zstd_index_land", k_spec_land, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, nchunks, land, chunk);
-        LAUNCH(c, "zstd_index_land2", k_spec_land2, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, (const u64 *)land, nchunks, G, chunk);
-        LAUNCH(c, "zstd_index_resolve", k_spec_resolve, 1, 64, 0, d_src, (u64)src_len, (const u64 *)land, (const u64 *)G, nchunks, start, st, chunk);
-        LAUNCH(c, "zstd_index_count", (k_spec_walk<false>), gl, 64, 0, d_src, (u64)src_len, (const u64 *)start, nchunks, cnt, (ZBlock *)nullptr, st);
+        LAUNCH(c, "zstd_index_find", k_spec_find, cdiv(win0, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, 0u, win0, chunk, skip);
+        if (win1 > win0) LAUNCH(c, "zstd_index_find2", k_spec_find, cdiv(win1 - win0, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, win0, win1, chunk, skip);
+        if (win2 > win1) LAUNCH(c, "zstd_index_find2", k_spec_find, cdiv(win2 - win1, 256 * 16) * (nchunks - 1), 256, 0, d_src, (u64)src_len, nchunks, first, win1, win2, chunk, skip);
+        LAUNCH(c, "zstd_index_land", k_spec_land, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, nchunks, land, chunk, skip);
+        LAUNCH(c, "zstd_index_land2", k_spec_land2, gl, 64, 0, d_src, (u64)src_len, (const u64 *)first, (const u64 *)land, nchunks, G, chunk, skip);
+        LAUNCH(c, "zstd_index_resolve", k_spec_resolve, 1, 64, 0, d_src, (u64)src_len, (const u64 *)land, (const u64 *)G, nchunks, start, st, chunk, skip);
+        LAUNCH(c, "zstd_index_count", (k_spec_walk<false>), gl, 64, 0, d_src, (u64)src_len, (const u64 *)start, nchunks, cnt, (ZBlock *)nullptr, st, skip);
         u64 *d_tot = cnt + nchunks + 1;
         if ((rc = scan_exclusive_u64(c, cnt, nchunks, d_tot))) return rc;
         u64 tot = 0;
@@ -2034,10 +2149,11 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         if (!hs.err && tot > 0 && tot < 0x7FFFFFFFull) {
             blk = arena_new<ZBlock>(c, tot);
             if (!blk) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "zstd_index_write", (k_spec_walk<true>), gl, 64, 0, d_src, (u64)src_len, (const u64 *)start, nchunks, cnt, blk, st);
+            LAUNCH(c, "zstd_index_write", (k_spec_walk<true>), gl, 64, 0, d_src, (u64)src_len, (const u64 *)start, nchunks, cnt, blk, st, (const u32 *)nullptr);
             hs.nblk = (u32)tot; indexed = true;
         } else {
             HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(ZStat), c->stream));     // not one well-formed frame for the parallel walk: serial walk decides
+        }
         }
     }
     if (!indexed) {

@@ -208,6 +208,10 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
     p.ssz[0] = p.ssz[1] = p.ssz[2] = p.ssz[3] = 0;
     bool huf = false, defer = false;
     if (bn && distinct == 1) { p.kind = ZK_RLE; p.csize = 4; }
+    // A mask block that is one unit repeated but for a few bytes (the end of an upper-case genome's mask: 0xFF units, then the rest of the
+    // run) stays Raw: the frame is then RLE and Raw blocks only, which this build's unnaf turns into toggles in one launch
+    // (emit.hip: k_mask_rle_frame) instead of taking it through the whole decoder -- for at most a block's bytes per stream.
+    else if (min_gain && bn >= 64 && __syncthreads_or(mine + 16 >= bn)) { }
     else if (bn >= 64 && distinct >= 2) {
         // 2^k symbols whose two rarest together outweigh the commonest one (packed random bases: sixteen near-equal counts): every
         // merge of the two-queue construction pairs leaves before it touches a node, level after level -- a balanced tree, every code
@@ -418,6 +422,7 @@ struct ZTreeLane { FseWS fse; u8 tmp[160]; u8 w[256]; u32 odd; };
 static_assert((sizeof(ZTreeLane) / 4) % 2 == 1, "odd word stride: the lanes' workspaces start in different LDS banks");
 __global__ __launch_bounds__(64) void k_zenc_tree(u32 nblk, ZEncPlan *plan, u8 *trees, u64 *csize, const u8 *wt_defer, u32 min_gain)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     extern __shared__ __attribute__((aligned(16))) u8 tree_lds[];
     const u32 b = blockIdx.x * 64 + threadIdx.x;
     const bool pending = b < nblk && (plan[b].pad & 0x80u);
@@ -455,6 +460,7 @@ struct LzBufs {
 // block size in use, since LDS per wavefront is what bounds the blocks in flight (16 KiB blocks: 6 per CU, 32 KiB: 3).
 __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk, LzBufs B, u32 buf_bytes)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     extern __shared__ __attribute__((aligned(16))) u8 lz_lds[];
     u8 *buf = lz_lds;
     u16 *tab = (u16 *)(lz_lds + buf_bytes);
@@ -530,6 +536,7 @@ __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk,
 // Sequences_Section of every block (one lane per block; predefined FSE encoding tables staged in LDS)
 __global__ __launch_bounds__(64) void k_lz_seqenc(u32 nblk, LzBufs B, const SeqCTabs *tabs)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     __shared__ SeqCTabs T;
     for (u32 i = threadIdx.x; i < sizeof(SeqCTabs) / 4; i += 64) ((u32 *)&T)[i] = ((const u32 *)tabs)[i];
     __syncthreads();
@@ -627,6 +634,7 @@ __device__ __forceinline__ u32 lzx_wave_back(const u8 *buf, const u8 *gblk, u64 
 
 __global__ __launch_bounds__(64) void k_lzx_parse(const u8 *src, u64 n, u32 nblk, LzBufs B, u32 buf_bytes, LdmTab L)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     extern __shared__ __attribute__((aligned(16))) u8 lz_lds[];
     u8 *buf = lz_lds;
     u16 *tab = (u16 *)(lz_lds + buf_bytes);
@@ -741,6 +749,7 @@ __global__ __launch_bounds__(64) void k_lzx_parse(const u8 *src, u64 n, u32 nblk
 // Sequences_Section of one block per wavefront: the tables live in LDS, lane 0 writes (zenc_write_sequences_x)
 __global__ __launch_bounds__(64) void k_lzx_seqenc(u32 nblk, LzBufs B, const SeqCTabs *tabs)
 {
+    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     __shared__ SeqCTabs T; __shared__ SeqWS ws;
     for (u32 i = threadIdx.x; i < sizeof(SeqCTabs) / 4; i += 64) ((u32 *)&T)[i] = ((const u32 *)tabs)[i];
     __syncthreads();

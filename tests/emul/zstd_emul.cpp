@@ -91,7 +91,7 @@ extern "C" long long emul_zstd_decompress_frame(const u8 *src, size_t len, u8 *d
         }
         sll[i].resize(b.nseq); sml[i].resize(b.nseq); sof[i].resize(b.nseq);
         u64 tl = 0, tm = 0; u32 ro[3];
-        u8 e = zstd_decode_sequences(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tab, sll[i].data(), sml[i].data(), sof[i].data(), ro, &tl, &tm, nullptr, BitReloadWindow());
+        u8 e = zstd_decode_sequences<BitReloadWindow, true>(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tab, sll[i].data(), sml[i].data(), sof[i].data(), ro, &tl, &tm, nullptr, BitReloadWindow());
         if (e) return -200 - e;
         if (tl > b.lit_regen) return -11;
         b.rep_out[0] = ro[0]; b.rep_out[1] = ro[1]; b.rep_out[2] = ro[2];
