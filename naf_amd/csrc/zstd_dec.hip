@@ -2112,6 +2112,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         // a read-back; a frame it cannot take costs that read-back before the speculative index starts
         {
             const char *se = getenv("NAF_GPU_STRIDE_INDEX");
+            if (getenv("NAF_GPU_DEBUG_STRIDE")) fprintf(stderr, "[stride?] len %zu hdr %u hl %zu first %02x %02x %02x\n", src_len, fh.hdr_size, hl, hb[fh.hdr_size], hb[fh.hdr_size + 1], hb[fh.hdr_size + 2]);
             if (src_len > 4ull * SPEC_CHUNK && fh.hdr_size + 3 <= hl && !(se && se[0] == '0')) {
                 const u32 h0 = (u32)hb[fh.hdr_size] | ((u32)hb[fh.hdr_size + 1] << 8) | ((u32)hb[fh.hdr_size + 2] << 16);
                 const u32 S = 3 + (h0 >> 3);
@@ -2127,6 +2128,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     u32 res2[2] = { 0, 0 };
                     rc = ctx_readback2(c, &hs, st, sizeof hs, res2, sres, 8); if (rc) return rc;
                     if (res2[1] == 1u && !hs.err && hs.nblk) { blk = sblk; indexed = true; }
+                    if (getenv("NAF_GPU_DEBUG_STRIDE")) fprintf(stderr, "[stride] len %zu S %u nmax %u prefix %u verdict %u err %u nblk %u\n", src_len, S, nmax, res2[0], res2[1], hs.err, hs.nblk);
                 }
             }
         }

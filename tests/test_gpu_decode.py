@@ -732,40 +732,44 @@ def test_tables_of_many_distinct_trees_sixteen_lanes_per_tree(gpu, oracle, monke
     assert oracle.zstd_decompress(f2, len(cut) + 16) == cut
 
 
-def test_stride_index_of_frames_of_equal_blocks(gpu, oracle, monkeypatch):
+def test_stride_index_of_frames_of_equal_blocks(gpu, oracle, monkeypatch, capfd):
     """zstd_dec.hip k_stride_probe / k_stride_tail: a frame whose blocks all repeat the first block's header (a genome's packed bases
-    under fixed-width codes) is indexed by testing every position off0 + i S at once; the speculative index's kernels return at once.
+    under fixed-width codes) is indexed by testing every position off0 + i S at once, in front of the speculative index.
     Even and odd base counts (the odd one ends in a Raw block of one byte), a stream that ends exactly on a block, a frame with
-    blocks of other sizes in the middle (left to the speculative index), against the text, the oracle and NAF_GPU_STRIDE_INDEX=0."""
+    blocks of other sizes in the middle (left to the speculative index), against the text, the oracle and NAF_GPU_STRIDE_INDEX=0;
+    the mask frames of these upper-case texts go through k_mask_rle_frame (emit.hip), against NAF_GPU_MASK_RLE=0."""
     from naf_amd import synth
+    import re
     import torch
     def names(c):
         return {n for n, ms, k in c.get_timing()}
     cases = [synth.fasta_acgt_device(30_000_000, n_records=3, width=80, seed=3, device="cuda"),
              synth.fasta_acgt_device(30_000_011, n_records=5, width=71, seed=4, device="cuda"),
-             synth.fasta_acgt_device(65536 * 200 + 200 // 60 + 20, n_records=1, width=60, seed=6, device="cuda")]
+             synth.fasta_acgt_device(65536 * 420, n_records=1, width=60, seed=6, device="cuda")]
     for t in cases:
         d_naf, rep = gpu.ennaf(t)
+        capfd.readouterr()
+        monkeypatch.setenv("NAF_GPU_DEBUG_STRIDE", "1")
         gpu.set_timing(True)
         out = gpu.unnaf(d_naf, 0)
         nm = names(gpu)
         gpu.set_timing(False)
+        err = capfd.readouterr().err
         assert torch.equal(out, t)
-        assert any(n.endswith("zstd_index_stride") for n in nm), " ".join(sorted(nm))
+        m = re.search(r"\[stride\] len (\d+) S (\d+) nmax (\d+) prefix (\d+) verdict 1 err 0 nblk (\d+)", err)
+        assert m and int(m.group(1)) > (4 << 20) and int(m.group(5)) >= int(m.group(4)) >= 64, err
         # (an all-upper-case text: its mask frame, RLE blocks of 0xFF units, is taken by k_mask_rle_frame in one launch)
         assert any(n.endswith("unnaf_mask_rle") for n in nm) and not any(n.endswith("unnaf_mask_count") for n in nm), " ".join(sorted(nm))
         monkeypatch.setenv("NAF_GPU_MASK_RLE", "0")
         assert torch.equal(gpu.unnaf(d_naf, 0), t)
         monkeypatch.delenv("NAF_GPU_MASK_RLE")
         monkeypatch.setenv("NAF_GPU_STRIDE_INDEX", "0")
-        gpu.set_timing(True)
+        capfd.readouterr()
         out2 = gpu.unnaf(d_naf, 0)
-        nm2 = names(gpu)
-        gpu.set_timing(False)
+        err2 = capfd.readouterr().err
         monkeypatch.delenv("NAF_GPU_STRIDE_INDEX")
-        assert torch.equal(out2, t) and not any(n.endswith("zstd_index_stride") for n in nm2), " ".join(sorted(nm2))
-        # the other emit paths and a byte range go through the same index
-        assert torch.equal(gpu.unnaf(d_naf, 2), gpu.unnaf(d_naf, 2))
+        assert torch.equal(out2, t) and "[stride]" not in err2
+        monkeypatch.delenv("NAF_GPU_DEBUG_STRIDE")
     naf = host(d_naf)
     assert oracle.unnaf(naf, 0) == host(t)
     # a few lower-case stretches in 30 MB: still a frame of a few dozen bytes for 100 K units, toggles from its Raw / RLE blocks
@@ -785,8 +789,10 @@ def test_stride_index_of_frames_of_equal_blocks(gpu, oracle, monkeypatch):
     # blocks of other sizes in the middle: the prefix ends early, the tail is long, the speculative index takes the frame
     t = synth.realistic_genome_device(40_000_000, n_records=4, device="cuda", n_run_every=3_000_000, iupac_every=150_000)
     d_naf, rep = gpu.ennaf(t)
-    gpu.set_timing(True)
+    monkeypatch.setenv("NAF_GPU_DEBUG_STRIDE", "1")
+    capfd.readouterr()
     out = gpu.unnaf(d_naf, 0)
-    nm = names(gpu)
-    gpu.set_timing(False)
-    assert torch.equal(out, t) and any(n.endswith("zstd_index_write") for n in nm), " ".join(sorted(nm))
+    err = capfd.readouterr().err
+    monkeypatch.delenv("NAF_GPU_DEBUG_STRIDE")
+    assert "verdict 1" not in err, err
+    assert torch.equal(out, t)
