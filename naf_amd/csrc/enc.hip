@@ -1430,6 +1430,8 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
     flush_tile(O.qual + W.qbase, qstage, (u32)totq);
 }
 
+struct SmallBytes { u8 b[60]; u32 n; };
+__global__ void k_put_bytes(u8 *dst, SmallBytes s) { if (threadIdx.x < s.n) dst[threadIdx.x] = s.b[threadIdx.x]; }
 // read lengths, quality-length check (process.c:531-535) and the longest read
 __global__ void k_fq_check(const u64 *rec_begin, const u64 *rec_end, const u64 *q_begin, const u64 *q_end, u64 N, u64 *first_error, u64 *longest)
 {
@@ -2020,15 +2022,26 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
             if (b0) LAUNCH(c, "ennaf_mask_b0", k_add_u64, 1, 64, 0, tc, (u64)1);
             if ((rc = scan_exclusive_u64(c, tc, mt, tc + mt + 1))) return rc;
             u64 nb = 0; if ((rc = ctx_readback(c, &nb, tc + mt + 1, 8))) return rc;
+            u64 nu = 0;
+            if (nb == 0 && !K.skip_run0) {
+                // no case change at all (a text in one case): one run of T bases, its units known here -- 0xFF but for the last one
+                const u64 len = T + K.run_ext;
+                nu = len / 255 + 1;
+                s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
+                HIP_TRY(c, hipMemsetAsync(s_mask, 0xFF, nu, c->stream));
+                SmallBytes lb; memset(&lb, 0, sizeof lb); lb.b[0] = (u8)(len % 255); lb.n = 1;
+                LAUNCH(c, "ennaf_mask_units", k_put_bytes, 1, 64, 0, s_mask + (nu - 1), lb);
+            } else {
             u64 *bnd = arena_new<u64>(c, nb + 1), *ru = arena_new<u64>(c, nb + 3);
             if (!bnd || !ru) return NAF_GPU_ENOMEM;
             if (nb) LAUNCH(c, "ennaf_mask_bscatter", k_maskb_scatter, mt, 256, 0, (const u64 *)S.casebits, T, (const u64 *)tc, nb, bnd, K.prev_masked);
             LAUNCH(c, "ennaf_mask_runs", k_mask_run_units, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, ru, K.run_ext, K.skip_run0);
             if ((rc = scan_exclusive_u64(c, ru, nb + 1, ru + nb + 2))) return rc;
-            u64 nu = 0; if ((rc = ctx_readback(c, &nu, ru + nb + 2, 8))) return rc;
+            if ((rc = ctx_readback(c, &nu, ru + nb + 2, 8))) return rc;
             s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
             if (nu) HIP_TRY(c, hipMemsetAsync(s_mask, 0xFF, nu, c->stream));
             LAUNCH(c, "ennaf_mask_units", k_mask_units_write, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, (const u64 *)ru, s_mask, K.run_ext, K.skip_run0);
+            }
             // Block size of the mask stream.  Real soft-masking (runs of a few hundred bases) gives a few MB of high-entropy units, i.e. a
             // few hundred blocks whose Huffman streams the decoder walks serially: 8 KiB blocks (2 KiB streams) cut that latency to a
             // quarter.  Very long runs give strings of 255s (constant blocks) and one last block with the remainder in it -- whose four
@@ -2070,6 +2083,10 @@ static int ennaf_windows(naf_gpu_ctx *c, EnnafStreams &X, const naf_gpu_ennaf_op
     // level 1 (the default, "fast"): the sequence stream's blocks of sixteen pair codes stay at four bits per code unless Huffman
     // coding saves a sixteenth (zstd_enc.hip: ZENC_PREFER_FLAT) -- the decoder then reads them in place
     if (o->level <= 1) X.flags[4] |= ZENC_PREFER_FLAT;
+    // ... and the sequence and quality streams keep their codes to 7 bits (zstd_enc.hip: ZENC_SHORT_CODES): a packed base pair next to an N
+    // is rare enough for an 11-bit code, which costs this build's decoder its one-level table and makes every symbol of the block a
+    // two-level look-up -- the decode of a FASTQ's sequence stream took as long as that of its quality stream, twice the size
+    if (o->level <= 1) { X.flags[4] |= ZENC_SHORT_CODES; X.flags[5] |= ZENC_SHORT_CODES; }
     if (o->long_log) { X.window_log[4] = o->long_log < 10 ? 10 : o->long_log > 31 ? 31 : o->long_log; X.lz[4] = 1; }
     else if (!wl && X.present[4] && X.len[4]) {
         const char *pe = getenv("NAF_GPU_PROBE");                 // "0": never look, "1": always match
@@ -2112,7 +2129,7 @@ static int encode_stream_begin(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int 
 {
     J->main = nullptr; J->d_stream = d_stream; J->len = len; J->level = level; J->flags = flags; J->tail = (tail && len > tail) ? tail : 0;
     int f1 = flags;
-    if (J->tail) f1 = ZENC_PART | ((!(flags & ZENC_PART) || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT));
+    if (J->tail) f1 = ZENC_PART | ((!(flags & ZENC_PART) || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES));
     if (direct && (lz || len - J->tail != (u64)nd << 15)) return ctx_fail(c, NAF_GPU_EARG, "direct blocks need a stream of whole blocks and no match finder");
     int rc = zstd_encode_begin(c, d_stream, len - J->tail, level, f1, lz, block_log, window_log, &J->main, direct, nd);
     if (rc) { zstd_encode_drop(J->main); J->main = nullptr; }
@@ -2142,7 +2159,7 @@ static int encode_stream(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level,
     }
     if (!tail || len <= tail) return zstd_encode(c, d_stream, len, level, dst, cap, clen, flags, lz, block_log, window_log);
     const bool part = (flags & ZENC_PART) != 0;
-    const int f1 = ZENC_PART | ((!part || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT));
+    const int f1 = ZENC_PART | ((!part || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES));
     const int f2 = ZENC_PART | ((!part || (flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0);
     size_t a = 0, b = 0;
     int rc = zstd_encode(c, d_stream, len - tail, level, dst, cap, &a, f1, lz, block_log, window_log); if (rc) return rc;
@@ -2154,8 +2171,6 @@ static int encode_stream(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level,
 struct SecOut { u64 orig, comp; };
 
 // a section = VLE(original size) VLE(compressed size) frame (ennaf.c:538-589): the frame is written behind its header at once
-struct SmallBytes { u8 b[60]; u32 n; };
-__global__ void k_put_bytes(u8 *dst, SmallBytes s) { if (threadIdx.x < s.n) dst[threadIdx.x] = s.b[threadIdx.x]; }
 struct SecPlace { naf_gpu_ctx *c; u8 *d_naf; size_t cap, pos; u64 orig; size_t hl; int rc; };
 static u8 *place_section(void *ud, size_t clen)
 {

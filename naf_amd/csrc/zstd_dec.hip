@@ -674,17 +674,20 @@ __global__ __launch_bounds__(64) void k_build_huf_lds(const u8 *src, ZBlock *blk
 #define FIND_MAIN_TREES 8u
 __global__ __launch_bounds__(64) void k_flat_find_main(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, const i32 *own_huf)
 {
-    __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
+    __builtin_amdgcn_s_setprio(3);
     __shared__ HufLdsWS S;
     if (st->n_huf_distinct <= HUF_FEW) return;
-    u32 tried = 0;
-    for (u32 i = 0; i < nblk && tried < FIND_MAIN_TREES; i++) {                 // (uniform: every lane walks the same blocks)
+    // workgroup w builds the w-th tree the frame defines (one wavefront building them one after the other until it met the flat one was
+    // 140 us in front of a realistic genome's tile index: its first block holds the telomere's Ns, the second tree is the flat one);
+    // flat_main_inv keeps the FIRST flat 4-bit tree whichever workgroup finishes first
+    u32 seen = 0, i = 0;
+    for (; i < nblk; i++) {                                                    // (uniform: every lane walks the same blocks)
         if (own_huf[i] != (i32)i || blk[i].btype != BT_COMP || blk[i].lit_type != LIT_HUF || blk[i].err) continue;
-        build_huf_one_lds(src, blk, i, pool, pool_cap, st, S);                   // table, huf_flat, flat_main_inv (a wavefront per tree, in LDS)
-        __syncthreads();
-        tried++;
-        if (blk[i].huf_flat && blk[i].huf_log == 4) return;
+        if (seen == blockIdx.x) break;
+        seen++;
     }
+    if (i >= nblk) return;
+    build_huf_one_lds(src, blk, i, pool, pool_cap, st, S);                     // table, huf_flat, flat_main_inv (a wavefront per tree, in LDS)
 }
 // A frame of many blocks and few distinct trees: every workgroup looks through its share of the blocks, 64 at a time, and builds the
 // few owners it finds.  Does nothing when the frame has more than HUF_FEW distinct trees (k_build_huf has it then).
@@ -739,7 +742,9 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
     __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     // the predefined tables (what this build's own LZ blocks use) in LDS: the lane's whole job is a chain of dependent table reads
     __shared__ FseE s_pre[160];
+    __shared__ u32 s_llt[36], s_mlt[53];
     for (u32 k = threadIdx.x; k < 160; k += blockDim.x) s_pre[k] = predef[k];
+    zstd_seq_code_tables(s_llt, s_mlt, threadIdx.x, blockDim.x);
     __syncthreads();
     predef = s_pre;
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -768,11 +773,15 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
     if (blk[own[0][i]].modes[0] == SM_PREDEF && blk[own[1][i]].modes[1] == SM_PREDEF && blk[own[2][i]].modes[2] == SM_PREDEF) {
         // the predefined tables (this build's LZ blocks at level 1): cells read from LDS as LDS -- through the table pointers of the general
         // case, which may point into the pool in global memory, every look-up was a flat load
-        SeqTab tp[3];
-        tp[0].t = s_pre; tp[0].log = 6; tp[1].t = s_pre + 64; tp[1].log = 5; tp[2].t = s_pre + 96; tp[2].log = 6;
-        tp[0].rle = tp[1].rle = tp[2].rle = false; tp[0].rle_sym = tp[1].rle_sym = tp[2].rle_sym = 0;
-        e = zstd_decode_sequences<BitReloadWindow, true>(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tp,
+        e = zstd_decode_sequences_predef<const FseE *, const u32 *, true>(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, s_pre, s_pre + 64, s_pre + 96, s_llt, s_mlt,
+                                 o_ll + base, o_ml + base, o_of + base, rep_out, &sll, &sml, &uses_rep);
+        if (e == 0xFF) {                                           // a stream of fewer than 8 bytes: the general routine
+            SeqTab tp[3];
+            tp[0].t = s_pre; tp[0].log = 6; tp[1].t = s_pre + 64; tp[1].log = 5; tp[2].t = s_pre + 96; tp[2].log = 6;
+            tp[0].rle = tp[1].rle = tp[2].rle = false; tp[0].rle_sym = tp[1].rle_sym = tp[2].rle_sym = 0;
+            e = zstd_decode_sequences<BitReloadWindow, true>(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tp,
                                  o_ll + base, o_ml + base, o_of + base, rep_out, &sll, &sml, &uses_rep, BitReloadWindow());
+        }
     } else
     e = zstd_decode_sequences<BitReloadWindow, true>(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tab,
                                  o_ll + base, o_ml + base, o_of + base, rep_out, &sll, &sml, &uses_rep, BitReloadWindow());
@@ -1125,15 +1134,17 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
                         gp -= bits >> 3; bits &= 7;
                         u32 o = (u32)(gp & 127), sh = (o & 7) * 8;
                         u64 q0 = *(const u64 *)(irow + (o & ~7u)), q1 = *(const u64 *)(irow + (((o & ~7u) + 8) & 127));
-                        u64 w = (sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0) << bits;
-                        u64 acc = 0;
+                        const u64 w = (sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0) << bits;
+                        // the container as two dwords: a code of 1 .. 11 bits leaves through v_alignbit_b32 + a 32-bit shift (a 64-bit
+                        // shift is a quarter-rate instruction, and this loop is bound by its vector instructions)
+                        u32 whi = (u32)(w >> 32), wlo = (u32)w, a0 = 0, a1 = 0;
 #pragma unroll
                         for (u32 q = 0; q < 8; q++) {
-                            u32 e = tab[(u32)(w >> 32) >> (32 - log)];
-                            w <<= (e & 63); bits += hufe_nb(e);           // nbits <= 11: the shift reads it straight from the entry
-                            acc |= (u64)hufe_sym(e) << (8 * q);
+                            const u32 e = tab[whi >> (32 - log)], nb = hufe_nb(e);
+                            whi = __builtin_amdgcn_alignbit(whi, wlo, 32u - nb); wlo <<= nb; bits += nb;
+                            if (q < 4) a0 |= hufe_sym(e) << (8 * q); else a1 |= hufe_sym(e) << (8 * (q - 4));
                         }
-                        accs[g] = acc;
+                        accs[g] = (u64)a0 | ((u64)a1 << 32);
                     }
                 } else {
 #pragma unroll
@@ -1144,13 +1155,15 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
                             gp -= bits >> 3; bits &= 7;
                             u32 o = (u32)(gp & 255), sh = (o & 7) * 8;
                             u64 q0 = *(const u64 *)(irow + (o & ~7u)), q1 = *(const u64 *)(irow + (((o & ~7u) + 8) & 255));
-                            u64 w = (sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0) << bits;
+                            const u64 w = (sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0) << bits;
+                            u32 whi = (u32)(w >> 32), wlo = (u32)w, a4 = 0;
 #pragma unroll
                             for (u32 q = 0; q < 4; q++) {
-                                u32 e = huf_look(tab, (u32)(w >> 32) >> (32 - log), log);
-                                w <<= (e & 63); bits += hufe_nb(e);
-                                acc |= (u64)hufe_sym(e) << (8 * (4 * h + q));
+                                const u32 e = huf_look(tab, whi >> (32 - log), log), nb = hufe_nb(e);
+                                whi = __builtin_amdgcn_alignbit(whi, wlo, 32u - nb); wlo <<= nb; bits += nb;
+                                a4 |= hufe_sym(e) << (8 * q);
                             }
+                            acc |= (u64)a4 << (32 * h);
                         }
                         accs[g] = acc;
                     }
@@ -1669,10 +1682,10 @@ __device__ __forceinline__ u32 wave_excl_sum(u32 v, u32 *total)
 }
 __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *offs, u32 nblk,
                                                       const u32 *o_ll, const u32 *o_ml, const u32 *o_of,
-                                                      const u8 *lit_scratch, u8 *dst, u32 *done, ZStat *st)
+                                                      const u8 *lit_scratch, u8 *dst, u32 *done, ZStat *st, u32 obuf_cap)
 {
     __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
-    __shared__ __attribute__((aligned(16))) u8 obuf[EXEC_LDS + 64];
+    extern __shared__ __attribute__((aligned(16))) u8 obuf[];      // the frame's largest block with sequences + 64 (the launch sizes it: smaller blocks, more workgroups per CU)
     __shared__ u32 sh_ticket;
     const u32 lane = threadIdx.x;
     if (lane == 0) sh_ticket = atomicAdd(&st->ticket, 1u);
@@ -1686,7 +1699,7 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
     u32 rep_in[3] = { b.rep_in[0], b.rep_in[1], b.rep_in[2] };
     const u64 sbase = b.seq_base;
     u32 op = 0, lp = 0, nseq = b.err ? 0 : b.nseq, lo_idx = bi;
-    bool bad = b.regen > EXEC_LDS;
+    bool bad = b.regen > obuf_cap;
     for (u32 s0 = 0; s0 < nseq && !bad; s0 += 64) {
         u32 n = nseq - s0 < 64 ? nseq - s0 : 64;
         u32 ll = 0, ml = 0, of = 0;
@@ -2216,7 +2229,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             LAUNCH(c, "zstd_build_huf", k_build_huf_few, 1024, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, (const u64 *)r4, (const i32 *)own_huf);
             // (a caller that can read flat blocks in place gets the flat trees recognised now and the other tables later: see phase 2 below)
             two_phase = c->zflat && !rg && !always_table;
-            if (two_phase) LAUNCH(c, "zstd_build_huf", k_flat_find_main, 1, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, (const i32 *)own_huf);
+            if (two_phase) LAUNCH(c, "zstd_build_huf", k_flat_find_main, FIND_MAIN_TREES, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, (const i32 *)own_huf);
             else if ((rc = launch_build_huf(c, nblk, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)r4, always_table, (const i32 *)own_huf, 1u, 0u))) return rc;
         }
         ZSplit *sp = c->zsplit;
@@ -2511,8 +2524,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         const char *el = getenv("NAF_GPU_EXEC_LDS");                      // "0": always the HBM executor (cross-check)
         const u32 nx = seq_t1 - seq_t0;
         if (max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
-            LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, nx, 64, 0, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, nblk,
-                   (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st);
+            LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, nx, 64, ((max_seq_regen + 1023u) & ~1023u) + 64u, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, nblk,
+                   (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st, (max_seq_regen + 1023u) & ~1023u);
         else
             LAUNCH(c, "zstd_exec_seq", k_exec_seq, nx, 64, 0, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, nblk,
                    (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st);

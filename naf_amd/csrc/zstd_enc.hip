@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
                     if (lane == 0) ws.log = K == full ? ml : 0u;
                 }
             }
-        } else if (threadIdx.x == 0) ws.log = huf_lengths_sorted(ws.tot, ws.order, distinct, ws.len, ws.w, ws.parent, ws.depth, maxbits);
+        } else if (threadIdx.x == 0) ws.log = huf_lengths_sorted(ws.tot, ws.order, distinct, ws.len, ws.w, ws.parent, ws.depth, maxbits < 9 ? 9u : maxbits);   // (more than 64 symbols: 9 bits hold any alphabet)
         __syncthreads();
         u32 log = ws.log;
         // Flat preference (prefer_flat = d: on when Huffman coding would save less than 1/d of the block).  A block of 2^k distinct
@@ -1079,12 +1079,13 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     const bool part = (with_magic & ZENC_PART) != 0, part_first = (with_magic & ZENC_PART_FIRST) != 0, part_last = (with_magic & ZENC_PART_LAST) != 0;
     const u32 min_gain = (with_magic & ZENC_PREFER_RAW) ? 32u : 0u;
     // (the same streams -- the mask -- keep their codes to 9 bits: this build's decoder then walks them with its single-level table)
-    const u32 maxbits = (with_magic & ZENC_PREFER_RAW) ? 9u : (u32)ZENC_HUF_MAXBITS;
+    u32 maxbits = (with_magic & ZENC_PREFER_RAW) ? 9u : (with_magic & ZENC_SHORT_CODES) ? 7u : (u32)ZENC_HUF_MAXBITS;
+    { const char *mb = getenv("NAF_GPU_HUF_MAXBITS"); if (mb && atoi(mb) >= 7 && atoi(mb) <= (int)ZENC_HUF_MAXBITS && (with_magic & ZENC_SHORT_CODES)) maxbits = (u32)atoi(mb); }
     // ZENC_PREFER_FLAT: blocks of 2^k distinct symbols take k-bit codes unless Huffman coding saves a sixteenth of the block
     // (NAF_GPU_PREFER_FLAT=0: never; =d: the threshold 1/d)
     u32 prefer_flat = (with_magic & ZENC_PREFER_FLAT) ? 16u : 0u;
     if (prefer_flat) { const char *pf = getenv("NAF_GPU_PREFER_FLAT"); if (pf && pf[0]) prefer_flat = (u32)atoi(pf); }
-    with_magic &= ~(ZENC_PREFER_RAW | ZENC_PREFER_FLAT);
+    with_magic &= ~(ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES);
     if (part) with_magic = 0;
     if (part && n == 0 && !part_last) {
         J->empty = 1; J->hdr = part_first ? 2 : 0; J->frame_wlog = (u32)(window_log >= 10 ? window_log : 19);
@@ -1098,9 +1099,10 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     bool use_lz = lz || level >= 2;
     if (el && !strcmp(el, "0")) use_lz = false;
     if (el && !strcmp(el, "all")) use_lz = true;
-    // LZ-coded streams: 16 KiB blocks.  The decoder decodes and executes the sequences of a block serially, so a stream's latency is
-    // that of its longest block; matches in ids / names / lengths are a few dozen bytes back anyway.
-    if (use_lz && !e) { block_log = 14; const char *lb = getenv("NAF_GPU_LZ_BLOCK_LOG"); if (lb && atoi(lb) >= 10 && atoi(lb) <= 15) block_log = (u32)atoi(lb); }
+    // LZ-coded streams: 8 KiB blocks.  The decoder decodes and executes the sequences of a block serially -- a lane, then a wavefront per
+    // block whose LDS buffer is the block's size -- so smaller blocks are more lanes, more workgroups per CU and shorter chains; matches in
+    // ids / names / lengths are a few dozen bytes back anyway (a FASTQ's read names: the archive is no larger than with 16 KiB blocks).
+    if (use_lz && !e) { block_log = 13; const char *lb = getenv("NAF_GPU_LZ_BLOCK_LOG"); if (lb && atoi(lb) >= 10 && atoi(lb) <= 15) block_log = (u32)atoi(lb); }
     if (use_lz && block_log > 15) block_log = 15;                // LZ lengths and distances are kept in 16 bits
     // cross-block matching (window_log >= 10; the host maps level / --long to it): 64 KiB blocks -- fewer block and table headers,
     // and a repeat is cut less often; lengths still fit 16 bits (k_lzx_parse clamps a match at 65535)

@@ -91,7 +91,13 @@ extern "C" long long emul_zstd_decompress_frame(const u8 *src, size_t len, u8 *d
         }
         sll[i].resize(b.nseq); sml[i].resize(b.nseq); sof[i].resize(b.nseq);
         u64 tl = 0, tm = 0; u32 ro[3];
-        u8 e = zstd_decode_sequences<BitReloadWindow, true>(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tab, sll[i].data(), sml[i].data(), sof[i].data(), ro, &tl, &tm, nullptr, BitReloadWindow());
+        u8 e = 0xFF;
+        if (blk[own[1][i]].modes[0] == SM_PREDEF && blk[own[2][i]].modes[1] == SM_PREDEF && blk[own[3][i]].modes[2] == SM_PREDEF) {
+            u32 llt[36], mlt[53]; zstd_seq_code_tables(llt, mlt, 0, 1);          // the kernel's fast routine for blocks of predefined tables
+            e = zstd_decode_sequences_predef<const FseE *, const u32 *, true>(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, predef, predef + 64, predef + 96, llt, mlt,
+                                                                             sll[i].data(), sml[i].data(), sof[i].data(), ro, &tl, &tm, nullptr);
+        }
+        if (e == 0xFF) e = zstd_decode_sequences<BitReloadWindow, true>(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tab, sll[i].data(), sml[i].data(), sof[i].data(), ro, &tl, &tm, nullptr, BitReloadWindow());
         if (e) return -200 - e;
         if (tl > b.lit_regen) return -11;
         b.rep_out[0] = ro[0]; b.rep_out[1] = ro[1]; b.rep_out[2] = ro[2];

@@ -22,6 +22,10 @@ NAF_GPU_FLAT=0 NAF_GPU_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format 
 cp $(ls $out/stats3/*/*kernel_stats.csv | head -1) $out/${tag}_serial_huffman_alone_rocprofv3_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats4 -- python tools/perf_side.py realistic 4e9 > $out/stats4.log 2>&1
 cp $(ls $out/stats4/*/*kernel_stats.csv | head -1) $out/${tag}_realistic_rocprofv3_kernel_stats.csv
+bash tools/trace_step.sh uniform 10e9 ${tag}_uniform > /dev/null 2>&1; cp gpurun_out/trace_${tag}_uniform/timeline.txt $out/${tag}_timeline_uniform_10GB.txt; cp gpurun_out/trace_${tag}_uniform/timeline_ennaf.txt $out/${tag}_timeline_ennaf_uniform_10GB.txt
+bash tools/trace_step.sh fastq 4e9 ${tag}_fastq > /dev/null 2>&1; cp gpurun_out/trace_${tag}_fastq/timeline.txt $out/${tag}_timeline_fastq_4GB.txt; cp gpurun_out/trace_${tag}_fastq/timeline_ennaf.txt $out/${tag}_timeline_ennaf_fastq_4GB.txt
+bash tools/trace_step.sh realistic 4e9 ${tag}_realistic > /dev/null 2>&1; cp gpurun_out/trace_${tag}_realistic/timeline.txt $out/${tag}_timeline_realistic_4GB.txt; cp gpurun_out/trace_${tag}_realistic/timeline_ennaf.txt $out/${tag}_timeline_ennaf_realistic_4GB.txt
+python tools/perf_stream.py fastq 4e9 > $out/${tag}_fastq_streams_alone.txt 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do
   printf 'pmc: %s\n' $ctr > $out/pmc_$ctr.txt
   rocprofv3 -i $out/pmc_$ctr.txt --output-format csv -d $out/pmc_$ctr -- python bench.py --steps 1 --warmup 0 --no-cpu --softmask-size 0 --realistic-size 0 --fastq1-size 0 > $out/pmc_$ctr.log 2>&1
@@ -56,9 +60,10 @@ text_bytes = int(line["config"]["workload"].split("FASTA ")[-1].split(" B")[0])
 # instrumented step = 3 unnaf calls, and 2 ennaf calls
 names = {"k_huf_literals": "zstd_huf_literals", "k_flat_literals": "zstd_flat_literals", "k_emit_tile": "unnaf_emit", "k_emit_tile_flat": "unnaf_emit_flat",
          "k_emit_rest": "unnaf_emit_rest", "k_build_huf": "zstd_build_huf", "k_spec_find": "zstd_index_find", "k_spec_resolve": "zstd_index_resolve",
-         "k_copy_fill": "zstd_copy_fill", "k_flat_streams": "zstd_flat_streams", "k_tile_index": "unnaf_tile_index"}
+         "k_copy_fill": "zstd_copy_fill", "k_flat_streams": "zstd_flat_streams", "k_tile_index": "unnaf_tile_index", "k_stride_probe": "zstd_index_stride", "k_parse_blocks": "zstd_parse_blocks", "k_mask_rle_frame": "unnaf_mask_rle"}
 enc_names = {"k_enc_scatter_regular": "ennaf_scatter_regular", "k_enc_scatter": "ennaf_scatter", "k_enc_count_pure": "ennaf_count_pure", "k_enc_count": "ennaf_count", "k_enc_last_fa": "ennaf_last", "k_maskb_count": "ennaf_mask_count", "k_pack_edges_zero": "ennaf_pack_edges",
-             "k_zenc_plan": "zenc_plan", "k_zenc_write": "zenc_write", "k_mask_run_units": "ennaf_mask_runs", "k_mask_units_write": "ennaf_mask_units"}
+             "k_zenc_plan": "zenc_plan", "k_zenc_write": "zenc_write", "k_zenc_write_direct": "zenc_write_direct", "k_zenc_flat_scan": "zenc_flat_scan", "k_zenc_tree": "zenc_tree", "k_direct_blocks": "ennaf_direct_blocks",
+             "k_mask_run_units": "ennaf_mask_runs", "k_mask_units_write": "ennaf_mask_units"}
 calls = 3
 enc_calls = 4            # three timed ennaf calls and the instrumented one
 k = {}
