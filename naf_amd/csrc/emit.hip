@@ -946,15 +946,16 @@ __global__ void k_flat_pair(EmitP P, u32 *pair)               // sixteen-entry t
     }
     pair[t] = v;
 }
-#define FLAT_TPW 4                                               // tiles per workgroup: a tile alone is three dependent loads and a store, i.e. pure latency
+#define FLAT_TPW 8                                               // tiles per workgroup: a tile alone is three dependent loads and a store, i.e. pure latency
+template <u32 TPW>
 __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *ti, const TileFlat *tsig, u8 *out, u64 ntiles, u32 xcd_chunk)
 {
     // Workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md): with xcd_chunk = ceil(grid / 8) every XCD walks one contiguous
     // eighth of the text instead of every eighth 16 KiB piece of all of it -- no data is shared between workgroups, but an XCD's
     // address translation then covers an eighth of the pages in flight.  xcd_chunk = 0: workgroups in launch order.
     u32 wg = blockIdx.x;
-    if (xcd_chunk) { wg = (blockIdx.x & 7u) * xcd_chunk + (blockIdx.x >> 3); if ((u64)wg * FLAT_TPW >= ntiles) return; }
-    __shared__ u64 s_tog[FLAT_TPW][EMIT_TOG_LDS];                  // every tile's window of mask toggles (a dozen per tile of a soft-masked genome)
+    if (xcd_chunk) { wg = (blockIdx.x & 7u) * xcd_chunk + (blockIdx.x >> 3); if ((u64)wg * TPW >= ntiles) return; }
+    __shared__ u64 s_tog[TPW][EMIT_TOG_LDS];                  // every tile's window of mask toggles (a dozen per tile of a soft-masked genome)
     // a line end inside a chunk: bytes in front of it stay, the byte at it becomes '\n', bytes behind it take the byte in front of
     // them -- per position d of the line end, sixteen v_perm_b32 selector bytes (source = this dword and the one below it; 0x0C
     // selects a zero byte) and the sixteen bytes to OR in
@@ -978,20 +979,20 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     const u32 lane16 = threadIdx.x * 16;
     // ---- phase 0: the records of the workgroup's tiles (uniform addresses: scalar loads, all of them in flight together -- one
     // tile after the other, each waiting for its own records and then for its own codes, was four memory latencies in a row)
-    TileIdx A[FLAT_TPW]; TileFlatE F[FLAT_TPW]; bool live[FLAT_TPW];
+    TileIdx A[TPW]; TileFlatE F[TPW]; bool live[TPW];
     {
-        // (both arrays have FLAT_TPW spare entries behind ntiles, made harmless by k_tile_index; the workgroup's four records are
+        // (both arrays have TPW spare entries behind ntiles, made harmless by k_tile_index; the workgroup's four records are
         // read as whole 16-byte words so that no field waits for a test on another one)
         static_assert(sizeof(TileIdx) == 32 && sizeof(TileFlatE) == 48, "records are read as 16-byte words");
-        const u64 t0 = (u64)wg * FLAT_TPW;
+        const u64 t0 = (u64)wg * TPW;
         const uint4 *pa = (const uint4 *)(ti + t0), *pf = (const uint4 *)(tsig + t0);
-        uint4 ra[2 * FLAT_TPW], rf[3 * FLAT_TPW];
+        uint4 ra[2 * TPW], rf[3 * TPW];
 #pragma unroll
-        for (u32 i = 0; i < 2 * FLAT_TPW; i++) ra[i] = pa[i];
+        for (u32 i = 0; i < 2 * TPW; i++) ra[i] = pa[i];
 #pragma unroll
-        for (u32 i = 0; i < 3 * FLAT_TPW; i++) rf[i] = pf[i];
+        for (u32 i = 0; i < 3 * TPW; i++) rf[i] = pf[i];
 #pragma unroll
-        for (u32 j = 0; j < FLAT_TPW; j++) {
+        for (u32 j = 0; j < TPW; j++) {
             __builtin_memcpy(&A[j], &ra[2 * j], 32); __builtin_memcpy(&F[j], &rf[3 * j], 48);
             live[j] = t0 + j < ntiles && A[j].fast == 1;
         }
@@ -1002,9 +1003,9 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     // k_tile_index); the load is scalar base + 32-bit lane offset.
     // No branches here: a value that is only loaded on one path needs a copy where the paths join, and that copy waits for the load.
     // A tile that is not live (it goes to k_emit_rest, or lies behind the last one) has a record that points at the source's first bytes.
-    u64 X[FLAT_TPW]; u32 offs[FLAT_TPW], grels[FLAT_TPW], nls[FLAT_TPW], haves[FLAT_TPW];
+    u64 X[TPW]; u32 offs[TPW], grels[TPW], nls[TPW], haves[TPW];
 #pragma unroll
-    for (u32 j = 0; j < FLAT_TPW; j++) {
+    for (u32 j = 0; j < TPW; j++) {
         const TileIdx &a = A[j]; const TileFlatE &e = F[j];
         u32 grel, nl_b = 64;                                          // grel: the chunk's first base, counted from a.gline
         if (P.mode == EM_FASTA && P.L != 0) {
@@ -1031,20 +1032,20 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
     // the toggles of the four tiles' windows: fetched with the codes (after them: a wait in the middle of phase 2, tile after tile, was
     // half a millisecond per 4 GB of a soft-masked genome) and parked in LDS before the barrier that s_spl needs anyway
     if (P.masking) {
-        u64 tg[FLAT_TPW];
+        u64 tg[TPW];
 #pragma unroll
-        for (u32 j = 0; j < FLAT_TPW; j++) {
+        for (u32 j = 0; j < TPW; j++) {
             const u64 nt = A[j].khi - A[j].k;
             tg[j] = (live[j] && threadIdx.x < nt && nt <= EMIT_TOG_LDS) ? P.toggles[A[j].k + threadIdx.x] : 0ull;
         }
 #pragma unroll
-        for (u32 j = 0; j < FLAT_TPW; j++) s_tog[j][threadIdx.x] = tg[j];
+        for (u32 j = 0; j < TPW; j++) s_tog[j][threadIdx.x] = tg[j];
     }
     __syncthreads();                                              // s_spl, s_tog (the loads are in flight meanwhile)
     // ---- phase 2: codes -> characters, mask, line ends, store
 #pragma unroll
-    for (u32 j = 0; j < FLAT_TPW; j++) {
-        const u64 t = (u64)wg * FLAT_TPW + j;
+    for (u32 j = 0; j < TPW; j++) {
+        const u64 t = (u64)wg * TPW + j;
         if (!live[j]) continue;
         const TileIdx &a = A[j];
         const u64 g0 = a.gline + grels[j];
@@ -1790,9 +1791,11 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                 HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX], 0));         // the index
             }
             if (zflat.ready) {
-                const u32 nwg = cdiv(ntiles, FLAT_TPW), chunk = (nwg + 7) / 8;
+                static const u32 tpw = (getenv("NAF_GPU_FLAT_TPW") && atoi(getenv("NAF_GPU_FLAT_TPW")) == 8) ? 8u : 4u;     // tiles per workgroup (the records have FLAT_TPW spare entries)
+                const u32 nwg = cdiv(ntiles, tpw), chunk = (nwg + 7) / 8;
                 static const bool xcd = !(getenv("NAF_GPU_XCD") && getenv("NAF_GPU_XCD")[0] == '0');
-                LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat, xcd ? chunk * 8 : nwg, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, xcd ? chunk : 0u);
+                if (tpw == 8) LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat<8>, xcd ? chunk * 8 : nwg, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, xcd ? chunk : 0u);
+                else LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat<4>, xcd ? chunk * 8 : nwg, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, xcd ? chunk : 0u);
                 if (flat_job) {                                                               // (queued behind the flat emit: the job waits for its tables on the host)
                     if ((rc = zstd_flat_later(c, &zflat))) return rc;
                     if (zflat.aux) xc = zflat.aux;

@@ -2267,7 +2267,9 @@ extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, cons
         }
         // lengths and mask: their units and the first half of their frames on a second side context with a host thread of its own,
         // beside ids and names on the first (many reads make each of the two chains several milliseconds long)
-        sb = (S.N >= 65536 || force_overlap) ? c->side2 : nullptr;                  // a few records: one chain is short enough, and a thread hand-over is not free
+        // (a few records and no mask to speak of: one chain is short enough, and a thread hand-over is not free; the mask of a long text is
+        // a pass over its case bits and a stream of MBs to code, a third of a millisecond and more that ids and names need not wait behind)
+        sb = (S.N >= 65536 || force_overlap || (S.store_mask && S.T >= (256u << 20))) ? c->side2 : nullptr;
         if (sb) {
             arena_reset(sb);
             HIP_TRY(c, hipStreamWaitEvent(sb->stream, c->fork_ev, 0));

@@ -981,7 +981,7 @@ __global__ __launch_bounds__(256) void k_zenc_write_direct(const u8 *src, u32 nb
 #pragma unroll
     for (u32 r = 0; r < 4; r++) v[r] = in[r * 64 + lane];
 #pragma unroll
-    for (u32 r = 0; r < 4; r++) __builtin_memcpy(so + 16u * (r * 64 + lane), &v[r], 16);
+    for (u32 r = 0; r < 4; r++) __builtin_memcpy(so + 16u * (r * 64 + lane), &v[r], 16);   // (stores at aligned addresses with the LOADS taking the misalignment: 1.04 -> 1.26 ms)
     if (lane == 0) so[4096] = 1;
 }
 

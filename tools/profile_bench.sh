@@ -65,7 +65,7 @@ enc_names = {"k_enc_scatter_regular": "ennaf_scatter_regular", "k_enc_scatter": 
              "k_zenc_plan": "zenc_plan", "k_zenc_write": "zenc_write", "k_zenc_write_direct": "zenc_write_direct", "k_zenc_flat_scan": "zenc_flat_scan", "k_zenc_tree": "zenc_tree", "k_direct_blocks": "ennaf_direct_blocks",
              "k_mask_run_units": "ennaf_mask_runs", "k_mask_units_write": "ennaf_mask_units"}
 calls = 3
-enc_calls = 4            # three timed ennaf calls and the instrumented one
+enc_calls = 5            # the untimed first ennaf call, three timed ones and the instrumented one
 k = {}
 # counter unit = KiB.  FETCH_SIZE tallies a wide coalesced read at 1/2 (guide; k_expand / k_read calibration: x2), the
 # Huffman kernel's one-64-byte-sector-per-lane reads at 1/1.742 (k_sector_read calibration); WRITE_SIZE is exact (k_expand / k_write)
