@@ -23,6 +23,7 @@ struct EmitP {
     int mode, has_ids, has_names, masking, upper;
     u8 sep, hdr_char;
     int force_slow;
+    int nt_store;                                              // NAF_GPU_EMIT_NT=1: k_emit_tile_flat stores the text with the nontemporal hint
     // a flat frame read in place (ctx.h: ZFlat): stream table, source, code -> packed byte; fsrc == nullptr otherwise
     const u8 *ftail; u64 ftail_q; u32 ftail_n;   // the frame's final Raw block, if it has one (ZFlat)
     const u8 *fsrc; const void *fsi; u64 fslots; const u8 *fsym; const u32 *fpair;
