@@ -267,7 +267,8 @@ __global__ void k_stride_tail(const u8 *src, u64 len, u64 off0, u32 S, u32 nmax,
     const u32 np = res[0] < nmax ? res[0] : nmax;
     res[0] = np;
     u64 pos = off0 + (u64)np * S; u32 n = 0; bool done = false;
-    while (n < STRIDE_TAIL) {
+    // (more bytes behind the prefix than STRIDE_TAIL blocks of the largest size hold: a frame of mixed blocks, not worth a walk of dependent loads)
+    while (n < STRIDE_TAIL && len - pos <= (u64)STRIDE_TAIL * (ZBLOCK_MAX + 3u)) {
         if (pos + 3 > len) break;
         const u32 h = ld24(src + pos), last = h & 1, type = (h >> 1) & 3, size = h >> 3;
         if (type == 3 || size > ZBLOCK_MAX) break;
@@ -1849,7 +1850,7 @@ struct SmallRes { u32 err, out, pos; };
 // The frame's bytes, its output, a block's literals and sequences all sit in LDS while the one lane works (a dependent access costs
 // an LDS round trip, not an HBM one: 180 -> about 15 ns per byte); the other lanes copy the frame in and the output out.
 __device__ void small_frame_decode(const u8 *src, u32 len, u8 *dst, u32 cap, u8 *lit, u32 *sll, u32 *sml, u32 *sof, const FseE *predef,
-                                   HufBuildWS &ws, u16 *huf, FseE *fse, u8 *w, i16 *norm, u16 *nx, SmallRes *res)
+                                   HufBuildWS &ws, u16 *huf, FseE *fse, u8 *w, i16 *norm, u16 *nx, SmallRes *res, const u32 *llt, const u32 *mlt)
 {
     u32 err = 0, out = 0, pos = 0;
     ZFrameHdr fh = zstd_parse_frame_header(src, len);
@@ -1919,7 +1920,11 @@ __device__ void small_frame_decode(const u8 *src, u32 len, u8 *dst, u32 cap, u8 
         }
         if (tbad || p != b.seq_bits_off) { err = ZE_CORRUPT; break; }
         u64 tl = 0, tm = 0; u32 ro[3];
-        const u8 e = zstd_decode_sequences(c + b.seq_bits_off, b.seq_bits_size, b.nseq, tab, sll, sml, sof, ro, &tl, &tm);
+        // (blocks of predefined tables: the routine k_decode_seq uses for them -- a lane alone on the general one took 2 - 3 us per sequence)
+        u8 e = 0xFF;
+        if (b.modes[0] == SM_PREDEF && b.modes[1] == SM_PREDEF && b.modes[2] == SM_PREDEF)
+            e = zstd_decode_sequences_predef<const FseE *, const u32 *, false>(c + b.seq_bits_off, b.seq_bits_size, b.nseq, predef, predef + 64, predef + 96, llt, mlt, sll, sml, sof, ro, &tl, &tm, nullptr);
+        if (e == 0xFF) e = zstd_decode_sequences(c + b.seq_bits_off, b.seq_bits_size, b.nseq, tab, sll, sml, sof, ro, &tl, &tm);
         if (e) { err = e; break; }
         if (tl > b.lit_regen) { err = ZE_CORRUPT; break; }
         const u64 regen = b.lit_regen + tm;
@@ -1928,14 +1933,17 @@ __device__ void small_frame_decode(const u8 *src, u32 len, u8 *dst, u32 cap, u8 
         u32 op = out, l = 0; bool xbad = false;
         for (u32 q = 0; q < b.nseq; q++) {
             const u32 ll = sll[q], ml = sml[q], of = sym_resolve(sof[q], rep);
-            for (u32 k = 0; k < ll; k++) dst[op + k] = lit[l + k];
+            // eight bytes at a time (the lane waits an LDS round trip per access): what is copied past a run's end is overwritten by what
+            // follows it, and the buffers have 16 bytes of slack behind the frame's last byte
+            for (u32 k = 0; k < ll; k += 8) st64(dst + op + k, ld64(lit + l + k));
             op += ll; l += ll;
             if (of == 0 || of > op) { xbad = true; break; }
-            for (u32 k = 0; k < ml; k++) dst[op + k] = dst[op + k - of];
+            if (of >= 8) for (u32 k = 0; k < ml; k += 8) st64(dst + op + k, ld64(dst + op + k - of));
+            else for (u32 k = 0; k < ml; k++) dst[op + k] = dst[op + k - of];
             op += ml;
         }
         if (xbad) { err = ZE_CORRUPT; break; }
-        for (u32 k = l; k < b.lit_regen; k++) dst[op++] = lit[k];
+        { const u32 rest = b.lit_regen - l; for (u32 k = 0; k < rest; k += 8) st64(dst + op + k, ld64(lit + l + k)); op += rest; }
         { const u32 r0 = sym_resolve(ro[0], rep), r1 = sym_resolve(ro[1], rep), r2 = sym_resolve(ro[2], rep); rep[0] = r0; rep[1] = r1; rep[2] = r2; }
         out = op;
         if (last) break;
@@ -1957,11 +1965,13 @@ __global__ __launch_bounds__(64) void k_small_frame(const u8 *src, u32 len, u8 *
     __shared__ i16 norm[64];
     __shared__ u16 nx[64];
     __shared__ SmallRes r;
+    __shared__ u32 s_llt[36], s_mlt[53];
+    zstd_seq_code_tables(s_llt, s_mlt, threadIdx.x, 64);
     for (u32 k = threadIdx.x; k < len; k += 64) s_src[k] = src[k];
     for (u32 k = threadIdx.x; k < 16; k += 64) s_src[len + k] = 0;
     for (u32 k = threadIdx.x; k < 160; k += 64) s_predef[k] = predef[k];
     __syncthreads();
-    if (threadIdx.x == 0) small_frame_decode(s_src, len, s_out, cap < SMALL_OUT ? cap : SMALL_OUT, s_lit, s_ll, s_ml, s_of, s_predef, ws, huf, fse, w, norm, nx, &r);
+    if (threadIdx.x == 0) small_frame_decode(s_src, len, s_out, cap < SMALL_OUT ? cap : SMALL_OUT, s_lit, s_ll, s_ml, s_of, s_predef, ws, huf, fse, w, norm, nx, &r, s_llt, s_mlt);
     __syncthreads();
     if (r.err == 0) for (u32 k = threadIdx.x; k < r.out; k += 64) dst[k] = s_out[k];
     if (threadIdx.x == 0) { res[0] = r.err; res[1] = r.out; res[2] = r.pos; }
@@ -1982,13 +1992,15 @@ __global__ __launch_bounds__(64) void k_small_frames(SmallJobs J, const FseE *pr
     __shared__ i16 norm[64];
     __shared__ u16 nx[64];
     __shared__ SmallRes r;
+    __shared__ u32 s_llt[36], s_mlt[53];
+    zstd_seq_code_tables(s_llt, s_mlt, threadIdx.x, 64);
     const u32 j = blockIdx.x;
     const u8 *src = J.src[j]; const u32 len = J.len[j], cap = J.cap[j]; u8 *dst = J.dst[j];
     for (u32 k = threadIdx.x; k < len; k += 64) s_src[k] = src[k];
     for (u32 k = threadIdx.x; k < 16; k += 64) s_src[len + k] = 0;
     for (u32 k = threadIdx.x; k < 160; k += 64) s_predef[k] = predef[k];
     __syncthreads();
-    if (threadIdx.x == 0) small_frame_decode(s_src, len, s_out, cap < SMALL_OUT ? cap : SMALL_OUT, s_lit, s_ll, s_ml, s_of, s_predef, ws, huf, fse, w, norm, nx, &r);
+    if (threadIdx.x == 0) small_frame_decode(s_src, len, s_out, cap < SMALL_OUT ? cap : SMALL_OUT, s_lit, s_ll, s_ml, s_of, s_predef, ws, huf, fse, w, norm, nx, &r, s_llt, s_mlt);
     __syncthreads();
     if (r.err == 0) for (u32 k = threadIdx.x; k < r.out; k += 64) dst[k] = s_out[k];
     if (threadIdx.x == 0) { res[4 * j] = r.err; res[4 * j + 1] = r.out; res[4 * j + 2] = r.pos; }
