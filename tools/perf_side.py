@@ -18,7 +18,7 @@ if which == "fastq":
 elif which == "realistic":
     text = synth.realistic_genome_device(size, device="cuda"); mode = capi.OUT_FASTA
 elif which == "uniform":
-    text = synth.fasta_acgt_device(size, n_records=24, width=80, seed=5, device="cuda"); mode = capi.OUT_FASTA
+    text = synth.fasta_acgt_device(size, n_records=100, width=80, seed=2024, device="cuda"); mode = capi.OUT_FASTA      # the bench line's headline text
 else:
     text = synth.softmask_device(synth.fasta_acgt_device(size, n_records=24, width=60, seed=7, device="cuda")); mode = capi.OUT_FASTA
 n = text.numel()
