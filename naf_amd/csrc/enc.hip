@@ -33,7 +33,21 @@ struct EncP {
     u32 qlo, qhi;                // quick table of accepted letters (enc_swar.h), built in set_expected
     u32 plo, phi;                // the same with '\n' and '\r' in slots 5 and 6 (piece_plain)
     u32 nuc32[8];                // 4-bit code of the letter whose low five bits are the index (tables.c:189-197), 15 in the other slots
+    u32 *any_case;               // count pass: set to 1 when some byte of a sequence line carries the case bit (see case_bytes16); may be null
 };
+// one bit per byte that the packing pass would give a case bit (bits 5 and 6 both set, or bit 7): a superset of the masked bases
+__device__ __forceinline__ u32 case_bytes16(const u32 w[4])
+{
+    const u32 H = 0x80808080u;
+    return swar_movemask16((w[0] | ((w[0] << 1) & (w[0] << 2))) & H, (w[1] | ((w[1] << 1) & (w[1] << 2))) & H,
+                           (w[2] | ((w[2] << 1) & (w[2] << 2))) & H, (w[3] | ((w[3] << 1) & (w[3] << 2))) & H);
+}
+// a wavefront's verdict: one atomic per wave at most, none once the flag is up
+__device__ __forceinline__ void note_case(const EncP &P, bool mine)
+{
+    if (!P.any_case) return;
+    if (__ballot(mine) != 0 && (threadIdx.x & 63) == 0 && __atomic_load_n(P.any_case, __ATOMIC_RELAXED) == 0) atomicOr(P.any_case, 1u);
+}
 
 __device__ __forceinline__ bool c_eol(u32 c) { return c >= 0x0A && c <= 0x0D; }
 __device__ __forceinline__ bool c_space(u32 c) { return (c >= 0x09 && c <= 0x0D) || c == 0x20; }
@@ -331,15 +345,20 @@ __device__ __forceinline__ void piece_from(const Piece &pc, u32 a, u64 &lo, u64 
 
 struct CountSink {
     u32 nseq = 0, nids = 0, ncmt = 0, nrec = 0, tail = 0;      // tail = sequence bytes since the last EOL seen
-    bool saw_eol = false;
-    __device__ void emit(int s, u32) { if (s == EV_SEQ) { nseq++; tail++; } else if (s == EV_IDS) nids++; else ncmt++; }
+    bool saw_eol = false, cased = false;                         // cased: some sequence byte carries the case bit (what is emitted for it, or the byte itself)
+    __device__ void emit(int s, u32 ch) { if (s == EV_SEQ) { nseq++; tail++; cased = cased || (ch & 0x80u) || ((ch & 0x60u) == 0x60u); } else if (s == EV_IDS) nids++; else ncmt++; }
     __device__ void header_start(u64) { nrec++; }
     __device__ void header_end(u64) { tail = 0; saw_eol = true; }
     __device__ void line_end(u64) { tail = 0; saw_eol = true; }
     __device__ void unexpected(int, u32, u64) {}
     __device__ void ids_range(const Piece &, u32 a, u32 b) { nids += b - a; }
     __device__ void cmt_range(const Piece &, u32 a, u32 b) { ncmt += b - a; }
-    __device__ void seq_range(const Piece &, u32 a, u32 b, u32 sp) { u32 c = (u32)__popc(range_mask(a, b) & ~sp); nseq += c; tail += c; }
+    __device__ void seq_range(const Piece &pc, u32 a, u32 b, u32 sp)
+    {
+        u32 c = (u32)__popc(range_mask(a, b) & ~sp); nseq += c; tail += c;
+        const u32 w[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) };
+        cased = cased || (case_bytes16(w) & range_mask(a, b) & ~sp) != 0;
+    }
     __device__ void term(int st) { if (st == EV_IDS) nids++; else ncmt++; }
 };
 
@@ -400,6 +419,7 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
         const u32 hib = threadIdx.x * ET_BYTES + (pl.eol ? 31u - (u32)__clz((int)pl.eol) : 0u);
         const u32 lastpos = (u32)__builtin_amdgcn_readlane((int)hib, lastl < 0 ? 0 : lastl);
         const bool wave_bad = __ballot(!plain) != 0;
+        if (maybe && !wave_bad) note_case(P, case_bytes16(w) != 0);        // (a pure tile: letters and line ends only; a tile that is not comes back below)
         if (lane == 0) { s_a[wave] = nb | (lastpos << 16); s_last[wave] = (bal ? 1u : 0u) | (wave_bad ? 2u : 0u); }
         if (maybe) {
             const bool has = pl.eol != 0;
@@ -449,6 +469,7 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
         // a full piece inside sequence lines: every non-space byte is a base (process.c:387-412)
         S.nseq = 16 - __popc(pm.sp); S.saw_eol = pm.eol != 0;
         S.tail = pm.eol ? __popc(~pm.sp & 0xFFFFu & ~((2u << (31 - __clz((int)pm.eol))) - 1)) : S.nseq;
+        { const u32 w4[4] = { (u32)pc.w0, (u32)(pc.w0 >> 32), (u32)pc.w1, (u32)(pc.w1 >> 32) }; S.cased = (case_bytes16(w4) & ~pm.sp & 0xFFFFu) != 0; }
     } else if (base <= P.n) {
         // the virtual end-of-input byte belongs to the thread whose piece contains position n
         bool eof_here = (base + pc.cnt == P.n) && pc.cnt < ET_BYTES;
@@ -458,6 +479,7 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
     // four counts in two scans of packed 16-bit fields (a tile holds 4096 bytes, a byte adds at most 2 to a field); the tail of
     // the tile -- sequence bytes after its last EOL, the whole tile if it has none -- falls out of the same scan: the last
     // thread that saw an EOL knows how many bases follow it.
+    note_case(P, S.cased);
     u32 wa = wave_scan_inclusive<u32, OpAdd>(S.nseq | (S.nids << 16)), wb = wave_scan_inclusive<u32, OpAdd>(S.ncmt | (S.nrec << 16));
     u64 bal = __ballot(S.saw_eol);
     if (lane == 63) { s_a[wave] = wa; s_b[wave] = wb; }
@@ -489,14 +511,17 @@ __global__ __launch_bounds__(256) void k_enc_count_pure(EncP P, const i64 *tile_
     uint4 v[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) __builtin_memcpy(&v[k], tp + (64u * (u32)k + lane) * ET_BYTES, 16);
-    u32 eol[4]; bool plain = true; u32 has_n = 0;
+    u32 eol[4]; bool plain = true; u32 has_n = 0, lower = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const u32 w[4] = { v[k].x, v[k].y, v[k].z, v[k].w }; plain = piece_plain(w, P.plo, P.phi, &eol[k]) && plain;
         // among the plain bytes (A C G T U N in either case, LF, CR) only N has both bit 3 and bit 6
         has_n |= ((w[0] >> 3) & (w[0] >> 6)) | ((w[1] >> 3) & (w[1] >> 6)) | ((w[2] >> 3) & (w[2] >> 6)) | ((w[3] >> 3) & (w[3] >> 6));
+        // ... and only lower-case letters have bits 5 and 6 (line ends have neither 6 nor 7)
+        lower |= ((w[0] >> 5) & (w[0] >> 6)) | ((w[1] >> 5) & (w[1] >> 6)) | ((w[2] >> 5) & (w[2] >> 6)) | ((w[3] >> 5) & (w[3] >> 6));
     }
     if (__ballot(!plain) != 0) { if (lane == 0) { t_needf[t] = 1; t_need[t] = 1; } return; }
+    note_case(P, (lower & 0x01010101u) != 0);
     const bool acgt = __ballot((has_n & 0x01010101u) != 0) == 0;
     u32 E = 0, nbytes = 0, p1 = 0, period = 0, prev_last = 0, lastpos = 0; bool any = false, two = false, lat_ok = true;
 #pragma unroll
@@ -1703,6 +1728,7 @@ static int ennaf_sniff(naf_gpu_ctx *c, const u8 *d_text, u64 n, int want_format,
 enum { SE_NONE = 0, SE_AT, SE_PLUS, SE_QLEN, SE_NOSEQ, SE_NOQUAL, SE_STRICT };
 struct EnnafSplit {
     int format, seq_type; bool fourbit, store_mask, store_qual, no_mask;
+    bool no_case = false;                                       // the count pass met no byte with the case bit in a sequence line: the mask is one run (FASTA, one call)
     u8 *bases, *s_ids, *s_cmt, *s_qual;                        // bases: one byte per base (protein / text only)
     u8 *packed; u64 *casebits;                                 // 4-bit: codes of the shard's own base stream (base 0 in the low nibble of byte 0), case bits (store_mask)
     u64 n_ids, n_cmt, n_qual, T, N, longest, lead;
@@ -1868,6 +1894,9 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         u64 *t_irr = arena_new<u64>(c, tiles + 2);
         u64 *tot = arena_new<u64>(c, 8);
         if (!t_eol || !t_sp || !t_seq || !t_ids || !t_cmt || !t_rec || !t_tail || !t_reg || !irr_list || !t_irr || !tot) return NAF_GPU_ENOMEM;
+        // the case census rides on the count pass (tot[6]): an upper-case text needs no pass over its case bits to learn that its mask is one run
+        HIP_TRY(c, hipMemsetAsync(tot + 6, 0, 8, c->stream));
+        P.any_case = (u32 *)(tot + 6);
         LAUNCH(c, "ennaf_last", k_enc_last_fa, cdiv(tiles, 4 * LAST_TPW), 256, 0, P, t_eol, t_sp, tiles);
         // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
         if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
@@ -1897,9 +1926,11 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         LAUNCH(c, "ennaf_irregular_list", k_irregular_list, cdiv(tiles, 256), 256, 0, (const u32 *)t_reg, (const u64 *)t_irr, tiles, irr_list);
         // t_seq[tiles] must hold the grand total for the "line began in an earlier tile" lookup
         HIP_TRY(c, hipMemcpyAsync(t_seq + tiles, tot + 0, 8, hipMemcpyDeviceToDevice, c->stream));
-        u64 h[5];
-        if ((rc = ctx_readback(c, h, tot, 40))) return rc;
+        u64 h[7];
+        if ((rc = ctx_readback(c, h, tot, 56))) return rc;
         T = h[0]; n_ids = h[1]; n_cmt = h[2]; N = h[3];
+        S.no_case = (u32)h[6] == 0 && !(getenv("NAF_GPU_CASE_CENSUS") && getenv("NAF_GPU_CASE_CENSUS")[0] == '0');
+        P.any_case = nullptr;
         const u64 n_irregular = h[4];
         if ((rc = alloc_bases(c, S))) return rc;
         s_ids = (u8 *)arena_alloc(c, n_ids + 16); s_cmt = (u8 *)arena_alloc(c, n_cmt + 16);
@@ -2014,6 +2045,9 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
         }
         // mask (only ever stored next to a 4-bit sequence stream, ennaf.c:445); a shard has counted its boundaries in the census already
         if (S.store_mask && T && (part & 2)) {
+            u64 nb = 0;
+            const bool one_run = !S.census && S.no_case && !K.skip_run0 && !K.prev_masked;         // (the count pass saw no case bit: no pass over the case bits, no scan, no read-back)
+            if (!one_run) {
             if (!S.census) {
                 tc = arena_new<u64>(c, mt + 2); if (!tc) return NAF_GPU_ENOMEM;
                 LAUNCH(c, "ennaf_mask_count", k_maskb_count, mt, 256, 0, (const u64 *)S.casebits, T, tc, 0);
@@ -2021,7 +2055,8 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
             const int b0 = S.census ? ((S.first_base >= 96) != (K.prev_masked != 0)) : 0;          // a shard's case change at its first base
             if (b0) LAUNCH(c, "ennaf_mask_b0", k_add_u64, 1, 64, 0, tc, (u64)1);
             if ((rc = scan_exclusive_u64(c, tc, mt, tc + mt + 1))) return rc;
-            u64 nb = 0; if ((rc = ctx_readback(c, &nb, tc + mt + 1, 8))) return rc;
+            if ((rc = ctx_readback(c, &nb, tc + mt + 1, 8))) return rc;
+            }
             u64 nu = 0;
             if (nb == 0 && !K.skip_run0) {
                 // no case change at all (a text in one case): one run of T bases, its units known here -- 0xFF but for the last one

@@ -773,3 +773,34 @@ def test_tree_descriptions_coded_a_lane_per_block_give_the_same_frame(gpu, oracl
             if level == 1:
                 assert oracle.zstd_decompress(a[:], len(data) + 16) == data.tobytes()
             assert host(gpu.zstd_decompress(gpu.to_device(a), len(data) + 64)) == data.tobytes()
+
+
+def test_case_census_of_the_count_pass(gpu, oracle, monkeypatch):
+    """enc.hip note_case: the count pass tells whether any byte of a sequence line carries the case bit; a text without one gets its
+    mask -- one run of all the bases -- without the pass over the case bits.  Texts of 1.3 MB (pure tiles a wavefront each, the tiles with
+    headers by the general kernel): all upper case with lower-case HEADERS; one lower-case base in the middle of a pure tile, in a tile
+    with a header, as the first and as the last base; a byte >= 0x80 in a sequence line; all lower case -- every stream against the
+    oracle's, and the same archive with NAF_GPU_CASE_CENSUS=0."""
+    rng = np.random.default_rng(31)
+    def fasta(nrec=5, per=260_000, width=70):
+        parts = []
+        for r in range(nrec):
+            b = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), per).tobytes()
+            parts.append(b">chr%d some lower case words %d\n" % (r + 1, r) + b"\n".join(b[i:i + width] for i in range(0, per, width)) + b"\n")
+        return b"".join(parts)
+    base = fasta()
+    def with_lower(text, at):
+        t = bytearray(text)
+        while t[at] not in b"ACGT":
+            at += 1
+        t[at] |= 0x20
+        return bytes(t)
+    first_base = base.index(b"\n") + 1
+    texts = [base, with_lower(base, 600_000), with_lower(base, base.index(b">chr3") + 40), with_lower(base, first_base), with_lower(base, len(base) - 50),
+             base[:700_000] + b"\xc1" + base[700_001:], base.replace(b"A", b"a").replace(b"C", b"c").replace(b"G", b"g").replace(b"T", b"t")]
+    for k, text in enumerate(texts):
+        a = check_ennaf(gpu, oracle, text)
+        monkeypatch.setenv("NAF_GPU_CASE_CENSUS", "0")
+        b = host(gpu.ennaf(gpu.to_device(text))[0])
+        monkeypatch.delenv("NAF_GPU_CASE_CENSUS")
+        assert a == b, k
