@@ -872,8 +872,8 @@ __device__ __forceinline__ void zenc_flat4_stream(u8 *out, const u8 *s, u32 n, c
 
 // LZ-coded blocks (mode[b] != 0) take their literals from L.lits with the plan / codes / tree of those literals (plan1 ...)
 // and append the Sequences_Section made by k_lz_seqenc; all other blocks are coded from src as literal-only blocks.
-struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u16 *codes1; const u8 *trees1; LzBufs B; u32 not_last; };   // not_last: the frame continues behind these blocks (a shard's part of a frame)
-struct ZencJob { const u8 *src; size_t n; u32 nblk, frame_wlog; ZEncPlan *plan; u16 *codes; u8 *trees; u64 *offs; u64 hdr; int with_magic, empty; ZWriteLz L; bool direct; };
+struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u16 *codes1; const u8 *trees1; LzBufs B; u32 not_last; u32 wave_general; };   // wave_general: blocks of general Huffman codes are k_zenc_write_wave's   // not_last: the frame continues behind these blocks (a shard's part of a frame)
+struct ZencJob { const u8 *src; size_t n; u32 nblk, frame_wlog; ZEncPlan *plan; u16 *codes; u8 *trees; u64 *offs; u64 hdr; int with_magic, empty; ZWriteLz L; bool direct; u32 block_bytes; };
 __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nblk, const ZEncPlan *plan, const u16 *codes_g, const u8 *trees,
                                                     const u64 *offs, u8 *dst, u64 frame_hdr, ZWriteLz L)
 {
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
     u32 b0 = blockIdx.x * ZENC_BLOCKS_PER_WG;
     {   // nothing but direct blocks (k_zenc_write_direct's): one look at the sixteen plans instead of three walks over them
         const u32 bb = b0 + (u32)lane;
-        const bool other = lane < ZENC_BLOCKS_PER_WG && bb < nblk && !(plan[bb].kind == ZK_HUF && plan[bb].pad == 2 && !(L.mode && L.mode[bb]));
+        const bool other = lane < ZENC_BLOCKS_PER_WG && bb < nblk && !(plan[bb].kind == ZK_HUF && (plan[bb].pad == 2 || (L.wave_general && !plan[bb].pad)) && !(L.mode && L.mode[bb]));
         if (__ballot(other) == 0) return;
     }
     for (u32 jj = 0; jj < ZENC_BLOCKS_PER_WG; jj++) {               // code tables made by k_zenc_plan: 512 B per block, coalesced
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
     if (b < nblk) {
         const bool lzb = L.mode && L.mode[b];
         u8 *out = dst + frame_hdr + offs[b];
-        if (!lzb && plan[b].kind == ZK_HUF && plan[b].pad) { }          // written above
+        if (!lzb && plan[b].kind == ZK_HUF && (plan[b].pad || L.wave_general)) { }          // written above, or k_zenc_write_wave's
         else if (!lzb) {
             const ZEncPlan p = plan[b];
             u64 lo = zenc_block_lo(n, nblk, b);
@@ -961,6 +961,81 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
         const u8 *s = src + lo; u8 *o = dst + frame_hdr + offs[bb] + 3;
         for (u32 i = lane * 8; i + 8 <= bn; i += 64 * 8) st64(o + i, ld64(s + i));
         for (u32 i = (bn & ~7u) + lane; i < bn; i += 64) o[i] = s[i];
+    }
+}
+
+// Blocks of general Huffman codes a WAVEFRONT per stream (frames where they are few: the blocks of a genome that hold an N or an IUPAC
+// code among direct blocks, the ragged last block of any stream).  One lane per stream walks 8 K symbols one after the other -- 0.4 to
+// 1 ms however few the blocks, at the end of an ennaf call.  Code lengths add up: a lane sums the lengths of its 1/64 of the symbols,
+// a wave scan gives the bit its piece starts at (the LAST symbol is written first, 4.2.2), the pieces are ORed into the stream's
+// image in LDS and the image is copied to its place.  Blocks of up to 32 KiB (11 bits x 8 K symbols per stream).
+#define ZWW_OBUF 12288u
+#define ZWW_BLOCKS 64u
+__global__ __launch_bounds__(256) void k_zenc_write_wave(const u8 *src, u64 n, u32 nblk, const ZEncPlan *plan, const u16 *codes_g, const u8 *trees,
+                                                         const u64 *offs, u8 *dst, u64 frame_hdr, u32 not_last)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 zww[];      // the block's code table, then the four streams' images
+    // (a workgroup looks at ZWW_BLOCKS plans: a launch of one workgroup per block that mostly returns at once cost 0.1 ms per 150 K blocks)
+    __shared__ u64 s_general;
+    if (threadIdx.x < 64) {                                       // which of its blocks are this kernel's: one look by one wavefront
+        const u32 bb = blockIdx.x * ZWW_BLOCKS + threadIdx.x;
+        const u64 m = __ballot(bb < nblk && plan[bb].kind == ZK_HUF && !plan[bb].pad);   // (direct / flat blocks, Raw and RLE blocks: k_zenc_write(_direct))
+        if (threadIdx.x == 0) s_general = m;
+    }
+    __syncthreads();
+    for (u64 todo = s_general; todo; todo &= todo - 1) {
+    const u32 b = blockIdx.x * ZWW_BLOCKS + (u32)(__ffsll((long long)todo) - 1);
+    const ZEncPlan p = plan[b];
+    __syncthreads();                                              // (the images of the block before this one have been copied out)
+    u16 *codes = (u16 *)zww;
+    if (threadIdx.x < 32) ((uint4 *)codes)[threadIdx.x] = ((const uint4 *)(codes_g + (u64)b * 256))[threadIdx.x];
+    const u32 k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32 *ob = (u32 *)(zww + 512 + k * ZWW_OBUF);
+    const u32 per = (p.n + 3) / 4, cnt = k < 3 ? per : p.n - 3 * per, sbytes = p.ssz[k];
+    for (u32 i = lane; i < (sbytes + 11) / 4; i += 64) ob[i] = 0;
+    __syncthreads();
+    const u64 lo_b = zenc_block_lo(n, nblk, b);
+    const u8 *s = src + lo_b + (u64)k * per;
+    const u32 chunk = (cnt + 63) / 64, lo = lane * chunk < cnt ? lane * chunk : cnt, hi = lo + chunk < cnt ? lo + chunk : cnt;
+    // (the piece eight bytes per load: a byte per load was 256 dependent trips to memory per lane)
+    u32 bits = 0;
+    {
+        u32 i = lo;
+        for (; i + 8 <= hi; i += 8) { const u64 v = ld64(s + i);
+#pragma unroll
+            for (u32 q = 0; q < 8; q++) bits += codes[(u32)(v >> (8 * q)) & 0xFFu] >> 12; }
+        for (; i < hi; i++) bits += codes[s[i]] >> 12;
+    }
+    const u32 incl = wave_scan_inclusive<u32, OpAdd>(bits);
+    const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+    u32 pos = total - incl;                                       // where the piece's last symbol goes
+    u64 acc = 0; u32 nb = pos & 31, w = pos >> 5;
+    {
+        u32 i = hi;
+        for (; i >= lo + 8; i -= 8) { const u64 v = ld64(s + i - 8);
+#pragma unroll
+            for (int q = 7; q >= 0; q--) {
+                const u32 e = codes[(u32)(v >> (8 * q)) & 0xFFu];
+                acc |= (u64)(e & 0xFFFu) << nb; nb += e >> 12;
+                if (nb >= 32) { atomicOr(&ob[w], (u32)acc); w++; acc >>= 32; nb -= 32; }
+            } }
+        for (; i-- > lo;) {
+            const u32 e = codes[s[i]];
+            acc |= (u64)(e & 0xFFFu) << nb; nb += e >> 12;
+            if (nb >= 32) { atomicOr(&ob[w], (u32)acc); w++; acc >>= 32; nb -= 32; }
+        }
+    }
+    if (nb) atomicOr(&ob[w], (u32)acc);
+    if (lane == 0) atomicOr(&ob[total >> 5], 1u << (total & 31)); // the end mark
+    __syncthreads();
+    u8 *out = dst + frame_hdr + offs[b];
+    u32 o = 3 + p.lhdr + p.tree_bytes + 6;
+    for (u32 q = 0; q < k; q++) o += p.ssz[q];
+    const u8 *img = (const u8 *)ob;
+    for (u32 i = lane * 8; i + 8 <= sbytes; i += 64 * 8) st64(out + o + i, ld64(img + i));
+    for (u32 i = (sbytes & ~7u) + lane; i < sbytes; i += 64) out[o + i] = img[i];
+    if (threadIdx.x == 0) zenc_write_block_prefix(out, p, trees + (u64)b * ZENC_TREE_SLOT, b + 1 == nblk && !not_last, 0);
+    if (threadIdx.x == 255) out[p.csize - 1] = 0;                 // Number_of_Sequences = 0
     }
 }
 
@@ -1188,7 +1263,7 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     }
     int rc = scan_exclusive_u64(c, offs, nblk, offs + nblk + 1); if (rc) return rc;
     J->direct = direct != nullptr;
-    J->nblk = nblk; J->plan = plan; J->codes = codes; J->trees = trees; J->offs = offs; J->hdr = hdr; J->with_magic = with_magic; J->frame_wlog = frame_wlog;
+    J->block_bytes = (u32)bs; J->nblk = nblk; J->plan = plan; J->codes = codes; J->trees = trees; J->offs = offs; J->hdr = hdr; J->with_magic = with_magic; J->frame_wlog = frame_wlog;
     return 0;
 }
 
@@ -1221,8 +1296,15 @@ static int zenc_finish(naf_gpu_ctx *c, ZencJob *J, u8 *d_dst, size_t cap, size_t
         if (!(d_dst = place->fn(place->ud, hdr + total))) return NAF_GPU_ECAP;
     }
     if (hdr) LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, J->with_magic, J->frame_wlog);
+    {
+        // few blocks of general codes (a frame of direct blocks, a short frame): a wavefront per stream for those (NAF_GPU_WRITE_WAVE=0: never)
+        const char *ww = getenv("NAF_GPU_WRITE_WAVE");
+        J->L.wave_general = (!J->L.mode && J->block_bytes <= 32768u && (J->direct || nblk <= 2048u) && !(ww && ww[0] == '0')) ? 1u : 0u;
+    }
     LAUNCH(c, "zenc_write", k_zenc_write, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, J->src, (u64)J->n, nblk, (const ZEncPlan *)J->plan, (const u16 *)J->codes, (const u8 *)J->trees,
            (const u64 *)J->offs, d_dst, hdr, J->L);
+    if (J->L.wave_general) LAUNCH(c, "zenc_write_wave", k_zenc_write_wave, cdiv(nblk, ZWW_BLOCKS), 256, 512u + 4u * ZWW_OBUF, J->src, (u64)J->n, nblk, (const ZEncPlan *)J->plan, (const u16 *)J->codes, (const u8 *)J->trees,
+           (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
     if (J->direct) LAUNCH(c, "zenc_write_direct", k_zenc_write_direct, nblk, 256, 0, J->src, nblk, (const ZEncPlan *)J->plan, (const u8 *)J->trees, (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
     if (!place && (rc = ctx_readback(c, &total, J->offs + nblk + 1, 8))) return rc;
     *out_len = hdr + total;
