@@ -884,7 +884,7 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
     u32 b0 = blockIdx.x * ZENC_BLOCKS_PER_WG;
     {   // nothing but direct blocks (k_zenc_write_direct's): one look at the sixteen plans instead of three walks over them
         const u32 bb = b0 + (u32)lane;
-        const bool other = lane < ZENC_BLOCKS_PER_WG && bb < nblk && !(plan[bb].kind == ZK_HUF && (plan[bb].pad == 2 || (L.wave_general && !plan[bb].pad)) && !(L.mode && L.mode[bb]));
+        const bool other = lane < ZENC_BLOCKS_PER_WG && bb < nblk && !(plan[bb].kind == ZK_HUF && (plan[bb].pad == 2 || L.wave_general) && !(L.mode && L.mode[bb]));
         if (__ballot(other) == 0) return;
     }
     for (u32 jj = 0; jj < ZENC_BLOCKS_PER_WG; jj++) {               // code tables made by k_zenc_plan: 512 B per block, coalesced
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
         if (bb >= nblk) break;
         if (L.mode && L.mode[bb]) continue;
         const ZEncPlan p = plan[bb];
-        if (p.kind != ZK_HUF || !p.pad) continue;
+        if (p.kind != ZK_HUF || !p.pad || L.wave_general) continue;   // (wave_general: every Huffman block that is not direct is k_zenc_write_wave's)
         if (p.pad == 2) continue;                                     // a direct block: prefix and streams are k_zenc_write_direct's
         u8 *out = dst + frame_hdr + offs[bb];
         const u64 lo = zenc_block_lo(n, nblk, bb);
@@ -923,8 +923,7 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
             if (p.kind == ZK_HUF) {
                 u32 per = (p.n + 3) / 4;
                 u32 cnt = k < 3 ? per : p.n - 3 * per;
-                u32 o = 3 + p.lhdr + p.tree_bytes + 6;
-                for (u32 q = 0; q < k; q++) o += p.ssz[q];
+                const u32 o = 3 + p.lhdr + p.tree_bytes + 6 + (k > 0 ? p.ssz[0] : 0u) + (k > 1 ? p.ssz[1] : 0u) + (k > 2 ? p.ssz[2] : 0u);
                 if (p.log <= 7) huf_encode_stream_staged<8>(out + o, src + lo + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
                 else huf_encode_stream_staged<4>(out + o, src + lo + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
                 if (k == 3) out[p.csize - 1] = 0;                   // Number_of_Sequences = 0
@@ -938,8 +937,7 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
                 if (k == 0) zenc_write_huf_lit_prefix(out + 3, p, L.trees1 + (u64)b * ZENC_TREE_SLOT);
                 u32 per = (p.n + 3) / 4;
                 u32 cnt = k < 3 ? per : p.n - 3 * per;
-                u32 o = 3 + p.lhdr + p.tree_bytes + 6;
-                for (u32 q = 0; q < k; q++) o += p.ssz[q];
+                const u32 o = 3 + p.lhdr + p.tree_bytes + 6 + (k > 0 ? p.ssz[0] : 0u) + (k > 1 ? p.ssz[1] : 0u) + (k > 2 ? p.ssz[2] : 0u);
                 if (p.log <= 7) huf_encode_stream_staged<8>(out + o, lits + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
                 else huf_encode_stream_staged<4>(out + o, lits + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
             } else if (k == 0) {
@@ -978,24 +976,34 @@ __global__ __launch_bounds__(256) void k_zenc_write_wave(const u8 *src, u64 n, u
     // (a workgroup looks at ZWW_BLOCKS plans: a launch of one workgroup per block that mostly returns at once cost 0.1 ms per 150 K blocks)
     __shared__ u64 s_general;
     if (threadIdx.x < 64) {                                       // which of its blocks are this kernel's: one look by one wavefront
-        const u32 bb = blockIdx.x * ZWW_BLOCKS + threadIdx.x;
-        const u64 m = __ballot(bb < nblk && plan[bb].kind == ZK_HUF && !plan[bb].pad);   // (direct / flat blocks, Raw and RLE blocks: k_zenc_write(_direct))
+        // (block blockIdx.x + t gridDim.x: neighbouring blocks -- a probed MiB of a genome is 32 blocks of sixteen 4-bit codes in a row, and one
+        // wavefront writing sixteen of them one after the other was 0.4 ms at the end of every ennaf call -- go to different workgroups)
+        const u64 bb = (u64)blockIdx.x + (u64)threadIdx.x * gridDim.x;
+        const u64 m = __ballot(bb < nblk && plan[bb].kind == ZK_HUF && plan[bb].pad != 2);   // (direct blocks, Raw and RLE blocks: k_zenc_write(_direct))
         if (threadIdx.x == 0) s_general = m;
     }
     __syncthreads();
     for (u64 todo = s_general; todo; todo &= todo - 1) {
-    const u32 b = blockIdx.x * ZWW_BLOCKS + (u32)(__ffsll((long long)todo) - 1);
+    const u32 b = blockIdx.x + (u32)(__ffsll((long long)todo) - 1) * gridDim.x;
     const ZEncPlan p = plan[b];
     __syncthreads();                                              // (the images of the block before this one have been copied out)
     u16 *codes = (u16 *)zww;
     if (threadIdx.x < 32) ((uint4 *)codes)[threadIdx.x] = ((const uint4 *)(codes_g + (u64)b * 256))[threadIdx.x];
     const u32 k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32 *ob = (u32 *)(zww + 512 + k * ZWW_OBUF);
-    const u32 per = (p.n + 3) / 4, cnt = k < 3 ? per : p.n - 3 * per, sbytes = p.ssz[k];
+    const u32 per = (p.n + 3) / 4, cnt = k < 3 ? per : p.n - 3 * per, sbytes = k == 0 ? p.ssz[0] : k == 1 ? p.ssz[1] : k == 2 ? p.ssz[2] : p.ssz[3];
     for (u32 i = lane; i < (sbytes + 11) / 4; i += 64) ob[i] = 0;
     __syncthreads();
     const u64 lo_b = zenc_block_lo(n, nblk, b);
     const u8 *s = src + lo_b + (u64)k * per;
+    u8 *out = dst + frame_hdr + offs[b];
+    const u32 o = 3 + p.lhdr + p.tree_bytes + 6 + (k > 0 ? p.ssz[0] : 0u) + (k > 1 ? p.ssz[1] : 0u) + (k > 2 ? p.ssz[2] : 0u);
+    if (p.pad == 1) {                                             // sixteen 4-bit codes: the stream straight from the symbols, all lanes (zenc_flat4_stream)
+        zenc_flat4_stream(out + o, s, cnt, codes, lane);
+        if (threadIdx.x == 0) zenc_write_block_prefix(out, p, trees + (u64)b * ZENC_TREE_SLOT, b + 1 == nblk && !not_last, 0);
+        if (threadIdx.x == 255) out[p.csize - 1] = 0;
+        continue;
+    }
     const u32 chunk = (cnt + 63) / 64, lo = lane * chunk < cnt ? lane * chunk : cnt, hi = lo + chunk < cnt ? lo + chunk : cnt;
     // (the piece eight bytes per load: a byte per load was 256 dependent trips to memory per lane)
     u32 bits = 0;
@@ -1028,9 +1036,6 @@ __global__ __launch_bounds__(256) void k_zenc_write_wave(const u8 *src, u64 n, u
     if (nb) atomicOr(&ob[w], (u32)acc);
     if (lane == 0) atomicOr(&ob[total >> 5], 1u << (total & 31)); // the end mark
     __syncthreads();
-    u8 *out = dst + frame_hdr + offs[b];
-    u32 o = 3 + p.lhdr + p.tree_bytes + 6;
-    for (u32 q = 0; q < k; q++) o += p.ssz[q];
     const u8 *img = (const u8 *)ob;
     for (u32 i = lane * 8; i + 8 <= sbytes; i += 64 * 8) st64(out + o + i, ld64(img + i));
     for (u32 i = (sbytes & ~7u) + lane; i < sbytes; i += 64) out[o + i] = img[i];
@@ -1047,8 +1052,7 @@ __global__ __launch_bounds__(256) void k_zenc_write_direct(const u8 *src, u32 nb
     const u32 b = blockIdx.x, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const ZEncPlan p = plan[b];
     if (p.kind != ZK_HUF || p.pad != 2) return;
-    u32 o = 3 + p.lhdr + p.tree_bytes + 6;
-    for (u32 k = 0; k < q; k++) o += p.ssz[k];
+    const u32 o = 3 + p.lhdr + p.tree_bytes + 6 + (q > 0 ? p.ssz[0] : 0u) + (q > 1 ? p.ssz[1] : 0u) + (q > 2 ? p.ssz[2] : 0u);   // (no run-time index into the plan: that puts it in scratch memory)
     const uint4 *in = (const uint4 *)(src + ((u64)b << 15) + 4096u * q);
     u8 *out = dst + frame_hdr + offs[b], *so = out + o;
     if (threadIdx.x == 255) { zenc_write_block_prefix(out, p, trees + (u64)b * ZENC_TREE_SLOT, b + 1 == nblk && !not_last, 0); out[p.csize - 1] = 0; }
