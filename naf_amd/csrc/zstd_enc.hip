@@ -446,6 +446,8 @@ __global__ __launch_bounds__(64) void k_zenc_tree(u32 nblk, ZEncPlan *plan, u8 *
 // against a hash table of earlier positions (block and table in LDS), the first lane with a match of >= LZ_MINMATCH wins,
 // the literals before it and the (ll, ml, distance) triple are emitted, and the round restarts behind the match.
 #define LZ_MINMATCH 5
+// a value of lane l, l the same in every lane (found through a ballot): v_readlane_b32, not a trip through the LDS crossbar
+__device__ __forceinline__ u32 rdlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 #define LZ_HASH_LOG 12
 #define LZ_BLOCK_MAX 32768
 #define LZ_LANE_EXT 32                    // bytes a lane extends its own match by before the wave takes over
@@ -458,7 +460,7 @@ struct LzBufs {
 };
 // Dynamic LDS: the block (block size + 320 bytes of zero padding) followed by the hash table; sized by the host for the
 // block size in use, since LDS per wavefront is what bounds the blocks in flight (16 KiB blocks: 6 per CU, 32 KiB: 3).
-__global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk, LzBufs B, u32 buf_bytes)
+__global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk, LzBufs B, u32 buf_bytes, u32 hash_log)
 {
     __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     extern __shared__ __attribute__((aligned(16))) u8 lz_lds[];
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk,
         if (i + 16 <= bn) { uint4 v; __builtin_memcpy(&v, src + lo + i, 16); *(uint4 *)(buf + i) = v; }
         else for (u32 k = i; k < bn; k++) buf[k] = src[lo + k];
     }
-    for (u32 i = lane; i < (1u << LZ_HASH_LOG); i += 64) tab[i] = 0;     // 0 = empty, else position + 1
+    for (u32 i = lane; i < (1u << hash_log); i += 64) tab[i] = 0;     // 0 = empty, else position + 1
     for (u32 i = bn + lane; i < bn + 320 && i < buf_bytes; i += 64) buf[i] = 0;
     __syncthreads();
     u8 *lits = B.lits + (u64)b * B.slot;
@@ -482,17 +484,17 @@ __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk,
         u32 v = 0, h = 0, c = 0, m = 0;
         if (valid) {
             __builtin_memcpy(&v, buf + p, 4);
-            h = (v * 2654435761u) >> (32 - LZ_HASH_LOG);
+            h = (v * 2654435761u) >> (32 - hash_log);
             c = tab[h];                                              // positions of earlier rounds only (< cur)
             if (c) {
                 u32 q = c - 1, cv; __builtin_memcpy(&cv, buf + q, 4);
                 if (cv == v) {
                     m = 4;
-                    for (;;) {                                       // 4 bytes per step; buf is zero-padded behind bn
-                        u32 x, y; __builtin_memcpy(&x, buf + q + m, 4); __builtin_memcpy(&y, buf + p + m, 4);
-                        u32 d = x ^ y;
-                        if (d) { m += (u32)(__ffs((int)d) - 1) >> 3; break; }
-                        m += 4;
+                    for (;;) {                                       // 8 bytes per step; buf is zero-padded behind bn
+                        u64 x, y; __builtin_memcpy(&x, buf + q + m, 8); __builtin_memcpy(&y, buf + p + m, 8);
+                        const u64 d = x ^ y;
+                        if (d) { m += (u32)(__ffsll((long long)d) - 1) >> 3; break; }
+                        m += 8;
                         if (p + m >= bn || m >= LZ_LANE_EXT) break;   // long matches are finished by the whole wave (below)
                     }
                     if (p + m > bn) m = bn - p;
@@ -507,14 +509,14 @@ __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk,
             u64 w2 = win & ~((1ull << (next - cur)) - 1);
             if (!w2) break;
             u32 f = (u32)__ffsll((long long)w2) - 1;
-            u32 pf = cur + f, mf = (u32)__shfl((int)m, (int)f, 64), cf = (u32)__shfl((int)c, (int)f, 64) - 1;
+            u32 pf = cur + f, mf = rdlane(m, f), cf = rdlane(c, f) - 1;
             while (mf >= LZ_LANE_EXT && pf + mf < bn) {              // 256 bytes per step: lane k compares bytes [4k, 4k+4) behind the match so far
                 u32 x, y; __builtin_memcpy(&x, buf + cf + mf + 4 * lane, 4); __builtin_memcpy(&y, buf + pf + mf + 4 * lane, 4);
                 u32 d = x ^ y;                                        // reads stay inside the zero padding behind bn (bn + 256 + 4)
                 u64 ne = __ballot(d != 0);
                 if (!ne) { mf += 256; continue; }
                 u32 l0 = (u32)__ffsll((long long)ne) - 1;
-                u32 d0 = (u32)__shfl((int)d, (int)l0, 64);
+                u32 d0 = rdlane(d, l0);
                 mf += 4 * l0 + (((u32)__ffs((int)d0) - 1) >> 3);
                 break;
             }
@@ -608,7 +610,7 @@ __device__ __forceinline__ u32 lzx_wave_match(const u8 *buf, const u8 *gblk /* s
         const u64 ne = __ballot(d != 0 || oob);
         if (!ne) { m += 256; continue; }
         const u32 l0 = (u32)__ffsll((long long)ne) - 1;
-        const u32 d0 = (u32)__shfl((int)d, (int)l0, 64);
+        const u32 d0 = rdlane(d, l0);
         m += 4 * l0 + (d0 ? ((u32)__ffs((int)d0) - 1) >> 3 : 0u);
         break;
     }
@@ -717,8 +719,8 @@ __global__ __launch_bounds__(64) void k_lzx_parse(const u8 *src, u64 n, u32 nblk
             const u64 w2 = win & ~((1ull << (next - cur)) - 1);
             if (!w2) break;
             const u32 f = (u32)__ffsll((long long)w2) - 1;
-            u32 pf = cur + f, mf = (u32)__shfl((int)m, (int)f, 64);
-            const u32 clo = (u32)__shfl((int)(u32)(u64)c, (int)f, 64), chi = (u32)__shfl((int)(u32)((u64)c >> 32), (int)f, 64);
+            u32 pf = cur + f, mf = rdlane(m, f);
+            const u32 clo = rdlane((u32)(u64)c, f), chi = rdlane((u32)((u64)c >> 32), f);
             i64 cf = (i64)(((u64)chi << 32) | clo);
             if (mf >= LZ_LANE_EXT) mf = lzx_wave_match(buf, gblk, n - lo, bn, pf, cf, mf);
             const u32 back = lzx_wave_back(buf, gblk, lo, pf, cf, anchor);
@@ -1257,7 +1259,10 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
             LAUNCH(c, "zenc_lz_parse", k_lzx_parse, nblk, 64, lz_buf + (2u << LZ_HASH_LOG), d_src, (u64)n, nblk, B, lz_buf, T);
             LAUNCH(c, "zenc_lz_seqenc", k_lzx_seqenc, nblk, 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
         } else {
-            LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << LZ_HASH_LOG), d_src, (u64)n, nblk, B, lz_buf);
+            // the table's size is LDS a wavefront holds for the whole block: what bounds the blocks in flight per CU -- and what is left
+            // of a CU for the kernels of the other streams (NAF_GPU_LZ_HASH_LOG, 9 .. 12)
+            u32 hash_log = LZ_HASH_LOG; { const char *hl = getenv("NAF_GPU_LZ_HASH_LOG"); if (hl && atoi(hl) >= 9 && atoi(hl) <= 12) hash_log = (u32)atoi(hl); }
+            LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << hash_log), d_src, (u64)n, nblk, B, lz_buf, hash_log);
             LAUNCH(c, "zenc_lz_seqenc", k_lz_seqenc, cdiv(nblk, 64), 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
         }
         LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse, min_gain, maxbits, 0u, (const u8 *)nullptr, wt_defer);
