@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnaf_gpu.so")
+LIB_PATH = os.environ.get("NAF_GPU_LIB") or os.path.join(_HERE, "libnaf_gpu.so")       # NAF_GPU_LIB: another build of the same C-ABI (A / B measurements)
 
 OUT_DEFAULT, OUT_FASTA, OUT_FASTQ, OUT_SEQ, OUT_SEQUENCES, OUT_4BIT = -1, 0, 1, 2, 3, 4
 SEQ_DNA, SEQ_RNA, SEQ_PROTEIN, SEQ_TEXT = 0, 1, 2, 3
