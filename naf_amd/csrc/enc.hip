@@ -1491,26 +1491,32 @@ __global__ void k_add_u64(u64 *p, u64 v) { if (threadIdx.x == 0 && blockIdx.x ==
 // run r (0-based) spans [start_r, start_{r+1}) with start_0 = 0, start_{r} = bnd[r-1]; the last one ends at T + ext, ext = the
 // bases of the following shards that continue it (0 for a whole input).  skip0: run 0 -- the bases in front of this shard's first
 // case change -- continues a run of an earlier shard, which emits its units.
-// *any_long is raised by a run of 255 bases or more (more than one unit): where none is -- reads whose case changes every few bases --
-// run r's unit is unit r, and the scan of the unit counts (and its read-back) is not needed.
-__global__ void k_mask_run_units(const u64 *bnd, u64 nb, u64 T, u64 *units, u64 ext, int skip0, u64 *any_long)
+__global__ void k_mask_run_units(const u64 *bnd, u64 nb, u64 T, u64 *units, u64 ext, int skip0)
 {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > nb) return;
     u64 s = r ? bnd[r - 1] : 0, e = r < nb ? bnd[r] : T + ext;
-    const u64 u = (skip0 && r == 0) ? 0 : (e - s) / 255 + 1;
-    units[r] = u;
-    if (u > 1) *any_long = 1;
+    units[r] = (skip0 && r == 0) ? 0 : (e - s) / 255 + 1;
 }
-// every unit that is not the last of its run is 255: the array is pre-filled with 255 and one lane per run writes the remainder.
-// unit_off == nullptr: every run is one unit (k_mask_run_units found no long one), run r's unit is r, or r - 1 behind a skipped run 0.
+// The units of a mask whose runs are ALL shorter than 255 bases -- reads whose case changes every few bases: 170 M runs per 4 GB of
+// such a FASTQ -- are one per run, in run order: written here on that assumption, run r's unit at r (r - 1 behind a skipped run 0).
+// *any_long is raised by a run that needs more than one unit; the caller then takes the general way (unit counts, their scan, the
+// read-back of their sum, k_mask_units_write) and this kernel's output is dropped.
+__global__ void k_mask_units_short(const u64 *bnd, u64 nb, u64 T, u8 *out, u64 ext, int skip0, u64 *any_long)
+{
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nb || (skip0 && r == 0)) return;
+    u64 s = r ? bnd[r - 1] : 0, e = r < nb ? bnd[r] : T + ext, len = e - s;
+    if (len >= 255) { *any_long = 1; return; }
+    out[r - (skip0 ? 1 : 0)] = (u8)len;
+}
+// every unit that is not the last of its run is 255: the array is pre-filled with 255 and one lane per run writes the remainder
 __global__ void k_mask_units_write(const u64 *bnd, u64 nb, u64 T, const u64 *unit_off, u8 *out, u64 ext, int skip0)
 {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > nb || (skip0 && r == 0)) return;
     u64 s = r ? bnd[r - 1] : 0, e = r < nb ? bnd[r] : T + ext, len = e - s;
-    const u64 off = unit_off ? unit_off[r] : r - (skip0 ? 1 : 0);
-    out[off + len / 255] = (u8)(len % 255);
+    out[unit_off[r] + len / 255] = (u8)(len % 255);
 }
 
 // ---- the same scan over the case BITS that flush_pack leaves for a 4-bit stream: 64 bases per lane, 16384 per tile -------------------
@@ -2073,24 +2079,28 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
                 SmallBytes lb; memset(&lb, 0, sizeof lb); lb.b[0] = (u8)(len % 255); lb.n = 1;
                 LAUNCH(c, "ennaf_mask_units", k_put_bytes, 1, 64, 0, s_mask + (nu - 1), lb);
             } else {
-            u64 *bnd = arena_new<u64>(c, nb + 1), *ru = arena_new<u64>(c, nb + 4);
-            if (!bnd || !ru) return NAF_GPU_ENOMEM;
-            u64 *any_long = ru + nb + 3;
-            HIP_TRY(c, hipMemsetAsync(any_long, 0, 8, c->stream));
+            u64 *bnd = arena_new<u64>(c, nb + 1), *any_long = arena_new<u64>(c, 1);
+            if (!bnd || !any_long) return NAF_GPU_ENOMEM;
             if (nb) LAUNCH(c, "ennaf_mask_bscatter", k_maskb_scatter, mt, 256, 0, (const u64 *)S.casebits, T, (const u64 *)tc, nb, bnd, K.prev_masked);
-            LAUNCH(c, "ennaf_mask_runs", k_mask_run_units, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, ru, K.run_ext, K.skip_run0, any_long);
-            // runs of fewer than 255 bases only (a FASTQ whose reads change case every few bases: 170 M runs per 4 GB): a unit per run, in
-            // run order -- no scan over the unit counts (NAF_GPU_MASK_SHORT=0: always the scan)
+            // runs of fewer than 255 bases only: a unit per run, in run order, written on that assumption (NAF_GPU_MASK_SHORT=0: never assumed)
             u64 longs = 1;
-            { const char *ms = getenv("NAF_GPU_MASK_SHORT"); if (!(ms && ms[0] == '0') && (rc = ctx_readback(c, &longs, any_long, 8))) return rc; }
-            if (!longs) nu = nb + 1 - (K.skip_run0 ? 1 : 0);
-            else {
+            { const char *ms = getenv("NAF_GPU_MASK_SHORT");
+              if (!(ms && ms[0] == '0')) {
+                  nu = nb + 1 - (K.skip_run0 ? 1 : 0);
+                  s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
+                  HIP_TRY(c, hipMemsetAsync(any_long, 0, 8, c->stream));
+                  LAUNCH(c, "ennaf_mask_units", k_mask_units_short, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, s_mask, K.run_ext, K.skip_run0, any_long);
+                  if ((rc = ctx_readback(c, &longs, any_long, 8))) return rc;
+              } }
+            if (longs) {
+                u64 *ru = arena_new<u64>(c, nb + 3); if (!ru) return NAF_GPU_ENOMEM;
+                LAUNCH(c, "ennaf_mask_runs", k_mask_run_units, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, ru, K.run_ext, K.skip_run0);
                 if ((rc = scan_exclusive_u64(c, ru, nb + 1, ru + nb + 2))) return rc;
                 if ((rc = ctx_readback(c, &nu, ru + nb + 2, 8))) return rc;
+                s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
+                if (nu) HIP_TRY(c, hipMemsetAsync(s_mask, 0xFF, nu, c->stream));
+                LAUNCH(c, "ennaf_mask_units", k_mask_units_write, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, (const u64 *)ru, s_mask, K.run_ext, K.skip_run0);
             }
-            s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
-            if (nu) HIP_TRY(c, hipMemsetAsync(s_mask, 0xFF, nu, c->stream));
-            LAUNCH(c, "ennaf_mask_units", k_mask_units_write, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, longs ? (const u64 *)ru : (const u64 *)nullptr, s_mask, K.run_ext, K.skip_run0);
             }
             // Block size of the mask stream.  Real soft-masking (runs of a few hundred bases) gives a few MB of high-entropy units, i.e. a
             // few hundred blocks whose Huffman streams the decoder walks serially: 8 KiB blocks (2 KiB streams) cut that latency to a
