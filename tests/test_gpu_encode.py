@@ -804,3 +804,39 @@ def test_case_census_of_the_count_pass(gpu, oracle, monkeypatch):
         b = host(gpu.ennaf(gpu.to_device(text))[0])
         monkeypatch.delenv("NAF_GPU_CASE_CENSUS")
         assert a == b, k
+
+
+def test_mask_of_short_runs_written_without_the_scan(gpu, oracle, monkeypatch):
+    """enc.hip k_mask_units_short: a mask whose runs are all shorter than 255 bases has one unit per run, written straight from the
+    boundaries; a run of 255 bases or more raises the flag and the general way (unit counts, scan, k_mask_units_write) runs instead.
+    Texts of 1.2 MB whose case changes every 1..40 bases: as they are (short way); with ONE run of exactly 254 bases (still short), of
+    255 (the first long one: two units, the second 0), of 300 and of 70 000 bases in the middle, as the first run, as the last run
+    -- every stream against the oracle's, and the same archive with NAF_GPU_MASK_SHORT=0."""
+    rng = np.random.default_rng(77)
+    def fasta(nrec=4, per=300_000, width=60):
+        parts = []
+        for r in range(nrec):
+            b = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), per)
+            runs = rng.integers(1, 41, per // 10)
+            edges = np.cumsum(runs); edges = edges[edges < per]
+            lower = (np.searchsorted(edges, np.arange(per), side="right") & 1).astype(bool)
+            b = np.where(lower, b | 0x20, b).astype(np.uint8).tobytes()
+            parts.append(b">s%d\n" % (r + 1) + b"\n".join(b[i:i + width] for i in range(0, per, width)) + b"\n")
+        return b"".join(parts)
+    base = fasta()
+    def with_run(text, at, n, lower):
+        t = bytearray(text); k = 0
+        while k < n:
+            if t[at] in b"ACGTacgt":
+                t[at] = (t[at] | 0x20) if lower else (t[at] & 0xDF); k += 1
+            at += 1
+        return bytes(t)
+    first = base.index(b"\n") + 1
+    texts = [base, with_run(base, 500_000, 254, True), with_run(base, 500_000, 255, True), with_run(base, 500_000, 300, False),
+             with_run(base, 400_000, 70_000, True), with_run(base, first, 300, False), with_run(base, len(base) - 400, 300, True)]
+    for k, text in enumerate(texts):
+        a = check_ennaf(gpu, oracle, text)
+        monkeypatch.setenv("NAF_GPU_MASK_SHORT", "0")
+        b = host(gpu.ennaf(gpu.to_device(text))[0])
+        monkeypatch.delenv("NAF_GPU_MASK_SHORT")
+        assert a == b, k
