@@ -55,7 +55,7 @@ struct naf_gpu_ctx {
     naf_gpu_ctx *side = nullptr;
     naf_gpu_ctx *side2 = nullptr;         // third one: the quality stream of a FASTQ archive decodes beside the sequence stream
     naf_gpu_ctx *side3 = nullptr;         // fourth: ids and names beside lengths and mask
-    naf_gpu_ctx *side4 = nullptr;         // unused (a fifth thread for the mask stream measured slower); unnaf_sections still takes one
+    naf_gpu_ctx *side4 = nullptr;         // fifth: the names of an archive of many records beside its ids (emit.hip: unnaf_sections_main)
     hipEvent_t fork_ev = nullptr;
     struct ZSplit *zsplit = nullptr;        // set by unnaf for the sequence stream of a whole-text call: Huffman literals in parts (below)
     hipEvent_t split_ev[ZSPLIT_MAX + 2] = {};

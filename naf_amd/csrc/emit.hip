@@ -1371,7 +1371,7 @@ static int unnaf_prepare(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const 
 // Lengths, ids, names and the prefix tables built from them (text offset / first base of every record).  `aux`: a context of its
 // own for ids + names (second host thread and stream); nullptr = everything on c, in order.
 template <typename Hook>
-static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gpu_ctx *aux, Hook early, bool early_has_work)
+static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gpu_ctx *aux, Hook early, bool early_has_work, naf_gpu_ctx *aux_names)
 {
     const naf_gpu_header &h = pl.h;
     EmitP &P = pl.P;
@@ -1402,16 +1402,17 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
             for (int q = 0; q < m; q++) if (ok[q]) pre[idx[q]] = dst[q];
             return 0;
         };
-        auto ids_names = [&](naf_gpu_ctx *x) -> int {
+        // which = 1: ids, 2: names, 3: both (one after the other)
+        auto ids_names = [&](naf_gpu_ctx *x, int which = 3) -> int {
             int r;
-            if (want_names && has_ids) {
+            if ((which & 1) && want_names && has_ids) {
                 u8 *b = pre[0]; u64 *z = nullptr;
                 if (h.orig_size[S_IDS] == 0) return ctx_fail(x, NAF_GPU_EFORMAT, "corrupted ids - not 0-terminated\n");
                 if (!b && (r = load_section(x, d_naf, h, S_IDS, h.orig_size[S_IDS], "ids", &b, pl.frame_head[S_IDS]))) return r;
                 if ((r = zero_positions(x, b, h.orig_size[S_IDS], N, &z, false))) return r;
                 P.ids = b; P.idz = z;
             }
-            if (want_names && has_names) {
+            if ((which & 2) && want_names && has_names) {
                 u8 *b = pre[1]; u64 *z = nullptr;
                 if (h.orig_size[S_NAMES] == 0) return ctx_fail(x, NAF_GPU_EFORMAT, "corrupted names - not 0-terminated\n");
                 if (!b && (r = load_section(x, d_naf, h, S_NAMES, h.orig_size[S_NAMES], "names", &b, pl.frame_head[S_NAMES]))) return r;
@@ -1444,15 +1445,23 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
         const bool len_on_aux = aux_run && early_has_work;
         int rc_small = 0;
         if (aux_run && !len_on_aux) rc_small = small3(c);                    // this context has nothing else to do meanwhile
-        if (aux_run) ctx_worker_start(aux, [&] { if (len_on_aux) rc_small = small3(aux); rc_aux = rc_small ? rc_small : ids_names(aux); if (len_on_aux && !rc_small) rc_len = lengths(aux); });     // no return until it is joined
+        // Ids and names of an archive of many records (a FASTQ's 12 M reads per 4 GB: two streams through the sequence executor, 3.9 and
+        // 1.1 ms one after the other, and the emit waits for both) go to a context each (NAF_GPU_NAMES_BESIDE=0: both on `aux`).
+        bool names_beside = aux_run && aux_names && !len_on_aux && has_ids && has_names && h.orig_size[S_IDS] >= (1u << 20) && h.orig_size[S_NAMES] >= (1u << 20);
+        { const char *nb = getenv("NAF_GPU_NAMES_BESIDE"); if (nb && nb[0] == '0') names_beside = false; }
+        int rc_names = 0;
+        if (names_beside) ctx_worker_start(aux_names, [&] { rc_names = ids_names(aux_names, 2); });               // pre[] is set by now (small3 ran on c above), no return until it is joined
+        if (aux_run) ctx_worker_start(aux, [&] { if (len_on_aux) rc_small = small3(aux); rc_aux = rc_small ? rc_small : ids_names(aux, names_beside ? 1 : 3); if (len_on_aux && !rc_small) rc_len = lengths(aux); });     // no return until it is joined
         early();                                                                                         // work that needs none of this (the mask stream)
         if (!aux_run) rc_small = small3(c);
         if (!len_on_aux) rc_len = rc_small ? rc_small : lengths(c);
         if (aux_run) { ctx_worker_join(aux); hipStreamSynchronize(aux->stream); }
+        if (names_beside) { ctx_worker_join(aux_names); hipStreamSynchronize(aux_names->stream); }
         if (rc_len) { if (len_on_aux) memcpy(c->err, aux->err, sizeof c->err); return rc_len; }           // the order a sequential run reports in: lengths, ids, names
         if (!aux_run) rc_aux = ids_names(c);
         else if (rc_aux) memcpy(c->err, aux->err, sizeof c->err);
         if (rc_aux) return rc_aux;
+        if (rc_names) { memcpy(c->err, aux_names->err, sizeof c->err); return rc_names; }                      // (ids, then names: the order a sequential run reports in)
         P.rec_len = rec_len;
         u32 *hdr_len = arena_new<u32>(c, N + 1);
         u64 *rec_out = arena_new<u64>(c, N + 2), *rec_base = arena_new<u64>(c, N + 2);
@@ -1502,7 +1511,7 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
 // The side streams (lengths, ids, names, mask) and the tables built from them.  Runs on whichever context it is given: the
 // archive's own for byte-range calls (aux = aux_mask = nullptr: sequential), the side context for whole-text calls, which also
 // hands over contexts for ids + names and for the mask.
-static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gpu_ctx *aux = nullptr, naf_gpu_ctx *aux_mask = nullptr)
+static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gpu_ctx *aux = nullptr, naf_gpu_ctx *aux_mask = nullptr, naf_gpu_ctx *aux_names = nullptr)
 {
     const naf_gpu_header &h = pl.h;
     EmitP &P = pl.P;
@@ -1557,7 +1566,7 @@ static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gp
     auto early = [&]() {
         if (P.masking && !mask_started && P.mode != EM_SEQ && aux) { mask_early = true; rc_mask = mask_part(c); if (rc_mask) memcpy(mask_err, c->err, sizeof c->err); }
     };
-    int rc = unnaf_sections_main(c, d_naf, pl, aux, early, P.masking && !mask_started && P.mode != EM_SEQ && aux != nullptr);
+    int rc = unnaf_sections_main(c, d_naf, pl, aux, early, P.masking && !mask_started && P.mode != EM_SEQ && aux != nullptr, aux_names);
     if (mask_started) { ctx_worker_join(aux_mask); hipStreamSynchronize(aux_mask->stream); }
     if (rc) return rc;                                                                                     // the order a sequential run reports in
     if (mask_started && rc_mask) { memcpy(c->err, aux_mask->err, sizeof c->err); return rc_mask; }
@@ -1641,7 +1650,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         if (c->side3) { arena_reset(c->side3); HIP_TRY(c, hipStreamWaitEvent(c->side3->stream, c->fork_ev, 0)); }
         if (c->side4) { arena_reset(c->side4); HIP_TRY(c, hipStreamWaitEvent(c->side4->stream, c->fork_ev, 0)); }
         // no early return between here and the joins
-        ctx_worker_start(c->side, [&] { rc_side = unnaf_sections(c->side, d_naf, pl, c->side3, nullptr); });   // the mask stays on this context: a thread of its own measured slower, with and without the split decode
+        ctx_worker_start(c->side, [&] { rc_side = unnaf_sections(c->side, d_naf, pl, c->side3, nullptr, c->side4); });   // the mask stays on this context: a thread of its own measured slower, with and without the split decode
         if (qpar) ctx_worker_start(c->side2, [&] { rc_q = payload_qual(c->side2); });
         // decode -> emit pipeline (ZSplit): the quality context is free when there is no quality stream
         const char *nsp = getenv("NAF_GPU_SPLIT");

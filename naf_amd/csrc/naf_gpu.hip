@@ -55,7 +55,7 @@ extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
     // side contexts: share the device and the constant tables
     if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess) { naf_gpu_shutdown(c); return NAF_GPU_EHIP; }
     for (int k = 0; k < ZSPLIT_MAX + 2; k++) if (hipEventCreateWithFlags(&c->split_ev[k], hipEventDisableTiming) != hipSuccess) { naf_gpu_shutdown(c); return NAF_GPU_EHIP; }
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 4; k++) {
         naf_gpu_ctx *sc = new naf_gpu_ctx();
         sc->device = device; sc->d_predef = c->d_predef; sc->h_stage_cap = 1 << 16;
         // highest priority: the side chains are many tiny kernels; behind the payload's bulk kernels they would only be scheduled
@@ -65,7 +65,7 @@ extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
             delete sc; naf_gpu_shutdown(c); return NAF_GPU_EHIP;
         }
         sc->own_stream = true;
-        (k == 0 ? c->side : k == 1 ? c->side2 : c->side3) = sc;
+        (k == 0 ? c->side : k == 1 ? c->side2 : k == 2 ? c->side3 : c->side4) = sc;
     }
     *out = c;
     return NAF_GPU_OK;
