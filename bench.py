@@ -287,8 +287,8 @@ def side_workload(ctx, text, out_mode, what, fold_case=False, reps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=float, default=10e9, help="FASTA bytes per GPU (default: the 10 GB config)")
     ap.add_argument("--records", type=int, default=100)
     ap.add_argument("--cpu-sample", type=float, default=2e9, help="bytes of FASTA timed on the CPU reference")
