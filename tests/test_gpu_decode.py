@@ -796,3 +796,25 @@ def test_stride_index_of_frames_of_equal_blocks(gpu, oracle, monkeypatch, capfd)
     monkeypatch.delenv("NAF_GPU_DEBUG_STRIDE")
     assert "verdict 1" not in err, err
     assert torch.equal(out, t)
+
+
+def test_names_decoded_beside_ids(gpu, monkeypatch):
+    """emit.hip unnaf_sections_main: ids and names of an archive whose two streams are both above 1 MB go to a side context each (the
+    emit of a FASTQ waits for the later of the two chains).  200 000 reads `@readN len=L` (ids 2.4 MB, names 1.6 MB), archive made by
+    this build: the FASTQ text back (bases upper-cased, R3), the same bytes with NAF_GPU_NAMES_BESIDE=0, and the FASTA view of it."""
+    from naf_amd import synth, capi
+    text = synth.fastq_reads(200_000, 100, seed=5, var_len=True)
+    d_naf, rep = gpu.ennaf(gpu.to_device(text))
+    assert rep.n_sequences == 200_000
+    a = host(gpu.unnaf(d_naf, capi.OUT_FASTQ))
+    monkeypatch.setenv("NAF_GPU_NAMES_BESIDE", "0")
+    b = host(gpu.unnaf(d_naf, capi.OUT_FASTQ))
+    fa0 = host(gpu.unnaf(d_naf, capi.OUT_FASTA))
+    monkeypatch.delenv("NAF_GPU_NAMES_BESIDE")
+    assert a == b
+    # the text itself, with the bases of every read upper-cased (unnaf.c:442): lines 2 of 4
+    lines = text.split(b"\n")
+    for i in range(1, len(lines), 4):
+        lines[i] = lines[i].upper()
+    assert a == b"\n".join(lines)
+    assert host(gpu.unnaf(d_naf, capi.OUT_FASTA)) == fa0
