@@ -6,7 +6,7 @@ CSRC     = naf_amd/csrc
 OBJS     = $(CSRC)/naf_gpu.o $(CSRC)/scan.o $(CSRC)/zstd_dec.o $(CSRC)/emit.o $(CSRC)/zstd_enc.o $(CSRC)/enc.o $(CSRC)/io.o
 HDRS     = $(wildcard $(CSRC)/*.h) include/naf_gpu.h
 
-all: naf_amd/libnaf_gpu.so hosts oracle emul tools/bw_calibrate tools/lds_probe
+all: naf_amd/libnaf_gpu.so hosts oracle emul tools/bw_calibrate tools/lds_probe tools/io_probe
 
 # known-byte-count kernels used to calibrate the PMC counters (tools/profile_bench.sh)
 tools/bw_calibrate: tools/bw_calibrate.hip
@@ -14,6 +14,10 @@ tools/bw_calibrate: tools/bw_calibrate.hip
 # what an LDS operation of a wavefront costs, by kind
 tools/lds_probe: tools/lds_probe.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -w -o $@ $<
+
+# what the box can do file <-> HBM (profiles/r03_io_probe.txt)
+tools/io_probe: tools/io_probe.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -w -o $@ $< -lpthread
 
 naf_amd/libnaf_gpu.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS)

@@ -62,7 +62,10 @@ const char *naf_gpu_last_error(const naf_gpu_ctx *ctx);
  * (null) stream, as in the HIP API.  Until called, the ctx uses a private non-blocking stream. */
 int         naf_gpu_set_stream(naf_gpu_ctx *ctx, void *hip_stream);
 int         naf_gpu_synchronize(naf_gpu_ctx *ctx);
-/* Pre-size the internal scratch arena (otherwise grown on demand; growth synchronises). */
+/* Pre-size the internal scratch arena (otherwise grown on demand; growth synchronises).  The contexts of the side chains
+ * (side sections, a FASTQ's quality stream, the chains behind an encode's split) get an eighth of `bytes` each, at most
+ * 4 GiB.  A whole call (unnaf, unnaf_range, ennaf) that had to grow an arena leaves it as ONE allocation when it returns:
+ * the growing call pays, the call after it is already in steady state. */
 int         naf_gpu_reserve(naf_gpu_ctx *ctx, size_t bytes);
 
 /* ---- device memory for hosts that do not link HIP themselves (the C CLIs) ---------------------------- */
@@ -77,6 +80,21 @@ int  naf_gpu_host_free(naf_gpu_ctx *ctx, void *h_pinned);
 int  naf_gpu_upload(naf_gpu_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);     /* async on the stream */
 int  naf_gpu_download(naf_gpu_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* returns after completion */
 int  naf_gpu_download_async(naf_gpu_ctx *ctx, void *h_pinned_dst, const void *d_src, size_t bytes);   /* async on the stream; pair with naf_gpu_synchronize */
+int  naf_gpu_copy(naf_gpu_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);         /* device -> device, async on the stream */
+
+/* ---- the collective of the decode path (BASELINE configs[3]: "per-GPU frame ranges, gather") ----------------
+ * One process, one context per GPU (what the C hosts do under NAF_GPUS=0,1,...): ctx k decodes its byte range of the text with
+ * naf_gpu_unnaf_range on its own device; this call brings the ranges together in d_dst on dst's device -- every source pushes
+ * its range over its own xGMI link (peer copy on the source's stream, behind its decode), dst's stream waits for all of them.
+ * srcs[k] may be dst itself (its range is copied in place, or left where it is when d_src[k] already lies at its offset).
+ * Decision on RCCL (north_star names "an RCCL gather over xGMI"): between the GPUs of ONE process a gather-to-root is N - 1
+ * point-to-point pushes whatever library issues them, bound by the root's xGMI ingress (7 links x ~153 GB/s) -- this entry
+ * issues exactly those and libnaf_gpu.so stays free of a communicator.  Jobs of one PROCESS per GPU (torch.distributed; bench.py
+ * and the tests) do the same exchange as one group of RCCL send/recv (naf_amd/shard.py: gather_ranges).  When the consumer is the
+ * HOST (a file, a pipe), no gather between GPUs is wanted at all: every GPU downloads its range over its own PCIe link
+ * (naf_gpu_write_file / naf_gpu_download_async per context -- unnaf.c under NAF_GPUS). */
+int  naf_gpu_gather_ranges(naf_gpu_ctx *dst, void *d_dst, naf_gpu_ctx *const *srcs, const void *const *d_src,
+                           const uint64_t *dst_off, const size_t *len, int n);
 
 /* File <-> HBM through pinned staging on several host threads (io.hip; NAF_GPU_IO_THREADS, default 8): what the reference does with
  * fread / fwrite of 16 KiB (ennaf/src/process.c:143-150, unnaf/src/files.c).  fd must support pread / pwrite (a regular file); the
@@ -250,6 +268,8 @@ int  naf_gpu_ennaf_stitch(naf_gpu_ctx *ctx, const naf_gpu_stitch_seg *segs, size
  * object.  names[i] points to static strings.  Returns the number of entries written (<= cap). */
 int  naf_gpu_set_timing(naf_gpu_ctx *ctx, int enable);
 int  naf_gpu_get_timing(naf_gpu_ctx *ctx, const char **names, float *ms, int *launches, int cap);
+/* kernel time of that aggregation per stream: [0] the caller's stream, [1..4] the side chains' (a call is at least the largest) */
+int  naf_gpu_get_timing_streams(naf_gpu_ctx *ctx, float ms[5]);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ EXPORTS = [
     "naf_gpu_set_timing", "naf_gpu_get_timing",
     "naf_gpu_ennaf_sniff", "naf_gpu_ennaf_count_lines", "naf_gpu_ennaf_find_cut", "naf_gpu_ennaf_shard_begin", "naf_gpu_ennaf_shard_bound",
     "naf_gpu_ennaf_shard_finish", "naf_gpu_ennaf_shard_carry", "naf_gpu_ennaf_stitch_plan", "naf_gpu_ennaf_stitch",
-    "naf_gpu_read_file", "naf_gpu_write_file",
+    "naf_gpu_read_file", "naf_gpu_write_file", "naf_gpu_copy", "naf_gpu_gather_ranges", "naf_gpu_get_timing_streams",
 ]
 MAX_SHARDS = 64
 
@@ -142,6 +142,9 @@ def load():
         L.naf_gpu_ennaf_stitch_plan.argtypes = [C.POINTER(EnnafOpts), C.POINTER(ShardInfo), C.POINTER(ShardPieces), C.c_uint32, C.POINTER(StitchSeg), sz,
                                                 C.POINTER(sz), C.c_char_p, sz, C.POINTER(sz), u64p, C.POINTER(EnnafReport)]
         L.naf_gpu_ennaf_stitch.argtypes = [vp, C.POINTER(StitchSeg), sz, C.c_char_p, C.POINTER(vp), vp, sz]
+        L.naf_gpu_copy.argtypes = [vp, vp, vp, sz]
+        L.naf_gpu_get_timing_streams.argtypes = [vp, C.POINTER(C.c_float)]
+        L.naf_gpu_gather_ranges.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), u64p, C.POINTER(sz), i]
         _lib = L
     return _lib
 
@@ -217,6 +220,16 @@ class Context:
 
     def reserve(self, nbytes):
         self._check(self.L.naf_gpu_reserve(self.h, nbytes))
+
+    def gather_ranges(self, out, parts):
+        """naf_gpu_gather_ranges: parts = [(ctx, tensor, dst_offset)] -- every part is pushed into `out` (a tensor on this context's
+        device) by its own context's stream; this context's stream waits for all of them."""
+        n = len(parts)
+        srcs = (C.c_void_p * n)(*[p[0].h.value for p in parts])
+        ptrs = (C.c_void_p * n)(*[p[1].data_ptr() for p in parts])
+        offs = (C.c_uint64 * n)(*[int(p[2]) for p in parts])
+        lens = (C.c_size_t * n)(*[int(p[1].numel()) for p in parts])
+        self._check(self.L.naf_gpu_gather_ranges(self.h, _ptr(out), srcs, ptrs, offs, lens, n))
 
     # ---- zstd ----
     def zstd_decompress(self, d_frame, out_cap, has_magic=True):
@@ -329,6 +342,12 @@ class Context:
         cnt = (C.c_int * cap)()
         n = self.L.naf_gpu_get_timing(self.h, names, ms, cnt, cap)
         return [(names[i].decode(), ms[i], cnt[i]) for i in range(n)]
+
+    def get_timing_streams(self):
+        """Kernel time of the last get_timing() per stream: [caller's stream, side chain 1..4]."""
+        ms = (C.c_float * 5)()
+        self._check(self.L.naf_gpu_get_timing_streams(self.h, ms))
+        return [float(x) for x in ms]
 
     def synchronize(self):
         self._check(self.L.naf_gpu_synchronize(self.h))

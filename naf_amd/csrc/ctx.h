@@ -50,6 +50,7 @@ struct naf_gpu_ctx {
     size_t ev_used = 0;
     // result of the last get_timing aggregation
     std::vector<std::string> agg_names; std::vector<float> agg_ms; std::vector<int> agg_n;
+    float stream_ms[5] = { 0, 0, 0, 0, 0 };    // kernel time per stream of that aggregation (naf_gpu_get_timing_streams)
     // second context (own stream, arena, staging) for the host thread that prepares the side streams of an archive while
     // this one decodes the sequence stream; nullptr inside the side context itself
     naf_gpu_ctx *side = nullptr;
@@ -76,6 +77,7 @@ int  ctx_fail(naf_gpu_ctx *c, int code, const char *fmt, ...);
 // Scratch arena: pointers stay valid until arena_reset.  Returns nullptr on allocation failure.
 void  arena_reset(naf_gpu_ctx *c);
 void *arena_alloc(naf_gpu_ctx *c, size_t bytes);
+void  arena_settle(naf_gpu_ctx *c);            // end of a whole call: arenas that grew become one allocation each (naf_gpu.hip)
 template <typename T> T *arena_new(naf_gpu_ctx *c, size_t n) { return (T *)arena_alloc(c, n * sizeof(T)); }
 
 // Small device->host readback through pinned staging (synchronises the stream).

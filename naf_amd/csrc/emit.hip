@@ -1863,12 +1863,16 @@ extern "C" int naf_gpu_unnaf_size(naf_gpu_ctx *c, const void *d_naf, size_t naf_
 }
 extern "C" int naf_gpu_unnaf(naf_gpu_ctx *c, const void *d_naf, size_t naf_len, const naf_gpu_unnaf_opts *o, void *d_out, size_t out_cap, size_t *out_len)
 {
-    return unnaf_run(c, (const u8 *)d_naf, naf_len, o, 0, 0, true, (u8 *)d_out, out_cap, out_len, false);
+    int rc = unnaf_run(c, (const u8 *)d_naf, naf_len, o, 0, 0, true, (u8 *)d_out, out_cap, out_len, false);
+    if (c) arena_settle(c);
+    return rc;
 }
 extern "C" int naf_gpu_unnaf_range(naf_gpu_ctx *c, const void *d_naf, size_t naf_len, const naf_gpu_unnaf_opts *o,
                                    uint64_t out_begin, uint64_t out_end, void *d_out, size_t out_cap, size_t *out_len)
 {
-    return unnaf_run(c, (const u8 *)d_naf, naf_len, o, out_begin, out_end, false, (u8 *)d_out, out_cap, out_len, false);
+    int rc = unnaf_run(c, (const u8 *)d_naf, naf_len, o, out_begin, out_end, false, (u8 *)d_out, out_cap, out_len, false);
+    if (c) arena_settle(c);
+    return rc;
 }
 
 // ---- byte histogram (unnaf --charcount, output.c:515-605) ------------------------------------------------------------------

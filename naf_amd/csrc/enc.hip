@@ -2260,10 +2260,19 @@ static int put_section(naf_gpu_ctx *c, naf_gpu_ctx *report, const u8 *d_stream, 
     return 0;
 }
 
+static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_gpu_ennaf_opts *o,
+                       void *d_naf_, size_t cap, size_t *naf_len, naf_gpu_ennaf_report *rep);
 extern "C" int naf_gpu_ennaf(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_gpu_ennaf_opts *o,
                              void *d_naf_, size_t cap, size_t *naf_len, naf_gpu_ennaf_report *rep)
 {
     if (!c || !o || !d_naf_ || !naf_len || (!d_text_ && n)) return NAF_GPU_EARG;
+    int rc = ennaf_whole(c, d_text_, n, o, d_naf_, cap, naf_len, rep);
+    arena_settle(c);                                            // a call that grew an arena leaves it as one allocation (naf_gpu.hip)
+    return rc;
+}
+static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_gpu_ennaf_opts *o,
+                       void *d_naf_, size_t cap, size_t *naf_len, naf_gpu_ennaf_report *rep)
+{
     arena_reset(c);
     const u8 *d_text = (const u8 *)d_text_; u8 *d_naf = (u8 *)d_naf_;
     naf_gpu_ennaf_report R; memset(&R, 0, sizeof R);
@@ -2591,6 +2600,7 @@ extern "C" int naf_gpu_ennaf_shard_finish(naf_gpu_ctx *c, const naf_gpu_ennaf_op
     }
     pieces->total = pos;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    arena_settle(c);                                            // the shard's split state is no longer needed: a grown arena becomes one allocation
     return 0;
 }
 

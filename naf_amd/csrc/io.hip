@@ -11,7 +11,7 @@
 #include <errno.h>
 
 static const size_t IO_CHUNK = (size_t)16 << 20;
-struct IoLane { hipStream_t s = nullptr; void *pin[2] = { nullptr, nullptr }; hipEvent_t ev[2] = { nullptr, nullptr }; };
+struct IoLane { hipStream_t s = nullptr; void *pin[2] = { nullptr, nullptr }; hipEvent_t ev[2] = { nullptr, nullptr }; bool ready = false; };
 struct IoPool { int lanes = 0; IoLane lane[16]; };
 
 static IoPool *io_pool(naf_gpu_ctx *c)
@@ -29,9 +29,14 @@ static IoPool *io_pool(naf_gpu_ctx *c)
 // transfer that uses one lane (every write) pins one lane's.
 static bool lane_ready(IoLane &L)
 {
-    if (L.s) return true;
-    bool ok = hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; k < 2 && ok; k++) ok = hipHostMalloc(&L.pin[k], IO_CHUNK, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming) == hipSuccess;
+    if (L.ready) return true;
+    // a lane left half built by a failed attempt (stream without its buffers) is completed here, never used as it is
+    bool ok = L.s || hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++) {
+        if (!L.pin[k]) ok = hipHostMalloc(&L.pin[k], IO_CHUNK, hipHostMallocDefault) == hipSuccess;
+        if (ok && !L.ev[k]) ok = hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming) == hipSuccess;
+    }
+    L.ready = ok;
     return ok;
 }
 

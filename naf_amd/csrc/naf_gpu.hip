@@ -169,6 +169,28 @@ void arena_reset(naf_gpu_ctx *c)
     }
 }
 
+// End of a whole call (unnaf, ennaf, shard_finish): an arena that grew during the call -- the main context's or a side context's -- is
+// made one allocation NOW, so that the growing call pays for its growth and the next call starts in steady state (the consolidation
+// used to happen at the next call's reset: the first TWO calls on a context were slow, and a caller that timed from the second one
+// on measured a hipFree + hipMalloc of the whole high-water mark).  Kernels of the main stream read what the side contexts made, so
+// every stream of the context is waited for first.
+void arena_settle(naf_gpu_ctx *c)
+{
+    bool any = false;
+    for (naf_gpu_ctx *x : { c, c->side, c->side2, c->side3, c->side4 }) if (x && x->chunks.size() > 1) any = true;
+    if (!any) return;
+    hipSetDevice(c->device);
+    for (naf_gpu_ctx *x : { c, c->side, c->side2, c->side3, c->side4 }) if (x) hipStreamSynchronize(x->stream);
+    for (naf_gpu_ctx *x : { c, c->side, c->side2, c->side3, c->side4 }) {
+        if (!x || x->chunks.size() <= 1) continue;
+        size_t total = 0;
+        for (auto &ch : x->chunks) { total += ch.cap; hipFree(ch.base); }
+        x->chunks.clear();
+        u8 *p = nullptr;
+        if (hipMalloc((void **)&p, total) == hipSuccess) x->chunks.push_back({ p, total, 0 });
+    }
+}
+
 void *arena_alloc(naf_gpu_ctx *c, size_t bytes)
 {
     bytes = (bytes + ARENA_ALIGN - 1) & ~(ARENA_ALIGN - 1);
@@ -198,9 +220,20 @@ extern "C" int naf_gpu_release_scratch(naf_gpu_ctx *c)
     c->chunks.clear();
     return 0;
 }
+static int reserve_one(naf_gpu_ctx *c, size_t bytes);
 extern "C" int naf_gpu_reserve(naf_gpu_ctx *c, size_t bytes)
 {
     if (!c) return NAF_GPU_EARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = reserve_one(c, bytes);
+    // the side contexts (side sections of an archive, a FASTQ's quality stream, the chains behind an encode's split) take an eighth
+    // each, at most 4 GiB: their arenas grow past that like any arena, in the first call that needs more
+    size_t each = bytes / 8; if (each > ((size_t)4 << 30)) each = (size_t)4 << 30;
+    for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3, c->side4 }) if (sc && !rc && each) { rc = reserve_one(sc, each); if (rc) memcpy(c->err, sc->err, sizeof c->err); }
+    return rc;
+}
+static int reserve_one(naf_gpu_ctx *c, size_t bytes)
+{
     size_t total = 0;
     for (auto &ch : c->chunks) total += ch.cap;
     if (total >= bytes && c->chunks.size() <= 1) return 0;
@@ -264,6 +297,47 @@ extern "C" int naf_gpu_download(naf_gpu_ctx *c, void *h, const void *d, size_t n
     return 0;
 }
 
+extern "C" int naf_gpu_copy(naf_gpu_ctx *c, void *d_dst, const void *d_src, size_t n)
+{
+    if (!c || (n && (!d_dst || !d_src))) return NAF_GPU_EARG;
+    if (n) HIP_TRY(c, hipMemcpyAsync(d_dst, d_src, n, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+// Ranges of one text decoded by several contexts -- one per GPU of the node, driven by one process (the C hosts' NAF_GPUS) -- brought
+// together in one buffer on dst's device: every source pushes its range over its xGMI link to dst (hipMemcpyPeerAsync on the source's
+// own stream, behind the range decode queued there, so a rank's copy starts when ITS decode is done), and dst's stream waits for all
+// of them.  xGMI is point to point: N - 1 pushes into one GPU use N - 1 different links and are bound by the target's ingress, which
+// is what a ring or a tree of RCCL send/recv into one root would be bound by as well; RCCL adds nothing between the GPUs of one
+// process, so the product's collective is this (processes per GPU -- bench.py, the tests -- gather with torch.distributed instead).
+extern "C" int naf_gpu_gather_ranges(naf_gpu_ctx *dst, void *d_dst, naf_gpu_ctx *const *srcs, const void *const *d_src,
+                                     const uint64_t *dst_off, const size_t *len, int n)
+{
+    if (!dst || !d_dst || !srcs || !d_src || !dst_off || !len || n < 0) return NAF_GPU_EARG;
+    for (int k = 0; k < n; k++) {
+        naf_gpu_ctx *s = srcs[k];
+        if (!s || (len[k] && !d_src[k])) return ctx_fail(dst, NAF_GPU_EARG, "gather_ranges: source %d missing", k);
+        if (!len[k]) continue;
+        u8 *to = (u8 *)d_dst + dst_off[k];
+        HIP_TRY(dst, hipSetDevice(s->device));
+        if (s->device == dst->device) {
+            if ((const void *)to != d_src[k]) HIP_TRY(dst, hipMemcpyAsync(to, d_src[k], len[k], hipMemcpyDeviceToDevice, s->stream));
+        } else {
+            hipError_t e = hipDeviceEnablePeerAccess(dst->device, 0);             // without it the copy is staged through the host
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            HIP_TRY(dst, hipMemcpyPeerAsync(to, dst->device, d_src[k], s->device, len[k], s->stream));
+        }
+        if (s != dst) {
+            if (!s->fork_ev) HIP_TRY(dst, hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming));
+            HIP_TRY(dst, hipEventRecord(s->fork_ev, s->stream));
+            HIP_TRY(dst, hipStreamWaitEvent(dst->stream, s->fork_ev, 0));
+        }
+    }
+    HIP_TRY(dst, hipSetDevice(dst->device));
+    return 0;
+}
+
 extern "C" int naf_gpu_download_async(naf_gpu_ctx *c, void *h, const void *d, size_t n)
 {
     if (!c) return NAF_GPU_EARG;
@@ -313,10 +387,14 @@ extern "C" int naf_gpu_get_timing(naf_gpu_ctx *c, const char **names, float *ms,
     for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3, c->side4 }) if (sc) hipStreamSynchronize(sc->stream);
     std::map<std::string, std::pair<float, int>> agg;
     std::vector<std::string> order;
+    int xi = 0;
+    for (int k = 0; k < 5; k++) c->stream_ms[k] = 0;
     for (naf_gpu_ctx *x : { c, c->side, c->side2, c->side3, c->side4 }) {
+        const int xk = xi++;
         if (!x) continue;
         for (auto &k : x->ktimes) {
             float t = 0; hipEventElapsedTime(&t, k.a, k.b);
+            c->stream_ms[xk] += t;
             // launches of the side context run concurrently with the payload decode: listed under their own names
             std::string nm = x == c ? std::string(k.name) : std::string("side:") + k.name;
             auto it = agg.find(nm);
@@ -331,4 +409,13 @@ extern "C" int naf_gpu_get_timing(naf_gpu_ctx *c, const char **names, float *ms,
     for (int i = 0; i < n; i++) { names[i] = c->agg_names[i].c_str(); ms[i] = c->agg_ms[i]; launches[i] = c->agg_n[i]; }
     c->ktimes.clear(); c->ev_used = 0;
     return n;
+}
+
+// Sum of the kernel times of the last naf_gpu_get_timing per stream of the context: [0] the caller's stream, [1..4] the side chains'.
+// A call cannot be shorter than the largest of them; what it takes beyond that is launch gaps, host read-backs and waits between streams.
+extern "C" int naf_gpu_get_timing_streams(naf_gpu_ctx *c, float ms[5])
+{
+    if (!c || !ms) return NAF_GPU_EARG;
+    for (int k = 0; k < 5; k++) ms[k] = c->stream_ms[k];
+    return 0;
 }

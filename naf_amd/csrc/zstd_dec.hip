@@ -1578,7 +1578,7 @@ __global__ __launch_bounds__(256) void k_copy_fill(const u8 *src, const ZBlock *
 }
 
 // ---- sequence execution (3.1.1.4): one wave per block with sequences ----------------------------------------
-__device__ __forceinline__ void wait_block_done(volatile u32 *done, u32 j)
+__device__ __forceinline__ void wait_block_done(volatile u32 *done, u32 j, ZStat *st)
 {
     // lane 0 polls (relaxed, agent scope); one acquire afterwards drops stale L1 lines (guide G16)
     if (threadIdx.x == 0) {
@@ -1586,6 +1586,7 @@ __device__ __forceinline__ void wait_block_done(volatile u32 *done, u32 j)
         // and an error, not in a device that has to be reset; about ten seconds)
         u32 spins = 0;
         while (__hip_atomic_load(&done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(2);
+        if (spins >= (1u << 26)) set_err(st, ZE_CORRUPT);          // gave up: what is read from block j is not its output -- the call reports the frame as corrupt
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -1638,7 +1639,7 @@ __global__ __launch_bounds__(64) void k_exec_seq(const ZBlock *blk, const u32 *s
             // ever in a range decode, where blocks in front of the range's closure never run.)
             u32 lo = 0, hi = lo_idx;                                 // largest j with offs[j] <= src_abs
             while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (offs[mid] <= src_abs) lo = mid; else hi = mid; }
-            for (u32 j = lo_idx; j-- > lo;) wait_block_done(done, j);
+            for (u32 j = lo_idx; j-- > lo;) wait_block_done(done, j, st);
             if (lo < lo_idx) lo_idx = lo;
         }
         u64 src_end = src_abs + (off < ml ? off : ml);
@@ -1734,7 +1735,7 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
                 if (src_abs < offs[lo_idx]) {
                     u32 lo = 0, hi = lo_idx;
                     while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (offs[mid] <= src_abs) lo = mid; else hi = mid; }
-                    for (u32 q = lo_idx; q-- > lo;) wait_block_done(done, q);
+                    for (u32 q = lo_idx; q-- > lo;) wait_block_done(done, q, st);
                     if (lo < lo_idx) lo_idx = lo;
                 }
                 u32 outside = (u32)(out_off - src_abs);                                // bytes of the pattern that lie before this block

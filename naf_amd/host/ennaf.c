@@ -7,7 +7,22 @@
 #include <strings.h>
 
 static bool verbose = false, no_mask = false, force_stdout = false, strict = false, well_formed = false;
-static char *in_file_path = NULL, *out_file_path = NULL, *title = NULL;
+static char *in_file_path = NULL, *out_file_path = NULL, *title = NULL, *temp_dir_arg = NULL;
+/* Where a temporary file goes (the spill of a pipe larger than the device buffer, the parts of an input encoded in chunks): --temp-dir,
+ * then $TMPDIR, then $TMP like the reference (ennaf.c:309-319) -- which dies without one of them; a regular file needs no temporary
+ * file here at all, so this falls back to /tmp instead of refusing every run. */
+static FILE *temp_file(const char *stem)
+{
+    const char *td = temp_dir_arg; char path[4096];
+    if (!td || !*td) td = getenv("TMPDIR");
+    if (!td || !*td) td = getenv("TMP");
+    if (!td || !*td) td = "/tmp";
+    snprintf(path, sizeof path, "%s/%s-XXXXXX", td, stem);
+    int tfd = mkstemp(path); if (tfd < 0) die("can't create temporary file in \"%s\"\n", td);
+    unlink(path);
+    FILE *f = fdopen(tfd, "w+b"); if (!f) die("can't create temporary file in \"%s\"\n", td);
+    return f;
+}
 static int level = 1, fmt_cmd = NAF_FMT_AUTO, seq_type = NAF_SEQ_DNA, long_log = 0;
 static bool line_length_is_specified = false; static long long requested_line_length = 0;
 static bool created_output_file = false, success = false;
@@ -46,7 +61,7 @@ static void parse_command_line(int argc, char **argv)
         if (argv[i][0] == '-') {
             if (argv[i][1] == '-') {
                 if (i < argc - 1) {
-                    if (!strcmp(argv[i], "--temp-dir")) { i++; if (!*argv[i]) die("empty --temp-dir parameter\n"); continue; }
+                    if (!strcmp(argv[i], "--temp-dir")) { i++; if (temp_dir_arg) die("double --temp-dir parameter\n"); if (!*argv[i]) die("empty --temp-dir parameter\n"); temp_dir_arg = argv[i]; continue; }
                     if (!strcmp(argv[i], "--name")) { i++; if (!*argv[i]) die("empty --name parameter\n"); continue; }
                     if (!strcmp(argv[i], "--title")) { i++; if (title) die("double --title parameter\n"); if (!*argv[i]) die("empty --title parameter\n"); title = argv[i]; continue; }
                     if (!strcmp(argv[i], "--level")) { i++; set_level(argv[i]); continue; }
@@ -266,10 +281,7 @@ static bool encode_chunked(FILE *IN, size_t base, size_t fn, const naf_gpu_ennaf
     ch_n = k; ch_start[k] = fn;
     for (int i = 0; i < ch_n; i++) ch_infos[i].n_shards = (uint32_t)ch_n;
     /* pass 2: the parts */
-    { const char *td = getenv("TMPDIR"); char path[4096];
-      snprintf(path, sizeof path, "%s/ennaf-gpu-XXXXXX", (td && *td) ? td : "/tmp");
-      int tfd = mkstemp(path); if (tfd < 0) die("can't create temporary file\n");
-      unlink(path); ch_tmp = fdopen(tfd, "w+b"); if (!ch_tmp) die("can't create temporary file\n"); }
+    ch_tmp = temp_file("ennaf-gpu");
     size_t tmp_at = 0;
     for (k = 0; k < ch_n; k++) {
         const size_t a = ch_start[k], len = ch_start[k + 1] - a;
@@ -391,10 +403,19 @@ int main(int argc, char **argv)
         const char *pe = getenv("NAF_GPU_PIPE_BYTES");
         size_t limit = pe ? (size_t)strtoull(pe, NULL, 10) : ((size_t)8 << 30);
         { size_t fr = 0, tot = 0; GPU_TRY(naf_gpu_mem_info(gpu, &fr, &tot)); if (limit > fr / 6) limit = fr / 6; if (limit < 4096) limit = 4096; }
-        GPU_TRY(naf_gpu_malloc(gpu, limit + 64, &d_piped));
+        /* the device buffer starts at 256 MiB and grows fourfold up to the limit (a small pipe used to take the whole 8 GiB first) */
+        size_t have = limit < ((size_t)256 << 20) ? limit : ((size_t)256 << 20);
+        GPU_TRY(naf_gpu_malloc(gpu, have + 64, &d_piped));
         int cur = 0; bool eof = false, busy[2] = { false, false };
         while (!eof && n_piped < limit) {
-            size_t want = limit - n_piped < IO_CHUNK ? limit - n_piped : IO_CHUNK, got = 0;
+            if (n_piped == have) {
+                size_t more = have * 4 < limit ? have * 4 : limit; void *d_more = NULL;
+                GPU_TRY(naf_gpu_malloc(gpu, more + 64, &d_more));
+                GPU_TRY(naf_gpu_copy(gpu, d_more, d_piped, n_piped));
+                GPU_TRY(naf_gpu_free(gpu, d_piped));                                   /* waits for the stream: the copy and the uploads are done */
+                busy[0] = busy[1] = false; d_piped = d_more; have = more;
+            }
+            size_t want = have - n_piped < IO_CHUNK ? have - n_piped : IO_CHUNK, got = 0;
             if (busy[cur]) { GPU_TRY(naf_gpu_synchronize(gpu)); busy[0] = busy[1] = false; }      /* the upload that last read this buffer */
             while (got < want) { size_t r = fread((char *)io_pin[cur] + got, 1, want - got, IN); if (!r) { eof = true; break; } got += r; }
             if (got) { GPU_TRY(naf_gpu_upload(gpu, (char *)d_piped + n_piped, io_pin[cur], got)); busy[cur] = true; n_piped += got; cur ^= 1; }
@@ -402,10 +423,7 @@ int main(int argc, char **argv)
         GPU_TRY(naf_gpu_synchronize(gpu));
         if (!eof) { int c1 = fgetc(IN); if (c1 == EOF) eof = true; else ungetc(c1, IN); }
         if (!eof) {
-            const char *td = getenv("TMPDIR"); char path[4096];
-            snprintf(path, sizeof path, "%s/ennaf-gpu-in-XXXXXX", (td && *td) ? td : "/tmp");
-            int tfd = mkstemp(path); if (tfd < 0) die("can't create temporary file\n");
-            unlink(path); spill = fdopen(tfd, "w+b"); if (!spill) die("can't create temporary file\n");
+            spill = temp_file("ennaf-gpu-in");
             write_from_device(spill, d_piped, n_piped);
             GPU_TRY(naf_gpu_free(gpu, d_piped)); d_piped = NULL;
             size_t total = n_piped, r;

@@ -340,7 +340,9 @@ def test_flat_tree_literals_every_width(gpu, oracle, monkeypatch):
     bad = bytearray(fb); bad[len(bad) // 2] ^= 0xFF
     try:
         got = host(gpu.zstd_decompress(gpu.to_device(bytes(bad)), len(data) + 64))
-        assert got != data or True                                  # a flipped payload byte decodes to different symbols: fine
+        # no error: then the sizes (they come from the headers) held and a flipped payload byte decoded to different symbols -- a complete
+        # prefix code maps different bit strings to different symbol strings, so the text cannot have come out unchanged
+        assert len(got) == len(data) and got != data
     except NafGpuError:
         pass
     assert made == 49

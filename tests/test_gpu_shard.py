@@ -131,6 +131,30 @@ def test_sharded_large_roundtrip(ctxs, oracle):
         assert oracle.ref_unnaf(host(naf))[:4_000_000] == sample
 
 
+def test_gather_ranges_of_the_c_abi(ctxs, oracle):
+    """naf_gpu_gather_ranges (the product's collective for one process driving N GPUs): every context decodes its byte range of the
+    text into a buffer of its own, the ranges are brought together in one buffer of context 0's device -- here the N contexts share the
+    one device of the box, so every push is a device-to-device copy; the root's own range is decoded in place and left where it is."""
+    import torch
+    from naf_amd import synth, shard, capi
+    text = synth.softmask_device(synth.fasta_acgt_device(60_000_000, n_records=5, width=60, seed=11))
+    naf, _rep = ctxs[0].ennaf(text)
+    total = ctxs[0].unnaf_size(naf, capi.OUT_FASTA)
+    assert total == text.numel()
+    for n in (1, 2, 3, 8):
+        out = torch.zeros(total + 64, dtype=torch.uint8, device=text.device)
+        parts = []
+        for r in range(n):
+            b, e = shard.byte_range(total, r, n)
+            buf = out[b:e] if r == 0 else torch.empty(e - b + 64, dtype=torch.uint8, device=text.device)
+            got = ctxs[r].unnaf_range(naf, b, e, capi.OUT_FASTA, out=buf)
+            assert got.numel() == e - b
+            parts.append((ctxs[r], got, b))
+        ctxs[0].gather_ranges(out, parts)
+        torch.cuda.synchronize()
+        assert torch.equal(out[:total], text), n
+
+
 def test_shard_records_match_the_stand_in(ctxs, oracle):
     """naf_gpu_ennaf_shard_begin on the device reports what the CPU stand-in derives from the oracle's view of the same slice."""
     from naf_amd import shard, synth

@@ -10,6 +10,9 @@ set -u
 tag=${1:-r03}
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
+# the box these files come from (bench.py prints the same stamp as "box" in its line: a `frac` recomputed from the CSVs below and the
+# line's own can be matched, or known to come from two boxes)
+python -c "import bench; print(bench.box_id())" > $out/${tag}_box.txt
 python bench.py > $out/${tag}_bench_line.json 2> $out/bench.err
 tail -c 400 $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 3 --no-cpu --softmask-size 0 --realistic-size 0 --fastq1-size 0 > $out/stats.log 2>&1
@@ -65,7 +68,7 @@ enc_names = {"k_enc_scatter_regular": "ennaf_scatter_regular", "k_enc_scatter": 
              "k_zenc_plan": "zenc_plan", "k_zenc_write": "zenc_write", "k_zenc_write_direct": "zenc_write_direct", "k_zenc_flat_scan": "zenc_flat_scan", "k_zenc_tree": "zenc_tree", "k_direct_blocks": "ennaf_direct_blocks",
              "k_mask_run_units": "ennaf_mask_runs", "k_mask_units_write": "ennaf_mask_units"}
 calls = 3
-enc_calls = 5            # the untimed first ennaf call, three timed ones and the instrumented one
+enc_calls = 13           # two untimed ennaf calls, ten timed ones and the instrumented one
 k = {}
 # counter unit = KiB.  FETCH_SIZE tallies a wide coalesced read at 1/2 (guide; k_expand / k_read calibration: x2), the
 # Huffman kernel's one-64-byte-sector-per-lane reads at 1/1.742 (k_sector_read calibration); WRITE_SIZE is exact (k_expand / k_write)
