@@ -557,10 +557,10 @@ __global__ __launch_bounds__(256) void k_enc_count_pure(EncP P, const i64 *tile_
         t_needf[t] = 0; t_need[t] = 0;
     }
 }
-__global__ void k_need_list(const u32 *t_needf, const u64 *pre, u64 tiles, u32 *list)
+__global__ void k_need_list(const u32 *t_needf, const u64 *pre, u64 tiles, u32 *list, const u32 *t_reg = nullptr)
 {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < tiles && t_needf[t]) list[pre[t]] = (u32)t;
+    if (t < tiles && (t_needf ? t_needf[t] != 0 : t_reg[t] == 0)) list[pre[t]] = (u32)t;       // (t_reg: the FASTQ count's verdict, 0 = needs the general kernel)
 }
 
 // --strict (process.c:98-140): the reference dies at the FIRST unexpected byte of the input.  Every unexpected byte reports
@@ -1160,6 +1160,9 @@ struct FqOut {
     u64 *strict_first;            // --strict: min over strict_key of the unexpected bytes (nullptr otherwise)
     const u64 *t_seq, *t_ids, *t_cmt, *t_qual, *t_ls;
     const u32 *piece_cnt;         // per 16-byte piece: the four stream counts found by k_encq_count, 8 bits each
+    const u32 *list;              // k_encq_scatter: the tiles that are not regular, in order (nullptr: every tile)
+    const u32 *t_reg;             // k_encq_count_reg's verdict on a tile (1: regular)
+    u32 *redo_list, *n_redo;      // k_encq_scatter_reg: regular tiles whose letters want the general kernel after all
 };
 
 template <typename Sink>
@@ -1333,7 +1336,7 @@ __device__ __forceinline__ i64 thread_ord(const EncP &P, const u64 *t_ls, u64 ba
 {
     u32 nls = pc.cnt ? count_line_starts_m(P, base, pc, pm) : 0;
     u64 t; u64 incl = wg_scan_inclusive<u64, OpAdd>((u64)nls, &t, lds);
-    return (i64)(t_ls[blockIdx.x] + incl - nls) - 1;
+    return (i64)(t_ls[base / ET_TILE] + incl - nls) - 1;          // (the workgroup's tile: not always blockIdx.x, see k_encq_count's list)
 }
 
 struct SlowCtx { i64 le, ls, ord; };
@@ -1365,12 +1368,14 @@ __device__ __forceinline__ int fq_piece(const EncP &P, u64 base, const Piece &pc
 }
 
 __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol, const i64 *tile_sp, const u64 *t_ls,
-                                                     u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_qual, u32 *piece_cnt)
+                                                     u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_qual, u32 *piece_cnt, const u32 *list, int piece_only)
 {
+    const u64 tile = list ? list[blockIdx.x] : blockIdx.x;      // list: the tiles k_encq_count_reg left (those that are not regular)
+                                                                // piece_only: a tile k_encq_scatter_reg handed back -- its counts stand (and are scanned), its pieces' are wanted
     __shared__ u64 lds[4];
     __shared__ u8 cls[256];
     fill_classes(P, cls);
-    u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
+    u64 base = tile * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
     PMask pm = piece_masks(pc);
     TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, pm);
@@ -1385,7 +1390,7 @@ __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol,
     slow_gather(slow, ctx, s_ctx, s_list, &s_nslow);
     if (threadIdx.x < s_nslow) {
         u32 who = s_list[threadIdx.x];
-        u64 b2 = (u64)blockIdx.x * ET_TILE + (u64)who * ET_BYTES;
+        u64 b2 = tile * ET_TILE + (u64)who * ET_BYTES;
         Piece p2 = load_piece(P, b2);
         TileCtx c2; c2.last_eol = s_ctx[who].le; c2.last_sp = s_ctx[who].ls; c2.hdr = false; c2.ord = s_ctx[who].ord;
         FqCount S2; bool segok = false;
@@ -1402,19 +1407,20 @@ __global__ __launch_bounds__(256) void k_encq_count(EncP P, const i64 *tile_eol,
     if (slow) { u64 v = s_cnt[threadIdx.x]; S.nseq = v & 0xFFFF; S.nids = (v >> 16) & 0xFFFF; S.ncmt = (v >> 32) & 0xFFFF; S.nqual = (u32)(v >> 48) & 0x7FFFu; segok_bit = (u32)(v >> 63); }
     // the four counts of every piece (each at most 17) are kept for the scatter pass, which then walks the slow pieces once, not twice;
     // bit 31: the verdict of the segment-wise test
-    piece_cnt[(u64)blockIdx.x * 256 + threadIdx.x] = S.nseq | (S.nids << 8) | (S.ncmt << 16) | (S.nqual << 24) | (segok_bit << 31);
+    piece_cnt[tile * 256 + threadIdx.x] = S.nseq | (S.nids << 8) | (S.ncmt << 16) | (S.nqual << 24) | (segok_bit << 31);
     u64 tot;
     wg_scan_inclusive<u64, OpAdd>((u64)S.nseq | ((u64)S.nids << 16) | ((u64)S.ncmt << 32) | ((u64)S.nqual << 48), &tot, lds);
-    if (threadIdx.x == 0) { t_seq[blockIdx.x] = tot & 0xFFFF; t_ids[blockIdx.x] = (tot >> 16) & 0xFFFF; t_cmt[blockIdx.x] = (tot >> 32) & 0xFFFF; t_qual[blockIdx.x] = tot >> 48; }
+    if (threadIdx.x == 0 && !piece_only) { t_seq[tile] = tot & 0xFFFF; t_ids[tile] = (tot >> 16) & 0xFFFF; t_cmt[tile] = (tot >> 32) & 0xFFFF; t_qual[tile] = tot >> 48; }
 }
 
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eol, const i64 *tile_sp, FqOut O)
 {
+    const u64 tile = O.list ? O.list[blockIdx.x] : blockIdx.x;   // list: the tiles that are not regular (k_encq_scatter_reg does the others)
     __shared__ u64 lds[4];
     __shared__ u8 cls[256];
     fill_classes(P, cls);
-    u64 base = (u64)blockIdx.x * ET_TILE + (u64)threadIdx.x * ET_BYTES;
+    u64 base = tile * ET_TILE + (u64)threadIdx.x * ET_BYTES;
     Piece pc = load_piece(P, base);
     PMask pm = piece_masks(pc);
     TileCtx ctx = thread_ctx(P, tile_eol, tile_sp, base, pm);
@@ -1422,7 +1428,7 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
     bool active = base <= P.n;
     FqCount C;
     const int fast = fq_piece(P, base, pc, pm, ctx, cls);
-    { u32 v = O.piece_cnt[(u64)blockIdx.x * 256 + threadIdx.x]; C.nseq = v & 0xFF; C.nids = (v >> 8) & 0xFF; C.ncmt = (v >> 16) & 0xFF; C.nqual = (v >> 24) & 0x7F; }
+    { u32 v = O.piece_cnt[tile * 256 + threadIdx.x]; C.nseq = v & 0xFF; C.nids = (v >> 8) & 0xFF; C.ncmt = (v >> 16) & 0xFF; C.nqual = (v >> 24) & 0x7F; }
     __shared__ SlowCtx s_ctx[256]; __shared__ u16 s_list[256]; __shared__ u32 s_nslow;
     __shared__ u64 s_w[256][4];                                   // stream positions of the slow pieces for the write pass
     const bool slow = !fast && active;
@@ -1431,28 +1437,311 @@ __global__ __launch_bounds__(256) void k_encq_scatter(EncP P, const i64 *tile_eo
     u64 ip = wg_scan_inclusive<u64, OpAdd>((u64)C.nseq | ((u64)C.nids << 16) | ((u64)C.ncmt << 32) | ((u64)C.nqual << 48), &totp, lds);
     u64 iseq = ip & 0xFFFF, iids = (ip >> 16) & 0xFFFF, icmt = (ip >> 32) & 0xFFFF, iq = ip >> 48, tots = totp & 0xFFFF, totq = totp >> 48;
     __shared__ __attribute__((aligned(16))) u8 sstage0[ET_TILE + 48], qstage[ET_TILE + 16];
-    FqWrite W(O); W.qstage = qstage; W.sbase = O.t_seq[blockIdx.x]; W.qbase = O.t_qual[blockIdx.x];
+    FqWrite W(O); W.qstage = qstage; W.sbase = O.t_seq[tile]; W.qbase = O.t_qual[tile];
     u8 *const sstage = sstage0 + (PACK ? (u32)(W.sbase & 15) : 0u); W.sstage = sstage;
-    W.bseq = O.t_seq[blockIdx.x] + iseq - C.nseq; W.bids = O.t_ids[blockIdx.x] + iids - C.nids;
-    W.bcmt = O.t_cmt[blockIdx.x] + icmt - C.ncmt; W.bqual = O.t_qual[blockIdx.x] + iq - C.nqual;
+    W.bseq = O.t_seq[tile] + iseq - C.nseq; W.bids = O.t_ids[tile] + iids - C.nids;
+    W.bcmt = O.t_cmt[tile] + icmt - C.ncmt; W.bqual = O.t_qual[tile] + iq - C.nqual;
     if (fast == 1) lds_store_n(sstage + (W.bseq - W.sbase), pc.w0, pc.w1, 16);
     else if (fast == 3) lds_store_n(qstage + (W.bqual - W.qbase), pc.w0, pc.w1, 16);
     else if (slow) { s_w[threadIdx.x][0] = W.bseq; s_w[threadIdx.x][1] = W.bids; s_w[threadIdx.x][2] = W.bcmt; s_w[threadIdx.x][3] = W.bqual; }
     __syncthreads();
     if (threadIdx.x < s_nslow) {                                  // write pass of the slow pieces, again by the first lanes
         u32 who = s_list[threadIdx.x];
-        u64 b2 = (u64)blockIdx.x * ET_TILE + (u64)who * ET_BYTES;
+        u64 b2 = tile * ET_TILE + (u64)who * ET_BYTES;
         Piece p2 = load_piece(P, b2);
         TileCtx c2; c2.last_eol = s_ctx[who].le; c2.last_sp = s_ctx[who].ls; c2.hdr = false; c2.ord = s_ctx[who].ord;
         FqWrite W2(O); W2.sstage = sstage; W2.qstage = qstage; W2.sbase = W.sbase; W2.qbase = W.qbase;
         W2.bseq = s_w[who][0]; W2.bids = s_w[who][1]; W2.bcmt = s_w[who][2]; W2.bqual = s_w[who][3];
-        if (O.piece_cnt[(u64)blockIdx.x * 256 + who] >> 31) classify_segments_fastq(P, b2, p2, piece_masks(p2), c2, W2);   // k_encq_count's verdict
+        if (O.piece_cnt[tile * 256 + who] >> 31) classify_segments_fastq(P, b2, p2, piece_masks(p2), c2, W2);   // k_encq_count's verdict
         else classify_range_fastq(P, b2, p2, (b2 + p2.cnt == P.n) && p2.cnt < ET_BYTES, c2, W2, cls);
     }
     __syncthreads();
     if (PACK) flush_pack<false>(P, O.packed, O.casebits, W.sbase, (u32)tots, sstage0);
     else flush_tile(O.seq + W.sbase, sstage, (u32)tots);
     flush_tile(O.qual + W.qbase, qstage, (u32)totq);
+}
+
+
+// ---- REGULAR tiles of a FASTQ text, by lines ------------------------------------------------------------------------------------
+// The reference has a fast parser for FASTQ that is what sequencers write (process_well_formed_fastq, process.c:430-474) beside the
+// tolerant one (:477-544); the general kernels above are the tolerant one -- a context per 16-byte piece (two workgroup scans), and a
+// third of the pieces of 150-base reads (those with a line end or header bytes) walked by a lane on its own.  A tile is REGULAR when
+// the tolerant parser has nothing to tolerate in its STRUCTURE: it lies wholly behind p0 and inside the text; its only EOL-class byte
+// is '\n' and no line of it is empty; it has at most 255 line ends; no byte of it is 0x7F or above; header lines begin with '@' and
+// hold no byte below 0x21 but the first blank or tab (which ends the ID) and blanks behind it; sequence and quality lines hold no
+// byte below 0x21 at all; '+' lines begin with '+'.
+// Such a tile is a string of at most 256 LINE SEGMENTS cut by its '\n' bytes whose types are the line ordinal mod 4, counted on from
+// the line in progress at its first byte (t_ls, tile_eol: the same tables the general kernels take their contexts from).  One
+// wavefront takes a segment per lane: lengths, the ID / comment split of header segments (from a bit map of the bytes below 0x21),
+// one scan -- and every byte's place in its stream follows from its segment's.  Counts, streams and record tables are those of the
+// general kernels bit for bit (a byte is counted in the tile it lies in); a tile that is not regular is left to them (t_reg = 0, the
+// list).  Whether the LETTERS of the sequence lines are accepted ones is not part of the structure (a replaced letter counts like an
+// accepted one): the scatter pass looks at them anyway and hands a tile with a letter that is not A C G T/U N back (the redo list).
+#define FQR_MAXSEG 256
+#define FQR_SKIP ((i32)0x40000000)
+struct FqrLds {
+    __attribute__((aligned(16))) u8 txt[ET_TILE + 16];
+    u64 segoff[FQR_MAXSEG];         // exclusive prefix over the segments of nseq | nids << 16 | ncmt << 32 | nqual << 48
+    u64 total;                      // ... and the tile's totals
+    u32 segse[FQR_MAXSEG];          // first byte | end << 16 of the segment (positions in the tile)
+    u32 seghdr[FQR_MAXSEG];         // header segments: first ID byte | position of the blank that ends the ID (0xFFFF: the ID began and ended in front of the tile; == end: none so far) << 16
+    i32 segdst[FQR_MAXSEG];         // scatter: where in the staging buffer the segment's first byte goes, minus its position in the tile (sequence and quality segments; FQR_SKIP: the others)
+    u32 so[4];                      // scatter: where the four streams' regions begin in the staging buffer
+    u16 nlpos[FQR_MAXSEG];          // the tile's '\n' bytes
+    u16 oth[256];                   // per piece: its bytes below 0x21 that are not '\n'
+    u8  segtype[FQR_MAXSEG];        // line ordinal & 3 | 4: the segment begins its line | 8: its line ends in the tile
+    u32 wcnt[4];
+    u32 bad;
+};
+// '\n' bytes and the other bytes below 0x21 of a piece, one bit per byte; *high: some byte is 0x7F or above
+__device__ __forceinline__ void fqr_masks(const u32 w[4], u32 &nlm, u32 &oth, bool &high)
+{
+    const u32 H = 0x80808080u, L = 0x7F7F7F7Fu; u32 f[4], g[4], hi = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u32 x = w[i], l = x & L, y = x ^ 0x0A0A0A0Au;
+        f[i] = ~(((y & L) + L) | y) & H;                          // == 0x0A
+        g[i] = ~(x | (l + 0x5F5F5F5Fu)) & H & ~f[i];              // < 0x21 and not 0x0A
+        hi |= x | (l + 0x01010101u);                              // >= 0x80, or 0x7F
+    }
+    nlm = swar_movemask16(f[0], f[1], f[2], f[3]); oth = swar_movemask16(g[0], g[1], g[2], g[3]); high = (hi & H) != 0;
+}
+// Segments of the tile into LDS; returns false when the tile has too many of them (uniform).  CHECK: also sets S.bad for what makes
+// the tile irregular in its segments' framing.  k0 = the segment of the lane's first byte.  Ends on a barrier.
+template <bool CHECK>
+__device__ __forceinline__ bool fqr_segments(const EncP &P, u64 tile, const i64 *tile_eol, const i64 *tile_sp, const u64 *t_ls, FqrLds &S,
+                                             const u32 w[4], u32 nlm, u32 oth, u32 &k0, u32 &nseg, const u64 *bases = nullptr /* scatter: the tile's offsets in the four streams */)
+{
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    { uint4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3]; *(uint4 *)(S.txt + 16 * tid) = v; }
+    S.oth[tid] = (u16)oth;
+    if (tid == 0) S.bad = 0;
+    const u32 cnt = (u32)__popc(nlm);
+    const u32 incl = wave_scan_inclusive<u32, OpAdd>(cnt);
+    if (lane == 63) S.wcnt[wave] = incl;
+    __syncthreads();
+    u32 pre = 0, tot = 0;
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) { const u32 x = S.wcnt[q]; if (q < wave) pre += x; tot += x; }
+    k0 = pre + incl - cnt; nseg = tot + 1;
+    if (tot >= FQR_MAXSEG) return false;                                             // (uniform)
+    { u32 m = nlm, idx = k0; while (m) { S.nlpos[idx++] = (u16)(16 * tid + (u32)__ffs((int)m) - 1); m &= m - 1; } }
+    __syncthreads();
+    if (wave == 0) {
+        const u64 tb = tile * ET_TILE;
+        const i64 le = tile_eol[tile - 1], lsp = tile_sp[tile - 1];
+        const bool prev_eol = le == (i64)tb - 1;
+        i64 ls0 = le + 1; if ((u64)ls0 < P.p0) ls0 = (i64)P.p0;
+        const u64 ord0 = t_ls[tile] - (prev_eol ? 0u : 1u);                          // ordinal of segment 0's line
+        u64 carry = 0; bool bad = false;
+        for (u32 kb = 0; kb <= tot; kb += 64) {                                      // (uniform: 64 segments a round)
+            const u32 k = kb + lane;
+            u64 c = 0;
+            if (k <= tot) {
+                const u32 s_ = k ? (u32)S.nlpos[k - 1] + 1 : 0u, e_ = k < tot ? (u32)S.nlpos[k] : (u32)ET_TILE;
+                const u32 len = e_ - s_;
+                const bool starts = k > 0 || prev_eol, closed = k < tot;
+                if (CHECK && len == 0 && starts && closed) bad = true;               // an empty line
+                const u32 ty = (u32)((ord0 + k) & 3);
+                u32 hdr = 0;
+                if (ty == 1) c = (u64)len;
+                else if (ty == 3) c = (u64)len << 48;
+                else if (ty == 2) { if (CHECK && starts && len && S.txt[s_] != '+') bad = true; }
+                else {
+                    u32 a = s_;
+                    if (starts && len) { if (CHECK && S.txt[s_] != '@') bad = true; a++; }
+                    const bool seen = !starts && lsp >= ls0;                         // the blank that ends the ID came in front of the tile
+                    u32 f = e_;                                                      // ... or is here (e_: not in this segment)
+                    if (a < e_) for (u32 q = a >> 4; q <= (e_ - 1) >> 4; q++) {
+                        u32 m = S.oth[q];
+                        if (!m) continue;
+                        const u32 lo = 16 * q;
+                        if (a > lo) m &= ~((1u << (a - lo)) - 1);
+                        if (e_ < lo + 16) m &= (1u << (e_ - lo)) - 1;
+                        if (m && !seen && f == e_) {
+                            f = lo + (u32)__ffs((int)m) - 1; m &= m - 1;
+                            if (CHECK) { const u32 ch = S.txt[f]; if (ch != 0x20 && ch != 0x09) bad = true; }
+                        }
+                        if (!CHECK && (seen || f != e_)) break;
+                        while (CHECK && m) { if (S.txt[lo + (u32)__ffs((int)m) - 1] != 0x20) bad = true; m &= m - 1; }   // a comment's bytes below 0x21 are blanks
+                    }
+                    u32 nids, ncmt;
+                    if (seen) { nids = 0; ncmt = e_ - a; f = 0xFFFFu; }
+                    else { nids = f - a; ncmt = 0; if (f < e_) { nids++; ncmt = e_ - (f + 1); } }
+                    if (closed) { if (!seen && f == e_) nids++; ncmt++; }
+                    c = ((u64)nids << 16) | ((u64)ncmt << 32);
+                    hdr = a | (f << 16);
+                }
+                S.segse[k] = s_ | (e_ << 16); S.seghdr[k] = hdr;
+                S.segtype[k] = (u8)(ty | (starts ? 4u : 0u) | (closed ? 8u : 0u));
+            }
+            const u64 inc = wave_scan_inclusive<u64, OpAdd>(c) + carry;
+            if (k <= tot) S.segoff[k] = inc - c;
+            if (k == tot) S.total = inc;
+            carry = shfl_idx_t<u64>(inc, 63);
+        }
+        if (CHECK && bad) S.bad = 1;
+        if (bases) {
+            // The staging buffer holds the tile's share of the four streams one behind the other, each region placed so that its address
+            // is congruent to the stream's own mod 16: whole 16-byte words of LDS then go out as aligned 16-byte stores.
+            const u32 tots = (u32)(carry & 0xFFFF), toti = (u32)((carry >> 16) & 0xFFFF), totc = (u32)((carry >> 32) & 0xFFFF), totq = (u32)(carry >> 48);
+            const u32 sO = (u32)(bases[0] & 15);
+            const u32 qO = ((sO + tots + 15) & ~15u) + (u32)(bases[3] & 15);
+            const u32 iO = ((qO + totq + 15) & ~15u) + (u32)(bases[1] & 15);
+            const u32 cO = ((iO + toti + 15) & ~15u) + (u32)(bases[2] & 15);
+            (void)totc;
+            if (lane == 0) { S.so[0] = sO; S.so[1] = iO; S.so[2] = cO; S.so[3] = qO; }
+            for (u32 kb = 0; kb <= tot; kb += 64) {
+                const u32 k = kb + lane;
+                if (k <= tot) {
+                    const u32 ty = S.segtype[k] & 3u, s_ = S.segse[k] & 0xFFFF; const u64 off = S.segoff[k];
+                    S.segdst[k] = ty == 1 ? (i32)(sO + (u32)(off & 0xFFFF)) - (i32)s_ : ty == 3 ? (i32)(qO + (u32)(off >> 48)) - (i32)s_ : FQR_SKIP;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return true;
+}
+// n bytes from LDS to global memory where stage and dst are congruent mod 16, by the lanes t = 0 .. nt-1 of a group
+__device__ __forceinline__ void flush_congruent(u8 *dst, const u8 *stage, u32 n, u32 t, u32 nt)
+{
+    u32 head = (u32)((16 - ((uintptr_t)dst & 15)) & 15); if (head > n) head = n;
+    if (t < head) dst[t] = stage[t];
+    const u32 chunks = (n - head) >> 4;
+    for (u32 q = t; q < chunks; q += nt) *(uint4 *)(dst + head + 16 * q) = *(const uint4 *)(stage + head + 16 * q);
+    const u32 done = head + 16 * chunks;
+    if (t < n - done) dst[done + t] = stage[done + t];
+}
+
+__global__ __launch_bounds__(256) void k_encq_count_reg(EncP P, const i64 *tile_eol, const i64 *tile_sp, const u64 *t_ls,
+                                                         u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_qual, u32 *t_reg, u64 *t_need, u64 tiles)
+{
+    const u64 tile = blockIdx.x, tb = tile * ET_TILE;
+    __shared__ FqrLds S;
+    bool regular = tile > 0 && tb > P.p0 && tb + ET_TILE <= P.n;                      // (uniform)
+    if (regular) {
+        const u8 *src = P.text + tb + 16 * threadIdx.x;
+        const u64 w0 = ld64(src), w1 = ld64(src + 8);
+        const u32 w[4] = { (u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32) };
+        u32 nlm, oth, k0, nseg; bool high;
+        fqr_masks(w, nlm, oth, high);
+        regular = fqr_segments<true>(P, tile, tile_eol, tile_sp, t_ls, S, w, nlm, oth, k0, nseg);
+        if (regular) {
+            // a piece's bytes below 0x21 against the types of its segments: none in sequence and quality lines; no EOL-class byte in a
+            // '+' line (whatever else it holds is skipped); header segments were looked at by their lanes
+            bool bad = high;
+            if (oth) {
+                u32 a = 0, m = nlm, k = k0;
+                for (;;) {
+                    const u32 b = m ? (u32)__ffs((int)m) - 1 : 16u;
+                    u32 o = b > a ? oth & range_mask(a, b) : 0u;
+                    if (o) {
+                        const u32 ty = S.segtype[k] & 3u;
+                        if (ty & 1) bad = true;
+                        else if (ty == 2) while (o) { const u32 q = (u32)__ffs((int)o) - 1; o &= o - 1; const u32 ch = (w[q >> 2] >> (8 * (q & 3))) & 0xFF; if (ch >= 0x0B && ch <= 0x0D) bad = true; }
+                    }
+                    if (!m) break;
+                    m &= m - 1; a = b + 1; k++;
+                }
+            }
+            if (bad) S.bad = 1;
+            __syncthreads();
+            regular = S.bad == 0;
+        }
+    }
+    if (threadIdx.x == 0) {
+        t_reg[tile] = regular ? 1u : 0u; t_need[tile] = regular ? 0u : 1u;
+        if (regular) { const u64 t = S.total; t_seq[tile] = t & 0xFFFF; t_ids[tile] = (t >> 16) & 0xFFFF; t_cmt[tile] = (t >> 32) & 0xFFFF; t_qual[tile] = t >> 48; }
+    }
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_encq_scatter_reg(EncP P, const i64 *tile_eol, const i64 *tile_sp, FqOut O)
+{
+    const u64 tile = blockIdx.x, tb = tile * ET_TILE;
+    if (!O.t_reg[tile]) return;                                                       // (uniform) the general kernel takes it from the list
+    __shared__ FqrLds S;
+    __shared__ __attribute__((aligned(16))) u8 stage[ET_TILE + 512 + 5 * 16];
+    const u32 tid = threadIdx.x;
+    const u8 *src = P.text + tb + 16 * tid;
+    const u64 w0 = ld64(src), w1 = ld64(src + 8);
+    const u32 w[4] = { (u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32) };
+    u32 nlm, oth, k0, nseg; bool high;
+    fqr_masks(w, nlm, oth, high);
+    const u64 bases[4] = { O.t_seq[tile], O.t_ids[tile], O.t_cmt[tile], O.t_qual[tile] };
+    fqr_segments<false>(P, tile, tile_eol, tile_sp, O.t_ls, S, w, nlm, oth, k0, nseg, bases);
+    const u64 sbase = bases[0], qbase = bases[3];
+    // every piece moves its sequence and quality bytes to their places in the staging buffer
+    {
+        const Piece pc = { w0, w1, 16 };
+        u32 a = 0, m = nlm, k = k0;
+        for (;;) {
+            const u32 b = m ? (u32)__ffs((int)m) - 1 : 16u;
+            if (b > a) {
+                const i32 d = S.segdst[k];
+                if (d != FQR_SKIP) { u64 lo, hi; piece_from(pc, a, lo, hi); lds_store_n(stage + (d + (i32)(16 * tid + a)), lo, hi, b - a); }
+            }
+            if (!m) break;
+            m &= m - 1; a = b + 1; k++;
+        }
+    }
+    // a lane per segment: the header's bytes to the ID and comment regions with their terminators, the record tables
+    if (tid < nseg) {
+        const u32 k = tid, tyf = S.segtype[k], ty = tyf & 3;
+        const bool starts = tyf & 4, closed = tyf & 8;
+        const u32 s_ = S.segse[k] & 0xFFFF, e_ = S.segse[k] >> 16;
+        const u64 off = S.segoff[k];
+        const u64 ord = O.t_ls[tile] - ((S.segtype[0] & 4) ? 0u : 1u) + k, rec = ord >> 2;
+        if (ty == 0) {
+            const u32 a = S.seghdr[k] & 0xFFFF, f = S.seghdr[k] >> 16;
+            u8 *ip = stage + S.so[1] + (u32)((off >> 16) & 0xFFFF), *cp = stage + S.so[2] + (u32)((off >> 32) & 0xFFFF);
+            u32 ca = a;                                                               // first comment byte
+            if (f != 0xFFFFu) {
+                for (u32 q = a; q < f; q += 16) { const u32 nb = f - q < 16 ? f - q : 16u; lds_store_n(ip, ld64(S.txt + q), ld64(S.txt + q + 8), nb); ip += nb; }
+                if (f < e_ || closed) *ip = 0;
+                ca = f < e_ ? f + 1 : e_;
+            }
+            for (u32 q = ca; q < e_; q += 16) { const u32 nb = e_ - q < 16 ? e_ - q : 16u; lds_store_n(cp, ld64(S.txt + q), ld64(S.txt + q + 8), nb); cp += nb; }
+            if (closed) { *cp = 0; O.rec_begin[rec] = sbase + (off & 0xFFFF); }
+        } else if (ty == 1) { if (closed) O.rec_end[rec] = sbase + (off & 0xFFFF) + (e_ - s_); }
+        else if (ty == 3) {
+            if (starts && e_ > s_) O.q_begin[rec] = qbase + (off >> 48);
+            if (closed) O.q_end[rec] = qbase + (off >> 48) + (e_ - s_);
+        }
+    }
+    __syncthreads();
+    const u64 t = S.total;
+    const u32 tots = (u32)(t & 0xFFFF), toti = (u32)((t >> 16) & 0xFFFF), totc = (u32)((t >> 32) & 0xFFFF), totq = (u32)(t >> 48);
+    const u32 so = S.so[0];
+    // the letters: a group of sixteen staged bases with a byte that is not A C G T/U N (either case) sends the tile to the general
+    // kernel (an IUPAC code, a letter to be replaced and counted) -- before anything of its streams is written
+    {
+        bool odd = false;
+        const u32 span = so + tots, ng = (span + 15) >> 4;
+        for (u32 j = tid; j < ng; j += 256) {
+            uint4 v = *(const uint4 *)(stage + 16 * j);
+            u32 x[4] = { v.x, v.y, v.z, v.w };
+            const u32 a = j == 0 ? so : 0u, b = span - 16 * j < 16 ? span - 16 * j : 16u;
+            if (a || b < 16) {                                                        // what lies outside the tile's own bases reads as 'A'
+                const u64 klo = low_bytes(b < 8 ? b : 8u) & ~low_bytes(a < 8 ? a : 8u), khi = low_bytes(b > 8 ? b - 8 : 0u) & ~low_bytes(a > 8 ? a - 8 : 0u);
+                const u64 A = 0x4141414141414141ull;
+                const u64 lo = ((((u64)x[1] << 32) | x[0]) & klo) | (A & ~klo), hi = ((((u64)x[3] << 32) | x[2]) & khi) | (A & ~khi);
+                x[0] = (u32)lo; x[1] = (u32)(lo >> 32); x[2] = (u32)hi; x[3] = (u32)(hi >> 32);
+            }
+            if (!all_quick16(x, P.qlo, P.qhi)) odd = true;
+        }
+        if (__syncthreads_or(odd)) {
+            if (tid == 0) O.redo_list[atomicAdd(O.n_redo, 1u)] = (u32)tile;
+            return;
+        }
+    }
+    if (PACK) flush_pack<true>(P, O.packed, O.casebits, sbase, tots, stage);
+    else flush_congruent(O.seq + sbase, stage + so, tots, tid, 256);
+    flush_congruent(O.qual + qbase, stage + S.so[3], totq, tid, 256);
+    // the two small streams by a wavefront each
+    if (tid >= 192) flush_congruent(O.ids + bases[1], stage + S.so[1], toti, tid - 192, 64);
+    else if (tid >= 128) flush_congruent(O.cmt + bases[2], stage + S.so[2], totc, tid - 128, 64);
 }
 
 struct SmallBytes { u8 b[60]; u32 n; };
@@ -1822,7 +2111,23 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
         if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
         if ((rc = scan_exclusive_u64(c, t_ls, tiles, tot + 4))) return rc;
-        LAUNCH(c, "ennaf_fq_count", k_encq_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, piece_cnt);
+        // regular tiles by lines (k_encq_count_reg), the others -- the first and the last one always, whatever the tolerant parser has
+        // something to tolerate in -- from a list by the general kernel; NAF_GPU_FQ_REG=0: every tile by the general kernel
+        const bool fq_reg = !(getenv("NAF_GPU_FQ_REG") && getenv("NAF_GPU_FQ_REG")[0] == '0');
+        u32 *t_reg = nullptr, *need_list = nullptr; u64 n_need = tiles;
+        u32 *redo_list = nullptr, *n_redo = nullptr;
+        if (fq_reg && S.fourbit && n >= 16 * ET_TILE) {
+            t_reg = arena_new<u32>(c, tiles + 1); need_list = arena_new<u32>(c, tiles + 1); redo_list = arena_new<u32>(c, tiles + 1); n_redo = arena_new<u32>(c, 2);
+            u64 *t_need = arena_new<u64>(c, tiles + 2);
+            if (!t_reg || !need_list || !t_need || !redo_list || !n_redo) return NAF_GPU_ENOMEM;
+            HIP_TRY(c, hipMemsetAsync(n_redo, 0, 8, c->stream));
+            LAUNCH(c, "ennaf_fq_count_reg", k_encq_count_reg, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, t_reg, t_need, tiles);
+            if ((rc = scan_exclusive_u64(c, t_need, tiles, tot + 5))) return rc;
+            LAUNCH(c, "ennaf_need_list", k_need_list, cdiv(tiles, 256), 256, 0, (const u32 *)nullptr, (const u64 *)t_need, tiles, need_list, (const u32 *)t_reg);
+            if ((rc = ctx_readback(c, &n_need, tot + 5, 8))) return rc;
+            if (getenv("NAF_GPU_DEBUG_REG")) fprintf(stderr, "[fq reg] tiles %llu, not regular %llu\n", (unsigned long long)tiles, (unsigned long long)n_need);
+        }
+        if (n_need) LAUNCH(c, "ennaf_fq_count", k_encq_count, n_need, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, piece_cnt, (const u32 *)need_list, 0);
         if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
         if ((rc = scan_exclusive_u64(c, t_ids, tiles, tot + 1))) return rc;
         if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;
@@ -1848,10 +2153,22 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         HIP_TRY(c, hipMemsetAsync(q_begin, 0, (N + 1) * 8, c->stream)); HIP_TRY(c, hipMemsetAsync(q_end, 0, (N + 1) * 8, c->stream));
         FqOut O; O.seq = bases; O.packed = S.packed; O.casebits = (u32 *)S.casebits; O.ids = s_ids; O.cmt = s_cmt; O.qual = s_qual; O.rec_begin = rec_begin; O.rec_end = rec_end; O.q_begin = q_begin; O.q_end = q_end;
         O.unexpected = d_unexp; O.first_error = d_unexp + 4 * 257; O.strict_first = o->strict ? d_unexp + 4 * 257 + 2 : nullptr;
-        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_qual = t_qual; O.t_ls = t_ls; O.piece_cnt = piece_cnt;
+        O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_qual = t_qual; O.t_ls = t_ls; O.piece_cnt = piece_cnt; O.list = need_list; O.t_reg = t_reg; O.redo_list = redo_list; O.n_redo = n_redo;
         if (S.fourbit) {
             if (T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(tiles, 256), 256, 0, (const u64 *)t_seq, tiles, T, S.packed, (u32 *)S.casebits, (const u8 *)nullptr, 0u);
-            LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter<true>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+            if (t_reg) LAUNCH(c, "ennaf_fq_scatter_reg", k_encq_scatter_reg<true>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+            if (n_need) LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter<true>, n_need, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+            if (t_reg) {
+                // regular tiles handed back for their letters (an IUPAC code, a letter to be replaced): their pieces' counts, then the general scatter
+                u32 nr = 0;
+                if ((rc = ctx_readback(c, &nr, n_redo, 4))) return rc;
+                if (getenv("NAF_GPU_DEBUG_REG")) fprintf(stderr, "[fq reg] handed back %u\n", nr);
+                if (nr) {
+                    LAUNCH(c, "ennaf_fq_count", k_encq_count, nr, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, piece_cnt, (const u32 *)redo_list, 1);
+                    O.list = redo_list;
+                    LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter<true>, nr, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+                }
+            }
         } else LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter<false>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
         if (nlines / 4) LAUNCH(c, "ennaf_fq_check", k_fq_check, cdiv(nlines / 4, 256), 256, 0, (const u64 *)rec_begin, (const u64 *)rec_end, (const u64 *)q_begin, (const u64 *)q_end, nlines / 4, O.first_error, d_unexp + 4 * 257 + 1);
         std::vector<u64> hu(NU);
@@ -1919,7 +2236,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
             if (!t_needf || !need_list || !t_need) return NAF_GPU_ENOMEM;
             LAUNCH(c, "ennaf_count_pure", k_enc_count_pure, cdiv(tiles, 4), 256, 0, P, (const i64 *)t_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, tiles);
             if ((rc = scan_exclusive_u64(c, t_need, tiles, tot + 5))) return rc;
-            LAUNCH(c, "ennaf_need_list", k_need_list, cdiv(tiles, 256), 256, 0, (const u32 *)t_needf, (const u64 *)t_need, tiles, need_list);
+            LAUNCH(c, "ennaf_need_list", k_need_list, cdiv(tiles, 256), 256, 0, (const u32 *)t_needf, (const u64 *)t_need, tiles, need_list, (const u32 *)nullptr);
             u64 n_need = 0;
             if ((rc = ctx_readback(c, &n_need, tot + 5, 8))) return rc;
             if (getenv("NAF_GPU_DEBUG_REG")) {

@@ -372,6 +372,74 @@ def test_ennaf_fastq_fuzz_realistic_records(gpu, oracle):
         check_ennaf(gpu, oracle, t)
 
 
+def _fastq_text(rng, n_bytes, read_len, comment=0.8, damage=(), iupac=0.0, p_damage=0.004):
+    """Reads as a sequencer writes them, to `n_bytes`; `read_len` = (lo, hi); `damage`: kinds of irregular spots sprinkled in, one
+    every few hundred reads."""
+    bases = np.frombuffer(b"ACGTACGTACGTACGTNacgtn", dtype=np.uint8)
+    quals = np.frombuffer(bytes(range(0x21, 0x7F)), dtype=np.uint8)
+    out = bytearray(); r = 0
+    while len(out) < n_bytes:
+        hdr = b"@SRR%d.%d" % (int(rng.integers(1, 9)), r)
+        if rng.random() < comment:
+            hdr += (b" " if r % 5 else b"\t") + b"%d:N:0:ACGT length=%d" % (1 + (r & 1), r)
+        n = int(rng.integers(read_len[0], read_len[1] + 1))
+        seq = bytearray(bases[rng.integers(0, len(bases), n)].tobytes())
+        qual = bytearray(quals[rng.integers(0, len(quals), n)].tobytes())
+        if rng.random() < iupac: seq[int(rng.integers(0, n))] = int(rng.choice(list(b"RYKMSWryk")))
+        plus = b"+" + (hdr[1:] if r % 11 == 0 else b"")
+        e = [b"\n"] * 4
+        if damage and rng.random() < p_damage:
+            d = damage[int(rng.integers(0, len(damage)))]
+            if d == "blank": e[int(rng.integers(1, 4))] = b"\n\n"
+            elif d == "crlf": e = [b"\n", b"\r\n", b"\r\n", b"\r\n"]
+            elif d == "space_seq" and n > 1: k = int(rng.integers(1, n)); seq = seq[:k] + b" " + seq[k:]
+            elif d == "bad_seq": seq[int(rng.integers(0, n))] = ord("z")
+            elif d == "bad_qual" and n > 1: qual[int(rng.integers(1, n))] = int(rng.choice([0x01, 0x80, 0x7F]))
+            elif d == "ctl_hdr": hdr += b"\x01"
+            elif d == "tabs_hdr": hdr += b"\tmore\tfields"
+            elif d == "plus_space": plus = b"+ a b\tc"
+        out += hdr + e[0] + seq + e[1] + plus + e[2] + qual + e[3]
+        r += 1
+    return bytes(out)
+
+
+def test_ennaf_fastq_regular_tiles_by_lines(gpu, oracle, monkeypatch, capfd):
+    """k_encq_count_reg / k_encq_scatter_reg (tiles of a FASTQ text the tolerant parser has nothing to tolerate in, split by lines)
+    against the oracle and, byte for byte, against the archive of the general kernels alone (NAF_GPU_FQ_REG=0): 150-base reads, reads
+    of 1..400 bases, of one to three bases (more than 63 line ends in a tile: not regular), of 20-60 kbases (tiles inside one line),
+    headers with and without comments, tab-separated comments, '+' lines that repeat the name -- and the same with irregular spots
+    sprinkled in (blank lines, CR LF, blanks in sequence lines, letters that are replaced, bad quality bytes, control bytes and second
+    tabs in headers), each of which must send its tile, and only its tile, to the general kernel."""
+    rng = np.random.default_rng(4242)
+    all_damage = ("blank", "crlf", "space_seq", "bad_seq", "bad_qual", "ctl_hdr", "tabs_hdr", "plus_space")
+    cases = [(400_000, (150, 150), 0.8, (), 0.0), (300_000, (1, 400), 0.5, (), 0.0), (150_000, (1, 3), 0.0, (), 0.0), (500_000, (20_000, 60_000), 1.0, (), 0.0),
+             (300_000, (30, 60), 0.0, (), 0.0), (300_000, (100, 200), 0.8, (), 0.01), (600_000, (100, 250), 0.8, all_damage, 0.002), (300_000, (1, 40), 0.3, all_damage, 0.0)]
+    cases += [(200_000, (150, 150), 0.8, (d,), 0.0) for d in all_damage]
+    for n_bytes, rl, cm, dmg, iupac in cases:
+        t = _fastq_text(rng, n_bytes, rl, cm, dmg, iupac, 0.02 if len(dmg) == 1 else 0.004)
+        for tail in (t, t.rstrip(b"\n"), b"\n \n" + t):
+            monkeypatch.setenv("NAF_GPU_FQ_REG", "1"); monkeypatch.setenv("NAF_GPU_DEBUG_REG", "1")
+            capfd.readouterr()
+            mine = check_ennaf(gpu, oracle, tail)
+            err = capfd.readouterr().err
+            tiles, irregular = [int(x) for x in err.split("[fq reg] tiles ")[1].split("\n")[0].replace(", not regular", "").split()]
+            back = int(err.split("[fq reg] handed back ")[1].split("\n")[0])
+            if not dmg and rl[0] > 3:
+                assert irregular <= 3, (rl, tiles, irregular)          # the first tile (p0) and the last (partial) ones
+                assert (back > 0) == (iupac > 0), (rl, back)
+            if rl[1] <= 3:
+                assert irregular == tiles
+            if dmg == ("bad_seq",):
+                assert back > 0 and irregular <= 3
+            elif dmg == ("plus_space",):
+                assert irregular <= 3                                   # whatever a '+' line holds behind its '+' is skipped
+            elif dmg:
+                assert 2 < irregular < tiles, (dmg, tiles, irregular)
+            monkeypatch.setenv("NAF_GPU_FQ_REG", "0"); monkeypatch.delenv("NAF_GPU_DEBUG_REG")
+            general, _ = gpu.ennaf(gpu.to_device(tail))
+            assert host(general) == mine, (rl, dmg)
+
+
 def test_single_record_of_more_than_2_32_bases(gpu, oracle):
     """One record of 4.4 G bases: its length takes a 0xFFFFFFFF continuation unit (encoders.c:72-95), base indices and text offsets
     inside the record pass 2^32, and the mask run is 17 million units of 255.  Round trip on the device, the lengths stream
