@@ -98,7 +98,8 @@ int  naf_gpu_gather_ranges(naf_gpu_ctx *dst, void *d_dst, naf_gpu_ctx *const *sr
 
 /* File <-> HBM through pinned staging on several host threads (io.hip; NAF_GPU_IO_THREADS, default 8): what the reference does with
  * fread / fwrite of 16 KiB (ennaf/src/process.c:143-150, unnaf/src/files.c).  fd must support pread / pwrite (a regular file); the
- * calls return when the transfer is complete.  naf_gpu_write_file first waits for the work queued on the ctx stream. */
+ * calls return when the transfer is complete.  The copies run on the ctx stream, in order behind whatever was queued there (the
+ * kernels that make d_src). */
 int  naf_gpu_read_file(naf_gpu_ctx *ctx, int fd, uint64_t file_off, size_t len, void *d_dst);
 int  naf_gpu_write_file(naf_gpu_ctx *ctx, int fd, uint64_t file_off, const void *d_src, size_t len);
 

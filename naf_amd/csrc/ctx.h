@@ -57,6 +57,7 @@ struct naf_gpu_ctx {
     naf_gpu_ctx *side2 = nullptr;         // third one: the quality stream of a FASTQ archive decodes beside the sequence stream
     naf_gpu_ctx *side3 = nullptr;         // fourth: ids and names beside lengths and mask
     naf_gpu_ctx *side4 = nullptr;         // fifth: the names of an archive of many records beside its ids (emit.hip: unnaf_sections_main)
+    void *sides_thread = nullptr; int sides_rc = 0;     // naf_gpu_init's thread that makes the side contexts (naf_gpu.hip: ctx_sides_ready)
     hipEvent_t fork_ev = nullptr;
     struct ZSplit *zsplit = nullptr;        // set by unnaf for the sequence stream of a whole-text call: Huffman literals in parts (below)
     hipEvent_t split_ev[ZSPLIT_MAX + 2] = {};
@@ -70,6 +71,7 @@ struct naf_gpu_ctx {
 // more than the chains it ran).  One job at a time; ctx_worker_join returns once the job has.
 void ctx_worker_start(naf_gpu_ctx *x, std::function<void()> job);
 void ctx_worker_join(naf_gpu_ctx *x);
+int  ctx_sides_ready(naf_gpu_ctx *c);       // before c->side .. c->side4 are looked at: waits for the thread of naf_gpu_init that makes them
 
 int  ctx_fail(naf_gpu_ctx *c, int code, const char *fmt, ...);
 #define HIP_TRY(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return ctx_fail((c), NAF_GPU_EHIP, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)

@@ -1580,6 +1580,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
 {
     if (!c || !d_naf || !o || !out_len) return NAF_GPU_EARG;
     arena_reset(c);
+    if (whole && !size_only) { int rs = ctx_sides_ready(c); if (rs) return rs; }        // (a range or a size call stays on this context)
     UnnafPlan pl;
     int rc = unnaf_prepare(c, d_naf, naf_len, o, pl); if (rc) return rc;
     if (pl.empty) { *out_len = 0; return 0; }

@@ -2591,6 +2591,7 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
                        void *d_naf_, size_t cap, size_t *naf_len, naf_gpu_ennaf_report *rep)
 {
     arena_reset(c);
+    { int rs = ctx_sides_ready(c); if (rs) return rs; }
     const u8 *d_text = (const u8 *)d_text_; u8 *d_naf = (u8 *)d_naf_;
     naf_gpu_ennaf_report R; memset(&R, 0, sizeof R);
     if (o->seq_type < 0 || o->seq_type > 3) return ctx_fail(c, NAF_GPU_EARG, "bad seq_type");

@@ -1,9 +1,12 @@
 // io.hip -- file <-> HBM ("host I/O path").  The reference moves every byte through one thread and 16 KiB
 // fread / fwrite calls (ennaf/src/process.c:143-150, unnaf/src/output.c:640-651, files.c); a device-resident codec that finishes
 // 10 GB in milliseconds is then only as fast as its file I/O.  Here a transfer is cut into 16 MiB chunks dealt round-robin to a
-// few host threads, each with two pinned staging buffers and a HIP stream of its own: while one chunk of a lane is on the PCIe
-// link (hipMemcpyAsync), the lane's thread is in pread / pwrite for its other chunk, and the lanes run beside each other -- page
-// cache copies, PCIe and (for tmpfs / NVMe) the file system all see several requests in flight.
+// few host threads, each with two pinned staging buffers: while one chunk of a lane is on the PCIe link (hipMemcpyAsync), the lane's
+// thread is in pread / pwrite for its other chunk, and the lanes run beside each other -- page cache copies, PCIe and (for tmpfs /
+// NVMe) the file system all see several requests in flight.  The copies of all lanes go through the CONTEXT's stream, each followed by
+// an event of its lane: one stream feeds the link at 49 GB/s of its 55 (tools/io_probe), a stream per lane was 45 ms of
+// hipStreamCreate each (rocprofv3 --hip-trace of the CLIs) -- more than the transfer of a GB -- and copies behind the kernels that
+// make their source need no wait in between.
 #include "ctx.h"
 #include <thread>
 #include <atomic>
@@ -11,8 +14,8 @@
 #include <errno.h>
 
 static const size_t IO_CHUNK = (size_t)16 << 20;
-struct IoLane { hipStream_t s = nullptr; void *pin[2] = { nullptr, nullptr }; hipEvent_t ev[2] = { nullptr, nullptr }; bool ready = false; };
-struct IoPool { int lanes = 0; IoLane lane[16]; };
+struct IoLane { void *pin[2] = { nullptr, nullptr }; hipEvent_t ev[2] = { nullptr, nullptr }; bool ready = false; };
+struct IoPool { int lanes = 0; IoLane lane[16]; std::vector<void *> blocks; };
 
 static IoPool *io_pool(naf_gpu_ctx *c)
 {
@@ -24,30 +27,32 @@ static IoPool *io_pool(naf_gpu_ctx *c)
     c->io_pool = p;
     return p;
 }
-// A lane's stream and its two pinned buffers are made by the thread that first uses the lane: pinning 256 MiB for eight lanes took the
-// calling thread 0.1 - 0.15 s in front of the first byte moved; the lanes' threads now pin their 32 MiB each beside one another, and a
-// transfer that uses one lane (every write) pins one lane's.
-static bool lane_ready(IoLane &L)
+// The pinned buffers of the lanes a transfer is going to use, in ONE allocation for those that have none yet: a hipHostMalloc is
+// 4.5 ms whatever its size up to tens of MB and the calls of several threads do not run beside each other (rocprofv3 --hip-trace of
+// the CLIs: 16 calls, 72 ms in front of the first byte of a 1 GB archive); a transfer of one lane (every write) still pins one lane's.
+static bool lanes_ready(IoPool *P, int T)
 {
-    if (L.ready) return true;
-    // a lane left half built by a failed attempt (stream without its buffers) is completed here, never used as it is
-    bool ok = L.s || hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; k < 2 && ok; k++) {
-        if (!L.pin[k]) ok = hipHostMalloc(&L.pin[k], IO_CHUNK, hipHostMallocDefault) == hipSuccess;
-        if (ok && !L.ev[k]) ok = hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming) == hipSuccess;
+    int need = 0;
+    for (int t = 0; t < T; t++) if (!P->lane[t].ready) need++;
+    if (!need) return true;
+    u8 *base = nullptr;
+    if (hipHostMalloc((void **)&base, (size_t)need * 2 * IO_CHUNK, hipHostMallocDefault) != hipSuccess) return false;
+    P->blocks.push_back(base);
+    for (int t = 0; t < T; t++) {
+        IoLane &L = P->lane[t]; if (L.ready) continue;
+        bool ok = true;
+        for (int k = 0; k < 2 && ok; k++) { L.pin[k] = base; base += IO_CHUNK; if (!L.ev[k]) ok = hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming) == hipSuccess; }
+        if (!ok) return false;
+        L.ready = true;
     }
-    L.ready = ok;
-    return ok;
+    return true;
 }
 
 void io_pool_free(naf_gpu_ctx *c)
 {
     IoPool *p = (IoPool *)c->io_pool; if (!p) return;
-    for (int i = 0; i < 16; i++) {
-        IoLane &L = p->lane[i];
-        for (int k = 0; k < 2; k++) { if (L.pin[k]) hipHostFree(L.pin[k]); if (L.ev[k]) hipEventDestroy(L.ev[k]); }
-        if (L.s) hipStreamDestroy(L.s);
-    }
+    for (int i = 0; i < 16; i++) for (int k = 0; k < 2; k++) if (p->lane[i].ev[k]) hipEventDestroy(p->lane[i].ev[k]);
+    for (void *b : p->blocks) hipHostFree(b);
     delete p; c->io_pool = nullptr;
 }
 
@@ -70,20 +75,23 @@ extern "C" int naf_gpu_read_file(naf_gpu_ctx *c, int fd, uint64_t file_off, size
     if (!len) return 0;
     IoPool *P = io_pool(c);
     const u64 nchunks = (len + IO_CHUNK - 1) / IO_CHUNK;
-    const int T = (int)(nchunks < (u64)P->lanes ? nchunks : (u64)P->lanes);
+    // a lane per 256 MiB, up to the pool's: pinning a lane's two buffers costs what reading 100 MB through them takes
+    u64 want = (len >> 28) + 1; if (want > (u64)P->lanes) want = (u64)P->lanes;
+    const int T = (int)(nchunks < want ? nchunks : want);
     std::atomic<int> bad(0);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!lanes_ready(P, T)) return ctx_fail(c, NAF_GPU_ENOMEM, "can't allocate pinned staging buffers");
     auto work = [&](int t) {
         hipSetDevice(c->device);
         IoLane &L = P->lane[t]; bool used[2] = { false, false };
-        if (!lane_ready(L)) { bad = 3; return; }
         for (u64 i = (u64)t, k = 0; i < nchunks && !bad.load(); i += (u64)T, k++) {
             const int slot = (int)(k & 1); const u64 off = i * IO_CHUNK; const size_t n = len - off < IO_CHUNK ? (size_t)(len - off) : IO_CHUNK;
             if (used[slot] && hipEventSynchronize(L.ev[slot]) != hipSuccess) { bad = 2; break; }          // the upload that last read this buffer
             if (!pread_full(fd, L.pin[slot], n, file_off + off)) { bad = 1; break; }
-            if (hipMemcpyAsync((u8 *)d_dst + off, L.pin[slot], n, hipMemcpyHostToDevice, L.s) != hipSuccess || hipEventRecord(L.ev[slot], L.s) != hipSuccess) { bad = 2; break; }
+            if (hipMemcpyAsync((u8 *)d_dst + off, L.pin[slot], n, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipEventRecord(L.ev[slot], c->stream) != hipSuccess) { bad = 2; break; }
             used[slot] = true;
         }
-        if (hipStreamSynchronize(L.s) != hipSuccess) bad = 2;
+        for (int k = 0; k < 2; k++) if (used[k] && hipEventSynchronize(L.ev[k]) != hipSuccess) bad = 2;
     };
     std::vector<std::thread> th;
     for (int t = 1; t < T; t++) th.emplace_back(work, t);
@@ -99,7 +107,6 @@ extern "C" int naf_gpu_write_file(naf_gpu_ctx *c, int fd, uint64_t file_off, con
 {
     if (!c || (!d_src && len)) return NAF_GPU_EARG;
     if (!len) return 0;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));                      // whatever produced d_src
     IoPool *P = io_pool(c);
     const u64 nchunks = (len + IO_CHUNK - 1) / IO_CHUNK;
     // ONE writer unless told otherwise (NAF_GPU_IO_WRITE_THREADS): pwrite() into a new tmpfs file runs 7.5 GB/s from one thread and
@@ -108,13 +115,14 @@ extern "C" int naf_gpu_write_file(naf_gpu_ctx *c, int fd, uint64_t file_off, con
     static const int wt = [] { const char *e = getenv("NAF_GPU_IO_WRITE_THREADS"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
     int T = (int)(nchunks < (u64)P->lanes ? nchunks : (u64)P->lanes); if (T > wt) T = wt;
     std::atomic<int> bad(0);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!lanes_ready(P, T)) return ctx_fail(c, NAF_GPU_ENOMEM, "can't allocate pinned staging buffers");
     auto work = [&](int t) {
         hipSetDevice(c->device);
         IoLane &L = P->lane[t];
-        if (!lane_ready(L)) { bad = 3; return; }
         auto issue = [&](u64 i, int slot) -> bool {
             const u64 off = i * IO_CHUNK; const size_t n = len - off < IO_CHUNK ? (size_t)(len - off) : IO_CHUNK;
-            return hipMemcpyAsync(L.pin[slot], (const u8 *)d_src + off, n, hipMemcpyDeviceToHost, L.s) == hipSuccess && hipEventRecord(L.ev[slot], L.s) == hipSuccess;
+            return hipMemcpyAsync(L.pin[slot], (const u8 *)d_src + off, n, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipEventRecord(L.ev[slot], c->stream) == hipSuccess;
         };
         if ((u64)t < nchunks && !issue((u64)t, 0)) { bad = 2; return; }
         for (u64 i = (u64)t, k = 0; i < nchunks && !bad.load(); i += (u64)T, k++) {
@@ -123,7 +131,6 @@ extern "C" int naf_gpu_write_file(naf_gpu_ctx *c, int fd, uint64_t file_off, con
             if (hipEventSynchronize(L.ev[slot]) != hipSuccess) { bad = 2; break; }
             if (!pwrite_full(fd, L.pin[slot], n, file_off + off)) { bad = 1; break; }
         }
-        hipStreamSynchronize(L.s);
     };
     std::vector<std::thread> th;
     for (int t = 1; t < T; t++) th.emplace_back(work, t);

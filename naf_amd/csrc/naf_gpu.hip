@@ -52,23 +52,37 @@ extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
     if (hipHostMalloc((void **)&c->h_stage, c->h_stage_cap, hipHostMallocDefault) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return NAF_GPU_ENOMEM; }
     int rc = zstd_init_tables(c);
     if (rc) { naf_gpu_shutdown(c); return rc; }
-    // side contexts: share the device and the constant tables
+    // side contexts: share the device and the constant tables.  Their streams are made by a thread of their own while the caller goes on
+    // (a stream is 10 - 45 ms of hipStreamCreate on this runtime, five of them were most of what naf_gpu_init took: rocprofv3 --hip-trace of
+    // the CLIs); whoever needs a side context first waits for that thread (ctx_sides_ready).
     if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess) { naf_gpu_shutdown(c); return NAF_GPU_EHIP; }
     for (int k = 0; k < ZSPLIT_MAX + 2; k++) if (hipEventCreateWithFlags(&c->split_ev[k], hipEventDisableTiming) != hipSuccess) { naf_gpu_shutdown(c); return NAF_GPU_EHIP; }
-    for (int k = 0; k < 4; k++) {
-        naf_gpu_ctx *sc = new naf_gpu_ctx();
-        sc->device = device; sc->d_predef = c->d_predef; sc->h_stage_cap = 1 << 16;
-        // highest priority: the side chains are many tiny kernels; behind the payload's bulk kernels they would only be scheduled
-        // once those drain, and the call would end up waiting for them
+    c->sides_rc = 0;
+    c->sides_thread = new std::thread([c, device] {
+        hipSetDevice(device);
         int prio_lo = 0, prio_hi = 0; hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        if (hipStreamCreateWithPriority(&sc->stream, hipStreamNonBlocking, prio_hi) != hipSuccess || hipHostMalloc((void **)&sc->h_stage, sc->h_stage_cap, hipHostMallocDefault) != hipSuccess) {
-            delete sc; naf_gpu_shutdown(c); return NAF_GPU_EHIP;
+        for (int k = 0; k < 4; k++) {
+            naf_gpu_ctx *sc = new naf_gpu_ctx();
+            sc->device = device; sc->d_predef = c->d_predef; sc->h_stage_cap = 1 << 16;
+            // highest priority: the side chains are many tiny kernels; behind the payload's bulk kernels they would only be scheduled
+            // once those drain, and the call would end up waiting for them
+            if (hipStreamCreateWithPriority(&sc->stream, hipStreamNonBlocking, prio_hi) != hipSuccess || hipHostMalloc((void **)&sc->h_stage, sc->h_stage_cap, hipHostMallocDefault) != hipSuccess) {
+                if (sc->stream) hipStreamDestroy(sc->stream);
+                delete sc; c->sides_rc = NAF_GPU_EHIP; return;
+            }
+            sc->own_stream = true;
+            (k == 0 ? c->side : k == 1 ? c->side2 : k == 2 ? c->side3 : c->side4) = sc;
         }
-        sc->own_stream = true;
-        (k == 0 ? c->side : k == 1 ? c->side2 : k == 2 ? c->side3 : c->side4) = sc;
-    }
+    });
     *out = c;
     return NAF_GPU_OK;
+}
+
+// The side contexts are there (naf_gpu_init's thread has made them); an error of that thread becomes the caller's.
+int ctx_sides_ready(naf_gpu_ctx *c)
+{
+    if (c->sides_thread) { std::thread *t = (std::thread *)c->sides_thread; t->join(); delete t; c->sides_thread = nullptr; }
+    return c->sides_rc ? ctx_fail(c, c->sides_rc, "can't create the side streams") : 0;
 }
 
 struct HostWorker { std::thread th; std::mutex m; std::condition_variable cv; std::function<void()> job; int state = 0; /* 0 idle, 1 posted, 2 running */ bool quit = false; };
@@ -112,7 +126,8 @@ extern "C" void naf_gpu_shutdown(naf_gpu_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    ctx_sides_ready(c);
+    if (c->stream) hipStreamSynchronize(c->stream);
     for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3, c->side4 }) {
         if (!sc) continue;
         ctx_worker_stop(sc);
@@ -176,12 +191,15 @@ void arena_reset(naf_gpu_ctx *c)
 // every stream of the context is waited for first.
 void arena_settle(naf_gpu_ctx *c)
 {
+    // (while naf_gpu_init's thread is still making the side contexts nobody has used them: they hold nothing)
+    naf_gpu_ctx *all[5] = { c, nullptr, nullptr, nullptr, nullptr };
+    if (!c->sides_thread) { all[1] = c->side; all[2] = c->side2; all[3] = c->side3; all[4] = c->side4; }
     bool any = false;
-    for (naf_gpu_ctx *x : { c, c->side, c->side2, c->side3, c->side4 }) if (x && x->chunks.size() > 1) any = true;
+    for (naf_gpu_ctx *x : all) if (x && x->chunks.size() > 1) any = true;
     if (!any) return;
     hipSetDevice(c->device);
-    for (naf_gpu_ctx *x : { c, c->side, c->side2, c->side3, c->side4 }) if (x) hipStreamSynchronize(x->stream);
-    for (naf_gpu_ctx *x : { c, c->side, c->side2, c->side3, c->side4 }) {
+    for (naf_gpu_ctx *x : all) if (x) hipStreamSynchronize(x->stream);
+    for (naf_gpu_ctx *x : all) {
         if (!x || x->chunks.size() <= 1) continue;
         size_t total = 0;
         for (auto &ch : x->chunks) { total += ch.cap; hipFree(ch.base); }
@@ -225,7 +243,8 @@ extern "C" int naf_gpu_reserve(naf_gpu_ctx *c, size_t bytes)
 {
     if (!c) return NAF_GPU_EARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = reserve_one(c, bytes);
+    int rc = ctx_sides_ready(c); if (rc) return rc;
+    rc = reserve_one(c, bytes);
     // the side contexts (side sections of an archive, a FASTQ's quality stream, the chains behind an encode's split) take an eighth
     // each, at most 4 GiB: their arenas grow past that like any arena, in the first call that needs more
     size_t each = bytes / 8; if (each > ((size_t)4 << 30)) each = (size_t)4 << 30;
@@ -349,6 +368,7 @@ extern "C" int naf_gpu_download_async(naf_gpu_ctx *c, void *h, const void *d, si
 extern "C" int naf_gpu_set_timing(naf_gpu_ctx *c, int enable)
 {
     if (!c) return NAF_GPU_EARG;
+    ctx_sides_ready(c);
     c->timing = enable != 0; c->ktimes.clear(); c->ev_used = 0;
     for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3, c->side4 }) if (sc) { sc->timing = c->timing; sc->ktimes.clear(); sc->ev_used = 0; }
     return 0;
@@ -383,6 +403,7 @@ void ktime_end(naf_gpu_ctx *c)
 extern "C" int naf_gpu_get_timing(naf_gpu_ctx *c, const char **names, float *ms, int *launches, int cap)
 {
     if (!c) return NAF_GPU_EARG;
+    ctx_sides_ready(c);
     hipStreamSynchronize(c->stream);
     for (naf_gpu_ctx *sc : { c->side, c->side2, c->side3, c->side4 }) if (sc) hipStreamSynchronize(sc->stream);
     std::map<std::string, std::pair<float, int>> agg;

@@ -27,7 +27,14 @@ static int level = 1, fmt_cmd = NAF_FMT_AUTO, seq_type = NAF_SEQ_DNA, long_log =
 static bool line_length_is_specified = false; static long long requested_line_length = 0;
 static bool created_output_file = false, success = false;
 
-static void done(void) { if (!success && created_output_file && out_file_path) remove(out_file_path); if (gpu) naf_gpu_shutdown(gpu); }
+static void done(int status, void *arg)
+{
+    (void)arg;
+    if (!success && created_output_file && out_file_path) remove(out_file_path);
+    detach_report(status);                                        /* the foreground process leaves with this status now; what follows is nobody's wait */
+    if (gpu_init_started) { pthread_join(gpu_init_thread, NULL); gpu_init_started = false; }       /* (an exit while the device is still being opened) */
+    if (gpu) naf_gpu_shutdown(gpu);
+}
 
 static int parse_input_format(const char *s)
 {
@@ -328,7 +335,7 @@ static void write_chunked(FILE *OUT)
 int main(int argc, char **argv)
 {
     prog_name = "ennaf";
-    atexit(done);
+    on_exit(done, NULL);
     parse_command_line(argc, argv);
     if (in_file_path == NULL && isatty(fileno(stdin))) { err("no input specified, use \"ennaf -h\" for help\n"); exit(0); }
     int fmt_ext = NAF_FMT_AUTO;
@@ -340,6 +347,8 @@ int main(int argc, char **argv)
     FILE *IN = in_file_path ? fopen(in_file_path, "rb") : stdin;
     if (!IN) die("can't open input file\n");
     phase("start");
+    detach_teardown();                                             /* from here on a worker process; the foreground one leaves when the archive is written (host_common.h) */
+    gpu_open_early();                                              /* the device starts beside the rest of the set-up */
     char *auto_path = NULL;
     if (!force_stdout && !out_file_path && isatty(fileno(stdout))) {
         if (!in_file_path) die("output file is not specified\n");
@@ -497,6 +506,7 @@ int main(int argc, char **argv)
     success = true;
     /* everything is written and closed: the process ends here, without the device-side teardown (freeing gigabytes of device memory,
      * streams, the runtime's own exit handlers: 0.1 - 0.2 s that nobody waits for; NAF_GPU_SLOW_EXIT=1 runs it) */
-    { const char *se = getenv("NAF_GPU_SLOW_EXIT"); if (!(se && se[0] == '1')) { fflush(NULL); _exit(0); } }
+    fflush(NULL); detach_done(0);
+    { const char *se = getenv("NAF_GPU_SLOW_EXIT"); if (!(se && se[0] == '1')) _exit(0); }
     return 0;
 }

@@ -5,12 +5,17 @@
  * gfx950 device the programs stop with an error. */
 #ifndef NAF_HOST_COMMON_H
 #define NAF_HOST_COMMON_H
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <stdarg.h>
 #include <stdbool.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <signal.h>
+#include <fcntl.h>
 #include "../../include/naf_gpu.h"
 
 #define VERSION "1.3.0"
@@ -71,21 +76,71 @@ __attribute__((unused)) static int decimal_arg(const char *s, long long *v)
 static naf_gpu_ctx *gpu = NULL;
 static void devices_parse(void);
 static int first_device(void);
+/* The device is opened by a thread of its own while the main thread parses, opens and maps its files (the HIP runtime's start and
+ * the first stream are 0.1 s and more of a run that moves 4 GB in a second): gpu_open_early() as soon as it is known that the GPU
+ * will be needed, gpu_open() where it is needed first. */
+#include <pthread.h>
+static pthread_t gpu_init_thread; static bool gpu_init_started = false; static int gpu_init_rc = 0;
+static void *gpu_init_main(void *arg) { (void)arg; gpu_init_rc = naf_gpu_init(first_device(), &gpu); return NULL; }
+__attribute__((unused)) static void gpu_open_early(void)
+{
+    if (gpu || gpu_init_started) return;
+    devices_parse();
+    if (pthread_create(&gpu_init_thread, NULL, gpu_init_main, NULL) == 0) gpu_init_started = true;
+}
 static void gpu_open(void)
 {
+    if (gpu_init_started) {
+        phase("before GPU init");
+        pthread_join(gpu_init_thread, NULL); gpu_init_started = false;
+        if (gpu_init_rc) die("can't initialize the GPU path: %s\n", naf_gpu_strerror(gpu_init_rc));
+        phase("GPU init (the wait for it)");
+        return;
+    }
     if (gpu) return;
     phase("before GPU init");
     int rc = naf_gpu_init(first_device(), &gpu);
     if (rc) die("can't initialize the GPU path: %s\n", naf_gpu_strerror(rc));
     phase("GPU init");
 }
+/* The process that the caller waits for ends when the OUTPUT is complete, not when the driver has taken the device state apart: the
+ * work is done by a forked worker, the foreground process waits for its verdict on a pipe and leaves at once with the worker's exit
+ * status, while the worker's teardown (4 GB and more of device memory, pinned buffers, queues: 0.15 - 0.2 s of a run that takes one
+ * second -- DESIGN.md section 5) goes on behind it.  Called before anything touches the device.  NAF_GPU_DETACH=0: one process. */
+#include <sys/types.h>
+#include <sys/wait.h>
+static int detach_fd = -1;
+/* the worker's verdict; its standard streams are let go with it (a reader behind a pipe would otherwise wait for the teardown too) */
+static void detach_report(int status)
+{
+    if (detach_fd < 0) return;
+    fflush(NULL);
+    int dn = open("/dev/null", O_RDWR); if (dn >= 0) { dup2(dn, 0); dup2(dn, 1); dup2(dn, 2); if (dn > 2) close(dn); }
+    unsigned char b = (unsigned char)status; if (write(detach_fd, &b, 1) != 1) {}
+    close(detach_fd); detach_fd = -1;
+}
+__attribute__((unused)) static void detach_teardown(void)
+{
+    const char *e = getenv("NAF_GPU_DETACH"); if (e && e[0] == '0') return;
+    int pf[2]; if (pipe(pf) != 0) return;
+    fflush(NULL);
+    pid_t pid = fork();
+    if (pid < 0) { close(pf[0]); close(pf[1]); return; }
+    if (pid == 0) { close(pf[0]); detach_fd = pf[1]; return; }       /* the worker: reports when it is done (detach_done) or exits (the hosts' exit handler) */
+    close(pf[1]);
+    unsigned char b = 0; ssize_t r;
+    do r = read(pf[0], &b, 1); while (r < 0);
+    if (r == 1) _exit(b);
+    int st = 0; if (waitpid(pid, &st, 0) == pid) { if (WIFEXITED(st)) _exit(WEXITSTATUS(st)); if (WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); raise(WTERMSIG(st)); } }   /* it died without a word */
+    _exit(1);
+}
+__attribute__((unused)) static void detach_done(int status) { detach_report(status); }
 #define GPU_TRY(call) do { int rc_ = (call); if (rc_) { const char *m_ = naf_gpu_last_error(gpu); size_t l_ = strlen(m_); \
     die("%s%s", m_, (l_ && m_[l_ - 1] == '\n') ? "" : "\n"); } } while (0)
 
 /* ---- devices ----------------------------------------------------------------------------------------------------------------
  * NAF_GPUS=0,1,2,...  one context per entry (an entry may repeat a device: several contexts on one GPU); without it the single
  * device NAF_GPU_DEVICE (default 0).  The first entry is also the context `gpu` of the single-device paths. */
-#include <pthread.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #define MAX_DEVS 64
@@ -130,7 +185,7 @@ static off_t fd_pwrite_pos(int fd)
 /* ---- file <-> device --------------------------------------------------------------------------------------------------------
  * Regular files go through naf_gpu_read_file / naf_gpu_write_file (several host threads, pinned staging, pread / pwrite at
  * offsets); pipes through the sequential two-chunk ring below. */
-#define IO_CHUNK ((size_t)64 << 20)
+#define IO_CHUNK ((size_t)16 << 20)
 static void *io_pin[2] = { NULL, NULL };
 static void io_open(void)
 {

@@ -13,7 +13,14 @@ static char *in_file_path = NULL, *out_file_path = NULL;
 static bool line_length_is_specified = false; static long long requested_line_length = 0;
 static FILE *OUT = NULL; static bool created_output_file = false, success = false;
 
-static void done(void) { if (!success && created_output_file && out_file_path) remove(out_file_path); if (gpu) naf_gpu_shutdown(gpu); }
+static void done(int status, void *arg)
+{
+    (void)arg;
+    if (!success && created_output_file && out_file_path) remove(out_file_path);
+    detach_report(status);                                        /* the foreground process leaves with this status now; what follows is nobody's wait */
+    if (gpu_init_started) { pthread_join(gpu_init_thread, NULL); gpu_init_started = false; }       /* (an exit while the device is still being opened) */
+    if (gpu) naf_gpu_shutdown(gpu);
+}
 static void set_out_type(OUTPUT_TYPE t) { if (out_type != UNDECIDED) die("only one output type should be specified\n"); out_type = t; }
 
 static void set_line_length(char *str)
@@ -150,6 +157,7 @@ static void *text_worker(void *arg)
         if (j->n == 1 && cap == j->total) CTX_TRY(c, naf_gpu_unnaf(c, d_arc, naf_len, &j->o, d, cap, &got));       /* everything at once: the whole-text call overlaps its side streams */
         else CTX_TRY(c, naf_gpu_unnaf_range(c, d_arc, naf_len, &j->o, b, e, d, cap, &got));
         if (got != e - b) die("can't decompress sequence\n");
+        if (j->n == 1 && getenv("NAF_GPU_CLI_TIMING")) { CTX_TRY(c, naf_gpu_synchronize(c)); phase("unnaf on the GPU (waited for: timing only)"); }
         CTX_TRY(c, naf_gpu_write_file(c, fileno(OUT), (uint64_t)j->file_at + b, d, got));
     }
     naf_gpu_free(c, d);
@@ -199,12 +207,15 @@ static void run_text(int mode, int masking_allowed)
 int main(int argc, char **argv)
 {
     prog_name = "unnaf";
-    atexit(done);
+    on_exit(done, NULL);
     parse_command_line(argc, argv);
     if (in_file_path == NULL && isatty(fileno(stdin))) { err("no input specified, use \"unnaf -h\" for help\n"); exit(0); }
     FILE *IN = in_file_path ? fopen(in_file_path, "rb") : stdin;
     if (!IN) die("can't open input file\n");
     phase("start");
+    /* every output but the few that the header alone answers needs the device: its start runs beside the reading of the archive */
+    if (!(out_type == FORMAT_NAME || out_type == PART_LIST || out_type == PART_SIZES || out_type == NUMBER_OF_SEQUENCES || out_type == TITLE || out_type == TOTAL_LENGTH)) detach_teardown();
+    if (!(out_type == FORMAT_NAME || out_type == PART_LIST || out_type == PART_SIZES || out_type == NUMBER_OF_SEQUENCES || out_type == TITLE || out_type == TOTAL_LENGTH)) gpu_open_early();
     struct stat ist;
     if (fd_is_regular(fileno(IN)) && fstat(fileno(IN), &ist) == 0 && ist.st_size > 0) {
         void *m = mmap(NULL, (size_t)ist.st_size, PROT_READ, MAP_PRIVATE, fileno(IN), 0);
@@ -310,6 +321,7 @@ int main(int argc, char **argv)
     success = true;
     /* everything is written and closed: the process ends here, without the device-side teardown (freeing gigabytes of device memory,
      * streams, the runtime's own exit handlers: 0.1 - 0.2 s that nobody waits for; NAF_GPU_SLOW_EXIT=1 runs it) */
-    { const char *se = getenv("NAF_GPU_SLOW_EXIT"); if (!(se && se[0] == '1')) { fflush(NULL); _exit(0); } }
+    fflush(NULL); detach_done(0);
+    { const char *se = getenv("NAF_GPU_SLOW_EXIT"); if (!(se && se[0] == '1')) _exit(0); }
     return 0;
 }
