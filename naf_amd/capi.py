@@ -143,6 +143,7 @@ def load():
                                                 C.POINTER(sz), C.c_char_p, sz, C.POINTER(sz), u64p, C.POINTER(EnnafReport)]
         L.naf_gpu_ennaf_stitch.argtypes = [vp, C.POINTER(StitchSeg), sz, C.c_char_p, C.POINTER(vp), vp, sz]
         L.naf_gpu_copy.argtypes = [vp, vp, vp, sz]
+        L.naf_gpu_release_scratch.argtypes = [vp]
         L.naf_gpu_get_timing_streams.argtypes = [vp, C.POINTER(C.c_float)]
         L.naf_gpu_gather_ranges.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), u64p, C.POINTER(sz), i]
         _lib = L
@@ -220,6 +221,10 @@ class Context:
 
     def reserve(self, nbytes):
         self._check(self.L.naf_gpu_reserve(self.h, nbytes))
+
+    def release_scratch(self):
+        """Give the context's scratch arena back to the device (the next call grows it again)."""
+        self._check(self.L.naf_gpu_release_scratch(self.h))
 
     def gather_ranges(self, out, parts):
         """naf_gpu_gather_ranges: parts = [(ctx, tensor, dst_offset)] -- every part is pushed into `out` (a tensor on this context's

@@ -2072,12 +2072,12 @@ static int split_error_text(naf_gpu_ctx *c, int seq_type, int kind, u32 ch, u64 
 }
 
 // where the bases go: packed codes (+ case bits when the mask is stored) for a 4-bit stream, one byte per base otherwise
-static int alloc_bases(naf_gpu_ctx *c, EnnafSplit &S)
+static int alloc_bases(naf_gpu_ctx *c, EnnafSplit &S, bool case_bits = true)
 {
     if (S.fourbit) {
         S.packed = (u8 *)arena_alloc(c, (S.T + 1) / 2 + 64);
         if (!S.packed) return NAF_GPU_ENOMEM;
-        if (S.store_mask) { S.casebits = (u64 *)arena_alloc(c, (S.T + 63) / 64 * 8 + 64); if (!S.casebits) return NAF_GPU_ENOMEM; }
+        if (S.store_mask && case_bits) { S.casebits = (u64 *)arena_alloc(c, (S.T + 63) / 64 * 8 + 64); if (!S.casebits) return NAF_GPU_ENOMEM; }
     } else { S.bases = (u8 *)arena_alloc(c, S.T + 64); if (!S.bases) return NAF_GPU_ENOMEM; }
     return 0;
 }
@@ -2261,7 +2261,9 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         S.no_case = (u32)h[6] == 0 && !(getenv("NAF_GPU_CASE_CENSUS") && getenv("NAF_GPU_CASE_CENSUS")[0] == '0');
         P.any_case = nullptr;
         const u64 n_irregular = h[4];
-        if ((rc = alloc_bases(c, S))) return rc;
+        // a whole input in which the count pass met no case bit: its mask is one run whatever the scatter pass would write -- no case bits
+        // are made at all (an eighth of a byte per base less to write; a shard's finish reads them for the census of its cut)
+        if ((rc = alloc_bases(c, S, !(allow_direct && S.no_case)))) return rc;
         s_ids = (u8 *)arena_alloc(c, n_ids + 16); s_cmt = (u8 *)arena_alloc(c, n_cmt + 16);
         rec_begin = arena_new<u64>(c, N + 1); rec_end = arena_new<u64>(c, N + 1);
         const size_t NU = 3 * 257 + 3;                                                             // histograms, longest, strict key, lead
