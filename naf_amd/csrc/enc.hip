@@ -2466,6 +2466,8 @@ static int ennaf_windows(naf_gpu_ctx *c, EnnafStreams &X, const naf_gpu_ennaf_op
     // is rare enough for an 11-bit code, which costs this build's decoder its one-level table and makes every symbol of the block a
     // two-level look-up -- the decode of a FASTQ's sequence stream took as long as that of its quality stream, twice the size
     if (o->level <= 1) { X.flags[4] |= ZENC_SHORT_CODES; X.flags[5] |= ZENC_SHORT_CODES; }
+    // ... and one tree for the frame where it fits (zstd_enc.hip: ZENC_FRAME_TREE): the quality stream, a sequence stream's blocks that are not flat, the mask
+    if (o->level <= 1) { X.flags[3] |= ZENC_FRAME_TREE; X.flags[4] |= ZENC_FRAME_TREE; X.flags[5] |= ZENC_FRAME_TREE; }
     if (o->long_log) { X.window_log[4] = o->long_log < 10 ? 10 : o->long_log > 31 ? 31 : o->long_log; X.lz[4] = 1; }
     else if (!wl && X.present[4] && X.len[4]) {
         const char *pe = getenv("NAF_GPU_PROBE");                 // "0": never look, "1": always match
@@ -2508,7 +2510,7 @@ static int encode_stream_begin(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int 
 {
     J->main = nullptr; J->d_stream = d_stream; J->len = len; J->level = level; J->flags = flags; J->tail = (tail && len > tail) ? tail : 0;
     int f1 = flags;
-    if (J->tail) f1 = ZENC_PART | ((!(flags & ZENC_PART) || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES));
+    if (J->tail) f1 = ZENC_PART | ((!(flags & ZENC_PART) || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES | ZENC_FRAME_TREE));
     if (direct && (lz || len - J->tail != (u64)nd << 15)) return ctx_fail(c, NAF_GPU_EARG, "direct blocks need a stream of whole blocks and no match finder");
     int rc = zstd_encode_begin(c, d_stream, len - J->tail, level, f1, lz, block_log, window_log, &J->main, direct, nd);
     if (rc) { zstd_encode_drop(J->main); J->main = nullptr; }
@@ -2538,7 +2540,7 @@ static int encode_stream(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level,
     }
     if (!tail || len <= tail) return zstd_encode(c, d_stream, len, level, dst, cap, clen, flags, lz, block_log, window_log);
     const bool part = (flags & ZENC_PART) != 0;
-    const int f1 = ZENC_PART | ((!part || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES));
+    const int f1 = ZENC_PART | ((!part || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES | ZENC_FRAME_TREE));
     const int f2 = ZENC_PART | ((!part || (flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0);
     size_t a = 0, b = 0;
     int rc = zstd_encode(c, d_stream, len - tail, level, dst, cap, &a, f1, lz, block_log, window_log); if (rc) return rc;

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(con
     }
     if (fast) {
         const u32 perq = (bn + 3) / 4;
-        ZEncPlan p; p.n = bn; p.kind = ZK_RAW; p.csize = 3 + bn; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0;
+        ZEncPlan p; p.n = bn; p.kind = ZK_RAW; p.csize = 3 + bn; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0; p.frame = 0; p.pad2 = 0;
         for (u32 k = 0; k < 4; k++) p.ssz[k] = ((k < 3 ? perq : bn - 3 * perq) * 4 + 8) >> 3;
         zenc_plan_finish(p, bn, 4, f16.tb, min_gain);
         fast = p.kind == ZK_HUF;
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(con
 
 // blk_len == nullptr: block b is the b-th piece of the even split of src[0..n).  Otherwise block b is src[b*slot .. b*slot + blk_len[b])
 // (the literals the LZ stage left of block b).
-__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse, u32 min_gain, u32 maxbits, u32 prefer_flat, const u8 *done, u8 *wt_defer)
+__global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse, u32 min_gain, u32 maxbits, u32 prefer_flat, const u8 *done, u8 *wt_defer,
+                                                    u32 *fhist = nullptr, const ZEncPlan *fplan = nullptr, const u16 *fcodes = nullptr)
 {
     // ZENC_HCOPIES copies of the 4 quarter histograms (copy = lane % copies): few distinct symbols (packed ACGT has 16) would
     // otherwise serialise every LDS atomic of a wave on the same handful of addresses
@@ -204,8 +205,30 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
     for (u32 w = 0; w < (threadIdx.x >> 6); w++) myidx += wave_n[w];
     if (mine) plist[myidx] = (u16)sym;
     __syncthreads();
-    ZEncPlan p; p.n = bn; p.kind = ZK_RAW; p.csize = 3 + bn; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0;
+    ZEncPlan p; p.n = bn; p.kind = ZK_RAW; p.csize = 3 + bn; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0; p.frame = 0; p.pad2 = 0;
     p.ssz[0] = p.ssz[1] = p.ssz[2] = p.ssz[3] = 0;
+    // ---- the FRAME's tree (zstd_encode_begin: ZENC_FRAME_TREE).  The sample launch leaves the sum of its blocks' histograms; one code is
+    // made of it, and a block whose symbols that code covers, at a cost within 4 % (+ 8 bytes) of the block's own entropy, is coded with
+    // it: no code construction, no tree description (k_zenc_frame_fix decides which of these blocks carry the tree: the first one, and
+    // those behind a block with a tree of its own) -- the serial steps of a plan are what the planner's time is, and the decoder meets
+    // one tree instead of one per block.
+    if (fhist && sample_stride && mine) atomicAdd(&fhist[sym], mine);
+    if (fcodes && !sample_stride && fplan->kind == ZK_HUF && bn >= 64 && distinct >= 2) {
+        __shared__ u64 fred[4];
+        const u32 fl = (u32)fcodes[sym] >> 12;
+        if (__syncthreads_and(mine == 0 || fl != 0)) {
+            const float ent = mine ? (float)mine * __log2f((float)bn / (float)mine) : 0.f;
+            u64 both; wg_scan_inclusive<u64, OpAdd>(((u64)(mine * fl) << 32) | (u64)(u32)(ent + 0.5f), &both, fred);
+            const u64 fbits = both >> 32, ebits = both & 0xFFFFFFFFull;
+            if (fbits * 100 <= ebits * 104 + 6400) {
+                for (u32 k = 0; k < 4; k++) { u64 bits; wg_scan_inclusive<u64, OpAdd>((u64)hist[256 * k + sym] * fl, &bits, fred); p.ssz[k] = (u32)((bits + 1 + 7) / 8); }
+                zenc_plan_finish(p, bn, fplan->log, 0, min_gain);
+                if (p.kind == ZK_HUF) { p.frame = 1; codes[(u64)b * 256 + sym] = fcodes[sym]; }
+                if (threadIdx.x == 0) { plan[b] = p; if (csize) csize[b] = p.csize; }
+                return;
+            }
+        }
+    }
     bool huf = false, defer = false;
     if (bn && distinct == 1) { p.kind = ZK_RLE; p.csize = 4; }
     // A mask block that is one unit repeated but for a few bytes (the end of an upper-case genome's mask: 0xFF units, then the rest of the
@@ -416,6 +439,41 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
     }
 }
 
+// A block of ZENC_FRAME_BLOCK bytes whose histogram is the sampled blocks' (every symbol that occurred at least once): the planner's own
+// routines then make the frame's code lengths, codes and tree description of it (one more k_zenc_plan launch of one workgroup).
+#define ZENC_FRAME_BLOCK 32768u
+__global__ __launch_bounds__(256) void k_zenc_frame_block(const u32 *fhist, u8 *blockbuf, u32 *blen)
+{
+    __shared__ u64 red[4];
+    const u32 sym = threadIdx.x, h = fhist[sym];
+    u64 tot; wg_scan_inclusive<u64, OpAdd>((u64)h, &tot, red);
+    u32 cnt = 0;
+    if (h && tot) { cnt = (u32)(((u64)h * (ZENC_FRAME_BLOCK - 256)) / tot); if (!cnt) cnt = 1; }
+    u64 all; const u64 inc = wg_scan_inclusive<u64, OpAdd>((u64)cnt, &all, red);
+    u8 *o = blockbuf + (inc - cnt);
+    for (u32 k = 0; k < cnt; k++) o[k] = (u8)sym;
+    if (sym == 0) *blen = (u32)all;
+}
+// Which blocks of the frame's code carry the tree.  v[b] = 2 b + 1 for a Huffman block with a tree of its own, 2 b for one of the frame's
+// code, -1 for the others, running maximum taken: a block of the frame's code is treeless when the Huffman block in front of it is one as well.
+__global__ void k_zenc_frame_class(const ZEncPlan *plan, u32 nblk, i32 *v)
+{
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nblk) v[b] = plan[b].kind == ZK_HUF ? (i32)(2 * b + (plan[b].frame ? 0u : 1u)) : -1;
+}
+__global__ void k_zenc_frame_fix(ZEncPlan *plan, u32 nblk, const i32 *v, const ZEncPlan *fplan, const u8 *ftree, u8 *trees, u64 *csize)
+{
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk || plan[b].kind != ZK_HUF || !plan[b].frame) return;
+    const i32 prev = b ? v[b - 1] : -1;
+    if (prev >= 0 && !(prev & 1)) return;                          // the tree in force is the frame's: treeless, as planned
+    ZEncPlan p = plan[b];
+    const u32 tb = fplan->tree_bytes;
+    zenc_plan_force(p, tb);
+    for (u32 k = 0; k < tb; k++) trees[(u64)b * ZENC_TREE_SLOT + k] = ftree[k];
+    plan[b] = p; if (csize) csize[b] = p.csize;
+}
+
 // Tree descriptions k_zenc_plan left pending (plan.pad bit 7): one LANE per block, 64 blocks per wavefront, the weight coder's workspace
 // of every lane in LDS at an odd word stride.  Finishes the plan (Huffman or Raw, sizes) exactly as k_zenc_plan would have.
 struct ZTreeLane { FseWS fse; u8 tmp[160]; u8 w[256]; u32 odd; };
@@ -434,7 +492,7 @@ __global__ __launch_bounds__(64) void k_zenc_tree(u32 nblk, ZEncPlan *plan, u8 *
     for (u32 k = 0; k < 256; k += 4) *(u32 *)(L.w + k) = *(const u32 *)(wt_defer + (u64)b * 256 + k);
     u8 *tree = trees + (u64)b * ZENC_TREE_SLOT;
     const u32 tb = huf_write_tree_w(tree, L.w, lastw, L.tmp, L.fse, try_fse != 0);
-    p.kind = ZK_RAW; p.csize = 3 + p.n; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0;
+    p.kind = ZK_RAW; p.csize = 3 + p.n; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0; p.frame = 0; p.pad2 = 0;
     if (tb) { zenc_plan_finish(p, p.n, log, tb, min_gain); if (p.kind == ZK_HUF && flat16) p.pad = 1; }
     plan[b] = p;
     if (csize) csize[b] = p.csize;
@@ -1159,6 +1217,7 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     J->src = d_src; J->n = n;
     const bool part = (with_magic & ZENC_PART) != 0, part_first = (with_magic & ZENC_PART_FIRST) != 0, part_last = (with_magic & ZENC_PART_LAST) != 0;
     const u32 min_gain = (with_magic & ZENC_PREFER_RAW) ? 32u : 0u;
+    const bool frame_tree_ok = level <= 1 && (with_magic & ZENC_FRAME_TREE) != 0;
     // (the same streams -- the mask -- keep their codes to 9 bits: this build's decoder then walks them with its single-level table)
     u32 maxbits = (with_magic & ZENC_PREFER_RAW) ? 9u : (with_magic & ZENC_SHORT_CODES) ? 7u : (u32)ZENC_HUF_MAXBITS;
     { const char *mb = getenv("NAF_GPU_HUF_MAXBITS"); if (mb && atoi(mb) >= 7 && atoi(mb) <= (int)ZENC_HUF_MAXBITS && (with_magic & ZENC_SHORT_CODES)) maxbits = (u32)atoi(mb); }
@@ -1166,7 +1225,7 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     // (NAF_GPU_PREFER_FLAT=0: never; =d: the threshold 1/d)
     u32 prefer_flat = (with_magic & ZENC_PREFER_FLAT) ? 16u : 0u;
     if (prefer_flat) { const char *pf = getenv("NAF_GPU_PREFER_FLAT"); if (pf && pf[0]) prefer_flat = (u32)atoi(pf); }
-    with_magic &= ~(ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES);
+    with_magic &= ~(ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES | ZENC_FRAME_TREE);
     if (part) with_magic = 0;
     if (part && n == 0 && !part_last) {
         J->empty = 1; J->hdr = part_first ? 2 : 0; J->frame_wlog = (u32)(window_log >= 10 ? window_log : 19);
@@ -1221,12 +1280,35 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
         done = (u8 *)arena_alloc(c, nblk); if (!done) return NAF_GPU_ENOMEM;
         LAUNCH(c, "zenc_flat_scan", k_zenc_flat_scan, cdiv(nblk, ZENC_FLATSCAN_WAVES), 64 * ZENC_FLATSCAN_WAVES, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, done, min_gain, prefer_flat, zenc_flat16(), direct);
     }
-    if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done, (u8 *)nullptr);
+    // the frame's tree (k_zenc_plan): level 1 without the match finder, frames of enough blocks to sample; NAF_GPU_FRAME_TREE=0: a tree per block
+    const char *eft = getenv("NAF_GPU_FRAME_TREE");
+    const bool frame_tree = frame_tree_ok && cache && !use_lz && !direct && !(eft && eft[0] == '0');
+    u32 *fhist = nullptr; ZEncPlan *fplan = nullptr; u16 *fcodes = nullptr; u8 *ftree = nullptr;
+    if (frame_tree) {
+        fhist = arena_new<u32>(c, 256 + 1); fplan = arena_new<ZEncPlan>(c, 1); fcodes = arena_new<u16>(c, 256); ftree = (u8 *)arena_alloc(c, ZENC_TREE_SLOT);
+        if (!fhist || !fplan || !fcodes || !ftree) return NAF_GPU_ENOMEM;
+        HIP_TRY(c, hipMemsetAsync(fhist, 0, 257 * 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(fplan, 0, sizeof(ZEncPlan), c->stream));
+        HIP_TRY(c, hipMemsetAsync(fcodes, 0, 512, c->stream));
+    }
+    if (cache) LAUNCH(c, "zenc_plan_sample", k_zenc_plan, ZENC_CACHE_ENTRIES, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, sample_stride, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done, (u8 *)nullptr, fhist, (const ZEncPlan *)nullptr, (const u16 *)nullptr);
+    if (frame_tree) {
+        u8 *fblock = (u8 *)arena_alloc(c, ZENC_FRAME_BLOCK + 64); if (!fblock) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zenc_frame_block", k_zenc_frame_block, 1, 256, 0, (const u32 *)fhist, fblock, fhist + 256);
+        // (no flat preference, no deferred description: the code of the summed histogram as it is, with its tree description)
+        LAUNCH(c, "zenc_plan_frame", k_zenc_plan, 1, 256, 0, (const u8 *)fblock, (u64)0, 1u, fplan, fcodes, ftree, (u64 *)nullptr, (const u32 *)(fhist + 256), (u64)0, (ZTreeCache *)nullptr, 0u, try_fse, 0u, maxbits, 0u, (const u8 *)nullptr, (u8 *)nullptr, (u32 *)nullptr, (const ZEncPlan *)nullptr, (const u16 *)nullptr);
+    }
     // (frames of a few blocks keep the tree with the planner: nothing to gain from a second launch)
     const char *td = getenv("NAF_GPU_TREE_DEFER");
     u8 *wt_defer = (nblk >= 256 && !(td && td[0] == '0')) ? (u8 *)arena_alloc(c, (size_t)nblk * 256) : nullptr;
-    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done, wt_defer);
+    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done, wt_defer, (u32 *)nullptr, (const ZEncPlan *)fplan, (const u16 *)fcodes);
     if (wt_defer) LAUNCH(c, "zenc_tree", k_zenc_tree, cdiv(nblk, 64), 64, 64 * sizeof(ZTreeLane), nblk, plan, trees, offs, (const u8 *)wt_defer, min_gain);
+    if (frame_tree) {
+        i32 *fv = arena_new<i32>(c, (size_t)nblk + 1); if (!fv) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zenc_frame_class", k_zenc_frame_class, cdiv(nblk, 256), 256, 0, (const ZEncPlan *)plan, nblk, fv);
+        int rcs = scan_inclusive_max_i32(c, fv, nblk); if (rcs) return rcs;
+        LAUNCH(c, "zenc_frame_fix", k_zenc_frame_fix, cdiv(nblk, 256), 256, 0, plan, nblk, (const i32 *)fv, (const ZEncPlan *)fplan, (const u8 *)ftree, trees, offs);
+    }
     ZWriteLz &L = J->L;
     L.not_last = part && !part_last;
     if (use_lz && n >= 64) {

@@ -326,13 +326,15 @@ struct ZEncPlan {
     u16 tree_bytes;     // Huffman tree description size
     u8  kind, log, lhdr;// ZK_*, table log, literals-section header size (3/4/5)
     u8  pad;
+    u8  frame;          // 1: coded with the FRAME's code (zstd_enc.hip: frame tree); tree_bytes == 0 then means a treeless literals section
+    u8  pad2;
 };
 
 NAF_HD void zenc_plan_finish(ZEncPlan &p, u32 n, u32 log, u32 tb, u32 min_gain = 0);
 // hist[4][256] = byte counts of the four stream quarters of the block.  Fills plan, len[256], tree[<=160].
 NAF_HD void zenc_plan_block(const u32 *hist, u32 n, ZEncPlan &p, u8 *len, u8 *tree)
 {
-    p.n = n; p.kind = ZK_RAW; p.csize = 3 + n; p.log = 0; p.tree_bytes = 0; p.lhdr = 0;
+    p.n = n; p.kind = ZK_RAW; p.csize = 3 + n; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.frame = 0; p.pad2 = 0;
     if (n == 0) return;
     u32 tot[256]; u32 distinct = 0, only = 0;
     for (u32 s = 0; s < 256; s++) { tot[s] = hist[s] + hist[256 + s] + hist[512 + s] + hist[768 + s]; if (tot[s]) { distinct++; only = s; } }
@@ -359,14 +361,25 @@ NAF_HD void zenc_plan_finish(ZEncPlan &p, u32 n, u32 log, u32 tb, u32 min_gain)
     p.kind = ZK_HUF; p.csize = csize; p.log = (u8)log; p.tree_bytes = (u16)tb; p.lhdr = (u8)lhdr;
 }
 
+// The plan of a block coded with the frame's code once it is known whether the block has to carry the tree (tb bytes) or not (0):
+// Huffman whatever it costs -- its neighbours' sections were planned on this block being a Huffman block.
+NAF_HD void zenc_plan_force(ZEncPlan &p, u32 tb)
+{
+    u32 body = tb + 6;
+    for (u32 k = 0; k < 4; k++) body += p.ssz[k];
+    const u32 lhdr = (p.n < 1024 && body < 1024) ? 3 : ((p.n < 16384 && body < 16384) ? 4 : 5);
+    p.kind = ZK_HUF; p.csize = 3 + lhdr + body + 1; p.tree_bytes = (u16)tb; p.lhdr = (u8)lhdr;
+}
+
 // Huffman literals section header + tree + jump table at out[0..); returns the offset of the first stream.
 // body = tree + 6 + streams (Compressed_Size), p.n = Regenerated_Size.
 NAF_HD u32 zenc_write_huf_lit_prefix(u8 *out, const ZEncPlan &p, const u8 *tree)
 {
     u32 body = p.csize - 3 - p.lhdr - 1, pos = 0;
-    if (p.lhdr == 3) { u32 h = 2u | (1u << 2) | (p.n << 4) | (body << 14); out[pos] = (u8)h; out[pos + 1] = (u8)(h >> 8); out[pos + 2] = (u8)(h >> 16); }
-    else if (p.lhdr == 4) { u32 h = 2u | (2u << 2) | (p.n << 4) | (body << 18); st32(out + pos, h); }
-    else { u64 h = 2u | (3u << 2) | ((u64)p.n << 4) | ((u64)body << 22); st32(out + pos, (u32)h); out[pos + 4] = (u8)(h >> 32); }
+    const u32 ty = (p.frame && p.tree_bytes == 0) ? 3u : 2u;     // Treeless_Literals_Block (3.1.1.3.1.1): the tree of the last block that carried one
+    if (p.lhdr == 3) { u32 h = ty | (1u << 2) | (p.n << 4) | (body << 14); out[pos] = (u8)h; out[pos + 1] = (u8)(h >> 8); out[pos + 2] = (u8)(h >> 16); }
+    else if (p.lhdr == 4) { u32 h = ty | (2u << 2) | (p.n << 4) | (body << 18); st32(out + pos, h); }
+    else { u64 h = ty | (3u << 2) | ((u64)p.n << 4) | ((u64)body << 22); st32(out + pos, (u32)h); out[pos + 4] = (u8)(h >> 32); }
     pos += p.lhdr;
     for (u32 i = 0; i < p.tree_bytes; i++) out[pos + i] = tree[i];
     pos += p.tree_bytes;
