@@ -18,7 +18,7 @@
 #include <thread>
 
 // 16 bytes of output text that nothing on the device reads again: the nontemporal hint keeps them from displacing the compressed stream
-// and the tables in L2 (k_emit_tile_flat: 3.08 -> 2.93 ms per 10 GB; NAF_GPU_EMIT_NT=0: plain stores)
+// and the tables in L2 (k_emit_tile_flat: 3.08 -> 2.93 ms per 10 GB)
 __device__ __forceinline__ void st_text16(u8 *p, const uint4 &v, int nt)
 {
     if (nt) {
@@ -1362,7 +1362,7 @@ static int unnaf_prepare(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const 
     const char *tab = h.seq_type == NAF_SEQ_RNA ? "-UGKCYSBAWRDMHVN" : "-TGKCYSBAWRDMHVN";   // unnaf.c:13,369
     memcpy(P.lut, tab, 16);
     const char *fs = getenv("NAF_GPU_FORCE_SLOW"); P.force_slow = fs && fs[0] == '1';
-    { const char *nt = getenv("NAF_GPU_EMIT_NT"); P.nt_store = !(nt && nt[0] == '0'); }
+    P.nt_store = 1;
     pl.need_qual = P.mode == EM_FASTQ;
 
     return 0;
@@ -1627,10 +1627,9 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     auto payload = [&]() -> int { int r = payload_seq(); if (r) return r; return pl.need_qual ? payload_qual(c) : 0; };
     const char *fuse = getenv("NAF_GPU_FUSE");
     const bool fuse_on = fuse && fuse[0] == '1';
-    const char *ser = getenv("NAF_GPU_SERIAL_SECTIONS");
     // Whole-text call: the side streams (a chain of small launches and read-backs, mostly latency) are prepared by a second
     // host thread on the side context's stream while this thread decodes the payload; they meet before the emit.
-    const bool par = whole && !size_only && pl.P.mode != -1 && c->side && !fuse_on && !(ser && ser[0] == '1');
+    const bool par = whole && !size_only && pl.P.mode != -1 && c->side && !fuse_on;
     bool payload_done = false;
     ZSplit split; split.parts = 0; split.done = 0; split.status = nullptr;
     // A whole 4-bit text with long records goes through the tile kernels: if its sequence stream turns out to be a flat frame
@@ -1813,11 +1812,9 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                 HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX], 0));         // the index
             }
             if (zflat.ready) {
-                static const u32 tpw = (getenv("NAF_GPU_FLAT_TPW") && atoi(getenv("NAF_GPU_FLAT_TPW")) == 8) ? 8u : 4u;     // tiles per workgroup (the records have FLAT_TPW spare entries)
-                const u32 nwg = cdiv(ntiles, tpw), chunk = (nwg + 7) / 8;
-                static const bool xcd = !(getenv("NAF_GPU_XCD") && getenv("NAF_GPU_XCD")[0] == '0');
-                if (tpw == 8) LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat<8>, xcd ? chunk * 8 : nwg, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, xcd ? chunk : 0u);
-                else LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat<4>, xcd ? chunk * 8 : nwg, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, xcd ? chunk : 0u);
+                // four tiles per workgroup (eight measured slower: DESIGN.md section 8), workgroups dealt to the XCDs in contiguous chunks
+                const u32 nwg = cdiv(ntiles, 4u), chunk = (nwg + 7) / 8;
+                LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat<4>, chunk * 8, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, chunk);
                 if (flat_job) {                                                               // (queued behind the flat emit: the job waits for its tables on the host)
                     if ((rc = zstd_flat_later(c, &zflat))) return rc;
                     if (zflat.aux) xc = zflat.aux;

@@ -2425,7 +2425,7 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
             // few hundred blocks whose Huffman streams the decoder walks serially: 8 KiB blocks (2 KiB streams) cut that latency to a
             // quarter.  Very long runs give strings of 255s (constant blocks) and one last block with the remainder in it -- whose four
             // streams are one lane's work each on either side: small blocks there too.
-            { const char *mb = getenv("NAF_GPU_MASK_BLOCK_LOG"); mask_block_log = mb && atoi(mb) >= 10 && atoi(mb) <= 15 ? atoi(mb) : 13; }
+            mask_block_log = 13;
             n_mask = nu;
         }
     }
@@ -2475,10 +2475,7 @@ static int ennaf_windows(naf_gpu_ctx *c, EnnafStreams &X, const naf_gpu_ennaf_op
         if (pe && pe[0] == '1') share = 1024;
         else if (!(pe && pe[0] == '0') && defer) { *defer = true; return 0; }
         else if (!(pe && pe[0] == '0')) {
-            struct timespec t0, t1, t2; const bool dbg = getenv("NAF_GPU_DEBUG_PROBE") != nullptr;
-            if (dbg) { clock_gettime(CLOCK_MONOTONIC, &t0); hipStreamSynchronize(c->stream); clock_gettime(CLOCK_MONOTONIC, &t1); }
             int rc = zenc_repeat_probe(c, X.ptr[4], X.len[4], &share); if (rc) return rc;
-            if (dbg) { clock_gettime(CLOCK_MONOTONIC, &t2); fprintf(stderr, "[probe] drain %.3f ms, probe %.3f ms, share %u/1024\n", (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) * 1e-6, share); }
         }
         ennaf_probe_verdict(X, share);
     }

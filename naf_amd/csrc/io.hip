@@ -109,11 +109,10 @@ extern "C" int naf_gpu_write_file(naf_gpu_ctx *c, int fd, uint64_t file_off, con
     if (!len) return 0;
     IoPool *P = io_pool(c);
     const u64 nchunks = (len + IO_CHUNK - 1) / IO_CHUNK;
-    // ONE writer unless told otherwise (NAF_GPU_IO_WRITE_THREADS): pwrite() into a new tmpfs file runs 7.5 GB/s from one thread and
+    // ONE writer: pwrite() into a new tmpfs file runs 7.5 GB/s from one thread and
     // 4.7 / 3.8 GB/s from two / eight (the file's pages are added under one lock: tools/io_probe, profiles/r03_io_probe.txt), while the
     // link delivers 50 GB/s to a single stream -- the download of chunk i + 1 runs beside the write of chunk i either way
-    static const int wt = [] { const char *e = getenv("NAF_GPU_IO_WRITE_THREADS"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
-    int T = (int)(nchunks < (u64)P->lanes ? nchunks : (u64)P->lanes); if (T > wt) T = wt;
+    const int T = 1;
     std::atomic<int> bad(0);
     HIP_TRY(c, hipSetDevice(c->device));
     if (!lanes_ready(P, T)) return ctx_fail(c, NAF_GPU_ENOMEM, "can't allocate pinned staging buffers");

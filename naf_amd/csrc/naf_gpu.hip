@@ -271,8 +271,7 @@ __global__ void k_small_to_host(u8 *h, const u8 *d, u32 n) { if (threadIdx.x < n
 
 int ctx_readback(naf_gpu_ctx *c, void *h_dst, const void *d_src, size_t bytes)
 {
-    static const bool by_kernel = getenv("NAF_GPU_READBACK_COPY") == nullptr;
-    if (by_kernel && bytes && bytes <= 256) {
+    if (bytes && bytes <= 256) {
         hipLaunchKernelGGL(k_small_to_host, dim3(1), dim3(256), 0, c->stream, (u8 *)c->h_stage, (const u8 *)d_src, (u32)bytes);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));

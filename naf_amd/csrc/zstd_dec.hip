@@ -2011,11 +2011,9 @@ __global__ __launch_bounds__(64) void k_small_frames(SmallJobs J, const FseE *pr
 // also words the error).
 int zstd_small_batch(naf_gpu_ctx *c, int n, const u8 *const *src, const size_t *len, u8 *const *dst, const size_t *cap, bool *ok)
 {
-    const char *sm = getenv("NAF_GPU_SMALL");
     SmallJobs J; memset(&J, 0, sizeof J); int m = 0, map[4];
     for (int k = 0; k < n && k < 4; k++) {
         ok[k] = false;
-        if (sm && sm[0] == '0') continue;
         if (len[k] == 0 || len[k] > SMALL_SRC || cap[k] > SMALL_OUT) continue;
         J.src[m] = src[k]; J.len[m] = (u32)len[k]; J.dst[m] = dst[k]; J.cap[m] = (u32)cap[k]; map[m++] = k;
     }
@@ -2087,8 +2085,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
 {
     int rc;
     // small frames (side streams of archives with few records): one launch, one read-back
-    const char *sm = getenv("NAF_GPU_SMALL");                            // "0": never (cross-check)
-    if (!rg && !fuse && src_len && src_len <= SMALL_SRC && dst_cap <= SMALL_OUT && !(sm && sm[0] == '0')) {
+    if (!rg && !fuse && src_len && src_len <= SMALL_SRC && dst_cap <= SMALL_OUT) {
         u32 *d_res = arena_new<u32>(c, 4);
         if (!d_res) return NAF_GPU_ENOMEM;
         LAUNCH(c, "zstd_small_frame", k_small_frame, 1, 64, 0, d_src, (u32)src_len, d_dst, (u32)dst_cap, (const FseE *)c->d_predef, d_res);
@@ -2487,7 +2484,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         if (b_count && fuse) LAUNCH(c, "zstd_huf_fused_emit", (k_huf_literals<true>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 512,
                d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, 0u, (const u8 *)nullptr);
         else if (b_count) {
-            const u32 huf_lds = slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512 + (getenv("NAF_GPU_PADLDS") ? atoi(getenv("NAF_GPU_PADLDS")) : 0);
+            const u32 huf_lds = slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512;
             // blocks whose tree is flat go to k_flat_literals; the serial kernel is not launched when that is all of them
             const u32 flat_on = (hs.n_flat && !always_table) ? 1u : 0u;
             const bool serial_needed = !flat_on || hs.n_flat < hs.n_huf_built;

@@ -1220,7 +1220,6 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     const bool frame_tree_ok = level <= 1 && (with_magic & ZENC_FRAME_TREE) != 0;
     // (the same streams -- the mask -- keep their codes to 9 bits: this build's decoder then walks them with its single-level table)
     u32 maxbits = (with_magic & ZENC_PREFER_RAW) ? 9u : (with_magic & ZENC_SHORT_CODES) ? 7u : (u32)ZENC_HUF_MAXBITS;
-    { const char *mb = getenv("NAF_GPU_HUF_MAXBITS"); if (mb && atoi(mb) >= 7 && atoi(mb) <= (int)ZENC_HUF_MAXBITS && (with_magic & ZENC_SHORT_CODES)) maxbits = (u32)atoi(mb); }
     // ZENC_PREFER_FLAT: blocks of 2^k distinct symbols take k-bit codes unless Huffman coding saves a sixteenth of the block
     // (NAF_GPU_PREFER_FLAT=0: never; =d: the threshold 1/d)
     u32 prefer_flat = (with_magic & ZENC_PREFER_FLAT) ? 16u : 0u;
@@ -1242,14 +1241,14 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     // LZ-coded streams: 8 KiB blocks.  The decoder decodes and executes the sequences of a block serially -- a lane, then a wavefront per
     // block whose LDS buffer is the block's size -- so smaller blocks are more lanes, more workgroups per CU and shorter chains; matches in
     // ids / names / lengths are a few dozen bytes back anyway (a FASTQ's read names: the archive is no larger than with 16 KiB blocks).
-    if (use_lz && !e) { block_log = 13; const char *lb = getenv("NAF_GPU_LZ_BLOCK_LOG"); if (lb && atoi(lb) >= 10 && atoi(lb) <= 15) block_log = (u32)atoi(lb); }
+    if (use_lz && !e) block_log = 13;
     if (use_lz && block_log > 15) block_log = 15;                // LZ lengths and distances are kept in 16 bits
     // cross-block matching (window_log >= 10; the host maps level / --long to it): 64 KiB blocks -- fewer block and table headers,
     // and a repeat is cut less often; lengths still fit 16 bits (k_lzx_parse clamps a match at 65535)
     const bool lzx = use_lz && window_log >= 10 && n >= 64;
     if (window_log > 31) window_log = 31;
     if (lzx) {
-        block_log = 16; const char *lb = getenv("NAF_GPU_LZX_BLOCK_LOG"); if (lb && atoi(lb) >= 12 && atoi(lb) <= 16) block_log = (u32)atoi(lb);
+        block_log = 16;
         if (block_log > (u32)window_log) block_log = (u32)window_log;          // Block_Maximum_Size is the smaller of Window_Size and 128 KiB (3.1.1.2.4)
     }
     // The window announced in the frame header follows from the OPTIONS alone, not from this part's size: the header is written by the
@@ -1342,8 +1341,8 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
             LAUNCH(c, "zenc_lz_seqenc", k_lzx_seqenc, nblk, 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
         } else {
             // the table's size is LDS a wavefront holds for the whole block: what bounds the blocks in flight per CU -- and what is left
-            // of a CU for the kernels of the other streams (NAF_GPU_LZ_HASH_LOG, 9 .. 12)
-            u32 hash_log = LZ_HASH_LOG; { const char *hl = getenv("NAF_GPU_LZ_HASH_LOG"); if (hl && atoi(hl) >= 9 && atoi(hl) <= 12) hash_log = (u32)atoi(hl); }
+            // of a CU for the kernels of the other streams (2^11 and 2^10 entries measured: DESIGN.md section 8)
+            const u32 hash_log = LZ_HASH_LOG;
             LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << hash_log), d_src, (u64)n, nblk, B, lz_buf, hash_log);
             LAUNCH(c, "zenc_lz_seqenc", k_lz_seqenc, cdiv(nblk, 64), 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
         }
@@ -1388,9 +1387,8 @@ static int zenc_finish(naf_gpu_ctx *c, ZencJob *J, u8 *d_dst, size_t cap, size_t
     }
     if (hdr) LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, J->with_magic, J->frame_wlog);
     {
-        // few blocks of general codes (a frame of direct blocks, a short frame): a wavefront per stream for those (NAF_GPU_WRITE_WAVE=0: never)
-        const char *ww = getenv("NAF_GPU_WRITE_WAVE");
-        J->L.wave_general = (!J->L.mode && J->block_bytes <= 32768u && (J->direct || nblk <= 2048u) && !(ww && ww[0] == '0')) ? 1u : 0u;
+        // few blocks of general codes (a frame of direct blocks, a short frame): a wavefront per stream for those
+        J->L.wave_general = (!J->L.mode && J->block_bytes <= 32768u && (J->direct || nblk <= 2048u)) ? 1u : 0u;
     }
     LAUNCH(c, "zenc_write", k_zenc_write, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, J->src, (u64)J->n, nblk, (const ZEncPlan *)J->plan, (const u16 *)J->codes, (const u8 *)J->trees,
            (const u64 *)J->offs, d_dst, hdr, J->L);

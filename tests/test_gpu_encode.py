@@ -440,6 +440,41 @@ def test_ennaf_fastq_regular_tiles_by_lines(gpu, oracle, monkeypatch, capfd):
             assert host(general) == mine, (rl, dmg)
 
 
+def test_frame_tree_of_the_quality_stream(gpu, oracle, monkeypatch):
+    """ZENC_FRAME_TREE (zstd_enc.hip): the quality and sequence frames of a FASTQ of a few hundred MB carry one Huffman code for nearly
+    all of their blocks -- treeless literals sections behind the block that holds the tree; a block with a byte the code does not
+    cover keeps a tree of its own and the block behind it carries the frame's again.  The frames decode under the from-spec oracle,
+    this build's decoder and the real reference; against NAF_GPU_FRAME_TREE=0 (a tree per block) the archive is within half a per
+    cent and decodes to the same text."""
+    import torch
+    from naf_amd import synth, capi
+    fq = synth.fastq_reads_device(320_000_000, seed=11, device="cuda")
+    # a few reads with quality bytes the sampled blocks will not have met, far apart: their blocks are not the frame's
+    t = fq.clone()
+    nl = (t[:200_000_000] == 10).nonzero().flatten()
+    for k in (40_001, 200_003, 600_001):
+        q0 = int(nl[4 * k + 2].item()) + 1                       # first quality byte of read k
+        t[q0 + 3] = 0x7E; t[q0 + 5] = 0x7D
+    monkeypatch.setenv("NAF_GPU_FRAME_TREE", "1")
+    a1, rep1 = gpu.ennaf(t)
+    monkeypatch.setenv("NAF_GPU_FRAME_TREE", "0")
+    a0, rep0 = gpu.ennaf(t)
+    monkeypatch.delenv("NAF_GPU_FRAME_TREE")
+    assert abs(int(a1.numel()) - int(a0.numel())) < 0.005 * int(a0.numel())
+    m1 = host(a1); h = oracle.parse_naf(m1)
+    fi = oracle.zstd_frame_info(h.frame(m1, 5))                 # (the quality frame: 4.4 K blocks; the sequence frame of this text is too short to be sampled)
+    assert fi.lit_treeless > 0.9 * fi.n_compressed, (fi.lit_treeless, fi.lit_huf, fi.n_compressed)
+    assert 4 <= fi.lit_huf <= 64                                # the frame's tree, the three odd blocks' own, the frame's again behind each of them
+    back1 = gpu.unnaf(a1, capi.OUT_FASTQ); back0 = gpu.unnaf(a0, capi.OUT_FASTQ)
+    assert torch.equal(back1, back0) and back1.numel() == t.numel()
+    x, y = back1, t
+    assert bool(((x == y) | ((x ^ 32) == y)).all())
+    sp_q = oracle.zstd_decompress(h.frame(m1, 5), int(h.orig[5]) + 16)
+    assert len(sp_q) == int(h.orig[5])
+    if oracle.have_ref():
+        assert oracle.ref_unnaf(m1) == host(back1)
+
+
 def test_single_record_of_more_than_2_32_bases(gpu, oracle):
     """One record of 4.4 G bases: its length takes a 0xFFFFFFFF continuation unit (encoders.c:72-95), base indices and text offsets
     inside the record pass 2^32, and the mask run is 17 million units of 255.  Round trip on the device, the lengths stream
