@@ -195,8 +195,19 @@ def cpu_baseline(text_dev, size_bytes, ctx=None, full_ref_archive=True, e2e_byte
                 rc = subprocess.call(cmd, env=env, stderr=subprocess.DEVNULL)
                 return round(time.perf_counter() - t0, 3) if rc == 0 else None
             res = {"text_bytes": cut2, "unit": "s, file -> file on tmpfs"}
-            res["ennaf"] = timed([os.path.join(BIN, "ennaf"), P("e.fa"), "-o", P("e.naf")])
-            res["unnaf"] = timed([os.path.join(BIN, "unnaf"), P("e.naf"), "-o", P("e.out")])
+            # each CLI twice, into a new file both times; the figure is the faster run, both are listed (the first process on a box that has
+            # just finished other work pays for a cold driver: 0.2 - 0.4 s more in "GPU init")
+            def twice(cmd, out):
+                ts = []
+                for _ in range(2):
+                    if os.path.exists(out):
+                        os.remove(out)
+                    ts.append(timed(cmd))
+                return ts
+            ts = twice([os.path.join(BIN, "ennaf"), P("e.fa"), "-o", P("e.naf")], P("e.naf"))
+            res["ennaf"] = min(t for t in ts if t is not None) if any(t is not None for t in ts) else None; res["ennaf_runs"] = ts
+            ts = twice([os.path.join(BIN, "unnaf"), P("e.naf"), "-o", P("e.out")], P("e.out"))
+            res["unnaf"] = min(t for t in ts if t is not None) if any(t is not None for t in ts) else None; res["unnaf_runs"] = ts
             res["roundtrip_ok"] = subprocess.call(["cmp", "-s", P("e.fa"), P("e.out")]) == 0
             same = lambda a, b: subprocess.call(["cmp", "-s", P(a), P(b)]) == 0
             # the drop-in direction at this size: the REFERENCE's streaming loop (unnaf/src/output.c:640-651) on the archive this build made
@@ -210,7 +221,10 @@ def cpu_baseline(text_dev, size_bytes, ctx=None, full_ref_archive=True, e2e_byte
             res["unnaf_of_reference_archive"] = timed([os.path.join(BIN, "unnaf"), P("e.ref.naf"), "-o", P("e.out")])
             res["unnaf_of_reference_archive_bit_exact"] = same("e.fa", "e.out")
             # where a CLI's wall time goes (the hosts print their phases under NAF_GPU_PHASES=1)
-            res["phases"] = {"ennaf": cli_phases([os.path.join(BIN, "ennaf"), P("e.fa"), "-o", P("e.naf")], env),
+            for f in ("e.out", "e.naf2"):
+                if os.path.exists(P(f)):
+                    os.remove(P(f))
+            res["phases"] = {"ennaf": cli_phases([os.path.join(BIN, "ennaf"), P("e.fa"), "-o", P("e.naf2")], env),
                              "unnaf": cli_phases([os.path.join(BIN, "unnaf"), P("e.naf"), "-o", P("e.out")], env),
                              "unnaf_to_devnull": cli_phases([os.path.join(BIN, "unnaf"), P("e.naf"), "-o", "/dev/null"], env)}
             out["end_to_end"] = res
@@ -579,8 +593,9 @@ def main():
         T = rep.n_bases
         comp = rep.section_comp[4]
         # what the scatter pass has to move: the text in; out, the sequence stream's codes -- for direct blocks (pure ACGT: all of this
-        # config) the FINAL 4-bit Huffman codes of packed pairs, 2 bits per base, not the packed bytes -- and one case bit per base
-        ealg = {"ennaf_scatter_regular": n_text + T // 4 + T // 8, "ennaf_scatter": n_text + packed + T // 8, "ennaf_count_pure": n_text, "ennaf_count": n_text, "ennaf_last": n_text // 16, "zenc_plan": packed, "zenc_write": packed + comp}
+        # config) the FINAL 4-bit Huffman codes of packed pairs, 2 bits per base, not the packed bytes
+        # (this text has no lower case: the count pass learns it and the scatter pass writes no case bits -- enc.hip: alloc_bases)
+        ealg = {"ennaf_scatter_regular": n_text + T // 4, "ennaf_scatter": n_text + packed + T // 8, "ennaf_count_pure": n_text, "ennaf_count": n_text, "ennaf_last": n_text // 16, "zenc_plan": packed, "zenc_write": packed + comp}
         enc_ms = median(enc_times) * 1e3
         ennaf_roofline = roofline_of(enc_kt, ealg, n_text, n_text + n_naf, enc_ms, fname="pmc_traffic_ennaf.json")
         if ennaf_roofline:
