@@ -143,6 +143,8 @@ def load():
                                                 C.POINTER(sz), C.c_char_p, sz, C.POINTER(sz), u64p, C.POINTER(EnnafReport)]
         L.naf_gpu_ennaf_stitch.argtypes = [vp, C.POINTER(StitchSeg), sz, C.c_char_p, C.POINTER(vp), vp, sz]
         L.naf_gpu_copy.argtypes = [vp, vp, vp, sz]
+        L.naf_gpu_write_file.argtypes = [vp, i, C.c_uint64, vp, sz]
+        L.naf_gpu_read_file.argtypes = [vp, i, C.c_uint64, sz, vp]
         L.naf_gpu_release_scratch.argtypes = [vp]
         L.naf_gpu_get_timing_streams.argtypes = [vp, C.POINTER(C.c_float)]
         L.naf_gpu_gather_ranges.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), u64p, C.POINTER(sz), i]
@@ -221,6 +223,10 @@ class Context:
 
     def reserve(self, nbytes):
         self._check(self.L.naf_gpu_reserve(self.h, nbytes))
+
+    def write_file(self, fd, file_off, t):
+        """naf_gpu_write_file: the bytes of device tensor t at file_off of descriptor fd (a regular file)."""
+        self._check(self.L.naf_gpu_write_file(self.h, int(fd), C.c_uint64(int(file_off)), _ptr(t), int(t.numel())))
 
     def release_scratch(self):
         """Give the context's scratch arena back to the device (the next call grows it again)."""

@@ -2442,7 +2442,7 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
     }
     if (part & 2) {
         X.ptr[2] = (const u8 *)s_len; X.len[2] = X.orig[2] = n_lenb; X.lz[2] = 1; X.present[2] = true;
-        X.ptr[3] = s_mask; X.len[3] = X.orig[3] = n_mask; X.block_log[3] = mask_block_log; X.present[3] = S.store_mask; X.flags[3] = ZENC_PREFER_RAW;
+        X.ptr[3] = s_mask; X.len[3] = X.orig[3] = n_mask; X.block_log[3] = mask_block_log; X.present[3] = S.store_mask; X.flags[3] = ZENC_PREFER_RAW;   // (no frame tree for the mask: measured -- its 8 KiB blocks' own trees are 4 % smaller and mostly of 7 bits, the frame's code of 9, which the decoder walks with its two-level look-up)
     }
     return 0;
 }
@@ -2466,8 +2466,8 @@ static int ennaf_windows(naf_gpu_ctx *c, EnnafStreams &X, const naf_gpu_ennaf_op
     // is rare enough for an 11-bit code, which costs this build's decoder its one-level table and makes every symbol of the block a
     // two-level look-up -- the decode of a FASTQ's sequence stream took as long as that of its quality stream, twice the size
     if (o->level <= 1) { X.flags[4] |= ZENC_SHORT_CODES; X.flags[5] |= ZENC_SHORT_CODES; }
-    // ... and one tree for the frame where it fits (zstd_enc.hip: ZENC_FRAME_TREE): the quality stream, a sequence stream's blocks that are not flat, the mask
-    if (o->level <= 1) { X.flags[3] |= ZENC_FRAME_TREE; X.flags[4] |= ZENC_FRAME_TREE; X.flags[5] |= ZENC_FRAME_TREE; }
+    // ... and one tree for the frame where it fits (zstd_enc.hip: ZENC_FRAME_TREE): the quality stream, a sequence stream's blocks that are not flat
+    if (o->level <= 1) { X.flags[4] |= ZENC_FRAME_TREE; X.flags[5] |= ZENC_FRAME_TREE; }
     if (o->long_log) { X.window_log[4] = o->long_log < 10 ? 10 : o->long_log > 31 ? 31 : o->long_log; X.lz[4] = 1; }
     else if (!wl && X.present[4] && X.len[4]) {
         const char *pe = getenv("NAF_GPU_PROBE");                 // "0": never look, "1": always match

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(con
 // blk_len == nullptr: block b is the b-th piece of the even split of src[0..n).  Otherwise block b is src[b*slot .. b*slot + blk_len[b])
 // (the literals the LZ stage left of block b).
 __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, const u32 *blk_len, u64 slot, ZTreeCache *cache, u32 sample_stride, u32 try_fse, u32 min_gain, u32 maxbits, u32 prefer_flat, const u8 *done, u8 *wt_defer,
-                                                    u32 *fhist = nullptr, const ZEncPlan *fplan = nullptr, const u16 *fcodes = nullptr)
+                                                    u32 *fhist = nullptr, const ZEncPlan *fplan = nullptr, const u16 *fcodes = nullptr, const u32 *fratio = nullptr)
 {
     // ZENC_HCOPIES copies of the 4 quarter histograms (copy = lane % copies): few distinct symbols (packed ACGT has 16) would
     // otherwise serialise every LDS atomic of a wave on the same handful of addresses
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
     ZEncPlan p; p.n = bn; p.kind = ZK_RAW; p.csize = 3 + bn; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0; p.frame = 0; p.pad2 = 0;
     p.ssz[0] = p.ssz[1] = p.ssz[2] = p.ssz[3] = 0;
     // ---- the FRAME's tree (zstd_encode_begin: ZENC_FRAME_TREE).  The sample launch leaves the sum of its blocks' histograms; one code is
-    // made of it, and a block whose symbols that code covers, at a cost within 4 % (+ 8 bytes) of the block's own entropy, is coded with
+    // made of it, and a block whose symbols that code covers, at a cost within 3 % (+ 8 bytes) of what such a code makes of the block's own entropy (k_zenc_frame_ratio), is coded with
     // it: no code construction, no tree description (k_zenc_frame_fix decides which of these blocks carry the tree: the first one, and
     // those behind a block with a tree of its own) -- the serial steps of a plan are what the planner's time is, and the decoder meets
     // one tree instead of one per block.
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
             const float ent = mine ? (float)mine * __log2f((float)bn / (float)mine) : 0.f;
             u64 both; wg_scan_inclusive<u64, OpAdd>(((u64)(mine * fl) << 32) | (u64)(u32)(ent + 0.5f), &both, fred);
             const u64 fbits = both >> 32, ebits = both & 0xFFFFFFFFull;
-            if (fbits * 100 <= ebits * 104 + 6400) {
+            if (fbits * 1024 * 100 <= ebits * fratio[0] * 103 + 6400ull * 1024) {
                 for (u32 k = 0; k < 4; k++) { u64 bits; wg_scan_inclusive<u64, OpAdd>((u64)hist[256 * k + sym] * fl, &bits, fred); p.ssz[k] = (u32)((bits + 1 + 7) / 8); }
                 zenc_plan_finish(p, bn, fplan->log, 0, min_gain);
                 if (p.kind == ZK_HUF) { p.frame = 1; codes[(u64)b * 256 + sym] = fcodes[sym]; }
@@ -453,6 +453,21 @@ __global__ __launch_bounds__(256) void k_zenc_frame_block(const u32 *fhist, u8 *
     u8 *o = blockbuf + (inc - cnt);
     for (u32 k = 0; k < cnt; k++) o[k] = (u8)sym;
     if (sym == 0) *blen = (u32)all;
+}
+// How far the frame's code is from the entropy of the histogram it was made of, in 1024ths (a Huffman code of a skewed alphabet -- a
+// mask's units, half of them one value -- loses a few per cent whatever block it is made for): the bound a block's cost is held to
+// is its own entropy times this.
+__global__ __launch_bounds__(256) void k_zenc_frame_ratio(u32 *fhist, const u16 *fcodes)
+{
+    __shared__ u64 red[4];
+    const u32 h = fhist[threadIdx.x], l = (u32)fcodes[threadIdx.x] >> 12;
+    u64 tot = wg_reduce1<u64, OpAdd>((u64)h, red);
+    __syncthreads();
+    const float ent = (h && tot) ? (float)h * __log2f((float)tot / (float)h) : 0.f;
+    const u64 both = wg_reduce1<u64, OpAdd>(((u64)h * l) << 0 | 0ull, red);
+    __syncthreads();
+    const u64 e = wg_reduce1<u64, OpAdd>((u64)(ent + 0.5f), red);
+    if (threadIdx.x == 0) { u64 r = e ? both * 1024 / e : 1024; fhist[257] = (u32)(r < 1024 ? 1024 : r > 1229 ? 1229 : r); }
 }
 // Which blocks of the frame's code carry the tree.  v[b] = 2 b + 1 for a Huffman block with a tree of its own, 2 b for one of the frame's
 // code, -1 for the others, running maximum taken: a block of the frame's code is treeless when the Huffman block in front of it is one as well.
@@ -1284,9 +1299,9 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     const bool frame_tree = frame_tree_ok && cache && !use_lz && !direct && !(eft && eft[0] == '0');
     u32 *fhist = nullptr; ZEncPlan *fplan = nullptr; u16 *fcodes = nullptr; u8 *ftree = nullptr;
     if (frame_tree) {
-        fhist = arena_new<u32>(c, 256 + 1); fplan = arena_new<ZEncPlan>(c, 1); fcodes = arena_new<u16>(c, 256); ftree = (u8 *)arena_alloc(c, ZENC_TREE_SLOT);
+        fhist = arena_new<u32>(c, 256 + 2); fplan = arena_new<ZEncPlan>(c, 1); fcodes = arena_new<u16>(c, 256); ftree = (u8 *)arena_alloc(c, ZENC_TREE_SLOT);
         if (!fhist || !fplan || !fcodes || !ftree) return NAF_GPU_ENOMEM;
-        HIP_TRY(c, hipMemsetAsync(fhist, 0, 257 * 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(fhist, 0, 258 * 4, c->stream));
         HIP_TRY(c, hipMemsetAsync(fplan, 0, sizeof(ZEncPlan), c->stream));
         HIP_TRY(c, hipMemsetAsync(fcodes, 0, 512, c->stream));
     }
@@ -1294,13 +1309,17 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     if (frame_tree) {
         u8 *fblock = (u8 *)arena_alloc(c, ZENC_FRAME_BLOCK + 64); if (!fblock) return NAF_GPU_ENOMEM;
         LAUNCH(c, "zenc_frame_block", k_zenc_frame_block, 1, 256, 0, (const u32 *)fhist, fblock, fhist + 256);
-        // (no flat preference, no deferred description: the code of the summed histogram as it is, with its tree description)
-        LAUNCH(c, "zenc_plan_frame", k_zenc_plan, 1, 256, 0, (const u8 *)fblock, (u64)0, 1u, fplan, fcodes, ftree, (u64 *)nullptr, (const u32 *)(fhist + 256), (u64)0, (ZTreeCache *)nullptr, 0u, try_fse, 0u, maxbits, 0u, (const u8 *)nullptr, (u8 *)nullptr, (u32 *)nullptr, (const ZEncPlan *)nullptr, (const u16 *)nullptr);
+        // (no flat preference: the code of the summed histogram as it is, with its tree description -- FSE-coded by k_zenc_tree where
+        // the weights reach past symbol 127, a mask stream's units, like any other block's)
+        u8 *fwt = (u8 *)arena_alloc(c, 256); if (!fwt) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zenc_plan_frame", k_zenc_plan, 1, 256, 0, (const u8 *)fblock, (u64)0, 1u, fplan, fcodes, ftree, (u64 *)nullptr, (const u32 *)(fhist + 256), (u64)0, (ZTreeCache *)nullptr, 0u, try_fse, 0u, maxbits, 0u, (const u8 *)nullptr, fwt, (u32 *)nullptr, (const ZEncPlan *)nullptr, (const u16 *)nullptr);
+        LAUNCH(c, "zenc_tree", k_zenc_tree, 1, 64, 64 * sizeof(ZTreeLane), 1u, fplan, ftree, (u64 *)nullptr, (const u8 *)fwt, 0u);
+        LAUNCH(c, "zenc_frame_ratio", k_zenc_frame_ratio, 1, 256, 0, fhist, (const u16 *)fcodes);
     }
     // (frames of a few blocks keep the tree with the planner: nothing to gain from a second launch)
     const char *td = getenv("NAF_GPU_TREE_DEFER");
     u8 *wt_defer = (nblk >= 256 && !(td && td[0] == '0')) ? (u8 *)arena_alloc(c, (size_t)nblk * 256) : nullptr;
-    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done, wt_defer, (u32 *)nullptr, (const ZEncPlan *)fplan, (const u16 *)fcodes);
+    LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done, wt_defer, (u32 *)nullptr, (const ZEncPlan *)fplan, (const u16 *)fcodes, (const u32 *)(fhist ? fhist + 257 : nullptr));
     if (wt_defer) LAUNCH(c, "zenc_tree", k_zenc_tree, cdiv(nblk, 64), 64, 64 * sizeof(ZTreeLane), nblk, plan, trees, offs, (const u8 *)wt_defer, min_gain);
     if (frame_tree) {
         i32 *fv = arena_new<i32>(c, (size_t)nblk + 1); if (!fv) return NAF_GPU_ENOMEM;

@@ -335,6 +335,25 @@ def _two_rank_worker(rank, world, port, q, kind):
                     assert O.ref_unnaf(arc) == want
             else:
                 assert got is None
+            # "gather to host" without a hop through one GPU (what the C hosts do under NAF_GPUS): every rank decodes its byte range and
+            # writes it into its place of ONE file over its own link (naf_gpu_write_file); rank 0 reads the file back
+            total = ctx.unnaf_size(naf, mode)
+            b0, e0 = sh.byte_range(total, rank, world)
+            piece = ctx.unnaf_range(naf, b0, e0, mode)
+            path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "naf_to_host_%d.out" % port)
+            if rank == 0:
+                with open(path, "wb") as f:
+                    f.truncate(total)
+            dist.barrier()
+            fd = os.open(path, os.O_WRONLY)
+            if e0 > b0:
+                ctx.write_file(fd, b0, piece)
+            os.close(fd)
+            dist.barrier()
+            if rank == 0:
+                with open(path, "rb") as f:
+                    assert f.read() == want
+                os.remove(path)
         except AssertionError as e:
             ok = "rank %d: %r" % (rank, e)
         ctx.close()
