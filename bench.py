@@ -190,6 +190,12 @@ def cpu_baseline(text_dev, size_bytes, ctx=None, full_ref_archive=True, e2e_byte
             e2e = text_dev[:e2e_bytes]
             cut2 = last_line_end(e2e)
             e2e[:cut2].cpu().numpy().tofile(P("e.fa"))
+            del e2e
+            # the CLIs are processes of their own on this GPU: this process gives back what it holds beside the text (its context's
+            # arenas, torch's cached blocks) before they start
+            if ctx is not None:
+                import torch
+                torch.cuda.synchronize(); ctx.release_scratch(); torch.cuda.empty_cache()
             def timed(cmd):
                 t0 = time.perf_counter()
                 rc = subprocess.call(cmd, env=env, stderr=subprocess.DEVNULL)
