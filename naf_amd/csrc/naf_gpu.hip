@@ -58,7 +58,7 @@ extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
     if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess) { naf_gpu_shutdown(c); return NAF_GPU_EHIP; }
     for (int k = 0; k < ZSPLIT_MAX + 2; k++) if (hipEventCreateWithFlags(&c->split_ev[k], hipEventDisableTiming) != hipSuccess) { naf_gpu_shutdown(c); return NAF_GPU_EHIP; }
     c->sides_rc = 0;
-    c->sides_thread = new std::thread([c, device] {
+    auto make_sides = [c, device] {
         hipSetDevice(device);
         int prio_lo = 0, prio_hi = 0; hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         for (int k = 0; k < 4; k++) {
@@ -73,7 +73,10 @@ extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
             sc->own_stream = true;
             (k == 0 ? c->side : k == 1 ? c->side2 : k == 2 ? c->side3 : c->side4) = sc;
         }
-    });
+    };
+    try { c->sides_thread = new std::thread(make_sides); }
+    catch (...) { c->sides_thread = nullptr; make_sides(); }       // no thread to be had: made here, as they used to be
+    if (!c->sides_thread && c->sides_rc) { naf_gpu_shutdown(c); return NAF_GPU_EHIP; }
     *out = c;
     return NAF_GPU_OK;
 }
