@@ -2219,6 +2219,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     const bool spec = nblk > (smin ? (u32)atoi(smin) : 512u) && !fuse;
     u64 *r4 = nullptr, *ends = nullptr; u8 *huf_pool = nullptr; u32 pool_cap = 0; bool tables_built = false; bool ranged_build = false; bool two_phase = false;
     u64 h4[5] = { 0, 0, 0, 0, 0 }, hends[ZSPLIT_MAX] = { 0 };
+    bool late_build = false;
     if (spec) {
         if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
         u64 *extra = arena_new<u64>(c, 8 + ZSPLIT_MAX); if (!extra) return NAF_GPU_ENOMEM;
@@ -2240,7 +2241,10 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             // (a caller that can read flat blocks in place gets the flat trees recognised now and the other tables later: see phase 2 below)
             two_phase = c->zflat && !rg && !always_table;
             if (two_phase) LAUNCH(c, "zstd_build_huf", k_flat_find_main, FIND_MAIN_TREES, 64, 0, d_src, blk, nblk, huf_pool, pool_cap, st, (const i32 *)own_huf);
-            else if ((rc = launch_build_huf(c, nblk, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)r4, always_table, (const i32 *)own_huf, 1u, 0u))) return rc;
+            else late_build = true;
+            // (the group builder for frames of MANY distinct trees is queued once the counters say there are that many: its workgroups hold
+            // 64 KB of LDS each, and beside a Huffman walk of another stream -- which fills every CU's LDS -- even workgroups that find
+            // nothing to do waited a millisecond to start: a FASTQ's sequence frame, one tree, behind its quality frame's walk)
         }
         ZSplit *sp = c->zsplit;
         if (sp && !rg && sp->parts >= 2) {
@@ -2253,6 +2257,10 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         u64 hx[8 + ZSPLIT_MAX];
         rc = ctx_readback2(c, &hs, st, sizeof hs, hx, extra, sizeof hx); if (rc) return rc;
         memcpy(h4, hx, sizeof h4); memcpy(hends, hx + 8, sizeof hends);
+        if (late_build && !hs.err && hs.n_huf_distinct > HUF_FEW) {
+            if ((rc = launch_build_huf(c, nblk, d_src, blk, nblk, huf_pool, pool_cap, st, 0u, (const u64 *)r4, always_table, (const i32 *)own_huf, 1u, 0u))) return rc;
+            rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+        }
         tables_built = true;
     } else {
         rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
