@@ -1008,13 +1008,16 @@ __global__ void k_emit_headers(EmitP P, u8 *text)
 #define HUF_OROW 72                        // output row pitch (64 + 8)
 #define HUF_IROW 136                       // input window pitch (128 + 8)
 #define HUF_IROW_BIG 264                   // four-sector window for tables of more than 7 bits
-template <bool FUSE>
+// SHARED: launched for a frame of few trees with room for ONE table per workgroup (13.6 instead of 17.4 KB of LDS per wavefront for
+// 7-bit codes: 11 instead of 9 wavefronts per CU of a kernel that is bound by its chains' latency at the occupancy LDS allows).  A
+// workgroup whose blocks are under different trees marks them in `redo` (as a `sel` array) and leaves them to a launch of the plain kernel.
+template <bool FUSE, bool SHARED = false>
 __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf,
                                                       const u8 *pool, u32 slot_bytes, u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first,
-                                                      EmitP EP, u8 *text, u32 ipitch, u64 src_len, u32 flat_on, const u8 *sel)
+                                                      EmitP EP, u8 *text, u32 ipitch, u64 src_len, u32 flat_on, const u8 *sel, u8 *redo = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
-    u8 *irows = lds + HUF_BLOCKS_PER_WG * slot_bytes;                // 64 input rings of ipitch bytes (136: 2 sectors, 264: 4 sectors)
+    u8 *irows = lds + (SHARED ? 1u : HUF_BLOCKS_PER_WG) * slot_bytes;   // 64 input rings of ipitch bytes (136: 2 sectors, 264: 4 sectors)
     u16 *lut2 = (u16 *)(irows + 64 * ipitch);                         // FUSE: packed byte -> two ASCII bytes
     u8 *orows = (u8 *)lut2;                                           // !FUSE: 64 output rows of 72 B + 64 row pointers
     u64 *row_out = (u64 *)(orows + 64 * HUF_OROW);
@@ -1037,6 +1040,19 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
         wanted = __ballot(want);
         if (!wanted) return;
     }
+    if (SHARED) {
+        // one tree for all the blocks decoded here?  (the first wanted block's owner against every wanted block's)
+        const u32 j0 = (u32)(__ffsll((long long)wanted) - 1) >> 2;
+        const i32 ob0 = own_huf[b0 + j0];
+        const u32 bi = b0 + ((u32)lane >> 2);
+        const bool mine = (wanted >> (4 * ((u32)lane >> 2))) & 1;
+        const bool same = ob0 >= 0 && __all(!mine || own_huf[bi] == ob0);
+        if (!same) { if (mine && (lane & 3) == 0) redo[bi] = 2; return; }
+        const u32 bytes = huf_tab_bytes(blk[ob0].huf_log);
+        const uint4 *g = (const uint4 *)(pool + blk[ob0].huf_tab);
+        uint4 *l = (uint4 *)lds;
+        for (u32 k = lane; k < bytes / 16; k += 64) l[k] = g[k];
+    } else
     for (u32 j = 0; j < HUF_BLOCKS_PER_WG; j++) {                     // stage the table in force for each block
         u32 bi = b0 + j;
         if (bi >= nblk) break;
@@ -1062,7 +1078,7 @@ __global__ __launch_bounds__(64) void k_huf_literals(const u8 *src, const ZBlock
             if (ob < 0) { if (s == 0) err = ZE_CORRUPT; }                // treeless without a previous table
             else if (!FUSE && flat_on && blk[ob].huf_flat) {}            // fixed-width codes: k_flat_literals has them
             else {
-                log = blk[ob].huf_log; tab = (const u16 *)(lds + j * slot_bytes);
+                log = blk[ob].huf_log; tab = (const u16 *)(lds + (SHARED ? 0u : j * slot_bytes));
                 const u8 *c = src + b.src_off + b.huf_streams_off;
                 u8 *o = (b.nseq == 0 ? dst : lit_scratch) + b.out_off;
                 u32 regen = b.lit_regen;
@@ -2497,6 +2513,15 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             const u32 flat_on = (hs.n_flat && !always_table) ? 1u : 0u;
             const bool serial_needed = !flat_on || hs.n_flat < hs.n_huf_built;
             const u32 plog = huf_par_plog(hs.max_lit_regen, b_count), par_lds = (plog >= 4 ? 1u : 16u >> plog) * slot;
+            // a frame of few trees (this build's frame tree, libzstd's runs of treeless blocks): workgroups with ONE table in LDS, the
+            // workgroups whose blocks are under several trees through a second launch of the plain kernel (NAF_GPU_HUF_SHARED=0: never)
+            u8 *redo = nullptr;
+            { const char *hsx = getenv("NAF_GPU_HUF_SHARED");
+              if (serial_needed && !plog && (u64)hs.n_huf_distinct * 64 <= b_count && !(hsx && hsx[0] == '0')) {
+                redo = (u8 *)arena_alloc(c, (size_t)nblk + 16); if (!redo) return NAF_GPU_ENOMEM;
+                HIP_TRY(c, hipMemsetAsync(redo, 0, nblk, c->stream));
+              } }
+            const u32 huf_lds_shared = huf_lds - slot * (HUF_BLOCKS_PER_WG - 1u);
             ZSplit *sp = c->zsplit;
             const char *smin = getenv("NAF_GPU_SPLIT_MIN");                      // blocks per part below which a split is not worth its launches (tests lower it)
             const u32 split_min = smin ? (u32)atoi(smin) : 4096u;
@@ -2522,6 +2547,12 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     if (hi_b > lo_b && flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, hi_b - lo_b, 256, 0, d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, lo_b, (const u8 *)nullptr);
                     if (hi_b > lo_b && serial_needed && plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)(hi_b - lo_b) << (plog + 2), 64), 64, par_lds,
                            d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(), 0u, (u64)src_len);
+                    else if (hi_b > lo_b && serial_needed && redo) {
+                        LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false, true>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds_shared,
+                               d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr, redo);
+                        LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds,
+                               d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)redo);
+                    }
                     else if (hi_b > lo_b && serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds,
                            d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr);
                     HIP_TRY(c, hipEventRecord(sp->ev[k], c->stream));
@@ -2532,6 +2563,12 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                 if (flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, b_count, 256, 0, d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, b_first, (const u8 *)nullptr);
                 if (serial_needed && plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)b_count << (plog + 2), 64), 64, par_lds,
                    d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(), 0u, (u64)src_len);
+                else if (serial_needed && redo) {
+                    LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false, true>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, huf_lds_shared,
+                       d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr, redo);
+                    LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, huf_lds,
+                       d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)redo);
+                }
                 else if (serial_needed) LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, huf_lds,
                    d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr);
             }
