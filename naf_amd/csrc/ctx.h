@@ -124,6 +124,8 @@ int zstd_flat_later(naf_gpu_ctx *c, ZFlat *zf);
 void zstd_flat_drop(ZFlat *zf);
 // up to 4 small frames (no magic) in one launch; ok[k] false = take the ordinary path for frame k
 int zstd_small_batch(naf_gpu_ctx *c, int n, const u8 *const *src, const size_t *len, u8 *const *dst, const size_t *cap, bool *ok);
+bool zstd_small_fits(size_t len, size_t cap);
+int zstd_small_launch(naf_gpu_ctx *c, int n, const u8 *const *src, const size_t *len, u8 *const *dst, const size_t *cap, u32 **d_res_out);
 // One frame of independently coded blocks; with_magic=0 omits the 4 magic bytes (as stored in a .naf section).
 // level >= 2 (or lz != 0) adds the LZ stage (matches inside a block).
 enum { ZENC_PART = 16, ZENC_PART_FIRST = 32, ZENC_PART_LAST = 64, ZENC_PREFER_RAW = 128, ZENC_PREFER_FLAT = 256, ZENC_SHORT_CODES = 512, ZENC_FRAME_TREE = 1024 };   // FRAME_TREE: one Huffman code for the blocks of the frame that it fits, the other blocks of it treeless (zstd_enc.hip)   // SHORT_CODES: Huffman codes of at most 7 bits where the block has at most 64 symbols (9 otherwise): the decoder's one-level table and two-sector window   // PREFER_FLAT: k-bit codes for blocks of 2^k symbols unless Huffman coding saves a sixteenth (zstd_enc.hip)   // PREFER_RAW: Huffman only where it saves an eighth of the block     // with_magic flags: a shard's part of a frame (zstd_enc.hip)

@@ -189,12 +189,8 @@ __global__ __launch_bounds__(256) void k_mask_rle_frame(const u8 *src, u32 len, 
 }
 
 // per-record header length and text size
-__global__ void k_rec_sizes(u64 N, const u64 *rec_len, const u64 *idz, const u64 *nmz, int has_ids, int has_names,
-                            int mode, u64 L, u32 *hdr_len, u64 *out_size, u64 *base_size)
+__device__ __forceinline__ void rec_size_of(u64 r, u64 len, const u64 *idz, const u64 *nmz, int has_ids, int has_names, int mode, u64 L, u32 *hdr, u64 *out)
 {
-    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= N) return;
-    u64 len = rec_len[r];
     u64 h = 0;
     if (mode == EM_FASTA || mode == EM_FASTQ) {
         u64 idl = 0, nml = 0;
@@ -203,13 +199,81 @@ __global__ void k_rec_sizes(u64 N, const u64 *rec_len, const u64 *idz, const u64
         u64 name = has_ids ? idl + ((has_names && nml) ? 1 + nml : 0) : nml;     // output.c:105-124
         h = 1 + name + 1;
     }
-    hdr_len[r] = (u32)h;
     u64 body;
     if (mode == EM_FASTQ) body = 2 * len + 4;                                       // SEQ \n + \n QUAL \n
     else if (mode == EM_SEQUENCES) body = len + 1;
     else body = len ? len + (L ? (len + L - 1) / L : 1) : 0;                        // ceil(len/L) newlines, none if empty
-    out_size[r] = h + body;
+    *hdr = (u32)h; *out = h + body;
+}
+__global__ void k_rec_sizes(u64 N, const u64 *rec_len, const u64 *idz, const u64 *nmz, int has_ids, int has_names,
+                            int mode, u64 L, u32 *hdr_len, u64 *out_size, u64 *base_size)
+{
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    u64 len = rec_len[r];
+    rec_size_of(r, len, idz, nmz, has_ids, has_names, mode, L, &hdr_len[r], &out_size[r]);
     base_size[r] = len;
+}
+
+// The record tables of an archive of few records in ONE launch behind the one that decodes its ids, names and lengths
+// (k_small_frames): the chain above -- zero positions of two streams, lengths, sizes, two scans -- is sixteen launches and four
+// read-backs of a few microseconds of work each, and the emit of a 10 GB archive of a hundred chromosomes waits for the last of
+// them (profiles/r04_timeline_uniform_10GB.txt: 0.55 ms, a fifth of a millisecond longer than the sequence stream's own front).
+// One workgroup; status: [0] 1 = the frames were good and the tables are made (0: the caller takes the long way, which also words the
+// errors), [1] zero bytes among the ids, [2] among the names, [3] records the lengths describe, [4] bytes of text, [5] bases.
+#define SIDE_FUSED_N 4096u
+struct SideJob { const u32 *res; u32 n_jobs; u32 cap[3], len[3];
+                 const u8 *ids, *names; const u32 *lens; u64 ids_n, names_n, n_len;
+                 u64 N, L; int has_ids, has_names, mode;
+                 u64 *idz, *nmz, *rec_len, *rec_out, *rec_base, *status; u32 *hdr_len; };
+__device__ u64 wg_zero_positions(const u8 *p, u64 n, u64 *pos, u64 cap, u64 *lds)
+{
+    u64 run = 0;
+    for (u64 tb = 0; tb < n; tb += ZT_TILE) {
+        const u64 base = tb + (u64)threadIdx.x * ZT_BYTES;
+        u32 m = base < n ? zero_byte_mask16(p, base, n) : 0;
+        u64 c = __popc(m), tot;
+        const u64 incl = wg_scan_inclusive<u64, OpAdd>(c, &tot, lds);
+        u64 k = run + incl - c;
+        while (m) { int b = __ffs(m) - 1; m &= m - 1; if (k < cap) pos[k] = base + b; k++; }
+        run += tot;
+    }
+    return run;
+}
+__global__ __launch_bounds__(256) void k_side_tables(SideJob J)
+{
+    __shared__ u64 lds[4];
+    __shared__ unsigned long long s_len[SIDE_FUSED_N];
+    const u32 t = threadIdx.x;
+    bool ok = true;
+    for (u32 q = 0; q < J.n_jobs; q++) ok = ok && J.res[4 * q] == 0 && J.res[4 * q + 1] == J.cap[q] && J.res[4 * q + 2] == J.len[q];
+    if (!ok) { if (t == 0) J.status[0] = 0; return; }
+    for (u32 r = t; r < SIDE_FUSED_N; r += 256) s_len[r] = 0;
+    const u64 n_ids = J.has_ids ? wg_zero_positions(J.ids, J.ids_n, J.idz, J.N, lds) : 0;
+    const u64 n_names = J.has_names ? wg_zero_positions(J.names, J.names_n, J.nmz, J.N, lds) : 0;
+    // lengths: a record's units add up, the one that is not 0xFFFFFFFF is its last (k_len_flags / k_len_acc)
+    u64 nrec = 0;
+    for (u64 b = 0; b < J.n_len; b += 256) {
+        const u64 i = b + t; const u32 u = i < J.n_len ? J.lens[i] : 0xFFFFFFFFu;
+        u64 f = i < J.n_len && u != 0xFFFFFFFFu, tot;
+        const u64 incl = wg_scan_inclusive<u64, OpAdd>(f, &tot, lds);
+        const u64 ridx = nrec + incl - f;
+        if (i < J.n_len && ridx < J.N) atomicAdd(&s_len[ridx], (unsigned long long)u);
+        nrec += tot;
+    }
+    __syncthreads();
+    u64 run_out = 0, run_base = 0;
+    for (u64 b = 0; b < J.N; b += 256) {
+        const u64 r = b + t; u64 len = 0, o = 0, tot_o, tot_b; u32 hd = 0;
+        if (r < J.N) { len = s_len[r]; rec_size_of(r, len, J.idz, J.nmz, J.has_ids, J.has_names, J.mode, J.L, &hd, &o); }
+        const u64 io = wg_scan_inclusive<u64, OpAdd>(o, &tot_o, lds), ib = wg_scan_inclusive<u64, OpAdd>(len, &tot_b, lds);
+        if (r < J.N) { J.rec_len[r] = len; J.hdr_len[r] = hd; J.rec_out[r] = run_out + io - o; J.rec_base[r] = run_base + ib - len; }
+        run_out += tot_o; run_base += tot_b;
+    }
+    if (t == 0) {
+        J.rec_len[J.N] = 0; J.rec_out[J.N] = run_out; J.rec_base[J.N] = run_base;
+        J.status[1] = n_ids; J.status[2] = n_names; J.status[3] = nrec; J.status[4] = run_out; J.status[5] = run_base; J.status[0] = 1;
+    }
 }
 
 // ---- emit ---------------------------------------------------------------------------------------------------------
@@ -1438,6 +1502,61 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
             if (nrec < N) return ctx_fail(x, NAF_GPU_EFORMAT, "corrupted lengths: %llu records described, %llu expected", (unsigned long long)nrec, (unsigned long long)N);
             return 0;
         };
+        // Few records, every one of the three streams a small frame: two launches and one read-back make all the tables (k_side_tables),
+        // on `aux` beside the mask stream when there is one (NAF_GPU_SIDE_FUSED=0: the long way below, which is also where a frame that
+        // turns out not to decode goes, for its message)
+        u64 tot[2] = { 0, 0 };
+        bool fused_done = false;
+        {
+            const char *sf = getenv("NAF_GPU_SIDE_FUSED");
+            const int sec[3] = { S_IDS, S_NAMES, S_LEN }; const bool wanted[3] = { want_names && has_ids != 0, want_names && has_names != 0, true };
+            bool fits = !(sf && sf[0] == '0') && N <= SIDE_FUSED_N && h.orig_size[S_LEN] % 4 == 0;
+            for (int k = 0; k < 3; k++) if (wanted[k] && !zstd_small_fits(h.comp_size[sec[k]], h.orig_size[sec[k]])) fits = false;
+            for (int k = 0; k < 3; k++) if (wanted[k] && h.orig_size[sec[k]] == 0) fits = false;
+            if (fits) {
+                u64 st[6] = { 0, 0, 0, 0, 0, 0 };
+                auto fused = [&](naf_gpu_ctx *x) -> int {
+                    const u8 *src[3]; size_t len[3], cap[3]; u8 *dst[3]; u8 *buf[3] = { nullptr, nullptr, nullptr }; int m = 0, r;
+                    SideJob J; memset(&J, 0, sizeof J);
+                    for (int k = 0; k < 3; k++) {
+                        if (!wanted[k]) continue;
+                        u8 *b = (u8 *)arena_alloc(x, h.orig_size[sec[k]] + 32); if (!b) return NAF_GPU_ENOMEM;
+                        src[m] = d_naf + h.payload_off[sec[k]]; len[m] = h.comp_size[sec[k]]; dst[m] = b; cap[m] = h.orig_size[sec[k]];
+                        J.cap[m] = (u32)cap[m]; J.len[m] = (u32)len[m]; buf[k] = b; m++;
+                    }
+                    u32 *d_res = nullptr;
+                    if ((r = zstd_small_launch(x, m, src, len, dst, cap, &d_res))) return r;
+                    J.res = d_res; J.n_jobs = (u32)m;
+                    J.ids = buf[0]; J.ids_n = h.orig_size[S_IDS]; J.names = buf[1]; J.names_n = h.orig_size[S_NAMES];
+                    J.lens = (const u32 *)buf[2]; J.n_len = h.orig_size[S_LEN] / 4;
+                    J.N = N; J.L = P.L; J.has_ids = P.has_ids; J.has_names = P.has_names; J.mode = P.mode;
+                    J.idz = P.has_ids ? arena_new<u64>(x, N + 1) : nullptr; J.nmz = P.has_names ? arena_new<u64>(x, N + 1) : nullptr;
+                    J.rec_len = arena_new<u64>(x, N + 1); J.hdr_len = arena_new<u32>(x, N + 1);
+                    J.rec_out = arena_new<u64>(x, N + 2); J.rec_base = arena_new<u64>(x, N + 2); J.status = arena_new<u64>(x, 8);
+                    if ((P.has_ids && !J.idz) || (P.has_names && !J.nmz) || !J.rec_len || !J.hdr_len || !J.rec_out || !J.rec_base || !J.status) return NAF_GPU_ENOMEM;
+                    LAUNCH(x, "unnaf_side_tables", k_side_tables, 1, 256, 0, J);
+                    if ((r = ctx_readback(x, st, J.status, sizeof st))) return r;
+                    if (st[0] != 1) return 0;
+                    P.ids = buf[0]; P.idz = J.idz; P.names = buf[1]; P.nmz = J.nmz;
+                    P.rec_len = J.rec_len; P.hdr_len = J.hdr_len; P.rec_out = J.rec_out; P.rec_base = J.rec_base;
+                    fused_done = true;
+                    return 0;
+                };
+                int rf = 0;
+                if (aux) { ctx_worker_start(aux, [&] { rf = fused(aux); }); early(); ctx_worker_join(aux); if (rf) memcpy(c->err, aux->err, sizeof c->err); }   // no return until it is joined
+                else rf = fused(c);
+                if (rf) return rf;
+                if (fused_done) {
+                    // the order (and the words) of the long way: lengths, ids, names
+                    if (st[3] < N) return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted lengths: %llu records described, %llu expected", (unsigned long long)st[3], (unsigned long long)N);
+                    if (P.has_ids && st[1] < N) return ctx_fail(c, NAF_GPU_EFORMAT, "currupted ids - can't read id %llu\n", (unsigned long long)st[1]);
+                    if (P.has_names && st[2] < N) return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted names - can't read name %llu\n", (unsigned long long)st[2]);
+                    tot[0] = st[4]; tot[1] = st[5];
+                }
+            }
+        }
+        if (fused_done) rec_len = (u64 *)P.rec_len;
+        else {
         // With a second context: ids and names go there.  When this context also has the mask stream to decode (`early`), the
         // lengths follow the names over there, so that the two chains (mask | ids, names, lengths) are about as long as each other.
         const bool aux_run = aux && want_names && (has_ids || has_names);
@@ -1472,15 +1591,15 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
         HIP_TRY(c, hipMemsetAsync(rec_base + N, 0, 8, c->stream));
         if ((rc = scan_exclusive_u64(c, rec_out, N + 1, (u64 *)nullptr))) return rc;
         if ((rc = scan_exclusive_u64(c, rec_base, N + 1, (u64 *)nullptr))) return rc;
-        u64 tot[2];
         if ((rc = ctx_readback2(c, &tot[0], rec_out + N, 8, &tot[1], rec_base + N, 8))) return rc;
+        P.hdr_len = hdr_len; P.rec_out = rec_out; P.rec_base = rec_base;
+        }
         if (tot[1] > T) return ctx_fail(c, NAF_GPU_EFORMAT, "sum of lengths (%llu) exceeds the stored sequence length (%llu)", (unsigned long long)tot[1], (unsigned long long)T);
         // every base of a read needs its quality byte: a shorter quality stream would be read past its end by the emit kernels (the
         // reference has no message for this -- print_quality_from_file, output-fastq.c:69-85, never returns on such an archive)
         if (P.mode == EM_FASTQ && h.orig_size[S_QUAL] < tot[1])
             return ctx_fail(c, NAF_GPU_EFORMAT, "corrupted quality: %llu quality codes stored for %llu bases\n", (unsigned long long)h.orig_size[S_QUAL], (unsigned long long)tot[1]);
         if (P.mode == EM_SEQUENCES && T == 0) tot[0] = 0;                            // output-sequences.c:81: nothing printed
-        P.hdr_len = hdr_len; P.rec_out = rec_out; P.rec_base = rec_base;
         pl.total = pl.main_total = tot[0]; pl.surplus = 0; pl.sur_c = 0;
         if (tot[1] < T && P.mode != EM_FASTQ) {
             // more bases than the lengths account for.  FASTQ never prints them (output-fastq.c:100-149 stops after the N-th

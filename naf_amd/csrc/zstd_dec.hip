@@ -2040,6 +2040,19 @@ int zstd_small_batch(naf_gpu_ctx *c, int n, const u8 *const *src, const size_t *
     for (int q = 0; q < m; q++) ok[map[q]] = res[4 * q] == 0 && res[4 * q + 1] == J.cap[q] && res[4 * q + 2] == J.len[q];
     return 0;
 }
+// The same without the read-back, for a caller whose next kernel checks the results itself: frame k is good when
+// res[4k] == 0, res[4k + 1] == cap[k] and res[4k + 2] == len[k].  Every frame must be small (zstd_small_fits).
+bool zstd_small_fits(size_t len, size_t cap) { return len != 0 && len <= SMALL_SRC && cap <= SMALL_OUT; }
+int zstd_small_launch(naf_gpu_ctx *c, int n, const u8 *const *src, const size_t *len, u8 *const *dst, const size_t *cap, u32 **d_res_out)
+{
+    SmallJobs J; memset(&J, 0, sizeof J);
+    if (n < 1 || n > 4) return NAF_GPU_EARG;
+    for (int k = 0; k < n; k++) { if (!zstd_small_fits(len[k], cap[k])) return NAF_GPU_EARG; J.src[k] = src[k]; J.len[k] = (u32)len[k]; J.dst[k] = dst[k]; J.cap[k] = (u32)cap[k]; }
+    u32 *d_res = arena_new<u32>(c, 16); if (!d_res) return NAF_GPU_ENOMEM;
+    LAUNCH(c, "zstd_small_frame", k_small_frames, n, 64, 0, J, (const FseE *)c->d_predef, d_res);
+    *d_res_out = d_res;
+    return 0;
+}
 
 // ---- host orchestration ------------------------------------------------------------------------------------------
 int zstd_init_tables(naf_gpu_ctx *c)

@@ -127,6 +127,20 @@ def test_unnaf_matches_reference_outputs(gpu, case, path, monkeypatch):
         assert sha(got) == exp["sha256"], m
 
 
+@pytest.mark.parametrize("case", naf_cases(), ids=lambda c: c["name"])
+def test_unnaf_record_tables_the_long_way(gpu, case, monkeypatch):
+    """The record tables of an archive of few records come from one launch behind the small-frame decoder (k_side_tables); with
+    NAF_GPU_SIDE_FUSED=0 they come from the chain of kernels archives of many records take.  Same reference outputs."""
+    monkeypatch.setenv("NAF_GPU_SIDE_FUSED", "0")
+    d = gpu.to_device(golden_bytes("naf", case["name"] + ".naf"))
+    for m, (mode, use_mask, ll) in MODES.items():
+        if m not in case["outputs"]:
+            continue
+        exp = case["outputs"][m]
+        got = host(gpu.unnaf(d, mode, use_mask, ll))
+        assert len(got) == exp["len"] and sha(got) == exp["sha256"], m
+
+
 def test_histogram_matches_numpy(gpu):
     rng = np.random.default_rng(2)
     for n in (0, 1, 7, 65536, 65537, 1000003):
