@@ -85,6 +85,7 @@ template <typename T> T *arena_new(naf_gpu_ctx *c, size_t n) { return (T *)arena
 // Small device->host readback through pinned staging (synchronises the stream).
 int ctx_readback(naf_gpu_ctx *c, void *h_dst, const void *d_src, size_t bytes);
 int ctx_readback2(naf_gpu_ctx *c, void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2);
+int ctx_readbackv(naf_gpu_ctx *c, int n, void *const *h, const void *const *d, const size_t *bytes);
 
 void ktime_begin(naf_gpu_ctx *c, const char *name);
 void ktime_end(naf_gpu_ctx *c);

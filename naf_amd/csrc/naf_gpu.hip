@@ -304,6 +304,19 @@ int ctx_readback2(naf_gpu_ctx *c, void *h1, const void *d1, size_t n1, void *h2,
     return 0;
 }
 
+// n read-backs (each up to a few hundred bytes) with one wait for the stream
+int ctx_readbackv(naf_gpu_ctx *c, int n, void *const *h, const void *const *d, const size_t *bytes)
+{
+    size_t off[8], tot = 0;
+    if (n < 1 || n > 8) return NAF_GPU_EARG;
+    for (int k = 0; k < n; k++) { off[k] = tot; tot += (bytes[k] + 15) & ~(size_t)15; }
+    if (tot > c->h_stage_cap) { for (int k = 0; k < n; k++) { int rc = ctx_readback(c, h[k], d[k], bytes[k]); if (rc) return rc; } return 0; }
+    for (int k = 0; k < n; k++) HIP_TRY(c, hipMemcpyAsync(c->h_stage + off[k], d[k], bytes[k], hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < n; k++) memcpy(h[k], c->h_stage + off[k], bytes[k]);
+    return 0;
+}
+
 // ---- memory helpers for hosts that do not link HIP ----------------------------------------------------------
 extern "C" int naf_gpu_malloc(naf_gpu_ctx *c, size_t bytes, void **p) { if (!c || !p) return NAF_GPU_EARG; HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipMalloc(p, bytes ? bytes : 1)); return 0; }
 extern "C" int naf_gpu_free(naf_gpu_ctx *c, void *p) { if (!c) return NAF_GPU_EARG; HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(p)); return 0; }

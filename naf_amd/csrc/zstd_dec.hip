@@ -281,10 +281,11 @@ __global__ void k_stride_tail(const u8 *src, u64 len, u64 off0, u32 S, u32 nmax,
     res[1] = done ? 1u : 0u;
     if (done) { st->nblk = np + n; st->end_off = pos; }
 }
-__global__ void k_stride_write(u64 off0, u32 S, u32 h0, const u32 *res, ZBlock *blk)
+__global__ void k_stride_write(u64 off0, u32 S, u32 h0, const u32 *res, ZBlock *blk, const u32 *uni)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (res[1] != 1 || i >= res[0]) return;
+    if (uni && uni[0] && !uni[1]) return;                        // a uniform flat frame (k_uni_head / k_uni_streams: UniInfo.ok, .bad): nobody reads the block table
     ZBlock &b = blk[i]; b.src_off = off0 + (u64)i * S + 3; b.bsize = h0 >> 3; b.btype = (u8)((h0 >> 1) & 3); b.last = 0;
 }
 
@@ -1439,35 +1440,175 @@ __global__ __launch_bounds__(256) void k_flat_literals(const u8 *src, const ZBlo
 
 // Stream table of a flat frame for the fused emit (ctx.h: ZFlat): four slots per block, the unused ones of a single-stream block
 // empty (they start where the block ends).  Checks what k_flat_literals checks: jump table, end marker, size = n x 4 bits.
-__global__ void k_flat_streams(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf, const u8 *pool, FlatStream *si, u8 *sym, ZStat *st, const u64 *total_out, u64 tail_bytes)
+// Slot s of Huffman block b: false = the block's jump table or the stream's end marker is not what a flat stream has.
+static __device__ __forceinline__ bool flat_slot(const u8 *src, const ZBlock &b, u32 s, FlatStream &f)
 {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) si[4ull * nblk].q0 = *total_out - tail_bytes, si[4ull * nblk].A = 0;      // (nblk: the Huffman blocks; a final Raw block's bytes follow them)
-    if (t < 16) {                                                 // code -> symbol, from the one table of the frame
-        u32 b0 = 0; while (b0 < nblk && own_huf[b0] < 0) b0++;
-        if (b0 < nblk) sym[t] = (u8)(((const u16 *)(pool + blk[own_huf[b0]].huf_tab))[t] >> 8);
-    }
-    if (t >= 4ull * nblk) return;
-    const u32 bi = (u32)(t >> 2), s = (u32)t & 3;
-    const ZBlock &b = blk[bi];
     const u8 *c = src + b.src_off + b.huf_streams_off;
     const u32 regen = b.lit_regen;
-    FlatStream f; f.q0 = b.out_off + regen; f.A = 0;
+    f.q0 = b.out_off + regen; f.A = 0;
     u32 sz = 0, n = 0; const u8 *sp = c;
     if (b.nstreams == 1) { if (s == 0) { sz = b.huf_streams_size; n = regen; f.q0 = b.out_off; } }
     else {
         const u32 s1 = ld16(c), s2 = ld16(c + 2), s3 = ld16(c + 4), tot = b.huf_streams_size - 6, per = (regen + 3) / 4;
-        if (s1 + s2 + s3 >= tot || !s1 || !s2 || !s3 || per * 3 > regen) { set_err(st, ZE_CORRUPT); si[t] = f; return; }
+        if (s1 + s2 + s3 >= tot || !s1 || !s2 || !s3 || per * 3 > regen) return false;
         const u32 off = s == 0 ? 0 : (s == 1 ? s1 : (s == 2 ? s1 + s2 : s1 + s2 + s3));
         sz = s == 0 ? s1 : (s == 1 ? s2 : (s == 2 ? s3 : tot - s1 - s2 - s3));
         sp = c + 6 + off; n = s < 3 ? per : regen - 3 * per; f.q0 = b.out_off + (u64)s * per;
     }
+    bool ok = true;
     if (n) {
         const u32 last = sz ? sp[sz - 1] : 0;
         const u64 E = last ? 8ull * (sz - 1) + (u32)hibit32(last) : 0;
-        if (!last || E != 4ull * n) set_err(st, ZE_CORRUPT);
+        if (!last || E != 4ull * n) ok = false;
         f.A = 8ull * (u64)(sp - src) + E;
     }
+    return ok;
+}
+// code -> symbol of a flat 4-bit tree from its description (block content + lit_off): code k is the k-th symbol of weight 1 in symbol
+// order, the last one implied.  One wavefront; false = not sixteen codes of four bits.  Directly stored weights or FSE-coded ones (the
+// sixteen pair codes of packed bases reach up to symbol 0x88: more than the 128 weights a direct description holds).
+struct FlatSymWS { HufBuildWS ws; __attribute__((aligned(16))) u8 in[192], w[256]; u32 nw, log; };
+static __device__ bool flat_sym_of_tree(const u8 *desc, u32 len, u8 *sym, FlatSymWS &S)
+{
+    // (one wavefront of a larger workgroup: no workgroup barrier in here)
+    const u32 lane = threadIdx.x & 63, n_in = len < 192 ? len : 192;
+    for (u32 k = lane; k < n_in; k += 64) S.in[k] = desc[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) { u32 nw = 0, used = 0; S.log = n_in ? huf_read_weights_ws(S.in, n_in, S.w, &nw, &used, S.ws) : 0u; S.nw = nw; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const u32 nw = S.nw;
+    if (S.log != 4 || nw > 256) return false;
+    u32 run = 0; bool bad = false;
+    for (u32 b0 = 0; b0 < nw; b0 += 64) {
+        const u32 k = b0 + lane, w = k < nw ? S.w[k] : 0u;
+        if (w > 1) bad = true;
+        const u64 bal = __ballot(w == 1);
+        const u32 rank = run + (u32)__popcll(bal & ((1ull << lane) - 1));
+        if (w == 1 && rank < 16) sym[rank] = (u8)k;
+        run += (u32)__popcll(bal);
+    }
+    return !__ballot(bad) && run == 16;
+}
+__global__ void k_flat_streams(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf, const u8 *pool, FlatStream *si, u8 *sym, ZStat *st, const u64 *total_out, u64 tail_bytes)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) si[4ull * nblk].q0 = *total_out - tail_bytes, si[4ull * nblk].A = 0;      // (nblk: the Huffman blocks; a final Raw block's bytes follow them)
+    if (blockIdx.x == 0) {                                        // code -> symbol, from the one tree of the frame (uniform per workgroup)
+        u32 b0 = 0; while (b0 < nblk && own_huf[b0] < 0) b0++;
+        if (b0 < nblk) {
+            const ZBlock &m = blk[own_huf[b0]];
+            if (m.huf_tab != 0xFFFFFFFFu) { if (t < 16) sym[t] = (u8)(((const u16 *)(pool + m.huf_tab))[t] >> 8); }
+            else {                                                // a flat tree recognised from its directly stored weights: no table was built
+                __shared__ FlatSymWS S;
+                if (threadIdx.x < 64 && !flat_sym_of_tree(src + m.src_off + m.lit_off, m.lit_csize, sym, S) && threadIdx.x == 0) set_err(st, ZE_CORRUPT);
+            }
+        }
+    }
+    if (t >= 4ull * nblk) return;
+    FlatStream f;
+    if (!flat_slot(src, blk[(u32)(t >> 2)], (u32)t & 3, f)) set_err(st, ZE_CORRUPT);
+    si[t] = f;
+}
+
+// ---- a UNIFORM flat frame ----------------------------------------------------------------------------------------------------------
+// The frames this build's encoder makes of packed random bases are a string of blocks that repeat the first one in everything but
+// their stream bytes: same size (which is what the stride index rests on), same literals header, same tree description, same jump
+// table, no sequences.  For such a frame the stream table the in-place emit needs is arithmetic -- block i's slots are block 0's,
+// moved by i strides -- and nothing of the general front (parse of every block, ownership scans, tables, offsets: 0.26 ms in front of
+// the emit of a 10 GB text, profiles/r04_timeline_uniform_10GB.txt) has to run.  k_uni_head parses block 0 and the few blocks behind the
+// stride prefix (k_stride_tail) the ordinary way and decides whether the shape is the one; k_uni_streams has four lanes per block
+// compare the block's front bytes with block 0's, check the sequences byte and the end marker of every stream -- everything
+// k_parse_blocks, k_huf_dedup and k_flat_streams would have checked -- and write the table; one more workgroup of it decodes the
+// tree description for the code -> symbol table.  Any doubt leaves U->ok = 0 or sets U->bad and the frame takes the general way.
+struct UniInfo { u32 ok, bad, np, nblk, nhb, regen0, nstreams0, hso0, front, pos0, per, last_raw; u32 off[4], sz[4], n[4]; u64 total_out, end_off; };
+__global__ __launch_bounds__(64) void k_uni_head(const u8 *src, u64 off0, u32 S, u32 h0, u32 nmax, const u32 *res, const ZBlock *sblk, const ZStat *st, UniInfo *U, ZBlock *ublk, u32 spec_min)
+{
+    const u32 lane = threadIdx.x;
+    if (lane == 0) { U->ok = 0; U->bad = 0; }
+    if (res[1] != 1) return;
+    const u32 np = res[0], nblk = st->nblk;
+    if (np < 1 || np > nmax || nblk <= spec_min || nblk < np || nblk - np > STRIDE_TAIL) return;
+    const u32 ntail = nblk - np;
+    if (lane < ntail) { ZBlock b = sblk[np + lane]; zstd_parse_block(src + b.src_off, b); ublk[1 + lane] = b; }
+    if (lane == 63) { ZBlock b; memset(&b, 0, sizeof b); b.src_off = off0 + 3; b.bsize = h0 >> 3; b.btype = (u8)((h0 >> 1) & 3); b.last = 0; zstd_parse_block(src + b.src_off, b); b.out_off = 0; ublk[0] = b; }
+    __threadfence_block();
+    __syncthreads();
+    if (lane) return;
+    const ZBlock b0 = ublk[0];
+    if (b0.err || b0.btype != BT_COMP || b0.lit_type != LIT_HUF || b0.nseq != 0 || b0.lit_regen == 0) return;
+    UniInfo u; memset(&u, 0, sizeof u);
+    u.np = np; u.nblk = nblk; u.regen0 = b0.lit_regen; u.nstreams0 = b0.nstreams; u.hso0 = b0.huf_streams_off;
+    u.front = b0.huf_streams_off + (b0.nstreams == 4 ? 6u : 0u); u.pos0 = b0.lit_off + b0.lit_csize;
+    const u8 *c0 = src + b0.src_off;
+    if (b0.nstreams == 4) {
+        const u8 *c = c0 + b0.huf_streams_off;
+        const u32 s1 = ld16(c), s2 = ld16(c + 2), s3 = ld16(c + 4), tot = b0.huf_streams_size - 6, per = (b0.lit_regen + 3) / 4;
+        if (s1 + s2 + s3 >= tot || !s1 || !s2 || !s3 || per * 3 > b0.lit_regen) return;
+        u.per = per;
+        u.off[0] = 6; u.off[1] = 6 + s1; u.off[2] = 6 + s1 + s2; u.off[3] = 6 + s1 + s2 + s3;
+        u.sz[0] = s1; u.sz[1] = s2; u.sz[2] = s3; u.sz[3] = tot - s1 - s2 - s3;
+        u.n[0] = u.n[1] = u.n[2] = per; u.n[3] = b0.lit_regen - 3 * per;
+    } else { u.per = 0; u.off[0] = 0; u.sz[0] = b0.huf_streams_size; u.n[0] = b0.lit_regen; }
+    // the blocks behind the prefix: plain Huffman blocks of the same tree (its description repeated byte for byte, or none), then at
+    // most one final Raw / RLE block that is not empty
+    u64 out = (u64)np * b0.lit_regen; u32 nhb = np;
+    const u32 dlen = b0.huf_streams_off - b0.lit_off;
+    for (u32 j = 0; j < ntail; j++) {
+        ZBlock &t = ublk[1 + j];
+        if (t.err) return;
+        if (t.btype == BT_COMP) {
+            if (nhb != np + j || t.lit_type < LIT_HUF || t.nseq != 0) return;
+            if (t.lit_type == LIT_HUF) {
+                if (t.huf_streams_off - t.lit_off != dlen) return;
+                const u8 *p = c0 + b0.lit_off, *q = src + t.src_off + t.lit_off;
+                for (u32 k = 0; k < dlen; k++) if (p[k] != q[k]) return;
+            }
+            t.out_off = out; out += t.regen; nhb++;
+        } else {
+            if (j + 1 != ntail || !t.bsize || nblk < 2) return;
+            u.last_raw = t.bsize | (t.btype == BT_RLE ? 0x80000000u : 0u);
+            out += t.bsize;
+        }
+    }
+    u.nhb = nhb; u.total_out = out; u.end_off = st->end_off;
+    u.ok = 1;
+    *U = u;
+}
+__global__ __launch_bounds__(256) void k_uni_streams(const u8 *src, u64 off0, u32 S, const ZBlock *ublk, UniInfo *U, FlatStream *si, u8 *sym)
+{
+    if (!U->ok) return;
+    if (blockIdx.x + 1 == gridDim.x) {                            // the tree: sixteen 4-bit codes, and which symbols they are
+        __shared__ FlatSymWS W;
+        if (threadIdx.x < 64) {
+            const ZBlock &b0 = ublk[0];
+            if (!flat_sym_of_tree(src + b0.src_off + b0.lit_off, b0.huf_streams_off - b0.lit_off, sym, W) && threadIdx.x == 0) atomicOr(&U->bad, 1u);
+        }
+        return;
+    }
+    const u32 np = U->np, nhb = U->nhb;
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 4ull * nhb) { si[t].q0 = U->total_out - (U->last_raw & 0x7FFFFFFFu); si[t].A = 0; }
+    if (t >= 4ull * nhb) return;
+    const u32 bi = (u32)(t >> 2), s = (u32)t & 3;
+    FlatStream f; bool ok = true;
+    if (bi < np) {
+        const u8 *c = src + off0 + (u64)bi * S + 3, *c0 = src + off0 + 3;
+        if (bi) {                                                 // the front bytes, a quarter per lane; the sequences byte
+            const u32 F = U->front, lo = F * s / 4, hi = F * (s + 1) / 4;
+            for (u32 k = lo; k < hi; k++) ok = ok && c[k] == c0[k];
+            if (s == 3) ok = ok && c[U->pos0] == 0;
+        }
+        const u32 regen = U->regen0, n = U->n[s];
+        f.q0 = (u64)bi * regen + (U->nstreams0 == 4 ? (u64)s * U->per : (s ? regen : 0u)); f.A = 0;
+        if (n) {
+            const u8 *sp = c + U->hso0 + U->off[s]; const u32 sz = U->sz[s];
+            const u32 last = sz ? sp[sz - 1] : 0;
+            const u64 E = last ? 8ull * (sz - 1) + (u32)hibit32(last) : 0;
+            if (!last || E != 4ull * n) ok = false;
+            f.A = 8ull * (u64)(sp - src) + E;
+        }
+    } else ok = flat_slot(src, ublk[1 + (bi - np)], s, f);
+    if (!ok) atomicOr(&U->bad, 1u);
     si[t] = f;
 }
 
@@ -2134,6 +2275,12 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     // ---- block index
     ZBlock *blk = nullptr; ZStat hs; bool indexed = false;
     const char *nospec = getenv("NAF_GPU_SERIAL_INDEX");
+    const char *fl_env = getenv("NAF_GPU_FLAT");                                 // "0": every block through the serial kernel (cross-check)
+    const u32 always_table = (fl_env && fl_env[0] == '0') ? 1u : 0u;
+    const char *smin = getenv("NAF_GPU_SPEC_MIN");                      // tests: frames of a few dozen blocks through the paths of the big ones
+    const u32 spec_min = smin ? (u32)atoi(smin) : 512u;
+    const char *un_env = getenv("NAF_GPU_UNIFORM");                              // "0": a uniform flat frame takes the general front too
+    const bool uni_wanted = c->zflat && !fuse && !always_table && !(un_env && un_env[0] == '0');
     // Frames of more than 4 MiB: 1 MiB chunks, candidates in the first 40 KiB / 128 KiB of each.  Smaller frames can still hold
     // thousands of tiny blocks (ids / names / lengths that compress 100:1 in 16 KiB blocks, a mask stream that is 1200 RLE blocks
     // of 4 bytes -- a serial walk of those costs milliseconds): small chunks with every byte tested as a candidate.  The chunk size changes nothing but how much of
@@ -2176,11 +2323,39 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     HIP_TRY(c, hipMemsetAsync(sres, 0xFF, 8, c->stream));
                     LAUNCH(c, "zstd_index_stride", k_stride_probe, cdiv(nmax, 256), 256, 0, d_src, (u64)src_len, (u64)fh.hdr_size, S, h0, nmax, sres);
                     LAUNCH(c, "zstd_index_stride", k_stride_tail, 1, 64, 0, d_src, (u64)src_len, (u64)fh.hdr_size, S, nmax, sres, sblk, st);
-                    LAUNCH(c, "zstd_index_stride", k_stride_write, cdiv(nmax, 256), 256, 0, (u64)fh.hdr_size, S, h0, (const u32 *)sres, sblk);
-                    u32 res2[2] = { 0, 0 };
-                    rc = ctx_readback2(c, &hs, st, sizeof hs, res2, sres, 8); if (rc) return rc;
-                    if (res2[1] == 1u && !hs.err && hs.nblk) { blk = sblk; indexed = true; }
+                    // a uniform flat frame (k_uni_head) needs nothing of what follows: its stream table is made here, beside the verdict
+                    UniInfo *U = nullptr; FlatStream *usi = nullptr; u8 *usym = nullptr;
+                    if (uni_wanted) {
+                        U = arena_new<UniInfo>(c, 1); ZBlock *ublk = arena_new<ZBlock>(c, STRIDE_TAIL + 1);
+                        usi = arena_new<FlatStream>(c, 4 * ((size_t)nmax + STRIDE_TAIL) + 1); usym = (u8 *)arena_alloc(c, 16);
+                        if (!U || !ublk || !usi || !usym) return NAF_GPU_ENOMEM;
+                        LAUNCH(c, "zstd_flat_uniform", k_uni_head, 1, 64, 0, d_src, (u64)fh.hdr_size, S, h0, nmax, (const u32 *)sres, (const ZBlock *)sblk, (const ZStat *)st, U, ublk, spec_min);
+                        LAUNCH(c, "zstd_flat_uniform", k_uni_streams, cdiv(4ull * ((u64)nmax + STRIDE_TAIL) + 1, 256) + 1, 256, 0, d_src, (u64)fh.hdr_size, S, (const ZBlock *)ublk, U, usi, usym);
+                    }
+                    LAUNCH(c, "zstd_index_stride", k_stride_write, cdiv(nmax, 256), 256, 0, (u64)fh.hdr_size, S, h0, (const u32 *)sres, sblk, (const u32 *)U);
+                    u32 res2[2] = { 0, 0 }; UniInfo hu; memset(&hu, 0, sizeof hu);
+                    if (U) { void *hp[3] = { &hs, res2, &hu }; const void *dp[3] = { st, sres, U }; const size_t nb[3] = { sizeof hs, 8, sizeof hu }; rc = ctx_readbackv(c, 3, hp, dp, nb); }
+                    else rc = ctx_readback2(c, &hs, st, sizeof hs, res2, sres, 8);
+                    if (rc) return rc;
                     if (getenv("NAF_GPU_DEBUG_STRIDE")) fprintf(stderr, "[stride] len %zu S %u nmax %u prefix %u verdict %u err %u nblk %u\n", src_len, S, nmax, res2[0], res2[1], hs.err, hs.nblk);
+                    if (getenv("NAF_GPU_DEBUG_FLAT") && U) fprintf(stderr, "[uniform?] ok %u bad %u prefix %u blocks %u huffman %u regen %u total %llu\n", hu.ok, hu.bad, hu.np, hu.nblk, hu.nhb, hu.regen0, (unsigned long long)hu.total_out);
+                    if (res2[1] == 1u && !hs.err && hs.nblk && hu.ok && !hu.bad) {
+                        // every block repeats the first: the caller's emit kernel reads the streams in place (as below, without the block table)
+                        ZFlat *zf = c->zflat;
+                        const size_t frame_end = hs.end_off + (fh.checksum ? 4 : 0);
+                        if (frame_end > src_len) return zerr(c, ZE_TRUNC, "checksum");
+                        *consumed = frame_end;
+                        const bool flat_tail = hu.last_raw != 0;
+                        zf->src = d_src; zf->si = usi; zf->nslots = 4ull * hu.nhb; zf->sym = usym; zf->status = st; zf->ready = true;
+                        const u32 tn = hu.last_raw & 0x7FFFFFFFu; const bool rle = (hu.last_raw >> 31) != 0;       // an RLE block stores one byte
+                        zf->tail = flat_tail ? d_src + (hs.end_off - (rle ? 1u : tn)) : nullptr; zf->tail_q = hu.total_out - (flat_tail ? tn : 0u);
+                        zf->tail_n = flat_tail ? (rle ? tn | 0x80000000u : tn) : 0u;
+                        if (rg) { rg->got_lo = 0; rg->got_hi = hu.total_out; rg->ranged = false; }
+                        *out_len = hu.total_out;
+                        if (fh.has_fcs && fh.content_size != hu.total_out) return zerr(c, ZE_CORRUPT, "content size mismatch");
+                        return 0;
+                    }
+                    if (res2[1] == 1u && !hs.err && hs.nblk) { blk = sblk; indexed = true; }
                 }
             }
         }
@@ -2238,14 +2413,11 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     LAUNCH(c, "zstd_huf_dedup", k_huf_dedup, g, 64, 0, d_src, (const ZBlock *)blk, nblk, own_huf, st);
     if ((rc = scan_inclusive_max_i32(c, own_huf, nblk))) return rc;
     u64 *d_total_out = (u64 *)((u8 *)st + offsetof(ZStat, total_out));
-    const char *fl_env = getenv("NAF_GPU_FLAT");                                 // "0": every block through the serial kernel (cross-check)
-    const u32 always_table = (fl_env && fl_env[0] == '0') ? 1u : 0u;
     // Speculative continuation.  Most frames that are long enough to matter are literal-only (this build's own sequence, mask and
     // quality streams); for those nothing below needs the host: block sizes are final after the parse, so offsets, the block range
     // of a byte-range request, the Huffman tables and the part boundaries of a split decode are queued right away and the counters
     // come back in ONE read-back.  A frame that does have sequences then takes the long way from here (its tables are kept).
-    const char *smin = getenv("NAF_GPU_SPEC_MIN");                      // tests: frames of a few dozen blocks through the paths of the big ones
-    const bool spec = nblk > (smin ? (u32)atoi(smin) : 512u) && !fuse;
+    const bool spec = nblk > spec_min && !fuse;
     u64 *r4 = nullptr, *ends = nullptr; u8 *huf_pool = nullptr; u32 pool_cap = 0; bool tables_built = false; bool ranged_build = false; bool two_phase = false;
     u64 h4[5] = { 0, 0, 0, 0, 0 }, hends[ZSPLIT_MAX] = { 0 };
     bool late_build = false;

@@ -748,6 +748,82 @@ def test_tables_of_many_distinct_trees_sixteen_lanes_per_tree(gpu, oracle, monke
     assert oracle.zstd_decompress(f2, len(cut) + 16) == cut
 
 
+def test_uniform_flat_frame_without_the_block_table(gpu, oracle, monkeypatch, capfd):
+    """zstd_dec.hip k_uni_head / k_uni_streams: a frame whose blocks repeat the first one in all but their stream bytes gets its stream
+    table by arithmetic, with every byte the general front would have looked at compared instead.  Even / odd base counts (a Raw block
+    of one byte at the end), a stream that ends on a block, whole texts, every output mode that reads the streams in place, byte ranges,
+    against the text, the oracle and NAF_GPU_UNIFORM=0; then archives with one byte changed in a block's front, in its sequences byte
+    and in a stream's end marker: the uniform front must step aside and the call must end the way it ends with NAF_GPU_UNIFORM=0."""
+    from naf_amd import synth
+    from naf_amd.capi import NafGpuError
+    import re
+    import torch
+    monkeypatch.setenv("NAF_GPU_SPEC_MIN", "8")
+    cases = [synth.fasta_acgt_device(30_000_000, n_records=3, width=80, seed=13, device="cuda"),
+             synth.fasta_acgt_device(30_000_011, n_records=5, width=71, seed=14, device="cuda"),
+             synth.fasta_acgt_device(65536 * 420, n_records=1, width=60, seed=16, device="cuda")]
+    for t in cases:
+        d_naf, rep = gpu.ennaf(t)
+        capfd.readouterr()
+        monkeypatch.setenv("NAF_GPU_DEBUG_FLAT", "1")
+        gpu.set_timing(True)
+        out = gpu.unnaf(d_naf, 0)
+        ran = {n for n, ms, k in gpu.get_timing()}
+        gpu.set_timing(False)
+        err = capfd.readouterr().err
+        monkeypatch.delenv("NAF_GPU_DEBUG_FLAT")
+        assert torch.equal(out, t)
+        m = re.search(r"\[uniform\?\] ok 1 bad 0 prefix (\d+) blocks (\d+) huffman (\d+)", err)
+        assert m and int(m.group(1)) >= 64 and int(m.group(2)) - int(m.group(1)) <= 2, err
+        assert "unnaf_emit_flat" in ran and not any(x.endswith("zstd_parse_blocks") or x.endswith("zstd_flat_streams") for x in ran), sorted(ran)
+        naf = host(d_naf)
+        for mode, ll, mask in ((0, -1, True), (0, -1, False), (2, -1, True), (3, -1, True), (0, 50, True), (0, 0, True)):
+            got = host(gpu.unnaf(d_naf, mode, line_length=ll, use_mask=mask))
+            monkeypatch.setenv("NAF_GPU_UNIFORM", "0")
+            assert got == host(gpu.unnaf(d_naf, mode, line_length=ll, use_mask=mask)), (mode, ll, mask)
+            monkeypatch.delenv("NAF_GPU_UNIFORM")
+        assert oracle.unnaf(naf, 0) == host(t)
+        n = t.numel()
+        for a, b in ((0, 1), (0, 5000), (n // 3, n // 3 + 123_457), (n - 70_000, n), (n // 2, n // 2 + 1)):
+            assert torch.equal(gpu.unnaf_range(d_naf, a, b, 0), t[a:b]), (a, b)
+    # sixteen byte values below 128 (bases T, G, K, C only): a flat tree whose weights can be stored directly
+    lut = torch.tensor(list(b"TGKC"), dtype=torch.uint8, device="cuda")
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    body = lut[torch.randint(0, 4, (24_000_000,), device="cuda", generator=g)]
+    t4 = torch.cat([torch.tensor(list(b">tgkc only\n"), dtype=torch.uint8, device="cuda"), body, torch.tensor([10], dtype=torch.uint8, device="cuda")])
+    d4, _ = gpu.ennaf(t4)
+    n4 = host(d4)
+    for un in ("1", "0"):
+        monkeypatch.setenv("NAF_GPU_UNIFORM", un)
+        assert torch.equal(gpu.unnaf(d4, 0), t4), un
+    monkeypatch.delenv("NAF_GPU_UNIFORM")
+    assert oracle.unnaf(n4, 0) == host(t4)
+    # one byte changed: where the general front finds an error, or another shape, so must this one
+    t = cases[1]
+    d_naf, rep = gpu.ennaf(t)
+    naf = bytearray(host(d_naf))
+    h = gpu.parse_header(d_naf)
+    off, size = h.payload_off[4], h.comp_size[4]
+    fr = bytes(naf[off:off + size])
+    fhd = fr[0]; hdr = 1 + (0 if (fhd >> 5) & 1 else 1) + ((1 if (fhd >> 5) & 1 else 0) if (fhd >> 6) == 0 else (2, 4, 8)[(fhd >> 6) - 1])
+    b0 = fr[hdr] | (fr[hdr + 1] << 8) | (fr[hdr + 2] << 16)
+    S = 3 + (b0 >> 3)
+    def outcome(buf):
+        d = gpu.to_device(bytes(buf))
+        try:
+            return ("ok", sha(host(gpu.unnaf(d, 0))))
+        except NafGpuError as e:
+            return ("error", e.code)
+    for blk, where in ((7, 3 + 2), (100, 3 + 9), (200, 3 + 40), (33, S - 1), (150, S - 2), (5, 3 + 5 + 60)):
+        bad = bytearray(naf)
+        bad[off + hdr + blk * S + where] ^= 0x5A
+        got = outcome(bad)
+        monkeypatch.setenv("NAF_GPU_UNIFORM", "0")
+        want = outcome(bad)
+        monkeypatch.delenv("NAF_GPU_UNIFORM")
+        assert got == want, (blk, where, got, want)
+
+
 def test_stride_index_of_frames_of_equal_blocks(gpu, oracle, monkeypatch, capfd):
     """zstd_dec.hip k_stride_probe / k_stride_tail: a frame whose blocks all repeat the first block's header (a genome's packed bases
     under fixed-width codes) is indexed by testing every position off0 + i S at once, in front of the speculative index.
