@@ -14,6 +14,7 @@
 //   k_copy_fill      raw / RLE blocks and raw / RLE literals, one workgroup per block
 //   k_exec_seq       one wave per block with sequences, ticket-ordered, waits on per-block done flags
 #include "ctx.h"
+#include "wgscan.h"
 #include "zstd_dec_core.h"
 #include "emit_core.h"
 
@@ -2005,11 +2006,18 @@ __global__ __launch_bounds__(64) void k_range_closure(const u32 *f, const u64 *o
 #define SMALL_SEQ 2048u
 #define SMALL_TOO_BIG 100u
 struct SmallRes { u32 err, out, pos; };
-// The frame's bytes, its output, a block's literals and sequences all sit in LDS while the one lane works (a dependent access costs
-// an LDS round trip, not an HBM one: 180 -> about 15 ns per byte); the other lanes copy the frame in and the output out.
+// The frame's bytes, its output, a block's literals and sequences all sit in LDS (a dependent access costs an LDS round trip, not an
+// HBM one).  EVERY lane of the one wavefront runs this routine: what is serial by nature (headers, FSE-coded weights, the sequences'
+// state machines) all 64 lanes compute alike -- same reads, same values written to the same LDS words, the time of one lane -- and
+// what is not is spread over them: copies and fills, the Huffman table (build_huf_one_lds), the four streams of a literals section
+// on four lanes, the execution of the sequences (literal runs beside each other, then the matches one after the other, each by the
+// whole wavefront).  One lane doing all of it took 120 - 180 us for the few hundred bytes of ids, names and lengths of an archive of
+// a hundred records -- which the emit of 10 GB waits for (profiles/r04_timeline_uniform_10GB.txt).
+struct SmallWS { HufLdsWS H; ZBlock b; ZStat st; };
 __device__ void small_frame_decode(const u8 *src, u32 len, u8 *dst, u32 cap, u8 *lit, u32 *sll, u32 *sml, u32 *sof, const FseE *predef,
-                                   HufBuildWS &ws, u16 *huf, FseE *fse, u8 *w, i16 *norm, u16 *nx, SmallRes *res, const u32 *llt, const u32 *mlt)
+                                   SmallWS &W, u16 *huf, FseE *fse, i16 *norm, u16 *nx, SmallRes *res, const u32 *llt, const u32 *mlt)
 {
+    const u32 lane = threadIdx.x;
     u32 err = 0, out = 0, pos = 0;
     ZFrameHdr fh = zstd_parse_frame_header(src, len);
     if (fh.err) { res->err = (u32)fh.err; res->out = 0; res->pos = 0; return; }
@@ -2028,8 +2036,9 @@ __device__ void small_frame_decode(const u8 *src, u32 len, u8 *dst, u32 cap, u8 
         pos += 3 + csize;
         if (type != BT_COMP) {
             if ((u64)out + size > cap) { err = SMALL_TOO_BIG; break; }
-            if (type == BT_RAW) for (u32 k = 0; k < size; k++) dst[out + k] = c[k];
-            else { const u8 v = c[0]; for (u32 k = 0; k < size; k++) dst[out + k] = v; }
+            if (type == BT_RAW) for (u32 k = lane; k < size; k += 64) dst[out + k] = c[k];
+            else { const u8 v = c[0]; for (u32 k = lane; k < size; k += 64) dst[out + k] = v; }
+            __syncthreads();
             out += size;
             if (last) break;
             continue;
@@ -2040,27 +2049,34 @@ __device__ void small_frame_decode(const u8 *src, u32 len, u8 *dst, u32 cap, u8 
         if ((u64)out + b.lit_regen > cap) { err = SMALL_TOO_BIG; break; }             // (lit is as large as the output buffer)
         // literals: straight into the output when the block has no sequences
         u8 *lp = b.nseq ? lit : dst + out;
-        if (b.lit_type == LIT_RAW) for (u32 k = 0; k < b.lit_regen; k++) lp[k] = c[b.lit_off + k];
-        else if (b.lit_type == LIT_RLE) { const u8 v = c[b.lit_off]; for (u32 k = 0; k < b.lit_regen; k++) lp[k] = v; }
+        if (b.lit_type == LIT_RAW) for (u32 k = lane; k < b.lit_regen; k += 64) lp[k] = c[b.lit_off + k];
+        else if (b.lit_type == LIT_RLE) { const u8 v = c[b.lit_off]; for (u32 k = lane; k < b.lit_regen; k += 64) lp[k] = v; }
         else {
             if (b.lit_type == LIT_HUF) {
-                u32 nw = 0, used = 0;
-                const u32 lg = huf_read_weights_ws(c + b.lit_off, b.lit_csize, w, &nw, &used, ws);
-                if (!lg || used != b.huf_streams_off - b.lit_off) { err = ZE_CORRUPT; break; }
-                huf_build_any_ws(huf, w, nw, lg, ws); huf_log = lg; have_huf = true;
+                __syncthreads();
+                if (lane == 0) { W.b = b; W.b.src_off = 0; }
+                __syncthreads();
+                build_huf_one_lds(c, &W.b, 0, nullptr, 0, &W.st, W.H, (u8 *)huf);
+                __syncthreads();
+                const u32 lg = W.H.log;
+                if (!lg) { err = ZE_CORRUPT; break; }
+                huf_log = lg; have_huf = true;
             } else if (!have_huf) { err = ZE_CORRUPT; break; }              // treeless without a previous table
             const u8 *sp = c + b.huf_streams_off;
-            if (b.nstreams == 1) { if (huf_decode_stream(sp, b.huf_streams_size, (const u16 *)huf, huf_log, lp, b.lit_regen)) { err = ZE_CORRUPT; break; } }
+            bool bad = false;
+            if (b.nstreams == 1) { if (lane == 0) bad = huf_decode_stream(sp, b.huf_streams_size, (const u16 *)huf, huf_log, lp, b.lit_regen) != 0; }
             else {
                 const u32 s1 = ld16(sp), s2 = ld16(sp + 2), s3 = ld16(sp + 4), tot = b.huf_streams_size - 6, per = (b.lit_regen + 3) / 4;
                 if (s1 + s2 + s3 >= tot || !s1 || !s2 || !s3 || per * 3 > b.lit_regen) { err = ZE_CORRUPT; break; }
-                const u32 offs[4] = { 0, s1, s1 + s2, s1 + s2 + s3 }, szs[4] = { s1, s2, s3, tot - s1 - s2 - s3 };
-                bool bad = false;
-                for (u32 k = 0; k < 4 && !bad; k++)
-                    bad = huf_decode_stream(sp + 6 + offs[k], szs[k], (const u16 *)huf, huf_log, lp + k * per, k < 3 ? per : b.lit_regen - 3 * per) != 0;
-                if (bad) { err = ZE_CORRUPT; break; }
+                if (lane < 4) {                                             // a lane per stream
+                    const u32 k = lane;
+                    const u32 o = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3)), z = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : tot - s1 - s2 - s3));
+                    bad = huf_decode_stream(sp + 6 + o, z, (const u16 *)huf, huf_log, lp + k * per, k < 3 ? per : b.lit_regen - 3 * per) != 0;
+                }
             }
+            if (__ballot(bad)) { err = ZE_CORRUPT; break; }
         }
+        __syncthreads();
         if (!b.nseq) { out += b.lit_regen; if (last) break; continue; }
         if (b.nseq > SMALL_SEQ) { err = SMALL_TOO_BIG; break; }
         // sequence tables (3.1.1.3.2.1): predefined, RLE, FSE description, or the table of the previous block
@@ -2088,20 +2104,30 @@ __device__ void small_frame_decode(const u8 *src, u32 len, u8 *dst, u32 cap, u8 
         const u64 regen = b.lit_regen + tm;
         if (regen > ZBLOCK_MAX) { err = ZE_CORRUPT; break; }
         if ((u64)out + regen > cap) { err = SMALL_TOO_BIG; break; }
+        __syncthreads();
+        // execution, 64 sequences at a time: where each one's literals come from and go to by a scan of the lengths; the literal runs
+        // of all of them at once (a lane each); then the matches in order, every one by the whole wavefront (a match that overlaps
+        // itself repeats its first `of` bytes)
         u32 op = out, l = 0; bool xbad = false;
-        for (u32 q = 0; q < b.nseq; q++) {
-            const u32 ll = sll[q], ml = sml[q], of = sym_resolve(sof[q], rep);
-            // eight bytes at a time (the lane waits an LDS round trip per access): what is copied past a run's end is overwritten by what
-            // follows it, and the buffers have 16 bytes of slack behind the frame's last byte
-            for (u32 k = 0; k < ll; k += 8) st64(dst + op + k, ld64(lit + l + k));
-            op += ll; l += ll;
-            if (of == 0 || of > op) { xbad = true; break; }
-            if (of >= 8) for (u32 k = 0; k < ml; k += 8) st64(dst + op + k, ld64(dst + op + k - of));
-            else for (u32 k = 0; k < ml; k++) dst[op + k] = dst[op + k - of];
-            op += ml;
+        for (u32 q0 = 0; q0 < b.nseq && !xbad; q0 += 64) {
+            const u32 q = q0 + lane; const bool on = q < b.nseq;
+            const u32 ll = on ? sll[q] : 0, ml = on ? sml[q] : 0;
+            const u32 ill = wave_scan_inclusive<u32, OpAdd>(ll), iml = wave_scan_inclusive<u32, OpAdd>(ml);
+            const u32 my_l = l + ill - ll, my_op = op + (ill - ll) + (iml - ml);
+            { u32 k = 0; for (; k + 8 <= ll; k += 8) st64(dst + my_op + k, ld64(lit + my_l + k)); for (; k < ll; k++) dst[my_op + k] = lit[my_l + k]; }
+            __syncthreads();
+            const u32 cnt = b.nseq - q0 < 64 ? b.nseq - q0 : 64;
+            for (u32 j = 0; j < cnt; j++) {
+                const u32 mop = (u32)__shfl((int)(my_op + ll), (int)j, 64), mlj = (u32)__shfl((int)ml, (int)j, 64), of = sym_resolve(sof[q0 + j], rep);
+                if (of == 0 || of > mop) { xbad = true; break; }
+                if (of >= mlj || of >= 64) for (u32 k0 = 0; k0 < mlj; k0 += 64) { const u32 k = k0 + lane; if (k < mlj) { const u8 v = dst[mop + k - of]; dst[mop + k] = v; } __syncthreads(); }
+                else { for (u32 k = lane; k < mlj; k += 64) dst[mop + k] = dst[mop - of + k % of]; __syncthreads(); }
+            }
+            op += (u32)__shfl((int)(ill + iml), 63, 64); l += (u32)__shfl((int)ill, 63, 64);
         }
         if (xbad) { err = ZE_CORRUPT; break; }
-        { const u32 rest = b.lit_regen - l; for (u32 k = 0; k < rest; k += 8) st64(dst + op + k, ld64(lit + l + k)); op += rest; }
+        { const u32 rest = b.lit_regen - l; for (u32 k = lane; k < rest; k += 64) dst[op + k] = lit[l + k]; op += rest; }
+        __syncthreads();
         { const u32 r0 = sym_resolve(ro[0], rep), r1 = sym_resolve(ro[1], rep), r2 = sym_resolve(ro[2], rep); rep[0] = r0; rep[1] = r1; rep[2] = r2; }
         out = op;
         if (last) break;
@@ -2115,11 +2141,10 @@ __global__ __launch_bounds__(64) void k_small_frame(const u8 *src, u32 len, u8 *
     __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     __shared__ __attribute__((aligned(16))) u8 s_src[SMALL_SRC + 16], s_out[SMALL_OUT + 16], s_lit[SMALL_OUT + 16];
     __shared__ u32 s_ll[SMALL_SEQ], s_ml[SMALL_SEQ], s_of[SMALL_SEQ];
-    __shared__ HufBuildWS ws;
+    __shared__ SmallWS W;
     __shared__ __attribute__((aligned(16))) u16 huf[HUF_TAB_MAX / 2];
     __shared__ FseE fse[512 + 256 + 512];
     __shared__ FseE s_predef[160];
-    __shared__ u8 w[256];
     __shared__ i16 norm[64];
     __shared__ u16 nx[64];
     __shared__ SmallRes r;
@@ -2129,7 +2154,7 @@ __global__ __launch_bounds__(64) void k_small_frame(const u8 *src, u32 len, u8 *
     for (u32 k = threadIdx.x; k < 16; k += 64) s_src[len + k] = 0;
     for (u32 k = threadIdx.x; k < 160; k += 64) s_predef[k] = predef[k];
     __syncthreads();
-    if (threadIdx.x == 0) small_frame_decode(s_src, len, s_out, cap < SMALL_OUT ? cap : SMALL_OUT, s_lit, s_ll, s_ml, s_of, s_predef, ws, huf, fse, w, norm, nx, &r, s_llt, s_mlt);
+    small_frame_decode(s_src, len, s_out, cap < SMALL_OUT ? cap : SMALL_OUT, s_lit, s_ll, s_ml, s_of, s_predef, W, huf, fse, norm, nx, &r, s_llt, s_mlt);
     __syncthreads();
     if (r.err == 0) for (u32 k = threadIdx.x; k < r.out; k += 64) dst[k] = s_out[k];
     if (threadIdx.x == 0) { res[0] = r.err; res[1] = r.out; res[2] = r.pos; }
@@ -2142,11 +2167,10 @@ __global__ __launch_bounds__(64) void k_small_frames(SmallJobs J, const FseE *pr
     __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     __shared__ __attribute__((aligned(16))) u8 s_src[SMALL_SRC + 16], s_out[SMALL_OUT + 16], s_lit[SMALL_OUT + 16];
     __shared__ u32 s_ll[SMALL_SEQ], s_ml[SMALL_SEQ], s_of[SMALL_SEQ];
-    __shared__ HufBuildWS ws;
+    __shared__ SmallWS W;
     __shared__ __attribute__((aligned(16))) u16 huf[HUF_TAB_MAX / 2];
     __shared__ FseE fse[512 + 256 + 512];
     __shared__ FseE s_predef[160];
-    __shared__ u8 w[256];
     __shared__ i16 norm[64];
     __shared__ u16 nx[64];
     __shared__ SmallRes r;
@@ -2158,7 +2182,7 @@ __global__ __launch_bounds__(64) void k_small_frames(SmallJobs J, const FseE *pr
     for (u32 k = threadIdx.x; k < 16; k += 64) s_src[len + k] = 0;
     for (u32 k = threadIdx.x; k < 160; k += 64) s_predef[k] = predef[k];
     __syncthreads();
-    if (threadIdx.x == 0) small_frame_decode(s_src, len, s_out, cap < SMALL_OUT ? cap : SMALL_OUT, s_lit, s_ll, s_ml, s_of, s_predef, ws, huf, fse, w, norm, nx, &r, s_llt, s_mlt);
+    small_frame_decode(s_src, len, s_out, cap < SMALL_OUT ? cap : SMALL_OUT, s_lit, s_ll, s_ml, s_of, s_predef, W, huf, fse, norm, nx, &r, s_llt, s_mlt);
     __syncthreads();
     if (r.err == 0) for (u32 k = threadIdx.x; k < r.out; k += 64) dst[k] = s_out[k];
     if (threadIdx.x == 0) { res[4 * j] = r.err; res[4 * j + 1] = r.out; res[4 * j + 2] = r.pos; }
