@@ -1971,6 +1971,32 @@ __global__ void k_seq_reach(const ZBlock *blk, const u32 *seq_list, u32 n_seq_bl
     f[bi] = lo;
 }
 __global__ void k_iota_u32(u32 *f, u32 n) { const u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) f[i] = i; }
+// The blocks a block's matches copy from, marked "to be decoded" (2) in the class table of a mostly-flat frame (ZFlat.cls): a lane per
+// block with sequences walks them; a source block that has sequences itself is in the table already and marks its own sources.
+__global__ void k_seq_sources(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *offs, const u32 *o_ll, const u32 *o_ml, const u32 *o_of, u8 *cls0)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seq_blk) return;
+    const u32 bi = seq_list[t];
+    const ZBlock &b = blk[bi];
+    if (b.err) return;
+    const u64 start = offs[bi];
+    u64 pos = start;
+    const u32 rep_in[3] = { b.rep_in[0], b.rep_in[1], b.rep_in[2] };
+    for (u32 q = 0; q < b.nseq; q++) {
+        const u32 ll = o_ll[b.seq_base + q], ml = o_ml[b.seq_base + q], off = sym_resolve(o_of[b.seq_base + q], rep_in);
+        pos += ll;
+        if (off && off <= pos && ml) {                          // (an offset beyond the start of the output is the executor's error to report)
+            const u64 src = pos - off, end = src + ml < start ? src + ml : start;
+            if (src < start) {
+                u32 lo = 0, hi = bi;                                // largest j with offs[j] <= src
+                while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (offs[mid] <= src) lo = mid; else hi = mid; }
+                for (u32 j = lo; j < bi && offs[j] < end; j++) cls0[j] = 2;
+            }
+        }
+        pos += ml;
+    }
+}
 // One wavefront: blocks [b_lo, b_hi) hold the wanted bytes (k_find_range); the closure's first block c is the least fixed point of
 // c = min(c, f[b] for b in [c, b_hi)).  out: [0] c, [1] b_hi, [2] offs[c], [3] offs[b_hi] (or the total), [4] block whose Huffman
 // table is in force at c, [5] / [6] ranks of c / b_hi among the blocks with sequences.
@@ -2642,6 +2668,67 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     if (n_seq_blk && (hs.rep_slow & 1)) LAUNCH(c, "zstd_rep_chain", k_rep_chain, 1, 64, 0, blk, nblk);
     *out_len = hs.total_out;
     if (fh.has_fcs && fh.content_size != hs.total_out) return zerr(c, ZE_CORRUPT, "content size mismatch");
+    // A frame that is mostly flat AND has a few blocks with matches -- what libzstd makes of packed random bases: one 4-bit tree,
+    // treeless blocks behind it, a chance match every few dozen blocks -- takes the mostly-flat way too: the blocks with sequences, the
+    // blocks their matches copy from (k_seq_sources) and the neighbours of both are decoded into d_dst (literals, then the executor,
+    // as below), everything else is read in place by the caller's emit.  Whole-stream calls (NAF_GPU_FLAT_SEQ=0: never).
+    {
+        const char *fm = getenv("NAF_GPU_FLAT_MIXED"), *fsq = getenv("NAF_GPU_FLAT_SEQ");
+        if (c->zflat && spec && n_seq_blk && tables_built && !fuse && !always_table && !rg && hs.flat_main_inv && d_dst && hs.total_out <= dst_cap &&
+            (u64)n_seq_blk * 8 <= nblk && !(fm && fm[0] == '0') && !(fsq && fsq[0] == '0')) {
+            const u32 main = 0xFFFFFFFFu - hs.flat_main_inv;
+            ZFlat *zf = c->zflat;
+            FlatStream *si = arena_new<FlatStream>(c, 4 * (size_t)nblk + 1); u8 *d_sym = (u8 *)arena_alloc(c, 16);
+            u8 *cls0 = (u8 *)arena_alloc(c, nblk), *cls = (u8 *)arena_alloc(c, nblk); u32 *d_nx = arena_new<u32>(c, 2);
+            u32 *done2 = arena_new<u32>(c, nblk); u8 *lits = (u8 *)arena_alloc(c, hs.total_out + 16);
+            if (!si || !d_sym || !cls0 || !cls || !d_nx || !done2 || !lits) return NAF_GPU_ENOMEM;
+            HIP_TRY(c, hipMemsetAsync(d_nx, 0, 8, c->stream));
+            LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, done2, (u32 *)nullptr, (u32 *)nullptr);
+            LAUNCH(c, "zstd_flat_class", k_flat_mark_owner, g, 64, 0, d_src, blk, nblk, (const i32 *)own_huf, main, 0u);
+            LAUNCH(c, "zstd_flat_class", k_flat_sym, 1, 256, 0, d_src, (const ZBlock *)blk, main, (const u8 *)huf_pool, d_sym);
+            LAUNCH(c, "zstd_flat_class", k_flat_class, g, 64, 0, (const ZBlock *)blk, nblk, (const i32 *)own_huf, cls0, d_nx + 1);
+            LAUNCH(c, "zstd_flat_class", k_seq_sources, cdiv(n_seq_blk, 64), 64, 0, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, cls0);
+            LAUNCH(c, "zstd_flat_class", k_flat_class2, g, 64, 0, (const u8 *)cls0, nblk, cls, d_nx);
+            u32 nx2[2] = { 0, 0 };
+            if ((rc = ctx_readback(c, nx2, d_nx, 8))) return rc;
+            const u32 n_dec = nx2[0], n_walk = nx2[1];
+            if (getenv("NAF_GPU_DEBUG_FLAT")) fprintf(stderr, "[flat mixed] nblk %u decoded %u main %u (blocks with sequences %u)\n", nblk, n_dec, main, n_seq_blk);
+            if ((u64)n_dec * 2 <= nblk) {
+                LAUNCH(c, "zstd_flat_streams", k_flat_streams_mixed, cdiv(4ull * nblk, 256), 256, 0, d_src, (const ZBlock *)blk, nblk, (const u8 *)cls, si, st, (const u64 *)d_total_out);
+                zf->decoded_ev = nullptr;
+                const ZStat hs0 = hs; naf_gpu_ctx *mc = c; naf_gpu_ctx *aux = zf->aux;
+                const u64 src_len64 = (u64)src_len;
+                zf->later = new std::function<int()>([=]() -> int {
+                    naf_gpu_ctx *c = aux ? aux : mc;
+                    if (c != mc) HIP_TRY(mc, hipStreamWaitEvent(c->stream, mc->split_ev[0], 0));      // recorded by the caller behind its tile index
+                    const u32 plog = n_walk ? huf_par_plog(hs0.max_lit_regen, n_walk) : 0u;
+                    LAUNCH(c, "zstd_copy_fill", k_copy_fill, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, d_dst, lits, 0u, (const u8 *)cls);
+                    LAUNCH(c, "zstd_flat_literals", k_flat_literals, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lits, st, 0u, (const u8 *)cls);
+                    if (n_walk && plog) {
+                        const u32 slot = huf_slot_bytes(hs0.max_huf_log);
+                        LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)nblk << (plog + 2), 64), 64, (plog >= 4 ? 1u : 16u >> plog) * slot,
+                               d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lits, st, 0u, plog, (const u8 *)cls, 1u, huf_par_margin_env(), 0u, src_len64);
+                    } else if (n_walk) {
+                        const u32 slot = huf_slot_bytes(hs0.max_huf_log), ipitch = hs0.max_huf_log > 7 ? HUF_IROW_BIG : HUF_IROW;
+                        EmitP ep; memset(&ep, 0, sizeof ep);
+                        LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(nblk, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512,
+                               d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lits, st, 0u, ep, (u8 *)nullptr, ipitch, src_len64, 1u, (const u8 *)cls);
+                    }
+                    const char *el = getenv("NAF_GPU_EXEC_LDS");
+                    if (hs0.max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
+                        LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, n_seq_blk, 64, ((hs0.max_seq_regen + 1023u) & ~1023u) + 64u, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
+                               (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lits, d_dst, done2, st, (hs0.max_seq_regen + 1023u) & ~1023u);
+                    else
+                        LAUNCH(c, "zstd_exec_seq", k_exec_seq, n_seq_blk, 64, 0, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
+                               (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lits, d_dst, done2, st);
+                    return 0;
+                });
+                zf->src = d_src; zf->si = si; zf->nslots = 4ull * nblk; zf->sym = d_sym; zf->status = st; zf->ready = true;
+                zf->tail = nullptr; zf->tail_q = hs.total_out; zf->tail_n = 0; zf->cls = cls; zf->n_decoded = n_dec;
+                return 0;
+            }
+        }
+    }
     // Range request (multi-GPU sharding): decode only the blocks that feed [want_lo, want_hi).  Needs blocks that
     // do not reference earlier output, i.e. a frame without sequences (this build's own frames; reference-made
     // random-ACGT frames); otherwise the whole frame is decoded.

@@ -541,6 +541,52 @@ def test_realistic_genome_both_ways_against_the_reference(gpu, oracle, monkeypat
         assert host(gpu.unnaf(gpu.to_device(ref_naf), 0, use_mask=False)) == oracle.ref_unnaf(ref_naf, ("--no-mask",))
 
 
+def test_reference_archive_of_random_bases_read_in_place_around_its_matches(gpu, oracle, monkeypatch, capfd):
+    """What the REFERENCE makes of packed random bases: one flat 4-bit tree, treeless blocks behind it, and a match every now and then
+    (here also a few planted repeats, near and far).  The blocks with sequences, the blocks their matches copy from and their neighbours
+    are decoded, the rest is read in place (zstd_dec.hip: k_seq_sources; "mostly flat" frames WITH matches).  Against the text, every
+    output mode of the tile kernels and NAF_GPU_FLAT_SEQ=0 (the two-pass decode); short frames forced through the same way."""
+    import re
+    import torch
+    from naf_amd import synth
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built")
+    monkeypatch.setenv("NAF_GPU_SPEC_MIN", "8")
+    for n, seed, width in ((40_000_000, 21, 80), (9_000_011, 22, 61)):
+        rng = np.random.default_rng(seed)
+        bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+        # repeats of 60 .. 3000 bases, 1 KB .. 400 KB back, at the same parity (the stream that is compressed holds two bases per byte)
+        for _ in range(40):
+            ln = int(rng.integers(60, 3000)); back = 2 * int(rng.integers(500, 200_000))
+            at = int(rng.integers(back + 10, n - ln - 10))
+            bases[at:at + ln] = bases[at - back:at - back + ln]
+        per = n // 3
+        text = b"".join(b">r%d planted repeats\n" % r + synth.wrap_lines(bases[r * per:(r + 1) * per if r < 2 else n], width) for r in range(3))
+        ref_naf = oracle.ref_ennaf(text)
+        info = oracle.zstd_frame_info(oracle.parse_naf(ref_naf).frame(ref_naf, 4))
+        assert info.seq_blocks > 0
+        d = gpu.to_device(ref_naf)
+        capfd.readouterr()
+        monkeypatch.setenv("NAF_GPU_DEBUG_FLAT", "1")
+        gpu.set_timing(True)
+        got = host(gpu.unnaf(d, 0))
+        ran = {x for x, ms, k in gpu.get_timing()}
+        gpu.set_timing(False)
+        monkeypatch.delenv("NAF_GPU_DEBUG_FLAT")
+        err = capfd.readouterr().err
+        assert got == text
+        m = re.search(r"\[flat mixed\] nblk (\d+) decoded (\d+) main \d+ \(blocks with sequences (\d+)\)", err)
+        assert m and 0 < int(m.group(3)) <= int(m.group(2)) * 1 and int(m.group(2)) * 2 <= int(m.group(1)), err
+        assert "unnaf_emit_flat" in ran and any(x.endswith("zstd_exec_seq") for x in ran), sorted(ran)
+        for mode, ll, mask in ((0, -1, False), (2, -1, True), (3, -1, True), (0, 50, True), (0, 0, True)):
+            a = host(gpu.unnaf(d, mode, line_length=ll, use_mask=mask))
+            monkeypatch.setenv("NAF_GPU_FLAT_SEQ", "0")
+            b = host(gpu.unnaf(d, mode, line_length=ll, use_mask=mask))
+            monkeypatch.delenv("NAF_GPU_FLAT_SEQ")
+            assert a == b, (mode, ll, mask)
+        assert oracle.ref_unnaf(ref_naf) == text
+
+
 @pytest.mark.parametrize("part,margin", [("64", "0"), ("64", "8"), ("256", "64"), ("1024", "0"), ("4096", "0")])
 def test_huffman_streams_decoded_in_parts(gpu, oracle, monkeypatch, part, margin):
     """k_huf_par: P lanes per Huffman stream, every part started inside its predecessor and re-walked until the starts agree

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""The decode of a REFERENCE-made archive of random bases (oracle/_ref/ennaf on the host, then this build's unnaf on the GPU):
+tools/perf_refarc.py [bytes]  -- per-call times and the kernel list; NAF_GPU_DEBUG_FLAT=1 shows how many blocks were decoded."""
+import os, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from naf_amd import capi, synth
+
+size = int(float(sys.argv[1])) if len(sys.argv) > 1 else int(4e9)
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ctx = capi.Context(0)
+text = synth.fasta_acgt_device(size, n_records=100, width=80, seed=2024, device="cuda")
+n = text.numel()
+d = "/dev/shm/refarc_%d" % os.getpid(); os.makedirs(d, exist_ok=True)
+try:
+    text.cpu().numpy().tofile(d + "/t.fa")
+    t0 = time.perf_counter()
+    subprocess.check_call([root + "/oracle/_ref/ennaf", d + "/t.fa", "-o", d + "/t.naf"], env=dict(os.environ, TMPDIR=d))
+    print("reference ennaf: %.1f s" % (time.perf_counter() - t0))
+    naf = torch.from_numpy(np.fromfile(d + "/t.naf", dtype=np.uint8)).to("cuda")
+finally:
+    subprocess.call(["rm", "-rf", d])
+ctx.reserve(int(n * 1.7) + (2 << 30))
+out = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+for it in range(6):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    r = ctx.unnaf(naf, capi.OUT_FASTA, out=out)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("unnaf call %d: %.2f ms  %.1f GB/s" % (it, dt * 1e3, n / dt / 1e9), flush=True)
+print("bit-exact:", bool(torch.equal(r, text)))
+ctx.set_timing(True); ctx.unnaf(naf, capi.OUT_FASTA, out=out)
+for nm, ms, k in sorted(ctx.get_timing(), key=lambda x: -x[1])[:22]:
+    print("   %-28s %8.3f ms x%d" % (nm, ms, k))
+print("   streams:", ["%.3f" % x for x in ctx.get_timing_streams()])
+ctx.set_timing(False)
