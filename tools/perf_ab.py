@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Two contexts of one process, made under two values of one of the library's switches, called turn by turn on the same data:
-tools/perf_ab.py NAF_GPU_POLL 0 1 [uniform|fastq|realistic|softmasked] [bytes]   (only for switches a context reads when it is made or per call;
-per-call switches are set before each call).  Prints the median / min of ten calls each for ennaf and unnaf."""
+"""Two values of one of the library's switches, called turn by turn on the same data:
+tools/perf_ab.py NAF_GPU_POLL 0 1 [uniform|fastq|realistic|softmasked] [bytes] [same]
+Two contexts of one process, each made under its value (a switch a context reads when it is made) -- the context made first tends to be
+the faster one by a few per cent, so run both orders -- or, with `same`, ONE context and the switch set before each call (a switch the
+library reads per call: most of them).  Prints the median / min of ten calls each for ennaf and unnaf."""
 import os
 import statistics
 import sys
@@ -13,7 +15,8 @@ from naf_amd import capi, synth
 
 name, va, vb = sys.argv[1], sys.argv[2], sys.argv[3]
 which = sys.argv[4] if len(sys.argv) > 4 else "uniform"
-size = int(float(sys.argv[5])) if len(sys.argv) > 5 else int(10e9 if which == "uniform" else 4e9)
+size = int(float(sys.argv[5])) if len(sys.argv) > 5 and sys.argv[5] != "same" else int(10e9 if which == "uniform" else 4e9)
+same = "same" in sys.argv[5:]
 mode = capi.OUT_FASTA
 if which == "fastq":
     text = synth.fastq_reads_device(size, seed=7, device="cuda"); mode = capi.OUT_FASTQ
@@ -27,6 +30,7 @@ n = text.numel()
 ctxs = []
 for v in (va, vb):
     os.environ[name] = v
+    if same and ctxs: ctxs.append(ctxs[0]); break
     c = capi.Context(0); c.reserve(int(n * 3.0) + (1 << 30)); ctxs.append(c)
 buf = torch.empty(int(ctxs[0].L.naf_gpu_ennaf_bound(n)), dtype=torch.uint8, device="cuda")
 out = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
