@@ -988,6 +988,74 @@ __global__ __launch_bounds__(256) void k_emit_tile(EmitP P, const TileIdx *ti, u
     if (a.fast != 1) return;
     emit_tile_body<FOURBIT>(P, a, out + (u64)blockIdx.x * 4096);
 }
+// The same with a wavefront per TW tiles (workgroups of 64; a tile's four KiB as four rows of 64 chunks): every lane has 4 TW loads
+// in flight behind one look at the tiles' records, waits for no other wavefront, and leaves its slot when its own stores are out
+// (k_emit_tile_flat_wave has the measurement).  The last tile of the text is never fast (k_tile_index), the records behind it read
+// fast = 0.
+template <bool FOURBIT, u32 TW>
+__global__ __launch_bounds__(64) void k_emit_tile_wave(EmitP P, const TileIdx *ti, u8 *out, u64 ntiles)
+{
+    __shared__ u64 s_tog[TW][EMIT_TOG_LDS];
+    const u32 lane = threadIdx.x;
+    const u64 t0 = (u64)blockIdx.x * TW;
+    TileIdx A[TW]; bool live[TW];
+#pragma unroll
+    for (u32 j = 0; j < TW; j++) { A[j] = ti[t0 + j < ntiles ? t0 + j : ntiles - 1]; live[j] = t0 + j < ntiles && A[j].fast == 1; }
+    u64 g0s[TW][4]; u32 nls[TW][4]; uint4 Q[TW][4];
+#pragma unroll
+    for (u32 j = 0; j < TW; j++) {
+        const TileIdx &a = A[j];
+#pragma unroll
+        for (u32 r = 0; r < 4; r++) {
+            const u32 lane16 = (r * 64 + lane) * 16;
+            u64 g0; u32 nl_b = 64;
+            if (P.mode == EM_FASTA && P.L != 0) {
+                const u32 Lp1 = (u32)P.L + 1;
+                u32 c = a.col + lane16, dl;
+                if (Lp1 < 32768) dl = __umulhi(c, P.Ldiv_magic); else dl = c >= Lp1 ? 1u : 0u;
+                u32 col = c - dl * Lp1;
+                g0 = a.gline + (u64)dl * (u32)P.L + col;
+                u32 d = (u32)P.L - col;
+                nl_b = d < 16 ? d : 64;
+            } else g0 = a.gline + lane16;
+            g0s[j][r] = g0; nls[j][r] = nl_b;
+            // (a tile that is not fast has no geometry to speak of, and the packed stream of a range call starts at its first base: no load)
+            if (FOURBIT) Q[j][r] = live[j] ? ldg_at<uint4>(((u64)P.seq + (g0 >> 1)) & ~7ull) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    if (P.masking) {
+#pragma unroll
+        for (u32 j = 0; j < TW; j++) {
+            const u64 nt = A[j].khi - A[j].k;
+            for (u32 i = lane; i < EMIT_TOG_LDS; i += 64) s_tog[j][i] = (live[j] && i < nt && nt <= EMIT_TOG_LDS) ? P.toggles[A[j].k + i] : 0ull;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (u32 j = 0; j < TW; j++) {
+        if (!live[j]) continue;
+        const TileIdx &a = A[j];
+        const u32 ntog = (u32)(a.khi - a.k < EMIT_TOG_LDS ? a.khi - a.k : EMIT_TOG_LDS);
+        const bool use_tog = P.masking && a.k < a.khi && a.khi - a.k <= EMIT_TOG_LDS;
+#pragma unroll
+        for (u32 r = 0; r < 4; r++) {
+            const u64 g0 = g0s[j][r];
+            u64 lo, hi;
+            if (FOURBIT) {
+                const u64 addr = (u64)P.seq + (g0 >> 1);
+                const uint4 q = Q[j][r];
+                const u64 q0 = (u64)q.x | ((u64)q.y << 32), q1 = (u64)q.z | ((u64)q.w << 32);
+                const u32 sh = (u32)(addr & 7) * 8 + (u32)(g0 & 1) * 4;
+                expand16(P.lut, sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0, lo, hi);
+            } else bases16<false>(P, g0, lo, hi);
+            if (use_tog) mask16_from(s_tog[j], ntog, a.k, g0, lo, hi);
+            else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
+            if (nls[j][r] < 16) splice_newline(lo, hi, (int)nls[j][r]);
+            uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
+            st_text16(out + (t0 + j) * 4096 + (r * 64 + lane) * 16, v, P.nt_store);
+        }
+    }
+}
 // the tiles of a list (its length stays on the device): the decoded stretches of a mostly-flat frame
 template <bool FOURBIT>
 __global__ __launch_bounds__(256) void k_emit_tile_list(EmitP P, const TileIdx *ti, const u32 *list, const u32 *count, u8 *out)
@@ -1011,6 +1079,20 @@ __global__ void k_flat_pair(EmitP P, u32 *pair)               // sixteen-entry t
 {
     // [0..3] code -> packed byte; [4..7] code -> character of the byte's first base (low nibble, encoders.c:44-57); [8..11] -> of its second
     const u32 t = threadIdx.x;
+    // [16 .. 272): two codes -> their four characters; [272 .. 400): the line-end splice table, 32 x uint4 (k_emit_tile_flat_wave copies
+    // both into its LDS: a table made by 64 lanes per tile would cost four times what the 256 of k_emit_tile_flat spend on it)
+    {
+        const u32 pa = P.fsym[t >> 4], pb = P.fsym[t & 15];
+        pair[16 + t] = expand_codes4(P.lut, (pa & 15u) | ((pa >> 4) << 8) | ((pb & 15u) << 16) | ((pb >> 4) << 24));
+        if (t < 16) {
+            const u32 d = t; u32 sel[4], orv[4];
+            for (u32 i = 0; i < 4; i++) {
+                sel[i] = 0; orv[i] = 0;
+                for (u32 j = 0; j < 4; j++) { const u32 q = 4 * i + j; sel[i] |= (q < d ? 4 + j : (q == d ? 0x0Cu : 3 + j)) << (8 * j); if (q == d) orv[i] |= 0x0Au << (8 * j); }
+            }
+            for (u32 i = 0; i < 4; i++) { pair[272 + 8 * d + i] = sel[i]; pair[272 + 8 * d + 4 + i] = orv[i]; }
+        }
+    }
     if (t >= 12) return;
     const u8 *lut = (const u8 *)P.lut;
     u32 v = 0;
@@ -1155,6 +1237,115 @@ __global__ __launch_bounds__(256) void k_emit_tile_flat(EmitP P, const TileIdx *
             v.z = __builtin_amdgcn_perm(x2, x1, sel.z) | orv.z; v.w = __builtin_amdgcn_perm(x3, x2, sel.w) | orv.w;
         }
         st_text16(out + t * 4096 + lane16, v, P.nt_store);
+    }
+}
+
+// The same with a WAVEFRONT per tile (workgroups of 64): TW tiles per wavefront, a tile's four KiB as four rows of 64 chunks.  A wavefront
+// reads the records of its own tiles only (a quarter of the scalar loads per wavefront of the kernel above), waits for no other
+// wavefront, and its slot is free again as soon as its own stores are out.  Tables from k_flat_pair's global copies.
+template <u32 TW>
+__global__ __launch_bounds__(64) void k_emit_tile_flat_wave(EmitP P, const TileIdx *ti, const TileFlat *tsig, u8 *out, u64 ntiles, u32 xcd_chunk)
+{
+    u32 wg = blockIdx.x;
+    if (xcd_chunk) { wg = (blockIdx.x & 7u) * xcd_chunk + (blockIdx.x >> 3); if ((u64)wg * TW >= ntiles) return; }
+    __shared__ u64 s_tog[TW][EMIT_TOG_LDS];
+    __shared__ uint4 s_spl[32];
+    __shared__ u32 s_pair[256];
+    const u32 lane = threadIdx.x;
+    if (lane < 32) s_spl[lane] = ((const uint4 *)(P.fpair + 272))[lane];
+    ((uint4 *)s_pair)[lane] = ((const uint4 *)(P.fpair + 16))[lane];
+    TileIdx A[TW]; TileFlatE F[TW]; bool live[TW];
+    {
+        const u64 t0 = (u64)wg * TW;
+        const uint4 *pa = (const uint4 *)(ti + t0), *pf = (const uint4 *)(tsig + t0);
+        uint4 ra[2 * TW], rf[3 * TW];
+#pragma unroll
+        for (u32 i = 0; i < 2 * TW; i++) ra[i] = pa[i];
+#pragma unroll
+        for (u32 i = 0; i < 3 * TW; i++) rf[i] = pf[i];
+#pragma unroll
+        for (u32 j = 0; j < TW; j++) {
+            __builtin_memcpy(&A[j], &ra[2 * j], 32); __builtin_memcpy(&F[j], &rf[3 * j], 48);
+            live[j] = t0 + j < ntiles && A[j].fast == 1;
+        }
+    }
+    u64 X[TW][4]; u32 grels[TW][4], pk[TW][4];                  // pk: line-end position | symbols left in the stream << 8 | bit offset of the codes in their byte << 16
+#pragma unroll
+    for (u32 j = 0; j < TW; j++) {
+        const TileIdx &a = A[j]; const TileFlatE &e = F[j];
+#pragma unroll
+        for (u32 r = 0; r < 4; r++) {
+            const u32 lane16 = (r * 64 + lane) * 16;
+            u32 grel, nl_b = 64;
+            if (P.mode == EM_FASTA && P.L != 0) {
+                const u32 Lp1 = (u32)P.L + 1;
+                u32 c = a.col + lane16, dl;
+                if (Lp1 < 32768) dl = __umulhi(c, P.Ldiv_magic); else dl = c >= Lp1 ? 1u : 0u;
+                u32 col = c - dl * Lp1;
+                grel = dl * (u32)P.L + col;
+                u32 d = (u32)P.L - col;
+                nl_b = d < 16 ? d : 64;
+            } else grel = lane16;
+            grels[j][r] = grel;
+            const u32 par = e.par0 + grel;
+            const u32 need = 8 + (par & 1u);
+            const u32 qrel = (par >> 1) + e.qoff;
+            const bool second = qrel >= e.d1;
+            const u32 qm = live[j] ? ~0u : 0u;
+            const u32 off = (second ? e.K1 : e.K0) - ((4 * qrel) & qm);
+            const u32 rem = (second ? e.d2 : e.d1) - qrel;
+            X[j][r] = ldg_at_unaligned<u64>(e.base + (off >> 3));
+            pk[j][r] = nl_b | ((need > rem ? rem : 16u) << 8) | ((off & 7u) << 16);
+        }
+    }
+    if (P.masking) {
+#pragma unroll
+        for (u32 j = 0; j < TW; j++) {
+            const u64 nt = A[j].khi - A[j].k;
+            for (u32 i = lane; i < EMIT_TOG_LDS; i += 64) s_tog[j][i] = (live[j] && i < nt && nt <= EMIT_TOG_LDS) ? P.toggles[A[j].k + i] : 0ull;
+        }
+    }
+    __syncthreads();                                              // (one wavefront: the tables and toggles it has just written)
+#pragma unroll
+    for (u32 j = 0; j < TW; j++) {
+        const u64 t = (u64)wg * TW + j;
+        if (!live[j]) continue;
+        const TileIdx &a = A[j];
+        const u32 ntog = (u32)(a.khi - a.k < EMIT_TOG_LDS ? a.khi - a.k : EMIT_TOG_LDS);
+        const bool use_tog = P.masking && a.k < a.khi && a.khi - a.k <= EMIT_TOG_LDS;
+#pragma unroll
+        for (u32 r = 0; r < 4; r++) {
+            const u64 g0 = a.gline + grels[j][r];
+            const u32 nl = pk[j][r] & 0xFFu, have = (pk[j][r] >> 8) & 0xFFu;
+            u64 h36 = X[j][r] >> ((pk[j][r] >> 16) + 4);
+            if (have < 9) {
+                const u64 y = ldg_at_unaligned<u64>(F[j].a1_addr);
+                const u64 n36 = (y >> F[j].a1_sh) & 0xFFFFFFFFFull;
+                const u32 keep = 4 * have;
+                h36 = (h36 & ~(0xFFFFFFFFFull >> keep)) | (n36 >> keep);
+            }
+            const u32 h = (u32)(h36 >> 4), n9 = (u32)h36 & 15u;
+            u64 lo, hi;
+            {
+                u32 w0 = s_pair[h >> 24], w1 = s_pair[(h >> 16) & 0xFFu], w2 = s_pair[(h >> 8) & 0xFFu], w3 = s_pair[h & 0xFFu];
+                if (g0 & 1) {
+                    const u32 c9 = s_pair[n9 << 4];
+                    w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+                    w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 = __builtin_amdgcn_alignbyte(c9, w3, 1);
+                }
+                lo = (u64)w0 | ((u64)w1 << 32); hi = (u64)w2 | ((u64)w3 << 32);
+            }
+            if (use_tog) mask16_from(s_tog[j], ntog, a.k, g0, lo, hi);
+            else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
+            uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
+            if (nl < 16) {
+                const uint4 sel = s_spl[2 * nl], orv = s_spl[2 * nl + 1];
+                const u32 x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+                v.x = __builtin_amdgcn_perm(x0, 0u, sel.x) | orv.x; v.y = __builtin_amdgcn_perm(x1, x0, sel.y) | orv.y;
+                v.z = __builtin_amdgcn_perm(x2, x1, sel.z) | orv.z; v.w = __builtin_amdgcn_perm(x3, x2, sel.w) | orv.w;
+            }
+            st_text16(out + t * 4096 + (r * 64 + lane) * 16, v, P.nt_store);
+        }
     }
 }
 
@@ -1897,10 +2088,11 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             // With a split decode (ZSplit) the index and the tiles behind the finished parts run on the second stream beside the
             // decode of the next part; this stream takes the tiles behind the last part, the boundary tiles, and waits for the other.
             naf_gpu_ctx *ic = split.done ? c->side2 : c;                                     // context the tile index is built on
+            const bool tile_wave = !(getenv("NAF_GPU_EMIT_WAVE") && getenv("NAF_GPU_EMIT_WAVE")[0] == '0');      // k_emit_tile_wave / k_emit_tile_flat_wave ("0": the workgroups of 256)
             if (split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 8, ic->stream));
             TileFlat *tsig = nullptr;
             if (zflat.ready) {
-                tsig = arena_new<TileFlat>(c, ntiles + 2 + FLAT_TPW); u32 *fpair = arena_new<u32>(c, 256); if (!tsig || !fpair) return NAF_GPU_ENOMEM;
+                tsig = arena_new<TileFlat>(c, ntiles + 2 + FLAT_TPW); u32 *fpair = arena_new<u32>(c, 400); if (!tsig || !fpair) return NAF_GPU_ENOMEM;
                 LAUNCH(ic, "unnaf_flat_pair", k_flat_pair, 1, 256, 0, pl.P, fpair);
                 pl.P.fpair = fpair;
             }
@@ -1923,7 +2115,9 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                     if (t_hi > ntiles) t_hi = ntiles;
                     if (t_hi <= t_done) continue;
                     HIP_TRY(c, hipStreamWaitEvent(ic->stream, split.ev[k], 0));
-                    if (pl.fourbit) LAUNCH(ic, "unnaf_emit", k_emit_tile<true>, (u32)(t_hi - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
+                    if (tile_wave && pl.fourbit) LAUNCH(ic, "unnaf_emit", (k_emit_tile_wave<true, 2>), cdiv(t_hi - t_done, 2u), 64, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096, (u64)(t_hi - t_done));
+                    else if (tile_wave) LAUNCH(ic, "unnaf_emit", (k_emit_tile_wave<false, 2>), cdiv(t_hi - t_done, 2u), 64, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096, (u64)(t_hi - t_done));
+                    else if (pl.fourbit) LAUNCH(ic, "unnaf_emit", k_emit_tile<true>, (u32)(t_hi - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
                     else LAUNCH(ic, "unnaf_emit", k_emit_tile<false>, (u32)(t_hi - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
                     t_done = t_hi;
                 }
@@ -1933,6 +2127,15 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             if (zflat.ready) {
                 // four tiles per workgroup (eight measured slower: DESIGN.md section 8), workgroups dealt to the XCDs in contiguous chunks
                 const u32 nwg = cdiv(ntiles, 4u), chunk = (nwg + 7) / 8;
+                // A frame that is read in place everywhere: a wavefront per two tiles (per tile when there are mask toggles to stage), in
+                // workgroups of 64 -- 3.17 -> 2.44 ms per 10 GB against four tiles per workgroup of 256 (k_emit_tile_flat_wave).  A mostly-flat
+                // frame keeps the workgroups of 256: beside them the decode job's kernels find the LDS they need (a realistic genome,
+                // 4 GB: 3.11 -> 3.30 / 3.57 ms with two / one tile per wavefront).  NAF_GPU_EMIT_WAVE=0: always those.
+                const char *ew = getenv("NAF_GPU_EMIT_WAVE");
+                const bool wave = !flat_job && !(zflat.cls && zflat.n_decoded) && !(ew && ew[0] == '0');
+                if (wave && pl.P.masking) { const u32 ch = ((u32)ntiles + 7) / 8; LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat_wave<1>, ch * 8, 64, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, ch); }
+                else if (wave) { const u32 ch = (cdiv(ntiles, 2u) + 7) / 8; LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat_wave<2>, ch * 8, 64, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, ch); }
+                else
                 LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat<4>, chunk * 8, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, chunk);
                 if (flat_job) {                                                               // (queued behind the flat emit: the job waits for its tables on the host)
                     if ((rc = zstd_flat_later(c, &zflat))) return rc;
@@ -1946,7 +2149,9 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                 }
             }
             else if (t_done < ntiles) {
-                if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit_tile<true>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
+                if (tile_wave && pl.fourbit) LAUNCH(c, "unnaf_emit", (k_emit_tile_wave<true, 2>), cdiv(ntiles - t_done, 2u), 64, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096, (u64)(ntiles - t_done));
+                else if (tile_wave) LAUNCH(c, "unnaf_emit", (k_emit_tile_wave<false, 2>), cdiv(ntiles - t_done, 2u), 64, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096, (u64)(ntiles - t_done));
+                else if (pl.fourbit) LAUNCH(c, "unnaf_emit", k_emit_tile<true>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
                 else LAUNCH(c, "unnaf_emit", k_emit_tile<false>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
             }
             // tiles holding a header or a record boundary (their number stays on the device)
