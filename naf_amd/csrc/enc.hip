@@ -500,17 +500,12 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
 // neighbouring lanes touch neighbouring bytes, all four in flight together); the whole tile is in one wavefront, so counts, the
 // position of the last line end and the lattice test need no LDS and no barrier.  A tile that is not pure (it starts in a header, is
 // not wholly inside the text, or holds anything but plain letters and line ends) is left to k_enc_count (t_needf / t_need).
-__global__ __launch_bounds__(256) void k_enc_count_pure(EncP P, const i64 *tile_eol, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
-                                                         u32 *t_needf, u64 *t_need, u64 tiles)
+// one tile of k_enc_count_pure: v = the tile's bytes, sixteen per lane and quarter (loaded by the caller when `inside`)
+__device__ __forceinline__ void count_pure_tile(const EncP &P, const i64 *tile_eol, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
+                                                u32 *t_needf, u64 *t_need, u64 t, bool inside, const uint4 (&v)[4])
 {
     const u32 lane = threadIdx.x & 63;
-    const u64 t = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= tiles) return;
-    if (!tile_may_be_pure(P, tile_eol, t)) { if (lane == 0) { t_needf[t] = 1; t_need[t] = 1; } return; }
-    const u8 *tp = P.text + t * ET_TILE;
-    uint4 v[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) __builtin_memcpy(&v[k], tp + (64u * (u32)k + lane) * ET_BYTES, 16);
+    if (!inside || !tile_may_be_pure(P, tile_eol, t)) { if (lane == 0) { t_needf[t] = 1; t_need[t] = 1; } return; }
     u32 eol[4]; bool plain = true; u32 has_n = 0, lower = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -556,6 +551,30 @@ __global__ __launch_bounds__(256) void k_enc_count_pure(EncP P, const i64 *tile_
         t_tail[t] = any ? ((ET_TILE - 1 - lastpos) | 0x80000000u) : tot;
         t_needf[t] = 0; t_need[t] = 0;
     }
+}
+// TW tiles per wavefront, the loads of all of them in flight before the first is looked at (two measured slower than one: 2.23 -> 2.55 ms
+// per 10 GB, the call 8.0 -> 8.2 ms)
+template <u32 WPW, u32 TW>
+__global__ __launch_bounds__(64 * WPW) void k_enc_count_pure(EncP P, const i64 *tile_eol, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
+                                                         u32 *t_needf, u64 *t_need, u64 tiles)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u64 t0 = ((u64)blockIdx.x * WPW + (threadIdx.x >> 6)) * TW;
+    // the tile's sixteen bytes per lane and quarter are asked for BEFORE the look at the line in front of the tile (two dependent loads
+    // of its own): three memory latencies in a row were two too many for a kernel that does nothing else
+    uint4 v[TW][4]; bool inside[TW];
+#pragma unroll
+    for (u32 j = 0; j < TW; j++) {
+        const u64 t = t0 + j;
+        inside[j] = t < tiles && t * ET_TILE >= P.p0 && (t + 1) * ET_TILE <= P.n;
+        if (inside[j]) {
+            const u8 *tp = P.text + t * ET_TILE;
+#pragma unroll
+            for (int k = 0; k < 4; k++) __builtin_memcpy(&v[j][k], tp + (64u * (u32)k + lane) * ET_BYTES, 16);
+        }
+    }
+#pragma unroll
+    for (u32 j = 0; j < TW; j++) if (t0 + j < tiles) count_pure_tile(P, tile_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, t0 + j, inside[j], v[j]);
 }
 __global__ void k_need_list(const u32 *t_needf, const u64 *pre, u64 tiles, u32 *list, const u32 *t_reg = nullptr)
 {
@@ -834,6 +853,8 @@ __device__ __forceinline__ u64 tile_line_base(const EncP &P, const EncOut &O, co
 // 2-byte ones).  Quads that reach over the tile's ends go group by group (atomic OR into the groups shared with the neighbours).
 // Tiles that are not regular are skipped here and done by k_enc_scatter, which skips the regular ones.
 #define REG_TPW 4
+// workgroups of one wavefront for the kernels that work a wavefront per tile anyway (NAF_GPU_ENC_WAVE=0: four wavefronts per workgroup)
+static bool enc_wave_wg() { const char *e = getenv("NAF_GPU_ENC_WAVE"); return !(e && e[0] == '0'); }
 struct RegGroup { u32 ga, gb, e, nb; };
 __device__ __forceinline__ void reg_group_geometry(u32 j, u32 o, u32 span, u32 p1, u32 W, float rW, RegGroup &g, u32 &x)
 {
@@ -913,14 +934,15 @@ __device__ __forceinline__ void reg_group_store(const EncOut &O, u64 G, const Re
         if (O.casebits) atomicOr(O.casebits + (G >> 1), cb << (16 * (u32)(G & 1)));
     }
 }
-__global__ __launch_bounds__(256) void k_enc_scatter_regular(EncP P, const i64 *tile_eol, EncOut O, u64 tiles)
+template <u32 TPW>
+__global__ __launch_bounds__(64 * TPW) void k_enc_scatter_regular(EncP P, const i64 *tile_eol, EncOut O, u64 tiles)
 {
     // per wavefront: the tile's packed groups and case bits on their way from "a group per lane" (loads of neighbouring lanes touch
     // neighbouring bytes) to "four groups per lane" (wide stores); slot = group index inside the tile + lead
-    __shared__ __attribute__((aligned(16))) u64 s_pk[REG_TPW][264];
-    __shared__ __attribute__((aligned(16))) u16 s_cb[REG_TPW][264];
+    __shared__ __attribute__((aligned(16))) u64 s_pk[TPW][264];
+    __shared__ __attribute__((aligned(16))) u16 s_cb[TPW][264];
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const u64 t = (u64)blockIdx.x * REG_TPW + wv;                      // the wavefront's tile
+    const u64 t = (u64)blockIdx.x * TPW + wv;                          // the wavefront's tile
     if (t >= tiles) return;
     const u32 reg = O.t_reg[t];
     const u64 tb = O.t_seq[t];
@@ -2047,7 +2069,8 @@ struct EnnafSplit {
 static int ennaf_scatter4(naf_gpu_ctx *c, const EnnafSplit::Scatter4 &R, u8 *packed, u64 *casebits)
 {
     if (R.T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(R.tiles, 256), 256, 0, R.t_seq, R.tiles, R.T, packed, (u32 *)casebits, R.O.direct, R.O.nd);
-    if (R.n >= 2 * ET_TILE) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular, cdiv(R.tiles, REG_TPW), 256, 0, R.P, R.t_eol, R.O, R.tiles);   // (shorter texts have no regular tile)
+    if (R.n >= 2 * ET_TILE && enc_wave_wg()) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular<1>, (u32)R.tiles, 64, 0, R.P, R.t_eol, R.O, R.tiles);
+    else if (R.n >= 2 * ET_TILE) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular<REG_TPW>, cdiv(R.tiles, REG_TPW), 256, 0, R.P, R.t_eol, R.O, R.tiles);   // (shorter texts have no regular tile)
     if (R.n_irregular) LAUNCH(c, "ennaf_scatter", k_enc_scatter<true>, R.n_irregular, 256, 0, R.P, R.t_eol, R.t_sp, R.O);
     return 0;
 }
@@ -2234,7 +2257,8 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
             // pure tiles (nearly all of a genome) a wavefront per tile; the others, from a list, by the general kernel
             u32 *t_needf = arena_new<u32>(c, tiles + 1), *need_list = arena_new<u32>(c, tiles + 1); u64 *t_need = arena_new<u64>(c, tiles + 2);
             if (!t_needf || !need_list || !t_need) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "ennaf_count_pure", k_enc_count_pure, cdiv(tiles, 4), 256, 0, P, (const i64 *)t_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, tiles);
+            if (enc_wave_wg()) LAUNCH(c, "ennaf_count_pure", (k_enc_count_pure<1, 1>), (u32)tiles, 64, 0, P, (const i64 *)t_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, tiles);
+            else LAUNCH(c, "ennaf_count_pure", (k_enc_count_pure<4, 1>), cdiv(tiles, 4), 256, 0, P, (const i64 *)t_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, tiles);
             if ((rc = scan_exclusive_u64(c, t_need, tiles, tot + 5))) return rc;
             LAUNCH(c, "ennaf_need_list", k_need_list, cdiv(tiles, 256), 256, 0, (const u32 *)t_needf, (const u64 *)t_need, tiles, need_list, (const u32 *)nullptr);
             u64 n_need = 0;
