@@ -767,18 +767,20 @@ __global__ __launch_bounds__(256) void k_emit_short(EmitP P, u8 *out)
 // ER_LANES lanes per read, 256 / ER_LANES reads per workgroup: a workgroup's time is two rounds of dependent loads whatever it moves, so
 // short reads go many to a workgroup (150-base reads, 4 GB of text: 3.8 ms with 16 lanes per read, 2.9 with 8, 2.4 with 4); the host picks
 // the widest grouping whose reads still fit the LDS stage on average.
-template <bool FOURBIT, u32 ER_LANES>
-__global__ __launch_bounds__(256) void k_emit_fastq_records(EmitP P, u8 *out)
+// WGT: threads per workgroup -- 64 (a wavefront on its own: its slot and its LDS come and go with its own reads; 4 GB of 150-base reads:
+// 2.33 -> 2.19 ms; NAF_GPU_EMIT_WAVE=0: 256)
+template <bool FOURBIT, u32 ER_LANES, u32 WGT>
+__global__ __launch_bounds__(WGT) void k_emit_fastq_records(EmitP P, u8 *out)
 {
-    constexpr u32 ER_READS = 256u / ER_LANES;
+    constexpr u32 ER_READS = WGT / ER_LANES, STAGE = ER_STAGE / (256u / WGT);
     // the reads of a workgroup are one contiguous piece of text: assembled in LDS (their pieces start at arbitrary byte
     // offsets) and written out as aligned 16-byte stores; only when it does not fit (long reads) the pieces go straight to HBM
-    __shared__ __attribute__((aligned(16))) u8 stage[ER_STAGE + 32];
+    __shared__ __attribute__((aligned(16))) u8 stage[STAGE + 32];
     const u32 g = threadIdx.x & (ER_LANES - 1);
     const u64 r0 = (u64)blockIdx.x * ER_READS, r = r0 + threadIdx.x / ER_LANES;
     const u64 rend = r0 + ER_READS < P.N ? r0 + ER_READS : P.N;
     const u64 wbase = P.rec_out[r0], wspan = P.rec_out[rend] - wbase;
-    const bool in_lds = wspan <= ER_STAGE;
+    const bool in_lds = wspan <= STAGE;
     if (r < P.N) {
         const u64 len = P.rec_len[r], base = P.rec_base[r];
         const u32 hl = P.hdr_len[r];
@@ -807,12 +809,12 @@ __global__ __launch_bounds__(256) void k_emit_fastq_records(EmitP P, u8 *out)
     u32 head = (u32)((16 - ((uintptr_t)dst & 15)) & 15); if (head > n) head = n;
     if (threadIdx.x < head) dst[threadIdx.x] = stage[threadIdx.x];
     u32 words = (n - head) >> 4;
-    for (u32 w = threadIdx.x; w < words; w += 256) {
+    for (u32 w = threadIdx.x; w < words; w += WGT) {
         u64 a, b2; __builtin_memcpy(&a, stage + head + 16 * w, 8); __builtin_memcpy(&b2, stage + head + 16 * w + 8, 8);
         uint4 v; v.x = (u32)a; v.y = (u32)(a >> 32); v.z = (u32)b2; v.w = (u32)(b2 >> 32);
         st_text16(dst + head + 16 * w, v, P.nt_store);
     }
-    for (u32 k = head + 16 * words + threadIdx.x; k < n; k += 256) dst[k] = stage[k];
+    for (u32 k = head + 16 * words + threadIdx.x; k < n; k += WGT) dst[k] = stage[k];
 }
 
 // ---- long-record emit: one 4 KiB tile per workgroup, one 16-byte chunk per lane ---------------------------------------
@@ -2046,16 +2048,13 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             {
                 const u64 avg = pl.P.N ? (pl.P.out_end - pl.P.out_begin) / pl.P.N + 1 : 1;        // bytes of text per read
                 const u32 lanes = avg * 64 <= ER_STAGE * 7 / 8 ? 4u : avg * 32 <= ER_STAGE * 7 / 8 ? 8u : 16u;
-                const u32 grid = (u32)cdiv(pl.P.N, 256u / lanes);
-                if (pl.fourbit) {
-                    if (lanes == 4) LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<true, 4>), grid, 256, 0, pl.P, d_out);
-                    else if (lanes == 8) LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<true, 8>), grid, 256, 0, pl.P, d_out);
-                    else LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<true, 16>), grid, 256, 0, pl.P, d_out);
-                } else {
-                    if (lanes == 4) LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<false, 4>), grid, 256, 0, pl.P, d_out);
-                    else if (lanes == 8) LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<false, 8>), grid, 256, 0, pl.P, d_out);
-                    else LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<false, 16>), grid, 256, 0, pl.P, d_out);
-                }
+                const bool w1 = !(getenv("NAF_GPU_EMIT_WAVE") && getenv("NAF_GPU_EMIT_WAVE")[0] == '0');
+                const u32 wgt = w1 ? 64u : 256u, grid = (u32)cdiv(pl.P.N, wgt / lanes);
+#define ER_LAUNCH(FB, LN) do { if (w1) LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<FB, LN, 64>), grid, 64, 0, pl.P, d_out); \
+                               else LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<FB, LN, 256>), grid, 256, 0, pl.P, d_out); } while (0)
+                if (pl.fourbit) { if (lanes == 4) ER_LAUNCH(true, 4); else if (lanes == 8) ER_LAUNCH(true, 8); else ER_LAUNCH(true, 16); }
+                else { if (lanes == 4) ER_LAUNCH(false, 4); else if (lanes == 8) ER_LAUNCH(false, 8); else ER_LAUNCH(false, 16); }
+#undef ER_LAUNCH
             }
         } else if (short_rec) {
             if (pl.P.mode == EM_FASTA || pl.P.mode == EM_FASTQ) {
