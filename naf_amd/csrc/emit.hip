@@ -1352,10 +1352,10 @@ __global__ __launch_bounds__(64) void k_emit_tile_flat_wave(EmitP P, const TileI
 }
 
 template <bool FOURBIT>
-__device__ __forceinline__ void emit_rest_tile(const EmitP &P, const TileIdx *ti, const u64 *tr, u64 t, u8 *out)
+__device__ __forceinline__ void emit_rest_tile(const EmitP &P, const TileIdx *ti, const u64 *tr, u64 t, u8 *out, u32 chunk)
 {
     const TileIdx a = ti[t];
-    u64 p0 = P.out_begin + t * 4096 + threadIdx.x * 16;
+    u64 p0 = P.out_begin + t * 4096 + chunk * 16;
     if (p0 >= P.out_end) return;
     u32 nbytes = P.out_end - p0 < 16 ? (u32)(P.out_end - p0) : 16;
     const u32 Lp1_32 = (P.L + 1) >> 32 ? 0 : (u32)(P.L + 1);
@@ -1373,10 +1373,12 @@ __device__ __forceinline__ void emit_rest_tile(const EmitP &P, const TileIdx *ti
 // kernel without reading the count back -- a synchronisation in front of the main emit launch otherwise.
 #define EMIT_REST_GRID 4096
 template <bool FOURBIT>
-__global__ __launch_bounds__(256) void k_emit_rest(EmitP P, const TileIdx *ti, const u64 *tr, const u32 *list, const u32 *count, u8 *out)
+__global__ __launch_bounds__(64) void k_emit_rest(EmitP P, const TileIdx *ti, const u64 *tr, const u32 *list, const u32 *count, u8 *out)
 {
+    // workgroups of one wavefront, a quarter of a tile each (beside k_emit_tile_flat_wave a workgroup of 256 waits for four wave slots of
+    // one CU to be free at once: 0.28 -> 1.4 ms for the hundred tiles of the headline text)
     const u32 n = *count;
-    for (u32 i = blockIdx.x; i < n; i += gridDim.x) emit_rest_tile<FOURBIT>(P, ti, tr, list[i], out);
+    for (u32 i = blockIdx.x; i < 4 * n; i += gridDim.x) emit_rest_tile<FOURBIT>(P, ti, tr, list[i >> 2], out, (i & 3) * 64 + threadIdx.x);
 }
 
 // Base-index range [g_lo, g_hi) that output bytes [out_begin, out_end) can touch (conservative on both sides).
@@ -2126,13 +2128,14 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             if (zflat.ready) {
                 // four tiles per workgroup (eight measured slower: DESIGN.md section 8), workgroups dealt to the XCDs in contiguous chunks
                 const u32 nwg = cdiv(ntiles, 4u), chunk = (nwg + 7) / 8;
-                // A frame that is read in place everywhere: a wavefront per two tiles (per tile when there are mask toggles to stage), in
+                // A frame that is read in place everywhere: a wavefront per two tiles (per tile when there are many mask toggles to stage), in
                 // workgroups of 64 -- 3.17 -> 2.44 ms per 10 GB against four tiles per workgroup of 256 (k_emit_tile_flat_wave).  A mostly-flat
                 // frame keeps the workgroups of 256: beside them the decode job's kernels find the LDS they need (a realistic genome,
                 // 4 GB: 3.11 -> 3.30 / 3.57 ms with two / one tile per wavefront).  NAF_GPU_EMIT_WAVE=0: always those.
                 const char *ew = getenv("NAF_GPU_EMIT_WAVE");
                 const bool wave = !flat_job && !(zflat.cls && zflat.n_decoded) && !(ew && ew[0] == '0');
-                if (wave && pl.P.masking) { const u32 ch = ((u32)ntiles + 7) / 8; LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat_wave<1>, ch * 8, 64, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, ch); }
+                // (many: about a toggle per tile or more -- a soft-masked genome, not the odd lower-case stretch)
+                if (wave && pl.P.masking && pl.P.n_toggles >= ntiles) { const u32 ch = ((u32)ntiles + 7) / 8; LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat_wave<1>, ch * 8, 64, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, ch); }
                 else if (wave) { const u32 ch = (cdiv(ntiles, 2u) + 7) / 8; LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat_wave<2>, ch * 8, 64, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, ch); }
                 else
                 LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat<4>, chunk * 8, 256, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, chunk);
@@ -2154,9 +2157,9 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                 else LAUNCH(c, "unnaf_emit", k_emit_tile<false>, (u32)(ntiles - t_done), 256, 0, pl.P, (const TileIdx *)(ti + t_done), d_out + t_done * 4096);
             }
             // tiles holding a header or a record boundary (their number stays on the device)
-            const u32 rest_grid = (u32)(ntiles < EMIT_REST_GRID ? ntiles : EMIT_REST_GRID);
-            if (pl.fourbit) LAUNCH(xc, "unnaf_emit_rest", k_emit_rest<true>, rest_grid, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
-            else LAUNCH(xc, "unnaf_emit_rest", k_emit_rest<false>, rest_grid, 256, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
+            const u32 rest_grid = 4u * (u32)(ntiles < EMIT_REST_GRID ? ntiles : EMIT_REST_GRID);      // (quarter tiles: k_emit_rest)
+            if (pl.fourbit) LAUNCH(xc, "unnaf_emit_rest", k_emit_rest<true>, rest_grid, 64, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
+            else LAUNCH(xc, "unnaf_emit_rest", k_emit_rest<false>, rest_grid, 64, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
             if (xc != c) { HIP_TRY(c, hipEventRecord(c->split_ev[1], xc->stream)); HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[1], 0)); }
             if (split.done) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX + 1], 0));
             if (zflat.ready && getenv("NAF_GPU_DEBUG_FLAT")) {          // tests: how the tiles were dealt
