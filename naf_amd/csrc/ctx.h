@@ -31,7 +31,8 @@ struct FlatStream { u64 q0, A; };
 #define FLAT_DECODED (~0ull)
 struct ZFlat { const u8 *src; const FlatStream *si; u64 nslots; const u8 *sym; void *status; bool ready;
                const u8 *tail; u64 tail_q; u32 tail_n;
-               const u8 *cls; u32 n_decoded;       // cls == nullptr: every block is flat (nothing was decoded)
+               const u8 *cls; u32 n_decoded; u32 n_walk;   // n_walk: decoded blocks whose literals need the Huffman walk (a latency-bound job beside the emit)
+                     // cls == nullptr: every block is flat (nothing was decoded)
                struct naf_gpu_ctx *aux; hipEvent_t decoded_ev; void *later; };   // later: the decode of the blocks that are not flat, as a job to be run by the caller once its tile index is queued (zstd_flat_later)   // aux: a context whose stream is free for the decode of the blocks that are not flat (set by the caller; the emit of the flat tiles runs beside it); decoded_ev: set by the decoder when it used it -- to be waited for before the decoded bytes are read   // tail: a final Raw block (the byte that holds the padding nibble of an odd stream, zstd_enc) -- its bytes lie in the frame as they are; packed index of its first byte; its length
 struct naf_gpu_ctx {
     int device = 0;

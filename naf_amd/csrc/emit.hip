@@ -994,15 +994,14 @@ __global__ __launch_bounds__(256) void k_emit_tile(EmitP P, const TileIdx *ti, u
 // in flight behind one look at the tiles' records, waits for no other wavefront, and leaves its slot when its own stores are out
 // (k_emit_tile_flat_wave has the measurement).  The last tile of the text is never fast (k_tile_index), the records behind it read
 // fast = 0.
+// tn[j]: the wavefront's tiles (~0: none); want: the class of tile taken (TileIdx.fast: 1 = k_emit_tile_wave, 2 = the list kernel's)
 template <bool FOURBIT, u32 TW>
-__global__ __launch_bounds__(64) void k_emit_tile_wave(EmitP P, const TileIdx *ti, u8 *out, u64 ntiles)
+__device__ __forceinline__ void emit_tiles_wave(const EmitP &P, const TileIdx *ti, u8 *out, const u64 (&tn)[TW], u32 want, u64 (*s_tog)[EMIT_TOG_LDS])
 {
-    __shared__ u64 s_tog[TW][EMIT_TOG_LDS];
     const u32 lane = threadIdx.x;
-    const u64 t0 = (u64)blockIdx.x * TW;
     TileIdx A[TW]; bool live[TW];
 #pragma unroll
-    for (u32 j = 0; j < TW; j++) { A[j] = ti[t0 + j < ntiles ? t0 + j : ntiles - 1]; live[j] = t0 + j < ntiles && A[j].fast == 1; }
+    for (u32 j = 0; j < TW; j++) { A[j] = ti[tn[j] == ~0ull ? 0 : tn[j]]; live[j] = tn[j] != ~0ull && A[j].fast == want; }
     u64 g0s[TW][4]; u32 nls[TW][4]; uint4 Q[TW][4];
 #pragma unroll
     for (u32 j = 0; j < TW; j++) {
@@ -1054,8 +1053,29 @@ __global__ __launch_bounds__(64) void k_emit_tile_wave(EmitP P, const TileIdx *t
             else mask16(P, a.k, a.khi, P.masking && a.k < a.khi, g0, lo, hi);
             if (nls[j][r] < 16) splice_newline(lo, hi, (int)nls[j][r]);
             uint4 v; v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
-            st_text16(out + (t0 + j) * 4096 + (r * 64 + lane) * 16, v, P.nt_store);
+            st_text16(out + tn[j] * 4096 + (r * 64 + lane) * 16, v, P.nt_store);
         }
+    }
+}
+template <bool FOURBIT, u32 TW>
+__global__ __launch_bounds__(64) void k_emit_tile_wave(EmitP P, const TileIdx *ti, u8 *out, u64 ntiles)
+{
+    __shared__ u64 s_tog[TW][EMIT_TOG_LDS];
+    u64 tn[TW];
+#pragma unroll
+    for (u32 j = 0; j < TW; j++) { const u64 t = (u64)blockIdx.x * TW + j; tn[j] = t < ntiles ? t : ~0ull; }
+    emit_tiles_wave<FOURBIT, TW>(P, ti, out, tn, 1u, s_tog);
+}
+// ... and the tiles of a list (k_emit_tile_list's), a wavefront per tile
+template <bool FOURBIT>
+__global__ __launch_bounds__(64) void k_emit_tile_list_wave(EmitP P, const TileIdx *ti, const u32 *list, const u32 *count, u8 *out)
+{
+    __shared__ u64 s_tog[1][EMIT_TOG_LDS];
+    const u32 n = *count;
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        const u64 tn[1] = { list[i] };
+        emit_tiles_wave<FOURBIT, 1>(P, ti, out, tn, 2u, s_tog);
+        __syncthreads();                                          // s_tog is written again
     }
 }
 // the tiles of a list (its length stays on the device): the decoded stretches of a mostly-flat frame
@@ -2128,12 +2148,15 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             if (zflat.ready) {
                 // four tiles per workgroup (eight measured slower: DESIGN.md section 8), workgroups dealt to the XCDs in contiguous chunks
                 const u32 nwg = cdiv(ntiles, 4u), chunk = (nwg + 7) / 8;
-                // A frame that is read in place everywhere: a wavefront per two tiles (per tile when there are many mask toggles to stage), in
-                // workgroups of 64 -- 3.17 -> 2.44 ms per 10 GB against four tiles per workgroup of 256 (k_emit_tile_flat_wave).  A mostly-flat
-                // frame keeps the workgroups of 256: beside them the decode job's kernels find the LDS they need (a realistic genome,
-                // 4 GB: 3.11 -> 3.30 / 3.57 ms with two / one tile per wavefront).  NAF_GPU_EMIT_WAVE=0: always those.
+                // A wavefront per two tiles (per tile when there are many mask toggles to stage), in workgroups of 64 -- 3.17 -> 2.24 ms per
+                // 10 GB against four tiles per workgroup of 256 (k_emit_tile_flat_wave).  A mostly-flat frame whose decode job walks Huffman
+                // streams keeps the workgroups of 256: that walk is bound by latency, and beside the wavefront-per-tile emit it takes
+                // 1.9 instead of 1.1 ms (a realistic genome, 4 GB: 3.16 -> 3.41 ms); a job of flat literals and matches only (the reference's
+                // archive of random bases) is better off with it (4 GB: 2.45 -> 2.31 ms), its kernels in workgroups of 64 as well -- a
+                // workgroup of 256 waits for four wave slots of one CU to be free at once.  NAF_GPU_EMIT_WAVE=0: workgroups of 256 everywhere.
                 const char *ew = getenv("NAF_GPU_EMIT_WAVE");
-                const bool wave = !flat_job && !(zflat.cls && zflat.n_decoded) && !(ew && ew[0] == '0');
+                const bool mixed = flat_job || (zflat.cls && zflat.n_decoded);
+                const bool wave = !(ew && ew[0] == '0') && (!mixed || zflat.n_walk == 0);
                 // (many: about a toggle per tile or more -- a soft-masked genome, not the odd lower-case stretch)
                 if (wave && pl.P.masking && pl.P.n_toggles >= ntiles) { const u32 ch = ((u32)ntiles + 7) / 8; LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat_wave<1>, ch * 8, 64, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, ch); }
                 else if (wave) { const u32 ch = (cdiv(ntiles, 2u) + 7) / 8; LAUNCH(c, "unnaf_emit_flat", k_emit_tile_flat_wave<2>, ch * 8, 64, 0, pl.P, (const TileIdx *)ti, (const TileFlat *)tsig, d_out, (u64)ntiles, ch); }
@@ -2147,7 +2170,8 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                     // a tile costs this kernel about what it costs k_emit_tile: as many workgroups as there can be tiles over decoded blocks, up to a few waves of the device
                     const u64 est = (u64)zflat.n_decoded * 64 + 64;                           // (blocks of up to 128 KiB: 64 tiles each)
                     const u32 lgrid = (u32)(est < ntiles ? (est < 16384 ? est : 16384) : (ntiles < 16384 ? ntiles : 16384));
-                    LAUNCH(xc, "unnaf_emit", k_emit_tile_list<true>, lgrid, 256, 0, pl.P, (const TileIdx *)ti, (const u32 *)list2, (const u32 *)(cnt + 1), d_out);
+                    if (wave) LAUNCH(xc, "unnaf_emit", k_emit_tile_list_wave<true>, lgrid, 64, 0, pl.P, (const TileIdx *)ti, (const u32 *)list2, (const u32 *)(cnt + 1), d_out);
+                    else LAUNCH(xc, "unnaf_emit", k_emit_tile_list<true>, lgrid, 256, 0, pl.P, (const TileIdx *)ti, (const u32 *)list2, (const u32 *)(cnt + 1), d_out);
                 }
             }
             else if (t_done < ntiles) {

@@ -1361,12 +1361,16 @@ __global__ __launch_bounds__(64) void k_huf_par(const u8 *src, const ZBlock *blk
 // at consecutive addresses.  L = 4 (sixteen symbols: packed random ACGT) goes through a 256-entry table byte -> two symbols;
 // other widths take the fields out one by one.  Reads stay inside the stream; a stream whose size does not match n x L bits is
 // corrupt (the serial reader's "all bits consumed" test).
-__global__ __launch_bounds__(256) void k_flat_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf, const u8 *pool,
+// WGT = 256: a workgroup per block, a wavefront per stream; WGT = 64: a workgroup per STREAM (four per block, each with the tables of its own) --
+// beside kernels of single-wavefront workgroups a workgroup of 256 waits for four wave slots of one CU to be free at once.
+template <u32 WGT>
+__global__ __launch_bounds__(WGT) void k_flat_literals(const u8 *src, const ZBlock *blk, u32 nblk, const i32 *own_huf, const u8 *pool,
                                                         u8 *dst, u8 *lit_scratch, ZStat *st, u32 b_first, const u8 *sel)
 {
     __shared__ u16 pair[256];                                    // L == 4: byte -> symbol of its high nibble | symbol of its low nibble << 8
     __shared__ u8 sym[256];                                      // code -> symbol
-    const u32 bi = b_first + blockIdx.x;
+    constexpr u32 PER = 256u / WGT;                              // workgroups per block
+    const u32 bi = b_first + blockIdx.x / PER;
     if (bi >= nblk) return;
     if (sel && !(sel[bi] & 2)) return;
     const ZBlock &b = blk[bi];
@@ -1376,24 +1380,25 @@ __global__ __launch_bounds__(256) void k_flat_literals(const u8 *src, const ZBlo
     const u32 L = blk[ob].huf_log;
     if (blk[ob].huf_tab != 0xFFFFFFFFu) {
         const u16 *tab = (const u16 *)(pool + blk[ob].huf_tab);
-        if (threadIdx.x < (1u << L)) sym[threadIdx.x] = (u8)(tab[threadIdx.x] >> 8);
-    } else {
+        for (u32 t = threadIdx.x; t < (1u << L); t += WGT) sym[t] = (u8)(tab[t] >> 8);
+    } else if (threadIdx.x < 64) {
         // no table was built (huf_flat_direct): code k is the k-th symbol of weight 1, in symbol order; the last one is implied
-        __shared__ u32 s_wc[4];
+        // (the first wavefront, 64 symbols at a time)
         const u8 *d = src + blk[ob].src_off + blk[ob].lit_off;
-        const u32 nw = (u32)d[0] - 127, t = threadIdx.x;
-        const bool one = t < nw ? (((t & 1) ? d[1 + (t >> 1)] & 15 : d[1 + (t >> 1)] >> 4) == 1) : t == nw;
-        const u64 bal = __ballot(one);
-        if ((t & 63) == 0) s_wc[t >> 6] = (u32)__popcll(bal);
-        __syncthreads();
-        u32 rank = (u32)__popcll(bal & ((1ull << (t & 63)) - 1));
-        for (u32 q = 0; q < (t >> 6); q++) rank += s_wc[q];
-        if (one) sym[rank] = (u8)t;
+        const u32 nw = (u32)d[0] - 127; u32 run = 0;
+        for (u32 t0 = 0; t0 <= nw; t0 += 64) {
+            const u32 t = t0 + threadIdx.x;
+            const bool one = t < nw ? (((t & 1) ? d[1 + (t >> 1)] & 15 : d[1 + (t >> 1)] >> 4) == 1) : t == nw;
+            const u64 bal = __ballot(one);
+            const u32 rank = run + (u32)__popcll(bal & ((1ull << threadIdx.x) - 1));
+            if (one && rank < 256) sym[rank] = (u8)t;
+            run += (u32)__popcll(bal);
+        }
     }
     __syncthreads();
-    if (L == 4) pair[threadIdx.x] = (u16)(sym[threadIdx.x >> 4] | ((u32)sym[threadIdx.x & 15] << 8));
+    if (L == 4) for (u32 t = threadIdx.x; t < 256; t += WGT) pair[t] = (u16)(sym[t >> 4] | ((u32)sym[t & 15] << 8));
     __syncthreads();
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 wave = WGT == 256 ? threadIdx.x >> 6 : blockIdx.x % PER, lane = threadIdx.x & 63;
     const u8 *c = src + b.src_off + b.huf_streams_off;
     u8 *o = (b.nseq == 0 ? dst : lit_scratch) + b.out_off;
     const u32 regen = b.lit_regen;
@@ -1712,9 +1717,10 @@ __global__ void k_flat_streams_mixed(const u8 *src, const ZBlock *blk, u32 nblk,
 }
 
 // ---- raw / RLE blocks and raw / RLE literal sections: one workgroup per block ------------------------------
-__global__ __launch_bounds__(256) void k_copy_fill(const u8 *src, const ZBlock *blk, u32 nblk, u8 *dst, u8 *lit_scratch, u32 b_first, const u8 *sel)
+template <u32 WGT>
+__global__ __launch_bounds__(WGT) void k_copy_fill(const u8 *src, const ZBlock *blk, u32 nblk, u8 *dst, u8 *lit_scratch, u32 b_first, const u8 *sel)
 {
-    u32 i = b_first + blockIdx.x;
+    u32 i = b_first + blockIdx.x / (256u / WGT);                 // (WGT = 64: four workgroups per block, as in k_flat_literals)
     if (i >= nblk) return;
     if (sel && !(sel[i] & 2)) return;
     const ZBlock &b = blk[i];
@@ -1724,7 +1730,7 @@ __global__ __launch_bounds__(256) void k_copy_fill(const u8 *src, const ZBlock *
     else if (!b.err && b.lit_type <= LIT_RLE) {
         from = src + b.src_off + b.lit_off; to = (b.nseq == 0 ? dst : lit_scratch) + b.out_off; n = b.lit_regen; fill = b.lit_type == LIT_RLE;
     } else return;
-    u32 t = threadIdx.x;
+    u32 t = (blockIdx.x % (256u / WGT)) * WGT + threadIdx.x;
     if (fill) {
         u64 v = 0x0101010101010101ull * from[0];
         for (u32 k = t * 8; k + 8 <= n; k += 256 * 8) st64(to + k, v);
@@ -2596,8 +2602,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                             if (h2.err) return zerr(mc, h2.err, "Huffman tables");
                             max_log = h2.max_huf_log;
                         }
-                        if (hs0.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, d_dst, (u8 *)nullptr, 0u, (const u8 *)cls);
-                        LAUNCH(c, "zstd_flat_literals", k_flat_literals, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, (u8 *)nullptr, st, 0u, (const u8 *)cls);
+                        if (hs0.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill<64>, 4 * nblk, 64, 0, d_src, (const ZBlock *)blk, nblk, d_dst, (u8 *)nullptr, 0u, (const u8 *)cls);
+                        LAUNCH(c, "zstd_flat_literals", k_flat_literals<64>, 4 * nblk, 64, 0, d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, (u8 *)nullptr, st, 0u, (const u8 *)cls);
                         if (n_walk && plog) {
                             // (k_huf_par builds the tables it lacks itself, a workgroup at a time, in LDS)
                             const u32 slot = pending ? (u32)HUF_TAB_MAX : huf_slot_bytes(max_log);
@@ -2613,7 +2619,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     });
                 }
                 zf->src = d_src; zf->si = si; zf->nslots = 4ull * nblk; zf->sym = d_sym; zf->status = st; zf->ready = true;
-                zf->tail = nullptr; zf->tail_q = hs.total_out; zf->tail_n = 0; zf->cls = cls; zf->n_decoded = n_dec;
+                zf->tail = nullptr; zf->tail_q = hs.total_out; zf->tail_n = 0; zf->cls = cls; zf->n_decoded = n_dec; zf->n_walk = n_walk;
                 *out_len = hs.total_out;
                 if (fh.has_fcs && fh.content_size != hs.total_out) return zerr(c, ZE_CORRUPT, "content size mismatch");
                 return 0;
@@ -2702,8 +2708,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     naf_gpu_ctx *c = aux ? aux : mc;
                     if (c != mc) HIP_TRY(mc, hipStreamWaitEvent(c->stream, mc->split_ev[0], 0));      // recorded by the caller behind its tile index
                     const u32 plog = n_walk ? huf_par_plog(hs0.max_lit_regen, n_walk) : 0u;
-                    LAUNCH(c, "zstd_copy_fill", k_copy_fill, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, d_dst, lits, 0u, (const u8 *)cls);
-                    LAUNCH(c, "zstd_flat_literals", k_flat_literals, nblk, 256, 0, d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lits, st, 0u, (const u8 *)cls);
+                    LAUNCH(c, "zstd_copy_fill", k_copy_fill<64>, 4 * nblk, 64, 0, d_src, (const ZBlock *)blk, nblk, d_dst, lits, 0u, (const u8 *)cls);
+                    LAUNCH(c, "zstd_flat_literals", k_flat_literals<64>, 4 * nblk, 64, 0, d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lits, st, 0u, (const u8 *)cls);
                     if (n_walk && plog) {
                         const u32 slot = huf_slot_bytes(hs0.max_huf_log);
                         LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)nblk << (plog + 2), 64), 64, (plog >= 4 ? 1u : 16u >> plog) * slot,
@@ -2724,7 +2730,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     return 0;
                 });
                 zf->src = d_src; zf->si = si; zf->nslots = 4ull * nblk; zf->sym = d_sym; zf->status = st; zf->ready = true;
-                zf->tail = nullptr; zf->tail_q = hs.total_out; zf->tail_n = 0; zf->cls = cls; zf->n_decoded = n_dec;
+                zf->tail = nullptr; zf->tail_q = hs.total_out; zf->tail_n = 0; zf->cls = cls; zf->n_decoded = n_dec; zf->n_walk = n_walk;
                 return 0;
             }
         }
@@ -2824,7 +2830,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             if (sp && !rg && n_seq_blk == 0 && b_first == 0 && b_count == nblk && b_count >= split_min * (u32)sp->parts && b_count >= 16u * HUF_BLOCKS_PER_WG * (u32)sp->parts) {
                 // literal-only frame of a whole-text call: block ranges in order, an event behind each (see ZSplit); the raw / RLE
                 // blocks first, so that a finished part is complete
-                if (hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first, (const u8 *)nullptr);
+                if (hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill<256>, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first, (const u8 *)nullptr);
                 copy_fill_done = true;
                 // output offsets of the part ends: they came with the counters when the frame took the speculative route
                 if (ends) for (int k = 0; k + 1 < sp->parts; k++) sp->out_end[k] = hends[k];
@@ -2840,7 +2846,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                 u32 lo_b = 0;
                 for (int k = 0; k < sp->parts; k++) {
                     u32 hi_b = k + 1 == sp->parts ? b_count : (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
-                    if (hi_b > lo_b && flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, hi_b - lo_b, 256, 0, d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, lo_b, (const u8 *)nullptr);
+                    if (hi_b > lo_b && flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals<256>, hi_b - lo_b, 256, 0, d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, lo_b, (const u8 *)nullptr);
                     if (hi_b > lo_b && serial_needed && plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)(hi_b - lo_b) << (plog + 2), 64), 64, par_lds,
                            d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(), 0u, (u64)src_len);
                     else if (hi_b > lo_b && serial_needed && redo) {
@@ -2856,7 +2862,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                 }
                 sp->done = 1;
             } else {
-                if (flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals, b_count, 256, 0, d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, b_first, (const u8 *)nullptr);
+                if (flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals<256>, b_count, 256, 0, d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, b_first, (const u8 *)nullptr);
                 if (serial_needed && plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)b_count << (plog + 2), 64), 64, par_lds,
                    d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(), 0u, (u64)src_len);
                 else if (serial_needed && redo) {
@@ -2870,7 +2876,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             }
         }
     }
-    if (b_count && !fuse && !copy_fill_done && hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first, (const u8 *)nullptr);
+    if (b_count && !fuse && !copy_fill_done && hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill<256>, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first, (const u8 *)nullptr);
     if (seq_t1 > seq_t0) {
         const char *el = getenv("NAF_GPU_EXEC_LDS");                      // "0": always the HBM executor (cross-check)
         const u32 nx = seq_t1 - seq_t0;
