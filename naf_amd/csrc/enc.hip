@@ -2655,29 +2655,20 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
     if (tl) { HIP_TRY(c, hipMemcpyAsync(d_naf + pos, o->title, tl, hipMemcpyHostToDevice, c->stream)); pos += tl; HIP_TRY(c, hipStreamSynchronize(c->stream)); }
     StreamJob big[6]; bool early[6] = { false, false, false, false, false, false };
     naf_gpu_ctx *sb = nullptr; int rcB = 0;                       // second side context (lengths, mask) and what its thread returns
+    // (an error below leaves through here: the second side context's thread works on this frame's variables until it is joined)
+    auto bail = [&](int r, naf_gpu_ctx *from) -> int {
+        if (sb) ctx_worker_join(sb);
+        for (int k = 0; k < 6; k++) if (early[k]) { zstd_encode_drop(big[k].main); early[k] = false; }
+        hipStreamSynchronize(sc->stream); if (sb) hipStreamSynchronize(sb->stream);
+        return from && from != c ? ctx_fail(c, r, "%s", from->err) : r;
+    };
     if (overlap) {
         arena_reset(sc);
         HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(sc->stream, c->fork_ev, 0));
-        for (int i = 4; i < 6; i++)
-            if (X.present[i]) {
-                if ((rc = encode_stream_begin(c, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i], i == 4 ? X.direct : nullptr, i == 4 ? X.nd : 0u))) { for (int k = 4; k < i; k++) if (early[k]) zstd_encode_drop(big[k].main); return rc; }
-                early[i] = true;
-            }
-        if (probe_later) {
-            // the frame is planned as if there were nothing to match (what the look says of nearly every input); a repeat-rich
-            // stream drops that plan and starts over with the match finder
-            u32 share = 0;
-            if ((rc = zenc_repeat_probe(sc, X.ptr[4], X.len[4], &share))) { for (int k = 4; k < 6; k++) if (early[k]) zstd_encode_drop(big[k].main); hipStreamSynchronize(sc->stream); return ctx_fail(c, rc, "%s", sc->err); }
-            ennaf_probe_verdict(X, share);
-            if (X.lz[4]) {
-                zstd_encode_drop(big[4].main); early[4] = false;
-                if ((rc = undirect())) { if (early[5]) zstd_encode_drop(big[5].main); hipStreamSynchronize(sc->stream); return rc; }
-                if ((rc = encode_stream_begin(c, X.ptr[4], X.len[4], o->level, X.flags[4], X.lz[4], X.block_log[4], X.window_log[4], X.tail[4], &big[4]))) { if (early[5]) zstd_encode_drop(big[5].main); hipStreamSynchronize(sc->stream); return rc; }
-                early[4] = true;
-            }
-        }
-        // lengths and mask: their units and the first half of their frames on a second side context with a host thread of its own,
+        // The side chains first: with millions of reads they are what the call ends up waiting for (ids through the match finder, the
+        // mask units), and queued behind the two big streams' planning they started a millisecond later than they could.
+        // Lengths and mask: their units and the first half of their frames on a second side context with a host thread of its own,
         // beside ids and names on the first (many reads make each of the two chains several milliseconds long)
         // (a few records and no mask to speak of: one chain is short enough, and a thread hand-over is not free; the mask of a long text is
         // a pass over its case bits and a stream of MBs to code, a third of a millisecond and more that ids and names need not wait behind)
@@ -2690,11 +2681,31 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
                 for (int i = 2; i < 4 && !rcB; i++)
                     if (X.present[i]) { rcB = encode_stream_begin(sb, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]); early[i] = !rcB; }
             });
-        } else if ((rc = ennaf_streams(sc, S, K, X, 2))) {
-            for (int k = 4; k < 6; k++) if (early[k]) zstd_encode_drop(big[k].main);
-            hipStreamSynchronize(sc->stream);
-            return ctx_fail(c, rc, "%s", sc->err);
+        } else if ((rc = ennaf_streams(sc, S, K, X, 2))) return bail(rc, sc);
+        for (int i = 4; i < 6; i++)
+            if (X.present[i]) {
+                if ((rc = encode_stream_begin(c, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i], i == 4 ? X.direct : nullptr, i == 4 ? X.nd : 0u))) return bail(rc, c);
+                early[i] = true;
+            }
+        if (probe_later) {
+            // the frame is planned as if there were nothing to match (what the look says of nearly every input); a repeat-rich
+            // stream drops that plan and starts over with the match finder
+            u32 share = 0;
+            if ((rc = zenc_repeat_probe(sc, X.ptr[4], X.len[4], &share))) return bail(rc, sc);
+            ennaf_probe_verdict(X, share);
+            if (X.lz[4]) {
+                zstd_encode_drop(big[4].main); early[4] = false;
+                if ((rc = undirect())) return bail(rc, c);
+                if ((rc = encode_stream_begin(c, X.ptr[4], X.len[4], o->level, X.flags[4], X.lz[4], X.block_log[4], X.window_log[4], X.tail[4], &big[4]))) return bail(rc, c);
+                early[4] = true;
+            }
         }
+        // (ids and names behind the look at the sequence stream, which waits for its answer on the same side stream)
+        for (int i = 0; i < 2; i++)
+            if (X.present[i]) {
+                if ((rc = encode_stream_begin(sc, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]))) return bail(rc, sc);
+                early[i] = true;
+            }
     }
     for (int i = 0; i < 257; i++) { R.unexpected_id[i] = S.unexpected[0][i]; R.unexpected_comment[i] = S.unexpected[1][i]; R.unexpected_seq[i] = S.unexpected[2][i]; R.unexpected_qual[i] = S.unexpected[3][i]; }
     R.n_sequences = S.N; R.n_bases = S.T; R.longest_line = S.longest;
