@@ -174,6 +174,60 @@ def test_unnaf_survives_corrupt_sections(gpu, oracle):
                         pass
 
 
+def test_small_frames_damaged_the_oracle_is_the_judge(gpu, oracle):
+    """The small-frame decoder (one wavefront per frame, zstd_dec.hip small_frame_decode) on the reference-made section frames of the
+    golden archives with one bit flipped, a byte replaced, or the frame cut short: the oracle's verdict -- these bytes, or an error --
+    must be this decoder's; and whole archives damaged in their small sections end the same way with the record tables made in one
+    launch (k_side_tables) as with NAF_GPU_SIDE_FUSED=0."""
+    import os
+    from naf_amd.capi import NafGpuError
+    rng = np.random.default_rng(77)
+    n_frames = n_ok = n_err = 0
+    for case in naf_cases():
+        naf = golden_bytes("naf", case["name"] + ".naf")
+        h = oracle.parse_naf(naf)
+        for i in range(4):
+            if h.payload_off[i] is None or not (8 <= h.comp[i] <= 16384) or h.orig[i] > 32768:
+                continue
+            fr = bytes(naf[h.payload_off[i]:h.payload_off[i] + h.comp[i]])
+            n_frames += 1
+            for trial in range(24):
+                bad = bytearray(fr)
+                kind = trial % 3
+                if kind == 0: bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+                elif kind == 1: bad[int(rng.integers(0, len(bad)))] = int(rng.integers(0, 256))
+                else: bad = bad[: int(rng.integers(1, len(bad)))]
+                try:
+                    want = oracle.zstd_decompress(b"\x28\xb5\x2f\xfd" + bytes(bad), h.orig[i] + 64)
+                except ValueError:
+                    want = None
+                try:
+                    got = host(gpu.zstd_decompress(gpu.to_device(bytes(bad)), h.orig[i] + 64, has_magic=False))
+                except NafGpuError:
+                    got = None
+                assert got == want, (case["name"], i, trial, None if got is None else len(got), None if want is None else len(want))
+                n_ok += want is not None; n_err += want is None
+    assert n_frames >= 6 and n_ok and n_err
+    for name in ("mixed_60", "fastq_4k"):
+        naf = bytearray(golden_bytes("naf", name + ".naf"))
+        h = oracle.parse_naf(bytes(naf))
+        for i in range(3):
+            if h.payload_off[i] is None or h.comp[i] < 8:
+                continue
+            for trial in range(10):
+                bad = bytearray(naf)
+                bad[h.payload_off[i] + int(rng.integers(0, h.comp[i]))] ^= 1 << int(rng.integers(0, 8))
+                res = []
+                for fused in ("1", "0"):
+                    os.environ["NAF_GPU_SIDE_FUSED"] = fused
+                    try:
+                        res.append(("ok", sha(host(gpu.unnaf(gpu.to_device(bytes(bad)), -1)))))
+                    except NafGpuError as e:
+                        res.append(("error", e.code, str(e)))
+                os.environ.pop("NAF_GPU_SIDE_FUSED")
+                assert res[0] == res[1], (name, i, trial, res)
+
+
 def test_unnaf_reference_suite(gpu, oracle):
     """The reference's own tests: oracle-made archive -> GPU unnaf == *.out-ref."""
     from conftest import ref_cases
