@@ -16,6 +16,7 @@
 #include <unistd.h>
 #include <signal.h>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include "../../include/naf_gpu.h"
 
 #define VERSION "1.3.0"
@@ -103,35 +104,57 @@ static void gpu_open(void)
     if (rc) die("can't initialize the GPU path: %s\n", naf_gpu_strerror(rc));
     phase("GPU init");
 }
-/* The process that the caller waits for ends when the OUTPUT is complete, not when the driver has taken the device state apart: the
- * work is done by a forked worker, the foreground process waits for its verdict on a pipe and leaves at once with the worker's exit
- * status, while the worker's teardown (4 GB and more of device memory, pinned buffers, queues: 0.15 - 0.2 s of a run that takes one
- * second -- DESIGN.md section 5) goes on behind it.  Called before anything touches the device.  NAF_GPU_DETACH=0: one process. */
+/* NAF_GPU_DETACH=1 (opt-in; the default is ONE process, as the reference is -- unnaf.c:355, ennaf.c:433): the process the caller waits
+ * for ends when the OUTPUT is complete, not when the driver has taken the device state apart.  The work is done by a forked worker, the
+ * foreground process waits for its verdict on a pipe and leaves at once with the worker's exit status, while the worker's teardown
+ * (4 GB and more of device memory, pinned buffers, queues: 0.15 - 0.2 s of a run that takes one second -- DESIGN.md section 5) goes on
+ * behind it -- the next process on the same device finds less free memory for that long, which is why it is not the default.  Until the
+ * verdict is sent the two processes are one job: SIGINT / SIGTERM / SIGHUP / SIGQUIT that reach the foreground process are forwarded,
+ * and the worker asks to be sent SIGTERM should the foreground process die (PR_SET_PDEATHSIG), so a `kill` or a `timeout` of the pid the
+ * caller knows stops the work and no orphan keeps writing.  Called before anything touches the device. */
 #include <sys/types.h>
 #include <sys/wait.h>
+#include <sys/prctl.h>
+#include <errno.h>
 static int detach_fd = -1;
-/* the worker's verdict; its standard streams are let go with it (a reader behind a pipe would otherwise wait for the teardown too) */
+static volatile pid_t detach_worker = 0;
+static void detach_forward(int sig) { if (detach_worker > 0) kill(detach_worker, sig); }
+/* the worker's verdict; its standard input and output are let go with it (a reader behind a pipe would otherwise wait for the teardown
+ * too); stderr stays when it is a terminal or a file, so that an error of the teardown is still seen */
 static void detach_report(int status)
 {
     if (detach_fd < 0) return;
     fflush(NULL);
-    int dn = open("/dev/null", O_RDWR); if (dn >= 0) { dup2(dn, 0); dup2(dn, 1); dup2(dn, 2); if (dn > 2) close(dn); }
+    prctl(PR_SET_PDEATHSIG, 0);                                          /* the job is done: what is left is this process's own end */
+    struct stat st_; bool keep_err = fstat(2, &st_) == 0 && (S_ISCHR(st_.st_mode) || S_ISREG(st_.st_mode));
+    int dn = open("/dev/null", O_RDWR); if (dn >= 0) { dup2(dn, 0); dup2(dn, 1); if (!keep_err) dup2(dn, 2); if (dn > 2) close(dn); }
     unsigned char b = (unsigned char)status; if (write(detach_fd, &b, 1) != 1) {}
     close(detach_fd); detach_fd = -1;
 }
 __attribute__((unused)) static void detach_teardown(void)
 {
-    const char *e = getenv("NAF_GPU_DETACH"); if (e && e[0] == '0') return;
+    const char *e = getenv("NAF_GPU_DETACH"); if (!e || e[0] != '1') return;
     int pf[2]; if (pipe(pf) != 0) return;
     fflush(NULL);
+    pid_t parent = getpid();
     pid_t pid = fork();
     if (pid < 0) { close(pf[0]); close(pf[1]); return; }
-    if (pid == 0) { close(pf[0]); detach_fd = pf[1]; return; }       /* the worker: reports when it is done (detach_done) or exits (the hosts' exit handler) */
+    if (pid == 0) {                                                      /* the worker: reports when it is done (detach_done) or exits (the hosts' exit handler) */
+        close(pf[0]); detach_fd = pf[1];
+        prctl(PR_SET_PDEATHSIG, SIGTERM);
+        if (getppid() != parent) _exit(1);                               /* the foreground process went away between fork and prctl */
+        return;
+    }
     close(pf[1]);
+    detach_worker = pid;
+    struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_handler = detach_forward; sigemptyset(&sa.sa_mask);
+    sigaction(SIGINT, &sa, NULL); sigaction(SIGTERM, &sa, NULL); sigaction(SIGHUP, &sa, NULL); sigaction(SIGQUIT, &sa, NULL);
     unsigned char b = 0; ssize_t r;
-    do r = read(pf[0], &b, 1); while (r < 0);
+    do r = read(pf[0], &b, 1); while (r < 0 && errno == EINTR);
     if (r == 1) _exit(b);
-    int st = 0; if (waitpid(pid, &st, 0) == pid) { if (WIFEXITED(st)) _exit(WEXITSTATUS(st)); if (WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); raise(WTERMSIG(st)); } }   /* it died without a word */
+    int st = 0; pid_t w;
+    do w = waitpid(pid, &st, 0); while (w < 0 && errno == EINTR);        /* it ended without a word: its status is this process's */
+    if (w == pid) { if (WIFEXITED(st)) _exit(WEXITSTATUS(st)); if (WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); raise(WTERMSIG(st)); } }
     _exit(1);
 }
 __attribute__((unused)) static void detach_done(int status) { detach_report(status); }

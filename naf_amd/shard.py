@@ -37,9 +37,11 @@ def _staged(t, group):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def _p2p(ops):
+def _p2p_post(ops):
+    """Post a group of point-to-point transfers; returns what _p2p_wait needs.  Over RCCL the group is enqueued on the communicator's
+    stream behind what the current stream holds NOW: kernels launched on the current stream after this call run beside the transfers."""
     if not ops:
-        return
+        return None
     back = []
     real = []
     for op in ops:
@@ -50,10 +52,21 @@ def _p2p(ops):
             real.append(dist.P2POp(op.op, h, op.peer, op.group))
         else:
             real.append(op)
-    for w in dist.batch_isend_irecv(real):
+    return dist.batch_isend_irecv(real), back
+
+
+def _p2p_wait(posted):
+    if posted is None:
+        return
+    works, back = posted
+    for w in works:
         w.wait()
     for d, h in back:
         d.copy_(h)
+
+
+def _p2p(ops):
+    _p2p_wait(_p2p_post(ops))
 
 
 def _all_gather(outs, t, group):
@@ -117,14 +130,17 @@ def unnaf_sharded(ctx, d_naf, out_type=0, use_mask=True, line_length=-1, dst=0, 
         return None
     if out is None:
         out = torch.empty(max(total, 1), dtype=torch.uint8, device=d_naf.device)
-    if e > b:
-        ctx.unnaf_range(d_naf, b, e, out_type, use_mask, line_length, out=out[b:e])
+    # the receives first, the root's own range beside them: the peers' ranges arrive over their own xGMI links while the root decodes
+    # (the transfers take ~20 times what a range decode takes -- DESIGN.md section 6 -- so the root's decode is hidden entirely)
     ops = []
     for r in range(world):
         rb, re_ = byte_range(total, r, world)
         if r != rank and re_ > rb:
             ops.append(dist.P2POp(dist.irecv, out[rb:re_], r, group))
-    _p2p(ops)
+    posted = _p2p_post(ops)
+    if e > b:
+        ctx.unnaf_range(d_naf, b, e, out_type, use_mask, line_length, out=out[b:e])
+    _p2p_wait(posted)
     return out[:total]
 
 

@@ -253,3 +253,43 @@ def realistic_genome_device(total_bytes: int, n_records: int = 24, width: int = 
     if softmask:
         softmask_device(out, seed=seed + 1)
     return out
+
+
+def repeat_genome_device(total_bytes: int, n_records: int = 8, width: int = 60, seed: int = 5, device="cuda",
+                         families: int = 96, coverage: float = 0.45, div_lo: float = 0.003, div_hi: float = 0.06):
+    """Repeat-rich genome in device memory (uint8 torch tensor): random ACGT of which `coverage` is overwritten by copies of `families`
+    repeat units (300 .. 6000 bases, the spread of SINE / LINE fragments), every copy with its own substitution rate between `div_lo` and
+    `div_hi` -- what the match finders of levels >= 2 and `--long` are for (ennaf/src/compressor.c:7-21, ennaf.c:247-273).  Copies land at
+    any base offset, so half of them are a nibble off their unit in the packed stream: a byte-wise match finder sees the other half."""
+    import torch
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    hdrs = [b">scaffold%d repeat-rich synthetic\n" % (k + 1) for k in range(n_records)]
+    hdr_total = sum(len(h) for h in hdrs)
+    rows_per = max(1, (total_bytes - hdr_total) // (width + 1) // n_records)
+    nb = rows_per * n_records * width
+    seq = torch.randint(0, 4, (nb,), dtype=torch.uint8, device=device, generator=g)
+    cpu = torch.Generator().manual_seed(seed * 7 + 1)
+    lens = torch.randint(300, 6000, (families,), generator=cpu).tolist()
+    per_family = int(nb * coverage / families)
+    for f, L in enumerate(lens):
+        unit = torch.randint(0, 4, (L,), dtype=torch.uint8, device=device, generator=g)
+        copies = max(1, per_family // L)
+        at = torch.randint(0, nb - L, (copies,), dtype=torch.int64, device=device, generator=g)
+        rate = div_lo + (div_hi - div_lo) * torch.rand((copies, 1), device=device, generator=g)
+        body = unit.repeat(copies, 1)
+        hit = torch.rand((copies, L), device=device, generator=g) < rate
+        body[hit] = torch.randint(0, 4, (int(hit.sum().item()),), dtype=torch.uint8, device=device, generator=g)
+        idx = at[:, None] + torch.arange(L, device=device)[None, :]
+        seq[idx.reshape(-1)] = body.reshape(-1)
+        del body, hit, idx
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    out = torch.empty(hdr_total + rows_per * n_records * (width + 1), dtype=torch.uint8, device=device)
+    pos = 0
+    for k in range(n_records):
+        h = torch.tensor(list(hdrs[k]), dtype=torch.uint8, device=device)
+        out[pos:pos + len(h)] = h; pos += len(h)
+        body = out[pos:pos + rows_per * (width + 1)].view(rows_per, width + 1)
+        body[:, :width] = lut[seq[k * rows_per * width:(k + 1) * rows_per * width].to(torch.int64)].view(rows_per, width)
+        body[:, width] = 10
+        pos += rows_per * (width + 1)
+    return out
