@@ -264,6 +264,17 @@ int  naf_gpu_ennaf_stitch_plan(const naf_gpu_ennaf_opts *opts, const naf_gpu_sha
 int  naf_gpu_ennaf_stitch(naf_gpu_ctx *ctx, const naf_gpu_stitch_seg *segs, size_t n_segs, const uint8_t *lit,
                           const void *const *d_piece_bufs, void *d_naf, size_t naf_cap);
 
+/* ---- switches ------------------------------------------------------------------------------------------
+ * The library's cross-check levers and development aids (INTEGRATION.md section 6 lists them).  naf_gpu_init reads the NAF_GPU_<NAME>
+ * variables of the environment ONCE into the context; no later call looks at the environment.  naf_gpu_set_option changes one
+ * afterwards (name with or without the NAF_GPU_ prefix; value NULL = not set).  None is needed in production.
+ * TRACE=1: the calls keep the verdicts of the paths they took ("[flat mixed] nblk ... decoded ...") as text in the context instead of
+ * printing anything; naf_gpu_get_trace returns what has accumulated (valid until the next call on the context), naf_gpu_clear_trace
+ * empties it.  The tests ask through this which kernels ran. */
+int         naf_gpu_set_option(naf_gpu_ctx *ctx, const char *name, const char *value);
+const char *naf_gpu_get_trace(naf_gpu_ctx *ctx);
+void        naf_gpu_clear_trace(naf_gpu_ctx *ctx);
+
 /* ---- instrumentation ---------------------------------------------------------------------------------- */
 /* Per-kernel device time (hipEvent pairs on the ctx stream) of the last call, for bench.py's roofline
  * object.  names[i] points to static strings.  Returns the number of entries written (<= cap). */

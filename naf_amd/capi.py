@@ -26,6 +26,7 @@ EXPORTS = [
     "naf_gpu_ennaf_sniff", "naf_gpu_ennaf_count_lines", "naf_gpu_ennaf_find_cut", "naf_gpu_ennaf_shard_begin", "naf_gpu_ennaf_shard_bound",
     "naf_gpu_ennaf_shard_finish", "naf_gpu_ennaf_shard_carry", "naf_gpu_ennaf_stitch_plan", "naf_gpu_ennaf_stitch",
     "naf_gpu_read_file", "naf_gpu_write_file", "naf_gpu_copy", "naf_gpu_gather_ranges", "naf_gpu_get_timing_streams",
+    "naf_gpu_set_option", "naf_gpu_get_trace", "naf_gpu_clear_trace",
 ]
 MAX_SHARDS = 64
 
@@ -148,6 +149,11 @@ def load():
         L.naf_gpu_release_scratch.argtypes = [vp]
         L.naf_gpu_get_timing_streams.argtypes = [vp, C.POINTER(C.c_float)]
         L.naf_gpu_gather_ranges.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), u64p, C.POINTER(sz), i]
+        L.naf_gpu_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+        L.naf_gpu_get_trace.argtypes = [vp]
+        L.naf_gpu_get_trace.restype = C.c_char_p
+        L.naf_gpu_clear_trace.argtypes = [vp]
+        L.naf_gpu_clear_trace.restype = None
         _lib = L
     return _lib
 
@@ -184,16 +190,56 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+class _SyncedLib:
+    """The library as a Context sees it.  The library reads its NAF_GPU_* switches from the environment once, in naf_gpu_init, and
+    afterwards only through naf_gpu_set_option; tests and tools flip switches between calls by changing os.environ, so every entry point
+    taken through this proxy first hands the library what changed since the last one (a NAF_GPU_DEBUG_* variable turns TRACE on), and a
+    trace a call left is written to stderr when the call returns -- where the tests read which path ran."""
+
+    def __init__(self, lib, ctx):
+        object.__setattr__(self, "_lib", lib)
+        object.__setattr__(self, "_ctx", ctx)
+
+    def __getattr__(self, name):
+        f = getattr(self._lib, name)
+        ctx = self._ctx
+        if not ctx.h or name in ("naf_gpu_set_option", "naf_gpu_get_trace", "naf_gpu_clear_trace", "naf_gpu_last_error", "naf_gpu_strerror", "naf_gpu_shutdown"):
+            return f
+        ctx._sync_options()
+        if not ctx._tracing:
+            return f
+
+        def traced(*a):
+            try:
+                return f(*a)
+            finally:
+                t = self._lib.naf_gpu_get_trace(ctx.h)
+                if t:
+                    os.write(2, t)
+                    self._lib.naf_gpu_clear_trace(ctx.h)
+        return traced
+
+
+def _env_options():
+    o = {k[8:]: v for k, v in os.environ.items() if k.startswith("NAF_GPU_")}
+    if any(k.startswith("DEBUG_") for k in o) and "TRACE" not in o:
+        o["TRACE"] = "1"
+    return o
+
+
 class Context:
     """One per device / per process rank.  Work is enqueued on torch's current stream for the device."""
 
     def __init__(self, device=0, use_torch_stream=True):
         import torch
-        self.L = load()
         self.h = C.c_void_p()
-        rc = self.L.naf_gpu_init(device, C.byref(self.h))
+        self._opts = {}
+        self._tracing = False
+        self.L = _SyncedLib(load(), self)
+        rc = load().naf_gpu_init(device, C.byref(self.h))
         if rc:
-            raise NafGpuError(rc, self.L.naf_gpu_strerror(rc).decode())
+            raise NafGpuError(rc, load().naf_gpu_strerror(rc).decode())
+        self._opts = {k[8:]: v for k, v in os.environ.items() if k.startswith("NAF_GPU_")}      # what naf_gpu_init has read
         self.device = torch.device("cuda", device)
         if use_torch_stream:
             s = torch.cuda.current_stream(self.device)
@@ -203,6 +249,21 @@ class Context:
         if self.h:
             self.L.naf_gpu_shutdown(self.h)
             self.h = C.c_void_p()
+
+    def set_option(self, name, value):
+        """naf_gpu_set_option: one switch of this context (value None: not set)."""
+        self._check(load().naf_gpu_set_option(self.h, name.encode(), None if value is None else str(value).encode()))
+
+    def _sync_options(self):
+        want = _env_options()
+        if want != self._opts:
+            for k in set(self._opts) - set(want):
+                self.set_option(k, None)
+            for k, v in want.items():
+                if self._opts.get(k) != v:
+                    self.set_option(k, v)
+            self._opts = want
+        self._tracing = want.get("TRACE", "")[:1] == "1"
 
     def __del__(self):
         try:

@@ -34,8 +34,15 @@ struct ZFlat { const u8 *src; const FlatStream *si; u64 nslots; const u8 *sym; v
                const u8 *cls; u32 n_decoded; u32 n_walk;   // n_walk: decoded blocks whose literals need the Huffman walk (a latency-bound job beside the emit)
                      // cls == nullptr: every block is flat (nothing was decoded)
                struct naf_gpu_ctx *aux; hipEvent_t decoded_ev; void *later; };   // later: the decode of the blocks that are not flat, as a job to be run by the caller once its tile index is queued (zstd_flat_later)   // aux: a context whose stream is free for the decode of the blocks that are not flat (set by the caller; the emit of the flat tiles runs beside it); decoded_ev: set by the decoder when it used it -- to be waited for before the decoded bytes are read   // tail: a final Raw block (the byte that holds the padding nibble of an odd stream, zstd_enc) -- its bytes lie in the frame as they are; packed index of its first byte; its length
+// The NAF_GPU_* switches (cross-check levers of the tests, development aids).  naf_gpu_init reads them from
+// the environment ONCE; afterwards only naf_gpu_set_option changes them -- no call looks at the environment.  Names are kept without
+// the NAF_GPU_ prefix.  Side contexts look at the options of the context they belong to (`root`).  TRACE=1: the verdicts of the paths a
+// call took are kept as text for naf_gpu_get_trace (the tests ask which path ran; nothing is ever printed by the library).
+struct CtxOpts { std::vector<std::pair<std::string, std::string>> kv; std::string trace; bool tracing = false; };
 struct naf_gpu_ctx {
     int device = 0;
+    CtxOpts *opts = nullptr;              // owned by the context naf_gpu_init returned
+    naf_gpu_ctx *root = nullptr;          // side contexts: that context
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::vector<ArenaChunk> chunks;       // scratch arena; consolidated into one chunk at reset
@@ -75,6 +82,10 @@ void ctx_worker_join(naf_gpu_ctx *x);
 int  ctx_sides_ready(naf_gpu_ctx *c);       // before c->side .. c->side4 are looked at: waits for the thread of naf_gpu_init that makes them
 
 int  ctx_fail(naf_gpu_ctx *c, int code, const char *fmt, ...);
+const char *ctx_opt(const naf_gpu_ctx *c, const char *name);           // value of switch NAF_GPU_<name>, nullptr when not set
+static inline bool ctx_opt_is(const naf_gpu_ctx *c, const char *name, char v) { const char *e = ctx_opt(c, name); return e && e[0] == v; }
+bool ctx_tracing(const naf_gpu_ctx *c);
+void ctx_trace(naf_gpu_ctx *c, const char *fmt, ...);                  // a path's verdict, kept when TRACE is on
 #define HIP_TRY(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return ctx_fail((c), NAF_GPU_EHIP, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
 // Scratch arena: pointers stay valid until arena_reset.  Returns nullptr on allocation failure.

@@ -1640,7 +1640,7 @@ static int unnaf_prepare(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const 
     P.upper = !pl.fourbit && !o->use_mask;
     const char *tab = h.seq_type == NAF_SEQ_RNA ? "-UGKCYSBAWRDMHVN" : "-TGKCYSBAWRDMHVN";   // unnaf.c:13,369
     memcpy(P.lut, tab, 16);
-    const char *fs = getenv("NAF_GPU_FORCE_SLOW"); P.force_slow = fs && fs[0] == '1';
+    const char *fs = ctx_opt(c, "FORCE_SLOW"); P.force_slow = fs && fs[0] == '1';
     P.nt_store = 1;
     pl.need_qual = P.mode == EM_FASTQ;
 
@@ -1723,7 +1723,7 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
         u64 tot[2] = { 0, 0 };
         bool fused_done = false;
         {
-            const char *sf = getenv("NAF_GPU_SIDE_FUSED");
+            const char *sf = ctx_opt(c, "SIDE_FUSED");
             const int sec[3] = { S_IDS, S_NAMES, S_LEN }; const bool wanted[3] = { want_names && has_ids != 0, want_names && has_names != 0, true };
             bool fits = !(sf && sf[0] == '0') && N <= SIDE_FUSED_N && h.orig_size[S_LEN] % 4 == 0;
             for (int k = 0; k < 3; k++) if (wanted[k] && !zstd_small_fits(h.comp_size[sec[k]], h.orig_size[sec[k]])) fits = false;
@@ -1782,7 +1782,7 @@ static int unnaf_sections_main(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, n
         // Ids and names of an archive of many records (a FASTQ's 12 M reads per 4 GB: two streams through the sequence executor, 3.9 and
         // 1.1 ms one after the other, and the emit waits for both) go to a context each (NAF_GPU_NAMES_BESIDE=0: both on `aux`).
         bool names_beside = aux_run && aux_names && !len_on_aux && has_ids && has_names && h.orig_size[S_IDS] >= (1u << 20) && h.orig_size[S_NAMES] >= (1u << 20);
-        { const char *nb = getenv("NAF_GPU_NAMES_BESIDE"); if (nb && nb[0] == '0') names_beside = false; }
+        { const char *nb = ctx_opt(c, "NAMES_BESIDE"); if (nb && nb[0] == '0') names_beside = false; }
         int rc_names = 0;
         if (names_beside) ctx_worker_start(aux_names, [&] { rc_names = ids_names(aux_names, 2); });               // pre[] is set by now (small3 ran on c above), no return until it is joined
         if (aux_run) ctx_worker_start(aux, [&] { if (len_on_aux) rc_small = small3(aux); rc_aux = rc_small ? rc_small : ids_names(aux, names_beside ? 1 : 3); if (len_on_aux && !rc_small) rc_len = lengths(aux); });     // no return until it is joined
@@ -1856,7 +1856,7 @@ static int unnaf_sections(naf_gpu_ctx *c, const u8 *d_naf, UnnafPlan &pl, naf_gp
         u8 *mu = nullptr; u64 n_mask = h.orig_size[S_MASK];
         {
             // a frame of a few KB for MBs of units: Raw / RLE blocks, one launch (NAF_GPU_MASK_RLE=0: never)
-            const char *mr = getenv("NAF_GPU_MASK_RLE");
+            const char *mr = ctx_opt(c, "MASK_RLE");
             const u64 cs = h.comp_size[S_MASK];
             if (cs >= 4 && cs <= MASK_RLE_SRC && n_mask >= 2 * cs && !(mr && mr[0] == '0')) {
                 // Frame_Header (RFC 8878 3.1.1.1) of a frame without dictionary and checksum: descriptor, window byte, content size
@@ -1959,7 +1959,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         return 0;
     };
     auto payload = [&]() -> int { int r = payload_seq(); if (r) return r; return pl.need_qual ? payload_qual(c) : 0; };
-    const char *fuse = getenv("NAF_GPU_FUSE");
+    const char *fuse = ctx_opt(c, "FUSE");
     const bool fuse_on = fuse && fuse[0] == '1';
     // Whole-text call: the side streams (a chain of small launches and read-backs, mostly latency) are prepared by a second
     // host thread on the side context's stream while this thread decodes the payload; they meet before the emit.
@@ -1970,7 +1970,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     // (ctx.h: ZFlat) those read it in place and nothing is decoded.  NAF_GPU_FLAT_FUSE=0: always decode first (cross-check).
     ZFlat zflat; memset(&zflat, 0, sizeof zflat);
     struct FlatGuard { ZFlat *z; ~FlatGuard() { zstd_flat_drop(z); } } flat_guard{ &zflat };      // (a job the decoder left and nobody ran: an error on the way)
-    const char *ff = getenv("NAF_GPU_FLAT_FUSE"), *ek0 = getenv("NAF_GPU_EMIT");
+    const char *ff = ctx_opt(c, "FLAT_FUSE"), *ek0 = ctx_opt(c, "EMIT");
     const bool try_flat = !size_only && pl.fourbit && !fuse_on && !pl.P.force_slow && !(ff && ff[0] == '0') && !(ek0 && ek0[0]) &&
                           (pl.P.mode == EM_FASTA || pl.P.mode == EM_SEQ || pl.P.mode == EM_SEQUENCES) && pl.P.N && h.orig_size[S_SEQ] / pl.P.N >= 16384 &&
                           (pl.P.mode != EM_FASTA || pl.P.L == 0 || pl.P.L >= 16);
@@ -1987,7 +1987,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
         ctx_worker_start(c->side, [&] { rc_side = unnaf_sections(c->side, d_naf, pl, c->side3, nullptr, c->side4); });   // the mask stays on this context: a thread of its own measured slower, with and without the split decode
         if (qpar) ctx_worker_start(c->side2, [&] { rc_q = payload_qual(c->side2); });
         // decode -> emit pipeline (ZSplit): the quality context is free when there is no quality stream
-        const char *nsp = getenv("NAF_GPU_SPLIT");
+        const char *nsp = ctx_opt(c, "SPLIT");
         const int nparts = nsp ? atoi(nsp) : 4;
         if (!pl.need_qual && c->side2 && nparts >= 2 && nparts <= ZSPLIT_MAX && pl.P.mode != -1) {
             split.parts = nparts; split.done = 0;
@@ -2061,7 +2061,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
     }
     if (has_main) {
         // short records (FASTQ reads, contigs, proteins): segment-composing kernel; long records: streaming kernel
-        const char *ek = getenv("NAF_GPU_EMIT");
+        const char *ek = ctx_opt(c, "EMIT");
         bool short_rec = pl.P.mode != EM_SEQ && pl.total / pl.P.N < 16384;
         if (ek && !strcmp(ek, "short")) short_rec = pl.P.mode != EM_SEQ;
         if (ek && !strcmp(ek, "long")) short_rec = false;
@@ -2070,7 +2070,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             {
                 const u64 avg = pl.P.N ? (pl.P.out_end - pl.P.out_begin) / pl.P.N + 1 : 1;        // bytes of text per read
                 const u32 lanes = avg * 64 <= ER_STAGE * 7 / 8 ? 4u : avg * 32 <= ER_STAGE * 7 / 8 ? 8u : 16u;
-                const bool w1 = !(getenv("NAF_GPU_EMIT_WAVE") && getenv("NAF_GPU_EMIT_WAVE")[0] == '0');
+                const bool w1 = !(ctx_opt(c, "EMIT_WAVE") && ctx_opt(c, "EMIT_WAVE")[0] == '0');
                 const u32 wgt = w1 ? 64u : 256u, grid = (u32)cdiv(pl.P.N, wgt / lanes);
 #define ER_LAUNCH(FB, LN) do { if (w1) LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<FB, LN, 64>), grid, 64, 0, pl.P, d_out); \
                                else LAUNCH(c, "unnaf_emit_records", (k_emit_fastq_records<FB, LN, 256>), grid, 256, 0, pl.P, d_out); } while (0)
@@ -2109,7 +2109,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             // With a split decode (ZSplit) the index and the tiles behind the finished parts run on the second stream beside the
             // decode of the next part; this stream takes the tiles behind the last part, the boundary tiles, and waits for the other.
             naf_gpu_ctx *ic = split.done ? c->side2 : c;                                     // context the tile index is built on
-            const bool tile_wave = !(getenv("NAF_GPU_EMIT_WAVE") && getenv("NAF_GPU_EMIT_WAVE")[0] == '0');      // k_emit_tile_wave / k_emit_tile_flat_wave ("0": the workgroups of 256)
+            const bool tile_wave = !(ctx_opt(c, "EMIT_WAVE") && ctx_opt(c, "EMIT_WAVE")[0] == '0');      // k_emit_tile_wave / k_emit_tile_flat_wave ("0": the workgroups of 256)
             if (split.done) HIP_TRY(c, hipMemsetAsync(cnt, 0, 8, ic->stream));
             TileFlat *tsig = nullptr;
             if (zflat.ready) {
@@ -2154,7 +2154,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
                 // 1.9 instead of 1.1 ms (a realistic genome, 4 GB: 3.16 -> 3.41 ms); a job of flat literals and matches only (the reference's
                 // archive of random bases) is better off with it (4 GB: 2.45 -> 2.31 ms), its kernels in workgroups of 64 as well -- a
                 // workgroup of 256 waits for four wave slots of one CU to be free at once.  NAF_GPU_EMIT_WAVE=0: workgroups of 256 everywhere.
-                const char *ew = getenv("NAF_GPU_EMIT_WAVE");
+                const char *ew = ctx_opt(c, "EMIT_WAVE");
                 const bool mixed = flat_job || (zflat.cls && zflat.n_decoded);
                 const bool wave = !(ew && ew[0] == '0') && (!mixed || zflat.n_walk == 0);
                 // (many: about a toggle per tile or more -- a soft-masked genome, not the odd lower-case stretch)
@@ -2186,9 +2186,9 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             else LAUNCH(xc, "unnaf_emit_rest", k_emit_rest<false>, rest_grid, 64, 0, pl.P, (const TileIdx *)ti, (const u64 *)tr, (const u32 *)list, (const u32 *)cnt, d_out);
             if (xc != c) { HIP_TRY(c, hipEventRecord(c->split_ev[1], xc->stream)); HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[1], 0)); }
             if (split.done) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX + 1], 0));
-            if (zflat.ready && getenv("NAF_GPU_DEBUG_FLAT")) {          // tests: how the tiles were dealt
+            if (zflat.ready && ctx_tracing(c)) {          // tests: how the tiles were dealt
                 u32 hc[2] = { 0, 0 };
-                if (!ctx_readback(c, hc, cnt, 8)) fprintf(stderr, "[flat tiles] total %llu rest %u decoded %u\n", (unsigned long long)ntiles, hc[0], hc[1]);
+                if (!ctx_readback(c, hc, cnt, 8)) ctx_trace(c, "[flat tiles] total %llu rest %u decoded %u\n", (unsigned long long)ntiles, hc[0], hc[1]);
             }
         }
     }

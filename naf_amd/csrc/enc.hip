@@ -854,7 +854,7 @@ __device__ __forceinline__ u64 tile_line_base(const EncP &P, const EncOut &O, co
 // Tiles that are not regular are skipped here and done by k_enc_scatter, which skips the regular ones.
 #define REG_TPW 4
 // workgroups of one wavefront for the kernels that work a wavefront per tile anyway (NAF_GPU_ENC_WAVE=0: four wavefronts per workgroup)
-static bool enc_wave_wg() { const char *e = getenv("NAF_GPU_ENC_WAVE"); return !(e && e[0] == '0'); }
+static bool enc_wave_wg(const naf_gpu_ctx *c) { const char *e = ctx_opt(c, "ENC_WAVE"); return !(e && e[0] == '0'); }
 struct RegGroup { u32 ga, gb, e, nb; };
 __device__ __forceinline__ void reg_group_geometry(u32 j, u32 o, u32 span, u32 p1, u32 W, float rW, RegGroup &g, u32 &x)
 {
@@ -2069,7 +2069,7 @@ struct EnnafSplit {
 static int ennaf_scatter4(naf_gpu_ctx *c, const EnnafSplit::Scatter4 &R, u8 *packed, u64 *casebits)
 {
     if (R.T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(R.tiles, 256), 256, 0, R.t_seq, R.tiles, R.T, packed, (u32 *)casebits, R.O.direct, R.O.nd);
-    if (R.n >= 2 * ET_TILE && enc_wave_wg()) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular<1>, (u32)R.tiles, 64, 0, R.P, R.t_eol, R.O, R.tiles);
+    if (R.n >= 2 * ET_TILE && enc_wave_wg(c)) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular<1>, (u32)R.tiles, 64, 0, R.P, R.t_eol, R.O, R.tiles);
     else if (R.n >= 2 * ET_TILE) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular<REG_TPW>, cdiv(R.tiles, REG_TPW), 256, 0, R.P, R.t_eol, R.O, R.tiles);   // (shorter texts have no regular tile)
     if (R.n_irregular) LAUNCH(c, "ennaf_scatter", k_enc_scatter<true>, R.n_irregular, 256, 0, R.P, R.t_eol, R.t_sp, R.O);
     return 0;
@@ -2136,7 +2136,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         if ((rc = scan_exclusive_u64(c, t_ls, tiles, tot + 4))) return rc;
         // regular tiles by lines (k_encq_count_reg), the others -- the first and the last one always, whatever the tolerant parser has
         // something to tolerate in -- from a list by the general kernel; NAF_GPU_FQ_REG=0: every tile by the general kernel
-        const bool fq_reg = !(getenv("NAF_GPU_FQ_REG") && getenv("NAF_GPU_FQ_REG")[0] == '0');
+        const bool fq_reg = !(ctx_opt(c, "FQ_REG") && ctx_opt(c, "FQ_REG")[0] == '0');
         u32 *t_reg = nullptr, *need_list = nullptr; u64 n_need = tiles;
         u32 *redo_list = nullptr, *n_redo = nullptr;
         if (fq_reg && S.fourbit && n >= 16 * ET_TILE) {
@@ -2148,7 +2148,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
             if ((rc = scan_exclusive_u64(c, t_need, tiles, tot + 5))) return rc;
             LAUNCH(c, "ennaf_need_list", k_need_list, cdiv(tiles, 256), 256, 0, (const u32 *)nullptr, (const u64 *)t_need, tiles, need_list, (const u32 *)t_reg);
             if ((rc = ctx_readback(c, &n_need, tot + 5, 8))) return rc;
-            if (getenv("NAF_GPU_DEBUG_REG")) fprintf(stderr, "[fq reg] tiles %llu, not regular %llu\n", (unsigned long long)tiles, (unsigned long long)n_need);
+            if (ctx_tracing(c)) ctx_trace(c, "[fq reg] tiles %llu, not regular %llu\n", (unsigned long long)tiles, (unsigned long long)n_need);
         }
         if (n_need) LAUNCH(c, "ennaf_fq_count", k_encq_count, n_need, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, piece_cnt, (const u32 *)need_list, 0);
         if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
@@ -2185,7 +2185,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
                 // regular tiles handed back for their letters (an IUPAC code, a letter to be replaced): their pieces' counts, then the general scatter
                 u32 nr = 0;
                 if ((rc = ctx_readback(c, &nr, n_redo, 4))) return rc;
-                if (getenv("NAF_GPU_DEBUG_REG")) fprintf(stderr, "[fq reg] handed back %u\n", nr);
+                if (ctx_tracing(c)) ctx_trace(c, "[fq reg] handed back %u\n", nr);
                 if (nr) {
                     LAUNCH(c, "ennaf_fq_count", k_encq_count, nr, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, piece_cnt, (const u32 *)redo_list, 1);
                     O.list = redo_list;
@@ -2257,16 +2257,16 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
             // pure tiles (nearly all of a genome) a wavefront per tile; the others, from a list, by the general kernel
             u32 *t_needf = arena_new<u32>(c, tiles + 1), *need_list = arena_new<u32>(c, tiles + 1); u64 *t_need = arena_new<u64>(c, tiles + 2);
             if (!t_needf || !need_list || !t_need) return NAF_GPU_ENOMEM;
-            if (enc_wave_wg()) LAUNCH(c, "ennaf_count_pure", (k_enc_count_pure<1, 1>), (u32)tiles, 64, 0, P, (const i64 *)t_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, tiles);
+            if (enc_wave_wg(c)) LAUNCH(c, "ennaf_count_pure", (k_enc_count_pure<1, 1>), (u32)tiles, 64, 0, P, (const i64 *)t_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, tiles);
             else LAUNCH(c, "ennaf_count_pure", (k_enc_count_pure<4, 1>), cdiv(tiles, 4), 256, 0, P, (const i64 *)t_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, tiles);
             if ((rc = scan_exclusive_u64(c, t_need, tiles, tot + 5))) return rc;
             LAUNCH(c, "ennaf_need_list", k_need_list, cdiv(tiles, 256), 256, 0, (const u32 *)t_needf, (const u64 *)t_need, tiles, need_list, (const u32 *)nullptr);
             u64 n_need = 0;
             if ((rc = ctx_readback(c, &n_need, tot + 5, 8))) return rc;
-            if (getenv("NAF_GPU_DEBUG_REG")) {
+            if (ctx_tracing(c)) {
                 std::vector<u32> hr(tiles); hipMemcpy(hr.data(), t_reg, tiles * 4, hipMemcpyDeviceToHost);
                 u64 nz = 0; for (u64 i = 0; i < tiles; i++) nz += hr[i] != 0;
-                fprintf(stderr, "[reg] tiles %llu need %llu regular %llu; reg[1..4] = %08x %08x %08x %08x\n", (unsigned long long)tiles, (unsigned long long)n_need, (unsigned long long)nz, hr[1], hr[2], hr[3], hr[4]);
+                ctx_trace(c, "[reg] tiles %llu need %llu regular %llu; reg[1..4] = %08x %08x %08x %08x\n", (unsigned long long)tiles, (unsigned long long)n_need, (unsigned long long)nz, hr[1], hr[2], hr[3], hr[4]);
             }
             if (n_need) LAUNCH(c, "ennaf_count", k_enc_count, n_need, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, (const u32 *)need_list);
         } else
@@ -2282,7 +2282,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         u64 h[7];
         if ((rc = ctx_readback(c, h, tot, 56))) return rc;
         T = h[0]; n_ids = h[1]; n_cmt = h[2]; N = h[3];
-        S.no_case = (u32)h[6] == 0 && !(getenv("NAF_GPU_CASE_CENSUS") && getenv("NAF_GPU_CASE_CENSUS")[0] == '0');
+        S.no_case = (u32)h[6] == 0 && !(ctx_opt(c, "CASE_CENSUS") && ctx_opt(c, "CASE_CENSUS")[0] == '0');
         P.any_case = nullptr;
         const u64 n_irregular = h[4];
         // a whole input in which the count pass met no case bit: its mask is one run whatever the scatter pass would write -- no case bits
@@ -2304,7 +2304,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
             // Direct blocks: a whole input at level 1 (no match finder unless the look at the stream says so), blocks of exactly 32 KiB
             // (the stream's ragged end is coded as a part of its own, ennaf_streams), from 8 MiB of packed bases up
             const u64 n_seqb = (T + 1) / 2;
-            const char *ed = getenv("NAF_GPU_DIRECT"), *epf = getenv("NAF_GPU_PREFER_FLAT"), *ebl = getenv("NAF_GPU_BLOCK_LOG"), *epr = getenv("NAF_GPU_PROBE"), *elz = getenv("NAF_GPU_LZ");
+            const char *ed = ctx_opt(c, "DIRECT"), *epf = ctx_opt(c, "PREFER_FLAT"), *ebl = ctx_opt(c, "BLOCK_LOG"), *epr = ctx_opt(c, "PROBE"), *elz = ctx_opt(c, "LZ");
             const u32 prefer_flat = epf && epf[0] ? (u32)atoi(epf) : 16u;
             const u64 nd64 = n_seqb >> 15;
             if (allow_direct && o->level <= 1 && !o->long_log && !(ed && ed[0] == '0') && prefer_flat >= 2 && !(ebl && atoi(ebl) != 15) && !(epr && epr[0] == '1') && !(elz && !strcmp(elz, "all"))
@@ -2312,10 +2312,10 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
                 S.nd = (u32)nd64; S.direct = (u8 *)arena_alloc(c, S.nd); if (!S.direct) return NAF_GPU_ENOMEM;
                 LAUNCH(c, "ennaf_direct_blocks", k_direct_blocks, cdiv(S.nd, 4), 256, 0, d_text, (const u64 *)t_seq, (const u32 *)t_reg, tiles, S.nd, prefer_flat, (epr && epr[0] == '0') ? 0 : 1, S.direct);
                 O.direct = S.direct; O.nd = S.nd;
-                if (getenv("NAF_GPU_DEBUG_DIRECT")) {
+                if (ctx_tracing(c)) {
                     std::vector<u8> hd(S.nd); hipStreamSynchronize(c->stream); hipMemcpy(hd.data(), S.direct, S.nd, hipMemcpyDeviceToHost);
                     u64 k = 0; for (u8 v : hd) k += v;
-                    fprintf(stderr, "[direct] %llu of %u blocks\n", (unsigned long long)k, S.nd);
+                    ctx_trace(c, "[direct] %llu of %u blocks\n", (unsigned long long)k, S.nd);
                 }
             }
             // (S.sc4 stays valid until the call ends -- the tables live in the arena: the same pass can run again without direct blocks
@@ -2427,7 +2427,7 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
             if (nb) LAUNCH(c, "ennaf_mask_bscatter", k_maskb_scatter, mt, 256, 0, (const u64 *)S.casebits, T, (const u64 *)tc, nb, bnd, K.prev_masked);
             // runs of fewer than 255 bases only: a unit per run, in run order, written on that assumption (NAF_GPU_MASK_SHORT=0: never assumed)
             u64 longs = 1;
-            { const char *ms = getenv("NAF_GPU_MASK_SHORT");
+            { const char *ms = ctx_opt(c, "MASK_SHORT");
               if (!(ms && ms[0] == '0')) {
                   nu = nb + 1 - (K.skip_run0 ? 1 : 0);
                   s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
@@ -2494,7 +2494,7 @@ static int ennaf_windows(naf_gpu_ctx *c, EnnafStreams &X, const naf_gpu_ennaf_op
     if (o->level <= 1) { X.flags[4] |= ZENC_FRAME_TREE; X.flags[5] |= ZENC_FRAME_TREE; }
     if (o->long_log) { X.window_log[4] = o->long_log < 10 ? 10 : o->long_log > 31 ? 31 : o->long_log; X.lz[4] = 1; }
     else if (!wl && X.present[4] && X.len[4]) {
-        const char *pe = getenv("NAF_GPU_PROBE");                 // "0": never look, "1": always match
+        const char *pe = ctx_opt(c, "PROBE");                 // "0": never look, "1": always match
         u32 share = 0;
         if (pe && pe[0] == '1') share = 1024;
         else if (!(pe && pe[0] == '0') && defer) { *defer = true; return 0; }
@@ -2631,7 +2631,7 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
     // codes ids, names, lengths and mask (dozens of small launches and a dozen read-backs) on its own; the sections still land in
     // file order, each behind the one before.
     naf_gpu_ctx *sc = c->side;
-    const char *eo = getenv("NAF_GPU_ENC_OVERLAP");
+    const char *eo = ctx_opt(c, "ENC_OVERLAP");
     const bool force_overlap = eo && !strcmp(eo, "2");             // tests: the concurrent path on inputs of any size
     const bool overlap = sc && !(eo && !strcmp(eo, "0")) && (force_overlap || S.T >= (32u << 20) || S.n_qual >= (16u << 20));
     EnnafStreams X;

@@ -21,7 +21,7 @@ static IoPool *io_pool(naf_gpu_ctx *c)
 {
     if (c->io_pool) return (IoPool *)c->io_pool;
     IoPool *p = new IoPool();
-    const char *e = getenv("NAF_GPU_IO_THREADS");
+    const char *e = ctx_opt(c, "IO_THREADS");
     int n = e ? atoi(e) : 8; if (n < 1) n = 1; if (n > 16) n = 16;
     p->lanes = n;
     c->io_pool = p;

@@ -34,6 +34,56 @@ extern "C" const char *naf_gpu_strerror(int code)
 
 extern "C" const char *naf_gpu_last_error(const naf_gpu_ctx *c) { return c ? c->err : "no context"; }
 
+// ---- options ---------------------------------------------------------------------------------------------------------------------
+extern char **environ;
+static const naf_gpu_ctx *opt_root(const naf_gpu_ctx *c) { return c && c->root ? c->root : c; }
+const char *ctx_opt(const naf_gpu_ctx *c, const char *name)
+{
+    const naf_gpu_ctx *r = opt_root(c);
+    if (!r || !r->opts) return nullptr;
+    for (const auto &kv : r->opts->kv) if (kv.first == name) return kv.second.c_str();
+    return nullptr;
+}
+bool ctx_tracing(const naf_gpu_ctx *c) { const naf_gpu_ctx *r = opt_root(c); return r && r->opts && r->opts->tracing; }
+static std::mutex trace_mutex;
+void ctx_trace(naf_gpu_ctx *c, const char *fmt, ...)
+{
+    naf_gpu_ctx *r = (naf_gpu_ctx *)opt_root(c);
+    if (!r || !r->opts || !r->opts->tracing) return;
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    std::lock_guard<std::mutex> g(trace_mutex);
+    if (r->opts->trace.size() < (1u << 20)) r->opts->trace += buf;
+}
+static void opts_set(CtxOpts *o, const char *name, const char *value)
+{
+    for (size_t i = 0; i < o->kv.size(); i++) if (o->kv[i].first == name) {
+        if (value) o->kv[i].second = value; else o->kv.erase(o->kv.begin() + i);
+        goto done;
+    }
+    if (value) o->kv.emplace_back(name, value);
+done:
+    if (!strcmp(name, "TRACE")) o->tracing = value && value[0] == '1';
+}
+static void opts_from_environment(CtxOpts *o)
+{
+    for (char **e = environ; e && *e; e++) {
+        if (strncmp(*e, "NAF_GPU_", 8) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        if (!eq) continue;
+        opts_set(o, std::string(*e + 8, (size_t)(eq - (*e + 8))).c_str(), eq + 1);
+    }
+}
+extern "C" int naf_gpu_set_option(naf_gpu_ctx *c, const char *name, const char *value)
+{
+    if (!c || !c->opts || !name || !name[0]) return NAF_GPU_EARG;
+    if (!strncmp(name, "NAF_GPU_", 8)) name += 8;
+    opts_set(c->opts, name, value);
+    return NAF_GPU_OK;
+}
+extern "C" const char *naf_gpu_get_trace(naf_gpu_ctx *c) { return c && c->opts ? c->opts->trace.c_str() : ""; }
+extern "C" void naf_gpu_clear_trace(naf_gpu_ctx *c) { if (c && c->opts) c->opts->trace.clear(); }
+
 extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
 {
     if (!out) return NAF_GPU_EARG;
@@ -46,6 +96,7 @@ extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
     if (hipSetDevice(device) != hipSuccess) return NAF_GPU_ENODEV;
     naf_gpu_ctx *c = new naf_gpu_ctx();
     c->device = device;
+    c->opts = new CtxOpts(); opts_from_environment(c->opts);          // the one look at the environment
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return NAF_GPU_EHIP; }
     c->own_stream = true;
     c->h_stage_cap = 1 << 16;
@@ -63,7 +114,7 @@ extern "C" int naf_gpu_init(int device, naf_gpu_ctx **out)
         int prio_lo = 0, prio_hi = 0; hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         for (int k = 0; k < 4; k++) {
             naf_gpu_ctx *sc = new naf_gpu_ctx();
-            sc->device = device; sc->d_predef = c->d_predef; sc->h_stage_cap = 1 << 16;
+            sc->device = device; sc->d_predef = c->d_predef; sc->h_stage_cap = 1 << 16; sc->root = c;
             // highest priority: the side chains are many tiny kernels; behind the payload's bulk kernels they would only be scheduled
             // once those drain, and the call would end up waiting for them
             if (hipStreamCreateWithPriority(&sc->stream, hipStreamNonBlocking, prio_hi) != hipSuccess || hipHostMalloc((void **)&sc->h_stage, sc->h_stage_cap, hipHostMallocDefault) != hipSuccess) {
@@ -152,6 +203,7 @@ extern "C" void naf_gpu_shutdown(naf_gpu_ctx *c)
     if (c->d_seqctab) hipFree(c->d_seqctab);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c->opts;
     delete c;
 }
 
@@ -205,10 +257,22 @@ void arena_settle(naf_gpu_ctx *c)
     for (naf_gpu_ctx *x : all) {
         if (!x || x->chunks.size() <= 1) continue;
         size_t total = 0;
-        for (auto &ch : x->chunks) { total += ch.cap; hipFree(ch.base); }
-        x->chunks.clear();
+        for (auto &ch : x->chunks) total += ch.cap;
+        // the new block first when the device has room for both (a failure then changes nothing); else the chunks go first, and a
+        // failure of the one allocation -- the memory was just there -- is left in the context's error text: the next call grows again
         u8 *p = nullptr;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > total + ((size_t)1 << 30) && hipMalloc((void **)&p, total) == hipSuccess) {
+            for (auto &ch : x->chunks) hipFree(ch.base);
+            x->chunks.clear();
+            x->chunks.push_back({ p, total, 0 });
+            continue;
+        }
+        (void)hipGetLastError();
+        for (auto &ch : x->chunks) hipFree(ch.base);
+        x->chunks.clear();
         if (hipMalloc((void **)&p, total) == hipSuccess) x->chunks.push_back({ p, total, 0 });
+        else { (void)hipGetLastError(); ctx_fail(c, NAF_GPU_ENOMEM, "arena consolidation: hipMalloc(%zu) failed after the call (the next call allocates again)", total); }
     }
 }
 
@@ -397,8 +461,9 @@ static hipEvent_t ev_get(naf_gpu_ctx *c)
 
 void ktime_begin(naf_gpu_ctx *c, const char *name)
 {
-    static const int sync_debug = (getenv("NAF_GPU_SYNC_DEBUG") && getenv("NAF_GPU_SYNC_DEBUG")[0] == '1') ? 1 : 0;
-    if (sync_debug) fprintf(stderr, "[launch] %s\n", name);
+#ifdef NAF_GPU_DEVELOPMENT
+    if (ctx_opt_is(c, "SYNC_DEBUG", '1')) fprintf(stderr, "[launch] %s\n", name);
+#endif
     if (!c->timing) return;
     KTime k; k.name = name; k.a = ev_get(c); k.b = ev_get(c);
     hipEventRecord(k.a, c->stream);
@@ -407,10 +472,11 @@ void ktime_begin(naf_gpu_ctx *c, const char *name)
 
 void ktime_end(naf_gpu_ctx *c)
 {
-    // NAF_GPU_SYNC_DEBUG=1 (development): every launch is waited for and named on stderr -- the last name printed before a hang or a
-    // fault is the kernel that did it
-    static const int sync_debug = (getenv("NAF_GPU_SYNC_DEBUG") && getenv("NAF_GPU_SYNC_DEBUG")[0] == '1') ? 1 : 0;
-    if (sync_debug) { fprintf(stderr, "[launch] ...\n"); hipError_t e = hipStreamSynchronize(c->stream); fprintf(stderr, "[launch] done: %s\n", hipGetErrorString(e)); }
+    // development builds (make DEV=1: -DNAF_GPU_DEVELOPMENT) with SYNC_DEBUG=1: every launch is waited for and named on stderr -- the last
+    // name printed before a hang or a fault is the kernel that did it.  Compiled out of the release build.
+#ifdef NAF_GPU_DEVELOPMENT
+    if (ctx_opt_is(c, "SYNC_DEBUG", '1')) { fprintf(stderr, "[launch] ...\n"); hipError_t e = hipStreamSynchronize(c->stream); fprintf(stderr, "[launch] done: %s\n", hipGetErrorString(e)); }
+#endif
     if (!c->timing) return;
     hipEventRecord(c->ktimes.back().b, c->stream);
 }

@@ -740,7 +740,7 @@ __global__ void k_build_fse(const u8 *src, ZBlock *blk, u32 nblk, FseE *pool, u3
 
 __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
                              const u64 *seq_base, const FseE *pool, const FseE *predef,
-                             u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st)
+                             u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st, u32 skip_own_tables)
 {
     __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     // the predefined tables (what this build's own LZ blocks use) in LDS: the lane's whole job is a chain of dependent table reads
@@ -756,6 +756,8 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
     sizes[i] = b.regen;
     if (b.btype != BT_COMP || b.nseq == 0 || b.err) return;
     const i32 *own[3] = { own_ll, own_of, own_ml };
+    if (skip_own_tables && own_ll[i] >= 0 && own_of[i] >= 0 && own_ml[i] >= 0 &&
+        !(blk[own_ll[i]].modes[0] == SM_PREDEF && blk[own_of[i]].modes[1] == SM_PREDEF && blk[own_ml[i]].modes[2] == SM_PREDEF)) return;     // k_decode_seq_wave's
     const u32 predef_off[3] = { 0, 64, 96 }, predef_log[3] = { 6, 5, 6 };
     SeqTab tab[3];
     for (int k = 0; k < 3; k++) {
@@ -788,6 +790,68 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
     } else
     e = zstd_decode_sequences<BitReloadWindow, true>(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tab,
                                  o_ll + base, o_ml + base, o_of + base, rep_out, &sll, &sml, &uses_rep, BitReloadWindow());
+    if (e) { set_err(st, e); b.err = e; return; }
+    if (uses_rep) atomicOr(&st->rep_slow, 2u);
+    if (sll > b.lit_regen || b.lit_regen + sml > ZBLOCK_MAX) { set_err(st, ZE_CORRUPT); b.err = ZE_CORRUPT; return; }
+    b.rep_out[0] = rep_out[0]; b.rep_out[1] = rep_out[1]; b.rep_out[2] = rep_out[2];
+    b.regen = (u32)(b.lit_regen + sml);
+    sizes[i] = b.regen;
+    atomicMax(&st->max_seq_regen, b.regen);
+}
+
+// The sequences of a block that is NOT under the three predefined tables (what libzstd writes: FSE-coded tables of the block's own or of
+// an earlier block, RLE symbols) -- a WAVEFRONT per block: its 64 lanes copy the three tables in force into LDS (at most 512 + 256 + 512
+// cells, an RLE symbol as one cell of zero bits under log 0), then one lane walks the sequences with the routine the predefined tables
+// have (zstd_decode_sequences_predef with the tables' own logs): every cell a 4-byte LDS read.  A lane per block on tables in the pool
+// (k_decode_seq's general routine: three dependent flat loads from global memory per sequence) took 2.4 us per sequence -- 12 ms for a
+// block of five thousand, whatever the size of the frame (profiles/r05_levels_before.txt).
+__global__ __launch_bounds__(64) void k_decode_seq_wave(const u8 *src, ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
+                                                         const u64 *seq_base, const FseE *pool, const FseE *predef,
+                                                         u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st)
+{
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ FseE s_tab[512 + 256 + 512];
+    __shared__ u32 s_llt[36], s_mlt[53];
+    const u32 t = blockIdx.x, lane = threadIdx.x;
+    if (t >= n_seq_blk) return;
+    const u32 i = seq_list[t];
+    ZBlock &b = blk[i];
+    if (b.err) return;
+    const i32 ob[3] = { own_ll[i], own_of[i], own_ml[i] };
+    if (ob[0] < 0 || ob[1] < 0 || ob[2] < 0) { if (lane == 0) { set_err(st, ZE_CORRUPT); b.err = ZE_CORRUPT; } return; }      // repeat mode without a table
+    const u32 m0 = blk[ob[0]].modes[0], m1 = blk[ob[1]].modes[1], m2 = blk[ob[2]].modes[2];
+    if (m0 == SM_PREDEF && m1 == SM_PREDEF && m2 == SM_PREDEF) return;                                                  // k_decode_seq's
+    const u32 tab_off[3] = { 0, 512, 768 }, predef_off[3] = { 0, 64, 96 }, predef_log[3] = { 6, 5, 6 }, max_sym[3] = { 35, 31, 52 };
+    const u32 mode[3] = { m0, m1, m2 };
+    u32 log[3]; bool bad = false;
+    for (int k = 0; k < 3; k++) {
+        const ZBlock &q = blk[ob[k]];
+        if (mode[k] == SM_RLE) {
+            log[k] = 0;
+            if (q.fse_tab[k] > max_sym[k]) bad = true;
+            if (lane == 0) { FseE r; r.sym = (u8)q.fse_tab[k]; r.nbits = 0; r.base = 0; s_tab[tab_off[k]] = r; }
+        } else {
+            const FseE *from = mode[k] == SM_PREDEF ? predef + predef_off[k] : pool + q.fse_tab[k];
+            log[k] = mode[k] == SM_PREDEF ? predef_log[k] : q.fse_log[k];
+            for (u32 x = lane; x < (1u << log[k]); x += 64) s_tab[tab_off[k] + x] = from[x];
+        }
+    }
+    zstd_seq_code_tables(s_llt, s_mlt, lane, 64);
+    __syncthreads();
+    if (lane) return;
+    if (bad) { set_err(st, ZE_CORRUPT); b.err = ZE_CORRUPT; return; }
+    b.fse_owner[0] = ob[0]; b.fse_owner[1] = ob[1]; b.fse_owner[2] = ob[2];
+    const u64 base = seq_base[i]; u64 sll = 0, sml = 0;
+    b.seq_base = base;
+    u32 rep_out[3]; bool uses_rep = false;
+    u8 e = zstd_decode_sequences_predef<const FseE *, const u32 *, true>(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, s_tab, s_tab + 512, s_tab + 768, s_llt, s_mlt,
+                                                                        o_ll + base, o_ml + base, o_of + base, rep_out, &sll, &sml, &uses_rep, log[0], log[1], log[2]);
+    if (e == 0xFF) {                                               // a stream of fewer than 8 bytes: the general routine
+        SeqTab tp[3];
+        for (int k = 0; k < 3; k++) { tp[k].t = s_tab + tab_off[k]; tp[k].log = log[k]; tp[k].rle = mode[k] == SM_RLE; tp[k].rle_sym = blk[ob[k]].fse_tab[k]; }
+        e = zstd_decode_sequences<BitReloadWindow, true>(src + b.src_off + b.seq_bits_off, b.seq_bits_size, b.nseq, tp,
+                                                          o_ll + base, o_ml + base, o_of + base, rep_out, &sll, &sml, &uses_rep, BitReloadWindow());
+    }
     if (e) { set_err(st, e); b.err = e; return; }
     if (uses_rep) atomicOr(&st->rep_slow, 2u);
     if (sll > b.lit_regen || b.lit_regen + sml > ZBLOCK_MAX) { set_err(st, ZE_CORRUPT); b.err = ZE_CORRUPT; return; }
@@ -2274,11 +2338,11 @@ int zstd_init_tables(naf_gpu_ctx *c)
 // per symbol of the longest stream: 0.7 GB of this build's blocks, 2.8 GB of libzstd's -- with as many parts as leave a lane
 // NAF_GPU_HUF_PART symbols (default 128) and the device no more than a quarter of a million lanes.
 // NAF_GPU_HUF_PAR=0: never, =N: 2^N parts wherever the streams are long enough.
-static u32 huf_par_plog(u32 max_lit_regen, u64 n_blocks)
+static u32 huf_par_plog(const naf_gpu_ctx *c, u32 max_lit_regen, u64 n_blocks)
 {
-    const char *e = getenv("NAF_GPU_HUF_PAR");
+    const char *e = ctx_opt(c, "HUF_PAR");
     if (e && e[0] == '0') return 0;
-    const char *t = getenv("NAF_GPU_HUF_PART");
+    const char *t = ctx_opt(c, "HUF_PART");
     u32 target = t ? (u32)atoi(t) : 128u; if (target < 64) target = 64;
     const u32 nmax = (max_lit_regen + 3) / 4;                     // symbols of the longest stream (blocks of more than 1 KiB have four)
     u32 plog = 0;
@@ -2288,13 +2352,13 @@ static u32 huf_par_plog(u32 max_lit_regen, u64 n_blocks)
     while (plog && ((n_blocks * 4) << plog) > (1u << 18)) plog--;      // (the device holds 200 k of this kernel's lanes at a time: more parts only add margins)
     return plog;
 }
-static u32 huf_par_margin_env() { const char *m = getenv("NAF_GPU_HUF_MARGIN"); return m ? (u32)atoi(m) : 0u; }
+static u32 huf_par_margin_env(const naf_gpu_ctx *c) { const char *m = ctx_opt(c, "HUF_MARGIN"); return m ? (u32)atoi(m) : 0u; }
 
 #define ZSTD_NEED_TWO_PASS (-100)
 // tables of many distinct trees: sixteen lanes per tree (NAF_GPU_HUF_BUILD16=0: one lane per tree, the cross-check)
 static int launch_build_huf(naf_gpu_ctx *c, u32 count, const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table, const i32 *own_huf, u32 gate, u32 phase)
 {
-    const char *e = getenv("NAF_GPU_HUF_BUILD16");
+    const char *e = ctx_opt(c, "HUF_BUILD16");
     if (e && e[0] == '0') LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(count, 64), 64, 0, src, blk, nblk, pool, pool_cap, st, first, range4, always_table, own_huf, gate, phase);
     else LAUNCH(c, "zstd_build_huf", k_build_huf16, cdiv(count, HUFG_TREES), 256, 0, src, blk, nblk, pool, pool_cap, st, first, range4, always_table, own_huf, gate, phase);
     return 0;
@@ -2330,12 +2394,12 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(ZStat), c->stream));
     // ---- block index
     ZBlock *blk = nullptr; ZStat hs; bool indexed = false;
-    const char *nospec = getenv("NAF_GPU_SERIAL_INDEX");
-    const char *fl_env = getenv("NAF_GPU_FLAT");                                 // "0": every block through the serial kernel (cross-check)
+    const char *nospec = ctx_opt(c, "SERIAL_INDEX");
+    const char *fl_env = ctx_opt(c, "FLAT");                                 // "0": every block through the serial kernel (cross-check)
     const u32 always_table = (fl_env && fl_env[0] == '0') ? 1u : 0u;
-    const char *smin = getenv("NAF_GPU_SPEC_MIN");                      // tests: frames of a few dozen blocks through the paths of the big ones
+    const char *smin = ctx_opt(c, "SPEC_MIN");                      // tests: frames of a few dozen blocks through the paths of the big ones
     const u32 spec_min = smin ? (u32)atoi(smin) : 512u;
-    const char *un_env = getenv("NAF_GPU_UNIFORM");                              // "0": a uniform flat frame takes the general front too
+    const char *un_env = ctx_opt(c, "UNIFORM");                              // "0": a uniform flat frame takes the general front too
     const bool uni_wanted = c->zflat && !fuse && !always_table && !(un_env && un_env[0] == '0');
     // Frames of more than 4 MiB: 1 MiB chunks, candidates in the first 40 KiB / 128 KiB of each.  Smaller frames can still hold
     // thousands of tiny blocks (ids / names / lengths that compress 100:1 in 16 KiB blocks, a mask stream that is 1200 RLE blocks
@@ -2366,8 +2430,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         // the stride index first (frames of more than 4 MiB whose first block is a compressed one that is not the last): three launches and
         // a read-back; a frame it cannot take costs that read-back before the speculative index starts
         {
-            const char *se = getenv("NAF_GPU_STRIDE_INDEX");
-            if (getenv("NAF_GPU_DEBUG_STRIDE")) fprintf(stderr, "[stride?] len %zu hdr %u hl %zu first %02x %02x %02x\n", src_len, fh.hdr_size, hl, hb[fh.hdr_size], hb[fh.hdr_size + 1], hb[fh.hdr_size + 2]);
+            const char *se = ctx_opt(c, "STRIDE_INDEX");
+            if (ctx_tracing(c)) ctx_trace(c, "[stride?] len %zu hdr %u hl %zu first %02x %02x %02x\n", src_len, fh.hdr_size, hl, hb[fh.hdr_size], hb[fh.hdr_size + 1], hb[fh.hdr_size + 2]);
             if (src_len > 4ull * SPEC_CHUNK && fh.hdr_size + 3 <= hl && !(se && se[0] == '0')) {
                 const u32 h0 = (u32)hb[fh.hdr_size] | ((u32)hb[fh.hdr_size + 1] << 8) | ((u32)hb[fh.hdr_size + 2] << 16);
                 const u32 S = 3 + (h0 >> 3);
@@ -2393,8 +2457,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     if (U) { void *hp[3] = { &hs, res2, &hu }; const void *dp[3] = { st, sres, U }; const size_t nb[3] = { sizeof hs, 8, sizeof hu }; rc = ctx_readbackv(c, 3, hp, dp, nb); }
                     else rc = ctx_readback2(c, &hs, st, sizeof hs, res2, sres, 8);
                     if (rc) return rc;
-                    if (getenv("NAF_GPU_DEBUG_STRIDE")) fprintf(stderr, "[stride] len %zu S %u nmax %u prefix %u verdict %u err %u nblk %u\n", src_len, S, nmax, res2[0], res2[1], hs.err, hs.nblk);
-                    if (getenv("NAF_GPU_DEBUG_FLAT") && U) fprintf(stderr, "[uniform?] ok %u bad %u prefix %u blocks %u huffman %u regen %u total %llu\n", hu.ok, hu.bad, hu.np, hu.nblk, hu.nhb, hu.regen0, (unsigned long long)hu.total_out);
+                    if (ctx_tracing(c)) ctx_trace(c, "[stride] len %zu S %u nmax %u prefix %u verdict %u err %u nblk %u\n", src_len, S, nmax, res2[0], res2[1], hs.err, hs.nblk);
+                    if (ctx_tracing(c) && U) ctx_trace(c, "[uniform?] ok %u bad %u prefix %u blocks %u huffman %u regen %u total %llu\n", hu.ok, hu.bad, hu.np, hu.nblk, hu.nhb, hu.regen0, (unsigned long long)hu.total_out);
                     if (res2[1] == 1u && !hs.err && hs.nblk && hu.ok && !hu.bad) {
                         // every block repeats the first: the caller's emit kernel reads the streams in place (as below, without the block table)
                         ZFlat *zf = c->zflat;
@@ -2538,7 +2602,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     // (a final Raw block is allowed: this build's encoder puts the byte with the padding nibble of an odd stream there, so that it does
     // not bring a seventeenth symbol into the last Huffman block)
     const bool flat_tail = hs.last_raw != 0 && nblk >= 2 && hs.n_plain_huf == nblk - 1;
-    if (getenv("NAF_GPU_DEBUG_FLAT") && c->zflat) fprintf(stderr, "[flat?] spec %d nblk %u seq_blk %u distinct %u built %u n_flat %u log %u plain %u last_raw %u always %u\n", (int)spec, nblk, n_seq_blk, hs.n_huf_distinct, hs.n_huf_built, hs.n_flat, hs.max_huf_log, hs.n_plain_huf, hs.last_raw, always_table);
+    if (ctx_tracing(c) && c->zflat) ctx_trace(c, "[flat?] spec %d nblk %u seq_blk %u distinct %u built %u n_flat %u log %u plain %u last_raw %u always %u\n", (int)spec, nblk, n_seq_blk, hs.n_huf_distinct, hs.n_huf_built, hs.n_flat, hs.max_huf_log, hs.n_plain_huf, hs.last_raw, always_table);
     if (c->zflat && lit_only_spec && nblk > 0 && hs.n_huf_distinct == 1 && hs.n_huf_built == 1 && hs.n_flat == 1 && hs.max_huf_log == 4 && (hs.n_plain_huf == nblk || flat_tail) && !always_table) {
         // every block a plain Huffman block of the same flat 4-bit tree: the caller's emit kernel reads the streams in place
         ZFlat *zf = c->zflat;
@@ -2562,7 +2626,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     // natural offsets; the caller's emit reads the rest in place.  Whole-stream calls only; a frame whose blocks mostly need
     // decoding takes the ordinary path below (NAF_GPU_FLAT_MIXED=0: always).
     {
-        const char *fm = getenv("NAF_GPU_FLAT_MIXED");
+        const char *fm = ctx_opt(c, "FLAT_MIXED");
         if (c->zflat && lit_only_spec && nblk > 0 && !always_table && !rg && hs.flat_main_inv && d_dst && hs.total_out <= dst_cap && !(fm && fm[0] == '0')) {
             const u32 main = 0xFFFFFFFFu - hs.flat_main_inv;
             ZFlat *zf = c->zflat;
@@ -2578,7 +2642,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             u32 nx2[2] = { 0, 0 };
             if ((rc = ctx_readback(c, nx2, d_nx, 8))) return rc;
             const u32 n_dec = nx2[0], n_walk = nx2[1];
-            if (getenv("NAF_GPU_DEBUG_FLAT")) fprintf(stderr, "[flat mixed] nblk %u decoded %u main %u\n", nblk, n_dec, main);
+            if (ctx_tracing(c)) ctx_trace(c, "[flat mixed] nblk %u decoded %u main %u\n", nblk, n_dec, main);
             if ((u64)n_dec * 2 <= nblk) {
                 LAUNCH(c, "zstd_flat_streams", k_flat_streams_mixed, cdiv(4ull * nblk, 256), 256, 0, d_src, (const ZBlock *)blk, nblk, (const u8 *)cls, si, st, (const u64 *)d_total_out);
                 zf->decoded_ev = nullptr; zf->later = nullptr;
@@ -2592,7 +2656,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     zf->later = new std::function<int()>([=]() -> int {
                         naf_gpu_ctx *c = aux ? aux : mc;
                         if (c != mc) HIP_TRY(mc, hipStreamWaitEvent(c->stream, mc->split_ev[0], 0));      // recorded by the caller behind its tile index
-                        const u32 plog = n_walk ? huf_par_plog(hs0.max_lit_regen, n_walk) : 0u;
+                        const u32 plog = n_walk ? huf_par_plog(c, hs0.max_lit_regen, n_walk) : 0u;
                         u32 max_log = hs0.max_huf_log;
                         if (pending && n_walk && !plog) {
                             // the one-lane-per-stream kernel takes its tables from the pool: the trees left out so far, now
@@ -2608,7 +2672,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                             // (k_huf_par builds the tables it lacks itself, a workgroup at a time, in LDS)
                             const u32 slot = pending ? (u32)HUF_TAB_MAX : huf_slot_bytes(max_log);
                             LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)nblk << (plog + 2), 64), 64, (plog >= 4 ? 1u : 16u >> plog) * slot,
-                                   d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, (u8 *)nullptr, st, 0u, plog, (const u8 *)cls, 1u, huf_par_margin_env(), pending ? 1u : 0u, src_len64);
+                                   d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, (u8 *)nullptr, st, 0u, plog, (const u8 *)cls, 1u, huf_par_margin_env(c), pending ? 1u : 0u, src_len64);
                         } else if (n_walk) {
                             const u32 slot = huf_slot_bytes(max_log), ipitch = max_log > 7 ? HUF_IROW_BIG : HUF_IROW;
                             EmitP ep; memset(&ep, 0, sizeof ep);
@@ -2662,7 +2726,11 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     if (!lit_only_spec) {
         // (a lane per block, every lane on a chain of its own: a frame of a few thousand blocks spreads over more wavefronts, 16 lanes each)
         const u32 dsl = nblk < 32768 ? 16u : 64u;
+        // blocks under tables of their own (libzstd's) by a wavefront each with the tables in LDS, the others a lane per block
+        const u32 own_tabs = (n_seq_blk && !ctx_opt_is(c, "SEQ_WAVE", '0')) ? 1u : 0u;
         LAUNCH(c, "zstd_decode_seq", k_decode_seq, cdiv(nblk, dsl), dsl, 0, d_src, blk, nblk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
+               (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st, own_tabs);
+        if (own_tabs) LAUNCH(c, "zstd_decode_seq", k_decode_seq_wave, n_seq_blk, 64, 0, d_src, blk, (const u32 *)seq_list, n_seq_blk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
                (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st);
         if (n_seq_blk) LAUNCH(c, "zstd_rep_fast", k_rep_fast, cdiv(n_seq_blk, 256), 256, 0, blk, (const u32 *)seq_list, n_seq_blk, st);
         if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
@@ -2679,7 +2747,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     // blocks their matches copy from (k_seq_sources) and the neighbours of both are decoded into d_dst (literals, then the executor,
     // as below), everything else is read in place by the caller's emit.  Whole-stream calls (NAF_GPU_FLAT_SEQ=0: never).
     {
-        const char *fm = getenv("NAF_GPU_FLAT_MIXED"), *fsq = getenv("NAF_GPU_FLAT_SEQ");
+        const char *fm = ctx_opt(c, "FLAT_MIXED"), *fsq = ctx_opt(c, "FLAT_SEQ");
         if (c->zflat && spec && n_seq_blk && tables_built && !fuse && !always_table && !rg && hs.flat_main_inv && d_dst && hs.total_out <= dst_cap &&
             (u64)n_seq_blk * 8 <= nblk && !(fm && fm[0] == '0') && !(fsq && fsq[0] == '0')) {
             const u32 main = 0xFFFFFFFFu - hs.flat_main_inv;
@@ -2698,7 +2766,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             u32 nx2[2] = { 0, 0 };
             if ((rc = ctx_readback(c, nx2, d_nx, 8))) return rc;
             const u32 n_dec = nx2[0], n_walk = nx2[1];
-            if (getenv("NAF_GPU_DEBUG_FLAT")) fprintf(stderr, "[flat mixed] nblk %u decoded %u main %u (blocks with sequences %u)\n", nblk, n_dec, main, n_seq_blk);
+            if (ctx_tracing(c)) ctx_trace(c, "[flat mixed] nblk %u decoded %u main %u (blocks with sequences %u)\n", nblk, n_dec, main, n_seq_blk);
             if ((u64)n_dec * 2 <= nblk) {
                 LAUNCH(c, "zstd_flat_streams", k_flat_streams_mixed, cdiv(4ull * nblk, 256), 256, 0, d_src, (const ZBlock *)blk, nblk, (const u8 *)cls, si, st, (const u64 *)d_total_out);
                 zf->decoded_ev = nullptr;
@@ -2707,20 +2775,20 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                 zf->later = new std::function<int()>([=]() -> int {
                     naf_gpu_ctx *c = aux ? aux : mc;
                     if (c != mc) HIP_TRY(mc, hipStreamWaitEvent(c->stream, mc->split_ev[0], 0));      // recorded by the caller behind its tile index
-                    const u32 plog = n_walk ? huf_par_plog(hs0.max_lit_regen, n_walk) : 0u;
+                    const u32 plog = n_walk ? huf_par_plog(c, hs0.max_lit_regen, n_walk) : 0u;
                     LAUNCH(c, "zstd_copy_fill", k_copy_fill<64>, 4 * nblk, 64, 0, d_src, (const ZBlock *)blk, nblk, d_dst, lits, 0u, (const u8 *)cls);
                     LAUNCH(c, "zstd_flat_literals", k_flat_literals<64>, 4 * nblk, 64, 0, d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lits, st, 0u, (const u8 *)cls);
                     if (n_walk && plog) {
                         const u32 slot = huf_slot_bytes(hs0.max_huf_log);
                         LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)nblk << (plog + 2), 64), 64, (plog >= 4 ? 1u : 16u >> plog) * slot,
-                               d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lits, st, 0u, plog, (const u8 *)cls, 1u, huf_par_margin_env(), 0u, src_len64);
+                               d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lits, st, 0u, plog, (const u8 *)cls, 1u, huf_par_margin_env(c), 0u, src_len64);
                     } else if (n_walk) {
                         const u32 slot = huf_slot_bytes(hs0.max_huf_log), ipitch = hs0.max_huf_log > 7 ? HUF_IROW_BIG : HUF_IROW;
                         EmitP ep; memset(&ep, 0, sizeof ep);
                         LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false>), cdiv(nblk, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 64 * HUF_OROW + 512,
                                d_src, (const ZBlock *)blk, nblk, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lits, st, 0u, ep, (u8 *)nullptr, ipitch, src_len64, 1u, (const u8 *)cls);
                     }
-                    const char *el = getenv("NAF_GPU_EXEC_LDS");
+                    const char *el = ctx_opt(c, "EXEC_LDS");
                     if (hs0.max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
                         LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, n_seq_blk, 64, ((hs0.max_seq_regen + 1023u) & ~1023u) + 64u, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
                                (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lits, d_dst, done2, st, (hs0.max_seq_regen + 1023u) & ~1023u);
@@ -2753,7 +2821,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         rg->got_lo = h4[2]; rg->got_hi = h4[3]; rg->ranged = true;
         if (h4[3] - h4[2] > dst_cap) return ctx_fail(c, NAF_GPU_ECAP, "zstd range output needs %llu bytes, capacity %zu", (unsigned long long)(h4[3] - h4[2]), dst_cap);
         d_dst -= bias;                                       // block b lands at d_dst_orig + (out_off[b] - got_lo)
-    } else if (rg && n_seq_blk && nblk > 0 && rg->want_hi > rg->want_lo && !(getenv("NAF_GPU_RANGE_CLOSURE") && getenv("NAF_GPU_RANGE_CLOSURE")[0] == '0')) {
+    } else if (rg && n_seq_blk && nblk > 0 && rg->want_hi > rg->want_lo && !(ctx_opt(c, "RANGE_CLOSURE") && ctx_opt(c, "RANGE_CLOSURE")[0] == '0')) {
         // blocks with matches: the range's dependency closure (kernels above).  On archives that are mostly literals -- what the
         // reference makes of a genome at its default level -- that is the range's own blocks and a few in front of them.
         u32 *f = arena_new<u32>(c, nblk); u64 *r4b = arena_new<u64>(c, 5 + 8); if (!f || !r4b) return NAF_GPU_ENOMEM;
@@ -2763,7 +2831,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         LAUNCH(c, "zstd_range_closure", k_range_closure, 1, 64, 0, (const u32 *)f, (const u64 *)sizes, nblk, (const u64 *)d_total_out, (const u64 *)r4b, (const i32 *)own_huf, (const u64 *)seq_rank, n_seq_blk, r4b + 5);
         u64 h7[7]; rc = ctx_readback(c, h7, r4b + 5, sizeof h7); if (rc) return rc;
         const u64 need = h7[3] - h7[2];
-        if (getenv("NAF_GPU_DEBUG_RANGE")) fprintf(stderr, "[range] want %llu..%llu -> blocks %llu..%llu (bytes %llu..%llu of %llu), tables from %llu, seq blocks %llu..%llu of %u\n", (unsigned long long)rg->want_lo, (unsigned long long)rg->want_hi,
+        if (ctx_tracing(c)) ctx_trace(c, "[range] want %llu..%llu -> blocks %llu..%llu (bytes %llu..%llu of %llu), tables from %llu, seq blocks %llu..%llu of %u\n", (unsigned long long)rg->want_lo, (unsigned long long)rg->want_hi,
                     (unsigned long long)h7[0], (unsigned long long)h7[1], (unsigned long long)h7[2], (unsigned long long)h7[3], (unsigned long long)hs.total_out, (unsigned long long)h7[4], (unsigned long long)h7[5], (unsigned long long)h7[6], n_seq_blk);
         if (need < hs.total_out) {
             if (need > dst_cap) {
@@ -2806,7 +2874,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         if (fuse && hs.max_huf_log > 7) return ZSTD_NEED_TWO_PASS;
         EmitP ep; memset(&ep, 0, sizeof ep); if (fuse) ep = *fuse;
         u32 ipitch = hs.max_huf_log > 7 ? HUF_IROW_BIG : HUF_IROW;
-        u32 ipitch_arg = ipitch | ((getenv("NAF_GPU_HUF_GENERIC") && getenv("NAF_GPU_HUF_GENERIC")[0] == '1') ? 0x8000u : 0u);
+        u32 ipitch_arg = ipitch | ((ctx_opt(c, "HUF_GENERIC") && ctx_opt(c, "HUF_GENERIC")[0] == '1') ? 0x8000u : 0u);
         if (b_count && fuse) LAUNCH(c, "zstd_huf_fused_emit", (k_huf_literals<true>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, slot * HUF_BLOCKS_PER_WG + 64 * ipitch + 512,
                d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, 0u, (const u8 *)nullptr);
         else if (b_count) {
@@ -2814,18 +2882,18 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             // blocks whose tree is flat go to k_flat_literals; the serial kernel is not launched when that is all of them
             const u32 flat_on = (hs.n_flat && !always_table) ? 1u : 0u;
             const bool serial_needed = !flat_on || hs.n_flat < hs.n_huf_built;
-            const u32 plog = huf_par_plog(hs.max_lit_regen, b_count), par_lds = (plog >= 4 ? 1u : 16u >> plog) * slot;
+            const u32 plog = huf_par_plog(c, hs.max_lit_regen, b_count), par_lds = (plog >= 4 ? 1u : 16u >> plog) * slot;
             // a frame of few trees (this build's frame tree, libzstd's runs of treeless blocks): workgroups with ONE table in LDS, the
             // workgroups whose blocks are under several trees through a second launch of the plain kernel (NAF_GPU_HUF_SHARED=0: never)
             u8 *redo = nullptr;
-            { const char *hsx = getenv("NAF_GPU_HUF_SHARED");
+            { const char *hsx = ctx_opt(c, "HUF_SHARED");
               if (serial_needed && !plog && (u64)hs.n_huf_distinct * 64 <= b_count && !(hsx && hsx[0] == '0')) {
                 redo = (u8 *)arena_alloc(c, (size_t)nblk + 16); if (!redo) return NAF_GPU_ENOMEM;
                 HIP_TRY(c, hipMemsetAsync(redo, 0, nblk, c->stream));
               } }
             const u32 huf_lds_shared = huf_lds - slot * (HUF_BLOCKS_PER_WG - 1u);
             ZSplit *sp = c->zsplit;
-            const char *smin = getenv("NAF_GPU_SPLIT_MIN");                      // blocks per part below which a split is not worth its launches (tests lower it)
+            const char *smin = ctx_opt(c, "SPLIT_MIN");                      // blocks per part below which a split is not worth its launches (tests lower it)
             const u32 split_min = smin ? (u32)atoi(smin) : 4096u;
             if (sp && !rg && n_seq_blk == 0 && b_first == 0 && b_count == nblk && b_count >= split_min * (u32)sp->parts && b_count >= 16u * HUF_BLOCKS_PER_WG * (u32)sp->parts) {
                 // literal-only frame of a whole-text call: block ranges in order, an event behind each (see ZSplit); the raw / RLE
@@ -2848,7 +2916,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     u32 hi_b = k + 1 == sp->parts ? b_count : (u32)((u64)b_count * (k + 1) / sp->parts) & ~(HUF_BLOCKS_PER_WG - 1u);
                     if (hi_b > lo_b && flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals<256>, hi_b - lo_b, 256, 0, d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, lo_b, (const u8 *)nullptr);
                     if (hi_b > lo_b && serial_needed && plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)(hi_b - lo_b) << (plog + 2), 64), 64, par_lds,
-                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(), 0u, (u64)src_len);
+                           d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(c), 0u, (u64)src_len);
                     else if (hi_b > lo_b && serial_needed && redo) {
                         LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false, true>), cdiv(hi_b - lo_b, HUF_BLOCKS_PER_WG), 64, huf_lds_shared,
                                d_src, (const ZBlock *)blk, hi_b, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, lo_b, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr, redo);
@@ -2864,7 +2932,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             } else {
                 if (flat_on) LAUNCH(c, "zstd_flat_literals", k_flat_literals<256>, b_count, 256, 0, d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, d_dst, lit_scratch, st, b_first, (const u8 *)nullptr);
                 if (serial_needed && plog) LAUNCH(c, "zstd_huf_literals", k_huf_par, cdiv((u64)b_count << (plog + 2), 64), 64, par_lds,
-                   d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(), 0u, (u64)src_len);
+                   d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, plog, (const u8 *)nullptr, flat_on, huf_par_margin_env(c), 0u, (u64)src_len);
                 else if (serial_needed && redo) {
                     LAUNCH(c, "zstd_huf_literals", (k_huf_literals<false, true>), cdiv(b_count, HUF_BLOCKS_PER_WG), 64, huf_lds_shared,
                        d_src, (const ZBlock *)blk, b_end, (const i32 *)own_huf, (const u8 *)huf_pool, slot, d_dst, lit_scratch, st, b_first, ep, text, ipitch_arg, (u64)src_len, flat_on, (const u8 *)nullptr, redo);
@@ -2878,7 +2946,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
     }
     if (b_count && !fuse && !copy_fill_done && hs.n_plain_huf != nblk) LAUNCH(c, "zstd_copy_fill", k_copy_fill<256>, b_count, 256, 0, d_src, (const ZBlock *)blk, b_first + b_count, d_dst, lit_scratch, b_first, (const u8 *)nullptr);
     if (seq_t1 > seq_t0) {
-        const char *el = getenv("NAF_GPU_EXEC_LDS");                      // "0": always the HBM executor (cross-check)
+        const char *el = ctx_opt(c, "EXEC_LDS");                      // "0": always the HBM executor (cross-check)
         const u32 nx = seq_t1 - seq_t0;
         if (max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
             LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, nx, 64, ((max_seq_regen + 1023u) & ~1023u) + 64u, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, nblk,

@@ -1238,7 +1238,7 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     // ZENC_PREFER_FLAT: blocks of 2^k distinct symbols take k-bit codes unless Huffman coding saves a sixteenth of the block
     // (NAF_GPU_PREFER_FLAT=0: never; =d: the threshold 1/d)
     u32 prefer_flat = (with_magic & ZENC_PREFER_FLAT) ? 16u : 0u;
-    if (prefer_flat) { const char *pf = getenv("NAF_GPU_PREFER_FLAT"); if (pf && pf[0]) prefer_flat = (u32)atoi(pf); }
+    if (prefer_flat) { const char *pf = ctx_opt(c, "PREFER_FLAT"); if (pf && pf[0]) prefer_flat = (u32)atoi(pf); }
     with_magic &= ~(ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES | ZENC_FRAME_TREE);
     if (part) with_magic = 0;
     if (part && n == 0 && !part_last) {
@@ -1247,9 +1247,9 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     }
     u32 block_log = 15;                                          // 32 KiB: 4 streams of 8 KiB; more streams = more decode parallelism
     if (block_log_hint >= 10 && block_log_hint <= 17) block_log = (u32)block_log_hint;
-    const char *e = getenv("NAF_GPU_BLOCK_LOG");
+    const char *e = ctx_opt(c, "BLOCK_LOG");
     if (e) { int v = atoi(e); if (v >= 10 && v <= 17) block_log = (u32)v; }
-    const char *el = getenv("NAF_GPU_LZ");                       // "0": never, "all": every stream (tests)
+    const char *el = ctx_opt(c, "LZ");                       // "0": never, "all": every stream (tests)
     bool use_lz = lz || level >= 2;
     if (el && !strcmp(el, "0")) use_lz = false;
     if (el && !strcmp(el, "all")) use_lz = true;
@@ -1295,7 +1295,7 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
         LAUNCH(c, "zenc_flat_scan", k_zenc_flat_scan, cdiv(nblk, ZENC_FLATSCAN_WAVES), 64 * ZENC_FLATSCAN_WAVES, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, done, min_gain, prefer_flat, zenc_flat16(), direct);
     }
     // the frame's tree (k_zenc_plan): level 1 without the match finder, frames of enough blocks to sample; NAF_GPU_FRAME_TREE=0: a tree per block
-    const char *eft = getenv("NAF_GPU_FRAME_TREE");
+    const char *eft = ctx_opt(c, "FRAME_TREE");
     const bool frame_tree = frame_tree_ok && cache && !use_lz && !direct && !(eft && eft[0] == '0');
     u32 *fhist = nullptr; ZEncPlan *fplan = nullptr; u16 *fcodes = nullptr; u8 *ftree = nullptr;
     if (frame_tree) {
@@ -1317,7 +1317,7 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
         LAUNCH(c, "zenc_frame_ratio", k_zenc_frame_ratio, 1, 256, 0, fhist, (const u16 *)fcodes);
     }
     // (frames of a few blocks keep the tree with the planner: nothing to gain from a second launch)
-    const char *td = getenv("NAF_GPU_TREE_DEFER");
+    const char *td = ctx_opt(c, "TREE_DEFER");
     u8 *wt_defer = (nblk >= 256 && !(td && td[0] == '0')) ? (u8 *)arena_alloc(c, (size_t)nblk * 256) : nullptr;
     LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, (const u32 *)nullptr, (u64)0, cache, 0u, try_fse, min_gain, maxbits, prefer_flat, (const u8 *)done, wt_defer, (u32 *)nullptr, (const ZEncPlan *)fplan, (const u16 *)fcodes, (const u32 *)(fhist ? fhist + 257 : nullptr));
     if (wt_defer) LAUNCH(c, "zenc_tree", k_zenc_tree, cdiv(nblk, 64), 64, 64 * sizeof(ZTreeLane), nblk, plan, trees, offs, (const u8 *)wt_defer, min_gain);

@@ -31,6 +31,7 @@ static void done(int status, void *arg)
 {
     (void)arg;
     if (!success && created_output_file && out_file_path) remove(out_file_path);
+    if (gpu) { const char *tr = naf_gpu_get_trace(gpu); if (tr && *tr) fputs(tr, stderr); }       /* NAF_GPU_TRACE=1 (development): which paths the library took */
     detach_report(status);                                        /* the foreground process leaves with this status now; what follows is nobody's wait */
     if (gpu_init_started) { pthread_join(gpu_init_thread, NULL); gpu_init_started = false; }       /* (an exit while the device is still being opened) */
     if (gpu) naf_gpu_shutdown(gpu);

@@ -170,14 +170,14 @@ def test_cli_input_in_chunks(oracle, tmp_path):
 
 def test_line_wrapped_text_takes_the_regular_tile_kernels(tmp_path):
     """A guard on speed paths that parity tests cannot see: nearly every tile of a line-wrapped genome must be judged pure and
-    regular (k_enc_count_pure -> k_enc_scatter_regular), soft-masked or not; NAF_GPU_DEBUG_REG makes the encoder say how many were."""
+    regular (k_enc_count_pure -> k_enc_scatter_regular), soft-masked or not; under NAF_GPU_TRACE=1 the host prints what the library noted."""
     import re
     from naf_amd import synth
     rng = np.random.default_rng(9)
     bases = rng.choice(np.frombuffer(b"ACGTacgtNn", dtype=np.uint8), 3_000_000, p=[.2, .2, .2, .2, .04, .04, .04, .04, .02, .02])
     text = b">chr1 a line-wrapped record\n" + synth.wrap_lines(bases, 70) + b">chr2\n" + synth.wrap_lines(bases[:500_000], 70)
     src = tmp_path / "g.fa"; src.write_bytes(text)
-    e = subprocess.run([os.path.join(BIN, "ennaf"), str(src), "-c"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=dict(os.environ, NAF_GPU_DEBUG_REG="1"))
+    e = subprocess.run([os.path.join(BIN, "ennaf"), str(src), "-c"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=dict(os.environ, NAF_GPU_TRACE="1"))
     assert e.returncode == 0, e.stderr
     m = re.search(rb"\[reg\] tiles (\d+) need (\d+) regular (\d+)", e.stderr)
     assert m, e.stderr
