@@ -12,7 +12,9 @@
 //   scan             regenerated sizes -> output offsets
 //   k_huf_literals   ONE LANE PER HUFFMAN STREAM (4 per block, 16 blocks per wave), tables in LDS
 //   k_copy_fill      raw / RLE blocks and raw / RLE literals, one workgroup per block
-//   k_exec_seq       one wave per block with sequences, ticket-ordered, waits on per-block done flags
+//   k_lz_prep/_deps/_exec   sequences executed as dataflow: literals and positions per block, per match the earlier matches its
+//                    source was written by, then units of 1024 sequences sweep over whatever has its sources done
+//                    (k_exec_seq_lds: blocks of at most 16 KiB assembled in LDS, in block order; k_exec_batch / k_exec_seq: cross-checks)
 #include "ctx.h"
 #include "wgscan.h"
 #include "zstd_dec_core.h"
@@ -28,6 +30,7 @@ struct ZStat {                 // device-side counters read back by the host
     u32 n_huf_distinct, n_huf_built;   // tree descriptions that differ from their predecessor's (k_huf_dedup); tables actually built
     u32 max_lit_regen, n_huf_pending;  // largest literals section of a Huffman-coded block (k_huf_par sizes its parts by it); trees left without a table by k_build_huf's first phase
     u32 last_raw, flat_main_inv;       // size of the frame's last block when it is a Raw or (bit 31) RLE one, else 0; 0xFFFFFFFF - index of the FIRST block that defines a flat 4-bit tree (0: none)
+    u32 n_exec_done, pad_;             // blocks the sequence executors have published: a waiting block gives up only when this stands still
 };
 
 static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
@@ -1805,6 +1808,15 @@ __global__ __launch_bounds__(WGT) void k_copy_fill(const u8 *src, const ZBlock *
     }
 }
 
+// the block that holds output byte x, among blocks [0, hi) (offs[hi] > x is known); shift: log2 of the frame's block size when its first
+// blocks regenerate the same power of two (libzstd: 2^17 until the last block), 0xFF otherwise
+__device__ __forceinline__ u32 find_block(const u64 *offs, u32 hi, u64 x, u32 shift)
+{
+    if (shift < 64) { const u64 g = x >> shift; if (g < hi && offs[g] <= x && x < offs[g + 1]) return (u32)g; }
+    u32 lo = 0;
+    while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (offs[mid] <= x) lo = mid; else hi = mid; }
+    return lo;
+}
 // ---- sequence execution (3.1.1.4): one wave per block with sequences ----------------------------------------
 __device__ __forceinline__ void wait_block_done(volatile u32 *done, u32 j, ZStat *st)
 {
@@ -1812,9 +1824,16 @@ __device__ __forceinline__ void wait_block_done(volatile u32 *done, u32 j, ZStat
     if (threadIdx.x == 0) {
         // (bounded: a block that never completes -- a bug, or a frame whose sequences lie about their sources -- must end in wrong bytes
         // and an error, not in a device that has to be reset; about ten seconds)
-        u32 spins = 0;
-        while (__hip_atomic_load(&done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(2);
-        if (spins >= (1u << 26)) set_err(st, ZE_CORRUPT);          // gave up: what is read from block j is not its output -- the call reports the frame as corrupt
+        // (the count starts again whenever some block of the launch has finished meanwhile: a long chain of blocks is not a hang)
+        u32 spins = 0, seen = __hip_atomic_load(&st->n_exec_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(&done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins >= (1u << 24)) {
+                const u32 now = __hip_atomic_load(&st->n_exec_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (now == seen) { set_err(st, ZE_CORRUPT); break; }   // gave up: what is read from block j is not its output -- the call reports the frame as corrupt
+                seen = now; spins = 0;
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -1895,6 +1914,7 @@ __global__ __launch_bounds__(64) void k_exec_seq(const ZBlock *blk, const u32 *s
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&done[bi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&st->n_exec_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1928,7 +1948,9 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
     const u8 *lits = lit_scratch + out_off;
     u32 rep_in[3] = { b.rep_in[0], b.rep_in[1], b.rep_in[2] };
     const u64 sbase = b.seq_base;
-    u32 op = 0, lp = 0, nseq = b.err ? 0 : b.nseq, lo_idx = bi;
+    u32 op = 0, lp = 0, nseq = b.err ? 0 : b.nseq;
+    u32 shift = 0xFF;
+    if (nblk > 1) { const u64 b0 = offs[1] - offs[0]; if (b0 && !(b0 & (b0 - 1))) shift = (u32)(63 - __builtin_clzll(b0)); }
     bool bad = b.regen > obuf_cap;
     for (u32 s0 = 0; s0 < nseq && !bad; s0 += 64) {
         u32 n = nseq - s0 < 64 ? nseq - s0 : 64;
@@ -1960,13 +1982,16 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
             } else {
                 // source (partly) in earlier blocks: confirm every block from the one holding it up to the lowest one confirmed so far, then read HBM
                 u64 src_abs = pos_abs - ofj;
-                if (src_abs < offs[lo_idx]) {
-                    u32 lo = 0, hi = lo_idx;
-                    while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (offs[mid] <= src_abs) lo = mid; else hi = mid; }
-                    for (u32 q = lo_idx; q-- > lo;) wait_block_done(done, q, st);
-                    if (lo < lo_idx) lo_idx = lo;
-                }
                 u32 outside = (u32)(out_off - src_abs);                                // bytes of the pattern that lie before this block
+                {
+                    // only the blocks that hold those bytes (every block from there up to this one used to be confirmed: a frame whose
+                    // matches reach far back ran block after block)
+                    const u32 span = ofj < mlj ? ofj : mlj;
+                    const u64 last = src_abs + (span < outside ? span : outside) - 1;
+                    const u32 a = find_block(offs, bi, src_abs, shift);
+                    const u32 z = last < offs[a + 1] ? a : find_block(offs, bi, last, shift);
+                    for (u32 q = a; q <= z; q++) wait_block_done(done, q, st);
+                }
                 for (u32 k = lane; k < mlj; k += 64) {
                     u32 r = ofj >= mlj ? k : k % ofj;
                     obuf[d + k] = r < outside ? dst[src_abs + r] : obuf[r - outside];
@@ -1997,7 +2022,437 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&done[bi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&st->n_exec_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// ---- sequence execution, 64 sequences at a time (k_exec_batch) -------------------------------------------------------------------
+// k_exec_seq above walks a block's sequences one by one -- a load of the triple, a literal copy, a match copy, each behind the other,
+// ~1 us per sequence -- and, worse, confirmed EVERY block between a match's source and itself before it read that source: a frame whose
+// matches reach far back (a genome's repeats under libzstd's --long, or under levels that chain blocks) ran as one serial chain, block
+// after block: 0.75 s for 25 MB of packed bases, 15 s for 500 MB, at which point the bounded wait called the frame corrupt
+// (profiles/r05_levels_before.txt).  Here a wavefront still owns a block, but
+//   * takes 64 sequences per step: triples in one coalesced load, output and literal positions by two prefix sums;
+//   * copies the 64 literal runs a lane each (16 bytes at a time; long runs by the whole wavefront);
+//   * splits the matches: FAR ones -- the source ends in front of what this step writes, and does not overlap the match -- are
+//     independent of each other and of the step's own output: a lane each, as soon as the blocks their source lies in are done (only
+//     those blocks are looked at: one or two `done` flags found by a shift when the frame's blocks are equal, a binary search otherwise);
+//     NEAR ones -- source inside the step's own output, or overlapping -- go in order, the wavefront on one at a time, behind the far ones;
+//   * gives up a wait only when no block of the whole launch has finished for ~4 M polls (ZStat.n_exec_done), not after a fixed count.
+// Blocks are ticket-ordered as before: whatever a block waits for holds an earlier ticket, so it is running or done.
+__device__ __forceinline__ void lane_copy(u8 *d, const u8 *s, u32 n)                 // n bytes by ONE lane, at any alignment
+{
+    u32 i = 0;
+    for (; i + 16 <= n; i += 16) { uint4 v; __builtin_memcpy(&v, s + i, 16); __builtin_memcpy(d + i, &v, 16); }
+    if (n & 8) { u64 v; __builtin_memcpy(&v, s + i, 8); __builtin_memcpy(d + i, &v, 8); i += 8; }
+    if (n & 4) { u32 v; __builtin_memcpy(&v, s + i, 4); __builtin_memcpy(d + i, &v, 4); i += 4; }
+    if (n & 2) { u16 v; __builtin_memcpy(&v, s + i, 2); __builtin_memcpy(d + i, &v, 2); i += 2; }
+    if (n & 1) d[i] = s[i];
+}
+// blocks j0 .. j1 - 1 done, and block j1 done or at least `need` bytes into its output (prog: what a running block has published)
+__device__ __forceinline__ bool source_ready(const u32 *done, const u32 *prog, u32 j0, u32 j1, u32 need)
+{
+    for (u32 j = j0; j < j1; j++) if (__hip_atomic_load(&done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return false;
+    return __hip_atomic_load(&done[j1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || __hip_atomic_load(&prog[j1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+}
+#define EXEC_LANE_MAX 256u              // literal runs and far matches up to this many bytes are copied by their own lane
+__global__ __launch_bounds__(64) void k_exec_batch(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *offs, u32 nblk,
+                                                    const u32 *o_ll, const u32 *o_ml, const u32 *o_of,
+                                                    const u8 *lit_scratch, u8 *dst, u32 *done, u32 *prog, ZStat *st)
+{
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ u32 sh_ticket;
+    const u32 lane = threadIdx.x;
+    if (lane == 0) sh_ticket = atomicAdd(&st->ticket, 1u);
+    __syncthreads();
+    const u32 t = sh_ticket;
+    if (t >= n_seq_blk) return;
+    const u32 bi = seq_list[t];
+    const ZBlock &b = blk[bi];
+    const u64 out_off = b.out_off;
+    u8 *out = dst + out_off;
+    const u8 *lits = lit_scratch + out_off;
+    u32 rep_in[3] = { b.rep_in[0], b.rep_in[1], b.rep_in[2] };
+    const u64 sbase = b.seq_base;
+    const u32 nseq = b.err ? 0 : b.nseq;
+    u32 shift = 0xFF;
+    if (nblk > 1) { const u64 b0 = offs[1] - offs[0]; if (b0 && !(b0 & (b0 - 1))) shift = (u32)(63 - __builtin_clzll(b0)); }
+    u32 op = 0, lp = 0;
+    bool bad = false;
+    u32 spins = 0, seen = 0;                                   // the bounded wait: wave-uniform
+    for (u32 s0 = 0; s0 < nseq; s0 += 64) {
+        const u32 n = nseq - s0 < 64 ? nseq - s0 : 64;
+        u32 ll = 0, ml = 0, of = 0;
+        if (lane < n) { ll = o_ll[sbase + s0 + lane]; ml = o_ml[sbase + s0 + lane]; of = sym_resolve(o_of[sbase + s0 + lane], rep_in); }
+        u32 tot_all, tot_ll;
+        const u32 my_op = op + wave_excl_sum(ll + ml, &tot_all), my_lp = lp + wave_excl_sum(ll, &tot_ll);
+        if ((u64)op + tot_all > b.regen || (u64)lp + tot_ll > b.lit_regen) { bad = true; break; }
+        // what the earlier steps stored is visible to every lane from here on
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // literals
+        if (ll && ll <= EXEC_LANE_MAX) lane_copy(out + my_op, lits + my_lp, ll);
+        for (u64 big = __ballot(ll > EXEC_LANE_MAX); big; big &= big - 1) {
+            const int j = __ffsll((long long)big) - 1;
+            wave_copy(out + (u32)__builtin_amdgcn_readlane((int)my_op, j), lits + (u32)__builtin_amdgcn_readlane((int)my_lp, j), (u32)__builtin_amdgcn_readlane((int)ll, j), lane);
+        }
+        // matches
+        const bool valid = lane < n;
+        const u32 d = my_op + ll;                                  // where the match lands, block-relative
+        const u64 pos_abs = out_off + d;
+        if (valid && (of == 0 || of > pos_abs)) bad = true;        // no offset, or one that reaches before the frame start
+        if (__ballot(bad)) { bad = true; break; }
+        const u64 src_abs = pos_abs - of, batch_abs = out_off + op;
+        const bool far = valid && of >= ml && src_abs + ml <= batch_abs;
+        // a far match's source blocks (in front of this block); inside this block the source was written by earlier steps
+        const bool outside = far && src_abs < out_off;
+        u32 j0 = 0, j1 = 0, need = 0;
+        if (outside) {
+            j0 = find_block(offs, bi, src_abs, shift);
+            const u64 last = src_abs + ml - 1;
+            j1 = last < out_off ? (last < offs[j0 + 1] ? j0 : find_block(offs, bi, last, shift)) : bi - 1;
+            need = last < out_off ? (u32)(last + 1 - offs[j1]) : 0xFFFFFFFFu;           // (a far match ends in front of this step: last < out_off unless the step is the block's first)
+        }
+        bool pend = far;
+        while (__ballot(pend)) {
+            const bool can = pend && (!outside || source_ready(done, prog, j0, j1, need));
+            const u64 m = __ballot(can);
+            if (m) {
+                if (__ballot(can && outside)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // what the other blocks stored, not what an old cache line says
+                if (can && ml <= EXEC_LANE_MAX) lane_copy(out + d, dst + src_abs, ml);
+                for (u64 big = __ballot(can && ml > EXEC_LANE_MAX); big; big &= big - 1) {
+                    const int j = __ffsll((long long)big) - 1;
+                    const u32 dj = (u32)__builtin_amdgcn_readlane((int)d, j), mlj = (u32)__builtin_amdgcn_readlane((int)ml, j), ofj = (u32)__builtin_amdgcn_readlane((int)of, j);
+                    wave_copy(out + dj, dst + (out_off + dj - ofj), mlj, lane);
+                }
+                pend = pend && !can; spins = 0;
+            } else {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins >= (1u << 22)) {                        // nothing of this step became ready for a long time: has ANY block finished meanwhile?
+                    const u32 now = __hip_atomic_load(&st->n_exec_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (now != seen) { seen = now; spins = 0; } else { bad = true; break; }
+                }
+            }
+        }
+        if (bad) break;
+        // near matches, in order, behind everything above
+        u64 near = __ballot(valid && !far);
+        if (near) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (; near; near &= near - 1) {
+            const int j = __ffsll((long long)near) - 1;
+            const u32 dj = (u32)__builtin_amdgcn_readlane((int)d, j), mlj = (u32)__builtin_amdgcn_readlane((int)ml, j), ofj = (u32)__builtin_amdgcn_readlane((int)of, j);
+            const u64 sj = out_off + dj - ofj;
+            if (sj < out_off) {
+                // reaches into earlier blocks: those that hold [sj, min(sj + mlj, out_off)) -- wave-uniform, lane 0 polls
+                const u32 a = find_block(offs, bi, sj, shift);
+                const u64 last = sj + (ofj < mlj ? ofj : mlj) - 1;
+                const u32 z = last < out_off ? (last < offs[a + 1] ? a : find_block(offs, bi, last, shift)) : bi - 1;
+                const u32 needz = last < out_off ? (u32)(last + 1 - offs[z]) : 0xFFFFFFFFu;
+                for (;;) {
+                    if (source_ready(done, prog, a, z, needz)) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins >= (1u << 22)) {
+                        const u32 now = __hip_atomic_load(&st->n_exec_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (now != seen) { seen = now; spins = 0; } else { bad = true; break; }
+                    }
+                }
+                if (bad) break;
+                spins = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            const u8 *from = dst + sj;
+            if (ofj >= mlj) wave_copy(out + dj, from, mlj, lane);
+            else { for (u32 k = lane; k < mlj; k += 64) out[dj + k] = from[k % ofj]; }
+            if (near & (near - 1)) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the next near match may read this one
+        }
+        if (bad) break;
+        op += tot_all; lp += tot_ll;
+        // what is complete so far, for the blocks whose matches read this one: they need not wait for its end
+        if (s0 + 64 < nseq) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_store(&prog[bi], op, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (!bad && !b.err) {
+        const u32 rest = b.lit_regen - lp;
+        if (op + rest != b.regen) bad = true;
+        else wave_copy(out + op, lits + lp, rest, lane);
+    }
+    if (bad && lane == 0) set_err(st, ZE_CORRUPT);
+    // publish: every lane's stores drained, then agent-scope release, then the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&done[bi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&st->n_exec_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- sequence execution as DATAFLOW (k_lz_prep, k_lz_deps, k_lz_exec) --------------------------------------------------------------
+// k_exec_batch keeps a block's sequences in order: a step of 64 waits for the slowest source among its matches.  On a frame whose
+// matches read all over the blocks in front of them (a genome's repeats under `--long`, or any level that matches across blocks) nearly
+// every step has a source in a block that is itself still waiting, and the blocks end up running one behind the other: 0.46 ms per
+// 128 KiB block whatever the device (tools/perf_exec.py: 344 ms for 200 MB of text with the waits, 3 ms without them).  What has to be
+// respected is less than block order: a match may run as soon as the MATCHES that wrote its source bytes have run -- literals are final
+// from the start.  So:
+//   k_lz_prep   a wavefront per block: positions of its sequences (two prefix sums per 64), offsets resolved, every literal run copied;
+//               per sequence: where its match lands (block-relative), its final offset, and a `done` byte (0 = a match still to run);
+//   k_lz_deps   per match: the range [lo, lo + n) of earlier sequences whose match bytes intersect its source -- the first sequence whose
+//               match ends behind the source's first byte, the last whose match starts in front of its end (two searches in the arrays
+//               of the blocks that hold those bytes);
+//   k_lz_exec   a wavefront per block, ticket-ordered, sweeps over its pending matches: whatever has all its `done` bytes set is copied
+//               -- a lane per match, long ones by the wavefront -- and marked done; the others stay for the next sweep.
+// Everything the executing wavefronts exchange -- match bytes and `done` bytes -- moves with agent-scope (sc1) loads and stores, which
+// bypass the caches that are not coherent between XCDs: no release / acquire fence in the loop (an agent-scope acquire invalidates an
+// XCD's whole L2 share; tools/perf_exec.py: the fences alone were five times the copies).  The earliest pending match of the frame always
+// has its sources done, so a valid frame always moves; a wavefront gives up when nothing anywhere has run for a long time.
+template <typename T> __device__ __forceinline__ T ld_sc1(const void *p) { return __hip_atomic_load((const T *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void st_sc1(void *p, T v) { __hip_atomic_store((T *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lane_copy_sc1(u8 *d, const u8 *s, u32 n)            // n bytes by ONE lane, any alignment, source in front of (or clear of) the destination
+{
+    u32 i = 0;
+    for (; i + 8 <= n; i += 8) st_sc1<u64>(d + i, ld_sc1<u64>(s + i));
+    if (n & 4) { st_sc1<u32>(d + i, ld_sc1<u32>(s + i)); i += 4; }
+    if (n & 2) { st_sc1<u16>(d + i, ld_sc1<u16>(s + i)); i += 2; }
+    if (n & 1) st_sc1<u8>(d + i, ld_sc1<u8>(s + i));
+}
+__device__ __forceinline__ void wave_copy_sc1(u8 *d, const u8 *s, u32 n, u32 lane)  // the same by 64 lanes
+{
+    for (u32 i = lane * 8; i + 8 <= n; i += 64 * 8) st_sc1<u64>(d + i, ld_sc1<u64>(s + i));
+    const u32 done = n & ~7u;
+    if (lane < (n & 7u)) st_sc1<u8>(d + done + lane, ld_sc1<u8>(s + done + lane));
+}
+struct LzArrays { u32 *x_dst; u32 *ml; u32 *of; u32 *dep_lo; u32 *dep_n; u8 *sdone; };    // x_dst: the sequence arrays' `ll` slot, rewritten
+__global__ __launch_bounds__(64) void k_lz_prep(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *seq_cnt, u32 nblk, u64 ns_total,
+                                                 LzArrays A, const u8 *lit_scratch, u8 *dst, ZStat *st)
+{
+    const u32 t = blockIdx.x, lane = threadIdx.x;
+    if (t >= n_seq_blk) return;
+    const u32 bi = seq_list[t];
+    const ZBlock &b = blk[bi];
+    const u64 out_off = b.out_off, sbase = b.seq_base;
+    u8 *out = dst + out_off;
+    const u8 *lits = lit_scratch + out_off;
+    u32 rep_in[3] = { b.rep_in[0], b.rep_in[1], b.rep_in[2] };
+    const u32 nseq = b.err ? 0 : b.nseq;
+    const u32 cnt = (u32)((bi + 1 < nblk ? seq_cnt[bi + 1] : ns_total) - seq_cnt[bi]);     // with the padding up to a multiple of four
+    u32 op = 0, lp = 0;
+    bool bad = false;
+    for (u32 s0 = 0; s0 < cnt; s0 += 64) {
+        const bool real = s0 + lane < nseq && !bad;                         // (behind an error every entry gets its no-op form: nothing may wait for it)
+        u32 ll = 0, ml = 0, of = 0;
+        if (real) { ll = A.x_dst[sbase + s0 + lane]; ml = A.ml[sbase + s0 + lane]; of = sym_resolve(A.of[sbase + s0 + lane], rep_in); }
+        u32 tot_all, tot_ll;
+        const u32 my_op = op + wave_excl_sum(ll + ml, &tot_all), my_lp = lp + wave_excl_sum(ll, &tot_ll);
+        if ((u64)op + tot_all > b.regen || (u64)lp + tot_ll > b.lit_regen) { bad = true; ll = 0; ml = 0; }
+        if (ll && ll <= EXEC_LANE_MAX) lane_copy(out + my_op, lits + my_lp, ll);
+        for (u64 big = __ballot(ll > EXEC_LANE_MAX); big; big &= big - 1) {
+            const int j = __ffsll((long long)big) - 1;
+            wave_copy(out + (u32)__builtin_amdgcn_readlane((int)my_op, j), lits + (u32)__builtin_amdgcn_readlane((int)my_lp, j), (u32)__builtin_amdgcn_readlane((int)ll, j), lane);
+        }
+        const u32 d = my_op + ll;
+        if (real && ml && (of == 0 || of > out_off + d)) { bad = true; ml = 0; }       // no offset, or one that reaches before the frame start
+        if (s0 + lane < cnt) {
+            const u64 i = sbase + s0 + lane;
+            A.x_dst[i] = real && ml ? d : 0xFFFFFFFFu; A.ml[i] = ml; A.of[i] = of;
+            A.sdone[i] = ml ? 0 : 1;
+        }
+        bad = __ballot(bad) != 0;
+        if (!bad) { op += tot_all; lp += tot_ll; }
+    }
+    if (!__ballot(bad) && !b.err) {
+        const u32 rest = b.lit_regen - lp;
+        if (op + rest != b.regen) bad = true;
+        else wave_copy(out + op, lits + lp, rest, lane);
+    }
+    if (__ballot(bad) && lane == 0) set_err(st, ZE_CORRUPT);
+}
+// first j in [0, n) with x_dst[j] + ml[j] > rel (match ends are increasing; padding entries: 0xFFFFFFFF + 0)
+__device__ __forceinline__ u32 lz_first_end_after(const u32 *x, const u32 *m, u32 n, u32 rel)
+{
+    u32 lo = 0, hi = n;
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if ((u64)x[mid] + m[mid] > rel) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+// number of j in [0, n) with x_dst[j] < rel_end (match starts are increasing)
+__device__ __forceinline__ u32 lz_count_start_before(const u32 *x, u32 n, u32 rel_end)
+{
+    u32 lo = 0, hi = n;
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (x[mid] < rel_end) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(64) void k_lz_deps(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *offs, const u64 *seq_cnt, u32 nblk, u64 ns_total, LzArrays A)
+{
+    const u32 t = blockIdx.x, lane = threadIdx.x;
+    if (t >= n_seq_blk) return;
+    const u32 bi = seq_list[t];
+    const ZBlock &b = blk[bi];
+    const u64 out_off = b.out_off, sbase = b.seq_base;
+    const u32 nseq = b.err ? 0 : b.nseq;
+    u32 shift = 0xFF;
+    if (nblk > 1) { const u64 b0 = offs[1] - offs[0]; if (b0 && !(b0 & (b0 - 1))) shift = (u32)(63 - __builtin_clzll(b0)); }
+    for (u32 s = lane; s < nseq; s += 64) {
+        const u64 i = sbase + s;
+        const u32 ml = A.ml[i];
+        if (!ml) { A.dep_lo[i] = 0; A.dep_n[i] = 0; continue; }
+        const u32 d = A.x_dst[i], of = A.of[i];
+        const u64 src = out_off + d - of, src_end = src + (of < ml ? of : ml);          // the bytes that exist before the match runs
+        // the blocks of the first and of the last source byte (this block among them)
+        const u32 ja = src >= out_off ? bi : find_block(offs, bi, src, shift);
+        const u32 jb = src_end - 1 >= out_off ? bi : (src_end - 1 < offs[ja + 1] ? ja : find_block(offs, bi, src_end - 1, shift));
+        const u64 base_a = seq_cnt[ja], base_b = seq_cnt[jb];
+        const u32 cnt_a = (u32)((ja + 1 < nblk ? seq_cnt[ja + 1] : ns_total) - base_a), cnt_b = ja == jb ? cnt_a : (u32)((jb + 1 < nblk ? seq_cnt[jb + 1] : ns_total) - base_b);
+        // (in this block only the sequences in front of this one count: its own match starts at d >= the source's end)
+        const u64 lo = base_a + lz_first_end_after(A.x_dst + base_a, A.ml + base_a, ja == bi ? s : cnt_a, (u32)(src - offs[ja]));
+        const u64 hi = base_b + lz_count_start_before(A.x_dst + base_b, jb == bi ? s : cnt_b, (u32)(src_end - offs[jb]));     // one past the last
+        A.dep_lo[i] = (u32)lo; A.dep_n[i] = hi > lo ? (u32)(hi - lo) : 0;
+    }
+}
+__device__ __forceinline__ bool lz_deps_done(const u8 *sdone, u32 lo, u32 n)
+{
+    // (the first four without a branch between them: independent loads in flight together; most matches have one to three)
+    bool ok = true;
+    if (n > 0) ok &= ld_sc1<u8>(sdone + lo) != 0;
+    if (n > 1) ok &= ld_sc1<u8>(sdone + lo + 1) != 0;
+    if (n > 2) ok &= ld_sc1<u8>(sdone + lo + 2) != 0;
+    if (n > 3) ok &= ld_sc1<u8>(sdone + lo + 3) != 0;
+    if (n <= 4 || !ok) return ok;
+    u32 k = 4;
+    for (; k + 8 <= n; k += 8) if (ld_sc1<u64>(sdone + lo + k) != 0x0101010101010101ull) return false;
+    for (; k < n; k++) if (!ld_sc1<u8>(sdone + lo + k)) return false;
+    return true;
+}
+// A wavefront owns a UNIT of U x 64 consecutive sequences of one block (not the whole block: a sweep over a block's hundred words took
+// as long as a hundred round trips, and that was the time a level of the dependency graph cost).  Units are numbered in frame order
+// (unit_base: exclusive sum of the blocks' unit counts, k_lz_units) and taken by ticket: what a unit waits for lies in units with
+// earlier tickets or in itself.  The unit's sequences stay in registers; a sweep is one round of `done` loads for everything pending.
+__global__ void k_lz_units(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, u32 per_unit, u64 *units)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seq_blk) return;
+    const ZBlock &b = blk[seq_list[t]];
+    units[t] = b.err ? 0 : (b.nseq + per_unit - 1) / per_unit;
+}
+template <u32 U>
+__global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A, u8 *dst, ZStat *st)
+{
+    __shared__ u32 sh_ticket;
+    const u32 lane = threadIdx.x;
+    if (lane == 0) sh_ticket = atomicAdd(&st->ticket, 1u);
+    __syncthreads();
+    const u64 u = sh_ticket;
+    if (u >= *n_units) return;
+    if (ld_sc1<u32>(&st->err)) return;                                       // k_lz_prep found the frame corrupt: the call fails, nothing to copy
+    u32 t = 0;
+    { u32 hi = n_seq_blk; while (t + 1 < hi) { const u32 mid = (t + hi) >> 1; if (unit_base[mid] <= u) t = mid; else hi = mid; } }      // last block with unit_base <= u
+    const ZBlock &b = blk[seq_list[t]];
+    const u32 s_first = (u32)(u - unit_base[t]) * (U * 64u), nseq = b.nseq;
+    const u64 sbase = b.seq_base + s_first;
+    u8 *out = dst + b.out_off;
+    u32 dlo[U], dn[U], xd[U], xml[U], xof[U];
+    u64 pend[U];
+    u32 left = 0;
+#pragma unroll
+    for (u32 w = 0; w < U; w++) {
+        const u32 s = s_first + w * 64 + lane;
+        const u64 i = sbase + w * 64 + lane;
+        xml[w] = s < nseq ? A.ml[i] : 0;
+        dlo[w] = 0; dn[w] = 0; xd[w] = 0; xof[w] = 0;
+        if (xml[w]) { dlo[w] = A.dep_lo[i]; dn[w] = A.dep_n[i]; xd[w] = A.x_dst[i]; xof[w] = A.of[i]; }
+        pend[w] = __ballot(xml[w] != 0);
+        left += (u32)__popcll(pend[w]);
+    }
+    u32 idle = 0, seen = 0;
+    while (left) {
+        u64 rdy[U]; u64 any = 0;
+#pragma unroll
+        for (u32 w = 0; w < U; w++) {
+            bool ready = false;
+            if ((pend[w] >> lane) & 1) ready = lz_deps_done(A.sdone, dlo[w], dn[w]);
+            rdy[w] = pend[w] ? __ballot(ready) : 0;
+            any |= rdy[w];
+        }
+        if (any) {
+            asm volatile("" ::: "memory");                                   // (the sources are read after their `done` bytes, not before)
+#pragma unroll
+            for (u32 w = 0; w < U; w++) {
+                const u64 r = rdy[w];
+                if (!r) continue;
+                const bool ready = (r >> lane) & 1;
+                const u32 d = xd[w], ml = xml[w], of = xof[w];
+                const bool plain = ready && of >= ml;
+                if (plain && ml <= EXEC_LANE_MAX) lane_copy_sc1(out + d, out + d - of, ml);
+                for (u64 big = __ballot(plain && ml > EXEC_LANE_MAX); big; big &= big - 1) {
+                    const int j = __ffsll((long long)big) - 1;
+                    const u32 dj = (u32)__builtin_amdgcn_readlane((int)d, j), mlj = (u32)__builtin_amdgcn_readlane((int)ml, j), ofj = (u32)__builtin_amdgcn_readlane((int)of, j);
+                    wave_copy_sc1(out + dj, out + dj - ofj, mlj, lane);
+                }
+                // a match that overlaps itself repeats its first `of` bytes: only bytes in front of the match are read
+                for (u64 ov = __ballot(ready && of < ml); ov; ov &= ov - 1) {
+                    const int j = __ffsll((long long)ov) - 1;
+                    const u32 dj = (u32)__builtin_amdgcn_readlane((int)d, j), mlj = (u32)__builtin_amdgcn_readlane((int)ml, j), ofj = (u32)__builtin_amdgcn_readlane((int)of, j);
+                    const u8 *from = out + dj - ofj;
+                    for (u32 k = lane; k < mlj; k += 64) st_sc1<u8>(out + dj + k, ld_sc1<u8>(from + k % ofj));
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the bytes are out before anybody is told
+            u32 ran = 0;
+#pragma unroll
+            for (u32 w = 0; w < U; w++) {
+                if ((rdy[w] >> lane) & 1) st_sc1<u8>(A.sdone + sbase + w * 64 + lane, (u8)1);
+                pend[w] &= ~rdy[w]; ran += (u32)__popcll(rdy[w]);
+            }
+            left -= ran;
+            if (lane == 0) __hip_atomic_fetch_add(&st->n_exec_done, ran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            idle = 0;
+            continue;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        if (++idle >= (1u << 18)) {                                           // nothing of this unit could run for a long time: has ANYTHING run meanwhile?
+            const u32 now = ld_sc1<u32>(&st->n_exec_done);
+            if (ld_sc1<u32>(&st->err) || now == seen) { if (lane == 0) set_err(st, ZE_CORRUPT); break; }
+            seen = now; idle = 0;
+        }
+    }
+}
+
+// The sequences of blocks seq_list[0 .. nx) executed: as dataflow (above), or in block order (EXEC=batch / =serial: the cross-checks; frames
+// of more than 2^32 sequences).  `done` / `prog`: per-block arrays of the block-ordered executors.
+static int launch_lz_exec(naf_gpu_ctx *c, const ZBlock *blk, const u32 *seq_list, u32 nx, const u64 *offs, const u64 *seq_cnt, u32 nblk, u64 ns_total,
+                          u32 *o_ll, u32 *o_ml, u32 *o_of, const u8 *lits, u8 *d_dst, u32 *done, ZStat *st)
+{
+    const char *how = ctx_opt(c, "EXEC");
+    if (how && how[0] == 's') {
+        LAUNCH(c, "zstd_exec_seq", k_exec_seq, nx, 64, 0, blk, seq_list, nx, offs, nblk, (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, lits, d_dst, done, st);
+        return 0;
+    }
+    if ((how && how[0] == 'b') || ns_total >= 0xFFFFFFF0ull) {
+        u32 *prog = arena_new<u32>(c, nblk); if (!prog) return NAF_GPU_ENOMEM;
+        HIP_TRY(c, hipMemsetAsync(prog, 0, 4 * (size_t)nblk, c->stream));
+        LAUNCH(c, "zstd_exec_seq", k_exec_batch, nx, 64, 0, blk, seq_list, nx, offs, nblk, (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, lits, d_dst, done, prog, st);
+        return 0;
+    }
+    LzArrays A; A.x_dst = o_ll; A.ml = o_ml; A.of = o_of;
+    A.dep_lo = arena_new<u32>(c, ns_total + 1); A.dep_n = arena_new<u32>(c, ns_total + 1); A.sdone = (u8 *)arena_alloc(c, ns_total + 16);
+    if (!A.dep_lo || !A.dep_n || !A.sdone) return NAF_GPU_ENOMEM;
+    HIP_TRY(c, hipMemsetAsync(A.sdone, 1, ns_total + 16, c->stream));
+    LAUNCH(c, "zstd_lz_prep", k_lz_prep, nx, 64, 0, blk, seq_list, nx, seq_cnt, nblk, ns_total, A, lits, d_dst, st);
+    LAUNCH(c, "zstd_lz_deps", k_lz_deps, nx, 64, 0, blk, seq_list, nx, offs, seq_cnt, nblk, ns_total, A);
+    // units of U x 64 sequences: their numbering in frame order
+    const char *ue = ctx_opt(c, "EXEC_UNIT");
+    const u32 U = ue ? (u32)atoi(ue) : 16u, per_unit = (U == 4 ? 4u : U == 8 ? 8u : 16u) * 64u;     // (1 GB of a repeat-rich genome under --long 27: 25 / 15 / 10 ms with 4 / 8 / 16; a unit per block: 44)
+    u64 *units = arena_new<u64>(c, (size_t)nx + 2); if (!units) return NAF_GPU_ENOMEM;
+    LAUNCH(c, "zstd_lz_units", k_lz_units, cdiv(nx, 256), 256, 0, blk, seq_list, nx, per_unit, units);
+    int rc = scan_exclusive_u64(c, units, nx, units + nx + 1); if (rc) return rc;
+    const u32 grid = (u32)(ns_total / per_unit + nx + 1);                    // (an upper bound known without a read-back: wavefronts behind the last unit leave at once)
+    if (per_unit == 4 * 64) LAUNCH(c, "zstd_exec_seq", k_lz_exec<4>, grid, 64, 0, blk, seq_list, nx, (const u64 *)units, (const u64 *)(units + nx + 1), A, d_dst, st);
+    else if (per_unit == 16 * 64) LAUNCH(c, "zstd_exec_seq", k_lz_exec<16>, grid, 64, 0, blk, seq_list, nx, (const u64 *)units, (const u64 *)(units + nx + 1), A, d_dst, st);
+    else LAUNCH(c, "zstd_exec_seq", k_lz_exec<8>, grid, 64, 0, blk, seq_list, nx, (const u64 *)units, (const u64 *)(units + nx + 1), A, d_dst, st);
+    return 0;
 }
 
 // Blocks whose regenerated bytes intersect [want_lo, want_hi): first block index, one-past-last, and their byte span.
@@ -2738,6 +3193,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         if (hs.err) return zerr(c, hs.err, "sequences");
     }
     const u32 max_seq_regen = hs.max_seq_regen;
+    if (ctx_tracing(c) && n_seq_blk) ctx_trace(c, "[seq] blocks %u with sequences %u sequences %llu out %llu\n", nblk, n_seq_blk, (unsigned long long)hs.total_seq, (unsigned long long)hs.total_out);
     // entry states matter only when some sequence of the frame uses a repeat code (this build's own LZ blocks never do)
     if (n_seq_blk && (hs.rep_slow & 1)) LAUNCH(c, "zstd_rep_chain", k_rep_chain, 1, 64, 0, blk, nblk);
     *out_len = hs.total_out;
@@ -2754,8 +3210,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             ZFlat *zf = c->zflat;
             FlatStream *si = arena_new<FlatStream>(c, 4 * (size_t)nblk + 1); u8 *d_sym = (u8 *)arena_alloc(c, 16);
             u8 *cls0 = (u8 *)arena_alloc(c, nblk), *cls = (u8 *)arena_alloc(c, nblk); u32 *d_nx = arena_new<u32>(c, 2);
-            u32 *done2 = arena_new<u32>(c, nblk); u8 *lits = (u8 *)arena_alloc(c, hs.total_out + 16);
-            if (!si || !d_sym || !cls0 || !cls || !d_nx || !done2 || !lits) return NAF_GPU_ENOMEM;
+            u32 *done2 = arena_new<u32>(c, nblk), *prog2 = arena_new<u32>(c, nblk); u8 *lits = (u8 *)arena_alloc(c, hs.total_out + 16);
+            if (!si || !d_sym || !cls0 || !cls || !d_nx || !done2 || !prog2 || !lits) return NAF_GPU_ENOMEM;
             HIP_TRY(c, hipMemsetAsync(d_nx, 0, 8, c->stream));
             LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, done2, (u32 *)nullptr, (u32 *)nullptr);
             LAUNCH(c, "zstd_flat_class", k_flat_mark_owner, g, 64, 0, d_src, blk, nblk, (const i32 *)own_huf, main, 0u);
@@ -2770,7 +3226,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             if ((u64)n_dec * 2 <= nblk) {
                 LAUNCH(c, "zstd_flat_streams", k_flat_streams_mixed, cdiv(4ull * nblk, 256), 256, 0, d_src, (const ZBlock *)blk, nblk, (const u8 *)cls, si, st, (const u64 *)d_total_out);
                 zf->decoded_ev = nullptr;
-                const ZStat hs0 = hs; naf_gpu_ctx *mc = c; naf_gpu_ctx *aux = zf->aux;
+                const ZStat hs0 = hs; naf_gpu_ctx *mc = c; naf_gpu_ctx *aux = zf->aux; const u64 ns_all = hs.total_seq;
                 const u64 src_len64 = (u64)src_len;
                 zf->later = new std::function<int()>([=]() -> int {
                     naf_gpu_ctx *c = aux ? aux : mc;
@@ -2792,9 +3248,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     if (hs0.max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
                         LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, n_seq_blk, 64, ((hs0.max_seq_regen + 1023u) & ~1023u) + 64u, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
                                (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lits, d_dst, done2, st, (hs0.max_seq_regen + 1023u) & ~1023u);
-                    else
-                        LAUNCH(c, "zstd_exec_seq", k_exec_seq, n_seq_blk, 64, 0, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
-                               (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lits, d_dst, done2, st);
+                    else { const int rcx = launch_lz_exec(c, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, (const u64 *)seq_cnt, nblk, ns_all, o_ll, o_ml, o_of, (const u8 *)lits, d_dst, done2, st); if (rcx) return rcx; }
                     return 0;
                 });
                 zf->src = d_src; zf->si = si; zf->nslots = 4ull * nblk; zf->sym = d_sym; zf->status = st; zf->ready = true;
@@ -2951,9 +3405,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         if (max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
             LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, nx, 64, ((max_seq_regen + 1023u) & ~1023u) + 64u, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, nblk,
                    (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st, (max_seq_regen + 1023u) & ~1023u);
-        else
-            LAUNCH(c, "zstd_exec_seq", k_exec_seq, nx, 64, 0, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, nblk,
-                   (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st);
+        else if ((rc = launch_lz_exec(c, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, (const u64 *)seq_cnt, nblk, hs.total_seq, o_ll, o_ml, o_of, (const u8 *)lit_scratch, d_dst, done, st))) return rc;
     }
     if (c->zsplit && c->zsplit->done) { c->zsplit->status = st; return 0; }      // the caller checks the status once the emit is queued (zstd_split_status)
     rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;

@@ -31,7 +31,7 @@ static void done(int status, void *arg)
 {
     (void)arg;
     if (!success && created_output_file && out_file_path) remove(out_file_path);
-    if (gpu) { const char *tr = naf_gpu_get_trace(gpu); if (tr && *tr) fputs(tr, stderr); }       /* NAF_GPU_TRACE=1 (development): which paths the library took */
+    trace_out();
     detach_report(status);                                        /* the foreground process leaves with this status now; what follows is nobody's wait */
     if (gpu_init_started) { pthread_join(gpu_init_thread, NULL); gpu_init_started = false; }       /* (an exit while the device is still being opened) */
     if (gpu) naf_gpu_shutdown(gpu);
@@ -507,7 +507,7 @@ int main(int argc, char **argv)
     success = true;
     /* everything is written and closed: the process ends here, without the device-side teardown (freeing gigabytes of device memory,
      * streams, the runtime's own exit handlers: 0.1 - 0.2 s that nobody waits for; NAF_GPU_SLOW_EXIT=1 runs it) */
-    fflush(NULL); detach_done(0);
+    trace_out(); fflush(NULL); detach_done(0);
     { const char *se = getenv("NAF_GPU_SLOW_EXIT"); if (!(se && se[0] == '1')) _exit(0); }
     return 0;
 }

@@ -75,6 +75,8 @@ __attribute__((unused)) static int decimal_arg(const char *s, long long *v)
 }
 
 static naf_gpu_ctx *gpu = NULL;
+/* NAF_GPU_TRACE=1 (development): which paths the library took, on stderr when the program ends */
+static void trace_out(void) { if (gpu) { const char *tr = naf_gpu_get_trace(gpu); if (tr && *tr) { fputs(tr, stderr); fflush(stderr); } naf_gpu_clear_trace(gpu); } }
 static void devices_parse(void);
 static int first_device(void);
 /* The device is opened by a thread of its own while the main thread parses, opens and maps its files (the HIP runtime's start and

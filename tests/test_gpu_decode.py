@@ -29,12 +29,18 @@ def host(t):
     return t.cpu().numpy().tobytes()
 
 
-@pytest.mark.parametrize("executor", ["auto", "hbm"])
+@pytest.mark.parametrize("executor", ["auto", "hbm", "hbm-unit4", "batch", "serial"])
 @pytest.mark.parametrize("case", zstd_cases(), ids=lambda c: c["name"])
 def test_zstd_decode_golden_frames(gpu, case, executor, monkeypatch):
     """libzstd-made frames (every level, long windows, multi-threaded, streaming): frames whose blocks regenerate at most 16 KiB
-    run their sequences in the LDS executor, the others in the HBM executor; "hbm" forces the latter for every frame."""
-    monkeypatch.setenv("NAF_GPU_EXEC_LDS", "0" if executor == "hbm" else "1")
+    run their sequences in the LDS executor, the others as dataflow (k_lz_prep / _deps / _exec); "hbm" forces the latter for every
+    frame, "hbm-unit4" with units of 256 sequences (more units than blocks even for the small frames), "batch" and "serial" the two
+    block-ordered executors kept as cross-checks."""
+    monkeypatch.setenv("NAF_GPU_EXEC_LDS", "1" if executor == "auto" else "0")
+    if executor == "hbm-unit4":
+        monkeypatch.setenv("NAF_GPU_EXEC_UNIT", "4")
+    if executor in ("batch", "serial"):
+        monkeypatch.setenv("NAF_GPU_EXEC", executor)
     frame = golden_bytes("zstd", case["name"] + ".zst")
     out = gpu.zstd_decompress(gpu.to_device(frame), case["len"] + 64)
     got = host(out)
@@ -1010,3 +1016,34 @@ def test_names_decoded_beside_ids(gpu, monkeypatch):
         lines[i] = lines[i].upper()
     assert a == b"\n".join(lines)
     assert host(gpu.unnaf(d_naf, capi.OUT_FASTA)) == fa0
+
+
+@pytest.mark.parametrize("flags", [("--level", "3", "--long", "27"), ("--level", "19"), ("--level", "1")], ids=lambda f: "".join(f))
+def test_reference_archive_of_a_repeat_rich_genome_under_every_executor(gpu, oracle, monkeypatch, flags):
+    """What the reference makes of a genome full of repeats (libzstd's match finders, `--long`: thousands of sequences per 128 KiB block,
+    matches that read all over the blocks in front of them -- ennaf/src/compressor.c:7-21, ennaf.c:247-273) decoded by the dataflow
+    executor in units of 16 / 8 / 4 words and by the two block-ordered ones: the reference's own text every time.  (In block order this
+    kind of frame ran one block behind the other, and at 1 GB the bounded wait called it corrupt: DESIGN.md 4.30.)"""
+    from naf_amd import capi, synth
+    O = oracle
+    if not O.have_ref():
+        pytest.skip("needs oracle/_ref")
+    text = host(synth.repeat_genome_device(12_000_000, device="cuda", families=24))
+    naf = O.ref_ennaf(text, flags)
+    want = O.ref_unnaf(naf)
+    assert want == text
+    d_naf = gpu.to_device(naf)
+    for how, unit in (("dataflow", "16"), ("dataflow", "8"), ("dataflow", "4"), ("batch", ""), ("serial", "")):
+        monkeypatch.setenv("NAF_GPU_EXEC", how); monkeypatch.setenv("NAF_GPU_EXEC_UNIT", unit); monkeypatch.setenv("NAF_GPU_EXEC_LDS", "0")
+        assert host(gpu.unnaf(d_naf, capi.OUT_FASTA)) == want, (flags, how, unit)
+        # a byte range of it: the range's dependency closure through the same executor
+        b, e = len(want) // 3, len(want) // 3 + 1_000_003
+        assert host(gpu.unnaf_range(d_naf, b, e, capi.OUT_FASTA)) == want[b:e], (flags, how, unit)
+    monkeypatch.delenv("NAF_GPU_EXEC"); monkeypatch.delenv("NAF_GPU_EXEC_UNIT"); monkeypatch.delenv("NAF_GPU_EXEC_LDS")
+    # this build's own archives at the levels that match across blocks, through the same executors (16 KiB blocks: the LDS executor by default)
+    for level, long_log in ((19, 0), (3, 27)):
+        mine, _ = gpu.ennaf(gpu.to_device(text), level=level, long_log=long_log)
+        for lds in ("1", "0"):
+            monkeypatch.setenv("NAF_GPU_EXEC_LDS", lds)
+            assert host(gpu.unnaf(mine, capi.OUT_FASTA)) == text, (level, long_log, lds)
+        monkeypatch.delenv("NAF_GPU_EXEC_LDS")
