@@ -892,7 +892,8 @@ def main():
                              "realistic_unnaf_gbps": g("realistic", "unnaf_value"), "realistic_ennaf_gbps": g("realistic", "ennaf_value"),
                              "softmasked_unnaf_gbps": g("softmasked", "unnaf_value"), "softmasked_ennaf_gbps": g("softmasked", "ennaf_value")})
             lv = extra.get("levels") or {}
-            for k in ("lvl19_ennaf_gbps", "lvl19_ratio_vs_ref", "lvl19_ref_decodes", "long27_ennaf_gbps", "long27_ratio_vs_ref", "long27_ref_decodes"):
+            for k in ("lvl19_ennaf_gbps", "lvl19_ratio_vs_ref", "lvl19_ref_decodes", "lvl19_ref_ennaf_gbps", "long27_ennaf_gbps", "long27_ratio_vs_ref", "long27_ref_decodes", "long27_ref_ennaf_gbps",
+                      "long27_ref_archive_unnaf_gbps", "long27_ref_archive_bit_exact", "long27_ref_archive_ref_unnaf_gbps"):
                 roofline[k] = lv.get(k)
             ra = (cb or {}).get("gpu_unnaf_of_reference_archive") or {}
             roofline.update({"ref_archive_gbps": ra.get("value"), "ref_archive_bit_exact": ra.get("bit_exact"), "ref_archive_range8_ms": ra.get("range_eighth_ms"),
