@@ -6,7 +6,7 @@ CSRC     = naf_amd/csrc
 OBJS     = $(CSRC)/naf_gpu.o $(CSRC)/scan.o $(CSRC)/zstd_dec.o $(CSRC)/emit.o $(CSRC)/zstd_enc.o $(CSRC)/enc.o $(CSRC)/io.o
 HDRS     = $(wildcard $(CSRC)/*.h) include/naf_gpu.h
 
-all: naf_amd/libnaf_gpu.so hosts oracle emul tools/bw_calibrate tools/lds_probe tools/io_probe
+all: naf_amd/libnaf_gpu.so hosts oracle emul tools/bw_calibrate tools/lds_probe tools/io_probe tests/c/test_gather
 
 # known-byte-count kernels used to calibrate the PMC counters (tools/profile_bench.sh)
 tools/bw_calibrate: tools/bw_calibrate.hip
@@ -29,6 +29,10 @@ hosts: naf_amd/bin/ennaf naf_amd/bin/unnaf
 naf_amd/bin/%: naf_amd/host/%.c naf_amd/host/host_common.h include/naf_gpu.h naf_amd/libnaf_gpu.so
 	@mkdir -p naf_amd/bin
 	gcc -O2 -std=gnu99 -Wall -o $@ $< -Lnaf_amd -lnaf_gpu -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
+
+# a C caller of the decode path's collective (tests/test_gpu_shard.py runs it)
+tests/c/test_gather: tests/c/test_gather.c include/naf_gpu.h naf_amd/libnaf_gpu.so
+	gcc -O2 -std=gnu99 -Wall -o $@ $< -Lnaf_amd -lnaf_gpu -Wl,-rpath,'$$ORIGIN/../../naf_amd' -Wl,-rpath,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -s -C oracle all

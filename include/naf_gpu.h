@@ -102,6 +102,9 @@ int  naf_gpu_gather_ranges(naf_gpu_ctx *dst, void *d_dst, naf_gpu_ctx *const *sr
  * kernels that make d_src). */
 int  naf_gpu_read_file(naf_gpu_ctx *ctx, int fd, uint64_t file_off, size_t len, void *d_dst);
 int  naf_gpu_write_file(naf_gpu_ctx *ctx, int fd, uint64_t file_off, const void *d_src, size_t len);
+/* The same for a descriptor that takes its bytes in order (a pipe, a terminal, /dev/null, `>>`): write() from the calling thread, the
+ * next chunks already on the link.  The reference's counterpart is fwrite to stdout (unnaf/src/output.c:640-651). */
+int  naf_gpu_write_fd(naf_gpu_ctx *ctx, int fd, const void *d_src, size_t len);
 
 /* Byte histogram of a device buffer (unnaf --charcount over the --seq text, output.c:515-605). */
 int  naf_gpu_histogram(naf_gpu_ctx *ctx, const void *d_buf, size_t n, uint64_t counts[256]);

@@ -26,7 +26,7 @@ EXPORTS = [
     "naf_gpu_ennaf_sniff", "naf_gpu_ennaf_count_lines", "naf_gpu_ennaf_find_cut", "naf_gpu_ennaf_shard_begin", "naf_gpu_ennaf_shard_bound",
     "naf_gpu_ennaf_shard_finish", "naf_gpu_ennaf_shard_carry", "naf_gpu_ennaf_stitch_plan", "naf_gpu_ennaf_stitch",
     "naf_gpu_read_file", "naf_gpu_write_file", "naf_gpu_copy", "naf_gpu_gather_ranges", "naf_gpu_get_timing_streams",
-    "naf_gpu_set_option", "naf_gpu_get_trace", "naf_gpu_clear_trace",
+    "naf_gpu_set_option", "naf_gpu_get_trace", "naf_gpu_clear_trace", "naf_gpu_write_fd",
 ]
 MAX_SHARDS = 64
 

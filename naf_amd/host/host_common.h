@@ -212,7 +212,7 @@ static off_t fd_pwrite_pos(int fd)
  * offsets); pipes through the sequential two-chunk ring below. */
 #define IO_CHUNK ((size_t)16 << 20)
 static void *io_pin[2] = { NULL, NULL };
-static void io_open(void)
+__attribute__((unused)) static void io_open(void)
 {
     gpu_open();
     if (!io_pin[0]) { GPU_TRY(naf_gpu_host_alloc(gpu, IO_CHUNK, &io_pin[0])); GPU_TRY(naf_gpu_host_alloc(gpu, IO_CHUNK, &io_pin[1])); }
@@ -227,16 +227,8 @@ static void write_from_device(FILE *f, const void *d, size_t n)
         if (lseek(fileno(f), at + (off_t)n, SEEK_SET) < 0) die("can't write to file - disk full?\n");
         return;
     }
-    io_open();
-    size_t off = 0; int cur = 0;
-    GPU_TRY(naf_gpu_download_async(gpu, io_pin[0], d, n < IO_CHUNK ? n : IO_CHUNK));
-    while (off < n) {
-        size_t len = n - off < IO_CHUNK ? n - off : IO_CHUNK, nxt = off + len, nlen = n - nxt < IO_CHUNK ? n - nxt : IO_CHUNK;
-        GPU_TRY(naf_gpu_synchronize(gpu));                                   /* chunk `cur` has arrived */
-        if (nlen) GPU_TRY(naf_gpu_download_async(gpu, io_pin[cur ^ 1], (const char *)d + nxt, nlen));
-        if (fwrite(io_pin[cur], 1, len, f) != len) die("can't write to file - disk full?\n");
-        off = nxt; cur ^= 1;
-    }
+    if (fflush(f) != 0) die("can't write to file - disk full?\n");
+    GPU_TRY(naf_gpu_write_fd(gpu, fileno(f), d, n));
 }
 /* Regular file of known size straight into device memory; returns NULL when the size is not known up front (pipes). */
 __attribute__((unused)) static void *read_to_device(FILE *f, size_t *len)

@@ -155,6 +155,17 @@ def test_gather_ranges_of_the_c_abi(ctxs, oracle):
         assert torch.equal(out[:total], text), n
 
 
+def test_gather_ranges_from_a_c_caller():
+    """The same collective with no Python between the caller and the library: tests/c/test_gather.c opens N contexts, decodes unequal
+    byte ranges of a golden archive on each, gathers them with naf_gpu_gather_ranges and compares with one whole-text decode -- a FASTA
+    archive with a soft mask, a FASTQ one, and the reference's archive of repeats (a frame with matches: the ranges' closures)."""
+    exe = os.path.join(ROOT, "tests", "c", "test_gather")
+    assert os.access(exe, os.X_OK), "tests/c/test_gather is not built (make)"
+    for name, n in (("mixed_60.naf", 3), ("fastq_var.naf", 4), ("repeat_l19.naf", 5), ("acgt_1m2.naf", 8), ("tiny_many.naf", 2)):
+        p = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "naf", name), str(n)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert p.returncode == 0 and p.stdout.startswith(b"gather ok"), (name, n, p.stdout, p.stderr)
+
+
 def test_shard_records_match_the_stand_in(ctxs, oracle):
     """naf_gpu_ennaf_shard_begin on the device reports what the CPU stand-in derives from the oracle's view of the same slice."""
     from naf_amd import shard, synth
