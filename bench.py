@@ -697,6 +697,8 @@ def main():
             # rank r's records are numbered from r * records on: the concatenation of the slices is one FASTA
             text_buf = torch.empty(n_text + spare, dtype=torch.uint8, device=dev)
             text_buf[:n_text] = text
+            text = None
+            torch.cuda.synchronize(); torch.cuda.empty_cache()        # (the generator's copy goes back to the device: the library's arenas are not torch's)
             text = text_buf[:n_text]
         if n_text <= 40e9:
             ctx.reserve(int(n_text * 1.7) + (2 << 30))
@@ -787,7 +789,7 @@ def main():
             # "gather to host" (north_star) without the hop through one GPU: every rank copies its range into its own pinned host buffer
             # (per-GPU D2H, what the C hosts do with NAF_GPUS); step = range decode + the copy, max over ranks
             hsteps = max(1, min(args.steps, 3))
-            hbuf = torch.empty(min(e - b, 8 << 30), dtype=torch.uint8).pin_memory()
+            hbuf = torch.empty(min(e - b, 1 << 30), dtype=torch.uint8).pin_memory()
             def to_host():
                 ctx.unnaf_range(d_naf, b, e, capi.OUT_FASTA, out=buf)
                 for p in range(0, e - b, int(hbuf.numel())):       # a ring of one pinned buffer: the consumer (a file, a pipe) takes it from there
