@@ -435,8 +435,12 @@ __global__ void k_build_huf(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 
 // trees) in front of the first literal.  Directly stored weights (4.2.1.1: up to 128 of four bits) whose longest code fits the
 // single-level table are handled by the group: eight weights per lane in registers, weight groups ranked by shuffles, the table made
 // in LDS and copied out 16 bytes per lane.  FSE-coded weights and codes longer than HUF_FULL_LOG bits: the group's first lane, the old way.
-#define HUFG_TREES 16u
-__global__ __launch_bounds__(256) void k_build_huf16(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table, const i32 *own_huf, u32 gate, u32 phase)
+// HUFG_TREES trees per workgroup: four = ONE wavefront and 7 KB of LDS.  With sixteen (256 threads, 27.5 KB) the launch of a FASTQ's read
+// names waited 8.9 ms for its turn beside the two Huffman walks of that call, whose wavefronts hold 150 of a CU's 160 KB of LDS: a
+// workgroup that needs four wave slots and 27 KB on ONE CU at once gets them when several walks there have ended together, a single
+// wavefront takes any slot as it frees (profiles/r05_timeline_fastq_12GB_before.txt; the same finding as DESIGN.md 4.29).
+template <u32 HUFG_TREES>
+__global__ __launch_bounds__(16 * HUFG_TREES) void k_build_huf16(const u8 *src, ZBlock *blk, u32 nblk, u8 *pool, u32 pool_cap, ZStat *st, u32 first, const u64 *range4, u32 always_table, const i32 *own_huf, u32 gate, u32 phase)
 {
     __shared__ __attribute__((aligned(16))) u16 s_tab[HUFG_TREES][HUF_TAB_MAX / 2];
     const u32 lane = threadIdx.x & 63u, grp = threadIdx.x >> 4, sl = threadIdx.x & 15u;
@@ -1968,7 +1972,57 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
             for (u32 k = lane; k < l; k += 64) obuf[o + k] = lits[p + k];
         }
         __syncthreads();
+        // ---- the matches of the step that need not wait for each other, all at once.  A stream of similar records (a FASTQ's read names:
+        // every name copies its predecessor's first bytes) is a chain -- match j reads what match j - 1 wrote, which read what j - 2
+        // wrote ... -- and one match per round trip through LDS was the executor's time (2.8 ms for the 490 MB of names of a 12.5 GB
+        // FASTQ with the device to itself).  But a source that lies wholly inside an earlier plain match of the step is the same bytes
+        // as the place THAT match copied from: the lane moves its source there, and again (the owner's own moved source: the hops double),
+        // until the source is in front of the step, or in literal bytes, or straddles a boundary.  Sources of the first two kinds are
+        // final: those matches are copied a lane each, side by side; the rest go in order below.
+        u64 todo;
+        {
+            const bool valid = lane < n;
+            const u32 dm = valid ? my_op + ll : 0xFFFFFFFFu;                             // where the match lands (ascending with the lane)
+            const bool plain = valid && of >= ml && of != 0 && of <= dm;                // copies bytes of this block that do not overlap it
+            u32 src = plain ? dm - of : 0;
+            // (uniform control flow around every shuffle: a lane that sits out cannot be read)
+            for (int round = 0; round < 7; round++) {
+                const bool need = plain && src + ml > op;                                // reaches into what this step writes
+                if (!__ballot(need)) break;
+                // the last lane i whose match starts at or in front of src (match starts ascend): six probes
+                u32 cnt = 0;
+#pragma unroll
+                for (u32 bit = 32; bit; bit >>= 1) { const u32 cand = cnt + bit; const u32 dc = (u32)__shfl((int)dm, (int)(cand - 1) & 63, 64); if (need && dc <= src) cnt = cand; }
+                const int i = (int)cnt - 1;
+                const u32 di = (u32)__shfl((int)dm, i & 63, 64), mli = (u32)__shfl((int)ml, i & 63, 64), si = (u32)__shfl((int)src, i & 63, 64);
+                const bool pi = __shfl((int)plain, i & 63, 64) != 0;
+                const bool hop = need && i >= 0 && (u32)i < lane && pi && src + ml <= di + mli;
+                if (!__ballot(hop)) break;
+                if (hop) src = si + (src - di);
+            }
+            // final sources: in front of the step, or between two matches of it (literal bytes)
+            bool fin = plain && src + ml <= op;
+            {
+                const bool need = plain && !fin;
+                u32 cnt = 0;
+#pragma unroll
+                for (u32 bit = 32; bit; bit >>= 1) { const u32 cand = cnt + bit; const u32 dc = (u32)__shfl((int)dm, (int)(cand - 1) & 63, 64); if (need && dc <= src) cnt = cand; }
+                const int i = (int)cnt - 1;
+                const u32 di = (u32)__shfl((int)dm, i & 63, 64), mli = (u32)__shfl((int)ml, i & 63, 64), dnext = (u32)__shfl((int)dm, (i + 1) & 63, 64);
+                const u32 next_start = i + 1 < 64 ? dnext : 0xFFFFFFFFu;                  // (0xFFFFFFFF behind the step's last sequence)
+                if (need) fin = (i < 0 || src >= di + mli) && src + ml <= next_start;
+            }
+            if (fin && ml <= 64) for (u32 k = 0; k < ml; k++) obuf[dm + k] = obuf[src + k];
+            for (u64 bigm = __ballot(fin && ml > 64); bigm; bigm &= bigm - 1) {
+                const int j = __ffsll((long long)bigm) - 1;
+                const u32 dj = (u32)__builtin_amdgcn_readlane((int)dm, j), mlj = (u32)__builtin_amdgcn_readlane((int)ml, j), sj = (u32)__builtin_amdgcn_readlane((int)src, j);
+                for (u32 k = lane; k < mlj; k += 64) obuf[dj + k] = obuf[sj + k];
+            }
+            todo = __ballot(valid && !fin);
+            __syncthreads();
+        }
         for (u32 j = 0; j < n; j++) {
+            if (!((todo >> j) & 1)) continue;
             // (j is uniform: v_readlane, not a trip through the LDS crossbar three times per match)
             const int ju = __builtin_amdgcn_readfirstlane((int)j);
             u32 mlj = (u32)__builtin_amdgcn_readlane((int)ml, ju), ofj = (u32)__builtin_amdgcn_readlane((int)of, ju);
@@ -2815,7 +2869,8 @@ static int launch_build_huf(naf_gpu_ctx *c, u32 count, const u8 *src, ZBlock *bl
 {
     const char *e = ctx_opt(c, "HUF_BUILD16");
     if (e && e[0] == '0') LAUNCH(c, "zstd_build_huf", k_build_huf, cdiv(count, 64), 64, 0, src, blk, nblk, pool, pool_cap, st, first, range4, always_table, own_huf, gate, phase);
-    else LAUNCH(c, "zstd_build_huf", k_build_huf16, cdiv(count, HUFG_TREES), 256, 0, src, blk, nblk, pool, pool_cap, st, first, range4, always_table, own_huf, gate, phase);
+    else if (ctx_opt_is(c, "HUF_BUILD_WG", '1')) LAUNCH(c, "zstd_build_huf", k_build_huf16<16>, cdiv(count, 16), 256, 0, src, blk, nblk, pool, pool_cap, st, first, range4, always_table, own_huf, gate, phase);
+    else LAUNCH(c, "zstd_build_huf", k_build_huf16<4>, cdiv(count, 4), 64, 0, src, blk, nblk, pool, pool_cap, st, first, range4, always_table, own_huf, gate, phase);
     return 0;
 }
 static int zerr(naf_gpu_ctx *c, u32 e, const char *where)
