@@ -2325,6 +2325,68 @@ __global__ __launch_bounds__(64) void k_lz_prep(const ZBlock *blk, const u32 *se
     }
     if (__ballot(bad) && lane == 0) set_err(st, ZE_CORRUPT);
 }
+// ---- chains of copies (k_lz_collapse) ----------------------------------------------------------------------------------------------
+// Records that resemble their neighbours -- a FASTQ's read names under libzstd: every name copies the first bytes of the one before --
+// make chains: match i reads what match i - 1 wrote, which read what i - 2 wrote ...  As dataflow that is one round trip through memory
+// per LINK (the reference's archive of 2 GB of reads: 210 ms in k_lz_exec for chains of ten thousand names per block).  But a source
+// that lies wholly inside an earlier PLAIN match holds the same bytes as the place that match copied from: the match may as well read
+// there, and from where THAT place was copied from.  Per unit of 1024 sequences (the units of k_lz_exec), in LDS: every match whose
+// source lies inside a match of its unit moves it to that match's own current source, all matches at once, round after round -- the
+// hops double, ten rounds cover a unit -- until the source leaves the unit, falls into literals, or straddles a boundary.  The moved
+// source is written back as a larger offset; k_lz_deps and k_lz_exec never know.  Chains that cross units keep one link per unit.
+#define LZ_UNIT 1024u
+__global__ __launch_bounds__(64) void k_lz_collapse(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A)
+{
+    __shared__ u32 s_dst[LZ_UNIT], s_ml[LZ_UNIT], s_src[LZ_UNIT];
+    const u32 lane = threadIdx.x;
+    const u64 u = blockIdx.x;
+    if (u >= *n_units) return;
+    u32 t = 0;
+    { u32 hi = n_seq_blk; while (t + 1 < hi) { const u32 mid = (t + hi) >> 1; if (unit_base[mid] <= u) t = mid; else hi = mid; } }
+    const ZBlock &b = blk[seq_list[t]];
+    const u32 s_first = (u32)(u - unit_base[t]) * LZ_UNIT, nseq = b.err ? 0 : b.nseq;
+    if (s_first >= nseq) return;
+    const u32 cnt = nseq - s_first < LZ_UNIT ? nseq - s_first : LZ_UNIT;
+    const u64 sbase = b.seq_base + s_first;
+    u32 my_ml[LZ_UNIT / 64];
+#pragma unroll
+    for (u32 k = 0; k < LZ_UNIT / 64; k++) {
+        const u32 idx = k * 64 + lane;
+        u32 d = 0xFFFFFFFFu, ml = 0, of = 0;
+        if (idx < cnt) { d = A.x_dst[sbase + idx]; ml = A.ml[sbase + idx]; of = A.of[sbase + idx]; }
+        const bool plain = ml && of >= ml && of <= d;                            // a copy of bytes of this block that do not overlap it
+        my_ml[k] = plain ? ml : 0;
+        s_dst[idx] = d; s_ml[idx] = plain ? ml : 0; s_src[idx] = plain ? d - of : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const u32 first_dst = s_dst[0];
+    bool moved_any = false;
+    for (int round = 0; round < 11; round++) {
+        u32 nsrc[LZ_UNIT / 64]; bool hop = false;
+#pragma unroll
+        for (u32 k = 0; k < LZ_UNIT / 64; k++) {
+            const u32 idx = k * 64 + lane;
+            const u32 s = idx < cnt && my_ml[k] ? s_src[idx] : 0xFFFFFFFFu;
+            nsrc[k] = s;
+            if (s == 0xFFFFFFFFu || s < first_dst) continue;                     // not a plain copy, or a source in front of the unit
+            u32 lo = 0, hi = idx;                                                // the last sequence j < idx whose match starts at or in front of s
+            while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (s_dst[mid] <= s) lo = mid + 1; else hi = mid; }
+            if (!lo) continue;
+            const u32 j = lo - 1, dj = s_dst[j], mlj = s_ml[j], sj = s_src[j];
+            if (mlj && sj != 0xFFFFFFFFu && s + my_ml[k] <= dj + mlj) { nsrc[k] = sj + (s - dj); hop = true; }
+        }
+        if (!__ballot(hop)) break;
+        moved_any = true;
+        __syncthreads();
+#pragma unroll
+        for (u32 k = 0; k < LZ_UNIT / 64; k++) { const u32 idx = k * 64 + lane; if (idx < cnt && my_ml[k]) s_src[idx] = nsrc[k]; }
+        __syncthreads();
+    }
+    if (!moved_any) return;
+#pragma unroll
+    for (u32 k = 0; k < LZ_UNIT / 64; k++) { const u32 idx = k * 64 + lane; if (idx < cnt && my_ml[k]) A.of[sbase + idx] = s_dst[idx] - s_src[idx]; }
+}
+
 // first j in [0, n) with x_dst[j] + ml[j] > rel (match ends are increasing; padding entries: 0xFFFFFFFF + 0)
 __device__ __forceinline__ u32 lz_first_end_after(const u32 *x, const u32 *m, u32 n, u32 rel)
 {
@@ -2420,7 +2482,7 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
         pend[w] = __ballot(xml[w] != 0);
         left += (u32)__popcll(pend[w]);
     }
-    u32 idle = 0, seen = 0;
+    u32 idle = 0, seen = 0, unsaid = 0;
     while (left) {
         u64 rdy[U]; u64 any = 0;
 #pragma unroll
@@ -2461,17 +2523,40 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
                 pend[w] &= ~rdy[w]; ran += (u32)__popcll(rdy[w]);
             }
             left -= ran;
-            if (lane == 0) __hip_atomic_fetch_add(&st->n_exec_done, ran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (the frame's progress counter -- what a unit that cannot move looks at before it gives up -- is told in lumps: one atomic per
+            // sweep from every unit of the device was a queue on one address, a third of the launch's time on a stream of short copies)
+            unsaid += ran;
+            if (unsaid >= 512 || !left) { if (lane == 0) __hip_atomic_fetch_add(&st->n_exec_done, unsaid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); unsaid = 0; }
             idle = 0;
             continue;
         }
         __builtin_amdgcn_s_sleep(2);
+        if (unsaid && idle == 1024) { if (lane == 0) __hip_atomic_fetch_add(&st->n_exec_done, unsaid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); unsaid = 0; }
         if (++idle >= (1u << 18)) {                                           // nothing of this unit could run for a long time: has ANYTHING run meanwhile?
             const u32 now = ld_sc1<u32>(&st->n_exec_done);
             if (ld_sc1<u32>(&st->err) || now == seen) { if (lane == 0) set_err(st, ZE_CORRUPT); break; }
             seen = now; idle = 0;
         }
     }
+}
+
+// (TRACE only) what a frame's matches look like: counts by kind and the first sequences of the first executed block
+struct LzStats { u64 n_match, n_overlap, n_dep0, n_dep1, n_dep2, n_dep3p, sum_ml, max_dep; u32 first[32][4]; };
+__global__ void k_lz_stats(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, LzArrays A, LzStats *S)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seq_blk) return;
+    const ZBlock &b = blk[seq_list[t]];
+    const u32 nseq = b.err ? 0 : b.nseq;
+    u64 nm = 0, no = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, sm = 0, mx = 0;
+    for (u32 s = 0; s < nseq; s++) {
+        const u64 i = b.seq_base + s; const u32 ml = A.ml[i]; if (!ml) continue;
+        nm++; sm += ml; if (A.of[i] < ml) no++;
+        const u32 n = A.dep_n[i]; if (n == 0) d0++; else if (n == 1) d1++; else if (n == 2) d2++; else d3++; if (n > mx) mx = n;
+        if (t == 0 && s < 32) { S->first[s][0] = A.x_dst[i]; S->first[s][1] = ml; S->first[s][2] = A.of[i]; S->first[s][3] = n ? (u32)(A.dep_lo[i] - b.seq_base) | (n << 20) : 0xFFFFFFFFu; }
+    }
+    atomicAdd((unsigned long long *)&S->n_match, nm); atomicAdd((unsigned long long *)&S->n_overlap, no); atomicAdd((unsigned long long *)&S->n_dep0, d0); atomicAdd((unsigned long long *)&S->n_dep1, d1);
+    atomicAdd((unsigned long long *)&S->n_dep2, d2); atomicAdd((unsigned long long *)&S->n_dep3p, d3); atomicAdd((unsigned long long *)&S->sum_ml, sm); atomicMax((unsigned long long *)&S->max_dep, mx);
 }
 
 // The sequences of blocks seq_list[0 .. nx) executed: as dataflow (above), or in block order (EXEC=batch / =serial: the cross-checks; frames
@@ -2495,17 +2580,24 @@ static int launch_lz_exec(naf_gpu_ctx *c, const ZBlock *blk, const u32 *seq_list
     if (!A.dep_lo || !A.dep_n || !A.sdone) return NAF_GPU_ENOMEM;
     HIP_TRY(c, hipMemsetAsync(A.sdone, 1, ns_total + 16, c->stream));
     LAUNCH(c, "zstd_lz_prep", k_lz_prep, nx, 64, 0, blk, seq_list, nx, seq_cnt, nblk, ns_total, A, lits, d_dst, st);
-    LAUNCH(c, "zstd_lz_deps", k_lz_deps, nx, 64, 0, blk, seq_list, nx, offs, seq_cnt, nblk, ns_total, A);
-    // units of U x 64 sequences: their numbering in frame order
-    const char *ue = ctx_opt(c, "EXEC_UNIT");
-    const u32 U = ue ? (u32)atoi(ue) : 16u, per_unit = (U == 4 ? 4u : U == 8 ? 8u : 16u) * 64u;     // (1 GB of a repeat-rich genome under --long 27: 25 / 15 / 10 ms with 4 / 8 / 16; a unit per block: 44)
+    // units of 1024 sequences in frame order (k_lz_collapse's and k_lz_exec's)
     u64 *units = arena_new<u64>(c, (size_t)nx + 2); if (!units) return NAF_GPU_ENOMEM;
-    LAUNCH(c, "zstd_lz_units", k_lz_units, cdiv(nx, 256), 256, 0, blk, seq_list, nx, per_unit, units);
+    LAUNCH(c, "zstd_lz_units", k_lz_units, cdiv(nx, 256), 256, 0, blk, seq_list, nx, LZ_UNIT, units);
     int rc = scan_exclusive_u64(c, units, nx, units + nx + 1); if (rc) return rc;
-    const u32 grid = (u32)(ns_total / per_unit + nx + 1);                    // (an upper bound known without a read-back: wavefronts behind the last unit leave at once)
-    if (per_unit == 4 * 64) LAUNCH(c, "zstd_exec_seq", k_lz_exec<4>, grid, 64, 0, blk, seq_list, nx, (const u64 *)units, (const u64 *)(units + nx + 1), A, d_dst, st);
-    else if (per_unit == 16 * 64) LAUNCH(c, "zstd_exec_seq", k_lz_exec<16>, grid, 64, 0, blk, seq_list, nx, (const u64 *)units, (const u64 *)(units + nx + 1), A, d_dst, st);
-    else LAUNCH(c, "zstd_exec_seq", k_lz_exec<8>, grid, 64, 0, blk, seq_list, nx, (const u64 *)units, (const u64 *)(units + nx + 1), A, d_dst, st);
+    const u32 grid = (u32)(ns_total / LZ_UNIT + nx + 1);                     // (an upper bound known without a read-back: wavefronts behind the last unit leave at once)
+    if (!ctx_opt_is(c, "EXEC_COLLAPSE", '0'))
+        LAUNCH(c, "zstd_lz_collapse", k_lz_collapse, grid, 64, 0, blk, seq_list, nx, (const u64 *)units, (const u64 *)(units + nx + 1), A);
+    LAUNCH(c, "zstd_lz_deps", k_lz_deps, nx, 64, 0, blk, seq_list, nx, offs, seq_cnt, nblk, ns_total, A);
+    if (ctx_tracing(c)) {
+        LzStats *S = arena_new<LzStats>(c, 1), hs; if (!S) return NAF_GPU_ENOMEM;
+        HIP_TRY(c, hipMemsetAsync(S, 0, sizeof(LzStats), c->stream));
+        LAUNCH(c, "zstd_lz_stats", k_lz_stats, cdiv(nx, 64), 64, 0, blk, seq_list, nx, A, S);
+        if ((rc = ctx_readback(c, &hs, S, sizeof hs))) return rc;
+        ctx_trace(c, "[lz] blocks %u sequences %llu matches %llu (overlapping %llu) bytes %llu; sources written by 0 / 1 / 2 / more matches: %llu / %llu / %llu / %llu (most: %llu)\n", nx, (unsigned long long)ns_total,
+                  (unsigned long long)hs.n_match, (unsigned long long)hs.n_overlap, (unsigned long long)hs.sum_ml, (unsigned long long)hs.n_dep0, (unsigned long long)hs.n_dep1, (unsigned long long)hs.n_dep2, (unsigned long long)hs.n_dep3p, (unsigned long long)hs.max_dep);
+        for (int k = 0; k < 32 && (u64)k < hs.n_match; k++) ctx_trace(c, "[lz]   seq %2d: dst %6u ml %5u of %7u deps %s%u+%u\n", k, hs.first[k][0], hs.first[k][1], hs.first[k][2], hs.first[k][3] == 0xFFFFFFFFu ? "-" : "", hs.first[k][3] == 0xFFFFFFFFu ? 0 : hs.first[k][3] & 0xFFFFF, hs.first[k][3] == 0xFFFFFFFFu ? 0 : hs.first[k][3] >> 20);
+    }
+    LAUNCH(c, "zstd_exec_seq", k_lz_exec<LZ_UNIT / 64>, grid, 64, 0, blk, seq_list, nx, (const u64 *)units, (const u64 *)(units + nx + 1), A, d_dst, st);
     return 0;
 }
 

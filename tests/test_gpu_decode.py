@@ -29,16 +29,16 @@ def host(t):
     return t.cpu().numpy().tobytes()
 
 
-@pytest.mark.parametrize("executor", ["auto", "hbm", "hbm-unit4", "batch", "serial"])
+@pytest.mark.parametrize("executor", ["auto", "hbm", "hbm-nocollapse", "batch", "serial"])
 @pytest.mark.parametrize("case", zstd_cases(), ids=lambda c: c["name"])
 def test_zstd_decode_golden_frames(gpu, case, executor, monkeypatch):
     """libzstd-made frames (every level, long windows, multi-threaded, streaming): frames whose blocks regenerate at most 16 KiB
     run their sequences in the LDS executor, the others as dataflow (k_lz_prep / _deps / _exec); "hbm" forces the latter for every
-    frame, "hbm-unit4" with units of 256 sequences (more units than blocks even for the small frames), "batch" and "serial" the two
+    frame, "hbm-nocollapse" without the move of sources back along chains of copies (k_lz_collapse), "batch" and "serial" the two
     block-ordered executors kept as cross-checks."""
     monkeypatch.setenv("NAF_GPU_EXEC_LDS", "1" if executor == "auto" else "0")
-    if executor == "hbm-unit4":
-        monkeypatch.setenv("NAF_GPU_EXEC_UNIT", "4")
+    if executor == "hbm-nocollapse":
+        monkeypatch.setenv("NAF_GPU_EXEC_COLLAPSE", "0")
     if executor in ("batch", "serial"):
         monkeypatch.setenv("NAF_GPU_EXEC", executor)
     frame = golden_bytes("zstd", case["name"] + ".zst")
@@ -1022,7 +1022,7 @@ def test_names_decoded_beside_ids(gpu, monkeypatch):
 def test_reference_archive_of_a_repeat_rich_genome_under_every_executor(gpu, oracle, monkeypatch, flags):
     """What the reference makes of a genome full of repeats (libzstd's match finders, `--long`: thousands of sequences per 128 KiB block,
     matches that read all over the blocks in front of them -- ennaf/src/compressor.c:7-21, ennaf.c:247-273) decoded by the dataflow
-    executor in units of 16 / 8 / 4 words and by the two block-ordered ones: the reference's own text every time.  (In block order this
+    executor with and without k_lz_collapse and by the two block-ordered ones: the reference's own text every time.  (In block order this
     kind of frame ran one block behind the other, and at 1 GB the bounded wait called it corrupt: DESIGN.md 4.30.)"""
     from naf_amd import capi, synth
     O = oracle
@@ -1033,13 +1033,13 @@ def test_reference_archive_of_a_repeat_rich_genome_under_every_executor(gpu, ora
     want = O.ref_unnaf(naf)
     assert want == text
     d_naf = gpu.to_device(naf)
-    for how, unit in (("dataflow", "16"), ("dataflow", "8"), ("dataflow", "4"), ("batch", ""), ("serial", "")):
-        monkeypatch.setenv("NAF_GPU_EXEC", how); monkeypatch.setenv("NAF_GPU_EXEC_UNIT", unit); monkeypatch.setenv("NAF_GPU_EXEC_LDS", "0")
-        assert host(gpu.unnaf(d_naf, capi.OUT_FASTA)) == want, (flags, how, unit)
+    for how, collapse in (("dataflow", "1"), ("dataflow", "0"), ("batch", "1"), ("serial", "1")):
+        monkeypatch.setenv("NAF_GPU_EXEC", how); monkeypatch.setenv("NAF_GPU_EXEC_COLLAPSE", collapse); monkeypatch.setenv("NAF_GPU_EXEC_LDS", "0")
+        assert host(gpu.unnaf(d_naf, capi.OUT_FASTA)) == want, (flags, how, collapse)
         # a byte range of it: the range's dependency closure through the same executor
         b, e = len(want) // 3, len(want) // 3 + 1_000_003
-        assert host(gpu.unnaf_range(d_naf, b, e, capi.OUT_FASTA)) == want[b:e], (flags, how, unit)
-    monkeypatch.delenv("NAF_GPU_EXEC"); monkeypatch.delenv("NAF_GPU_EXEC_UNIT"); monkeypatch.delenv("NAF_GPU_EXEC_LDS")
+        assert host(gpu.unnaf_range(d_naf, b, e, capi.OUT_FASTA)) == want[b:e], (flags, how, collapse)
+    monkeypatch.delenv("NAF_GPU_EXEC"); monkeypatch.delenv("NAF_GPU_EXEC_COLLAPSE"); monkeypatch.delenv("NAF_GPU_EXEC_LDS")
     # this build's own archives at the levels that match across blocks, through the same executors (16 KiB blocks: the LDS executor by default)
     for level, long_log in ((19, 0), (3, 27)):
         mine, _ = gpu.ennaf(gpu.to_device(text), level=level, long_log=long_log)
@@ -1047,3 +1047,23 @@ def test_reference_archive_of_a_repeat_rich_genome_under_every_executor(gpu, ora
             monkeypatch.setenv("NAF_GPU_EXEC_LDS", lds)
             assert host(gpu.unnaf(mine, capi.OUT_FASTA)) == text, (level, long_log, lds)
         monkeypatch.delenv("NAF_GPU_EXEC_LDS")
+
+
+def test_reference_archive_of_reads_whose_names_copy_each_other(gpu, oracle, monkeypatch):
+    """The reference's archive of a FASTQ: libzstd codes every read name as a copy of the name before it plus a digit or two -- chains of
+    ten thousand links per 128 KiB block of the ids stream.  k_lz_collapse moves every source back along its chain (what is left: a link
+    where the counter's digits roll over); the text must be the reference's with it, without it (NAF_GPU_EXEC_COLLAPSE=0) and in block order."""
+    from naf_amd import capi, synth
+    O = oracle
+    if not O.have_ref():
+        pytest.skip("needs oracle/_ref")
+    text = synth.fastq_reads(60_000, 100, seed=3) + synth.fastq_reads(3_000, 120, seed=4, var_len=True)
+    naf = O.ref_ennaf(text, ("--fastq",))
+    want = O.ref_unnaf(naf)
+    d_naf = gpu.to_device(naf)
+    for how, collapse in (("dataflow", "1"), ("dataflow", "0"), ("batch", "1")):
+        monkeypatch.setenv("NAF_GPU_EXEC", how); monkeypatch.setenv("NAF_GPU_EXEC_COLLAPSE", collapse)
+        assert host(gpu.unnaf(d_naf, capi.OUT_FASTQ)) == want, (how, collapse)
+        for mode, args in ((capi.OUT_FASTA, ("--fasta",)),):
+            assert host(gpu.unnaf(d_naf, mode)) == O.ref_unnaf(naf, args), (how, collapse, mode)
+    monkeypatch.delenv("NAF_GPU_EXEC"); monkeypatch.delenv("NAF_GPU_EXEC_COLLAPSE")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The decode of a REFERENCE-made archive of random bases (oracle/_ref/ennaf on the host, then this build's unnaf on the GPU):
-tools/perf_refarc.py [bytes]  -- per-call times and the kernel list; NAF_GPU_DEBUG_FLAT=1 shows how many blocks were decoded."""
+"""The decode of a REFERENCE-made archive (oracle/_ref/ennaf on the host with its default level, then this build's unnaf on the GPU):
+tools/perf_refarc.py [bytes] [uniform|realistic|repeats|fastq] [ennaf flags ...]  -- per-call times and the kernel list; NAF_GPU_TRACE=1
+shows how many blocks were decoded."""
 import os, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,16 +9,24 @@ import torch
 from naf_amd import capi, synth
 
 size = int(float(sys.argv[1])) if len(sys.argv) > 1 else int(4e9)
+which = sys.argv[2] if len(sys.argv) > 2 else "uniform"
+flags = sys.argv[3:]
+mode = capi.OUT_FASTQ if which == "fastq" else capi.OUT_FASTA
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ctx = capi.Context(0)
-text = synth.fasta_acgt_device(size, n_records=100, width=80, seed=2024, device="cuda")
+text = (synth.fasta_acgt_device(size, n_records=100, width=80, seed=2024, device="cuda") if which == "uniform" else
+        synth.realistic_genome_device(size, device="cuda") if which == "realistic" else
+        synth.repeat_genome_device(size, device="cuda") if which == "repeats" else synth.fastq_reads_device(size, seed=7, device="cuda"))
 n = text.numel()
 d = "/dev/shm/refarc_%d" % os.getpid(); os.makedirs(d, exist_ok=True)
 try:
     text.cpu().numpy().tofile(d + "/t.fa")
     t0 = time.perf_counter()
-    subprocess.check_call([root + "/oracle/_ref/ennaf", d + "/t.fa", "-o", d + "/t.naf"], env=dict(os.environ, TMPDIR=d))
-    print("reference ennaf: %.1f s" % (time.perf_counter() - t0))
+    subprocess.check_call([root + "/oracle/_ref/ennaf", *flags, d + "/t.fa", "-o", d + "/t.naf"], env=dict(os.environ, TMPDIR=d))
+    print("reference ennaf: %.1f s, archive %d B" % (time.perf_counter() - t0, os.path.getsize(d + "/t.naf")))
+    t0 = time.perf_counter(); subprocess.check_call([root + "/oracle/_ref/unnaf", d + "/t.naf", "-o", d + "/t.out"]); tr = time.perf_counter() - t0
+    print("reference unnaf: %.2f s = %.2f GB/s" % (tr, n / tr / 1e9))
+    want = torch.from_numpy(np.fromfile(d + "/t.out", dtype=np.uint8)).to("cuda")
     naf = torch.from_numpy(np.fromfile(d + "/t.naf", dtype=np.uint8)).to("cuda")
 finally:
     subprocess.call(["rm", "-rf", d])
@@ -25,11 +34,11 @@ ctx.reserve(int(n * 1.7) + (2 << 30))
 out = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
 for it in range(6):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    r = ctx.unnaf(naf, capi.OUT_FASTA, out=out)
+    r = ctx.unnaf(naf, mode, out=out)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("unnaf call %d: %.2f ms  %.1f GB/s" % (it, dt * 1e3, n / dt / 1e9), flush=True)
-print("bit-exact:", bool(torch.equal(r, text)))
-ctx.set_timing(True); ctx.unnaf(naf, capi.OUT_FASTA, out=out)
+print("bit-exact with the reference's output:", bool(torch.equal(r, want)))
+ctx.set_timing(True); ctx.unnaf(naf, mode, out=out)
 for nm, ms, k in sorted(ctx.get_timing(), key=lambda x: -x[1])[:22]:
     print("   %-28s %8.3f ms x%d" % (nm, ms, k))
 print("   streams:", ["%.3f" % x for x in ctx.get_timing_streams()])
