@@ -2280,7 +2280,14 @@ __device__ __forceinline__ void wave_copy_sc1(u8 *d, const u8 *s, u32 n, u32 lan
     const u32 done = n & ~7u;
     if (lane < (n & 7u)) st_sc1<u8>(d + done + lane, ld_sc1<u8>(s + done + lane));
 }
-struct LzArrays { u32 *x_dst; u32 *ml; u32 *of; u32 *dep_lo; u32 *dep_n; u8 *sdone; };    // x_dst: the sequence arrays' `ll` slot, rewritten
+struct LzArrays { u32 *x_dst; u32 *ml; u32 *of; u32 *dep_lo; u32 *dep_n; u8 *sdone; u8 *stail; };    // x_dst: the sequence arrays' `ll` slot, rewritten
+// A match that overlaps itself (offset < length: a run of a repeated unit -- a FASTQ's "len=150" names and its lengths under libzstd are
+// ONE such match per 128 KiB block, each continuing the run of the block before) writes its last LZ_TAIL bytes first and says so in
+// `stail`; a match whose source lies in those bytes of one such match (the next block's eight-byte seed) waits for that, not for the
+// 128 KiB in front of it: the chain through the blocks of a run costs a round trip and a few stores per link instead of a block's copy
+// (names of 2 GB of reads, 376 blocks: 206 ms a byte a lane and a block per link, 31 ms with the doubling copy below, 2.9 ms with the tail).
+#define LZ_TAIL 256u
+#define LZ_DEP_TAIL 0x80000000u
 __global__ __launch_bounds__(64) void k_lz_prep(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *seq_cnt, u32 nblk, u64 ns_total,
                                                  LzArrays A, const u8 *lit_scratch, u8 *dst, ZStat *st)
 {
@@ -2313,7 +2320,7 @@ __global__ __launch_bounds__(64) void k_lz_prep(const ZBlock *blk, const u32 *se
         if (s0 + lane < cnt) {
             const u64 i = sbase + s0 + lane;
             A.x_dst[i] = real && ml ? d : 0xFFFFFFFFu; A.ml[i] = ml; A.of[i] = of;
-            A.sdone[i] = ml ? 0 : 1;
+            A.sdone[i] = ml ? 0 : 1; A.stail[i] = (ml && of < ml) ? 0 : 1;
         }
         bad = __ballot(bad) != 0;
         if (!bad) { op += tot_all; lp += tot_ll; }
@@ -2425,7 +2432,20 @@ __global__ __launch_bounds__(64) void k_lz_deps(const ZBlock *blk, const u32 *se
         // (in this block only the sequences in front of this one count: its own match starts at d >= the source's end)
         const u64 lo = base_a + lz_first_end_after(A.x_dst + base_a, A.ml + base_a, ja == bi ? s : cnt_a, (u32)(src - offs[ja]));
         const u64 hi = base_b + lz_count_start_before(A.x_dst + base_b, jb == bi ? s : cnt_b, (u32)(src_end - offs[jb]));     // one past the last
-        A.dep_lo[i] = (u32)lo; A.dep_n[i] = hi > lo ? (u32)(hi - lo) : 0;
+        u64 lo2 = lo, hi2 = hi;                                                    // (without the padding entries at the blocks' ends: they are done from the start)
+        while (hi2 > lo2 && A.ml[hi2 - 1] == 0) hi2--;
+        while (hi2 > lo2 && A.ml[lo2] == 0) lo2++;
+        u32 n = hi2 > lo2 ? (u32)(hi2 - lo2) : 0;
+        if (n == 1) {
+            // written by ONE match: when that one overlaps itself and the source starts in its last LZ_TAIL bytes, its tail is all this one waits for
+            const bool in_b = lo2 >= base_b && lo2 < base_b + cnt_b, in_a = lo2 >= base_a && lo2 < base_a + cnt_a;
+            if (in_a || in_b) {
+                const u32 mlj = A.ml[lo2], ofj = A.of[lo2];
+                const u64 endj = offs[in_b ? jb : ja] + A.x_dst[lo2] + mlj;
+                if (ofj < mlj && src + (mlj < LZ_TAIL ? mlj : LZ_TAIL) >= endj) n |= LZ_DEP_TAIL;      // (what of the source lies behind that match's end is not its bytes)
+            }
+        }
+        A.dep_lo[i] = (u32)lo2; A.dep_n[i] = n;
     }
 }
 __device__ __forceinline__ bool lz_deps_done(const u8 *sdone, u32 lo, u32 n)
@@ -2488,7 +2508,7 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
 #pragma unroll
         for (u32 w = 0; w < U; w++) {
             bool ready = false;
-            if ((pend[w] >> lane) & 1) ready = lz_deps_done(A.sdone, dlo[w], dn[w]);
+            if ((pend[w] >> lane) & 1) ready = (dn[w] & LZ_DEP_TAIL) ? ld_sc1<u8>(A.stail + dlo[w]) != 0 : lz_deps_done(A.sdone, dlo[w], dn[w]);
             rdy[w] = pend[w] ? __ballot(ready) : 0;
             any |= rdy[w];
         }
@@ -2512,14 +2532,29 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
                     const int j = __ffsll((long long)ov) - 1;
                     const u32 dj = (u32)__builtin_amdgcn_readlane((int)d, j), mlj = (u32)__builtin_amdgcn_readlane((int)ml, j), ofj = (u32)__builtin_amdgcn_readlane((int)of, j);
                     const u8 *from = out + dj - ofj;
-                    for (u32 k = lane; k < mlj; k += 64) st_sc1<u8>(out + dj + k, ld_sc1<u8>(from + k % ofj));
+                    if (mlj <= 2 * LZ_TAIL) { for (u32 k = lane; k < mlj; k += 64) st_sc1<u8>(out + dj + k, ld_sc1<u8>(from + k % ofj)); continue; }
+                    // a long run: its last LZ_TAIL bytes first (the run of the next block starts from them: k_lz_deps, LZ_DEP_TAIL) ...
+                    for (u32 k = mlj - LZ_TAIL + lane; k < mlj; k += 64) st_sc1<u8>(out + dj + k, ld_sc1<u8>(from + k % ofj));
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) st_sc1<u8>(A.stail + sbase + w * 64 + (u32)j, (u8)1);
+                    // ... then the rest by doubling: what is there -- the unit in front of the match and `have` bytes of the match, a whole
+                    // number of units -- is copied behind itself (eight bytes a lane; a byte a lane took 0.55 ms per 128 KiB block)
+                    const u32 body = mlj - LZ_TAIL;
+                    u32 have = 0;
+                    if (ofj < 64) { const u32 first = (64 / ofj) * ofj < body ? (64 / ofj) * ofj : body; for (u32 k = lane; k < first; k += 64) st_sc1<u8>(out + dj + k, ld_sc1<u8>(from + k % ofj)); have = first; }
+                    while (have < body) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        const u32 n = ofj + have < body - have ? ((ofj + have) / ofj) * ofj : body - have;
+                        wave_copy_sc1(out + dj + have, from, n, lane);
+                        have += n;
+                    }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the bytes are out before anybody is told
             u32 ran = 0;
 #pragma unroll
             for (u32 w = 0; w < U; w++) {
-                if ((rdy[w] >> lane) & 1) st_sc1<u8>(A.sdone + sbase + w * 64 + lane, (u8)1);
+                if ((rdy[w] >> lane) & 1) { st_sc1<u8>(A.sdone + sbase + w * 64 + lane, (u8)1); st_sc1<u8>(A.stail + sbase + w * 64 + lane, (u8)1); }
                 pend[w] &= ~rdy[w]; ran += (u32)__popcll(rdy[w]);
             }
             left -= ran;
@@ -2552,8 +2587,8 @@ __global__ void k_lz_stats(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk
     for (u32 s = 0; s < nseq; s++) {
         const u64 i = b.seq_base + s; const u32 ml = A.ml[i]; if (!ml) continue;
         nm++; sm += ml; if (A.of[i] < ml) no++;
-        const u32 n = A.dep_n[i]; if (n == 0) d0++; else if (n == 1) d1++; else if (n == 2) d2++; else d3++; if (n > mx) mx = n;
-        if (t == 0 && s < 32) { S->first[s][0] = A.x_dst[i]; S->first[s][1] = ml; S->first[s][2] = A.of[i]; S->first[s][3] = n ? (u32)(A.dep_lo[i] - b.seq_base) | (n << 20) : 0xFFFFFFFFu; }
+        const u32 n = A.dep_n[i] & ~LZ_DEP_TAIL; if (n == 0) d0++; else if (n == 1) d1++; else if (n == 2) d2++; else d3++; if (n > mx) mx = n;
+        if (t < 2 && s < 16) { S->first[16 * t + s][0] = A.x_dst[i]; S->first[16 * t + s][1] = ml; S->first[16 * t + s][2] = A.of[i]; S->first[16 * t + s][3] = A.dep_n[i] ? (u32)((i - A.dep_lo[i]) & 0xFFFFF) | ((n > 255 ? 255 : n) << 20) | (A.dep_n[i] & LZ_DEP_TAIL) : 0xFFFFFFFFu; }
     }
     atomicAdd((unsigned long long *)&S->n_match, nm); atomicAdd((unsigned long long *)&S->n_overlap, no); atomicAdd((unsigned long long *)&S->n_dep0, d0); atomicAdd((unsigned long long *)&S->n_dep1, d1);
     atomicAdd((unsigned long long *)&S->n_dep2, d2); atomicAdd((unsigned long long *)&S->n_dep3p, d3); atomicAdd((unsigned long long *)&S->sum_ml, sm); atomicMax((unsigned long long *)&S->max_dep, mx);
@@ -2576,9 +2611,10 @@ static int launch_lz_exec(naf_gpu_ctx *c, const ZBlock *blk, const u32 *seq_list
         return 0;
     }
     LzArrays A; A.x_dst = o_ll; A.ml = o_ml; A.of = o_of;
-    A.dep_lo = arena_new<u32>(c, ns_total + 1); A.dep_n = arena_new<u32>(c, ns_total + 1); A.sdone = (u8 *)arena_alloc(c, ns_total + 16);
+    A.dep_lo = arena_new<u32>(c, ns_total + 1); A.dep_n = arena_new<u32>(c, ns_total + 1); A.sdone = (u8 *)arena_alloc(c, 2 * (ns_total + 16));
     if (!A.dep_lo || !A.dep_n || !A.sdone) return NAF_GPU_ENOMEM;
-    HIP_TRY(c, hipMemsetAsync(A.sdone, 1, ns_total + 16, c->stream));
+    A.stail = A.sdone + ns_total + 16;
+    HIP_TRY(c, hipMemsetAsync(A.sdone, 1, 2 * (ns_total + 16), c->stream));
     LAUNCH(c, "zstd_lz_prep", k_lz_prep, nx, 64, 0, blk, seq_list, nx, seq_cnt, nblk, ns_total, A, lits, d_dst, st);
     // units of 1024 sequences in frame order (k_lz_collapse's and k_lz_exec's)
     u64 *units = arena_new<u64>(c, (size_t)nx + 2); if (!units) return NAF_GPU_ENOMEM;
@@ -2595,7 +2631,11 @@ static int launch_lz_exec(naf_gpu_ctx *c, const ZBlock *blk, const u32 *seq_list
         if ((rc = ctx_readback(c, &hs, S, sizeof hs))) return rc;
         ctx_trace(c, "[lz] blocks %u sequences %llu matches %llu (overlapping %llu) bytes %llu; sources written by 0 / 1 / 2 / more matches: %llu / %llu / %llu / %llu (most: %llu)\n", nx, (unsigned long long)ns_total,
                   (unsigned long long)hs.n_match, (unsigned long long)hs.n_overlap, (unsigned long long)hs.sum_ml, (unsigned long long)hs.n_dep0, (unsigned long long)hs.n_dep1, (unsigned long long)hs.n_dep2, (unsigned long long)hs.n_dep3p, (unsigned long long)hs.max_dep);
-        for (int k = 0; k < 32 && (u64)k < hs.n_match; k++) ctx_trace(c, "[lz]   seq %2d: dst %6u ml %5u of %7u deps %s%u+%u\n", k, hs.first[k][0], hs.first[k][1], hs.first[k][2], hs.first[k][3] == 0xFFFFFFFFu ? "-" : "", hs.first[k][3] == 0xFFFFFFFFu ? 0 : hs.first[k][3] & 0xFFFFF, hs.first[k][3] == 0xFFFFFFFFu ? 0 : hs.first[k][3] >> 20);
+        for (int k = 0; k < 32; k++) if (hs.first[k][1]) {
+            const u32 v = hs.first[k][3];
+            if (v == 0xFFFFFFFFu) ctx_trace(c, "[lz]   block %d seq %2d: lands at %6u length %6u offset %7u, source final\n", k / 16, k % 16, hs.first[k][0], hs.first[k][1], hs.first[k][2]);
+            else ctx_trace(c, "[lz]   block %d seq %2d: lands at %6u length %6u offset %7u, source written by %u match(es) from %u sequences back%s\n", k / 16, k % 16, hs.first[k][0], hs.first[k][1], hs.first[k][2], (v >> 20) & 255, v & 0xFFFFF, (v & LZ_DEP_TAIL) ? " (their tail)" : "");
+        }
     }
     LAUNCH(c, "zstd_exec_seq", k_lz_exec<LZ_UNIT / 64>, grid, 64, 0, blk, seq_list, nx, (const u64 *)units, (const u64 *)(units + nx + 1), A, d_dst, st);
     return 0;
