@@ -2276,7 +2276,14 @@ __device__ __forceinline__ void lane_copy_sc1(u8 *d, const u8 *s, u32 n)        
 }
 __device__ __forceinline__ void wave_copy_sc1(u8 *d, const u8 *s, u32 n, u32 lane)  // the same by 64 lanes
 {
-    for (u32 i = lane * 8; i + 8 <= n; i += 64 * 8) st_sc1<u64>(d + i, ld_sc1<u64>(s + i));
+    // (four loads in flight per lane before the first store: one at a time a 128 KiB copy -- a block that repeats its predecessor -- was 256
+    // round trips through memory in a row, 80 us)
+    u32 i = lane * 8;
+    for (; i + 3 * 512 + 8 <= n; i += 4 * 512) {
+        const u64 a = ld_sc1<u64>(s + i), b = ld_sc1<u64>(s + i + 512), c = ld_sc1<u64>(s + i + 1024), e = ld_sc1<u64>(s + i + 1536);
+        st_sc1<u64>(d + i, a); st_sc1<u64>(d + i + 512, b); st_sc1<u64>(d + i + 1024, c); st_sc1<u64>(d + i + 1536, e);
+    }
+    for (; i + 8 <= n; i += 64 * 8) st_sc1<u64>(d + i, ld_sc1<u64>(s + i));
     const u32 done = n & ~7u;
     if (lane < (n & 7u)) st_sc1<u8>(d + done + lane, ld_sc1<u8>(s + done + lane));
 }
@@ -2489,17 +2496,21 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
     const u32 s_first = (u32)(u - unit_base[t]) * (U * 64u), nseq = b.nseq;
     const u64 sbase = b.seq_base + s_first;
     u8 *out = dst + b.out_off;
-    u32 dlo[U], dn[U], xd[U], xml[U], xof[U];
+    // (where a match lands, its length and offset wait in LDS -- a wavefront's own columns, no barrier -- until the match runs: in registers
+    // beside the dependency ranges they made the kernel 268 VGPRs with the long-copy paths, one wavefront per SIMD instead of two)
+    __shared__ u32 s_d[U * 64], s_ml[U * 64], s_of[U * 64];
+    u32 dlo[U], dn[U];
     u64 pend[U];
     u32 left = 0;
 #pragma unroll
     for (u32 w = 0; w < U; w++) {
         const u32 s = s_first + w * 64 + lane;
         const u64 i = sbase + w * 64 + lane;
-        xml[w] = s < nseq ? A.ml[i] : 0;
-        dlo[w] = 0; dn[w] = 0; xd[w] = 0; xof[w] = 0;
-        if (xml[w]) { dlo[w] = A.dep_lo[i]; dn[w] = A.dep_n[i]; xd[w] = A.x_dst[i]; xof[w] = A.of[i]; }
-        pend[w] = __ballot(xml[w] != 0);
+        const u32 m = s < nseq ? A.ml[i] : 0;
+        dlo[w] = 0; dn[w] = 0;
+        s_ml[w * 64 + lane] = m;
+        if (m) { dlo[w] = A.dep_lo[i]; dn[w] = A.dep_n[i]; s_d[w * 64 + lane] = A.x_dst[i]; s_of[w * 64 + lane] = A.of[i]; }
+        pend[w] = __ballot(m != 0);
         left += (u32)__popcll(pend[w]);
     }
     u32 idle = 0, seen = 0, unsaid = 0;
@@ -2519,7 +2530,7 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
                 const u64 r = rdy[w];
                 if (!r) continue;
                 const bool ready = (r >> lane) & 1;
-                const u32 d = xd[w], ml = xml[w], of = xof[w];
+                const u32 d = s_d[w * 64 + lane], ml = s_ml[w * 64 + lane], of = s_of[w * 64 + lane];
                 const bool plain = ready && of >= ml;
                 if (plain && ml <= EXEC_LANE_MAX) lane_copy_sc1(out + d, out + d - of, ml);
                 for (u64 big = __ballot(plain && ml > EXEC_LANE_MAX); big; big &= big - 1) {
@@ -2554,7 +2565,7 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
             u32 ran = 0;
 #pragma unroll
             for (u32 w = 0; w < U; w++) {
-                if ((rdy[w] >> lane) & 1) { st_sc1<u8>(A.sdone + sbase + w * 64 + lane, (u8)1); st_sc1<u8>(A.stail + sbase + w * 64 + lane, (u8)1); }
+                if ((rdy[w] >> lane) & 1) { st_sc1<u8>(A.sdone + sbase + w * 64 + lane, (u8)1); if (s_of[w * 64 + lane] < s_ml[w * 64 + lane]) st_sc1<u8>(A.stail + sbase + w * 64 + lane, (u8)1); }   // (`stail` of a short overlapping match: set with the match)
                 pend[w] &= ~rdy[w]; ran += (u32)__popcll(rdy[w]);
             }
             left -= ran;
