@@ -2516,10 +2516,15 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
     u32 idle = 0, seen = 0, unsaid = 0;
     while (left) {
         u64 rdy[U]; u64 any = 0;
+        // the first `done` byte of everything pending, all loads in flight together (a word at a time they were U round trips in a row: the
+        // time of a sweep, and a sweep is what a link of a chain costs); a match with several sources looks at the others once its first is done
+        u8 f0[U];
+#pragma unroll
+        for (u32 w = 0; w < U; w++) f0[w] = (((pend[w] >> lane) & 1) && (dn[w] & ~LZ_DEP_TAIL)) ? ld_sc1<u8>(((dn[w] & LZ_DEP_TAIL) ? A.stail : A.sdone) + dlo[w]) : (u8)1;
 #pragma unroll
         for (u32 w = 0; w < U; w++) {
-            bool ready = false;
-            if ((pend[w] >> lane) & 1) ready = (dn[w] & LZ_DEP_TAIL) ? ld_sc1<u8>(A.stail + dlo[w]) != 0 : lz_deps_done(A.sdone, dlo[w], dn[w]);
+            bool ready = ((pend[w] >> lane) & 1) && f0[w];
+            if (ready && (dn[w] & ~LZ_DEP_TAIL) > 1) ready = lz_deps_done(A.sdone, dlo[w] + 1, dn[w] - 1);
             rdy[w] = pend[w] ? __ballot(ready) : 0;
             any |= rdy[w];
         }
