@@ -62,52 +62,67 @@ static void show_help(void)
         "  --keep-temp-files  - Keep temporary files\n  --no-mask          - Don't store mask\n  -h, --help         - Show help\n  -V, --version      - Show version\n", -131072, 22, 10, 31);
 }
 
+/* The command line (ennaf/src/ennaf.c:360-430: the same options, texts and order of complaints), as a table: an option that takes a
+ * value is only recognised with an argument behind it -- alone at the end it is "unknown or incomplete", like any unknown one. */
+enum { OP_TEMP_DIR, OP_NAME, OP_TITLE, OP_LEVEL, OP_LINE_LENGTH, OP_LONG, OP_OUT, OP_IN, OP_IN_FORMAT, OP_HELP, OP_VERSION, OP_VERBOSE, OP_IGNORED,
+       OP_NO_MASK, OP_FASTA, OP_FASTQ, OP_SEQ_TYPE, OP_WELL_FORMED, OP_STRICT, OP_STDOUT };
+static const struct { const char *name; int op; bool value; int arg; } option_table[] = {
+    { "--temp-dir", OP_TEMP_DIR, true, 0 }, { "--name", OP_NAME, true, 0 }, { "--title", OP_TITLE, true, 0 }, { "--level", OP_LEVEL, true, 0 },
+    { "--line-length", OP_LINE_LENGTH, true, 0 }, { "--long", OP_LONG, true, 0 }, { "--out", OP_OUT, true, 0 }, { "--in", OP_IN, true, 0 },
+    { "--in-format", OP_IN_FORMAT, true, 0 }, { "-o", OP_OUT, true, 0 },
+    { "--help", OP_HELP, false, 0 }, { "-h", OP_HELP, false, 0 }, { "--version", OP_VERSION, false, 0 }, { "-V", OP_VERSION, false, 0 }, { "--verbose", OP_VERBOSE, false, 0 },
+    { "--binary-stderr", OP_IGNORED, false, 0 }, { "--keep-temp-files", OP_IGNORED, false, 0 }, { "--no-mask", OP_NO_MASK, false, 0 },
+    { "--fasta", OP_FASTA, false, 0 }, { "--fastq", OP_FASTQ, false, 0 }, { "--dna", OP_SEQ_TYPE, false, NAF_SEQ_DNA }, { "--rna", OP_SEQ_TYPE, false, NAF_SEQ_RNA },
+    { "--protein", OP_SEQ_TYPE, false, NAF_SEQ_PROTEIN }, { "--text", OP_SEQ_TYPE, false, NAF_SEQ_TEXT }, { "--well-formed", OP_WELL_FORMED, false, 0 },
+    { "--strict", OP_STRICT, false, 0 }, { "-c", OP_STDOUT, false, 0 } };
+static bool print_version = false;
+static void set_input_path(char *v) { if (in_file_path) die("can compress only one file at a time\n"); if (!*v) die("empty input file name\n"); in_file_path = v; }
+static void apply_option(int op, int arg, char *v)
+{
+    long long a; int how;
+    switch (op) {
+    case OP_TEMP_DIR: if (temp_dir_arg) die("double --temp-dir parameter\n"); if (!*v) die("empty --temp-dir parameter\n"); temp_dir_arg = v; break;
+    case OP_NAME: if (!*v) die("empty --name parameter\n"); break;
+    case OP_TITLE: if (title) die("double --title parameter\n"); if (!*v) die("empty --title parameter\n"); title = v; break;
+    case OP_LEVEL: set_level(v); break;
+    case OP_LINE_LENGTH:
+        how = decimal_arg(v, &a);
+        if (how == 0) die("can't parse the value of --line-length parameter\n");
+        if (a < 0) die("negative line length specified\n");
+        if (how != 2) die("can't parse the value of --line-length parameter\n");
+        requested_line_length = a; line_length_is_specified = true; break;
+    case OP_LONG:
+        if (decimal_arg(v, &a) != 2) die("can't parse the value of --long argument\n");
+        if (a < 10) { warn("--long value of is %lld is smaller than the lowest supported value %d, using %d instead\n", a, 10, 10); a = 10; }
+        else if (a > 31) { warn("--long value of is %lld is larger than the largest supported value %d, using %d instead\n", a, 31, 31); a = 31; }
+        long_log = (int)a; break;
+    case OP_OUT: if (out_file_path) die("double --out parameter\n"); if (!*v) die("empty --out parameter\n"); out_file_path = v; break;
+    case OP_IN: set_input_path(v); break;
+    case OP_IN_FORMAT: set_format(v); break;
+    case OP_HELP: show_help(); exit(0);
+    case OP_VERSION: print_version = true; break;
+    case OP_VERBOSE: verbose = true; break;
+    case OP_IGNORED: break;
+    case OP_NO_MASK: no_mask = true; break;
+    case OP_FASTA: set_format("fasta"); break;
+    case OP_FASTQ: set_format("fastq"); break;
+    case OP_SEQ_TYPE: seq_type = arg; break;
+    case OP_WELL_FORMED: well_formed = true; break;
+    case OP_STRICT: strict = true; break;
+    case OP_STDOUT: force_stdout = true; break;
+    }
+}
 static void parse_command_line(int argc, char **argv)
 {
-    bool print_version = false;
     for (int i = 1; i < argc; i++) {
-        if (argv[i][0] == '-') {
-            if (argv[i][1] == '-') {
-                if (i < argc - 1) {
-                    if (!strcmp(argv[i], "--temp-dir")) { i++; if (temp_dir_arg) die("double --temp-dir parameter\n"); if (!*argv[i]) die("empty --temp-dir parameter\n"); temp_dir_arg = argv[i]; continue; }
-                    if (!strcmp(argv[i], "--name")) { i++; if (!*argv[i]) die("empty --name parameter\n"); continue; }
-                    if (!strcmp(argv[i], "--title")) { i++; if (title) die("double --title parameter\n"); if (!*argv[i]) die("empty --title parameter\n"); title = argv[i]; continue; }
-                    if (!strcmp(argv[i], "--level")) { i++; set_level(argv[i]); continue; }
-                    if (!strcmp(argv[i], "--line-length")) { i++; long long a; int how = decimal_arg(argv[i], &a); if (how == 0) die("can't parse the value of --line-length parameter\n"); if (a < 0) die("negative line length specified\n"); if (how != 2) die("can't parse the value of --line-length parameter\n"); requested_line_length = a; line_length_is_specified = true; continue; }
-                    if (!strcmp(argv[i], "--long")) { i++; long long a; if (decimal_arg(argv[i], &a) != 2) die("can't parse the value of --long argument\n");
-                        if (a < 10) { warn("--long value of is %lld is smaller than the lowest supported value %d, using %d instead\n", a, 10, 10); a = 10; }
-                        else if (a > 31) { warn("--long value of is %lld is larger than the largest supported value %d, using %d instead\n", a, 31, 31); a = 31; }
-                        long_log = (int)a;
-                        continue; }
-                    if (!strcmp(argv[i], "--out")) { i++; if (out_file_path) die("double --out parameter\n"); if (!*argv[i]) die("empty --out parameter\n"); out_file_path = argv[i]; continue; }
-                    if (!strcmp(argv[i], "--in")) { i++; if (in_file_path) die("can compress only one file at a time\n"); if (!*argv[i]) die("empty input file name\n"); in_file_path = argv[i]; continue; }
-                    if (!strcmp(argv[i], "--in-format")) { i++; set_format(argv[i]); continue; }
-                }
-                if (!strcmp(argv[i], "--help")) { show_help(); exit(0); }
-                if (!strcmp(argv[i], "--version")) { print_version = true; continue; }
-                if (!strcmp(argv[i], "--verbose")) { verbose = true; continue; }
-                if (!strcmp(argv[i], "--binary-stderr")) continue;
-                if (!strcmp(argv[i], "--keep-temp-files")) continue;
-                if (!strcmp(argv[i], "--no-mask")) { no_mask = true; continue; }
-                if (!strcmp(argv[i], "--fasta")) { set_format("fasta"); continue; }
-                if (!strcmp(argv[i], "--fastq")) { set_format("fastq"); continue; }
-                if (!strcmp(argv[i], "--dna")) { seq_type = NAF_SEQ_DNA; continue; }
-                if (!strcmp(argv[i], "--rna")) { seq_type = NAF_SEQ_RNA; continue; }
-                if (!strcmp(argv[i], "--protein")) { seq_type = NAF_SEQ_PROTEIN; continue; }
-                if (!strcmp(argv[i], "--text")) { seq_type = NAF_SEQ_TEXT; continue; }
-                if (!strcmp(argv[i], "--well-formed")) { well_formed = true; continue; }
-                if (!strcmp(argv[i], "--strict")) { strict = true; continue; }
-            }
-            if (i < argc - 1 && !strcmp(argv[i], "-o")) { i++; if (out_file_path) die("double --out parameter\n"); if (!*argv[i]) die("empty --out parameter\n"); out_file_path = argv[i]; continue; }
-            if (!strcmp(argv[i], "-c")) { force_stdout = true; continue; }
-            if (argv[i][1] >= '0' && argv[i][1] <= '9') { set_level(argv[i] + 1); continue; }
-            if (!strcmp(argv[i], "-h")) { show_help(); exit(0); }
-            if (!strcmp(argv[i], "-V")) { print_version = true; continue; }
-            die("unknown or incomplete argument \"%s\"\n", argv[i]);
-        }
-        if (in_file_path) die("can compress only one file at a time\n");
-        if (!*argv[i]) die("empty input file name\n");
-        in_file_path = argv[i];
+        char *arg = argv[i];
+        if (arg[0] != '-') { set_input_path(arg); continue; }
+        const size_t n_opts = sizeof option_table / sizeof option_table[0];
+        size_t k = 0;
+        while (k < n_opts && !(!strcmp(arg, option_table[k].name) && (!option_table[k].value || i < argc - 1))) k++;
+        if (k < n_opts) { apply_option(option_table[k].op, option_table[k].arg, option_table[k].value ? argv[++i] : NULL); continue; }
+        if (arg[1] >= '0' && arg[1] <= '9') { set_level(arg + 1); continue; }                  /* -#: the level */
+        die("unknown or incomplete argument \"%s\"\n", arg);
     }
     if (print_version) {
         msg("ennaf - NAF compressor, version " VERSION ", " DATE "\nCopyright (c) " COPYRIGHT_YEARS " Kirill Kryukov\n");

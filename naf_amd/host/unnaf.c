@@ -58,28 +58,37 @@ static void parse_command_line(int argc, char **argv)
         {"--total-mask-length", TOTAL_MASK_LENGTH}, {"--4bit", FOUR_BIT}, {"--seq", SEQ}, {"--sequences", SEQUENCES}, {"--charcount", CHARCOUNT},
         {"--fasta", FASTA}, {"--fastq", FASTQ}, {"--dna", DNA}, {"--masked-dna", MASKED_DNA}, {"--unmasked-dna", UNMASKED_DNA},
         {"--masked-fasta", MASKED_FASTA}, {"--unmasked-fasta", UNMASKED_FASTA} };
+    /* the other options (unnaf/src/unnaf.c:282-353), as a table: one that takes a value is only recognised with an argument behind it */
+    enum { OP_LINE_LENGTH, OP_OUT, OP_NO_MASK, OP_IGNORED, OP_HELP, OP_VERBOSE, OP_VERSION, OP_STDOUT };
+    static const struct { const char *name; int op; bool value; } option_table[] = {
+        { "--line-length", OP_LINE_LENGTH, true }, { "-o", OP_OUT, true }, { "--no-mask", OP_NO_MASK, false }, { "--binary-stdout", OP_IGNORED, false },
+        { "--binary-stderr", OP_IGNORED, false }, { "--binary", OP_IGNORED, false }, { "--help", OP_HELP, false }, { "-h", OP_HELP, false },
+        { "--verbose", OP_VERBOSE, false }, { "--version", OP_VERSION, false }, { "-V", OP_VERSION, false }, { "-c", OP_STDOUT, false } };
     for (int i = 1; i < argc; i++) {
-        if (argv[i][0] == '-') {
-            if (argv[i][1] == '-') {
-                if (i < argc - 1 && !strcmp(argv[i], "--line-length")) { i++; set_line_length(argv[i]); continue; }
-                bool hit = false;
-                for (size_t k = 0; k < sizeof types / sizeof types[0]; k++) if (!strcmp(argv[i], types[k].name)) { set_out_type(types[k].t); hit = true; break; }
-                if (hit) continue;
-                if (!strcmp(argv[i], "--no-mask")) { use_mask = false; continue; }
-                if (!strcmp(argv[i], "--binary-stdout") || !strcmp(argv[i], "--binary-stderr") || !strcmp(argv[i], "--binary")) continue;
-                if (!strcmp(argv[i], "--help")) { show_help(); exit(0); }
-                if (!strcmp(argv[i], "--verbose")) { verbose = true; continue; }
-                if (!strcmp(argv[i], "--version")) { print_version = true; continue; }
-            }
-            if (i < argc - 1 && !strcmp(argv[i], "-o")) { i++; if (out_file_path) die("double --out parameter\n"); if (!*argv[i]) die("empty --out parameter\n"); out_file_path = argv[i]; continue; }
-            if (!strcmp(argv[i], "-c")) { force_stdout = true; continue; }
-            if (!strcmp(argv[i], "-h")) { show_help(); exit(0); }
-            if (!strcmp(argv[i], "-V")) { print_version = true; continue; }
-            die("unknown or incomplete argument \"%s\"\n", argv[i]);
+        char *arg = argv[i];
+        if (arg[0] != '-') {
+            if (in_file_path) die("can process only one file at a time\n");
+            if (!*arg) die("empty input path specified\n");
+            in_file_path = arg; continue;
         }
-        if (in_file_path) die("can process only one file at a time\n");
-        if (!*argv[i]) die("empty input path specified\n");
-        in_file_path = argv[i];
+        size_t k = 0;
+        const size_t n_types = sizeof types / sizeof types[0], n_opts = sizeof option_table / sizeof option_table[0];
+        while (k < n_types && strcmp(arg, types[k].name)) k++;
+        if (k < n_types) { set_out_type(types[k].t); continue; }
+        k = 0;
+        while (k < n_opts && !(!strcmp(arg, option_table[k].name) && (!option_table[k].value || i < argc - 1))) k++;
+        if (k == n_opts) die("unknown or incomplete argument \"%s\"\n", arg);
+        char *v = option_table[k].value ? argv[++i] : NULL;
+        switch (option_table[k].op) {
+        case OP_LINE_LENGTH: set_line_length(v); break;
+        case OP_OUT: if (out_file_path) die("double --out parameter\n"); if (!*v) die("empty --out parameter\n"); out_file_path = v; break;
+        case OP_NO_MASK: use_mask = false; break;
+        case OP_IGNORED: break;
+        case OP_HELP: show_help(); exit(0);
+        case OP_VERBOSE: verbose = true; break;
+        case OP_VERSION: print_version = true; break;
+        case OP_STDOUT: force_stdout = true; break;
+        }
     }
     if (print_version) {
         msg("unnaf - NAF decompressor, version " VERSION ", " DATE "\nCopyright (c) " COPYRIGHT_YEARS " Kirill Kryukov\n");
