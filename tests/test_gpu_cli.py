@@ -248,3 +248,31 @@ def test_ennaf_from_a_pipe_of_any_size(oracle, tmp_path):
             assert u.returncode == 0 and u.stdout == want
             if oracle.have_ref():
                 assert oracle.ref_unnaf(naf) == want
+
+
+def test_detached_teardown_is_opt_in_and_dies_with_its_foreground(tmp_path):
+    """NAF_GPU_DETACH=1 (host_common.h: detach_teardown): the foreground process leaves when the output is complete, a worker's device
+    teardown goes on behind it -- same bytes as the one-process default.  The two are one job until then: a SIGTERM to the pid the
+    caller knows reaches the worker (forwarded; PR_SET_PDEATHSIG for a SIGKILL), no orphan finishes the output behind the caller's back."""
+    import signal
+    import time
+    from naf_amd import synth
+    text = synth.fasta_acgt(60_000_000, n_records=7, width=70, seed=5)
+    src = tmp_path / "d.fa"; src.write_bytes(text)
+    one, two = tmp_path / "one.naf", tmp_path / "two.naf"
+    assert subprocess.run([os.path.join(BIN, "ennaf"), str(src), "-o", str(one)], timeout=120).returncode == 0
+    env = dict(os.environ, NAF_GPU_DETACH="1")
+    assert subprocess.run([os.path.join(BIN, "ennaf"), str(src), "-o", str(two)], timeout=120, env=env).returncode == 0
+    assert one.read_bytes() == two.read_bytes()
+    back = subprocess.run([os.path.join(BIN, "unnaf"), str(two), "-c"], stdout=subprocess.PIPE, timeout=120, env=env)
+    assert back.returncode == 0 and back.stdout == text
+    time.sleep(1.0)                                            # (the workers of the runs above are gone)
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        out = tmp_path / ("killed_%d.naf" % sig)
+        p = subprocess.Popen([os.path.join(BIN, "ennaf"), str(src), "-o", str(out)], env=env)
+        time.sleep(0.03)                                       # the device is still being opened
+        p.send_signal(sig)
+        p.wait(timeout=30)
+        assert p.returncode == -sig
+        time.sleep(2.0)
+        assert not out.exists() or out.stat().st_size < len(one.read_bytes()), "a worker finished the output after its foreground process was killed"
