@@ -57,7 +57,7 @@ for ctr, name in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         agg = collections.OrderedDict()
         for r in csv.DictReader(open(fs[0])):
             if r["Counter_Name"] != ctr: continue
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].split("(")[0].replace(",", ";")          # (template arguments: no commas inside a CSV field)
             a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
         for k, (n, v) in agg.items():
             rows.append((label, k, n, v))
