@@ -2349,7 +2349,6 @@ __global__ __launch_bounds__(64) void k_lz_prep(const ZBlock *blk, const u32 *se
 // hops double, ten rounds cover a unit -- until the source leaves the unit, falls into literals, or straddles a boundary.  The moved
 // source is written back as a larger offset; k_lz_deps and k_lz_exec never know.  Chains that cross units keep one link per unit.
 #define LZ_UNIT 1024u
-#define LZ_WIN 32768u                // the LDS window a unit of short sequences is assembled in (k_lz_exec)
 __global__ __launch_bounds__(64) void k_lz_collapse(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A)
 {
     __shared__ u32 s_dst[LZ_UNIT], s_ml[LZ_UNIT], s_src[LZ_UNIT];
@@ -2482,9 +2481,8 @@ __global__ void k_lz_units(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk
     units[t] = b.err ? 0 : (b.nseq + per_unit - 1) / per_unit;
 }
 template <u32 U>
-__global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A, u8 *dst, ZStat *st, u32 win_cap)
+__global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A, u8 *dst, ZStat *st)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 lz_win[];            // win_cap bytes (0: no unit is assembled in LDS)
     __shared__ u32 sh_ticket;
     const u32 lane = threadIdx.x;
     if (lane == 0) sh_ticket = atomicAdd(&st->ticket, 1u);
@@ -2516,145 +2514,6 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
         left += (u32)__popcll(pend[w]);
     }
     u32 idle = 0, seen = 0, unsaid = 0;
-    // ---- a unit of short records, assembled in LDS ------------------------------------------------------------------------------------
-    // Records that copy their neighbours (a FASTQ's read names: a dozen bytes a sequence, each copying the name before it) are chains that
-    // k_lz_collapse shortens but does not remove -- a link wherever a source straddles a literal and a match, a hundred per unit -- and as
-    // dataflow every link is a round trip through memory: 51 ms for the names of 2 GB of reads.  When the unit's whole output fits the
-    // window (win_cap: the launch gives one to frames of short sequences) and three matches of four copy from inside it, the unit is
-    // put together in LDS instead, in order, 64 sequences a step the way k_exec_seq_lds does it -- sources inside the window are LDS
-    // reads, a link costs an LDS round trip; sources in front of it are waited for through their `done` bytes and fetched from memory --
-    // and leaves as one coalesced copy, its `done` bytes set at the end.
-    if (win_cap && left) {
-        u32 ws = 0; bool okw = true;
-        if (s_first) { const u32 pm = A.ml[sbase - 1], pd = A.x_dst[sbase - 1]; okw = pm != 0; ws = pd + pm; }       // where the sequence in front of the unit ends
-        u32 we = 0, n_local = 0;
-#pragma unroll
-        for (u32 w = 0; w < U; w++) {
-            const u32 m = s_ml[w * 64 + lane], d = m ? s_d[w * 64 + lane] : 0, of = m ? s_of[w * 64 + lane] : 0;
-            u32 e = m ? d + m : 0;
-            for (int dd = 32; dd; dd >>= 1) { const u32 o = (u32)__shfl_xor((int)e, dd, 64); e = o > e ? o : e; }
-            we = e > we ? e : we;
-            n_local += (u32)__popcll(__ballot(m && d >= ws && of <= d - ws));
-        }
-        if (okw && we > ws && we - ws <= win_cap && n_local * 4 >= left * 3) {
-            const u32 span = we - ws;
-            u8 *base = out + ws;
-            for (u32 k = lane * 8; k < span; k += 512) { u64 v; __builtin_memcpy(&v, base + k, 8); *(u64 *)(lz_win + k) = v; }      // the literals k_lz_prep placed (and whatever lies where the matches will)
-            __syncthreads();
-            bool bad = false;
-            u32 op = 0;                                                      // window-relative end of the steps done so far
-#pragma unroll
-            for (u32 w = 0; w < U; w++) {
-                if (!pend[w]) continue;
-                const u32 ml = s_ml[w * 64 + lane];
-                const bool valid = ml != 0;
-                const u32 d = valid ? s_d[w * 64 + lane] : 0, of = valid ? s_of[w * 64 + lane] : 0;
-                const u32 dm = valid ? d - ws : 0xFFFFFFFFu;                 // window-relative, ascending with the lane
-                const bool local = valid && of <= d - ws;
-                // sources in front of the window: waited for (their matches' `done` bytes), then fetched -- plain short ones a lane each
-                const bool ext_fast = valid && !local && ml <= 64 && of >= (d - ws) + ml;        // (the whole source in front of the window; one that reaches into it goes in order below)
-                {
-                    bool got = !ext_fast;
-                    for (;;) {
-                        const bool can = !got && ((dn[w] & LZ_DEP_TAIL) ? ld_sc1<u8>(A.stail + dlo[w]) != 0 : lz_deps_done(A.sdone, dlo[w], dn[w] & ~LZ_DEP_TAIL));
-                        if (__ballot(can)) asm volatile("" ::: "memory");
-                        if (can) {
-                            const u8 *from = out + d - of;                   // (may lie in front of the block: the frame's buffer is one)
-                            for (u32 k = 0; k < ml; k += 8) {
-                                const u64 v = ld_sc1<u64>(from + k);
-                                const u32 nb = ml - k < 8 ? ml - k : 8;
-                                for (u32 q = 0; q < nb; q++) lz_win[dm + k + q] = (u8)(v >> (8 * q));
-                            }
-                            got = true;
-                        }
-                        if (!__ballot(!got)) break;
-                        if (!__ballot(can)) {
-                            __builtin_amdgcn_s_sleep(2);
-                            if (++idle >= (1u << 18)) {
-                                const u32 now = ld_sc1<u32>(&st->n_exec_done);
-                                if (ld_sc1<u32>(&st->err) || now == seen) { bad = true; break; }
-                                seen = now; idle = 0;
-                            }
-                        } else idle = 0;
-                    }
-                    if (bad) break;
-                }
-                __syncthreads();
-                // sources inside the window: moved back through the plain matches of the step that contain them (k_exec_seq_lds), the final ones copied side by side
-                const bool plain = local && of >= ml && of != 0;
-                u32 src = plain ? dm - of : 0;
-                for (int round = 0; round < 7; round++) {
-                    const bool need = plain && src + ml > op;
-                    if (!__ballot(need)) break;
-                    u32 c2 = 0;
-#pragma unroll
-                    for (u32 bit = 32; bit; bit >>= 1) { const u32 cand = c2 + bit; const u32 dc = (u32)__shfl((int)dm, (int)(cand - 1) & 63, 64); if (need && dc <= src) c2 = cand; }
-                    const int i = (int)c2 - 1;
-                    const u32 di = (u32)__shfl((int)dm, i & 63, 64), mli = (u32)__shfl((int)ml, i & 63, 64), si = (u32)__shfl((int)src, i & 63, 64);
-                    const bool pi = __shfl((int)plain, i & 63, 64) != 0;
-                    const bool hop = need && i >= 0 && (u32)i < lane && pi && src + ml <= di + mli;
-                    if (!__ballot(hop)) break;
-                    if (hop) src = si + (src - di);
-                }
-                bool fin = plain && src + ml <= op;
-                {
-                    const bool need = plain && !fin;
-                    u32 c2 = 0;
-#pragma unroll
-                    for (u32 bit = 32; bit; bit >>= 1) { const u32 cand = c2 + bit; const u32 dc = (u32)__shfl((int)dm, (int)(cand - 1) & 63, 64); if (need && dc <= src) c2 = cand; }
-                    const int i = (int)c2 - 1;
-                    const u32 di = (u32)__shfl((int)dm, i & 63, 64), mli = (u32)__shfl((int)ml, i & 63, 64), dnext = (u32)__shfl((int)dm, (i + 1) & 63, 64);
-                    const u32 next_start = i + 1 < 64 ? dnext : 0xFFFFFFFFu;
-                    if (need) fin = (i < 0 || src >= di + mli) && src + ml <= next_start;
-                }
-                if (fin && ml <= 64) for (u32 k = 0; k < ml; k++) lz_win[dm + k] = lz_win[src + k];
-                for (u64 bigm = __ballot(fin && ml > 64); bigm; bigm &= bigm - 1) {
-                    const int j = __ffsll((long long)bigm) - 1;
-                    const u32 dj = (u32)__builtin_amdgcn_readlane((int)dm, j), mlj = (u32)__builtin_amdgcn_readlane((int)ml, j), sj = (u32)__builtin_amdgcn_readlane((int)src, j);
-                    for (u32 k = lane; k < mlj; k += 64) lz_win[dj + k] = lz_win[sj + k];
-                }
-                __syncthreads();
-                // the rest in order, the wavefront on one at a time: a byte of the source comes from the window or, in front of it, from memory
-                for (u64 todo = __ballot(valid && !fin && !ext_fast); todo; todo &= todo - 1) {
-                    const int j = __ffsll((long long)todo) - 1;
-                    const u32 dj = (u32)__builtin_amdgcn_readlane((int)d, j), mlj = (u32)__builtin_amdgcn_readlane((int)ml, j), ofj = (u32)__builtin_amdgcn_readlane((int)of, j);
-                    const u32 lo_j = (u32)__builtin_amdgcn_readlane((int)dlo[w], j), n_j = (u32)__builtin_amdgcn_readlane((int)dn[w], j);
-                    if (ofj > dj - ws) {                                      // reaches in front of the window: its writers first
-                        for (;;) {
-                            if ((n_j & LZ_DEP_TAIL) ? ld_sc1<u8>(A.stail + lo_j) != 0 : lz_deps_done(A.sdone, lo_j, n_j & ~LZ_DEP_TAIL)) break;
-                            __builtin_amdgcn_s_sleep(2);
-                            if (++idle >= (1u << 18)) {
-                                const u32 now = ld_sc1<u32>(&st->n_exec_done);
-                                if (ld_sc1<u32>(&st->err) || now == seen) { bad = true; break; }
-                                seen = now; idle = 0;
-                            }
-                        }
-                        if (bad) break;
-                        idle = 0;
-                        asm volatile("" ::: "memory");
-                    }
-                    const u32 outside = ofj > dj - ws ? ofj - (dj - ws) : 0;        // bytes of the pattern that lie in front of the window
-                    const u8 *from = out + dj - ofj;
-                    for (u32 k = lane; k < mlj; k += 64) {
-                        const u32 r = ofj >= mlj ? k : k % ofj;
-                        lz_win[dj - ws + k] = r < outside ? ld_sc1<u8>(from + r) : lz_win[dj - ws - ofj + r];
-                    }
-                    __syncthreads();
-                }
-                if (bad) break;
-                { u32 e = valid ? dm + ml : 0; for (int dd = 32; dd; dd >>= 1) { const u32 o = (u32)__shfl_xor((int)e, dd, 64); e = o > e ? o : e; } op = e > op ? e : op; }
-            }
-            if (bad) { if (lane == 0) set_err(st, ZE_CORRUPT); return; }
-            __syncthreads();
-            for (u32 k = lane * 8; k + 8 <= span; k += 512) st_sc1<u64>(base + k, *(const u64 *)(lz_win + k));
-            if (lane < (span & 7u)) st_sc1<u8>(base + (span & ~7u) + lane, lz_win[(span & ~7u) + lane]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (u32 w = 0; w < U; w++) if ((pend[w] >> lane) & 1) { st_sc1<u8>(A.sdone + sbase + w * 64 + lane, (u8)1); st_sc1<u8>(A.stail + sbase + w * 64 + lane, (u8)1); }
-            if (lane == 0) __hip_atomic_fetch_add(&st->n_exec_done, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-    }
     while (left) {
         u64 rdy[U]; u64 any = 0;
         // the first `done` byte of everything pending, all loads in flight together (a word at a time they were U round trips in a row: the
@@ -2753,7 +2612,7 @@ __global__ void k_lz_stats(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk
 
 // The sequences of blocks seq_list[0 .. nx) executed: as dataflow (above), or in block order (EXEC=batch / =serial: the cross-checks; frames
 // of more than 2^32 sequences).  `done` / `prog`: per-block arrays of the block-ordered executors.
-static int launch_lz_exec(naf_gpu_ctx *c, const ZBlock *blk, const u32 *seq_list, u32 nx, const u64 *offs, const u64 *seq_cnt, u32 nblk, u64 ns_total, u64 total_out,
+static int launch_lz_exec(naf_gpu_ctx *c, const ZBlock *blk, const u32 *seq_list, u32 nx, const u64 *offs, const u64 *seq_cnt, u32 nblk, u64 ns_total,
                           u32 *o_ll, u32 *o_ml, u32 *o_of, const u8 *lits, u8 *d_dst, u32 *done, ZStat *st)
 {
     const char *how = ctx_opt(c, "EXEC");
@@ -2794,11 +2653,7 @@ static int launch_lz_exec(naf_gpu_ctx *c, const ZBlock *blk, const u32 *seq_list
             else ctx_trace(c, "[lz]   block %d seq %2d: lands at %6u length %6u offset %7u, source written by %u match(es) from %u sequences back%s\n", k / 16, k % 16, hs.first[k][0], hs.first[k][1], hs.first[k][2], (v >> 20) & 255, v & 0xFFFFF, (v & LZ_DEP_TAIL) ? " (their tail)" : "");
         }
     }
-    // frames of short sequences (a FASTQ's read names, a mask's run lengths: a unit's output is a few KB) get a window to assemble units in
-    u32 win = 0;
-    { const char *we = ctx_opt(c, "EXEC_WINDOW");                            // "0": never, "1": always (cross-checks)
-      if ((we && we[0]) ? we[0] == '1' : (total_out && ns_total && total_out / ns_total <= 24)) win = LZ_WIN; }
-    LAUNCH(c, "zstd_exec_seq", k_lz_exec<LZ_UNIT / 64>, grid, 64, win, blk, seq_list, nx, (const u64 *)units, (const u64 *)(units + nx + 1), A, d_dst, st, win);
+    LAUNCH(c, "zstd_exec_seq", k_lz_exec<LZ_UNIT / 64>, grid, 64, 0, blk, seq_list, nx, (const u64 *)units, (const u64 *)(units + nx + 1), A, d_dst, st);
     return 0;
 }
 
@@ -3596,7 +3451,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     if (hs0.max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
                         LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, n_seq_blk, 64, ((hs0.max_seq_regen + 1023u) & ~1023u) + 64u, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
                                (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lits, d_dst, done2, st, (hs0.max_seq_regen + 1023u) & ~1023u);
-                    else { const int rcx = launch_lz_exec(c, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, (const u64 *)seq_cnt, nblk, ns_all, hs0.total_out, o_ll, o_ml, o_of, (const u8 *)lits, d_dst, done2, st); if (rcx) return rcx; }
+                    else { const int rcx = launch_lz_exec(c, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, (const u64 *)seq_cnt, nblk, ns_all, o_ll, o_ml, o_of, (const u8 *)lits, d_dst, done2, st); if (rcx) return rcx; }
                     return 0;
                 });
                 zf->src = d_src; zf->si = si; zf->nslots = 4ull * nblk; zf->sym = d_sym; zf->status = st; zf->ready = true;
@@ -3753,7 +3608,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         if (max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
             LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, nx, 64, ((max_seq_regen + 1023u) & ~1023u) + 64u, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, nblk,
                    (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st, (max_seq_regen + 1023u) & ~1023u);
-        else if ((rc = launch_lz_exec(c, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, (const u64 *)seq_cnt, nblk, hs.total_seq, hs.total_out, o_ll, o_ml, o_of, (const u8 *)lit_scratch, d_dst, done, st))) return rc;
+        else if ((rc = launch_lz_exec(c, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, (const u64 *)seq_cnt, nblk, hs.total_seq, o_ll, o_ml, o_of, (const u8 *)lit_scratch, d_dst, done, st))) return rc;
     }
     if (c->zsplit && c->zsplit->done) { c->zsplit->status = st; return 0; }      // the caller checks the status once the emit is queued (zstd_split_status)
     rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;

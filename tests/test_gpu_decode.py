@@ -29,19 +29,16 @@ def host(t):
     return t.cpu().numpy().tobytes()
 
 
-@pytest.mark.parametrize("executor", ["auto", "hbm", "hbm-nocollapse", "hbm-window", "batch", "serial"])
+@pytest.mark.parametrize("executor", ["auto", "hbm", "hbm-nocollapse", "batch", "serial"])
 @pytest.mark.parametrize("case", zstd_cases(), ids=lambda c: c["name"])
 def test_zstd_decode_golden_frames(gpu, case, executor, monkeypatch):
     """libzstd-made frames (every level, long windows, multi-threaded, streaming): frames whose blocks regenerate at most 16 KiB
     run their sequences in the LDS executor, the others as dataflow (k_lz_prep / _deps / _exec); "hbm" forces the latter for every
-    frame, "hbm-nocollapse" without the move of sources back along chains of copies (k_lz_collapse), "hbm-window" with every unit that
-    fits assembled in the LDS window (what frames of short sequences get), "batch" and "serial" the two block-ordered executors kept as
+    frame, "hbm-nocollapse" without the move of sources back along chains of copies (k_lz_collapse), "batch" and "serial" the two block-ordered executors kept as
     cross-checks."""
     monkeypatch.setenv("NAF_GPU_EXEC_LDS", "1" if executor == "auto" else "0")
     if executor == "hbm-nocollapse":
         monkeypatch.setenv("NAF_GPU_EXEC_COLLAPSE", "0")
-    if executor == "hbm-window":
-        monkeypatch.setenv("NAF_GPU_EXEC_WINDOW", "1")
     if executor in ("batch", "serial"):
         monkeypatch.setenv("NAF_GPU_EXEC", executor)
     frame = golden_bytes("zstd", case["name"] + ".zst")
@@ -1036,14 +1033,13 @@ def test_reference_archive_of_a_repeat_rich_genome_under_every_executor(gpu, ora
     want = O.ref_unnaf(naf)
     assert want == text
     d_naf = gpu.to_device(naf)
-    for how, collapse in (("dataflow", "1"), ("dataflow", "0"), ("window", "1"), ("batch", "1"), ("serial", "1")):
+    for how, collapse in (("dataflow", "1"), ("dataflow", "0"), ("batch", "1"), ("serial", "1")):
         monkeypatch.setenv("NAF_GPU_EXEC", how); monkeypatch.setenv("NAF_GPU_EXEC_COLLAPSE", collapse); monkeypatch.setenv("NAF_GPU_EXEC_LDS", "0")
-        monkeypatch.setenv("NAF_GPU_EXEC_WINDOW", "1" if how == "window" else "")
         assert host(gpu.unnaf(d_naf, capi.OUT_FASTA)) == want, (flags, how, collapse)
         # a byte range of it: the range's dependency closure through the same executor
         b, e = len(want) // 3, len(want) // 3 + 1_000_003
         assert host(gpu.unnaf_range(d_naf, b, e, capi.OUT_FASTA)) == want[b:e], (flags, how, collapse)
-    monkeypatch.delenv("NAF_GPU_EXEC"); monkeypatch.delenv("NAF_GPU_EXEC_COLLAPSE"); monkeypatch.delenv("NAF_GPU_EXEC_LDS"); monkeypatch.delenv("NAF_GPU_EXEC_WINDOW")
+    monkeypatch.delenv("NAF_GPU_EXEC"); monkeypatch.delenv("NAF_GPU_EXEC_COLLAPSE"); monkeypatch.delenv("NAF_GPU_EXEC_LDS")
     # this build's own archives at the levels that match across blocks, through the same executors (16 KiB blocks: the LDS executor by default)
     for level, long_log in ((19, 0), (3, 27)):
         mine, _ = gpu.ennaf(gpu.to_device(text), level=level, long_log=long_log)
@@ -1065,9 +1061,9 @@ def test_reference_archive_of_reads_whose_names_copy_each_other(gpu, oracle, mon
     naf = O.ref_ennaf(text, ("--fastq",))
     want = O.ref_unnaf(naf)
     d_naf = gpu.to_device(naf)
-    for how, collapse, window in (("dataflow", "1", ""), ("dataflow", "0", "1"), ("dataflow", "1", "0"), ("dataflow", "0", "0"), ("batch", "1", "")):
-        monkeypatch.setenv("NAF_GPU_EXEC", how); monkeypatch.setenv("NAF_GPU_EXEC_COLLAPSE", collapse); monkeypatch.setenv("NAF_GPU_EXEC_WINDOW", window)
-        assert host(gpu.unnaf(d_naf, capi.OUT_FASTQ)) == want, (how, collapse, window)
+    for how, collapse in (("dataflow", "1"), ("dataflow", "0"), ("batch", "1")):
+        monkeypatch.setenv("NAF_GPU_EXEC", how); monkeypatch.setenv("NAF_GPU_EXEC_COLLAPSE", collapse)
+        assert host(gpu.unnaf(d_naf, capi.OUT_FASTQ)) == want, (how, collapse)
         for mode, args in ((capi.OUT_FASTA, ("--fasta",)),):
-            assert host(gpu.unnaf(d_naf, mode)) == O.ref_unnaf(naf, args), (how, collapse, window, mode)
-    monkeypatch.delenv("NAF_GPU_EXEC"); monkeypatch.delenv("NAF_GPU_EXEC_COLLAPSE"); monkeypatch.delenv("NAF_GPU_EXEC_WINDOW")
+            assert host(gpu.unnaf(d_naf, mode)) == O.ref_unnaf(naf, args), (how, collapse, mode)
+    monkeypatch.delenv("NAF_GPU_EXEC"); monkeypatch.delenv("NAF_GPU_EXEC_COLLAPSE")
