@@ -373,7 +373,7 @@ def weighted_sum(t, offset):
     return tot
 
 
-def realistic_vs_reference(ctx, text_dev, size_bytes):
+def realistic_vs_reference(ctx, text_dev, size_bytes, out_mode=None, fold_case=False):
     """The realistic genome against the real reference on a bounded sample: the reference's archive of the sample decoded by the GPU
     (bit-exact, timed, per kernel) and by the reference itself (one thread), and the GPU's archive of the sample decoded by the
     reference (the drop-in direction)."""
@@ -385,6 +385,12 @@ def realistic_vs_reference(ctx, text_dev, size_bytes):
     P = lambda name: os.path.join(shm, name)
     try:
         cut = last_line_end(text_dev[:size_bytes])
+        if fold_case:
+            # FASTQ: the sample ends with a whole record -- in front of the last line that starts a record ("\n@read")
+            w = min(cut, 8192)
+            tail = text_dev[cut - w:cut].cpu().numpy().tobytes()
+            k = tail.rfind(b"\n@read")
+            cut = cut - w + k + 1
         sample = text_dev[:cut]
         sample.cpu().numpy().tofile(P("r.fa"))
         env = dict(os.environ, TMPDIR=shm)
@@ -392,15 +398,19 @@ def realistic_vs_reference(ctx, text_dev, size_bytes):
         t0 = time.perf_counter(); subprocess.check_call([REF_U, P("r.naf"), "-o", P("r.out")]); t_u = time.perf_counter() - t0
         ref_naf = torch.from_numpy(np.fromfile(P("r.naf"), dtype=np.uint8)).to(text_dev.device)
         buf = torch.empty(cut + 64, dtype=torch.uint8, device=text_dev.device)
-        r = ctx.unnaf(ref_naf, capi.OUT_FASTA, out=buf); torch.cuda.synchronize()
-        ok = bool(torch.equal(r, sample))
-        ts = timed_calls(lambda: ctx.unnaf(ref_naf, capi.OUT_FASTA, out=buf), 10)
+        mode = capi.OUT_FASTA if out_mode is None else out_mode
+        r = ctx.unnaf(ref_naf, mode, out=buf); torch.cuda.synchronize()
+        # the reference's own output of its archive is what "bit exact" means (FASTQ comes back with upper-case bases: unnaf.c:442)
+        want = torch.from_numpy(np.fromfile(P("r.out"), dtype=np.uint8)).to(text_dev.device)
+        ok = bool(torch.equal(r, want))
+        del want
+        ts = timed_calls(lambda: ctx.unnaf(ref_naf, mode, out=buf), 10)
         dt = median(ts)
-        kt, _all, streams = instrumented(ctx, lambda: ctx.unnaf(ref_naf, capi.OUT_FASTA, out=buf))
+        kt, _all, streams = instrumented(ctx, lambda: ctx.unnaf(ref_naf, mode, out=buf))
         mine, _rep = ctx.ennaf(sample)
         mine.cpu().numpy().tofile(P("m.naf"))
         subprocess.check_call([REF_U, P("m.naf"), "-o", P("m.out")])
-        drop_in = subprocess.call(["cmp", "-s", P("r.fa"), P("m.out")]) == 0
+        drop_in = subprocess.call(["cmp", "-s", P("r.out") if fold_case else P("r.fa"), P("m.out")]) == 0
         return {"reference_sample": {"text_bytes": int(cut), "reference_archive_bytes": int(ref_naf.numel()), "gpu_archive_bytes": int(mine.numel()),
                                      "reference_unnaf_value": round(cut / t_u / 1e9, 3), "reference_ennaf_value": round(cut / t_e / 1e9, 3),
                                      "gpu_unnaf_of_reference_archive": {"value": round(cut / dt / 1e9, 2), "ms": round(dt * 1e3, 3), "calls": stats_ms(ts), "bit_exact": ok,
@@ -882,6 +892,9 @@ def main():
             fq = synth.fastq_reads_device(int(args.fastq1_size), seed=7, device=dev)
             ctx.reserve(int(fq.numel() * 1.7) + (2 << 30))
             extra["fastq"], _ = side_workload(ctx, fq, capi.OUT_FASTQ, "FASTQ, 150-base reads `@readN len=150`, ACGT 0.22 each / acgt 0.025 each / N 0.02, quality uniform Phred 0-40 (SURVEY 8(d) cfg5 generator)", fold_case=True)
+            if have_ref() and not args.no_cpu:
+                # the reference's archive of a sample of it decoded here (libzstd's frames: names that copy each other, runs of "len=150")
+                extra["fastq"].update(realistic_vs_reference(ctx, fq, int(min(args.cpu_sample / 2, fq.numel())), out_mode=capi.OUT_FASTQ, fold_case=True))
             del fq, _
             torch.cuda.synchronize(); ctx.release_scratch(); torch.cuda.empty_cache()
         if args.levels_size > 0 and have_ref() and not args.no_cpu:
@@ -893,6 +906,11 @@ def main():
                              "fastq_roundtrip_ok_case_folded": g("fastq", "roundtrip_ok_case_folded"),
                              "realistic_unnaf_gbps": g("realistic", "unnaf_value"), "realistic_ennaf_gbps": g("realistic", "ennaf_value"),
                              "softmasked_unnaf_gbps": g("softmasked", "unnaf_value"), "softmasked_ennaf_gbps": g("softmasked", "ennaf_value")})
+            for wl in ("fastq", "realistic"):
+                rs = (extra.get(wl) or {}).get("reference_sample") or {}
+                ga = rs.get("gpu_unnaf_of_reference_archive") or {}
+                roofline.update({wl + "_ref_archive_gbps": ga.get("value"), wl + "_ref_archive_bit_exact": ga.get("bit_exact"), wl + "_ref_archive_ref_unnaf_gbps": rs.get("reference_unnaf_value"),
+                                 wl + "_ref_decodes_gpu_archive": rs.get("reference_unnaf_of_gpu_archive_bit_exact")})
             lv = extra.get("levels") or {}
             for k in ("lvl19_ennaf_gbps", "lvl19_ratio_vs_ref", "lvl19_ref_decodes", "lvl19_ref_ennaf_gbps", "long27_ennaf_gbps", "long27_ratio_vs_ref", "long27_ref_decodes", "long27_ref_ennaf_gbps",
                       "long27_ref_archive_unnaf_gbps", "long27_ref_archive_bit_exact", "long27_ref_archive_ref_unnaf_gbps"):
