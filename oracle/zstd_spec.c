@@ -13,6 +13,11 @@
 #include "naf_oracle.h"
 #include <string.h>
 #include <stdlib.h>
+#include <stdio.h>
+/* test aid: NAF_ORACLE_SEQ_DUMP=<path> appends "match position, literal length, match length, offset" of every sequence decoded */
+static FILE *seq_dump = NULL;
+static void seq_dump_open(void) { static int tried = 0; if (!tried) { tried = 1; const char *pth = getenv("NAF_ORACLE_SEQ_DUMP"); if (pth) seq_dump = fopen(pth, "a"); } }
+
 
 #define ERR_SRC   (-1)   /* truncated / malformed source */
 #define ERR_DST   (-2)   /* destination too small */
@@ -340,6 +345,7 @@ static long long decode_compressed_block(frame_ctx *c, const uint8_t *src, size_
         if (op + ll + ml > room) return ERR_DST;
         if (op + ll + ml > MAX_BLOCK) return ERR_CORR;
         memcpy(out + op, lits + lp, ll); op += ll; lp += ll;
+        if (seq_dump) fprintf(seq_dump, "%llu %llu %llu %llu\n", (unsigned long long)(dst_pos + op), (unsigned long long)ll, (unsigned long long)ml, (unsigned long long)off);
         if (off > dst_pos + op - frame_start) return ERR_CORR;
         if (c->info && off > c->info->max_offset) c->info->max_offset = off;
         for (uint64_t k = 0; k < ml; k++) { out[op] = out[op - off]; op++; }
@@ -355,6 +361,7 @@ static long long decode_compressed_block(frame_ctx *c, const uint8_t *src, size_
 static long long decode_frame(const uint8_t *src, size_t len, uint8_t *dst, size_t dst_pos, size_t dst_cap,
                               size_t *consumed, nafo_zstd_frame_info *info)
 {
+    seq_dump_open();
     if (len < 4) return ERR_SRC;
     uint32_t magic = src[0] | (src[1] << 8) | (src[2] << 16) | ((uint32_t)src[3] << 24);
     if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {                /* skippable frame */
