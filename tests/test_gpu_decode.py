@@ -1067,3 +1067,47 @@ def test_reference_archive_of_reads_whose_names_copy_each_other(gpu, oracle, mon
         for mode, args in ((capi.OUT_FASTA, ("--fasta",)),):
             assert host(gpu.unnaf(d_naf, mode)) == O.ref_unnaf(naf, args), (how, collapse, mode)
     monkeypatch.delenv("NAF_GPU_EXEC"); monkeypatch.delenv("NAF_GPU_EXEC_COLLAPSE")
+
+
+def test_reference_archives_of_structured_texts_at_every_level(gpu, oracle):
+    """The sequence executors against libzstd's own frames beyond the golden set: texts with repeats at every distance (units copied with a
+    few substitutions, tandem runs, long runs of one base, records with counting names), packed by the real `ennaf` at levels 1 ... 22 with
+    and without `--long`, FASTA and FASTQ -- the HIP decoder must return what the real `unnaf` returns, whole and by byte range."""
+    from naf_amd import capi, synth
+    O = oracle
+    if not O.have_ref():
+        pytest.skip("needs oracle/_ref")
+    rng = np.random.default_rng(2025)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def genome(n):
+        parts, made = [], 0
+        units = [acgt[rng.integers(0, 4, int(rng.integers(50, 5000)))] for _ in range(12)]
+        while made < n:
+            k = int(rng.integers(0, 4))
+            if k == 0:
+                p = acgt[rng.integers(0, 4, int(rng.integers(10, 3000)))]
+            elif k == 1:
+                p = units[int(rng.integers(0, len(units)))].copy(); idx = rng.integers(0, len(p), max(1, len(p) // 40)); p[idx] = acgt[rng.integers(0, 4, len(idx))]
+            elif k == 2:
+                u = acgt[rng.integers(0, 4, int(rng.integers(1, 9)))]; p = np.tile(u, int(rng.integers(5, 4000)))
+            else:
+                p = np.full(int(rng.integers(100, 70000)), acgt[int(rng.integers(0, 4))], dtype=np.uint8)
+            parts.append(p); made += len(p)
+        return np.concatenate(parts)[:n]
+
+    cases = []
+    for i, (n, width) in enumerate(((700_000, 60), (2_500_000, 80), (300_000, 0))):
+        g = genome(n)
+        recs = [b">rec%d part %d\n" % (j, i) + synth.wrap_lines(g[a:b], width) for j, (a, b) in enumerate(zip(range(0, n, n // 7 + 1), list(range(n // 7 + 1, n, n // 7 + 1)) + [n]))]
+        cases.append((b"".join(recs), ()))
+    cases.append((synth.fastq_reads(30_000, 90, seed=8) + synth.fastq_reads(2_000, 140, seed=9, var_len=True), ("--fastq",)))
+    for text, fmt in cases:
+        for flags in (("--level", "1"), ("--level", "3"), ("--level", "9", "--long", "20"), ("--level", "19"), ("--level", "22", "--long", "27"), ("--level", "5", "--long", "12")):
+            naf = O.ref_ennaf(text, fmt + flags)
+            want = O.ref_unnaf(naf)
+            d_naf = gpu.to_device(naf)
+            got = host(gpu.unnaf(d_naf))
+            assert got == want, (len(text), fmt, flags)
+            b, e = len(want) // 5, len(want) // 5 + 300_001
+            assert host(gpu.unnaf_range(d_naf, b, min(e, len(want)))) == want[b:e], (len(text), fmt, flags, "range")
