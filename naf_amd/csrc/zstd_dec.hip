@@ -2349,58 +2349,48 @@ __global__ __launch_bounds__(64) void k_lz_prep(const ZBlock *blk, const u32 *se
 // hops double, ten rounds cover a unit -- until the source leaves the unit, falls into literals, or straddles a boundary.  The moved
 // source is written back as a larger offset; k_lz_deps and k_lz_exec never know.  Chains that cross units keep one link per unit.
 #define LZ_UNIT 1024u
-__global__ __launch_bounds__(64) void k_lz_collapse(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A)
+// (the collapse has units of its own: 8192 sequences -- 96 KB of LDS, a workgroup of 256 per CU -- because what it leaves is a link per unit
+// edge, and a frame that is one chain, a counter's names through every block, is then as long as its unit edges are many)
+#define LZ_CUNIT 8192u
+__global__ __launch_bounds__(256) void k_lz_collapse(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A)
 {
-    __shared__ u32 s_dst[LZ_UNIT], s_ml[LZ_UNIT], s_src[LZ_UNIT];
-    const u32 lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) u32 lzc[];              // s_dst | s_ml | s_src, LZ_CUNIT each
+    u32 *s_dst = lzc, *s_ml = lzc + LZ_CUNIT, *s_src = lzc + 2 * LZ_CUNIT;
     const u64 u = blockIdx.x;
     if (u >= *n_units) return;
     u32 t = 0;
     { u32 hi = n_seq_blk; while (t + 1 < hi) { const u32 mid = (t + hi) >> 1; if (unit_base[mid] <= u) t = mid; else hi = mid; } }
     const ZBlock &b = blk[seq_list[t]];
-    const u32 s_first = (u32)(u - unit_base[t]) * LZ_UNIT, nseq = b.err ? 0 : b.nseq;
+    const u32 s_first = (u32)(u - unit_base[t]) * LZ_CUNIT, nseq = b.err ? 0 : b.nseq;
     if (s_first >= nseq) return;
-    const u32 cnt = nseq - s_first < LZ_UNIT ? nseq - s_first : LZ_UNIT;
+    const u32 cnt = nseq - s_first < LZ_CUNIT ? nseq - s_first : LZ_CUNIT;
     const u64 sbase = b.seq_base + s_first;
-    u32 my_ml[LZ_UNIT / 64];
-#pragma unroll
-    for (u32 k = 0; k < LZ_UNIT / 64; k++) {
-        const u32 idx = k * 64 + lane;
-        u32 d = 0xFFFFFFFFu, ml = 0, of = 0;
-        if (idx < cnt) { d = A.x_dst[sbase + idx]; ml = A.ml[sbase + idx]; of = A.of[sbase + idx]; }
+    for (u32 idx = threadIdx.x; idx < cnt; idx += 256) {
+        const u32 d = A.x_dst[sbase + idx], ml = A.ml[sbase + idx], of = A.of[sbase + idx];
         const bool plain = ml && of >= ml && of <= d;                            // a copy of bytes of this block that do not overlap it
-        my_ml[k] = plain ? ml : 0;
         s_dst[idx] = d; s_ml[idx] = plain ? ml : 0; s_src[idx] = plain ? d - of : 0xFFFFFFFFu;
     }
     __syncthreads();
     const u32 first_dst = s_dst[0];
     bool moved_any = false;
-    for (int round = 0; round < 11; round++) {
-        u32 nsrc[LZ_UNIT / 64]; bool hop = false;
-#pragma unroll
-        for (u32 k = 0; k < LZ_UNIT / 64; k++) {
-            const u32 idx = k * 64 + lane;
-            const u32 s = idx < cnt && my_ml[k] ? s_src[idx] : 0xFFFFFFFFu;
-            nsrc[k] = s;
-            if (s == 0xFFFFFFFFu || s < first_dst) continue;                     // not a plain copy, or a source in front of the unit
+    // (a lane writes only its own sources and may read another's while it moves: either value names the same bytes)
+    for (int round = 0; round < 16; round++) {
+        bool hop = false;
+        for (u32 idx = threadIdx.x; idx < cnt; idx += 256) {
+            const u32 ml = s_ml[idx], s = s_src[idx];
+            if (!ml || s == 0xFFFFFFFFu || s < first_dst) continue;              // not a plain copy, or a source in front of the unit
             u32 lo = 0, hi = idx;                                                // the last sequence j < idx whose match starts at or in front of s
             while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (s_dst[mid] <= s) lo = mid + 1; else hi = mid; }
             if (!lo) continue;
             const u32 j = lo - 1, dj = s_dst[j], mlj = s_ml[j], sj = s_src[j];
-            if (mlj && sj != 0xFFFFFFFFu && s + my_ml[k] <= dj + mlj) { nsrc[k] = sj + (s - dj); hop = true; }
+            if (mlj && sj != 0xFFFFFFFFu && s + ml <= dj + mlj) { s_src[idx] = sj + (s - dj); hop = true; }
         }
-        if (!__ballot(hop)) break;
+        if (!__syncthreads_or(hop)) break;
         moved_any = true;
-        __syncthreads();
-#pragma unroll
-        for (u32 k = 0; k < LZ_UNIT / 64; k++) { const u32 idx = k * 64 + lane; if (idx < cnt && my_ml[k]) s_src[idx] = nsrc[k]; }
-        __syncthreads();
     }
     if (!moved_any) return;
-#pragma unroll
-    for (u32 k = 0; k < LZ_UNIT / 64; k++) { const u32 idx = k * 64 + lane; if (idx < cnt && my_ml[k]) A.of[sbase + idx] = s_dst[idx] - s_src[idx]; }
+    for (u32 idx = threadIdx.x; idx < cnt; idx += 256) if (s_ml[idx]) A.of[sbase + idx] = s_dst[idx] - s_src[idx];
 }
-
 // first j in [0, n) with x_dst[j] + ml[j] > rel (match ends are increasing; padding entries: 0xFFFFFFFF + 0)
 __device__ __forceinline__ u32 lz_first_end_after(const u32 *x, const u32 *m, u32 n, u32 rel)
 {
@@ -2632,13 +2622,18 @@ static int launch_lz_exec(naf_gpu_ctx *c, const ZBlock *blk, const u32 *seq_list
     A.stail = A.sdone + ns_total + 16;
     HIP_TRY(c, hipMemsetAsync(A.sdone, 1, 2 * (ns_total + 16), c->stream));
     LAUNCH(c, "zstd_lz_prep", k_lz_prep, nx, 64, 0, blk, seq_list, nx, seq_cnt, nblk, ns_total, A, lits, d_dst, st);
-    // units of 1024 sequences in frame order (k_lz_collapse's and k_lz_exec's)
-    u64 *units = arena_new<u64>(c, (size_t)nx + 2); if (!units) return NAF_GPU_ENOMEM;
+    // units of 1024 sequences in frame order (k_lz_exec's), of 8192 (k_lz_collapse's)
+    u64 *units = arena_new<u64>(c, 2 * ((size_t)nx + 2)); if (!units) return NAF_GPU_ENOMEM;
+    u64 *cunits = units + nx + 2;
     LAUNCH(c, "zstd_lz_units", k_lz_units, cdiv(nx, 256), 256, 0, blk, seq_list, nx, LZ_UNIT, units);
     int rc = scan_exclusive_u64(c, units, nx, units + nx + 1); if (rc) return rc;
     const u32 grid = (u32)(ns_total / LZ_UNIT + nx + 1);                     // (an upper bound known without a read-back: wavefronts behind the last unit leave at once)
-    if (!ctx_opt_is(c, "EXEC_COLLAPSE", '0'))
-        LAUNCH(c, "zstd_lz_collapse", k_lz_collapse, grid, 64, 0, blk, seq_list, nx, (const u64 *)units, (const u64 *)(units + nx + 1), A);
+    if (!ctx_opt_is(c, "EXEC_COLLAPSE", '0')) {
+        LAUNCH(c, "zstd_lz_units", k_lz_units, cdiv(nx, 256), 256, 0, blk, seq_list, nx, LZ_CUNIT, cunits);
+        if ((rc = scan_exclusive_u64(c, cunits, nx, cunits + nx + 1))) return rc;
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k_lz_collapse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * LZ_CUNIT * 4)));
+        LAUNCH(c, "zstd_lz_collapse", k_lz_collapse, (u32)(ns_total / LZ_CUNIT + nx + 1), 256, 3 * LZ_CUNIT * 4, blk, seq_list, nx, (const u64 *)cunits, (const u64 *)(cunits + nx + 1), A);
+    }
     LAUNCH(c, "zstd_lz_deps", k_lz_deps, nx, 64, 0, blk, seq_list, nx, offs, seq_cnt, nblk, ns_total, A);
     if (ctx_tracing(c)) {
         LzStats *S = arena_new<LzStats>(c, 1), hs; if (!S) return NAF_GPU_ENOMEM;
