@@ -812,6 +812,7 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
 // have (zstd_decode_sequences_predef with the tables' own logs): every cell a 4-byte LDS read.  A lane per block on tables in the pool
 // (k_decode_seq's general routine: three dependent flat loads from global memory per sequence) took 2.4 us per sequence -- 12 ms for a
 // block of five thousand, whatever the size of the frame (profiles/r05_levels_before.txt).
+#define SEQW_CELLS (512 + 256 + 512)
 __global__ __launch_bounds__(64) void k_decode_seq_wave(const u8 *src, ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
                                                          const u64 *seq_base, const FseE *pool, const FseE *predef,
                                                          u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st)
@@ -863,6 +864,173 @@ __global__ __launch_bounds__(64) void k_decode_seq_wave(const u8 *src, ZBlock *b
     if (uses_rep) atomicOr(&st->rep_slow, 2u);
     if (sll > b.lit_regen || b.lit_regen + sml > ZBLOCK_MAX) { set_err(st, ZE_CORRUPT); b.err = ZE_CORRUPT; return; }
     b.rep_out[0] = rep_out[0]; b.rep_out[1] = rep_out[1]; b.rep_out[2] = rep_out[2];
+    b.regen = (u32)(b.lit_regen + sml);
+    sizes[i] = b.regen;
+    atomicMax(&st->max_seq_regen, b.regen);
+}
+
+// ---- the same, the walk split in two ------------------------------------------------------------------------------------------------
+// k_decode_seq_wave's lane spends 1.1 us on a sequence (2600 cycles for some 150 instructions and twenty branches: refills, the repeat
+// codes, three dependent rounds of LDS reads), and nothing of it overlaps: the next cell depends on the last bit taken.  But of a
+// sequence's bits only the three STATE fields are on that chain -- the extra bits of the offset, match length and literal length are
+// skipped by their count, which a cell can carry (SQC_XB: the count that belongs to its symbol).  So:
+//   pass 1, the chain, branch-free: three cells (one LDS read each), the end of the unread bits e -= extra bits + state bits, one
+//     32-bit window of the stream at e (two dwords of the segment staged in LDS, v_alignbit), three bit fields, three additions.  Every
+//     lane runs it on the same values; lane j keeps what sequence j of the batch started from (e and the three cells);
+//   pass 2, a lane per sequence: the extra bits out of two windows, the values, coalesced stores;
+//   the repeat offsets: a batch without repeat codes (ballot) shifts its last three offsets in; one with them is walked in scalar
+//     registers (v_readlane by a uniform index, s_cselect).
+// The bit stream is staged 2 KB at a time (a batch of 64 sequences reads at most 64 x 89 bits of it), as aligned dwords counted from
+// the aligned address below the stream's start; positions are bit indices from there, the stream read downwards (RFC 8878 4.1).
+#define SQC_PACK(base, nb, sym, xb) ((u32)(base) | (u32)(nb) << 10 | (u32)(sym) << 14 | (u32)(xb) << 20)
+#define SQC_BASE(c) ((c) & 1023u)
+#define SQC_NB(c)   (((c) >> 10) & 15u)
+#define SQC_SYM(c)  (((c) >> 14) & 63u)
+#define SQC_XB(c)   (((c) >> 20) & 31u)
+#define SEQW_SEG_DW 512u
+#define SEQW_BATCH_BITS (64 * 89 + 64)
+__device__ __forceinline__ u32 seqw_window(const u32 *s_seg, i32 lo, u32 segD)         // the 32 bits of the stream from bit lo up
+{
+    const u32 l = (u32)(lo < (i32)(segD << 5) ? (i32)(segD << 5) : lo);                  // (a corrupt stream runs off its start: clamped, caught by the final position)
+    const u32 d = (l >> 5) - segD;
+    return __builtin_amdgcn_alignbit(s_seg[d + 1], s_seg[d], l & 31);
+}
+__global__ __launch_bounds__(64) void k_decode_seq_wave2(const u8 *src, ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
+                                                          const u64 *seq_base, const FseE *pool, const FseE *predef,
+                                                          u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st, u32 with_predef)
+{
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ u32 s_cell[SEQW_CELLS];
+    __shared__ u32 s_seg[SEQW_SEG_DW + 2];
+    __shared__ u32 s_llt[36], s_mlt[53];
+    const u32 t = blockIdx.x, lane = threadIdx.x;
+    if (t >= n_seq_blk) return;
+    const u32 i = seq_list[t];
+    ZBlock &b = blk[i];
+    if (b.err) return;
+    const i32 ob[3] = { own_ll[i], own_of[i], own_ml[i] };
+    if (ob[0] < 0 || ob[1] < 0 || ob[2] < 0) { if (lane == 0) { set_err(st, ZE_CORRUPT); b.err = ZE_CORRUPT; } return; }      // repeat mode without a table
+    const u32 mode[3] = { blk[ob[0]].modes[0], blk[ob[1]].modes[1], blk[ob[2]].modes[2] };
+    if (!with_predef && mode[0] == SM_PREDEF && mode[1] == SM_PREDEF && mode[2] == SM_PREDEF) return;                   // k_decode_seq's
+    const u32 tab_off[3] = { 0, 512, 768 }, predef_off[3] = { 0, 64, 96 }, predef_log[3] = { 6, 5, 6 }, max_sym[3] = { 35, 31, 52 };
+    u32 log[3]; bool bad = false;
+    for (int k = 0; k < 3; k++) {
+        const ZBlock &q = blk[ob[k]];
+        if (mode[k] == SM_RLE) {
+            log[k] = 0;
+            const u32 sym = q.fse_tab[k];
+            if (sym > max_sym[k]) bad = true;
+            else if (lane == 0) s_cell[tab_off[k]] = SQC_PACK(0, 0, sym, k == 0 ? ll_bits(sym) : k == 1 ? sym : ml_bits(sym));
+        } else {
+            const FseE *from = mode[k] == SM_PREDEF ? predef + predef_off[k] : pool + q.fse_tab[k];
+            log[k] = mode[k] == SM_PREDEF ? predef_log[k] : q.fse_log[k];
+            for (u32 x = lane; x < (1u << log[k]); x += 64) {
+                const FseE e = from[x];
+                s_cell[tab_off[k] + x] = SQC_PACK(e.base, e.nbits, e.sym, k == 0 ? ll_bits(e.sym) : k == 1 ? e.sym : ml_bits(e.sym));
+            }
+        }
+    }
+    zstd_seq_code_tables(s_llt, s_mlt, lane, 64);
+    const u32 size = b.seq_bits_size, nseq = b.nseq;
+    const u8 *const bits = src + b.src_off + b.seq_bits_off, *const end = bits + size;
+    if (bad || size == 0 || end[-1] == 0) { if (lane == 0) { set_err(st, ZE_CORRUPT); b.err = ZE_CORRUPT; } return; }
+    const u32 pre = (u32)((u64)bits & 3);
+    const u8 *const A = bits - pre;                                // (at least 8 readable bytes lie in front of the stream)
+    i32 e = (i32)(8 * (pre + size) - (8 - (u32)hibit32(end[-1])));  // the end of the unread bits: below the padding and its marker
+    u32 segD = 0;
+    auto stage = [&](i32 e_now) {                                  // the 2 KB of the stream below e_now (all of it, if it is shorter), dword segD first
+        const u32 hiD = ((u32)(e_now > 0 ? e_now : 0) + 31) >> 5;
+        segD = hiD > SEQW_SEG_DW ? hiD - SEQW_SEG_DW : 0u;
+        __syncthreads();
+        for (u32 x = lane; x < SEQW_SEG_DW + 2; x += 64) {
+            const u8 *q = A + 4 * (u64)(segD + x);
+            u32 v = 0;
+            if (q + 4 <= end) v = *(const u32 *)q;
+            else for (u32 k = 0; k < 4; k++) if (q + k < end) v |= (u32)q[k] << (8 * k);
+            s_seg[x] = v;
+        }
+        __syncthreads();
+    };
+    stage(e);
+    // the three initial states: LL, OF, ML from the top
+    u32 s0, s1, s2;
+    {
+        e -= (i32)(log[0] + log[1] + log[2]);
+        const u32 x = seqw_window(s_seg, e, segD);
+        s2 = __builtin_amdgcn_ubfe(x, 0, log[2]); s1 = __builtin_amdgcn_ubfe(x, log[2], log[1]); s0 = __builtin_amdgcn_ubfe(x, log[2] + log[1], log[0]);
+    }
+    const u64 base = seq_base[i];
+    u32 r0 = sym_make(0, 0), r1 = sym_make(1, 0), r2 = sym_make(2, 0);
+    bool any_rep = false, corrupt = e < (i32)(8 * pre);
+    u32 tll = 0, tml = 0;
+    for (u32 i0 = 0; i0 < nseq; i0 += 64) {
+        const u32 nb = nseq - i0 < 64 ? nseq - i0 : 64u;
+        if (segD && e - (i32)SEQW_BATCH_BITS < (i32)(segD << 5)) stage(e);
+        // pass 1
+        i32 my_e = 0; u32 my_c0 = 0, my_c1 = 0, my_c2 = 0;
+        for (u32 j = 0; j < nb; j++) {
+            const u32 c0 = s_cell[s0], c1 = s_cell[512 + s1], c2 = s_cell[768 + s2];
+            if (lane == j) { my_e = e; my_c0 = c0; my_c1 = c1; my_c2 = c2; }
+            e -= (i32)(SQC_XB(c0) + SQC_XB(c1) + SQC_XB(c2));
+            if (i0 + j + 1 < nseq) {                           // (the last sequence leaves the states alone)
+                const u32 n0 = SQC_NB(c0), n1 = SQC_NB(c1), n2 = SQC_NB(c2);
+                e -= (i32)(n0 + n1 + n2);
+                const u32 x = seqw_window(s_seg, e, segD);     // from the top: LL's bits, ML's, OF's
+                s1 = SQC_BASE(c1) + __builtin_amdgcn_ubfe(x, 0, n1);
+                s2 = SQC_BASE(c2) + __builtin_amdgcn_ubfe(x, n1, n2);
+                s0 = SQC_BASE(c0) + __builtin_amdgcn_ubfe(x, n1 + n2, n0);
+            }
+        }
+        // pass 2: from the top of a sequence's bits the offset's extra bits, the match length's, the literal length's
+        u32 ofv = 4, ll = 1, ml = 0;
+        if (lane < nb) {
+            const u32 ofc = SQC_SYM(my_c1), lt = s_llt[SQC_SYM(my_c0)], mt = s_mlt[SQC_SYM(my_c2)];
+            const u32 lb = lt >> 24, mb = mt >> 24;
+            ofv = (1u << ofc) + __builtin_amdgcn_ubfe(seqw_window(s_seg, my_e - (i32)ofc, segD), 0, ofc);
+            const u32 x = seqw_window(s_seg, my_e - (i32)(ofc + mb + lb), segD);
+            ll = (lt & 0xFFFFFFu) + __builtin_amdgcn_ubfe(x, 0, lb);
+            ml = (mt & 0xFFFFFFu) + __builtin_amdgcn_ubfe(x, lb, mb);
+            if (ofv - 3 >= SYM_BASE && ofv > 3) corrupt = true;    // beyond any window the format allows
+            tll += ll; tml += ml;
+        }
+        // the repeat offsets (3.1.1.5)
+        u32 off = ofv - 3;
+        const u64 reps = __ballot(lane < nb && ofv <= 3);
+        if (!reps) {
+            const u32 a = __builtin_amdgcn_readlane(off, nb - 1), bb = nb >= 2 ? __builtin_amdgcn_readlane(off, nb - 2) : r0,
+                      cc = nb >= 3 ? __builtin_amdgcn_readlane(off, nb - 3) : (nb == 2 ? r0 : r1);
+            r0 = a; r1 = bb; r2 = cc;
+        } else {
+            any_rep = true;
+            const u32 llz = ll == 0;
+            for (u32 j = 0; j < nb; j++) {
+                const u32 v = __builtin_amdgcn_readlane(ofv, j), z = __builtin_amdgcn_readlane(llz, j);
+                u32 o;
+                if (v > 3) { o = v - 3; r2 = r1; r1 = r0; r0 = o; }
+                else {
+                    const u32 idx = v - 1 + z;
+                    if (idx == 0) o = r0;
+                    else {
+                        o = idx == 3 ? sym_minus1(r0) : (idx == 1 ? r1 : r2);
+                        if (idx > 1) r2 = r1;
+                        r1 = r0; r0 = o;
+                    }
+                }
+                if (lane == j) off = o;
+            }
+        }
+        if (lane < nb) { o_ll[base + i0 + lane] = ll; o_ml[base + i0 + lane] = ml; o_of[base + i0 + lane] = off; }
+    }
+    corrupt = __ballot(corrupt) != 0 || e != (i32)(8 * pre);    // every bit of the stream, and no more
+    u64 sll = tll, sml = tml;
+    for (u32 d = 32; d; d >>= 1) { sll += __shfl_xor(sll, d); sml += __shfl_xor(sml, d); }
+    if (lane) return;
+    if (corrupt) { set_err(st, ZE_CORRUPT); b.err = ZE_CORRUPT; return; }
+    b.fse_owner[0] = ob[0]; b.fse_owner[1] = ob[1]; b.fse_owner[2] = ob[2];
+    b.seq_base = base;
+    if (any_rep) atomicOr(&st->rep_slow, 2u);
+    if (sll > b.lit_regen || b.lit_regen + sml > ZBLOCK_MAX) { set_err(st, ZE_CORRUPT); b.err = ZE_CORRUPT; return; }
+    b.rep_out[0] = r0; b.rep_out[1] = r1; b.rep_out[2] = r2;
     b.regen = (u32)(b.lit_regen + sml);
     sizes[i] = b.regen;
     atomicMax(&st->max_seq_regen, b.regen);
@@ -3387,8 +3555,12 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         const u32 own_tabs = (n_seq_blk && !ctx_opt_is(c, "SEQ_WAVE", '0')) ? 1u : 0u;
         LAUNCH(c, "zstd_decode_seq", k_decode_seq, cdiv(nblk, dsl), dsl, 0, d_src, blk, nblk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
                (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st, own_tabs);
-        if (own_tabs) LAUNCH(c, "zstd_decode_seq", k_decode_seq_wave, n_seq_blk, 64, 0, d_src, blk, (const u32 *)seq_list, n_seq_blk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
-               (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st);
+        if (own_tabs && ctx_opt_is(c, "SEQ_WAVE", 'l'))       // (kept as a cross-check: one lane walking the block with the general routine's shape)
+            LAUNCH(c, "zstd_decode_seq", k_decode_seq_wave, n_seq_blk, 64, 0, d_src, blk, (const u32 *)seq_list, n_seq_blk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
+                   (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st);
+        else if (own_tabs)
+            LAUNCH(c, "zstd_decode_seq", k_decode_seq_wave2, n_seq_blk, 64, 0, d_src, blk, (const u32 *)seq_list, n_seq_blk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
+                   (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st, 0u);
         if (n_seq_blk) LAUNCH(c, "zstd_rep_fast", k_rep_fast, cdiv(n_seq_blk, 256), 256, 0, blk, (const u32 *)seq_list, n_seq_blk, st);
         if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
         rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
