@@ -763,6 +763,7 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
     sizes[i] = b.regen;
     if (b.btype != BT_COMP || b.nseq == 0 || b.err) return;
     const i32 *own[3] = { own_ll, own_of, own_ml };
+    if (skip_own_tables == 2) return;                            // (SEQ_WAVE=all: k_decode_seq_wave2 takes the blocks under the predefined tables as well)
     if (skip_own_tables && own_ll[i] >= 0 && own_of[i] >= 0 && own_ml[i] >= 0 &&
         !(blk[own_ll[i]].modes[0] == SM_PREDEF && blk[own_of[i]].modes[1] == SM_PREDEF && blk[own_ml[i]].modes[2] == SM_PREDEF)) return;     // k_decode_seq_wave's
     const u32 predef_off[3] = { 0, 64, 96 }, predef_log[3] = { 6, 5, 6 };
@@ -2524,7 +2525,9 @@ __global__ __launch_bounds__(64) void k_lz_prep(const ZBlock *blk, const u32 *se
 // (the collapse has units of its own: 8192 sequences -- 96 KB of LDS, a workgroup of 256 per CU -- because what it leaves is a link per unit
 // edge, and a frame that is one chain, a counter's names through every block, is then as long as its unit edges are many)
 #define LZ_CUNIT 8192u
-__global__ __launch_bounds__(256) void k_lz_collapse(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A)
+#define LZ_CWG 1024u
+#define LZ_FAR_ROUNDS 14u
+__global__ __launch_bounds__(LZ_CWG) void k_lz_collapse(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A, u32 *hops)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lzc[];              // s_dst | s_ml | s_src, LZ_CUNIT each
     u32 *s_dst = lzc, *s_ml = lzc + LZ_CUNIT, *s_src = lzc + 2 * LZ_CUNIT;
@@ -2537,7 +2540,7 @@ __global__ __launch_bounds__(256) void k_lz_collapse(const ZBlock *blk, const u3
     if (s_first >= nseq) return;
     const u32 cnt = nseq - s_first < LZ_CUNIT ? nseq - s_first : LZ_CUNIT;
     const u64 sbase = b.seq_base + s_first;
-    for (u32 idx = threadIdx.x; idx < cnt; idx += 256) {
+    for (u32 idx = threadIdx.x; idx < cnt; idx += LZ_CWG) {
         const u32 d = A.x_dst[sbase + idx], ml = A.ml[sbase + idx], of = A.of[sbase + idx];
         const bool plain = ml && of >= ml && of <= d;                            // a copy of bytes of this block that do not overlap it
         s_dst[idx] = d; s_ml[idx] = plain ? ml : 0; s_src[idx] = plain ? d - of : 0xFFFFFFFFu;
@@ -2548,7 +2551,7 @@ __global__ __launch_bounds__(256) void k_lz_collapse(const ZBlock *blk, const u3
     // (a lane writes only its own sources and may read another's while it moves: either value names the same bytes)
     for (int round = 0; round < 16; round++) {
         bool hop = false;
-        for (u32 idx = threadIdx.x; idx < cnt; idx += 256) {
+        for (u32 idx = threadIdx.x; idx < cnt; idx += LZ_CWG) {
             const u32 ml = s_ml[idx], s = s_src[idx];
             if (!ml || s == 0xFFFFFFFFu || s < first_dst) continue;              // not a plain copy, or a source in front of the unit
             u32 lo = 0, hi = idx;                                                // the last sequence j < idx whose match starts at or in front of s
@@ -2561,7 +2564,117 @@ __global__ __launch_bounds__(256) void k_lz_collapse(const ZBlock *blk, const u3
         moved_any = true;
     }
     if (!moved_any) return;
-    for (u32 idx = threadIdx.x; idx < cnt; idx += 256) if (s_ml[idx]) A.of[sbase + idx] = s_dst[idx] - s_src[idx];
+    for (u32 idx = threadIdx.x; idx < cnt; idx += LZ_CWG) if (s_ml[idx]) A.of[sbase + idx] = s_dst[idx] - s_src[idx];
+    if (threadIdx.x == 0) atomicAdd(hops, 1u);
+}
+// ---- ... and across units (k_lz_collapse_far) -----------------------------------------------------------------------------------------
+// What the collapse above leaves of a chain is a link per unit edge and block edge: the ids of the reference's archive of 2 GB of reads,
+// every name a copy of the name in front of it through all 556 blocks, were 18.7 ms in k_lz_exec -- 10 us a link.  The same jump from unit
+// to unit: a unit takes the source of its first match that reads in front of the unit, finds the unit T that holds that place (blocks by
+// their out_off, units by their first landing place), stages T's matches in LDS, then T + 1's (a unit's sources span about a unit), and
+// every match of its own whose source lies wholly inside a plain match j of those adds j's offset to its own (its bytes are the bytes j
+// copied).  One launch, a workgroup per unit, each going round by itself until a round moves nothing (at most LZ_FAR_ROUNDS; a unit that
+// could not move never will: its first match, the two units it stages and the edges of what they hold stay the same) -- no barrier
+// between units: T's offsets may be moving while they are read, and either value names the same bytes.  Units start in order, so
+// most find the units in front of them finished and reach the chain's root in a hop or two; those in flight together double their hops.
+// Only for frames that are chains (most units moved sources within themselves: hops[0]).  Sources in other units than those two keep
+// their links: k_lz_exec works them off as before.
+__device__ __forceinline__ void lz_locate_unit(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, u64 u, u32 &t, u32 &s_first, u32 &cnt)
+{
+    t = 0;
+    { u32 hi = n_seq_blk; while (t + 1 < hi) { const u32 mid = (t + hi) >> 1; if (unit_base[mid] <= u) t = mid; else hi = mid; } }
+    const ZBlock &b = blk[seq_list[t]];
+    const u32 nseq = b.err ? 0 : b.nseq;
+    s_first = (u32)(u - unit_base[t]) * LZ_CUNIT;
+    cnt = s_first >= nseq ? 0u : (nseq - s_first < LZ_CUNIT ? nseq - s_first : LZ_CUNIT);
+}
+__global__ __launch_bounds__(LZ_CWG) void k_lz_collapse_far(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A, u32 *hops)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lzc[];              // s_dst | s_ml | s_of of the staged unit, LZ_CUNIT each
+    u32 *s_dst = lzc, *s_ml = lzc + LZ_CUNIT, *s_of = lzc + 2 * LZ_CUNIT;
+    __shared__ u32 s_pick, s_geo[4];
+    __shared__ u64 s_pos[2];
+    constexpr u32 PER = LZ_CUNIT / LZ_CWG;
+    const u64 u = blockIdx.x, nu = *n_units;
+    if (u == 0 || u >= nu) return;
+    if (2 * (u64)hops[0] < nu) return;                           // worth it for frames that are chains: most units moved sources inside themselves
+    u32 t, s_first, cnt; lz_locate_unit(blk, seq_list, n_seq_blk, unit_base, u, t, s_first, cnt);
+    if (!cnt) return;
+    const ZBlock &b = blk[seq_list[t]];
+    const u64 sbase = b.seq_base + s_first, B_u = b.out_off;
+    const u32 d0 = A.x_dst[sbase];
+    if (d0 == 0xFFFFFFFFu) return;
+    const u64 first_abs = B_u + d0;
+    if (threadIdx.x == 0) s_pick = 0xFFFFFFFFu;
+    __syncthreads();
+    u32 d[PER], ml[PER], of[PER]; u32 elig = 0;
+#pragma unroll
+    for (u32 k = 0; k < PER; k++) {
+        const u32 idx = threadIdx.x + k * LZ_CWG;
+        d[k] = 0xFFFFFFFFu; ml[k] = 0; of[k] = 0;
+        if (idx < cnt) { d[k] = A.x_dst[sbase + idx]; ml[k] = A.ml[sbase + idx]; of[k] = A.of[sbase + idx]; }
+        if (ml[k] && of[k] >= ml[k] && d[k] != 0xFFFFFFFFu && B_u + d[k] - of[k] < first_abs) { elig |= 1u << k; atomicMin(&s_pick, idx); }
+    }
+    __syncthreads();
+    const u32 pick = s_pick;
+    if (pick == 0xFFFFFFFFu) return;
+    u32 rounds = 0;
+    for (; rounds < LZ_FAR_ROUNDS; rounds++) {
+#pragma unroll
+        for (u32 k = 0; k < PER; k++) if (threadIdx.x + k * LZ_CWG == pick) s_pos[0] = B_u + d[k] - of[k];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // the block that holds that place, then the unit of it
+            const u64 P = s_pos[0];
+            u32 tb = 0; { u32 hi = t + 1; while (tb + 1 < hi) { const u32 mid = (tb + hi) >> 1; if (blk[seq_list[mid]].out_off <= P) tb = mid; else hi = mid; } }
+            const ZBlock &q = blk[seq_list[tb]];
+            const u32 nsq = q.err ? 0 : q.nseq, nun = (nsq + LZ_CUNIT - 1) / LZ_CUNIT;
+            const u64 rel = P - q.out_off;
+            u32 k = 0; { u32 hi = nun; while (k + 1 < hi) { const u32 mid = (k + hi) >> 1; if ((u64)A.x_dst[q.seq_base + (u64)mid * LZ_CUNIT] <= rel) k = mid; else hi = mid; } }
+            s_pos[1] = unit_base[tb] + k;
+        }
+        __syncthreads();
+        const u64 T0 = s_pos[1];
+        bool moved = false;
+        for (u32 pass = 0; pass < 2; pass++) {
+            const u64 T = T0 + pass;
+            if (T >= u) break;
+            if (threadIdx.x == 0) {
+                u32 t2, sf2, c2; lz_locate_unit(blk, seq_list, n_seq_blk, unit_base, T, t2, sf2, c2);
+                s_geo[0] = t2; s_geo[1] = sf2; s_geo[2] = c2;
+            }
+            __syncthreads();
+            const u32 t2 = s_geo[0], sf2 = s_geo[1], c2 = s_geo[2];
+            const ZBlock &q = blk[seq_list[t2]];
+            const u64 sb2 = q.seq_base + sf2, B_T = q.out_off;
+            for (u32 idx = threadIdx.x; idx < c2; idx += LZ_CWG) {
+                const u32 dj = A.x_dst[sb2 + idx], mj = A.ml[sb2 + idx], oj = __hip_atomic_load(A.of + sb2 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_dst[idx] = dj; s_ml[idx] = (mj && oj >= mj) ? mj : 0; s_of[idx] = oj;
+            }
+            __syncthreads();
+            if (c2) {
+#pragma unroll
+                for (u32 k = 0; k < PER; k++) {
+                    if (!((elig >> k) & 1)) continue;
+                    const u64 sabs = B_u + d[k] - of[k];
+                    if (sabs < B_T || sabs - B_T >= 0xFFFFFFFFull) continue;
+                    const u32 srel = (u32)(sabs - B_T);
+                    u32 lo = 0, hi = c2;                                             // the last match of the staged unit that lands at or in front of srel
+                    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (s_dst[mid] <= srel) lo = mid + 1; else hi = mid; }
+                    if (!lo) continue;
+                    const u32 j = lo - 1, dj = s_dst[j], mj = s_ml[j], oj = s_of[j];
+                    if (!mj || (u64)srel + ml[k] > (u64)dj + mj) continue;
+                    const u32 nof = of[k] + oj;
+                    if (nof < of[k] || nof >= 0x80000000u) continue;               // (offsets stay 31-bit)
+                    of[k] = nof; moved = true;
+                    __hip_atomic_store(A.of + sbase + threadIdx.x + k * LZ_CWG, nof, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+        }
+        if (!__syncthreads_or(moved)) break;
+    }
+    if (rounds && threadIdx.x == 0) atomicAdd(hops + 1 + (rounds < LZ_FAR_ROUNDS ? rounds : LZ_FAR_ROUNDS), 1u);      // (tracing: units by the rounds they took)
 }
 // first j in [0, n) with x_dst[j] + ml[j] > rel (match ends are increasing; padding entries: 0xFFFFFFFF + 0)
 __device__ __forceinline__ u32 lz_first_end_after(const u32 *x, const u32 *m, u32 n, u32 rel)
@@ -2797,14 +2910,27 @@ static int launch_lz_exec(naf_gpu_ctx *c, const ZBlock *blk, const u32 *seq_list
     // units of 1024 sequences in frame order (k_lz_exec's), of 8192 (k_lz_collapse's)
     u64 *units = arena_new<u64>(c, 2 * ((size_t)nx + 2)); if (!units) return NAF_GPU_ENOMEM;
     u64 *cunits = units + nx + 2;
-    LAUNCH(c, "zstd_lz_units", k_lz_units, cdiv(nx, 256), 256, 0, blk, seq_list, nx, LZ_UNIT, units);
+    LAUNCH(c, "zstd_lz_units", k_lz_units, cdiv(nx, 64), 64, 0, blk, seq_list, nx, LZ_UNIT, units);
     int rc = scan_exclusive_u64(c, units, nx, units + nx + 1); if (rc) return rc;
     const u32 grid = (u32)(ns_total / LZ_UNIT + nx + 1);                     // (an upper bound known without a read-back: wavefronts behind the last unit leave at once)
     if (!ctx_opt_is(c, "EXEC_COLLAPSE", '0')) {
-        LAUNCH(c, "zstd_lz_units", k_lz_units, cdiv(nx, 256), 256, 0, blk, seq_list, nx, LZ_CUNIT, cunits);
+        LAUNCH(c, "zstd_lz_units", k_lz_units, cdiv(nx, 64), 64, 0, blk, seq_list, nx, LZ_CUNIT, cunits);
         if ((rc = scan_exclusive_u64(c, cunits, nx, cunits + nx + 1))) return rc;
         HIP_TRY(c, hipFuncSetAttribute((const void *)k_lz_collapse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * LZ_CUNIT * 4)));
-        LAUNCH(c, "zstd_lz_collapse", k_lz_collapse, (u32)(ns_total / LZ_CUNIT + nx + 1), 256, 3 * LZ_CUNIT * 4, blk, seq_list, nx, (const u64 *)cunits, (const u64 *)(cunits + nx + 1), A);
+        const u32 cgrid = (u32)(ns_total / LZ_CUNIT + nx + 1);
+        u32 *hops = arena_new<u32>(c, LZ_FAR_ROUNDS + 2); if (!hops) return NAF_GPU_ENOMEM;
+        HIP_TRY(c, hipMemsetAsync(hops, 0, (LZ_FAR_ROUNDS + 2) * 4, c->stream));
+        LAUNCH(c, "zstd_lz_collapse", k_lz_collapse, cgrid, LZ_CWG, 3 * LZ_CUNIT * 4, blk, seq_list, nx, (const u64 *)cunits, (const u64 *)(cunits + nx + 1), A, hops);
+        if (!ctx_opt_is(c, "EXEC_COLLAPSE", 'n')) {                       // ('n': within units only)
+            HIP_TRY(c, hipFuncSetAttribute((const void *)k_lz_collapse_far, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * LZ_CUNIT * 4)));
+            LAUNCH(c, "zstd_lz_collapse_far", k_lz_collapse_far, cgrid, LZ_CWG, 3 * LZ_CUNIT * 4, blk, seq_list, nx, (const u64 *)cunits, (const u64 *)(cunits + nx + 1), A, hops);
+            if (ctx_tracing(c)) {
+                u32 hh[LZ_FAR_ROUNDS + 2]; if ((rc = ctx_readback(c, hh, hops, sizeof hh))) return rc;
+                ctx_trace(c, "[lz] units that moved sources: within %u; across, by the rounds they took (1, 2, ...):", hh[0]);
+                for (u32 r = 1; r <= LZ_FAR_ROUNDS; r++) ctx_trace(c, " %u", hh[r]);
+                ctx_trace(c, "\n");
+            }
+        }
     }
     LAUNCH(c, "zstd_lz_deps", k_lz_deps, nx, 64, 0, blk, seq_list, nx, offs, seq_cnt, nblk, ns_total, A);
     if (ctx_tracing(c)) {
@@ -3552,7 +3678,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         // (a lane per block, every lane on a chain of its own: a frame of a few thousand blocks spreads over more wavefronts, 16 lanes each)
         const u32 dsl = nblk < 32768 ? 16u : 64u;
         // blocks under tables of their own (libzstd's) by a wavefront each with the tables in LDS, the others a lane per block
-        const u32 own_tabs = (n_seq_blk && !ctx_opt_is(c, "SEQ_WAVE", '0')) ? 1u : 0u;
+        const u32 all_wave = ctx_opt_is(c, "SEQ_WAVE", 'a') ? 1u : 0u;
+        const u32 own_tabs = (n_seq_blk && !ctx_opt_is(c, "SEQ_WAVE", '0')) ? 1u + all_wave : 0u;
         LAUNCH(c, "zstd_decode_seq", k_decode_seq, cdiv(nblk, dsl), dsl, 0, d_src, blk, nblk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
                (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st, own_tabs);
         if (own_tabs && ctx_opt_is(c, "SEQ_WAVE", 'l'))       // (kept as a cross-check: one lane walking the block with the general routine's shape)
@@ -3560,7 +3687,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                    (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st);
         else if (own_tabs)
             LAUNCH(c, "zstd_decode_seq", k_decode_seq_wave2, n_seq_blk, 64, 0, d_src, blk, (const u32 *)seq_list, n_seq_blk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
-                   (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st, 0u);
+                   (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st, all_wave);
         if (n_seq_blk) LAUNCH(c, "zstd_rep_fast", k_rep_fast, cdiv(n_seq_blk, 256), 256, 0, blk, (const u32 *)seq_list, n_seq_blk, st);
         if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
         rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
