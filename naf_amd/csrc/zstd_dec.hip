@@ -2570,10 +2570,13 @@ __global__ __launch_bounds__(LZ_CWG) void k_lz_collapse(const ZBlock *blk, const
 // ---- ... and across units (k_lz_collapse_far) -----------------------------------------------------------------------------------------
 // What the collapse above leaves of a chain is a link per unit edge and block edge: the ids of the reference's archive of 2 GB of reads,
 // every name a copy of the name in front of it through all 556 blocks, were 18.7 ms in k_lz_exec -- 10 us a link.  The same jump from unit
-// to unit: a unit takes the source of its first match that reads in front of the unit, finds the unit T that holds that place (blocks by
-// their out_off, units by their first landing place), stages T's matches in LDS, then T + 1's (a unit's sources span about a unit), and
-// every match of its own whose source lies wholly inside a plain match j of those adds j's offset to its own (its bytes are the bytes j
-// copied).  One launch, a workgroup per unit, each going round by itself until a round moves nothing (at most LZ_FAR_ROUNDS; a unit that
+// to unit: a unit takes the source of its first match, finds the unit T that holds that place (blocks by their out_off, units by their
+// first landing place), stages T's matches in LDS, then T + 1's (a unit's sources span about a unit), and every match of its own whose
+// source lies wholly inside a plain match j of those adds j's offset to its own (its bytes are the bytes j copied); then the same from
+// the first match whose source lay in neither, LZ_FAR_TARGETS times a round -- names that count have chains at 1000, 10 000, 100 000
+// names' distance in the same unit, and the unit itself is one of the places: a match of it that has moved takes those behind it along
+// (the ids above: depth 1071 staging one place a round and never the unit itself, 486 with four and itself; 466 is what hops through
+// WHOLE matches can reach there -- the rest reads a match and the literal behind it).  One launch, a workgroup per unit, each going round by itself until a round moves nothing (at most LZ_FAR_ROUNDS; a unit that
 // could not move never will: its first match, the two units it stages and the edges of what they hold stay the same) -- no barrier
 // between units: T's offsets may be moving while they are read, and either value names the same bytes.  Units start in order, so
 // most find the units in front of them finished and reach the chain's root in a hop or two; those in flight together double their hops.
@@ -2588,89 +2591,100 @@ __device__ __forceinline__ void lz_locate_unit(const ZBlock *blk, const u32 *seq
     s_first = (u32)(u - unit_base[t]) * LZ_CUNIT;
     cnt = s_first >= nseq ? 0u : (nseq - s_first < LZ_CUNIT ? nseq - s_first : LZ_CUNIT);
 }
+#define LZ_FAR_TARGETS 4u
 __global__ __launch_bounds__(LZ_CWG) void k_lz_collapse_far(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A, u32 *hops)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lzc[];              // s_dst | s_ml | s_of of the staged unit, LZ_CUNIT each
     u32 *s_dst = lzc, *s_ml = lzc + LZ_CUNIT, *s_of = lzc + 2 * LZ_CUNIT;
     __shared__ u32 s_pick, s_geo[4];
-    __shared__ u64 s_pos[2];
+    __shared__ u64 s_pos[3];
     constexpr u32 PER = LZ_CUNIT / LZ_CWG;
     const u64 u = blockIdx.x, nu = *n_units;
-    if (u == 0 || u >= nu) return;
+    if (u >= nu) return;
     if (2 * (u64)hops[0] < nu) return;                           // worth it for frames that are chains: most units moved sources inside themselves
     u32 t, s_first, cnt; lz_locate_unit(blk, seq_list, n_seq_blk, unit_base, u, t, s_first, cnt);
     if (!cnt) return;
     const ZBlock &b = blk[seq_list[t]];
     const u64 sbase = b.seq_base + s_first, B_u = b.out_off;
-    const u32 d0 = A.x_dst[sbase];
-    if (d0 == 0xFFFFFFFFu) return;
-    const u64 first_abs = B_u + d0;
-    if (threadIdx.x == 0) s_pick = 0xFFFFFFFFu;
-    __syncthreads();
     u32 d[PER], ml[PER], of[PER]; u32 elig = 0;
 #pragma unroll
     for (u32 k = 0; k < PER; k++) {
         const u32 idx = threadIdx.x + k * LZ_CWG;
         d[k] = 0xFFFFFFFFu; ml[k] = 0; of[k] = 0;
         if (idx < cnt) { d[k] = A.x_dst[sbase + idx]; ml[k] = A.ml[sbase + idx]; of[k] = A.of[sbase + idx]; }
-        if (ml[k] && of[k] >= ml[k] && d[k] != 0xFFFFFFFFu && B_u + d[k] - of[k] < first_abs) { elig |= 1u << k; atomicMin(&s_pick, idx); }
+        if (ml[k] && of[k] >= ml[k] && d[k] != 0xFFFFFFFFu) elig |= 1u << k;      // a plain copy
     }
-    __syncthreads();
-    const u32 pick = s_pick;
-    if (pick == 0xFFFFFFFFu) return;
     u32 rounds = 0;
     for (; rounds < LZ_FAR_ROUNDS; rounds++) {
-#pragma unroll
-        for (u32 k = 0; k < PER; k++) if (threadIdx.x + k * LZ_CWG == pick) s_pos[0] = B_u + d[k] - of[k];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            // the block that holds that place, then the unit of it
-            const u64 P = s_pos[0];
-            u32 tb = 0; { u32 hi = t + 1; while (tb + 1 < hi) { const u32 mid = (tb + hi) >> 1; if (blk[seq_list[mid]].out_off <= P) tb = mid; else hi = mid; } }
-            const ZBlock &q = blk[seq_list[tb]];
-            const u32 nsq = q.err ? 0 : q.nseq, nun = (nsq + LZ_CUNIT - 1) / LZ_CUNIT;
-            const u64 rel = P - q.out_off;
-            u32 k = 0; { u32 hi = nun; while (k + 1 < hi) { const u32 mid = (k + hi) >> 1; if ((u64)A.x_dst[q.seq_base + (u64)mid * LZ_CUNIT] <= rel) k = mid; else hi = mid; } }
-            s_pos[1] = unit_base[tb] + k;
-        }
-        __syncthreads();
-        const u64 T0 = s_pos[1];
         bool moved = false;
-        for (u32 pass = 0; pass < 2; pass++) {
-            const u64 T = T0 + pass;
-            if (T >= u) break;
-            if (threadIdx.x == 0) {
-                u32 t2, sf2, c2; lz_locate_unit(blk, seq_list, n_seq_blk, unit_base, T, t2, sf2, c2);
-                s_geo[0] = t2; s_geo[1] = sf2; s_geo[2] = c2;
-            }
+        u32 cov = 0;                                             // matches whose source lay in a unit staged this round
+        for (u32 tg = 0; tg < LZ_FAR_TARGETS; tg++) {
+            // the first match not looked at yet this round: where it reads is the next unit to stage
+            if (threadIdx.x == 0) s_pick = 0xFFFFFFFFu;
             __syncthreads();
-            const u32 t2 = s_geo[0], sf2 = s_geo[1], c2 = s_geo[2];
-            const ZBlock &q = blk[seq_list[t2]];
-            const u64 sb2 = q.seq_base + sf2, B_T = q.out_off;
-            for (u32 idx = threadIdx.x; idx < c2; idx += LZ_CWG) {
-                const u32 dj = A.x_dst[sb2 + idx], mj = A.ml[sb2 + idx], oj = __hip_atomic_load(A.of + sb2 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_dst[idx] = dj; s_ml[idx] = (mj && oj >= mj) ? mj : 0; s_of[idx] = oj;
-            }
-            __syncthreads();
-            if (c2) {
+            u32 mine = 0xFFFFFFFFu;
 #pragma unroll
-                for (u32 k = 0; k < PER; k++) {
-                    if (!((elig >> k) & 1)) continue;
-                    const u64 sabs = B_u + d[k] - of[k];
-                    if (sabs < B_T || sabs - B_T >= 0xFFFFFFFFull) continue;
-                    const u32 srel = (u32)(sabs - B_T);
-                    u32 lo = 0, hi = c2;                                             // the last match of the staged unit that lands at or in front of srel
-                    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (s_dst[mid] <= srel) lo = mid + 1; else hi = mid; }
-                    if (!lo) continue;
-                    const u32 j = lo - 1, dj = s_dst[j], mj = s_ml[j], oj = s_of[j];
-                    if (!mj || (u64)srel + ml[k] > (u64)dj + mj) continue;
-                    const u32 nof = of[k] + oj;
-                    if (nof < of[k] || nof >= 0x80000000u) continue;               // (offsets stay 31-bit)
-                    of[k] = nof; moved = true;
-                    __hip_atomic_store(A.of + sbase + threadIdx.x + k * LZ_CWG, nof, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            for (u32 k = 0; k < PER; k++) if (((elig & ~cov) >> k) & 1) { const u32 idx = threadIdx.x + k * LZ_CWG; mine = idx < mine ? idx : mine; }
+#pragma unroll
+            for (u32 sh = 32; sh; sh >>= 1) { const u32 o = (u32)__shfl_xor((int)mine, (int)sh, 64); mine = o < mine ? o : mine; }
+            if ((threadIdx.x & 63) == 0 && mine != 0xFFFFFFFFu) atomicMin(&s_pick, mine);
+            __syncthreads();
+            const u32 pick = s_pick;
+            if (pick == 0xFFFFFFFFu) break;
+#pragma unroll
+            for (u32 k = 0; k < PER; k++) if (threadIdx.x + k * LZ_CWG == pick) { s_pos[0] = B_u + d[k] - of[k]; cov |= 1u << k; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                // the block that holds that place, then the unit of it
+                const u64 P = s_pos[0];
+                u32 tb = 0; { u32 hi = t + 1; while (tb + 1 < hi) { const u32 mid = (tb + hi) >> 1; if (blk[seq_list[mid]].out_off <= P) tb = mid; else hi = mid; } }
+                const ZBlock &q = blk[seq_list[tb]];
+                const u32 nsq = q.err ? 0 : q.nseq, nun = (nsq + LZ_CUNIT - 1) / LZ_CUNIT;
+                const u64 rel = P - q.out_off;
+                u32 k = 0; { u32 hi = nun; while (k + 1 < hi) { const u32 mid = (k + hi) >> 1; if ((u64)A.x_dst[q.seq_base + (u64)mid * LZ_CUNIT] <= rel) k = mid; else hi = mid; } }
+                s_pos[1] = unit_base[tb] + k;
             }
             __syncthreads();
+            const u64 T0 = s_pos[1];
+            for (u32 pass = 0; pass < 2; pass++) {
+                const u64 T = T0 + pass;
+                if (T > u) break;                                // (the unit itself is a target like any other: a match in front of this one that has moved since)
+                if (threadIdx.x == 0) {
+                    u32 t2, sf2, c2; lz_locate_unit(blk, seq_list, n_seq_blk, unit_base, T, t2, sf2, c2);
+                    s_geo[0] = t2; s_geo[1] = sf2; s_geo[2] = c2;
+                }
+                __syncthreads();
+                const u32 t2 = s_geo[0], sf2 = s_geo[1], c2 = s_geo[2];
+                const ZBlock &q = blk[seq_list[t2]];
+                const u64 sb2 = q.seq_base + sf2, B_T = q.out_off;
+                for (u32 idx = threadIdx.x; idx < c2; idx += LZ_CWG) {
+                    const u32 dj = A.x_dst[sb2 + idx], mj = A.ml[sb2 + idx], oj = __hip_atomic_load(A.of + sb2 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_dst[idx] = dj; s_ml[idx] = (mj && oj >= mj) ? mj : 0; s_of[idx] = oj;
+                    if (idx + 1 == c2) s_pos[2] = dj == 0xFFFFFFFFu ? 0 : (u64)dj + mj;          // where the unit's matches end
+                }
+                __syncthreads();
+                if (c2 && s_dst[0] != 0xFFFFFFFFu) {
+                    const u64 lo_abs = B_T + s_dst[0], hi_abs = B_T + s_pos[2];
+#pragma unroll
+                    for (u32 k = 0; k < PER; k++) {
+                        if (!(((elig & ~cov) >> k) & 1)) continue;
+                        const u64 sabs = B_u + d[k] - of[k];
+                        if (sabs < lo_abs || sabs >= hi_abs) continue;
+                        cov |= 1u << k;
+                        const u32 srel = (u32)(sabs - B_T);
+                        u32 lo = 0, hi = c2;                                         // the last match of the staged unit that lands at or in front of srel
+                        while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (s_dst[mid] <= srel) lo = mid + 1; else hi = mid; }
+                        if (!lo) continue;
+                        const u32 j = lo - 1, dj = s_dst[j], mj = s_ml[j], oj = s_of[j];
+                        if (!mj || (u64)srel + ml[k] > (u64)dj + mj) continue;
+                        const u32 nof = of[k] + oj;
+                        if (nof < of[k] || nof >= 0x80000000u) continue;           // (offsets stay 31-bit)
+                        of[k] = nof; moved = true;
+                        __hip_atomic_store(A.of + sbase + threadIdx.x + k * LZ_CWG, nof, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                __syncthreads();
+            }
         }
         if (!__syncthreads_or(moved)) break;
     }
