@@ -1001,6 +1001,27 @@ __global__ __launch_bounds__(64) void k_decode_seq_wave2(const u8 *src, ZBlock *
             const u32 a = __builtin_amdgcn_readlane(off, nb - 1), bb = nb >= 2 ? __builtin_amdgcn_readlane(off, nb - 2) : r0,
                       cc = nb >= 3 ? __builtin_amdgcn_readlane(off, nb - 3) : (nb == 2 ? r0 : r1);
             r0 = a; r1 = bb; r2 = cc;
+        } else if (!__ballot(lane < nb && ofv <= 3 && ofv - 1 + (ll == 0) != 0)) {
+            // repeat codes, but only "the last offset again" (code 1 behind literals: what a run of records with one distance is made
+            // of): such a lane takes the last NEW offset in front of it in the batch, or the one the batch came in with; the state behind
+            // the batch is its last three new offsets
+            any_rep = true;
+            const u64 m_new = __ballot(lane < nb && ofv > 3), below = m_new & ((1ull << lane) - 1);
+            const u32 got = (u32)__shfl((int)off, below ? 63 - __clzll((long long)below) : 0, 64);
+            if (lane < nb && ofv <= 3) off = below ? got : r0;
+            if (m_new) {
+                u64 m = m_new;
+                const int a = 63 - __clzll((long long)m); m &= ~(1ull << a);
+                const u32 va = __builtin_amdgcn_readlane(off, a);
+                if (!m) { r2 = r1; r1 = r0; }
+                else {
+                    const int bl = 63 - __clzll((long long)m); m &= ~(1ull << bl);
+                    const u32 vb = __builtin_amdgcn_readlane(off, bl);
+                    r2 = m ? __builtin_amdgcn_readlane(off, 63 - __clzll((long long)m)) : r0;
+                    r1 = vb;
+                }
+                r0 = va;
+            }
         } else {
             any_rep = true;
             const u32 llz = ll == 0;
