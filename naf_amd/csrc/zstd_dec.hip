@@ -2585,8 +2585,14 @@ __global__ __launch_bounds__(LZ_CWG) void k_lz_collapse(const ZBlock *blk, const
         moved_any = true;
     }
     if (!moved_any) return;
-    for (u32 idx = threadIdx.x; idx < cnt; idx += LZ_CWG) if (s_ml[idx]) A.of[sbase + idx] = s_dst[idx] - s_src[idx];
-    if (threadIdx.x == 0) atomicAdd(hops, 1u);
+    u32 n_moved = 0;                                             // matches of the unit that read somewhere else now: what k_lz_collapse_far asks before it starts
+    for (u32 idx = threadIdx.x; idx < cnt; idx += LZ_CWG) if (s_ml[idx]) {
+        const u32 nof = s_dst[idx] - s_src[idx];
+        if (nof != A.of[sbase + idx]) { A.of[sbase + idx] = nof; n_moved++; }
+    }
+#pragma unroll
+    for (u32 sh = 32; sh; sh >>= 1) n_moved += (u32)__shfl_xor((int)n_moved, (int)sh, 64);
+    if ((threadIdx.x & 63) == 0 && n_moved) atomicAdd(hops, n_moved);
 }
 // ---- ... and across units (k_lz_collapse_far) -----------------------------------------------------------------------------------------
 // What the collapse above leaves of a chain is a link per unit edge and block edge: the ids of the reference's archive of 2 GB of reads,
@@ -2601,7 +2607,8 @@ __global__ __launch_bounds__(LZ_CWG) void k_lz_collapse(const ZBlock *blk, const
 // could not move never will: its first match, the two units it stages and the edges of what they hold stay the same) -- no barrier
 // between units: T's offsets may be moving while they are read, and either value names the same bytes.  Units start in order, so
 // most find the units in front of them finished and reach the chain's root in a hop or two; those in flight together double their hops.
-// Only for frames that are chains (most units moved sources within themselves: hops[0]).  Sources in other units than those two keep
+// Only for frames that are chains (most MATCHES moved their source within their unit: hops[0] -- a `-3 --long 27` genome, where every
+// unit has a few that do, paid 6.9 ms here to save 3 in the executor).  Sources in other units than those two keep
 // their links: k_lz_exec works them off as before.
 __device__ __forceinline__ void lz_locate_unit(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, u64 u, u32 &t, u32 &s_first, u32 &cnt)
 {
@@ -2613,7 +2620,7 @@ __device__ __forceinline__ void lz_locate_unit(const ZBlock *blk, const u32 *seq
     cnt = s_first >= nseq ? 0u : (nseq - s_first < LZ_CUNIT ? nseq - s_first : LZ_CUNIT);
 }
 #define LZ_FAR_TARGETS 4u
-__global__ __launch_bounds__(LZ_CWG) void k_lz_collapse_far(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A, u32 *hops)
+__global__ __launch_bounds__(LZ_CWG) void k_lz_collapse_far(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A, u32 *hops, u64 ns_total)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lzc[];              // s_dst | s_ml | s_of of the staged unit, LZ_CUNIT each
     u32 *s_dst = lzc, *s_ml = lzc + LZ_CUNIT, *s_of = lzc + 2 * LZ_CUNIT;
@@ -2622,7 +2629,7 @@ __global__ __launch_bounds__(LZ_CWG) void k_lz_collapse_far(const ZBlock *blk, c
     constexpr u32 PER = LZ_CUNIT / LZ_CWG;
     const u64 u = blockIdx.x, nu = *n_units;
     if (u >= nu) return;
-    if (2 * (u64)hops[0] < nu) return;                           // worth it for frames that are chains: most units moved sources inside themselves
+    if (4 * (u64)hops[0] < ns_total) return;                     // worth it for frames that are chains: a quarter of the matches and more moved their source within their unit (names that count: 57 %; a genome's repeats: under 1 %)
     u32 t, s_first, cnt; lz_locate_unit(blk, seq_list, n_seq_blk, unit_base, u, t, s_first, cnt);
     if (!cnt) return;
     const ZBlock &b = blk[seq_list[t]];
@@ -2958,10 +2965,10 @@ static int launch_lz_exec(naf_gpu_ctx *c, const ZBlock *blk, const u32 *seq_list
         LAUNCH(c, "zstd_lz_collapse", k_lz_collapse, cgrid, LZ_CWG, 3 * LZ_CUNIT * 4, blk, seq_list, nx, (const u64 *)cunits, (const u64 *)(cunits + nx + 1), A, hops);
         if (!ctx_opt_is(c, "EXEC_COLLAPSE", 'n')) {                       // ('n': within units only)
             HIP_TRY(c, hipFuncSetAttribute((const void *)k_lz_collapse_far, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * LZ_CUNIT * 4)));
-            LAUNCH(c, "zstd_lz_collapse_far", k_lz_collapse_far, cgrid, LZ_CWG, 3 * LZ_CUNIT * 4, blk, seq_list, nx, (const u64 *)cunits, (const u64 *)(cunits + nx + 1), A, hops);
+            LAUNCH(c, "zstd_lz_collapse_far", k_lz_collapse_far, cgrid, LZ_CWG, 3 * LZ_CUNIT * 4, blk, seq_list, nx, (const u64 *)cunits, (const u64 *)(cunits + nx + 1), A, hops, ns_total);
             if (ctx_tracing(c)) {
                 u32 hh[LZ_FAR_ROUNDS + 2]; if ((rc = ctx_readback(c, hh, hops, sizeof hh))) return rc;
-                ctx_trace(c, "[lz] units that moved sources: within %u; across, by the rounds they took (1, 2, ...):", hh[0]);
+                ctx_trace(c, "[lz] matches that moved their source within their unit: %u of %llu sequences; units by the rounds they took across units (1, 2, ...):", hh[0], (unsigned long long)ns_total);
                 for (u32 r = 1; r <= LZ_FAR_ROUNDS; r++) ctx_trace(c, " %u", hh[r]);
                 ctx_trace(c, "\n");
             }
