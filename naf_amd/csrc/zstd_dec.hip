@@ -721,28 +721,35 @@ __global__ __launch_bounds__(64) void k_build_huf_few(const u8 *src, ZBlock *blk
     }
 }
 
+// (a lane per TABLE: the lane of a block's second or third table measures the descriptions in front of its own first -- the walk over
+// the symbols' counts is short beside the spreading and numbering of up to 512 cells)
 __global__ void k_build_fse(const u8 *src, ZBlock *blk, u32 nblk, FseE *pool, u32 pool_cap, ZStat *st)
 {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 i = tid / 3, mine = tid % 3;
     if (i >= nblk) return;
     if (blk[i].btype != BT_COMP || blk[i].nseq == 0 || blk[i].err) return;
+    if (blk[i].modes[mine] != SM_FSE) return;
     const u8 *c = src + blk[i].src_off;
     u32 pos = blk[i].seq_off, len = blk[i].bsize;
     const u32 max_log[3] = { 9, 8, 9 }, max_sym[3] = { 35, 31, 52 };
-    for (int k = 0; k < 3; k++) {
-        u32 m = blk[i].modes[k];
+    for (u32 k = 0; k < mine; k++) {
+        const u32 m = blk[i].modes[k];
         if (m == SM_RLE) pos++;
         else if (m == SM_FSE) {
-            i16 norm[64]; u16 next[64]; u32 nsym, log;
-            u32 d = fse_read_ncount(c + pos, len - pos, max_log[k], max_sym[k], norm, &nsym, &log);
-            if (!d) { set_err(st, ZE_CORRUPT); return; }
+            u32 nsym, log;
+            const u32 d = fse_read_ncount(c + pos, len - pos, max_log[k], max_sym[k], NULL, &nsym, &log);
+            if (!d) return;                                      // (the lane of that table says so)
             pos += d;
-            u32 off = atomicAdd(&st->fse_pool_used, 1u << log);
-            if (off + (1u << log) > pool_cap) { set_err(st, ZE_POOL); return; }
-            if (!fse_build_table(pool + off, norm, nsym, log, next)) { set_err(st, ZE_CORRUPT); return; }
-            blk[i].fse_tab[k] = off;
         }
     }
+    i16 norm[64]; u16 next[64]; u32 nsym, log;
+    const u32 d = fse_read_ncount(c + pos, len - pos, max_log[mine], max_sym[mine], norm, &nsym, &log);
+    if (!d) { set_err(st, ZE_CORRUPT); return; }
+    const u32 off = atomicAdd(&st->fse_pool_used, 1u << log);
+    if (off + (1u << log) > pool_cap) { set_err(st, ZE_POOL); return; }
+    if (!fse_build_table(pool + off, norm, nsym, log, next)) { set_err(st, ZE_CORRUPT); return; }
+    blk[i].fse_tab[mine] = off;
 }
 
 __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
@@ -2547,6 +2554,7 @@ __global__ __launch_bounds__(64) void k_lz_prep(const ZBlock *blk, const u32 *se
 // edge, and a frame that is one chain, a counter's names through every block, is then as long as its unit edges are many)
 #define LZ_CUNIT 8192u
 #define LZ_CWG 1024u
+#define LZ_DEPS_PARTS 8u
 #define LZ_FAR_ROUNDS 14u
 __global__ __launch_bounds__(LZ_CWG) void k_lz_collapse(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A, u32 *hops)
 {
@@ -2742,7 +2750,9 @@ __global__ __launch_bounds__(64) void k_lz_deps(const ZBlock *blk, const u32 *se
     const u32 nseq = b.err ? 0 : b.nseq;
     u32 shift = 0xFF;
     if (nblk > 1) { const u64 b0 = offs[1] - offs[0]; if (b0 && !(b0 & (b0 - 1))) shift = (u32)(63 - __builtin_clzll(b0)); }
-    for (u32 s = lane; s < nseq; s += 64) {
+    // (gridDim.y wavefronts share a block: a frame of a few hundred blocks of ten thousand sequences each was 2 ms of one wavefront's
+    // dependent searches per block)
+    for (u32 s = blockIdx.y * 64 + lane; s < nseq; s += 64 * gridDim.y) {
         const u64 i = sbase + s;
         const u32 ml = A.ml[i];
         if (!ml) { A.dep_lo[i] = 0; A.dep_n[i] = 0; continue; }
@@ -2974,7 +2984,7 @@ static int launch_lz_exec(naf_gpu_ctx *c, const ZBlock *blk, const u32 *seq_list
             }
         }
     }
-    LAUNCH(c, "zstd_lz_deps", k_lz_deps, nx, 64, 0, blk, seq_list, nx, offs, seq_cnt, nblk, ns_total, A);
+    LAUNCH(c, "zstd_lz_deps", k_lz_deps, (dim3(nx, nx >= 4096 ? 1u : (4096u / nx < LZ_DEPS_PARTS ? 4096u / nx : LZ_DEPS_PARTS))), 64, 0, blk, seq_list, nx, offs, seq_cnt, nblk, ns_total, A);
     if (ctx_tracing(c)) {
         LzStats *S = arena_new<LzStats>(c, 1), hs; if (!S) return NAF_GPU_ENOMEM;
         HIP_TRY(c, hipMemsetAsync(S, 0, sizeof(LzStats), c->stream));
@@ -3699,7 +3709,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         u32 fse_cap = n_seq_blk * (512 + 256 + 512);
         fse_pool = arena_new<FseE>(c, fse_cap);
         if (!fse_pool) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "zstd_build_fse", k_build_fse, g, 64, 0, d_src, blk, nblk, fse_pool, fse_cap, st);
+        LAUNCH(c, "zstd_build_fse", k_build_fse, cdiv(3 * (u64)nblk, 64), 64, 0, d_src, blk, nblk, fse_pool, fse_cap, st);
         rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
         if (hs.err) return zerr(c, hs.err, "table build");
         size_t ns = hs.total_seq ? hs.total_seq : 1;
