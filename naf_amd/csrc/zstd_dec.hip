@@ -30,7 +30,7 @@ struct ZStat {                 // device-side counters read back by the host
     u32 n_huf_distinct, n_huf_built;   // tree descriptions that differ from their predecessor's (k_huf_dedup); tables actually built
     u32 max_lit_regen, n_huf_pending;  // largest literals section of a Huffman-coded block (k_huf_par sizes its parts by it); trees left without a table by k_build_huf's first phase
     u32 last_raw, flat_main_inv;       // size of the frame's last block when it is a Raw or (bit 31) RLE one, else 0; 0xFFFFFFFF - index of the FIRST block that defines a flat 4-bit tree (0: none)
-    u32 n_exec_done, pad_;             // blocks the sequence executors have published: a waiting block gives up only when this stands still
+    u32 n_exec_done, n_wave;           // blocks the sequence executors have published: a waiting block gives up only when this stands still; blocks k_decode_seq left to k_decode_seq_wave(2)
 };
 
 static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
@@ -754,7 +754,7 @@ __global__ void k_build_fse(const u8 *src, ZBlock *blk, u32 nblk, FseE *pool, u3
 
 __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
                              const u64 *seq_base, const FseE *pool, const FseE *predef,
-                             u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st, u32 skip_own_tables)
+                             u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st, u32 skip_own_tables, u32 *wave_list)
 {
     __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     // the predefined tables (what this build's own LZ blocks use) in LDS: the lane's whole job is a chain of dependent table reads
@@ -770,9 +770,13 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
     sizes[i] = b.regen;
     if (b.btype != BT_COMP || b.nseq == 0 || b.err) return;
     const i32 *own[3] = { own_ll, own_of, own_ml };
-    if (skip_own_tables == 2) return;                            // (SEQ_WAVE=all: k_decode_seq_wave2 takes the blocks under the predefined tables as well)
-    if (skip_own_tables && own_ll[i] >= 0 && own_of[i] >= 0 && own_ml[i] >= 0 &&
-        !(blk[own_ll[i]].modes[0] == SM_PREDEF && blk[own_of[i]].modes[1] == SM_PREDEF && blk[own_ml[i]].modes[2] == SM_PREDEF)) return;     // k_decode_seq_wave's
+    // blocks left to k_decode_seq_wave(2) go on its list (a frame of this build's own has none, and a launch of a workgroup per block
+    // only to find that out was 0.7 ... 2.2 ms of dispatch for the hundreds of thousands of blocks of a FASTQ's names)
+    if (skip_own_tables == 2 || (skip_own_tables && own_ll[i] >= 0 && own_of[i] >= 0 && own_ml[i] >= 0 &&
+        !(blk[own_ll[i]].modes[0] == SM_PREDEF && blk[own_of[i]].modes[1] == SM_PREDEF && blk[own_ml[i]].modes[2] == SM_PREDEF))) {
+        wave_list[atomicAdd(&st->n_wave, 1u)] = i;
+        return;
+    }
     const u32 predef_off[3] = { 0, 64, 96 }, predef_log[3] = { 6, 5, 6 };
     SeqTab tab[3];
     for (int k = 0; k < 3; k++) {
@@ -821,16 +825,13 @@ __global__ void k_decode_seq(const u8 *src, ZBlock *blk, u32 nblk, const i32 *ow
 // (k_decode_seq's general routine: three dependent flat loads from global memory per sequence) took 2.4 us per sequence -- 12 ms for a
 // block of five thousand, whatever the size of the frame (profiles/r05_levels_before.txt).
 #define SEQW_CELLS (512 + 256 + 512)
-__global__ __launch_bounds__(64) void k_decode_seq_wave(const u8 *src, ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
-                                                         const u64 *seq_base, const FseE *pool, const FseE *predef,
-                                                         u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st)
+__device__ __forceinline__ void seq_wave_block(const u8 *src, ZBlock *blk, u32 i, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
+                                               const u64 *seq_base, const FseE *pool, const FseE *predef,
+                                               u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st)
 {
-    __builtin_amdgcn_s_setprio(3);
     __shared__ FseE s_tab[512 + 256 + 512];
     __shared__ u32 s_llt[36], s_mlt[53];
-    const u32 t = blockIdx.x, lane = threadIdx.x;
-    if (t >= n_seq_blk) return;
-    const u32 i = seq_list[t];
+    const u32 lane = threadIdx.x;
     ZBlock &b = blk[i];
     if (b.err) return;
     const i32 ob[3] = { own_ll[i], own_of[i], own_ml[i] };
@@ -877,6 +878,18 @@ __global__ __launch_bounds__(64) void k_decode_seq_wave(const u8 *src, ZBlock *b
     atomicMax(&st->max_seq_regen, b.regen);
 }
 
+// (a bounded grid over the list k_decode_seq left: see there)
+__global__ __launch_bounds__(64) void k_decode_seq_wave(const u8 *src, ZBlock *blk, const u32 *wave_list, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
+                                                         const u64 *seq_base, const FseE *pool, const FseE *predef,
+                                                         u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const u32 n = st->n_wave;
+    for (u32 t = blockIdx.x; t < n; t += gridDim.x) {
+        seq_wave_block(src, blk, wave_list[t], own_ll, own_of, own_ml, seq_base, pool, predef, o_ll, o_ml, o_of, sizes, st);
+        __syncthreads();
+    }
+}
 // ---- the same, the walk split in two ------------------------------------------------------------------------------------------------
 // k_decode_seq_wave's lane spends 1.1 us on a sequence (2600 cycles for some 150 instructions and twenty branches: refills, the repeat
 // codes, three dependent rounds of LDS reads), and nothing of it overlaps: the next cell depends on the last bit taken.  But of a
@@ -903,17 +916,14 @@ __device__ __forceinline__ u32 seqw_window(const u32 *s_seg, i32 lo, u32 segD)  
     const u32 d = (l >> 5) - segD;
     return __builtin_amdgcn_alignbit(s_seg[d + 1], s_seg[d], l & 31);
 }
-__global__ __launch_bounds__(64) void k_decode_seq_wave2(const u8 *src, ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
-                                                          const u64 *seq_base, const FseE *pool, const FseE *predef,
-                                                          u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st, u32 with_predef)
+__device__ __forceinline__ void seq_wave2_block(const u8 *src, ZBlock *blk, u32 i, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
+                                                const u64 *seq_base, const FseE *pool, const FseE *predef,
+                                                u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st, u32 with_predef)
 {
-    __builtin_amdgcn_s_setprio(3);
     __shared__ u32 s_cell[SEQW_CELLS];
     __shared__ u32 s_seg[SEQW_SEG_DW + 2];
     __shared__ u32 s_llt[36], s_mlt[53];
-    const u32 t = blockIdx.x, lane = threadIdx.x;
-    if (t >= n_seq_blk) return;
-    const u32 i = seq_list[t];
+    const u32 lane = threadIdx.x;
     ZBlock &b = blk[i];
     if (b.err) return;
     const i32 ob[3] = { own_ll[i], own_of[i], own_ml[i] };
@@ -1063,6 +1073,18 @@ __global__ __launch_bounds__(64) void k_decode_seq_wave2(const u8 *src, ZBlock *
     b.regen = (u32)(b.lit_regen + sml);
     sizes[i] = b.regen;
     atomicMax(&st->max_seq_regen, b.regen);
+}
+
+__global__ __launch_bounds__(64) void k_decode_seq_wave2(const u8 *src, ZBlock *blk, const u32 *wave_list, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
+                                                          const u64 *seq_base, const FseE *pool, const FseE *predef,
+                                                          u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st, u32 with_predef)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const u32 n = st->n_wave;
+    for (u32 t = blockIdx.x; t < n; t += gridDim.x) {
+        seq_wave2_block(src, blk, wave_list[t], own_ll, own_of, own_ml, seq_base, pool, predef, o_ll, o_ml, o_of, sizes, st, with_predef);
+        __syncthreads();
+    }
 }
 
 // Entry repeat offsets of every block with sequences, in parallel: a block that introduces three new offsets leaves a state that
@@ -3732,13 +3754,16 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         // blocks under tables of their own (libzstd's) by a wavefront each with the tables in LDS, the others a lane per block
         const u32 all_wave = ctx_opt_is(c, "SEQ_WAVE", 'a') ? 1u : 0u;
         const u32 own_tabs = (n_seq_blk && !ctx_opt_is(c, "SEQ_WAVE", '0')) ? 1u + all_wave : 0u;
+        u32 *wave_list = own_tabs ? arena_new<u32>(c, n_seq_blk) : nullptr;
+        if (own_tabs && !wave_list) return NAF_GPU_ENOMEM;
         LAUNCH(c, "zstd_decode_seq", k_decode_seq, cdiv(nblk, dsl), dsl, 0, d_src, blk, nblk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
-               (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st, own_tabs);
+               (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st, own_tabs, wave_list);
+        const u32 wgrid = n_seq_blk < 8192u ? n_seq_blk : 8192u;
         if (own_tabs && ctx_opt_is(c, "SEQ_WAVE", 'l'))       // (kept as a cross-check: one lane walking the block with the general routine's shape)
-            LAUNCH(c, "zstd_decode_seq", k_decode_seq_wave, n_seq_blk, 64, 0, d_src, blk, (const u32 *)seq_list, n_seq_blk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
+            LAUNCH(c, "zstd_decode_seq", k_decode_seq_wave, wgrid, 64, 0, d_src, blk, (const u32 *)wave_list, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
                    (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st);
         else if (own_tabs)
-            LAUNCH(c, "zstd_decode_seq", k_decode_seq_wave2, n_seq_blk, 64, 0, d_src, blk, (const u32 *)seq_list, n_seq_blk, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
+            LAUNCH(c, "zstd_decode_seq", k_decode_seq_wave2, wgrid, 64, 0, d_src, blk, (const u32 *)wave_list, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
                    (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st, all_wave);
         if (n_seq_blk) LAUNCH(c, "zstd_rep_fast", k_rep_fast, cdiv(n_seq_blk, 256), 256, 0, blk, (const u32 *)seq_list, n_seq_blk, st);
         if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
