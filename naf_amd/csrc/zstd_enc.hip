@@ -223,9 +223,20 @@ __global__ __launch_bounds__(256) void k_zenc_plan(const u8 *src, u64 n, u32 nbl
             if (fbits * 1024 * 100 <= ebits * fratio[0] * 103 + 6400ull * 1024) {
                 for (u32 k = 0; k < 4; k++) { u64 bits; wg_scan_inclusive<u64, OpAdd>((u64)hist[256 * k + sym] * fl, &bits, fred); p.ssz[k] = (u32)((bits + 1 + 7) / 8); }
                 zenc_plan_finish(p, bn, fplan->log, 0, min_gain);
-                if (p.kind == ZK_HUF) { p.frame = 1; codes[(u64)b * 256 + sym] = fcodes[sym]; }
-                if (threadIdx.x == 0) { plan[b] = p; if (csize) csize[b] = p.csize; }
-                return;
+                // (only when the block would stay below its Raw size even if k_zenc_frame_fix makes it carry the tree: a forced block is
+                // Huffman "whatever it costs", and naf_gpu_zstd_compress_bound -- and Block_Maximum_Size at 128 KiB blocks -- count on
+                // no block being larger than Raw.  A block that close to incompressible goes the general way, Raw fallback included.)
+                if (p.kind == ZK_HUF && p.csize + fplan->tree_bytes <= 3 + bn) {
+                    p.frame = 1; codes[(u64)b * 256 + sym] = fcodes[sym];
+                    if (threadIdx.x == 0) { plan[b] = p; if (csize) csize[b] = p.csize; }
+                    return;
+                }
+                if (p.kind != ZK_HUF) {
+                    if (threadIdx.x == 0) { plan[b] = p; if (csize) csize[b] = p.csize; }
+                    return;
+                }
+                p.kind = ZK_RAW; p.csize = 3 + bn; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0; p.frame = 0; p.pad2 = 0;
+                p.ssz[0] = p.ssz[1] = p.ssz[2] = p.ssz[3] = 0;
             }
         }
     }

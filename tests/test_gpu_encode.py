@@ -475,6 +475,25 @@ def test_frame_tree_of_the_quality_stream(gpu, oracle, monkeypatch):
         assert oracle.ref_unnaf(m1) == host(back1)
 
 
+def test_no_block_of_a_nearly_incompressible_stream_is_larger_than_raw(gpu, oracle):
+    """A block coded with the FRAME's tree may have to carry the tree after all (k_zenc_frame_fix), "whatever it costs": the planner
+    takes the frame's code for a block only when the block stays below its Raw size even then.  Streams of 256 symbols a few hundredths
+    of a bit below eight bits a byte: the frame is never larger than Raw blocks would make it (what naf_gpu_zstd_compress_bound and
+    Block_Maximum_Size count on) and decodes to the same bytes under the from-spec oracle and this build's decoder."""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(77)
+    n = 24_000_000
+    for skew in (0.97, 0.9, 0.8, 0.6):
+        w = torch.ones(256, device="cuda"); w[::2] = skew
+        src = torch.multinomial(w, n, replacement=True, generator=g).to(torch.uint8)
+        fr = gpu.zstd_compress(src)
+        nb = (n + 32767) // 32768
+        assert fr.numel() <= n + 3 * nb + 32, (skew, int(fr.numel()), n)
+        assert fr.numel() <= gpu.L.naf_gpu_zstd_compress_bound(n)
+        assert torch.equal(gpu.zstd_decompress(fr, n + 64), src), skew
+        assert oracle.zstd_decompress(host(fr), n + 64) == host(src), skew
+
+
 def test_single_record_of_more_than_2_32_bases(gpu, oracle):
     """One record of 4.4 G bases: its length takes a 0xFFFFFFFF continuation unit (encoders.c:72-95), base indices and text offsets
     inside the record pass 2^32, and the mask run is 17 million units of 255.  Round trip on the device, the lengths stream
