@@ -894,7 +894,7 @@ __global__ __launch_bounds__(64) void k_decode_seq_wave(const u8 *src, ZBlock *b
 // k_decode_seq_wave's lane spends 1.1 us on a sequence (2600 cycles for some 150 instructions and twenty branches: refills, the repeat
 // codes, three dependent rounds of LDS reads), and nothing of it overlaps: the next cell depends on the last bit taken.  But of a
 // sequence's bits only the three STATE fields are on that chain -- the extra bits of the offset, match length and literal length are
-// skipped by their count, which a cell can carry (SQC_XB: the count that belongs to its symbol).  So:
+// skipped by their count, which a cell can carry (SQC_TB: state bits + the extra bits that belong to its symbol).  So:
 //   pass 1, the chain, branch-free: three cells (one LDS read each), the end of the unread bits e -= extra bits + state bits, one
 //     32-bit window of the stream at e (two dwords of the segment staged in LDS, v_alignbit), three bit fields, three additions.  Every
 //     lane runs it on the same values; lane j keeps what sequence j of the batch started from (e and the three cells);
@@ -903,11 +903,13 @@ __global__ __launch_bounds__(64) void k_decode_seq_wave(const u8 *src, ZBlock *b
 //     registers (v_readlane by a uniform index, s_cselect).
 // The bit stream is staged 2 KB at a time (a batch of 64 sequences reads at most 64 x 89 bits of it), as aligned dwords counted from
 // the aligned address below the stream's start; positions are bit indices from there, the stream read downwards (RFC 8878 4.1).
-#define SQC_PACK(base, nb, sym, xb) ((u32)(base) | (u32)(nb) << 10 | (u32)(sym) << 14 | (u32)(xb) << 20)
-#define SQC_BASE(c) ((c) & 1023u)
-#define SQC_NB(c)   (((c) >> 10) & 15u)
-#define SQC_SYM(c)  (((c) >> 14) & 63u)
-#define SQC_XB(c)   (((c) >> 20) & 31u)
+// a cell: the next state's base as a BYTE offset into its table (states are kept that way: no shift in front of a cell read), the
+// state bits to read, the symbol, and state bits + the symbol's extra bits -- what the walk moves down by
+#define SQC_PACK(base, nb, sym, xb) ((u32)(base) << 2 | (u32)(nb) << 12 | (u32)(sym) << 16 | ((u32)(xb) + (u32)(nb)) << 22)
+#define SQC_BASE4(c) ((c) & 0xFFFu)
+#define SQC_NB(c)   (((c) >> 12) & 15u)
+#define SQC_SYM(c)  (((c) >> 16) & 63u)
+#define SQC_TB(c)   (((c) >> 22) & 63u)
 #define SEQW_SEG_DW 512u
 #define SEQW_BATCH_BITS (64 * 89 + 64)
 __device__ __forceinline__ u32 seqw_window(const u32 *s_seg, i32 lo, u32 segD)         // the 32 bits of the stream from bit lo up
@@ -970,35 +972,40 @@ __device__ __forceinline__ void seq_wave2_block(const u8 *src, ZBlock *blk, u32 
         __syncthreads();
     };
     stage(e);
-    // the three initial states: LL, OF, ML from the top
+    // the three initial states: LL, OF, ML from the top (as byte offsets into their tables)
     u32 s0, s1, s2;
     {
         e -= (i32)(log[0] + log[1] + log[2]);
         const u32 x = seqw_window(s_seg, e, segD);
-        s2 = __builtin_amdgcn_ubfe(x, 0, log[2]); s1 = __builtin_amdgcn_ubfe(x, log[2], log[1]); s0 = __builtin_amdgcn_ubfe(x, log[2] + log[1], log[0]);
+        s2 = __builtin_amdgcn_ubfe(x, 0, log[2]) << 2; s1 = __builtin_amdgcn_ubfe(x, log[2], log[1]) << 2; s0 = __builtin_amdgcn_ubfe(x, log[2] + log[1], log[0]) << 2;
     }
     const u64 base = seq_base[i];
     u32 r0 = sym_make(0, 0), r1 = sym_make(1, 0), r2 = sym_make(2, 0);
     bool any_rep = false, corrupt = e < (i32)(8 * pre);
     u32 tll = 0, tml = 0;
+    __shared__ uint4 s_rec[64];                                  // what sequence j of the batch started from: e and its three cells
+    const u8 *const cells = (const u8 *)s_cell;
     for (u32 i0 = 0; i0 < nseq; i0 += 64) {
         const u32 nb = nseq - i0 < 64 ? nseq - i0 : 64u;
         if (segD && e - (i32)SEQW_BATCH_BITS < (i32)(segD << 5)) stage(e);
-        // pass 1
-        i32 my_e = 0; u32 my_c0 = 0, my_c1 = 0, my_c2 = 0;
+        // pass 1.  (In vector registers: every lane holds the same values, and left to itself the compiler moves them to scalar registers
+        // and back -- v_readfirstlane in front of every use, v_mov in front of every LDS address: a fifth slower on a genome's frame.
+        // Thirty-odd instructions a sequence, and their number is what the walk costs.)
         for (u32 j = 0; j < nb; j++) {
-            const u32 c0 = s_cell[s0], c1 = s_cell[512 + s1], c2 = s_cell[768 + s2];
-            if (lane == j) { my_e = e; my_c0 = c0; my_c1 = c1; my_c2 = c2; }
-            e -= (i32)(SQC_XB(c0) + SQC_XB(c1) + SQC_XB(c2));
-            if (i0 + j + 1 < nseq) {                           // (the last sequence leaves the states alone)
-                const u32 n0 = SQC_NB(c0), n1 = SQC_NB(c1), n2 = SQC_NB(c2);
-                e -= (i32)(n0 + n1 + n2);
+            asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(e));
+            const u32 c0 = *(const u32 *)(cells + s0), c1 = *(const u32 *)(cells + 2048 + s1), c2 = *(const u32 *)(cells + 3072 + s2);
+            s_rec[j] = make_uint4((u32)e, c0, c1, c2);           // (every lane the same value to the same place)
+            const u32 n0 = SQC_NB(c0), n1 = SQC_NB(c1), n2 = SQC_NB(c2);
+            e -= (i32)(SQC_TB(c0) + SQC_TB(c1) + SQC_TB(c2));
+            if (i0 + j + 1 < nseq) {
                 const u32 x = seqw_window(s_seg, e, segD);     // from the top: LL's bits, ML's, OF's
-                s1 = SQC_BASE(c1) + __builtin_amdgcn_ubfe(x, 0, n1);
-                s2 = SQC_BASE(c2) + __builtin_amdgcn_ubfe(x, n1, n2);
-                s0 = SQC_BASE(c0) + __builtin_amdgcn_ubfe(x, n1 + n2, n0);
-            }
+                s1 = SQC_BASE4(c1) + (__builtin_amdgcn_ubfe(x, 0, n1) << 2);
+                s2 = SQC_BASE4(c2) + (__builtin_amdgcn_ubfe(x, n1, n2) << 2);
+                s0 = SQC_BASE4(c0) + (__builtin_amdgcn_ubfe(x, n1 + n2, n0) << 2);
+            } else e += (i32)(n0 + n1 + n2);                   // (the last sequence leaves the states alone)
         }
+        const uint4 rec = s_rec[lane];
+        const i32 my_e = (i32)rec.x; const u32 my_c0 = rec.y, my_c1 = rec.z, my_c2 = rec.w;
         // pass 2: from the top of a sequence's bits the offset's extra bits, the match length's, the literal length's
         u32 ofv = 4, ll = 1, ml = 0;
         if (lane < nb) {
@@ -1042,19 +1049,18 @@ __device__ __forceinline__ void seq_wave2_block(const u8 *src, ZBlock *blk, u32 
         } else {
             any_rep = true;
             const u32 llz = ll == 0;
+            // (selects in vector registers, every lane the same values: as scalar code the compiler makes a ladder of branches of it, six
+            // taken ones a sequence)
             for (u32 j = 0; j < nb; j++) {
-                const u32 v = __builtin_amdgcn_readlane(ofv, j), z = __builtin_amdgcn_readlane(llz, j);
-                u32 o;
-                if (v > 3) { o = v - 3; r2 = r1; r1 = r0; r0 = o; }
-                else {
-                    const u32 idx = v - 1 + z;
-                    if (idx == 0) o = r0;
-                    else {
-                        o = idx == 3 ? sym_minus1(r0) : (idx == 1 ? r1 : r2);
-                        if (idx > 1) r2 = r1;
-                        r1 = r0; r0 = o;
-                    }
-                }
+                u32 v = __builtin_amdgcn_readlane(ofv, j), idx = v - 1 + __builtin_amdgcn_readlane(llz, j);
+                asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(v), "+v"(idx));
+                const bool isnew = v > 3, i0_ = idx == 0, i1_ = idx == 1, i2_ = idx == 2, sh2 = isnew | (idx >= 2), change = isnew | !i0_;
+                const u32 dec = r0 - 1, m1c = dec ? dec : 1u, m1 = r0 >= SYM_BASE ? r0 + 1 : m1c;      // sym_minus1
+                u32 o = m1;
+                o = i2_ ? r2 : o; o = i1_ ? r1 : o; o = i0_ ? r0 : o; o = isnew ? v - 3 : o;
+                r2 = sh2 ? r1 : r2;
+                r1 = change ? r0 : r1;
+                r0 = o;
                 if (lane == j) off = o;
             }
         }
