@@ -918,10 +918,41 @@ __device__ __forceinline__ u32 seqw_window(const u32 *s_seg, i32 lo, u32 segD)  
     const u32 d = (l >> 5) - segD;
     return __builtin_amdgcn_alignbit(s_seg[d + 1], s_seg[d], l & 31);
 }
+// ---- repeat offsets of a batch of 64 sequences as a scan (3.1.1.5) ---------------------------------------------------------------------
+// A sequence turns the three offsets (r0, r1, r2) into three new ones, each of which is one of the old ones, k times "minus one", or a
+// constant (its own new offset); such a turn after another is a turn of the same kind, so the lanes' turns are composed by a prefix
+// scan (six steps) instead of walked one after the other.  A term: tag = source slot 0 .. 2 (3: the constant `val`) | k << 2.
+struct RepT { u32 tag[3], val[3]; };
+__device__ __forceinline__ u32 rep_minus(u32 x, u32 k) { return x >= SYM_BASE ? x + k : (x > k ? x - k : 1u); }     // sym_minus1, k times
+__device__ __forceinline__ u32 rep_eval(u32 tag, u32 val, u32 r0, u32 r1, u32 r2)
+{
+    const u32 src = tag & 3u, k = tag >> 2;
+    u32 x = r2; x = src == 1 ? r1 : x; x = src == 0 ? r0 : x;
+    const u32 y = rep_minus(x, k);
+    return src == 3 ? val : y;
+}
+// B after A: what B's terms read are A's terms
+__device__ __forceinline__ RepT rep_compose(const RepT &A, const RepT &B)
+{
+    RepT R;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const u32 src = B.tag[i] & 3u, k = B.tag[i] >> 2;
+        u32 at = A.tag[2], av = A.val[2];
+        at = src == 1 ? A.tag[1] : at; av = src == 1 ? A.val[1] : av;
+        at = src == 0 ? A.tag[0] : at; av = src == 0 ? A.val[0] : av;
+        const bool a_const = (at & 3u) == 3u;
+        const u32 cv = av > k ? av - k : 1u;                    // (constants are concrete offsets)
+        const u32 nt = a_const ? at : at + (k << 2), nv = a_const ? cv : av;
+        R.tag[i] = src == 3 ? B.tag[i] : nt; R.val[i] = src == 3 ? B.val[i] : nv;
+    }
+    return R;
+}
 __device__ __forceinline__ void seq_wave2_block(const u8 *src, ZBlock *blk, u32 i, const i32 *own_ll, const i32 *own_of, const i32 *own_ml,
                                                 const u64 *seq_base, const FseE *pool, const FseE *predef,
-                                                u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st, u32 with_predef)
+                                                u32 *o_ll, u32 *o_ml, u32 *o_of, u64 *sizes, ZStat *st, u32 how)
 {
+    const u32 with_predef = how & 1u; const bool rep_walk = (how & 2u) != 0;
     __shared__ u32 s_cell[SEQW_CELLS];
     __shared__ u32 s_seg[SEQW_SEG_DW + 2];
     __shared__ u32 s_llt[36], s_mlt[53];
@@ -1046,10 +1077,37 @@ __device__ __forceinline__ void seq_wave2_block(const u8 *src, ZBlock *blk, u32 
                 }
                 r0 = va;
             }
+        } else if (!rep_walk) {
+            any_rep = true;
+            // every lane's turn, composed with the turns in front of it
+            const bool act = lane < nb, isnew = act && ofv > 3;
+            const u32 idx = act && !isnew ? ofv - 1 + (ll == 0) : 0u;           // (idle lanes and new offsets aside: 0 = nothing moves)
+            RepT P;
+            P.tag[0] = isnew ? 3u : idx == 1 ? 1u : idx == 2 ? 2u : idx == 3 ? (0u | 1u << 2) : 0u; P.val[0] = off;
+            P.tag[1] = (isnew || idx != 0) ? 0u : 1u; P.val[1] = 0;
+            P.tag[2] = (isnew || idx >= 2) ? 1u : 2u; P.val[2] = 0;
+#pragma unroll
+            for (u32 d = 1; d < 64; d <<= 1) {
+                RepT A;
+#pragma unroll
+                for (int i = 0; i < 3; i++) { A.tag[i] = (u32)__shfl_up((int)P.tag[i], d, 64); A.val[i] = (u32)__shfl_up((int)P.val[i], d, 64); }
+                const RepT C = rep_compose(A, P);
+                if (lane >= d) P = C;
+            }
+            // the offsets in force in front of this lane's sequence: the turns of the lanes below, applied to what the batch came in with
+            RepT E;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { E.tag[i] = (u32)__shfl_up((int)P.tag[i], 1, 64); E.val[i] = (u32)__shfl_up((int)P.val[i], 1, 64); if (lane == 0) { E.tag[i] = (u32)i; E.val[i] = 0; } }
+            const u32 b0 = rep_eval(E.tag[0], E.val[0], r0, r1, r2), b1 = rep_eval(E.tag[1], E.val[1], r0, r1, r2), b2 = rep_eval(E.tag[2], E.val[2], r0, r1, r2);
+            u32 o = rep_minus(b0, 1);
+            o = idx == 2 ? b2 : o; o = idx == 1 ? b1 : o; o = idx == 0 ? b0 : o;
+            if (act && !isnew) off = o;
+            const u32 f0 = rep_eval(P.tag[0], P.val[0], r0, r1, r2), f1 = rep_eval(P.tag[1], P.val[1], r0, r1, r2), f2 = rep_eval(P.tag[2], P.val[2], r0, r1, r2);
+            r0 = __builtin_amdgcn_readlane(f0, 63); r1 = __builtin_amdgcn_readlane(f1, 63); r2 = __builtin_amdgcn_readlane(f2, 63);
         } else {
             any_rep = true;
             const u32 llz = ll == 0;
-            // (selects in vector registers, every lane the same values: as scalar code the compiler makes a ladder of branches of it, six
+            // (SEQ_REP=walk, a cross-check of the scan above: one sequence after the other; selects in vector registers, every lane the same values: as scalar code the compiler makes a ladder of branches of it, six
             // taken ones a sequence)
             for (u32 j = 0; j < nb; j++) {
                 u32 v = __builtin_amdgcn_readlane(ofv, j), idx = v - 1 + __builtin_amdgcn_readlane(llz, j);
@@ -3770,7 +3828,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                    (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st);
         else if (own_tabs)
             LAUNCH(c, "zstd_decode_seq", k_decode_seq_wave2, wgrid, 64, 0, d_src, blk, (const u32 *)wave_list, (const i32 *)own_ll, (const i32 *)own_of, (const i32 *)own_ml,
-                   (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st, all_wave);
+                   (const u64 *)seq_cnt, (const FseE *)fse_pool, (const FseE *)c->d_predef, o_ll, o_ml, o_of, sizes, st, all_wave | (ctx_opt_is(c, "SEQ_REP", 'w') ? 2u : 0u));
         if (n_seq_blk) LAUNCH(c, "zstd_rep_fast", k_rep_fast, cdiv(n_seq_blk, 256), 256, 0, blk, (const u32 *)seq_list, n_seq_blk, st);
         if ((rc = scan_exclusive_u64(c, sizes, nblk, d_total_out))) return rc;
         rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;

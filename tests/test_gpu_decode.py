@@ -49,6 +49,19 @@ def test_zstd_decode_golden_frames(gpu, case, executor, monkeypatch):
     assert len(got) == case["len"] and sha(got) == case["sha256"]
 
 
+@pytest.mark.parametrize("lever", [("NAF_GPU_SEQ_WAVE", "l"), ("NAF_GPU_SEQ_WAVE", "all"), ("NAF_GPU_SEQ_REP", "walk")], ids=lambda l: l[0][8:] + "=" + l[1])
+@pytest.mark.parametrize("case", zstd_cases(), ids=lambda c: c["name"])
+def test_zstd_decode_golden_frames_under_the_sequence_walks_kept_as_cross_checks(gpu, case, lever, monkeypatch):
+    """The sequences of a block under tables of its own are walked by k_decode_seq_wave2 (a branch-free chain over the state bits, a lane
+    per sequence for the values, the repeat offsets as a prefix scan of the sequences' turns).  Kept beside it: the single-lane walk
+    (SEQ_WAVE=l), the same kernel for blocks under the predefined tables too (SEQ_WAVE=all), the repeat offsets one sequence after the
+    other (SEQ_REP=walk) -- every golden frame must come out the same under each."""
+    monkeypatch.setenv(*lever)
+    frame = golden_bytes("zstd", case["name"] + ".zst")
+    got = host(gpu.zstd_decompress(gpu.to_device(frame), case["len"] + 64))
+    assert len(got) == case["len"] and sha(got) == case["sha256"]
+
+
 def test_zstd_decode_matches_oracle_on_naf_sections(gpu, oracle):
     for case in naf_cases():
         naf = golden_bytes("naf", case["name"] + ".naf")
