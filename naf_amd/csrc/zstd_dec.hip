@@ -2638,10 +2638,16 @@ __global__ __launch_bounds__(64) void k_lz_prep(const ZBlock *blk, const u32 *se
 #define LZ_UNIT 1024u
 // (the collapse has units of its own: 8192 sequences -- 96 KB of LDS, a workgroup of 256 per CU -- because what it leaves is a link per unit
 // edge, and a frame that is one chain, a counter's names through every block, is then as long as its unit edges are many)
-#define LZ_CUNIT 8192u
-#define LZ_CWG 1024u
+// (two shapes: 8192 sequences by 1024 threads, 96 KB of LDS -- a CU to itself -- for the frames that are chains; 1024 by a single wavefront
+// and 12 KB for every other frame, because a workgroup that needs sixteen wave slots and most of a CU's LDS AT ONCE does not get in beside a
+// long-running kernel: in the decode of the reference's archive of 10 GB the job's collapse waited 1.6 ms for the flat emit to end, §4.32)
+#define LZ_CUNIT_BIG 8192u
+#define LZ_CWG_BIG 1024u
+#define LZ_CUNIT_SMALL 1024u
+#define LZ_CWG_SMALL 64u
 #define LZ_DEPS_PARTS 8u
 #define LZ_FAR_ROUNDS 14u
+template <u32 LZ_CUNIT, u32 LZ_CWG>
 __global__ __launch_bounds__(LZ_CWG) void k_lz_collapse(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A, u32 *hops)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lzc[];              // s_dst | s_ml | s_src, LZ_CUNIT each
@@ -2704,6 +2710,7 @@ __global__ __launch_bounds__(LZ_CWG) void k_lz_collapse(const ZBlock *blk, const
 // Only for frames that are chains (most MATCHES moved their source within their unit: hops[0] -- a `-3 --long 27` genome, where every
 // unit has a few that do, paid 6.9 ms here to save 3 in the executor).  Sources in other units than those two keep
 // their links: k_lz_exec works them off as before.
+template <u32 LZ_CUNIT>
 __device__ __forceinline__ void lz_locate_unit(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, u64 u, u32 &t, u32 &s_first, u32 &cnt)
 {
     t = 0;
@@ -2714,6 +2721,7 @@ __device__ __forceinline__ void lz_locate_unit(const ZBlock *blk, const u32 *seq
     cnt = s_first >= nseq ? 0u : (nseq - s_first < LZ_CUNIT ? nseq - s_first : LZ_CUNIT);
 }
 #define LZ_FAR_TARGETS 4u
+template <u32 LZ_CUNIT, u32 LZ_CWG>
 __global__ __launch_bounds__(LZ_CWG) void k_lz_collapse_far(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *unit_base, const u64 *n_units, LzArrays A, u32 *hops, u64 ns_total)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lzc[];              // s_dst | s_ml | s_of of the staged unit, LZ_CUNIT each
@@ -2724,7 +2732,7 @@ __global__ __launch_bounds__(LZ_CWG) void k_lz_collapse_far(const ZBlock *blk, c
     const u64 u = blockIdx.x, nu = *n_units;
     if (u >= nu) return;
     if (4 * (u64)hops[0] < ns_total) return;                     // worth it for frames that are chains: a quarter of the matches and more moved their source within their unit (names that count: 57 %; a genome's repeats: under 1 %)
-    u32 t, s_first, cnt; lz_locate_unit(blk, seq_list, n_seq_blk, unit_base, u, t, s_first, cnt);
+    u32 t, s_first, cnt; lz_locate_unit<LZ_CUNIT>(blk, seq_list, n_seq_blk, unit_base, u, t, s_first, cnt);
     if (!cnt) return;
     const ZBlock &b = blk[seq_list[t]];
     const u64 sbase = b.seq_base + s_first, B_u = b.out_off;
@@ -2772,7 +2780,7 @@ __global__ __launch_bounds__(LZ_CWG) void k_lz_collapse_far(const ZBlock *blk, c
                 const u64 T = T0 + pass;
                 if (T > u) break;                                // (the unit itself is a target like any other: a match in front of this one that has moved since)
                 if (threadIdx.x == 0) {
-                    u32 t2, sf2, c2; lz_locate_unit(blk, seq_list, n_seq_blk, unit_base, T, t2, sf2, c2);
+                    u32 t2, sf2, c2; lz_locate_unit<LZ_CUNIT>(blk, seq_list, n_seq_blk, unit_base, T, t2, sf2, c2);
                     s_geo[0] = t2; s_geo[1] = sf2; s_geo[2] = c2;
                 }
                 __syncthreads();
@@ -3051,17 +3059,25 @@ static int launch_lz_exec(naf_gpu_ctx *c, const ZBlock *blk, const u32 *seq_list
     LAUNCH(c, "zstd_lz_units", k_lz_units, cdiv(nx, 64), 64, 0, blk, seq_list, nx, LZ_UNIT, units);
     int rc = scan_exclusive_u64(c, units, nx, units + nx + 1); if (rc) return rc;
     const u32 grid = (u32)(ns_total / LZ_UNIT + nx + 1);                     // (an upper bound known without a read-back: wavefronts behind the last unit leave at once)
-    if (!ctx_opt_is(c, "EXEC_COLLAPSE", '0')) {
-        LAUNCH(c, "zstd_lz_units", k_lz_units, cdiv(nx, 64), 64, 0, blk, seq_list, nx, LZ_CUNIT, cunits);
+    // (a frame of a few thousand sequences has no chain worth four launches: the few matches of a random genome's frame)
+    if (!ctx_opt_is(c, "EXEC_COLLAPSE", '0') && (ns_total >= 16384 || ctx_opt_is(c, "EXEC_COLLAPSE", 's'))) {
+        // the shape by the sequences a block holds on average: a frame that is a chain of copies is matches and little else
+        const bool big = ns_total / nx >= 4096 && !ctx_opt_is(c, "EXEC_COLLAPSE", 's');
+        const u32 cunit = big ? LZ_CUNIT_BIG : LZ_CUNIT_SMALL, cwg = big ? LZ_CWG_BIG : LZ_CWG_SMALL, clds = 3 * cunit * 4;
+        LAUNCH(c, "zstd_lz_units", k_lz_units, cdiv(nx, 64), 64, 0, blk, seq_list, nx, cunit, cunits);
         if ((rc = scan_exclusive_u64(c, cunits, nx, cunits + nx + 1))) return rc;
-        HIP_TRY(c, hipFuncSetAttribute((const void *)k_lz_collapse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * LZ_CUNIT * 4)));
-        const u32 cgrid = (u32)(ns_total / LZ_CUNIT + nx + 1);
+        const u32 cgrid = (u32)(ns_total / cunit + nx + 1);
         u32 *hops = arena_new<u32>(c, LZ_FAR_ROUNDS + 2); if (!hops) return NAF_GPU_ENOMEM;
         HIP_TRY(c, hipMemsetAsync(hops, 0, (LZ_FAR_ROUNDS + 2) * 4, c->stream));
-        LAUNCH(c, "zstd_lz_collapse", k_lz_collapse, cgrid, LZ_CWG, 3 * LZ_CUNIT * 4, blk, seq_list, nx, (const u64 *)cunits, (const u64 *)(cunits + nx + 1), A, hops);
+        if (big) {
+            HIP_TRY(c, hipFuncSetAttribute((const void *)k_lz_collapse<LZ_CUNIT_BIG, LZ_CWG_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+            LAUNCH(c, "zstd_lz_collapse", (k_lz_collapse<LZ_CUNIT_BIG, LZ_CWG_BIG>), cgrid, cwg, clds, blk, seq_list, nx, (const u64 *)cunits, (const u64 *)(cunits + nx + 1), A, hops);
+        } else LAUNCH(c, "zstd_lz_collapse", (k_lz_collapse<LZ_CUNIT_SMALL, LZ_CWG_SMALL>), cgrid, cwg, clds, blk, seq_list, nx, (const u64 *)cunits, (const u64 *)(cunits + nx + 1), A, hops);
         if (!ctx_opt_is(c, "EXEC_COLLAPSE", 'n')) {                       // ('n': within units only)
-            HIP_TRY(c, hipFuncSetAttribute((const void *)k_lz_collapse_far, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * LZ_CUNIT * 4)));
-            LAUNCH(c, "zstd_lz_collapse_far", k_lz_collapse_far, cgrid, LZ_CWG, 3 * LZ_CUNIT * 4, blk, seq_list, nx, (const u64 *)cunits, (const u64 *)(cunits + nx + 1), A, hops, ns_total);
+            if (big) {
+                HIP_TRY(c, hipFuncSetAttribute((const void *)k_lz_collapse_far<LZ_CUNIT_BIG, LZ_CWG_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+                LAUNCH(c, "zstd_lz_collapse_far", (k_lz_collapse_far<LZ_CUNIT_BIG, LZ_CWG_BIG>), cgrid, cwg, clds, blk, seq_list, nx, (const u64 *)cunits, (const u64 *)(cunits + nx + 1), A, hops, ns_total);
+            } else LAUNCH(c, "zstd_lz_collapse_far", (k_lz_collapse_far<LZ_CUNIT_SMALL, LZ_CWG_SMALL>), cgrid, cwg, clds, blk, seq_list, nx, (const u64 *)cunits, (const u64 *)(cunits + nx + 1), A, hops, ns_total);
             if (ctx_tracing(c)) {
                 u32 hh[LZ_FAR_ROUNDS + 2]; if ((rc = ctx_readback(c, hh, hops, sizeof hh))) return rc;
                 ctx_trace(c, "[lz] matches that moved their source within their unit: %u of %llu sequences; units by the rounds they took across units (1, 2, ...):", hh[0], (unsigned long long)ns_total);

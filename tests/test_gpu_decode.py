@@ -29,7 +29,7 @@ def host(t):
     return t.cpu().numpy().tobytes()
 
 
-@pytest.mark.parametrize("executor", ["auto", "hbm", "hbm-nearcollapse", "hbm-nocollapse", "batch", "serial"])
+@pytest.mark.parametrize("executor", ["auto", "hbm", "hbm-smallcollapse", "hbm-nearcollapse", "hbm-nocollapse", "batch", "serial"])
 @pytest.mark.parametrize("case", zstd_cases(), ids=lambda c: c["name"])
 def test_zstd_decode_golden_frames(gpu, case, executor, monkeypatch):
     """libzstd-made frames (every level, long windows, multi-threaded, streaming): frames whose blocks regenerate at most 16 KiB
@@ -41,6 +41,8 @@ def test_zstd_decode_golden_frames(gpu, case, executor, monkeypatch):
         monkeypatch.setenv("NAF_GPU_EXEC_COLLAPSE", "0")
     if executor == "hbm-nearcollapse":                        # within units only (k_lz_collapse without k_lz_collapse_far)
         monkeypatch.setenv("NAF_GPU_EXEC_COLLAPSE", "n")
+    if executor == "hbm-smallcollapse":                       # units of 1024 sequences by single wavefronts whatever the frame
+        monkeypatch.setenv("NAF_GPU_EXEC_COLLAPSE", "s")
     if executor in ("batch", "serial"):
         monkeypatch.setenv("NAF_GPU_EXEC", executor)
     frame = golden_bytes("zstd", case["name"] + ".zst")
@@ -1076,7 +1078,7 @@ def test_reference_archive_of_reads_whose_names_copy_each_other(gpu, oracle, mon
     naf = O.ref_ennaf(text, ("--fastq",))
     want = O.ref_unnaf(naf)
     d_naf = gpu.to_device(naf)
-    for how, collapse in (("dataflow", "1"), ("dataflow", "n"), ("dataflow", "0"), ("batch", "1")):
+    for how, collapse in (("dataflow", "1"), ("dataflow", "s"), ("dataflow", "n"), ("dataflow", "0"), ("batch", "1")):
         monkeypatch.setenv("NAF_GPU_EXEC", how); monkeypatch.setenv("NAF_GPU_EXEC_COLLAPSE", collapse)
         assert host(gpu.unnaf(d_naf, capi.OUT_FASTQ)) == want, (how, collapse)
         for mode, args in ((capi.OUT_FASTA, ("--fasta",)),):
