@@ -896,11 +896,11 @@ __global__ __launch_bounds__(64) void k_decode_seq_wave(const u8 *src, ZBlock *b
 // sequence's bits only the three STATE fields are on that chain -- the extra bits of the offset, match length and literal length are
 // skipped by their count, which a cell can carry (SQC_TB: state bits + the extra bits that belong to its symbol).  So:
 //   pass 1, the chain, branch-free: three cells (one LDS read each), the end of the unread bits e -= extra bits + state bits, one
-//     32-bit window of the stream at e (two dwords of the segment staged in LDS, v_alignbit), three bit fields, three additions.  Every
-//     lane runs it on the same values; lane j keeps what sequence j of the batch started from (e and the three cells);
+//     32-bit window of the stream at e (two dwords of the segment staged in LDS, v_alignbit), three bit fields, three shift-adds.  Every
+//     lane runs it on the same values; what sequence j of the batch started from (e and the three cells) goes to row j of s_rec;
 //   pass 2, a lane per sequence: the extra bits out of two windows, the values, coalesced stores;
-//   the repeat offsets: a batch without repeat codes (ballot) shifts its last three offsets in; one with them is walked in scalar
-//     registers (v_readlane by a uniform index, s_cselect).
+//   the repeat offsets: a batch without repeat codes (ballot) shifts its last three offsets in; one whose codes are all "the last offset
+//     again" takes the last new offset in front of each lane; any other batch composes its sequences' turns by a prefix scan (rep_compose).
 // The bit stream is staged 2 KB at a time (a batch of 64 sequences reads at most 64 x 89 bits of it), as aligned dwords counted from
 // the aligned address below the stream's start; positions are bit indices from there, the stream read downwards (RFC 8878 4.1).
 // a cell: the next state's base as a BYTE offset into its table (states are kept that way: no shift in front of a cell read), the
