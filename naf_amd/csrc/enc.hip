@@ -501,12 +501,11 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
 // position of the last line end and the lattice test need no LDS and no barrier.  A tile that is not pure (it starts in a header, is
 // not wholly inside the text, or holds anything but plain letters and line ends) is left to k_enc_count (t_needf / t_need).
 // one tile of k_enc_count_pure: v = the tile's bytes, sixteen per lane and quarter (loaded by the caller when `inside`)
-__device__ __forceinline__ void count_pure_tile(const EncP &P, const i64 *tile_eol, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
-                                                u32 *t_needf, u64 *t_need, u64 t, bool inside, const uint4 (&v)[4])
+struct PureTile { bool pure, ok, acgt, any; u32 p1, period, E, lastpos; };      // pure: the tables are written; ok: regular (t_reg != 0); any: it holds a line end
+// the plain test of a tile's 4 x 16 bytes per lane: line ends per quarter, N and lower case seen (wave-uniform verdict)
+__device__ __forceinline__ bool plain_tile(const EncP &P, const uint4 (&v)[4], u32 (&eol)[4], bool &acgt, bool &lower_any)
 {
-    const u32 lane = threadIdx.x & 63;
-    if (!inside || !tile_may_be_pure(P, tile_eol, t)) { if (lane == 0) { t_needf[t] = 1; t_need[t] = 1; } return; }
-    u32 eol[4]; bool plain = true; u32 has_n = 0, lower = 0;
+    bool plain = true; u32 has_n = 0, lower = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const u32 w[4] = { v[k].x, v[k].y, v[k].z, v[k].w }; plain = piece_plain(w, P.plo, P.phi, &eol[k]) && plain;
@@ -515,9 +514,16 @@ __device__ __forceinline__ void count_pure_tile(const EncP &P, const i64 *tile_e
         // ... and only lower-case letters have bits 5 and 6 (line ends have neither 6 nor 7)
         lower |= ((w[0] >> 5) & (w[0] >> 6)) | ((w[1] >> 5) & (w[1] >> 6)) | ((w[2] >> 5) & (w[2] >> 6)) | ((w[3] >> 5) & (w[3] >> 6));
     }
-    if (__ballot(!plain) != 0) { if (lane == 0) { t_needf[t] = 1; t_need[t] = 1; } return; }
-    note_case(P, (lower & 0x01010101u) != 0);
-    const bool acgt = __ballot((has_n & 0x01010101u) != 0) == 0;
+    if (__ballot(!plain) != 0) return false;
+    lower_any = (lower & 0x01010101u) != 0;
+    acgt = __ballot((has_n & 0x01010101u) != 0) == 0;
+    return true;
+}
+// counts, last line end and lattice of a plain tile from its line-end bits; writes the tile's table entries
+__device__ __forceinline__ PureTile count_plain_tile(const EncP &P, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
+                                                     u32 *t_needf, u64 *t_need, u64 t, const u32 (&eol)[4], bool acgt)
+{
+    const u32 lane = threadIdx.x & 63;
     u32 E = 0, nbytes = 0, p1 = 0, period = 0, prev_last = 0, lastpos = 0; bool any = false, two = false, lat_ok = true;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -542,15 +548,27 @@ __device__ __forceinline__ void count_pure_tile(const EncP &P, const i64 *tile_e
         if (__ballot(has && (any || mlow) && q - qprev != period) != 0) lat_ok = false;
         any = true; prev_last = ql; E += cnt;
     }
+    // (the gather of the scatter pass reads up to 17 bytes from a base's position: not in the text's last tiles)
+    const bool tile_ok = lat_ok && !two && E >= 2 && period >= 33 && (t + 1) * ET_TILE + 32 <= P.n;
     if (lane == 0) {
-        // (the gather of the scatter pass reads up to 17 bytes from a base's position: not in the text's last tiles)
-        const bool tile_ok = lat_ok && !two && E >= 2 && period >= 33 && (t + 1) * ET_TILE + 32 <= P.n;
         t_reg[t] = tile_ok ? (p1 | (period << 12) | (E << 24) | (acgt ? REG_ACGT : 0u)) : 0u; t_irr[t] = tile_ok ? 0 : 1;
         const u32 tot = ET_TILE - nbytes;
         t_seq[t] = tot; t_ids[t] = 0; t_cmt[t] = 0; t_rec[t] = 0;
         t_tail[t] = any ? ((ET_TILE - 1 - lastpos) | 0x80000000u) : tot;
         t_needf[t] = 0; t_need[t] = 0;
     }
+    PureTile r; r.pure = true; r.ok = tile_ok; r.acgt = acgt; r.any = any; r.p1 = p1; r.period = period; r.E = E; r.lastpos = lastpos;
+    return r;
+}
+__device__ __forceinline__ void count_pure_tile(const EncP &P, const i64 *tile_eol, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
+                                                u32 *t_needf, u64 *t_need, u64 t, bool inside, const uint4 (&v)[4])
+{
+    const u32 lane = threadIdx.x & 63;
+    if (!inside || !tile_may_be_pure(P, tile_eol, t)) { if (lane == 0) { t_needf[t] = 1; t_need[t] = 1; } return; }
+    u32 eol[4]; bool acgt = false, lower_any = false;
+    if (!plain_tile(P, v, eol, acgt, lower_any)) { if (lane == 0) { t_needf[t] = 1; t_need[t] = 1; } return; }
+    note_case(P, lower_any);
+    count_plain_tile(P, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, t, eol, acgt);
 }
 // TW tiles per wavefront, the loads of all of them in flight before the first is looked at (two measured slower than one: 2.23 -> 2.55 ms
 // per 10 GB, the call 8.0 -> 8.2 ms)
@@ -575,6 +593,98 @@ __global__ __launch_bounds__(64 * WPW) void k_enc_count_pure(EncP P, const i64 *
     }
 #pragma unroll
     for (u32 j = 0; j < TW; j++) if (t0 + j < tiles) count_pure_tile(P, tile_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, t0 + j, inside[j], v[j]);
+}
+// ---- ONE pass over the text (process.c:358-427 with encode_dna, encoders.c:30-69, touches an input byte once; so does this).
+// A whole 4-bit FASTA input at level 1 (the inputs that may have DIRECT blocks, see direct_word): the count pass of a tile that turns out
+// plain, regular and made of A C G T / U only has everything it needs to CODE the tile's bases -- two bits a base, the final Huffman code
+// of a direct block -- except where they go: that is the scan of the counts.  So it writes them at TILE-LOCAL positions (base i of the
+// tile in bits 2i, 2i + 1 of the tile's KiB of `loc`), and the kernel that moves a direct block's streams to their place in the frame
+// anyway (zstd_enc.hip: k_zenc_write_direct_loc) gathers them by the scanned counts with a funnel shift at the tile seams.  The text is
+// read once; tiles of blocks that are not direct (an N, a header, a probed MiB, few line ends) are packed by the scatter kernels as
+// before (EncOut::loc_mode: only those).  The kernel also leaves every tile's last line end / blank (k_enc_last_fa's tables): the
+// look at the line in front of a tile (tile_may_be_pure) needs their scan, so it comes behind the pass (k_pure_check) and hands the
+// few tiles that begin in a header line to k_enc_count.
+#define LOC_TILE 1024
+// two bits per base: log2 of its one-hot 4-bit code (T 0, G 1, C 2, A 3; tables.c:189-197) from bits 1..2 of the letter (A 0, C 1, T / U 2, G 3),
+// four letters -> eight bits, the first letter lowest
+__device__ __forceinline__ u32 code2x4(u32 x) { const u32 y = (x >> 1) & 0x03030303u; return swar_dot4(y ^ 0x03030303u ^ ((y >> 1) & 0x01010101u), 0x40100401u, 0); }
+__device__ __forceinline__ u32 last_pos_pair(u32 eol, u32 sp, u32 at)
+{
+    return (eol ? at + 1 + (31 - __clz((int)eol)) : 0u) | ((sp ? at + 1 + (31 - __clz((int)sp)) : 0u) << 16);
+}
+template <bool LOC>
+__global__ __launch_bounds__(64) void k_enc_fused(EncP P, i64 *tile_eol, i64 *tile_sp, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
+                                                  u32 *t_needf, u64 *t_need, u64 tiles, u8 *loc)
+{
+    __shared__ __attribute__((aligned(16))) u8 s_tile[LOC ? ET_TILE + 32 : 16];
+    const u32 lane = threadIdx.x;
+    const u64 t = blockIdx.x;
+    if (t >= tiles) return;
+    const u64 tb = t * ET_TILE;
+    const bool inside = tb >= P.p0 && tb + ET_TILE <= P.n;
+    uint4 v[4];
+    if (inside) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) __builtin_memcpy(&v[k], P.text + tb + (64u * (u32)k + lane) * ET_BYTES, 16);
+    }
+    u32 eol[4]; bool acgt = false, lower_any = false;
+    if (!inside || !plain_tile(P, v, eol, acgt, lower_any)) {
+        // not k_enc_count_pure's: its last line end and blank (all byte classes), the rest is k_enc_count's
+        u32 pp = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 at = (64u * (u32)k + lane) * ET_BYTES;
+            PMask pm;
+            if (inside) { const u32 w[4] = { v[k].x, v[k].y, v[k].z, v[k].w }; const PieceFlags f = piece_flags(w); pm.eol = f.eol; pm.sp = f.sp; }
+            else { const Piece pc = load_piece(P, tb + at); pm = piece_masks(pc); }
+            pp = OpPkMaxU16::f<u32>(pp, last_pos_pair(pm.eol, pm.sp, at));
+        }
+        pp = (u32)__builtin_amdgcn_readlane((int)wave_scan_inclusive<u32, OpPkMaxU16>(pp), 63);
+        if (lane == 0) {
+            tile_eol[t] = (pp & 0xFFFF) ? (i64)(tb + (pp & 0xFFFF) - 1) : -1; tile_sp[t] = (pp >> 16) ? (i64)(tb + (pp >> 16) - 1) : -1;
+            t_needf[t] = 1; t_need[t] = 1;
+        }
+        return;
+    }
+    note_case(P, lower_any);
+    const PureTile r = count_plain_tile(P, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, t, eol, acgt);
+    if (lane == 0) { const i64 le = r.any ? (i64)(tb + r.lastpos) : -1; tile_eol[t] = le; tile_sp[t] = le; }   // (a plain tile's blanks are its line ends)
+    if (!LOC || !r.ok || !r.acgt) return;
+    // the tile's bases, two bits each, in order: lane l codes bases 64 l .. 64 l + 63 (four groups of 16) from the tile staged in LDS
+#pragma unroll
+    for (int k = 0; k < 4; k++) *(uint4 *)(s_tile + (64u * (u32)k + lane) * ET_BYTES) = v[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const u32 W = r.period - 1, nb = ET_TILE - r.E;
+    const float rW = 1.0f / (float)W;
+    u32 wd[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const u32 b_lo = 64u * lane + 16u * (u32)g;
+        wd[g] = 0;
+        if (b_lo < nb) {
+            u32 x, e;                                                 // text position of base b_lo; bases from it to the next line end
+            if (b_lo < r.p1) { x = b_lo; e = r.p1 - b_lo; }
+            else {
+                const u32 d = b_lo - r.p1;
+                u32 k = (u32)((float)d * rW);
+                if (k * W > d) k--; else if ((k + 1) * W <= d) k++;
+                x = b_lo + 1 + k; e = W - (d - k * W);
+            }
+            const u32 *sp = (const u32 *)(s_tile + (x & ~3u));
+            const u64 c40 = (u64)(code2x4(sp[0]) | (code2x4(sp[1]) << 8) | (code2x4(sp[2]) << 16) | (code2x4(sp[3]) << 24)) | ((u64)code2x4(sp[4]) << 32);
+            u64 c = c40 >> (2u * (x & 3u));                           // 17 bytes from x on: the group's 16 bases and, when e < 16, its line end
+            if (e < 16) { const u64 lowm = (1ull << (2u * e)) - 1; c = (c & lowm) | ((c >> 2) & ~lowm); }
+            wd[g] = (u32)c;
+        }
+    }
+    *(uint4 *)(loc + t * LOC_TILE + lane * 16u) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+}
+// behind the scan of the last line ends: a tile k_enc_fused took for pure that begins in a header line is k_enc_count's after all
+__global__ void k_pure_check(EncP P, const i64 *tile_eol, u64 tiles, u32 *t_needf, u64 *t_need, u32 *t_reg, u64 *t_irr)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles || t_needf[t]) return;
+    if (!tile_may_be_pure(P, tile_eol, t)) { t_needf[t] = 1; t_need[t] = 1; t_reg[t] = 0; t_irr[t] = 1; }
 }
 __global__ void k_need_list(const u32 *t_needf, const u64 *pre, u64 tiles, u32 *list, const u32 *t_reg = nullptr)
 {
@@ -615,6 +725,9 @@ struct EncOut {
                                   // bit 31 (k_enc_count_pure): and its letters are A C G T / U only
     const u8 *direct; u32 nd;     // DIRECT blocks (k_direct_blocks; nullptr: none): block b < nd of 32 KiB of the packed stream takes its
                                   // four Huffman streams of 4-bit codes straight from the scatter pass (direct_word), never its packed bytes
+    u32 loc_mode;                 // 1: the direct blocks' codes were left by k_enc_fused (tile-local, `loc`): the scatter kernels pack only what lies
+                                  // in the other blocks
+    const u32 *sparse_list; const u32 *n_sparse;   // loc_mode: the regular tiles that reach into a block that is not direct (k_sparse_list)
 };
 
 
@@ -705,7 +818,7 @@ __device__ __forceinline__ void flush_pack(const EncP &P, u8 *packed, u32 *caseb
 //   - it is not in a region the level-1 look at the stream reads (zenc_repeat_probe: 1 MiB in every 64, as PACKED bytes).
 // t_seq is the exclusive scan of the tiles' base counts with the total behind it.
 #define DIRECT_PROBE_BLOCKS_LOG 5                                 // 32 blocks of 32 KiB per probed MiB, one MiB in 2^6
-__global__ __launch_bounds__(256) void k_direct_blocks(const u8 *text, const u64 *t_seq, const u32 *t_reg, u64 tiles, u32 nd, u32 prefer_flat, int probed, u8 *direct)
+__global__ __launch_bounds__(256) void k_direct_blocks(const u8 *text, const u64 *t_seq, const u32 *t_reg, u64 tiles, u32 nd, u32 prefer_flat, int probed, u8 *direct, u32 *blk_t0 = nullptr)
 {
     __shared__ u32 bins[4][64];                                   // 4 copies x 16 bins per wave
     const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -763,7 +876,7 @@ __global__ __launch_bounds__(256) void k_direct_blocks(const u8 *text, const u64
         ns = (u32)__shfl((int)ns, 0, 64); h = __shfl(h, 0, 64);
         ok = ns >= 1024 && h * (float)prefer_flat > 4.0f * (float)ns * (float)(prefer_flat - 1);
     }
-    if (b < nd && lane == 0) direct[b] = ok ? 1 : 0;
+    if (b < nd && lane == 0) { direct[b] = ok ? 1 : 0; if (blk_t0) blk_t0[b] = (u32)t0; }   // (blk_t0: the tile that holds the block's first base, for k_zenc_write_direct_loc)
 }
 // the tiles k_enc_count did not find regular, in order (pre = exclusive scan of its 0 / 1 verdicts)
 __global__ void k_irregular_list(const u32 *t_reg, const u64 *pre, u64 tiles, u32 *list)
@@ -772,7 +885,7 @@ __global__ void k_irregular_list(const u32 *t_reg, const u64 *pre, u64 tiles, u3
     if (t < tiles && !t_reg[t]) list[pre[t]] = (u32)t;
 }
 // the groups a tile shares with its neighbours (and the last group of the stream, whose padding must read as zero)
-__global__ void k_pack_edges_zero(const u64 *t_seq, u64 tiles, u64 T, u8 *packed, u32 *casebits, const u8 *direct, u32 nd)
+__global__ void k_pack_edges_zero(const u64 *t_seq, u64 tiles, u64 T, u8 *packed, u32 *casebits, const u8 *direct, u32 nd, u32 loc_mode = 0)
 {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tiles) return;
@@ -781,6 +894,11 @@ __global__ void k_pack_edges_zero(const u64 *t_seq, u64 tiles, u64 T, u8 *packed
     const u64 g0 = b0 >> 4, g1 = (b1 - 1) >> 4;
     // (a group of a direct block is one word of its stream, see direct_word)
     const bool d0 = direct && (g0 >> 12) < nd && direct[g0 >> 12], d1 = direct && (g1 >> 12) < nd && direct[g1 >> 12];
+    if (loc_mode) {                                               // (a direct block's codes are not in `packed` at all)
+        if (!d0) *(u64 *)(packed + 8 * g0) = 0;
+        if (!d1) *(u64 *)(packed + 8 * g1) = 0;
+        return;                                                   // (loc_mode: no case bits)
+    }
     if (d0) *((u32 *)(packed + ((g0 >> 12) << 15) + (((g0 >> 10) & 3) << 12)) + (1023u - (u32)(g0 & 1023u))) = 0; else *(u64 *)(packed + 8 * g0) = 0;
     if (d1) *((u32 *)(packed + ((g1 >> 12) << 15) + (((g1 >> 10) & 3) << 12)) + (1023u - (u32)(g1 & 1023u))) = 0; else *(u64 *)(packed + 8 * g1) = 0;
     if (casebits) { ((u16 *)casebits)[g0] = 0; ((u16 *)casebits)[g1] = 0; }
@@ -915,6 +1033,7 @@ __device__ __forceinline__ bool direct_group(const EncOut &O, u64 G) { const u64
 __device__ __forceinline__ void reg_group_store(const EncOut &O, u64 G, const RegGroup &g, u64 pk, u32 cb)
 {
     if (direct_group(O, G)) {
+        if (O.loc_mode) return;
         if (g.ga == 0 && g.gb == 16) { *direct_word(O.packed, G) = direct_code32(pk); if (O.casebits) ((u16 *)O.casebits)[G] = (u16)cb; }
         else {
             const u64 nm = (g.gb == 16 ? ~0ull : ((1ull << (4 * g.gb)) - 1)) & ~((1ull << (4 * g.ga)) - 1);
@@ -934,16 +1053,11 @@ __device__ __forceinline__ void reg_group_store(const EncOut &O, u64 G, const Re
         if (O.casebits) atomicOr(O.casebits + (G >> 1), cb << (16 * (u32)(G & 1)));
     }
 }
-template <u32 TPW>
-__global__ __launch_bounds__(64 * TPW) void k_enc_scatter_regular(EncP P, const i64 *tile_eol, EncOut O, u64 tiles)
+__device__ __forceinline__ void scatter_regular_tile(const EncP &P, const i64 *tile_eol, const EncOut &O, u64 t, u64 *spk, u16 *scb)
 {
     // per wavefront: the tile's packed groups and case bits on their way from "a group per lane" (loads of neighbouring lanes touch
     // neighbouring bytes) to "four groups per lane" (wide stores); slot = group index inside the tile + lead
-    __shared__ __attribute__((aligned(16))) u64 s_pk[TPW][264];
-    __shared__ __attribute__((aligned(16))) u16 s_cb[TPW][264];
-    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const u64 t = (u64)blockIdx.x * TPW + wv;                          // the wavefront's tile
-    if (t >= tiles) return;
+    const u32 lane = threadIdx.x & 63;
     const u32 reg = O.t_reg[t];
     const u64 tb = O.t_seq[t];
     if (!reg) return;
@@ -954,7 +1068,6 @@ __global__ __launch_bounds__(64 * TPW) void k_enc_scatter_regular(EncP P, const 
     const u32 nq = (lead + ng + 3) >> 2;
     const float rW = 1.0f / (float)W;
     const u8 *tt = P.text + t * ET_TILE;
-    u64 *spk = s_pk[wv]; u16 *scb = s_cb[wv];
     // phase 1: geometry and loads of groups lane, lane + 64, lane + 128, lane + 192 (all in flight together)
     RegGroup g[4]; u64 lo[4], hi[4]; u32 c16[4]; bool in[4];
 #pragma unroll
@@ -991,7 +1104,8 @@ __global__ __launch_bounds__(64 * TPW) void k_enc_scatter_regular(EncP P, const 
         const bool dq = direct_group(O, Gq0 + s0);                      // (a quad lies in one stream of one block)
         if (whole) {
             const uint4 a = *(const uint4 *)(spk + s0), b2 = *(const uint4 *)(spk + s0 + 2);
-            if (dq) {
+            if (dq && O.loc_mode) { }
+            else if (dq) {
                 // the quad's four words, the last group first
                 const uint4 cw = make_uint4(direct_code32((u64)b2.z | ((u64)b2.w << 32)), direct_code32((u64)b2.x | ((u64)b2.y << 32)),
                                             direct_code32((u64)a.z | ((u64)a.w << 32)), direct_code32((u64)a.x | ((u64)a.y << 32)));
@@ -1005,7 +1119,7 @@ __global__ __launch_bounds__(64 * TPW) void k_enc_scatter_regular(EncP P, const 
 #pragma unroll
             for (u32 i = 0; i < 4; i++) {
                 const u32 sl = s0 + i;
-                if (sl >= lead + j_first_whole && sl < lead + j_end_whole) {
+                if (sl >= lead + j_first_whole && sl < lead + j_end_whole && !(dq && O.loc_mode)) {
                     if (dq) *direct_word(O.packed, Gq0 + sl) = direct_code32(spk[sl]); else *(u64 *)(O.packed + 8 * (Gq0 + sl)) = spk[sl];
                     if (O.casebits) ((u16 *)O.casebits)[Gq0 + sl] = scb[sl];
                 }
@@ -1025,6 +1139,59 @@ __global__ __launch_bounds__(64 * TPW) void k_enc_scatter_regular(EncP P, const 
         }
         if (len > __atomic_load_n(O.longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)O.longest, (unsigned long long)len);
     }
+}
+template <u32 TPW>
+__global__ __launch_bounds__(64 * TPW) void k_enc_scatter_regular(EncP P, const i64 *tile_eol, EncOut O, u64 tiles)
+{
+    __shared__ __attribute__((aligned(16))) u64 s_pk[TPW][264];
+    __shared__ __attribute__((aligned(16))) u16 s_cb[TPW][264];
+    const u32 wv = threadIdx.x >> 6;
+    const u64 t = (u64)blockIdx.x * TPW + wv;                          // the wavefront's tile
+    if (t >= tiles) return;
+    scatter_regular_tile(P, tile_eol, O, t, s_pk[wv], s_cb[wv]);
+}
+// loc_mode: the regular tiles that reach into a block that is not direct, from k_sparse_list's list (a bounded grid walks it)
+__global__ __launch_bounds__(64) void k_enc_scatter_regular_list(EncP P, const i64 *tile_eol, EncOut O)
+{
+    __shared__ __attribute__((aligned(16))) u64 s_pk[264];
+    __shared__ __attribute__((aligned(16))) u16 s_cb[264];
+    const u32 n = *O.n_sparse;
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        scatter_regular_tile(P, tile_eol, O, O.sparse_list[i], s_pk, s_cb);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+// loc_mode: which regular tiles the scatter pass still has to pack (order does not matter), and the longest line of ALL regular tiles
+// (scatter_regular_tile's last step, which most of them no longer reach)
+__global__ __launch_bounds__(256) void k_sparse_list(EncP P, const i64 *tile_eol, EncOut O, u64 tiles, u32 *list, u32 *n_list)
+{
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u32 lane = threadIdx.x & 63;
+    bool want = false; u64 len = 0;
+    if (t < tiles) {
+        const u32 reg = O.t_reg[t];
+        if (reg) {
+            const u64 tb = O.t_seq[t];
+            const u32 p1 = reg & 0xFFFu, period = (reg >> 12) & 0xFFFu, E = REG_E(reg), W = period - 1, n = ET_TILE - E;
+            want = !(direct_group(O, tb >> 4) && direct_group(O, (tb + n - 1) >> 4));
+            const u32 rp = t ? O.t_reg[t - 1] : 0u;
+            const u32 pl_prev = (rp & 0xFFFu) + (REG_E(rp) - 1) * ((rp >> 12) & 0xFFFu);
+            len = W;
+            if (!(rp && ((rp >> 12) & 0xFFFu) == period && ET_TILE - 1 - pl_prev + p1 == W)) {
+                const u64 first = tb + p1 - tile_line_base(P, O, tile_eol, t);
+                if (first > len) len = first;
+            }
+        }
+    }
+    const u64 bal = __ballot(want);
+    if (bal) {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(n_list, (u32)__popcll(bal));
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        if (want) list[base + (u32)__popcll(bal & ((1ull << lane) - 1))] = (u32)t;
+    }
+    len = wave_scan_inclusive<u64, OpMaxU64>(len);
+    if (lane == 63 && len > __atomic_load_n(O.longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)O.longest, (unsigned long long)len);
 }
 
 template <bool PACK>
@@ -2063,13 +2230,15 @@ struct EnnafSplit {
     // direct blocks (k_direct_blocks): flags of the first nd blocks of 32 KiB of `packed`; rescatter() packs the bases again without them
     // (the stream turned out to be worth matching: the match finder wants packed bytes)
     u8 *direct; u32 nd;
+    ZencLoc dloc;                                              // dloc.loc != nullptr: the direct blocks' codes are tile-local (k_enc_fused read the text once)
     struct Scatter4 { EncP P; EncOut O; const i64 *t_eol, *t_sp; const u64 *t_seq; u64 tiles, T, n, n_irregular; } sc4;
 };
 // the scatter pass of a 4-bit FASTA input (O.direct says which blocks are direct)
 static int ennaf_scatter4(naf_gpu_ctx *c, const EnnafSplit::Scatter4 &R, u8 *packed, u64 *casebits)
 {
-    if (R.T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(R.tiles, 256), 256, 0, R.t_seq, R.tiles, R.T, packed, (u32 *)casebits, R.O.direct, R.O.nd);
-    if (R.n >= 2 * ET_TILE && enc_wave_wg(c)) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular<1>, (u32)R.tiles, 64, 0, R.P, R.t_eol, R.O, R.tiles);
+    if (R.T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(R.tiles, 256), 256, 0, R.t_seq, R.tiles, R.T, packed, (u32 *)casebits, R.O.direct, R.O.nd, R.O.loc_mode);
+    if (R.O.loc_mode) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular_list, 8192, 64, 0, R.P, R.t_eol, R.O);
+    else if (R.n >= 2 * ET_TILE && enc_wave_wg(c)) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular<1>, (u32)R.tiles, 64, 0, R.P, R.t_eol, R.O, R.tiles);
     else if (R.n >= 2 * ET_TILE) LAUNCH(c, "ennaf_scatter_regular", k_enc_scatter_regular<REG_TPW>, cdiv(R.tiles, REG_TPW), 256, 0, R.P, R.t_eol, R.O, R.tiles);   // (shorter texts have no regular tile)
     if (R.n_irregular) LAUNCH(c, "ennaf_scatter", k_enc_scatter<true>, R.n_irregular, 256, 0, R.P, R.t_eol, R.t_sp, R.O);
     return 0;
@@ -2249,15 +2418,31 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         // the case census rides on the count pass (tot[6]): an upper-case text needs no pass over its case bits to learn that its mask is one run
         HIP_TRY(c, hipMemsetAsync(tot + 6, 0, 8, c->stream));
         P.any_case = (u32 *)(tot + 6);
+        // ONE pass over the text (k_enc_fused) where direct blocks are possible at all: the options that allow them are known here, the
+        // stream's size and the text's case only behind the counts -- what the pass left in `loc` is then simply not used
+        // (NAF_GPU_ONEPASS=0: the two passes, the cross-check; =2: direct blocks from two of them, like NAF_GPU_DIRECT=2)
+        const char *e_ed = ctx_opt(c, "DIRECT"), *e_epf = ctx_opt(c, "PREFER_FLAT"), *e_ebl = ctx_opt(c, "BLOCK_LOG"), *e_epr = ctx_opt(c, "PROBE"), *e_elz = ctx_opt(c, "LZ"), *e_op = ctx_opt(c, "ONEPASS");
+        const u32 e_prefer_flat = e_epf && e_epf[0] ? (u32)atoi(e_epf) : 16u;
+        const bool direct_opts = allow_direct && S.fourbit && o->level <= 1 && !o->long_log && !(e_ed && e_ed[0] == '0') && e_prefer_flat >= 2 && !(e_ebl && atoi(e_ebl) != 15) && !(e_epr && e_epr[0] == '1')
+                                 && !(e_elz && !strcmp(e_elz, "all")) && n >= 16 * ET_TILE;
+        const bool fused = direct_opts && enc_wave_wg(c) && !(e_op && e_op[0] == '0') && (n >> 17) >= ((e_ed && e_ed[0] == '2') || (e_op && e_op[0] == '2') ? 2u : 256u);
+        u8 *loc = nullptr; u32 *t_needf0 = nullptr; u64 *t_need0 = nullptr;
+        if (fused) {
+            loc = (u8 *)arena_alloc(c, (tiles + 1) * LOC_TILE + 64);
+            t_needf0 = arena_new<u32>(c, tiles + 1); t_need0 = arena_new<u64>(c, tiles + 2);
+            if (!loc || !t_needf0 || !t_need0) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "ennaf_split_once", k_enc_fused<true>, (u32)tiles, 64, 0, P, t_eol, t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf0, t_need0, tiles, loc);
+        } else
         LAUNCH(c, "ennaf_last", k_enc_last_fa, cdiv(tiles, 4 * LAST_TPW), 256, 0, P, t_eol, t_sp, tiles);
         // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
         if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
         if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
         if (S.fourbit && n >= 16 * ET_TILE) {
             // pure tiles (nearly all of a genome) a wavefront per tile; the others, from a list, by the general kernel
-            u32 *t_needf = arena_new<u32>(c, tiles + 1), *need_list = arena_new<u32>(c, tiles + 1); u64 *t_need = arena_new<u64>(c, tiles + 2);
+            u32 *t_needf = fused ? t_needf0 : arena_new<u32>(c, tiles + 1), *need_list = arena_new<u32>(c, tiles + 1); u64 *t_need = fused ? t_need0 : arena_new<u64>(c, tiles + 2);
             if (!t_needf || !need_list || !t_need) return NAF_GPU_ENOMEM;
-            if (enc_wave_wg(c)) LAUNCH(c, "ennaf_count_pure", (k_enc_count_pure<1, 1>), (u32)tiles, 64, 0, P, (const i64 *)t_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, tiles);
+            if (fused) LAUNCH(c, "ennaf_pure_check", k_pure_check, cdiv(tiles, 256), 256, 0, P, (const i64 *)t_eol, tiles, t_needf, t_need, t_reg, t_irr);
+            else if (enc_wave_wg(c)) LAUNCH(c, "ennaf_count_pure", (k_enc_count_pure<1, 1>), (u32)tiles, 64, 0, P, (const i64 *)t_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, tiles);
             else LAUNCH(c, "ennaf_count_pure", (k_enc_count_pure<4, 1>), cdiv(tiles, 4), 256, 0, P, (const i64 *)t_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, tiles);
             if ((rc = scan_exclusive_u64(c, t_need, tiles, tot + 5))) return rc;
             LAUNCH(c, "ennaf_need_list", k_need_list, cdiv(tiles, 256), 256, 0, (const u32 *)t_needf, (const u64 *)t_need, tiles, need_list, (const u32 *)nullptr);
@@ -2299,19 +2484,32 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         EncOut O; O.seq = bases; O.packed = S.packed; O.casebits = (u32 *)S.casebits; O.ids = s_ids; O.cmt = s_cmt; O.rec_begin = rec_begin; O.rec_end = rec_end;
         O.unexpected = d_unexp; O.longest = d_unexp + 3 * 257; O.strict_first = o->strict ? d_unexp + 3 * 257 + 1 : nullptr; O.lead = d_unexp + 3 * 257 + 2;
         O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_rec = t_rec; O.t_tail = t_tail; O.tile_eol = t_eol; O.t_reg = t_reg; O.irr_list = S.fourbit ? irr_list : nullptr;
-        O.direct = nullptr; O.nd = 0;
+        O.direct = nullptr; O.nd = 0; O.loc_mode = 0; O.sparse_list = nullptr; O.n_sparse = nullptr;
         if (S.fourbit) {
             // Direct blocks: a whole input at level 1 (no match finder unless the look at the stream says so), blocks of exactly 32 KiB
             // (the stream's ragged end is coded as a part of its own, ennaf_streams), from 8 MiB of packed bases up
             const u64 n_seqb = (T + 1) / 2;
-            const char *ed = ctx_opt(c, "DIRECT"), *epf = ctx_opt(c, "PREFER_FLAT"), *ebl = ctx_opt(c, "BLOCK_LOG"), *epr = ctx_opt(c, "PROBE"), *elz = ctx_opt(c, "LZ");
-            const u32 prefer_flat = epf && epf[0] ? (u32)atoi(epf) : 16u;
+            const char *ed = e_ed, *epr = e_epr;
+            const u32 prefer_flat = e_prefer_flat;
             const u64 nd64 = n_seqb >> 15;
-            if (allow_direct && o->level <= 1 && !o->long_log && !(ed && ed[0] == '0') && prefer_flat >= 2 && !(ebl && atoi(ebl) != 15) && !(epr && epr[0] == '1') && !(elz && !strcmp(elz, "all"))
-                && n >= 16 * ET_TILE && nd64 >= ((ed && ed[0] == '2') ? 2u : 256u) && nd64 < 0x7FFFFFFFull && !((T & 1) && (n_seqb & 32767) == 0)) {
+            O.loc_mode = 0; O.sparse_list = nullptr; O.n_sparse = nullptr;
+            if (direct_opts && nd64 >= ((ed && ed[0] == '2') || (fused && e_op && e_op[0] == '2') ? 2u : 256u) && nd64 < 0x7FFFFFFFull && !((T & 1) && (n_seqb & 32767) == 0)) {
                 S.nd = (u32)nd64; S.direct = (u8 *)arena_alloc(c, S.nd); if (!S.direct) return NAF_GPU_ENOMEM;
-                LAUNCH(c, "ennaf_direct_blocks", k_direct_blocks, cdiv(S.nd, 4), 256, 0, d_text, (const u64 *)t_seq, (const u32 *)t_reg, tiles, S.nd, prefer_flat, (epr && epr[0] == '0') ? 0 : 1, S.direct);
+                // the codes k_enc_fused left are the direct blocks' when the text has no case bit to keep beside them (a text with lower case:
+                // the scatter pass makes codes and case bits of every tile, as before)
+                const bool use_loc = fused && S.no_case;
+                u32 *blk_t0 = use_loc ? arena_new<u32>(c, (size_t)S.nd + 1) : nullptr;
+                if (use_loc && !blk_t0) return NAF_GPU_ENOMEM;
+                LAUNCH(c, "ennaf_direct_blocks", k_direct_blocks, cdiv(S.nd, 4), 256, 0, d_text, (const u64 *)t_seq, (const u32 *)t_reg, tiles, S.nd, prefer_flat, (epr && epr[0] == '0') ? 0 : 1, S.direct, blk_t0);
                 O.direct = S.direct; O.nd = S.nd;
+                if (use_loc) {
+                    u32 *sparse_list = arena_new<u32>(c, tiles + 1), *n_sparse = arena_new<u32>(c, 2);
+                    if (!sparse_list || !n_sparse) return NAF_GPU_ENOMEM;
+                    HIP_TRY(c, hipMemsetAsync(n_sparse, 0, 8, c->stream));
+                    O.loc_mode = 1; O.sparse_list = sparse_list; O.n_sparse = n_sparse;
+                    LAUNCH(c, "ennaf_sparse_list", k_sparse_list, cdiv(tiles, 256), 256, 0, P, (const i64 *)t_eol, O, tiles, sparse_list, n_sparse);
+                    S.dloc.loc = loc; S.dloc.t_seq = t_seq; S.dloc.blk_t0 = blk_t0; S.dloc.tiles = tiles;
+                }
                 if (ctx_tracing(c)) {
                     std::vector<u8> hd(S.nd); hipStreamSynchronize(c->stream); hipMemcpy(hd.data(), S.direct, S.nd, hipMemcpyDeviceToHost);
                     u64 k = 0; for (u8 v : hd) k += v;
@@ -2353,7 +2551,7 @@ struct EnnafCarry {
 };
 struct EnnafStreams { const u8 *ptr[6]; u64 len[6], orig[6]; int lz[6], block_log[6], window_log[6]; bool present[6];
                       u32 tail[6]; int flags[6];
-                      const u8 *direct; u32 nd, tail_packed; };   // direct blocks of the sequence stream (EnnafSplit::direct); tail[4] without them   // flags: ZENC_PREFER_RAW for the mask stream   // tail: bytes at the end of the stream that go into a Raw block of their own (encode_stream)
+                      const u8 *direct; u32 nd, tail_packed; const ZencLoc *dloc; };   // direct blocks of the sequence stream (EnnafSplit::direct); tail[4] without them   // flags: ZENC_PREFER_RAW for the mask stream   // tail: bytes at the end of the stream that go into a Raw block of their own (encode_stream)
 
 // E5-E7: lengths, 4-bit pack, mask units -> the six uncompressed streams.
 // part: 1 = ids, names, sequence and quality (nothing to wait for), 2 = lengths and mask (a few read-backs), 3 = all of them.  The two
@@ -2460,7 +2658,8 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
         X.ptr[1] = S.s_cmt; X.len[1] = X.orig[1] = S.n_cmt; X.lz[1] = 1; X.present[1] = true;
         // direct blocks are blocks of exactly 32 KiB: the stream's ragged end (with the padding nibble, if any) is a part of its own
         X.tail_packed = seq_tail; X.direct = nullptr; X.nd = 0;
-        if (S.direct && (part & 1)) { X.direct = S.direct; X.nd = S.nd; seq_tail = (u32)(n_seqb & 32767); }
+        X.dloc = nullptr;
+        if (S.direct && (part & 1)) { X.direct = S.direct; X.nd = S.nd; seq_tail = (u32)(n_seqb & 32767); X.dloc = S.dloc.loc ? &S.dloc : nullptr; }
         X.ptr[4] = s_seq; X.len[4] = n_seqb; X.orig[4] = T; X.present[4] = true; X.tail[4] = seq_tail;   // ennaf.c:582: number of bases
         X.ptr[5] = S.s_qual; X.len[5] = X.orig[5] = S.n_qual; X.present[5] = S.store_qual;
     }
@@ -2527,13 +2726,13 @@ struct PlaceTail { const ZencPlace *outer; size_t tail_len; u8 *at; };
 static u8 *place_before_tail(void *ud, size_t len) { PlaceTail *t = (PlaceTail *)ud; return t->at = t->outer->fn(t->outer->ud, len + t->tail_len); }
 // the two halves of a placed stream (zstd_encode_begin / _finish): what the caller queues between them runs beside the planning
 struct StreamJob { ZencJob *main; const u8 *d_stream; u64 len; int level, flags; u32 tail; };
-static int encode_stream_begin(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level, int flags, int lz, int block_log, int window_log, u32 tail, StreamJob *J, const u8 *direct = nullptr, u32 nd = 0)
+static int encode_stream_begin(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level, int flags, int lz, int block_log, int window_log, u32 tail, StreamJob *J, const u8 *direct = nullptr, u32 nd = 0, const ZencLoc *dloc = nullptr)
 {
     J->main = nullptr; J->d_stream = d_stream; J->len = len; J->level = level; J->flags = flags; J->tail = (tail && len > tail) ? tail : 0;
     int f1 = flags;
     if (J->tail) f1 = ZENC_PART | ((!(flags & ZENC_PART) || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES | ZENC_FRAME_TREE));
     if (direct && (lz || len - J->tail != (u64)nd << 15)) return ctx_fail(c, NAF_GPU_EARG, "direct blocks need a stream of whole blocks and no match finder");
-    int rc = zstd_encode_begin(c, d_stream, len - J->tail, level, f1, lz, block_log, window_log, &J->main, direct, nd);
+    int rc = zstd_encode_begin(c, d_stream, len - J->tail, level, f1, lz, block_log, window_log, &J->main, direct, nd, dloc);
     if (rc) { zstd_encode_drop(J->main); J->main = nullptr; }
     return rc;
 }
@@ -2588,13 +2787,13 @@ static u8 *place_section(void *ud, size_t clen)
 
 // `early`: the stream's planning was queued before (encode_stream_begin); otherwise both halves run here.  The launches go to c's
 // stream (c may be a side context), a failure's text lands in `report`.
-static int put_section(naf_gpu_ctx *c, naf_gpu_ctx *report, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz, int block_log, int window_log, u32 tail, StreamJob *early, int flags = 0, const u8 *direct = nullptr, u32 nd = 0)
+static int put_section(naf_gpu_ctx *c, naf_gpu_ctx *report, const u8 *d_stream, u64 stream_len, u64 orig, int level, u8 *d_naf, size_t cap, size_t &pos, SecOut &so, int lz, int block_log, int window_log, u32 tail, StreamJob *early, int flags = 0, const u8 *direct = nullptr, u32 nd = 0, const ZencLoc *dloc = nullptr)
 {
     SecPlace sp = { c, d_naf, cap, pos, orig, 0, 0 }; ZencPlace P = { place_section, &sp };
     size_t clen = 0;
     StreamJob J;
     int rc = 0;
-    if (!early) { rc = encode_stream_begin(c, d_stream, stream_len, level, flags, lz, block_log, window_log, tail, &J, direct, nd); early = &J; }
+    if (!early) { rc = encode_stream_begin(c, d_stream, stream_len, level, flags, lz, block_log, window_log, tail, &J, direct, nd, dloc); early = &J; }
     if (!rc) rc = encode_stream_finish(c, early, &clen, &P);
     if (rc) { if (report != c) ctx_fail(report, sp.rc ? sp.rc : rc, "%s", c->err); return sp.rc ? sp.rc : rc; }
     pos += sp.hl + clen;
@@ -2641,8 +2840,8 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
     // the match finder wants packed bytes in every block: the bases are packed again, without direct blocks
     auto undirect = [&]() -> int {
         if (!X.direct) return 0;
-        X.direct = nullptr; X.nd = 0; X.tail[4] = X.tail_packed; S.direct = nullptr; S.nd = 0;
-        S.sc4.O.direct = nullptr; S.sc4.O.nd = 0;
+        X.direct = nullptr; X.nd = 0; X.tail[4] = X.tail_packed; S.direct = nullptr; S.nd = 0; X.dloc = nullptr; S.dloc.loc = nullptr;
+        S.sc4.O.direct = nullptr; S.sc4.O.nd = 0; S.sc4.O.loc_mode = 0;
         return ennaf_scatter4(c, S.sc4, S.packed, S.casebits);
     };
     if (X.lz[4] && (rc = undirect())) return rc;
@@ -2684,7 +2883,7 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
         } else if ((rc = ennaf_streams(sc, S, K, X, 2))) return bail(rc, sc);
         for (int i = 4; i < 6; i++)
             if (X.present[i]) {
-                if ((rc = encode_stream_begin(c, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i], i == 4 ? X.direct : nullptr, i == 4 ? X.nd : 0u))) return bail(rc, c);
+                if ((rc = encode_stream_begin(c, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i], i == 4 ? X.direct : nullptr, i == 4 ? X.nd : 0u, i == 4 ? X.dloc : nullptr))) return bail(rc, c);
                 early[i] = true;
             }
         if (probe_later) {
@@ -2730,7 +2929,7 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
         if (!X.present[i]) continue;
         if (i >= 4 && (rc = join())) break;
         naf_gpu_ctx *w = !overlap || i >= 4 ? c : (sb && i >= 2) ? sb : sc;
-        rc = put_section(w, c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], early[i] ? &big[i] : nullptr, X.flags[i], i == 4 ? X.direct : nullptr, i == 4 ? X.nd : 0u);
+        rc = put_section(w, c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pos, so[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], early[i] ? &big[i] : nullptr, X.flags[i], i == 4 ? X.direct : nullptr, i == 4 ? X.nd : 0u, i == 4 ? X.dloc : nullptr);
         early[i] = false;
     }
     if (!joinedB) { ctx_worker_join(sb); joinedB = true; }

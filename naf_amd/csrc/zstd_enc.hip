@@ -959,7 +959,7 @@ __device__ __forceinline__ void zenc_flat4_stream(u8 *out, const u8 *s, u32 n, c
 // LZ-coded blocks (mode[b] != 0) take their literals from L.lits with the plan / codes / tree of those literals (plan1 ...)
 // and append the Sequences_Section made by k_lz_seqenc; all other blocks are coded from src as literal-only blocks.
 struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u16 *codes1; const u8 *trees1; LzBufs B; u32 not_last; u32 wave_general; };   // wave_general: blocks of general Huffman codes are k_zenc_write_wave's   // not_last: the frame continues behind these blocks (a shard's part of a frame)
-struct ZencJob { const u8 *src; size_t n; u32 nblk, frame_wlog; ZEncPlan *plan; u16 *codes; u8 *trees; u64 *offs; u64 hdr; int with_magic, empty; ZWriteLz L; bool direct; u32 block_bytes; };
+struct ZencJob { const u8 *src; size_t n; u32 nblk, frame_wlog; ZEncPlan *plan; u16 *codes; u8 *trees; u64 *offs; u64 hdr; int with_magic, empty; ZWriteLz L; bool direct; u32 block_bytes; ZencLoc dloc; };   // dloc.loc != nullptr: the direct blocks' codes are tile-local (k_zenc_write_direct_loc)
 __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nblk, const ZEncPlan *plan, const u16 *codes_g, const u8 *trees,
                                                     const u64 *offs, u8 *dst, u64 frame_hdr, ZWriteLz L)
 {
@@ -1150,6 +1150,66 @@ __global__ __launch_bounds__(256) void k_zenc_write_direct(const u8 *src, u32 nb
     if (lane == 0) so[4096] = 1;
 }
 
+// The same blocks when the split pass read its text once (enc.hip: k_enc_fused): the codes wait tile by tile -- base i of tile t in bits
+// 2i, 2i + 1 of the KiB at loc + 1024 t -- and are gathered here: the sixteen bases of group G of the stream (bases 16 G ... of the base
+// stream) are one 32-bit word wherever they lie, two bits a base, the first lowest; in the stream that word stands with its nibbles
+// reversed at place 1023 - (G & 1023) (enc.hip: direct_word).  A lane takes four groups = 64 bases = 128 bits at a time: sixteen bytes and
+// one more from the tile that holds the first of them, shifted down by the two bits per base it starts behind a byte's first; where the
+// tile ends inside the 64 bases the rest comes from the first sixteen bytes of the next tile, shifted up (a direct block's tiles are
+// regular: at least 3972 bases each, so 64 bases touch two tiles at most and a block's 65536 at most eighteen).
+__device__ __forceinline__ u32 nibble_rev32(u32 x) { const u32 r = __builtin_bswap32(x); return ((r & 0x0F0F0F0Fu) << 4) | ((r >> 4) & 0x0F0F0F0Fu); }
+__global__ __launch_bounds__(256) void k_zenc_write_direct_loc(ZencLoc D, u32 nblk, const ZEncPlan *plan, const u8 *trees, const u64 *offs, u8 *dst, u64 frame_hdr, u32 not_last)
+{
+    __shared__ i32 s_bnd[24];                                     // base counts in front of tiles t0 .. t0 + 23, less the block's first base
+    const u32 b = blockIdx.x, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const ZEncPlan p = plan[b];
+    if (p.kind != ZK_HUF || p.pad != 2) return;
+    const u64 t0 = D.blk_t0[b], B0 = (u64)b << 16;
+    if (threadIdx.x < 24) {
+        const u64 t = t0 + threadIdx.x;
+        const i64 rel = t <= D.tiles ? (i64)D.t_seq[t] - (i64)B0 : (i64)(1 << 30);       // (t_seq[tiles] = the total)
+        s_bnd[threadIdx.x] = (i32)(rel > (1 << 30) ? (1 << 30) : rel);
+    }
+    const u32 o = 3 + p.lhdr + p.tree_bytes + 6 + (q > 0 ? p.ssz[0] : 0u) + (q > 1 ? p.ssz[1] : 0u) + (q > 2 ? p.ssz[2] : 0u);
+    u8 *out = dst + frame_hdr + offs[b], *so = out + o;
+    if (threadIdx.x == 255) { zenc_write_block_prefix(out, p, trees + (u64)b * ZENC_TREE_SLOT, b + 1 == nblk && !not_last, 0); out[p.csize - 1] = 0; }
+    __syncthreads();
+    const i32 b0rel = s_bnd[0];                                   // <= 0
+    u64 lo[4], hi[4]; u32 x[4], sh[4], avail[4]; const u8 *nx[4];
+#pragma unroll
+    for (u32 r = 0; r < 4; r++) {
+        const u32 cidx = r * 64 + lane, Q = 255u - cidx;              // sixteen bytes of the stream <- groups 4 Q .. 4 Q + 3 of it
+        const i32 r0 = (i32)(16384u * q + 64u * Q);                   // the quad's first base, counted from the block's first
+        u32 k = (u32)(r0 - b0rel) >> 12;                              // tiles hold at most 4096 bases: not behind this one ...
+        if (s_bnd[k + 1] <= r0) k++;                                  // ... and, as they hold at least 3972, at most two further
+        if (s_bnd[k + 1] <= r0) k++;
+        const u32 i = (u32)(r0 - s_bnd[k]);
+        const u8 *pp = D.loc + (t0 + k) * 1024 + (i >> 2);
+        lo[r] = ld64(pp); hi[r] = ld64(pp + 8); x[r] = pp[16];
+        sh[r] = 2u * (i & 3u);
+        const u32 av = (u32)(s_bnd[k + 1] - r0);                      // bases of the quad this tile still has (>= 1)
+        avail[r] = av < 64u ? av : 64u;
+        nx[r] = D.loc + (t0 + k + 1) * 1024;
+    }
+    uint4 v[4];
+#pragma unroll
+    for (u32 r = 0; r < 4; r++) {
+        u64 a = lo[r], c = hi[r];
+        if (sh[r]) { a = (a >> sh[r]) | (c << (64 - sh[r])); c = (c >> sh[r]) | ((u64)x[r] << (64 - sh[r])); }
+        if (avail[r] < 64u) {                                         // the tile ends inside the quad: the rest from the next tile's first bases
+            const u64 n0 = ld64(nx[r]), n1 = ld64(nx[r] + 8);
+            const u32 s = 2u * avail[r];                              // 2 .. 126
+            if (s < 64) { const u64 m = (1ull << s) - 1; a = (a & m) | (n0 << s); c = (n1 << s) | (n0 >> (64 - s)); }
+            else if (s == 64) { c = n0; }
+            else { const u64 m = (1ull << (s - 64)) - 1; c = (c & m) | (n0 << (s - 64)); }
+        }
+        v[r] = make_uint4(nibble_rev32((u32)(c >> 32)), nibble_rev32((u32)c), nibble_rev32((u32)(a >> 32)), nibble_rev32((u32)a));
+    }
+#pragma unroll
+    for (u32 r = 0; r < 4; r++) __builtin_memcpy(so + 16u * (r * 64 + lane), &v[r], 16);
+    if (lane == 0) so[4096] = 1;
+}
+
 __global__ void k_zenc_frame_header(u8 *dst, int with_magic, u32 wlog)
 {
     if (threadIdx.x || blockIdx.x) return;
@@ -1236,7 +1296,7 @@ extern "C" size_t naf_gpu_zstd_compress_bound(size_t n)
 // with_magic: 1 = whole frame with its magic number, 0 = whole frame without it (as stored in a .naf section),
 //   ZENC_PART | ZENC_PART_FIRST | ZENC_PART_LAST = a shard's part of a frame: blocks only, behind the 2-byte frame header when
 //   FIRST, ending the frame when LAST (an empty part that is not LAST is zero bytes; an empty LAST part is one empty Raw block).
-int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int with_magic, int lz, int block_log_hint, int window_log, ZencJob **job, const u8 *direct, u32 nd)
+int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int with_magic, int lz, int block_log_hint, int window_log, ZencJob **job, const u8 *direct, u32 nd, const ZencLoc *dloc)
 {
     ZencJob *J = new ZencJob; *job = J;                          // released by zstd_encode_finish
     memset(J, 0, sizeof *J);
@@ -1383,6 +1443,7 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     }
     int rc = scan_exclusive_u64(c, offs, nblk, offs + nblk + 1); if (rc) return rc;
     J->direct = direct != nullptr;
+    if (direct && dloc) J->dloc = *dloc;
     J->block_bytes = (u32)bs; J->nblk = nblk; J->plan = plan; J->codes = codes; J->trees = trees; J->offs = offs; J->hdr = hdr; J->with_magic = with_magic; J->frame_wlog = frame_wlog;
     return 0;
 }
@@ -1424,7 +1485,8 @@ static int zenc_finish(naf_gpu_ctx *c, ZencJob *J, u8 *d_dst, size_t cap, size_t
            (const u64 *)J->offs, d_dst, hdr, J->L);
     if (J->L.wave_general) LAUNCH(c, "zenc_write_wave", k_zenc_write_wave, cdiv(nblk, ZWW_BLOCKS), 256, 512u + 4u * ZWW_OBUF, J->src, (u64)J->n, nblk, (const ZEncPlan *)J->plan, (const u16 *)J->codes, (const u8 *)J->trees,
            (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
-    if (J->direct) LAUNCH(c, "zenc_write_direct", k_zenc_write_direct, nblk, 256, 0, J->src, nblk, (const ZEncPlan *)J->plan, (const u8 *)J->trees, (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
+    if (J->direct && J->dloc.loc) LAUNCH(c, "zenc_write_direct", k_zenc_write_direct_loc, nblk, 256, 0, J->dloc, nblk, (const ZEncPlan *)J->plan, (const u8 *)J->trees, (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
+    else if (J->direct) LAUNCH(c, "zenc_write_direct", k_zenc_write_direct, nblk, 256, 0, J->src, nblk, (const ZEncPlan *)J->plan, (const u8 *)J->trees, (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
     if (!place && (rc = ctx_readback(c, &total, J->offs + nblk + 1, 8))) return rc;
     *out_len = hdr + total;
     return 0;

@@ -849,6 +849,67 @@ def test_direct_blocks_of_the_sequence_stream(gpu, oracle, monkeypatch, capfd):
         assert oracle.ref_unnaf(host(d_naf)) == texts[2]
 
 
+def test_text_read_once_gives_the_archive_of_the_two_passes(gpu, oracle, monkeypatch, capfd):
+    """enc.hip k_enc_fused / zstd_enc.hip k_zenc_write_direct_loc: a whole 4-bit FASTA input at level 1 is read ONCE -- the count pass
+    leaves the two-bit codes of its plain, regular A C G T tiles tile by tile and the frame writer gathers the direct blocks' streams from
+    them across the tile seams; the blocks that are not direct are packed by the scatter kernels as before.  The archive is BYTE FOR BYTE
+    the one the two passes make (NAF_GPU_ONEPASS=0, round 5's path) and its streams are the oracle's: every line width from 33 up to a
+    few hundred in every phase against the groups of 16 and the tiles of 4096, headers made of A C G T that fill whole tiles (the tile
+    that begins in such a header line is handed back behind the scan), N runs, IUPAC letters, CRLF parts, low-entropy stretches, odd base
+    counts, and a text large enough for the blocks the look at the stream keeps back (direct and packed blocks side by side)."""
+    import torch
+    from naf_amd import synth
+    rng = np.random.default_rng(606)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    def seq(n, p=None):
+        return bytes(rng.choice(acgt, n, p=p))
+    def wrap(b, w, eol=b"\n"):
+        return eol.join(b[i:i + w] for i in range(0, len(b), w)) + eol
+    texts = []
+    texts.append(b">one record\n" + wrap(seq(1_500_001), 80))
+    texts.append(b"".join(b">w%d\n" % w + wrap(seq(300_000 + w), w) for w in (33, 34, 47, 59, 60, 61, 64, 79, 81, 100, 127, 128, 129, 255, 256, 500, 1000, 4000)))
+    texts.append(b">" + seq(9000) + b" a header of letters\n" + wrap(seq(400_000), 70) + b">" + seq(20000) + b"\n" + wrap(seq(400_001), 70) + b">ACGT\n" + wrap(seq(300_000), 70))
+    texts.append(b">runs\n" + wrap(seq(500_000) + b"N" * 100_000 + seq(400_000) + b"RYKM" * 50 + seq(400_000) + b"n" + seq(300_000), 70))
+    texts.append(b">low entropy in the middle\n" + wrap(seq(400_000) + seq(400_000, p=[0.48, 0.02, 0.02, 0.48]) + seq(400_003), 80))
+    texts.append(b">crlf part\r\n" + wrap(seq(300_000), 80, b"\r\n") + b">lf part\n" + wrap(seq(900_000), 80))
+    texts.append(b">exactly whole blocks\n" + wrap(seq(65536 * 6), 80))
+    texts.append(b">odd and whole blocks\n" + wrap(seq(65536 * 6 - 1), 80))
+    texts.append(b">u\n" + wrap(seq(700_000).replace(b"T", b"U"), 60))
+    texts.append(b">no line end at the end\n" + wrap(seq(500_000), 90)[:-1])
+    texts.append(b"\n\n>blank lines in front\n" + wrap(seq(300_000), 50) + b"\n\n>and between\n\n" + wrap(seq(300_000), 50))
+    monkeypatch.setenv("NAF_GPU_PROBE", "0")
+    monkeypatch.setenv("NAF_GPU_DIRECT", "2")
+    monkeypatch.setenv("NAF_GPU_DEBUG_DIRECT", "1")
+    n_direct = []
+    for i, text in enumerate(texts):
+        st = oracle.RNA if text.startswith(b">u\n") else oracle.DNA
+        monkeypatch.delenv("NAF_GPU_ONEPASS", raising=False)
+        capfd.readouterr()
+        a = check_ennaf(gpu, oracle, text, seq_type=st)
+        err = capfd.readouterr().err
+        k = [int(l.split()[1]) for l in err.splitlines() if l.startswith("[direct]")]
+        n_direct.append(k[0] if k else -1)
+        monkeypatch.setenv("NAF_GPU_ONEPASS", "0")
+        b = host(gpu.ennaf(gpu.to_device(text), seq_type=st)[0])
+        assert a == b, (i, len(a), len(b))
+    assert n_direct[0] >= 9 and n_direct[1] >= 30 and n_direct[2] >= 5 and n_direct[3] >= 8 and n_direct[6] >= 4, n_direct
+    # the default gates: 60 MB of text, the first MiB of the packed stream is the look's (32 blocks that are not direct beside 400 that are)
+    for k in ("NAF_GPU_PROBE", "NAF_GPU_DIRECT", "NAF_GPU_ONEPASS"):
+        monkeypatch.delenv(k, raising=False)
+    big = synth.fasta_acgt_device(60_000_000, n_records=7, width=80, seed=11, device="cuda")
+    capfd.readouterr()
+    a, rep = gpu.ennaf(big)
+    err = capfd.readouterr().err
+    k = [l.split() for l in err.splitlines() if l.startswith("[direct]")]
+    assert k and 300 <= int(k[0][1]) < int(k[0][3]), err
+    monkeypatch.setenv("NAF_GPU_ONEPASS", "0")
+    b, _ = gpu.ennaf(big)
+    assert torch.equal(a, b)
+    assert torch.equal(gpu.unnaf(a, 0), big)
+    if oracle.have_ref():
+        assert hashlib.sha256(oracle.ref_unnaf(host(a))).digest() == hashlib.sha256(host(big)).digest()
+
+
 def test_direct_blocks_at_scale_and_when_the_stream_is_worth_matching(gpu, monkeypatch, capfd):
     """The default path (from 8 MiB of packed bases up): most blocks direct, the blocks the look at the stream reads are not; a
     repeat-rich input packs its bases again for the match finder."""
