@@ -152,8 +152,10 @@ struct ZencPlace { u8 *(*fn)(void *ud, size_t frame_len); void *ud; };
 struct ZencJob;
 // direct / nd: blocks b < nd of exactly 32 KiB whose four streams of 4-bit codes are already in d_src (enc.hip: direct_word); n must be nd x 32 KiB
 // where the codes of a frame's DIRECT blocks wait when the split pass read its text once (enc.hip: k_enc_fused): tile t's bases, two bits
-// each, in the KiB at loc + 1024 t; t_seq = exclusive scan of the tiles' base counts; blk_t0[b] = the tile that holds block b's first base
-struct ZencLoc { const u8 *loc; const u64 *t_seq; const u32 *blk_t0; u64 tiles; };
+// each, in the KiB at loc + 1024 t; blk_t0[b] = the tile that holds block b's first base
+// blk_bnd[b][i] = the base count in front of tile blk_t0[b] + i less the block's first base 65536 b, for the tiles a block can reach
+#define ZENC_LOC_BND 20
+struct ZencLoc { const u8 *loc; const i32 *blk_bnd; const u32 *blk_t0; u64 tiles; };
 int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int with_magic, int lz, int block_log_hint, int window_log, ZencJob **job, const u8 *direct = nullptr, u32 nd = 0, const ZencLoc *dloc = nullptr);
 int zstd_encode_finish(naf_gpu_ctx *c, ZencJob *job, u8 *d_dst, size_t cap, size_t *out_len, const ZencPlace *place);
 void zstd_encode_drop(ZencJob *job);

@@ -32,6 +32,7 @@ struct EncP {
     u8 strict, pad;
     u32 qlo, qhi;                // quick table of accepted letters (enc_swar.h), built in set_expected
     u32 plo, phi;                // the same with '\n' and '\r' in slots 5 and 6 (piece_plain)
+    u32 slo, shi;                // upper-case A C G T / U and '\n' only, a byte that never matches in the other slots (k_enc_fused's first look)
     u32 nuc32[8];                // 4-bit code of the letter whose low five bits are the index (tables.c:189-197), 15 in the other slots
     u32 *any_case;               // count pass: set to 1 when some byte of a sequence line carries the case bit (see case_bytes16); may be null
 };
@@ -616,7 +617,7 @@ template <bool LOC>
 __global__ __launch_bounds__(64) void k_enc_fused(EncP P, i64 *tile_eol, i64 *tile_sp, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
                                                   u32 *t_needf, u64 *t_need, u64 tiles, u8 *loc)
 {
-    __shared__ __attribute__((aligned(16))) u8 s_tile[LOC ? ET_TILE + 32 : 16];
+    __shared__ u32 s_code[LOC ? 260 : 4];                          // the tile's bytes as two-bit codes, in text order (line ends among them)
     const u32 lane = threadIdx.x;
     const u64 t = blockIdx.x;
     if (t >= tiles) return;
@@ -627,8 +628,23 @@ __global__ __launch_bounds__(64) void k_enc_fused(EncP P, i64 *tile_eol, i64 *ti
 #pragma unroll
         for (int k = 0; k < 4; k++) __builtin_memcpy(&v[k], P.text + tb + (64u * (u32)k + lane) * ET_BYTES, 16);
     }
-    u32 eol[4]; bool acgt = false, lower_any = false;
-    if (!inside || !plain_tile(P, v, eol, acgt, lower_any)) {
+    u32 eol[4]; bool acgt = false, lower_any = false, fast = false;
+    if (inside) {
+        // first look: nothing but upper-case A C G T / U and '\n' (every tile of the texts this pass is for): a table look-up and a
+        // compare per four bytes; line ends are the bytes without bit 6
+        u32 bad = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 w[4] = { v[k].x, v[k].y, v[k].z, v[k].w }; u32 f[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { bad |= swar_perm(P.shi, P.slo, (w[i] >> 1) & 0x07070707u) ^ w[i]; f[i] = ~w[i] & 0x40404040u; }
+            const u32 lo = swar_dot4(f[1], 0x80402010u, swar_dot4(f[0], 0x08040201u, 0)), hi = swar_dot4(f[3], 0x80402010u, swar_dot4(f[2], 0x08040201u, 0));
+            eol[k] = (lo >> 6) | ((hi >> 6) << 8);
+        }
+        fast = __ballot(bad != 0) == 0;
+        acgt = fast;
+    }
+    if (!fast && (!inside || !plain_tile(P, v, eol, acgt, lower_any))) {
         // not k_enc_count_pure's: its last line end and blank (all byte classes), the rest is k_enc_count's
         u32 pp = 0;
 #pragma unroll
@@ -649,41 +665,48 @@ __global__ __launch_bounds__(64) void k_enc_fused(EncP P, i64 *tile_eol, i64 *ti
     note_case(P, lower_any);
     const PureTile r = count_plain_tile(P, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, t, eol, acgt);
     if (lane == 0) { const i64 le = r.any ? (i64)(tb + r.lastpos) : -1; tile_eol[t] = le; tile_sp[t] = le; }   // (a plain tile's blanks are its line ends)
-    if (!LOC || !r.ok || !r.acgt) return;
-    // the tile's bases, two bits each, in order: lane l codes bases 64 l .. 64 l + 63 (four groups of 16) from the tile staged in LDS
+    // (a tile that needed the second look and is regular A C G T all the same holds lower case: the text's codes are then not taken from `loc`)
+    if (!LOC || !fast || !r.ok) return;
+    // the tile's bytes as codes, once: four bytes -> eight bits, a lane's sixteen bytes -> one word of the LDS string
 #pragma unroll
-    for (int k = 0; k < 4; k++) *(uint4 *)(s_tile + (64u * (u32)k + lane) * ET_BYTES) = v[k];
+    for (int k = 0; k < 4; k++)
+        s_code[64u * (u32)k + lane] = code2x4(v[k].x) | (code2x4(v[k].y) << 8) | (code2x4(v[k].z) << 16) | (code2x4(v[k].w) << 24);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the tile's bases in order: lane l takes bases 64 l .. 64 l + 63, four groups of 16; a group is the 32 bits at twice its first base's
+    // text position, less the two bits of the line end when one lies among its 17 bytes (lines hold at least 32 bases: one at most)
     const u32 W = r.period - 1, nb = ET_TILE - r.E;
-    const float rW = 1.0f / (float)W;
-    u32 wd[4];
+    u32 wd[4] = { 0, 0, 0, 0 };
+    const u32 b0 = 64u * lane;
+    if (b0 < nb) {
+        u32 x, e;                                                     // text position of the group's first base; bases from it to the next line end
+        if (b0 < r.p1) { x = b0; e = r.p1 - b0; }
+        else {
+            const u32 d = b0 - r.p1;
+            u32 k = (u32)((float)d * (1.0f / (float)W));
+            if (k * W > d) k--; else if ((k + 1) * W <= d) k++;
+            x = b0 + 1 + k; e = W - (d - k * W);
+        }
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const u32 b_lo = 64u * lane + 16u * (u32)g;
-        wd[g] = 0;
-        if (b_lo < nb) {
-            u32 x, e;                                                 // text position of base b_lo; bases from it to the next line end
-            if (b_lo < r.p1) { x = b_lo; e = r.p1 - b_lo; }
-            else {
-                const u32 d = b_lo - r.p1;
-                u32 k = (u32)((float)d * rW);
-                if (k * W > d) k--; else if ((k + 1) * W <= d) k++;
-                x = b_lo + 1 + k; e = W - (d - k * W);
-            }
-            const u32 *sp = (const u32 *)(s_tile + (x & ~3u));
-            const u64 c40 = (u64)(code2x4(sp[0]) | (code2x4(sp[1]) << 8) | (code2x4(sp[2]) << 16) | (code2x4(sp[3]) << 24)) | ((u64)code2x4(sp[4]) << 32);
-            u64 c = c40 >> (2u * (x & 3u));                           // 17 bytes from x on: the group's 16 bases and, when e < 16, its line end
-            if (e < 16) { const u64 lowm = (1ull << (2u * e)) - 1; c = (c & lowm) | ((c >> 2) & ~lowm); }
-            wd[g] = (u32)c;
+        for (int g = 0; g < 4; g++) {
+            if (b0 + 16u * (u32)g >= nb) break;
+            const u32 d0 = s_code[x >> 4], d1 = s_code[(x >> 4) + 1], sh = 2u * (x & 15u);
+            const u32 lo = __builtin_amdgcn_alignbit(d1, d0, sh);
+            if (e < 16) {
+                const u32 lowm = (1u << (2u * e)) - 1u, up = __builtin_amdgcn_alignbit(d1 >> sh, lo, 2);
+                wd[g] = (lo & lowm) | (up & ~lowm);
+                x += 17; e += W - 16;
+            } else { wd[g] = lo; x += 16; e -= 16; }
         }
     }
     *(uint4 *)(loc + t * LOC_TILE + lane * 16u) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
 }
 // behind the scan of the last line ends: a tile k_enc_fused took for pure that begins in a header line is k_enc_count's after all
-__global__ void k_pure_check(EncP P, const i64 *tile_eol, u64 tiles, u32 *t_needf, u64 *t_need, u32 *t_reg, u64 *t_irr)
+__global__ void k_pure_check(EncP P, const i64 *tile_eol, u64 tiles, u32 *t_needf, u64 *t_need, u32 *t_reg, u64 *t_irr, const u32 *t_tail)
 {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tiles || t_needf[t]) return;
+    // the tile in front is plain too and holds a line end: the line at this tile's first byte begins among plain bytes -- not with '>'
+    if (t && !t_needf[t - 1] && (t_tail[t - 1] & 0x80000000u)) return;
     if (!tile_may_be_pure(P, tile_eol, t)) { t_needf[t] = 1; t_need[t] = 1; t_reg[t] = 0; t_irr[t] = 1; }
 }
 __global__ void k_need_list(const u32 *t_needf, const u64 *pre, u64 tiles, u32 *list, const u32 *t_reg = nullptr)
@@ -818,7 +841,7 @@ __device__ __forceinline__ void flush_pack(const EncP &P, u8 *packed, u32 *caseb
 //   - it is not in a region the level-1 look at the stream reads (zenc_repeat_probe: 1 MiB in every 64, as PACKED bytes).
 // t_seq is the exclusive scan of the tiles' base counts with the total behind it.
 #define DIRECT_PROBE_BLOCKS_LOG 5                                 // 32 blocks of 32 KiB per probed MiB, one MiB in 2^6
-__global__ __launch_bounds__(256) void k_direct_blocks(const u8 *text, const u64 *t_seq, const u32 *t_reg, u64 tiles, u32 nd, u32 prefer_flat, int probed, u8 *direct, u32 *blk_t0 = nullptr)
+__global__ __launch_bounds__(256) void k_direct_blocks(const u8 *text, const u64 *t_seq, const u32 *t_reg, u64 tiles, u32 nd, u32 prefer_flat, int probed, u8 *direct, const u32 *blk_t0 = nullptr, i32 *blk_bnd = nullptr)
 {
     __shared__ u32 bins[4][64];                                   // 4 copies x 16 bins per wave
     const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -830,8 +853,9 @@ __global__ __launch_bounds__(256) void k_direct_blocks(const u8 *text, const u64
     u64 t0 = 0, t1 = 0;
     if (ok) {
         const u64 B0 = (u64)b << 16, B1 = B0 + 65536;
-        // last tile with t_seq[t] <= B0: 64-ary search
+        // last tile with t_seq[t] <= B0: 64-ary search (blk_t0: looked up, k_irregular_list)
         u64 lo = 0, hi = tiles;                                   // answer in [lo, hi)
+        if (blk_t0) { lo = blk_t0[b]; hi = lo + 1; }
         while (hi - lo > 1) {
             const u64 step = (hi - lo + 63) / 64;
             const u64 p = lo + (u64)lane * step;
@@ -843,7 +867,10 @@ __global__ __launch_bounds__(256) void k_direct_blocks(const u8 *text, const u64
         t0 = lo;
         // the tiles behind it that hold bases below B1 (a regular tile holds ~4000: 17 of them at most)
         const u64 t = t0 + lane;
-        const bool in = t < tiles && t_seq[t] < B1;
+        const u64 ts = t <= tiles ? t_seq[t] : ~0ull;
+        const bool in = t < tiles && ts < B1;
+        // (k_zenc_write_direct_loc: the base counts in front of the block's tiles, less its first base)
+        if (blk_bnd && lane < ZENC_LOC_BND) { const i64 rel = (i64)ts - (i64)B0; blk_bnd[(u64)b * ZENC_LOC_BND + lane] = t <= tiles && rel < (1 << 30) ? (i32)rel : (i32)(1 << 30); }
         const u64 bal = __ballot(in);
         const bool good = !in || ((t_reg[t] & REG_ACGT) != 0);
         ok = __ballot(!good) == 0 && bal != ~0ull;                // (64 tiles and still not at B1: some hold few bases, leave it)
@@ -876,13 +903,20 @@ __global__ __launch_bounds__(256) void k_direct_blocks(const u8 *text, const u64
         ns = (u32)__shfl((int)ns, 0, 64); h = __shfl(h, 0, 64);
         ok = ns >= 1024 && h * (float)prefer_flat > 4.0f * (float)ns * (float)(prefer_flat - 1);
     }
-    if (b < nd && lane == 0) { direct[b] = ok ? 1 : 0; if (blk_t0) blk_t0[b] = (u32)t0; }   // (blk_t0: the tile that holds the block's first base, for k_zenc_write_direct_loc)
+    if (b < nd && lane == 0) direct[b] = ok ? 1 : 0;
 }
 // the tiles k_enc_count did not find regular, in order (pre = exclusive scan of its 0 / 1 verdicts)
-__global__ void k_irregular_list(const u32 *t_reg, const u64 *pre, u64 tiles, u32 *list)
+// blk_t0 (may be null): the tile that holds base 65536 b, the first of block b of the packed stream, for every such base there is
+// (t_seq: the exclusive scan of the tiles' base counts with the total behind it)
+__global__ void k_irregular_list(const u32 *t_reg, const u64 *pre, u64 tiles, u32 *list, const u64 *t_seq = nullptr, u32 *blk_t0 = nullptr)
 {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < tiles && !t_reg[t]) list[pre[t]] = (u32)t;
+    if (t >= tiles) return;
+    if (!t_reg[t]) list[pre[t]] = (u32)t;
+    if (blk_t0) {
+        const u64 lo = t_seq[t], hi = t_seq[t + 1];
+        for (u64 b = (lo + 65535) >> 16; (b << 16) < hi; b++) blk_t0[b] = (u32)t;
+    }
 }
 // the groups a tile shares with its neighbours (and the last group of the stream, whose padding must read as zero)
 __global__ void k_pack_edges_zero(const u64 *t_seq, u64 tiles, u64 T, u8 *packed, u32 *casebits, const u8 *direct, u32 nd, u32 loc_mode = 0)
@@ -1183,13 +1217,15 @@ __global__ __launch_bounds__(256) void k_sparse_list(EncP P, const i64 *tile_eol
             }
         }
     }
+    // (one atomic per workgroup: with one per wavefront 38 K of them queued on the one address for a tenth of a millisecond per 10 GB)
+    __shared__ u32 s_cnt[4], s_base;
     const u64 bal = __ballot(want);
-    if (bal) {
-        u32 base = 0;
-        if (lane == 0) base = atomicAdd(n_list, (u32)__popcll(bal));
-        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-        if (want) list[base + (u32)__popcll(bal & ((1ull << lane) - 1))] = (u32)t;
-    }
+    const u32 wv = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wv] = (u32)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) { const u32 tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]; s_base = tot ? atomicAdd(n_list, tot) : 0u; }
+    __syncthreads();
+    if (want) { u32 pre = s_base; for (u32 w = 0; w < wv; w++) pre += s_cnt[w]; list[pre + (u32)__popcll(bal & ((1ull << lane) - 1))] = (u32)t; }
     len = wave_scan_inclusive<u64, OpMaxU64>(len);
     if (lane == 63 && len > __atomic_load_n(O.longest, __ATOMIC_RELAXED)) atomicMax((unsigned long long *)O.longest, (unsigned long long)len);
 }
@@ -2193,6 +2229,8 @@ static void set_expected(EncP &P, int seq_type, bool fasta)
     for (const char *p = "ACGTUN"; *p; p++) { u32 ch = (u32)*p; if (has(ch) && has(ch | 0x20) && q[(ch >> 1) & 7] == 0xFF) q[(ch >> 1) & 7] = (u8)ch; }
     memcpy(&P.qlo, q, 4); memcpy(&P.qhi, q + 4, 4);
     q[5] = 0x0A; q[6] = 0x0D; memcpy(&P.plo, q, 4); memcpy(&P.phi, q + 4, 4);   // (slots 5 and 6 belong to no letter of A C G T U N)
+    // (0xFF sits in slot 7 and 0x00 in slot 0: neither equals the entry of another slot)
+    { u8 t[8] = { q[0], q[1], q[2], q[3], 0x00, 0x0A, 0x00, 0x00 }; memcpy(&P.slo, t, 4); memcpy(&P.shi, t + 4, 4); }
 }
 
 // confirm_input_format (process.c:547-583): first non-space byte, the byte in front of it
@@ -2441,7 +2479,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
             // pure tiles (nearly all of a genome) a wavefront per tile; the others, from a list, by the general kernel
             u32 *t_needf = fused ? t_needf0 : arena_new<u32>(c, tiles + 1), *need_list = arena_new<u32>(c, tiles + 1); u64 *t_need = fused ? t_need0 : arena_new<u64>(c, tiles + 2);
             if (!t_needf || !need_list || !t_need) return NAF_GPU_ENOMEM;
-            if (fused) LAUNCH(c, "ennaf_pure_check", k_pure_check, cdiv(tiles, 256), 256, 0, P, (const i64 *)t_eol, tiles, t_needf, t_need, t_reg, t_irr);
+            if (fused) LAUNCH(c, "ennaf_pure_check", k_pure_check, cdiv(tiles, 256), 256, 0, P, (const i64 *)t_eol, tiles, t_needf, t_need, t_reg, t_irr, (const u32 *)t_tail);
             else if (enc_wave_wg(c)) LAUNCH(c, "ennaf_count_pure", (k_enc_count_pure<1, 1>), (u32)tiles, 64, 0, P, (const i64 *)t_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, tiles);
             else LAUNCH(c, "ennaf_count_pure", (k_enc_count_pure<4, 1>), cdiv(tiles, 4), 256, 0, P, (const i64 *)t_eol, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, tiles);
             if ((rc = scan_exclusive_u64(c, t_need, tiles, tot + 5))) return rc;
@@ -2461,9 +2499,11 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;
         if ((rc = scan_exclusive_u64(c, t_rec, tiles, tot + 3))) return rc;
         if ((rc = scan_exclusive_u64(c, t_irr, tiles, tot + 4))) return rc;
-        LAUNCH(c, "ennaf_irregular_list", k_irregular_list, cdiv(tiles, 256), 256, 0, (const u32 *)t_reg, (const u64 *)t_irr, tiles, irr_list);
         // t_seq[tiles] must hold the grand total for the "line began in an earlier tile" lookup
         HIP_TRY(c, hipMemcpyAsync(t_seq + tiles, tot + 0, 8, hipMemcpyDeviceToDevice, c->stream));
+        u32 *blk_t0 = fused ? arena_new<u32>(c, (size_t)(n >> 16) + 2) : nullptr;            // (a block's 65536 bases are at least as many bytes of text)
+        if (fused && !blk_t0) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "ennaf_irregular_list", k_irregular_list, cdiv(tiles, 256), 256, 0, (const u32 *)t_reg, (const u64 *)t_irr, tiles, irr_list, (const u64 *)t_seq, blk_t0);
         u64 h[7];
         if ((rc = ctx_readback(c, h, tot, 56))) return rc;
         T = h[0]; n_ids = h[1]; n_cmt = h[2]; N = h[3];
@@ -2498,9 +2538,9 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
                 // the codes k_enc_fused left are the direct blocks' when the text has no case bit to keep beside them (a text with lower case:
                 // the scatter pass makes codes and case bits of every tile, as before)
                 const bool use_loc = fused && S.no_case;
-                u32 *blk_t0 = use_loc ? arena_new<u32>(c, (size_t)S.nd + 1) : nullptr;
-                if (use_loc && !blk_t0) return NAF_GPU_ENOMEM;
-                LAUNCH(c, "ennaf_direct_blocks", k_direct_blocks, cdiv(S.nd, 4), 256, 0, d_text, (const u64 *)t_seq, (const u32 *)t_reg, tiles, S.nd, prefer_flat, (epr && epr[0] == '0') ? 0 : 1, S.direct, blk_t0);
+                i32 *blk_bnd = use_loc ? arena_new<i32>(c, (size_t)S.nd * ZENC_LOC_BND + 1) : nullptr;
+                if (use_loc && !blk_bnd) return NAF_GPU_ENOMEM;
+                LAUNCH(c, "ennaf_direct_blocks", k_direct_blocks, cdiv(S.nd, 4), 256, 0, d_text, (const u64 *)t_seq, (const u32 *)t_reg, tiles, S.nd, prefer_flat, (epr && epr[0] == '0') ? 0 : 1, S.direct, (const u32 *)blk_t0, blk_bnd);
                 O.direct = S.direct; O.nd = S.nd;
                 if (use_loc) {
                     u32 *sparse_list = arena_new<u32>(c, tiles + 1), *n_sparse = arena_new<u32>(c, 2);
@@ -2508,7 +2548,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
                     HIP_TRY(c, hipMemsetAsync(n_sparse, 0, 8, c->stream));
                     O.loc_mode = 1; O.sparse_list = sparse_list; O.n_sparse = n_sparse;
                     LAUNCH(c, "ennaf_sparse_list", k_sparse_list, cdiv(tiles, 256), 256, 0, P, (const i64 *)t_eol, O, tiles, sparse_list, n_sparse);
-                    S.dloc.loc = loc; S.dloc.t_seq = t_seq; S.dloc.blk_t0 = blk_t0; S.dloc.tiles = tiles;
+                    S.dloc.loc = loc; S.dloc.blk_bnd = blk_bnd; S.dloc.blk_t0 = blk_t0; S.dloc.tiles = tiles;
                 }
                 if (ctx_tracing(c)) {
                     std::vector<u8> hd(S.nd); hipStreamSynchronize(c->stream); hipMemcpy(hd.data(), S.direct, S.nd, hipMemcpyDeviceToHost);

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(con
         if (fast) {
             p.pad = dir ? 2 : 1;                                  // (k_zenc_write packs such a block with all lanes; 2: copies its ready streams)
             if (lane == 0) { plan[b] = p; if (csize) csize[b] = p.csize; }
+            if (!dir)                                              // (nobody encodes a direct block's bytes)
             for (u32 sym = lane; sym < 256; sym += 64) {
                 const bool is16 = __popc(sym & 15u) == 1 && __popc(sym >> 4) == 1;
                 const u32 hn = sym >> 4, ln = sym & 15u, rank = 4 * ((hn >> 1) - (hn >> 3)) + ((ln >> 1) - (ln >> 3));
@@ -1160,37 +1161,37 @@ __global__ __launch_bounds__(256) void k_zenc_write_direct(const u8 *src, u32 nb
 __device__ __forceinline__ u32 nibble_rev32(u32 x) { const u32 r = __builtin_bswap32(x); return ((r & 0x0F0F0F0Fu) << 4) | ((r >> 4) & 0x0F0F0F0Fu); }
 __global__ __launch_bounds__(256) void k_zenc_write_direct_loc(ZencLoc D, u32 nblk, const ZEncPlan *plan, const u8 *trees, const u64 *offs, u8 *dst, u64 frame_hdr, u32 not_last)
 {
-    __shared__ i32 s_bnd[24];                                     // base counts in front of tiles t0 .. t0 + 23, less the block's first base
+    __shared__ i32 s_bnd[4][ZENC_LOC_BND];                        // base counts in front of tiles t0 .. t0 + 19, less the block's first base (k_direct_blocks)
     const u32 b = blockIdx.x, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (the three loads are asked for together: the tables are in bounds for every block, meaningful for the direct ones)
+    const u64 t0 = D.blk_t0[b];
+    const i32 mine = lane < ZENC_LOC_BND ? D.blk_bnd[(u64)b * ZENC_LOC_BND + lane] : 0;
     const ZEncPlan p = plan[b];
     if (p.kind != ZK_HUF || p.pad != 2) return;
-    const u64 t0 = D.blk_t0[b], B0 = (u64)b << 16;
-    if (threadIdx.x < 24) {
-        const u64 t = t0 + threadIdx.x;
-        const i64 rel = t <= D.tiles ? (i64)D.t_seq[t] - (i64)B0 : (i64)(1 << 30);       // (t_seq[tiles] = the total)
-        s_bnd[threadIdx.x] = (i32)(rel > (1 << 30) ? (1 << 30) : rel);
-    }
-    const u32 o = 3 + p.lhdr + p.tree_bytes + 6 + (q > 0 ? p.ssz[0] : 0u) + (q > 1 ? p.ssz[1] : 0u) + (q > 2 ? p.ssz[2] : 0u);
-    u8 *out = dst + frame_hdr + offs[b], *so = out + o;
-    if (threadIdx.x == 255) { zenc_write_block_prefix(out, p, trees + (u64)b * ZENC_TREE_SLOT, b + 1 == nblk && !not_last, 0); out[p.csize - 1] = 0; }
-    __syncthreads();
-    const i32 b0rel = s_bnd[0];                                   // <= 0
+    // every wavefront keeps its own copy: no barrier between the table and the loads that need it
+    if (lane < ZENC_LOC_BND) s_bnd[q][lane] = mine;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const i32 *bnd = s_bnd[q];
+    const i32 b0rel = bnd[0];                                     // <= 0
     u64 lo[4], hi[4]; u32 x[4], sh[4], avail[4]; const u8 *nx[4];
 #pragma unroll
     for (u32 r = 0; r < 4; r++) {
         const u32 cidx = r * 64 + lane, Q = 255u - cidx;              // sixteen bytes of the stream <- groups 4 Q .. 4 Q + 3 of it
         const i32 r0 = (i32)(16384u * q + 64u * Q);                   // the quad's first base, counted from the block's first
         u32 k = (u32)(r0 - b0rel) >> 12;                              // tiles hold at most 4096 bases: not behind this one ...
-        if (s_bnd[k + 1] <= r0) k++;                                  // ... and, as they hold at least 3972, at most two further
-        if (s_bnd[k + 1] <= r0) k++;
-        const u32 i = (u32)(r0 - s_bnd[k]);
+        if (bnd[k + 1] <= r0) k++;                                    // ... and, as they hold at least 3972, at most two further
+        if (bnd[k + 1] <= r0) k++;
+        const u32 i = (u32)(r0 - bnd[k]);
         const u8 *pp = D.loc + (t0 + k) * 1024 + (i >> 2);
         lo[r] = ld64(pp); hi[r] = ld64(pp + 8); x[r] = pp[16];
         sh[r] = 2u * (i & 3u);
-        const u32 av = (u32)(s_bnd[k + 1] - r0);                      // bases of the quad this tile still has (>= 1)
+        const u32 av = (u32)(bnd[k + 1] - r0);                      // bases of the quad this tile still has (>= 1)
         avail[r] = av < 64u ? av : 64u;
         nx[r] = D.loc + (t0 + k + 1) * 1024;
     }
+    const u32 o = 3 + p.lhdr + p.tree_bytes + 6 + (q > 0 ? p.ssz[0] : 0u) + (q > 1 ? p.ssz[1] : 0u) + (q > 2 ? p.ssz[2] : 0u);
+    u8 *out = dst + frame_hdr + offs[b], *so = out + o;
+    if (threadIdx.x == 255) { zenc_write_block_prefix(out, p, trees + (u64)b * ZENC_TREE_SLOT, b + 1 == nblk && !not_last, 0); out[p.csize - 1] = 0; }
     uint4 v[4];
 #pragma unroll
     for (u32 r = 0; r < 4; r++) {
