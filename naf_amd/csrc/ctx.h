@@ -146,6 +146,10 @@ int zenc_level_window(int level);
 int zenc_repeat_probe(naf_gpu_ctx *c, const u8 *d_src, size_t n, u32 *share_1024);   // level 1: share of sampled anchors that repeat inside their 1 MiB region
 // place != nullptr: the frame's size is read back once it is planned and place->fn(place->ud, size) names where it goes (nullptr = give up,
 // the hook has set the context's error); d_dst / cap are not looked at.  Saves the copy of a frame whose position depends on its size.
+// The level-1 look at a stream (zenc_repeat_probe) reads one MiB in every `zenc_probe_every(n)`: one in 64, fewer for streams above
+// 8 GiB so that at most 128 regions are read whatever the size (the share of repeats in 128 MiB is known well enough, and what the look
+// reads are blocks the split pass cannot make direct: enc.hip k_direct_blocks asks the same function)
+static inline u32 zenc_probe_every(u64 n) { u32 e = 64; while (((n >> 20) / e) > 128) e <<= 1; return e; }
 struct ZencPlace { u8 *(*fn)(void *ud, size_t frame_len); void *ud; };
 // zstd_encode in two halves: begin queues the planning of the blocks and returns without waiting; finish reads the size back, writes the
 // blocks and releases the job (also to be called after a failed begin that left a job).  What a caller queues in between runs beside the planning.

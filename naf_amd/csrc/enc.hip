@@ -614,20 +614,11 @@ __device__ __forceinline__ u32 last_pos_pair(u32 eol, u32 sp, u32 at)
     return (eol ? at + 1 + (31 - __clz((int)eol)) : 0u) | ((sp ? at + 1 + (31 - __clz((int)sp)) : 0u) << 16);
 }
 template <bool LOC>
-__global__ __launch_bounds__(64) void k_enc_fused(EncP P, i64 *tile_eol, i64 *tile_sp, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
-                                                  u32 *t_needf, u64 *t_need, u64 tiles, u8 *loc)
+__device__ __forceinline__ void fused_tile(const EncP &P, i64 *tile_eol, i64 *tile_sp, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
+                                           u32 *t_needf, u64 *t_need, u8 *loc, u8 *t_hist, u64 t, bool inside, const uint4 (&v)[4], u32 *s_code)
 {
-    __shared__ u32 s_code[LOC ? 260 : 4];                          // the tile's bytes as two-bit codes, in text order (line ends among them)
     const u32 lane = threadIdx.x;
-    const u64 t = blockIdx.x;
-    if (t >= tiles) return;
     const u64 tb = t * ET_TILE;
-    const bool inside = tb >= P.p0 && tb + ET_TILE <= P.n;
-    uint4 v[4];
-    if (inside) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) __builtin_memcpy(&v[k], P.text + tb + (64u * (u32)k + lane) * ET_BYTES, 16);
-    }
     u32 eol[4]; bool acgt = false, lower_any = false, fast = false;
     if (inside) {
         // first look: nothing but upper-case A C G T / U and '\n' (every tile of the texts this pass is for): a table look-up and a
@@ -668,10 +659,22 @@ __global__ __launch_bounds__(64) void k_enc_fused(EncP P, i64 *tile_eol, i64 *ti
     // (a tile that needed the second look and is regular A C G T all the same holds lower case: the text's codes are then not taken from `loc`)
     if (!LOC || !fast || !r.ok) return;
     // the tile's bytes as codes, once: four bytes -> eight bits, a lane's sixteen bytes -> one word of the LDS string
+    u32 cw0 = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-        s_code[64u * (u32)k + lane] = code2x4(v[k].x) | (code2x4(v[k].y) << 8) | (code2x4(v[k].z) << 16) | (code2x4(v[k].w) << 24);
+    for (int k = 0; k < 4; k++) {
+        const u32 cw = code2x4(v[k].x) | (code2x4(v[k].y) << 8) | (code2x4(v[k].z) << 16) | (code2x4(v[k].w) << 24);
+        s_code[64u * (u32)k + lane] = cw;
+        if (k == 0) cw0 = cw;
+    }
+    // what k_direct_verdict weighs a block by: the pair codes of bytes 0, 1 and 2, 3 of every lane's first piece (128 pairs of the tile's
+    // 2 K, none that holds a line end), counted in sixteen bins
+    u32 *s_hist = s_code + 264;
+    if (lane < 16) s_hist[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!(eol[0] & 3u)) atomicAdd(&s_hist[cw0 & 15u], 1u);
+    if (!(eol[0] & 12u)) atomicAdd(&s_hist[(cw0 >> 4) & 15u], 1u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 16) t_hist[t * 16 + lane] = (u8)s_hist[lane];
     // the tile's bases in order: lane l takes bases 64 l .. 64 l + 63, four groups of 16; a group is the 32 bits at twice its first base's
     // text position, less the two bits of the line end when one lies among its 17 bytes (lines hold at least 32 bases: one at most)
     const u32 W = r.period - 1, nb = ET_TILE - r.E;
@@ -699,6 +702,31 @@ __global__ __launch_bounds__(64) void k_enc_fused(EncP P, i64 *tile_eol, i64 *ti
         }
     }
     *(uint4 *)(loc + t * LOC_TILE + lane * 16u) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+}
+// TW tiles per wavefront, the loads of all of them in flight before the first is looked at
+template <bool LOC, u32 TW>
+__global__ __launch_bounds__(64) void k_enc_fused(EncP P, i64 *tile_eol, i64 *tile_sp, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
+                                                  u32 *t_needf, u64 *t_need, u64 tiles, u8 *loc, u8 *t_hist)
+{
+    __shared__ u32 s_code[LOC ? 264 + 16 : 4];                     // the tile's bytes as two-bit codes, in text order (line ends among them); sixteen bins
+    const u32 lane = threadIdx.x;
+    const u64 t0 = (u64)blockIdx.x * TW;
+    uint4 v[TW][4]; bool inside[TW];
+#pragma unroll
+    for (u32 j = 0; j < TW; j++) {
+        const u64 tb = (t0 + j) * ET_TILE;
+        inside[j] = t0 + j < tiles && tb >= P.p0 && tb + ET_TILE <= P.n;
+        if (inside[j]) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) __builtin_memcpy(&v[j][k], P.text + tb + (64u * (u32)k + lane) * ET_BYTES, 16);
+        }
+    }
+#pragma unroll
+    for (u32 j = 0; j < TW; j++) {
+        if (t0 + j >= tiles) break;
+        fused_tile<LOC>(P, tile_eol, tile_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, loc, t_hist, t0 + j, inside[j], v[j], s_code);
+        if (TW > 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+    }
 }
 // behind the scan of the last line ends: a tile k_enc_fused took for pure that begins in a header line is k_enc_count's after all
 __global__ void k_pure_check(EncP P, const i64 *tile_eol, u64 tiles, u32 *t_needf, u64 *t_need, u32 *t_reg, u64 *t_irr, const u32 *t_tail)
@@ -840,7 +868,7 @@ __device__ __forceinline__ void flush_pack(const EncP &P, u8 *packed, u32 *caseb
 //     four bits: Huffman coding could not save the encoder's threshold (the same test k_zenc_flat_scan makes on the packed bytes);
 //   - it is not in a region the level-1 look at the stream reads (zenc_repeat_probe: 1 MiB in every 64, as PACKED bytes).
 // t_seq is the exclusive scan of the tiles' base counts with the total behind it.
-#define DIRECT_PROBE_BLOCKS_LOG 5                                 // 32 blocks of 32 KiB per probed MiB, one MiB in 2^6
+#define DIRECT_PROBE_BLOCKS_LOG 5                                 // 32 blocks of 32 KiB per probed MiB, one MiB in zenc_probe_every()
 __global__ __launch_bounds__(256) void k_direct_blocks(const u8 *text, const u64 *t_seq, const u32 *t_reg, u64 tiles, u32 nd, u32 prefer_flat, int probed, u8 *direct, const u32 *blk_t0 = nullptr, i32 *blk_bnd = nullptr)
 {
     __shared__ u32 bins[4][64];                                   // 4 copies x 16 bins per wave
@@ -849,7 +877,7 @@ __global__ __launch_bounds__(256) void k_direct_blocks(const u8 *text, const u64
     bins[wv][lane] = 0;
     __syncthreads();
     bool ok = b < nd;
-    if (ok && probed && (((b >> DIRECT_PROBE_BLOCKS_LOG) & 63u) == 0)) ok = false;
+    if (ok && probed && (((b >> DIRECT_PROBE_BLOCKS_LOG) & (u32)(probed - 1)) == 0)) ok = false;       // probed: zenc_probe_every of the stream, 0: no look
     u64 t0 = 0, t1 = 0;
     if (ok) {
         const u64 B0 = (u64)b << 16, B1 = B0 + 65536;
@@ -904,6 +932,51 @@ __global__ __launch_bounds__(256) void k_direct_blocks(const u8 *text, const u64
         ok = ns >= 1024 && h * (float)prefer_flat > 4.0f * (float)ns * (float)(prefer_flat - 1);
     }
     if (b < nd && lane == 0) direct[b] = ok ? 1 : 0;
+}
+// The same verdict a THREAD per block, from what k_enc_fused left per tile (t_hist: sixteen counts of sampled pair codes): no look at
+// the text, and everything a block needs lies at addresses known once its first tile is (blk_t0) -- a wavefront per block that samples
+// the text was 2.1 ms per 100 GB of dependent loads.  A direct block's tiles are regular (at least 3971 bases each): nineteen at most.
+// Also writes blk_bnd (k_zenc_write_direct_loc).
+__global__ __launch_bounds__(256) void k_direct_verdict(const u64 *t_seq, const u32 *t_reg, const u8 *t_hist, u64 tiles, u32 nd, u32 prefer_flat, int probed, const u32 *blk_t0, u8 *direct, i32 *blk_bnd)
+{
+    const u32 b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nd) return;
+    const u64 B0 = (u64)b << 16, B1 = B0 + 65536, t0 = blk_t0[b];
+    bool ok = !(probed && (((b >> DIRECT_PROBE_BLOCKS_LOG) & (u32)(probed - 1)) == 0));
+    u64 ts[ZENC_LOC_BND];
+#pragma unroll
+    for (u32 i = 0; i < ZENC_LOC_BND; i++) ts[i] = t0 + i <= tiles ? t_seq[t0 + i] : ~0ull;
+#pragma unroll
+    for (u32 i = 0; i < ZENC_LOC_BND; i++) { const i64 rel = (i64)ts[i] - (i64)B0; blk_bnd[(u64)b * ZENC_LOC_BND + i] = ts[i] != ~0ull && rel < (1 << 30) ? (i32)rel : (i32)(1 << 30); }
+    u32 acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };                    // sixteen 16-bit sums
+    bool end = false;
+#pragma unroll
+    for (u32 i = 0; i < ZENC_LOC_BND - 1; i++) {
+        if (!end && ok) {
+            if (t0 + i >= tiles || ts[i] >= B1) end = true;
+            else if (!(t_reg[t0 + i] & REG_ACGT)) ok = false;
+            else {
+                const uint4 h = *(const uint4 *)(t_hist + (t0 + i) * 16);
+                acc[0] += h.x & 0x00FF00FFu; acc[1] += (h.x >> 8) & 0x00FF00FFu; acc[2] += h.y & 0x00FF00FFu; acc[3] += (h.y >> 8) & 0x00FF00FFu;
+                acc[4] += h.z & 0x00FF00FFu; acc[5] += (h.z >> 8) & 0x00FF00FFu; acc[6] += h.w & 0x00FF00FFu; acc[7] += (h.w >> 8) & 0x00FF00FFu;
+            }
+        }
+    }
+    ok = ok && end;
+    if (ok) {
+        u32 ns = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) ns += (acc[k] & 0xFFFFu) + (acc[k] >> 16);
+        float h = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32 c0 = acc[k] & 0xFFFFu, c1 = acc[k] >> 16;
+            if (c0) h += (float)c0 * __log2f((float)ns / (float)c0);
+            if (c1) h += (float)c1 * __log2f((float)ns / (float)c1);
+        }
+        ok = ns >= 1024 && h * (float)prefer_flat > 4.0f * (float)ns * (float)(prefer_flat - 1);
+    }
+    direct[b] = ok ? 1 : 0;
 }
 // the tiles k_enc_count did not find regular, in order (pre = exclusive scan of its 0 / 1 verdicts)
 // blk_t0 (may be null): the tile that holds base 65536 b, the first of block b of the packed stream, for every such base there is
@@ -2464,12 +2537,13 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         const bool direct_opts = allow_direct && S.fourbit && o->level <= 1 && !o->long_log && !(e_ed && e_ed[0] == '0') && e_prefer_flat >= 2 && !(e_ebl && atoi(e_ebl) != 15) && !(e_epr && e_epr[0] == '1')
                                  && !(e_elz && !strcmp(e_elz, "all")) && n >= 16 * ET_TILE;
         const bool fused = direct_opts && enc_wave_wg(c) && !(e_op && e_op[0] == '0') && (n >> 17) >= ((e_ed && e_ed[0] == '2') || (e_op && e_op[0] == '2') ? 2u : 256u);
-        u8 *loc = nullptr; u32 *t_needf0 = nullptr; u64 *t_need0 = nullptr;
+        u8 *loc = nullptr, *t_hist = nullptr; u32 *t_needf0 = nullptr; u64 *t_need0 = nullptr;
         if (fused) {
-            loc = (u8 *)arena_alloc(c, (tiles + 1) * LOC_TILE + 64);
+            loc = (u8 *)arena_alloc(c, (tiles + 1) * LOC_TILE + 64); t_hist = (u8 *)arena_alloc(c, (tiles + 1) * 16);
             t_needf0 = arena_new<u32>(c, tiles + 1); t_need0 = arena_new<u64>(c, tiles + 2);
-            if (!loc || !t_needf0 || !t_need0) return NAF_GPU_ENOMEM;
-            LAUNCH(c, "ennaf_split_once", k_enc_fused<true>, (u32)tiles, 64, 0, P, t_eol, t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf0, t_need0, tiles, loc);
+            if (!loc || !t_hist || !t_needf0 || !t_need0) return NAF_GPU_ENOMEM;
+            // (two and four tiles per wavefront, their loads in flight together: 23.8 -> 28.3 / 25.9 ms per 100 GB)
+            LAUNCH(c, "ennaf_split_once", (k_enc_fused<true, 1>), (u32)tiles, 64, 0, P, t_eol, t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf0, t_need0, tiles, loc, t_hist);
         } else
         LAUNCH(c, "ennaf_last", k_enc_last_fa, cdiv(tiles, 4 * LAST_TPW), 256, 0, P, t_eol, t_sp, tiles);
         // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
@@ -2540,7 +2614,8 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
                 const bool use_loc = fused && S.no_case;
                 i32 *blk_bnd = use_loc ? arena_new<i32>(c, (size_t)S.nd * ZENC_LOC_BND + 1) : nullptr;
                 if (use_loc && !blk_bnd) return NAF_GPU_ENOMEM;
-                LAUNCH(c, "ennaf_direct_blocks", k_direct_blocks, cdiv(S.nd, 4), 256, 0, d_text, (const u64 *)t_seq, (const u32 *)t_reg, tiles, S.nd, prefer_flat, (epr && epr[0] == '0') ? 0 : 1, S.direct, (const u32 *)blk_t0, blk_bnd);
+                if (use_loc) LAUNCH(c, "ennaf_direct_blocks", k_direct_verdict, cdiv(S.nd, 256), 256, 0, (const u64 *)t_seq, (const u32 *)t_reg, (const u8 *)t_hist, tiles, S.nd, prefer_flat, (epr && epr[0] == '0') ? 0 : (int)zenc_probe_every(n_seqb), (const u32 *)blk_t0, S.direct, blk_bnd);
+                else LAUNCH(c, "ennaf_direct_blocks", k_direct_blocks, cdiv(S.nd, 4), 256, 0, d_text, (const u64 *)t_seq, (const u32 *)t_reg, tiles, S.nd, prefer_flat, (epr && epr[0] == '0') ? 0 : (int)zenc_probe_every(n_seqb), S.direct, (const u32 *)blk_t0, blk_bnd);
                 O.direct = S.direct; O.nd = S.nd;
                 if (use_loc) {
                     u32 *sparse_list = arena_new<u32>(c, tiles + 1), *n_sparse = arena_new<u32>(c, 2);

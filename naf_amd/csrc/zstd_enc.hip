@@ -55,11 +55,15 @@ __host__ __device__ static inline u64 zenc_block_lo(u64 n, u32 nblk, u32 b) { u6
 // workspace cleared first, a dozen barriers) 152 K blocks took 1.6 - 2.0 ms.
 #define ZENC_FLATSCAN_WAVES 4
 // direct[b] != 0: the block is known to be such a block and its four streams are already coded (enc.hip: direct_word; plan.pad = 2) -- nothing is read.
-__global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, u8 *done, u32 min_gain, u32 prefer_flat, ZFlat16 f16, const u8 *direct)
+__global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u8 *trees, u64 *csize, u8 *done, u32 min_gain, u32 prefer_flat, ZFlat16 f16, const u8 *planned, const u8 *direct)
 {
     __shared__ u32 bins[ZENC_FLATSCAN_WAVES][64];                 // 4 copies x 16 bins per wave: copy = (lane >> 2) & 3
     const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 b = blockIdx.x * ZENC_FLATSCAN_WAVES + wv;
+    // (a bounded grid walks the blocks four at a time: a workgroup per four blocks that only finds them settled was 2 ms of dispatch per 100 GB)
+    for (u32 bq = blockIdx.x; bq * ZENC_FLATSCAN_WAVES < nblk; bq += gridDim.x) {
+    const u32 b = bq * ZENC_FLATSCAN_WAVES + wv;
+    // four direct blocks (nearly every four of a genome's frame): settled by k_zenc_direct_plans, a thread each
+    if (planned && bq * ZENC_FLATSCAN_WAVES + ZENC_FLATSCAN_WAVES <= nblk && *(const u32 *)(planned + bq * ZENC_FLATSCAN_WAVES) == 0x01010101u) continue;
     bins[wv][lane] = 0;
     __syncthreads();
     bool ok = b < nblk;
@@ -124,6 +128,16 @@ __global__ __launch_bounds__(64 * ZENC_FLATSCAN_WAVES) void k_zenc_flat_scan(con
         }
     }
     if (b < nblk && lane == 0) done[b] = fast ? 1 : 0;
+    }
+}
+
+// the plan of a direct block is the same for all of them (32 KiB, the tree f16, four streams of 4096 + 1 bytes): a thread per block
+__global__ void k_zenc_direct_plans(const u8 *direct, u32 nblk, ZEncPlan pd, ZFlat16 f16, ZEncPlan *plan, u8 *trees, u64 *csize, u8 *done)
+{
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk || !direct[b]) return;
+    plan[b] = pd; if (csize) csize[b] = pd.csize; done[b] = 1;
+    for (u32 k = 0; k < pd.tree_bytes; k++) trees[(u64)b * ZENC_TREE_SLOT + k] = f16.tree[k];
 }
 
 // blk_len == nullptr: block b is the b-th piece of the even split of src[0..n).  Otherwise block b is src[b*slot .. b*slot + blk_len[b])
@@ -1154,8 +1168,8 @@ __global__ __launch_bounds__(256) void k_zenc_write_direct(const u8 *src, u32 nb
 // The same blocks when the split pass read its text once (enc.hip: k_enc_fused): the codes wait tile by tile -- base i of tile t in bits
 // 2i, 2i + 1 of the KiB at loc + 1024 t -- and are gathered here: the sixteen bases of group G of the stream (bases 16 G ... of the base
 // stream) are one 32-bit word wherever they lie, two bits a base, the first lowest; in the stream that word stands with its nibbles
-// reversed at place 1023 - (G & 1023) (enc.hip: direct_word).  A lane takes four groups = 64 bases = 128 bits at a time: sixteen bytes and
-// one more from the tile that holds the first of them, shifted down by the two bits per base it starts behind a byte's first; where the
+// reversed at place 1023 - (G & 1023) (enc.hip: direct_word).  A lane takes four groups = 64 bases = 128 bits at a time: five words
+// of the tile that holds the first of them, shifted down by the two bits per base it starts behind a word's first; where the
 // tile ends inside the 64 bases the rest comes from the first sixteen bytes of the next tile, shifted up (a direct block's tiles are
 // regular: at least 3972 bases each, so 64 bases touch two tiles at most and a block's 65536 at most eighteen).
 __device__ __forceinline__ u32 nibble_rev32(u32 x) { const u32 r = __builtin_bswap32(x); return ((r & 0x0F0F0F0Fu) << 4) | ((r >> 4) & 0x0F0F0F0Fu); }
@@ -1173,7 +1187,7 @@ __global__ __launch_bounds__(256) void k_zenc_write_direct_loc(ZencLoc D, u32 nb
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const i32 *bnd = s_bnd[q];
     const i32 b0rel = bnd[0];                                     // <= 0
-    u64 lo[4], hi[4]; u32 x[4], sh[4], avail[4]; const u8 *nx[4];
+    uint4 A[4]; u32 E[4], sh[4], avail[4]; u64 N0[4], N1[4];
 #pragma unroll
     for (u32 r = 0; r < 4; r++) {
         const u32 cidx = r * 64 + lane, Q = 255u - cidx;              // sixteen bytes of the stream <- groups 4 Q .. 4 Q + 3 of it
@@ -1182,12 +1196,14 @@ __global__ __launch_bounds__(256) void k_zenc_write_direct_loc(ZencLoc D, u32 nb
         if (bnd[k + 1] <= r0) k++;                                    // ... and, as they hold at least 3972, at most two further
         if (bnd[k + 1] <= r0) k++;
         const u32 i = (u32)(r0 - bnd[k]);
-        const u8 *pp = D.loc + (t0 + k) * 1024 + (i >> 2);
-        lo[r] = ld64(pp); hi[r] = ld64(pp + 8); x[r] = pp[16];
-        sh[r] = 2u * (i & 3u);
+        // the 128 bits from bit 2 i of the tile's string on: five words from word i / 16 (one 16-byte load at a 4-byte boundary and a word)
+        const u32 *pw = (const u32 *)(D.loc + (t0 + k) * 1024) + (i >> 4);
+        __builtin_memcpy(&A[r], pw, 16); E[r] = pw[4];
+        sh[r] = 2u * (i & 15u);
         const u32 av = (u32)(bnd[k + 1] - r0);                      // bases of the quad this tile still has (>= 1)
         avail[r] = av < 64u ? av : 64u;
-        nx[r] = D.loc + (t0 + k + 1) * 1024;
+        N0[r] = N1[r] = 0;
+        if (av < 64u) { const u8 *nx = D.loc + (t0 + k + 1) * 1024; N0[r] = ld64(nx); N1[r] = ld64(nx + 8); }   // the tile ends inside the quad: the next tile's first bases
     }
     const u32 o = 3 + p.lhdr + p.tree_bytes + 6 + (q > 0 ? p.ssz[0] : 0u) + (q > 1 ? p.ssz[1] : 0u) + (q > 2 ? p.ssz[2] : 0u);
     u8 *out = dst + frame_hdr + offs[b], *so = out + o;
@@ -1195,10 +1211,11 @@ __global__ __launch_bounds__(256) void k_zenc_write_direct_loc(ZencLoc D, u32 nb
     uint4 v[4];
 #pragma unroll
     for (u32 r = 0; r < 4; r++) {
-        u64 a = lo[r], c = hi[r];
-        if (sh[r]) { a = (a >> sh[r]) | (c << (64 - sh[r])); c = (c >> sh[r]) | ((u64)x[r] << (64 - sh[r])); }
-        if (avail[r] < 64u) {                                         // the tile ends inside the quad: the rest from the next tile's first bases
-            const u64 n0 = ld64(nx[r]), n1 = ld64(nx[r] + 8);
+        const u32 w0 = __builtin_amdgcn_alignbit(A[r].y, A[r].x, sh[r]), w1 = __builtin_amdgcn_alignbit(A[r].z, A[r].y, sh[r]),
+                  w2 = __builtin_amdgcn_alignbit(A[r].w, A[r].z, sh[r]), w3 = __builtin_amdgcn_alignbit(E[r], A[r].w, sh[r]);
+        u64 a = (u64)w0 | ((u64)w1 << 32), c = (u64)w2 | ((u64)w3 << 32);
+        if (avail[r] < 64u) {                                         // the rest from the next tile
+            const u64 n0 = N0[r], n1 = N1[r];
             const u32 s = 2u * avail[r];                              // 2 .. 126
             if (s < 64) { const u64 m = (1ull << s) - 1; a = (a & m) | (n0 << s); c = (n1 << s) | (n0 >> (64 - s)); }
             else if (s == 64) { c = n0; }
@@ -1227,12 +1244,11 @@ __global__ void k_zenc_frame_header(u8 *dst, int with_magic, u32 wlog)
 // anchor of the same regions asks the table whether an earlier position of its region holds the same 16 bytes.  The share of anchors
 // that do is read back.
 #define PROBE_REGION_LOG 20
-#define PROBE_EVERY 64
 #define PROBE_TLOG 16
-__global__ __launch_bounds__(256) void k_ldm_probe(const u8 *src, u64 n, u32 *tab, u32 *counts /* per workgroup: anchors | hits << 16 */, int pass)
+__global__ __launch_bounds__(256) void k_ldm_probe(const u8 *src, u64 n, u32 *tab, u32 *counts /* per workgroup: anchors | hits << 16 */, int pass, u32 every)
 {
     // thread: 8 consecutive positions of a sampled region (grid: regions x 512 workgroups)
-    const u64 region = (u64)(blockIdx.x >> 9) * PROBE_EVERY, rbase = region << PROBE_REGION_LOG;
+    const u64 region = (u64)(blockIdx.x >> 9) * every, rbase = region << PROBE_REGION_LOG;
     const u64 p0 = rbase + ((u64)(blockIdx.x & 511) * 256 + threadIdx.x) * 8;
     u32 anchors = 0, hits = 0;
     if (p0 + 24 <= n) {
@@ -1264,13 +1280,14 @@ int zenc_repeat_probe(naf_gpu_ctx *c, const u8 *d_src, size_t n, u32 *share_1024
     *share_1024 = 0;
     if (n < 65536) return 0;                                      // nothing a second block could refer to
     if (n < (4u << PROBE_REGION_LOG)) { *share_1024 = 1024; return 0; }   // a few megabytes: matching them costs a millisecond or two, just do it
-    const u64 regions = ((n >> PROBE_REGION_LOG) + PROBE_EVERY - 1) / PROBE_EVERY;
+    const u32 every = zenc_probe_every(n);
+    const u64 regions = ((n >> PROBE_REGION_LOG) + every - 1) / every;
     const u32 nwg = (u32)(regions * 512);
     u32 *tab = arena_new<u32>(c, regions << PROBE_TLOG), *cnt = arena_new<u32>(c, nwg);
     if (!tab || !cnt) return NAF_GPU_ENOMEM;
     HIP_TRY(c, hipMemsetAsync(tab, 0xFF, (regions << PROBE_TLOG) * 4, c->stream));
-    LAUNCH(c, "zenc_probe_insert", k_ldm_probe, nwg, 256, 0, d_src, (u64)n, tab, cnt, 0);
-    LAUNCH(c, "zenc_probe_count", k_ldm_probe, nwg, 256, 0, d_src, (u64)n, tab, cnt, 1);
+    LAUNCH(c, "zenc_probe_insert", k_ldm_probe, nwg, 256, 0, d_src, (u64)n, tab, cnt, 0, every);
+    LAUNCH(c, "zenc_probe_count", k_ldm_probe, nwg, 256, 0, d_src, (u64)n, tab, cnt, 1, every);
     std::vector<u32> hc(nwg);
     int rc = ctx_readback(c, hc.data(), cnt, (size_t)nwg * 4); if (rc) return rc;
     u64 h[2] = { 0, 0 };
@@ -1364,7 +1381,20 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
         return ctx_fail(c, NAF_GPU_EARG, "direct blocks: the stream must be %u blocks of 32 KiB coded without the match finder", nd);
     if (prefer_flat >= 2 && n >= 2048 && zenc_flat16().tb) {
         done = (u8 *)arena_alloc(c, nblk); if (!done) return NAF_GPU_ENOMEM;
-        LAUNCH(c, "zenc_flat_scan", k_zenc_flat_scan, cdiv(nblk, ZENC_FLATSCAN_WAVES), 64 * ZENC_FLATSCAN_WAVES, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, done, min_gain, prefer_flat, zenc_flat16(), direct);
+        bool dplans = false;
+        if (direct) {
+            // what k_zenc_flat_scan makes of a direct block, once, on the host
+            ZEncPlan pd; memset(&pd, 0, sizeof pd);
+            const u32 bn = 32768, perq = bn / 4;
+            pd.n = bn; pd.kind = ZK_RAW; pd.csize = 3 + bn;
+            for (u32 k = 0; k < 4; k++) pd.ssz[k] = (perq * 4 + 8) >> 3;
+            zenc_plan_finish(pd, bn, 4, zenc_flat16().tb, min_gain);
+            if (pd.kind == ZK_HUF) {
+                pd.pad = 2; dplans = true;
+                LAUNCH(c, "zenc_direct_plans", k_zenc_direct_plans, cdiv(nblk, 256), 256, 0, direct, nblk, pd, zenc_flat16(), plan, trees, offs, done);
+            }
+        }
+        LAUNCH(c, "zenc_flat_scan", k_zenc_flat_scan, (dplans && cdiv(nblk, ZENC_FLATSCAN_WAVES) > 16384u) ? 16384u : cdiv(nblk, ZENC_FLATSCAN_WAVES), 64 * ZENC_FLATSCAN_WAVES, 0, d_src, (u64)n, nblk, plan, codes, trees, offs, done, min_gain, prefer_flat, zenc_flat16(), dplans ? direct : (const u8 *)nullptr, direct);
     }
     // the frame's tree (k_zenc_plan): level 1 without the match finder, frames of enough blocks to sample; NAF_GPU_FRAME_TREE=0: a tree per block
     const char *eft = ctx_opt(c, "FRAME_TREE");
