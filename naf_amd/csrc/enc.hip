@@ -452,7 +452,9 @@ __global__ __launch_bounds__(256) void k_enc_count(EncP P, const i64 *tile_eol, 
                 any = true; prev_last = r_last[v]; E += cnt;
             }
             // (the gather of the scatter pass reads up to 17 bytes from a base's position: not in the text's last tiles)
-            const bool tile_ok = ok && E >= 2 && period >= 33 && ((u64)tile + 1) * ET_TILE + 32 <= P.n;
+            // ... and the lattice's NEXT point lies behind the tile: a tile whose line ends stop short of its end (wrapped lines, then a long
+            // one) is not regular -- the scatter pass places a regular tile's bases by the lattice alone
+            const bool tile_ok = ok && E >= 2 && period >= 33 && p1 + E * period >= ET_TILE && ((u64)tile + 1) * ET_TILE + 32 <= P.n;
             t_reg[tile] = tile_ok ? (p1 | (period << 12) | (E << 24)) : 0u; t_irr[tile] = tile_ok ? 0 : 1;
             u32 tot = ET_TILE, tail = 0; bool found = false;
 #pragma unroll
@@ -550,7 +552,69 @@ __device__ __forceinline__ PureTile count_plain_tile(const EncP &P, u64 *t_seq, 
         any = true; prev_last = ql; E += cnt;
     }
     // (the gather of the scatter pass reads up to 17 bytes from a base's position: not in the text's last tiles)
-    const bool tile_ok = lat_ok && !two && E >= 2 && period >= 33 && (t + 1) * ET_TILE + 32 <= P.n;
+    // (the lattice's next point lies behind the tile: line ends that stop short of the tile's end -- wrapped lines, then a long one -- are no lattice)
+    const bool tile_ok = lat_ok && !two && E >= 2 && period >= 33 && p1 + E * period >= ET_TILE && (t + 1) * ET_TILE + 32 <= P.n;
+    if (lane == 0) {
+        t_reg[t] = tile_ok ? (p1 | (period << 12) | (E << 24) | (acgt ? REG_ACGT : 0u)) : 0u; t_irr[t] = tile_ok ? 0 : 1;
+        const u32 tot = ET_TILE - nbytes;
+        t_seq[t] = tot; t_ids[t] = 0; t_cmt[t] = 0; t_rec[t] = 0;
+        t_tail[t] = any ? ((ET_TILE - 1 - lastpos) | 0x80000000u) : tot;
+        t_needf[t] = 0; t_need[t] = 0;
+    }
+    PureTile r; r.pure = true; r.ok = tile_ok; r.acgt = acgt; r.any = any; r.p1 = p1; r.period = period; r.E = E; r.lastpos = lastpos;
+    return r;
+}
+// The same for k_enc_fused's tiles, in fewer vector instructions (the pass is bound by them): the first, second and last line end from
+// the four ballots and a few lane reads; then a tile is regular when no sixteen bytes hold two line ends, every line end lies a whole
+// number of periods behind the first, and there are as many as the lattice has points from the first one to the tile's end.
+__device__ __forceinline__ PureTile count_plain_tile2(const EncP &P, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
+                                                      u32 *t_needf, u64 *t_need, u64 t, const u32 (&eol)[4], bool acgt)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u32 nbytes = (u32)__builtin_amdgcn_readlane((int)wave_scan_inclusive<u32, OpAdd>((u32)(__popc(eol[0]) + __popc(eol[1]) + __popc(eol[2]) + __popc(eol[3]))), 63);
+    const u64 B[4] = { __ballot(eol[0] != 0), __ballot(eol[1] != 0), __ballot(eol[2] != 0), __ballot(eol[3] != 0) };
+    u32 p1 = 0, q2 = 0, lastpos = 0; int found = 0; bool gotlast = false;      // (all uniform)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u64 bal = B[k];
+        if (found < 2 && bal) {
+            const int L = __ffsll((long long)bal) - 1;
+            const u32 e = (u32)__builtin_amdgcn_readlane((int)eol[k], L), at = (64u * (u32)k + (u32)L) * ET_BYTES;
+            if (found == 0) {
+                p1 = at + (u32)__ffs((int)e) - 1; found = 1;
+                const u32 e2 = e & (e - 1); const u64 b2 = bal & (bal - 1);
+                if (e2) { q2 = at + (u32)__ffs((int)e2) - 1; found = 2; }
+                else if (b2) { const int L2 = __ffsll((long long)b2) - 1; q2 = (64u * (u32)k + (u32)L2) * ET_BYTES + (u32)__ffs(__builtin_amdgcn_readlane((int)eol[k], L2)) - 1; found = 2; }
+            } else { q2 = at + (u32)__ffs((int)e) - 1; found = 2; }
+        }
+    }
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+        const u64 bal = B[k];
+        if (!gotlast && bal) {
+            const int L = 63 - __clzll((long long)bal);
+            lastpos = (64u * (u32)k + (u32)L) * ET_BYTES + 31u - (u32)__clz(__builtin_amdgcn_readlane((int)eol[k], L));
+            gotlast = true;
+        }
+    }
+    const bool any = found != 0;
+    const u32 period = found == 2 ? q2 - p1 : 0u;
+    bool tile_ok = false;
+    if (period >= 33 && (t + 1) * ET_TILE + 32 <= P.n) {                 // (uniform)
+        const float rP = 1.0f / (float)period;
+        u32 nl = (u32)((float)(ET_TILE - 1 - p1) * rP);                  // lattice points from p1 to the tile's end: (4095 - p1) / period + 1
+        if (nl * period > ET_TILE - 1 - p1) nl--; else if ((nl + 1) * period <= ET_TILE - 1 - p1) nl++;
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 e = eol[k];
+            const u32 dq = (64u * (u32)k + lane) * ET_BYTES + (u32)__ffs((int)e) - 1 - p1;       // (e == 0: not looked at)
+            const u32 j = (u32)((float)dq * rP + 0.5f);
+            bad = bad || (e != 0 && (j * period != dq || (e & (e - 1)) != 0));
+        }
+        tile_ok = __ballot(bad) == 0 && nbytes == nl + 1 && nbytes >= 2;
+    }
+    const u32 E = nbytes;
     if (lane == 0) {
         t_reg[t] = tile_ok ? (p1 | (period << 12) | (E << 24) | (acgt ? REG_ACGT : 0u)) : 0u; t_irr[t] = tile_ok ? 0 : 1;
         const u32 tot = ET_TILE - nbytes;
@@ -619,18 +683,25 @@ __device__ __forceinline__ void fused_tile(const EncP &P, i64 *tile_eol, i64 *ti
 {
     const u32 lane = threadIdx.x;
     const u64 tb = t * ET_TILE;
-    u32 eol[4]; bool acgt = false, lower_any = false, fast = false;
+    u32 eol[4], cw[4]; bool acgt = false, lower_any = false, fast = false;
     if (inside) {
         // first look: nothing but upper-case A C G T / U and '\n' (every tile of the texts this pass is for): a table look-up and a
-        // compare per four bytes; line ends are the bytes without bit 6
+        // compare per four bytes; line ends are the bytes without bit 6.  The same bits 1..3 select a byte's two-bit code -- log2 of its
+        // one-hot 4-bit code: T 0, G 1, C 2, A 3 (tables.c:189-197) from the slots A 0, C 1, T / U 2, G 3, zero for a line end -- and four
+        // codes are one byte (code2x4's, by table): a lane's sixteen bytes -> one word
         u32 bad = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const u32 w[4] = { v[k].x, v[k].y, v[k].z, v[k].w }; u32 f[4];
+            const u32 w[4] = { v[k].x, v[k].y, v[k].z, v[k].w }; u32 f[4], c[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { bad |= swar_perm(P.shi, P.slo, (w[i] >> 1) & 0x07070707u) ^ w[i]; f[i] = ~w[i] & 0x40404040u; }
+            for (int i = 0; i < 4; i++) {
+                const u32 sel = (w[i] >> 1) & 0x07070707u;
+                bad |= swar_perm(P.shi, P.slo, sel) ^ w[i]; f[i] = ~w[i] & 0x40404040u;
+                c[i] = swar_dot4(swar_perm(0u, 0x01000203u, sel), 0x40100401u, 0);
+            }
             const u32 lo = swar_dot4(f[1], 0x80402010u, swar_dot4(f[0], 0x08040201u, 0)), hi = swar_dot4(f[3], 0x80402010u, swar_dot4(f[2], 0x08040201u, 0));
             eol[k] = (lo >> 6) | ((hi >> 6) << 8);
+            cw[k] = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
         }
         fast = __ballot(bad != 0) == 0;
         acgt = fast;
@@ -654,18 +725,15 @@ __device__ __forceinline__ void fused_tile(const EncP &P, i64 *tile_eol, i64 *ti
         return;
     }
     note_case(P, lower_any);
-    const PureTile r = count_plain_tile(P, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, t, eol, acgt);
+    const PureTile r = fast ? count_plain_tile2(P, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, t, eol, acgt)
+                            : count_plain_tile(P, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, t, eol, acgt);
     if (lane == 0) { const i64 le = r.any ? (i64)(tb + r.lastpos) : -1; tile_eol[t] = le; tile_sp[t] = le; }   // (a plain tile's blanks are its line ends)
     // (a tile that needed the second look and is regular A C G T all the same holds lower case: the text's codes are then not taken from `loc`)
     if (!LOC || !fast || !r.ok) return;
-    // the tile's bytes as codes, once: four bytes -> eight bits, a lane's sixteen bytes -> one word of the LDS string
-    u32 cw0 = 0;
+    // the tile's bytes as codes: a lane's four words of the LDS string
+    const u32 cw0 = cw[0];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const u32 cw = code2x4(v[k].x) | (code2x4(v[k].y) << 8) | (code2x4(v[k].z) << 16) | (code2x4(v[k].w) << 24);
-        s_code[64u * (u32)k + lane] = cw;
-        if (k == 0) cw0 = cw;
-    }
+    for (int k = 0; k < 4; k++) s_code[64u * (u32)k + lane] = cw[k];
     // what k_direct_verdict weighs a block by: the pair codes of bytes 0, 1 and 2, 3 of every lane's first piece (128 pairs of the tile's
     // 2 K, none that holds a line end), counted in sixteen bins
     u32 *s_hist = s_code + 264;
@@ -2543,6 +2611,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
             t_needf0 = arena_new<u32>(c, tiles + 1); t_need0 = arena_new<u64>(c, tiles + 2);
             if (!loc || !t_hist || !t_needf0 || !t_need0) return NAF_GPU_ENOMEM;
             // (two and four tiles per wavefront, their loads in flight together: 23.8 -> 28.3 / 25.9 ms per 100 GB)
+            // (a bounded grid of wavefronts that walk the tiles with the next tile's bytes asked for in advance: 117 VGPRs, 2.40 -> 2.87 ms per 10 GB)
             LAUNCH(c, "ennaf_split_once", (k_enc_fused<true, 1>), (u32)tiles, 64, 0, P, t_eol, t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf0, t_need0, tiles, loc, t_hist);
         } else
         LAUNCH(c, "ennaf_last", k_enc_last_fa, cdiv(tiles, 4 * LAST_TPW), 256, 0, P, t_eol, t_sp, tiles);

@@ -915,6 +915,33 @@ def test_text_read_once_gives_the_archive_of_the_two_passes(gpu, oracle, monkeyp
         assert hashlib.sha256(oracle.ref_unnaf(host(a))).digest() == hashlib.sha256(host(big)).digest()
 
 
+def test_wrapped_lines_followed_by_a_long_line(gpu, oracle, monkeypatch):
+    """A tile whose line ends sit on a lattice that STOPS before the tile's end (lines of 80, then one of thousands of bases) is not a
+    regular tile: the scatter pass places a regular tile's bases by the lattice alone and would skip a base for every line end the
+    lattice predicts behind the last real one.  (Round 5's verdict looked only at the gaps between the line ends there are: such a text
+    came back with bases out of place -- found by this round's one-pass work.)  Both split paths, every phase of the long line against
+    the tiles."""
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    def seq(n):
+        return bytes(rng.choice(acgt, n))
+    def wrap(b, w):
+        return b"\n".join(b[i:i + w] for i in range(0, len(b), w)) + b"\n"
+    monkeypatch.setenv("NAF_GPU_DIRECT", "2")
+    monkeypatch.setenv("NAF_GPU_PROBE", "0")
+    for onepass in ("1", "0"):
+        monkeypatch.setenv("NAF_GPU_ONEPASS", onepass)
+        for longlen in (1500, 2000, 3000, 5000, 9000):
+            for pre in (0, 700, 1500, 3000):
+                text = b">x\n" + wrap(seq(200_000 + pre), 80)[: -1 - (pre % 81)] + b"\n" + seq(longlen) + b"\n" + wrap(seq(300_000), 80)
+                check_ennaf(gpu, oracle, text)
+    # the general kernel's own verdict (tiles that are not pure: a header in front of the lines)
+    monkeypatch.setenv("NAF_GPU_ONEPASS", "0")
+    for k in range(6):
+        text = b"".join(b">r%d\n" % i + wrap(seq(900 + 80 * k), 80)[:-1] + seq(2500 + 97 * i) + b"\n" for i in range(40))
+        check_ennaf(gpu, oracle, text)
+
+
 def test_direct_blocks_at_scale_and_when_the_stream_is_worth_matching(gpu, monkeypatch, capfd):
     """The default path (from 8 MiB of packed bases up): most blocks direct, the blocks the look at the stream reads are not; a
     repeat-rich input packs its bases again for the match finder."""
