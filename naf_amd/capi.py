@@ -146,6 +146,7 @@ def load():
         L.naf_gpu_copy.argtypes = [vp, vp, vp, sz]
         L.naf_gpu_write_file.argtypes = [vp, i, C.c_uint64, vp, sz]
         L.naf_gpu_read_file.argtypes = [vp, i, C.c_uint64, sz, vp]
+        L.naf_gpu_write_fd.argtypes = [vp, i, vp, sz]
         L.naf_gpu_release_scratch.argtypes = [vp]
         L.naf_gpu_get_timing_streams.argtypes = [vp, C.POINTER(C.c_float)]
         L.naf_gpu_gather_ranges.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), u64p, C.POINTER(sz), i]
@@ -255,6 +256,12 @@ class Context:
         self._check(load().naf_gpu_set_option(self.h, name.encode(), None if value is None else str(value).encode()))
 
     def _sync_options(self):
+        # (os.environ is looked through per call: cheap beside a call, but not inside a timed loop of short ones -- the raw items are
+        # compared first, the dictionary work only when one of them changed)
+        key = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("NAF_GPU_")))
+        if key == getattr(self, "_opts_key", None):
+            return
+        self._opts_key = key
         want = _env_options()
         if want != self._opts:
             for k in set(self._opts) - set(want):

@@ -1993,6 +1993,7 @@ static int unnaf_run(naf_gpu_ctx *c, const u8 *d_naf, size_t naf_len, const naf_
             split.parts = nparts; split.done = 0;
             for (int k = 0; k < nparts; k++) split.ev[k] = c->split_ev[k];
             c->zsplit = &split;
+            arena_reset(c->side2);                                // (what the pipeline and the flat frame's job allocate there -- launch_lz_exec's arrays among it -- is this call's: ADVICE r05)
         }
         if (try_flat) { zflat.ready = false; zflat.aux = c->zsplit ? c->side2 : nullptr; c->zflat = &zflat; }
         rc = payload_seq();

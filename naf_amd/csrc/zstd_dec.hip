@@ -2105,6 +2105,17 @@ __device__ __forceinline__ u32 find_block(const u64 *offs, u32 hi, u64 x, u32 sh
     return lo;
 }
 // ---- sequence execution (3.1.1.4): one wave per block with sequences ----------------------------------------
+// A wait gives up when nothing anywhere has run for a count of polls AND for three seconds of wall time (s_memrealtime, 100 MHz): a
+// device that is time-sliced or busy with another stream's kernels polls slowly without being stuck -- a valid frame must
+// never be called corrupt because its executor was kept waiting.
+#define EXEC_GIVE_UP_TICKS 300000000ull
+__device__ __forceinline__ bool exec_stalled(u64 &since)
+{
+    const u64 now = __builtin_amdgcn_s_memrealtime();
+    if (!since) { since = now ? now : 1; return false; }
+    return now - since > EXEC_GIVE_UP_TICKS;
+}
+
 __device__ __forceinline__ void wait_block_done(volatile u32 *done, u32 j, ZStat *st)
 {
     // lane 0 polls (relaxed, agent scope); one acquire afterwards drops stale L1 lines (guide G16)
@@ -2112,12 +2123,13 @@ __device__ __forceinline__ void wait_block_done(volatile u32 *done, u32 j, ZStat
         // (bounded: a block that never completes -- a bug, or a frame whose sequences lie about their sources -- must end in wrong bytes
         // and an error, not in a device that has to be reset; about ten seconds)
         // (the count starts again whenever some block of the launch has finished meanwhile: a long chain of blocks is not a hang)
-        u32 spins = 0, seen = __hip_atomic_load(&st->n_exec_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u32 spins = 0, seen = __hip_atomic_load(&st->n_exec_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); u64 since = 0;
         while (__hip_atomic_load(&done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins >= (1u << 24)) {
+            if (++spins >= (1u << 22)) {
                 const u32 now = __hip_atomic_load(&st->n_exec_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (now == seen) { set_err(st, ZE_CORRUPT); break; }   // gave up: what is read from block j is not its output -- the call reports the frame as corrupt
+                if (now != seen) since = 0;
+                else if (exec_stalled(since)) { set_err(st, ZE_CORRUPT); break; }   // gave up: what is read from block j is not its output -- the call reports the frame as corrupt
                 seen = now; spins = 0;
             }
         }
@@ -2416,7 +2428,7 @@ __global__ __launch_bounds__(64) void k_exec_batch(const ZBlock *blk, const u32 
     if (nblk > 1) { const u64 b0 = offs[1] - offs[0]; if (b0 && !(b0 & (b0 - 1))) shift = (u32)(63 - __builtin_clzll(b0)); }
     u32 op = 0, lp = 0;
     bool bad = false;
-    u32 spins = 0, seen = 0;                                   // the bounded wait: wave-uniform
+    u64 since = 0; u32 spins = 0, seen = 0;                                   // the bounded wait: wave-uniform
     for (u32 s0 = 0; s0 < nseq; s0 += 64) {
         const u32 n = nseq - s0 < 64 ? nseq - s0 : 64;
         u32 ll = 0, ml = 0, of = 0;
@@ -2466,7 +2478,8 @@ __global__ __launch_bounds__(64) void k_exec_batch(const ZBlock *blk, const u32 
                 __builtin_amdgcn_s_sleep(4);
                 if (++spins >= (1u << 22)) {                        // nothing of this step became ready for a long time: has ANY block finished meanwhile?
                     const u32 now = __hip_atomic_load(&st->n_exec_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (now != seen) { seen = now; spins = 0; } else { bad = true; break; }
+                    if (now != seen) { seen = now; since = 0; } else if (exec_stalled(since)) { bad = true; break; }
+                    spins = 0;
                 }
             }
         }
@@ -2489,7 +2502,8 @@ __global__ __launch_bounds__(64) void k_exec_batch(const ZBlock *blk, const u32 
                     __builtin_amdgcn_s_sleep(4);
                     if (++spins >= (1u << 22)) {
                         const u32 now = __hip_atomic_load(&st->n_exec_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (now != seen) { seen = now; spins = 0; } else { bad = true; break; }
+                        if (now != seen) { seen = now; since = 0; } else if (exec_stalled(since)) { bad = true; break; }
+                        spins = 0;
                     }
                 }
                 if (bad) break;
@@ -2547,6 +2561,13 @@ __global__ __launch_bounds__(64) void k_exec_batch(const ZBlock *blk, const u32 
 // bypass the caches that are not coherent between XCDs: no release / acquire fence in the loop (an agent-scope acquire invalidates an
 // XCD's whole L2 share; tools/perf_exec.py: the fences alone were five times the copies).  The earliest pending match of the frame always
 // has its sources done, so a valid frame always moves; a wavefront gives up when nothing anywhere has run for a long time.
+// (the bulk copies below use these at ANY byte alignment.  A relaxed agent-scope atomic of 2 / 4 / 8 bytes lowers on gfx950 to one
+// global_load / global_store with the sc1 bit, and gfx950 handles unaligned global accesses in hardware (common.h: ld64) -- single-copy
+// atomicity is not asked of the match bytes, only that they bypass the per-XCD caches; the `done` flags, which ARE synchronisation, are
+// single bytes.  Another target would have to give the bytes a cache-bypassing load of their own: pinned here.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "ld_sc1 / st_sc1: unaligned sc1 accesses as relaxed atomics are a gfx950 lowering; port lane_copy_sc1 / wave_copy_sc1 before building for another target"
+#endif
 template <typename T> __device__ __forceinline__ T ld_sc1(const void *p) { return __hip_atomic_load((const T *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename T> __device__ __forceinline__ void st_sc1(void *p, T v) { __hip_atomic_store((T *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void lane_copy_sc1(u8 *d, const u8 *s, u32 n)            // n bytes by ONE lane, any alignment, source clear of the destination
@@ -2934,7 +2955,7 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
         pend[w] = __ballot(m != 0);
         left += (u32)__popcll(pend[w]);
     }
-    u32 idle = 0, seen = 0, unsaid = 0;
+    u32 idle = 0, seen = 0, unsaid = 0; u64 since = 0;
     while (left) {
         u64 rdy[U]; u64 any = 0;
         // the first `done` byte of everything pending, all loads in flight together (a word at a time they were U round trips in a row: the
@@ -3006,7 +3027,8 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
         if (unsaid && idle == 1024) { if (lane == 0) __hip_atomic_fetch_add(&st->n_exec_done, unsaid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); unsaid = 0; }
         if (++idle >= (1u << 18)) {                                           // nothing of this unit could run for a long time: has ANYTHING run meanwhile?
             const u32 now = ld_sc1<u32>(&st->n_exec_done);
-            if (ld_sc1<u32>(&st->err) || now == seen) { if (lane == 0) set_err(st, ZE_CORRUPT); break; }
+            if (now != seen) since = 0;
+            if (ld_sc1<u32>(&st->err) || (now == seen && exec_stalled(since))) { if (lane == 0) set_err(st, ZE_CORRUPT); break; }
             seen = now; idle = 0;
         }
     }
@@ -3868,8 +3890,8 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
             ZFlat *zf = c->zflat;
             FlatStream *si = arena_new<FlatStream>(c, 4 * (size_t)nblk + 1); u8 *d_sym = (u8 *)arena_alloc(c, 16);
             u8 *cls0 = (u8 *)arena_alloc(c, nblk), *cls = (u8 *)arena_alloc(c, nblk); u32 *d_nx = arena_new<u32>(c, 2);
-            u32 *done2 = arena_new<u32>(c, nblk), *prog2 = arena_new<u32>(c, nblk); u8 *lits = (u8 *)arena_alloc(c, hs.total_out + 16);
-            if (!si || !d_sym || !cls0 || !cls || !d_nx || !done2 || !prog2 || !lits) return NAF_GPU_ENOMEM;
+            u32 *done2 = arena_new<u32>(c, nblk); u8 *lits = (u8 *)arena_alloc(c, hs.total_out + 16);
+            if (!si || !d_sym || !cls0 || !cls || !d_nx || !done2 || !lits) return NAF_GPU_ENOMEM;
             HIP_TRY(c, hipMemsetAsync(d_nx, 0, 8, c->stream));
             LAUNCH(c, "zstd_set_offsets", k_set_offsets, g, 64, 0, blk, nblk, (const u64 *)sizes, done2, (u32 *)nullptr, (u32 *)nullptr);
             LAUNCH(c, "zstd_flat_class", k_flat_mark_owner, g, 64, 0, d_src, blk, nblk, (const i32 *)own_huf, main, 0u);
