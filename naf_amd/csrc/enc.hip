@@ -2184,12 +2184,60 @@ __device__ __forceinline__ u64 maskb_bits(const u64 *cb, u64 i, u64 T, bool prev
     if (T - 64 * i < 64) m &= (1ull << (T - 64 * i)) - 1;
     return m;
 }
-__global__ __launch_bounds__(256) void k_maskb_count(const u64 *cb, u64 T, u64 *tile_cnt, int prev0)
+// tile_last (may be null): position + 1 of the tile's last case change, 0 when it has none (k_maskb_units_direct)
+__global__ __launch_bounds__(256) void k_maskb_count(const u64 *cb, u64 T, u64 *tile_cnt, int prev0, i64 *tile_last = nullptr)
 {
-    __shared__ u32 s_c[4];
+    __shared__ u32 s_c[4]; __shared__ u64 s_l[4];
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    u32 tot = wg_reduce1<u32, OpAdd>(64 * i < T ? (u32)__popcll(maskb_bits(cb, i, T, prev0 != 0)) : 0u, s_c);
+    const u64 m = 64 * i < T ? maskb_bits(cb, i, T, prev0 != 0) : 0;
+    u32 tot = wg_reduce1<u32, OpAdd>((u32)__popcll(m), s_c);
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+    if (tile_last) {
+        const u64 last = wg_reduce1<u64, OpMaxU64>(m ? 64 * i + 64 - (u32)__clzll((long long)m) : 0ull, s_l);
+        if (threadIdx.x == 0) tile_last[blockIdx.x] = (i64)last;
+    }
+}
+// The units of a mask whose runs are all shorter than 255 bases straight from the case bits: run r's unit is the distance of case change
+// r from the one before it, written at r -- the case change in front of a lane's first one comes from a running maximum over the lanes
+// and, across tiles, from the scan of tile_last.  (The way over the list of positions writes and reads eight bytes per case change:
+// 16 GB for the billion case changes of 12.5 GB of mixed-case reads.)  *any_long is raised by a run of 255 bases or more; the caller
+// then takes the general way and this kernel's output is dropped.  The last run, from the last case change to T + ext, is lane 0's.
+__global__ __launch_bounds__(256) void k_maskb_units_direct(const u64 *cb, u64 T, const u64 *tile_pre, const i64 *last_scan, u64 nb, u8 *out, u64 ext, int skip0, int prev0, u64 *any_long)
+{
+    __shared__ u64 lds[4], ldm[4];
+    const u64 t = blockIdx.x, i = t * 256 + threadIdx.x;
+    if (t == 0 && threadIdx.x == 0) {
+        const u64 lastb = (u64)last_scan[gridDim.x - 1];             // position + 1 of the last case change, 0: none
+        const u64 len = T + ext - (lastb ? lastb - 1 : 0);
+        if (!(skip0 && nb == 0)) { if (len >= 255) *any_long = 1; else out[nb - (skip0 ? 1 : 0)] = (u8)len; }
+    }
+    if ((t + 1 < gridDim.x ? tile_pre[t + 1] : nb) == tile_pre[t]) return;
+    u64 m = 64 * i < T ? maskb_bits(cb, i, T, prev0 != 0) : 0;
+    const u64 c = (u64)__popcll(m);
+    u64 tot, mx;
+    const u64 incl = wg_scan_inclusive<u64, OpAdd>(c, &tot, lds);
+    const u64 mine = m ? 64 * i + 64 - (u32)__clzll((long long)m) : 0ull;
+    const u64 minc = wg_scan_inclusive<u64, OpMaxU64>(mine, &mx, ldm);
+    u64 prevp = shfl_up_t<u64>(minc, 1);                          // position + 1 of the last case change in front of this lane
+    if ((threadIdx.x & 63) == 0) prevp = 0;
+    // (wg_scan_inclusive's value is inclusive over the workgroup: the lane in front across a wavefront's edge)
+    __shared__ u64 s_edge[4];
+    if ((threadIdx.x & 63) == 63) s_edge[threadIdx.x >> 6] = minc;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && threadIdx.x) prevp = s_edge[(threadIdx.x >> 6) - 1];
+    const u64 carry = t ? (u64)last_scan[t - 1] : 0ull;
+    if (carry > prevp) prevp = carry;
+    u64 prev = prevp ? prevp - 1 : 0;                               // (no case change in front: the run began at base 0)
+    u64 k = tile_pre[t] + incl - c;
+    bool lng = false;
+    while (m) {
+        const int b = __ffsll((unsigned long long)m) - 1; m &= m - 1;
+        const u64 pos = 64 * i + (u32)b, len = pos - prev;
+        prev = pos;
+        if (!(skip0 && k == 0)) { if (len >= 255) lng = true; else out[k - (skip0 ? 1 : 0)] = (u8)len; }
+        k++;
+    }
+    if (lng) *any_long = 1;
 }
 __global__ __launch_bounds__(256) void k_maskb_scatter(const u64 *cb, u64 T, const u64 *tile_pre, u64 nb, u64 *bnd, int prev0)
 {
@@ -2782,12 +2830,13 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
         }
         // mask (only ever stored next to a 4-bit sequence stream, ennaf.c:445); a shard has counted its boundaries in the census already
         if (S.store_mask && T && (part & 2)) {
-            u64 nb = 0;
+            u64 nb = 0; i64 *tile_last = nullptr;
             const bool one_run = !S.census && S.no_case && !K.skip_run0 && !K.prev_masked;         // (the count pass saw no case bit: no pass over the case bits, no scan, no read-back)
             if (!one_run) {
             if (!S.census) {
-                tc = arena_new<u64>(c, mt + 2); if (!tc) return NAF_GPU_ENOMEM;
-                LAUNCH(c, "ennaf_mask_count", k_maskb_count, mt, 256, 0, (const u64 *)S.casebits, T, tc, 0);
+                tc = arena_new<u64>(c, mt + 2); tile_last = arena_new<i64>(c, mt + 1); if (!tc || !tile_last) return NAF_GPU_ENOMEM;
+                LAUNCH(c, "ennaf_mask_count", k_maskb_count, mt, 256, 0, (const u64 *)S.casebits, T, tc, 0, tile_last);
+                if ((rc = scan_inclusive_max_i64(c, tile_last, mt))) return rc;
             }
             const int b0 = S.census ? ((S.first_base >= 96) != (K.prev_masked != 0)) : 0;          // a shard's case change at its first base
             if (b0) LAUNCH(c, "ennaf_mask_b0", k_add_u64, 1, 64, 0, tc, (u64)1);
@@ -2804,12 +2853,24 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
                 SmallBytes lb; memset(&lb, 0, sizeof lb); lb.b[0] = (u8)(len % 255); lb.n = 1;
                 LAUNCH(c, "ennaf_mask_units", k_put_bytes, 1, 64, 0, s_mask + (nu - 1), lb);
             } else {
-            u64 *bnd = arena_new<u64>(c, nb + 1), *any_long = arena_new<u64>(c, 1);
-            if (!bnd || !any_long) return NAF_GPU_ENOMEM;
+            u64 *any_long = arena_new<u64>(c, 1), *bnd = nullptr;
+            if (!any_long) return NAF_GPU_ENOMEM;
+            u64 longs = 1;
+            const char *ms = ctx_opt(c, "MASK_SHORT");
+            // many case changes close to each other, all of them (it is assumed) less than 255 bases apart: the units straight from the case bits
+            // (NAF_GPU_MASK_SHORT=1: by way of the list of positions, the cross-check; =0: never assumed)
+            if (tile_last && nb >= (1u << 16) && nb * 64 >= T && !(ms && (ms[0] == '0' || ms[0] == '1'))) {   // (runs of 64 bases on average: longer ones are likely to hold one of 255)
+                nu = nb + 1 - (K.skip_run0 ? 1 : 0);
+                s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
+                HIP_TRY(c, hipMemsetAsync(any_long, 0, 8, c->stream));
+                LAUNCH(c, "ennaf_mask_units", k_maskb_units_direct, mt, 256, 0, (const u64 *)S.casebits, T, (const u64 *)tc, (const i64 *)tile_last, nb, s_mask, K.run_ext, K.skip_run0, K.prev_masked, any_long);
+                if ((rc = ctx_readback(c, &longs, any_long, 8))) return rc;
+            }
+            if (longs) {
+            bnd = arena_new<u64>(c, nb + 1); if (!bnd) return NAF_GPU_ENOMEM;
             if (nb) LAUNCH(c, "ennaf_mask_bscatter", k_maskb_scatter, mt, 256, 0, (const u64 *)S.casebits, T, (const u64 *)tc, nb, bnd, K.prev_masked);
             // runs of fewer than 255 bases only: a unit per run, in run order, written on that assumption (NAF_GPU_MASK_SHORT=0: never assumed)
-            u64 longs = 1;
-            { const char *ms = ctx_opt(c, "MASK_SHORT");
+            { 
               if (!(ms && ms[0] == '0')) {
                   nu = nb + 1 - (K.skip_run0 ? 1 : 0);
                   s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
@@ -2817,6 +2878,7 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
                   LAUNCH(c, "ennaf_mask_units", k_mask_units_short, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, s_mask, K.run_ext, K.skip_run0, any_long);
                   if ((rc = ctx_readback(c, &longs, any_long, 8))) return rc;
               } }
+            }
             if (longs) {
                 u64 *ru = arena_new<u64>(c, nb + 3); if (!ru) return NAF_GPU_ENOMEM;
                 LAUNCH(c, "ennaf_mask_runs", k_mask_run_units, cdiv(nb + 1, 256), 256, 0, (const u64 *)bnd, nb, T, ru, K.run_ext, K.skip_run0);
@@ -2832,6 +2894,9 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
             // quarter.  Very long runs give strings of 255s (constant blocks) and one last block with the remainder in it -- whose four
             // streams are one lane's work each on either side: small blocks there too.
             mask_block_log = 13;
+            // (a mask of tens of MB -- reads whose case changes every few bases -- has blocks enough for every lane of the decoder at the
+            // sequence stream's 32 KiB, and a quarter of the blocks to plan here: NAF_GPU_MASK_BLOCK_LOG sets it)
+            { const char *mb = ctx_opt(c, "MASK_BLOCK_LOG"); if (mb && atoi(mb) >= 10 && atoi(mb) <= 17) mask_block_log = atoi(mb); else if (nu >= (64ull << 20)) mask_block_log = 15; }
             n_mask = nu;
         }
     }
