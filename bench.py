@@ -745,7 +745,9 @@ def main():
             b, e = shard.byte_range(total_text, rank, world)
             out = torch.empty(total_text + 64, dtype=torch.uint8, device=dev) if rank == 0 else None
             scratch = torch.empty(e - b + 64, dtype=torch.uint8, device=dev) if rank != 0 else None
-            step = lambda: shard.unnaf_sharded(ctx, d_naf, capi.OUT_FASTA, dst=0, out=out, total=total_text, scratch=scratch)
+            if world == 1 and scratch is None:                     # --force-sharded on one GPU: the range travels through the communicator to its place (shard._self_exchange)
+                scratch = torch.empty(e - b + 64, dtype=torch.uint8, device=dev)
+            step = lambda: shard.unnaf_sharded(ctx, d_naf, capi.OUT_FASTA, dst=0, out=out, total=total_text, scratch=scratch, self_exchange=(world == 1))
             r = step()
             torch.cuda.synchronize()
             # full-size check: sum over ranks of the weighted sum of every slice == weighted sum of the gathered text on rank 0, and
@@ -793,7 +795,7 @@ def main():
             dist.barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                shard.gather_ranges(buf[: e - b], total_text, dst=0, out=out)
+                shard.gather_ranges(buf[: e - b] if world > 1 else scratch[: e - b], total_text, dst=0, out=out, self_exchange=(world == 1))
             torch.cuda.synchronize(); dist.barrier()
             tg = time.perf_counter() - t0
             # "gather to host" (north_star) without the hop through one GPU: every rank copies its range into its own pinned host buffer

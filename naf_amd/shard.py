@@ -88,11 +88,24 @@ def _broadcast(t, src, group):
         dist.broadcast(t, src, group=group)
 
 
-def gather_ranges(local: torch.Tensor, total: int, dst: int = 0, group=None, out: torch.Tensor = None):
+def _self_exchange(local: torch.Tensor, dst_view: torch.Tensor, group=None):
+    """A world of ONE rank has nobody to exchange with: under `self_exchange` the rank posts the SAME group of point-to-point
+    transfers a root and a peer would post between them -- a receive into the range's place and a send of the decoded range, to
+    itself -- so that the communicator's send / recv path (RCCL on a GPU box) moves the bytes once on the hardware there is.  What a
+    test or `bench.py --force-sharded` on a one-GPU box can exercise of the N > 1 path; not a product mode."""
+    _p2p([dist.P2POp(dist.irecv, dst_view, dist.get_rank(group), group), dist.P2POp(dist.isend, local, dist.get_rank(group), group)])
+
+
+def gather_ranges(local: torch.Tensor, total: int, dst: int = 0, group=None, out: torch.Tensor = None, self_exchange: bool = False):
     """Gather-to-root of every rank's byte range: returns the whole text on `dst` (None elsewhere).  `out`: where the root
     wants it (at least `total` bytes); the root's own range is copied in place, the others are received in place."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if world == 1 and self_exchange and local.numel():
+        if out is None:
+            out = torch.empty(max(total, 1), dtype=torch.uint8, device=local.device)
+        _self_exchange(local[:total], out[:total], group)
+        return out[:total]
     if rank != dst:
         if local.numel():
             _p2p([dist.P2POp(dist.isend, local, dst, group)])
@@ -112,7 +125,7 @@ def gather_ranges(local: torch.Tensor, total: int, dst: int = 0, group=None, out
     return out[:total]
 
 
-def unnaf_sharded(ctx, d_naf, out_type=0, use_mask=True, line_length=-1, dst=0, group=None, out=None, total=None, scratch=None):
+def unnaf_sharded(ctx, d_naf, out_type=0, use_mask=True, line_length=-1, dst=0, group=None, out=None, total=None, scratch=None, self_exchange=False):
     """Each rank holds the archive (it is ~25 % of the text) and decodes its byte range of the text; the root decodes its own
     range straight into its place of `out` and receives the others in place.  Returns the whole text on `dst`, None elsewhere.
     `scratch`: buffer for a non-root rank's range (allocated when missing)."""
@@ -121,6 +134,13 @@ def unnaf_sharded(ctx, d_naf, out_type=0, use_mask=True, line_length=-1, dst=0, 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     b, e = byte_range(total, rank, world)
+    if world == 1 and self_exchange and dist.is_initialized() and e > b:
+        # (see _self_exchange: the range is decoded into scratch and travels through the communicator to its place)
+        local = ctx.unnaf_range(d_naf, b, e, out_type, use_mask, line_length, out=scratch)
+        if out is None:
+            out = torch.empty(max(total, 1), dtype=torch.uint8, device=d_naf.device)
+        _self_exchange(local, out[b:e], group)
+        return out[:total]
     if world == 1:
         return ctx.unnaf_range(d_naf, b, e, out_type, use_mask, line_length, out=out)
     if rank != dst:

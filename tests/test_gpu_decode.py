@@ -1066,6 +1066,41 @@ def test_reference_archive_of_a_repeat_rich_genome_under_every_executor(gpu, ora
         monkeypatch.delenv("NAF_GPU_EXEC_LDS")
 
 
+def test_executors_at_the_size_where_the_wait_once_gave_up(gpu, oracle):
+    """VERDICT r05 item 7(b).  The reference's `--level 3 --long 27` archive of 300 MB of a repeat-rich genome -- the size class where round 5's
+    block-ordered executor ran out of polls and called a VALID frame corrupt (the pytest guard was 12 MB) -- and its archive
+    of two million reads whose names copy each other (one chain through the whole ids frame): the reference's own text, and within a bound
+    of seconds where the slow path took minutes (a call of this size is tens of milliseconds)."""
+    import time
+    import torch
+    from naf_amd import capi, synth
+    O = oracle
+    if not O.have_ref():
+        pytest.skip("needs oracle/_ref")
+    text = host(synth.repeat_genome_device(300_000_000, device="cuda", families=24))
+    naf = O.ref_ennaf(text, ("--level", "3", "--long", "27"))
+    d_naf = gpu.to_device(naf)
+    gpu.unnaf(d_naf, capi.OUT_FASTA)                              # (arena growth)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    got = gpu.unnaf(d_naf, capi.OUT_FASTA)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    assert hashlib.sha256(host(got)).digest() == hashlib.sha256(text).digest()
+    assert dt < 3.0, dt
+    b, e = len(text) // 2, len(text) // 2 + 20_000_003                # ... and a byte range of it through its dependency closure
+    assert host(gpu.unnaf_range(d_naf, b, e, capi.OUT_FASTA)) == text[b:e]
+    del text, got
+    fq = host(synth.fastq_reads_device(400_000_000, seed=11, device="cuda"))
+    naf = O.ref_ennaf(fq, ("--fastq",))
+    want = hashlib.sha256(O.ref_unnaf(naf)).digest()
+    d_naf = gpu.to_device(naf)
+    gpu.unnaf(d_naf, capi.OUT_FASTQ)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    got = gpu.unnaf(d_naf, capi.OUT_FASTQ)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    assert hashlib.sha256(host(got)).digest() == want
+    assert dt < 3.0, dt
+
+
 def test_reference_archive_of_reads_whose_names_copy_each_other(gpu, oracle, monkeypatch):
     """The reference's archive of a FASTQ: libzstd codes every read name as a copy of the name before it plus a digit or two -- chains of
     ten thousand links per 128 KiB block of the ids stream.  k_lz_collapse moves every source back along its chain (what is left: a link

@@ -393,3 +393,46 @@ def test_two_processes_one_device_real_library_over_gloo(kind):
                 p.kill()
     assert all(r[1] is True for r in res), res
     assert res[1][2]["cut"] > 0 and res[0][2]["halo"] == res[1][2]["cut"]
+
+
+_RCCL_SELF = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = %(port)r
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from naf_amd import capi, shard, synth
+ctx = capi.Context(0)
+text = synth.fasta_acgt_device(40_000_000, n_records=9, width=80, seed=3, device="cuda")
+d_naf, _ = ctx.ennaf(text)
+want = ctx.unnaf(d_naf, capi.OUT_FASTA).clone()
+assert dist.get_backend() == "nccl"
+got = shard.unnaf_sharded(ctx, d_naf, capi.OUT_FASTA, self_exchange=True)
+torch.cuda.synchronize()
+assert torch.equal(got, want) and torch.equal(got, text), "unnaf_sharded through the communicator"
+piece = want[: want.numel()].clone()
+g2 = shard.gather_ranges(piece, int(piece.numel()), self_exchange=True)
+torch.cuda.synchronize()
+assert torch.equal(g2, want), "gather_ranges through the communicator"
+outs = [torch.empty_like(piece)]
+shard._all_gather(outs, piece, None)
+torch.cuda.synchronize()
+assert torch.equal(outs[0], want), "all_gather of one rank"
+ctx.close()
+dist.destroy_process_group()
+print("rccl self exchange ok")
+"""
+
+
+def test_rccl_branch_of_the_gather_on_one_rank():
+    """`shard.gather_ranges` / `unnaf_sharded` have an RCCL branch (`_p2p_post` with device tensors over the
+    `nccl` backend) that no one-GPU box reached -- a world of one rank returned before it.  Under `self_exchange` the rank posts the
+    receive and the send of its own range to itself as ONE group of point-to-point transfers, so the communicator moves 40 MB of decoded
+    text on this box; a one-rank all_gather goes the same way.  A process of its own under a timeout: a communicator that hangs must
+    not take the suite (or the box) with it."""
+    import subprocess, sys
+    src = _RCCL_SELF % {"root": ROOT, "port": str(34100 + os.getpid() % 1500)}
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0 and "rccl self exchange ok" in r.stdout, (r.returncode, r.stdout[-800:], r.stderr[-1500:])
