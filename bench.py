@@ -420,6 +420,46 @@ def realistic_vs_reference(ctx, text_dev, size_bytes, out_mode=None, fold_case=F
         subprocess.call(["rm", "-rf", shm])
 
 
+def reference_archive_at_size(ctx, text_dev, out_mode, fold_case=False, reps=5):
+    """The REFERENCE's archive of the whole text of a side workload (the real `ennaf`, one thread: about half a minute for 12.5 GB of reads)
+    decoded here: what a drop-in `unnaf` meets, at the size the config names rather than at a sample where a call is its latency
+    (unnaf/src/input.c:145-246,295-434).  Bit-exact against the text (FASTQ: up to the case of the bases, unnaf.c:442)."""
+    import numpy as np
+    import torch
+    shm = "/dev/shm/naf_bench_big_%d" % os.getpid()
+    os.makedirs(shm, exist_ok=True)
+    P = lambda name: os.path.join(shm, name)
+    try:
+        n = int(text_dev.numel())
+        with open(P("t.txt"), "wb") as f:
+            for a in range(0, n, 1 << 30):
+                text_dev[a:a + (1 << 30)].cpu().numpy().tofile(f)
+        env = dict(os.environ, TMPDIR=shm)
+        t0 = time.perf_counter(); subprocess.check_call([REF_E, P("t.txt"), "-o", P("t.naf")] if not fold_case else [REF_E, "--fastq", P("t.txt"), "-o", P("t.naf")], env=env); t_e = time.perf_counter() - t0
+        os.remove(P("t.txt"))
+        ref_naf = torch.from_numpy(np.fromfile(P("t.naf"), dtype=np.uint8)).to(text_dev.device)
+        os.remove(P("t.naf"))
+        buf = torch.empty(n + 64, dtype=torch.uint8, device=text_dev.device)
+        r = ctx.unnaf(ref_naf, out_mode, out=buf); torch.cuda.synchronize()
+        ok = fastq_same_but_case(r, text_dev) if fold_case else equal_in_chunks(r, text_dev)
+        ts = timed_calls(lambda: ctx.unnaf(ref_naf, out_mode, out=buf), reps)
+        dt = median(ts)
+        kt, _all, streams = instrumented(ctx, lambda: ctx.unnaf(ref_naf, out_mode, out=buf))
+        return {"text_bytes": n, "reference_archive_bytes": int(ref_naf.numel()), "reference_ennaf_value": round(n / t_e / 1e9, 3),
+                "value": round(n / dt / 1e9, 2), "ms": round(dt * 1e3, 3), "calls": stats_ms(ts), "bit_exact": bool(ok),
+                "path_frac": round((n + int(ref_naf.numel())) / dt / HBM_PEAK, 4), "gap": gap_of(dt * 1e3, streams),
+                "kernels_ms": {k: round(ms, 3) for k, ms, c in kt}, "unit": "GB/s of text out, the reference's own archive of the whole text in (device-resident)"}
+    except (OSError, subprocess.CalledProcessError, capi_error()) as ex:
+        return {"error": repr(ex)[:200]}
+    finally:
+        subprocess.call(["rm", "-rf", shm])
+
+
+def capi_error():
+    from naf_amd import capi
+    return capi.NafGpuError
+
+
 def side_workload(ctx, text, out_mode, what, fold_case=False, reps=10):
     """One more workload beside the headline config, device-resident both ways: ennaf then unnaf of `text`, each as `reps` calls timed on
     their own after two untimed ones (median = the figure; min, max and mean beside it), the round trip checked at full size, per-kernel
@@ -638,6 +678,7 @@ def main():
     ap.add_argument("--realistic-size", type=float, default=4e9, help="N = 1: bytes of a synthetic repeat-masked genome (skewed composition, N runs, IUPAC, soft mask) encoded and decoded beside the headline config (0: skip)")
     ap.add_argument("--fastq1-size", type=float, default=12.5e9, help="N = 1: bytes of cfg5 FASTQ encoded and decoded beside the headline config: one GPU's share of configs[4] (0: skip)")
     ap.add_argument("--fastq-size", type=float, default=12.5e9, help="N > 1: FASTQ bytes per GPU for the sharded FASTQ encode (configs[4] = 100 GB over 8 GPUs; 0: skip)")
+    ap.add_argument("--no-ref-full", dest="ref_full", action="store_false", help="N = 1: skip the reference's archives of the WHOLE FASTQ / realistic texts (half a minute of the reference's ennaf)")
     ap.add_argument("--levels-size", type=float, default=1e9, help="N = 1: bytes of a repeat-rich genome encoded at -19 and -3 --long 27 beside the reference with the same flags (0: skip)")
     args = ap.parse_args()
 
@@ -887,6 +928,9 @@ def main():
             extra["realistic"], rg_naf = side_workload(ctx, rg, capi.OUT_FASTA, "synthetic repeat-masked genome: GC 41 %, CpG at 0.22 of expectation, N runs (telomeres, gaps of 5-100 k), an IUPAC code per Mbase, soft-mask runs of 20..600, 24 records of unequal length, 60-column lines")
             if have_ref() and not args.no_cpu:
                 extra["realistic"].update(realistic_vs_reference(ctx, rg, int(min(args.cpu_sample / 4, rg.numel()))))
+                if args.ref_full:
+                    del rg_naf; rg_naf = None
+                    extra["realistic"]["reference_archive_full"] = reference_archive_at_size(ctx, rg, capi.OUT_FASTA)
             del rg, rg_naf
         if args.fastq1_size > 0:
             # BASELINE configs[4] on one GPU: FASTQ, 150-base reads, mixed case + N, full quality range (SURVEY 8(d) cfg5 generator)
@@ -897,6 +941,10 @@ def main():
             if have_ref() and not args.no_cpu:
                 # the reference's archive of a sample of it decoded here (libzstd's frames: names that copy each other, runs of "len=150")
                 extra["fastq"].update(realistic_vs_reference(ctx, fq, int(min(args.cpu_sample / 2, fq.numel())), out_mode=capi.OUT_FASTQ, fold_case=True))
+                if args.ref_full:
+                    _ = None
+                    torch.cuda.synchronize(); ctx.release_scratch(); torch.cuda.empty_cache()
+                    extra["fastq"]["reference_archive_full"] = reference_archive_at_size(ctx, fq, capi.OUT_FASTQ, fold_case=True)
             del fq, _
             torch.cuda.synchronize(); ctx.release_scratch(); torch.cuda.empty_cache()
         if args.levels_size > 0 and have_ref() and not args.no_cpu:
@@ -911,7 +959,12 @@ def main():
             for wl in ("fastq", "realistic"):
                 rs = (extra.get(wl) or {}).get("reference_sample") or {}
                 ga = rs.get("gpu_unnaf_of_reference_archive") or {}
-                roofline.update({wl + "_ref_archive_gbps": ga.get("value"), wl + "_ref_archive_bit_exact": ga.get("bit_exact"), wl + "_ref_archive_ref_unnaf_gbps": rs.get("reference_unnaf_value"),
+                full = (extra.get(wl) or {}).get("reference_archive_full") or {}
+                # (the figure at the config's own size when the leg ran, the sample's beside it)
+                roofline.update({wl + "_ref_archive_gbps": full.get("value", ga.get("value")), wl + "_ref_archive_bit_exact": full.get("bit_exact", ga.get("bit_exact")),
+                                 wl + "_ref_archive_text_bytes": full.get("text_bytes", rs.get("text_bytes")),
+                                 wl + "_ref_archive_sample_gbps": ga.get("value"), wl + "_ref_archive_sample_bit_exact": ga.get("bit_exact"),
+                                 wl + "_ref_archive_ref_unnaf_gbps": rs.get("reference_unnaf_value"),
                                  wl + "_ref_decodes_gpu_archive": rs.get("reference_unnaf_of_gpu_archive_bit_exact")})
             lv = extra.get("levels") or {}
             for k in ("lvl19_ennaf_gbps", "lvl19_ratio_vs_ref", "lvl19_ref_decodes", "lvl19_ref_ennaf_gbps", "long27_ennaf_gbps", "long27_ratio_vs_ref", "long27_ref_decodes", "long27_ref_ennaf_gbps",
