@@ -3475,7 +3475,12 @@ static u32 huf_par_plog(const naf_gpu_ctx *c, u32 max_lit_regen, u64 n_blocks)
     while (plog < 6 && (nmax >> (plog + 1)) >= target) plog++;
     if (e && e[0] >= '1' && e[0] <= '6') { const u32 f = (u32)(e[0] - '0'); return f < plog ? f : plog; }
     if (n_blocks * (u64)max_lit_regen >= (u64)nmax * 86016) return 0;
-    while (plog && ((n_blocks * 4) << plog) > (1u << 18)) plog--;      // (the device holds 200 k of this kernel's lanes at a time: more parts only add margins)
+    // (the device holds 200 k of this kernel's lanes at a time, but a lane's chain is what a frame of few long streams waits for: the
+    // reference's archive of a 4 GB genome -- 61 K streams of 32 K symbols -- 9.2 ms with 4 parts a stream, 6.9 with 16, 6.7 with 32)
+    const char *ll = ctx_opt(c, "HUF_LANES_LOG");                 // (the cap as a lever: 18 = round 5's)
+    // (... for streams of libzstd's length only: this build's own realistic archive, 8 K symbols a stream beside the flat emit, 3.04 -> 3.35 ms with the larger cap)
+    const u32 lanes_log = ll && atoi(ll) >= 10 && atoi(ll) <= 24 ? (u32)atoi(ll) : (nmax >= 16384 ? 20u : 18u);
+    while (plog && ((n_blocks * 4) << plog) > (1ull << lanes_log)) plog--;
     return plog;
 }
 static u32 huf_par_margin_env(const naf_gpu_ctx *c) { const char *m = ctx_opt(c, "HUF_MARGIN"); return m ? (u32)atoi(m) : 0u; }

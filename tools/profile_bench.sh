@@ -1,5 +1,5 @@
 #!/bin/bash
-# Produces the files under profiles/ for one round:  tools/profile_bench.sh r05   (run on the GPU box, from the repo root)
+# Produces the files under profiles/ for one round:  tools/profile_bench.sh r06   (run on the GPU box, from the repo root)
 #   <tag>_bench_line.json                     the JSON line of a plain `python bench.py` (100 GB headline, every side leg)
 #   <tag>_bench_rocprofv3_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the headline alone: `python bench.py --steps 3 --no-cpu` + SIDE0 (below)
 #   <tag>_cfg10_rocprofv3_kernel_stats.csv    the same at BASELINE configs[1]'s 10 GB (`--size 10e9`)
@@ -74,7 +74,9 @@ line = json.loads(open(f"{out}/{tag}_bench_line.json").read().strip().splitlines
 names = {"k_huf_literals": "zstd_huf_literals", "k_flat_literals": "zstd_flat_literals", "k_emit_tile": "unnaf_emit", "k_emit_tile_wave": "unnaf_emit", "k_emit_tile_flat": "unnaf_emit_flat", "k_emit_tile_flat_wave": "unnaf_emit_flat",
          "k_emit_rest": "unnaf_emit_rest", "k_build_huf": "zstd_build_huf", "k_spec_find": "zstd_index_find", "k_spec_resolve": "zstd_index_resolve",
          "k_copy_fill": "zstd_copy_fill", "k_flat_streams": "zstd_flat_streams", "k_uni_streams": "zstd_flat_uniform", "k_uni_head": "zstd_flat_uniform", "k_tile_index": "unnaf_tile_index", "k_stride_probe": "zstd_index_stride", "k_parse_blocks": "zstd_parse_blocks", "k_mask_rle_frame": "unnaf_mask_rle"}
-enc_names = {"k_enc_scatter_regular": "ennaf_scatter_regular", "k_enc_scatter": "ennaf_scatter", "k_enc_count_pure": "ennaf_count_pure", "k_enc_count": "ennaf_count", "k_enc_last_fa": "ennaf_last", "k_maskb_count": "ennaf_mask_count", "k_pack_edges_zero": "ennaf_pack_edges",
+enc_names = {"k_enc_fused": "ennaf_split_once", "k_zenc_write_direct_loc": "zenc_write_direct", "k_direct_verdict": "ennaf_direct_blocks", "k_sparse_list": "ennaf_sparse_list", "k_pure_check": "ennaf_pure_check",
+             "k_zenc_direct_plans": "zenc_direct_plans", "k_irregular_list": "ennaf_irregular_list", "k_enc_scatter_regular_list": "ennaf_scatter_regular", "k_need_list": "ennaf_need_list", "k_scan_tile_reduce": "scan", "k_scan_tile_apply": "scan", "k_scan_small": "scan",
+             "k_enc_scatter_regular": "ennaf_scatter_regular", "k_enc_scatter": "ennaf_scatter", "k_enc_count_pure": "ennaf_count_pure", "k_enc_count": "ennaf_count", "k_enc_last_fa": "ennaf_last", "k_maskb_count": "ennaf_mask_count", "k_pack_edges_zero": "ennaf_pack_edges",
              "k_zenc_plan": "zenc_plan", "k_zenc_write": "zenc_write", "k_zenc_write_direct": "zenc_write_direct", "k_zenc_flat_scan": "zenc_flat_scan", "k_zenc_tree": "zenc_tree", "k_direct_blocks": "ennaf_direct_blocks",
              "k_mask_run_units": "ennaf_mask_runs", "k_mask_units_write": "ennaf_mask_units"}
 calls, enc_calls = 3, 13
