@@ -679,24 +679,25 @@ __device__ __forceinline__ u32 last_pos_pair(u32 eol, u32 sp, u32 at)
 }
 template <bool LOC>
 __device__ __forceinline__ void fused_tile(const EncP &P, i64 *tile_eol, i64 *tile_sp, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
-                                           u32 *t_needf, u64 *t_need, u8 *loc, u8 *t_hist, u64 t, bool inside, const uint4 (&v)[4], u32 *s_code)
+                                           u32 *t_needf, u64 *t_need, u8 *loc, u8 *t_hist, u8 *locc, u8 *t_lower, u64 t, bool inside, const uint4 (&v)[4], u32 *s_code)
 {
     const u32 lane = threadIdx.x;
     const u64 tb = t * ET_TILE;
-    u32 eol[4], cw[4]; bool acgt = false, lower_any = false, fast = false;
+    u32 eol[4], cw[4]; bool acgt = false, lower_any = false, fast = false, tile_lower = false;
     if (inside) {
-        // first look: nothing but upper-case A C G T / U and '\n' (every tile of the texts this pass is for): a table look-up and a
-        // compare per four bytes; line ends are the bytes without bit 6.  The same bits 1..3 select a byte's two-bit code -- log2 of its
-        // one-hot 4-bit code: T 0, G 1, C 2, A 3 (tables.c:189-197) from the slots A 0, C 1, T / U 2, G 3, zero for a line end -- and four
-        // codes are one byte (code2x4's, by table): a lane's sixteen bytes -> one word
-        u32 bad = 0;
+        // first look: nothing but A C G T / U in either case and '\n' (every tile of the texts this pass is for): a table look-up and a
+        // compare per four bytes, the case bit cleared in the bytes that have bit 6 (so '*' is not taken for '\n': piece_plain's way); line
+        // ends are the bytes without bit 6.  The same bits 1..3 select a byte's two-bit code -- log2 of its one-hot 4-bit code: T 0, G 1,
+        // C 2, A 3 (tables.c:189-197) from the slots A 0, C 1, T / U 2, G 3, zero for a line end -- and four codes are one byte
+        // (code2x4's, by table): a lane's sixteen bytes -> one word
+        u32 bad = 0, lacc = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const u32 w[4] = { v[k].x, v[k].y, v[k].z, v[k].w }; u32 f[4], c[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const u32 sel = (w[i] >> 1) & 0x07070707u;
-                bad |= swar_perm(P.shi, P.slo, sel) ^ w[i]; f[i] = ~w[i] & 0x40404040u;
+                const u32 h = w[i] >> 1, sel = h & 0x07070707u, low = w[i] & h & 0x20202020u;       // low: bit 5 of the bytes that have bits 5 and 6 -- lower-case letters
+                bad |= swar_perm(P.shi, P.slo, sel) ^ (w[i] ^ low); f[i] = ~w[i] & 0x40404040u; lacc |= low;
                 c[i] = swar_dot4(swar_perm(0u, 0x01000203u, sel), 0x40100401u, 0);
             }
             const u32 lo = swar_dot4(f[1], 0x80402010u, swar_dot4(f[0], 0x08040201u, 0)), hi = swar_dot4(f[3], 0x80402010u, swar_dot4(f[2], 0x08040201u, 0));
@@ -705,6 +706,7 @@ __device__ __forceinline__ void fused_tile(const EncP &P, i64 *tile_eol, i64 *ti
         }
         fast = __ballot(bad != 0) == 0;
         acgt = fast;
+        if (fast) { lower_any = lacc != 0; tile_lower = __ballot(lower_any) != 0; }
     }
     if (!fast && (!inside || !plain_tile(P, v, eol, acgt, lower_any))) {
         // not k_enc_count_pure's: its last line end and blank (all byte classes), the rest is k_enc_count's
@@ -728,12 +730,24 @@ __device__ __forceinline__ void fused_tile(const EncP &P, i64 *tile_eol, i64 *ti
     const PureTile r = fast ? count_plain_tile2(P, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, t, eol, acgt)
                             : count_plain_tile(P, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, t, eol, acgt);
     if (lane == 0) { const i64 le = r.any ? (i64)(tb + r.lastpos) : -1; tile_eol[t] = le; tile_sp[t] = le; }   // (a plain tile's blanks are its line ends)
-    // (a tile that needed the second look and is regular A C G T all the same holds lower case: the text's codes are then not taken from `loc`)
     if (!LOC || !fast || !r.ok) return;
-    // the tile's bytes as codes: a lane's four words of the LDS string
+    // the tile's bytes as codes: a lane's four words of the LDS string; and, in a tile with lower case, their case bits (a bit per byte,
+    // sixteen per piece: encoders.c:98-124's test, `>= 96`, is bit 5 of a letter here)
     const u32 cw0 = cw[0];
 #pragma unroll
     for (int k = 0; k < 4; k++) s_code[64u * (u32)k + lane] = cw[k];
+    u16 *s_case = (u16 *)(s_code + 280);
+    if (tile_lower) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 w[4] = { v[k].x, v[k].y, v[k].z, v[k].w }; u32 f[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) f[i] = w[i] & (w[i] >> 1) & 0x20202020u;
+            const u32 lo = swar_dot4(f[1], 0x80402010u, swar_dot4(f[0], 0x08040201u, 0)), hi = swar_dot4(f[3], 0x80402010u, swar_dot4(f[2], 0x08040201u, 0));
+            s_case[64u * (u32)k + lane] = (u16)((lo >> 5) | ((hi >> 5) << 8));
+        }
+        if (lane == 0) { s_case[256] = 0; s_case[257] = 0; t_lower[t] = 1; }
+    }
     // what k_direct_verdict weighs a block by: the pair codes of bytes 0, 1 and 2, 3 of every lane's first piece (128 pairs of the tile's
     // 2 K, none that holds a line end), counted in sixteen bins
     u32 *s_hist = s_code + 264;
@@ -746,7 +760,7 @@ __device__ __forceinline__ void fused_tile(const EncP &P, i64 *tile_eol, i64 *ti
     // the tile's bases in order: lane l takes bases 64 l .. 64 l + 63, four groups of 16; a group is the 32 bits at twice its first base's
     // text position, less the two bits of the line end when one lies among its 17 bytes (lines hold at least 32 bases: one at most)
     const u32 W = r.period - 1, nb = ET_TILE - r.E;
-    u32 wd[4] = { 0, 0, 0, 0 };
+    u32 wd[4] = { 0, 0, 0, 0 }, cs[4] = { 0, 0, 0, 0 };
     const u32 b0 = 64u * lane;
     if (b0 < nb) {
         u32 x, e;                                                     // text position of the group's first base; bases from it to the next line end
@@ -762,21 +776,26 @@ __device__ __forceinline__ void fused_tile(const EncP &P, i64 *tile_eol, i64 *ti
             if (b0 + 16u * (u32)g >= nb) break;
             const u32 d0 = s_code[x >> 4], d1 = s_code[(x >> 4) + 1], sh = 2u * (x & 15u);
             const u32 lo = __builtin_amdgcn_alignbit(d1, d0, sh);
+            u32 cl = 0;
+            if (tile_lower) { const u32 *sc = (const u32 *)s_case; cl = __builtin_amdgcn_alignbit(sc[(x >> 5) + 1], sc[x >> 5], x & 31u); }   // the 17 bytes' case bits
             if (e < 16) {
                 const u32 lowm = (1u << (2u * e)) - 1u, up = __builtin_amdgcn_alignbit(d1 >> sh, lo, 2);
                 wd[g] = (lo & lowm) | (up & ~lowm);
+                const u32 lm1 = (1u << e) - 1u;
+                cs[g] = ((cl & lm1) | ((cl >> 1) & ~lm1)) & 0xFFFFu;
                 x += 17; e += W - 16;
-            } else { wd[g] = lo; x += 16; e -= 16; }
+            } else { wd[g] = lo; cs[g] = cl & 0xFFFFu; x += 16; e -= 16; }
         }
     }
     *(uint4 *)(loc + t * LOC_TILE + lane * 16u) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    if (tile_lower) *(uint2 *)(locc + t * (LOC_TILE / 2) + lane * 8u) = make_uint2(cs[0] | (cs[1] << 16), cs[2] | (cs[3] << 16));
 }
 // TW tiles per wavefront, the loads of all of them in flight before the first is looked at
 template <bool LOC, u32 TW>
 __global__ __launch_bounds__(64) void k_enc_fused(EncP P, i64 *tile_eol, i64 *tile_sp, u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_rec, u32 *t_tail, u32 *t_reg, u64 *t_irr,
-                                                  u32 *t_needf, u64 *t_need, u64 tiles, u8 *loc, u8 *t_hist)
+                                                  u32 *t_needf, u64 *t_need, u64 tiles, u8 *loc, u8 *t_hist, u8 *locc, u8 *t_lower)
 {
-    __shared__ u32 s_code[LOC ? 264 + 16 : 4];                     // the tile's bytes as two-bit codes, in text order (line ends among them); sixteen bins
+    __shared__ u32 s_code[LOC ? 264 + 16 + 132 : 4];               // the tile's bytes as two-bit codes, in text order (line ends among them); sixteen bins; the bytes' case bits
     const u32 lane = threadIdx.x;
     const u64 t0 = (u64)blockIdx.x * TW;
     uint4 v[TW][4]; bool inside[TW];
@@ -792,7 +811,7 @@ __global__ __launch_bounds__(64) void k_enc_fused(EncP P, i64 *tile_eol, i64 *ti
 #pragma unroll
     for (u32 j = 0; j < TW; j++) {
         if (t0 + j >= tiles) break;
-        fused_tile<LOC>(P, tile_eol, tile_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, loc, t_hist, t0 + j, inside[j], v[j], s_code);
+        fused_tile<LOC>(P, tile_eol, tile_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, loc, t_hist, locc, t_lower, t0 + j, inside[j], v[j], s_code);
         if (TW > 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
     }
 }
@@ -1046,6 +1065,37 @@ __global__ __launch_bounds__(256) void k_direct_verdict(const u64 *t_seq, const 
     }
     direct[b] = ok ? 1 : 0;
 }
+// The case bits of the direct blocks' bases when the text has lower case (k_enc_fused left them tile by tile like the codes: base i of
+// tile t in bit i of the 512 bytes at locc + 512 t, tiles without lower case not at all -- t_lower): a thread per 64 bases, the word of
+// the global bit string (extract_mask's input, encoders.c:126-146) funnelled out of the tile that holds its first base and, across a
+// tile's end, the next one.  The blocks that are not direct get theirs from the scatter kernels as before.
+__global__ __launch_bounds__(256) void k_case_gather(const u8 *direct, u32 nd, const u32 *blk_t0, const i32 *blk_bnd, const u8 *locc, const u8 *t_lower, u64 *casebits)
+{
+    __shared__ i32 s_bnd[ZENC_LOC_BND];
+    const u32 b = blockIdx.x >> 2;                                    // four workgroups a block: 1024 words of 64 bases
+    if (b >= nd || !direct[b]) return;
+    if (threadIdx.x < ZENC_LOC_BND) s_bnd[threadIdx.x] = blk_bnd[(u64)b * ZENC_LOC_BND + threadIdx.x];
+    __syncthreads();
+    const u64 t0 = blk_t0[b];
+    const u32 W = (blockIdx.x & 3u) * 256u + threadIdx.x;
+    const i32 r0 = (i32)(64u * W);
+    u32 k = (u32)(r0 - s_bnd[0]) >> 12;
+    if (s_bnd[k + 1] <= r0) k++;
+    if (s_bnd[k + 1] <= r0) k++;
+    const u32 i = (u32)(r0 - s_bnd[k]);
+    const u32 av = (u32)(s_bnd[k + 1] - r0);
+    u64 w = 0;
+    if (t_lower[t0 + k]) {
+        const u32 *p = (const u32 *)(locc + (t0 + k) * (LOC_TILE / 2)) + (i >> 5);
+        const u32 a = p[0], c = p[1], e = p[2], sh = i & 31u;
+        w = (u64)__builtin_amdgcn_alignbit(c, a, sh) | ((u64)__builtin_amdgcn_alignbit(e, c, sh) << 32);
+    }
+    if (av < 64u) {                                                   // the tile ends inside the word: the rest from the next tile's first bases
+        w &= (1ull << av) - 1;
+        if (t_lower[t0 + k + 1]) w |= ld64(locc + (t0 + k + 1) * (LOC_TILE / 2)) << av;
+    }
+    casebits[((u64)b << 10) + W] = w;
+}
 // the tiles k_enc_count did not find regular, in order (pre = exclusive scan of its 0 / 1 verdicts)
 // blk_t0 (may be null): the tile that holds base 65536 b, the first of block b of the packed stream, for every such base there is
 // (t_seq: the exclusive scan of the tiles' base counts with the total behind it)
@@ -1069,10 +1119,10 @@ __global__ void k_pack_edges_zero(const u64 *t_seq, u64 tiles, u64 T, u8 *packed
     const u64 g0 = b0 >> 4, g1 = (b1 - 1) >> 4;
     // (a group of a direct block is one word of its stream, see direct_word)
     const bool d0 = direct && (g0 >> 12) < nd && direct[g0 >> 12], d1 = direct && (g1 >> 12) < nd && direct[g1 >> 12];
-    if (loc_mode) {                                               // (a direct block's codes are not in `packed` at all)
-        if (!d0) *(u64 *)(packed + 8 * g0) = 0;
-        if (!d1) *(u64 *)(packed + 8 * g1) = 0;
-        return;                                                   // (loc_mode: no case bits)
+    if (loc_mode) {                                               // (a direct block's codes are not in `packed` at all, its case bits are k_case_gather's)
+        if (!d0) { *(u64 *)(packed + 8 * g0) = 0; if (casebits) ((u16 *)casebits)[g0] = 0; }
+        if (!d1) { *(u64 *)(packed + 8 * g1) = 0; if (casebits) ((u16 *)casebits)[g1] = 0; }
+        return;
     }
     if (d0) *((u32 *)(packed + ((g0 >> 12) << 15) + (((g0 >> 10) & 3) << 12)) + (1023u - (u32)(g0 & 1023u))) = 0; else *(u64 *)(packed + 8 * g0) = 0;
     if (d1) *((u32 *)(packed + ((g1 >> 12) << 15) + (((g1 >> 10) & 3) << 12)) + (1023u - (u32)(g1 & 1023u))) = 0; else *(u64 *)(packed + 8 * g1) = 0;
@@ -1289,7 +1339,7 @@ __device__ __forceinline__ void scatter_regular_tile(const EncP &P, const i64 *t
                 uint4 *pp = (uint4 *)(O.packed + 8 * (Gq0 + s0));
                 pp[0] = a; pp[1] = b2;
             }
-            if (O.casebits) *(uint2 *)((u16 *)O.casebits + Gq0 + s0) = *(const uint2 *)(scb + s0);
+            if (O.casebits && !(dq && O.loc_mode)) *(uint2 *)((u16 *)O.casebits + Gq0 + s0) = *(const uint2 *)(scb + s0);
         } else {
 #pragma unroll
             for (u32 i = 0; i < 4; i++) {
@@ -2653,14 +2703,17 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         const bool direct_opts = allow_direct && S.fourbit && o->level <= 1 && !o->long_log && !(e_ed && e_ed[0] == '0') && e_prefer_flat >= 2 && !(e_ebl && atoi(e_ebl) != 15) && !(e_epr && e_epr[0] == '1')
                                  && !(e_elz && !strcmp(e_elz, "all")) && n >= 16 * ET_TILE;
         const bool fused = direct_opts && enc_wave_wg(c) && !(e_op && e_op[0] == '0') && (n >> 17) >= ((e_ed && e_ed[0] == '2') || (e_op && e_op[0] == '2') ? 2u : 256u);
-        u8 *loc = nullptr, *t_hist = nullptr; u32 *t_needf0 = nullptr; u64 *t_need0 = nullptr;
+        u8 *loc = nullptr, *t_hist = nullptr, *locc = nullptr, *t_lower = nullptr; u32 *t_needf0 = nullptr; u64 *t_need0 = nullptr;
         if (fused) {
             loc = (u8 *)arena_alloc(c, (tiles + 1) * LOC_TILE + 64); t_hist = (u8 *)arena_alloc(c, (tiles + 1) * 16);
+            locc = (u8 *)arena_alloc(c, (tiles + 1) * (LOC_TILE / 2) + 64); t_lower = (u8 *)arena_alloc(c, tiles + 2);
+            if (!locc || !t_lower) return NAF_GPU_ENOMEM;
+            HIP_TRY(c, hipMemsetAsync(t_lower, 0, tiles + 2, c->stream));
             t_needf0 = arena_new<u32>(c, tiles + 1); t_need0 = arena_new<u64>(c, tiles + 2);
             if (!loc || !t_hist || !t_needf0 || !t_need0) return NAF_GPU_ENOMEM;
             // (two and four tiles per wavefront, their loads in flight together: 23.8 -> 28.3 / 25.9 ms per 100 GB)
             // (a bounded grid of wavefronts that walk the tiles with the next tile's bytes asked for in advance: 117 VGPRs, 2.40 -> 2.87 ms per 10 GB)
-            LAUNCH(c, "ennaf_split_once", (k_enc_fused<true, 1>), (u32)tiles, 64, 0, P, t_eol, t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf0, t_need0, tiles, loc, t_hist);
+            LAUNCH(c, "ennaf_split_once", (k_enc_fused<true, 1>), (u32)tiles, 64, 0, P, t_eol, t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf0, t_need0, tiles, loc, t_hist, locc, t_lower);
         } else
         LAUNCH(c, "ennaf_last", k_enc_last_fa, cdiv(tiles, 4 * LAST_TPW), 256, 0, P, t_eol, t_sp, tiles);
         // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
@@ -2726,9 +2779,8 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
             O.loc_mode = 0; O.sparse_list = nullptr; O.n_sparse = nullptr;
             if (direct_opts && nd64 >= ((ed && ed[0] == '2') || (fused && e_op && e_op[0] == '2') ? 2u : 256u) && nd64 < 0x7FFFFFFFull && !((T & 1) && (n_seqb & 32767) == 0)) {
                 S.nd = (u32)nd64; S.direct = (u8 *)arena_alloc(c, S.nd); if (!S.direct) return NAF_GPU_ENOMEM;
-                // the codes k_enc_fused left are the direct blocks' when the text has no case bit to keep beside them (a text with lower case:
-                // the scatter pass makes codes and case bits of every tile, as before)
-                const bool use_loc = fused && S.no_case;
+                // the codes k_enc_fused left are the direct blocks'; a text with lower case has its tiles' case bits beside them (k_case_gather)
+                const bool use_loc = fused && !(e_op && e_op[0] == '3' && !S.no_case);       // (NAF_GPU_ONEPASS=3: only texts without a case bit, round 6's first form)
                 i32 *blk_bnd = use_loc ? arena_new<i32>(c, (size_t)S.nd * ZENC_LOC_BND + 1) : nullptr;
                 if (use_loc && !blk_bnd) return NAF_GPU_ENOMEM;
                 if (use_loc) LAUNCH(c, "ennaf_direct_blocks", k_direct_verdict, cdiv(S.nd, 256), 256, 0, (const u64 *)t_seq, (const u32 *)t_reg, (const u8 *)t_hist, tiles, S.nd, prefer_flat, (epr && epr[0] == '0') ? 0 : (int)zenc_probe_every(n_seqb), (const u32 *)blk_t0, S.direct, blk_bnd);
@@ -2741,6 +2793,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
                     O.loc_mode = 1; O.sparse_list = sparse_list; O.n_sparse = n_sparse;
                     LAUNCH(c, "ennaf_sparse_list", k_sparse_list, cdiv(tiles, 256), 256, 0, P, (const i64 *)t_eol, O, tiles, sparse_list, n_sparse);
                     S.dloc.loc = loc; S.dloc.blk_bnd = blk_bnd; S.dloc.blk_t0 = blk_t0; S.dloc.tiles = tiles;
+                    if (S.casebits) LAUNCH(c, "ennaf_case_gather", k_case_gather, 4 * S.nd, 256, 0, (const u8 *)S.direct, S.nd, (const u32 *)blk_t0, (const i32 *)blk_bnd, (const u8 *)locc, (const u8 *)t_lower, S.casebits);
                 }
                 if (ctx_tracing(c)) {
                     std::vector<u8> hd(S.nd); hipStreamSynchronize(c->stream); hipMemcpy(hd.data(), S.direct, S.nd, hipMemcpyDeviceToHost);
