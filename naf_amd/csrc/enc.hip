@@ -1071,30 +1071,36 @@ __global__ __launch_bounds__(256) void k_direct_verdict(const u64 *t_seq, const 
 // tile's end, the next one.  The blocks that are not direct get theirs from the scatter kernels as before.
 __global__ __launch_bounds__(256) void k_case_gather(const u8 *direct, u32 nd, const u32 *blk_t0, const i32 *blk_bnd, const u8 *locc, const u8 *t_lower, u64 *casebits)
 {
-    __shared__ i32 s_bnd[ZENC_LOC_BND];
-    const u32 b = blockIdx.x >> 2;                                    // four workgroups a block: 1024 words of 64 bases
+    __shared__ i32 s_bnd[ZENC_LOC_BND]; __shared__ u8 s_low[ZENC_LOC_BND];
+    const u32 b = blockIdx.x;                                         // a workgroup a block: 1024 words of 64 bases, four a thread
     if (b >= nd || !direct[b]) return;
-    if (threadIdx.x < ZENC_LOC_BND) s_bnd[threadIdx.x] = blk_bnd[(u64)b * ZENC_LOC_BND + threadIdx.x];
-    __syncthreads();
     const u64 t0 = blk_t0[b];
-    const u32 W = (blockIdx.x & 3u) * 256u + threadIdx.x;
-    const i32 r0 = (i32)(64u * W);
-    u32 k = (u32)(r0 - s_bnd[0]) >> 12;
-    if (s_bnd[k + 1] <= r0) k++;
-    if (s_bnd[k + 1] <= r0) k++;
-    const u32 i = (u32)(r0 - s_bnd[k]);
-    const u32 av = (u32)(s_bnd[k + 1] - r0);
-    u64 w = 0;
-    if (t_lower[t0 + k]) {
+    if (threadIdx.x < ZENC_LOC_BND) { s_bnd[threadIdx.x] = blk_bnd[(u64)b * ZENC_LOC_BND + threadIdx.x]; s_low[threadIdx.x] = t_lower[t0 + threadIdx.x]; }   // (t_lower has a tile's byte for every tile a block can reach: ZENC_LOC_BND behind the last)
+    __syncthreads();
+    u32 a[4], c[4], e[4], sh[4], av[4], kk[4]; u64 nx[4];
+#pragma unroll
+    for (u32 r = 0; r < 4; r++) {
+        const u32 W = r * 256u + threadIdx.x;
+        const i32 r0 = (i32)(64u * W);
+        u32 k = (u32)(r0 - s_bnd[0]) >> 12;
+        if (s_bnd[k + 1] <= r0) k++;
+        if (s_bnd[k + 1] <= r0) k++;
+        const u32 i = (u32)(r0 - s_bnd[k]);
+        av[r] = (u32)(s_bnd[k + 1] - r0); kk[r] = k; sh[r] = i & 31u;
+        // (asked for whether the tile has lower case or not -- its 512 bytes exist either way --: the loads do not wait for the flag)
         const u32 *p = (const u32 *)(locc + (t0 + k) * (LOC_TILE / 2)) + (i >> 5);
-        const u32 a = p[0], c = p[1], e = p[2], sh = i & 31u;
-        w = (u64)__builtin_amdgcn_alignbit(c, a, sh) | ((u64)__builtin_amdgcn_alignbit(e, c, sh) << 32);
+        a[r] = p[0]; c[r] = p[1]; e[r] = p[2];
+        nx[r] = av[r] < 64u ? ld64(locc + (t0 + k + 1) * (LOC_TILE / 2)) : 0ull;
     }
-    if (av < 64u) {                                                   // the tile ends inside the word: the rest from the next tile's first bases
-        w &= (1ull << av) - 1;
-        if (t_lower[t0 + k + 1]) w |= ld64(locc + (t0 + k + 1) * (LOC_TILE / 2)) << av;
+#pragma unroll
+    for (u32 r = 0; r < 4; r++) {
+        u64 w = s_low[kk[r]] ? (u64)__builtin_amdgcn_alignbit(c[r], a[r], sh[r]) | ((u64)__builtin_amdgcn_alignbit(e[r], c[r], sh[r]) << 32) : 0ull;
+        if (av[r] < 64u) {                                            // the tile ends inside the word: the rest from the next tile's first bases
+            w &= (1ull << av[r]) - 1;
+            if (s_low[kk[r] + 1]) w |= nx[r] << av[r];
+        }
+        casebits[((u64)b << 10) + r * 256u + threadIdx.x] = w;
     }
-    casebits[((u64)b << 10) + W] = w;
 }
 // the tiles k_enc_count did not find regular, in order (pre = exclusive scan of its 0 / 1 verdicts)
 // blk_t0 (may be null): the tile that holds base 65536 b, the first of block b of the packed stream, for every such base there is
@@ -2706,9 +2712,9 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         u8 *loc = nullptr, *t_hist = nullptr, *locc = nullptr, *t_lower = nullptr; u32 *t_needf0 = nullptr; u64 *t_need0 = nullptr;
         if (fused) {
             loc = (u8 *)arena_alloc(c, (tiles + 1) * LOC_TILE + 64); t_hist = (u8 *)arena_alloc(c, (tiles + 1) * 16);
-            locc = (u8 *)arena_alloc(c, (tiles + 1) * (LOC_TILE / 2) + 64); t_lower = (u8 *)arena_alloc(c, tiles + 2);
+            locc = (u8 *)arena_alloc(c, (tiles + 1) * (LOC_TILE / 2) + 64); t_lower = (u8 *)arena_alloc(c, tiles + ZENC_LOC_BND + 2);
             if (!locc || !t_lower) return NAF_GPU_ENOMEM;
-            HIP_TRY(c, hipMemsetAsync(t_lower, 0, tiles + 2, c->stream));
+            HIP_TRY(c, hipMemsetAsync(t_lower, 0, tiles + ZENC_LOC_BND + 2, c->stream));
             t_needf0 = arena_new<u32>(c, tiles + 1); t_need0 = arena_new<u64>(c, tiles + 2);
             if (!loc || !t_hist || !t_needf0 || !t_need0) return NAF_GPU_ENOMEM;
             // (two and four tiles per wavefront, their loads in flight together: 23.8 -> 28.3 / 25.9 ms per 100 GB)
@@ -2793,7 +2799,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
                     O.loc_mode = 1; O.sparse_list = sparse_list; O.n_sparse = n_sparse;
                     LAUNCH(c, "ennaf_sparse_list", k_sparse_list, cdiv(tiles, 256), 256, 0, P, (const i64 *)t_eol, O, tiles, sparse_list, n_sparse);
                     S.dloc.loc = loc; S.dloc.blk_bnd = blk_bnd; S.dloc.blk_t0 = blk_t0; S.dloc.tiles = tiles;
-                    if (S.casebits) LAUNCH(c, "ennaf_case_gather", k_case_gather, 4 * S.nd, 256, 0, (const u8 *)S.direct, S.nd, (const u32 *)blk_t0, (const i32 *)blk_bnd, (const u8 *)locc, (const u8 *)t_lower, S.casebits);
+                    if (S.casebits) LAUNCH(c, "ennaf_case_gather", k_case_gather, S.nd, 256, 0, (const u8 *)S.direct, S.nd, (const u32 *)blk_t0, (const i32 *)blk_bnd, (const u8 *)locc, (const u8 *)t_lower, S.casebits);
                 }
                 if (ctx_tracing(c)) {
                     std::vector<u8> hd(S.nd); hipStreamSynchronize(c->stream); hipMemcpy(hd.data(), S.direct, S.nd, hipMemcpyDeviceToHost);
@@ -2924,7 +2930,7 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
             if (nb) LAUNCH(c, "ennaf_mask_bscatter", k_maskb_scatter, mt, 256, 0, (const u64 *)S.casebits, T, (const u64 *)tc, nb, bnd, K.prev_masked);
             // runs of fewer than 255 bases only: a unit per run, in run order, written on that assumption (NAF_GPU_MASK_SHORT=0: never assumed)
             { 
-              if (!(ms && ms[0] == '0')) {
+              if (!(ms && ms[0] == '0') && (nb + 1) * 255 > T + K.run_ext) {          // (fewer runs than that: one of them holds 255 bases)
                   nu = nb + 1 - (K.skip_run0 ? 1 : 0);
                   s_mask = (u8 *)arena_alloc(c, nu + 16); if (!s_mask) return NAF_GPU_ENOMEM;
                   HIP_TRY(c, hipMemsetAsync(any_long, 0, 8, c->stream));
