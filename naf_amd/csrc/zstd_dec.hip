@@ -2911,6 +2911,97 @@ __device__ __forceinline__ bool lz_deps_done(const u8 *sdone, u32 lo, u32 n)
     for (; k < n; k++) if (!ld_sc1<u8>(sdone + lo + k)) return false;
     return true;
 }
+// ---- runs that continue from block to block (k_lz_runs_mark, k_lz_runs_check, k_lz_runs_apply) ----------------------------------------
+// What libzstd makes of a FASTQ's lengths ("150" as a u32, a few hundred MB of it) and of names that repeat ("len=150\0"): per 128 KiB
+// block ONE literal and ONE match that overlaps itself -- offset p, the period -- whose source is the last p - 1 bytes of the block in
+// front and that literal, block after block: a chain with a link per block even with the tail trick above (30 - 40 us a link: 48 ms for
+// the lengths of 12.5 GB of reads).  But every byte of such a run is a byte of the p-byte SEED in front of the run's first match,
+// out[x] = seed[(x - seed) mod p] -- as long as the literals on the way are what the pattern says they are.  So, behind k_lz_deps: a
+// block whose first sequence has fewer than p literals and overlaps itself with the offset of the last sequence of the block in
+// front, which runs to that block's end, is a LINK (k_lz_runs_mark; a running maximum names the block whose last match the run began
+// with); where that match's seed is final from the start, every link compares its literals with the pattern (k_lz_runs_check); a
+// link with no mismatch between the run's first block and itself becomes "fill with period p from the seed, in phase" and waits for
+// nothing (k_lz_runs_apply): every block of the run goes at once.  Encoded for k_lz_exec (the only reader behind this point) as
+// of = distance from the match to the seed, ml |= p << 18 (a match is at most 131074 bytes: 18 bits).
+#define LZ_PER_SHIFT 18u
+#define LZ_PER_MAX 8191u
+#define LZ_ML(x) ((x) & ((1u << LZ_PER_SHIFT) - 1))
+// (Two shapes of link in libzstd's frames: the match overlaps itself with the run's period as its offset -- the first blocks -- or, once
+// the window holds a whole block, copies the block in front, offset 131072: any multiple of the period whose source lies inside the run
+// is the same bytes.)
+__global__ void k_lz_runs_mark(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, LzArrays A, i32 *through, u32 *lnk)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seq_blk) return;
+    // lnk[t] = 1 when block t's first match MAY continue a run that reaches it: the block in front is the one in front in the frame and
+    // ends with a match (k_lz_runs_check looks at the rest once the run's period is known); through[t] = -1 when block t would
+    // moreover hand the run on (that match is its only one and runs to its last byte), else t: a run that goes on behind block t starts
+    // with block t's last match.
+    const u32 bi = seq_list[t]; const ZBlock &b = blk[bi];
+    u32 cand = 0; bool thr = false;
+    if (t && !b.err && b.nseq && seq_list[t - 1] + 1 == bi) {
+        const ZBlock &a = blk[seq_list[t - 1]];
+        if (!a.err && a.nseq && a.out_off + a.regen == b.out_off) {
+            const u64 i = b.seq_base, j = a.seq_base + a.nseq - 1;
+            const u32 ml = A.ml[i], d = A.x_dst[i], mlj = A.ml[j];
+            if (ml && d <= LZ_PER_MAX && mlj && A.x_dst[j] + mlj == a.regen) { cand = 1; thr = b.nseq == 1 && d + ml == b.regen; }
+        }
+    }
+    lnk[t] = cand; through[t] = thr ? -1 : (i32)t;
+}
+// the run that reaches block t, if any: it began with the last match of block h = head[t - 1] -- one that overlaps itself (its offset is the
+// period), runs to its block's end and has a seed that is final from the start
+__device__ __forceinline__ bool lz_run_of(const ZBlock *blk, const u32 *seq_list, const LzArrays &A, i32 h, u32 &per, u64 &seed)
+{
+    if (h < 0) return false;
+    const ZBlock &hb = blk[seq_list[h]];
+    if (hb.err || !hb.nseq) return false;
+    const u64 ih = hb.seq_base + hb.nseq - 1;
+    const u32 mlh = A.ml[ih], ofh = A.of[ih];                         // (never a sequence k_lz_runs_apply rewrites while this is read: see there)
+    if (!mlh || (mlh >> LZ_PER_SHIFT) || ofh >= mlh || ofh > LZ_PER_MAX || A.x_dst[ih] + mlh != hb.regen || A.dep_n[ih] != 0) return false;
+    per = ofh; seed = hb.out_off + A.x_dst[ih] - ofh;
+    return true;
+}
+// bad[t] = t when block t is no link of the run that reaches it -- its offset is no multiple of the period, its source begins in front of
+// the seed, it has a period's worth of literals or more, or its literals differ from the pattern -- else -1; the running maximum says
+// whether a link behind it may be rewritten
+__global__ void k_lz_runs_check(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, LzArrays A, const i32 *head, const u32 *lnk, const u8 *dst, i32 *bad)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seq_blk) return;
+    i32 v = -1;
+    if (t && lnk[t]) {
+        v = (i32)t;
+        u32 per; u64 seed;
+        if (lz_run_of(blk, seq_list, A, head[t - 1], per, seed)) {
+            const ZBlock &b = blk[seq_list[t]];
+            const u32 ll = A.x_dst[b.seq_base], of = A.of[b.seq_base];
+            if (ll < per && of % per == 0 && b.out_off + ll >= seed + of) {
+                bool same = true;
+                for (u32 q = 0; q < ll; q++) same = same && dst[b.out_off + q] == dst[seed + (b.out_off + q - seed) % per];
+                if (same) v = -1;
+            }
+        }
+    }
+    bad[t] = v;
+}
+__global__ void k_lz_runs_apply(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, LzArrays A, const i32 *head /* running maximum of `through` */, const u32 *lnk, const i32 *lastbad /* of `bad` */)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 || t >= n_seq_blk || !lnk[t]) return;
+    const i32 h = head[t - 1];
+    if (h < 0 || lastbad[t] > h) return;                              // (a block between the run's first and this one, or this one, is no link of it)
+    // (the run's first match is the LAST match of a block that is not handed through: if it is that block's first match as well it does
+    // not run to the block's end, and lz_run_of turns the run down whatever this kernel has made of it meanwhile)
+    u32 per; u64 seed;
+    if (!lz_run_of(blk, seq_list, A, h, per, seed)) return;
+    const ZBlock &b = blk[seq_list[t]];
+    const u64 i = b.seq_base;
+    const u64 dist = b.out_off + A.x_dst[i] - seed;
+    if (dist >= 0x80000000ull) return;
+    A.dep_lo[i] = 0; A.dep_n[i] = 0;                                  // (the seed is final)
+    A.of[i] = (u32)dist; A.ml[i] = LZ_ML(A.ml[i]) | (per << LZ_PER_SHIFT);
+}
 // A wavefront owns a UNIT of U x 64 consecutive sequences of one block (not the whole block: a sweep over a block's hundred words took
 // as long as a hundred round trips, and that was the time a level of the dependency graph cost).  Units are numbered in frame order
 // (unit_base: exclusive sum of the blocks' unit counts, k_lz_units) and taken by ticket: what a unit waits for lies in units with
@@ -2948,7 +3039,7 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
     for (u32 w = 0; w < U; w++) {
         const u32 s = s_first + w * 64 + lane;
         const u64 i = sbase + w * 64 + lane;
-        const u32 m = s < nseq ? A.ml[i] : 0;
+        const u32 m = s < nseq ? A.ml[i] : 0;                                 // (with the period of a run's continuation in its high bits: k_lz_runs_apply)
         dlo[w] = 0; dn[w] = 0;
         s_ml[w * 64 + lane] = m;
         if (m) { dlo[w] = A.dep_lo[i]; dn[w] = A.dep_n[i]; s_d[w * 64 + lane] = A.x_dst[i]; s_of[w * 64 + lane] = A.of[i]; }
@@ -2977,8 +3068,8 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
                 const u64 r = rdy[w];
                 if (!r) continue;
                 const bool ready = (r >> lane) & 1;
-                const u32 d = s_d[w * 64 + lane], ml = s_ml[w * 64 + lane], of = s_of[w * 64 + lane];
-                const bool plain = ready && of >= ml;
+                const u32 d = s_d[w * 64 + lane], mlp = s_ml[w * 64 + lane], ml = mlp & ((1u << LZ_PER_SHIFT) - 1), per = mlp >> LZ_PER_SHIFT, of = s_of[w * 64 + lane];
+                const bool plain = ready && !per && of >= ml;
                 if (plain && ml <= EXEC_LANE_MAX) lane_copy_sc1(out + d, out + d - of, ml);
                 for (u64 big = __ballot(plain && ml > EXEC_LANE_MAX); big; big &= big - 1) {
                     const int j = __ffsll((long long)big) - 1;
@@ -2986,9 +3077,19 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
                     wave_copy_sc1(out + dj, out + dj - ofj, mlj, lane);
                 }
                 // a match that overlaps itself repeats its first `of` bytes: only bytes in front of the match are read
-                for (u64 ov = __ballot(ready && of < ml); ov; ov &= ov - 1) {
+                for (u64 ov = __ballot(ready && (per || of < ml)); ov; ov &= ov - 1) {
                     const int j = __ffsll((long long)ov) - 1;
-                    const u32 dj = (u32)__builtin_amdgcn_readlane((int)d, j), mlj = (u32)__builtin_amdgcn_readlane((int)ml, j), ofj = (u32)__builtin_amdgcn_readlane((int)of, j);
+                    u32 dj = (u32)__builtin_amdgcn_readlane((int)d, j), mlj = (u32)__builtin_amdgcn_readlane((int)ml, j), ofj = (u32)__builtin_amdgcn_readlane((int)of, j);
+                    const u32 pj = (u32)__builtin_amdgcn_readlane((int)per, j);
+                    if (pj) {
+                        // a run's continuation: its first period from the seed (ofj bytes in front of the match), in phase; the rest repeats it
+                        const u8 *seed = out + dj - ofj;
+                        const u32 first = pj < mlj ? pj : mlj, ph = ofj % pj;
+                        for (u32 k = lane; k < first; k += 64) st_sc1<u8>(out + dj + k, ld_sc1<u8>(seed + (ph + k) % pj));
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        dj += first; mlj -= first; ofj = pj;
+                        if (!mlj) { if (lane == 0) st_sc1<u8>(A.stail + sbase + w * 64 + (u32)j, (u8)1); continue; }
+                    }
                     const u8 *from = out + dj - ofj;
                     if (mlj <= 2 * LZ_TAIL) { for (u32 k = lane; k < mlj; k += 64) st_sc1<u8>(out + dj + k, ld_sc1<u8>(from + k % ofj)); continue; }
                     // a long run: its last LZ_TAIL bytes first (the run of the next block starts from them: k_lz_deps, LZ_DEP_TAIL) ...
@@ -3012,7 +3113,7 @@ __global__ __launch_bounds__(64) void k_lz_exec(const ZBlock *blk, const u32 *se
             u32 ran = 0;
 #pragma unroll
             for (u32 w = 0; w < U; w++) {
-                if ((rdy[w] >> lane) & 1) { st_sc1<u8>(A.sdone + sbase + w * 64 + lane, (u8)1); if (s_of[w * 64 + lane] < s_ml[w * 64 + lane]) st_sc1<u8>(A.stail + sbase + w * 64 + lane, (u8)1); }   // (`stail` of a short overlapping match: set with the match)
+                if ((rdy[w] >> lane) & 1) { st_sc1<u8>(A.sdone + sbase + w * 64 + lane, (u8)1); if ((s_ml[w * 64 + lane] >> LZ_PER_SHIFT) || s_of[w * 64 + lane] < s_ml[w * 64 + lane]) st_sc1<u8>(A.stail + sbase + w * 64 + lane, (u8)1); }   // (`stail` of a short overlapping match: set with the match)
                 pend[w] &= ~rdy[w]; ran += (u32)__popcll(rdy[w]);
             }
             left -= ran;
@@ -3044,8 +3145,8 @@ __global__ void k_lz_stats(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk
     const u32 nseq = b.err ? 0 : b.nseq;
     u64 nm = 0, no = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, sm = 0, mx = 0;
     for (u32 s = 0; s < nseq; s++) {
-        const u64 i = b.seq_base + s; const u32 ml = A.ml[i]; if (!ml) continue;
-        nm++; sm += ml; if (A.of[i] < ml) no++;
+        const u64 i = b.seq_base + s; const u32 ml = A.ml[i] & ((1u << LZ_PER_SHIFT) - 1); if (!ml) continue;
+        nm++; sm += ml; if (A.of[i] < ml || (A.ml[i] >> LZ_PER_SHIFT)) no++;
         const u32 n = A.dep_n[i] & ~LZ_DEP_TAIL; if (n == 0) d0++; else if (n == 1) d1++; else if (n == 2) d2++; else d3++; if (n > mx) mx = n;
         if (t < 2 && s < 16) { S->first[16 * t + s][0] = A.x_dst[i]; S->first[16 * t + s][1] = ml; S->first[16 * t + s][2] = A.of[i]; S->first[16 * t + s][3] = A.dep_n[i] ? (u32)((i - A.dep_lo[i]) & 0xFFFFF) | ((n > 255 ? 255 : n) << 20) | (A.dep_n[i] & LZ_DEP_TAIL) : 0xFFFFFFFFu; }
     }
@@ -3109,6 +3210,16 @@ static int launch_lz_exec(naf_gpu_ctx *c, const ZBlock *blk, const u32 *seq_list
         }
     }
     LAUNCH(c, "zstd_lz_deps", k_lz_deps, (dim3(nx, nx >= 4096 ? 1u : (4096u / nx < LZ_DEPS_PARTS ? 4096u / nx : LZ_DEPS_PARTS))), 64, 0, blk, seq_list, nx, offs, seq_cnt, nblk, ns_total, A);
+    // runs that continue from block to block read their seed (NAF_GPU_EXEC_RUNS=0: every block from the block in front, the cross-check)
+    if (nx >= 2 && !ctx_opt_is(c, "EXEC_RUNS", '0')) {
+        i32 *through = arena_new<i32>(c, (size_t)nx + 1), *bad = arena_new<i32>(c, (size_t)nx + 1); u32 *lnk = arena_new<u32>(c, (size_t)nx + 1);
+        if (!through || !lnk || !bad) return NAF_GPU_ENOMEM;
+        LAUNCH(c, "zstd_lz_runs", k_lz_runs_mark, cdiv(nx, 256), 256, 0, blk, seq_list, nx, A, through, lnk);
+        if ((rc = scan_inclusive_max_i32(c, through, nx))) return rc;
+        LAUNCH(c, "zstd_lz_runs", k_lz_runs_check, cdiv(nx, 256), 256, 0, blk, seq_list, nx, A, (const i32 *)through, (const u32 *)lnk, (const u8 *)d_dst, bad);
+        if ((rc = scan_inclusive_max_i32(c, bad, nx))) return rc;
+        LAUNCH(c, "zstd_lz_runs", k_lz_runs_apply, cdiv(nx, 256), 256, 0, blk, seq_list, nx, A, (const i32 *)through, (const u32 *)lnk, (const i32 *)bad);
+    }
     if (ctx_tracing(c)) {
         LzStats *S = arena_new<LzStats>(c, 1), hs; if (!S) return NAF_GPU_ENOMEM;
         HIP_TRY(c, hipMemsetAsync(S, 0, sizeof(LzStats), c->stream));

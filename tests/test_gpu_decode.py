@@ -1101,6 +1101,38 @@ def test_executors_at_the_size_where_the_wait_once_gave_up(gpu, oracle):
     assert dt < 3.0, dt
 
 
+def test_runs_that_continue_from_block_to_block(gpu, oracle, monkeypatch):
+    """zstd_dec.hip k_lz_runs_*: libzstd codes a FASTQ's lengths and its repeating names as one literal and one match per 128 KiB block --
+    first overlapping itself with the period as its offset, then copying the whole block in front -- a chain of a link per block.  The
+    links of such a run read the period's seed instead, as long as their literals are what the pattern says: archives of
+    the real `ennaf` whose reads all have one length (every block a link), with ONE read of another length at a block's first, second and
+    last record or in the middle (the run breaks there and a new one begins), with two lengths in turn (period 8) and with random lengths
+    (no run at all) must decode to the reference's text with the rewrite and without it (NAF_GPU_EXEC_RUNS=0)."""
+    from naf_amd import capi
+    O = oracle
+    if not O.have_ref():
+        pytest.skip("needs oracle/_ref")
+    rng = np.random.default_rng(12)
+    n = 150_000                                                          # 600 KB of lengths, 1.2 MB of names: five and ten blocks
+    def fastq(lens):
+        return b"".join(b"@r len=%d\n%s\n+\n%s\n" % (L, b"ACGT"[:L] if L <= 4 else b"A" * L, b"I" * L) for L in lens)
+    cases = []
+    cases.append([4] * n)
+    for odd in (32767, 32768, 32769, 65535, 65536, 100_000):
+        lens = [4] * n; lens[odd] = 3; cases.append(lens)
+    cases.append([4 if i & 1 else 2 for i in range(n)])
+    cases.append([int(x) for x in rng.integers(1, 5, n)])
+    for lens in cases:
+        text = fastq(lens)
+        naf = O.ref_ennaf(text, ("--fastq",))
+        want = O.ref_unnaf(naf)
+        d_naf = gpu.to_device(naf)
+        for runs in ("1", "0"):
+            monkeypatch.setenv("NAF_GPU_EXEC_RUNS", runs)
+            assert host(gpu.unnaf(d_naf, capi.OUT_FASTQ)) == want, (runs, lens[:4], [i for i, L in enumerate(lens[:110_000]) if L == 3][:2])
+    monkeypatch.delenv("NAF_GPU_EXEC_RUNS")
+
+
 def test_reference_archive_of_reads_whose_names_copy_each_other(gpu, oracle, monkeypatch):
     """The reference's archive of a FASTQ: libzstd codes every read name as a copy of the name before it plus a digit or two -- chains of
     ten thousand links per 128 KiB block of the ids stream.  k_lz_collapse moves every source back along its chain (what is left: a link
