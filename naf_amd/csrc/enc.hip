@@ -3069,7 +3069,7 @@ static int encode_stream(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level,
     if (!tail || len <= tail) return zstd_encode(c, d_stream, len, level, dst, cap, clen, flags, lz, block_log, window_log);
     const bool part = (flags & ZENC_PART) != 0;
     const int f1 = ZENC_PART | ((!part || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES | ZENC_FRAME_TREE));
-    const int f2 = ZENC_PART | ((!part || (flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0);
+    const int f2 = ZENC_PART | ((!part || (flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0) | (tail >= 2048 ? (flags & (ZENC_PREFER_FLAT | ZENC_SHORT_CODES)) : 0);   // (a ragged block of some size is coded like the blocks in front of it)
     size_t a = 0, b = 0;
     int rc = zstd_encode(c, d_stream, len - tail, level, dst, cap, &a, f1, lz, block_log, window_log); if (rc) return rc;
     rc = zstd_encode(c, d_stream + (len - tail), tail, level, dst + a, cap - a, &b, f2, 0, 0, 0); if (rc) return rc;
@@ -3455,7 +3455,12 @@ extern "C" int naf_gpu_ennaf_shard_finish(naf_gpu_ctx *c, const naf_gpu_ennaf_op
         if (pos + need > cap) return ctx_fail(c, NAF_GPU_ECAP, "shard piece buffer of %zu bytes is too small", cap);
         size_t clen = 0;
         const int flags = ZENC_PART | (V.first[i] ? ZENC_PART_FIRST : 0) | (V.last[i] ? ZENC_PART_LAST : 0) | X.flags[i];
-        if ((rc = encode_stream(c, X.ptr[i], X.len[i], o->level, dst + pos, cap - pos, &clen, flags, X.lz[i], X.block_log[i], X.window_log[i], V.last[i] ? X.tail[i] : 0u))) return rc;
+        // a part of the packed sequence stream is whole blocks of 32 KiB and ONE ragged block behind them (not an even split of two sizes): the
+        // stitched frame is then runs of equal blocks with a short block at every seam, which the decoder's stride index takes in place
+        // (zstd_dec.hip: k_runs_*); a single part is a uniform frame outright
+        u32 tail = V.last[i] ? X.tail[i] : 0u;
+        if (i == 4 && st->S.fourbit && !X.lz[4] && !X.block_log[4] && X.len[4] >= 65536 && !(ctx_opt(c, "BLOCK_LOG") && atoi(ctx_opt(c, "BLOCK_LOG")) != 15)) { const u32 rag = (u32)(X.len[4] & 32767); if (rag > tail) tail = rag; }
+        if ((rc = encode_stream(c, X.ptr[i], X.len[i], o->level, dst + pos, cap - pos, &clen, flags, X.lz[i], X.block_log[i], X.window_log[i], tail))) return rc;
         pieces->off[i] = pos; pieces->len[i] = clen; pieces->raw[i] = X.orig[i];
         pos += (clen + 15) & ~(size_t)15;
     }

@@ -284,6 +284,8 @@ __global__ void k_stride_tail(const u8 *src, u64 len, u64 off0, u32 S, u32 nmax,
     }
     res[1] = done ? 1u : 0u;
     if (done) { st->nblk = np + n; st->end_off = pos; }
+    // (a prefix of equal blocks that ends far in front of the frame's end: the frame may be RUNS of equal blocks -- k_runs_*)
+    else if (np >= 16 && n == 0) res[1] = 2u;
 }
 __global__ void k_stride_write(u64 off0, u32 S, u32 h0, const u32 *res, ZBlock *blk, const u32 *uni)
 {
@@ -1968,6 +1970,169 @@ __global__ __launch_bounds__(256) void k_uni_streams(const u8 *src, u64 off0, u3
             f.A = 8ull * (u64)(sp - src) + E;
         }
     } else ok = flat_slot(src, ublk[1 + (bi - np)], s, f);
+    if (!ok) atomicOr(&U->bad, 1u);
+    si[t] = f;
+}
+
+// ---- RUNS of equal blocks (k_runs_next, k_runs_probe, k_uni_head_runs, k_uni_streams_runs) --------------------------------------------
+// The frame the SHARDED encoder makes of packed bases (enc.hip: naf_gpu_ennaf_shard_finish) is one run of equal blocks per shard
+// with a short block where two shards' parts meet: the stride index's prefix ends at the first seam, and every range call of an N-GPU
+// decode paid the universal decoder's front (2.8 ms per 50 GB of frame).  Behind a prefix that ends far from the frame's end the walk goes
+// on: one thread steps over the few odd blocks (k_runs_next) until a header repeats the first block's -- a new run, whose length the
+// next launch probes at all its places at once (k_runs_probe) -- up to URUN_MAX times, then the uniform frame's verdict and stream
+// table are made of the segments (runs by arithmetic, odd blocks parsed one by one).  Nothing of it runs for a frame of one run.
+#define URUN_MAX 16u
+#define USEG_MAX (2u * URUN_MAX + STRIDE_TAIL)
+struct UniRuns {
+    u32 n_seg, done, fail, nblk, pending, n_odd, pad0, pad1;
+    u64 cur, run_off, end_off;
+    u32 seg_first[USEG_MAX], seg_n[USEG_MAX], seg_odd[USEG_MAX];  // first block, blocks; seg_odd: index + 1 into the odd blocks (0: a run)
+    u64 seg_off[USEG_MAX], seg_out[USEG_MAX];                     // a run's first header; where the segment's bytes land
+};
+__global__ void k_runs_next(const u8 *src, u64 len, u64 off0, u32 S, u32 h0, const u32 *res, UniRuns *R, ZBlock *odd, u32 *probe, int first)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    if (first) {
+        memset(R, 0, sizeof(UniRuns));
+        if (res[1] != 2u) { R->fail = 1; return; }
+        R->seg_first[0] = 0; R->seg_n[0] = res[0]; R->seg_off[0] = off0; R->seg_odd[0] = 0; R->n_seg = 1;
+        R->nblk = res[0]; R->cur = off0 + (u64)res[0] * S;
+    }
+    if (R->done || R->fail) return;
+    if (R->pending) {                                              // the run k_runs_probe measured
+        const u64 room = (len - R->run_off) / S;
+        const u32 n = *probe < room ? *probe : (u32)room;
+        if (!n || R->n_seg >= USEG_MAX) { R->fail = 1; return; }
+        const u32 j = R->n_seg++;
+        R->seg_first[j] = R->nblk; R->seg_n[j] = n; R->seg_off[j] = R->run_off; R->seg_odd[j] = 0;
+        R->nblk += n; R->cur = R->run_off + (u64)n * S; R->pending = 0;
+    }
+    u64 pos = R->cur;
+    for (u32 k = 0; k < STRIDE_TAIL; k++) {
+        if (pos + 3 > len) { R->fail = 1; return; }
+        const u32 h = ld24(src + pos), last = h & 1, type = (h >> 1) & 3, size = h >> 3;
+        if (h == h0 && pos + S <= len && k > 0) {                      // a new run (k == 0: the probe said this block differs -- it cannot be one)
+            if (R->n_seg >= 2u * URUN_MAX) { R->fail = 1; return; }
+            R->run_off = pos; R->pending = 1; R->cur = pos; *probe = 0xFFFFFFFFu;
+            return;
+        }
+        if (type == 3 || size > ZBLOCK_MAX) { R->fail = 1; return; }
+        const u32 csize = type == BT_RLE ? 1 : size;
+        if (pos + 3 + csize > len || R->n_odd >= STRIDE_TAIL || R->n_seg >= USEG_MAX) { R->fail = 1; return; }
+        ZBlock &b = odd[R->n_odd]; memset(&b, 0, sizeof b); b.src_off = pos + 3; b.bsize = size; b.btype = (u8)type; b.last = (u8)last;
+        const u32 j = R->n_seg++;
+        R->seg_first[j] = R->nblk; R->seg_n[j] = 1; R->seg_off[j] = pos; R->seg_odd[j] = ++R->n_odd;
+        R->nblk++; pos += 3 + csize; R->cur = pos;
+        if (last) { R->done = 1; R->end_off = pos; return; }
+        // (more than a few odd blocks in a row somewhere else than at the frame's end: not this shape)
+        if (k >= 4 && len - pos > (u64)STRIDE_TAIL * (ZBLOCK_MAX + 3u)) { R->fail = 1; return; }
+    }
+    R->fail = 1;
+}
+__global__ void k_runs_probe(const u8 *src, u64 len, u32 S, u32 h0, const UniRuns *R, u32 *probe)
+{
+    if (!R->pending || R->done || R->fail) return;
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 pos = R->run_off + i * S;
+    if (pos >= len) return;                                        // (what lies behind the frame is nobody's place: the first place that does not fit is `room` in k_runs_next)
+    const bool ok = pos + S <= len && ld24(src + pos) == h0;
+    const u64 bad = __ballot(!ok);
+    if (bad && (threadIdx.x & 63) == (u32)(__ffsll((long long)bad) - 1)) atomicMin(probe, (u32)i);
+}
+// the verdict on a frame of runs: k_uni_head's, with the odd blocks wherever they stand (plain Huffman blocks of the first block's
+// tree, or treeless; a Raw / RLE block only as the frame's last); fills the segments' landing places
+__global__ __launch_bounds__(64) void k_uni_head_runs(const u8 *src, u64 off0, u32 h0, UniRuns *R, ZBlock *odd, UniInfo *U, ZBlock *ublk0, u32 spec_min)
+{
+    const u32 lane = threadIdx.x;
+    if (lane == 0) { U->ok = 0; U->bad = 0; }
+    if (!R->done || R->fail || R->nblk <= spec_min) return;
+    const u32 n_odd = R->n_odd;
+    if (lane < n_odd) { ZBlock b = odd[lane]; zstd_parse_block(src + b.src_off, b); odd[lane] = b; }
+    if (lane == 63) { ZBlock b; memset(&b, 0, sizeof b); b.src_off = off0 + 3; b.bsize = h0 >> 3; b.btype = (u8)((h0 >> 1) & 3); b.last = 0; zstd_parse_block(src + b.src_off, b); b.out_off = 0; ublk0[0] = b; }
+    __threadfence_block();
+    __syncthreads();
+    if (lane) return;
+    const ZBlock b0 = ublk0[0];
+    if (b0.err || b0.btype != BT_COMP || b0.lit_type != LIT_HUF || b0.nseq != 0 || b0.lit_regen == 0) return;
+    UniInfo u; memset(&u, 0, sizeof u);
+    u.np = R->seg_n[0]; u.nblk = R->nblk; u.regen0 = b0.lit_regen; u.nstreams0 = b0.nstreams; u.hso0 = b0.huf_streams_off;
+    u.front = b0.huf_streams_off + (b0.nstreams == 4 ? 6u : 0u); u.pos0 = b0.lit_off + b0.lit_csize;
+    const u8 *c0 = src + b0.src_off;
+    if (b0.nstreams == 4) {
+        const u8 *c = c0 + b0.huf_streams_off;
+        const u32 s1 = ld16(c), s2 = ld16(c + 2), s3 = ld16(c + 4), tot = b0.huf_streams_size - 6, per = (b0.lit_regen + 3) / 4;
+        if (s1 + s2 + s3 >= tot || !s1 || !s2 || !s3 || per * 3 > b0.lit_regen) return;
+        u.per = per;
+        u.off[0] = 6; u.off[1] = 6 + s1; u.off[2] = 6 + s1 + s2; u.off[3] = 6 + s1 + s2 + s3;
+        u.sz[0] = s1; u.sz[1] = s2; u.sz[2] = s3; u.sz[3] = tot - s1 - s2 - s3;
+        u.n[0] = u.n[1] = u.n[2] = per; u.n[3] = b0.lit_regen - 3 * per;
+    } else { u.per = 0; u.off[0] = 0; u.sz[0] = b0.huf_streams_size; u.n[0] = b0.lit_regen; }
+    u64 out = 0; u32 nhb = 0;
+    const u32 dlen = b0.huf_streams_off - b0.lit_off;
+    for (u32 j = 0; j < R->n_seg; j++) {
+        R->seg_out[j] = out;
+        if (!R->seg_odd[j]) { out += (u64)R->seg_n[j] * b0.lit_regen; nhb += R->seg_n[j]; continue; }
+        ZBlock &t = odd[R->seg_odd[j] - 1];
+        if (t.err) return;
+        if (t.btype == BT_COMP) {
+            if (t.lit_type < LIT_HUF || t.nseq != 0) return;
+            if (t.lit_type == LIT_HUF) {
+                if (t.huf_streams_off - t.lit_off != dlen) return;
+                const u8 *p = c0 + b0.lit_off, *q = src + t.src_off + t.lit_off;
+                for (u32 k = 0; k < dlen; k++) if (p[k] != q[k]) return;
+            }
+            t.out_off = out; out += t.regen; nhb++;
+        } else {
+            if (j + 1 != R->n_seg || !t.bsize || R->nblk < 2) return;
+            u.last_raw = t.bsize | (t.btype == BT_RLE ? 0x80000000u : 0u);
+            out += t.bsize;
+        }
+    }
+    u.nhb = nhb; u.total_out = out; u.end_off = R->end_off;
+    u.ok = 1;
+    *U = u;
+}
+__global__ __launch_bounds__(256) void k_uni_streams_runs(const u8 *src, u32 S, const UniRuns *R, const ZBlock *odd, const ZBlock *ublk0, UniInfo *U, FlatStream *si, u8 *sym)
+{
+    if (!U->ok) return;
+    if (blockIdx.x + 1 == gridDim.x) {                            // the tree: sixteen 4-bit codes, and which symbols they are
+        __shared__ FlatSymWS W;
+        if (threadIdx.x < 64) {
+            const ZBlock &b0 = ublk0[0];
+            if (!flat_sym_of_tree(src + b0.src_off + b0.lit_off, b0.huf_streams_off - b0.lit_off, sym, W) && threadIdx.x == 0) atomicOr(&U->bad, 1u);
+        }
+        return;
+    }
+    __shared__ u32 s_first[USEG_MAX]; __shared__ u32 s_nseg;
+    if (threadIdx.x < USEG_MAX) s_first[threadIdx.x] = threadIdx.x < R->n_seg ? R->seg_first[threadIdx.x] : 0xFFFFFFFFu;
+    if (threadIdx.x == 0) s_nseg = R->n_seg;
+    __syncthreads();
+    const u32 nhb = U->nhb;
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 4ull * nhb) { si[t].q0 = U->total_out - (U->last_raw & 0x7FFFFFFFu); si[t].A = 0; }
+    if (t >= 4ull * nhb) return;
+    const u32 bi = (u32)(t >> 2), s = (u32)t & 3;
+    u32 lo = 0, hi = s_nseg;                                       // the segment that holds block bi: the last one with seg_first <= bi
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_first[mid] <= bi) lo = mid; else hi = mid; }
+    FlatStream f; bool ok = true;
+    if (!R->seg_odd[lo]) {
+        const u32 k = bi - s_first[lo];
+        const u8 *c0 = src + ublk0[0].src_off, *cb = src + R->seg_off[lo] + (u64)k * S + 3;
+        if (bi) {
+            const u32 F = U->front, l0 = F * s / 4, h1 = F * (s + 1) / 4;
+            for (u32 q = l0; q < h1; q++) ok = ok && cb[q] == c0[q];
+            if (s == 3) ok = ok && cb[U->pos0] == 0;
+        }
+        const u32 regen = U->regen0, n = U->n[s];
+        f.q0 = R->seg_out[lo] + (u64)k * regen + (U->nstreams0 == 4 ? (u64)s * U->per : (s ? regen : 0u)); f.A = 0;
+        if (n) {
+            const u8 *sp = cb + U->hso0 + U->off[s]; const u32 sz = U->sz[s];
+            const u32 last = sz ? sp[sz - 1] : 0;
+            const u64 E = last ? 8ull * (sz - 1) + (u32)hibit32(last) : 0;
+            if (!last || E != 4ull * n) ok = false;
+            f.A = 8ull * (u64)(sp - src) + E;
+        }
+    } else ok = flat_slot(src, odd[R->seg_odd[lo] - 1], s, f);
     if (!ok) atomicOr(&U->bad, 1u);
     si[t] = f;
 }
@@ -3719,6 +3884,37 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                         return 0;
                     }
                     if (res2[1] == 1u && !hs.err && hs.nblk) { blk = sblk; indexed = true; }
+                    // runs of equal blocks (the sharded encoder's frames): NAF_GPU_STRIDE_RUNS=0: the universal front, as before
+                    if (res2[1] == 2u && !hs.err && uni_wanted && !ctx_opt_is(c, "STRIDE_RUNS", '0')) {
+                        UniRuns *R = arena_new<UniRuns>(c, 1); ZBlock *odd = arena_new<ZBlock>(c, STRIDE_TAIL + 1), *ublk0 = arena_new<ZBlock>(c, 1);
+                        u32 *probe = arena_new<u32>(c, 2); UniInfo *U2 = arena_new<UniInfo>(c, 1);
+                        FlatStream *usi2 = arena_new<FlatStream>(c, 4 * ((size_t)nmax + USEG_MAX) + 1); u8 *usym2 = (u8 *)arena_alloc(c, 16);
+                        if (!R || !odd || !ublk0 || !probe || !U2 || !usi2 || !usym2) return NAF_GPU_ENOMEM;
+                        for (u32 r = 0; r <= URUN_MAX; r++) {
+                            LAUNCH(c, "zstd_index_stride", k_runs_next, 1, 64, 0, d_src, (u64)src_len, (u64)fh.hdr_size, S, h0, (const u32 *)sres, R, odd, probe, r == 0 ? 1 : 0);
+                            if (r < URUN_MAX) LAUNCH(c, "zstd_index_stride", k_runs_probe, cdiv(nmax, 256), 256, 0, d_src, (u64)src_len, S, h0, (const UniRuns *)R, probe);
+                        }
+                        LAUNCH(c, "zstd_flat_uniform", k_uni_head_runs, 1, 64, 0, d_src, (u64)fh.hdr_size, h0, R, odd, U2, ublk0, spec_min);
+                        LAUNCH(c, "zstd_flat_uniform", k_uni_streams_runs, cdiv(4ull * ((u64)nmax + USEG_MAX) + 1, 256) + 1, 256, 0, d_src, S, (const UniRuns *)R, (const ZBlock *)odd, (const ZBlock *)ublk0, U2, usi2, usym2);
+                        UniInfo hu2; memset(&hu2, 0, sizeof hu2);
+                        if ((rc = ctx_readback(c, &hu2, U2, sizeof hu2))) return rc;
+                        if (ctx_tracing(c)) ctx_trace(c, "[runs?] ok %u bad %u first run %u blocks %u huffman %u total %llu\n", hu2.ok, hu2.bad, hu2.np, hu2.nblk, hu2.nhb, (unsigned long long)hu2.total_out);
+                        if (hu2.ok && !hu2.bad) {
+                            ZFlat *zf = c->zflat;
+                            const size_t frame_end = hu2.end_off + (fh.checksum ? 4 : 0);
+                            if (frame_end > src_len) return zerr(c, ZE_TRUNC, "checksum");
+                            *consumed = frame_end;
+                            const bool flat_tail = hu2.last_raw != 0;
+                            zf->src = d_src; zf->si = usi2; zf->nslots = 4ull * hu2.nhb; zf->sym = usym2; zf->status = st; zf->ready = true;
+                            const u32 tn = hu2.last_raw & 0x7FFFFFFFu; const bool rle = (hu2.last_raw >> 31) != 0;
+                            zf->tail = flat_tail ? d_src + (hu2.end_off - (rle ? 1u : tn)) : nullptr; zf->tail_q = hu2.total_out - (flat_tail ? tn : 0u);
+                            zf->tail_n = flat_tail ? (rle ? tn | 0x80000000u : tn) : 0u;
+                            if (rg) { rg->got_lo = 0; rg->got_hi = hu2.total_out; rg->ranged = false; }
+                            *out_len = hu2.total_out;
+                            if (fh.has_fcs && fh.content_size != hu2.total_out) return zerr(c, ZE_CORRUPT, "content size mismatch");
+                            return 0;
+                        }
+                    }
                 }
             }
         }
