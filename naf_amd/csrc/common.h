@@ -112,3 +112,19 @@ NAF_HD u32 bitf_peek(const BitF &b, u32 n)
     for (u32 i = 0; i < 4; i++) if (byte + i < b.len) v |= (u64)b.p[byte + i] << (8 * i);
     return (u32)((v >> (b.bitpos & 7)) & ((1u << n) - 1));
 }
+
+#if defined(__HIPCC__)
+// Workgroups are dealt to the eight XCDs in turn (workgroup b runs on XCD b % 8: MI355X_MICROARCH.md), each XCD with an L2 of its own.
+// xcd_block() renumbers a launch's workgroups so that every XCD walks ONE contiguous eighth of the grid: neighbouring units of work --
+// tiles of a text, blocks of a frame -- whose outputs share cache lines (unaligned stream pieces, eight-byte table entries) then meet in
+// one L2 instead of leaving partial lines in eight.  A bijection on [0, gridDim.x) whatever the grid.  (-DNAF_NO_XCD_MAP: launch order.)
+__device__ __forceinline__ u32 xcd_block()
+{
+#if defined(NAF_NO_XCD_MAP)
+    return blockIdx.x;
+#else
+    const u32 G = gridDim.x, b = blockIdx.x, q = G >> 3, rem = G & 7u, x = b & 7u;
+    return x * q + (x < rem ? x : rem) + (b >> 3);
+#endif
+}
+#endif
