@@ -728,8 +728,9 @@ __device__ __forceinline__ void fused_tile(const EncP &P, i64 *tile_eol, i64 *ti
         return;
     }
     note_case(P, lower_any);
+    // (a tile that needed the second look -- '\r' as its line end -- leaves no codes: it must not count as a direct block's tile)
     const PureTile r = fast ? count_plain_tile2(P, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, t, eol, acgt)
-                            : count_plain_tile(P, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, t, eol, acgt);
+                            : count_plain_tile(P, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, t_needf, t_need, t, eol, false);
     if (lane == 0) { const i64 le = r.any ? (i64)(tb + r.lastpos) : -1; tile_eol[t] = le; tile_sp[t] = le; }   // (a plain tile's blanks are its line ends)
     if (!LOC || !fast || !r.ok) return;
     // the tile's bytes as codes: a lane's four words of the LDS string; and, in a tile with lower case, their case bits (a bit per byte,

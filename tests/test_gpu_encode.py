@@ -876,6 +876,7 @@ def test_text_read_once_gives_the_archive_of_the_two_passes(gpu, oracle, monkeyp
     texts.append(b">odd and whole blocks\n" + wrap(seq(65536 * 6 - 1), 80))
     texts.append(b">u\n" + wrap(seq(700_000).replace(b"T", b"U"), 60))
     texts.append(b">no line end at the end\n" + wrap(seq(500_000), 90)[:-1])
+    texts.append(b">cr only\r" + wrap(seq(700_000), 80, b"\r") + b">lf\n" + wrap(seq(300_000), 80))   # (plain, regular, A C G T -- and not the first look's: no codes left for it)
     texts.append(b"\n\n>blank lines in front\n" + wrap(seq(300_000), 50) + b"\n\n>and between\n\n" + wrap(seq(300_000), 50))
     monkeypatch.setenv("NAF_GPU_PROBE", "0")
     monkeypatch.setenv("NAF_GPU_DIRECT", "2")
