@@ -3199,11 +3199,20 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
                 if ((rc = encode_stream_begin(c, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i], i == 4 ? X.direct : nullptr, i == 4 ? X.nd : 0u, i == 4 ? X.dloc : nullptr))) return bail(rc, c);
                 early[i] = true;
             }
+        // ids and names are queued BEFORE the look at the sequence stream is waited for, and the look has a stream of its own (the third
+        // side context): on the first side stream it stood 0.2 ms in front of them, and the call of a 10 GB text ends on that chain
+        for (int i = 0; i < 2; i++)
+            if (X.present[i]) {
+                if ((rc = encode_stream_begin(sc, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]))) return bail(rc, sc);
+                early[i] = true;
+            }
         if (probe_later) {
             // the frame is planned as if there were nothing to match (what the look says of nearly every input); a repeat-rich
             // stream drops that plan and starts over with the match finder
             u32 share = 0;
-            if ((rc = zenc_repeat_probe(sc, X.ptr[4], X.len[4], &share))) return bail(rc, sc);
+            naf_gpu_ctx *pc = c->side3 ? c->side3 : sc;
+            if (pc != sc) { arena_reset(pc); if (hipStreamWaitEvent(pc->stream, c->fork_ev, 0) != hipSuccess) return bail(ctx_fail(c, NAF_GPU_EHIP, "ennaf: the look's stream"), c); }
+            if ((rc = zenc_repeat_probe(pc, X.ptr[4], X.len[4], &share))) return bail(rc, pc);
             ennaf_probe_verdict(X, share);
             if (X.lz[4]) {
                 zstd_encode_drop(big[4].main); early[4] = false;
@@ -3212,12 +3221,6 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
                 early[4] = true;
             }
         }
-        // (ids and names behind the look at the sequence stream, which waits for its answer on the same side stream)
-        for (int i = 0; i < 2; i++)
-            if (X.present[i]) {
-                if ((rc = encode_stream_begin(sc, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]))) return bail(rc, sc);
-                early[i] = true;
-            }
     }
     for (int i = 0; i < 257; i++) { R.unexpected_id[i] = S.unexpected[0][i]; R.unexpected_comment[i] = S.unexpected[1][i]; R.unexpected_seq[i] = S.unexpected[2][i]; R.unexpected_qual[i] = S.unexpected[3][i]; }
     R.n_sequences = S.N; R.n_bases = S.T; R.longest_line = S.longest;
