@@ -2082,6 +2082,185 @@ __global__ __launch_bounds__(256) void k_encq_count_reg(EncP P, const i64 *tile_
     }
 }
 
+// ---- the first pass of a FASTQ text read ONCE: k_enc_last's tables and k_encq_count_reg's counts from one look (k_fq_first, k_fq_pick) ----
+// What a tile's lines ARE -- header, bases, '+', qualities -- follows from the ordinal of its first line, and that is the scan of the line
+// starts of every tile in front of it: k_encq_count_reg reads the text a second time only to apply that one number.  But the ordinal only
+// says which of FOUR ways the tile's segments take their roles (segment k is line ordinal + k), so the first look counts under all four:
+// per class k & 3 the bytes of its segments, what they would give the ID and the comment stream if they were headers, and whether they
+// could be headers, '+' lines, letters at all (the checks of fqr_segments<true> and k_encq_count_reg, role by role).  The segment in
+// progress at the tile's first byte keeps its header reading apart, in both forms (the blank that ends its ID seen in front of the tile or
+// not: the previous tile's table says which).  k_fq_pick, a lane per tile behind the scans, takes the class each role falls to: counts,
+// verdict and tables are those of the two kernels this replaces, value for value (NAF_GPU_FQ_FIRST=0: those two kernels; =check: both,
+// compared).  One wavefront per tile, 64 bytes a lane, no barrier that waits for another wavefront.
+struct FqCand { u16 L[4], I[4], C[4]; u16 I0, C0, C0s, pad; u32 flags; };
+enum { FQC_OK = 1u, FQC_STARTS = 2u, FQC_BADS = 1u << 4, FQC_BADP = 1u << 8, FQC_BADH = 1u << 12, FQC_BADH0 = 1u << 16, FQC_BADH0S = 1u << 17 };
+__device__ __forceinline__ u64 bits_from_to(u32 a, u32 b) { return (b >= 64 ? ~0ull : (1ull << b) - 1) & ~((1ull << a) - 1); }   // bits [a, b), a < 64, b <= 64
+__device__ __forceinline__ u32 swar_eq_mask16(const u32 w[4], u32 c4)                  // one bit per byte: == the byte c4 repeats
+{
+    const u32 H = 0x80808080u, L = 0x7F7F7F7Fu; u32 f[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const u32 y = w[i] ^ c4; f[i] = ~(((y & L) + L) | y) & H; }
+    return swar_movemask16(f[0], f[1], f[2], f[3]);
+}
+__global__ __launch_bounds__(64) void k_fq_first(EncP P, i64 *tile_eol, i64 *tile_sp, u64 *tile_ls, FqCand *cand)
+{
+    __shared__ __attribute__((aligned(16))) u8 txt[ET_TILE + 16];
+    __shared__ u64 s_oth[64], s_othx[64];
+    __shared__ u16 s_nl[FQR_MAXSEG];
+    const u64 tile = xcd_block(), tb = tile * ET_TILE;
+    const u32 lane = threadIdx.x;
+    if (!(tile > 0 && tb > P.p0 && tb + ET_TILE <= P.n)) {
+        // the text's first tiles and its last one: the tables as k_enc_last makes them, a piece at a time; nothing to pick from
+        u32 pos = 0, nls = 0;
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) {
+            const u32 idx = k * 64 + lane, t16 = idx * ET_BYTES + 1;
+            const u64 base = tb + (u64)idx * ET_BYTES;
+            const Piece pc = load_piece(P, base);
+            const PMask pm = piece_masks(pc);
+            pos = OpPkMaxU16::f<u32>(pos, (pm.eol ? t16 + (31 - __clz((int)pm.eol)) : 0u) | ((pm.sp ? t16 + (31 - __clz((int)pm.sp)) : 0u) << 16));
+            nls += pc.cnt ? count_line_starts_m(P, base, pc, pm) : 0u;
+        }
+        pos = wave_scan_inclusive<u32, OpPkMaxU16>(pos); nls = wave_scan_inclusive<u32, OpAdd>(nls);
+        if (lane == 63) {
+            tile_eol[tile] = (pos & 0xFFFF) ? (i64)(tb + (pos & 0xFFFF) - 1) : -1;
+            tile_sp[tile] = (pos >> 16) ? (i64)(tb + (pos >> 16) - 1) : -1;
+            tile_ls[tile] = nls;
+            cand[tile].flags = 0;
+        }
+        return;
+    }
+    const u8 *src = P.text + tb + 64 * lane;
+    u64 wv[8];
+#pragma unroll
+    for (u32 k = 0; k < 8; k++) wv[k] = ld64(src + 8 * k);
+    u64 nl = 0, oth = 0, othx = 0, eol = 0, sp = 0; bool high = false;
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+        const u32 w[4] = { (u32)wv[2 * k], (u32)(wv[2 * k] >> 32), (u32)wv[2 * k + 1], (u32)(wv[2 * k + 1] >> 32) };
+        u32 nlm, o; bool hi;
+        fqr_masks(w, nlm, o, hi);
+        const PieceFlags f = piece_flags(w);
+        const u32 m20 = swar_eq_mask16(w, 0x20202020u);
+        nl |= (u64)nlm << (16 * k); oth |= (u64)o << (16 * k); othx |= (u64)(o & ~m20) << (16 * k);
+        eol |= (u64)f.eol << (16 * k); sp |= (u64)f.sp << (16 * k); high |= hi;
+        uint4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        *(uint4 *)(txt + 64 * lane + 16 * k) = v;
+    }
+    s_oth[lane] = oth; s_othx[lane] = othx;
+    const bool prev_eol = c_eol(P.text[tb - 1]);
+    // k_enc_last's three values
+    {
+        const u32 last_e = (u32)(eol >> 63), up = (u32)__shfl_up((int)last_e, 1, 64);
+        const u32 prevbit = lane ? up : (prev_eol ? 1u : 0u);
+        const u32 nls = wave_scan_inclusive<u32, OpAdd>((u32)__popcll(~eol & ((eol << 1) | prevbit)));
+        const u64 be = __ballot(eol != 0), bs = __ballot(sp != 0);
+        const u32 pe = eol ? 64 * lane + 64 - (u32)__clzll((long long)eol) : 0u, ps = sp ? 64 * lane + 64 - (u32)__clzll((long long)sp) : 0u;
+        const u32 pe_t = be ? (u32)__shfl((int)pe, 63 - __clzll((long long)be), 64) : 0u, ps_t = bs ? (u32)__shfl((int)ps, 63 - __clzll((long long)bs), 64) : 0u;
+        if (lane == 63) { tile_eol[tile] = pe_t ? (i64)(tb + pe_t - 1) : -1; tile_sp[tile] = ps_t ? (i64)(tb + ps_t - 1) : -1; tile_ls[tile] = nls; }
+    }
+    // the segments
+    const u32 cnt = (u32)__popcll(nl), incl = wave_scan_inclusive<u32, OpAdd>(cnt), k0 = incl - cnt;
+    const u32 tot = (u32)__shfl((int)incl, 63, 64);
+    if (__ballot(high) || tot >= FQR_MAXSEG) { if (lane == 0) cand[tile].flags = 0; return; }   // (uniform)
+    { u64 m = nl; u32 idx = k0; while (m) { s_nl[idx++] = (u16)(64 * lane + (u32)__ffsll((long long)m) - 1); m &= m - 1; } }
+    // a lane's own bytes: what its segments' classes could not be (letters or qualities with a byte below 0x21; a '+' line with 0x0B..0x0D)
+    u32 own = 0;
+    if (oth) {
+        const u64 crm = eol & ~nl;
+        u32 a = 0, k = k0; u64 m = nl;
+        for (;;) {
+            const u32 b = m ? (u32)__ffsll((long long)m) - 1 : 64u;
+            if (b > a) { const u64 r = bits_from_to(a, b); if (oth & r) own |= 1u << (k & 3); if (crm & r) own |= 16u << (k & 3); }
+            if (!m) break;
+            m &= m - 1; a = b + 1; k++;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d; d >>= 1) own |= (u32)__shfl_xor((int)own, d, 64);
+    __syncthreads();
+    // a lane per segment, 64 a round; the lane's class is lane & 3 in every round
+    u64 sums = 0; u32 badp = 0, badh = 0, empty = 0;
+    u32 I0 = 0, C0 = 0, C0s = 0, bad0 = 0;
+    for (u32 kb = 0; kb <= tot; kb += 64) {
+        const u32 k = kb + lane;
+        if (k <= tot) {
+            const u32 s_ = k ? (u32)s_nl[k - 1] + 1 : 0u, e_ = k < tot ? (u32)s_nl[k] : (u32)ET_TILE, len = e_ - s_;
+            const bool starts = k > 0 || prev_eol, closed = k < tot;
+            if (len == 0 && starts && closed) empty = 1;
+            const u32 first = len ? (u32)txt[s_] : 0u;
+            if (starts && len && first != '+') badp = 1;
+            u32 a = s_; bool bh = false;
+            if (starts && len) { if (first != '@') bh = true; a++; }
+            u32 f = e_; bool x_any = false, x_after = false;
+            if (a < e_) for (u32 q = a >> 6; q <= (e_ - 1) >> 6; q++) {
+                const u32 lo = 64 * q;
+                const u64 r = bits_from_to(a > lo ? a - lo : 0u, e_ - lo < 64 ? e_ - lo : 64u);
+                const u64 m = s_oth[q] & r; u64 mx = s_othx[q] & r;
+                x_any |= mx != 0;
+                if (f != e_) x_after |= mx != 0;
+                else if (m) { const u32 bit = (u32)__ffsll((long long)m) - 1; f = lo + bit; mx &= ~((2ull << bit) - 1); x_after |= mx != 0; }
+            }
+            u32 nids = f - a, ncmt = 0;
+            if (f < e_) { nids++; ncmt = e_ - (f + 1); const u32 ch = txt[f]; if (ch != 0x20 && ch != 0x09) bh = true; if (x_after) bh = true; }
+            if (closed) { if (f == e_) nids++; ncmt++; }
+            if (k == 0 && !starts) {                                  // the line in progress: kept apart, both readings
+                I0 = nids; C0 = ncmt; C0s = e_ - a + (closed ? 1u : 0u);
+                bad0 = (bh ? (u32)FQC_BADH0 : 0u) | (x_any ? (u32)FQC_BADH0S : 0u);
+                sums += (u64)len;
+            } else { sums += (u64)len | ((u64)nids << 16) | ((u64)ncmt << 32); if (bh) badh = 1; }
+        }
+    }
+    // per class: lanes of one residue mod 4 add up
+#pragma unroll
+    for (int d = 32; d >= 4; d >>= 1) {
+        sums += shfl_idx_t<u64>(sums, (int)(lane ^ (u32)d));
+        badp |= (u32)__shfl_xor((int)badp, d, 64); badh |= (u32)__shfl_xor((int)badh, d, 64);
+    }
+    const u32 fp = (u32)(__ballot(badp != 0) & 15ull), fh = (u32)(__ballot(badh != 0) & 15ull);
+    const bool any_empty = __ballot(empty != 0) != 0;
+    FqCand *o = cand + tile;
+    if (lane < 4) { o->L[lane] = (u16)(sums & 0xFFFF); o->I[lane] = (u16)((sums >> 16) & 0xFFFF); o->C[lane] = (u16)((sums >> 32) & 0xFFFF); }
+    if (lane == 0) {
+        o->I0 = (u16)I0; o->C0 = (u16)C0; o->C0s = (u16)C0s; o->pad = 0;
+        o->flags = (any_empty ? 0u : (u32)FQC_OK) | (prev_eol ? (u32)FQC_STARTS : 0u) | ((own & 15u) * FQC_BADS) | ((fp | ((own >> 4) & 15u)) * FQC_BADP) | (fh * FQC_BADH) | bad0;
+    }
+}
+// The class each role falls to, a lane per tile: k_encq_count_reg's outputs.
+__global__ void k_fq_pick(EncP P, const FqCand *cand, const i64 *tile_eol, const i64 *tile_sp, const u64 *t_ls,
+                          u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_qual, u32 *t_reg, u64 *t_need, u64 tiles)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    const FqCand c = cand[t];
+    bool regular = (c.flags & FQC_OK) != 0;
+    if (regular) {
+        const bool starts = (c.flags & FQC_STARTS) != 0;
+        const u32 ord0 = (u32)(t_ls[t] - (starts ? 0u : 1u)) & 3u;
+        const u32 jh = (0u - ord0) & 3u, js = (1u - ord0) & 3u, jp = (2u - ord0) & 3u, jq = (3u - ord0) & 3u;
+        u32 bad = (c.flags & (FQC_BADS << js)) | (c.flags & (FQC_BADS << jq)) | (c.flags & (FQC_BADP << jp)) | (c.flags & (FQC_BADH << jh));
+        u32 ids = c.I[jh], cmt = c.C[jh];
+        if (jh == 0 && !starts) {
+            const i64 le = tile_eol[t - 1], lsp = tile_sp[t - 1];
+            i64 ls0 = le + 1; if ((u64)ls0 < P.p0) ls0 = (i64)P.p0;
+            if (lsp >= ls0) { cmt += c.C0s; bad |= c.flags & FQC_BADH0S; }
+            else { ids += c.I0; cmt += c.C0; bad |= c.flags & FQC_BADH0; }
+        }
+        regular = bad == 0;
+        if (regular) { t_seq[t] = c.L[js]; t_ids[t] = ids; t_cmt[t] = cmt; t_qual[t] = c.L[jq]; }
+    }
+    t_reg[t] = regular ? 1u : 0u; t_need[t] = regular ? 0u : 1u;
+}
+
+__global__ void k_fq_compare(const u32 *r1, const u32 *r2, const u64 *s1, const u64 *i1, const u64 *c1, const u64 *q1, const u64 *x2, u64 tiles, u64 *first)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    bool d = r1[t] != r2[t];
+    if (!d && r1[t]) d = s1[t] != x2[t] || i1[t] != x2[(tiles + 2) + t] || c1[t] != x2[2 * (tiles + 2) + t] || q1[t] != x2[3 * (tiles + 2) + t];
+    if (d) atomicMin((unsigned long long *)first, (unsigned long long)t);
+}
+
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_encq_scatter_reg(EncP P, const i64 *tile_eol, const i64 *tile_sp, FqOut O)
 {
@@ -2587,21 +2766,41 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         u64 *tot = arena_new<u64>(c, 8);
         u32 *piece_cnt = arena_new<u32>(c, tiles * 256);
         if (!t_eol || !t_sp || !t_ls || !t_seq || !t_ids || !t_cmt || !t_qual || !tot || !piece_cnt) return NAF_GPU_ENOMEM;
+        // regular tiles by lines (k_encq_count_reg), the others -- the first and the last one always, whatever the tolerant parser has
+        // something to tolerate in -- from a list by the general kernel; NAF_GPU_FQ_REG=0: every tile by the general kernel
+        const bool fq_reg = !(ctx_opt(c, "FQ_REG") && ctx_opt(c, "FQ_REG")[0] == '0') && S.fourbit && n >= 16 * ET_TILE;
+        // ... and their counts from the look that makes the tables (k_fq_first); NAF_GPU_FQ_FIRST=0: a second look (k_encq_count_reg), =check: both
+        const char *ff = ctx_opt(c, "FQ_FIRST");
+        const bool fq_first = fq_reg && !(ff && ff[0] == '0'), fq_check = fq_first && ff && !strcmp(ff, "check");
+        FqCand *cand = nullptr;
+        if (fq_first) {
+            cand = arena_new<FqCand>(c, tiles + 1); if (!cand) return NAF_GPU_ENOMEM;
+            LAUNCH(c, "ennaf_fq_first", k_fq_first, tiles, 64, 0, P, t_eol, t_sp, t_ls, cand);
+        } else
         LAUNCH(c, "ennaf_last", k_enc_last, tiles, 256, 0, P, t_eol, t_sp, t_ls);
         if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
         if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
         if ((rc = scan_exclusive_u64(c, t_ls, tiles, tot + 4))) return rc;
-        // regular tiles by lines (k_encq_count_reg), the others -- the first and the last one always, whatever the tolerant parser has
-        // something to tolerate in -- from a list by the general kernel; NAF_GPU_FQ_REG=0: every tile by the general kernel
-        const bool fq_reg = !(ctx_opt(c, "FQ_REG") && ctx_opt(c, "FQ_REG")[0] == '0');
         u32 *t_reg = nullptr, *need_list = nullptr; u64 n_need = tiles;
         u32 *redo_list = nullptr, *n_redo = nullptr;
-        if (fq_reg && S.fourbit && n >= 16 * ET_TILE) {
+        if (fq_reg) {
             t_reg = arena_new<u32>(c, tiles + 1); need_list = arena_new<u32>(c, tiles + 1); redo_list = arena_new<u32>(c, tiles + 1); n_redo = arena_new<u32>(c, 2);
             u64 *t_need = arena_new<u64>(c, tiles + 2);
             if (!t_reg || !need_list || !t_need || !redo_list || !n_redo) return NAF_GPU_ENOMEM;
             HIP_TRY(c, hipMemsetAsync(n_redo, 0, 8, c->stream));
-            LAUNCH(c, "ennaf_fq_count_reg", k_encq_count_reg, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, t_reg, t_need, tiles);
+            if (fq_first) LAUNCH(c, "ennaf_fq_pick", k_fq_pick, cdiv(tiles, 256), 256, 0, P, (const FqCand *)cand, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, t_reg, t_need, tiles);
+            else LAUNCH(c, "ennaf_fq_count_reg", k_encq_count_reg, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, t_reg, t_need, tiles);
+            if (fq_check) {
+                // the second look beside the first: every tile's verdict and, for regular tiles, its four counts must agree
+                u32 *r2 = arena_new<u32>(c, tiles + 1); u64 *n2 = arena_new<u64>(c, tiles + 2), *q2 = arena_new<u64>(c, 4 * (tiles + 2)), *dif = arena_new<u64>(c, 2);
+                if (!r2 || !n2 || !q2 || !dif) return NAF_GPU_ENOMEM;
+                HIP_TRY(c, hipMemsetAsync(dif, 0xFF, 8, c->stream));
+                LAUNCH(c, "ennaf_fq_count_reg", k_encq_count_reg, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, q2, q2 + (tiles + 2), q2 + 2 * (tiles + 2), q2 + 3 * (tiles + 2), r2, n2, tiles);
+                LAUNCH(c, "ennaf_fq_compare", k_fq_compare, cdiv(tiles, 256), 256, 0, (const u32 *)t_reg, (const u32 *)r2, (const u64 *)t_seq, (const u64 *)t_ids, (const u64 *)t_cmt, (const u64 *)t_qual, (const u64 *)q2, tiles, dif);
+                u64 hd = 0;
+                if ((rc = ctx_readback(c, &hd, dif, 8))) return rc;
+                if (hd != ~0ull) return ctx_fail(c, NAF_GPU_EHIP, "FASTQ: the first look and the second disagree on tile %llu", (unsigned long long)hd);
+            }
             if ((rc = scan_exclusive_u64(c, t_need, tiles, tot + 5))) return rc;
             LAUNCH(c, "ennaf_need_list", k_need_list, cdiv(tiles, 256), 256, 0, (const u32 *)nullptr, (const u64 *)t_need, tiles, need_list, (const u32 *)t_reg);
             if ((rc = ctx_readback(c, &n_need, tot + 5, 8))) return rc;

@@ -419,8 +419,11 @@ def test_ennaf_fastq_regular_tiles_by_lines(gpu, oracle, monkeypatch, capfd):
         t = _fastq_text(rng, n_bytes, rl, cm, dmg, iupac, 0.02 if len(dmg) == 1 else 0.004)
         for tail in (t, t.rstrip(b"\n"), b"\n \n" + t):
             monkeypatch.setenv("NAF_GPU_FQ_REG", "1"); monkeypatch.setenv("NAF_GPU_DEBUG_REG", "1")
+            # (check: the counts of the first look, k_fq_first / k_fq_pick, beside those of a second one, tile for tile -- the call fails where they differ)
+            monkeypatch.setenv("NAF_GPU_FQ_FIRST", "check")
             capfd.readouterr()
             mine = check_ennaf(gpu, oracle, tail)
+            monkeypatch.delenv("NAF_GPU_FQ_FIRST")
             err = capfd.readouterr().err
             tiles, irregular = [int(x) for x in err.split("[fq reg] tiles ")[1].split("\n")[0].replace(", not regular", "").split()]
             back = int(err.split("[fq reg] handed back ")[1].split("\n")[0])
@@ -438,6 +441,10 @@ def test_ennaf_fastq_regular_tiles_by_lines(gpu, oracle, monkeypatch, capfd):
             monkeypatch.setenv("NAF_GPU_FQ_REG", "0"); monkeypatch.delenv("NAF_GPU_DEBUG_REG")
             general, _ = gpu.ennaf(gpu.to_device(tail))
             assert host(general) == mine, (rl, dmg)
+            monkeypatch.setenv("NAF_GPU_FQ_REG", "1"); monkeypatch.setenv("NAF_GPU_FQ_FIRST", "0")
+            second, _ = gpu.ennaf(gpu.to_device(tail))
+            assert host(second) == mine, (rl, dmg)
+            monkeypatch.delenv("NAF_GPU_FQ_FIRST")
 
 
 def test_frame_tree_of_the_quality_stream(gpu, oracle, monkeypatch):
