@@ -1587,7 +1587,8 @@ struct FqOut {
     const u64 *t_seq, *t_ids, *t_cmt, *t_qual, *t_ls;
     const u32 *piece_cnt;         // per 16-byte piece: the four stream counts found by k_encq_count, 8 bits each
     const u32 *list;              // k_encq_scatter: the tiles that are not regular, in order (nullptr: every tile)
-    const u32 *t_reg;             // k_encq_count_reg's verdict on a tile (1: regular)
+    const u32 *t_reg;             // k_encq_count_reg's / k_fq_pick's verdict on a tile (0: not regular)
+    u32 reg_kind;                 // k_encq_scatter_reg: the verdict it takes (1; 2 beside k_fq_scatter_wave)
     u32 *redo_list, *n_redo;      // k_encq_scatter_reg: regular tiles whose letters want the general kernel after all
 };
 
@@ -2092,7 +2093,7 @@ __global__ __launch_bounds__(256) void k_encq_count_reg(EncP P, const i64 *tile_
 // not: the previous tile's table says which).  k_fq_pick, a lane per tile behind the scans, takes the class each role falls to: counts,
 // verdict and tables are those of the two kernels this replaces, value for value (NAF_GPU_FQ_FIRST=0: those two kernels; =check: both,
 // compared).  One wavefront per tile, 64 bytes a lane, no barrier that waits for another wavefront.
-struct FqCand { u16 L[4], I[4], C[4]; u16 I0, C0, C0s, pad; u32 flags; };
+struct FqCand { u16 L[4], I[4], C[4]; u16 I0, C0, C0s, nseg; u32 flags; };
 enum { FQC_OK = 1u, FQC_STARTS = 2u, FQC_BADS = 1u << 4, FQC_BADP = 1u << 8, FQC_BADH = 1u << 12, FQC_BADH0 = 1u << 16, FQC_BADH0S = 1u << 17 };
 __device__ __forceinline__ u64 bits_from_to(u32 a, u32 b) { return (b >= 64 ? ~0ull : (1ull << b) - 1) & ~((1ull << a) - 1); }   // bits [a, b), a < 64, b <= 64
 __device__ __forceinline__ u32 swar_eq_mask16(const u32 w[4], u32 c4)                  // one bit per byte: == the byte c4 repeats
@@ -2222,14 +2223,15 @@ __global__ __launch_bounds__(64) void k_fq_first(EncP P, i64 *tile_eol, i64 *til
     FqCand *o = cand + tile;
     if (lane < 4) { o->L[lane] = (u16)(sums & 0xFFFF); o->I[lane] = (u16)((sums >> 16) & 0xFFFF); o->C[lane] = (u16)((sums >> 32) & 0xFFFF); }
     if (lane == 0) {
-        o->I0 = (u16)I0; o->C0 = (u16)C0; o->C0s = (u16)C0s; o->pad = 0;
+        o->I0 = (u16)I0; o->C0 = (u16)C0; o->C0s = (u16)C0s; o->nseg = (u16)(tot + 1);
         o->flags = (any_empty ? 0u : (u32)FQC_OK) | (prev_eol ? (u32)FQC_STARTS : 0u) | ((own & 15u) * FQC_BADS) | ((fp | ((own >> 4) & 15u)) * FQC_BADP) | (fh * FQC_BADH) | bad0;
     }
 }
 // The class each role falls to, a lane per tile: k_encq_count_reg's outputs.
 __global__ void k_fq_pick(EncP P, const FqCand *cand, const i64 *tile_eol, const i64 *tile_sp, const u64 *t_ls,
-                          u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_qual, u32 *t_reg, u64 *t_need, u64 tiles)
+                          u64 *t_seq, u64 *t_ids, u64 *t_cmt, u64 *t_qual, u32 *t_reg, u64 *t_need, u64 tiles, u32 *n_wide, u32 wave_max)
 {
+    // t_reg: 1 = regular, up to 64 segments (k_fq_scatter_wave); 2 = regular with more (k_encq_scatter_reg); 0 = the general kernels
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tiles) return;
     const FqCand c = cand[t];
@@ -2249,14 +2251,16 @@ __global__ void k_fq_pick(EncP P, const FqCand *cand, const i64 *tile_eol, const
         regular = bad == 0;
         if (regular) { t_seq[t] = c.L[js]; t_ids[t] = ids; t_cmt[t] = cmt; t_qual[t] = c.L[jq]; }
     }
-    t_reg[t] = regular ? 1u : 0u; t_need[t] = regular ? 0u : 1u;
+    const bool wide = regular && c.nseg > wave_max;                 // (wave_max = 0xFFFF.. : none, every regular tile is 1)
+    t_reg[t] = regular ? (wide ? 2u : 1u) : 0u; t_need[t] = regular ? 0u : 1u;
+    if (wide) atomicAdd(n_wide, 1u);
 }
 
 __global__ void k_fq_compare(const u32 *r1, const u32 *r2, const u64 *s1, const u64 *i1, const u64 *c1, const u64 *q1, const u64 *x2, u64 tiles, u64 *first)
 {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tiles) return;
-    bool d = r1[t] != r2[t];
+    bool d = (r1[t] != 0) != (r2[t] != 0);
     if (!d && r1[t]) d = s1[t] != x2[t] || i1[t] != x2[(tiles + 2) + t] || c1[t] != x2[2 * (tiles + 2) + t] || q1[t] != x2[3 * (tiles + 2) + t];
     if (d) atomicMin((unsigned long long *)first, (unsigned long long)t);
 }
@@ -2265,7 +2269,7 @@ template <bool PACK>
 __global__ __launch_bounds__(256) void k_encq_scatter_reg(EncP P, const i64 *tile_eol, const i64 *tile_sp, FqOut O)
 {
     const u64 tile = blockIdx.x, tb = tile * ET_TILE;
-    if (!O.t_reg[tile]) return;                                                       // (uniform) the general kernel takes it from the list
+    if (O.t_reg[tile] != O.reg_kind) return;                                          // (uniform) 0: the general kernel takes it from the list; 1 where k_fq_scatter_wave runs: that kernel's
     __shared__ FqrLds S;
     __shared__ __attribute__((aligned(16))) u8 stage[ET_TILE + 512 + 5 * 16];
     const u32 tid = threadIdx.x;
@@ -2347,6 +2351,161 @@ __global__ __launch_bounds__(256) void k_encq_scatter_reg(EncP P, const i64 *til
     // the two small streams by a wavefront each
     if (tid >= 192) flush_congruent(O.ids + bases[1], stage + S.so[1], toti, tid - 192, 64);
     else if (tid >= 128) flush_congruent(O.cmt + bases[2], stage + S.so[2], totc, tid - 128, 64);
+}
+
+// ---- regular tiles of up to 64 segments, a WAVEFRONT per tile -------------------------------------------------------------------------
+// k_encq_scatter_reg's work without its barriers: a tile's chain there is a load, four workgroup barriers around one wavefront's walk
+// over the segments, the moves, two more barriers, the flush -- 6 us for a tile with eight workgroups to a CU, 1 TB/s.  Here a lane
+// holds 64 bytes of the tile in registers, the segment walk is the same lane-per-segment arithmetic (no checks: the count pass made
+// them), header bytes move from the registers like the letters and qualities (the text is not staged at all), and a CU holds twenty
+// tiles in flight.  Same streams, same record tables, same hand-back of tiles whose letters want the general kernel.
+#define FQW_MAXSEG 64
+template <bool PACK>
+__global__ __launch_bounds__(64) void k_fq_scatter_wave(EncP P, const i64 *tile_eol, const i64 *tile_sp, FqOut O)
+{
+    const u64 tile = xcd_block(), tb = tile * ET_TILE;
+    if (O.t_reg[tile] != 1u) return;
+    __shared__ __attribute__((aligned(16))) u8 stage[ET_TILE + 512 + 5 * 16];
+    __shared__ u64 s_oth[64];
+    __shared__ u16 s_nl[FQW_MAXSEG];
+    __shared__ i32 s_dst[FQW_MAXSEG];            // letters and qualities: where the segment's first byte goes in the staging buffer, minus its position; FQR_SKIP: a '+' line; header: the ID's place minus the position of its first byte
+    __shared__ u32 s_hdr[FQW_MAXSEG];            // header segments: first ID byte | the position behind the last one << 16
+    __shared__ i32 s_cdst[FQW_MAXSEG];           // header segments: the comment's place minus the position of its first byte ...
+    __shared__ u16 s_ca[FQW_MAXSEG];             // ... and that position
+    __shared__ u8 s_ty[FQW_MAXSEG];
+    const u32 lane = threadIdx.x;
+    const u8 *src = P.text + tb + 64 * lane;
+    u64 wv[8];
+#pragma unroll
+    for (u32 k = 0; k < 8; k++) wv[k] = ld64(src + 8 * k);
+    const u64 bases[4] = { O.t_seq[tile], O.t_ids[tile], O.t_cmt[tile], O.t_qual[tile] };
+    const i64 le = tile_eol[tile - 1], lsp = tile_sp[tile - 1];
+    const u64 ls_tile = O.t_ls[tile];
+    u64 nl = 0, oth = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+        const u32 w[4] = { (u32)wv[2 * k], (u32)(wv[2 * k] >> 32), (u32)wv[2 * k + 1], (u32)(wv[2 * k + 1] >> 32) };
+        u32 nlm, o; bool hi;
+        fqr_masks(w, nlm, o, hi);
+        nl |= (u64)nlm << (16 * k); oth |= (u64)o << (16 * k);
+    }
+    s_oth[lane] = oth;
+    const u32 cnt = (u32)__popcll(nl), incl = wave_scan_inclusive<u32, OpAdd>(cnt), k0 = incl - cnt;
+    const u32 tot = (u32)__shfl((int)incl, 63, 64);                                   // (< FQW_MAXSEG: k_fq_pick)
+    { u64 m = nl; u32 idx = k0; while (m) { s_nl[idx++] = (u16)(64 * lane + (u32)__ffsll((long long)m) - 1); m &= m - 1; } }
+    __syncthreads();
+    const bool prev_eol = le == (i64)tb - 1;
+    i64 ls0 = le + 1; if ((u64)ls0 < P.p0) ls0 = (i64)P.p0;
+    const u64 ord0 = ls_tile - (prev_eol ? 0u : 1u);
+    // a lane per segment
+    const u32 k = lane;
+    u64 c = 0; u32 s_ = 0, e_ = 0, ty = 0, a = 0, f = 0; bool starts = false, closed = false;
+    if (k <= tot) {
+        s_ = k ? (u32)s_nl[k - 1] + 1 : 0u; e_ = k < tot ? (u32)s_nl[k] : (u32)ET_TILE;
+        const u32 len = e_ - s_;
+        starts = k > 0 || prev_eol; closed = k < tot;
+        ty = (u32)((ord0 + k) & 3);
+        if (ty == 1) c = (u64)len;
+        else if (ty == 3) c = (u64)len << 48;
+        else if (ty == 0) {
+            a = s_; if (starts && len) a++;
+            const bool seen = !starts && lsp >= ls0;
+            f = e_;
+            if (!seen && a < e_) for (u32 q = a >> 6; q <= (e_ - 1) >> 6 && f == e_; q++) {
+                const u32 lo = 64 * q;
+                const u64 m = s_oth[q] & bits_from_to(a > lo ? a - lo : 0u, e_ - lo < 64 ? e_ - lo : 64u);
+                if (m) f = lo + (u32)__ffsll((long long)m) - 1;
+            }
+            u32 nids, ncmt;
+            if (seen) { nids = 0; ncmt = e_ - a; f = 0xFFFFu; }
+            else { nids = f - a; ncmt = 0; if (f < e_) { nids++; ncmt = e_ - (f + 1); } }
+            if (closed) { if (!seen && f == e_) nids++; ncmt++; }
+            c = ((u64)nids << 16) | ((u64)ncmt << 32);
+        }
+    }
+    const u64 inc = wave_scan_inclusive<u64, OpAdd>(c), off = inc - c;
+    const u64 total = shfl_idx_t<u64>(inc, 63);
+    const u32 tots = (u32)(total & 0xFFFF), toti = (u32)((total >> 16) & 0xFFFF), totc = (u32)((total >> 32) & 0xFFFF), totq = (u32)(total >> 48);
+    // the staging buffer: the four streams' shares one behind the other, each congruent to its stream's address mod 16 (fqr_segments)
+    const u32 sO = (u32)(bases[0] & 15);
+    const u32 qO = ((sO + tots + 15) & ~15u) + (u32)(bases[3] & 15);
+    const u32 iO = ((qO + totq + 15) & ~15u) + (u32)(bases[1] & 15);
+    const u32 cO = ((iO + toti + 15) & ~15u) + (u32)(bases[2] & 15);
+    const u64 sbase = bases[0], qbase = bases[3];
+    if (k <= tot) {
+        const u64 rec = (ord0 + k) >> 2;
+        i32 d = FQR_SKIP; u32 hdr = 0; i32 cd = 0;
+        if (ty == 1) { d = (i32)(sO + (u32)(off & 0xFFFF)) - (i32)s_; if (closed) O.rec_end[rec] = sbase + (off & 0xFFFF) + (e_ - s_); }
+        else if (ty == 3) {
+            d = (i32)(qO + (u32)(off >> 48)) - (i32)s_;
+            if (starts && e_ > s_) O.q_begin[rec] = qbase + (off >> 48);
+            if (closed) O.q_end[rec] = qbase + (off >> 48) + (e_ - s_);
+        } else if (ty == 0) {
+            const u32 ip = iO + (u32)((off >> 16) & 0xFFFF), cp = cO + (u32)((off >> 32) & 0xFFFF);
+            u32 ca = a;                                                               // first comment byte
+            if (f != 0xFFFFu) { if (f < e_ || closed) stage[ip + (f - a)] = 0; ca = f < e_ ? f + 1 : e_; }
+            if (closed) { stage[cp + (e_ - ca)] = 0; O.rec_begin[rec] = sbase + (off & 0xFFFF); }
+            d = (i32)ip - (i32)a; cd = (i32)cp - (i32)ca;
+            hdr = a | ((f == 0xFFFFu ? a : f) << 16);
+            s_ca[k] = (u16)ca;
+        }
+        s_dst[k] = d; s_hdr[k] = hdr; s_cdst[k] = cd; s_ty[k] = (u8)ty;
+    }
+    __syncthreads();
+    // every piece moves its bytes: letters and qualities to their segment's place, a header's to the ID and the comment
+    {
+        u32 seg = k0;
+#pragma unroll
+        for (u32 i = 0; i < 4; i++) {
+            const Piece pc = { wv[2 * i], wv[2 * i + 1], 16 };
+            const u32 pb = 64 * lane + 16 * i;
+            u32 x = 0, m = (u32)(nl >> (16 * i)) & 0xFFFFu;
+            for (;;) {
+                const u32 b = m ? (u32)__ffs((int)m) - 1 : 16u;
+                if (b > x) {
+                    const u32 t = s_ty[seg]; const i32 d = s_dst[seg];
+                    if (t & 1) { u64 lo, hi; piece_from(pc, x, lo, hi); lds_store_n(stage + (d + (i32)(pb + x)), lo, hi, b - x); }
+                    else if (t == 0) {
+                        const u32 h = s_hdr[seg], ha = h & 0xFFFF, ie = h >> 16, ca = s_ca[seg];
+                        const u32 p0 = pb + x, p1 = pb + b;                            // the portion, in tile positions
+                        const u32 i0 = p0 > ha ? p0 : ha, i1 = p1 < ie ? p1 : ie;
+                        if (i1 > i0) { u64 lo, hi; piece_from(pc, i0 - pb, lo, hi); lds_store_n(stage + (d + (i32)i0), lo, hi, i1 - i0); }
+                        const u32 c0 = p0 > ca ? p0 : ca;
+                        if (p1 > c0) { u64 lo, hi; piece_from(pc, c0 - pb, lo, hi); lds_store_n(stage + (s_cdst[seg] + (i32)c0), lo, hi, p1 - c0); }
+                    }
+                }
+                if (!m) break;
+                m &= m - 1; x = b + 1; seg++;
+            }
+        }
+    }
+    __syncthreads();
+    // the letters: a group of sixteen staged bases with a byte that is not A C G T/U N (either case) sends the tile to the general kernel
+    {
+        bool odd = false;
+        const u32 span = sO + tots, ng = (span + 15) >> 4;
+        for (u32 j = lane; j < ng; j += 64) {
+            uint4 v = *(const uint4 *)(stage + 16 * j);
+            u32 xw[4] = { v.x, v.y, v.z, v.w };
+            const u32 a0 = j == 0 ? sO : 0u, b0 = span - 16 * j < 16 ? span - 16 * j : 16u;
+            if (a0 || b0 < 16) {                                                      // what lies outside the tile's own bases reads as 'A'
+                const u64 klo = low_bytes(b0 < 8 ? b0 : 8u) & ~low_bytes(a0 < 8 ? a0 : 8u), khi = low_bytes(b0 > 8 ? b0 - 8 : 0u) & ~low_bytes(a0 > 8 ? a0 - 8 : 0u);
+                const u64 A = 0x4141414141414141ull;
+                const u64 lo = ((((u64)xw[1] << 32) | xw[0]) & klo) | (A & ~klo), hi = ((((u64)xw[3] << 32) | xw[2]) & khi) | (A & ~khi);
+                xw[0] = (u32)lo; xw[1] = (u32)(lo >> 32); xw[2] = (u32)hi; xw[3] = (u32)(hi >> 32);
+            }
+            if (!all_quick16(xw, P.qlo, P.qhi)) odd = true;
+        }
+        if (__ballot(odd)) {
+            if (lane == 0) O.redo_list[atomicAdd(O.n_redo, 1u)] = (u32)tile;
+            return;
+        }
+    }
+    if (PACK) flush_pack<true>(P, O.packed, O.casebits, sbase, tots, stage);
+    else flush_congruent(O.seq + sbase, stage + sO, tots, lane, 64);
+    flush_congruent(O.qual + qbase, stage + qO, totq, lane, 64);
+    flush_congruent(O.ids + bases[1], stage + iO, toti, lane, 64);
+    flush_congruent(O.cmt + bases[2], stage + cO, totc, lane, 64);
 }
 
 struct SmallBytes { u8 b[60]; u32 n; };
@@ -2772,6 +2931,9 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         // ... and their counts from the look that makes the tables (k_fq_first); NAF_GPU_FQ_FIRST=0: a second look (k_encq_count_reg), =check: both
         const char *ff = ctx_opt(c, "FQ_FIRST");
         const bool fq_first = fq_reg && !(ff && ff[0] == '0'), fq_check = fq_first && ff && !strcmp(ff, "check");
+        // ... and split by a wavefront each where they have no more than 64 segments (k_fq_scatter_wave); NAF_GPU_FQ_WAVE=0: by k_encq_scatter_reg's workgroups
+        const bool fq_wave = fq_first && !(ctx_opt(c, "FQ_WAVE") && ctx_opt(c, "FQ_WAVE")[0] == '0');
+        u32 n_wide = 0;
         FqCand *cand = nullptr;
         if (fq_first) {
             cand = arena_new<FqCand>(c, tiles + 1); if (!cand) return NAF_GPU_ENOMEM;
@@ -2788,7 +2950,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
             u64 *t_need = arena_new<u64>(c, tiles + 2);
             if (!t_reg || !need_list || !t_need || !redo_list || !n_redo) return NAF_GPU_ENOMEM;
             HIP_TRY(c, hipMemsetAsync(n_redo, 0, 8, c->stream));
-            if (fq_first) LAUNCH(c, "ennaf_fq_pick", k_fq_pick, cdiv(tiles, 256), 256, 0, P, (const FqCand *)cand, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, t_reg, t_need, tiles);
+            if (fq_first) LAUNCH(c, "ennaf_fq_pick", k_fq_pick, cdiv(tiles, 256), 256, 0, P, (const FqCand *)cand, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, t_reg, t_need, tiles, n_redo + 1, fq_wave ? (u32)FQW_MAXSEG : 0xFFFFFFFFu);
             else LAUNCH(c, "ennaf_fq_count_reg", k_encq_count_reg, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, t_reg, t_need, tiles);
             if (fq_check) {
                 // the second look beside the first: every tile's verdict and, for regular tiles, its four counts must agree
@@ -2803,7 +2965,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
             }
             if ((rc = scan_exclusive_u64(c, t_need, tiles, tot + 5))) return rc;
             LAUNCH(c, "ennaf_need_list", k_need_list, cdiv(tiles, 256), 256, 0, (const u32 *)nullptr, (const u64 *)t_need, tiles, need_list, (const u32 *)t_reg);
-            if ((rc = ctx_readback(c, &n_need, tot + 5, 8))) return rc;
+            if ((rc = ctx_readback2(c, &n_need, tot + 5, 8, &n_wide, n_redo + 1, 4))) return rc;
             if (ctx_tracing(c)) ctx_trace(c, "[fq reg] tiles %llu, not regular %llu\n", (unsigned long long)tiles, (unsigned long long)n_need);
         }
         if (n_need) LAUNCH(c, "ennaf_fq_count", k_encq_count, n_need, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, piece_cnt, (const u32 *)need_list, 0);
@@ -2835,7 +2997,9 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         O.t_seq = t_seq; O.t_ids = t_ids; O.t_cmt = t_cmt; O.t_qual = t_qual; O.t_ls = t_ls; O.piece_cnt = piece_cnt; O.list = need_list; O.t_reg = t_reg; O.redo_list = redo_list; O.n_redo = n_redo;
         if (S.fourbit) {
             if (T) LAUNCH(c, "ennaf_pack_edges", k_pack_edges_zero, cdiv(tiles, 256), 256, 0, (const u64 *)t_seq, tiles, T, S.packed, (u32 *)S.casebits, (const u8 *)nullptr, 0u);
-            if (t_reg) LAUNCH(c, "ennaf_fq_scatter_reg", k_encq_scatter_reg<true>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+            O.reg_kind = fq_wave ? 2u : 1u;
+            if (t_reg && fq_wave) LAUNCH(c, "ennaf_fq_scatter_wave", k_fq_scatter_wave<true>, tiles, 64, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
+            if (t_reg && (!fq_wave || n_wide)) LAUNCH(c, "ennaf_fq_scatter_reg", k_encq_scatter_reg<true>, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
             if (n_need) LAUNCH(c, "ennaf_fq_scatter", k_encq_scatter<true>, n_need, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, O);
             if (t_reg) {
                 // regular tiles handed back for their letters (an IUPAC code, a letter to be replaced): their pieces' counts, then the general scatter

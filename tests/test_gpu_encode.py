@@ -444,7 +444,10 @@ def test_ennaf_fastq_regular_tiles_by_lines(gpu, oracle, monkeypatch, capfd):
             monkeypatch.setenv("NAF_GPU_FQ_REG", "1"); monkeypatch.setenv("NAF_GPU_FQ_FIRST", "0")
             second, _ = gpu.ennaf(gpu.to_device(tail))
             assert host(second) == mine, (rl, dmg)
-            monkeypatch.delenv("NAF_GPU_FQ_FIRST")
+            monkeypatch.delenv("NAF_GPU_FQ_FIRST"); monkeypatch.setenv("NAF_GPU_FQ_WAVE", "0")   # (every regular tile by k_encq_scatter_reg's workgroups)
+            third, _ = gpu.ennaf(gpu.to_device(tail))
+            assert host(third) == mine, (rl, dmg)
+            monkeypatch.delenv("NAF_GPU_FQ_WAVE")
 
 
 def test_frame_tree_of_the_quality_stream(gpu, oracle, monkeypatch):
