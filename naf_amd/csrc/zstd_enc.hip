@@ -559,8 +559,10 @@ struct LzBufs {
 };
 // Dynamic LDS: the block (block size + 320 bytes of zero padding) followed by the hash table; sized by the host for the
 // block size in use, since LDS per wavefront is what bounds the blocks in flight (16 KiB blocks: 6 per CU, 32 KiB: 3).
-__global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk, LzBufs B, u32 buf_bytes, u32 hash_log)
+__global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk, LzBufs B, u32 buf_bytes, u32 hash_log, const u8 *fallback = nullptr)
 {
+    if (fallback && !fallback[blockIdx.x]) return;              // k_lz_parse_lines has the block
+
     __builtin_amdgcn_s_setprio(3);                           // a serial chain: first in line for the SIMD's issue slots beside the bulk kernels of the other streams
     extern __shared__ __attribute__((aligned(16))) u8 lz_lds[];
     u8 *buf = lz_lds;
@@ -632,6 +634,137 @@ __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk,
     for (u32 k = lane; k < bn - anchor; k += 64) lits[nl + k] = buf[anchor + k];
     nl += bn - anchor;
     if (lane == 0) { B.nseq[b] = ns; B.nlit[b] = nl; }
+}
+
+// ---- streams of zero-terminated names: a LANE per line against the line in front of it (k_lz_parse_lines) --------------------------------
+// A FASTQ's read names are 38 M strings that differ from their predecessor in a digit or two.  k_lz_parse finds that -- one match per
+// name, offset = the length of the name in front -- but finds it SERIALLY: its greedy walk over a round's 64 positions takes the matches
+// one after the other, five names a round, 7.5 ms for the 0.5 GB of names of a 12.5 GB FASTQ (a sixth of the whole encode, on a
+// stream that is a twenty-fifth of the text).  Here a lane takes a LINE (the bytes up to and including a zero byte) and compares it with
+// the line in front of it, column by column: the common prefix (segment A) and the next run of equal bytes behind the first difference
+// (segment B), both at the offset of the previous line's start.  Nothing is serial between lines: where a line's literals go and which
+// sequence numbers it writes are prefix sums over the lines.  A prefix that continues the match the line in front ended on (that
+// match reached its terminator, and the offset is the same: lines of equal length) JOINS it instead of opening a sequence -- what the
+// greedy walk gets from running across the line end: `SRR1.12 length=150\0SRR1.1` is one match, and comments that are all alike one per
+// block.  The head a joining prefix adds its length to is the sequence open at the end of the line in front, handed on through lines that
+// are wholly one match by a scan.  Blocks the picture does not fit -- fewer than half of the bytes matched, more lines than an eighth of
+// the bytes, fewer than two -- are left to k_lz_parse (fallback[b] = 1), which skips the others.  NAF_GPU_LZ_LINES=0: every block by k_lz_parse.
+__device__ __forceinline__ u64 zero_bytes64(u64 w) { const u64 L = 0x7F7F7F7F7F7F7F7Full; return ~(((w & L) + L) | w) & ~L; }   // 0x80 where the byte is zero
+__global__ __launch_bounds__(64) void k_lz_parse_lines(const u8 *src, u64 n, u32 nblk, LzBufs B, u32 buf_bytes, u8 *fallback)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 lz_lds[];
+    u8 *buf = lz_lds;
+    u32 *s_ml = (u32 *)(lz_lds + buf_bytes);                              // match length of sequence q: its head's own bytes + what joined it
+    u16 *ends = (u16 *)(lz_lds + buf_bytes + 4 * (size_t)B.seq_slot);
+    const u32 b = blockIdx.x, lane = threadIdx.x;
+    const u64 lo = zenc_block_lo(n, nblk, b);
+    const u32 bn = (u32)(zenc_block_lo(n, nblk, b + 1) - lo);
+    const u32 max_lines = bn / 8;
+    for (u32 i = lane * 16; i < bn; i += 64 * 16) {
+        if (i + 16 <= bn) { uint4 v; __builtin_memcpy(&v, src + lo + i, 16); *(uint4 *)(buf + i) = v; }
+        else for (u32 k = i; k < bn; k++) buf[k] = src[lo + k];
+    }
+    for (u32 i = bn + lane; i < bn + 64 && i < buf_bytes; i += 64) buf[i] = 0xFF;
+    __syncthreads();
+    // the terminators: a lane's share of the block, eight bytes at a time
+    const u32 per = (((bn + 63) / 64) + 7) & ~7u, c0 = lane * per < bn ? lane * per : bn, c1 = c0 + per < bn ? c0 + per : bn;
+    u32 cnt = 0;
+    for (u32 i = c0; i < c1; i += 8) { u64 z = zero_bytes64(*(const u64 *)(buf + i)); if (i + 8 > c1) z &= (1ull << (8 * (c1 - i))) - 1; cnt += (u32)__popcll(z); }
+    const u32 incl = wave_scan_inclusive<u32, OpAdd>(cnt), L = (u32)__shfl((int)incl, 63, 64);
+    if (L < 2 || L > max_lines) { if (lane == 0) fallback[b] = 1; return; }       // (uniform)
+    {
+        u32 idx = incl - cnt;
+        for (u32 i = c0; i < c1; i += 8) {
+            u64 z = zero_bytes64(*(const u64 *)(buf + i)); if (i + 8 > c1) z &= (1ull << (8 * (c1 - i))) - 1;
+            while (z) { ends[idx++] = (u16)(i + (((u32)__ffsll((long long)z) - 1) >> 3)); z &= z - 1; }
+        }
+    }
+    __syncthreads();
+    const u32 last_end = (u32)ends[L - 1] + 1, NL = L + (last_end < bn ? 1u : 0u);   // (the bytes behind the last terminator: a line without one)
+    u16 *sll = B.ll + (u64)b * B.seq_slot, *sml = B.ml + (u64)b * B.seq_slot, *sof = B.of + (u64)b * B.seq_slot;
+    u8 *lits = B.lits + (u64)b * B.slot;
+    u32 seq_base = 0, matched_base = 0, anchor = 0;
+    u32 c_open = 0xFFFFFFFFu, c_of = 0; bool c_tail = false;             // the line in front of the round's first: the sequence open at its end, its offset, whether its last match reached its end
+    for (u32 r = 0; r < NL; r += 64) {
+        const u32 i = r + lane;
+        u32 s = 0, e = 0, of = 0, m1 = 0, k2 = 0, m2 = 0, len = 0;
+        if (i < NL) {
+            s = i ? (u32)ends[i - 1] + 1 : 0u; e = i < L ? (u32)ends[i] + 1 : bn; len = e - s;
+            if (i >= 1) {
+                of = s - (i >= 2 ? (u32)ends[i - 2] + 1 : 0u);
+                // the common prefix, then the first run of equal bytes behind it (lines of up to 256 bytes: what lies behind stays literal)
+                const u32 lim = len < 256 ? len : 256u;
+                const u64 H = 0x8080808080808080ull;
+                u32 k = 0;
+                for (; k < lim; k += 8) { u64 x, y; __builtin_memcpy(&x, buf + s + k, 8); __builtin_memcpy(&y, buf + s + k - of, 8); const u64 d = x ^ y; if (d) { k += ((u32)__ffsll((long long)d) - 1) >> 3; break; } }
+                m1 = k < lim ? k : lim;
+                if (m1 < lim) {
+                    u32 q = m1 + 1; bool found = false;
+                    while (q < lim) {                                                  // the first equal byte behind the difference
+                        u64 x, y; __builtin_memcpy(&x, buf + s + q, 8); __builtin_memcpy(&y, buf + s + q - of, 8);
+                        u64 eq = zero_bytes64(x ^ y);
+                        if (q + 8 > lim) eq &= (1ull << (8 * (lim - q))) - 1;
+                        if (eq) { k2 = q + (((u32)__ffsll((long long)eq) - 1) >> 3); found = true; break; }
+                        q += 8;
+                    }
+                    if (found) {
+                        m2 = lim - k2;                                                 // ... and how far the run goes
+                        for (q = k2; q < lim; q += 8) {
+                            u64 x, y; __builtin_memcpy(&x, buf + s + q, 8); __builtin_memcpy(&y, buf + s + q - of, 8);
+                            u64 ne = ~zero_bytes64(x ^ y) & H;
+                            if (q + 8 > lim) ne &= (1ull << (8 * (lim - q))) - 1;
+                            if (ne) { m2 = q + (((u32)__ffsll((long long)ne) - 1) >> 3) - k2; break; }
+                        }
+                    }
+                }
+                if (m2 < LZ_MINMATCH) m2 = 0;
+            }
+        }
+        const bool full = len && m1 == len;                                            // the whole line is its prefix
+        const bool tail = (m2 && k2 + m2 == len) || (full && len >= LZ_MINMATCH);      // its last match reaches its end
+        // does the prefix continue the match the line in front ended on?
+        const u32 p_of = (u32)__shfl_up((int)of, 1, 64); const bool p_tail = __shfl_up((int)tail, 1, 64) != 0;
+        const bool join = i < NL && i >= 1 && m1 >= 1 && (lane ? (p_tail && p_of == of) : (c_tail && c_of == of));
+        const bool a_on = join || m1 >= LZ_MINMATCH, a_head = a_on && !join, b_on = m2 != 0;
+        const u32 la = a_on ? m1 : 0u;
+        const u32 ns_i = (a_head ? 1u : 0u) + (b_on ? 1u : 0u), mt_i = la + m2;
+        const u32 end_i = b_on ? s + k2 + m2 : (a_on ? s + la : 0u);
+        const u32 ns_in = wave_scan_inclusive<u32, OpAdd>(ns_i), mt_in = wave_scan_inclusive<u32, OpAdd>(mt_i);
+        const u32 an_in = (u32)wave_scan_inclusive<i32, OpMax>((i32)end_i);
+        const u32 an_ex = (u32)__shfl_up((int)an_in, 1, 64);
+        const u32 my_anchor = lane ? (an_ex > anchor ? an_ex : anchor) : anchor;
+        const u32 my_seq = seq_base + ns_in - ns_i, my_matched = matched_base + mt_in - mt_i;
+        // the sequence open at the end of each line: B's when B reaches the end; a full line's own head, or -- when it joined -- the one it
+        // joined (handed on from the nearest line in front that is not such a line)
+        const bool pass = tail && !(m2 && k2 + m2 == len) && join;
+        const u32 own_open = !tail ? 0xFFFFFFFFu : ((m2 && k2 + m2 == len) ? my_seq + (a_head ? 1u : 0u) : my_seq);
+        const i32 srcl = wave_scan_inclusive<i32, OpMax>(pass ? -1 : (i32)lane);
+        const u32 got = (u32)__shfl((int)own_open, srcl < 0 ? 0 : srcl, 64);
+        const u32 open_i = srcl < 0 ? c_open : got;
+        const u32 p_open = (u32)__shfl_up((int)open_i, 1, 64);
+        if (i < NL) {
+            u32 q = my_seq, a = my_anchor;
+            if (a_head) { sll[q] = (u16)(s - a); sof[q] = (u16)of; s_ml[q] = m1; q++; }
+            if (a_on) a = s + m1;
+            if (b_on) { sll[q] = (u16)(s + k2 - a); sof[q] = (u16)of; s_ml[q] = m2; }
+        }
+        if (join) atomicAdd(&s_ml[lane ? p_open : c_open], m1);                        // (behind the heads' stores: LDS operations of a wavefront keep their order)
+        if (i < NL) {
+            // literals: the line's bytes outside its matches, to their place among the block's literals
+            const u32 g0 = s + la, g1 = b_on ? s + k2 : e;
+            u32 dstp = g0 - (my_matched + la);
+            for (u32 k = g0; k < g1; k++) lits[dstp++] = buf[k];
+            if (b_on) for (u32 k = s + k2 + m2; k < e; k++) lits[dstp++] = buf[k];
+        }
+        seq_base += (u32)__shfl((int)ns_in, 63, 64); matched_base += (u32)__shfl((int)mt_in, 63, 64);
+        const u32 an_last = (u32)__shfl((int)an_in, 63, 64);
+        if (an_last > anchor) anchor = an_last;
+        c_open = (u32)__shfl((int)open_i, 63, 64); c_of = (u32)__shfl((int)of, 63, 64); c_tail = __shfl((int)tail, 63, 64) != 0;
+    }
+    if (matched_base * 2 < bn) { if (lane == 0) fallback[b] = 1; return; }
+    __syncthreads();
+    for (u32 k = lane; k < seq_base; k += 64) sml[k] = (u16)s_ml[k];
+    if (lane == 0) { B.nseq[b] = seq_base; B.nlit[b] = bn - matched_base; fallback[b] = 0; }
 }
 
 // Sequences_Section of every block (one lane per block; predefined FSE encoding tables staged in LDS)
@@ -1464,7 +1597,14 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
             // the table's size is LDS a wavefront holds for the whole block: what bounds the blocks in flight per CU -- and what is left
             // of a CU for the kernels of the other streams (2^11 and 2^10 entries measured: DESIGN.md section 8)
             const u32 hash_log = LZ_HASH_LOG;
-            LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << hash_log), d_src, (u64)n, nblk, B, lz_buf, hash_log);
+            // names against the name in front, a lane each (k_lz_parse_lines); what that leaves to the hash table's walk is marked in `fallback`
+            const char *ll_ = ctx_opt(c, "LZ_LINES");
+            u8 *fallback = nullptr;
+            if (!(ll_ && ll_[0] == '0') && bs <= 16384 && nblk >= 64) {
+                fallback = (u8 *)arena_alloc(c, nblk); if (!fallback) return NAF_GPU_ENOMEM;
+                LAUNCH(c, "zenc_lz_lines", k_lz_parse_lines, nblk, 64, lz_buf + 4 * (u32)B.seq_slot + 2 * (u32)(bs / 8 + 2), d_src, (u64)n, nblk, B, lz_buf, fallback);
+            }
+            LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << hash_log), d_src, (u64)n, nblk, B, lz_buf, hash_log, (const u8 *)fallback);
             LAUNCH(c, "zenc_lz_seqenc", k_lz_seqenc, cdiv(nblk, 64), 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
         }
         LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse, min_gain, maxbits, 0u, (const u8 *)nullptr, wt_defer);

@@ -43,3 +43,17 @@ for nm, ms, k in sorted(ctx.get_timing(), key=lambda x: -x[1])[:22]:
     print("   %-28s %8.3f ms x%d" % (nm, ms, k))
 print("   streams:", ["%.3f" % x for x in ctx.get_timing_streams()])
 ctx.set_timing(False)
+if os.environ.get("RANGE8"):                     # an eighth of it by byte range (what a rank of an 8-GPU job decodes), the fourth eighth
+    b = n * 3 // 8 // 4096 * 4096; e = b + n // 8
+    o8 = torch.empty(e - b + 64, dtype=torch.uint8, device="cuda")
+    for it in range(6):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r8 = ctx.unnaf_range(naf, b, e, mode, out=o8)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print("range call %d: %.3f ms" % (it, dt * 1e3), flush=True)
+    print("bit-exact:", bool(torch.equal(r8, want[b:e])))
+    ctx.set_timing(True); ctx.unnaf_range(naf, b, e, mode, out=o8)
+    for nm, ms, k in sorted(ctx.get_timing(), key=lambda x: -x[1])[:22]:
+        print("   %-28s %8.3f ms x%d" % (nm, ms, k))
+    print("   streams:", ["%.3f" % x for x in ctx.get_timing_streams()])
+    ctx.set_timing(False)
