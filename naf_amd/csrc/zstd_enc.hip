@@ -1106,19 +1106,31 @@ __device__ __forceinline__ void zenc_flat4_stream(u8 *out, const u8 *s, u32 n, c
 
 // LZ-coded blocks (mode[b] != 0) take their literals from L.lits with the plan / codes / tree of those literals (plan1 ...)
 // and append the Sequences_Section made by k_lz_seqenc; all other blocks are coded from src as literal-only blocks.
-struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u16 *codes1; const u8 *trees1; LzBufs B; u32 not_last; u32 wave_general; };   // wave_general: blocks of general Huffman codes are k_zenc_write_wave's   // not_last: the frame continues behind these blocks (a shard's part of a frame)
+struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u16 *codes1; const u8 *trees1; LzBufs B; u32 not_last; u32 wave_general; u32 frame_split; };   // frame_split: the blocks coded with the frame's code are k_zenc_write<true>'s   // wave_general: blocks of general Huffman codes are k_zenc_write_wave's   // not_last: the frame continues behind these blocks (a shard's part of a frame)
 struct ZencJob { const u8 *src; size_t n; u32 nblk, frame_wlog; ZEncPlan *plan; u16 *codes; u8 *trees; u64 *offs; u64 hdr; int with_magic, empty; ZWriteLz L; bool direct; u32 block_bytes; ZencLoc dloc; };   // dloc.loc != nullptr: the direct blocks' codes are tile-local (k_zenc_write_direct_loc)
+// FRAME: the blocks coded with the FRAME's code only (ZENC_FRAME_TREE: nearly every block of a FASTQ's quality and sequence frames) -- one
+// table for the workgroup instead of sixteen, 5.6 KiB of LDS instead of 13: twice the wavefronts per CU for a kernel whose lanes each walk
+// a stream of 8 K symbols.  The plain instantiation then leaves those blocks alone (L.frame_split).
+template <bool FRAME>
 __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nblk, const ZEncPlan *plan, const u16 *codes_g, const u8 *trees,
                                                     const u64 *offs, u8 *dst, u64 frame_hdr, ZWriteLz L)
 {
     // 16-bit entries: 8 KiB of tables per workgroup instead of 16 -- LDS is what bounds the waves resident per CU here
-    __shared__ __attribute__((aligned(16))) u16 codes[ZENC_BLOCKS_PER_WG][256];
+    __shared__ __attribute__((aligned(16))) u16 codes[FRAME ? 1 : ZENC_BLOCKS_PER_WG][256];
     __shared__ __attribute__((aligned(16))) u8 orows[64 * ZENC_OROW];
     int lane = threadIdx.x;
     u32 b0 = blockIdx.x * ZENC_BLOCKS_PER_WG;
+    auto framed = [&](u32 bb) { return plan[bb].kind == ZK_HUF && plan[bb].frame != 0 && !plan[bb].pad; };
+    if (FRAME) {
+        const u32 bb = b0 + (u32)lane;
+        const u64 fr = __ballot(lane < ZENC_BLOCKS_PER_WG && bb < nblk && framed(bb));
+        if (!fr) return;
+        const uint4 *g = (const uint4 *)(codes_g + (u64)(b0 + (u32)__ffsll((long long)fr) - 1) * 256);   // (every such block holds the frame's table)
+        if (lane < 32) ((uint4 *)codes[0])[lane] = g[lane];
+    } else {
     {   // nothing but direct blocks (k_zenc_write_direct's): one look at the sixteen plans instead of three walks over them
         const u32 bb = b0 + (u32)lane;
-        const bool other = lane < ZENC_BLOCKS_PER_WG && bb < nblk && !(plan[bb].kind == ZK_HUF && (plan[bb].pad == 2 || L.wave_general) && !(L.mode && L.mode[bb]));
+        const bool other = lane < ZENC_BLOCKS_PER_WG && bb < nblk && !(plan[bb].kind == ZK_HUF && (plan[bb].pad == 2 || L.wave_general) && !(L.mode && L.mode[bb])) && !(L.frame_split && framed(bb));
         if (__ballot(other) == 0) return;
     }
     for (u32 jj = 0; jj < ZENC_BLOCKS_PER_WG; jj++) {               // code tables made by k_zenc_plan: 512 B per block, coalesced
@@ -1126,12 +1138,14 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
         if (bb >= nblk) break;
         const bool lzb = L.mode && L.mode[bb];
         if ((lzb ? L.plan1[bb].kind : plan[bb].kind) != ZK_HUF || (!lzb && plan[bb].pad == 2)) continue;
+        if (L.frame_split && framed(bb)) continue;
         const uint4 *g = (const uint4 *)((lzb ? L.codes1 : codes_g) + (u64)bb * 256);
-        if (lane < 32) ((uint4 *)codes[jj])[lane] = g[lane];
+        if (lane < 32) ((uint4 *)codes[FRAME ? 0 : jj])[lane] = g[lane];
+    }
     }
     __syncthreads();
     // blocks of sixteen 4-bit codes: the whole wave, a stream after the other
-    for (u32 jj = 0; jj < ZENC_BLOCKS_PER_WG; jj++) {
+    if (!FRAME) for (u32 jj = 0; jj < ZENC_BLOCKS_PER_WG; jj++) {
         const u32 bb = b0 + jj;
         if (bb >= nblk) break;
         if (L.mode && L.mode[bb]) continue;
@@ -1143,11 +1157,12 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
         if (lane == 0) { zenc_write_block_prefix(out, p, trees + (u64)bb * ZENC_TREE_SLOT, bb + 1 == nblk && !L.not_last, src[lo]); out[p.csize - 1] = 0; }
         const u32 per = (p.n + 3) / 4;
         u32 o = 3 + p.lhdr + p.tree_bytes + 6;
-        for (u32 q = 0; q < 4; q++) { zenc_flat4_stream(out + o, src + lo + (u64)q * per, q < 3 ? per : p.n - 3 * per, codes[jj], (u32)lane); o += p.ssz[q]; }
+        for (u32 q = 0; q < 4; q++) { zenc_flat4_stream(out + o, src + lo + (u64)q * per, q < 3 ? per : p.n - 3 * per, codes[FRAME ? 0 : jj], (u32)lane); o += p.ssz[q]; }
     }
     u32 j = lane >> 2, k = lane & 3, b = b0 + j;
-    if (b < nblk) {
+    if (b < nblk && (FRAME ? framed(b) : !(L.frame_split && framed(b)))) {
         const bool lzb = L.mode && L.mode[b];
+        const u16 *ct = codes[FRAME ? 0 : j];
         u8 *out = dst + frame_hdr + offs[b];
         if (!lzb && plan[b].kind == ZK_HUF && (plan[b].pad || L.wave_general)) { }          // written above, or k_zenc_write_wave's
         else if (!lzb) {
@@ -1158,8 +1173,8 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
                 u32 per = (p.n + 3) / 4;
                 u32 cnt = k < 3 ? per : p.n - 3 * per;
                 const u32 o = 3 + p.lhdr + p.tree_bytes + 6 + (k > 0 ? p.ssz[0] : 0u) + (k > 1 ? p.ssz[1] : 0u) + (k > 2 ? p.ssz[2] : 0u);
-                if (p.log <= 7) huf_encode_stream_staged<8>(out + o, src + lo + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
-                else huf_encode_stream_staged<4>(out + o, src + lo + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
+                if (p.log <= 7) huf_encode_stream_staged<8>(out + o, src + lo + (u64)k * per, cnt, ct, orows + lane * ZENC_OROW);
+                else huf_encode_stream_staged<4>(out + o, src + lo + (u64)k * per, cnt, ct, orows + lane * ZENC_OROW);
                 if (k == 3) out[p.csize - 1] = 0;                   // Number_of_Sequences = 0
             }
         } else {
@@ -1172,8 +1187,8 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
                 u32 per = (p.n + 3) / 4;
                 u32 cnt = k < 3 ? per : p.n - 3 * per;
                 const u32 o = 3 + p.lhdr + p.tree_bytes + 6 + (k > 0 ? p.ssz[0] : 0u) + (k > 1 ? p.ssz[1] : 0u) + (k > 2 ? p.ssz[2] : 0u);
-                if (p.log <= 7) huf_encode_stream_staged<8>(out + o, lits + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
-                else huf_encode_stream_staged<4>(out + o, lits + (u64)k * per, cnt, codes[j], orows + lane * ZENC_OROW);
+                if (p.log <= 7) huf_encode_stream_staged<8>(out + o, lits + (u64)k * per, cnt, ct, orows + lane * ZENC_OROW);
+                else huf_encode_stream_staged<4>(out + o, lits + (u64)k * per, cnt, ct, orows + lane * ZENC_OROW);
             } else if (k == 0) {
                 u32 h = zenc_lit_header_raw(out + 3, p.kind == ZK_RLE ? 1u : 0u, p.n);
                 if (p.kind == ZK_RLE) out[3 + h] = lits[0];
@@ -1184,7 +1199,7 @@ __global__ __launch_bounds__(64) void k_zenc_write(const u8 *src, u64 n, u32 nbl
         }
     }
     // raw blocks: whole-wave copy
-    for (u32 jj = 0; jj < ZENC_BLOCKS_PER_WG; jj++) {
+    if (!FRAME) for (u32 jj = 0; jj < ZENC_BLOCKS_PER_WG; jj++) {
         u32 bb = b0 + jj;
         if (bb >= nblk) break;
         if ((L.mode && L.mode[bb]) || plan[bb].kind != ZK_RAW) continue;
@@ -1564,6 +1579,7 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     }
     ZWriteLz &L = J->L;
     L.not_last = part && !part_last;
+    { const char *fs = ctx_opt(c, "FRAME_WRITE"); L.frame_split = (frame_tree && !(fs && fs[0] == '0')) ? 1u : 0u; }   // (NAF_GPU_FRAME_WRITE=0: every block by the sixteen-table writer)
     if (use_lz && n >= 64) {
         if (!c->d_seqctab) {
             SeqCTabs T; zenc_build_predefined(T);
@@ -1652,7 +1668,9 @@ static int zenc_finish(naf_gpu_ctx *c, ZencJob *J, u8 *d_dst, size_t cap, size_t
         // few blocks of general codes (a frame of direct blocks, a short frame): a wavefront per stream for those
         J->L.wave_general = (!J->L.mode && J->block_bytes <= 32768u && (J->direct || nblk <= 2048u)) ? 1u : 0u;
     }
-    LAUNCH(c, "zenc_write", k_zenc_write, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, J->src, (u64)J->n, nblk, (const ZEncPlan *)J->plan, (const u16 *)J->codes, (const u8 *)J->trees,
+    if (J->L.frame_split) LAUNCH(c, "zenc_write", k_zenc_write<true>, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, J->src, (u64)J->n, nblk, (const ZEncPlan *)J->plan, (const u16 *)J->codes, (const u8 *)J->trees,
+           (const u64 *)J->offs, d_dst, hdr, J->L);
+    LAUNCH(c, "zenc_write", k_zenc_write<false>, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, J->src, (u64)J->n, nblk, (const ZEncPlan *)J->plan, (const u16 *)J->codes, (const u8 *)J->trees,
            (const u64 *)J->offs, d_dst, hdr, J->L);
     if (J->L.wave_general) LAUNCH(c, "zenc_write_wave", k_zenc_write_wave, cdiv(nblk, ZWW_BLOCKS), 256, 512u + 4u * ZWW_OBUF, J->src, (u64)J->n, nblk, (const ZEncPlan *)J->plan, (const u16 *)J->codes, (const u8 *)J->trees,
            (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
