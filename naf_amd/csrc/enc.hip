@@ -2134,7 +2134,7 @@ __global__ __launch_bounds__(64) void k_fq_first(EncP P, i64 *tile_eol, i64 *til
     const u8 *src = P.text + tb + 64 * lane;
     u64 wv[8];
 #pragma unroll
-    for (u32 k = 0; k < 8; k++) wv[k] = ld64(src + 8 * k);
+    for (u32 k = 0; k < 4; k++) { uint4 q; __builtin_memcpy(&q, src + 16 * k, 16); wv[2 * k] = (u64)q.x | ((u64)q.y << 32); wv[2 * k + 1] = (u64)q.z | ((u64)q.w << 32); }
     u64 nl = 0, oth = 0, othx = 0, eol = 0, sp = 0; bool high = false;
 #pragma unroll
     for (u32 k = 0; k < 4; k++) {
@@ -2377,7 +2377,7 @@ __global__ __launch_bounds__(64) void k_fq_scatter_wave(EncP P, const i64 *tile_
     const u8 *src = P.text + tb + 64 * lane;
     u64 wv[8];
 #pragma unroll
-    for (u32 k = 0; k < 8; k++) wv[k] = ld64(src + 8 * k);
+    for (u32 k = 0; k < 4; k++) { uint4 q; __builtin_memcpy(&q, src + 16 * k, 16); wv[2 * k] = (u64)q.x | ((u64)q.y << 32); wv[2 * k + 1] = (u64)q.z | ((u64)q.w << 32); }
     const u64 bases[4] = { O.t_seq[tile], O.t_ids[tile], O.t_cmt[tile], O.t_qual[tile] };
     const i64 le = tile_eol[tile - 1], lsp = tile_sp[tile - 1];
     const u64 ls_tile = O.t_ls[tile];
