@@ -13,6 +13,7 @@
 
 #define ZENC_TREE_SLOT 192
 #include "wgscan.h"
+#include "enc_swar.h"
 struct OpMaxU64 { template <typename T> __device__ static T id() { return (T)0; } template <typename T> __device__ static T f(T a, T b) { return a > b ? a : b; } };
 #define ZENC_HCOPIES 4
 // Huffman tree descriptions of a sample of the blocks, looked up by weight table (one per zstd_encode call, zeroed by the host).
@@ -495,6 +496,108 @@ __global__ __launch_bounds__(256) void k_zenc_frame_ratio(u32 *fhist, const u16 
     const u64 e = wg_reduce1<u64, OpAdd>((u64)(ent + 0.5f), red);
     if (threadIdx.x == 0) { u64 r = e ? both * 1024 / e : 1024; fhist[257] = (u32)(r < 1024 ? 1024 : r > 1229 ? 1229 : r); }
 }
+// ---- blocks settled under the frame's code WITHOUT a histogram (k_zenc_frame_quick) ---------------------------------------------------
+// What the planner spends on a block is an LDS atomic per byte, half of them conflicts (profiles/r04_fastq_huf_counters.txt) -- 0.6 GB/ms on
+// a device that reads 4 GB/ms -- and a frame whose blocks all look like its sample (a FASTQ's qualities, its packed reads with their Ns)
+// learns nothing from 280 K histograms that one did not tell it.  What the block's plan needs from its bytes is the four streams' bit
+// counts under the frame's code: sums of code lengths, a table look-up per byte.  The table is a row of 64 copies per symbol (lane l reads
+// byte 64 s + l: lanes of a wavefront never meet in a word unless they read the same row), a wavefront per quarter of the block.
+// Whether the block IS like the sample is judged by three moments of its bytes instead of its entropy: the sums of the code length, of its
+// square and of a nibble hash of the byte, each within six standard deviations (of a block of independent bytes drawn from the sample's
+// histogram) + 0.5 % of what the sample predicts.  A block that passes is planned as k_zenc_plan plans a block its 3 % rule accepts
+// (same record, same sizes); one that fails, or holds a byte the code has no length for, is left to k_zenc_plan and its histogram.
+// NAF_GPU_FRAME_QUICK=0: every block by its histogram.
+#define ZQ_MISSING 0x80u
+__device__ __forceinline__ u32 zq_hash4(u32 x) { return (x ^ (x >> 4)) & 0x0F0F0F0Fu; }     // per byte: low nibble ^ high nibble
+__global__ __launch_bounds__(256) void k_zenc_frame_stats(const u32 *fhist, const u16 *fcodes, float *fstat)
+{
+    __shared__ u64 red[4];
+    const u32 sym = threadIdx.x, h = fhist[sym], l = (u32)fcodes[sym] >> 12, x[3] = { l, l * l, (sym ^ (sym >> 4)) & 15u };
+    const u64 N = wg_reduce1<u64, OpAdd>((u64)h, red);
+    __syncthreads();
+    for (u32 k = 0; k < 3; k++) {
+        const u64 a = wg_reduce1<u64, OpAdd>((u64)h * x[k], red);
+        __syncthreads();
+        const u64 b2 = wg_reduce1<u64, OpAdd>((u64)h * x[k] * x[k], red);
+        __syncthreads();
+        if (sym == 0) {
+            const double mu = N ? (double)a / (double)N : 0.0, var = N ? (double)b2 / (double)N - mu * mu : 0.0;
+            fstat[2 * k] = (float)mu; fstat[2 * k + 1] = var > 0.0 ? (float)sqrt(var) : 0.f;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_zenc_frame_quick(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u64 *csize, u8 *done,
+                                                           const ZEncPlan *fplan, const u16 *fcodes, const float *fstat, u32 min_gain)
+{
+    __shared__ __attribute__((aligned(16))) u8 tab[256 * 64];
+    __shared__ u32 s_q[4][4], s_accept;
+    const u32 b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    if (done[b] || fplan->kind != ZK_HUF) return;                 // (uniform)
+    const u64 lo = zenc_block_lo(n, nblk, b), hi = zenc_block_lo(n, nblk, b + 1);
+    const u32 bn = (u32)(hi - lo);
+    if (bn < 64) return;
+    const u16 fc = fcodes[tid];
+    {
+        const u32 l = (u32)fc >> 12, v = (l ? l : ZQ_MISSING) * 0x01010101u;
+        uint4 r; r.x = r.y = r.z = r.w = v;
+        uint4 *row = (uint4 *)(tab + 64 * tid);
+        row[0] = r; row[1] = r; row[2] = r; row[3] = r;
+    }
+    __syncthreads();
+    const u32 per = (bn + 3) / 4;                                  // k_zenc_plan's quarters: [q per, (q + 1) per), the last one to the block's end
+    const u32 qlo = q * per < bn ? q * per : bn, qhi = q == 3 ? bn : (qlo + per < bn ? qlo + per : bn);
+    const u8 *s = src + lo, *my = tab + lane;
+    u32 s1 = 0, s2 = 0, orr = 0, sh = 0;
+    for (u32 i0 = qlo + lane * 8; i0 < qhi; i0 += 8 * 512) {
+        u64 wv[8];
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) { const u32 i = i0 + j * 512; wv[j] = i + 8 <= qhi ? ld64(s + i) : 0; }
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) {
+            const u32 i = i0 + j * 512;
+            if (i >= qhi) break;
+            if (i + 8 <= qhi) {
+                const u32 x0 = (u32)wv[j], x1 = (u32)(wv[j] >> 32);
+#pragma unroll
+                for (u32 k = 0; k < 4; k++) {
+                    const u32 t0 = my[((x0 >> (8 * k)) & 0xFF) << 6], t1 = my[((x1 >> (8 * k)) & 0xFF) << 6];
+                    s1 += t0 + t1; s2 += t0 * t0; s2 += t1 * t1; orr |= t0 | t1;
+                }
+                sh = swar_dot4(zq_hash4(x0), 0x01010101u, sh); sh = swar_dot4(zq_hash4(x1), 0x01010101u, sh);
+            } else for (u32 k = 0; i + k < qhi; k++) {
+                const u32 c = s[i + k], t = my[c << 6];
+                s1 += t; s2 += t * t; orr |= t; sh += (c ^ (c >> 4)) & 15u;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d; d >>= 1) { s1 += (u32)__shfl_xor((int)s1, d, 64); s2 += (u32)__shfl_xor((int)s2, d, 64); sh += (u32)__shfl_xor((int)sh, d, 64); orr |= (u32)__shfl_xor((int)orr, d, 64); }
+    if (lane == 0) { s_q[q][0] = s1; s_q[q][1] = s2; s_q[q][2] = sh; s_q[q][3] = orr; }
+    __syncthreads();
+    ZEncPlan p;
+    if (tid == 0) {
+        u32 accept = 0;
+        const u32 S[3] = { s_q[0][0] + s_q[1][0] + s_q[2][0] + s_q[3][0], s_q[0][1] + s_q[1][1] + s_q[2][1] + s_q[3][1], s_q[0][2] + s_q[1][2] + s_q[2][2] + s_q[3][2] };
+        bool like = !((s_q[0][3] | s_q[1][3] | s_q[2][3] | s_q[3][3]) & ZQ_MISSING);
+        const float fb = (float)bn, rt = sqrtf(fb);
+        for (u32 k = 0; k < 3 && like; k++) {
+            const float want = fb * fstat[2 * k], d = fabsf((float)S[k] - want);
+            if (d > 6.f * rt * fstat[2 * k + 1] + 0.005f * want) like = false;
+        }
+        if (like) {
+            p.n = bn; p.kind = ZK_RAW; p.csize = 3 + bn; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0; p.frame = 0; p.pad2 = 0;
+            for (u32 k = 0; k < 4; k++) p.ssz[k] = (s_q[k][0] + 1 + 7) / 8;
+            zenc_plan_finish(p, bn, fplan->log, 0, min_gain);
+            if (p.kind == ZK_HUF && p.csize + fplan->tree_bytes <= 3 + bn) { p.frame = 1; accept = 1; }
+            else if (p.kind != ZK_HUF) accept = 2;
+        }
+        if (accept) { plan[b] = p; if (csize) csize[b] = p.csize; done[b] = 1; }
+        s_accept = accept;
+    }
+    __syncthreads();
+    if (s_accept == 1) codes[(u64)b * 256 + tid] = fc;
+}
+
 // Which blocks of the frame's code carry the tree.  v[b] = 2 b + 1 for a Huffman block with a tree of its own, 2 b for one of the frame's
 // code, -1 for the others, running maximum taken: a block of the frame's code is treeless when the Huffman block in front of it is one as well.
 __global__ void k_zenc_frame_class(const ZEncPlan *plan, u32 nblk, i32 *v)
@@ -650,7 +753,7 @@ __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk,
 // are wholly one match by a scan.  Blocks the picture does not fit -- fewer than half of the bytes matched, more lines than an eighth of
 // the bytes, fewer than two -- are left to k_lz_parse (fallback[b] = 1), which skips the others.  NAF_GPU_LZ_LINES=0: every block by k_lz_parse.
 __device__ __forceinline__ u64 zero_bytes64(u64 w) { const u64 L = 0x7F7F7F7F7F7F7F7Full; return ~(((w & L) + L) | w) & ~L; }   // 0x80 where the byte is zero
-__global__ __launch_bounds__(64) void k_lz_parse_lines(const u8 *src, u64 n, u32 nblk, LzBufs B, u32 buf_bytes, u8 *fallback)
+__global__ __launch_bounds__(64) void k_lz_parse_lines(const u8 *src, u64 n, u32 nblk, LzBufs B, u32 buf_bytes, u8 *fallback, ZEncPlan *plan, u64 *csize, u8 *done)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lz_lds[];
     u8 *buf = lz_lds;
@@ -764,7 +867,13 @@ __global__ __launch_bounds__(64) void k_lz_parse_lines(const u8 *src, u64 n, u32
     if (matched_base * 2 < bn) { if (lane == 0) fallback[b] = 1; return; }
     __syncthreads();
     for (u32 k = lane; k < seq_base; k += 64) sml[k] = (u16)s_ml[k];
-    if (lane == 0) { B.nseq[b] = seq_base; B.nlit[b] = bn - matched_base; fallback[b] = 0; }
+    if (lane == 0) {
+        B.nseq[b] = seq_base; B.nlit[b] = bn - matched_base; fallback[b] = 0;
+        // the block without its matches: Raw, as far as k_lz_choose is told (k_zenc_plan leaves it alone)
+        ZEncPlan p; p.n = bn; p.kind = ZK_RAW; p.csize = 3 + bn; p.log = 0; p.tree_bytes = 0; p.lhdr = 0; p.pad = 0; p.frame = 0; p.pad2 = 0;
+        p.ssz[0] = p.ssz[1] = p.ssz[2] = p.ssz[3] = 0;
+        plan[b] = p; if (csize) csize[b] = p.csize; done[b] = 1;
+    }
 }
 
 // Sequences_Section of every block (one lane per block; predefined FSE encoding tables staged in LDS)
@@ -1565,6 +1674,34 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
         LAUNCH(c, "zenc_plan_frame", k_zenc_plan, 1, 256, 0, (const u8 *)fblock, (u64)0, 1u, fplan, fcodes, ftree, (u64 *)nullptr, (const u32 *)(fhist + 256), (u64)0, (ZTreeCache *)nullptr, 0u, try_fse, 0u, maxbits, 0u, (const u8 *)nullptr, fwt, (u32 *)nullptr, (const ZEncPlan *)nullptr, (const u16 *)nullptr);
         LAUNCH(c, "zenc_tree", k_zenc_tree, 1, 64, 64 * sizeof(ZTreeLane), 1u, fplan, ftree, (u64 *)nullptr, (const u8 *)fwt, 0u);
         LAUNCH(c, "zenc_frame_ratio", k_zenc_frame_ratio, 1, 256, 0, fhist, (const u16 *)fcodes);
+        // most blocks of such a frame without a histogram (k_zenc_frame_quick); the planner below takes what that leaves
+        const char *fq = ctx_opt(c, "FRAME_QUICK");
+        if (!(fq && fq[0] == '0')) {
+            float *fstat = arena_new<float>(c, 8); if (!fstat) return NAF_GPU_ENOMEM;
+            if (!done) { done = (u8 *)arena_alloc(c, nblk); if (!done) return NAF_GPU_ENOMEM; HIP_TRY(c, hipMemsetAsync(done, 0, nblk, c->stream)); }
+            LAUNCH(c, "zenc_frame_stats", k_zenc_frame_stats, 1, 256, 0, (const u32 *)fhist, (const u16 *)fcodes, fstat);
+            LAUNCH(c, "zenc_frame_quick", k_zenc_frame_quick, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, offs, done, (const ZEncPlan *)fplan, (const u16 *)fcodes, (const float *)fstat, min_gain);
+        }
+    }
+    // the match finder's buffers; and the blocks of zero-terminated names a lane per line settles (k_lz_parse_lines) in FRONT of the planner:
+    // a block that kernel takes is coded with its matches or, should that come out larger, Raw -- the planner's histogram of its bytes, code
+    // and tree (the literal-only coding k_lz_choose would weigh against the matches) are not made at all
+    LzBufs B; memset(&B, 0, sizeof B);
+    u8 *lz_fallback = nullptr;
+    const u32 lz_buf = (u32)((bs + 1 + 320 + 15) & ~15ull);               // a block of the even split holds at most bs bytes
+    if (use_lz && n >= 64) {
+        B.slot = bs; B.seq_slot = bs / 4 + 2; B.of = nullptr; B.ofv = nullptr;
+        B.lits = (u8 *)arena_alloc(c, (size_t)nblk * B.slot + 64); B.seqbuf = (u8 *)arena_alloc(c, (size_t)nblk * B.slot + 64);
+        B.ll = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8); B.ml = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8);   // + 8: read in groups of eight
+        if (lzx) B.ofv = arena_new<u32>(c, (size_t)nblk * B.seq_slot + 8); else B.of = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8);
+        B.nseq = arena_new<u32>(c, nblk); B.nlit = arena_new<u32>(c, nblk); B.seq_bytes = arena_new<u32>(c, nblk);
+        if (!B.lits || !B.seqbuf || !B.ll || !B.ml || (!B.of && !B.ofv) || !B.nseq || !B.nlit || !B.seq_bytes) return NAF_GPU_ENOMEM;
+        const char *ll_ = ctx_opt(c, "LZ_LINES");
+        if (!lzx && !(ll_ && ll_[0] == '0') && bs <= 16384 && nblk >= 64) {
+            lz_fallback = (u8 *)arena_alloc(c, nblk); if (!lz_fallback) return NAF_GPU_ENOMEM;
+            if (!done) { done = (u8 *)arena_alloc(c, nblk); if (!done) return NAF_GPU_ENOMEM; HIP_TRY(c, hipMemsetAsync(done, 0, nblk, c->stream)); }
+            LAUNCH(c, "zenc_lz_lines", k_lz_parse_lines, nblk, 64, lz_buf + 4 * (u32)B.seq_slot + 2 * (u32)(bs / 8 + 2), d_src, (u64)n, nblk, B, lz_buf, lz_fallback, plan, offs, done);
+        }
     }
     // (frames of a few blocks keep the tree with the planner: nothing to gain from a second launch)
     const char *td = ctx_opt(c, "TREE_DEFER");
@@ -1586,16 +1723,10 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
             HIP_TRY(c, hipMalloc(&c->d_seqctab, sizeof T));
             HIP_TRY(c, hipMemcpy(c->d_seqctab, &T, sizeof T, hipMemcpyHostToDevice));
         }
-        LzBufs B; B.slot = bs; B.seq_slot = bs / 4 + 2; B.of = nullptr; B.ofv = nullptr;
-        B.lits = (u8 *)arena_alloc(c, (size_t)nblk * B.slot + 64); B.seqbuf = (u8 *)arena_alloc(c, (size_t)nblk * B.slot + 64);
-        B.ll = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8); B.ml = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8);   // + 8: read in groups of eight
-        if (lzx) B.ofv = arena_new<u32>(c, (size_t)nblk * B.seq_slot + 8); else B.of = arena_new<u16>(c, (size_t)nblk * B.seq_slot + 8);
-        B.nseq = arena_new<u32>(c, nblk); B.nlit = arena_new<u32>(c, nblk); B.seq_bytes = arena_new<u32>(c, nblk);
         ZEncPlan *plan1 = arena_new<ZEncPlan>(c, nblk);
         u16 *codes1 = arena_new<u16>(c, (size_t)nblk * 256); u8 *trees1 = (u8 *)arena_alloc(c, (size_t)nblk * ZENC_TREE_SLOT);
         u8 *mode = (u8 *)arena_alloc(c, nblk);
-        if (!B.lits || !B.seqbuf || !B.ll || !B.ml || (!B.of && !B.ofv) || !B.nseq || !B.nlit || !B.seq_bytes || !plan1 || !codes1 || !trees1 || !mode) return NAF_GPU_ENOMEM;
-        const u32 lz_buf = (u32)((bs + 1 + 320 + 15) & ~15ull);           // a block of the even split holds at most bs bytes
+        if (!plan1 || !codes1 || !trees1 || !mode) return NAF_GPU_ENOMEM;
         if (lzx) {
             // table of first occurrences: one in eight positions is an anchor, epochs of half the window, load factor <= 1/2
             LdmTab T; T.wlog = (u32)window_log; T.elog = T.wlog - 1; T.pad = 0;
@@ -1613,14 +1744,8 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
             // the table's size is LDS a wavefront holds for the whole block: what bounds the blocks in flight per CU -- and what is left
             // of a CU for the kernels of the other streams (2^11 and 2^10 entries measured: DESIGN.md section 8)
             const u32 hash_log = LZ_HASH_LOG;
-            // names against the name in front, a lane each (k_lz_parse_lines); what that leaves to the hash table's walk is marked in `fallback`
-            const char *ll_ = ctx_opt(c, "LZ_LINES");
-            u8 *fallback = nullptr;
-            if (!(ll_ && ll_[0] == '0') && bs <= 16384 && nblk >= 64) {
-                fallback = (u8 *)arena_alloc(c, nblk); if (!fallback) return NAF_GPU_ENOMEM;
-                LAUNCH(c, "zenc_lz_lines", k_lz_parse_lines, nblk, 64, lz_buf + 4 * (u32)B.seq_slot + 2 * (u32)(bs / 8 + 2), d_src, (u64)n, nblk, B, lz_buf, fallback);
-            }
-            LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << hash_log), d_src, (u64)n, nblk, B, lz_buf, hash_log, (const u8 *)fallback);
+            // (names against the name in front, a lane each: k_lz_parse_lines above; what that left to the hash table's walk is marked in `lz_fallback`)
+            LAUNCH(c, "zenc_lz_parse", k_lz_parse, nblk, 64, lz_buf + (2u << hash_log), d_src, (u64)n, nblk, B, lz_buf, hash_log, (const u8 *)lz_fallback);
             LAUNCH(c, "zenc_lz_seqenc", k_lz_seqenc, cdiv(nblk, 64), 64, 0, nblk, B, (const SeqCTabs *)c->d_seqctab);
         }
         LAUNCH(c, "zenc_plan", k_zenc_plan, nblk, 256, 0, (const u8 *)B.lits, (u64)n, nblk, plan1, codes1, trees1, (u64 *)nullptr, (const u32 *)B.nlit, B.slot, (ZTreeCache *)nullptr, 0u, try_fse, min_gain, maxbits, 0u, (const u8 *)nullptr, wt_defer);

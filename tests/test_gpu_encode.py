@@ -485,6 +485,37 @@ def test_frame_tree_of_the_quality_stream(gpu, oracle, monkeypatch):
         assert oracle.ref_unnaf(m1) == host(back1)
 
 
+def test_blocks_of_a_frame_settled_without_a_histogram(gpu, oracle, monkeypatch):
+    """k_zenc_frame_quick (zstd_enc.hip): a block of a frame with a tree of its own is planned from the sums of the frame's code lengths
+    over its bytes when three moments of those bytes say it is like the sample, and by k_zenc_plan's histogram when they do not.  A
+    FASTQ whose qualities change half way through -- uniform Phred 0..40, then nine in ten 'F' -- has blocks of both kinds and, where
+    the two halves meet, blocks that are neither: against NAF_GPU_FRAME_QUICK=0 (every block by its histogram) the archive is within
+    half a per cent, both decode to the same text here, and the reference decodes the quick one."""
+    import torch
+    from naf_amd import synth, capi
+    fq = synth.fastq_reads_device(320_000_000, seed=23, device="cuda")
+    line = torch.cumsum((fq == 10).to(torch.int32), 0)
+    is_q = ((line & 3) == 3) & (fq != 10)
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    pick = is_q & (torch.arange(fq.numel(), device="cuda") > fq.numel() // 2) & (torch.rand(fq.numel(), device="cuda", generator=g) < 0.9)
+    t = torch.where(pick, torch.tensor(ord("F"), dtype=torch.uint8, device="cuda"), fq)
+    del line, is_q, pick
+    monkeypatch.setenv("NAF_GPU_FRAME_QUICK", "1")
+    a1, _ = gpu.ennaf(t)
+    a1 = a1.clone()
+    gpu.set_timing(True); gpu.ennaf(t); names = {nm for nm, ms, k in gpu.get_timing()}; gpu.set_timing(False)
+    assert any(nm.endswith("zenc_frame_quick") for nm in names)
+    monkeypatch.setenv("NAF_GPU_FRAME_QUICK", "0")
+    a0, _ = gpu.ennaf(t)
+    monkeypatch.delenv("NAF_GPU_FRAME_QUICK")
+    assert abs(int(a1.numel()) - int(a0.numel())) < 0.005 * int(a0.numel()), (int(a1.numel()), int(a0.numel()))
+    back1 = gpu.unnaf(a1, capi.OUT_FASTQ); back0 = gpu.unnaf(a0, capi.OUT_FASTQ)
+    assert torch.equal(back1, back0) and back1.numel() == t.numel()
+    assert bool(((back1 == t) | ((back1 ^ 32) == t)).all())
+    if oracle.have_ref():
+        assert oracle.ref_unnaf(host(a1)) == host(back1)
+
+
 def test_no_block_of_a_nearly_incompressible_stream_is_larger_than_raw(gpu, oracle):
     """A block coded with the FRAME's tree may have to carry the tree after all (k_zenc_frame_fix), "whatever it costs": the planner
     takes the frame's code for a block only when the block stays below its Raw size even then.  Streams of 256 symbols a few hundredths
