@@ -3401,10 +3401,11 @@ static size_t naf_header_bytes(const naf_gpu_ennaf_opts *o, bool store_mask, boo
 struct PlaceTail { const ZencPlace *outer; size_t tail_len; u8 *at; };
 static u8 *place_before_tail(void *ud, size_t len) { PlaceTail *t = (PlaceTail *)ud; return t->at = t->outer->fn(t->outer->ud, len + t->tail_len); }
 // the two halves of a placed stream (zstd_encode_begin / _finish): what the caller queues between them runs beside the planning
-struct StreamJob { ZencJob *main; const u8 *d_stream; u64 len; int level, flags; u32 tail; };
+struct StreamJob { ZencJob *main; const u8 *d_stream; u64 len; int level, flags; u32 tail; bool sized; u8 *tail_tmp; size_t tail_len; };   // sized: encode_stream_size ran (the tail part is coded, the main part's size is known)
 static int encode_stream_begin(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level, int flags, int lz, int block_log, int window_log, u32 tail, StreamJob *J, const u8 *direct = nullptr, u32 nd = 0, const ZencLoc *dloc = nullptr)
 {
     J->main = nullptr; J->d_stream = d_stream; J->len = len; J->level = level; J->flags = flags; J->tail = (tail && len > tail) ? tail : 0;
+    J->sized = false; J->tail_tmp = nullptr; J->tail_len = 0;
     int f1 = flags;
     if (J->tail) f1 = ZENC_PART | ((!(flags & ZENC_PART) || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES | ZENC_FRAME_TREE));
     if (direct && (lz || len - J->tail != (u64)nd << 15)) return ctx_fail(c, NAF_GPU_EARG, "direct blocks need a stream of whole blocks and no match finder");
@@ -3412,16 +3413,38 @@ static int encode_stream_begin(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int 
     if (rc) { zstd_encode_drop(J->main); J->main = nullptr; }
     return rc;
 }
+// The size of the stream's frame before anything of it is placed: the tail part is coded (into scratch, as encode_stream_finish would),
+// the main part's size read back.  encode_stream_finish then writes without a read-back of its own.
+static int encode_stream_size(naf_gpu_ctx *c, StreamJob *J, size_t *clen)
+{
+    if (J->tail && !J->sized) {
+        const int f2 = ZENC_PART | ((!(J->flags & ZENC_PART) || (J->flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0);
+        const size_t tb = naf_gpu_zstd_compress_bound(J->tail);
+        u8 *tmp = (u8 *)arena_alloc(c, tb); if (!tmp) return NAF_GPU_ENOMEM;
+        size_t b = 0;
+        int rc = zstd_encode(c, J->d_stream + (J->len - J->tail), J->tail, J->level, tmp, tb, &b, f2, 0, 0, 0); if (rc) return rc;
+        J->tail_tmp = tmp; J->tail_len = b;
+    }
+    size_t a = 0;
+    int rc = zstd_encode_size(c, J->main, &a); if (rc) return rc;
+    J->sized = true;
+    *clen = a + J->tail_len;
+    return 0;
+}
 static int encode_stream_finish(naf_gpu_ctx *c, StreamJob *J, size_t *clen, const ZencPlace *place)
 {
     ZencJob *mj = J->main; J->main = nullptr;
     if (!J->tail) return zstd_encode_finish(c, mj, nullptr, 0, clen, place);
     const int f2 = ZENC_PART | ((!(J->flags & ZENC_PART) || (J->flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0);
-    size_t a = 0, b = 0;
-    const size_t tb = naf_gpu_zstd_compress_bound(J->tail);
-    u8 *tmp = (u8 *)arena_alloc(c, tb); if (!tmp) { zstd_encode_drop(mj); return NAF_GPU_ENOMEM; }
-    int rc = zstd_encode(c, J->d_stream + (J->len - J->tail), J->tail, J->level, tmp, tb, &b, f2, 0, 0, 0);
-    if (rc) { zstd_encode_drop(mj); return rc; }
+    size_t a = 0, b = J->tail_len;
+    u8 *tmp = J->tail_tmp;
+    int rc = 0;
+    if (!J->sized) {
+        const size_t tb = naf_gpu_zstd_compress_bound(J->tail);
+        tmp = (u8 *)arena_alloc(c, tb); if (!tmp) { zstd_encode_drop(mj); return NAF_GPU_ENOMEM; }
+        rc = zstd_encode(c, J->d_stream + (J->len - J->tail), J->tail, J->level, tmp, tb, &b, f2, 0, 0, 0);
+        if (rc) { zstd_encode_drop(mj); return rc; }
+    }
     PlaceTail T = { place, b, nullptr }; ZencPlace P = { place_before_tail, &T };
     if ((rc = zstd_encode_finish(c, mj, nullptr, 0, &a, &P))) return rc;
     HIP_TRY(c, hipMemcpyAsync(T.at + a, tmp, b, hipMemcpyDeviceToDevice, c->stream));
@@ -3530,9 +3553,11 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
     if (tl) { HIP_TRY(c, hipMemcpyAsync(d_naf + pos, o->title, tl, hipMemcpyHostToDevice, c->stream)); pos += tl; HIP_TRY(c, hipStreamSynchronize(c->stream)); }
     StreamJob big[6]; bool early[6] = { false, false, false, false, false, false };
     naf_gpu_ctx *sb = nullptr; int rcB = 0;                       // second side context (lengths, mask) and what its thread returns
-    // (an error below leaves through here: the second side context's thread works on this frame's variables until it is joined)
+    naf_gpu_ctx *pc = nullptr; int rcP = 0; u32 probe_share = 0; bool probe_out = false;   // third side context: the look at the sequence stream, on a thread of its own
+    // (an error below leaves through here: the side contexts' threads work on this frame's variables until they are joined)
     auto bail = [&](int r, naf_gpu_ctx *from) -> int {
         if (sb) ctx_worker_join(sb);
+        if (probe_out) { ctx_worker_join(pc); probe_out = false; hipStreamSynchronize(pc->stream); }
         for (int k = 0; k < 6; k++) if (early[k]) { zstd_encode_drop(big[k].main); early[k] = false; }
         hipStreamSynchronize(sc->stream); if (sb) hipStreamSynchronize(sb->stream);
         return from && from != c ? ctx_fail(c, r, "%s", from->err) : r;
@@ -3557,13 +3582,21 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
                     if (X.present[i]) { rcB = encode_stream_begin(sb, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]); early[i] = !rcB; }
             });
         } else if ((rc = ennaf_streams(sc, S, K, X, 2))) return bail(rc, sc);
+        // The look at the sequence stream has a stream AND a thread of its own (the third side context): its two launches and its read-back
+        // are then in flight while this thread queues the four streams' forty launches -- on the first side stream it stood 0.2 ms in front of
+        // ids and names, and queued behind them it answered 0.3 ms after they were done (a 10 GB text's call ends on these chains)
+        if (probe_later && c->side3) {
+            pc = c->side3;
+            arena_reset(pc);
+            if (hipStreamWaitEvent(pc->stream, c->fork_ev, 0) != hipSuccess) return bail(ctx_fail(c, NAF_GPU_EHIP, "ennaf: the look's stream"), c);
+            probe_out = true;
+            ctx_worker_start(pc, [&] { rcP = zenc_repeat_probe(pc, X.ptr[4], X.len[4], &probe_share); });
+        }
         for (int i = 4; i < 6; i++)
             if (X.present[i]) {
                 if ((rc = encode_stream_begin(c, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i], i == 4 ? X.direct : nullptr, i == 4 ? X.nd : 0u, i == 4 ? X.dloc : nullptr))) return bail(rc, c);
                 early[i] = true;
             }
-        // ids and names are queued BEFORE the look at the sequence stream is waited for, and the look has a stream of its own (the third
-        // side context): on the first side stream it stood 0.2 ms in front of them, and the call of a 10 GB text ends on that chain
         for (int i = 0; i < 2; i++)
             if (X.present[i]) {
                 if ((rc = encode_stream_begin(sc, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i]))) return bail(rc, sc);
@@ -3572,11 +3605,9 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
         if (probe_later) {
             // the frame is planned as if there were nothing to match (what the look says of nearly every input); a repeat-rich
             // stream drops that plan and starts over with the match finder
-            u32 share = 0;
-            naf_gpu_ctx *pc = c->side3 ? c->side3 : sc;
-            if (pc != sc) { arena_reset(pc); if (hipStreamWaitEvent(pc->stream, c->fork_ev, 0) != hipSuccess) return bail(ctx_fail(c, NAF_GPU_EHIP, "ennaf: the look's stream"), c); }
-            if ((rc = zenc_repeat_probe(pc, X.ptr[4], X.len[4], &share))) return bail(rc, pc);
-            ennaf_probe_verdict(X, share);
+            if (probe_out) { ctx_worker_join(pc); probe_out = false; if (rcP) return bail(rcP, pc); }
+            else if ((rc = zenc_repeat_probe(sc, X.ptr[4], X.len[4], &probe_share))) return bail(rc, sc);
+            ennaf_probe_verdict(X, probe_share);
             if (X.lz[4]) {
                 zstd_encode_drop(big[4].main); early[4] = false;
                 if ((rc = undirect())) return bail(rc, c);
@@ -3603,6 +3634,39 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
         ctx_worker_join(sb);
         return rcB ? ctx_fail(c, rcB, "%s", sb->err) : 0;
     };
+    const char *sf = ctx_opt(c, "SIZES_FIRST");
+    if (overlap && !(sf && sf[0] == '0')) {
+        // The sections' SIZES first, then their bytes, side by side: a section's place is the sum of the sizes in front of it, and learning
+        // those by writing the sections one after the other made the sequence stream's gather (0.9 ms of a 10 GB text's 4.5) wait for four small
+        // frames' read-backs and writes, and a FASTQ's two big writes for its mask's and its names'.  Every begun job's size is one read-back
+        // on its own stream (the tail parts are coded on the way); then the main stream's sections are queued first, the others beside them.
+        size_t csz[6] = { 0, 0, 0, 0, 0, 0 }, at[6] = { 0, 0, 0, 0, 0, 0 };
+        static const int order[6] = { 4, 5, 2, 3, 0, 1 };
+        auto ctx_of = [&](int i) -> naf_gpu_ctx * { return i >= 4 ? c : (sb && i >= 2) ? sb : sc; };
+        for (int k = 0; k < 6 && !rc; k++) {
+            const int i = order[k];
+            if (i == 2 && (rc = joinB())) break;
+            if (!X.present[i]) continue;
+            naf_gpu_ctx *w = ctx_of(i);
+            if (!early[i]) {
+                if ((rc = encode_stream_begin(w, X.ptr[i], X.len[i], o->level, X.flags[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i], i == 4 ? X.direct : nullptr, i == 4 ? X.nd : 0u, i == 4 ? X.dloc : nullptr))) { if (w != c) ctx_fail(c, rc, "%s", w->err); break; }
+                early[i] = true;
+            }
+            if ((rc = encode_stream_size(w, &big[i], &csz[i])) && w != c) ctx_fail(c, rc, "%s", w->err);
+        }
+        if (!rc) {
+            size_t p = pos;
+            for (int i = 0; i < 6; i++) if (X.present[i]) { u8 tmp[24]; at[i] = p; p += vle(X.orig[i], tmp) + vle(csz[i], tmp) + csz[i]; }
+            for (int k = 0; k < 6 && !rc; k++) {
+                const int i = order[k];
+                if (!X.present[i]) continue;
+                size_t pp = at[i];
+                rc = put_section(ctx_of(i), c, X.ptr[i], X.len[i], X.orig[i], o->level, d_naf, cap, pp, so[i], X.lz[i], X.block_log[i], X.window_log[i], X.tail[i], &big[i], X.flags[i]);
+                early[i] = false;
+            }
+            pos = p;
+        }
+    } else
     for (int i = 0; i < 6 && !rc; i++) {
         if (i >= 2 && (rc = joinB())) break;
         if (!X.present[i]) continue;
@@ -3612,7 +3676,7 @@ static int ennaf_whole(naf_gpu_ctx *c, const void *d_text_, size_t n, const naf_
         early[i] = false;
     }
     if (!joinedB) { ctx_worker_join(sb); joinedB = true; }
-    for (int k = 2; k < 6; k++) if (early[k]) zstd_encode_drop(big[k].main);
+    for (int k = 0; k < 6; k++) if (early[k]) { zstd_encode_drop(big[k].main); early[k] = false; }
     if (!rc) rc = join(); else if (overlap) { hipStreamSynchronize(sc->stream); if (sb) hipStreamSynchronize(sb->stream); }
     if (rc) return rc;
     for (int i = 0; i < 6; i++) { R.section_orig[i] = so[i].orig; R.section_comp[i] = so[i].comp; }

@@ -1216,7 +1216,7 @@ __device__ __forceinline__ void zenc_flat4_stream(u8 *out, const u8 *s, u32 n, c
 // LZ-coded blocks (mode[b] != 0) take their literals from L.lits with the plan / codes / tree of those literals (plan1 ...)
 // and append the Sequences_Section made by k_lz_seqenc; all other blocks are coded from src as literal-only blocks.
 struct ZWriteLz { const u8 *mode; const ZEncPlan *plan1; const u16 *codes1; const u8 *trees1; LzBufs B; u32 not_last; u32 wave_general; u32 frame_split; };   // frame_split: the blocks coded with the frame's code are k_zenc_write<true>'s   // wave_general: blocks of general Huffman codes are k_zenc_write_wave's   // not_last: the frame continues behind these blocks (a shard's part of a frame)
-struct ZencJob { const u8 *src; size_t n; u32 nblk, frame_wlog; ZEncPlan *plan; u16 *codes; u8 *trees; u64 *offs; u64 hdr; int with_magic, empty; ZWriteLz L; bool direct; u32 block_bytes; ZencLoc dloc; };   // dloc.loc != nullptr: the direct blocks' codes are tile-local (k_zenc_write_direct_loc)
+struct ZencJob { const u8 *src; size_t n; u32 nblk, frame_wlog; ZEncPlan *plan; u16 *codes; u8 *trees; u64 *offs; u64 hdr; int with_magic, empty; ZWriteLz L; bool direct; u32 block_bytes; ZencLoc dloc; u64 known_total; int have_total; };   // have_total: the blocks' bytes were read back already (zstd_encode_size)   // dloc.loc != nullptr: the direct blocks' codes are tile-local (k_zenc_write_direct_loc)
 // FRAME: the blocks coded with the FRAME's code only (ZENC_FRAME_TREE: nearly every block of a FASTQ's quality and sequence frames) -- one
 // table for the workgroup instead of sixteen, 5.6 KiB of LDS instead of 13: twice the wavefronts per CU for a kernel whose lanes each walk
 // a stream of 8 K symbols.  The plain instantiation then leaves those blocks alone (L.frame_split).
@@ -1785,7 +1785,8 @@ static int zenc_finish(naf_gpu_ctx *c, ZencJob *J, u8 *d_dst, size_t cap, size_t
     int rc;
     u64 total = 0;
     if (place) {
-        if ((rc = ctx_readback(c, &total, J->offs + nblk + 1, 8))) return rc;
+        if (J->have_total) total = J->known_total;
+        else if ((rc = ctx_readback(c, &total, J->offs + nblk + 1, 8))) return rc;
         if (!(d_dst = place->fn(place->ud, hdr + total))) return NAF_GPU_ECAP;
     }
     if (hdr) LAUNCH(c, "zenc_frame_header", k_zenc_frame_header, 1, 64, 0, d_dst, J->with_magic, J->frame_wlog);
@@ -1801,8 +1802,21 @@ static int zenc_finish(naf_gpu_ctx *c, ZencJob *J, u8 *d_dst, size_t cap, size_t
            (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
     if (J->direct && J->dloc.loc) LAUNCH(c, "zenc_write_direct", k_zenc_write_direct_loc, nblk, 256, 0, J->dloc, nblk, (const ZEncPlan *)J->plan, (const u8 *)J->trees, (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
     else if (J->direct) LAUNCH(c, "zenc_write_direct", k_zenc_write_direct, nblk, 256, 0, J->src, nblk, (const ZEncPlan *)J->plan, (const u8 *)J->trees, (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
-    if (!place && (rc = ctx_readback(c, &total, J->offs + nblk + 1, 8))) return rc;
+    if (!place) { if (J->have_total) total = J->known_total; else if ((rc = ctx_readback(c, &total, J->offs + nblk + 1, 8))) return rc; }
     *out_len = hdr + total;
+    return 0;
+}
+// The size of the frame a begun job will write (its header and its blocks), read back ONCE and kept for zstd_encode_finish: a caller that
+// places several frames one behind the other learns all their sizes first and then writes them side by side (enc.hip: ennaf_whole).
+int zstd_encode_size(naf_gpu_ctx *c, ZencJob *J, size_t *frame_len)
+{
+    if (!J || !frame_len) return NAF_GPU_EARG;
+    if (J->empty) { *frame_len = J->hdr; return 0; }
+    if (!J->have_total) {
+        u64 t = 0; int rc = ctx_readback(c, &t, J->offs + J->nblk + 1, 8); if (rc) return rc;
+        J->known_total = t; J->have_total = 1;
+    }
+    *frame_len = J->hdr + J->known_total;
     return 0;
 }
 
