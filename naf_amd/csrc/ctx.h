@@ -163,5 +163,7 @@ struct ZencLoc { const u8 *loc; const i32 *blk_bnd; const u32 *blk_t0; u64 tiles
 int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int with_magic, int lz, int block_log_hint, int window_log, ZencJob **job, const u8 *direct = nullptr, u32 nd = 0, const ZencLoc *dloc = nullptr);
 int zstd_encode_finish(naf_gpu_ctx *c, ZencJob *job, u8 *d_dst, size_t cap, size_t *out_len, const ZencPlace *place);
 void zstd_encode_drop(ZencJob *job);
-int zstd_encode_size(naf_gpu_ctx *c, ZencJob *job, size_t *frame_len);   // the frame's size, read back once and kept for zstd_encode_finish
+int zstd_encode_size(naf_gpu_ctx *c, ZencJob *job, size_t *frame_len);
+const u64 *zstd_encode_total_ptr(const ZencJob *job);
+void zstd_encode_set_total(ZencJob *job, u64 total);   // the frame's size, read back once and kept for zstd_encode_finish
 int zstd_encode(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, u8 *d_dst, size_t cap, size_t *out_len, int with_magic, int lz = 0, int block_log_hint = 0, int window_log = 0, const ZencPlace *place = nullptr);   // window_log >= 10: cross-block matching inside that window (zstd_enc.hip)

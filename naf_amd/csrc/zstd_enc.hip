@@ -1798,16 +1798,29 @@ static int zenc_finish(naf_gpu_ctx *c, ZencJob *J, u8 *d_dst, size_t cap, size_t
            (const u64 *)J->offs, d_dst, hdr, J->L);
     LAUNCH(c, "zenc_write", k_zenc_write<false>, cdiv(nblk, ZENC_BLOCKS_PER_WG), 64, 0, J->src, (u64)J->n, nblk, (const ZEncPlan *)J->plan, (const u16 *)J->codes, (const u8 *)J->trees,
            (const u64 *)J->offs, d_dst, hdr, J->L);
+    // (a frame of direct blocks whose size is known already -- nothing of this stream is in flight: the few blocks of general codes beside the gather,
+    // on the look's idle stream, instead of 60 us in front of it)
+    naf_gpu_ctx *aux = (J->L.wave_general && J->direct && J->have_total && c->side3 && c->split_ev[ZSPLIT_MAX - 1]) ? c->side3 : nullptr;
+    if (aux && hipStreamWaitEvent(aux->stream, c->fork_ev, 0) != hipSuccess) aux = nullptr;
+    if (aux) {
+        hipLaunchKernelGGL(k_zenc_write_wave, dim3(cdiv(nblk, ZWW_BLOCKS)), dim3(256), 512u + 4u * ZWW_OBUF, aux->stream, J->src, (u64)J->n, nblk, (const ZEncPlan *)J->plan, (const u16 *)J->codes, (const u8 *)J->trees,
+                           (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
+        if (hipGetLastError() != hipSuccess || hipEventRecord(c->split_ev[ZSPLIT_MAX - 1], aux->stream) != hipSuccess) return ctx_fail(c, NAF_GPU_EHIP, "zenc_write_wave beside the gather: launch failed");
+    } else
     if (J->L.wave_general) LAUNCH(c, "zenc_write_wave", k_zenc_write_wave, cdiv(nblk, ZWW_BLOCKS), 256, 512u + 4u * ZWW_OBUF, J->src, (u64)J->n, nblk, (const ZEncPlan *)J->plan, (const u16 *)J->codes, (const u8 *)J->trees,
            (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
     if (J->direct && J->dloc.loc) LAUNCH(c, "zenc_write_direct", k_zenc_write_direct_loc, nblk, 256, 0, J->dloc, nblk, (const ZEncPlan *)J->plan, (const u8 *)J->trees, (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
     else if (J->direct) LAUNCH(c, "zenc_write_direct", k_zenc_write_direct, nblk, 256, 0, J->src, nblk, (const ZEncPlan *)J->plan, (const u8 *)J->trees, (const u64 *)J->offs, d_dst, hdr, J->L.not_last);
+    if (aux && hipStreamWaitEvent(c->stream, c->split_ev[ZSPLIT_MAX - 1], 0) != hipSuccess) return ctx_fail(c, NAF_GPU_EHIP, "zenc_write_wave beside the gather: join failed");
     if (!place) { if (J->have_total) total = J->known_total; else if ((rc = ctx_readback(c, &total, J->offs + nblk + 1, 8))) return rc; }
     *out_len = hdr + total;
     return 0;
 }
 // The size of the frame a begun job will write (its header and its blocks), read back ONCE and kept for zstd_encode_finish: a caller that
 // places several frames one behind the other learns all their sizes first and then writes them side by side (enc.hip: ennaf_whole).
+// (for a caller that reads several jobs' totals back with one copy: where a job's total lies -- null when there is nothing to read -- and the way to hand it in)
+const u64 *zstd_encode_total_ptr(const ZencJob *J) { return (!J || J->empty || J->have_total) ? nullptr : J->offs + J->nblk + 1; }
+void zstd_encode_set_total(ZencJob *J, u64 total) { if (J && !J->empty) { J->known_total = total; J->have_total = 1; } }
 int zstd_encode_size(naf_gpu_ctx *c, ZencJob *J, size_t *frame_len)
 {
     if (!J || !frame_len) return NAF_GPU_EARG;
