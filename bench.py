@@ -938,6 +938,18 @@ def main():
             fq = synth.fastq_reads_device(int(args.fastq1_size), seed=7, device=dev)
             ctx.reserve(int(fq.numel() * 1.7) + (2 << 30))
             extra["fastq"], _ = side_workload(ctx, fq, capi.OUT_FASTQ, "FASTQ, 150-base reads `@readN len=150`, ACGT 0.22 each / acgt 0.025 each / N 0.02, quality uniform Phred 0-40 (SURVEY 8(d) cfg5 generator)", fold_case=True)
+            # HBM traffic of the leg's two calls, replayed from the round's PMC pass over the same workload (tools/profile_bench.sh: pmc_traffic_fastq.json)
+            try:
+                pf = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_fastq.json")))
+                fqb, nafb = int(extra["fastq"]["text_bytes"]), int(extra["fastq"]["naf_bytes"])
+                if abs(fqb - 12_500_000_000) < 50_000_000:
+                    for side in ("ennaf", "unnaf"):
+                        tb = int(pf[side]["call_traffic_bytes"])
+                        extra["fastq"][side + "_call_traffic"] = tb
+                        extra["fastq"][side + "_traffic_ratio"] = round(tb / (fqb + nafb), 3)
+                    extra["fastq"]["traffic_source"] = "profiles/pmc_traffic_fastq.json (replayed)"
+            except (OSError, KeyError, ValueError):
+                pass
             if have_ref() and not args.no_cpu:
                 # the reference's archive of a sample of it decoded here (libzstd's frames: names that copy each other, runs of "len=150")
                 extra["fastq"].update(realistic_vs_reference(ctx, fq, int(min(args.cpu_sample / 2, fq.numel())), out_mode=capi.OUT_FASTQ, fold_case=True))
@@ -954,6 +966,7 @@ def main():
             g = lambda k, f: (extra.get(k) or {}).get(f)
             roofline.update({"fastq_unnaf_gbps": g("fastq", "unnaf_value"), "fastq_ennaf_gbps": g("fastq", "ennaf_value"), "fastq_text_bytes": g("fastq", "text_bytes"),
                              "fastq_roundtrip_ok_case_folded": g("fastq", "roundtrip_ok_case_folded"),
+                             "fastq_ennaf_traffic_ratio": g("fastq", "ennaf_traffic_ratio"), "fastq_unnaf_traffic_ratio": g("fastq", "unnaf_traffic_ratio"),
                              "realistic_unnaf_gbps": g("realistic", "unnaf_value"), "realistic_ennaf_gbps": g("realistic", "ennaf_value"),
                              "softmasked_unnaf_gbps": g("softmasked", "unnaf_value"), "softmasked_ennaf_gbps": g("softmasked", "ennaf_value")})
             for wl in ("fastq", "realistic"):

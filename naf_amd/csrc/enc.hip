@@ -2235,13 +2235,16 @@ __global__ void k_fq_pick(EncP P, const FqCand *cand, const i64 *tile_eol, const
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tiles) return;
     const FqCand c = cand[t];
+    // (the four classes' counts as three words: a class is picked with a shift, not by indexing a private array)
+    const u64 L4 = (u64)c.L[0] | ((u64)c.L[1] << 16) | ((u64)c.L[2] << 32) | ((u64)c.L[3] << 48), I4 = (u64)c.I[0] | ((u64)c.I[1] << 16) | ((u64)c.I[2] << 32) | ((u64)c.I[3] << 48),
+              C4 = (u64)c.C[0] | ((u64)c.C[1] << 16) | ((u64)c.C[2] << 32) | ((u64)c.C[3] << 48);
     bool regular = (c.flags & FQC_OK) != 0;
     if (regular) {
         const bool starts = (c.flags & FQC_STARTS) != 0;
         const u32 ord0 = (u32)(t_ls[t] - (starts ? 0u : 1u)) & 3u;
         const u32 jh = (0u - ord0) & 3u, js = (1u - ord0) & 3u, jp = (2u - ord0) & 3u, jq = (3u - ord0) & 3u;
         u32 bad = (c.flags & (FQC_BADS << js)) | (c.flags & (FQC_BADS << jq)) | (c.flags & (FQC_BADP << jp)) | (c.flags & (FQC_BADH << jh));
-        u32 ids = c.I[jh], cmt = c.C[jh];
+        u32 ids = (u32)(I4 >> (16 * jh)) & 0xFFFFu, cmt = (u32)(C4 >> (16 * jh)) & 0xFFFFu;
         if (jh == 0 && !starts) {
             const i64 le = tile_eol[t - 1], lsp = tile_sp[t - 1];
             i64 ls0 = le + 1; if ((u64)ls0 < P.p0) ls0 = (i64)P.p0;
@@ -2249,7 +2252,7 @@ __global__ void k_fq_pick(EncP P, const FqCand *cand, const i64 *tile_eol, const
             else { ids += c.I0; cmt += c.C0; bad |= c.flags & FQC_BADH0; }
         }
         regular = bad == 0;
-        if (regular) { t_seq[t] = c.L[js]; t_ids[t] = ids; t_cmt[t] = cmt; t_qual[t] = c.L[jq]; }
+        if (regular) { t_seq[t] = (L4 >> (16 * js)) & 0xFFFFu; t_ids[t] = ids; t_cmt[t] = cmt; t_qual[t] = (L4 >> (16 * jq)) & 0xFFFFu; }
     }
     const bool wide = regular && c.nseg > wave_max;                 // (wave_max = 0xFFFF.. : none, every regular tile is 1)
     t_reg[t] = regular ? (wide ? 2u : 1u) : 0u; t_need[t] = regular ? 0u : 1u;

@@ -30,6 +30,9 @@ NAF_GPU_FLAT=0 NAF_GPU_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format 
 cp $(ls $out/stats3/*/*kernel_stats.csv | head -1) $out/${tag}_serial_huffman_alone_rocprofv3_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats4 -- python tools/perf_side.py realistic 4e9 > $out/stats4.log 2>&1
 cp $(ls $out/stats4/*/*kernel_stats.csv | head -1) $out/${tag}_realistic_rocprofv3_kernel_stats.csv
+# the FASTQ leg (one GPU's share of configs[4]): kernel stats, and below its PMC traffic
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats5 -- python tools/perf_side.py fastq 12.5e9 > $out/stats5.log 2>&1
+cp $(ls $out/stats5/*/*kernel_stats.csv | head -1) $out/${tag}_fastq_rocprofv3_kernel_stats.csv
 bash tools/trace_step.sh uniform 10e9 ${tag}_uniform > /dev/null 2>&1; cp gpurun_out/trace_${tag}_uniform/timeline.txt $out/${tag}_timeline_uniform_10GB.txt; cp gpurun_out/trace_${tag}_uniform/timeline_ennaf.txt $out/${tag}_timeline_ennaf_uniform_10GB.txt
 bash tools/trace_step.sh fastq 12.5e9 ${tag}_fastq > /dev/null 2>&1; cp gpurun_out/trace_${tag}_fastq/timeline.txt $out/${tag}_timeline_fastq_12GB.txt; cp gpurun_out/trace_${tag}_fastq/timeline_ennaf.txt $out/${tag}_timeline_ennaf_fastq_12GB.txt
 bash tools/trace_step.sh realistic 4e9 ${tag}_realistic > /dev/null 2>&1; cp gpurun_out/trace_${tag}_realistic/timeline.txt $out/${tag}_timeline_realistic_4GB.txt; cp gpurun_out/trace_${tag}_realistic/timeline_ennaf.txt $out/${tag}_timeline_ennaf_realistic_4GB.txt
@@ -46,6 +49,39 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   fi
 done
 done
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 -i $out/pmc_$ctr.txt --output-format csv -d $out/pmcfq_$ctr -- python tools/perf_side.py fastq 12.5e9 > $out/pmcfq_$ctr.log 2>&1
+done
+python - "$out" "$tag" <<'PY'
+# the FASTQ leg's traffic: per-kernel sums of the two passes, the calls counted by the kernels that run once per call
+import csv, glob, json, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+enc_prefix = ("k_enc", "k_fq_", "k_encq", "k_zenc", "k_lz_parse", "k_lz_seqenc", "k_lz_choose", "k_ldm", "k_maskb", "k_mask_", "k_len_unit", "k_pack_edges", "k_need_list", "k_put_bytes", "k_sniff", "k_collect4", "k_add_u64")
+res = {"ennaf": collections.OrderedDict(), "unnaf": collections.OrderedDict(), "shared": collections.OrderedDict()}
+calls = {"ennaf": 0, "unnaf": 0}
+for ctr, fac in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+    fs = glob.glob(f"{out}/pmcfq_{ctr}/**/*counter_collection.csv", recursive=True)
+    if not fs: continue
+    n_sniff = n_parse = 0
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] != ctr: continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        if k == "k_sniff": n_sniff += 1
+        if k == "k_parse_container": n_parse += 1
+        side = "ennaf" if k.startswith(enc_prefix) else ("shared" if k.startswith(("k_scan_", "k_small_to_host", "__amd")) else "unnaf")
+        f = 1.742 if (ctr == "FETCH_SIZE" and k == "k_huf_literals") else fac
+        res[side][k] = res[side].get(k, 0.0) + float(r["Counter_Value"]) * 1024 * f
+    calls = {"ennaf": n_sniff, "unnaf": n_parse}
+if calls["ennaf"] and calls["unnaf"]:
+    doc = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python tools/perf_side.py fastq 12.5e9`; counter unit KiB; FETCH_SIZE x2 (x1.742 for k_huf_literals), WRITE_SIZE x1; per call = sum / calls (k_sniff / k_parse_container dispatches); kernels both directions use (scans, read-backs) are listed apart and in neither total",
+           "calls_in_pass": calls}
+    for side in ("ennaf", "unnaf"):
+        per = {k: int(v / calls[side]) for k, v in sorted(res[side].items(), key=lambda x: -x[1])}
+        doc[side] = {"call_traffic_bytes": int(sum(per.values())), "kernels": dict(list(per.items())[:16])}
+    doc["shared_bytes_in_pass"] = int(sum(res["shared"].values()))
+    json.dump(doc, open(f"{out}/pmc_traffic_fastq.json", "w"), indent=1)
+    print("fastq traffic per call:", doc["ennaf"]["call_traffic_bytes"], doc["unnaf"]["call_traffic_bytes"])
+PY
 python - "$out" "$tag" <<'PY'
 import csv, glob, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
