@@ -31,6 +31,9 @@ struct ZStat {                 // device-side counters read back by the host
     u32 max_lit_regen, n_huf_pending;  // largest literals section of a Huffman-coded block (k_huf_par sizes its parts by it); trees left without a table by k_build_huf's first phase
     u32 last_raw, flat_main_inv;       // size of the frame's last block when it is a Raw or (bit 31) RLE one, else 0; 0xFFFFFFFF - index of the FIRST block that defines a flat 4-bit tree (0: none)
     u32 n_exec_done, n_wave;           // blocks the sequence executors have published: a waiting block gives up only when this stands still; blocks k_decode_seq left to k_decode_seq_wave(2)
+#ifdef NAF_EXEC_PROF
+    unsigned long long prof[8];
+#endif
 };
 
 static __device__ __forceinline__ void set_err(ZStat *st, u32 e) { if (e) atomicMax(&st->err, e); }
@@ -2387,11 +2390,11 @@ __global__ __launch_bounds__(64) void k_exec_seq(const ZBlock *blk, const u32 *s
 // round trip through L2, and leaves as one coalesced copy.  Sequences are taken 64 at a time: every lane places the literals
 // of one sequence (their positions are a prefix sum), then the matches run in order.
 #define EXEC_LDS 16384u
+#define EXEC_PJ_MAX 1024u                // a step's output up to this many bytes is resolved byte by byte (k_exec_seq_lds)
 __device__ __forceinline__ u32 wave_excl_sum(u32 v, u32 *total)
 {
-    u32 x = v;
-    for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)x, d, 64); if ((int)(threadIdx.x & 63) >= d) x += y; }
-    *total = (u32)__shfl((int)x, 63, 64);
+    const u32 x = wave_scan_inclusive<u32, OpAdd>(v);              // (DPP row shifts: six trips through the LDS crossbar as shuffles)
+    *total = (u32)__builtin_amdgcn_readlane((int)x, 63);
     return x - v;
 }
 __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u32 *seq_list, u32 n_seq_blk, const u64 *offs, u32 nblk,
@@ -2416,14 +2419,30 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
     u32 shift = 0xFF;
     if (nblk > 1) { const u64 b0 = offs[1] - offs[0]; if (b0 && !(b0 & (b0 - 1))) shift = (u32)(63 - __builtin_clzll(b0)); }
     bool bad = b.regen > obuf_cap;
+#ifdef NAF_EXEC_PROF
+    unsigned long long pt[6] = { 0, 0, 0, 0, 0, 0 }; unsigned long long tA = __builtin_readcyclecounter(), tB;
+#define PROF(k) { tB = __builtin_readcyclecounter(); pt[k] += tB - tA; tA = tB; }
+#else
+#define PROF(k)
+#endif
+    u16 *par = (u16 *)(obuf + obuf_cap + 64);                       // EXEC_PJ_MAX entries: where each byte of a step's output comes from
+    // (the next step's triples are asked for while this one runs: three dependent trips to memory a step were a fifth of the kernel)
+    u32 n_ll = 0, n_ml = 0, n_of = 0;
+    if (lane < nseq) { n_ll = o_ll[sbase + lane]; n_ml = o_ml[sbase + lane]; n_of = o_of[sbase + lane]; }
     for (u32 s0 = 0; s0 < nseq && !bad; s0 += 64) {
         u32 n = nseq - s0 < 64 ? nseq - s0 : 64;
         u32 ll = 0, ml = 0, of = 0;
-        if (lane < n) { ll = o_ll[sbase + s0 + lane]; ml = o_ml[sbase + s0 + lane]; of = sym_resolve(o_of[sbase + s0 + lane], rep_in); }
+        if (lane < n) { ll = n_ll; ml = n_ml; of = sym_resolve(n_of, rep_in); }
+        if (s0 + 64 + lane < nseq) { n_ll = o_ll[sbase + s0 + 64 + lane]; n_ml = o_ml[sbase + s0 + 64 + lane]; n_of = o_of[sbase + s0 + 64 + lane]; }
         u32 tot_all, tot_ll;
         u32 my_op = op + wave_excl_sum(ll + ml, &tot_all), my_lp = lp + wave_excl_sum(ll, &tot_ll);
         if (op + tot_all > b.regen || lp + tot_ll > b.lit_regen) { bad = true; break; }
-        // literals: short runs by their own lane, long ones by the whole wave
+        PROF(0)
+        // literals: short runs by their own lane (up to eight bytes: ONE load, not a trip to memory per byte), long ones by the whole wave
+        if (ll && ll <= 8 && my_lp + 8 <= b.regen) {
+            u64 v; __builtin_memcpy(&v, lits + my_lp, 8);
+            for (u32 k = 0; k < ll; k++) obuf[my_op + k] = (u8)(v >> (8 * k));
+        } else
         if (ll <= 32) for (u32 k = 0; k < ll; k++) obuf[my_op + k] = lits[my_lp + k];
         u64 big = __ballot(ll > 32);
         while (big) {
@@ -2432,6 +2451,55 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
             for (u32 k = lane; k < l; k += 64) obuf[o + k] = lits[p + k];
         }
         __syncthreads();
+        PROF(1)
+        // ---- a step of short sequences whose sources all lie in this block: every BYTE finds where it comes from.  The lane-per-match
+        // hops below settle a match only when its source lies wholly inside ONE earlier match; names that differ from their predecessor
+        // in a digit or two break that every tenth name (...19 -> ...20 matches a byte less, ...21 a byte more: its source straddles a
+        // match and the literal behind it), every later name of the step hops to that straddling source, and 85 % of a FASTQ's names went
+        // one by one (46 % of the kernel, profiles/r06_exec_phases.txt).  Per byte there is nothing to straddle: a literal byte is its
+        // own source, a match byte's is the byte `of` in front of it, and pointer doubling (par[p] = par[par[p]], in place: whatever a
+        // lane reads is an ancestor) ends in a literal of the step or a byte in front of it after log2(chain) rounds; then one gather.
+        if (tot_all <= EXEC_PJ_MAX && !__ballot(lane < n && (of == 0 || of > my_op + ll))) {
+            constexpr u32 PJ = EXEC_PJ_MAX / 64;                                         // bytes a lane looks after: lane, lane + 64, ...
+#pragma unroll
+            for (u32 i = 0; i < PJ; i++) { const u32 p = lane + 64 * i; if (p < tot_all) par[p] = (u16)(op + p); }
+            __syncthreads();
+            {
+                const u32 dm = my_op + ll;
+                if (lane < n && ml <= 64) for (u32 k = 0; k < ml; k++) par[dm - op + k] = (u16)(dm + k - of);
+                for (u64 bigm = __ballot(lane < n && ml > 64); bigm; bigm &= bigm - 1) {
+                    const int j = __ffsll((long long)bigm) - 1;
+                    const u32 dj = (u32)__builtin_amdgcn_readlane((int)dm, j), mlj = (u32)__builtin_amdgcn_readlane((int)ml, j), ofj = (u32)__builtin_amdgcn_readlane((int)of, j);
+                    for (u32 k = lane; k < mlj; k += 64) par[dj - op + k] = (u16)(dj + k - ofj);
+                }
+            }
+            __syncthreads();
+            // (a lane's sixteen look-ups of a round are asked for together: one after the other, each behind the store of the one before, they
+            // were two LDS round trips a byte and the step no faster than the matches one by one)
+            u32 q[PJ];
+#pragma unroll
+            for (u32 i = 0; i < PJ; i++) { const u32 p = lane + 64 * i; q[i] = p < tot_all ? (u32)par[p] : 0u; }
+            for (u32 round = 0; round < 12; round++) {                                    // (a chain is at most the step's 2^10 bytes long)
+                u32 nq[PJ]; bool changed = false;
+#pragma unroll
+                for (u32 i = 0; i < PJ; i++) nq[i] = q[i] >= op ? (u32)par[q[i] - op] : q[i];
+#pragma unroll
+                for (u32 i = 0; i < PJ; i++) if (nq[i] != q[i]) { par[lane + 64 * i] = (u16)nq[i]; q[i] = nq[i]; changed = true; }
+                __syncthreads();
+                if (!__ballot(changed)) break;
+            }
+            {
+                u8 v[PJ];
+#pragma unroll
+                for (u32 i = 0; i < PJ; i++) v[i] = obuf[q[i]];
+#pragma unroll
+                for (u32 i = 0; i < PJ; i++) { const u32 p = lane + 64 * i; if (p < tot_all && q[i] != op + p) obuf[op + p] = v[i]; }
+            }
+            __syncthreads();
+            PROF(2)
+            op += tot_all; lp += tot_ll;
+            continue;
+        }
         // ---- the matches of the step that need not wait for each other, all at once.  A stream of similar records (a FASTQ's read names:
         // every name copies its predecessor's first bytes) is a chain -- match j reads what match j - 1 wrote, which read what j - 2
         // wrote ... -- and one match per round trip through LDS was the executor's time (2.8 ms for the 490 MB of names of a 12.5 GB
@@ -2460,6 +2528,7 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
                 if (!__ballot(hop)) break;
                 if (hop) src = si + (src - di);
             }
+            PROF(2)
             // final sources: in front of the step, or between two matches of it (literal bytes)
             bool fin = plain && src + ml <= op;
             {
@@ -2480,6 +2549,10 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
             }
             todo = __ballot(valid && !fin);
             __syncthreads();
+            PROF(3)
+#ifdef NAF_EXEC_PROF
+            pt[5] += __popcll(todo);
+#endif
         }
         for (u32 j = 0; j < n; j++) {
             if (!((todo >> j) & 1)) continue;
@@ -2492,7 +2565,11 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
             if (ofj <= d) {                                                            // source inside this block: LDS to LDS
                 const u8 *from = obuf + d - ofj;
                 if (ofj >= mlj) { for (u32 k = lane; k < mlj; k += 64) obuf[d + k] = from[k]; }
-                else            { for (u32 k = lane; k < mlj; k += 64) obuf[d + k] = from[k % ofj]; }
+                else {
+                    // (the pattern's phase by adding, not by a division per byte: a block that is ONE overlapping match -- 8 KiB of `len=150`, of the number 150 -- was 6 K instructions of `%`)
+                    const u32 stepr = 64u % ofj; u32 r = lane % ofj;
+                    for (u32 k = lane; k < mlj; k += 64) { obuf[d + k] = from[r]; r += stepr; if (r >= ofj) r -= ofj; }
+                }
             } else {
                 // source (partly) in earlier blocks: confirm every block from the one holding it up to the lowest one confirmed so far, then read HBM
                 u64 src_abs = pos_abs - ofj;
@@ -2514,7 +2591,11 @@ __global__ __launch_bounds__(64) void k_exec_seq_lds(const ZBlock *blk, const u3
             __syncthreads();
         }
         op += tot_all; lp += tot_ll;
+        PROF(4)
     }
+#ifdef NAF_EXEC_PROF
+    if (lane == 0) { for (int k = 0; k < 6; k++) atomicAdd(&st->prof[k], pt[k]); atomicAdd(&st->prof[6], 1ull); atomicAdd(&st->prof[7], (unsigned long long)nseq); }
+#endif
     if (!bad && !b.err) {
         u32 rest = b.lit_regen - lp;
         if (op + rest != b.regen) bad = true;
@@ -4238,7 +4319,7 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
                     }
                     const char *el = ctx_opt(c, "EXEC_LDS");
                     if (hs0.max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
-                        LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, n_seq_blk, 64, ((hs0.max_seq_regen + 1023u) & ~1023u) + 64u, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
+                         LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, n_seq_blk, 64, ((hs0.max_seq_regen + 1023u) & ~1023u) + 64u + 2u * EXEC_PJ_MAX, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, nblk,
                                (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lits, d_dst, done2, st, (hs0.max_seq_regen + 1023u) & ~1023u);
                     else { const int rcx = launch_lz_exec(c, (const ZBlock *)blk, (const u32 *)seq_list, n_seq_blk, (const u64 *)sizes, (const u64 *)seq_cnt, nblk, ns_all, o_ll, o_ml, o_of, (const u8 *)lits, d_dst, done2, st); if (rcx) return rcx; }
                     return 0;
@@ -4395,12 +4476,16 @@ static int zstd_decode_one(naf_gpu_ctx *c, const u8 *d_src, size_t src_len, u8 *
         const char *el = ctx_opt(c, "EXEC_LDS");                      // "0": always the HBM executor (cross-check)
         const u32 nx = seq_t1 - seq_t0;
         if (max_seq_regen <= EXEC_LDS && !(el && el[0] == '0'))
-            LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, nx, 64, ((max_seq_regen + 1023u) & ~1023u) + 64u, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, nblk,
+             LAUNCH(c, "zstd_exec_seq", k_exec_seq_lds, nx, 64, ((max_seq_regen + 1023u) & ~1023u) + 64u + 2u * EXEC_PJ_MAX, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, nblk,
                    (const u32 *)o_ll, (const u32 *)o_ml, (const u32 *)o_of, (const u8 *)lit_scratch, d_dst, done, st, (max_seq_regen + 1023u) & ~1023u);
         else if ((rc = launch_lz_exec(c, (const ZBlock *)blk, (const u32 *)(seq_list + seq_t0), nx, (const u64 *)sizes, (const u64 *)seq_cnt, nblk, hs.total_seq, o_ll, o_ml, o_of, (const u8 *)lit_scratch, d_dst, done, st))) return rc;
     }
     if (c->zsplit && c->zsplit->done) { c->zsplit->status = st; return 0; }      // the caller checks the status once the emit is queued (zstd_split_status)
     rc = ctx_readback(c, &hs, st, sizeof hs); if (rc) return rc;
+#ifdef NAF_EXEC_PROF
+    if (hs.prof[6]) fprintf(stderr, "[exec prof] blocks %llu seqs %llu | cycles per block: load+scan %llu literals %llu hops %llu final copies %llu serial %llu | serial matches per block %.1f\n", hs.prof[6], hs.prof[7],
+                            hs.prof[0] / hs.prof[6], hs.prof[1] / hs.prof[6], hs.prof[2] / hs.prof[6], hs.prof[3] / hs.prof[6], hs.prof[4] / hs.prof[6], (double)hs.prof[5] / (double)hs.prof[6]);
+#endif
     if (hs.err) return zerr(c, hs.err, "block decode");
     return 0;
 }

@@ -68,6 +68,7 @@ for ctr, fac in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         if k == "k_sniff": n_sniff += 1
         if k == "k_parse_container": n_parse += 1
+        if not k.startswith(("k_", "__amd")): continue                     # (the generator's and the comparison's torch kernels)
         side = "ennaf" if k.startswith(enc_prefix) else ("shared" if k.startswith(("k_scan_", "k_small_to_host", "__amd")) else "unnaf")
         f = 1.742 if (ctr == "FETCH_SIZE" and k == "k_huf_literals") else fac
         res[side][k] = res[side].get(k, 0.0) + float(r["Counter_Value"]) * 1024 * f
