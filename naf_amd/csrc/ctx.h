@@ -116,6 +116,9 @@ int scan_exclusive_u64(naf_gpu_ctx *c, u64 *d_vals, size_t n, u64 *d_total);
 // Inclusive running maximum of i32 values in place (table-ownership propagation).
 int scan_inclusive_max_i32(naf_gpu_ctx *c, i32 *d_vals, size_t n);
 int scan_inclusive_max_i64(naf_gpu_ctx *c, i64 *d_vals, size_t n);
+// k arrays of one length in one set of launches (scan.hip: scan_multi)
+int scan_exclusive_u64_multi(naf_gpu_ctx *c, u64 *const *arrs, int k, size_t n, u64 *const *totals);
+int scan_inclusive_max_i64_multi(naf_gpu_ctx *c, i64 *const *arrs, int k, size_t n);
 
 // ---- zstd (zstd_dec.hip) -----------------------------------------------------------------------------
 // Decode frames at d_src (device).  If only_size, stops after sizes are known.

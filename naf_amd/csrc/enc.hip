@@ -2943,8 +2943,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
             LAUNCH(c, "ennaf_fq_first", k_fq_first, tiles, 64, 0, P, t_eol, t_sp, t_ls, cand);
         } else
         LAUNCH(c, "ennaf_last", k_enc_last, tiles, 256, 0, P, t_eol, t_sp, t_ls);
-        if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
-        if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
+        { i64 *const a2[2] = { t_eol, t_sp }; if ((rc = scan_inclusive_max_i64_multi(c, a2, 2, tiles))) return rc; }
         if ((rc = scan_exclusive_u64(c, t_ls, tiles, tot + 4))) return rc;
         u32 *t_reg = nullptr, *need_list = nullptr; u64 n_need = tiles;
         u32 *redo_list = nullptr, *n_redo = nullptr;
@@ -2972,10 +2971,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
             if (ctx_tracing(c)) ctx_trace(c, "[fq reg] tiles %llu, not regular %llu\n", (unsigned long long)tiles, (unsigned long long)n_need);
         }
         if (n_need) LAUNCH(c, "ennaf_fq_count", k_encq_count, n_need, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, (const u64 *)t_ls, t_seq, t_ids, t_cmt, t_qual, piece_cnt, (const u32 *)need_list, 0);
-        if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_ids, tiles, tot + 1))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_qual, tiles, tot + 3))) return rc;
+        { u64 *const a4[4] = { t_seq, t_ids, t_cmt, t_qual }, *const t4[4] = { tot + 0, tot + 1, tot + 2, tot + 3 }; if ((rc = scan_exclusive_u64_multi(c, a4, 4, tiles, t4))) return rc; }
         u64 h[5]; u8 lastb = 0x0A;
         if (n) { if ((rc = ctx_readback2(c, h, tot, 40, &lastb, d_text + n - 1, 1))) return rc; }
         else if ((rc = ctx_readback(c, h, tot, 40))) return rc;
@@ -3094,8 +3090,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
         } else
         LAUNCH(c, "ennaf_last", k_enc_last_fa, cdiv(tiles, 4 * LAST_TPW), 256, 0, P, t_eol, t_sp, tiles);
         // running maxima across tiles (positions are non-negative i64; reuse the u64-add scan machinery via max on i64)
-        if ((rc = scan_inclusive_max_i64(c, t_eol, tiles))) return rc;
-        if ((rc = scan_inclusive_max_i64(c, t_sp, tiles))) return rc;
+        { i64 *const a2[2] = { t_eol, t_sp }; if ((rc = scan_inclusive_max_i64_multi(c, a2, 2, tiles))) return rc; }
         if (S.fourbit && n >= 16 * ET_TILE) {
             // pure tiles (nearly all of a genome) a wavefront per tile; the others, from a list, by the general kernel
             u32 *t_needf = fused ? t_needf0 : arena_new<u32>(c, tiles + 1), *need_list = arena_new<u32>(c, tiles + 1); u64 *t_need = fused ? t_need0 : arena_new<u64>(c, tiles + 2);
@@ -3115,11 +3110,7 @@ static int ennaf_split(naf_gpu_ctx *c, const u8 *d_text, u64 n, const naf_gpu_en
             if (n_need) LAUNCH(c, "ennaf_count", k_enc_count, n_need, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, (const u32 *)need_list);
         } else
         LAUNCH(c, "ennaf_count", k_enc_count, tiles, 256, 0, P, (const i64 *)t_eol, (const i64 *)t_sp, t_seq, t_ids, t_cmt, t_rec, t_tail, t_reg, t_irr, (const u32 *)nullptr);
-        if ((rc = scan_exclusive_u64(c, t_seq, tiles, tot + 0))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_ids, tiles, tot + 1))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_cmt, tiles, tot + 2))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_rec, tiles, tot + 3))) return rc;
-        if ((rc = scan_exclusive_u64(c, t_irr, tiles, tot + 4))) return rc;
+        { u64 *const a5[5] = { t_seq, t_ids, t_cmt, t_rec, t_irr }, *const t5[5] = { tot + 0, tot + 1, tot + 2, tot + 3, tot + 4 }; if ((rc = scan_exclusive_u64_multi(c, a5, 5, tiles, t5))) return rc; }
         // t_seq[tiles] must hold the grand total for the "line began in an earlier tile" lookup
         HIP_TRY(c, hipMemcpyAsync(t_seq + tiles, tot + 0, 8, hipMemcpyDeviceToDevice, c->stream));
         u32 *blk_t0 = fused ? arena_new<u32>(c, (size_t)(n >> 16) + 2) : nullptr;            // (a block's 65536 bases are at least as many bytes of text)

@@ -101,3 +101,78 @@ int scan_inclusive_max_i64(naf_gpu_ctx *c, i64 *d_vals, size_t n)
 {
     return scan_rec<i64, OpMax, false>(c, d_vals, n, (i64 *)nullptr);
 }
+
+// ---- several arrays of one length in ONE set of launches (blockIdx.y = the array) ------------------------------------------------------
+// The encoder's split is followed by four or five scans over the tile table, each three launches of a few microseconds that wait for
+// each other: fifteen launches as three.  Arrays of more than SCAN_SMALL tiles' aggregates (a 100 GB text) take the plain routine.
+#define SCAN_MULTI_MAX 8
+template <typename T> struct ScanSet { T *v[SCAN_MULTI_MAX]; T *sums[SCAN_MULTI_MAX]; T *tot[SCAN_MULTI_MAX]; };
+template <typename T, typename Op>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_reduce_multi(ScanSet<T> S, size_t n)
+{
+    __shared__ T lds[4];
+    const T *vals = S.v[blockIdx.y];
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + threadIdx.x;
+    T acc = Op::template id<T>();
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) { size_t k = base + (size_t)i * SCAN_THREADS; if (k < n) acc = Op::template f<T>(acc, vals[k]); }
+    T tot = wg_reduce1<T, Op>(acc, lds);
+    if (threadIdx.x == 0) S.sums[blockIdx.y][blockIdx.x] = tot;
+}
+template <typename T, typename Op>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_small_multi(ScanSet<T> S, size_t n)      // exclusive scan of every array's tile aggregates
+{
+    __shared__ T lds[4];
+    __shared__ T s_incl[SCAN_THREADS];
+    T *vals = S.sums[blockIdx.x];
+    const size_t per = (n + SCAN_THREADS - 1) / SCAN_THREADS, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    T acc = Op::template id<T>();
+    for (size_t k = lo; k < hi; k++) acc = Op::template f<T>(acc, vals[k]);
+    T tot;
+    const T incl = wg_scan_inclusive<T, Op>(acc, &tot, lds);
+    s_incl[threadIdx.x] = incl;
+    __syncthreads();
+    T run = threadIdx.x ? s_incl[threadIdx.x - 1] : Op::template id<T>();
+    for (size_t k = lo; k < hi; k++) { const T v = vals[k]; vals[k] = run; run = Op::template f<T>(run, v); }
+    if (S.tot[blockIdx.x] && threadIdx.x == 0) *S.tot[blockIdx.x] = tot;
+}
+template <typename T, typename Op, bool EXCL>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_apply_multi(ScanSet<T> S, size_t n)
+{
+    __shared__ T lds[2][4];
+    T *vals = S.v[blockIdx.y]; const T *tile_pre = S.sums[blockIdx.y];
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + threadIdx.x;
+    T v[SCAN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) { size_t k = base + (size_t)i * SCAN_THREADS; v[i] = k < n ? vals[k] : Op::template id<T>(); }
+    T run = tile_pre[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        T pre, tot;
+        T wi = wg_scan1<T, Op>(v[i], &pre, &tot, lds[i & 1]);
+        T r = Op::template f<T>(run, Op::template f<T>(pre, EXCL ? wave_shift_up1<T, Op>(wi) : wi));
+        size_t k = base + (size_t)i * SCAN_THREADS;
+        if (k < n) vals[k] = r;
+        run = Op::template f<T>(run, tot);
+    }
+}
+template <typename T, typename Op, bool EXCL>
+static int scan_multi(naf_gpu_ctx *c, T *const *arrs, int k, size_t n, T *const *totals)
+{
+    const size_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (k < 2 || k > SCAN_MULTI_MAX || n <= SCAN_SMALL || ntiles > SCAN_SMALL) {
+        for (int i = 0; i < k; i++) { int rc = scan_rec<T, Op, EXCL>(c, arrs[i], n, totals ? totals[i] : (T *)nullptr); if (rc) return rc; }
+        return 0;
+    }
+    ScanSet<T> S; memset(&S, 0, sizeof S);
+    for (int i = 0; i < k; i++) {
+        S.v[i] = arrs[i]; S.tot[i] = totals ? totals[i] : nullptr;
+        S.sums[i] = arena_new<T>(c, ntiles + 1); if (!S.sums[i]) return ctx_fail(c, NAF_GPU_ENOMEM, "scan scratch");
+    }
+    LAUNCH(c, "scan_reduce", (k_scan_tile_reduce_multi<T, Op>), dim3((unsigned)ntiles, (unsigned)k), SCAN_THREADS, 0, S, n);
+    LAUNCH(c, "scan_small", (k_scan_small_multi<T, Op>), (unsigned)k, SCAN_THREADS, 0, S, ntiles);
+    LAUNCH(c, "scan_apply", (k_scan_tile_apply_multi<T, Op, EXCL>), dim3((unsigned)ntiles, (unsigned)k), SCAN_THREADS, 0, S, n);
+    return 0;
+}
+int scan_exclusive_u64_multi(naf_gpu_ctx *c, u64 *const *arrs, int k, size_t n, u64 *const *totals) { return scan_multi<u64, OpAdd, true>(c, arrs, k, n, totals); }
+int scan_inclusive_max_i64_multi(naf_gpu_ctx *c, i64 *const *arrs, int k, size_t n) { return scan_multi<i64, OpMax, false>(c, arrs, k, n, (i64 *const *)nullptr); }

@@ -63,6 +63,9 @@ def lz_datasets():
     for name, d in datasets():
         yield name, d
     yield "srr_ids", b"".join(b"SRR%07d.%d length=%d\x00" % (1234567, i, 150) for i in range(1, 30000))
+    # names short enough for a step of 64 of them to be resolved byte by byte in the LDS executor (k_exec_seq_lds: up to 1 KiB a step), with
+    # prefixes that shrink and grow by a byte or two (...9 -> ...10, ...99 -> ...100: sources that straddle a match and the literal behind it)
+    yield "short_ids", b"".join(b"r%d\x00" % i for i in range(1, 150000))
     yield "lengths", np.full(50000, 150, dtype="<u4").tobytes()
     yield "lengths_var", rng.integers(100, 160, 50000).astype("<u4").tobytes()
     rep = (b"abcdefghij" * 1000 + rng.integers(0, 256, 5000, dtype=np.uint8).tobytes()) * 5
