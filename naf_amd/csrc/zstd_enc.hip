@@ -744,10 +744,11 @@ __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk,
 // name, offset = the length of the name in front -- but finds it SERIALLY: its greedy walk over a round's 64 positions takes the matches
 // one after the other, five names a round, 7.5 ms for the 0.5 GB of names of a 12.5 GB FASTQ (a sixth of the whole encode, on a
 // stream that is a twenty-fifth of the text).  Here a lane takes a LINE (the bytes up to and including a zero byte) and compares it with
-// the line in front of it, column by column: the common prefix (segment A) and the next run of equal bytes behind the first difference
-// (segment B), both at the offset of the previous line's start.  Nothing is serial between lines: where a line's literals go and which
-// sequence numbers it writes are prefix sums over the lines.  A prefix that continues the match the line in front ended on (that
-// match reached its terminator, and the offset is the same: lines of equal length) JOINS it instead of opening a sequence -- what the
+// the line in front of it: the common prefix (segment A, columns aligned: offset = the previous line's length) and the common suffix
+// (segment B, ends aligned: offset = the line's own length -- Illumina names share their comment wherever the coordinates end).  Nothing
+// is serial between lines: where a line's literals go and which sequence numbers it writes are prefix sums over the lines.  A prefix
+// that continues the match the line in front ended on (a suffix match reaches the terminator at the very offset the next prefix has; a
+// line that is wholly its prefix does when the lines are equally long) JOINS it instead of opening a sequence -- what the
 // greedy walk gets from running across the line end: `SRR1.12 length=150\0SRR1.1` is one match, and comments that are all alike one per
 // block.  The head a joining prefix adds its length to is the sequence open at the end of the line in front, handed on through lines that
 // are wholly one match by a scan.  Blocks the picture does not fit -- fewer than half of the bytes matched, more lines than an eighth of
@@ -795,38 +796,33 @@ __global__ __launch_bounds__(64) void k_lz_parse_lines(const u8 *src, u64 n, u32
             s = i ? (u32)ends[i - 1] + 1 : 0u; e = i < L ? (u32)ends[i] + 1 : bn; len = e - s;
             if (i >= 1) {
                 of = s - (i >= 2 ? (u32)ends[i - 2] + 1 : 0u);
-                // the common prefix, then the first run of equal bytes behind it (lines of up to 256 bytes: what lies behind stays literal)
+                // the common prefix (up to 256 bytes of it), then the common suffix
                 const u32 lim = len < 256 ? len : 256u;
-                const u64 H = 0x8080808080808080ull;
                 u32 k = 0;
                 for (; k < lim; k += 8) { u64 x, y; __builtin_memcpy(&x, buf + s + k, 8); __builtin_memcpy(&y, buf + s + k - of, 8); const u64 d = x ^ y; if (d) { k += ((u32)__ffsll((long long)d) - 1) >> 3; break; } }
                 m1 = k < lim ? k : lim;
-                if (m1 < lim) {
-                    u32 q = m1 + 1; bool found = false;
-                    while (q < lim) {                                                  // the first equal byte behind the difference
-                        u64 x, y; __builtin_memcpy(&x, buf + s + q, 8); __builtin_memcpy(&y, buf + s + q - of, 8);
-                        u64 eq = zero_bytes64(x ^ y);
-                        if (q + 8 > lim) eq &= (1ull << (8 * (lim - q))) - 1;
-                        if (eq) { k2 = q + (((u32)__ffsll((long long)eq) - 1) >> 3); found = true; break; }
-                        q += 8;
+                if (m1 < len) {
+                    // the common SUFFIX with the line in front, ends aligned (offset = this line's own length: the lines need not be equally long):
+                    // `...:1101:2345:6789 1:N:0:ACGT` shares its comment with its predecessor wherever the coordinates end
+                    const u32 plen = of;                                               // (the line in front is [s - of, s))
+                    u32 maxs = len - m1; if (maxs > plen) maxs = plen; if (maxs > 256) maxs = 256;
+                    u32 ks = 0; bool stop = false;
+                    for (; ks + 8 <= maxs; ks += 8) {
+                        u64 x, y; __builtin_memcpy(&x, buf + e - 8 - ks, 8); __builtin_memcpy(&y, buf + s - 8 - ks, 8);
+                        const u64 d = x ^ y;
+                        if (d) { ks += (u32)__clzll((long long)d) >> 3; stop = true; break; }
                     }
-                    if (found) {
-                        m2 = lim - k2;                                                 // ... and how far the run goes
-                        for (q = k2; q < lim; q += 8) {
-                            u64 x, y; __builtin_memcpy(&x, buf + s + q, 8); __builtin_memcpy(&y, buf + s + q - of, 8);
-                            u64 ne = ~zero_bytes64(x ^ y) & H;
-                            if (q + 8 > lim) ne &= (1ull << (8 * (lim - q))) - 1;
-                            if (ne) { m2 = q + (((u32)__ffsll((long long)ne) - 1) >> 3) - k2; break; }
-                        }
-                    }
+                    if (!stop) while (ks < maxs && buf[e - 1 - ks] == buf[s - 1 - ks]) ks++;
+                    m2 = ks; k2 = len - m2;
                 }
                 if (m2 < LZ_MINMATCH) m2 = 0;
             }
         }
         const bool full = len && m1 == len;                                            // the whole line is its prefix
         const bool tail = (m2 && k2 + m2 == len) || (full && len >= LZ_MINMATCH);      // its last match reaches its end
+        const u32 tail_of = m2 ? len : of;                                             // ... at this offset (a suffix match's is the line's own length)
         // does the prefix continue the match the line in front ended on?
-        const u32 p_of = (u32)__shfl_up((int)of, 1, 64); const bool p_tail = __shfl_up((int)tail, 1, 64) != 0;
+        const u32 p_of = (u32)__shfl_up((int)tail_of, 1, 64); const bool p_tail = __shfl_up((int)tail, 1, 64) != 0;
         const bool join = i < NL && i >= 1 && m1 >= 1 && (lane ? (p_tail && p_of == of) : (c_tail && c_of == of));
         const bool a_on = join || m1 >= LZ_MINMATCH, a_head = a_on && !join, b_on = m2 != 0;
         const u32 la = a_on ? m1 : 0u;
@@ -849,7 +845,7 @@ __global__ __launch_bounds__(64) void k_lz_parse_lines(const u8 *src, u64 n, u32
             u32 q = my_seq, a = my_anchor;
             if (a_head) { sll[q] = (u16)(s - a); sof[q] = (u16)of; s_ml[q] = m1; q++; }
             if (a_on) a = s + m1;
-            if (b_on) { sll[q] = (u16)(s + k2 - a); sof[q] = (u16)of; s_ml[q] = m2; }
+            if (b_on) { sll[q] = (u16)(s + k2 - a); sof[q] = (u16)len; s_ml[q] = m2; }
         }
         if (join) atomicAdd(&s_ml[lane ? p_open : c_open], m1);                        // (behind the heads' stores: LDS operations of a wavefront keep their order)
         if (i < NL) {
@@ -862,7 +858,7 @@ __global__ __launch_bounds__(64) void k_lz_parse_lines(const u8 *src, u64 n, u32
         seq_base += (u32)__shfl((int)ns_in, 63, 64); matched_base += (u32)__shfl((int)mt_in, 63, 64);
         const u32 an_last = (u32)__shfl((int)an_in, 63, 64);
         if (an_last > anchor) anchor = an_last;
-        c_open = (u32)__shfl((int)open_i, 63, 64); c_of = (u32)__shfl((int)of, 63, 64); c_tail = __shfl((int)tail, 63, 64) != 0;
+        c_open = (u32)__shfl((int)open_i, 63, 64); c_of = (u32)__shfl((int)tail_of, 63, 64); c_tail = __shfl((int)tail, 63, 64) != 0;
     }
     if (matched_base * 2 < bn) { if (lane == 0) fallback[b] = 1; return; }
     __syncthreads();

@@ -519,6 +519,53 @@ def test_blocks_of_a_frame_settled_without_a_histogram(gpu, oracle, monkeypatch)
         assert oracle.ref_unnaf(host(a1)) == host(back1)
 
 
+def test_names_parsed_a_lane_per_line_fuzz(gpu, oracle, monkeypatch):
+    """k_lz_parse_lines on streams of zero-terminated names of many shapes -- counters with and without fixed width, Illumina-style
+    colon fields, names with comments that repeat, names that repeat wholly, empty names, lines longer than 256 bytes, a stream without
+    a last terminator, blocks that fall back to the hash table's walk beside blocks that do not -- at three block sizes: every frame
+    decodes to its input under the from-spec oracle, this build's LDS and HBM executors, and is never larger than the literal-only
+    coding; against NAF_GPU_LZ_LINES=0 (the hash table's walk alone) it is at most 12 % larger (it is mostly smaller)."""
+    rng = np.random.default_rng(20260930)
+    def names(kind, n):
+        out = []
+        x = int(rng.integers(1, 10 ** int(rng.integers(1, 9))))
+        for i in range(n):
+            if kind == 0: out.append(b"read%d" % (x + i))
+            elif kind == 1: out.append(b"SRR%07d.%d.%d" % (1234567, x + i // 2, 1 + i % 2))
+            elif kind == 2: out.append(b"A00123:45:HXXXXDSXX:%d:%d:%d:%d 1:N:0:ACGTACGT" % (1 + i // 50000, 1101 + i // 700, int(rng.integers(1000, 30000)), int(rng.integers(1000, 30000))))
+            elif kind == 3: out.append(b"len=150" if rng.random() < 0.97 else b"len=%d" % int(rng.integers(30, 151)))
+            elif kind == 4: out.append(bytes(rng.integers(33, 127, int(rng.integers(0, 40)), dtype=np.uint8)))
+            elif kind == 5: out.append(b"x" * int(rng.integers(200, 700)) + b"%d" % i)
+            elif kind == 6: out.append(b"" if i % 7 == 0 else b"q%06d/%d" % (i, i % 3))
+            else: out.append(b"chr%d_%d_%s" % (1 + i % 22, x + 13 * i, b"fwd" if i % 2 else b"rev"))
+        return out
+    for trial in range(24):
+        kinds = [int(k) for k in rng.integers(0, 8, int(rng.integers(1, 4)))]
+        parts = []
+        for k in kinds:
+            parts += names(k, int(rng.integers(2000, 30000)) if k != 5 else int(rng.integers(50, 400)))
+        d = b"\x00".join(parts) + (b"\x00" if trial % 3 else b"")
+        d = d[: 1_500_000]
+        for bl in ("11", "13", "14"):
+            monkeypatch.setenv("NAF_GPU_BLOCK_LOG", bl)
+            monkeypatch.setenv("NAF_GPU_LZ", "0")
+            plain = gpu.zstd_compress(gpu.to_device(d))
+            monkeypatch.setenv("NAF_GPU_LZ", "all")
+            frame = gpu.zstd_compress(gpu.to_device(d))
+            fb = host(frame)
+            assert len(fb) <= int(plain.numel()), (trial, bl)
+            assert oracle.zstd_decompress(fb, len(d) + 16) == d, (trial, bl, kinds)
+            assert host(gpu.zstd_decompress(frame, len(d) + 64)) == d, (trial, bl, kinds)
+            monkeypatch.setenv("NAF_GPU_EXEC_LDS", "0")
+            assert host(gpu.zstd_decompress(frame, len(d) + 64)) == d, (trial, bl, kinds)
+            monkeypatch.delenv("NAF_GPU_EXEC_LDS")
+            monkeypatch.setenv("NAF_GPU_LZ_LINES", "0")
+            walk = gpu.zstd_compress(gpu.to_device(d))
+            monkeypatch.delenv("NAF_GPU_LZ_LINES")
+            assert len(fb) <= 1.12 * int(walk.numel()) + 64, (trial, bl, kinds, len(fb), int(walk.numel()))
+    monkeypatch.delenv("NAF_GPU_BLOCK_LOG")
+
+
 def test_no_block_of_a_nearly_incompressible_stream_is_larger_than_raw(gpu, oracle):
     """A block coded with the FRAME's tree may have to carry the tree after all (k_zenc_frame_fix), "whatever it costs": the planner
     takes the frame's code for a block only when the block stays below its Raw size even then.  Streams of 256 symbols a few hundredths
