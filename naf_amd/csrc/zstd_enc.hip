@@ -526,13 +526,18 @@ __global__ __launch_bounds__(256) void k_zenc_frame_stats(const u32 *fhist, cons
         }
     }
 }
+// tally / stride: a DRY run over every stride-th block that only counts how many it would take (tally[0]) of how many it looked at
+// (tally[1]); gate: the tally of such a run -- the launch over all blocks leaves at once when the sample took fewer than half (reads whose
+// qualities wander do not look like independent draws from the sample: nearly every block would fail the moments and the pass over the
+// stream would be paid for nothing).
 __global__ __launch_bounds__(256) void k_zenc_frame_quick(const u8 *src, u64 n, u32 nblk, ZEncPlan *plan, u16 *codes, u64 *csize, u8 *done,
-                                                           const ZEncPlan *fplan, const u16 *fcodes, const float *fstat, u32 min_gain)
+                                                           const ZEncPlan *fplan, const u16 *fcodes, const float *fstat, u32 min_gain, u32 stride, u32 *tally, const u32 *gate)
 {
     __shared__ __attribute__((aligned(16))) u8 tab[256 * 64];
     __shared__ u32 s_q[4][4], s_accept;
-    const u32 b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
-    if (done[b] || fplan->kind != ZK_HUF) return;                 // (uniform)
+    const u32 b = stride ? blockIdx.x * stride : blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    if (!stride && gate && gate[0] * 2 < gate[1]) return;         // (uniform)
+    if (b >= nblk || done[b] || fplan->kind != ZK_HUF) return;    // (uniform)
     const u64 lo = zenc_block_lo(n, nblk, b), hi = zenc_block_lo(n, nblk, b + 1);
     const u32 bn = (u32)(hi - lo);
     if (bn < 64) return;
@@ -591,6 +596,7 @@ __global__ __launch_bounds__(256) void k_zenc_frame_quick(const u8 *src, u64 n, 
             if (p.kind == ZK_HUF && p.csize + fplan->tree_bytes <= 3 + bn) { p.frame = 1; accept = 1; }
             else if (p.kind != ZK_HUF) accept = 2;
         }
+        if (stride) { atomicAdd(&tally[1], 1u); if (accept) atomicAdd(&tally[0], 1u); accept = 0; }
         if (accept) { plan[b] = p; if (csize) csize[b] = p.csize; done[b] = 1; }
         s_accept = accept;
     }
@@ -1676,7 +1682,11 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
             float *fstat = arena_new<float>(c, 8); if (!fstat) return NAF_GPU_ENOMEM;
             if (!done) { done = (u8 *)arena_alloc(c, nblk); if (!done) return NAF_GPU_ENOMEM; HIP_TRY(c, hipMemsetAsync(done, 0, nblk, c->stream)); }
             LAUNCH(c, "zenc_frame_stats", k_zenc_frame_stats, 1, 256, 0, (const u32 *)fhist, (const u16 *)fcodes, fstat);
-            LAUNCH(c, "zenc_frame_quick", k_zenc_frame_quick, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, offs, done, (const ZEncPlan *)fplan, (const u16 *)fcodes, (const float *)fstat, min_gain);
+            u32 *tally = arena_new<u32>(c, 2); if (!tally) return NAF_GPU_ENOMEM;
+            HIP_TRY(c, hipMemsetAsync(tally, 0, 8, c->stream));
+            const u32 qs = nblk / 512 ? nblk / 512 : 1u;                      // (a dry run over ~512 blocks decides whether the pass over all of them is worth its read)
+            LAUNCH(c, "zenc_frame_quick", k_zenc_frame_quick, cdiv(nblk, qs), 256, 0, d_src, (u64)n, nblk, plan, codes, offs, done, (const ZEncPlan *)fplan, (const u16 *)fcodes, (const float *)fstat, min_gain, qs, tally, (const u32 *)nullptr);
+            LAUNCH(c, "zenc_frame_quick", k_zenc_frame_quick, nblk, 256, 0, d_src, (u64)n, nblk, plan, codes, offs, done, (const ZEncPlan *)fplan, (const u16 *)fcodes, (const float *)fstat, min_gain, 0u, (u32 *)nullptr, (const u32 *)tally);
         }
     }
     // the match finder's buffers; and the blocks of zero-terminated names a lane per line settles (k_lz_parse_lines) in FRONT of the planner:

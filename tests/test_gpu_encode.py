@@ -517,6 +517,23 @@ def test_blocks_of_a_frame_settled_without_a_histogram(gpu, oracle, monkeypatch)
     assert bool(((back1 == t) | ((back1 ^ 32) == t)).all())
     if oracle.have_ref():
         assert oracle.ref_unnaf(host(a1)) == host(back1)
+    # qualities that are anything but independent draws -- runs of 300 reads on one of three levels, a block of the stream mostly one level:
+    # the dry run over a sample takes next to none, the pass over all blocks leaves at once, and the archive is the histogram planner's
+    del t, back1, back0, a0, a1
+    line = torch.cumsum((fq == 10).to(torch.int32), 0)
+    is_q = ((line & 3) == 3) & (fq != 10)
+    lvl = torch.tensor([5, 20, 38], dtype=torch.int32, device="cuda")[((line >> 2) // 300) % 3]
+    noise = torch.randint(0, 3, (fq.numel(),), device="cuda", generator=g, dtype=torch.int32)
+    t2 = torch.where(is_q, (33 + lvl + noise).to(torch.uint8), fq)
+    del line, is_q, lvl, noise
+    monkeypatch.setenv("NAF_GPU_FRAME_QUICK", "1")
+    b1, _ = gpu.ennaf(t2); b1 = b1.clone()
+    monkeypatch.setenv("NAF_GPU_FRAME_QUICK", "0")
+    b0, _ = gpu.ennaf(t2)
+    monkeypatch.delenv("NAF_GPU_FRAME_QUICK")
+    assert torch.equal(b1, b0)
+    back = gpu.unnaf(b1, capi.OUT_FASTQ)
+    assert bool(((back == t2) | ((back ^ 32) == t2)).all())
 
 
 def test_names_parsed_a_lane_per_line_fuzz(gpu, oracle, monkeypatch):
