@@ -3335,6 +3335,12 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
     if (part & 1) {
         X.ptr[0] = S.s_ids; X.len[0] = X.orig[0] = S.n_ids; X.lz[0] = 1; X.present[0] = true;
         X.ptr[1] = S.s_cmt; X.len[1] = X.orig[1] = S.n_cmt; X.lz[1] = 1; X.present[1] = true;
+        // Comments and lengths of many records -- `len=150` and the number 150, 38 M times -- in blocks of 32 KiB instead of the match finder's 8:
+        // coded 8 KiB at a time they were 56 K blocks of one match each, and this build's own decoder spent 3 of a 12.5 GB FASTQ's 22.9 ms on
+        // their per-block chores (index, tables, a workgroup of the LDS executor per block); as 14 K blocks they go through the dataflow
+        // executor, whose runs that continue from block to block cost next to nothing: unnaf 22.9 -> 19.9 ms.
+        // NAF_GPU_SIDE_BLOCK_LOG=10..15: these two streams' block size whatever their length (13: as before).
+        { const char *sb_ = ctx_opt(c, "NAMES_BLOCK_LOG"); const int v = sb_ ? atoi(sb_) : 0; if (v >= 10 && v <= 15) X.block_log[1] = v; else if (S.n_cmt >= (16u << 20)) X.block_log[1] = 15; }
         // direct blocks are blocks of exactly 32 KiB: the stream's ragged end (with the padding nibble, if any) is a part of its own
         X.tail_packed = seq_tail; X.direct = nullptr; X.nd = 0;
         X.dloc = nullptr;
@@ -3344,6 +3350,7 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
     }
     if (part & 2) {
         X.ptr[2] = (const u8 *)s_len; X.len[2] = X.orig[2] = n_lenb; X.lz[2] = 1; X.present[2] = true;
+        { const char *sb_ = ctx_opt(c, "SIDE_BLOCK_LOG"); const int v = sb_ ? atoi(sb_) : 0; if (v >= 10 && v <= 15) X.block_log[2] = v; else if (n_lenb >= (16u << 20)) X.block_log[2] = 15; }
         X.ptr[3] = s_mask; X.len[3] = X.orig[3] = n_mask; X.block_log[3] = mask_block_log; X.present[3] = S.store_mask; X.flags[3] = ZENC_PREFER_RAW;   // (no frame tree for the mask: measured -- its 8 KiB blocks' own trees are 4 % smaller and mostly of 7 bits, the frame's code of 9, which the decoder walks with its two-level look-up)
     }
     return 0;

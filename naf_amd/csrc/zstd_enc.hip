@@ -760,16 +760,18 @@ __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk,
 // are wholly one match by a scan.  Blocks the picture does not fit -- fewer than half of the bytes matched, more lines than an eighth of
 // the bytes, fewer than two -- are left to k_lz_parse (fallback[b] = 1), which skips the others.  NAF_GPU_LZ_LINES=0: every block by k_lz_parse.
 __device__ __forceinline__ u64 zero_bytes64(u64 w) { const u64 L = 0x7F7F7F7F7F7F7F7Full; return ~(((w & L) + L) | w) & ~L; }   // 0x80 where the byte is zero
-__global__ __launch_bounds__(64) void k_lz_parse_lines(const u8 *src, u64 n, u32 nblk, LzBufs B, u32 buf_bytes, u8 *fallback, ZEncPlan *plan, u64 *csize, u8 *done)
+// line_div: a block may hold bn / line_div lines (8; 16 for blocks above 16 KiB, whose tables would otherwise leave two workgroups a CU --
+// comments of eight bytes in such blocks are the hash table's walk's, which takes a block of them as one match)
+__global__ __launch_bounds__(64) void k_lz_parse_lines(const u8 *src, u64 n, u32 nblk, LzBufs B, u32 buf_bytes, u8 *fallback, ZEncPlan *plan, u64 *csize, u8 *done, u32 line_div, u32 ml_slots)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lz_lds[];
     u8 *buf = lz_lds;
     u32 *s_ml = (u32 *)(lz_lds + buf_bytes);                              // match length of sequence q: its head's own bytes + what joined it
-    u16 *ends = (u16 *)(lz_lds + buf_bytes + 4 * (size_t)B.seq_slot);
+    u16 *ends = (u16 *)(lz_lds + buf_bytes + 4 * (size_t)ml_slots);
     const u32 b = blockIdx.x, lane = threadIdx.x;
     const u64 lo = zenc_block_lo(n, nblk, b);
     const u32 bn = (u32)(zenc_block_lo(n, nblk, b + 1) - lo);
-    const u32 max_lines = bn / 8;
+    const u32 max_lines = bn / line_div;
     for (u32 i = lane * 16; i < bn; i += 64 * 16) {
         if (i + 16 <= bn) { uint4 v; __builtin_memcpy(&v, src + lo + i, 16); *(uint4 *)(buf + i) = v; }
         else for (u32 k = i; k < bn; k++) buf[k] = src[lo + k];
@@ -1604,7 +1606,7 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
     // LZ-coded streams: 8 KiB blocks.  The decoder decodes and executes the sequences of a block serially -- a lane, then a wavefront per
     // block whose LDS buffer is the block's size -- so smaller blocks are more lanes, more workgroups per CU and shorter chains; matches in
     // ids / names / lengths are a few dozen bytes back anyway (a FASTQ's read names: the archive is no larger than with 16 KiB blocks).
-    if (use_lz && !e) block_log = 13;
+    if (use_lz && !e) block_log = (lz && block_log_hint >= 10 && block_log_hint <= 15) ? (u32)block_log_hint : 13u;   // (the hint of a caller that asked for the match finder itself: ennaf's comments and lengths of many records)
     if (use_lz && block_log > 15) block_log = 15;                // LZ lengths and distances are kept in 16 bits
     // cross-block matching (window_log >= 10; the host maps level / --long to it): 64 KiB blocks -- fewer block and table headers,
     // and a repeat is cut less often; lengths still fit 16 bits (k_lzx_parse clamps a match at 65535)
@@ -1703,10 +1705,12 @@ int zstd_encode_begin(naf_gpu_ctx *c, const u8 *d_src, size_t n, int level, int 
         B.nseq = arena_new<u32>(c, nblk); B.nlit = arena_new<u32>(c, nblk); B.seq_bytes = arena_new<u32>(c, nblk);
         if (!B.lits || !B.seqbuf || !B.ll || !B.ml || (!B.of && !B.ofv) || !B.nseq || !B.nlit || !B.seq_bytes) return NAF_GPU_ENOMEM;
         const char *ll_ = ctx_opt(c, "LZ_LINES");
-        if (!lzx && !(ll_ && ll_[0] == '0') && bs <= 16384 && nblk >= 64) {
+        if (!lzx && !(ll_ && ll_[0] == '0') && bs <= 32768 && nblk >= 64) {
             lz_fallback = (u8 *)arena_alloc(c, nblk); if (!lz_fallback) return NAF_GPU_ENOMEM;
             if (!done) { done = (u8 *)arena_alloc(c, nblk); if (!done) return NAF_GPU_ENOMEM; HIP_TRY(c, hipMemsetAsync(done, 0, nblk, c->stream)); }
-            LAUNCH(c, "zenc_lz_lines", k_lz_parse_lines, nblk, 64, lz_buf + 4 * (u32)B.seq_slot + 2 * (u32)(bs / 8 + 2), d_src, (u64)n, nblk, B, lz_buf, lz_fallback, plan, offs, done);
+            const u32 line_div = bs > 16384 ? 16u : 8u, ml_slots = 2 * (u32)(bs / line_div) + 4;   // (at most two sequences a line, a line more than the terminators)
+            const u32 lines_lds = lz_buf + 4 * ml_slots + 2 * (u32)(bs / line_div + 2);              // 19 KiB for blocks of 8 KiB, 53 for 32
+            LAUNCH(c, "zenc_lz_lines", k_lz_parse_lines, nblk, 64, lines_lds, d_src, (u64)n, nblk, B, lz_buf, lz_fallback, plan, offs, done, line_div, ml_slots);
         }
     }
     // (frames of a few blocks keep the tree with the planner: nothing to gain from a second launch)

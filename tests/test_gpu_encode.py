@@ -451,6 +451,10 @@ def test_ennaf_fastq_regular_tiles_by_lines(gpu, oracle, monkeypatch, capfd):
             third, _ = gpu.ennaf(gpu.to_device(tail))
             assert host(third) == mine, (rl, dmg)
             monkeypatch.delenv("NAF_GPU_FQ_WAVE")
+            # comments and lengths in blocks of 32 KiB (what they get from 16 MiB up): every stream as the oracle splits it, again
+            monkeypatch.setenv("NAF_GPU_NAMES_BLOCK_LOG", "15"); monkeypatch.setenv("NAF_GPU_SIDE_BLOCK_LOG", "15")
+            check_ennaf(gpu, oracle, tail)
+            monkeypatch.delenv("NAF_GPU_NAMES_BLOCK_LOG"); monkeypatch.delenv("NAF_GPU_SIDE_BLOCK_LOG")
 
 
 def test_frame_tree_of_the_quality_stream(gpu, oracle, monkeypatch):
@@ -539,7 +543,8 @@ def test_blocks_of_a_frame_settled_without_a_histogram(gpu, oracle, monkeypatch)
 def test_names_parsed_a_lane_per_line_fuzz(gpu, oracle, monkeypatch):
     """k_lz_parse_lines on streams of zero-terminated names of many shapes -- counters with and without fixed width, Illumina-style
     colon fields, names with comments that repeat, names that repeat wholly, empty names, lines longer than 256 bytes, a stream without
-    a last terminator, blocks that fall back to the hash table's walk beside blocks that do not -- at three block sizes: every frame
+    a last terminator, blocks that fall back to the hash table's walk beside blocks that do not -- at four block sizes (32 KiB: half as
+    many lines a block): every frame
     decodes to its input under the from-spec oracle, this build's LDS and HBM executors, and is never larger than the literal-only
     coding; against NAF_GPU_LZ_LINES=0 (the hash table's walk alone) it is at most 12 % larger (it is mostly smaller)."""
     rng = np.random.default_rng(20260930)
@@ -563,7 +568,7 @@ def test_names_parsed_a_lane_per_line_fuzz(gpu, oracle, monkeypatch):
             parts += names(k, int(rng.integers(2000, 30000)) if k != 5 else int(rng.integers(50, 400)))
         d = b"\x00".join(parts) + (b"\x00" if trial % 3 else b"")
         d = d[: 1_500_000]
-        for bl in ("11", "13", "14"):
+        for bl in ("11", "13", "14", "15"):
             monkeypatch.setenv("NAF_GPU_BLOCK_LOG", bl)
             monkeypatch.setenv("NAF_GPU_LZ", "0")
             plain = gpu.zstd_compress(gpu.to_device(d))
