@@ -37,11 +37,33 @@ def _staged(t, group):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
+P2P_MAX_BYTES = 1 << 29      # a transfer of more than this goes as pieces of this size, in order, on both sides
+
+
+def _pieces(ops):
+    """Transfers of more than P2P_MAX_BYTES as several, in order (sender and receiver cut a range of one length the same way).  RCCL
+    2.26's send / recv of a rank to ITSELF drops the second half of a message above 1 GiB (profiles/r06_rccl_self_exchange.txt: what
+    `--force-sharded` on one GPU runs into); a rank's range of a 100 GB text is 12.5 GB, and nothing is lost by not finding out on an
+    8-GPU box whether the path between two ranks has a limit of its own."""
+    out = []
+    for op in ops:
+        t = op.tensor
+        nb = t.numel() * t.element_size()
+        if nb <= P2P_MAX_BYTES or t.dim() != 1 or not t.is_contiguous():
+            out.append(op)
+            continue
+        step = P2P_MAX_BYTES // t.element_size()
+        for i in range(0, t.numel(), step):
+            out.append(dist.P2POp(op.op, t[i:i + step], op.peer, op.group))
+    return out
+
+
 def _p2p_post(ops):
     """Post a group of point-to-point transfers; returns what _p2p_wait needs.  Over RCCL the group is enqueued on the communicator's
     stream behind what the current stream holds NOW: kernels launched on the current stream after this call run beside the transfers."""
     if not ops:
         return None
+    ops = _pieces(ops)
     back = []
     real = []
     for op in ops:

@@ -455,6 +455,13 @@ outs = [torch.empty_like(piece)]
 shard._all_gather(outs, piece, None)
 torch.cuda.synchronize()
 assert torch.equal(outs[0], want), "all_gather of one rank"
+# a range of more than a GiB (a rank's share of the headline text is 12.5 GB): RCCL 2.26's exchange of a rank with itself loses the
+# second half of such a message as ONE transfer (profiles/r06_rccl_self_exchange.txt); shard._pieces posts it 512 MiB at a time
+big = torch.arange(0, 1_400_000_000 // 8, dtype=torch.int64, device="cuda").view(torch.uint8)
+g3 = shard.gather_ranges(big, int(big.numel()), self_exchange=True)
+torch.cuda.synchronize()
+assert torch.equal(g3, big), "gather_ranges of 1.4 GB through the communicator"
+del g3, big
 ctx.close()
 dist.destroy_process_group()
 print("rccl self exchange ok")
