@@ -2664,7 +2664,10 @@ __global__ __launch_bounds__(256) void k_maskb_scatter(const u64 *cb, u64 T, con
 // The census of a shard: case changes INSIDE the shard (positions >= 1) per tile, and their first and last position -- what the
 // neighbours need to continue a run across the cut.  out: [0] first internal boundary (~0: none), [1] last internal boundary (0: none).
 // One atomic per workgroup at most, and only when it can still improve the value (mixed-case reads change case every few bases).
-__global__ __launch_bounds__(256) void k_maskb_census(const u64 *cb, u64 T, u64 *tile_cnt, unsigned long long *out)
+// tile_last: position + 1 of the tile's last change, 0 when it has none -- k_maskb_count's table (every later tile's last change is larger than
+// every earlier one's: an atomicMax per workgroup on ONE address was 176 K atomics in a row, 5 ms of a 12.5 GB shard; its running maximum
+// is also what k_maskb_units_direct wants, which a shard could not use without it)
+__global__ __launch_bounds__(256) void k_maskb_census(const u64 *cb, u64 T, u64 *tile_cnt, unsigned long long *out, i64 *tile_last)
 {
     __shared__ u32 s_c[4]; __shared__ u64 s_lo[4], s_hi[4];
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -2682,7 +2685,7 @@ __global__ __launch_bounds__(256) void k_maskb_census(const u64 *cb, u64 T, u64 
         u64 lo = ~0ull, hi = 0;
         for (int w = 0; w < 4; w++) { lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; }
         if (lo < __atomic_load_n(&out[0], __ATOMIC_RELAXED)) atomicMin(&out[0], (unsigned long long)lo);
-        if (hi > __atomic_load_n(&out[1], __ATOMIC_RELAXED)) atomicMax(&out[1], (unsigned long long)hi);
+        tile_last[blockIdx.x] = hi ? (i64)(hi + 1) : 0;
     }
 }
 // first and last base of a packed stream as letters (upper case from the table of unnaf.c:13, lower when the case bit is set)
@@ -2864,7 +2867,7 @@ struct EnnafSplit {
     u64 unexpected[4][257];
     int err_kind; u32 err_char; u64 err_rec, err_a, err_b;
     // soft-mask census of a shard (positions >= 1); tc = per-tile counts kept for the finish
-    bool census; u64 *tc; u64 mask_changes, mask_first, mask_last; u8 first_base, last_base;
+    bool census; u64 *tc; i64 *census_last; u64 mask_changes, mask_first, mask_last; u8 first_base, last_base;   // census_last: running maximum of the tiles' last change + 1 (k_maskb_census)
     // direct blocks (k_direct_blocks): flags of the first nd blocks of 32 KiB of `packed`; rescatter() packs the bases again without them
     // (the stream turned out to be worth matching: the match finder wants packed bytes)
     u8 *direct; u32 nd;
@@ -3260,7 +3263,7 @@ static int ennaf_streams(naf_gpu_ctx *c, EnnafSplit &S, const EnnafCarry &K, Enn
         }
         // mask (only ever stored next to a 4-bit sequence stream, ennaf.c:445); a shard has counted its boundaries in the census already
         if (S.store_mask && T && (part & 2)) {
-            u64 nb = 0; i64 *tile_last = nullptr;
+            u64 nb = 0; i64 *tile_last = S.census ? S.census_last : nullptr;
             const bool one_run = !S.census && S.no_case && !K.skip_run0 && !K.prev_masked;         // (the count pass saw no case bit: no pass over the case bits, no scan, no read-back)
             if (!one_run) {
             if (!S.census) {
@@ -3411,11 +3414,11 @@ static size_t naf_header_bytes(const naf_gpu_ennaf_opts *o, bool store_mask, boo
 struct PlaceTail { const ZencPlace *outer; size_t tail_len; u8 *at; };
 static u8 *place_before_tail(void *ud, size_t len) { PlaceTail *t = (PlaceTail *)ud; return t->at = t->outer->fn(t->outer->ud, len + t->tail_len); }
 // the two halves of a placed stream (zstd_encode_begin / _finish): what the caller queues between them runs beside the planning
-struct StreamJob { ZencJob *main; const u8 *d_stream; u64 len; int level, flags; u32 tail; bool sized; u8 *tail_tmp; size_t tail_len; };   // sized: encode_stream_size ran (the tail part is coded, the main part's size is known)
+struct StreamJob { ZencJob *main; const u8 *d_stream; u64 len; int level, flags; u32 tail; bool sized; u8 *tail_tmp; size_t tail_len; int tail_flags; };   // tail_flags: what the tail part is coded with beside its PART flags (a shard's ragged block: like the blocks in front of it)   // sized: encode_stream_size ran (the tail part is coded, the main part's size is known)
 static int encode_stream_begin(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int level, int flags, int lz, int block_log, int window_log, u32 tail, StreamJob *J, const u8 *direct = nullptr, u32 nd = 0, const ZencLoc *dloc = nullptr)
 {
     J->main = nullptr; J->d_stream = d_stream; J->len = len; J->level = level; J->flags = flags; J->tail = (tail && len > tail) ? tail : 0;
-    J->sized = false; J->tail_tmp = nullptr; J->tail_len = 0;
+    J->sized = false; J->tail_tmp = nullptr; J->tail_len = 0; J->tail_flags = 0;
     int f1 = flags;
     if (J->tail) f1 = ZENC_PART | ((!(flags & ZENC_PART) || (flags & ZENC_PART_FIRST)) ? ZENC_PART_FIRST : 0) | (flags & (ZENC_PREFER_RAW | ZENC_PREFER_FLAT | ZENC_SHORT_CODES | ZENC_FRAME_TREE));
     if (direct && (lz || len - J->tail != (u64)nd << 15)) return ctx_fail(c, NAF_GPU_EARG, "direct blocks need a stream of whole blocks and no match finder");
@@ -3428,7 +3431,7 @@ static int encode_stream_begin(naf_gpu_ctx *c, const u8 *d_stream, u64 len, int 
 static int encode_stream_size(naf_gpu_ctx *c, StreamJob *J, size_t *clen)
 {
     if (J->tail && !J->sized) {
-        const int f2 = ZENC_PART | ((!(J->flags & ZENC_PART) || (J->flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0);
+        const int f2 = ZENC_PART | ((!(J->flags & ZENC_PART) || (J->flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0) | J->tail_flags;
         const size_t tb = naf_gpu_zstd_compress_bound(J->tail);
         u8 *tmp = (u8 *)arena_alloc(c, tb); if (!tmp) return NAF_GPU_ENOMEM;
         size_t b = 0;
@@ -3445,7 +3448,7 @@ static int encode_stream_finish(naf_gpu_ctx *c, StreamJob *J, size_t *clen, cons
 {
     ZencJob *mj = J->main; J->main = nullptr;
     if (!J->tail) return zstd_encode_finish(c, mj, nullptr, 0, clen, place);
-    const int f2 = ZENC_PART | ((!(J->flags & ZENC_PART) || (J->flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0);
+    const int f2 = ZENC_PART | ((!(J->flags & ZENC_PART) || (J->flags & ZENC_PART_LAST)) ? ZENC_PART_LAST : 0) | J->tail_flags;
     size_t a = 0, b = J->tail_len;
     u8 *tmp = J->tail_tmp;
     int rc = 0;
@@ -3803,15 +3806,18 @@ extern "C" int naf_gpu_ennaf_shard_begin(naf_gpu_ctx *c, const void *d_slice, si
         if (S.store_mask) {
             const u64 mt = (S.T + MBB_TILE - 1) / MBB_TILE;
             S.tc = arena_new<u64>(c, mt + 2); unsigned long long *d_o = arena_new<unsigned long long>(c, 3);
-            if (!S.tc || !d_o) return NAF_GPU_ENOMEM;
+            S.census_last = arena_new<i64>(c, mt + 1);
+            if (!S.tc || !d_o || !S.census_last) return NAF_GPU_ENOMEM;
             u64 init[3] = { ~0ull, 0, 0 };
             HIP_TRY(c, hipMemcpyAsync(d_o, init, 24, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            LAUNCH(c, "ennaf_mask_census", k_maskb_census, mt, 256, 0, (const u64 *)S.casebits, S.T, S.tc, d_o);
+            LAUNCH(c, "ennaf_mask_census", k_maskb_census, mt, 256, 0, (const u64 *)S.casebits, S.T, S.tc, d_o, S.census_last);
+            if ((rc = scan_inclusive_max_i64(c, S.census_last, mt))) return rc;
             LAUNCH(c, "ennaf_ends", k_packed_ends, 1, 64, 0, (const u8 *)S.packed, (const u64 *)S.casebits, S.T, d_o + 2);
             u64 *d_tot = arena_new<u64>(c, 1); if (!d_tot) return NAF_GPU_ENOMEM;
-            u64 got[3]; if ((rc = ctx_readback(c, got, d_o, 24))) return rc;
-            S.mask_first = got[0]; S.mask_last = got[1]; S.first_base = (u8)got[2]; S.last_base = (u8)(got[2] >> 8);
+            u64 got[3]; i64 lastp1 = 0;
+            if ((rc = ctx_readback2(c, got, d_o, 24, &lastp1, S.census_last + (mt - 1), 8))) return rc;
+            S.mask_first = got[0]; S.mask_last = lastp1 > 0 ? (u64)(lastp1 - 1) : 0; S.first_base = (u8)got[2]; S.last_base = (u8)(got[2] >> 8);
             // number of changes: the per-tile counts are summed by the scan of the finish; here a reduction of the same array
             u64 *tmp = arena_new<u64>(c, mt + 2); if (!tmp) return NAF_GPU_ENOMEM;
             HIP_TRY(c, hipMemcpyAsync(tmp, S.tc, mt * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -3909,17 +3915,67 @@ extern "C" int naf_gpu_ennaf_shard_finish(naf_gpu_ctx *c, const naf_gpu_ennaf_op
     if ((rc = ennaf_windows(c, X, o))) return rc;
     memset(pieces, 0, sizeof *pieces);
     u8 *dst = (u8 *)d_pieces_; size_t pos = 0;
+    // Every section has a place of its own in the piece buffer -- its bound, not its size, is what it is given -- so no section waits for
+    // the one in front: ids and comments are queued on the first side context, lengths and mask on the second, sequence and quality here,
+    // and the sizes are read back when all of them are queued (the sections one after the other, each with a read-back behind its write,
+    // were 52 ms of a 12.5 GB FASTQ shard whose kernels are 33).  NAF_GPU_SHARD_OVERLAP=0: one after the other on this context.
+    auto part_tail = [&](int i) -> u32 {
+        // a part of the packed sequence stream is whole blocks of 32 KiB and ONE ragged block behind them (not an even split of two sizes): the
+        // stitched frame is then runs of equal blocks with a short block at every seam, which the decoder's stride index takes in place
+        // (zstd_dec.hip: k_runs_*); a single part is a uniform frame outright
+        u32 tail = V.last[i] ? X.tail[i] : 0u;
+        if (i == 4 && st->S.fourbit && !X.lz[4] && !X.block_log[4] && X.len[4] >= 65536 && !(ctx_opt(c, "BLOCK_LOG") && atoi(ctx_opt(c, "BLOCK_LOG")) != 15)) { const u32 rag = (u32)(X.len[4] & 32767); if (rag > tail) tail = rag; }
+        return tail;
+    };
+    size_t at[6] = { 0, 0, 0, 0, 0, 0 }, bound_sum = 0;
+    for (int i = 0; i < 6; i++) if (X.present[i]) { at[i] = bound_sum; bound_sum += (naf_gpu_zstd_compress_bound(X.len[i]) + 64 + 15) & ~(size_t)15; }
+    const char *so_ = ctx_opt(c, "SHARD_OVERLAP");
+    u64 big_bytes = 0; for (int i = 0; i < 6; i++) if (X.present[i]) big_bytes += X.len[i];
+    const bool overlap = !(so_ && so_[0] == '0') && bound_sum <= cap && (big_bytes >= (64u << 20) || (so_ && so_[0] == '1')) && ctx_sides_ready(c) == 0 && c->side && c->side2;   // (=1: whatever the size)
+    if (overlap) {
+        naf_gpu_ctx *sc = c->side, *sb = c->side2;
+        arena_reset(sc); arena_reset(sb);
+        HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(sc->stream, c->fork_ev, 0));
+        HIP_TRY(c, hipStreamWaitEvent(sb->stream, c->fork_ev, 0));
+        StreamJob job[6]; bool begun[6] = { false, false, false, false, false, false };
+        auto ctx_of = [&](int i) -> naf_gpu_ctx * { return i >= 4 ? c : i >= 2 ? sb : sc; };
+        static const int order[6] = { 0, 1, 2, 3, 4, 5 };
+        for (int q = 0; q < 6 && !rc; q++) {
+            const int i = order[q];
+            if (!X.present[i]) continue;
+            naf_gpu_ctx *w = ctx_of(i);
+            const int flags = ZENC_PART | (V.first[i] ? ZENC_PART_FIRST : 0) | (V.last[i] ? ZENC_PART_LAST : 0) | X.flags[i];
+            const u32 tail = part_tail(i);
+            if ((rc = encode_stream_begin(w, X.ptr[i], X.len[i], o->level, flags, X.lz[i], X.block_log[i], X.window_log[i], tail, &job[i]))) { if (w != c) ctx_fail(c, rc, "%s", w->err); break; }
+            job[i].tail_flags = tail >= 2048 ? (flags & (ZENC_PREFER_FLAT | ZENC_SHORT_CODES)) : 0;    // (a ragged block of some size is coded like the blocks in front of it: encode_stream)
+            begun[i] = true;
+        }
+        struct Fixed { u8 *at; size_t len; };
+        auto fixed_place = [](void *ud, size_t len) -> u8 * { Fixed *f = (Fixed *)ud; f->len = len; return f->at; };
+        static const int fin[6] = { 4, 5, 2, 3, 0, 1 };
+        for (int q = 0; q < 6 && !rc; q++) {
+            const int i = fin[q];
+            if (!X.present[i] || !begun[i]) continue;
+            naf_gpu_ctx *w = ctx_of(i);
+            Fixed F = { dst + at[i], 0 }; ZencPlace P = { fixed_place, &F };
+            size_t clen = 0;
+            begun[i] = false;
+            if ((rc = encode_stream_finish(w, &job[i], &clen, &P))) { if (w != c) ctx_fail(c, rc, "%s", w->err); break; }
+            pieces->off[i] = at[i]; pieces->len[i] = clen; pieces->raw[i] = X.orig[i];
+        }
+        for (int i = 0; i < 6; i++) if (begun[i]) zstd_encode_drop(job[i].main);
+        hipStreamSynchronize(sc->stream); hipStreamSynchronize(sb->stream);
+        if (rc) { hipStreamSynchronize(c->stream); return rc; }
+        pos = bound_sum;
+    } else
     for (int i = 0; i < 6; i++) {
         if (!X.present[i]) continue;
         const size_t need = naf_gpu_zstd_compress_bound(X.len[i]);
         if (pos + need > cap) return ctx_fail(c, NAF_GPU_ECAP, "shard piece buffer of %zu bytes is too small", cap);
         size_t clen = 0;
         const int flags = ZENC_PART | (V.first[i] ? ZENC_PART_FIRST : 0) | (V.last[i] ? ZENC_PART_LAST : 0) | X.flags[i];
-        // a part of the packed sequence stream is whole blocks of 32 KiB and ONE ragged block behind them (not an even split of two sizes): the
-        // stitched frame is then runs of equal blocks with a short block at every seam, which the decoder's stride index takes in place
-        // (zstd_dec.hip: k_runs_*); a single part is a uniform frame outright
-        u32 tail = V.last[i] ? X.tail[i] : 0u;
-        if (i == 4 && st->S.fourbit && !X.lz[4] && !X.block_log[4] && X.len[4] >= 65536 && !(ctx_opt(c, "BLOCK_LOG") && atoi(ctx_opt(c, "BLOCK_LOG")) != 15)) { const u32 rag = (u32)(X.len[4] & 32767); if (rag > tail) tail = rag; }
+        const u32 tail = part_tail(i);
         if ((rc = encode_stream(c, X.ptr[i], X.len[i], o->level, dst + pos, cap - pos, &clen, flags, X.lz[i], X.block_log[i], X.window_log[i], tail))) return rc;
         pieces->off[i] = pos; pieces->len[i] = clen; pieces->raw[i] = X.orig[i];
         pos += (clen + 15) & ~(size_t)15;

@@ -131,6 +131,42 @@ def test_sharded_large_roundtrip(ctxs, oracle):
         assert oracle.ref_unnaf(host(naf))[:4_000_000] == sample
 
 
+def test_sharded_dense_mask_units_straight_from_the_case_bits(ctxs, oracle, monkeypatch):
+    """A shard's mask units straight from its case bits (k_maskb_units_direct behind k_maskb_census's table of last changes): a text
+    whose case changes every few bases -- 3 M changes per 60 MB, far above the 65 536 the path starts at -- over 2 / 3 / 8 shards, with
+    runs that cross the cuts and a first base in either case: the joined archive decodes to the text, case and all, and its mask
+    stream is the one-GPU encoder's byte for byte; NAF_GPU_MASK_SHORT=1 (the list of positions) gives the same archive."""
+    import torch
+    from naf_amd import synth, shard
+    g = torch.Generator(device="cuda"); g.manual_seed(41)
+    base = synth.fasta_acgt_device(60_000_000, n_records=5, width=70, seed=12)
+    low = (torch.rand(base.numel(), device="cuda", generator=g) < 0.12) & (base >= 65) & (base <= 90)
+    hdr = torch.cumsum((base == 10).to(torch.int32), 0)            # (header lines keep their case: they are the lines that begin with '>')
+    is_hdr = torch.zeros_like(low)
+    starts = (base == 62).nonzero().flatten().tolist()
+    for p0 in starts:
+        e = int((base[p0:p0 + 200] == 10).nonzero().flatten()[0].item()) + p0
+        is_hdr[p0:e] = True
+    text = torch.where(low & ~is_hdr, base + 32, base)
+    del low, hdr, is_hdr
+    one, _ = ctxs[0].ennaf(text)
+    h1 = ctxs[0].parse_header(one)
+    m1 = ctxs[0].zstd_decompress(one[h1.payload_off[3]: h1.payload_off[3] + h1.comp_size[3]], int(h1.orig_size[3]) + 64, has_magic=False).clone()
+    for n in (2, 3, 8):
+        if n == 8: monkeypatch.setenv("NAF_GPU_SHARD_OVERLAP", "1")          # (the sections of a shard side by side on three streams, whatever its size)
+        naf, rep = shard.ennaf_sharded_local(ctxs[:n], text)
+        if n == 8: monkeypatch.delenv("NAF_GPU_SHARD_OVERLAP")
+        assert torch.equal(ctxs[0].unnaf(naf, 0), text), n
+        hn = ctxs[0].parse_header(naf)
+        mn = ctxs[0].zstd_decompress(naf[hn.payload_off[3]: hn.payload_off[3] + hn.comp_size[3]], int(hn.orig_size[3]) + 64, has_magic=False)
+        assert torch.equal(mn, m1), n
+        if n == 3:
+            monkeypatch.setenv("NAF_GPU_MASK_SHORT", "1")
+            naf2, _ = shard.ennaf_sharded_local(ctxs[:n], text)
+            monkeypatch.delenv("NAF_GPU_MASK_SHORT")
+            assert torch.equal(naf2, naf)
+
+
 def test_seamed_frames_are_read_in_place_whole_and_by_range(ctxs, monkeypatch, capfd):
     """VERDICT r05 item 4.  The sharded encoder's sequence frame is one run of equal blocks per shard with a short block at every seam (and
     a part is whole blocks + one ragged block, not an even split of two sizes): the decoder's stride index goes on behind the first run
