@@ -154,6 +154,7 @@ def _worker(rank, world, port, q, kind):
         text = b"\n \n" + me.fasta_fuzz(rng, 3, 5000, width=60)
     else:
         text = synth.fastq_reads(57, 90, seed=5, var_len=True)
+        sh.P2P_MAX_BYTES = 700                                      # (every part of the archive travels as several pieces, cut the same way on both ranks: shard._pieces)
     a = [0, len(text) * 2 // 5, len(text)]                          # uneven nominal slices, cut anywhere
     mine = text[a[rank]:a[rank + 1]]
     buf = torch.zeros(len(mine) + 4096, dtype=torch.uint8)
