@@ -758,7 +758,7 @@ __global__ __launch_bounds__(64) void k_lz_parse(const u8 *src, u64 n, u32 nblk,
 // greedy walk gets from running across the line end: `SRR1.12 length=150\0SRR1.1` is one match, and comments that are all alike one per
 // block.  The head a joining prefix adds its length to is the sequence open at the end of the line in front, handed on through lines that
 // are wholly one match by a scan.  Blocks the picture does not fit -- fewer than half of the bytes matched, more lines than an eighth of
-// the bytes, fewer than two -- are left to k_lz_parse (fallback[b] = 1), which skips the others.  NAF_GPU_LZ_LINES=0: every block by k_lz_parse.
+// the bytes, fewer than two, lines of more than 128 bytes on average -- are left to k_lz_parse (fallback[b] = 1), which skips the others.  NAF_GPU_LZ_LINES=0: every block by k_lz_parse.
 __device__ __forceinline__ u64 zero_bytes64(u64 w) { const u64 L = 0x7F7F7F7F7F7F7F7Full; return ~(((w & L) + L) | w) & ~L; }   // 0x80 where the byte is zero
 // line_div: a block may hold bn / line_div lines (8; 16 for blocks above 16 KiB, whose tables would otherwise leave two workgroups a CU --
 // comments of eight bytes in such blocks are the hash table's walk's, which takes a block of them as one match)
@@ -783,7 +783,9 @@ __global__ __launch_bounds__(64) void k_lz_parse_lines(const u8 *src, u64 n, u32
     u32 cnt = 0;
     for (u32 i = c0; i < c1; i += 8) { u64 z = zero_bytes64(*(const u64 *)(buf + i)); if (i + 8 > c1) z &= (1ull << (8 * (c1 - i))) - 1; cnt += (u32)__popcll(z); }
     const u32 incl = wave_scan_inclusive<u32, OpAdd>(cnt), L = (u32)__shfl((int)incl, 63, 64);
-    if (L < 2 || L > max_lines) { if (lane == 0) fallback[b] = 1; return; }       // (uniform)
+    // (lines of more than 128 bytes on average are not names: what repeats INSIDE such a line -- a run of one letter -- is the hash table's
+    // walk's to find, and it has few matches a block to take one after the other)
+    if (L < 2 || L > max_lines || L * 128 < bn) { if (lane == 0) fallback[b] = 1; return; }       // (uniform)
     {
         u32 idx = incl - cnt;
         for (u32 i = c0; i < c1; i += 8) {

@@ -413,7 +413,7 @@ def test_ennaf_fastq_regular_tiles_by_lines(gpu, oracle, monkeypatch, capfd):
     headers with and without comments, tab-separated comments, '+' lines that repeat the name -- and the same with irregular spots
     sprinkled in (blank lines, CR LF, blanks in sequence lines, letters that are replaced, bad quality bytes, control bytes and second
     tabs in headers), each of which must send its tile, and only its tile, to the general kernel."""
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(4242 + int(os.environ.get("NAF_TEST_SEED", "0")))      # (NAF_TEST_SEED: other texts of the same kinds)
     all_damage = ("blank", "crlf", "space_seq", "bad_seq", "bad_qual", "ctl_hdr", "tabs_hdr", "plus_space")
     cases = [(400_000, (150, 150), 0.8, (), 0.0), (300_000, (1, 400), 0.5, (), 0.0), (150_000, (1, 3), 0.0, (), 0.0), (500_000, (20_000, 60_000), 1.0, (), 0.0),
              (300_000, (30, 60), 0.0, (), 0.0), (300_000, (100, 200), 0.8, (), 0.01), (600_000, (100, 250), 0.8, all_damage, 0.002), (300_000, (1, 40), 0.3, all_damage, 0.0)]
@@ -430,12 +430,16 @@ def test_ennaf_fastq_regular_tiles_by_lines(gpu, oracle, monkeypatch, capfd):
             err = capfd.readouterr().err
             tiles, irregular = [int(x) for x in err.split("[fq reg] tiles ")[1].split("\n")[0].replace(", not regular", "").split()]
             back = int(err.split("[fq reg] handed back ")[1].split("\n")[0])
-            if not dmg and rl[0] > 3:
+            if os.environ.get("NAF_TEST_SEED", "0") != "0":
+                pass                                                   # (how many tiles a text's irregular spots touch is this seed's: under another, parity only)
+            elif not dmg and rl[0] > 3:
                 assert irregular <= 3, (rl, tiles, irregular)          # the first tile (p0) and the last (partial) ones
                 assert (back > 0) == (iupac > 0), (rl, back)
-            if rl[1] <= 3:
+            if os.environ.get("NAF_TEST_SEED", "0") != "0":
+                pass
+            elif rl[1] <= 3:
                 assert irregular == tiles
-            if dmg == ("bad_seq",):
+            elif dmg == ("bad_seq",):
                 assert back > 0 and irregular <= 3
             elif dmg == ("plus_space",):
                 assert irregular <= 3                                   # whatever a '+' line holds behind its '+' is skipped
@@ -547,7 +551,7 @@ def test_names_parsed_a_lane_per_line_fuzz(gpu, oracle, monkeypatch):
     many lines a block): every frame
     decodes to its input under the from-spec oracle, this build's LDS and HBM executors, and is never larger than the literal-only
     coding; against NAF_GPU_LZ_LINES=0 (the hash table's walk alone) it is at most 12 % larger (it is mostly smaller)."""
-    rng = np.random.default_rng(20260930)
+    rng = np.random.default_rng(20260930 + int(os.environ.get("NAF_TEST_SEED", "0")))
     def names(kind, n):
         out = []
         x = int(rng.integers(1, 10 ** int(rng.integers(1, 9))))
