@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+SEED = int(os.environ.get("NAF_TEST_SEED", "0"))          # other texts of the same kinds: NAF_TEST_SEED=n python -m pytest ... (count expectations are seed 0's)
+
 from conftest import golden_bytes, naf_cases, zstd_cases
 
 pytestmark = pytest.mark.gpu
@@ -165,7 +167,7 @@ def test_unnaf_record_tables_the_long_way(gpu, case, monkeypatch):
 
 
 def test_histogram_matches_numpy(gpu):
-    rng = np.random.default_rng(2)
+    rng = np.random.default_rng(2 + SEED)
     for n in (0, 1, 7, 65536, 65537, 1000003):
         d = rng.integers(0, 256, n, dtype=np.uint8)
         d[: n // 3] = 65
@@ -177,7 +179,7 @@ def test_unnaf_survives_corrupt_sections(gpu, oracle):
     """A damaged section must come back as an error (or, when the damage happens to decode, as some text) -- never a crash or a
     hang; the side streams are decoded by helper host threads, so this also walks their error paths."""
     from naf_amd.capi import NafGpuError
-    rng = np.random.default_rng(8)
+    rng = np.random.default_rng(8 + SEED)
     for name in ("mixed_60", "fastq_4k"):
         naf = bytearray(golden_bytes("naf", name + ".naf"))
         h = oracle.parse_naf(bytes(naf))
@@ -204,7 +206,7 @@ def test_small_frames_damaged_the_oracle_is_the_judge(gpu, oracle):
     launch (k_side_tables) as with NAF_GPU_SIDE_FUSED=0."""
     import os
     from naf_amd.capi import NafGpuError
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SEED)
     n_frames = n_ok = n_err = 0
     for case in naf_cases():
         naf = golden_bytes("naf", case["name"] + ".naf")
@@ -284,7 +286,7 @@ def test_unnaf_range_on_own_archives_decodes_only_needed_blocks(gpu, oracle, emi
     --sequences text equals the slice of the whole text."""
     from naf_amd import synth
     monkeypatch.setenv("NAF_GPU_EMIT", emit)
-    rng = np.random.default_rng(4)
+    rng = np.random.default_rng(4 + SEED)
     texts = [synth.fasta_acgt(700000, 5, 80, seed=21), synth.fasta_mixed(25, 30000, 60, seed=22), synth.fastq_reads(3000, 150, seed=23)]
     for text in texts:
         d_naf, rep = gpu.ennaf(gpu.to_device(text))
@@ -302,7 +304,7 @@ def test_fused_path_on_own_archives(gpu, oracle, monkeypatch):
     """Own archives are literal-only, so whole-FASTA calls take the fused kernel: compare with the two-pass path
     and the oracle over record shapes that stress it (empty records, tiny records, masks, odd totals, line widths)."""
     from naf_amd import synth
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SEED)
     texts = [synth.fasta_acgt(1000001, 3, 80, seed=31), synth.fasta_acgt(300000, 2, 0, seed=32), synth.fasta_acgt(99999, 7, 16, seed=33),
              synth.fasta_mixed(60, 9000, 60, seed=34, empty_every=4), synth.fasta_mixed(400, 40, 17, seed=35, empty_every=3),
              synth.fasta_mixed(30, 70000, 1000, seed=36), b">only\n" + b"acgtn" * 20001 + b"\n>e1\n>e2\n>last\nA\n"]
@@ -330,7 +332,7 @@ def test_unnaf_random_archives_against_oracle(gpu, oracle, emit, monkeypatch):
     """Seeded random FASTA/FASTQ -> oracle archive (raw zstd blocks) -> GPU == oracle, all modes."""
     from naf_amd import synth
     monkeypatch.setenv("NAF_GPU_EMIT", emit)
-    rng = np.random.default_rng(123)
+    rng = np.random.default_rng(123 + SEED)
     for i in range(12):
         if i % 3 == 2:
             text = synth.fastq_reads(int(rng.integers(1, 400)), int(rng.integers(1, 200)), seed=i, var_len=True)
@@ -401,7 +403,7 @@ def test_flat_tree_literals_every_width(gpu, oracle, monkeypatch):
     GPU encoder's frames and against the serial kernel (NAF_GPU_FLAT=0); a stream with a flipped size byte is rejected."""
     import torch
     from naf_amd.capi import NafGpuError
-    rng = np.random.default_rng(31)
+    rng = np.random.default_rng(31 + SEED)
     syms16 = np.array([0x88, 0x84, 0x82, 0x81, 0x48, 0x44, 0x42, 0x41, 0x28, 0x24, 0x22, 0x21, 0x18, 0x14, 0x12, 0x11], dtype=np.uint8)
     made = 0
     for L in range(1, 8):
@@ -446,7 +448,7 @@ def test_flat_frame_read_in_place_by_the_emit_kernel(gpu, oracle, monkeypatch):
     toggles, --seq / --sequences / --line-length, RNA."""
     import torch
     from naf_amd import synth
-    rng = np.random.default_rng(101)
+    rng = np.random.default_rng(101 + SEED)
     def uniform_fasta(n_rec, per_rec, width, lower=False, rna=False):
         out = bytearray()
         alpha = np.frombuffer(b"ACGU" if rna else b"ACGT", dtype=np.uint8)
@@ -686,7 +688,7 @@ def test_huffman_streams_decoded_in_parts(gpu, oracle, monkeypatch, part, margin
             except Exception:
                 continue
             assert host(gpu.unnaf(d, mode)) == want, (case["name"], mode)
-    rng = np.random.default_rng(17)
+    rng = np.random.default_rng(17 + SEED)
     p2 = np.array([2.0 ** -(i + 1) for i in range(30)])
     pr = np.array([1.0] * 15 + [0.5, 0.5])
     datas = [rng.choice(np.arange(30, dtype=np.uint8), 700_001, p=p2 / p2.sum()).tobytes(),
@@ -724,7 +726,7 @@ def test_unnaf_range_of_frames_with_matches_decodes_the_dependency_closure(gpu, 
     repeat archives (levels 1, 19, --long 27), on reference- and own-made archives of text with far-apart repeats, for the packed
     4-bit stream, FASTA and FASTQ; the closure is a fraction of the stream where matches are sparse."""
     from naf_amd import synth
-    rng = np.random.default_rng(9)
+    rng = np.random.default_rng(9 + SEED)
     arcs = [(name, golden_bytes("naf", name + ".naf")) for name in ("repeat_l1", "repeat_l19", "repeat_long27", "fastq_4k", "mixed_60")]
     # mostly unique sequence with a few far-apart copies: sparse matches, long literal stretches
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -836,7 +838,7 @@ def test_tables_of_many_distinct_trees_sixteen_lanes_per_tree(gpu, oracle, monke
     -- directly stored weights with codes of up to HUF_FULL_LOG bits by the group, FSE-coded weights and longer codes by the group's
     first lane the old way.  Quality-like, skewed (long codes), wide (symbols up to 255: FSE-coded weights), flat and two-symbol
     alphabets in 1 KiB blocks, against the data, the one-lane-per-tree kernel and (a cut) the oracle."""
-    rng = np.random.default_rng(23)
+    rng = np.random.default_rng(23 + SEED)
     p2 = np.array([2.0 ** -(i + 1) for i in range(30)])
     n = 20_000_000
     datas = [rng.integers(33, 74, n, dtype=np.uint8),
@@ -1112,7 +1114,7 @@ def test_runs_that_continue_from_block_to_block(gpu, oracle, monkeypatch):
     O = oracle
     if not O.have_ref():
         pytest.skip("needs oracle/_ref")
-    rng = np.random.default_rng(12)
+    rng = np.random.default_rng(12 + SEED)
     n = 150_000                                                          # 600 KB of lengths, 1.2 MB of names: five and ten blocks
     def fastq(lens):
         return b"".join(b"@r len=%d\n%s\n+\n%s\n" % (L, b"ACGT"[:L] if L <= 4 else b"A" * L, b"I" * L) for L in lens)
@@ -1161,7 +1163,7 @@ def test_reference_archives_of_structured_texts_at_every_level(gpu, oracle):
     O = oracle
     if not O.have_ref():
         pytest.skip("needs oracle/_ref")
-    rng = np.random.default_rng(2025)
+    rng = np.random.default_rng(2025 + SEED)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 
     def genome(n):

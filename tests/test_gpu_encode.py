@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+SEED = int(os.environ.get("NAF_TEST_SEED", "0"))          # other texts of the same kinds: NAF_TEST_SEED=n python -m pytest ... (count expectations are seed 0's)
+
 from conftest import golden_bytes, naf_cases, ref_cases
 
 pytestmark = pytest.mark.gpu
@@ -28,7 +30,7 @@ def host(t):
 
 
 def datasets():
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + SEED)
     syms = np.array([0x88, 0x84, 0x82, 0x81, 0x48, 0x44, 0x42, 0x41, 0x28, 0x24, 0x22, 0x21, 0x18, 0x14, 0x12, 0x11], dtype=np.uint8)
     yield "empty", b""
     yield "one", b"A"
@@ -59,7 +61,7 @@ def test_zstd_compress_roundtrip(gpu, oracle, block_log, monkeypatch):
 
 
 def lz_datasets():
-    rng = np.random.default_rng(9)
+    rng = np.random.default_rng(9 + SEED)
     for name, d in datasets():
         yield name, d
     yield "srr_ids", b"".join(b"SRR%07d.%d length=%d\x00" % (1234567, i, 150) for i in range(1, 30000))
@@ -177,7 +179,7 @@ def test_ennaf_golden_fasta_cases(gpu, oracle):
 
 
 def test_ennaf_fuzz_against_oracle(gpu, oracle):
-    rng = np.random.default_rng(17)
+    rng = np.random.default_rng(17 + SEED)
     alphabet = np.frombuffer(b">>\n\n\r\t ACGTNacgtn-XZ*\x00\x7f\xff\x0b", dtype=np.uint8)
     for i in range(150):
         n = int(rng.integers(0, 400)) if i % 3 else int(rng.integers(4000, 9000))
@@ -194,7 +196,7 @@ def test_ennaf_fuzz_realistic_records(gpu, oracle):
     """Record-shaped inputs: printable headers with IDs and comments of every length (the pieces that take the segment-wise
     header path of the split kernels), ragged line widths, LF / CRLF / blank lines, the odd tab, '>' or control byte inside a
     header and unexpected letter inside a sequence (pieces that must fall back to the per-byte walk)."""
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(2024 + SEED)
     printable = np.frombuffer(bytes(range(0x21, 0x7F)), dtype=np.uint8)
     bases = np.frombuffer(b"ACGTACGTACGTNacgtnRYKM-", dtype=np.uint8)
 
@@ -258,7 +260,7 @@ def test_ennaf_level3_lz_on_every_stream(gpu, oracle):
     """--level >= 2 runs the LZ stage on mask, sequence and quality too: the archive still decodes bit-exactly here, under the
     oracle and under the real reference, and repeat-rich sequence shrinks."""
     from naf_amd import synth
-    rng = np.random.default_rng(17)
+    rng = np.random.default_rng(17 + SEED)
     unit = bytes(rng.choice(list(b"ACGT"), 3000).tolist())
     rep_fa = b">rep tandem copies\n" + synth.wrap_lines(np.frombuffer(unit * 40 + b"ACGTNNNNacgt" * 50, dtype=np.uint8), 70)
     texts = [rep_fa, synth.fasta_mixed(12, 4000, 60, seed=3), synth.fastq_reads(400, 120, seed=5, var_len=True)]
@@ -279,7 +281,7 @@ def test_ennaf_level3_lz_on_every_stream(gpu, oracle):
 def test_ennaf_fastq_against_oracle(gpu, oracle):
     from naf_amd import synth
     from naf_amd.capi import NafGpuError
-    rng = np.random.default_rng(23)
+    rng = np.random.default_rng(23 + SEED)
     for i in range(10):
         text = synth.fastq_reads(int(rng.integers(1, 600)), int(rng.integers(1, 300)), seed=100 + i, var_len=bool(i % 2))
         check_ennaf(gpu, oracle, text)
@@ -310,7 +312,7 @@ def test_ennaf_fastq_against_oracle(gpu, oracle):
 def test_ennaf_fastq_fuzz(gpu, oracle):
     """Structured fuzz: mostly valid records with random damage; both sides must agree on die-or-encode."""
     from naf_amd.capi import NafGpuError
-    rng = np.random.default_rng(29)
+    rng = np.random.default_rng(29 + SEED)
     seq_al = np.frombuffer(b"ACGTNacgtn-RYxz \t", dtype=np.uint8)
     q_al = np.frombuffer(b"!#5AIZ~ \t\x01\x80", dtype=np.uint8)
     eols = [b"\n", b"\n", b"\n", b"\n\n", b"\n\r\n", b"\x0b"]
@@ -349,7 +351,7 @@ def test_ennaf_fastq_fuzz_realistic_records(gpu, oracle):
     """Instrument-style reads: long headers with comments (the segment-wise path of the FASTQ split kernels), read lengths
     from 1 to 400 with N and lower case, the full quality range, '+' lines that repeat the header, blank lines between
     records; a few pieces with a control byte or a stray space so that the per-byte walk is taken beside it."""
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SEED)
     bases = np.frombuffer(b"ACGTACGTACGTNacgtn", dtype=np.uint8)
     quals = np.frombuffer(bytes(range(0x21, 0x7F)), dtype=np.uint8)
     for i in range(60):
@@ -413,7 +415,7 @@ def test_ennaf_fastq_regular_tiles_by_lines(gpu, oracle, monkeypatch, capfd):
     headers with and without comments, tab-separated comments, '+' lines that repeat the name -- and the same with irregular spots
     sprinkled in (blank lines, CR LF, blanks in sequence lines, letters that are replaced, bad quality bytes, control bytes and second
     tabs in headers), each of which must send its tile, and only its tile, to the general kernel."""
-    rng = np.random.default_rng(4242 + int(os.environ.get("NAF_TEST_SEED", "0")))      # (NAF_TEST_SEED: other texts of the same kinds)
+    rng = np.random.default_rng(4242 + SEED)      # (NAF_TEST_SEED: other texts of the same kinds)
     all_damage = ("blank", "crlf", "space_seq", "bad_seq", "bad_qual", "ctl_hdr", "tabs_hdr", "plus_space")
     cases = [(400_000, (150, 150), 0.8, (), 0.0), (300_000, (1, 400), 0.5, (), 0.0), (150_000, (1, 3), 0.0, (), 0.0), (500_000, (20_000, 60_000), 1.0, (), 0.0),
              (300_000, (30, 60), 0.0, (), 0.0), (300_000, (100, 200), 0.8, (), 0.01), (600_000, (100, 250), 0.8, all_damage, 0.002), (300_000, (1, 40), 0.3, all_damage, 0.0)]
@@ -551,7 +553,7 @@ def test_names_parsed_a_lane_per_line_fuzz(gpu, oracle, monkeypatch):
     many lines a block): every frame
     decodes to its input under the from-spec oracle, this build's LDS and HBM executors, and is never larger than the literal-only
     coding; against NAF_GPU_LZ_LINES=0 (the hash table's walk alone) it is at most 12 % larger (it is mostly smaller)."""
-    rng = np.random.default_rng(20260930 + int(os.environ.get("NAF_TEST_SEED", "0")))
+    rng = np.random.default_rng(20260930 + SEED)
     def names(kind, n):
         out = []
         x = int(rng.integers(1, 10 ** int(rng.integers(1, 9))))
@@ -666,7 +668,7 @@ def test_bases_behind_the_last_record(gpu, oracle):
     surplus behind the last record, wrapped on from the line the last non-empty record stopped in (output.c:369-430), --sequences
     appends it raw (output-sequences.c:82-116), FASTQ drops it (output-fastq.c:100-149)."""
     O = oracle
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SEED)
     def dna(n):
         return bytes(rng.choice(np.frombuffer(b"ACGTacgtNn", dtype=np.uint8), n).tobytes())
     cases = []
@@ -740,7 +742,7 @@ def test_levels_and_long_match_across_blocks(gpu, oracle):
 def test_zstd_compress_levels_through_the_c_abi(gpu, oracle):
     """naf_gpu_zstd_compress at levels 2 / 9 / 19 / 22: cross-block matches, windows 2^20 .. 2^27; frames decode under the oracle
     and shrink repeats that lie blocks apart."""
-    rng = np.random.default_rng(31)
+    rng = np.random.default_rng(31 + SEED)
     unit = rng.integers(0, 256, 200000, dtype=np.uint8).tobytes()
     far = unit + rng.integers(0, 256, 700000, dtype=np.uint8).tobytes() + unit + b"tail" + unit[5:150000]
     cases = [b"", b"x", b"ab" * 50, far, rng.integers(0, 4, 300000, dtype=np.uint8).tobytes(), b"\x00" * 500000,
@@ -759,7 +761,7 @@ def test_small_windows_and_many_epochs(gpu, oracle):
     offset beyond it comes back as garbage or an error, not as the text."""
     from naf_amd import synth
     O = oracle
-    rng = np.random.default_rng(17)
+    rng = np.random.default_rng(17 + SEED)
     texts = [synth.repeat_genome(seed=21, unit=3000, copies=60), synth.repeat_genome(seed=22, unit=700, copies=300),
              synth.repeat_genome(seed=23, unit=50000, copies=6),
              b">one line\n" + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 5000)) * 40 + b"\n"]
@@ -787,7 +789,7 @@ def test_small_windows_and_many_epochs(gpu, oracle):
 def test_zstd_compress_levels_fuzz(gpu, oracle):
     """naf_gpu_zstd_compress at levels 2 .. 22 on random structured inputs (copies at random distances, alphabets of 2 .. 256, runs,
     edits inside copies): every frame decodes under the from-spec oracle."""
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(99 + SEED)
     for it in range(40):
         a = int(rng.choice([2, 4, 16, 64, 256]))
         parts = []
@@ -815,7 +817,7 @@ def test_pure_tiles_and_their_edges(gpu, oracle):
     """The pure-tile paths of k_enc_count / k_enc_scatter (4 KiB tiles of plain sequence text: quick letters, LF, CR) next to every
     way a tile can fail to be pure: line widths around the piece and tile sizes, CRLF, blank lines, leading white space, IUPAC
     letters, tabs and spaces inside lines, headers at tile borders, a text that ends inside a pure tile."""
-    rng = np.random.default_rng(123)
+    rng = np.random.default_rng(123 + SEED)
     acgt = np.frombuffer(b"ACGTacgtNn", dtype=np.uint8)
     def seq(n, p=None):
         return bytes(rng.choice(acgt, n, p=p))
@@ -863,7 +865,7 @@ def test_sections_coded_beside_each_other_give_the_same_archive(gpu, oracle, mon
     base count (the padding byte's block of its own), FASTQ with mixed case, level 1 and a matching level."""
     import torch
     from naf_amd import synth
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SEED)
     fa = synth.fasta_acgt_device(70_000_001, n_records=9, width=61, seed=12)
     lines = fa.view(-1)
     m = torch.from_numpy(rng.integers(0, lines.numel() - 5000, 4000)).to(lines.device)
@@ -902,7 +904,7 @@ def test_concurrent_sections_on_small_inputs_and_when_the_archive_does_not_fit(g
     from naf_amd import synth
     from naf_amd.capi import NafGpuError
     monkeypatch.setenv("NAF_GPU_ENC_OVERLAP", "2")
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + SEED)
     texts = [synth.fasta_mixed(30, 3000, 60, seed=2), synth.fastq_reads(300, 120, seed=3, var_len=True), b">only a header\n", b">e\n\n>f\nACGTN\n",
              b">p1 protein\n" + bytes(rng.choice(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY*", dtype=np.uint8), 5000)) + b"\n"]
     for i, text in enumerate(texts):
@@ -929,7 +931,7 @@ def test_direct_blocks_of_the_sequence_stream(gpu, oracle, monkeypatch, capfd):
     blocks take the path (NAF_GPU_PROBE=0: no block is kept back for the look at the stream): stream parity with the oracle, the
     decoded text, and the same text as without direct blocks -- around N runs, IUPAC letters, lower case, headers, CRLF, low-entropy
     stretches (not direct: Huffman coding wins there), odd base counts and every line width's phase against the 16-base groups."""
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(2024 + SEED)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     def seq(n, p=None):
         return bytes(rng.choice(acgt, n, p=p))
@@ -976,7 +978,7 @@ def test_text_read_once_gives_the_archive_of_the_two_passes(gpu, oracle, monkeyp
     counts, and a text large enough for the blocks the look at the stream keeps back (direct and packed blocks side by side)."""
     import torch
     from naf_amd import synth
-    rng = np.random.default_rng(606)
+    rng = np.random.default_rng(606 + SEED)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     def seq(n, p=None):
         return bytes(rng.choice(acgt, n, p=p))
@@ -1039,7 +1041,7 @@ def test_wrapped_lines_followed_by_a_long_line(gpu, oracle, monkeypatch):
     lattice predicts behind the last real one.  (Round 5's verdict looked only at the gaps between the line ends there are: such a text
     came back with bases out of place -- found by this round's one-pass work.)  Both split paths, every phase of the long line against
     the tiles."""
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SEED)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     def seq(n):
         return bytes(rng.choice(acgt, n))
@@ -1088,7 +1090,7 @@ def test_tree_descriptions_coded_a_lane_per_block_give_the_same_frame(gpu, oracl
     64 blocks per wavefront behind the planner instead of by one lane of each planner workgroup.  The frame is byte for byte the one
     the planner alone makes (NAF_GPU_TREE_DEFER=0) and decodes under the oracle: packed bases with N (symbols up to 0xFF), a wide
     alphabet, a quality-like one (direct weights at level 1, FSE at level 3) and incompressible bytes."""
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + SEED)
     n = 12_000_000
     pairs = np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88, 0xF1, 0x1F, 0xF8, 0x8F, 0xFF], dtype=np.uint8)
     pp = np.array([6.0] * 16 + [0.5] * 4 + [0.04]); pp /= pp.sum()
@@ -1114,7 +1116,7 @@ def test_case_census_of_the_count_pass(gpu, oracle, monkeypatch):
     headers by the general kernel): all upper case with lower-case HEADERS; one lower-case base in the middle of a pure tile, in a tile
     with a header, as the first and as the last base; a byte >= 0x80 in a sequence line; all lower case -- every stream against the
     oracle's, and the same archive with NAF_GPU_CASE_CENSUS=0."""
-    rng = np.random.default_rng(31)
+    rng = np.random.default_rng(31 + SEED)
     def fasta(nrec=5, per=260_000, width=70):
         parts = []
         for r in range(nrec):
@@ -1145,7 +1147,7 @@ def test_mask_of_short_runs_written_without_the_scan(gpu, oracle, monkeypatch):
     Texts of 1.2 MB whose case changes every 1..40 bases: as they are (short way); with ONE run of exactly 254 bases (still short), of
     255 (the first long one: two units, the second 0), of 300 and of 70 000 bases in the middle, as the first run, as the last run
     -- every stream against the oracle's, and the same archive with NAF_GPU_MASK_SHORT=0."""
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SEED)
     def fasta(nrec=4, per=300_000, width=60):
         parts = []
         for r in range(nrec):

@@ -9,6 +9,8 @@ import subprocess
 import numpy as np
 import pytest
 
+SEED = int(os.environ.get("NAF_TEST_SEED", "0"))          # other texts of the same kinds: NAF_TEST_SEED=n python -m pytest ... (count expectations are seed 0's)
+
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
@@ -55,7 +57,7 @@ def check(O, ctxs, text, n, seq_type=0, no_mask=False, ref=True):
 
 def test_sharded_fasta_fuzz(ctxs, oracle):
     from test_shard_cpu import fasta_fuzz
-    rng = np.random.default_rng(41)
+    rng = np.random.default_rng(41 + SEED)
     for i in range(40):
         text = fasta_fuzz(rng, int(rng.integers(1, 8)), int(rng.integers(1, 6000)))
         for n in (2, 3, 8):
@@ -76,7 +78,7 @@ def test_sharded_one_record_mask_run_across_three_shards(ctxs, oracle):
 def test_sharded_odd_base_counts_at_every_cut(ctxs, oracle):
     """Lines of 7 bases and cuts behind any of them: every shard starts at an odd or even base index as it falls; the packed
     stream must be the one of the whole text, nibble for nibble."""
-    rng = np.random.default_rng(8)
+    rng = np.random.default_rng(8 + SEED)
     bases = np.frombuffer(b"ACGTNacgtRY", dtype=np.uint8)
     for L in (1, 7, 9, 61):
         body = bases[rng.integers(0, len(bases), 4001)].tobytes()
@@ -94,7 +96,7 @@ def test_sharded_tiny_and_edge_inputs(ctxs, oracle):
 
 def test_sharded_other_sequence_types(ctxs, oracle):
     from test_shard_cpu import fasta_fuzz
-    rng = np.random.default_rng(3)
+    rng = np.random.default_rng(3 + SEED)
     text = fasta_fuzz(rng, 5, 2500)
     for st, nm in ((oracle.PROTEIN, False), (oracle.TEXT, False), (oracle.DNA, True), (oracle.RNA, False), (oracle.TEXT, True)):
         for n in (2, 3):
@@ -103,7 +105,7 @@ def test_sharded_other_sequence_types(ctxs, oracle):
 
 def test_sharded_fastq_mixed_case(ctxs, oracle):
     from naf_amd import synth
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(11 + SEED)
     for i in range(10):
         text = synth.fastq_reads(int(rng.integers(1, 400)), int(rng.integers(1, 200)), seed=200 + i, var_len=bool(i % 2))
         for n in (2, 3, 8):
@@ -243,7 +245,7 @@ def test_shard_records_match_the_stand_in(ctxs, oracle):
     from naf_amd import shard, synth
     from shard_standin import StandInCtx
     from test_shard_cpu import fasta_fuzz
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SEED)
     texts = [fasta_fuzz(rng, 4, 3000) for _ in range(6)] + [synth.fastq_reads(90, 60, seed=9, var_len=True)]
     fields = ("n_sequences", "n_bases", "longest_line", "lead_bases", "n_ids", "n_comments", "n_quality", "mask_changes", "store_mask", "store_quality")
     for text in texts:
@@ -350,7 +352,7 @@ def test_window_descriptor_of_a_sharded_frame_follows_the_options(ctxs, oracle):
     bytes (one chromosome: an ids stream of 5 bytes) -- the reference's streaming decoder sizes its history from that field
     (unnaf/src/input.c:262-285)."""
     from naf_amd import shard
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SEED)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     big = acgt[rng.integers(0, 4, 1300000)].tobytes()
     unit = acgt[rng.integers(0, 4, 3000)].tobytes()
@@ -391,7 +393,7 @@ def _two_rank_worker(rank, world, port, q, kind):
         import test_shard_cpu as me
         torch.cuda.set_device(0)
         ctx = capi.Context(0)
-        rng = np.random.default_rng(123)
+        rng = np.random.default_rng(123 + SEED)
         if kind == "fasta":
             text = b"\n \n" + me.fasta_fuzz(rng, 4, 40000, width=60) + synth.fasta_acgt(600_001, 2, 80, seed=5)
         elif kind == "fastq":
