@@ -347,6 +347,26 @@ def test_ennaf_fastq_fuzz(gpu, oracle):
     assert agree > 40 and died > 20, (agree, died)
 
 
+def test_ennaf_fastq_an_earlier_record_stops_the_reference_before_the_truncation(gpu, oracle):
+    """A text that ends in a header line without its line end ("last sequence has no sequence data", process.c:499) AND has a quality line
+    of the wrong length in a record in front of it: the reference reads record by record and dies on the quality length (process.c:531-535);
+    so must this build (found under NAF_TEST_SEED=5 of the fuzz above: the truncation was reported first)."""
+    from naf_amd.capi import NafGpuError
+    t = b"@r0\nACGTAC\n+\nIIIIIII\n@r1\nACGT\n+\nIIII\n@r2"
+    with pytest.raises(ValueError) as eo:
+        oracle.split_text(t)
+    assert "quality length" in str(eo.value)
+    with pytest.raises(NafGpuError) as ei:
+        gpu.ennaf(gpu.to_device(t))
+    assert str(eo.value).strip() in str(ei.value), (str(eo.value), str(ei.value))
+    t2 = b"@r0\nACGTAC\n+\nIIIIII\n@r1\nACGT\n+\nIIII\n@r2"                 # without the wrong length: the truncation is what both report
+    with pytest.raises(ValueError) as eo2:
+        oracle.split_text(t2)
+    with pytest.raises(NafGpuError) as ei2:
+        gpu.ennaf(gpu.to_device(t2))
+    assert "no sequence data" in str(eo2.value) and str(eo2.value).strip() in str(ei2.value), (str(eo2.value), str(ei2.value))
+
+
 def test_ennaf_fastq_fuzz_realistic_records(gpu, oracle):
     """Instrument-style reads: long headers with comments (the segment-wise path of the FASTQ split kernels), read lengths
     from 1 to 400 with N and lower case, the full quality range, '+' lines that repeat the header, blank lines between
