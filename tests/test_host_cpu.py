@@ -11,6 +11,8 @@ import sys
 import numpy as np
 import pytest
 
+SEED = int(os.environ.get("NAF_TEST_SEED", "0"))          # other texts of the same kinds (tests/test_gpu_encode.py)
+
 from conftest import GOLDEN, ROOT, golden_bytes, naf_cases, zstd_cases
 
 BIN = os.path.join(ROOT, "naf_amd", "bin")
@@ -96,7 +98,7 @@ def test_decoder_kernel_logic_on_reference_archives(emul, oracle):
 
 
 def test_encoder_kernel_logic_roundtrips_through_oracle(emul, oracle):
-    rng = np.random.default_rng(3)
+    rng = np.random.default_rng(3 + SEED)
     syms = np.array([0x88, 0x84, 0x82, 0x81, 0x48, 0x44, 0x42, 0x41, 0x28, 0x24, 0x22, 0x21, 0x18, 0x14, 0x12, 0x11], dtype=np.uint8)
     p2 = np.array([2.0 ** -(i + 1) for i in range(40)])
     data = [b"", b"A", b"\x07" * 100000, syms[rng.integers(0, 16, 300001)].tobytes(),
@@ -128,7 +130,7 @@ def test_lz_block_format_against_three_decoders(emul, oracle):
     if zlib is not None:
         zlib.ZSTD_decompress.restype = ctypes.c_size_t
         zlib.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
-    rng = np.random.default_rng(21)
+    rng = np.random.default_rng(21 + SEED)
     data = [b"", b"A", b"abcabcabcabcabc", b"".join(b"SRR%07d.%d length=%d\x00" % (1234567, i, 150) for i in range(1, 6000)),
             np.full(20000, 150, dtype="<u4").tobytes(), (b"abcdefghij" * 700 + rng.integers(0, 256, 3000, dtype=np.uint8).tobytes()) * 4,
             b"A" * 40000 + b"CGT" * 9000, rng.integers(0, 4, 50000, dtype=np.uint8).tobytes()]
@@ -157,7 +159,7 @@ def test_lzx_block_format_against_the_decoders(emul, oracle):
     tables chosen per block): frames decode under the from-spec oracle and the decoder kernels' logic, windows 2^10 .. 2^27."""
     emul.emul_zstd_compress_lzx.restype = ctypes.c_longlong
     emul.emul_zstd_compress_lzx.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)]
-    rng = np.random.default_rng(23)
+    rng = np.random.default_rng(23 + SEED)
     unit = rng.integers(0, 16, 30000, dtype=np.uint8).tobytes()
     def mutated(k):
         a = bytearray(unit)
@@ -212,7 +214,7 @@ def test_decoder_window_reader_at_every_rate_and_alignment(emul):
     (A 1-bit code moves the read position by 4 bytes a round -- the case that once let the ring overwrite live bytes.)"""
     emul.emul_window_roundtrip.restype = ctypes.c_int
     emul.emul_window_roundtrip.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int]
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(11 + SEED)
     streams = []
     for alpha in (2, 3, 4, 16, 41, 100, 256):
         streams.append(rng.integers(0, alpha, 9000, dtype=np.uint8).tobytes())
@@ -235,7 +237,7 @@ def test_huffman_stream_decoded_in_parts(emul):
     must happen and must converge), every P, margins down to none at all, streams shorter than their number of parts."""
     emul.emul_parts_roundtrip.restype = ctypes.c_int
     emul.emul_parts_roundtrip.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
-    rng = np.random.default_rng(12)
+    rng = np.random.default_rng(12 + SEED)
     streams = []
     for alpha in (2, 3, 4, 16, 17, 41, 100, 256):
         streams.append(rng.integers(0, alpha, 9000, dtype=np.uint8).tobytes())
@@ -384,7 +386,7 @@ def test_swar_piece_plain_every_byte_every_position(alphabet):
     assert t[5] == 0xFF and t[6] == 0xFF                        # the two slots the line ends go into are free
     t[5], t[6] = 0x0A, 0x0D
     plo, phi = int.from_bytes(bytes(t[:4]), "little"), int.from_bytes(bytes(t[4:]), "little")
-    rng = np.random.default_rng(6)
+    rng = np.random.default_rng(6 + SEED)
     eol = ctypes.c_uint32()
     fills = [bytes([65] * 16), bytes([10] * 16), bytes([13] * 16), bytes(rng.choice(np.frombuffer(b"ACGTNacgtnUu\n\r", dtype=np.uint8), 16)),
              bytes(rng.choice(np.frombuffer(b"ACGTNacgtn\n", dtype=np.uint8), 16))]
@@ -405,7 +407,7 @@ def test_swar_piece_flags_every_byte_every_position(alphabet):
     expected = set(alphabet) | {c | 0x20 for c in alphabet} | {ord("-")}
     qlo, qhi, quick = _quick_table(expected)
     assert quick                                                # the table is not empty for any of the reference's alphabets
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + SEED)
     out = (ctypes.c_uint32 * 8)()
     fills = [bytes([65] * 16), bytes([10] * 16), bytes([0x20] * 16), bytes([0x7E] * 16), bytes(rng.integers(0, 256, 16, dtype=np.uint8)),
              bytes(rng.choice(np.frombuffer(b"ACGTNacgtn\n", dtype=np.uint8), 16))]

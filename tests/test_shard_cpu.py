@@ -8,6 +8,8 @@ import sys
 import numpy as np
 import pytest
 
+SEED = int(os.environ.get("NAF_TEST_SEED", "0"))          # other texts of the same kinds (tests/test_gpu_encode.py)
+
 from conftest import ROOT
 
 from naf_amd import capi, shard
@@ -61,7 +63,7 @@ def fasta_fuzz(rng, n_records, max_len, width=None):
 
 
 def test_shard_carry_join_fasta_fuzz(oracle):
-    rng = np.random.default_rng(41)
+    rng = np.random.default_rng(41 + SEED)
     for i in range(60):
         text = fasta_fuzz(rng, int(rng.integers(1, 8)), int(rng.integers(1, 3000)))
         for n in (2, 3, 8):
@@ -92,7 +94,7 @@ def test_shard_more_shards_than_lines(oracle):
 
 
 def test_shard_join_protein_text_nomask(oracle):
-    rng = np.random.default_rng(3)
+    rng = np.random.default_rng(3 + SEED)
     text = fasta_fuzz(rng, 5, 900)
     for st, nm in ((oracle.PROTEIN, False), (oracle.TEXT, False), (oracle.DNA, True), (oracle.RNA, False)):
         for n in (2, 3):
@@ -102,7 +104,7 @@ def test_shard_join_protein_text_nomask(oracle):
 
 def test_shard_join_fastq(oracle):
     from naf_amd import synth
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(11 + SEED)
     for i in range(12):
         text = synth.fastq_reads(int(rng.integers(1, 80)), int(rng.integers(1, 120)), seed=200 + i, var_len=bool(i % 2))
         for n in (2, 3, 8):
@@ -149,7 +151,7 @@ def _worker(rank, world, port, q, kind):
     from naf_amd import shard as sh, synth
     from shard_standin import StandInCtx
     import test_shard_cpu as me
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(99 + SEED)
     if kind == "fasta":
         text = b"\n \n" + me.fasta_fuzz(rng, 3, 5000, width=60)
     else:
